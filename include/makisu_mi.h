@@ -1,0 +1,188 @@
+/*
+ * makisu_mi.h -- C ABI of libmakisu_mi.so, the MI355X (gfx950) layer-snapshot
+ * content-scan and dedup engine for uber/makisu.
+ *
+ * The reference has no cgo/FFI today; this header is the
+ * boundary a ~100-line cgo shim in lib/snapshot would bind (INTEGRATION.md shows
+ * it).  Each entry point cites the reference seam it serves (paths relative to
+ * the makisu tree).  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Conventions (mirror Go's "wrap the error with context" style):
+ *   - every function returns int: 0 = MI_OK, <0 = error code;
+ *   - mi_last_error(ctx) returns a NUL-terminated message valid until the next
+ *     call on that ctx, so the shim can do fmt.Errorf("gpu scan: %s", C.GoString(..));
+ *   - a ctx is not re-entrant but may be called from any OS thread (the engine
+ *     calls hipSetDevice itself and keeps no thread-local state -- goroutines
+ *     migrate between threads); several ctxs may run concurrently;
+ *   - the engine never retains caller memory after a call returns (cgo pointer
+ *     rule): mi_batch_add_bytes copies before returning;
+ *   - no callbacks, no exceptions/longjmp across the boundary.
+ *   - there is NO CPU fallback: if no gfx950 device is usable, mi_ctx_create
+ *     fails with MI_ERR_NO_DEVICE.
+ */
+#ifndef MAKISU_MI_H
+#define MAKISU_MI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_ABI_VERSION 1
+
+enum {
+    MI_OK = 0,
+    MI_ERR_INVALID = -1,     /* bad argument / bad state                         */
+    MI_ERR_NO_DEVICE = -2,   /* no usable gfx950 device (there is no CPU path)   */
+    MI_ERR_HIP = -3,         /* a HIP runtime call failed (message has detail)   */
+    MI_ERR_NOMEM = -4,       /* host or device allocation failed                 */
+    MI_ERR_IO = -5,          /* open/pread of a path failed (mi_batch_add_path)  */
+    MI_ERR_STATE = -6,       /* call out of order (e.g. results before run)      */
+    MI_ERR_CAPACITY = -7     /* caller buffer too small                          */
+};
+
+/* mi_config.flags */
+#define MI_FLAG_FILE_SHA256 0x1u  /* also compute SHA-256 of each whole file: what
+                                     image.Digester.FromReader returns per file in
+                                     `makisu push` (bin/makisu/cmd/push.go:207,230;
+                                     lib/docker/image/digester.go:45-52)             */
+#define MI_FLAG_FILE_CRC32  0x2u  /* also compute CRC32-IEEE of each whole file: the
+                                     per-file term of checksumPathContents
+                                     (lib/builder/step/add_copy_step.go:194-238)     */
+#define MI_FLAG_NO_DEDUP    0x4u  /* skip in-batch duplicate marking                 */
+
+typedef struct mi_ctx mi_ctx;
+typedef struct mi_batch mi_batch;
+
+/* Gear-CDC parameters + engine resources.  The reference has no CDC; the spec is
+ * DESIGN.md "Gear-CDC spec".  Defaults (mi_config_default): seed 0x4D414B49,
+ * mask_bits 13 (8 KiB mean gap), min 2 KiB, max 64 KiB. */
+typedef struct {
+    uint32_t struct_size;     /* sizeof(mi_config), for ABI evolution              */
+    int32_t  device;          /* HIP device ordinal                                 */
+    uint64_t gear_seed;       /* Gear table = first 256 outputs of splitmix64(seed) */
+    uint32_t mask_bits;       /* 0..32: candidate iff top mask_bits bits of h == 0  */
+    uint32_t min_size;        /* >= 64                                              */
+    uint32_t max_size;        /* >= min_size, <= 2^30                               */
+    uint32_t flags;           /* MI_FLAG_*                                          */
+    uint64_t staging_bytes;   /* pinned staging bytes per copy stream (0 = 64 MiB)  */
+    uint32_t n_streams;       /* copy streams for host-fed batches (0 = 2)          */
+    uint32_t reserved;
+} mi_config;
+
+/* One result row per file, in the order files were added.  This is what a
+ * content-aware MemFS.isUpdated (lib/snapshot/mem_fs.go:487-503) would compare
+ * next to tario.IsSimilarHeader's metadata (lib/tario/compare.go:104-120).       */
+typedef struct {
+    uint64_t user_tag;         /* caller's tag from mi_batch_add_*                  */
+    uint64_t size;             /* bytes                                             */
+    uint64_t first_chunk;      /* index of the file's first row in the chunk table  */
+    uint32_t n_chunks;
+    uint32_t crc32;            /* CRC32-IEEE of the bytes (MI_FLAG_FILE_CRC32)      */
+    uint8_t  chunk_root[32];   /* SHA-256 over the concatenated chunk digests       */
+    uint8_t  file_sha256[32];  /* SHA-256 of the bytes (MI_FLAG_FILE_SHA256)        */
+} mi_file_result;
+
+/* One row per chunk, files in add order, chunks in file order.                    */
+typedef struct {
+    uint64_t file_index;       /* index into the file table                         */
+    uint64_t offset;           /* byte offset inside the file                       */
+    uint32_t length;           /* bytes (min_size..max_size except a file's last)   */
+    uint32_t reserved;
+    int64_t  dup_of;           /* smallest chunk index (global index after
+                                  mi_dedup_mark_global) with the same digest, -1 if
+                                  this row is the first occurrence                  */
+    uint8_t  sha256[32];       /* what sha256.Sum256(chunk) gives in Go             */
+} mi_chunk_result;
+
+/* Per-ctx counters for roofline reporting.                          */
+typedef struct {
+    uint64_t bytes_in;         /* file bytes scanned by the last mi_batch_run       */
+    uint64_t n_files;
+    uint64_t n_chunks;
+    uint64_t n_unique;         /* chunks with dup_of == -1 after the last dedup     */
+    double   ms_h2d;           /* host->device staging (0 for device-resident)      */
+    double   ms_cdc;           /* Gear marking + cut selection kernels              */
+    double   ms_sort;          /* chunk-table compaction + length binning           */
+    double   ms_sha_chunks;    /* SHA-256-per-chunk kernel (the dominant kernel)    */
+    double   ms_sha_files;     /* chunk_root (+ whole-file SHA-256 / CRC32) kernels */
+    double   ms_dedup;         /* duplicate marking                                 */
+    double   ms_total;         /* first kernel start to last kernel end             */
+} mi_stats;
+
+/* ---- context ----------------------------------------------------------------- */
+int  mi_abi_version(void);
+int  mi_config_default(mi_config* cfg);
+int  mi_ctx_create(const mi_config* cfg, mi_ctx** out);
+void mi_ctx_destroy(mi_ctx* ctx);
+/* ctx may be NULL: returns the message of the last failed mi_ctx_create.           */
+const char* mi_last_error(mi_ctx* ctx);
+int  mi_get_stats(mi_ctx* ctx, mi_stats* out);
+/* device properties as measured by hipGetDeviceProperties: CUs, clock, HBM bytes   */
+int  mi_device_info(mi_ctx* ctx, int32_t* n_cu, int32_t* clock_mhz, uint64_t* hbm_bytes,
+                    char* name, size_t name_cap);
+
+/* ---- batch: a set of files scanned in one pass --------------------------------- *
+ * Serves the per-entry loop of MemFS.commitLayer -> contentMemFile.commit ->
+ * tario.WriteEntry (lib/snapshot/mem_fs.go:424-433, mem_layer.go:83-88,
+ * lib/tario/write.go:28-52): the shim registers each regular file it is about to
+ * write to the layer tar; directories/links/whiteouts have no bytes and are not
+ * added.  Order of results == order of adds (the caller adds in sorted-path order,
+ * lib/snapshot/mem_layer.go:232-244).                                              */
+int mi_batch_begin(mi_ctx* ctx, uint64_t n_files_hint, uint64_t bytes_hint, mi_batch** out);
+/* Copies [data, data+len) into pinned staging before returning (len may be 0).     */
+int mi_batch_add_bytes(mi_batch* b, const void* data, uint64_t len, uint64_t user_tag);
+/* The engine opens `path` and reads exactly `size` bytes (the size at stat time,
+ * like io.CopyN(w, f, h.Size) at lib/tario/write.go:43-45).  Short files are an
+ * error, extra appended bytes are ignored.                                          */
+int mi_batch_add_path(mi_batch* b, const char* path, uint64_t size, uint64_t user_tag);
+/* Device-generated synthetic files (bench / roofline runs):
+ * file i has sizes[i] bytes of the counter-mode stream keyed by (seed,
+ * content_ids[i]); equal content ids give byte-identical files.  content_ids may be
+ * NULL (ids = running file index).  user_tag = content id.                         */
+int mi_batch_add_synthetic(mi_batch* b, uint64_t n_files, const uint64_t* sizes,
+                           const uint64_t* content_ids, uint64_t seed);
+/* Blocking: stage -> Gear CDC -> SHA-256 per chunk -> per-file roots -> dedup.     */
+int mi_batch_run(mi_batch* b);
+/* Re-runs the device pipeline on data already resident from a previous run (bench
+ * steps; no re-staging / re-generation).                                            */
+int mi_batch_rerun(mi_batch* b);
+int mi_batch_counts(mi_batch* b, uint64_t* n_files, uint64_t* n_chunks, uint64_t* n_bytes);
+int mi_batch_files(mi_batch* b, mi_file_result* out, uint64_t cap);
+int mi_batch_chunks(mi_batch* b, mi_chunk_result* out, uint64_t cap);
+/* Device pointer to the batch's n_chunks x 32-byte digest array (valid until
+ * mi_batch_free); what a rank contributes to the all-gather.        */
+int mi_batch_device_digests(mi_batch* b, const void** d_digests, uint64_t* n_chunks);
+/* Copies the batch's file bytes back to the host (tests; cap >= total bytes, files
+ * concatenated in add order, no padding).                                           */
+int mi_batch_read_back(mi_batch* b, void* out, uint64_t cap);
+int mi_batch_free(mi_batch* b);
+
+/* ---- cross-batch / cross-GPU dedup --------------------------------------------- *
+ * Plugs in where the reference dedups layer blobs by digest
+ * (lib/builder/step/common.go:88-91 LinkStoreFileFrom && !os.IsExist;
+ * lib/cache/cache_manager.go:239-252 entry codec): here the unit is a chunk.
+ * d_digests: device pointer to n x 32 bytes (e.g. the all-gathered digest set of
+ * every rank).  d_dup_of: device pointer to n x int64, receives for every row the
+ * smallest row index with an equal digest, or -1 for first occurrences.
+ * n_unique (host, optional) receives the number of -1 rows.                        */
+int mi_dedup_mark(mi_ctx* ctx, const void* d_digests, uint64_t n, void* d_dup_of,
+                  uint64_t* n_unique);
+/* Rewrites the batch's dup_of column from a global marking: row i of the batch is
+ * global row first_global + i of d_dup_of_global (device, int64).                  */
+int mi_batch_set_global_dedup(mi_batch* b, const void* d_dup_of_global, uint64_t first_global);
+
+/* ---- standalone digests (image.Digester seam) ---------------------------------- *
+ * n independent byte strings -> n SHA-256 digests on the GPU, one lane per string:
+ * the batched form of image.NewDigester().FromBytes / FromReader
+ * (lib/docker/image/digester.go:45-60).  data: host pointer, string i =
+ * data[offsets[i] .. offsets[i]+lens[i]).  out: n x 32 bytes.                       */
+int mi_sha256_many(mi_ctx* ctx, const void* data, const uint64_t* offsets,
+                   const uint64_t* lens, uint64_t n, uint8_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAKISU_MI_H */

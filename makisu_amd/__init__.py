@@ -1,0 +1,304 @@
+"""makisu_amd -- MI355X (gfx950) layer-snapshot content scan + dedup engine.
+
+Thin ctypes binding over the C ABI (include/makisu_mi.h, libmakisu_mi.so).  It is
+the stand-in for the cgo shim a Makisu maintainer would add and
+what tests/ and bench.py drive.  No CPU fallback: without the built HIP library
+or without a gfx950 device every entry point raises.  Nothing here imports
+oracle/.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+__all__ = ["Engine", "Batch", "Config", "MiError", "load_library", "FILE_DTYPE", "CHUNK_DTYPE",
+           "FLAG_FILE_SHA256", "FLAG_FILE_CRC32", "FLAG_NO_DEDUP", "Digest", "digest_hex"]
+
+FLAG_FILE_SHA256 = 0x1
+FLAG_FILE_CRC32 = 0x2
+FLAG_NO_DEDUP = 0x4
+
+ERR_NAMES = {0: "MI_OK", -1: "MI_ERR_INVALID", -2: "MI_ERR_NO_DEVICE", -3: "MI_ERR_HIP",
+             -4: "MI_ERR_NOMEM", -5: "MI_ERR_IO", -6: "MI_ERR_STATE", -7: "MI_ERR_CAPACITY"}
+
+
+class MiError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s: %s" % (ERR_NAMES.get(code, code), msg))
+        self.code = code
+
+
+class Config(C.Structure):
+    """mi_config (include/makisu_mi.h)."""
+    _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("gear_seed", C.c_uint64),
+                ("mask_bits", C.c_uint32), ("min_size", C.c_uint32), ("max_size", C.c_uint32),
+                ("flags", C.c_uint32), ("staging_bytes", C.c_uint64), ("n_streams", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+class _FileResult(C.Structure):
+    _fields_ = [("user_tag", C.c_uint64), ("size", C.c_uint64), ("first_chunk", C.c_uint64),
+                ("n_chunks", C.c_uint32), ("crc32", C.c_uint32), ("chunk_root", C.c_uint8 * 32),
+                ("file_sha256", C.c_uint8 * 32)]
+
+
+class _ChunkResult(C.Structure):
+    _fields_ = [("file_index", C.c_uint64), ("offset", C.c_uint64), ("length", C.c_uint32),
+                ("reserved", C.c_uint32), ("dup_of", C.c_int64), ("sha256", C.c_uint8 * 32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("bytes_in", C.c_uint64), ("n_files", C.c_uint64), ("n_chunks", C.c_uint64),
+                ("n_unique", C.c_uint64), ("ms_h2d", C.c_double), ("ms_cdc", C.c_double),
+                ("ms_sort", C.c_double), ("ms_sha_chunks", C.c_double),
+                ("ms_sha_files", C.c_double), ("ms_dedup", C.c_double), ("ms_total", C.c_double)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+def _np_dtype(struct):
+    names, fmts, offs = [], [], []
+    for name, ctype in struct._fields_:
+        names.append(name)
+        offs.append(getattr(struct, name).offset)
+        if issubclass(ctype, C.Array):
+            fmts.append(("u1", ctype._length_))
+        else:
+            fmts.append(np.dtype(ctype))
+    return np.dtype({"names": names, "formats": fmts, "offsets": offs,
+                     "itemsize": C.sizeof(struct)})
+
+
+FILE_DTYPE = _np_dtype(_FileResult)
+CHUNK_DTYPE = _np_dtype(_ChunkResult)
+
+_lib = None
+
+
+def load_library(rebuild=False):
+    """Loads (building first if stale) makisu_amd/libmakisu_mi.so.  Raises if it is missing."""
+    global _lib
+    if _lib is not None and not rebuild:
+        return _lib
+    path = _build.LIB
+    if rebuild or (_build.needs_build() and os.path.exists(_build.HIPCC)):
+        _build.build(force=rebuild)
+    if not os.path.exists(path):
+        raise MiError(-2, "libmakisu_mi.so is not built (run `python -m makisu_amd.build`); "
+                          "there is no CPU fallback")
+    L = C.CDLL(path)
+    vp, u64, u64p = C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)
+    sigs = {
+        "mi_abi_version": ([], C.c_int),
+        "mi_config_default": ([C.POINTER(Config)], C.c_int),
+        "mi_ctx_create": ([C.POINTER(Config), C.POINTER(vp)], C.c_int),
+        "mi_ctx_destroy": ([vp], None),
+        "mi_last_error": ([vp], C.c_char_p),
+        "mi_get_stats": ([vp, C.POINTER(Stats)], C.c_int),
+        "mi_device_info": ([vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), u64p, C.c_char_p,
+                            C.c_size_t], C.c_int),
+        "mi_batch_begin": ([vp, u64, u64, C.POINTER(vp)], C.c_int),
+        "mi_batch_add_bytes": ([vp, vp, u64, u64], C.c_int),
+        "mi_batch_add_path": ([vp, C.c_char_p, u64, u64], C.c_int),
+        "mi_batch_add_synthetic": ([vp, u64, u64p, u64p, u64], C.c_int),
+        "mi_batch_run": ([vp], C.c_int),
+        "mi_batch_rerun": ([vp], C.c_int),
+        "mi_batch_counts": ([vp, u64p, u64p, u64p], C.c_int),
+        "mi_batch_files": ([vp, vp, u64], C.c_int),
+        "mi_batch_chunks": ([vp, vp, u64], C.c_int),
+        "mi_batch_device_digests": ([vp, C.POINTER(vp), u64p], C.c_int),
+        "mi_batch_read_back": ([vp, vp, u64], C.c_int),
+        "mi_batch_free": ([vp], C.c_int),
+        "mi_dedup_mark": ([vp, vp, u64, vp, u64p], C.c_int),
+        "mi_batch_set_global_dedup": ([vp, vp, u64], C.c_int),
+        "mi_sha256_many": ([vp, vp, u64p, u64p, u64, vp], C.c_int),
+    }
+    for name, (args, res) in sigs.items():
+        fn = getattr(L, name)          # AttributeError here = header/library drift
+        fn.argtypes = args
+        fn.restype = res
+    L._mi_symbols = tuple(sigs)
+    _lib = L
+    return L
+
+
+def digest_hex(raw32):
+    return bytes(bytearray(raw32)).hex()
+
+
+class Digest(str):
+    """"sha256:<hex>" -- mirrors image.Digest (lib/docker/image/digest.go:26-50)."""
+
+    @classmethod
+    def from_raw(cls, raw32):
+        return cls("sha256:" + digest_hex(raw32))
+
+    def hex(self):                      # Digest.Hex()
+        return self[self.index(":") + 1:]
+
+
+def default_config(**overrides):
+    cfg = Config()
+    rc = load_library().mi_config_default(C.byref(cfg))
+    if rc:
+        raise MiError(rc, "mi_config_default")
+    for k, v in overrides.items():
+        if not hasattr(cfg, k):
+            raise AttributeError(k)
+        setattr(cfg, k, v)
+    return cfg
+
+
+class Engine:
+    """One mi_ctx: a device, its streams and the Gear parameters."""
+
+    def __init__(self, **cfg_overrides):
+        self._lib = load_library()
+        self.cfg = default_config(**cfg_overrides)
+        h = C.c_void_p()
+        rc = self._lib.mi_ctx_create(C.byref(self.cfg), C.byref(h))
+        if rc:
+            raise MiError(rc, self._lib.mi_last_error(None).decode())
+        self._h = h
+
+    def _check(self, rc):
+        if rc:
+            raise MiError(rc, self._lib.mi_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mi_ctx_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def device_info(self):
+        ncu, mhz, mem = C.c_int32(), C.c_int32(), C.c_uint64()
+        name = C.create_string_buffer(256)
+        self._check(self._lib.mi_device_info(self._h, C.byref(ncu), C.byref(mhz), C.byref(mem),
+                                             name, 256))
+        return {"n_cu": ncu.value, "clock_mhz": mhz.value, "hbm_bytes": mem.value,
+                "name": name.value.decode()}
+
+    def stats(self):
+        st = Stats()
+        self._check(self._lib.mi_get_stats(self._h, C.byref(st)))
+        return st.as_dict()
+
+    def batch(self, n_files_hint=0, bytes_hint=0):
+        return Batch(self, n_files_hint, bytes_hint)
+
+    def sha256_many(self, blobs):
+        """Batched image.Digester.FromBytes: list of bytes-like -> list of 32-byte digests."""
+        lens = np.array([len(b) for b in blobs], dtype=np.uint64)
+        offs = np.zeros(len(blobs), dtype=np.uint64)
+        if len(blobs):
+            offs[1:] = np.cumsum(lens)[:-1]
+        data = np.frombuffer(b"".join(bytes(b) for b in blobs), dtype=np.uint8)
+        out = np.zeros((len(blobs), 32), dtype=np.uint8)
+        u64p = C.POINTER(C.c_uint64)
+        self._check(self._lib.mi_sha256_many(self._h, data.ctypes.data if data.size else None,
+                                             offs.ctypes.data_as(u64p), lens.ctypes.data_as(u64p),
+                                             len(blobs), out.ctypes.data))
+        return [out[i].tobytes() for i in range(len(blobs))]
+
+    def dedup_mark(self, d_digests_ptr, n, d_dup_of_ptr):
+        """dup_of over a device-resident digest set (e.g. the all-gathered one)."""
+        nu = C.c_uint64()
+        self._check(self._lib.mi_dedup_mark(self._h, d_digests_ptr, n, d_dup_of_ptr, C.byref(nu)))
+        return nu.value
+
+
+class Batch:
+    def __init__(self, engine, n_files_hint=0, bytes_hint=0):
+        self.engine = engine
+        self._lib = engine._lib
+        h = C.c_void_p()
+        engine._check(self._lib.mi_batch_begin(engine._h, n_files_hint, bytes_hint, C.byref(h)))
+        self._h = h
+
+    def _check(self, rc):
+        self.engine._check(rc)
+
+    def add_bytes(self, data, tag=0):
+        a = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else \
+            np.ascontiguousarray(data).view(np.uint8)
+        self._check(self._lib.mi_batch_add_bytes(self._h, a.ctypes.data if a.size else None,
+                                                 a.size, tag))
+
+    def add_path(self, path, size=None, tag=0):
+        if size is None:
+            size = os.stat(path).st_size
+        self._check(self._lib.mi_batch_add_path(self._h, os.fsencode(path), size, tag))
+
+    def add_synthetic(self, sizes, content_ids=None, seed=0x4D414B49):
+        s = np.ascontiguousarray(sizes, dtype=np.uint64)
+        u64p = C.POINTER(C.c_uint64)
+        cp = None
+        if content_ids is not None:
+            cids = np.ascontiguousarray(content_ids, dtype=np.uint64)
+            assert cids.size == s.size
+            cp = cids.ctypes.data_as(u64p)
+        self._check(self._lib.mi_batch_add_synthetic(self._h, s.size, s.ctypes.data_as(u64p), cp,
+                                                     seed))
+
+    def run(self):
+        self._check(self._lib.mi_batch_run(self._h))
+        return self
+
+    def rerun(self):
+        self._check(self._lib.mi_batch_rerun(self._h))
+        return self
+
+    def counts(self):
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._check(self._lib.mi_batch_counts(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def files(self):
+        n = self.counts()[0]
+        out = np.zeros(max(n, 1), dtype=FILE_DTYPE)
+        self._check(self._lib.mi_batch_files(self._h, out.ctypes.data, n))
+        return out[:n]
+
+    def chunks(self):
+        n = self.counts()[1]
+        out = np.zeros(max(n, 1), dtype=CHUNK_DTYPE)
+        self._check(self._lib.mi_batch_chunks(self._h, out.ctypes.data, n))
+        return out[:n]
+
+    def device_digests(self):
+        p, n = C.c_void_p(), C.c_uint64()
+        self._check(self._lib.mi_batch_device_digests(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def set_global_dedup(self, d_dup_of_global_ptr, first_global):
+        self._check(self._lib.mi_batch_set_global_dedup(self._h, d_dup_of_global_ptr, first_global))
+
+    def read_back(self):
+        n = self.counts()[2]
+        out = np.zeros(max(n, 1), dtype=np.uint8)
+        self._check(self._lib.mi_batch_read_back(self._h, out.ctypes.data, n))
+        return out[:n]
+
+    def free(self):
+        if getattr(self, "_h", None):
+            self._lib.mi_batch_free(self._h)
+            self._h = None
+
+    __del__ = free
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.free()

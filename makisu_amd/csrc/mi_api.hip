@@ -1,0 +1,787 @@
+// mi_api.hip -- host pipeline behind the C ABI of include/makisu_mi.h.
+//
+// Data layout in HBM (DESIGN.md "HBM layout"):
+//   arena      : all file bytes of a batch, every file on a 256-byte boundary
+//   file table : file_off[], file_size[], slot_base[]            (u64 SoA)
+//   slots      : chunk END offsets per file, slot_base[f] .. +size/min+2  (u64)
+//   chunk table: chunk_off[] (arena offset), chunk_len[], chunk_start[] (u64),
+//                chunk_file[] (u32), order[] (u32, longest first), digests[] (32 B)
+//   file out   : roots[] (32 B), file_sha[] (32 B, optional)
+// One HIP stream per ctx for kernels, n_streams copy streams for staging.
+// There is no CPU fallback anywhere in this file.
+#include "../../include/makisu_mi.h"
+#include "mi_common.h"
+
+#include <errno.h>
+#include <fcntl.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+using namespace mi;
+
+namespace {
+
+std::mutex g_err_mu;
+std::string g_create_err;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    hipError_t ensure(size_t want) {
+        if (want <= bytes) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        size_t alloc = want + want / 8 + 256;
+        hipError_t e = hipMalloc(&p, alloc);
+        if (e == hipSuccess) bytes = alloc;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    template <typename T> T* as() const { return (T*)p; }
+};
+
+struct SynthSpec { u64 f0, n, seed; std::vector<u64> cids; };
+
+}  // namespace
+
+struct mi_ctx {
+    mi_config cfg;
+    int device = 0;
+    hipDeviceProp_t prop;
+    hipStream_t stream = nullptr;
+    std::vector<hipStream_t> copy_streams;
+    std::vector<void*> staging;          // pinned, staging_bytes each
+    std::vector<hipEvent_t> staging_done;
+    size_t staging_bytes = 0;
+    DevBuf gear_table, heads;
+    DevBuf dd_rep, dd_minid, dd_slot, dd_nuniq;     // dedup scratch
+    hipEvent_t ev[8];
+    int sha_blocks_per_cu = 3;
+    CdcParams cdc;
+    std::string err;
+    mi_stats stats;
+};
+
+struct mi_batch {
+    mi_ctx* ctx;
+    struct FileRec { u64 off, size, tag; };
+    std::vector<FileRec> files;
+    std::vector<SynthSpec> synth;
+    u64 total_bytes = 0;     // sum of sizes
+    u64 arena_used = 0;      // next free arena offset
+    DevBuf arena;
+    // staging window
+    int cur = 0;             // staging buffer being filled
+    u64 win_start = 0;       // arena offset the current staging buffer maps to
+    u64 win_fill = 0;        // bytes valid in it
+    bool staged_any = false;
+    double ms_h2d = 0;
+    bool ran = false, results_valid = false;
+    u64 n_chunks = 0, total_slots = 0;
+    DevBuf file_off, file_size, slot_base, cids, slot_ends, n_chunks_d, first, total_d, scratch;
+    DevBuf chunk_off, chunk_len, chunk_file, chunk_start, hist, cursor, order, digests;
+    DevBuf item_off, item_len, roots, file_sha, dup_of;
+    std::vector<mi_file_result> h_files;
+    std::vector<mi_chunk_result> h_chunks;
+};
+
+namespace {
+
+int fail(mi_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    else { std::lock_guard<std::mutex> g(g_err_mu); g_create_err = buf; }
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                     \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail((c), e_ == hipErrorOutOfMemory ? MI_ERR_NOMEM : MI_ERR_HIP,          \
+                        "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__,     \
+                        __LINE__);                                                          \
+    } while (0)
+
+u64 align_up(u64 v, u64 a) { return (v + a - 1) / a * a; }
+
+// ---- arena + staging ------------------------------------------------------------
+int arena_reserve(mi_batch* b, u64 want) {
+    mi_ctx* c = b->ctx;
+    want += 4096;                                   // slack: tile loads may touch 15 B past a file
+    if (want <= b->arena.bytes) return MI_OK;
+    for (auto s : c->copy_streams) HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    u64 alloc = want + want / 2;
+    void* np = nullptr;
+    hipError_t e = hipMalloc(&np, alloc);
+    if (e != hipSuccess) { alloc = want; HIPCHK(c, hipMalloc(&np, alloc)); }
+    if (b->arena.p && b->arena_used) {
+        const u64 keep = b->arena_used < b->arena.bytes ? b->arena_used : b->arena.bytes;
+        HIPCHK(c, hipMemcpy(np, b->arena.p, keep, hipMemcpyDeviceToDevice));
+    }
+    if (b->arena.p) (void)hipFree(b->arena.p);
+    b->arena.p = np;
+    b->arena.bytes = alloc;
+    return MI_OK;
+}
+
+int staging_flush(mi_batch* b) {
+    mi_ctx* c = b->ctx;
+    if (b->win_fill == 0) return MI_OK;
+    HIPCHK(c, hipMemcpyAsync((u8*)b->arena.p + b->win_start, c->staging[b->cur], b->win_fill,
+                             hipMemcpyHostToDevice, c->copy_streams[b->cur]));
+    HIPCHK(c, hipEventRecord(c->staging_done[b->cur], c->copy_streams[b->cur]));
+    b->staged_any = true;
+    b->cur = (b->cur + 1) % (int)c->staging.size();
+    HIPCHK(c, hipEventSynchronize(c->staging_done[b->cur]));   // the buffer we are about to reuse
+    b->win_start += b->win_fill;
+    b->win_fill = 0;
+    return MI_OK;
+}
+
+// Appends `len` bytes at arena offset `at` through the pinned staging ring.  `src`
+// (memory) or `fd` (file, read with pread at file offset `foff`).
+int staging_append(mi_batch* b, u64 at, const u8* src, int fd, u64 foff, u64 len,
+                   const char* path) {
+    mi_ctx* c = b->ctx;
+    if (b->win_fill == 0) b->win_start = at;
+    if (at != b->win_start + b->win_fill) {
+        const u64 gap = at - (b->win_start + b->win_fill);      // alignment padding
+        if (b->win_fill + gap > c->staging_bytes) {
+            int rc = staging_flush(b);
+            if (rc) return rc;
+            b->win_start = at;
+        } else {
+            memset((u8*)c->staging[b->cur] + b->win_fill, 0, gap);
+            b->win_fill += gap;
+        }
+    }
+    while (len) {
+        if (b->win_fill == c->staging_bytes) {
+            int rc = staging_flush(b);
+            if (rc) return rc;
+        }
+        u64 take = c->staging_bytes - b->win_fill;
+        if (take > len) take = len;
+        u8* dst = (u8*)c->staging[b->cur] + b->win_fill;
+        if (src) {
+            memcpy(dst, src, take);
+            src += take;
+        } else {
+            u64 got = 0;
+            while (got < take) {
+                ssize_t r = pread(fd, dst + got, take - got, (off_t)(foff + got));
+                if (r < 0 && errno == EINTR) continue;
+                if (r <= 0)
+                    return fail(c, MI_ERR_IO, "read %s: %s", path,
+                                r == 0 ? "file shorter than the size given" : strerror(errno));
+                got += (u64)r;
+            }
+            foff += take;
+        }
+        b->win_fill += take;
+        len -= take;
+    }
+    return MI_OK;
+}
+
+int batch_add_common(mi_batch* b, u64 len, u64 tag, u64* at) {
+    if (!b) return MI_ERR_INVALID;
+    if (b->ran) return fail(b->ctx, MI_ERR_STATE, "batch already ran; begin a new batch");
+    *at = align_up(b->arena_used, kFileAlign);
+    int rc = arena_reserve(b, *at + align_up(len, kFileAlign));
+    if (rc) return rc;
+    b->files.push_back({*at, len, tag});
+    b->arena_used = *at + len;
+    b->total_bytes += len;
+    return MI_OK;
+}
+
+template <typename T>
+int upload(mi_ctx* c, DevBuf& d, const std::vector<T>& h) {
+    HIPCHK(c, d.ensure(h.size() * sizeof(T) + 16));
+    if (!h.empty())
+        HIPCHK(c, hipMemcpyAsync(d.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice,
+                                 c->stream));
+    return MI_OK;
+}
+
+float ev_ms(hipEvent_t a, hipEvent_t b) {
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, a, b);
+    return ms;
+}
+
+// ---- the device pipeline ---------------------------------------------------------
+int run_pipeline(mi_batch* b) {
+    mi_ctx* c = b->ctx;
+    hipStream_t s = c->stream;
+    const u64 nf = b->files.size();
+    b->results_valid = false;
+    memset(&c->stats, 0, sizeof c->stats);
+    c->stats.bytes_in = b->total_bytes;
+    c->stats.n_files = nf;
+    c->stats.ms_h2d = b->ms_h2d;
+    b->n_chunks = 0;
+    if (nf == 0) { b->ran = true; return MI_OK; }
+    if (nf >= 0x7FFFFFFFull) return fail(c, MI_ERR_INVALID, "too many files in one batch");
+
+    HIPCHK(c, b->slot_ends.ensure(b->total_slots * 8));
+    HIPCHK(c, b->n_chunks_d.ensure(nf * 4));
+    HIPCHK(c, b->first.ensure(nf * 8));
+    HIPCHK(c, b->total_d.ensure(8));
+    HIPCHK(c, b->scratch.ensure(scan_scratch_elems(nf) * 8));
+
+    const u64* d_off = b->file_off.as<u64>();
+    const u64* d_size = b->file_size.as<u64>();
+
+    HIPCHK(c, hipEventRecord(c->ev[0], s));
+    launch_gear_cdc_files(b->arena.as<u8>(), d_off, d_size, b->slot_base.as<u64>(),
+                          b->slot_ends.as<u64>(), b->n_chunks_d.as<u32>(), nf,
+                          c->gear_table.as<u64>(), c->cdc, s);
+    launch_scan_counts(b->n_chunks_d.as<u32>(), b->first.as<u64>(), b->total_d.as<u64>(), nf,
+                       b->scratch.as<u64>(), s);
+    HIPCHK(c, hipEventRecord(c->ev[1], s));
+    u64 total = 0;
+    HIPCHK(c, hipMemcpyAsync(&total, b->total_d.p, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, hipGetLastError());
+    if (total > b->total_slots || total >= 0xFFFFFFFFull)
+        return fail(c, MI_ERR_HIP, "chunk count %llu out of range (slots %llu)",
+                    (unsigned long long)total, (unsigned long long)b->total_slots);
+    b->n_chunks = total;
+    const u32 nc = (u32)total;
+
+    u32 n_bins = c->cfg.max_size / 64 + 3;
+    if (n_bins > 65536) n_bins = 65536;
+    HIPCHK(c, b->chunk_off.ensure(total * 8));
+    HIPCHK(c, b->chunk_len.ensure(total * 8));
+    HIPCHK(c, b->chunk_start.ensure(total * 8));
+    HIPCHK(c, b->chunk_file.ensure(total * 4));
+    HIPCHK(c, b->hist.ensure(n_bins * 4));
+    HIPCHK(c, b->cursor.ensure(n_bins * 4));
+    HIPCHK(c, b->order.ensure(total * 4));
+    HIPCHK(c, b->digests.ensure(total * 32));
+    HIPCHK(c, b->item_off.ensure(nf * 8));
+    HIPCHK(c, b->item_len.ensure(nf * 8));
+    HIPCHK(c, b->roots.ensure(nf * 32));
+    HIPCHK(c, b->dup_of.ensure(total * 8));
+
+    launch_compact_chunks(d_off, b->slot_base.as<u64>(), b->slot_ends.as<u64>(),
+                          b->n_chunks_d.as<u32>(), b->first.as<u64>(), nf, b->chunk_off.as<u64>(),
+                          b->chunk_len.as<u64>(), b->chunk_file.as<u32>(),
+                          b->chunk_start.as<u64>(), b->hist.as<u32>(), n_bins, s);
+    launch_bin_order(b->chunk_len.as<u64>(), nc, b->hist.as<u32>(), b->cursor.as<u32>(), n_bins,
+                     b->order.as<u32>(), s);
+    HIPCHK(c, hipEventRecord(c->ev[2], s));
+    launch_sha256_items(b->arena.as<u8>(), b->chunk_off.as<u64>(), b->chunk_len.as<u64>(),
+                        b->order.as<u32>(), nc, c->heads.as<u32>(), b->digests.as<u8>(),
+                        c->sha_blocks_per_cu, c->prop.multiProcessorCount, s);
+    HIPCHK(c, hipEventRecord(c->ev[3], s));
+    // per-file roots: SHA-256 over each file's run of chunk digests
+    launch_file_items(b->first.as<u64>(), b->n_chunks_d.as<u32>(), nf, b->item_off.as<u64>(),
+                      b->item_len.as<u64>(), s);
+    launch_sha256_items(b->digests.as<u8>(), b->item_off.as<u64>(), b->item_len.as<u64>(), nullptr,
+                        (u32)nf, c->heads.as<u32>(), b->roots.as<u8>(), c->sha_blocks_per_cu,
+                        c->prop.multiProcessorCount, s);
+    if (c->cfg.flags & MI_FLAG_FILE_SHA256) {
+        HIPCHK(c, b->file_sha.ensure(nf * 32));
+        launch_sha256_items(b->arena.as<u8>(), d_off, d_size, nullptr, (u32)nf,
+                            c->heads.as<u32>(), b->file_sha.as<u8>(), c->sha_blocks_per_cu,
+                            c->prop.multiProcessorCount, s);
+    }
+    HIPCHK(c, hipEventRecord(c->ev[4], s));
+    u64 n_unique = total;
+    if (!(c->cfg.flags & MI_FLAG_NO_DEDUP)) {
+        u64 cap = 1024;
+        while (cap < 2 * total) cap <<= 1;
+        HIPCHK(c, c->dd_rep.ensure(cap * 4));
+        HIPCHK(c, c->dd_minid.ensure(cap * 4));
+        HIPCHK(c, c->dd_slot.ensure(total * 4));
+        HIPCHK(c, c->dd_nuniq.ensure(8));
+        launch_dedup_mark(b->digests.as<u8>(), total, c->dd_rep.as<u32>(), c->dd_minid.as<u32>(),
+                          c->dd_slot.as<u32>(), cap, b->dup_of.as<i64>(), c->dd_nuniq.as<u64>(), s);
+        HIPCHK(c, hipMemcpyAsync(&n_unique, c->dd_nuniq.p, 8, hipMemcpyDeviceToHost, s));
+    } else {
+        HIPCHK(c, hipMemsetAsync(b->dup_of.p, 0xFF, total * 8, s));
+    }
+    HIPCHK(c, hipEventRecord(c->ev[5], s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, hipGetLastError());
+
+    c->stats.n_chunks = total;
+    c->stats.n_unique = n_unique;
+    c->stats.ms_cdc = ev_ms(c->ev[0], c->ev[1]);
+    c->stats.ms_sort = ev_ms(c->ev[1], c->ev[2]);
+    c->stats.ms_sha_chunks = ev_ms(c->ev[2], c->ev[3]);
+    c->stats.ms_sha_files = ev_ms(c->ev[3], c->ev[4]);
+    c->stats.ms_dedup = ev_ms(c->ev[4], c->ev[5]);
+    c->stats.ms_total = ev_ms(c->ev[0], c->ev[5]);
+    b->ran = true;
+    return MI_OK;
+}
+
+int fetch_results(mi_batch* b) {
+    mi_ctx* c = b->ctx;
+    if (!b->ran) return fail(c, MI_ERR_STATE, "results requested before mi_batch_run");
+    if (b->results_valid) return MI_OK;
+    const u64 nf = b->files.size(), nc = b->n_chunks;
+    b->h_files.assign(nf, mi_file_result{});
+    b->h_chunks.assign(nc, mi_chunk_result{});
+    if (nf) {
+        std::vector<u32> ncs(nf);
+        std::vector<u64> first(nf);
+        std::vector<u8> roots(nf * 32), fsha;
+        HIPCHK(c, hipMemcpy(ncs.data(), b->n_chunks_d.p, nf * 4, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(first.data(), b->first.p, nf * 8, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(roots.data(), b->roots.p, nf * 32, hipMemcpyDeviceToHost));
+        if (c->cfg.flags & MI_FLAG_FILE_SHA256) {
+            fsha.resize(nf * 32);
+            HIPCHK(c, hipMemcpy(fsha.data(), b->file_sha.p, nf * 32, hipMemcpyDeviceToHost));
+        }
+        for (u64 f = 0; f < nf; ++f) {
+            mi_file_result& r = b->h_files[f];
+            r.user_tag = b->files[f].tag;
+            r.size = b->files[f].size;
+            r.first_chunk = first[f];
+            r.n_chunks = ncs[f];
+            memcpy(r.chunk_root, &roots[f * 32], 32);
+            if (!fsha.empty()) memcpy(r.file_sha256, &fsha[f * 32], 32);
+        }
+    }
+    if (nc) {
+        std::vector<u64> start(nc), len(nc);
+        std::vector<u32> file(nc);
+        std::vector<i64> dup(nc);
+        std::vector<u8> dg(nc * 32);
+        HIPCHK(c, hipMemcpy(start.data(), b->chunk_start.p, nc * 8, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(len.data(), b->chunk_len.p, nc * 8, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(file.data(), b->chunk_file.p, nc * 4, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(dup.data(), b->dup_of.p, nc * 8, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(dg.data(), b->digests.p, nc * 32, hipMemcpyDeviceToHost));
+        for (u64 i = 0; i < nc; ++i) {
+            mi_chunk_result& r = b->h_chunks[i];
+            r.file_index = file[i];
+            r.offset = start[i];
+            r.length = (u32)len[i];
+            r.dup_of = dup[i];
+            memcpy(r.sha256, &dg[i * 32], 32);
+        }
+    }
+    b->results_valid = true;
+    return MI_OK;
+}
+
+}  // namespace
+
+// ================================ C ABI ============================================
+extern "C" {
+
+int mi_abi_version(void) { return MI_ABI_VERSION; }
+
+int mi_config_default(mi_config* cfg) {
+    if (!cfg) return MI_ERR_INVALID;
+    memset(cfg, 0, sizeof *cfg);
+    cfg->struct_size = sizeof *cfg;
+    cfg->device = 0;
+    cfg->gear_seed = 0x4D414B49ull;
+    cfg->mask_bits = 13;
+    cfg->min_size = 2048;
+    cfg->max_size = 65536;
+    cfg->flags = 0;
+    cfg->staging_bytes = 64ull << 20;
+    cfg->n_streams = 2;
+    return MI_OK;
+}
+
+const char* mi_last_error(mi_ctx* ctx) {
+    if (ctx) return ctx->err.c_str();
+    std::lock_guard<std::mutex> g(g_err_mu);
+    static std::string copy;
+    copy = g_create_err;
+    return copy.c_str();
+}
+
+int mi_ctx_create(const mi_config* cfg, mi_ctx** out) {
+    if (!cfg || !out) return fail(nullptr, MI_ERR_INVALID, "mi_ctx_create: null argument");
+    if (cfg->struct_size != sizeof(mi_config))
+        return fail(nullptr, MI_ERR_INVALID, "mi_ctx_create: struct_size %u != %zu",
+                    cfg->struct_size, sizeof(mi_config));
+    if (cfg->mask_bits > 32 || cfg->min_size < 64 || cfg->max_size < cfg->min_size ||
+        cfg->max_size > (1u << 30))
+        return fail(nullptr, MI_ERR_INVALID,
+                    "mi_ctx_create: need mask_bits<=32, 64<=min_size<=max_size<=2^30");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, MI_ERR_NO_DEVICE,
+                    "no HIP device visible; this engine has no CPU path");
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(nullptr, MI_ERR_NO_DEVICE, "device %d not present (%d visible)", cfg->device,
+                    ndev);
+    mi_ctx* c = new mi_ctx();
+    c->cfg = *cfg;
+    c->device = cfg->device;
+#define CREATE_CHK(call)                                                                      \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            int rc_ = fail(nullptr, MI_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+            mi_ctx_destroy(c);                                                                \
+            return rc_;                                                                       \
+        }                                                                                     \
+    } while (0)
+    CREATE_CHK(hipSetDevice(c->device));
+    CREATE_CHK(hipGetDeviceProperties(&c->prop, c->device));
+    if (strncmp(c->prop.gcnArchName, "gfx950", 6) != 0) {
+        int rc = fail(nullptr, MI_ERR_NO_DEVICE, "device %d is %s; kernels are built for gfx950 only",
+                      c->device, c->prop.gcnArchName);
+        mi_ctx_destroy(c);
+        return rc;
+    }
+    CREATE_CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (auto& e : c->ev) e = nullptr;
+    for (auto& e : c->ev) CREATE_CHK(hipEventCreate(&e));
+    c->staging_bytes = cfg->staging_bytes ? cfg->staging_bytes : (64ull << 20);
+    const u32 ns = cfg->n_streams ? cfg->n_streams : 2;
+    for (u32 i = 0; i < ns; ++i) {
+        hipStream_t st = nullptr;
+        CREATE_CHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        c->copy_streams.push_back(st);
+        hipEvent_t ev = nullptr;
+        CREATE_CHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        c->staging_done.push_back(ev);
+    }
+    // Gear table: first 256 outputs of splitmix64(seed)
+    u64 table[256];
+    u64 st = cfg->gear_seed;
+    for (int i = 0; i < 256; ++i) { st += kSmGamma; table[i] = splitmix64_mix(st); }
+    CREATE_CHK(c->gear_table.ensure(sizeof table));
+    CREATE_CHK(hipMemcpy(c->gear_table.p, table, sizeof table, hipMemcpyHostToDevice));
+    CREATE_CHK(c->heads.ensure(sizeof(u32) * kShaQueues));
+    c->cdc.thresh_m1 = cfg->mask_bits == 0 ? 0xFFFFFFFFu : (u32)((1ull << (32 - cfg->mask_bits)) - 1);
+    c->cdc.min_size = cfg->min_size;
+    c->cdc.max_size = cfg->max_size;
+    c->cdc.pad = 0;
+    if (const char* e = getenv("MI_SHA_BLOCKS_PER_CU")) {
+        int v = atoi(e);
+        if (v >= 1 && v <= 8) c->sha_blocks_per_cu = v;
+    }
+    memset(&c->stats, 0, sizeof c->stats);
+#undef CREATE_CHK
+    *out = c;
+    return MI_OK;
+}
+
+void mi_ctx_destroy(mi_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto p : c->staging) if (p) (void)hipHostFree(p);
+    for (auto s : c->copy_streams) if (s) (void)hipStreamDestroy(s);
+    for (auto e : c->staging_done) if (e) (void)hipEventDestroy(e);
+    for (auto e : c->ev) if (e) (void)hipEventDestroy(e);
+    c->gear_table.release(); c->heads.release();
+    c->dd_rep.release(); c->dd_minid.release(); c->dd_slot.release(); c->dd_nuniq.release();
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int mi_get_stats(mi_ctx* c, mi_stats* out) {
+    if (!c || !out) return MI_ERR_INVALID;
+    *out = c->stats;
+    return MI_OK;
+}
+
+int mi_device_info(mi_ctx* c, int32_t* n_cu, int32_t* clock_mhz, uint64_t* hbm_bytes, char* name,
+                   size_t name_cap) {
+    if (!c) return MI_ERR_INVALID;
+    if (n_cu) *n_cu = c->prop.multiProcessorCount;
+    if (clock_mhz) *clock_mhz = c->prop.clockRate / 1000;
+    if (hbm_bytes) *hbm_bytes = c->prop.totalGlobalMem;
+    if (name && name_cap) snprintf(name, name_cap, "%s (%s)", c->prop.name, c->prop.gcnArchName);
+    return MI_OK;
+}
+
+int mi_batch_begin(mi_ctx* c, uint64_t n_files_hint, uint64_t bytes_hint, mi_batch** out) {
+    if (!c || !out) return MI_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    mi_batch* b = new mi_batch();
+    b->ctx = c;
+    b->files.reserve(n_files_hint);
+    if (bytes_hint) {
+        int rc = arena_reserve(b, bytes_hint + n_files_hint * kFileAlign);
+        if (rc) { delete b; return rc; }
+    }
+    *out = b;
+    return MI_OK;
+}
+
+static int ensure_staging(mi_ctx* c) {
+    if (!c->staging.empty()) return MI_OK;
+    for (size_t i = 0; i < c->copy_streams.size(); ++i) {
+        void* p = nullptr;
+        HIPCHK(c, hipHostMalloc(&p, c->staging_bytes, hipHostMallocDefault));
+        c->staging.push_back(p);
+    }
+    return MI_OK;
+}
+
+int mi_batch_add_bytes(mi_batch* b, const void* data, uint64_t len, uint64_t user_tag) {
+    if (!b || (!data && len)) return MI_ERR_INVALID;
+    mi_ctx* c = b->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure_staging(c);
+    if (rc) return rc;
+    u64 at;
+    rc = batch_add_common(b, len, user_tag, &at);
+    if (rc) return rc;
+    if (len == 0) return MI_OK;
+    return staging_append(b, at, (const u8*)data, -1, 0, len, nullptr);
+}
+
+int mi_batch_add_path(mi_batch* b, const char* path, uint64_t size, uint64_t user_tag) {
+    if (!b || !path) return MI_ERR_INVALID;
+    mi_ctx* c = b->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure_staging(c);
+    if (rc) return rc;
+    int fd = open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) return fail(c, MI_ERR_IO, "open %s: %s", path, strerror(errno));
+    u64 at;
+    rc = batch_add_common(b, size, user_tag, &at);
+    if (rc == MI_OK && size) {
+        rc = staging_append(b, at, nullptr, fd, 0, size, path);
+        if (rc) {                                   // undo the registration: the file is unusable
+            b->total_bytes -= size;                 // (its arena range stays reserved, unused)
+            b->files.pop_back();
+        }
+    }
+    close(fd);
+    return rc;
+}
+
+int mi_batch_add_synthetic(mi_batch* b, uint64_t n_files, const uint64_t* sizes,
+                           const uint64_t* content_ids, uint64_t seed) {
+    if (!b || (!sizes && n_files)) return MI_ERR_INVALID;
+    mi_ctx* c = b->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (b->ran) return fail(c, MI_ERR_STATE, "batch already ran; begin a new batch");
+    // synthetic files are generated on the device at run time; flush any host window first
+    int rc = staging_flush(b);
+    if (rc) return rc;
+    SynthSpec sp;
+    sp.f0 = b->files.size();
+    sp.n = n_files;
+    sp.seed = seed;
+    sp.cids.resize(n_files);
+    u64 end = b->arena_used;
+    for (u64 i = 0; i < n_files; ++i) {
+        const u64 at = align_up(end, kFileAlign);
+        const u64 cid = content_ids ? content_ids[i] : sp.f0 + i;
+        sp.cids[i] = cid;
+        b->files.push_back({at, sizes[i], cid});
+        end = at + sizes[i];
+        b->total_bytes += sizes[i];
+    }
+    rc = arena_reserve(b, align_up(end, kFileAlign));
+    if (rc) return rc;
+    b->arena_used = end;
+    b->synth.push_back(std::move(sp));
+    return MI_OK;
+}
+
+int mi_batch_run(mi_batch* b) {
+    if (!b) return MI_ERR_INVALID;
+    mi_ctx* c = b->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (b->ran) return fail(c, MI_ERR_STATE, "batch already ran; use mi_batch_rerun");
+    int rc = staging_flush(b);
+    if (rc) return rc;
+    for (auto s : c->copy_streams) HIPCHK(c, hipStreamSynchronize(s));
+    // file tables
+    const u64 nf = b->files.size();
+    std::vector<u64> off(nf), size(nf), slot(nf);
+    u64 slots = 0;
+    for (u64 f = 0; f < nf; ++f) {
+        off[f] = b->files[f].off;
+        size[f] = b->files[f].size;
+        slot[f] = slots;
+        slots += size[f] / c->cfg.min_size + 2;
+    }
+    b->total_slots = slots;
+    if ((rc = upload(c, b->file_off, off))) return rc;
+    if ((rc = upload(c, b->file_size, size))) return rc;
+    if ((rc = upload(c, b->slot_base, slot))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));    // the vectors above go out of scope
+    for (const SynthSpec& sp : b->synth) {
+        HIPCHK(c, b->cids.ensure(sp.n * 8 + 16));
+        HIPCHK(c, hipMemcpyAsync(b->cids.p, sp.cids.data(), sp.n * 8, hipMemcpyHostToDevice,
+                                 c->stream));
+        launch_synth_fill(b->arena.as<u8>(), b->file_off.as<u64>() + sp.f0,
+                          b->file_size.as<u64>() + sp.f0, b->cids.as<u64>(), sp.n, sp.seed,
+                          c->stream);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return run_pipeline(b);
+}
+
+int mi_batch_rerun(mi_batch* b) {
+    if (!b) return MI_ERR_INVALID;
+    mi_ctx* c = b->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!b->ran) return fail(c, MI_ERR_STATE, "mi_batch_rerun before mi_batch_run");
+    return run_pipeline(b);
+}
+
+int mi_batch_counts(mi_batch* b, uint64_t* n_files, uint64_t* n_chunks, uint64_t* n_bytes) {
+    if (!b) return MI_ERR_INVALID;
+    if (n_files) *n_files = b->files.size();
+    if (n_chunks) *n_chunks = b->n_chunks;
+    if (n_bytes) *n_bytes = b->total_bytes;
+    return MI_OK;
+}
+
+int mi_batch_files(mi_batch* b, mi_file_result* out, uint64_t cap) {
+    if (!b || (!out && cap)) return MI_ERR_INVALID;
+    HIPCHK(b->ctx, hipSetDevice(b->ctx->device));
+    int rc = fetch_results(b);
+    if (rc) return rc;
+    if (cap < b->h_files.size())
+        return fail(b->ctx, MI_ERR_CAPACITY, "file result buffer holds %llu rows, need %zu",
+                    (unsigned long long)cap, b->h_files.size());
+    if (!b->h_files.empty()) memcpy(out, b->h_files.data(), b->h_files.size() * sizeof(mi_file_result));
+    return MI_OK;
+}
+
+int mi_batch_chunks(mi_batch* b, mi_chunk_result* out, uint64_t cap) {
+    if (!b || (!out && cap)) return MI_ERR_INVALID;
+    HIPCHK(b->ctx, hipSetDevice(b->ctx->device));
+    int rc = fetch_results(b);
+    if (rc) return rc;
+    if (cap < b->h_chunks.size())
+        return fail(b->ctx, MI_ERR_CAPACITY, "chunk result buffer holds %llu rows, need %zu",
+                    (unsigned long long)cap, b->h_chunks.size());
+    if (!b->h_chunks.empty())
+        memcpy(out, b->h_chunks.data(), b->h_chunks.size() * sizeof(mi_chunk_result));
+    return MI_OK;
+}
+
+int mi_batch_device_digests(mi_batch* b, const void** d_digests, uint64_t* n_chunks) {
+    if (!b || !d_digests || !n_chunks) return MI_ERR_INVALID;
+    if (!b->ran) return fail(b->ctx, MI_ERR_STATE, "digests requested before mi_batch_run");
+    *d_digests = b->digests.p;
+    *n_chunks = b->n_chunks;
+    return MI_OK;
+}
+
+int mi_batch_read_back(mi_batch* b, void* out, uint64_t cap) {
+    if (!b || (!out && cap)) return MI_ERR_INVALID;
+    mi_ctx* c = b->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!b->ran) return fail(c, MI_ERR_STATE, "read back before mi_batch_run");
+    if (cap < b->total_bytes) return fail(c, MI_ERR_CAPACITY, "read-back buffer too small");
+    u8* dst = (u8*)out;
+    for (const auto& f : b->files) {
+        if (f.size) HIPCHK(c, hipMemcpy(dst, b->arena.as<u8>() + f.off, f.size, hipMemcpyDeviceToHost));
+        dst += f.size;
+    }
+    return MI_OK;
+}
+
+int mi_batch_free(mi_batch* b) {
+    if (!b) return MI_ERR_INVALID;
+    mi_ctx* c = b->ctx;
+    (void)hipSetDevice(c->device);
+    for (auto s : c->copy_streams) (void)hipStreamSynchronize(s);
+    (void)hipStreamSynchronize(c->stream);
+    DevBuf* bufs[] = {&b->arena, &b->file_off, &b->file_size, &b->slot_base, &b->cids,
+                      &b->slot_ends, &b->n_chunks_d, &b->first, &b->total_d, &b->scratch,
+                      &b->chunk_off, &b->chunk_len, &b->chunk_file, &b->chunk_start, &b->hist,
+                      &b->cursor, &b->order, &b->digests, &b->item_off, &b->item_len, &b->roots,
+                      &b->file_sha, &b->dup_of};
+    for (DevBuf* d : bufs) d->release();
+    delete b;
+    return MI_OK;
+}
+
+int mi_dedup_mark(mi_ctx* c, const void* d_digests, uint64_t n, void* d_dup_of, uint64_t* n_unique) {
+    if (!c || (n && (!d_digests || !d_dup_of))) return MI_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n >= 0xFFFFFFFFull) return fail(c, MI_ERR_INVALID, "dedup set too large");
+    u64 cap = 1024;
+    while (cap < 2 * n) cap <<= 1;
+    HIPCHK(c, c->dd_rep.ensure(cap * 4));
+    HIPCHK(c, c->dd_minid.ensure(cap * 4));
+    HIPCHK(c, c->dd_slot.ensure(n * 4 + 16));
+    HIPCHK(c, c->dd_nuniq.ensure(8));
+    HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
+    launch_dedup_mark((const u8*)d_digests, n, c->dd_rep.as<u32>(), c->dd_minid.as<u32>(),
+                      c->dd_slot.as<u32>(), cap, (i64*)d_dup_of, c->dd_nuniq.as<u64>(), c->stream);
+    HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
+    u64 nu = 0;
+    HIPCHK(c, hipMemcpyAsync(&nu, c->dd_nuniq.p, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    c->stats.ms_dedup = ev_ms(c->ev[6], c->ev[7]);
+    c->stats.n_unique = nu;
+    if (n_unique) *n_unique = nu;
+    return MI_OK;
+}
+
+int mi_batch_set_global_dedup(mi_batch* b, const void* d_dup_of_global, uint64_t first_global) {
+    if (!b || !d_dup_of_global) return MI_ERR_INVALID;
+    mi_ctx* c = b->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!b->ran) return fail(c, MI_ERR_STATE, "global dedup before mi_batch_run");
+    if (b->n_chunks)
+        HIPCHK(c, hipMemcpy(b->dup_of.p, (const i64*)d_dup_of_global + first_global,
+                            b->n_chunks * 8, hipMemcpyDeviceToDevice));
+    b->results_valid = false;
+    return MI_OK;
+}
+
+int mi_sha256_many(mi_ctx* c, const void* data, const uint64_t* offsets, const uint64_t* lens,
+                   uint64_t n, uint8_t* out) {
+    if (!c || (n && (!offsets || !lens || !out))) return MI_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n == 0) return MI_OK;
+    if (n >= 0xFFFFFFFFull) return fail(c, MI_ERR_INVALID, "too many strings");
+    u64 span = 0;
+    for (u64 i = 0; i < n; ++i) if (offsets[i] + lens[i] > span) span = offsets[i] + lens[i];
+    if (span && !data) return MI_ERR_INVALID;
+    DevBuf d_data, d_off, d_len, d_out;
+    int rc = MI_OK;
+    hipError_t e;
+    if ((e = d_data.ensure(span + 64)) != hipSuccess || (e = d_off.ensure(n * 8)) != hipSuccess ||
+        (e = d_len.ensure(n * 8)) != hipSuccess || (e = d_out.ensure(n * 32)) != hipSuccess) {
+        rc = fail(c, MI_ERR_NOMEM, "mi_sha256_many: %s", hipGetErrorString(e));
+    } else {
+        if (span) e = hipMemcpy(d_data.p, data, span, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d_off.p, offsets, n * 8, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d_len.p, lens, n * 8, hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            launch_sha256_items(d_data.as<u8>(), d_off.as<u64>(), d_len.as<u64>(), nullptr, (u32)n,
+                                c->heads.as<u32>(), d_out.as<u8>(), c->sha_blocks_per_cu,
+                                c->prop.multiProcessorCount, c->stream);
+            e = hipStreamSynchronize(c->stream);
+        }
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpy(out, d_out.p, n * 32, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(c, MI_ERR_HIP, "mi_sha256_many: %s", hipGetErrorString(e));
+    }
+    d_data.release(); d_off.release(); d_len.release(); d_out.release();
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,77 @@
+// mi_common.h -- shared declarations for the gfx950 kernels and the host pipeline.
+// Product code: never includes anything under oracle/.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mi {
+
+typedef uint8_t  u8;
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef int64_t  i64;
+
+// ---- Gear-CDC tile geometry (gear_cdc.hip) ------------------------------------
+constexpr int kGearWG     = 256;                 // threads per workgroup (4 waves)
+constexpr int kGearRun    = 256;                 // bytes one lane owns in a tile
+constexpr int kGearTile   = kGearWG * kGearRun;  // 64 KiB of file per tile
+constexpr int kGearHalo   = 64;                  // Gear window: h depends on <= 64 bytes
+constexpr int kGearTableCopies = 1;
+
+// ---- SHA-256 work queues (sha256.hip) ----------------------------------------
+constexpr int kShaQueues  = 8;                   // one head word per XCD (block b runs on XCD b % 8)
+constexpr int kShaWG      = 256;
+
+// file placement in the device arena: every file starts on this boundary so tile
+// loads are 16-byte aligned and coalesced
+constexpr u64 kFileAlign  = 256;
+
+struct CdcParams {
+    u32 thresh_m1;     // candidate iff hi32(h) <= thresh_m1  (top mask_bits bits zero)
+    u32 min_size;
+    u32 max_size;
+    u32 pad;
+};
+
+// splitmix64 finalizer (Steele, Lea, Flood 2014) -- synthetic data + Gear table
+__host__ __device__ inline u64 splitmix64_mix(u64 z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+constexpr u64 kSmGamma = 0x9E3779B97F4A7C15ULL;
+
+// ---- kernel launchers (each defined next to its kernels) ----------------------
+// gear_cdc.hip
+void launch_gear_cdc_files(const u8* d_data, const u64* d_file_off, const u64* d_file_size,
+                           const u64* d_slot_base, u64* d_slot_ends, u32* d_n_chunks,
+                           u64 n_files, const u64* d_gear_table, CdcParams p, hipStream_t s);
+
+// sha256.hip : n independent byte strings -> n digests.  item i = base[off[i] .. +len[i]).
+// order (optional) = processing order, longest first; heads = kShaQueues zeroed words.
+void launch_sha256_items(const u8* d_base, const u64* d_off, const u64* d_len, const u32* d_order,
+                         u32 n, u32* d_heads, u8* d_out, int blocks_per_cu, int n_cu,
+                         hipStream_t s);
+
+// tables.hip
+void launch_synth_fill(u8* d_data, const u64* d_file_off, const u64* d_file_size,
+                       const u64* d_content_id, u64 n_files, u64 seed, hipStream_t s);
+// n_chunks[f] -> first_chunk[f] (exclusive scan); d_total receives the sum
+void launch_scan_counts(const u32* d_counts, u64* d_first, u64* d_total, u64 n,
+                        u64* d_scratch, hipStream_t s);
+u64  scan_scratch_elems(u64 n);
+void launch_compact_chunks(const u64* d_file_off, const u64* d_slot_base, const u64* d_slot_ends,
+                           const u32* d_n_chunks, const u64* d_first, u64 n_files,
+                           u64* d_chunk_off, u64* d_chunk_len, u32* d_chunk_file,
+                           u64* d_chunk_start, u32* d_hist, u32 n_bins, hipStream_t s);
+void launch_bin_order(const u64* d_len, u32 n, u32* d_hist, u32* d_cursor, u32 n_bins,
+                      u32* d_order, hipStream_t s);
+void launch_file_items(const u64* d_first, const u32* d_n_chunks, u64 n_files, u64* d_off,
+                       u64* d_len, hipStream_t s);
+void launch_crc32_files(const u8* d_data, const u64* d_file_off, const u64* d_file_size,
+                        u64 n_files, u32* d_crc, hipStream_t s);
+void launch_dedup_mark(const u8* d_digests, u64 n, u32* d_rep, u32* d_minid, u32* d_slot_of,
+                       u64 cap_pow2, i64* d_dup_of, u64* d_n_unique, hipStream_t s);
+
+}  // namespace mi

@@ -1,0 +1,283 @@
+// tables.hip -- the small kernels around the two hot ones: synthetic file
+// generation, chunk-table compaction, longest-first binning for the SHA queues,
+// per-file root items, and duplicate marking over a digest set.
+//
+// None of these has a reference counterpart except duplicate marking, which is the
+// chunk-granular analogue of the reference's content-addressed layer dedup
+// (lib/builder/step/common.go:88-91; lib/registry/client.go:123-131,177-185).
+#include "mi_common.h"
+
+namespace mi {
+
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+
+// ---- synthetic content: BASELINE.md section 3 / oracle mi_ref_synth_fill -------
+// word w of content c under seed s = mix(mix(s + (c+1)*G) + (w+1)*G); bytes little-endian.
+__global__ __launch_bounds__(256)
+void synth_fill_kernel(u8* __restrict__ data, const u64* __restrict__ file_off,
+                       const u64* __restrict__ file_size, const u64* __restrict__ content_id,
+                       u64 n_files, u64 seed) {
+    // blockIdx.x = file, blockIdx.y strides the file in 64 KiB pieces
+    const u64 f = blockIdx.x;
+    const u64 size = file_size[f];
+    const u64 cid = content_id ? content_id[f] : f;
+    const u64 base = splitmix64_mix(seed + (cid + 1) * kSmGamma);
+    u64x2* dst = (u64x2*)(data + file_off[f]);
+    const u64 n16 = (size + 15) / 16;
+    for (u64 u = (u64)blockIdx.y * blockDim.x + threadIdx.x; u < n16;
+         u += (u64)gridDim.y * blockDim.x) {
+        u64x2 v;
+        v.x = splitmix64_mix(base + (2 * u + 1) * kSmGamma);
+        v.y = splitmix64_mix(base + (2 * u + 2) * kSmGamma);
+        dst[u] = v;
+    }
+}
+
+void launch_synth_fill(u8* d_data, const u64* d_file_off, const u64* d_file_size,
+                       const u64* d_content_id, u64 n_files, u64 seed, hipStream_t s) {
+    if (n_files == 0) return;
+    // y-dimension: enough pieces that a handful of huge files still fill the chip
+    u32 gy = n_files >= 4096 ? 1 : (u32)(4096 / n_files);
+    if (gy > 1024) gy = 1024;
+    hipLaunchKernelGGL(synth_fill_kernel, dim3((u32)n_files, gy), dim3(256), 0, s, d_data,
+                       d_file_off, d_file_size, d_content_id, n_files, seed);
+}
+
+// ---- exclusive scan of per-file chunk counts ------------------------------------
+constexpr int kScanBlock = 256;
+constexpr int kScanPer   = 8;                      // elements per thread
+constexpr int kScanTile  = kScanBlock * kScanPer;  // 2048 per block
+
+__device__ __forceinline__ u64 block_exclusive_scan(u64 v, u64* total, u64* lds /*>=8*/) {
+    // wave inclusive scan with DPP-free shuffles, then across the 4 waves through LDS
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    u64 x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 lo = __shfl_up((u32)x, d), hi = __shfl_up((u32)(x >> 32), d);
+        const u64 y = ((u64)hi << 32) | lo;
+        if (lane >= d) x += y;
+    }
+    if (lane == 63) lds[wave] = x;
+    __syncthreads();
+    u64 wave_off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kScanBlock / 64; ++w) {
+        const u64 s = lds[w];
+        if (w < wave) wave_off += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return wave_off + x - v;
+}
+
+__global__ __launch_bounds__(kScanBlock)
+void scan_block_sums_kernel(const u32* __restrict__ counts, u64 n, u64* __restrict__ block_sums) {
+    __shared__ u64 lds[8];
+    const u64 base = (u64)blockIdx.x * kScanTile + (u64)threadIdx.x * kScanPer;
+    u64 s = 0;
+#pragma unroll
+    for (int k = 0; k < kScanPer; ++k) if (base + k < n) s += counts[base + k];
+    u64 tot;
+    (void)block_exclusive_scan(s, &tot, lds);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(kScanBlock)
+void scan_block_offsets_kernel(u64* __restrict__ block_sums, u64 n_blocks, u64* __restrict__ total) {
+    // single block: exclusive scan of block_sums in place
+    __shared__ u64 lds[8];
+    u64 carry = 0;
+    for (u64 b0 = 0; b0 < n_blocks; b0 += kScanBlock) {
+        const u64 i = b0 + threadIdx.x;
+        const u64 v = i < n_blocks ? block_sums[i] : 0;
+        u64 tot;
+        const u64 ex = block_exclusive_scan(v, &tot, lds);
+        if (i < n_blocks) block_sums[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ __launch_bounds__(kScanBlock)
+void scan_final_kernel(const u32* __restrict__ counts, u64 n, const u64* __restrict__ block_off,
+                       u64* __restrict__ first) {
+    __shared__ u64 lds[8];
+    const u64 base = (u64)blockIdx.x * kScanTile + (u64)threadIdx.x * kScanPer;
+    u32 c[kScanPer];
+    u64 s = 0;
+#pragma unroll
+    for (int k = 0; k < kScanPer; ++k) { c[k] = base + k < n ? counts[base + k] : 0; s += c[k]; }
+    u64 tot;
+    u64 ex = block_exclusive_scan(s, &tot, lds) + block_off[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < kScanPer; ++k) {
+        if (base + k < n) first[base + k] = ex;
+        ex += c[k];
+    }
+}
+
+u64 scan_scratch_elems(u64 n) { return (n + kScanTile - 1) / kScanTile + 1; }
+
+void launch_scan_counts(const u32* d_counts, u64* d_first, u64* d_total, u64 n, u64* d_scratch,
+                        hipStream_t s) {
+    if (n == 0) { (void)hipMemsetAsync(d_total, 0, sizeof(u64), s); return; }
+    const u64 nb = (n + kScanTile - 1) / kScanTile;
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3((u32)nb), dim3(kScanBlock), 0, s, d_counts, n,
+                       d_scratch);
+    hipLaunchKernelGGL(scan_block_offsets_kernel, dim3(1), dim3(kScanBlock), 0, s, d_scratch, nb,
+                       d_total);
+    hipLaunchKernelGGL(scan_final_kernel, dim3((u32)nb), dim3(kScanBlock), 0, s, d_counts, n,
+                       d_scratch, d_first);
+}
+
+// ---- chunk-table compaction + length histogram ----------------------------------
+__device__ __forceinline__ u32 sha_blocks_of(u64 len) {
+    // 64-byte compressions SHA-256 needs for len bytes (data + 0x80 + 8-byte length)
+    return (u32)(len >> 6) + 1u + ((len & 63) > 55 ? 1u : 0u);
+}
+
+__global__ __launch_bounds__(256)
+void compact_chunks_kernel(const u64* __restrict__ file_off, const u64* __restrict__ slot_base,
+                           const u64* __restrict__ slot_ends, const u32* __restrict__ n_chunks,
+                           const u64* __restrict__ first, u64 n_files, u64* __restrict__ chunk_off,
+                           u64* __restrict__ chunk_len, u32* __restrict__ chunk_file,
+                           u64* __restrict__ chunk_start, u32* __restrict__ hist, u32 n_bins) {
+    const u64 f = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_files) return;
+    const u64* ends = slot_ends + slot_base[f];
+    const u32 nc = n_chunks[f];
+    const u64 g0 = first[f], fo = file_off[f];
+    u64 start = 0;
+    for (u32 k = 0; k < nc; ++k) {
+        const u64 e = ends[k];
+        const u64 len = e - start;
+        chunk_off[g0 + k] = fo + start;
+        chunk_len[g0 + k] = len;
+        chunk_file[g0 + k] = (u32)f;
+        chunk_start[g0 + k] = start;
+        u32 bin = sha_blocks_of(len);
+        if (bin >= n_bins) bin = n_bins - 1;
+        atomicAdd(&hist[bin], 1u);
+        start = e;
+    }
+}
+
+void launch_compact_chunks(const u64* d_file_off, const u64* d_slot_base, const u64* d_slot_ends,
+                           const u32* d_n_chunks, const u64* d_first, u64 n_files,
+                           u64* d_chunk_off, u64* d_chunk_len, u32* d_chunk_file,
+                           u64* d_chunk_start, u32* d_hist, u32 n_bins, hipStream_t s) {
+    if (n_files == 0) return;
+    (void)hipMemsetAsync(d_hist, 0, sizeof(u32) * n_bins, s);
+    hipLaunchKernelGGL(compact_chunks_kernel, dim3((u32)((n_files + 255) / 256)), dim3(256), 0, s,
+                       d_file_off, d_slot_base, d_slot_ends, d_n_chunks, d_first, n_files,
+                       d_chunk_off, d_chunk_len, d_chunk_file, d_chunk_start, d_hist, n_bins);
+}
+
+// ---- longest-first processing order (counting sort by block count) --------------
+__global__ __launch_bounds__(256)
+void bin_cursor_kernel(const u32* __restrict__ hist, u32* __restrict__ cursor, u32 n_bins) {
+    // single block; cursor[b] = number of items in bins > b  (descending order start)
+    __shared__ u64 lds[8];
+    u64 carry = 0;
+    for (u32 b0 = 0; b0 < n_bins; b0 += 256) {
+        const u32 i = b0 + threadIdx.x;                     // position from the top
+        const u32 bin = n_bins - 1 - i;
+        const u64 v = i < n_bins ? hist[bin] : 0;
+        u64 tot;
+        const u64 ex = block_exclusive_scan(v, &tot, lds);
+        if (i < n_bins) cursor[bin] = (u32)(carry + ex);
+        carry += tot;
+    }
+}
+
+__global__ __launch_bounds__(256)
+void bin_scatter_kernel(const u64* __restrict__ len, u32 n, u32* __restrict__ cursor, u32 n_bins,
+                        u32* __restrict__ order) {
+    const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    u32 bin = sha_blocks_of(len[g]);
+    if (bin >= n_bins) bin = n_bins - 1;
+    order[atomicAdd(&cursor[bin], 1u)] = g;
+}
+
+void launch_bin_order(const u64* d_len, u32 n, u32* d_hist, u32* d_cursor, u32 n_bins,
+                      u32* d_order, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(bin_cursor_kernel, dim3(1), dim3(256), 0, s, d_hist, d_cursor, n_bins);
+    hipLaunchKernelGGL(bin_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_len, n,
+                       d_cursor, n_bins, d_order);
+}
+
+// ---- per-file root items: string f = digests[first[f] .. +n_chunks[f]) ----------
+__global__ __launch_bounds__(256)
+void file_items_kernel(const u64* __restrict__ first, const u32* __restrict__ n_chunks, u64 n_files,
+                       u64* __restrict__ off, u64* __restrict__ len) {
+    const u64 f = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_files) return;
+    off[f] = first[f] * 32;
+    len[f] = (u64)n_chunks[f] * 32;
+}
+
+void launch_file_items(const u64* d_first, const u32* d_n_chunks, u64 n_files, u64* d_off,
+                       u64* d_len, hipStream_t s) {
+    if (n_files == 0) return;
+    hipLaunchKernelGGL(file_items_kernel, dim3((u32)((n_files + 255) / 256)), dim3(256), 0, s,
+                       d_first, d_n_chunks, n_files, d_off, d_len);
+}
+
+// ---- duplicate marking over a digest set -----------------------------------------
+// Open-addressing table keyed by the first 8 digest bytes (already uniform).  A slot
+// holds a representative row (rep) and the minimum row index among equal digests
+// (minid); equality is always checked on all 32 bytes, so a 64-bit key collision only
+// costs an extra probe.  Output is deterministic: dup_of = smallest equal row, or -1.
+__device__ __forceinline__ bool digest_eq(const u8* a, const u8* b) {
+    const u32x4 a0 = ((const u32x4*)a)[0], a1 = ((const u32x4*)a)[1];
+    const u32x4 b0 = ((const u32x4*)b)[0], b1 = ((const u32x4*)b)[1];
+    const u32x4 d0 = a0 ^ b0, d1 = a1 ^ b1;
+    return (d0.x | d0.y | d0.z | d0.w | d1.x | d1.y | d1.z | d1.w) == 0;
+}
+
+__global__ __launch_bounds__(256)
+void dedup_insert_kernel(const u8* __restrict__ digests, u64 n, u32* __restrict__ rep,
+                         u32* __restrict__ minid, u32* __restrict__ slot_of, u64 mask) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u8* mine = digests + 32 * i;
+    u64 slot = *(const u64*)mine & mask;
+    for (;;) {
+        u32 r = atomicCAS(&rep[slot], 0u, (u32)i + 1u);
+        if (r == 0u || r == (u32)i + 1u || digest_eq(digests + 32ull * (r - 1u), mine)) break;
+        slot = (slot + 1) & mask;
+    }
+    atomicMin(&minid[slot], (u32)i);
+    slot_of[i] = (u32)slot;
+}
+
+__global__ __launch_bounds__(256)
+void dedup_finish_kernel(u64 n, const u32* __restrict__ minid, const u32* __restrict__ slot_of,
+                         i64* __restrict__ dup_of, u64* __restrict__ n_unique) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u32 m = minid[slot_of[i]];
+    const bool first = (m == (u32)i);
+    dup_of[i] = first ? -1 : (i64)m;
+    if (first) atomicAdd((unsigned long long*)n_unique, 1ull);
+}
+
+void launch_dedup_mark(const u8* d_digests, u64 n, u32* d_rep, u32* d_minid, u32* d_slot_of,
+                       u64 cap_pow2, i64* d_dup_of, u64* d_n_unique, hipStream_t s) {
+    (void)hipMemsetAsync(d_n_unique, 0, sizeof(u64), s);
+    if (n == 0) return;
+    (void)hipMemsetAsync(d_rep, 0, sizeof(u32) * cap_pow2, s);
+    (void)hipMemsetAsync(d_minid, 0xFF, sizeof(u32) * cap_pow2, s);
+    const u32 grid = (u32)((n + 255) / 256);
+    hipLaunchKernelGGL(dedup_insert_kernel, dim3(grid), dim3(256), 0, s, d_digests, n, d_rep,
+                       d_minid, d_slot_of, cap_pow2 - 1);
+    hipLaunchKernelGGL(dedup_finish_kernel, dim3(grid), dim3(256), 0, s, n, d_minid, d_slot_of,
+                       d_dup_of, d_n_unique);
+}
+
+}  // namespace mi

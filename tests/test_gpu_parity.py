@@ -1,0 +1,228 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle, bit-exact.
+
+Cut points: parity UNPINNED w.r.t. the reference (it has no CDC);
+the oracle is this repo's restatement of its own Gear spec.  SHA-256: pinned by the
+reference's fixtures (tests/test_oracle.py) and checked here on the GPU as well.
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x4D414B49
+
+
+def _params(oracle, eng):
+    c = eng.cfg
+    return oracle.CdcParams(c.gear_seed, c.mask_bits, c.min_size, c.max_size)
+
+
+def _check_batch(oracle, eng, blobs, flags_sha=False):
+    """Runs blobs through the engine and the oracle; asserts every column is identical."""
+    with eng.batch(len(blobs), sum(len(b) for b in blobs)) as b:
+        for i, blob in enumerate(blobs):
+            b.add_bytes(blob, tag=1000 + i)
+        b.run()
+        files, chunks = b.files().copy(), b.chunks().copy()
+        back = b.read_back().copy()
+    data = np.frombuffer(b"".join(bytes(x) for x in blobs), dtype=np.uint8)
+    assert np.array_equal(back, data), "staged bytes differ from what was added"
+    sizes = np.array([len(x) for x in blobs], dtype=np.uint64)
+    offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.uint64) if len(blobs) else sizes
+    rf, rc = oracle.scan_batch(data if data.size else np.zeros(1, np.uint8), offs, sizes,
+                               _params(oracle, eng))
+    assert len(chunks) == len(rc)
+    assert np.array_equal(files["n_chunks"], rf["n_chunks"])
+    assert np.array_equal(files["first_chunk"], rf["first_chunk"])
+    assert np.array_equal(files["size"], sizes)
+    assert np.array_equal(files["user_tag"], 1000 + np.arange(len(blobs)))
+    assert np.array_equal(chunks["file_index"], rc["file_index"])
+    assert np.array_equal(chunks["offset"], rc["offset"]), "cut points differ"
+    assert np.array_equal(chunks["length"], rc["length"]), "cut points differ"
+    assert np.array_equal(chunks["sha256"], rc["sha256"]), "chunk digests differ"
+    assert np.array_equal(files["chunk_root"], rf["chunk_root"]), "file roots differ"
+    assert np.array_equal(chunks["dup_of"], rc["dup_of"]), "dedup marking differs"
+    if flags_sha:
+        assert np.array_equal(files["file_sha256"], rf["file_sha256"])
+    return files, chunks
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import makisu_amd
+    e = makisu_amd.Engine()
+    yield e
+    e.close()
+
+
+def test_device_is_gfx950(eng):
+    info = eng.device_info()
+    assert "gfx950" in info["name"]
+    assert info["n_cu"] >= 200
+
+
+def test_sha256_many_kats(eng):
+    # FIPS 180-4 / NIST examples + the reference's empty-tar constants
+    # (lib/docker/image/const_linux.go:18, const_darwin.go:18, digest.go:25)
+    blobs = [b"", b"abc", b"abcdbcdecdefdefgefghfghighijhijkijkljklmklmnlmnomnopnopq",
+             b"a" * 1000000, bytes(10240), bytes(1024)]
+    blobs += [bytes(range(256)) * 3][:1] + [b"x" * n for n in (55, 56, 57, 63, 64, 65, 119, 120, 127, 128)]
+    got = eng.sha256_many(blobs)
+    for blob, d in zip(blobs, got):
+        assert d == hashlib.sha256(blob).digest(), len(blob)
+    assert got[4].hex() == "84ff92691f909a05b224e1c56abb4864f01b4f8e3c854e4bb4c7baf1d3f6d652"
+    assert got[5].hex() == "5f70bf18a086007016e948b04aed3b82103a36bea41755b6cddfaf10ace3c6ef"
+    assert got[0].hex() == "e3b0c44298fc1c149afbf4c8996fb92427ae41e4649b934ca495991b7852b855"
+
+
+def test_sha256_many_random_lengths(eng):
+    rng = np.random.default_rng(7)
+    blobs = [rng.integers(0, 256, int(n), dtype=np.uint8).tobytes()
+             for n in rng.integers(0, 5000, 700)]
+    for blob, d in zip(blobs, eng.sha256_many(blobs)):
+        assert d == hashlib.sha256(blob).digest()
+
+
+def test_small_batch_random_files(oracle, eng):
+    rng = np.random.default_rng(1)
+    blobs = [oracle.synth_fill(SEED, i, 0, int(n)).tobytes()
+             for i, n in enumerate([65536, 65536, 100000, 1, 63, 64, 65, 2047, 2048, 2049,
+                                    4096, 131072, 65535, 65537, 300000])]
+    _check_batch(oracle, eng, blobs)
+
+
+def test_empty_and_ragged(oracle, eng):
+    blobs = [b"", b"a", b"", bytes(5000), b"\xff" * 70000, b""]
+    files, chunks = _check_batch(oracle, eng, blobs)
+    assert files["n_chunks"][0] == 0 and files["n_chunks"][2] == 0
+    # SHA-256 of zero chunk digests = SHA-256("")
+    assert files["chunk_root"][0].tobytes() == hashlib.sha256(b"").digest()
+
+
+def test_empty_batch(eng):
+    with eng.batch() as b:
+        b.run()
+        assert b.counts() == (0, 0, 0)
+        assert len(b.files()) == 0 and len(b.chunks()) == 0
+
+
+def test_low_entropy_forced_cuts(oracle, eng):
+    # all-zero, period-4 KiB and short-period content exercise max_size forced cuts
+    period = oracle.synth_fill(SEED, 99, 0, 4096).tobytes()
+    blobs = [bytes(500000), period * 100, b"ab" * 150000, b"\x01" * 65536]
+    files, chunks = _check_batch(oracle, eng, blobs)
+    assert chunks["length"].max() <= eng.cfg.max_size
+
+
+def test_duplicates_are_marked(oracle, eng):
+    a = oracle.synth_fill(SEED, 1, 0, 200000).tobytes()
+    b_ = oracle.synth_fill(SEED, 2, 0, 70000).tobytes()
+    files, chunks = _check_batch(oracle, eng, [a, b_, a, a[:150000], b_])
+    assert (chunks["dup_of"] >= 0).sum() > 0
+    first = chunks[chunks["dup_of"] < 0]
+    assert len({x.tobytes() for x in first["sha256"]}) == len(first)
+
+
+def test_multi_tile_file(oracle, eng):
+    # > 64 KiB tiles: the cut carry across tiles and the 64-byte halo
+    blobs = [oracle.synth_fill(SEED, 5, 0, 5 * 65536 + 1234).tobytes(),
+             oracle.synth_fill(SEED, 6, 0, 3 * 65536).tobytes()]
+    _check_batch(oracle, eng, blobs)
+
+
+@pytest.mark.parametrize("mask_bits,min_size,max_size", [
+    (0, 64, 64), (0, 64, 4096), (2, 64, 256), (6, 256, 1024), (10, 1024, 8192),
+    (13, 2048, 65536), (16, 4096, 262144), (32, 2048, 65536)])
+def test_param_sweep(oracle, mask_bits, min_size, max_size):
+    import makisu_amd
+    with makisu_amd.Engine(mask_bits=mask_bits, min_size=min_size, max_size=max_size) as e:
+        blobs = [oracle.synth_fill(SEED, 40 + i, 0, n).tobytes()
+                 for i, n in enumerate([70000, 5000, 200000, 64, 1])]
+        blobs.append(bytes(30000))
+        _check_batch(oracle, e, blobs)
+
+
+def test_file_sha256_flag(oracle):
+    import makisu_amd
+    with makisu_amd.Engine(flags=makisu_amd.FLAG_FILE_SHA256) as e:
+        blobs = [oracle.synth_fill(SEED, 70 + i, 0, n).tobytes() for i, n in enumerate([1, 70000, 0, 4097])]
+        files, _ = _check_batch(oracle, e, blobs, flags_sha=True)
+        for blob, row in zip(blobs, files):
+            assert row["file_sha256"].tobytes() == hashlib.sha256(blob).digest()
+
+
+def test_synthetic_matches_oracle_generator(oracle, eng):
+    sizes = [65536, 1000, 65536, 7, 200000]
+    cids = [3, 4, 3, 9, 11]
+    with eng.batch() as b:
+        b.add_synthetic(sizes, cids, seed=SEED)
+        b.run()
+        back = b.read_back().copy()
+        files, chunks = b.files().copy(), b.chunks().copy()
+    want = np.concatenate([oracle.synth_fill(SEED, c, 0, n) for c, n in zip(cids, sizes)])
+    assert np.array_equal(back, want)
+    offs = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+    rf, rc = oracle.scan_batch(want, offs, sizes, _params(oracle, eng))
+    assert np.array_equal(chunks["sha256"], rc["sha256"])
+    assert np.array_equal(chunks["dup_of"], rc["dup_of"])
+    assert np.array_equal(files["chunk_root"], rf["chunk_root"])
+    # file 2 is a copy of file 0: all of its chunks are duplicates
+    f2 = chunks[chunks["file_index"] == 2]
+    assert (f2["dup_of"] >= 0).all()
+
+
+def test_many_small_files_vs_oracle(oracle, eng):
+    # 2000 x 64 KiB of the C2 generator -- oracle runs in ~1 s
+    n = 2000
+    with eng.batch() as b:
+        b.add_synthetic([65536] * n, None, seed=SEED)
+        b.run()
+        files, chunks = b.files().copy(), b.chunks().copy()
+    data = np.concatenate([oracle.synth_fill(SEED, i, 0, 65536) for i in range(n)])
+    rf, rc = oracle.scan_batch(data, np.arange(n) * 65536, [65536] * n, _params(oracle, eng))
+    assert np.array_equal(chunks["offset"], rc["offset"])
+    assert np.array_equal(chunks["length"], rc["length"])
+    assert np.array_equal(chunks["sha256"], rc["sha256"])
+    assert np.array_equal(files["chunk_root"], rf["chunk_root"])
+
+
+def test_rerun_is_idempotent(eng):
+    with eng.batch() as b:
+        b.add_synthetic([65536] * 500, None, seed=SEED + 3)
+        b.run()
+        c1 = b.chunks().copy()
+        b.rerun()
+        c2 = b.chunks().copy()
+    assert np.array_equal(c1, c2)
+
+
+def test_add_path(oracle, eng, tmp_path):
+    blobs = [oracle.synth_fill(SEED, 80 + i, 0, n).tobytes() for i, n in enumerate([100000, 0, 5])]
+    with eng.batch() as b:
+        for i, blob in enumerate(blobs):
+            p = tmp_path / ("f%d" % i)
+            p.write_bytes(blob)
+            b.add_path(str(p), tag=i)
+        b.run()
+        chunks = b.chunks().copy()
+    data = np.frombuffer(b"".join(blobs), dtype=np.uint8)
+    sizes = [len(x) for x in blobs]
+    rf, rc = oracle.scan_batch(data, np.concatenate([[0], np.cumsum(sizes)[:-1]]), sizes, _params(oracle, eng))
+    assert np.array_equal(chunks["sha256"], rc["sha256"])
+
+
+def test_add_path_errors(eng, tmp_path):
+    import makisu_amd
+    with eng.batch() as b:
+        with pytest.raises(makisu_amd.MiError) as ei:
+            b.add_path(str(tmp_path / "missing"), size=10)
+        assert ei.value.code == -5
+        p = tmp_path / "short"
+        p.write_bytes(b"abc")
+        with pytest.raises(makisu_amd.MiError):
+            b.add_path(str(p), size=10)      # shorter than the stat-time size
+        b.add_path(str(p), size=2)           # CopyN semantics: only `size` bytes are read
+        b.run()
+        assert b.counts()[2] == 2
