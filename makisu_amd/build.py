@@ -11,8 +11,13 @@ LIB = os.path.join(HERE, "libmakisu_mi.so")
 SOURCES = ["mi_api.hip", "gear_cdc.hip", "sha256.hip", "tables.hip"]
 HEADERS = ["mi_common.h", os.path.join("..", "..", "include", "makisu_mi.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-         "-Wno-unused-result", "-fgpu-rdc" if False else "-fno-gpu-rdc"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result",
+         "-fno-gpu-rdc"]
+# sha256.hip aggregates its dequeue atomic per wave by hand and consumes the result one
+# iteration later; LLVM's atomic optimizer would wrap it in its own reduction + an immediate
+# wait for the result, which stalls the wave for a memory round trip per dequeue.
+EXTRA = {"sha256.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]}
+OBJ_DIR = os.path.join(HERE, "_obj")
 
 
 def needs_build():
@@ -26,10 +31,22 @@ def needs_build():
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
-    cmd = [HIPCC] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    objs, procs = [], []
+    for src in SOURCES:
+        obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
+        objs.append(obj)
+        cmd = [HIPCC] + FLAGS + EXTRA.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    link = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", "-Wl,--no-undefined"] + objs + ["-o", LIB]
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+        print(" ".join(link))
+    subprocess.check_call(link)
     return LIB
 
 

@@ -13,34 +13,44 @@
 // cuts are then SELECTED sequentially: skip candidates closer than min_size to
 // the previous cut, force a cut at max_size, the file end always cuts.
 //
-// Mapping: one 256-thread workgroup per file, walking the file in 64 KiB tiles.
-//   1. tile (+64 B halo) -> LDS with coalesced 16 B/lane global loads; rows of 256 B
-//      are padded by 16 B so the per-lane ds_read_b128 below are conflict-free;
-//   2. every lane owns a 256 B run: warms h over the 64 bytes before it, then rolls
-//      over its run (Gear table = 2 KiB in LDS), tracking min(hi32(h)) per 16 bytes
-//      with v_min3_u32 so the candidate test costs 1/2 VALU op per byte; hits set
-//      bits in an LDS bitmap (one bit per byte of the tile);
-//   3. wave 0 selects cuts from the bitmap with wave-wide find-first-set
-//      (64 lanes x 64 bits per step, __ballot + ctz), carrying last_cut across
-//      tiles, and appends chunk ends to the file's slot region in HBM.
-// HBM traffic: every file byte read once (+64 B halo per tile), 8 B written per
-// chunk.  Bound: HBM / LDS-lookup rate.
+// Mapping (v2): one WAVE marks one 64 KiB tile; every lane owns a contiguous 1 KiB
+// run of it.
+//   1. a lane streams its run straight from HBM in 128-byte pieces (8 x 16 B loads
+//      = exactly one cache line, touched once), the next piece in flight while the
+//      current one is hashed; it warms h over the 64 bytes before its run (6 % extra
+//      reads, L2 hits: they are the previous lane's last line);
+//   2. the Gear table lives in LDS, replicated kCopies times and interleaved so lanes
+//      that differ in (lane % kCopies) never share a bank: the byte-indexed
+//      ds_read_b64 lookups -- the dominant LDS traffic, 8 B per input byte -- stay
+//      near conflict-free.  No file bytes are staged in LDS, so the LDS budget goes
+//      to the table copies and the per-wave candidate bitmaps;
+//   3. h rolls with one v_lshl_add_u64 per byte; the candidate test costs half a VALU
+//      op per byte (v_min3_u32 over the high words of 16 consecutive hashes, a slow
+//      path only when the minimum passes the mask); hits set bits in the wave's LDS
+//      bitmap (one bit per byte of the tile);
+//   4. cuts are selected from the bitmap with wave-wide find-first-set (64 lanes x
+//      64 bits per step, __ballot + ctz), carrying last_cut across tiles, and the
+//      chunk ends appended to the file's slot region in HBM.
+// Small files (<= one tile): one wave per file, four files per workgroup, no
+// workgroup barrier at all.  Large files: one workgroup per file, four tiles marked
+// in parallel per step, then wave 0 selects across them in order.
+// HBM traffic: every file byte read once (+6 % warm-up, mostly L2 hits), 8 B written
+// per chunk.  Bound: HBM bandwidth / LDS lookup rate.
 #include "mi_common.h"
 
 namespace mi {
 
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kRowPad     = 16;
-constexpr int kTileLogical = kGearHalo + kGearTile;                 // halo + tile bytes
-constexpr int kTileRows   = kTileLogical / kGearRun + 1;            // 257 rows of 256 B
-constexpr int kTileLds    = kTileLogical + kRowPad * kTileRows;     // padded bytes
-constexpr int kBitmapWords = kGearTile / 32;                        // u32 words
-constexpr int kGearLdsBytes = ((kTileLds + 15) / 16) * 16 + kBitmapWords * 4 + 256 * 8;
+constexpr int kCopies      = kGearTableCopies;          // Gear table replicas in LDS
+constexpr int kWavesPerWG  = kGearWG / 64;              // 4
+constexpr int kLaneRun     = kGearTile / 64;            // 1 KiB per lane
+constexpr int kPiece       = 128;                       // bytes per load group (one cache line)
+constexpr int kBitmapWords = kGearTile / 32;            // u32 words per wave bitmap (8 KiB)
+constexpr int kTableBytes  = 256 * 8 * kCopies;
+constexpr int kGearLdsBytes = kTableBytes + kWavesPerWG * kBitmapWords * 4;
 
-__device__ __forceinline__ u32 lds_phys(u32 x) { return x + ((x >> 8) << 4); }
-
-// first set bit of the LDS bitmap within [lo, hi] (bit indices, inclusive), -1 if none.
+// first set bit of an LDS bitmap within [lo, hi] (bit indices, inclusive), -1 if none.
 // Executed by one full wave; all lanes return the same value.
 __device__ __forceinline__ int bitmap_find_first(const u64* bm, int lo, int hi, int lane) {
     const int w_lo = lo >> 6, w_hi = hi >> 6;
@@ -61,131 +71,197 @@ __device__ __forceinline__ int bitmap_find_first(const u64* bm, int lo, int hi, 
     return -1;
 }
 
+// 16 more bytes into the rolling hash; hh[k] = high word after byte k.
+__device__ __forceinline__ void roll16(u64& h, const u32x4 v, const u64* tab, u32 (&hh)[16]) {
+    const u32 wv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const u32 b = (wv[k >> 2] >> (8 * (k & 3))) & 0xFF;
+        h = (h << 1) + tab[b * kCopies];
+        hh[k] = (u32)(h >> 32);
+    }
+}
+
+__device__ __forceinline__ void load_piece(const u8* p, u32x4 (&d)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d[i] = *(const u32x4*)(p + 16 * i);
+}
+
+// One wave marks the candidates of tile [ts, ts+tlen) of a file into `bitmap`
+// (bit p <-> cut end ts + p + 1).  fptr is 16-byte aligned, ts a multiple of kGearTile.
+__device__ __forceinline__ void mark_tile(const u8* __restrict__ fptr, u64 ts, u32 tlen,
+                                          u32* bitmap, const u64* tab, u32 thresh_m1, int lane) {
+    {   // clear the bitmap: 32 words per lane
+        u32x4* bz = (u32x4*)bitmap;
+        const u32x4 z = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < kBitmapWords / 4 / 64; ++i) bz[i * 64 + lane] = z;
+    }
+    const u32 run0 = (u32)lane * kLaneRun;               // tile-relative start of my run
+    if (run0 >= tlen) return;
+    const u8* p = fptr + ts + run0;
+    const u32 run_len = tlen - run0 < (u32)kLaneRun ? tlen - run0 : (u32)kLaneRun;
+    const int n_pieces = (int)((run_len + kPiece - 1) / kPiece);
+    u32x4 cur[8], nxt[8];
+    load_piece(p, cur);
+    u64 h = 0;
+    u32 hh[16];
+    if (ts + run0 != 0) {                                // warm the window: 64 bytes before my run
+        u32x4 wq[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wq[i] = *(const u32x4*)(p - 64 + 16 * i);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) roll16(h, wq[i], tab, hh);
+    }
+    for (int pc = 0; pc < n_pieces; ++pc) {
+        if (pc + 1 < n_pieces) load_piece(p + (pc + 1) * kPiece, nxt);   // in flight while hashing
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            roll16(h, cur[g], tab, hh);
+            u32 m = 0xFFFFFFFFu;
+#pragma unroll
+            for (int k = 0; k < 16; k += 2) m = min(m, min(hh[k], hh[k + 1]));   // v_min3_u32
+            if (m <= thresh_m1) {                        // rare: a candidate among these 16 bytes
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const u32 pos = run0 + pc * kPiece + g * 16 + k;            // byte index in tile
+                    if (hh[k] <= thresh_m1 && pos < tlen)
+                        atomicOr(&bitmap[pos >> 5], 1u << (pos & 31));
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
+    }
+}
+
+// Wave-uniform cut selection over one marked tile; appends chunk ends, updates last/n_out.
+__device__ __forceinline__ void select_tile(const u32* bitmap, u64 ts, u32 tlen, const CdcParams& p,
+                                            u64& last, u32& n_out, u64* __restrict__ ends, int lane) {
+    const u64 te = ts + tlen;                            // ends in this tile: (ts, te]
+    for (;;) {
+        u64 lo = last + p.min_size;
+        if (lo < ts + 1) lo = ts + 1;
+        u64 hi = last + p.max_size;
+        if (hi > te) hi = te;
+        if (lo <= hi) {
+            const int b = bitmap_find_first((const u64*)bitmap, (int)(lo - ts - 1),
+                                            (int)(hi - ts - 1), lane);
+            if (b >= 0) {
+                last = ts + (u64)b + 1;
+                if (lane == 0) ends[n_out] = last;
+                ++n_out;
+                continue;
+            }
+        }
+        if (last + p.max_size <= te) {                   // forced cut at max_size
+            last += p.max_size;
+            if (lane == 0) ends[n_out] = last;
+            ++n_out;
+            continue;
+        }
+        break;
+    }
+}
+
+__device__ __forceinline__ void load_table(u64* table, const u64* __restrict__ gear_table, int tid) {
+    // table[b * kCopies + c] = G[b] for every copy c
+    for (int i = tid; i < 256 * kCopies; i += kGearWG) table[i] = gear_table[i / kCopies];
+}
+
+// ---- small files: one wave per file (size <= kGearTile) ----------------------------------
 __global__ __launch_bounds__(kGearWG)
-void gear_cdc_files_kernel(const u8* __restrict__ data, const u64* __restrict__ file_off,
+void gear_cdc_small_kernel(const u8* __restrict__ data, const u64* __restrict__ file_off,
                            const u64* __restrict__ file_size, const u64* __restrict__ slot_base,
                            u64* __restrict__ slot_ends, u32* __restrict__ n_chunks,
+                           const u32* __restrict__ list, u32 n_list,
                            const u64* __restrict__ gear_table, CdcParams p) {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
-    u8*  tile   = smem;                                                  // kTileLds bytes
-    u32* bitmap = (u32*)(smem + ((kTileLds + 15) / 16) * 16);            // kBitmapWords
-    u64* table  = (u64*)(bitmap + kBitmapWords);                         // 256 x u64
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const u64 f = blockIdx.x;
+    u64* table = (u64*)smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    u32* bitmap = (u32*)(smem + kTableBytes) + wave * kBitmapWords;
+    load_table(table, gear_table, tid);
+    __syncthreads();
+    const u32 li = blockIdx.x * kWavesPerWG + wave;
+    if (li >= n_list) return;
+    const u32 f = list[li];
     const u64 size = file_size[f];
-    const u8* fptr = data + file_off[f];
     u64* ends = slot_ends + slot_base[f];
-
-    table[tid] = gear_table[tid];                                        // kGearWG == 256
-
-    u64 last = 0;          // wave-0 uniform: previous cut
-    u32 n_out = 0;         // wave-0 uniform: chunks emitted
-
-    for (u64 ts = 0; ts < size; ts += kGearTile) {
-        const u32 tlen = (u32)((size - ts < (u64)kGearTile) ? (size - ts) : (u64)kGearTile);
-        // ---- 1. stage halo + tile into LDS -----------------------------------------
-        // logical byte x of the staging space = file byte ts - 64 + x
-        const u32 n16 = (kGearHalo + tlen + 15) / 16;
-        const u32 u_first = (ts == 0) ? kGearHalo / 16 : 0;              // no halo before byte 0
-#pragma unroll 4
-        for (u32 u = u_first + tid; u < n16; u += kGearWG) {
-            const u32 x = u * 16;
-            const u32x4 v = *(const u32x4*)(fptr + ts + x - kGearHalo);
-            *(u32x4*)(tile + lds_phys(x)) = v;
-        }
-        for (u32 i = tid; i < (u32)kBitmapWords; i += kGearWG) bitmap[i] = 0;
-        __syncthreads();
-
-        // ---- 2. mark candidates -----------------------------------------------------
-        {
-            const u32 run0 = (u32)tid * kGearRun;        // tile-relative first byte of my run
-            if (run0 < tlen) {
-                u64 h = 0;
-                const u32 xb = run0;                     // logical x of the warm-up start
-#pragma unroll
-                for (int j = 0; j < kGearHalo / 16; ++j) {
-                    const u32x4 v = *(const u32x4*)(tile + lds_phys(xb + 16 * j));
-                    const u32 wv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                    for (int k = 0; k < 16; ++k)
-                        h = (h << 1) + table[(wv[k >> 2] >> (8 * (k & 3))) & 0xFF];
-                }
-                if (ts == 0 && tid == 0) h = 0;          // file start: window starts empty
-#pragma unroll 2
-                for (int j = 0; j < kGearRun / 16; ++j) {
-                    const u32x4 v = *(const u32x4*)(tile + lds_phys(xb + kGearHalo + 16 * j));
-                    const u32 wv[4] = {v.x, v.y, v.z, v.w};
-                    u32 hh[16];
-                    u32 m = 0xFFFFFFFFu;
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) {
-                        h = (h << 1) + table[(wv[k >> 2] >> (8 * (k & 3))) & 0xFF];
-                        hh[k] = (u32)(h >> 32);
-                    }
-#pragma unroll
-                    for (int k = 0; k < 16; k += 2) m = min(m, min(hh[k], hh[k + 1]));   // v_min3_u32
-                    if (m <= p.thresh_m1) {              // rare: ~1 lane in 512 per step
-#pragma unroll
-                        for (int k = 0; k < 16; ++k) {
-                            const u32 pos = run0 + 16 * j + k;           // byte index in tile
-                            if (hh[k] <= p.thresh_m1 && pos < tlen)
-                                atomicOr(&bitmap[pos >> 5], 1u << (pos & 31));
-                        }
-                    }
-                }
-            }
-        }
-        __syncthreads();
-
-        // ---- 3. select cuts (wave 0) -------------------------------------------------
-        if (tid < 64) {
-            const u64 te = ts + tlen;                    // ends in this tile: (ts, te]
-            for (;;) {
-                u64 lo = last + p.min_size;
-                if (lo < ts + 1) lo = ts + 1;
-                u64 hi = last + p.max_size;
-                if (hi > te) hi = te;
-                if (lo <= hi) {
-                    const int b = bitmap_find_first((const u64*)bitmap, (int)(lo - ts - 1),
-                                                    (int)(hi - ts - 1), lane);
-                    if (b >= 0) {
-                        last = ts + (u64)b + 1;
-                        if (lane == 0) ends[n_out] = last;
-                        ++n_out;
-                        continue;
-                    }
-                }
-                if (last + p.max_size <= te) {           // forced cut at max_size
-                    last += p.max_size;
-                    if (lane == 0) ends[n_out] = last;
-                    ++n_out;
-                    continue;
-                }
-                break;
-            }
-        }
-        __syncthreads();                                 // bitmap + tile are reused
+    u64 last = 0;
+    u32 n_out = 0;
+    if (size) {
+        mark_tile(data + file_off[f], 0, (u32)size, bitmap, table + (lane % kCopies), p.thresh_m1, lane);
+        // the wave's own LDS writes are ordered for the wave itself after the waitcnt the
+        // compiler inserts; no other wave touches this bitmap
+        __builtin_amdgcn_wave_barrier();
+        select_tile(bitmap, 0, (u32)size, p, last, n_out, ends, lane);
     }
-    if (tid == 0) {
+    if (lane == 0) {
         if (size > last) { ends[n_out] = size; ++n_out; }   // the file end always cuts
         n_chunks[f] = n_out;
     }
 }
 
-void launch_gear_cdc_files(const u8* d_data, const u64* d_file_off, const u64* d_file_size,
-                           const u64* d_slot_base, u64* d_slot_ends, u32* d_n_chunks,
-                           u64 n_files, const u64* d_gear_table, CdcParams p, hipStream_t s) {
-    if (n_files == 0) return;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gear_cdc_files_kernel,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, kGearLdsBytes);
-        attr_set = true;
+// ---- large files: one workgroup per file, kWavesPerWG tiles per step -------------------------
+__global__ __launch_bounds__(kGearWG)
+void gear_cdc_large_kernel(const u8* __restrict__ data, const u64* __restrict__ file_off,
+                           const u64* __restrict__ file_size, const u64* __restrict__ slot_base,
+                           u64* __restrict__ slot_ends, u32* __restrict__ n_chunks,
+                           const u32* __restrict__ list, u32 n_list,
+                           const u64* __restrict__ gear_table, CdcParams p) {
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    u64* table = (u64*)smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    u32* bitmaps = (u32*)(smem + kTableBytes);
+    load_table(table, gear_table, tid);
+    __syncthreads();
+    const u32 f = list[blockIdx.x];
+    const u64 size = file_size[f];
+    const u8* fptr = data + file_off[f];
+    u64* ends = slot_ends + slot_base[f];
+    u64 last = 0;          // wave-0 uniform
+    u32 n_out = 0;
+    for (u64 g0 = 0; g0 < size; g0 += (u64)kGearTile * kWavesPerWG) {
+        const u64 ts = g0 + (u64)wave * kGearTile;
+        if (ts < size) {
+            const u32 tlen = (u32)((size - ts < (u64)kGearTile) ? (size - ts) : (u64)kGearTile);
+            mark_tile(fptr, ts, tlen, bitmaps + wave * kBitmapWords, table + (lane % kCopies),
+                      p.thresh_m1, lane);
+        }
+        __syncthreads();
+        if (wave == 0) {
+            for (int t = 0; t < kWavesPerWG; ++t) {
+                const u64 tts = g0 + (u64)t * kGearTile;
+                if (tts >= size) break;
+                const u32 tlen = (u32)((size - tts < (u64)kGearTile) ? (size - tts) : (u64)kGearTile);
+                select_tile(bitmaps + t * kBitmapWords, tts, tlen, p, last, n_out, ends, lane);
+            }
+        }
+        __syncthreads();                                 // bitmaps are reused by the next step
     }
-    hipLaunchKernelGGL(gear_cdc_files_kernel, dim3((u32)n_files), dim3(kGearWG), kGearLdsBytes, s,
-                       d_data, d_file_off, d_file_size, d_slot_base, d_slot_ends, d_n_chunks,
-                       d_gear_table, p);
+    if (tid == 0) {
+        if (size > last) { ends[n_out] = size; ++n_out; }
+        n_chunks[f] = n_out;
+    }
+}
+
+void launch_gear_cdc(const u8* d_data, const u64* d_file_off, const u64* d_file_size,
+                     const u64* d_slot_base, u64* d_slot_ends, u32* d_n_chunks,
+                     const u32* d_small_list, u32 n_small, const u32* d_large_list, u32 n_large,
+                     const u64* d_gear_table, CdcParams p, hipStream_t s) {
+    (void)hipFuncSetAttribute((const void*)gear_cdc_small_kernel,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kGearLdsBytes);
+    (void)hipFuncSetAttribute((const void*)gear_cdc_large_kernel,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kGearLdsBytes);
+    if (n_small)
+        hipLaunchKernelGGL(gear_cdc_small_kernel, dim3((n_small + kWavesPerWG - 1) / kWavesPerWG),
+                           dim3(kGearWG), kGearLdsBytes, s, d_data, d_file_off, d_file_size,
+                           d_slot_base, d_slot_ends, d_n_chunks, d_small_list, n_small,
+                           d_gear_table, p);
+    if (n_large)
+        hipLaunchKernelGGL(gear_cdc_large_kernel, dim3(n_large), dim3(kGearWG), kGearLdsBytes, s,
+                           d_data, d_file_off, d_file_size, d_slot_base, d_slot_ends, d_n_chunks,
+                           d_large_list, n_large, d_gear_table, p);
 }
 
 }  // namespace mi

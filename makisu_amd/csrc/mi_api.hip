@@ -62,7 +62,7 @@ struct mi_ctx {
     DevBuf gear_table, heads;
     DevBuf dd_rep, dd_minid, dd_slot, dd_nuniq;     // dedup scratch
     hipEvent_t ev[8];
-    int sha_blocks_per_cu = 3;
+    int sha_blocks_per_cu = 2;
     CdcParams cdc;
     std::string err;
     mi_stats stats;
@@ -84,8 +84,11 @@ struct mi_batch {
     double ms_h2d = 0;
     bool ran = false, results_valid = false;
     u64 n_chunks = 0, total_slots = 0;
+    DevBuf small_list, large_list;      // file indices by CDC kernel variant
+    u32 n_small = 0, n_large = 0;
     DevBuf file_off, file_size, slot_base, cids, slot_ends, n_chunks_d, first, total_d, scratch;
-    DevBuf chunk_off, chunk_len, chunk_file, chunk_start, hist, cursor, order, digests;
+    DevBuf chunk_off, chunk_len, chunk_file, chunk_start, hist, cursor, digests;
+    DevBuf q_off, q_len, q_id;          // SHA queue descriptors, longest chunk first
     DevBuf item_off, item_len, roots, file_sha, dup_of;
     std::vector<mi_file_result> h_files;
     std::vector<mi_chunk_result> h_chunks;
@@ -247,9 +250,10 @@ int run_pipeline(mi_batch* b) {
     const u64* d_size = b->file_size.as<u64>();
 
     HIPCHK(c, hipEventRecord(c->ev[0], s));
-    launch_gear_cdc_files(b->arena.as<u8>(), d_off, d_size, b->slot_base.as<u64>(),
-                          b->slot_ends.as<u64>(), b->n_chunks_d.as<u32>(), nf,
-                          c->gear_table.as<u64>(), c->cdc, s);
+    launch_gear_cdc(b->arena.as<u8>(), d_off, d_size, b->slot_base.as<u64>(),
+                    b->slot_ends.as<u64>(), b->n_chunks_d.as<u32>(), b->small_list.as<u32>(),
+                    b->n_small, b->large_list.as<u32>(), b->n_large, c->gear_table.as<u64>(),
+                    c->cdc, s);
     launch_scan_counts(b->n_chunks_d.as<u32>(), b->first.as<u64>(), b->total_d.as<u64>(), nf,
                        b->scratch.as<u64>(), s);
     HIPCHK(c, hipEventRecord(c->ev[1], s));
@@ -271,7 +275,9 @@ int run_pipeline(mi_batch* b) {
     HIPCHK(c, b->chunk_file.ensure(total * 4));
     HIPCHK(c, b->hist.ensure(n_bins * 4));
     HIPCHK(c, b->cursor.ensure(n_bins * 4));
-    HIPCHK(c, b->order.ensure(total * 4));
+    HIPCHK(c, b->q_off.ensure(total * 8));
+    HIPCHK(c, b->q_len.ensure(total * 8));
+    HIPCHK(c, b->q_id.ensure(total * 4));
     HIPCHK(c, b->digests.ensure(total * 32));
     HIPCHK(c, b->item_off.ensure(nf * 8));
     HIPCHK(c, b->item_len.ensure(nf * 8));
@@ -282,11 +288,12 @@ int run_pipeline(mi_batch* b) {
                           b->n_chunks_d.as<u32>(), b->first.as<u64>(), nf, b->chunk_off.as<u64>(),
                           b->chunk_len.as<u64>(), b->chunk_file.as<u32>(),
                           b->chunk_start.as<u64>(), b->hist.as<u32>(), n_bins, s);
-    launch_bin_order(b->chunk_len.as<u64>(), nc, b->hist.as<u32>(), b->cursor.as<u32>(), n_bins,
-                     b->order.as<u32>(), s);
+    launch_bin_order(b->chunk_off.as<u64>(), b->chunk_len.as<u64>(), nc, b->hist.as<u32>(),
+                     b->cursor.as<u32>(), n_bins, b->q_off.as<u64>(), b->q_len.as<u64>(),
+                     b->q_id.as<u32>(), s);
     HIPCHK(c, hipEventRecord(c->ev[2], s));
-    launch_sha256_items(b->arena.as<u8>(), b->chunk_off.as<u64>(), b->chunk_len.as<u64>(),
-                        b->order.as<u32>(), nc, c->heads.as<u32>(), b->digests.as<u8>(),
+    launch_sha256_items(b->arena.as<u8>(), b->q_off.as<u64>(), b->q_len.as<u64>(),
+                        b->q_id.as<u32>(), nc, c->heads.as<u32>(), b->digests.as<u8>(),
                         c->sha_blocks_per_cu, c->prop.multiProcessorCount, s);
     HIPCHK(c, hipEventRecord(c->ev[3], s));
     // per-file roots: SHA-256 over each file's run of chunk digests
@@ -612,13 +619,19 @@ int mi_batch_run(mi_batch* b) {
     // file tables
     const u64 nf = b->files.size();
     std::vector<u64> off(nf), size(nf), slot(nf);
+    std::vector<u32> small, large;
     u64 slots = 0;
     for (u64 f = 0; f < nf; ++f) {
         off[f] = b->files[f].off;
         size[f] = b->files[f].size;
         slot[f] = slots;
         slots += size[f] / c->cfg.min_size + 2;
+        (size[f] <= (u64)kGearTile ? small : large).push_back((u32)f);
     }
+    b->n_small = (u32)small.size();
+    b->n_large = (u32)large.size();
+    if ((rc = upload(c, b->small_list, small))) return rc;
+    if ((rc = upload(c, b->large_list, large))) return rc;
     b->total_slots = slots;
     if ((rc = upload(c, b->file_off, off))) return rc;
     if ((rc = upload(c, b->file_size, size))) return rc;
@@ -705,10 +718,10 @@ int mi_batch_free(mi_batch* b) {
     (void)hipSetDevice(c->device);
     for (auto s : c->copy_streams) (void)hipStreamSynchronize(s);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&b->arena, &b->file_off, &b->file_size, &b->slot_base, &b->cids,
+    DevBuf* bufs[] = {&b->arena, &b->small_list, &b->large_list, &b->file_off, &b->file_size, &b->slot_base, &b->cids,
                       &b->slot_ends, &b->n_chunks_d, &b->first, &b->total_d, &b->scratch,
                       &b->chunk_off, &b->chunk_len, &b->chunk_file, &b->chunk_start, &b->hist,
-                      &b->cursor, &b->order, &b->digests, &b->item_off, &b->item_len, &b->roots,
+                      &b->cursor, &b->q_off, &b->q_len, &b->q_id, &b->digests, &b->item_off, &b->item_len, &b->roots,
                       &b->file_sha, &b->dup_of};
     for (DevBuf* d : bufs) d->release();
     delete b;

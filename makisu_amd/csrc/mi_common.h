@@ -14,10 +14,9 @@ typedef int64_t  i64;
 
 // ---- Gear-CDC tile geometry (gear_cdc.hip) ------------------------------------
 constexpr int kGearWG     = 256;                 // threads per workgroup (4 waves)
-constexpr int kGearRun    = 256;                 // bytes one lane owns in a tile
-constexpr int kGearTile   = kGearWG * kGearRun;  // 64 KiB of file per tile
+constexpr int kGearTile   = 65536;               // bytes of file one wave marks at a time
 constexpr int kGearHalo   = 64;                  // Gear window: h depends on <= 64 bytes
-constexpr int kGearTableCopies = 1;
+constexpr int kGearTableCopies = 8;              // LDS replicas of the Gear table
 
 // ---- SHA-256 work queues (sha256.hip) ----------------------------------------
 constexpr int kShaQueues  = 8;                   // one head word per XCD (block b runs on XCD b % 8)
@@ -44,13 +43,17 @@ constexpr u64 kSmGamma = 0x9E3779B97F4A7C15ULL;
 
 // ---- kernel launchers (each defined next to its kernels) ----------------------
 // gear_cdc.hip
-void launch_gear_cdc_files(const u8* d_data, const u64* d_file_off, const u64* d_file_size,
-                           const u64* d_slot_base, u64* d_slot_ends, u32* d_n_chunks,
-                           u64 n_files, const u64* d_gear_table, CdcParams p, hipStream_t s);
+// small_list: files of <= kGearTile bytes (one wave each); large_list: the rest (one
+// workgroup each).  Lists hold file indices.
+void launch_gear_cdc(const u8* d_data, const u64* d_file_off, const u64* d_file_size,
+                     const u64* d_slot_base, u64* d_slot_ends, u32* d_n_chunks,
+                     const u32* d_small_list, u32 n_small, const u32* d_large_list, u32 n_large,
+                     const u64* d_gear_table, CdcParams p, hipStream_t s);
 
-// sha256.hip : n independent byte strings -> n digests.  item i = base[off[i] .. +len[i]).
-// order (optional) = processing order, longest first; heads = kShaQueues zeroed words.
-void launch_sha256_items(const u8* d_base, const u64* d_off, const u64* d_len, const u32* d_order,
+// sha256.hip : n independent byte strings -> n digests.  Queue position p holds the string
+// base[off[p] .. +len[p]) whose digest goes to out[32 * (ids ? ids[p] : p)]; positions are
+// consumed in order, so put the longest strings first.  heads = kShaQueues words.
+void launch_sha256_items(const u8* d_base, const u64* d_off, const u64* d_len, const u32* d_ids,
                          u32 n, u32* d_heads, u8* d_out, int blocks_per_cu, int n_cu,
                          hipStream_t s);
 
@@ -65,8 +68,9 @@ void launch_compact_chunks(const u64* d_file_off, const u64* d_slot_base, const 
                            const u32* d_n_chunks, const u64* d_first, u64 n_files,
                            u64* d_chunk_off, u64* d_chunk_len, u32* d_chunk_file,
                            u64* d_chunk_start, u32* d_hist, u32 n_bins, hipStream_t s);
-void launch_bin_order(const u64* d_len, u32 n, u32* d_hist, u32* d_cursor, u32 n_bins,
-                      u32* d_order, hipStream_t s);
+// queue descriptors in processing order (longest first): s_off/s_len/s_id[pos]
+void launch_bin_order(const u64* d_off, const u64* d_len, u32 n, u32* d_hist, u32* d_cursor,
+                      u32 n_bins, u64* d_s_off, u64* d_s_len, u32* d_s_id, hipStream_t s);
 void launch_file_items(const u64* d_first, const u32* d_n_chunks, u64 n_files, u64* d_off,
                        u64* d_len, hipStream_t s);
 void launch_crc32_files(const u8* d_data, const u64* d_file_off, const u64* d_file_size,

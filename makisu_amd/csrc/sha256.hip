@@ -22,7 +22,6 @@ namespace mi {
 
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 typedef u32x4 u32x4_unaligned __attribute__((aligned(1)));
-typedef u32 u32_unaligned __attribute__((aligned(1)));
 
 __device__ __forceinline__ u32 rotr(u32 x, u32 n) { return __builtin_amdgcn_alignbit(x, x, n); }
 // gfx950 v_bitop3_b32: any 3-input boolean in ONE VALU op (truth table: a=0xF0, b=0xCC, c=0xAA)
@@ -76,105 +75,181 @@ __device__ __forceinline__ void sha256_iv(u32 (&st)[8]) {
     st[4] = 0x510e527f; st[5] = 0x9b05688c; st[6] = 0x1f83d9ab; st[7] = 0x5be0cd19;
 }
 
-// Final partial block: rem (<64) data bytes, 0x80, zeros; exact reads only (no
-// byte past the string is touched).
-__device__ __forceinline__ void load_tail_block(const u8* p, u32 rem, u32 (&w)[16]) {
+// Turns the big-endian words of a 64-byte load into the final partial block of a
+// string that has r (<64) bytes left: data bytes, 0x80, zeros.  Pure register work.
+__device__ __forceinline__ void mask_tail_block(u32 (&w)[16], u32 r) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        u32 v = 0;
         const u32 o = 4u * k;
-        if (o + 4 <= rem) {
-            v = __builtin_bswap32(*(const u32_unaligned*)(p + o));
-        } else if (o <= rem) {
-            const u32 r = rem - o;                     // 0..3 data bytes in this word
-            if (r > 0) v |= (u32)p[o] << 24;
-            if (r > 1) v |= (u32)p[o + 1] << 16;
-            if (r > 2) v |= (u32)p[o + 2] << 8;
-            v |= 0x80000000u >> (8 * r);
+        u32 v = w[k];
+        if (r < o + 4) {
+            if (r <= o) {
+                v = (r == o) ? 0x80000000u : 0u;
+            } else {
+                const u32 nb = r - o;                  // 1..3 data bytes stay
+                v = (v & (0xFFFFFFFFu << (32 - 8 * nb))) | (0x80000000u >> (8 * nb));
+            }
         }
         w[k] = v;
     }
 }
 
+// Lane pipeline (one iteration = one 64-byte compression per lane):
+//   cur  : the string being hashed: ptr/rem/total/slot, state st[8], and nx* = its NEXT
+//          64 bytes, loaded one iteration ahead so HBM latency hides under 64 rounds;
+//   next : the lane's next string, acquired kLook iterations before cur ends through a
+//          4-stage pipeline  (1) wave-aggregated atomic dequeue, (1b) resolve it to a queue
+//          position, (2) load off/len/slot of that position, (3) load its first 64 bytes.
+//          Each stage is consumed one iteration after it was issued, so a lane switches
+//          strings without ever waiting on memory.
+// Reads may run up to 63 bytes past a string's end (never used); every buffer this is
+// launched on carries that slack (arena, digest array, mi_sha256_many staging).
+constexpr u32 kLook = 5;
+
 __global__ __launch_bounds__(kShaWG)
 void sha256_items_kernel(const u8* __restrict__ base, const u64* __restrict__ off,
-                         const u64* __restrict__ len, const u32* __restrict__ order, u32 n,
+                         const u64* __restrict__ len, const u32* __restrict__ ids, u32 n,
                          u32* __restrict__ heads, u8* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int q0 = blockIdx.x % kShaQueues;
-    // items of queue q: order[q], order[q + Q], ...  (order is longest-first)
+    // current string
     const u8* ptr = nullptr;
     u64 rem = 0, total = 0;
-    u32 item = 0;
+    u32 slot = 0;
     u32 st[8];
-    bool active = false, exhausted = false, pad_block = false;
+    u32x4 nx0, nx1, nx2, nx3;
+    bool active = false, pad_block = false;
+    // next string
+    enum : u32 { kNone = 0, kReq = 1, kPos = 2, kDesc = 3, kReady = 4, kDry = 5 };
+    u32 nstate = kNone, npos = 0, nslot = 0, areq = 0, req_rank = 0;
+    int req_q = 0, req_leader = 0;     // wave-uniform: the dequeue in flight
+    u64 noff = 0, nlen = 0;
+    u32x4 f0, f1, f2, f3;
+    int qtry = 0;                // queues already found empty by this wave (uniform)
+    bool first_fill = true;
 
     for (;;) {
-        // ---- refill: lanes without a string dequeue one (wave-aggregated) ----------
-        if (__ballot(!active && !exhausted)) {
-            for (int t = 0; t < kShaQueues; ++t) {
-                const bool need = !active && !exhausted;
-                const u64 m = __ballot(need);
-                if (!m) break;
-                const int q = (q0 + t) % kShaQueues;
-                const int leader = __ffsll((unsigned long long)m) - 1;
-                u32 first = 0;
-                if (lane == leader) first = atomicAdd(&heads[q], (u32)__popcll(m));
-                first = __shfl(first, leader);
-                const u32 mine = first + (u32)__popcll(m & ((1ull << lane) - 1ull));
-                const u64 idx = (u64)mine * kShaQueues + (u32)q;
-                if (need && idx < n) {
-                    item = order ? order[idx] : (u32)idx;
-                    ptr = base + off[item];
-                    total = rem = len[item];
-                    sha256_iv(st);
-                    pad_block = false;
-                    active = true;
+        // Everything issued in the previous iteration (first-block loads, descriptors, the
+        // dequeue atomic, the nx prefetch) has had a whole compression to land.  Consume it
+        // all HERE, before this iteration issues anything new, so no wait below can stall on
+        // a freshly issued request (hipcc's s_waitcnt for a divergent region is vmcnt(0)).
+        asm volatile("" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(nx0), "+v"(nx1),
+                          "+v"(nx2), "+v"(nx3));
+        asm volatile("" : "+v"(noff), "+v"(nlen), "+v"(nslot), "+v"(areq));
+        // ---- stage 1b: resolve last iteration's dequeue --------------------------------
+        if (__ballot(nstate == kReq)) {
+            const u32 first = __shfl(areq, req_leader);
+            if (first_fill) {
+                // LPT order: the earliest positions hold the longest strings; one string is a
+                // serial chain, so the waves that own them get issue priority over the waves
+                // that fill in short ones.
+                const u64 rank = (u64)first * kShaQueues;
+                if (rank < (u64)n / 32)     __builtin_amdgcn_s_setprio(3);
+                else if (rank < (u64)n / 8) __builtin_amdgcn_s_setprio(2);
+                else if (rank < (u64)n / 2) __builtin_amdgcn_s_setprio(1);
+                first_fill = false;
+            }
+            bool missed = false;
+            if (nstate == kReq) {
+                const u64 pos = (u64)(first + req_rank) * kShaQueues + (u32)req_q;
+                if (pos < n) { npos = (u32)pos; nstate = kPos; }
+                else { nstate = kNone; missed = true; }
+            }
+            if (__ballot(missed)) ++qtry;              // a position past the end: that queue is dry
+        }
+        // ---- switch to the next string (its first block arrived an iteration ago) -------
+        if (!active && nstate == kReady) {
+            ptr = base + noff;
+            total = rem = nlen;
+            slot = nslot;
+            nx0 = f0; nx1 = f1; nx2 = f2; nx3 = f3;
+            sha256_iv(st);
+            pad_block = false;
+            active = true;
+            nstate = kNone;
+        }
+        // ---- stage 3: descriptor known -> fetch the first block -----------------------
+        if (nstate == kDesc) {
+            const u8* p = base + noff;
+            if (nlen) {
+                f0 = *(const u32x4_unaligned*)(p);
+                f1 = *(const u32x4_unaligned*)(p + 16);
+                f2 = *(const u32x4_unaligned*)(p + 32);
+                f3 = *(const u32x4_unaligned*)(p + 48);
+            }
+            nstate = kReady;
+        }
+        // ---- stage 2: position known -> load its descriptor ---------------------------
+        if (nstate == kPos) {
+            noff = off[npos];
+            nlen = len[npos];
+            nslot = ids ? ids[npos] : npos;
+            nstate = kDesc;
+        }
+        // ---- stage 1: reserve a position for lanes about to run dry -------------------
+        // Only ISSUES the wave-aggregated atomic; its result is resolved at the top of the
+        // next iteration (stage 1b), so the wave never waits for the atomic round trip.
+        {
+            const bool want = nstate == kNone && (!active || rem < 64ull * kLook);
+            const u64 m = __ballot(want);
+            if (m) {
+                if (qtry >= kShaQueues) {
+                    if (want) nstate = kDry;
+                } else {
+                    req_q = (q0 + qtry) % kShaQueues;
+                    req_leader = __ffsll((unsigned long long)m) - 1;
+                    if (lane == req_leader) areq = atomicAdd(&heads[req_q], (u32)__popcll(m));
+                    if (want) {
+                        req_rank = (u32)__popcll(m & ((1ull << lane) - 1ull));
+                        nstate = kReq;
+                    }
                 }
             }
-            if (!active) exhausted = true;
         }
-        if (!__ballot(active)) break;
+        if (!__ballot(active || nstate != kDry)) break;
 
         if (active) {
             u32 w[16];
             bool last = false;
-            if (rem >= 64) {
-                const u32x4 v0 = *(const u32x4_unaligned*)(ptr);
-                const u32x4 v1 = *(const u32x4_unaligned*)(ptr + 16);
-                const u32x4 v2 = *(const u32x4_unaligned*)(ptr + 32);
-                const u32x4 v3 = *(const u32x4_unaligned*)(ptr + 48);
-                w[0] = __builtin_bswap32(v0.x); w[1] = __builtin_bswap32(v0.y);
-                w[2] = __builtin_bswap32(v0.z); w[3] = __builtin_bswap32(v0.w);
-                w[4] = __builtin_bswap32(v1.x); w[5] = __builtin_bswap32(v1.y);
-                w[6] = __builtin_bswap32(v1.z); w[7] = __builtin_bswap32(v1.w);
-                w[8] = __builtin_bswap32(v2.x); w[9] = __builtin_bswap32(v2.y);
-                w[10] = __builtin_bswap32(v2.z); w[11] = __builtin_bswap32(v2.w);
-                w[12] = __builtin_bswap32(v3.x); w[13] = __builtin_bswap32(v3.y);
-                w[14] = __builtin_bswap32(v3.z); w[15] = __builtin_bswap32(v3.w);
-                ptr += 64;
-                rem -= 64;
-            } else {
-                const u64 bits = total * 8;
-                if (!pad_block) {
-                    load_tail_block(ptr, (u32)rem, w);
+            if (!pad_block) {
+                w[0] = __builtin_bswap32(nx0.x); w[1] = __builtin_bswap32(nx0.y);
+                w[2] = __builtin_bswap32(nx0.z); w[3] = __builtin_bswap32(nx0.w);
+                w[4] = __builtin_bswap32(nx1.x); w[5] = __builtin_bswap32(nx1.y);
+                w[6] = __builtin_bswap32(nx1.z); w[7] = __builtin_bswap32(nx1.w);
+                w[8] = __builtin_bswap32(nx2.x); w[9] = __builtin_bswap32(nx2.y);
+                w[10] = __builtin_bswap32(nx2.z); w[11] = __builtin_bswap32(nx2.w);
+                w[12] = __builtin_bswap32(nx3.x); w[13] = __builtin_bswap32(nx3.y);
+                w[14] = __builtin_bswap32(nx3.z); w[15] = __builtin_bswap32(nx3.w);
+                if (rem >= 64) {
+                    ptr += 64;
+                    rem -= 64;
+                    if (rem) {                         // in flight during this block's 64 rounds
+                        nx0 = *(const u32x4_unaligned*)(ptr);
+                        nx1 = *(const u32x4_unaligned*)(ptr + 16);
+                        nx2 = *(const u32x4_unaligned*)(ptr + 32);
+                        nx3 = *(const u32x4_unaligned*)(ptr + 48);
+                    }
+                } else {
+                    mask_tail_block(w, (u32)rem);
                     if (rem <= 55) {
+                        const u64 bits = total * 8;
                         w[14] = (u32)(bits >> 32); w[15] = (u32)bits;
                         last = true;
                     } else {
-                        pad_block = true;             // length goes into one more block
+                        pad_block = true;             // the length needs one more block
                     }
                     rem = 0;
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 14; ++k) w[k] = 0;
-                    w[14] = (u32)(bits >> 32); w[15] = (u32)bits;
-                    last = true;
                 }
+            } else {
+                const u64 bits = total * 8;
+#pragma unroll
+                for (int k = 0; k < 14; ++k) w[k] = 0;
+                w[14] = (u32)(bits >> 32); w[15] = (u32)bits;
+                last = true;
             }
             sha256_compress(st, w);
             if (last) {
-                u32x4* o = (u32x4*)(out + 32ull * item);
+                u32x4* o = (u32x4*)(out + 32ull * slot);
                 u32x4 d0, d1;
                 d0.x = __builtin_bswap32(st[0]); d0.y = __builtin_bswap32(st[1]);
                 d0.z = __builtin_bswap32(st[2]); d0.w = __builtin_bswap32(st[3]);

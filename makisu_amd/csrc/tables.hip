@@ -194,21 +194,26 @@ void bin_cursor_kernel(const u32* __restrict__ hist, u32* __restrict__ cursor, u
 }
 
 __global__ __launch_bounds__(256)
-void bin_scatter_kernel(const u64* __restrict__ len, u32 n, u32* __restrict__ cursor, u32 n_bins,
-                        u32* __restrict__ order) {
+void bin_scatter_kernel(const u64* __restrict__ off, const u64* __restrict__ len, u32 n,
+                        u32* __restrict__ cursor, u32 n_bins, u64* __restrict__ s_off,
+                        u64* __restrict__ s_len, u32* __restrict__ s_id) {
     const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n) return;
-    u32 bin = sha_blocks_of(len[g]);
+    const u64 l = len[g];
+    u32 bin = sha_blocks_of(l);
     if (bin >= n_bins) bin = n_bins - 1;
-    order[atomicAdd(&cursor[bin], 1u)] = g;
+    const u32 pos = atomicAdd(&cursor[bin], 1u);    // queue position, longest first
+    s_off[pos] = off[g];
+    s_len[pos] = l;
+    s_id[pos] = g;
 }
 
-void launch_bin_order(const u64* d_len, u32 n, u32* d_hist, u32* d_cursor, u32 n_bins,
-                      u32* d_order, hipStream_t s) {
+void launch_bin_order(const u64* d_off, const u64* d_len, u32 n, u32* d_hist, u32* d_cursor,
+                      u32 n_bins, u64* d_s_off, u64* d_s_len, u32* d_s_id, hipStream_t s) {
     if (n == 0) return;
     hipLaunchKernelGGL(bin_cursor_kernel, dim3(1), dim3(256), 0, s, d_hist, d_cursor, n_bins);
-    hipLaunchKernelGGL(bin_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_len, n,
-                       d_cursor, n_bins, d_order);
+    hipLaunchKernelGGL(bin_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_off, d_len, n,
+                       d_cursor, n_bins, d_s_off, d_s_len, d_s_id);
 }
 
 // ---- per-file root items: string f = digests[first[f] .. +n_chunks[f]) ----------

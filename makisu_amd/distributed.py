@@ -1,0 +1,99 @@
+"""Multi-GPU sharding and the chunk-digest exchange.
+
+One process per GPU.  Files are independent units, so the scan itself needs no
+collective: every rank scans its shard.  The ONE exchange step is the all-gather
+of the per-rank chunk-digest arrays (32 B per chunk) so every rank can mark
+duplicates against the global set -- the chunk-granular analogue of the
+reference's content-addressed layer dedup (lib/builder/step/common.go:88-91).
+
+`torch.distributed` is plumbing here (backend "nccl" = RCCL over xGMI on the GPU
+box, "gloo" in the CPU tests); the marking itself is the HIP kernel behind
+`mi_dedup_mark`.  Nothing in this file imports oracle/.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_round_robin(n_files, rank, world):
+    """C4: file_index mod world."""
+    return np.arange(rank, n_files, world, dtype=np.int64)
+
+
+def shard_lpt(sizes, world):
+    """C5: greedy longest-processing-time by bytes.  Returns a list of index arrays, one
+    per rank; deterministic (ties broken by lower rank, files visited largest first,
+    stable for equal sizes)."""
+    sizes = np.asarray(sizes, dtype=np.int64)
+    order = np.argsort(-sizes, kind="stable")
+    load = np.zeros(world, dtype=np.int64)
+    out = [[] for _ in range(world)]
+    for i in order:
+        r = int(np.argmin(load))
+        out[r].append(int(i))
+        load[r] += int(sizes[i])
+    return [np.array(sorted(x), dtype=np.int64) for x in out]
+
+
+class DeviceArray:
+    """Zero-copy view of engine-owned device memory for torch (__cuda_array_interface__)."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr,
+                                         "data": (int(ptr), False), "version": 2}
+
+
+def digests_tensor(batch, device):
+    """The batch's n_chunks x 32 digest array as a torch uint8 tensor on `device`."""
+    ptr, n = batch.device_digests()
+    if n == 0:
+        return torch.empty((0, 32), dtype=torch.uint8, device=device)
+    return torch.as_tensor(DeviceArray(ptr, (n, 32), "|u1"), device=device)
+
+
+def all_gather_digests(local, group=None):
+    """Variable-length all-gather of (n_r, 32) uint8 digest arrays.
+
+    Step 1: all-gather the 1-element counts.  Step 2: pad to the max count and
+    all-gather the slabs (one collective, every xGMI link carries one peer's slab),
+    then drop the padding.  Returns (global (N, 32) tensor ordered by rank,
+    counts list, first_global index of this rank's rows)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = local.device
+    n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
+    counts_t = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(counts_t, n_local, group=group)
+    counts = [int(x) for x in counts_t.tolist()]
+    m = max(counts) if counts else 0
+    if m == 0:
+        return torch.empty((0, 32), dtype=torch.uint8, device=dev), counts, 0
+    slab = torch.zeros((m, 32), dtype=torch.uint8, device=dev)
+    slab[: local.shape[0]] = local
+    gathered = torch.empty((world * m, 32), dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(gathered, slab, group=group)
+    if all(c == m for c in counts):
+        glob = gathered
+    else:
+        glob = torch.cat([gathered[r * m: r * m + counts[r]] for r in range(world)], dim=0)
+    return glob.contiguous(), counts, sum(counts[:rank])
+
+
+def global_dedup(engine, batch, device, group=None, mark=None, local=None):
+    """Exchange + mark.  Rewrites the batch's dup_of column with GLOBAL chunk indices
+    (rank-major order).  `mark(glob) -> (dup_of int64 tensor, n_unique)` defaults to
+    the HIP kernel (engine.dedup_mark); the gloo CPU tests pass `local` digests and
+    inject their own checker as `mark`.
+    Returns (n_total, n_unique_global, first_global, dup_of_global)."""
+    if local is None:
+        local = digests_tensor(batch, device)
+    glob, counts, first = all_gather_digests(local, group)
+    n_total = glob.shape[0]
+    if mark is None:
+        dup = torch.empty(max(n_total, 1), dtype=torch.int64, device=device)
+        torch.cuda.synchronize(device)
+        n_unique = engine.dedup_mark(glob.data_ptr(), n_total, dup.data_ptr())
+        batch.set_global_dedup(dup.data_ptr(), first)
+    else:
+        dup, n_unique = mark(glob)
+    return n_total, n_unique, first, dup

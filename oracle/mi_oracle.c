@@ -358,6 +358,7 @@ typedef struct {
     uint64_t n_files;
     const mi_ref_cdc_params* p;
     int allow_shani;
+    int flags;
     mi_ref_file* files;
     mi_ref_chunk* slots;        /* per-file slot regions */
     const uint64_t* slot_base;
@@ -392,8 +393,8 @@ static void scan_one(scan_job* j, uint64_t f) {
 #undef CUT
     fo->n_chunks = n;
     mi_ref_sha256_final(&root, fo->chunk_root);
-    mi_ref_sha256(d, (size_t)len, fo->file_sha256, j->allow_shani);
-    fo->crc32 = mi_ref_crc32(0, d, (size_t)len);
+    if (j->flags & MI_REF_FILE_SHA256) mi_ref_sha256(d, (size_t)len, fo->file_sha256, j->allow_shani);
+    if (j->flags & MI_REF_FILE_CRC32) fo->crc32 = mi_ref_crc32(0, d, (size_t)len);
 }
 
 static void* scan_worker(void* arg) {
@@ -434,8 +435,8 @@ uint64_t mi_ref_dedup(const uint8_t* digests, uint64_t n, int64_t* dup_of) {
 
 uint64_t mi_ref_scan_batch(const uint8_t* data, const uint64_t* offsets, const uint64_t* sizes,
                            uint64_t n_files, const mi_ref_cdc_params* p, int allow_shani,
-                           int n_threads, mi_ref_file* files, mi_ref_chunk* chunks,
-                           uint64_t chunk_cap) {
+                           int n_threads, int flags, mi_ref_file* files,
+                           mi_ref_chunk* chunks, uint64_t chunk_cap) {
     if (p->min_size < 64 || p->max_size < p->min_size) return (uint64_t)-1;
     uint64_t* slot_base = (uint64_t*)malloc((n_files + 1) * sizeof(uint64_t));
     uint64_t total_slots = 0;
@@ -445,7 +446,8 @@ uint64_t mi_ref_scan_batch(const uint8_t* data, const uint64_t* offsets, const u
     }
     slot_base[n_files] = total_slots;
     mi_ref_chunk* slots = (mi_ref_chunk*)malloc((total_slots ? total_slots : 1) * sizeof(mi_ref_chunk));
-    scan_job j = {data, offsets, sizes, n_files, p, allow_shani, files, slots, slot_base, {0}, 0};
+    scan_job j = {data, offsets, sizes, n_files, p, allow_shani, flags, files, slots, slot_base, {0}, 0};
+    memset(files, 0, sizeof(mi_ref_file) * n_files);
     mi_ref_gear_table(p->gear_seed, j.table);
     if (n_threads <= 1) {
         scan_worker(&j);
@@ -465,7 +467,7 @@ uint64_t mi_ref_scan_batch(const uint8_t* data, const uint64_t* offsets, const u
     }
     free(slots);
     free(slot_base);
-    if (total <= chunk_cap && total) {
+    if (total <= chunk_cap && total && !(flags & MI_REF_NO_DEDUP)) {
         uint8_t* dg = (uint8_t*)malloc(32 * total);
         int64_t* dup = (int64_t*)malloc(sizeof(int64_t) * total);
         for (uint64_t i = 0; i < total; i++) memcpy(dg + 32 * i, chunks[i].sha256, 32);

@@ -121,12 +121,16 @@ typedef struct {
 } mi_ref_file;
 
 /* Scans n_files files (file f = data + offsets[f], sizes[f] bytes).
- * chunks must have room for sum(ceil(size/min)+1).  Returns total chunks.
- * n_threads > 1 spreads files over pthreads (one file per thread at a time). */
+ * chunks must have room for sum(size/min+2).  Returns total chunks.
+ * n_threads > 1 spreads files over pthreads (one file per thread at a time).
+ * flags: which optional columns to compute (the GPU engine's MI_FLAG_* twins). */
+#define MI_REF_FILE_SHA256 0x1
+#define MI_REF_FILE_CRC32  0x2
+#define MI_REF_NO_DEDUP    0x4
 uint64_t mi_ref_scan_batch(const uint8_t* data, const uint64_t* offsets,
                            const uint64_t* sizes, uint64_t n_files,
                            const mi_ref_cdc_params* p, int allow_shani,
-                           int n_threads, mi_ref_file* files,
+                           int n_threads, int flags, mi_ref_file* files,
                            mi_ref_chunk* chunks, uint64_t chunk_cap);
 
 /* Marks dup_of over an arbitrary digest list (n x 32 bytes): dup_of[i] =

@@ -85,7 +85,7 @@ def lib():
         L.mi_ref_synth_fill.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]
         L.mi_ref_synth_fill.restype = None
         L.mi_ref_scan_batch.argtypes = [C.c_void_p, u64p, u64p, C.c_uint64, C.POINTER(CdcParams),
-                                        C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64]
+                                        C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64]
         L.mi_ref_scan_batch.restype = C.c_uint64
         L.mi_ref_dedup.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
         L.mi_ref_dedup.restype = C.c_uint64
@@ -176,7 +176,11 @@ def synth_fill(seed, content_id, offset, length):
     return out
 
 
-def scan_batch(data, offsets, sizes, params, allow_shani=True, n_threads=1):
+FILE_SHA256, FILE_CRC32, NO_DEDUP = 1, 2, 4
+
+
+def scan_batch(data, offsets, sizes, params, allow_shani=True, n_threads=1,
+               flags=FILE_SHA256 | FILE_CRC32):
     """Returns (files structured array, chunks structured array)."""
     a, p = _buf(data)
     offs = np.ascontiguousarray(offsets, dtype=np.uint64)
@@ -187,7 +191,7 @@ def scan_batch(data, offsets, sizes, params, allow_shani=True, n_threads=1):
     chunks = np.zeros(max(cap, 1), dtype=CHUNK_DTYPE)
     u64p = C.POINTER(C.c_uint64)
     total = lib().mi_ref_scan_batch(p, offs.ctypes.data_as(u64p), szs.ctypes.data_as(u64p), n,
-                                    C.byref(params), int(allow_shani), n_threads,
+                                    C.byref(params), int(allow_shani), n_threads, flags,
                                     files.ctypes.data, chunks.ctypes.data, cap)
     if total == 2**64 - 1:
         raise ValueError("invalid CDC params")

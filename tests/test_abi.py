@@ -1,0 +1,106 @@
+"""CPU tests of the C-ABI boundary: the library builds/loads and exports every symbol
+include/makisu_mi.h declares, struct layouts match the header, and without a GPU the product
+path fails LOUDLY (there is no CPU fallback).  No compute calls here."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "makisu_mi.h")
+
+
+def _declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mi_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(engine_lib):
+    names = _declared_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(engine_lib, n), "header declares %s but the library does not export it" % n
+    # and the binding covers all of them
+    assert set(engine_lib._mi_symbols) == set(names)
+
+
+def test_abi_version_and_defaults(engine_lib):
+    import makisu_amd
+    assert engine_lib.mi_abi_version() == 1
+    cfg = makisu_amd.default_config()
+    assert cfg.struct_size == C.sizeof(makisu_amd.Config)
+    assert (cfg.gear_seed, cfg.mask_bits, cfg.min_size, cfg.max_size) == (0x4D414B49, 13, 2048, 65536)
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    """Compile a tiny C program against the header and compare sizeof/offsetof with ctypes."""
+    import makisu_amd
+    prog = tmp_path / "layout.c"
+    prog.write_text(r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "makisu_mi.h"
+int main(void) {
+  printf("%zu %zu %zu %zu\n", sizeof(mi_config), sizeof(mi_file_result), sizeof(mi_chunk_result), sizeof(mi_stats));
+  printf("%zu %zu %zu %zu\n", offsetof(mi_file_result, chunk_root), offsetof(mi_file_result, file_sha256),
+         offsetof(mi_chunk_result, dup_of), offsetof(mi_chunk_result, sha256));
+  return 0; }''')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)]).decode().split()
+    got = [int(x) for x in out]
+    want = [C.sizeof(makisu_amd.Config), makisu_amd.FILE_DTYPE.itemsize, makisu_amd.CHUNK_DTYPE.itemsize,
+            C.sizeof(makisu_amd.Stats),
+            makisu_amd.FILE_DTYPE.fields["chunk_root"][1], makisu_amd.FILE_DTYPE.fields["file_sha256"][1],
+            makisu_amd.CHUNK_DTYPE.fields["dup_of"][1], makisu_amd.CHUNK_DTYPE.fields["sha256"][1]]
+    assert got == want
+
+
+def test_invalid_config_is_rejected(engine_lib):
+    import makisu_amd
+    for kw in ({"min_size": 32}, {"max_size": 1024, "min_size": 2048}, {"mask_bits": 33}):
+        cfg = makisu_amd.default_config(**kw)
+        h = C.c_void_p()
+        assert engine_lib.mi_ctx_create(C.byref(cfg), C.byref(h)) == -1
+        assert b"mi_ctx_create" in engine_lib.mi_last_error(None)
+    cfg = makisu_amd.default_config()
+    cfg.struct_size = 8
+    assert engine_lib.mi_ctx_create(C.byref(cfg), C.byref(C.c_void_p())) == -1
+
+
+def test_no_gpu_means_loud_failure_not_a_cpu_fallback():
+    import makisu_amd
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if has_gpu:
+        pytest.skip("a GPU is visible here")
+    with pytest.raises(makisu_amd.MiError) as ei:
+        makisu_amd.Engine()
+    assert ei.value.code == -2 and "no CPU path" in str(ei.value)
+
+
+def test_product_never_imports_the_oracle():
+    """The product path (makisu_amd/, include/) must not reference oracle/ anywhere."""
+    bad = []
+    for base in ("makisu_amd", "include"):
+        for dp, _, fns in os.walk(os.path.join(ROOT, base)):
+            if "_obj" in dp or "__pycache__" in dp:
+                continue
+            for fn in fns:
+                if fn.endswith((".py", ".hip", ".h", ".cpp")):
+                    txt = open(os.path.join(dp, fn), errors="replace").read()
+                    if fn.endswith(".py"):           # code only: drop docstrings and comments
+                        txt = re.sub(r'""".*?"""', "", txt, flags=re.S)
+                        txt = re.sub(r"#.*", "", txt)
+                    else:
+                        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+                        txt = re.sub(r"//.*", "", txt)
+                    if re.search(r"mi_oracle|mi_ref_|from oracle|import oracle|oracle/", txt):
+                        bad.append(os.path.join(dp, fn))
+    assert not bad, bad

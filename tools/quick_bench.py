@@ -14,8 +14,11 @@ def main():
     ap.add_argument("--size", type=int, default=65536)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--flags", type=int, default=0)
+    ap.add_argument("--max-size", type=int, default=65536)
+    ap.add_argument("--min-size", type=int, default=2048)
+    ap.add_argument("--mask-bits", type=int, default=13)
     a = ap.parse_args()
-    with makisu_amd.Engine(flags=a.flags) as e:
+    with makisu_amd.Engine(flags=a.flags, max_size=a.max_size, min_size=a.min_size, mask_bits=a.mask_bits) as e:
         print(json.dumps(e.device_info()))
         with e.batch() as b:
             b.add_synthetic([a.size] * a.files, None)
