@@ -55,7 +55,7 @@ def cpu_baseline(budget_s=12.0):
     t0 = time.perf_counter()
     O.layer_scan(probe, offs, szs, True)
     ref_shaped = probe.size / (time.perf_counter() - t0)
-    n = int(min(max(rate1 * cores * budget_s / FILE_SIZE, 512), 32768, N_FILES))
+    n = int(min(max(rate1 * cores * budget_s / FILE_SIZE, 512), N_FILES))
     data = np.empty(n * FILE_SIZE, dtype=np.uint8)
     for i in range(n):
         data[i * FILE_SIZE:(i + 1) * FILE_SIZE] = O.synth_fill(SEED, i, 0, FILE_SIZE)

@@ -267,8 +267,10 @@ int run_pipeline(mi_batch* b) {
     b->n_chunks = total;
     const u32 nc = (u32)total;
 
-    u32 n_bins = c->cfg.max_size / 64 + 3;
-    if (n_bins > 65536) n_bins = 65536;
+    // length bins for the longest-first order: SHA block counts >> bin_shift, <= 1024 bins
+    u32 bin_shift = 2;
+    while (((c->cfg.max_size / 64 + 3) >> bin_shift) + 1 > 1024) ++bin_shift;
+    const u32 n_bins = ((c->cfg.max_size / 64 + 3) >> bin_shift) + 1;
     HIPCHK(c, b->chunk_off.ensure(total * 8));
     HIPCHK(c, b->chunk_len.ensure(total * 8));
     HIPCHK(c, b->chunk_start.ensure(total * 8));
@@ -287,24 +289,24 @@ int run_pipeline(mi_batch* b) {
     launch_compact_chunks(d_off, b->slot_base.as<u64>(), b->slot_ends.as<u64>(),
                           b->n_chunks_d.as<u32>(), b->first.as<u64>(), nf, b->chunk_off.as<u64>(),
                           b->chunk_len.as<u64>(), b->chunk_file.as<u32>(),
-                          b->chunk_start.as<u64>(), b->hist.as<u32>(), n_bins, s);
+                          b->chunk_start.as<u64>(), b->hist.as<u32>(), n_bins, bin_shift, s);
     launch_bin_order(b->chunk_off.as<u64>(), b->chunk_len.as<u64>(), nc, b->hist.as<u32>(),
-                     b->cursor.as<u32>(), n_bins, b->q_off.as<u64>(), b->q_len.as<u64>(),
+                     b->cursor.as<u32>(), n_bins, bin_shift, b->q_off.as<u64>(), b->q_len.as<u64>(),
                      b->q_id.as<u32>(), s);
     HIPCHK(c, hipEventRecord(c->ev[2], s));
-    launch_sha256_items(b->arena.as<u8>(), b->q_off.as<u64>(), b->q_len.as<u64>(),
+    launch_sha256_items(kShaChunks, b->arena.as<u8>(), b->q_off.as<u64>(), b->q_len.as<u64>(),
                         b->q_id.as<u32>(), nc, c->heads.as<u32>(), b->digests.as<u8>(),
                         c->sha_blocks_per_cu, c->prop.multiProcessorCount, s);
     HIPCHK(c, hipEventRecord(c->ev[3], s));
     // per-file roots: SHA-256 over each file's run of chunk digests
     launch_file_items(b->first.as<u64>(), b->n_chunks_d.as<u32>(), nf, b->item_off.as<u64>(),
                       b->item_len.as<u64>(), s);
-    launch_sha256_items(b->digests.as<u8>(), b->item_off.as<u64>(), b->item_len.as<u64>(), nullptr,
+    launch_sha256_items(kShaRoots, b->digests.as<u8>(), b->item_off.as<u64>(), b->item_len.as<u64>(), nullptr,
                         (u32)nf, c->heads.as<u32>(), b->roots.as<u8>(), c->sha_blocks_per_cu,
                         c->prop.multiProcessorCount, s);
     if (c->cfg.flags & MI_FLAG_FILE_SHA256) {
         HIPCHK(c, b->file_sha.ensure(nf * 32));
-        launch_sha256_items(b->arena.as<u8>(), d_off, d_size, nullptr, (u32)nf,
+        launch_sha256_items(kShaFiles, b->arena.as<u8>(), d_off, d_size, nullptr, (u32)nf,
                             c->heads.as<u32>(), b->file_sha.as<u8>(), c->sha_blocks_per_cu,
                             c->prop.multiProcessorCount, s);
     }
@@ -784,7 +786,7 @@ int mi_sha256_many(mi_ctx* c, const void* data, const uint64_t* offsets, const u
         if (e == hipSuccess) e = hipMemcpy(d_off.p, offsets, n * 8, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(d_len.p, lens, n * 8, hipMemcpyHostToDevice);
         if (e == hipSuccess) {
-            launch_sha256_items(d_data.as<u8>(), d_off.as<u64>(), d_len.as<u64>(), nullptr, (u32)n,
+            launch_sha256_items(kShaBlobs, d_data.as<u8>(), d_off.as<u64>(), d_len.as<u64>(), nullptr, (u32)n,
                                 c->heads.as<u32>(), d_out.as<u8>(), c->sha_blocks_per_cu,
                                 c->prop.multiProcessorCount, c->stream);
             e = hipStreamSynchronize(c->stream);

@@ -106,6 +106,8 @@ __device__ __forceinline__ void mask_tail_block(u32 (&w)[16], u32 r) {
 // launched on carries that slack (arena, digest array, mi_sha256_many staging).
 constexpr u32 kLook = 5;
 
+// kPass only names the instantiation (chunk pass / root pass / ...) so profiles tell them apart.
+template <int kPass>
 __global__ __launch_bounds__(kShaWG)
 void sha256_items_kernel(const u8* __restrict__ base, const u64* __restrict__ off,
                          const u64* __restrict__ len, const u32* __restrict__ ids, u32 n,
@@ -262,9 +264,9 @@ void sha256_items_kernel(const u8* __restrict__ base, const u64* __restrict__ of
     }
 }
 
-void launch_sha256_items(const u8* d_base, const u64* d_off, const u64* d_len, const u32* d_order,
-                         u32 n, u32* d_heads, u8* d_out, int blocks_per_cu, int n_cu,
-                         hipStream_t s) {
+void launch_sha256_items(ShaPass pass, const u8* d_base, const u64* d_off, const u64* d_len,
+                         const u32* d_order, u32 n, u32* d_heads, u8* d_out, int blocks_per_cu,
+                         int n_cu, hipStream_t s) {
     if (n == 0) return;
     (void)hipMemsetAsync(d_heads, 0, sizeof(u32) * kShaQueues, s);
     u64 want = ((u64)n + kShaWG - 1) / kShaWG;
@@ -273,8 +275,16 @@ void launch_sha256_items(const u8* d_base, const u64* d_off, const u64* d_len, c
     // keep the grid a multiple of the queue count so every queue has the same number of pullers
     if (grid >= (u32)kShaQueues) grid -= grid % kShaQueues;
     if (grid == 0) grid = 1;
-    hipLaunchKernelGGL(sha256_items_kernel, dim3(grid), dim3(kShaWG), 0, s, d_base, d_off, d_len,
-                       d_order, n, d_heads, d_out);
+#define MI_SHA_LAUNCH(P)                                                                      \
+    hipLaunchKernelGGL(sha256_items_kernel<P>, dim3(grid), dim3(kShaWG), 0, s, d_base, d_off,   \
+                       d_len, d_order, n, d_heads, d_out)
+    switch (pass) {
+        case kShaChunks: MI_SHA_LAUNCH(kShaChunks); break;
+        case kShaRoots:  MI_SHA_LAUNCH(kShaRoots); break;
+        case kShaFiles:  MI_SHA_LAUNCH(kShaFiles); break;
+        default:         MI_SHA_LAUNCH(kShaBlobs); break;
+    }
+#undef MI_SHA_LAUNCH
 }
 
 }  // namespace mi

@@ -138,45 +138,64 @@ __device__ __forceinline__ u32 sha_blocks_of(u64 len) {
     // 64-byte compressions SHA-256 needs for len bytes (data + 0x80 + 8-byte length)
     return (u32)(len >> 6) + 1u + ((len & 63) > 55 ? 1u : 0u);
 }
+__device__ __forceinline__ u32 bin_of(u64 len, u32 n_bins, u32 bin_shift) {
+    const u32 b = sha_blocks_of(len) >> bin_shift;
+    return b < n_bins ? b : n_bins - 1;
+}
 
+constexpr int kMaxBins = 1024;          // LDS-private histogram size (bins are block counts >> shift)
+constexpr int kLanesPerFile = 8;        // a file's chunk rows are written by 8 adjacent lanes
+
+// Grid-stride over files, 8 lanes per file: lane k writes rows k, k+8, ... of the file, so a
+// 64 KiB file's ~7 rows go out as one coalesced group.  Length bins are counted in LDS and
+// flushed once per workgroup (no hot global atomics).
 __global__ __launch_bounds__(256)
 void compact_chunks_kernel(const u64* __restrict__ file_off, const u64* __restrict__ slot_base,
                            const u64* __restrict__ slot_ends, const u32* __restrict__ n_chunks,
                            const u64* __restrict__ first, u64 n_files, u64* __restrict__ chunk_off,
                            u64* __restrict__ chunk_len, u32* __restrict__ chunk_file,
-                           u64* __restrict__ chunk_start, u32* __restrict__ hist, u32 n_bins) {
-    const u64 f = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= n_files) return;
-    const u64* ends = slot_ends + slot_base[f];
-    const u32 nc = n_chunks[f];
-    const u64 g0 = first[f], fo = file_off[f];
-    u64 start = 0;
-    for (u32 k = 0; k < nc; ++k) {
-        const u64 e = ends[k];
-        const u64 len = e - start;
-        chunk_off[g0 + k] = fo + start;
-        chunk_len[g0 + k] = len;
-        chunk_file[g0 + k] = (u32)f;
-        chunk_start[g0 + k] = start;
-        u32 bin = sha_blocks_of(len);
-        if (bin >= n_bins) bin = n_bins - 1;
-        atomicAdd(&hist[bin], 1u);
-        start = e;
+                           u64* __restrict__ chunk_start, u32* __restrict__ hist, u32 n_bins,
+                           u32 bin_shift) {
+    __shared__ u32 lh[kMaxBins];
+    for (u32 i = threadIdx.x; i < n_bins; i += blockDim.x) lh[i] = 0;
+    __syncthreads();
+    const u32 sub = threadIdx.x % kLanesPerFile;
+    const u64 stride = (u64)gridDim.x * (blockDim.x / kLanesPerFile);
+    for (u64 f = (u64)blockIdx.x * (blockDim.x / kLanesPerFile) + threadIdx.x / kLanesPerFile;
+         f < n_files; f += stride) {
+        const u64* ends = slot_ends + slot_base[f];
+        const u32 nc = n_chunks[f];
+        const u64 g0 = first[f], fo = file_off[f];
+        for (u32 k = sub; k < nc; k += kLanesPerFile) {
+            const u64 start = k ? ends[k - 1] : 0;
+            const u64 len = ends[k] - start;
+            chunk_off[g0 + k] = fo + start;
+            chunk_len[g0 + k] = len;
+            chunk_file[g0 + k] = (u32)f;
+            chunk_start[g0 + k] = start;
+            atomicAdd(&lh[bin_of(len, n_bins, bin_shift)], 1u);
+        }
     }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < n_bins; i += blockDim.x)
+        if (lh[i]) atomicAdd(&hist[i], lh[i]);
 }
 
 void launch_compact_chunks(const u64* d_file_off, const u64* d_slot_base, const u64* d_slot_ends,
                            const u32* d_n_chunks, const u64* d_first, u64 n_files,
                            u64* d_chunk_off, u64* d_chunk_len, u32* d_chunk_file,
-                           u64* d_chunk_start, u32* d_hist, u32 n_bins, hipStream_t s) {
+                           u64* d_chunk_start, u32* d_hist, u32 n_bins, u32 bin_shift,
+                           hipStream_t s) {
     if (n_files == 0) return;
     (void)hipMemsetAsync(d_hist, 0, sizeof(u32) * n_bins, s);
-    hipLaunchKernelGGL(compact_chunks_kernel, dim3((u32)((n_files + 255) / 256)), dim3(256), 0, s,
-                       d_file_off, d_slot_base, d_slot_ends, d_n_chunks, d_first, n_files,
-                       d_chunk_off, d_chunk_len, d_chunk_file, d_chunk_start, d_hist, n_bins);
+    u64 want = (n_files * kLanesPerFile + 255) / 256;
+    const u32 grid = (u32)(want < 1024 ? want : 1024);
+    hipLaunchKernelGGL(compact_chunks_kernel, dim3(grid), dim3(256), 0, s, d_file_off, d_slot_base,
+                       d_slot_ends, d_n_chunks, d_first, n_files, d_chunk_off, d_chunk_len,
+                       d_chunk_file, d_chunk_start, d_hist, n_bins, bin_shift);
 }
 
-// ---- longest-first processing order (counting sort by block count) --------------
+// ---- longest-first processing order (counting sort by block-count bin) -----------
 __global__ __launch_bounds__(256)
 void bin_cursor_kernel(const u32* __restrict__ hist, u32* __restrict__ cursor, u32 n_bins) {
     // single block; cursor[b] = number of items in bins > b  (descending order start)
@@ -193,27 +212,55 @@ void bin_cursor_kernel(const u32* __restrict__ hist, u32* __restrict__ cursor, u
     }
 }
 
+// Two-level scatter: a workgroup ranks its kScatterPer*256 items per bin in LDS, reserves one
+// range per non-empty bin with a single global atomic, then every item writes its queue
+// descriptor at range start + local rank.
+constexpr int kScatterPer = 8;
 __global__ __launch_bounds__(256)
 void bin_scatter_kernel(const u64* __restrict__ off, const u64* __restrict__ len, u32 n,
-                        u32* __restrict__ cursor, u32 n_bins, u64* __restrict__ s_off,
-                        u64* __restrict__ s_len, u32* __restrict__ s_id) {
-    const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= n) return;
-    const u64 l = len[g];
-    u32 bin = sha_blocks_of(l);
-    if (bin >= n_bins) bin = n_bins - 1;
-    const u32 pos = atomicAdd(&cursor[bin], 1u);    // queue position, longest first
-    s_off[pos] = off[g];
-    s_len[pos] = l;
-    s_id[pos] = g;
+                        u32* __restrict__ cursor, u32 n_bins, u32 bin_shift,
+                        u64* __restrict__ s_off, u64* __restrict__ s_len, u32* __restrict__ s_id) {
+    __shared__ u32 cnt[kMaxBins];
+    for (u32 i = threadIdx.x; i < n_bins; i += blockDim.x) cnt[i] = 0;
+    __syncthreads();
+    const u32 base = blockIdx.x * (256 * kScatterPer);
+    u32 bin[kScatterPer], rank[kScatterPer];
+    u64 l[kScatterPer];
+#pragma unroll
+    for (int k = 0; k < kScatterPer; ++k) {
+        const u32 g = base + k * 256 + threadIdx.x;
+        if (g < n) {
+            l[k] = len[g];
+            bin[k] = bin_of(l[k], n_bins, bin_shift);
+            rank[k] = atomicAdd(&cnt[bin[k]], 1u);
+        }
+    }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < n_bins; i += blockDim.x) {
+        const u32 c = cnt[i];
+        if (c) cnt[i] = atomicAdd(&cursor[i], c);           // now the range start of bin i
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kScatterPer; ++k) {
+        const u32 g = base + k * 256 + threadIdx.x;
+        if (g < n) {
+            const u32 pos = cnt[bin[k]] + rank[k];          // queue position, longest first
+            s_off[pos] = off[g];
+            s_len[pos] = l[k];
+            s_id[pos] = g;
+        }
+    }
 }
 
 void launch_bin_order(const u64* d_off, const u64* d_len, u32 n, u32* d_hist, u32* d_cursor,
-                      u32 n_bins, u64* d_s_off, u64* d_s_len, u32* d_s_id, hipStream_t s) {
+                      u32 n_bins, u32 bin_shift, u64* d_s_off, u64* d_s_len, u32* d_s_id,
+                      hipStream_t s) {
     if (n == 0) return;
     hipLaunchKernelGGL(bin_cursor_kernel, dim3(1), dim3(256), 0, s, d_hist, d_cursor, n_bins);
-    hipLaunchKernelGGL(bin_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_off, d_len, n,
-                       d_cursor, n_bins, d_s_off, d_s_len, d_s_id);
+    const u32 per = 256 * kScatterPer;
+    hipLaunchKernelGGL(bin_scatter_kernel, dim3((n + per - 1) / per), dim3(256), 0, s, d_off, d_len,
+                       n, d_cursor, n_bins, bin_shift, d_s_off, d_s_len, d_s_id);
 }
 
 // ---- per-file root items: string f = digests[first[f] .. +n_chunks[f]) ----------
