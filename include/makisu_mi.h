@@ -149,6 +149,14 @@ int mi_batch_run(mi_batch* b);
 /* Re-runs the device pipeline on data already resident from a previous run (bench
  * steps; no re-staging / re-generation).                                            */
 int mi_batch_rerun(mi_batch* b);
+/* Asynchronous form: mi_batch_submit stages the batch on first use and ENQUEUES the
+ * whole pipeline on the batch's own HIP stream without any host synchronisation, then
+ * returns; mi_batch_wait blocks until it has finished and publishes counts and stats.
+ * Two batches may be in flight on one ctx: the Gear pass of one overlaps the SHA-256
+ * pass of the other (they bind different units of the CU).  mi_batch_run ==
+ * submit + wait.  A batch may be submitted again after its wait (same data).         */
+int mi_batch_submit(mi_batch* b);
+int mi_batch_wait(mi_batch* b);
 int mi_batch_counts(mi_batch* b, uint64_t* n_files, uint64_t* n_chunks, uint64_t* n_bytes);
 int mi_batch_files(mi_batch* b, mi_file_result* out, uint64_t cap);
 int mi_batch_chunks(mi_batch* b, mi_chunk_result* out, uint64_t cap);

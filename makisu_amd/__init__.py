@@ -106,6 +106,8 @@ def load_library(rebuild=False):
         "mi_batch_add_synthetic": ([vp, u64, u64p, u64p, u64], C.c_int),
         "mi_batch_run": ([vp], C.c_int),
         "mi_batch_rerun": ([vp], C.c_int),
+        "mi_batch_submit": ([vp], C.c_int),
+        "mi_batch_wait": ([vp], C.c_int),
         "mi_batch_counts": ([vp, u64p, u64p, u64p], C.c_int),
         "mi_batch_files": ([vp, vp, u64], C.c_int),
         "mi_batch_chunks": ([vp, vp, u64], C.c_int),
@@ -257,6 +259,15 @@ class Batch:
 
     def rerun(self):
         self._check(self._lib.mi_batch_rerun(self._h))
+        return self
+
+    def submit(self):
+        """Enqueue the pipeline on the batch's own stream and return (no host sync)."""
+        self._check(self._lib.mi_batch_submit(self._h))
+        return self
+
+    def wait(self):
+        self._check(self._lib.mi_batch_wait(self._h))
         return self
 
     def counts(self):

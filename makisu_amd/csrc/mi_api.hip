@@ -54,14 +54,14 @@ struct mi_ctx {
     mi_config cfg;
     int device = 0;
     hipDeviceProp_t prop;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;        // ctx-level work (mi_dedup_mark, mi_sha256_many, uploads)
     std::vector<hipStream_t> copy_streams;
     std::vector<void*> staging;          // pinned, staging_bytes each
     std::vector<hipEvent_t> staging_done;
     size_t staging_bytes = 0;
     DevBuf gear_table, heads;
-    DevBuf dd_rep, dd_minid, dd_slot, dd_nuniq;     // dedup scratch
-    hipEvent_t ev[8];
+    DevBuf dd_rep, dd_minid, dd_slot, dd_nuniq;     // dedup scratch of mi_dedup_mark
+    hipEvent_t ev[2];
     int sha_blocks_per_cu = 2;
     CdcParams cdc;
     std::string err;
@@ -82,14 +82,22 @@ struct mi_batch {
     u64 win_fill = 0;        // bytes valid in it
     bool staged_any = false;
     double ms_h2d = 0;
-    bool ran = false, results_valid = false;
+    // pipeline state: every batch owns a stream, so two batches can be in flight and the
+    // Gear pass of one overlaps the SHA pass of the other (they bind different units)
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    u64* h_counts = nullptr;             // pinned: [0] = chunk count, [1] = unique count
+    bool staged = false, in_flight = false, ran = false, results_valid = false;
     u64 n_chunks = 0, total_slots = 0;
-    DevBuf small_list, large_list;      // file indices by CDC kernel variant
+    mi_stats stats;
+    DevBuf small_list, large_list;       // file indices by CDC kernel variant
     u32 n_small = 0, n_large = 0;
     DevBuf file_off, file_size, slot_base, cids, slot_ends, n_chunks_d, first, total_d, scratch;
     DevBuf chunk_off, chunk_len, chunk_file, chunk_start, hist, cursor, digests;
-    DevBuf q_off, q_len, q_id;          // SHA queue descriptors, longest chunk first
+    DevBuf q_off, q_len, q_id;           // SHA queue descriptors, longest chunk first
     DevBuf item_off, item_len, roots, file_sha, dup_of;
+    DevBuf heads_chunks, heads_files;    // SHA queue heads (one set per concurrent launch)
+    DevBuf dd_rep, dd_minid, dd_slot, dd_nuniq;
     std::vector<mi_file_result> h_files;
     std::vector<mi_chunk_result> h_chunks;
 };
@@ -201,7 +209,7 @@ int staging_append(mi_batch* b, u64 at, const u8* src, int fd, u64 foff, u64 len
 
 int batch_add_common(mi_batch* b, u64 len, u64 tag, u64* at) {
     if (!b) return MI_ERR_INVALID;
-    if (b->ran) return fail(b->ctx, MI_ERR_STATE, "batch already ran; begin a new batch");
+    if (b->staged) return fail(b->ctx, MI_ERR_STATE, "batch already ran; begin a new batch");
     *at = align_up(b->arena_used, kFileAlign);
     int rc = arena_reserve(b, *at + align_up(len, kFileAlign));
     if (rc) return rc;
@@ -227,116 +235,136 @@ float ev_ms(hipEvent_t a, hipEvent_t b) {
 }
 
 // ---- the device pipeline ---------------------------------------------------------
-int run_pipeline(mi_batch* b) {
+// submit_pipeline only ENQUEUES (kernels, memsets, two 8-byte async copies into pinned
+// memory) on the batch's stream: there is no host synchronisation between the stages.  Table
+// sizes come from host-side upper bounds (slots = sum(size/min_size + 2)); the real chunk
+// count lives in device memory (total_d) and every kernel that needs it reads it there.
+int submit_pipeline(mi_batch* b) {
     mi_ctx* c = b->ctx;
-    hipStream_t s = c->stream;
+    hipStream_t s = b->stream;
     const u64 nf = b->files.size();
     b->results_valid = false;
-    memset(&c->stats, 0, sizeof c->stats);
-    c->stats.bytes_in = b->total_bytes;
-    c->stats.n_files = nf;
-    c->stats.ms_h2d = b->ms_h2d;
+    memset(&b->stats, 0, sizeof b->stats);
+    b->stats.bytes_in = b->total_bytes;
+    b->stats.n_files = nf;
+    b->stats.ms_h2d = b->ms_h2d;
     b->n_chunks = 0;
-    if (nf == 0) { b->ran = true; return MI_OK; }
+    b->h_counts[0] = b->h_counts[1] = 0;
+    b->in_flight = true;
+    if (nf == 0) return MI_OK;
     if (nf >= 0x7FFFFFFFull) return fail(c, MI_ERR_INVALID, "too many files in one batch");
+    const u64 cap = b->total_slots;                     // upper bound of the chunk count
+    if (cap >= 0xFFFFFFFFull) return fail(c, MI_ERR_INVALID, "batch too large: %llu chunk slots",
+                                          (unsigned long long)cap);
+    // length bins for the longest-first order: SHA block counts >> bin_shift, <= 1024 bins
+    u32 bin_shift = 2;
+    while (((c->cfg.max_size / 64 + 3) >> bin_shift) + 1 > 1024) ++bin_shift;
+    const u32 n_bins = ((c->cfg.max_size / 64 + 3) >> bin_shift) + 1;
+    u64 dd_cap = 1024;
+    while (dd_cap < 2 * cap) dd_cap <<= 1;
+    const bool dedup = !(c->cfg.flags & MI_FLAG_NO_DEDUP);
 
-    HIPCHK(c, b->slot_ends.ensure(b->total_slots * 8));
+    HIPCHK(c, b->slot_ends.ensure(cap * 8));
     HIPCHK(c, b->n_chunks_d.ensure(nf * 4));
     HIPCHK(c, b->first.ensure(nf * 8));
     HIPCHK(c, b->total_d.ensure(8));
     HIPCHK(c, b->scratch.ensure(scan_scratch_elems(nf) * 8));
+    HIPCHK(c, b->chunk_off.ensure(cap * 8));
+    HIPCHK(c, b->chunk_len.ensure(cap * 8));
+    HIPCHK(c, b->chunk_start.ensure(cap * 8));
+    HIPCHK(c, b->chunk_file.ensure(cap * 4));
+    HIPCHK(c, b->hist.ensure(n_bins * 4));
+    HIPCHK(c, b->cursor.ensure(n_bins * 4));
+    HIPCHK(c, b->q_off.ensure(cap * 8));
+    HIPCHK(c, b->q_len.ensure(cap * 8));
+    HIPCHK(c, b->q_id.ensure(cap * 4));
+    HIPCHK(c, b->digests.ensure(cap * 32));
+    HIPCHK(c, b->item_off.ensure(nf * 8));
+    HIPCHK(c, b->item_len.ensure(nf * 8));
+    HIPCHK(c, b->roots.ensure(nf * 32));
+    HIPCHK(c, b->dup_of.ensure(cap * 8));
+    HIPCHK(c, b->heads_chunks.ensure(sizeof(u32) * kShaQueues));
+    HIPCHK(c, b->heads_files.ensure(sizeof(u32) * kShaQueues));
+    if (c->cfg.flags & MI_FLAG_FILE_SHA256) HIPCHK(c, b->file_sha.ensure(nf * 32));
+    if (dedup) {
+        HIPCHK(c, b->dd_rep.ensure(dd_cap * 4));
+        HIPCHK(c, b->dd_minid.ensure(dd_cap * 4));
+        HIPCHK(c, b->dd_slot.ensure(cap * 4));
+        HIPCHK(c, b->dd_nuniq.ensure(8));
+    }
 
     const u64* d_off = b->file_off.as<u64>();
     const u64* d_size = b->file_size.as<u64>();
+    const u64* d_n = b->total_d.as<u64>();
+    const int ncu = c->prop.multiProcessorCount;
 
-    HIPCHK(c, hipEventRecord(c->ev[0], s));
+    HIPCHK(c, hipEventRecord(b->ev[0], s));
     launch_gear_cdc(b->arena.as<u8>(), d_off, d_size, b->slot_base.as<u64>(),
                     b->slot_ends.as<u64>(), b->n_chunks_d.as<u32>(), b->small_list.as<u32>(),
                     b->n_small, b->large_list.as<u32>(), b->n_large, c->gear_table.as<u64>(),
                     c->cdc, s);
     launch_scan_counts(b->n_chunks_d.as<u32>(), b->first.as<u64>(), b->total_d.as<u64>(), nf,
                        b->scratch.as<u64>(), s);
-    HIPCHK(c, hipEventRecord(c->ev[1], s));
-    u64 total = 0;
-    HIPCHK(c, hipMemcpyAsync(&total, b->total_d.p, 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
-    HIPCHK(c, hipGetLastError());
-    if (total > b->total_slots || total >= 0xFFFFFFFFull)
-        return fail(c, MI_ERR_HIP, "chunk count %llu out of range (slots %llu)",
-                    (unsigned long long)total, (unsigned long long)b->total_slots);
-    b->n_chunks = total;
-    const u32 nc = (u32)total;
-
-    // length bins for the longest-first order: SHA block counts >> bin_shift, <= 1024 bins
-    u32 bin_shift = 2;
-    while (((c->cfg.max_size / 64 + 3) >> bin_shift) + 1 > 1024) ++bin_shift;
-    const u32 n_bins = ((c->cfg.max_size / 64 + 3) >> bin_shift) + 1;
-    HIPCHK(c, b->chunk_off.ensure(total * 8));
-    HIPCHK(c, b->chunk_len.ensure(total * 8));
-    HIPCHK(c, b->chunk_start.ensure(total * 8));
-    HIPCHK(c, b->chunk_file.ensure(total * 4));
-    HIPCHK(c, b->hist.ensure(n_bins * 4));
-    HIPCHK(c, b->cursor.ensure(n_bins * 4));
-    HIPCHK(c, b->q_off.ensure(total * 8));
-    HIPCHK(c, b->q_len.ensure(total * 8));
-    HIPCHK(c, b->q_id.ensure(total * 4));
-    HIPCHK(c, b->digests.ensure(total * 32));
-    HIPCHK(c, b->item_off.ensure(nf * 8));
-    HIPCHK(c, b->item_len.ensure(nf * 8));
-    HIPCHK(c, b->roots.ensure(nf * 32));
-    HIPCHK(c, b->dup_of.ensure(total * 8));
-
+    HIPCHK(c, hipMemcpyAsync(&b->h_counts[0], b->total_d.p, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipEventRecord(b->ev[1], s));
     launch_compact_chunks(d_off, b->slot_base.as<u64>(), b->slot_ends.as<u64>(),
                           b->n_chunks_d.as<u32>(), b->first.as<u64>(), nf, b->chunk_off.as<u64>(),
                           b->chunk_len.as<u64>(), b->chunk_file.as<u32>(),
                           b->chunk_start.as<u64>(), b->hist.as<u32>(), n_bins, bin_shift, s);
-    launch_bin_order(b->chunk_off.as<u64>(), b->chunk_len.as<u64>(), nc, b->hist.as<u32>(),
-                     b->cursor.as<u32>(), n_bins, bin_shift, b->q_off.as<u64>(), b->q_len.as<u64>(),
-                     b->q_id.as<u32>(), s);
-    HIPCHK(c, hipEventRecord(c->ev[2], s));
+    launch_bin_order(b->chunk_off.as<u64>(), b->chunk_len.as<u64>(), (u32)cap, d_n,
+                     b->hist.as<u32>(), b->cursor.as<u32>(), n_bins, bin_shift,
+                     b->q_off.as<u64>(), b->q_len.as<u64>(), b->q_id.as<u32>(), s);
+    HIPCHK(c, hipEventRecord(b->ev[2], s));
     launch_sha256_items(kShaChunks, b->arena.as<u8>(), b->q_off.as<u64>(), b->q_len.as<u64>(),
-                        b->q_id.as<u32>(), nc, c->heads.as<u32>(), b->digests.as<u8>(),
-                        c->sha_blocks_per_cu, c->prop.multiProcessorCount, s);
-    HIPCHK(c, hipEventRecord(c->ev[3], s));
+                        b->q_id.as<u32>(), (u32)cap, d_n, b->heads_chunks.as<u32>(),
+                        b->digests.as<u8>(), c->sha_blocks_per_cu, ncu, s);
+    HIPCHK(c, hipEventRecord(b->ev[3], s));
     // per-file roots: SHA-256 over each file's run of chunk digests
     launch_file_items(b->first.as<u64>(), b->n_chunks_d.as<u32>(), nf, b->item_off.as<u64>(),
                       b->item_len.as<u64>(), s);
-    launch_sha256_items(kShaRoots, b->digests.as<u8>(), b->item_off.as<u64>(), b->item_len.as<u64>(), nullptr,
-                        (u32)nf, c->heads.as<u32>(), b->roots.as<u8>(), c->sha_blocks_per_cu,
-                        c->prop.multiProcessorCount, s);
-    if (c->cfg.flags & MI_FLAG_FILE_SHA256) {
-        HIPCHK(c, b->file_sha.ensure(nf * 32));
-        launch_sha256_items(kShaFiles, b->arena.as<u8>(), d_off, d_size, nullptr, (u32)nf,
-                            c->heads.as<u32>(), b->file_sha.as<u8>(), c->sha_blocks_per_cu,
-                            c->prop.multiProcessorCount, s);
-    }
-    HIPCHK(c, hipEventRecord(c->ev[4], s));
-    u64 n_unique = total;
-    if (!(c->cfg.flags & MI_FLAG_NO_DEDUP)) {
-        u64 cap = 1024;
-        while (cap < 2 * total) cap <<= 1;
-        HIPCHK(c, c->dd_rep.ensure(cap * 4));
-        HIPCHK(c, c->dd_minid.ensure(cap * 4));
-        HIPCHK(c, c->dd_slot.ensure(total * 4));
-        HIPCHK(c, c->dd_nuniq.ensure(8));
-        launch_dedup_mark(b->digests.as<u8>(), total, c->dd_rep.as<u32>(), c->dd_minid.as<u32>(),
-                          c->dd_slot.as<u32>(), cap, b->dup_of.as<i64>(), c->dd_nuniq.as<u64>(), s);
-        HIPCHK(c, hipMemcpyAsync(&n_unique, c->dd_nuniq.p, 8, hipMemcpyDeviceToHost, s));
+    launch_sha256_items(kShaRoots, b->digests.as<u8>(), b->item_off.as<u64>(),
+                        b->item_len.as<u64>(), nullptr, (u32)nf, nullptr,
+                        b->heads_files.as<u32>(), b->roots.as<u8>(), c->sha_blocks_per_cu, ncu, s);
+    if (c->cfg.flags & MI_FLAG_FILE_SHA256)
+        launch_sha256_items(kShaFiles, b->arena.as<u8>(), d_off, d_size, nullptr, (u32)nf, nullptr,
+                            b->heads_files.as<u32>(), b->file_sha.as<u8>(), c->sha_blocks_per_cu,
+                            ncu, s);
+    HIPCHK(c, hipEventRecord(b->ev[4], s));
+    if (dedup) {
+        launch_dedup_mark(b->digests.as<u8>(), cap, d_n, b->dd_rep.as<u32>(),
+                          b->dd_minid.as<u32>(), b->dd_slot.as<u32>(), dd_cap,
+                          b->dup_of.as<i64>(), b->dd_nuniq.as<u64>(), s);
+        HIPCHK(c, hipMemcpyAsync(&b->h_counts[1], b->dd_nuniq.p, 8, hipMemcpyDeviceToHost, s));
     } else {
-        HIPCHK(c, hipMemsetAsync(b->dup_of.p, 0xFF, total * 8, s));
+        HIPCHK(c, hipMemsetAsync(b->dup_of.p, 0xFF, cap * 8, s));
     }
-    HIPCHK(c, hipEventRecord(c->ev[5], s));
-    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, hipEventRecord(b->ev[5], s));
     HIPCHK(c, hipGetLastError());
+    return MI_OK;
+}
 
-    c->stats.n_chunks = total;
-    c->stats.n_unique = n_unique;
-    c->stats.ms_cdc = ev_ms(c->ev[0], c->ev[1]);
-    c->stats.ms_sort = ev_ms(c->ev[1], c->ev[2]);
-    c->stats.ms_sha_chunks = ev_ms(c->ev[2], c->ev[3]);
-    c->stats.ms_sha_files = ev_ms(c->ev[3], c->ev[4]);
-    c->stats.ms_dedup = ev_ms(c->ev[4], c->ev[5]);
-    c->stats.ms_total = ev_ms(c->ev[0], c->ev[5]);
+int wait_pipeline(mi_batch* b) {
+    mi_ctx* c = b->ctx;
+    if (!b->in_flight) return fail(c, MI_ERR_STATE, "mi_batch_wait without a submitted run");
+    b->in_flight = false;
+    HIPCHK(c, hipStreamSynchronize(b->stream));
+    HIPCHK(c, hipGetLastError());
+    const u64 total = b->h_counts[0];
+    if (total > b->total_slots)
+        return fail(c, MI_ERR_HIP, "chunk count %llu exceeds its bound %llu",
+                    (unsigned long long)total, (unsigned long long)b->total_slots);
+    b->n_chunks = total;
+    b->stats.n_chunks = total;
+    b->stats.n_unique = (c->cfg.flags & MI_FLAG_NO_DEDUP) ? total : b->h_counts[1];
+    if (!b->files.empty()) {
+        b->stats.ms_cdc = ev_ms(b->ev[0], b->ev[1]);
+        b->stats.ms_sort = ev_ms(b->ev[1], b->ev[2]);
+        b->stats.ms_sha_chunks = ev_ms(b->ev[2], b->ev[3]);
+        b->stats.ms_sha_files = ev_ms(b->ev[3], b->ev[4]);
+        b->stats.ms_dedup = ev_ms(b->ev[4], b->ev[5]);
+        b->stats.ms_total = ev_ms(b->ev[0], b->ev[5]);
+    }
+    c->stats = b->stats;
     b->ran = true;
     return MI_OK;
 }
@@ -527,10 +555,19 @@ int mi_batch_begin(mi_ctx* c, uint64_t n_files_hint, uint64_t bytes_hint, mi_bat
     HIPCHK(c, hipSetDevice(c->device));
     mi_batch* b = new mi_batch();
     b->ctx = c;
+    memset(&b->stats, 0, sizeof b->stats);
     b->files.reserve(n_files_hint);
+    hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+    for (auto& ev : b->ev) if (e == hipSuccess) e = hipEventCreate(&ev);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&b->h_counts, 16, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        int rc = fail(c, MI_ERR_HIP, "mi_batch_begin: %s", hipGetErrorString(e));
+        mi_batch_free(b);
+        return rc;
+    }
     if (bytes_hint) {
         int rc = arena_reserve(b, bytes_hint + n_files_hint * kFileAlign);
-        if (rc) { delete b; return rc; }
+        if (rc) { mi_batch_free(b); return rc; }
     }
     *out = b;
     return MI_OK;
@@ -585,7 +622,7 @@ int mi_batch_add_synthetic(mi_batch* b, uint64_t n_files, const uint64_t* sizes,
     if (!b || (!sizes && n_files)) return MI_ERR_INVALID;
     mi_ctx* c = b->ctx;
     HIPCHK(c, hipSetDevice(c->device));
-    if (b->ran) return fail(c, MI_ERR_STATE, "batch already ran; begin a new batch");
+    if (b->staged) return fail(c, MI_ERR_STATE, "batch already ran; begin a new batch");
     // synthetic files are generated on the device at run time; flush any host window first
     int rc = staging_flush(b);
     if (rc) return rc;
@@ -610,15 +647,14 @@ int mi_batch_add_synthetic(mi_batch* b, uint64_t n_files, const uint64_t* sizes,
     return MI_OK;
 }
 
-int mi_batch_run(mi_batch* b) {
-    if (!b) return MI_ERR_INVALID;
+// Stages everything that was added (flush of the pinned ring, file tables, synthetic
+// generation).  Done once per batch, before its first submit.
+static int stage_batch(mi_batch* b) {
     mi_ctx* c = b->ctx;
-    HIPCHK(c, hipSetDevice(c->device));
-    if (b->ran) return fail(c, MI_ERR_STATE, "batch already ran; use mi_batch_rerun");
+    if (b->staged) return MI_OK;
     int rc = staging_flush(b);
     if (rc) return rc;
     for (auto s : c->copy_streams) HIPCHK(c, hipStreamSynchronize(s));
-    // file tables
     const u64 nf = b->files.size();
     std::vector<u64> off(nf), size(nf), slot(nf);
     std::vector<u32> small, large;
@@ -630,11 +666,11 @@ int mi_batch_run(mi_batch* b) {
         slots += size[f] / c->cfg.min_size + 2;
         (size[f] <= (u64)kGearTile ? small : large).push_back((u32)f);
     }
+    b->total_slots = slots;
     b->n_small = (u32)small.size();
     b->n_large = (u32)large.size();
     if ((rc = upload(c, b->small_list, small))) return rc;
     if ((rc = upload(c, b->large_list, large))) return rc;
-    b->total_slots = slots;
     if ((rc = upload(c, b->file_off, off))) return rc;
     if ((rc = upload(c, b->file_size, size))) return rc;
     if ((rc = upload(c, b->slot_base, slot))) return rc;
@@ -648,15 +684,41 @@ int mi_batch_run(mi_batch* b) {
                           c->stream);
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
-    return run_pipeline(b);
+    b->staged = true;
+    return MI_OK;
+}
+
+int mi_batch_submit(mi_batch* b) {
+    if (!b) return MI_ERR_INVALID;
+    mi_ctx* c = b->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (b->in_flight) return fail(c, MI_ERR_STATE, "batch is already in flight; mi_batch_wait first");
+    int rc = stage_batch(b);
+    if (rc) return rc;
+    return submit_pipeline(b);
+}
+
+int mi_batch_wait(mi_batch* b) {
+    if (!b) return MI_ERR_INVALID;
+    HIPCHK(b->ctx, hipSetDevice(b->ctx->device));
+    return wait_pipeline(b);
+}
+
+int mi_batch_run(mi_batch* b) {
+    if (!b) return MI_ERR_INVALID;
+    if (b->ran || b->in_flight)
+        return fail(b->ctx, MI_ERR_STATE, "batch already ran; use mi_batch_rerun");
+    int rc = mi_batch_submit(b);
+    if (rc) { b->in_flight = false; return rc; }
+    return mi_batch_wait(b);
 }
 
 int mi_batch_rerun(mi_batch* b) {
     if (!b) return MI_ERR_INVALID;
-    mi_ctx* c = b->ctx;
-    HIPCHK(c, hipSetDevice(c->device));
-    if (!b->ran) return fail(c, MI_ERR_STATE, "mi_batch_rerun before mi_batch_run");
-    return run_pipeline(b);
+    if (!b->ran) return fail(b->ctx, MI_ERR_STATE, "mi_batch_rerun before mi_batch_run");
+    int rc = mi_batch_submit(b);
+    if (rc) { b->in_flight = false; return rc; }
+    return mi_batch_wait(b);
 }
 
 int mi_batch_counts(mi_batch* b, uint64_t* n_files, uint64_t* n_chunks, uint64_t* n_bytes) {
@@ -720,10 +782,14 @@ int mi_batch_free(mi_batch* b) {
     (void)hipSetDevice(c->device);
     for (auto s : c->copy_streams) (void)hipStreamSynchronize(s);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&b->arena, &b->small_list, &b->large_list, &b->file_off, &b->file_size, &b->slot_base, &b->cids,
+    if (b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
+    for (auto e : b->ev) if (e) (void)hipEventDestroy(e);
+    if (b->h_counts) (void)hipHostFree(b->h_counts);
+    DevBuf* bufs[] = {&b->heads_chunks, &b->heads_files, &b->dd_rep, &b->dd_minid, &b->dd_slot,
+                      &b->dd_nuniq, &b->q_off, &b->q_len, &b->q_id,&b->arena, &b->small_list, &b->large_list, &b->file_off, &b->file_size, &b->slot_base, &b->cids,
                       &b->slot_ends, &b->n_chunks_d, &b->first, &b->total_d, &b->scratch,
                       &b->chunk_off, &b->chunk_len, &b->chunk_file, &b->chunk_start, &b->hist,
-                      &b->cursor, &b->q_off, &b->q_len, &b->q_id, &b->digests, &b->item_off, &b->item_len, &b->roots,
+                      &b->cursor, &b->digests, &b->item_off, &b->item_len, &b->roots,
                       &b->file_sha, &b->dup_of};
     for (DevBuf* d : bufs) d->release();
     delete b;
@@ -740,15 +806,15 @@ int mi_dedup_mark(mi_ctx* c, const void* d_digests, uint64_t n, void* d_dup_of, 
     HIPCHK(c, c->dd_minid.ensure(cap * 4));
     HIPCHK(c, c->dd_slot.ensure(n * 4 + 16));
     HIPCHK(c, c->dd_nuniq.ensure(8));
-    HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
-    launch_dedup_mark((const u8*)d_digests, n, c->dd_rep.as<u32>(), c->dd_minid.as<u32>(),
+    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    launch_dedup_mark((const u8*)d_digests, n, nullptr, c->dd_rep.as<u32>(), c->dd_minid.as<u32>(),
                       c->dd_slot.as<u32>(), cap, (i64*)d_dup_of, c->dd_nuniq.as<u64>(), c->stream);
-    HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     u64 nu = 0;
     HIPCHK(c, hipMemcpyAsync(&nu, c->dd_nuniq.p, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
-    c->stats.ms_dedup = ev_ms(c->ev[6], c->ev[7]);
+    c->stats.ms_dedup = ev_ms(c->ev[0], c->ev[1]);
     c->stats.n_unique = nu;
     if (n_unique) *n_unique = nu;
     return MI_OK;
@@ -787,7 +853,7 @@ int mi_sha256_many(mi_ctx* c, const void* data, const uint64_t* offsets, const u
         if (e == hipSuccess) e = hipMemcpy(d_len.p, lens, n * 8, hipMemcpyHostToDevice);
         if (e == hipSuccess) {
             launch_sha256_items(kShaBlobs, d_data.as<u8>(), d_off.as<u64>(), d_len.as<u64>(), nullptr, (u32)n,
-                                c->heads.as<u32>(), d_out.as<u8>(), c->sha_blocks_per_cu,
+                                nullptr, c->heads.as<u32>(), d_out.as<u8>(), c->sha_blocks_per_cu,
                                 c->prop.multiProcessorCount, c->stream);
             e = hipStreamSynchronize(c->stream);
         }

@@ -54,9 +54,10 @@ void launch_gear_cdc(const u8* d_data, const u64* d_file_off, const u64* d_file_
 // base[off[p] .. +len[p]) whose digest goes to out[32 * (ids ? ids[p] : p)]; positions are
 // consumed in order, so put the longest strings first.  heads = kShaQueues words.
 enum ShaPass { kShaChunks = 0, kShaRoots = 1, kShaFiles = 2, kShaBlobs = 3 };
-void launch_sha256_items(ShaPass pass, const u8* d_base, const u64* d_off, const u64* d_len, const u32* d_ids,
-                         u32 n, u32* d_heads, u8* d_out, int blocks_per_cu, int n_cu,
-                         hipStream_t s);
+// n = string count (or its upper bound when d_n, a device word holding the real count, is given)
+void launch_sha256_items(ShaPass pass, const u8* d_base, const u64* d_off, const u64* d_len,
+                         const u32* d_ids, u32 n, const u64* d_n, u32* d_heads, u8* d_out,
+                         int blocks_per_cu, int n_cu, hipStream_t s);
 
 // tables.hip
 void launch_synth_fill(u8* d_data, const u64* d_file_off, const u64* d_file_size,
@@ -71,14 +72,15 @@ void launch_compact_chunks(const u64* d_file_off, const u64* d_slot_base, const 
                            u64* d_chunk_start, u32* d_hist, u32 n_bins, u32 bin_shift,
                            hipStream_t s);
 // queue descriptors in processing order (longest first): s_off/s_len/s_id[pos]
-void launch_bin_order(const u64* d_off, const u64* d_len, u32 n, u32* d_hist, u32* d_cursor,
-                      u32 n_bins, u32 bin_shift, u64* d_s_off, u64* d_s_len, u32* d_s_id,
-                      hipStream_t s);
+void launch_bin_order(const u64* d_off, const u64* d_len, u32 n, const u64* d_n, u32* d_hist,
+                      u32* d_cursor, u32 n_bins, u32 bin_shift, u64* d_s_off, u64* d_s_len,
+                      u32* d_s_id, hipStream_t s);
 void launch_file_items(const u64* d_first, const u32* d_n_chunks, u64 n_files, u64* d_off,
                        u64* d_len, hipStream_t s);
 void launch_crc32_files(const u8* d_data, const u64* d_file_off, const u64* d_file_size,
                         u64 n_files, u32* d_crc, hipStream_t s);
-void launch_dedup_mark(const u8* d_digests, u64 n, u32* d_rep, u32* d_minid, u32* d_slot_of,
-                       u64 cap_pow2, i64* d_dup_of, u64* d_n_unique, hipStream_t s);
+void launch_dedup_mark(const u8* d_digests, u64 n, const u64* d_n, u32* d_rep, u32* d_minid,
+                       u32* d_slot_of, u64 cap_pow2, i64* d_dup_of, u64* d_n_unique,
+                       hipStream_t s);
 
 }  // namespace mi

@@ -110,8 +110,11 @@ constexpr u32 kLook = 5;
 template <int kPass>
 __global__ __launch_bounds__(kShaWG)
 void sha256_items_kernel(const u8* __restrict__ base, const u64* __restrict__ off,
-                         const u64* __restrict__ len, const u32* __restrict__ ids, u32 n,
-                         u32* __restrict__ heads, u8* __restrict__ out) {
+                         const u64* __restrict__ len, const u32* __restrict__ ids, u32 n_max,
+                         const u64* __restrict__ n_ptr, u32* __restrict__ heads,
+                         u8* __restrict__ out) {
+    // the string count may only be known on the device (no host sync between pipeline stages)
+    const u32 n = n_ptr ? (u32)*n_ptr : n_max;
     const int lane = threadIdx.x & 63;
     const int q0 = blockIdx.x % kShaQueues;
     // current string
@@ -265,8 +268,8 @@ void sha256_items_kernel(const u8* __restrict__ base, const u64* __restrict__ of
 }
 
 void launch_sha256_items(ShaPass pass, const u8* d_base, const u64* d_off, const u64* d_len,
-                         const u32* d_order, u32 n, u32* d_heads, u8* d_out, int blocks_per_cu,
-                         int n_cu, hipStream_t s) {
+                         const u32* d_order, u32 n, const u64* d_n, u32* d_heads, u8* d_out,
+                         int blocks_per_cu, int n_cu, hipStream_t s) {
     if (n == 0) return;
     (void)hipMemsetAsync(d_heads, 0, sizeof(u32) * kShaQueues, s);
     u64 want = ((u64)n + kShaWG - 1) / kShaWG;
@@ -277,7 +280,7 @@ void launch_sha256_items(ShaPass pass, const u8* d_base, const u64* d_off, const
     if (grid == 0) grid = 1;
 #define MI_SHA_LAUNCH(P)                                                                      \
     hipLaunchKernelGGL(sha256_items_kernel<P>, dim3(grid), dim3(kShaWG), 0, s, d_base, d_off,   \
-                       d_len, d_order, n, d_heads, d_out)
+                       d_len, d_order, n, d_n, d_heads, d_out)
     switch (pass) {
         case kShaChunks: MI_SHA_LAUNCH(kShaChunks); break;
         case kShaRoots:  MI_SHA_LAUNCH(kShaRoots); break;

@@ -217,13 +217,15 @@ void bin_cursor_kernel(const u32* __restrict__ hist, u32* __restrict__ cursor, u
 // descriptor at range start + local rank.
 constexpr int kScatterPer = 8;
 __global__ __launch_bounds__(256)
-void bin_scatter_kernel(const u64* __restrict__ off, const u64* __restrict__ len, u32 n,
-                        u32* __restrict__ cursor, u32 n_bins, u32 bin_shift,
+void bin_scatter_kernel(const u64* __restrict__ off, const u64* __restrict__ len, u32 n_max,
+                        const u64* __restrict__ n_ptr, u32* __restrict__ cursor, u32 n_bins, u32 bin_shift,
                         u64* __restrict__ s_off, u64* __restrict__ s_len, u32* __restrict__ s_id) {
     __shared__ u32 cnt[kMaxBins];
+    const u32 n = n_ptr ? (u32)*n_ptr : n_max;
+    const u32 base = blockIdx.x * (256 * kScatterPer);
+    if (base >= n) return;
     for (u32 i = threadIdx.x; i < n_bins; i += blockDim.x) cnt[i] = 0;
     __syncthreads();
-    const u32 base = blockIdx.x * (256 * kScatterPer);
     u32 bin[kScatterPer], rank[kScatterPer];
     u64 l[kScatterPer];
 #pragma unroll
@@ -253,14 +255,14 @@ void bin_scatter_kernel(const u64* __restrict__ off, const u64* __restrict__ len
     }
 }
 
-void launch_bin_order(const u64* d_off, const u64* d_len, u32 n, u32* d_hist, u32* d_cursor,
-                      u32 n_bins, u32 bin_shift, u64* d_s_off, u64* d_s_len, u32* d_s_id,
-                      hipStream_t s) {
+void launch_bin_order(const u64* d_off, const u64* d_len, u32 n, const u64* d_n, u32* d_hist,
+                      u32* d_cursor, u32 n_bins, u32 bin_shift, u64* d_s_off, u64* d_s_len,
+                      u32* d_s_id, hipStream_t s) {
     if (n == 0) return;
     hipLaunchKernelGGL(bin_cursor_kernel, dim3(1), dim3(256), 0, s, d_hist, d_cursor, n_bins);
     const u32 per = 256 * kScatterPer;
     hipLaunchKernelGGL(bin_scatter_kernel, dim3((n + per - 1) / per), dim3(256), 0, s, d_off, d_len,
-                       n, d_cursor, n_bins, bin_shift, d_s_off, d_s_len, d_s_id);
+                       n, d_n, d_cursor, n_bins, bin_shift, d_s_off, d_s_len, d_s_id);
 }
 
 // ---- per-file root items: string f = digests[first[f] .. +n_chunks[f]) ----------
@@ -293,8 +295,10 @@ __device__ __forceinline__ bool digest_eq(const u8* a, const u8* b) {
 }
 
 __global__ __launch_bounds__(256)
-void dedup_insert_kernel(const u8* __restrict__ digests, u64 n, u32* __restrict__ rep,
-                         u32* __restrict__ minid, u32* __restrict__ slot_of, u64 mask) {
+void dedup_insert_kernel(const u8* __restrict__ digests, u64 n_max, const u64* __restrict__ n_ptr,
+                         u32* __restrict__ rep, u32* __restrict__ minid,
+                         u32* __restrict__ slot_of, u64 mask) {
+    const u64 n = n_ptr ? *n_ptr : n_max;
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const u8* mine = digests + 32 * i;
@@ -309,8 +313,10 @@ void dedup_insert_kernel(const u8* __restrict__ digests, u64 n, u32* __restrict_
 }
 
 __global__ __launch_bounds__(256)
-void dedup_finish_kernel(u64 n, const u32* __restrict__ minid, const u32* __restrict__ slot_of,
-                         i64* __restrict__ dup_of, u64* __restrict__ n_unique) {
+void dedup_finish_kernel(u64 n_max, const u64* __restrict__ n_ptr, const u32* __restrict__ minid,
+                         const u32* __restrict__ slot_of, i64* __restrict__ dup_of,
+                         u64* __restrict__ n_unique) {
+    const u64 n = n_ptr ? *n_ptr : n_max;
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const u32 m = minid[slot_of[i]];
@@ -319,16 +325,17 @@ void dedup_finish_kernel(u64 n, const u32* __restrict__ minid, const u32* __rest
     if (first) atomicAdd((unsigned long long*)n_unique, 1ull);
 }
 
-void launch_dedup_mark(const u8* d_digests, u64 n, u32* d_rep, u32* d_minid, u32* d_slot_of,
-                       u64 cap_pow2, i64* d_dup_of, u64* d_n_unique, hipStream_t s) {
+void launch_dedup_mark(const u8* d_digests, u64 n, const u64* d_n, u32* d_rep, u32* d_minid,
+                       u32* d_slot_of, u64 cap_pow2, i64* d_dup_of, u64* d_n_unique,
+                       hipStream_t s) {
     (void)hipMemsetAsync(d_n_unique, 0, sizeof(u64), s);
     if (n == 0) return;
     (void)hipMemsetAsync(d_rep, 0, sizeof(u32) * cap_pow2, s);
     (void)hipMemsetAsync(d_minid, 0xFF, sizeof(u32) * cap_pow2, s);
     const u32 grid = (u32)((n + 255) / 256);
-    hipLaunchKernelGGL(dedup_insert_kernel, dim3(grid), dim3(256), 0, s, d_digests, n, d_rep,
+    hipLaunchKernelGGL(dedup_insert_kernel, dim3(grid), dim3(256), 0, s, d_digests, n, d_n, d_rep,
                        d_minid, d_slot_of, cap_pow2 - 1);
-    hipLaunchKernelGGL(dedup_finish_kernel, dim3(grid), dim3(256), 0, s, n, d_minid, d_slot_of,
+    hipLaunchKernelGGL(dedup_finish_kernel, dim3(grid), dim3(256), 0, s, n, d_n, d_minid, d_slot_of,
                        d_dup_of, d_n_unique);
 }
 
