@@ -248,7 +248,7 @@ void gear_cdc_large_kernel(const u8* __restrict__ data, const u64* __restrict__ 
 void launch_gear_cdc(const u8* d_data, const u64* d_file_off, const u64* d_file_size,
                      const u64* d_slot_base, u64* d_slot_ends, u32* d_n_chunks,
                      const u32* d_small_list, u32 n_small, const u32* d_large_list, u32 n_large,
-                     const u64* d_gear_table, CdcParams p, hipStream_t s) {
+                     const u64* d_gear_table, CdcParams p, int /*n_cu*/, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)gear_cdc_small_kernel,
                               hipFuncAttributeMaxDynamicSharedMemorySize, kGearLdsBytes);
     (void)hipFuncSetAttribute((const void*)gear_cdc_large_kernel,

@@ -302,7 +302,7 @@ int submit_pipeline(mi_batch* b) {
     launch_gear_cdc(b->arena.as<u8>(), d_off, d_size, b->slot_base.as<u64>(),
                     b->slot_ends.as<u64>(), b->n_chunks_d.as<u32>(), b->small_list.as<u32>(),
                     b->n_small, b->large_list.as<u32>(), b->n_large, c->gear_table.as<u64>(),
-                    c->cdc, s);
+                    c->cdc, ncu, s);
     launch_scan_counts(b->n_chunks_d.as<u32>(), b->first.as<u64>(), b->total_d.as<u64>(), nf,
                        b->scratch.as<u64>(), s);
     HIPCHK(c, hipMemcpyAsync(&b->h_counts[0], b->total_d.p, 8, hipMemcpyDeviceToHost, s));

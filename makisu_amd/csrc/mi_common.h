@@ -13,7 +13,7 @@ typedef uint64_t u64;
 typedef int64_t  i64;
 
 // ---- Gear-CDC tile geometry (gear_cdc.hip) ------------------------------------
-constexpr int kGearWG     = 256;                 // threads per workgroup (4 waves)
+constexpr int kGearWG     = 256;                 // threads per workgroup (4 waves, 3 workgroups per CU)
 constexpr int kGearTile   = 65536;               // bytes of file one wave marks at a time
 constexpr int kGearHalo   = 64;                  // Gear window: h depends on <= 64 bytes
 constexpr int kGearTableCopies = 8;              // LDS replicas of the Gear table
@@ -48,7 +48,7 @@ constexpr u64 kSmGamma = 0x9E3779B97F4A7C15ULL;
 void launch_gear_cdc(const u8* d_data, const u64* d_file_off, const u64* d_file_size,
                      const u64* d_slot_base, u64* d_slot_ends, u32* d_n_chunks,
                      const u32* d_small_list, u32 n_small, const u32* d_large_list, u32 n_large,
-                     const u64* d_gear_table, CdcParams p, hipStream_t s);
+                     const u64* d_gear_table, CdcParams p, int n_cu, hipStream_t s);
 
 // sha256.hip : n independent byte strings -> n digests.  Queue position p holds the string
 // base[off[p] .. +len[p]) whose digest goes to out[32 * (ids ? ids[p] : p)]; positions are
