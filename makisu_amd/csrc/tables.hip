@@ -316,13 +316,27 @@ __global__ __launch_bounds__(256)
 void dedup_finish_kernel(u64 n_max, const u64* __restrict__ n_ptr, const u32* __restrict__ minid,
                          const u32* __restrict__ slot_of, i64* __restrict__ dup_of,
                          u64* __restrict__ n_unique) {
+    // grid-stride; uniques are counted per wave (ballot) and per workgroup (LDS) so the one
+    // global counter sees a few hundred atomics, not one per wave (same-address atomics
+    // retire at ~90 per microsecond)
+    __shared__ u32 wg_count;
+    if (threadIdx.x == 0) wg_count = 0;
+    __syncthreads();
     const u64 n = n_ptr ? *n_ptr : n_max;
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const u32 m = minid[slot_of[i]];
-    const bool first = (m == (u32)i);
-    dup_of[i] = first ? -1 : (i64)m;
-    if (first) atomicAdd((unsigned long long*)n_unique, 1ull);
+    u32 mine = 0;
+    for (u64 i0 = (u64)blockIdx.x * blockDim.x; i0 < n; i0 += (u64)gridDim.x * blockDim.x) {
+        const u64 i = i0 + threadIdx.x;
+        bool first = false;
+        if (i < n) {
+            const u32 m = minid[slot_of[i]];
+            first = (m == (u32)i);
+            dup_of[i] = first ? -1 : (i64)m;
+        }
+        mine += (u32)__popcll(__ballot(first));
+    }
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&wg_count, mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && wg_count) atomicAdd((unsigned long long*)n_unique, (unsigned long long)wg_count);
 }
 
 void launch_dedup_mark(const u8* d_digests, u64 n, const u64* d_n, u32* d_rep, u32* d_minid,
@@ -335,8 +349,8 @@ void launch_dedup_mark(const u8* d_digests, u64 n, const u64* d_n, u32* d_rep, u
     const u32 grid = (u32)((n + 255) / 256);
     hipLaunchKernelGGL(dedup_insert_kernel, dim3(grid), dim3(256), 0, s, d_digests, n, d_n, d_rep,
                        d_minid, d_slot_of, cap_pow2 - 1);
-    hipLaunchKernelGGL(dedup_finish_kernel, dim3(grid), dim3(256), 0, s, n, d_n, d_minid, d_slot_of,
-                       d_dup_of, d_n_unique);
+    hipLaunchKernelGGL(dedup_finish_kernel, dim3(grid < 1024 ? grid : 1024), dim3(256), 0, s, n, d_n,
+                       d_minid, d_slot_of, d_dup_of, d_n_unique);
 }
 
 }  // namespace mi

@@ -335,3 +335,101 @@ def test_global_dedup_single_rank_nccl(eng, oracle):
             assert np.array_equal(dup.cpu().numpy()[:n_total], want)
     finally:
         dist.destroy_process_group()
+
+
+def _oracle_threads():
+    import os
+    return max(1, min(64, (os.cpu_count() or 1)))
+
+
+def _compare_synth(oracle, eng, sizes, cids, seed=SEED):
+    with eng.batch() as b:
+        b.add_synthetic(sizes, cids, seed=seed)
+        b.run()
+        files, chunks = b.files().copy(), b.chunks().copy()
+    data = np.concatenate([oracle.synth_fill(seed, c, 0, n) for c, n in zip(cids, sizes)])
+    offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.uint64)
+    rf, rc = oracle.scan_batch(data, offs, sizes, _params(oracle, eng), True, _oracle_threads(), 0)
+    assert len(chunks) == len(rc)
+    assert np.array_equal(chunks["file_index"], rc["file_index"])
+    assert np.array_equal(chunks["offset"], rc["offset"]), "cut points differ"
+    assert np.array_equal(chunks["length"], rc["length"]), "cut points differ"
+    assert np.array_equal(chunks["sha256"], rc["sha256"]), "chunk digests differ"
+    assert np.array_equal(files["chunk_root"], rf["chunk_root"])
+    assert np.array_equal(chunks["dup_of"], rc["dup_of"])
+    return files, chunks
+
+
+def test_large_files_workgroup_path(oracle, eng):
+    # files > 64 KiB take the one-workgroup-per-file kernel (4 tiles per step, cut carry
+    # across tiles and steps); sizes straddle tile and step boundaries
+    sizes = [65537, 4 * 65536, 4 * 65536 + 1, 5 * 1024 * 1024 + 77, 20 * 1024 * 1024, 65536, 3]
+    _compare_synth(oracle, eng, sizes, list(range(100, 100 + len(sizes))))
+
+
+def test_c3_scaled_128mib_files(oracle, eng):
+    # BASELINE.json configs[2] shape (128 MiB files) at 6 files: ~0.75 GiB, oracle needs seconds
+    sizes = [128 * 1024 * 1024] * 6
+    files, chunks = _compare_synth(oracle, eng, sizes, [500, 501, 502, 500, 503, 501], seed=SEED + 1)
+    assert (chunks["dup_of"][chunks["file_index"] == 3] >= 0).all()      # file 3 repeats file 0
+
+
+def test_c5_zipf_mix_with_duplicates(oracle, eng):
+    # BASELINE.json configs[4] shape, scaled: sizes 1 KiB..32 MiB on a log scale, 90 % of the
+    # files are copies of the other 10 %; the unique chunk count must equal what the distinct
+    # contents alone produce
+    rng = np.random.default_rng(5)
+    n = 400
+    sizes = (2.0 ** rng.uniform(10, 25, n)).astype(np.int64)
+    sizes[0] = 1 << 25
+    distinct = n // 10
+    cids = np.arange(n)
+    src = rng.integers(0, distinct, n - distinct)
+    cids[distinct:] = src
+    sizes[distinct:] = sizes[src]
+    files, chunks = _compare_synth(oracle, eng, [int(s) for s in sizes], [int(c) for c in cids], seed=SEED + 2)
+    n_first = int(files["n_chunks"][:distinct].sum())
+    uniq_in_distinct = len({x.tobytes() for x in chunks["sha256"][:n_first]})
+    assert (chunks["dup_of"] < 0).sum() == uniq_in_distinct
+    assert (chunks["dup_of"][n_first:] >= 0).all()
+
+
+def test_host_staging_bigger_than_the_ring(oracle, eng):
+    # host-fed bytes larger than both 64 MiB pinned staging buffers: flush/reuse of the ring
+    blob = oracle.synth_fill(SEED, 900, 0, 150 * 1024 * 1024 + 13)
+    small = [oracle.synth_fill(SEED, 901 + i, 0, n).tobytes() for i, n in enumerate([10, 70000, 0])]
+    with eng.batch() as b:
+        b.add_bytes(small[0], tag=1)
+        b.add_bytes(blob, tag=2)
+        b.add_bytes(small[1], tag=3)
+        b.add_bytes(small[2], tag=4)
+        b.run()
+        back = b.read_back().copy()
+        files, chunks = b.files().copy(), b.chunks().copy()
+    want = np.concatenate([np.frombuffer(small[0], np.uint8), blob, np.frombuffer(small[1], np.uint8)])
+    assert np.array_equal(back, want)
+    sizes = [len(small[0]), blob.size, len(small[1]), 0]
+    offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.uint64)
+    rf, rc = oracle.scan_batch(want, offs, sizes, _params(oracle, eng), True, _oracle_threads(), 0)
+    assert np.array_equal(chunks["offset"], rc["offset"]) and np.array_equal(chunks["sha256"], rc["sha256"])
+    assert np.array_equal(files["chunk_root"], rf["chunk_root"])
+    assert [int(t) for t in files["user_tag"]] == [1, 2, 3, 4]
+
+
+def test_two_batches_in_flight(oracle, eng):
+    # mi_batch_submit / mi_batch_wait with two batches overlapping on one ctx
+    a, b = eng.batch(), eng.batch()
+    try:
+        a.add_synthetic([65536] * 3000, list(range(3000)), seed=SEED)
+        b.add_synthetic([65536] * 3000, list(range(3000, 6000)), seed=SEED)
+        a.submit(); b.submit(); a.wait(); b.wait()
+        ca1, cb1 = a.chunks().copy(), b.chunks().copy()
+        for _ in range(3):
+            a.submit(); b.submit(); a.wait(); b.wait()
+        assert np.array_equal(a.chunks(), ca1) and np.array_equal(b.chunks(), cb1)
+        assert not np.array_equal(ca1["sha256"][:100], cb1["sha256"][:100])
+        data = np.concatenate([oracle.synth_fill(SEED, i, 0, 65536) for i in range(3000, 3040)])
+        rf, rc = oracle.scan_batch(data, np.arange(40) * 65536, [65536] * 40, _params(oracle, eng), True, 1, 4)
+        assert np.array_equal(cb1["sha256"][:len(rc)], rc["sha256"])
+    finally:
+        a.free(); b.free()
