@@ -82,6 +82,8 @@ def main():
     ap.add_argument("--files", type=int, default=N_FILES, help="files per GPU (default = C2)")
     ap.add_argument("--inflight", type=int, default=2, help="batches in flight (1 = serial steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="run the RCCL digest exchange + global marking even with one rank (self-test)")
     args = ap.parse_args()
 
     import torch
@@ -98,11 +100,15 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the hot path)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    exchange = world > 1 or args.force_exchange
+    if exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    eng = makisu_amd.Engine(device=local_rank)
+    # with more than one rank the global marking after the all-gather supersedes the in-batch one
+    eng = makisu_amd.Engine(device=local_rank,
+                            flags=makisu_amd.FLAG_NO_DEDUP if exchange else 0)
     info = eng.device_info()
     # INFLIGHT batches alternate: step k runs on batch k % INFLIGHT.  Every step is a complete
     # pass (all outputs recomputed); a step is submitted while the previous one is still
@@ -119,7 +125,7 @@ def main():
 
     def finish(b, record):
         b.wait()
-        if world > 1:
+        if exchange:
             mdist.global_dedup(eng, b, device)    # digest all-gather over RCCL + global marking
         if record:
             st = eng.stats()
@@ -141,7 +147,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize(device)
-        if world > 1:
+        if exchange:
             dist.barrier()
             torch.cuda.synchronize(device)
 
@@ -151,7 +157,7 @@ def main():
     run_steps(args.steps, True)
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if exchange:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -182,7 +188,7 @@ def main():
                                "device-resident), Gear CDC mask 13 bits / min 2 KiB / max 64 KiB, "
                                "SHA-256 per chunk, per-file chunk root, duplicate marking%s"
                                % (args.files, "; digest-set all-gather over RCCL + global marking"
-                                  if world > 1 else ""),
+                                  if exchange else ""),
                    "files_per_gpu": args.files, "bytes_per_gpu": int(bytes_per_gpu),
                    "chunks_per_gpu": int(n_chunks), "parallelism": "files sharded x%d" % world,
                    "batches_in_flight": args.inflight,
@@ -203,13 +209,22 @@ def main():
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
     for b in batches:
         b.free()
     eng.close()
-    if world > 1:
+    if exchange:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints its version banner through C stdio; flush it first so the JSON line
+        # is the last thing on stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stderr.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -91,7 +91,9 @@ def global_dedup(engine, batch, device, group=None, mark=None, local=None):
     n_total = glob.shape[0]
     if mark is None:
         dup = torch.empty(max(n_total, 1), dtype=torch.int64, device=device)
-        torch.cuda.synchronize(device)
+        # only torch's stream (which produced `glob`) has to drain -- a device-wide sync would
+        # also wait for the OTHER batch's pipeline and serialise the two batches in flight
+        torch.cuda.current_stream(device).synchronize()
         n_unique = engine.dedup_mark(glob.data_ptr(), n_total, dup.data_ptr())
         batch.set_global_dedup(dup.data_ptr(), first)
     else:
