@@ -182,6 +182,24 @@ int mi_dedup_mark(mi_ctx* ctx, const void* d_digests, uint64_t n, void* d_dup_of
  * global row first_global + i of d_dup_of_global (device, int64).                  */
 int mi_batch_set_global_dedup(mi_batch* b, const void* d_dup_of_global, uint64_t first_global);
 
+/* ---- COPY/ADD context checksum (addCopyStep.SetCacheID seam) ------------------------ *
+ * Reproduces the ONE running CRC32-IEEE the reference feeds at plan time
+ * (lib/builder/step/add_copy_step.go:102-122,153-238): `prefix` = seed + directive +
+ * args (:104-105), then for every walked path, in filepath.Walk order: its relpath
+ * (:211), and for a symlink its target (:221-227), for a regular file all of its bytes
+ * (:230-236); directories contribute only their relpath (:216-218), special files are
+ * skipped by the caller (:198-203).  File bytes are reduced on the GPU (the batch must
+ * come from a ctx with MI_FLAG_FILE_CRC32 and have run); the strings are spliced in on
+ * the host with crc(A||B) = crc(A)*x^(8|B|) + crc(B).  The shim prints the result with
+ * fmt.Sprintf("%x", crc) (:119) -- unpadded hex -- to get the reference's cacheID.    */
+typedef struct {
+    const char* relpath;       /* filepath.Rel(ctx.ContextDir, path)                     */
+    const char* link_target;   /* non-NULL for a symlink: os.Readlink(path)              */
+    int64_t     file_index;    /* regular file: its index in the batch; otherwise -1     */
+} mi_ctx_entry;
+int mi_context_checksum(mi_batch* b, const void* prefix, uint64_t prefix_len,
+                        const mi_ctx_entry* entries, uint64_t n, uint32_t* crc_out);
+
 /* ---- standalone digests (image.Digester seam) ---------------------------------- *
  * n independent byte strings -> n SHA-256 digests on the GPU, one lane per string:
  * the batched form of image.NewDigester().FromBytes / FromReader

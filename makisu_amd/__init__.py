@@ -49,6 +49,11 @@ class _ChunkResult(C.Structure):
                 ("reserved", C.c_uint32), ("dup_of", C.c_int64), ("sha256", C.c_uint8 * 32)]
 
 
+class CtxEntry(C.Structure):
+    """mi_ctx_entry: one walked path of a COPY/ADD source tree."""
+    _fields_ = [("relpath", C.c_char_p), ("link_target", C.c_char_p), ("file_index", C.c_int64)]
+
+
 class Stats(C.Structure):
     _fields_ = [("bytes_in", C.c_uint64), ("n_files", C.c_uint64), ("n_chunks", C.c_uint64),
                 ("n_unique", C.c_uint64), ("ms_h2d", C.c_double), ("ms_cdc", C.c_double),
@@ -117,6 +122,8 @@ def load_library(rebuild=False):
         "mi_dedup_mark": ([vp, vp, u64, vp, u64p], C.c_int),
         "mi_batch_set_global_dedup": ([vp, vp, u64], C.c_int),
         "mi_sha256_many": ([vp, vp, u64p, u64p, u64, vp], C.c_int),
+        "mi_context_checksum": ([vp, vp, u64, C.POINTER(CtxEntry), u64, C.POINTER(C.c_uint32)],
+                                C.c_int),
     }
     for name, (args, res) in sigs.items():
         fn = getattr(L, name)          # AttributeError here = header/library drift
@@ -291,6 +298,22 @@ class Batch:
         p, n = C.c_void_p(), C.c_uint64()
         self._check(self._lib.mi_batch_device_digests(self._h, C.byref(p), C.byref(n)))
         return p.value, n.value
+
+    def context_checksum(self, prefix, entries):
+        """The reference's COPY/ADD running CRC32 (add_copy_step.go:102-238).
+
+        entries: walk-ordered list of (relpath, link_target_or_None, file_index_or_-1);
+        returns the cache ID the way SetCacheID prints it ("%x", unpadded)."""
+        arr = (CtxEntry * max(len(entries), 1))()
+        for i, (rel, link, idx) in enumerate(entries):
+            arr[i].relpath = os.fsencode(rel)
+            arr[i].link_target = os.fsencode(link) if link is not None else None
+            arr[i].file_index = idx
+        pre = bytes(prefix)
+        out = C.c_uint32()
+        self._check(self._lib.mi_context_checksum(self._h, pre, len(pre), arr, len(entries),
+                                                  C.byref(out)))
+        return "%x" % out.value
 
     def set_global_dedup(self, d_dup_of_global_ptr, first_global):
         self._check(self._lib.mi_batch_set_global_dedup(self._h, d_dup_of_global_ptr, first_global))

@@ -59,7 +59,7 @@ struct mi_ctx {
     std::vector<void*> staging;          // pinned, staging_bytes each
     std::vector<hipEvent_t> staging_done;
     size_t staging_bytes = 0;
-    DevBuf gear_table, heads;
+    DevBuf gear_table, heads, crc_consts;
     DevBuf dd_rep, dd_minid, dd_slot, dd_nuniq;     // dedup scratch of mi_dedup_mark
     hipEvent_t ev[2];
     int sha_blocks_per_cu = 2;
@@ -97,6 +97,8 @@ struct mi_batch {
     DevBuf q_off, q_len, q_id;           // SHA queue descriptors, longest chunk first
     DevBuf item_off, item_len, roots, file_sha, dup_of;
     DevBuf heads_chunks, heads_files;    // SHA queue heads (one set per concurrent launch)
+    DevBuf tile_file, first_tile, tile_raw, crc_d;   // MI_FLAG_FILE_CRC32
+    u64 n_tiles = 0;
     DevBuf dd_rep, dd_minid, dd_slot, dd_nuniq;
     std::vector<mi_file_result> h_files;
     std::vector<mi_chunk_result> h_chunks;
@@ -329,6 +331,13 @@ int submit_pipeline(mi_batch* b) {
         launch_sha256_items(kShaFiles, b->arena.as<u8>(), d_off, d_size, nullptr, (u32)nf, nullptr,
                             b->heads_files.as<u32>(), b->file_sha.as<u8>(), c->sha_blocks_per_cu,
                             ncu, s);
+    if (c->cfg.flags & MI_FLAG_FILE_CRC32) {
+        HIPCHK(c, b->tile_raw.ensure(b->n_tiles * 4 + 16));
+        HIPCHK(c, b->crc_d.ensure(nf * 4));
+        launch_crc32_files(b->arena.as<u8>(), d_off, d_size, b->tile_file.as<u32>(),
+                           b->first_tile.as<u64>(), b->n_tiles, nf, c->crc_consts.as<u32>(),
+                           b->tile_raw.as<u32>(), b->crc_d.as<u32>(), s);
+    }
     HIPCHK(c, hipEventRecord(b->ev[4], s));
     if (dedup) {
         launch_dedup_mark(b->digests.as<u8>(), cap, d_n, b->dd_rep.as<u32>(),
@@ -387,6 +396,11 @@ int fetch_results(mi_batch* b) {
             fsha.resize(nf * 32);
             HIPCHK(c, hipMemcpy(fsha.data(), b->file_sha.p, nf * 32, hipMemcpyDeviceToHost));
         }
+        std::vector<u32> crcs;
+        if (c->cfg.flags & MI_FLAG_FILE_CRC32) {
+            crcs.resize(nf);
+            HIPCHK(c, hipMemcpy(crcs.data(), b->crc_d.p, nf * 4, hipMemcpyDeviceToHost));
+        }
         for (u64 f = 0; f < nf; ++f) {
             mi_file_result& r = b->h_files[f];
             r.user_tag = b->files[f].tag;
@@ -395,6 +409,7 @@ int fetch_results(mi_batch* b) {
             r.n_chunks = ncs[f];
             memcpy(r.chunk_root, &roots[f * 32], 32);
             if (!fsha.empty()) memcpy(r.file_sha256, &fsha[f * 32], 32);
+            if (!crcs.empty()) r.crc32 = crcs[f];
         }
     }
     if (nc) {
@@ -506,6 +521,12 @@ int mi_ctx_create(const mi_config* cfg, mi_ctx** out) {
     CREATE_CHK(c->gear_table.ensure(sizeof table));
     CREATE_CHK(hipMemcpy(c->gear_table.p, table, sizeof table, hipMemcpyHostToDevice));
     CREATE_CHK(c->heads.ensure(sizeof(u32) * kShaQueues));
+    {
+        std::vector<u32> consts(kCrcConstWords);
+        crc32_build_tables(consts.data());
+        CREATE_CHK(c->crc_consts.ensure(consts.size() * 4));
+        CREATE_CHK(hipMemcpy(c->crc_consts.p, consts.data(), consts.size() * 4, hipMemcpyHostToDevice));
+    }
     c->cdc.thresh_m1 = cfg->mask_bits == 0 ? 0xFFFFFFFFu : (u32)((1ull << (32 - cfg->mask_bits)) - 1);
     c->cdc.min_size = cfg->min_size;
     c->cdc.max_size = cfg->max_size;
@@ -528,7 +549,7 @@ void mi_ctx_destroy(mi_ctx* c) {
     for (auto s : c->copy_streams) if (s) (void)hipStreamDestroy(s);
     for (auto e : c->staging_done) if (e) (void)hipEventDestroy(e);
     for (auto e : c->ev) if (e) (void)hipEventDestroy(e);
-    c->gear_table.release(); c->heads.release();
+    c->gear_table.release(); c->heads.release(); c->crc_consts.release();
     c->dd_rep.release(); c->dd_minid.release(); c->dd_slot.release(); c->dd_nuniq.release();
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -674,6 +695,19 @@ static int stage_batch(mi_batch* b) {
     if ((rc = upload(c, b->file_off, off))) return rc;
     if ((rc = upload(c, b->file_size, size))) return rc;
     if ((rc = upload(c, b->slot_base, slot))) return rc;
+    std::vector<u32> tile_file;
+    std::vector<u64> first_tile;
+    if (c->cfg.flags & MI_FLAG_FILE_CRC32) {
+        first_tile.resize(nf);
+        for (u64 f = 0; f < nf; ++f) {
+            first_tile[f] = tile_file.size();
+            const u64 nt = (size[f] + kGearTile - 1) / kGearTile;
+            tile_file.insert(tile_file.end(), nt, (u32)f);
+        }
+        b->n_tiles = tile_file.size();
+        if ((rc = upload(c, b->tile_file, tile_file))) return rc;
+        if ((rc = upload(c, b->first_tile, first_tile))) return rc;
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));    // the vectors above go out of scope
     for (const SynthSpec& sp : b->synth) {
         HIPCHK(c, b->cids.ensure(sp.n * 8 + 16));
@@ -785,7 +819,7 @@ int mi_batch_free(mi_batch* b) {
     if (b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
     for (auto e : b->ev) if (e) (void)hipEventDestroy(e);
     if (b->h_counts) (void)hipHostFree(b->h_counts);
-    DevBuf* bufs[] = {&b->heads_chunks, &b->heads_files, &b->dd_rep, &b->dd_minid, &b->dd_slot,
+    DevBuf* bufs[] = {&b->tile_file, &b->first_tile, &b->tile_raw, &b->crc_d, &b->heads_chunks, &b->heads_files, &b->dd_rep, &b->dd_minid, &b->dd_slot,
                       &b->dd_nuniq, &b->q_off, &b->q_len, &b->q_id,&b->arena, &b->small_list, &b->large_list, &b->file_off, &b->file_size, &b->slot_base, &b->cids,
                       &b->slot_ends, &b->n_chunks_d, &b->first, &b->total_d, &b->scratch,
                       &b->chunk_off, &b->chunk_len, &b->chunk_file, &b->chunk_start, &b->hist,
@@ -793,6 +827,38 @@ int mi_batch_free(mi_batch* b) {
                       &b->file_sha, &b->dup_of};
     for (DevBuf* d : bufs) d->release();
     delete b;
+    return MI_OK;
+}
+
+int mi_context_checksum(mi_batch* b, const void* prefix, uint64_t prefix_len,
+                        const mi_ctx_entry* entries, uint64_t n, uint32_t* crc_out) {
+    if (!b || !crc_out || (n && !entries) || (prefix_len && !prefix)) return MI_ERR_INVALID;
+    mi_ctx* c = b->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!(c->cfg.flags & MI_FLAG_FILE_CRC32))
+        return fail(c, MI_ERR_STATE, "mi_context_checksum needs a ctx created with MI_FLAG_FILE_CRC32");
+    int rc = fetch_results(b);
+    if (rc) return rc;
+    // one running CRC32-IEEE over: prefix, then per walked path its relpath and
+    // (symlink) the link target or (regular file) all file bytes -- the byte stream
+    // checksumPathContents writes (lib/builder/step/add_copy_step.go:194-238).  File bytes
+    // were reduced on the GPU; they are spliced in with crc(A||B) = crc(A)*x^(8|B|) + crc(B).
+    u32 crc = crc32_host_bytes(0, prefix, prefix_len);
+    for (u64 i = 0; i < n; ++i) {
+        const mi_ctx_entry& e = entries[i];
+        if (!e.relpath) return fail(c, MI_ERR_INVALID, "entry %llu has no relpath", (unsigned long long)i);
+        crc = crc32_host_bytes(crc, e.relpath, strlen(e.relpath));
+        if (e.link_target) {
+            crc = crc32_host_bytes(crc, e.link_target, strlen(e.link_target));
+        } else if (e.file_index >= 0) {
+            if ((u64)e.file_index >= b->h_files.size())
+                return fail(c, MI_ERR_INVALID, "entry %llu: file index %lld out of range",
+                            (unsigned long long)i, (long long)e.file_index);
+            const mi_file_result& fr = b->h_files[(size_t)e.file_index];
+            crc = crc32_host_combine(crc, fr.crc32, fr.size);
+        }
+    }
+    *crc_out = crc;
     return MI_OK;
 }
 

@@ -3,6 +3,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 namespace mi {
@@ -77,8 +78,14 @@ void launch_bin_order(const u64* d_off, const u64* d_len, u32 n, const u64* d_n,
                       u32* d_s_id, hipStream_t s);
 void launch_file_items(const u64* d_first, const u32* d_n_chunks, u64 n_files, u64* d_off,
                        u64* d_len, hipStream_t s);
+// crc32.hip: constant block layout (u32 words) + launcher + host helpers for path strings
+constexpr u32 kCrcPow1kOff = 1024, kCrcPowBytesOff = 1024 + 65, kCrcConstWords = 1024 + 65 + 1025;
+void crc32_build_tables(u32* out /* kCrcConstWords */);
 void launch_crc32_files(const u8* d_data, const u64* d_file_off, const u64* d_file_size,
-                        u64 n_files, u32* d_crc, hipStream_t s);
+                        const u32* d_tile_file, const u64* d_first_tile, u64 n_tiles, u64 n_files,
+                        const u32* d_consts, u32* d_tile_raw, u32* d_crc, hipStream_t s);
+u32 crc32_host_bytes(u32 crc, const void* data, size_t len);
+u32 crc32_host_combine(u32 crc1, u32 crc2, u64 len2);
 void launch_dedup_mark(const u8* d_digests, u64 n, const u64* d_n, u32* d_rep, u32* d_minid,
                        u32* d_slot_of, u64 cap_pow2, i64* d_dup_of, u64* d_n_unique,
                        hipStream_t s);

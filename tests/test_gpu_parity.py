@@ -433,3 +433,107 @@ def test_two_batches_in_flight(oracle, eng):
         assert np.array_equal(cb1["sha256"][:len(rc)], rc["sha256"])
     finally:
         a.free(); b.free()
+
+
+def test_file_crc32_matches_zlib(oracle):
+    """MI_FLAG_FILE_CRC32: per-file CRC32-IEEE from the GPU (lane runs + GF(2) folding) against
+    zlib, which is the same polynomial as Go's hash/crc32 IEEE the reference uses
+    (lib/builder/step/add_copy_step.go:104)."""
+    import zlib
+    import makisu_amd
+    sizes = [0, 1, 3, 4, 5, 127, 128, 129, 1023, 1024, 1025, 4096, 65535, 65536, 65537,
+             3 * 65536, 3 * 65536 + 1000, 1 << 20, 5 * (1 << 20) + 3]
+    blobs = [oracle.synth_fill(SEED, 300 + i, 0, n).tobytes() for i, n in enumerate(sizes)]
+    blobs += [bytes(70000), b"\xff" * 1500, b"123456789"]
+    with makisu_amd.Engine(flags=makisu_amd.FLAG_FILE_CRC32) as e, e.batch() as b:
+        for blob in blobs:
+            b.add_bytes(blob)
+        b.run()
+        rows = b.files().copy()
+    for blob, row in zip(blobs, rows):
+        assert int(row["crc32"]) == zlib.crc32(blob), len(blob)
+    assert int(rows["crc32"][-1]) == 0xCBF43926            # the classic CRC-32 check value
+
+
+def _walk_order(entries):
+    """filepath.Walk order over a set of relative paths: lexical per directory, a directory
+    before its children (Go path/filepath: Walk sorts names in each directory)."""
+    tree = {}
+    for e in entries:
+        node = tree
+        parts = e["path"].split("/")
+        for d in parts[:-1]:
+            node = node.setdefault(d, {})
+        node[parts[-1]] = e
+    out = []
+
+    def rec(node, prefix):
+        for name in sorted(node):
+            v = node[name]
+            rel = prefix + name
+            if isinstance(v, dict) and "path" not in v:
+                out.append({"path": rel, "dir": True})
+                rec(v, rel + "/")
+            else:
+                out.append(v)
+    rec(tree, "")
+    return out
+
+
+def test_context_checksum_c1_build_context():
+    """The reference's COPY/ADD cache ID over testdata/build-context (BASELINE.json configs[0]):
+    one running CRC32 over seed+directive+args, then per walked path relpath + bytes / link
+    target (add_copy_step.go:102-238).  Expected value: zlib over the same byte stream, built
+    independently here; the engine must give the same unpadded-hex cacheID."""
+    import base64
+    import json
+    import os
+    import zlib
+    import makisu_amd
+    ctx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "build_context_c1.json")))["entries"]
+    # the fixture tree has no symlinks; add two so that branch (:221-227) is exercised too
+    ctx = ctx + [{"path": "simple/zz-link", "symlink": "Dockerfile"}, {"path": "a-link", "symlink": "/etc/hosts"}]
+    walk = _walk_order(ctx)
+    prefix = b"deadbeef" + b"COPY" + b". /app/"
+    running = zlib.crc32(prefix)
+    entries, blobs = [], []
+    for e in walk:
+        running = zlib.crc32(e["path"].encode(), running)
+        if e.get("dir"):
+            entries.append((e["path"], None, -1))
+        elif "symlink" in e:
+            running = zlib.crc32(e["symlink"].encode(), running)
+            entries.append((e["path"], e["symlink"], -1))
+        else:
+            data = base64.b64decode(e["b64"])
+            running = zlib.crc32(data, running)
+            entries.append((e["path"], None, len(blobs)))
+            blobs.append(data)
+    assert len(blobs) >= 20 and any(x[1] for x in entries) and any(x[2] == -1 and not x[1] for x in entries)
+    with makisu_amd.Engine(flags=makisu_amd.FLAG_FILE_CRC32) as eng, eng.batch() as b:
+        for blob in blobs:
+            b.add_bytes(blob)
+        b.run()
+        assert b.context_checksum(prefix, entries) == "%x" % running
+        # cache-ID relations the reference's own test asserts (copy_step_test.go:51-169):
+        # same inputs -> same ID, different args -> different ID
+        assert b.context_checksum(prefix, entries) == b.context_checksum(prefix, entries)
+        assert b.context_checksum(b"deadbeefCOPY. /other/", entries) != "%x" % running
+    # changing one byte of one file changes the ID
+    blobs2 = list(blobs)
+    blobs2[3] = blobs2[3][:-1] + bytes([blobs2[3][-1] ^ 1]) if blobs2[3] else b"x"
+    with makisu_amd.Engine(flags=makisu_amd.FLAG_FILE_CRC32) as eng, eng.batch() as b:
+        for blob in blobs2:
+            b.add_bytes(blob)
+        b.run()
+        assert b.context_checksum(prefix, entries) != "%x" % running
+
+
+def test_context_checksum_needs_the_flag(eng):
+    import makisu_amd
+    with eng.batch() as b:
+        b.add_bytes(b"abc")
+        b.run()
+        with pytest.raises(makisu_amd.MiError) as ei:
+            b.context_checksum(b"", [("a", None, 0)])
+        assert ei.value.code == -6
