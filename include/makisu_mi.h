@@ -200,6 +200,37 @@ typedef struct {
 int mi_context_checksum(mi_batch* b, const void* prefix, uint64_t prefix_len,
                         const mi_ctx_entry* entries, uint64_t n, uint32_t* crc_out);
 
+/* ---- host-side walks: which files reach the batch, in what order -------------------- *
+ * C++ restatement of the two walks that feed the hot path (filepath.Walk order: lexical
+ * per directory, a directory before its children, symlinks never followed):
+ *   MI_TREE_CONTEXT  checksumPathContents' walk (lib/builder/step/add_copy_step.go:
+ *                    153-169,194-238): only special files are skipped;
+ *   MI_TREE_SCAN     the snapshot walk (lib/snapshot/utils.go:37-75): also skips
+ *                    ".wh..wh."-prefixed names, blacklist descendants
+ *                    (lib/pathutils/path.go:24-35) and mountpoints
+ *                    (lib/mountutils/mountutils.go:54-93); skipped directories are pruned.
+ * Every regular file is added to the batch (stat-time size, user_tag = entry index);
+ * relpath = filepath.Rel(rel_base, path) (rel_base NULL = root).  May be called several
+ * times (one per COPY source, add_copy_step.go:158-167); entries accumulate.          */
+#define MI_TREE_CONTEXT 0u
+#define MI_TREE_SCAN    1u
+typedef struct {
+    const char* relpath;       /* valid until mi_batch_free                              */
+    const char* link_target;   /* symlinks only                                          */
+    int64_t     file_index;    /* regular files: index in the batch, else -1             */
+    uint64_t    size;
+    int64_t     mtime_sec;     /* truncated to seconds like tario.WriteHeader (write.go:62) */
+    uint32_t    mode;          /* st_mode                                                */
+    uint8_t     kind;          /* 0 directory, 1 regular file, 2 symlink                 */
+} mi_tree_entry;
+int mi_batch_add_tree(mi_batch* b, const char* root, const char* rel_base,
+                      const char* const* blacklist, uint64_t n_blacklist, uint32_t mode,
+                      uint64_t* n_entries);
+int mi_batch_tree_entries(mi_batch* b, mi_tree_entry* out, uint64_t cap);
+/* mi_context_checksum over the recorded walk (the batch must have run).                */
+int mi_context_checksum_tree(mi_batch* b, const void* prefix, uint64_t prefix_len,
+                             uint32_t* crc_out);
+
 /* ---- standalone digests (image.Digester seam) ---------------------------------- *
  * n independent byte strings -> n SHA-256 digests on the GPU, one lane per string:
  * the batched form of image.NewDigester().FromBytes / FromReader

@@ -54,6 +54,16 @@ class CtxEntry(C.Structure):
     _fields_ = [("relpath", C.c_char_p), ("link_target", C.c_char_p), ("file_index", C.c_int64)]
 
 
+class TreeEntry(C.Structure):
+    """mi_tree_entry: one path recorded by mi_batch_add_tree."""
+    _fields_ = [("relpath", C.c_char_p), ("link_target", C.c_char_p), ("file_index", C.c_int64),
+                ("size", C.c_uint64), ("mtime_sec", C.c_int64), ("mode", C.c_uint32),
+                ("kind", C.c_uint8)]
+
+
+TREE_CONTEXT, TREE_SCAN = 0, 1
+
+
 class Stats(C.Structure):
     _fields_ = [("bytes_in", C.c_uint64), ("n_files", C.c_uint64), ("n_chunks", C.c_uint64),
                 ("n_unique", C.c_uint64), ("ms_h2d", C.c_double), ("ms_cdc", C.c_double),
@@ -124,6 +134,10 @@ def load_library(rebuild=False):
         "mi_sha256_many": ([vp, vp, u64p, u64p, u64, vp], C.c_int),
         "mi_context_checksum": ([vp, vp, u64, C.POINTER(CtxEntry), u64, C.POINTER(C.c_uint32)],
                                 C.c_int),
+        "mi_batch_add_tree": ([vp, C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), u64, C.c_uint32,
+                               u64p], C.c_int),
+        "mi_batch_tree_entries": ([vp, C.POINTER(TreeEntry), u64], C.c_int),
+        "mi_context_checksum_tree": ([vp, vp, u64, C.POINTER(C.c_uint32)], C.c_int),
     }
     for name, (args, res) in sigs.items():
         fn = getattr(L, name)          # AttributeError here = header/library drift
@@ -298,6 +312,28 @@ class Batch:
         p, n = C.c_void_p(), C.c_uint64()
         self._check(self._lib.mi_batch_device_digests(self._h, C.byref(p), C.byref(n)))
         return p.value, n.value
+
+    def add_tree(self, root, rel_base=None, blacklist=(), mode=TREE_CONTEXT):
+        """Walk `root` the way the reference does (filepath.Walk order) and add its regular
+        files; returns the number of recorded entries so far."""
+        bl = (C.c_char_p * max(len(blacklist), 1))(*[os.fsencode(x) for x in blacklist])
+        n = C.c_uint64()
+        self._check(self._lib.mi_batch_add_tree(self._h, os.fsencode(root),
+                                                os.fsencode(rel_base) if rel_base else None,
+                                                bl, len(blacklist), mode, C.byref(n)))
+        return n.value
+
+    def tree_entries(self, n):
+        arr = (TreeEntry * max(n, 1))()
+        self._check(self._lib.mi_batch_tree_entries(self._h, arr, n))
+        return [(os.fsdecode(e.relpath), os.fsdecode(e.link_target) if e.link_target else None,
+                 e.file_index, e.size, e.kind, e.mode) for e in arr[:n]]
+
+    def context_checksum_tree(self, prefix):
+        pre = bytes(prefix)
+        out = C.c_uint32()
+        self._check(self._lib.mi_context_checksum_tree(self._h, pre, len(pre), C.byref(out)))
+        return "%x" % out.value
 
     def context_checksum(self, prefix, entries):
         """The reference's COPY/ADD running CRC32 (add_copy_step.go:102-238).

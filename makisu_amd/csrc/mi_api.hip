@@ -99,6 +99,7 @@ struct mi_batch {
     DevBuf heads_chunks, heads_files;    // SHA queue heads (one set per concurrent launch)
     DevBuf tile_file, first_tile, tile_raw, crc_d;   // MI_FLAG_FILE_CRC32
     u64 n_tiles = 0;
+    void* tree = nullptr;                // host-side walk record (mi_tree.hip)
     DevBuf dd_rep, dd_minid, dd_slot, dd_nuniq;
     std::vector<mi_file_result> h_files;
     std::vector<mi_chunk_result> h_chunks;
@@ -810,8 +811,13 @@ int mi_batch_read_back(mi_batch* b, void* out, uint64_t cap) {
     return MI_OK;
 }
 
+void mi_batch_tree_free(void* tree);
+void** mi_batch_tree_slot(mi_batch* b) { return &b->tree; }
+void mi_set_error(mi_batch* b, const char* msg) { b->ctx->err = msg; }
+
 int mi_batch_free(mi_batch* b) {
     if (!b) return MI_ERR_INVALID;
+    if (b->tree) { mi_batch_tree_free(b->tree); b->tree = nullptr; }
     mi_ctx* c = b->ctx;
     (void)hipSetDevice(c->device);
     for (auto s : c->copy_streams) (void)hipStreamSynchronize(s);

@@ -1,0 +1,246 @@
+// mi_tree.hip -- host side of the two callers of the hot path (no device code here):
+// the directory walks that decide WHICH files reach the GPU batch and in what order.
+//
+// Restates, for a C++ host (the reference is Go; `go` is absent in this environment):
+//   * filepath.Walk order as Go's path/filepath defines it: lstat the root, call the
+//     visitor, and for a directory visit its names in sort.Strings (bytewise) order,
+//     never following symlinks;
+//   * MI_TREE_CONTEXT -- checksumPathContents (lib/builder/step/add_copy_step.go:194-238):
+//     special files are skipped (a special directory would SkipDir), every other path
+//     contributes filepath.Rel(contextDir, path), symlinks their target, files their bytes;
+//   * MI_TREE_SCAN -- the snapshot walk (lib/snapshot/utils.go:37-75 walk/shouldSkip):
+//     skip names starting with the AUFS whiteout-meta prefix ".wh..wh."
+//     (lib/snapshot/const.go:17-22), descendants of the blacklist
+//     (pathutils.IsDescendantOfAny, lib/pathutils/path.go:24-35), special files
+//     (utils.IsSpecialFile, lib/utils/utils.go:161-163) and mountpoints
+//     (mountutils.IsMountpoint, lib/mountutils/mountutils.go:54-93: targets of /proc/mounts
+//     except "/"); a skipped directory is not descended into.
+// Regular files are registered with the batch (mi_batch_add_path, stat-time size as in
+// tario.WriteEntry's io.CopyN, lib/tario/write.go:43-45) in visit order; results come back
+// in the same order.
+#include "../../include/makisu_mi.h"
+
+#include <dirent.h>
+#include <errno.h>
+#include <stdio.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <set>
+#include <string>
+#include <vector>
+
+namespace mi_tree {
+
+struct Entry {
+    std::string relpath, link;
+    bool has_link = false;
+    int64_t file_index = -1;
+    uint32_t mode = 0;
+    uint64_t size = 0;
+    int64_t mtime = 0;
+    uint8_t kind = 0;      // 0 dir, 1 regular, 2 symlink
+};
+
+struct Tree {
+    std::vector<Entry> entries;
+};
+
+// path/filepath.Clean-free helpers: inputs here never contain "." / ".." components
+static std::string abs_path(const std::string& p) {          // pathutils.AbsPath
+    std::string t = p;
+    while (t.size() > 1 && t.back() == '/') t.pop_back();
+    if (t.empty() || t[0] != '/') t = "/" + t;
+    while (t.size() > 1 && t.back() == '/') t.pop_back();
+    return t;
+}
+static std::string dir_of(const std::string& p) {            // path.Dir for clean absolute paths
+    size_t i = p.find_last_of('/');
+    if (i == std::string::npos) return ".";
+    if (i == 0) return "/";
+    return p.substr(0, i);
+}
+static std::string base_of(const std::string& p) {
+    size_t i = p.find_last_of('/');
+    return i == std::string::npos ? p : p.substr(i + 1);
+}
+static bool has_prefix(const std::string& s, const std::string& pre) {
+    return s.size() >= pre.size() && memcmp(s.data(), pre.data(), pre.size()) == 0;
+}
+static bool is_descendant_of_any(const std::string& path, const std::vector<std::string>& anc) {
+    const std::string p = abs_path(path);
+    for (const std::string& a0 : anc) {
+        const std::string a = abs_path(a0);
+        std::string d = dir_of(p);
+        if (d.back() != '/') d += "/";
+        if (p == a || a == "/" || has_prefix(d, a + "/")) return true;
+    }
+    return false;
+}
+static std::string rel_to(const std::string& base, const std::string& path) {   // filepath.Rel, descendants only
+    const std::string b = abs_path(base), p = abs_path(path);
+    if (p == b) return ".";
+    if (b == "/") return p.substr(1);
+    if (has_prefix(p, b + "/")) return p.substr(b.size() + 1);
+    return std::string();                                                        // outside: caller errors
+}
+
+static const std::set<std::string>& mountpoints() {
+    static std::set<std::string> mp;
+    static bool init = false;
+    if (!init) {
+        init = true;
+        if (FILE* f = fopen("/proc/mounts", "r")) {
+            char line[8192];
+            while (fgets(line, sizeof line, f)) {
+                char* sp1 = strchr(line, ' ');
+                if (!sp1) continue;
+                char* sp2 = strchr(sp1 + 1, ' ');
+                if (!sp2) continue;
+                std::string target(sp1 + 1, sp2);
+                if (target != "/") mp.insert(target);     // "/" skipped as the reference does
+            }
+            fclose(f);
+        }
+    }
+    return mp;
+}
+
+struct Walker {
+    mi_batch* batch;
+    std::string rel_base;
+    std::vector<std::string> blacklist;
+    uint32_t mode;
+    Tree* tree;
+    std::string err;
+    int rc = MI_OK;
+
+    bool should_skip(const std::string& path, const struct stat& st) {
+        const bool special = S_ISCHR(st.st_mode) || S_ISBLK(st.st_mode) || S_ISFIFO(st.st_mode) || S_ISSOCK(st.st_mode);
+        if (mode == MI_TREE_CONTEXT) return special;
+        if (has_prefix(base_of(path), ".wh..wh.")) return true;
+        if (is_descendant_of_any(path, blacklist) || special) return true;
+        return mountpoints().count(path) != 0;
+    }
+
+    void visit(const std::string& path) {
+        if (rc) return;
+        struct stat st;
+        if (lstat(path.c_str(), &st) != 0) {
+            err = "lstat " + path + ": " + strerror(errno);
+            rc = MI_ERR_IO;
+            return;
+        }
+        if (should_skip(path, st)) return;                  // a skipped directory is not entered
+        Entry e;
+        e.relpath = rel_to(rel_base, path);
+        if (e.relpath.empty()) {
+            err = "path is outside of the base dir (" + rel_base + "," + path + ")";
+            rc = MI_ERR_INVALID;
+            return;
+        }
+        e.mode = (uint32_t)st.st_mode;
+        e.mtime = (int64_t)st.st_mtime;
+        if (S_ISDIR(st.st_mode)) {
+            e.kind = 0;
+            tree->entries.push_back(e);
+            std::vector<std::string> names;
+            DIR* d = opendir(path.c_str());
+            if (!d) { err = "open " + path + ": " + strerror(errno); rc = MI_ERR_IO; return; }
+            while (struct dirent* de = readdir(d)) {
+                if (!strcmp(de->d_name, ".") || !strcmp(de->d_name, "..")) continue;
+                names.push_back(de->d_name);
+            }
+            closedir(d);
+            std::sort(names.begin(), names.end());          // sort.Strings: bytewise
+            for (const std::string& n : names) visit(path == "/" ? "/" + n : path + "/" + n);
+        } else if (S_ISLNK(st.st_mode)) {
+            e.kind = 2;
+            std::vector<char> buf(4096);
+            ssize_t n = readlink(path.c_str(), buf.data(), buf.size() - 1);
+            if (n < 0) { err = "read link " + path + ": " + strerror(errno); rc = MI_ERR_IO; return; }
+            e.link.assign(buf.data(), (size_t)n);
+            e.has_link = true;
+            tree->entries.push_back(e);
+        } else {
+            e.kind = 1;
+            e.size = (uint64_t)st.st_size;
+            uint64_t nf = 0;
+            mi_batch_counts(batch, &nf, nullptr, nullptr);
+            e.file_index = (int64_t)nf;
+            int r = mi_batch_add_path(batch, path.c_str(), e.size, tree->entries.size());
+            if (r) { rc = r; return; }                      // message already on the ctx
+            tree->entries.push_back(e);
+        }
+    }
+};
+
+}  // namespace mi_tree
+
+using mi_tree::Tree;
+
+// the batch keeps its tree behind an opaque pointer (mi_api.hip owns the slot)
+extern "C" void** mi_batch_tree_slot(mi_batch* b);
+extern "C" void mi_set_error(mi_batch* b, const char* msg);
+
+extern "C" {
+
+int mi_batch_add_tree(mi_batch* b, const char* root, const char* rel_base, const char* const* blacklist,
+                      uint64_t n_blacklist, uint32_t mode, uint64_t* n_entries) {
+    if (!b || !root || (n_blacklist && !blacklist) || mode > MI_TREE_SCAN) return MI_ERR_INVALID;
+    void** slot = mi_batch_tree_slot(b);
+    if (!*slot) *slot = new Tree();
+    Tree* t = (Tree*)*slot;
+    mi_tree::Walker w;
+    w.batch = b;
+    w.rel_base = rel_base ? rel_base : root;
+    w.mode = mode;
+    w.tree = t;
+    for (uint64_t i = 0; i < n_blacklist; ++i) w.blacklist.push_back(blacklist[i]);
+    std::string r = root;
+    while (r.size() > 1 && r.back() == '/') r.pop_back();
+    w.visit(r);
+    if (w.rc) {
+        if (!w.err.empty()) mi_set_error(b, w.err.c_str());
+        return w.rc;
+    }
+    if (n_entries) *n_entries = t->entries.size();
+    return MI_OK;
+}
+
+int mi_batch_tree_entries(mi_batch* b, mi_tree_entry* out, uint64_t cap) {
+    if (!b || (!out && cap)) return MI_ERR_INVALID;
+    Tree* t = (Tree*)*mi_batch_tree_slot(b);
+    const uint64_t n = t ? t->entries.size() : 0;
+    if (cap < n) { mi_set_error(b, "tree entry buffer too small"); return MI_ERR_CAPACITY; }
+    for (uint64_t i = 0; i < n; ++i) {
+        const mi_tree::Entry& e = t->entries[i];
+        out[i].relpath = e.relpath.c_str();
+        out[i].link_target = e.has_link ? e.link.c_str() : nullptr;
+        out[i].file_index = e.file_index;
+        out[i].size = e.size;
+        out[i].mtime_sec = e.mtime;
+        out[i].mode = e.mode;
+        out[i].kind = e.kind;
+    }
+    return MI_OK;
+}
+
+int mi_context_checksum_tree(mi_batch* b, const void* prefix, uint64_t prefix_len, uint32_t* crc_out) {
+    if (!b || !crc_out) return MI_ERR_INVALID;
+    Tree* t = (Tree*)*mi_batch_tree_slot(b);
+    std::vector<mi_ctx_entry> es(t ? t->entries.size() : 0);
+    for (size_t i = 0; i < es.size(); ++i) {
+        const mi_tree::Entry& e = t->entries[i];
+        es[i].relpath = e.relpath.c_str();
+        es[i].link_target = e.has_link ? e.link.c_str() : nullptr;
+        es[i].file_index = e.file_index;
+    }
+    return mi_context_checksum(b, prefix, prefix_len, es.data(), es.size(), crc_out);
+}
+
+void mi_batch_tree_free(void* tree) { delete (Tree*)tree; }
+
+}  // extern "C"

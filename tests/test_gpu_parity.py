@@ -537,3 +537,89 @@ def test_context_checksum_needs_the_flag(eng):
         with pytest.raises(makisu_amd.MiError) as ei:
             b.context_checksum(b"", [("a", None, 0)])
         assert ei.value.code == -6
+
+
+def _go_walk(root):
+    """path/filepath.Walk: lstat, visit, then children in bytewise name order; no symlink following."""
+    import os
+    import stat
+    st = os.lstat(root)
+    yield root, st
+    if stat.S_ISDIR(st.st_mode):
+        for name in sorted(os.listdir(root), key=os.fsencode):
+            yield from _go_walk(os.path.join(root, name))
+
+
+def _make_tree(base):
+    import os
+    os.makedirs(base / "a" / "deep" / "er")
+    os.makedirs(base / "a-b")
+    os.makedirs(base / "empty-dir")
+    os.makedirs(base / "z" / ".wh..wh.plnk")
+    (base / "a" / "x.txt").write_bytes(b"hello world\n" * 1000)
+    (base / "a" / "deep" / "er" / "big.bin").write_bytes(bytes(range(256)) * 1500)      # 384000 B, multi tile
+    (base / "a-b" / "y").write_bytes(b"")
+    (base / "a.txt").write_bytes(b"sorted between a/ and a-b? Walk order decides\n")
+    (base / "z" / "last").write_bytes(b"\x00" * 70000)
+    (base / "z" / ".wh..wh.plnk" / "hidden").write_bytes(b"aufs metadata")
+    (base / "z" / ".wh.deleted").write_bytes(b"")                                       # a plain whiteout marker
+    os.symlink("x.txt", base / "a" / "link-to-x")
+    os.symlink("/nonexistent/target", base / "dangling")
+    os.mkfifo(base / "a" / "fifo")
+    return base
+
+
+def test_tree_walk_context_checksum(tmp_path):
+    """mi_batch_add_tree(MI_TREE_CONTEXT) + mi_context_checksum_tree against an independent
+    emulation of filepath.Walk + checksumPathContents (add_copy_step.go:153-238) with zlib."""
+    import os
+    import stat
+    import zlib
+    import makisu_amd
+    root = str(_make_tree(tmp_path / "ctx"))
+    prefix = b"seedADD. /dst/"
+    running = zlib.crc32(prefix)
+    want_rel = []
+    for path, st in _go_walk(root):
+        if stat.S_ISFIFO(st.st_mode) or stat.S_ISSOCK(st.st_mode) or stat.S_ISCHR(st.st_mode) or stat.S_ISBLK(st.st_mode):
+            continue                                             # utils.IsSpecialFile -> skipped
+        rel = os.path.relpath(path, root)
+        want_rel.append(rel)
+        running = zlib.crc32(rel.encode(), running)
+        if stat.S_ISLNK(st.st_mode):
+            running = zlib.crc32(os.readlink(path).encode(), running)
+        elif stat.S_ISREG(st.st_mode):
+            running = zlib.crc32(open(path, "rb").read(), running)
+    with makisu_amd.Engine(flags=makisu_amd.FLAG_FILE_CRC32) as eng, eng.batch() as b:
+        n = b.add_tree(root)
+        ents = b.tree_entries(n)
+        assert [e[0] for e in ents] == want_rel                 # Walk order, "." first, fifo skipped
+        assert want_rel[0] == "." and "a/fifo" not in want_rel
+        assert want_rel.index("a-b") > want_rel.index("a/x.txt")          # Walk order != sorted full paths
+        assert dict((e[0], e[1]) for e in ents)["dangling"] == "/nonexistent/target"
+        b.run()
+        assert b.context_checksum_tree(prefix) == "%x" % running
+        files = b.files()
+        regular = [e for e in ents if e[4] == 1]
+        assert [int(t) for t in files["user_tag"]] == [ents.index(e) for e in regular]
+        assert [int(s) for s in files["size"]] == [e[3] for e in regular]
+
+
+def test_tree_walk_scan_mode_skips(tmp_path):
+    """MI_TREE_SCAN follows shouldSkip (lib/snapshot/utils.go:37-52): whiteout-META names and
+    blacklisted subtrees are pruned, plain ".wh." whiteout markers are kept, special files skipped;
+    relpaths are relative to rel_base."""
+    import makisu_amd
+    base = _make_tree(tmp_path / "root")
+    with makisu_amd.Engine() as eng, eng.batch() as b:
+        n = b.add_tree(str(base), rel_base=str(tmp_path), blacklist=[str(base / "a" / "deep")],
+                       mode=makisu_amd.TREE_SCAN)
+        rels = [e[0] for e in b.tree_entries(n)]
+        b.run()
+        assert b.counts()[0] == sum(1 for e in b.tree_entries(n) if e[4] == 1)
+    assert rels[0] == "root"
+    assert "root/z/.wh.deleted" in rels and "root/z/last" in rels
+    assert not any(".wh..wh." in r for r in rels)
+    assert not any(r.startswith("root/a/deep") for r in rels)      # blacklist prunes the subtree
+    assert "root/a/fifo" not in rels and "root/a/link-to-x" in rels
+    assert rels == sorted(rels, key=lambda r: [p.encode() for p in r.split("/")])   # lexical per level
