@@ -82,6 +82,9 @@ def main():
     ap.add_argument("--files", type=int, default=N_FILES, help="files per GPU (default = C2)")
     ap.add_argument("--inflight", type=int, default=2, help="batches in flight (1 = serial steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl",
+                    help="torch.distributed backend for the digest exchange (nccl = RCCL; gloo only "
+                         "for the single-GPU self-test of the N>1 logic)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the RCCL digest exchange + global marking even with one rank (self-test)")
     args = ap.parse_args()
@@ -98,16 +101,20 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the hot path)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = int(os.environ.get("MI_BENCH_FORCE_DEVICE", local_rank))   # self-test: all ranks on one GPU
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     exchange = world > 1 or args.force_exchange
     if exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     # with more than one rank the global marking after the all-gather supersedes the in-batch one
-    eng = makisu_amd.Engine(device=local_rank,
+    eng = makisu_amd.Engine(device=dev_index,
                             flags=makisu_amd.FLAG_NO_DEDUP if exchange else 0)
     info = eng.device_info()
     # INFLIGHT batches alternate: step k runs on batch k % INFLIGHT.  Every step is a complete

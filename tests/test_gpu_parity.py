@@ -623,3 +623,63 @@ def test_tree_walk_scan_mode_skips(tmp_path):
     assert not any(r.startswith("root/a/deep") for r in rels)      # blacklist prunes the subtree
     assert "root/a/fifo" not in rels and "root/a/link-to-x" in rels
     assert rels == sorted(rels, key=lambda r: [p.encode() for p in r.split("/")])   # lexical per level
+
+
+def _two_rank_worker(rank, world, port, q):
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    import makisu_amd
+    from makisu_amd import distributed as mdist
+    torch.cuda.set_device(0)                       # the test box has one GPU: both ranks share it
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    n_files = 600
+    mine = mdist.shard_round_robin(n_files, rank, world)            # C4: file_index mod world
+    cids = [int(i) % 251 for i in mine]                             # content repeats across ranks
+    sizes = [30000 + 7000 * (c % 9) for c in cids]
+    with makisu_amd.Engine(device=0, flags=makisu_amd.FLAG_NO_DEDUP) as eng, eng.batch() as b:
+        b.add_synthetic(sizes, cids, seed=SEED)
+        b.run()
+        n_total, n_unique, first, dup = mdist.global_dedup(eng, b, dev)
+        chunks = b.chunks().copy()
+    q.put((rank, int(n_total), int(n_unique), int(first), chunks["sha256"].tobytes(),
+           chunks["dup_of"].tolist(), [int(c) for c in cids], sizes))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_global_dedup_on_gpu(oracle):
+    """N=2 through the real engine: two processes (sharing the one GPU of the test box, gloo as
+    the transport) scan their round-robin shards, all-gather the digest sets, mark duplicates
+    globally with the HIP kernel and rewrite dup_of with global rank-major indices; the result
+    must equal the oracle's marking of the concatenated digest set."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=500) for _ in range(2))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    (r0, nt0, nu0, f0, d0, dup0, cids0, sz0), (r1, nt1, nu1, f1, d1, dup1, cids1, sz1) = res
+    assert nt0 == nt1 == len(dup0) + len(dup1) and nu0 == nu1
+    assert f0 == 0 and f1 == len(dup0)
+    all_digests = np.frombuffer(d0 + d1, dtype=np.uint8).reshape(-1, 32)
+    want, uniq = oracle.dedup(all_digests)
+    assert np.array_equal(np.array(dup0 + dup1), want) and uniq == nu0
+    assert (np.array(dup1) >= 0).sum() > 0 and (np.array(dup1)[np.array(dup1) >= 0] < f1).any()  # cross-rank hits
+    # and the digests themselves are what the oracle computes for rank 1's shard
+    data = np.concatenate([oracle.synth_fill(SEED, c, 0, n) for c, n in zip(cids1, sz1)])
+    offs = np.concatenate([[0], np.cumsum(sz1)[:-1]])
+    rf, rc = oracle.scan_batch(data, offs, sz1, oracle.CdcParams(SEED, 13, 2048, 65536), True, 4, 4)
+    assert rc["sha256"].tobytes() == d1
