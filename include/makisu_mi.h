@@ -182,6 +182,24 @@ int mi_dedup_mark(mi_ctx* ctx, const void* d_digests, uint64_t n, void* d_dup_of
  * global row first_global + i of d_dup_of_global (device, int64).                  */
 int mi_batch_set_global_dedup(mi_batch* b, const void* d_dup_of_global, uint64_t first_global);
 
+/* ---- the digest exchange inside the library: RCCL all-gather over xGMI ---------------- *
+ * For hosts without torch (the Go shim).  RCCL is loaded at run time (dlopen), so these
+ * fail with MI_ERR_NO_DEVICE where no librccl exists.  Multi-process: rank 0 obtains the
+ * id, ships it to the peers, every rank calls mi_comm_init_rank.  Single process driving n
+ * devices (one ctx each): mi_comm_init_all + mi_dedup_allgather_all.
+ * mi_dedup_allgather: all-gathers the batches' digest arrays (counts first, then slabs
+ * padded to the largest count), marks duplicates over the gathered set and rewrites the
+ * batch's dup_of with GLOBAL row indices (rank-major); collective: every rank must call
+ * it.  Outputs are optional.                                                            */
+#define MI_COMM_ID_BYTES 128
+int mi_comm_unique_id(void* id_out /* MI_COMM_ID_BYTES */);
+int mi_comm_init_rank(mi_ctx* ctx, int nranks, int rank, const void* id);
+int mi_comm_init_all(mi_ctx** ctxs, int n);
+int mi_comm_destroy(mi_ctx* ctx);
+int mi_dedup_allgather(mi_batch* b, uint64_t* n_total, uint64_t* n_unique,
+                       uint64_t* first_global);
+int mi_dedup_allgather_all(mi_batch** batches, int n, uint64_t* n_total, uint64_t* n_unique);
+
 /* ---- COPY/ADD context checksum (addCopyStep.SetCacheID seam) ------------------------ *
  * Reproduces the ONE running CRC32-IEEE the reference feeds at plan time
  * (lib/builder/step/add_copy_step.go:102-122,153-238): `prefix` = seed + directive +

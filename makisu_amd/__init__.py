@@ -138,6 +138,12 @@ def load_library(rebuild=False):
                                u64p], C.c_int),
         "mi_batch_tree_entries": ([vp, C.POINTER(TreeEntry), u64], C.c_int),
         "mi_context_checksum_tree": ([vp, vp, u64, C.POINTER(C.c_uint32)], C.c_int),
+        "mi_comm_unique_id": ([vp], C.c_int),
+        "mi_comm_init_rank": ([vp, C.c_int, C.c_int, vp], C.c_int),
+        "mi_comm_init_all": ([C.POINTER(vp), C.c_int], C.c_int),
+        "mi_comm_destroy": ([vp], C.c_int),
+        "mi_dedup_allgather": ([vp, u64p, u64p, u64p], C.c_int),
+        "mi_dedup_allgather_all": ([C.POINTER(vp), C.c_int, u64p, u64p], C.c_int),
     }
     for name, (args, res) in sigs.items():
         fn = getattr(L, name)          # AttributeError here = header/library drift
@@ -233,6 +239,21 @@ class Engine:
                                              offs.ctypes.data_as(u64p), lens.ctypes.data_as(u64p),
                                              len(blobs), out.ctypes.data))
         return [out[i].tobytes() for i in range(len(blobs))]
+
+    # ---- native RCCL exchange (what a Go host would use; bench.py drives torch instead) ----
+    @staticmethod
+    def comm_unique_id():
+        buf = C.create_string_buffer(128)
+        rc = load_library().mi_comm_unique_id(buf)
+        if rc:
+            raise MiError(rc, load_library().mi_last_error(None).decode())
+        return buf.raw
+
+    def comm_init_rank(self, nranks, rank, uid):
+        self._check(self._lib.mi_comm_init_rank(self._h, nranks, rank, uid))
+
+    def comm_destroy(self):
+        self._check(self._lib.mi_comm_destroy(self._h))
 
     def dedup_mark(self, d_digests_ptr, n, d_dup_of_ptr):
         """dup_of over a device-resident digest set (e.g. the all-gathered one)."""
@@ -350,6 +371,13 @@ class Batch:
         self._check(self._lib.mi_context_checksum(self._h, pre, len(pre), arr, len(entries),
                                                   C.byref(out)))
         return "%x" % out.value
+
+    def dedup_allgather(self):
+        """Collective: RCCL all-gather of the digest sets + global marking inside the library.
+        Returns (n_total, n_unique, first_global)."""
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._check(self._lib.mi_dedup_allgather(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     def set_global_dedup(self, d_dup_of_global_ptr, first_global):
         self._check(self._lib.mi_batch_set_global_dedup(self._h, d_dup_of_global_ptr, first_global))

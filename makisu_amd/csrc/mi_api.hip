@@ -9,8 +9,7 @@
 //   file out   : roots[] (32 B), file_sha[] (32 B, optional)
 // One HIP stream per ctx for kernels, n_streams copy streams for staging.
 // There is no CPU fallback anywhere in this file.
-#include "../../include/makisu_mi.h"
-#include "mi_common.h"
+#include "mi_internal.h"
 
 #include <errno.h>
 #include <fcntl.h>
@@ -31,81 +30,9 @@ namespace {
 std::mutex g_err_mu;
 std::string g_create_err;
 
-struct DevBuf {
-    void* p = nullptr;
-    size_t bytes = 0;
-    hipError_t ensure(size_t want) {
-        if (want <= bytes) return hipSuccess;
-        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
-        size_t alloc = want + want / 8 + 256;
-        hipError_t e = hipMalloc(&p, alloc);
-        if (e == hipSuccess) bytes = alloc;
-        return e;
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
-    template <typename T> T* as() const { return (T*)p; }
-};
-
-struct SynthSpec { u64 f0, n, seed; std::vector<u64> cids; };
-
 }  // namespace
 
-struct mi_ctx {
-    mi_config cfg;
-    int device = 0;
-    hipDeviceProp_t prop;
-    hipStream_t stream = nullptr;        // ctx-level work (mi_dedup_mark, mi_sha256_many, uploads)
-    std::vector<hipStream_t> copy_streams;
-    std::vector<void*> staging;          // pinned, staging_bytes each
-    std::vector<hipEvent_t> staging_done;
-    size_t staging_bytes = 0;
-    DevBuf gear_table, heads, crc_consts;
-    DevBuf dd_rep, dd_minid, dd_slot, dd_nuniq;     // dedup scratch of mi_dedup_mark
-    hipEvent_t ev[2];
-    int sha_blocks_per_cu = 2;
-    CdcParams cdc;
-    std::string err;
-    mi_stats stats;
-};
-
-struct mi_batch {
-    mi_ctx* ctx;
-    struct FileRec { u64 off, size, tag; };
-    std::vector<FileRec> files;
-    std::vector<SynthSpec> synth;
-    u64 total_bytes = 0;     // sum of sizes
-    u64 arena_used = 0;      // next free arena offset
-    DevBuf arena;
-    // staging window
-    int cur = 0;             // staging buffer being filled
-    u64 win_start = 0;       // arena offset the current staging buffer maps to
-    u64 win_fill = 0;        // bytes valid in it
-    bool staged_any = false;
-    double ms_h2d = 0;
-    // pipeline state: every batch owns a stream, so two batches can be in flight and the
-    // Gear pass of one overlaps the SHA pass of the other (they bind different units)
-    hipStream_t stream = nullptr;
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    u64* h_counts = nullptr;             // pinned: [0] = chunk count, [1] = unique count
-    bool staged = false, in_flight = false, ran = false, results_valid = false;
-    u64 n_chunks = 0, total_slots = 0;
-    mi_stats stats;
-    DevBuf small_list, large_list;       // file indices by CDC kernel variant
-    u32 n_small = 0, n_large = 0;
-    DevBuf file_off, file_size, slot_base, cids, slot_ends, n_chunks_d, first, total_d, scratch;
-    DevBuf chunk_off, chunk_len, chunk_file, chunk_start, hist, cursor, digests;
-    DevBuf q_off, q_len, q_id;           // SHA queue descriptors, longest chunk first
-    DevBuf item_off, item_len, roots, file_sha, dup_of;
-    DevBuf heads_chunks, heads_files;    // SHA queue heads (one set per concurrent launch)
-    DevBuf tile_file, first_tile, tile_raw, crc_d;   // MI_FLAG_FILE_CRC32
-    u64 n_tiles = 0;
-    void* tree = nullptr;                // host-side walk record (mi_tree.hip)
-    DevBuf dd_rep, dd_minid, dd_slot, dd_nuniq;
-    std::vector<mi_file_result> h_files;
-    std::vector<mi_chunk_result> h_chunks;
-};
-
-namespace {
+namespace mi {
 
 int fail(mi_ctx* c, int code, const char* fmt, ...) {
     char buf[512];
@@ -118,14 +45,9 @@ int fail(mi_ctx* c, int code, const char* fmt, ...) {
     return code;
 }
 
-#define HIPCHK(c, call)                                                                     \
-    do {                                                                                    \
-        hipError_t e_ = (call);                                                             \
-        if (e_ != hipSuccess)                                                               \
-            return fail((c), e_ == hipErrorOutOfMemory ? MI_ERR_NOMEM : MI_ERR_HIP,          \
-                        "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__,     \
-                        __LINE__);                                                          \
-    } while (0)
+}  // namespace mi
+
+namespace {
 
 u64 align_up(u64 v, u64 a) { return (v + a - 1) / a * a; }
 
@@ -545,6 +467,7 @@ int mi_ctx_create(const mi_config* cfg, mi_ctx** out) {
 void mi_ctx_destroy(mi_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    (void)mi_comm_destroy(c);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto p : c->staging) if (p) (void)hipHostFree(p);
     for (auto s : c->copy_streams) if (s) (void)hipStreamDestroy(s);

@@ -1,0 +1,283 @@
+// mi_comm.hip -- the ONE collective of the path, inside the C ABI: an RCCL all-gather of
+// the per-GPU chunk-digest arrays over xGMI, then global duplicate marking.
+//
+// A Go host has no torch: the library itself must be able to exchange the digest sets.
+// RCCL is bound at run time with dlopen("librccl.so.1") -- no link-time dependency, so a
+// process that already carries an RCCL (e.g. PyTorch's) keeps exactly one copy.
+//   multi-process (one rank per GPU):  rank 0 calls mi_comm_unique_id, ships the 128 bytes
+//     to its peers by any side channel, every rank calls mi_comm_init_rank, then
+//     mi_dedup_allgather(batch) after each mi_batch_run/wait;
+//   single process, n GPUs (the natural shape for a Go host: one ctx per device):
+//     mi_comm_init_all(ctxs, n) and mi_dedup_allgather_all(batches, n) -- the n collectives
+//     are issued inside one ncclGroupStart/End.
+// Exchange: counts first (one u64 per rank), then slabs padded to the largest count in one
+// ncclAllGather -- every xGMI link carries exactly one peer's slab, no ring of 7 hops --
+// then the padding is squeezed out with device copies and mi_dedup_mark's kernel runs on the
+// gathered set; dup_of of the batch is rewritten with GLOBAL row indices (rank-major).
+#include "mi_internal.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+#include <string.h>
+
+#include <mutex>
+
+using namespace mi;
+
+namespace {
+
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err;
+};
+
+Rccl* rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (r.lib) break;
+        }
+        if (!r.lib) { r.err = std::string("cannot load librccl: ") + dlerror(); return; }
+#define MI_SYM(field, sym)                                                    \
+        r.field = (decltype(r.field))dlsym(r.lib, sym);                          \
+        if (!r.field) { r.err = std::string("librccl lacks ") + sym; r.lib = nullptr; return; }
+        MI_SYM(GetUniqueId, "ncclGetUniqueId")
+        MI_SYM(CommInitRank, "ncclCommInitRank")
+        MI_SYM(CommInitAll, "ncclCommInitAll")
+        MI_SYM(CommDestroy, "ncclCommDestroy")
+        MI_SYM(AllGather, "ncclAllGather")
+        MI_SYM(GroupStart, "ncclGroupStart")
+        MI_SYM(GroupEnd, "ncclGroupEnd")
+        MI_SYM(GetErrorString, "ncclGetErrorString")
+#undef MI_SYM
+    });
+    return &r;
+}
+
+#define NCCLCHK(c, call)                                                                     \
+    do {                                                                                     \
+        ncclResult_t r_ = (call);                                                            \
+        if (r_ != ncclSuccess)                                                               \
+            return fail((c), MI_ERR_HIP, "%s failed: %s", #call, rccl()->GetErrorString(r_)); \
+    } while (0)
+
+int need_rccl(mi_ctx* c) {
+    Rccl* r = rccl();
+    if (!r->lib) return fail(c, MI_ERR_NO_DEVICE, "RCCL unavailable: %s", r->err.c_str());
+    return MI_OK;
+}
+
+// per-exchange scratch kept on the ctx side of things (one exchange at a time per ctx)
+struct Exchange {
+    DevBuf counts, slab, gathered, compact, dup;
+};
+Exchange* exchange_of(mi_ctx* c) {
+    if (!c->comm_scratch) c->comm_scratch = new Exchange();
+    return (Exchange*)c->comm_scratch;
+}
+
+// phase 1: counts.  phase 2: slabs.  Split so the single-process form can group them.
+int exchange_counts_enqueue(mi_batch* b) {
+    mi_ctx* c = b->ctx;
+    Exchange* x = exchange_of(c);
+    HIPCHK(c, x->counts.ensure(8 * (size_t)(c->comm_nranks + 1)));
+    u64* d_counts = x->counts.as<u64>();
+    const u64 mine = b->n_chunks;
+    HIPCHK(c, hipMemcpyAsync(d_counts + c->comm_nranks, &mine, 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));            // `mine` is a stack variable
+    NCCLCHK(c, rccl()->AllGather(d_counts + c->comm_nranks, d_counts, 1, ncclUint64,
+                                 (ncclComm_t)c->comm, c->stream));
+    return MI_OK;
+}
+
+int exchange_slabs_enqueue(mi_batch* b, std::vector<u64>& counts, u64* max_out) {
+    mi_ctx* c = b->ctx;
+    Exchange* x = exchange_of(c);
+    counts.resize((size_t)c->comm_nranks);
+    HIPCHK(c, hipMemcpyAsync(counts.data(), x->counts.p, 8 * counts.size(), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    u64 m = 0;
+    for (u64 v : counts) m = v > m ? v : m;
+    *max_out = m;
+    if (m == 0) return MI_OK;
+    HIPCHK(c, x->slab.ensure(m * 32));
+    HIPCHK(c, x->gathered.ensure(m * 32 * counts.size()));
+    HIPCHK(c, hipMemsetAsync(x->slab.p, 0, m * 32, c->stream));
+    if (b->n_chunks)
+        HIPCHK(c, hipMemcpyAsync(x->slab.p, b->digests.p, b->n_chunks * 32, hipMemcpyDeviceToDevice, c->stream));
+    NCCLCHK(c, rccl()->AllGather(x->slab.p, x->gathered.p, m * 32, ncclUint8, (ncclComm_t)c->comm, c->stream));
+    return MI_OK;
+}
+
+int mark_and_rewrite(mi_batch* b, const std::vector<u64>& counts, u64 m, uint64_t* n_total,
+                     uint64_t* n_unique, uint64_t* first_global) {
+    mi_ctx* c = b->ctx;
+    Exchange* x = exchange_of(c);
+    u64 total = 0, first = 0;
+    for (size_t r = 0; r < counts.size(); ++r) {
+        if ((int)r < c->comm_rank) first += counts[r];
+        total += counts[r];
+    }
+    const u8* glob = x->gathered.as<u8>();
+    bool ragged = false;
+    for (u64 v : counts) ragged |= (v != m);
+    if (ragged && total) {                                   // squeeze the padding out, rank-major
+        HIPCHK(c, x->compact.ensure(total * 32));
+        u64 at = 0;
+        for (size_t r = 0; r < counts.size(); ++r) {
+            if (counts[r])
+                HIPCHK(c, hipMemcpyAsync(x->compact.as<u8>() + at * 32, glob + r * m * 32, counts[r] * 32,
+                                         hipMemcpyDeviceToDevice, c->stream));
+            at += counts[r];
+        }
+        glob = x->compact.as<u8>();
+    }
+    HIPCHK(c, x->dup.ensure(total * 8 + 16));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    uint64_t nu = 0;
+    int rc = mi_dedup_mark(c, glob, total, x->dup.p, &nu);
+    if (rc) return rc;
+    rc = mi_batch_set_global_dedup(b, x->dup.p, first);
+    if (rc) return rc;
+    if (n_total) *n_total = total;
+    if (n_unique) *n_unique = nu;
+    if (first_global) *first_global = first;
+    return MI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi_comm_unique_id(void* id_out) {
+    if (!id_out) return MI_ERR_INVALID;
+    int rc = need_rccl(nullptr);
+    if (rc) return rc;
+    ncclUniqueId id;
+    ncclResult_t r = rccl()->GetUniqueId(&id);
+    if (r != ncclSuccess) return fail(nullptr, MI_ERR_HIP, "ncclGetUniqueId: %s", rccl()->GetErrorString(r));
+    static_assert(sizeof id == MI_COMM_ID_BYTES, "unique id size");
+    memcpy(id_out, &id, sizeof id);
+    return MI_OK;
+}
+
+int mi_comm_init_rank(mi_ctx* c, int nranks, int rank, const void* id) {
+    if (!c || !id || nranks < 1 || rank < 0 || rank >= nranks) return MI_ERR_INVALID;
+    int rc = need_rccl(c);
+    if (rc) return rc;
+    if (c->comm) return fail(c, MI_ERR_STATE, "communicator already initialised");
+    HIPCHK(c, hipSetDevice(c->device));
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof uid);
+    ncclComm_t comm = nullptr;
+    NCCLCHK(c, rccl()->CommInitRank(&comm, nranks, uid, rank));
+    c->comm = comm;
+    c->comm_rank = rank;
+    c->comm_nranks = nranks;
+    return MI_OK;
+}
+
+int mi_comm_init_all(mi_ctx** ctxs, int n) {
+    if (!ctxs || n < 1) return MI_ERR_INVALID;
+    int rc = need_rccl(ctxs[0]);
+    if (rc) return rc;
+    std::vector<int> devs((size_t)n);
+    std::vector<ncclComm_t> comms((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        if (!ctxs[i]) return MI_ERR_INVALID;
+        if (ctxs[i]->comm) return fail(ctxs[i], MI_ERR_STATE, "communicator already initialised");
+        devs[(size_t)i] = ctxs[i]->device;
+    }
+    NCCLCHK(ctxs[0], rccl()->CommInitAll(comms.data(), n, devs.data()));
+    for (int i = 0; i < n; ++i) {
+        ctxs[i]->comm = comms[(size_t)i];
+        ctxs[i]->comm_rank = i;
+        ctxs[i]->comm_nranks = n;
+    }
+    return MI_OK;
+}
+
+int mi_comm_destroy(mi_ctx* c) {
+    if (!c) return MI_ERR_INVALID;
+    if (c->comm) {
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+        (void)rccl()->CommDestroy((ncclComm_t)c->comm);
+        c->comm = nullptr;
+    }
+    if (c->comm_scratch) {
+        Exchange* x = (Exchange*)c->comm_scratch;
+        x->counts.release(); x->slab.release(); x->gathered.release(); x->compact.release(); x->dup.release();
+        delete x;
+        c->comm_scratch = nullptr;
+    }
+    c->comm_rank = 0;
+    c->comm_nranks = 1;
+    return MI_OK;
+}
+
+int mi_dedup_allgather(mi_batch* b, uint64_t* n_total, uint64_t* n_unique, uint64_t* first_global) {
+    if (!b) return MI_ERR_INVALID;
+    mi_ctx* c = b->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->comm) return fail(c, MI_ERR_STATE, "mi_dedup_allgather before mi_comm_init_rank/_all");
+    if (!b->ran || b->in_flight) return fail(c, MI_ERR_STATE, "the batch must have run (and been waited for)");
+    int rc = exchange_counts_enqueue(b);
+    if (rc) return rc;
+    std::vector<u64> counts;
+    u64 m = 0;
+    rc = exchange_slabs_enqueue(b, counts, &m);
+    if (rc) return rc;
+    return mark_and_rewrite(b, counts, m, n_total, n_unique, first_global);
+}
+
+int mi_dedup_allgather_all(mi_batch** batches, int n, uint64_t* n_total, uint64_t* n_unique) {
+    if (!batches || n < 1) return MI_ERR_INVALID;
+    for (int i = 0; i < n; ++i) {
+        if (!batches[i]) return MI_ERR_INVALID;
+        mi_ctx* c = batches[i]->ctx;
+        if (!c->comm || c->comm_nranks != n || c->comm_rank != i)
+            return fail(c, MI_ERR_STATE, "batch %d does not belong to rank %d of an %d-rank mi_comm_init_all", i, i, n);
+        if (!batches[i]->ran || batches[i]->in_flight)
+            return fail(c, MI_ERR_STATE, "every batch must have run (and been waited for)");
+    }
+    mi_ctx* c0 = batches[0]->ctx;
+    int rc = MI_OK;
+    NCCLCHK(c0, rccl()->GroupStart());
+    for (int i = 0; i < n && !rc; ++i) {
+        (void)hipSetDevice(batches[i]->ctx->device);
+        rc = exchange_counts_enqueue(batches[i]);
+    }
+    NCCLCHK(c0, rccl()->GroupEnd());
+    if (rc) return rc;
+    std::vector<std::vector<u64>> counts((size_t)n);
+    std::vector<u64> maxes((size_t)n, 0);
+    NCCLCHK(c0, rccl()->GroupStart());
+    for (int i = 0; i < n && !rc; ++i) {
+        (void)hipSetDevice(batches[i]->ctx->device);
+        rc = exchange_slabs_enqueue(batches[i], counts[(size_t)i], &maxes[(size_t)i]);
+    }
+    NCCLCHK(c0, rccl()->GroupEnd());
+    if (rc) return rc;
+    for (int i = 0; i < n; ++i) {
+        (void)hipSetDevice(batches[i]->ctx->device);
+        uint64_t nt = 0, nu = 0;
+        rc = mark_and_rewrite(batches[i], counts[(size_t)i], maxes[(size_t)i], &nt, &nu, nullptr);
+        if (rc) return rc;
+        if (n_total) *n_total = nt;
+        if (n_unique) *n_unique = nu;
+    }
+    return MI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,101 @@
+// mi_internal.h -- engine-internal state shared by the host translation units
+// (mi_api.hip: pipeline and C ABI; mi_comm.hip: RCCL digest exchange).  Not installed.
+#pragma once
+
+#include "../../include/makisu_mi.h"
+#include "mi_common.h"
+
+#include <string>
+#include <vector>
+
+namespace mi {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    hipError_t ensure(size_t want) {
+        if (want <= bytes) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        size_t alloc = want + want / 8 + 256;
+        hipError_t e = hipMalloc(&p, alloc);
+        if (e == hipSuccess) bytes = alloc;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    template <typename T> T* as() const { return (T*)p; }
+};
+
+struct SynthSpec { u64 f0, n, seed; std::vector<u64> cids; };
+
+// sets the ctx's (or, for c == nullptr, the create-time) error message; returns code
+int fail(mi_ctx* c, int code, const char* fmt, ...);
+
+}  // namespace mi
+
+struct mi_ctx {
+    mi_config cfg;
+    int device = 0;
+    hipDeviceProp_t prop;
+    hipStream_t stream = nullptr;        // ctx-level work (mi_dedup_mark, mi_sha256_many, uploads)
+    std::vector<hipStream_t> copy_streams;
+    std::vector<void*> staging;          // pinned, staging_bytes each
+    std::vector<hipEvent_t> staging_done;
+    size_t staging_bytes = 0;
+    mi::DevBuf gear_table, heads, crc_consts;
+    mi::DevBuf dd_rep, dd_minid, dd_slot, dd_nuniq;     // dedup scratch of mi_dedup_mark
+    hipEvent_t ev[2];
+    int sha_blocks_per_cu = 2;
+    mi::CdcParams cdc;
+    void* comm = nullptr;                // ncclComm_t when mi_comm_init_* was called (mi_comm.hip)
+    int comm_rank = 0, comm_nranks = 1;
+    void* comm_scratch = nullptr;        // exchange buffers (mi_comm.hip)
+    std::string err;
+    mi_stats stats;
+};
+
+struct mi_batch {
+    mi_ctx* ctx;
+    struct FileRec { mi::u64 off, size, tag; };
+    std::vector<FileRec> files;
+    std::vector<mi::SynthSpec> synth;
+    mi::u64 total_bytes = 0;     // sum of sizes
+    mi::u64 arena_used = 0;      // next free arena offset
+    mi::DevBuf arena;
+    // staging window
+    int cur = 0;             // staging buffer being filled
+    mi::u64 win_start = 0;       // arena offset the current staging buffer maps to
+    mi::u64 win_fill = 0;        // bytes valid in it
+    bool staged_any = false;
+    double ms_h2d = 0;
+    // pipeline state: every batch owns a stream, so two batches can be in flight and the
+    // Gear pass of one overlaps the SHA pass of the other (they bind different units)
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    mi::u64* h_counts = nullptr;             // pinned: [0] = chunk count, [1] = unique count
+    bool staged = false, in_flight = false, ran = false, results_valid = false;
+    mi::u64 n_chunks = 0, total_slots = 0;
+    mi_stats stats;
+    mi::DevBuf small_list, large_list;       // file indices by CDC kernel variant
+    mi::u32 n_small = 0, n_large = 0;
+    mi::DevBuf file_off, file_size, slot_base, cids, slot_ends, n_chunks_d, first, total_d, scratch;
+    mi::DevBuf chunk_off, chunk_len, chunk_file, chunk_start, hist, cursor, digests;
+    mi::DevBuf q_off, q_len, q_id;           // SHA queue descriptors, longest chunk first
+    mi::DevBuf item_off, item_len, roots, file_sha, dup_of;
+    mi::DevBuf heads_chunks, heads_files;    // SHA queue heads (one set per concurrent launch)
+    mi::DevBuf tile_file, first_tile, tile_raw, crc_d;   // MI_FLAG_FILE_CRC32
+    mi::u64 n_tiles = 0;
+    void* tree = nullptr;                // host-side walk record (mi_tree.hip)
+    mi::DevBuf dd_rep, dd_minid, dd_slot, dd_nuniq;
+    std::vector<mi_file_result> h_files;
+    std::vector<mi_chunk_result> h_chunks;
+};
+
+
+#define HIPCHK(c, call)                                                                     \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return mi::fail((c), e_ == hipErrorOutOfMemory ? MI_ERR_NOMEM : MI_ERR_HIP,      \
+                            "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
+                            __LINE__);                                                      \
+    } while (0)

@@ -683,3 +683,44 @@ def test_two_ranks_global_dedup_on_gpu(oracle):
     offs = np.concatenate([[0], np.cumsum(sz1)[:-1]])
     rf, rc = oracle.scan_batch(data, offs, sz1, oracle.CdcParams(SEED, 13, 2048, 65536), True, 4, 4)
     assert rc["sha256"].tobytes() == d1
+
+
+def test_native_rccl_exchange_single_rank(oracle):
+    """mi_comm_* + mi_dedup_allgather: the digest exchange done by the library itself over RCCL
+    (what a Go host would call).  One rank here; the multi-rank logic (ragged counts, rank-major
+    global indices) is the same code and is exercised by the gloo / two-rank tests above."""
+    import makisu_amd
+    with makisu_amd.Engine(flags=makisu_amd.FLAG_NO_DEDUP) as eng:
+        eng.comm_init_rank(1, 0, makisu_amd.Engine.comm_unique_id())
+        with eng.batch() as b:
+            b.add_synthetic([65536] * 400, [i % 300 for i in range(400)], seed=SEED)
+            b.run()
+            assert (b.chunks()["dup_of"] == -1).all()            # local marking was off
+            n_total, n_unique, first = b.dedup_allgather()
+            chunks = b.chunks().copy()
+        want, uniq = oracle.dedup(chunks["sha256"])
+        assert n_total == len(chunks) and first == 0 and n_unique == uniq
+        assert np.array_equal(chunks["dup_of"], want)
+        with pytest.raises(makisu_amd.MiError):
+            eng.comm_init_rank(1, 0, makisu_amd.Engine.comm_unique_id())     # already initialised
+        eng.comm_destroy()
+
+
+def test_native_rccl_init_all_single_device(oracle):
+    """Single-process form (mi_comm_init_all + mi_dedup_allgather_all) with the one device here."""
+    import ctypes as C
+    import makisu_amd
+    lib = makisu_amd.load_library()
+    with makisu_amd.Engine() as eng, eng.batch() as b:
+        ctxs = (C.c_void_p * 1)(eng._h)
+        assert lib.mi_comm_init_all(ctxs, 1) == 0, lib.mi_last_error(eng._h)
+        b.add_synthetic([30000] * 50, [i % 20 for i in range(50)], seed=SEED)
+        b.run()
+        local = b.chunks()["dup_of"].copy()
+        batches = (C.c_void_p * 1)(b._h)
+        nt, nu = C.c_uint64(), C.c_uint64()
+        assert lib.mi_dedup_allgather_all(batches, 1, C.byref(nt), C.byref(nu)) == 0, lib.mi_last_error(eng._h)
+        b._lib.mi_batch_counts  # keep binding alive
+        assert nt.value == len(local) and nu.value == (local < 0).sum()
+        # results cache must be refreshed after the rewrite
+        assert np.array_equal(b.chunks()["dup_of"], local)
