@@ -5,9 +5,11 @@
 //   file table : file_off[], file_size[], slot_base[]            (u64 SoA)
 //   slots      : chunk END offsets per file, slot_base[f] .. +size/min+2  (u64)
 //   chunk table: chunk_off[] (arena offset), chunk_len[], chunk_start[] (u64),
-//                chunk_file[] (u32), order[] (u32, longest first), digests[] (32 B)
-//   file out   : roots[] (32 B), file_sha[] (32 B, optional)
-// One HIP stream per ctx for kernels, n_streams copy streams for staging.
+//                chunk_file[] (u32), digests[] (32 B)
+//   SHA queue  : q_off[], q_len[] (u64), q_id[] (u32): chunk descriptors, longest first
+//   file out   : roots[] (32 B), file_sha[] (32 B, optional), crc[] (u32, optional)
+// One HIP stream per BATCH for its pipeline (two batches may be in flight), one per ctx for
+// ctx-level work, n_streams copy streams for staging.
 // There is no CPU fallback anywhere in this file.
 #include "mi_internal.h"
 

@@ -29,7 +29,6 @@ __device__ __forceinline__ u32 xor3(u32 a, u32 b, u32 c) { return __builtin_amdg
 __device__ __forceinline__ u32 ch3(u32 e, u32 f, u32 g)  { return __builtin_amdgcn_bitop3_b32(e, f, g, 0xCA); }
 __device__ __forceinline__ u32 maj3(u32 a, u32 b, u32 c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xE8); }
 
-#define MI_SHA_K(i) kK256[i]
 __device__ constexpr u32 kK256[64] = {
     0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4,
     0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe,
