@@ -32,8 +32,9 @@
 //      64 bits per step, __ballot + ctz), carrying last_cut across tiles, and the
 //      chunk ends appended to the file's slot region in HBM.
 // Small files (<= one tile): one wave per file, four files per workgroup, no
-// workgroup barrier at all.  Large files: one workgroup per file, four tiles marked
-// in parallel per step, then wave 0 selects across them in order.
+// workgroup barrier at all.  Large files: chained groups of four tiles -- persistent
+// workgroups mark groups in parallel (even within ONE file) and pass the cut state from
+// group to group (see gear_cdc_large_kernel).
 // HBM traffic: every file byte read once (+6 % warm-up, mostly L2 hits), 8 B written
 // per chunk.  Bound: HBM bandwidth / LDS lookup rate.
 #include "mi_common.h"
@@ -202,26 +203,48 @@ void gear_cdc_small_kernel(const u8* __restrict__ data, const u64* __restrict__ 
     }
 }
 
-// ---- large files: one workgroup per file, kWavesPerWG tiles per step -------------------------
+// ---- large files: chained groups ------------------------------------------------------------
+// A large file is cut into GROUPS of kWavesPerWG tiles (256 KiB).  Persistent workgroups draw
+// group tickets from one atomic counter in file-major order; a workgroup marks its group's
+// tiles independently of everybody else (the expensive part), then wave 0 waits for the CUT
+// STATE (last cut, chunks emitted) handed over by the previous group of the same file,
+// selects this group's cuts and hands the state on.  So even ONE huge file keeps the whole
+// chip busy; only the cheap selection is serial.
+// Hand-over (MI355X_MICROARCH.md "R2: the data IS the flag"): two 8-byte granules per group,
+// {tag:32 | n_out:32} and {tag:16 | last:48}, each written by ONE relaxed agent-scope store and
+// polled with relaxed agent-scope loads -- no fences; granules are zeroed before every launch.
+// Deadlock-free: tickets are drawn in order by running workgroups, so the predecessor of any
+// waiting group already holds a ticket and never waits on its successors.
+struct GroupToken { u64 a, b; };
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+
 __global__ __launch_bounds__(kGearWG)
 void gear_cdc_large_kernel(const u8* __restrict__ data, const u64* __restrict__ file_off,
                            const u64* __restrict__ file_size, const u64* __restrict__ slot_base,
                            u64* __restrict__ slot_ends, u32* __restrict__ n_chunks,
-                           const u32* __restrict__ list, u32 n_list,
-                           const u64* __restrict__ gear_table, CdcParams p) {
+                           const u32* __restrict__ group_file, const u32* __restrict__ group_index,
+                           const u32* __restrict__ group_prev, u32 n_groups,
+                           u32* __restrict__ ticket_counter,
+                           GroupToken* __restrict__ tokens, const u64* __restrict__ gear_table,
+                           CdcParams p) {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     u64* table = (u64*)smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     u32* bitmaps = (u32*)(smem + kTableBytes);
+    // (the ticket word lives in the dynamic region: a static __shared__ would shift its base)
+    volatile u32* s_ticket = (volatile u32*)(smem + kGearLdsBytes);
     load_table(table, gear_table, tid);
     __syncthreads();
-    const u32 f = list[blockIdx.x];
-    const u64 size = file_size[f];
-    const u8* fptr = data + file_off[f];
-    u64* ends = slot_ends + slot_base[f];
-    u64 last = 0;          // wave-0 uniform
-    u32 n_out = 0;
-    for (u64 g0 = 0; g0 < size; g0 += (u64)kGearTile * kWavesPerWG) {
+    constexpr u64 kGroupBytes = (u64)kGearTile * kWavesPerWG;
+    for (;;) {
+        if (tid == 0) *s_ticket = atomicAdd(ticket_counter, 1u);
+        __syncthreads();
+        const u32 g = *s_ticket;
+        if (g >= n_groups) break;
+        const u32 f = group_file[g], gi = group_index[g];
+        const u64 size = file_size[f];
+        const u8* fptr = data + file_off[f];
+        const u64 g0 = (u64)gi * kGroupBytes;
         const u64 ts = g0 + (u64)wave * kGearTile;
         if (ts < size) {
             const u32 tlen = (u32)((size - ts < (u64)kGearTile) ? (size - ts) : (u64)kGearTile);
@@ -230,38 +253,81 @@ void gear_cdc_large_kernel(const u8* __restrict__ data, const u64* __restrict__ 
         }
         __syncthreads();
         if (wave == 0) {
+            u64 last = 0;
+            u32 n_out = 0;
+            if (gi > 0) {                                 // cut state from the file's previous group
+                const u32 prev = group_prev[g];           // its ticket (always < g)
+                gu64* ta = (gu64*)&tokens[prev].a;
+                gu64* tb = (gu64*)&tokens[prev].b;
+                u64 a = 0, b = 0;
+                if (lane == 0) {
+                    // bounded: a broken chain must surface as an error, not as a hung GPU
+                    for (u32 spins = 0;; ++spins) {
+                        a = __hip_atomic_load(ta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        b = __hip_atomic_load(tb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((a >> 32) == 1u && (b >> 48) == 1u) break;
+                        if (spins > (1u << 24)) { atomicExch(ticket_counter + 1, 1u); a = b = 0; break; }
+                        __builtin_amdgcn_s_sleep(4);
+                    }
+                }
+                const u32 alo = __shfl((u32)a, 0);
+                const u32 blo = __shfl((u32)b, 0), bhi = __shfl((u32)(b >> 32), 0);
+                n_out = alo;
+                last = (((u64)bhi << 32) | blo) & 0xFFFFFFFFFFFFull;
+            }
+            u64* ends = slot_ends + slot_base[f];
             for (int t = 0; t < kWavesPerWG; ++t) {
                 const u64 tts = g0 + (u64)t * kGearTile;
                 if (tts >= size) break;
                 const u32 tlen = (u32)((size - tts < (u64)kGearTile) ? (size - tts) : (u64)kGearTile);
                 select_tile(bitmaps + t * kBitmapWords, tts, tlen, p, last, n_out, ends, lane);
             }
+            if (lane == 0) {
+                if (g0 + kGroupBytes >= size) {           // the file's last group
+                    if (size > last) { ends[n_out] = size; ++n_out; }
+                    n_chunks[f] = n_out;
+                } else {
+                    __hip_atomic_store((gu64*)&tokens[g].a, ((u64)1 << 32) | n_out, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store((gu64*)&tokens[g].b, ((u64)1 << 48) | last, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
         }
-        __syncthreads();                                 // bitmaps are reused by the next step
+        __syncthreads();                                  // bitmaps and s_ticket are reused
     }
-    if (tid == 0) {
-        if (size > last) { ends[n_out] = size; ++n_out; }
-        n_chunks[f] = n_out;
-    }
+}
+
+u64 gear_large_groups(u64 size) {
+    const u64 gb = (u64)kGearTile * kWavesPerWG;
+    return (size + gb - 1) / gb;
 }
 
 void launch_gear_cdc(const u8* d_data, const u64* d_file_off, const u64* d_file_size,
                      const u64* d_slot_base, u64* d_slot_ends, u32* d_n_chunks,
-                     const u32* d_small_list, u32 n_small, const u32* d_large_list, u32 n_large,
-                     const u64* d_gear_table, CdcParams p, int /*n_cu*/, hipStream_t s) {
+                     const u32* d_small_list, u32 n_small, const u32* d_group_file,
+                     const u32* d_group_index, const u32* d_group_prev, u32 n_groups,
+                     u32* d_ticket, void* d_tokens, const u64* d_gear_table, CdcParams p, int n_cu,
+                     hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)gear_cdc_small_kernel,
                               hipFuncAttributeMaxDynamicSharedMemorySize, kGearLdsBytes);
     (void)hipFuncSetAttribute((const void*)gear_cdc_large_kernel,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, kGearLdsBytes);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kGearLdsBytes + 16);
     if (n_small)
         hipLaunchKernelGGL(gear_cdc_small_kernel, dim3((n_small + kWavesPerWG - 1) / kWavesPerWG),
                            dim3(kGearWG), kGearLdsBytes, s, d_data, d_file_off, d_file_size,
                            d_slot_base, d_slot_ends, d_n_chunks, d_small_list, n_small,
                            d_gear_table, p);
-    if (n_large)
-        hipLaunchKernelGGL(gear_cdc_large_kernel, dim3(n_large), dim3(kGearWG), kGearLdsBytes, s,
+    if (n_groups) {
+        (void)hipMemsetAsync(d_ticket, 0, 2 * sizeof(u32), s);   // [0] ticket counter, [1] chain error
+        (void)hipMemsetAsync(d_tokens, 0, sizeof(GroupToken) * (size_t)n_groups, s);
+        u32 grid = (u32)n_cu * 3;                         // 3 workgroups per CU fit (LDS, VGPRs)
+        if (grid > n_groups) grid = n_groups;
+        hipLaunchKernelGGL(gear_cdc_large_kernel, dim3(grid), dim3(kGearWG), kGearLdsBytes + 16, s,
                            d_data, d_file_off, d_file_size, d_slot_base, d_slot_ends, d_n_chunks,
-                           d_large_list, n_large, d_gear_table, p);
+                           d_group_file, d_group_index, d_group_prev, n_groups, d_ticket,
+                           (GroupToken*)d_tokens, d_gear_table, p);
+    }
 }
 
 }  // namespace mi

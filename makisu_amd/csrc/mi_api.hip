@@ -226,16 +226,22 @@ int submit_pipeline(mi_batch* b) {
     const int ncu = c->prop.multiProcessorCount;
 
     HIPCHK(c, hipEventRecord(b->ev[0], s));
+    if (b->n_groups) {
+        HIPCHK(c, b->group_ticket.ensure(16));
+        HIPCHK(c, b->group_tokens.ensure(16ull * b->n_groups));
+    }
     launch_gear_cdc(b->arena.as<u8>(), d_off, d_size, b->slot_base.as<u64>(),
                     b->slot_ends.as<u64>(), b->n_chunks_d.as<u32>(), b->small_list.as<u32>(),
-                    b->n_small, b->large_list.as<u32>(), b->n_large, c->gear_table.as<u64>(),
+                    b->n_small, b->group_file.as<u32>(), b->group_index.as<u32>(),
+                    b->group_prev.as<u32>(), b->n_groups,
+                    b->group_ticket.as<u32>(), b->group_tokens.p, c->gear_table.as<u64>(),
                     c->cdc, ncu, s);
     launch_scan_counts(b->n_chunks_d.as<u32>(), b->first.as<u64>(), b->total_d.as<u64>(), nf,
                        b->scratch.as<u64>(), s);
     HIPCHK(c, hipMemcpyAsync(&b->h_counts[0], b->total_d.p, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipEventRecord(b->ev[1], s));
     launch_compact_chunks(d_off, b->slot_base.as<u64>(), b->slot_ends.as<u64>(),
-                          b->n_chunks_d.as<u32>(), b->first.as<u64>(), nf, b->chunk_off.as<u64>(),
+                          b->n_chunks_d.as<u32>(), b->first.as<u64>(), nf, cap, d_n, b->chunk_off.as<u64>(),
                           b->chunk_len.as<u64>(), b->chunk_file.as<u32>(),
                           b->chunk_start.as<u64>(), b->hist.as<u32>(), n_bins, bin_shift, s);
     launch_bin_order(b->chunk_off.as<u64>(), b->chunk_len.as<u64>(), (u32)cap, d_n,
@@ -283,6 +289,11 @@ int wait_pipeline(mi_batch* b) {
     b->in_flight = false;
     HIPCHK(c, hipStreamSynchronize(b->stream));
     HIPCHK(c, hipGetLastError());
+    if (b->n_groups) {
+        u32 chain_err = 0;
+        HIPCHK(c, hipMemcpy(&chain_err, b->group_ticket.as<u32>() + 1, 4, hipMemcpyDeviceToHost));
+        if (chain_err) return fail(c, MI_ERR_HIP, "large-file cut chain timed out (internal error)");
+    }
     const u64 total = b->h_counts[0];
     if (total > b->total_slots)
         return fail(c, MI_ERR_HIP, "chunk count %llu exceeds its bound %llu",
@@ -604,20 +615,52 @@ static int stage_batch(mi_batch* b) {
     for (auto s : c->copy_streams) HIPCHK(c, hipStreamSynchronize(s));
     const u64 nf = b->files.size();
     std::vector<u64> off(nf), size(nf), slot(nf);
-    std::vector<u32> small, large;
-    u64 slots = 0;
+    std::vector<u32> small, gfile, gindex, gprev, large;
+    u64 slots = 0, max_groups = 0, n_groups = 0;
     for (u64 f = 0; f < nf; ++f) {
         off[f] = b->files[f].off;
         size[f] = b->files[f].size;
         slot[f] = slots;
         slots += size[f] / c->cfg.min_size + 2;
-        (size[f] <= (u64)kGearTile ? small : large).push_back((u32)f);
+        if (size[f] <= (u64)kGearTile) {
+            small.push_back((u32)f);
+        } else {
+            large.push_back((u32)f);
+            const u64 ng = gear_large_groups(size[f]);
+            n_groups += ng;
+            if (ng > max_groups) max_groups = ng;
+        }
+    }
+    if (n_groups >= 0xFFFFFFFFull)
+        return fail(c, MI_ERR_INVALID, "batch too large: more than 2^32 tile groups");
+    // Ticket order of the chained groups: round-robin over the large files (group 0 of every
+    // file, then group 1, ...), so the cut-state chains of different files advance in parallel
+    // and a group's predecessor is usually long done when its turn comes; inside a file the
+    // order is increasing, which is what makes the chain deadlock-free.
+    gfile.reserve(n_groups);
+    gindex.reserve(n_groups);
+    gprev.reserve(n_groups);
+    {
+        std::vector<u32> live = large, last_ticket(nf, 0xFFFFFFFFu);
+        for (u64 gi = 0; gi < max_groups && !live.empty(); ++gi) {
+            size_t keep = 0;
+            for (u32 f : live) {
+                gprev.push_back(last_ticket[f]);          // ticket of the file's previous group
+                last_ticket[f] = (u32)gfile.size();
+                gfile.push_back(f);
+                gindex.push_back((u32)gi);
+                if (gi + 1 < gear_large_groups(size[f])) live[keep++] = f;
+            }
+            live.resize(keep);
+        }
     }
     b->total_slots = slots;
     b->n_small = (u32)small.size();
-    b->n_large = (u32)large.size();
+    b->n_groups = (u32)gfile.size();
     if ((rc = upload(c, b->small_list, small))) return rc;
-    if ((rc = upload(c, b->large_list, large))) return rc;
+    if ((rc = upload(c, b->group_file, gfile))) return rc;
+    if ((rc = upload(c, b->group_index, gindex))) return rc;
+    if ((rc = upload(c, b->group_prev, gprev))) return rc;
     if ((rc = upload(c, b->file_off, off))) return rc;
     if ((rc = upload(c, b->file_size, size))) return rc;
     if ((rc = upload(c, b->slot_base, slot))) return rc;
@@ -750,8 +793,8 @@ int mi_batch_free(mi_batch* b) {
     if (b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
     for (auto e : b->ev) if (e) (void)hipEventDestroy(e);
     if (b->h_counts) (void)hipHostFree(b->h_counts);
-    DevBuf* bufs[] = {&b->tile_file, &b->first_tile, &b->tile_raw, &b->crc_d, &b->heads_chunks, &b->heads_files, &b->dd_rep, &b->dd_minid, &b->dd_slot,
-                      &b->dd_nuniq, &b->q_off, &b->q_len, &b->q_id,&b->arena, &b->small_list, &b->large_list, &b->file_off, &b->file_size, &b->slot_base, &b->cids,
+    DevBuf* bufs[] = {&b->group_file, &b->group_index, &b->group_prev, &b->group_ticket, &b->group_tokens, &b->tile_file, &b->first_tile, &b->tile_raw, &b->crc_d, &b->heads_chunks, &b->heads_files, &b->dd_rep, &b->dd_minid, &b->dd_slot,
+                      &b->dd_nuniq, &b->q_off, &b->q_len, &b->q_id,&b->arena, &b->small_list, &b->file_off, &b->file_size, &b->slot_base, &b->cids,
                       &b->slot_ends, &b->n_chunks_d, &b->first, &b->total_d, &b->scratch,
                       &b->chunk_off, &b->chunk_len, &b->chunk_file, &b->chunk_start, &b->hist,
                       &b->cursor, &b->digests, &b->item_off, &b->item_len, &b->roots,

@@ -44,12 +44,18 @@ constexpr u64 kSmGamma = 0x9E3779B97F4A7C15ULL;
 
 // ---- kernel launchers (each defined next to its kernels) ----------------------
 // gear_cdc.hip
-// small_list: files of <= kGearTile bytes (one wave each); large_list: the rest (one
-// workgroup each).  Lists hold file indices.
+// small_list: indices of files of <= kGearTile bytes (one wave each).  Larger files are
+// cut into groups of gear_large_groups(size) x 256 KiB, listed file-major in
+// group_file[]/group_index[]/group_prev[] (file index, group index inside the file, ticket of
+// the file's previous group); d_ticket (2 x u32: counter, chain-error flag) and d_tokens
+// (16 B per group) are scratch the launcher zeroes.
+u64  gear_large_groups(u64 size);
 void launch_gear_cdc(const u8* d_data, const u64* d_file_off, const u64* d_file_size,
                      const u64* d_slot_base, u64* d_slot_ends, u32* d_n_chunks,
-                     const u32* d_small_list, u32 n_small, const u32* d_large_list, u32 n_large,
-                     const u64* d_gear_table, CdcParams p, int n_cu, hipStream_t s);
+                     const u32* d_small_list, u32 n_small, const u32* d_group_file,
+                     const u32* d_group_index, const u32* d_group_prev, u32 n_groups,
+                     u32* d_ticket, void* d_tokens, const u64* d_gear_table, CdcParams p, int n_cu,
+                     hipStream_t s);
 
 // sha256.hip : n independent byte strings -> n digests.  Queue position p holds the string
 // base[off[p] .. +len[p]) whose digest goes to out[32 * (ids ? ids[p] : p)]; positions are
@@ -68,8 +74,8 @@ void launch_scan_counts(const u32* d_counts, u64* d_first, u64* d_total, u64 n,
                         u64* d_scratch, hipStream_t s);
 u64  scan_scratch_elems(u64 n);
 void launch_compact_chunks(const u64* d_file_off, const u64* d_slot_base, const u64* d_slot_ends,
-                           const u32* d_n_chunks, const u64* d_first, u64 n_files,
-                           u64* d_chunk_off, u64* d_chunk_len, u32* d_chunk_file,
+                           const u32* d_n_chunks, const u64* d_first, u64 n_files, u64 n_max,
+                           const u64* d_n, u64* d_chunk_off, u64* d_chunk_len, u32* d_chunk_file,
                            u64* d_chunk_start, u32* d_hist, u32 n_bins, u32 bin_shift,
                            hipStream_t s);
 // queue descriptors in processing order (longest first): s_off/s_len/s_id[pos]

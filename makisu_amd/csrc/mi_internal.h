@@ -75,8 +75,9 @@ struct mi_batch {
     bool staged = false, in_flight = false, ran = false, results_valid = false;
     mi::u64 n_chunks = 0, total_slots = 0;
     mi_stats stats;
-    mi::DevBuf small_list, large_list;       // file indices by CDC kernel variant
-    mi::u32 n_small = 0, n_large = 0;
+    mi::DevBuf small_list;                   // indices of files <= one tile (wave per file)
+    mi::DevBuf group_file, group_index, group_prev, group_ticket, group_tokens;   // chained groups of large files
+    mi::u32 n_small = 0, n_groups = 0;
     mi::DevBuf file_off, file_size, slot_base, cids, slot_ends, n_chunks_d, first, total_d, scratch;
     mi::DevBuf chunk_off, chunk_len, chunk_file, chunk_start, hist, cursor, digests;
     mi::DevBuf q_off, q_len, q_id;           // SHA queue descriptors, longest chunk first

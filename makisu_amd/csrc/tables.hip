@@ -144,37 +144,38 @@ __device__ __forceinline__ u32 bin_of(u64 len, u32 n_bins, u32 bin_shift) {
 }
 
 constexpr int kMaxBins = 1024;          // LDS-private histogram size (bins are block counts >> shift)
-constexpr int kLanesPerFile = 8;        // a file's chunk rows are written by 8 adjacent lanes
-
-// Grid-stride over files, 8 lanes per file: lane k writes rows k, k+8, ... of the file, so a
-// 64 KiB file's ~7 rows go out as one coalesced group.  Length bins are counted in LDS and
-// flushed once per workgroup (no hot global atomics).
+// One thread per chunk row: row g belongs to the file f with first[f] <= g < first[f+1]
+// (binary search over the scanned counts -- a handful of L2-resident probes), so a batch of
+// four 4 GiB files is compacted as fast as one of 100 000 small ones.  Length bins are counted
+// in LDS and flushed once per workgroup (no hot global atomics).
 __global__ __launch_bounds__(256)
 void compact_chunks_kernel(const u64* __restrict__ file_off, const u64* __restrict__ slot_base,
-                           const u64* __restrict__ slot_ends, const u32* __restrict__ n_chunks,
-                           const u64* __restrict__ first, u64 n_files, u64* __restrict__ chunk_off,
+                           const u64* __restrict__ slot_ends, const u32* __restrict__ /*n_chunks*/,
+                           const u64* __restrict__ first, u64 n_files, u64 n_max,
+                           const u64* __restrict__ n_ptr, u64* __restrict__ chunk_off,
                            u64* __restrict__ chunk_len, u32* __restrict__ chunk_file,
                            u64* __restrict__ chunk_start, u32* __restrict__ hist, u32 n_bins,
                            u32 bin_shift) {
     __shared__ u32 lh[kMaxBins];
     for (u32 i = threadIdx.x; i < n_bins; i += blockDim.x) lh[i] = 0;
     __syncthreads();
-    const u32 sub = threadIdx.x % kLanesPerFile;
-    const u64 stride = (u64)gridDim.x * (blockDim.x / kLanesPerFile);
-    for (u64 f = (u64)blockIdx.x * (blockDim.x / kLanesPerFile) + threadIdx.x / kLanesPerFile;
-         f < n_files; f += stride) {
-        const u64* ends = slot_ends + slot_base[f];
-        const u32 nc = n_chunks[f];
-        const u64 g0 = first[f], fo = file_off[f];
-        for (u32 k = sub; k < nc; k += kLanesPerFile) {
-            const u64 start = k ? ends[k - 1] : 0;
-            const u64 len = ends[k] - start;
-            chunk_off[g0 + k] = fo + start;
-            chunk_len[g0 + k] = len;
-            chunk_file[g0 + k] = (u32)f;
-            chunk_start[g0 + k] = start;
-            atomicAdd(&lh[bin_of(len, n_bins, bin_shift)], 1u);
+    const u64 n = n_ptr ? *n_ptr : n_max;
+    for (u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (u64)gridDim.x * blockDim.x) {
+        u64 lo = 0, hi = n_files;                            // last f with first[f] <= g
+        while (hi - lo > 1) {
+            const u64 mid = (lo + hi) >> 1;
+            if (first[mid] <= g) lo = mid; else hi = mid;
         }
+        const u64 f = lo;                                    // (empty files never win: the search
+        const u64 k = g - first[f];                          //  keeps the LAST index with first <= g)
+        const u64* ends = slot_ends + slot_base[f];
+        const u64 start = k ? ends[k - 1] : 0;
+        const u64 len = ends[k] - start;
+        chunk_off[g] = file_off[f] + start;
+        chunk_len[g] = len;
+        chunk_file[g] = (u32)f;
+        chunk_start[g] = start;
+        atomicAdd(&lh[bin_of(len, n_bins, bin_shift)], 1u);
     }
     __syncthreads();
     for (u32 i = threadIdx.x; i < n_bins; i += blockDim.x)
@@ -182,17 +183,17 @@ void compact_chunks_kernel(const u64* __restrict__ file_off, const u64* __restri
 }
 
 void launch_compact_chunks(const u64* d_file_off, const u64* d_slot_base, const u64* d_slot_ends,
-                           const u32* d_n_chunks, const u64* d_first, u64 n_files,
-                           u64* d_chunk_off, u64* d_chunk_len, u32* d_chunk_file,
+                           const u32* d_n_chunks, const u64* d_first, u64 n_files, u64 n_max,
+                           const u64* d_n, u64* d_chunk_off, u64* d_chunk_len, u32* d_chunk_file,
                            u64* d_chunk_start, u32* d_hist, u32 n_bins, u32 bin_shift,
                            hipStream_t s) {
     if (n_files == 0) return;
     (void)hipMemsetAsync(d_hist, 0, sizeof(u32) * n_bins, s);
-    u64 want = (n_files * kLanesPerFile + 255) / 256;
-    const u32 grid = (u32)(want < 1024 ? want : 1024);
+    u64 want = (n_max + 255) / 256;
+    const u32 grid = (u32)(want < 2048 ? (want ? want : 1) : 2048);
     hipLaunchKernelGGL(compact_chunks_kernel, dim3(grid), dim3(256), 0, s, d_file_off, d_slot_base,
-                       d_slot_ends, d_n_chunks, d_first, n_files, d_chunk_off, d_chunk_len,
-                       d_chunk_file, d_chunk_start, d_hist, n_bins, bin_shift);
+                       d_slot_ends, d_n_chunks, d_first, n_files, n_max, d_n, d_chunk_off,
+                       d_chunk_len, d_chunk_file, d_chunk_start, d_hist, n_bins, bin_shift);
 }
 
 // ---- longest-first processing order (counting sort by block-count bin) -----------
