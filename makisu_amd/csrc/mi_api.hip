@@ -252,12 +252,38 @@ int submit_pipeline(mi_batch* b) {
                         b->q_id.as<u32>(), (u32)cap, d_n, b->heads_chunks.as<u32>(),
                         b->digests.as<u8>(), c->sha_blocks_per_cu, ncu, s);
     HIPCHK(c, hipEventRecord(b->ev[3], s));
-    // per-file roots: SHA-256 over each file's run of chunk digests
-    launch_file_items(b->first.as<u64>(), b->n_chunks_d.as<u32>(), nf, b->item_off.as<u64>(),
-                      b->item_len.as<u64>(), s);
-    launch_sha256_items(kShaRoots, b->digests.as<u8>(), b->item_off.as<u64>(),
-                        b->item_len.as<u64>(), nullptr, (u32)nf, nullptr,
-                        b->heads_files.as<u32>(), b->roots.as<u8>(), c->sha_blocks_per_cu, ncu, s);
+    // per-file chunk roots: fan-out-1024 tree; reduction passes only exist for files with
+    // more than 1024 chunks (> ~9 MiB), the final pass hashes every file's <= 1024 nodes
+    HIPCHK(c, b->root_addr.ensure(nf * 8));
+    HIPCHK(c, b->root_cnt.ensure(nf * 4));
+    launch_root_init(b->digests.as<u8>(), b->first.as<u64>(), b->n_chunks_d.as<u32>(), nf,
+                     b->root_addr.as<u64>(), b->root_cnt.as<u32>(), s);
+    {
+        u64 nodes_ub = cap;                              // upper bound of nodes entering a pass
+        for (int r = 0; r < b->root_passes; ++r) {
+            const u64 out_ub = nodes_ub / 1024 + nf;     // nodes it can produce
+            HIPCHK(c, b->seg_cnt.ensure(nf * 4));
+            HIPCHK(c, b->seg_first.ensure(nf * 8));
+            HIPCHK(c, b->seg_total.ensure(8));
+            HIPCHK(c, b->root_items_off.ensure(out_ub * 8));
+            HIPCHK(c, b->root_items_len.ensure(out_ub * 8));
+            HIPCHK(c, b->root_level[r].ensure(out_ub * 32));
+            launch_root_level(nf, b->root_addr.as<u64>(), b->root_cnt.as<u32>(), b->seg_cnt.as<u32>(),
+                              b->seg_first.as<u64>(), b->seg_total.as<u64>(), b->scratch.as<u64>(),
+                              b->root_level[r].as<u8>(), b->root_items_off.as<u64>(),
+                              b->root_items_len.as<u64>(), s);
+            launch_sha256_items(kShaRoots, nullptr, b->root_items_off.as<u64>(),
+                                b->root_items_len.as<u64>(), nullptr, (u32)out_ub,
+                                b->seg_total.as<u64>(), b->heads_files.as<u32>(),
+                                b->root_level[r].as<u8>(), c->sha_blocks_per_cu, ncu, s);
+            nodes_ub = out_ub;
+        }
+    }
+    launch_root_final_items(b->root_addr.as<u64>(), b->root_cnt.as<u32>(), nf, b->item_off.as<u64>(),
+                            b->item_len.as<u64>(), s);
+    launch_sha256_items(kShaRoots, nullptr, b->item_off.as<u64>(), b->item_len.as<u64>(), nullptr,
+                        (u32)nf, nullptr, b->heads_files.as<u32>(), b->roots.as<u8>(),
+                        c->sha_blocks_per_cu, ncu, s);
     if (c->cfg.flags & MI_FLAG_FILE_SHA256)
         launch_sha256_items(kShaFiles, b->arena.as<u8>(), d_off, d_size, nullptr, (u32)nf, nullptr,
                             b->heads_files.as<u32>(), b->file_sha.as<u8>(), c->sha_blocks_per_cu,
@@ -654,6 +680,14 @@ static int stage_batch(mi_batch* b) {
             live.resize(keep);
         }
     }
+    {
+        u64 mx = 0;
+        for (u64 f = 0; f < nf; ++f) mx = size[f] > mx ? size[f] : mx;
+        u64 nodes = mx / c->cfg.min_size + 2;              // upper bound of a file's chunk count
+        b->root_passes = 0;
+        while (nodes > 1024) { nodes = (nodes + 1023) / 1024; ++b->root_passes; }
+        if (b->root_passes > 3) return fail(c, MI_ERR_INVALID, "file too large for the root tree");
+    }
     b->total_slots = slots;
     b->n_small = (u32)small.size();
     b->n_groups = (u32)gfile.size();
@@ -793,7 +827,9 @@ int mi_batch_free(mi_batch* b) {
     if (b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
     for (auto e : b->ev) if (e) (void)hipEventDestroy(e);
     if (b->h_counts) (void)hipHostFree(b->h_counts);
-    DevBuf* bufs[] = {&b->group_file, &b->group_index, &b->group_prev, &b->group_ticket, &b->group_tokens, &b->tile_file, &b->first_tile, &b->tile_raw, &b->crc_d, &b->heads_chunks, &b->heads_files, &b->dd_rep, &b->dd_minid, &b->dd_slot,
+    DevBuf* bufs[] = {&b->root_addr, &b->root_cnt, &b->seg_cnt, &b->seg_first, &b->seg_total,
+                      &b->root_items_off, &b->root_items_len, &b->root_level[0], &b->root_level[1],
+                      &b->root_level[2], &b->group_file, &b->group_index, &b->group_prev, &b->group_ticket, &b->group_tokens, &b->tile_file, &b->first_tile, &b->tile_raw, &b->crc_d, &b->heads_chunks, &b->heads_files, &b->dd_rep, &b->dd_minid, &b->dd_slot,
                       &b->dd_nuniq, &b->q_off, &b->q_len, &b->q_id,&b->arena, &b->small_list, &b->file_off, &b->file_size, &b->slot_base, &b->cids,
                       &b->slot_ends, &b->n_chunks_d, &b->first, &b->total_d, &b->scratch,
                       &b->chunk_off, &b->chunk_len, &b->chunk_file, &b->chunk_start, &b->hist,

@@ -82,8 +82,15 @@ void launch_compact_chunks(const u64* d_file_off, const u64* d_slot_base, const 
 void launch_bin_order(const u64* d_off, const u64* d_len, u32 n, const u64* d_n, u32* d_hist,
                       u32* d_cursor, u32 n_bins, u32 bin_shift, u64* d_s_off, u64* d_s_len,
                       u32* d_s_id, hipStream_t s);
-void launch_file_items(const u64* d_first, const u32* d_n_chunks, u64 n_files, u64* d_off,
-                       u64* d_len, hipStream_t s);
+// chunk roots: node lists as (absolute device address, digest count) per file; one
+// launch_root_level per reduction pass (files with > 1024 nodes), then the final items
+void launch_root_init(const u8* d_digests, const u64* d_first, const u32* d_n_chunks, u64 n_files,
+                      u64* d_cur_addr, u32* d_cur_cnt, hipStream_t s);
+void launch_root_level(u64 n_files, u64* d_cur_addr, u32* d_cur_cnt, u32* d_seg_cnt, u64* d_seg_first,
+                       u64* d_seg_total, u64* d_scratch, u8* d_level_out, u64* d_item_off,
+                       u64* d_item_len, hipStream_t s);
+void launch_root_final_items(const u64* d_cur_addr, const u32* d_cur_cnt, u64 n_files, u64* d_off,
+                             u64* d_len, hipStream_t s);
 // crc32.hip: constant block layout (u32 words) + launcher + host helpers for path strings
 constexpr u32 kCrcPow1kOff = 1024, kCrcPowBytesOff = 1024 + 65, kCrcConstWords = 1024 + 65 + 1025;
 void crc32_build_tables(u32* out /* kCrcConstWords */);

@@ -82,6 +82,10 @@ struct mi_batch {
     mi::DevBuf chunk_off, chunk_len, chunk_file, chunk_start, hist, cursor, digests;
     mi::DevBuf q_off, q_len, q_id;           // SHA queue descriptors, longest chunk first
     mi::DevBuf item_off, item_len, roots, file_sha, dup_of;
+    mi::DevBuf root_addr, root_cnt, seg_cnt, seg_first, seg_total, root_items_off, root_items_len;
+    mi::DevBuf root_level[3];            // node digests of the reduction passes
+    int root_passes = 0;                 // reduction passes this batch can need (from max file size)
+    mi::u64 max_file_size = 0;
     mi::DevBuf heads_chunks, heads_files;    // SHA queue heads (one set per concurrent launch)
     mi::DevBuf tile_file, first_tile, tile_raw, crc_d;   // MI_FLAG_FILE_CRC32
     mi::u64 n_tiles = 0;

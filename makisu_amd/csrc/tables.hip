@@ -266,21 +266,84 @@ void launch_bin_order(const u64* d_off, const u64* d_len, u32 n, const u64* d_n,
                        n, d_n, d_cursor, n_bins, bin_shift, d_s_off, d_s_len, d_s_id);
 }
 
-// ---- per-file root items: string f = digests[first[f] .. +n_chunks[f]) ----------
+// ---- per-file chunk roots -----------------------------------------------------------
+// chunk_root(f): SHA-256 over the file's concatenated chunk digests when it has <= 1024
+// chunks; beyond that a fan-out-1024 tree: REDUCTION passes hash runs of 1024
+// child digests into node digests until <= 1024 nodes are left, the FINAL pass hashes those.
+// A file's current node list is (cur_addr, cur_cnt): absolute device address + digest count.
+constexpr u32 kRootFanout = 1024;
+
 __global__ __launch_bounds__(256)
-void file_items_kernel(const u64* __restrict__ first, const u32* __restrict__ n_chunks, u64 n_files,
-                       u64* __restrict__ off, u64* __restrict__ len) {
+void root_init_kernel(const u8* __restrict__ digests, const u64* __restrict__ first,
+                      const u32* __restrict__ n_chunks, u64 n_files, u64* __restrict__ cur_addr,
+                      u32* __restrict__ cur_cnt) {
     const u64 f = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n_files) return;
-    off[f] = first[f] * 32;
-    len[f] = (u64)n_chunks[f] * 32;
+    cur_addr[f] = (u64)(uintptr_t)digests + first[f] * 32;
+    cur_cnt[f] = n_chunks[f];
 }
 
-void launch_file_items(const u64* d_first, const u32* d_n_chunks, u64 n_files, u64* d_off,
-                       u64* d_len, hipStream_t s) {
+__global__ __launch_bounds__(256)
+void root_level_counts_kernel(const u32* __restrict__ cur_cnt, u64 n_files, u32* __restrict__ seg_cnt) {
+    const u64 f = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_files) return;
+    const u32 c = cur_cnt[f];
+    seg_cnt[f] = c > kRootFanout ? (c + kRootFanout - 1) / kRootFanout : 0;
+}
+
+// items of one reduction pass (absolute addresses), then the file moves on to its node list
+__global__ __launch_bounds__(256)
+void root_level_items_kernel(const u32* __restrict__ seg_cnt, const u64* __restrict__ seg_first,
+                             u64 n_files, u8* __restrict__ level_out, u64* __restrict__ cur_addr,
+                             u32* __restrict__ cur_cnt, u64* __restrict__ item_off,
+                             u64* __restrict__ item_len) {
+    const u64 f = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_files) return;
+    const u32 ns = seg_cnt[f];
+    if (!ns) return;
+    const u64 base = cur_addr[f], s0 = seg_first[f];
+    const u32 cnt = cur_cnt[f];
+    for (u32 j = 0; j < ns; ++j) {
+        const u32 left = cnt - j * kRootFanout;
+        item_off[s0 + j] = base + (u64)j * kRootFanout * 32;
+        item_len[s0 + j] = (u64)(left < kRootFanout ? left : kRootFanout) * 32;
+    }
+    cur_addr[f] = (u64)(uintptr_t)level_out + s0 * 32;
+    cur_cnt[f] = ns;
+}
+
+__global__ __launch_bounds__(256)
+void root_final_items_kernel(const u64* __restrict__ cur_addr, const u32* __restrict__ cur_cnt,
+                             u64 n_files, u64* __restrict__ off, u64* __restrict__ len) {
+    const u64 f = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_files) return;
+    off[f] = cur_addr[f];
+    len[f] = (u64)cur_cnt[f] * 32;
+}
+
+void launch_root_init(const u8* d_digests, const u64* d_first, const u32* d_n_chunks, u64 n_files,
+                      u64* d_cur_addr, u32* d_cur_cnt, hipStream_t s) {
     if (n_files == 0) return;
-    hipLaunchKernelGGL(file_items_kernel, dim3((u32)((n_files + 255) / 256)), dim3(256), 0, s,
-                       d_first, d_n_chunks, n_files, d_off, d_len);
+    hipLaunchKernelGGL(root_init_kernel, dim3((u32)((n_files + 255) / 256)), dim3(256), 0, s, d_digests,
+                       d_first, d_n_chunks, n_files, d_cur_addr, d_cur_cnt);
+}
+
+void launch_root_level(u64 n_files, u64* d_cur_addr, u32* d_cur_cnt, u32* d_seg_cnt, u64* d_seg_first,
+                       u64* d_seg_total, u64* d_scratch, u8* d_level_out, u64* d_item_off,
+                       u64* d_item_len, hipStream_t s) {
+    if (n_files == 0) return;
+    const u32 grid = (u32)((n_files + 255) / 256);
+    hipLaunchKernelGGL(root_level_counts_kernel, dim3(grid), dim3(256), 0, s, d_cur_cnt, n_files, d_seg_cnt);
+    launch_scan_counts(d_seg_cnt, d_seg_first, d_seg_total, n_files, d_scratch, s);
+    hipLaunchKernelGGL(root_level_items_kernel, dim3(grid), dim3(256), 0, s, d_seg_cnt, d_seg_first, n_files,
+                       d_level_out, d_cur_addr, d_cur_cnt, d_item_off, d_item_len);
+}
+
+void launch_root_final_items(const u64* d_cur_addr, const u32* d_cur_cnt, u64 n_files, u64* d_off,
+                             u64* d_len, hipStream_t s) {
+    if (n_files == 0) return;
+    hipLaunchKernelGGL(root_final_items_kernel, dim3((u32)((n_files + 255) / 256)), dim3(256), 0, s,
+                       d_cur_addr, d_cur_cnt, n_files, d_off, d_len);
 }
 
 // ---- duplicate marking over a digest set -----------------------------------------

@@ -366,6 +366,30 @@ typedef struct {
     uint64_t next;              /* atomic file cursor */
 } scan_job;
 
+/* chunk_root: SHA-256 over the concatenated chunk digests for files of up to 1024 chunks;
+ * beyond that a tree with fan-out 1024 (each node = SHA-256 over up to 1024 consecutive child
+ * digests), repeated until at most 1024 nodes remain, whose concatenation is hashed.  The tree
+ * keeps the root of a multi-GiB file from being one serial million-block SHA-256 stream. */
+void mi_ref_chunk_root(const uint8_t* digests, uint64_t n, uint8_t out[32], int allow_shani) {
+    const uint64_t F = 1024;
+    uint8_t* owned = NULL;
+    const uint8_t* cur = digests;
+    while (n > F) {
+        uint64_t m = (n + F - 1) / F;
+        uint8_t* next = (uint8_t*)malloc((size_t)m * 32);
+        for (uint64_t g = 0; g < m; g++) {
+            uint64_t cnt = n - g * F < F ? n - g * F : F;
+            mi_ref_sha256(cur + g * F * 32, (size_t)cnt * 32, next + g * 32, allow_shani);
+        }
+        free(owned);
+        owned = next;
+        cur = next;
+        n = m;
+    }
+    mi_ref_sha256(cur, (size_t)n * 32, out, allow_shani);
+    free(owned);
+}
+
 static void scan_one(scan_job* j, uint64_t f) {
     const uint8_t* d = j->data + j->offsets[f];
     const uint64_t len = j->sizes[f];
@@ -374,13 +398,10 @@ static void scan_one(scan_job* j, uint64_t f) {
     mi_ref_chunk* out = j->slots + j->slot_base[f];
     /* streaming two-phase: mark + select in one pass, O(1) memory */
     uint64_t h = 0, last = 0, n = 0;
-    mi_ref_sha256_ctx root;
-    mi_ref_sha256_init(&root, j->allow_shani);
 #define CUT(e) do { \
         out[n].file_index = f; out[n].offset = last; out[n].length = (uint32_t)((e) - last); \
         out[n].dup_of = -1; \
         mi_ref_sha256(d + last, (size_t)((e) - last), out[n].sha256, j->allow_shani); \
-        mi_ref_sha256_update(&root, out[n].sha256, 32); \
         n++; last = (e); } while (0)
     for (uint64_t i = 0; i < len; i++) {
         h = (h << 1) + j->table[d[i]];
@@ -392,7 +413,12 @@ static void scan_one(scan_job* j, uint64_t f) {
     if (len > last) CUT(len);
 #undef CUT
     fo->n_chunks = n;
-    mi_ref_sha256_final(&root, fo->chunk_root);
+    {
+        uint8_t* dg = (uint8_t*)malloc((size_t)(n ? n : 1) * 32);
+        for (uint64_t k = 0; k < n; k++) memcpy(dg + 32 * k, out[k].sha256, 32);
+        mi_ref_chunk_root(dg, n, fo->chunk_root, j->allow_shani);
+        free(dg);
+    }
     if (j->flags & MI_REF_FILE_SHA256) mi_ref_sha256(d, (size_t)len, fo->file_sha256, j->allow_shani);
     if (j->flags & MI_REF_FILE_CRC32) fo->crc32 = mi_ref_crc32(0, d, (size_t)len);
 }

@@ -115,7 +115,7 @@ typedef struct {
 typedef struct {
     uint64_t n_chunks;
     uint64_t first_chunk;
-    uint8_t  chunk_root[32];   /* SHA-256 over the concatenated chunk digests */
+    uint8_t  chunk_root[32];   /* mi_ref_chunk_root over the file's chunk digests */
     uint8_t  file_sha256[32];  /* SHA-256 of the file bytes */
     uint32_t crc32;            /* CRC32-IEEE of the file bytes */
 } mi_ref_file;
@@ -132,6 +132,10 @@ uint64_t mi_ref_scan_batch(const uint8_t* data, const uint64_t* offsets,
                            const mi_ref_cdc_params* p, int allow_shani,
                            int n_threads, int flags, mi_ref_file* files,
                            mi_ref_chunk* chunks, uint64_t chunk_cap);
+
+/* chunk_root of n chunk digests (n x 32 bytes): SHA-256 over their concatenation when
+ * n <= 1024, else a fan-out-1024 tree of SHA-256 nodes (DESIGN.md "chunk_root"). */
+void mi_ref_chunk_root(const uint8_t* digests, uint64_t n, uint8_t out[32], int allow_shani);
 
 /* Marks dup_of over an arbitrary digest list (n x 32 bytes): dup_of[i] =
  * smallest j < i with equal digest, else -1.  Returns the unique count. */

@@ -87,6 +87,8 @@ def lib():
         L.mi_ref_scan_batch.argtypes = [C.c_void_p, u64p, u64p, C.c_uint64, C.POINTER(CdcParams),
                                         C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64]
         L.mi_ref_scan_batch.restype = C.c_uint64
+        L.mi_ref_chunk_root.argtypes = [C.c_void_p, C.c_uint64, u8p, C.c_int]
+        L.mi_ref_chunk_root.restype = None
         L.mi_ref_dedup.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
         L.mi_ref_dedup.restype = C.c_uint64
         L.mi_ref_layer_scan.argtypes = [C.c_void_p, u64p, u64p, C.c_void_p, C.c_uint64, C.c_int, u8p]
@@ -197,6 +199,13 @@ def scan_batch(data, offsets, sizes, params, allow_shani=True, n_threads=1,
         raise ValueError("invalid CDC params")
     assert total <= cap
     return files[:n].copy(), chunks[:total].copy()
+
+
+def chunk_root(digests, allow_shani=True):
+    d = np.ascontiguousarray(digests, dtype=np.uint8).reshape(-1, 32)
+    out = (C.c_uint8 * 32)()
+    lib().mi_ref_chunk_root(d.ctypes.data if d.size else None, d.shape[0], out, int(allow_shani))
+    return bytes(out)
 
 
 def dedup(digests):
