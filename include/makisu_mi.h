@@ -245,6 +245,13 @@ int mi_batch_add_tree(mi_batch* b, const char* root, const char* rel_base,
                       const char* const* blacklist, uint64_t n_blacklist, uint32_t mode,
                       uint64_t* n_entries);
 int mi_batch_tree_entries(mi_batch* b, mi_tree_entry* out, uint64_t cap);
+/* The same walk on its own -- no ctx, no GPU: lists what mi_batch_add_tree WOULD add and in
+ * which order (file_index = running ordinal of the regular files).  Host logic only.      */
+typedef struct mi_tree mi_tree;
+int  mi_tree_walk(const char* root, const char* rel_base, const char* const* blacklist,
+                  uint64_t n_blacklist, uint32_t mode, mi_tree** out, uint64_t* n_entries);
+int  mi_tree_entries(const mi_tree* tree, mi_tree_entry* out, uint64_t cap);
+void mi_tree_free(mi_tree* tree);
 /* mi_context_checksum over the recorded walk (the batch must have run).                */
 int mi_context_checksum_tree(mi_batch* b, const void* prefix, uint64_t prefix_len,
                              uint32_t* crc_out);

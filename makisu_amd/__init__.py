@@ -138,6 +138,10 @@ def load_library(rebuild=False):
                                u64p], C.c_int),
         "mi_batch_tree_entries": ([vp, C.POINTER(TreeEntry), u64], C.c_int),
         "mi_context_checksum_tree": ([vp, vp, u64, C.POINTER(C.c_uint32)], C.c_int),
+        "mi_tree_walk": ([C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), u64, C.c_uint32,
+                          C.POINTER(vp), u64p], C.c_int),
+        "mi_tree_entries": ([vp, C.POINTER(TreeEntry), u64], C.c_int),
+        "mi_tree_free": ([vp], None),
         "mi_comm_unique_id": ([vp], C.c_int),
         "mi_comm_init_rank": ([vp, C.c_int, C.c_int, vp], C.c_int),
         "mi_comm_init_all": ([C.POINTER(vp), C.c_int], C.c_int),
@@ -167,6 +171,27 @@ class Digest(str):
 
     def hex(self):                      # Digest.Hex()
         return self[self.index(":") + 1:]
+
+
+def tree_walk(root, rel_base=None, blacklist=(), mode=TREE_CONTEXT):
+    """The reference's directory walk on its own (host logic, no GPU): list of
+    (relpath, link_target, file_ordinal, size, kind, mode) in visit order."""
+    L = load_library()
+    bl = (C.c_char_p * max(len(blacklist), 1))(*[os.fsencode(x) for x in blacklist])
+    h, n = C.c_void_p(), C.c_uint64()
+    rc = L.mi_tree_walk(os.fsencode(root), os.fsencode(rel_base) if rel_base else None, bl,
+                        len(blacklist), mode, C.byref(h), C.byref(n))
+    if rc:
+        raise MiError(rc, "mi_tree_walk(%s)" % root)
+    try:
+        arr = (TreeEntry * max(n.value, 1))()
+        rc = L.mi_tree_entries(h, arr, n.value)
+        if rc:
+            raise MiError(rc, "mi_tree_entries")
+        return [(os.fsdecode(e.relpath), os.fsdecode(e.link_target) if e.link_target else None,
+                 e.file_index, e.size, e.kind, e.mode) for e in arr[:n.value]]
+    finally:
+        L.mi_tree_free(h)
 
 
 def default_config(**overrides):

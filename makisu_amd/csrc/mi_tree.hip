@@ -32,7 +32,7 @@
 #include <string>
 #include <vector>
 
-namespace mi_tree {
+namespace mi_walk {
 
 struct Entry {
     std::string relpath, link;
@@ -116,6 +116,7 @@ struct Walker {
     Tree* tree;
     std::string err;
     int rc = MI_OK;
+    int64_t n_regular = 0;
 
     bool should_skip(const std::string& path, const struct stat& st) {
         const bool special = S_ISCHR(st.st_mode) || S_ISBLK(st.st_mode) || S_ISFIFO(st.st_mode) || S_ISSOCK(st.st_mode);
@@ -167,19 +168,24 @@ struct Walker {
         } else {
             e.kind = 1;
             e.size = (uint64_t)st.st_size;
-            uint64_t nf = 0;
-            mi_batch_counts(batch, &nf, nullptr, nullptr);
-            e.file_index = (int64_t)nf;
-            int r = mi_batch_add_path(batch, path.c_str(), e.size, tree->entries.size());
-            if (r) { rc = r; return; }                      // message already on the ctx
+            if (batch) {
+                uint64_t nf = 0;
+                mi_batch_counts(batch, &nf, nullptr, nullptr);
+                e.file_index = (int64_t)nf;
+                int r = mi_batch_add_path(batch, path.c_str(), e.size, tree->entries.size());
+                if (r) { rc = r; return; }                  // message already on the ctx
+            } else {
+                e.file_index = n_regular;                   // listing only: running file ordinal
+            }
+            ++n_regular;
             tree->entries.push_back(e);
         }
     }
 };
 
-}  // namespace mi_tree
+}  // namespace mi_walk
 
-using mi_tree::Tree;
+using mi_walk::Tree;
 
 // the batch keeps its tree behind an opaque pointer (mi_api.hip owns the slot)
 extern "C" void** mi_batch_tree_slot(mi_batch* b);
@@ -193,7 +199,7 @@ int mi_batch_add_tree(mi_batch* b, const char* root, const char* rel_base, const
     void** slot = mi_batch_tree_slot(b);
     if (!*slot) *slot = new Tree();
     Tree* t = (Tree*)*slot;
-    mi_tree::Walker w;
+    mi_walk::Walker w;
     w.batch = b;
     w.rel_base = rel_base ? rel_base : root;
     w.mode = mode;
@@ -210,13 +216,9 @@ int mi_batch_add_tree(mi_batch* b, const char* root, const char* rel_base, const
     return MI_OK;
 }
 
-int mi_batch_tree_entries(mi_batch* b, mi_tree_entry* out, uint64_t cap) {
-    if (!b || (!out && cap)) return MI_ERR_INVALID;
-    Tree* t = (Tree*)*mi_batch_tree_slot(b);
-    const uint64_t n = t ? t->entries.size() : 0;
-    if (cap < n) { mi_set_error(b, "tree entry buffer too small"); return MI_ERR_CAPACITY; }
+static void fill_entries(const Tree* t, mi_tree_entry* out, uint64_t n) {
     for (uint64_t i = 0; i < n; ++i) {
-        const mi_tree::Entry& e = t->entries[i];
+        const mi_walk::Entry& e = t->entries[i];
         out[i].relpath = e.relpath.c_str();
         out[i].link_target = e.has_link ? e.link.c_str() : nullptr;
         out[i].file_index = e.file_index;
@@ -225,6 +227,44 @@ int mi_batch_tree_entries(mi_batch* b, mi_tree_entry* out, uint64_t cap) {
         out[i].mode = e.mode;
         out[i].kind = e.kind;
     }
+}
+
+// ---- the walk on its own (no ctx, no GPU): what the engine WOULD add, in which order -------
+int mi_tree_walk(const char* root, const char* rel_base, const char* const* blacklist,
+                 uint64_t n_blacklist, uint32_t mode, mi_tree** out, uint64_t* n_entries) {
+    if (!root || !out || (n_blacklist && !blacklist) || mode > MI_TREE_SCAN) return MI_ERR_INVALID;
+    Tree* t = new Tree();
+    mi_walk::Walker w;
+    w.batch = nullptr;
+    w.rel_base = rel_base ? rel_base : root;
+    w.mode = mode;
+    w.tree = t;
+    for (uint64_t i = 0; i < n_blacklist; ++i) w.blacklist.push_back(blacklist[i]);
+    std::string r = root;
+    while (r.size() > 1 && r.back() == '/') r.pop_back();
+    w.visit(r);
+    if (w.rc) { delete t; return w.rc; }
+    *out = (mi_tree*)t;
+    if (n_entries) *n_entries = t->entries.size();
+    return MI_OK;
+}
+
+int mi_tree_entries(const mi_tree* tree, mi_tree_entry* out, uint64_t cap) {
+    if (!tree || (!out && cap)) return MI_ERR_INVALID;
+    const Tree* t = (const Tree*)tree;
+    if (cap < t->entries.size()) return MI_ERR_CAPACITY;
+    fill_entries(t, out, t->entries.size());
+    return MI_OK;
+}
+
+void mi_tree_free(mi_tree* tree) { delete (Tree*)tree; }
+
+int mi_batch_tree_entries(mi_batch* b, mi_tree_entry* out, uint64_t cap) {
+    if (!b || (!out && cap)) return MI_ERR_INVALID;
+    Tree* t = (Tree*)*mi_batch_tree_slot(b);
+    const uint64_t n = t ? t->entries.size() : 0;
+    if (cap < n) { mi_set_error(b, "tree entry buffer too small"); return MI_ERR_CAPACITY; }
+    if (n) fill_entries(t, out, n);
     return MI_OK;
 }
 
@@ -233,7 +273,7 @@ int mi_context_checksum_tree(mi_batch* b, const void* prefix, uint64_t prefix_le
     Tree* t = (Tree*)*mi_batch_tree_slot(b);
     std::vector<mi_ctx_entry> es(t ? t->entries.size() : 0);
     for (size_t i = 0; i < es.size(); ++i) {
-        const mi_tree::Entry& e = t->entries[i];
+        const mi_walk::Entry& e = t->entries[i];
         es[i].relpath = e.relpath.c_str();
         es[i].link_target = e.has_link ? e.link.c_str() : nullptr;
         es[i].file_index = e.file_index;
