@@ -169,6 +169,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # Outside the timed region: a few SERIAL steps (one batch at a time) so the dominant
+    # kernel's launch duration can also be read without another batch sharing the GPU.
+    serial_sha_ms = []
+    if args.inflight > 1:
+        for _ in range(3):
+            batches[0].submit()
+            batches[0].wait()
+            serial_sha_ms.append(eng.stats()["ms_sha_chunks"])
+
     st = eng.stats()
     bytes_per_gpu = st["bytes_in"]
     n_chunks = st["n_chunks"]
@@ -208,11 +217,22 @@ def main():
                      "valu_roof_GBps": SHA_VALU_ROOF_GBPS,
                      "frac_of_valu_roof": round(achieved / SHA_VALU_ROOF_GBPS, 4),
                      "note": "SHA-256 is integer-VALU bound on CDNA4 (measured roof 1.77 TB/s "
-                             "hashed, tools/ubench_sha.hip); the HBM fraction cannot exceed 0.22"},
+                             "hashed, tools/ubench_sha.hip); the HBM fraction cannot exceed 0.22. "
+                             "achieved/avg_launch_ms are from the timed region, where the kernel "
+                             "shares the GPU with the other in-flight batch's Gear pass; "
+                             "serial_* = the same kernel with one batch at a time (3 extra "
+                             "untimed steps)"},
         "phase_ms_avg": {k: round(v / args.steps, 4) for k, v in sorted(stats_sum.items())},
         "phase_note": "per-batch stream timelines; with 2 batches in flight a phase's span includes "
                       "time it shared the GPU with the other batch",
     }
+    if serial_sha_ms:
+        s_ms = float(np.mean(serial_sha_ms))
+        s_ach = alg_bytes / (s_ms * 1e-3) / 1e9
+        out["roofline"].update({"serial_avg_launch_ms": round(s_ms, 4),
+                                "serial_achieved": round(s_ach, 1),
+                                "serial_frac": round(s_ach / HBM_PEAK_GBPS, 4),
+                                "serial_frac_of_valu_roof": round(s_ach / SHA_VALU_ROOF_GBPS, 4)})
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
