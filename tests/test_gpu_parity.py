@@ -747,3 +747,46 @@ def test_chunk_root_definition(oracle):
             nodes = b"".join(hashlib.sha256(d[i:i + 1024].tobytes()).digest() for i in range(0, n, 1024))
             want = hashlib.sha256(nodes).digest()
         assert oracle.chunk_root(d) == want
+
+
+def test_plain_c_consumer(oracle, tmp_path):
+    """The C ABI used from plain C (tests/cabi/driver.c, gcc + -lmakisu_mi) the way the cgo shim
+    would: files by path, one batch, result tables printed as text; compared with hashlib / zlib
+    and the oracle's cut points."""
+    import hashlib
+    import os
+    import subprocess
+    import zlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "driver")
+    subprocess.check_call(["gcc", "-O1", "-Wall", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cabi", "driver.c"), "-o", exe,
+                           "-L", os.path.join(root, "makisu_amd"), "-lmakisu_mi",
+                           "-Wl,-rpath," + os.path.join(root, "makisu_amd")])
+    blobs = [oracle.synth_fill(SEED, 700 + i, 0, n).tobytes() for i, n in enumerate([200000, 0, 65536, 1])]
+    blobs.append(blobs[0])                                  # a duplicate file
+    paths = []
+    for i, blob in enumerate(blobs):
+        p = tmp_path / ("in%d.bin" % i)
+        p.write_bytes(blob)
+        paths.append(str(p))
+    out = subprocess.run([exe] + paths, check=True, capture_output=True, text=True)
+    frows = [l.split() for l in out.stdout.splitlines() if l.startswith("F ")]
+    crows = [l.split() for l in out.stdout.splitlines() if l.startswith("C ")]
+    assert len(frows) == len(blobs)
+    for blob, r in zip(blobs, frows):
+        assert int(r[2]) == len(blob)
+        assert r[5] == "sha256:" + hashlib.sha256(blob).hexdigest()          # image.Digest format
+        assert r[6] == "%x" % zlib.crc32(blob)
+    data = np.frombuffer(b"".join(blobs), dtype=np.uint8)
+    sizes = [len(b) for b in blobs]
+    offs = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+    rf, rc = oracle.scan_batch(data, offs, sizes, oracle.CdcParams(SEED, 13, 2048, 65536))
+    assert [(int(r[1]), int(r[2]), int(r[3]), int(r[4]), r[5]) for r in crows] == \
+        [(int(c["file_index"]), int(c["offset"]), int(c["length"]), int(c["dup_of"]),
+          "sha256:" + c["sha256"].tobytes().hex()) for c in rc]
+    assert [r[4] for r in frows] == ["sha256:" + f["chunk_root"].tobytes().hex() for f in rf]
+    assert "unique" in out.stderr
+    # error behaviour: a missing path is reported through mi_last_error, exit code 1
+    bad = subprocess.run([exe, str(tmp_path / "nope")], capture_output=True, text=True)
+    assert bad.returncode == 1
