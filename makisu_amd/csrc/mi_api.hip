@@ -21,6 +21,7 @@
 #include <string.h>
 #include <unistd.h>
 
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -577,7 +578,10 @@ int mi_batch_add_bytes(mi_batch* b, const void* data, uint64_t len, uint64_t use
     rc = batch_add_common(b, len, user_tag, &at);
     if (rc) return rc;
     if (len == 0) return MI_OK;
-    return staging_append(b, at, (const u8*)data, -1, 0, len, nullptr);
+    const auto t0 = std::chrono::steady_clock::now();
+    rc = staging_append(b, at, (const u8*)data, -1, 0, len, nullptr);
+    b->ms_h2d += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
 }
 
 int mi_batch_add_path(mi_batch* b, const char* path, uint64_t size, uint64_t user_tag) {
@@ -591,7 +595,9 @@ int mi_batch_add_path(mi_batch* b, const char* path, uint64_t size, uint64_t use
     u64 at;
     rc = batch_add_common(b, size, user_tag, &at);
     if (rc == MI_OK && size) {
+        const auto t0 = std::chrono::steady_clock::now();
         rc = staging_append(b, at, nullptr, fd, 0, size, path);
+        b->ms_h2d += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         if (rc) {                                   // undo the registration: the file is unusable
             b->total_bytes -= size;                 // (its arena range stays reserved, unused)
             b->files.pop_back();
@@ -636,9 +642,12 @@ int mi_batch_add_synthetic(mi_batch* b, uint64_t n_files, const uint64_t* sizes,
 static int stage_batch(mi_batch* b) {
     mi_ctx* c = b->ctx;
     if (b->staged) return MI_OK;
+    const auto t0 = std::chrono::steady_clock::now();
     int rc = staging_flush(b);
     if (rc) return rc;
     for (auto s : c->copy_streams) HIPCHK(c, hipStreamSynchronize(s));
+    if (b->staged_any)          // host->device staging time: ring memcpy/pread + waits + final drain
+        b->ms_h2d += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     const u64 nf = b->files.size();
     std::vector<u64> off(nf), size(nf), slot(nf);
     std::vector<u32> small, gfile, gindex, gprev, large;
