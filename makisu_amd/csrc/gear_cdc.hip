@@ -49,7 +49,39 @@ constexpr int kLaneRun     = kGearTile / 64;            // 1 KiB per lane
 constexpr int kPiece       = 128;                       // bytes per load group (one cache line)
 constexpr int kBitmapWords = kGearTile / 32;            // u32 words per wave bitmap (8 KiB)
 constexpr int kTableBytes  = 256 * 8 * kCopies;
-constexpr int kGearLdsBytes = kTableBytes + kWavesPerWG * kBitmapWords * 4;
+// LDS: table | one bitmap per wave | one 64-entry candidate list per wave | fast flags
+constexpr int kLdsListOff  = kTableBytes + kWavesPerWG * kBitmapWords * 4;
+constexpr int kLdsFastOff  = kLdsListOff + kWavesPerWG * 64 * 4;
+constexpr int kGearLdsBytes = kLdsFastOff + 16;
+constexpr u32 kNoCand = 0xFFFFFFFFu;
+
+// ---- fast path for cut selection: a tile's candidates as ONE sorted 64-entry list ----------
+// While marking, a lane also packs up to three candidates of its run into one VGPR (10-bit
+// run offsets, count in bits 30..31).  If no lane overflowed and the tile has <= 64
+// candidates (mask 13 bits: ~8 expected), the wave compacts them -- ballot + popcount prefix
+// sums over the 2-bit counts -- into a sorted list in LDS; selection then needs one ballot per
+// cut instead of a bitmap search.  Otherwise the bitmap (exact for any density) is used.
+__device__ __forceinline__ void cand_push(u32& pk, bool& ovf, u32 o) {
+    const u32 cnt = pk >> 30;
+    if (cnt < 3) pk = ((cnt + 1) << 30) | (((pk & 0x3FFFFFFFu) << 10) | o);
+    else ovf = true;
+}
+
+// returns true (wave-uniform) when `list` holds the tile's candidates (tile-relative byte
+// indices, ascending, padded with kNoCand)
+__device__ __forceinline__ bool cand_compact(u32 pk, bool ovf, u32 run0, int lane, u32* list) {
+    const u32 cnt = pk >> 30;
+    const u64 b0 = __ballot(cnt & 1u), b1 = __ballot(cnt & 2u);
+    const u32 total = (u32)__popcll(b0) + 2u * (u32)__popcll(b1);
+    if (__ballot(ovf) || total > 64u) return false;
+    const u64 below = (1ull << lane) - 1ull;
+    const u32 first = (u32)__popcll(b0 & below) + 2u * (u32)__popcll(b1 & below);
+    list[lane] = kNoCand;
+#pragma unroll
+    for (u32 k = 0; k < 3; ++k)                          // field cnt-1-k holds my k-th (ascending) one
+        if (k < cnt) list[first + k] = run0 + ((pk >> (10 * (cnt - 1 - k))) & 1023u);
+    return true;
+}
 
 // first set bit of an LDS bitmap within [lo, hi] (bit indices, inclusive), -1 if none.
 // Executed by one full wave; all lanes return the same value.
@@ -90,14 +122,18 @@ __device__ __forceinline__ void load_piece(const u8* p, u32x4 (&d)[8]) {
 
 // One wave marks the candidates of tile [ts, ts+tlen) of a file into `bitmap`
 // (bit p <-> cut end ts + p + 1).  fptr is 16-byte aligned, ts a multiple of kGearTile.
+// pk/ovf: the lane's packed candidates for the fast selection path (cand_push / cand_compact).
 __device__ __forceinline__ void mark_tile(const u8* __restrict__ fptr, u64 ts, u32 tlen,
-                                          u32* bitmap, const u64* tab, u32 thresh_m1, int lane) {
+                                          u32* bitmap, const u64* tab, u32 thresh_m1, int lane,
+                                          u32& pk, bool& ovf) {
     {   // clear the bitmap: 32 words per lane
         u32x4* bz = (u32x4*)bitmap;
         const u32x4 z = {0, 0, 0, 0};
 #pragma unroll
         for (int i = 0; i < kBitmapWords / 4 / 64; ++i) bz[i * 64 + lane] = z;
     }
+    pk = 0;
+    ovf = false;
     const u32 run0 = (u32)lane * kLaneRun;               // tile-relative start of my run
     if (run0 >= tlen) return;
     const u8* p = fptr + ts + run0;
@@ -126,8 +162,10 @@ __device__ __forceinline__ void mark_tile(const u8* __restrict__ fptr, u64 ts, u
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
                     const u32 pos = run0 + pc * kPiece + g * 16 + k;            // byte index in tile
-                    if (hh[k] <= thresh_m1 && pos < tlen)
+                    if (hh[k] <= thresh_m1 && pos < tlen) {
                         atomicOr(&bitmap[pos >> 5], 1u << (pos & 31));
+                        cand_push(pk, ovf, pos - run0);
+                    }
                 }
             }
         }
@@ -137,17 +175,27 @@ __device__ __forceinline__ void mark_tile(const u8* __restrict__ fptr, u64 ts, u
 }
 
 // Wave-uniform cut selection over one marked tile; appends chunk ends, updates last/n_out.
-__device__ __forceinline__ void select_tile(const u32* bitmap, u64 ts, u32 tlen, const CdcParams& p,
-                                            u64& last, u32& n_out, u64* __restrict__ ends, int lane) {
+// `list` != nullptr: the tile's sorted candidate list (cand_compact succeeded) -- one ballot per
+// cut; otherwise the bitmap is searched.
+__device__ __forceinline__ void select_tile(const u32* bitmap, const u32* list, u64 ts, u32 tlen,
+                                            const CdcParams& p, u64& last, u32& n_out,
+                                            u64* __restrict__ ends, int lane) {
     const u64 te = ts + tlen;                            // ends in this tile: (ts, te]
+    const u32 cand = list ? list[lane] : kNoCand;        // lane i = i-th candidate (ascending)
     for (;;) {
         u64 lo = last + p.min_size;
         if (lo < ts + 1) lo = ts + 1;
         u64 hi = last + p.max_size;
         if (hi > te) hi = te;
         if (lo <= hi) {
-            const int b = bitmap_find_first((const u64*)bitmap, (int)(lo - ts - 1),
-                                            (int)(hi - ts - 1), lane);
+            int b;
+            if (list) {
+                const u32 lo_rel = (u32)(lo - ts - 1), hi_rel = (u32)(hi - ts - 1);
+                const u64 bal = __ballot(cand >= lo_rel && cand <= hi_rel);
+                b = bal ? (int)__shfl(cand, __ffsll((unsigned long long)bal) - 1) : -1;
+            } else {
+                b = bitmap_find_first((const u64*)bitmap, (int)(lo - ts - 1), (int)(hi - ts - 1), lane);
+            }
             if (b >= 0) {
                 last = ts + (u64)b + 1;
                 if (lane == 0) ends[n_out] = last;
@@ -181,6 +229,7 @@ void gear_cdc_small_kernel(const u8* __restrict__ data, const u64* __restrict__ 
     u64* table = (u64*)smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     u32* bitmap = (u32*)(smem + kTableBytes) + wave * kBitmapWords;
+    u32* cand_list = (u32*)(smem + kLdsListOff) + wave * 64;
     load_table(table, gear_table, tid);
     __syncthreads();
     const u32 li = blockIdx.x * kWavesPerWG + wave;
@@ -191,11 +240,15 @@ void gear_cdc_small_kernel(const u8* __restrict__ data, const u64* __restrict__ 
     u64 last = 0;
     u32 n_out = 0;
     if (size) {
-        mark_tile(data + file_off[f], 0, (u32)size, bitmap, table + (lane % kCopies), p.thresh_m1, lane);
+        u32 pk;
+        bool ovf;
+        mark_tile(data + file_off[f], 0, (u32)size, bitmap, table + (lane % kCopies), p.thresh_m1, lane,
+                  pk, ovf);
+        const bool fast = cand_compact(pk, ovf, (u32)lane * kLaneRun, lane, cand_list);
         // the wave's own LDS writes are ordered for the wave itself after the waitcnt the
-        // compiler inserts; no other wave touches this bitmap
+        // compiler inserts; no other wave touches this bitmap / list
         __builtin_amdgcn_wave_barrier();
-        select_tile(bitmap, 0, (u32)size, p, last, n_out, ends, lane);
+        select_tile(bitmap, fast ? cand_list : nullptr, 0, (u32)size, p, last, n_out, ends, lane);
     }
     if (lane == 0) {
         if (size > last) { ends[n_out] = size; ++n_out; }   // the file end always cuts
@@ -231,6 +284,8 @@ void gear_cdc_large_kernel(const u8* __restrict__ data, const u64* __restrict__ 
     u64* table = (u64*)smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     u32* bitmaps = (u32*)(smem + kTableBytes);
+    u32* cand_lists = (u32*)(smem + kLdsListOff);
+    volatile u32* fast_flags = (volatile u32*)(smem + kLdsFastOff);
     // (the ticket word lives in the dynamic region: a static __shared__ would shift its base)
     volatile u32* s_ticket = (volatile u32*)(smem + kGearLdsBytes);
     load_table(table, gear_table, tid);
@@ -248,8 +303,12 @@ void gear_cdc_large_kernel(const u8* __restrict__ data, const u64* __restrict__ 
         const u64 ts = g0 + (u64)wave * kGearTile;
         if (ts < size) {
             const u32 tlen = (u32)((size - ts < (u64)kGearTile) ? (size - ts) : (u64)kGearTile);
+            u32 pk;
+            bool ovf;
             mark_tile(fptr, ts, tlen, bitmaps + wave * kBitmapWords, table + (lane % kCopies),
-                      p.thresh_m1, lane);
+                      p.thresh_m1, lane, pk, ovf);
+            const bool fast = cand_compact(pk, ovf, (u32)lane * kLaneRun, lane, cand_lists + wave * 64);
+            if (lane == 0) fast_flags[wave] = fast ? 1u : 0u;
         }
         __syncthreads();
         if (wave == 0) {
@@ -280,7 +339,8 @@ void gear_cdc_large_kernel(const u8* __restrict__ data, const u64* __restrict__ 
                 const u64 tts = g0 + (u64)t * kGearTile;
                 if (tts >= size) break;
                 const u32 tlen = (u32)((size - tts < (u64)kGearTile) ? (size - tts) : (u64)kGearTile);
-                select_tile(bitmaps + t * kBitmapWords, tts, tlen, p, last, n_out, ends, lane);
+                select_tile(bitmaps + t * kBitmapWords, fast_flags[t] ? cand_lists + t * 64 : nullptr,
+                            tts, tlen, p, last, n_out, ends, lane);
             }
             if (lane == 0) {
                 if (g0 + kGroupBytes >= size) {           // the file's last group

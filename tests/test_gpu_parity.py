@@ -790,3 +790,35 @@ def test_plain_c_consumer(oracle, tmp_path):
     # error behaviour: a missing path is reported through mi_last_error, exit code 1
     bad = subprocess.run([exe, str(tmp_path / "nope")], capture_output=True, text=True)
     assert bad.returncode == 1
+
+
+def test_file_beyond_4gib_offsets(oracle, eng):
+    """One 5 GiB file (every 32-bit offset assumption would break): size-independent properties,
+    the oracle's cuts on the first 48 MiB prefix, and re-hashed spot checks deep inside the file."""
+    import hashlib
+    size = 5 * (1 << 30) + 12345
+    with eng.batch() as b:
+        b.add_synthetic([size, 70000], [77, 78], seed=SEED + 9)
+        b.run()
+        files, chunks = b.files().copy(), b.chunks().copy()
+    big = chunks[chunks["file_index"] == 0]
+    assert int(files["n_chunks"][0]) == len(big) and int(files["size"][0]) == size
+    ends = big["offset"] + big["length"]
+    assert big["offset"][0] == 0 and ends[-1] == size
+    assert np.array_equal(big["offset"][1:], ends[:-1])                       # exact tiling
+    assert big["length"].max() <= 65536 and big["length"][:-1].min() >= 2048
+    assert (big["offset"] > 2**32).sum() > 1000                               # really beyond 4 GiB
+    # cut points are prefix-stable: the oracle on a 48 MiB prefix must reproduce every cut whose
+    # chunk ends well before the prefix end
+    n_pre = 48 << 20
+    pre = oracle.synth_fill(SEED + 9, 77, 0, n_pre)
+    want = oracle.cdc_two_phase(pre, oracle.CdcParams(SEED, 13, 2048, 65536))
+    keep = want[want < n_pre - 65536]
+    assert np.array_equal(ends[: len(keep)], keep)
+    rng = np.random.default_rng(1)
+    for i in list(rng.integers(0, len(big), 24)) + [len(big) - 1, int(np.searchsorted(big["offset"], 2**32))]:
+        row = big[i]
+        blob = oracle.synth_fill(SEED + 9, 77, int(row["offset"]), int(row["length"]))
+        assert row["sha256"].tobytes() == hashlib.sha256(blob.tobytes()).digest(), int(row["offset"])
+    # the root of a 600k-chunk file goes through the tree; recompute it from the chunk digests
+    assert files["chunk_root"][0].tobytes() == oracle.chunk_root(big["sha256"])
