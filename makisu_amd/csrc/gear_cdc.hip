@@ -28,9 +28,11 @@
 //      op per byte (v_min3_u32 over the high words of 16 consecutive hashes, a slow
 //      path only when the minimum passes the mask); hits set bits in the wave's LDS
 //      bitmap (one bit per byte of the tile);
-//   4. cuts are selected from the bitmap with wave-wide find-first-set (64 lanes x
-//      64 bits per step, __ballot + ctz), carrying last_cut across tiles, and the
-//      chunk ends appended to the file's slot region in HBM.
+//   4. cuts are selected per tile, carrying last_cut across tiles: normally from a sorted
+//      64-entry candidate list the wave compacts out of its lanes' packed candidates
+//      (__ballot + popcount prefix sums) -- one ballot per cut --, and from the bitmap with
+//      wave-wide find-first-set (64 lanes x 64 bits per step, __ballot + ctz) when a tile
+//      has too many candidates for the list; chunk ends go to the file's slot region in HBM.
 // Small files (<= one tile): one wave per file, four files per workgroup, no
 // workgroup barrier at all.  Large files: chained groups of four tiles -- persistent
 // workgroups mark groups in parallel (even within ONE file) and pass the cut state from
