@@ -28,6 +28,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <mutex>
 #include <set>
 #include <string>
 #include <vector>
@@ -89,9 +90,8 @@ static std::string rel_to(const std::string& base, const std::string& path) {   
 
 static const std::set<std::string>& mountpoints() {
     static std::set<std::string> mp;
-    static bool init = false;
-    if (!init) {
-        init = true;
+    static std::once_flag once;                              // like the reference's sync.Once
+    std::call_once(once, [] {
         if (FILE* f = fopen("/proc/mounts", "r")) {
             char line[8192];
             while (fgets(line, sizeof line, f)) {
@@ -104,7 +104,7 @@ static const std::set<std::string>& mountpoints() {
             }
             fclose(f);
         }
-    }
+    });
     return mp;
 }
 
