@@ -264,6 +264,28 @@ int mi_context_checksum_tree(mi_batch* b, const void* prefix, uint64_t prefix_le
 int mi_sha256_many(mi_ctx* ctx, const void* data, const uint64_t* offsets,
                    const uint64_t* lens, uint64_t n, uint8_t* out);
 
+/* ---- chunk index: dedup across batches (keyvalue.Store seam) -------------------- *
+ * A device-resident set of chunk digests that outlives a batch.  The reference
+ * remembers earlier work as content-addressed layers (IsExist + CAS link,
+ * lib/builder/step/common.go:88-91) and as cacheID -> "tarHex,gzipHex" strings
+ * behind keyvalue.Store (lib/cache/keyvalue/store.go:22-26, written at
+ * lib/cache/cache_manager.go:239-252); this is the chunk-granular analogue:
+ * "which chunks of this layer did an earlier layer already hold?".
+ *
+ * mi_index_add_batch: for every chunk of a batch that has run, known[i] = 1 if its
+ * digest was in the index BEFORE the call (an in-batch repeat of a new digest stays
+ * 0 - dup_of already says so), then the new digests are added.  known may be NULL.
+ * mi_index_export / mi_index_import move the set as a flat blob of 32-byte digests
+ * (order unspecified) so the shim can keep it behind keyvalue.Store.Put/Get.      */
+typedef struct mi_index mi_index;
+int  mi_index_create(mi_ctx* ctx, uint64_t capacity_hint, mi_index** out);
+void mi_index_free(mi_index* index);
+int  mi_index_count(mi_index* index, uint64_t* n_digests);
+int  mi_index_add_batch(mi_index* index, mi_batch* b, uint8_t* known, uint64_t cap,
+                        uint64_t* n_new, uint64_t* n_known);
+int  mi_index_export(mi_index* index, void* out_digests, uint64_t cap_digests);
+int  mi_index_import(mi_index* index, const void* digests, uint64_t n, uint64_t* n_new);
+
 #ifdef __cplusplus
 }
 #endif

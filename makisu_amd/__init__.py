@@ -148,6 +148,12 @@ def load_library(rebuild=False):
         "mi_comm_destroy": ([vp], C.c_int),
         "mi_dedup_allgather": ([vp, u64p, u64p, u64p], C.c_int),
         "mi_dedup_allgather_all": ([C.POINTER(vp), C.c_int, u64p, u64p], C.c_int),
+        "mi_index_create": ([vp, u64, C.POINTER(vp)], C.c_int),
+        "mi_index_free": ([vp], None),
+        "mi_index_count": ([vp, u64p], C.c_int),
+        "mi_index_add_batch": ([vp, vp, vp, u64, u64p, u64p], C.c_int),
+        "mi_index_export": ([vp, vp, u64], C.c_int),
+        "mi_index_import": ([vp, vp, u64, u64p], C.c_int),
     }
     for name, (args, res) in sigs.items():
         fn = getattr(L, name)          # AttributeError here = header/library drift
@@ -192,6 +198,57 @@ def tree_walk(root, rel_base=None, blacklist=(), mode=TREE_CONTEXT):
                  e.file_index, e.size, e.kind, e.mode) for e in arr[:n.value]]
     finally:
         L.mi_tree_free(h)
+
+
+class ChunkIndex:
+    """mi_index_*: device-resident digest set; add_batch() says which chunks earlier
+    batches already held, export()/load() move it as bytes (keyvalue.Store value)."""
+
+    def __init__(self, engine, capacity_hint=0):
+        self._eng = engine
+        self._lib = engine._lib
+        self._h = C.c_void_p()
+        engine._check(self._lib.mi_index_create(engine._h, capacity_hint, C.byref(self._h)))
+
+    def __len__(self):
+        n = C.c_uint64()
+        self._eng._check(self._lib.mi_index_count(self._h, C.byref(n)))
+        return n.value
+
+    def add_batch(self, batch):
+        """-> (known flags per chunk as np.uint8, n_new, n_known)."""
+        n = batch.counts()[1]
+        known = np.zeros(max(n, 1), dtype=np.uint8)
+        n_new, n_known = C.c_uint64(), C.c_uint64()
+        self._eng._check(self._lib.mi_index_add_batch(self._h, batch._h, known.ctypes.data, n,
+                                                      C.byref(n_new), C.byref(n_known)))
+        return known[:n], n_new.value, n_known.value
+
+    def export(self):
+        n = len(self)
+        out = np.zeros((max(n, 1), 32), dtype=np.uint8)
+        self._eng._check(self._lib.mi_index_export(self._h, out.ctypes.data, n))
+        return out[:n].tobytes()
+
+    def load(self, blob):
+        if len(blob) % 32:
+            raise ValueError("index blob must be a multiple of 32 bytes")
+        arr = np.frombuffer(blob, dtype=np.uint8)
+        n_new = C.c_uint64()
+        self._eng._check(self._lib.mi_index_import(self._h, arr.ctypes.data if arr.size else None,
+                                                   len(blob) // 32, C.byref(n_new)))
+        return n_new.value
+
+    def close(self):
+        if self._h:
+            self._lib.mi_index_free(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
 
 def default_config(**overrides):
@@ -264,6 +321,10 @@ class Engine:
                                              offs.ctypes.data_as(u64p), lens.ctypes.data_as(u64p),
                                              len(blobs), out.ctypes.data))
         return [out[i].tobytes() for i in range(len(blobs))]
+
+    def index(self, capacity_hint=0):
+        """A chunk-digest set that outlives batches (dedup across layers)."""
+        return ChunkIndex(self, capacity_hint)
 
     # ---- native RCCL exchange (what a Go host would use; bench.py drives torch instead) ----
     @staticmethod

@@ -822,3 +822,55 @@ def test_file_beyond_4gib_offsets(oracle, eng):
         assert row["sha256"].tobytes() == hashlib.sha256(blob.tobytes()).digest(), int(row["offset"])
     # the root of a 600k-chunk file goes through the tree; recompute it from the chunk digests
     assert files["chunk_root"][0].tobytes() == oracle.chunk_root(big["sha256"])
+
+
+def test_chunk_index_across_batches(oracle, eng):
+    """mi_index_*: 'known' = the digest was held before this batch; checked against Python sets of
+    the oracle-verified digests; growth from the minimum table; export -> import round trip."""
+    rng = np.random.default_rng(5)
+    sizes1 = rng.integers(1, 300000, 40).astype(np.uint64)
+    cids1 = np.arange(40, dtype=np.uint64)
+    sizes2 = np.concatenate([sizes1[:15], rng.integers(1, 300000, 25).astype(np.uint64)])
+    cids2 = np.concatenate([cids1[:15], 100 + np.arange(25, dtype=np.uint64)])   # 15 files repeat
+    cids2[20] = cids2[21]                                                         # an in-batch repeat
+    sizes2[20] = sizes2[21]
+    with eng.index() as idx:
+        assert len(idx) == 0
+        _, ch1 = _compare_synth(oracle, eng, sizes1, cids1)
+        with eng.batch() as b:
+            b.add_synthetic(sizes1, cids1, seed=SEED)
+            b.run()
+            known1, new1, nk1 = idx.add_batch(b)
+        set1 = {r.tobytes() for r in ch1["sha256"]}
+        assert new1 == len(set1) > 512                 # grew past the 1024-slot start
+        assert nk1 == 0 and not known1.any() and len(idx) == len(set1)
+        _, ch2 = _compare_synth(oracle, eng, sizes2, cids2)
+        with eng.batch() as b:
+            b.add_synthetic(sizes2, cids2, seed=SEED)
+            b.run()
+            known2, new2, nk2 = idx.add_batch(b)
+            known_again, new_again, _ = idx.add_batch(b)
+        want = np.array([r.tobytes() in set1 for r in ch2["sha256"]], dtype=np.uint8)
+        assert np.array_equal(known2, want)
+        assert nk2 == int(want.sum()) > 0
+        set2 = {r.tobytes() for r in ch2["sha256"]}
+        assert new2 == len(set2 - set1) > 0
+        assert new_again == 0 and known_again.all()
+        blob = idx.export()
+        assert len(blob) == 32 * len(set1 | set2)
+        assert {blob[i:i + 32] for i in range(0, len(blob), 32)} == set1 | set2
+        with eng.index(len(set1)) as idx2:
+            assert idx2.load(blob + blob[:64]) == len(set1 | set2)     # repeats inside the blob are fine
+            assert idx2.load(blob[:320]) == 0
+            with eng.batch() as b:
+                b.add_synthetic(sizes2, cids2, seed=SEED)
+                b.run()
+                k, n_new, n_known = idx2.add_batch(b)
+            assert k.all() and n_new == 0 and n_known == len(ch2)
+
+
+def test_chunk_index_empty_batch(eng):
+    with eng.index() as idx, eng.batch() as b:
+        b.run()
+        k, n_new, n_known = idx.add_batch(b)
+        assert len(k) == 0 and n_new == 0 and n_known == 0 and idx.export() == b""
