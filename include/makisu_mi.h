@@ -239,7 +239,10 @@ typedef struct {
     uint64_t    size;
     int64_t     mtime_sec;     /* truncated to seconds like tario.WriteHeader (write.go:62) */
     uint32_t    mode;          /* st_mode                                                */
-    uint8_t     kind;          /* 0 directory, 1 regular file, 2 symlink                 */
+    uint8_t     kind;          /* 0 directory, 1 regular file, 2 symlink, 3 hard link
+                                  (3 is never produced by the walks; callers that track
+                                  inodes like the reference's snapshot may set it)       */
+    uint32_t    uid, gid;
 } mi_tree_entry;
 int mi_batch_add_tree(mi_batch* b, const char* root, const char* rel_base,
                       const char* const* blacklist, uint64_t n_blacklist, uint32_t mode,
@@ -255,6 +258,19 @@ void mi_tree_free(mi_tree* tree);
 /* mi_context_checksum over the recorded walk (the batch must have run).                */
 int mi_context_checksum_tree(mi_batch* b, const void* prefix, uint64_t prefix_len,
                              uint32_t* crc_out);
+
+/* "Did this path change?" -- tario.IsSimilarHeader (lib/tario/compare.go:24-117), the test
+ * behind MemFS.isUpdated (lib/snapshot/mem_fs.go:487-503), on walk entries: two entries with
+ * empty relpaths are similar; otherwise the kinds must match and symlinks compare their
+ * targets; hard links mtime+target+uid+gid+mode; directories mtime+uid+gid+mode; regular
+ * files mtime+uid+gid+size+mode (mtime at second resolution, skipped when ignore_time;
+ * mode = permission, setuid/setgid/sticky bits).  Content-aware extension: when BOTH roots
+ * are given (32-byte chunk_root of each file) regular files are similar only if the roots
+ * are equal too -- the reference "ignores path and content" (compare.go:101-103) because it
+ * has no cheap content identity; with NULL roots the answer is exactly the reference's.
+ * Unknown kind -> MI_ERR_INVALID (the reference's "unsupported type" error).  Host logic.  */
+int mi_entry_similar(const mi_tree_entry* a, const mi_tree_entry* b, int ignore_time,
+                     const uint8_t* root_a, const uint8_t* root_b, int* similar);
 
 /* ---- standalone digests (image.Digester seam) ---------------------------------- *
  * n independent byte strings -> n SHA-256 digests on the GPU, one lane per string:

@@ -58,7 +58,7 @@ class TreeEntry(C.Structure):
     """mi_tree_entry: one path recorded by mi_batch_add_tree."""
     _fields_ = [("relpath", C.c_char_p), ("link_target", C.c_char_p), ("file_index", C.c_int64),
                 ("size", C.c_uint64), ("mtime_sec", C.c_int64), ("mode", C.c_uint32),
-                ("kind", C.c_uint8)]
+                ("kind", C.c_uint8), ("uid", C.c_uint32), ("gid", C.c_uint32)]
 
 
 TREE_CONTEXT, TREE_SCAN = 0, 1
@@ -142,6 +142,8 @@ def load_library(rebuild=False):
                           C.POINTER(vp), u64p], C.c_int),
         "mi_tree_entries": ([vp, C.POINTER(TreeEntry), u64], C.c_int),
         "mi_tree_free": ([vp], None),
+        "mi_entry_similar": ([C.POINTER(TreeEntry), C.POINTER(TreeEntry), C.c_int, vp, vp,
+                              C.POINTER(C.c_int)], C.c_int),
         "mi_comm_unique_id": ([vp], C.c_int),
         "mi_comm_init_rank": ([vp, C.c_int, C.c_int, vp], C.c_int),
         "mi_comm_init_all": ([C.POINTER(vp), C.c_int], C.c_int),
@@ -179,9 +181,40 @@ class Digest(str):
         return self[self.index(":") + 1:]
 
 
-def tree_walk(root, rel_base=None, blacklist=(), mode=TREE_CONTEXT):
+KIND_DIR, KIND_FILE, KIND_SYMLINK, KIND_HARDLINK = 0, 1, 2, 3
+
+
+def entry_similar(a, b, ignore_time=False, root_a=None, root_b=None):
+    """tario.IsSimilarHeader on two entry dicts (keys: relpath, link_target, size, mtime_sec, mode,
+    kind, uid, gid; missing keys = 0/None), optionally content-aware through 32-byte chunk roots."""
+    def make(d):
+        e = TreeEntry()
+        e.relpath = os.fsencode(d.get("relpath", "x"))
+        lt = d.get("link_target")
+        e.link_target = os.fsencode(lt) if lt is not None else None
+        e.file_index = d.get("file_index", -1)
+        for k in ("size", "mtime_sec", "mode", "kind", "uid", "gid"):
+            setattr(e, k, d.get(k, 0))
+        return e
+    ea, eb, out = make(a), make(b), C.c_int()
+    ra = (C.c_uint8 * 32).from_buffer_copy(bytes(root_a)) if root_a is not None else None
+    rb = (C.c_uint8 * 32).from_buffer_copy(bytes(root_b)) if root_b is not None else None
+    rc = load_library().mi_entry_similar(C.byref(ea), C.byref(eb), int(ignore_time), ra, rb, C.byref(out))
+    if rc:
+        raise MiError(rc, "mi_entry_similar: unsupported type")
+    return bool(out.value)
+
+
+def _entry_dict(e):
+    return {"relpath": os.fsdecode(e.relpath), "link_target": os.fsdecode(e.link_target) if e.link_target else None,
+            "file_index": e.file_index, "size": e.size, "mtime_sec": e.mtime_sec, "mode": e.mode,
+            "kind": e.kind, "uid": e.uid, "gid": e.gid}
+
+
+def tree_walk(root, rel_base=None, blacklist=(), mode=TREE_CONTEXT, full=False):
     """The reference's directory walk on its own (host logic, no GPU): list of
-    (relpath, link_target, file_ordinal, size, kind, mode) in visit order."""
+    (relpath, link_target, file_ordinal, size, kind, mode) in visit order (full=True: dicts
+    with every mi_tree_entry field)."""
     L = load_library()
     bl = (C.c_char_p * max(len(blacklist), 1))(*[os.fsencode(x) for x in blacklist])
     h, n = C.c_void_p(), C.c_uint64()
@@ -194,6 +227,8 @@ def tree_walk(root, rel_base=None, blacklist=(), mode=TREE_CONTEXT):
         rc = L.mi_tree_entries(h, arr, n.value)
         if rc:
             raise MiError(rc, "mi_tree_entries")
+        if full:
+            return [_entry_dict(e) for e in arr[:n.value]]
         return [(os.fsdecode(e.relpath), os.fsdecode(e.link_target) if e.link_target else None,
                  e.file_index, e.size, e.kind, e.mode) for e in arr[:n.value]]
     finally:

@@ -43,6 +43,7 @@ struct Entry {
     uint64_t size = 0;
     int64_t mtime = 0;
     uint8_t kind = 0;      // 0 dir, 1 regular, 2 symlink
+    uint32_t uid = 0, gid = 0;
 };
 
 struct Tree {
@@ -144,6 +145,8 @@ struct Walker {
         }
         e.mode = (uint32_t)st.st_mode;
         e.mtime = (int64_t)st.st_mtime;
+        e.uid = (uint32_t)st.st_uid;
+        e.gid = (uint32_t)st.st_gid;
         if (S_ISDIR(st.st_mode)) {
             e.kind = 0;
             tree->entries.push_back(e);
@@ -226,6 +229,8 @@ static void fill_entries(const Tree* t, mi_tree_entry* out, uint64_t n) {
         out[i].mtime_sec = e.mtime;
         out[i].mode = e.mode;
         out[i].kind = e.kind;
+        out[i].uid = e.uid;
+        out[i].gid = e.gid;
     }
 }
 
@@ -282,5 +287,29 @@ int mi_context_checksum_tree(mi_batch* b, const void* prefix, uint64_t prefix_le
 }
 
 void mi_batch_tree_free(void* tree) { delete (Tree*)tree; }
+
+// tario.IsSimilarHeader (lib/tario/compare.go:24-117) on walk entries, plus the optional
+// content roots (see the header)
+int mi_entry_similar(const mi_tree_entry* a, const mi_tree_entry* b, int ignore_time,
+                     const uint8_t* root_a, const uint8_t* root_b, int* similar) {
+    if (!a || !b || !similar) return MI_ERR_INVALID;
+    auto empty = [](const char* s) { return !s || !*s; };
+    auto same_str = [&](const char* x, const char* y) { return strcmp(x ? x : "", y ? y : "") == 0; };
+    *similar = 0;
+    if (empty(a->relpath) && empty(b->relpath)) { *similar = 1; return MI_OK; }   // "/" is never modified
+    if (a->kind > 3) return MI_ERR_INVALID;                                       // unsupported type
+    if (a->kind != b->kind) return MI_OK;
+    const bool time_eq = ignore_time || a->mtime_sec == b->mtime_sec;
+    const bool owner_mode_eq = a->uid == b->uid && a->gid == b->gid && (a->mode & 07777u) == (b->mode & 07777u);
+    switch (a->kind) {
+    case 2: *similar = same_str(a->link_target, b->link_target); break;
+    case 3: *similar = time_eq && same_str(a->link_target, b->link_target) && owner_mode_eq; break;
+    case 0: *similar = time_eq && owner_mode_eq; break;
+    default:
+        *similar = time_eq && owner_mode_eq && a->size == b->size &&
+                   (!(root_a && root_b) || memcmp(root_a, root_b, 32) == 0);
+    }
+    return MI_OK;
+}
 
 }  // extern "C"

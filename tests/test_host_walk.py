@@ -92,3 +92,95 @@ def test_walk_single_file_and_errors(tree, engine_lib):
     with pytest.raises(makisu_amd.MiError) as ei:       # "write path is outside of context dir" (:205-209)
         makisu_amd.tree_walk(str(tree / "a"), rel_base=str(tree / "z"))
     assert ei.value.code == -1
+
+
+# ---- mi_entry_similar: the cases of lib/tario/compare_test.go, on real lstat results ---------
+def _entries(root):
+    import makisu_amd
+    return {e["relpath"]: e for e in makisu_amd.tree_walk(str(root), full=True)}
+
+
+def _touch(p, t):
+    import os
+    os.utime(p, (t, t), follow_symlinks=False)
+
+
+def test_entry_similar_mirrors_compare_test(tmp_path):
+    import os
+    import time
+    import makisu_amd
+    sim = makisu_amd.entry_similar
+    now = int(time.time())
+    (tmp_path / "dir1").mkdir()
+    (tmp_path / "dir2").mkdir()
+    (tmp_path / "dir2" / "child").write_bytes(b"x")          # DifferentContentConsideredSimilar (dirs)
+    (tmp_path / "f1").write_bytes(b"test1")
+    (tmp_path / "f2").write_bytes(b"test2")                  # same size, different content
+    (tmp_path / "f3").write_bytes(b"test33")
+    os.symlink(str(tmp_path / "f1"), tmp_path / "l1")
+    os.symlink(str(tmp_path / "f1"), tmp_path / "l2")
+    os.symlink(str(tmp_path / "f2"), tmp_path / "l3")
+    for name in ("dir1", "dir2", "f1", "f2", "f3", "l1", "l2", "l3"):
+        _touch(tmp_path / name, now - 7200)
+    e = _entries(tmp_path)
+    # TestIsSimilar
+    assert not sim(e["dir1"], e["f1"])                       # DirAndFileConsideredDifferent
+    assert sim(dict(e["f1"], relpath=""), dict(e["f2"], relpath=""))   # RootsConsideredSimilar
+    assert not sim(e["dir1"], e["l1"])                       # DirAndSymlinkConsideredDifferent
+    assert not sim(e["f1"], e["l1"])                         # FileAndSymlinkConsideredDifferent
+    hard = dict(e["f1"], kind=makisu_amd.KIND_HARDLINK, link_target=str(tmp_path / "f1"), size=0)
+    assert not sim(e["f1"], hard)                            # FileAndHardLinkConsideredDifferent
+    # TestIsSimilarSymlink
+    assert sim(e["l1"], e["l2"]) and sim(e["l1"], e["l2"], ignore_time=True)    # NoChange
+    assert not sim(e["l1"], e["l3"])                         # DifferentLinkTargetConsideredDifferent
+    _touch(tmp_path / "l2", now)                             # symlinks only compare the target
+    assert sim(e["l1"], _entries(tmp_path)["l2"])
+    # TestIsSimilarHardlink
+    hard2 = dict(hard)
+    assert sim(hard, hard2)                                  # NoChange
+    assert not sim(hard, dict(hard, link_target=str(tmp_path / "f2")))          # DifferentLinkTarget
+    assert not sim(hard, dict(hard, mtime_sec=hard["mtime_sec"] + 5))
+    assert sim(hard, dict(hard, mtime_sec=hard["mtime_sec"] + 5), ignore_time=True)
+    # TestIsSimilarDirectory
+    assert sim(e["dir1"], e["dir2"])                         # NoChange / DifferentContentConsideredSimilar
+    _touch(tmp_path / "dir1", now - 3600)
+    e2 = _entries(tmp_path)
+    assert not sim(e2["dir1"], e2["dir2"])                   # DifferentModTimeConsideredDifferent
+    assert sim(e2["dir1"], e2["dir2"], ignore_time=True)     # ...SimilarIfIgnored
+    _touch(tmp_path / "dir1", now - 7200)
+    os.chmod(tmp_path / "dir1", 0o777)
+    e2 = _entries(tmp_path)
+    assert not sim(e2["dir1"], e2["dir2"])                   # DifferentModeConsideredDifferent
+    # TestIsSimilarRegularFile
+    assert sim(e["f1"], e["f2"])                             # NoChange / DifferentContentButSameSize
+    assert not sim(e["f1"], e["f3"])                         # DifferentSizeConsideredDifferent
+    _touch(tmp_path / "f1", now - 3600)
+    e2 = _entries(tmp_path)
+    assert not sim(e2["f1"], e2["f2"])                       # DifferentModTimeConsideredDifferent
+    assert sim(e2["f1"], e2["f2"], ignore_time=True)         # ...SimilarIfIgnored
+    _touch(tmp_path / "f1", now - 7200)
+    os.chmod(tmp_path / "f1", 0o777)
+    e2 = _entries(tmp_path)
+    assert not sim(e2["f1"], e2["f2"])                       # DifferentModeConsideredDifferent
+    assert not sim(e["f1"], dict(e["f2"], uid=e["f2"]["uid"] + 1))
+    assert not sim(e["f1"], dict(e["f2"], gid=e["f2"]["gid"] + 1))
+    # sub-second mtime differences vanish (Truncate(1s) in compare.go:67-69)
+    os.utime(tmp_path / "f2", ns=((now - 7200) * 10**9 + 5 * 10**8,) * 2)
+    assert sim(e["f1"], _entries(tmp_path)["f2"])
+    # unsupported type
+    with pytest.raises(makisu_amd.MiError):
+        sim(dict(e["f1"], kind=9), e["f1"])
+
+
+def test_entry_similar_content_roots():
+    """The content-aware extension: same metadata + different chunk roots = updated."""
+    import hashlib
+    import makisu_amd
+    a = {"relpath": "etc/passwd", "size": 5, "mtime_sec": 100, "mode": 0o100644, "kind": 1, "uid": 0, "gid": 0}
+    r1, r2 = hashlib.sha256(b"test1").digest(), hashlib.sha256(b"test2").digest()
+    assert makisu_amd.entry_similar(a, dict(a))                               # the reference's answer
+    assert makisu_amd.entry_similar(a, dict(a), root_a=r1, root_b=r1)
+    assert not makisu_amd.entry_similar(a, dict(a), root_a=r1, root_b=r2)     # same size, new content
+    assert makisu_amd.entry_similar(a, dict(a), root_a=r1, root_b=None)       # one side unknown: metadata only
+    d = dict(a, kind=0)
+    assert makisu_amd.entry_similar(d, dict(d), root_a=r1, root_b=r2)         # roots only matter for files
