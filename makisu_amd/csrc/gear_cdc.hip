@@ -107,14 +107,31 @@ __device__ __forceinline__ int bitmap_find_first(const u64* bm, int lo, int hi, 
 }
 
 // 16 more bytes into the rolling hash; hh[k] = high word after byte k.
-__device__ __forceinline__ void roll16(u64& h, const u32x4 v, const u64* tab, u32 (&hh)[16]) {
+// The table sits at the start of the workgroup's LDS (16 KiB-aligned), entry b of copy c at
+// byte b * 64 + c * 8: the lookup address of byte k of a dword is
+// ((w >> (8k - 6)) & 0x3FC0) | (c * 8) -- one full-rate shift and one v_bitop3_b32
+// ((a & b) | c) instead of the half-rate v_bfe_u32 + v_lshl_add_u32 pair.
+typedef __attribute__((address_space(3))) const u64 lds_cu64;
+static_assert(kCopies == 8, "lookup address arithmetic assumes a 64-byte entry stride");
+__device__ __forceinline__ void roll16(u64& h, const u32x4 v, u32 lane_tab, u32 (&hh)[16]) {
     const u32 wv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        const u32 b = (wv[k >> 2] >> (8 * (k & 3))) & 0xFF;
-        h = (h << 1) + tab[b * kCopies];
+        const u32 w = wv[k >> 2];
+        const int sh = 8 * (k & 3) - 6;
+        const u32 t = sh < 0 ? w << 6 : w >> sh;
+        const u32 addr = __builtin_amdgcn_bitop3_b32(t, 0x3FC0u, lane_tab, 0xEA);   // (t & 0x3FC0) | lane_tab
+        h = (h << 1) + *(lds_cu64*)(size_t)addr;
         hh[k] = (u32)(h >> 32);
     }
+}
+
+// LDS byte address of this lane's table copy (entry 0); traps if the table is not where the
+// OR-based lookup arithmetic needs it (start of LDS, 16 KiB-aligned).
+__device__ __forceinline__ u32 lds_lane_table(const u64* table, int lane) {
+    const u32 base = (u32)(size_t)(__attribute__((address_space(3))) const u64*)table;
+    if (base & (u32)(kTableBytes - 1)) __builtin_trap();
+    return base | ((u32)(lane % kCopies) * 8u);
 }
 
 __device__ __forceinline__ void load_piece(const u8* p, u32x4 (&d)[8]) {
@@ -126,7 +143,7 @@ __device__ __forceinline__ void load_piece(const u8* p, u32x4 (&d)[8]) {
 // (bit p <-> cut end ts + p + 1).  fptr is 16-byte aligned, ts a multiple of kGearTile.
 // pk/ovf: the lane's packed candidates for the fast selection path (cand_push / cand_compact).
 __device__ __forceinline__ void mark_tile(const u8* __restrict__ fptr, u64 ts, u32 tlen,
-                                          u32* bitmap, const u64* tab, u32 thresh_m1, int lane,
+                                          u32* bitmap, u32 tab, u32 thresh_m1, int lane,
                                           u32& pk, bool& ovf) {
     {   // clear the bitmap: 32 words per lane
         u32x4* bz = (u32x4*)bitmap;
@@ -234,6 +251,7 @@ void gear_cdc_small_kernel(const u8* __restrict__ data, const u64* __restrict__ 
     u32* cand_list = (u32*)(smem + kLdsListOff) + wave * 64;
     load_table(table, gear_table, tid);
     __syncthreads();
+    const u32 lane_tab = lds_lane_table(table, lane);
     const u32 li = blockIdx.x * kWavesPerWG + wave;
     if (li >= n_list) return;
     const u32 f = list[li];
@@ -244,7 +262,7 @@ void gear_cdc_small_kernel(const u8* __restrict__ data, const u64* __restrict__ 
     if (size) {
         u32 pk;
         bool ovf;
-        mark_tile(data + file_off[f], 0, (u32)size, bitmap, table + (lane % kCopies), p.thresh_m1, lane,
+        mark_tile(data + file_off[f], 0, (u32)size, bitmap, lane_tab, p.thresh_m1, lane,
                   pk, ovf);
         const bool fast = cand_compact(pk, ovf, (u32)lane * kLaneRun, lane, cand_list);
         // the wave's own LDS writes are ordered for the wave itself after the waitcnt the
@@ -292,6 +310,7 @@ void gear_cdc_large_kernel(const u8* __restrict__ data, const u64* __restrict__ 
     volatile u32* s_ticket = (volatile u32*)(smem + kGearLdsBytes);
     load_table(table, gear_table, tid);
     __syncthreads();
+    const u32 lane_tab = lds_lane_table(table, lane);
     constexpr u64 kGroupBytes = (u64)kGearTile * kWavesPerWG;
     for (;;) {
         if (tid == 0) *s_ticket = atomicAdd(ticket_counter, 1u);
@@ -307,7 +326,7 @@ void gear_cdc_large_kernel(const u8* __restrict__ data, const u64* __restrict__ 
             const u32 tlen = (u32)((size - ts < (u64)kGearTile) ? (size - ts) : (u64)kGearTile);
             u32 pk;
             bool ovf;
-            mark_tile(fptr, ts, tlen, bitmaps + wave * kBitmapWords, table + (lane % kCopies),
+            mark_tile(fptr, ts, tlen, bitmaps + wave * kBitmapWords, lane_tab,
                       p.thresh_m1, lane, pk, ovf);
             const bool fast = cand_compact(pk, ovf, (u32)lane * kLaneRun, lane, cand_lists + wave * 64);
             if (lane == 0) fast_flags[wave] = fast ? 1u : 0u;

@@ -19,7 +19,11 @@ def main():
     ap.add_argument("--min-size", type=int, default=2048)
     ap.add_argument("--mask-bits", type=int, default=13)
     ap.add_argument("--inflight", type=int, default=1, help="batches in flight (1 = serial steps)")
+    ap.add_argument("--lib", default=None, help="dev: load this build of the library instead")
     a = ap.parse_args()
+    if a.lib:
+        makisu_amd._build.LIB = os.path.abspath(a.lib)
+        makisu_amd._build.needs_build = lambda: False
     with makisu_amd.Engine(flags=a.flags, max_size=a.max_size, min_size=a.min_size,
                            mask_bits=a.mask_bits) as e:
         print(json.dumps(e.device_info()))
