@@ -80,7 +80,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--files", type=int, default=N_FILES, help="files per GPU (default = C2)")
-    ap.add_argument("--inflight", type=int, default=2, help="batches in flight (1 = serial steps)")
+    ap.add_argument("--inflight", type=int, default=3, help="batches in flight (1 = serial steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend for the digest exchange (nccl = RCCL; gloo only "

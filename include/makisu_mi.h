@@ -116,6 +116,8 @@ typedef struct {
 int  mi_abi_version(void);
 int  mi_config_default(mi_config* cfg);
 int  mi_ctx_create(const mi_config* cfg, mi_ctx** out);
+/* Free every batch and index of the ctx first (mi_batch_free / mi_index_free): they hold a
+ * pointer to it.                                                                        */
 void mi_ctx_destroy(mi_ctx* ctx);
 /* ctx may be NULL: returns the message of the last failed mi_ctx_create.           */
 const char* mi_last_error(mi_ctx* ctx);
@@ -178,6 +180,15 @@ int mi_batch_free(mi_batch* b);
  * n_unique (host, optional) receives the number of -1 rows.                        */
 int mi_dedup_mark(mi_ctx* ctx, const void* d_digests, uint64_t n, void* d_dup_of,
                   uint64_t* n_unique);
+/* The same marking for ONE rank of a multi-GPU job: d_digests holds the job-wide, rank-major
+ * digest set (n_total rows, after the all-gather); only the rank's own rows
+ * [own_first, own_first + own_n) are answered: d_dup_of_own[i] = smallest GLOBAL index with
+ * the digest of row own_first + i, or -1.  Identical values to mi_dedup_mark over the whole
+ * set, at a fraction of the work: own rows build the table, rows of earlier ranks probe it,
+ * rows of later ranks cannot be a minimum and are not touched.  n_own_first = own rows that
+ * are the job-wide first occurrence (their sum over ranks = the unique count).          */
+int mi_dedup_mark_range(mi_ctx* ctx, const void* d_digests, uint64_t n_total, uint64_t own_first,
+                        uint64_t own_n, void* d_dup_of_own, uint64_t* n_own_first);
 /* Rewrites the batch's dup_of column from a global marking: row i of the batch is
  * global row first_global + i of d_dup_of_global (device, int64).                  */
 int mi_batch_set_global_dedup(mi_batch* b, const void* d_dup_of_global, uint64_t first_global);

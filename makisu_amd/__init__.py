@@ -8,6 +8,7 @@ oracle/.
 """
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -131,6 +132,7 @@ def load_library(rebuild=False):
         "mi_batch_free": ([vp], C.c_int),
         "mi_dedup_mark": ([vp, vp, u64, vp, u64p], C.c_int),
         "mi_batch_set_global_dedup": ([vp, vp, u64], C.c_int),
+        "mi_dedup_mark_range": ([vp, vp, u64, u64, u64, vp, u64p], C.c_int),
         "mi_sha256_many": ([vp, vp, u64p, u64p, u64, vp], C.c_int),
         "mi_context_checksum": ([vp, vp, u64, C.POINTER(CtxEntry), u64, C.POINTER(C.c_uint32)],
                                 C.c_int),
@@ -244,6 +246,7 @@ class ChunkIndex:
         self._lib = engine._lib
         self._h = C.c_void_p()
         engine._check(self._lib.mi_index_create(engine._h, capacity_hint, C.byref(self._h)))
+        engine._children.add(self)
 
     def __len__(self):
         n = C.c_uint64()
@@ -275,9 +278,12 @@ class ChunkIndex:
         return n_new.value
 
     def close(self):
-        if self._h:
+        if getattr(self, "_h", None):
             self._lib.mi_index_free(self._h)
-            self._h = C.c_void_p()
+            self._h = None
+
+    free = close
+    __del__ = close
 
     def __enter__(self):
         return self
@@ -309,6 +315,7 @@ class Engine:
         if rc:
             raise MiError(rc, self._lib.mi_last_error(None).decode())
         self._h = h
+        self._children = weakref.WeakSet()     # live batches / indexes: they die before the ctx
 
     def _check(self, rc):
         if rc:
@@ -316,6 +323,8 @@ class Engine:
 
     def close(self):
         if getattr(self, "_h", None):
+            for child in list(self._children):  # a batch freed after its ctx would touch freed memory
+                child.free()
             self._lib.mi_ctx_destroy(self._h)
             self._h = None
 
@@ -376,6 +385,14 @@ class Engine:
     def comm_destroy(self):
         self._check(self._lib.mi_comm_destroy(self._h))
 
+    def dedup_mark_range(self, d_digests_ptr, n_total, own_first, own_n, d_dup_of_own_ptr):
+        """dup_of (global indices) for the rows [own_first, own_first+own_n) of a job-wide,
+        rank-major digest set; returns how many of them are job-wide first occurrences."""
+        nf = C.c_uint64()
+        self._check(self._lib.mi_dedup_mark_range(self._h, d_digests_ptr, n_total, own_first, own_n,
+                                                  d_dup_of_own_ptr, C.byref(nf)))
+        return nf.value
+
     def dedup_mark(self, d_digests_ptr, n, d_dup_of_ptr):
         """dup_of over a device-resident digest set (e.g. the all-gathered one)."""
         nu = C.c_uint64()
@@ -390,6 +407,7 @@ class Batch:
         h = C.c_void_p()
         engine._check(self._lib.mi_batch_begin(engine._h, n_files_hint, bytes_hint, C.byref(h)))
         self._h = h
+        engine._children.add(self)
 
     def _check(self, rc):
         self.engine._check(rc)

@@ -515,6 +515,7 @@ void mi_ctx_destroy(mi_ctx* c) {
     for (auto e : c->ev) if (e) (void)hipEventDestroy(e);
     c->gear_table.release(); c->heads.release(); c->crc_consts.release();
     c->dd_rep.release(); c->dd_minid.release(); c->dd_slot.release(); c->dd_nuniq.release();
+    c->dd_tag.release(); c->dd_fmin.release();
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -902,6 +903,34 @@ int mi_dedup_mark(mi_ctx* c, const void* d_digests, uint64_t n, void* d_dup_of, 
     c->stats.ms_dedup = ev_ms(c->ev[0], c->ev[1]);
     c->stats.n_unique = nu;
     if (n_unique) *n_unique = nu;
+    return MI_OK;
+}
+
+int mi_dedup_mark_range(mi_ctx* c, const void* d_digests, uint64_t n_total, uint64_t own_first,
+                        uint64_t own_n, void* d_dup_of_own, uint64_t* n_own_first) {
+    if (!c || own_first > n_total || own_n > n_total - own_first || (own_n && (!d_digests || !d_dup_of_own)))
+        return MI_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n_total >= 0xFFFFFFFFull) return fail(c, MI_ERR_INVALID, "dedup set too large");
+    u64 cap = 1024;
+    while (cap < 2 * own_n) cap <<= 1;
+    HIPCHK(c, c->dd_rep.ensure(cap * 4));
+    HIPCHK(c, c->dd_minid.ensure(cap * 4));
+    HIPCHK(c, c->dd_fmin.ensure(cap * 4));
+    HIPCHK(c, c->dd_tag.ensure(cap * 8));
+    HIPCHK(c, c->dd_slot.ensure(own_n * 4 + 16));
+    HIPCHK(c, c->dd_nuniq.ensure(8));
+    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    launch_dedup_mark_range((const u8*)d_digests, own_first, own_n, c->dd_rep.as<u32>(),
+                            c->dd_minid.as<u32>(), c->dd_tag.as<u64>(), c->dd_fmin.as<u32>(),
+                            c->dd_slot.as<u32>(), cap, (i64*)d_dup_of_own, c->dd_nuniq.as<u64>(), c->stream);
+    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    u64 nf = 0;
+    HIPCHK(c, hipMemcpyAsync(&nf, c->dd_nuniq.p, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    c->stats.ms_dedup = ev_ms(c->ev[0], c->ev[1]);
+    if (n_own_first) *n_own_first = nf;
     return MI_OK;
 }
 

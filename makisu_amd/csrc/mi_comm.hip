@@ -142,16 +142,40 @@ int mark_and_rewrite(mi_batch* b, const std::vector<u64>& counts, u64 m, uint64_
         }
         glob = x->compact.as<u8>();
     }
-    HIPCHK(c, x->dup.ensure(total * 8 + 16));
+    const u64 own_n = counts[(size_t)c->comm_rank];
+    HIPCHK(c, x->dup.ensure(own_n * 8 + 16));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    uint64_t nu = 0;
-    int rc = mi_dedup_mark(c, glob, total, x->dup.p, &nu);
+    // this rank answers for its own rows only (mi_dedup_mark_range); the job-wide unique count
+    // is the sum of the ranks' first-occurrence counts, summed by the caller
+    uint64_t nf = 0;
+    int rc = mi_dedup_mark_range(c, glob, total, first, own_n, x->dup.p, &nf);
     if (rc) return rc;
-    rc = mi_batch_set_global_dedup(b, x->dup.p, first);
+    rc = mi_batch_set_global_dedup(b, x->dup.p, 0);
     if (rc) return rc;
     if (n_total) *n_total = total;
-    if (n_unique) *n_unique = nu;
+    if (n_unique) *n_unique = nf;
     if (first_global) *first_global = first;
+    return MI_OK;
+}
+
+// sums one u64 per rank over the communicator (an all-gather of the 8-byte counts, added on
+// the host: no second collective type to bind)
+int sum_over_ranks_enqueue(mi_ctx* c, u64 mine) {
+    Exchange* x = exchange_of(c);
+    u64* d_counts = x->counts.as<u64>();
+    HIPCHK(c, hipMemcpyAsync(d_counts + c->comm_nranks, &mine, 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    NCCLCHK(c, rccl()->AllGather(d_counts + c->comm_nranks, d_counts, 1, ncclUint64,
+                                 (ncclComm_t)c->comm, c->stream));
+    return MI_OK;
+}
+int sum_over_ranks_finish(mi_ctx* c, u64* sum) {
+    Exchange* x = exchange_of(c);
+    std::vector<u64> v((size_t)c->comm_nranks);
+    HIPCHK(c, hipMemcpyAsync(v.data(), x->counts.p, 8 * v.size(), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *sum = 0;
+    for (u64 t : v) *sum += t;
     return MI_OK;
 }
 
@@ -238,7 +262,16 @@ int mi_dedup_allgather(mi_batch* b, uint64_t* n_total, uint64_t* n_unique, uint6
     u64 m = 0;
     rc = exchange_slabs_enqueue(b, counts, &m);
     if (rc) return rc;
-    return mark_and_rewrite(b, counts, m, n_total, n_unique, first_global);
+    uint64_t own_first_count = 0;
+    rc = mark_and_rewrite(b, counts, m, n_total, &own_first_count, first_global);
+    if (rc) return rc;
+    rc = sum_over_ranks_enqueue(c, own_first_count);
+    if (rc) return rc;
+    u64 sum = 0;
+    rc = sum_over_ranks_finish(c, &sum);
+    if (rc) return rc;
+    if (n_unique) *n_unique = sum;
+    return MI_OK;
 }
 
 int mi_dedup_allgather_all(mi_batch** batches, int n, uint64_t* n_total, uint64_t* n_unique) {
@@ -269,14 +302,16 @@ int mi_dedup_allgather_all(mi_batch** batches, int n, uint64_t* n_total, uint64_
     }
     NCCLCHK(c0, rccl()->GroupEnd());
     if (rc) return rc;
+    uint64_t unique_sum = 0;
     for (int i = 0; i < n; ++i) {
         (void)hipSetDevice(batches[i]->ctx->device);
         uint64_t nt = 0, nu = 0;
         rc = mark_and_rewrite(batches[i], counts[(size_t)i], maxes[(size_t)i], &nt, &nu, nullptr);
         if (rc) return rc;
         if (n_total) *n_total = nt;
-        if (n_unique) *n_unique = nu;
+        unique_sum += nu;                  // every rank counted its own first occurrences
     }
+    if (n_unique) *n_unique = unique_sum;
     return MI_OK;
 }
 

@@ -102,5 +102,8 @@ u32 crc32_host_combine(u32 crc1, u32 crc2, u64 len2);
 void launch_dedup_mark(const u8* d_digests, u64 n, const u64* d_n, u32* d_rep, u32* d_minid,
                        u32* d_slot_of, u64 cap_pow2, i64* d_dup_of, u64* d_n_unique,
                        hipStream_t s);
+void launch_dedup_mark_range(const u8* d_all, u64 own_first, u64 own_n, u32* d_rep, u32* d_minid,
+                             u64* d_tag, u32* d_fmin, u32* d_slot_of, u64 cap_pow2, i64* d_dup_own,
+                             u64* d_n_first, hipStream_t s);
 
 }  // namespace mi

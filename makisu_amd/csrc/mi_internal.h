@@ -43,6 +43,7 @@ struct mi_ctx {
     size_t staging_bytes = 0;
     mi::DevBuf gear_table, heads, crc_consts;
     mi::DevBuf dd_rep, dd_minid, dd_slot, dd_nuniq;     // dedup scratch of mi_dedup_mark
+    mi::DevBuf dd_tag, dd_fmin;                         // ... and of mi_dedup_mark_range
     hipEvent_t ev[2];
     int sha_blocks_per_cu = 2;
     mi::CdcParams cdc;

@@ -417,4 +417,91 @@ void launch_dedup_mark(const u8* d_digests, u64 n, const u64* d_n, u32* d_rep, u
                        d_minid, d_slot_of, d_dup_of, d_n_unique);
 }
 
+// ---- marking ONE rank's rows against the job-wide set --------------------------------
+// After the digest all-gather every rank holds all n_total rows (rank-major), but it only has to
+// answer for its OWN rows [own_first, own_first + own_n): dup_of = the smallest global index
+// holding the same digest, or -1.  Rows of later ranks can never be that minimum, so:
+//   1. the own rows build the table (same insert kernel as the in-batch marking; a tag kernel
+//      then stores the first 8 digest bytes next to every occupied slot),
+//   2. the rows of EARLIER ranks only probe it (read-only walk: tag, then the full 32 bytes on a
+//      tag match) and atomicMin their global index into the slot they hit,
+//   3. an own row takes the foreign minimum if there is one, else its in-rank first occurrence.
+// Cost on rank r of R: own_n inserts + r * own_n probes into a table that stays cache-resident,
+// instead of R * own_n inserts into a table R times the size.
+__global__ __launch_bounds__(256)
+void dedup_tag_kernel(const u8* __restrict__ own, const u32* __restrict__ rep, u64* __restrict__ tag,
+                      u64 cap) {
+    const u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= cap) return;
+    const u32 r = rep[s];
+    if (r) tag[s] = *(const u64*)(own + 32ull * (r - 1u));
+}
+
+__global__ __launch_bounds__(256)
+void dedup_probe_kernel(const u8* __restrict__ all, u64 n_foreign, const u8* __restrict__ own,
+                        const u32* __restrict__ rep, const u64* __restrict__ tag,
+                        u32* __restrict__ fmin, u64 mask) {
+    const u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_foreign) return;
+    const u8* mine = all + 32 * g;
+    const u64 key = *(const u64*)mine;
+    u64 slot = key & mask;
+    for (;;) {
+        const u32 r = rep[slot];
+        if (r == 0u) return;                                 // not among the own rows
+        if (tag[slot] == key && digest_eq(own + 32ull * (r - 1u), mine)) {
+            atomicMin(&fmin[slot], (u32)g);
+            return;
+        }
+        slot = (slot + 1) & mask;
+    }
+}
+
+__global__ __launch_bounds__(256)
+void dedup_finish_range_kernel(u64 own_n, u64 own_first, const u32* __restrict__ minid,
+                               const u32* __restrict__ fmin, const u32* __restrict__ slot_of,
+                               i64* __restrict__ dup_own, u64* __restrict__ n_first) {
+    __shared__ u32 wg_count;
+    if (threadIdx.x == 0) wg_count = 0;
+    __syncthreads();
+    u32 mine = 0;
+    for (u64 i0 = (u64)blockIdx.x * blockDim.x; i0 < own_n; i0 += (u64)gridDim.x * blockDim.x) {
+        const u64 i = i0 + threadIdx.x;
+        bool first = false;
+        if (i < own_n) {
+            const u32 s = slot_of[i];
+            const u32 f = fmin[s], m = minid[s];
+            if (f != 0xFFFFFFFFu) dup_own[i] = (i64)f;                   // an earlier rank has it
+            else if (m != (u32)i) dup_own[i] = (i64)(own_first + m);     // earlier in this rank
+            else { dup_own[i] = -1; first = true; }
+        }
+        mine += (u32)__popcll(__ballot(first));
+    }
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&wg_count, mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && wg_count) atomicAdd((unsigned long long*)n_first, (unsigned long long)wg_count);
+}
+
+void launch_dedup_mark_range(const u8* d_all, u64 own_first, u64 own_n, u32* d_rep, u32* d_minid,
+                             u64* d_tag, u32* d_fmin, u32* d_slot_of, u64 cap_pow2, i64* d_dup_own,
+                             u64* d_n_first, hipStream_t s) {
+    (void)hipMemsetAsync(d_n_first, 0, sizeof(u64), s);
+    if (own_n == 0) return;
+    (void)hipMemsetAsync(d_rep, 0, sizeof(u32) * cap_pow2, s);
+    (void)hipMemsetAsync(d_minid, 0xFF, sizeof(u32) * cap_pow2, s);
+    (void)hipMemsetAsync(d_fmin, 0xFF, sizeof(u32) * cap_pow2, s);
+    const u8* own = d_all + 32 * own_first;
+    const u32 grid = (u32)((own_n + 255) / 256);
+    hipLaunchKernelGGL(dedup_insert_kernel, dim3(grid), dim3(256), 0, s, own, own_n, (const u64*)nullptr,
+                       d_rep, d_minid, d_slot_of, cap_pow2 - 1);
+    if (own_first) {
+        hipLaunchKernelGGL(dedup_tag_kernel, dim3((u32)((cap_pow2 + 255) / 256)), dim3(256), 0, s, own,
+                           d_rep, d_tag, cap_pow2);
+        hipLaunchKernelGGL(dedup_probe_kernel, dim3((u32)((own_first + 255) / 256)), dim3(256), 0, s, d_all,
+                           own_first, own, d_rep, d_tag, d_fmin, cap_pow2 - 1);
+    }
+    hipLaunchKernelGGL(dedup_finish_range_kernel, dim3(grid < 1024 ? grid : 1024), dim3(256), 0, s, own_n,
+                       own_first, d_minid, d_fmin, d_slot_of, d_dup_own, d_n_first);
+}
+
 }  // namespace mi

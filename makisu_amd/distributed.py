@@ -81,21 +81,27 @@ def all_gather_digests(local, group=None):
 
 def global_dedup(engine, batch, device, group=None, mark=None, local=None):
     """Exchange + mark.  Rewrites the batch's dup_of column with GLOBAL chunk indices
-    (rank-major order).  `mark(glob) -> (dup_of int64 tensor, n_unique)` defaults to
-    the HIP kernel (engine.dedup_mark); the gloo CPU tests pass `local` digests and
-    inject their own checker as `mark`.
-    Returns (n_total, n_unique_global, first_global, dup_of_global)."""
+    (rank-major order).  The default marking is the HIP kernel behind mi_dedup_mark_range:
+    a rank only answers for its own rows (own rows build the table, rows of earlier ranks
+    probe it), then the per-rank first-occurrence counts are summed with one 8-byte
+    all-reduce.  The gloo CPU tests pass `local` digests and inject their own checker as
+    `mark(glob) -> (dup_of int64 tensor over ALL rows, n_unique)`.
+    Returns (n_total, n_unique_global, first_global, dup_of) -- dup_of covers this rank's
+    rows (global indices) on the default path, all rows when `mark` is given."""
     if local is None:
         local = digests_tensor(batch, device)
     glob, counts, first = all_gather_digests(local, group)
     n_total = glob.shape[0]
-    if mark is None:
-        dup = torch.empty(max(n_total, 1), dtype=torch.int64, device=device)
-        # only torch's stream (which produced `glob`) has to drain -- a device-wide sync would
-        # also wait for the OTHER batch's pipeline and serialise the two batches in flight
-        torch.cuda.current_stream(device).synchronize()
-        n_unique = engine.dedup_mark(glob.data_ptr(), n_total, dup.data_ptr())
-        batch.set_global_dedup(dup.data_ptr(), first)
-    else:
+    if mark is not None:
         dup, n_unique = mark(glob)
-    return n_total, n_unique, first, dup
+        return n_total, n_unique, first, dup
+    n_own = counts[dist.get_rank(group)]
+    dup = torch.empty(max(n_own, 1), dtype=torch.int64, device=device)
+    # only torch's stream (which produced `glob`) has to drain -- a device-wide sync would
+    # also wait for the OTHER batches' pipelines and serialise the batches in flight
+    torch.cuda.current_stream(device).synchronize()
+    n_first = engine.dedup_mark_range(glob.data_ptr(), n_total, first, n_own, dup.data_ptr())
+    batch.set_global_dedup(dup.data_ptr(), 0)
+    t = torch.tensor([n_first], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return n_total, int(t.item()), first, dup

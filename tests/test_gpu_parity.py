@@ -9,6 +9,14 @@ import hashlib
 import numpy as np
 import pytest
 
+try:
+    # Several tests below use torch next to the engine.  PyTorch-ROCm wheels bundle their own HIP
+    # runtime, and it only finds the GPU if it is loaded before libmakisu_mi.so pulls in the
+    # system one -- so torch comes first in any process that uses both (bench.py does the same).
+    import torch  # noqa: F401
+except ImportError:          # CPU-only collection without torch: the GPU tests are skipped anyway
+    torch = None
+
 pytestmark = pytest.mark.gpu
 
 SEED = 0x4D414B49
@@ -874,3 +882,33 @@ def test_chunk_index_empty_batch(eng):
         b.run()
         k, n_new, n_known = idx.add_batch(b)
         assert len(k) == 0 and n_new == 0 and n_known == 0 and idx.export() == b""
+
+
+def test_dedup_mark_range_equals_full_marking(oracle, eng):
+    """mi_dedup_mark_range answers only a rank's own rows but must give exactly the values the
+    full marking (oracle over the whole job-wide set) has for them, for every split of the set
+    into earlier / own / later rows -- including empty ranges and own rows that repeat both
+    inside the range and in earlier ranks."""
+    import torch
+    rng = np.random.default_rng(11)
+    base = rng.integers(0, 256, (4000, 32), dtype=np.uint8)
+    rows = base[rng.integers(0, 4000, 20000)]                 # heavy repetition, random order
+    rows[7] = rows[19999]                                      # an early row equal to the last one
+    want, n_unique = oracle.dedup(rows)
+    dev = torch.device("cuda", 0)
+    glob = torch.from_numpy(rows).to(dev)
+    firsts = 0
+    bounds = [0, 1, 2500, 2500, 9000, 19999, 20000]           # 6 "ranks": sizes 1, 2499, 0, 6500, 10999, 1
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        dup = torch.full((max(b - a, 1),), -7, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        nf = eng.dedup_mark_range(glob.data_ptr(), len(rows), a, b - a, dup.data_ptr())
+        got = dup.cpu().numpy()[: b - a]
+        assert np.array_equal(got, want[a:b]), (a, b)
+        assert nf == int((want[a:b] < 0).sum())
+        firsts += nf
+    assert firsts == n_unique
+    # the whole set as one range = mi_dedup_mark
+    dup = torch.empty(len(rows), dtype=torch.int64, device=dev)
+    assert eng.dedup_mark_range(glob.data_ptr(), len(rows), 0, len(rows), dup.data_ptr()) == n_unique
+    assert np.array_equal(dup.cpu().numpy(), want)
