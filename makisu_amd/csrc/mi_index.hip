@@ -25,6 +25,11 @@ typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+// a DevBuf that frees itself: temporaries stay leak-free on every error return
+struct ScopedBuf : DevBuf {
+    ~ScopedBuf() { release(); }
+};
+
 __device__ __forceinline__ bool digest_eq32(const u8* a, const u8* b) {
     const u32x4 a0 = ((const u32x4*)a)[0], a1 = ((const u32x4*)a)[1];
     const u32x4 b0 = ((const u32x4*)b)[0], b1 = ((const u32x4*)b)[1];
@@ -112,7 +117,7 @@ int index_grow(mi_index* x, u64 min_cap) {
     while (cap < min_cap) cap <<= 1;
     if (cap == x->cap) return MI_OK;
     // export the current content, reallocate, re-insert
-    DevBuf old;
+    ScopedBuf old;
     const u64 have = x->count;
     if (have) {
         HIPCHK(c, old.ensure(have * 32));
@@ -124,12 +129,11 @@ int index_grow(mi_index* x, u64 min_cap) {
     x->state.release();
     x->slots.release();
     int rc = index_alloc(x, cap);
-    if (rc) { old.release(); return rc; }
+    if (rc) { x->cap = 0; x->count = 0; return rc; }     // out of memory: an empty, still usable index
     x->count = 0;
     if (have) {
         u64 n_new = 0;
         rc = index_insert(x, old.as<u8>(), nullptr, have, nullptr, &n_new);
-        old.release();
         if (rc) return rc;
         if (n_new != have) return fail(c, MI_ERR_HIP, "index rebuild lost entries (%llu of %llu)",
                                        (unsigned long long)n_new, (unsigned long long)have);
@@ -229,14 +233,13 @@ int mi_index_export(mi_index* x, void* out, uint64_t cap_digests) {
     if (cap_digests < x->count) return fail(c, MI_ERR_CAPACITY, "export buffer holds %llu digests, need %llu",
                                             (unsigned long long)cap_digests, (unsigned long long)x->count);
     if (x->count == 0) return MI_OK;
-    DevBuf tmp;
+    ScopedBuf tmp;
     HIPCHK(c, tmp.ensure(x->count * 32));
     HIPCHK(c, hipMemsetAsync(x->counter.p, 0, 8, c->stream));
     hipLaunchKernelGGL(index_export_kernel, dim3((u32)((x->cap + 255) / 256)), dim3(256), 0, c->stream,
                        x->state.as<u32>(), x->slots.as<u8>(), x->cap, tmp.as<u8>(), x->counter.as<u64>());
     hipError_t e = hipMemcpyAsync(out, tmp.p, x->count * 32, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    tmp.release();
     if (e != hipSuccess) return fail(c, MI_ERR_HIP, "mi_index_export: %s", hipGetErrorString(e));
     return MI_OK;
 }
@@ -249,17 +252,14 @@ int mi_index_import(mi_index* x, const void* digests, uint64_t n, uint64_t* n_ne
     if (n == 0) return MI_OK;
     // imported digests may repeat each other or the table's content: mark them first so only
     // unique rows probe (the kernel's no-equal-probers precondition)
-    DevBuf d, dup;
-    hipError_t e = d.ensure(n * 32);
-    if (e == hipSuccess) e = dup.ensure(n * 8);
-    if (e == hipSuccess) e = hipMemcpy(d.p, digests, n * 32, hipMemcpyHostToDevice);
-    if (e != hipSuccess) { d.release(); dup.release(); return fail(c, MI_ERR_HIP, "mi_index_import: %s", hipGetErrorString(e)); }
+    ScopedBuf d, dup;
+    HIPCHK(c, d.ensure(n * 32));
+    HIPCHK(c, dup.ensure(n * 8));
+    HIPCHK(c, hipMemcpy(d.p, digests, n * 32, hipMemcpyHostToDevice));
     uint64_t uniq = 0;
     int rc = mi_dedup_mark(c, d.p, n, dup.p, &uniq);
     u64 added = 0;
     if (!rc) rc = index_insert(x, d.as<u8>(), dup.as<i64>(), n, nullptr, &added);
-    d.release();
-    dup.release();
     if (!rc && n_new) *n_new = added;
     return rc;
 }
