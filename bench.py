@@ -219,12 +219,12 @@ def main():
                      "note": "SHA-256 is integer-VALU bound on CDNA4 (measured roof 1.77 TB/s "
                              "hashed, tools/ubench_sha.hip); the HBM fraction cannot exceed 0.22. "
                              "achieved/avg_launch_ms are from the timed region, where the kernel "
-                             "shares the GPU with the other in-flight batch's Gear pass; "
+                             "shares the GPU with the other in-flight batches' passes; "
                              "serial_* = the same kernel with one batch at a time (3 extra "
                              "untimed steps)"},
         "phase_ms_avg": {k: round(v / args.steps, 4) for k, v in sorted(stats_sum.items())},
-        "phase_note": "per-batch stream timelines; with 2 batches in flight a phase's span includes "
-                      "time it shared the GPU with the other batch",
+        "phase_note": "per-batch stream timelines; with several batches in flight a phase's span "
+                      "includes time it shared the GPU with the other batches",
     }
     if serial_sha_ms:
         s_ms = float(np.mean(serial_sha_ms))
