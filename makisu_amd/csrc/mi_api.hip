@@ -464,7 +464,14 @@ int mi_ctx_create(const mi_config* cfg, mi_ctx** out) {
         mi_ctx_destroy(c);
         return rc;
     }
-    CREATE_CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    {
+        // the ctx stream carries the small, latency-sensitive work (duplicate marking after an
+        // exchange, standalone digests): highest priority, so its kernels are dispatched ahead
+        // of the multi-millisecond scan kernels of the batches in flight
+        int prio_low = 0, prio_high = 0;
+        CREATE_CHK(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+        CREATE_CHK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_high));
+    }
     for (auto& e : c->ev) e = nullptr;
     for (auto& e : c->ev) CREATE_CHK(hipEventCreate(&e));
     c->staging_bytes = cfg->staging_bytes ? cfg->staging_bytes : (64ull << 20);

@@ -51,40 +51,85 @@ def digests_tensor(batch, device):
     return torch.as_tensor(DeviceArray(ptr, (n, 32), "|u1"), device=device)
 
 
+_host_groups = {}
+_exchange_streams = {}
+
+
+def _host_group(group):
+    """A process group for the HOST-side scalars of the exchange (per-rank counts, the unique
+    count).  On a GPU busy with persistent scan kernels even an 8-byte device collective waits
+    milliseconds for a hardware queue slot, and its result needs a host sync on top; the counts
+    are host integers anyway, so they travel over a gloo group (TCP/shared memory on one node)
+    and never touch the GPU.  With a gloo default group (the CPU tests) that group is used."""
+    key = id(group) if group is not None else None
+    if key not in _host_groups:
+        if dist.get_backend(group) == "gloo":
+            _host_groups[key] = group
+        else:
+            ranks = None if group is None else dist.get_process_group_ranks(group)
+            _host_groups[key] = dist.new_group(ranks=ranks, backend="gloo")   # collective: every rank gets here
+    return _host_groups[key]
+
+
+def _exchange_stream(device):
+    """High-priority torch stream for the slab all-gather: its kernels are tiny next to the scan
+    kernels they share the GPU with and should be dispatched as soon as they are enqueued."""
+    key = (device.type, device.index)
+    if key not in _exchange_streams:
+        _exchange_streams[key] = torch.cuda.Stream(device=device, priority=-1)
+    return _exchange_streams[key]
+
+
+def all_gather_counts(n_local, group=None):
+    """Every rank's row count, as host integers (no GPU work)."""
+    world = dist.get_world_size(group)
+    mine = torch.tensor([int(n_local)], dtype=torch.int64)
+    out = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(out, mine, group=_host_group(group))
+    return [int(t.item()) for t in out]
+
+
 def all_gather_digests(local, group=None):
     """Variable-length all-gather of (n_r, 32) uint8 digest arrays.
 
-    Step 1: all-gather the 1-element counts.  Step 2: pad to the max count and
-    all-gather the slabs (one collective, every xGMI link carries one peer's slab),
-    then drop the padding.  Returns (global (N, 32) tensor ordered by rank,
-    counts list, first_global index of this rank's rows)."""
+    Step 1: all-gather the counts on the host.  Step 2: pad to the max count and all-gather the
+    slabs (one collective, every xGMI link carries one peer's slab), then drop the padding.
+    Returns (global (N, 32) tensor ordered by rank, counts list, first_global index of this
+    rank's rows).  On a GPU the device work runs on a high-priority stream that has been
+    synchronised when this returns."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = local.device
-    n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
-    counts_t = torch.zeros(world, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(counts_t, n_local, group=group)
-    counts = [int(x) for x in counts_t.tolist()]
+    counts = all_gather_counts(local.shape[0], group)
     m = max(counts) if counts else 0
     if m == 0:
         return torch.empty((0, 32), dtype=torch.uint8, device=dev), counts, 0
-    slab = torch.zeros((m, 32), dtype=torch.uint8, device=dev)
-    slab[: local.shape[0]] = local
-    gathered = torch.empty((world * m, 32), dtype=torch.uint8, device=dev)
-    dist.all_gather_into_tensor(gathered, slab, group=group)
-    if all(c == m for c in counts):
-        glob = gathered
+
+    def gather():
+        slab = torch.zeros((m, 32), dtype=torch.uint8, device=dev)
+        slab[: local.shape[0]] = local
+        gathered = torch.empty((world * m, 32), dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(gathered, slab, group=group)
+        if all(c == m for c in counts):
+            return gathered
+        return torch.cat([gathered[r * m: r * m + counts[r]] for r in range(world)], dim=0).contiguous()
+
+    if dev.type == "cuda":
+        st = _exchange_stream(dev)
+        with torch.cuda.stream(st):
+            glob = gather()
+        st.synchronize()          # only this stream: the batches in flight keep running
     else:
-        glob = torch.cat([gathered[r * m: r * m + counts[r]] for r in range(world)], dim=0)
-    return glob.contiguous(), counts, sum(counts[:rank])
+        glob = gather()
+    return glob, counts, sum(counts[:rank])
 
 
 def global_dedup(engine, batch, device, group=None, mark=None, local=None):
     """Exchange + mark.  Rewrites the batch's dup_of column with GLOBAL chunk indices
     (rank-major order).  The default marking is the HIP kernel behind mi_dedup_mark_range:
     a rank only answers for its own rows (own rows build the table, rows of earlier ranks
-    probe it), then the per-rank first-occurrence counts are summed with one 8-byte
-    all-reduce.  The gloo CPU tests pass `local` digests and inject their own checker as
+    probe it), then the per-rank first-occurrence counts are summed on the host group.
+    The gloo CPU tests pass `local` digests and inject their own checker as
     `mark(glob) -> (dup_of int64 tensor over ALL rows, n_unique)`.
     Returns (n_total, n_unique_global, first_global, dup_of) -- dup_of covers this rank's
     rows (global indices) on the default path, all rows when `mark` is given."""
@@ -96,12 +141,10 @@ def global_dedup(engine, batch, device, group=None, mark=None, local=None):
         dup, n_unique = mark(glob)
         return n_total, n_unique, first, dup
     n_own = counts[dist.get_rank(group)]
-    dup = torch.empty(max(n_own, 1), dtype=torch.int64, device=device)
-    # only torch's stream (which produced `glob`) has to drain -- a device-wide sync would
-    # also wait for the OTHER batches' pipelines and serialise the batches in flight
-    torch.cuda.current_stream(device).synchronize()
+    with torch.cuda.stream(_exchange_stream(device)):
+        dup = torch.empty(max(n_own, 1), dtype=torch.int64, device=device)
     n_first = engine.dedup_mark_range(glob.data_ptr(), n_total, first, n_own, dup.data_ptr())
     batch.set_global_dedup(dup.data_ptr(), 0)
-    t = torch.tensor([n_first], dtype=torch.int64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    t = torch.tensor([n_first], dtype=torch.int64)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=_host_group(group))
     return n_total, int(t.item()), first, dup

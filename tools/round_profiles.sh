@@ -1,0 +1,23 @@
+#!/bin/bash
+# Regenerates everything under profiles/ that comes from a GPU run (run on the MI355X box from the
+# repo root; results land in gpurun_out/round/, copy what is to be judged into profiles/).
+#   tools/round_profiles.sh r01
+set -u
+tag=${1:-rXX}
+out=gpurun_out/round
+mkdir -p $out
+export TMPDIR=/tmp
+T="timeout 170"
+$T python bench.py > $out/${tag}_bench_n1.json 2> $out/bench.err
+tail -c 400 $out/${tag}_bench_n1.json; echo
+# same command as the bench (batches in flight) and the serial form
+$T rocprofv3 --kernel-trace --stats -d $out/kt -o kt -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline > $out/kt.log 2>&1
+$T rocprofv3 --kernel-trace --stats -d $out/kts -o kts -- python bench.py --steps 10 --warmup 2 --inflight 1 --no-cpu-baseline > $out/kts.log 2>&1
+# HBM traffic: one --pmc pass per counter, kernel trace only
+$T rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/fetch -o fetch -- python bench.py --steps 3 --warmup 1 --inflight 1 --no-cpu-baseline > $out/fetch.log 2>&1
+$T rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/write -o write -- python bench.py --steps 3 --warmup 1 --inflight 1 --no-cpu-baseline > $out/write.log 2>&1
+for n in kt kts fetch write; do
+  db=$(find $out/$n -name "*_results.db" | head -1)
+  [ -n "$db" ] && python tools/prof_summary.py $db > $out/${tag}_$n.txt 2>&1
+done
+ls -la $out
