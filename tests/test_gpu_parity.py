@@ -11,8 +11,9 @@ import pytest
 
 try:
     # Several tests below use torch next to the engine.  PyTorch-ROCm wheels bundle their own HIP
-    # runtime, and it only finds the GPU if it is loaded before libmakisu_mi.so pulls in the
-    # system one -- so torch comes first in any process that uses both (bench.py does the same).
+    # runtime (SONAME libamdhip64.so.7); loaded first it also serves libmakisu_mi.so, loaded
+    # second it would be a second runtime that finds no GPU -- so torch comes first in any
+    # process that uses both (bench.py does the same).
     import torch  # noqa: F401
 except ImportError:          # CPU-only collection without torch: the GPU tests are skipped anyway
     torch = None
