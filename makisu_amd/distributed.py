@@ -141,8 +141,11 @@ def global_dedup(engine, batch, device, group=None, mark=None, local=None):
         dup, n_unique = mark(glob)
         return n_total, n_unique, first, dup
     n_own = counts[dist.get_rank(group)]
-    with torch.cuda.stream(_exchange_stream(device)):
-        dup = torch.empty(max(n_own, 1), dtype=torch.int64, device=device)
+    if device.type == "cuda":
+        with torch.cuda.stream(_exchange_stream(device)):
+            dup = torch.empty(max(n_own, 1), dtype=torch.int64, device=device)
+    else:                                   # CPU tests drive this path with a stand-in engine
+        dup = torch.empty(max(n_own, 1), dtype=torch.int64)
     n_first = engine.dedup_mark_range(glob.data_ptr(), n_total, first, n_own, dup.data_ptr())
     batch.set_global_dedup(dup.data_ptr(), 0)
     t = torch.tensor([n_first], dtype=torch.int64)

@@ -77,6 +77,77 @@ def test_digest_all_gather_and_global_marking_world2():
     assert (dup < np.arange(len(dup))).all()                      # always points to an earlier row
 
 
+class _HostEngine:
+    """Stand-in for makisu_amd.Engine on a CPU: mi_dedup_mark_range's contract (own rows of the
+    job-wide marking) computed by the oracle on the memory global_dedup hands over."""
+
+    def __init__(self, O):
+        self.O = O
+
+    def dedup_mark_range(self, d_digests_ptr, n_total, own_first, own_n, d_dup_of_own_ptr):
+        import ctypes
+        rows = np.ctypeslib.as_array((ctypes.c_uint8 * (n_total * 32)).from_address(d_digests_ptr))
+        full, _ = self.O.dedup(rows.reshape(n_total, 32).copy())
+        own = full[own_first: own_first + own_n]
+        out = np.ctypeslib.as_array((ctypes.c_int64 * max(own_n, 1)).from_address(d_dup_of_own_ptr))
+        out[:own_n] = own
+        return int((own < 0).sum())
+
+
+class _HostBatch:
+    def __init__(self):
+        self.dup = None
+
+    def set_global_dedup(self, ptr, first):
+        self.ptr, self.first = ptr, first
+
+
+def _worker_default_path(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from makisu_amd import distributed as mdist
+    from oracle import mi_oracle as O
+    rng = np.random.default_rng(100)                       # same pool on every rank
+    pool = rng.integers(0, 256, (50, 32), dtype=np.uint8)
+    pick = np.random.default_rng(rank).integers(0, 50, 20 + 7 * rank)   # ragged counts, many repeats
+    local = torch.from_numpy(np.ascontiguousarray(pool[pick]))
+    b = _HostBatch()
+    n_total, n_unique, first, dup = mdist.global_dedup(_HostEngine(O), b, torch.device("cpu"), local=local)
+    assert b.first == 0 and b.ptr == dup.data_ptr()        # the batch gets the own rows, from row 0
+    q.put((rank, n_total, n_unique, first, dup.numpy()[: len(pick)].tolist(), local.numpy().tobytes()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_global_dedup_default_path_world3():
+    """The production path of global_dedup (host-group counts, own-rows marking, summed unique
+    count) with three ranks and ragged shards; the marking kernel is replaced by the oracle."""
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_default_path, args=(r, world, port, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    res = sorted(q.get(timeout=240) for _ in range(world))
+    for pr in procs:
+        pr.join(60)
+        assert pr.exitcode == 0
+    sys.path.insert(0, ROOT)
+    from oracle import mi_oracle as O
+    rows = np.frombuffer(b"".join(r[5] for r in res), dtype=np.uint8).reshape(-1, 32)
+    want, uniq = O.dedup(rows)
+    at = 0
+    for rank, n_total, n_unique, first, dup, _ in res:
+        assert n_total == len(rows) and n_unique == uniq and first == at
+        assert dup == want[at: at + len(dup)].tolist()
+        at += len(dup)
+    assert at == len(rows)
+
+
 def test_shard_helpers():
     sys.path.insert(0, ROOT)
     from makisu_amd import distributed as mdist
