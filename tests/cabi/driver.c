@@ -5,6 +5,7 @@
  *   C <file_index> <offset> <length> <dup_of> sha256:<digest>
  * Built and run by tests/test_gpu_parity.py::test_plain_c_consumer. */
 #include <stdio.h>
+#include <string.h>
 #include <stdlib.h>
 #include <sys/stat.h>
 
@@ -59,6 +60,29 @@ int main(int argc, char** argv) {
         hex(chunks[c].sha256, h1);
         printf("C %llu %llu %u %lld sha256:%s\n", (unsigned long long)chunks[c].file_index,
                (unsigned long long)chunks[c].offset, chunks[c].length, (long long)chunks[c].dup_of, h1);
+    }
+    /* the chunk index across batches: first pass everything is new, second pass all known */
+    mi_index* idx = NULL;
+    CHECK(mi_index_create(ctx, 0, &idx));
+    for (int pass = 0; pass < 2; pass++) {
+        uint64_t n_new = 0, n_known = 0, held = 0;
+        CHECK(mi_index_add_batch(idx, b, NULL, 0, &n_new, &n_known));
+        CHECK(mi_index_count(idx, &held));
+        printf("I %d %llu %llu %llu\n", pass, (unsigned long long)n_new, (unsigned long long)n_known,
+               (unsigned long long)held);
+    }
+    mi_index_free(idx);
+    /* tario.IsSimilarHeader on two entries that differ only in content */
+    if (nf >= 2) {
+        mi_tree_entry ea, eb;
+        memset(&ea, 0, sizeof ea);
+        ea.relpath = "etc/passwd";
+        ea.size = 5; ea.mtime_sec = 100; ea.mode = 0100644; ea.kind = 1;
+        eb = ea;
+        int same_meta = 0, same_content = 0;
+        CHECK(mi_entry_similar(&ea, &eb, 0, NULL, NULL, &same_meta));
+        CHECK(mi_entry_similar(&ea, &eb, 0, files[0].chunk_root, files[1].chunk_root, &same_content));
+        printf("S %d %d\n", same_meta, same_content);
     }
     mi_stats st;
     CHECK(mi_get_stats(ctx, &st));

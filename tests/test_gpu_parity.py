@@ -796,6 +796,12 @@ def test_plain_c_consumer(oracle, tmp_path):
           "sha256:" + c["sha256"].tobytes().hex()) for c in rc]
     assert [r[4] for r in frows] == ["sha256:" + f["chunk_root"].tobytes().hex() for f in rf]
     assert "unique" in out.stderr
+    irows = [l.split() for l in out.stdout.splitlines() if l.startswith("I ")]
+    n_distinct = len({c["sha256"].tobytes() for c in rc})
+    assert irows == [["I", "0", str(n_distinct), "0", str(n_distinct)],
+                     ["I", "1", "0", str(len(rc)), str(n_distinct)]]
+    # files 0 and 1 (200000 bytes vs empty) have equal made-up headers but different roots
+    assert [l for l in out.stdout.splitlines() if l.startswith("S ")] == ["S 1 0"]
     # error behaviour: a missing path is reported through mi_last_error, exit code 1
     bad = subprocess.run([exe, str(tmp_path / "nope")], capture_output=True, text=True)
     assert bad.returncode == 1
