@@ -72,11 +72,13 @@ def _host_group(group):
 
 
 def _exchange_stream(device):
-    """High-priority torch stream for the slab all-gather: its kernels are tiny next to the scan
-    kernels they share the GPU with and should be dispatched as soon as they are enqueued."""
+    """The torch stream the slab all-gather runs on, so that waiting for the exchange never means
+    waiting for torch's default stream or for the device.  Default priority on purpose: creating
+    streams with an explicit priority changed how the ROCm 7.0 runtime spreads the batch streams
+    over the hardware queues and cost the batches their overlap."""
     key = (device.type, device.index)
     if key not in _exchange_streams:
-        _exchange_streams[key] = torch.cuda.Stream(device=device, priority=-1)
+        _exchange_streams[key] = torch.cuda.Stream(device=device)
     return _exchange_streams[key]
 
 
@@ -95,7 +97,7 @@ def all_gather_digests(local, group=None):
     Step 1: all-gather the counts on the host.  Step 2: pad to the max count and all-gather the
     slabs (one collective, every xGMI link carries one peer's slab), then drop the padding.
     Returns (global (N, 32) tensor ordered by rank, counts list, first_global index of this
-    rank's rows).  On a GPU the device work runs on a high-priority stream that has been
+    rank's rows).  On a GPU the device work runs on a stream of its own that has been
     synchronised when this returns."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
