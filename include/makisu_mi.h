@@ -192,6 +192,13 @@ int mi_dedup_mark_range(mi_ctx* ctx, const void* d_digests, uint64_t n_total, ui
 /* Rewrites the batch's dup_of column from a global marking: row i of the batch is
  * global row first_global + i of d_dup_of_global (device, int64).                  */
 int mi_batch_set_global_dedup(mi_batch* b, const void* d_dup_of_global, uint64_t first_global);
+/* mi_dedup_mark_range for a batch's own chunks, written straight into its dup_of column (no
+ * intermediate array, no copy): the batch's rows are rows [own_first, own_first + n_chunks) of
+ * the job-wide set d_digests_all.                                                        */
+int mi_batch_mark_global(mi_batch* b, const void* d_digests_all, uint64_t n_total,
+                         uint64_t own_first, uint64_t* n_own_first);
+/* Device pointer to the batch's dup_of column (n_chunks x int64; valid until mi_batch_free). */
+int mi_batch_device_dup_of(mi_batch* b, const void** d_dup_of, uint64_t* n_chunks);
 
 /* ---- the digest exchange inside the library: RCCL all-gather over xGMI ---------------- *
  * For hosts without torch (the Go shim).  RCCL is loaded at run time (dlopen), so these

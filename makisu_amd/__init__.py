@@ -133,6 +133,8 @@ def load_library(rebuild=False):
         "mi_dedup_mark": ([vp, vp, u64, vp, u64p], C.c_int),
         "mi_batch_set_global_dedup": ([vp, vp, u64], C.c_int),
         "mi_dedup_mark_range": ([vp, vp, u64, u64, u64, vp, u64p], C.c_int),
+        "mi_batch_mark_global": ([vp, vp, u64, u64, u64p], C.c_int),
+        "mi_batch_device_dup_of": ([vp, C.POINTER(vp), u64p], C.c_int),
         "mi_sha256_many": ([vp, vp, u64p, u64p, u64, vp], C.c_int),
         "mi_context_checksum": ([vp, vp, u64, C.POINTER(CtxEntry), u64, C.POINTER(C.c_uint32)],
                                 C.c_int),
@@ -517,6 +519,19 @@ class Batch:
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
         self._check(self._lib.mi_dedup_allgather(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
+
+    def mark_global(self, d_digests_all_ptr, n_total, own_first):
+        """Job-wide marking of this batch's chunks (rows own_first.. of the gathered set) straight
+        into its dup_of column; returns how many of them are job-wide first occurrences."""
+        nf = C.c_uint64()
+        self._check(self._lib.mi_batch_mark_global(self._h, d_digests_all_ptr, n_total, own_first,
+                                                   C.byref(nf)))
+        return nf.value
+
+    def device_dup_of(self):
+        p, n = C.c_void_p(), C.c_uint64()
+        self._check(self._lib.mi_batch_device_dup_of(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
 
     def set_global_dedup(self, d_dup_of_global_ptr, first_global):
         self._check(self._lib.mi_batch_set_global_dedup(self._h, d_dup_of_global_ptr, first_global))

@@ -813,6 +813,14 @@ int mi_batch_device_digests(mi_batch* b, const void** d_digests, uint64_t* n_chu
     return MI_OK;
 }
 
+int mi_batch_device_dup_of(mi_batch* b, const void** d_dup_of, uint64_t* n_chunks) {
+    if (!b || !d_dup_of || !n_chunks) return MI_ERR_INVALID;
+    if (!b->ran) return fail(b->ctx, MI_ERR_STATE, "dup_of requested before mi_batch_run");
+    *d_dup_of = b->dup_of.p;
+    *n_chunks = b->n_chunks;
+    return MI_OK;
+}
+
 int mi_batch_read_back(mi_batch* b, void* out, uint64_t cap) {
     if (!b || (!out && cap)) return MI_ERR_INVALID;
     mi_ctx* c = b->ctx;
@@ -936,6 +944,18 @@ int mi_dedup_mark_range(mi_ctx* c, const void* d_digests, uint64_t n_total, uint
     c->stats.ms_dedup = ev_ms(c->ev[0], c->ev[1]);
     if (n_own_first) *n_own_first = nf;
     return MI_OK;
+}
+
+int mi_batch_mark_global(mi_batch* b, const void* d_digests_all, uint64_t n_total, uint64_t own_first,
+                         uint64_t* n_own_first) {
+    if (!b) return MI_ERR_INVALID;
+    mi_ctx* c = b->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!b->ran || b->in_flight) return fail(c, MI_ERR_STATE, "the batch must have run (and been waited for)");
+    HIPCHK(c, b->dup_of.ensure(b->n_chunks * 8 + 16));      // absent when the ctx has MI_FLAG_NO_DEDUP
+    int rc = mi_dedup_mark_range(c, d_digests_all, n_total, own_first, b->n_chunks, b->dup_of.p, n_own_first);
+    b->results_valid = false;
+    return rc;
 }
 
 int mi_batch_set_global_dedup(mi_batch* b, const void* d_dup_of_global, uint64_t first_global) {

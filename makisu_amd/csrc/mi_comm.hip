@@ -142,15 +142,12 @@ int mark_and_rewrite(mi_batch* b, const std::vector<u64>& counts, u64 m, uint64_
         }
         glob = x->compact.as<u8>();
     }
-    const u64 own_n = counts[(size_t)c->comm_rank];
-    HIPCHK(c, x->dup.ensure(own_n * 8 + 16));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    // this rank answers for its own rows only (mi_dedup_mark_range); the job-wide unique count
-    // is the sum of the ranks' first-occurrence counts, summed by the caller
+    // this rank answers for its own rows only, straight into the batch's dup_of column
+    // (mi_batch_mark_global); the job-wide unique count is the sum of the ranks'
+    // first-occurrence counts, summed by the caller
     uint64_t nf = 0;
-    int rc = mi_dedup_mark_range(c, glob, total, first, own_n, x->dup.p, &nf);
-    if (rc) return rc;
-    rc = mi_batch_set_global_dedup(b, x->dup.p, 0);
+    int rc = mi_batch_mark_global(b, glob, total, first, &nf);
     if (rc) return rc;
     if (n_total) *n_total = total;
     if (n_unique) *n_unique = nf;

@@ -128,13 +128,13 @@ def all_gather_digests(local, group=None):
 
 def global_dedup(engine, batch, device, group=None, mark=None, local=None):
     """Exchange + mark.  Rewrites the batch's dup_of column with GLOBAL chunk indices
-    (rank-major order).  The default marking is the HIP kernel behind mi_dedup_mark_range:
+    (rank-major order).  The default marking is the HIP kernel behind mi_batch_mark_global:
     a rank only answers for its own rows (own rows build the table, rows of earlier ranks
     probe it), then the per-rank first-occurrence counts are summed on the host group.
     The gloo CPU tests pass `local` digests and inject their own checker as
     `mark(glob) -> (dup_of int64 tensor over ALL rows, n_unique)`.
-    Returns (n_total, n_unique_global, first_global, dup_of) -- dup_of covers this rank's
-    rows (global indices) on the default path, all rows when `mark` is given."""
+    Returns (n_total, n_unique_global, first_global, dup_of) -- dup_of is a zero-copy view of
+    the batch's own column (global indices) on the default path, all rows when `mark` is given."""
     if local is None:
         local = digests_tensor(batch, device)
     glob, counts, first = all_gather_digests(local, group)
@@ -142,14 +142,12 @@ def global_dedup(engine, batch, device, group=None, mark=None, local=None):
     if mark is not None:
         dup, n_unique = mark(glob)
         return n_total, n_unique, first, dup
-    n_own = counts[dist.get_rank(group)]
-    if device.type == "cuda":
-        with torch.cuda.stream(_exchange_stream(device)):
-            dup = torch.empty(max(n_own, 1), dtype=torch.int64, device=device)
-    else:                                   # CPU tests drive this path with a stand-in engine
-        dup = torch.empty(max(n_own, 1), dtype=torch.int64)
-    n_first = engine.dedup_mark_range(glob.data_ptr(), n_total, first, n_own, dup.data_ptr())
-    batch.set_global_dedup(dup.data_ptr(), 0)
+    n_first = batch.mark_global(glob.data_ptr(), n_total, first)     # into the batch's own column
+    ptr, n_own = batch.device_dup_of()
+    if device.type == "cuda" and n_own:
+        dup = torch.as_tensor(DeviceArray(ptr, (n_own,), "<i8"), device=device)
+    else:                                   # CPU tests drive this path with a stand-in batch
+        dup = batch.dup_of_host() if n_own else torch.empty(0, dtype=torch.int64)
     t = torch.tensor([n_first], dtype=torch.int64)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=_host_group(group))
     return n_total, int(t.item()), first, dup

@@ -77,29 +77,27 @@ def test_digest_all_gather_and_global_marking_world2():
     assert (dup < np.arange(len(dup))).all()                      # always points to an earlier row
 
 
-class _HostEngine:
-    """Stand-in for makisu_amd.Engine on a CPU: mi_dedup_mark_range's contract (own rows of the
-    job-wide marking) computed by the oracle on the memory global_dedup hands over."""
+class _HostBatch:
+    """Stand-in for makisu_amd.Batch on a CPU: mi_batch_mark_global's contract (own rows of the
+    job-wide marking, written into the batch's column) computed by the oracle on the memory
+    global_dedup hands over."""
 
-    def __init__(self, O):
-        self.O = O
+    def __init__(self, O, n_own):
+        self.O, self.n_own, self.col = O, n_own, None
 
-    def dedup_mark_range(self, d_digests_ptr, n_total, own_first, own_n, d_dup_of_own_ptr):
+    def mark_global(self, d_digests_ptr, n_total, own_first):
         import ctypes
         rows = np.ctypeslib.as_array((ctypes.c_uint8 * (n_total * 32)).from_address(d_digests_ptr))
         full, _ = self.O.dedup(rows.reshape(n_total, 32).copy())
-        own = full[own_first: own_first + own_n]
-        out = np.ctypeslib.as_array((ctypes.c_int64 * max(own_n, 1)).from_address(d_dup_of_own_ptr))
-        out[:own_n] = own
-        return int((own < 0).sum())
+        self.col = full[own_first: own_first + self.n_own].copy()
+        self.first = own_first
+        return int((self.col < 0).sum())
 
+    def device_dup_of(self):
+        return 0, self.n_own
 
-class _HostBatch:
-    def __init__(self):
-        self.dup = None
-
-    def set_global_dedup(self, ptr, first):
-        self.ptr, self.first = ptr, first
+    def dup_of_host(self):
+        return torch.from_numpy(self.col)
 
 
 def _worker_default_path(rank, world, port, q):
@@ -113,9 +111,9 @@ def _worker_default_path(rank, world, port, q):
     pool = rng.integers(0, 256, (50, 32), dtype=np.uint8)
     pick = np.random.default_rng(rank).integers(0, 50, 20 + 7 * rank)   # ragged counts, many repeats
     local = torch.from_numpy(np.ascontiguousarray(pool[pick]))
-    b = _HostBatch()
-    n_total, n_unique, first, dup = mdist.global_dedup(_HostEngine(O), b, torch.device("cpu"), local=local)
-    assert b.first == 0 and b.ptr == dup.data_ptr()        # the batch gets the own rows, from row 0
+    b = _HostBatch(O, len(pick))
+    n_total, n_unique, first, dup = mdist.global_dedup(None, b, torch.device("cpu"), local=local)
+    assert b.first == first
     q.put((rank, n_total, n_unique, first, dup.numpy()[: len(pick)].tolist(), local.numpy().tobytes()))
     dist.barrier()
     dist.destroy_process_group()
