@@ -206,8 +206,9 @@ int mi_batch_device_dup_of(mi_batch* b, const void** d_dup_of, uint64_t* n_chunk
  * id, ships it to the peers, every rank calls mi_comm_init_rank.  Single process driving n
  * devices (one ctx each): mi_comm_init_all + mi_dedup_allgather_all.
  * mi_dedup_allgather: all-gathers the batches' digest arrays (counts first, then slabs
- * padded to the largest count), marks duplicates over the gathered set and rewrites the
- * batch's dup_of with GLOBAL row indices (rank-major); collective: every rank must call
+ * padded to the largest count), marks this rank's chunks against the gathered set
+ * (mi_batch_mark_global) so the batch's dup_of holds GLOBAL row indices (rank-major), and
+ * sums the ranks' first-occurrence counts into n_unique; collective: every rank must call
  * it.  Outputs are optional.                                                            */
 #define MI_COMM_ID_BYTES 128
 int mi_comm_unique_id(void* id_out /* MI_COMM_ID_BYTES */);
