@@ -469,6 +469,7 @@ int mi_ctx_create(const mi_config* cfg, mi_ctx** out) {
     // hardware queues, and the batches in flight stop overlapping (measured: 6.2 vs 5.87 ms
     // per C2 step under the ROCm 7.0 runtime PyTorch bundles).
     CREATE_CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CREATE_CHK(hipHostMalloc((void**)&c->h_word, 64, hipHostMallocDefault));
     for (auto& e : c->ev) e = nullptr;
     for (auto& e : c->ev) CREATE_CHK(hipEventCreate(&e));
     c->staging_bytes = cfg->staging_bytes ? cfg->staging_bytes : (64ull << 20);
@@ -517,6 +518,7 @@ void mi_ctx_destroy(mi_ctx* c) {
     for (auto s : c->copy_streams) if (s) (void)hipStreamDestroy(s);
     for (auto e : c->staging_done) if (e) (void)hipEventDestroy(e);
     for (auto e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->h_word) (void)hipHostFree(c->h_word);
     c->gear_table.release(); c->heads.release(); c->crc_consts.release();
     c->dd_rep.release(); c->dd_minid.release(); c->dd_slot.release(); c->dd_nuniq.release();
     c->dd_tag.release(); c->dd_fmin.release();
@@ -908,10 +910,10 @@ int mi_dedup_mark(mi_ctx* c, const void* d_digests, uint64_t n, void* d_dup_of, 
     launch_dedup_mark((const u8*)d_digests, n, nullptr, c->dd_rep.as<u32>(), c->dd_minid.as<u32>(),
                       c->dd_slot.as<u32>(), cap, (i64*)d_dup_of, c->dd_nuniq.as<u64>(), c->stream);
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-    u64 nu = 0;
-    HIPCHK(c, hipMemcpyAsync(&nu, c->dd_nuniq.p, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_word, c->dd_nuniq.p, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
+    const u64 nu = *c->h_word;
     c->stats.ms_dedup = ev_ms(c->ev[0], c->ev[1]);
     c->stats.n_unique = nu;
     if (n_unique) *n_unique = nu;
@@ -937,10 +939,10 @@ int mi_dedup_mark_range(mi_ctx* c, const void* d_digests, uint64_t n_total, uint
                             c->dd_minid.as<u32>(), c->dd_tag.as<u64>(), c->dd_fmin.as<u32>(),
                             c->dd_slot.as<u32>(), cap, (i64*)d_dup_of_own, c->dd_nuniq.as<u64>(), c->stream);
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-    u64 nf = 0;
-    HIPCHK(c, hipMemcpyAsync(&nf, c->dd_nuniq.p, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_word, c->dd_nuniq.p, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
+    const u64 nf = *c->h_word;
     c->stats.ms_dedup = ev_ms(c->ev[0], c->ev[1]);
     if (n_own_first) *n_own_first = nf;
     return MI_OK;

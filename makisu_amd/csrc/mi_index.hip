@@ -157,10 +157,10 @@ int index_insert(mi_index* x, const u8* d_digests, const i64* d_dup_of, u64 n, u
     if (d_dup_of && d_known)
         hipLaunchKernelGGL(index_inherit_kernel, dim3((u32)((n + 255) / 256)), dim3(256), 0, c->stream,
                            d_dup_of, n, d_known);
-    u64 added = 0;
-    HIPCHK(c, hipMemcpyAsync(&added, x->counter.p, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_word, x->counter.p, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
+    const u64 added = *c->h_word;
     x->count += added;
     *n_new = added;
     return MI_OK;

@@ -44,6 +44,7 @@ struct mi_ctx {
     mi::DevBuf gear_table, heads, crc_consts;
     mi::DevBuf dd_rep, dd_minid, dd_slot, dd_nuniq;     // dedup scratch of mi_dedup_mark
     mi::DevBuf dd_tag, dd_fmin;                         // ... and of mi_dedup_mark_range
+    mi::u64* h_word = nullptr;           // pinned: small read-backs on the ctx stream
     hipEvent_t ev[2];
     int sha_blocks_per_cu = 2;
     mi::CdcParams cdc;
