@@ -246,6 +246,10 @@ int mi_context_checksum(mi_batch* b, const void* prefix, uint64_t prefix_len,
  *                    ".wh..wh."-prefixed names, blacklist descendants
  *                    (lib/pathutils/path.go:24-35) and mountpoints
  *                    (lib/mountutils/mountutils.go:54-93); skipped directories are pruned.
+ *                    As in memLayer.createHeader (lib/snapshot/mem_layer.go:171-185) an
+ *                    ABSOLUTE symlink target loses the rel_base prefix (pathutils.TrimRoot,
+ *                    path.go:63-68: plain string prefix, then AbsPath); a target outside
+ *                    rel_base fails the walk with MI_ERR_INVALID, as it fails the scan there.
  * Every regular file is added to the batch (stat-time size, user_tag = entry index);
  * relpath = filepath.Rel(rel_base, path) (rel_base NULL = root).  May be called several
  * times (one per COPY source, add_copy_step.go:158-167); entries accumulate.          */
@@ -253,7 +257,7 @@ int mi_context_checksum(mi_batch* b, const void* prefix, uint64_t prefix_len,
 #define MI_TREE_SCAN    1u
 typedef struct {
     const char* relpath;       /* valid until mi_batch_free                              */
-    const char* link_target;   /* symlinks only                                          */
+    const char* link_target;   /* symlinks only: os.Readlink (context walk) / root-trimmed (scan) */
     int64_t     file_index;    /* regular files: index in the batch, else -1             */
     uint64_t    size;
     int64_t     mtime_sec;     /* truncated to seconds like tario.WriteHeader (write.go:62) */

@@ -50,13 +50,28 @@ struct Tree {
     std::vector<Entry> entries;
 };
 
-// path/filepath.Clean-free helpers: inputs here never contain "." / ".." components
-static std::string abs_path(const std::string& p) {          // pathutils.AbsPath
-    std::string t = p;
-    while (t.size() > 1 && t.back() == '/') t.pop_back();
-    if (t.empty() || t[0] != '/') t = "/" + t;
-    while (t.size() > 1 && t.back() == '/') t.pop_back();
-    return t;
+// Go's path.Clean for a ROOTED path (what path.Join("/", p) returns): single slashes, no "."
+// elements, ".." removes the element before it, ".." at the root disappears.
+static std::string clean_rooted(const std::string& p) {
+    std::vector<std::string> parts;
+    size_t i = 0;
+    while (i < p.size()) {
+        while (i < p.size() && p[i] == '/') ++i;
+        size_t j = i;
+        while (j < p.size() && p[j] != '/') ++j;
+        if (j > i) {
+            const std::string el = p.substr(i, j - i);
+            if (el == "..") { if (!parts.empty()) parts.pop_back(); }
+            else if (el != ".") parts.push_back(el);
+        }
+        i = j;
+    }
+    std::string out;
+    for (const std::string& el : parts) out += "/" + el;
+    return out.empty() ? "/" : out;
+}
+static std::string abs_path(const std::string& p) {          // pathutils.AbsPath (lib/pathutils/path.go:41-43)
+    return clean_rooted(p);                                  // path.Join("/", strings.TrimRight(p, "/"))
 }
 static std::string dir_of(const std::string& p) {            // path.Dir for clean absolute paths
     size_t i = p.find_last_of('/');
@@ -167,6 +182,17 @@ struct Walker {
             if (n < 0) { err = "read link " + path + ": " + strerror(errno); rc = MI_ERR_IO; return; }
             e.link.assign(buf.data(), (size_t)n);
             e.has_link = true;
+            if (mode == MI_TREE_SCAN && !e.link.empty() && e.link[0] == '/') {
+                // memLayer.createHeader (lib/snapshot/mem_layer.go:171-185): an absolute target
+                // loses the root prefix -- pathutils.TrimRoot (lib/pathutils/path.go:63-68):
+                // plain string prefix, then AbsPath; a target outside the root fails the scan
+                if (!has_prefix(e.link, rel_base)) {
+                    err = "trim symlink root: failed to trim root prefix " + rel_base + " from path " + e.link;
+                    rc = MI_ERR_INVALID;
+                    return;
+                }
+                e.link = abs_path(e.link.substr(rel_base.size()));
+            }
             tree->entries.push_back(e);
         } else {
             e.kind = 1;

@@ -65,6 +65,7 @@ def test_context_walk_matches_go_order(tree, engine_lib):
 
 def test_scan_walk_should_skip(tree, engine_lib):
     import makisu_amd
+    os.unlink(tree / "dangling")        # absolute target outside the root: createHeader would fail (below)
     bl = [str(tree / "a" / "deep"), str(tree / "a.d") + "/"]
     got = [g[0] for g in makisu_amd.tree_walk(str(tree), rel_base=str(tree.parent), blacklist=bl,
                                               mode=makisu_amd.TREE_SCAN)]
@@ -79,6 +80,43 @@ def test_scan_walk_should_skip(tree, engine_lib):
     # a path that only shares a name prefix with a blacklisted dir is NOT a descendant
     got2 = [g[0] for g in makisu_amd.tree_walk(str(tree), blacklist=[str(tree / "a")], mode=makisu_amd.TREE_SCAN)]
     assert "a-b" in got2 and "a.txt" in got2 and "a" not in got2 and "a/x.txt" not in got2
+
+
+def test_scan_walk_trims_symlink_root(tree, engine_lib):
+    """memLayer.createHeader (lib/snapshot/mem_layer.go:171-185): in the snapshot walk an ABSOLUTE
+    symlink target loses the root prefix through pathutils.TrimRoot (the cases of
+    lib/pathutils/path_test.go:60-79: inside the root, the root itself, outside -> error); relative
+    targets and the context walk keep the raw os.Readlink value."""
+    import makisu_amd
+    os.unlink(tree / "dangling")
+    root = str(tree)
+    os.symlink(root + "/a/x.txt", tree / "abs-in-root")
+    os.symlink(root + "/a//deep/../deep/er/", tree / "abs-unclean")      # AbsPath = path.Join: cleaned
+    os.symlink(root + "/", tree / "abs-root")
+    os.symlink(root, tree / "abs-root-bare")
+    got = {e["relpath"]: e["link_target"] for e in
+           makisu_amd.tree_walk(root, mode=makisu_amd.TREE_SCAN, full=True) if e["kind"] == 2}
+    assert got["abs-in-root"] == "/a/x.txt"
+    assert got["abs-unclean"] == "/a/deep/er"
+    assert got["abs-root"] == "/" and got["abs-root-bare"] == "/"
+    assert got["a/lnk"] == "x.txt" and got["dirlink"] == "a"             # relative: untouched
+    raw = {e["relpath"]: e["link_target"] for e in makisu_amd.tree_walk(root, full=True) if e["kind"] == 2}
+    assert raw["abs-in-root"] == root + "/a/x.txt"                        # context walk: raw target
+    # TrimRoot is a plain string-prefix test (strings.HasPrefix): a sibling that merely shares the
+    # prefix passes it, as in the reference
+    os.symlink(root + "-sibling/f", tree / "abs-prefix-quirk")
+    got = {e["relpath"]: e["link_target"] for e in
+           makisu_amd.tree_walk(root, mode=makisu_amd.TREE_SCAN, full=True) if e["kind"] == 2}
+    assert got["abs-prefix-quirk"] == "/-sibling/f"
+    # outside the root: "failed to trim root prefix" -> the scan fails
+    os.symlink("/no/such", tree / "dangling")
+    with pytest.raises(makisu_amd.MiError) as ei:
+        makisu_amd.tree_walk(root, mode=makisu_amd.TREE_SCAN)
+    assert ei.value.code == -1
+    # with the real root "/" every absolute target is inside: it is only cleaned
+    assert {e["relpath"]: e["link_target"] for e in
+            makisu_amd.tree_walk(root, rel_base="/", mode=makisu_amd.TREE_SCAN, full=True)
+            if e["kind"] == 2}[root.lstrip("/") + "/dangling"] == "/no/such"
 
 
 def test_walk_single_file_and_errors(tree, engine_lib):
