@@ -282,6 +282,12 @@ void mi_tree_free(mi_tree* tree);
 int mi_context_checksum_tree(mi_batch* b, const void* prefix, uint64_t prefix_len,
                              uint32_t* crc_out);
 
+/* The order MemFS.commitLayer writes entries in (memLayer.rangeFiles, lib/snapshot/
+ * mem_layer.go:232-244: sort.Strings over the absolute dst paths; a whiteout marker
+ * ".wh.<name>" sorts under the path it deletes, addHeader :190-211) -- not the walk order
+ * ("a-b" < "a/x").  order_out[k] = index of the k-th entry to commit.  Host logic.        */
+int mi_entries_commit_order(const mi_tree_entry* entries, uint64_t n, uint64_t* order_out);
+
 /* "Did this path change?" -- tario.IsSimilarHeader (lib/tario/compare.go:24-117), the test
  * behind MemFS.isUpdated (lib/snapshot/mem_fs.go:487-503), on walk entries: two entries with
  * empty relpaths are similar; otherwise the kinds must match and symlinks compare their

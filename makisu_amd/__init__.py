@@ -146,6 +146,7 @@ def load_library(rebuild=False):
                           C.POINTER(vp), u64p], C.c_int),
         "mi_tree_entries": ([vp, C.POINTER(TreeEntry), u64], C.c_int),
         "mi_tree_free": ([vp], None),
+        "mi_entries_commit_order": ([C.POINTER(TreeEntry), u64, u64p], C.c_int),
         "mi_entry_similar": ([C.POINTER(TreeEntry), C.POINTER(TreeEntry), C.c_int, vp, vp,
                               C.POINTER(C.c_int)], C.c_int),
         "mi_comm_unique_id": ([vp], C.c_int),
@@ -207,6 +208,21 @@ def entry_similar(a, b, ignore_time=False, root_a=None, root_b=None):
     if rc:
         raise MiError(rc, "mi_entry_similar: unsupported type")
     return bool(out.value)
+
+
+def commit_order(relpaths):
+    """memLayer.rangeFiles' order (sort.Strings over absolute dst paths, whiteout markers under the
+    path they delete) for a list of relpaths: list of indices in commit order."""
+    n = len(relpaths)
+    arr = (TreeEntry * max(n, 1))()
+    keep = [os.fsencode(r) for r in relpaths]
+    for i, r in enumerate(keep):
+        arr[i].relpath = r
+    out = (C.c_uint64 * max(n, 1))()
+    rc = load_library().mi_entries_commit_order(arr, n, out)
+    if rc:
+        raise MiError(rc, "mi_entries_commit_order")
+    return [int(out[i]) for i in range(n)]
 
 
 def _entry_dict(e):

@@ -314,6 +314,30 @@ int mi_context_checksum_tree(mi_batch* b, const void* prefix, uint64_t prefix_le
 
 void mi_batch_tree_free(void* tree) { delete (Tree*)tree; }
 
+// The order MemFS.commitLayer writes a layer's entries in: memLayer.rangeFiles
+// (lib/snapshot/mem_layer.go:232-244) sort.Strings the map keys, and addHeader (:190-211) keys
+// an entry by its absolute dst path -- a whiteout marker ".wh.<name>" by the path of the file it
+// deletes (dir + name without the prefix).  This is NOT the walk order ("a-b" sorts before
+// "a/x": '-' < '/'), so the shim needs it to line the engine's per-file results up with the tar
+// stream.  order_out[k] = index of the k-th entry to commit; equal keys keep their input order.
+int mi_entries_commit_order(const mi_tree_entry* entries, uint64_t n, uint64_t* order_out) {
+    if ((n && !entries) || (n && !order_out)) return MI_ERR_INVALID;
+    std::vector<std::string> keys((size_t)n);
+    for (uint64_t i = 0; i < n; ++i) {
+        const char* rp = entries[i].relpath ? entries[i].relpath : "";
+        std::string dst = mi_walk::abs_path(strcmp(rp, ".") == 0 ? "" : rp);
+        const size_t cut = dst.find_last_of('/');
+        const std::string dir = dst.substr(0, cut + 1), base = dst.substr(cut + 1);
+        keys[(size_t)i] = mi_walk::has_prefix(base, ".wh.") ? dir + base.substr(4) : dst;
+    }
+    std::vector<uint64_t> idx((size_t)n);
+    for (uint64_t i = 0; i < n; ++i) idx[(size_t)i] = i;
+    std::stable_sort(idx.begin(), idx.end(),
+                     [&](uint64_t a, uint64_t b) { return keys[(size_t)a] < keys[(size_t)b]; });   // bytewise
+    for (uint64_t i = 0; i < n; ++i) order_out[i] = idx[(size_t)i];
+    return MI_OK;
+}
+
 // tario.IsSimilarHeader (lib/tario/compare.go:24-117) on walk entries, plus the optional
 // content roots (see the header)
 int mi_entry_similar(const mi_tree_entry* a, const mi_tree_entry* b, int ignore_time,

@@ -222,3 +222,28 @@ def test_entry_similar_content_roots():
     assert makisu_amd.entry_similar(a, dict(a), root_a=r1, root_b=None)       # one side unknown: metadata only
     d = dict(a, kind=0)
     assert makisu_amd.entry_similar(d, dict(d), root_a=r1, root_b=r2)         # roots only matter for files
+
+
+def test_commit_order_is_sorted_dst_paths_not_walk_order(tree, engine_lib):
+    """memLayer.rangeFiles (lib/snapshot/mem_layer.go:232-244): sort.Strings over the absolute dst
+    paths; addHeader keys a whiteout marker by the path it deletes (:190-211)."""
+    import makisu_amd
+    os.unlink(tree / "dangling")
+    rels = [g[0] for g in makisu_amd.tree_walk(str(tree), mode=makisu_amd.TREE_SCAN)]
+
+    def key(r):
+        dst = "/" if r == "." else "/" + r
+        d, b = dst.rsplit("/", 1)
+        return ((d + "/" + b[4:]) if b.startswith(".wh.") else dst).encode()
+
+    order = makisu_amd.commit_order(rels)
+    assert sorted(order) == list(range(len(rels)))
+    assert order == sorted(range(len(rels)), key=lambda i: key(rels[i]))
+    names = [rels[i] for i in order]
+    assert names[0] == "."                                             # "/" first
+    assert names.index("a-b") < names.index("a/x.txt")                 # '-' < '/': differs from Walk
+    assert rels.index("a-b") > rels.index("a/x.txt")
+    assert names.index("z/.wh.gone") < names.index("z/last")           # keyed as /z/gone
+    # equal keys (a whiteout marker and the file it hides) keep input order; empty input is fine
+    assert makisu_amd.commit_order(["d/.wh.x", "d/x", "d/.wh.x"]) == [0, 1, 2]
+    assert makisu_amd.commit_order([]) == []
