@@ -301,6 +301,31 @@ int mi_entries_commit_order(const mi_tree_entry* entries, uint64_t n, uint64_t* 
 int mi_entry_similar(const mi_tree_entry* a, const mi_tree_entry* b, int ignore_time,
                      const uint8_t* root_a, const uint8_t* root_b, int* similar);
 
+/* The layer diff of a scan, on two walks -- what MemFS.createLayerByScan + maybeAddToLayer
+ * (lib/snapshot/mem_fs.go:315-341, 440-480) decide against the in-memory tree:
+ *   after_flags[i]      MI_DIFF_CHANGED  the path is new or mi_entry_similar says it changed
+ *                                        (content-aware when both sides carry chunk roots);
+ *                       MI_DIFF_ANCESTOR an unchanged directory carried along because something
+ *                                        below it changed or was deleted (addAncestors);
+ *                       MI_DIFF_SAME     not part of the layer.  The root ("." ) never is.
+ *   before_whiteout[j]  1 = write a whiteout for this path: it is gone, and it is the top of
+ *                       the deleted subtree under a parent that still is a directory
+ *                       ("only one whiteout file is needed for a deleted subtree", :461).
+ * A side's roots: 32-byte chunk roots indexed by entry.file_index with a byte stride (pass
+ * &files[0].chunk_root and sizeof(mi_file_result)), or NULL for the reference's
+ * metadata-only rule.  Host logic.                                                       */
+#define MI_DIFF_SAME     0u
+#define MI_DIFF_CHANGED  1u
+#define MI_DIFF_ANCESTOR 2u
+typedef struct {
+    const mi_tree_entry* entries;
+    uint64_t             n;
+    const void*          roots;        /* may be NULL */
+    uint64_t             root_stride;
+} mi_snapshot_side;
+int mi_snapshot_diff(const mi_snapshot_side* before, const mi_snapshot_side* after, int ignore_time,
+                     uint8_t* after_flags, uint8_t* before_whiteout);
+
 /* ---- standalone digests (image.Digester seam) ---------------------------------- *
  * n independent byte strings -> n SHA-256 digests on the GPU, one lane per string:
  * the batched form of image.NewDigester().FromBytes / FromReader

@@ -65,6 +65,15 @@ class TreeEntry(C.Structure):
 TREE_CONTEXT, TREE_SCAN = 0, 1
 
 
+class SnapshotSide(C.Structure):
+    """mi_snapshot_side: one walk (+ optional chunk roots by file_index) for mi_snapshot_diff."""
+    _fields_ = [("entries", C.POINTER(TreeEntry)), ("n", C.c_uint64), ("roots", C.c_void_p),
+                ("root_stride", C.c_uint64)]
+
+
+DIFF_SAME, DIFF_CHANGED, DIFF_ANCESTOR = 0, 1, 2
+
+
 class Stats(C.Structure):
     _fields_ = [("bytes_in", C.c_uint64), ("n_files", C.c_uint64), ("n_chunks", C.c_uint64),
                 ("n_unique", C.c_uint64), ("ms_h2d", C.c_double), ("ms_cdc", C.c_double),
@@ -147,6 +156,7 @@ def load_library(rebuild=False):
         "mi_tree_entries": ([vp, C.POINTER(TreeEntry), u64], C.c_int),
         "mi_tree_free": ([vp], None),
         "mi_entries_commit_order": ([C.POINTER(TreeEntry), u64, u64p], C.c_int),
+        "mi_snapshot_diff": ([C.POINTER(SnapshotSide), C.POINTER(SnapshotSide), C.c_int, vp, vp], C.c_int),
         "mi_entry_similar": ([C.POINTER(TreeEntry), C.POINTER(TreeEntry), C.c_int, vp, vp,
                               C.POINTER(C.c_int)], C.c_int),
         "mi_comm_unique_id": ([vp], C.c_int),
@@ -223,6 +233,45 @@ def commit_order(relpaths):
     if rc:
         raise MiError(rc, "mi_entries_commit_order")
     return [int(out[i]) for i in range(n)]
+
+
+def _entry_array(dicts, keep):
+    arr = (TreeEntry * max(len(dicts), 1))()
+    for i, d in enumerate(dicts):
+        rp = os.fsencode(d.get("relpath", ""))
+        lt = d.get("link_target")
+        lt = os.fsencode(lt) if lt is not None else None
+        keep += [rp, lt]
+        arr[i].relpath, arr[i].link_target = rp, lt
+        arr[i].file_index = d.get("file_index", -1)
+        for k in ("size", "mtime_sec", "mode", "kind", "uid", "gid"):
+            setattr(arr[i], k, d.get(k, 0))
+    return arr
+
+
+def snapshot_diff(before, after, ignore_time=False, roots_before=None, roots_after=None):
+    """mi_snapshot_diff on two lists of entry dicts (tree_walk(..., full=True)); roots_* = (n_files,
+    32) uint8 arrays indexed by file_index, or None.  Returns (flags per `after` entry, whiteout
+    flags per `before` entry) as lists of ints."""
+    keep = []
+    sides = []
+    for ents, roots in ((before, roots_before), (after, roots_after)):
+        side = SnapshotSide()
+        arr = _entry_array(ents, keep)
+        keep.append(arr)
+        side.entries, side.n = arr, len(ents)
+        if roots is not None:
+            r = np.ascontiguousarray(roots, dtype=np.uint8).reshape(-1, 32)
+            keep.append(r)
+            side.roots, side.root_stride = r.ctypes.data, 32
+        sides.append(side)
+    flags = np.zeros(max(len(after), 1), dtype=np.uint8)
+    wh = np.zeros(max(len(before), 1), dtype=np.uint8)
+    rc = load_library().mi_snapshot_diff(C.byref(sides[0]), C.byref(sides[1]), int(ignore_time),
+                                         flags.ctypes.data, wh.ctypes.data)
+    if rc:
+        raise MiError(rc, "mi_snapshot_diff")
+    return flags[: len(after)].tolist(), wh[: len(before)].tolist()
 
 
 def _entry_dict(e):

@@ -28,6 +28,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <map>
 #include <mutex>
 #include <set>
 #include <string>
@@ -335,6 +336,71 @@ int mi_entries_commit_order(const mi_tree_entry* entries, uint64_t n, uint64_t* 
     std::stable_sort(idx.begin(), idx.end(),
                      [&](uint64_t a, uint64_t b) { return keys[(size_t)a] < keys[(size_t)b]; });   // bytewise
     for (uint64_t i = 0; i < n; ++i) order_out[i] = idx[(size_t)i];
+    return MI_OK;
+}
+
+extern "C" int mi_entry_similar(const mi_tree_entry* a, const mi_tree_entry* b, int ignore_time,
+                                const uint8_t* root_a, const uint8_t* root_b, int* similar);
+
+// The layer diff of a scan, on two walks: what MemFS.createLayerByScan + maybeAddToLayer
+// (lib/snapshot/mem_fs.go:315-341, 440-480) decide entry by entry against the in-memory tree --
+//   * an entry is added when its path is new or isUpdated says so (mem_fs.go:487-503; here
+//     mi_entry_similar, content-aware when both sides carry chunk roots); the root itself never is;
+//   * every ancestor directory of an added entry and of a whiteout is carried along
+//     (addAncestors);
+//   * a path that was there and is gone gets ONE whiteout at the top of the deleted subtree, and
+//     only under a parent that still is a directory (the loop over n.children of a TypeDir header).
+extern "C" int mi_snapshot_diff(const mi_snapshot_side* before, const mi_snapshot_side* after, int ignore_time,
+                                uint8_t* after_flags, uint8_t* before_whiteout) {
+    if (!before || !after || (before->n && !before->entries) || (after->n && !after->entries) ||
+        (after->n && !after_flags) || (before->n && !before_whiteout))
+        return MI_ERR_INVALID;
+    auto path_of = [](const mi_tree_entry& e) {
+        const char* rp = e.relpath ? e.relpath : "";
+        return mi_walk::abs_path(strcmp(rp, ".") == 0 ? "" : rp);
+    };
+    auto root_of = [](const mi_snapshot_side* s, const mi_tree_entry& e) -> const uint8_t* {
+        if (!s->roots || e.kind != 1 || e.file_index < 0) return nullptr;
+        return (const uint8_t*)s->roots + (uint64_t)e.file_index * s->root_stride;
+    };
+    std::map<std::string, uint64_t> old_at, new_at;
+    for (uint64_t i = 0; i < before->n; ++i) old_at[path_of(before->entries[i])] = i;
+    for (uint64_t i = 0; i < after->n; ++i) new_at[path_of(after->entries[i])] = i;
+    for (uint64_t i = 0; i < after->n; ++i) after_flags[i] = MI_DIFF_SAME;
+    for (uint64_t i = 0; i < before->n; ++i) before_whiteout[i] = 0;
+    auto carry_ancestors = [&](const std::string& p) {
+        std::string d = mi_walk::dir_of(p);
+        while (d != "/" && d != ".") {
+            auto it = new_at.find(d);
+            if (it != new_at.end() && after_flags[it->second] == MI_DIFF_SAME) after_flags[it->second] = MI_DIFF_ANCESTOR;
+            d = mi_walk::dir_of(d);
+        }
+    };
+    for (auto& kv : new_at) {
+        if (kv.first == "/") continue;                       // "Root itself is not added to layers"
+        const mi_tree_entry& e = after->entries[kv.second];
+        bool updated = true;
+        auto it = old_at.find(kv.first);
+        if (it != old_at.end()) {
+            const mi_tree_entry& o = before->entries[it->second];
+            int similar = 0;
+            int rc = mi_entry_similar(&o, &e, ignore_time, root_of(before, o), root_of(after, e), &similar);
+            if (rc) return rc;                               // "unsupported type"
+            updated = !similar;
+        }
+        if (updated) {
+            after_flags[kv.second] = MI_DIFF_CHANGED;
+            carry_ancestors(kv.first);
+        }
+    }
+    for (auto& kv : old_at) {
+        if (kv.first == "/" || new_at.count(kv.first)) continue;
+        const std::string parent = mi_walk::dir_of(kv.first);
+        auto pit = new_at.find(parent);
+        if (pit == new_at.end() || after->entries[pit->second].kind != 0) continue;   // deeper in a deleted subtree,
+        before_whiteout[kv.second] = 1;                                                // or its parent became a file
+        carry_ancestors(kv.first);
+    }
     return MI_OK;
 }
 

@@ -5,6 +5,7 @@ The table cases for IsDescendantOfAny follow lib/pathutils/path.go:24-35."""
 import os
 import stat
 
+import numpy as np
 import pytest
 
 
@@ -247,3 +248,84 @@ def test_commit_order_is_sorted_dst_paths_not_walk_order(tree, engine_lib):
     # equal keys (a whiteout marker and the file it hides) keep input order; empty input is fine
     assert makisu_amd.commit_order(["d/.wh.x", "d/x", "d/.wh.x"]) == [0, 1, 2]
     assert makisu_amd.commit_order([]) == []
+
+
+# ---- mi_snapshot_diff: createLayerByScan + maybeAddToLayer on two walks ----------------------
+def _diff_names(before, after, **kw):
+    import makisu_amd
+    flags, wh = makisu_amd.snapshot_diff(before, after, **kw)
+    changed = sorted(e["relpath"] for e, f in zip(after, flags) if f == makisu_amd.DIFF_CHANGED)
+    carried = sorted(e["relpath"] for e, f in zip(after, flags) if f == makisu_amd.DIFF_ANCESTOR)
+    whiteouts = sorted(e["relpath"] for e, w in zip(before, wh) if w)
+    return changed, carried, whiteouts
+
+
+def test_snapshot_diff_on_real_trees(tmp_path, engine_lib):
+    """Two lstat walks of the same directory before/after edits -- the cases of the reference's
+    scan tests (lib/snapshot/mem_fs_test.go: TestCreateLayerByScan :572-686 add / modify / delete,
+    TestAddLayerByScanWhiteout :1038-1116 one whiteout per deleted subtree)."""
+    import shutil
+    import time
+    import makisu_amd
+    root = tmp_path / "fs"
+    os.makedirs(root / "etc" / "conf.d")
+    os.makedirs(root / "usr" / "lib" / "deep" / "er")
+    os.makedirs(root / "var")
+    (root / "etc" / "passwd").write_bytes(b"root:x:0:0\n")
+    (root / "etc" / "conf.d" / "a.conf").write_bytes(b"a=1\n")
+    (root / "usr" / "lib" / "libx.so").write_bytes(b"\x7fELF" + bytes(100))
+    (root / "usr" / "lib" / "deep" / "er" / "f").write_bytes(b"f")
+    (root / "var" / "log").write_bytes(b"")
+    os.symlink("passwd", root / "etc" / "alias")
+    old = int(time.time()) - 7200
+    for dp, dns, fns in os.walk(root):
+        for n in dns + fns:
+            os.utime(os.path.join(dp, n), (old, old), follow_symlinks=False)
+    os.utime(root, (old, old))
+    before = makisu_amd.tree_walk(str(root), mode=makisu_amd.TREE_SCAN, full=True)
+    assert _diff_names(before, before) == ([], [], [])                     # nothing happened
+
+    (root / "etc" / "conf.d" / "b.conf").write_bytes(b"b=2\n")            # added (dir mtime changes too)
+    (root / "etc" / "passwd").write_bytes(b"root:x:0:0\nme:x:1:1\n")      # modified: new size
+    os.unlink(root / "etc" / "alias")
+    os.symlink("conf.d/a.conf", root / "etc" / "alias")                    # symlink retargeted
+    shutil.rmtree(root / "usr" / "lib" / "deep")                           # a subtree goes away
+    os.unlink(root / "var" / "log")
+    os.mkdir(root / "var" / "log")                                         # file replaced by a directory
+    for p in (root / "etc", root / "usr" / "lib", root / "var"):           # undo the dir mtime bumps we do not
+        os.utime(p, (old, old))                                            # want to test here
+    after = makisu_amd.tree_walk(str(root), mode=makisu_amd.TREE_SCAN, full=True)
+    changed, carried, whiteouts = _diff_names(before, after)
+    assert changed == ["etc/alias", "etc/conf.d", "etc/conf.d/b.conf", "etc/passwd", "var/log"]
+    assert carried == ["etc", "usr", "usr/lib", "var"]                     # ancestors of changes AND of the whiteout
+    assert whiteouts == ["usr/lib/deep"]                                   # one for the whole subtree
+    # ignore_time: the conf.d directory (mtime bumped by the new file) no longer counts
+    changed_it, _, _ = _diff_names(before, after, ignore_time=True)
+    assert "etc/conf.d" not in changed_it and "etc/conf.d/b.conf" in changed_it
+    # a directory replaced by a FILE: the children get no whiteouts (the file overwrites the dir)
+    shutil.rmtree(root / "etc" / "conf.d")
+    (root / "etc" / "conf.d").write_bytes(b"now a file")
+    after2 = makisu_amd.tree_walk(str(root), mode=makisu_amd.TREE_SCAN, full=True)
+    changed2, _, whiteouts2 = _diff_names(before, after2)
+    assert "etc/conf.d" in changed2 and not any(w.startswith("etc/conf.d") for w in whiteouts2)
+
+
+def test_snapshot_diff_content_aware(engine_lib):
+    """Same size, same second, same owner, different bytes: invisible to the reference's rule
+    (compare.go:101-103), caught once both sides carry chunk roots."""
+    import hashlib
+    f = {"relpath": "app/bin", "size": 5, "mtime_sec": 100, "mode": 0o100755, "kind": 1, "file_index": 0}
+    d = {"relpath": "app", "mode": 0o40755, "kind": 0, "mtime_sec": 100}
+    top = {"relpath": ".", "mode": 0o40755, "kind": 0, "mtime_sec": 100}
+    r1 = np.frombuffer(hashlib.sha256(b"test1").digest(), dtype=np.uint8)
+    r2 = np.frombuffer(hashlib.sha256(b"test2").digest(), dtype=np.uint8)
+    assert _diff_names([top, d, f], [top, d, f]) == ([], [], [])
+    assert _diff_names([top, d, f], [top, d, f], roots_before=r1, roots_after=r1) == ([], [], [])
+    assert _diff_names([top, d, f], [top, d, f], roots_before=r1, roots_after=r2) == (["app/bin"], ["app"], [])
+    assert _diff_names([top, d, f], [top, d, f], roots_before=r1, roots_after=None) == ([], [], [])
+    # deleting everything below the root: whiteouts only for the top-level children
+    assert _diff_names([top, d, f], [top]) == ([], [], ["app"])
+    # an entry of an unsupported kind on the old side is the reference's "unsupported type" error
+    import makisu_amd
+    with pytest.raises(makisu_amd.MiError):
+        makisu_amd.snapshot_diff([dict(f, kind=9)], [f])
