@@ -329,3 +329,24 @@ def test_snapshot_diff_content_aware(engine_lib):
     import makisu_amd
     with pytest.raises(makisu_amd.MiError):
         makisu_amd.snapshot_diff([dict(f, kind=9)], [f])
+
+
+def test_snapshot_diff_mirrors_add_layer_by_scan_whiteout(tmp_path, engine_lib):
+    """lib/snapshot/mem_fs_test.go:1038-1116 (TestAddLayerByScanWhiteout): six entries under /test1
+    make a 6-entry layer (the root is not added); removing /test1 makes a 1-entry layer: one
+    whiteout for the whole subtree."""
+    import shutil
+    import makisu_amd
+    root = tmp_path / "fs"
+    os.makedirs(root / "test1" / "test2")
+    (root / "test1" / "test2" / "test3.txt").write_bytes(b"hello")
+    os.makedirs(root / "test1" / "test4" / "test5")
+    (root / "test1" / "test4" / "test5" / "test6.txt").write_bytes(b"hello")
+    empty = makisu_amd.tree_walk(str(tmp_path / "fs"), mode=makisu_amd.TREE_SCAN, full=True)[:1]   # just "."
+    first = makisu_amd.tree_walk(str(root), mode=makisu_amd.TREE_SCAN, full=True)
+    changed, carried, whiteouts = _diff_names(empty, first)
+    assert len(changed) == 6 and not carried and not whiteouts              # require.Equal(6, ...count())
+    shutil.rmtree(root / "test1")
+    second = makisu_amd.tree_walk(str(root), mode=makisu_amd.TREE_SCAN, full=True)
+    changed, carried, whiteouts = _diff_names(first, second, ignore_time=True)
+    assert (changed, carried, whiteouts) == ([], [], ["test1"])             # require.Equal(1, ...count())
