@@ -350,3 +350,54 @@ def test_snapshot_diff_mirrors_add_layer_by_scan_whiteout(tmp_path, engine_lib):
     second = makisu_amd.tree_walk(str(root), mode=makisu_amd.TREE_SCAN, full=True)
     changed, carried, whiteouts = _diff_names(first, second, ignore_time=True)
     assert (changed, carried, whiteouts) == ([], [], ["test1"])             # require.Equal(1, ...count())
+
+
+def _layer_members(before, after):
+    """The set of tar entry names the diff puts in the layer (whiteouts as dir/.wh.<name>)."""
+    changed, carried, whiteouts = _diff_names(before, after)
+    wh = [os.path.join(os.path.dirname(w), ".wh." + os.path.basename(w)) for w in whiteouts]
+    return sorted(changed + carried + wh)
+
+
+def test_snapshot_diff_mirrors_create_layer_by_scan(tmp_path, engine_lib):
+    """lib/snapshot/mem_fs_test.go:572-686 (TestCreateLayerByScan: Simple, Symlink, Whiteout): the
+    layer each scan must produce, given what the previous scan saw."""
+    import shutil
+    import makisu_amd
+
+    def scan(root):
+        return makisu_amd.tree_walk(str(root), mode=makisu_amd.TREE_SCAN, full=True)
+
+    # Simple
+    root = tmp_path / "simple"
+    os.makedirs(root)
+    s0 = scan(root)
+    os.makedirs(root / "test1")
+    (root / "test1" / "test.txt").write_bytes(b"hello")
+    s1 = scan(root)
+    assert _layer_members(s0, s1) == ["test1", "test1/test.txt"]
+    os.makedirs(root / "test1" / "test2" / "test3")
+    s2 = scan(root)
+    assert _layer_members(s1, s2) == ["test1", "test1/test2", "test1/test2/test3"]   # not test.txt
+
+    # Symlink
+    root = tmp_path / "symlink"
+    os.makedirs(root / "test11" / "test12" / "ignore1")
+    s1 = scan(root)
+    assert _layer_members(scan(tmp_path / "simple")[:1], s1) == ["test11", "test11/test12", "test11/test12/ignore1"]
+    os.makedirs(root / "test21" / "test22" / "ignore2")
+    os.symlink(str(root / "test11"), root / "test21" / "test22" / "link")
+    s2 = scan(root)
+    assert _layer_members(s1, s2) == ["test21", "test21/test22", "test21/test22/ignore2", "test21/test22/link"]
+    assert [e["link_target"] for e in s2 if e["relpath"].endswith("/link")] == ["/test11"]   # root-trimmed
+
+    # Whiteout
+    root = tmp_path / "whiteout"
+    os.makedirs(root / "test11" / "test12")
+    (root / "test11" / "test12" / "test.txt").write_bytes(b"hello")
+    (root / "test11" / "test14.txt").write_bytes(b"hello")
+    s1 = scan(root)
+    shutil.rmtree(root / "test11" / "test12")
+    os.unlink(root / "test11" / "test14.txt")
+    s2 = scan(root)
+    assert _layer_members(s1, s2) == ["test11", "test11/.wh.test12", "test11/.wh.test14.txt"]
