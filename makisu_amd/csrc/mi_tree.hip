@@ -23,6 +23,7 @@
 #include <dirent.h>
 #include <errno.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -105,24 +106,37 @@ static std::string rel_to(const std::string& base, const std::string& path) {   
     return std::string();                                                        // outside: caller errors
 }
 
-static const std::set<std::string>& mountpoints() {
-    static std::set<std::string> mp;
+// mountutils' table (lib/mountutils/mountutils.go:54-93): targets of /proc/mounts except "/";
+// a missing file means "no mountpoints", a line with fewer than four fields is an error that
+// fails every walk ("cannot parse mounts file").  MI_MOUNTS_FILE names another file, the way
+// the reference's tests swap mountInfo.mountsFile (mountutils_test.go:25-45).
+struct MountTable {
+    std::set<std::string> targets;
+    std::string error;
+};
+static const MountTable& mountpoints() {
+    static MountTable mt;
     static std::once_flag once;                              // like the reference's sync.Once
     std::call_once(once, [] {
-        if (FILE* f = fopen("/proc/mounts", "r")) {
-            char line[8192];
-            while (fgets(line, sizeof line, f)) {
-                char* sp1 = strchr(line, ' ');
-                if (!sp1) continue;
-                char* sp2 = strchr(sp1 + 1, ' ');
-                if (!sp2) continue;
-                std::string target(sp1 + 1, sp2);
-                if (target != "/") mp.insert(target);     // "/" skipped as the reference does
-            }
-            fclose(f);
+        const char* over = getenv("MI_MOUNTS_FILE");
+        const std::string file = over && *over ? over : "/proc/mounts";
+        FILE* f = fopen(file.c_str(), "r");
+        if (!f) return;                                      // "Skipping mountmanager init"
+        char line[8192];
+        while (fgets(line, sizeof line, f)) {
+            size_t n = strlen(line);
+            while (n && (line[n - 1] == '\n')) line[--n] = 0;
+            if (n == 0) continue;
+            char* sp1 = strchr(line, ' ');
+            char* sp2 = sp1 ? strchr(sp1 + 1, ' ') : nullptr;
+            char* sp3 = sp2 ? strchr(sp2 + 1, ' ') : nullptr;
+            if (!sp3) { mt.error = "cannot parse mounts file " + file; break; }
+            std::string target(sp1 + 1, sp2);
+            if (target != "/") mt.targets.insert(target);    // "/" skipped as the reference does
         }
+        fclose(f);
     });
-    return mp;
+    return mt;
 }
 
 struct Walker {
@@ -140,7 +154,9 @@ struct Walker {
         if (mode == MI_TREE_CONTEXT) return special;
         if (has_prefix(base_of(path), ".wh..wh.")) return true;
         if (is_descendant_of_any(path, blacklist) || special) return true;
-        return mountpoints().count(path) != 0;
+        const MountTable& mt = mountpoints();
+        if (!mt.error.empty()) { err = "ismount: mountmanager initialize: " + mt.error; rc = MI_ERR_IO; return true; }
+        return mt.targets.count(path) != 0;
     }
 
     void visit(const std::string& path) {

@@ -401,3 +401,50 @@ def test_snapshot_diff_mirrors_create_layer_by_scan(tmp_path, engine_lib):
     os.unlink(root / "test11" / "test14.txt")
     s2 = scan(root)
     assert _layer_members(s1, s2) == ["test11", "test11/.wh.test12", "test11/.wh.test14.txt"]
+
+
+def _walk_in_subprocess(code, env_extra):
+    import subprocess
+    import sys
+    env = dict(os.environ, **env_extra)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r)\n%s" % (root, code)],
+                          env=env, capture_output=True, text=True)
+
+
+def test_scan_walk_skips_mountpoints_from_the_mounts_table(tmp_path, engine_lib):
+    """mountutils.IsMountpoint (lib/mountutils/mountutils.go:54-93) with a swapped mounts file, as
+    in mountutils_test.go:25-45: an exact target match is a mountpoint (its subtree is pruned), a
+    longer name is not; "/" lines are ignored; the context walk does not look at mounts; a line
+    with fewer than four fields fails the walk (:102-116 "Bad /proc/mounts format")."""
+    root = tmp_path / "fs"
+    os.makedirs(root / "etc" / "hosts")                     # a directory mountpoint with content below
+    (root / "etc" / "hosts" / "inside").write_bytes(b"x")
+    (root / "etc" / "hosts.txt").write_bytes(b"not a mountpoint")
+    (root / "etc" / "hostname").write_bytes(b"file mountpoint")
+    mounts = tmp_path / "mounts"
+    mounts.write_text("overlay / overlay rw 0 0\n"
+                      "cgroup %s/etc/hostname etx4 ro,nosuid,nodev,noexec,mode=755 0 0\n"
+                      "cgroup %s/etc/hosts etx4 ro,nosuid,nodev,noexec,mode=755 0 0\n" % (root, root))
+    code = ("import makisu_amd, json\n"
+            "print(json.dumps([[g[0] for g in makisu_amd.tree_walk(%r, mode=m)] for m in (makisu_amd.TREE_SCAN, makisu_amd.TREE_CONTEXT)]))"
+            % str(root))
+    out = _walk_in_subprocess(code, {"MI_MOUNTS_FILE": str(mounts)})
+    assert out.returncode == 0, out.stderr
+    import json
+    scan, context = json.loads(out.stdout.strip().splitlines()[-1])
+    assert scan == [".", "etc", "etc/hosts.txt"]
+    assert context == [".", "etc", "etc/hostname", "etc/hosts", "etc/hosts/inside", "etc/hosts.txt"]
+    # a missing mounts file = no mountpoints (:118-127)
+    out = _walk_in_subprocess(code, {"MI_MOUNTS_FILE": str(tmp_path / "absent")})
+    assert json.loads(out.stdout.strip().splitlines()[-1])[0] == context
+    # bad format: every scan walk fails, the context walk still works
+    mounts.write_text("cgroup /etc/hostname\n")
+    code_bad = ("import makisu_amd\n"
+                "print(len(makisu_amd.tree_walk(%r)))\n"
+                "try:\n"
+                "    makisu_amd.tree_walk(%r, mode=makisu_amd.TREE_SCAN)\n"
+                "except makisu_amd.MiError as e:\n"
+                "    print('ERR', e.code)\n" % (str(root), str(root)))
+    out = _walk_in_subprocess(code_bad, {"MI_MOUNTS_FILE": str(mounts)})
+    assert out.stdout.split() == ["6", "ERR", "-5"], out.stdout + out.stderr
