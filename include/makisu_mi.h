@@ -245,7 +245,10 @@ int mi_context_checksum(mi_batch* b, const void* prefix, uint64_t prefix_len,
  *   MI_TREE_SCAN     the snapshot walk (lib/snapshot/utils.go:37-75): also skips
  *                    ".wh..wh."-prefixed names, blacklist descendants
  *                    (lib/pathutils/path.go:24-35) and mountpoints
- *                    (lib/mountutils/mountutils.go:54-93); skipped directories are pruned.
+ *                    (lib/mountutils/mountutils.go:54-93; the table is read once per
+ *                    process from /proc/mounts, or from the file MI_MOUNTS_FILE names -- the
+ *                    reference's tests swap mountInfo.mountsFile the same way; a malformed
+ *                    table fails the walk with MI_ERR_IO); skipped directories are pruned.
  *                    As in memLayer.createHeader (lib/snapshot/mem_layer.go:171-185) an
  *                    ABSOLUTE symlink target loses the rel_base prefix (pathutils.TrimRoot,
  *                    path.go:63-68: plain string prefix, then AbsPath); a target outside
