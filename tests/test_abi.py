@@ -47,6 +47,12 @@ int main(void) {
   printf("%zu %zu %zu %zu\n", sizeof(mi_config), sizeof(mi_file_result), sizeof(mi_chunk_result), sizeof(mi_stats));
   printf("%zu %zu %zu %zu\n", offsetof(mi_file_result, chunk_root), offsetof(mi_file_result, file_sha256),
          offsetof(mi_chunk_result, dup_of), offsetof(mi_chunk_result, sha256));
+  printf("%zu %zu %zu\n", sizeof(mi_tree_entry), sizeof(mi_ctx_entry), sizeof(mi_snapshot_side));
+  printf("%zu %zu %zu %zu %zu %zu\n", offsetof(mi_tree_entry, file_index), offsetof(mi_tree_entry, mtime_sec),
+         offsetof(mi_tree_entry, mode), offsetof(mi_tree_entry, kind), offsetof(mi_tree_entry, uid),
+         offsetof(mi_tree_entry, gid));
+  printf("%zu %zu %zu\n", offsetof(mi_ctx_entry, file_index), offsetof(mi_snapshot_side, roots),
+         offsetof(mi_snapshot_side, root_stride));
   return 0; }''')
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
@@ -56,6 +62,10 @@ int main(void) {
             C.sizeof(makisu_amd.Stats),
             makisu_amd.FILE_DTYPE.fields["chunk_root"][1], makisu_amd.FILE_DTYPE.fields["file_sha256"][1],
             makisu_amd.CHUNK_DTYPE.fields["dup_of"][1], makisu_amd.CHUNK_DTYPE.fields["sha256"][1]]
+    T, X, S = makisu_amd.TreeEntry, makisu_amd.CtxEntry, makisu_amd.SnapshotSide
+    want += [C.sizeof(T), C.sizeof(X), C.sizeof(S),
+             T.file_index.offset, T.mtime_sec.offset, T.mode.offset, T.kind.offset, T.uid.offset, T.gid.offset,
+             X.file_index.offset, S.roots.offset, S.root_stride.offset]
     assert got == want
 
 
