@@ -448,3 +448,37 @@ def test_scan_walk_skips_mountpoints_from_the_mounts_table(tmp_path, engine_lib)
                 "    print('ERR', e.code)\n" % (str(root), str(root)))
     out = _walk_in_subprocess(code_bad, {"MI_MOUNTS_FILE": str(mounts)})
     assert out.stdout.split() == ["6", "ERR", "-5"], out.stdout + out.stderr
+
+
+def test_plain_c_host_consumer(tmp_path, engine_lib):
+    """tests/cabi/host_driver.c: the host-side entry points (walk, commit order, layer diff,
+    header comparison) used from plain C against the header, compared with the Python binding."""
+    import shutil
+    import subprocess
+    import makisu_amd
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "host_driver")
+    subprocess.check_call(["gcc", "-O1", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cabi", "host_driver.c"), "-o", exe,
+                           "-L", os.path.join(root, "makisu_amd"), "-lmakisu_mi",
+                           "-Wl,-rpath," + os.path.join(root, "makisu_amd")])
+    a, b = tmp_path / "before", tmp_path / "after"
+    os.makedirs(a / "d" / "sub")
+    (a / "d" / "sub" / "f").write_bytes(b"1")
+    (a / "d-x").write_bytes(b"2")
+    (a / "gone").write_bytes(b"3")
+    shutil.copytree(a, b, symlinks=True)
+    os.unlink(b / "gone")
+    (b / "d" / "sub" / "f").write_bytes(b"12")               # size change
+    (b / "d" / "new").write_bytes(b"n")
+    out = subprocess.run([exe, str(a), str(b)], check=True, capture_output=True, text=True).stdout.splitlines()
+    after = makisu_amd.tree_walk(str(b), mode=makisu_amd.TREE_SCAN, full=True)
+    before = makisu_amd.tree_walk(str(a), mode=makisu_amd.TREE_SCAN, full=True)
+    rels = [e["relpath"] for e in after]
+    assert [l[2:] for l in out if l.startswith("O ")] == [rels[i] for i in makisu_amd.commit_order(rels)]
+    flags, wh = makisu_amd.snapshot_diff(before, after, ignore_time=True)
+    assert sorted(l[2:] for l in out if l.startswith("C ")) == sorted(
+        e["relpath"] for e, f in zip(after, flags) if f == makisu_amd.DIFF_CHANGED) == ["d/new", "d/sub/f"]
+    assert sorted(l[2:] for l in out if l.startswith("A ")) == ["d", "d/sub"]
+    assert [l[2:] for l in out if l.startswith("W ")] == ["gone"]
+    assert out[-1] == "S 1"                                   # the two top directories: same owner/mode, mtime ignored
