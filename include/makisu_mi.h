@@ -304,6 +304,21 @@ int mi_entries_commit_order(const mi_tree_entry* entries, uint64_t n, uint64_t* 
 int mi_entry_similar(const mi_tree_entry* a, const mi_tree_entry* b, int ignore_time,
                      const uint8_t* root_a, const uint8_t* root_b, int* similar);
 
+/* ---- a layer tar as a source: entries and the byte range of every file, no extraction ---- *
+ * MemFS.UpdateFromTarReader (lib/snapshot/mem_fs.go:165-255) fills the in-memory tree from the
+ * headers of base / cached layers.  mi_tar_open reads the headers of an UNCOMPRESSED tar (ustar,
+ * pax 'x'/'g' records, GNU long names / base-256 numbers -- what Go's archive/tar and docker
+ * write) and lists them as mi_tree_entry rows: relpath = the cleaned header name ("." for the
+ * root, no leading or trailing "/"), kind 0 directory / 1 regular / 2 symlink / 3 hard link /
+ * 4 other (device, fifo), file_index = ordinal among the regular files.  data_offsets[i]
+ * (optional) = where entry i's bytes start in the archive (regular files only): a file is one
+ * contiguous range of the tar.  Whiteout markers (".wh.<name>") are listed as the entries they
+ * are.  Strings live until mi_tar_free.  Host logic.                                        */
+typedef struct mi_tar mi_tar;
+int  mi_tar_open(const char* path, mi_tar** out, uint64_t* n_entries);
+int  mi_tar_entries(const mi_tar* tar, mi_tree_entry* out, uint64_t* data_offsets, uint64_t cap);
+void mi_tar_free(mi_tar* tar);
+
 /* The layer diff of a scan, on two walks -- what MemFS.createLayerByScan + maybeAddToLayer
  * (lib/snapshot/mem_fs.go:315-341, 440-480) decide against the in-memory tree:
  *   after_flags[i]      MI_DIFF_CHANGED  the path is new or mi_entry_similar says it changed

@@ -157,6 +157,9 @@ def load_library(rebuild=False):
         "mi_tree_free": ([vp], None),
         "mi_entries_commit_order": ([C.POINTER(TreeEntry), u64, u64p], C.c_int),
         "mi_snapshot_diff": ([C.POINTER(SnapshotSide), C.POINTER(SnapshotSide), C.c_int, vp, vp], C.c_int),
+        "mi_tar_open": ([C.c_char_p, C.POINTER(vp), u64p], C.c_int),
+        "mi_tar_entries": ([vp, C.POINTER(TreeEntry), u64p, u64], C.c_int),
+        "mi_tar_free": ([vp], None),
         "mi_entry_similar": ([C.POINTER(TreeEntry), C.POINTER(TreeEntry), C.c_int, vp, vp,
                               C.POINTER(C.c_int)], C.c_int),
         "mi_comm_unique_id": ([vp], C.c_int),
@@ -233,6 +236,30 @@ def commit_order(relpaths):
     if rc:
         raise MiError(rc, "mi_entries_commit_order")
     return [int(out[i]) for i in range(n)]
+
+
+def tar_entries(path):
+    """mi_tar_open + mi_tar_entries: the entries of an uncompressed layer tar as dicts (the keys of
+    tree_walk(full=True) plus "data_offset": where a regular file's bytes start in the archive)."""
+    L = load_library()
+    h, n = C.c_void_p(), C.c_uint64()
+    rc = L.mi_tar_open(os.fsencode(path), C.byref(h), C.byref(n))
+    if rc:
+        raise MiError(rc, "mi_tar_open(%s)" % path)
+    try:
+        arr = (TreeEntry * max(n.value, 1))()
+        offs = (C.c_uint64 * max(n.value, 1))()
+        rc = L.mi_tar_entries(h, arr, offs, n.value)
+        if rc:
+            raise MiError(rc, "mi_tar_entries")
+        out = []
+        for i in range(n.value):
+            d = _entry_dict(arr[i])
+            d["data_offset"] = int(offs[i])
+            out.append(d)
+        return out
+    finally:
+        L.mi_tar_free(h)
 
 
 def _entry_array(dicts, keep):

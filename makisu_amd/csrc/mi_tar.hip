@@ -1,0 +1,287 @@
+// mi_tar.hip -- host side, no device code: reading a layer tar WITHOUT extracting it.
+//
+// The reference fills its in-memory tree from base / cached layers by walking their tar headers
+// (MemFS.UpdateFromTarReader, lib/snapshot/mem_fs.go:165-255: tar.Reader.Next per entry, hard
+// links collected for a second pass, whiteouts applied by untarOneItem :571-650).  For the
+// content scan the interesting part of a layer tar is that every regular file's bytes sit in ONE
+// contiguous range of it: mi_tar_open lists the entries (as mi_tree_entry rows, the "before"
+// side of mi_snapshot_diff) together with those ranges, so the files of a pulled layer can be
+// handed to a batch straight out of the archive.
+//
+// Format: POSIX ustar / pax (typeflags 'x' and 'g': path, linkpath, size, uid, gid, mtime) and
+// the GNU extensions Go's archive/tar and docker write (typeflags 'L' / 'K' long name / link,
+// base-256 numeric fields, the old-GNU magic).  Checked against Python's tarfile on ustar, pax
+// and GNU archives and on the reference's own layer fixture (tests/test_host_tar.py).
+#include "../../include/makisu_mi.h"
+
+#include <errno.h>
+#include <math.h>
+#include <fcntl.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+namespace mi_tarfile {
+
+struct Item {
+    std::string name, link;
+    bool has_link = false;
+    uint64_t size = 0, data_off = 0;
+    int64_t mtime = 0;
+    uint32_t mode = 0, uid = 0, gid = 0;
+    uint8_t kind = 0;      // 0 dir, 1 regular, 2 symlink, 3 hard link, 4 other (device, fifo)
+    int64_t file_index = -1;
+};
+
+struct Tar {
+    std::vector<Item> items;
+    std::string error;
+};
+
+static std::string field(const unsigned char* p, size_t n) {        // NUL-terminated or full width
+    size_t k = 0;
+    while (k < n && p[k]) ++k;
+    return std::string((const char*)p, k);
+}
+
+// numeric field: octal text (leading spaces / trailing space or NUL), or GNU base-256 (top bit set)
+static bool number(const unsigned char* p, size_t n, int64_t* out) {
+    if (p[0] & 0x80) {                                       // GNU base-256, big-endian two's complement
+        const bool neg = (p[0] & 0x40) != 0;
+        uint64_t v = neg ? ~0ull : 0;
+        for (size_t i = 0; i < n; ++i) {
+            unsigned char c = p[i];
+            if (i == 0) c = neg ? (unsigned char)(c | 0x80) : (unsigned char)(c & 0x7f);   // the flag bit is not data
+            if (n - i > 8) {                                 // beyond 64 bits: must be sign extension
+                if (c != (neg ? 0xff : 0x00)) return false;
+                continue;
+            }
+            v = (v << 8) | c;
+        }
+        *out = (int64_t)v;
+        return true;
+    }
+    size_t i = 0;
+    while (i < n && (p[i] == ' ')) ++i;
+    uint64_t v = 0;
+    bool any = false;
+    for (; i < n && p[i] >= '0' && p[i] <= '7'; ++i) { v = (v << 3) | (uint64_t)(p[i] - '0'); any = true; }
+    for (; i < n; ++i) if (p[i] != ' ' && p[i] != 0) return false;
+    *out = (int64_t)v;
+    return any || n == 0 || p[0] == 0 || p[0] == ' ';      // an empty field reads as 0
+}
+
+static bool all_zero(const unsigned char* b) {
+    for (int i = 0; i < 512; ++i) if (b[i]) return false;
+    return true;
+}
+
+static bool checksum_ok(const unsigned char* b) {
+    int64_t want = 0;
+    if (!number(b + 148, 8, &want)) return false;
+    int64_t u = 0, s = 0;
+    for (int i = 0; i < 512; ++i) {
+        const unsigned char c = (i >= 148 && i < 156) ? (unsigned char)' ' : b[i];
+        u += c;
+        s += (signed char)c;
+    }
+    return want == u || want == s;
+}
+
+// "len key=value\n" records
+static bool parse_pax(const std::string& body, std::map<std::string, std::string>* kv) {
+    size_t at = 0;
+    while (at < body.size()) {
+        size_t sp = body.find(' ', at);
+        if (sp == std::string::npos) return false;
+        const long len = strtol(body.substr(at, sp - at).c_str(), nullptr, 10);
+        if (len <= 0 || at + (size_t)len > body.size()) return false;
+        const std::string rec = body.substr(sp + 1, at + (size_t)len - sp - 2);   // without the '\n'
+        const size_t eq = rec.find('=');
+        if (eq == std::string::npos) return false;
+        (*kv)[rec.substr(0, eq)] = rec.substr(eq + 1);
+        at += (size_t)len;
+    }
+    return true;
+}
+
+static bool read_at(int fd, uint64_t off, void* dst, size_t n) {
+    size_t got = 0;
+    while (got < n) {
+        ssize_t r = pread(fd, (char*)dst + got, n - got, (off_t)(off + got));
+        if (r < 0 && errno == EINTR) continue;
+        if (r <= 0) return false;
+        got += (size_t)r;
+    }
+    return true;
+}
+
+static int parse(int fd, uint64_t file_size, Tar* t) {
+    uint64_t off = 0;
+    std::map<std::string, std::string> global_pax, next_pax;
+    std::string gnu_name, gnu_link;
+    bool has_gnu_name = false, has_gnu_link = false;
+    int64_t n_regular = 0;
+    unsigned char blk[512];
+    while (off + 512 <= file_size) {
+        if (!read_at(fd, off, blk, 512)) { t->error = "short read in the archive"; return MI_ERR_IO; }
+        if (all_zero(blk)) break;                              // end-of-archive marker
+        if (!checksum_ok(blk)) { t->error = "bad tar header checksum at offset " + std::to_string(off); return MI_ERR_INVALID; }
+        int64_t size = 0, mode = 0, uid = 0, gid = 0, mtime = 0;
+        if (!number(blk + 124, 12, &size) || !number(blk + 100, 8, &mode) || !number(blk + 108, 8, &uid) ||
+            !number(blk + 116, 8, &gid) || !number(blk + 136, 12, &mtime) || size < 0) {
+            t->error = "bad numeric field in the tar header at offset " + std::to_string(off);
+            return MI_ERR_INVALID;
+        }
+        const unsigned char type = blk[156];
+        const uint64_t data = off + 512;
+        const uint64_t padded = ((uint64_t)size + 511) & ~511ull;
+        if (type == 'x' || type == 'g' || type == 'L' || type == 'K') {           // metadata for the next entry
+            if ((uint64_t)size > (64u << 20) || data + (uint64_t)size > file_size) {
+                t->error = "truncated extended header at offset " + std::to_string(off);
+                return MI_ERR_INVALID;
+            }
+            std::string body((size_t)size, '\0');
+            if (size && !read_at(fd, data, &body[0], (size_t)size)) { t->error = "short read in the archive"; return MI_ERR_IO; }
+            if (type == 'L' || type == 'K') {
+                const std::string v = body.substr(0, body.find('\0'));
+                if (type == 'L') { gnu_name = v; has_gnu_name = true; }
+                else { gnu_link = v; has_gnu_link = true; }
+            } else if (!parse_pax(body, type == 'g' ? &global_pax : &next_pax)) {
+                t->error = "malformed pax record at offset " + std::to_string(off);
+                return MI_ERR_INVALID;
+            }
+            off = data + padded;
+            continue;
+        }
+        Item it;
+        it.name = field(blk, 100);
+        if (memcmp(blk + 257, "ustar\0", 6) == 0) {            // POSIX ustar (not old GNU "ustar  "): prefix field
+            const std::string prefix = field(blk + 345, 155);
+            if (!prefix.empty()) it.name = prefix + "/" + it.name;
+        }
+        it.link = field(blk + 157, 100);
+        std::map<std::string, std::string> kv = global_pax;
+        for (auto& p : next_pax) kv[p.first] = p.second;
+        next_pax.clear();
+        if (has_gnu_name) it.name = gnu_name;
+        if (has_gnu_link) it.link = gnu_link;
+        has_gnu_name = has_gnu_link = false;
+        if (kv.count("path")) it.name = kv["path"];
+        if (kv.count("linkpath")) it.link = kv["linkpath"];
+        if (kv.count("size")) size = strtoll(kv["size"].c_str(), nullptr, 10);
+        if (kv.count("uid")) uid = strtoll(kv["uid"].c_str(), nullptr, 10);
+        if (kv.count("gid")) gid = strtoll(kv["gid"].c_str(), nullptr, 10);
+        if (kv.count("mtime")) mtime = (int64_t)floor(strtod(kv["mtime"].c_str(), nullptr));   // whole seconds
+        uint32_t type_bits = 0;
+        switch (type) {
+            case '0': case 0: case '7': it.kind = 1; type_bits = S_IFREG; break;
+            case '5': it.kind = 0; type_bits = S_IFDIR; break;
+            case '2': it.kind = 2; type_bits = S_IFLNK; break;
+            case '1': it.kind = 3; type_bits = S_IFREG; break;
+            case '3': it.kind = 4; type_bits = S_IFCHR; break;
+            case '4': it.kind = 4; type_bits = S_IFBLK; break;
+            case '6': it.kind = 4; type_bits = S_IFIFO; break;
+            default:  it.kind = 4; break;
+        }
+        if (type == 0 && !it.name.empty() && it.name.back() == '/') { it.kind = 0; type_bits = S_IFDIR; }   // pre-POSIX tars
+        it.has_link = it.kind == 2 || it.kind == 3;
+        it.mode = ((uint32_t)mode & 07777u) | type_bits;
+        it.uid = (uint32_t)uid;
+        it.gid = (uint32_t)gid;
+        it.mtime = mtime;
+        const bool has_data = it.kind == 1 || (it.kind == 4 && type != '3' && type != '4' && type != '6');
+        it.size = it.kind == 1 ? (uint64_t)size : 0;
+        it.data_off = it.kind == 1 ? data : 0;
+        const uint64_t skip = (it.kind == 1 || has_data) ? (((uint64_t)size + 511) & ~511ull) : 0;
+        if (it.kind == 1) {
+            if (data + (uint64_t)size > file_size) { t->error = "entry " + it.name + " runs past the end of the archive"; return MI_ERR_INVALID; }
+            it.file_index = n_regular++;
+        }
+        t->items.push_back(it);
+        off = data + skip;
+    }
+    return MI_OK;
+}
+
+// header name -> the relpath form the walks use: no leading "/" or "./", no trailing "/", "." for
+// the root (pathutils.RelPath + AbsPath semantics of untarOneItem's filepath.Join(root, hdr.Name))
+static std::string rel_name(const std::string& n) {
+    std::vector<std::string> parts;
+    size_t i = 0;
+    while (i < n.size()) {
+        while (i < n.size() && n[i] == '/') ++i;
+        size_t j = i;
+        while (j < n.size() && n[j] != '/') ++j;
+        if (j > i) {
+            const std::string el = n.substr(i, j - i);
+            if (el == "..") { if (!parts.empty()) parts.pop_back(); }
+            else if (el != ".") parts.push_back(el);
+        }
+        i = j;
+    }
+    std::string out;
+    for (size_t k = 0; k < parts.size(); ++k) out += (k ? "/" : "") + parts[k];
+    return out.empty() ? "." : out;
+}
+
+}  // namespace mi_tarfile
+
+using mi_tarfile::Tar;
+
+struct mi_tar {
+    Tar t;
+    std::vector<std::string> rel;
+};
+
+extern "C" {
+
+int mi_tar_open(const char* path, mi_tar** out, uint64_t* n_entries) {
+    if (!path || !out) return MI_ERR_INVALID;
+    const int fd = open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) return MI_ERR_IO;
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); return MI_ERR_IO; }
+    mi_tar* h = new mi_tar();
+    const int rc = mi_tarfile::parse(fd, (uint64_t)st.st_size, &h->t);
+    close(fd);
+    if (rc) {
+        fprintf(stderr, "mi_tar_open(%s): %s\n", path, h->t.error.c_str());
+        delete h;
+        return rc;
+    }
+    for (const mi_tarfile::Item& it : h->t.items) h->rel.push_back(mi_tarfile::rel_name(it.name));
+    *out = h;
+    if (n_entries) *n_entries = h->t.items.size();
+    return MI_OK;
+}
+
+int mi_tar_entries(const mi_tar* tar, mi_tree_entry* out, uint64_t* data_offsets, uint64_t cap) {
+    if (!tar || (cap && !out)) return MI_ERR_INVALID;
+    const uint64_t n = tar->t.items.size();
+    if (cap < n) return MI_ERR_CAPACITY;
+    for (uint64_t i = 0; i < n; ++i) {
+        const mi_tarfile::Item& it = tar->t.items[(size_t)i];
+        out[i].relpath = tar->rel[(size_t)i].c_str();
+        out[i].link_target = it.has_link ? it.link.c_str() : nullptr;
+        out[i].file_index = it.file_index;
+        out[i].size = it.size;
+        out[i].mtime_sec = it.mtime;
+        out[i].mode = it.mode;
+        out[i].kind = it.kind;
+        out[i].uid = it.uid;
+        out[i].gid = it.gid;
+        if (data_offsets) data_offsets[i] = it.data_off;
+    }
+    return MI_OK;
+}
+
+void mi_tar_free(mi_tar* tar) { delete tar; }
+
+}  // extern "C"

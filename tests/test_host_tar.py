@@ -1,0 +1,190 @@
+"""CPU tests of the layer-tar reader (csrc/mi_tar.hip, no GPU): entries and file byte ranges of
+ustar / pax / GNU archives against Python's tarfile (an independent implementation of the same
+formats), plus the reference's own docker-made layer fixture when /root/reference is present
+(testdata/files/busybox/.../layer.tar)."""
+import hashlib
+import io
+import os
+import posixpath
+import tarfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FIXTURE = "/root/reference/testdata/files/busybox/393ccd5c4dd90344c9d725125e13f636ce0087c62f5ca89050faaacbb9e3ed5b/layer.tar"
+
+
+def _rel(name):
+    n = posixpath.normpath("/" + name).lstrip("/")
+    return n or "."
+
+
+def _kind(m):
+    if m.isdir():
+        return 0
+    if m.isreg():
+        return 1
+    if m.issym():
+        return 2
+    if m.islnk():
+        return 3
+    return 4
+
+
+def _compare_with_tarfile(path):
+    import makisu_amd
+    got = makisu_amd.tar_entries(path)
+    with tarfile.open(path) as tf:
+        members = tf.getmembers()
+        assert len(got) == len(members)
+        n_reg = 0
+        raw = open(path, "rb")
+        for g, m in zip(got, members):
+            assert g["relpath"] == _rel(m.name), m.name
+            assert g["kind"] == _kind(m), m.name
+            assert g["mode"] & 0o7777 == m.mode & 0o7777 and g["uid"] == m.uid and g["gid"] == m.gid
+            assert g["mtime_sec"] == int(m.mtime // 1), m.name
+            if m.issym() or m.islnk():
+                assert g["link_target"] == m.linkname
+            else:
+                assert g["link_target"] is None
+            if m.isreg():
+                assert g["size"] == m.size and g["file_index"] == n_reg
+                assert g["data_offset"] == m.offset_data
+                raw.seek(g["data_offset"])
+                assert hashlib.sha256(raw.read(g["size"])).digest() == \
+                    hashlib.sha256(tf.extractfile(m).read()).digest()
+                n_reg += 1
+            else:
+                assert g["size"] == 0 and g["file_index"] == -1
+        raw.close()
+    return got
+
+
+def _build(path, fmt):
+    long_dir = "d" * 60 + "/" + "e" * 70 + "/" + "f" * 90                 # > 100: prefix / long name
+    very_long = "v" * 200 + "/" + "w" * 120 + "/file"                      # > 255 in total: pax path / GNU 'L'
+    with tarfile.open(path, "w", format=fmt) as tf:
+        def add(name, type_=tarfile.REGTYPE, data=b"", **kw):
+            ti = tarfile.TarInfo(name)
+            ti.type = type_
+            ti.size = len(data)
+            ti.mode = kw.get("mode", 0o644)
+            ti.uid, ti.gid = kw.get("uid", 0), kw.get("gid", 0)
+            ti.mtime = kw.get("mtime", 1494882420)
+            ti.linkname = kw.get("linkname", "")
+            ti.uname = ti.gname = ""
+            ti.devmajor, ti.devminor = kw.get("dev", (0, 0))
+            tf.addfile(ti, io.BytesIO(data) if data else None)
+        add("./", tarfile.DIRTYPE, mode=0o755)
+        add("bin/", tarfile.DIRTYPE, mode=0o755)
+        add("bin/busybox", data=os.urandom(70001), mode=0o755)
+        add("bin/sh", tarfile.LNKTYPE, linkname="bin/busybox", mode=0o755)          # hard link
+        add("bin/link", tarfile.SYMTYPE, linkname="/bin/busybox", mode=0o777)
+        add("etc/", tarfile.DIRTYPE)
+        add("etc/empty")
+        add("etc/one", data=b"x")
+        add("etc/block512", data=bytes(512))                                          # exactly one block
+        add("etc/.wh.removed")                                                        # a whiteout marker
+        add("dev/null", tarfile.CHRTYPE, dev=(1, 3), mode=0o666)
+        add("dev/fifo", tarfile.FIFOTYPE)
+        add(long_dir + "/", tarfile.DIRTYPE)
+        add(long_dir + "/payload", data=b"long path payload", uid=1000, gid=2000)
+        add("owner", data=b"o", uid=123456, gid=654321, mtime=1)
+        if fmt != tarfile.USTAR_FORMAT:
+            add(very_long, data=b"very long")
+            add("sym-long", tarfile.SYMTYPE, linkname="t" * 200)                     # > 100: linkpath / 'K'
+            add("café/üml", data=b"utf8")
+            add("big-ids", data=b"b", uid=3000000, gid=4000000)                       # > 7 octal digits
+    return path
+
+
+@pytest.mark.parametrize("fmt", [tarfile.USTAR_FORMAT, tarfile.PAX_FORMAT, tarfile.GNU_FORMAT])
+def test_tar_entries_match_tarfile(tmp_path, fmt):
+    got = _compare_with_tarfile(_build(str(tmp_path / "layer.tar"), fmt))
+    by = {g["relpath"]: g for g in got}
+    assert got[0]["relpath"] == "." and got[0]["kind"] == 0
+    assert by["bin/sh"]["kind"] == 3 and by["bin/sh"]["link_target"] == "bin/busybox"
+    assert by["bin/link"]["link_target"] == "/bin/busybox"
+    assert by["dev/null"]["kind"] == 4 and by["dev/fifo"]["kind"] == 4
+    assert by["etc/.wh.removed"]["kind"] == 1 and by["etc/.wh.removed"]["size"] == 0
+    assert by["etc/block512"]["data_offset"] % 512 == 0
+    regs = [g for g in got if g["kind"] == 1]
+    assert [g["file_index"] for g in regs] == list(range(len(regs)))
+
+
+def test_tar_pax_mtime_fraction_and_errors(tmp_path):
+    import makisu_amd
+    p = str(tmp_path / "frac.tar")
+    with tarfile.open(p, "w", format=tarfile.PAX_FORMAT) as tf:
+        ti = tarfile.TarInfo("a")
+        ti.mtime = 1494882420.75                       # pax carries the fraction; entries hold whole seconds
+        tf.addfile(ti)
+    assert makisu_amd.tar_entries(p)[0]["mtime_sec"] == 1494882420
+    # an empty archive (two zero blocks, what Go's tar.Writer writes on Close) has no entries
+    empty = str(tmp_path / "empty.tar")
+    open(empty, "wb").write(bytes(1024))
+    assert makisu_amd.tar_entries(empty) == []
+    # a flipped header byte fails the checksum; a truncated member is reported, not read past
+    raw = bytearray(open(_build(str(tmp_path / "ok.tar"), tarfile.USTAR_FORMAT), "rb").read())
+    bad = bytearray(raw)
+    bad[512 + 3] ^= 0x20
+    open(str(tmp_path / "bad.tar"), "wb").write(bad)
+    with pytest.raises(makisu_amd.MiError) as ei:
+        makisu_amd.tar_entries(str(tmp_path / "bad.tar"))
+    assert ei.value.code == -1
+    open(str(tmp_path / "cut.tar"), "wb").write(raw[: 3 * 512 + 1000])      # inside bin/busybox's data
+    with pytest.raises(makisu_amd.MiError):
+        makisu_amd.tar_entries(str(tmp_path / "cut.tar"))
+    with pytest.raises(makisu_amd.MiError) as ei:
+        makisu_amd.tar_entries(str(tmp_path / "missing.tar"))
+    assert ei.value.code == -5
+
+
+@pytest.mark.skipif(not os.path.exists(FIXTURE), reason="reference fixture not present (GPU box)")
+def test_reference_layer_fixture():
+    """The reference's docker-made busybox layer (390 entries, one binary and its hard links)."""
+    got = _compare_with_tarfile(FIXTURE)
+    assert len(got) == 390
+    kinds = [g["kind"] for g in got]
+    assert kinds.count(3) > 300 and kinds.count(1) >= 1
+    big = max(got, key=lambda g: g["size"])
+    assert big["relpath"] == "bin/[" and big["size"] == 1026712
+
+
+def test_tar_entries_feed_the_snapshot_diff(tmp_path):
+    """A layer tar as the 'before' side: extract it, edit the tree, walk, diff."""
+    import makisu_amd
+    p = _build(str(tmp_path / "layer.tar"), tarfile.GNU_FORMAT)
+    before = [e for e in makisu_amd.tar_entries(p) if e["kind"] in (0, 1, 2)]
+    root = tmp_path / "fs"
+    with tarfile.open(p) as tf:
+        members = [m for m in tf.getmembers() if m.isdir() or m.isreg() or m.issym()]
+        tf.extractall(root, members=members)
+    # the archive's absolute symlink means "inside the image root": on disk under `root` it has to
+    # point there, and the scan walk trims the root off again (createHeader's TrimRoot)
+    os.unlink(root / "bin" / "link")
+    os.symlink(str(root) + "/bin/busybox", root / "bin" / "link")
+    for m in members:                                    # extraction order leaves directory mtimes bumped
+        os.utime(root / m.name, (m.mtime, m.mtime), follow_symlinks=False)
+    after = makisu_amd.tree_walk(str(root), rel_base=str(root), mode=makisu_amd.TREE_SCAN, full=True)
+    for e in after:                                      # we are not root here: owners differ from the archive's
+        e["uid"] = e["gid"] = 0
+    for e in before:
+        e["uid"] = e["gid"] = 0
+    flags, wh = makisu_amd.snapshot_diff(before, after)
+    changed = sorted(e["relpath"] for e, f in zip(after, flags) if f == makisu_amd.DIFF_CHANGED)
+    # the only "new" paths are parent directories the archive never listed (tar allows that)
+    known = {e["relpath"] for e in before}
+    implied = sorted(e["relpath"] for e in after if e["relpath"] not in known)
+    assert implied and all(e["kind"] == 0 for e in after if e["relpath"] in implied)
+    assert changed == implied and not any(wh), changed
+    (root / "etc" / "one").write_bytes(b"xy")
+    os.unlink(root / "bin" / "link")
+    after = makisu_amd.tree_walk(str(root), rel_base=str(root), mode=makisu_amd.TREE_SCAN, full=True)
+    for e in after:
+        e["uid"] = e["gid"] = 0
+    flags, wh = makisu_amd.snapshot_diff(before, after, ignore_time=True)
+    assert sorted(e["relpath"] for e, f in zip(after, flags)
+                  if f == makisu_amd.DIFF_CHANGED and e["relpath"] in known) == ["etc/one"]
+    assert [e["relpath"] for e, w in zip(before, wh) if w] == ["bin/link"]
