@@ -319,6 +319,18 @@ int  mi_tar_open(const char* path, mi_tar** out, uint64_t* n_entries);
 int  mi_tar_entries(const mi_tar* tar, mi_tree_entry* out, uint64_t* data_offsets, uint64_t cap);
 void mi_tar_free(mi_tar* tar);
 
+/* A layer's entries applied on top of a tree -- MemFS.UpdateFromTarReader / untarOneItem
+ * (lib/snapshot/mem_fs.go:165-255, 571-660) on entry lists: ".wh.<name>" markers delete
+ * <dir>/<name> with its subtree and are not part of the result; an entry whose header is
+ * similar to the one already there changes nothing (the OLD entry stays, :607-613); a
+ * directory on a directory only updates the directory; anything else replaces the old path and
+ * its subtree.  Result: the merged tree in sorted-path order, entry k = layer[index[k]] if
+ * from_layer[k] else base[index[k]].  *n_out = its size (MI_ERR_CAPACITY if cap is smaller;
+ * call with cap 0 to size).  Host logic.                                                   */
+int mi_entries_apply_layer(const mi_tree_entry* base, uint64_t n_base, const mi_tree_entry* layer,
+                           uint64_t n_layer, uint8_t* from_layer, uint64_t* index, uint64_t cap,
+                           uint64_t* n_out);
+
 /* The layer diff of a scan, on two walks -- what MemFS.createLayerByScan + maybeAddToLayer
  * (lib/snapshot/mem_fs.go:315-341, 440-480) decide against the in-memory tree:
  *   after_flags[i]      MI_DIFF_CHANGED  the path is new or mi_entry_similar says it changed

@@ -157,6 +157,8 @@ def load_library(rebuild=False):
         "mi_tree_free": ([vp], None),
         "mi_entries_commit_order": ([C.POINTER(TreeEntry), u64, u64p], C.c_int),
         "mi_snapshot_diff": ([C.POINTER(SnapshotSide), C.POINTER(SnapshotSide), C.c_int, vp, vp], C.c_int),
+        "mi_entries_apply_layer": ([C.POINTER(TreeEntry), u64, C.POINTER(TreeEntry), u64, vp, u64p, u64, u64p],
+                                   C.c_int),
         "mi_tar_open": ([C.c_char_p, C.POINTER(vp), u64p], C.c_int),
         "mi_tar_entries": ([vp, C.POINTER(TreeEntry), u64p, u64], C.c_int),
         "mi_tar_free": ([vp], None),
@@ -274,6 +276,22 @@ def _entry_array(dicts, keep):
         for k in ("size", "mtime_sec", "mode", "kind", "uid", "gid"):
             setattr(arr[i], k, d.get(k, 0))
     return arr
+
+
+def apply_layer(base, layer):
+    """mi_entries_apply_layer on two lists of entry dicts: the merged list (the dicts themselves, in
+    sorted-path order)."""
+    keep = []
+    ab, al = _entry_array(base, keep), _entry_array(layer, keep)
+    cap = len(base) + len(layer)
+    src = np.zeros(max(cap, 1), dtype=np.uint8)
+    idx = np.zeros(max(cap, 1), dtype=np.uint64)
+    n = C.c_uint64()
+    rc = load_library().mi_entries_apply_layer(ab, len(base), al, len(layer), src.ctypes.data,
+                                               idx.ctypes.data_as(C.POINTER(C.c_uint64)), cap, C.byref(n))
+    if rc:
+        raise MiError(rc, "mi_entries_apply_layer")
+    return [(layer if src[k] else base)[int(idx[k])] for k in range(n.value)]
 
 
 def snapshot_diff(before, after, ignore_time=False, roots_before=None, roots_after=None):

@@ -420,6 +420,63 @@ extern "C" int mi_snapshot_diff(const mi_snapshot_side* before, const mi_snapsho
     return MI_OK;
 }
 
+// Applying a layer's entries on top of a tree, the way MemFS.UpdateFromTarReader does entry by
+// entry through untarOneItem (lib/snapshot/mem_fs.go:165-255, 571-660):
+//   * a whiteout marker ".wh.<name>" removes <dir>/<name> and everything below it, and is not
+//     itself part of the tree (untarWhiteout :652-660);
+//   * an entry whose header is similar to what is already there changes nothing -- the old entry
+//     (and so the old content) stays (:607-613);
+//   * a directory arriving on a directory only updates the directory, its children stay
+//     (:615-623); anything else replaces the old path together with its subtree (:625-629).
+// Output: the merged tree in sorted-path order as (from_layer, index) pairs.
+extern "C" int mi_entries_apply_layer(const mi_tree_entry* base, uint64_t n_base, const mi_tree_entry* layer,
+                                      uint64_t n_layer, uint8_t* from_layer, uint64_t* index, uint64_t cap,
+                                      uint64_t* n_out) {
+    if ((n_base && !base) || (n_layer && !layer) || !n_out || (cap && (!from_layer || !index)))
+        return MI_ERR_INVALID;
+    auto path_of = [](const mi_tree_entry& e) {
+        const char* rp = e.relpath ? e.relpath : "";
+        return mi_walk::abs_path(strcmp(rp, ".") == 0 ? "" : rp);
+    };
+    struct Ref { uint8_t side; uint64_t idx; };
+    std::map<std::string, Ref> tree;
+    for (uint64_t i = 0; i < n_base; ++i) tree[path_of(base[i])] = Ref{0, i};
+    auto remove_subtree = [&](const std::string& p) {
+        tree.erase(p);
+        const std::string pre = p == "/" ? p : p + "/";
+        for (auto it = tree.lower_bound(pre); it != tree.end() && mi_walk::has_prefix(it->first, pre);)
+            it = tree.erase(it);
+    };
+    for (uint64_t j = 0; j < n_layer; ++j) {
+        const std::string p = path_of(layer[j]);
+        const std::string name = mi_walk::base_of(p);
+        if (mi_walk::has_prefix(name, ".wh.")) {
+            const std::string dir = mi_walk::dir_of(p);
+            remove_subtree((dir == "/" ? "" : dir) + "/" + name.substr(4));
+            continue;
+        }
+        auto it = tree.find(p);
+        if (it != tree.end()) {
+            const mi_tree_entry& old = it->second.side ? layer[it->second.idx] : base[it->second.idx];
+            int similar = 0;
+            const int rc = mi_entry_similar(&old, &layer[j], 0, nullptr, nullptr, &similar);
+            if (rc) return rc;
+            if (similar) continue;                                            // already there
+            if (!(old.kind == 0 && layer[j].kind == 0)) remove_subtree(p);    // dir on dir: children stay
+        }
+        tree[p] = Ref{1, j};
+    }
+    *n_out = tree.size();
+    if (cap < tree.size()) return MI_ERR_CAPACITY;
+    uint64_t k = 0;
+    for (auto& kv : tree) {
+        from_layer[k] = kv.second.side;
+        index[k] = kv.second.idx;
+        ++k;
+    }
+    return MI_OK;
+}
+
 // tario.IsSimilarHeader (lib/tario/compare.go:24-117) on walk entries, plus the optional
 // content roots (see the header)
 int mi_entry_similar(const mi_tree_entry* a, const mi_tree_entry* b, int ignore_time,

@@ -188,3 +188,101 @@ def test_tar_entries_feed_the_snapshot_diff(tmp_path):
     assert sorted(e["relpath"] for e, f in zip(after, flags)
                   if f == makisu_amd.DIFF_CHANGED and e["relpath"] in known) == ["etc/one"]
     assert [e["relpath"] for e, w in zip(before, wh) if w] == ["bin/link"]
+
+
+def _layer_tar(path, items):
+    """items: (name, kind, data_or_link, mtime) with kind 'd' / 'f' / 'l'."""
+    with tarfile.open(path, "w", format=tarfile.GNU_FORMAT) as tf:
+        for name, kind, payload, mtime in items:
+            ti = tarfile.TarInfo(name)
+            ti.mtime = mtime
+            ti.uname = ti.gname = ""
+            if kind == "d":
+                ti.type, ti.mode = tarfile.DIRTYPE, 0o755
+                tf.addfile(ti)
+            elif kind == "l":
+                ti.type, ti.mode, ti.linkname = tarfile.SYMTYPE, 0o777, payload
+                tf.addfile(ti)
+            else:
+                ti.size, ti.mode = len(payload), 0o644
+                tf.addfile(ti, io.BytesIO(payload))
+    return path
+
+
+def _extract_like_untar_one_item(root, tar_path):
+    """Independent emulation of untarOneItem on a real directory: whiteouts delete, dir-on-dir keeps
+    children, everything else replaces (RemoveAll + recreate)."""
+    import shutil
+    with tarfile.open(tar_path) as tf:
+        for m in tf.getmembers():
+            dst = os.path.join(root, m.name)
+            base = os.path.basename(m.name.rstrip("/"))
+            if base.startswith(".wh."):
+                victim = os.path.join(os.path.dirname(dst.rstrip("/")), base[4:])
+                if os.path.islink(victim) or os.path.isfile(victim):
+                    os.unlink(victim)
+                elif os.path.isdir(victim):
+                    shutil.rmtree(victim)
+                continue
+            if os.path.lexists(dst):
+                if m.isdir() and os.path.isdir(dst) and not os.path.islink(dst):
+                    continue
+                if os.path.isdir(dst) and not os.path.islink(dst):
+                    shutil.rmtree(dst)
+                else:
+                    os.unlink(dst)
+            if m.isdir():
+                os.makedirs(dst)
+            elif m.issym():
+                os.symlink(m.linkname, dst)
+            else:
+                with open(dst, "wb") as f:
+                    f.write(tf.extractfile(m).read())
+
+
+def test_apply_layer_matches_sequential_extraction(tmp_path):
+    """mi_entries_apply_layer over three layer tars == the paths (and kinds, sizes) left on disk
+    after extracting the same tars in order with untarOneItem's rules."""
+    import makisu_amd
+    t = 1500000000
+    l1 = _layer_tar(str(tmp_path / "l1.tar"), [
+        ("etc/", "d", None, t), ("etc/passwd", "f", b"root\n", t), ("etc/conf.d/", "d", None, t),
+        ("etc/conf.d/a", "f", b"a", t), ("etc/conf.d/b", "f", b"b", t), ("usr/", "d", None, t),
+        ("usr/bin/", "d", None, t), ("usr/bin/tool", "f", b"v1", t), ("usr/share/", "d", None, t),
+        ("usr/share/doc/", "d", None, t), ("usr/share/doc/readme", "f", b"r", t), ("link", "l", "etc/passwd", t)])
+    l2 = _layer_tar(str(tmp_path / "l2.tar"), [
+        ("etc/", "d", None, t + 5),                                   # dir on dir: children stay
+        ("etc/passwd", "f", b"root\nme\n", t + 5),                    # replaced (size differs)
+        ("etc/conf.d/.wh.a", "f", b"", t + 5),                        # whiteout of a file
+        ("usr/share/.wh.doc", "f", b"", t + 5),                       # whiteout of a subtree
+        ("usr/bin/tool", "f", b"v2", t),                              # similar header (same size, mtime): stays OLD
+        ("link", "d", None, t + 5),                                   # symlink replaced by a directory
+        ("link/inside", "f", b"i", t + 5)])
+    l3 = _layer_tar(str(tmp_path / "l3.tar"), [
+        ("etc/conf.d", "f", b"now a file", t + 9),                    # directory replaced by a file: subtree goes
+        ("usr/share/doc/", "d", None, t + 9), ("usr/share/doc/new", "f", b"n", t + 9),   # deleted path comes back
+        (".wh.link", "f", b"", t + 9)])                               # top-level whiteout
+    root = tmp_path / "fs"
+    os.makedirs(root)
+    tree = [{"relpath": ".", "kind": 0, "mode": 0o40755}]
+    for tar_path in (l1, l2, l3):
+        layer = makisu_amd.tar_entries(tar_path)
+        tree = makisu_amd.apply_layer(tree, layer)
+        _extract_like_untar_one_item(str(root), tar_path)
+        on_disk = {}
+        for dp, dns, fns in os.walk(root):
+            for n in dns + fns:
+                full = os.path.join(dp, n)
+                st = os.lstat(full)
+                kind = 2 if os.path.islink(full) else (0 if os.path.isdir(full) else 1)
+                on_disk[os.path.relpath(full, root)] = (kind, st.st_size if kind == 1 else 0)
+        got = {e["relpath"]: (e["kind"], e["size"]) for e in tree if e["relpath"] != "."}
+        assert got == on_disk, tar_path
+        rels = [e["relpath"] for e in tree]
+        assert rels == sorted(rels, key=lambda r: ("/" if r == "." else "/" + r).encode())
+    final = {e["relpath"]: e for e in tree}
+    assert "link" not in final and "etc/conf.d/b" not in final and final["etc/conf.d"]["kind"] == 1
+    assert final["usr/bin/tool"]["data_offset"] > 0 and final["usr/share/doc/new"]["size"] == 1
+    # the "similar header" quirk: layer 2's usr/bin/tool did NOT replace layer 1's entry
+    l1_tool = [e for e in makisu_amd.tar_entries(l1) if e["relpath"] == "usr/bin/tool"][0]
+    assert final["usr/bin/tool"]["data_offset"] == l1_tool["data_offset"]
