@@ -122,9 +122,11 @@ static const MountTable& mountpoints() {
         const std::string file = over && *over ? over : "/proc/mounts";
         FILE* f = fopen(file.c_str(), "r");
         if (!f) return;                                      // "Skipping mountmanager init"
-        char line[8192];
-        while (fgets(line, sizeof line, f)) {
-            size_t n = strlen(line);
+        char* line = nullptr;                                // getline: overlay mounts list every lower
+        size_t cap = 0;                                      // layer on ONE line, easily > 8 KiB
+        ssize_t got;
+        while ((got = getline(&line, &cap, f)) >= 0) {
+            size_t n = (size_t)got;
             while (n && (line[n - 1] == '\n')) line[--n] = 0;
             if (n == 0) continue;
             char* sp1 = strchr(line, ' ');
@@ -134,6 +136,7 @@ static const MountTable& mountpoints() {
             std::string target(sp1 + 1, sp2);
             if (target != "/") mt.targets.insert(target);    // "/" skipped as the reference does
         }
+        free(line);
         fclose(f);
     });
     return mt;

@@ -423,7 +423,8 @@ def test_scan_walk_skips_mountpoints_from_the_mounts_table(tmp_path, engine_lib)
     (root / "etc" / "hosts.txt").write_bytes(b"not a mountpoint")
     (root / "etc" / "hostname").write_bytes(b"file mountpoint")
     mounts = tmp_path / "mounts"
-    mounts.write_text("overlay / overlay rw 0 0\n"
+    mounts.write_text("overlay / overlay rw,lowerdir=" + ":".join("/var/lib/l%04d" % i for i in range(2000)) + " 0 0\n"   # one 30 KB line
+                      "overlay / overlay rw 0 0\n"
                       "cgroup %s/etc/hostname etx4 ro,nosuid,nodev,noexec,mode=755 0 0\n"
                       "cgroup %s/etc/hosts etx4 ro,nosuid,nodev,noexec,mode=755 0 0\n" % (root, root))
     code = ("import makisu_amd, json\n"
