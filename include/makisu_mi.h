@@ -140,6 +140,10 @@ int mi_batch_add_bytes(mi_batch* b, const void* data, uint64_t len, uint64_t use
  * like io.CopyN(w, f, h.Size) at lib/tario/write.go:43-45).  Short files are an
  * error, extra appended bytes are ignored.                                          */
 int mi_batch_add_path(mi_batch* b, const char* path, uint64_t size, uint64_t user_tag);
+/* The same for a byte range of a file -- a member of an uncompressed layer tar, whose ranges
+ * mi_tar_entries lists: the file's bytes are [offset, offset + size) of `path`.             */
+int mi_batch_add_path_range(mi_batch* b, const char* path, uint64_t offset, uint64_t size,
+                            uint64_t user_tag);
 /* Device-generated synthetic files (bench / roofline runs):
  * file i has sizes[i] bytes of the counter-mode stream keyed by (seed,
  * content_ids[i]); equal content ids give byte-identical files.  content_ids may be

@@ -128,6 +128,7 @@ def load_library(rebuild=False):
         "mi_batch_begin": ([vp, u64, u64, C.POINTER(vp)], C.c_int),
         "mi_batch_add_bytes": ([vp, vp, u64, u64], C.c_int),
         "mi_batch_add_path": ([vp, C.c_char_p, u64, u64], C.c_int),
+        "mi_batch_add_path_range": ([vp, C.c_char_p, u64, u64, u64], C.c_int),
         "mi_batch_add_synthetic": ([vp, u64, u64p, u64p, u64], C.c_int),
         "mi_batch_run": ([vp], C.c_int),
         "mi_batch_rerun": ([vp], C.c_int),
@@ -534,6 +535,22 @@ class Batch:
         if size is None:
             size = os.stat(path).st_size
         self._check(self._lib.mi_batch_add_path(self._h, os.fsencode(path), size, tag))
+
+    def add_path_range(self, path, offset, size, tag=0):
+        """A file that is bytes [offset, offset+size) of `path` (a member of a layer tar)."""
+        self._check(self._lib.mi_batch_add_path_range(self._h, os.fsencode(path), offset, size, tag))
+
+    def add_tar(self, path):
+        """Registers every regular file of an uncompressed layer tar straight from its byte range
+        in the archive (no extraction).  Returns the archive's entries (tar_entries) with
+        "file_index" rewritten to the files' indices in THIS batch."""
+        ents = tar_entries(path)
+        base = self.counts()[0]
+        for e in ents:
+            if e["kind"] == KIND_FILE:
+                self.add_path_range(path, e["data_offset"], e["size"], tag=e["file_index"])
+                e["file_index"] += base
+        return ents
 
     def add_synthetic(self, sizes, content_ids=None, seed=0x4D414B49):
         s = np.ascontiguousarray(sizes, dtype=np.uint64)

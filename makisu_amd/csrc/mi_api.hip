@@ -614,6 +614,32 @@ int mi_batch_add_path(mi_batch* b, const char* path, uint64_t size, uint64_t use
     return rc;
 }
 
+// A file that is a byte range of another file: a member of an uncompressed layer tar
+// (mi_tar_entries gives the ranges).  Same staging path as mi_batch_add_path, the read starts at
+// `offset`.
+int mi_batch_add_path_range(mi_batch* b, const char* path, uint64_t offset, uint64_t size, uint64_t user_tag) {
+    if (!b || !path) return MI_ERR_INVALID;
+    mi_ctx* c = b->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure_staging(c);
+    if (rc) return rc;
+    int fd = open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) return fail(c, MI_ERR_IO, "open %s: %s", path, strerror(errno));
+    u64 at;
+    rc = batch_add_common(b, size, user_tag, &at);
+    if (rc == MI_OK && size) {
+        const auto t0 = std::chrono::steady_clock::now();
+        rc = staging_append(b, at, nullptr, fd, offset, size, path);
+        b->ms_h2d += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (rc) {                                   // undo the registration: the range is unusable
+            b->total_bytes -= size;
+            b->files.pop_back();
+        }
+    }
+    close(fd);
+    return rc;
+}
+
 int mi_batch_add_synthetic(mi_batch* b, uint64_t n_files, const uint64_t* sizes,
                            const uint64_t* content_ids, uint64_t seed) {
     if (!b || (!sizes && n_files)) return MI_ERR_INVALID;
