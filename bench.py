@@ -1,12 +1,19 @@
 #!/usr/bin/env python3
 """bench.py -- GiB/s hashed (Gear CDC + SHA-256 per chunk) on MI355X, BASELINE.json's metric.
 
-One "step" = one pass of the hot path over one batch that is already resident in HBM:
-Gear marking + cut selection -> chunk table -> SHA-256 per chunk -> per-file roots ->
-duplicate marking (+ for N > 1 the all-gather of the chunk-digest set over RCCL and the
-global duplicate marking).  Workload at N=1 = BASELINE.json configs[1] ("C2"): 100 000
-synthetic 64 KiB files, Gear mask 13 bits, min 2 KiB, max 64 KiB; for N > 1 every rank
-scans its own 100 000 files (weak scaling, distinct content per rank).
+One "step" = one pass of the hot path over one rank's share of the config, already resident in
+HBM: Gear marking + cut selection -> chunk table -> SHA-256 per chunk -> per-file roots ->
+duplicate marking (+ for N > 1 the all-gather of the chunk-digest set over RCCL and the job-wide
+duplicate marking).
+
+  --config c2   BASELINE.json configs[1]: 100 000 x 64 KiB per GPU          (default at N = 1:
+                the configuration the metric is quoted on)
+  --config c3   configs[2]: 1 000 x 128 MiB per GPU, as two half-batches in flight; also reports
+                the HOST-FED rate (page-cache files -> pinned staging -> H2D overlapped with the
+                scan) next to the resident one
+  --config c4   configs[3]: N x 1.25 M x 64 KiB, file index mod N            (default at N > 1)
+  --config c5   configs[4]: sizes 2^U(10,30) B, 90 % duplicate files, LPT shards; the job-wide
+                unique-chunk count is checked against the generator's closed form
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     -- the dominant kernel (sha256_items_kernel, chunk pass): algorithmic bytes
@@ -29,72 +36,137 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 SEED = 0x4D414B49
-N_FILES = 100000
-FILE_SIZE = 65536
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 # Measured with tools/ubench_sha.hip on MI355X: the 64-round compression alone, 8 waves/SIMD,
 # hashes 1.767 TB/s chip-wide -- the VALU roof of any one-lane-per-string SHA-256 kernel.
 SHA_VALU_ROOF_GBPS = 1767.0
 
 
-def cpu_baseline(budget_s=12.0):
-    """Oracle (port) on a bounded sample of the same workload, all host cores."""
+def cpu_baseline(shard, budget_files=None):
+    """The oracle (a port of the same spec) on a bounded sample of the SAME workload, timed around
+    the C call only.  Three numbers: all host cores (one file per thread at a time, threaded
+    bucketed duplicate marking), one thread, and the reference-shaped single stream (what Makisu
+    does today: one running SHA-256 over the tar-framed files, lib/builder/step/common.go:35-63)."""
     from oracle import mi_oracle as O
     O.build()
     cores = os.cpu_count() or 1
     p = O.CdcParams(SEED, 13, 2048, 65536)
-    flags = 0  # same columns as the GPU step: chunks, digests, roots, dedup
-    # calibrate single-thread rate on 256 files, then size the sample for ~budget_s
-    probe_n = 256
-    probe = np.concatenate([O.synth_fill(SEED, i, 0, FILE_SIZE) for i in range(probe_n)])
-    offs = np.arange(probe_n, dtype=np.uint64) * FILE_SIZE
-    szs = np.full(probe_n, FILE_SIZE, dtype=np.uint64)
+    # sample: a prefix of this rank's files, at most ~6.5 GB of host memory (all of C2)
+    sizes = shard.sizes
+    keep = np.cumsum(sizes) <= 6_600_000_000
+    n = max(1, int(keep.sum()))
+    if budget_files:
+        n = min(n, budget_files)
+    sizes, cids = sizes[:n], shard.cids[:n]
     t0 = time.perf_counter()
-    O.scan_batch(probe, offs, szs, p, True, 1, flags)
-    rate1 = probe.size / (time.perf_counter() - t0)
+    data, offs = O.synth_fill_many(shard.seed, cids, sizes, cores)
+    gen_s = time.perf_counter() - t0
+    nbytes = int(sizes.sum())
+    best, phases, n_chunks = None, None, 0
+    for _ in range(3):
+        t0 = time.perf_counter()
+        _, chunks = O.scan_batch(data, offs, sizes, p, True, cores, 0)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best:
+            best, phases, n_chunks = dt, O.last_phase_seconds(), len(chunks)
+    # one thread: a slice of the sample that takes about a second
+    n1 = max(1, min(n, int(1.0e9 // max(1, nbytes // n))))
+    b1 = int(sizes[:n1].sum())
     t0 = time.perf_counter()
-    O.layer_scan(probe, offs, szs, True)
-    ref_shaped = probe.size / (time.perf_counter() - t0)
-    n = int(min(max(rate1 * cores * budget_s / FILE_SIZE, 512), N_FILES))
-    data = np.empty(n * FILE_SIZE, dtype=np.uint8)
-    for i in range(n):
-        data[i * FILE_SIZE:(i + 1) * FILE_SIZE] = O.synth_fill(SEED, i, 0, FILE_SIZE)
-    offs = np.arange(n, dtype=np.uint64) * FILE_SIZE
-    szs = np.full(n, FILE_SIZE, dtype=np.uint64)
+    O.scan_batch(data[:b1], offs[:n1], sizes[:n1], p, True, 1, 0)
+    rate1 = b1 / (time.perf_counter() - t0)
+    # reference-shaped: ONE stream over the whole sample (bounded to ~4 GB: it is one core)
+    nr = max(1, int((np.cumsum(sizes) <= 4_000_000_000).sum()))
+    br = int(sizes[:nr].sum())
     t0 = time.perf_counter()
-    _, chunks = O.scan_batch(data, offs, szs, p, True, cores, flags)
-    dt = time.perf_counter() - t0
-    return {"value": round(data.size / dt / 2**30, 3), "unit": "GiB/s", "cores": cores,
+    O.layer_scan(data[:br], offs[:nr], sizes[:nr], True)
+    ref_rate = br / (time.perf_counter() - t0)
+    scan_rate = nbytes / max(phases["scan_s"], 1e-9)
+    return {"value": round(nbytes / best / 2**30, 3), "unit": "GiB/s", "cores": cores,
             "kind": "port",
-            "sample": "first %d of the %d files (%.0f MiB), same Gear CDC + SHA-256 per chunk + "
-                      "roots + dedup, one file per thread, SHA-NI=%s"
-                      % (n, N_FILES, data.size / 2**20, O.have_shani()),
+            "sample": "first %d files of this rank's %s shard (%.0f MiB): Gear CDC + SHA-256 per chunk + "
+                      "roots on all cores (one file per thread at a time), duplicate marking in 4096 "
+                      "digest-prefix buckets across threads; best of 3, timed around the C call, data "
+                      "already in host memory (generated in %.1f s, untimed)"
+                      % (n, shard.name, nbytes / 2**20, gen_s),
+            "sha_ni": bool(O.have_shani()),
+            "phase_s": {k: round(v, 4) for k, v in phases.items()},
+            "scan_phase_GiBps": round(scan_rate / 2**30, 3),
             "single_thread_GiBps": round(rate1 / 2**30, 3),
-            "reference_shaped_single_stream_GiBps": round(ref_shaped / 2**30, 3),
-            "n_chunks_sample": int(len(chunks))}
+            "parallel_efficiency": round(nbytes / best / (rate1 * cores), 3),
+            "reference_shaped_single_stream_GiBps": round(ref_rate / 2**30, 3),
+            "reference_shaped_sample_MiB": round(br / 2**20),
+            "n_chunks_sample": int(n_chunks)}
+
+
+def host_fed_rate(eng, n_files=48, file_bytes=128 << 20, reps=2):
+    """C3 as BASELINE.json words it: files streamed from the page cache through the pinned staging
+    ring with H2D overlapping the scan.  Bounded sample (default 6 GiB in /dev/shm or TMPDIR)."""
+    import tempfile
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    d = tempfile.mkdtemp(prefix="mi_hostfed_", dir=base)
+    rng = np.random.default_rng(7)
+    paths = []
+    try:
+        blob = rng.integers(0, 256, file_bytes, dtype=np.uint8)
+        for i in range(n_files):
+            blob[:8] = np.frombuffer(np.uint64(i).tobytes(), dtype=np.uint8)   # distinct files
+            pth = os.path.join(d, "f%04d" % i)
+            blob.tofile(pth)
+            paths.append(pth)
+        best = None
+        for _ in range(reps + 1):                      # first pass warms the page cache / ring
+            t0 = time.perf_counter()
+            with eng.batch(n_files, n_files * file_bytes) as b:
+                for i, pth in enumerate(paths):
+                    b.add_path(pth, file_bytes, i)
+                b.run()
+            dt = time.perf_counter() - t0
+            if _ > 0 and (best is None or dt < best):
+                best = dt
+        return {"host_fed_GBps": round(n_files * file_bytes / best / 1e9, 2),
+                "host_fed_sample": "%d x %d MiB files in %s (page-cache warm), mi_batch_add_path + run, "
+                                   "end to end, best of %d" % (n_files, file_bytes >> 20, base or "TMPDIR", reps)}
+    finally:
+        for pth in paths:
+            try:
+                os.unlink(pth)
+            except OSError:
+                pass
+        try:
+            os.rmdir(d)
+        except OSError:
+            pass
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--files", type=int, default=N_FILES, help="files per GPU (default = C2)")
+    ap.add_argument("--steps", type=int, default=0, help="default 20 (c2) / 3-5 for the larger configs")
+    ap.add_argument("--warmup", type=int, default=-1)
+    ap.add_argument("--config", default="auto", choices=["auto", "c2", "c3", "c4", "c5"],
+                    help="auto = c2 on one GPU (the config the metric is quoted on), c4 on several")
+    ap.add_argument("--files", type=int, default=0, help="files per GPU (c2: 100000, c3: 1000, c4: 1250000)")
+    ap.add_argument("--bytes-per-gpu", type=float, default=0, help="c5: GiB per GPU (default 32)")
     ap.add_argument("--inflight", type=int, default=0,
-                    help="batches in flight (1 = serial steps; default 2 on one GPU, 3 when the "
-                         "digest exchange has to hide behind the scans of the other batches)")
+                    help="batches in flight (1 = serial steps; default 2, 3 for c2 with an exchange)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-fed", action="store_true", help="c3: skip the host-fed leg")
     ap.add_argument("--backend", default="nccl",
-                    help="torch.distributed backend for the digest exchange (nccl = RCCL; gloo only "
-                         "for the single-GPU self-test of the N>1 logic)")
+                    help="torch.distributed backend (nccl = RCCL; gloo only for the single-GPU "
+                         "self-test of the N>1 logic)")
+    ap.add_argument("--exchange", default="torch", choices=["torch", "native"],
+                    help="who runs the digest all-gather: torch.distributed (default) or the library's "
+                         "own RCCL binding, mi_dedup_allgather (what a Go host uses)")
     ap.add_argument("--force-exchange", action="store_true",
-                    help="run the RCCL digest exchange + global marking even with one rank (self-test)")
+                    help="run the digest exchange + global marking even with one rank (self-test)")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     import makisu_amd
     from makisu_amd import distributed as mdist
+    from makisu_amd import workloads as W
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -106,13 +178,18 @@ def main():
     dev_index = int(os.environ.get("MI_BENCH_FORCE_DEVICE", local_rank))   # self-test: all ranks on one GPU
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
+    config = args.config if args.config != "auto" else ("c2" if world == 1 else "c4")
     exchange = world > 1 or args.force_exchange
     if args.inflight <= 0:
         # two batches already overlap one batch's Gear pass with the other's SHA pass; a third
-        # only pays off when there is host-synchronised exchange work to hide (measured: +2 % at
-        # N=1 for a dominant-kernel launch time 12 % longer)
-        args.inflight = 3 if exchange else 2
-    if exchange:
+        # only pays off when there is host-synchronised exchange work to hide and
+        # only fits for the small config
+        args.inflight = 3 if (exchange and config == "c2") else 2
+    if args.steps <= 0:
+        args.steps = {"c2": 20, "c3": 3, "c4": 3, "c5": 5}[config]
+    if args.warmup < 0:
+        args.warmup = 3 if config == "c2" else 1
+    if exchange or world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         if args.backend == "nccl":
@@ -124,44 +201,80 @@ def main():
     eng = makisu_amd.Engine(device=dev_index,
                             flags=makisu_amd.FLAG_NO_DEDUP if exchange else 0)
     info = eng.device_info()
-    # INFLIGHT batches alternate: step k runs on batch k % INFLIGHT.  Every step is a complete
-    # pass (all outputs recomputed); a step is submitted while the previous one is still
-    # running so the Gear pass of one overlaps the SHA pass of the other.
+    if exchange and args.exchange == "native":
+        uid = [eng.comm_unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(uid, src=0)          # torchrun only ships the 128-byte id
+        eng.comm_init_rank(world, rank, uid[0])
+
+    # The rank's share of the config, as `inflight` batches of distinct content.  Step k runs on
+    # batch k % inflight: every step is a complete pass (all outputs recomputed); a step is
+    # submitted while the previous one is still running so the Gear pass of one overlaps the SHA
+    # pass of the other.  c3 cuts the rank's 1000 files into `inflight` parts that
+    # together make ONE step (125 GiB fits HBM once, not twice).
+    def make(generation):
+        if config == "c2":
+            return W.c2(rank, world, args.files or 100000, generation)
+        if config == "c3":
+            return W.c3(rank, world, args.files or 1000, generation=generation)
+        if config == "c4":
+            return W.c4(rank, world, args.files or 1250000, generation)
+        return W.c5(rank, world, int((args.bytes_per_gpu or 32) * W.GIB), generation)
+
+    split = config == "c3"
+    shards = []
+    if split:
+        whole = make(0)
+        for part in np.array_split(np.arange(whole.n_files), args.inflight):
+            shards.append(W.Shard(whole.name, whole.seed, whole.sizes[part], whole.cids[part],
+                                  whole.global_index[part], whole.n_global_files, describe=whole.describe))
+        step_bytes = whole.n_bytes
+        desc_shard = whole
+    else:
+        shards = [make(i) for i in range(args.inflight)]
+        step_bytes = shards[0].n_bytes
+        desc_shard = shards[0]
     batches = []
-    for i in range(args.inflight):
-        b = eng.batch(args.files, args.files * FILE_SIZE)
-        # distinct content per rank and per batch: content id = global file index
-        cids = np.arange(args.files, dtype=np.uint64) + np.uint64((i * world + rank) * args.files)
-        b.add_synthetic(np.full(args.files, FILE_SIZE, dtype=np.uint64), cids, seed=SEED)
+    for sh in shards:
+        b = eng.batch(sh.n_files, sh.n_bytes)
+        b.add_synthetic(sh.sizes, sh.cids, seed=sh.seed)
         b.run()                                   # generates the data on the device, first pass
         batches.append(b)
-    sha_ms, stats_sum = [], {}
+    launches_per_step = len(batches) if split else 1
+    sha_ms, sha_alg_bytes, stats_sum, checks = [], [], {}, {}
 
-    def finish(b, record):
+    def finish(i, record):
+        b = batches[i]
         b.wait()
+        n_unique = None
         if exchange:
-            mdist.global_dedup(eng, b, device)    # digest all-gather over RCCL + global marking
+            if args.exchange == "native":
+                _, n_unique, _ = b.dedup_allgather()      # RCCL inside the library
+            else:
+                _, n_unique, _, _ = mdist.global_dedup(eng, b, device)
         if record:
             st = eng.stats()
             sha_ms.append(st["ms_sha_chunks"])
+            sha_alg_bytes.append(st["bytes_in"] + 52 * st["n_chunks"])
             for k, v in st.items():
                 if k.startswith("ms_"):
                     stats_sum[k] = stats_sum.get(k, 0.0) + v
+            checks[i] = (st["n_chunks"], n_unique if exchange else st["n_unique"])
 
     def run_steps(n, record):
         pending = []
-        for k in range(n):
+        for k in range(n * launches_per_step):
             if len(pending) == args.inflight:
                 finish(pending.pop(0), record)
-            b = batches[k % args.inflight]
-            b.submit()
-            pending.append(b)
+            i = k % len(batches)
+            batches[i].submit()
+            pending.append(i)
         while pending:
             finish(pending.pop(0), record)
 
     def fence():
         torch.cuda.synchronize(device)
-        if exchange:
+        if dist.is_initialized():
             dist.barrier()
             torch.cuda.synchronize(device)
 
@@ -171,82 +284,127 @@ def main():
     run_steps(args.steps, True)
     fence()
     dt = time.perf_counter() - t0
-    if exchange:
+    if dist.is_initialized() and world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    job_bytes = step_bytes
+    if dist.is_initialized() and world > 1:             # shards differ in size for c5
+        t = torch.tensor([step_bytes], dtype=torch.int64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        job_bytes = int(t.item())
+    else:
+        job_bytes = step_bytes * world
 
     # Outside the timed region: a few SERIAL steps (one batch at a time) so the dominant
     # kernel's launch duration can also be read without another batch sharing the GPU.
-    serial_sha_ms = []
+    serial_sha_ms, serial_phase = [], {}
     if args.inflight > 1:
         for _ in range(3):
             batches[0].submit()
             batches[0].wait()
-            serial_sha_ms.append(eng.stats()["ms_sha_chunks"])
+            st = eng.stats()
+            serial_sha_ms.append(st["ms_sha_chunks"])
+            serial_phase = {k: round(v, 4) for k, v in st.items() if k.startswith("ms_")}
+        serial_alg = st["bytes_in"] + 52 * st["n_chunks"]
 
-    st = eng.stats()
-    bytes_per_gpu = st["bytes_in"]
-    n_chunks = st["n_chunks"]
-    value = world * bytes_per_gpu * args.steps / dt / 2**30
+    # closed-form check of the duplicate marking (c5: 90 % duplicate files): the job-wide unique
+    # count must equal the chunk count of the first file of every distinct content
+    dedup_check = None
+    if config == "c5" or (config == "c2" and not exchange):
+        expect_local = 0
+        if config == "c5":
+            files0 = batches[0].files()
+            expect_local = int(files0["n_chunks"][shards[0].originals].sum())
+        else:
+            expect_local = checks[0][0]
+        if dist.is_initialized() and world > 1:
+            t = torch.tensor([expect_local], dtype=torch.int64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            expect_local = int(t.item())
+        got = checks[0][1]
+        dedup_check = {"n_unique": int(got) if got is not None else None, "closed_form": int(expect_local),
+                       "ok": got is not None and int(got) == int(expect_local)}
+
+    value = job_bytes * args.steps / dt / 2**30
     # dominant kernel: SHA-256 per chunk.  Algorithmic bytes per launch: every file byte read
     # once + 32 B digest written per chunk + the 20 B queue descriptor read per chunk.
-    alg_bytes = bytes_per_gpu + 52 * n_chunks
+    alg_bytes = float(np.mean(sha_alg_bytes))
     sha_avg_ms = float(np.mean(sha_ms))
     achieved = alg_bytes / (sha_avg_ms * 1e-3) / 1e9
-    traffic = None
+    traffic, traffic_src = None, None
     tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(tfile):
+    if config == "c2" and os.path.exists(tfile):
         try:
-            traffic = json.load(open(tfile)).get("sha256_items_kernel_bytes_per_launch")
+            tj = json.load(open(tfile))
+            traffic = tj.get("sha256_items_kernel_bytes_per_launch")
+            traffic_src = tj.get("source")
         except Exception:
             traffic = None
+    st = eng.stats()
     out = {
         "metric": "GiB/s hashed (Gear CDC + SHA-256 per chunk)",
         "value": round(value, 2), "unit": "GiB/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u32", "data": "synthetic",
-        "config": {"workload": "C2: %d x 64 KiB synthetic files per GPU (seed 0x4D414B49, "
-                               "device-resident), Gear CDC mask 13 bits / min 2 KiB / max 64 KiB, "
-                               "SHA-256 per chunk, per-file chunk root, duplicate marking%s"
-                               % (args.files, "; digest-set all-gather over RCCL + global marking"
+        "config": {"workload": "%s (seed 0x%X, device-resident), Gear CDC mask 13 bits / min 2 KiB / "
+                               "max 64 KiB, SHA-256 per chunk, per-file chunk root, duplicate marking%s"
+                               % (desc_shard.describe, desc_shard.seed,
+                                  "; digest-set all-gather over RCCL (%s) + job-wide marking" % args.exchange
                                   if exchange else ""),
-                   "files_per_gpu": args.files, "bytes_per_gpu": int(bytes_per_gpu),
-                   "chunks_per_gpu": int(n_chunks), "parallelism": "files sharded x%d" % world,
-                   "batches_in_flight": args.inflight,
-                   "device": info["name"].strip(), "n_cu": info["n_cu"]},
+                   "name": config, "files_per_gpu": int(sum(s.n_files for s in shards) if split else shards[0].n_files),
+                   "bytes_per_gpu": int(step_bytes), "job_bytes_per_step": int(job_bytes),
+                   "chunks_last_batch": int(st["n_chunks"]),
+                   "parallelism": "files sharded x%d (%s)" % (world, "LPT by bytes" if config == "c5" else "file index mod N"),
+                   "batches_in_flight": args.inflight, "launches_per_step": launches_per_step,
+                   "exchange": (args.exchange if exchange else None),
+                   "device": info["name"].strip(), "n_cu": info["n_cu"],
+                   "results": "left on the device (16 B of counts read back per batch); mi_batch_files/"
+                              "mi_batch_chunks copy ~62 B per chunk + 104 B per file to the host on demand, "
+                              "outside this metric"},
         "roofline": {"bound": "hbm", "kernel": "sha256_items_kernel (chunk pass)",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                     "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": int(alg_bytes),
                      "avg_launch_ms": round(sha_avg_ms, 4),
                      "valu_roof_GBps": SHA_VALU_ROOF_GBPS,
                      "frac_of_valu_roof": round(achieved / SHA_VALU_ROOF_GBPS, 4),
+                     "path_frac": round(job_bytes / world * 1.006 / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS, 4),
                      "note": "SHA-256 is integer-VALU bound on CDNA4 (measured roof 1.77 TB/s "
                              "hashed, tools/ubench_sha.hip); the HBM fraction cannot exceed 0.22. "
                              "achieved/avg_launch_ms are from the timed region, where the kernel "
                              "shares the GPU with the other in-flight batches' passes; "
                              "serial_* = the same kernel with one batch at a time (3 extra "
-                             "untimed steps)"},
-        "phase_ms_avg": {k: round(v / args.steps, 4) for k, v in sorted(stats_sum.items())},
+                             "untimed steps); path_frac = whole CDC+SHA step per GPU, algorithmic "
+                             "bytes / ms_per_step / peak"},
+        "phase_ms_avg": {k: round(v / max(1, len(sha_ms)), 4) for k, v in sorted(stats_sum.items())},
         "phase_note": "per-batch stream timelines; with several batches in flight a phase's span "
                       "includes time it shared the GPU with the other batches",
     }
+    if dedup_check:
+        out["dedup_check"] = dedup_check
     if serial_sha_ms:
         s_ms = float(np.mean(serial_sha_ms))
-        s_ach = alg_bytes / (s_ms * 1e-3) / 1e9
+        s_ach = serial_alg / (s_ms * 1e-3) / 1e9
         out["roofline"].update({"serial_avg_launch_ms": round(s_ms, 4),
                                 "serial_achieved": round(s_ach, 1),
                                 "serial_frac": round(s_ach / HBM_PEAK_GBPS, 4),
                                 "serial_frac_of_valu_roof": round(s_ach / SHA_VALU_ROOF_GBPS, 4)})
-    if rank == 0:
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline()
+        out["serial_phase_ms"] = serial_phase
+    if rank == 0 and world == 1:
+        if config == "c3" and not args.no_host_fed:
+            for b in batches:                          # make room: the host-fed leg allocates its own arena
+                b.free()
+            batches = []
+            out["config"].update(host_fed_rate(eng))
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(desc_shard)
     for b in batches:
         b.free()
     eng.close()
-    if exchange:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

@@ -34,9 +34,11 @@
 //      wave-wide find-first-set (64 lanes x 64 bits per step, __ballot + ctz) when a tile
 //      has too many candidates for the list; chunk ends go to the file's slot region in HBM.
 // Small files (<= one tile): one wave per file, four files per workgroup, no
-// workgroup barrier at all.  Large files: chained groups of four tiles -- persistent
-// workgroups mark groups in parallel (even within ONE file) and pass the cut state from
-// group to group (see gear_cdc_large_kernel).
+// workgroup barrier at all.  Large files: GROUPS of four tiles (256 KiB) that are marked AND
+// cut in parallel -- every group selects speculatively as if a cut fell on its first byte,
+// a second pass re-selects from the previous group's speculative exit until it meets the
+// speculative cut list again (Gear + min/max re-synchronises within a few chunks), and a
+// per-file pass only walks the groups whose assumption failed (see "large files" below).
 // HBM traffic: every file byte read once (+6 % warm-up, mostly L2 hits), 8 B written
 // per chunk.  Bound: HBM bandwidth / LDS lookup rate.
 #include "mi_common.h"
@@ -193,12 +195,14 @@ __device__ __forceinline__ void mark_tile(const u8* __restrict__ fptr, u64 ts, u
     }
 }
 
-// Wave-uniform cut selection over one marked tile; appends chunk ends, updates last/n_out.
-// `list` != nullptr: the tile's sorted candidate list (cand_compact succeeded) -- one ballot per
-// cut; otherwise the bitmap is searched.
-__device__ __forceinline__ void select_tile(const u32* bitmap, const u32* list, u64 ts, u32 tlen,
-                                            const CdcParams& p, u64& last, u32& n_out,
-                                            u64* __restrict__ ends, int lane) {
+// Wave-uniform cut selection over one marked tile.  Every cut is handed to emit(cut) (wave-uniform
+// call, absolute END offset inside the file); emit returns true to stop the selection at once
+// (the validation pass stops where it meets the speculative cut list again).  Returns true when
+// stopped.  `list` != nullptr: the tile's sorted candidate list (cand_compact / list_from_bitmap
+// succeeded) -- one ballot per cut; otherwise the bitmap is searched.
+template <typename Emit>
+__device__ __forceinline__ bool select_tile(const u32* bitmap, const u32* list, u64 ts, u32 tlen,
+                                            const CdcParams& p, u64& last, int lane, Emit&& emit) {
     const u64 te = ts + tlen;                            // ends in this tile: (ts, te]
     const u32 cand = list ? list[lane] : kNoCand;        // lane i = i-th candidate (ascending)
     for (;;) {
@@ -217,19 +221,49 @@ __device__ __forceinline__ void select_tile(const u32* bitmap, const u32* list, 
             }
             if (b >= 0) {
                 last = ts + (u64)b + 1;
-                if (lane == 0) ends[n_out] = last;
-                ++n_out;
+                if (emit(last)) return true;
                 continue;
             }
         }
         if (last + p.max_size <= te) {                   // forced cut at max_size
             last += p.max_size;
-            if (lane == 0) ends[n_out] = last;
-            ++n_out;
+            if (emit(last)) return true;
             continue;
         }
         break;
     }
+    return false;
+}
+
+// Slow path of the list construction: a tile whose lanes overflowed their 3 packed candidates
+// (about 6 in 10 000 tiles on random data) still has few candidates in total; rebuild the sorted
+// list from the bitmap -- lane i owns words [32 i, 32 i + 32) = its own 1 KiB run.  False
+// (wave-uniform) when the tile really holds more than 64 candidates.
+__device__ __forceinline__ bool list_from_bitmap(const u32* bitmap, int lane, u32* list) {
+    u32 cnt = 0;
+#pragma unroll 4
+    for (int w = 0; w < 32; ++w) cnt += (u32)__popc(bitmap[lane * 32 + w]);
+    u32 incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 y = __shfl_up(incl, d);
+        if (lane >= d) incl += y;
+    }
+    const u32 total = __shfl(incl, 63);
+    if (total > 64u) return false;
+    list[lane] = kNoCand;
+    u32 pos = incl - cnt;
+    if (cnt) {
+        for (int w = 0; w < 32; ++w) {
+            u32 bits = bitmap[lane * 32 + w];
+            while (bits) {
+                const int b = __ffs(bits) - 1;
+                bits &= bits - 1;
+                list[pos++] = (u32)lane * kLaneRun + (u32)w * 32u + (u32)b;
+            }
+        }
+    }
+    return true;
 }
 
 __device__ __forceinline__ void load_table(u64* table, const u64* __restrict__ gear_table, int tid) {
@@ -238,11 +272,13 @@ __device__ __forceinline__ void load_table(u64* table, const u64* __restrict__ g
 }
 
 // ---- small files: one wave per file (size <= kGearTile) ----------------------------------
+// A small file is one SEGMENT: its chunk ends go to ends32[seg_slot[s] ..] (u32, file-relative),
+// its chunk count to seg_n[s].
 __global__ __launch_bounds__(kGearWG)
 void gear_cdc_small_kernel(const u8* __restrict__ data, const u64* __restrict__ file_off,
-                           const u64* __restrict__ file_size, const u64* __restrict__ slot_base,
-                           u64* __restrict__ slot_ends, u32* __restrict__ n_chunks,
-                           const u32* __restrict__ list, u32 n_list,
+                           const u64* __restrict__ file_size, const u32* __restrict__ seg_file,
+                           const u64* __restrict__ seg_slot, u32* __restrict__ ends32,
+                           u32* __restrict__ seg_n, const u32* __restrict__ list, u32 n_list,
                            const u64* __restrict__ gear_table, CdcParams p) {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     u64* table = (u64*)smem;
@@ -254,9 +290,10 @@ void gear_cdc_small_kernel(const u8* __restrict__ data, const u64* __restrict__ 
     const u32 lane_tab = lds_lane_table(table, lane);
     const u32 li = blockIdx.x * kWavesPerWG + wave;
     if (li >= n_list) return;
-    const u32 f = list[li];
+    const u32 s = list[li];
+    const u32 f = seg_file[s];
     const u64 size = file_size[f];
-    u64* ends = slot_ends + slot_base[f];
+    u32* ends = ends32 + seg_slot[s];
     u64 last = 0;
     u32 n_out = 0;
     if (size) {
@@ -268,146 +305,330 @@ void gear_cdc_small_kernel(const u8* __restrict__ data, const u64* __restrict__ 
         // the wave's own LDS writes are ordered for the wave itself after the waitcnt the
         // compiler inserts; no other wave touches this bitmap / list
         __builtin_amdgcn_wave_barrier();
-        select_tile(bitmap, fast ? cand_list : nullptr, 0, (u32)size, p, last, n_out, ends, lane);
+        select_tile(bitmap, fast ? cand_list : nullptr, 0, (u32)size, p, last, lane,
+                    [&](u64 c) { if (lane == 0) ends[n_out] = (u32)c; ++n_out; return false; });
     }
     if (lane == 0) {
-        if (size > last) { ends[n_out] = size; ++n_out; }   // the file end always cuts
-        n_chunks[f] = n_out;
+        if (size > last) { ends[n_out] = (u32)size; ++n_out; }   // the file end always cuts
+        seg_n[s] = n_out;
     }
 }
 
-// ---- large files: chained groups ------------------------------------------------------------
-// A large file is cut into GROUPS of kWavesPerWG tiles (256 KiB).  Persistent workgroups draw
-// group tickets from one atomic counter in file-major order; a workgroup marks its group's
-// tiles independently of everybody else (the expensive part), then wave 0 waits for the CUT
-// STATE (last cut, chunks emitted) handed over by the previous group of the same file,
-// selects this group's cuts and hands the state on.  So even ONE huge file keeps the whole
-// chip busy; only the cheap selection is serial.
-// Hand-over (MI355X_MICROARCH.md "R2: the data IS the flag"): two 8-byte granules per group,
-// {tag:32 | n_out:32} and {tag:16 | last:48}, each written by ONE relaxed agent-scope store and
-// polled with relaxed agent-scope loads -- no fences; granules are zeroed before every launch.
-// Deadlock-free: tickets are drawn in order by running workgroups, so the predecessor of any
-// waiting group already holds a ticket and never waits on its successors.
-struct GroupToken { u64 a, b; };
-typedef __attribute__((address_space(1))) unsigned long long gu64;
+// ---- large files: speculative groups, validation, per-file fix-up ---------------------------
+// A large file is cut into GROUPS of kWavesPerWG tiles (256 KiB); group gi of file f is segment
+// file_seg0[f] + gi.  Cut selection is a sequential recurrence over the file (the next cut depends
+// on the previous one), but it forgets its start quickly: from ANY previous cut the chosen sequence
+// joins the true one as soon as both pick the same candidate, and then stays on it.  So:
+//   A  gear_group_mark_kernel (all groups in parallel): mark the four tiles, keep every tile's
+//      sorted candidate list (<= 64 entries, u32) in HBM, and select SPECULATIVELY as if a cut
+//      fell on the group's first byte -> spec list (u32, relative to the group start), spec exit
+//      E_g = its last cut.  Group 0 of a file starts at a true cut: its spec list is final.
+//   B  gear_group_validate_kernel (all groups gi > 0 in parallel, one wave each): re-select from
+//      the ASSUMED entry E_{g-1} until a cut is also a spec cut of this group (index sidx): the
+//      group's cuts are then prefix[0, pcnt) ++ spec[sidx, spec_n) and its exit is E_g again.  If it
+//      never meets the spec list the whole re-selection is the prefix and the exit is its own.
+//   C  gear_file_fix_kernel (one workgroup per large file): walks the file's groups 64 at a time
+//      checking entry_g == exit_{g-1}; where that fails (the previous group did not come back to
+//      its spec exit, or the group is DENSE) the group is re-selected from the true entry, which
+//      usually re-synchronises inside that same group.  Data that never re-synchronises (e.g.
+//      forced cuts only, with max_size not dividing the group size) degenerates to one sequential
+//      re-selection per group -- correct, as slow as a serial chunker.
+// DENSE tile: more than 64 candidates (mask_bits far below the default): no list; B skips such
+// groups and C re-marks their tiles to get the bitmaps back.
+// Result per group: GroupRec + two u32 regions of R = kGroupBytes / min_size + 2 entries at
+// ends32[seg_slot[s]]: [0, R) spec list, [R, 2R) prefix.
 
-__global__ __launch_bounds__(kGearWG)
-void gear_cdc_large_kernel(const u8* __restrict__ data, const u64* __restrict__ file_off,
-                           const u64* __restrict__ file_size, const u64* __restrict__ slot_base,
-                           u64* __restrict__ slot_ends, u32* __restrict__ n_chunks,
-                           const u32* __restrict__ group_file, const u32* __restrict__ group_index,
-                           const u32* __restrict__ group_prev, u32 n_groups,
-                           u32* __restrict__ ticket_counter,
-                           GroupToken* __restrict__ tokens, const u64* __restrict__ gear_table,
-                           CdcParams p) {
+// Re-selection of one group by one wave from `entry` (<= g0), meeting the spec list if it can.
+// lists: LDS, kWavesPerWG x 64 candidates (tile-relative); bitmaps (LDS) are used for tiles whose
+// bit in fast_mask is clear.  Writes prefix cuts (relative to g0) and fills rec's final fields.
+__device__ __forceinline__ u64 reselect_group(const u32* lists, const u32* bitmaps, u32 fast_mask,
+                                               u64 g0, u64 size, u64 entry, const u32* __restrict__ spec,
+                                               u32 spec_n, u64 spec_exit, u32* __restrict__ prefix,
+                                               const CdcParams& p, int lane, GroupRec* rec, u32* seg_n_out) {
+    u64 last = entry;
+    u32 pcnt = 0, sidx = spec_n;
+    u32 sbase = 0;
+    u32 sreg = lane < (int)spec_n ? spec[lane] : kNoCand;      // spec[sbase + lane]
+    bool synced = false;
+    auto emit = [&](u64 c) -> bool {
+        const u32 rel = (u32)(c - g0);
+        for (;;) {                                             // first spec cut >= rel
+            const u64 bal = __ballot(sreg >= rel);
+            if (bal) {
+                const int i = __ffsll((unsigned long long)bal) - 1;
+                if (__shfl(sreg, i) == rel && sbase + (u32)i < spec_n) { sidx = sbase + (u32)i; synced = true; }
+                break;
+            }
+            if (sbase + 64u >= spec_n) break;
+            sbase += 64u;
+            sreg = sbase + (u32)lane < spec_n ? spec[sbase + lane] : kNoCand;
+        }
+        if (synced) return true;
+        if (lane == 0) prefix[pcnt] = rel;
+        ++pcnt;
+        return false;
+    };
+    for (int t = 0; t < kWavesPerWG && !synced; ++t) {
+        const u64 tts = g0 + (u64)t * kGearTile;
+        if (tts >= size) break;
+        const u32 tlen = (u32)((size - tts < (u64)kGearTile) ? (size - tts) : (u64)kGearTile);
+        select_tile(bitmaps + t * kBitmapWords, (fast_mask >> t) & 1u ? lists + t * 64 : nullptr, tts, tlen,
+                    p, last, lane, emit);
+    }
+    if (!synced && g0 + kGroupBytes >= size && size > last) {  // the file's last group: the end cuts
+        if (!emit(size)) last = size;
+    }
+    const u64 exit = synced ? spec_exit : last;
+    if (lane == 0) {
+        rec->entry = entry;
+        rec->pcnt = pcnt;
+        rec->sidx = sidx;
+        rec->final_exit = exit;
+        rec->flags = (rec->flags & kGroupDense) | kGroupValid;
+        *seg_n_out = pcnt + (spec_n - sidx);
+    }
+    return exit;                                               // wave-uniform
+}
+
+__global__ __launch_bounds__(kGearWG, 3)       // 3 workgroups per CU: <= 168 VGPRs
+void gear_group_mark_kernel(const u8* __restrict__ data, const u64* __restrict__ file_off,
+                            const u64* __restrict__ file_size, const u64* __restrict__ file_seg0,
+                            const u64* __restrict__ seg_slot, u32* __restrict__ ends32,
+                            u32* __restrict__ seg_n, const u32* __restrict__ group_file,
+                            const u32* __restrict__ group_index, u32 n_groups,
+                            GroupRec* __restrict__ recs, u32* __restrict__ tile_lists,
+                            const u64* __restrict__ gear_table, CdcParams p) {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     u64* table = (u64*)smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     u32* bitmaps = (u32*)(smem + kTableBytes);
     u32* cand_lists = (u32*)(smem + kLdsListOff);
     volatile u32* fast_flags = (volatile u32*)(smem + kLdsFastOff);
-    // (the ticket word lives in the dynamic region: a static __shared__ would shift its base)
-    volatile u32* s_ticket = (volatile u32*)(smem + kGearLdsBytes);
     load_table(table, gear_table, tid);
     __syncthreads();
     const u32 lane_tab = lds_lane_table(table, lane);
-    constexpr u64 kGroupBytes = (u64)kGearTile * kWavesPerWG;
-    for (;;) {
-        if (tid == 0) *s_ticket = atomicAdd(ticket_counter, 1u);
-        __syncthreads();
-        const u32 g = *s_ticket;
-        if (g >= n_groups) break;
+    for (u32 g = blockIdx.x; g < n_groups; g += gridDim.x) {
         const u32 f = group_file[g], gi = group_index[g];
         const u64 size = file_size[f];
         const u8* fptr = data + file_off[f];
         const u64 g0 = (u64)gi * kGroupBytes;
         const u64 ts = g0 + (u64)wave * kGearTile;
+        if (lane == 0) fast_flags[wave] = 1u;                 // tiles past the end count as listed
         if (ts < size) {
             const u32 tlen = (u32)((size - ts < (u64)kGearTile) ? (size - ts) : (u64)kGearTile);
             u32 pk;
             bool ovf;
-            mark_tile(fptr, ts, tlen, bitmaps + wave * kBitmapWords, lane_tab,
-                      p.thresh_m1, lane, pk, ovf);
-            const bool fast = cand_compact(pk, ovf, (u32)lane * kLaneRun, lane, cand_lists + wave * 64);
+            u32* bm = bitmaps + wave * kBitmapWords;
+            u32* cl = cand_lists + wave * 64;
+            mark_tile(fptr, ts, tlen, bm, lane_tab, p.thresh_m1, lane, pk, ovf);
+            bool fast = cand_compact(pk, ovf, (u32)lane * kLaneRun, lane, cl);
+            if (!fast) {
+                __builtin_amdgcn_wave_barrier();
+                fast = list_from_bitmap(bm, lane, cl);
+            }
+            __builtin_amdgcn_wave_barrier();
+            tile_lists[((u64)g * kWavesPerWG + wave) * 64 + lane] = fast ? cl[lane] : kNoCand;
             if (lane == 0) fast_flags[wave] = fast ? 1u : 0u;
         }
         __syncthreads();
         if (wave == 0) {
-            u64 last = 0;
-            u32 n_out = 0;
-            if (gi > 0) {                                 // cut state from the file's previous group
-                const u32 prev = group_prev[g];           // its ticket (always < g)
-                gu64* ta = (gu64*)&tokens[prev].a;
-                gu64* tb = (gu64*)&tokens[prev].b;
-                u64 a = 0, b = 0;
-                if (lane == 0) {
-                    // bounded: a broken chain must surface as an error, not as a hung GPU
-                    for (u32 spins = 0;; ++spins) {
-                        a = __hip_atomic_load(ta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        b = __hip_atomic_load(tb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if ((a >> 32) == 1u && (b >> 48) == 1u) break;
-                        if (spins > (1u << 24)) { atomicExch(ticket_counter + 1, 1u); a = b = 0; break; }
-                        __builtin_amdgcn_s_sleep(4);
-                    }
-                }
-                const u32 alo = __shfl((u32)a, 0);
-                const u32 blo = __shfl((u32)b, 0), bhi = __shfl((u32)(b >> 32), 0);
-                n_out = alo;
-                last = (((u64)bhi << 32) | blo) & 0xFFFFFFFFFFFFull;
-            }
-            u64* ends = slot_ends + slot_base[f];
+            const u64 s = file_seg0[f] + gi;
+            u32* spec = ends32 + seg_slot[s];
+            u64 last = g0;                                    // speculation: a cut at the group start
+            u32 n_out = 0, fast_mask = 0;
+            for (int t = 0; t < kWavesPerWG; ++t) fast_mask |= (fast_flags[t] ? 1u : 0u) << t;
             for (int t = 0; t < kWavesPerWG; ++t) {
                 const u64 tts = g0 + (u64)t * kGearTile;
                 if (tts >= size) break;
                 const u32 tlen = (u32)((size - tts < (u64)kGearTile) ? (size - tts) : (u64)kGearTile);
-                select_tile(bitmaps + t * kBitmapWords, fast_flags[t] ? cand_lists + t * 64 : nullptr,
-                            tts, tlen, p, last, n_out, ends, lane);
+                select_tile(bitmaps + t * kBitmapWords, (fast_mask >> t) & 1u ? cand_lists + t * 64 : nullptr,
+                            tts, tlen, p, last, lane,
+                            [&](u64 c) { if (lane == 0) spec[n_out] = (u32)(c - g0); ++n_out; return false; });
             }
             if (lane == 0) {
-                if (g0 + kGroupBytes >= size) {           // the file's last group
-                    if (size > last) { ends[n_out] = size; ++n_out; }
-                    n_chunks[f] = n_out;
-                } else {
-                    __hip_atomic_store((gu64*)&tokens[g].a, ((u64)1 << 32) | n_out, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store((gu64*)&tokens[g].b, ((u64)1 << 48) | last, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
+                if (g0 + kGroupBytes >= size && size > last) {   // the file's last group: the end cuts
+                    spec[n_out] = (u32)(size - g0); ++n_out; last = size;
                 }
+                GroupRec r;
+                r.spec_exit = last;
+                r.spec_n = n_out;
+                r.flags = fast_mask == (1u << kWavesPerWG) - 1u ? 0u : kGroupDense;
+                r.entry = gi == 0 ? 0ull : ~0ull;
+                r.final_exit = last;
+                r.pcnt = 0;
+                r.sidx = 0;
+                if (gi == 0) { r.flags |= kGroupValid; seg_n[s] = n_out; }
+                recs[g] = r;
             }
         }
-        __syncthreads();                                  // bitmaps and s_ticket are reused
+        __syncthreads();                                      // bitmaps / lists are reused
     }
 }
 
-u64 gear_large_groups(u64 size) {
-    const u64 gb = (u64)kGearTile * kWavesPerWG;
-    return (size + gb - 1) / gb;
+// B: one wave per group.  Groups of one file are consecutive in g, so g - 1 is the previous group
+// of the same file whenever gi > 0.
+__global__ __launch_bounds__(kGearWG)
+void gear_group_validate_kernel(const u64* __restrict__ file_size, const u64* __restrict__ file_seg0,
+                                const u64* __restrict__ seg_slot, u32* __restrict__ ends32,
+                                u32* __restrict__ seg_n, const u32* __restrict__ group_file,
+                                const u32* __restrict__ group_index, u32 n_groups,
+                                GroupRec* __restrict__ recs, const u32* __restrict__ tile_lists,
+                                u32 region, CdcParams p) {
+    __shared__ u32 lists[kWavesPerWG][kWavesPerWG * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u32 g = blockIdx.x * kWavesPerWG + wave;
+    if (g >= n_groups) return;
+    const u32 gi = group_index[g];
+    if (gi == 0) return;
+    GroupRec* rec = recs + g;
+    if (rec->flags & kGroupDense) return;                     // left to the per-file pass
+    const u32 f = group_file[g];
+    const u64 s = file_seg0[f] + gi;
+#pragma unroll
+    for (int t = 0; t < kWavesPerWG; ++t)
+        lists[wave][t * 64 + lane] = tile_lists[((u64)g * kWavesPerWG + t) * 64 + lane];
+    __builtin_amdgcn_wave_barrier();
+    u32* spec = ends32 + seg_slot[s];
+    (void)reselect_group(lists[wave], nullptr, (1u << kWavesPerWG) - 1u, (u64)gi * kGroupBytes, file_size[f],
+                         recs[g - 1].spec_exit, spec, rec->spec_n, rec->spec_exit, spec + region, p, lane,
+                         rec, seg_n + s);
 }
 
-void launch_gear_cdc(const u8* d_data, const u64* d_file_off, const u64* d_file_size,
-                     const u64* d_slot_base, u64* d_slot_ends, u32* d_n_chunks,
-                     const u32* d_small_list, u32 n_small, const u32* d_group_file,
-                     const u32* d_group_index, const u32* d_group_prev, u32 n_groups,
-                     u32* d_ticket, void* d_tokens, const u64* d_gear_table, CdcParams p, int n_cu,
-                     hipStream_t s) {
+// C: one workgroup per large file.
+__global__ __launch_bounds__(kGearWG)
+void gear_file_fix_kernel(const u8* __restrict__ data, const u64* __restrict__ file_off,
+                          const u64* __restrict__ file_size, const u64* __restrict__ file_seg0,
+                          const u64* __restrict__ seg_slot, u32* __restrict__ ends32,
+                          u32* __restrict__ seg_n, const u32* __restrict__ large_list,
+                          const u32* __restrict__ large_group0, GroupRec* __restrict__ recs,
+                          const u32* __restrict__ tile_lists, u32 region,
+                          const u64* __restrict__ gear_table, CdcParams p) {
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    u64* table = (u64*)smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    u32* bitmaps = (u32*)(smem + kTableBytes);
+    u32* cand_lists = (u32*)(smem + kLdsListOff);
+    volatile u32* fast_flags = (volatile u32*)(smem + kLdsFastOff);
+    volatile u32* s_next = (volatile u32*)(smem + kGearLdsBytes);     // [0] group to redo or ~0, [1] dense?
+    volatile u64* s_entry = (volatile u64*)(smem + kGearLdsBytes + 8);
+    load_table(table, gear_table, tid);
+    __syncthreads();
+    const u32 lane_tab = lds_lane_table(table, lane);
+    const u32 f = large_list[blockIdx.x];
+    const u64 size = file_size[f];
+    const u8* fptr = data + file_off[f];
+    const u32 gb = large_group0[blockIdx.x];
+    const u32 ng = (u32)((size + kGroupBytes - 1) / kGroupBytes);
+    u32 gi = 1;                                               // next group to check
+    u64 prev_exit = 0;                                        // true exit of group gi - 1 (wave 0)
+    if (wave == 0) prev_exit = recs[gb].final_exit;
+    for (;;) {
+        // wave 0: skip ahead over groups whose assumption holds
+        if (wave == 0) {
+            u32 redo = 0xFFFFFFFFu, dense = 0;
+            while (gi < ng) {
+                const u32 my = gi + (u32)lane;
+                bool bad = false;
+                u64 ex = 0;
+                if (my < ng) {
+                    const GroupRec r = recs[gb + my];
+                    const u64 pe = lane == 0 ? prev_exit : recs[gb + my - 1].final_exit;
+                    ex = r.final_exit;
+                    bad = !(r.flags & kGroupValid) || r.entry != pe;
+                }
+                const u64 bal = __ballot(bad);
+                if (!bal) {                                   // 64 good groups: their exits are true
+                    const u32 n = ng - gi < 64u ? ng - gi : 64u;
+                    const u32 lo = __shfl((u32)ex, (int)n - 1), hi = __shfl((u32)(ex >> 32), (int)n - 1);
+                    prev_exit = ((u64)hi << 32) | lo;
+                    gi += n;
+                    continue;
+                }
+                const int j = __ffsll((unsigned long long)bal) - 1;
+                if (j > 0) {                                  // groups before j are good
+                    const u32 lo = __shfl((u32)ex, j - 1), hi = __shfl((u32)(ex >> 32), j - 1);
+                    prev_exit = ((u64)hi << 32) | lo;
+                }
+                gi += (u32)j;
+                redo = gi;
+                dense = recs[gb + gi].flags & kGroupDense;
+                break;
+            }
+            if (lane == 0) { s_next[0] = redo; s_next[1] = dense; *s_entry = prev_exit; }
+        }
+        __syncthreads();
+        const u32 redo = s_next[0];
+        if (redo == 0xFFFFFFFFu) break;
+        const u32 g = gb + redo;
+        const u64 g0 = (u64)redo * kGroupBytes;
+        if (s_next[1]) {                                      // dense: the bitmaps have to be rebuilt
+            const u64 ts = g0 + (u64)wave * kGearTile;
+            if (lane == 0) fast_flags[wave] = 1u;
+            if (ts < size) {
+                const u32 tlen = (u32)((size - ts < (u64)kGearTile) ? (size - ts) : (u64)kGearTile);
+                u32 pk;
+                bool ovf;
+                u32* bm = bitmaps + wave * kBitmapWords;
+                u32* cl = cand_lists + wave * 64;
+                mark_tile(fptr, ts, tlen, bm, lane_tab, p.thresh_m1, lane, pk, ovf);
+                bool fast = cand_compact(pk, ovf, (u32)lane * kLaneRun, lane, cl);
+                if (!fast) {
+                    __builtin_amdgcn_wave_barrier();
+                    fast = list_from_bitmap(bm, lane, cl);
+                }
+                if (lane == 0) fast_flags[wave] = fast ? 1u : 0u;
+            }
+        } else {
+            cand_lists[wave * 64 + lane] = tile_lists[((u64)g * kWavesPerWG + wave) * 64 + lane];
+            if (lane == 0) fast_flags[wave] = 1u;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            u32 fast_mask = 0;
+            for (int t = 0; t < kWavesPerWG; ++t) fast_mask |= (fast_flags[t] ? 1u : 0u) << t;
+            const u64 s = file_seg0[f] + redo;
+            u32* spec = ends32 + seg_slot[s];
+            GroupRec* rec = recs + g;
+            const u64 entry = *s_entry;
+            prev_exit = reselect_group(cand_lists, bitmaps, fast_mask, g0, size, entry, spec, rec->spec_n,
+                                       rec->spec_exit, spec + region, p, lane, rec, seg_n + s);
+            gi = redo + 1;
+        }
+        __syncthreads();
+    }
+}
+
+u64 gear_large_groups(u64 size) { return (size + kGroupBytes - 1) / kGroupBytes; }
+u64 gear_group_region(u32 min_size) { return kGroupBytes / min_size + 2; }
+size_t gear_group_rec_bytes() { return sizeof(GroupRec); }
+
+void launch_gear_cdc(const GearLaunch& a, CdcParams p, int n_cu, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)gear_cdc_small_kernel,
                               hipFuncAttributeMaxDynamicSharedMemorySize, kGearLdsBytes);
-    (void)hipFuncSetAttribute((const void*)gear_cdc_large_kernel,
+    (void)hipFuncSetAttribute((const void*)gear_group_mark_kernel,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kGearLdsBytes);
+    (void)hipFuncSetAttribute((const void*)gear_file_fix_kernel,
                               hipFuncAttributeMaxDynamicSharedMemorySize, kGearLdsBytes + 16);
-    if (n_small)
-        hipLaunchKernelGGL(gear_cdc_small_kernel, dim3((n_small + kWavesPerWG - 1) / kWavesPerWG),
-                           dim3(kGearWG), kGearLdsBytes, s, d_data, d_file_off, d_file_size,
-                           d_slot_base, d_slot_ends, d_n_chunks, d_small_list, n_small,
-                           d_gear_table, p);
-    if (n_groups) {
-        (void)hipMemsetAsync(d_ticket, 0, 2 * sizeof(u32), s);   // [0] ticket counter, [1] chain error
-        (void)hipMemsetAsync(d_tokens, 0, sizeof(GroupToken) * (size_t)n_groups, s);
+    if (a.n_small)
+        hipLaunchKernelGGL(gear_cdc_small_kernel, dim3((a.n_small + kWavesPerWG - 1) / kWavesPerWG),
+                           dim3(kGearWG), kGearLdsBytes, s, a.data, a.file_off, a.file_size, a.seg_file,
+                           a.seg_slot, a.ends32, a.seg_n, a.small_list, a.n_small, a.gear_table, p);
+    if (a.n_groups) {
+        const u32 region = (u32)gear_group_region(p.min_size);
         u32 grid = (u32)n_cu * 3;                         // 3 workgroups per CU fit (LDS, VGPRs)
-        if (grid > n_groups) grid = n_groups;
-        hipLaunchKernelGGL(gear_cdc_large_kernel, dim3(grid), dim3(kGearWG), kGearLdsBytes + 16, s,
-                           d_data, d_file_off, d_file_size, d_slot_base, d_slot_ends, d_n_chunks,
-                           d_group_file, d_group_index, d_group_prev, n_groups, d_ticket,
-                           (GroupToken*)d_tokens, d_gear_table, p);
+        if (grid > a.n_groups) grid = a.n_groups;
+        GroupRec* recs = (GroupRec*)a.group_recs;
+        hipLaunchKernelGGL(gear_group_mark_kernel, dim3(grid), dim3(kGearWG), kGearLdsBytes, s, a.data,
+                           a.file_off, a.file_size, a.file_seg0, a.seg_slot, a.ends32, a.seg_n,
+                           a.group_file, a.group_index, a.n_groups, recs, a.tile_lists, a.gear_table, p);
+        if (a.n_groups > a.n_large) {                     // some file has more than one group
+            hipLaunchKernelGGL(gear_group_validate_kernel, dim3((a.n_groups + kWavesPerWG - 1) / kWavesPerWG),
+                               dim3(kGearWG), 0, s, a.file_size, a.file_seg0, a.seg_slot, a.ends32, a.seg_n,
+                               a.group_file, a.group_index, a.n_groups, recs, a.tile_lists, region, p);
+            hipLaunchKernelGGL(gear_file_fix_kernel, dim3(a.n_large), dim3(kGearWG), kGearLdsBytes + 16, s,
+                               a.data, a.file_off, a.file_size, a.file_seg0, a.seg_slot, a.ends32, a.seg_n,
+                               a.large_list, a.large_group0, recs, a.tile_lists, region, a.gear_table, p);
+        }
     }
 }
 

@@ -2,8 +2,9 @@
 //
 // Data layout in HBM (DESIGN.md "HBM layout"):
 //   arena      : all file bytes of a batch, every file on a 256-byte boundary
-//   file table : file_off[], file_size[], slot_base[]            (u64 SoA)
-//   slots      : chunk END offsets per file, slot_base[f] .. +size/min+2  (u64)
+//   file table : file_off[], file_size[], file_seg0[]            (u64 SoA)
+//   segments   : a small file or one 256 KiB group of a large file; ends32[seg_slot[s] ..] = its
+//                chunk END offsets (u32, relative to the segment start), seg_n[s] their count
 //   chunk table: chunk_off[] (arena offset), chunk_len[], chunk_start[] (u64),
 //                chunk_file[] (u32), digests[] (32 B)
 //   SHA queue  : q_off[], q_len[] (u64), q_id[] (u32): chunk descriptors, longest first
@@ -192,11 +193,13 @@ int submit_pipeline(mi_batch* b) {
     while (dd_cap < 2 * cap) dd_cap <<= 1;
     const bool dedup = !(c->cfg.flags & MI_FLAG_NO_DEDUP);
 
-    HIPCHK(c, b->slot_ends.ensure(cap * 8));
+    HIPCHK(c, b->ends32.ensure(b->ends_total * 4 + 16));
+    HIPCHK(c, b->seg_n.ensure(b->n_segs * 4 + 16));
+    HIPCHK(c, b->seg_first.ensure(b->n_segs * 8 + 16));
     HIPCHK(c, b->n_chunks_d.ensure(nf * 4));
     HIPCHK(c, b->first.ensure(nf * 8));
     HIPCHK(c, b->total_d.ensure(8));
-    HIPCHK(c, b->scratch.ensure(scan_scratch_elems(nf) * 8));
+    HIPCHK(c, b->scratch.ensure(scan_scratch_elems(b->n_segs > nf ? b->n_segs : nf) * 8));
     HIPCHK(c, b->chunk_off.ensure(cap * 8));
     HIPCHK(c, b->chunk_len.ensure(cap * 8));
     HIPCHK(c, b->chunk_start.ensure(cap * 8));
@@ -227,24 +230,44 @@ int submit_pipeline(mi_batch* b) {
     const int ncu = c->prop.multiProcessorCount;
 
     HIPCHK(c, hipEventRecord(b->ev[0], s));
+    const u32 region = (u32)gear_group_region(c->cfg.min_size);
     if (b->n_groups) {
-        HIPCHK(c, b->group_ticket.ensure(16));
-        HIPCHK(c, b->group_tokens.ensure(16ull * b->n_groups));
+        HIPCHK(c, b->group_recs.ensure(gear_group_rec_bytes() * (size_t)b->n_groups));
+        HIPCHK(c, b->tile_lists.ensure(1024ull * b->n_groups));
     }
-    launch_gear_cdc(b->arena.as<u8>(), d_off, d_size, b->slot_base.as<u64>(),
-                    b->slot_ends.as<u64>(), b->n_chunks_d.as<u32>(), b->small_list.as<u32>(),
-                    b->n_small, b->group_file.as<u32>(), b->group_index.as<u32>(),
-                    b->group_prev.as<u32>(), b->n_groups,
-                    b->group_ticket.as<u32>(), b->group_tokens.p, c->gear_table.as<u64>(),
-                    c->cdc, ncu, s);
-    launch_scan_counts(b->n_chunks_d.as<u32>(), b->first.as<u64>(), b->total_d.as<u64>(), nf,
+    {
+        GearLaunch g;
+        g.data = b->arena.as<u8>();
+        g.file_off = d_off;
+        g.file_size = d_size;
+        g.file_seg0 = b->file_seg0.as<u64>();
+        g.seg_file = b->seg_file.as<u32>();
+        g.seg_slot = b->seg_slot.as<u64>();
+        g.ends32 = b->ends32.as<u32>();
+        g.seg_n = b->seg_n.as<u32>();
+        g.small_list = b->small_list.as<u32>();
+        g.n_small = b->n_small;
+        g.group_file = b->group_file.as<u32>();
+        g.group_index = b->group_index.as<u32>();
+        g.n_groups = b->n_groups;
+        g.large_list = b->large_list.as<u32>();
+        g.large_group0 = b->large_group0.as<u32>();
+        g.n_large = b->n_large;
+        g.group_recs = b->group_recs.p;
+        g.tile_lists = b->tile_lists.as<u32>();
+        g.gear_table = c->gear_table.as<u64>();
+        launch_gear_cdc(g, c->cdc, ncu, s);
+    }
+    launch_scan_counts(b->seg_n.as<u32>(), b->seg_first.as<u64>(), b->total_d.as<u64>(), b->n_segs,
                        b->scratch.as<u64>(), s);
     HIPCHK(c, hipMemcpyAsync(&b->h_counts[0], b->total_d.p, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipEventRecord(b->ev[1], s));
-    launch_compact_chunks(d_off, b->slot_base.as<u64>(), b->slot_ends.as<u64>(),
-                          b->n_chunks_d.as<u32>(), b->first.as<u64>(), nf, cap, d_n, b->chunk_off.as<u64>(),
-                          b->chunk_len.as<u64>(), b->chunk_file.as<u32>(),
-                          b->chunk_start.as<u64>(), b->hist.as<u32>(), n_bins, bin_shift, s);
+    launch_compact_chunks(d_off, b->file_seg0.as<u64>(), b->seg_file.as<u32>(), b->seg_slot.as<u64>(),
+                          b->ends32.as<u32>(), b->seg_first.as<u64>(),
+                          b->n_groups ? b->seg_group.as<u32>() : nullptr, b->group_recs.p, region, nf,
+                          b->n_segs, cap, d_n, b->chunk_off.as<u64>(), b->chunk_len.as<u64>(),
+                          b->chunk_file.as<u32>(), b->chunk_start.as<u64>(), b->first.as<u64>(),
+                          b->n_chunks_d.as<u32>(), b->hist.as<u32>(), n_bins, bin_shift, s);
     launch_bin_order(b->chunk_off.as<u64>(), b->chunk_len.as<u64>(), (u32)cap, d_n,
                      b->hist.as<u32>(), b->cursor.as<u32>(), n_bins, bin_shift,
                      b->q_off.as<u64>(), b->q_len.as<u64>(), b->q_id.as<u32>(), s);
@@ -263,19 +286,19 @@ int submit_pipeline(mi_batch* b) {
         u64 nodes_ub = cap;                              // upper bound of nodes entering a pass
         for (int r = 0; r < b->root_passes; ++r) {
             const u64 out_ub = nodes_ub / 1024 + nf;     // nodes it can produce
-            HIPCHK(c, b->seg_cnt.ensure(nf * 4));
-            HIPCHK(c, b->seg_first.ensure(nf * 8));
-            HIPCHK(c, b->seg_total.ensure(8));
+            HIPCHK(c, b->rseg_cnt.ensure(nf * 4));
+            HIPCHK(c, b->rseg_first.ensure(nf * 8));
+            HIPCHK(c, b->rseg_total.ensure(8));
             HIPCHK(c, b->root_items_off.ensure(out_ub * 8));
             HIPCHK(c, b->root_items_len.ensure(out_ub * 8));
             HIPCHK(c, b->root_level[r].ensure(out_ub * 32));
-            launch_root_level(nf, b->root_addr.as<u64>(), b->root_cnt.as<u32>(), b->seg_cnt.as<u32>(),
-                              b->seg_first.as<u64>(), b->seg_total.as<u64>(), b->scratch.as<u64>(),
+            launch_root_level(nf, b->root_addr.as<u64>(), b->root_cnt.as<u32>(), b->rseg_cnt.as<u32>(),
+                              b->rseg_first.as<u64>(), b->rseg_total.as<u64>(), b->scratch.as<u64>(),
                               b->root_level[r].as<u8>(), b->root_items_off.as<u64>(),
                               b->root_items_len.as<u64>(), s);
             launch_sha256_items(kShaRoots, nullptr, b->root_items_off.as<u64>(),
                                 b->root_items_len.as<u64>(), nullptr, (u32)out_ub,
-                                b->seg_total.as<u64>(), b->heads_files.as<u32>(),
+                                b->rseg_total.as<u64>(), b->heads_files.as<u32>(),
                                 b->root_level[r].as<u8>(), c->sha_blocks_per_cu, ncu, s);
             nodes_ub = out_ub;
         }
@@ -316,11 +339,6 @@ int wait_pipeline(mi_batch* b) {
     b->in_flight = false;
     HIPCHK(c, hipStreamSynchronize(b->stream));
     HIPCHK(c, hipGetLastError());
-    if (b->n_groups) {
-        u32 chain_err = 0;
-        HIPCHK(c, hipMemcpy(&chain_err, b->group_ticket.as<u32>() + 1, 4, hipMemcpyDeviceToHost));
-        if (chain_err) return fail(c, MI_ERR_HIP, "large-file cut chain timed out (internal error)");
-    }
     const u64 total = b->h_counts[0];
     if (total > b->total_slots)
         return fail(c, MI_ERR_HIP, "chunk count %llu exceeds its bound %llu",
@@ -682,64 +700,70 @@ static int stage_batch(mi_batch* b) {
     if (b->staged_any)          // host->device staging time: ring memcpy/pread + waits + final drain
         b->ms_h2d += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     const u64 nf = b->files.size();
-    std::vector<u64> off(nf), size(nf), slot(nf);
-    std::vector<u32> small, gfile, gindex, gprev, large;
-    u64 slots = 0, max_groups = 0, n_groups = 0;
+    // Segment tables (gear_cdc.hip): files in add order, a large file's 256 KiB groups in place.
+    std::vector<u64> off(nf), size(nf), seg0(nf + 1), seg_slot;
+    std::vector<u32> small, seg_file, seg_group, gfile, gindex, large, large_g0;
+    const u64 region = gear_group_region(c->cfg.min_size);
+    u64 cap_chunks = 0, ends_total = 0, mx = 0;
+    bool any_group = false;
+    for (u64 f = 0; f < nf; ++f)
+        if (b->files[f].size > (u64)kGearTile) { any_group = true; break; }
+    seg_file.reserve(nf);
+    seg_slot.reserve(nf);
     for (u64 f = 0; f < nf; ++f) {
         off[f] = b->files[f].off;
         size[f] = b->files[f].size;
-        slot[f] = slots;
-        slots += size[f] / c->cfg.min_size + 2;
+        mx = size[f] > mx ? size[f] : mx;
+        seg0[f] = seg_file.size();
+        cap_chunks += size[f] / c->cfg.min_size + 2;          // upper bound of the file's chunk count
         if (size[f] <= (u64)kGearTile) {
-            small.push_back((u32)f);
+            small.push_back((u32)seg_file.size());
+            seg_file.push_back((u32)f);
+            seg_slot.push_back(ends_total);
+            if (any_group) seg_group.push_back(0xFFFFFFFFu);
+            ends_total += size[f] / c->cfg.min_size + 2;
         } else {
-            large.push_back((u32)f);
             const u64 ng = gear_large_groups(size[f]);
-            n_groups += ng;
-            if (ng > max_groups) max_groups = ng;
-        }
-    }
-    if (n_groups >= 0xFFFFFFFFull)
-        return fail(c, MI_ERR_INVALID, "batch too large: more than 2^32 tile groups");
-    // Ticket order of the chained groups: round-robin over the large files (group 0 of every
-    // file, then group 1, ...), so the cut-state chains of different files advance in parallel
-    // and a group's predecessor is usually long done when its turn comes; inside a file the
-    // order is increasing, which is what makes the chain deadlock-free.
-    gfile.reserve(n_groups);
-    gindex.reserve(n_groups);
-    gprev.reserve(n_groups);
-    {
-        std::vector<u32> live = large, last_ticket(nf, 0xFFFFFFFFu);
-        for (u64 gi = 0; gi < max_groups && !live.empty(); ++gi) {
-            size_t keep = 0;
-            for (u32 f : live) {
-                gprev.push_back(last_ticket[f]);          // ticket of the file's previous group
-                last_ticket[f] = (u32)gfile.size();
-                gfile.push_back(f);
+            if (gfile.size() + ng >= 0xFFFFFFFFull || seg_file.size() + ng >= 0xFFFFFFFFull)
+                return fail(c, MI_ERR_INVALID, "batch too large: more than 2^32 tile groups");
+            large.push_back((u32)f);
+            large_g0.push_back((u32)gfile.size());
+            for (u64 gi = 0; gi < ng; ++gi) {
+                seg_group.push_back((u32)gfile.size());
+                gfile.push_back((u32)f);
                 gindex.push_back((u32)gi);
-                if (gi + 1 < gear_large_groups(size[f])) live[keep++] = f;
+                seg_file.push_back((u32)f);
+                seg_slot.push_back(ends_total);
+                ends_total += 2 * region;                     // speculative list + prefix
             }
-            live.resize(keep);
         }
     }
+    seg0[nf] = seg_file.size();
+    if (seg_file.size() >= 0xFFFFFFFFull)
+        return fail(c, MI_ERR_INVALID, "batch too large: more than 2^32 segments");
     {
-        u64 mx = 0;
-        for (u64 f = 0; f < nf; ++f) mx = size[f] > mx ? size[f] : mx;
         u64 nodes = mx / c->cfg.min_size + 2;              // upper bound of a file's chunk count
         b->root_passes = 0;
         while (nodes > 1024) { nodes = (nodes + 1023) / 1024; ++b->root_passes; }
         if (b->root_passes > 3) return fail(c, MI_ERR_INVALID, "file too large for the root tree");
     }
-    b->total_slots = slots;
+    b->total_slots = cap_chunks;
+    b->ends_total = ends_total;
+    b->n_segs = seg_file.size();
     b->n_small = (u32)small.size();
     b->n_groups = (u32)gfile.size();
+    b->n_large = (u32)large.size();
     if ((rc = upload(c, b->small_list, small))) return rc;
+    if ((rc = upload(c, b->seg_file, seg_file))) return rc;
+    if ((rc = upload(c, b->seg_slot, seg_slot))) return rc;
+    if ((rc = upload(c, b->seg_group, seg_group))) return rc;
+    if ((rc = upload(c, b->file_seg0, seg0))) return rc;
     if ((rc = upload(c, b->group_file, gfile))) return rc;
     if ((rc = upload(c, b->group_index, gindex))) return rc;
-    if ((rc = upload(c, b->group_prev, gprev))) return rc;
+    if ((rc = upload(c, b->large_list, large))) return rc;
+    if ((rc = upload(c, b->large_group0, large_g0))) return rc;
     if ((rc = upload(c, b->file_off, off))) return rc;
     if ((rc = upload(c, b->file_size, size))) return rc;
-    if ((rc = upload(c, b->slot_base, slot))) return rc;
     std::vector<u32> tile_file;
     std::vector<u64> first_tile;
     if (c->cfg.flags & MI_FLAG_FILE_CRC32) {
@@ -877,11 +901,13 @@ int mi_batch_free(mi_batch* b) {
     if (b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
     for (auto e : b->ev) if (e) (void)hipEventDestroy(e);
     if (b->h_counts) (void)hipHostFree(b->h_counts);
-    DevBuf* bufs[] = {&b->root_addr, &b->root_cnt, &b->seg_cnt, &b->seg_first, &b->seg_total,
+    DevBuf* bufs[] = {&b->root_addr, &b->root_cnt, &b->rseg_cnt, &b->rseg_first, &b->rseg_total,
                       &b->root_items_off, &b->root_items_len, &b->root_level[0], &b->root_level[1],
-                      &b->root_level[2], &b->group_file, &b->group_index, &b->group_prev, &b->group_ticket, &b->group_tokens, &b->tile_file, &b->first_tile, &b->tile_raw, &b->crc_d, &b->heads_chunks, &b->heads_files, &b->dd_rep, &b->dd_minid, &b->dd_slot,
-                      &b->dd_nuniq, &b->q_off, &b->q_len, &b->q_id,&b->arena, &b->small_list, &b->file_off, &b->file_size, &b->slot_base, &b->cids,
-                      &b->slot_ends, &b->n_chunks_d, &b->first, &b->total_d, &b->scratch,
+                      &b->root_level[2], &b->group_file, &b->group_index, &b->group_recs, &b->tile_lists, &b->large_list,
+                      &b->large_group0, &b->seg_file, &b->seg_slot, &b->seg_n, &b->seg_first, &b->seg_group,
+                      &b->file_seg0, &b->ends32, &b->tile_file, &b->first_tile, &b->tile_raw, &b->crc_d, &b->heads_chunks, &b->heads_files, &b->dd_rep, &b->dd_minid, &b->dd_slot,
+                      &b->dd_nuniq, &b->q_off, &b->q_len, &b->q_id,&b->arena, &b->small_list, &b->file_off, &b->file_size, &b->cids,
+                      &b->n_chunks_d, &b->first, &b->total_d, &b->scratch,
                       &b->chunk_off, &b->chunk_len, &b->chunk_file, &b->chunk_start, &b->hist,
                       &b->cursor, &b->digests, &b->item_off, &b->item_len, &b->roots,
                       &b->file_sha, &b->dup_of};

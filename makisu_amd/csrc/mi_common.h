@@ -43,19 +43,46 @@ __host__ __device__ inline u64 splitmix64_mix(u64 z) {
 constexpr u64 kSmGamma = 0x9E3779B97F4A7C15ULL;
 
 // ---- kernel launchers (each defined next to its kernels) ----------------------
-// gear_cdc.hip
-// small_list: indices of files of <= kGearTile bytes (one wave each).  Larger files are
-// cut into groups of gear_large_groups(size) x 256 KiB, listed file-major in
-// group_file[]/group_index[]/group_prev[] (file index, group index inside the file, ticket of
-// the file's previous group); d_ticket (2 x u32: counter, chain-error flag) and d_tokens
-// (16 B per group) are scratch the launcher zeroes.
-u64  gear_large_groups(u64 size);
-void launch_gear_cdc(const u8* d_data, const u64* d_file_off, const u64* d_file_size,
-                     const u64* d_slot_base, u64* d_slot_ends, u32* d_n_chunks,
-                     const u32* d_small_list, u32 n_small, const u32* d_group_file,
-                     const u32* d_group_index, const u32* d_group_prev, u32 n_groups,
-                     u32* d_ticket, void* d_tokens, const u64* d_gear_table, CdcParams p, int n_cu,
-                     hipStream_t s);
+// gear_cdc.hip.  The unit the CDC pass writes is a SEGMENT: a file of <= kGearTile bytes, or one
+// 256 KiB group of a larger file (segments are numbered in file order, a large file's groups in
+// place: group gi of file f is segment file_seg0[f] + gi).  A segment's chunk ends are u32
+// offsets relative to the segment start at ends32[seg_slot[s] ..]; seg_n[s] = its chunk count.
+// A group segment owns 2 x gear_group_region(min_size) entries (speculative list, prefix) and a
+// GroupRec; see gear_cdc.hip "large files".
+struct GearLaunch {
+    const u8*  data;
+    const u64* file_off;
+    const u64* file_size;
+    const u64* file_seg0;      // first segment of every file (n_files + 1 entries)
+    const u32* seg_file;
+    const u64* seg_slot;
+    u32*       ends32;
+    u32*       seg_n;
+    const u32* small_list;     // segments that are small files
+    u32        n_small;
+    const u32* group_file;     // per group: file, index inside the file
+    const u32* group_index;
+    u32        n_groups;
+    const u32* large_list;     // per large file: file index, its first group
+    const u32* large_group0;
+    u32        n_large;
+    void*      group_recs;     // n_groups x gear_group_rec_bytes()
+    u32*       tile_lists;     // n_groups x 4 tiles x 64 candidates
+    const u64* gear_table;
+};
+struct GroupRec {
+    u64 spec_exit;      // E_g: last cut of the speculative selection (a cut assumed at the group start)
+    u64 final_exit;     // last cut of the final list, i.e. under `entry`
+    u64 entry;          // the previous cut the group's final list starts from
+    u32 spec_n, pcnt, sidx, flags;   // final list = prefix[0, pcnt) ++ spec[sidx, spec_n)
+};
+constexpr u32 kGroupDense = 1u;      // some tile has more than 64 candidates: no list
+constexpr u32 kGroupValid = 2u;      // pcnt / sidx / final_exit are set for `entry`
+constexpr u64 kGroupBytes = (u64)kGearTile * (kGearWG / 64);
+u64    gear_large_groups(u64 size);
+u64    gear_group_region(u32 min_size);
+size_t gear_group_rec_bytes();
+void   launch_gear_cdc(const GearLaunch& a, CdcParams p, int n_cu, hipStream_t s);
 
 // sha256.hip : n independent byte strings -> n digests.  Queue position p holds the string
 // base[off[p] .. +len[p]) whose digest goes to out[32 * (ids ? ids[p] : p)]; positions are
@@ -73,11 +100,15 @@ void launch_synth_fill(u8* d_data, const u64* d_file_off, const u64* d_file_size
 void launch_scan_counts(const u32* d_counts, u64* d_first, u64* d_total, u64 n,
                         u64* d_scratch, hipStream_t s);
 u64  scan_scratch_elems(u64 n);
-void launch_compact_chunks(const u64* d_file_off, const u64* d_slot_base, const u64* d_slot_ends,
-                           const u32* d_n_chunks, const u64* d_first, u64 n_files, u64 n_max,
-                           const u64* d_n, u64* d_chunk_off, u64* d_chunk_len, u32* d_chunk_file,
-                           u64* d_chunk_start, u32* d_hist, u32 n_bins, u32 bin_shift,
-                           hipStream_t s);
+// chunk rows from the segments' end lists (scan of seg_n in d_seg_first, total in d_n); also the
+// per-file first row / row count.  d_seg_group (segment -> group index, ~0u for small files),
+// d_group_recs and region are only read when the batch has groups (d_seg_group != nullptr).
+void launch_compact_chunks(const u64* d_file_off, const u64* d_file_seg0, const u32* d_seg_file,
+                           const u64* d_seg_slot, const u32* d_ends32, const u64* d_seg_first,
+                           const u32* d_seg_group, const void* d_group_recs, u32 region,
+                           u64 n_files, u64 n_segs, u64 n_max, const u64* d_n, u64* d_chunk_off,
+                           u64* d_chunk_len, u32* d_chunk_file, u64* d_chunk_start, u64* d_first,
+                           u32* d_n_chunks, u32* d_hist, u32 n_bins, u32 bin_shift, hipStream_t s);
 // queue descriptors in processing order (longest first): s_off/s_len/s_id[pos]
 void launch_bin_order(const u64* d_off, const u64* d_len, u32 n, const u64* d_n, u32* d_hist,
                       u32* d_cursor, u32 n_bins, u32 bin_shift, u64* d_s_off, u64* d_s_len,

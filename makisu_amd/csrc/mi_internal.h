@@ -77,14 +77,17 @@ struct mi_batch {
     bool staged = false, in_flight = false, ran = false, results_valid = false;
     mi::u64 n_chunks = 0, total_slots = 0;
     mi_stats stats;
-    mi::DevBuf small_list;                   // indices of files <= one tile (wave per file)
-    mi::DevBuf group_file, group_index, group_prev, group_ticket, group_tokens;   // chained groups of large files
-    mi::u32 n_small = 0, n_groups = 0;
-    mi::DevBuf file_off, file_size, slot_base, cids, slot_ends, n_chunks_d, first, total_d, scratch;
+    // CDC segments (gear_cdc.hip): a small file or one 256 KiB group of a large file
+    mi::DevBuf small_list;                   // segments that are files <= one tile (wave per file)
+    mi::DevBuf seg_file, seg_slot, seg_n, seg_first, seg_group, file_seg0, ends32;
+    mi::DevBuf group_file, group_index, group_recs, tile_lists, large_list, large_group0;
+    mi::u32 n_small = 0, n_groups = 0, n_large = 0;
+    mi::u64 n_segs = 0, ends_total = 0;
+    mi::DevBuf file_off, file_size, cids, n_chunks_d, first, total_d, scratch;
     mi::DevBuf chunk_off, chunk_len, chunk_file, chunk_start, hist, cursor, digests;
     mi::DevBuf q_off, q_len, q_id;           // SHA queue descriptors, longest chunk first
     mi::DevBuf item_off, item_len, roots, file_sha, dup_of;
-    mi::DevBuf root_addr, root_cnt, seg_cnt, seg_first, seg_total, root_items_off, root_items_len;
+    mi::DevBuf root_addr, root_cnt, rseg_cnt, rseg_first, rseg_total, root_items_off, root_items_len;
     mi::DevBuf root_level[3];            // node digests of the reduction passes
     int root_passes = 0;                 // reduction passes this batch can need (from max file size)
     mi::u64 max_file_size = 0;

@@ -144,36 +144,57 @@ __device__ __forceinline__ u32 bin_of(u64 len, u32 n_bins, u32 bin_shift) {
 }
 
 constexpr int kMaxBins = 1024;          // LDS-private histogram size (bins are block counts >> shift)
-// One thread per chunk row: row g belongs to the file f with first[f] <= g < first[f+1]
+// End offset (file-relative) of chunk k of segment s.  Small-file segments hold one list; a group
+// segment's final list is prefix[0, pcnt) ++ spec[sidx, spec_n) (gear_cdc.hip "large files").
+__device__ __forceinline__ u64 seg_chunk_end(const u32* __restrict__ ends, u64 k, u64 seg_start,
+                                             const GroupRec* r, u32 region) {
+    if (!r) return ends[k];
+    const u32 rel = k < r->pcnt ? ends[region + k] : ends[r->sidx + (k - r->pcnt)];
+    return seg_start + rel;
+}
+
+// One thread per chunk row: row g belongs to the segment s with seg_first[s] <= g < seg_first[s+1]
 // (binary search over the scanned counts -- a handful of L2-resident probes), so a batch of
 // four 4 GiB files is compacted as fast as one of 100 000 small ones.  Length bins are counted
 // in LDS and flushed once per workgroup (no hot global atomics).
 __global__ __launch_bounds__(256)
-void compact_chunks_kernel(const u64* __restrict__ file_off, const u64* __restrict__ slot_base,
-                           const u64* __restrict__ slot_ends, const u32* __restrict__ /*n_chunks*/,
-                           const u64* __restrict__ first, u64 n_files, u64 n_max,
-                           const u64* __restrict__ n_ptr, u64* __restrict__ chunk_off,
-                           u64* __restrict__ chunk_len, u32* __restrict__ chunk_file,
-                           u64* __restrict__ chunk_start, u32* __restrict__ hist, u32 n_bins,
-                           u32 bin_shift) {
+void compact_chunks_kernel(const u64* __restrict__ file_off, const u64* __restrict__ file_seg0,
+                           const u32* __restrict__ seg_file, const u64* __restrict__ seg_slot,
+                           const u32* __restrict__ ends32, const u64* __restrict__ seg_first,
+                           const u32* __restrict__ seg_group, const GroupRec* __restrict__ recs,
+                           u32 region, u64 n_segs, u64 n_max, const u64* __restrict__ n_ptr,
+                           u64* __restrict__ chunk_off, u64* __restrict__ chunk_len,
+                           u32* __restrict__ chunk_file, u64* __restrict__ chunk_start,
+                           u32* __restrict__ hist, u32 n_bins, u32 bin_shift) {
     __shared__ u32 lh[kMaxBins];
     for (u32 i = threadIdx.x; i < n_bins; i += blockDim.x) lh[i] = 0;
     __syncthreads();
     const u64 n = n_ptr ? *n_ptr : n_max;
     for (u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (u64)gridDim.x * blockDim.x) {
-        u64 lo = 0, hi = n_files;                            // last f with first[f] <= g
+        u64 lo = 0, hi = n_segs;                             // last s with seg_first[s] <= g
         while (hi - lo > 1) {
             const u64 mid = (lo + hi) >> 1;
-            if (first[mid] <= g) lo = mid; else hi = mid;
+            if (seg_first[mid] <= g) lo = mid; else hi = mid;
         }
-        const u64 f = lo;                                    // (empty files never win: the search
-        const u64 k = g - first[f];                          //  keeps the LAST index with first <= g)
-        const u64* ends = slot_ends + slot_base[f];
-        const u64 start = k ? ends[k - 1] : 0;
-        const u64 len = ends[k] - start;
+        const u64 s = lo;                                    // (empty segments never win: the search
+        const u64 k = g - seg_first[s];                      //  keeps the LAST index with first <= g)
+        const u32 f = seg_file[s];
+        const u32* ends = ends32 + seg_slot[s];
+        const GroupRec* r = nullptr;
+        u64 seg_start = 0, entry = 0;
+        if (seg_group) {
+            const u32 gr = seg_group[s];
+            if (gr != 0xFFFFFFFFu) {
+                r = recs + gr;
+                seg_start = (s - file_seg0[f]) * kGroupBytes;
+                entry = r->entry;
+            }
+        }
+        const u64 start = k ? seg_chunk_end(ends, k - 1, seg_start, r, region) : entry;
+        const u64 len = seg_chunk_end(ends, k, seg_start, r, region) - start;
         chunk_off[g] = file_off[f] + start;
         chunk_len[g] = len;
-        chunk_file[g] = (u32)f;
+        chunk_file[g] = f;
         chunk_start[g] = start;
         atomicAdd(&lh[bin_of(len, n_bins, bin_shift)], 1u);
     }
@@ -182,17 +203,35 @@ void compact_chunks_kernel(const u64* __restrict__ file_off, const u64* __restri
         if (lh[i]) atomicAdd(&hist[i], lh[i]);
 }
 
-void launch_compact_chunks(const u64* d_file_off, const u64* d_slot_base, const u64* d_slot_ends,
-                           const u32* d_n_chunks, const u64* d_first, u64 n_files, u64 n_max,
-                           const u64* d_n, u64* d_chunk_off, u64* d_chunk_len, u32* d_chunk_file,
-                           u64* d_chunk_start, u32* d_hist, u32 n_bins, u32 bin_shift,
-                           hipStream_t s) {
+// first chunk row / row count of every file, from the scanned segment counts
+__global__ __launch_bounds__(256)
+void file_rows_kernel(const u64* __restrict__ file_seg0, const u64* __restrict__ seg_first,
+                      u64 n_files, u64 n_segs, const u64* __restrict__ total,
+                      u64* __restrict__ first, u32* __restrict__ n_chunks) {
+    const u64 f = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_files) return;
+    const u64 s0 = file_seg0[f], s1 = file_seg0[f + 1];
+    const u64 a = s0 < n_segs ? seg_first[s0] : *total;
+    const u64 b = s1 < n_segs ? seg_first[s1] : *total;
+    first[f] = a;
+    n_chunks[f] = (u32)(b - a);
+}
+
+void launch_compact_chunks(const u64* d_file_off, const u64* d_file_seg0, const u32* d_seg_file,
+                           const u64* d_seg_slot, const u32* d_ends32, const u64* d_seg_first,
+                           const u32* d_seg_group, const void* d_group_recs, u32 region,
+                           u64 n_files, u64 n_segs, u64 n_max, const u64* d_n, u64* d_chunk_off,
+                           u64* d_chunk_len, u32* d_chunk_file, u64* d_chunk_start, u64* d_first,
+                           u32* d_n_chunks, u32* d_hist, u32 n_bins, u32 bin_shift, hipStream_t s) {
     if (n_files == 0) return;
     (void)hipMemsetAsync(d_hist, 0, sizeof(u32) * n_bins, s);
+    hipLaunchKernelGGL(file_rows_kernel, dim3((u32)((n_files + 255) / 256)), dim3(256), 0, s, d_file_seg0,
+                       d_seg_first, n_files, n_segs, d_n, d_first, d_n_chunks);
     u64 want = (n_max + 255) / 256;
     const u32 grid = (u32)(want < 2048 ? (want ? want : 1) : 2048);
-    hipLaunchKernelGGL(compact_chunks_kernel, dim3(grid), dim3(256), 0, s, d_file_off, d_slot_base,
-                       d_slot_ends, d_n_chunks, d_first, n_files, n_max, d_n, d_chunk_off,
+    hipLaunchKernelGGL(compact_chunks_kernel, dim3(grid), dim3(256), 0, s, d_file_off, d_file_seg0,
+                       d_seg_file, d_seg_slot, d_ends32, d_seg_first, d_seg_group,
+                       (const GroupRec*)d_group_recs, region, n_segs, n_max, d_n, d_chunk_off,
                        d_chunk_len, d_chunk_file, d_chunk_start, d_hist, n_bins, bin_shift);
 }
 

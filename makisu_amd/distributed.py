@@ -15,24 +15,7 @@ import torch
 import torch.distributed as dist
 
 
-def shard_round_robin(n_files, rank, world):
-    """C4: file_index mod world."""
-    return np.arange(rank, n_files, world, dtype=np.int64)
-
-
-def shard_lpt(sizes, world):
-    """C5: greedy longest-processing-time by bytes.  Returns a list of index arrays, one
-    per rank; deterministic (ties broken by lower rank, files visited largest first,
-    stable for equal sizes)."""
-    sizes = np.asarray(sizes, dtype=np.int64)
-    order = np.argsort(-sizes, kind="stable")
-    load = np.zeros(world, dtype=np.int64)
-    out = [[] for _ in range(world)]
-    for i in order:
-        r = int(np.argmin(load))
-        out[r].append(int(i))
-        load[r] += int(sizes[i])
-    return [np.array(sorted(x), dtype=np.int64) for x in out]
+from .workloads import shard_lpt, shard_round_robin  # noqa: E402,F401  (re-exported)
 
 
 class DeviceArray:

@@ -1,0 +1,127 @@
+"""BASELINE.json's synthetic configs as (sizes, content ids, seed) lists per rank.
+
+SURVEY.md 8(d): content = counter-mode splitmix64 keyed by (seed, content id, offset / 8),
+generated ON THE DEVICE by mi_batch_add_synthetic; equal content ids = byte-identical files.
+Deterministic: every rank builds the same global list and takes its shard, so nothing has to
+be communicated to agree on the workload.  Used by bench.py and by the parity tests (which
+regenerate the same files with the oracle's generator).  Nothing here imports oracle/.
+
+  C2  100 000 x 64 KiB per GPU, distinct contents (seed S)
+  C3  1 000 x 128 MiB per GPU (seed S + 1)
+  C4  N x 1 250 000 x 64 KiB, global file index i -> rank i mod N (seed S)
+  C5  sizes 2^U(10, 30) bytes, fixed total per GPU, 90 % of the files (by count) are copies of
+      the other 10 % (seeded choice); longest-processing-time sharding by bytes (seed S + 2)
+"""
+import numpy as np
+
+SEED = 0x4D414B49
+KIB, MIB, GIB = 1 << 10, 1 << 20, 1 << 30
+
+
+def shard_round_robin(n_files, rank, world):
+    """C4: file_index mod world."""
+    return np.arange(rank, n_files, world, dtype=np.int64)
+
+
+def shard_lpt(sizes, world):
+    """C5: greedy longest-processing-time by bytes.  Returns a list of index arrays, one
+    per rank; deterministic (ties broken by lower rank, files visited largest first,
+    stable for equal sizes)."""
+    import heapq
+    sizes = np.asarray(sizes, dtype=np.int64)
+    order = np.argsort(-sizes, kind="stable")
+    heap = [(0, r) for r in range(world)]          # (load, rank): lowest load, then lowest rank
+    out = [[] for _ in range(world)]
+    for i in order:
+        load, r = heapq.heappop(heap)
+        out[r].append(int(i))
+        heapq.heappush(heap, (load + int(sizes[i]), r))
+    return [np.array(sorted(x), dtype=np.int64) for x in out]
+
+
+class Shard:
+    """One rank's share of a config: parallel arrays + what the generator knows in closed form."""
+
+    def __init__(self, name, seed, sizes, cids, global_index, n_global_files, originals=None,
+                 describe=""):
+        self.name = name
+        self.seed = int(seed)
+        self.sizes = np.ascontiguousarray(sizes, dtype=np.uint64)
+        self.cids = np.ascontiguousarray(cids, dtype=np.uint64)
+        self.global_index = np.ascontiguousarray(global_index, dtype=np.int64)
+        self.n_global_files = int(n_global_files)
+        # originals[i]: file i is the job-wide FIRST file with its content id (global file order).
+        # sum of n_chunks over the originals of all ranks = the job's unique-chunk count (contents
+        # are independent random streams: no chunk repeats across or inside distinct contents)
+        self.originals = (np.ones(len(self.sizes), dtype=bool) if originals is None
+                          else np.ascontiguousarray(originals, dtype=bool))
+        self.describe = describe
+
+    @property
+    def n_files(self):
+        return len(self.sizes)
+
+    @property
+    def n_bytes(self):
+        return int(self.sizes.sum())
+
+
+def c2(rank=0, world=1, files_per_gpu=100000, generation=0):
+    """generation: which of the in-flight batches (distinct content per batch)."""
+    n = files_per_gpu * world
+    idx = shard_round_robin(n, rank, world)
+    cids = idx + generation * n
+    return Shard("c2", SEED, np.full(len(idx), 64 * KIB), cids, idx, n,
+                 describe="C2: %d x 64 KiB synthetic files per GPU" % files_per_gpu)
+
+
+def c3(rank=0, world=1, files_per_gpu=1000, file_bytes=128 * MIB, generation=0):
+    n = files_per_gpu * world
+    idx = shard_round_robin(n, rank, world)
+    return Shard("c3", SEED + 1, np.full(len(idx), file_bytes), idx + generation * n, idx, n,
+                 describe="C3: %d x %d MiB synthetic files per GPU" % (files_per_gpu, file_bytes // MIB))
+
+
+def c4(rank=0, world=8, files_per_gpu=1250000, generation=0):
+    n = files_per_gpu * world                       # 10 M at 8 GPUs
+    idx = shard_round_robin(n, rank, world)
+    return Shard("c4", SEED, np.full(len(idx), 64 * KIB), idx + generation * n, idx, n,
+                 describe="C4: %d x 64 KiB files, file index mod %d" % (n, world))
+
+
+def c5_global(world=1, bytes_per_gpu=32 * GIB, lo_log2=10, hi_log2=30):
+    """The job-wide C5 file list: (sizes, cids, originals)."""
+    rng = np.random.default_rng(SEED + 2)
+    target = bytes_per_gpu * world
+    # the 10 % distinct contents: log-uniform sizes (Zipf-like over log2 buckets) until they hold
+    # a tenth of the bytes; then nine copies per original on average, drawn with replacement
+    sizes = []
+    acc = 0
+    while acc < target // 10:
+        s = int(2.0 ** rng.uniform(lo_log2, hi_log2))
+        sizes.append(s)
+        acc += s
+    distinct = len(sizes)
+    sizes = np.array(sizes, dtype=np.int64)
+    src = rng.integers(0, distinct, 9 * distinct)
+    all_sizes = np.concatenate([sizes, sizes[src]])
+    cids = np.concatenate([np.arange(distinct), src])
+    keep = np.cumsum(all_sizes) <= target
+    keep[:distinct] = True
+    all_sizes, cids = all_sizes[keep], cids[keep]
+    originals = np.zeros(len(cids), dtype=bool)
+    originals[:distinct] = True                     # copies come after every original
+    return all_sizes, cids, originals
+
+
+def c5(rank=0, world=1, bytes_per_gpu=32 * GIB, generation=0, lo_log2=10, hi_log2=30):
+    sizes, cids, originals = c5_global(world, bytes_per_gpu, lo_log2, hi_log2)
+    mine = shard_lpt(sizes, world)[rank]
+    n_contents = int(cids.max()) + 1
+    return Shard("c5", SEED + 2, sizes[mine], cids[mine] + generation * n_contents, mine, len(sizes),
+                 originals=originals[mine],
+                 describe="C5: sizes 2^U(%d,%d) B, %d files / %d distinct contents job-wide, LPT shards"
+                          % (lo_log2, hi_log2, len(sizes), n_contents))
+
+
+CONFIGS = {"c2": c2, "c3": c3, "c4": c4, "c5": c5}

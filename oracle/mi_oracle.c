@@ -12,6 +12,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #if defined(__x86_64__)
 #include <cpuid.h>
@@ -339,11 +340,20 @@ void mi_ref_synth_fill(uint64_t seed, uint64_t content_id, uint64_t offset, uint
                        uint8_t* out) {
     const uint64_t base = splitmix64_mix(seed + (content_id + 1) * SM_GAMMA);
     uint64_t o = offset, end = offset + len;
-    while (o < end) {
-        uint64_t w = o >> 3;
-        uint64_t v = splitmix64_mix(base + (w + 1) * SM_GAMMA);
-        unsigned b = (unsigned)(o & 7);
-        while (b < 8 && o < end) { *out++ = (uint8_t)(v >> (8 * b)); b++; o++; }
+    while (o < end && (o & 7)) {                       /* unaligned head */
+        uint64_t v = splitmix64_mix(base + ((o >> 3) + 1) * SM_GAMMA);
+        *out++ = (uint8_t)(v >> (8 * (o & 7)));
+        o++;
+    }
+    while (o + 8 <= end) {                             /* whole little-endian words */
+        uint64_t v = splitmix64_mix(base + ((o >> 3) + 1) * SM_GAMMA);
+        memcpy(out, &v, 8);                            /* x86-64: little-endian */
+        out += 8;
+        o += 8;
+    }
+    if (o < end) {
+        uint64_t v = splitmix64_mix(base + ((o >> 3) + 1) * SM_GAMMA);
+        while (o < end) { *out++ = (uint8_t)(v >> (8 * (o & 7))); o++; }
     }
 }
 
@@ -352,9 +362,11 @@ void mi_ref_synth_fill(uint64_t seed, uint64_t content_id, uint64_t offset, uint
 /* ======================================================================= */
 
 typedef struct {
-    const uint8_t* data;
+    const uint8_t* data;        /* NULL: synthetic content, generated per file by the worker */
     const uint64_t* offsets;
     const uint64_t* sizes;
+    const uint64_t* content_ids;/* synthetic mode: content id per file (NULL = file index)   */
+    uint64_t synth_seed;
     uint64_t n_files;
     const mi_ref_cdc_params* p;
     int allow_shani;
@@ -364,6 +376,8 @@ typedef struct {
     const uint64_t* slot_base;
     uint64_t table[256];
     uint64_t next;              /* atomic file cursor */
+    mi_ref_chunk* chunks;       /* gather phase */
+    uint64_t chunk_cap;
 } scan_job;
 
 /* chunk_root: SHA-256 over the concatenated chunk digests for files of up to 1024 chunks;
@@ -390,8 +404,7 @@ void mi_ref_chunk_root(const uint8_t* digests, uint64_t n, uint8_t out[32], int 
     free(owned);
 }
 
-static void scan_one(scan_job* j, uint64_t f) {
-    const uint8_t* d = j->data + j->offsets[f];
+static void scan_one(scan_job* j, uint64_t f, const uint8_t* d) {
     const uint64_t len = j->sizes[f];
     const mi_ref_cdc_params* p = j->p;
     mi_ref_file* fo = &j->files[f];
@@ -425,84 +438,262 @@ static void scan_one(scan_job* j, uint64_t f) {
 
 static void* scan_worker(void* arg) {
     scan_job* j = (scan_job*)arg;
+    uint8_t* buf = NULL;
+    uint64_t buf_cap = 0;
     for (;;) {
         uint64_t f = __atomic_fetch_add(&j->next, 1, __ATOMIC_RELAXED);
         if (f >= j->n_files) break;
-        scan_one(j, f);
+        if (j->data) {
+            scan_one(j, f, j->data + j->offsets[f]);
+        } else {                                   /* synthetic: generate, scan, forget */
+            if (j->sizes[f] > buf_cap) {
+                free(buf);
+                buf_cap = j->sizes[f] + (j->sizes[f] >> 2) + 64;
+                buf = (uint8_t*)malloc((size_t)buf_cap);
+            }
+            mi_ref_synth_fill(j->synth_seed, j->content_ids ? j->content_ids[f] : f, 0, j->sizes[f], buf);
+            scan_one(j, f, buf);
+        }
+    }
+    free(buf);
+    return NULL;
+}
+
+/* gather: files' slot regions -> the compact chunk table, one file per worker at a time */
+static void* gather_worker(void* arg) {
+    scan_job* j = (scan_job*)arg;
+    for (;;) {
+        uint64_t f0 = __atomic_fetch_add(&j->next, 256, __ATOMIC_RELAXED);
+        if (f0 >= j->n_files) break;
+        uint64_t f1 = f0 + 256 < j->n_files ? f0 + 256 : j->n_files;
+        for (uint64_t f = f0; f < f1; f++) {
+            uint64_t at = j->files[f].first_chunk, n = j->files[f].n_chunks;
+            if (at >= j->chunk_cap) continue;
+            if (at + n > j->chunk_cap) n = j->chunk_cap - at;
+            memcpy(j->chunks + at, j->slots + j->slot_base[f], (size_t)n * sizeof(mi_ref_chunk));
+        }
     }
     return NULL;
 }
 
-static int cmp_digest_idx(const void* a, const void* b, void* ctx) {
-    const uint8_t* dg = (const uint8_t*)ctx;
+static void run_threads(void* (*fn)(void*), void* arg, int n_threads) {
+    if (n_threads <= 1) { fn(arg); return; }
+    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)n_threads);
+    int started = 0;
+    for (int t = 0; t < n_threads; t++)
+        if (pthread_create(&th[started], NULL, fn, arg) == 0) started++;
+    if (started == 0) fn(arg);
+    for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+    free(th);
+}
+
+/* ---- duplicate marking ---------------------------------------------------------------- *
+ * dup_of[i] = smallest j < i with an equal digest, else -1.  Digests are uniform, so the rows
+ * are partitioned by their first 12 bits into 4096 buckets (a counting pass and a scatter pass,
+ * both over contiguous row ranges per thread); every bucket is then sorted by (digest, row) and
+ * marked independently -- the buckets are the parallel unit.                                  */
+#define DD_BUCKET_BITS 12
+#define DD_BUCKETS (1u << DD_BUCKET_BITS)
+typedef struct {
+    const uint8_t* base;        /* digest of row i at base + i * stride */
+    size_t stride;
+    uint64_t n;
+    int64_t* dup_of;            /* dup_of of row i at (uint8_t*)dup_of + i * dup_stride */
+    size_t dup_stride;
+    int n_threads;
+    uint64_t* counts;           /* n_threads x DD_BUCKETS */
+    uint64_t* bucket_start;     /* DD_BUCKETS + 1 */
+    uint64_t* idx;
+    uint64_t next;              /* atomic cursor (thread ids, then buckets) */
+    uint64_t uniq;
+} dedup_job;
+
+static inline uint32_t dd_bucket(const uint8_t* d) { return ((uint32_t)d[0] << 4) | (d[1] >> 4); }
+static inline const uint8_t* dd_row(const dedup_job* j, uint64_t i) { return j->base + i * j->stride; }
+static inline int64_t* dd_dup(const dedup_job* j, uint64_t i) {
+    return (int64_t*)((uint8_t*)j->dup_of + i * j->dup_stride);
+}
+
+static void* dd_count_worker(void* arg) {
+    dedup_job* j = (dedup_job*)arg;
+    uint64_t t = __atomic_fetch_add(&j->next, 1, __ATOMIC_RELAXED);
+    uint64_t per = (j->n + (uint64_t)j->n_threads - 1) / (uint64_t)j->n_threads;
+    uint64_t lo = t * per, hi = lo + per < j->n ? lo + per : j->n;
+    uint64_t* c = j->counts + t * DD_BUCKETS;
+    for (uint64_t i = lo; i < hi; i++) c[dd_bucket(dd_row(j, i))]++;
+    return NULL;
+}
+
+static void* dd_scatter_worker(void* arg) {
+    dedup_job* j = (dedup_job*)arg;
+    uint64_t t = __atomic_fetch_add(&j->next, 1, __ATOMIC_RELAXED);
+    uint64_t per = (j->n + (uint64_t)j->n_threads - 1) / (uint64_t)j->n_threads;
+    uint64_t lo = t * per, hi = lo + per < j->n ? lo + per : j->n;
+    uint64_t* c = j->counts + t * DD_BUCKETS;      /* now: this thread's write cursor per bucket */
+    for (uint64_t i = lo; i < hi; i++) j->idx[c[dd_bucket(dd_row(j, i))]++] = i;
+    return NULL;
+}
+
+static int dd_cmp(const void* a, const void* b, void* ctx) {
+    const dedup_job* j = (const dedup_job*)ctx;
     uint64_t ia = *(const uint64_t*)a, ib = *(const uint64_t*)b;
-    int c = memcmp(dg + 32 * ia, dg + 32 * ib, 32);
+    int c = memcmp(dd_row(j, ia), dd_row(j, ib), 32);
     if (c) return c;
     return ia < ib ? -1 : (ia > ib);
 }
 
-uint64_t mi_ref_dedup(const uint8_t* digests, uint64_t n, int64_t* dup_of) {
-    if (n == 0) return 0;
-    uint64_t* idx = (uint64_t*)malloc(n * sizeof(uint64_t));
-    for (uint64_t i = 0; i < n; i++) idx[i] = i;
-    qsort_r(idx, n, sizeof(uint64_t), cmp_digest_idx, (void*)digests);
-    uint64_t uniq = 0, head = 0;
-    for (uint64_t k = 0; k < n; k++) {
-        if (k == 0 || memcmp(digests + 32 * idx[k], digests + 32 * idx[head], 32) != 0) {
-            head = k; uniq++;
-            dup_of[idx[k]] = -1;
-        } else {
-            dup_of[idx[k]] = (int64_t)idx[head];   /* idx ascending within a group */
+static void* dd_mark_worker(void* arg) {
+    dedup_job* j = (dedup_job*)arg;
+    uint64_t uniq = 0;
+    for (;;) {
+        uint64_t b = __atomic_fetch_add(&j->next, 1, __ATOMIC_RELAXED);
+        if (b >= DD_BUCKETS) break;
+        uint64_t lo = j->bucket_start[b], hi = j->bucket_start[b + 1];
+        if (hi - lo > 1) qsort_r(j->idx + lo, (size_t)(hi - lo), sizeof(uint64_t), dd_cmp, j);
+        uint64_t head = lo;
+        for (uint64_t k = lo; k < hi; k++) {
+            if (k == lo || memcmp(dd_row(j, j->idx[k]), dd_row(j, j->idx[head]), 32) != 0) {
+                head = k; uniq++;
+                *dd_dup(j, j->idx[k]) = -1;
+            } else {
+                *dd_dup(j, j->idx[k]) = (int64_t)j->idx[head];   /* rows ascend within a group */
+            }
         }
     }
-    free(idx);
-    return uniq;
+    __atomic_fetch_add(&j->uniq, uniq, __ATOMIC_RELAXED);
+    return NULL;
+}
+
+static uint64_t dedup_strided(const uint8_t* base, size_t stride, uint64_t n, int64_t* dup_of,
+                              size_t dup_stride, int n_threads) {
+    if (n == 0) return 0;
+    if (n_threads < 1) n_threads = 1;
+    if ((uint64_t)n_threads > n) n_threads = (int)n;
+    dedup_job j;
+    memset(&j, 0, sizeof j);
+    j.base = base; j.stride = stride; j.n = n; j.dup_of = dup_of; j.dup_stride = dup_stride;
+    j.n_threads = n_threads;
+    j.counts = (uint64_t*)calloc((size_t)n_threads * DD_BUCKETS, sizeof(uint64_t));
+    j.bucket_start = (uint64_t*)malloc((DD_BUCKETS + 1) * sizeof(uint64_t));
+    j.idx = (uint64_t*)malloc((size_t)n * sizeof(uint64_t));
+    run_threads(dd_count_worker, &j, n_threads);
+    uint64_t at = 0;                              /* bucket-major, thread-minor write cursors */
+    for (uint32_t b = 0; b < DD_BUCKETS; b++) {
+        j.bucket_start[b] = at;
+        for (int t = 0; t < n_threads; t++) {
+            uint64_t c = j.counts[(size_t)t * DD_BUCKETS + b];
+            j.counts[(size_t)t * DD_BUCKETS + b] = at;
+            at += c;
+        }
+    }
+    j.bucket_start[DD_BUCKETS] = at;
+    j.next = 0;
+    run_threads(dd_scatter_worker, &j, n_threads);  /* thread t scatters its own row range in order */
+    j.next = 0;
+    run_threads(dd_mark_worker, &j, n_threads);
+    free(j.counts); free(j.bucket_start); free(j.idx);
+    return j.uniq;
+}
+
+uint64_t mi_ref_dedup(const uint8_t* digests, uint64_t n, int64_t* dup_of) {
+    return dedup_strided(digests, 32, n, dup_of, sizeof(int64_t), 1);
+}
+
+uint64_t mi_ref_dedup_mt(const uint8_t* digests, uint64_t n, int64_t* dup_of, int n_threads) {
+    return dedup_strided(digests, 32, n, dup_of, sizeof(int64_t), n_threads);
+}
+
+static double g_phase_s[3];
+static double now_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+void mi_ref_last_phase_seconds(double out[3]) { memcpy(out, g_phase_s, sizeof g_phase_s); }
+
+static uint64_t scan_batch_impl(scan_job* j, int n_threads, mi_ref_chunk* chunks, uint64_t chunk_cap,
+                                uint64_t* n_unique) {
+    const mi_ref_cdc_params* p = j->p;
+    const uint64_t n_files = j->n_files;
+    if (p->min_size < 64 || p->max_size < p->min_size) return (uint64_t)-1;
+    uint64_t* slot_base = (uint64_t*)malloc((n_files + 1) * sizeof(uint64_t));
+    uint64_t total_slots = 0;
+    for (uint64_t f = 0; f < n_files; f++) {
+        slot_base[f] = total_slots;
+        total_slots += j->sizes[f] / p->min_size + 2;
+    }
+    slot_base[n_files] = total_slots;
+    mi_ref_chunk* slots = (mi_ref_chunk*)malloc((total_slots ? total_slots : 1) * sizeof(mi_ref_chunk));
+    j->slots = slots;
+    j->slot_base = slot_base;
+    j->next = 0;
+    memset(j->files, 0, sizeof(mi_ref_file) * n_files);
+    mi_ref_gear_table(p->gear_seed, j->table);
+    double t0 = now_s();
+    run_threads(scan_worker, j, n_threads);
+    double t1 = now_s();
+    uint64_t total = 0;
+    for (uint64_t f = 0; f < n_files; f++) {
+        j->files[f].first_chunk = total;
+        total += j->files[f].n_chunks;
+    }
+    j->chunks = chunks;
+    j->chunk_cap = chunk_cap;
+    j->next = 0;
+    run_threads(gather_worker, j, n_threads);
+    free(slots);
+    free(slot_base);
+    double t2 = now_s();
+    uint64_t uniq = total;
+    if (total <= chunk_cap && total && !(j->flags & MI_REF_NO_DEDUP))
+        uniq = dedup_strided(chunks[0].sha256, sizeof(mi_ref_chunk), total, &chunks[0].dup_of,
+                             sizeof(mi_ref_chunk), n_threads);
+    double t3 = now_s();
+    g_phase_s[0] = t1 - t0; g_phase_s[1] = t2 - t1; g_phase_s[2] = t3 - t2;
+    if (n_unique) *n_unique = uniq;
+    return total;
 }
 
 uint64_t mi_ref_scan_batch(const uint8_t* data, const uint64_t* offsets, const uint64_t* sizes,
                            uint64_t n_files, const mi_ref_cdc_params* p, int allow_shani,
                            int n_threads, int flags, mi_ref_file* files,
                            mi_ref_chunk* chunks, uint64_t chunk_cap) {
-    if (p->min_size < 64 || p->max_size < p->min_size) return (uint64_t)-1;
-    uint64_t* slot_base = (uint64_t*)malloc((n_files + 1) * sizeof(uint64_t));
-    uint64_t total_slots = 0;
-    for (uint64_t f = 0; f < n_files; f++) {
-        slot_base[f] = total_slots;
-        total_slots += sizes[f] / p->min_size + 2;
+    scan_job j;
+    memset(&j, 0, sizeof j);
+    j.data = data; j.offsets = offsets; j.sizes = sizes; j.n_files = n_files; j.p = p;
+    j.allow_shani = allow_shani; j.flags = flags; j.files = files;
+    return scan_batch_impl(&j, n_threads, chunks, chunk_cap, NULL);
+}
+
+uint64_t mi_ref_scan_synthetic(uint64_t seed, const uint64_t* content_ids, const uint64_t* sizes,
+                               uint64_t n_files, const mi_ref_cdc_params* p, int allow_shani,
+                               int n_threads, int flags, mi_ref_file* files,
+                               mi_ref_chunk* chunks, uint64_t chunk_cap, uint64_t* n_unique) {
+    scan_job j;
+    memset(&j, 0, sizeof j);
+    j.data = NULL; j.content_ids = content_ids; j.synth_seed = seed; j.sizes = sizes;
+    j.n_files = n_files; j.p = p; j.allow_shani = allow_shani; j.flags = flags; j.files = files;
+    return scan_batch_impl(&j, n_threads, chunks, chunk_cap, n_unique);
+}
+
+/* Synthetic files into one host buffer, files spread over threads (bench.py's CPU sample). */
+typedef struct {
+    uint64_t seed; const uint64_t* cids; const uint64_t* sizes; const uint64_t* offsets;
+    uint64_t n; uint8_t* out; uint64_t next;
+} fill_job;
+static void* fill_worker(void* arg) {
+    fill_job* j = (fill_job*)arg;
+    for (;;) {
+        uint64_t f = __atomic_fetch_add(&j->next, 1, __ATOMIC_RELAXED);
+        if (f >= j->n) break;
+        mi_ref_synth_fill(j->seed, j->cids ? j->cids[f] : f, 0, j->sizes[f], j->out + j->offsets[f]);
     }
-    slot_base[n_files] = total_slots;
-    mi_ref_chunk* slots = (mi_ref_chunk*)malloc((total_slots ? total_slots : 1) * sizeof(mi_ref_chunk));
-    scan_job j = {data, offsets, sizes, n_files, p, allow_shani, flags, files, slots, slot_base, {0}, 0};
-    memset(files, 0, sizeof(mi_ref_file) * n_files);
-    mi_ref_gear_table(p->gear_seed, j.table);
-    if (n_threads <= 1) {
-        scan_worker(&j);
-    } else {
-        pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)n_threads);
-        for (int t = 0; t < n_threads; t++) pthread_create(&th[t], NULL, scan_worker, &j);
-        for (int t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
-        free(th);
-    }
-    uint64_t total = 0;
-    for (uint64_t f = 0; f < n_files; f++) {
-        files[f].first_chunk = total;
-        for (uint64_t k = 0; k < files[f].n_chunks; k++) {
-            if (total < chunk_cap) chunks[total] = slots[slot_base[f] + k];
-            total++;
-        }
-    }
-    free(slots);
-    free(slot_base);
-    if (total <= chunk_cap && total && !(flags & MI_REF_NO_DEDUP)) {
-        uint8_t* dg = (uint8_t*)malloc(32 * total);
-        int64_t* dup = (int64_t*)malloc(sizeof(int64_t) * total);
-        for (uint64_t i = 0; i < total; i++) memcpy(dg + 32 * i, chunks[i].sha256, 32);
-        mi_ref_dedup(dg, total, dup);
-        for (uint64_t i = 0; i < total; i++) chunks[i].dup_of = dup[i];
-        free(dg);
-        free(dup);
-    }
-    return total;
+    return NULL;
+}
+void mi_ref_synth_fill_many(uint64_t seed, const uint64_t* content_ids, const uint64_t* sizes,
+                            const uint64_t* offsets, uint64_t n_files, uint8_t* out, int n_threads) {
+    fill_job j = {seed, content_ids, sizes, offsets, n_files, out, 0};
+    run_threads(fill_worker, &j, n_threads);
 }
 
 /* ======================================================================= */

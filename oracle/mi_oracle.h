@@ -103,6 +103,10 @@ size_t mi_ref_cdc_classic(const uint8_t* data, size_t len,
 void mi_ref_synth_fill(uint64_t seed, uint64_t content_id, uint64_t offset,
                        uint64_t len, uint8_t* out);
 
+/* n files at once, file f at out + offsets[f], spread over n_threads */
+void mi_ref_synth_fill_many(uint64_t seed, const uint64_t* content_ids, const uint64_t* sizes,
+                            const uint64_t* offsets, uint64_t n_files, uint8_t* out, int n_threads);
+
 /* ---- whole-batch scan: the twin of the C-ABI mi_batch_run -------------- */
 typedef struct {
     uint64_t file_index;
@@ -133,6 +137,17 @@ uint64_t mi_ref_scan_batch(const uint8_t* data, const uint64_t* offsets,
                            int n_threads, int flags, mi_ref_file* files,
                            mi_ref_chunk* chunks, uint64_t chunk_cap);
 
+/* The same scan over SYNTHETIC files (mi_ref_synth_fill(seed, content_ids[f] or f, 0, sizes[f])):
+ * every worker generates one file at a time into its own buffer, so a full-size config never
+ * exists in host memory.  n_unique (optional) receives the number of dup_of == -1 rows. */
+uint64_t mi_ref_scan_synthetic(uint64_t seed, const uint64_t* content_ids, const uint64_t* sizes,
+                               uint64_t n_files, const mi_ref_cdc_params* p, int allow_shani,
+                               int n_threads, int flags, mi_ref_file* files,
+                               mi_ref_chunk* chunks, uint64_t chunk_cap, uint64_t* n_unique);
+/* seconds the last mi_ref_scan_* call spent in: [0] scan (Gear + SHA-256 per chunk + roots, all
+ * threads), [1] gather into the chunk table, [2] duplicate marking */
+void mi_ref_last_phase_seconds(double out[3]);
+
 /* chunk_root of n chunk digests (n x 32 bytes): SHA-256 over their concatenation when
  * n <= 1024, else a fan-out-1024 tree of SHA-256 nodes (DESIGN.md "chunk_root"). */
 void mi_ref_chunk_root(const uint8_t* digests, uint64_t n, uint8_t out[32], int allow_shani);
@@ -140,6 +155,8 @@ void mi_ref_chunk_root(const uint8_t* digests, uint64_t n, uint8_t out[32], int 
 /* Marks dup_of over an arbitrary digest list (n x 32 bytes): dup_of[i] =
  * smallest j < i with equal digest, else -1.  Returns the unique count. */
 uint64_t mi_ref_dedup(const uint8_t* digests, uint64_t n, int64_t* dup_of);
+/* the same, rows partitioned into 4096 digest-prefix buckets sorted and marked by n_threads */
+uint64_t mi_ref_dedup_mt(const uint8_t* digests, uint64_t n, int64_t* dup_of, int n_threads);
 
 /* ---- reference-shaped layer scanner (CPU baseline) ---------------------- */
 /* One running SHA-256 over a tar-framed stream of the files in the given

@@ -84,9 +84,19 @@ def lib():
             fn.restype = C.c_size_t
         L.mi_ref_synth_fill.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]
         L.mi_ref_synth_fill.restype = None
+        L.mi_ref_synth_fill_many.argtypes = [C.c_uint64, u64p, u64p, u64p, C.c_uint64, C.c_void_p, C.c_int]
+        L.mi_ref_synth_fill_many.restype = None
         L.mi_ref_scan_batch.argtypes = [C.c_void_p, u64p, u64p, C.c_uint64, C.POINTER(CdcParams),
                                         C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64]
         L.mi_ref_scan_batch.restype = C.c_uint64
+        L.mi_ref_scan_synthetic.argtypes = [C.c_uint64, u64p, u64p, C.c_uint64, C.POINTER(CdcParams),
+                                            C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                            C.c_uint64, u64p]
+        L.mi_ref_scan_synthetic.restype = C.c_uint64
+        L.mi_ref_last_phase_seconds.argtypes = [C.POINTER(C.c_double)]
+        L.mi_ref_last_phase_seconds.restype = None
+        L.mi_ref_dedup_mt.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
+        L.mi_ref_dedup_mt.restype = C.c_uint64
         L.mi_ref_chunk_root.argtypes = [C.c_void_p, C.c_uint64, u8p, C.c_int]
         L.mi_ref_chunk_root.restype = None
         L.mi_ref_dedup.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p]
@@ -178,6 +188,23 @@ def synth_fill(seed, content_id, offset, length):
     return out
 
 
+def synth_fill_many(seed, content_ids, sizes, n_threads=1):
+    """-> (data u8 array, offsets u64 array): the files back to back."""
+    szs = np.ascontiguousarray(sizes, dtype=np.uint64)
+    offs = np.zeros(szs.size, dtype=np.uint64)
+    if szs.size:
+        offs[1:] = np.cumsum(szs)[:-1]
+    out = np.empty(int(szs.sum()), dtype=np.uint8)
+    u64p = C.POINTER(C.c_uint64)
+    cp = None
+    if content_ids is not None:
+        cids = np.ascontiguousarray(content_ids, dtype=np.uint64)
+        cp = cids.ctypes.data_as(u64p)
+    lib().mi_ref_synth_fill_many(seed, cp, szs.ctypes.data_as(u64p), offs.ctypes.data_as(u64p),
+                                 szs.size, out.ctypes.data, n_threads)
+    return out, offs
+
+
 FILE_SHA256, FILE_CRC32, NO_DEDUP = 1, 2, 4
 
 
@@ -188,7 +215,7 @@ def scan_batch(data, offsets, sizes, params, allow_shani=True, n_threads=1,
     offs = np.ascontiguousarray(offsets, dtype=np.uint64)
     szs = np.ascontiguousarray(sizes, dtype=np.uint64)
     n = offs.size
-    cap = int(sum(int(s) // params.min_size + 2 for s in szs)) if n else 1
+    cap = int((szs // np.uint64(params.min_size) + np.uint64(2)).sum()) if n else 1
     files = np.zeros(max(n, 1), dtype=FILE_DTYPE)
     chunks = np.zeros(max(cap, 1), dtype=CHUNK_DTYPE)
     u64p = C.POINTER(C.c_uint64)
@@ -199,6 +226,44 @@ def scan_batch(data, offsets, sizes, params, allow_shani=True, n_threads=1,
         raise ValueError("invalid CDC params")
     assert total <= cap
     return files[:n].copy(), chunks[:total].copy()
+
+
+def scan_synthetic(seed, content_ids, sizes, params, allow_shani=True, n_threads=1, flags=0,
+                   chunk_cap=None):
+    """scan_batch over synthetic files generated inside the workers (no host copy of the data).
+    Returns (files, chunks, n_unique)."""
+    szs = np.ascontiguousarray(sizes, dtype=np.uint64)
+    n = szs.size
+    u64p = C.POINTER(C.c_uint64)
+    cp = None
+    if content_ids is not None:
+        cids = np.ascontiguousarray(content_ids, dtype=np.uint64)
+        assert cids.size == n
+        cp = cids.ctypes.data_as(u64p)
+    cap = int((szs // np.uint64(params.min_size) + np.uint64(2)).sum()) if chunk_cap is None else chunk_cap
+    files = np.zeros(max(n, 1), dtype=FILE_DTYPE)
+    chunks = np.zeros(max(cap, 1), dtype=CHUNK_DTYPE)
+    nu = C.c_uint64()
+    total = lib().mi_ref_scan_synthetic(seed, cp, szs.ctypes.data_as(u64p), n, C.byref(params),
+                                        int(allow_shani), n_threads, flags, files.ctypes.data,
+                                        chunks.ctypes.data, cap, C.byref(nu))
+    if total == 2**64 - 1:
+        raise ValueError("invalid CDC params")
+    assert total <= cap
+    return files[:n], chunks[:total], nu.value
+
+
+def last_phase_seconds():
+    out = (C.c_double * 3)()
+    lib().mi_ref_last_phase_seconds(out)
+    return {"scan_s": out[0], "gather_s": out[1], "dedup_s": out[2]}
+
+
+def dedup_mt(digests, n_threads):
+    d = np.ascontiguousarray(digests, dtype=np.uint8).reshape(-1, 32)
+    out = np.zeros(d.shape[0], dtype=np.int64)
+    uniq = lib().mi_ref_dedup_mt(d.ctypes.data, d.shape[0], out.ctypes.data, n_threads)
+    return out, uniq
 
 
 def chunk_root(digests, allow_shani=True):

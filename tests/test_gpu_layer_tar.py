@@ -1,6 +1,5 @@
-"""GPU test of the layer-tar staging path (mi_batch_add_path_range / Batch.add_tar).  Kept in a file
-of its own that sorts last: it was written after round 1's GPU minutes were spent and has not run
-on a GPU yet, so it is a non-strict xfail and cannot take anything else down with it."""
+"""GPU test of the layer-tar staging path (mi_batch_add_path_range / Batch.add_tar): the regular
+files of a layer tar scanned straight out of the archive."""
 import hashlib
 
 import numpy as np
@@ -16,8 +15,6 @@ pytestmark = pytest.mark.gpu
 SEED = 0x4D414B49
 
 
-@pytest.mark.xfail(strict=False, reason="written after this round's GPU minutes were spent: first run is the "
-                                        "driver's; non-strict so a defect here cannot stop the suite")
 def test_layer_tar_members_scanned_in_place(oracle, tmp_path):
     """mi_tar_entries + mi_batch_add_path_range: the regular files of a layer tar hashed straight out
     of the archive equal the same bytes added one by one (whole-file SHA-256 vs hashlib, chunk

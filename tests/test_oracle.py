@@ -236,3 +236,44 @@ def test_layer_scan_is_sha256_of_a_readable_tar(oracle, tmp_path):
         assert [m.name for m in members] == ["f%08d" % i for i in range(4)]
         assert [m.size for m in members] == sizes
         assert tf.extractfile(members[1]).read() == blobs[1]
+
+
+def test_threaded_dedup_equals_serial(oracle):
+    """mi_ref_dedup_mt (bucketed, n threads) against the single-bucket-sort form and a python dict."""
+    rng = np.random.default_rng(3)
+    base = rng.integers(0, 256, (3000, 32), dtype=np.uint8)
+    rows = base[rng.integers(0, 3000, 20000)]
+    rows[::7, 0] = 0                                   # crowd one bucket
+    d1, u1 = oracle.dedup(rows)
+    for t in (1, 2, 5, 16):
+        dt, ut = oracle.dedup_mt(rows, t)
+        assert ut == u1 and np.array_equal(dt, d1)
+    seen, want = {}, np.empty(len(rows), dtype=np.int64)
+    for i, r in enumerate(rows):
+        k = r.tobytes()
+        want[i] = seen.get(k, -1)
+        seen.setdefault(k, i)
+    assert np.array_equal(d1, want) and u1 == len(seen)
+
+
+def test_scan_synthetic_equals_scan_batch(oracle):
+    """Generating inside the workers (full-size configs) == scanning a host copy, any thread count."""
+    seed = 0x4D414B49 + 2
+    sizes = [65536, 1, 0, 300000, 70000, 65536, 2048, 100]
+    cids = [5, 6, 7, 8, 5, 9, 10, 6]
+    p = oracle.CdcParams(0x4D414B49, 13, 2048, 65536)
+    data = np.concatenate([oracle.synth_fill(seed, c, 0, n) for c, n in zip(cids, sizes)])
+    offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.uint64)
+    rf, rc = oracle.scan_batch(data, offs, sizes, p, True, 1, 0)
+    for t in (1, 4):
+        sf, sc, nu = oracle.scan_synthetic(seed, cids, sizes, p, True, t, 0)
+        assert np.array_equal(sf, rf) and np.array_equal(sc, rc)
+        assert nu == int((rc["dup_of"] < 0).sum())
+    ph = oracle.last_phase_seconds()
+    assert set(ph) == {"scan_s", "gather_s", "dedup_s"} and ph["scan_s"] > 0
+
+
+def test_synth_fill_unaligned_ranges(oracle):
+    whole = oracle.synth_fill(7, 3, 0, 1000)
+    for off, n in ((0, 0), (1, 7), (3, 13), (8, 64), (5, 900), (999, 1)):
+        assert np.array_equal(oracle.synth_fill(7, 3, off, n), whole[off:off + n])
