@@ -42,6 +42,32 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 SHA_VALU_ROOF_GBPS = 1767.0
 
 
+def usable_cores():
+    """Host cores this process may actually use: the affinity mask, capped by a cgroup CPU quota
+    (cpu.max / cpu.cfs_quota_us) when one is set -- os.cpu_count() alone reports the node's cores
+    even inside a container that is throttled to a few of them."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        txt = open("/sys/fs/cgroup/cpu.max").read().split()
+        if txt and txt[0] != "max":
+            quota = float(txt[0]) / float(txt[1])
+    except (OSError, ValueError, IndexError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, quota
+
+
 def cpu_baseline(shard, budget_files=None):
     """The oracle (a port of the same spec) on a bounded sample of the SAME workload, timed around
     the C call only.  Three numbers: all host cores (one file per thread at a time, threaded
@@ -49,7 +75,7 @@ def cpu_baseline(shard, budget_files=None):
     does today: one running SHA-256 over the tar-framed files, lib/builder/step/common.go:35-63)."""
     from oracle import mi_oracle as O
     O.build()
-    cores = os.cpu_count() or 1
+    cores, quota = usable_cores()
     p = O.CdcParams(SEED, 13, 2048, 65536)
     # sample: a prefix of this rank's files, at most ~6.5 GB of host memory (all of C2)
     sizes = shard.sizes
@@ -89,7 +115,7 @@ def cpu_baseline(shard, budget_files=None):
                       "digest-prefix buckets across threads; best of 3, timed around the C call, data "
                       "already in host memory (generated in %.1f s, untimed)"
                       % (n, shard.name, nbytes / 2**20, gen_s),
-            "sha_ni": bool(O.have_shani()),
+            "sha_ni": bool(O.have_shani()), "node_cores": os.cpu_count(), "cgroup_cpu_quota": quota,
             "phase_s": {k: round(v, 4) for k, v in phases.items()},
             "scan_phase_GiBps": round(scan_rate / 2**30, 3),
             "single_thread_GiBps": round(rate1 / 2**30, 3),

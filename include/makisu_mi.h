@@ -67,8 +67,9 @@ typedef struct {
     uint32_t min_size;        /* >= 64                                              */
     uint32_t max_size;        /* >= min_size, <= 2^30                               */
     uint32_t flags;           /* MI_FLAG_*                                          */
-    uint64_t staging_bytes;   /* pinned staging bytes per copy stream (0 = 64 MiB)  */
-    uint32_t n_streams;       /* copy streams for host-fed batches (0 = 2)          */
+    uint64_t staging_bytes;   /* bytes per pinned staging slab (0 = 8 MiB)          */
+    uint32_t n_streams;       /* reader threads for host-fed batches, one pinned slab
+                                 and one copy stream each (0 = 8)                   */
     uint32_t reserved;
 } mi_config;
 
@@ -116,9 +117,11 @@ typedef struct {
 int  mi_abi_version(void);
 int  mi_config_default(mi_config* cfg);
 int  mi_ctx_create(const mi_config* cfg, mi_ctx** out);
-/* Free every batch and index of the ctx first (mi_batch_free / mi_index_free): they hold a
- * pointer to it.                                                                        */
-void mi_ctx_destroy(mi_ctx* ctx);
+/* Batches and indexes hold a pointer to their ctx: free them first (mi_batch_free /
+ * mi_index_free).  With live children the call changes nothing and returns MI_ERR_STATE (the
+ * count is in the message) -- a finalizer that runs in the wrong order gets an error, not a
+ * use-after-free.  NULL is MI_OK.                                                       */
+int  mi_ctx_destroy(mi_ctx* ctx);
 /* ctx may be NULL: returns the message of the last failed mi_ctx_create.           */
 const char* mi_last_error(mi_ctx* ctx);
 int  mi_get_stats(mi_ctx* ctx, mi_stats* out);
@@ -134,11 +137,16 @@ int  mi_device_info(mi_ctx* ctx, int32_t* n_cu, int32_t* clock_mhz, uint64_t* hb
  * added.  Order of results == order of adds (the caller adds in sorted-path order,
  * lib/snapshot/mem_layer.go:232-244).                                              */
 int mi_batch_begin(mi_ctx* ctx, uint64_t n_files_hint, uint64_t bytes_hint, mi_batch** out);
-/* Copies [data, data+len) into pinned staging before returning (len may be 0).     */
+/* The bytes have been consumed when the call returns (len may be 0): small buffers are copied
+ * into the batch's own pinned window by the calling thread, buffers of 1 MiB and more by the
+ * ctx's reader threads in parallel.  Two batches of one ctx may be filled at the same time.  */
 int mi_batch_add_bytes(mi_batch* b, const void* data, uint64_t len, uint64_t user_tag);
 /* The engine opens `path` and reads exactly `size` bytes (the size at stat time,
  * like io.CopyN(w, f, h.Size) at lib/tario/write.go:43-45).  Short files are an
- * error, extra appended bytes are ignored.                                          */
+ * error, extra appended bytes are ignored.  The open and the size check happen in this call;
+ * the bytes are read by the ctx's reader threads (several files at once, consecutive small
+ * files share one PCIe transfer), so a file that shrinks afterwards fails mi_batch_run /
+ * mi_batch_submit with MI_ERR_IO.                                                    */
 int mi_batch_add_path(mi_batch* b, const char* path, uint64_t size, uint64_t user_tag);
 /* The same for a byte range of a file -- a member of an uncompressed layer tar, whose ranges
  * mi_tar_entries lists: the file's bytes are [offset, offset + size) of `path`.             */

@@ -120,7 +120,7 @@ def load_library(rebuild=False):
         "mi_abi_version": ([], C.c_int),
         "mi_config_default": ([C.POINTER(Config)], C.c_int),
         "mi_ctx_create": ([C.POINTER(Config), C.POINTER(vp)], C.c_int),
-        "mi_ctx_destroy": ([vp], None),
+        "mi_ctx_destroy": ([vp], C.c_int),
         "mi_last_error": ([vp], C.c_char_p),
         "mi_get_stats": ([vp, C.POINTER(Stats)], C.c_int),
         "mi_device_info": ([vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), u64p, C.c_char_p,
@@ -436,9 +436,11 @@ class Engine:
 
     def close(self):
         if getattr(self, "_h", None):
-            for child in list(self._children):  # a batch freed after its ctx would touch freed memory
+            for child in list(self._children):  # the library refuses to destroy a ctx with live children
                 child.free()
-            self._lib.mi_ctx_destroy(self._h)
+            rc = self._lib.mi_ctx_destroy(self._h)
+            if rc:
+                raise MiError(rc, self._lib.mi_last_error(self._h).decode())
             self._h = None
 
     __del__ = close

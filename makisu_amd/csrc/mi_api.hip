@@ -19,6 +19,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <sys/stat.h>
 #include <string.h>
 #include <unistd.h>
 
@@ -56,11 +57,22 @@ namespace {
 u64 align_up(u64 v, u64 a) { return (v + a - 1) / a * a; }
 
 // ---- arena + staging ------------------------------------------------------------
+// Two ways into the arena: small mi_batch_add_bytes calls are copied inline into the batch's own
+// pinned window (two slabs, the copy of one in flight while the other fills); files and large
+// buffers go through the ctx's reader threads (mi_stage.hip).
+int staging_sync(mi_batch* b) {
+    mi_ctx* c = b->ctx;
+    if (b->ring_stream) HIPCHK(c, hipStreamSynchronize(b->ring_stream));
+    if (c->stager) return stager_drain(c->stager, b);
+    return MI_OK;
+}
+
 int arena_reserve(mi_batch* b, u64 want) {
     mi_ctx* c = b->ctx;
     want += 4096;                                   // slack: tile loads may touch 15 B past a file
     if (want <= b->arena.bytes) return MI_OK;
-    for (auto s : c->copy_streams) HIPCHK(c, hipStreamSynchronize(s));
+    int rc = staging_sync(b);                       // copies in flight target the old arena
+    if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     u64 alloc = want + want / 2;
     void* np = nullptr;
@@ -76,60 +88,62 @@ int arena_reserve(mi_batch* b, u64 want) {
     return MI_OK;
 }
 
+int ensure_ring(mi_batch* b) {
+    mi_ctx* c = b->ctx;
+    if (b->ring[0]) return MI_OK;
+    HIPCHK(c, hipStreamCreateWithFlags(&b->ring_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+        HIPCHK(c, hipHostMalloc(&b->ring[i], c->staging_bytes, hipHostMallocDefault));
+        HIPCHK(c, hipEventCreateWithFlags(&b->ring_ev[i], hipEventDisableTiming));
+    }
+    return MI_OK;
+}
+
+int ensure_stager(mi_ctx* c) {
+    if (!c->stager) c->stager = stager_create(c, c->stage_threads, c->staging_bytes);
+    return MI_OK;
+}
+
 int staging_flush(mi_batch* b) {
     mi_ctx* c = b->ctx;
     if (b->win_fill == 0) return MI_OK;
-    HIPCHK(c, hipMemcpyAsync((u8*)b->arena.p + b->win_start, c->staging[b->cur], b->win_fill,
-                             hipMemcpyHostToDevice, c->copy_streams[b->cur]));
-    HIPCHK(c, hipEventRecord(c->staging_done[b->cur], c->copy_streams[b->cur]));
+    HIPCHK(c, hipMemcpyAsync((u8*)b->arena.p + b->win_start, b->ring[b->cur], b->win_fill,
+                             hipMemcpyHostToDevice, b->ring_stream));
+    HIPCHK(c, hipEventRecord(b->ring_ev[b->cur], b->ring_stream));
     b->staged_any = true;
-    b->cur = (b->cur + 1) % (int)c->staging.size();
-    HIPCHK(c, hipEventSynchronize(c->staging_done[b->cur]));   // the buffer we are about to reuse
+    b->cur ^= 1;
+    HIPCHK(c, hipEventSynchronize(b->ring_ev[b->cur]));        // the slab we are about to reuse
     b->win_start += b->win_fill;
     b->win_fill = 0;
     return MI_OK;
 }
 
-// Appends `len` bytes at arena offset `at` through the pinned staging ring.  `src`
-// (memory) or `fd` (file, read with pread at file offset `foff`).
-int staging_append(mi_batch* b, u64 at, const u8* src, int fd, u64 foff, u64 len,
-                   const char* path) {
+// Appends `len` bytes of caller memory at arena offset `at` through the batch's pinned window.
+int staging_append(mi_batch* b, u64 at, const u8* src, u64 len) {
     mi_ctx* c = b->ctx;
+    int rc = ensure_ring(b);
+    if (rc) return rc;
     if (b->win_fill == 0) b->win_start = at;
     if (at != b->win_start + b->win_fill) {
-        const u64 gap = at - (b->win_start + b->win_fill);      // alignment padding
-        if (b->win_fill + gap > c->staging_bytes) {
-            int rc = staging_flush(b);
+        const u64 gap = at - (b->win_start + b->win_fill);      // alignment padding (or a staged file)
+        if (at < b->win_start + b->win_fill || b->win_fill + gap > c->staging_bytes) {
+            rc = staging_flush(b);
             if (rc) return rc;
             b->win_start = at;
         } else {
-            memset((u8*)c->staging[b->cur] + b->win_fill, 0, gap);
+            memset((u8*)b->ring[b->cur] + b->win_fill, 0, gap);
             b->win_fill += gap;
         }
     }
     while (len) {
         if (b->win_fill == c->staging_bytes) {
-            int rc = staging_flush(b);
+            rc = staging_flush(b);
             if (rc) return rc;
         }
         u64 take = c->staging_bytes - b->win_fill;
         if (take > len) take = len;
-        u8* dst = (u8*)c->staging[b->cur] + b->win_fill;
-        if (src) {
-            memcpy(dst, src, take);
-            src += take;
-        } else {
-            u64 got = 0;
-            while (got < take) {
-                ssize_t r = pread(fd, dst + got, take - got, (off_t)(foff + got));
-                if (r < 0 && errno == EINTR) continue;
-                if (r <= 0)
-                    return fail(c, MI_ERR_IO, "read %s: %s", path,
-                                r == 0 ? "file shorter than the size given" : strerror(errno));
-                got += (u64)r;
-            }
-            foff += take;
-        }
+        memcpy((u8*)b->ring[b->cur] + b->win_fill, src, take);
+        src += take;
         b->win_fill += take;
         len -= take;
     }
@@ -490,15 +504,13 @@ int mi_ctx_create(const mi_config* cfg, mi_ctx** out) {
     CREATE_CHK(hipHostMalloc((void**)&c->h_word, 64, hipHostMallocDefault));
     for (auto& e : c->ev) e = nullptr;
     for (auto& e : c->ev) CREATE_CHK(hipEventCreate(&e));
-    c->staging_bytes = cfg->staging_bytes ? cfg->staging_bytes : (64ull << 20);
-    const u32 ns = cfg->n_streams ? cfg->n_streams : 2;
-    for (u32 i = 0; i < ns; ++i) {
-        hipStream_t st = nullptr;
-        CREATE_CHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-        c->copy_streams.push_back(st);
-        hipEvent_t ev = nullptr;
-        CREATE_CHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        c->staging_done.push_back(ev);
+    // host-fed staging (mi_stage.hip): slab bytes and reader threads; both lazily allocated
+    c->staging_bytes = cfg->staging_bytes ? cfg->staging_bytes : (8ull << 20);
+    if (c->staging_bytes < (1ull << 16)) c->staging_bytes = 1ull << 16;
+    c->stage_threads = cfg->n_streams ? cfg->n_streams : 8;
+    if (const char* e = getenv("MI_STAGE_THREADS")) {
+        int v = atoi(e);
+        if (v >= 1 && v <= 64) c->stage_threads = (u32)v;
     }
     // Gear table: first 256 outputs of splitmix64(seed)
     u64 table[256];
@@ -527,14 +539,18 @@ int mi_ctx_create(const mi_config* cfg, mi_ctx** out) {
     return MI_OK;
 }
 
-void mi_ctx_destroy(mi_ctx* c) {
-    if (!c) return;
+int mi_ctx_destroy(mi_ctx* c) {
+    if (!c) return MI_OK;
+    if (c->live_children > 0)
+        // batches and indexes hold a pointer to their ctx: destroying it under them would leave
+        // dangling handles (a Go finalizer order can do exactly that).  Refuse; the ctx stays usable.
+        return fail(c, MI_ERR_STATE, "mi_ctx_destroy: %d batch(es)/index(es) of this ctx are still alive",
+                    c->live_children);
     (void)hipSetDevice(c->device);
     (void)mi_comm_destroy(c);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (auto p : c->staging) if (p) (void)hipHostFree(p);
-    for (auto s : c->copy_streams) if (s) (void)hipStreamDestroy(s);
-    for (auto e : c->staging_done) if (e) (void)hipEventDestroy(e);
+    stager_destroy(c->stager);
+    c->stager = nullptr;
     for (auto e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->h_word) (void)hipHostFree(c->h_word);
     c->gear_table.release(); c->heads.release(); c->crc_consts.release();
@@ -542,6 +558,7 @@ void mi_ctx_destroy(mi_ctx* c) {
     c->dd_tag.release(); c->dd_fmin.release();
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+    return MI_OK;
 }
 
 int mi_get_stats(mi_ctx* c, mi_stats* out) {
@@ -570,6 +587,7 @@ int mi_batch_begin(mi_ctx* c, uint64_t n_files_hint, uint64_t bytes_hint, mi_bat
     hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
     for (auto& ev : b->ev) if (e == hipSuccess) e = hipEventCreate(&ev);
     if (e == hipSuccess) e = hipHostMalloc((void**)&b->h_counts, 16, hipHostMallocDefault);
+    ++c->live_children;                                 // mi_batch_free undoes it (error paths included)
     if (e != hipSuccess) {
         int rc = fail(c, MI_ERR_HIP, "mi_batch_begin: %s", hipGetErrorString(e));
         mi_batch_free(b);
@@ -583,79 +601,68 @@ int mi_batch_begin(mi_ctx* c, uint64_t n_files_hint, uint64_t bytes_hint, mi_bat
     return MI_OK;
 }
 
-static int ensure_staging(mi_ctx* c) {
-    if (!c->staging.empty()) return MI_OK;
-    for (size_t i = 0; i < c->copy_streams.size(); ++i) {
-        void* p = nullptr;
-        HIPCHK(c, hipHostMalloc(&p, c->staging_bytes, hipHostMallocDefault));
-        c->staging.push_back(p);
-    }
-    return MI_OK;
-}
+// host buffers below this size are copied inline by the calling thread; larger ones are split
+// over the reader threads (a single memcpy stream tops out far below PCIe Gen5)
+static const u64 kInlineBytes = 1ull << 20;
 
 int mi_batch_add_bytes(mi_batch* b, const void* data, uint64_t len, uint64_t user_tag) {
     if (!b || (!data && len)) return MI_ERR_INVALID;
     mi_ctx* c = b->ctx;
     HIPCHK(c, hipSetDevice(c->device));
-    int rc = ensure_staging(c);
-    if (rc) return rc;
     u64 at;
-    rc = batch_add_common(b, len, user_tag, &at);
+    int rc = batch_add_common(b, len, user_tag, &at);
     if (rc) return rc;
     if (len == 0) return MI_OK;
     const auto t0 = std::chrono::steady_clock::now();
-    rc = staging_append(b, at, (const u8*)data, -1, 0, len, nullptr);
+    if (len < kInlineBytes) {
+        rc = staging_append(b, at, (const u8*)data, len);
+    } else {
+        rc = ensure_stager(c);
+        if (!rc) rc = stager_put_bytes(c->stager, b, at, data, len);   // returns when `data` has been consumed
+        b->staged_any = true;
+    }
+    b->ms_h2d += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+}
+
+// mi_batch_add_path / _range: the file is opened and checked NOW (a missing or short file is the
+// caller's error to see at this call, like the reference's open + CopyN at lib/tario/write.go:37-45);
+// its bytes are read by the reader threads, so a file that shrinks later fails the batch at run time.
+static int add_file_range(mi_batch* b, const char* path, uint64_t offset, uint64_t size, uint64_t user_tag) {
+    if (!b || !path) return MI_ERR_INVALID;
+    mi_ctx* c = b->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    int fd = open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) return fail(c, MI_ERR_IO, "open %s: %s", path, strerror(errno));
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) {
+        int rc = fail(c, MI_ERR_IO, "stat %s: %s", path, strerror(errno));
+        close(fd);
+        return rc;
+    }
+    if (S_ISREG(sb.st_mode) && (offset > (u64)sb.st_size || size > (u64)sb.st_size - offset)) {
+        close(fd);
+        return fail(c, MI_ERR_IO, "read %s: file shorter than the size given", path);
+    }
+    u64 at;
+    int rc = batch_add_common(b, size, user_tag, &at);
+    if (rc == MI_OK) rc = ensure_stager(c);
+    if (rc) { close(fd); return rc; }
+    const auto t0 = std::chrono::steady_clock::now();
+    rc = stager_put_file(c->stager, b, at, fd, offset, size, path);       // owns fd from here on
+    b->staged_any = true;
     b->ms_h2d += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return rc;
 }
 
 int mi_batch_add_path(mi_batch* b, const char* path, uint64_t size, uint64_t user_tag) {
-    if (!b || !path) return MI_ERR_INVALID;
-    mi_ctx* c = b->ctx;
-    HIPCHK(c, hipSetDevice(c->device));
-    int rc = ensure_staging(c);
-    if (rc) return rc;
-    int fd = open(path, O_RDONLY | O_CLOEXEC);
-    if (fd < 0) return fail(c, MI_ERR_IO, "open %s: %s", path, strerror(errno));
-    u64 at;
-    rc = batch_add_common(b, size, user_tag, &at);
-    if (rc == MI_OK && size) {
-        const auto t0 = std::chrono::steady_clock::now();
-        rc = staging_append(b, at, nullptr, fd, 0, size, path);
-        b->ms_h2d += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        if (rc) {                                   // undo the registration: the file is unusable
-            b->total_bytes -= size;                 // (its arena range stays reserved, unused)
-            b->files.pop_back();
-        }
-    }
-    close(fd);
-    return rc;
+    return add_file_range(b, path, 0, size, user_tag);
 }
 
 // A file that is a byte range of another file: a member of an uncompressed layer tar
-// (mi_tar_entries gives the ranges).  Same staging path as mi_batch_add_path, the read starts at
-// `offset`.
+// (mi_tar_entries gives the ranges).
 int mi_batch_add_path_range(mi_batch* b, const char* path, uint64_t offset, uint64_t size, uint64_t user_tag) {
-    if (!b || !path) return MI_ERR_INVALID;
-    mi_ctx* c = b->ctx;
-    HIPCHK(c, hipSetDevice(c->device));
-    int rc = ensure_staging(c);
-    if (rc) return rc;
-    int fd = open(path, O_RDONLY | O_CLOEXEC);
-    if (fd < 0) return fail(c, MI_ERR_IO, "open %s: %s", path, strerror(errno));
-    u64 at;
-    rc = batch_add_common(b, size, user_tag, &at);
-    if (rc == MI_OK && size) {
-        const auto t0 = std::chrono::steady_clock::now();
-        rc = staging_append(b, at, nullptr, fd, offset, size, path);
-        b->ms_h2d += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        if (rc) {                                   // undo the registration: the range is unusable
-            b->total_bytes -= size;
-            b->files.pop_back();
-        }
-    }
-    close(fd);
-    return rc;
+    return add_file_range(b, path, offset, size, user_tag);
 }
 
 int mi_batch_add_synthetic(mi_batch* b, uint64_t n_files, const uint64_t* sizes,
@@ -696,7 +703,8 @@ static int stage_batch(mi_batch* b) {
     const auto t0 = std::chrono::steady_clock::now();
     int rc = staging_flush(b);
     if (rc) return rc;
-    for (auto s : c->copy_streams) HIPCHK(c, hipStreamSynchronize(s));
+    rc = staging_sync(b);                       // everything the reader threads hold has landed
+    if (rc) return rc;
     if (b->staged_any)          // host->device staging time: ring memcpy/pread + waits + final drain
         b->ms_h2d += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     const u64 nf = b->files.size();
@@ -896,8 +904,14 @@ int mi_batch_free(mi_batch* b) {
     if (b->tree) { mi_batch_tree_free(b->tree); b->tree = nullptr; }
     mi_ctx* c = b->ctx;
     (void)hipSetDevice(c->device);
-    for (auto s : c->copy_streams) (void)hipStreamSynchronize(s);
+    (void)staging_sync(b);                      // reader threads may still hold pieces of this batch
+    for (int i = 0; i < 2; ++i) {
+        if (b->ring_ev[i]) (void)hipEventDestroy(b->ring_ev[i]);
+        if (b->ring[i]) (void)hipHostFree(b->ring[i]);
+    }
+    if (b->ring_stream) (void)hipStreamDestroy(b->ring_stream);
     (void)hipStreamSynchronize(c->stream);
+    --c->live_children;
     if (b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
     for (auto e : b->ev) if (e) (void)hipEventDestroy(e);
     if (b->h_counts) (void)hipHostFree(b->h_counts);

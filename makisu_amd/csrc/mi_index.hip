@@ -8,11 +8,17 @@
 // already contain?" -- and that can be exported/imported as a flat byte blob so the shim can
 // keep it behind the same keyvalue.Store next to the existing entries.
 //
-// Device side: open addressing, slot = {state word, 32-byte digest}.  mi_index_add_batch
-// marks the batch's digests (mi_dedup_mark) and probes the UNIQUE rows only (dup_of == -1, so no
-// two probing threads carry the same
-// digest and a half-written slot can never be a false match); a row whose digest is found is
-// "known", otherwise it claims an empty slot with one atomicCAS and stores its digest.
+// Device side: open addressing, slot = {64-bit tag, 32-byte digest}; tag = the digest's first 8
+// bytes (0 is stored as 1), 0 = empty.  mi_index_add_batch marks the batch's digests
+// (mi_dedup_mark) and probes the UNIQUE rows only (dup_of == -1), in two kernels per round:
+//   probe   walks from the row's slot comparing TAGS only -- the value atomicCAS returns, coherent
+//           by itself: an empty slot is claimed (CAS 0 -> tag) and the digest stored, a slot with
+//           an equal tag is remembered for the next kernel, anything else is walked past;
+//   verify  (after the kernel boundary, when every digest stored by `probe` is visible) compares
+//           all 32 bytes at the remembered slot: equal = "known"; different = a 64-bit tag
+//           collision, the row goes on probing from the next slot in another round.
+// No thread ever reads digest bytes another thread of the same launch may still be writing, and
+// never trusts a slot's bytes without its tag, so recycled device memory cannot fake a match.
 // Duplicate rows inherit the flag of the row they point to.  The table is rebuilt at twice
 // the size when it gets more than half full.
 #include "mi_internal.h"
@@ -37,36 +43,77 @@ __device__ __forceinline__ bool digest_eq32(const u8* a, const u8* b) {
     return (d0.x | d0.y | d0.z | d0.w | d1.x | d1.y | d1.z | d1.w) == 0;
 }
 
-// rows: n digests; only rows with dup_of == -1 (or all rows when dup_of == nullptr) are probed.
-// known[i] = 1 if the digest was already in the table, 0 if it was inserted now.
+__device__ __forceinline__ u64 tag_of(const u8* d) {
+    const u64 t = *(const u64*)d;
+    return t ? t : 1ull;
+}
+
+// Row states while an insert is in progress.
+enum : u8 { kRowDone = 0, kRowVerify = 1, kRowProbe = 2 };
+
+// first round: rows with dup_of == -1 (or all rows when dup_of == nullptr) start probing
 __global__ __launch_bounds__(256)
-void index_probe_kernel(const u8* __restrict__ digests, const i64* __restrict__ dup_of, u64 n,
-                        u32* __restrict__ state, u8* __restrict__ slots, u64 mask,
-                        u8* __restrict__ known, u64* __restrict__ n_new) {
+void index_begin_kernel(const u8* __restrict__ digests, const i64* __restrict__ dup_of, u64 n, u64 mask,
+                        u8* __restrict__ row_state, u64* __restrict__ row_slot) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const bool probe = !(dup_of && dup_of[i] >= 0);
+    row_state[i] = probe ? kRowProbe : kRowDone;
+    row_slot[i] = tag_of(digests + 32 * i) & mask;
+}
+
+// known[i] = 0 if the row's digest was inserted now (known may be nullptr)
+__global__ __launch_bounds__(256)
+void index_probe_kernel(const u8* __restrict__ digests, u64 n, u64* __restrict__ tags,
+                        u8* __restrict__ slots, u64 mask, u8* __restrict__ row_state,
+                        u64* __restrict__ row_slot, u8* __restrict__ known, u64* __restrict__ n_new) {
     __shared__ u32 wg_new;
     if (threadIdx.x == 0) wg_new = 0;
     __syncthreads();
     u32 mine_new = 0;
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
-        if (dup_of && dup_of[i] >= 0) continue;
+        if (row_state[i] != kRowProbe) continue;
         const u8* d = digests + 32 * i;
-        u64 slot = *(const u64*)d & mask;
+        const u64 tag = tag_of(d);
+        u64 slot = row_slot[i];
         for (;;) {
-            const u32 s = atomicCAS(&state[slot], 0u, 1u);
-            if (s == 0u) {                                   // empty: mine now
+            const u64 old = atomicCAS((unsigned long long*)&tags[slot], 0ull, (unsigned long long)tag);
+            if (old == 0ull) {                               // empty: mine now
                 ((u32x4*)(slots + 32 * slot))[0] = ((const u32x4*)d)[0];
                 ((u32x4*)(slots + 32 * slot))[1] = ((const u32x4*)d)[1];
                 if (known) known[i] = 0;
+                row_state[i] = kRowDone;
                 ++mine_new;
                 break;
             }
-            if (digest_eq32(slots + 32 * slot, d)) { if (known) known[i] = 1; break; }
+            if (old == tag) {                                // full compare after the kernel boundary
+                row_slot[i] = slot;
+                row_state[i] = kRowVerify;
+                break;
+            }
             slot = (slot + 1) & mask;
         }
     }
     if (mine_new) atomicAdd(&wg_new, mine_new);
     __syncthreads();
     if (threadIdx.x == 0 && wg_new) atomicAdd((unsigned long long*)n_new, (unsigned long long)wg_new);
+}
+
+__global__ __launch_bounds__(256)
+void index_verify_kernel(const u8* __restrict__ digests, u64 n, const u8* __restrict__ slots, u64 mask,
+                         u8* __restrict__ row_state, u64* __restrict__ row_slot, u8* __restrict__ known,
+                         u64* __restrict__ n_retry) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || row_state[i] != kRowVerify) return;
+    const u64 slot = row_slot[i];
+    if (digest_eq32(slots + 32 * slot, digests + 32 * i)) {
+        if (known) known[i] = 1;
+        row_state[i] = kRowDone;
+    } else {                                                 // equal tags, different digests
+        row_slot[i] = (slot + 1) & mask;
+        row_state[i] = kRowProbe;
+        atomicAdd((unsigned long long*)n_retry, 1ull);
+    }
 }
 
 __global__ __launch_bounds__(256)
@@ -78,10 +125,10 @@ void index_inherit_kernel(const i64* __restrict__ dup_of, u64 n, u8* __restrict_
 }
 
 __global__ __launch_bounds__(256)
-void index_export_kernel(const u32* __restrict__ state, const u8* __restrict__ slots, u64 cap,
+void index_export_kernel(const u64* __restrict__ state, const u8* __restrict__ slots, u64 cap,
                          u8* __restrict__ out, u64* __restrict__ cursor) {
     const u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= cap || state[s] == 0u) return;
+    if (s >= cap || state[s] == 0ull) return;
     const u64 at = atomicAdd((unsigned long long*)cursor, 1ull);
     ((u32x4*)(out + 32 * at))[0] = ((const u32x4*)(slots + 32 * s))[0];
     ((u32x4*)(out + 32 * at))[1] = ((const u32x4*)(slots + 32 * s))[1];
@@ -91,7 +138,7 @@ void index_export_kernel(const u32* __restrict__ state, const u8* __restrict__ s
 
 struct mi_index {
     mi_ctx* ctx;
-    DevBuf state, slots, counter, scratch, dup;
+    DevBuf state, slots, counter, scratch, dup, row_state, row_slot;
     u64 cap = 0;           // slots, power of two
     u64 count = 0;         // digests held
 };
@@ -100,10 +147,10 @@ namespace {
 
 int index_alloc(mi_index* x, u64 cap) {
     mi_ctx* c = x->ctx;
-    HIPCHK(c, x->state.ensure(cap * 4));
+    HIPCHK(c, x->state.ensure(cap * 8));
     HIPCHK(c, x->slots.ensure(cap * 32));
     HIPCHK(c, x->counter.ensure(16));
-    HIPCHK(c, hipMemsetAsync(x->state.p, 0, cap * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(x->state.p, 0, cap * 8, c->stream));
     x->cap = cap;
     return MI_OK;
 }
@@ -123,7 +170,7 @@ int index_grow(mi_index* x, u64 min_cap) {
         HIPCHK(c, old.ensure(have * 32));
         HIPCHK(c, hipMemsetAsync(x->counter.p, 0, 8, c->stream));
         hipLaunchKernelGGL(index_export_kernel, dim3((u32)((x->cap + 255) / 256)), dim3(256), 0, c->stream,
-                           x->state.as<u32>(), x->slots.as<u8>(), x->cap, old.as<u8>(), x->counter.as<u64>());
+                           x->state.as<u64>(), x->slots.as<u8>(), x->cap, old.as<u8>(), x->counter.as<u64>());
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     x->state.release();
@@ -149,18 +196,34 @@ int index_insert(mi_index* x, const u8* d_digests, const i64* d_dup_of, u64 n, u
         int rc = index_grow(x, (x->count + n) * 2);
         if (rc) return rc;
     }
-    HIPCHK(c, hipMemsetAsync(x->counter.p, 0, 8, c->stream));
-    u64 want = (n + 255) / 256;
-    const u32 grid = (u32)(want < 2048 ? want : 2048);
-    hipLaunchKernelGGL(index_probe_kernel, dim3(grid), dim3(256), 0, c->stream, d_digests, d_dup_of, n,
-                       x->state.as<u32>(), x->slots.as<u8>(), x->cap - 1, d_known, x->counter.as<u64>());
+    HIPCHK(c, x->row_state.ensure(n + 16));
+    HIPCHK(c, x->row_slot.ensure(n * 8 + 16));
+    HIPCHK(c, hipMemsetAsync(x->counter.p, 0, 16, c->stream));   // [0] inserted, [1] rows to re-probe
+    const u32 per_row = (u32)((n + 255) / 256);
+    const u32 grid = per_row < 2048u ? per_row : 2048u;
+    u64* d_cnt = x->counter.as<u64>();
+    hipLaunchKernelGGL(index_begin_kernel, dim3(per_row), dim3(256), 0, c->stream, d_digests, d_dup_of, n,
+                       x->cap - 1, x->row_state.as<u8>(), x->row_slot.as<u64>());
+    for (int round = 0;; ++round) {
+        hipLaunchKernelGGL(index_probe_kernel, dim3(grid), dim3(256), 0, c->stream, d_digests, n,
+                           x->state.as<u64>(), x->slots.as<u8>(), x->cap - 1, x->row_state.as<u8>(),
+                           x->row_slot.as<u64>(), d_known, d_cnt);
+        hipLaunchKernelGGL(index_verify_kernel, dim3(per_row), dim3(256), 0, c->stream, d_digests, n,
+                           x->slots.as<u8>(), x->cap - 1, x->row_state.as<u8>(), x->row_slot.as<u64>(),
+                           d_known, d_cnt + 1);
+        HIPCHK(c, hipMemcpyAsync(c->h_word, x->counter.p, 16, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->h_word[1] == 0) break;                       // no 64-bit tag collisions (the normal case)
+        if (round > 64) return fail(c, MI_ERR_HIP, "chunk index: probing does not converge");
+        HIPCHK(c, hipMemsetAsync(d_cnt + 1, 0, 8, c->stream));
+    }
     if (d_dup_of && d_known)
         hipLaunchKernelGGL(index_inherit_kernel, dim3((u32)((n + 255) / 256)), dim3(256), 0, c->stream,
                            d_dup_of, n, d_known);
     HIPCHK(c, hipMemcpyAsync(c->h_word, x->counter.p, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
-    const u64 added = *c->h_word;
+    const u64 added = c->h_word[0];
     x->count += added;
     *n_new = added;
     return MI_OK;
@@ -175,6 +238,7 @@ int mi_index_create(mi_ctx* c, uint64_t capacity_hint, mi_index** out) {
     HIPCHK(c, hipSetDevice(c->device));
     mi_index* x = new mi_index();
     x->ctx = c;
+    ++c->live_children;                                 // mi_index_free undoes it
     u64 cap = 1024;
     while (cap < 2 * capacity_hint) cap <<= 1;
     int rc = index_alloc(x, cap);
@@ -189,6 +253,8 @@ void mi_index_free(mi_index* x) {
     (void)hipSetDevice(x->ctx->device);
     (void)hipStreamSynchronize(x->ctx->stream);
     x->state.release(); x->slots.release(); x->counter.release(); x->scratch.release(); x->dup.release();
+    x->row_state.release(); x->row_slot.release();
+    --x->ctx->live_children;
     delete x;
 }
 
@@ -237,7 +303,7 @@ int mi_index_export(mi_index* x, void* out, uint64_t cap_digests) {
     HIPCHK(c, tmp.ensure(x->count * 32));
     HIPCHK(c, hipMemsetAsync(x->counter.p, 0, 8, c->stream));
     hipLaunchKernelGGL(index_export_kernel, dim3((u32)((x->cap + 255) / 256)), dim3(256), 0, c->stream,
-                       x->state.as<u32>(), x->slots.as<u8>(), x->cap, tmp.as<u8>(), x->counter.as<u64>());
+                       x->state.as<u64>(), x->slots.as<u8>(), x->cap, tmp.as<u8>(), x->counter.as<u64>());
     hipError_t e = hipMemcpyAsync(out, tmp.p, x->count * 32, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) return fail(c, MI_ERR_HIP, "mi_index_export: %s", hipGetErrorString(e));

@@ -30,6 +30,14 @@ struct SynthSpec { u64 f0, n, seed; std::vector<u64> cids; };
 // sets the ctx's (or, for c == nullptr, the create-time) error message; returns code
 int fail(mi_ctx* c, int code, const char* fmt, ...);
 
+// mi_stage.hip: reader threads + pinned slabs behind mi_batch_add_path / large mi_batch_add_bytes
+struct Stager;
+Stager* stager_create(mi_ctx* c, u32 n_threads, u64 slab_bytes);
+void    stager_destroy(Stager* st);
+int     stager_put_bytes(Stager* st, mi_batch* b, u64 arena_off, const void* src, u64 len);
+int     stager_put_file(Stager* st, mi_batch* b, u64 arena_off, int fd, u64 file_off, u64 len, const char* path);
+int     stager_drain(Stager* st, mi_batch* b);
+
 }  // namespace mi
 
 struct mi_ctx {
@@ -37,10 +45,10 @@ struct mi_ctx {
     int device = 0;
     hipDeviceProp_t prop;
     hipStream_t stream = nullptr;        // ctx-level work (mi_dedup_mark, mi_sha256_many, uploads)
-    std::vector<hipStream_t> copy_streams;
-    std::vector<void*> staging;          // pinned, staging_bytes each
-    std::vector<hipEvent_t> staging_done;
-    size_t staging_bytes = 0;
+    mi::Stager* stager = nullptr;        // reader threads + pinned slabs, created on the first host-fed add
+    mi::u32 stage_threads = 0;
+    size_t staging_bytes = 0;            // bytes per pinned slab (reader threads, per-batch inline ring)
+    int live_children = 0;               // batches + indexes that still point at this ctx
     mi::DevBuf gear_table, heads, crc_consts;
     mi::DevBuf dd_rep, dd_minid, dd_slot, dd_nuniq;     // dedup scratch of mi_dedup_mark
     mi::DevBuf dd_tag, dd_fmin;                         // ... and of mi_dedup_mark_range
@@ -63,11 +71,18 @@ struct mi_batch {
     mi::u64 total_bytes = 0;     // sum of sizes
     mi::u64 arena_used = 0;      // next free arena offset
     mi::DevBuf arena;
-    // staging window
-    int cur = 0;             // staging buffer being filled
-    mi::u64 win_start = 0;       // arena offset the current staging buffer maps to
+    // inline staging window for small mi_batch_add_bytes calls: the batch's OWN two pinned slabs
+    // (two batches may be filled at the same time), copied on the batch's own copy stream
+    void* ring[2] = {nullptr, nullptr};
+    hipEvent_t ring_ev[2] = {nullptr, nullptr};
+    hipStream_t ring_stream = nullptr;
+    int cur = 0;             // slab being filled
+    mi::u64 win_start = 0;       // arena offset the current slab maps to
     mi::u64 win_fill = 0;        // bytes valid in it
     bool staged_any = false;
+    // reader-thread staging (mi_stage.hip); guarded by the stager's mutex
+    mi::u64 stage_pending = 0;   // queued pieces not yet in HBM
+    std::string stage_err;       // first read / copy error
     double ms_h2d = 0;
     // pipeline state: every batch owns a stream, so two batches can be in flight and the
     // Gear pass of one overlaps the SHA pass of the other (they bind different units)

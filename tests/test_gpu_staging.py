@@ -1,0 +1,135 @@
+"""GPU tests of the host-fed path: reader-thread staging (mi_stage.hip), the per-batch inline
+window, and the ctx's child accounting.  Bit-exact against the oracle like every parity test."""
+import os
+
+import numpy as np
+import pytest
+
+try:
+    import torch  # noqa: F401  (must come before the engine: see test_gpu_parity.py)
+except ImportError:
+    torch = None
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x4D414B49
+
+
+def _oracle_rows(oracle, blobs, cfg, threads=8):
+    data = np.frombuffer(b"".join(bytes(x) for x in blobs), dtype=np.uint8)
+    sizes = np.array([len(x) for x in blobs], dtype=np.uint64)
+    offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.uint64)
+    p = oracle.CdcParams(cfg.gear_seed, cfg.mask_bits, cfg.min_size, cfg.max_size)
+    return oracle.scan_batch(data if data.size else np.zeros(1, np.uint8), offs, sizes, p, True, threads, 0)
+
+
+def _same(files, chunks, rf, rc):
+    assert len(chunks) == len(rc)
+    assert np.array_equal(chunks["offset"], rc["offset"]) and np.array_equal(chunks["length"], rc["length"])
+    assert np.array_equal(chunks["sha256"], rc["sha256"])
+    assert np.array_equal(files["chunk_root"], rf["chunk_root"])
+    assert np.array_equal(chunks["dup_of"], rc["dup_of"])
+
+
+def test_two_batches_filled_at_the_same_time(oracle):
+    """interleaved mi_batch_add_bytes on two batches of one ctx must not mix bytes."""
+    import makisu_amd
+    a_blobs = [oracle.synth_fill(SEED, 5000 + i, 0, n).tobytes() for i, n in enumerate([70000, 10, 300000, 65536, 2 << 20])]
+    b_blobs = [oracle.synth_fill(SEED, 5100 + i, 0, n).tobytes() for i, n in enumerate([5, 131072, 99999, 3 << 20, 64])]
+    with makisu_amd.Engine() as e:
+        a, b = e.batch(), e.batch()
+        for x, y in zip(a_blobs, b_blobs):
+            a.add_bytes(x)
+            b.add_bytes(y)
+        b.run()
+        a.run()
+        for batch, blobs in ((a, a_blobs), (b, b_blobs)):
+            assert batch.read_back().tobytes() == b"".join(blobs)
+            _same(batch.files(), batch.chunks(), *_oracle_rows(oracle, blobs, e.cfg))
+        a.free()
+        b.free()
+
+
+def test_host_fed_mix_large_and_small_files(oracle, tmp_path):
+    """4 x 1 GiB + many small files through mi_batch_add_path (reader threads,
+    several files at once, small files sharing a slab), mixed with inline and large add_bytes."""
+    import makisu_amd
+    big = 1 << 30
+    sizes = [big, 700, big, 65536, 0, big, 1, 4097, big] + [int(x) for x in
+             np.random.default_rng(4).integers(1, 200000, 300)]
+    cids = list(range(6000, 6000 + len(sizes)))
+    data, offs = oracle.synth_fill_many(SEED + 1, cids, sizes, 8)
+    paths = []
+    for i, (o, n) in enumerate(zip(offs, sizes)):
+        pth = str(tmp_path / ("f%04d" % i))
+        data[int(o):int(o) + n].tofile(pth)
+        paths.append(pth)
+    extra = [oracle.synth_fill(SEED, 6500, 0, 5 << 20).tobytes(), b"tiny", oracle.synth_fill(SEED, 6501, 0, 90000).tobytes()]
+    with makisu_amd.Engine() as e, e.batch() as b:
+        for i, (pth, n) in enumerate(zip(paths, sizes)):
+            b.add_path(pth, n, i)
+            if i == 5:
+                for x in extra:                     # caller memory between the files
+                    b.add_bytes(x)
+        b.run()
+        files, chunks = b.files().copy(), b.chunks().copy()
+        st = e.stats()
+    blobs = []
+    for i, (o, n) in enumerate(zip(offs, sizes)):
+        blobs.append(data[int(o):int(o) + n])
+        if i == 5:
+            blobs += [np.frombuffer(x, dtype=np.uint8) for x in extra]
+    all_sizes = np.array([len(x) for x in blobs], dtype=np.uint64)
+    whole = np.concatenate(blobs)
+    all_offs = np.concatenate([[0], np.cumsum(all_sizes)[:-1]]).astype(np.uint64)
+    p = oracle.CdcParams(e.cfg.gear_seed, e.cfg.mask_bits, e.cfg.min_size, e.cfg.max_size)
+    rf, rc = oracle.scan_batch(whole, all_offs, all_sizes, p, True, 16, 0)
+    _same(files, chunks, rf, rc)
+    assert st["ms_h2d"] > 0
+    for pth in paths:
+        os.unlink(pth)
+
+
+def test_file_that_shrinks_after_add_fails_the_run(tmp_path):
+    import makisu_amd
+    pth = str(tmp_path / "shrinks")
+    with open(pth, "wb") as f:
+        f.write(os.urandom(3 << 20))
+    with makisu_amd.Engine(n_streams=1) as e:
+        with e.batch() as b:
+            with pytest.raises(makisu_amd.MiError) as ei:      # too short at add time: this call fails
+                b.add_path(pth, (3 << 20) + 1)
+            assert ei.value.code == -5
+        with e.batch() as b:
+            blocker = os.urandom(64 << 20)
+            b.add_bytes(blocker)                               # keeps the one reader thread busy
+            b.add_path(pth, 3 << 20)
+            os.truncate(pth, 100)                              # usually before the reader gets there
+            try:
+                b.run()
+                ok = True
+            except makisu_amd.MiError as err:
+                ok = False
+                assert err.code == -5 and "shorter" in str(err)
+            if ok:                                             # the reader won the race: bytes are the old ones
+                assert b.counts()[0] == 2
+
+
+def test_ctx_destroy_refuses_with_live_children():
+    import ctypes as C
+    import makisu_amd
+    L = makisu_amd.load_library()
+    e = makisu_amd.Engine()
+    b = e.batch()
+    idx = e.index()
+    assert L.mi_ctx_destroy(e._h) == -6                        # MI_ERR_STATE, nothing freed
+    assert b"still alive" in L.mi_last_error(e._h)
+    b.add_bytes(b"x" * 1000)
+    b.run()                                                    # the ctx is still fully usable
+    assert b.counts() == (1, 1, 1000)
+    b.free()
+    assert L.mi_ctx_destroy(e._h) == -6                        # the index is still there
+    idx.free()
+    e.close()
+    assert e._h is None
+    assert L.mi_ctx_destroy(None) == 0

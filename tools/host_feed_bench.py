@@ -1,6 +1,8 @@
-"""PCIe-inclusive rate: host buffers -> mi_batch_add_bytes (pinned ring + hipMemcpyAsync) -> scan."""
+"""PCIe-inclusive rate: host memory / page-cache files -> reader threads + pinned slabs -> H2D -> scan.
+Usage: host_feed_bench.py [n_files] [MiB per file]   (MI_STAGE_THREADS picks the reader-thread count)"""
 import os
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -10,24 +12,40 @@ import makisu_amd  # noqa: E402
 
 
 def main():
-    n, size = 64, 64 << 20
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 48
+    size = (int(sys.argv[2]) if len(sys.argv) > 2 else 128) << 20
     rng = np.random.default_rng(0)
     blob = rng.integers(0, 256, size, dtype=np.uint8)
+    base = "/dev/shm" if os.access("/dev/shm", os.W_OK) else None
+    d = tempfile.mkdtemp(prefix="mi_feed_", dir=base)
+    paths = []
+    for i in range(n):
+        blob[:8] = np.frombuffer(np.uint64(i).tobytes(), dtype=np.uint8)
+        p = os.path.join(d, "f%04d" % i)
+        blob.tofile(p)
+        paths.append(p)
+    thr = os.environ.get("MI_STAGE_THREADS", "default")
     with makisu_amd.Engine() as e:
-        for rep in range(3):
+        for mode in ("add_bytes", "add_path", "add_path"):
             b = e.batch(n, n * size)
             t0 = time.perf_counter()
             for i in range(n):
-                b.add_bytes(blob, tag=i)
+                if mode == "add_bytes":
+                    b.add_bytes(blob, tag=i)
+                else:
+                    b.add_path(paths[i], size, i)
             t1 = time.perf_counter()
             b.run()
             t2 = time.perf_counter()
             st = e.stats()
-            print("host feed: %d x %d MiB: add %.3f s (%.1f GB/s into the pinned ring + H2D), run %.3f s, "
-                  "end to end %.1f GB/s, device pipeline alone %.1f GB/s"
-                  % (n, size >> 20, t1 - t0, n * size / (t1 - t0) / 1e9, t2 - t1,
-                     n * size / (t2 - t0) / 1e9, st["bytes_in"] / st["ms_total"] / 1e6))
+            print("threads %s %s: %d x %d MiB: add %.3f s, run %.3f s (ms_h2d %.1f), end to end %.1f GB/s, "
+                  "device pipeline alone %.1f GB/s"
+                  % (thr, mode, n, size >> 20, t1 - t0, t2 - t1, st["ms_h2d"], n * size / (t2 - t0) / 1e9,
+                     st["bytes_in"] / st["ms_total"] / 1e6), flush=True)
             b.free()
+    for p in paths:
+        os.unlink(p)
+    os.rmdir(d)
 
 
 if __name__ == "__main__":
