@@ -125,8 +125,10 @@ int staging_append(mi_batch* b, u64 at, const u8* src, u64 len) {
     if (rc) return rc;
     if (b->win_fill == 0) b->win_start = at;
     if (at != b->win_start + b->win_fill) {
-        const u64 gap = at - (b->win_start + b->win_fill);      // alignment padding (or a staged file)
-        if (at < b->win_start + b->win_fill || b->win_fill + gap > c->staging_bytes) {
+        // only alignment padding may be bridged: a larger gap is a file the reader threads are
+        // staging, and zero-filling across it would overwrite their bytes
+        const u64 gap = at - (b->win_start + b->win_fill);
+        if (at < b->win_start + b->win_fill || gap >= kFileAlign || b->win_fill + gap > c->staging_bytes) {
             rc = staging_flush(b);
             if (rc) return rc;
             b->win_start = at;
@@ -507,7 +509,7 @@ int mi_ctx_create(const mi_config* cfg, mi_ctx** out) {
     // host-fed staging (mi_stage.hip): slab bytes and reader threads; both lazily allocated
     c->staging_bytes = cfg->staging_bytes ? cfg->staging_bytes : (8ull << 20);
     if (c->staging_bytes < (1ull << 16)) c->staging_bytes = 1ull << 16;
-    c->stage_threads = cfg->n_streams ? cfg->n_streams : 8;
+    c->stage_threads = cfg->n_streams ? cfg->n_streams : 16;
     if (const char* e = getenv("MI_STAGE_THREADS")) {
         int v = atoi(e);
         if (v >= 1 && v <= 64) c->stage_threads = (u32)v;

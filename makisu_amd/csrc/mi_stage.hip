@@ -62,11 +62,15 @@ void batch_fail(Stager* st, mi_batch* b, const std::string& msg) {
     if (b->stage_err.empty()) b->stage_err = msg;
 }
 
-void item_done(Stager* st, const StageItem& it) {
-    if (it.latch) {
-        std::lock_guard<std::mutex> g(it.latch->mu);
-        if (--it.latch->left == 0) it.latch->cv.notify_all();
-    }
+// the item's source bytes sit in a pinned slab: a blocking adder may return (cgo pointer rule)
+void item_consumed(const StageItem& it) {
+    if (!it.latch) return;
+    std::lock_guard<std::mutex> g(it.latch->mu);
+    if (--it.latch->left == 0) it.latch->cv.notify_all();
+}
+
+// the item's bytes are in HBM (or its batch has been marked failed)
+void item_landed(Stager* st, const StageItem& it) {
     bool wake = false;
     {
         std::lock_guard<std::mutex> g(st->mu);
@@ -78,7 +82,8 @@ void item_done(Stager* st, const StageItem& it) {
 // One reader thread: pops a run of queued items whose arena span fits its slab, fills the slab
 // (slab offset = arena offset - span start, so alignment gaps between files travel as they are),
 // issues ONE H2D copy for the span on its own stream and waits for it; the other threads read and
-// copy meanwhile, so PCIe stays busy without any cross-thread event hand-over.
+// copy meanwhile, so PCIe stays busy without any cross-thread event hand-over.  A blocking
+// mi_batch_add_bytes returns as soon as its pieces sit in slabs, before their transfers finish.
 void worker(Stager* st) {
     mi_ctx* c = st->ctx;
     (void)hipSetDevice(c->device);
@@ -128,13 +133,14 @@ void worker(Stager* st) {
             }
             end = it.arena_off + it.len;
         }
+        for (const StageItem& it : run) item_consumed(it);
         if (err.empty()) {
             hipError_t e = hipMemcpyAsync((u8*)b->arena.p + start, slab, end - start, hipMemcpyHostToDevice, stream);
             if (e == hipSuccess) e = hipStreamSynchronize(stream);
             if (e != hipSuccess) err = std::string("host-to-device copy (staging): ") + hipGetErrorString(e);
         }
         if (!err.empty()) batch_fail(st, b, err);
-        for (const StageItem& it : run) item_done(st, it);       // bytes are in HBM (or the batch failed)
+        for (const StageItem& it : run) item_landed(st, it);
     }
     if (slab) (void)hipHostFree(slab);
     if (stream) (void)hipStreamDestroy(stream);

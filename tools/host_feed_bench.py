@@ -26,7 +26,7 @@ def main():
         paths.append(p)
     thr = os.environ.get("MI_STAGE_THREADS", "default")
     with makisu_amd.Engine() as e:
-        for mode in ("add_bytes", "add_path", "add_path"):
+        for mode in (os.environ.get("MI_FEED_MODES") or "add_bytes,add_bytes,add_path,add_path,add_bytes,add_path").split(","):
             b = e.batch(n, n * size)
             t0 = time.perf_counter()
             for i in range(n):
