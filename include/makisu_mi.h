@@ -368,6 +368,63 @@ typedef struct {
 int mi_snapshot_diff(const mi_snapshot_side* before, const mi_snapshot_side* after, int ignore_time,
                      uint8_t* after_flags, uint8_t* before_whiteout);
 
+/* ---- the layer writer: tar framing + the two serial layer digests (host threads) ---------- *
+ * step.tarAndGzipDiffs + MemFS.commitLayer (lib/builder/step/common.go:35-111,
+ * lib/snapshot/mem_fs.go:424-433) behind the ABI: the shim hands over the layer's entries in
+ * commit order (mi_entries_commit_order) and gets the DigestPair's numbers back, while the GPU
+ * scans the same files' content (an mi_batch fed with the same paths).  Pipeline, one thread
+ * per stage, 1 MiB blocks, every sink sees every block (stream.ConcurrentMultiWriter,
+ * lib/stream/multi_writer.go:35-66):
+ *     framer --tee--> SHA-256 of the tar stream                      (tarDigester, common.go:45)
+ *               '---> gzip (zlib) --> out_fd + SHA-256 of the blob   (gzipper/gzipDigester, :44-52)
+ * Entries: memLayer.createHeader's rules (lib/snapshot/mem_layer.go:152-190: Name = dst without
+ * the leading "/", directories with a trailing "/", Uname/Gname empty, symlink target as given --
+ * mi_tree_walk already root-trims it) written the way tario.WriteEntry / WriteHeader do
+ * (lib/tario/write.go:28-68: mtime in whole seconds; regular files followed by EXACTLY size bytes
+ * read from src_path -- io.CopyN; a shorter file is MI_ERR_IO; directories, symlinks and hard
+ * links header-only; any other kind MI_ERR_INVALID "unsupported type").  The header bytes follow
+ * Go's archive/tar Writer (USTAR, PAX when a field does not fit); byte parity with Go is
+ * UNPINNED here (no Go toolchain) -- see csrc/mi_layer.hip.  mi_layer_finish writes
+ * tar.Writer.Close's 1024-byte trailer: an empty layer is 1024 zero bytes, digest 5f70bf18...
+ * (lib/docker/image/const_darwin.go:18).  Not thread-safe per layer; layers are independent. */
+#define MI_GZIP_OFF     (-2)   /* no gzip leg: out_fd receives the tar itself                    */
+#define MI_GZIP_DEFAULT (-1)   /* "default"; 0 = "no", 1 = "speed", 9 = "size" (lib/tario/gzip.go:26-43) */
+typedef struct mi_layer mi_layer;
+typedef struct {
+    uint32_t struct_size;
+    int32_t  gzip_level;       /* MI_GZIP_OFF, MI_GZIP_DEFAULT or 0..9                          */
+    int32_t  out_fd;           /* where the layer blob is written; -1 = digests only           */
+    uint32_t reserved;
+} mi_layer_config;
+typedef struct {
+    uint8_t  tar_sha256[32];   /* DigestPair.TarDigest      (common.go:97)                      */
+    uint8_t  gzip_sha256[32];  /* GzipDescriptor.Digest     (:98-102); zero with MI_GZIP_OFF   */
+    uint64_t tar_bytes;
+    uint64_t gzip_bytes;       /* GzipDescriptor.Size                                           */
+    uint64_t n_entries;
+} mi_layer_result;
+int  mi_layer_config_default(mi_layer_config* cfg);
+int  mi_layer_begin(const mi_layer_config* cfg, mi_layer** out);
+/* e->relpath = the entry's dst path; src_path = where a regular file's bytes are read from.     */
+int  mi_layer_add(mi_layer* layer, const mi_tree_entry* e, const char* src_path);
+/* whiteoutMemFile.commit (mem_layer.go:101-132): a zero header named <dir>/.wh.<base>.          */
+int  mi_layer_add_whiteout(mi_layer* layer, const char* deleted_path);
+int  mi_layer_finish(mi_layer* layer, mi_layer_result* out);
+const char* mi_layer_error(mi_layer* layer);
+void mi_layer_free(mi_layer* layer);
+/* The header block(s) mi_layer_add would write for `e` (512 bytes, or 1536+ with a PAX record). */
+int  mi_layer_header_bytes(const mi_tree_entry* e, uint8_t* out, uint64_t cap, uint64_t* n);
+
+/* ---- cache entry codec (cache.Manager seam, lib/cache/cache_manager.go:34-35,239-252) -------- *
+ * key   = "makisu_builder_cache_" + cacheID;
+ * entry = "<tarHex>,<gzipHex>" (createEntry), or "MAKISU_CACHE_EMPTY" for a step that produced no
+ *         layer (pass NULL, NULL); parse is parseEntry + PullCache's empty-entry case: *is_empty
+ *         = 1 means "cached, and there is no layer"; an entry without "," is MI_ERR_INVALID
+ *         (the reference wraps it as ErrorLayerNotFound).                                      */
+int mi_cache_key(const char* cache_id, char* out, uint64_t cap);
+int mi_cache_create_entry(const uint8_t* tar_sha256, const uint8_t* gzip_sha256, char* out, uint64_t cap);
+int mi_cache_parse_entry(const char* entry, int* is_empty, uint8_t* tar_sha256, uint8_t* gzip_sha256);
+
 /* ---- standalone digests (image.Digester seam) ---------------------------------- *
  * n independent byte strings -> n SHA-256 digests on the GPU, one lane per string:
  * the batched form of image.NewDigester().FromBytes / FromReader

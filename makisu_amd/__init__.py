@@ -74,6 +74,21 @@ class SnapshotSide(C.Structure):
 DIFF_SAME, DIFF_CHANGED, DIFF_ANCESTOR = 0, 1, 2
 
 
+class LayerConfig(C.Structure):
+    """mi_layer_config."""
+    _fields_ = [("struct_size", C.c_uint32), ("gzip_level", C.c_int32), ("out_fd", C.c_int32),
+                ("reserved", C.c_uint32)]
+
+
+class LayerResult(C.Structure):
+    """mi_layer_result: the numbers of step.commitLayer's DigestPair."""
+    _fields_ = [("tar_sha256", C.c_uint8 * 32), ("gzip_sha256", C.c_uint8 * 32), ("tar_bytes", C.c_uint64),
+                ("gzip_bytes", C.c_uint64), ("n_entries", C.c_uint64)]
+
+
+GZIP_OFF, GZIP_DEFAULT = -2, -1
+
+
 class Stats(C.Structure):
     _fields_ = [("bytes_in", C.c_uint64), ("n_files", C.c_uint64), ("n_chunks", C.c_uint64),
                 ("n_unique", C.c_uint64), ("ms_h2d", C.c_double), ("ms_cdc", C.c_double),
@@ -165,6 +180,17 @@ def load_library(rebuild=False):
         "mi_tar_free": ([vp], None),
         "mi_entry_similar": ([C.POINTER(TreeEntry), C.POINTER(TreeEntry), C.c_int, vp, vp,
                               C.POINTER(C.c_int)], C.c_int),
+        "mi_layer_config_default": ([C.POINTER(LayerConfig)], C.c_int),
+        "mi_layer_begin": ([C.POINTER(LayerConfig), C.POINTER(vp)], C.c_int),
+        "mi_layer_add": ([vp, C.POINTER(TreeEntry), C.c_char_p], C.c_int),
+        "mi_layer_add_whiteout": ([vp, C.c_char_p], C.c_int),
+        "mi_layer_finish": ([vp, C.POINTER(LayerResult)], C.c_int),
+        "mi_layer_error": ([vp], C.c_char_p),
+        "mi_layer_free": ([vp], None),
+        "mi_layer_header_bytes": ([C.POINTER(TreeEntry), vp, u64, u64p], C.c_int),
+        "mi_cache_key": ([C.c_char_p, C.c_char_p, u64], C.c_int),
+        "mi_cache_create_entry": ([vp, vp, C.c_char_p, u64], C.c_int),
+        "mi_cache_parse_entry": ([C.c_char_p, C.POINTER(C.c_int), vp, vp], C.c_int),
         "mi_comm_unique_id": ([vp], C.c_int),
         "mi_comm_init_rank": ([vp, C.c_int, C.c_int, vp], C.c_int),
         "mi_comm_init_all": ([C.POINTER(vp), C.c_int], C.c_int),
@@ -348,6 +374,100 @@ def tree_walk(root, rel_base=None, blacklist=(), mode=TREE_CONTEXT, full=False):
                  e.file_index, e.size, e.kind, e.mode) for e in arr[:n.value]]
     finally:
         L.mi_tree_free(h)
+
+
+class Layer:
+    """mi_layer_*: the layer tar writer with its two stream digests (host threads, no GPU).
+
+    with Layer(out_fd=fd, gzip_level=GZIP_DEFAULT) as l:
+        l.add(entry_dict, src_path); l.add_whiteout("/deleted/path"); pair = l.finish()
+    finish() -> dict(tar_digest="sha256:..", gzip_digest=.., tar_bytes, gzip_bytes, n_entries)."""
+
+    def __init__(self, out_fd=-1, gzip_level=GZIP_DEFAULT):
+        self._lib = load_library()
+        cfg = LayerConfig()
+        self._lib.mi_layer_config_default(C.byref(cfg))
+        cfg.out_fd, cfg.gzip_level = out_fd, gzip_level
+        self._gzip = gzip_level != GZIP_OFF
+        self._h = C.c_void_p()
+        rc = self._lib.mi_layer_begin(C.byref(cfg), C.byref(self._h))
+        if rc:
+            raise MiError(rc, "mi_layer_begin")
+
+    def _check(self, rc):
+        if rc:
+            raise MiError(rc, self._lib.mi_layer_error(self._h).decode(errors="replace"))
+
+    def add(self, entry, src_path=None):
+        keep = []
+        arr = _entry_array([entry], keep)
+        self._check(self._lib.mi_layer_add(self._h, arr, os.fsencode(src_path) if src_path is not None else None))
+
+    def add_whiteout(self, deleted_path):
+        self._check(self._lib.mi_layer_add_whiteout(self._h, os.fsencode(deleted_path)))
+
+    def finish(self):
+        res = LayerResult()
+        self._check(self._lib.mi_layer_finish(self._h, C.byref(res)))
+        return {"tar_digest": Digest.from_raw(res.tar_sha256),
+                "gzip_digest": Digest.from_raw(res.gzip_sha256) if self._gzip else None,
+                "tar_sha256": bytes(res.tar_sha256), "gzip_sha256": bytes(res.gzip_sha256),
+                "tar_bytes": res.tar_bytes, "gzip_bytes": res.gzip_bytes, "n_entries": res.n_entries}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mi_layer_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def layer_header_bytes(entry):
+    """The tar header block(s) the layer writer emits for one entry dict."""
+    keep = []
+    arr = _entry_array([entry], keep)
+    n = C.c_uint64()
+    buf = (C.c_uint8 * 8192)()
+    rc = load_library().mi_layer_header_bytes(arr, buf, 8192, C.byref(n))
+    if rc:
+        raise MiError(rc, "mi_layer_header_bytes")
+    return bytes(buf[: n.value])
+
+
+def cache_key(cache_id):
+    out = C.create_string_buffer(len(os.fsencode(cache_id)) + 64)
+    rc = load_library().mi_cache_key(os.fsencode(cache_id), out, len(out))
+    if rc:
+        raise MiError(rc, "mi_cache_key")
+    return out.value.decode()
+
+
+def cache_create_entry(tar_sha256=None, gzip_sha256=None):
+    """createEntry: raw 32-byte digests -> "tarHex,gzipHex"; (None, None) -> the empty marker."""
+    out = C.create_string_buffer(160)
+    t = (C.c_uint8 * 32).from_buffer_copy(tar_sha256) if tar_sha256 is not None else None
+    g = (C.c_uint8 * 32).from_buffer_copy(gzip_sha256) if gzip_sha256 is not None else None
+    rc = load_library().mi_cache_create_entry(t, g, out, len(out))
+    if rc:
+        raise MiError(rc, "mi_cache_create_entry")
+    return out.value.decode()
+
+
+def cache_parse_entry(entry):
+    """parseEntry: -> None for the empty marker, else (tar Digest, gzip Digest); ValueError if malformed."""
+    t, g, e = (C.c_uint8 * 32)(), (C.c_uint8 * 32)(), C.c_int()
+    rc = load_library().mi_cache_parse_entry(entry.encode(), C.byref(e), t, g)
+    if rc:
+        raise ValueError("parse redis entry: %s" % entry)
+    if e.value:
+        return None
+    return Digest.from_raw(t), Digest.from_raw(g)
 
 
 class ChunkIndex:

@@ -1,0 +1,623 @@
+// mi_layer.hip -- the layer writer: tar framing + the two serial layer digests, behind the C ABI.
+// Host code only (no kernels).
+//
+// What it restates (reference = uber/makisu):
+//   step.tarAndGzipDiffs        lib/builder/step/common.go:35-63   tar.Writer -> tee -> {tarDigester,
+//                               gzip -> tee -> {file, gzipDigester}}
+//   step.commitLayer            common.go:67-111                   the DigestPair it returns
+//   memLayer.createHeader       lib/snapshot/mem_layer.go:152-190  Name = RelPath(dst), Uname/Gname "",
+//                               directories get a trailing "/", symlinks carry their target
+//   whiteoutMemFile.commit      mem_layer.go:127-132               header-only entry {Name: ".wh.<x>"}
+//   tario.WriteEntry/WriteHeader lib/tario/write.go:28-68          leading "/" stripped, mtime truncated
+//                               to seconds, then exactly h.Size bytes (io.CopyN) for regular files;
+//                               dirs / links / symlinks header-only; anything else "unsupported type"
+//   stream.ConcurrentMultiWriter lib/stream/multi_writer.go:35-66  every sink gets every block, sinks
+//                               run concurrently, a block is handed on only when all took the last
+//   tario.NewGzipWriter         lib/tario/gzip.go:26-48            level no / speed / size / default
+// The header bytes themselves are Go's archive/tar (not under /root/reference): Writer.WriteHeader
+// with Format unknown -> USTAR when every field fits (names up to 100 bytes or prefix/name split at a
+// "/", octal numbers), else PAX (an "x" record file "PaxHeaders.0/<name>" with path / linkpath / uid /
+// gid / size / mtime records, then the same header with what fits).  Restated from the Go 1.14
+// sources from memory; BYTE PARITY WITH GO IS UNPINNED (no Go toolchain here) -- what is pinned: the
+// empty layer's digest (1024 zero bytes, lib/docker/image/const_darwin.go:18), read-back by python
+// tarfile and GNU tar, and field-for-field agreement with the oracle's independent ustar header.
+// The gzip bytes are zlib's (the reference uses klauspost/pgzip, whose block splitting is its own):
+// the gzip digest is a faithful DigestPair member for THIS writer, not comparable across writers.
+#include "../../include/makisu_mi.h"
+#include "host_sha256.h"
+
+#include <errno.h>
+#include <fcntl.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+typedef std::vector<uint8_t> Bytes;
+typedef std::shared_ptr<const Bytes> Block;
+const size_t kBlockBytes = 1u << 20;
+
+// ---- one sink of the tee: its own thread, blocks in order ---------------------------------
+class Sink {
+public:
+    virtual ~Sink() {}
+    void start() { th_ = std::thread([this] { run(); }); }
+    void push(const Block& b) {                    // blocks while the sink is 4 blocks behind
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return q_.size() < 4; });
+        q_.push_back(b);
+        cv_.notify_all();
+    }
+    void close() {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            closed_ = true;
+        }
+        cv_.notify_all();
+        if (th_.joinable()) th_.join();
+    }
+    std::string error() {                          // the sink thread may be setting it right now
+        std::lock_guard<std::mutex> g(mu_);
+        return err;
+    }
+
+protected:
+    std::string err;                               // written by the sink thread only (under mu_)
+    void set_error(const std::string& m) {
+        std::lock_guard<std::mutex> g(mu_);
+        if (err.empty()) err = m;
+    }
+    bool failed() {
+        std::lock_guard<std::mutex> g(mu_);
+        return !err.empty();
+    }
+    virtual void consume(const uint8_t* p, size_t n) = 0;
+    virtual void finish() = 0;
+
+private:
+    void run() {
+        for (;;) {
+            Block b;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return closed_ || !q_.empty(); });
+                if (q_.empty()) break;
+                b = q_.front();
+            }
+            if (!failed()) consume(b->data(), b->size());
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                q_.pop_front();
+            }
+            cv_.notify_all();
+        }
+        if (!failed()) finish();
+    }
+    std::thread th_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<Block> q_;
+    bool closed_ = false;
+};
+
+bool write_all(int fd, const uint8_t* p, size_t n, std::string* err) {
+    while (n) {
+        const ssize_t w = write(fd, p, n);
+        if (w < 0 && errno == EINTR) continue;
+        if (w <= 0) { *err = std::string("write layer blob: ") + strerror(errno); return false; }
+        p += w;
+        n -= (size_t)w;
+    }
+    return true;
+}
+
+class DigestSink : public Sink {                   // tarDigester (common.go:45)
+public:
+    uint8_t digest[32];
+    uint64_t bytes = 0;
+    int raw_fd = -1;                               // without a gzip leg the tar itself is the blob
+protected:
+    void consume(const uint8_t* p, size_t n) override {
+        sha_.update(p, n);
+        bytes += n;
+        std::string e;
+        if (raw_fd >= 0 && !write_all(raw_fd, p, n, &e)) set_error(e);
+    }
+    void finish() override { sha_.final(digest); }
+private:
+    mi_host::Sha256 sha_;
+};
+
+class GzipSink : public Sink {                     // gzipper -> {tempGzipTar, gzipDigester} (common.go:44-52)
+public:
+    uint8_t digest[32];
+    uint64_t bytes = 0;
+    int out_fd = -1;
+    bool init(int level) {
+        memset(&z_, 0, sizeof z_);
+        const int rc = deflateInit2(&z_, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY);
+        if (rc != Z_OK) { set_error("deflateInit2 failed"); return false; }
+        ready_ = true;
+        out_.resize(256 << 10);
+        return true;
+    }
+    ~GzipSink() override { if (ready_) deflateEnd(&z_); }
+protected:
+    void consume(const uint8_t* p, size_t n) override { pump(p, n, Z_NO_FLUSH); }
+    void finish() override {
+        pump(nullptr, 0, Z_FINISH);
+        sha_.final(digest);
+    }
+private:
+    void pump(const uint8_t* p, size_t n, int flush) {
+        z_.next_in = (Bytef*)p;
+        z_.avail_in = (uInt)n;
+        for (;;) {
+            z_.next_out = out_.data();
+            z_.avail_out = (uInt)out_.size();
+            const int rc = deflate(&z_, flush);
+            if (rc == Z_STREAM_ERROR) { set_error("deflate failed"); return; }
+            const size_t got = out_.size() - z_.avail_out;
+            if (got) {
+                sha_.update(out_.data(), got);
+                bytes += got;
+                std::string e;
+                if (out_fd >= 0 && !write_all(out_fd, out_.data(), got, &e)) { set_error(e); return; }
+            }
+            if (flush == Z_FINISH ? rc == Z_STREAM_END : (z_.avail_in == 0 && z_.avail_out != 0)) break;
+        }
+    }
+    z_stream z_;
+    bool ready_ = false;
+    Bytes out_;
+    mi_host::Sha256 sha_;
+};
+
+// ---- Go archive/tar header formatting -------------------------------------------------------
+bool is_ascii(const std::string& s) {
+    for (unsigned char ch : s) if (ch >= 0x80) return false;
+    return true;
+}
+std::string to_ascii(const std::string& s) {       // archive/tar toASCII: non-ASCII bytes dropped
+    if (is_ascii(s)) return s;
+    std::string o;
+    for (unsigned char ch : s) if (ch < 0x80) o.push_back((char)ch);
+    return o;
+}
+bool fits_octal(int field, int64_t x) {            // fitsInOctal: field-1 digits
+    const unsigned bits = (unsigned)(field - 1) * 3;
+    return x >= 0 && (field >= 22 || x < ((int64_t)1 << bits));
+}
+void put_str(uint8_t* b, size_t n, const std::string& s) {      // formatter.formatString
+    const size_t c = s.size() < n ? s.size() : n;
+    memcpy(b, s.data(), c);
+    if (s.size() < n) b[s.size()] = 0;
+}
+void put_octal(uint8_t* b, int n, int64_t x) {     // formatter.formatOctal: zero-padded, NUL-terminated
+    if (!fits_octal(n, x)) x = 0;                  // the PAX record carries the real value
+    char tmp[32];
+    snprintf(tmp, sizeof tmp, "%0*llo", n - 1, (unsigned long long)x);
+    memcpy(b, tmp, (size_t)n - 1);
+    b[n - 1] = 0;
+}
+// splitUSTARPath: name = prefix + "/" + suffix with len(prefix) <= 155, len(suffix) <= 100
+bool split_ustar(const std::string& name, std::string* prefix, std::string* suffix) {
+    size_t length = name.size();
+    if (length <= 100 || !is_ascii(name)) return false;
+    if (length > 155 + 1) length = 155 + 1;
+    else if (name[length - 1] == '/') --length;
+    const size_t i = name.rfind('/', length ? length - 1 : 0);
+    if (i == std::string::npos || i >= length) return false;
+    const size_t nlen = name.size() - i - 1, plen = i;
+    if (i == 0 || nlen > 100 || nlen == 0 || plen > 155) return false;
+    *prefix = name.substr(0, i);
+    *suffix = name.substr(i + 1);
+    return true;
+}
+void set_checksum(uint8_t* blk) {                  // block.SetFormat: 6 octal digits, NUL, space
+    memset(blk + 148, ' ', 8);
+    unsigned sum = 0;
+    for (int i = 0; i < 512; ++i) sum += blk[i];
+    put_octal(blk + 148, 7, sum);
+    blk[155] = ' ';
+}
+std::string pax_record(const std::string& k, const std::string& v) {   // formatPAXRecord
+    size_t size = k.size() + v.size() + 3;
+    size += std::to_string(size).size();
+    std::string rec = std::to_string(size) + " " + k + "=" + v + "\n";
+    if (rec.size() != size) rec = std::to_string(rec.size()) + " " + k + "=" + v + "\n";
+    return rec;
+}
+std::string path_clean_join(const std::string& dir, const std::string& mid, const std::string& file) {
+    // path.Join(dir, mid, file) for the shapes PAX names take: dir is "" or ends with "/"
+    std::string d = dir;
+    while (!d.empty() && d.back() == '/') d.pop_back();
+    std::string out = d.empty() ? (dir.empty() ? mid : "/" + mid) : d + "/" + mid;
+    if (!file.empty()) out += "/" + file;
+    return out;
+}
+
+struct Hdr {
+    std::string name, linkname;
+    char typeflag = '0';
+    int64_t mode = 0, uid = 0, gid = 0, size = 0, mtime = 0;
+};
+
+// Writer.WriteHeader with Format unknown: USTAR if everything fits, else PAX.  Appends the header
+// block(s) to out.  False: neither format can carry the entry (a NUL in a name).
+bool format_header(const Hdr& h, Bytes* out, std::string* err) {
+    if (h.name.find('\0') != std::string::npos || h.linkname.find('\0') != std::string::npos) {
+        *err = "archive/tar: header field contains NUL";
+        return false;
+    }
+    std::vector<std::pair<std::string, std::string>> pax;
+    bool ustar = true;
+    std::string prefix, suffix;
+    const bool long_name = h.name.size() > 100 || !is_ascii(h.name);
+    const bool can_split = split_ustar(h.name, &prefix, &suffix);
+    if (long_name) {
+        if (!can_split) ustar = false;
+        pax.push_back({"path", h.name});
+    }
+    if (h.linkname.size() > 100 || !is_ascii(h.linkname)) { ustar = false; pax.push_back({"linkpath", h.linkname}); }
+    if (!fits_octal(8, h.uid)) { ustar = false; pax.push_back({"uid", std::to_string(h.uid)}); }
+    if (!fits_octal(8, h.gid)) { ustar = false; pax.push_back({"gid", std::to_string(h.gid)}); }
+    if (!fits_octal(12, h.size)) { ustar = false; pax.push_back({"size", std::to_string(h.size)}); }
+    if (!fits_octal(12, h.mtime)) { ustar = false; pax.push_back({"mtime", std::to_string(h.mtime)}); }
+    if (!fits_octal(8, h.mode)) { *err = "archive/tar: mode does not fit"; return false; }
+
+    auto main_block = [&](const std::string& name, const std::string& linkname, const std::string& pfx) {
+        uint8_t b[512];
+        memset(b, 0, sizeof b);
+        put_str(b + 0, 100, name);
+        put_octal(b + 100, 8, h.mode);
+        put_octal(b + 108, 8, h.uid);
+        put_octal(b + 116, 8, h.gid);
+        put_octal(b + 124, 12, h.size);
+        put_octal(b + 136, 12, h.mtime);
+        b[156] = (uint8_t)h.typeflag;
+        put_str(b + 157, 100, linkname);
+        memcpy(b + 257, "ustar\0" "00", 8);
+        put_str(b + 265, 32, "");                  // Uname, Gname: cleared by createHeader
+        put_str(b + 297, 32, "");
+        put_octal(b + 329, 8, 0);                  // Devmajor / Devminor
+        put_octal(b + 337, 8, 0);
+        put_str(b + 345, 155, pfx);
+        set_checksum(b);
+        out->insert(out->end(), b, b + 512);
+    };
+    if (ustar) {
+        if (can_split) main_block(suffix, h.linkname, prefix);
+        else main_block(h.name, h.linkname, "");
+        return true;
+    }
+    // PAX: the extended-header file first (writeRawFile: no uname/gname/dev fields at all)
+    std::sort(pax.begin(), pax.end());
+    std::string data;
+    for (auto& kv : pax) data += pax_record(kv.first, kv.second);
+    {
+        // path.Split(realName): dir = up to and including the last "/", file = the rest
+        const size_t slash = h.name.rfind('/');
+        const std::string dir = slash == std::string::npos ? "" : h.name.substr(0, slash + 1);
+        const std::string file = slash == std::string::npos ? h.name : h.name.substr(slash + 1);
+        std::string xname = to_ascii(path_clean_join(dir, "PaxHeaders.0", file));
+        if (xname.size() > 100) xname.resize(100);
+        while (!xname.empty() && xname.back() == '/') xname.pop_back();
+        uint8_t b[512];
+        memset(b, 0, sizeof b);
+        b[156] = 'x';
+        put_str(b + 0, 100, xname);
+        put_octal(b + 100, 8, 0);
+        put_octal(b + 108, 8, 0);
+        put_octal(b + 116, 8, 0);
+        put_octal(b + 124, 12, (int64_t)data.size());
+        put_octal(b + 136, 12, 0);
+        memcpy(b + 257, "ustar\0" "00", 8);
+        set_checksum(b);
+        out->insert(out->end(), b, b + 512);
+        out->insert(out->end(), data.begin(), data.end());
+        out->insert(out->end(), (512 - data.size() % 512) % 512, 0);
+    }
+    main_block(to_ascii(h.name), to_ascii(h.linkname), "");
+    return true;
+}
+
+// os.FileMode -> tar Mode: permission bits + setuid / setgid / sticky (FileInfoHeader)
+int64_t tar_mode(uint32_t st_mode) { return (int64_t)(st_mode & 07777u); }
+
+std::string trim_left_slashes(const char* s) {
+    while (*s == '/') ++s;
+    return std::string(s);
+}
+
+}  // namespace
+
+struct mi_layer {
+    std::string err;
+    DigestSink tar;
+    std::unique_ptr<GzipSink> gz;
+    std::shared_ptr<Bytes> cur;
+    uint64_t n_entries = 0, tar_bytes = 0;
+    bool finished = false, failed = false;
+
+    int fail(int code, const char* fmt, ...) {
+        char buf[600];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        err = buf;
+        failed = true;
+        return code;
+    }
+    void flush_block() {
+        if (!cur || cur->empty()) return;
+        Block b = cur;
+        tar.push(b);                               // the tee: both sinks see the same immutable block
+        if (gz) gz->push(b);
+        cur.reset();
+    }
+    uint8_t* room(size_t* n) {                     // space in the current block (at most *n bytes)
+        if (!cur) { cur = std::make_shared<Bytes>(); cur->reserve(kBlockBytes); }
+        if (cur->size() == kBlockBytes) { flush_block(); cur = std::make_shared<Bytes>(); cur->reserve(kBlockBytes); }
+        const size_t left = kBlockBytes - cur->size();
+        if (*n > left) *n = left;
+        const size_t at = cur->size();
+        cur->resize(at + *n);
+        return cur->data() + at;
+    }
+    void append(const uint8_t* p, size_t n) {
+        tar_bytes += n;
+        while (n) {
+            size_t take = n;
+            uint8_t* dst = room(&take);
+            if (p) { memcpy(dst, p, take); p += take; } else memset(dst, 0, take);
+            n -= take;
+        }
+    }
+    int sink_error() {
+        std::string e = tar.error();
+        if (e.empty() && gz) e = gz->error();
+        if (!e.empty()) return fail(MI_ERR_IO, "%s", e.c_str());
+        return MI_OK;
+    }
+};
+
+extern "C" {
+
+int mi_layer_config_default(mi_layer_config* cfg) {
+    if (!cfg) return MI_ERR_INVALID;
+    memset(cfg, 0, sizeof *cfg);
+    cfg->struct_size = sizeof *cfg;
+    cfg->gzip_level = MI_GZIP_DEFAULT;
+    cfg->out_fd = -1;
+    return MI_OK;
+}
+
+int mi_layer_begin(const mi_layer_config* cfg, mi_layer** out) {
+    if (!cfg || !out || cfg->struct_size != sizeof(mi_layer_config)) return MI_ERR_INVALID;
+    if (cfg->gzip_level != MI_GZIP_OFF && (cfg->gzip_level < -1 || cfg->gzip_level > 9)) return MI_ERR_INVALID;
+    mi_layer* l = new mi_layer();
+    if (cfg->gzip_level == MI_GZIP_OFF) {
+        l->tar.raw_fd = cfg->out_fd;
+    } else {
+        l->gz.reset(new GzipSink());
+        l->gz->out_fd = cfg->out_fd;
+        if (!l->gz->init(cfg->gzip_level)) { delete l; return MI_ERR_NOMEM; }
+        l->gz->start();
+    }
+    l->tar.start();
+    *out = l;
+    return MI_OK;
+}
+
+const char* mi_layer_error(mi_layer* l) { return l ? l->err.c_str() : "null layer"; }
+
+static int add_header(mi_layer* l, const Hdr& h) {
+    Bytes hb;
+    std::string err;
+    if (!format_header(h, &hb, &err)) return l->fail(MI_ERR_INVALID, "write header %s: %s", h.name.c_str(), err.c_str());
+    l->append(hb.data(), hb.size());
+    ++l->n_entries;
+    return MI_OK;
+}
+
+int mi_layer_add(mi_layer* l, const mi_tree_entry* e, const char* src_path) {
+    if (!l || !e || !e->relpath) return MI_ERR_INVALID;
+    if (l->finished || l->failed) return l->fail(MI_ERR_STATE, "layer is finished or failed");
+    Hdr h;
+    h.name = trim_left_slashes(e->relpath);                    // RelPath(dst) + WriteHeader's TrimLeft
+    h.mode = tar_mode(e->mode);
+    h.uid = e->uid;
+    h.gid = e->gid;
+    h.mtime = e->mtime_sec;                                     // already truncated to seconds
+    switch (e->kind) {
+        case 0:                                                 // directory: trailing "/" (mem_layer.go:166-170)
+            h.typeflag = '5';
+            if (h.name.empty() || h.name.back() != '/') h.name += "/";
+            break;
+        case 1: h.typeflag = '0'; h.size = (int64_t)e->size; break;
+        case 2: h.typeflag = '2'; h.linkname = e->link_target ? e->link_target : ""; break;
+        case 3: h.typeflag = '1'; h.linkname = e->link_target ? e->link_target : ""; break;
+        default:
+            return l->fail(MI_ERR_INVALID, "content commit %s: unsupported type %u", h.name.c_str(), (unsigned)e->kind);
+    }
+    int fd = -1;
+    if (e->kind == 1) {                                         // open before the header, like os.Open failing first would
+        if (!src_path) return l->fail(MI_ERR_INVALID, "content commit %s: no source path", h.name.c_str());
+        fd = open(src_path, O_RDONLY | O_CLOEXEC);
+        if (fd < 0) return l->fail(MI_ERR_IO, "open src file %s: %s", src_path, strerror(errno));
+    }
+    int rc = add_header(l, h);
+    if (rc) { if (fd >= 0) close(fd); return rc; }
+    if (e->kind == 1) {
+        uint64_t left = e->size, off = 0;                       // io.CopyN(w, f, h.Size): exactly Size bytes
+        while (left) {
+            size_t take = left > kBlockBytes ? kBlockBytes : (size_t)left;
+            uint8_t* dst = l->room(&take);
+            size_t got = 0;
+            while (got < take) {
+                const ssize_t r = pread(fd, dst + got, take - got, (off_t)(off + got));
+                if (r < 0 && errno == EINTR) continue;
+                if (r <= 0) {
+                    close(fd);
+                    return l->fail(MI_ERR_IO, "copy file %s to tar writer: %s", src_path,
+                                   r == 0 ? "unexpected EOF" : strerror(errno));
+                }
+                got += (size_t)r;
+            }
+            l->tar_bytes += take;
+            off += take;
+            left -= take;
+        }
+        close(fd);
+        l->append(nullptr, (size_t)((512 - e->size % 512) % 512));   // tar.Writer pads at the next header
+    }
+    return l->sink_error();
+}
+
+int mi_layer_add_whiteout(mi_layer* l, const char* deleted_path) {
+    if (!l || !deleted_path) return MI_ERR_INVALID;
+    if (l->finished || l->failed) return l->fail(MI_ERR_STATE, "layer is finished or failed");
+    // memLayer.addWhiteout (mem_layer.go:213-228): <dir>/.wh.<base>, a zero header with only a Name
+    std::string p = trim_left_slashes(deleted_path);
+    while (!p.empty() && p.back() == '/') p.pop_back();
+    const size_t slash = p.rfind('/');
+    const std::string base = slash == std::string::npos ? p : p.substr(slash + 1);
+    if (base.empty()) return l->fail(MI_ERR_INVALID, "whiteout of the root");
+    if (base.compare(0, 4, ".wh.") == 0)
+        return l->fail(MI_ERR_INVALID, "base name contains whiteout prefix: %s", deleted_path);
+    Hdr h;
+    h.name = (slash == std::string::npos ? "" : p.substr(0, slash + 1)) + ".wh." + base;
+    h.typeflag = '0';                                           // TypeRegA promoted to TypeReg by WriteHeader
+    int rc = add_header(l, h);
+    return rc ? rc : l->sink_error();
+}
+
+int mi_layer_finish(mi_layer* l, mi_layer_result* out) {
+    if (!l || !out) return MI_ERR_INVALID;
+    if (l->finished) return l->fail(MI_ERR_STATE, "layer already finished");
+    l->finished = true;
+    if (!l->failed) l->append(nullptr, 1024);                   // tar.Writer.Close: two zero blocks
+    l->flush_block();
+    l->tar.close();
+    if (l->gz) l->gz->close();
+    if (l->failed) return MI_ERR_STATE;
+    int rc = l->sink_error();
+    if (rc) return rc;
+    memset(out, 0, sizeof *out);
+    memcpy(out->tar_sha256, l->tar.digest, 32);
+    out->tar_bytes = l->tar.bytes;
+    out->n_entries = l->n_entries;
+    if (l->gz) {
+        memcpy(out->gzip_sha256, l->gz->digest, 32);
+        out->gzip_bytes = l->gz->bytes;
+    }
+    return MI_OK;
+}
+
+void mi_layer_free(mi_layer* l) {
+    if (!l) return;
+    if (!l->finished) {                                         // abandon: stop the sink threads
+        l->tar.close();
+        if (l->gz) l->gz->close();
+    }
+    delete l;
+}
+
+int mi_layer_header_bytes(const mi_tree_entry* e, uint8_t* out, uint64_t cap, uint64_t* n) {
+    if (!e || !e->relpath || !n) return MI_ERR_INVALID;
+    Hdr h;
+    h.name = trim_left_slashes(e->relpath);
+    h.mode = tar_mode(e->mode);
+    h.uid = e->uid;
+    h.gid = e->gid;
+    h.mtime = e->mtime_sec;
+    if (e->kind == 0) { h.typeflag = '5'; if (h.name.empty() || h.name.back() != '/') h.name += "/"; }
+    else if (e->kind == 1) { h.typeflag = '0'; h.size = (int64_t)e->size; }
+    else if (e->kind == 2 || e->kind == 3) { h.typeflag = e->kind == 2 ? '2' : '1'; h.linkname = e->link_target ? e->link_target : ""; }
+    else return MI_ERR_INVALID;
+    Bytes hb;
+    std::string err;
+    if (!format_header(h, &hb, &err)) return MI_ERR_INVALID;
+    *n = hb.size();
+    if (cap < hb.size()) return MI_ERR_CAPACITY;
+    if (out) memcpy(out, hb.data(), hb.size());
+    return MI_OK;
+}
+
+// ---- cache entry codec (lib/cache/cache_manager.go:34-35, 239-252) ---------------------------
+static const char kCachePrefix[] = "makisu_builder_cache_";
+static const char kCacheEmpty[] = "MAKISU_CACHE_EMPTY";
+
+int mi_cache_key(const char* cache_id, char* out, uint64_t cap) {
+    if (!cache_id || !out) return MI_ERR_INVALID;
+    const size_t need = sizeof kCachePrefix - 1 + strlen(cache_id) + 1;
+    if (cap < need) return MI_ERR_CAPACITY;
+    snprintf(out, (size_t)cap, "%s%s", kCachePrefix, cache_id);
+    return MI_OK;
+}
+
+static void hex32(const uint8_t* d, char* out) {
+    static const char* x = "0123456789abcdef";
+    for (int i = 0; i < 32; ++i) { out[2 * i] = x[d[i] >> 4]; out[2 * i + 1] = x[d[i] & 15]; }
+    out[64] = 0;
+}
+
+int mi_cache_create_entry(const uint8_t* tar_sha256, const uint8_t* gzip_sha256, char* out, uint64_t cap) {
+    if (!out) return MI_ERR_INVALID;
+    if (!tar_sha256 && !gzip_sha256) {                          // createEntry(nil): the step made no layer
+        if (cap < sizeof kCacheEmpty) return MI_ERR_CAPACITY;
+        memcpy(out, kCacheEmpty, sizeof kCacheEmpty);
+        return MI_OK;
+    }
+    if (!tar_sha256 || !gzip_sha256) return MI_ERR_INVALID;
+    if (cap < 130) return MI_ERR_CAPACITY;
+    hex32(tar_sha256, out);
+    out[64] = ',';
+    hex32(gzip_sha256, out + 65);
+    return MI_OK;
+}
+
+static int unhex32(const char* s, uint8_t* out) {
+    for (int i = 0; i < 32; ++i) {
+        int v = 0;
+        for (int k = 0; k < 2; ++k) {
+            const char ch = s[2 * i + k];
+            int d;
+            if (ch >= '0' && ch <= '9') d = ch - '0';
+            else if (ch >= 'a' && ch <= 'f') d = ch - 'a' + 10;
+            else if (ch >= 'A' && ch <= 'F') d = ch - 'A' + 10;
+            else return -1;
+            v = v * 16 + d;
+        }
+        out[i] = (uint8_t)v;
+    }
+    return 0;
+}
+
+int mi_cache_parse_entry(const char* entry, int* is_empty, uint8_t* tar_sha256, uint8_t* gzip_sha256) {
+    if (!entry || !is_empty || !tar_sha256 || !gzip_sha256) return MI_ERR_INVALID;
+    *is_empty = 0;
+    if (strcmp(entry, kCacheEmpty) == 0) { *is_empty = 1; return MI_OK; }   // PullCache returns (nil, nil)
+    const char* comma = strchr(entry, ',');
+    if (!comma) return MI_ERR_INVALID;                          // parseEntry: "parse redis entry"
+    // SplitN(entry, ",", 2): both halves must be sha256 hex for the digests to mean anything
+    if (comma - entry != 64 || strlen(comma + 1) != 64) return MI_ERR_INVALID;
+    if (unhex32(entry, tar_sha256) || unhex32(comma + 1, gzip_sha256)) return MI_ERR_INVALID;
+    return MI_OK;
+}
+
+}  // extern "C"

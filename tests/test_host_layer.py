@@ -1,0 +1,255 @@
+"""CPU tests of the layer writer (mi_layer_*, csrc/mi_layer.hip): tar framing + the two stream
+digests of step.tarAndGzipDiffs / commitLayer (lib/builder/step/common.go:35-111), and the cache
+entry codec (lib/cache/cache_manager.go:239-252).
+
+Pins available here: the empty layer (1024 zero bytes -> 5f70bf18..., the constant the reference
+holds at lib/docker/image/const_darwin.go:18), read-back of every field through python tarfile and
+GNU tar (the reference's own write_test.go round-trips through the tar command the same way), and
+agreement with the oracle's independent ustar header writer.  Byte parity with Go's archive/tar is
+UNPINNED (no Go toolchain in this environment).
+"""
+import gzip
+import hashlib
+import io
+import os
+import shutil
+import subprocess
+import tarfile
+
+import pytest
+
+import makisu_amd as M
+
+EMPTY_TAR_TRAILER_DIGEST = "5f70bf18a086007016e948b04aed3b82103a36bea41755b6cddfaf10ace3c6ef"
+
+
+def _build_tree(root):
+    os.makedirs(root / "bin")
+    os.makedirs(root / "etc" / "deep" / "er")
+    os.makedirs(root / "empty-dir")
+    (root / "bin" / "tool").write_bytes(os.urandom(300000))
+    (root / "bin" / "tool").chmod(0o4755)                     # setuid survives (FileInfoHeader c_ISUID)
+    (root / "etc" / "passwd").write_bytes(b"root:x:0:0\n")
+    (root / "etc" / "empty").write_bytes(b"")
+    (root / "etc" / "exact512").write_bytes(b"z" * 512)
+    (root / "etc" / "deep" / "er" / "x.conf").write_bytes(b"k=v\n" * 1000)
+    os.symlink("passwd", root / "etc" / "alias")
+    os.symlink(str(root / "etc" / "passwd"), root / "etc" / "abs-alias")   # the scan walk root-trims it to /etc/passwd
+    long_dir = root / ("d" * 60) / ("e" * 60)
+    os.makedirs(long_dir)
+    (long_dir / ("f" * 30)).write_bytes(b"split me")          # 152 chars: USTAR prefix/name split
+    (long_dir / ("g" * 120)).write_bytes(b"pax path")         # base name > 100: PAX "path" record
+    (root / "café.txt").write_bytes(b"non-ascii name")   # PAX "path" record
+    os.utime(root / "etc" / "passwd", (1_500_000_000.75, 1_500_000_000.75))
+
+
+def _write_layer(tmp_path, root, gzip_level, blacklist=()):
+    ents = M.tree_walk(str(root), None, blacklist, M.TREE_SCAN, full=True)
+    ents = [e for e in ents if e["relpath"] not in (".", "")]
+    order = M.commit_order([e["relpath"] for e in ents])
+    out = tmp_path / ("layer.%d" % gzip_level)
+    fd = os.open(out, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+    try:
+        with M.Layer(out_fd=fd, gzip_level=gzip_level) as layer:
+            for k in order:
+                e = ents[k]
+                layer.add(e, os.path.join(str(root), e["relpath"]) if e["kind"] == M.KIND_FILE else None)
+            pair = layer.finish()
+    finally:
+        os.close(fd)
+    return ents, [ents[k] for k in order], pair, out.read_bytes()
+
+
+def test_empty_layer_is_the_go_tar_trailer():
+    with M.Layer(gzip_level=M.GZIP_OFF) as layer:
+        pair = layer.finish()
+    assert pair["tar_bytes"] == 1024 and pair["n_entries"] == 0
+    assert pair["tar_digest"] == "sha256:" + EMPTY_TAR_TRAILER_DIGEST
+    assert hashlib.sha256(bytes(1024)).hexdigest() == EMPTY_TAR_TRAILER_DIGEST
+    with M.Layer() as layer:                                   # with the gzip leg: same tar digest
+        pair = layer.finish()
+    assert pair["tar_digest"].hex() == EMPTY_TAR_TRAILER_DIGEST and pair["gzip_bytes"] > 0
+
+
+@pytest.mark.parametrize("level", [M.GZIP_OFF, 0, 1, M.GZIP_DEFAULT, 9])
+def test_layer_reads_back_and_digests_match(tmp_path, level):
+    root = tmp_path / "rootfs"
+    root.mkdir()
+    _build_tree(root)
+    ents, ordered, pair, blob = _write_layer(tmp_path, root, level)
+    if level == M.GZIP_OFF:
+        tar_bytes = blob
+        assert pair["gzip_digest"] is None
+    else:
+        assert hashlib.sha256(blob).hexdigest() == pair["gzip_digest"].hex()      # gzipDigester
+        assert len(blob) == pair["gzip_bytes"]                                    # GzipDescriptor.Size
+        tar_bytes = gzip.decompress(blob)
+    assert hashlib.sha256(tar_bytes).hexdigest() == pair["tar_digest"].hex()      # tarDigester
+    assert len(tar_bytes) == pair["tar_bytes"] and len(tar_bytes) % 512 == 0
+    assert tar_bytes[-1024:] == bytes(1024)
+    assert pair["n_entries"] == len(ents)
+    with tarfile.open(fileobj=io.BytesIO(tar_bytes)) as tf:
+        members = tf.getmembers()
+        assert len(members) == len(ordered)
+        for m, e in zip(members, ordered):                    # commit order, field for field
+            want = e["relpath"] + ("/" if e["kind"] == M.KIND_DIR else "")
+            assert m.name.rstrip("/") == e["relpath"] and not m.name.startswith("/")
+            assert (m.isdir(), m.isreg(), m.issym()) == (e["kind"] == 0, e["kind"] == 1, e["kind"] == 2), want
+            assert m.mode == e["mode"] & 0o7777
+            assert (m.uid, m.gid) == (e["uid"], e["gid"])
+            assert m.mtime == e["mtime_sec"]                  # whole seconds (write.go:62)
+            assert m.uname == "" and m.gname == ""            # mem_layer.go:161-162
+            if e["kind"] == M.KIND_FILE:
+                assert m.size == e["size"]
+                assert tf.extractfile(m).read() == (root / e["relpath"]).read_bytes()
+            else:
+                assert m.size == 0
+            if e["kind"] == M.KIND_SYMLINK:
+                assert m.linkname == e["link_target"]
+    names = [e["relpath"] for e in ordered]
+    assert names == sorted(names, key=lambda p: ("/" + p))    # sort.Strings over absolute paths
+
+
+def test_directory_names_carry_a_trailing_slash_and_formats(tmp_path):
+    d = {"relpath": "/usr/lib", "kind": M.KIND_DIR, "mode": 0o40755, "mtime_sec": 7}
+    h = M.layer_header_bytes(d)
+    assert len(h) == 512 and h[:8] == b"usr/lib/" and h[156:157] == b"5"
+    assert h[257:265] == b"ustar\x0000"
+    assert h[100:108] == b"0000755\x00" and h[124:136] == b"00000000000\x00" and h[136:148] == b"00000000007\x00"
+    assert h[329:337] == b"0000000\x00" and h[337:345] == b"0000000\x00"      # Devmajor/Devminor via templateV7Plus
+    assert h[154:156] == b"\x00 "                              # checksum: 6 digits, NUL, space
+    assert int(h[148:154], 8) == sum(h[:148]) + 8 * 32 + sum(h[156:])
+    # prefix split exactly like splitUSTARPath
+    name = "p" * 90 + "/" + "s" * 60
+    h = M.layer_header_bytes({"relpath": name, "kind": M.KIND_FILE, "mode": 0o644, "size": 3})
+    assert len(h) == 512 and h[:60] == b"s" * 60 and h[60] == 0 and h[345:345 + 90] == b"p" * 90
+    # unsplittable long name -> PAX record file first
+    name = "q" * 130
+    h = M.layer_header_bytes({"relpath": name, "kind": M.KIND_FILE, "mode": 0o600, "size": 5})
+    assert len(h) == 1536 and h[156:157] == b"x" and h[:13] == b"PaxHeaders.0/"
+    rec = b"%d path=%s\n" % (len(name) + 10, name.encode())
+    assert h[512:512 + len(rec)] == rec and int(h[124:135], 8) == len(rec)
+    assert h[1024:1024 + 100] == name.encode()[:100] and h[1024 + 156:1024 + 157] == b"0"
+    # large uid -> PAX uid record, field zeroed
+    h = M.layer_header_bytes({"relpath": "f", "kind": M.KIND_FILE, "mode": 0o600, "size": 1, "uid": 3000000})
+    assert len(h) == 1536 and b" uid=3000000\n" in h[512:1024] and h[1024 + 108:1024 + 116] == b"0000000\x00"
+
+
+def test_headers_agree_with_the_oracles_independent_writer(oracle):
+    """Two restatements of the ustar layout written separately (product C++, oracle C) must agree
+    wherever the oracle's simpler writer applies: regular files, uid/gid 0, ASCII names."""
+    for name in ("a", "dir/file.txt", "x" * 100, "p" * 80 + "/" + "s" * 90, "a/" * 70 + "end"):
+        for size, mtime, mode in ((0, 0, 0o644), (12345, 1_600_000_000, 0o755), (8 << 30 - 1, 1, 0o600)):
+            mine = M.layer_header_bytes({"relpath": name, "kind": M.KIND_FILE, "mode": mode, "size": size,
+                                         "mtime_sec": mtime})
+            try:
+                ref = oracle.tar_header(name, size, mtime, mode)
+            except ValueError:
+                assert len(mine) > 512                         # the oracle gives up where Go switches to PAX
+                continue
+            assert mine == ref, name
+
+
+def test_gnu_tar_extracts_the_layer(tmp_path):
+    if not shutil.which("tar"):
+        pytest.skip("no tar binary")
+    root = tmp_path / "rootfs"
+    root.mkdir()
+    _build_tree(root)
+    _, ordered, pair, blob = _write_layer(tmp_path, root, M.GZIP_DEFAULT)
+    (tmp_path / "layer.tgz").write_bytes(blob)
+    out = tmp_path / "extracted"
+    out.mkdir()
+    subprocess.check_call(["tar", "-xzf", str(tmp_path / "layer.tgz"), "-C", str(out), "--no-same-owner"])
+    for e in ordered:
+        p = out / e["relpath"]
+        if e["kind"] == M.KIND_FILE:
+            assert p.read_bytes() == (root / e["relpath"]).read_bytes()
+            assert int(os.lstat(p).st_mtime) == e["mtime_sec"]
+        elif e["kind"] == M.KIND_SYMLINK:
+            assert os.readlink(p) == e["link_target"]
+        else:
+            assert p.is_dir()
+
+
+def test_whiteouts_hardlinks_and_errors(tmp_path):
+    src = tmp_path / "data"
+    src.write_bytes(b"0123456789")
+    fd = os.open(tmp_path / "l.tar", os.O_WRONLY | os.O_CREAT, 0o644)
+    with M.Layer(out_fd=fd, gzip_level=M.GZIP_OFF) as layer:
+        layer.add({"relpath": "/opt", "kind": M.KIND_DIR, "mode": 0o755, "mtime_sec": 5})
+        layer.add_whiteout("/opt/gone")
+        layer.add({"relpath": "opt/data", "kind": M.KIND_FILE, "mode": 0o640, "size": 10, "uid": 7, "gid": 8}, str(src))
+        layer.add({"relpath": "opt/hard", "kind": M.KIND_HARDLINK, "mode": 0o640, "link_target": "opt/data"})
+        with pytest.raises(M.MiError) as ei:
+            layer.add_whiteout("/opt/.wh.already")             # mem_layer.go:216-218
+        assert "whiteout prefix" in str(ei.value)
+    os.close(fd)
+    # a failed layer stays failed; build it again without the bad call
+    fd = os.open(tmp_path / "l.tar", os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+    with M.Layer(out_fd=fd, gzip_level=M.GZIP_OFF) as layer:
+        layer.add({"relpath": "/opt", "kind": M.KIND_DIR, "mode": 0o755, "mtime_sec": 5})
+        layer.add_whiteout("/opt/gone")
+        layer.add({"relpath": "opt/data", "kind": M.KIND_FILE, "mode": 0o640, "size": 10, "uid": 7, "gid": 8}, str(src))
+        layer.add({"relpath": "opt/hard", "kind": M.KIND_HARDLINK, "mode": 0o640, "link_target": "opt/data"})
+        pair = layer.finish()
+    os.close(fd)
+    raw = (tmp_path / "l.tar").read_bytes()
+    assert hashlib.sha256(raw).hexdigest() == pair["tar_digest"].hex()
+    with tarfile.open(tmp_path / "l.tar") as tf:
+        m = {x.name: x for x in tf.getmembers()}
+        wh = m["opt/.wh.gone"]
+        assert wh.isreg() and wh.size == 0 and wh.mode == 0 and wh.mtime == 0 and wh.uid == 0   # zero header
+        assert m["opt/hard"].islnk() and m["opt/hard"].linkname == "opt/data"
+        assert (m["opt/data"].uid, m["opt/data"].gid) == (7, 8)
+    # CopyN semantics: a source shorter than the header's size is an error, a longer one is cut
+    with M.Layer(gzip_level=M.GZIP_OFF) as layer:
+        with pytest.raises(M.MiError) as ei:
+            layer.add({"relpath": "short", "kind": M.KIND_FILE, "mode": 0o600, "size": 11}, str(src))
+        assert ei.value.code == -5 and "EOF" in str(ei.value)
+    with M.Layer(gzip_level=M.GZIP_OFF) as layer:
+        layer.add({"relpath": "cut", "kind": M.KIND_FILE, "mode": 0o600, "size": 4}, str(src))
+        pair = layer.finish()
+        assert pair["tar_bytes"] == 512 + 512 + 1024
+    with M.Layer(gzip_level=M.GZIP_OFF) as layer:
+        with pytest.raises(M.MiError) as ei:
+            layer.add({"relpath": "dev/null", "kind": 4, "mode": 0o666})         # write.go:49-51
+        assert "unsupported type" in str(ei.value)
+    with M.Layer(gzip_level=M.GZIP_OFF) as layer:
+        with pytest.raises(M.MiError) as ei:
+            layer.add({"relpath": "nope", "kind": M.KIND_FILE, "mode": 0o600, "size": 1}, str(tmp_path / "missing"))
+        assert ei.value.code == -5 and "open src file" in str(ei.value)
+
+
+def test_big_file_spans_many_blocks(tmp_path):
+    big = tmp_path / "big"
+    data = os.urandom(5 * (1 << 20) + 777)
+    big.write_bytes(data)
+    fd = os.open(tmp_path / "b.tgz", os.O_WRONLY | os.O_CREAT, 0o644)
+    with M.Layer(out_fd=fd, gzip_level=1) as layer:
+        layer.add({"relpath": "big", "kind": M.KIND_FILE, "mode": 0o644, "size": len(data)}, str(big))
+        pair = layer.finish()
+    os.close(fd)
+    tar_bytes = gzip.decompress((tmp_path / "b.tgz").read_bytes())
+    assert hashlib.sha256(tar_bytes).hexdigest() == pair["tar_digest"].hex()
+    assert tar_bytes[512:512 + len(data)] == data
+
+
+def test_cache_entry_codec():
+    """createEntry / parseEntry / the key prefix (lib/cache/cache_manager.go:34-35,239-252)."""
+    assert M.cache_key("abc123") == "makisu_builder_cache_abc123"
+    t, g = hashlib.sha256(b"tar").digest(), hashlib.sha256(b"gz").digest()
+    entry = M.cache_create_entry(t, g)
+    assert entry == "%s,%s" % (t.hex(), g.hex())
+    td, gd = M.cache_parse_entry(entry)
+    assert td == "sha256:" + t.hex() and gd == "sha256:" + g.hex() and td.hex() == t.hex()
+    assert M.cache_create_entry() == "MAKISU_CACHE_EMPTY"      # createEntry(nil)
+    assert M.cache_parse_entry("MAKISU_CACHE_EMPTY") is None   # PullCache -> (nil, nil)
+    for bad in ("", "nocomma", t.hex(), t.hex() + "," + "zz" * 32, t.hex()[:-1] + "," + g.hex()):
+        with pytest.raises(ValueError):
+            M.cache_parse_entry(bad)
+    # the layer writer's pair feeds the codec directly
+    with M.Layer() as layer:
+        pair = layer.finish()
+    e = M.cache_create_entry(pair["tar_sha256"], pair["gzip_sha256"])
+    assert M.cache_parse_entry(e) == (pair["tar_digest"], pair["gzip_digest"])
