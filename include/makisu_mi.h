@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 1
+#define MI_ABI_VERSION 2
 
 enum {
     MI_OK = 0,
@@ -328,6 +328,19 @@ int mi_entry_similar(const mi_tree_entry* a, const mi_tree_entry* b, int ignore_
  * are.  Strings live until mi_tar_free.  Host logic.                                        */
 typedef struct mi_tar mi_tar;
 int  mi_tar_open(const char* path, mi_tar** out, uint64_t* n_entries);
+/* The same with the failure reason as text (err, err_cap; nothing is printed anywhere) and
+ * *is_gzip = 1 when `path` is a gzip blob -- the form layers are stored and pulled in
+ * (tario.NewGzipReader, lib/tario/gzip.go:50-53; lib/builder/build_node.go:133-148).  A gzip blob is
+ * listed through a streaming inflate; its data offsets are offsets in the UNCOMPRESSED tar.   */
+int  mi_tar_open_ex(const char* path, mi_tar** out, uint64_t* n_entries, int* is_gzip, char* err,
+                    uint64_t err_cap);
+/* gzip blob -> the uncompressed tar at tar_path_out (NULL = digests only), its size and SHA-256
+ * (the layer's TarDigest / diffID) and, optionally, the blob's own SHA-256 (GzipDescriptor.Digest):
+ * the reference's fixture pair 393ccd5c... / 4ac76077... (lib/utils/testutil/constants.go:28) is
+ * the test.  Then mi_tar_open(tar_path_out) + mi_batch_add_path_range scan the members.  A plain
+ * tar is copied through unchanged.  Host logic (zlib, SHA-NI).                                */
+int  mi_tar_inflate(const char* blob_path, const char* tar_path_out, uint64_t* tar_bytes,
+                    uint8_t* tar_sha256, uint8_t* blob_sha256, char* err, uint64_t err_cap);
 int  mi_tar_entries(const mi_tar* tar, mi_tree_entry* out, uint64_t* data_offsets, uint64_t cap);
 void mi_tar_free(mi_tar* tar);
 
@@ -342,6 +355,18 @@ void mi_tar_free(mi_tar* tar);
 int mi_entries_apply_layer(const mi_tree_entry* base, uint64_t n_base, const mi_tree_entry* layer,
                            uint64_t n_layer, uint8_t* from_layer, uint64_t* index, uint64_t cap,
                            uint64_t* n_out);
+/* The same with UpdateFromTarReader's per-header filter (mem_fs.go:190-199): with `root` = the
+ * directory the layers are (or would be) untarred to, a header is dropped when shouldSkip says so
+ * for filepath.Join(root, name) -- ".wh..wh." AUFS metadata, blacklist descendants, special files
+ * (kind 4), mountpoints -- or when it lies under a mountpoint (mountutils.IsMounted).  Use it for
+ * base layers, so that /proc, /sys, /dev nodes or /etc/resolv.conf of the base image never enter
+ * the "before" side of mi_snapshot_diff (the scan walk skips them too).  Hard links are applied
+ * in a second pass after all other entries (:219-236).  root NULL = no filter.               */
+int mi_entries_apply_layer_filtered(const mi_tree_entry* base, uint64_t n_base,
+                                    const mi_tree_entry* layer, uint64_t n_layer, const char* root,
+                                    const char* const* blacklist, uint64_t n_blacklist,
+                                    uint8_t* from_layer, uint64_t* index, uint64_t cap,
+                                    uint64_t* n_out);
 
 /* The layer diff of a scan, on two walks -- what MemFS.createLayerByScan + maybeAddToLayer
  * (lib/snapshot/mem_fs.go:315-341, 440-480) decide against the in-memory tree:
@@ -364,6 +389,12 @@ typedef struct {
     uint64_t             n;
     const void*          roots;        /* may be NULL */
     uint64_t             root_stride;
+    const char*          disk_root;    /* `after` side only, may be NULL: the directory that was walked.
+                                          When given, a path missing from `after` is whited out only
+                                          if it is really gone from disk (memFSNode.isOnDisk,
+                                          mem_fs.go:49-57,466) -- a path the walk now SKIPS (a new
+                                          mountpoint, a blacklisted directory) still exists and gets
+                                          no whiteout.                                              */
 } mi_snapshot_side;
 int mi_snapshot_diff(const mi_snapshot_side* before, const mi_snapshot_side* after, int ignore_time,
                      uint8_t* after_flags, uint8_t* before_whiteout);

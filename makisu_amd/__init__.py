@@ -68,7 +68,7 @@ TREE_CONTEXT, TREE_SCAN = 0, 1
 class SnapshotSide(C.Structure):
     """mi_snapshot_side: one walk (+ optional chunk roots by file_index) for mi_snapshot_diff."""
     _fields_ = [("entries", C.POINTER(TreeEntry)), ("n", C.c_uint64), ("roots", C.c_void_p),
-                ("root_stride", C.c_uint64)]
+                ("root_stride", C.c_uint64), ("disk_root", C.c_char_p)]
 
 
 DIFF_SAME, DIFF_CHANGED, DIFF_ANCESTOR = 0, 1, 2
@@ -175,7 +175,11 @@ def load_library(rebuild=False):
         "mi_snapshot_diff": ([C.POINTER(SnapshotSide), C.POINTER(SnapshotSide), C.c_int, vp, vp], C.c_int),
         "mi_entries_apply_layer": ([C.POINTER(TreeEntry), u64, C.POINTER(TreeEntry), u64, vp, u64p, u64, u64p],
                                    C.c_int),
+        "mi_entries_apply_layer_filtered": ([C.POINTER(TreeEntry), u64, C.POINTER(TreeEntry), u64, C.c_char_p,
+                                             C.POINTER(C.c_char_p), u64, vp, u64p, u64, u64p], C.c_int),
         "mi_tar_open": ([C.c_char_p, C.POINTER(vp), u64p], C.c_int),
+        "mi_tar_open_ex": ([C.c_char_p, C.POINTER(vp), u64p, C.POINTER(C.c_int), C.c_char_p, u64], C.c_int),
+        "mi_tar_inflate": ([C.c_char_p, C.c_char_p, u64p, vp, vp, C.c_char_p, u64], C.c_int),
         "mi_tar_entries": ([vp, C.POINTER(TreeEntry), u64p, u64], C.c_int),
         "mi_tar_free": ([vp], None),
         "mi_entry_similar": ([C.POINTER(TreeEntry), C.POINTER(TreeEntry), C.c_int, vp, vp,
@@ -272,9 +276,10 @@ def tar_entries(path):
     tree_walk(full=True) plus "data_offset": where a regular file's bytes start in the archive)."""
     L = load_library()
     h, n = C.c_void_p(), C.c_uint64()
-    rc = L.mi_tar_open(os.fsencode(path), C.byref(h), C.byref(n))
+    err = C.create_string_buffer(512)
+    rc = L.mi_tar_open_ex(os.fsencode(path), C.byref(h), C.byref(n), None, err, len(err))
     if rc:
-        raise MiError(rc, "mi_tar_open(%s)" % path)
+        raise MiError(rc, "mi_tar_open: %s" % err.value.decode(errors="replace"))
     try:
         arr = (TreeEntry * max(n.value, 1))()
         offs = (C.c_uint64 * max(n.value, 1))()
@@ -291,6 +296,20 @@ def tar_entries(path):
         L.mi_tar_free(h)
 
 
+def tar_inflate(blob_path, tar_path_out=None):
+    """mi_tar_inflate: a stored (gzip) layer blob -> uncompressed tar file; returns
+    dict(tar_bytes, tar_digest, blob_digest)."""
+    nb = C.c_uint64()
+    t, g = (C.c_uint8 * 32)(), (C.c_uint8 * 32)()
+    err = C.create_string_buffer(512)
+    rc = load_library().mi_tar_inflate(os.fsencode(blob_path),
+                                       os.fsencode(tar_path_out) if tar_path_out is not None else None,
+                                       C.byref(nb), t, g, err, len(err))
+    if rc:
+        raise MiError(rc, "mi_tar_inflate: %s" % err.value.decode(errors="replace"))
+    return {"tar_bytes": nb.value, "tar_digest": Digest.from_raw(t), "blob_digest": Digest.from_raw(g)}
+
+
 def _entry_array(dicts, keep):
     arr = (TreeEntry * max(len(dicts), 1))()
     for i, d in enumerate(dicts):
@@ -305,23 +324,26 @@ def _entry_array(dicts, keep):
     return arr
 
 
-def apply_layer(base, layer):
-    """mi_entries_apply_layer on two lists of entry dicts: the merged list (the dicts themselves, in
-    sorted-path order)."""
+def apply_layer(base, layer, root=None, blacklist=()):
+    """mi_entries_apply_layer[_filtered] on two lists of entry dicts: the merged list (the dicts
+    themselves, in sorted-path order).  root: apply UpdateFromTarReader's skip rules for layers
+    untarred to that directory (blacklist, special files, ".wh..wh." metadata, mounts)."""
     keep = []
     ab, al = _entry_array(base, keep), _entry_array(layer, keep)
     cap = len(base) + len(layer)
     src = np.zeros(max(cap, 1), dtype=np.uint8)
     idx = np.zeros(max(cap, 1), dtype=np.uint64)
     n = C.c_uint64()
-    rc = load_library().mi_entries_apply_layer(ab, len(base), al, len(layer), src.ctypes.data,
-                                               idx.ctypes.data_as(C.POINTER(C.c_uint64)), cap, C.byref(n))
+    bl = (C.c_char_p * max(len(blacklist), 1))(*[os.fsencode(x) for x in blacklist])
+    rc = load_library().mi_entries_apply_layer_filtered(
+        ab, len(base), al, len(layer), os.fsencode(root) if root is not None else None, bl, len(blacklist),
+        src.ctypes.data, idx.ctypes.data_as(C.POINTER(C.c_uint64)), cap, C.byref(n))
     if rc:
         raise MiError(rc, "mi_entries_apply_layer")
     return [(layer if src[k] else base)[int(idx[k])] for k in range(n.value)]
 
 
-def snapshot_diff(before, after, ignore_time=False, roots_before=None, roots_after=None):
+def snapshot_diff(before, after, ignore_time=False, roots_before=None, roots_after=None, disk_root=None):
     """mi_snapshot_diff on two lists of entry dicts (tree_walk(..., full=True)); roots_* = (n_files,
     32) uint8 arrays indexed by file_index, or None.  Returns (flags per `after` entry, whiteout
     flags per `before` entry) as lists of ints."""
@@ -337,6 +359,8 @@ def snapshot_diff(before, after, ignore_time=False, roots_before=None, roots_aft
             keep.append(r)
             side.roots, side.root_stride = r.ctypes.data, 32
         sides.append(side)
+    if disk_root is not None:
+        sides[1].disk_root = os.fsencode(disk_root)
     flags = np.zeros(max(len(after), 1), dtype=np.uint8)
     wh = np.zeros(max(len(before), 1), dtype=np.uint8)
     rc = load_library().mi_snapshot_diff(C.byref(sides[0]), C.byref(sides[1]), int(ignore_time),

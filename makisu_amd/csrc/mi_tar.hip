@@ -8,6 +8,12 @@
 // side of mi_snapshot_diff) together with those ranges, so the files of a pulled layer can be
 // handed to a batch straight out of the archive.
 //
+// Stored layers are gzip blobs (tario.NewGzipReader, lib/tario/gzip.go:50-53; pulled by
+// lib/builder/build_node.go:133-148): mi_tar_open recognises the gzip magic and lists the entries
+// through a streaming inflate (zlib); the data offsets it reports are offsets in the UNCOMPRESSED
+// tar, which mi_tar_inflate writes out (returning its SHA-256 -- the layer's tar digest / diffID)
+// so that mi_batch_add_path_range can read the members from it.
+//
 // Format: POSIX ustar / pax (typeflags 'x' and 'g': path, linkpath, size, uid, gid, mtime) and
 // the GNU extensions Go's archive/tar and docker write (typeflags 'L' / 'K' long name / link,
 // base-256 numeric fields, the old-GNU magic).  Checked against Python's tarfile on ustar, pax
@@ -22,6 +28,9 @@
 #include <string.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <zlib.h>
+
+#include "host_sha256.h"
 
 #include <map>
 #include <string>
@@ -111,26 +120,105 @@ static bool parse_pax(const std::string& body, std::map<std::string, std::string
     return true;
 }
 
-static bool read_at(int fd, uint64_t off, void* dst, size_t n) {
-    size_t got = 0;
-    while (got < n) {
-        ssize_t r = pread(fd, (char*)dst + got, n - got, (off_t)(off + got));
-        if (r < 0 && errno == EINTR) continue;
-        if (r <= 0) return false;
-        got += (size_t)r;
-    }
-    return true;
-}
+// Where the tar bytes come from: a plain file (random access) or a gzip stream (forward only --
+// the parser only ever moves forward).
+struct Source {
+    int fd = -1;
+    bool gz = false;
+    uint64_t size = 0;                 // plain: file size; gzip: unknown until the stream ends
+    // gzip state
+    z_stream z;
+    bool z_ready = false, z_end = false;
+    std::vector<unsigned char> in;
+    uint64_t in_off = 0, pos = 0;      // compressed bytes consumed from fd, uncompressed position
+    std::string error;
 
-static int parse(int fd, uint64_t file_size, Tar* t) {
+    ~Source() { if (z_ready) inflateEnd(&z); }
+
+    bool open_fd(int f) {
+        fd = f;
+        struct stat st;
+        if (fstat(fd, &st) != 0) { error = std::string("stat: ") + strerror(errno); return false; }
+        size = (uint64_t)st.st_size;
+        unsigned char magic[2] = {0, 0};
+        if (size >= 2 && pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
+            gz = true;
+            memset(&z, 0, sizeof z);
+            if (inflateInit2(&z, 15 + 16) != Z_OK) { error = "inflateInit2 failed"; return false; }
+            z_ready = true;
+            in.resize(1 << 20);
+        }
+        return true;
+    }
+    // inflates up to n bytes into dst (dst may be NULL: discard); returns bytes produced
+    size_t inflate_some(unsigned char* dst, size_t n) {
+        static unsigned char sink[1 << 16];
+        size_t made = 0;
+        while (made < n && !z_end) {
+            if (z.avail_in == 0) {
+                const ssize_t r = pread(fd, in.data(), in.size(), (off_t)in_off);
+                if (r < 0 && errno == EINTR) continue;
+                if (r <= 0) { error = "gzip stream ends early"; return made; }
+                in_off += (uint64_t)r;
+                z.next_in = in.data();
+                z.avail_in = (uInt)r;
+            }
+            const size_t want = n - made;
+            unsigned char* out = dst ? dst + made : sink;
+            const size_t room = dst ? want : (want < sizeof sink ? want : sizeof sink);
+            z.next_out = out;
+            z.avail_out = (uInt)(room > 0x40000000u ? 0x40000000u : room);
+            const uInt before = z.avail_out;
+            const int rc = inflate(&z, Z_NO_FLUSH);
+            made += before - z.avail_out;
+            if (rc == Z_STREAM_END) {
+                // concatenated members (pgzip writes one, but RFC 1952 allows several)
+                if (z.avail_in > 0 || in_off < size) { if (inflateReset(&z) != Z_OK) { error = "inflateReset failed"; return made; } }
+                if (z.avail_in == 0 && in_off >= size) z_end = true;
+            } else if (rc != Z_OK && rc != Z_BUF_ERROR) {
+                error = "corrupt gzip stream";
+                return made;
+            }
+        }
+        pos += made;
+        return made;
+    }
+    // exactly n bytes at uncompressed offset off; false at end of data (error empty) or on error
+    bool read_at(uint64_t off, void* dst, size_t n) {
+        if (!gz) {
+            if (off + n > size) return false;
+            size_t got = 0;
+            while (got < n) {
+                const ssize_t r = pread(fd, (char*)dst + got, n - got, (off_t)(off + got));
+                if (r < 0 && errno == EINTR) continue;
+                if (r <= 0) { error = "short read in the archive"; return false; }
+                got += (size_t)r;
+            }
+            return true;
+        }
+        if (off < pos) { error = "gzip source cannot seek backwards"; return false; }
+        while (pos < off) {
+            const uint64_t skip = off - pos;
+            if (inflate_some(nullptr, (size_t)(skip > (1u << 30) ? (1u << 30) : skip)) == 0) return false;
+        }
+        return inflate_some((unsigned char*)dst, n) == n;
+    }
+    // can [off, off+n) exist?  (plain files: bounds check; gzip: only known by reading on)
+    bool has_range(uint64_t off, uint64_t n) const { return gz || off + n <= size; }
+};
+
+static int parse(Source& src, Tar* t) {
     uint64_t off = 0;
     std::map<std::string, std::string> global_pax, next_pax;
     std::string gnu_name, gnu_link;
     bool has_gnu_name = false, has_gnu_link = false;
     int64_t n_regular = 0;
     unsigned char blk[512];
-    while (off + 512 <= file_size) {
-        if (!read_at(fd, off, blk, 512)) { t->error = "short read in the archive"; return MI_ERR_IO; }
+    for (;;) {
+        if (!src.read_at(off, blk, 512)) {
+            if (!src.error.empty()) { t->error = src.error; return MI_ERR_IO; }
+            break;                                             // end of data without the zero blocks
+        }
         if (all_zero(blk)) break;                              // end-of-archive marker
         if (!checksum_ok(blk)) { t->error = "bad tar header checksum at offset " + std::to_string(off); return MI_ERR_INVALID; }
         int64_t size = 0, mode = 0, uid = 0, gid = 0, mtime = 0;
@@ -143,12 +231,15 @@ static int parse(int fd, uint64_t file_size, Tar* t) {
         const uint64_t data = off + 512;
         const uint64_t padded = ((uint64_t)size + 511) & ~511ull;
         if (type == 'x' || type == 'g' || type == 'L' || type == 'K') {           // metadata for the next entry
-            if ((uint64_t)size > (64u << 20) || data + (uint64_t)size > file_size) {
+            if ((uint64_t)size > (64u << 20) || !src.has_range(data, (uint64_t)size)) {
                 t->error = "truncated extended header at offset " + std::to_string(off);
                 return MI_ERR_INVALID;
             }
             std::string body((size_t)size, '\0');
-            if (size && !read_at(fd, data, &body[0], (size_t)size)) { t->error = "short read in the archive"; return MI_ERR_IO; }
+            if (size && !src.read_at(data, &body[0], (size_t)size)) {
+                t->error = src.error.empty() ? "truncated extended header at offset " + std::to_string(off) : src.error;
+                return MI_ERR_INVALID;
+            }
             if (type == 'L' || type == 'K') {
                 const std::string v = body.substr(0, body.find('\0'));
                 if (type == 'L') { gnu_name = v; has_gnu_name = true; }
@@ -201,7 +292,7 @@ static int parse(int fd, uint64_t file_size, Tar* t) {
         it.data_off = it.kind == 1 ? data : 0;
         const uint64_t skip = (it.kind == 1 || has_data) ? (((uint64_t)size + 511) & ~511ull) : 0;
         if (it.kind == 1) {
-            if (data + (uint64_t)size > file_size) { t->error = "entry " + it.name + " runs past the end of the archive"; return MI_ERR_INVALID; }
+            if (!src.has_range(data, (uint64_t)size)) { t->error = "entry " + it.name + " runs past the end of the archive"; return MI_ERR_INVALID; }
             it.file_index = n_regular++;
         }
         t->items.push_back(it);
@@ -242,23 +333,102 @@ struct mi_tar {
 
 extern "C" {
 
-int mi_tar_open(const char* path, mi_tar** out, uint64_t* n_entries) {
+static void put_err(char* err, uint64_t cap, const std::string& msg) {
+    if (err && cap) snprintf(err, (size_t)cap, "%s", msg.c_str());
+}
+
+int mi_tar_open_ex(const char* path, mi_tar** out, uint64_t* n_entries, int* is_gzip, char* err, uint64_t err_cap) {
     if (!path || !out) return MI_ERR_INVALID;
     const int fd = open(path, O_RDONLY | O_CLOEXEC);
-    if (fd < 0) return MI_ERR_IO;
-    struct stat st;
-    if (fstat(fd, &st) != 0) { close(fd); return MI_ERR_IO; }
+    if (fd < 0) { put_err(err, err_cap, std::string("open ") + path + ": " + strerror(errno)); return MI_ERR_IO; }
     mi_tar* h = new mi_tar();
-    const int rc = mi_tarfile::parse(fd, (uint64_t)st.st_size, &h->t);
+    int rc;
+    {
+        mi_tarfile::Source src;
+        if (!src.open_fd(fd)) { h->t.error = src.error; rc = MI_ERR_IO; }
+        else {
+            rc = mi_tarfile::parse(src, &h->t);
+            if (is_gzip) *is_gzip = src.gz ? 1 : 0;
+        }
+    }
     close(fd);
     if (rc) {
-        fprintf(stderr, "mi_tar_open(%s): %s\n", path, h->t.error.c_str());
+        put_err(err, err_cap, std::string(path) + ": " + h->t.error);
         delete h;
         return rc;
     }
     for (const mi_tarfile::Item& it : h->t.items) h->rel.push_back(mi_tarfile::rel_name(it.name));
     *out = h;
     if (n_entries) *n_entries = h->t.items.size();
+    return MI_OK;
+}
+
+int mi_tar_open(const char* path, mi_tar** out, uint64_t* n_entries) {
+    return mi_tar_open_ex(path, out, n_entries, nullptr, nullptr, 0);
+}
+
+// gzip blob -> uncompressed tar file + its SHA-256 (the layer's tar digest).  A plain tar is copied.
+int mi_tar_inflate(const char* blob_path, const char* tar_path_out, uint64_t* tar_bytes, uint8_t* tar_sha256,
+                   uint8_t* blob_sha256, char* err, uint64_t err_cap) {
+    if (!blob_path) return MI_ERR_INVALID;
+    const int fd = open(blob_path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) { put_err(err, err_cap, std::string("open ") + blob_path + ": " + strerror(errno)); return MI_ERR_IO; }
+    int ofd = -1;
+    if (tar_path_out) {
+        ofd = open(tar_path_out, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0644);
+        if (ofd < 0) {
+            put_err(err, err_cap, std::string("create ") + tar_path_out + ": " + strerror(errno));
+            close(fd);
+            return MI_ERR_IO;
+        }
+    }
+    int rc = MI_OK;
+    uint64_t total = 0;
+    mi_host::Sha256 sha_tar, sha_blob;
+    {
+        mi_tarfile::Source src;
+        std::vector<unsigned char> buf(1 << 20);
+        if (!src.open_fd(fd)) { put_err(err, err_cap, src.error); rc = MI_ERR_IO; }
+        while (!rc) {
+            size_t got;
+            if (src.gz) {
+                got = src.inflate_some(buf.data(), buf.size());
+                if (!src.error.empty()) { put_err(err, err_cap, std::string(blob_path) + ": " + src.error); rc = MI_ERR_INVALID; break; }
+            } else {
+                const uint64_t left = src.size - total;
+                got = (size_t)(left < buf.size() ? left : buf.size());
+                if (got && !src.read_at(total, buf.data(), got)) { put_err(err, err_cap, src.error); rc = MI_ERR_IO; break; }
+            }
+            if (got == 0) break;
+            sha_tar.update(buf.data(), got);
+            total += got;
+            size_t w = 0;
+            while (ofd >= 0 && w < got) {
+                const ssize_t r = write(ofd, buf.data() + w, got - w);
+                if (r < 0 && errno == EINTR) continue;
+                if (r <= 0) { put_err(err, err_cap, std::string("write ") + tar_path_out + ": " + strerror(errno)); rc = MI_ERR_IO; break; }
+                w += (size_t)r;
+            }
+        }
+    }
+    if (!rc && blob_sha256) {                                   // the blob's own digest (GzipDescriptor.Digest)
+        std::vector<unsigned char> buf(1 << 20);
+        uint64_t off = 0;
+        for (;;) {
+            const ssize_t r = pread(fd, buf.data(), buf.size(), (off_t)off);
+            if (r < 0 && errno == EINTR) continue;
+            if (r < 0) { put_err(err, err_cap, std::string("read ") + blob_path + ": " + strerror(errno)); rc = MI_ERR_IO; break; }
+            if (r == 0) break;
+            sha_blob.update(buf.data(), (size_t)r);
+            off += (uint64_t)r;
+        }
+        if (!rc) sha_blob.final(blob_sha256);
+    }
+    close(fd);
+    if (ofd >= 0) close(ofd);
+    if (rc) return rc;
+    if (tar_bytes) *tar_bytes = total;
+    if (tar_sha256) sha_tar.final(tar_sha256);
     return MI_OK;
 }
 

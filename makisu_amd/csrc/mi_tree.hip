@@ -417,29 +417,65 @@ extern "C" int mi_snapshot_diff(const mi_snapshot_side* before, const mi_snapsho
         const std::string parent = mi_walk::dir_of(kv.first);
         auto pit = new_at.find(parent);
         if (pit == new_at.end() || after->entries[pit->second].kind != 0) continue;   // deeper in a deleted subtree,
-        before_whiteout[kv.second] = 1;                                                // or its parent became a file
+                                                                                       // or its parent became a file
+        if (after->disk_root) {
+            // child.isOnDisk() (mem_fs.go:49-57, 466): a path the walk no longer lists because it is now
+            // skipped (a new mountpoint, a blacklisted dir) is still on disk and gets NO whiteout
+            const std::string on_disk = std::string(after->disk_root) + (kv.first == "/" ? "" : kv.first);
+            struct stat st;
+            if (lstat(on_disk.c_str(), &st) == 0) continue;
+            if (errno != ENOENT && errno != ENOTDIR) return MI_ERR_IO;           // "check on disk"
+        }
+        before_whiteout[kv.second] = 1;
         carry_ancestors(kv.first);
     }
     return MI_OK;
 }
 
-// Applying a layer's entries on top of a tree, the way MemFS.UpdateFromTarReader does entry by
-// entry through untarOneItem (lib/snapshot/mem_fs.go:165-255, 571-660):
+// Applying a layer's entries on top of a tree, the way MemFS.UpdateFromTarReader does header by
+// header (lib/snapshot/mem_fs.go:165-255) through maybeAddToLayer / updateMemFS:
+//   * with a filter (root != NULL) every header first passes the reference's skip rules on
+//     path = filepath.Join(root, hdr.Name): AUFS metadata (".wh..wh." base names), blacklist
+//     descendants, special files (shouldSkip, utils.go:37-52), mountpoints and everything under
+//     one (mountutils.IsMounted) never enter the tree -- so /proc, /dev/null, /etc/resolv.conf of a
+//     base image are not "deleted" later when the scan walk skips them too;
+//   * hard links wait for a second pass after every other entry (:219-236), and their targets
+//     compare as pathutils.AbsPath(linkname) (:214-216);
 //   * a whiteout marker ".wh.<name>" removes <dir>/<name> and everything below it, and is not
-//     itself part of the tree (untarWhiteout :652-660);
+//     itself part of the tree;
 //   * an entry whose header is similar to what is already there changes nothing -- the old entry
-//     (and so the old content) stays (:607-613);
-//   * a directory arriving on a directory only updates the directory, its children stay
-//     (:615-623); anything else replaces the old path together with its subtree (:625-629).
+//     (and so the old content) stays; a directory arriving on a directory only updates the
+//     directory, its children stay; anything else replaces the old path together with its subtree.
 // Output: the merged tree in sorted-path order as (from_layer, index) pairs.
-extern "C" int mi_entries_apply_layer(const mi_tree_entry* base, uint64_t n_base, const mi_tree_entry* layer,
-                                      uint64_t n_layer, uint8_t* from_layer, uint64_t* index, uint64_t cap,
-                                      uint64_t* n_out) {
-    if ((n_base && !base) || (n_layer && !layer) || !n_out || (cap && (!from_layer || !index)))
+extern "C" int mi_entries_apply_layer_filtered(const mi_tree_entry* base, uint64_t n_base,
+                                               const mi_tree_entry* layer, uint64_t n_layer, const char* root,
+                                               const char* const* blacklist, uint64_t n_blacklist,
+                                               uint8_t* from_layer, uint64_t* index, uint64_t cap,
+                                               uint64_t* n_out) {
+    if ((n_base && !base) || (n_layer && !layer) || !n_out || (cap && (!from_layer || !index)) ||
+        (n_blacklist && !blacklist))
         return MI_ERR_INVALID;
     auto path_of = [](const mi_tree_entry& e) {
         const char* rp = e.relpath ? e.relpath : "";
         return mi_walk::abs_path(strcmp(rp, ".") == 0 ? "" : rp);
+    };
+    std::vector<std::string> bl;
+    for (uint64_t i = 0; i < n_blacklist; ++i) bl.push_back(mi_walk::abs_path(blacklist[i] ? blacklist[i] : ""));
+    const std::string root_abs = root ? mi_walk::abs_path(root) : std::string();
+    const mi_walk::MountTable* mt = nullptr;
+    if (root) {
+        mt = &mi_walk::mountpoints();
+        if (!mt->error.empty()) return MI_ERR_IO;                              // "check if mounted"
+    }
+    auto skipped = [&](const mi_tree_entry& e, const std::string& p) {
+        if (!root) return false;
+        const std::string on_disk = root_abs == "/" ? p : root_abs + (p == "/" ? "" : p);
+        if (mi_walk::has_prefix(mi_walk::base_of(p), ".wh..wh.")) return true;
+        if (mi_walk::is_descendant_of_any(on_disk, bl) || e.kind > 3) return true;
+        if (mt->targets.count(on_disk)) return true;
+        for (const std::string& t : mt->targets)                               // isMounted: below a mountpoint
+            if (mi_walk::has_prefix(on_disk, t.back() == '/' ? t : t + "/")) return true;
+        return false;
     };
     struct Ref { uint8_t side; uint64_t idx; };
     std::map<std::string, Ref> tree;
@@ -450,24 +486,38 @@ extern "C" int mi_entries_apply_layer(const mi_tree_entry* base, uint64_t n_base
         for (auto it = tree.lower_bound(pre); it != tree.end() && mi_walk::has_prefix(it->first, pre);)
             it = tree.erase(it);
     };
-    for (uint64_t j = 0; j < n_layer; ++j) {
-        const std::string p = path_of(layer[j]);
+    auto apply = [&](uint64_t j, const std::string& p) -> int {
         const std::string name = mi_walk::base_of(p);
         if (mi_walk::has_prefix(name, ".wh.")) {
             const std::string dir = mi_walk::dir_of(p);
             remove_subtree((dir == "/" ? "" : dir) + "/" + name.substr(4));
-            continue;
+            return MI_OK;
         }
         auto it = tree.find(p);
         if (it != tree.end()) {
             const mi_tree_entry& old = it->second.side ? layer[it->second.idx] : base[it->second.idx];
             int similar = 0;
-            const int rc = mi_entry_similar(&old, &layer[j], 0, nullptr, nullptr, &similar);
-            if (rc) return rc;
-            if (similar) continue;                                            // already there
+            if (old.kind <= 3 && layer[j].kind <= 3) {                        // special files never compare equal
+                const int rc = mi_entry_similar(&old, &layer[j], 0, nullptr, nullptr, &similar);
+                if (rc) return rc;
+            }
+            if (similar) return MI_OK;                                        // already there
             if (!(old.kind == 0 && layer[j].kind == 0)) remove_subtree(p);    // dir on dir: children stay
         }
         tree[p] = Ref{1, j};
+        return MI_OK;
+    };
+    std::vector<uint64_t> hardlinks;
+    for (uint64_t j = 0; j < n_layer; ++j) {
+        const std::string p = path_of(layer[j]);
+        if (skipped(layer[j], p)) continue;
+        if (layer[j].kind == 3) { hardlinks.push_back(j); continue; }
+        const int rc = apply(j, p);
+        if (rc) return rc;
+    }
+    for (uint64_t j : hardlinks) {
+        const int rc = apply(j, path_of(layer[j]));
+        if (rc) return rc;
     }
     *n_out = tree.size();
     if (cap < tree.size()) return MI_ERR_CAPACITY;
@@ -478,6 +528,13 @@ extern "C" int mi_entries_apply_layer(const mi_tree_entry* base, uint64_t n_base
         ++k;
     }
     return MI_OK;
+}
+
+extern "C" int mi_entries_apply_layer(const mi_tree_entry* base, uint64_t n_base, const mi_tree_entry* layer,
+                                      uint64_t n_layer, uint8_t* from_layer, uint64_t* index, uint64_t cap,
+                                      uint64_t* n_out) {
+    return mi_entries_apply_layer_filtered(base, n_base, layer, n_layer, nullptr, nullptr, 0, from_layer, index,
+                                           cap, n_out);
 }
 
 // tario.IsSimilarHeader (lib/tario/compare.go:24-117) on walk entries, plus the optional
@@ -495,7 +552,11 @@ int mi_entry_similar(const mi_tree_entry* a, const mi_tree_entry* b, int ignore_
     const bool owner_mode_eq = a->uid == b->uid && a->gid == b->gid && (a->mode & 07777u) == (b->mode & 07777u);
     switch (a->kind) {
     case 2: *similar = same_str(a->link_target, b->link_target); break;
-    case 3: *similar = time_eq && same_str(a->link_target, b->link_target) && owner_mode_eq; break;
+    case 3:                                       // UpdateFromTarReader stores AbsPath(Linkname) (mem_fs.go:214-216)
+        *similar = time_eq && owner_mode_eq &&
+                   mi_walk::abs_path(a->link_target ? a->link_target : "") ==
+                       mi_walk::abs_path(b->link_target ? b->link_target : "");
+        break;
     case 0: *similar = time_eq && owner_mode_eq; break;
     default:
         *similar = time_eq && owner_mode_eq && a->size == b->size &&

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol(engine_lib):
 
 def test_abi_version_and_defaults(engine_lib):
     import makisu_amd
-    assert engine_lib.mi_abi_version() == 1
+    assert engine_lib.mi_abi_version() == 2
     cfg = makisu_amd.default_config()
     assert cfg.struct_size == C.sizeof(makisu_amd.Config)
     assert (cfg.gear_seed, cfg.mask_bits, cfg.min_size, cfg.max_size) == (0x4D414B49, 13, 2048, 65536)

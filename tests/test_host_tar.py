@@ -286,3 +286,117 @@ def test_apply_layer_matches_sequential_extraction(tmp_path):
     # the "similar header" quirk: layer 2's usr/bin/tool did NOT replace layer 1's entry
     l1_tool = [e for e in makisu_amd.tar_entries(l1) if e["relpath"] == "usr/bin/tool"][0]
     assert final["usr/bin/tool"]["data_offset"] == l1_tool["data_offset"]
+
+
+# ---- round 2: stored (gzip) layers, UpdateFromTarReader's filter, hard-link pass, isOnDisk ----
+import makisu_amd as M  # noqa: E402
+
+GZ_FIXTURE = "/root/reference/testdata/files/alpine/test_layer.tar"     # a gzip blob despite its name
+GZ_BLOB_SHA = "393ccd5c4dd90344c9d725125e13f636ce0087c62f5ca89050faaacbb9e3ed5b"   # testutil.SampleLayerTarDigest
+GZ_TAR_SHA = "4ac76077f2c741c856a2419dfdb0804b18e48d2e1a9ce9c6a3f0605a2078caba"    # its gunzip
+
+
+@pytest.mark.skipif(not os.path.exists(GZ_FIXTURE), reason="reference fixture not present (GPU box)")
+def test_reference_gzip_layer_blob(tmp_path):
+    """The reference's stored layer blob (lib/utils/testutil/constants.go:28): listed through the
+    streaming inflate, inflated with both digests, and equal to the plain-tar fixture's listing."""
+    gz = M.tar_entries(GZ_FIXTURE)
+    plain = M.tar_entries(FIXTURE)
+    assert len(gz) == len(plain) == 390
+    assert gz == plain                                      # same entries, same uncompressed offsets
+    out = str(tmp_path / "layer.tar")
+    r = M.tar_inflate(GZ_FIXTURE, out)
+    assert r["blob_digest"].hex() == GZ_BLOB_SHA and r["tar_digest"].hex() == GZ_TAR_SHA
+    assert r["tar_bytes"] == os.path.getsize(out) == os.path.getsize(FIXTURE)
+    assert open(out, "rb").read() == open(FIXTURE, "rb").read()
+    assert M.tar_inflate(GZ_FIXTURE)["tar_digest"].hex() == GZ_TAR_SHA      # digests only
+
+
+def test_gzip_layer_roundtrip_and_errors(tmp_path):
+    import gzip as gz
+    blobs = {"a/b.txt": os.urandom(70000), "a/empty": b"", "c": b"x" * 513}
+    p = str(tmp_path / "l.tar")
+    with tarfile.open(p, "w", format=tarfile.PAX_FORMAT) as tf:
+        ti = tarfile.TarInfo("a/"); ti.type = tarfile.DIRTYPE; tf.addfile(ti)
+        for name, data in blobs.items():
+            ti = tarfile.TarInfo(name); ti.size = len(data); tf.addfile(ti, io.BytesIO(data))
+    raw = open(p, "rb").read()
+    pz = str(tmp_path / "l.tar.gz")
+    with open(pz, "wb") as f:                               # two gzip members back to back (RFC 1952)
+        f.write(gz.compress(raw[:5000]) + gz.compress(raw[5000:]))
+    assert M.tar_entries(pz) == M.tar_entries(p)
+    r = M.tar_inflate(pz, str(tmp_path / "back.tar"))
+    assert open(tmp_path / "back.tar", "rb").read() == raw
+    assert r["tar_digest"].hex() == hashlib.sha256(raw).hexdigest()
+    assert r["blob_digest"].hex() == hashlib.sha256(open(pz, "rb").read()).hexdigest()
+    r2 = M.tar_inflate(p, str(tmp_path / "copy.tar"))      # a plain tar passes through
+    assert r2["tar_digest"].hex() == hashlib.sha256(raw).hexdigest()
+    bad = str(tmp_path / "bad.gz")
+    with open(bad, "wb") as f:
+        f.write(gz.compress(raw)[:-300])                    # truncated stream
+    with pytest.raises(M.MiError) as ei:
+        M.tar_entries(bad)
+    assert "gzip" in str(ei.value)
+    with pytest.raises(M.MiError) as ei:
+        M.tar_entries(str(tmp_path / "missing.tar"))
+    assert ei.value.code == -5 and "missing.tar" in str(ei.value)
+
+
+def _e(relpath, kind, **kw):
+    d = {"relpath": relpath, "kind": kind, "mode": 0o755 if kind == 0 else 0o644, "mtime_sec": 100, "size": 0}
+    d.update(kw)
+    return d
+
+
+def test_apply_layer_filter_drops_what_the_scan_walk_skips(tmp_path):
+    """base-image entries the SCAN walk never reports (blacklist, special files, AUFS
+    metadata) must not enter the tree, or mi_snapshot_diff writes whiteouts for them."""
+    root = str(tmp_path / "rootfs")
+    layer = [_e("bin", 0), _e("bin/sh", 1, size=10), _e("proc", 0), _e("proc/cpuinfo", 1, size=1),
+             _e("dev", 0), _e("dev/null", 4, mode=0o666), _e(".wh..wh.plnk", 0), _e(".wh..wh.plnk/x", 1),
+             _e("etc", 0), _e("etc/passwd", 1, size=5), _e("var/.wh..wh.opq", 1)]
+    merged = M.apply_layer([], layer, root=root, blacklist=[root + "/proc"])
+    # (".wh..wh.plnk/x" stays: shouldSkip looks at the BASE name only, utils.go:38 -- the reference
+    # keeps it too, and isOnDisk later finds it on disk, so it is never whited out)
+    assert [m["relpath"] for m in merged] == [".wh..wh.plnk/x", "bin", "bin/sh", "dev", "etc", "etc/passwd"]
+    # unfiltered (root=None): everything is kept, and a special file recurring in a later layer no
+    # longer aborts the merge (it simply replaces the old entry)
+    all_ = M.apply_layer([], layer)
+    assert "dev/null" in [m["relpath"] for m in all_]
+    again = M.apply_layer(all_, [_e("dev/null", 4, mode=0o600)])
+    assert [m for m in again if m["relpath"] == "dev/null"][0]["mode"] == 0o600
+
+
+def test_hard_links_are_applied_after_everything_else():
+    base = [_e("a", 0), _e("a/f", 1, size=3), _e("a/h", 3, link_target="a/f")]
+    # stream order: the link first, then a whiteout of the same name -- the reference's second pass
+    # re-adds the link after the whiteout removed the old one (mem_fs.go:219-236)
+    layer = [_e("a/h", 3, link_target="/a/f", mtime_sec=200), _e("a/.wh.h", 1)]
+    merged = M.apply_layer(base, layer)
+    h = [m for m in merged if m["relpath"] == "a/h"]
+    assert len(h) == 1 and h[0]["mtime_sec"] == 200
+    # the same link written as bin/x, ./bin/x and /bin/x is ONE target (AbsPath, mem_fs.go:214-216)
+    for other in ("/a/f", "./a/f", "a//f"):
+        assert M.entry_similar(base[2], dict(base[2], link_target=other))
+    assert not M.entry_similar(base[2], dict(base[2], link_target="a/g"))
+    same = M.apply_layer(base, [dict(base[2], link_target="/a/f")])
+    assert [m for m in same if m["relpath"] == "a/h"][0]["link_target"] == "a/f"      # similar: the OLD entry stays
+
+
+def test_snapshot_diff_asks_the_disk_before_writing_a_whiteout(tmp_path):
+    """memFSNode.isOnDisk (mem_fs.go:49-57,466) -- a path that still exists but
+    is now skipped by the walk gets no whiteout; a path that is really gone gets one."""
+    root = tmp_path / "rootfs"
+    (root / "data").mkdir(parents=True)
+    (root / "mnt").mkdir()
+    (root / "data" / "keep").write_bytes(b"k")
+    (root / "data" / "gone").write_bytes(b"g")
+    (root / "mnt" / "x").write_bytes(b"x")
+    before = M.tree_walk(str(root), None, (), M.TREE_SCAN, full=True)
+    os.unlink(root / "data" / "gone")
+    after = M.tree_walk(str(root), None, [str(root / "mnt")], M.TREE_SCAN, full=True)   # mnt is skipped now
+    names = [e["relpath"] for e in before]
+    _, wh = M.snapshot_diff(before, after, ignore_time=True)
+    assert {names[i] for i, w in enumerate(wh) if w} == {"data/gone", "mnt"}            # entry lists alone
+    _, wh = M.snapshot_diff(before, after, ignore_time=True, disk_root=str(root))
+    assert {names[i] for i, w in enumerate(wh) if w} == {"data/gone"}                   # the reference's answer
