@@ -298,6 +298,8 @@ def main():
         while pending:
             finish(pending.pop(0), record)
 
+    red_dev = device if args.backend == "nccl" else torch.device("cpu")   # small host-side reductions
+
     def fence():
         torch.cuda.synchronize(device)
         if dist.is_initialized():
@@ -311,12 +313,12 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if dist.is_initialized() and world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     job_bytes = step_bytes
     if dist.is_initialized() and world > 1:             # shards differ in size for c5
-        t = torch.tensor([step_bytes], dtype=torch.int64, device=device)
+        t = torch.tensor([step_bytes], dtype=torch.int64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         job_bytes = int(t.item())
     else:
@@ -337,20 +339,19 @@ def main():
     # closed-form check of the duplicate marking (c5: 90 % duplicate files): the job-wide unique
     # count must equal the chunk count of the first file of every distinct content
     dedup_check = None
-    if config == "c5" or (config == "c2" and not exchange):
-        expect_local = 0
+    if not split and (exchange or world == 1):
         if config == "c5":
             files0 = batches[0].files()
-            expect_local = int(files0["n_chunks"][shards[0].originals].sum())
+            expect = int(files0["n_chunks"][shards[0].originals].sum())
         else:
-            expect_local = checks[0][0]
+            expect = checks[0][0]                      # c2 / c4: every content is distinct
         if dist.is_initialized() and world > 1:
-            t = torch.tensor([expect_local], dtype=torch.int64, device=device)
+            t = torch.tensor([expect], dtype=torch.int64, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            expect_local = int(t.item())
+            expect = int(t.item())
         got = checks[0][1]
-        dedup_check = {"n_unique": int(got) if got is not None else None, "closed_form": int(expect_local),
-                       "ok": got is not None and int(got) == int(expect_local)}
+        dedup_check = {"n_unique": int(got) if got is not None else None, "closed_form": int(expect),
+                       "ok": got is not None and int(got) == int(expect)}
 
     value = job_bytes * args.steps / dt / 2**30
     # dominant kernel: SHA-256 per chunk.  Algorithmic bytes per launch: every file byte read
