@@ -56,6 +56,12 @@ namespace {
 
 u64 align_up(u64 v, u64 a) { return (v + a - 1) / a * a; }
 
+// per-batch control block (device): see submit_pipeline
+constexpr size_t kCtlHeadsOff = 16;
+constexpr size_t kCtlCursorOff = kCtlHeadsOff + 8 * kShaQueues * sizeof(u32);
+constexpr size_t kCtlHistOff = kCtlCursorOff + 1024 * sizeof(u32);
+constexpr size_t kCtlBytes = kCtlHistOff + 1024 * sizeof(u32);
+
 // ---- arena + staging ------------------------------------------------------------
 // Two ways into the arena: small mi_batch_add_bytes calls are copied inline into the batch's own
 // pinned window (two slabs, the copy of one in flight while the other fills); files and large
@@ -183,7 +189,7 @@ float ev_ms(hipEvent_t a, hipEvent_t b) {
 // submit_pipeline only ENQUEUES (kernels, memsets, two 8-byte async copies into pinned
 // memory) on the batch's stream: there is no host synchronisation between the stages.  Table
 // sizes come from host-side upper bounds (slots = sum(size/min_size + 2)); the real chunk
-// count lives in device memory (total_d) and every kernel that needs it reads it there.
+// count lives in device memory (the control block) and every kernel that needs it reads it there.
 int submit_pipeline(mi_batch* b) {
     mi_ctx* c = b->ctx;
     hipStream_t s = b->stream;
@@ -214,14 +220,12 @@ int submit_pipeline(mi_batch* b) {
     HIPCHK(c, b->seg_first.ensure(b->n_segs * 8 + 16));
     HIPCHK(c, b->n_chunks_d.ensure(nf * 4));
     HIPCHK(c, b->first.ensure(nf * 8));
-    HIPCHK(c, b->total_d.ensure(8));
+    HIPCHK(c, b->ctl.ensure(kCtlBytes));
     HIPCHK(c, b->scratch.ensure(scan_scratch_elems(b->n_segs > nf ? b->n_segs : nf) * 8));
     HIPCHK(c, b->chunk_off.ensure(cap * 8));
     HIPCHK(c, b->chunk_len.ensure(cap * 8));
     HIPCHK(c, b->chunk_start.ensure(cap * 8));
     HIPCHK(c, b->chunk_file.ensure(cap * 4));
-    HIPCHK(c, b->hist.ensure(n_bins * 4));
-    HIPCHK(c, b->cursor.ensure(n_bins * 4));
     HIPCHK(c, b->q_off.ensure(cap * 8));
     HIPCHK(c, b->q_len.ensure(cap * 8));
     HIPCHK(c, b->q_id.ensure(cap * 4));
@@ -230,22 +234,27 @@ int submit_pipeline(mi_batch* b) {
     HIPCHK(c, b->item_len.ensure(nf * 8));
     HIPCHK(c, b->roots.ensure(nf * 32));
     HIPCHK(c, b->dup_of.ensure(cap * 8));
-    HIPCHK(c, b->heads_chunks.ensure(sizeof(u32) * kShaQueues));
-    HIPCHK(c, b->heads_files.ensure(sizeof(u32) * kShaQueues));
     if (c->cfg.flags & MI_FLAG_FILE_SHA256) HIPCHK(c, b->file_sha.ensure(nf * 32));
     if (dedup) {
-        HIPCHK(c, b->dd_rep.ensure(dd_cap * 4));
-        HIPCHK(c, b->dd_minid.ensure(dd_cap * 4));
+        HIPCHK(c, b->dd_table.ensure(dd_cap * 8));
         HIPCHK(c, b->dd_slot.ensure(cap * 4));
-        HIPCHK(c, b->dd_nuniq.ensure(8));
     }
 
     const u64* d_off = b->file_off.as<u64>();
     const u64* d_size = b->file_size.as<u64>();
-    const u64* d_n = b->total_d.as<u64>();
+    // control block: {u64 total, u64 n_unique | SHA queue heads, one set per launch | bin cursor |
+    // length histogram} -- everything the pipeline needs zeroed, cleared by ONE memset
+    u8* ctl = b->ctl.as<u8>();
+    u64* d_total = (u64*)ctl;
+    u64* d_nuniq = (u64*)(ctl + 8);
+    auto heads = [&](int set) { return (u32*)(ctl + kCtlHeadsOff) + set * kShaQueues; };
+    u32* d_cursor = (u32*)(ctl + kCtlCursorOff);
+    u32* d_hist = (u32*)(ctl + kCtlHistOff);
+    const u64* d_n = d_total;
     const int ncu = c->prop.multiProcessorCount;
 
     HIPCHK(c, hipEventRecord(b->ev[0], s));
+    HIPCHK(c, hipMemsetAsync(ctl, 0, kCtlBytes, s));
     const u32 region = (u32)gear_group_region(c->cfg.min_size);
     if (b->n_groups) {
         HIPCHK(c, b->group_recs.ensure(gear_group_rec_bytes() * (size_t)b->n_groups));
@@ -274,31 +283,33 @@ int submit_pipeline(mi_batch* b) {
         g.gear_table = c->gear_table.as<u64>();
         launch_gear_cdc(g, c->cdc, ncu, s);
     }
-    launch_scan_counts(b->seg_n.as<u32>(), b->seg_first.as<u64>(), b->total_d.as<u64>(), b->n_segs,
+    launch_scan_counts(b->seg_n.as<u32>(), b->seg_first.as<u64>(), d_total, b->n_segs,
                        b->scratch.as<u64>(), s);
-    HIPCHK(c, hipMemcpyAsync(&b->h_counts[0], b->total_d.p, 8, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipEventRecord(b->ev[1], s));
+    const bool flat_roots = b->root_passes == 0;             // every file's root is one string
     launch_compact_chunks(d_off, b->file_seg0.as<u64>(), b->seg_file.as<u32>(), b->seg_slot.as<u64>(),
                           b->ends32.as<u32>(), b->seg_first.as<u64>(),
                           b->n_groups ? b->seg_group.as<u32>() : nullptr, b->group_recs.p, region, nf,
                           b->n_segs, cap, d_n, b->chunk_off.as<u64>(), b->chunk_len.as<u64>(),
                           b->chunk_file.as<u32>(), b->chunk_start.as<u64>(), b->first.as<u64>(),
-                          b->n_chunks_d.as<u32>(), b->hist.as<u32>(), n_bins, bin_shift, s);
+                          b->n_chunks_d.as<u32>(), d_hist, n_bins, bin_shift, b->digests.as<u8>(),
+                          flat_roots ? b->item_off.as<u64>() : nullptr,
+                          flat_roots ? b->item_len.as<u64>() : nullptr, s);
     launch_bin_order(b->chunk_off.as<u64>(), b->chunk_len.as<u64>(), (u32)cap, d_n,
-                     b->hist.as<u32>(), b->cursor.as<u32>(), n_bins, bin_shift,
+                     d_hist, d_cursor, n_bins, bin_shift,
                      b->q_off.as<u64>(), b->q_len.as<u64>(), b->q_id.as<u32>(), s);
     HIPCHK(c, hipEventRecord(b->ev[2], s));
     launch_sha256_items(kShaChunks, b->arena.as<u8>(), b->q_off.as<u64>(), b->q_len.as<u64>(),
-                        b->q_id.as<u32>(), (u32)cap, d_n, b->heads_chunks.as<u32>(),
+                        b->q_id.as<u32>(), (u32)cap, d_n, heads(0), false,
                         b->digests.as<u8>(), c->sha_blocks_per_cu, ncu, s);
     HIPCHK(c, hipEventRecord(b->ev[3], s));
     // per-file chunk roots: fan-out-1024 tree; reduction passes only exist for files with
     // more than 1024 chunks (> ~9 MiB), the final pass hashes every file's <= 1024 nodes
-    HIPCHK(c, b->root_addr.ensure(nf * 8));
-    HIPCHK(c, b->root_cnt.ensure(nf * 4));
-    launch_root_init(b->digests.as<u8>(), b->first.as<u64>(), b->n_chunks_d.as<u32>(), nf,
-                     b->root_addr.as<u64>(), b->root_cnt.as<u32>(), s);
-    {
+    if (!flat_roots) {
+        HIPCHK(c, b->root_addr.ensure(nf * 8));
+        HIPCHK(c, b->root_cnt.ensure(nf * 4));
+        launch_root_init(b->digests.as<u8>(), b->first.as<u64>(), b->n_chunks_d.as<u32>(), nf,
+                         b->root_addr.as<u64>(), b->root_cnt.as<u32>(), s);
         u64 nodes_ub = cap;                              // upper bound of nodes entering a pass
         for (int r = 0; r < b->root_passes; ++r) {
             const u64 out_ub = nodes_ub / 1024 + nf;     // nodes it can produce
@@ -314,20 +325,19 @@ int submit_pipeline(mi_batch* b) {
                               b->root_items_len.as<u64>(), s);
             launch_sha256_items(kShaRoots, nullptr, b->root_items_off.as<u64>(),
                                 b->root_items_len.as<u64>(), nullptr, (u32)out_ub,
-                                b->rseg_total.as<u64>(), b->heads_files.as<u32>(),
+                                b->rseg_total.as<u64>(), heads(3 + r), false,
                                 b->root_level[r].as<u8>(), c->sha_blocks_per_cu, ncu, s);
             nodes_ub = out_ub;
         }
+        launch_root_final_items(b->root_addr.as<u64>(), b->root_cnt.as<u32>(), nf, b->item_off.as<u64>(),
+                                b->item_len.as<u64>(), s);
     }
-    launch_root_final_items(b->root_addr.as<u64>(), b->root_cnt.as<u32>(), nf, b->item_off.as<u64>(),
-                            b->item_len.as<u64>(), s);
     launch_sha256_items(kShaRoots, nullptr, b->item_off.as<u64>(), b->item_len.as<u64>(), nullptr,
-                        (u32)nf, nullptr, b->heads_files.as<u32>(), b->roots.as<u8>(),
+                        (u32)nf, nullptr, heads(1), false, b->roots.as<u8>(),
                         c->sha_blocks_per_cu, ncu, s);
     if (c->cfg.flags & MI_FLAG_FILE_SHA256)
         launch_sha256_items(kShaFiles, b->arena.as<u8>(), d_off, d_size, nullptr, (u32)nf, nullptr,
-                            b->heads_files.as<u32>(), b->file_sha.as<u8>(), c->sha_blocks_per_cu,
-                            ncu, s);
+                            heads(2), false, b->file_sha.as<u8>(), c->sha_blocks_per_cu, ncu, s);
     if (c->cfg.flags & MI_FLAG_FILE_CRC32) {
         HIPCHK(c, b->tile_raw.ensure(b->n_tiles * 4 + 16));
         HIPCHK(c, b->crc_d.ensure(nf * 4));
@@ -337,13 +347,12 @@ int submit_pipeline(mi_batch* b) {
     }
     HIPCHK(c, hipEventRecord(b->ev[4], s));
     if (dedup) {
-        launch_dedup_mark(b->digests.as<u8>(), cap, d_n, b->dd_rep.as<u32>(),
-                          b->dd_minid.as<u32>(), b->dd_slot.as<u32>(), dd_cap,
-                          b->dup_of.as<i64>(), b->dd_nuniq.as<u64>(), s);
-        HIPCHK(c, hipMemcpyAsync(&b->h_counts[1], b->dd_nuniq.p, 8, hipMemcpyDeviceToHost, s));
+        launch_dedup_mark(b->digests.as<u8>(), cap, d_n, b->dd_table.as<u32>(), b->dd_slot.as<u32>(), dd_cap,
+                          b->dup_of.as<i64>(), d_nuniq, false, s);
     } else {
         HIPCHK(c, hipMemsetAsync(b->dup_of.p, 0xFF, cap * 8, s));
     }
+    HIPCHK(c, hipMemcpyAsync(&b->h_counts[0], ctl, 16, hipMemcpyDeviceToHost, s));   // {total, n_unique}
     HIPCHK(c, hipEventRecord(b->ev[5], s));
     HIPCHK(c, hipGetLastError());
     return MI_OK;
@@ -556,8 +565,7 @@ int mi_ctx_destroy(mi_ctx* c) {
     for (auto e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->h_word) (void)hipHostFree(c->h_word);
     c->gear_table.release(); c->heads.release(); c->crc_consts.release();
-    c->dd_rep.release(); c->dd_minid.release(); c->dd_slot.release(); c->dd_nuniq.release();
-    c->dd_tag.release(); c->dd_fmin.release();
+    c->dd_table.release(); c->dd_slot.release(); c->dd_nuniq.release(); c->dd_tag.release();
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return MI_OK;
@@ -921,11 +929,10 @@ int mi_batch_free(mi_batch* b) {
                       &b->root_items_off, &b->root_items_len, &b->root_level[0], &b->root_level[1],
                       &b->root_level[2], &b->group_file, &b->group_index, &b->group_recs, &b->tile_lists, &b->large_list,
                       &b->large_group0, &b->seg_file, &b->seg_slot, &b->seg_n, &b->seg_first, &b->seg_group,
-                      &b->file_seg0, &b->ends32, &b->tile_file, &b->first_tile, &b->tile_raw, &b->crc_d, &b->heads_chunks, &b->heads_files, &b->dd_rep, &b->dd_minid, &b->dd_slot,
-                      &b->dd_nuniq, &b->q_off, &b->q_len, &b->q_id,&b->arena, &b->small_list, &b->file_off, &b->file_size, &b->cids,
-                      &b->n_chunks_d, &b->first, &b->total_d, &b->scratch,
-                      &b->chunk_off, &b->chunk_len, &b->chunk_file, &b->chunk_start, &b->hist,
-                      &b->cursor, &b->digests, &b->item_off, &b->item_len, &b->roots,
+                      &b->file_seg0, &b->ends32, &b->tile_file, &b->first_tile, &b->tile_raw, &b->crc_d, &b->ctl, &b->dd_table, &b->dd_slot,
+                      &b->q_off, &b->q_len, &b->q_id,&b->arena, &b->small_list, &b->file_off, &b->file_size, &b->cids,
+                      &b->n_chunks_d, &b->first, &b->scratch,
+                      &b->chunk_off, &b->chunk_len, &b->chunk_file, &b->chunk_start, &b->digests, &b->item_off, &b->item_len, &b->roots,
                       &b->file_sha, &b->dup_of};
     for (DevBuf* d : bufs) d->release();
     delete b;
@@ -970,13 +977,12 @@ int mi_dedup_mark(mi_ctx* c, const void* d_digests, uint64_t n, void* d_dup_of, 
     if (n >= 0xFFFFFFFFull) return fail(c, MI_ERR_INVALID, "dedup set too large");
     u64 cap = 1024;
     while (cap < 2 * n) cap <<= 1;
-    HIPCHK(c, c->dd_rep.ensure(cap * 4));
-    HIPCHK(c, c->dd_minid.ensure(cap * 4));
+    HIPCHK(c, c->dd_table.ensure(cap * 8));
     HIPCHK(c, c->dd_slot.ensure(n * 4 + 16));
     HIPCHK(c, c->dd_nuniq.ensure(8));
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-    launch_dedup_mark((const u8*)d_digests, n, nullptr, c->dd_rep.as<u32>(), c->dd_minid.as<u32>(),
-                      c->dd_slot.as<u32>(), cap, (i64*)d_dup_of, c->dd_nuniq.as<u64>(), c->stream);
+    launch_dedup_mark((const u8*)d_digests, n, nullptr, c->dd_table.as<u32>(), c->dd_slot.as<u32>(), cap,
+                      (i64*)d_dup_of, c->dd_nuniq.as<u64>(), true, c->stream);
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_word, c->dd_nuniq.p, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -996,15 +1002,12 @@ int mi_dedup_mark_range(mi_ctx* c, const void* d_digests, uint64_t n_total, uint
     if (n_total >= 0xFFFFFFFFull) return fail(c, MI_ERR_INVALID, "dedup set too large");
     u64 cap = 1024;
     while (cap < 2 * own_n) cap <<= 1;
-    HIPCHK(c, c->dd_rep.ensure(cap * 4));
-    HIPCHK(c, c->dd_minid.ensure(cap * 4));
-    HIPCHK(c, c->dd_fmin.ensure(cap * 4));
+    HIPCHK(c, c->dd_table.ensure(cap * 12));
     HIPCHK(c, c->dd_tag.ensure(cap * 8));
     HIPCHK(c, c->dd_slot.ensure(own_n * 4 + 16));
     HIPCHK(c, c->dd_nuniq.ensure(8));
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-    launch_dedup_mark_range((const u8*)d_digests, own_first, own_n, c->dd_rep.as<u32>(),
-                            c->dd_minid.as<u32>(), c->dd_tag.as<u64>(), c->dd_fmin.as<u32>(),
+    launch_dedup_mark_range((const u8*)d_digests, own_first, own_n, c->dd_table.as<u32>(), c->dd_tag.as<u64>(),
                             c->dd_slot.as<u32>(), cap, (i64*)d_dup_of_own, c->dd_nuniq.as<u64>(), c->stream);
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_word, c->dd_nuniq.p, 8, hipMemcpyDeviceToHost, c->stream));
@@ -1061,7 +1064,7 @@ int mi_sha256_many(mi_ctx* c, const void* data, const uint64_t* offsets, const u
         if (e == hipSuccess) e = hipMemcpy(d_len.p, lens, n * 8, hipMemcpyHostToDevice);
         if (e == hipSuccess) {
             launch_sha256_items(kShaBlobs, d_data.as<u8>(), d_off.as<u64>(), d_len.as<u64>(), nullptr, (u32)n,
-                                nullptr, c->heads.as<u32>(), d_out.as<u8>(), c->sha_blocks_per_cu,
+                                nullptr, c->heads.as<u32>(), true, d_out.as<u8>(), c->sha_blocks_per_cu,
                                 c->prop.multiProcessorCount, c->stream);
             e = hipStreamSynchronize(c->stream);
         }

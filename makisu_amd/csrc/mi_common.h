@@ -89,9 +89,10 @@ void   launch_gear_cdc(const GearLaunch& a, CdcParams p, int n_cu, hipStream_t s
 // consumed in order, so put the longest strings first.  heads = kShaQueues words.
 enum ShaPass { kShaChunks = 0, kShaRoots = 1, kShaFiles = 2, kShaBlobs = 3 };
 // n = string count (or its upper bound when d_n, a device word holding the real count, is given)
+// d_heads must be zero on entry unless zero_heads (then the launcher clears it first)
 void launch_sha256_items(ShaPass pass, const u8* d_base, const u64* d_off, const u64* d_len,
-                         const u32* d_ids, u32 n, const u64* d_n, u32* d_heads, u8* d_out,
-                         int blocks_per_cu, int n_cu, hipStream_t s);
+                         const u32* d_ids, u32 n, const u64* d_n, u32* d_heads, bool zero_heads,
+                         u8* d_out, int blocks_per_cu, int n_cu, hipStream_t s);
 
 // tables.hip
 void launch_synth_fill(u8* d_data, const u64* d_file_off, const u64* d_file_size,
@@ -108,7 +109,10 @@ void launch_compact_chunks(const u64* d_file_off, const u64* d_file_seg0, const 
                            const u32* d_seg_group, const void* d_group_recs, u32 region,
                            u64 n_files, u64 n_segs, u64 n_max, const u64* d_n, u64* d_chunk_off,
                            u64* d_chunk_len, u32* d_chunk_file, u64* d_chunk_start, u64* d_first,
-                           u32* d_n_chunks, u32* d_hist, u32 n_bins, u32 bin_shift, hipStream_t s);
+                           u32* d_n_chunks, u32* d_hist, u32 n_bins, u32 bin_shift, const u8* d_digests,
+                           u64* d_item_off, u64* d_item_len, hipStream_t s);
+// d_hist (compaction) and d_cursor (binning) must be zero on entry; d_item_off/len (optional): the
+// root pass's item list when no file needs a reduction pass
 // queue descriptors in processing order (longest first): s_off/s_len/s_id[pos]
 void launch_bin_order(const u64* d_off, const u64* d_len, u32 n, const u64* d_n, u32* d_hist,
                       u32* d_cursor, u32 n_bins, u32 bin_shift, u64* d_s_off, u64* d_s_len,
@@ -130,11 +134,12 @@ void launch_crc32_files(const u8* d_data, const u64* d_file_off, const u64* d_fi
                         const u32* d_consts, u32* d_tile_raw, u32* d_crc, hipStream_t s);
 u32 crc32_host_bytes(u32 crc, const void* data, size_t len);
 u32 crc32_host_combine(u32 crc1, u32 crc2, u64 len2);
-void launch_dedup_mark(const u8* d_digests, u64 n, const u64* d_n, u32* d_rep, u32* d_minid,
-                       u32* d_slot_of, u64 cap_pow2, i64* d_dup_of, u64* d_n_unique,
-                       hipStream_t s);
-void launch_dedup_mark_range(const u8* d_all, u64 own_first, u64 own_n, u32* d_rep, u32* d_minid,
-                             u64* d_tag, u32* d_fmin, u32* d_slot_of, u64 cap_pow2, i64* d_dup_own,
-                             u64* d_n_first, hipStream_t s);
+// d_table: 2 x cap_pow2 words (rep | complemented minima), cleared here with one memset
+void launch_dedup_mark(const u8* d_digests, u64 n, const u64* d_n, u32* d_table, u32* d_slot_of,
+                       u64 cap_pow2, i64* d_dup_of, u64* d_n_unique, bool zero_count, hipStream_t s);
+// d_table: 3 x cap_pow2 words (rep | minima | foreign minima)
+void launch_dedup_mark_range(const u8* d_all, u64 own_first, u64 own_n, u32* d_table, u64* d_tag,
+                             u32* d_slot_of, u64 cap_pow2, i64* d_dup_own, u64* d_n_first,
+                             hipStream_t s);
 
 }  // namespace mi

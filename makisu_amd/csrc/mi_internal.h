@@ -50,8 +50,8 @@ struct mi_ctx {
     size_t staging_bytes = 0;            // bytes per pinned slab (reader threads, per-batch inline ring)
     int live_children = 0;               // batches + indexes that still point at this ctx
     mi::DevBuf gear_table, heads, crc_consts;
-    mi::DevBuf dd_rep, dd_minid, dd_slot, dd_nuniq;     // dedup scratch of mi_dedup_mark
-    mi::DevBuf dd_tag, dd_fmin;                         // ... and of mi_dedup_mark_range
+    mi::DevBuf dd_table, dd_slot, dd_nuniq;             // dedup scratch of mi_dedup_mark
+    mi::DevBuf dd_tag;                                  // ... and of mi_dedup_mark_range
     mi::u64* h_word = nullptr;           // pinned: small read-backs on the ctx stream
     hipEvent_t ev[2];
     int sha_blocks_per_cu = 2;
@@ -98,19 +98,19 @@ struct mi_batch {
     mi::DevBuf group_file, group_index, group_recs, tile_lists, large_list, large_group0;
     mi::u32 n_small = 0, n_groups = 0, n_large = 0;
     mi::u64 n_segs = 0, ends_total = 0;
-    mi::DevBuf file_off, file_size, cids, n_chunks_d, first, total_d, scratch;
-    mi::DevBuf chunk_off, chunk_len, chunk_file, chunk_start, hist, cursor, digests;
+    mi::DevBuf file_off, file_size, cids, n_chunks_d, first, scratch;
+    mi::DevBuf ctl;                          // control block: counts, queue heads, bin cursor, histogram
+    mi::DevBuf chunk_off, chunk_len, chunk_file, chunk_start, digests;
     mi::DevBuf q_off, q_len, q_id;           // SHA queue descriptors, longest chunk first
     mi::DevBuf item_off, item_len, roots, file_sha, dup_of;
     mi::DevBuf root_addr, root_cnt, rseg_cnt, rseg_first, rseg_total, root_items_off, root_items_len;
     mi::DevBuf root_level[3];            // node digests of the reduction passes
     int root_passes = 0;                 // reduction passes this batch can need (from max file size)
     mi::u64 max_file_size = 0;
-    mi::DevBuf heads_chunks, heads_files;    // SHA queue heads (one set per concurrent launch)
     mi::DevBuf tile_file, first_tile, tile_raw, crc_d;   // MI_FLAG_FILE_CRC32
     mi::u64 n_tiles = 0;
     void* tree = nullptr;                // host-side walk record (mi_tree.hip)
-    mi::DevBuf dd_rep, dd_minid, dd_slot, dd_nuniq;
+    mi::DevBuf dd_table, dd_slot;
     std::vector<mi_file_result> h_files;
     std::vector<mi_chunk_result> h_chunks;
 };

@@ -267,10 +267,10 @@ void sha256_items_kernel(const u8* __restrict__ base, const u64* __restrict__ of
 }
 
 void launch_sha256_items(ShaPass pass, const u8* d_base, const u64* d_off, const u64* d_len,
-                         const u32* d_order, u32 n, const u64* d_n, u32* d_heads, u8* d_out,
-                         int blocks_per_cu, int n_cu, hipStream_t s) {
+                         const u32* d_order, u32 n, const u64* d_n, u32* d_heads, bool zero_heads,
+                         u8* d_out, int blocks_per_cu, int n_cu, hipStream_t s) {
     if (n == 0) return;
-    (void)hipMemsetAsync(d_heads, 0, sizeof(u32) * kShaQueues, s);
+    if (zero_heads) (void)hipMemsetAsync(d_heads, 0, sizeof(u32) * kShaQueues, s);
     u64 want = ((u64)n + kShaWG - 1) / kShaWG;
     u64 cap = (u64)blocks_per_cu * (u64)n_cu;
     u32 grid = (u32)(want < cap ? want : cap);

@@ -76,6 +76,7 @@ __device__ __forceinline__ u64 block_exclusive_scan(u64 v, u64* total, u64* lds 
 __global__ __launch_bounds__(kScanBlock)
 void scan_block_sums_kernel(const u32* __restrict__ counts, u64 n, u64* __restrict__ block_sums) {
     __shared__ u64 lds[8];
+    __builtin_amdgcn_s_setprio(3);     // tiny kernels between the two long ones: do not queue behind them
     const u64 base = (u64)blockIdx.x * kScanTile + (u64)threadIdx.x * kScanPer;
     u64 s = 0;
 #pragma unroll
@@ -119,6 +120,40 @@ void scan_final_kernel(const u32* __restrict__ counts, u64 n, const u64* __restr
     }
 }
 
+// offsets + final in one launch: every block sums the block totals before it (a few hundred
+// L2-resident loads) instead of waiting for a single-block scan kernel in between
+__global__ __launch_bounds__(kScanBlock)
+void scan_final_fused_kernel(const u32* __restrict__ counts, u64 n, const u64* __restrict__ block_sums,
+                             u64 n_blocks, u64* __restrict__ first, u64* __restrict__ total) {
+    __shared__ u64 lds[8];
+    __shared__ u64 s_before, s_all;
+    __builtin_amdgcn_s_setprio(3);
+    u64 before = 0, all = 0;
+    for (u64 i = threadIdx.x; i < n_blocks; i += kScanBlock) {
+        const u64 v = block_sums[i];
+        all += v;
+        if (i < blockIdx.x) before += v;
+    }
+    u64 t0, t1;
+    (void)block_exclusive_scan(before, &t0, lds);
+    (void)block_exclusive_scan(all, &t1, lds);
+    if (threadIdx.x == 0) { s_before = t0; s_all = t1; }
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x == 0) *total = s_all;
+    const u64 base = (u64)blockIdx.x * kScanTile + (u64)threadIdx.x * kScanPer;
+    u32 c[kScanPer];
+    u64 sum = 0;
+#pragma unroll
+    for (int k = 0; k < kScanPer; ++k) { c[k] = base + k < n ? counts[base + k] : 0; sum += c[k]; }
+    u64 tot;
+    u64 ex = block_exclusive_scan(sum, &tot, lds) + s_before;
+#pragma unroll
+    for (int k = 0; k < kScanPer; ++k) {
+        if (base + k < n) first[base + k] = ex;
+        ex += c[k];
+    }
+}
+
 u64 scan_scratch_elems(u64 n) { return (n + kScanTile - 1) / kScanTile + 1; }
 
 void launch_scan_counts(const u32* d_counts, u64* d_first, u64* d_total, u64 n, u64* d_scratch,
@@ -127,6 +162,11 @@ void launch_scan_counts(const u32* d_counts, u64* d_first, u64* d_total, u64 n, 
     const u64 nb = (n + kScanTile - 1) / kScanTile;
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3((u32)nb), dim3(kScanBlock), 0, s, d_counts, n,
                        d_scratch);
+    if (nb <= 4096) {                                     // two launches
+        hipLaunchKernelGGL(scan_final_fused_kernel, dim3((u32)nb), dim3(kScanBlock), 0, s, d_counts, n,
+                           d_scratch, nb, d_first, d_total);
+        return;
+    }
     hipLaunchKernelGGL(scan_block_offsets_kernel, dim3(1), dim3(kScanBlock), 0, s, d_scratch, nb,
                        d_total);
     hipLaunchKernelGGL(scan_final_kernel, dim3((u32)nb), dim3(kScanBlock), 0, s, d_counts, n,
@@ -167,6 +207,7 @@ void compact_chunks_kernel(const u64* __restrict__ file_off, const u64* __restri
                            u32* __restrict__ chunk_file, u64* __restrict__ chunk_start,
                            u32* __restrict__ hist, u32 n_bins, u32 bin_shift) {
     __shared__ u32 lh[kMaxBins];
+    __builtin_amdgcn_s_setprio(3);
     for (u32 i = threadIdx.x; i < n_bins; i += blockDim.x) lh[i] = 0;
     __syncthreads();
     const u64 n = n_ptr ? *n_ptr : n_max;
@@ -203,11 +244,15 @@ void compact_chunks_kernel(const u64* __restrict__ file_off, const u64* __restri
         if (lh[i]) atomicAdd(&hist[i], lh[i]);
 }
 
-// first chunk row / row count of every file, from the scanned segment counts
+// first chunk row / row count of every file, from the scanned segment counts; when no file of the
+// batch needs a root reduction pass (all <= 1024 chunks) also the root pass's item list: file f's
+// string is its digest run (what root_init + root_final_items produce otherwise)
 __global__ __launch_bounds__(256)
 void file_rows_kernel(const u64* __restrict__ file_seg0, const u64* __restrict__ seg_first,
                       u64 n_files, u64 n_segs, const u64* __restrict__ total,
-                      u64* __restrict__ first, u32* __restrict__ n_chunks) {
+                      u64* __restrict__ first, u32* __restrict__ n_chunks, const u8* __restrict__ digests,
+                      u64* __restrict__ item_off, u64* __restrict__ item_len) {
+    __builtin_amdgcn_s_setprio(3);
     const u64 f = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n_files) return;
     const u64 s0 = file_seg0[f], s1 = file_seg0[f + 1];
@@ -215,6 +260,10 @@ void file_rows_kernel(const u64* __restrict__ file_seg0, const u64* __restrict__
     const u64 b = s1 < n_segs ? seg_first[s1] : *total;
     first[f] = a;
     n_chunks[f] = (u32)(b - a);
+    if (item_off) {
+        item_off[f] = (u64)(uintptr_t)digests + a * 32;
+        item_len[f] = (b - a) * 32;
+    }
 }
 
 void launch_compact_chunks(const u64* d_file_off, const u64* d_file_seg0, const u32* d_seg_file,
@@ -222,11 +271,12 @@ void launch_compact_chunks(const u64* d_file_off, const u64* d_file_seg0, const 
                            const u32* d_seg_group, const void* d_group_recs, u32 region,
                            u64 n_files, u64 n_segs, u64 n_max, const u64* d_n, u64* d_chunk_off,
                            u64* d_chunk_len, u32* d_chunk_file, u64* d_chunk_start, u64* d_first,
-                           u32* d_n_chunks, u32* d_hist, u32 n_bins, u32 bin_shift, hipStream_t s) {
-    if (n_files == 0) return;
-    (void)hipMemsetAsync(d_hist, 0, sizeof(u32) * n_bins, s);
+                           u32* d_n_chunks, u32* d_hist, u32 n_bins, u32 bin_shift, const u8* d_digests,
+                           u64* d_item_off, u64* d_item_len, hipStream_t s) {
+    if (n_files == 0) return;                             // d_hist: zeroed by the caller
     hipLaunchKernelGGL(file_rows_kernel, dim3((u32)((n_files + 255) / 256)), dim3(256), 0, s, d_file_seg0,
-                       d_seg_first, n_files, n_segs, d_n, d_first, d_n_chunks);
+                       d_seg_first, n_files, n_segs, d_n, d_first, d_n_chunks, d_digests, d_item_off,
+                       d_item_len);
     u64 want = (n_max + 255) / 256;
     const u32 grid = (u32)(want < 2048 ? (want ? want : 1) : 2048);
     hipLaunchKernelGGL(compact_chunks_kernel, dim3(grid), dim3(256), 0, s, d_file_off, d_file_seg0,
@@ -236,34 +286,36 @@ void launch_compact_chunks(const u64* d_file_off, const u64* d_file_seg0, const 
 }
 
 // ---- longest-first processing order (counting sort by block-count bin) -----------
-__global__ __launch_bounds__(256)
-void bin_cursor_kernel(const u32* __restrict__ hist, u32* __restrict__ cursor, u32 n_bins) {
-    // single block; cursor[b] = number of items in bins > b  (descending order start)
-    __shared__ u64 lds[8];
-    u64 carry = 0;
-    for (u32 b0 = 0; b0 < n_bins; b0 += 256) {
-        const u32 i = b0 + threadIdx.x;                     // position from the top
-        const u32 bin = n_bins - 1 - i;
-        const u64 v = i < n_bins ? hist[bin] : 0;
-        u64 tot;
-        const u64 ex = block_exclusive_scan(v, &tot, lds);
-        if (i < n_bins) cursor[bin] = (u32)(carry + ex);
-        carry += tot;
-    }
-}
-
 // Two-level scatter: a workgroup ranks its kScatterPer*256 items per bin in LDS, reserves one
 // range per non-empty bin with a single global atomic, then every item writes its queue
-// descriptor at range start + local rank.
+// descriptor at range start + local rank.  The range starts are the descending exclusive scan of
+// the length histogram; every workgroup recomputes it in LDS (<= 1024 bins) instead of waiting
+// for a single-block kernel, `cursor` (zeroed by the caller) only counts what has been handed out.
 constexpr int kScatterPer = 8;
 __global__ __launch_bounds__(256)
 void bin_scatter_kernel(const u64* __restrict__ off, const u64* __restrict__ len, u32 n_max,
-                        const u64* __restrict__ n_ptr, u32* __restrict__ cursor, u32 n_bins, u32 bin_shift,
+                        const u64* __restrict__ n_ptr, const u32* __restrict__ hist,
+                        u32* __restrict__ cursor, u32 n_bins, u32 bin_shift,
                         u64* __restrict__ s_off, u64* __restrict__ s_len, u32* __restrict__ s_id) {
     __shared__ u32 cnt[kMaxBins];
+    __shared__ u32 start[kMaxBins];
+    __shared__ u64 lds[8];
+    __builtin_amdgcn_s_setprio(3);
     const u32 n = n_ptr ? (u32)*n_ptr : n_max;
     const u32 base = blockIdx.x * (256 * kScatterPer);
     if (base >= n) return;
+    {   // start[bin] = number of items in bins > bin
+        u64 carry = 0;
+        for (u32 b0 = 0; b0 < n_bins; b0 += 256) {
+            const u32 i = b0 + threadIdx.x;                     // position from the top
+            const u32 bin = n_bins - 1 - i;
+            const u64 v = i < n_bins ? hist[bin] : 0;
+            u64 tot;
+            const u64 ex = block_exclusive_scan(v, &tot, lds);
+            if (i < n_bins) start[bin] = (u32)(carry + ex);
+            carry += tot;
+        }
+    }
     for (u32 i = threadIdx.x; i < n_bins; i += blockDim.x) cnt[i] = 0;
     __syncthreads();
     u32 bin[kScatterPer], rank[kScatterPer];
@@ -280,7 +332,7 @@ void bin_scatter_kernel(const u64* __restrict__ off, const u64* __restrict__ len
     __syncthreads();
     for (u32 i = threadIdx.x; i < n_bins; i += blockDim.x) {
         const u32 c = cnt[i];
-        if (c) cnt[i] = atomicAdd(&cursor[i], c);           // now the range start of bin i
+        if (c) cnt[i] = start[i] + atomicAdd(&cursor[i], c);   // now the range start of bin i
     }
     __syncthreads();
 #pragma unroll
@@ -298,11 +350,10 @@ void bin_scatter_kernel(const u64* __restrict__ off, const u64* __restrict__ len
 void launch_bin_order(const u64* d_off, const u64* d_len, u32 n, const u64* d_n, u32* d_hist,
                       u32* d_cursor, u32 n_bins, u32 bin_shift, u64* d_s_off, u64* d_s_len,
                       u32* d_s_id, hipStream_t s) {
-    if (n == 0) return;
-    hipLaunchKernelGGL(bin_cursor_kernel, dim3(1), dim3(256), 0, s, d_hist, d_cursor, n_bins);
+    if (n == 0) return;                                   // d_cursor: zeroed by the caller
     const u32 per = 256 * kScatterPer;
     hipLaunchKernelGGL(bin_scatter_kernel, dim3((n + per - 1) / per), dim3(256), 0, s, d_off, d_len,
-                       n, d_n, d_cursor, n_bins, bin_shift, d_s_off, d_s_len, d_s_id);
+                       n, d_n, d_hist, d_cursor, n_bins, bin_shift, d_s_off, d_s_len, d_s_id);
 }
 
 // ---- per-file chunk roots -----------------------------------------------------------
@@ -390,6 +441,8 @@ void launch_root_final_items(const u64* d_cur_addr, const u32* d_cur_cnt, u64 n_
 // holds a representative row (rep) and the minimum row index among equal digests
 // (minid); equality is always checked on all 32 bytes, so a 64-bit key collision only
 // costs an extra probe.  Output is deterministic: dup_of = smallest equal row, or -1.
+// Minima are kept COMPLEMENTED (atomicMax of ~index, 0 = none) so that the whole table --
+// rep | minid [| fmin], contiguous -- is cleared by ONE memset.
 __device__ __forceinline__ bool digest_eq(const u8* a, const u8* b) {
     const u32x4 a0 = ((const u32x4*)a)[0], a1 = ((const u32x4*)a)[1];
     const u32x4 b0 = ((const u32x4*)b)[0], b1 = ((const u32x4*)b)[1];
@@ -401,6 +454,7 @@ __global__ __launch_bounds__(256)
 void dedup_insert_kernel(const u8* __restrict__ digests, u64 n_max, const u64* __restrict__ n_ptr,
                          u32* __restrict__ rep, u32* __restrict__ minid,
                          u32* __restrict__ slot_of, u64 mask) {
+    __builtin_amdgcn_s_setprio(3);
     const u64 n = n_ptr ? *n_ptr : n_max;
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -411,7 +465,7 @@ void dedup_insert_kernel(const u8* __restrict__ digests, u64 n_max, const u64* _
         if (r == 0u || r == (u32)i + 1u || digest_eq(digests + 32ull * (r - 1u), mine)) break;
         slot = (slot + 1) & mask;
     }
-    atomicMin(&minid[slot], (u32)i);
+    atomicMax(&minid[slot], ~(u32)i);
     slot_of[i] = (u32)slot;
 }
 
@@ -423,6 +477,7 @@ void dedup_finish_kernel(u64 n_max, const u64* __restrict__ n_ptr, const u32* __
     // global counter sees a few hundred atomics, not one per wave (same-address atomics
     // retire at ~90 per microsecond)
     __shared__ u32 wg_count;
+    __builtin_amdgcn_s_setprio(3);
     if (threadIdx.x == 0) wg_count = 0;
     __syncthreads();
     const u64 n = n_ptr ? *n_ptr : n_max;
@@ -431,7 +486,7 @@ void dedup_finish_kernel(u64 n_max, const u64* __restrict__ n_ptr, const u32* __
         const u64 i = i0 + threadIdx.x;
         bool first = false;
         if (i < n) {
-            const u32 m = minid[slot_of[i]];
+            const u32 m = ~minid[slot_of[i]];
             first = (m == (u32)i);
             dup_of[i] = first ? -1 : (i64)m;
         }
@@ -442,13 +497,13 @@ void dedup_finish_kernel(u64 n_max, const u64* __restrict__ n_ptr, const u32* __
     if (threadIdx.x == 0 && wg_count) atomicAdd((unsigned long long*)n_unique, (unsigned long long)wg_count);
 }
 
-void launch_dedup_mark(const u8* d_digests, u64 n, const u64* d_n, u32* d_rep, u32* d_minid,
-                       u32* d_slot_of, u64 cap_pow2, i64* d_dup_of, u64* d_n_unique,
-                       hipStream_t s) {
-    (void)hipMemsetAsync(d_n_unique, 0, sizeof(u64), s);
+void launch_dedup_mark(const u8* d_digests, u64 n, const u64* d_n, u32* d_table, u32* d_slot_of,
+                       u64 cap_pow2, i64* d_dup_of, u64* d_n_unique, bool zero_count, hipStream_t s) {
+    if (zero_count) (void)hipMemsetAsync(d_n_unique, 0, sizeof(u64), s);
     if (n == 0) return;
-    (void)hipMemsetAsync(d_rep, 0, sizeof(u32) * cap_pow2, s);
-    (void)hipMemsetAsync(d_minid, 0xFF, sizeof(u32) * cap_pow2, s);
+    u32* d_rep = d_table;
+    u32* d_minid = d_table + cap_pow2;
+    (void)hipMemsetAsync(d_table, 0, sizeof(u32) * 2 * cap_pow2, s);
     const u32 grid = (u32)((n + 255) / 256);
     hipLaunchKernelGGL(dedup_insert_kernel, dim3(grid), dim3(256), 0, s, d_digests, n, d_n, d_rep,
                        d_minid, d_slot_of, cap_pow2 - 1);
@@ -489,7 +544,7 @@ void dedup_probe_kernel(const u8* __restrict__ all, u64 n_foreign, const u8* __r
         const u32 r = rep[slot];
         if (r == 0u) return;                                 // not among the own rows
         if (tag[slot] == key && digest_eq(own + 32ull * (r - 1u), mine)) {
-            atomicMin(&fmin[slot], (u32)g);
+            atomicMax(&fmin[slot], ~(u32)g);
             return;
         }
         slot = (slot + 1) & mask;
@@ -509,7 +564,7 @@ void dedup_finish_range_kernel(u64 own_n, u64 own_first, const u32* __restrict__
         bool first = false;
         if (i < own_n) {
             const u32 s = slot_of[i];
-            const u32 f = fmin[s], m = minid[s];
+            const u32 f = ~fmin[s], m = ~minid[s];
             if (f != 0xFFFFFFFFu) dup_own[i] = (i64)f;                   // an earlier rank has it
             else if (m != (u32)i) dup_own[i] = (i64)(own_first + m);     // earlier in this rank
             else { dup_own[i] = -1; first = true; }
@@ -521,14 +576,15 @@ void dedup_finish_range_kernel(u64 own_n, u64 own_first, const u32* __restrict__
     if (threadIdx.x == 0 && wg_count) atomicAdd((unsigned long long*)n_first, (unsigned long long)wg_count);
 }
 
-void launch_dedup_mark_range(const u8* d_all, u64 own_first, u64 own_n, u32* d_rep, u32* d_minid,
-                             u64* d_tag, u32* d_fmin, u32* d_slot_of, u64 cap_pow2, i64* d_dup_own,
-                             u64* d_n_first, hipStream_t s) {
+void launch_dedup_mark_range(const u8* d_all, u64 own_first, u64 own_n, u32* d_table, u64* d_tag,
+                             u32* d_slot_of, u64 cap_pow2, i64* d_dup_own, u64* d_n_first,
+                             hipStream_t s) {
     (void)hipMemsetAsync(d_n_first, 0, sizeof(u64), s);
     if (own_n == 0) return;
-    (void)hipMemsetAsync(d_rep, 0, sizeof(u32) * cap_pow2, s);
-    (void)hipMemsetAsync(d_minid, 0xFF, sizeof(u32) * cap_pow2, s);
-    (void)hipMemsetAsync(d_fmin, 0xFF, sizeof(u32) * cap_pow2, s);
+    u32* d_rep = d_table;
+    u32* d_minid = d_table + cap_pow2;
+    u32* d_fmin = d_table + 2 * cap_pow2;
+    (void)hipMemsetAsync(d_table, 0, sizeof(u32) * 3 * cap_pow2, s);
     const u8* own = d_all + 32 * own_first;
     const u32 grid = (u32)((own_n + 255) / 256);
     hipLaunchKernelGGL(dedup_insert_kernel, dim3(grid), dim3(256), 0, s, own, own_n, (const u64*)nullptr,

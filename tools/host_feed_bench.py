@@ -7,6 +7,9 @@ import time
 
 import numpy as np
 
+if os.environ.get("MI_FEED_TORCH"):      # PyTorch-ROCm bundles its own (older) HIP runtime: loaded first it serves the engine too
+    import torch  # noqa: F401
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import makisu_amd  # noqa: E402
 
