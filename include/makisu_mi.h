@@ -180,6 +180,11 @@ int mi_batch_device_digests(mi_batch* b, const void** d_digests, uint64_t* n_chu
 /* Copies the batch's file bytes back to the host (tests; cap >= total bytes, files
  * concatenated in add order, no padding).                                           */
 int mi_batch_read_back(mi_batch* b, void* out, uint64_t cap);
+/* Empties the batch (files, results, recorded walk) but keeps its device memory and pinned window
+ * for the next set of files: the way to scan layer after layer without paying allocation -- and
+ * the driver's clearing of fresh device memory, which slows the first host-to-device copies into
+ * it -- every time.  Not while in flight.                                                  */
+int mi_batch_reset(mi_batch* b);
 int mi_batch_free(mi_batch* b);
 
 /* ---- cross-batch / cross-GPU dedup --------------------------------------------- *

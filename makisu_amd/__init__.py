@@ -154,6 +154,7 @@ def load_library(rebuild=False):
         "mi_batch_chunks": ([vp, vp, u64], C.c_int),
         "mi_batch_device_digests": ([vp, C.POINTER(vp), u64p], C.c_int),
         "mi_batch_read_back": ([vp, vp, u64], C.c_int),
+        "mi_batch_reset": ([vp], C.c_int),
         "mi_batch_free": ([vp], C.c_int),
         "mi_dedup_mark": ([vp, vp, u64, vp, u64p], C.c_int),
         "mi_batch_set_global_dedup": ([vp, vp, u64], C.c_int),
@@ -814,6 +815,11 @@ class Batch:
         out = np.zeros(max(n, 1), dtype=np.uint8)
         self._check(self._lib.mi_batch_read_back(self._h, out.ctypes.data, n))
         return out[:n]
+
+    def reset(self):
+        """Empty the batch, keep its device memory (next layer, same buffers)."""
+        self._check(self._lib.mi_batch_reset(self._h))
+        return self
 
     def free(self):
         if getattr(self, "_h", None):

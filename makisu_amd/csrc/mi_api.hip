@@ -446,6 +446,8 @@ int fetch_results(mi_batch* b) {
 // ================================ C ABI ============================================
 extern "C" {
 
+void mi_batch_tree_free(void* tree);                   // mi_tree.hip
+
 int mi_abi_version(void) { return MI_ABI_VERSION; }
 
 int mi_config_default(mi_config* cfg) {
@@ -842,6 +844,33 @@ int mi_batch_rerun(mi_batch* b) {
     return mi_batch_wait(b);
 }
 
+// Empties the batch for the next set of files; every device allocation (arena, tables) and the
+// pinned window stay, so a host that scans layer after layer pays hipMalloc -- and the driver's
+// clearing of fresh VRAM, which competes with the H2D copies for the SDMA engines -- once.
+int mi_batch_reset(mi_batch* b) {
+    if (!b) return MI_ERR_INVALID;
+    mi_ctx* c = b->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (b->in_flight) return fail(c, MI_ERR_STATE, "batch is in flight; mi_batch_wait first");
+    int rc = staging_sync(b);                           // nothing may still be writing into the arena
+    b->stage_err.clear();
+    (void)rc;
+    if (b->tree) { mi_batch_tree_free(b->tree); b->tree = nullptr; }
+    b->files.clear();
+    b->synth.clear();
+    b->total_bytes = b->arena_used = 0;
+    b->cur = 0;
+    b->win_start = b->win_fill = 0;
+    b->staged_any = false;
+    b->ms_h2d = 0;
+    b->staged = b->ran = b->results_valid = false;
+    b->n_chunks = b->total_slots = 0;
+    b->h_files.clear();
+    b->h_chunks.clear();
+    memset(&b->stats, 0, sizeof b->stats);
+    return MI_OK;
+}
+
 int mi_batch_counts(mi_batch* b, uint64_t* n_files, uint64_t* n_chunks, uint64_t* n_bytes) {
     if (!b) return MI_ERR_INVALID;
     if (n_files) *n_files = b->files.size();
@@ -905,7 +934,6 @@ int mi_batch_read_back(mi_batch* b, void* out, uint64_t cap) {
     return MI_OK;
 }
 
-void mi_batch_tree_free(void* tree);
 void** mi_batch_tree_slot(mi_batch* b) { return &b->tree; }
 void mi_set_error(mi_batch* b, const char* msg) { b->ctx->err = msg; }
 

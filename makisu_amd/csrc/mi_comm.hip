@@ -12,8 +12,12 @@
 //     are issued inside one ncclGroupStart/End.
 // Exchange: counts first (one u64 per rank), then slabs padded to the largest count in one
 // ncclAllGather -- every xGMI link carries exactly one peer's slab, no ring of 7 hops --
-// then the padding is squeezed out with device copies and mi_dedup_mark's kernel runs on the
-// gathered set; dup_of of the batch is rewritten with GLOBAL row indices (rank-major).
+// then the padding is squeezed out with device copies and the rank marks ITS OWN rows against
+// the gathered set (mi_batch_mark_global); dup_of of the batch is rewritten with GLOBAL row
+// indices (rank-major); a last 8-byte all-gather sums the ranks' first-occurrence counts.
+// Host synchronisations per exchange: three (the counts, the marking's count, the sum); scalars
+// travel through one pinned block, never through stack memory; the digest array is sent from
+// where the batch keeps it whenever the padded slab fits its allocation.
 #include "mi_internal.h"
 
 #include <dlfcn.h>
@@ -80,7 +84,18 @@ int need_rccl(mi_ctx* c) {
 // per-exchange scratch kept on the ctx side of things (one exchange at a time per ctx)
 struct Exchange {
     DevBuf counts, slab, gathered, compact, dup;
+    u64* pin = nullptr;                 // pinned: [0] this rank's scalar, [1 .. nranks] gathered scalars
+    size_t pin_words = 0;
 };
+int ensure_pin(mi_ctx* c, Exchange* x) {
+    const size_t want = (size_t)c->comm_nranks + 1;
+    if (x->pin_words >= want) return MI_OK;
+    if (x->pin) (void)hipHostFree(x->pin);
+    x->pin = nullptr;
+    HIPCHK(c, hipHostMalloc((void**)&x->pin, want * 8, hipHostMallocDefault));
+    x->pin_words = want;
+    return MI_OK;
+}
 Exchange* exchange_of(mi_ctx* c) {
     if (!c->comm_scratch) c->comm_scratch = new Exchange();
     return (Exchange*)c->comm_scratch;
@@ -91,10 +106,11 @@ int exchange_counts_enqueue(mi_batch* b) {
     mi_ctx* c = b->ctx;
     Exchange* x = exchange_of(c);
     HIPCHK(c, x->counts.ensure(8 * (size_t)(c->comm_nranks + 1)));
+    int rc = ensure_pin(c, x);
+    if (rc) return rc;
     u64* d_counts = x->counts.as<u64>();
-    const u64 mine = b->n_chunks;
-    HIPCHK(c, hipMemcpyAsync(d_counts + c->comm_nranks, &mine, 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));            // `mine` is a stack variable
+    x->pin[0] = b->n_chunks;                               // pinned: the async copy needs no sync
+    HIPCHK(c, hipMemcpyAsync(d_counts + c->comm_nranks, x->pin, 8, hipMemcpyHostToDevice, c->stream));
     NCCLCHK(c, rccl()->AllGather(d_counts + c->comm_nranks, d_counts, 1, ncclUint64,
                                  (ncclComm_t)c->comm, c->stream));
     return MI_OK;
@@ -104,18 +120,21 @@ int exchange_slabs_enqueue(mi_batch* b, std::vector<u64>& counts, u64* max_out) 
     mi_ctx* c = b->ctx;
     Exchange* x = exchange_of(c);
     counts.resize((size_t)c->comm_nranks);
-    HIPCHK(c, hipMemcpyAsync(counts.data(), x->counts.p, 8 * counts.size(), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpyAsync(x->pin + 1, x->counts.p, 8 * counts.size(), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));            // sync 1 of 3: the slab size is a host decision
     u64 m = 0;
-    for (u64 v : counts) m = v > m ? v : m;
+    for (size_t r = 0; r < counts.size(); ++r) { counts[r] = x->pin[1 + r]; m = counts[r] > m ? counts[r] : m; }
     *max_out = m;
     if (m == 0) return MI_OK;
-    HIPCHK(c, x->slab.ensure(m * 32));
     HIPCHK(c, x->gathered.ensure(m * 32 * counts.size()));
-    HIPCHK(c, hipMemsetAsync(x->slab.p, 0, m * 32, c->stream));
-    if (b->n_chunks)
-        HIPCHK(c, hipMemcpyAsync(x->slab.p, b->digests.p, b->n_chunks * 32, hipMemcpyDeviceToDevice, c->stream));
-    NCCLCHK(c, rccl()->AllGather(x->slab.p, x->gathered.p, m * 32, ncclUint8, (ncclComm_t)c->comm, c->stream));
+    const void* send = b->digests.p;                       // rows past n_chunks are padding nobody reads
+    if (m * 32 > b->digests.bytes) {                       // a peer holds more rows than this batch could
+        HIPCHK(c, x->slab.ensure(m * 32));
+        if (b->n_chunks)
+            HIPCHK(c, hipMemcpyAsync(x->slab.p, b->digests.p, b->n_chunks * 32, hipMemcpyDeviceToDevice, c->stream));
+        send = x->slab.p;
+    }
+    NCCLCHK(c, rccl()->AllGather(send, x->gathered.p, m * 32, ncclUint8, (ncclComm_t)c->comm, c->stream));
     return MI_OK;
 }
 
@@ -142,7 +161,7 @@ int mark_and_rewrite(mi_batch* b, const std::vector<u64>& counts, u64 m, uint64_
         }
         glob = x->compact.as<u8>();
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // (no sync here: the marking below is enqueued on the same stream)
     // this rank answers for its own rows only, straight into the batch's dup_of column
     // (mi_batch_mark_global); the job-wide unique count is the sum of the ranks'
     // first-occurrence counts, summed by the caller
@@ -160,19 +179,18 @@ int mark_and_rewrite(mi_batch* b, const std::vector<u64>& counts, u64 m, uint64_
 int sum_over_ranks_enqueue(mi_ctx* c, u64 mine) {
     Exchange* x = exchange_of(c);
     u64* d_counts = x->counts.as<u64>();
-    HIPCHK(c, hipMemcpyAsync(d_counts + c->comm_nranks, &mine, 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    x->pin[0] = mine;
+    HIPCHK(c, hipMemcpyAsync(d_counts + c->comm_nranks, x->pin, 8, hipMemcpyHostToDevice, c->stream));
     NCCLCHK(c, rccl()->AllGather(d_counts + c->comm_nranks, d_counts, 1, ncclUint64,
                                  (ncclComm_t)c->comm, c->stream));
     return MI_OK;
 }
 int sum_over_ranks_finish(mi_ctx* c, u64* sum) {
     Exchange* x = exchange_of(c);
-    std::vector<u64> v((size_t)c->comm_nranks);
-    HIPCHK(c, hipMemcpyAsync(v.data(), x->counts.p, 8 * v.size(), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpyAsync(x->pin + 1, x->counts.p, 8 * (size_t)c->comm_nranks, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));            // sync 3 of 3
     *sum = 0;
-    for (u64 t : v) *sum += t;
+    for (int r = 0; r < c->comm_nranks; ++r) *sum += x->pin[1 + r];
     return MI_OK;
 }
 
@@ -239,6 +257,7 @@ int mi_comm_destroy(mi_ctx* c) {
     if (c->comm_scratch) {
         Exchange* x = (Exchange*)c->comm_scratch;
         x->counts.release(); x->slab.release(); x->gathered.release(); x->compact.release(); x->dup.release();
+        if (x->pin) (void)hipHostFree(x->pin);
         delete x;
         c->comm_scratch = nullptr;
     }

@@ -133,3 +133,33 @@ def test_ctx_destroy_refuses_with_live_children():
     e.close()
     assert e._h is None
     assert L.mi_ctx_destroy(None) == 0
+
+
+def test_batch_reset_reuses_the_buffers(oracle, tmp_path):
+    """mi_batch_reset: layer after layer through ONE batch (no reallocation), results of every pass
+    bit-exact and independent of what the batch held before."""
+    import makisu_amd
+    with makisu_amd.Engine() as e, e.batch() as b:
+        for rnd, sizes in enumerate(([300000, 10, 70000], [5], [2 << 20, 0, 4097, 65536, 99], [64])):
+            blobs = [oracle.synth_fill(SEED, 7000 + 10 * rnd + i, 0, n).tobytes() for i, n in enumerate(sizes)]
+            b.reset()
+            assert b.counts() == (0, 0, 0)
+            for i, x in enumerate(blobs):
+                if i % 2 == 0:
+                    b.add_bytes(x, tag=i)
+                else:
+                    pth = tmp_path / ("r%d_%d" % (rnd, i))
+                    pth.write_bytes(x)
+                    b.add_path(str(pth), len(x), i)
+            b.run()
+            assert b.read_back().tobytes() == b"".join(blobs)
+            _same(b.files(), b.chunks(), *_oracle_rows(oracle, blobs, e.cfg))
+        b.reset()
+        b.add_synthetic([65536, 200000], [1, 2], seed=SEED)      # synthetic after host-fed, same buffers
+        b.run()
+        data = [oracle.synth_fill(SEED, c, 0, n).tobytes() for c, n in ((1, 65536), (2, 200000))]
+        _same(b.files(), b.chunks(), *_oracle_rows(oracle, data, e.cfg))
+        b.submit()
+        with pytest.raises(makisu_amd.MiError):
+            b.reset()                                            # not while in flight
+        b.wait()

@@ -29,8 +29,13 @@ def main():
         paths.append(p)
     thr = os.environ.get("MI_STAGE_THREADS", "default")
     with makisu_amd.Engine() as e:
+        b = e.batch(n, n * size)
         for mode in (os.environ.get("MI_FEED_MODES") or "add_bytes,add_bytes,add_path,add_path,add_bytes,add_path").split(","):
-            b = e.batch(n, n * size)
+            if os.environ.get("MI_FEED_FRESH"):        # a new arena every pass (fresh VRAM is cleared by the driver)
+                b.free()
+                b = e.batch(n, n * size)
+            else:
+                b.reset()
             t0 = time.perf_counter()
             for i in range(n):
                 if mode == "add_bytes":
@@ -45,7 +50,7 @@ def main():
                   "device pipeline alone %.1f GB/s"
                   % (thr, mode, n, size >> 20, t1 - t0, t2 - t1, st["ms_h2d"], n * size / (t2 - t0) / 1e9,
                      st["bytes_in"] / st["ms_total"] / 1e6), flush=True)
-            b.free()
+        b.free()
     for p in paths:
         os.unlink(p)
     os.rmdir(d)
