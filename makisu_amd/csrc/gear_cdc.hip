@@ -136,6 +136,12 @@ __device__ __forceinline__ u32 lds_lane_table(const u64* table, int lane) {
     return base | ((u32)(lane % kCopies) * 8u);
 }
 
+__device__ __forceinline__ u32 umin3(u32 a, u32 b, u32 c) {
+    u32 r;
+    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 __device__ __forceinline__ void load_piece(const u8* p, u32x4 (&d)[8]) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) d[i] = *(const u32x4*)(p + 16 * i);
@@ -176,16 +182,21 @@ __device__ __forceinline__ void mark_tile(const u8* __restrict__ fptr, u64 ts, u
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
             roll16(h, cur[g], tab, hh);
-            u32 m = 0xFFFFFFFFu;
+            // one v_min3_u32 per two hashes: 8 ops for 16 bytes (hipcc builds a deeper v_min_u32 tree)
+            u32 m = umin3(hh[0], hh[1], hh[2]);
 #pragma unroll
-            for (int k = 0; k < 16; k += 2) m = min(m, min(hh[k], hh[k + 1]));   // v_min3_u32
+            for (int k = 3; k < 15; k += 2) m = umin3(m, hh[k], hh[k + 1]);
+            m = min(m, hh[15]);
             if (m <= thresh_m1) {                        // rare: a candidate among these 16 bytes
+                // (positions at or past the file end are not filtered here: selection never looks
+                // beyond the tile's last byte, and at most one lane hashes up to 127 slack bytes)
+                const u32 base = (u32)(pc * kPiece + g * 16);
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
-                    const u32 pos = run0 + pc * kPiece + g * 16 + k;            // byte index in tile
-                    if (hh[k] <= thresh_m1 && pos < tlen) {
+                    if (hh[k] <= thresh_m1) {
+                        const u32 pos = run0 + base + (u32)k;                       // byte index in tile
                         atomicOr(&bitmap[pos >> 5], 1u << (pos & 31));
-                        cand_push(pk, ovf, pos - run0);
+                        cand_push(pk, ovf, base + (u32)k);
                     }
                 }
             }
