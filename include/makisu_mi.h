@@ -404,6 +404,37 @@ typedef struct {
 int mi_snapshot_diff(const mi_snapshot_side* before, const mi_snapshot_side* after, int ignore_time,
                      uint8_t* after_flags, uint8_t* before_whiteout);
 
+/* ---- the layer of a COPY / ADD step: MemFS.AddLayerByCopyOps on entry lists ---------------- *
+ * addToLayer + maybeAddToLayer + addAncestors (lib/snapshot/mem_fs.go:276-289, 343-421, 440-566)
+ * and CopyOperation's source handling (lib/snapshot/copy_op.go:29-100, utils.go:249-327):
+ *   tree / tree_root  the merged view so far (entries with relpaths below tree_root, e.g. the
+ *                     result of mi_entries_apply_layer) and the directory it describes;
+ *   ops               one per COPY/ADD: srcs relative to src_root (symlinks inside src_root are
+ *                     resolved, one leaving it is an error), dst absolute, "dir/" = copy INTO it;
+ *                     a single non-directory source with a dst not ending in "/" copies onto dst;
+ *   now_sec           mtime of the directories the step has to create.
+ * The destination directory chain is ensured first (existing ancestors are carried into the layer,
+ * symlinks on the way followed, missing directories created with the op's uid/gid), then every
+ * walked source path (snapshot walk rules, no blacklist) gets its header with the op's uid/gid and
+ * is added iff tario.IsSimilarHeader says it differs from what the tree holds.  No whiteouts: a
+ * copy never deletes.  Result: the layer's entries in commit order (mi_copy_layer_entries), each
+ * with the path its bytes are read from ("" for created directories) -- feed them to mi_layer_add
+ * and the regular files to a batch.  The caller's tree is not modified.  Host logic.           */
+typedef struct {
+    const char*        src_root;
+    const char* const* srcs;
+    uint64_t           n_srcs;
+    const char*        dst;
+    uint32_t           uid, gid;
+} mi_copy_op;
+typedef struct mi_copy_layer mi_copy_layer;
+int  mi_snapshot_copy_ops(const mi_tree_entry* tree, uint64_t n_tree, const char* tree_root,
+                          const mi_copy_op* ops, uint64_t n_ops, int64_t now_sec,
+                          mi_copy_layer** out, uint64_t* n_entries, char* err, uint64_t err_cap);
+int  mi_copy_layer_entries(const mi_copy_layer* layer, mi_tree_entry* out, const char** src_paths,
+                           uint64_t cap);
+void mi_copy_layer_free(mi_copy_layer* layer);
+
 /* ---- the layer writer: tar framing + the two serial layer digests (host threads) ---------- *
  * step.tarAndGzipDiffs + MemFS.commitLayer (lib/builder/step/common.go:35-111,
  * lib/snapshot/mem_fs.go:424-433) behind the ABI: the shim hands over the layer's entries in

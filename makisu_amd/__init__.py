@@ -74,6 +74,12 @@ class SnapshotSide(C.Structure):
 DIFF_SAME, DIFF_CHANGED, DIFF_ANCESTOR = 0, 1, 2
 
 
+class CopyOp(C.Structure):
+    """mi_copy_op."""
+    _fields_ = [("src_root", C.c_char_p), ("srcs", C.POINTER(C.c_char_p)), ("n_srcs", C.c_uint64),
+                ("dst", C.c_char_p), ("uid", C.c_uint32), ("gid", C.c_uint32)]
+
+
 class LayerConfig(C.Structure):
     """mi_layer_config."""
     _fields_ = [("struct_size", C.c_uint32), ("gzip_level", C.c_int32), ("out_fd", C.c_int32),
@@ -185,6 +191,10 @@ def load_library(rebuild=False):
         "mi_tar_free": ([vp], None),
         "mi_entry_similar": ([C.POINTER(TreeEntry), C.POINTER(TreeEntry), C.c_int, vp, vp,
                               C.POINTER(C.c_int)], C.c_int),
+        "mi_snapshot_copy_ops": ([C.POINTER(TreeEntry), u64, C.c_char_p, C.POINTER(CopyOp), u64, C.c_int64,
+                                  C.POINTER(vp), u64p, C.c_char_p, u64], C.c_int),
+        "mi_copy_layer_entries": ([vp, C.POINTER(TreeEntry), C.POINTER(C.c_char_p), u64], C.c_int),
+        "mi_copy_layer_free": ([vp], None),
         "mi_layer_config_default": ([C.POINTER(LayerConfig)], C.c_int),
         "mi_layer_begin": ([C.POINTER(LayerConfig), C.POINTER(vp)], C.c_int),
         "mi_layer_add": ([vp, C.POINTER(TreeEntry), C.c_char_p], C.c_int),
@@ -399,6 +409,43 @@ def tree_walk(root, rel_base=None, blacklist=(), mode=TREE_CONTEXT, full=False):
                  e.file_index, e.size, e.kind, e.mode) for e in arr[:n.value]]
     finally:
         L.mi_tree_free(h)
+
+
+def copy_ops_layer(tree, tree_root, ops, now_sec=0):
+    """mi_snapshot_copy_ops: tree = list of entry dicts, ops = list of dicts(src_root, srcs, dst, uid,
+    gid).  Returns the layer as a list of entry dicts (commit order) with an extra "src" key."""
+    L = load_library()
+    keep = []
+    arr = _entry_array(tree, keep)
+    cops = (CopyOp * max(len(ops), 1))()
+    for i, o in enumerate(ops):
+        srcs = [os.fsencode(x) for x in o["srcs"]]
+        sarr = (C.c_char_p * max(len(srcs), 1))(*srcs)
+        keep += [srcs, sarr]
+        cops[i].src_root = os.fsencode(o["src_root"])
+        cops[i].srcs, cops[i].n_srcs = sarr, len(srcs)
+        cops[i].dst = os.fsencode(o["dst"])
+        cops[i].uid, cops[i].gid = o.get("uid", 0), o.get("gid", 0)
+    h, n = C.c_void_p(), C.c_uint64()
+    err = C.create_string_buffer(600)
+    rc = L.mi_snapshot_copy_ops(arr, len(tree), os.fsencode(tree_root), cops, len(ops), now_sec, C.byref(h),
+                                C.byref(n), err, len(err))
+    if rc:
+        raise MiError(rc, "mi_snapshot_copy_ops: %s" % err.value.decode(errors="replace"))
+    try:
+        out = (TreeEntry * max(n.value, 1))()
+        srcp = (C.c_char_p * max(n.value, 1))()
+        rc = L.mi_copy_layer_entries(h, out, srcp, n.value)
+        if rc:
+            raise MiError(rc, "mi_copy_layer_entries")
+        res = []
+        for i in range(n.value):
+            d = _entry_dict(out[i])
+            d["src"] = os.fsdecode(srcp[i]) if srcp[i] is not None else ""
+            res.append(d)
+        return res
+    finally:
+        L.mi_copy_layer_free(h)
 
 
 class Layer:

@@ -183,10 +183,16 @@ __device__ __forceinline__ void mark_tile(const u8* __restrict__ fptr, u64 ts, u
         for (int g = 0; g < 8; ++g) {
             roll16(h, cur[g], tab, hh);
             // one v_min3_u32 per two hashes: 8 ops for 16 bytes (hipcc builds a deeper v_min_u32 tree)
+#ifndef MI_GEAR_MIN_TREE
             u32 m = umin3(hh[0], hh[1], hh[2]);
 #pragma unroll
             for (int k = 3; k < 15; k += 2) m = umin3(m, hh[k], hh[k + 1]);
             m = min(m, hh[15]);
+#else       // A/B knob: let hipcc build its own (deeper, 11-op) v_min_u32 / v_min3_u32 tree
+            u32 m = 0xFFFFFFFFu;
+#pragma unroll
+            for (int k = 0; k < 16; k += 2) m = min(m, min(hh[k], hh[k + 1]));
+#endif
             if (m <= thresh_m1) {                        // rare: a candidate among these 16 bytes
                 // (positions at or past the file end are not filtered here: selection never looks
                 // beyond the tile's last byte, and at most one lane hashes up to 127 slack bytes)

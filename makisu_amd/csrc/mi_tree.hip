@@ -145,6 +145,7 @@ static const MountTable& mountpoints() {
 struct Walker {
     mi_batch* batch;
     std::string rel_base;
+    std::string link_root;     // root that absolute symlink targets lose (empty = rel_base)
     std::vector<std::string> blacklist;
     uint32_t mode;
     Tree* tree;
@@ -206,12 +207,13 @@ struct Walker {
                 // memLayer.createHeader (lib/snapshot/mem_layer.go:171-185): an absolute target
                 // loses the root prefix -- pathutils.TrimRoot (lib/pathutils/path.go:63-68):
                 // plain string prefix, then AbsPath; a target outside the root fails the scan
-                if (!has_prefix(e.link, rel_base)) {
-                    err = "trim symlink root: failed to trim root prefix " + rel_base + " from path " + e.link;
+                const std::string& lr = link_root.empty() ? rel_base : link_root;
+                if (!has_prefix(e.link, lr)) {
+                    err = "trim symlink root: failed to trim root prefix " + lr + " from path " + e.link;
                     rc = MI_ERR_INVALID;
                     return;
                 }
-                e.link = abs_path(e.link.substr(rel_base.size()));
+                e.link = abs_path(e.link.substr(lr.size()));
             }
             tree->entries.push_back(e);
         } else {
@@ -566,3 +568,311 @@ int mi_entry_similar(const mi_tree_entry* a, const mi_tree_entry* b, int ignore_
 }
 
 }  // extern "C"
+
+// ---- MemFS.AddLayerByCopyOps: the layer a COPY / ADD step creates, on entry lists -----------------
+// addToLayer + maybeAddToLayer(createWhiteout = false) + addAncestors + isUpdated + createHeader
+// (lib/snapshot/mem_fs.go:276-289, 343-421, 440-503, 505-566; mem_layer.go:152-190) and
+// CopyOperation's source resolution (copy_op.go, utils.go:249-327), restated on a path-keyed tree:
+//   * a single non-directory source copies onto dst (or into dst + "/" + base when dst ends with "/");
+//     otherwise dst is ensured to exist -- every EXISTING ancestor is carried into the layer, a
+//     symlink on the way is followed (its target joined with the rest of the path, the reference's
+//     own rule, depth-limited), missing directories are created with the last existing ancestor's
+//     mode, the op's uid/gid and mtime = now -- and the sources' CONTENTS are copied below it;
+//   * sources are resolved through symlinks inside src_root (a link leaving the root is an error)
+//     and walked like every snapshot walk (".wh..wh." names, special files and mountpoints skipped;
+//     no blacklist: the reference passes nil here);
+//   * every walked path gets createHeader's header with the op's uid/gid and is added iff isUpdated
+//     says so (tario.IsSimilarHeader against what the tree holds); adding a path first carries its
+//     existing ancestors, then replaces the node: a directory keeps the old node's children, anything
+//     else drops them.
+// Result: the layer's entries in commit order (sorted by dst), each with the path its content is
+// read from ("" for directories the op created).  The caller's tree is not modified; to continue,
+// apply the layer to it with mi_entries_apply_layer.
+namespace mi_copy {
+
+struct Node {
+    mi_walk::Entry e;          // relpath = dst without the leading "/"
+    std::string src;
+};
+struct Fs {
+    std::map<std::string, Node> tree;      // key = absolute dst path ("/" = root)
+    std::map<std::string, Node> layer;     // memLayer.files, keyed by dst
+    std::string root;                      // fs.tree.src
+    int64_t now = 0;
+    std::string err;
+    int rc = MI_OK;
+
+    bool fail(int code, const std::string& m) { if (!rc) { rc = code; err = m; } return false; }
+
+    void update_memfs(const std::string& dst, const Node& n) {          // contentMemFile.updateMemFS
+        if (n.e.kind != 0) {                                            // not a directory: children go
+            const std::string pre = dst == "/" ? dst : dst + "/";
+            for (auto it = tree.lower_bound(pre); it != tree.end() && mi_walk::has_prefix(it->first, pre);)
+                it = tree.erase(it);
+        }
+        tree[dst] = n;
+    }
+    void add_header(const std::string& dst, const Node& n) {
+        layer[dst] = n;
+        // contentMemFile.updateMemFS walks the tree part by part (mem_layer.go:57-80): every
+        // intermediate node has to exist ("missing intermediate directory"); a symlink in the
+        // path has no children, so a destination spelled THROUGH a link fails here exactly as it
+        // does in the reference (addAncestors' resolved path is only used by the createDst branch)
+        for (std::string d = mi_walk::dir_of(dst); d != "/" && d != "."; d = mi_walk::dir_of(d)) {
+            auto it = tree.find(d);
+            if (it == tree.end() || it->second.e.kind == 2) {
+                fail(MI_ERR_INVALID, "update memfs with file " + dst + ": missing intermediate directory " +
+                                         mi_walk::base_of(d) + " in " + dst);
+                return;
+            }
+        }
+        update_memfs(dst, n);
+    }
+    static std::vector<std::string> split(const std::string& p) {       // pathutils.SplitPath
+        std::vector<std::string> parts;
+        size_t i = 0;
+        while (i < p.size()) {
+            while (i < p.size() && p[i] == '/') ++i;
+            size_t j = i;
+            while (j < p.size() && p[j] != '/') ++j;
+            if (j > i) parts.push_back(p.substr(i, j - i));
+            i = j;
+        }
+        return parts;
+    }
+    static std::string join(const std::vector<std::string>& parts, size_t n) {
+        std::string s;
+        for (size_t i = 0; i < n; ++i) s += "/" + parts[i];
+        return s.empty() ? "/" : s;
+    }
+    // addAncestors (mem_fs.go:505-566); returns the resolved dst
+    std::string add_ancestors(const std::string& dst, bool inclusive, int depth, uint32_t uid, uint32_t gid) {
+        if (depth >= 1024) { fail(MI_ERR_INVALID, "symlink loop at " + dst); return dst; }
+        const std::vector<std::string> parts = split(dst);
+        const size_t end = inclusive ? parts.size() : (parts.empty() ? 0 : parts.size() - 1);
+        std::string curr = "/", last_ancestor = "/";
+        size_t i = 0;
+        for (; i < end; ++i) {
+            const std::string child = (curr == "/" ? "" : curr) + "/" + parts[i];
+            auto it = tree.find(child);
+            if (it == tree.end()) break;
+            const Node n = it->second;                                  // copy: add_header mutates the map
+            add_header(child, n);
+            if (n.e.kind == 0) {
+                last_ancestor = child;
+                curr = child;
+            } else if (n.e.kind == 2) {                                 // add ancestors of the symlink target too
+                std::string target = n.e.link;
+                for (size_t k = i + 1; k < parts.size(); ++k) target += "/" + parts[k];
+                return add_ancestors(mi_walk::clean_rooted(target), inclusive, depth + 1, uid, gid);
+            }
+            // any other type: the walk goes on below the same directory (the reference's switch
+            // has no case for it)
+        }
+        for (size_t j = i; j < end; ++j) {                              // missing intermediate directories
+            const std::string p = join(parts, j + 1);
+            Node d;
+            auto la = tree.find(last_ancestor);
+            d.e.mode = la != tree.end() ? la->second.e.mode : (uint32_t)(S_IFDIR | 0755);
+            d.e.kind = 0;
+            d.e.relpath = p.substr(1);
+            d.e.mtime = now;
+            d.e.uid = uid;
+            d.e.gid = gid;
+            add_header(p, d);
+        }
+        return dst;
+    }
+    // maybeAddToLayer(l, src, dst, hdr, createWhiteout = false)
+    void maybe_add(const std::string& src, const std::string& dst, Node n) {
+        bool updated = true;
+        auto it = tree.find(dst);
+        if (it != tree.end()) {
+            mi_tree_entry a, b;
+            auto fill = [](const Node& x, mi_tree_entry* o) {
+                memset(o, 0, sizeof *o);
+                o->relpath = x.e.relpath.empty() ? "" : x.e.relpath.c_str();
+                o->link_target = x.e.has_link ? x.e.link.c_str() : nullptr;
+                o->size = x.e.size; o->mtime_sec = x.e.mtime; o->mode = x.e.mode; o->kind = x.e.kind;
+                o->uid = x.e.uid; o->gid = x.e.gid; o->file_index = -1;
+            };
+            fill(it->second, &a);
+            fill(n, &b);
+            int similar = 0;
+            if (a.kind <= 3 && b.kind <= 3 && mi_entry_similar(&a, &b, 0, nullptr, nullptr, &similar) != MI_OK) {
+                fail(MI_ERR_INVALID, "check header " + dst + ": unsupported type");
+                return;
+            }
+            updated = !similar;
+        }
+        if (updated && dst != "/") {
+            add_ancestors(dst, false, 0, 0, 0);
+            if (rc) return;
+            n.src = src;
+            add_header(dst, n);
+        }
+    }
+};
+
+// evalSymlinks (utils.go:249-327): resolves the symlinks of p inside root; a link that leaves the
+// root is an error.  Returns the path relative to root ("/"-rooted).
+static bool eval_symlinks(const std::string& p, const std::string& root, std::string* out, std::string* err) {
+    if (p.empty()) { *out = p; return true; }
+    std::string cur = p;
+    for (int walked = 0; walked <= 255;) {
+        // resolve the first symlink found walking the components of cur
+        const std::vector<std::string> parts = Fs::split(cur);
+        std::string acc;
+        bool replaced = false;
+        for (size_t i = 0; i < parts.size(); ++i) {
+            const std::string here = acc + "/" + parts[i];
+            struct stat st;
+            if (lstat((root + here).c_str(), &st) != 0) { *err = "walk link: lstat: " + here + ": " + strerror(errno); return false; }
+            if (S_ISLNK(st.st_mode)) {
+                std::vector<char> buf(4096);
+                const ssize_t n = readlink((root + here).c_str(), buf.data(), buf.size() - 1);
+                if (n < 0) { *err = "readlink " + here + ": " + strerror(errno); return false; }
+                std::string target(buf.data(), (size_t)n);
+                if (!target.empty() && target[0] == '/') {
+                    if (!mi_walk::has_prefix(target, root)) {
+                        *err = "link points outside of root: " + root + here + " -> " + target;
+                        return false;
+                    }
+                    target = target.substr(root.size());
+                    if (target.empty() || target[0] != '/') target = "/" + target;
+                } else {
+                    target = acc + "/" + target;                         // relative to the link's directory
+                }
+                for (size_t k = i + 1; k < parts.size(); ++k) target += "/" + parts[k];
+                cur = mi_walk::clean_rooted(target);
+                ++walked;
+                replaced = true;
+                break;
+            }
+            acc = here;
+        }
+        if (!replaced) { *out = mi_walk::abs_path(cur); return true; }
+    }
+    *err = "eval symlinks: too many links";
+    return false;
+}
+
+}  // namespace mi_copy
+
+struct mi_copy_layer {
+    std::vector<mi_copy::Node> nodes;                       // commit order
+};
+
+extern "C" int mi_snapshot_copy_ops(const mi_tree_entry* tree, uint64_t n_tree, const char* tree_root,
+                                    const mi_copy_op* ops, uint64_t n_ops, int64_t now_sec,
+                                    mi_copy_layer** out, uint64_t* n_entries, char* err, uint64_t err_cap) {
+    auto put_err = [&](const std::string& m) { if (err && err_cap) snprintf(err, (size_t)err_cap, "%s", m.c_str()); };
+    if ((n_tree && !tree) || (n_ops && !ops) || !out || !tree_root) return MI_ERR_INVALID;
+    mi_copy::Fs fs;
+    fs.root = mi_walk::abs_path(tree_root);
+    fs.now = now_sec;
+    {   // the root node always exists (NewMemFS stats it)
+        mi_copy::Node r;
+        r.e.kind = 0;
+        r.e.mode = S_IFDIR | 0755;
+        struct stat st;
+        if (lstat(fs.root.c_str(), &st) == 0) { r.e.mode = st.st_mode; r.e.mtime = st.st_mtime; r.e.uid = st.st_uid; r.e.gid = st.st_gid; }
+        fs.tree["/"] = r;
+    }
+    for (uint64_t i = 0; i < n_tree; ++i) {
+        const mi_tree_entry& e = tree[i];
+        mi_copy::Node n;
+        const char* rp = e.relpath ? e.relpath : "";
+        const std::string p = mi_walk::abs_path(strcmp(rp, ".") == 0 ? "" : rp);
+        n.e.relpath = p == "/" ? "" : p.substr(1);
+        n.e.kind = e.kind; n.e.mode = e.mode; n.e.mtime = e.mtime_sec; n.e.uid = e.uid; n.e.gid = e.gid; n.e.size = e.size;
+        if (e.link_target) { n.e.link = e.link_target; n.e.has_link = true; }
+        n.src = fs.root == "/" ? p : fs.root + (p == "/" ? "" : p);
+        fs.tree[p] = n;
+    }
+    for (uint64_t k = 0; k < n_ops && !fs.rc; ++k) {
+        const mi_copy_op& c = ops[k];
+        if (!c.src_root || !c.dst || (c.n_srcs && !c.srcs) || c.n_srcs == 0) return MI_ERR_INVALID;
+        const std::string src_root = mi_walk::abs_path(c.src_root);
+        std::string dst = c.dst;
+        bool create_dst = true;
+        if (c.n_srcs == 1) {
+            struct stat st;
+            const std::string s0 = src_root + mi_walk::abs_path(c.srcs[0] ? c.srcs[0] : "");
+            if (stat(s0.c_str(), &st) != 0) { put_err("stat src " + s0 + ": " + strerror(errno)); return MI_ERR_IO; }
+            if (!S_ISDIR(st.st_mode)) create_dst = false;            // case 1: file onto file
+        }
+        if (create_dst) {
+            std::string resolved = fs.add_ancestors(mi_walk::abs_path(dst), true, 0, c.uid, c.gid);
+            if (fs.rc) break;
+            if (resolved.empty() || resolved.back() != '/') resolved += "/";
+            dst = resolved;
+        }
+        const bool dst_is_dir = !dst.empty() && dst.back() == '/';
+        for (uint64_t si = 0; si < c.n_srcs && !fs.rc; ++si) {
+            std::string rel, e2;
+            if (!mi_copy::eval_symlinks(mi_walk::abs_path(c.srcs[si] ? c.srcs[si] : ""), src_root, &rel, &e2)) {
+                put_err("eval symlinks for " + std::string(c.srcs[si] ? c.srcs[si] : "") + ": " + e2);
+                return MI_ERR_IO;
+            }
+            const std::string src = src_root == "/" ? rel : src_root + (rel == "/" ? "" : rel);
+            mi_walk::Tree walked;
+            mi_walk::Walker w;
+            w.batch = nullptr;
+            w.rel_base = src;
+            w.mode = MI_TREE_SCAN;                                      // shouldSkip with a nil blacklist
+            w.tree = &walked;
+            w.link_root = fs.root;                                      // createHeader trims by the MEMFS root
+            w.visit(src);
+            if (w.rc) { put_err("copy src " + src + ": " + w.err); return w.rc; }
+            for (const mi_walk::Entry& we : walked.entries) {
+                const bool is_src = we.relpath == ".";
+                std::string curr_dst;
+                if (is_src) {
+                    if (we.kind == 0) continue;                         // the directory itself: contents only
+                    curr_dst = !dst_is_dir ? dst : mi_walk::clean_rooted(dst + "/" + mi_walk::base_of(src));
+                } else {
+                    curr_dst = mi_walk::clean_rooted(dst + "/" + we.relpath);
+                }
+                curr_dst = mi_walk::abs_path(curr_dst);
+                mi_copy::Node n;
+                n.e = we;
+                n.e.relpath = curr_dst == "/" ? "" : curr_dst.substr(1);
+                n.e.uid = c.uid;
+                n.e.gid = c.gid;
+                const std::string curr_src = is_src ? src : src + "/" + we.relpath;
+                fs.maybe_add(curr_src, curr_dst, n);
+                if (fs.rc) break;
+            }
+        }
+    }
+    if (fs.rc) { put_err(fs.err); return fs.rc; }
+    mi_copy_layer* l = new mi_copy_layer();
+    for (auto& kv : fs.layer) l->nodes.push_back(kv.second);             // std::map order == sort.Strings order
+    *out = l;
+    if (n_entries) *n_entries = l->nodes.size();
+    return MI_OK;
+}
+
+extern "C" int mi_copy_layer_entries(const mi_copy_layer* l, mi_tree_entry* out, const char** src_paths, uint64_t cap) {
+    if (!l || (cap && !out)) return MI_ERR_INVALID;
+    if (cap < l->nodes.size()) return MI_ERR_CAPACITY;
+    int64_t n_regular = 0;
+    for (size_t i = 0; i < l->nodes.size(); ++i) {
+        const mi_copy::Node& n = l->nodes[i];
+        memset(&out[i], 0, sizeof out[i]);
+        out[i].relpath = n.e.relpath.c_str();
+        out[i].link_target = n.e.has_link ? n.e.link.c_str() : nullptr;
+        out[i].file_index = n.e.kind == 1 ? n_regular++ : -1;
+        out[i].size = n.e.size;
+        out[i].mtime_sec = n.e.mtime;
+        out[i].mode = n.e.mode;
+        out[i].kind = n.e.kind;
+        out[i].uid = n.e.uid;
+        out[i].gid = n.e.gid;
+        if (src_paths) src_paths[i] = n.src.c_str();
+    }
+    return MI_OK;
+}
+
+extern "C" void mi_copy_layer_free(mi_copy_layer* l) { delete l; }

@@ -1,0 +1,168 @@
+"""CPU tests of mi_snapshot_copy_ops: MemFS.AddLayerByCopyOps on entry lists.
+
+The cases of the reference's TestCreateLayerByCopy (lib/snapshot/mem_fs_test.go:688-1036) replayed
+on real trees -- where the reference asserts findNode(fs, dst).src == <source path>, these assert
+that the layer holds dst with that source -- plus addAncestors' symlink cases from TestGetAncestors
+(:340-570) and the isUpdated filter (a copy onto an identical header adds nothing).
+"""
+import os
+
+import pytest
+
+import makisu_amd as M
+
+UID, GID = 1234, 5678            # validChown in the reference's tests
+
+
+def _tree(root, spec):
+    """spec: list of (path, kind, content); builds it under root, returns the walk's entries."""
+    for p, kind, content in spec:
+        full = root / p.lstrip("/")
+        if kind == "d":
+            full.mkdir(parents=True, exist_ok=True)
+        elif kind == "f":
+            full.parent.mkdir(parents=True, exist_ok=True)
+            full.write_text(content)
+            full.chmod(0o755)
+        else:
+            full.parent.mkdir(parents=True, exist_ok=True)
+            os.symlink(content, full)
+    ents = M.tree_walk(str(root), None, (), M.TREE_SCAN, full=True)
+    return [e for e in ents if e["relpath"] != "."]
+
+
+def _op(root, srcs, dst):
+    return {"src_root": str(root), "srcs": [s.lstrip("/") for s in srcs], "dst": dst, "uid": UID, "gid": GID}
+
+
+def _by_dst(layer):
+    return {"/" + e["relpath"]: e for e in layer}
+
+
+def test_file_to_dir_file(tmp_path):                         # "file dir/file"
+    tree = _tree(tmp_path, [("/test1", "d", ""), ("/test1/test.txt", "f", "hello")])
+    layer = M.copy_ops_layer(tree, str(tmp_path), [_op(tmp_path, ["/test1/test.txt"], "/test2/test.txt")], now_sec=77)
+    got = _by_dst(layer)
+    assert set(got) == {"/test2", "/test2/test.txt"}
+    assert got["/test2/test.txt"]["src"] == str(tmp_path / "test1/test.txt")
+    assert (got["/test2/test.txt"]["uid"], got["/test2/test.txt"]["gid"]) == (UID, GID)
+    # the missing parent: created with default owner 0/0 (maybeAddToLayer's addAncestors(..., 0, 0, 0)),
+    # the clock's time, and no source
+    d = got["/test2"]
+    assert d["kind"] == M.KIND_DIR and d["src"] == "" and d["mtime_sec"] == 77 and (d["uid"], d["gid"]) == (0, 0)
+    assert [e["relpath"] for e in layer] == ["test2", "test2/test.txt"]          # commit order
+
+
+def test_file_to_dir_slash(tmp_path):                        # "file dir/"
+    tree = _tree(tmp_path, [("/test1", "d", ""), ("/test1/test.txt", "f", "hello")])
+    got = _by_dst(M.copy_ops_layer(tree, str(tmp_path), [_op(tmp_path, ["/test1/test.txt"], "/dst/")], now_sec=5))
+    assert set(got) == {"/dst", "/dst/test.txt"}
+    assert got["/dst/test.txt"]["src"] == str(tmp_path / "test1/test.txt")
+    # a single non-directory source never runs the createDst branch (mem_fs.go:357-366): /dst is only
+    # created as the file's missing ancestor, owner 0/0
+    assert (got["/dst"]["uid"], got["/dst"]["gid"]) == (0, 0)
+
+
+def test_file_file_to_dir(tmp_path):                         # "file file dir/"
+    tree = _tree(tmp_path, [("/test1", "d", ""), ("/test1/test2.txt", "f", "hello"), ("/test1/test3.txt", "f", "hello")])
+    got = _by_dst(M.copy_ops_layer(tree, str(tmp_path),
+                                   [_op(tmp_path, ["/test1/test2.txt", "/test1/test3.txt"], "/dst/")]))
+    assert got["/dst/test2.txt"]["src"] == str(tmp_path / "test1/test2.txt")
+    assert got["/dst/test3.txt"]["src"] == str(tmp_path / "test1/test3.txt")
+    assert got["/dst"]["kind"] == M.KIND_DIR
+    assert (got["/dst"]["uid"], got["/dst"]["gid"]) == (UID, GID)                # createDst: the op's owner
+
+
+def test_dir_to_dir_copies_contents(tmp_path):               # "dir dir/"
+    tree = _tree(tmp_path, [("/test1/test2", "d", ""), ("/test1/test2/test.txt", "f", "hello")])
+    got = _by_dst(M.copy_ops_layer(tree, str(tmp_path), [_op(tmp_path, ["/test1/test2"], "/dst/")]))
+    assert set(got) == {"/dst", "/dst/test.txt"}             # the directory itself is not copied
+    assert got["/dst/test.txt"]["src"] == str(tmp_path / "test1/test2/test.txt")
+
+
+def test_dir_dir_and_file_dir_to_dir(tmp_path):              # "dir dir dir/", "file dir dir/"
+    spec = [("/test1/test2", "d", ""), ("/test1/test2/test3.txt", "f", "hello"), ("/test1/test4/test5", "d", ""),
+            ("/test1/test4/test5/test6.txt", "f", "hello")]
+    tree = _tree(tmp_path, spec)
+    for srcs in (["/test1/test2", "/test1/test4"], ["/test1/test2/test3.txt", "/test1/test4"]):
+        got = _by_dst(M.copy_ops_layer(tree, str(tmp_path), [_op(tmp_path, srcs, "/dst/")]))
+        assert set(got) == {"/dst", "/dst/test3.txt", "/dst/test5", "/dst/test5/test6.txt"}
+        assert got["/dst/test3.txt"]["src"] == str(tmp_path / "test1/test2/test3.txt")
+        assert got["/dst/test5"]["src"] == str(tmp_path / "test1/test4/test5")
+        assert got["/dst/test5/test6.txt"]["src"] == str(tmp_path / "test1/test4/test5/test6.txt")
+
+
+def test_workdir_relative_destination(tmp_path):             # "workdir": resolveDestination("/wrk", "dst/")
+    spec = [("/test1/test2", "d", ""), ("/test1/test2/test3.txt", "f", "hello"), ("/test1/test4/test5", "d", ""),
+            ("/test1/test4/test5/test6.txt", "f", "hello")]
+    tree = _tree(tmp_path, spec)
+    got = _by_dst(M.copy_ops_layer(tree, str(tmp_path),
+                                   [_op(tmp_path, ["/test1/test2/test3.txt", "/test1/test4"], "/wrk/dst/")]))
+    assert {"/wrk", "/wrk/dst", "/wrk/dst/test3.txt", "/wrk/dst/test5", "/wrk/dst/test5/test6.txt"} == set(got)
+
+
+def test_unchanged_copy_adds_nothing_and_existing_ancestors_are_carried(tmp_path):
+    tree = _tree(tmp_path, [("/app", "d", ""), ("/app/conf", "d", ""), ("/app/conf/a.txt", "f", "same"),
+                            ("/src/a.txt", "f", "same"), ("/src/b.txt", "f", "new")])
+    # make /src/a.txt's header identical to /app/conf/a.txt's: same size, mode, mtime; the op's owner
+    # equals the tree entry's owner (the test runs as this uid/gid)
+    st = os.lstat(tmp_path / "app/conf/a.txt")
+    os.utime(tmp_path / "src/a.txt", (st.st_mtime, st.st_mtime))
+    tree = M.tree_walk(str(tmp_path), None, (), M.TREE_SCAN, full=True)[1:]
+    op = {"src_root": str(tmp_path), "srcs": ["src"], "dst": "/app/conf/", "uid": st.st_uid, "gid": st.st_gid}
+    got = _by_dst(M.copy_ops_layer(tree, str(tmp_path), [op]))
+    assert "/app/conf/a.txt" not in got                      # isUpdated: similar header, not added
+    assert got["/app/conf/b.txt"]["src"] == str(tmp_path / "src/b.txt")
+    # the existing directories on the way are part of the layer, with their own source paths
+    assert got["/app"]["src"] == str(tmp_path / "app") and got["/app/conf"]["src"] == str(tmp_path / "app/conf")
+
+
+def test_destination_through_a_symlink(tmp_path):
+    """TestGetAncestors FollowSymlinkFullResolve: /lnk -> /real; copying into /lnk/sub/ carries the
+    link, then creates below its target."""
+    tree = _tree(tmp_path, [("/real", "d", ""), ("/lnk", "l", str(tmp_path / "real")), ("/src/f", "f", "x")])
+    assert [e for e in tree if e["relpath"] == "lnk"][0]["link_target"] == "/real"     # root-trimmed by the walk
+    got = _by_dst(M.copy_ops_layer(tree, str(tmp_path), [_op(tmp_path, ["/src"], "/lnk/sub/")]))
+    assert "/lnk" in got and got["/lnk"]["kind"] == M.KIND_SYMLINK
+    assert "/real" in got and "/real/sub" in got and got["/real/sub"]["kind"] == M.KIND_DIR
+    assert got["/real/sub/f"]["src"] == str(tmp_path / "src/f")                   # dst resolved through the link
+    # a single FILE source skips the createDst branch: its destination stays spelled through the
+    # link and updateMemFS refuses it ("missing intermediate directory"), as in the reference
+    with pytest.raises(M.MiError) as ei:
+        M.copy_ops_layer(tree, str(tmp_path), [_op(tmp_path, ["/src/f"], "/lnk/sub/")])
+    assert "missing intermediate directory" in str(ei.value)
+
+
+def test_symlink_loop_and_errors(tmp_path):
+    tree = _tree(tmp_path, [("/a", "l", str(tmp_path / "a" / "b")), ("/src/f", "f", "x")])   # /a -> /a/b -> ...
+    with pytest.raises(M.MiError) as ei:
+        M.copy_ops_layer(tree, str(tmp_path), [_op(tmp_path, ["/src/f"], "/a/c/")])
+    assert "symlink loop" in str(ei.value)
+    with pytest.raises(M.MiError) as ei:                     # stat src fails
+        M.copy_ops_layer(tree, str(tmp_path), [_op(tmp_path, ["/nope"], "/dst/")])
+    assert ei.value.code == -5
+    os.symlink("/etc", tmp_path / "src" / "out")             # a source symlink leaving the root
+    with pytest.raises(M.MiError) as ei:
+        M.copy_ops_layer(tree, str(tmp_path), [_op(tmp_path, ["/src/out/passwd", "/src/f"], "/dst/")])
+    assert "outside of root" in str(ei.value)
+
+
+def test_copy_layer_feeds_the_layer_writer(tmp_path):
+    """The COPY step end to end on the host side: copy-ops layer -> mi_layer_* tar -> read back."""
+    import io
+    import tarfile
+    tree = _tree(tmp_path / "ctx", [("/app/main.py", "f", "print(1)\n"), ("/app/lib/util.py", "f", "x = 2\n")])
+    layer = M.copy_ops_layer([], str(tmp_path / "ctx"), [_op(tmp_path / "ctx", ["/app"], "/srv/app/")], now_sec=9)
+    out = tmp_path / "layer.tar"
+    fd = os.open(out, os.O_WRONLY | os.O_CREAT, 0o644)
+    with M.Layer(out_fd=fd, gzip_level=M.GZIP_OFF) as lw:
+        for e in layer:
+            lw.add(e, e["src"] if e["kind"] == M.KIND_FILE else None)
+        pair = lw.finish()
+    os.close(fd)
+    with tarfile.open(out) as tf:
+        names = tf.getnames()
+        assert names == ["srv", "srv/app", "srv/app/lib", "srv/app/lib/util.py", "srv/app/main.py"]
+        assert tf.extractfile("srv/app/main.py").read() == b"print(1)\n"
+        assert tf.getmember("srv/app/main.py").uid == UID
+    assert pair["n_entries"] == 5
