@@ -69,7 +69,7 @@ typedef struct {
     uint32_t flags;           /* MI_FLAG_*                                          */
     uint64_t staging_bytes;   /* bytes per pinned staging slab (0 = 8 MiB)          */
     uint32_t n_streams;       /* reader threads for host-fed batches, one pinned slab
-                                 and one copy stream each (0 = 16)                   */
+                                 and one copy stream each (0 = 8)                   */
     uint32_t reserved;
 } mi_config;
 

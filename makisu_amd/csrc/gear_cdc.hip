@@ -136,12 +136,6 @@ __device__ __forceinline__ u32 lds_lane_table(const u64* table, int lane) {
     return base | ((u32)(lane % kCopies) * 8u);
 }
 
-__device__ __forceinline__ u32 umin3(u32 a, u32 b, u32 c) {
-    u32 r;
-    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-
 __device__ __forceinline__ void load_piece(const u8* p, u32x4 (&d)[8]) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) d[i] = *(const u32x4*)(p + 16 * i);
@@ -182,17 +176,11 @@ __device__ __forceinline__ void mark_tile(const u8* __restrict__ fptr, u64 ts, u
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
             roll16(h, cur[g], tab, hh);
-            // one v_min3_u32 per two hashes: 8 ops for 16 bytes (hipcc builds a deeper v_min_u32 tree)
-#ifndef MI_GEAR_MIN_TREE
-            u32 m = umin3(hh[0], hh[1], hh[2]);
-#pragma unroll
-            for (int k = 3; k < 15; k += 2) m = umin3(m, hh[k], hh[k + 1]);
-            m = min(m, hh[15]);
-#else       // A/B knob: let hipcc build its own (deeper, 11-op) v_min_u32 / v_min3_u32 tree
+// (a v_min3_u32 chain would be 8 ops instead of the 11 hipcc emits, but it is one dependent
+            // chain: A/B on one box, 1.50 ms against 1.46 ms for the compiler's tree)
             u32 m = 0xFFFFFFFFu;
 #pragma unroll
             for (int k = 0; k < 16; k += 2) m = min(m, min(hh[k], hh[k + 1]));
-#endif
             if (m <= thresh_m1) {                        // rare: a candidate among these 16 bytes
                 // (positions at or past the file end are not filtered here: selection never looks
                 // beyond the tile's last byte, and at most one lane hashes up to 127 slack bytes)

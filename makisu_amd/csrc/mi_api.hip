@@ -460,8 +460,8 @@ int mi_config_default(mi_config* cfg) {
     cfg->min_size = 2048;
     cfg->max_size = 65536;
     cfg->flags = 0;
-    cfg->staging_bytes = 64ull << 20;
-    cfg->n_streams = 2;
+    cfg->staging_bytes = 0;                          // 0 = engine defaults: 8 MiB slabs,
+    cfg->n_streams = 0;                              //     8 reader threads
     return MI_OK;
 }
 
@@ -520,7 +520,7 @@ int mi_ctx_create(const mi_config* cfg, mi_ctx** out) {
     // host-fed staging (mi_stage.hip): slab bytes and reader threads; both lazily allocated
     c->staging_bytes = cfg->staging_bytes ? cfg->staging_bytes : (8ull << 20);
     if (c->staging_bytes < (1ull << 16)) c->staging_bytes = 1ull << 16;
-    c->stage_threads = cfg->n_streams ? cfg->n_streams : 16;
+    c->stage_threads = cfg->n_streams ? cfg->n_streams : 8;    // 8 readers already saturate PCIe Gen5 x16
     if (const char* e = getenv("MI_STAGE_THREADS")) {
         int v = atoi(e);
         if (v >= 1 && v <= 64) c->stage_threads = (u32)v;

@@ -16,10 +16,10 @@ _LIB_PATH = os.path.join(_HERE, "libmi_oracle.so")
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "mi_oracle.c")
-    hdr = os.path.join(_HERE, "mi_oracle.h")
+    deps = [os.path.join(_HERE, f) for f in ("mi_oracle.c", "mi_oracle_abi.c", "mi_oracle.h", "Makefile")]
+    deps.append(os.path.join(os.path.dirname(_HERE), "include", "makisu_mi.h"))
     if (not force and os.path.exists(_LIB_PATH)
-            and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
+            and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(d) for d in deps)):
         return _LIB_PATH
     subprocess.check_call(["make", "-C", _HERE, "-B", "libmi_oracle.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH

@@ -9,6 +9,10 @@ import numpy as np
 
 if os.environ.get("MI_FEED_TORCH"):      # PyTorch-ROCm bundles its own (older) HIP runtime: loaded first it serves the engine too
     import torch  # noqa: F401
+    if os.environ.get("MI_FEED_TORCH") == "cuda":
+        torch.cuda.set_device(0)
+        torch.cuda.synchronize()
+        print("torch cuda initialised", torch.cuda.is_available(), flush=True)
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import makisu_amd  # noqa: E402
