@@ -368,12 +368,13 @@ def main():
     # kernel's launch duration can also be read without another batch sharing the GPU.
     serial_sha_ms, serial_phase = [], {}
     if args.inflight > 1:
-        for _ in range(3):
-            batches[0].submit()
+        torch.cuda.synchronize(device)
+        for _ in range(5):                                   # median of 5: one slow launch (clock ramp after
+            batches[0].submit()                              # the host-side pause) must not be the number
             batches[0].wait()
             st = eng.stats()
             serial_sha_ms.append(st["ms_sha_chunks"])
-            serial_phase = {k: round(v, 4) for k, v in st.items() if k.startswith("ms_")}
+        serial_phase = {k: round(v, 4) for k, v in st.items() if k.startswith("ms_")}
         serial_alg = st["bytes_in"] + 52 * st["n_chunks"]
 
     # closed-form check of the duplicate marking (c5: 90 % duplicate files): the job-wide unique
@@ -443,7 +444,7 @@ def main():
                              "hashed, tools/ubench_sha.hip); the HBM fraction cannot exceed 0.22. "
                              "achieved/avg_launch_ms are from the timed region, where the kernel "
                              "shares the GPU with the other in-flight batches' passes; "
-                             "serial_* = the same kernel with one batch at a time (3 extra "
+                             "serial_* = the same kernel with one batch at a time (median of 5 extra "
                              "untimed steps); path_frac = whole CDC+SHA step per GPU, algorithmic "
                              "bytes / ms_per_step / peak"},
         "phase_ms_avg": {k: round(v / max(1, len(sha_ms)), 4) for k, v in sorted(stats_sum.items())},
@@ -453,7 +454,7 @@ def main():
     if dedup_check:
         out["dedup_check"] = dedup_check
     if serial_sha_ms:
-        s_ms = float(np.mean(serial_sha_ms))
+        s_ms = float(np.median(serial_sha_ms))
         s_ach = serial_alg / (s_ms * 1e-3) / 1e9
         out["roofline"].update({"serial_avg_launch_ms": round(s_ms, 4),
                                 "serial_achieved": round(s_ach, 1),

@@ -145,16 +145,20 @@ void launch_crc32_files(const u8* d_data, const u64* d_file_off, const u64* d_fi
 
 // ---- host-side helpers for the context-checksum splice (strings only) -----------------
 u32 crc32_host_bytes(u32 crc, const void* data, size_t len) {
-    static u32 T[256];
-    static bool init = false;
-    if (!init) {
-        for (u32 i = 0; i < 256; ++i) {
-            u32 c = i;
-            for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ kCrcPoly : c >> 1;
-            T[i] = c;
+    // several ctxs may compute checksums on different threads at once: the table is built by a
+    // thread-safe function-local static (C++11 "magic static"), not by a hand-rolled init flag
+    struct Table {
+        u32 t[256];
+        Table() {
+            for (u32 i = 0; i < 256; ++i) {
+                u32 c = i;
+                for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ kCrcPoly : c >> 1;
+                t[i] = c;
+            }
         }
-        init = true;
-    }
+    };
+    static const Table table;
+    const u32* T = table.t;
     const u8* p = (const u8*)data;
     u32 c = ~crc;
     while (len--) c = (c >> 8) ^ T[(c ^ *p++) & 0xFF];
