@@ -1,0 +1,64 @@
+"""CPU tests of BASELINE.json's config generators (makisu_amd/workloads.py): every rank must derive
+the same job from nothing but (config, rank, world), and the closed forms bench.py checks the GPU
+against must hold by construction."""
+import numpy as np
+
+from makisu_amd import workloads as W
+from makisu_amd import distributed as D
+
+
+def test_c4_round_robin_partition():
+    world, per = 8, 1000
+    shards = [W.c4(r, world, per) for r in range(world)]
+    allidx = np.concatenate([s.global_index for s in shards])
+    assert sorted(allidx.tolist()) == list(range(world * per))                 # a partition
+    for r, s in enumerate(shards):
+        assert (s.global_index % world == r).all()                             # file index mod N
+        assert s.n_files == per and (s.sizes == 65536).all()
+        assert np.array_equal(s.cids, s.global_index.astype(np.uint64))        # distinct content per file
+        assert s.originals.all()
+    assert W.c4(3, 8).n_files == 1250000 and W.c4(3, 8).n_global_files == 10_000_000   # BASELINE configs[3]
+    gen1 = W.c4(0, 8, per, generation=1)
+    assert len(set(gen1.cids.tolist()) & set(shards[0].cids.tolist())) == 0    # batches in flight differ
+
+
+def test_c5_lpt_shards_are_a_balanced_partition_with_known_duplicates():
+    world = 4
+    sizes, cids, originals = W.c5_global(world, bytes_per_gpu=W.GIB, hi_log2=26)
+    assert (sizes >= 1 << 10).all() and (sizes < 1 << 26).all()
+    n_contents = int(cids.max()) + 1
+    assert originals[:n_contents].all() and not originals[n_contents:].any()
+    assert len(sizes) - n_contents > 5 * n_contents                            # copies dominate by count
+    assert np.array_equal(sizes[n_contents:], sizes[cids[n_contents:]])        # a copy has its original's size
+    shards = [W.c5(r, world, bytes_per_gpu=W.GIB, hi_log2=26) for r in range(world)]
+    allidx = np.concatenate([s.global_index for s in shards])
+    assert sorted(allidx.tolist()) == list(range(len(sizes)))
+    loads = [s.n_bytes for s in shards]
+    assert max(loads) - min(loads) <= int(sizes.max())                         # LPT: within one file
+    assert sum(int(s.originals.sum()) for s in shards) == n_contents           # every original lives on one rank
+    again = W.c5(2, world, bytes_per_gpu=W.GIB, hi_log2=26)                    # deterministic
+    assert np.array_equal(again.sizes, shards[2].sizes) and np.array_equal(again.cids, shards[2].cids)
+
+
+def test_shard_lpt_matches_the_reference_form():
+    rng = np.random.default_rng(1)
+    sizes = rng.integers(1, 10**6, 500)
+    got = W.shard_lpt(sizes, 5)
+    # the O(n * world) form used in round 1: lowest load, ties to the lowest rank
+    order = np.argsort(-sizes, kind="stable")
+    load = np.zeros(5, dtype=np.int64)
+    want = [[] for _ in range(5)]
+    for i in order:
+        r = int(np.argmin(load))
+        want[r].append(int(i))
+        load[r] += int(sizes[i])
+    assert [g.tolist() for g in got] == [sorted(w) for w in want]
+    assert D.shard_lpt is W.shard_lpt and D.shard_round_robin is W.shard_round_robin
+
+
+def test_c2_c3_shapes():
+    s = W.c2(0, 1)
+    assert s.n_files == 100000 and s.n_bytes == 100000 * 65536 and s.seed == W.SEED
+    s = W.c3(1, 2, 10)
+    assert s.n_files == 10 and (s.sizes == 128 * W.MIB).all() and s.seed == W.SEED + 1
+    assert (s.global_index % 2 == 1).all()
