@@ -391,8 +391,15 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             expect = int(t.item())
         got = checks[0][1]
+        # Distinct contents are independent random streams, so chunks of different contents differ --
+        # except the shortest ones: a cut candidate on a file's second-to-last byte leaves a 1-BYTE
+        # tail chunk (P = 2^-13 per file), and there are only 256 of those.  Measured on a C4 shard
+        # (1.25 M files, 9 023 970 chunks): 21 such coincidences, every one a pair of equal 1-byte
+        # chunks (tools/debug_c4_dups.py).  The closed form therefore holds up to ~1e-5.
+        coincidences = int(expect) - int(got) if got is not None else None
         dedup_check = {"n_unique": int(got) if got is not None else None, "closed_form": int(expect),
-                       "ok": got is not None and int(got) == int(expect)}
+                       "short_chunk_coincidences": coincidences,
+                       "ok": got is not None and 0 <= coincidences <= 2 + int(expect) // 50000}
 
     value = job_bytes * args.steps / dt / 2**30
     # dominant kernel: SHA-256 per chunk.  Algorithmic bytes per launch: every file byte read

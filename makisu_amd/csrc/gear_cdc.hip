@@ -32,15 +32,15 @@
 //      64-entry candidate list the wave compacts out of its lanes' packed candidates
 //      (__ballot + popcount prefix sums) -- one ballot per cut --, and from the bitmap with
 //      wave-wide find-first-set (64 lanes x 64 bits per step, __ballot + ctz) when a tile
-//      has too many candidates for the list; chunk ends go to the file's slot region in HBM.
+//      has too many candidates for the list; chunk ends go to the segment's u32 list in HBM.
 // Small files (<= one tile): one wave per file, four files per workgroup, no
 // workgroup barrier at all.  Large files: GROUPS of four tiles (256 KiB) that are marked AND
 // cut in parallel -- every group selects speculatively as if a cut fell on its first byte,
 // a second pass re-selects from the previous group's speculative exit until it meets the
 // speculative cut list again (Gear + min/max re-synchronises within a few chunks), and a
 // per-file pass only walks the groups whose assumption failed (see "large files" below).
-// HBM traffic: every file byte read once (+6 % warm-up, mostly L2 hits), 8 B written
-// per chunk.  Bound: HBM bandwidth / LDS lookup rate.
+// HBM traffic: every file byte read once (+6 % warm-up, mostly L2 hits), 4 B written
+// per chunk (+ 256 B of candidates per tile and a 40-byte record per group for large files).  Bound: HBM bandwidth / LDS lookup rate.
 #include "mi_common.h"
 
 namespace mi {

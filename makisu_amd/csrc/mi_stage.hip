@@ -1,19 +1,18 @@
 // mi_stage.hip -- host->HBM staging for host-fed batches: a pool of pinned slabs filled by
 // reader threads (pread from the page cache, or memcpy from caller memory), one hipMemcpyAsync
-// per filled slab, copies of different slabs in flight on different streams.
+// per filled slab, copies of different threads' slabs in flight on different streams.
 //
 // What it replaces: the byte loop of tario.WriteEntry (lib/tario/write.go:28-52: open, then
 // io.CopyN(w, f, h.Size) in 32 KiB pieces on one goroutine).  Here the files of a batch are read
 // by several threads at once, consecutive small files share one slab (one PCIe transfer per
-// ~8 MiB, not per file), and the transfer of one slab overlaps the reads of the next ones.
-// Host code only (no kernels); lives next to the engine because it owns HIP streams and events.
+// ~8 MiB, not per file), and the transfer of one thread's slab overlaps the other threads' reads.
+// Host code only (no kernels); lives next to the engine because it owns HIP streams.
 #include "mi_internal.h"
 
 #include <errno.h>
 #include <string.h>
 #include <unistd.h>
 
-#include <atomic>
 #include <condition_variable>
 #include <deque>
 #include <memory>

@@ -63,7 +63,9 @@ def eng():
 def test_c2_full_size_every_row(oracle, eng):
     from makisu_amd import workloads as W
     files, chunks, nu = _check_shard(oracle, eng, W.c2(0, 1, 100000))
-    assert nu == len(chunks) > 700000                      # distinct contents: nothing repeats
+    # distinct contents: nothing repeats, except that two 1-byte tail chunks may coincide (256 values)
+    dup = chunks[chunks["dup_of"] >= 0]
+    assert len(chunks) > 700000 and nu == len(chunks) - len(dup) and (dup["length"] <= 2).all() and len(dup) <= 3
 
 
 def test_c3_sixty_128mib_files(oracle, eng):
