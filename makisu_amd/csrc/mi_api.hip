@@ -26,6 +26,7 @@
 #include <chrono>
 #include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 using namespace mi;
@@ -303,23 +304,30 @@ int submit_pipeline(mi_batch* b) {
                         b->q_id.as<u32>(), (u32)cap, d_n, heads(0), false,
                         b->digests.as<u8>(), c->sha_blocks_per_cu, ncu, s);
     HIPCHK(c, hipEventRecord(b->ev[3], s));
-    // per-file chunk roots: fan-out-1024 tree; reduction passes only exist for files with
-    // more than 1024 chunks (> ~9 MiB), the final pass hashes every file's <= 1024 nodes
+    // per-file chunk roots: fan-out-64 tree; reduction passes only exist for files with more than
+    // 64 chunks (> ~0.5 MiB), the final pass hashes every file's <= 64 nodes
     if (!flat_roots) {
         HIPCHK(c, b->root_addr.ensure(nf * 8));
         HIPCHK(c, b->root_cnt.ensure(nf * 4));
         launch_root_init(b->digests.as<u8>(), b->first.as<u64>(), b->n_chunks_d.as<u32>(), nf,
                          b->root_addr.as<u64>(), b->root_cnt.as<u32>(), s);
+        HIPCHK(c, b->root_addr2.ensure(nf * 8));
+        HIPCHK(c, b->root_cnt2.ensure(nf * 4));
+        u64* cur_addr = b->root_addr.as<u64>();
+        u32* cur_cnt = b->root_cnt.as<u32>();
+        u64* next_addr = b->root_addr2.as<u64>();
+        u32* next_cnt = b->root_cnt2.as<u32>();
         u64 nodes_ub = cap;                              // upper bound of nodes entering a pass
         for (int r = 0; r < b->root_passes; ++r) {
-            const u64 out_ub = nodes_ub / 1024 + nf;     // nodes it can produce
+            const u64 out_ub = nodes_ub / kChunkRootFanout + nf;     // nodes it can produce
+            if (out_ub >= 0xFFFFFFFFull) return fail(c, MI_ERR_INVALID, "batch too large for the root tree");
             HIPCHK(c, b->rseg_cnt.ensure(nf * 4));
             HIPCHK(c, b->rseg_first.ensure(nf * 8));
             HIPCHK(c, b->rseg_total.ensure(8));
             HIPCHK(c, b->root_items_off.ensure(out_ub * 8));
             HIPCHK(c, b->root_items_len.ensure(out_ub * 8));
             HIPCHK(c, b->root_level[r].ensure(out_ub * 32));
-            launch_root_level(nf, b->root_addr.as<u64>(), b->root_cnt.as<u32>(), b->rseg_cnt.as<u32>(),
+            launch_root_level(nf, out_ub, cur_addr, cur_cnt, next_addr, next_cnt, b->rseg_cnt.as<u32>(),
                               b->rseg_first.as<u64>(), b->rseg_total.as<u64>(), b->scratch.as<u64>(),
                               b->root_level[r].as<u8>(), b->root_items_off.as<u64>(),
                               b->root_items_len.as<u64>(), s);
@@ -328,9 +336,10 @@ int submit_pipeline(mi_batch* b) {
                                 b->rseg_total.as<u64>(), heads(3 + r), false,
                                 b->root_level[r].as<u8>(), c->sha_blocks_per_cu, ncu, s);
             nodes_ub = out_ub;
+            std::swap(cur_addr, next_addr);
+            std::swap(cur_cnt, next_cnt);
         }
-        launch_root_final_items(b->root_addr.as<u64>(), b->root_cnt.as<u32>(), nf, b->item_off.as<u64>(),
-                                b->item_len.as<u64>(), s);
+        launch_root_final_items(cur_addr, cur_cnt, nf, b->item_off.as<u64>(), b->item_len.as<u64>(), s);
     }
     launch_sha256_items(kShaRoots, nullptr, b->item_off.as<u64>(), b->item_len.as<u64>(), nullptr,
                         (u32)nf, nullptr, heads(1), false, b->roots.as<u8>(),
@@ -764,8 +773,8 @@ static int stage_batch(mi_batch* b) {
     {
         u64 nodes = mx / c->cfg.min_size + 2;              // upper bound of a file's chunk count
         b->root_passes = 0;
-        while (nodes > 1024) { nodes = (nodes + 1023) / 1024; ++b->root_passes; }
-        if (b->root_passes > 3) return fail(c, MI_ERR_INVALID, "file too large for the root tree");
+        while (nodes > kChunkRootFanout) { nodes = (nodes + kChunkRootFanout - 1) / kChunkRootFanout; ++b->root_passes; }
+        if (b->root_passes > kMaxRootPasses) return fail(c, MI_ERR_INVALID, "file too large for the root tree");
     }
     b->total_slots = cap_chunks;
     b->ends_total = ends_total;
@@ -955,7 +964,8 @@ int mi_batch_free(mi_batch* b) {
     if (b->h_counts) (void)hipHostFree(b->h_counts);
     DevBuf* bufs[] = {&b->root_addr, &b->root_cnt, &b->rseg_cnt, &b->rseg_first, &b->rseg_total,
                       &b->root_items_off, &b->root_items_len, &b->root_level[0], &b->root_level[1],
-                      &b->root_level[2], &b->group_file, &b->group_index, &b->group_recs, &b->tile_lists, &b->large_list,
+                      &b->root_level[2], &b->root_level[3], &b->root_level[4], &b->root_addr2, &b->root_cnt2,
+                      &b->group_file, &b->group_index, &b->group_recs, &b->tile_lists, &b->large_list,
                       &b->large_group0, &b->seg_file, &b->seg_slot, &b->seg_n, &b->seg_first, &b->seg_group,
                       &b->file_seg0, &b->ends32, &b->tile_file, &b->first_tile, &b->tile_raw, &b->crc_d, &b->ctl, &b->dd_table, &b->dd_slot,
                       &b->q_off, &b->q_len, &b->q_id,&b->arena, &b->small_list, &b->file_off, &b->file_size, &b->cids,

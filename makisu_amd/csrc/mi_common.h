@@ -23,6 +23,10 @@ constexpr int kGearTableCopies = 8;              // LDS replicas of the Gear tab
 constexpr int kShaQueues  = 8;                   // one head word per XCD (block b runs on XCD b % 8)
 constexpr int kShaWG      = 256;
 
+// chunk_root tree fan-out (tables.hip "per-file chunk roots"; the oracle's mi_ref_chunk_root)
+constexpr u32 kChunkRootFanout = 64;
+constexpr int kMaxRootPasses = 5;                // 64^6 nodes: more than a batch can hold rows
+
 // file placement in the device arena: every file starts on this boundary so tile
 // loads are 16-byte aligned and coalesced
 constexpr u64 kFileAlign  = 256;
@@ -121,7 +125,9 @@ void launch_bin_order(const u64* d_off, const u64* d_len, u32 n, const u64* d_n,
 // launch_root_level per reduction pass (files with > 1024 nodes), then the final items
 void launch_root_init(const u8* d_digests, const u64* d_first, const u32* d_n_chunks, u64 n_files,
                       u64* d_cur_addr, u32* d_cur_cnt, hipStream_t s);
-void launch_root_level(u64 n_files, u64* d_cur_addr, u32* d_cur_cnt, u32* d_seg_cnt, u64* d_seg_first,
+// one reduction pass: reads cur_*, writes next_* (the caller swaps); n_nodes_ub bounds the nodes it makes
+void launch_root_level(u64 n_files, u64 n_nodes_ub, const u64* d_cur_addr, const u32* d_cur_cnt,
+                       u64* d_next_addr, u32* d_next_cnt, u32* d_seg_cnt, u64* d_seg_first,
                        u64* d_seg_total, u64* d_scratch, u8* d_level_out, u64* d_item_off,
                        u64* d_item_len, hipStream_t s);
 void launch_root_final_items(const u64* d_cur_addr, const u32* d_cur_cnt, u64 n_files, u64* d_off,

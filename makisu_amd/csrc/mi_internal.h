@@ -104,7 +104,8 @@ struct mi_batch {
     mi::DevBuf q_off, q_len, q_id;           // SHA queue descriptors, longest chunk first
     mi::DevBuf item_off, item_len, roots, file_sha, dup_of;
     mi::DevBuf root_addr, root_cnt, rseg_cnt, rseg_first, rseg_total, root_items_off, root_items_len;
-    mi::DevBuf root_level[3];            // node digests of the reduction passes
+    mi::DevBuf root_level[mi::kMaxRootPasses];   // node digests of the reduction passes
+    mi::DevBuf root_addr2, root_cnt2;    // ping-pong partner of root_addr / root_cnt
     int root_passes = 0;                 // reduction passes this batch can need (from max file size)
     mi::u64 max_file_size = 0;
     mi::DevBuf tile_file, first_tile, tile_raw, crc_d;   // MI_FLAG_FILE_CRC32

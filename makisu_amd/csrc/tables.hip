@@ -245,7 +245,7 @@ void compact_chunks_kernel(const u64* __restrict__ file_off, const u64* __restri
 }
 
 // first chunk row / row count of every file, from the scanned segment counts; when no file of the
-// batch needs a root reduction pass (all <= 1024 chunks) also the root pass's item list: file f's
+// batch needs a root reduction pass (all <= 64 chunks) also the root pass's item list: file f's
 // string is its digest run (what root_init + root_final_items produce otherwise)
 __global__ __launch_bounds__(256)
 void file_rows_kernel(const u64* __restrict__ file_seg0, const u64* __restrict__ seg_first,
@@ -357,11 +357,14 @@ void launch_bin_order(const u64* d_off, const u64* d_len, u32 n, const u64* d_n,
 }
 
 // ---- per-file chunk roots -----------------------------------------------------------
-// chunk_root(f): SHA-256 over the file's concatenated chunk digests when it has <= 1024
-// chunks; beyond that a fan-out-1024 tree: REDUCTION passes hash runs of 1024
-// child digests into node digests until <= 1024 nodes are left, the FINAL pass hashes those.
-// A file's current node list is (cur_addr, cur_cnt): absolute device address + digest count.
-constexpr u32 kRootFanout = 1024;
+// chunk_root(f): SHA-256 over the file's concatenated chunk digests when it has <= 64 chunks;
+// beyond that a fan-out-64 tree: REDUCTION passes hash runs of 64 child digests
+// (2 KiB strings, 33 compressions) into node digests until <= 64 nodes are left, the FINAL pass
+// hashes those.  (Round 1 used a fan-out of 1024: every pass was then as long as ONE 32 KiB
+// string -- 1.5-2.5 ms of a single lane -- whatever the batch held; 3-5 ms per batch with files
+// above 8 MiB.)  A file's current node list is (cur_addr, cur_cnt): absolute device address +
+// digest count; a pass reads cur_* and writes next_* (ping-pong).
+constexpr u32 kRootFanout = kChunkRootFanout;
 
 __global__ __launch_bounds__(256)
 void root_init_kernel(const u8* __restrict__ digests, const u64* __restrict__ first,
@@ -373,33 +376,44 @@ void root_init_kernel(const u8* __restrict__ digests, const u64* __restrict__ fi
     cur_cnt[f] = n_chunks[f];
 }
 
+// nodes a file contributes to this pass (0 = it already fits the final pass: carried over)
 __global__ __launch_bounds__(256)
-void root_level_counts_kernel(const u32* __restrict__ cur_cnt, u64 n_files, u32* __restrict__ seg_cnt) {
+void root_level_counts_kernel(const u64* __restrict__ cur_addr, const u32* __restrict__ cur_cnt, u64 n_files,
+                              u32* __restrict__ seg_cnt, u64* __restrict__ next_addr,
+                              u32* __restrict__ next_cnt) {
     const u64 f = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n_files) return;
     const u32 c = cur_cnt[f];
     seg_cnt[f] = c > kRootFanout ? (c + kRootFanout - 1) / kRootFanout : 0;
+    next_addr[f] = cur_addr[f];
+    next_cnt[f] = c;
 }
 
-// items of one reduction pass (absolute addresses), then the file moves on to its node list
+// items of one reduction pass (absolute addresses): one thread per node, its file found by binary
+// search over the scanned node counts (a 4 GiB file has 6 500 nodes in its first pass)
 __global__ __launch_bounds__(256)
-void root_level_items_kernel(const u32* __restrict__ seg_cnt, const u64* __restrict__ seg_first,
-                             u64 n_files, u8* __restrict__ level_out, u64* __restrict__ cur_addr,
-                             u32* __restrict__ cur_cnt, u64* __restrict__ item_off,
+void root_level_items_kernel(const u64* __restrict__ seg_first, const u64* __restrict__ seg_total,
+                             u64 n_files, u8* __restrict__ level_out, const u64* __restrict__ cur_addr,
+                             const u32* __restrict__ cur_cnt, u64* __restrict__ next_addr,
+                             u32* __restrict__ next_cnt, u64* __restrict__ item_off,
                              u64* __restrict__ item_len) {
-    const u64 f = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= n_files) return;
-    const u32 ns = seg_cnt[f];
-    if (!ns) return;
-    const u64 base = cur_addr[f], s0 = seg_first[f];
-    const u32 cnt = cur_cnt[f];
-    for (u32 j = 0; j < ns; ++j) {
+    const u64 n = *seg_total;
+    for (u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (u64)gridDim.x * blockDim.x) {
+        u64 lo = 0, hi = n_files;                            // last f with seg_first[f] <= g
+        while (hi - lo > 1) {
+            const u64 mid = (lo + hi) >> 1;
+            if (seg_first[mid] <= g) lo = mid; else hi = mid;
+        }
+        const u64 f = lo, s0 = seg_first[f];
+        const u32 j = (u32)(g - s0), cnt = cur_cnt[f];
         const u32 left = cnt - j * kRootFanout;
-        item_off[s0 + j] = base + (u64)j * kRootFanout * 32;
-        item_len[s0 + j] = (u64)(left < kRootFanout ? left : kRootFanout) * 32;
+        item_off[g] = cur_addr[f] + (u64)j * kRootFanout * 32;
+        item_len[g] = (u64)(left < kRootFanout ? left : kRootFanout) * 32;
+        if (j == 0) {                                        // the file moves on to its node list
+            next_addr[f] = (u64)(uintptr_t)level_out + s0 * 32;
+            next_cnt[f] = (cnt + kRootFanout - 1) / kRootFanout;
+        }
     }
-    cur_addr[f] = (u64)(uintptr_t)level_out + s0 * 32;
-    cur_cnt[f] = ns;
 }
 
 __global__ __launch_bounds__(256)
@@ -418,15 +432,19 @@ void launch_root_init(const u8* d_digests, const u64* d_first, const u32* d_n_ch
                        d_first, d_n_chunks, n_files, d_cur_addr, d_cur_cnt);
 }
 
-void launch_root_level(u64 n_files, u64* d_cur_addr, u32* d_cur_cnt, u32* d_seg_cnt, u64* d_seg_first,
+void launch_root_level(u64 n_files, u64 n_nodes_ub, const u64* d_cur_addr, const u32* d_cur_cnt,
+                       u64* d_next_addr, u32* d_next_cnt, u32* d_seg_cnt, u64* d_seg_first,
                        u64* d_seg_total, u64* d_scratch, u8* d_level_out, u64* d_item_off,
                        u64* d_item_len, hipStream_t s) {
     if (n_files == 0) return;
     const u32 grid = (u32)((n_files + 255) / 256);
-    hipLaunchKernelGGL(root_level_counts_kernel, dim3(grid), dim3(256), 0, s, d_cur_cnt, n_files, d_seg_cnt);
+    hipLaunchKernelGGL(root_level_counts_kernel, dim3(grid), dim3(256), 0, s, d_cur_addr, d_cur_cnt, n_files,
+                       d_seg_cnt, d_next_addr, d_next_cnt);
     launch_scan_counts(d_seg_cnt, d_seg_first, d_seg_total, n_files, d_scratch, s);
-    hipLaunchKernelGGL(root_level_items_kernel, dim3(grid), dim3(256), 0, s, d_seg_cnt, d_seg_first, n_files,
-                       d_level_out, d_cur_addr, d_cur_cnt, d_item_off, d_item_len);
+    u64 want = (n_nodes_ub + 255) / 256;
+    const u32 igrid = (u32)(want < 2048 ? (want ? want : 1) : 2048);
+    hipLaunchKernelGGL(root_level_items_kernel, dim3(igrid), dim3(256), 0, s, d_seg_first, d_seg_total, n_files,
+                       d_level_out, d_cur_addr, d_cur_cnt, d_next_addr, d_next_cnt, d_item_off, d_item_len);
 }
 
 void launch_root_final_items(const u64* d_cur_addr, const u32* d_cur_cnt, u64 n_files, u64* d_off,

@@ -380,12 +380,12 @@ typedef struct {
     uint64_t chunk_cap;
 } scan_job;
 
-/* chunk_root: SHA-256 over the concatenated chunk digests for files of up to 1024 chunks;
- * beyond that a tree with fan-out 1024 (each node = SHA-256 over up to 1024 consecutive child
- * digests), repeated until at most 1024 nodes remain, whose concatenation is hashed.  The tree
+/* chunk_root: SHA-256 over the concatenated chunk digests for files of up to 64 chunks;
+ * beyond that a tree with fan-out 64 (each node = SHA-256 over up to 64 consecutive child
+ * digests), repeated until at most 64 nodes remain, whose concatenation is hashed.  The tree
  * keeps the root of a multi-GiB file from being one serial million-block SHA-256 stream. */
 void mi_ref_chunk_root(const uint8_t* digests, uint64_t n, uint8_t out[32], int allow_shani) {
-    const uint64_t F = 1024;
+    const uint64_t F = MI_REF_ROOT_FANOUT;
     uint8_t* owned = NULL;
     const uint8_t* cur = digests;
     while (n > F) {

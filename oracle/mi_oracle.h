@@ -149,7 +149,8 @@ uint64_t mi_ref_scan_synthetic(uint64_t seed, const uint64_t* content_ids, const
 void mi_ref_last_phase_seconds(double out[3]);
 
 /* chunk_root of n chunk digests (n x 32 bytes): SHA-256 over their concatenation when
- * n <= 1024, else a fan-out-1024 tree of SHA-256 nodes (DESIGN.md "chunk_root"). */
+ * n <= 64, else a fan-out-64 tree of SHA-256 nodes (DESIGN.md "chunk_root"). */
+#define MI_REF_ROOT_FANOUT 64
 void mi_ref_chunk_root(const uint8_t* digests, uint64_t n, uint8_t out[32], int allow_shani);
 
 /* Marks dup_of over an arbitrary digest list (n x 32 bytes): dup_of[i] =

@@ -738,8 +738,8 @@ def test_native_rccl_init_all_single_device(oracle):
 
 
 def test_chunk_root_tree_three_levels(oracle):
-    """chunk_root is a fan-out-1024 tree above 1024 chunks: 1.3 M tiny chunks in one file need two
-    reduction passes plus the final one; a 3000-chunk and a 5-chunk file ride along."""
+    """chunk_root is a fan-out-64 tree above 64 chunks: 1.3 M tiny chunks in one file need three
+    reduction passes plus the final one; a 3000-chunk (one pass) and a 5-chunk file ride along."""
     import makisu_amd
     with makisu_amd.Engine(mask_bits=6, min_size=64, max_size=256) as e:
         _compare_synth(oracle, e, [160 * 1024 * 1024, 400000, 700, 0], [40, 41, 42, 43])
@@ -747,17 +747,15 @@ def test_chunk_root_tree_three_levels(oracle):
 
 @pytest.mark.skipif(False, reason="")
 def test_chunk_root_definition(oracle):
-    """<= 1024 chunks: root = SHA-256(concat digests); above: SHA-256 over the 1024-wide node digests."""
+    """<= 64 chunks: root = SHA-256(concat digests); above: the same over 64-wide node digests, repeated."""
     import hashlib
     rng = np.random.default_rng(3)
-    for n in (0, 1, 1024, 1025, 5000):
+    for n in (0, 1, 64, 65, 4096, 4097, 300000):
         d = rng.integers(0, 256, (n, 32), dtype=np.uint8)
-        if n <= 1024:
-            want = hashlib.sha256(d.tobytes()).digest()
-        else:
-            nodes = b"".join(hashlib.sha256(d[i:i + 1024].tobytes()).digest() for i in range(0, n, 1024))
-            want = hashlib.sha256(nodes).digest()
-        assert oracle.chunk_root(d) == want
+        nodes = [d[i].tobytes() for i in range(n)]
+        while len(nodes) > 64:
+            nodes = [hashlib.sha256(b"".join(nodes[i:i + 64])).digest() for i in range(0, len(nodes), 64)]
+        assert oracle.chunk_root(d) == hashlib.sha256(b"".join(nodes)).digest()
 
 
 def test_plain_c_consumer(oracle, tmp_path):

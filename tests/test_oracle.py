@@ -277,3 +277,15 @@ def test_synth_fill_unaligned_ranges(oracle):
     whole = oracle.synth_fill(7, 3, 0, 1000)
     for off, n in ((0, 0), (1, 7), (3, 13), (8, 64), (5, 900), (999, 1)):
         assert np.array_equal(oracle.synth_fill(7, 3, off, n), whole[off:off + n])
+
+
+def test_chunk_root_is_a_fanout_64_tree(oracle):
+    """The root definition (ours; the reference has no per-file content digest): flat SHA-256 over the
+    concatenated digests up to 64 chunks, above that 64-wide node digests, repeated."""
+    rng = np.random.default_rng(3)
+    for n in (0, 1, 64, 65, 4096, 4097, 70000):
+        d = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        nodes = [d[i].tobytes() for i in range(n)]
+        while len(nodes) > 64:
+            nodes = [hashlib.sha256(b"".join(nodes[i:i + 64])).digest() for i in range(0, len(nodes), 64)]
+        assert oracle.chunk_root(d) == hashlib.sha256(b"".join(nodes)).digest()
