@@ -395,7 +395,10 @@ __device__ __forceinline__ u64 reselect_group(const u32* lists, const u32* bitma
     return exit;                                               // wave-uniform
 }
 
-__global__ __launch_bounds__(kGearWG, 3)       // 3 workgroups per CU: <= 168 VGPRs
+#ifndef MI_GEAR_MARK_BOUND
+#define MI_GEAR_MARK_BOUND 3
+#endif
+__global__ __launch_bounds__(kGearWG, MI_GEAR_MARK_BOUND)       // 3 workgroups per CU: <= 168 VGPRs
 void gear_group_mark_kernel(const u8* __restrict__ data, const u64* __restrict__ file_off,
                             const u64* __restrict__ file_size, const u64* __restrict__ file_seg0,
                             const u64* __restrict__ seg_slot, u32* __restrict__ ends32,
