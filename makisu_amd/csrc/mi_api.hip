@@ -95,12 +95,16 @@ int arena_reserve(mi_batch* b, u64 want) {
     return MI_OK;
 }
 
+// the inline window: buffers below kInlineBytes only, so 2 MiB per slab is plenty (pinned
+// allocation is what makes a fresh batch expensive: ~3 ms per 8 MiB)
+constexpr u64 kRingBytes = 2ull << 20;
+
 int ensure_ring(mi_batch* b) {
     mi_ctx* c = b->ctx;
     if (b->ring[0]) return MI_OK;
     HIPCHK(c, hipStreamCreateWithFlags(&b->ring_stream, hipStreamNonBlocking));
     for (int i = 0; i < 2; ++i) {
-        HIPCHK(c, hipHostMalloc(&b->ring[i], c->staging_bytes, hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc(&b->ring[i], kRingBytes, hipHostMallocDefault));
         HIPCHK(c, hipEventCreateWithFlags(&b->ring_ev[i], hipEventDisableTiming));
     }
     return MI_OK;
@@ -127,7 +131,6 @@ int staging_flush(mi_batch* b) {
 
 // Appends `len` bytes of caller memory at arena offset `at` through the batch's pinned window.
 int staging_append(mi_batch* b, u64 at, const u8* src, u64 len) {
-    mi_ctx* c = b->ctx;
     int rc = ensure_ring(b);
     if (rc) return rc;
     if (b->win_fill == 0) b->win_start = at;
@@ -135,7 +138,7 @@ int staging_append(mi_batch* b, u64 at, const u8* src, u64 len) {
         // only alignment padding may be bridged: a larger gap is a file the reader threads are
         // staging, and zero-filling across it would overwrite their bytes
         const u64 gap = at - (b->win_start + b->win_fill);
-        if (at < b->win_start + b->win_fill || gap >= kFileAlign || b->win_fill + gap > c->staging_bytes) {
+        if (at < b->win_start + b->win_fill || gap >= kFileAlign || b->win_fill + gap > kRingBytes) {
             rc = staging_flush(b);
             if (rc) return rc;
             b->win_start = at;
@@ -145,11 +148,11 @@ int staging_append(mi_batch* b, u64 at, const u8* src, u64 len) {
         }
     }
     while (len) {
-        if (b->win_fill == c->staging_bytes) {
+        if (b->win_fill == kRingBytes) {
             rc = staging_flush(b);
             if (rc) return rc;
         }
-        u64 take = c->staging_bytes - b->win_fill;
+        u64 take = kRingBytes - b->win_fill;
         if (take > len) take = len;
         memcpy((u8*)b->ring[b->cur] + b->win_fill, src, take);
         src += take;
