@@ -253,3 +253,39 @@ def test_cache_entry_codec():
         pair = layer.finish()
     e = M.cache_create_entry(pair["tar_sha256"], pair["gzip_sha256"])
     assert M.cache_parse_entry(e) == (pair["tar_digest"], pair["gzip_digest"])
+
+
+def test_ustar_headers_equal_python_tarfile():
+    """A third independent ustar writer: Python's tarfile (USTAR_FORMAT) produces the same header as
+    the product's framer for names that need no prefix split (the two split long names at different
+    slashes, both legally) -- except devmajor/devminor, which Go's templateV7Plus formats as
+    "0000000\0" for EVERY entry while Python 3.10 leaves them empty for non-devices; the test puts
+    Go's form there and recomputes the checksum.  With the oracle's writer that makes three
+    implementations agreeing on every other byte; Go's archive/tar itself stays unpinned."""
+    cases = [
+        ({"relpath": "etc/passwd", "kind": M.KIND_FILE, "mode": 0o100644, "size": 1234, "mtime_sec": 1_600_000_000,
+          "uid": 0, "gid": 0}, tarfile.REGTYPE),
+        ({"relpath": "usr/local/bin/tool", "kind": M.KIND_FILE, "mode": 0o104755, "size": 0, "mtime_sec": 1,
+          "uid": 1000, "gid": 100}, tarfile.REGTYPE),
+        ({"relpath": "var/lib", "kind": M.KIND_DIR, "mode": 0o40750, "mtime_sec": 86400, "uid": 7, "gid": 8}, tarfile.DIRTYPE),
+        ({"relpath": "bin/sh", "kind": M.KIND_SYMLINK, "mode": 0o120777, "link_target": "/bin/busybox", "mtime_sec": 5},
+         tarfile.SYMTYPE),
+        ({"relpath": "bin/ln2", "kind": M.KIND_HARDLINK, "mode": 0o644, "link_target": "bin/busybox", "mtime_sec": 5},
+         tarfile.LNKTYPE),
+        ({"relpath": "x" * 100, "kind": M.KIND_FILE, "mode": 0o600, "size": 8 * 1024 ** 3 - 1, "mtime_sec": 2 ** 31},
+         tarfile.REGTYPE),
+    ]
+    for e, typ in cases:
+        ti = tarfile.TarInfo(e["relpath"])
+        ti.type = typ
+        ti.mode = e["mode"] & 0o7777
+        ti.size = e.get("size", 0)
+        ti.mtime = e["mtime_sec"]
+        ti.uid, ti.gid = e.get("uid", 0), e.get("gid", 0)
+        ti.uname = ti.gname = ""
+        ti.linkname = e.get("link_target") or ""
+        want = bytearray(ti.tobuf(format=tarfile.USTAR_FORMAT, encoding="utf-8", errors="surrogateescape"))
+        want[329:337] = want[337:345] = b"0000000\x00"
+        want[148:156] = b" " * 8
+        want[148:156] = b"%06o\x00 " % sum(want)
+        assert M.layer_header_bytes(e) == bytes(want), e["relpath"]
