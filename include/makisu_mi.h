@@ -187,6 +187,46 @@ int mi_batch_read_back(mi_batch* b, void* out, uint64_t cap);
 int mi_batch_reset(mi_batch* b);
 int mi_batch_free(mi_batch* b);
 
+/* ---- parts: ONE file split across batches / GPUs (files >= 256 MiB) ------------- *
+ * No reference counterpart: the reference streams a file through one goroutine
+ * (lib/tario/write.go:28-52).  A part is the byte range [begin, end) of a file; begin and end are
+ * multiples of MI_PART_ALIGN (end may also be the file size).  The engine stages the part behind a
+ * halo of max_size bytes (rounded up to MI_PART_ALIGN) so that the chunk straddling `begin` lies
+ * inside the item; a part OWNS the chunks that END in (begin, end], wherever they begin.
+ * The only thing the parts' owners exchange is 8 bytes per boundary -- the previous part's last cut:
+ *     every owner:  mi_batch_scan_cuts(batch)          cuts under an assumed entry (the halo's own
+ *                   mi_batch_parts(batch, ...)         selection: right unless it never re-synchronised)
+ *     exchange exits; for every part but a file's first:
+ *                   mi_batch_set_part_entry(batch, file_index, exit of the previous part)
+ *                   mi_batch_fix_cuts(batch)           re-selects only where the entry differed
+ *     repeat while some part's exit changed (at most parts-per-file rounds; one on ordinary data)
+ *     then mi_batch_submit / mi_batch_run as usual.
+ * Submitting a batch that holds a part with an unconfirmed entry is MI_ERR_STATE.
+ * Results: mi_chunk_result.offset is the offset inside the WHOLE file; mi_file_result.size is
+ * end - begin, chunk_root covers the part's own chunks only, file_sha256 / crc32 are zero.      */
+#define MI_PART_ALIGN 262144u
+typedef struct {
+    uint64_t file_index;       /* the part's row in this batch's file table                       */
+    uint64_t file_size, begin, end;
+    uint64_t entry;            /* file offset of the cut the part's first chunk starts at          */
+    uint64_t exit;             /* file offset of the part's last cut (<= end): the next part's entry */
+    uint32_t entry_confirmed;  /* mi_batch_set_part_entry was called (always 1 for begin == 0)     */
+    uint32_t cuts_current;     /* 0: the confirmed entry differs, mi_batch_fix_cuts is due         */
+} mi_part_state;
+int mi_batch_add_path_part(mi_batch* b, const char* path, uint64_t file_size, uint64_t begin,
+                           uint64_t end, uint64_t user_tag);
+/* the part of the synthetic file (seed, content_id) of file_size bytes: same bytes as the range
+ * [begin, end) of what mi_batch_add_synthetic generates for that content id                     */
+int mi_batch_add_synthetic_part(mi_batch* b, uint64_t file_size, uint64_t content_id, uint64_t seed,
+                                uint64_t begin, uint64_t end);
+/* Blocking: stages the batch and runs Gear marking + cut selection only.                         */
+int mi_batch_scan_cuts(mi_batch* b);
+int mi_batch_parts(mi_batch* b, mi_part_state* out, uint64_t cap, uint64_t* n_parts);
+int mi_batch_set_part_entry(mi_batch* b, uint64_t file_index, uint64_t entry);
+/* Blocking: re-selects the parts whose confirmed entry differs from the one their cuts were made
+ * with and refreshes their exits.                                                              */
+int mi_batch_fix_cuts(mi_batch* b);
+
 /* ---- cross-batch / cross-GPU dedup --------------------------------------------- *
  * Plugs in where the reference dedups layer blobs by digest
  * (lib/builder/step/common.go:88-91 LinkStoreFileFrom && !os.IsExist;

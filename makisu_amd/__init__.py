@@ -95,6 +95,16 @@ class LayerResult(C.Structure):
 GZIP_OFF, GZIP_DEFAULT = -2, -1
 
 
+class PartState(C.Structure):
+    """mi_part_state: one part of a split file (include/makisu_mi.h "parts")."""
+    _fields_ = [("file_index", C.c_uint64), ("file_size", C.c_uint64), ("begin", C.c_uint64),
+                ("end", C.c_uint64), ("entry", C.c_uint64), ("exit", C.c_uint64),
+                ("entry_confirmed", C.c_uint32), ("cuts_current", C.c_uint32)]
+
+
+PART_ALIGN = 262144
+
+
 class Stats(C.Structure):
     _fields_ = [("bytes_in", C.c_uint64), ("n_files", C.c_uint64), ("n_chunks", C.c_uint64),
                 ("n_unique", C.c_uint64), ("ms_h2d", C.c_double), ("ms_cdc", C.c_double),
@@ -151,6 +161,12 @@ def load_library(rebuild=False):
         "mi_batch_add_path": ([vp, C.c_char_p, u64, u64], C.c_int),
         "mi_batch_add_path_range": ([vp, C.c_char_p, u64, u64, u64], C.c_int),
         "mi_batch_add_synthetic": ([vp, u64, u64p, u64p, u64], C.c_int),
+        "mi_batch_add_path_part": ([vp, C.c_char_p, u64, u64, u64, u64], C.c_int),
+        "mi_batch_add_synthetic_part": ([vp, u64, u64, u64, u64, u64], C.c_int),
+        "mi_batch_scan_cuts": ([vp], C.c_int),
+        "mi_batch_parts": ([vp, C.POINTER(PartState), u64, u64p], C.c_int),
+        "mi_batch_set_part_entry": ([vp, u64, u64], C.c_int),
+        "mi_batch_fix_cuts": ([vp], C.c_int),
         "mi_batch_run": ([vp], C.c_int),
         "mi_batch_rerun": ([vp], C.c_int),
         "mi_batch_submit": ([vp], C.c_int),
@@ -756,6 +772,34 @@ class Batch:
             cp = cids.ctypes.data_as(u64p)
         self._check(self._lib.mi_batch_add_synthetic(self._h, s.size, s.ctypes.data_as(u64p), cp,
                                                      seed))
+
+    # ---- parts: one file split across batches / GPUs ------------------------------------
+    def add_path_part(self, path, begin, end, file_size=None, tag=0):
+        if file_size is None:
+            file_size = os.stat(path).st_size
+        self._check(self._lib.mi_batch_add_path_part(self._h, os.fsencode(path), file_size, begin, end, tag))
+
+    def add_synthetic_part(self, file_size, content_id, begin, end, seed=0x4D414B49):
+        self._check(self._lib.mi_batch_add_synthetic_part(self._h, file_size, content_id, seed, begin, end))
+
+    def scan_cuts(self):
+        """Blocking: stage + Gear marking + cut selection only (the parts' exits become known)."""
+        self._check(self._lib.mi_batch_scan_cuts(self._h))
+        return self
+
+    def parts(self):
+        n = C.c_uint64()
+        self._check(self._lib.mi_batch_parts(self._h, None, 0, C.byref(n)))
+        arr = (PartState * max(n.value, 1))()
+        self._check(self._lib.mi_batch_parts(self._h, arr, n.value, None))
+        return [{k: getattr(arr[i], k) for k, _ in PartState._fields_} for i in range(n.value)]
+
+    def set_part_entry(self, file_index, entry):
+        self._check(self._lib.mi_batch_set_part_entry(self._h, file_index, entry))
+
+    def fix_cuts(self):
+        self._check(self._lib.mi_batch_fix_cuts(self._h))
+        return self
 
     def run(self):
         self._check(self._lib.mi_batch_run(self._h))

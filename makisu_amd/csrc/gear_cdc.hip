@@ -349,7 +349,8 @@ void gear_cdc_small_kernel(const u8* __restrict__ data, const u64* __restrict__ 
 __device__ __forceinline__ u64 reselect_group(const u32* lists, const u32* bitmaps, u32 fast_mask,
                                                u64 g0, u64 size, u64 entry, const u32* __restrict__ spec,
                                                u32 spec_n, u64 spec_exit, u32* __restrict__ prefix,
-                                               const CdcParams& p, int lane, GroupRec* rec, u32* seg_n_out) {
+                                               const CdcParams& p, int lane, GroupRec* rec, u32* seg_n_out,
+                                               bool open_end) {
     u64 last = entry;
     u32 pcnt = 0, sidx = spec_n;
     u32 sbase = 0;
@@ -380,7 +381,7 @@ __device__ __forceinline__ u64 reselect_group(const u32* lists, const u32* bitma
         select_tile(bitmaps + t * kBitmapWords, (fast_mask >> t) & 1u ? lists + t * 64 : nullptr, tts, tlen,
                     p, last, lane, emit);
     }
-    if (!synced && g0 + kGroupBytes >= size && size > last) {  // the file's last group: the end cuts
+    if (!synced && !open_end && g0 + kGroupBytes >= size && size > last) {  // the file's last group: the end cuts
         if (!emit(size)) last = size;
     }
     const u64 exit = synced ? spec_exit : last;
@@ -405,6 +406,7 @@ void gear_group_mark_kernel(const u8* __restrict__ data, const u64* __restrict__
                             u32* __restrict__ seg_n, const u32* __restrict__ group_file,
                             const u32* __restrict__ group_index, u32 n_groups,
                             GroupRec* __restrict__ recs, u32* __restrict__ tile_lists,
+                            const u32* __restrict__ file_flags,
                             const u64* __restrict__ gear_table, CdcParams p) {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     u64* table = (u64*)smem;
@@ -418,6 +420,7 @@ void gear_group_mark_kernel(const u8* __restrict__ data, const u64* __restrict__
     for (u32 g = blockIdx.x; g < n_groups; g += gridDim.x) {
         const u32 f = group_file[g], gi = group_index[g];
         const u64 size = file_size[f];
+        const bool open_end = file_flags && (file_flags[f] & kFileOpenEnd);
         const u8* fptr = data + file_off[f];
         const u64 g0 = (u64)gi * kGroupBytes;
         const u64 ts = g0 + (u64)wave * kGearTile;
@@ -454,7 +457,7 @@ void gear_group_mark_kernel(const u8* __restrict__ data, const u64* __restrict__
                             [&](u64 c) { if (lane == 0) spec[n_out] = (u32)(c - g0); ++n_out; return false; });
             }
             if (lane == 0) {
-                if (g0 + kGroupBytes >= size && size > last) {   // the file's last group: the end cuts
+                if (!open_end && g0 + kGroupBytes >= size && size > last) {   // the file's last group: the end cuts
                     spec[n_out] = (u32)(size - g0); ++n_out; last = size;
                 }
                 GroupRec r;
@@ -481,7 +484,7 @@ void gear_group_validate_kernel(const u64* __restrict__ file_size, const u64* __
                                 u32* __restrict__ seg_n, const u32* __restrict__ group_file,
                                 const u32* __restrict__ group_index, u32 n_groups,
                                 GroupRec* __restrict__ recs, const u32* __restrict__ tile_lists,
-                                u32 region, CdcParams p) {
+                                const u32* __restrict__ file_flags, u32 region, CdcParams p) {
     __shared__ u32 lists[kWavesPerWG][kWavesPerWG * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const u32 g = blockIdx.x * kWavesPerWG + wave;
@@ -499,7 +502,7 @@ void gear_group_validate_kernel(const u64* __restrict__ file_size, const u64* __
     u32* spec = ends32 + seg_slot[s];
     (void)reselect_group(lists[wave], nullptr, (1u << kWavesPerWG) - 1u, (u64)gi * kGroupBytes, file_size[f],
                          recs[g - 1].spec_exit, spec, rec->spec_n, rec->spec_exit, spec + region, p, lane,
-                         rec, seg_n + s);
+                         rec, seg_n + s, file_flags && (file_flags[f] & kFileOpenEnd));
 }
 
 // C: one workgroup per large file.
@@ -509,8 +512,8 @@ void gear_file_fix_kernel(const u8* __restrict__ data, const u64* __restrict__ f
                           const u64* __restrict__ seg_slot, u32* __restrict__ ends32,
                           u32* __restrict__ seg_n, const u32* __restrict__ large_list,
                           const u32* __restrict__ large_group0, GroupRec* __restrict__ recs,
-                          const u32* __restrict__ tile_lists, u32 region,
-                          const u64* __restrict__ gear_table, CdcParams p) {
+                          const u32* __restrict__ tile_lists, const u32* __restrict__ file_flags,
+                          u32 region, const u64* __restrict__ gear_table, CdcParams p) {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     u64* table = (u64*)smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -526,6 +529,7 @@ void gear_file_fix_kernel(const u8* __restrict__ data, const u64* __restrict__ f
     const u64 size = file_size[f];
     const u8* fptr = data + file_off[f];
     const u32 gb = large_group0[blockIdx.x];
+    const bool open_end = file_flags && (file_flags[f] & kFileOpenEnd);
     const u32 ng = (u32)((size + kGroupBytes - 1) / kGroupBytes);
     u32 gi = 1;                                               // next group to check
     u64 prev_exit = 0;                                        // true exit of group gi - 1 (wave 0)
@@ -599,7 +603,7 @@ void gear_file_fix_kernel(const u8* __restrict__ data, const u64* __restrict__ f
             GroupRec* rec = recs + g;
             const u64 entry = *s_entry;
             prev_exit = reselect_group(cand_lists, bitmaps, fast_mask, g0, size, entry, spec, rec->spec_n,
-                                       rec->spec_exit, spec + region, p, lane, rec, seg_n + s);
+                                       rec->spec_exit, spec + region, p, lane, rec, seg_n + s, open_end);
             gi = redo + 1;
         }
         __syncthreads();
@@ -628,16 +632,62 @@ void launch_gear_cdc(const GearLaunch& a, CdcParams p, int n_cu, hipStream_t s) 
         GroupRec* recs = (GroupRec*)a.group_recs;
         hipLaunchKernelGGL(gear_group_mark_kernel, dim3(grid), dim3(kGearWG), kGearLdsBytes, s, a.data,
                            a.file_off, a.file_size, a.file_seg0, a.seg_slot, a.ends32, a.seg_n,
-                           a.group_file, a.group_index, a.n_groups, recs, a.tile_lists, a.gear_table, p);
+                           a.group_file, a.group_index, a.n_groups, recs, a.tile_lists, a.file_flags,
+                           a.gear_table, p);
         if (a.n_groups > a.n_large) {                     // some file has more than one group
             hipLaunchKernelGGL(gear_group_validate_kernel, dim3((a.n_groups + kWavesPerWG - 1) / kWavesPerWG),
                                dim3(kGearWG), 0, s, a.file_size, a.file_seg0, a.seg_slot, a.ends32, a.seg_n,
-                               a.group_file, a.group_index, a.n_groups, recs, a.tile_lists, region, p);
+                               a.group_file, a.group_index, a.n_groups, recs, a.tile_lists, a.file_flags,
+                               region, p);
             hipLaunchKernelGGL(gear_file_fix_kernel, dim3(a.n_large), dim3(kGearWG), kGearLdsBytes + 16, s,
                                a.data, a.file_off, a.file_size, a.file_seg0, a.seg_slot, a.ends32, a.seg_n,
-                               a.large_list, a.large_group0, recs, a.tile_lists, region, a.gear_table, p);
+                               a.large_list, a.large_group0, recs, a.tile_lists, a.file_flags, region,
+                               a.gear_table, p);
         }
     }
+}
+
+// ---- parts: a byte range of a file that is split across batches / GPUs ------------------------
+// A part is staged with a HALO of whole groups in front of its own range (>= max_size bytes, so the
+// chunk that straddles the part's start lies inside the item) and is chunked like any large file;
+// then: (1) part_apply puts the TRUE entry of the first own group -- the previous part's last cut,
+// known only after the parts' owners have talked -- where the fix-up pass reads the halo's exit, and
+// that pass runs again over the parts (a no-op walk when the halo had re-synchronised, the usual
+// case); (2) the halo groups' chunk counts are cleared: their cuts belong to the previous part.
+// A part that is not the file's last ends OPEN (kFileOpenEnd): no cut at its last byte.
+__global__ __launch_bounds__(64)
+void part_apply_kernel(const u32* __restrict__ part_group0, const u32* __restrict__ part_halo,
+                       const u64* __restrict__ part_entry, u32 n_parts, GroupRec* __restrict__ recs) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_parts || part_halo[i] == 0 || part_entry[i] == ~0ull) return;
+    recs[part_group0[i] + part_halo[i] - 1].final_exit = part_entry[i];
+}
+
+__global__ __launch_bounds__(64)
+void part_halo_clear_kernel(const u32* __restrict__ part_file, const u32* __restrict__ part_halo,
+                            u32 n_parts, const u64* __restrict__ file_seg0, u32* __restrict__ seg_n) {
+    const u32 i = blockIdx.x;
+    if (i >= n_parts) return;
+    const u64 s0 = file_seg0[part_file[i]];
+    for (u32 g = threadIdx.x; g < part_halo[i]; g += blockDim.x) seg_n[s0 + g] = 0;
+}
+
+void launch_gear_parts(const GearLaunch& a, const u32* d_part_file, const u32* d_part_group0,
+                       const u32* d_part_halo, const u64* d_part_entry, u32 n_parts, bool refix,
+                       CdcParams p, hipStream_t s) {
+    if (n_parts == 0) return;
+    GroupRec* recs = (GroupRec*)a.group_recs;
+    if (refix) {
+        const u32 region = (u32)gear_group_region(p.min_size);
+        hipLaunchKernelGGL(part_apply_kernel, dim3((n_parts + 63) / 64), dim3(64), 0, s, d_part_group0,
+                           d_part_halo, d_part_entry, n_parts, recs);
+        hipLaunchKernelGGL(gear_file_fix_kernel, dim3(n_parts), dim3(kGearWG), kGearLdsBytes + 16, s,
+                           a.data, a.file_off, a.file_size, a.file_seg0, a.seg_slot, a.ends32, a.seg_n,
+                           d_part_file, d_part_group0, recs, a.tile_lists, a.file_flags, region,
+                           a.gear_table, p);
+    }
+    hipLaunchKernelGGL(part_halo_clear_kernel, dim3(n_parts), dim3(64), 0, s, d_part_file, d_part_halo,
+                       n_parts, a.file_seg0, a.seg_n);
 }
 
 }  // namespace mi

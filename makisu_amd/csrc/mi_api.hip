@@ -189,6 +189,95 @@ float ev_ms(hipEvent_t a, hipEvent_t b) {
     return ms;
 }
 
+// ---- cut selection stage ------------------------------------------------------------------
+GearLaunch gear_args(mi_batch* b) {
+    mi_ctx* c = b->ctx;
+    GearLaunch g;
+    g.data = b->arena.as<u8>();
+    g.file_off = b->file_off.as<u64>();
+    g.file_size = b->file_size.as<u64>();
+    g.file_seg0 = b->file_seg0.as<u64>();
+    g.seg_file = b->seg_file.as<u32>();
+    g.seg_slot = b->seg_slot.as<u64>();
+    g.ends32 = b->ends32.as<u32>();
+    g.seg_n = b->seg_n.as<u32>();
+    g.small_list = b->small_list.as<u32>();
+    g.n_small = b->n_small;
+    g.group_file = b->group_file.as<u32>();
+    g.group_index = b->group_index.as<u32>();
+    g.n_groups = b->n_groups;
+    g.large_list = b->large_list.as<u32>();
+    g.large_group0 = b->large_group0.as<u32>();
+    g.n_large = b->n_large;
+    g.group_recs = b->group_recs.p;
+    g.tile_lists = b->tile_lists.as<u32>();
+    g.file_flags = b->parts.empty() ? nullptr : b->file_flags.as<u32>();
+    g.gear_table = c->gear_table.as<u64>();
+    return g;
+}
+
+int ensure_cut_buffers(mi_batch* b) {
+    mi_ctx* c = b->ctx;
+    HIPCHK(c, b->ends32.ensure(b->ends_total * 4 + 16));
+    HIPCHK(c, b->seg_n.ensure(b->n_segs * 4 + 16));
+    if (b->n_groups) {
+        HIPCHK(c, b->group_recs.ensure(gear_group_rec_bytes() * (size_t)b->n_groups));
+        HIPCHK(c, b->tile_lists.ensure(1024ull * b->n_groups));
+    }
+    return MI_OK;
+}
+
+// the parts' confirmed entries -> device (the vector lives in the batch: pageable async copy)
+int upload_part_entries(mi_batch* b) {
+    mi_ctx* c = b->ctx;
+    std::vector<u64> e(b->parts.size());
+    for (size_t i = 0; i < e.size(); ++i) e[i] = b->parts[i].set_entry_rel;
+    HIPCHK(c, b->part_entry.ensure(e.size() * 8 + 16));
+    HIPCHK(c, hipMemcpy(b->part_entry.p, e.data(), e.size() * 8, hipMemcpyHostToDevice));
+    return MI_OK;
+}
+
+// Gear marking + cut selection of the whole batch on the batch's stream -- unless mi_batch_scan_cuts
+// already made the cuts, then only what the parts still need (entries confirmed since).
+int enqueue_cuts(mi_batch* b) {
+    mi_ctx* c = b->ctx;
+    hipStream_t s = b->stream;
+    int rc = ensure_cut_buffers(b);
+    if (rc) return rc;
+    const GearLaunch g = gear_args(b);
+    const bool fresh = !b->cuts_ready;
+    if (fresh) launch_gear_cdc(g, c->cdc, c->prop.multiProcessorCount, s);
+    if (!b->parts.empty()) {
+        const bool refix = fresh || b->parts_dirty;
+        if (refix && (rc = upload_part_entries(b))) return rc;
+        launch_gear_parts(g, b->part_file.as<u32>(), b->part_group0.as<u32>(), b->part_halo.as<u32>(),
+                          b->part_entry.as<u64>(), (u32)b->parts.size(), refix, c->cdc, s);
+    }
+    b->cuts_ready = false;
+    b->parts_dirty = false;
+    return MI_OK;
+}
+
+// entry of the first own group and exit of the last group of every part, after the stream drained
+int read_part_states(mi_batch* b) {
+    mi_ctx* c = b->ctx;
+    HIPCHK(c, hipStreamSynchronize(b->stream));
+    const size_t rb = gear_group_rec_bytes();
+    for (PartRec& p : b->parts) {
+        GroupRec r;
+        const u8* recs = b->group_recs.as<u8>();
+        HIPCHK(c, hipMemcpy(&r, recs + rb * (p.group0 + p.n_groups - 1), rb, hipMemcpyDeviceToHost));
+        p.exit_rel = r.final_exit;
+        if (p.halo_groups) {
+            HIPCHK(c, hipMemcpy(&r, recs + rb * (p.group0 + p.halo_groups), rb, hipMemcpyDeviceToHost));
+            p.entry_rel = r.entry;
+        } else {
+            p.entry_rel = 0;
+        }
+    }
+    return MI_OK;
+}
+
 // ---- the device pipeline ---------------------------------------------------------
 // submit_pipeline only ENQUEUES (kernels, memsets, two 8-byte async copies into pinned
 // memory) on the batch's stream: there is no host synchronisation between the stages.  Table
@@ -208,6 +297,13 @@ int submit_pipeline(mi_batch* b) {
     b->in_flight = true;
     if (nf == 0) return MI_OK;
     if (nf >= 0x7FFFFFFFull) return fail(c, MI_ERR_INVALID, "too many files in one batch");
+    for (const PartRec& p : b->parts)
+        if (p.halo_groups && !p.confirmed) {
+            b->in_flight = false;
+            return fail(c, MI_ERR_STATE, "file %llu is a part whose entry cut is not confirmed: "
+                        "mi_batch_scan_cuts, exchange the exits, mi_batch_set_part_entry",
+                        (unsigned long long)p.file_index);
+        }
     const u64 cap = b->total_slots;                     // upper bound of the chunk count
     if (cap >= 0xFFFFFFFFull) return fail(c, MI_ERR_INVALID, "batch too large: %llu chunk slots",
                                           (unsigned long long)cap);
@@ -219,8 +315,6 @@ int submit_pipeline(mi_batch* b) {
     while (dd_cap < 2 * cap) dd_cap <<= 1;
     const bool dedup = !(c->cfg.flags & MI_FLAG_NO_DEDUP);
 
-    HIPCHK(c, b->ends32.ensure(b->ends_total * 4 + 16));
-    HIPCHK(c, b->seg_n.ensure(b->n_segs * 4 + 16));
     HIPCHK(c, b->seg_first.ensure(b->n_segs * 8 + 16));
     HIPCHK(c, b->n_chunks_d.ensure(nf * 4));
     HIPCHK(c, b->first.ensure(nf * 8));
@@ -260,32 +354,9 @@ int submit_pipeline(mi_batch* b) {
     HIPCHK(c, hipEventRecord(b->ev[0], s));
     HIPCHK(c, hipMemsetAsync(ctl, 0, kCtlBytes, s));
     const u32 region = (u32)gear_group_region(c->cfg.min_size);
-    if (b->n_groups) {
-        HIPCHK(c, b->group_recs.ensure(gear_group_rec_bytes() * (size_t)b->n_groups));
-        HIPCHK(c, b->tile_lists.ensure(1024ull * b->n_groups));
-    }
     {
-        GearLaunch g;
-        g.data = b->arena.as<u8>();
-        g.file_off = d_off;
-        g.file_size = d_size;
-        g.file_seg0 = b->file_seg0.as<u64>();
-        g.seg_file = b->seg_file.as<u32>();
-        g.seg_slot = b->seg_slot.as<u64>();
-        g.ends32 = b->ends32.as<u32>();
-        g.seg_n = b->seg_n.as<u32>();
-        g.small_list = b->small_list.as<u32>();
-        g.n_small = b->n_small;
-        g.group_file = b->group_file.as<u32>();
-        g.group_index = b->group_index.as<u32>();
-        g.n_groups = b->n_groups;
-        g.large_list = b->large_list.as<u32>();
-        g.large_group0 = b->large_group0.as<u32>();
-        g.n_large = b->n_large;
-        g.group_recs = b->group_recs.p;
-        g.tile_lists = b->tile_lists.as<u32>();
-        g.gear_table = c->gear_table.as<u64>();
-        launch_gear_cdc(g, c->cdc, ncu, s);
+        int rc = enqueue_cuts(b);
+        if (rc) return rc;
     }
     launch_scan_counts(b->seg_n.as<u32>(), b->seg_first.as<u64>(), d_total, b->n_segs,
                        b->scratch.as<u64>(), s);
@@ -428,6 +499,12 @@ int fetch_results(mi_batch* b) {
             memcpy(r.chunk_root, &roots[f * 32], 32);
             if (!fsha.empty()) memcpy(r.file_sha256, &fsha[f * 32], 32);
             if (!crcs.empty()) r.crc32 = crcs[f];
+            if (b->files[f].part >= 0) {                 // a part: its own range; no whole-file values
+                const PartRec& p = b->parts[b->files[f].part];
+                r.size = p.end - p.begin;
+                r.crc32 = 0;
+                memset(r.file_sha256, 0, 32);
+            }
         }
     }
     if (nc) {
@@ -444,6 +521,8 @@ int fetch_results(mi_batch* b) {
             mi_chunk_result& r = b->h_chunks[i];
             r.file_index = file[i];
             r.offset = start[i];
+            const int part = b->files[file[i]].part;     // parts report offsets inside the whole file
+            if (part >= 0) r.offset += b->parts[part].begin - b->parts[part].halo_bytes;
             r.length = (u32)len[i];
             r.dup_of = dup[i];
             memcpy(r.sha256, &dg[i * 32], 32);
@@ -721,6 +800,133 @@ int mi_batch_add_synthetic(mi_batch* b, uint64_t n_files, const uint64_t* sizes,
 
 // Stages everything that was added (flush of the pinned ring, file tables, synthetic
 // generation).  Done once per batch, before its first submit.
+static int stage_batch(mi_batch* b);
+
+// ---- parts: one file split across batches / GPUs ------------------------------
+static int part_geometry(mi_batch* b, uint64_t file_size, uint64_t begin, uint64_t end, PartRec* pr) {
+    mi_ctx* c = b->ctx;
+    if (begin >= end || end > file_size)
+        return fail(c, MI_ERR_INVALID, "part [%llu, %llu) of a %llu-byte file", (unsigned long long)begin,
+                    (unsigned long long)end, (unsigned long long)file_size);
+    if (begin % MI_PART_ALIGN || (end % MI_PART_ALIGN && end != file_size))
+        return fail(c, MI_ERR_INVALID, "part bounds must be multiples of MI_PART_ALIGN (the end may be the file's)");
+    u64 hg = 0;
+    if (begin) {
+        hg = (c->cfg.max_size + kGroupBytes - 1) / kGroupBytes;      // >= max_size bytes of halo
+        if (hg == 0) hg = 1;
+        if (hg * kGroupBytes > begin) hg = begin / kGroupBytes;      // the file starts inside it
+    }
+    pr->file_index = b->files.size();
+    pr->file_size = file_size;
+    pr->begin = begin;
+    pr->end = end;
+    pr->halo_groups = (u32)hg;
+    pr->halo_bytes = hg * kGroupBytes;
+    pr->confirmed = hg == 0;
+    return MI_OK;
+}
+
+int mi_batch_add_path_part(mi_batch* b, const char* path, uint64_t file_size, uint64_t begin, uint64_t end,
+                           uint64_t user_tag) {
+    if (!b || !path) return MI_ERR_INVALID;
+    PartRec pr;
+    int rc = part_geometry(b, file_size, begin, end, &pr);
+    if (rc) return rc;
+    rc = add_file_range(b, path, begin - pr.halo_bytes, pr.halo_bytes + (end - begin), user_tag);
+    if (rc) return rc;
+    b->files.back().part = (int)b->parts.size();
+    b->parts.push_back(pr);
+    return MI_OK;
+}
+
+int mi_batch_add_synthetic_part(mi_batch* b, uint64_t file_size, uint64_t content_id, uint64_t seed,
+                                uint64_t begin, uint64_t end) {
+    if (!b) return MI_ERR_INVALID;
+    PartRec pr;
+    int rc = part_geometry(b, file_size, begin, end, &pr);
+    if (rc) return rc;
+    const uint64_t size = pr.halo_bytes + (end - begin);
+    rc = mi_batch_add_synthetic(b, 1, &size, &content_id, seed);
+    if (rc) return rc;
+    b->synth.back().unit0 = (begin - pr.halo_bytes) / 16;
+    b->files.back().part = (int)b->parts.size();
+    b->parts.push_back(pr);
+    return MI_OK;
+}
+
+int mi_batch_scan_cuts(mi_batch* b) {
+    if (!b) return MI_ERR_INVALID;
+    mi_ctx* c = b->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (b->in_flight) return fail(c, MI_ERR_STATE, "batch is in flight; mi_batch_wait first");
+    int rc = stage_batch(b);
+    if (rc) return rc;
+    if (b->files.empty()) return MI_OK;
+    b->cuts_ready = false;
+    if ((rc = enqueue_cuts(b))) return rc;
+    if ((rc = read_part_states(b))) return rc;
+    HIPCHK(c, hipGetLastError());
+    b->cuts_ready = true;
+    return MI_OK;
+}
+
+int mi_batch_parts(mi_batch* b, mi_part_state* out, uint64_t cap, uint64_t* n_parts) {
+    if (!b || (!out && cap)) return MI_ERR_INVALID;
+    if (n_parts) *n_parts = b->parts.size();
+    for (size_t i = 0; i < b->parts.size() && i < cap; ++i) {
+        const PartRec& p = b->parts[i];
+        const u64 base = p.begin - p.halo_bytes;
+        mi_part_state& o = out[i];
+        memset(&o, 0, sizeof o);
+        o.file_index = p.file_index;
+        o.file_size = p.file_size;
+        o.begin = p.begin;
+        o.end = p.end;
+        o.entry = base + (p.set_entry_rel != ~0ull ? p.set_entry_rel : p.entry_rel);
+        o.exit = base + p.exit_rel;
+        o.entry_confirmed = p.confirmed ? 1u : 0u;
+        o.cuts_current = (p.set_entry_rel == ~0ull || p.set_entry_rel == p.entry_rel) ? 1u : 0u;
+    }
+    return MI_OK;
+}
+
+int mi_batch_set_part_entry(mi_batch* b, uint64_t file_index, uint64_t entry) {
+    if (!b) return MI_ERR_INVALID;
+    mi_ctx* c = b->ctx;
+    if (b->in_flight) return fail(c, MI_ERR_STATE, "batch is in flight; mi_batch_wait first");
+    if (file_index >= b->files.size() || b->files[file_index].part < 0)
+        return fail(c, MI_ERR_INVALID, "file %llu is not a part", (unsigned long long)file_index);
+    PartRec& p = b->parts[b->files[file_index].part];
+    if (p.halo_groups == 0) {
+        if (entry != 0) return fail(c, MI_ERR_INVALID, "a file's first part starts at its first byte");
+        return MI_OK;
+    }
+    const u64 base = p.begin - p.halo_bytes;
+    if (entry > p.begin || entry < base || p.begin - entry > c->cfg.max_size)
+        return fail(c, MI_ERR_INVALID, "entry cut %llu cannot precede a part that begins at %llu (max chunk %u)",
+                    (unsigned long long)entry, (unsigned long long)p.begin, c->cfg.max_size);
+    p.set_entry_rel = entry - base;
+    p.confirmed = true;
+    if (p.set_entry_rel != p.entry_rel || !b->cuts_ready) b->parts_dirty = true;
+    b->results_valid = false;
+    return MI_OK;
+}
+
+int mi_batch_fix_cuts(mi_batch* b) {
+    if (!b) return MI_ERR_INVALID;
+    mi_ctx* c = b->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (b->in_flight) return fail(c, MI_ERR_STATE, "batch is in flight; mi_batch_wait first");
+    if (!b->cuts_ready) return fail(c, MI_ERR_STATE, "mi_batch_fix_cuts without mi_batch_scan_cuts");
+    if (!b->parts_dirty) return MI_OK;
+    int rc = enqueue_cuts(b);                   // cuts_ready: only the parts' entry override + fix-up
+    if (rc) return rc;
+    if ((rc = read_part_states(b))) return rc;
+    HIPCHK(c, hipGetLastError());
+    b->cuts_ready = true;
+    return MI_OK;
+}
+
 static int stage_batch(mi_batch* b) {
     mi_ctx* c = b->ctx;
     if (b->staged) return MI_OK;
@@ -739,7 +945,7 @@ static int stage_batch(mi_batch* b) {
     u64 cap_chunks = 0, ends_total = 0, mx = 0;
     bool any_group = false;
     for (u64 f = 0; f < nf; ++f)
-        if (b->files[f].size > (u64)kGearTile) { any_group = true; break; }
+        if (b->files[f].size > (u64)kGearTile || b->files[f].part >= 0) { any_group = true; break; }
     seg_file.reserve(nf);
     seg_slot.reserve(nf);
     for (u64 f = 0; f < nf; ++f) {
@@ -748,7 +954,7 @@ static int stage_batch(mi_batch* b) {
         mx = size[f] > mx ? size[f] : mx;
         seg0[f] = seg_file.size();
         cap_chunks += size[f] / c->cfg.min_size + 2;          // upper bound of the file's chunk count
-        if (size[f] <= (u64)kGearTile) {
+        if (size[f] <= (u64)kGearTile && b->files[f].part < 0) {
             small.push_back((u32)seg_file.size());
             seg_file.push_back((u32)f);
             seg_slot.push_back(ends_total);
@@ -760,6 +966,11 @@ static int stage_batch(mi_batch* b) {
                 return fail(c, MI_ERR_INVALID, "batch too large: more than 2^32 tile groups");
             large.push_back((u32)f);
             large_g0.push_back((u32)gfile.size());
+            if (b->files[f].part >= 0) {
+                PartRec& pr = b->parts[b->files[f].part];
+                pr.group0 = (u32)gfile.size();
+                pr.n_groups = (u32)ng;
+            }
             for (u64 gi = 0; gi < ng; ++gi) {
                 seg_group.push_back((u32)gfile.size());
                 gfile.push_back((u32)f);
@@ -796,6 +1007,20 @@ static int stage_batch(mi_batch* b) {
     if ((rc = upload(c, b->large_group0, large_g0))) return rc;
     if ((rc = upload(c, b->file_off, off))) return rc;
     if ((rc = upload(c, b->file_size, size))) return rc;
+    std::vector<u32> fflags, pfile, pg0, phalo;
+    if (!b->parts.empty()) {
+        fflags.assign(nf, 0u);
+        for (const PartRec& pr : b->parts) {
+            if (pr.end < pr.file_size) fflags[pr.file_index] |= kFileOpenEnd;
+            pfile.push_back((u32)pr.file_index);
+            pg0.push_back(pr.group0);
+            phalo.push_back(pr.halo_groups);
+        }
+        if ((rc = upload(c, b->file_flags, fflags))) return rc;
+        if ((rc = upload(c, b->part_file, pfile))) return rc;
+        if ((rc = upload(c, b->part_group0, pg0))) return rc;
+        if ((rc = upload(c, b->part_halo, phalo))) return rc;
+    }
     std::vector<u32> tile_file;
     std::vector<u64> first_tile;
     if (c->cfg.flags & MI_FLAG_FILE_CRC32) {
@@ -815,7 +1040,7 @@ static int stage_batch(mi_batch* b) {
         HIPCHK(c, hipMemcpyAsync(b->cids.p, sp.cids.data(), sp.n * 8, hipMemcpyHostToDevice,
                                  c->stream));
         launch_synth_fill(b->arena.as<u8>(), b->file_off.as<u64>() + sp.f0,
-                          b->file_size.as<u64>() + sp.f0, b->cids.as<u64>(), sp.n, sp.seed,
+                          b->file_size.as<u64>() + sp.f0, b->cids.as<u64>(), sp.n, sp.seed, sp.unit0,
                           c->stream);
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
@@ -870,6 +1095,8 @@ int mi_batch_reset(mi_batch* b) {
     if (b->tree) { mi_batch_tree_free(b->tree); b->tree = nullptr; }
     b->files.clear();
     b->synth.clear();
+    b->parts.clear();
+    b->cuts_ready = b->parts_dirty = false;
     b->total_bytes = b->arena_used = 0;
     b->cur = 0;
     b->win_start = b->win_fill = 0;
@@ -974,7 +1201,8 @@ int mi_batch_free(mi_batch* b) {
                       &b->q_off, &b->q_len, &b->q_id,&b->arena, &b->small_list, &b->file_off, &b->file_size, &b->cids,
                       &b->n_chunks_d, &b->first, &b->scratch,
                       &b->chunk_off, &b->chunk_len, &b->chunk_file, &b->chunk_start, &b->digests, &b->item_off, &b->item_len, &b->roots,
-                      &b->file_sha, &b->dup_of};
+                      &b->file_sha, &b->dup_of, &b->file_flags, &b->part_file, &b->part_group0, &b->part_halo,
+                      &b->part_entry};
     for (DevBuf* d : bufs) d->release();
     delete b;
     return MI_OK;

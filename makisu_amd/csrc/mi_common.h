@@ -72,8 +72,10 @@ struct GearLaunch {
     u32        n_large;
     void*      group_recs;     // n_groups x gear_group_rec_bytes()
     u32*       tile_lists;     // n_groups x 4 tiles x 64 candidates
+    const u32* file_flags;     // per file, kFile* bits; nullptr when the batch holds no parts
     const u64* gear_table;
 };
+constexpr u32 kFileOpenEnd = 1u;     // a part that is not its file's last: no cut at its last byte
 struct GroupRec {
     u64 spec_exit;      // E_g: last cut of the speculative selection (a cut assumed at the group start)
     u64 final_exit;     // last cut of the final list, i.e. under `entry`
@@ -87,6 +89,12 @@ u64    gear_large_groups(u64 size);
 u64    gear_group_region(u32 min_size);
 size_t gear_group_rec_bytes();
 void   launch_gear_cdc(const GearLaunch& a, CdcParams p, int n_cu, hipStream_t s);
+// parts (split files): entry override + fix-up over the parts (refix), then the halo groups' chunk
+// counts are cleared; d_part_* are per part: file index, first group, halo groups, entry (relative
+// to the item's first byte, ~0 = keep the halo's own exit)
+void   launch_gear_parts(const GearLaunch& a, const u32* d_part_file, const u32* d_part_group0,
+                         const u32* d_part_halo, const u64* d_part_entry, u32 n_parts, bool refix,
+                         CdcParams p, hipStream_t s);
 
 // sha256.hip : n independent byte strings -> n digests.  Queue position p holds the string
 // base[off[p] .. +len[p]) whose digest goes to out[32 * (ids ? ids[p] : p)]; positions are
@@ -99,8 +107,9 @@ void launch_sha256_items(ShaPass pass, const u8* d_base, const u64* d_off, const
                          u8* d_out, int blocks_per_cu, int n_cu, hipStream_t s);
 
 // tables.hip
+// unit0: the files' first byte is byte 16 * unit0 of their content stream (0 except for parts)
 void launch_synth_fill(u8* d_data, const u64* d_file_off, const u64* d_file_size,
-                       const u64* d_content_id, u64 n_files, u64 seed, hipStream_t s);
+                       const u64* d_content_id, u64 n_files, u64 seed, u64 unit0, hipStream_t s);
 // n_chunks[f] -> first_chunk[f] (exclusive scan); d_total receives the sum
 void launch_scan_counts(const u32* d_counts, u64* d_first, u64* d_total, u64 n,
                         u64* d_scratch, hipStream_t s);

@@ -25,7 +25,18 @@ struct DevBuf {
     template <typename T> T* as() const { return (T*)p; }
 };
 
-struct SynthSpec { u64 f0, n, seed; std::vector<u64> cids; };
+struct SynthSpec { u64 f0, n, seed; std::vector<u64> cids; u64 unit0 = 0; };   // unit0: first 16-byte unit (parts)
+
+// A part: bytes [begin, end) of a file that is split across batches / GPUs, staged behind a halo of
+// whole 256 KiB groups (gear_cdc.hip "parts").  Offsets with _rel are relative to the item's first
+// byte, i.e. to file offset begin - halo_bytes.
+struct PartRec {
+    u64 file_index, file_size, begin, end, halo_bytes;
+    u32 halo_groups = 0, group0 = 0, n_groups = 0;
+    u64 entry_rel = 0, exit_rel = 0;   // as of the last read-back (scan / fix)
+    u64 set_entry_rel = ~0ull;         // what the caller confirmed (~0: nothing yet)
+    bool confirmed = false;
+};
 
 // sets the ctx's (or, for c == nullptr, the create-time) error message; returns code
 int fail(mi_ctx* c, int code, const char* fmt, ...);
@@ -65,9 +76,13 @@ struct mi_ctx {
 
 struct mi_batch {
     mi_ctx* ctx;
-    struct FileRec { mi::u64 off, size, tag; };
+    struct FileRec { mi::u64 off, size, tag; int part = -1; };   // part: index into `parts`
     std::vector<FileRec> files;
     std::vector<mi::SynthSpec> synth;
+    std::vector<mi::PartRec> parts;          // split files (mi_batch_add_*_part)
+    mi::DevBuf file_flags, part_file, part_group0, part_halo, part_entry;
+    bool cuts_ready = false;                 // mi_batch_scan_cuts ran: the next submit reuses its cuts
+    bool parts_dirty = false;                // a confirmed entry differs from the one the cuts were made with
     mi::u64 total_bytes = 0;     // sum of sizes
     mi::u64 arena_used = 0;      // next free arena offset
     mi::DevBuf arena;

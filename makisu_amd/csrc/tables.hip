@@ -17,7 +17,7 @@ typedef u64 u64x2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256)
 void synth_fill_kernel(u8* __restrict__ data, const u64* __restrict__ file_off,
                        const u64* __restrict__ file_size, const u64* __restrict__ content_id,
-                       u64 n_files, u64 seed) {
+                       u64 n_files, u64 seed, u64 unit0) {
     // blockIdx.x = file, blockIdx.y strides the file in 64 KiB pieces
     const u64 f = blockIdx.x;
     const u64 size = file_size[f];
@@ -28,20 +28,20 @@ void synth_fill_kernel(u8* __restrict__ data, const u64* __restrict__ file_off,
     for (u64 u = (u64)blockIdx.y * blockDim.x + threadIdx.x; u < n16;
          u += (u64)gridDim.y * blockDim.x) {
         u64x2 v;
-        v.x = splitmix64_mix(base + (2 * u + 1) * kSmGamma);
-        v.y = splitmix64_mix(base + (2 * u + 2) * kSmGamma);
+        v.x = splitmix64_mix(base + (2 * (u + unit0) + 1) * kSmGamma);
+        v.y = splitmix64_mix(base + (2 * (u + unit0) + 2) * kSmGamma);
         dst[u] = v;
     }
 }
 
 void launch_synth_fill(u8* d_data, const u64* d_file_off, const u64* d_file_size,
-                       const u64* d_content_id, u64 n_files, u64 seed, hipStream_t s) {
+                       const u64* d_content_id, u64 n_files, u64 seed, u64 unit0, hipStream_t s) {
     if (n_files == 0) return;
     // y-dimension: enough pieces that a handful of huge files still fill the chip
     u32 gy = n_files >= 4096 ? 1 : (u32)(4096 / n_files);
     if (gy > 1024) gy = 1024;
     hipLaunchKernelGGL(synth_fill_kernel, dim3((u32)n_files, gy), dim3(256), 0, s, d_data,
-                       d_file_off, d_file_size, d_content_id, n_files, seed);
+                       d_file_off, d_file_size, d_content_id, n_files, seed, unit0);
 }
 
 // ---- exclusive scan of per-file chunk counts ------------------------------------

@@ -134,3 +134,72 @@ def global_dedup(engine, batch, device, group=None, mark=None, local=None):
     t = torch.tensor([n_first], dtype=torch.int64)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=_host_group(group))
     return n_total, int(t.item()), first, dup
+
+
+# ---- parts: one file split across GPUs (include/makisu_mi.h "parts") --------------------------------
+def _apply_exits(batch, keys, states, exits):
+    """Gives every part of `batch` the exit of its predecessor.  keys[i] = (file_key, part_no) of the
+    i-th part batch.parts() lists.  Returns True when some part's cuts have to be made again."""
+    redo = False
+    for (fkey, pno), st in zip(keys, states):
+        if pno == 0:
+            continue
+        e = exits[(fkey, pno - 1)]
+        if e != st["entry"]:
+            redo = True
+        if e != st["entry"] or not st["entry_confirmed"]:
+            batch.set_part_entry(st["file_index"], e)
+    return redo
+
+
+def resolve_parts_local(owners):
+    """All parts live in this process (several batches standing in for GPUs, or one GPU working
+    through a file larger than its memory): owners = [(batch, keys), ...].  Runs the scan /
+    exchange / fix rounds until every part starts at its predecessor's last cut; the batches can
+    then be submitted.  Returns the number of rounds."""
+    for b, _ in owners:
+        b.scan_cuts()
+    rounds = 0
+    while True:
+        rounds += 1
+        states = [b.parts() for b, _ in owners]
+        exits = {k: st["exit"] for (b, keys), sts in zip(owners, states) for k, st in zip(keys, sts)}
+        redo = False
+        for (b, keys), sts in zip(owners, states):
+            if _apply_exits(b, keys, sts, exits):
+                redo = True
+            b.fix_cuts()
+        if not redo:
+            return rounds
+
+
+def resolve_parts(batch, keys, group=None):
+    """One process per GPU: the same rounds with the exits travelling over the host group (gloo;
+    8 bytes per part and round, no device collective).  keys as in _apply_exits; every rank calls
+    this, also ranks without parts (keys = [])."""
+    hg = _host_group(group)
+    world = dist.get_world_size(group)
+    batch.scan_cuts()
+    rounds = 0
+    while True:
+        rounds += 1
+        states = batch.parts()
+        counts = all_gather_counts(len(states), group)
+        m = max(counts)
+        redo = False
+        if m:
+            slab = torch.full((m, 3), -1, dtype=torch.int64)
+            for i, ((fkey, pno), st) in enumerate(zip(keys, states)):
+                slab[i, 0], slab[i, 1], slab[i, 2] = int(fkey), int(pno), int(st["exit"])
+            out = [torch.empty((m, 3), dtype=torch.int64) for _ in range(world)]
+            dist.all_gather(out, slab, group=hg)
+            exits = {}
+            for r in range(world):
+                for row in out[r][: counts[r]].tolist():
+                    exits[(row[0], row[1])] = row[2]
+            redo = _apply_exits(batch, keys, states, exits)
+            batch.fix_cuts()
+        t = torch.tensor([1 if redo else 0], dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=hg)
+        if int(t.item()) == 0:
+            return rounds

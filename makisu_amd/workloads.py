@@ -125,3 +125,42 @@ def c5(rank=0, world=1, bytes_per_gpu=32 * GIB, generation=0, lo_log2=10, hi_log
 
 
 CONFIGS = {"c2": c2, "c3": c3, "c4": c4, "c5": c5}
+
+
+PART_ALIGN = 256 * KIB          # MI_PART_ALIGN: part bounds are multiples of the 256 KiB CDC group
+
+
+def split_file(file_size, n_parts, align=PART_ALIGN):
+    """SURVEY.md 8(e) "files >= 256 MiB split ... across GPUs": [begin, end) of n_parts (or fewer)
+    nearly equal parts with group-aligned bounds; the last part ends at file_size."""
+    groups = -(-int(file_size) // align)
+    n_parts = max(1, min(int(n_parts), groups))
+    cuts = [(groups * i // n_parts) * align for i in range(n_parts)] + [int(file_size)]
+    return [(cuts[i], cuts[i + 1]) for i in range(n_parts) if cuts[i + 1] > cuts[i]]
+
+
+def plan_split(sizes, world, threshold=256 * MIB):
+    """Work items for `world` GPUs: files below `threshold` stay whole, larger ones become `world`
+    parts.  Returns a list of (file, part_no, begin, end) -- part_no is None for a whole file --
+    and the rank of each item: parts go to consecutive ranks, whole files to the least loaded
+    rank (longest first), like shard_lpt."""
+    import heapq
+    sizes = np.asarray(sizes, dtype=np.int64)
+    items, ranks = [], []
+    load = [0] * world
+    for f in np.argsort(-sizes, kind="stable"):
+        if sizes[f] >= threshold and world > 1:
+            for k, (b, e) in enumerate(split_file(sizes[f], world)):
+                items.append((int(f), k, b, e))
+                ranks.append(k % world)
+                load[k % world] += e - b
+    heap = [(load[r], r) for r in range(world)]
+    heapq.heapify(heap)
+    for f in np.argsort(-sizes, kind="stable"):
+        if sizes[f] >= threshold and world > 1:
+            continue
+        ld, r = heapq.heappop(heap)
+        items.append((int(f), None, 0, int(sizes[f])))
+        ranks.append(r)
+        heapq.heappush(heap, (ld + int(sizes[f]), r))
+    return items, ranks

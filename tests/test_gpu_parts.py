@@ -1,0 +1,189 @@
+"""GPU parity for PARTS: one file split across batches / GPUs (include/makisu_mi.h "parts",
+SURVEY.md 8e "files >= 256 MiB split across GPUs").  A part is staged behind a halo, cut under an
+assumed entry, and corrected with the previous part's last cut; the parts' chunk rows, put end to
+end, must be EXACTLY the rows of the whole file -- checked against the oracle's sequential chunker
+and against the engine's own whole-file run.  Cut points: parity UNPINNED w.r.t. the reference (no
+CDC there); the oracle is this repo's spec.
+"""
+import os
+
+import numpy as np
+import pytest
+
+try:
+    import torch  # noqa: F401  (must come before the engine: see test_gpu_parity.py)
+except ImportError:
+    torch = None
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x4D414B49
+G = 256 * 1024
+
+
+def _whole(oracle, eng, data):
+    c = eng.cfg
+    p = oracle.CdcParams(c.gear_seed, c.mask_bits, c.min_size, c.max_size)
+    a = np.frombuffer(data, dtype=np.uint8)
+    _, rc = oracle.scan_batch(a, np.array([0], dtype=np.uint64), np.array([len(data)], dtype=np.uint64),
+                              p, True, 8, 0)
+    return rc
+
+
+def _check_parts(oracle, eng, data, bounds, add, one_batch=False):
+    """add(batch, begin, end) registers the part.  Every part gets its own batch (a GPU each) unless
+    one_batch.  Returns the number of exchange rounds."""
+    from makisu_amd.distributed import resolve_parts_local
+    ref = _whole(oracle, eng, data)
+    batches, owners = [], []
+    try:
+        if one_batch:
+            b = eng.batch()
+            batches.append(b)
+            for k, (lo, hi) in enumerate(bounds):
+                add(b, lo, hi)
+            owners.append((b, [(0, k) for k in range(len(bounds))]))
+        else:
+            for k, (lo, hi) in enumerate(bounds):
+                b = eng.batch()
+                batches.append(b)
+                add(b, lo, hi)
+                owners.append((b, [(0, k)]))
+        rounds = resolve_parts_local(owners)
+        rows = []
+        for b in batches:
+            b.run()
+            ch, fl = b.chunks().copy(), b.files().copy()
+            for st in b.parts():
+                mine = ch[ch["file_index"] == st["file_index"]]
+                assert fl["size"][st["file_index"]] == st["end"] - st["begin"]
+                assert fl["n_chunks"][st["file_index"]] == len(mine)
+                if len(mine):                              # owned: chunks that END in (begin, end]
+                    ends = mine["offset"] + mine["length"]
+                    assert ends[0] > st["begin"] and ends[-1] <= st["end"]
+                    assert mine["offset"][0] == st["entry"] and ends[-1] == st["exit"]
+                rows.append(mine)
+        got = np.concatenate(rows)
+        assert len(got) == len(ref), (len(got), len(ref))
+        assert np.array_equal(got["offset"], ref["offset"]), "cut points differ"
+        assert np.array_equal(got["length"], ref["length"]), "cut points differ"
+        assert np.array_equal(got["sha256"], ref["sha256"]), "chunk digests differ"
+        return rounds
+    finally:
+        for b in batches:
+            b.free()
+
+
+def test_synthetic_parts_equal_the_whole_file(oracle):
+    import makisu_amd
+    from makisu_amd.workloads import split_file
+    n = 21 * G + 12345
+    data = oracle.synth_fill(SEED, 4100, 0, n).tobytes()
+    with makisu_amd.Engine() as e:
+        for n_parts in (2, 3, 8):
+            bounds = split_file(n, n_parts)
+            assert bounds[0][0] == 0 and bounds[-1][1] == n
+            rounds = _check_parts(oracle, e, data, bounds,
+                                  lambda b, lo, hi: b.add_synthetic_part(n, 4100, lo, hi, seed=SEED))
+            assert rounds == 1                      # random data: every halo had re-synchronised
+        _check_parts(oracle, e, data, split_file(n, 4),
+                     lambda b, lo, hi: b.add_synthetic_part(n, 4100, lo, hi, seed=SEED), one_batch=True)
+        # and the engine's own whole-file run gives the same rows
+        with e.batch() as b:
+            b.add_synthetic([n], [4100], seed=SEED)
+            b.run()
+            ref = _whole(oracle, e, data)
+            assert np.array_equal(b.chunks()["sha256"], ref["sha256"])
+
+
+def test_path_parts_forced_cuts_need_every_round(oracle, tmp_path):
+    """All zeros, max_size not dividing the group: no halo ever re-synchronises, every part's cuts
+    depend on the previous part's exit -- the exchange needs one round per boundary."""
+    import makisu_amd
+    n = 9 * G + 777
+    data = bytes(n)
+    path = tmp_path / "zeros.bin"
+    path.write_bytes(data)
+    with makisu_amd.Engine(max_size=100000) as e:
+        bounds = [(0, 2 * G), (2 * G, 5 * G), (5 * G, 6 * G), (6 * G, n)]
+        rounds = _check_parts(oracle, e, data, bounds,
+                              lambda b, lo, hi: b.add_path_part(str(path), lo, hi, file_size=n))
+        assert 2 <= rounds <= len(bounds) + 1
+
+
+@pytest.mark.parametrize("mask_bits,min_size,max_size", [
+    (4, 128, 3000), (9, 512, 10000), (16, 4096, 262144), (18, 2048, 300000), (13, 2048, 1 << 20),
+    (32, 2048, 65536)])
+def test_parts_param_sweep(oracle, tmp_path, mask_bits, min_size, max_size):
+    """Dense tiles, chunks longer than a group (halo of several groups, or reaching back to the
+    file's first byte), no candidates at all."""
+    import makisu_amd
+    n = 11 * G + 4321
+    data = oracle.synth_fill(SEED, 4200, 0, 4 * G).tobytes() + bytes(2 * G + 99) + \
+        oracle.synth_fill(SEED, 4201, 0, n - 6 * G - 99).tobytes()
+    path = tmp_path / "mix.bin"
+    path.write_bytes(data)
+    with makisu_amd.Engine(mask_bits=mask_bits, min_size=min_size, max_size=max_size) as e:
+        bounds = [(0, G), (G, 4 * G), (4 * G, 7 * G), (7 * G, 8 * G), (8 * G, n)]
+        _check_parts(oracle, e, data, bounds,
+                     lambda b, lo, hi: b.add_path_part(str(path), lo, hi, file_size=n))
+
+
+def test_parts_next_to_ordinary_files(oracle, tmp_path):
+    """A batch holding whole files and parts of two different split files."""
+    import makisu_amd
+    from makisu_amd.distributed import resolve_parts_local
+    nA, nB = 6 * G + 100, 5 * G
+    A = oracle.synth_fill(SEED, 4300, 0, nA).tobytes()
+    B = oracle.synth_fill(SEED, 4301, 0, nB).tobytes()
+    small = [oracle.synth_fill(SEED, 4310 + i, 0, s).tobytes() for i, s in enumerate([100, 70000, 3 * G + 5])]
+    with makisu_amd.Engine() as e:
+        refA, refB = _whole(oracle, e, A), _whole(oracle, e, B)
+        b0, b1 = e.batch(), e.batch()
+        try:
+            b0.add_bytes(small[0]); b0.add_synthetic_part(nA, 4300, 0, 3 * G, seed=SEED)      # noqa: E702
+            b0.add_bytes(small[1]); b0.add_synthetic_part(nB, 4301, 2 * G, nB, seed=SEED)     # noqa: E702
+            b1.add_synthetic_part(nB, 4301, 0, 2 * G, seed=SEED); b1.add_bytes(small[2])      # noqa: E702
+            b1.add_synthetic_part(nA, 4300, 3 * G, nA, seed=SEED)
+            resolve_parts_local([(b0, [("A", 0), ("B", 1)]), (b1, [("B", 0), ("A", 1)])])
+            b0.run(); b1.run()                                                                 # noqa: E702
+            c0, c1 = b0.chunks().copy(), b1.chunks().copy()
+            gotA = np.concatenate([c0[c0["file_index"] == 1], c1[c1["file_index"] == 2]])
+            gotB = np.concatenate([c1[c1["file_index"] == 0], c0[c0["file_index"] == 3]])
+            for got, ref in ((gotA, refA), (gotB, refB)):
+                assert np.array_equal(got["offset"], ref["offset"])
+                assert np.array_equal(got["sha256"], ref["sha256"])
+            for blob, (c, f) in zip(small, ((c0, 0), (c0, 2), (c1, 1))):
+                ref = _whole(oracle, e, blob)
+                assert np.array_equal(c[c["file_index"] == f]["sha256"], ref["sha256"])
+            # a second submit of the same batches (bench steps) gives the same rows
+            b0.rerun()
+            assert np.array_equal(b0.chunks()["sha256"], c0["sha256"])
+        finally:
+            b0.free(); b1.free()                                                               # noqa: E702
+
+
+def test_part_errors(tmp_path):
+    import makisu_amd
+    with makisu_amd.Engine() as e:
+        with e.batch() as b:
+            with pytest.raises(makisu_amd.MiError):
+                b.add_synthetic_part(10 * G, 1, 100, 2 * G)            # begin not aligned
+            with pytest.raises(makisu_amd.MiError):
+                b.add_synthetic_part(10 * G, 1, 0, G + 5)              # end neither aligned nor the file's
+            with pytest.raises(makisu_amd.MiError):
+                b.add_synthetic_part(10 * G, 1, 2 * G, 11 * G)         # past the file
+            b.add_synthetic_part(10 * G, 1, 2 * G, 4 * G)
+            with pytest.raises(makisu_amd.MiError, match="not confirmed"):
+                b.run()                                                # entry never confirmed
+            b.scan_cuts()
+            st = b.parts()[0]
+            assert st["entry_confirmed"] == 0 and 2 * G - 65536 <= st["entry"] <= 2 * G
+            with pytest.raises(makisu_amd.MiError):
+                b.set_part_entry(0, 2 * G - 65537)                     # farther back than max_size
+            with pytest.raises(makisu_amd.MiError):
+                b.set_part_entry(0, 2 * G + 1)                         # inside the part
+            b.set_part_entry(0, st["entry"])
+            b.fix_cuts()
+            b.run()
+            assert b.parts()[0]["entry_confirmed"] == 1
