@@ -8,5 +8,5 @@ mkdir -p tools/bin
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result -fno-gpu-rdc \
   -mllvm -amdgpu-atomic-optimizer-strategy=None -Imakisu_amd/csrc $flags -c $src -o tools/bin/sha256_$name.o
 objs=$(ls makisu_amd/_obj/*.o | grep -v sha256.o)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fno-gpu-rdc -Wl,--no-undefined $objs tools/bin/sha256_$name.o -ldl -o tools/bin/libmi_$name.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fno-gpu-rdc -Wl,--no-undefined $objs tools/bin/sha256_$name.o -ldl -lpthread -lz -o tools/bin/libmi_$name.so
 echo tools/bin/libmi_$name.so
