@@ -376,7 +376,7 @@ int submit_pipeline(mi_batch* b) {
     HIPCHK(c, hipEventRecord(b->ev[2], s));
     launch_sha256_items(kShaChunks, b->arena.as<u8>(), b->q_off.as<u64>(), b->q_len.as<u64>(),
                         b->q_id.as<u32>(), (u32)cap, d_n, heads(0), false,
-                        b->digests.as<u8>(), c->sha_blocks_per_cu, ncu, s);
+                        b->digests.as<u8>(), c->sha_blocks_per_cu, ncu, b->arena_used, s);
     HIPCHK(c, hipEventRecord(b->ev[3], s));
     // per-file chunk roots: fan-out-64 tree; reduction passes only exist for files with more than
     // 64 chunks (> ~0.5 MiB), the final pass hashes every file's <= 64 nodes
@@ -408,7 +408,7 @@ int submit_pipeline(mi_batch* b) {
             launch_sha256_items(kShaRoots, nullptr, b->root_items_off.as<u64>(),
                                 b->root_items_len.as<u64>(), nullptr, (u32)out_ub,
                                 b->rseg_total.as<u64>(), heads(3 + r), false,
-                                b->root_level[r].as<u8>(), c->sha_blocks_per_cu, ncu, s);
+                                b->root_level[r].as<u8>(), c->sha_blocks_per_cu, ncu, 0, s);
             nodes_ub = out_ub;
             std::swap(cur_addr, next_addr);
             std::swap(cur_cnt, next_cnt);
@@ -417,10 +417,10 @@ int submit_pipeline(mi_batch* b) {
     }
     launch_sha256_items(kShaRoots, nullptr, b->item_off.as<u64>(), b->item_len.as<u64>(), nullptr,
                         (u32)nf, nullptr, heads(1), false, b->roots.as<u8>(),
-                        c->sha_blocks_per_cu, ncu, s);
+                        c->sha_blocks_per_cu, ncu, 0, s);
     if (c->cfg.flags & MI_FLAG_FILE_SHA256)
         launch_sha256_items(kShaFiles, b->arena.as<u8>(), d_off, d_size, nullptr, (u32)nf, nullptr,
-                            heads(2), false, b->file_sha.as<u8>(), c->sha_blocks_per_cu, ncu, s);
+                            heads(2), false, b->file_sha.as<u8>(), c->sha_blocks_per_cu, ncu, b->arena_used, s);
     if (c->cfg.flags & MI_FLAG_FILE_CRC32) {
         HIPCHK(c, b->tile_raw.ensure(b->n_tiles * 4 + 16));
         HIPCHK(c, b->crc_d.ensure(nf * 4));
@@ -1334,7 +1334,7 @@ int mi_sha256_many(mi_ctx* c, const void* data, const uint64_t* offsets, const u
         if (e == hipSuccess) {
             launch_sha256_items(kShaBlobs, d_data.as<u8>(), d_off.as<u64>(), d_len.as<u64>(), nullptr, (u32)n,
                                 nullptr, c->heads.as<u32>(), true, d_out.as<u8>(), c->sha_blocks_per_cu,
-                                c->prop.multiProcessorCount, c->stream);
+                                c->prop.multiProcessorCount, span, c->stream);
             e = hipStreamSynchronize(c->stream);
         }
         if (e == hipSuccess) e = hipGetLastError();

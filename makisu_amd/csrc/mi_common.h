@@ -104,7 +104,8 @@ enum ShaPass { kShaChunks = 0, kShaRoots = 1, kShaFiles = 2, kShaBlobs = 3 };
 // d_heads must be zero on entry unless zero_heads (then the launcher clears it first)
 void launch_sha256_items(ShaPass pass, const u8* d_base, const u64* d_off, const u64* d_len,
                          const u32* d_ids, u32 n, const u64* d_n, u32* d_heads, bool zero_heads,
-                         u8* d_out, int blocks_per_cu, int n_cu, hipStream_t s);
+                         u8* d_out, int blocks_per_cu, int n_cu, u64 footprint_bytes, hipStream_t s);
+// footprint_bytes: the span of memory the strings lie in (picks the load scheme, sha256.hip kCoop)
 
 // tables.hip
 // unit0: the files' first byte is byte 16 * unit0 of their content stream (0 except for parts)

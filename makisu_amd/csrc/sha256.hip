@@ -22,6 +22,26 @@ namespace mi {
 
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 typedef u32x4 u32x4_unaligned __attribute__((aligned(1)));
+typedef u32x4 u32x4_a4 __attribute__((aligned(4)));
+
+// kCoop: how a lane's next 64-byte block comes in.
+//   false  four byte-aligned 16-byte loads by the lane itself (64 lanes -> 64 pages per instruction,
+//      and the texture addresser splits every unaligned dwordx4);
+//   true   QUAD-COOPERATIVE: the four lanes of a quad fetch ONE owner's block with one instruction (lane
+//      l&3 takes 16-byte piece l&3: 64 contiguous, dword-aligned bytes per quad), four instructions
+//      for the quad's four owners; the pieces are transposed back to their owners through LDS
+//      (ds_write_b128 / ds_read_b128: no VALU work).  The block window is [q + 4 + 64 j, +64) with
+//      q = start & ~3 plus one carried dword in front, and the byte realignment rides on the
+//      big-endian v_perm_b32 every word needs anyway.
+// Cooperative loads cost ~2 % more VALU work and save TLB misses: they lose 2 % on a 6.5 GB arena
+// and win 14 % on a 32 GB one (profiles/r02_sha_utcl1_and_load_alignment.txt), so the launcher
+// picks by the footprint of the strings.
+__device__ __forceinline__ u32 be_word(u32 hi, u32 lo, u32 sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+template <int kM>
+__device__ __forceinline__ u32 quad_bcast(u32 v) {            // value of lane (lane & ~3) + kM
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, kM * 0x55, 0xF, 0xF, true);
+}
+constexpr int kXRow = 20;                                      // LDS row: 64 B of block + 16 B pad (dwords)
 
 __device__ __forceinline__ u32 rotr(u32 x, u32 n) { return __builtin_amdgcn_alignbit(x, x, n); }
 // gfx950 v_bitop3_b32: any 3-input boolean in ONE VALU op (truth table: a=0xF0, b=0xCC, c=0xAA)
@@ -106,7 +126,7 @@ __device__ __forceinline__ void mask_tail_block(u32 (&w)[16], u32 r) {
 constexpr u32 kLook = 5;
 
 // kPass only names the instantiation (chunk pass / root pass / ...) so profiles tell them apart.
-template <int kPass>
+template <int kPass, bool kCoop>
 __global__ __launch_bounds__(kShaWG)
 void sha256_items_kernel(const u8* __restrict__ base, const u64* __restrict__ off,
                          const u64* __restrict__ len, const u32* __restrict__ ids, u32 n_max,
@@ -122,6 +142,14 @@ void sha256_items_kernel(const u8* __restrict__ base, const u64* __restrict__ of
     u32 slot = 0;
     u32 st[8];
     u32x4 nx0, nx1, nx2, nx3;
+    // kCoop only:
+    __shared__ __attribute__((aligned(16))) u32 xpose[kCoop ? kShaWG / 64 : 1][kCoop ? 64 * kXRow : 4];
+    u32* xw = xpose[kCoop ? threadIdx.x >> 6 : 0];
+    const int sub = lane & 3, qbase = lane & ~3;
+    u32x4 g0 = {0, 0, 0, 0}, g1 = g0, g2 = g0, g3 = g0;   // piece `sub` of the blocks of owners qbase + 0..3
+    bool loaded = false;                                   // my next block is among the pieces in flight
+    u32 carry = 0, sel = 0x00010203u;   // dword in front of nx*, byte selector of the string's misalignment
+    u32 fc = 0;
     bool active = false, pad_block = false;
     // next string
     enum : u32 { kNone = 0, kReq = 1, kPos = 2, kDesc = 3, kReady = 4, kDry = 5 };
@@ -140,6 +168,25 @@ void sha256_items_kernel(const u8* __restrict__ base, const u64* __restrict__ of
         asm volatile("" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(nx0), "+v"(nx1),
                           "+v"(nx2), "+v"(nx3));
         asm volatile("" : "+v"(noff), "+v"(nlen), "+v"(nslot), "+v"(areq));
+        if constexpr (kCoop) asm volatile("" : "+v"(g0), "+v"(g1), "+v"(g2), "+v"(g3), "+v"(fc));
+        if (kCoop && __ballot(loaded)) {
+            // pieces -> owners: piece `sub` of owner qbase + m lies in g_m
+            *(u32x4*)&xw[(qbase + 0) * kXRow + 4 * sub] = g0;
+            *(u32x4*)&xw[(qbase + 1) * kXRow + 4 * sub] = g1;
+            *(u32x4*)&xw[(qbase + 2) * kXRow + 4 * sub] = g2;
+            *(u32x4*)&xw[(qbase + 3) * kXRow + 4 * sub] = g3;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (loaded) {
+                nx0 = *(const u32x4*)&xw[lane * kXRow];
+                nx1 = *(const u32x4*)&xw[lane * kXRow + 4];
+                nx2 = *(const u32x4*)&xw[lane * kXRow + 8];
+                nx3 = *(const u32x4*)&xw[lane * kXRow + 12];
+                loaded = false;
+            }
+            __builtin_amdgcn_wave_barrier();               // the rows are rewritten next iteration
+        }
         // ---- stage 1b: resolve last iteration's dequeue --------------------------------
         if (__ballot(nstate == kReq)) {
             const u32 first = __shfl(areq, req_leader);
@@ -163,7 +210,15 @@ void sha256_items_kernel(const u8* __restrict__ base, const u64* __restrict__ of
         }
         // ---- switch to the next string (its first block arrived an iteration ago) -------
         if (!active && nstate == kReady) {
-            ptr = base + noff;
+            if constexpr (kCoop) {
+                const u8* p = base + noff;
+                const u32 mis = (u32)(size_t)p & 3u;
+                ptr = p - mis + 4;                     // the aligned window behind the carried dword
+                sel = 0x00010203u + mis * 0x01010101u;
+                carry = fc;
+            } else {
+                ptr = base + noff;
+            }
             total = rem = nlen;
             slot = nslot;
             nx0 = f0; nx1 = f1; nx2 = f2; nx3 = f3;
@@ -176,10 +231,26 @@ void sha256_items_kernel(const u8* __restrict__ base, const u64* __restrict__ of
         if (nstate == kDesc) {
             const u8* p = base + noff;
             if (nlen) {
+              if constexpr (kCoop) {
+                // a string's FIRST block is fetched by its own lane (once per string)
+                const u8* q = p - ((size_t)p & 3u);
+                // (the dword in front comes through a laundered pointer: seeing q and q + 4 together,
+                // hipcc merges the five loads into overlapping ones and shuffles registers right
+                // behind them -- a full memory wait inside the iteration)
+                typedef __attribute__((address_space(1))) const u32 glob_cu32;   // stays a global_load
+                glob_cu32* qc = (glob_cu32*)q;
+                asm volatile("" : "+v"(qc));
+                fc = *qc;
+                f0 = *(const u32x4_a4*)(q + 4);
+                f1 = *(const u32x4_a4*)(q + 20);
+                f2 = *(const u32x4_a4*)(q + 36);
+                f3 = *(const u32x4_a4*)(q + 52);
+              } else {
                 f0 = *(const u32x4_unaligned*)(p);
                 f1 = *(const u32x4_unaligned*)(p + 16);
                 f2 = *(const u32x4_unaligned*)(p + 32);
                 f3 = *(const u32x4_unaligned*)(p + 48);
+              }
             }
             nstate = kReady;
         }
@@ -212,10 +283,22 @@ void sha256_items_kernel(const u8* __restrict__ base, const u64* __restrict__ of
         }
         if (!__ballot(active || nstate != kDry)) break;
 
+        u32 w[16];
+        bool last = false;
+        bool want = false;                                 // kCoop: my string has another block to fetch
         if (active) {
-            u32 w[16];
-            bool last = false;
             if (!pad_block) {
+              if constexpr (kCoop) {
+                w[0] = be_word(nx0.x, carry, sel); w[1] = be_word(nx0.y, nx0.x, sel);
+                w[2] = be_word(nx0.z, nx0.y, sel); w[3] = be_word(nx0.w, nx0.z, sel);
+                w[4] = be_word(nx1.x, nx0.w, sel); w[5] = be_word(nx1.y, nx1.x, sel);
+                w[6] = be_word(nx1.z, nx1.y, sel); w[7] = be_word(nx1.w, nx1.z, sel);
+                w[8] = be_word(nx2.x, nx1.w, sel); w[9] = be_word(nx2.y, nx2.x, sel);
+                w[10] = be_word(nx2.z, nx2.y, sel); w[11] = be_word(nx2.w, nx2.z, sel);
+                w[12] = be_word(nx3.x, nx2.w, sel); w[13] = be_word(nx3.y, nx3.x, sel);
+                w[14] = be_word(nx3.z, nx3.y, sel); w[15] = be_word(nx3.w, nx3.z, sel);
+                carry = nx3.w;
+              } else {
                 w[0] = __builtin_bswap32(nx0.x); w[1] = __builtin_bswap32(nx0.y);
                 w[2] = __builtin_bswap32(nx0.z); w[3] = __builtin_bswap32(nx0.w);
                 w[4] = __builtin_bswap32(nx1.x); w[5] = __builtin_bswap32(nx1.y);
@@ -224,14 +307,19 @@ void sha256_items_kernel(const u8* __restrict__ base, const u64* __restrict__ of
                 w[10] = __builtin_bswap32(nx2.z); w[11] = __builtin_bswap32(nx2.w);
                 w[12] = __builtin_bswap32(nx3.x); w[13] = __builtin_bswap32(nx3.y);
                 w[14] = __builtin_bswap32(nx3.z); w[15] = __builtin_bswap32(nx3.w);
+              }
                 if (rem >= 64) {
                     ptr += 64;
                     rem -= 64;
                     if (rem) {                         // in flight during this block's 64 rounds
-                        nx0 = *(const u32x4_unaligned*)(ptr);
-                        nx1 = *(const u32x4_unaligned*)(ptr + 16);
-                        nx2 = *(const u32x4_unaligned*)(ptr + 32);
-                        nx3 = *(const u32x4_unaligned*)(ptr + 48);
+                        if constexpr (kCoop) {
+                            want = true;
+                        } else {
+                            nx0 = *(const u32x4_unaligned*)(ptr);
+                            nx1 = *(const u32x4_unaligned*)(ptr + 16);
+                            nx2 = *(const u32x4_unaligned*)(ptr + 32);
+                            nx3 = *(const u32x4_unaligned*)(ptr + 48);
+                        }
                     }
                 } else {
                     mask_tail_block(w, (u32)rem);
@@ -251,6 +339,23 @@ void sha256_items_kernel(const u8* __restrict__ base, const u64* __restrict__ of
                 w[14] = (u32)(bits >> 32); w[15] = (u32)bits;
                 last = true;
             }
+        }
+        // kCoop.  The whole wave is here (no lane leaves the loop alone): every quad fetches the next blocks
+        // of its owners that want one, owner m's 64 bytes with ONE instruction.
+        if (kCoop && __ballot(want)) {
+            const u32 wf = want ? 1u : 0u;
+            const u32 plo = (u32)(size_t)ptr, phi = (u32)((size_t)ptr >> 32);
+            const u32 w0 = quad_bcast<0>(wf), w1 = quad_bcast<1>(wf), w2 = quad_bcast<2>(wf), w3 = quad_bcast<3>(wf);
+            const u32 l0 = quad_bcast<0>(plo), l1 = quad_bcast<1>(plo), l2 = quad_bcast<2>(plo), l3 = quad_bcast<3>(plo);
+            const u32 h0 = quad_bcast<0>(phi), h1 = quad_bcast<1>(phi), h2 = quad_bcast<2>(phi), h3 = quad_bcast<3>(phi);
+            const u64 mine = 16u * (u32)sub;                 // my 16-byte piece of every owner's block
+            if (w0) g0 = *(const u32x4_a4*)(size_t)((((u64)h0 << 32) | l0) + mine);
+            if (w1) g1 = *(const u32x4_a4*)(size_t)((((u64)h1 << 32) | l1) + mine);
+            if (w2) g2 = *(const u32x4_a4*)(size_t)((((u64)h2 << 32) | l2) + mine);
+            if (w3) g3 = *(const u32x4_a4*)(size_t)((((u64)h3 << 32) | l3) + mine);
+            loaded = want;
+        }
+        if (active) {
             sha256_compress(st, w);
             if (last) {
                 u32x4* o = (u32x4*)(out + 32ull * slot);
@@ -266,25 +371,50 @@ void sha256_items_kernel(const u8* __restrict__ base, const u64* __restrict__ of
     }
 }
 
+// footprint at or above which the chunk pass loads cooperatively (MI_SHA_COOP_MIN_GIB overrides: 0 =
+// always, a huge value = never)
+static u64 coop_min_bytes() {
+    static const u64 v = [] {
+        const char* e = getenv("MI_SHA_COOP_MIN_GIB");
+        const double gib = e ? atof(e) : 9.0;
+        return (u64)(gib * 1073741824.0);
+    }();
+    return v;
+}
+// ... and with the TLB out of the way a third workgroup per CU pays (161 VGPRs: three waves per SIMD
+// fit): 26 GB arena 1.43 (byte loads, 2/CU) -> 1.57 (cooperative, 2/CU) -> 1.63 TB/s (cooperative, 3/CU);
+// on 6.5 GB three are slower with either scheme (coarser tail).  MI_SHA_COOP_BLOCKS_PER_CU overrides.
+static int coop_blocks_per_cu(u64 footprint_bytes, int blocks_per_cu) {
+    static const int forced = [] {
+        const char* e = getenv("MI_SHA_COOP_BLOCKS_PER_CU");
+        const int n = e ? atoi(e) : 0;
+        return n >= 1 && n <= 3 ? n : 0;
+    }();
+    if (forced) return forced;
+    return footprint_bytes >= (24ull << 30) ? 3 : blocks_per_cu;    // enough work per lane for a third
+}
+
 void launch_sha256_items(ShaPass pass, const u8* d_base, const u64* d_off, const u64* d_len,
                          const u32* d_order, u32 n, const u64* d_n, u32* d_heads, bool zero_heads,
-                         u8* d_out, int blocks_per_cu, int n_cu, hipStream_t s) {
+                         u8* d_out, int blocks_per_cu, int n_cu, u64 footprint_bytes, hipStream_t s) {
     if (n == 0) return;
     if (zero_heads) (void)hipMemsetAsync(d_heads, 0, sizeof(u32) * kShaQueues, s);
+    const bool coop = pass != kShaRoots && footprint_bytes >= coop_min_bytes();
+    if (coop) blocks_per_cu = coop_blocks_per_cu(footprint_bytes, blocks_per_cu);
     u64 want = ((u64)n + kShaWG - 1) / kShaWG;
     u64 cap = (u64)blocks_per_cu * (u64)n_cu;
     u32 grid = (u32)(want < cap ? want : cap);
     // keep the grid a multiple of the queue count so every queue has the same number of pullers
     if (grid >= (u32)kShaQueues) grid -= grid % kShaQueues;
     if (grid == 0) grid = 1;
-#define MI_SHA_LAUNCH(P)                                                                      \
-    hipLaunchKernelGGL(sha256_items_kernel<P>, dim3(grid), dim3(kShaWG), 0, s, d_base, d_off,   \
+#define MI_SHA_LAUNCH(P, C)                                                                   \
+    hipLaunchKernelGGL((sha256_items_kernel<P, C>), dim3(grid), dim3(kShaWG), 0, s, d_base, d_off, \
                        d_len, d_order, n, d_n, d_heads, d_out)
     switch (pass) {
-        case kShaChunks: MI_SHA_LAUNCH(kShaChunks); break;
-        case kShaRoots:  MI_SHA_LAUNCH(kShaRoots); break;
-        case kShaFiles:  MI_SHA_LAUNCH(kShaFiles); break;
-        default:         MI_SHA_LAUNCH(kShaBlobs); break;
+        case kShaChunks: if (coop) MI_SHA_LAUNCH(kShaChunks, true); else MI_SHA_LAUNCH(kShaChunks, false); break;
+        case kShaRoots:  MI_SHA_LAUNCH(kShaRoots, false); break;
+        case kShaFiles:  if (coop) MI_SHA_LAUNCH(kShaFiles, true); else MI_SHA_LAUNCH(kShaFiles, false); break;
+        default:         if (coop) MI_SHA_LAUNCH(kShaBlobs, true); else MI_SHA_LAUNCH(kShaBlobs, false); break;
     }
 #undef MI_SHA_LAUNCH
 }
