@@ -9,7 +9,7 @@ bash tools/round_profiles.sh r02 > gpurun_out/r2j/round.log 2>&1
 tail -30 gpurun_out/r2j/round.log
 python - <<'PY'
 import json
-for n in ('n1','c3','c5','c2_native_exchange'):
+for n in ('n1','c3','c5','c2_native_exchange','c4_one_shard'):
     try:
         txt=[l for l in open('gpurun_out/round/r02_bench_%s.json'%n) if l.startswith('{')][-1]
         j=json.loads(txt)
@@ -17,4 +17,4 @@ for n in ('n1','c3','c5','c2_native_exchange'):
     except Exception as e:
         print(n, 'failed', e)
 PY
-cat gpurun_out/round/traffic_latest.json; cat gpurun_out/round/r02_large_files.txt
+cat gpurun_out/round/traffic_latest.json; cat gpurun_out/round/r02_large_files.txt; cat gpurun_out/round/r02_sha_schemes_32gb.txt

@@ -25,7 +25,7 @@ def main():
     fetch = counters("%s/%s_fetch.txt" % (d, tag), "FETCH_SIZE")
     write = counters("%s/%s_write.txt" % (d, tag), "WRITE_SIZE")
     bench = json.load(open("%s/%s_bench_n1.json" % (d, tag)))
-    sha = "void mi::sha256_items_kernel<0>"
+    sha = "void mi::sha256_items_kernel<0, false>"   # C2: lane-owned loads (arena below the cooperative switch)
     gear = "mi::gear_cdc_small_kernel"
     synth_kib = write.get("mi::synth_fill_kernel", (0, 0.0))[1]
     bytes_in = bench["config"]["bytes_per_gpu"]
@@ -35,7 +35,7 @@ def main():
         "source": "profiles/%s_pmc_fetch_size.txt + %s_pmc_write_size.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                   "--kernel-trace -- python bench.py --steps 3 --warmup 1 --inflight 1 --no-cpu-baseline), same "
                   "tools/round_profiles.sh run as the round's bench line" % (tag, tag),
-        "kernel": "mi::sha256_items_kernel<0> (chunk pass), C2 batch",
+        "kernel": "mi::sha256_items_kernel<0, false> (chunk pass), C2 batch",
         "FETCH_SIZE_KiB_raw": fetch[sha][1],
         "WRITE_SIZE_KiB_raw": write[sha][1],
         "correction": "gfx950: FETCH_SIZE tallies 128-B read requests at 64 B, so reads are doubled "
