@@ -187,3 +187,30 @@ def test_part_errors(tmp_path):
             b.fix_cuts()
             b.run()
             assert b.parts()[0]["entry_confirmed"] == 1
+
+
+def test_plain_c_parts(oracle, tmp_path):
+    """The parts interface from plain C (tests/cabi/parts_driver.c): the loop INTEGRATION.md gives
+    a Go host, fixing each part before the next one reads its exit -- so even data that never
+    re-synchronises settles in ONE sweep; the printed rows are the whole file's rows."""
+    import subprocess
+    import makisu_amd
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "parts_driver")
+    subprocess.check_call(["gcc", "-O1", "-Wall", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cabi", "parts_driver.c"), "-o", exe,
+                           "-L", os.path.join(root, "makisu_amd"), "-lmakisu_mi",
+                           "-Wl,-rpath," + os.path.join(root, "makisu_amd")])
+    cases = [(oracle.synth_fill(SEED, 4400, 0, 13 * G + 999).tobytes(), 5),
+             (bytes(3 * G) + oracle.synth_fill(SEED, 4401, 0, 2 * G + 1).tobytes() + b"\x01" * (4 * G), 4),
+             (oracle.synth_fill(SEED, 4402, 0, 70000).tobytes(), 3)]            # smaller than one group
+    with makisu_amd.Engine() as e:
+        for i, (data, n_parts) in enumerate(cases):
+            path = tmp_path / ("whole%d.bin" % i)
+            path.write_bytes(data)
+            out = subprocess.run([exe, str(path), str(n_parts)], check=True, capture_output=True, text=True)
+            rows = [l.split() for l in out.stdout.splitlines() if l.startswith("C ")]
+            ref = _whole(oracle, e, data)
+            assert [(int(r[1]), int(r[2]), r[3]) for r in rows] == \
+                [(int(c["offset"]), int(c["length"]), "sha256:" + c["sha256"].tobytes().hex()) for c in ref]
+            assert out.stdout.splitlines()[-1].startswith("R ")
