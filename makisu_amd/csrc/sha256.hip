@@ -165,6 +165,7 @@ void sha256_items_kernel(const u8* __restrict__ base, const u64* __restrict__ of
         // dequeue atomic, the nx prefetch) has had a whole compression to land.  Consume it
         // all HERE, before this iteration issues anything new, so no wait below can stall on
         // a freshly issued request (hipcc's s_waitcnt for a divergent region is vmcnt(0)).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // incl. the hand-issued dequeue atomic
         asm volatile("" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(nx0), "+v"(nx1),
                           "+v"(nx2), "+v"(nx3));
         asm volatile("" : "+v"(noff), "+v"(nlen), "+v"(nslot), "+v"(areq));
@@ -267,18 +268,37 @@ void sha256_items_kernel(const u8* __restrict__ base, const u64* __restrict__ of
         {
             const bool want = nstate == kNone && (!active || rem < 64ull * kLook);
             const u64 m = __ballot(want);
+            u64 leader_mask = 0;                           // wave-uniform: the lane that performs the atomic
             if (m) {
                 if (qtry >= kShaQueues) {
                     if (want) nstate = kDry;
                 } else {
                     req_q = (q0 + qtry) % kShaQueues;
                     req_leader = __ffsll((unsigned long long)m) - 1;
-                    if (lane == req_leader) areq = atomicAdd(&heads[req_q], (u32)__popcll(m));
+                    leader_mask = 1ull << req_leader;
                     if (want) {
                         req_rank = (u32)__popcll(m & ((1ull << lane) - 1ull));
                         nstate = kReq;
                     }
                 }
+            }
+            // The atomic itself, in straight-line code and by hand.  Written as
+            // `if (lane == leader) areq = atomicAdd(...)`, the merge of areq's two values behind the
+            // branch is a v_mov that needs the RESULT: hipcc put an s_waitcnt vmcnt(0) there -- a
+            // memory round trip, and a wait for every load this iteration had issued, in each
+            // iteration that dequeues.  EXEC is the leader lane alone (or empty: no request); the
+            // compiler does not know this load, the wait for it is the explicit one at the loop top.
+            {
+                u64 saved;
+                const u32 cnt = (u32)__popcll(m);
+                const u32* head = heads + req_q;
+                asm volatile("s_mov_b64 %[sv], exec\n\t"
+                             "s_mov_b64 exec, %[mk]\n\t"
+                             "global_atomic_add %[ret], %[hd], %[val], off sc0\n\t"
+                             "s_mov_b64 exec, %[sv]"
+                             : [ret] "+v"(areq), [sv] "=&s"(saved)
+                             : [mk] "s"(leader_mask), [val] "v"(cnt), [hd] "v"(head)
+                             : "memory");
             }
         }
         if (!__ballot(active || nstate != kDry)) break;
