@@ -214,3 +214,28 @@ def test_plain_c_parts(oracle, tmp_path):
             assert [(int(r[1]), int(r[2]), r[3]) for r in rows] == \
                 [(int(c["offset"]), int(c["length"]), "sha256:" + c["sha256"].tobytes().hex()) for c in ref]
             assert out.stdout.splitlines()[-1].startswith("R ")
+
+
+def test_scan_cuts_on_a_batch_without_parts(oracle):
+    """mi_batch_scan_cuts is not reserved for parts: the cuts it makes are the ones the following
+    submit uses (no second Gear pass), and a later rerun makes them again -- same rows every time."""
+    import makisu_amd
+    blobs = [oracle.synth_fill(SEED, 4500 + i, 0, n).tobytes() for i, n in enumerate([100, 70000, 5 * G + 3, 0, 2 * G])]
+    with makisu_amd.Engine() as e:
+        with e.batch() as b:
+            for blob in blobs:
+                b.add_bytes(blob)
+            b.scan_cuts()
+            assert b.parts() == []
+            b.fix_cuts()                                   # nothing to do
+            b.run()
+            first = b.chunks().copy()
+            b.rerun()
+            again = b.chunks().copy()
+        for blob, f in zip(blobs, range(len(blobs))):
+            ref = _whole(oracle, e, blob) if len(blob) else []
+            mine = first[first["file_index"] == f]
+            assert len(mine) == len(ref)
+            if len(ref):
+                assert np.array_equal(mine["offset"], ref["offset"]) and np.array_equal(mine["sha256"], ref["sha256"])
+        assert np.array_equal(first["sha256"], again["sha256"]) and np.array_equal(first["offset"], again["offset"])
