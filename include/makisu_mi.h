@@ -52,6 +52,10 @@ enum {
                                      per-file term of checksumPathContents
                                      (lib/builder/step/add_copy_step.go:194-238)     */
 #define MI_FLAG_NO_DEDUP    0x4u  /* skip in-batch duplicate marking                 */
+#define MI_FLAG_PREFETCH_ROWS 0x8u /* mi_batch_wait also brings the result rows to the host
+                                      (one packed copy, ~1 ms per 700 k chunks, while the
+                                      other batch in flight keeps the GPU busy): the
+                                      following mi_batch_chunks_view costs nothing      */
 
 typedef struct mi_ctx mi_ctx;
 typedef struct mi_batch mi_batch;
@@ -174,6 +178,10 @@ int mi_batch_wait(mi_batch* b);
 int mi_batch_counts(mi_batch* b, uint64_t* n_files, uint64_t* n_chunks, uint64_t* n_bytes);
 int mi_batch_files(mi_batch* b, mi_file_result* out, uint64_t cap);
 int mi_batch_chunks(mi_batch* b, mi_chunk_result* out, uint64_t cap);
+/* The same rows without the copy into caller memory: *rows points at the batch's own pinned host
+ * buffer (packed on the device, one device-to-host copy), valid until the batch is submitted
+ * again, marked globally, reset or freed.  What a cgo shim reads through unsafe.Slice.          */
+int mi_batch_chunks_view(mi_batch* b, const mi_chunk_result** rows, uint64_t* n_chunks);
 /* Device pointer to the batch's n_chunks x 32-byte digest array (valid until
  * mi_batch_free); what a rank contributes to the all-gather.        */
 int mi_batch_device_digests(mi_batch* b, const void** d_digests, uint64_t* n_chunks);

@@ -15,11 +15,12 @@ import numpy as np
 from . import build as _build
 
 __all__ = ["Engine", "Batch", "Config", "MiError", "load_library", "FILE_DTYPE", "CHUNK_DTYPE",
-           "FLAG_FILE_SHA256", "FLAG_FILE_CRC32", "FLAG_NO_DEDUP", "Digest", "digest_hex"]
+           "FLAG_FILE_SHA256", "FLAG_FILE_CRC32", "FLAG_NO_DEDUP", "FLAG_PREFETCH_ROWS", "Digest", "digest_hex"]
 
 FLAG_FILE_SHA256 = 0x1
 FLAG_FILE_CRC32 = 0x2
 FLAG_NO_DEDUP = 0x4
+FLAG_PREFETCH_ROWS = 0x8
 
 ERR_NAMES = {0: "MI_OK", -1: "MI_ERR_INVALID", -2: "MI_ERR_NO_DEVICE", -3: "MI_ERR_HIP",
              -4: "MI_ERR_NOMEM", -5: "MI_ERR_IO", -6: "MI_ERR_STATE", -7: "MI_ERR_CAPACITY"}
@@ -174,6 +175,7 @@ def load_library(rebuild=False):
         "mi_batch_counts": ([vp, u64p, u64p, u64p], C.c_int),
         "mi_batch_files": ([vp, vp, u64], C.c_int),
         "mi_batch_chunks": ([vp, vp, u64], C.c_int),
+        "mi_batch_chunks_view": ([vp, C.POINTER(vp), u64p], C.c_int),
         "mi_batch_device_digests": ([vp, C.POINTER(vp), u64p], C.c_int),
         "mi_batch_read_back": ([vp, vp, u64], C.c_int),
         "mi_batch_reset": ([vp], C.c_int),
@@ -834,6 +836,16 @@ class Batch:
         out = np.zeros(max(n, 1), dtype=CHUNK_DTYPE)
         self._check(self._lib.mi_batch_chunks(self._h, out.ctypes.data, n))
         return out[:n]
+
+    def chunks_view(self):
+        """The chunk rows WITHOUT a copy: a numpy array over the batch's own pinned buffer, valid
+        until the batch is submitted again, marked globally, reset or freed."""
+        p, n = C.c_void_p(), C.c_uint64()
+        self._check(self._lib.mi_batch_chunks_view(self._h, C.byref(p), C.byref(n)))
+        if n.value == 0:
+            return np.zeros(0, dtype=CHUNK_DTYPE)
+        buf = (C.c_char * (n.value * CHUNK_DTYPE.itemsize)).from_address(p.value)
+        return np.frombuffer(buf, dtype=CHUNK_DTYPE)
 
     def device_digests(self):
         p, n = C.c_void_p(), C.c_uint64()

@@ -441,6 +441,8 @@ int submit_pipeline(mi_batch* b) {
     return MI_OK;
 }
 
+int fetch_results(mi_batch* b);
+
 int wait_pipeline(mi_batch* b) {
     mi_ctx* c = b->ctx;
     if (!b->in_flight) return fail(c, MI_ERR_STATE, "mi_batch_wait without a submitted run");
@@ -464,6 +466,7 @@ int wait_pipeline(mi_batch* b) {
     }
     c->stats = b->stats;
     b->ran = true;
+    if (c->cfg.flags & MI_FLAG_PREFETCH_ROWS) return fetch_results(b);
     return MI_OK;
 }
 
@@ -473,7 +476,6 @@ int fetch_results(mi_batch* b) {
     if (b->results_valid) return MI_OK;
     const u64 nf = b->files.size(), nc = b->n_chunks;
     b->h_files.assign(nf, mi_file_result{});
-    b->h_chunks.assign(nc, mi_chunk_result{});
     if (nf) {
         std::vector<u32> ncs(nf);
         std::vector<u64> first(nf);
@@ -508,25 +510,31 @@ int fetch_results(mi_batch* b) {
         }
     }
     if (nc) {
-        std::vector<u64> start(nc), len(nc);
-        std::vector<u32> file(nc);
-        std::vector<i64> dup(nc);
-        std::vector<u8> dg(nc * 32);
-        HIPCHK(c, hipMemcpy(start.data(), b->chunk_start.p, nc * 8, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(len.data(), b->chunk_len.p, nc * 8, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(file.data(), b->chunk_file.p, nc * 4, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(dup.data(), b->dup_of.p, nc * 8, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(dg.data(), b->digests.p, nc * 32, hipMemcpyDeviceToHost));
-        for (u64 i = 0; i < nc; ++i) {
-            mi_chunk_result& r = b->h_chunks[i];
-            r.file_index = file[i];
-            r.offset = start[i];
-            const int part = b->files[file[i]].part;     // parts report offsets inside the whole file
-            if (part >= 0) r.offset += b->parts[part].begin - b->parts[part].halo_bytes;
-            r.length = (u32)len[i];
-            r.dup_of = dup[i];
-            memcpy(r.sha256, &dg[i * 32], 32);
+        // rows are packed by a kernel; ONE device-to-host copy into the batch's pinned buffer
+        static_assert(sizeof(mi_chunk_result) == 64, "pack_chunk_rows_kernel writes 64-byte rows");
+        const size_t bytes = nc * sizeof(mi_chunk_result);
+        HIPCHK(c, b->rows_d.ensure(bytes));
+        if (bytes > b->rows_h_bytes) {
+            if (b->rows_h) (void)hipHostFree(b->rows_h);
+            b->rows_h = nullptr;
+            b->rows_h_bytes = 0;
+            const size_t want = bytes + bytes / 8;
+            HIPCHK(c, hipHostMalloc(&b->rows_h, want, hipHostMallocDefault));
+            b->rows_h_bytes = want;
         }
+        const u64* d_base = nullptr;
+        if (!b->parts.empty()) {                         // parts report offsets inside the whole file
+            std::vector<u64> base(nf, 0);
+            for (const PartRec& p : b->parts) base[p.file_index] = p.begin - p.halo_bytes;
+            HIPCHK(c, b->file_base.ensure(nf * 8));
+            HIPCHK(c, hipMemcpy(b->file_base.p, base.data(), nf * 8, hipMemcpyHostToDevice));
+            d_base = b->file_base.as<u64>();
+        }
+        launch_pack_chunk_rows(nc, b->chunk_file.as<u32>(), b->chunk_start.as<u64>(), b->chunk_len.as<u64>(),
+                               b->dup_of.as<i64>(), b->digests.as<u8>(), d_base, b->rows_d.p, b->stream);
+        HIPCHK(c, hipMemcpyAsync(b->rows_h, b->rows_d.p, bytes, hipMemcpyDeviceToHost, b->stream));
+        HIPCHK(c, hipStreamSynchronize(b->stream));
+        HIPCHK(c, hipGetLastError());
     }
     b->results_valid = true;
     return MI_OK;
@@ -1105,7 +1113,6 @@ int mi_batch_reset(mi_batch* b) {
     b->staged = b->ran = b->results_valid = false;
     b->n_chunks = b->total_slots = 0;
     b->h_files.clear();
-    b->h_chunks.clear();
     memset(&b->stats, 0, sizeof b->stats);
     return MI_OK;
 }
@@ -1135,11 +1142,20 @@ int mi_batch_chunks(mi_batch* b, mi_chunk_result* out, uint64_t cap) {
     HIPCHK(b->ctx, hipSetDevice(b->ctx->device));
     int rc = fetch_results(b);
     if (rc) return rc;
-    if (cap < b->h_chunks.size())
-        return fail(b->ctx, MI_ERR_CAPACITY, "chunk result buffer holds %llu rows, need %zu",
-                    (unsigned long long)cap, b->h_chunks.size());
-    if (!b->h_chunks.empty())
-        memcpy(out, b->h_chunks.data(), b->h_chunks.size() * sizeof(mi_chunk_result));
+    if (cap < b->n_chunks)
+        return fail(b->ctx, MI_ERR_CAPACITY, "chunk result buffer holds %llu rows, need %llu",
+                    (unsigned long long)cap, (unsigned long long)b->n_chunks);
+    if (b->n_chunks) memcpy(out, b->rows_h, b->n_chunks * sizeof(mi_chunk_result));
+    return MI_OK;
+}
+
+int mi_batch_chunks_view(mi_batch* b, const mi_chunk_result** rows, uint64_t* n_chunks) {
+    if (!b || !rows) return MI_ERR_INVALID;
+    HIPCHK(b->ctx, hipSetDevice(b->ctx->device));
+    int rc = fetch_results(b);
+    if (rc) return rc;
+    *rows = b->n_chunks ? (const mi_chunk_result*)b->rows_h : nullptr;
+    if (n_chunks) *n_chunks = b->n_chunks;
     return MI_OK;
 }
 
@@ -1192,6 +1208,7 @@ int mi_batch_free(mi_batch* b) {
     if (b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
     for (auto e : b->ev) if (e) (void)hipEventDestroy(e);
     if (b->h_counts) (void)hipHostFree(b->h_counts);
+    if (b->rows_h) (void)hipHostFree(b->rows_h);
     DevBuf* bufs[] = {&b->root_addr, &b->root_cnt, &b->rseg_cnt, &b->rseg_first, &b->rseg_total,
                       &b->root_items_off, &b->root_items_len, &b->root_level[0], &b->root_level[1],
                       &b->root_level[2], &b->root_level[3], &b->root_level[4], &b->root_addr2, &b->root_cnt2,
@@ -1202,7 +1219,7 @@ int mi_batch_free(mi_batch* b) {
                       &b->n_chunks_d, &b->first, &b->scratch,
                       &b->chunk_off, &b->chunk_len, &b->chunk_file, &b->chunk_start, &b->digests, &b->item_off, &b->item_len, &b->roots,
                       &b->file_sha, &b->dup_of, &b->file_flags, &b->part_file, &b->part_group0, &b->part_halo,
-                      &b->part_entry};
+                      &b->part_entry, &b->rows_d, &b->file_base};
     for (DevBuf* d : bufs) d->release();
     delete b;
     return MI_OK;

@@ -125,6 +125,11 @@ void launch_compact_chunks(const u64* d_file_off, const u64* d_file_seg0, const 
                            u64* d_chunk_len, u32* d_chunk_file, u64* d_chunk_start, u64* d_first,
                            u32* d_n_chunks, u32* d_hist, u32 n_bins, u32 bin_shift, const u8* d_digests,
                            u64* d_item_off, u64* d_item_len, hipStream_t s);
+// the chunk table as mi_chunk_result rows (64 B each: file, offset (+ d_file_base[file] when given),
+// length, dup_of, digest)
+void launch_pack_chunk_rows(u64 n, const u32* d_chunk_file, const u64* d_chunk_start, const u64* d_chunk_len,
+                            const i64* d_dup_of, const u8* d_digests, const u64* d_file_base, void* d_rows,
+                            hipStream_t s);
 // d_hist (compaction) and d_cursor (binning) must be zero on entry; d_item_off/len (optional): the
 // root pass's item list when no file needs a reduction pass
 // queue descriptors in processing order (longest first): s_off/s_len/s_id[pos]

@@ -128,7 +128,9 @@ struct mi_batch {
     void* tree = nullptr;                // host-side walk record (mi_tree.hip)
     mi::DevBuf dd_table, dd_slot;
     std::vector<mi_file_result> h_files;
-    std::vector<mi_chunk_result> h_chunks;
+    mi::DevBuf rows_d, file_base;        // chunk rows packed on the device; per-file offset base (parts)
+    void* rows_h = nullptr;              // ... and in pinned host memory (what mi_batch_chunks_view hands out)
+    size_t rows_h_bytes = 0;
 };
 
 

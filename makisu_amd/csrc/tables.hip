@@ -266,6 +266,36 @@ void file_rows_kernel(const u64* __restrict__ file_seg0, const u64* __restrict__
     }
 }
 
+// ---- result rows: the chunk table as the ABI's mi_chunk_result rows (64 B each), packed on the
+// device so that the host needs ONE copy instead of five column copies and a repacking loop
+__global__ __launch_bounds__(256)
+void pack_chunk_rows_kernel(u64 n, const u32* __restrict__ chunk_file, const u64* __restrict__ chunk_start,
+                            const u64* __restrict__ chunk_len, const i64* __restrict__ dup_of,
+                            const u8* __restrict__ digests, const u64* __restrict__ file_base,
+                            u32x4* __restrict__ rows) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u32 f = chunk_file[i];
+    const u64 off = chunk_start[i] + (file_base ? file_base[f] : 0ull);
+    const i64 dup = dup_of[i];
+    const u32x4* dg = (const u32x4*)(digests + 32 * i);
+    u32x4 q0, q1;
+    q0.x = f; q0.y = 0; q0.z = (u32)off; q0.w = (u32)(off >> 32);
+    q1.x = (u32)chunk_len[i]; q1.y = 0; q1.z = (u32)(u64)dup; q1.w = (u32)((u64)dup >> 32);
+    rows[4 * i] = q0;
+    rows[4 * i + 1] = q1;
+    rows[4 * i + 2] = dg[0];
+    rows[4 * i + 3] = dg[1];
+}
+
+void launch_pack_chunk_rows(u64 n, const u32* d_chunk_file, const u64* d_chunk_start, const u64* d_chunk_len,
+                            const i64* d_dup_of, const u8* d_digests, const u64* d_file_base, void* d_rows,
+                            hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(pack_chunk_rows_kernel, dim3((u32)((n + 255) / 256)), dim3(256), 0, s, n, d_chunk_file,
+                       d_chunk_start, d_chunk_len, d_dup_of, d_digests, d_file_base, (u32x4*)d_rows);
+}
+
 void launch_compact_chunks(const u64* d_file_off, const u64* d_file_seg0, const u32* d_seg_file,
                            const u64* d_seg_slot, const u32* d_ends32, const u64* d_seg_first,
                            const u32* d_seg_group, const void* d_group_recs, u32 region,

@@ -919,3 +919,28 @@ def test_dedup_mark_range_equals_full_marking(oracle, eng):
     dup = torch.empty(len(rows), dtype=torch.int64, device=dev)
     assert eng.dedup_mark_range(glob.data_ptr(), len(rows), 0, len(rows), dup.data_ptr()) == n_unique
     assert np.array_equal(dup.cpu().numpy(), want)
+
+
+def test_chunk_rows_view_and_prefetch(oracle):
+    """mi_batch_chunks_view (rows packed on the device, one copy into the batch's pinned buffer) gives
+    the rows mi_batch_chunks copies out; with MI_FLAG_PREFETCH_ROWS they arrive with mi_batch_wait;
+    a global marking afterwards is visible in the next view."""
+    import makisu_amd
+    sizes = [0, 5, 70000, 3 * 262144 + 9, 2048, 65536] * 5
+    with makisu_amd.Engine(flags=makisu_amd.FLAG_PREFETCH_ROWS) as e:
+        with e.batch() as b:
+            b.add_synthetic(sizes, list(range(600, 600 + len(sizes) // 2)) * 2, seed=SEED)   # second half repeats
+            b.run()
+            rows = b.chunks()
+            view = b.chunks_view()
+            assert view.dtype == rows.dtype and len(view) == len(rows) == b.counts()[1]
+            assert view.tobytes() == rows.tobytes()
+            blobs = [oracle.synth_fill(SEED, 600 + i % (len(sizes) // 2), 0, n) for i, n in enumerate(sizes)]
+            data = np.concatenate(blobs)
+            offs = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+            _, rc = oracle.scan_batch(data, offs, sizes, oracle.CdcParams(SEED, 13, 2048, 65536))
+            for k in ("file_index", "offset", "length", "dup_of", "sha256"):
+                assert np.array_equal(view[k], rc[k]), k
+            assert (view["dup_of"] >= 0).sum() > 0
+            b.rerun()
+            assert b.chunks_view().tobytes() == rows.tobytes()
