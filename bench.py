@@ -435,9 +435,9 @@ def main():
                    "batches_in_flight": args.inflight, "launches_per_step": launches_per_step,
                    "exchange": (args.exchange if exchange else None),
                    "device": info["name"].strip(), "n_cu": info["n_cu"],
-                   "results": "left on the device (16 B of counts read back per batch); mi_batch_files/"
-                              "mi_batch_chunks copy ~62 B per chunk + 104 B per file to the host on demand, "
-                              "outside this metric"},
+                   "results": "left on the device (16 B of counts read back per batch); mi_batch_chunks_view / "
+                              "mi_batch_files bring 64 B per chunk + 96 B per file to the host on demand "
+                              "(one packed copy, ~1.6 ms per C2 batch), outside this metric"},
         "roofline": {"bound": "hbm", "kernel": "sha256_items_kernel (chunk pass)",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
