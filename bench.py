@@ -369,11 +369,12 @@ def main():
     serial_sha_ms, serial_phase = [], {}
     if args.inflight > 1:
         torch.cuda.synchronize(device)
-        for _ in range(5):                                   # median of 5: one slow launch (clock ramp after
-            batches[0].submit()                              # the host-side pause) must not be the number
+        for i in range(9):                                   # 2 untimed (the clock ramps up again after the
+            batches[0].submit()                              # host-side pause) + the median of 7
             batches[0].wait()
             st = eng.stats()
-            serial_sha_ms.append(st["ms_sha_chunks"])
+            if i >= 2:
+                serial_sha_ms.append(st["ms_sha_chunks"])
         serial_phase = {k: round(v, 4) for k, v in st.items() if k.startswith("ms_")}
         serial_alg = st["bytes_in"] + 52 * st["n_chunks"]
 
@@ -451,7 +452,7 @@ def main():
                              "hashed, tools/ubench_sha.hip); the HBM fraction cannot exceed 0.22. "
                              "achieved/avg_launch_ms are from the timed region, where the kernel "
                              "shares the GPU with the other in-flight batches' passes; "
-                             "serial_* = the same kernel with one batch at a time (median of 5 extra "
+                             "serial_* = the same kernel with one batch at a time (median of 7 extra "
                              "untimed steps); path_frac = whole CDC+SHA step per GPU, algorithmic "
                              "bytes / ms_per_step / peak"},
         "phase_ms_avg": {k: round(v / max(1, len(sha_ms)), 4) for k, v in sorted(stats_sum.items())},
