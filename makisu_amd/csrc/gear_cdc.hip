@@ -59,6 +59,10 @@ constexpr int kLdsFastOff  = kLdsListOff + kWavesPerWG * 64 * 4;
 constexpr int kGearLdsBytes = kLdsFastOff + 16;
 constexpr u32 kNoCand = 0xFFFFFFFFu;
 
+// value of `v` in lane `src` for a WAVE-UNIFORM src: v_readlane_b32 (a few cycles) instead of the
+// ds_bpermute round trip __shfl costs -- cut selection is one dependent chain of these
+__device__ __forceinline__ u32 lane_value(u32 v, int src) { return (u32)__builtin_amdgcn_readlane((int)v, src); }
+
 // ---- fast path for cut selection: a tile's candidates as ONE sorted 64-entry list ----------
 // While marking, a lane also packs up to three candidates of its run into one VGPR (10-bit
 // run offsets, count in bits 30..31).  If no lane overflowed and the tile has <= 64
@@ -100,7 +104,7 @@ __device__ __forceinline__ int bitmap_find_first(const u64* bm, int lo, int hi, 
         const u64 bal = __ballot(v != 0);
         if (bal) {
             const int src = __ffsll((unsigned long long)bal) - 1;
-            const u32 vlo = __shfl((u32)v, src), vhi = __shfl((u32)(v >> 32), src);
+            const u32 vlo = lane_value((u32)v, src), vhi = lane_value((u32)(v >> 32), src);
             const u64 vv = ((u64)vhi << 32) | vlo;
             return (w0 + src) * 64 + (__ffsll((unsigned long long)vv) - 1);
         }
@@ -220,7 +224,7 @@ __device__ __forceinline__ bool select_tile(const u32* bitmap, const u32* list, 
             if (list) {
                 const u32 lo_rel = (u32)(lo - ts - 1), hi_rel = (u32)(hi - ts - 1);
                 const u64 bal = __ballot(cand >= lo_rel && cand <= hi_rel);
-                b = bal ? (int)__shfl(cand, __ffsll((unsigned long long)bal) - 1) : -1;
+                b = bal ? (int)lane_value(cand, __ffsll((unsigned long long)bal) - 1) : -1;
             } else {
                 b = bitmap_find_first((const u64*)bitmap, (int)(lo - ts - 1), (int)(hi - ts - 1), lane);
             }
@@ -254,7 +258,7 @@ __device__ __forceinline__ bool list_from_bitmap(const u32* bitmap, int lane, u3
         const u32 y = __shfl_up(incl, d);
         if (lane >= d) incl += y;
     }
-    const u32 total = __shfl(incl, 63);
+    const u32 total = lane_value(incl, 63);
     if (total > 64u) return false;
     list[lane] = kNoCand;
     u32 pos = incl - cnt;
@@ -362,7 +366,7 @@ __device__ __forceinline__ u64 reselect_group(const u32* lists, const u32* bitma
             const u64 bal = __ballot(sreg >= rel);
             if (bal) {
                 const int i = __ffsll((unsigned long long)bal) - 1;
-                if (__shfl(sreg, i) == rel && sbase + (u32)i < spec_n) { sidx = sbase + (u32)i; synced = true; }
+                if (lane_value(sreg, i) == rel && sbase + (u32)i < spec_n) { sidx = sbase + (u32)i; synced = true; }
                 break;
             }
             if (sbase + 64u >= spec_n) break;
@@ -551,14 +555,14 @@ void gear_file_fix_kernel(const u8* __restrict__ data, const u64* __restrict__ f
                 const u64 bal = __ballot(bad);
                 if (!bal) {                                   // 64 good groups: their exits are true
                     const u32 n = ng - gi < 64u ? ng - gi : 64u;
-                    const u32 lo = __shfl((u32)ex, (int)n - 1), hi = __shfl((u32)(ex >> 32), (int)n - 1);
+                    const u32 lo = lane_value((u32)ex, (int)n - 1), hi = lane_value((u32)(ex >> 32), (int)n - 1);
                     prev_exit = ((u64)hi << 32) | lo;
                     gi += n;
                     continue;
                 }
                 const int j = __ffsll((unsigned long long)bal) - 1;
                 if (j > 0) {                                  // groups before j are good
-                    const u32 lo = __shfl((u32)ex, j - 1), hi = __shfl((u32)(ex >> 32), j - 1);
+                    const u32 lo = lane_value((u32)ex, j - 1), hi = lane_value((u32)(ex >> 32), j - 1);
                     prev_exit = ((u64)hi << 32) | lo;
                 }
                 gi += (u32)j;
