@@ -328,10 +328,13 @@ void gear_cdc_small_kernel(const u8* __restrict__ data, const u64* __restrict__ 
 // file_seg0[f] + gi.  Cut selection is a sequential recurrence over the file (the next cut depends
 // on the previous one), but it forgets its start quickly: from ANY previous cut the chosen sequence
 // joins the true one as soon as both pick the same candidate, and then stays on it.  So:
-//   A  gear_group_mark_kernel (all groups in parallel): mark the four tiles, keep every tile's
-//      sorted candidate list (<= 64 entries, u32) in HBM, and select SPECULATIVELY as if a cut
-//      fell on the group's first byte -> spec list (u32, relative to the group start), spec exit
+//   A1 gear_tile_mark_kernel (one wave per tile, all tiles in parallel, no workgroup barrier): mark,
+//      keep the tile's sorted candidate list (<= 64 entries, u32) in HBM.
+//   A2 gear_group_spec_kernel (one wave per group): select SPECULATIVELY from the four lists as if a
+//      cut fell on the group's first byte -> spec list (u32, relative to the group start), spec exit
 //      E_g = its last cut.  Group 0 of a file starts at a true cut: its spec list is final.
+//      (Until round 2's last change A1 + A2 were one kernel, a workgroup per group: three waves
+//      waited while wave 0 selected -- 15-20 % more wave-cycles for the same instructions.)
 //   B  gear_group_validate_kernel (all groups gi > 0 in parallel, one wave each): re-select from
 //      the ASSUMED entry E_{g-1} until a cut is also a spec cut of this group (index sidx): the
 //      group's cuts are then prefix[0, pcnt) ++ spec[sidx, spec_n) and its exit is E_g again.  If it
@@ -342,8 +345,9 @@ void gear_cdc_small_kernel(const u8* __restrict__ data, const u64* __restrict__ 
 //      usually re-synchronises inside that same group.  Data that never re-synchronises (e.g.
 //      forced cuts only, with max_size not dividing the group size) degenerates to one sequential
 //      re-selection per group -- correct, as slow as a serial chunker.
-// DENSE tile: more than 64 candidates (mask_bits far below the default): no list; B skips such
-// groups and C re-marks their tiles to get the bitmaps back.
+// DENSE tile: more than 64 candidates (mask_bits far below the default): no list, its group gets no
+// speculation; B skips such groups and their successors, C re-marks the tiles to get the bitmaps back
+// and selects from the true entry (a file of dense groups is cut at the pace of a serial chunker).
 // Result per group: GroupRec + two u32 regions of R = kGroupBytes / min_size + 2 entries at
 // ends32[seg_slot[s]]: [0, R) spec list, [R, 2R) prefix.
 
@@ -400,83 +404,103 @@ __device__ __forceinline__ u64 reselect_group(const u32* lists, const u32* bitma
     return exit;                                               // wave-uniform
 }
 
-#ifndef MI_GEAR_MARK_BOUND
-#define MI_GEAR_MARK_BOUND 3
-#endif
-__global__ __launch_bounds__(kGearWG, MI_GEAR_MARK_BOUND)       // 3 workgroups per CU: <= 168 VGPRs
-void gear_group_mark_kernel(const u8* __restrict__ data, const u64* __restrict__ file_off,
-                            const u64* __restrict__ file_size, const u64* __restrict__ file_seg0,
-                            const u64* __restrict__ seg_slot, u32* __restrict__ ends32,
-                            u32* __restrict__ seg_n, const u32* __restrict__ group_file,
-                            const u32* __restrict__ group_index, u32 n_groups,
-                            GroupRec* __restrict__ recs, u32* __restrict__ tile_lists,
-                            const u32* __restrict__ file_flags,
-                            const u64* __restrict__ gear_table, CdcParams p) {
+// A1: one wave per TILE of every large file -- the small-file kernel's marking without its selection: a
+// workgroup per group (four tiles), no workgroup barrier behind the table load, no loop (a persistent
+// form needs 168+ VGPRs where this one, like the small-file kernel, takes 146: three workgroups per CU).  Per tile: the sorted candidate list (64 x u32, HBM) and
+// tile_fast = 1, or tile_fast = 0 for a DENSE tile (more than 64 candidates: no list).
+__global__ __launch_bounds__(kGearWG)
+void gear_tile_mark_kernel(const u8* __restrict__ data, const u64* __restrict__ file_off,
+                           const u64* __restrict__ file_size, const u32* __restrict__ group_file,
+                           const u32* __restrict__ group_index, u32 n_groups,
+                           u32* __restrict__ tile_lists, u32* __restrict__ tile_fast,
+                           const u64* __restrict__ gear_table, CdcParams p) {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     u64* table = (u64*)smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    u32* bitmaps = (u32*)(smem + kTableBytes);
-    u32* cand_lists = (u32*)(smem + kLdsListOff);
-    volatile u32* fast_flags = (volatile u32*)(smem + kLdsFastOff);
+    u32* bm = (u32*)(smem + kTableBytes) + wave * kBitmapWords;
+    u32* cl = (u32*)(smem + kLdsListOff) + wave * 64;
     load_table(table, gear_table, tid);
     __syncthreads();
     const u32 lane_tab = lds_lane_table(table, lane);
-    for (u32 g = blockIdx.x; g < n_groups; g += gridDim.x) {
-        const u32 f = group_file[g], gi = group_index[g];
-        const u64 size = file_size[f];
-        const bool open_end = file_flags && (file_flags[f] & kFileOpenEnd);
-        const u8* fptr = data + file_off[f];
-        const u64 g0 = (u64)gi * kGroupBytes;
-        const u64 ts = g0 + (u64)wave * kGearTile;
-        if (lane == 0) fast_flags[wave] = 1u;                 // tiles past the end count as listed
-        if (ts < size) {
-            const u32 tlen = (u32)((size - ts < (u64)kGearTile) ? (size - ts) : (u64)kGearTile);
-            u32 pk;
-            bool ovf;
-            u32* bm = bitmaps + wave * kBitmapWords;
-            u32* cl = cand_lists + wave * 64;
-            mark_tile(fptr, ts, tlen, bm, lane_tab, p.thresh_m1, lane, pk, ovf);
-            bool fast = cand_compact(pk, ovf, (u32)lane * kLaneRun, lane, cl);
-            if (!fast) {
-                __builtin_amdgcn_wave_barrier();
-                fast = list_from_bitmap(bm, lane, cl);
-            }
+    const u32 g = blockIdx.x;                                 // workgroup = the four tiles of one group
+    const u64 t = (u64)g * kWavesPerWG + wave;
+    const u32 f = group_file[g];
+    const u64 size = file_size[f];
+    const u64 ts = (u64)group_index[g] * kGroupBytes + (u64)wave * kGearTile;
+    bool fast = true;                                         // tiles past the end count as listed
+    if (ts < size) {
+        const u32 tlen = (u32)((size - ts < (u64)kGearTile) ? (size - ts) : (u64)kGearTile);
+        u32 pk;
+        bool ovf;
+        mark_tile(data + file_off[f], ts, tlen, bm, lane_tab, p.thresh_m1, lane, pk, ovf);
+        fast = cand_compact(pk, ovf, (u32)lane * kLaneRun, lane, cl);
+        if (!fast) {
             __builtin_amdgcn_wave_barrier();
-            tile_lists[((u64)g * kWavesPerWG + wave) * 64 + lane] = fast ? cl[lane] : kNoCand;
-            if (lane == 0) fast_flags[wave] = fast ? 1u : 0u;
+            fast = list_from_bitmap(bm, lane, cl);
         }
-        __syncthreads();
-        if (wave == 0) {
-            const u64 s = file_seg0[f] + gi;
-            u32* spec = ends32 + seg_slot[s];
-            u64 last = g0;                                    // speculation: a cut at the group start
-            u32 n_out = 0, fast_mask = 0;
-            for (int t = 0; t < kWavesPerWG; ++t) fast_mask |= (fast_flags[t] ? 1u : 0u) << t;
-            for (int t = 0; t < kWavesPerWG; ++t) {
-                const u64 tts = g0 + (u64)t * kGearTile;
-                if (tts >= size) break;
-                const u32 tlen = (u32)((size - tts < (u64)kGearTile) ? (size - tts) : (u64)kGearTile);
-                select_tile(bitmaps + t * kBitmapWords, (fast_mask >> t) & 1u ? cand_lists + t * 64 : nullptr,
-                            tts, tlen, p, last, lane,
-                            [&](u64 c) { if (lane == 0) spec[n_out] = (u32)(c - g0); ++n_out; return false; });
-            }
-            if (lane == 0) {
-                if (!open_end && g0 + kGroupBytes >= size && size > last) {   // the file's last group: the end cuts
-                    spec[n_out] = (u32)(size - g0); ++n_out; last = size;
-                }
-                GroupRec r;
-                r.spec_exit = last;
-                r.spec_n = n_out;
-                r.flags = fast_mask == (1u << kWavesPerWG) - 1u ? 0u : kGroupDense;
-                r.entry = gi == 0 ? 0ull : ~0ull;
-                r.final_exit = last;
-                r.pcnt = 0;
-                r.sidx = 0;
-                if (gi == 0) { r.flags |= kGroupValid; seg_n[s] = n_out; }
-                recs[g] = r;
-            }
+        __builtin_amdgcn_wave_barrier();
+        tile_lists[t * 64 + lane] = fast ? cl[lane] : kNoCand;
+    }
+    if (lane == 0) tile_fast[t] = fast ? 1u : 0u;
+}
+
+// A2: one wave per group: the SPECULATIVE selection (a cut assumed at the group's first byte) from the
+// tiles' candidate lists.  A group with a dense tile gets no speculation: kGroupDense, left to C.
+__global__ __launch_bounds__(kGearWG)
+void gear_group_spec_kernel(const u64* __restrict__ file_size, const u64* __restrict__ file_seg0,
+                            const u64* __restrict__ seg_slot, u32* __restrict__ ends32,
+                            u32* __restrict__ seg_n, const u32* __restrict__ group_file,
+                            const u32* __restrict__ group_index, u32 n_groups,
+                            GroupRec* __restrict__ recs, const u32* __restrict__ tile_lists,
+                            const u32* __restrict__ tile_fast, const u32* __restrict__ file_flags,
+                            CdcParams p) {
+    __shared__ u32 lists[kWavesPerWG][kWavesPerWG * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u32 g = blockIdx.x * kWavesPerWG + wave;
+    if (g >= n_groups) return;
+    const u32 f = group_file[g], gi = group_index[g];
+    const u64 size = file_size[f];
+    const bool open_end = file_flags && (file_flags[f] & kFileOpenEnd);
+    const u64 g0 = (u64)gi * kGroupBytes;
+    const u64 s = file_seg0[f] + gi;
+    u32 fast_mask = 0;
+#pragma unroll
+    for (int t = 0; t < kWavesPerWG; ++t) {
+        lists[wave][t * 64 + lane] = tile_lists[((u64)g * kWavesPerWG + t) * 64 + lane];
+        fast_mask |= (tile_fast[(u64)g * kWavesPerWG + t] ? 1u : 0u) << t;
+    }
+    __builtin_amdgcn_wave_barrier();
+    GroupRec r;
+    r.pcnt = 0;
+    r.sidx = 0;
+    r.entry = gi == 0 ? 0ull : ~0ull;
+    if (fast_mask != (1u << kWavesPerWG) - 1u) {              // dense: C re-marks it and selects from the bitmaps
+        r.spec_exit = r.final_exit = ~0ull;
+        r.spec_n = 0;
+        r.flags = kGroupDense;
+        if (lane == 0) { recs[g] = r; seg_n[s] = 0; }
+        return;
+    }
+    u32* spec = ends32 + seg_slot[s];
+    u64 last = g0;                                            // speculation: a cut at the group start
+    u32 n_out = 0;
+    for (int t = 0; t < kWavesPerWG; ++t) {
+        const u64 tts = g0 + (u64)t * kGearTile;
+        if (tts >= size) break;
+        const u32 tlen = (u32)((size - tts < (u64)kGearTile) ? (size - tts) : (u64)kGearTile);
+        select_tile(nullptr, lists[wave] + t * 64, tts, tlen, p, last, lane,
+                    [&](u64 c) { if (lane == 0) spec[n_out] = (u32)(c - g0); ++n_out; return false; });
+    }
+    if (lane == 0) {
+        if (!open_end && g0 + kGroupBytes >= size && size > last) {   // the file's last group: the end cuts
+            spec[n_out] = (u32)(size - g0); ++n_out; last = size;
         }
-        __syncthreads();                                      // bitmaps / lists are reused
+        r.spec_exit = last;
+        r.spec_n = n_out;
+        r.final_exit = last;
+        r.flags = 0;
+        if (gi == 0) { r.flags |= kGroupValid; seg_n[s] = n_out; }   // starts at a true cut: final
+        recs[g] = r;
     }
 }
 
@@ -496,7 +520,7 @@ void gear_group_validate_kernel(const u64* __restrict__ file_size, const u64* __
     const u32 gi = group_index[g];
     if (gi == 0) return;
     GroupRec* rec = recs + g;
-    if (rec->flags & kGroupDense) return;                     // left to the per-file pass
+    if ((rec->flags | recs[g - 1].flags) & kGroupDense) return;   // own or previous group dense: left to the per-file pass
     const u32 f = group_file[g];
     const u64 s = file_seg0[f] + gi;
 #pragma unroll
@@ -526,18 +550,16 @@ void gear_file_fix_kernel(const u8* __restrict__ data, const u64* __restrict__ f
     volatile u32* fast_flags = (volatile u32*)(smem + kLdsFastOff);
     volatile u32* s_next = (volatile u32*)(smem + kGearLdsBytes);     // [0] group to redo or ~0, [1] dense?
     volatile u64* s_entry = (volatile u64*)(smem + kGearLdsBytes + 8);
-    load_table(table, gear_table, tid);
-    __syncthreads();
-    const u32 lane_tab = lds_lane_table(table, lane);
     const u32 f = large_list[blockIdx.x];
     const u64 size = file_size[f];
     const u8* fptr = data + file_off[f];
     const u32 gb = large_group0[blockIdx.x];
     const bool open_end = file_flags && (file_flags[f] & kFileOpenEnd);
     const u32 ng = (u32)((size + kGroupBytes - 1) / kGroupBytes);
-    u32 gi = 1;                                               // next group to check
-    u64 prev_exit = 0;                                        // true exit of group gi - 1 (wave 0)
-    if (wave == 0) prev_exit = recs[gb].final_exit;
+    u32 gi = 0;                                               // next group to check
+    u64 prev_exit = 0;                                        // true exit of group gi - 1 (wave 0); the file starts at a cut
+    bool have_table = false;                                  // loaded only if some group has to be redone
+    u32 lane_tab = 0;
     for (;;) {
         // wave 0: skip ahead over groups whose assumption holds
         if (wave == 0) {
@@ -548,7 +570,7 @@ void gear_file_fix_kernel(const u8* __restrict__ data, const u64* __restrict__ f
                 u64 ex = 0;
                 if (my < ng) {
                     const GroupRec r = recs[gb + my];
-                    const u64 pe = lane == 0 ? prev_exit : recs[gb + my - 1].final_exit;
+                    const u64 pe = lane == 0 ? prev_exit : recs[gb + my - 1].final_exit;   // (my >= 1 for lane > 0)
                     ex = r.final_exit;
                     bad = !(r.flags & kGroupValid) || r.entry != pe;
                 }
@@ -575,6 +597,12 @@ void gear_file_fix_kernel(const u8* __restrict__ data, const u64* __restrict__ f
         __syncthreads();
         const u32 redo = s_next[0];
         if (redo == 0xFFFFFFFFu) break;
+        if (!have_table) {                                    // first group to redo: now the table is needed
+            load_table(table, gear_table, tid);
+            __syncthreads();
+            lane_tab = lds_lane_table(table, lane);
+            have_table = true;
+        }
         const u32 g = gb + redo;
         const u64 g0 = (u64)redo * kGroupBytes;
         if (s_next[1]) {                                      // dense: the bitmaps have to be rebuilt
@@ -621,7 +649,7 @@ size_t gear_group_rec_bytes() { return sizeof(GroupRec); }
 void launch_gear_cdc(const GearLaunch& a, CdcParams p, int n_cu, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)gear_cdc_small_kernel,
                               hipFuncAttributeMaxDynamicSharedMemorySize, kGearLdsBytes);
-    (void)hipFuncSetAttribute((const void*)gear_group_mark_kernel,
+    (void)hipFuncSetAttribute((const void*)gear_tile_mark_kernel,
                               hipFuncAttributeMaxDynamicSharedMemorySize, kGearLdsBytes);
     (void)hipFuncSetAttribute((const void*)gear_file_fix_kernel,
                               hipFuncAttributeMaxDynamicSharedMemorySize, kGearLdsBytes + 16);
@@ -631,23 +659,24 @@ void launch_gear_cdc(const GearLaunch& a, CdcParams p, int n_cu, hipStream_t s) 
                            a.seg_slot, a.ends32, a.seg_n, a.small_list, a.n_small, a.gear_table, p);
     if (a.n_groups) {
         const u32 region = (u32)gear_group_region(p.min_size);
-        u32 grid = (u32)n_cu * 3;                         // 3 workgroups per CU fit (LDS, VGPRs)
-        if (grid > a.n_groups) grid = a.n_groups;
         GroupRec* recs = (GroupRec*)a.group_recs;
-        hipLaunchKernelGGL(gear_group_mark_kernel, dim3(grid), dim3(kGearWG), kGearLdsBytes, s, a.data,
-                           a.file_off, a.file_size, a.file_seg0, a.seg_slot, a.ends32, a.seg_n,
-                           a.group_file, a.group_index, a.n_groups, recs, a.tile_lists, a.file_flags,
+        hipLaunchKernelGGL(gear_tile_mark_kernel, dim3(a.n_groups), dim3(kGearWG), kGearLdsBytes, s, a.data,
+                           a.file_off, a.file_size, a.group_file, a.group_index, a.n_groups, a.tile_lists,
+                           a.tile_fast, a.gear_table, p);
+        const dim3 per_group((a.n_groups + kWavesPerWG - 1) / kWavesPerWG);
+        hipLaunchKernelGGL(gear_group_spec_kernel, per_group, dim3(kGearWG), 0, s, a.file_size, a.file_seg0,
+                           a.seg_slot, a.ends32, a.seg_n, a.group_file, a.group_index, a.n_groups, recs,
+                           a.tile_lists, a.tile_fast, a.file_flags, p);
+        if (a.n_groups > a.n_large)                       // some file has more than one group
+            hipLaunchKernelGGL(gear_group_validate_kernel, per_group, dim3(kGearWG), 0, s, a.file_size,
+                               a.file_seg0, a.seg_slot, a.ends32, a.seg_n, a.group_file, a.group_index,
+                               a.n_groups, recs, a.tile_lists, a.file_flags, region, p);
+        // always: a dense group (even a file's only one) is selected here; a file with nothing to redo
+        // costs one record read
+        hipLaunchKernelGGL(gear_file_fix_kernel, dim3(a.n_large), dim3(kGearWG), kGearLdsBytes + 16, s,
+                           a.data, a.file_off, a.file_size, a.file_seg0, a.seg_slot, a.ends32, a.seg_n,
+                           a.large_list, a.large_group0, recs, a.tile_lists, a.file_flags, region,
                            a.gear_table, p);
-        if (a.n_groups > a.n_large) {                     // some file has more than one group
-            hipLaunchKernelGGL(gear_group_validate_kernel, dim3((a.n_groups + kWavesPerWG - 1) / kWavesPerWG),
-                               dim3(kGearWG), 0, s, a.file_size, a.file_seg0, a.seg_slot, a.ends32, a.seg_n,
-                               a.group_file, a.group_index, a.n_groups, recs, a.tile_lists, a.file_flags,
-                               region, p);
-            hipLaunchKernelGGL(gear_file_fix_kernel, dim3(a.n_large), dim3(kGearWG), kGearLdsBytes + 16, s,
-                               a.data, a.file_off, a.file_size, a.file_seg0, a.seg_slot, a.ends32, a.seg_n,
-                               a.large_list, a.large_group0, recs, a.tile_lists, a.file_flags, region,
-                               a.gear_table, p);
-        }
     }
 }
 

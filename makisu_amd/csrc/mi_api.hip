@@ -211,6 +211,7 @@ GearLaunch gear_args(mi_batch* b) {
     g.n_large = b->n_large;
     g.group_recs = b->group_recs.p;
     g.tile_lists = b->tile_lists.as<u32>();
+    g.tile_fast = b->tile_fast.as<u32>();
     g.file_flags = b->parts.empty() ? nullptr : b->file_flags.as<u32>();
     g.gear_table = c->gear_table.as<u64>();
     return g;
@@ -223,6 +224,7 @@ int ensure_cut_buffers(mi_batch* b) {
     if (b->n_groups) {
         HIPCHK(c, b->group_recs.ensure(gear_group_rec_bytes() * (size_t)b->n_groups));
         HIPCHK(c, b->tile_lists.ensure(1024ull * b->n_groups));
+        HIPCHK(c, b->tile_fast.ensure(16ull * b->n_groups));
     }
     return MI_OK;
 }
@@ -1212,7 +1214,7 @@ int mi_batch_free(mi_batch* b) {
     DevBuf* bufs[] = {&b->root_addr, &b->root_cnt, &b->rseg_cnt, &b->rseg_first, &b->rseg_total,
                       &b->root_items_off, &b->root_items_len, &b->root_level[0], &b->root_level[1],
                       &b->root_level[2], &b->root_level[3], &b->root_level[4], &b->root_addr2, &b->root_cnt2,
-                      &b->group_file, &b->group_index, &b->group_recs, &b->tile_lists, &b->large_list,
+                      &b->group_file, &b->group_index, &b->group_recs, &b->tile_lists, &b->tile_fast, &b->large_list,
                       &b->large_group0, &b->seg_file, &b->seg_slot, &b->seg_n, &b->seg_first, &b->seg_group,
                       &b->file_seg0, &b->ends32, &b->tile_file, &b->first_tile, &b->tile_raw, &b->crc_d, &b->ctl, &b->dd_table, &b->dd_slot,
                       &b->q_off, &b->q_len, &b->q_id,&b->arena, &b->small_list, &b->file_off, &b->file_size, &b->cids,

@@ -72,6 +72,7 @@ struct GearLaunch {
     u32        n_large;
     void*      group_recs;     // n_groups x gear_group_rec_bytes()
     u32*       tile_lists;     // n_groups x 4 tiles x 64 candidates
+    u32*       tile_fast;      // n_groups x 4: 1 = the tile's list is complete, 0 = dense tile
     const u32* file_flags;     // per file, kFile* bits; nullptr when the batch holds no parts
     const u64* gear_table;
 };

@@ -110,7 +110,7 @@ struct mi_batch {
     // CDC segments (gear_cdc.hip): a small file or one 256 KiB group of a large file
     mi::DevBuf small_list;                   // segments that are files <= one tile (wave per file)
     mi::DevBuf seg_file, seg_slot, seg_n, seg_first, seg_group, file_seg0, ends32;
-    mi::DevBuf group_file, group_index, group_recs, tile_lists, large_list, large_group0;
+    mi::DevBuf group_file, group_index, group_recs, tile_lists, tile_fast, large_list, large_group0;
     mi::u32 n_small = 0, n_groups = 0, n_large = 0;
     mi::u64 n_segs = 0, ends_total = 0;
     mi::DevBuf file_off, file_size, cids, n_chunks_d, first, scratch;
