@@ -646,13 +646,24 @@ u64 gear_large_groups(u64 size) { return (size + kGroupBytes - 1) / kGroupBytes;
 u64 gear_group_region(u32 min_size) { return kGroupBytes / min_size + 2; }
 size_t gear_group_rec_bytes() { return sizeof(GroupRec); }
 
-void launch_gear_cdc(const GearLaunch& a, CdcParams p, int n_cu, hipStream_t s) {
+// more than 64 KiB of dynamic LDS needs the attribute; per device (several ctxs may use several GPUs)
+static void gear_lds_attributes() {
+    static thread_local int done_for = -1;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (done_for == dev) return;
     (void)hipFuncSetAttribute((const void*)gear_cdc_small_kernel,
                               hipFuncAttributeMaxDynamicSharedMemorySize, kGearLdsBytes);
     (void)hipFuncSetAttribute((const void*)gear_tile_mark_kernel,
                               hipFuncAttributeMaxDynamicSharedMemorySize, kGearLdsBytes);
     (void)hipFuncSetAttribute((const void*)gear_file_fix_kernel,
                               hipFuncAttributeMaxDynamicSharedMemorySize, kGearLdsBytes + 16);
+    done_for = dev;
+}
+
+void launch_gear_cdc(const GearLaunch& a, CdcParams p, int n_cu, hipStream_t s) {
+    (void)n_cu;
+    gear_lds_attributes();
     if (a.n_small)
         hipLaunchKernelGGL(gear_cdc_small_kernel, dim3((a.n_small + kWavesPerWG - 1) / kWavesPerWG),
                            dim3(kGearWG), kGearLdsBytes, s, a.data, a.file_off, a.file_size, a.seg_file,
