@@ -121,8 +121,10 @@ __device__ __forceinline__ void mask_tail_block(u32 (&w)[16], u32 r) {
 //          position, (2) load off/len/slot of that position, (3) load its first 64 bytes.
 //          Each stage is consumed one iteration after it was issued, so a lane switches
 //          strings without ever waiting on memory.
-// Reads may run up to 63 bytes past a string's end (never used); every buffer this is
-// launched on carries that slack (arena, digest array, mi_sha256_many staging).
+// Reads may run up to 63 bytes past a string's end (67 with kCoop, plus 3 bytes in front of a
+// string that does not start on a dword) -- never used; every buffer this is launched on carries
+// that slack (arena: 4 KiB; digest arrays and mi_sha256_many staging: DevBuf adds 256 bytes) and no
+// string starts unaligned at a buffer's first byte.
 constexpr u32 kLook = 5;
 
 // kPass only names the instantiation (chunk pass / root pass / ...) so profiles tell them apart.
