@@ -37,6 +37,7 @@
 #include <algorithm>
 #include <condition_variable>
 #include <deque>
+#include <sched.h>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -83,7 +84,7 @@ protected:
         std::lock_guard<std::mutex> g(mu_);
         return !err.empty();
     }
-    virtual void consume(const uint8_t* p, size_t n) = 0;
+    virtual void consume(const Block& b) = 0;
     virtual void finish() = 0;
 
 private:
@@ -96,7 +97,7 @@ private:
                 if (q_.empty()) break;
                 b = q_.front();
             }
-            if (!failed()) consume(b->data(), b->size());
+            if (!failed()) consume(b);
             {
                 std::lock_guard<std::mutex> g(mu_);
                 q_.pop_front();
@@ -129,7 +130,9 @@ public:
     uint64_t bytes = 0;
     int raw_fd = -1;                               // without a gzip leg the tar itself is the blob
 protected:
-    void consume(const uint8_t* p, size_t n) override {
+    void consume(const Block& b) override {
+        const uint8_t* p = b->data();
+        const size_t n = b->size();
         sha_.update(p, n);
         bytes += n;
         std::string e;
@@ -140,48 +143,143 @@ private:
     mi_host::Sha256 sha_;
 };
 
-class GzipSink : public Sink {                     // gzipper -> {tempGzipTar, gzipDigester} (common.go:44-52)
+// gzipper -> {tempGzipTar, gzipDigester} (common.go:44-52).  The reference compresses with pgzip
+// (lib/tario/gzip.go:31-47): blocks deflated in parallel, one gzip member.  Same construction here
+// (what pigz does): every 1 MiB block of the tar is deflated on its own by a pool thread as a raw
+// stream closed with a sync flush -- it ends on a byte boundary and needs no dictionary --, the sink
+// thread writes the pieces in order, then an empty final block and the trailer (CRC-32 of the blocks
+// combined, length mod 2^32).  The bytes are this writer's (pgzip's differ: its own block size and
+// deflate), so the gzip digest is valid for blobs written here -- as DESIGN.md says.
+class GzipSink : public Sink {
 public:
     uint8_t digest[32];
     uint64_t bytes = 0;
     int out_fd = -1;
     bool init(int level) {
-        memset(&z_, 0, sizeof z_);
-        const int rc = deflateInit2(&z_, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY);
-        if (rc != Z_OK) { set_error("deflateInit2 failed"); return false; }
-        ready_ = true;
-        out_.resize(256 << 10);
+        level_ = level;
+        unsigned n = 0;
+        if (const char* e = getenv("MI_GZIP_THREADS")) n = (unsigned)atoi(e);
+        if (n == 0) {
+            cpu_set_t set;
+            n = sched_getaffinity(0, sizeof set, &set) == 0 ? (unsigned)CPU_COUNT(&set) : 1u;
+            if (n > 16) n = 16;
+        }
+        if (n < 1) n = 1;
+        if (n > 64) n = 64;
+        window_ = 2 * n;
+        for (unsigned i = 0; i < n; ++i) pool_.emplace_back([this] { work(); });
+        // gzip header as compress/gzip writes it: no name, no mtime, XFL by level, OS "unknown"
+        const uint8_t hdr[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0,
+                                 (uint8_t)(level == 9 ? 2 : level == 1 ? 4 : 0), 255};
+        emit(hdr, sizeof hdr);
         return true;
     }
-    ~GzipSink() override { if (ready_) deflateEnd(&z_); }
+    ~GzipSink() override { stop_pool(); }
 protected:
-    void consume(const uint8_t* p, size_t n) override { pump(p, n, Z_NO_FLUSH); }
+    void consume(const Block& b) override {
+        if (b->empty()) return;
+        auto j = std::make_shared<Job>();
+        j->in = b;
+        {
+            std::lock_guard<std::mutex> g(pm_);
+            todo_.push_back(j);
+        }
+        pcv_.notify_one();
+        inflight_.push_back(j);
+        while (inflight_.size() >= window_) drain_one();
+    }
     void finish() override {
-        pump(nullptr, 0, Z_FINISH);
+        while (!inflight_.empty()) drain_one();
+        stop_pool();
+        if (failed()) return;
+        const uint8_t last[2] = {0x03, 0x00};                     // empty final deflate block
+        emit(last, 2);
+        uint8_t tr[8];
+        for (int i = 0; i < 4; ++i) { tr[i] = (uint8_t)(crc_ >> (8 * i)); tr[4 + i] = (uint8_t)(total_in_ >> (8 * i)); }
+        emit(tr, 8);
         sha_.final(digest);
     }
 private:
-    void pump(const uint8_t* p, size_t n, int flush) {
-        z_.next_in = (Bytef*)p;
-        z_.avail_in = (uInt)n;
-        for (;;) {
-            z_.next_out = out_.data();
-            z_.avail_out = (uInt)out_.size();
-            const int rc = deflate(&z_, flush);
-            if (rc == Z_STREAM_ERROR) { set_error("deflate failed"); return; }
-            const size_t got = out_.size() - z_.avail_out;
-            if (got) {
-                sha_.update(out_.data(), got);
-                bytes += got;
-                std::string e;
-                if (out_fd >= 0 && !write_all(out_fd, out_.data(), got, &e)) { set_error(e); return; }
-            }
-            if (flush == Z_FINISH ? rc == Z_STREAM_END : (z_.avail_in == 0 && z_.avail_out != 0)) break;
-        }
+    struct Job {
+        Block in;
+        Bytes out;
+        uint32_t crc = 0;
+        bool ok = true, done = false;
+        std::mutex m;
+        std::condition_variable cv;
+    };
+    void emit(const uint8_t* p, size_t n) {
+        sha_.update(p, n);
+        bytes += n;
+        std::string e;
+        if (out_fd >= 0 && !write_all(out_fd, p, n, &e)) set_error(e);
     }
-    z_stream z_;
-    bool ready_ = false;
-    Bytes out_;
+    void drain_one() {
+        std::shared_ptr<Job> j = inflight_.front();
+        inflight_.pop_front();
+        {
+            std::unique_lock<std::mutex> lk(j->m);
+            j->cv.wait(lk, [&] { return j->done; });
+        }
+        if (!j->ok) { set_error("deflate failed"); return; }
+        if (failed()) return;
+        emit(j->out.data(), j->out.size());
+        crc_ = total_in_ ? (uint32_t)crc32_combine(crc_, j->crc, (z_off_t)j->in->size()) : j->crc;
+        total_in_ += j->in->size();
+    }
+    void work() {
+        z_stream z;
+        memset(&z, 0, sizeof z);
+        bool ready = deflateInit2(&z, level_, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) == Z_OK;
+        for (;;) {
+            std::shared_ptr<Job> j;
+            {
+                std::unique_lock<std::mutex> lk(pm_);
+                pcv_.wait(lk, [&] { return stop_ || !todo_.empty(); });
+                if (todo_.empty()) break;
+                j = todo_.front();
+                todo_.pop_front();
+            }
+            bool ok = ready;
+            if (ok) {
+                deflateReset(&z);
+                j->out.resize(deflateBound(&z, (uLong)j->in->size()) + 16);
+                z.next_in = (Bytef*)j->in->data();
+                z.avail_in = (uInt)j->in->size();
+                z.next_out = j->out.data();
+                z.avail_out = (uInt)j->out.size();
+                const int rc = deflate(&z, Z_SYNC_FLUSH);         // whole block in one call: the bound holds
+                ok = rc == Z_OK && z.avail_in == 0 && z.avail_out != 0;
+                j->out.resize(j->out.size() - z.avail_out);
+                j->crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), j->in->data(), (uInt)j->in->size());
+            }
+            {
+                std::lock_guard<std::mutex> g(j->m);
+                j->ok = ok;
+                j->done = true;
+            }
+            j->cv.notify_all();
+        }
+        if (ready) deflateEnd(&z);
+    }
+    void stop_pool() {
+        {
+            std::lock_guard<std::mutex> g(pm_);
+            stop_ = true;
+        }
+        pcv_.notify_all();
+        for (auto& t : pool_) if (t.joinable()) t.join();
+        pool_.clear();
+    }
+    int level_ = Z_DEFAULT_COMPRESSION;
+    size_t window_ = 2;
+    std::vector<std::thread> pool_;
+    std::mutex pm_;
+    std::condition_variable pcv_;
+    std::deque<std::shared_ptr<Job>> todo_, inflight_;
+    bool stop_ = false;
+    uint32_t crc_ = 0;
+    uint64_t total_in_ = 0;
     mi_host::Sha256 sha_;
 };
 

@@ -289,3 +289,37 @@ def test_ustar_headers_equal_python_tarfile():
         want[148:156] = b" " * 8
         want[148:156] = b"%06o\x00 " % sum(want)
         assert M.layer_header_bytes(e) == bytes(want), e["relpath"]
+
+
+def test_parallel_gzip_is_one_member_and_independent_of_the_thread_count(tmp_path, monkeypatch):
+    """The gzip leg deflates 1 MiB blocks of the tar on a thread pool (the reference uses pgzip,
+    lib/tario/gzip.go:31-47).  The blob must be ONE gzip member that zlib reads back to exactly the
+    tar, at every level, with compressible, incompressible and empty content -- and its bytes must
+    not depend on how many threads compressed it."""
+    import zlib
+    files = {"zeros": bytes(3 * (1 << 20) + 5), "rand": os.urandom(2 * (1 << 20) + 123), "empty": b"",
+             "text": b"layer layer layer\n" * 200000, "tiny": b"x"}
+    for name, data in files.items():
+        (tmp_path / name).write_bytes(data)
+    blobs = {}
+    for threads in ("1", "3", "16"):
+        monkeypatch.setenv("MI_GZIP_THREADS", threads)
+        for level in (1, M.GZIP_DEFAULT, 9):
+            out = tmp_path / ("l%s_%d.tgz" % (threads, level))
+            fd = os.open(out, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+            with M.Layer(out_fd=fd, gzip_level=level) as layer:
+                for name in sorted(files):
+                    layer.add({"relpath": name, "kind": M.KIND_FILE, "mode": 0o644, "size": len(files[name])},
+                              str(tmp_path / name))
+                pair = layer.finish()
+            os.close(fd)
+            blob = out.read_bytes()
+            assert hashlib.sha256(blob).hexdigest() == pair["gzip_digest"].hex() and len(blob) == pair["gzip_bytes"]
+            d = zlib.decompressobj(16 + 15)                       # gzip framing, exactly one member
+            tar_bytes = d.decompress(blob) + d.flush()
+            assert d.eof and d.unused_data == b""
+            assert len(tar_bytes) == pair["tar_bytes"]
+            assert hashlib.sha256(tar_bytes).hexdigest() == pair["tar_digest"].hex()
+            assert len(blob) < len(tar_bytes) // 2                # the zeros and the text did compress
+            blobs.setdefault(level, set()).add(blob)
+    assert all(len(v) == 1 for v in blobs.values())               # same bytes with 1, 3 and 16 threads
