@@ -239,3 +239,76 @@ def test_scan_cuts_on_a_batch_without_parts(oracle):
             if len(ref):
                 assert np.array_equal(mine["offset"], ref["offset"]) and np.array_equal(mine["sha256"], ref["sha256"])
         assert np.array_equal(first["sha256"], again["sha256"]) and np.array_equal(first["offset"], again["offset"])
+
+
+def _parts_rank_worker(rank, world, port, n, cid, zeros, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    import makisu_amd
+    from makisu_amd import distributed as mdist
+    from makisu_amd.workloads import split_file
+    torch.cuda.set_device(0)                       # the test box has one GPU: both ranks share it
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    bounds = split_file(n, 2 * world)              # two parts per rank, interleaved over the ranks
+    cfg = dict(max_size=100000) if zeros else {}
+    with makisu_amd.Engine(device=0, **cfg) as eng, eng.batch() as b:
+        keys = []
+        for k, (lo, hi) in enumerate(bounds):
+            if k % world == rank:
+                if zeros:
+                    b.add_path_part(zeros, lo, hi, file_size=n)
+                else:
+                    b.add_synthetic_part(n, cid, lo, hi, seed=SEED)
+                keys.append((0, k))
+        rounds = mdist.resolve_parts(b, keys)
+        b.run()
+        ch = b.chunks().copy()
+        rows = [(k[1], ch[ch["file_index"] == i]["offset"].tolist(), ch[ch["file_index"] == i]["sha256"].tobytes())
+                for i, k in enumerate(keys)]
+    q.put((rank, rounds, rows))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("kind", ["random", "zeros"])
+def test_two_ranks_resolve_parts_on_gpu(oracle, tmp_path, kind):
+    """distributed.resolve_parts through the real engine: two processes (sharing the box's one GPU,
+    gloo as the transport) own alternating parts of one file, exchange exits, fix, scan; the rows of
+    all parts in part order are the oracle's rows of the whole file.  'zeros': forced cuts out of
+    phase with the groups -- the exchange has to run one round per boundary."""
+    import socket
+    import torch.multiprocessing as mp
+    import makisu_amd
+    n = 9 * G + 4321
+    if kind == "zeros":
+        data = bytes(n)
+        path = tmp_path / "z.bin"
+        path.write_bytes(data)
+        zeros, cfg = str(path), dict(max_size=100000)
+    else:
+        data = oracle.synth_fill(SEED, 4600, 0, n).tobytes()
+        zeros, cfg = None, {}
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()     # noqa: E702
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_parts_rank_worker, args=(r, 2, port, n, 4600, zeros, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=500) for _ in range(2))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    parts = sorted(x for _, _, rows in res for x in rows)
+    offsets = [o for _, offs, _ in parts for o in offs]
+    digests = b"".join(d for _, _, d in parts)
+    with makisu_amd.Engine(**cfg) as e:
+        ref = _whole(oracle, e, data)
+    assert offsets == ref["offset"].tolist()
+    assert digests == ref["sha256"].tobytes()
+    rounds = {r for _, r, _ in res}
+    assert len(rounds) == 1 and (rounds == {1} if kind == "random" else rounds.pop() >= 3)
