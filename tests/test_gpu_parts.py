@@ -312,3 +312,35 @@ def test_two_ranks_resolve_parts_on_gpu(oracle, tmp_path, kind):
     assert digests == ref["sha256"].tobytes()
     rounds = {r for _, r, _ in res}
     assert len(rounds) == 1 and (rounds == {1} if kind == "random" else rounds.pop() >= 3)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_parts_random_cases(oracle, tmp_path, seed):
+    """Seeded random cases: parameters, content made of random / zero / periodic stretches, part
+    bounds on random group boundaries, parts in separate batches or one."""
+    import makisu_amd
+    rng = np.random.default_rng(1000 + seed)
+    mask_bits, min_size, max_size = [(13, 2048, 65536), (11, 512, 8192), (8, 256, 4096), (15, 4096, 200000),
+                                     (13, 2048, 100000), (20, 2048, 524288), (6, 128, 1024), (12, 1024, 262144)][seed]
+    pieces = []
+    for _ in range(int(rng.integers(2, 6))):
+        kind, n = int(rng.integers(0, 3)), int(rng.integers(1, 5 * G))
+        if kind == 0:
+            pieces.append(oracle.synth_fill(SEED, 5000 + int(rng.integers(0, 1000)), 0, n).tobytes())
+        elif kind == 1:
+            pieces.append(bytes(n))
+        else:
+            period = oracle.synth_fill(SEED, 6000 + seed, 0, int(rng.integers(100, 9000))).tobytes()
+            pieces.append((period * (n // len(period) + 1))[:n])
+    data = b"".join(pieces)
+    n = len(data)
+    groups = -(-n // G)
+    k = int(rng.integers(1, min(6, groups) + 1))
+    cuts = sorted(set(int(x) for x in rng.integers(1, groups, k - 1))) if groups > 1 and k > 1 else []
+    edges = [0] + [c * G for c in cuts] + [n]
+    bounds = [(a, b) for a, b in zip(edges, edges[1:]) if b > a]
+    path = tmp_path / "case.bin"
+    path.write_bytes(data)
+    with makisu_amd.Engine(mask_bits=mask_bits, min_size=min_size, max_size=max_size) as e:
+        _check_parts(oracle, e, data, bounds, lambda b, lo, hi: b.add_path_part(str(path), lo, hi, file_size=n),
+                     one_batch=bool(seed % 2))
