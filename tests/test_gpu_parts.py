@@ -344,3 +344,43 @@ def test_parts_random_cases(oracle, tmp_path, seed):
     with makisu_amd.Engine(mask_bits=mask_bits, min_size=min_size, max_size=max_size) as e:
         _check_parts(oracle, e, data, bounds, lambda b, lo, hi: b.add_path_part(str(path), lo, hi, file_size=n),
                      one_batch=bool(seed % 2))
+
+
+def test_parts_of_a_3gib_file_equal_the_whole(oracle):
+    """Full-size parts: a 3 GiB synthetic file whole (one batch) and as three 1 GiB parts (a batch
+    each): identical chunk rows (offsets, lengths, digests), and a sample of the digests re-hashed
+    on the host from the generator."""
+    import hashlib
+    import makisu_amd
+    from makisu_amd.distributed import resolve_parts_local
+    from makisu_amd.workloads import split_file
+    n, cid = 3 * (1 << 30) + 12345, 4700
+    with makisu_amd.Engine() as e:
+        with e.batch() as b:
+            b.add_synthetic([n], [cid], seed=SEED)
+            b.run()
+            whole = b.chunks().copy()
+        batches = [e.batch() for _ in range(3)]
+        try:
+            owners = []
+            for k, (b, (lo, hi)) in enumerate(zip(batches, split_file(n, 3))):
+                b.add_synthetic_part(n, cid, lo, hi, seed=SEED)
+                owners.append((b, [(0, k)]))
+            assert resolve_parts_local(owners) == 1
+            rows = []
+            for b in batches:
+                b.run()
+                rows.append(b.chunks().copy())
+            got = np.concatenate(rows)
+        finally:
+            for b in batches:
+                b.free()
+    assert len(got) == len(whole)
+    assert np.array_equal(got["offset"], whole["offset"]) and np.array_equal(got["length"], whole["length"])
+    assert np.array_equal(got["sha256"], whole["sha256"])
+    rng = np.random.default_rng(4)
+    for i in rng.integers(0, len(got), 40):
+        r = got[int(i)]
+        off, ln = int(r["offset"]), int(r["length"])
+        blob = oracle.synth_fill(SEED, cid, off, ln)
+        assert bytes(r["sha256"]).hex() == hashlib.sha256(blob.tobytes()).hexdigest()
