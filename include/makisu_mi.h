@@ -152,6 +152,12 @@ int mi_batch_add_bytes(mi_batch* b, const void* data, uint64_t len, uint64_t use
  * files share one PCIe transfer), so a file that shrinks afterwards fails mi_batch_run /
  * mi_batch_submit with MI_ERR_IO.                                                    */
 int mi_batch_add_path(mi_batch* b, const char* path, uint64_t size, uint64_t user_tag);
+/* Bulk form for MANY files (a layer is mostly small ones): nothing is opened in this call, the reader
+ * threads open, read and close the files themselves, several at a time.  The price of the deferred
+ * open: a missing or short file does not fail this call but mi_batch_run / mi_batch_submit
+ * (MI_ERR_IO naming the path).  user_tags may be NULL (tags 0).                              */
+int mi_batch_add_paths(mi_batch* b, uint64_t n, const char* const* paths, const uint64_t* sizes,
+                       const uint64_t* user_tags);
 /* The same for a byte range of a file -- a member of an uncompressed layer tar, whose ranges
  * mi_tar_entries lists: the file's bytes are [offset, offset + size) of `path`.             */
 int mi_batch_add_path_range(mi_batch* b, const char* path, uint64_t offset, uint64_t size,

@@ -161,6 +161,7 @@ def load_library(rebuild=False):
         "mi_batch_add_bytes": ([vp, vp, u64, u64], C.c_int),
         "mi_batch_add_path": ([vp, C.c_char_p, u64, u64], C.c_int),
         "mi_batch_add_path_range": ([vp, C.c_char_p, u64, u64, u64], C.c_int),
+        "mi_batch_add_paths": ([vp, u64, C.POINTER(C.c_char_p), u64p, u64p], C.c_int),
         "mi_batch_add_synthetic": ([vp, u64, u64p, u64p, u64], C.c_int),
         "mi_batch_add_path_part": ([vp, C.c_char_p, u64, u64, u64, u64], C.c_int),
         "mi_batch_add_synthetic_part": ([vp, u64, u64, u64, u64, u64], C.c_int),
@@ -747,6 +748,17 @@ class Batch:
         if size is None:
             size = os.stat(path).st_size
         self._check(self._lib.mi_batch_add_path(self._h, os.fsencode(path), size, tag))
+
+    def add_paths(self, paths, sizes=None, tags=None):
+        """Many files at once, opened by the reader threads (deferred: a missing file fails run())."""
+        n = len(paths)
+        if sizes is None:
+            sizes = [os.stat(p).st_size for p in paths]
+        arr = (C.c_char_p * max(n, 1))(*[os.fsencode(p) for p in paths])
+        sz = np.ascontiguousarray(sizes, dtype=np.uint64)
+        u64p = C.POINTER(C.c_uint64)
+        tg = np.ascontiguousarray(tags, dtype=np.uint64).ctypes.data_as(u64p) if tags is not None else None
+        self._check(self._lib.mi_batch_add_paths(self._h, n, arr, sz.ctypes.data_as(u64p), tg))
 
     def add_path_range(self, path, offset, size, tag=0):
         """A file that is bytes [offset, offset+size) of `path` (a member of a layer tar)."""

@@ -772,6 +772,41 @@ int mi_batch_add_path(mi_batch* b, const char* path, uint64_t size, uint64_t use
     return add_file_range(b, path, 0, size, user_tag);
 }
 
+// Bulk form with DEFERRED opens: nothing is opened or read in this call -- the reader threads open,
+// read and close the files, several at a time, and consecutive small files share one PCIe transfer.
+// What it costs per file here is a table row (a tree of 100 000 4 KiB files: 9 us per file through
+// mi_batch_add_path -- open, fstat, a queue hand-over each -- against well under 1 us).
+int mi_batch_add_paths(mi_batch* b, uint64_t n, const char* const* paths, const uint64_t* sizes,
+                       const uint64_t* user_tags) {
+    if (!b || (n && (!paths || !sizes))) return MI_ERR_INVALID;
+    mi_ctx* c = b->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n == 0) return MI_OK;
+    if (b->staged) return fail(c, MI_ERR_STATE, "batch already ran; begin a new batch");
+    for (u64 i = 0; i < n; ++i)
+        if (!paths[i]) return fail(c, MI_ERR_INVALID, "mi_batch_add_paths: path %llu is NULL", (unsigned long long)i);
+    int rc = staging_flush(b);                    // the inline window may hold bytes of earlier small adds
+    if (rc) return rc;
+    const auto t0 = std::chrono::steady_clock::now();
+    // one reservation for all of them (arena_reserve may move the arena: nothing may be in flight into it)
+    u64 end = b->arena_used;
+    for (u64 i = 0; i < n; ++i) end = align_up(end, kFileAlign) + sizes[i];
+    rc = arena_reserve(b, align_up(end, kFileAlign));
+    if (rc == MI_OK) rc = ensure_stager(c);
+    if (rc) return rc;
+    std::vector<u64> at(n);
+    for (u64 i = 0; i < n; ++i) {
+        at[i] = align_up(b->arena_used, kFileAlign);
+        b->files.push_back({at[i], sizes[i], user_tags ? user_tags[i] : 0});
+        b->arena_used = at[i] + sizes[i];
+        b->total_bytes += sizes[i];
+    }
+    rc = stager_put_paths(c->stager, b, n, paths, at.data(), sizes);
+    b->staged_any = true;
+    b->ms_h2d += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+}
+
 // A file that is a byte range of another file: a member of an uncompressed layer tar
 // (mi_tar_entries gives the ranges).
 int mi_batch_add_path_range(mi_batch* b, const char* path, uint64_t offset, uint64_t size, uint64_t user_tag) {

@@ -47,6 +47,8 @@ Stager* stager_create(mi_ctx* c, u32 n_threads, u64 slab_bytes);
 void    stager_destroy(Stager* st);
 int     stager_put_bytes(Stager* st, mi_batch* b, u64 arena_off, const void* src, u64 len);
 int     stager_put_file(Stager* st, mi_batch* b, u64 arena_off, int fd, u64 file_off, u64 len, const char* path);
+int     stager_put_paths(Stager* st, mi_batch* b, u64 n, const char* const* paths, const u64* arena_off,
+                         const u64* len);
 int     stager_drain(Stager* st, mi_batch* b);
 
 }  // namespace mi

@@ -10,6 +10,7 @@
 #include "mi_internal.h"
 
 #include <errno.h>
+#include <fcntl.h>
 #include <string.h>
 #include <unistd.h>
 
@@ -23,9 +24,9 @@ using namespace mi;
 
 namespace mi {
 
-struct StageFile {                       // an open source file shared by its pieces
-    int fd;
-    std::string path;
+struct StageFile {                       // a source file shared by its pieces
+    int fd;                              // open (mi_batch_add_path: checked at the call), or -1:
+    std::string path;                    // ... the reader thread opens `path` for each piece itself
     ~StageFile() { if (fd >= 0) close(fd); }
 };
 
@@ -99,9 +100,15 @@ void worker(Stager* st) {
             if (st->queue.empty()) break;                      // stop requested and nothing left
             const mi_batch* b = st->queue.front().batch;
             const u64 start = st->queue.front().arena_off;
+            u64 prev_end = start;
             while (!st->queue.empty()) {
                 const StageItem& f = st->queue.front();
                 if (f.batch != b || f.arena_off < start || f.arena_off + f.len - start > st->slab_bytes) break;
+                // only alignment padding may lie between two items of a run: the span travels as ONE
+                // copy, and a larger hole is somebody else's bytes (the batch's inline window, a file
+                // another thread is staging) that this copy must not overwrite
+                if (f.arena_off < prev_end || f.arena_off - prev_end >= kFileAlign) break;
+                prev_end = f.arena_off + f.len;
                 run.push_back(f);
                 st->queue.pop_front();
             }
@@ -118,9 +125,15 @@ void worker(Stager* st) {
             if (it.src) {
                 memcpy(dst, it.src, it.len);
             } else {
+                // a deferred file (bulk adds, tree walks) is opened HERE, by one of several threads
+                int fd = it.file->fd, own = -1;
+                if (fd < 0) {
+                    own = fd = open(it.file->path.c_str(), O_RDONLY | O_CLOEXEC);
+                    if (fd < 0) { err = "open " + it.file->path + ": " + strerror(errno); break; }
+                }
                 u64 got = 0;
                 while (got < it.len) {
-                    const ssize_t r = pread(it.file->fd, dst + got, it.len - got, (off_t)(it.file_off + got));
+                    const ssize_t r = pread(fd, dst + got, it.len - got, (off_t)(it.file_off + got));
                     if (r < 0 && errno == EINTR) continue;
                     if (r <= 0) {
                         err = "read " + it.file->path + ": " +
@@ -129,6 +142,7 @@ void worker(Stager* st) {
                     }
                     got += (u64)r;
                 }
+                if (own >= 0) close(own);
             }
             end = it.arena_off + it.len;
         }
@@ -198,6 +212,32 @@ int stager_put_file(Stager* st, mi_batch* b, u64 arena_off, int fd, u64 file_off
     f->fd = fd;
     f->path = path ? path : "";
     if (len) enqueue(st, b, arena_off, len, nullptr, f, file_off, nullptr);
+    return MI_OK;
+}
+
+// n whole files that the reader threads open themselves: one lock, one wake-up for all of them
+int stager_put_paths(Stager* st, mi_batch* b, u64 n, const char* const* paths, const u64* arena_off,
+                     const u64* len) {
+    std::vector<StageItem> items;
+    items.reserve(n);
+    for (u64 i = 0; i < n; ++i) {
+        if (len[i] == 0) continue;
+        auto f = std::make_shared<StageFile>();
+        f->fd = -1;
+        f->path = paths[i];
+        for (u64 done = 0; done < len[i];) {
+            const u64 take = len[i] - done < st->slab_bytes ? len[i] - done : st->slab_bytes;
+            items.push_back({b, arena_off[i] + done, take, nullptr, f, done, nullptr});
+            done += take;
+        }
+    }
+    if (items.empty()) return MI_OK;
+    {
+        std::lock_guard<std::mutex> g(st->mu);
+        b->stage_pending += items.size();
+        for (auto& it : items) st->queue.push_back(std::move(it));
+    }
+    st->cv_work.notify_all();
     return MI_OK;
 }
 
