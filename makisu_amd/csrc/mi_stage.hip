@@ -195,7 +195,8 @@ static void enqueue(Stager* st, mi_batch* b, u64 arena_off, u64 len, const u8* s
         b->stage_pending += items.size();
         for (auto& it : items) st->queue.push_back(std::move(it));
     }
-    st->cv_work.notify_all();
+    if (items.size() == 1) st->cv_work.notify_one();      // one small file: one reader, not the whole pool
+    else st->cv_work.notify_all();
 }
 
 int stager_put_bytes(Stager* st, mi_batch* b, u64 arena_off, const void* src, u64 len) {
