@@ -42,5 +42,9 @@ for g in 1000 0; do
   [ -n "$db" ] && python tools/prof_summary.py $db 2>&1 | grep "sha256_items_kernel<0"
   rm -rf $out/utcl_$g
   MI_SHA_COOP_MIN_GIB=$g timeout 100 python tools/quick_bench.py --files 240 --size 134217728 --steps 4 2>&1 | grep inflight | tail -1
+  MI_SHA_COOP_MIN_GIB=$g $T rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/fs_$g -o p -- python tools/quick_bench.py --files 240 --size 134217728 --steps 2 > $out/fs_$g.log 2>&1
+  db=$(find $out/fs_$g -name "*_results.db" | head -1)
+  [ -n "$db" ] && python tools/prof_summary.py $db 2>&1 | grep "sha256_items_kernel<0.*FETCH_SIZE"
+  rm -rf $out/fs_$g
 done > $out/${tag}_sha_schemes_32gb.txt
 ls -la $out
