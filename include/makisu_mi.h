@@ -341,6 +341,9 @@ typedef struct {
                                   inodes like the reference's snapshot may set it)       */
     uint32_t    uid, gid;
 } mi_tree_entry;
+/* Regular files are handed to the batch in bulk while the walk goes on (mi_batch_add_paths: the
+ * reader threads open them); a file that vanishes or shrinks between the walk's lstat and the read
+ * fails mi_batch_run / mi_batch_submit with MI_ERR_IO naming it.                                 */
 int mi_batch_add_tree(mi_batch* b, const char* root, const char* rel_base,
                       const char* const* blacklist, uint64_t n_blacklist, uint32_t mode,
                       uint64_t* n_entries);
