@@ -217,7 +217,8 @@ int mi_batch_free(mi_batch* b);
  *     then mi_batch_submit / mi_batch_run as usual.
  * Submitting a batch that holds a part with an unconfirmed entry is MI_ERR_STATE.
  * Results: mi_chunk_result.offset is the offset inside the WHOLE file; mi_file_result.size is
- * end - begin, chunk_root covers the part's own chunks only, file_sha256 / crc32 are zero.      */
+ * end - begin, chunk_root covers the part's own chunks only (the file's root: mi_chunk_root over
+ * the parts' digests), file_sha256 / crc32 are zero.                                           */
 #define MI_PART_ALIGN 262144u
 typedef struct {
     uint64_t file_index;       /* the part's row in this batch's file table                       */
@@ -233,6 +234,10 @@ int mi_batch_add_path_part(mi_batch* b, const char* path, uint64_t file_size, ui
  * [begin, end) of what mi_batch_add_synthetic generates for that content id                     */
 int mi_batch_add_synthetic_part(mi_batch* b, uint64_t file_size, uint64_t content_id, uint64_t seed,
                                 uint64_t begin, uint64_t end);
+/* The chunk root of a file from its chunk digests (n x 32 bytes, file order) on the host: SHA-256
+ * over the concatenation when n <= 64, else the fan-out-64 tree the engine computes per file.  A
+ * split file's root = mi_chunk_root over its parts' digests put end to end.                     */
+int mi_chunk_root(const uint8_t* digests, uint64_t n, uint8_t* root_out);
 /* Blocking: stages the batch and runs Gear marking + cut selection only.                         */
 int mi_batch_scan_cuts(mi_batch* b);
 int mi_batch_parts(mi_batch* b, mi_part_state* out, uint64_t cap, uint64_t* n_parts);

@@ -165,6 +165,7 @@ def load_library(rebuild=False):
         "mi_batch_add_synthetic": ([vp, u64, u64p, u64p, u64], C.c_int),
         "mi_batch_add_path_part": ([vp, C.c_char_p, u64, u64, u64, u64], C.c_int),
         "mi_batch_add_synthetic_part": ([vp, u64, u64, u64, u64, u64], C.c_int),
+        "mi_chunk_root": ([vp, u64, vp], C.c_int),
         "mi_batch_scan_cuts": ([vp], C.c_int),
         "mi_batch_parts": ([vp, C.POINTER(PartState), u64, u64p], C.c_int),
         "mi_batch_set_part_entry": ([vp, u64, u64], C.c_int),
@@ -529,6 +530,18 @@ def layer_header_bytes(entry):
     if rc:
         raise MiError(rc, "mi_layer_header_bytes")
     return bytes(buf[: n.value])
+
+
+def chunk_root(digests):
+    """mi_chunk_root: the file-level root of a list of chunk digests (bytes-like of n x 32, or an
+    (n, 32) uint8 array) -- what a split file's parts combine to."""
+    a = np.ascontiguousarray(np.frombuffer(digests, dtype=np.uint8) if not isinstance(digests, np.ndarray) else digests,
+                             dtype=np.uint8).reshape(-1, 32)
+    out = np.zeros(32, dtype=np.uint8)
+    rc = load_library().mi_chunk_root(a.ctypes.data if a.size else None, a.shape[0], out.ctypes.data)
+    if rc:
+        raise MiError(rc, "mi_chunk_root")
+    return out.tobytes()
 
 
 def cache_key(cache_id):

@@ -718,4 +718,32 @@ int mi_cache_parse_entry(const char* entry, int* is_empty, uint8_t* tar_sha256, 
     return MI_OK;
 }
 
+// chunk_root of a digest list on the host: the definition the kernels implement (tables.hip root
+// passes) -- SHA-256 over the concatenation when n <= 64, else a fan-out-64 tree.
+// For a file whose chunk rows come from several batches (parts): concatenate the parts' digests in
+// part order and call this; equals mi_file_result.chunk_root of the file scanned whole.
+int mi_chunk_root(const uint8_t* digests, uint64_t n, uint8_t* root_out) {
+    if ((!digests && n) || !root_out) return MI_ERR_INVALID;
+    const uint64_t F = 64;
+    std::vector<uint8_t> cur, next;
+    const uint8_t* p = digests;
+    while (n > F) {
+        const uint64_t m = (n + F - 1) / F;
+        next.resize(m * 32);
+        for (uint64_t g = 0; g < m; ++g) {
+            const uint64_t cnt = n - g * F < F ? n - g * F : F;
+            mi_host::Sha256 h;
+            h.update(p + g * F * 32, cnt * 32);
+            h.final(&next[g * 32]);
+        }
+        cur.swap(next);
+        p = cur.data();
+        n = m;
+    }
+    mi_host::Sha256 h;
+    h.update(p, n * 32);
+    h.final(root_out);
+    return MI_OK;
+}
+
 }  // extern "C"

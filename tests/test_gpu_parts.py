@@ -360,6 +360,7 @@ def test_parts_of_a_3gib_file_equal_the_whole(oracle):
             b.add_synthetic([n], [cid], seed=SEED)
             b.run()
             whole = b.chunks().copy()
+            whole_root = bytes(b.files()["chunk_root"][0])
         batches = [e.batch() for _ in range(3)]
         try:
             owners = []
@@ -378,6 +379,7 @@ def test_parts_of_a_3gib_file_equal_the_whole(oracle):
     assert len(got) == len(whole)
     assert np.array_equal(got["offset"], whole["offset"]) and np.array_equal(got["length"], whole["length"])
     assert np.array_equal(got["sha256"], whole["sha256"])
+    assert makisu_amd.chunk_root(got["sha256"]) == whole_root       # the parts' digests give the file's root
     rng = np.random.default_rng(4)
     for i in rng.integers(0, len(got), 40):
         r = got[int(i)]

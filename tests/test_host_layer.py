@@ -323,3 +323,14 @@ def test_parallel_gzip_is_one_member_and_independent_of_the_thread_count(tmp_pat
             assert len(blob) < len(tar_bytes) // 2                # the zeros and the text did compress
             blobs.setdefault(level, set()).add(blob)
     assert all(len(v) == 1 for v in blobs.values())               # same bytes with 1, 3 and 16 threads
+
+
+def test_chunk_root_helper_equals_the_oracle_definition():
+    """mi_chunk_root (host): flat below 65 digests, fan-out-64 tree above -- the oracle's
+    mi_ref_chunk_root on the same lists, including the sizes where a level appears."""
+    import numpy as np
+    from oracle import mi_oracle as O
+    rng = np.random.default_rng(3)
+    for n in (0, 1, 2, 63, 64, 65, 128, 129, 4095, 4096, 4097, 70000):
+        dg = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        assert M.chunk_root(dg) == bytes(O.chunk_root(dg)), n
