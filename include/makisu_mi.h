@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 2
+#define MI_ABI_VERSION 3
 
 enum {
     MI_OK = 0,
@@ -56,6 +56,19 @@ enum {
                                       (one packed copy, ~1 ms per 700 k chunks, while the
                                       other batch in flight keeps the GPU busy): the
                                       following mi_batch_chunks_view costs nothing      */
+#define MI_FLAG_VERIFY_STAGING 0x10u /* host-fed batches check their own staged bytes: every
+                                      span a reader thread (or the inline window) copies is
+                                      summed on the host while it sits in the pinned slab and
+                                      summed again on the GPU where it landed -- right after the
+                                      copy and once more, every span of the batch, when staging
+                                      ends (after any arena growth).  A span that differs is
+                                      copied again from the slab; one that still differs, or
+                                      differs at the end, fails the run with MI_ERR_IO naming
+                                      the arena range, the reader thread and what the GPU holds
+                                      there.  io.CopyN must deliver exactly the file's bytes
+                                      (lib/tario/write.go:43-45).  New arena memory is filled
+                                      with 0xA5 first, so a byte that never arrived does not
+                                      read as a plausible zero.  Counters: mi_batch_stage_stats */
 
 typedef struct mi_ctx mi_ctx;
 typedef struct mi_batch mi_batch;
@@ -73,9 +86,21 @@ typedef struct {
     uint32_t flags;           /* MI_FLAG_*                                          */
     uint64_t staging_bytes;   /* bytes per pinned staging slab (0 = 8 MiB)          */
     uint32_t n_streams;       /* reader threads for host-fed batches, one pinned slab
-                                 and one copy stream each (0 = 8)                   */
+                                 and one copy stream each (0 = 8, at most 64)       */
+    /* SHA-256 pass tuning, per ctx (0 = the engine's default).  The defaults
+     * can also be moved for a whole process by MI_SHA_BLOCKS_PER_CU / MI_SHA_COOP_MIN_GIB /
+     * MI_SHA_COOP_BLOCKS_PER_CU, read at mi_ctx_create; a non-zero field here wins.      */
+    uint32_t sha_blocks_per_cu;      /* workgroups per CU of the hashing kernels (default 2, 1..8) */
+    uint32_t sha_load_scheme;        /* MI_SHA_LOADS_*: how a lane fetches its next block      */
+    uint32_t sha_coop_min_gib;       /* MI_SHA_LOADS_AUTO: arena footprint in GiB from which the
+                                        quad-cooperative loads are used (default 9)            */
+    uint32_t sha_coop_blocks_per_cu; /* workgroups per CU with cooperative loads (default: 3 from
+                                        24 GiB up, else sha_blocks_per_cu; 1..3)               */
     uint32_t reserved;
 } mi_config;
+#define MI_SHA_LOADS_AUTO 0u   /* by footprint (sha_coop_min_gib)                            */
+#define MI_SHA_LOADS_LANE 1u   /* every lane loads its own block, byte-aligned               */
+#define MI_SHA_LOADS_COOP 2u   /* the four lanes of a quad fetch one owner's block together  */
 
 /* One result row per file, in the order files were added.  This is what a
  * content-aware MemFS.isUpdated (lib/snapshot/mem_fs.go:487-503) would compare
@@ -116,6 +141,19 @@ typedef struct {
     double   ms_dedup;         /* duplicate marking                                 */
     double   ms_total;         /* first kernel start to last kernel end             */
 } mi_stats;
+
+/* Staging counters of one batch (MI_FLAG_VERIFY_STAGING; all zero without the flag except
+ * spans / bytes).                                                                   */
+typedef struct {
+    uint64_t spans;            /* host->device copies issued (reader-thread runs + inline flushes) */
+    uint64_t bytes;            /* bytes they carried                                       */
+    uint64_t verified_spans;   /* spans summed on both sides right after their copy        */
+    uint64_t mismatches;       /* ... whose sums differed                                  */
+    uint64_t repaired;         /* ... and matched after one more copy from the slab        */
+    uint64_t final_spans;      /* spans summed again when staging ended                    */
+    uint64_t final_mismatches; /* ... that no longer matched (the run fails)               */
+    double   ms_verify;        /* host time spent summing + waiting for the device sums    */
+} mi_stage_stats;
 
 /* ---- context ----------------------------------------------------------------- */
 int  mi_abi_version(void);
@@ -200,6 +238,16 @@ int mi_batch_read_back(mi_batch* b, void* out, uint64_t cap);
  * it -- every time.  Not while in flight.                                                  */
 int mi_batch_reset(mi_batch* b);
 int mi_batch_free(mi_batch* b);
+/* Staging counters since mi_batch_begin / mi_batch_reset (MI_FLAG_VERIFY_STAGING).  A staging
+ * failure (a missing, short or unreadable file, a failed copy, a span that does not verify) is
+ * STICKY: every later mi_batch_run / _submit / _scan_cuts of the batch returns MI_ERR_IO with the
+ * first failure's message until mi_batch_reset -- a failed batch never scans half-staged bytes.   */
+int mi_batch_stage_stats(mi_batch* b, mi_stage_stats* out);
+/* What the first verification mismatch of the batch looked like -- arena range, reader thread, both
+ * pairs of sums, how many bytes differed and what the GPU held there (zeros / the 0xA5 fill / other
+ * data), whether a second copy repaired it; "" if every span verified.  Valid until the batch is
+ * reset or freed.                                                                              */
+const char* mi_batch_stage_note(mi_batch* b);
 
 /* ---- parts: ONE file split across batches / GPUs (files >= 256 MiB) ------------- *
  * No reference counterpart: the reference streams a file through one goroutine

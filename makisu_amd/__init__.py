@@ -15,12 +15,15 @@ import numpy as np
 from . import build as _build
 
 __all__ = ["Engine", "Batch", "Config", "MiError", "load_library", "FILE_DTYPE", "CHUNK_DTYPE",
-           "FLAG_FILE_SHA256", "FLAG_FILE_CRC32", "FLAG_NO_DEDUP", "FLAG_PREFETCH_ROWS", "Digest", "digest_hex"]
+           "FLAG_FILE_SHA256", "FLAG_FILE_CRC32", "FLAG_NO_DEDUP", "FLAG_PREFETCH_ROWS", "FLAG_VERIFY_STAGING",
+           "SHA_LOADS_AUTO", "SHA_LOADS_LANE", "SHA_LOADS_COOP", "Digest", "digest_hex"]
 
 FLAG_FILE_SHA256 = 0x1
 FLAG_FILE_CRC32 = 0x2
 FLAG_NO_DEDUP = 0x4
 FLAG_PREFETCH_ROWS = 0x8
+FLAG_VERIFY_STAGING = 0x10
+SHA_LOADS_AUTO, SHA_LOADS_LANE, SHA_LOADS_COOP = 0, 1, 2
 
 ERR_NAMES = {0: "MI_OK", -1: "MI_ERR_INVALID", -2: "MI_ERR_NO_DEVICE", -3: "MI_ERR_HIP",
              -4: "MI_ERR_NOMEM", -5: "MI_ERR_IO", -6: "MI_ERR_STATE", -7: "MI_ERR_CAPACITY"}
@@ -37,6 +40,8 @@ class Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("gear_seed", C.c_uint64),
                 ("mask_bits", C.c_uint32), ("min_size", C.c_uint32), ("max_size", C.c_uint32),
                 ("flags", C.c_uint32), ("staging_bytes", C.c_uint64), ("n_streams", C.c_uint32),
+                ("sha_blocks_per_cu", C.c_uint32), ("sha_load_scheme", C.c_uint32),
+                ("sha_coop_min_gib", C.c_uint32), ("sha_coop_blocks_per_cu", C.c_uint32),
                 ("reserved", C.c_uint32)]
 
 
@@ -116,6 +121,16 @@ class Stats(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class StageStats(C.Structure):
+    """mi_stage_stats."""
+    _fields_ = [("spans", C.c_uint64), ("bytes", C.c_uint64), ("verified_spans", C.c_uint64),
+                ("mismatches", C.c_uint64), ("repaired", C.c_uint64), ("final_spans", C.c_uint64),
+                ("final_mismatches", C.c_uint64), ("ms_verify", C.c_double)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
 def _np_dtype(struct):
     names, fmts, offs = [], [], []
     for name, ctype in struct._fields_:
@@ -181,6 +196,8 @@ def load_library(rebuild=False):
         "mi_batch_device_digests": ([vp, C.POINTER(vp), u64p], C.c_int),
         "mi_batch_read_back": ([vp, vp, u64], C.c_int),
         "mi_batch_reset": ([vp], C.c_int),
+        "mi_batch_stage_stats": ([vp, C.POINTER(StageStats)], C.c_int),
+        "mi_batch_stage_note": ([vp], C.c_char_p),
         "mi_batch_free": ([vp], C.c_int),
         "mi_dedup_mark": ([vp, vp, u64, vp, u64p], C.c_int),
         "mi_batch_set_global_dedup": ([vp, vp, u64], C.c_int),
@@ -943,6 +960,14 @@ class Batch:
         out = np.zeros(max(n, 1), dtype=np.uint8)
         self._check(self._lib.mi_batch_read_back(self._h, out.ctypes.data, n))
         return out[:n]
+
+    def stage_stats(self):
+        """Staging counters (FLAG_VERIFY_STAGING) + "note": what the first mismatch looked like."""
+        st = StageStats()
+        self._check(self._lib.mi_batch_stage_stats(self._h, C.byref(st)))
+        d = st.as_dict()
+        d["note"] = self._lib.mi_batch_stage_note(self._h).decode(errors="replace")
+        return d
 
     def reset(self):
         """Empty the batch, keep its device memory (next layer, same buffers)."""

@@ -92,6 +92,13 @@ int arena_reserve(mi_batch* b, u64 want) {
     if (b->arena.p) (void)hipFree(b->arena.p);
     b->arena.p = np;
     b->arena.bytes = alloc;
+    if (c->verify_staging) {
+        // a byte that never arrives must not read as a plausible zero: fill what no copy has written
+        // yet, and be done with it before the first host-to-device copy may target it
+        const u64 keep = b->arena_used < alloc ? b->arena_used : alloc;
+        HIPCHK(c, hipMemsetAsync((u8*)np + keep, 0xA5, alloc - keep, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     return MI_OK;
 }
 
@@ -112,12 +119,23 @@ int ensure_ring(mi_batch* b) {
 
 int ensure_stager(mi_ctx* c) {
     if (!c->stager) c->stager = stager_create(c, c->stage_threads, c->staging_bytes);
+    if (!c->stager)
+        return fail(c, MI_ERR_NOMEM, "host-fed staging: none of the %u reader threads could allocate its "
+                    "%llu-byte pinned slab and copy stream", c->stage_threads, (unsigned long long)c->staging_bytes);
     return MI_OK;
 }
 
 int staging_flush(mi_batch* b) {
     mi_ctx* c = b->ctx;
     if (b->win_fill == 0) return MI_OK;
+    {
+        StageSpan sp{b->win_start, b->win_fill, 0, 0, kStageInlineThread};
+        if (c->verify_staging) stage_sum_host(b->ring[b->cur], b->win_fill, &sp.s1, &sp.s2);
+        std::lock_guard<std::mutex> g(b->span_mu);
+        ++b->stage_stats.spans;
+        b->stage_stats.bytes += b->win_fill;
+        if (c->verify_staging) b->stage_spans.push_back(sp);   // summed on the GPU when staging ends
+    }
     HIPCHK(c, hipMemcpyAsync((u8*)b->arena.p + b->win_start, b->ring[b->cur], b->win_fill,
                              hipMemcpyHostToDevice, b->ring_stream));
     HIPCHK(c, hipEventRecord(b->ring_ev[b->cur], b->ring_stream));
@@ -285,7 +303,20 @@ int read_part_states(mi_batch* b) {
 // memory) on the batch's stream: there is no host synchronisation between the stages.  Table
 // sizes come from host-side upper bounds (slots = sum(size/min_size + 2)); the real chunk
 // count lives in device memory (the control block) and every kernel that needs it reads it there.
+int submit_pipeline_enqueue(mi_batch* b);
+
+// in_flight is set only when everything was enqueued: a submit that failed half-way waits for what it
+// did launch and leaves the batch as it was (a following mi_batch_wait is MI_ERR_STATE, not an empty
+// "successful" run)
 int submit_pipeline(mi_batch* b) {
+    b->in_flight = false;
+    const int rc = submit_pipeline_enqueue(b);
+    if (rc == MI_OK) b->in_flight = true;
+    else (void)hipStreamSynchronize(b->stream);
+    return rc;
+}
+
+int submit_pipeline_enqueue(mi_batch* b) {
     mi_ctx* c = b->ctx;
     hipStream_t s = b->stream;
     const u64 nf = b->files.size();
@@ -296,12 +327,10 @@ int submit_pipeline(mi_batch* b) {
     b->stats.ms_h2d = b->ms_h2d;
     b->n_chunks = 0;
     b->h_counts[0] = b->h_counts[1] = 0;
-    b->in_flight = true;
     if (nf == 0) return MI_OK;
     if (nf >= 0x7FFFFFFFull) return fail(c, MI_ERR_INVALID, "too many files in one batch");
     for (const PartRec& p : b->parts)
         if (p.halo_groups && !p.confirmed) {
-            b->in_flight = false;
             return fail(c, MI_ERR_STATE, "file %llu is a part whose entry cut is not confirmed: "
                         "mi_batch_scan_cuts, exchange the exits, mi_batch_set_part_entry",
                         (unsigned long long)p.file_index);
@@ -378,7 +407,7 @@ int submit_pipeline(mi_batch* b) {
     HIPCHK(c, hipEventRecord(b->ev[2], s));
     launch_sha256_items(kShaChunks, b->arena.as<u8>(), b->q_off.as<u64>(), b->q_len.as<u64>(),
                         b->q_id.as<u32>(), (u32)cap, d_n, heads(0), false,
-                        b->digests.as<u8>(), c->sha_blocks_per_cu, ncu, b->arena_used, s);
+                        b->digests.as<u8>(), c->sha, ncu, b->arena_used, s);
     HIPCHK(c, hipEventRecord(b->ev[3], s));
     // per-file chunk roots: fan-out-64 tree; reduction passes only exist for files with more than
     // 64 chunks (> ~0.5 MiB), the final pass hashes every file's <= 64 nodes
@@ -410,7 +439,7 @@ int submit_pipeline(mi_batch* b) {
             launch_sha256_items(kShaRoots, nullptr, b->root_items_off.as<u64>(),
                                 b->root_items_len.as<u64>(), nullptr, (u32)out_ub,
                                 b->rseg_total.as<u64>(), heads(3 + r), false,
-                                b->root_level[r].as<u8>(), c->sha_blocks_per_cu, ncu, 0, s);
+                                b->root_level[r].as<u8>(), c->sha, ncu, 0, s);
             nodes_ub = out_ub;
             std::swap(cur_addr, next_addr);
             std::swap(cur_cnt, next_cnt);
@@ -419,10 +448,10 @@ int submit_pipeline(mi_batch* b) {
     }
     launch_sha256_items(kShaRoots, nullptr, b->item_off.as<u64>(), b->item_len.as<u64>(), nullptr,
                         (u32)nf, nullptr, heads(1), false, b->roots.as<u8>(),
-                        c->sha_blocks_per_cu, ncu, 0, s);
+                        c->sha, ncu, 0, s);
     if (c->cfg.flags & MI_FLAG_FILE_SHA256)
         launch_sha256_items(kShaFiles, b->arena.as<u8>(), d_off, d_size, nullptr, (u32)nf, nullptr,
-                            heads(2), false, b->file_sha.as<u8>(), c->sha_blocks_per_cu, ncu, b->arena_used, s);
+                            heads(2), false, b->file_sha.as<u8>(), c->sha, ncu, b->arena_used, s);
     if (c->cfg.flags & MI_FLAG_FILE_CRC32) {
         HIPCHK(c, b->tile_raw.ensure(b->n_tiles * 4 + 16));
         HIPCHK(c, b->crc_d.ensure(nf * 4));
@@ -583,6 +612,9 @@ int mi_ctx_create(const mi_config* cfg, mi_ctx** out) {
         cfg->max_size > (1u << 30))
         return fail(nullptr, MI_ERR_INVALID,
                     "mi_ctx_create: need mask_bits<=32, 64<=min_size<=max_size<=2^30");
+    if (cfg->sha_load_scheme > MI_SHA_LOADS_COOP)
+        return fail(nullptr, MI_ERR_INVALID, "mi_ctx_create: sha_load_scheme %u is not an MI_SHA_LOADS_* value",
+                    cfg->sha_load_scheme);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(nullptr, MI_ERR_NO_DEVICE,
@@ -621,10 +653,21 @@ int mi_ctx_create(const mi_config* cfg, mi_ctx** out) {
     // host-fed staging (mi_stage.hip): slab bytes and reader threads; both lazily allocated
     c->staging_bytes = cfg->staging_bytes ? cfg->staging_bytes : (8ull << 20);
     if (c->staging_bytes < (1ull << 16)) c->staging_bytes = 1ull << 16;
+    if (c->staging_bytes > (1ull << 30)) c->staging_bytes = 1ull << 30;
+    c->staging_bytes = (c->staging_bytes + 4095) / 4096 * 4096;   // spans start 8-byte aligned (stage_sum_kernel)
     c->stage_threads = cfg->n_streams ? cfg->n_streams : 8;    // 8 readers already saturate PCIe Gen5 x16
     if (const char* e = getenv("MI_STAGE_THREADS")) {
         int v = atoi(e);
         if (v >= 1 && v <= 64) c->stage_threads = (u32)v;
+    }
+    // every reader owns a pinned slab and a stream: a byte-like number from an old caller must not
+    // spawn thousands of them
+    if (c->stage_threads > 64) c->stage_threads = 64;
+    c->verify_staging = (cfg->flags & MI_FLAG_VERIFY_STAGING) != 0;
+    if (const char* e = getenv("MI_VERIFY_STAGING")) c->verify_staging = atoi(e) != 0;
+    if (const char* e = getenv("MI_STAGE_FAULT")) {
+        if (!strncmp(e, "copy:", 5)) c->fault_copy = atoll(e + 5);
+        if (!strncmp(e, "final:", 6)) c->fault_final = atoll(e + 6);
     }
     // Gear table: first 256 outputs of splitmix64(seed)
     u64 table[256];
@@ -643,10 +686,22 @@ int mi_ctx_create(const mi_config* cfg, mi_ctx** out) {
     c->cdc.min_size = cfg->min_size;
     c->cdc.max_size = cfg->max_size;
     c->cdc.pad = 0;
+    // hashing launches: mi_config.sha_* per ctx; the environment only moves the defaults
     if (const char* e = getenv("MI_SHA_BLOCKS_PER_CU")) {
         int v = atoi(e);
-        if (v >= 1 && v <= 8) c->sha_blocks_per_cu = v;
+        if (v >= 1 && v <= 8) c->sha.blocks_per_cu = v;
     }
+    if (const char* e = getenv("MI_SHA_COOP_MIN_GIB")) c->sha.coop_min_bytes = (u64)(atof(e) * 1073741824.0);
+    if (const char* e = getenv("MI_SHA_COOP_BLOCKS_PER_CU")) {
+        int v = atoi(e);
+        if (v >= 1 && v <= 3) c->sha.coop_blocks_per_cu = v;
+    }
+    if (cfg->sha_blocks_per_cu >= 1 && cfg->sha_blocks_per_cu <= 8) c->sha.blocks_per_cu = (int)cfg->sha_blocks_per_cu;
+    if (cfg->sha_coop_min_gib) c->sha.coop_min_bytes = (u64)cfg->sha_coop_min_gib << 30;
+    if (cfg->sha_load_scheme == MI_SHA_LOADS_LANE) c->sha.coop_min_bytes = ~0ull;
+    if (cfg->sha_load_scheme == MI_SHA_LOADS_COOP) c->sha.coop_min_bytes = 0;
+    if (cfg->sha_coop_blocks_per_cu >= 1 && cfg->sha_coop_blocks_per_cu <= 3)
+        c->sha.coop_blocks_per_cu = (int)cfg->sha_coop_blocks_per_cu;
     memset(&c->stats, 0, sizeof c->stats);
 #undef CREATE_CHK
     *out = c;
@@ -696,6 +751,7 @@ int mi_batch_begin(mi_ctx* c, uint64_t n_files_hint, uint64_t bytes_hint, mi_bat
     mi_batch* b = new mi_batch();
     b->ctx = c;
     memset(&b->stats, 0, sizeof b->stats);
+    memset(&b->stage_stats, 0, sizeof b->stage_stats);
     b->files.reserve(n_files_hint);
     hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
     for (auto& ev : b->ev) if (e == hipSuccess) e = hipEventCreate(&ev);
@@ -980,6 +1036,9 @@ static int stage_batch(mi_batch* b) {
     if (rc) return rc;
     rc = staging_sync(b);                       // everything the reader threads hold has landed
     if (rc) return rc;
+    if (!b->stage_err.empty())                  // sticky (a failed final verification, a batch without readers)
+        return fail(c, MI_ERR_IO, "%s", b->stage_err.c_str());
+    if (c->verify_staging && (rc = stage_verify_final(b))) return rc;
     if (b->staged_any)          // host->device staging time: ring memcpy/pread + waits + final drain
         b->ms_h2d += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     const u64 nf = b->files.size();
@@ -1135,8 +1194,14 @@ int mi_batch_reset(mi_batch* b) {
     HIPCHK(c, hipSetDevice(c->device));
     if (b->in_flight) return fail(c, MI_ERR_STATE, "batch is in flight; mi_batch_wait first");
     int rc = staging_sync(b);                           // nothing may still be writing into the arena
+    (void)rc;                                           // a sticky staging failure ends here
     b->stage_err.clear();
-    (void)rc;
+    b->stage_note.clear();
+    {
+        std::lock_guard<std::mutex> g(b->span_mu);
+        b->stage_spans.clear();
+        memset(&b->stage_stats, 0, sizeof b->stage_stats);
+    }
     if (b->tree) { mi_batch_tree_free(b->tree); b->tree = nullptr; }
     b->files.clear();
     b->synth.clear();
@@ -1152,6 +1217,19 @@ int mi_batch_reset(mi_batch* b) {
     b->h_files.clear();
     memset(&b->stats, 0, sizeof b->stats);
     return MI_OK;
+}
+
+int mi_batch_stage_stats(mi_batch* b, mi_stage_stats* out) {
+    if (!b || !out) return MI_ERR_INVALID;
+    std::lock_guard<std::mutex> g(b->span_mu);
+    *out = b->stage_stats;
+    return MI_OK;
+}
+
+const char* mi_batch_stage_note(mi_batch* b) {
+    if (!b) return "";
+    std::lock_guard<std::mutex> g(b->span_mu);
+    return b->stage_note.c_str();
 }
 
 int mi_batch_counts(mi_batch* b, uint64_t* n_files, uint64_t* n_chunks, uint64_t* n_bytes) {
@@ -1256,7 +1334,7 @@ int mi_batch_free(mi_batch* b) {
                       &b->n_chunks_d, &b->first, &b->scratch,
                       &b->chunk_off, &b->chunk_len, &b->chunk_file, &b->chunk_start, &b->digests, &b->item_off, &b->item_len, &b->roots,
                       &b->file_sha, &b->dup_of, &b->file_flags, &b->part_file, &b->part_group0, &b->part_halo,
-                      &b->part_entry, &b->rows_d, &b->file_base};
+                      &b->part_entry, &b->rows_d, &b->file_base, &b->span_off, &b->span_len, &b->span_sums};
     for (DevBuf* d : bufs) d->release();
     delete b;
     return MI_OK;
@@ -1387,7 +1465,7 @@ int mi_sha256_many(mi_ctx* c, const void* data, const uint64_t* offsets, const u
         if (e == hipSuccess) e = hipMemcpy(d_len.p, lens, n * 8, hipMemcpyHostToDevice);
         if (e == hipSuccess) {
             launch_sha256_items(kShaBlobs, d_data.as<u8>(), d_off.as<u64>(), d_len.as<u64>(), nullptr, (u32)n,
-                                nullptr, c->heads.as<u32>(), true, d_out.as<u8>(), c->sha_blocks_per_cu,
+                                nullptr, c->heads.as<u32>(), true, d_out.as<u8>(), c->sha,
                                 c->prop.multiProcessorCount, span, c->stream);
             e = hipStreamSynchronize(c->stream);
         }

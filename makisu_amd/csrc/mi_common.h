@@ -101,11 +101,18 @@ void   launch_gear_parts(const GearLaunch& a, const u32* d_part_file, const u32*
 // base[off[p] .. +len[p]) whose digest goes to out[32 * (ids ? ids[p] : p)]; positions are
 // consumed in order, so put the longest strings first.  heads = kShaQueues words.
 enum ShaPass { kShaChunks = 0, kShaRoots = 1, kShaFiles = 2, kShaBlobs = 3 };
+// per-ctx tuning of the hashing launches (mi_config.sha_*)
+struct ShaTune {
+    int blocks_per_cu = 2;                   // workgroups per CU
+    u64 coop_min_bytes = 9ull << 30;         // footprint from which the quad-cooperative loads are used
+                                             // (0 = always, ~0 = never)
+    int coop_blocks_per_cu = 0;              // 0 = 3 from 24 GiB up, else blocks_per_cu
+};
 // n = string count (or its upper bound when d_n, a device word holding the real count, is given)
 // d_heads must be zero on entry unless zero_heads (then the launcher clears it first)
 void launch_sha256_items(ShaPass pass, const u8* d_base, const u64* d_off, const u64* d_len,
                          const u32* d_ids, u32 n, const u64* d_n, u32* d_heads, bool zero_heads,
-                         u8* d_out, int blocks_per_cu, int n_cu, u64 footprint_bytes, hipStream_t s);
+                         u8* d_out, const ShaTune& tune, int n_cu, u64 footprint_bytes, hipStream_t s);
 // footprint_bytes: the span of memory the strings lie in (picks the load scheme, sha256.hip kCoop)
 
 // tables.hip

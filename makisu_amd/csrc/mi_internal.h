@@ -5,6 +5,7 @@
 #include "../../include/makisu_mi.h"
 #include "mi_common.h"
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -41,8 +42,22 @@ struct PartRec {
 // sets the ctx's (or, for c == nullptr, the create-time) error message; returns code
 int fail(mi_ctx* c, int code, const char* fmt, ...);
 
+// One host->device copy of a host-fed batch, with the sums of the bytes it carried
+// (MI_FLAG_VERIFY_STAGING): words w_0..w_{n-1} = the span as little-endian u64, the tail
+// zero-padded; s1 = sum w_i, s2 = sum (n - i) w_i (mod 2^64) -- what `s1 += w; s2 += s1` leaves.
+struct StageSpan { u64 off, len, s1, s2; u32 thread; };
+constexpr u32 kStageInlineThread = 0xFFFFu;        // the calling thread's inline window
+void stage_sum_host(const void* p, u64 len, u64* s1, u64* s2);
+// device sums of n spans of `base` (offsets 8-byte aligned) into d_out[2 * i .. +2), zeroed here
+void launch_stage_sums(const u8* base, const u64* d_off, const u64* d_len, u64 n, u64 max_len, u64* d_out,
+                       hipStream_t s);
+// every recorded span of the batch summed again where it lies now (after the readers drained, after
+// any arena growth); MI_ERR_IO naming the first span that differs
+int stage_verify_final(mi_batch* b);
+
 // mi_stage.hip: reader threads + pinned slabs behind mi_batch_add_path / large mi_batch_add_bytes
 struct Stager;
+// nullptr when no reader thread could get its pinned slab and stream
 Stager* stager_create(mi_ctx* c, u32 n_threads, u64 slab_bytes);
 void    stager_destroy(Stager* st);
 int     stager_put_bytes(Stager* st, mi_batch* b, u64 arena_off, const void* src, u64 len);
@@ -67,7 +82,11 @@ struct mi_ctx {
     mi::DevBuf dd_tag;                                  // ... and of mi_dedup_mark_range
     mi::u64* h_word = nullptr;           // pinned: small read-backs on the ctx stream
     hipEvent_t ev[2];
-    int sha_blocks_per_cu = 2;
+    mi::ShaTune sha;                     // per ctx (mi_config.sha_*), not per process
+    bool verify_staging = false;         // MI_FLAG_VERIFY_STAGING
+    // fault injection for the tests of that flag (MI_STAGE_FAULT=copy:N | final:N): the N-th span a
+    // reader copies loses 4 KiB right after its copy / just before the end-of-staging pass
+    long long fault_copy = -1, fault_final = -1;
     mi::CdcParams cdc;
     void* comm = nullptr;                // ncclComm_t when mi_comm_init_* was called (mi_comm.hip)
     int comm_rank = 0, comm_nranks = 1;
@@ -99,7 +118,12 @@ struct mi_batch {
     bool staged_any = false;
     // reader-thread staging (mi_stage.hip); guarded by the stager's mutex
     mi::u64 stage_pending = 0;   // queued pieces not yet in HBM
-    std::string stage_err;       // first read / copy error
+    std::string stage_err;       // first read / copy / verification error: STICKY until mi_batch_reset
+    std::string stage_note;      // what the first verification mismatch looked like (even if repaired)
+    std::mutex span_mu;          // guards the three below (reader threads + the inline window)
+    std::vector<mi::StageSpan> stage_spans;   // MI_FLAG_VERIFY_STAGING: every copy, for the final pass
+    mi_stage_stats stage_stats;
+    mi::DevBuf span_off, span_len, span_sums;
     double ms_h2d = 0;
     // pipeline state: every batch owns a stream, so two batches can be in flight and the
     // Gear pass of one overlaps the SHA pass of the other (they bind different units)

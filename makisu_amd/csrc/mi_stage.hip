@@ -6,7 +6,9 @@
 // io.CopyN(w, f, h.Size) in 32 KiB pieces on one goroutine).  Here the files of a batch are read
 // by several threads at once, consecutive small files share one slab (one PCIe transfer per
 // ~8 MiB, not per file), and the transfer of one thread's slab overlaps the other threads' reads.
-// Host code only (no kernels); lives next to the engine because it owns HIP streams.
+// MI_FLAG_VERIFY_STAGING: every copy is summed on the host (in the slab) and on the GPU (where it
+// landed) -- stage_sum_kernel below, the one kernel of this file --, copied again if the sums
+// differ, and summed once more when staging ends (stage_verify_final).
 #include "mi_internal.h"
 
 #include <errno.h>
@@ -14,6 +16,8 @@
 #include <string.h>
 #include <unistd.h>
 
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <memory>
@@ -53,14 +57,99 @@ struct Stager {
     std::condition_variable cv_work, cv_done;
     std::deque<StageItem> queue;
     bool stop = false;
+    u32 init_left = 0, n_ok = 0;         // reader threads still setting up / that got slab + stream
+    std::atomic<long long> spans_copied{0};   // fault injection (MI_STAGE_FAULT) counts spans with it
+    std::condition_variable cv_init;
 };
 
-namespace {
-
-void batch_fail(Stager* st, mi_batch* b, const std::string& msg) {
-    std::lock_guard<std::mutex> g(st->mu);
-    if (b->stage_err.empty()) b->stage_err = msg;
+// ---- span sums (MI_FLAG_VERIFY_STAGING) --------------------------------------------------------
+void stage_sum_host(const void* p, u64 len, u64* s1_out, u64* s2_out) {
+    const u8* b = (const u8*)p;
+    const u64 n = len / 8;
+    u64 s1 = 0, s2 = 0;
+    for (u64 i = 0; i < n; ++i) {
+        u64 w;
+        memcpy(&w, b + 8 * i, 8);
+        s1 += w;
+        s2 += s1;
+    }
+    if (len & 7) {
+        u64 w = 0;
+        memcpy(&w, b + 8 * n, len & 7);
+        s1 += w;
+        s2 += s1;
+    }
+    *s1_out = s1;
+    *s2_out = s2;
 }
+
+constexpr u32 kSumTile = 65536;          // bytes one workgroup sums
+
+// grid (spans, tiles): workgroup (i, t) sums words [8192 t, +8192) of span i (striding over t when a
+// span has more tiles than the grid is high); 16-byte loads, a wave touches 1 KiB per instruction
+__global__ __launch_bounds__(256)
+void stage_sum_kernel(const u8* __restrict__ base, const u64* __restrict__ off, const u64* __restrict__ len,
+                      u64 n_spans, u64* __restrict__ out) {
+    const u64 i = blockIdx.x;
+    if (i >= n_spans) return;
+    const u64 L = len[i];
+    const u64 n_words = (L + 7) / 8;                     // the tail word is zero-padded
+    const u64 full = L / 8;
+    const u8* p = base + off[i];
+    u64 s1 = 0, s2 = 0;
+    for (u64 t = blockIdx.y; t * (kSumTile / 8) < n_words; t += gridDim.y) {
+        const u64 w0 = t * (kSumTile / 8);
+#pragma unroll 4
+        for (u32 k = 0; k < kSumTile / 16 / 256; ++k) {
+            const u64 idx = w0 + 2ull * (k * 256u + threadIdx.x);   // my two words
+            if (idx >= n_words) break;
+            u64 a = 0, b = 0;
+            if (idx + 1 < full) {
+                const ulonglong2 v = *(const ulonglong2*)(p + 8 * idx);
+                a = v.x;
+                b = v.y;
+            } else {                                       // the span's last words, byte-wise past `full`
+                for (u32 j = 0; j < 16; ++j) {
+                    const u64 at = 8 * idx + j;
+                    if (at < L) {
+                        const u64 v = p[at];
+                        if (j < 8) a |= v << (8 * j); else b |= v << (8 * (j - 8));
+                    }
+                }
+            }
+            s1 += a;
+            s2 += (n_words - idx) * a;
+            if (idx + 1 < n_words) { s1 += b; s2 += (n_words - idx - 1) * b; }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        s1 += __shfl_xor(s1, d);
+        s2 += __shfl_xor(s2, d);
+    }
+    __shared__ u64 part[2][4];
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { part[0][wave] = s1; part[1][wave] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const u64 a = part[0][0] + part[0][1] + part[0][2] + part[0][3];
+        const u64 b = part[1][0] + part[1][1] + part[1][2] + part[1][3];
+        if (a) atomicAdd((unsigned long long*)&out[2 * i], (unsigned long long)a);
+        if (b) atomicAdd((unsigned long long*)&out[2 * i + 1], (unsigned long long)b);
+    }
+}
+
+void launch_stage_sums(const u8* base, const u64* d_off, const u64* d_len, u64 n, u64 max_len, u64* d_out,
+                       hipStream_t s) {
+    if (n == 0) return;
+    (void)hipMemsetAsync(d_out, 0, n * 16, s);
+    u64 tiles = (max_len + kSumTile - 1) / kSumTile;
+    if (tiles == 0) tiles = 1;
+    if (tiles > 1024) tiles = 1024;
+    hipLaunchKernelGGL(stage_sum_kernel, dim3((u32)n, (u32)tiles), dim3(256), 0, s, base, d_off, d_len, n, d_out);
+}
+
+namespace {
 
 // the item's source bytes sit in a pinned slab: a blocking adder may return (cgo pointer rule)
 void item_consumed(const StageItem& it) {
@@ -79,20 +168,61 @@ void item_landed(Stager* st, const StageItem& it) {
     if (wake) st->cv_done.notify_all();
 }
 
+// what the GPU holds in [dev, dev+len) next to what it should hold: one line for the error message
+static std::string describe_span(const u8* dev, const u8* want, u64 len, hipStream_t stream) {
+    std::vector<u8> got(len);
+    if (hipMemcpyAsync(got.data(), dev, len, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+        hipStreamSynchronize(stream) != hipSuccess)
+        return "(read-back failed)";
+    u64 first = ~0ull, last = 0, n = 0;
+    bool zeros = true, poison = true;
+    for (u64 i = 0; i < len; ++i) {
+        const bool differs = want ? got[i] != want[i] : true;
+        if (!differs) continue;
+        if (first == ~0ull) first = i;
+        last = i;
+        ++n;
+        zeros = zeros && got[i] == 0;
+        poison = poison && got[i] == 0xA5;
+    }
+    char buf[256];
+    if (want)
+        snprintf(buf, sizeof buf, "%llu byte(s) differ in [+%llu, +%llu], the GPU holds %s there",
+                 (unsigned long long)n, (unsigned long long)first, (unsigned long long)last,
+                 n == 0 ? "the right bytes (the sums raced a later write?)" : zeros ? "zeros" :
+                 poison ? "the 0xA5 fill of new arena memory (the copy never landed)" : "other data");
+    else
+        snprintf(buf, sizeof buf, "the GPU holds %s there",
+                 zeros ? "zeros" : poison ? "the 0xA5 fill of new arena memory" : "other data");
+    return buf;
+}
+
 // One reader thread: pops a run of queued items whose arena span fits its slab, fills the slab
 // (slab offset = arena offset - span start, so alignment gaps between files travel as they are),
 // issues ONE H2D copy for the span on its own stream and waits for it; the other threads read and
 // copy meanwhile, so PCIe stays busy without any cross-thread event hand-over.  A blocking
 // mi_batch_add_bytes returns as soon as its pieces sit in slabs, before their transfers finish.
-void worker(Stager* st) {
+void worker(Stager* st, u32 tid) {
     mi_ctx* c = st->ctx;
     (void)hipSetDevice(c->device);
     hipStream_t stream = nullptr;
     void* slab = nullptr;
+    u64* d_sums = nullptr;                                   // {off, len, s1, s2} on the device
+    u64* h_sums = nullptr;                                   // ... and pinned: [0..1] in, [2..3] out
     bool ok = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipHostMalloc(&slab, st->slab_bytes, hipHostMallocDefault) == hipSuccess;
+    if (c->verify_staging) {
+        ok = ok && hipMalloc((void**)&d_sums, 32) == hipSuccess;
+        ok = ok && hipHostMalloc((void**)&h_sums, 32, hipHostMallocDefault) == hipSuccess;
+    }
+    {
+        std::lock_guard<std::mutex> g(st->mu);
+        if (ok) ++st->n_ok;
+        --st->init_left;
+    }
+    st->cv_init.notify_all();
     std::vector<StageItem> run;
-    for (;;) {
+    while (ok) {                                             // a thread without slab or stream takes no work
         run.clear();
         {
             std::unique_lock<std::mutex> lk(st->mu);
@@ -116,7 +246,6 @@ void worker(Stager* st) {
         mi_batch* b = run.front().batch;
         const u64 start = run.front().arena_off;
         std::string err;
-        if (!ok) err = "staging thread could not allocate its pinned slab";
         u64 end = start;
         for (const StageItem& it : run) {
             if (!err.empty()) break;
@@ -147,15 +276,87 @@ void worker(Stager* st) {
             end = it.arena_off + it.len;
         }
         for (const StageItem& it : run) item_consumed(it);
-        if (err.empty()) {
-            hipError_t e = hipMemcpyAsync((u8*)b->arena.p + start, slab, end - start, hipMemcpyHostToDevice, stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        const u64 span = end - start;
+        StageSpan sp{start, span, 0, 0, tid};
+        double ms_verify = 0;
+        u64 mism = 0, repaired = 0;
+        std::string note;
+        if (err.empty() && span) {
+            u8* dev = (u8*)b->arena.p + start;
+            auto copy = [&]() -> hipError_t {
+                hipError_t e = hipMemcpyAsync(dev, slab, span, hipMemcpyHostToDevice, stream);
+                return e == hipSuccess ? hipStreamSynchronize(stream) : e;
+            };
+            // device sums of the span as it lies in HBM now
+            auto device_sums = [&](u64* s1, u64* s2) -> hipError_t {
+                h_sums[0] = start;
+                h_sums[1] = span;
+                hipError_t e = hipMemcpyAsync(d_sums, h_sums, 16, hipMemcpyHostToDevice, stream);
+                if (e != hipSuccess) return e;
+                launch_stage_sums((const u8*)b->arena.p, d_sums, d_sums + 1, 1, span, d_sums + 2, stream);
+                e = hipMemcpyAsync(h_sums + 2, d_sums + 2, 16, hipMemcpyDeviceToHost, stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(stream);
+                *s1 = h_sums[2];
+                *s2 = h_sums[3];
+                return e;
+            };
+            hipError_t e = hipSuccess;
+            if (c->verify_staging) {
+                const auto t0 = std::chrono::steady_clock::now();
+                stage_sum_host(slab, span, &sp.s1, &sp.s2);     // before the copy: while it runs the slab is the DMA's
+                ms_verify += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            }
+            e = copy();
+            if (e == hipSuccess && st->spans_copied.fetch_add(1) == c->fault_copy) {      // tests only
+                (void)hipMemsetAsync(dev + span / 2, 0, span / 2 < 4096 ? span / 2 : 4096, stream);
+                (void)hipStreamSynchronize(stream);
+            }
+            if (e == hipSuccess && c->verify_staging) {
+                const auto t0 = std::chrono::steady_clock::now();
+                u64 d1 = 0, d2 = 0;
+                e = device_sums(&d1, &d2);
+                if (e == hipSuccess && (d1 != sp.s1 || d2 != sp.s2)) {
+                    mism = 1;
+                    char head[256];
+                    snprintf(head, sizeof head, "staging verify: arena [%llu, +%llu) of batch %p, reader thread %u: "
+                             "host sums %016llx/%016llx, device %016llx/%016llx; ", (unsigned long long)start,
+                             (unsigned long long)span, (void*)b, tid, (unsigned long long)sp.s1,
+                             (unsigned long long)sp.s2, (unsigned long long)d1, (unsigned long long)d2);
+                    note = head + describe_span(dev, (const u8*)slab, span, stream);
+                    e = copy();                                 // the slab still holds the bytes: once more
+                    if (e == hipSuccess) e = device_sums(&d1, &d2);
+                    if (e == hipSuccess) {
+                        if (d1 == sp.s1 && d2 == sp.s2) { repaired = 1; note += "; a second copy from the slab matched"; }
+                        else err = note + "; a second copy from the slab did not match either";
+                    }
+                }
+                ms_verify += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            }
             if (e != hipSuccess) err = std::string("host-to-device copy (staging): ") + hipGetErrorString(e);
         }
-        if (!err.empty()) batch_fail(st, b, err);
+        if (err.empty() && span) {
+            std::lock_guard<std::mutex> g(b->span_mu);
+            mi_stage_stats& ss = b->stage_stats;
+            ++ss.spans;
+            ss.bytes += span;
+            if (c->verify_staging) {
+                ++ss.verified_spans;
+                ss.mismatches += mism;
+                ss.repaired += repaired;
+                ss.ms_verify += ms_verify;
+                b->stage_spans.push_back(sp);
+                if (mism && b->stage_note.empty()) b->stage_note = note;
+            }
+        }
+        if (!err.empty()) {
+            std::lock_guard<std::mutex> g(st->mu);
+            if (b->stage_err.empty()) b->stage_err = err;
+        }
         for (const StageItem& it : run) item_landed(st, it);
     }
     if (slab) (void)hipHostFree(slab);
+    if (d_sums) (void)hipFree(d_sums);
+    if (h_sums) (void)hipHostFree(h_sums);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -165,7 +366,16 @@ Stager* stager_create(mi_ctx* c, u32 n_threads, u64 slab_bytes) {
     Stager* st = new Stager();
     st->ctx = c;
     st->slab_bytes = slab_bytes;
-    for (u32 i = 0; i < n_threads; ++i) st->threads.emplace_back(worker, st);
+    st->init_left = n_threads;
+    for (u32 i = 0; i < n_threads; ++i) st->threads.emplace_back(worker, st, i);
+    {
+        std::unique_lock<std::mutex> lk(st->mu);
+        st->cv_init.wait(lk, [&] { return st->init_left == 0; });
+    }
+    if (st->n_ok == 0) {                                       // nobody could take work: say so now, not per batch
+        stager_destroy(st);
+        return nullptr;
+    }
     return st;
 }
 
@@ -242,18 +452,77 @@ int stager_put_paths(Stager* st, mi_batch* b, u64 n, const char* const* paths, c
     return MI_OK;
 }
 
-// Blocks until every byte queued for the batch has landed in HBM; returns the first staging error.
+// Blocks until every byte queued for the batch has landed in HBM; returns the batch's first staging
+// error -- STICKY: the message stays with the batch (every later run / submit / add fails the same
+// way) until mi_batch_reset; a failed batch must never be scanned over half-staged bytes.
 int stager_drain(Stager* st, mi_batch* b) {
+    std::string msg;
     {
         std::unique_lock<std::mutex> lk(st->mu);
         st->cv_done.wait(lk, [&] { return b->stage_pending == 0; });
+        msg = b->stage_err;
     }
-    if (!b->stage_err.empty()) {
-        const std::string msg = b->stage_err;
-        b->stage_err.clear();
-        return fail(b->ctx, MI_ERR_IO, "%s", msg.c_str());
-    }
+    if (!msg.empty()) return fail(b->ctx, MI_ERR_IO, "%s", msg.c_str());
     return MI_OK;
+}
+
+// MI_FLAG_VERIFY_STAGING, when staging ends: every span this batch ever copied is summed again
+// where it lies NOW -- after all readers drained and after any arena growth moved it -- in one
+// launch, and compared with the sums taken in the pinned slab.
+int stage_verify_final(mi_batch* b) {
+    mi_ctx* c = b->ctx;
+    std::vector<StageSpan> spans;
+    {
+        std::lock_guard<std::mutex> g(b->span_mu);
+        spans = b->stage_spans;
+    }
+    const u64 n = spans.size();
+    if (n == 0) return MI_OK;
+    if (c->fault_final >= 0 && (u64)c->fault_final < n) {              // tests only
+        const StageSpan& v = spans[c->fault_final];
+        HIPCHK(c, hipMemsetAsync(b->arena.as<u8>() + v.off + v.len / 2, 0, v.len / 2 < 4096 ? v.len / 2 : 4096, c->stream));
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<u64> off(n), len(n), sums(2 * n);
+    u64 max_len = 0;
+    for (u64 i = 0; i < n; ++i) {
+        off[i] = spans[i].off;
+        len[i] = spans[i].len;
+        max_len = len[i] > max_len ? len[i] : max_len;
+    }
+    HIPCHK(c, b->span_off.ensure(n * 8));
+    HIPCHK(c, b->span_len.ensure(n * 8));
+    HIPCHK(c, b->span_sums.ensure(n * 16));
+    HIPCHK(c, hipMemcpyAsync(b->span_off.p, off.data(), n * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(b->span_len.p, len.data(), n * 8, hipMemcpyHostToDevice, c->stream));
+    launch_stage_sums(b->arena.as<u8>(), b->span_off.as<u64>(), b->span_len.as<u64>(), n, max_len,
+                      b->span_sums.as<u64>(), c->stream);
+    HIPCHK(c, hipMemcpyAsync(sums.data(), b->span_sums.p, n * 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    u64 bad = 0, first_bad = 0;
+    for (u64 i = 0; i < n; ++i)
+        if (sums[2 * i] != spans[i].s1 || sums[2 * i + 1] != spans[i].s2) {
+            if (!bad) first_bad = i;
+            ++bad;
+        }
+    b->stage_stats.final_spans += n;
+    b->stage_stats.final_mismatches += bad;
+    b->stage_stats.ms_verify += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (!bad) return MI_OK;
+    const StageSpan& sp = spans[first_bad];
+    char head[320];
+    snprintf(head, sizeof head, "staging verify (end of staging): %llu of %llu span(s) no longer hold what was copied; "
+             "first: arena [%llu, +%llu) of batch %p, %s %u, matched right after its copy: host sums %016llx/%016llx, "
+             "device now %016llx/%016llx; ", (unsigned long long)bad, (unsigned long long)n,
+             (unsigned long long)sp.off, (unsigned long long)sp.len, (void*)b,
+             sp.thread == kStageInlineThread ? "inline window" : "reader thread",
+             sp.thread == kStageInlineThread ? 0u : sp.thread, (unsigned long long)sp.s1, (unsigned long long)sp.s2,
+             (unsigned long long)sums[2 * first_bad], (unsigned long long)sums[2 * first_bad + 1]);
+    const std::string msg = head + describe_span(b->arena.as<u8>() + sp.off, nullptr, sp.len, c->stream);
+    if (b->stage_note.empty()) b->stage_note = msg;
+    b->stage_err = msg;                                        // sticky (stager_drain / stage_batch)
+    return fail(c, MI_ERR_IO, "%s", msg.c_str());
 }
 
 }  // namespace mi

@@ -393,36 +393,18 @@ void sha256_items_kernel(const u8* __restrict__ base, const u64* __restrict__ of
     }
 }
 
-// footprint at or above which the chunk pass loads cooperatively (MI_SHA_COOP_MIN_GIB overrides: 0 =
-// always, a huge value = never)
-static u64 coop_min_bytes() {
-    static const u64 v = [] {
-        const char* e = getenv("MI_SHA_COOP_MIN_GIB");
-        const double gib = e ? atof(e) : 9.0;
-        return (u64)(gib * 1073741824.0);
-    }();
-    return v;
-}
-// ... and with the TLB out of the way a third workgroup per CU pays (161 VGPRs: three waves per SIMD
-// fit): 26 GB arena 1.43 (byte loads, 2/CU) -> 1.57 (cooperative, 2/CU) -> 1.63 TB/s (cooperative, 3/CU);
-// on 6.5 GB three are slower with either scheme (coarser tail).  MI_SHA_COOP_BLOCKS_PER_CU overrides.
-static int coop_blocks_per_cu(u64 footprint_bytes, int blocks_per_cu) {
-    static const int forced = [] {
-        const char* e = getenv("MI_SHA_COOP_BLOCKS_PER_CU");
-        const int n = e ? atoi(e) : 0;
-        return n >= 1 && n <= 3 ? n : 0;
-    }();
-    if (forced) return forced;
-    return footprint_bytes >= (24ull << 30) ? 3 : blocks_per_cu;    // enough work per lane for a third
-}
-
+// With the TLB out of the way (cooperative loads) a third workgroup per CU pays (161 VGPRs: three
+// waves per SIMD fit): 26 GB arena 1.43 (byte loads, 2/CU) -> 1.57 (cooperative, 2/CU) -> 1.63 TB/s
+// (cooperative, 3/CU); on 6.5 GB three are slower with either scheme (coarser tail).
 void launch_sha256_items(ShaPass pass, const u8* d_base, const u64* d_off, const u64* d_len,
                          const u32* d_order, u32 n, const u64* d_n, u32* d_heads, bool zero_heads,
-                         u8* d_out, int blocks_per_cu, int n_cu, u64 footprint_bytes, hipStream_t s) {
+                         u8* d_out, const ShaTune& tune, int n_cu, u64 footprint_bytes, hipStream_t s) {
     if (n == 0) return;
     if (zero_heads) (void)hipMemsetAsync(d_heads, 0, sizeof(u32) * kShaQueues, s);
-    const bool coop = pass != kShaRoots && footprint_bytes >= coop_min_bytes();
-    if (coop) blocks_per_cu = coop_blocks_per_cu(footprint_bytes, blocks_per_cu);
+    const bool coop = pass != kShaRoots && footprint_bytes >= tune.coop_min_bytes;
+    int blocks_per_cu = tune.blocks_per_cu;
+    if (coop) blocks_per_cu = tune.coop_blocks_per_cu ? tune.coop_blocks_per_cu
+                            : footprint_bytes >= (24ull << 30) ? 3 : blocks_per_cu;   // enough work per lane for a third
     u64 want = ((u64)n + kShaWG - 1) / kShaWG;
     u64 cap = (u64)blocks_per_cu * (u64)n_cu;
     u32 grid = (u32)(want < cap ? want : cap);

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol(engine_lib):
 
 def test_abi_version_and_defaults(engine_lib):
     import makisu_amd
-    assert engine_lib.mi_abi_version() == 2
+    assert engine_lib.mi_abi_version() == 3
     cfg = makisu_amd.default_config()
     assert cfg.struct_size == C.sizeof(makisu_amd.Config)
     assert (cfg.gear_seed, cfg.mask_bits, cfg.min_size, cfg.max_size) == (0x4D414B49, 13, 2048, 65536)
@@ -47,6 +47,7 @@ int main(void) {
   printf("%zu %zu %zu %zu\n", sizeof(mi_config), sizeof(mi_file_result), sizeof(mi_chunk_result), sizeof(mi_stats));
   printf("%zu %zu %zu %zu\n", offsetof(mi_file_result, chunk_root), offsetof(mi_file_result, file_sha256),
          offsetof(mi_chunk_result, dup_of), offsetof(mi_chunk_result, sha256));
+  printf("%zu %zu %zu\n", sizeof(mi_stage_stats), offsetof(mi_config, sha_blocks_per_cu), offsetof(mi_config, reserved));
   printf("%zu %zu %zu\n", sizeof(mi_tree_entry), sizeof(mi_ctx_entry), sizeof(mi_snapshot_side));
   printf("%zu %zu %zu %zu %zu %zu\n", offsetof(mi_tree_entry, file_index), offsetof(mi_tree_entry, mtime_sec),
          offsetof(mi_tree_entry, mode), offsetof(mi_tree_entry, kind), offsetof(mi_tree_entry, uid),
@@ -62,6 +63,8 @@ int main(void) {
             C.sizeof(makisu_amd.Stats),
             makisu_amd.FILE_DTYPE.fields["chunk_root"][1], makisu_amd.FILE_DTYPE.fields["file_sha256"][1],
             makisu_amd.CHUNK_DTYPE.fields["dup_of"][1], makisu_amd.CHUNK_DTYPE.fields["sha256"][1]]
+    want += [C.sizeof(makisu_amd.StageStats), makisu_amd.Config.sha_blocks_per_cu.offset,
+             makisu_amd.Config.reserved.offset]
     T, X, S = makisu_amd.TreeEntry, makisu_amd.CtxEntry, makisu_amd.SnapshotSide
     want += [C.sizeof(T), C.sizeof(X), C.sizeof(S),
              T.file_index.offset, T.mtime_sec.offset, T.mode.offset, T.kind.offset, T.uid.offset, T.gid.offset,
@@ -71,7 +74,7 @@ int main(void) {
 
 def test_invalid_config_is_rejected(engine_lib):
     import makisu_amd
-    for kw in ({"min_size": 32}, {"max_size": 1024, "min_size": 2048}, {"mask_bits": 33}):
+    for kw in ({"min_size": 32}, {"max_size": 1024, "min_size": 2048}, {"mask_bits": 33}, {"sha_load_scheme": 3}):
         cfg = makisu_amd.default_config(**kw)
         h = C.c_void_p()
         assert engine_lib.mi_ctx_create(C.byref(cfg), C.byref(h)) == -1

@@ -232,3 +232,231 @@ def test_reader_run_never_writes_over_an_inline_region(oracle, tmp_path):
             b.run()
             assert b.read_back().tobytes() == big + f1 + mid + f2
             _same(b.files(), b.chunks(), *_oracle_rows(oracle, [big, f1, mid, f2], e.cfg))
+
+
+# ---- MI_FLAG_VERIFY_STAGING: staged bytes check themselves ---------------------
+def _mix_inputs(oracle, tmp_path, n_small=300):
+    """The host-fed mix of test_host_fed_mix_large_and_small_files as files on disk + blobs in add order."""
+    big = 1 << 30
+    sizes = [big, 700, big, 65536, 0, big, 1, 4097, big] + [int(x) for x in
+             np.random.default_rng(4).integers(1, 200000, n_small)]
+    cids = list(range(6000, 6000 + len(sizes)))
+    data, offs = oracle.synth_fill_many(SEED + 1, cids, sizes, 8)
+    paths = []
+    for i, (o, n) in enumerate(zip(offs, sizes)):
+        pth = str(tmp_path / ("f%04d" % i))
+        data[int(o):int(o) + n].tofile(pth)
+        paths.append(pth)
+    extra = [oracle.synth_fill(SEED, 6500, 0, 5 << 20).tobytes(), b"tiny", oracle.synth_fill(SEED, 6501, 0, 90000).tobytes()]
+    blobs = []
+    for i, (o, n) in enumerate(zip(offs, sizes)):
+        blobs.append(data[int(o):int(o) + n])
+        if i == 5:
+            blobs += [np.frombuffer(x, dtype=np.uint8) for x in extra]
+    return paths, sizes, extra, blobs
+
+
+def _fill_mix(b, paths, sizes, extra):
+    for i, (pth, n) in enumerate(zip(paths, sizes)):
+        b.add_path(pth, n, i)
+        if i == 5:
+            for x in extra:                     # caller memory between the files
+                b.add_bytes(x)
+
+
+def _first_difference(got, blobs):
+    """Where the staged bytes differ from what was handed in: (file index, first, last, n, 'zeros'|'0xA5'|'other')."""
+    pos = 0
+    for f, want in enumerate(blobs):
+        n = len(want)
+        g = got[pos:pos + n]
+        pos += n
+        neq = np.nonzero(g != want)[0]
+        if len(neq):
+            vals = g[neq]
+            kind = "zeros" if not vals.any() else "0xA5" if (vals == 0xA5).all() else "other"
+            return f, int(neq[0]), int(neq[-1]), len(neq), kind
+    return None
+
+
+def test_verify_staging_clean_run_counts_every_span(oracle, tmp_path):
+    """With the flag every copy is summed on both sides (readers: right after the copy; everything:
+    once more when staging ends, after the arena has grown three times under this batch)."""
+    import makisu_amd
+    paths, sizes, extra, blobs = _mix_inputs(oracle, tmp_path, n_small=120)
+    with makisu_amd.Engine(flags=makisu_amd.FLAG_VERIFY_STAGING) as e, e.batch() as b:
+        _fill_mix(b, paths, sizes, extra)
+        b.run()
+        ss = b.stage_stats()
+        files, chunks = b.files().copy(), b.chunks().copy()
+        assert ss["mismatches"] == 0 and ss["final_mismatches"] == 0 and ss["note"] == "", ss
+        assert ss["spans"] >= 4 * 128 and ss["bytes"] >= sum(len(x) for x in blobs)
+        assert ss["spans"] - 2 <= ss["verified_spans"] < ss["spans"]   # all but the inline window's flush
+        assert ss["final_spans"] == ss["spans"]
+        all_sizes = np.array([len(x) for x in blobs], dtype=np.uint64)
+        all_offs = np.concatenate([[0], np.cumsum(all_sizes)[:-1]]).astype(np.uint64)
+        p = oracle.CdcParams(e.cfg.gear_seed, e.cfg.mask_bits, e.cfg.min_size, e.cfg.max_size)
+        _same(files, chunks, *oracle.scan_batch(np.concatenate(blobs), all_offs, all_sizes, p, True, 16, 0))
+        b.reset()
+        assert b.stage_stats()["spans"] == 0
+
+
+FAULT_CHILD = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+import torch  # noqa: F401
+import makisu_amd
+rng = np.random.default_rng(3)
+blobs = [bytes(rng.integers(0, 256, n, dtype=np.uint8)) for n in (20 << 20, 70000, 3 << 20, 9 << 20)]
+with makisu_amd.Engine(flags=makisu_amd.FLAG_VERIFY_STAGING if %(flag)d else 0, n_streams=2) as e, e.batch() as b:
+    for x in blobs:
+        b.add_bytes(x)
+    try:
+        b.run()
+        print("RAN", b.read_back().tobytes() == b"".join(blobs))
+    except makisu_amd.MiError as err:
+        print("ERR", err.code, err)
+        try:
+            b.run()
+        except makisu_amd.MiError as err2:
+            print("AGAIN", err2.code)
+    ss = b.stage_stats()
+    print("STATS", ss["mismatches"], ss["repaired"], ss["final_mismatches"])
+    print("NOTE", ss["note"])
+"""
+
+
+def _fault_child(fault, flag=1):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MI_STAGE_FAULT=fault)
+    r = subprocess.run([sys.executable, "-c", FAULT_CHILD % {"root": root, "flag": flag}], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    return r.stdout
+
+
+def test_verify_staging_repairs_a_span_lost_right_after_its_copy():
+    """Fault injection (MI_STAGE_FAULT=copy:N zeroes 4 KiB of the N-th span behind its copy): the reader's
+    own check sees it, says what the GPU held, copies the slab again -- the run is right."""
+    out = _fault_child("copy:2")
+    assert "RAN True" in out and "STATS 1 1 0" in out, out
+    assert "reader thread" in out and "byte(s) differ in [+" in out and "the GPU holds zeros there" in out, out
+    assert "a second copy from the slab matched" in out, out
+    # without the flag nobody notices: the bytes are wrong and the run "succeeds" -- what the flag is for
+    out = _fault_child("copy:2", flag=0)
+    assert "RAN False" in out and "STATS 0 0 0" in out, out
+
+
+def test_verify_staging_fails_a_span_lost_later_and_the_failure_is_sticky():
+    """A span that verified after its copy but differs when staging ends cannot be repaired (the slab
+    is gone): MI_ERR_IO naming the range, and the batch keeps failing until it is reset."""
+    out = _fault_child("final:1")
+    assert "ERR -5" in out and "AGAIN -5" in out and "STATS 0 0 1" in out, out
+    assert "end of staging" in out and "no longer hold what was copied" in out, out
+
+
+def test_staging_errors_are_sticky_until_reset(oracle, tmp_path):
+    """a missing file fails the run -- and the NEXT run of the same batch too (it used to
+    scan the uninitialised arena region and return MI_OK); mi_batch_reset clears it."""
+    import makisu_amd
+    good = oracle.synth_fill(SEED, 7200, 0, 300000).tobytes()
+    (tmp_path / "good").write_bytes(good)
+    with makisu_amd.Engine() as e, e.batch() as b:
+        b.add_paths([str(tmp_path / "good"), str(tmp_path / "missing")], [len(good), 10])
+        for _ in range(3):
+            with pytest.raises(makisu_amd.MiError, match="missing") as ei:
+                b.run()
+            assert ei.value.code == -5
+        with pytest.raises(makisu_amd.MiError, match="missing"):
+            b.submit()
+        with pytest.raises(makisu_amd.MiError):
+            b.wait()                                               # nothing was submitted
+        with pytest.raises(makisu_amd.MiError, match="missing"):
+            b.scan_cuts()
+        b.reset()
+        b.add_path(str(tmp_path / "good"))
+        b.run()
+        _same(b.files(), b.chunks(), *_oracle_rows(oracle, [good], e.cfg))
+
+
+def soak(oracle, tmp_path, rounds, verify, big_free_every=10, log=print):
+    """The host-fed mix, `rounds` times: fresh batches (the arena grows three times under the readers),
+    a reset-and-reuse batch, and -- every big_free_every rounds -- right after a batch with a >= 100 GB
+    arena was freed (the window in which the driver is clearing freed VRAM).  Returns
+    dict(rounds, bad_rounds, mismatches, repaired, notes)."""
+    import makisu_amd
+    paths, sizes, extra, blobs = _mix_inputs(oracle, tmp_path)
+    flags = makisu_amd.FLAG_VERIFY_STAGING if verify else 0
+    res = {"rounds": 0, "bad_rounds": 0, "mismatches": 0, "repaired": 0, "final_mismatches": 0, "notes": []}
+    ref = None
+    with makisu_amd.Engine(flags=flags) as e:
+        reused = e.batch()
+        for rnd in range(rounds):
+            if big_free_every and rnd % big_free_every == big_free_every - 1:
+                free_b = int(torch.cuda.mem_get_info()[0]) if torch is not None else 0
+                want = min(110 << 30, free_b - (24 << 30))
+                if want > (8 << 30):
+                    big = e.batch(bytes_hint=want)                 # arena_reserve: one allocation of that size
+                    big.add_bytes(b"x" * 4096)
+                    big.run()
+                    big.free()                                     # ... and straight into the next round
+            b = reused.reset() if rnd % 3 == 2 else e.batch()
+            try:
+                _fill_mix(b, paths, sizes, extra)
+                b.run()
+                roots = b.files()["chunk_root"].copy()
+                ss = b.stage_stats()
+                res["mismatches"] += ss["mismatches"]
+                res["repaired"] += ss["repaired"]
+                res["final_mismatches"] += ss["final_mismatches"]
+                if ss["note"]:
+                    res["notes"].append("round %d: %s" % (rnd, ss["note"]))
+                if ref is None:
+                    ref = roots
+                    all_sizes = np.array([len(x) for x in blobs], dtype=np.uint64)
+                    all_offs = np.concatenate([[0], np.cumsum(all_sizes)[:-1]]).astype(np.uint64)
+                    p = oracle.CdcParams(e.cfg.gear_seed, e.cfg.mask_bits, e.cfg.min_size, e.cfg.max_size)
+                    rf, rc = oracle.scan_batch(np.concatenate(blobs), all_offs, all_sizes, p, True, 16, 0)
+                    _same(b.files(), b.chunks(), rf, rc)
+                elif not np.array_equal(roots, ref):
+                    res["bad_rounds"] += 1
+                    d = _first_difference(b.read_back(), blobs)
+                    res["notes"].append("round %d (%s batch): WRONG RESULT, %d file root(s) differ; staged bytes: %s"
+                                        % (rnd, "reused" if b is reused else "fresh",
+                                           int((roots != ref).any(axis=1).sum()),
+                                           "identical to the input (scan-side?)" if d is None else
+                                           "file %d differs in [%d, %d], %d bytes, GPU holds %s" % d))
+            except makisu_amd.MiError as err:
+                res["bad_rounds"] += 1
+                res["notes"].append("round %d: %s" % (rnd, err))
+                ss = b.stage_stats()
+                res["mismatches"] += ss["mismatches"]
+                res["final_mismatches"] += ss["final_mismatches"]
+                if b is reused:
+                    b.reset()
+            finally:
+                if b is not reused:
+                    b.free()
+            res["rounds"] += 1
+        reused.free()
+    for n in res["notes"]:
+        log(n)
+    return res
+
+
+@pytest.mark.parametrize("verify", [False, True])
+def test_host_fed_soak(oracle, tmp_path, verify):
+    """>= 50 rounds of the 4 x 1 GiB + 300-small mix (25 per mode here; the long
+    runs are tools/stage_soak.py, results in profiles/), including the first copies into fresh VRAM
+    right after a >= 100 GB arena was freed.  Every round must give the first round's (oracle-checked)
+    roots; with the flag no span may have needed its second copy."""
+    rounds = int(os.environ.get("MI_SOAK_ROUNDS", "25"))
+    res = soak(oracle, tmp_path, rounds, verify)
+    assert res["bad_rounds"] == 0, res
+    assert res["final_mismatches"] == 0, res
+    if res["mismatches"]:                                          # repaired: right results, but on record
+        import warnings
+        warnings.warn("staging verification repaired %d span(s): %s" % (res["repaired"], res["notes"]))
