@@ -571,8 +571,16 @@ typedef struct {
     uint32_t struct_size;
     int32_t  gzip_level;       /* MI_GZIP_OFF, MI_GZIP_DEFAULT or 0..9                          */
     int32_t  out_fd;           /* where the layer blob is written; -1 = digests only           */
-    uint32_t reserved;
+    uint32_t flags;            /* MI_LAYER_*                                                    */
 } mi_layer_config;
+/* The header's Mode field keeps the file-type bits of the entry's st_mode (0100755, 040755,
+ * 0120777): what tar.FileInfoHeader produced up to Go 1.8 (Mode |= c_ISREG / c_ISDIR / c_ISLNK) and
+ * what the Go-written layer tars the reference holds as fixtures carry (testdata/files/busybox/
+ * 393ccd5c.../layer.tar).  Without the flag: the Go >= 1.9 rule -- permission bits + setuid / setgid
+ * / sticky only -- which is what createHeader (lib/snapshot/mem_layer.go:152-154) hands to the
+ * writer under the reference's Go 1.14 toolchain.  Everything else in the header is the same, and
+ * with the flag this writer reproduces that fixture byte for byte (tests/test_host_layer.py).     */
+#define MI_LAYER_MODE_WITH_TYPE 0x1u
 typedef struct {
     uint8_t  tar_sha256[32];   /* DigestPair.TarDigest      (common.go:97)                      */
     uint8_t  gzip_sha256[32];  /* GzipDescriptor.Digest     (:98-102); zero with MI_GZIP_OFF   */
@@ -589,8 +597,9 @@ int  mi_layer_add_whiteout(mi_layer* layer, const char* deleted_path);
 int  mi_layer_finish(mi_layer* layer, mi_layer_result* out);
 const char* mi_layer_error(mi_layer* layer);
 void mi_layer_free(mi_layer* layer);
-/* The header block(s) mi_layer_add would write for `e` (512 bytes, or 1536+ with a PAX record). */
-int  mi_layer_header_bytes(const mi_tree_entry* e, uint8_t* out, uint64_t cap, uint64_t* n);
+/* The header block(s) mi_layer_add would write for `e` (512 bytes, or 1536+ with a PAX record) in
+ * a layer begun with `layer_flags` (MI_LAYER_*).                                                 */
+int  mi_layer_header_bytes(const mi_tree_entry* e, uint32_t layer_flags, uint8_t* out, uint64_t cap, uint64_t* n);
 
 /* ---- cache entry codec (cache.Manager seam, lib/cache/cache_manager.go:34-35,239-252) -------- *
  * key   = "makisu_builder_cache_" + cacheID;
@@ -601,6 +610,12 @@ int  mi_layer_header_bytes(const mi_tree_entry* e, uint8_t* out, uint64_t cap, u
 int mi_cache_key(const char* cache_id, char* out, uint64_t cap);
 int mi_cache_create_entry(const uint8_t* tar_sha256, const uint8_t* gzip_sha256, char* out, uint64_t cap);
 int mi_cache_parse_entry(const char* entry, int* is_empty, uint8_t* tar_sha256, uint8_t* gzip_sha256);
+/* parseEntry to the letter (cache_manager.go:239-245): the two halves around the FIRST comma, each
+ * behind "sha256:", whatever they contain -- the reference does not validate them (the strict form
+ * above needs two 64-digit hex halves because it hands out raw digests).  MI_ERR_INVALID without a
+ * comma, MI_ERR_CAPACITY if a half does not fit.                                                 */
+int mi_cache_parse_entry_str(const char* entry, char* tar_digest, uint64_t tar_cap, char* gzip_digest,
+                             uint64_t gzip_cap);
 
 /* ---- standalone digests (image.Digester seam) ---------------------------------- *
  * n independent byte strings -> n SHA-256 digests on the GPU, one lane per string:

@@ -89,7 +89,10 @@ class CopyOp(C.Structure):
 class LayerConfig(C.Structure):
     """mi_layer_config."""
     _fields_ = [("struct_size", C.c_uint32), ("gzip_level", C.c_int32), ("out_fd", C.c_int32),
-                ("reserved", C.c_uint32)]
+                ("flags", C.c_uint32)]
+
+
+LAYER_MODE_WITH_TYPE = 0x1
 
 
 class LayerResult(C.Structure):
@@ -239,7 +242,8 @@ def load_library(rebuild=False):
         "mi_layer_finish": ([vp, C.POINTER(LayerResult)], C.c_int),
         "mi_layer_error": ([vp], C.c_char_p),
         "mi_layer_free": ([vp], None),
-        "mi_layer_header_bytes": ([C.POINTER(TreeEntry), vp, u64, u64p], C.c_int),
+        "mi_layer_header_bytes": ([C.POINTER(TreeEntry), C.c_uint32, vp, u64, u64p], C.c_int),
+        "mi_cache_parse_entry_str": ([C.c_char_p, C.c_char_p, u64, C.c_char_p, u64], C.c_int),
         "mi_cache_key": ([C.c_char_p, C.c_char_p, u64], C.c_int),
         "mi_cache_create_entry": ([vp, vp, C.c_char_p, u64], C.c_int),
         "mi_cache_parse_entry": ([C.c_char_p, C.POINTER(C.c_int), vp, vp], C.c_int),
@@ -492,11 +496,12 @@ class Layer:
         l.add(entry_dict, src_path); l.add_whiteout("/deleted/path"); pair = l.finish()
     finish() -> dict(tar_digest="sha256:..", gzip_digest=.., tar_bytes, gzip_bytes, n_entries)."""
 
-    def __init__(self, out_fd=-1, gzip_level=GZIP_DEFAULT):
+    def __init__(self, out_fd=-1, gzip_level=GZIP_DEFAULT, mode_with_type=False):
         self._lib = load_library()
         cfg = LayerConfig()
         self._lib.mi_layer_config_default(C.byref(cfg))
         cfg.out_fd, cfg.gzip_level = out_fd, gzip_level
+        cfg.flags = LAYER_MODE_WITH_TYPE if mode_with_type else 0
         self._gzip = gzip_level != GZIP_OFF
         self._h = C.c_void_p()
         rc = self._lib.mi_layer_begin(C.byref(cfg), C.byref(self._h))
@@ -537,13 +542,14 @@ class Layer:
         self.close()
 
 
-def layer_header_bytes(entry):
-    """The tar header block(s) the layer writer emits for one entry dict."""
+def layer_header_bytes(entry, mode_with_type=False):
+    """The tar header block(s) the layer writer emits for one entry dict (mode_with_type: the Mode field
+    keeps the st_mode's file-type bits like Go <= 1.8 wrote them, MI_LAYER_MODE_WITH_TYPE)."""
     keep = []
     arr = _entry_array([entry], keep)
     n = C.c_uint64()
     buf = (C.c_uint8 * 8192)()
-    rc = load_library().mi_layer_header_bytes(arr, buf, 8192, C.byref(n))
+    rc = load_library().mi_layer_header_bytes(arr, LAYER_MODE_WITH_TYPE if mode_with_type else 0, buf, 8192, C.byref(n))
     if rc:
         raise MiError(rc, "mi_layer_header_bytes")
     return bytes(buf[: n.value])
@@ -589,6 +595,16 @@ def cache_parse_entry(entry):
     if e.value:
         return None
     return Digest.from_raw(t), Digest.from_raw(g)
+
+
+def cache_parse_entry_str(entry):
+    """parseEntry to the letter: ("sha256:<first half>", "sha256:<rest>"); ValueError without a comma."""
+    raw = entry.encode()
+    a, b = C.create_string_buffer(len(raw) + 16), C.create_string_buffer(len(raw) + 16)
+    rc = load_library().mi_cache_parse_entry_str(raw, a, len(a), b, len(b))
+    if rc:
+        raise ValueError("parse redis entry: %s" % entry)
+    return Digest(a.value.decode()), Digest(b.value.decode())
 
 
 class ChunkIndex:

@@ -18,9 +18,14 @@
 // with Format unknown -> USTAR when every field fits (names up to 100 bytes or prefix/name split at a
 // "/", octal numbers), else PAX (an "x" record file "PaxHeaders.0/<name>" with path / linkpath / uid /
 // gid / size / mtime records, then the same header with what fits).  Restated from the Go 1.14
-// sources from memory; BYTE PARITY WITH GO IS UNPINNED (no Go toolchain here) -- what is pinned: the
-// empty layer's digest (1024 zero bytes, lib/docker/image/const_darwin.go:18), read-back by python
-// tarfile and GNU tar, and field-for-field agreement with the oracle's independent ustar header.
+// sources.  PINNED since round 3 for the USTAR path: the Go-written layer tar among the reference's
+// fixtures (testdata/files/busybox/393ccd5c.../layer.tar: 390 headers -- files, directories, hard
+// links --, 1 308 672 bytes, SHA-256 4ac76077...) is reproduced byte for byte, header by header and
+// as a whole stream (tests/test_host_layer.py, with MI_LAYER_MODE_WITH_TYPE: that tar's Mode fields
+// carry the pre-Go-1.9 file-type bits).  Also pinned: the empty layer's digest (1024 zero bytes,
+// lib/docker/image/const_darwin.go:18), read-back by python tarfile and GNU tar, agreement with the
+// oracle's independent ustar header.  STILL UNPINNED (no Go toolchain, no Go-written sample): the
+// PAX path (names over 100 bytes that do not split, non-ASCII names, ids over 2^21, sizes from 8 GiB).
 // The gzip bytes are zlib's (the reference uses klauspost/pgzip, whose block splitting is its own):
 // the gzip digest is a faithful DigestPair member for THIS writer, not comparable across writers.
 #include "../../include/makisu_mi.h"
@@ -338,13 +343,42 @@ std::string pax_record(const std::string& k, const std::string& v) {   // format
     if (rec.size() != size) rec = std::to_string(rec.size()) + " " + k + "=" + v + "\n";
     return rec;
 }
+// path.Clean (Go): single slashes, no "." elements, inner ".." elements eaten with the element before
+// them, ".." directly under the root dropped, no trailing slash; "" -> "."
+std::string path_clean(const std::string& p) {
+    if (p.empty()) return ".";
+    const bool rooted = p[0] == '/';
+    std::vector<std::string> el;
+    size_t i = 0;
+    while (i < p.size()) {
+        while (i < p.size() && p[i] == '/') ++i;
+        size_t j = i;
+        while (j < p.size() && p[j] != '/') ++j;
+        if (j > i) {
+            const std::string e = p.substr(i, j - i);
+            if (e == ".") {
+            } else if (e == "..") {
+                if (!el.empty() && el.back() != "..") el.pop_back();
+                else if (!rooted) el.push_back("..");
+            } else {
+                el.push_back(e);
+            }
+        }
+        i = j;
+    }
+    std::string out = rooted ? "/" : "";
+    for (size_t k = 0; k < el.size(); ++k) { if (k) out += "/"; out += el[k]; }
+    return out.empty() ? "." : out;
+}
+// path.Join: the non-empty elements joined by "/" and cleaned; "" if there is none
 std::string path_clean_join(const std::string& dir, const std::string& mid, const std::string& file) {
-    // path.Join(dir, mid, file) for the shapes PAX names take: dir is "" or ends with "/"
-    std::string d = dir;
-    while (!d.empty() && d.back() == '/') d.pop_back();
-    std::string out = d.empty() ? (dir.empty() ? mid : "/" + mid) : d + "/" + mid;
-    if (!file.empty()) out += "/" + file;
-    return out;
+    std::string j;
+    for (const std::string* e : {&dir, &mid, &file}) {
+        if (e->empty()) continue;
+        if (!j.empty()) j += "/";
+        j += *e;
+    }
+    return j.empty() ? j : path_clean(j);
 }
 
 struct Hdr {
@@ -444,6 +478,7 @@ std::string trim_left_slashes(const char* s) {
 
 struct mi_layer {
     std::string err;
+    uint32_t flags = 0;                            // MI_LAYER_*
     DigestSink tar;
     std::unique_ptr<GzipSink> gz;
     std::shared_ptr<Bytes> cur;
@@ -507,7 +542,9 @@ int mi_layer_config_default(mi_layer_config* cfg) {
 int mi_layer_begin(const mi_layer_config* cfg, mi_layer** out) {
     if (!cfg || !out || cfg->struct_size != sizeof(mi_layer_config)) return MI_ERR_INVALID;
     if (cfg->gzip_level != MI_GZIP_OFF && (cfg->gzip_level < -1 || cfg->gzip_level > 9)) return MI_ERR_INVALID;
+    if (cfg->flags & ~MI_LAYER_MODE_WITH_TYPE) return MI_ERR_INVALID;
     mi_layer* l = new mi_layer();
+    l->flags = cfg->flags;
     if (cfg->gzip_level == MI_GZIP_OFF) {
         l->tar.raw_fd = cfg->out_fd;
     } else {
@@ -537,7 +574,7 @@ int mi_layer_add(mi_layer* l, const mi_tree_entry* e, const char* src_path) {
     if (l->finished || l->failed) return l->fail(MI_ERR_STATE, "layer is finished or failed");
     Hdr h;
     h.name = trim_left_slashes(e->relpath);                    // RelPath(dst) + WriteHeader's TrimLeft
-    h.mode = tar_mode(e->mode);
+    h.mode = (l->flags & MI_LAYER_MODE_WITH_TYPE) ? (int64_t)(e->mode & 0177777u) : tar_mode(e->mode);
     h.uid = e->uid;
     h.gid = e->gid;
     h.mtime = e->mtime_sec;                                     // already truncated to seconds
@@ -635,11 +672,11 @@ void mi_layer_free(mi_layer* l) {
     delete l;
 }
 
-int mi_layer_header_bytes(const mi_tree_entry* e, uint8_t* out, uint64_t cap, uint64_t* n) {
-    if (!e || !e->relpath || !n) return MI_ERR_INVALID;
+int mi_layer_header_bytes(const mi_tree_entry* e, uint32_t layer_flags, uint8_t* out, uint64_t cap, uint64_t* n) {
+    if (!e || !e->relpath || !n || (layer_flags & ~MI_LAYER_MODE_WITH_TYPE)) return MI_ERR_INVALID;
     Hdr h;
     h.name = trim_left_slashes(e->relpath);
-    h.mode = tar_mode(e->mode);
+    h.mode = (layer_flags & MI_LAYER_MODE_WITH_TYPE) ? (int64_t)(e->mode & 0177777u) : tar_mode(e->mode);
     h.uid = e->uid;
     h.gid = e->gid;
     h.mtime = e->mtime_sec;
@@ -715,6 +752,21 @@ int mi_cache_parse_entry(const char* entry, int* is_empty, uint8_t* tar_sha256, 
     // SplitN(entry, ",", 2): both halves must be sha256 hex for the digests to mean anything
     if (comma - entry != 64 || strlen(comma + 1) != 64) return MI_ERR_INVALID;
     if (unhex32(entry, tar_sha256) || unhex32(comma + 1, gzip_sha256)) return MI_ERR_INVALID;
+    return MI_OK;
+}
+
+int mi_cache_parse_entry_str(const char* entry, char* tar_digest, uint64_t tar_cap, char* gzip_digest,
+                             uint64_t gzip_cap) {
+    if (!entry || !tar_digest || !gzip_digest) return MI_ERR_INVALID;
+    const char* comma = strchr(entry, ',');
+    if (!comma) return MI_ERR_INVALID;                          // "parse redis entry: ..."
+    const size_t a = (size_t)(comma - entry), b = strlen(comma + 1);
+    if (tar_cap < a + 8 || gzip_cap < b + 8) return MI_ERR_CAPACITY;
+    memcpy(tar_digest, "sha256:", 7);
+    memcpy(tar_digest + 7, entry, a);
+    tar_digest[7 + a] = 0;
+    memcpy(gzip_digest, "sha256:", 7);
+    memcpy(gzip_digest + 7, comma + 1, b + 1);
     return MI_OK;
 }
 

@@ -13,6 +13,7 @@
 
 #include <errno.h>
 #include <fcntl.h>
+#include <stdio.h>
 #include <string.h>
 #include <unistd.h>
 
@@ -346,6 +347,7 @@ void worker(Stager* st, u32 tid) {
                 ss.ms_verify += ms_verify;
                 b->stage_spans.push_back(sp);
                 if (mism && b->stage_note.empty()) b->stage_note = note;
+                if (mism) fprintf(stderr, "makisu_mi: %s\n", note.c_str());    // rare and worth a line even when repaired
             }
         }
         if (!err.empty()) {
@@ -521,6 +523,7 @@ int stage_verify_final(mi_batch* b) {
              (unsigned long long)sums[2 * first_bad], (unsigned long long)sums[2 * first_bad + 1]);
     const std::string msg = head + describe_span(b->arena.as<u8>() + sp.off, nullptr, sp.len, c->stream);
     if (b->stage_note.empty()) b->stage_note = msg;
+    fprintf(stderr, "makisu_mi: %s\n", msg.c_str());
     b->stage_err = msg;                                        // sticky (stager_drain / stage_batch)
     return fail(c, MI_ERR_IO, "%s", msg.c_str());
 }

@@ -129,7 +129,7 @@ struct Source {
     // gzip state
     z_stream z;
     bool z_ready = false, z_end = false;
-    std::vector<unsigned char> in;
+    std::vector<unsigned char> in, sink;   // compressed input window; where skipped bytes are inflated to
     uint64_t in_off = 0, pos = 0;      // compressed bytes consumed from fd, uncompressed position
     std::string error;
 
@@ -147,12 +147,12 @@ struct Source {
             if (inflateInit2(&z, 15 + 16) != Z_OK) { error = "inflateInit2 failed"; return false; }
             z_ready = true;
             in.resize(1 << 20);
+            sink.resize(1 << 16);      // per source: two threads may list two archives at once
         }
         return true;
     }
     // inflates up to n bytes into dst (dst may be NULL: discard); returns bytes produced
     size_t inflate_some(unsigned char* dst, size_t n) {
-        static unsigned char sink[1 << 16];
         size_t made = 0;
         while (made < n && !z_end) {
             if (z.avail_in == 0) {
@@ -164,8 +164,8 @@ struct Source {
                 z.avail_in = (uInt)r;
             }
             const size_t want = n - made;
-            unsigned char* out = dst ? dst + made : sink;
-            const size_t room = dst ? want : (want < sizeof sink ? want : sizeof sink);
+            unsigned char* out = dst ? dst + made : sink.data();
+            const size_t room = dst ? want : (want < sink.size() ? want : sink.size());
             z.next_out = out;
             z.avail_out = (uInt)(room > 0x40000000u ? 0x40000000u : room);
             const uInt before = z.avail_out;
@@ -214,11 +214,20 @@ static int parse(Source& src, Tar* t) {
     bool has_gnu_name = false, has_gnu_link = false;
     int64_t n_regular = 0;
     unsigned char blk[512];
+    std::string open_member;                                   // gzip source: the entry whose data must reach `off`
+    uint64_t open_member_end = 0;                              // ... its last byte + 1 (padding not counted)
     for (;;) {
         if (!src.read_at(off, blk, 512)) {
             if (!src.error.empty()) { t->error = src.error; return MI_ERR_IO; }
+            // a gzip stream is only as long as it inflates to: if it ended inside the previous
+            // entry's data, say what the plain-tar path says for the same archive
+            if (src.gz && !open_member.empty() && src.pos < open_member_end) {
+                t->error = "entry " + open_member + " runs past the end of the archive";
+                return MI_ERR_INVALID;
+            }
             break;                                             // end of data without the zero blocks
         }
+        open_member.clear();
         if (all_zero(blk)) break;                              // end-of-archive marker
         if (!checksum_ok(blk)) { t->error = "bad tar header checksum at offset " + std::to_string(off); return MI_ERR_INVALID; }
         int64_t size = 0, mode = 0, uid = 0, gid = 0, mtime = 0;
@@ -294,6 +303,7 @@ static int parse(Source& src, Tar* t) {
         if (it.kind == 1) {
             if (!src.has_range(data, (uint64_t)size)) { t->error = "entry " + it.name + " runs past the end of the archive"; return MI_ERR_INVALID; }
             it.file_index = n_regular++;
+            if (src.gz && size > 0) { open_member = it.name; open_member_end = data + (uint64_t)size; }
         }
         t->items.push_back(it);
         off = data + skip;

@@ -23,3 +23,26 @@ def oracle():
 def engine_lib():
     import makisu_amd
     return makisu_amd.load_library()
+
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GO_LAYER_TAR_DIGEST = "4ac76077f2c741c856a2419dfdb0804b18e48d2e1a9ce9c6a3f0605a2078caba"
+
+
+@pytest.fixture(scope="session")
+def go_layer_tar():
+    """(tar bytes, member table): the gunzip of the reference's alpine layer blob (the blob's digest
+    393ccd5c... is lib/utils/testutil/constants.go:28; the tar is testdata/files/busybox/393ccd5c.../
+    layer.tar, written by Go's archive/tar) and tests/golden/go_layer_tar_members.json, made from that
+    file with python tarfile (tests/golden/make_golden.py)."""
+    import base64
+    import hashlib
+    import json
+    import zlib
+    vec = json.load(open(os.path.join(GOLDEN, "sha256_reference_fixtures.json")))["vectors"][0]
+    assert vec["name"] == "alpine_layer_blob"
+    raw = zlib.decompress(base64.b64decode(vec["file_b64"]), 31)
+    table = json.load(open(os.path.join(GOLDEN, "go_layer_tar_members.json")))
+    assert len(raw) == table["tar_bytes"] == 1308672
+    assert hashlib.sha256(raw).hexdigest() == table["tar_sha256"] == GO_LAYER_TAR_DIGEST
+    return raw, table["members"]

@@ -66,7 +66,32 @@ def main():
     json.dump({"comment": "uber/makisu testdata/build-context (BASELINE.json configs[0]); answers "
                           "from hashlib/zlib, independent of the oracle", "entries": entries},
               open(os.path.join(HERE, "build_context_c1.json"), "w"), indent=1)
-    print("wrote", len(sha["vectors"]), "sha vectors and", len(entries), "context entries")
+    # The Go-written layer tar the reference holds: testdata/files/busybox/393ccd5c.../layer.tar
+    # (= gunzip of the alpine blob above).  Written by Go's archive/tar (docker save): USTAR magic
+    # "ustar\x0000", empty uname/gname, "0000000\0" dev fields, checksum "%06o\0 ", Mode values with
+    # the old file-type bits.  Per member: where its header sits, the SHA-256 of that 512-byte block
+    # and of its data -- the framer (mi_layer_*) has to reproduce every one of them.
+    import tarfile
+    lp = REF + "/testdata/files/busybox/393ccd5c4dd90344c9d725125e13f636ce0087c62f5ca89050faaacbb9e3ed5b/layer.tar"
+    raw = open(lp, "rb").read()
+    assert zlib.decompress(base64.b64decode(sha["vectors"][0]["file_b64"]), 31) == raw
+    members = []
+    with tarfile.open(lp) as tf:
+        for m in tf.getmembers():
+            members.append({"name": m.name, "type": m.type.decode(), "header_offset": m.offset,
+                            "header_sha256": hashlib.sha256(raw[m.offset:m.offset + 512]).hexdigest(),
+                            "mode_field": raw[m.offset + 100:m.offset + 108].decode("latin1"),
+                            "size": m.size, "linkname": m.linkname,
+                            "data_offset": m.offset_data if m.isreg() else 0,
+                            "data_sha256": hashlib.sha256(raw[m.offset_data:m.offset_data + m.size]).hexdigest()
+                            if m.isreg() else None})
+    json.dump({"comment": "headers of the reference's Go-written layer tar (testdata/files/busybox/393ccd5c.../layer.tar, "
+                          "the gunzip of sha256_reference_fixtures.json[alpine_layer_blob]); listed with python tarfile",
+               "tar_bytes": len(raw), "tar_sha256": hashlib.sha256(raw).hexdigest(),
+               "pinned_by": "computed from the fixture; the blob's digest is lib/utils/testutil/constants.go:28",
+               "members": members},
+              open(os.path.join(HERE, "go_layer_tar_members.json"), "w"), indent=0)
+    print("wrote", len(sha["vectors"]), "sha vectors,", len(entries), "context entries and", len(members), "tar members")
 
 
 if __name__ == "__main__":

@@ -331,7 +331,7 @@ def _fault_child(fault, flag=1):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MI_STAGE_FAULT=fault)
+    env = dict(os.environ, MI_STAGE_FAULT=fault, MI_VERIFY_STAGING=str(flag))
     r = subprocess.run([sys.executable, "-c", FAULT_CHILD % {"root": root, "flag": flag}], env=env,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]

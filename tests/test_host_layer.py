@@ -5,8 +5,11 @@ entry codec (lib/cache/cache_manager.go:239-252).
 Pins available here: the empty layer (1024 zero bytes -> 5f70bf18..., the constant the reference
 holds at lib/docker/image/const_darwin.go:18), read-back of every field through python tarfile and
 GNU tar (the reference's own write_test.go round-trips through the tar command the same way), and
-agreement with the oracle's independent ustar header writer.  Byte parity with Go's archive/tar is
-UNPINNED (no Go toolchain in this environment).
+agreement with the oracle's independent ustar header writer -- and, since round 3, the Go-written
+layer tar the reference holds (testdata/files/busybox/393ccd5c.../layer.tar, 390 USTAR headers): every
+header block and the whole stream are reproduced byte for byte (test_go_written_layer_*).  That pins
+the USTAR path of the writer to Go's archive/tar bytes; the PAX path (long / non-ASCII names, large
+ids) and tar.FileInfoHeader's Go >= 1.9 permission-only Mode stay unpinned (no Go toolchain here).
 """
 import gzip
 import hashlib
@@ -334,3 +337,102 @@ def test_chunk_root_helper_equals_the_oracle_definition():
     for n in (0, 1, 2, 63, 64, 65, 128, 129, 4095, 4096, 4097, 70000):
         dg = rng.integers(0, 256, (n, 32), dtype=np.uint8)
         assert M.chunk_root(dg) == bytes(O.chunk_root(dg)), n
+
+
+# ---- the Go-written layer of the reference's fixtures ------------------------------
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+GO_LAYER_TAR_DIGEST = "4ac76077f2c741c856a2419dfdb0804b18e48d2e1a9ce9c6a3f0605a2078caba"
+
+
+def test_go_written_layer_every_header_block_is_reproduced(tmp_path, go_layer_tar):
+    """(i) each of the 390 entries mi_tar_entries reads from the Go-written tar, handed back to the
+    writer with MI_LAYER_MODE_WITH_TYPE (the Mode field keeps the file-type bits: FileInfoHeader up to
+    Go 1.8, which is what wrote this fixture), gives exactly the 512 bytes Go wrote: names with the directory slash,
+    "ustar\0" + "00", empty uname/gname, "0000000\0" dev fields, the "%06o\0 " checksum, hard links
+    with size 0.  Without the flag (mode = an st_mode through FileInfoHeader's Go >= 1.9 rule) the
+    ONLY bytes that differ are the type bits of the mode field and the checksum."""
+    raw, members = go_layer_tar
+    p = tmp_path / "layer.tar"
+    p.write_bytes(raw)
+    ents = M.tar_entries(str(p))
+    assert len(ents) == len(members) == 390
+    kinds = {"5": M.KIND_DIR, "0": M.KIND_FILE, "1": M.KIND_HARDLINK, "2": M.KIND_SYMLINK}
+    n_by_kind = {}
+    for e, m in zip(ents, members):
+        assert e["kind"] == kinds[m["type"]] and e["relpath"].rstrip("/") == m["name"].rstrip("/")
+        n_by_kind[m["type"]] = n_by_kind.get(m["type"], 0) + 1
+        want = raw[m["header_offset"]:m["header_offset"] + 512]
+        assert hashlib.sha256(want).hexdigest() == m["header_sha256"]
+        got = M.layer_header_bytes(e, mode_with_type=True)
+        assert got == want, (m["name"], [i for i in range(512) if got[i] != want[i]][:8])
+        if e["kind"] == M.KIND_FILE:
+            assert e["data_offset"] == m["data_offset"] and e["size"] == m["size"]
+        cooked = M.layer_header_bytes(e)                      # FileInfoHeader's permission-only Mode
+        diff = [i for i in range(512) if cooked[i] != want[i]]
+        assert diff and all(100 <= i < 108 or 148 <= i < 156 for i in diff), (m["name"], diff)
+        assert cooked[100:108] == b"%07o\x00" % (int(m["mode_field"].rstrip("\x00"), 8) & 0o7777)
+    assert n_by_kind == {"1": 372, "5": 12, "0": 6}
+
+
+def test_go_written_layer_is_reframed_byte_for_byte(tmp_path, go_layer_tar):
+    """(ii) the whole layer through mi_layer_begin / add / finish -- members extracted to a directory,
+    entries (hard links included) in stream order -- is the Go-written stream again: 1 308 672 bytes,
+    TarDigest 4ac76077...caba, and through the gzip leg a blob that inflates to it."""
+    raw, members = go_layer_tar
+    p = tmp_path / "layer.tar"
+    p.write_bytes(raw)
+    ents = M.tar_entries(str(p))
+    src = tmp_path / "members"
+    src.mkdir()
+    paths = {}
+    for i, (e, m) in enumerate(zip(ents, members)):
+        if e["kind"] == M.KIND_FILE:
+            data = raw[m["data_offset"]:m["data_offset"] + m["size"]]
+            assert hashlib.sha256(data).hexdigest() == m["data_sha256"]
+            paths[i] = src / ("m%03d" % i)
+            paths[i].write_bytes(data)
+    for level in (M.GZIP_OFF, M.GZIP_DEFAULT):
+        out = tmp_path / ("out.%d" % level)
+        fd = os.open(out, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+        try:
+            with M.Layer(out_fd=fd, gzip_level=level, mode_with_type=True) as layer:
+                for i, e in enumerate(ents):
+                    layer.add(e, str(paths[i]) if i in paths else None)
+                pair = layer.finish()
+        finally:
+            os.close(fd)
+        assert pair["tar_bytes"] == 1308672 and pair["n_entries"] == 390
+        assert pair["tar_digest"] == "sha256:" + GO_LAYER_TAR_DIGEST
+        blob = out.read_bytes()
+        if level == M.GZIP_OFF:
+            assert blob == raw
+        else:
+            assert gzip.decompress(blob) == raw
+            assert pair["gzip_digest"].hex() == hashlib.sha256(blob).hexdigest()
+    # and the reader's own digest of the stream (mi_tar_inflate over the reference's blob) agrees
+    import base64
+    import json
+    blob_path = tmp_path / "blob"
+    blob_path.write_bytes(base64.b64decode(
+        json.load(open(os.path.join(GOLDEN, "sha256_reference_fixtures.json")))["vectors"][0]["file_b64"]))
+    inf = M.tar_inflate(str(blob_path))
+    assert inf["tar_digest"] == "sha256:" + GO_LAYER_TAR_DIGEST and inf["tar_bytes"] == 1308672
+
+
+def test_pax_name_is_path_cleaned_like_go():
+    """the PaxHeaders.0 name is path.Join(dir, "PaxHeaders.0", file) -- path.Clean'd."""
+    long = "g" * 120
+    for name, want in ((("a//b/./" + long), "a/b/PaxHeaders.0/" + long), (("a/../b/" + long), "b/PaxHeaders.0/" + long),
+                       (long, "PaxHeaders.0/" + long)):
+        hb = M.layer_header_bytes({"relpath": name, "kind": M.KIND_FILE, "mode": 0o100644, "size": 1})
+        assert len(hb) >= 1536 and hb[156:157] == b"x"
+        assert hb[:100].rstrip(b"\0") == want.encode()[:100].rstrip(b"/")
+
+
+def test_cache_parse_entry_str_accepts_what_the_reference_accepts():
+    """parseEntry (cache_manager.go:239-245) splits at the first comma and validates nothing."""
+    assert M.cache_parse_entry_str("abc,def") == ("sha256:abc", "sha256:def")
+    assert M.cache_parse_entry_str("a,b,c") == ("sha256:a", "sha256:b,c")
+    assert M.cache_parse_entry_str(",") == ("sha256:", "sha256:")
+    with pytest.raises(ValueError):
+        M.cache_parse_entry_str("no comma")

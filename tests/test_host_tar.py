@@ -337,6 +337,16 @@ def test_gzip_layer_roundtrip_and_errors(tmp_path):
     with pytest.raises(M.MiError) as ei:
         M.tar_entries(bad)
     assert "gzip" in str(ei.value)
+    # a WELL-FORMED gzip stream around a tar that stops inside a member's data: the same error the
+    # plain-tar path gives for that archive (the gzip path used to list it without a word)
+    cut = raw[: 512 + 512 + 30000]                          # dir header, a/b.txt's header, part of its data
+    assert b"a/b.txt" in cut[512:1024]
+    open(tmp_path / "cut.tar", "wb").write(cut)
+    open(tmp_path / "cut.tar.gz", "wb").write(gz.compress(cut))
+    for name in ("cut.tar", "cut.tar.gz"):
+        with pytest.raises(M.MiError) as ei:
+            M.tar_entries(str(tmp_path / name))
+        assert ei.value.code == -1 and "a/b.txt runs past the end of the archive" in str(ei.value), name
     with pytest.raises(M.MiError) as ei:
         M.tar_entries(str(tmp_path / "missing.tar"))
     assert ei.value.code == -5 and "missing.tar" in str(ei.value)
