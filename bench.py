@@ -12,8 +12,10 @@ duplicate marking).
                 the HOST-FED rate (page-cache files -> pinned staging -> H2D overlapped with the
                 scan) next to the resident one
   --config c4   configs[3]: N x 1.25 M x 64 KiB, file index mod N            (default at N > 1)
-  --config c5   configs[4]: sizes 2^U(10,30) B, 90 % duplicate files, LPT shards; the job-wide
-                unique-chunk count is checked against the generator's closed form
+  --config c5   configs[4]: sizes Zipf(s = 1.1) over the log2 buckets 2^10..2^30 B, 90 % of the files
+                copies of the other 10 %, LPT shards (with N > 1 files >= 256 MiB are split into one
+                part per GPU); the job-wide unique-chunk count is checked against the generator's
+                closed form.  --config c5u: rounds 1-2's log-uniform stand-in 2^U(10,30)
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     -- the dominant kernel (sha256_items_kernel, chunk pass): algorithmic bytes
@@ -203,10 +205,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=0, help="default 20 (c2) / 3-5 for the larger configs")
     ap.add_argument("--warmup", type=int, default=-1)
-    ap.add_argument("--config", default="auto", choices=["auto", "c2", "c3", "c4", "c5"],
+    ap.add_argument("--config", default="auto", choices=["auto", "c2", "c3", "c4", "c5", "c5u"],
                     help="auto = c2 on one GPU (the config the metric is quoted on), c4 on several")
     ap.add_argument("--files", type=int, default=0, help="files per GPU (c2: 100000, c3: 1000, c4: 1250000)")
-    ap.add_argument("--bytes-per-gpu", type=float, default=0, help="c5: GiB per GPU (default 32)")
+    ap.add_argument("--bytes-per-gpu", type=float, default=0, help="c5: GiB per GPU (default 64; c5u 32)")
+    ap.add_argument("--split-mib", type=int, default=256,
+                    help="c5 with N > 1: files of this many MiB and more are split into one part per GPU")
     ap.add_argument("--inflight", type=int, default=0,
                     help="batches in flight (1 = serial steps; default 2, 3 for c2 with an exchange)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -245,7 +249,7 @@ def main():
         # only fits for the small config
         args.inflight = 3 if (exchange and config == "c2") else 2
     if args.steps <= 0:
-        args.steps = {"c2": 20, "c3": 3, "c4": 3, "c5": 5}[config]
+        args.steps = {"c2": 20, "c3": 3, "c4": 3, "c5": 4, "c5u": 5}[config]
     if args.warmup < 0:
         args.warmup = 3 if config == "c2" else 1
     if exchange or world > 1:
@@ -278,7 +282,10 @@ def main():
             return W.c3(rank, world, args.files or 1000, generation=generation)
         if config == "c4":
             return W.c4(rank, world, args.files or 1250000, generation)
-        return W.c5(rank, world, int((args.bytes_per_gpu or 32) * W.GIB), generation)
+        if config == "c5u":
+            return W.c5u(rank, world, int((args.bytes_per_gpu or 32) * W.GIB), generation)
+        return W.c5(rank, world, int((args.bytes_per_gpu or 64) * W.GIB), generation,
+                    split_threshold=args.split_mib * W.MIB)
 
     # c3's host-fed leg runs FIRST: right after the resident batches are freed the driver is still
     # wiping their 130 GB of VRAM on the SDMA engines the H2D copies need (measured: 18 GB/s then,
@@ -301,9 +308,30 @@ def main():
         step_bytes = shards[0].n_bytes
         desc_shard = shards[0]
     batches = []
+    part_rounds = 0
     for sh in shards:
-        b = eng.batch(sh.n_files, sh.n_bytes)
-        b.add_synthetic(sh.sizes, sh.cids, seed=sh.seed)
+        b = eng.batch(sh.n_files, sh.n_bytes + (sh.n_files + 8) * 4096 + (len(sh.parts or ()) << 19))
+        if sh.parts is None:
+            b.add_synthetic(sh.sizes, sh.cids, seed=sh.seed)
+        else:
+            # c5 on several GPUs: runs of whole files, and parts of the files that were split
+            keys, i, n = [], 0, sh.n_files
+            while i < n:
+                if sh.parts[i][3] < 0:
+                    j = i
+                    while j < n and sh.parts[j][3] < 0:
+                        j += 1
+                    b.add_synthetic(sh.sizes[i:j], sh.cids[i:j], seed=sh.seed)
+                    i = j
+                else:
+                    fsize, begin, end, pno = sh.parts[i]
+                    b.add_synthetic_part(fsize, int(sh.cids[i]), begin, end, seed=sh.seed)
+                    keys.append((int(sh.cids[i]) * 4 * sh.n_global_files + int(sh.global_index[i]), pno))
+                    i += 1
+        if config in ("c5", "c5u") and world > 1:
+            # the parts' owners agree on the cuts at the part boundaries (8 bytes per boundary over the
+            # host group; every rank calls, also one that owns no part); later steps reuse the entries
+            part_rounds = max(part_rounds, mdist.resolve_parts(b, keys if sh.parts is not None else []))
         b.run()                                   # generates the data on the device, first pass
         batches.append(b)
     launches_per_step = len(batches) if split else 1
@@ -382,7 +410,7 @@ def main():
     # count must equal the chunk count of the first file of every distinct content
     dedup_check = None
     if not split and (exchange or world == 1):
-        if config == "c5":
+        if config in ("c5", "c5u"):
             files0 = batches[0].files()
             expect = int(files0["n_chunks"][shards[0].originals].sum())
         else:
@@ -432,7 +460,7 @@ def main():
                    "name": config, "files_per_gpu": int(sum(s.n_files for s in shards) if split else shards[0].n_files),
                    "bytes_per_gpu": int(step_bytes), "job_bytes_per_step": int(job_bytes),
                    "chunks_last_batch": int(st["n_chunks"]),
-                   "parallelism": "files sharded x%d (%s)" % (world, "LPT by bytes" if config == "c5" else "file index mod N"),
+                   "parallelism": "files sharded x%d (%s)" % (world, "LPT by bytes" if config in ("c5", "c5u") else "file index mod N"),
                    "batches_in_flight": args.inflight, "launches_per_step": launches_per_step,
                    "exchange": (args.exchange if exchange else None),
                    "device": info["name"].strip(), "n_cu": info["n_cu"],
@@ -459,6 +487,11 @@ def main():
         "phase_note": "per-batch stream timelines; with several batches in flight a phase's span "
                       "includes time it shared the GPU with the other batches",
     }
+    if config in ("c5", "c5u"):
+        out["config"].update({"lpt_imbalance_max_over_mean_bytes": round(desc_shard.imbalance, 6),
+                              "files_split_into_parts_job": getattr(desc_shard, "n_split_files_job", 0),
+                              "parts_this_rank": sum(1 for p_ in (desc_shard.parts or ()) if p_[3] >= 0),
+                              "part_boundary_rounds": part_rounds})
     if dedup_check:
         out["dedup_check"] = dedup_check
     if serial_sha_ms:

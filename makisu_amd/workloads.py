@@ -9,8 +9,11 @@ regenerate the same files with the oracle's generator).  Nothing here imports or
   C2  100 000 x 64 KiB per GPU, distinct contents (seed S)
   C3  1 000 x 128 MiB per GPU (seed S + 1)
   C4  N x 1 250 000 x 64 KiB, global file index i -> rank i mod N (seed S)
-  C5  sizes 2^U(10, 30) bytes, fixed total per GPU, 90 % of the files (by count) are copies of
-      the other 10 % (seeded choice); longest-processing-time sharding by bytes (seed S + 2)
+  C5  sizes Zipf(s = 1.1) over the 21 log2 buckets 2^10 .. 2^30 B (bucket rank 1 = 1 KiB; uniform
+      inside a bucket, the last bucket is exactly 1 GiB), fixed total per GPU, 90 % of the files (by
+      count) are copies of the other 10 % (seeded choice); longest-processing-time sharding by bytes,
+      files >= 256 MiB split into one part per GPU when there are several (seed S + 2)
+  C5U the round-1/2 stand-in: sizes 2^U(10, 30) (log-uniform: a large-file workload), same copies
 """
 import numpy as np
 
@@ -56,6 +59,8 @@ class Shard:
         self.originals = (np.ones(len(self.sizes), dtype=bool) if originals is None
                           else np.ascontiguousarray(originals, dtype=bool))
         self.describe = describe
+        self.parts = None          # c5 with several ranks: per item (file_size, begin, end, part_no)
+        self.imbalance = 1.0
 
     @property
     def n_files(self):
@@ -89,16 +94,33 @@ def c4(rank=0, world=8, files_per_gpu=1250000, generation=0):
                  describe="C4: %d x 64 KiB files, file index mod %d" % (n, world))
 
 
-def c5_global(world=1, bytes_per_gpu=32 * GIB, lo_log2=10, hi_log2=30):
-    """The job-wide C5 file list: (sizes, cids, originals)."""
+ZIPF_S = 1.1
+
+
+def zipf_bucket_probs(lo_log2=10, hi_log2=30, s=ZIPF_S):
+    """P(bucket b), b = lo_log2 .. hi_log2: Zipf over the bucket RANK (1 = the smallest sizes)."""
+    r = np.arange(1, hi_log2 - lo_log2 + 2, dtype=np.float64)
+    w = r ** -s
+    return w / w.sum()
+
+
+def c5_global(world=1, bytes_per_gpu=64 * GIB, lo_log2=10, hi_log2=30, law="zipf"):
+    """The job-wide C5 file list: (sizes, cids, originals).  law "zipf": BASELINE.json configs[4] /
+    SURVEY.md 8(d) -- by COUNT three files in four are below 128 KiB, by BYTES nearly everything sits
+    in the files of 64 MiB and more; "loguniform": 2^U(lo, hi), rounds 1-2."""
     rng = np.random.default_rng(SEED + 2)
     target = bytes_per_gpu * world
-    # the 10 % distinct contents: log-uniform sizes (Zipf-like over log2 buckets) until they hold
-    # a tenth of the bytes; then nine copies per original on average, drawn with replacement
+    # the 10 % distinct contents: sizes drawn until they hold a tenth of the bytes; then nine copies
+    # per original on average, drawn with replacement
+    probs = zipf_bucket_probs(lo_log2, hi_log2)
     sizes = []
     acc = 0
     while acc < target // 10:
-        s = int(2.0 ** rng.uniform(lo_log2, hi_log2))
+        if law == "zipf":
+            b = lo_log2 + int(rng.choice(len(probs), p=probs))
+            s = (1 << b) if b == hi_log2 else int(rng.integers(1 << b, 1 << (b + 1)))
+        else:
+            s = int(2.0 ** rng.uniform(lo_log2, hi_log2))
         sizes.append(s)
         acc += s
     distinct = len(sizes)
@@ -114,17 +136,42 @@ def c5_global(world=1, bytes_per_gpu=32 * GIB, lo_log2=10, hi_log2=30):
     return all_sizes, cids, originals
 
 
-def c5(rank=0, world=1, bytes_per_gpu=32 * GIB, generation=0, lo_log2=10, hi_log2=30):
-    sizes, cids, originals = c5_global(world, bytes_per_gpu, lo_log2, hi_log2)
-    mine = shard_lpt(sizes, world)[rank]
+def c5(rank=0, world=1, bytes_per_gpu=64 * GIB, generation=0, lo_log2=10, hi_log2=30, law="zipf",
+       split_threshold=256 * MIB):
+    """One rank's C5 items.  With several ranks, files of split_threshold bytes and more are cut into
+    one part per rank (plan_split), everything else goes whole to the least loaded
+    rank.  shard.parts (or None): per item (file_size, begin, end, part_no) -- whole files have
+    part_no -1; shard.imbalance = max / mean bytes per rank."""
+    sizes, cids, originals = c5_global(world, bytes_per_gpu, lo_log2, hi_log2, law)
     n_contents = int(cids.max()) + 1
-    return Shard("c5", SEED + 2, sizes[mine], cids[mine] + generation * n_contents, mine, len(sizes),
-                 originals=originals[mine],
-                 describe="C5: sizes 2^U(%d,%d) B, %d files / %d distinct contents job-wide, LPT shards"
-                          % (lo_log2, hi_log2, len(sizes), n_contents))
+    name = "c5" if law == "zipf" else "c5u"
+    what = ("Zipf s=%.1f over log2 buckets 2^%d..2^%d B" % (ZIPF_S, lo_log2, hi_log2)) if law == "zipf" \
+        else "sizes 2^U(%d,%d) B" % (lo_log2, hi_log2)
+    items, ranks = plan_split(sizes, world, split_threshold)
+    loads = np.zeros(world, dtype=np.int64)
+    for (f, pno, b, e), r in zip(items, ranks):
+        loads[r] += e - b
+    mine = sorted((it for it, r in zip(items, ranks) if r == rank), key=lambda it: (it[0], it[2]))
+    files = np.array([it[0] for it in mine], dtype=np.int64)
+    isz = np.array([it[3] - it[2] for it in mine], dtype=np.int64)
+    sh = Shard(name, SEED + 2, isz, cids[files] + generation * n_contents, files, len(sizes),
+               originals=originals[files],
+               describe="C5: %s, 90 %% of the files copies of the other 10 %%: %d files / %d distinct contents "
+                        "job-wide, LPT shards%s" % (what, len(sizes), n_contents,
+                                                    ", files >= %d MiB as %d parts" % (split_threshold // MIB, world)
+                                                    if world > 1 else ""))
+    n_split = sum(1 for it in mine if it[1] is not None)
+    sh.parts = [(int(sizes[it[0]]), it[2], it[3], -1 if it[1] is None else it[1]) for it in mine] if n_split else None
+    sh.imbalance = float(loads.max() / max(1.0, loads.mean()))
+    sh.n_split_files_job = int((sizes >= split_threshold).sum()) if world > 1 else 0
+    return sh
 
 
-CONFIGS = {"c2": c2, "c3": c3, "c4": c4, "c5": c5}
+def c5u(rank=0, world=1, bytes_per_gpu=32 * GIB, generation=0, lo_log2=10, hi_log2=30):
+    return c5(rank, world, bytes_per_gpu, generation, lo_log2, hi_log2, law="loguniform")
+
+
+CONFIGS = {"c2": c2, "c3": c3, "c4": c4, "c5": c5, "c5u": c5u}
 
 
 PART_ALIGN = 256 * KIB          # MI_PART_ALIGN: part bounds are multiples of the 256 KiB CDC group

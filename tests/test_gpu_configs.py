@@ -6,7 +6,9 @@ costs it about a second on the GPU box's host cores and never has to exist in ho
   C2  all 100 000 x 64 KiB files                                     (configs[1], full size)
   C3  60 x 128 MiB                                                   (configs[2] shape, 10x round 1)
   C4  two ranks' shards of file index mod 8, job-wide marking        (configs[3] shape)
-  C5  ~700 files 1 KiB..256 MiB (6 GiB), 90 % duplicates, LPT shard        (configs[4] shape, 10x round 1)
+  C4  one rank's FULL shard, 1.25 M x 64 KiB = 76 GiB                (configs[3], full size per rank)
+  C5  one GPU's full Zipf shard (3 350 files 1 KiB..1 GiB, 57 GiB), 90 % duplicates  (configs[4], full size)
+      + the rounds-1/2 log-uniform shard (6 GiB) + two ranks through bench.py with split files
 Cut points: parity UNPINNED w.r.t. the reference (no CDC there); SHA-256 pinned (tests/test_oracle.py).
 """
 import os
@@ -77,26 +79,58 @@ def test_c3_sixty_128mib_files(oracle, eng):
     assert np.array_equal(files["chunk_root"][40:], files["chunk_root"][:20])
 
 
-def test_c5_zipf_mix_lpt_shard_closed_form(oracle, eng):
-    """One rank's LPT shard of a 2-rank C5 job (sizes up to 256 MiB): every row against the oracle,
-    and the unique count against the generator's closed form restricted to this shard."""
-    from makisu_amd import workloads as W
-    sh = W.c5(0, 2, bytes_per_gpu=6 * W.GIB, hi_log2=28)
-    assert sh.n_files > 500 and int(sh.sizes.max()) > 64 * W.MIB
-    files, chunks, nu = _check_shard(oracle, eng, sh)
-    # closed form inside one shard: one set of chunks per distinct content present in it
+def _closed_form_in_shard(sh, files):
+    """one set of chunks per distinct content present in the shard"""
     first_of_content = np.zeros(sh.n_files, dtype=bool)
     seen = set()
     for i, c in enumerate(sh.cids.tolist()):
         if c not in seen:
             seen.add(c)
             first_of_content[i] = True
-    assert nu == int(files["n_chunks"][first_of_content].sum())
-    # the whole job: both shards together hold every file exactly once, byte-balanced within 2 %
-    other = W.c5(1, 2, bytes_per_gpu=6 * W.GIB, hi_log2=28)
+    return int(files["n_chunks"][first_of_content].sum())
+
+
+def test_c5u_loguniform_lpt_shard_closed_form(oracle, eng):
+    """Rounds 1-2's stand-in (sizes 2^U(10,28)): one rank's LPT shard of a 2-rank job, every row against
+    the oracle, the unique count against the generator's closed form restricted to this shard."""
+    from makisu_amd import workloads as W
+    sh = W.c5(0, 2, bytes_per_gpu=6 * W.GIB, hi_log2=28, law="loguniform", split_threshold=1 << 40)
+    assert sh.n_files > 500 and int(sh.sizes.max()) > 64 * W.MIB and sh.parts is None
+    files, chunks, nu = _check_shard(oracle, eng, sh)
+    assert nu == _closed_form_in_shard(sh, files)
+    other = W.c5(1, 2, bytes_per_gpu=6 * W.GIB, hi_log2=28, law="loguniform", split_threshold=1 << 40)
     assert sh.n_files + other.n_files == sh.n_global_files
     assert len(set(sh.global_index.tolist()) & set(other.global_index.tolist())) == 0
     assert abs(sh.n_bytes - other.n_bytes) <= 0.02 * sh.n_bytes
+
+
+@pytest.mark.timeout(900)
+def test_c5_zipf_full_shard_every_row(oracle, eng):
+    """BASELINE.json configs[4] as written -- Zipf(s = 1.1) over the log2 buckets
+    2^10..2^30, 64 GiB nominal per GPU (57 GiB drawn), 1 GiB files included -- one GPU's whole shard,
+    every row against the oracle; the unique count is the generator's closed form."""
+    from makisu_amd import workloads as W
+    sh = W.c5(0, 1)
+    assert sh.name == "c5" and sh.n_files > 3000 and int(sh.sizes.max()) == 1 << 30 and sh.n_bytes > 50 * W.GIB
+    assert (sh.sizes <= 64 * W.KIB).mean() > 0.6
+    files, chunks, nu = _check_shard(oracle, eng, sh)
+    assert nu == int(files["n_chunks"][sh.originals].sum()) == _closed_form_in_shard(sh, files)
+    assert nu < 0.2 * len(chunks)                            # nine copies per original: mostly duplicates
+
+
+@pytest.mark.timeout(900)
+def test_c4_one_rank_full_shard_every_row(oracle):
+    """one rank's whole C4 shard -- 1 250 000 x 64 KiB = 76 GiB, the files with global
+    index 3 mod 8 -- every one of its ~9 M rows against the oracle."""
+    import makisu_amd
+    from makisu_amd import workloads as W
+    sh = W.c4(3, 8)
+    assert sh.n_files == 1250000 and sh.global_index[:2].tolist() == [3, 11]
+    with makisu_amd.Engine() as e:
+        files, chunks, nu = _check_shard(oracle, e, sh)
+    assert len(chunks) > 9_000_000
+    dup = chunks[chunks["dup_of"] >= 0]
+    assert (dup["length"] <= 2).all() and len(dup) < 100     # only coincidences of 1-2 byte tail chunks
 
 
 def test_c4_two_of_eight_shards_job_wide_marking(oracle, eng):
@@ -155,3 +189,24 @@ def test_bench_c4_two_ranks_on_one_gpu_gloo():
     assert j["n_gpus"] == 2 and j["config"]["name"] == "c4" and j["value"] > 0
     assert j["config"]["job_bytes_per_step"] == 2 * 20000 * 65536
     assert j["dedup_check"]["ok"], j["dedup_check"]          # job-wide unique count == closed form
+
+
+@pytest.mark.timeout(900)
+def test_bench_c5_two_ranks_split_files_on_one_gpu_gloo():
+    """bench.py --gpus 2 --config c5: the Zipf mix LPT-sharded over two ranks (both on this GPU, gloo),
+    files >= 32 MiB split into two parts whose owners agree on the boundary cuts (resolve_parts), digest
+    exchange, and the job-wide unique count = the closed form of the generator -- which only holds if the
+    parts' rows put together are the rows of the whole files."""
+    env = dict(os.environ, MI_BENCH_FORCE_DEVICE="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29579", os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--config", "c5", "--bytes-per-gpu", "3", "--split-mib", "32", "--steps", "2",
+           "--warmup", "1", "--backend", "gloo", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=800)
+    assert out.returncode == 0, out.stderr[-3000:]
+    import json
+    j = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert j["n_gpus"] == 2 and j["config"]["name"] == "c5" and "Zipf s=1.1" in j["config"]["workload"]
+    assert j["config"]["parts_this_rank"] > 0 and j["config"]["files_split_into_parts_job"] > 0
+    assert j["config"]["lpt_imbalance_max_over_mean_bytes"] < 1.02
+    assert j["dedup_check"]["ok"], j["dedup_check"]

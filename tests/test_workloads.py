@@ -25,7 +25,7 @@ def test_c4_round_robin_partition():
 def test_c5_lpt_shards_are_a_balanced_partition_with_known_duplicates():
     world = 4
     sizes, cids, originals = W.c5_global(world, bytes_per_gpu=W.GIB, hi_log2=26)
-    assert (sizes >= 1 << 10).all() and (sizes < 1 << 26).all()
+    assert (sizes >= 1 << 10).all() and (sizes <= 1 << 26).all()
     n_contents = int(cids.max()) + 1
     assert originals[:n_contents].all() and not originals[n_contents:].any()
     assert len(sizes) - n_contents > 5 * n_contents                            # copies dominate by count
@@ -62,3 +62,51 @@ def test_c2_c3_shapes():
     s = W.c3(1, 2, 10)
     assert s.n_files == 10 and (s.sizes == 128 * W.MIB).all() and s.seed == W.SEED + 1
     assert (s.global_index % 2 == 1).all()
+
+
+def test_c5_is_zipf_over_log2_buckets():
+    """BASELINE.json configs[4] / SURVEY.md 8(d): sizes Zipf(s = 1.1) over the 21 log2 buckets
+    2^10 .. 2^30 (rank 1 = the 1 KiB bucket), uniform inside a bucket, the last bucket exactly 1 GiB;
+    90 % of the files (by count) copies of the other 10 %."""
+    p = W.zipf_bucket_probs()
+    assert len(p) == 21 and abs(p.sum() - 1) < 1e-12
+    assert np.allclose(p[0] / p[1], 2 ** 1.1) and np.allclose(p[0] / p[20], 21 ** 1.1)
+    sizes, cids, originals = W.c5_global(8, bytes_per_gpu=64 * W.GIB)
+    assert sizes.min() >= 1 << 10 and sizes.max() == 1 << 30
+    n_contents = int(originals.sum())
+    assert 0.85 <= 1 - n_contents / len(sizes) <= 0.91                       # ~90 % copies by count
+    assert 0.8 * 512 * W.GIB <= sizes.sum() <= 512 * W.GIB
+    # the empirical bucket histogram of the originals follows the law (chi-square-ish, loose)
+    b = np.floor(np.log2(sizes[:n_contents])).astype(int) - 10
+    hist = np.bincount(b, minlength=21) / n_contents
+    assert np.abs(hist - p).max() < 0.03
+    assert (sizes <= 64 * W.KIB).mean() > 0.6                                # the small-file head, by count
+    assert sizes[sizes >= 64 * W.MIB].sum() > 0.8 * sizes.sum()              # the large-file tail, by bytes
+    # the rounds-1/2 stand-in is still there under its own name
+    u = W.c5u(0, 1, bytes_per_gpu=W.GIB)
+    assert u.name == "c5u" and "2^U" in u.describe
+
+
+def test_c5_several_ranks_split_the_large_files_into_parts():
+    """files >= 256 MiB become one part per GPU (group-aligned bounds), the rest is
+    LPT-balanced; every byte of every file belongs to exactly one item of one rank."""
+    world = 4
+    sizes, cids, originals = W.c5_global(world, bytes_per_gpu=8 * W.GIB)
+    shards = [W.c5(r, world, bytes_per_gpu=8 * W.GIB) for r in range(world)]
+    covered = np.zeros(len(sizes), dtype=np.int64)
+    n_parts = 0
+    for sh in shards:
+        assert sh.parts is not None and sh.imbalance < 1.01
+        for i, (fsize, b, e, pno) in enumerate(sh.parts):
+            f = int(sh.global_index[i])
+            assert fsize == sizes[f] and 0 <= b < e <= fsize and int(sh.sizes[i]) == e - b
+            if pno < 0:
+                assert (b, e) == (0, fsize) and fsize < 256 * W.MIB
+            else:
+                n_parts += 1
+                assert fsize >= 256 * W.MIB and b % W.PART_ALIGN == 0 and (e % W.PART_ALIGN == 0 or e == fsize)
+            covered[f] += e - b
+    assert np.array_equal(covered, sizes)
+    assert n_parts == world * int((sizes >= 256 * W.MIB).sum()) > 0
+    loads = [s.n_bytes for s in shards]
+    assert max(loads) / (sum(loads) / world) == shards[0].imbalance
