@@ -39,9 +39,93 @@ sys.path.insert(0, ROOT)
 
 SEED = 0x4D414B49
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
-# Measured with tools/ubench_sha.hip on MI355X: the 64-round compression alone, 8 waves/SIMD,
-# hashes 1.767 TB/s chip-wide -- the VALU roof of any one-lane-per-string SHA-256 kernel.
-SHA_VALU_ROOF_GBPS = 1767.0
+# The VALU roof of SHA-256 (the 64-round compression alone, 8 waves/SIMD, no memory traffic) is
+# MEASURED IN THIS RUN on this device (mi_sha_valu_roof, ~30 ms, right after the timed region);
+# round 1's figure from tools/ubench_sha.hip on another box was 1767 GB/s.
+
+
+class ClockSampler:
+    """sclk / socket power of one GPU from sysfs (hwmon freq1_input, power1_average | power1_input),
+    sampled every 5 ms by a thread while a region runs; rocm-smi once if sysfs has nothing."""
+
+    def __init__(self, pci_bus_id=None):
+        import glob
+        self.freq, self.power = None, None
+        for card in sorted(glob.glob("/sys/class/drm/card[0-9]*/device")):
+            try:
+                if open(card + "/vendor").read().strip() != "0x1002":
+                    continue
+                real = os.path.realpath(card)
+                if pci_bus_id and os.path.basename(real).lower() != pci_bus_id.lower():
+                    continue
+                for hw in glob.glob(card + "/hwmon/hwmon*"):
+                    f = hw + "/freq1_input"
+                    pw = [x for x in (hw + "/power1_average", hw + "/power1_input") if os.path.exists(x)]
+                    if os.path.exists(f):
+                        self.freq, self.power = f, (pw[0] if pw else None)
+                        break
+                if self.freq:
+                    break
+            except OSError:
+                continue
+        self.samples = []
+        self._stop = None
+
+    def _read(self):
+        try:
+            mhz = int(open(self.freq).read()) / 1e6 if self.freq else None
+            w = int(open(self.power).read()) / 1e6 if self.power else None
+            return mhz, w
+        except (OSError, ValueError):
+            return None, None
+
+    def start(self):
+        import threading
+        self.samples = []
+        if not self.freq:
+            return
+        self._stop = threading.Event()
+
+        def loop():
+            while not self._stop.is_set():
+                self.samples.append(self._read())
+                self._stop.wait(0.005)
+        self._t = threading.Thread(target=loop, daemon=True)
+        self._t.start()
+
+    def stop(self):
+        if self._stop is None:
+            return self.smi_once()
+        self._stop.set()
+        self._t.join()
+        self._stop = None
+        mhz = [a for a, _ in self.samples if a]
+        w = [b for _, b in self.samples if b]
+        out = {"source": "sysfs hwmon (freq1_input, %s), %d samples at 5 ms" %
+                         (os.path.basename(self.power) if self.power else "no power file", len(self.samples))}
+        if mhz:
+            out.update({"sclk_mhz_min": round(min(mhz)), "sclk_mhz_mean": round(sum(mhz) / len(mhz)), "sclk_mhz_max": round(max(mhz))})
+        if w:
+            out.update({"power_w_mean": round(sum(w) / len(w)), "power_w_max": round(max(w))})
+        return out
+
+    @staticmethod
+    def smi_once():
+        import re
+        import subprocess
+        try:
+            txt = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True,
+                                 timeout=20).stdout
+        except Exception as e:                                  # noqa: BLE001
+            return {"source": "unavailable (%s)" % type(e).__name__}
+        out = {"source": "rocm-smi --showclocks --showpower, one sample AFTER the region (no sysfs hwmon here)"}
+        m = re.search(r"sclk clock level: \d+: \((\d+)Mhz\)", txt)
+        if m:
+            out["sclk_mhz_after"] = int(m.group(1))
+        m = re.search(r"Power \(W\): ([0-9.]+)", txt)
+        if m:
+            out["power_w_after"] = float(m.group(1))
+        return out
 
 
 def usable_cores():
@@ -374,12 +458,28 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
+    try:
+        bus = torch.cuda.get_device_properties(dev_index).pci_bus_id
+        dom = getattr(torch.cuda.get_device_properties(dev_index), "pci_domain_id", 0)
+        pci = "%04x:%02x:%02x.0" % (dom, bus, torch.cuda.get_device_properties(dev_index).pci_device_id)
+    except Exception:                                           # noqa: BLE001
+        pci = None
+    sampler = ClockSampler(pci)
+    if sampler.freq is None and pci is not None:
+        sampler = ClockSampler(None)                            # containers often show one card only
     run_steps(args.warmup, False)
     fence()
+    sampler.start()
     t0 = time.perf_counter()
     run_steps(args.steps, True)
     fence()
     dt = time.perf_counter() - t0
+    clocks = sampler.stop() if rank == 0 else None
+    # the SHA-256 VALU roof of THIS device in THIS run, right behind the timed region (same thermal and
+    # power state): best of three 10 ms launches of the compression alone
+    sampler.start()
+    valu_roof = eng.sha_valu_roof() / 1e9
+    roof_clocks = sampler.stop() if rank == 0 else None
     if dist.is_initialized() and world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -405,6 +505,26 @@ def main():
                 serial_sha_ms.append(st["ms_sha_chunks"])
         serial_phase = {k: round(v, 4) for k, v in st.items() if k.startswith("ms_")}
         serial_alg = st["bytes_in"] + 52 * st["n_chunks"]
+
+    # The same pass with the OTHER load scheme (quad-cooperative: far fewer address translations), a few
+    # serial steps on a second ctx: on a box whose lane-owned launches run well below the VALU roof this
+    # tells a translation-bound kernel (cooperative faster) from a clock-bound one (both slow alike).
+    other_scheme = None
+    if config == "c2" and world == 1 and rank == 0:
+        auto_coop = shards[0].n_bytes >= (9 << 30)
+        e2 = makisu_amd.Engine(device=dev_index, sha_load_scheme=makisu_amd.SHA_LOADS_LANE if auto_coop
+                               else makisu_amd.SHA_LOADS_COOP)
+        b2 = e2.batch(shards[0].n_files, shards[0].n_bytes)
+        b2.add_synthetic(shards[0].sizes, shards[0].cids, seed=shards[0].seed)
+        ms2 = []
+        for i in range(7):
+            b2.run() if i == 0 else b2.rerun()
+            if i >= 2:
+                ms2.append(e2.stats()["ms_sha_chunks"])
+        b2.free()
+        e2.close()
+        other_scheme = {"scheme": "lane-owned" if auto_coop else "quad-cooperative",
+                        "serial_launch_ms": round(float(np.median(ms2)), 4)}
 
     # closed-form check of the duplicate marking (c5: 90 % duplicate files): the job-wide unique
     # count must equal the chunk count of the first file of every distinct content
@@ -470,14 +590,16 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "sha256_items_kernel (chunk pass)",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                     "traffic_source": traffic_src,
+                     "traffic_from_profile_run": traffic_src,
                      "algorithmic_bytes_per_launch": int(alg_bytes),
                      "avg_launch_ms": round(sha_avg_ms, 4),
-                     "valu_roof_GBps": SHA_VALU_ROOF_GBPS,
-                     "frac_of_valu_roof": round(achieved / SHA_VALU_ROOF_GBPS, 4),
+                     "valu_roof_GBps": round(valu_roof, 1),
+                     "valu_roof_source": "mi_sha_valu_roof in this run, right after the timed region: the 64-round "
+                                         "compression alone on every SIMD (8 waves each, no memory traffic), best of 3",
+                     "frac_of_valu_roof": round(achieved / valu_roof, 4),
                      "path_frac": round(job_bytes / world * 1.006 / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS, 4),
-                     "note": "SHA-256 is integer-VALU bound on CDNA4 (measured roof 1.77 TB/s "
-                             "hashed, tools/ubench_sha.hip); the HBM fraction cannot exceed 0.22. "
+                     "note": "SHA-256 is integer-VALU bound on CDNA4 (valu_roof_GBps, measured in this run); "
+                             "the HBM fraction cannot exceed valu_roof / peak. "
                              "achieved/avg_launch_ms are from the timed region, where the kernel "
                              "shares the GPU with the other in-flight batches' passes; "
                              "serial_* = the same kernel with one batch at a time (median of 7 extra "
@@ -492,6 +614,8 @@ def main():
                               "files_split_into_parts_job": getattr(desc_shard, "n_split_files_job", 0),
                               "parts_this_rank": sum(1 for p_ in (desc_shard.parts or ()) if p_[3] >= 0),
                               "part_boundary_rounds": part_rounds})
+    if clocks is not None:
+        out["clocks"] = {"timed_region": clocks, "valu_roof_launches": roof_clocks}
     if dedup_check:
         out["dedup_check"] = dedup_check
     if serial_sha_ms:
@@ -500,8 +624,10 @@ def main():
         out["roofline"].update({"serial_avg_launch_ms": round(s_ms, 4),
                                 "serial_achieved": round(s_ach, 1),
                                 "serial_frac": round(s_ach / HBM_PEAK_GBPS, 4),
-                                "serial_frac_of_valu_roof": round(s_ach / SHA_VALU_ROOF_GBPS, 4)})
+                                "serial_frac_of_valu_roof": round(s_ach / valu_roof, 4)})
         out["serial_phase_ms"] = serial_phase
+    if other_scheme:
+        out["roofline"]["other_load_scheme_serial"] = other_scheme
     if rank == 0 and world == 1:
         if host_fed:
             out["config"].update(host_fed)

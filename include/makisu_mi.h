@@ -171,6 +171,13 @@ int  mi_get_stats(mi_ctx* ctx, mi_stats* out);
 int  mi_device_info(mi_ctx* ctx, int32_t* n_cu, int32_t* clock_mhz, uint64_t* hbm_bytes,
                     char* name, size_t name_cap);
 
+/* The integer-VALU roof of SHA-256 on this device, measured now: every lane runs `blocks` 64-round
+ * compressions over register data (the very function the hashing kernels inline; no memory traffic),
+ * waves_per_simd waves on every SIMD; *bytes_per_second = 64 bytes per compression over the best of
+ * three launches.  0 = defaults (8 waves, 512 blocks: ~10 ms).  bench.py quotes the SHA pass against
+ * this number from the same run (SURVEY.md 8d "second roof that actually binds SHA-256").          */
+int  mi_sha_valu_roof(mi_ctx* ctx, uint32_t waves_per_simd, uint32_t blocks, double* bytes_per_second);
+
 /* ---- batch: a set of files scanned in one pass --------------------------------- *
  * Serves the per-entry loop of MemFS.commitLayer -> contentMemFile.commit ->
  * tario.WriteEntry (lib/snapshot/mem_fs.go:424-433, mem_layer.go:83-88,

@@ -175,6 +175,7 @@ def load_library(rebuild=False):
         "mi_get_stats": ([vp, C.POINTER(Stats)], C.c_int),
         "mi_device_info": ([vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), u64p, C.c_char_p,
                             C.c_size_t], C.c_int),
+        "mi_sha_valu_roof": ([vp, C.c_uint32, C.c_uint32, C.POINTER(C.c_double)], C.c_int),
         "mi_batch_begin": ([vp, u64, u64, C.POINTER(vp)], C.c_int),
         "mi_batch_add_bytes": ([vp, vp, u64, u64], C.c_int),
         "mi_batch_add_path": ([vp, C.c_char_p, u64, u64], C.c_int),
@@ -715,6 +716,12 @@ class Engine:
                                              name, 256))
         return {"n_cu": ncu.value, "clock_mhz": mhz.value, "hbm_bytes": mem.value,
                 "name": name.value.decode()}
+
+    def sha_valu_roof(self, waves_per_simd=0, blocks=0):
+        """The SHA-256 VALU roof of this device right now, in bytes hashed per second (mi_sha_valu_roof)."""
+        v = C.c_double()
+        self._check(self._lib.mi_sha_valu_roof(self._h, waves_per_simd, blocks, C.byref(v)))
+        return v.value
 
     def stats(self):
         st = Stats()

@@ -735,6 +735,22 @@ int mi_get_stats(mi_ctx* c, mi_stats* out) {
     return MI_OK;
 }
 
+int mi_sha_valu_roof(mi_ctx* c, uint32_t waves_per_simd, uint32_t blocks, double* bytes_per_second) {
+    if (!c || !bytes_per_second) return MI_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (waves_per_simd == 0) waves_per_simd = 8;
+    if (blocks == 0) blocks = 512;
+    if (waves_per_simd > 8 || blocks > (1u << 20)) return fail(c, MI_ERR_INVALID, "mi_sha_valu_roof: waves_per_simd <= 8, blocks <= 2^20");
+    DevBuf scratch;
+    HIPCHK(c, scratch.ensure((size_t)c->prop.multiProcessorCount * waves_per_simd * kShaWG * 4));
+    *bytes_per_second = measure_sha_valu_roof(c->prop.multiProcessorCount, (int)waves_per_simd, blocks,
+                                              scratch.as<u32>(), c->stream, c->ev[0], c->ev[1]);
+    const hipError_t e = hipGetLastError();
+    scratch.release();
+    if (e != hipSuccess || *bytes_per_second <= 0) return fail(c, MI_ERR_HIP, "mi_sha_valu_roof: %s", hipGetErrorString(e));
+    return MI_OK;
+}
+
 int mi_device_info(mi_ctx* c, int32_t* n_cu, int32_t* clock_mhz, uint64_t* hbm_bytes, char* name,
                    size_t name_cap) {
     if (!c) return MI_ERR_INVALID;

@@ -114,6 +114,9 @@ void launch_sha256_items(ShaPass pass, const u8* d_base, const u64* d_off, const
                          const u32* d_ids, u32 n, const u64* d_n, u32* d_heads, bool zero_heads,
                          u8* d_out, const ShaTune& tune, int n_cu, u64 footprint_bytes, hipStream_t s);
 // footprint_bytes: the span of memory the strings lie in (picks the load scheme, sha256.hip kCoop)
+// d_scratch: n_cu * waves_per_simd * kShaWG words
+double measure_sha_valu_roof(int n_cu, int waves_per_simd, u32 blocks, u32* d_scratch, hipStream_t s,
+                             hipEvent_t e0, hipEvent_t e1);
 
 // tables.hip
 // unit0: the files' first byte is byte 16 * unit0 of their content stream (0 except for parts)

@@ -423,4 +423,45 @@ void launch_sha256_items(ShaPass pass, const u8* d_base, const u64* d_off, const
 #undef MI_SHA_LAUNCH
 }
 
+// ---- the VALU roof of this file's compression, measured on the device it runs on ------------------
+// 64 rounds per lane and iteration over register data: no memory traffic, no queues, no tails.  What it
+// times is sha256_compress itself -- the same code the item kernels inline -- so the rate it gives is
+// the ceiling of ANY one-lane-per-string form of them on this chip at this moment's clocks.
+__global__ __launch_bounds__(kShaWG)
+void sha256_roof_kernel(u32* __restrict__ out, u32 blocks) {
+    u32 st[8], w[16];
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) st[i] = t * 0x9E3779B9u + (u32)i;
+    u32 x = t * 0x85EBCA6Bu + 1u;
+    for (u32 b = 0; b < blocks; ++b) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { x = x * 1664525u + 1013904223u; w[i] = x ^ st[i & 7]; }
+        sha256_compress(st, w);
+    }
+    u32 r = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r ^= st[i];
+    out[t] = r;
+}
+
+// bytes "hashed" per second by n_cu * waves_per_simd workgroups running `blocks` compressions per lane
+double measure_sha_valu_roof(int n_cu, int waves_per_simd, u32 blocks, u32* d_scratch, hipStream_t s,
+                             hipEvent_t e0, hipEvent_t e1) {
+    const u32 grid = (u32)(n_cu * waves_per_simd);                 // a workgroup = one wave on each of the CU's 4 SIMDs
+    hipLaunchKernelGGL(sha256_roof_kernel, dim3(grid), dim3(kShaWG), 0, s, d_scratch, blocks / 8 + 1);   // clocks up
+    double best = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+        (void)hipEventRecord(e0, s);
+        hipLaunchKernelGGL(sha256_roof_kernel, dim3(grid), dim3(kShaWG), 0, s, d_scratch, blocks);
+        (void)hipEventRecord(e1, s);
+        if (hipStreamSynchronize(s) != hipSuccess) return 0;
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        const double rate = ms > 0 ? (double)grid * kShaWG * blocks * 64.0 / (ms * 1e-3) : 0;
+        best = rate > best ? rate : best;
+    }
+    return best;
+}
+
 }  // namespace mi
