@@ -353,6 +353,15 @@ def main():
         if world > 1:
             dist.broadcast_object_list(uid, src=0)          # torchrun only ships the 128-byte id
         eng.comm_init_rank(world, rank, uid[0])
+    # how many ranks the collective library itself sees -- a scaling line must be able to prove its N
+    rccl_ranks = None
+    if exchange:
+        if args.exchange == "native":
+            rccl_ranks = eng.comm_ranks()                    # ncclCommCount of the library's own communicator
+        elif args.backend == "nccl":
+            rccl_ranks = dist.get_world_size()               # torch's NCCL(=RCCL) group, created with device_id above
+        if rccl_ranks is not None and rccl_ranks != args.gpus and (world > 1 or args.force_exchange):
+            raise SystemExit("the collective library sees %d rank(s), --gpus says %d" % (rccl_ranks, args.gpus))
 
     # The rank's share of the config, as `inflight` batches of distinct content.  Step k runs on
     # batch k % inflight: every step is a complete pass (all outputs recomputed); a step is
@@ -583,6 +592,8 @@ def main():
                    "parallelism": "files sharded x%d (%s)" % (world, "LPT by bytes" if config in ("c5", "c5u") else "file index mod N"),
                    "batches_in_flight": args.inflight, "launches_per_step": launches_per_step,
                    "exchange": (args.exchange if exchange else None),
+                   "rccl_ranks": rccl_ranks,
+                   "exchange_backend": (args.backend if exchange else None),
                    "device": info["name"].strip(), "n_cu": info["n_cu"],
                    "results": "left on the device (16 B of counts read back per batch); mi_batch_chunks_view / "
                               "mi_batch_files bring 64 B per chunk + 96 B per file to the host on demand "

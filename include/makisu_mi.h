@@ -333,7 +333,8 @@ int mi_batch_device_dup_of(mi_batch* b, const void** d_dup_of, uint64_t* n_chunk
 
 /* ---- the digest exchange inside the library: RCCL all-gather over xGMI ---------------- *
  * For hosts without torch (the Go shim).  RCCL is loaded at run time (dlopen), so these
- * fail with MI_ERR_NO_DEVICE where no librccl exists.  Multi-process: rank 0 obtains the
+ * fail with MI_ERR_NO_DEVICE where no librccl exists (MI_RCCL_LIB=<path> names another library with
+ * the same eight nccl* entry points: tests/rccl_stub is one, for n ranks on a single GPU).  Multi-process: rank 0 obtains the
  * id, ships it to the peers, every rank calls mi_comm_init_rank.  Single process driving n
  * devices (one ctx each): mi_comm_init_all + mi_dedup_allgather_all.
  * mi_dedup_allgather: all-gathers the batches' digest arrays (counts first, then slabs
@@ -346,6 +347,9 @@ int mi_comm_unique_id(void* id_out /* MI_COMM_ID_BYTES */);
 int mi_comm_init_rank(mi_ctx* ctx, int nranks, int rank, const void* id);
 int mi_comm_init_all(mi_ctx** ctxs, int n);
 int mi_comm_destroy(mi_ctx* ctx);
+/* How many ranks the ctx's communicator spans (ncclCommCount); 0 without a communicator.  What a
+ * scaling run records next to its number: a job that believes it ran on 8 GPUs can prove it.     */
+int mi_comm_ranks(mi_ctx* ctx, int* n_ranks);
 int mi_dedup_allgather(mi_batch* b, uint64_t* n_total, uint64_t* n_unique,
                        uint64_t* first_global);
 int mi_dedup_allgather_all(mi_batch** batches, int n, uint64_t* n_total, uint64_t* n_unique);

@@ -252,6 +252,7 @@ def load_library(rebuild=False):
         "mi_comm_init_rank": ([vp, C.c_int, C.c_int, vp], C.c_int),
         "mi_comm_init_all": ([C.POINTER(vp), C.c_int], C.c_int),
         "mi_comm_destroy": ([vp], C.c_int),
+        "mi_comm_ranks": ([vp, C.POINTER(C.c_int)], C.c_int),
         "mi_dedup_allgather": ([vp, u64p, u64p, u64p], C.c_int),
         "mi_dedup_allgather_all": ([C.POINTER(vp), C.c_int, u64p, u64p], C.c_int),
         "mi_index_create": ([vp, u64, C.POINTER(vp)], C.c_int),
@@ -764,6 +765,12 @@ class Engine:
     def comm_destroy(self):
         self._check(self._lib.mi_comm_destroy(self._h))
 
+    def comm_ranks(self):
+        """Ranks of this ctx's communicator as the collective library counts them (0: none)."""
+        n = C.c_int()
+        self._check(self._lib.mi_comm_ranks(self._h, C.byref(n)))
+        return n.value
+
     def dedup_mark_range(self, d_digests_ptr, n_total, own_first, own_n, d_dup_of_own_ptr):
         """dup_of (global indices) for the rows [own_first, own_first+own_n) of a job-wide,
         rank-major digest set; returns how many of them are job-wide first occurrences."""
@@ -777,6 +784,26 @@ class Engine:
         nu = C.c_uint64()
         self._check(self._lib.mi_dedup_mark(self._h, d_digests_ptr, n, d_dup_of_ptr, C.byref(nu)))
         return nu.value
+
+
+def comm_init_all(engines):
+    """mi_comm_init_all: one communicator over the ctxs of ONE process (rank i = engines[i])."""
+    arr = (C.c_void_p * len(engines))(*[e._h for e in engines])
+    rc = load_library().mi_comm_init_all(arr, len(engines))
+    if rc:
+        raise MiError(rc, engines[0]._lib.mi_last_error(engines[0]._h).decode())
+
+
+def dedup_allgather_all(batches):
+    """mi_dedup_allgather_all: the exchange + job-wide marking for the batches of comm_init_all's ctxs,
+    rank order.  Returns (n_total, n_unique)."""
+    arr = (C.c_void_p * len(batches))(*[b._h for b in batches])
+    a, b_ = C.c_uint64(), C.c_uint64()
+    rc = load_library().mi_dedup_allgather_all(arr, len(batches), C.byref(a), C.byref(b_))
+    if rc:
+        e = batches[0].engine
+        raise MiError(rc, "; ".join(x.engine._lib.mi_last_error(x.engine._h).decode() for x in batches) or str(e))
+    return a.value, b_.value
 
 
 class Batch:

@@ -1411,8 +1411,10 @@ int mi_dedup_mark(mi_ctx* c, const void* d_digests, uint64_t n, void* d_dup_of, 
     return MI_OK;
 }
 
-int mi_dedup_mark_range(mi_ctx* c, const void* d_digests, uint64_t n_total, uint64_t own_first,
-                        uint64_t own_n, void* d_dup_of_own, uint64_t* n_own_first) {
+// enqueue only (ctx stream): the rows' dup_of and, in c->dd_nuniq (a device word), how many of them are
+// job-wide first occurrences -- mi_comm.hip all-gathers that word without a host round trip
+int mi_dedup_mark_range_enqueue(mi_ctx* c, const void* d_digests, uint64_t n_total, uint64_t own_first,
+                                uint64_t own_n, void* d_dup_of_own) {
     if (!c || own_first > n_total || own_n > n_total - own_first || (own_n && (!d_digests || !d_dup_of_own)))
         return MI_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
@@ -1427,6 +1429,13 @@ int mi_dedup_mark_range(mi_ctx* c, const void* d_digests, uint64_t n_total, uint
     launch_dedup_mark_range((const u8*)d_digests, own_first, own_n, c->dd_table.as<u32>(), c->dd_tag.as<u64>(),
                             c->dd_slot.as<u32>(), cap, (i64*)d_dup_of_own, c->dd_nuniq.as<u64>(), c->stream);
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    return MI_OK;
+}
+
+int mi_dedup_mark_range(mi_ctx* c, const void* d_digests, uint64_t n_total, uint64_t own_first,
+                        uint64_t own_n, void* d_dup_of_own, uint64_t* n_own_first) {
+    int rc = mi_dedup_mark_range_enqueue(c, d_digests, n_total, own_first, own_n, d_dup_of_own);
+    if (rc) return rc;
     HIPCHK(c, hipMemcpyAsync(c->h_word, c->dd_nuniq.p, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());

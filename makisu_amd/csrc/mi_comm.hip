@@ -15,13 +15,17 @@
 // then the padding is squeezed out with device copies and the rank marks ITS OWN rows against
 // the gathered set (mi_batch_mark_global); dup_of of the batch is rewritten with GLOBAL row
 // indices (rank-major); a last 8-byte all-gather sums the ranks' first-occurrence counts.
-// Host synchronisations per exchange: three (the counts, the marking's count, the sum); scalars
-// travel through one pinned block, never through stack memory; the digest array is sent from
-// where the batch keeps it whenever the padded slab fits its allocation.
+// Host synchronisations per exchange: TWO -- the counts (the slab size is a host decision) and the
+// end (round 2: three; the marking's first-occurrence count now goes from the kernel's device word
+// straight into the summing all-gather); scalars travel through one pinned block, never through
+// stack memory; the digest array is sent from where the batch keeps it whenever the padded slab
+// fits its allocation.  MI_RCCL_LIB=<path> loads that library instead of librccl (the test double of
+// tests/rccl_stub: n ranks on ONE GPU, which RCCL itself refuses).
 #include "mi_internal.h"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -36,6 +40,7 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
@@ -47,9 +52,13 @@ Rccl* rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
+        if (const char* over = getenv("MI_RCCL_LIB")) {         // a test double, or a differently named RCCL
+            r.lib = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+            if (!r.lib) { r.err = std::string("cannot load MI_RCCL_LIB: ") + dlerror(); return; }
+        }
         for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (r.lib) break;
+            r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         }
         if (!r.lib) { r.err = std::string("cannot load librccl: ") + dlerror(); return; }
 #define MI_SYM(field, sym)                                                    \
@@ -59,6 +68,7 @@ Rccl* rccl() {
         MI_SYM(CommInitRank, "ncclCommInitRank")
         MI_SYM(CommInitAll, "ncclCommInitAll")
         MI_SYM(CommDestroy, "ncclCommDestroy")
+        MI_SYM(CommCount, "ncclCommCount")
         MI_SYM(AllGather, "ncclAllGather")
         MI_SYM(GroupStart, "ncclGroupStart")
         MI_SYM(GroupEnd, "ncclGroupEnd")
@@ -121,7 +131,7 @@ int exchange_slabs_enqueue(mi_batch* b, std::vector<u64>& counts, u64* max_out) 
     Exchange* x = exchange_of(c);
     counts.resize((size_t)c->comm_nranks);
     HIPCHK(c, hipMemcpyAsync(x->pin + 1, x->counts.p, 8 * counts.size(), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));            // sync 1 of 3: the slab size is a host decision
+    HIPCHK(c, hipStreamSynchronize(c->stream));            // sync 1 of 2: the slab size is a host decision
     u64 m = 0;
     for (size_t r = 0; r < counts.size(); ++r) { counts[r] = x->pin[1 + r]; m = counts[r] > m ? counts[r] : m; }
     *max_out = m;
@@ -139,7 +149,7 @@ int exchange_slabs_enqueue(mi_batch* b, std::vector<u64>& counts, u64* max_out) 
 }
 
 int mark_and_rewrite(mi_batch* b, const std::vector<u64>& counts, u64 m, uint64_t* n_total,
-                     uint64_t* n_unique, uint64_t* first_global) {
+                     uint64_t* first_global) {
     mi_ctx* c = b->ctx;
     Exchange* x = exchange_of(c);
     u64 total = 0, first = 0;
@@ -161,34 +171,29 @@ int mark_and_rewrite(mi_batch* b, const std::vector<u64>& counts, u64 m, uint64_
         }
         glob = x->compact.as<u8>();
     }
-    // (no sync here: the marking below is enqueued on the same stream)
-    // this rank answers for its own rows only, straight into the batch's dup_of column
-    // (mi_batch_mark_global); the job-wide unique count is the sum of the ranks'
-    // first-occurrence counts, summed by the caller
-    uint64_t nf = 0;
-    int rc = mi_batch_mark_global(b, glob, total, first, &nf);
+    // no sync: the marking is enqueued on the same stream and leaves its first-occurrence count in the
+    // ctx's device word; this rank answers for its own rows only, straight into the batch's dup_of column
+    HIPCHK(c, b->dup_of.ensure(b->n_chunks * 8 + 16));      // absent when the ctx has MI_FLAG_NO_DEDUP
+    int rc = mi_dedup_mark_range_enqueue(c, glob, total, first, b->n_chunks, b->dup_of.p);
     if (rc) return rc;
+    b->results_valid = false;
     if (n_total) *n_total = total;
-    if (n_unique) *n_unique = nf;
     if (first_global) *first_global = first;
     return MI_OK;
 }
 
-// sums one u64 per rank over the communicator (an all-gather of the 8-byte counts, added on
-// the host: no second collective type to bind)
-int sum_over_ranks_enqueue(mi_ctx* c, u64 mine) {
+// sums the ranks' first-occurrence counts over the communicator: an all-gather of the marking kernel's
+// device word (no host round trip in between), added on the host -- no second collective type to bind
+int sum_over_ranks_enqueue(mi_ctx* c) {
     Exchange* x = exchange_of(c);
-    u64* d_counts = x->counts.as<u64>();
-    x->pin[0] = mine;
-    HIPCHK(c, hipMemcpyAsync(d_counts + c->comm_nranks, x->pin, 8, hipMemcpyHostToDevice, c->stream));
-    NCCLCHK(c, rccl()->AllGather(d_counts + c->comm_nranks, d_counts, 1, ncclUint64,
-                                 (ncclComm_t)c->comm, c->stream));
+    NCCLCHK(c, rccl()->AllGather(c->dd_nuniq.p, x->counts.p, 1, ncclUint64, (ncclComm_t)c->comm, c->stream));
     return MI_OK;
 }
 int sum_over_ranks_finish(mi_ctx* c, u64* sum) {
     Exchange* x = exchange_of(c);
     HIPCHK(c, hipMemcpyAsync(x->pin + 1, x->counts.p, 8 * (size_t)c->comm_nranks, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));            // sync 3 of 3
+    HIPCHK(c, hipStreamSynchronize(c->stream));            // sync 2 of 2
+    HIPCHK(c, hipGetLastError());
     *sum = 0;
     for (int r = 0; r < c->comm_nranks; ++r) *sum += x->pin[1 + r];
     return MI_OK;
@@ -246,6 +251,14 @@ int mi_comm_init_all(mi_ctx** ctxs, int n) {
     return MI_OK;
 }
 
+int mi_comm_ranks(mi_ctx* c, int* n_ranks) {
+    if (!c || !n_ranks) return MI_ERR_INVALID;
+    *n_ranks = 0;
+    if (!c->comm) return MI_OK;                // no communicator: 0 ranks
+    NCCLCHK(c, rccl()->CommCount((ncclComm_t)c->comm, n_ranks));
+    return MI_OK;
+}
+
 int mi_comm_destroy(mi_ctx* c) {
     if (!c) return MI_ERR_INVALID;
     if (c->comm) {
@@ -278,10 +291,9 @@ int mi_dedup_allgather(mi_batch* b, uint64_t* n_total, uint64_t* n_unique, uint6
     u64 m = 0;
     rc = exchange_slabs_enqueue(b, counts, &m);
     if (rc) return rc;
-    uint64_t own_first_count = 0;
-    rc = mark_and_rewrite(b, counts, m, n_total, &own_first_count, first_global);
+    rc = mark_and_rewrite(b, counts, m, n_total, first_global);
     if (rc) return rc;
-    rc = sum_over_ranks_enqueue(c, own_first_count);
+    rc = sum_over_ranks_enqueue(c);
     if (rc) return rc;
     u64 sum = 0;
     rc = sum_over_ranks_finish(c, &sum);
@@ -318,14 +330,21 @@ int mi_dedup_allgather_all(mi_batch** batches, int n, uint64_t* n_total, uint64_
     }
     NCCLCHK(c0, rccl()->GroupEnd());
     if (rc) return rc;
-    uint64_t unique_sum = 0;
-    for (int i = 0; i < n; ++i) {
+    for (int i = 0; i < n; ++i) {              // every rank's marking enqueued on its own stream ...
         (void)hipSetDevice(batches[i]->ctx->device);
-        uint64_t nt = 0, nu = 0;
-        rc = mark_and_rewrite(batches[i], counts[(size_t)i], maxes[(size_t)i], &nt, &nu, nullptr);
+        uint64_t nt = 0;
+        rc = mark_and_rewrite(batches[i], counts[(size_t)i], maxes[(size_t)i], &nt, nullptr);
         if (rc) return rc;
         if (n_total) *n_total = nt;
-        unique_sum += nu;                  // every rank counted its own first occurrences
+    }
+    uint64_t unique_sum = 0;
+    for (int i = 0; i < n; ++i) {              // ... then read: the counts are in this process, no collective
+        mi_ctx* c = batches[i]->ctx;
+        (void)hipSetDevice(c->device);
+        HIPCHK(c, hipMemcpyAsync(c->h_word, c->dd_nuniq.p, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipGetLastError());
+        unique_sum += *c->h_word;              // every rank counted its own first occurrences
     }
     if (n_unique) *n_unique = unique_sum;
     return MI_OK;

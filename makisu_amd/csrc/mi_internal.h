@@ -160,6 +160,11 @@ struct mi_batch {
 };
 
 
+// mi_api.hip, for mi_comm.hip: job-wide marking of a rank's own rows, enqueued on the ctx stream; the
+// first-occurrence count stays in ctx->dd_nuniq (device)
+extern "C" int mi_dedup_mark_range_enqueue(mi_ctx* c, const void* d_digests, uint64_t n_total, uint64_t own_first,
+                                           uint64_t own_n, void* d_dup_of_own);
+
 #define HIPCHK(c, call)                                                                     \
     do {                                                                                    \
         hipError_t e_ = (call);                                                             \

@@ -1,0 +1,245 @@
+// mi_rccl_stub.cpp -- a TEST DOUBLE for librccl: the eight nccl* entry points mi_comm.hip binds,
+// implemented so that n ranks can share ONE GPU (RCCL refuses that with ncclInvalidUsage), which is
+// the only way the n > 1 code paths of the native exchange can execute on a one-GPU box
+// (VERDICT r2 item 5).  Loaded through MI_RCCL_LIB=<this .so>.  Test infrastructure only.
+//
+//   multi-process (ncclCommInitRank): ranks rendezvous in a POSIX shared-memory segment named by the
+//     128-byte unique id; ncclAllGather waits for the caller's stream, copies its send buffer into its
+//     slot of the segment, meets the other ranks at a barrier, copies every slot into its receive
+//     buffer, meets them again (so the slots can be reused).  Synchronous -- a collective that has
+//     completed when the call returns is a legal, if slow, implementation of the stream semantics.
+//   single process (ncclCommInitAll): calls are recorded between ncclGroupStart / ncclGroupEnd and
+//     executed at the outermost ncclGroupEnd, when every rank's operation is there; outside a group a
+//     collective on such a communicator is ncclInvalidUsage (with the real library it would hang).
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <fcntl.h>
+#include <sched.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <mutex>
+#include <vector>
+
+namespace {
+
+constexpr size_t kHdr = 4096;
+struct ShmHdr {
+    std::atomic<uint32_t> arrived, gen, attached;
+};
+
+struct World {                        // single-process communicators share one
+    int n = 0;
+    std::vector<int> devs;
+    struct Op { const void* send; void* recv; size_t bytes; hipStream_t stream; bool set = false; };
+    std::vector<std::vector<Op>> pending;        // pending[k][rank]
+    std::vector<size_t> next;                    // per rank: index of its next op in this group
+};
+
+struct Comm {
+    int n = 1, rank = 0;
+    // multi-process
+    ShmHdr* hdr = nullptr;
+    uint8_t* slots = nullptr;
+    size_t slot_bytes = 0, map_bytes = 0;
+    char name[64] = {0};
+    // single process
+    World* world = nullptr;
+};
+
+std::mutex g_mu;
+int g_group_depth = 0;
+std::vector<World*> g_group_worlds;
+std::atomic<uint32_t> g_ids{0};
+
+size_t type_bytes(ncclDataType_t t) {
+    switch (t) {
+        case ncclInt8: case ncclUint8: return 1;
+        case ncclFloat16: case ncclBfloat16: return 2;
+        case ncclInt32: case ncclUint32: case ncclFloat32: return 4;
+        default: return 8;
+    }
+}
+
+void barrier(Comm* c) {
+    const uint32_t g = c->hdr->gen.load();
+    if (c->hdr->arrived.fetch_add(1) + 1 == (uint32_t)c->n) {
+        c->hdr->arrived.store(0);
+        c->hdr->gen.fetch_add(1);
+    } else {
+        while (c->hdr->gen.load() == g) sched_yield();
+    }
+}
+
+ncclResult_t run_world_ops(World* w) {
+    for (auto& row : w->pending) {
+        for (int r = 0; r < w->n; ++r)
+            if (!row[(size_t)r].set) return ncclInvalidUsage;      // a rank missed the collective
+        for (int r = 0; r < w->n; ++r) {
+            if (hipSetDevice(w->devs[(size_t)r]) != hipSuccess) return ncclUnhandledCudaError;
+            if (hipStreamSynchronize(row[(size_t)r].stream) != hipSuccess) return ncclUnhandledCudaError;
+        }
+        for (int r = 0; r < w->n; ++r)
+            for (int j = 0; j < w->n; ++j) {
+                if (row[(size_t)j].bytes != row[(size_t)r].bytes) return ncclInvalidArgument;
+                if (hipMemcpy((uint8_t*)row[(size_t)r].recv + (size_t)j * row[(size_t)j].bytes, row[(size_t)j].send,
+                              row[(size_t)j].bytes, hipMemcpyDeviceToDevice) != hipSuccess)
+                    return ncclUnhandledCudaError;
+            }
+    }
+    if (hipDeviceSynchronize() != hipSuccess) return ncclUnhandledCudaError;
+    w->pending.clear();
+    for (auto& x : w->next) x = 0;
+    return ncclSuccess;
+}
+
+}  // namespace
+
+extern "C" {
+
+ncclResult_t ncclGetUniqueId(ncclUniqueId* id) {
+    memset(id, 0, sizeof *id);
+    snprintf(id->internal, sizeof id->internal, "/mi_rccl_stub_%d_%u", (int)getpid(), g_ids.fetch_add(1));
+    return ncclSuccess;
+}
+
+ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int rank) {
+    if (!comm || nranks < 1 || rank < 0 || rank >= nranks) return ncclInvalidArgument;
+    Comm* c = new Comm();
+    c->n = nranks;
+    c->rank = rank;
+    const char* mb = getenv("MI_RCCL_STUB_SLOT_MB");
+    c->slot_bytes = (size_t)(mb ? atoi(mb) : 64) << 20;
+    c->map_bytes = kHdr + (size_t)nranks * c->slot_bytes;
+    snprintf(c->name, sizeof c->name, "%s", id.internal);
+    int fd = shm_open(c->name, O_RDWR | O_CREAT | O_EXCL, 0600);
+    if (fd >= 0) {
+        if (ftruncate(fd, (off_t)c->map_bytes) != 0) { close(fd); delete c; return ncclSystemError; }   // zero-filled
+    } else {
+        for (int tries = 0; tries < 200000 && fd < 0; ++tries) { fd = shm_open(c->name, O_RDWR, 0600); if (fd < 0) usleep(100); }
+        if (fd < 0) { delete c; return ncclSystemError; }
+        struct stat st;
+        for (int tries = 0; tries < 200000; ++tries) {
+            if (fstat(fd, &st) == 0 && (size_t)st.st_size >= c->map_bytes) break;
+            usleep(100);
+        }
+    }
+    void* p = mmap(nullptr, c->map_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) { delete c; return ncclSystemError; }
+    c->hdr = (ShmHdr*)p;
+    c->slots = (uint8_t*)p + kHdr;
+    c->hdr->attached.fetch_add(1);
+    while (c->hdr->attached.load() < (uint32_t)nranks) sched_yield();      // everybody is mapped: the name can go
+    barrier(c);
+    if (rank == 0) shm_unlink(c->name);
+    *comm = (ncclComm_t)c;
+    return ncclSuccess;
+}
+
+ncclResult_t ncclCommInitAll(ncclComm_t* comms, int ndev, const int* devlist) {
+    if (!comms || ndev < 1) return ncclInvalidArgument;
+    World* w = new World();
+    w->n = ndev;
+    w->next.assign((size_t)ndev, 0);
+    for (int i = 0; i < ndev; ++i) w->devs.push_back(devlist ? devlist[i] : i);
+    for (int i = 0; i < ndev; ++i) {
+        Comm* c = new Comm();
+        c->n = ndev;
+        c->rank = i;
+        c->world = w;
+        comms[i] = (ncclComm_t)c;
+    }
+    return ncclSuccess;
+}
+
+ncclResult_t ncclCommDestroy(ncclComm_t comm) {
+    Comm* c = (Comm*)comm;
+    if (!c) return ncclSuccess;
+    if (c->hdr) munmap((void*)c->hdr, c->map_bytes);
+    // (a World is leaked with its last communicator: test processes are short-lived)
+    delete c;
+    return ncclSuccess;
+}
+
+ncclResult_t ncclCommCount(const ncclComm_t comm, int* count) {
+    if (!comm || !count) return ncclInvalidArgument;
+    *count = ((Comm*)comm)->n;
+    return ncclSuccess;
+}
+
+ncclResult_t ncclGroupStart() {
+    std::lock_guard<std::mutex> g(g_mu);
+    ++g_group_depth;
+    return ncclSuccess;
+}
+
+ncclResult_t ncclGroupEnd() {
+    std::lock_guard<std::mutex> g(g_mu);
+    if (g_group_depth <= 0) return ncclInvalidUsage;
+    if (--g_group_depth > 0) return ncclSuccess;
+    ncclResult_t rc = ncclSuccess;
+    for (World* w : g_group_worlds) {
+        const ncclResult_t r = run_world_ops(w);
+        if (r != ncclSuccess) rc = r;
+    }
+    g_group_worlds.clear();
+    return rc;
+}
+
+ncclResult_t ncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcount, ncclDataType_t datatype,
+                           ncclComm_t comm, hipStream_t stream) {
+    Comm* c = (Comm*)comm;
+    if (!c) return ncclInvalidArgument;
+    const size_t bytes = sendcount * type_bytes(datatype);
+    if (c->world) {                                            // single process: record, run at ncclGroupEnd
+        std::lock_guard<std::mutex> g(g_mu);
+        World* w = c->world;
+        if (w->n == 1) {
+            if (hipMemcpyAsync(recvbuff, sendbuff, bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess) return ncclUnhandledCudaError;
+            return ncclSuccess;
+        }
+        if (g_group_depth == 0) return ncclInvalidUsage;       // the real library would wait for the peers forever
+        const size_t k = w->next[(size_t)c->rank]++;
+        if (w->pending.size() <= k) w->pending.resize(k + 1, std::vector<World::Op>((size_t)w->n));
+        w->pending[k][(size_t)c->rank] = {sendbuff, recvbuff, bytes, stream, true};
+        bool listed = false;
+        for (World* x : g_group_worlds) listed |= (x == w);
+        if (!listed) g_group_worlds.push_back(w);
+        return ncclSuccess;
+    }
+    if (hipStreamSynchronize(stream) != hipSuccess) return ncclUnhandledCudaError;
+    for (size_t done = 0; done < bytes || done == 0; done += c->slot_bytes) {       // rounds of one slot per rank
+        const size_t take = bytes - done < c->slot_bytes ? bytes - done : c->slot_bytes;
+        if (take && hipMemcpy(c->slots + (size_t)c->rank * c->slot_bytes, (const uint8_t*)sendbuff + done, take,
+                              hipMemcpyDeviceToHost) != hipSuccess)
+            return ncclUnhandledCudaError;
+        barrier(c);
+        for (int r = 0; r < c->n && take; ++r)
+            if (hipMemcpy((uint8_t*)recvbuff + (size_t)r * bytes + done, c->slots + (size_t)r * c->slot_bytes, take,
+                          hipMemcpyHostToDevice) != hipSuccess)
+                return ncclUnhandledCudaError;
+        barrier(c);
+        if (bytes == 0) break;
+    }
+    return ncclSuccess;
+}
+
+const char* ncclGetErrorString(ncclResult_t r) {
+    switch (r) {
+        case ncclSuccess: return "no error";
+        case ncclUnhandledCudaError: return "stub: a HIP call failed";
+        case ncclSystemError: return "stub: shared-memory rendezvous failed";
+        case ncclInvalidArgument: return "stub: invalid argument";
+        case ncclInvalidUsage: return "stub: invalid usage (a collective of an init_all communicator outside a group, or a rank missing)";
+        default: return "stub: error";
+    }
+}
+
+}  // extern "C"
