@@ -521,9 +521,11 @@ struct mi_layer {
         }
     }
     int sink_error() {
+        // ConcurrentMultiWriter.Write (multi_writer.go:62-64): every failing sink's message, joined
         std::string e = tar.error();
-        if (e.empty() && gz) e = gz->error();
-        if (!e.empty()) return fail(MI_ERR_IO, "%s", e.c_str());
+        const std::string g = gz ? gz->error() : std::string();
+        if (!g.empty()) e = e.empty() ? g : e + ", " + g;
+        if (!e.empty()) return fail(MI_ERR_IO, "failed to write: %s", e.c_str());
         return MI_OK;
     }
 };

@@ -436,3 +436,31 @@ def test_cache_parse_entry_str_accepts_what_the_reference_accepts():
     assert M.cache_parse_entry_str(",") == ("sha256:", "sha256:")
     with pytest.raises(ValueError):
         M.cache_parse_entry_str("no comma")
+
+
+@pytest.mark.parametrize("level", [M.GZIP_OFF, M.GZIP_DEFAULT])
+def test_a_failing_sink_fails_the_layer(tmp_path, level):
+    """lib/stream/multi_writer_test.go:45-57 (TestMultiWriterFailure): one sink of the tee cannot write --
+    the device is full, or the descriptor is gone -- and the writer reports it ("failed to write: ...",
+    multi_writer.go:62-64) from mi_layer_add or, at the latest, mi_layer_finish; never a digest pair."""
+    src = tmp_path / "payload"
+    src.write_bytes(os.urandom(5 << 20))
+    entry = {"relpath": "payload", "kind": M.KIND_FILE, "mode": 0o100644, "size": 5 << 20, "mtime_sec": 1}
+    for make_fd, what in ((lambda: os.open("/dev/full", os.O_WRONLY), "No space left"), (None, "Bad file descriptor")):
+        if make_fd is None:
+            fd = os.open(tmp_path / "gone", os.O_WRONLY | os.O_CREAT, 0o644)
+            os.close(fd)                                       # the writer gets a descriptor that is closed
+        else:
+            fd = make_fd()
+        try:
+            with M.Layer(out_fd=fd, gzip_level=level) as layer:
+                with pytest.raises(M.MiError) as ei:
+                    for _ in range(4):                         # enough blocks for the sink to have tried
+                        layer.add(entry, str(src))
+                    layer.finish()
+                assert ei.value.code == -5 and "failed to write" in str(ei.value) and what in str(ei.value)
+                with pytest.raises(M.MiError):                 # and the layer stays failed
+                    layer.finish()
+        finally:
+            if make_fd is not None:
+                os.close(fd)
