@@ -15,13 +15,24 @@
 //     (utils.IsSpecialFile, lib/utils/utils.go:161-163) and mountpoints
 //     (mountutils.IsMountpoint, lib/mountutils/mountutils.go:54-93: targets of /proc/mounts
 //     except "/"); a skipped directory is not descended into.
-// Regular files are registered with the batch (mi_batch_add_path, stat-time size as in
+// Regular files are registered with the batch (mi_batch_add_paths, stat-time size as in
 // tario.WriteEntry's io.CopyN, lib/tario/write.go:43-45) in visit order; results come back
 // in the same order.
+//
+// The reference walks on ONE goroutine (filepath.Walk: an lstat per path, 2.4 us each here -- a
+// layer of 100 000 small files spends 0.24 s on it, more than reading and scanning them takes).
+// Round 3: the ENUMERATION is parallel -- directories are a work queue, N threads readdir + sort +
+// fstatat (+ readlinkat) them and apply the skip rules -- and the ORDER is restored afterwards: one
+// thread walks the finished directory records depth-first, names in sort.Strings order, exactly the
+// sequence filepath.Walk produces, stopping at the first error in THAT order.  Same entries, same
+// order, same errors (tests/test_host_walk.py compares the two on randomized trees); MI_WALK_THREADS
+// (1 = the sequential walker below, the reference's shape) overrides the thread count.
 #include "../../include/makisu_mi.h"
 
 #include <dirent.h>
 #include <errno.h>
+#include <fcntl.h>
+#include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -29,8 +40,11 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <map>
+#include <memory>
 #include <mutex>
+#include <thread>
 #include <set>
 #include <string>
 #include <vector>
@@ -180,17 +194,13 @@ struct Walker {
         return mt.targets.count(path) != 0;
     }
 
-    void visit(const std::string& path) {
-        if (rc) return;
-        struct stat st;
-        if (lstat(path.c_str(), &st) != 0) {
-            err = "lstat " + path + ": " + strerror(errno);
-            rc = MI_ERR_IO;
-            return;
-        }
-        if (should_skip(path, st)) return;                  // a skipped directory is not entered
+    // One visited, not skipped path -> its entry (+ its registration with the batch); link = the raw
+    // readlink result of a symlink.  A directory's children are the caller's business.
+    // rel (optional): the path's relpath when the caller already knows it (a child's is its parent's
+    // plus its name; filepath.Rel per entry costs more than the lstat it follows)
+    void emit(const std::string& path, const struct stat& st, const std::string* link, const std::string* rel = nullptr) {
         Entry e;
-        e.relpath = rel_to(rel_base, path);
+        e.relpath = rel ? *rel : rel_to(rel_base, path);
         if (e.relpath.empty()) {
             err = "path is outside of the base dir (" + rel_base + "," + path + ")";
             rc = MI_ERR_INVALID;
@@ -202,23 +212,10 @@ struct Walker {
         e.gid = (uint32_t)st.st_gid;
         if (S_ISDIR(st.st_mode)) {
             e.kind = 0;
-            tree->entries.push_back(e);
-            std::vector<std::string> names;
-            DIR* d = opendir(path.c_str());
-            if (!d) { err = "open " + path + ": " + strerror(errno); rc = MI_ERR_IO; return; }
-            while (struct dirent* de = readdir(d)) {
-                if (!strcmp(de->d_name, ".") || !strcmp(de->d_name, "..")) continue;
-                names.push_back(de->d_name);
-            }
-            closedir(d);
-            std::sort(names.begin(), names.end());          // sort.Strings: bytewise
-            for (const std::string& n : names) visit(path == "/" ? "/" + n : path + "/" + n);
+            tree->entries.push_back(std::move(e));
         } else if (S_ISLNK(st.st_mode)) {
             e.kind = 2;
-            std::vector<char> buf(4096);
-            ssize_t n = readlink(path.c_str(), buf.data(), buf.size() - 1);
-            if (n < 0) { err = "read link " + path + ": " + strerror(errno); rc = MI_ERR_IO; return; }
-            e.link.assign(buf.data(), (size_t)n);
+            e.link = *link;
             e.has_link = true;
             if (mode == MI_TREE_SCAN && !e.link.empty() && e.link[0] == '/') {
                 // memLayer.createHeader (lib/snapshot/mem_layer.go:171-185): an absolute target
@@ -232,7 +229,7 @@ struct Walker {
                 }
                 e.link = abs_path(e.link.substr(lr.size()));
             }
-            tree->entries.push_back(e);
+            tree->entries.push_back(std::move(e));
         } else {
             e.kind = 1;
             e.size = (uint64_t)st.st_size;
@@ -247,10 +244,248 @@ struct Walker {
                 e.file_index = n_regular;                   // listing only: running file ordinal
             }
             ++n_regular;
-            tree->entries.push_back(e);
+            tree->entries.push_back(std::move(e));
+        }
+    }
+
+    // the sequential walk: filepath.Walk as the reference runs it
+    void visit(const std::string& path) {
+        if (rc) return;
+        struct stat st;
+        if (lstat(path.c_str(), &st) != 0) {
+            err = "lstat " + path + ": " + strerror(errno);
+            rc = MI_ERR_IO;
+            return;
+        }
+        if (should_skip(path, st)) return;                  // a skipped directory is not entered
+        if (S_ISDIR(st.st_mode)) {
+            emit(path, st, nullptr);
+            if (rc) return;
+            std::vector<std::string> names;
+            DIR* d = opendir(path.c_str());
+            if (!d) { err = "open " + path + ": " + strerror(errno); rc = MI_ERR_IO; return; }
+            while (struct dirent* de = readdir(d)) {
+                if (!strcmp(de->d_name, ".") || !strcmp(de->d_name, "..")) continue;
+                names.push_back(de->d_name);
+            }
+            closedir(d);
+            std::sort(names.begin(), names.end());          // sort.Strings: bytewise
+            for (const std::string& n : names) visit(path == "/" ? "/" + n : path + "/" + n);
+        } else if (S_ISLNK(st.st_mode)) {
+            std::vector<char> buf(4096);
+            ssize_t n = readlink(path.c_str(), buf.data(), buf.size() - 1);
+            if (n < 0) { err = "read link " + path + ": " + strerror(errno); rc = MI_ERR_IO; return; }
+            const std::string link(buf.data(), (size_t)n);
+            emit(path, st, &link);
+        } else {
+            emit(path, st, nullptr);
         }
     }
 };
+
+// ---- parallel enumeration, sequential order -------------------------------------------------------
+struct DirRec;
+struct Child {
+    std::string name, link;
+    uint32_t mode = 0, uid = 0, gid = 0;
+    uint64_t size = 0;
+    int64_t mtime = 0;
+    bool skip = false;
+    int rc = MI_OK;                      // this path's own failure (lstat / readlink / skip-rule error)
+    std::string err;
+    std::unique_ptr<DirRec> sub;         // a directory that is entered
+};
+struct DirRec {
+    std::string path;
+    std::vector<Child> kids;             // sort.Strings order
+    int rc = MI_OK;                      // opening / reading the directory failed
+    std::string err;
+    bool done = false;                   // read completely (guarded by ParallelWalker::mu)
+};
+
+struct ParallelWalker {
+    Walker* w;                           // rules, rel_base, blacklist, mode; receives the entries
+    std::mutex mu;
+    std::condition_variable cv, cv_done; // work for the readers / a finished directory for the assembly
+    std::vector<DirRec*> stack;          // LIFO: close to the depth-first order the assembly wants
+    size_t outstanding = 0;              // directories queued or being read
+    bool abort = false;                  // the assembly stopped (an error): the readers only drain
+    std::vector<std::thread> pool;
+
+    // Walker::should_skip without side effects on the shared walker: a broken mounts table is the
+    // child's own error here
+    bool skip_rule(const std::string& path, const struct stat& st, int* rc, std::string* err) const {
+        const bool special = S_ISCHR(st.st_mode) || S_ISBLK(st.st_mode) || S_ISFIFO(st.st_mode) || S_ISSOCK(st.st_mode);
+        if (w->mode == MI_TREE_CONTEXT) return special;
+        if (has_prefix(base_of(path), ".wh..wh.")) return true;
+        if (is_descendant_of_any(path, w->blacklist) || special) return true;
+        const MountTable& mt = mountpoints();
+        if (!mt.error.empty()) { *err = "ismount: mountmanager initialize: " + mt.error; *rc = MI_ERR_IO; return true; }
+        return mt.targets.count(path) != 0;
+    }
+
+    // one directory: names, sorted; every child's lstat, skip decision, link target; the
+    // subdirectories that are entered go back on the stack
+    void read_dir(DirRec* d) {
+        const int fd = open(d->path.c_str(), O_RDONLY | O_DIRECTORY | O_CLOEXEC);
+        DIR* dir = fd >= 0 ? fdopendir(fd) : nullptr;
+        if (!dir) {
+            d->rc = MI_ERR_IO;
+            d->err = "open " + d->path + ": " + strerror(errno);
+            if (fd >= 0) close(fd);
+            return;
+        }
+        std::vector<std::string> names;
+        while (struct dirent* de = readdir(dir)) {
+            if (!strcmp(de->d_name, ".") || !strcmp(de->d_name, "..")) continue;
+            names.push_back(de->d_name);
+        }
+        std::sort(names.begin(), names.end());              // sort.Strings: bytewise
+        d->kids.resize(names.size());
+        std::vector<DirRec*> subs;
+        for (size_t i = 0; i < names.size(); ++i) {
+            Child& c = d->kids[i];
+            c.name.swap(names[i]);
+            const std::string path = d->path == "/" ? "/" + c.name : d->path + "/" + c.name;
+            struct stat st;
+            if (fstatat(fd, c.name.c_str(), &st, AT_SYMLINK_NOFOLLOW) != 0) {
+                c.rc = MI_ERR_IO;
+                c.err = "lstat " + path + ": " + strerror(errno);
+                continue;
+            }
+            c.skip = skip_rule(path, st, &c.rc, &c.err);
+            if (c.rc || c.skip) continue;
+            c.mode = (uint32_t)st.st_mode;
+            c.mtime = (int64_t)st.st_mtime;
+            c.uid = (uint32_t)st.st_uid;
+            c.gid = (uint32_t)st.st_gid;
+            c.size = (uint64_t)st.st_size;
+            if (S_ISDIR(st.st_mode)) {
+                c.sub.reset(new DirRec());
+                c.sub->path = path;
+                subs.push_back(c.sub.get());
+            } else if (S_ISLNK(st.st_mode)) {
+                char buf[4096];
+                const ssize_t n = readlinkat(fd, c.name.c_str(), buf, sizeof buf - 1);
+                if (n < 0) { c.rc = MI_ERR_IO; c.err = "read link " + path + ": " + strerror(errno); continue; }
+                c.link.assign(buf, (size_t)n);
+            }
+        }
+        closedir(dir);                                       // closes fd
+        if (!subs.empty()) {
+            std::lock_guard<std::mutex> g(mu);
+            for (size_t i = subs.size(); i-- > 0;) stack.push_back(subs[i]);   // first name on top
+            outstanding += subs.size();
+            cv.notify_all();
+        }
+    }
+
+    void worker() {
+        for (;;) {
+            DirRec* d = nullptr;
+            bool skip_read = false;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return !stack.empty() || outstanding == 0; });
+                if (stack.empty()) return;
+                d = stack.back();
+                stack.pop_back();
+                skip_read = abort;
+            }
+            if (!skip_read) read_dir(d);
+            {
+                std::lock_guard<std::mutex> g(mu);
+                d->done = true;
+                if (--outstanding == 0) cv.notify_all();
+            }
+            cv_done.notify_all();
+        }
+    }
+
+    // the readers run on their own threads; the caller assembles behind them
+    void start(DirRec* root, unsigned n_threads) {
+        stack.push_back(root);
+        outstanding = 1;
+        for (unsigned i = 0; i < n_threads; ++i) pool.emplace_back([this] { worker(); });
+    }
+    void finish() {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            abort = true;                                    // whatever is still queued is only drained
+        }
+        cv.notify_all();
+        for (auto& t : pool) t.join();
+        pool.clear();
+    }
+    void wait_done(const DirRec* d) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return d->done; });
+    }
+
+    // filepath.Walk's sequence over the finished records (the directory's own entry was emitted by
+    // the caller): children in order, a directory child followed by its subtree; the first failure
+    // in THAT order is the walk's failure
+    // rel = the directory's own relpath ("." for the base itself)
+    void assemble(const DirRec* d, const std::string& rel) {
+        if (w->rc) return;
+        wait_done(d);                                        // usually is: the readers go depth-first too
+        if (d->rc) { w->rc = d->rc; w->err = d->err; return; }
+        std::string path, crel;
+        for (const Child& c : d->kids) {
+            if (c.rc) { w->rc = c.rc; w->err = c.err; return; }
+            if (c.skip) continue;
+            path.assign(d->path == "/" ? "" : d->path).append("/").append(c.name);
+            if (rel == ".") crel = c.name; else crel.assign(rel).append("/").append(c.name);
+            struct stat st;
+            memset(&st, 0, sizeof st);
+            st.st_mode = c.mode;
+            st.st_mtime = c.mtime;
+            st.st_uid = c.uid;
+            st.st_gid = c.gid;
+            st.st_size = (off_t)c.size;
+            w->emit(path, st, S_ISLNK(c.mode) ? &c.link : nullptr, &crel);
+            if (w->rc) return;
+            if (c.sub) { assemble(c.sub.get(), crel); if (w->rc) return; }
+        }
+    }
+};
+
+static unsigned walk_threads() {
+    if (const char* e = getenv("MI_WALK_THREADS")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 64) return (unsigned)v;
+    }
+    cpu_set_t set;
+    unsigned n = sched_getaffinity(0, sizeof set, &set) == 0 ? (unsigned)CPU_COUNT(&set) : 1u;
+    return n > 16 ? 16 : (n < 1 ? 1 : n);
+}
+
+// the walk of `root` into w->tree (and w->batch): the sequential Walker::visit with one thread, else
+// the parallel enumeration + ordered assembly
+static void walk_root(Walker* w, const std::string& root) {
+    const unsigned nt = walk_threads();
+    if (nt <= 1) { w->visit(root); return; }
+    struct stat st;
+    if (lstat(root.c_str(), &st) != 0) { w->err = "lstat " + root + ": " + strerror(errno); w->rc = MI_ERR_IO; return; }
+    if (w->should_skip(root, st) || w->rc) return;
+    std::string link;
+    if (S_ISLNK(st.st_mode)) {
+        char buf[4096];
+        const ssize_t n = readlink(root.c_str(), buf, sizeof buf - 1);
+        if (n < 0) { w->err = "read link " + root + ": " + strerror(errno); w->rc = MI_ERR_IO; return; }
+        link.assign(buf, (size_t)n);
+    }
+    w->emit(root, st, S_ISLNK(st.st_mode) ? &link : nullptr);
+    if (w->rc || !S_ISDIR(st.st_mode)) return;
+    ParallelWalker pw;
+    pw.w = w;
+    DirRec top;
+    top.path = root;
+    const std::string root_rel = w->tree->entries.back().relpath;   // the root's own entry was just emitted (a copy:
+    pw.start(&top, nt);                                               // the vector grows under the assembly)
+    pw.assemble(&top, root_rel);       // behind the readers: files reach the batch while the walk goes on
+    pw.finish();
+}
 
 }  // namespace mi_walk
 
@@ -276,7 +511,7 @@ int mi_batch_add_tree(mi_batch* b, const char* root, const char* rel_base, const
     for (uint64_t i = 0; i < n_blacklist; ++i) w.blacklist.push_back(blacklist[i]);
     std::string r = root;
     while (r.size() > 1 && r.back() == '/') r.pop_back();
-    w.visit(r);
+    mi_walk::walk_root(&w, r);
     w.flush_pending();
     if (w.rc) {
         if (!w.err.empty()) mi_set_error(b, w.err.c_str());
@@ -314,7 +549,7 @@ int mi_tree_walk(const char* root, const char* rel_base, const char* const* blac
     for (uint64_t i = 0; i < n_blacklist; ++i) w.blacklist.push_back(blacklist[i]);
     std::string r = root;
     while (r.size() > 1 && r.back() == '/') r.pop_back();
-    w.visit(r);
+    mi_walk::walk_root(&w, r);
     if (w.rc) { delete t; return w.rc; }
     *out = (mi_tree*)t;
     if (n_entries) *n_entries = t->entries.size();

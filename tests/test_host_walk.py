@@ -483,3 +483,106 @@ def test_plain_c_host_consumer(tmp_path, engine_lib):
     assert sorted(l[2:] for l in out if l.startswith("A ")) == ["d", "d/sub"]
     assert [l[2:] for l in out if l.startswith("W ")] == ["gone"]
     assert out[-1] == "S 1"                                   # the two top directories: same owner/mode, mtime ignored
+
+
+# ---- the parallel enumeration gives filepath.Walk's sequence ------------------------
+def _random_tree(root, rng, n_files):
+    """~n_files empty files under a randomized directory tree with everything the walks care about:
+    names that sort differently by byte than by locale, symlinks (relative, absolute into the tree,
+    dangling), a fifo, AUFS whiteout-meta names, a directory to blacklist, deep chains, empty dirs."""
+    alphabet = ["a", "B", "-", ".", "_", "z", "0", "9", "é", "Z"]
+    dirs = [root]
+    made = 0
+    os.makedirs(os.path.join(root, "skipme", "inner"))
+    open(os.path.join(root, "skipme", "inner", "never"), "w").close()
+    while made < n_files:
+        d = dirs[int(rng.integers(0, len(dirs)))]
+        depth = d.count(os.sep) - root.count(os.sep)
+        name = "".join(alphabet[int(i)] for i in rng.integers(0, len(alphabet), int(rng.integers(1, 9))))
+        if name in (".", ".."):
+            continue
+        p = os.path.join(d, name)
+        if os.path.lexists(p):
+            continue
+        r = rng.random()
+        if r < 0.06 and depth < 12:
+            os.mkdir(p)
+            dirs.append(p)
+        elif r < 0.08:
+            os.symlink("../" + name + ".target", p)               # relative, dangling
+        elif r < 0.09:
+            os.symlink(os.path.join(root, "skipme"), p)          # absolute, inside the root
+        elif r < 0.093:
+            os.mkfifo(p)
+        elif r < 0.096:
+            open(os.path.join(d, ".wh..wh." + name), "w").close()
+        else:
+            n = int(rng.integers(1, 400))                         # a burst of files in this directory
+            for k in range(n):
+                open("%s.%d" % (p, k), "w").close()
+            made += n
+    return made
+
+
+@pytest.mark.parametrize("mode", ["context", "scan"])
+def test_parallel_walk_equals_the_sequential_walk_on_a_random_tree(tmp_path, engine_lib, mode, monkeypatch):
+    """200 000 files (MI_WALK_TEST_FILES overrides): the N-thread enumeration + ordered assembly returns the
+    entries of the one-thread filepath.Walk restatement -- same paths, same order, same fields -- in both
+    walk modes, at several thread counts; and it is what the default configuration runs."""
+    import makisu_amd as M
+    import shutil
+    import tempfile
+    import time
+    n_files = int(os.environ.get("MI_WALK_TEST_FILES", "200000"))
+    base = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else str(tmp_path))
+    try:
+        root = os.path.join(base, "tree")
+        os.mkdir(root)
+        made = _random_tree(root, np.random.default_rng(11), n_files)
+        kw = dict(blacklist=[os.path.join(root, "skipme")], mode=M.TREE_SCAN, full=True) if mode == "scan" else \
+            dict(mode=M.TREE_CONTEXT, full=True)
+        monkeypatch.setenv("MI_WALK_THREADS", "1")
+        t0 = time.perf_counter()
+        want = M.tree_walk(root, None, **kw)
+        t_seq = time.perf_counter() - t0
+        n_reg = sum(1 for e in want if e["kind"] == M.KIND_FILE)
+        assert n_reg >= 0.95 * made and len(want) > n_reg        # (bursts may land on the same names)
+        if mode == "scan":
+            assert not any("skipme" in e["relpath"].split("/") or os.path.basename(e["relpath"]).startswith(".wh..wh.")
+                           for e in want)
+        assert not any(stat.S_ISFIFO(e["mode"]) for e in want)
+        times = {}
+        for nt in ("2", "5", "16"):
+            monkeypatch.setenv("MI_WALK_THREADS", nt)
+            t0 = time.perf_counter()
+            got = M.tree_walk(root, None, **kw)
+            times[nt] = time.perf_counter() - t0
+            assert len(got) == len(want)
+            assert got == want, next((i, a, b) for i, (a, b) in enumerate(zip(got, want)) if a != b)
+        monkeypatch.delenv("MI_WALK_THREADS")
+        assert M.tree_walk(root, None, **kw) == want             # the default thread count
+        print("walk of %d entries: 1 thread %.3f s, %s" % (len(want), t_seq, {k: round(v, 3) for k, v in times.items()}))
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
+
+
+def test_parallel_walk_reports_the_first_error_in_walk_order(tmp_path, engine_lib, monkeypatch):
+    """Two absolute symlinks that point outside the scan root, in different directories: a sequential
+    walk fails at the first one it reaches; the parallel one may have SEEN both -- it must still name
+    the first in filepath.Walk order, and list nothing."""
+    import makisu_amd as M
+    root = tmp_path / "r"
+    for d in ("a/deep/er", "b", "c/x"):
+        os.makedirs(root / d)
+    for i in range(300):
+        (root / "a" / "deep" / ("f%03d" % i)).write_bytes(b"")
+    os.symlink("/outside/one", root / "b" / "bad1")
+    os.symlink("/outside/two", root / "a" / "deep" / "er" / "bad0")      # a/... sorts before b/...
+    msgs = []
+    for nt in ("1", "8"):
+        monkeypatch.setenv("MI_WALK_THREADS", nt)
+        with pytest.raises(M.MiError) as ei:
+            M.tree_walk(str(root), None, mode=M.TREE_SCAN, full=True)
+        assert ei.value.code == -1
+        msgs.append(str(ei.value))
+    assert msgs[0] == msgs[1]
