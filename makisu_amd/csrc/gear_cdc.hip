@@ -47,12 +47,22 @@ namespace mi {
 
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kCopies      = kGearTableCopies;          // Gear table replicas in LDS
+constexpr int kCopies      = kGearTableCopies;          // Gear table replicas in LDS (kernels that keep bitmaps)
+constexpr int kFastCopies  = 16;                        // ... in the bitmap-free marking kernels (see below)
 constexpr int kWavesPerWG  = kGearWG / 64;              // 4
 constexpr int kLaneRun     = kGearTile / 64;            // 1 KiB per lane
 constexpr int kPiece       = 128;                       // bytes per load group (one cache line)
 constexpr int kBitmapWords = kGearTile / 32;            // u32 words per wave bitmap (8 KiB)
 constexpr int kTableBytes  = 256 * 8 * kCopies;
+// The bitmap-free kernels (round 3): a tile's candidates live ONLY in its lanes' packed registers (up to
+// six per lane) and the 64-entry list; the 8 KiB-per-wave LDS bitmap -- two thirds of the old LDS budget,
+// there for tiles with more than 64 candidates -- is gone from the fast path, and such tiles (none on
+// random data at the default mask) are redone by the bitmap kernel.  The freed LDS holds SIXTEEN table
+// copies: two lanes per bank pair and half-wave is the ds_read_b64 minimum, so the byte lookups --
+// 8 B of LDS traffic per input byte, the kernel's dominant cost -- run conflict-free instead of at
+// ~3.6 passes per half-wave (8 copies: four lanes share a bank pair whenever their bytes have equal parity).
+constexpr int kFastTableBytes = 256 * 8 * kFastCopies;  // 32 KiB
+constexpr int kFastLdsBytes = kFastTableBytes + kWavesPerWG * 64 * 4;
 // LDS: table | one bitmap per wave | one 64-entry candidate list per wave | fast flags
 constexpr int kLdsListOff  = kTableBytes + kWavesPerWG * kBitmapWords * 4;
 constexpr int kLdsFastOff  = kLdsListOff + kWavesPerWG * 64 * 4;
@@ -69,25 +79,34 @@ __device__ __forceinline__ u32 lane_value(u32 v, int src) { return (u32)__builti
 // candidates (mask 13 bits: ~8 expected), the wave compacts them -- ballot + popcount prefix
 // sums over the 2-bit counts -- into a sorted list in LDS; selection then needs one ballot per
 // cut instead of a bitmap search.  Otherwise the bitmap (exact for any density) is used.
-__device__ __forceinline__ void cand_push(u32& pk, bool& ovf, u32 o) {
-    const u32 cnt = pk >> 30;
-    if (cnt < 3) pk = ((cnt + 1) << 30) | (((pk & 0x3FFFFFFFu) << 10) | o);
+struct CandPack { u32 a, b; };                           // candidates 0..2 in a, 3..5 in b (10-bit run offsets, count in bits 30..31)
+__device__ __forceinline__ void cand_push(CandPack& pk, bool& ovf, u32 o) {
+    const u32 ca = pk.a >> 30;
+    if (ca < 3) { pk.a = ((ca + 1) << 30) | (((pk.a & 0x3FFFFFFFu) << 10) | o); return; }
+    const u32 cb = pk.b >> 30;
+    if (cb < 3) pk.b = ((cb + 1) << 30) | (((pk.b & 0x3FFFFFFFu) << 10) | o);
     else ovf = true;
 }
 
 // returns true (wave-uniform) when `list` holds the tile's candidates (tile-relative byte
 // indices, ascending, padded with kNoCand)
-__device__ __forceinline__ bool cand_compact(u32 pk, bool ovf, u32 run0, int lane, u32* list) {
-    const u32 cnt = pk >> 30;
-    const u64 b0 = __ballot(cnt & 1u), b1 = __ballot(cnt & 2u);
-    const u32 total = (u32)__popcll(b0) + 2u * (u32)__popcll(b1);
+__device__ __forceinline__ bool cand_compact(CandPack pk, bool ovf, u32 run0, int lane, u32* list) {
+    const u32 ca = pk.a >> 30, cb = pk.b >> 30;
+    const u32 cnt = ca + cb;                             // 0..6
+    const u64 b0 = __ballot(cnt & 1u), b1 = __ballot(cnt & 2u), b2 = __ballot(cnt & 4u);
+    const u32 total = (u32)__popcll(b0) + 2u * (u32)__popcll(b1) + 4u * (u32)__popcll(b2);
     if (__ballot(ovf) || total > 64u) return false;
     const u64 below = (1ull << lane) - 1ull;
-    const u32 first = (u32)__popcll(b0 & below) + 2u * (u32)__popcll(b1 & below);
+    const u32 first = (u32)__popcll(b0 & below) + 2u * (u32)__popcll(b1 & below) + 4u * (u32)__popcll(b2 & below);
     list[lane] = kNoCand;
 #pragma unroll
-    for (u32 k = 0; k < 3; ++k)                          // field cnt-1-k holds my k-th (ascending) one
-        if (k < cnt) list[first + k] = run0 + ((pk >> (10 * (cnt - 1 - k))) & 1023u);
+    for (u32 k = 0; k < 3; ++k)                          // field c-1-k of a register holds its k-th (ascending) one
+        if (k < ca) list[first + k] = run0 + ((pk.a >> (10 * (ca - 1 - k))) & 1023u);
+    if (cb) {                                            // rare: a fourth..sixth candidate in one 1 KiB run
+#pragma unroll
+        for (u32 k = 0; k < 3; ++k)
+            if (k < cb) list[first + 3 + k] = run0 + ((pk.b >> (10 * (cb - 1 - k))) & 1023u);
+    }
     return true;
 }
 
@@ -118,26 +137,31 @@ __device__ __forceinline__ int bitmap_find_first(const u64* bm, int lo, int hi, 
 // ((w >> (8k - 6)) & 0x3FC0) | (c * 8) -- one full-rate shift and one v_bitop3_b32
 // ((a & b) | c) instead of the half-rate v_bfe_u32 + v_lshl_add_u32 pair.
 typedef __attribute__((address_space(3))) const u64 lds_cu64;
-static_assert(kCopies == 8, "lookup address arithmetic assumes a 64-byte entry stride");
+// kC copies: entry b of copy c at byte b * (8 kC) + c * 8 -- a 64-byte stride for 8 copies, 128 for 16
+template <int kC>
 __device__ __forceinline__ void roll16(u64& h, const u32x4 v, u32 lane_tab, u32 (&hh)[16]) {
+    static_assert(kC == 8 || kC == 16, "lookup address arithmetic: 64- or 128-byte entry stride");
+    constexpr int kShift = kC == 8 ? 6 : 7;
+    constexpr u32 kMask = 0xFFu << kShift;
     const u32 wv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const u32 w = wv[k >> 2];
-        const int sh = 8 * (k & 3) - 6;
-        const u32 t = sh < 0 ? w << 6 : w >> sh;
-        const u32 addr = __builtin_amdgcn_bitop3_b32(t, 0x3FC0u, lane_tab, 0xEA);   // (t & 0x3FC0) | lane_tab
+        const int sh = 8 * (k & 3) - kShift;
+        const u32 t = sh < 0 ? w << -sh : w >> sh;
+        const u32 addr = __builtin_amdgcn_bitop3_b32(t, kMask, lane_tab, 0xEA);   // (t & mask) | lane_tab
         h = (h << 1) + *(lds_cu64*)(size_t)addr;
         hh[k] = (u32)(h >> 32);
     }
 }
 
 // LDS byte address of this lane's table copy (entry 0); traps if the table is not where the
-// OR-based lookup arithmetic needs it (start of LDS, 16 KiB-aligned).
+// OR-based lookup arithmetic needs it (start of LDS, aligned to its own size).
+template <int kC>
 __device__ __forceinline__ u32 lds_lane_table(const u64* table, int lane) {
     const u32 base = (u32)(size_t)(__attribute__((address_space(3))) const u64*)table;
-    if (base & (u32)(kTableBytes - 1)) __builtin_trap();
-    return base | ((u32)(lane % kCopies) * 8u);
+    if (base & (u32)(256 * 8 * kC - 1)) __builtin_trap();
+    return base | ((u32)(lane % kC) * 8u);
 }
 
 __device__ __forceinline__ void load_piece(const u8* p, u32x4 (&d)[8]) {
@@ -148,16 +172,18 @@ __device__ __forceinline__ void load_piece(const u8* p, u32x4 (&d)[8]) {
 // One wave marks the candidates of tile [ts, ts+tlen) of a file into `bitmap`
 // (bit p <-> cut end ts + p + 1).  fptr is 16-byte aligned, ts a multiple of kGearTile.
 // pk/ovf: the lane's packed candidates for the fast selection path (cand_push / cand_compact).
+// kBitmap = false: no bitmap at all (bitmap may be nullptr); the candidates are in pk only.
+template <int kC, bool kBitmap>
 __device__ __forceinline__ void mark_tile(const u8* __restrict__ fptr, u64 ts, u32 tlen,
                                           u32* bitmap, u32 tab, u32 thresh_m1, int lane,
-                                          u32& pk, bool& ovf) {
-    {   // clear the bitmap: 32 words per lane
+                                          CandPack& pk, bool& ovf) {
+    if (kBitmap) {   // clear the bitmap: 32 words per lane
         u32x4* bz = (u32x4*)bitmap;
         const u32x4 z = {0, 0, 0, 0};
 #pragma unroll
         for (int i = 0; i < kBitmapWords / 4 / 64; ++i) bz[i * 64 + lane] = z;
     }
-    pk = 0;
+    pk.a = pk.b = 0;
     ovf = false;
     const u32 run0 = (u32)lane * kLaneRun;               // tile-relative start of my run
     if (run0 >= tlen) return;
@@ -173,13 +199,13 @@ __device__ __forceinline__ void mark_tile(const u8* __restrict__ fptr, u64 ts, u
 #pragma unroll
         for (int i = 0; i < 4; ++i) wq[i] = *(const u32x4*)(p - 64 + 16 * i);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) roll16(h, wq[i], tab, hh);
+        for (int i = 0; i < 4; ++i) roll16<kC>(h, wq[i], tab, hh);
     }
     for (int pc = 0; pc < n_pieces; ++pc) {
         if (pc + 1 < n_pieces) load_piece(p + (pc + 1) * kPiece, nxt);   // in flight while hashing
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
-            roll16(h, cur[g], tab, hh);
+            roll16<kC>(h, cur[g], tab, hh);
 // (a v_min3_u32 chain would be 8 ops instead of the 11 hipcc emits, but it is one dependent
             // chain: A/B on one box, 1.50 ms against 1.46 ms for the compiler's tree)
             u32 m = 0xFFFFFFFFu;
@@ -193,7 +219,7 @@ __device__ __forceinline__ void mark_tile(const u8* __restrict__ fptr, u64 ts, u
                 for (int k = 0; k < 16; ++k) {
                     if (hh[k] <= thresh_m1) {
                         const u32 pos = run0 + base + (u32)k;                       // byte index in tile
-                        atomicOr(&bitmap[pos >> 5], 1u << (pos & 31));
+                        if (kBitmap) atomicOr(&bitmap[pos >> 5], 1u << (pos & 31));
                         cand_push(pk, ovf, base + (u32)k);
                     }
                 }
@@ -275,28 +301,33 @@ __device__ __forceinline__ bool list_from_bitmap(const u32* bitmap, int lane, u3
     return true;
 }
 
+template <int kC>
 __device__ __forceinline__ void load_table(u64* table, const u64* __restrict__ gear_table, int tid) {
-    // table[b * kCopies + c] = G[b] for every copy c
-    for (int i = tid; i < 256 * kCopies; i += kGearWG) table[i] = gear_table[i / kCopies];
+    // table[b * kC + c] = G[b] for every copy c
+    for (int i = tid; i < 256 * kC; i += kGearWG) table[i] = gear_table[i / kC];
 }
 
 // ---- small files: one wave per file (size <= kGearTile) ----------------------------------
 // A small file is one SEGMENT: its chunk ends go to ends32[seg_slot[s] ..] (u32, file-relative),
 // its chunk count to seg_n[s].
+// gear_cdc_small_fast_kernel: the bitmap-free form (16 table copies, candidates in registers + the
+// 64-entry list).  A file with more than 64 candidates (or a lane with more than six) is appended to
+// dense_list and left to gear_cdc_small_kernel, the round-1/2 form with its exact per-wave bitmap,
+// which runs over that list afterwards (n_list_dev: the list's length, known on the device only).
 __global__ __launch_bounds__(kGearWG)
-void gear_cdc_small_kernel(const u8* __restrict__ data, const u64* __restrict__ file_off,
-                           const u64* __restrict__ file_size, const u32* __restrict__ seg_file,
-                           const u64* __restrict__ seg_slot, u32* __restrict__ ends32,
-                           u32* __restrict__ seg_n, const u32* __restrict__ list, u32 n_list,
-                           const u64* __restrict__ gear_table, CdcParams p) {
+void gear_cdc_small_fast_kernel(const u8* __restrict__ data, const u64* __restrict__ file_off,
+                                const u64* __restrict__ file_size, const u32* __restrict__ seg_file,
+                                const u64* __restrict__ seg_slot, u32* __restrict__ ends32,
+                                u32* __restrict__ seg_n, const u32* __restrict__ list, u32 n_list,
+                                const u64* __restrict__ gear_table, CdcParams p,
+                                u32* __restrict__ dense_list, u32* __restrict__ dense_count) {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     u64* table = (u64*)smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    u32* bitmap = (u32*)(smem + kTableBytes) + wave * kBitmapWords;
-    u32* cand_list = (u32*)(smem + kLdsListOff) + wave * 64;
-    load_table(table, gear_table, tid);
+    u32* cand_list = (u32*)(smem + kFastTableBytes) + wave * 64;
+    load_table<kFastCopies>(table, gear_table, tid);
     __syncthreads();
-    const u32 lane_tab = lds_lane_table(table, lane);
+    const u32 lane_tab = lds_lane_table<kFastCopies>(table, lane);
     const u32 li = blockIdx.x * kWavesPerWG + wave;
     if (li >= n_list) return;
     const u32 s = list[li];
@@ -306,10 +337,57 @@ void gear_cdc_small_kernel(const u8* __restrict__ data, const u64* __restrict__ 
     u64 last = 0;
     u32 n_out = 0;
     if (size) {
-        u32 pk;
+        CandPack pk;
         bool ovf;
-        mark_tile(data + file_off[f], 0, (u32)size, bitmap, lane_tab, p.thresh_m1, lane,
-                  pk, ovf);
+        mark_tile<kFastCopies, false>(data + file_off[f], 0, (u32)size, nullptr, lane_tab, p.thresh_m1, lane, pk, ovf);
+        if (!cand_compact(pk, ovf, (u32)lane * kLaneRun, lane, cand_list)) {      // wave-uniform
+            if (lane == 0) dense_list[atomicAdd(dense_count, 1u)] = s;
+            return;
+        }
+        // the wave's own LDS writes are ordered for the wave itself after the waitcnt the
+        // compiler inserts; no other wave touches this list
+        __builtin_amdgcn_wave_barrier();
+        select_tile(nullptr, cand_list, 0, (u32)size, p, last, lane,
+                    [&](u64 c) { if (lane == 0) ends[n_out] = (u32)c; ++n_out; return false; });
+    }
+    if (lane == 0) {
+        if (size > last) { ends[n_out] = (u32)size; ++n_out; }   // the file end always cuts
+        seg_n[s] = n_out;
+    }
+}
+
+__global__ __launch_bounds__(kGearWG)
+void gear_cdc_small_kernel(const u8* __restrict__ data, const u64* __restrict__ file_off,
+                           const u64* __restrict__ file_size, const u32* __restrict__ seg_file,
+                           const u64* __restrict__ seg_slot, u32* __restrict__ ends32,
+                           u32* __restrict__ seg_n, const u32* __restrict__ list, u32 n_list,
+                           const u32* __restrict__ n_list_dev,
+                           const u64* __restrict__ gear_table, CdcParams p) {
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    u64* table = (u64*)smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (n_list_dev) {                                    // the fast kernel's leftovers: usually none
+        n_list = *n_list_dev;
+        if (blockIdx.x * kWavesPerWG >= n_list) return;
+    }
+    u32* bitmap = (u32*)(smem + kTableBytes) + wave * kBitmapWords;
+    u32* cand_list = (u32*)(smem + kLdsListOff) + wave * 64;
+    load_table<kCopies>(table, gear_table, tid);
+    __syncthreads();
+    const u32 lane_tab = lds_lane_table<kCopies>(table, lane);
+    const u32 li = blockIdx.x * kWavesPerWG + wave;
+    if (li >= n_list) return;
+    const u32 s = list[li];
+    const u32 f = seg_file[s];
+    const u64 size = file_size[f];
+    u32* ends = ends32 + seg_slot[s];
+    u64 last = 0;
+    u32 n_out = 0;
+    if (size) {
+        CandPack pk;
+        bool ovf;
+        mark_tile<kCopies, true>(data + file_off[f], 0, (u32)size, bitmap, lane_tab, p.thresh_m1, lane,
+                                 pk, ovf);
         const bool fast = cand_compact(pk, ovf, (u32)lane * kLaneRun, lane, cand_list);
         // the wave's own LDS writes are ordered for the wave itself after the waitcnt the
         // compiler inserts; no other wave touches this bitmap / list
@@ -414,14 +492,15 @@ void gear_tile_mark_kernel(const u8* __restrict__ data, const u64* __restrict__ 
                            const u32* __restrict__ group_index, u32 n_groups,
                            u32* __restrict__ tile_lists, u32* __restrict__ tile_fast,
                            const u64* __restrict__ gear_table, CdcParams p) {
+    // bitmap-free like gear_cdc_small_fast_kernel (16 table copies): a tile with more than 64 candidates
+    // -- or a lane with more than six -- is DENSE (tile_fast = 0) and re-marked, with bitmaps, by C
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     u64* table = (u64*)smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    u32* bm = (u32*)(smem + kTableBytes) + wave * kBitmapWords;
-    u32* cl = (u32*)(smem + kLdsListOff) + wave * 64;
-    load_table(table, gear_table, tid);
+    u32* cl = (u32*)(smem + kFastTableBytes) + wave * 64;
+    load_table<kFastCopies>(table, gear_table, tid);
     __syncthreads();
-    const u32 lane_tab = lds_lane_table(table, lane);
+    const u32 lane_tab = lds_lane_table<kFastCopies>(table, lane);
     const u32 g = blockIdx.x;                                 // workgroup = the four tiles of one group
     const u64 t = (u64)g * kWavesPerWG + wave;
     const u32 f = group_file[g];
@@ -430,14 +509,10 @@ void gear_tile_mark_kernel(const u8* __restrict__ data, const u64* __restrict__ 
     bool fast = true;                                         // tiles past the end count as listed
     if (ts < size) {
         const u32 tlen = (u32)((size - ts < (u64)kGearTile) ? (size - ts) : (u64)kGearTile);
-        u32 pk;
+        CandPack pk;
         bool ovf;
-        mark_tile(data + file_off[f], ts, tlen, bm, lane_tab, p.thresh_m1, lane, pk, ovf);
+        mark_tile<kFastCopies, false>(data + file_off[f], ts, tlen, nullptr, lane_tab, p.thresh_m1, lane, pk, ovf);
         fast = cand_compact(pk, ovf, (u32)lane * kLaneRun, lane, cl);
-        if (!fast) {
-            __builtin_amdgcn_wave_barrier();
-            fast = list_from_bitmap(bm, lane, cl);
-        }
         __builtin_amdgcn_wave_barrier();
         tile_lists[t * 64 + lane] = fast ? cl[lane] : kNoCand;
     }
@@ -611,9 +686,9 @@ void gear_file_fix_kernel(const u8* __restrict__ data, const u64* __restrict__ f
         const u32 redo = s_next[0];
         if (redo == 0xFFFFFFFFu) break;
         if (!have_table) {                                    // first group to redo: now the table is needed
-            load_table(table, gear_table, tid);
+            load_table<kCopies>(table, gear_table, tid);
             __syncthreads();
-            lane_tab = lds_lane_table(table, lane);
+            lane_tab = lds_lane_table<kCopies>(table, lane);
             have_table = true;
         }
         const u32 g = gb + redo;
@@ -623,11 +698,11 @@ void gear_file_fix_kernel(const u8* __restrict__ data, const u64* __restrict__ f
             if (lane == 0) fast_flags[wave] = 1u;
             if (ts < size) {
                 const u32 tlen = (u32)((size - ts < (u64)kGearTile) ? (size - ts) : (u64)kGearTile);
-                u32 pk;
+                CandPack pk;
                 bool ovf;
                 u32* bm = bitmaps + wave * kBitmapWords;
                 u32* cl = cand_lists + wave * 64;
-                mark_tile(fptr, ts, tlen, bm, lane_tab, p.thresh_m1, lane, pk, ovf);
+                mark_tile<kCopies, true>(fptr, ts, tlen, bm, lane_tab, p.thresh_m1, lane, pk, ovf);
                 bool fast = cand_compact(pk, ovf, (u32)lane * kLaneRun, lane, cl);
                 if (!fast) {
                     __builtin_amdgcn_wave_barrier();
@@ -667,8 +742,10 @@ static void gear_lds_attributes() {
     if (done_for == dev) return;
     (void)hipFuncSetAttribute((const void*)gear_cdc_small_kernel,
                               hipFuncAttributeMaxDynamicSharedMemorySize, kGearLdsBytes);
+    (void)hipFuncSetAttribute((const void*)gear_cdc_small_fast_kernel,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kFastLdsBytes);
     (void)hipFuncSetAttribute((const void*)gear_tile_mark_kernel,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, kGearLdsBytes);
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kFastLdsBytes);
     (void)hipFuncSetAttribute((const void*)gear_file_fix_kernel,
                               hipFuncAttributeMaxDynamicSharedMemorySize, kGearLdsBytes + 16);
     done_for = dev;
@@ -677,14 +754,29 @@ static void gear_lds_attributes() {
 void launch_gear_cdc(const GearLaunch& a, CdcParams p, int n_cu, hipStream_t s) {
     (void)n_cu;
     gear_lds_attributes();
-    if (a.n_small)
-        hipLaunchKernelGGL(gear_cdc_small_kernel, dim3((a.n_small + kWavesPerWG - 1) / kWavesPerWG),
-                           dim3(kGearWG), kGearLdsBytes, s, a.data, a.file_off, a.file_size, a.seg_file,
-                           a.seg_slot, a.ends32, a.seg_n, a.small_list, a.n_small, a.gear_table, p);
+    if (a.n_small) {
+        const dim3 grid((a.n_small + kWavesPerWG - 1) / kWavesPerWG);
+        // expected candidates per 64 KiB tile from the mask alone: with a dozen or more the 64-entry list
+        // overflows too often for the bitmap-free kernel to be worth its pass
+        const bool try_fast = a.dense_list && p.thresh_m1 <= 0x003FFFFFu;         // mask_bits >= 10
+        if (try_fast) {
+            (void)hipMemsetAsync(a.dense_count, 0, 4, s);
+            hipLaunchKernelGGL(gear_cdc_small_fast_kernel, grid, dim3(kGearWG), kFastLdsBytes, s, a.data,
+                               a.file_off, a.file_size, a.seg_file, a.seg_slot, a.ends32, a.seg_n, a.small_list,
+                               a.n_small, a.gear_table, p, a.dense_list, a.dense_count);
+            hipLaunchKernelGGL(gear_cdc_small_kernel, grid, dim3(kGearWG), kGearLdsBytes, s, a.data, a.file_off,
+                               a.file_size, a.seg_file, a.seg_slot, a.ends32, a.seg_n, a.dense_list, 0u,
+                               (const u32*)a.dense_count, a.gear_table, p);
+        } else {
+            hipLaunchKernelGGL(gear_cdc_small_kernel, grid, dim3(kGearWG), kGearLdsBytes, s, a.data, a.file_off,
+                               a.file_size, a.seg_file, a.seg_slot, a.ends32, a.seg_n, a.small_list, a.n_small,
+                               (const u32*)nullptr, a.gear_table, p);
+        }
+    }
     if (a.n_groups) {
         const u32 region = (u32)gear_group_region(p.min_size);
         GroupRec* recs = (GroupRec*)a.group_recs;
-        hipLaunchKernelGGL(gear_tile_mark_kernel, dim3(a.n_groups), dim3(kGearWG), kGearLdsBytes, s, a.data,
+        hipLaunchKernelGGL(gear_tile_mark_kernel, dim3(a.n_groups), dim3(kGearWG), kFastLdsBytes, s, a.data,
                            a.file_off, a.file_size, a.group_file, a.group_index, a.n_groups, a.tile_lists,
                            a.tile_fast, a.gear_table, p);
         const dim3 per_group((a.n_groups + kWavesPerWG - 1) / kWavesPerWG);

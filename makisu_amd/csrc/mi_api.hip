@@ -221,6 +221,8 @@ GearLaunch gear_args(mi_batch* b) {
     g.seg_n = b->seg_n.as<u32>();
     g.small_list = b->small_list.as<u32>();
     g.n_small = b->n_small;
+    g.dense_list = b->dense_list.as<u32>();
+    g.dense_count = b->dense_list.p ? b->dense_list.as<u32>() + b->n_small : nullptr;
     g.group_file = b->group_file.as<u32>();
     g.group_index = b->group_index.as<u32>();
     g.n_groups = b->n_groups;
@@ -239,6 +241,7 @@ int ensure_cut_buffers(mi_batch* b) {
     mi_ctx* c = b->ctx;
     HIPCHK(c, b->ends32.ensure(b->ends_total * 4 + 16));
     HIPCHK(c, b->seg_n.ensure(b->n_segs * 4 + 16));
+    if (b->n_small) HIPCHK(c, b->dense_list.ensure(((size_t)b->n_small + 1) * 4));
     if (b->n_groups) {
         HIPCHK(c, b->group_recs.ensure(gear_group_rec_bytes() * (size_t)b->n_groups));
         HIPCHK(c, b->tile_lists.ensure(1024ull * b->n_groups));
@@ -1350,7 +1353,7 @@ int mi_batch_free(mi_batch* b) {
                       &b->n_chunks_d, &b->first, &b->scratch,
                       &b->chunk_off, &b->chunk_len, &b->chunk_file, &b->chunk_start, &b->digests, &b->item_off, &b->item_len, &b->roots,
                       &b->file_sha, &b->dup_of, &b->file_flags, &b->part_file, &b->part_group0, &b->part_halo,
-                      &b->part_entry, &b->rows_d, &b->file_base, &b->span_off, &b->span_len, &b->span_sums};
+                      &b->part_entry, &b->rows_d, &b->file_base, &b->span_off, &b->span_len, &b->span_sums, &b->dense_list};
     for (DevBuf* d : bufs) d->release();
     delete b;
     return MI_OK;

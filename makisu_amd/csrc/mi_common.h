@@ -75,6 +75,8 @@ struct GearLaunch {
     u32*       tile_fast;      // n_groups x 4: 1 = the tile's list is complete, 0 = dense tile
     const u32* file_flags;     // per file, kFile* bits; nullptr when the batch holds no parts
     const u64* gear_table;
+    u32*       dense_list;     // n_small words + one count word: small files the bitmap-free kernel
+    u32*       dense_count;    // ... hands to the bitmap kernel (more than 64 candidates in the file)
 };
 constexpr u32 kFileOpenEnd = 1u;     // a part that is not its file's last: no cut at its last byte
 struct GroupRec {

@@ -135,6 +135,7 @@ struct mi_batch {
     mi_stats stats;
     // CDC segments (gear_cdc.hip): a small file or one 256 KiB group of a large file
     mi::DevBuf small_list;                   // segments that are files <= one tile (wave per file)
+    mi::DevBuf dense_list;                   // ... of them, those the bitmap-free kernel could not list (+ count)
     mi::DevBuf seg_file, seg_slot, seg_n, seg_first, seg_group, file_seg0, ends32;
     mi::DevBuf group_file, group_index, group_recs, tile_lists, tile_fast, large_list, large_group0;
     mi::u32 n_small = 0, n_groups = 0, n_large = 0;

@@ -50,6 +50,10 @@ struct StageItem {
     StageLatch* latch;
 };
 
+// Files per run: a slab of tiny files would otherwise be ONE thread's work for milliseconds (2 048
+// 4 KiB files at ~4 us of open + pread + close each) while the others idle at the end of a batch.
+constexpr size_t kMaxRunItems = 256;
+
 struct Stager {
     mi_ctx* ctx;
     u64 slab_bytes;
@@ -232,7 +236,7 @@ void worker(Stager* st, u32 tid) {
             const mi_batch* b = st->queue.front().batch;
             const u64 start = st->queue.front().arena_off;
             u64 prev_end = start;
-            while (!st->queue.empty()) {
+            while (!st->queue.empty() && run.size() < kMaxRunItems) {
                 const StageItem& f = st->queue.front();
                 if (f.batch != b || f.arena_off < start || f.arena_off + f.len - start > st->slab_bytes) break;
                 // only alignment padding may lie between two items of a run: the span travels as ONE
