@@ -158,8 +158,8 @@ def load_library(rebuild=False):
     global _lib
     if _lib is not None and not rebuild:
         return _lib
-    path = _build.LIB
-    if rebuild or (_build.needs_build() and os.path.exists(_build.HIPCC)):
+    path = os.environ.get("MAKISU_MI_LIB") or _build.LIB    # another build of the library (same-box A/B runs)
+    if path == _build.LIB and (rebuild or (_build.needs_build() and os.path.exists(_build.HIPCC))):
         _build.build(force=rebuild)
     if not os.path.exists(path):
         raise MiError(-2, "libmakisu_mi.so is not built (run `python -m makisu_amd.build`); "

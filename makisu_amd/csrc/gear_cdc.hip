@@ -62,7 +62,13 @@ constexpr int kTableBytes  = 256 * 8 * kCopies;
 // 8 B of LDS traffic per input byte, the kernel's dominant cost -- run conflict-free instead of at
 // ~3.6 passes per half-wave (8 copies: four lanes share a bank pair whenever their bytes have equal parity).
 constexpr int kFastTableBytes = 256 * 8 * kFastCopies;  // 32 KiB
-constexpr int kFastLdsBytes = kFastTableBytes + kWavesPerWG * 64 * 4;
+#ifndef MI_GEAR_COAL_BYTES
+#define MI_GEAR_COAL_BYTES 0                            // bytes per lane and exchange of mark_tile_coal; 0 = lane-owned
+                                                        // loads, the default: same-box A/B in profiles/r03_gear_ab.txt
+#endif
+constexpr int kCoalBytes = MI_GEAR_COAL_BYTES;
+constexpr int kFastListOff = kFastTableBytes + kWavesPerWG * 64 * kCoalBytes;     // table | stages | lists
+constexpr int kFastLdsBytes = kFastListOff + kWavesPerWG * 64 * 4;
 // LDS: table | one bitmap per wave | one 64-entry candidate list per wave | fast flags
 constexpr int kLdsListOff  = kTableBytes + kWavesPerWG * kBitmapWords * 4;
 constexpr int kLdsFastOff  = kLdsListOff + kWavesPerWG * 64 * 4;
@@ -169,6 +175,31 @@ __device__ __forceinline__ void load_piece(const u8* p, u32x4 (&d)[8]) {
     for (int i = 0; i < 8; ++i) d[i] = *(const u32x4*)(p + 16 * i);
 }
 
+// 16 more bytes of a lane's run (run-relative offset `base`): roll, test, record the candidates.
+template <int kC, bool kBitmap>
+__device__ __forceinline__ void hash16(u64& h, const u32x4 v, u32 tab, u32 thresh_m1, u32 run0, u32 base,
+                                       u32* bitmap, CandPack& pk, bool& ovf) {
+    u32 hh[16];
+    roll16<kC>(h, v, tab, hh);
+    // (a v_min3_u32 chain would be 8 ops instead of the 11 hipcc emits, but it is one dependent
+    // chain: A/B on one box, 1.50 ms against 1.46 ms for the compiler's tree)
+    u32 m = 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k < 16; k += 2) m = min(m, min(hh[k], hh[k + 1]));
+    if (m <= thresh_m1) {                                // rare: a candidate among these 16 bytes
+        // (positions at or past the file end are not filtered here: selection never looks
+        // beyond the tile's last byte, and at most one lane hashes up to 127 slack bytes)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (hh[k] <= thresh_m1) {
+                const u32 pos = run0 + base + (u32)k;    // byte index in tile
+                if (kBitmap) atomicOr(&bitmap[pos >> 5], 1u << (pos & 31));
+                cand_push(pk, ovf, base + (u32)k);
+            }
+        }
+    }
+}
+
 // One wave marks the candidates of tile [ts, ts+tlen) of a file into `bitmap`
 // (bit p <-> cut end ts + p + 1).  fptr is 16-byte aligned, ts a multiple of kGearTile.
 // pk/ovf: the lane's packed candidates for the fast selection path (cand_push / cand_compact).
@@ -204,29 +235,104 @@ __device__ __forceinline__ void mark_tile(const u8* __restrict__ fptr, u64 ts, u
     for (int pc = 0; pc < n_pieces; ++pc) {
         if (pc + 1 < n_pieces) load_piece(p + (pc + 1) * kPiece, nxt);   // in flight while hashing
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            roll16<kC>(h, cur[g], tab, hh);
-// (a v_min3_u32 chain would be 8 ops instead of the 11 hipcc emits, but it is one dependent
-            // chain: A/B on one box, 1.50 ms against 1.46 ms for the compiler's tree)
-            u32 m = 0xFFFFFFFFu;
-#pragma unroll
-            for (int k = 0; k < 16; k += 2) m = min(m, min(hh[k], hh[k + 1]));
-            if (m <= thresh_m1) {                        // rare: a candidate among these 16 bytes
-                // (positions at or past the file end are not filtered here: selection never looks
-                // beyond the tile's last byte, and at most one lane hashes up to 127 slack bytes)
-                const u32 base = (u32)(pc * kPiece + g * 16);
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    if (hh[k] <= thresh_m1) {
-                        const u32 pos = run0 + base + (u32)k;                       // byte index in tile
-                        if (kBitmap) atomicOr(&bitmap[pos >> 5], 1u << (pos & 31));
-                        cand_push(pk, ovf, base + (u32)k);
-                    }
-                }
-            }
-        }
+        for (int g = 0; g < 8; ++g)
+            hash16<kC, kBitmap>(h, cur[g], tab, thresh_m1, run0, (u32)(pc * kPiece + g * 16), bitmap, pk, ovf);
 #pragma unroll
         for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
+    }
+}
+
+// ---- coalesced form of the marking (round 3) ------------------------------------------------------
+// mark_tile lets every lane stream its own 1 KiB run: each load instruction of the wave touches 64
+// different cache lines, and that ACCESS PATTERN -- not HBM, not the LDS lookups -- bounded the kernel at
+// 4.4 TB/s (profiles/r01_ubench_stream.txt: 3.9-4.2 for the pattern, 6.1-6.4 coalesced; round 3's
+// conflict-free table changed the time by 3 %).  Here the WAVE fetches the next kP bytes of all 64 runs
+// with kP/16 instructions that each read whole (half) cache lines -- lane l takes 16-byte unit
+// l % (kP/16) of owner  (64 / (kP/16)) i + l / (kP/16) -- and the lanes swap the units through a per-wave
+// LDS stage (kP bytes per lane, rows XOR-swizzled so that both the 8-lane write and read passes of the
+// b128 accesses cover all banks): +2 B of LDS traffic per input byte next to the 8 B of table lookups.
+template <int kP>
+struct Coal {
+    static constexpr int kUnits = kP / 16;               // 16-byte units per lane and step (4 or 8)
+    static constexpr int kOwners = 64 / kUnits;          // owners served by one load instruction
+    static constexpr int kStageBytes = 64 * kP;          // per wave
+    static_assert(kP == 64 || kP == 128, "stage rows of 64 or 128 bytes");
+    __device__ static __forceinline__ u32 slot(u32 o, u32 u) { return o * kUnits + (u ^ ((o / (8 / kUnits)) & (kUnits - 1))); }
+};
+
+template <int kC, int kP>
+__device__ __forceinline__ void mark_tile_coal(const u8* __restrict__ fptr, u64 ts, u32 tlen, u32x4* stage,
+                                               u32 tab, u32 thresh_m1, int lane, CandPack& pk, bool& ovf) {
+    typedef Coal<kP> G;
+    pk.a = pk.b = 0;
+    ovf = false;
+    const u8* tile = fptr + ts;
+    const u32 run0 = (u32)lane * kLaneRun;               // tile-relative start of my run
+    const u32 run_len = run0 < tlen ? (tlen - run0 < (u32)kLaneRun ? tlen - run0 : (u32)kLaneRun) : 0u;
+    const int n_steps = (int)((run_len + kP - 1) / kP);  // mine
+    const u32 len0 = tlen < (u32)kLaneRun ? tlen : (u32)kLaneRun;
+    const int n_steps_w = (int)((len0 + kP - 1) / kP);   // lane 0's = the wave's (runs only get shorter)
+    const u32 lim = (tlen + 15u) & ~15u;                 // no load starts beyond the tile's last byte
+    const u32 u = (u32)lane % G::kUnits, orow = (u32)lane / G::kUnits;
+    const u32x4 zero = {0, 0, 0, 0};
+    u32x4 g[G::kUnits], cur[G::kUnits];
+
+    auto fetch = [&](int step) {                         // unit u of step `step` of owners kOwners i + orow
+#pragma unroll
+        for (int i = 0; i < G::kUnits; ++i) {
+            const u32 off = ((u32)G::kOwners * i + orow) * kLaneRun + (u32)step * kP + u * 16u;
+            g[i] = off < lim ? *(const u32x4*)(tile + off) : zero;
+        }
+    };
+    auto exchange = [&]() {                              // g (fetched for others) -> cur (mine)
+#pragma unroll
+        for (int i = 0; i < G::kUnits; ++i) stage[G::slot((u32)G::kOwners * i + orow, u)] = g[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int k = 0; k < G::kUnits; ++k) cur[k] = stage[G::slot((u32)lane, (u32)k)];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                 // the rows are rewritten by the next exchange
+    };
+
+    // warm-up: the 64 bytes before every run (the previous owner's last bytes; the previous tile's for
+    // lane 0), fetched 16 owners per instruction -- only the first four units of a row are used
+    u64 h = 0;
+    u32 hh[16];
+    {
+        const u32 wu = (u32)lane & 3u, wrow = (u32)lane >> 2;
+        u32x4 w4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const u32 o = 16u * i + wrow;
+            const bool has = o * kLaneRun < tlen && (ts + o * kLaneRun) != 0;
+            w4[i] = has ? *(const u32x4*)(tile + o * kLaneRun - 64 + wu * 16u) : zero;
+        }
+        fetch(0);                                        // in flight behind them
+#pragma unroll
+        for (int i = 0; i < 4; ++i) stage[G::slot(16u * i + wrow, wu)] = w4[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        u32x4 wq[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wq[k] = stage[G::slot((u32)lane, (u32)k)];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (run_len && ts + run0 != 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) roll16<kC>(h, wq[k], tab, hh);
+        }
+    }
+    for (int step = 0; step < n_steps_w; ++step) {
+        exchange();
+        if (step + 1 < n_steps_w) fetch(step + 1);       // in flight while hashing
+        if (step < n_steps) {
+#pragma unroll
+            for (int k = 0; k < G::kUnits; ++k)
+                hash16<kC, false>(h, cur[k], tab, thresh_m1, run0, (u32)(step * kP + k * 16), nullptr, pk, ovf);
+        }
     }
 }
 
@@ -324,7 +430,7 @@ void gear_cdc_small_fast_kernel(const u8* __restrict__ data, const u64* __restri
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     u64* table = (u64*)smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    u32* cand_list = (u32*)(smem + kFastTableBytes) + wave * 64;
+    u32* cand_list = (u32*)(smem + kFastListOff) + wave * 64;
     load_table<kFastCopies>(table, gear_table, tid);
     __syncthreads();
     const u32 lane_tab = lds_lane_table<kFastCopies>(table, lane);
@@ -339,7 +445,11 @@ void gear_cdc_small_fast_kernel(const u8* __restrict__ data, const u64* __restri
     if (size) {
         CandPack pk;
         bool ovf;
-        mark_tile<kFastCopies, false>(data + file_off[f], 0, (u32)size, nullptr, lane_tab, p.thresh_m1, lane, pk, ovf);
+        if (kCoalBytes)
+            mark_tile_coal<kFastCopies, kCoalBytes ? kCoalBytes : 64>(data + file_off[f], 0, (u32)size,
+                (u32x4*)(smem + kFastTableBytes) + wave * (kCoalBytes * 4), lane_tab, p.thresh_m1, lane, pk, ovf);
+        else
+            mark_tile<kFastCopies, false>(data + file_off[f], 0, (u32)size, nullptr, lane_tab, p.thresh_m1, lane, pk, ovf);
         if (!cand_compact(pk, ovf, (u32)lane * kLaneRun, lane, cand_list)) {      // wave-uniform
             if (lane == 0) dense_list[atomicAdd(dense_count, 1u)] = s;
             return;
@@ -497,7 +607,7 @@ void gear_tile_mark_kernel(const u8* __restrict__ data, const u64* __restrict__ 
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     u64* table = (u64*)smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    u32* cl = (u32*)(smem + kFastTableBytes) + wave * 64;
+    u32* cl = (u32*)(smem + kFastListOff) + wave * 64;
     load_table<kFastCopies>(table, gear_table, tid);
     __syncthreads();
     const u32 lane_tab = lds_lane_table<kFastCopies>(table, lane);
@@ -511,7 +621,11 @@ void gear_tile_mark_kernel(const u8* __restrict__ data, const u64* __restrict__ 
         const u32 tlen = (u32)((size - ts < (u64)kGearTile) ? (size - ts) : (u64)kGearTile);
         CandPack pk;
         bool ovf;
-        mark_tile<kFastCopies, false>(data + file_off[f], ts, tlen, nullptr, lane_tab, p.thresh_m1, lane, pk, ovf);
+        if (kCoalBytes)
+            mark_tile_coal<kFastCopies, kCoalBytes ? kCoalBytes : 64>(data + file_off[f], ts, tlen,
+                (u32x4*)(smem + kFastTableBytes) + wave * (kCoalBytes * 4), lane_tab, p.thresh_m1, lane, pk, ovf);
+        else
+            mark_tile<kFastCopies, false>(data + file_off[f], ts, tlen, nullptr, lane_tab, p.thresh_m1, lane, pk, ovf);
         fast = cand_compact(pk, ovf, (u32)lane * kLaneRun, lane, cl);
         __builtin_amdgcn_wave_barrier();
         tile_lists[t * 64 + lane] = fast ? cl[lane] : kNoCand;

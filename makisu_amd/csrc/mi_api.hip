@@ -314,7 +314,7 @@ int submit_pipeline_enqueue(mi_batch* b);
 int submit_pipeline(mi_batch* b) {
     b->in_flight = false;
     const int rc = submit_pipeline_enqueue(b);
-    if (rc == MI_OK) b->in_flight = true;
+    if (rc == MI_OK) { b->in_flight = true; ++b->ctx->batches_in_flight; }
     else (void)hipStreamSynchronize(b->stream);
     return rc;
 }
@@ -384,6 +384,12 @@ int submit_pipeline_enqueue(mi_batch* b) {
     u32* d_hist = (u32*)(ctl + kCtlHistOff);
     const u64* d_n = d_total;
     const int ncu = c->prop.multiProcessorCount;
+    // Pin the hashing workgroups to their CUs (sha256.hip launch_sha256_items) when this batch has the GPU to
+    // itself: a crowded CU then costs the launch up to 25 %.  With another batch in flight the passes of the
+    // two fill each other's gaps, the step is the same either way (5.8 ms on C2), and the unused LDS the pin
+    // reserves would only keep the other batch's Gear workgroups off the CU (measured: -1.3 %).
+    ShaTune sha = c->sha;
+    sha.pin_blocks_per_cu = c->sha.pin_blocks_per_cu && c->batches_in_flight == 0;
 
     HIPCHK(c, hipEventRecord(b->ev[0], s));
     HIPCHK(c, hipMemsetAsync(ctl, 0, kCtlBytes, s));
@@ -410,7 +416,7 @@ int submit_pipeline_enqueue(mi_batch* b) {
     HIPCHK(c, hipEventRecord(b->ev[2], s));
     launch_sha256_items(kShaChunks, b->arena.as<u8>(), b->q_off.as<u64>(), b->q_len.as<u64>(),
                         b->q_id.as<u32>(), (u32)cap, d_n, heads(0), false,
-                        b->digests.as<u8>(), c->sha, ncu, b->arena_used, s);
+                        b->digests.as<u8>(), sha, ncu, b->arena_used, s);
     HIPCHK(c, hipEventRecord(b->ev[3], s));
     // per-file chunk roots: fan-out-64 tree; reduction passes only exist for files with more than
     // 64 chunks (> ~0.5 MiB), the final pass hashes every file's <= 64 nodes
@@ -442,7 +448,7 @@ int submit_pipeline_enqueue(mi_batch* b) {
             launch_sha256_items(kShaRoots, nullptr, b->root_items_off.as<u64>(),
                                 b->root_items_len.as<u64>(), nullptr, (u32)out_ub,
                                 b->rseg_total.as<u64>(), heads(3 + r), false,
-                                b->root_level[r].as<u8>(), c->sha, ncu, 0, s);
+                                b->root_level[r].as<u8>(), sha, ncu, 0, s);
             nodes_ub = out_ub;
             std::swap(cur_addr, next_addr);
             std::swap(cur_cnt, next_cnt);
@@ -451,10 +457,10 @@ int submit_pipeline_enqueue(mi_batch* b) {
     }
     launch_sha256_items(kShaRoots, nullptr, b->item_off.as<u64>(), b->item_len.as<u64>(), nullptr,
                         (u32)nf, nullptr, heads(1), false, b->roots.as<u8>(),
-                        c->sha, ncu, 0, s);
+                        sha, ncu, 0, s);
     if (c->cfg.flags & MI_FLAG_FILE_SHA256)
         launch_sha256_items(kShaFiles, b->arena.as<u8>(), d_off, d_size, nullptr, (u32)nf, nullptr,
-                            heads(2), false, b->file_sha.as<u8>(), c->sha, ncu, b->arena_used, s);
+                            heads(2), false, b->file_sha.as<u8>(), sha, ncu, b->arena_used, s);
     if (c->cfg.flags & MI_FLAG_FILE_CRC32) {
         HIPCHK(c, b->tile_raw.ensure(b->n_tiles * 4 + 16));
         HIPCHK(c, b->crc_d.ensure(nf * 4));
@@ -481,6 +487,7 @@ int wait_pipeline(mi_batch* b) {
     mi_ctx* c = b->ctx;
     if (!b->in_flight) return fail(c, MI_ERR_STATE, "mi_batch_wait without a submitted run");
     b->in_flight = false;
+    if (c->batches_in_flight > 0) --c->batches_in_flight;
     HIPCHK(c, hipStreamSynchronize(b->stream));
     HIPCHK(c, hipGetLastError());
     const u64 total = b->h_counts[0];
@@ -699,6 +706,7 @@ int mi_ctx_create(const mi_config* cfg, mi_ctx** out) {
         int v = atoi(e);
         if (v >= 1 && v <= 3) c->sha.coop_blocks_per_cu = v;
     }
+    if (const char* e = getenv("MI_SHA_PIN_BLOCKS")) c->sha.pin_blocks_per_cu = atoi(e) != 0;
     if (cfg->sha_blocks_per_cu >= 1 && cfg->sha_blocks_per_cu <= 8) c->sha.blocks_per_cu = (int)cfg->sha_blocks_per_cu;
     if (cfg->sha_coop_min_gib) c->sha.coop_min_bytes = (u64)cfg->sha_coop_min_gib << 30;
     if (cfg->sha_load_scheme == MI_SHA_LOADS_LANE) c->sha.coop_min_bytes = ~0ull;

@@ -109,6 +109,8 @@ struct ShaTune {
     u64 coop_min_bytes = 9ull << 30;         // footprint from which the quad-cooperative loads are used
                                              // (0 = always, ~0 = never)
     int coop_blocks_per_cu = 0;              // 0 = 3 from 24 GiB up, else blocks_per_cu
+    bool pin_blocks_per_cu = true;           // pad every workgroup's LDS request so that NO CU can take more
+                                             // than blocks_per_cu of them (sha256.hip launch_sha256_items)
 };
 // n = string count (or its upper bound when d_n, a device word holding the real count, is given)
 // d_heads must be zero on entry unless zero_heads (then the launcher clears it first)

@@ -77,6 +77,7 @@ struct mi_ctx {
     mi::u32 stage_threads = 0;
     size_t staging_bytes = 0;            // bytes per pinned slab (reader threads, per-batch inline ring)
     int live_children = 0;               // batches + indexes that still point at this ctx
+    int batches_in_flight = 0;           // submitted, not yet waited for
     mi::DevBuf gear_table, heads, crc_consts;
     mi::DevBuf dd_table, dd_slot, dd_nuniq;             // dedup scratch of mi_dedup_mark
     mi::DevBuf dd_tag;                                  // ... and of mi_dedup_mark_range

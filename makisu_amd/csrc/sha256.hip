@@ -405,6 +405,28 @@ void launch_sha256_items(ShaPass pass, const u8* d_base, const u64* d_off, const
     int blocks_per_cu = tune.blocks_per_cu;
     if (coop) blocks_per_cu = tune.coop_blocks_per_cu ? tune.coop_blocks_per_cu
                             : footprint_bytes >= (24ull << 30) ? 3 : blocks_per_cu;   // enough work per lane for a third
+    // The grid is blocks_per_cu x n_cu persistent workgroups -- but the dispatcher places by free
+    // resources, and at 136 VGPRs a CU has room for THREE: some CUs take three workgroups and others one,
+    // the waves of a crowded CU run at two thirds of the pace, and the launch ends with them (measured on
+    // one box, same clocks: 4.13 ... 5.48 ms from launch to launch).  An LDS request of just over
+    // 160 KiB / (blocks_per_cu + 1) per workgroup -- unused memory -- makes the intended placement the
+    // only possible one.
+    size_t lds_pad = 0;
+    if (tune.pin_blocks_per_cu && blocks_per_cu >= 1 && blocks_per_cu <= 3) {
+        static thread_local int attr_dev = -1;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (attr_dev != dev) {
+#define MI_SHA_ATTR(P, C) (void)hipFuncSetAttribute((const void*)sha256_items_kernel<P, C>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)
+            MI_SHA_ATTR(kShaChunks, false); MI_SHA_ATTR(kShaChunks, true); MI_SHA_ATTR(kShaRoots, false);
+            MI_SHA_ATTR(kShaFiles, false); MI_SHA_ATTR(kShaFiles, true); MI_SHA_ATTR(kShaBlobs, false); MI_SHA_ATTR(kShaBlobs, true);
+#undef MI_SHA_ATTR
+            attr_dev = dev;
+        }
+        const size_t per_wg = (160u * 1024u) / (size_t)(blocks_per_cu + 1) + 1024u;
+        const size_t fixed = coop ? (size_t)(kShaWG / 64) * 64 * kXRow * 4 : 16;     // the kernel's own static LDS
+        lds_pad = per_wg > fixed ? per_wg - fixed : 0;
+    }
     u64 want = ((u64)n + kShaWG - 1) / kShaWG;
     u64 cap = (u64)blocks_per_cu * (u64)n_cu;
     u32 grid = (u32)(want < cap ? want : cap);
@@ -412,7 +434,7 @@ void launch_sha256_items(ShaPass pass, const u8* d_base, const u64* d_off, const
     if (grid >= (u32)kShaQueues) grid -= grid % kShaQueues;
     if (grid == 0) grid = 1;
 #define MI_SHA_LAUNCH(P, C)                                                                   \
-    hipLaunchKernelGGL((sha256_items_kernel<P, C>), dim3(grid), dim3(kShaWG), 0, s, d_base, d_off, \
+    hipLaunchKernelGGL((sha256_items_kernel<P, C>), dim3(grid), dim3(kShaWG), lds_pad, s, d_base, d_off, \
                        d_len, d_order, n, d_n, d_heads, d_out)
     switch (pass) {
         case kShaChunks: if (coop) MI_SHA_LAUNCH(kShaChunks, true); else MI_SHA_LAUNCH(kShaChunks, false); break;
