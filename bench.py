@@ -487,7 +487,8 @@ def main():
     # the SHA-256 VALU roof of THIS device in THIS run, right behind the timed region (same thermal and
     # power state): best of three 10 ms launches of the compression alone
     sampler.start()
-    valu_roof = eng.sha_valu_roof() / 1e9
+    roofs = {w: eng.sha_valu_roof(w, 0) / 1e9 for w in (8, 4)}   # waves per SIMD: the denser form draws more power
+    valu_roof = max(roofs.values())
     roof_clocks = sampler.stop() if rank == 0 else None
     if dist.is_initialized() and world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
@@ -606,7 +607,11 @@ def main():
                      "avg_launch_ms": round(sha_avg_ms, 4),
                      "valu_roof_GBps": round(valu_roof, 1),
                      "valu_roof_source": "mi_sha_valu_roof in this run, right after the timed region: the 64-round "
-                                         "compression alone on every SIMD (8 waves each, no memory traffic), best of 3",
+                                         "compression alone on every SIMD (no memory traffic), best of 3 launches at 8 and "
+                                         "at 4 waves per SIMD: %s GB/s.  The roof launch is pure VALU work and is itself "
+                                         "subject to the socket's power management: on a box where it is throttled the "
+                                         "hashing pass can sit at (or a few %% above) it -- both are then at the same limit"
+                                         % {k: round(v, 1) for k, v in roofs.items()},
                      "frac_of_valu_roof": round(achieved / valu_roof, 4),
                      "path_frac": round(job_bytes / world * 1.006 / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS, 4),
                      "note": "SHA-256 is integer-VALU bound on CDNA4 (valu_roof_GBps, measured in this run); "

@@ -58,9 +58,12 @@ constexpr int kTableBytes  = 256 * 8 * kCopies;
 // six per lane) and the 64-entry list; the 8 KiB-per-wave LDS bitmap -- two thirds of the old LDS budget,
 // there for tiles with more than 64 candidates -- is gone from the fast path, and such tiles (none on
 // random data at the default mask) are redone by the bitmap kernel.  The freed LDS holds SIXTEEN table
-// copies: two lanes per bank pair and half-wave is the ds_read_b64 minimum, so the byte lookups --
-// 8 B of LDS traffic per input byte, the kernel's dominant cost -- run conflict-free instead of at
-// ~3.6 passes per half-wave (8 copies: four lanes share a bank pair whenever their bytes have equal parity).
+// copies (entry stride 128 B).  CDNA4 serves a ds_read_b64 in two groups of 32 lanes over 64 banks
+// (bank = dword address mod 64): with 8 copies four lanes of a group share a copy and collide whenever
+// their bytes agree mod 4 positions of the row; with 16 copies two lanes share one and collide when
+// their bytes have equal parity -- SQ_LDS_BANK_CONFLICT falls from 62 % to 49 % of the LDS-array cycles
+// and those cycles by a third (profiles/r03_sq_counters.txt); conflict-free would take 32 copies =
+// 64 KiB, two workgroups per CU instead of four.
 constexpr int kFastTableBytes = 256 * 8 * kFastCopies;  // 32 KiB
 #ifndef MI_GEAR_COAL_BYTES
 #define MI_GEAR_COAL_BYTES 0                            // bytes per lane and exchange of mark_tile_coal; 0 = lane-owned

@@ -412,7 +412,10 @@ void launch_sha256_items(ShaPass pass, const u8* d_base, const u64* d_off, const
     // 160 KiB / (blocks_per_cu + 1) per workgroup -- unused memory -- makes the intended placement the
     // only possible one.
     size_t lds_pad = 0;
-    if (tune.pin_blocks_per_cu && blocks_per_cu >= 1 && blocks_per_cu <= 3) {
+    // (Only for the lane-owned scheme: the cooperative kernel's 161 VGPRs already cap a CU at three
+    // workgroups, and pinned to two it ran SLOWER on a 6.5 GB arena -- 5.4 against 4.5 ms,
+    // profiles/r03_sha_placement.txt -- so it is left to the dispatcher.)
+    if (tune.pin_blocks_per_cu && !coop && blocks_per_cu >= 1 && blocks_per_cu <= 3) {
         static thread_local int attr_dev = -1;
         int dev = 0;
         (void)hipGetDevice(&dev);

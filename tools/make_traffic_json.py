@@ -26,7 +26,7 @@ def main():
     write = counters("%s/%s_write.txt" % (d, tag), "WRITE_SIZE")
     bench = json.load(open("%s/%s_bench_n1.json" % (d, tag)))
     sha = "void mi::sha256_items_kernel<0, false>"   # C2: lane-owned loads (arena below the cooperative switch)
-    gear = "mi::gear_cdc_small_kernel"
+    gear = "mi::gear_cdc_small_fast_kernel" if "mi::gear_cdc_small_fast_kernel" in fetch else "mi::gear_cdc_small_kernel"
     synth_kib = write.get("mi::synth_fill_kernel", (0, 0.0))[1]
     bytes_in = bench["config"]["bytes_per_gpu"]
     n_chunks = bench["config"]["chunks_last_batch"]
@@ -43,11 +43,11 @@ def main():
                       "(%.0f KiB reported for %d bytes written per batch)" % (synth_kib, bytes_in),
         "sha256_items_kernel_bytes_per_launch": int(2 * fetch[sha][1] * 1024 + write[sha][1] * 1024),
         "algorithmic_bytes_per_launch": int(bytes_in + 52 * n_chunks),
-        "gear_cdc_small_kernel_bytes_per_launch": int(2 * fetch[gear][1] * 1024 + write[gear][1] * 1024),
+        "gear_cdc_small_fast_kernel_bytes_per_launch": int(2 * fetch[gear][1] * 1024 + write[gear][1] * 1024),
         "gear_algorithmic_bytes_per_launch": int(bytes_in + 4 * n_chunks),
     }
     out["sha_traffic_ratio"] = round(out["sha256_items_kernel_bytes_per_launch"] / out["algorithmic_bytes_per_launch"], 3)
-    out["gear_traffic_ratio"] = round(out["gear_cdc_small_kernel_bytes_per_launch"] / out["gear_algorithmic_bytes_per_launch"], 3)
+    out["gear_traffic_ratio"] = round(out["gear_cdc_small_fast_kernel_bytes_per_launch"] / out["gear_algorithmic_bytes_per_launch"], 3)
     print(json.dumps(out, indent=1))
 
 

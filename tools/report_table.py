@@ -6,12 +6,15 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
-rows = [("C2", "n1"), ("C3", "c3"), ("C4, one rank's shard", "c4_one_shard"), ("C5", "c5")]
+rows = [("C2", "n1"), ("C3", "c3"), ("C4, one rank's shard", "c4_one_shard"), ("C5 (Zipf s=1.1)", "c5"),
+        ("C5U (2^U(10,30), rounds 1-2)", "c5u")]
 print("| config | bytes / step | chunks (last batch) | serial phases: CDC / sort / SHA / roots / marking [ms] | step [ms] | GiB/s | path % of HBM | "
       "SHA pass % of HBM / of VALU roof (serial) | CPU 1 thread / N threads [GiB/s] | parity vs oracle |")
 print("|---|---|---|---|---|---|---|---|---|---|")
 for name, key in rows:
     path = os.path.join(ROOT, "profiles", "%s_bench_%s.json" % (tag, key))
+    if not os.path.exists(path):
+        continue
     d = json.loads([l for l in open(path) if l.startswith("{")][-1])
     r, c, ph = d["roofline"], d["config"], d.get("serial_phase_ms", {})
     cb = d.get("cpu_baseline")
