@@ -944,3 +944,27 @@ def test_chunk_rows_view_and_prefetch(oracle):
             assert (view["dup_of"] >= 0).sum() > 0
             b.rerun()
             assert b.chunks_view().tobytes() == rows.tobytes()
+
+
+def test_sha_valu_roof_and_per_ctx_tuning(oracle):
+    """mi_sha_valu_roof measures the compression-only rate of this device (what bench.py quotes the
+    hashing pass against, same run); the SHA tuning fields of mi_config belong to the ctx: two ctxs of
+    ONE process hash the same batch with different load schemes and workgroup counts, same digests."""
+    import makisu_amd
+    sizes = [65536] * 300 + [300000, 1, 0, 5 << 20]
+    rows = []
+    with makisu_amd.Engine() as e0:
+        roof = e0.sha_valu_roof()
+        assert 0.8e12 < roof < 3.0e12, roof                    # 1.57-1.78 TB/s on the pool's boxes
+        assert e0.sha_valu_roof(2, 64) < 1.2 * roof             # fewer waves per SIMD: not faster
+        assert e0.comm_ranks() == 0
+        for kw in ({}, {"sha_load_scheme": makisu_amd.SHA_LOADS_COOP, "sha_blocks_per_cu": 1},
+                   {"sha_load_scheme": makisu_amd.SHA_LOADS_LANE, "sha_blocks_per_cu": 3, "sha_coop_blocks_per_cu": 2}):
+            with makisu_amd.Engine(**kw) as e, e.batch() as b:  # e0 stays alive: ctxs side by side
+                b.add_synthetic(sizes, None, seed=SEED)
+                b.run()
+                rows.append((b.chunks()["sha256"].copy(), b.files()["chunk_root"].copy()))
+    for sha, roots in rows[1:]:
+        assert np.array_equal(sha, rows[0][0]) and np.array_equal(roots, rows[0][1])
+    with pytest.raises(makisu_amd.MiError):
+        makisu_amd.Engine(sha_load_scheme=7)
