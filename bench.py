@@ -68,8 +68,29 @@ class ClockSampler:
                     break
             except OSError:
                 continue
+        # memory-side clocks: pp_dpm_{mclk,fclk,socclk} list the levels, the current one starred
+        self.dpm = {}
+        if self.freq:
+            dev = os.path.dirname(os.path.dirname(os.path.dirname(self.freq)))
+            for k in ("mclk", "fclk", "socclk"):
+                f = os.path.join(dev, "pp_dpm_" + k)
+                if os.path.exists(f):
+                    self.dpm[k] = f
+        self.dpm_samples = []
         self.samples = []
         self._stop = None
+
+    def _read_dpm(self):
+        import re
+        out = {}
+        for k, f in self.dpm.items():
+            try:
+                m = re.search(r"(\d+)\s*mhz\s*\*", open(f).read(), re.I)
+                if m:
+                    out[k] = int(m.group(1))
+            except OSError:
+                pass
+        return out
 
     def _read(self):
         try:
@@ -82,13 +103,18 @@ class ClockSampler:
     def start(self):
         import threading
         self.samples = []
+        self.dpm_samples = []
         if not self.freq:
             return
         self._stop = threading.Event()
 
         def loop():
+            i = 0
             while not self._stop.is_set():
                 self.samples.append(self._read())
+                if self.dpm and i % 8 == 0:                     # the SMU answers these; every 40 ms is enough
+                    self.dpm_samples.append(self._read_dpm())
+                i += 1
                 self._stop.wait(0.005)
         self._t = threading.Thread(target=loop, daemon=True)
         self._t.start()
@@ -107,6 +133,10 @@ class ClockSampler:
             out.update({"sclk_mhz_min": round(min(mhz)), "sclk_mhz_mean": round(sum(mhz) / len(mhz)), "sclk_mhz_max": round(max(mhz))})
         if w:
             out.update({"power_w_mean": round(sum(w) / len(w)), "power_w_max": round(max(w))})
+        for k in self.dpm:
+            v = [d[k] for d in self.dpm_samples if k in d]
+            if v:
+                out[k + "_mhz_min_max"] = [min(v), max(v)]
         return out
 
     @staticmethod
@@ -296,7 +326,11 @@ def main():
     ap.add_argument("--split-mib", type=int, default=256,
                     help="c5 with N > 1: files of this many MiB and more are split into one part per GPU")
     ap.add_argument("--inflight", type=int, default=0,
-                    help="batches in flight (1 = serial steps; default 2, 3 for c2 with an exchange)")
+                    help="batches in flight (default: 1 = one batch at a time on one GPU without an exchange, "
+                         "where every kernel then has the GPU to itself and its event-bracketed duration is its "
+                         "own; 2 with an exchange to hide, 3 for c2 with an exchange)")
+    ap.add_argument("--no-inflight-extra", action="store_true",
+                    help="c2, one GPU: skip the extra region with two batches in flight")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-fed", action="store_true", help="c3: skip the host-fed leg")
     ap.add_argument("--backend", default="nccl",
@@ -328,10 +362,13 @@ def main():
     config = args.config if args.config != "auto" else ("c2" if world == 1 else "c4")
     exchange = world > 1 or args.force_exchange
     if args.inflight <= 0:
-        # two batches already overlap one batch's Gear pass with the other's SHA pass; a third
-        # only pays off when there is host-synchronised exchange work to hide and
-        # only fits for the small config
-        args.inflight = 3 if (exchange and config == "c2") else 2
+        # Without an exchange: ONE batch at a time.  Two in flight are 2-3 % faster (the second batch's
+        # passes fill the first one's tails -- reported as `two_batches_in_flight` below), but their
+        # persistent hashing grids then share the SIMDs for most of their lives and the span of a launch
+        # (7.9 ms between its events, in the bench and in rocprof alike) says nothing about the kernel
+        # (4.2 ms).  With an exchange there is host-synchronised work to hide: two batches, three for
+        # the small config.
+        args.inflight = (3 if config == "c2" else 2) if exchange else 1
     if args.steps <= 0:
         args.steps = {"c2": 20, "c3": 3, "c4": 3, "c5": 4, "c5u": 5}[config]
     if args.warmup < 0:
@@ -448,10 +485,11 @@ def main():
                     stats_sum[k] = stats_sum.get(k, 0.0) + v
             checks[i] = (st["n_chunks"], n_unique if exchange else st["n_unique"])
 
-    def run_steps(n, record):
+    def run_steps(n, record, inflight=None):
+        inflight = inflight or args.inflight
         pending = []
         for k in range(n * launches_per_step):
-            if len(pending) == args.inflight:
+            if len(pending) == inflight:
                 finish(pending.pop(0), record)
             i = k % len(batches)
             batches[i].submit()
@@ -515,6 +553,35 @@ def main():
                 serial_sha_ms.append(st["ms_sha_chunks"])
         serial_phase = {k: round(v, 4) for k, v in st.items() if k.startswith("ms_")}
         serial_alg = st["bytes_in"] + 52 * st["n_chunks"]
+
+    # c2 on one GPU: the same steps with TWO batches in flight (a second batch of distinct content), outside
+    # the timed region -- what a host that always has the next layer ready gets.
+    two_in_flight = None
+    if config == "c2" and world == 1 and not exchange and args.inflight == 1 and not args.no_inflight_extra:
+        sh2 = make(1)
+        b_extra = eng.batch(sh2.n_files, sh2.n_bytes + (sh2.n_files + 8) * 4096)
+        b_extra.add_synthetic(sh2.sizes, sh2.cids, seed=sh2.seed)
+        b_extra.run()
+        batches.append(b_extra)
+        keep = (list(sha_ms), list(sha_alg_bytes), dict(stats_sum), dict(checks))
+        del sha_ms[:], sha_alg_bytes[:]
+        run_steps(args.warmup, False, inflight=2)
+        torch.cuda.synchronize(device)
+        t1 = time.perf_counter()
+        run_steps(args.steps, True, inflight=2)
+        torch.cuda.synchronize(device)
+        dt2 = time.perf_counter() - t1
+        two_in_flight = {"value": round(step_bytes * args.steps / dt2 / 2**30, 2), "unit": "GiB/s",
+                         "ms_per_step": round(dt2 / args.steps * 1e3, 4), "steps": args.steps,
+                         "sha_chunk_pass_span_ms": round(float(np.mean(sha_ms)), 4),
+                         "note": "same steps, a second batch of distinct content submitted while the first runs; "
+                                 "the span of a hashing launch now includes the time it shares the SIMDs with the "
+                                 "other batch's passes"}
+        sha_ms[:], sha_alg_bytes[:] = keep[0], keep[1]
+        stats_sum.clear(); stats_sum.update(keep[2])
+        checks.clear(); checks.update(keep[3])
+        batches.pop()
+        b_extra.free()
 
     # The same pass with the OTHER load scheme (quad-cooperative: far fewer address translations), a few
     # serial steps on a second ctx: on a box whose lane-owned launches run well below the VALU roof this
@@ -616,15 +683,20 @@ def main():
                      "path_frac": round(job_bytes / world * 1.006 / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS, 4),
                      "note": "SHA-256 is integer-VALU bound on CDNA4 (valu_roof_GBps, measured in this run); "
                              "the HBM fraction cannot exceed valu_roof / peak. "
-                             "achieved/avg_launch_ms are from the timed region, where the kernel "
-                             "shares the GPU with the other in-flight batches' passes; "
-                             "serial_* = the same kernel with one batch at a time (median of 7 extra "
-                             "untimed steps); path_frac = whole CDC+SHA step per GPU, algorithmic "
-                             "bytes / ms_per_step / peak"},
+                             "achieved/avg_launch_ms are from the timed region (HIP events around the launch on "
+                             "the batch's stream)%s; path_frac = whole CDC+SHA step per GPU, algorithmic "
+                             "bytes / ms_per_step / peak"
+                             % (": one batch at a time, the kernel has the GPU to itself" if args.inflight == 1 else
+                                ", where the kernel shares the GPU with the other in-flight batches' passes; "
+                                "serial_* = the same kernel with one batch at a time (median of 7 extra untimed steps)")},
         "phase_ms_avg": {k: round(v / max(1, len(sha_ms)), 4) for k, v in sorted(stats_sum.items())},
         "phase_note": "per-batch stream timelines; with several batches in flight a phase's span "
                       "includes time it shared the GPU with the other batches",
     }
+    if args.inflight == 1:
+        out["serial_phase_ms"] = dict(out["phase_ms_avg"])      # one batch at a time: the timed region IS serial
+    if two_in_flight:
+        out["two_batches_in_flight"] = two_in_flight
     if config in ("c5", "c5u"):
         out["config"].update({"lpt_imbalance_max_over_mean_bytes": round(desc_shard.imbalance, 6),
                               "files_split_into_parts_job": getattr(desc_shard, "n_split_files_job", 0),

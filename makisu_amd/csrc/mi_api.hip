@@ -59,9 +59,10 @@ u64 align_up(u64 v, u64 a) { return (v + a - 1) / a * a; }
 
 // per-batch control block (device): see submit_pipeline
 constexpr size_t kCtlHeadsOff = 16;
-constexpr size_t kCtlCursorOff = kCtlHeadsOff + 8 * kShaQueues * sizeof(u32);
+constexpr size_t kCtlCursorOff = kCtlHeadsOff + 8 * kShaHeadWords * sizeof(u32);
 constexpr size_t kCtlHistOff = kCtlCursorOff + 1024 * sizeof(u32);
-constexpr size_t kCtlBytes = kCtlHistOff + 1024 * sizeof(u32);
+constexpr size_t kCtlRolesOff = kCtlHistOff + 1024 * sizeof(u32);       // SIMD arrival counters: chunk pass | file pass
+constexpr size_t kCtlBytes = kCtlRolesOff + 2 * kShaRoleWords * sizeof(u32);
 
 // ---- arena + staging ------------------------------------------------------------
 // Two ways into the arena: small mi_batch_add_bytes calls are copied inline into the batch's own
@@ -379,7 +380,8 @@ int submit_pipeline_enqueue(mi_batch* b) {
     u8* ctl = b->ctl.as<u8>();
     u64* d_total = (u64*)ctl;
     u64* d_nuniq = (u64*)(ctl + 8);
-    auto heads = [&](int set) { return (u32*)(ctl + kCtlHeadsOff) + set * kShaQueues; };
+    auto heads = [&](int set) { return (u32*)(ctl + kCtlHeadsOff) + set * kShaHeadWords; };
+    auto roles = [&](int set) { return (u32*)(ctl + kCtlRolesOff) + set * kShaRoleWords; };
     u32* d_cursor = (u32*)(ctl + kCtlCursorOff);
     u32* d_hist = (u32*)(ctl + kCtlHistOff);
     const u64* d_n = d_total;
@@ -413,11 +415,22 @@ int submit_pipeline_enqueue(mi_batch* b) {
     launch_bin_order(b->chunk_off.as<u64>(), b->chunk_len.as<u64>(), (u32)cap, d_n,
                      d_hist, d_cursor, n_bins, bin_shift,
                      b->q_off.as<u64>(), b->q_len.as<u64>(), b->q_id.as<u32>(), s);
+    // MI_SHA_SERIALIZE=1 (experiments; off by default): one chunk pass at a time on the device.  A chunk pass
+    // is a persistent grid that fills every SIMD; the chunk pass of ANOTHER batch in flight fits beside it
+    // (138 VGPRs: three waves per SIMD) and the two then stretch each other to 6-8 ms apiece.  Making a
+    // batch's chunk pass wait for the previous one of this ctx gives clean 4.45 ms launches again -- and
+    // costs 2-4 % of the two-batch throughput (5.94 vs 5.77 ms per C2 step: the tails and the table kernels
+    // of one batch are no longer filled by the other's hashing), which is what one batch at a time does too.
+    if (c->serialize_sha && c->sha_done_set) HIPCHK(c, hipStreamWaitEvent(s, c->sha_done, 0));
     HIPCHK(c, hipEventRecord(b->ev[2], s));
     launch_sha256_items(kShaChunks, b->arena.as<u8>(), b->q_off.as<u64>(), b->q_len.as<u64>(),
-                        b->q_id.as<u32>(), (u32)cap, d_n, heads(0), false,
+                        b->q_id.as<u32>(), (u32)cap, d_n, heads(0), roles(0), false,
                         b->digests.as<u8>(), sha, ncu, b->arena_used, s);
     HIPCHK(c, hipEventRecord(b->ev[3], s));
+    if (c->serialize_sha) {
+        HIPCHK(c, hipEventRecord(c->sha_done, s));
+        c->sha_done_set = true;
+    }
     // per-file chunk roots: fan-out-64 tree; reduction passes only exist for files with more than
     // 64 chunks (> ~0.5 MiB), the final pass hashes every file's <= 64 nodes
     if (!flat_roots) {
@@ -447,7 +460,7 @@ int submit_pipeline_enqueue(mi_batch* b) {
                               b->root_items_len.as<u64>(), s);
             launch_sha256_items(kShaRoots, nullptr, b->root_items_off.as<u64>(),
                                 b->root_items_len.as<u64>(), nullptr, (u32)out_ub,
-                                b->rseg_total.as<u64>(), heads(3 + r), false,
+                                b->rseg_total.as<u64>(), heads(3 + r), nullptr, false,
                                 b->root_level[r].as<u8>(), sha, ncu, 0, s);
             nodes_ub = out_ub;
             std::swap(cur_addr, next_addr);
@@ -456,11 +469,11 @@ int submit_pipeline_enqueue(mi_batch* b) {
         launch_root_final_items(cur_addr, cur_cnt, nf, b->item_off.as<u64>(), b->item_len.as<u64>(), s);
     }
     launch_sha256_items(kShaRoots, nullptr, b->item_off.as<u64>(), b->item_len.as<u64>(), nullptr,
-                        (u32)nf, nullptr, heads(1), false, b->roots.as<u8>(),
+                        (u32)nf, nullptr, heads(1), nullptr, false, b->roots.as<u8>(),
                         sha, ncu, 0, s);
     if (c->cfg.flags & MI_FLAG_FILE_SHA256)
         launch_sha256_items(kShaFiles, b->arena.as<u8>(), d_off, d_size, nullptr, (u32)nf, nullptr,
-                            heads(2), false, b->file_sha.as<u8>(), sha, ncu, b->arena_used, s);
+                            heads(2), roles(1), false, b->file_sha.as<u8>(), sha, ncu, b->arena_used, s);
     if (c->cfg.flags & MI_FLAG_FILE_CRC32) {
         HIPCHK(c, b->tile_raw.ensure(b->n_tiles * 4 + 16));
         HIPCHK(c, b->crc_d.ensure(nf * 4));
@@ -660,6 +673,8 @@ int mi_ctx_create(const mi_config* cfg, mi_ctx** out) {
     CREATE_CHK(hipHostMalloc((void**)&c->h_word, 64, hipHostMallocDefault));
     for (auto& e : c->ev) e = nullptr;
     for (auto& e : c->ev) CREATE_CHK(hipEventCreate(&e));
+    CREATE_CHK(hipEventCreateWithFlags(&c->sha_done, hipEventDisableTiming));
+    if (const char* e = getenv("MI_SHA_SERIALIZE")) c->serialize_sha = atoi(e) != 0;
     // host-fed staging (mi_stage.hip): slab bytes and reader threads; both lazily allocated
     c->staging_bytes = cfg->staging_bytes ? cfg->staging_bytes : (8ull << 20);
     if (c->staging_bytes < (1ull << 16)) c->staging_bytes = 1ull << 16;
@@ -685,7 +700,7 @@ int mi_ctx_create(const mi_config* cfg, mi_ctx** out) {
     for (int i = 0; i < 256; ++i) { st += kSmGamma; table[i] = splitmix64_mix(st); }
     CREATE_CHK(c->gear_table.ensure(sizeof table));
     CREATE_CHK(hipMemcpy(c->gear_table.p, table, sizeof table, hipMemcpyHostToDevice));
-    CREATE_CHK(c->heads.ensure(sizeof(u32) * kShaQueues));
+    CREATE_CHK(c->heads.ensure(sizeof(u32) * (kShaHeadWords + kShaRoleWords)));
     {
         std::vector<u32> consts(kCrcConstWords);
         crc32_build_tables(consts.data());
@@ -707,6 +722,12 @@ int mi_ctx_create(const mi_config* cfg, mi_ctx** out) {
         if (v >= 1 && v <= 3) c->sha.coop_blocks_per_cu = v;
     }
     if (const char* e = getenv("MI_SHA_PIN_BLOCKS")) c->sha.pin_blocks_per_cu = atoi(e) != 0;
+    if (const char* e = getenv("MI_SHA_ROLES")) c->sha.roles = atoi(e) != 0;
+    if (const char* e = getenv("MI_SHA_PRIO")) c->sha.prio = atoi(e) != 0;
+    if (const char* e = getenv("MI_SHA_LONG_SHIFT")) {
+        const int v = atoi(e);
+        if (v >= 0 && v <= 16) c->sha.long_shift = v;
+    }
     if (cfg->sha_blocks_per_cu >= 1 && cfg->sha_blocks_per_cu <= 8) c->sha.blocks_per_cu = (int)cfg->sha_blocks_per_cu;
     if (cfg->sha_coop_min_gib) c->sha.coop_min_bytes = (u64)cfg->sha_coop_min_gib << 30;
     if (cfg->sha_load_scheme == MI_SHA_LOADS_LANE) c->sha.coop_min_bytes = ~0ull;
@@ -732,6 +753,7 @@ int mi_ctx_destroy(mi_ctx* c) {
     stager_destroy(c->stager);
     c->stager = nullptr;
     for (auto e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->sha_done) (void)hipEventDestroy(c->sha_done);
     if (c->h_word) (void)hipHostFree(c->h_word);
     c->gear_table.release(); c->heads.release(); c->crc_consts.release();
     c->dd_table.release(); c->dd_slot.release(); c->dd_nuniq.release(); c->dd_tag.release();
@@ -1501,7 +1523,7 @@ int mi_sha256_many(mi_ctx* c, const void* data, const uint64_t* offsets, const u
         if (e == hipSuccess) e = hipMemcpy(d_len.p, lens, n * 8, hipMemcpyHostToDevice);
         if (e == hipSuccess) {
             launch_sha256_items(kShaBlobs, d_data.as<u8>(), d_off.as<u64>(), d_len.as<u64>(), nullptr, (u32)n,
-                                nullptr, c->heads.as<u32>(), true, d_out.as<u8>(), c->sha,
+                                nullptr, c->heads.as<u32>(), c->heads.as<u32>() + kShaHeadWords, true, d_out.as<u8>(), c->sha,
                                 c->prop.multiProcessorCount, span, c->stream);
             e = hipStreamSynchronize(c->stream);
         }

@@ -101,7 +101,11 @@ void   launch_gear_parts(const GearLaunch& a, const u32* d_part_file, const u32*
 
 // sha256.hip : n independent byte strings -> n digests.  Queue position p holds the string
 // base[off[p] .. +len[p]) whose digest goes to out[32 * (ids ? ids[p] : p)]; positions are
-// consumed in order, so put the longest strings first.  heads = kShaQueues words.
+// consumed in order, so put the longest strings first.  heads = kShaHeadWords words (two ranges of
+// kShaQueues queue heads); roles = kShaRoleWords words (one arrival counter per SIMD of the device) or
+// nullptr: without it every wave is equal and there is one range (strings of one length: the root passes).
+constexpr int kShaHeadWords = 2 * kShaQueues;
+constexpr int kShaRoleWords = 8 * 256 * 4;       // XCC x (SE SH CU of HW_ID) x SIMD
 enum ShaPass { kShaChunks = 0, kShaRoots = 1, kShaFiles = 2, kShaBlobs = 3 };
 // per-ctx tuning of the hashing launches (mi_config.sha_*)
 struct ShaTune {
@@ -111,11 +115,15 @@ struct ShaTune {
     int coop_blocks_per_cu = 0;              // 0 = 3 from 24 GiB up, else blocks_per_cu
     bool pin_blocks_per_cu = true;           // pad every workgroup's LDS request so that NO CU can take more
                                              // than blocks_per_cu of them (sha256.hip launch_sha256_items)
+    bool roles = true;                       // false: every wave equal, one range (the scheme before round 3)
+    bool prio = true;                        // the first wave on a SIMD runs at priority 3 (experiments: false)
+    int long_shift = 2;                      // the first n >> long_shift strings (the longest) go to the wave that
+                                             // arrived first on each SIMD and runs at priority (sha256.hip roles)
 };
 // n = string count (or its upper bound when d_n, a device word holding the real count, is given)
-// d_heads must be zero on entry unless zero_heads (then the launcher clears it first)
+// d_heads and d_roles must be zero on entry unless zero_heads (then the launcher clears them first)
 void launch_sha256_items(ShaPass pass, const u8* d_base, const u64* d_off, const u64* d_len,
-                         const u32* d_ids, u32 n, const u64* d_n, u32* d_heads, bool zero_heads,
+                         const u32* d_ids, u32 n, const u64* d_n, u32* d_heads, u32* d_roles, bool zero_heads,
                          u8* d_out, const ShaTune& tune, int n_cu, u64 footprint_bytes, hipStream_t s);
 // footprint_bytes: the span of memory the strings lie in (picks the load scheme, sha256.hip kCoop)
 // d_scratch: n_cu * waves_per_simd * kShaWG words

@@ -83,6 +83,9 @@ struct mi_ctx {
     mi::DevBuf dd_tag;                                  // ... and of mi_dedup_mark_range
     mi::u64* h_word = nullptr;           // pinned: small read-backs on the ctx stream
     hipEvent_t ev[2];
+    hipEvent_t sha_done = nullptr;       // end of the last chunk pass submitted on this ctx, whatever the batch
+    bool sha_done_set = false;           // (the next one waits for it: mi_api.hip submit_pipeline)
+    bool serialize_sha = false;          // MI_SHA_SERIALIZE=0: let the chunk passes of two batches overlap
     mi::ShaTune sha;                     // per ctx (mi_config.sha_*), not per process
     bool verify_staging = false;         // MI_FLAG_VERIFY_STAGING
     // fault injection for the tests of that flag (MI_STAGE_FAULT=copy:N | final:N): the N-th span a

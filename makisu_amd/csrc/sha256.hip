@@ -18,6 +18,10 @@
 // for all lanes that finished in the same iteration).
 #include "mi_common.h"
 
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
 namespace mi {
 
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
@@ -113,6 +117,47 @@ __device__ __forceinline__ void mask_tail_block(u32 (&w)[16], u32 r) {
     }
 }
 
+
+// the 16 big-endian words of the block in nx* (lane-owned loads: the block starts at nx0.x)
+__device__ __forceinline__ void block_words_lane(u32 (&w)[16], const u32x4& nx0, const u32x4& nx1,
+                                                 const u32x4& nx2, const u32x4& nx3) {
+    w[0] = __builtin_bswap32(nx0.x); w[1] = __builtin_bswap32(nx0.y);
+    w[2] = __builtin_bswap32(nx0.z); w[3] = __builtin_bswap32(nx0.w);
+    w[4] = __builtin_bswap32(nx1.x); w[5] = __builtin_bswap32(nx1.y);
+    w[6] = __builtin_bswap32(nx1.z); w[7] = __builtin_bswap32(nx1.w);
+    w[8] = __builtin_bswap32(nx2.x); w[9] = __builtin_bswap32(nx2.y);
+    w[10] = __builtin_bswap32(nx2.z); w[11] = __builtin_bswap32(nx2.w);
+    w[12] = __builtin_bswap32(nx3.x); w[13] = __builtin_bswap32(nx3.y);
+    w[14] = __builtin_bswap32(nx3.z); w[15] = __builtin_bswap32(nx3.w);
+}
+// cooperative loads: the window is dword-aligned, `carry` is the dword in front of it and `sel` realigns
+__device__ __forceinline__ void block_words_coop(u32 (&w)[16], const u32x4& nx0, const u32x4& nx1,
+                                                 const u32x4& nx2, const u32x4& nx3, u32& carry, u32 sel) {
+    w[0] = be_word(nx0.x, carry, sel); w[1] = be_word(nx0.y, nx0.x, sel);
+    w[2] = be_word(nx0.z, nx0.y, sel); w[3] = be_word(nx0.w, nx0.z, sel);
+    w[4] = be_word(nx1.x, nx0.w, sel); w[5] = be_word(nx1.y, nx1.x, sel);
+    w[6] = be_word(nx1.z, nx1.y, sel); w[7] = be_word(nx1.w, nx1.z, sel);
+    w[8] = be_word(nx2.x, nx1.w, sel); w[9] = be_word(nx2.y, nx2.x, sel);
+    w[10] = be_word(nx2.z, nx2.y, sel); w[11] = be_word(nx2.w, nx2.z, sel);
+    w[12] = be_word(nx3.x, nx2.w, sel); w[13] = be_word(nx3.y, nx3.x, sel);
+    w[14] = be_word(nx3.z, nx3.y, sel); w[15] = be_word(nx3.w, nx3.z, sel);
+    carry = nx3.w;
+}
+// every quad fetches the next blocks of its owners that want one (kAll: all four do), owner m's 64
+// bytes with ONE instruction; piece `sub` of owner qbase + m lands in g_m
+template <bool kAll>
+__device__ __forceinline__ void coop_fetch(u32x4& g0, u32x4& g1, u32x4& g2, u32x4& g3, const u8* ptr, bool want, int sub) {
+    const u32 wf = want ? 1u : 0u;
+    const u32 plo = (u32)(size_t)ptr, phi = (u32)((size_t)ptr >> 32);
+    const u32 l0 = quad_bcast<0>(plo), l1 = quad_bcast<1>(plo), l2 = quad_bcast<2>(plo), l3 = quad_bcast<3>(plo);
+    const u32 h0 = quad_bcast<0>(phi), h1 = quad_bcast<1>(phi), h2 = quad_bcast<2>(phi), h3 = quad_bcast<3>(phi);
+    const u64 mine = 16u * (u32)sub;                 // my 16-byte piece of every owner's block
+    if (kAll || quad_bcast<0>(wf)) g0 = *(const u32x4_a4*)(size_t)((((u64)h0 << 32) | l0) + mine);
+    if (kAll || quad_bcast<1>(wf)) g1 = *(const u32x4_a4*)(size_t)((((u64)h1 << 32) | l1) + mine);
+    if (kAll || quad_bcast<2>(wf)) g2 = *(const u32x4_a4*)(size_t)((((u64)h2 << 32) | l2) + mine);
+    if (kAll || quad_bcast<3>(wf)) g3 = *(const u32x4_a4*)(size_t)((((u64)h3 << 32) | l3) + mine);
+}
+
 // Lane pipeline (one iteration = one 64-byte compression per lane):
 //   cur  : the string being hashed: ptr/rem/total/slot, state st[8], and nx* = its NEXT
 //          64 bytes, loaded one iteration ahead so HBM latency hides under 64 rounds;
@@ -128,16 +173,49 @@ __device__ __forceinline__ void mask_tail_block(u32 (&w)[16], u32 r) {
 constexpr u32 kLook = 5;
 
 // kPass only names the instantiation (chunk pass / root pass / ...) so profiles tell them apart.
-template <int kPass, bool kCoop>
+// kStats: the per-wave record of MI_SHA_WAVE_STATS (a second instantiation: its two counters cost two
+// instructions per iteration).
+template <int kPass, bool kCoop, bool kStats = false>
 __global__ __launch_bounds__(kShaWG)
 void sha256_items_kernel(const u8* __restrict__ base, const u64* __restrict__ off,
                          const u64* __restrict__ len, const u32* __restrict__ ids, u32 n_max,
                          const u64* __restrict__ n_ptr, u32* __restrict__ heads,
-                         u8* __restrict__ out) {
+                         u32* __restrict__ roles, u32 long_shift,
+                         u8* __restrict__ out, u32* __restrict__ wave_stats) {
     // the string count may only be known on the device (no host sync between pipeline stages)
     const u32 n = n_ptr ? (u32)*n_ptr : n_max;
+    // diagnostics (MI_SHA_WAVE_STATS, see the launcher): where this wave ran, when, and how much it hashed
+    const u64 ws_t0 = kStats ? wall_clock64() : 0;
+    u32 ws_iters = 0, ws_lane_blocks = 0, ws_full = 0;
     const int lane = threadIdx.x & 63;
     const int q0 = blockIdx.x % kShaQueues;
+    // ---- the wave's role on its SIMD ---------------------------------------------------------------
+    // Two (or three) waves of this grid share every SIMD, and one string is a serial chain: a 64 KiB chunk
+    // is 1025 compressions, 5.4 ms at the pace two equal waves leave each other but 3.6 ms for a wave that
+    // has issue priority over its neighbour -- and the whole launch has 4.2 ms.  So the strings are split
+    // at position L (the array is sorted longest-first): the FIRST wave to arrive on a SIMD takes the long
+    // ones [0, L) at priority 3, the others take [L, n) at priority 1 with what the first leaves them
+    // (~1/3 of its pace); whoever runs dry continues in the other range.  Roles come from an atomic per
+    // SIMD (key = XCC | SE SH CU | SIMD of HW_ID), not from the dequeue order: with priorities by dequeue
+    // rank two long-string waves could land on one SIMD, halve each other's pace and finish ~1 ms after
+    // everybody else (profiles/r03_sha_wave_stats.txt: the 5.2 ms launches).
+    u32 role = 0;
+    if (roles) {
+        const u32 hw = __builtin_amdgcn_s_getreg(4 | (31 << 11));        // HW_REG_HW_ID
+        const u32 xcc = __builtin_amdgcn_s_getreg(20 | (31 << 11)) & 7u; // HW_REG_XCC_ID
+        const u32 key = (xcc << 10) | (((hw >> 8) & 0xFFu) << 2) | ((hw >> 4) & 3u);
+        u32 r = 0;
+        if (lane == 0) r = atomicAdd(roles + key, 1u);
+        role = (u32)__builtin_amdgcn_readfirstlane((int)r);
+        // (the others at 1, not 0: with another batch in flight its Gear waves run at 0, and a hashing pass
+        // that shares its SIMDs with them evenly stretches from 4.8 to 8 ms -- same step, unreadable profile)
+        if (long_shift & 0x100u)  __builtin_amdgcn_s_setprio(0);
+        else if (role == 0)       __builtin_amdgcn_s_setprio(3);
+        else                      __builtin_amdgcn_s_setprio(1);
+    }
+    const u32 long_n = roles ? ((n >> (long_shift & 31u)) & ~(u32)(kShaQueues - 1)) : 0u;   // L, a multiple of the queue count
+    const int my_set = role == 0 ? 0 : 1;            // range A = [0, L) | range B = [L, n), kShaQueues queues each
+    const int qtry_end = (role == 0 || long_n) ? 2 * kShaQueues : kShaQueues;
     // current string
     const u8* ptr = nullptr;
     u64 rem = 0, total = 0;
@@ -156,13 +234,17 @@ void sha256_items_kernel(const u8* __restrict__ base, const u64* __restrict__ of
     // next string
     enum : u32 { kNone = 0, kReq = 1, kPos = 2, kDesc = 3, kReady = 4, kDry = 5 };
     u32 nstate = kNone, npos = 0, nslot = 0, areq = 0, req_rank = 0;
-    int req_q = 0, req_leader = 0;     // wave-uniform: the dequeue in flight
+    int req_q = 0, req_set = 0, req_leader = 0;     // wave-uniform: the dequeue in flight
     u64 noff = 0, nlen = 0;
     u32x4 f0, f1, f2, f3;
-    int qtry = 0;                // queues already found empty by this wave (uniform)
-    bool first_fill = true;
+    // queues already found empty by this wave (uniform): my range's first, then the other range's
+    int qtry = (role == 0 && long_n == 0) ? kShaQueues : 0;
 
     for (;;) {
+        // (A lean inner loop for iterations in which all 64 lanes are mid-string -- 89 % of them on C2 -- was
+        // tried in round 3: ~75 instructions fewer per iteration, 175 instead of 144 VGPRs, and the same
+        // 4.5 ms: the general iteration below already averages 1 460 VALU instructions per block against the
+        // compression's 1 399 + 16 byte swaps, profiles/r03_sq_counters.txt.)
         // Everything issued in the previous iteration (first-block loads, descriptors, the
         // dequeue atomic, the nx prefetch) has had a whole compression to land.  Consume it
         // all HERE, before this iteration issues anything new, so no wait below can stall on
@@ -193,20 +275,10 @@ void sha256_items_kernel(const u8* __restrict__ base, const u64* __restrict__ of
         // ---- stage 1b: resolve last iteration's dequeue --------------------------------
         if (__ballot(nstate == kReq)) {
             const u32 first = __shfl(areq, req_leader);
-            if (first_fill) {
-                // LPT order: the earliest positions hold the longest strings; one string is a
-                // serial chain, so the waves that own them get issue priority over the waves
-                // that fill in short ones.
-                const u64 rank = (u64)first * kShaQueues;
-                if (rank < (u64)n / 32)     __builtin_amdgcn_s_setprio(3);
-                else if (rank < (u64)n / 8) __builtin_amdgcn_s_setprio(2);
-                else if (rank < (u64)n / 2) __builtin_amdgcn_s_setprio(1);
-                first_fill = false;
-            }
             bool missed = false;
             if (nstate == kReq) {
-                const u64 pos = (u64)(first + req_rank) * kShaQueues + (u32)req_q;
-                if (pos < n) { npos = (u32)pos; nstate = kPos; }
+                const u64 pos = (u64)(first + req_rank) * kShaQueues + (u32)req_q + (req_set ? long_n : 0u);
+                if (pos < (req_set ? n : long_n)) { npos = (u32)pos; nstate = kPos; }
                 else { nstate = kNone; missed = true; }
             }
             if (__ballot(missed)) ++qtry;              // a position past the end: that queue is dry
@@ -272,10 +344,11 @@ void sha256_items_kernel(const u8* __restrict__ base, const u64* __restrict__ of
             const u64 m = __ballot(want);
             u64 leader_mask = 0;                           // wave-uniform: the lane that performs the atomic
             if (m) {
-                if (qtry >= kShaQueues) {
+                if (qtry >= qtry_end) {
                     if (want) nstate = kDry;
                 } else {
                     req_q = (q0 + qtry) % kShaQueues;
+                    req_set = qtry < kShaQueues ? my_set : 1 - my_set;
                     req_leader = __ffsll((unsigned long long)m) - 1;
                     leader_mask = 1ull << req_leader;
                     if (want) {
@@ -293,7 +366,7 @@ void sha256_items_kernel(const u8* __restrict__ base, const u64* __restrict__ of
             {
                 u64 saved;
                 const u32 cnt = (u32)__popcll(m);
-                const u32* head = heads + req_q;
+                const u32* head = heads + req_set * kShaQueues + req_q;
                 asm volatile("s_mov_b64 %[sv], exec\n\t"
                              "s_mov_b64 exec, %[mk]\n\t"
                              "global_atomic_add %[ret], %[hd], %[val], off sc0\n\t"
@@ -304,32 +377,20 @@ void sha256_items_kernel(const u8* __restrict__ base, const u64* __restrict__ of
             }
         }
         if (!__ballot(active || nstate != kDry)) break;
+        if constexpr (kStats) {
+            ++ws_iters;
+            ws_lane_blocks += (u32)__popcll(__ballot(active));
+            // iterations in which every lane is mid-string: nothing pending, no request due
+            if (!__ballot(!(active && nstate == kNone && rem >= 64ull * kLook))) ++ws_full;
+        }
 
         u32 w[16];
         bool last = false;
         bool want = false;                                 // kCoop: my string has another block to fetch
         if (active) {
             if (!pad_block) {
-              if constexpr (kCoop) {
-                w[0] = be_word(nx0.x, carry, sel); w[1] = be_word(nx0.y, nx0.x, sel);
-                w[2] = be_word(nx0.z, nx0.y, sel); w[3] = be_word(nx0.w, nx0.z, sel);
-                w[4] = be_word(nx1.x, nx0.w, sel); w[5] = be_word(nx1.y, nx1.x, sel);
-                w[6] = be_word(nx1.z, nx1.y, sel); w[7] = be_word(nx1.w, nx1.z, sel);
-                w[8] = be_word(nx2.x, nx1.w, sel); w[9] = be_word(nx2.y, nx2.x, sel);
-                w[10] = be_word(nx2.z, nx2.y, sel); w[11] = be_word(nx2.w, nx2.z, sel);
-                w[12] = be_word(nx3.x, nx2.w, sel); w[13] = be_word(nx3.y, nx3.x, sel);
-                w[14] = be_word(nx3.z, nx3.y, sel); w[15] = be_word(nx3.w, nx3.z, sel);
-                carry = nx3.w;
-              } else {
-                w[0] = __builtin_bswap32(nx0.x); w[1] = __builtin_bswap32(nx0.y);
-                w[2] = __builtin_bswap32(nx0.z); w[3] = __builtin_bswap32(nx0.w);
-                w[4] = __builtin_bswap32(nx1.x); w[5] = __builtin_bswap32(nx1.y);
-                w[6] = __builtin_bswap32(nx1.z); w[7] = __builtin_bswap32(nx1.w);
-                w[8] = __builtin_bswap32(nx2.x); w[9] = __builtin_bswap32(nx2.y);
-                w[10] = __builtin_bswap32(nx2.z); w[11] = __builtin_bswap32(nx2.w);
-                w[12] = __builtin_bswap32(nx3.x); w[13] = __builtin_bswap32(nx3.y);
-                w[14] = __builtin_bswap32(nx3.z); w[15] = __builtin_bswap32(nx3.w);
-              }
+              if constexpr (kCoop) block_words_coop(w, nx0, nx1, nx2, nx3, carry, sel);
+              else                 block_words_lane(w, nx0, nx1, nx2, nx3);
                 if (rem >= 64) {
                     ptr += 64;
                     rem -= 64;
@@ -365,16 +426,7 @@ void sha256_items_kernel(const u8* __restrict__ base, const u64* __restrict__ of
         // kCoop.  The whole wave is here (no lane leaves the loop alone): every quad fetches the next blocks
         // of its owners that want one, owner m's 64 bytes with ONE instruction.
         if (kCoop && __ballot(want)) {
-            const u32 wf = want ? 1u : 0u;
-            const u32 plo = (u32)(size_t)ptr, phi = (u32)((size_t)ptr >> 32);
-            const u32 w0 = quad_bcast<0>(wf), w1 = quad_bcast<1>(wf), w2 = quad_bcast<2>(wf), w3 = quad_bcast<3>(wf);
-            const u32 l0 = quad_bcast<0>(plo), l1 = quad_bcast<1>(plo), l2 = quad_bcast<2>(plo), l3 = quad_bcast<3>(plo);
-            const u32 h0 = quad_bcast<0>(phi), h1 = quad_bcast<1>(phi), h2 = quad_bcast<2>(phi), h3 = quad_bcast<3>(phi);
-            const u64 mine = 16u * (u32)sub;                 // my 16-byte piece of every owner's block
-            if (w0) g0 = *(const u32x4_a4*)(size_t)((((u64)h0 << 32) | l0) + mine);
-            if (w1) g1 = *(const u32x4_a4*)(size_t)((((u64)h1 << 32) | l1) + mine);
-            if (w2) g2 = *(const u32x4_a4*)(size_t)((((u64)h2 << 32) | l2) + mine);
-            if (w3) g3 = *(const u32x4_a4*)(size_t)((((u64)h3 << 32) | l3) + mine);
+            coop_fetch<false>(g0, g1, g2, g3, ptr, want, sub);
             loaded = want;
         }
         if (active) {
@@ -391,16 +443,31 @@ void sha256_items_kernel(const u8* __restrict__ base, const u64* __restrict__ of
             }
         }
     }
+    if (kStats && wave_stats && lane == 0) {
+        u32* d = wave_stats + 8u * (blockIdx.x * (kShaWG / 64) + (threadIdx.x >> 6));
+        const u64 t1 = wall_clock64();
+        d[0] = __builtin_amdgcn_s_getreg(4 | (31 << 11));        // HW_REG_HW_ID: wave 3:0, SIMD 5:4, CU 11:8, SH 12, SE 15:13
+        d[1] = (__builtin_amdgcn_s_getreg(20 | (31 << 11)) & 0xFu) | (role << 8);   // HW_REG_XCC_ID | role on the SIMD
+        d[2] = (u32)ws_t0; d[3] = (u32)(ws_t0 >> 32);
+        d[4] = (u32)(t1 - ws_t0);                                 // 100 MHz ticks
+        d[5] = ws_iters;
+        d[6] = ws_lane_blocks;
+        d[7] = ws_full;
+    }
 }
 
 // With the TLB out of the way (cooperative loads) a third workgroup per CU pays (161 VGPRs: three
 // waves per SIMD fit): 26 GB arena 1.43 (byte loads, 2/CU) -> 1.57 (cooperative, 2/CU) -> 1.63 TB/s
 // (cooperative, 3/CU); on 6.5 GB three are slower with either scheme (coarser tail).
 void launch_sha256_items(ShaPass pass, const u8* d_base, const u64* d_off, const u64* d_len,
-                         const u32* d_order, u32 n, const u64* d_n, u32* d_heads, bool zero_heads,
+                         const u32* d_order, u32 n, const u64* d_n, u32* d_heads, u32* d_roles, bool zero_heads,
                          u8* d_out, const ShaTune& tune, int n_cu, u64 footprint_bytes, hipStream_t s) {
     if (n == 0) return;
-    if (zero_heads) (void)hipMemsetAsync(d_heads, 0, sizeof(u32) * kShaQueues, s);
+    if (!tune.roles) d_roles = nullptr;
+    if (zero_heads) {
+        (void)hipMemsetAsync(d_heads, 0, sizeof(u32) * kShaHeadWords, s);
+        if (d_roles) (void)hipMemsetAsync(d_roles, 0, sizeof(u32) * kShaRoleWords, s);
+    }
     const bool coop = pass != kShaRoots && footprint_bytes >= tune.coop_min_bytes;
     int blocks_per_cu = tune.blocks_per_cu;
     if (coop) blocks_per_cu = tune.coop_blocks_per_cu ? tune.coop_blocks_per_cu
@@ -422,6 +489,7 @@ void launch_sha256_items(ShaPass pass, const u8* d_base, const u64* d_off, const
         if (attr_dev != dev) {
 #define MI_SHA_ATTR(P, C) (void)hipFuncSetAttribute((const void*)sha256_items_kernel<P, C>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)
             MI_SHA_ATTR(kShaChunks, false); MI_SHA_ATTR(kShaChunks, true); MI_SHA_ATTR(kShaRoots, false);
+            (void)hipFuncSetAttribute((const void*)sha256_items_kernel<kShaChunks, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
             MI_SHA_ATTR(kShaFiles, false); MI_SHA_ATTR(kShaFiles, true); MI_SHA_ATTR(kShaBlobs, false); MI_SHA_ATTR(kShaBlobs, true);
 #undef MI_SHA_ATTR
             attr_dev = dev;
@@ -436,16 +504,47 @@ void launch_sha256_items(ShaPass pass, const u8* d_base, const u64* d_off, const
     // keep the grid a multiple of the queue count so every queue has the same number of pullers
     if (grid >= (u32)kShaQueues) grid -= grid % kShaQueues;
     if (grid == 0) grid = 1;
+    // Diagnostics: MI_SHA_WAVE_STATS=<file> appends, for every chunk-pass launch, one record per wave
+    // ({grid, waves per workgroup, coop, n} header, then 8 words per wave: HW_ID, XCC_ID | role << 8, start on the
+    // 100 MHz wall clock (2 words), duration, loop iterations, lane-blocks hashed, iterations with all 64 lanes mid-string) -- tools/sha_wave_stats.py reads it.  The launch
+    // is followed by a stream synchronize then: never set it for a measurement of anything else.
+    static const char* const stats_path = getenv("MI_SHA_WAVE_STATS");
+    u32* d_stats = nullptr;
+    const size_t stats_words = (size_t)grid * (kShaWG / 64) * 8;
+    if (stats_path && *stats_path && pass == kShaChunks) {
+        if (hipMalloc((void**)&d_stats, stats_words * sizeof(u32)) != hipSuccess) d_stats = nullptr;
+        else (void)hipMemsetAsync(d_stats, 0, stats_words * sizeof(u32), s);
+    }
 #define MI_SHA_LAUNCH(P, C)                                                                   \
     hipLaunchKernelGGL((sha256_items_kernel<P, C>), dim3(grid), dim3(kShaWG), lds_pad, s, d_base, d_off, \
-                       d_len, d_order, n, d_n, d_heads, d_out)
+                       d_len, d_order, n, d_n, d_heads, d_roles, (u32)tune.long_shift | (tune.prio ? 0u : 0x100u), d_out, nullptr)
+#define MI_SHA_LAUNCH_STATS(C)                                                                \
+    hipLaunchKernelGGL((sha256_items_kernel<kShaChunks, C, true>), dim3(grid), dim3(kShaWG), lds_pad, s, d_base, d_off, \
+                       d_len, d_order, n, d_n, d_heads, d_roles, (u32)tune.long_shift | (tune.prio ? 0u : 0x100u), d_out, d_stats)
     switch (pass) {
-        case kShaChunks: if (coop) MI_SHA_LAUNCH(kShaChunks, true); else MI_SHA_LAUNCH(kShaChunks, false); break;
+        case kShaChunks:
+            if (d_stats) { if (coop) MI_SHA_LAUNCH_STATS(true); else MI_SHA_LAUNCH_STATS(false); }
+            else if (coop) MI_SHA_LAUNCH(kShaChunks, true); else MI_SHA_LAUNCH(kShaChunks, false);
+            break;
         case kShaRoots:  MI_SHA_LAUNCH(kShaRoots, false); break;
         case kShaFiles:  if (coop) MI_SHA_LAUNCH(kShaFiles, true); else MI_SHA_LAUNCH(kShaFiles, false); break;
         default:         if (coop) MI_SHA_LAUNCH(kShaBlobs, true); else MI_SHA_LAUNCH(kShaBlobs, false); break;
     }
 #undef MI_SHA_LAUNCH
+#undef MI_SHA_LAUNCH_STATS
+    if (d_stats) {
+        std::vector<u32> h(stats_words);
+        if (hipStreamSynchronize(s) == hipSuccess &&
+            hipMemcpy(h.data(), d_stats, stats_words * sizeof(u32), hipMemcpyDeviceToHost) == hipSuccess) {
+            if (FILE* f = fopen(stats_path, "ab")) {
+                const u32 hdr[4] = {grid, (u32)(kShaWG / 64), coop ? 1u : 0u, n};
+                fwrite(hdr, sizeof(u32), 4, f);
+                fwrite(h.data(), sizeof(u32), stats_words, f);
+                fclose(f);
+            }
+        }
+        (void)hipFree(d_stats);
+    }
 }
 
 // ---- the VALU roof of this file's compression, measured on the device it runs on ------------------
