@@ -96,8 +96,16 @@ typedef struct {
                                         quad-cooperative loads are used (default 9)            */
     uint32_t sha_coop_blocks_per_cu; /* workgroups per CU with cooperative loads (default: 3 from
                                         24 GiB up, else sha_blocks_per_cu; 1..3)               */
-    uint32_t reserved;
+    uint32_t sha_sched;              /* MI_SHA_SCHED_*: how the strings of a hashing launch are shared
+                                        out among the waves of a SIMD (0 = default; this field was
+                                        `reserved`, always 0, before ABI 3's round-3 library)     */
 } mi_config;
+/* sha_sched.  Default: the wave that arrives FIRST on a SIMD takes the longest quarter of the launch's
+ * strings at issue priority, the other wave(s) the rest; whoever runs dry continues in the other range
+ * (one string is a serial chain, and the older wave of a SIMD runs three times as fast).   */
+#define MI_SHA_SCHED_FLAT      1u            /* one range, every wave equal (the scheme of rounds 1-2)      */
+#define MI_SHA_SCHED_LONG_SHIFT(k) ((((k) & 15u) + 1u) << 8)   /* the long range = the first n >> k strings
+                                                (k = 0..15; default 2)                                       */
 #define MI_SHA_LOADS_AUTO 0u   /* by footprint (sha_coop_min_gib)                            */
 #define MI_SHA_LOADS_LANE 1u   /* every lane loads its own block, byte-aligned               */
 #define MI_SHA_LOADS_COOP 2u   /* the four lanes of a quad fetch one owner's block together  */

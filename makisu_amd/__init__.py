@@ -24,6 +24,12 @@ FLAG_NO_DEDUP = 0x4
 FLAG_PREFETCH_ROWS = 0x8
 FLAG_VERIFY_STAGING = 0x10
 SHA_LOADS_AUTO, SHA_LOADS_LANE, SHA_LOADS_COOP = 0, 1, 2
+SHA_SCHED_FLAT = 1                       # mi_config.sha_sched: one range, every wave equal
+
+
+def sha_sched_long_shift(k):
+    """MI_SHA_SCHED_LONG_SHIFT(k): the long range of a hashing launch = its first n >> k strings."""
+    return ((k & 15) + 1) << 8
 
 ERR_NAMES = {0: "MI_OK", -1: "MI_ERR_INVALID", -2: "MI_ERR_NO_DEVICE", -3: "MI_ERR_HIP",
              -4: "MI_ERR_NOMEM", -5: "MI_ERR_IO", -6: "MI_ERR_STATE", -7: "MI_ERR_CAPACITY"}
@@ -42,7 +48,7 @@ class Config(C.Structure):
                 ("flags", C.c_uint32), ("staging_bytes", C.c_uint64), ("n_streams", C.c_uint32),
                 ("sha_blocks_per_cu", C.c_uint32), ("sha_load_scheme", C.c_uint32),
                 ("sha_coop_min_gib", C.c_uint32), ("sha_coop_blocks_per_cu", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("sha_sched", C.c_uint32)]
 
 
 class _FileResult(C.Structure):

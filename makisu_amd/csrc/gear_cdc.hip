@@ -48,7 +48,20 @@ namespace mi {
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kCopies      = kGearTableCopies;          // Gear table replicas in LDS (kernels that keep bitmaps)
-constexpr int kFastCopies  = 16;                        // ... in the bitmap-free marking kernels (see below)
+#ifndef MI_GEAR_COAL_BYTES
+#define MI_GEAR_COAL_BYTES 0                            // bytes per lane and exchange of mark_tile_coal; 0 = lane-owned
+                                                        // loads, the default: same-box A/B in profiles/r03_gear_ab.txt
+#endif
+#ifndef MI_GEAR_FAST_COPIES                             // 32: 64 KiB table shared by a 512-thread workgroup, two per CU
+#define MI_GEAR_FAST_COPIES (MI_GEAR_COAL_BYTES ? 16 : 32)   // 16: 32 KiB table, 256-thread workgroups, four per CU
+#endif                                                  //     (kept for the coalesced variants, whose stages need the LDS)
+constexpr int kFastCopies  = MI_GEAR_FAST_COPIES;       // ... in the bitmap-free marking kernels (see below)
+#ifndef MI_GEAR_FAST_WG
+#define MI_GEAR_FAST_WG (MI_GEAR_FAST_COPIES == 32 ? 512 : 256)   // the same 16 waves per CU either way
+#endif
+constexpr int kFastWG      = MI_GEAR_FAST_WG;
+constexpr int kFastWaves   = kFastWG / 64;
+
 constexpr int kWavesPerWG  = kGearWG / 64;              // 4
 constexpr int kLaneRun     = kGearTile / 64;            // 1 KiB per lane
 constexpr int kPiece       = 128;                       // bytes per load group (one cache line)
@@ -62,16 +75,17 @@ constexpr int kTableBytes  = 256 * 8 * kCopies;
 // (bank = dword address mod 64): with 8 copies four lanes of a group share a copy and collide whenever
 // their bytes agree mod 4 positions of the row; with 16 copies two lanes share one and collide when
 // their bytes have equal parity -- SQ_LDS_BANK_CONFLICT falls from 62 % to 49 % of the LDS-array cycles
-// and those cycles by a third (profiles/r03_sq_counters.txt); conflict-free would take 32 copies =
-// 64 KiB, two workgroups per CU instead of four.
-constexpr int kFastTableBytes = 256 * 8 * kFastCopies;  // 32 KiB
-#ifndef MI_GEAR_COAL_BYTES
-#define MI_GEAR_COAL_BYTES 0                            // bytes per lane and exchange of mark_tile_coal; 0 = lane-owned
-                                                        // loads, the default: same-box A/B in profiles/r03_gear_ab.txt
-#endif
+// and those cycles by a third (profiles/r03_sq_counters.txt).  THIRTY-TWO copies (entry stride 256 B, 64 KiB) are
+// conflict-free -- and the data byte then IS byte 1 of the lookup address, so the address is ONE v_perm_b32
+// instead of a shift and a v_bitop3_b32 (3.7 instead of 4.7 VALU/LDS instructions per byte).  Four 256-thread
+// workgroups per CU cannot hold 64 KiB each; two 512-thread workgroups can, with the same 16 waves per CU (the
+// marking kernels have no barrier behind the table load, a wave is on its own): C2 marking 1.38-1.42 -> 1.33-1.34 ms,
+// step 5.97-6.00 -> 5.80-5.85 ms on one box (profiles/r03_gear_ab.txt).
+constexpr int kFastTableBytes = 256 * 8 * kFastCopies;  // 64 KiB (32 KiB with 16 copies)
 constexpr int kCoalBytes = MI_GEAR_COAL_BYTES;
-constexpr int kFastListOff = kFastTableBytes + kWavesPerWG * 64 * kCoalBytes;     // table | stages | lists
-constexpr int kFastLdsBytes = kFastListOff + kWavesPerWG * 64 * 4;
+
+constexpr int kFastListOff = kFastTableBytes + kFastWaves * 64 * kCoalBytes;      // table | stages | lists
+constexpr int kFastLdsBytes = kFastListOff + kFastWaves * 64 * 4;
 // LDS: table | one bitmap per wave | one 64-entry candidate list per wave | fast flags
 constexpr int kLdsListOff  = kTableBytes + kWavesPerWG * kBitmapWords * 4;
 constexpr int kLdsFastOff  = kLdsListOff + kWavesPerWG * 64 * 4;
@@ -149,16 +163,23 @@ typedef __attribute__((address_space(3))) const u64 lds_cu64;
 // kC copies: entry b of copy c at byte b * (8 kC) + c * 8 -- a 64-byte stride for 8 copies, 128 for 16
 template <int kC>
 __device__ __forceinline__ void roll16(u64& h, const u32x4 v, u32 lane_tab, u32 (&hh)[16]) {
-    static_assert(kC == 8 || kC == 16, "lookup address arithmetic: 64- or 128-byte entry stride");
+    static_assert(kC == 8 || kC == 16 || kC == 32, "lookup address arithmetic: 64-, 128- or 256-byte entry stride");
     constexpr int kShift = kC == 8 ? 6 : 7;
     constexpr u32 kMask = 0xFFu << kShift;
     const u32 wv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const u32 w = wv[k >> 2];
-        const int sh = 8 * (k & 3) - kShift;
-        const u32 t = sh < 0 ? w << -sh : w >> sh;
-        const u32 addr = __builtin_amdgcn_bitop3_b32(t, kMask, lane_tab, 0xEA);   // (t & mask) | lane_tab
+        u32 addr;
+        if constexpr (kC == 32) {
+            // entry stride 256 B: the data byte IS byte 1 of the address -- ONE v_perm_b32
+            // {0, lane_tab.byte2 (table base / 64 KiB), w.byte k, lane_tab.byte0 (copy * 8)}
+            addr = __builtin_amdgcn_perm(w, lane_tab, 0x0C020000u | ((4u + (u32)(k & 3)) << 8));
+        } else {
+            const int sh = 8 * (k & 3) - kShift;
+            const u32 t = sh < 0 ? w << -sh : w >> sh;
+            addr = __builtin_amdgcn_bitop3_b32(t, kMask, lane_tab, 0xEA);   // (t & mask) | lane_tab
+        }
         h = (h << 1) + *(lds_cu64*)(size_t)addr;
         hh[k] = (u32)(h >> 32);
     }
@@ -224,7 +245,7 @@ __device__ __forceinline__ void mark_tile(const u8* __restrict__ fptr, u64 ts, u
     const u8* p = fptr + ts + run0;
     const u32 run_len = tlen - run0 < (u32)kLaneRun ? tlen - run0 : (u32)kLaneRun;
     const int n_pieces = (int)((run_len + kPiece - 1) / kPiece);
-    u32x4 cur[8], nxt[8];
+    u32x4 cur[8];
     load_piece(p, cur);
     u64 h = 0;
     u32 hh[16];
@@ -235,6 +256,7 @@ __device__ __forceinline__ void mark_tile(const u8* __restrict__ fptr, u64 ts, u
 #pragma unroll
         for (int i = 0; i < 4; ++i) roll16<kC>(h, wq[i], tab, hh);
     }
+    u32x4 nxt[8];
     for (int pc = 0; pc < n_pieces; ++pc) {
         if (pc + 1 < n_pieces) load_piece(p + (pc + 1) * kPiece, nxt);   // in flight while hashing
 #pragma unroll
@@ -243,6 +265,9 @@ __device__ __forceinline__ void mark_tile(const u8* __restrict__ fptr, u64 ts, u
 #pragma unroll
         for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
     }
+    // (Round 3 tried one piece of registers instead of two -- each 16-byte unit of the next piece requested
+    // into the registers of the unit just hashed, 84 VGPRs, five or six waves per SIMD: 2.15-2.28 ms instead
+    // of 1.34, profiles/r03_gear_ab.txt; a load per unit means a wait per unit.)
 }
 
 // ---- coalesced form of the marking (round 3) ------------------------------------------------------
@@ -410,10 +435,10 @@ __device__ __forceinline__ bool list_from_bitmap(const u32* bitmap, int lane, u3
     return true;
 }
 
-template <int kC>
+template <int kC, int kWG = kGearWG>
 __device__ __forceinline__ void load_table(u64* table, const u64* __restrict__ gear_table, int tid) {
     // table[b * kC + c] = G[b] for every copy c
-    for (int i = tid; i < 256 * kC; i += kGearWG) table[i] = gear_table[i / kC];
+    for (int i = tid; i < 256 * kC; i += kWG) table[i] = gear_table[i / kC];
 }
 
 // ---- small files: one wave per file (size <= kGearTile) ----------------------------------
@@ -423,7 +448,7 @@ __device__ __forceinline__ void load_table(u64* table, const u64* __restrict__ g
 // 64-entry list).  A file with more than 64 candidates (or a lane with more than six) is appended to
 // dense_list and left to gear_cdc_small_kernel, the round-1/2 form with its exact per-wave bitmap,
 // which runs over that list afterwards (n_list_dev: the list's length, known on the device only).
-__global__ __launch_bounds__(kGearWG)
+__global__ __launch_bounds__(kFastWG)
 void gear_cdc_small_fast_kernel(const u8* __restrict__ data, const u64* __restrict__ file_off,
                                 const u64* __restrict__ file_size, const u32* __restrict__ seg_file,
                                 const u64* __restrict__ seg_slot, u32* __restrict__ ends32,
@@ -434,10 +459,10 @@ void gear_cdc_small_fast_kernel(const u8* __restrict__ data, const u64* __restri
     u64* table = (u64*)smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     u32* cand_list = (u32*)(smem + kFastListOff) + wave * 64;
-    load_table<kFastCopies>(table, gear_table, tid);
+    load_table<kFastCopies, kFastWG>(table, gear_table, tid);
     __syncthreads();
     const u32 lane_tab = lds_lane_table<kFastCopies>(table, lane);
-    const u32 li = blockIdx.x * kWavesPerWG + wave;
+    const u32 li = blockIdx.x * kFastWaves + wave;
     if (li >= n_list) return;
     const u32 s = list[li];
     const u32 f = seg_file[s];
@@ -599,7 +624,7 @@ __device__ __forceinline__ u64 reselect_group(const u32* lists, const u32* bitma
 // workgroup per group (four tiles), no workgroup barrier behind the table load, no loop (a persistent
 // form needs 168+ VGPRs where this one, like the small-file kernel, takes 146: three workgroups per CU).  Per tile: the sorted candidate list (64 x u32, HBM) and
 // tile_fast = 1, or tile_fast = 0 for a DENSE tile (more than 64 candidates: no list).
-__global__ __launch_bounds__(kGearWG)
+__global__ __launch_bounds__(kFastWG)
 void gear_tile_mark_kernel(const u8* __restrict__ data, const u64* __restrict__ file_off,
                            const u64* __restrict__ file_size, const u32* __restrict__ group_file,
                            const u32* __restrict__ group_index, u32 n_groups,
@@ -611,14 +636,18 @@ void gear_tile_mark_kernel(const u8* __restrict__ data, const u64* __restrict__ 
     u64* table = (u64*)smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     u32* cl = (u32*)(smem + kFastListOff) + wave * 64;
-    load_table<kFastCopies>(table, gear_table, tid);
+    load_table<kFastCopies, kFastWG>(table, gear_table, tid);
     __syncthreads();
     const u32 lane_tab = lds_lane_table<kFastCopies>(table, lane);
-    const u32 g = blockIdx.x;                                 // workgroup = the four tiles of one group
-    const u64 t = (u64)g * kWavesPerWG + wave;
+    // one wave per tile, four tiles per group, whatever the workgroup's size
+    const u64 gw = (u64)blockIdx.x * kFastWaves + (u64)wave;
+    const u32 g = (u32)(gw / kWavesPerWG);
+    if (g >= n_groups) return;
+    const int tw = (int)(gw % kWavesPerWG);
+    const u64 t = (u64)g * kWavesPerWG + tw;
     const u32 f = group_file[g];
     const u64 size = file_size[f];
-    const u64 ts = (u64)group_index[g] * kGroupBytes + (u64)wave * kGearTile;
+    const u64 ts = (u64)group_index[g] * kGroupBytes + (u64)tw * kGearTile;
     bool fast = true;                                         // tiles past the end count as listed
     if (ts < size) {
         const u32 tlen = (u32)((size - ts < (u64)kGearTile) ? (size - ts) : (u64)kGearTile);
@@ -873,12 +902,13 @@ void launch_gear_cdc(const GearLaunch& a, CdcParams p, int n_cu, hipStream_t s) 
     gear_lds_attributes();
     if (a.n_small) {
         const dim3 grid((a.n_small + kWavesPerWG - 1) / kWavesPerWG);
+        const dim3 fast_grid((a.n_small + kFastWaves - 1) / kFastWaves);
         // expected candidates per 64 KiB tile from the mask alone: with a dozen or more the 64-entry list
         // overflows too often for the bitmap-free kernel to be worth its pass
         const bool try_fast = a.dense_list && p.thresh_m1 <= 0x003FFFFFu;         // mask_bits >= 10
         if (try_fast) {
             (void)hipMemsetAsync(a.dense_count, 0, 4, s);
-            hipLaunchKernelGGL(gear_cdc_small_fast_kernel, grid, dim3(kGearWG), kFastLdsBytes, s, a.data,
+            hipLaunchKernelGGL(gear_cdc_small_fast_kernel, fast_grid, dim3(kFastWG), kFastLdsBytes, s, a.data,
                                a.file_off, a.file_size, a.seg_file, a.seg_slot, a.ends32, a.seg_n, a.small_list,
                                a.n_small, a.gear_table, p, a.dense_list, a.dense_count);
             hipLaunchKernelGGL(gear_cdc_small_kernel, grid, dim3(kGearWG), kGearLdsBytes, s, a.data, a.file_off,
@@ -893,7 +923,8 @@ void launch_gear_cdc(const GearLaunch& a, CdcParams p, int n_cu, hipStream_t s) 
     if (a.n_groups) {
         const u32 region = (u32)gear_group_region(p.min_size);
         GroupRec* recs = (GroupRec*)a.group_recs;
-        hipLaunchKernelGGL(gear_tile_mark_kernel, dim3(a.n_groups), dim3(kGearWG), kFastLdsBytes, s, a.data,
+        const u64 n_tiles = (u64)a.n_groups * kWavesPerWG;
+        hipLaunchKernelGGL(gear_tile_mark_kernel, dim3((u32)((n_tiles + kFastWaves - 1) / kFastWaves)), dim3(kFastWG), kFastLdsBytes, s, a.data,
                            a.file_off, a.file_size, a.group_file, a.group_index, a.n_groups, a.tile_lists,
                            a.tile_fast, a.gear_table, p);
         const dim3 per_group((a.n_groups + kWavesPerWG - 1) / kWavesPerWG);

@@ -638,6 +638,9 @@ int mi_ctx_create(const mi_config* cfg, mi_ctx** out) {
     if (cfg->sha_load_scheme > MI_SHA_LOADS_COOP)
         return fail(nullptr, MI_ERR_INVALID, "mi_ctx_create: sha_load_scheme %u is not an MI_SHA_LOADS_* value",
                     cfg->sha_load_scheme);
+    if ((cfg->sha_sched & ~(MI_SHA_SCHED_FLAT | 0x1F00u)) || ((cfg->sha_sched >> 8) & 0x1Fu) > 16)
+        return fail(nullptr, MI_ERR_INVALID, "mi_ctx_create: sha_sched 0x%x is not a combination of MI_SHA_SCHED_* values",
+                    cfg->sha_sched);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(nullptr, MI_ERR_NO_DEVICE,
@@ -728,6 +731,8 @@ int mi_ctx_create(const mi_config* cfg, mi_ctx** out) {
         const int v = atoi(e);
         if (v >= 0 && v <= 16) c->sha.long_shift = v;
     }
+    if (cfg->sha_sched & MI_SHA_SCHED_FLAT) c->sha.roles = false;
+    if ((cfg->sha_sched >> 8) & 0x1Fu) c->sha.long_shift = (int)((cfg->sha_sched >> 8) & 0x1Fu) - 1;
     if (cfg->sha_blocks_per_cu >= 1 && cfg->sha_blocks_per_cu <= 8) c->sha.blocks_per_cu = (int)cfg->sha_blocks_per_cu;
     if (cfg->sha_coop_min_gib) c->sha.coop_min_bytes = (u64)cfg->sha_coop_min_gib << 30;
     if (cfg->sha_load_scheme == MI_SHA_LOADS_LANE) c->sha.coop_min_bytes = ~0ull;

@@ -186,7 +186,7 @@ void sha256_items_kernel(const u8* __restrict__ base, const u64* __restrict__ of
     const u32 n = n_ptr ? (u32)*n_ptr : n_max;
     // diagnostics (MI_SHA_WAVE_STATS, see the launcher): where this wave ran, when, and how much it hashed
     const u64 ws_t0 = kStats ? wall_clock64() : 0;
-    u32 ws_iters = 0, ws_lane_blocks = 0, ws_full = 0;
+    u32 ws_iters = 0, ws_lane_blocks = 0, ws_full = 0, ws_wait = 0;
     const int lane = threadIdx.x & 63;
     const int q0 = blockIdx.x % kShaQueues;
     // ---- the wave's role on its SIMD ---------------------------------------------------------------
@@ -249,7 +249,10 @@ void sha256_items_kernel(const u8* __restrict__ base, const u64* __restrict__ of
         // dequeue atomic, the nx prefetch) has had a whole compression to land.  Consume it
         // all HERE, before this iteration issues anything new, so no wait below can stall on
         // a freshly issued request (hipcc's s_waitcnt for a divergent region is vmcnt(0)).
+        u64 ws_w0 = 0;
+        if constexpr (kStats) ws_w0 = wall_clock64();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // incl. the hand-issued dequeue atomic
+        if constexpr (kStats) ws_wait += (u32)(wall_clock64() - ws_w0);
         asm volatile("" : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(nx0), "+v"(nx1),
                           "+v"(nx2), "+v"(nx3));
         asm volatile("" : "+v"(noff), "+v"(nlen), "+v"(nslot), "+v"(areq));
@@ -448,7 +451,7 @@ void sha256_items_kernel(const u8* __restrict__ base, const u64* __restrict__ of
         const u64 t1 = wall_clock64();
         d[0] = __builtin_amdgcn_s_getreg(4 | (31 << 11));        // HW_REG_HW_ID: wave 3:0, SIMD 5:4, CU 11:8, SH 12, SE 15:13
         d[1] = (__builtin_amdgcn_s_getreg(20 | (31 << 11)) & 0xFu) | (role << 8);   // HW_REG_XCC_ID | role on the SIMD
-        d[2] = (u32)ws_t0; d[3] = (u32)(ws_t0 >> 32);
+        d[2] = (u32)ws_t0; d[3] = ws_wait;                        // start (low word) | ticks spent in the loop-top s_waitcnt
         d[4] = (u32)(t1 - ws_t0);                                 // 100 MHz ticks
         d[5] = ws_iters;
         d[6] = ws_lane_blocks;
@@ -506,7 +509,7 @@ void launch_sha256_items(ShaPass pass, const u8* d_base, const u64* d_off, const
     if (grid == 0) grid = 1;
     // Diagnostics: MI_SHA_WAVE_STATS=<file> appends, for every chunk-pass launch, one record per wave
     // ({grid, waves per workgroup, coop, n} header, then 8 words per wave: HW_ID, XCC_ID | role << 8, start on the
-    // 100 MHz wall clock (2 words), duration, loop iterations, lane-blocks hashed, iterations with all 64 lanes mid-string) -- tools/sha_wave_stats.py reads it.  The launch
+    // 100 MHz wall clock (low word), ticks in the loop-top s_waitcnt, duration, loop iterations, lane-blocks hashed, iterations with all 64 lanes mid-string) -- tools/sha_wave_stats.py reads it.  The launch
     // is followed by a stream synchronize then: never set it for a measurement of anything else.
     static const char* const stats_path = getenv("MI_SHA_WAVE_STATS");
     u32* d_stats = nullptr;

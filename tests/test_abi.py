@@ -47,7 +47,7 @@ int main(void) {
   printf("%zu %zu %zu %zu\n", sizeof(mi_config), sizeof(mi_file_result), sizeof(mi_chunk_result), sizeof(mi_stats));
   printf("%zu %zu %zu %zu\n", offsetof(mi_file_result, chunk_root), offsetof(mi_file_result, file_sha256),
          offsetof(mi_chunk_result, dup_of), offsetof(mi_chunk_result, sha256));
-  printf("%zu %zu %zu\n", sizeof(mi_stage_stats), offsetof(mi_config, sha_blocks_per_cu), offsetof(mi_config, reserved));
+  printf("%zu %zu %zu\n", sizeof(mi_stage_stats), offsetof(mi_config, sha_blocks_per_cu), offsetof(mi_config, sha_sched));
   printf("%zu %zu %zu\n", sizeof(mi_tree_entry), sizeof(mi_ctx_entry), sizeof(mi_snapshot_side));
   printf("%zu %zu %zu %zu %zu %zu\n", offsetof(mi_tree_entry, file_index), offsetof(mi_tree_entry, mtime_sec),
          offsetof(mi_tree_entry, mode), offsetof(mi_tree_entry, kind), offsetof(mi_tree_entry, uid),
@@ -64,7 +64,7 @@ int main(void) {
             makisu_amd.FILE_DTYPE.fields["chunk_root"][1], makisu_amd.FILE_DTYPE.fields["file_sha256"][1],
             makisu_amd.CHUNK_DTYPE.fields["dup_of"][1], makisu_amd.CHUNK_DTYPE.fields["sha256"][1]]
     want += [C.sizeof(makisu_amd.StageStats), makisu_amd.Config.sha_blocks_per_cu.offset,
-             makisu_amd.Config.reserved.offset]
+             makisu_amd.Config.sha_sched.offset]
     T, X, S = makisu_amd.TreeEntry, makisu_amd.CtxEntry, makisu_amd.SnapshotSide
     want += [C.sizeof(T), C.sizeof(X), C.sizeof(S),
              T.file_index.offset, T.mtime_sec.offset, T.mode.offset, T.kind.offset, T.uid.offset, T.gid.offset,

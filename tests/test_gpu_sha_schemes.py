@@ -98,3 +98,88 @@ def test_batch_above_the_switch(oracle):
         blob = oracle.synth_fill(0x4D414B49, 50000 + int(r["file_index"]), 0, size)
         seg = blob[int(r["offset"]): int(r["offset"]) + int(r["length"])].tobytes()
         assert bytes(r["sha256"]).hex() == hashlib.sha256(seg).hexdigest()
+
+
+def test_string_sharing_schemes_agree(oracle):
+    """mi_config.sha_sched: the default (the first wave on a SIMD takes the longest quarter of the strings), every
+    long-range size from 'all of them' to 'none', and the flat scheme of rounds 1-2 -- on a shape whose string
+    lengths span three orders of magnitude, at 1, 2 and 3 workgroups per CU, with both load schemes: identical
+    chunk digests, roots and whole-file digests, equal to the oracle's."""
+    import numpy as np
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    import makisu_amd
+    rng = np.random.default_rng(11)
+    sizes = [int(x) for x in rng.integers(1, 5000, 3000)] + [1 << 20] * 6 + [40 << 20, 70001, 0, 64, 65]
+    cids = list(range(7000, 7000 + len(sizes)))
+    ref = None
+    variants = [{}, {"sha_sched": makisu_amd.SHA_SCHED_FLAT}]
+    variants += [{"sha_sched": makisu_amd.sha_sched_long_shift(k)} for k in (0, 1, 5, 15)]
+    variants += [{"sha_sched": makisu_amd.sha_sched_long_shift(3), "sha_blocks_per_cu": 1},
+                 {"sha_blocks_per_cu": 3, "sha_load_scheme": makisu_amd.SHA_LOADS_LANE},
+                 {"sha_load_scheme": makisu_amd.SHA_LOADS_COOP, "sha_coop_blocks_per_cu": 3},
+                 {"sha_load_scheme": makisu_amd.SHA_LOADS_COOP, "sha_sched": makisu_amd.SHA_SCHED_FLAT}]
+    for kw in variants:
+        with makisu_amd.Engine(flags=makisu_amd.FLAG_FILE_SHA256, mask_bits=8, min_size=64, max_size=1 << 16, **kw) as e:
+            with e.batch() as b:
+                b.add_synthetic(sizes, cids)
+                b.run()
+                got = (b.chunks()["sha256"].copy(), b.chunks()["length"].copy(), b.files()["chunk_root"].copy(),
+                       b.files()["file_sha256"].copy())
+        if ref is None:
+            ref = got
+            # the oracle on the same bytes
+            p = oracle.CdcParams(0x4D414B49, 8, 64, 1 << 16)
+            blobs = [oracle.synth_fill(0x4D414B49, c, 0, n) for c, n in zip(cids, sizes)]
+            data = np.concatenate(blobs) if blobs else np.zeros(0, np.uint8)
+            sz = np.array(sizes, dtype=np.uint64)
+            offs = np.concatenate([[0], np.cumsum(sz)[:-1]]).astype(np.uint64)
+            rf, rc = oracle.scan_batch(data, offs, sz, p, True, 8, 0)
+            assert np.array_equal(got[1], rc["length"]) and np.array_equal(got[0], rc["sha256"])
+            assert np.array_equal(got[2], rf["chunk_root"])
+        else:
+            for a, r in zip(got, ref):
+                assert np.array_equal(a, r), kw
+    with pytest.raises(makisu_amd.MiError):
+        makisu_amd.Engine(sha_sched=2)
+    with pytest.raises(makisu_amd.MiError):
+        makisu_amd.Engine(sha_sched=18 << 8)
+
+
+WAVES_CHILD = textwrap.dedent(r'''
+    import json, os, sys
+    import numpy as np
+    sys.path.insert(0, %(root)r)
+    sys.path.insert(0, os.path.join(%(root)r, "tools"))
+    import makisu_amd
+    import sha_wave_stats as WS
+    sizes = [65536] * 20000
+    with makisu_amd.Engine() as e, e.batch() as b:
+        b.add_synthetic(sizes, None)
+        b.run()
+        ch = b.chunks().copy()
+    recs = WS.read_records(os.environ["MI_SHA_WAVE_STATS"])
+    assert len(recs) == 1 and recs[0]["n"] >= len(ch)
+    a = WS.analyse(recs[0])
+    w = recs[0]["w"]
+    # every block of every chunk was hashed by exactly one lane: data blocks + the padding block(s)
+    blocks = int(((ch["length"].astype(np.int64) + 8) // 64 + 1).sum())
+    assert int(w[:, 6].astype(np.int64).sum()) == blocks, (int(w[:, 6].sum()), blocks)
+    assert a["waves"] == recs[0]["grid"] * 4 and set(a["waves_by_role"]) <= {0, 1, 2}
+    assert a["waves_by_role"][0] >= a["waves"] // 3          # at least one first-comer per occupied SIMD
+    assert 0.5 < a["lane_blocks_share_by_role"][0] <= 1.0    # ... and it does most of the work
+    print("OK", json.dumps(a))
+''')
+
+
+def test_wave_stats_record(tmp_path):
+    """MI_SHA_WAVE_STATS: one record per chunk-pass launch; the lane-blocks its waves report add up to the
+    blocks of the batch's chunks (64-byte blocks incl. padding), roles are 0..2 with the first-comers doing most
+    of the hashing."""
+    env = dict(os.environ, MI_SHA_WAVE_STATS=str(tmp_path / "waves.bin"))
+    r = subprocess.run([sys.executable, "-c", WAVES_CHILD % {"root": ROOT}], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "OK" in r.stdout

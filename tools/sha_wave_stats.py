@@ -33,7 +33,9 @@ def analyse(rec):
     w = rec["w"]
     hw, xcc, role = w[:, 0], w[:, 1] & 0xF, (w[:, 1] >> 8) & 0xFF
     simd, cu, sh, se = (hw >> 4) & 3, (hw >> 8) & 0xF, (hw >> 12) & 1, (hw >> 13) & 7
-    t0 = w[:, 2].astype(np.uint64) | (w[:, 3].astype(np.uint64) << np.uint64(32))
+    t0 = w[:, 2].astype(np.uint64)                     # low word of the 100 MHz clock: launches last milliseconds
+    t0 = t0 + np.where(t0 < t0.max() // 2 if t0.max() - t0.min() > (1 << 31) else False, np.uint64(1 << 32), np.uint64(0))
+    wait_ticks = w[:, 3].astype(np.float64)
     t1 = t0 + w[:, 4].astype(np.uint64)
     iters, lane_blocks, fast = w[:, 5].astype(np.float64), w[:, 6].astype(np.float64), w[:, 7].astype(np.float64)
     span_us = float(t1.max() - t0.min()) / 100.0
@@ -62,6 +64,8 @@ def analyse(rec):
                                              for k in np.unique(waves_on_my_cu)},
         "all_lanes_mid_string_iteration_share": round(float(fast.sum() / iters.sum()), 4),
         "all_lanes_mid_string_iteration_share_by_role": {int(k): round(float(fast[role == k].sum() / iters[role == k].sum()), 4) for k in np.unique(role)},
+        "loop_top_wait_share_of_wave_time_by_role": {int(k): round(float(wait_ticks[role == k].sum() / (dur_us[role == k].sum() * 100.0)), 4)
+                                                     for k in np.unique(role)},
         "waves_by_role": {int(k): int((role == k).sum()) for k in np.unique(role)},
         "us_per_iteration_by_role": {int(k): round(float(np.median(us_per_iter[role == k])), 3) for k in np.unique(role)},
         "lane_blocks_share_by_role": {int(k): round(float(lane_blocks[role == k].sum() / lane_blocks.sum()), 3) for k in np.unique(role)},
