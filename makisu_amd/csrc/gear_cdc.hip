@@ -61,10 +61,19 @@ constexpr int kFastCopies  = MI_GEAR_FAST_COPIES;       // ... in the bitmap-fre
 #endif
 constexpr int kFastWG      = MI_GEAR_FAST_WG;
 constexpr int kFastWaves   = kFastWG / 64;
+#ifdef MI_GEAR_FAST_WAVES_PER_SIMD                      // experiments: a VGPR budget for more waves per SIMD (with a
+#define MI_GEAR_FAST_ATTR __attribute__((amdgpu_waves_per_eu(MI_GEAR_FAST_WAVES_PER_SIMD, MI_GEAR_FAST_WAVES_PER_SIMD)))
+#else                                                   // smaller MI_GEAR_PIECE and a larger MI_GEAR_FAST_WG).  Measured: 64-byte
+#define MI_GEAR_FAST_ATTR                               // pieces 1.55 ms at 4 waves, 1.65 at 5, 1.71 at 6; 32-byte pieces 2.4 ms at 8
+#endif                                                  // (profiles/r03_gear_ab.txt) -- whole cache lines per lane matter, waves do not
 
 constexpr int kWavesPerWG  = kGearWG / 64;              // 4
 constexpr int kLaneRun     = kGearTile / 64;            // 1 KiB per lane
-constexpr int kPiece       = 128;                       // bytes per load group (one cache line)
+#ifndef MI_GEAR_PIECE
+#define MI_GEAR_PIECE 128
+#endif
+constexpr int kPiece       = MI_GEAR_PIECE;             // bytes per load group (128 = one cache line)
+constexpr int kPieceUnits  = kPiece / 16;
 constexpr int kBitmapWords = kGearTile / 32;            // u32 words per wave bitmap (8 KiB)
 constexpr int kTableBytes  = 256 * 8 * kCopies;
 // The bitmap-free kernels (round 3): a tile's candidates live ONLY in its lanes' packed registers (up to
@@ -194,9 +203,9 @@ __device__ __forceinline__ u32 lds_lane_table(const u64* table, int lane) {
     return base | ((u32)(lane % kC) * 8u);
 }
 
-__device__ __forceinline__ void load_piece(const u8* p, u32x4 (&d)[8]) {
+__device__ __forceinline__ void load_piece(const u8* p, u32x4 (&d)[kPieceUnits]) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) d[i] = *(const u32x4*)(p + 16 * i);
+    for (int i = 0; i < kPieceUnits; ++i) d[i] = *(const u32x4*)(p + 16 * i);
 }
 
 // 16 more bytes of a lane's run (run-relative offset `base`): roll, test, record the candidates.
@@ -245,7 +254,7 @@ __device__ __forceinline__ void mark_tile(const u8* __restrict__ fptr, u64 ts, u
     const u8* p = fptr + ts + run0;
     const u32 run_len = tlen - run0 < (u32)kLaneRun ? tlen - run0 : (u32)kLaneRun;
     const int n_pieces = (int)((run_len + kPiece - 1) / kPiece);
-    u32x4 cur[8];
+    u32x4 cur[kPieceUnits];
     load_piece(p, cur);
     u64 h = 0;
     u32 hh[16];
@@ -256,14 +265,14 @@ __device__ __forceinline__ void mark_tile(const u8* __restrict__ fptr, u64 ts, u
 #pragma unroll
         for (int i = 0; i < 4; ++i) roll16<kC>(h, wq[i], tab, hh);
     }
-    u32x4 nxt[8];
+    u32x4 nxt[kPieceUnits];
     for (int pc = 0; pc < n_pieces; ++pc) {
         if (pc + 1 < n_pieces) load_piece(p + (pc + 1) * kPiece, nxt);   // in flight while hashing
 #pragma unroll
-        for (int g = 0; g < 8; ++g)
+        for (int g = 0; g < kPieceUnits; ++g)
             hash16<kC, kBitmap>(h, cur[g], tab, thresh_m1, run0, (u32)(pc * kPiece + g * 16), bitmap, pk, ovf);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
+        for (int i = 0; i < kPieceUnits; ++i) cur[i] = nxt[i];
     }
     // (Round 3 tried one piece of registers instead of two -- each 16-byte unit of the next piece requested
     // into the registers of the unit just hashed, 84 VGPRs, five or six waves per SIMD: 2.15-2.28 ms instead
@@ -448,7 +457,7 @@ __device__ __forceinline__ void load_table(u64* table, const u64* __restrict__ g
 // 64-entry list).  A file with more than 64 candidates (or a lane with more than six) is appended to
 // dense_list and left to gear_cdc_small_kernel, the round-1/2 form with its exact per-wave bitmap,
 // which runs over that list afterwards (n_list_dev: the list's length, known on the device only).
-__global__ __launch_bounds__(kFastWG)
+__global__ __launch_bounds__(kFastWG) MI_GEAR_FAST_ATTR
 void gear_cdc_small_fast_kernel(const u8* __restrict__ data, const u64* __restrict__ file_off,
                                 const u64* __restrict__ file_size, const u32* __restrict__ seg_file,
                                 const u64* __restrict__ seg_slot, u32* __restrict__ ends32,
@@ -624,7 +633,7 @@ __device__ __forceinline__ u64 reselect_group(const u32* lists, const u32* bitma
 // workgroup per group (four tiles), no workgroup barrier behind the table load, no loop (a persistent
 // form needs 168+ VGPRs where this one, like the small-file kernel, takes 146: three workgroups per CU).  Per tile: the sorted candidate list (64 x u32, HBM) and
 // tile_fast = 1, or tile_fast = 0 for a DENSE tile (more than 64 candidates: no list).
-__global__ __launch_bounds__(kFastWG)
+__global__ __launch_bounds__(kFastWG) MI_GEAR_FAST_ATTR
 void gear_tile_mark_kernel(const u8* __restrict__ data, const u64* __restrict__ file_off,
                            const u64* __restrict__ file_size, const u32* __restrict__ group_file,
                            const u32* __restrict__ group_index, u32 n_groups,
