@@ -12,8 +12,8 @@
 // streaming pattern).  A lane runs slicing-by-4 (four 1 KiB tables in LDS) from state 0
 // over its run; the wave folds the 64 lane remainders with per-lane multiplications by
 // x^(8192*k) and one by x^(8*len_of_last_run) (tables of powers precomputed on the host),
-// then a second tiny kernel walks each file's tiles: s = s * x^(8*tile_len) ^ tile_raw
-// starting from 0xFFFFFFFF, crc = ~s.
+// then every tile's term of its file's CRC is folded in parallel (crc32_fold_kernel: one lane per
+// tile, x^(8 * distance) by square-and-multiply) and one lane per file finishes: crc = ~(acc ^ ~0 * x^(8 size)).
 // Bytes: 1 B read per file byte, 4 B written per tile.  This pass is optional
 // (MI_FLAG_FILE_CRC32) and not on the benchmarked path.
 #include "mi_common.h"
@@ -38,6 +38,7 @@ __host__ __device__ inline u32 crc_mulmod(u32 a, u32 b) {
 //   [0 .. 1024)        slicing tables T0..T3 (256 words each)
 //   [1024 .. 1024+65)  pow1k[k]  = x^(8*1024*k) mod P, k = 0..64
 //   [1089 .. 1089+1025) powb[j]  = x^(8*j) mod P,      j = 0..1024
+//   [2114 .. 2114+40)  powt[j]   = x^(8*65536*2^j) mod P, j = 0..39 (tile distances of files up to 2^55 bytes)
 void crc32_build_tables(u32* out) {
     u32* T = out;
     for (u32 i = 0; i < 256; ++i) {
@@ -54,6 +55,9 @@ void crc32_build_tables(u32* out) {
     u32* pow1k = out + kCrcPow1kOff;
     pow1k[0] = 0x80000000u;
     for (int k = 1; k <= 64; ++k) pow1k[k] = crc_mulmod(pow1k[k - 1], powb[1024]);
+    u32* powt = out + kCrcPowTileOff;
+    powt[0] = pow1k[64];
+    for (int j = 1; j < 40; ++j) powt[j] = crc_mulmod(powt[j - 1], powt[j - 1]);
 }
 
 __device__ __forceinline__ u32 crc_word(u32 c, u32 w, const u32* T) {
@@ -108,39 +112,76 @@ void crc32_tiles_kernel(const u8* __restrict__ data, const u64* __restrict__ fil
     if (lane == 0) tile_raw[tile] = crc_mulmod(part, consts[kCrcPowBytesOff + len_last]) ^ c_last;
 }
 
-// one lane per file: s = 0xFFFFFFFF; for each tile: s = s * x^(8*tlen) ^ raw; crc = ~s
+// x^(8 * 65536 * k) mod P by square-and-multiply over the precomputed squares
+__device__ __forceinline__ u32 crc_pow_tiles(u64 k, const u32* __restrict__ consts) {
+    u32 r = 0x80000000u;                                       // x^0
+    for (int j = 0; k; ++j, k >>= 1)
+        if (k & 1) r = crc_mulmod(r, consts[kCrcPowTileOff + j]);
+    return r;
+}
+__device__ __forceinline__ u32 crc_pow_tail(u32 len, const u32* __restrict__ consts) {   // x^(8 len), len <= 65536
+    return crc_mulmod(consts[kCrcPow1kOff + (len >> 10)], consts[kCrcPowBytesOff + (len & 1023u)]);
+}
+
+// A file's CRC is linear in its tiles:  ~crc = 0xFFFFFFFF * x^(8 size)  ^  XOR_t raw_t * x^(8 * bytes behind tile t),
+// so every tile's term is independent -- one LANE per tile here (a 16 GiB file has 262 144 of them; the first
+// form of this pass walked them one after the other on one lane per file: 48 ms for four 4 GiB files).  The terms
+// of a file are XORed into acc[f] (zeroed by the launcher): one atomic per wave when the wave's 64 tiles belong to
+// one file, one per lane otherwise (small files: one tile each, no contention).
 __global__ __launch_bounds__(256)
-void crc32_files_kernel(const u64* __restrict__ file_size, const u64* __restrict__ first_tile,
-                        u64 n_files, const u32* __restrict__ consts,
-                        const u32* __restrict__ tile_raw, u32* __restrict__ crc) {
+void crc32_fold_kernel(const u64* __restrict__ file_size, const u32* __restrict__ tile_file,
+                       const u64* __restrict__ first_tile, u64 n_tiles, const u32* __restrict__ consts,
+                       const u32* __restrict__ tile_raw, u32* __restrict__ acc) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = t < n_tiles;
+    u32 f = 0xFFFFFFFFu, term = 0;
+    if (live) {
+        f = tile_file[t];
+        const u64 size = file_size[f];
+        const u64 lt = t - first_tile[f];
+        const u64 nt = (size + kGearTile - 1) / kGearTile;
+        term = tile_raw[t];
+        if (lt + 1 < nt) {                                     // bytes behind me: nt-2-lt whole tiles + the last one
+            const u32 len_last = (u32)(size - (nt - 1) * (u64)kGearTile);
+            term = crc_mulmod(term, crc_mulmod(crc_pow_tiles(nt - 2 - lt, consts), crc_pow_tail(len_last, consts)));
+        }
+    }
+    const u32 f0 = (u32)__builtin_amdgcn_readfirstlane((int)f);
+    if (!__ballot(f != f0)) {                                  // the whole wave in one file (or all dead)
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) term ^= __shfl_xor(term, d);
+        if ((threadIdx.x & 63) == 0 && live) atomicXor(acc + f, term);
+    } else if (live) {
+        atomicXor(acc + f, term);
+    }
+}
+
+// one lane per file: crc = ~(acc ^ 0xFFFFFFFF * x^(8 size))
+__global__ __launch_bounds__(256)
+void crc32_files_kernel(const u64* __restrict__ file_size, u64 n_files, const u32* __restrict__ consts,
+                        u32* __restrict__ crc) {
     const u64 f = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= n_files) return;
     const u64 size = file_size[f];
-    const u64 t0 = first_tile[f];
-    const u64 nt = (size + kGearTile - 1) / kGearTile;
-    const u32 x_tile = consts[kCrcPow1kOff + 64];              // x^(8*65536)
-    u32 s = 0xFFFFFFFFu;
-    for (u64 t = 0; t < nt; ++t) {
-        u32 m = x_tile;
-        if (t + 1 == nt) {
-            const u32 tlen = (u32)(size - t * (u64)kGearTile);
-            m = crc_mulmod(consts[kCrcPow1kOff + (tlen >> 10)], consts[kCrcPowBytesOff + (tlen & 1023u)]);
-        }
-        s = crc_mulmod(s, m) ^ tile_raw[t0 + t];
-    }
-    crc[f] = ~s;
+    const u64 whole = size / kGearTile;
+    const u32 m = crc_mulmod(crc_pow_tiles(whole, consts), crc_pow_tail((u32)(size - whole * (u64)kGearTile), consts));
+    crc[f] = ~(crc[f] ^ crc_mulmod(0xFFFFFFFFu, m));
 }
 
 void launch_crc32_files(const u8* d_data, const u64* d_file_off, const u64* d_file_size,
                         const u32* d_tile_file, const u64* d_first_tile, u64 n_tiles, u64 n_files,
                         const u32* d_consts, u32* d_tile_raw, u32* d_crc, hipStream_t s) {
     if (n_files == 0) return;
-    if (n_tiles)
+    (void)hipMemsetAsync(d_crc, 0, n_files * sizeof(u32), s);          // the accumulators of the fold
+    if (n_tiles) {
         hipLaunchKernelGGL(crc32_tiles_kernel, dim3((u32)((n_tiles + 3) / 4)), dim3(256), 0, s, d_data,
                            d_file_off, d_file_size, d_tile_file, d_first_tile, n_tiles, d_consts,
                            d_tile_raw);
+        hipLaunchKernelGGL(crc32_fold_kernel, dim3((u32)((n_tiles + 255) / 256)), dim3(256), 0, s, d_file_size,
+                           d_tile_file, d_first_tile, n_tiles, d_consts, d_tile_raw, d_crc);
+    }
     hipLaunchKernelGGL(crc32_files_kernel, dim3((u32)((n_files + 255) / 256)), dim3(256), 0, s,
-                       d_file_size, d_first_tile, n_files, d_consts, d_tile_raw, d_crc);
+                       d_file_size, n_files, d_consts, d_crc);
 }
 
 // ---- host-side helpers for the context-checksum splice (strings only) -----------------

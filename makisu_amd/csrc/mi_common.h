@@ -171,7 +171,8 @@ void launch_root_level(u64 n_files, u64 n_nodes_ub, const u64* d_cur_addr, const
 void launch_root_final_items(const u64* d_cur_addr, const u32* d_cur_cnt, u64 n_files, u64* d_off,
                              u64* d_len, hipStream_t s);
 // crc32.hip: constant block layout (u32 words) + launcher + host helpers for path strings
-constexpr u32 kCrcPow1kOff = 1024, kCrcPowBytesOff = 1024 + 65, kCrcConstWords = 1024 + 65 + 1025;
+constexpr u32 kCrcPow1kOff = 1024, kCrcPowBytesOff = 1024 + 65, kCrcPowTileOff = 1024 + 65 + 1025,
+              kCrcConstWords = kCrcPowTileOff + 40;      // + x^(8 * 65536 * 2^j), j = 0..39
 void crc32_build_tables(u32* out /* kCrcConstWords */);
 void launch_crc32_files(const u8* d_data, const u64* d_file_off, const u64* d_file_size,
                         const u32* d_tile_file, const u64* d_first_tile, u64 n_tiles, u64 n_files,

@@ -464,6 +464,21 @@ def test_file_crc32_matches_zlib(oracle):
     assert int(rows["crc32"][-1]) == 0xCBF43926            # the classic CRC-32 check value
 
 
+def test_file_crc32_large_files_fold_in_parallel(oracle):
+    """The per-file combine is a parallel fold over the file's 64 KiB tiles (one lane per tile, terms XORed per
+    file): files whose tiles fill whole waves, straddle waves, and sit between one-tile files, against zlib."""
+    import zlib
+    import makisu_amd
+    sizes = [5, 300 * (1 << 20) + 12345, 70000, 64 * 65536, 9, 65 * 65536, 65536, 127 * 65536 + 1, 0, 3, 1 << 27]
+    cids = list(range(4100, 4100 + len(sizes)))
+    with makisu_amd.Engine(flags=makisu_amd.FLAG_FILE_CRC32) as e, e.batch() as b:
+        b.add_synthetic(sizes, cids, seed=SEED)
+        b.run()
+        rows = b.files().copy()
+    for n, c, row in zip(sizes, cids, rows):
+        assert int(row["crc32"]) == zlib.crc32(oracle.synth_fill(SEED, c, 0, n).tobytes()), n
+
+
 def _walk_order(entries):
     """filepath.Walk order over a set of relative paths: lexical per directory, a directory
     before its children (Go path/filepath: Walk sorts names in each directory)."""
