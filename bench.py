@@ -522,6 +522,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     clocks = sampler.stop() if rank == 0 else None
+    chunks_last_batch = int(eng.stats()["n_chunks"])            # of the timed region's last step
     # the SHA-256 VALU roof of THIS device in THIS run, right behind the timed region (same thermal and
     # power state): best of three 10 ms launches of the compression alone
     sampler.start()
@@ -656,7 +657,7 @@ def main():
                                   if exchange else ""),
                    "name": config, "files_per_gpu": int(sum(s.n_files for s in shards) if split else shards[0].n_files),
                    "bytes_per_gpu": int(step_bytes), "job_bytes_per_step": int(job_bytes),
-                   "chunks_last_batch": int(st["n_chunks"]),
+                   "chunks_last_batch": chunks_last_batch,
                    "parallelism": "files sharded x%d (%s)" % (world, "LPT by bytes" if config in ("c5", "c5u") else "file index mod N"),
                    "batches_in_flight": args.inflight, "launches_per_step": launches_per_step,
                    "exchange": (args.exchange if exchange else None),

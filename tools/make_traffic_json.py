@@ -25,7 +25,8 @@ def main():
     fetch = counters("%s/%s_fetch.txt" % (d, tag), "FETCH_SIZE")
     write = counters("%s/%s_write.txt" % (d, tag), "WRITE_SIZE")
     bench = json.load(open("%s/%s_bench_n1.json" % (d, tag)))
-    sha = "void mi::sha256_items_kernel<0, false>"   # C2: lane-owned loads (arena below the cooperative switch)
+    # C2: lane-owned loads (arena below the cooperative switch); the kernel has a third template argument since round 3
+    sha = next((k for k in fetch if k.startswith("void mi::sha256_items_kernel<0, false")), "void mi::sha256_items_kernel<0, false>")
     gear = "mi::gear_cdc_small_fast_kernel" if "mi::gear_cdc_small_fast_kernel" in fetch else "mi::gear_cdc_small_kernel"
     synth_kib = write.get("mi::synth_fill_kernel", (0, 0.0))[1]
     bytes_in = bench["config"]["bytes_per_gpu"]
@@ -33,7 +34,7 @@ def main():
     out = {
         "round": int(tag.lstrip("r")),
         "source": "profiles/%s_pmc_fetch_size.txt + %s_pmc_write_size.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                  "--kernel-trace -- python bench.py --steps 3 --warmup 1 --inflight 1 --no-cpu-baseline), same "
+                  "--kernel-trace -- python bench.py --steps 3 --warmup 1 --inflight 1 --no-cpu-baseline --no-inflight-extra), same "
                   "tools/round_profiles.sh run as the round's bench line" % (tag, tag),
         "kernel": "mi::sha256_items_kernel<0, false> (chunk pass), C2 batch",
         "FETCH_SIZE_KiB_raw": fetch[sha][1],

@@ -25,8 +25,8 @@ for name, key in rows:
         parity += "; unique count %s closed form%s" % (
             "=" if chk.get("ok") else "≠",
             " (+%d 1-byte tail coincidences)" % chk["short_chunk_coincidences"] if chk.get("short_chunk_coincidences") else "")
-    print("| %s | %.2f GB (%d batches in flight) | %s | %.2f / %.2f / %.2f / %.2f / %.2f | %.2f | %.1f | %.1f | %.1f / %.1f | %s | %s |" % (
+    print("| %s | %.2f GB (%d batch(es) in flight) | %s | %.2f / %.2f / %.2f / %.2f / %.2f | %.2f | %.1f | %.1f | %.1f / %.1f | %s | %s |" % (
         name, c["job_bytes_per_step"] / 1e9, c["batches_in_flight"], "{:,}".format(c["chunks_last_batch"]).replace(",", " "),
         ph.get("ms_cdc", 0), ph.get("ms_sort", 0), ph.get("ms_sha_chunks", 0), ph.get("ms_sha_files", 0),
         ph.get("ms_dedup", 0), d["ms_per_step"], d["value"], 100 * r["path_frac"],
-        100 * r.get("serial_frac", 0), 100 * r.get("serial_frac_of_valu_roof", 0), cpu, parity))
+        100 * r.get("serial_frac", r["frac"]), 100 * r.get("serial_frac_of_valu_roof", r["frac_of_valu_roof"]), cpu, parity))

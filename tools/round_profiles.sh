@@ -39,6 +39,11 @@ for scheme in 1000 0; do
 done
 } > $out/${tag}_sq_counters.txt
 
+# ---- per-wave records of the chunk pass (three processes) and the optional per-file passes ----
+{ for i in 1 2 3; do timeout 100 python tools/sha_wave_stats.py 3 2>/dev/null; done; } > $out/${tag}_sha_wave_stats_final.txt
+{ echo "# tools/quick_bench.py --steps 10 --flags F on C2 (F = 0 none, 2 MI_FLAG_FILE_CRC32): the CRC pass = roots(2) - roots(0)";
+  for f in 0 2; do echo -n "C2 flags=$f: "; timeout 100 python tools/quick_bench.py --steps 10 --flags $f 2>&1 | grep inflight | tail -1; done; } > $out/${tag}_crc_pass.txt
+
 # ---- the other BASELINE configs: bench lines; kernel trace + traffic for C3 and C5 ----
 $T python bench.py --config c3 --no-cpu-baseline > $out/${tag}_bench_c3.json 2> $out/bench_c3.err
 $T python bench.py --config c5 --no-cpu-baseline > $out/${tag}_bench_c5.json 2> $out/bench_c5.err
@@ -56,6 +61,7 @@ for cfg in c3 c5; do
   done
   rm -rf $out/kt_$cfg $out/pmc_$cfg
 done
+[ "${PARTS:-all}" = core ] && { ls -la $out; exit 0; }
 {
 for f in 4:4294967296 1:17179869184; do
   timeout 100 python tools/quick_bench.py --files ${f%%:*} --size ${f##*:} --steps 3 2>&1 | grep inflight | tail -1
