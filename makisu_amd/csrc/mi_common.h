@@ -116,7 +116,10 @@ struct ShaTune {
     bool pin_blocks_per_cu = true;           // pad every workgroup's LDS request so that NO CU can take more
                                              // than blocks_per_cu of them (sha256.hip launch_sha256_items)
     bool roles = true;                       // false: every wave equal, one range (the scheme before round 3)
-    bool prio = true;                        // the first wave on a SIMD runs at priority 3 (experiments: false)
+    bool prio = false;                       // true: the first wave on a SIMD also raises s_setprio (3, the others 1).
+                                             // The issue arbiter prefers the older wave anyway (3.5 vs 12 us per
+                                             // iteration with or without it); with two batches in flight the raised
+                                             // priorities cost 2 % (5.72 vs 5.61 ms per C2 step): off.
     int long_shift = 2;                      // the first n >> long_shift strings (the longest) go to the wave that
                                              // arrived first on each SIMD and runs at priority (sha256.hip roles)
 };

@@ -193,9 +193,9 @@ void sha256_items_kernel(const u8* __restrict__ base, const u64* __restrict__ of
     // Two (or three) waves of this grid share every SIMD, and one string is a serial chain: a 64 KiB chunk
     // is 1025 compressions, 5.4 ms at the pace two equal waves leave each other but 3.6 ms for a wave that
     // has issue priority over its neighbour -- and the whole launch has 4.2 ms.  So the strings are split
-    // at position L (the array is sorted longest-first): the FIRST wave to arrive on a SIMD takes the long
-    // ones [0, L) at priority 3, the others take [L, n) at priority 1 with what the first leaves them
-    // (~1/3 of its pace); whoever runs dry continues in the other range.  Roles come from an atomic per
+    // at position L (the array is sorted longest-first): the FIRST wave to arrive on a SIMD -- the one the issue
+    // arbiter prefers from then on, being the older -- takes the long ones [0, L), the others take [L, n) with
+    // what the first leaves them (~1/3 of its pace); whoever runs dry continues in the other range.  Roles come from an atomic per
     // SIMD (key = XCC | SE SH CU | SIMD of HW_ID), not from the dequeue order: with priorities by dequeue
     // rank two long-string waves could land on one SIMD, halve each other's pace and finish ~1 ms after
     // everybody else (profiles/r03_sha_wave_stats.txt: the 5.2 ms launches).
@@ -207,8 +207,8 @@ void sha256_items_kernel(const u8* __restrict__ base, const u64* __restrict__ of
         u32 r = 0;
         if (lane == 0) r = atomicAdd(roles + key, 1u);
         role = (u32)__builtin_amdgcn_readfirstlane((int)r);
-        // (the others at 1, not 0: with another batch in flight its Gear waves run at 0, and a hashing pass
-        // that shares its SIMDs with them evenly stretches from 4.8 to 8 ms -- same step, unreadable profile)
+        // s_setprio only on request (ShaTune.prio): age alone gives the same 3.5 / 12 us per iteration, and raised
+        // priorities starve the other batch's passes when two are in flight
         if (long_shift & 0x100u)  __builtin_amdgcn_s_setprio(0);
         else if (role == 0)       __builtin_amdgcn_s_setprio(3);
         else                      __builtin_amdgcn_s_setprio(1);
