@@ -192,7 +192,7 @@ void sha256_items_kernel(const u8* __restrict__ base, const u64* __restrict__ of
     // ---- the wave's role on its SIMD ---------------------------------------------------------------
     // Two (or three) waves of this grid share every SIMD, and one string is a serial chain: a 64 KiB chunk
     // is 1025 compressions, 5.4 ms at the pace two equal waves leave each other but 3.6 ms for a wave that
-    // has issue priority over its neighbour -- and the whole launch has 4.2 ms.  So the strings are split
+    // is preferred by the issue arbiter over its neighbour -- and the whole launch has 4.2 ms.  So the strings are split
     // at position L (the array is sorted longest-first): the FIRST wave to arrive on a SIMD -- the one the issue
     // arbiter prefers from then on, being the older -- takes the long ones [0, L), the others take [L, n) with
     // what the first leaves them (~1/3 of its pace); whoever runs dry continues in the other range.  Roles come from an atomic per
