@@ -609,7 +609,9 @@ typedef struct {
 } mi_layer_result;
 int  mi_layer_config_default(mi_layer_config* cfg);
 int  mi_layer_begin(const mi_layer_config* cfg, mi_layer** out);
-/* e->relpath = the entry's dst path; src_path = where a regular file's bytes are read from.     */
+/* e->relpath = the entry's dst path; src_path = where a regular file's bytes are read from.  A dst whose
+ * base name carries the whiteout prefix ".wh." is written as a whiteout -- a zero header with only that name,
+ * no content -- whatever the entry is (memLayer.addHeader, lib/snapshot/mem_layer.go:197-212).                */
 int  mi_layer_add(mi_layer* layer, const mi_tree_entry* e, const char* src_path);
 /* whiteoutMemFile.commit (mem_layer.go:101-132): a zero header named <dir>/.wh.<base>.          */
 int  mi_layer_add_whiteout(mi_layer* layer, const char* deleted_path);

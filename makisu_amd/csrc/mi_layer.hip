@@ -562,6 +562,20 @@ int mi_layer_begin(const mi_layer_config* cfg, mi_layer** out) {
 
 const char* mi_layer_error(mi_layer* l) { return l ? l->err.c_str() : "null layer"; }
 
+// memLayer.addHeader (mem_layer.go:197-212): a path whose base name carries the whiteout prefix is filed as a
+// whiteoutMemFile, whatever it is on disk -- committed as a zero header with only that name (newWhiteoutMemFile
+// :97-101, commit :127-132), no content (TestAddHeader/Whiteout, mem_layer_test.go:123-148)
+static bool whiteout_by_name(const std::string& rel_name, Hdr* z) {
+    std::string p = rel_name;
+    while (!p.empty() && p.back() == '/') p.pop_back();
+    const size_t slash = p.rfind('/');
+    if (p.compare(slash == std::string::npos ? 0 : slash + 1, 4, ".wh.") != 0) return false;
+    *z = Hdr();
+    z->name = p;
+    z->typeflag = '0';                                          // TypeRegA promoted to TypeReg by WriteHeader
+    return true;
+}
+
 static int add_header(mi_layer* l, const Hdr& h) {
     Bytes hb;
     std::string err;
@@ -576,6 +590,13 @@ int mi_layer_add(mi_layer* l, const mi_tree_entry* e, const char* src_path) {
     if (l->finished || l->failed) return l->fail(MI_ERR_STATE, "layer is finished or failed");
     Hdr h;
     h.name = trim_left_slashes(e->relpath);                    // RelPath(dst) + WriteHeader's TrimLeft
+    {
+        Hdr z;
+        if (whiteout_by_name(h.name, &z)) {
+            int rc = add_header(l, z);
+            return rc ? rc : l->sink_error();
+        }
+    }
     h.mode = (l->flags & MI_LAYER_MODE_WITH_TYPE) ? (int64_t)(e->mode & 0177777u) : tar_mode(e->mode);
     h.uid = e->uid;
     h.gid = e->gid;
@@ -682,7 +703,9 @@ int mi_layer_header_bytes(const mi_tree_entry* e, uint32_t layer_flags, uint8_t*
     h.uid = e->uid;
     h.gid = e->gid;
     h.mtime = e->mtime_sec;
-    if (e->kind == 0) { h.typeflag = '5'; if (h.name.empty() || h.name.back() != '/') h.name += "/"; }
+    Hdr z;
+    if (e->kind <= 3 && whiteout_by_name(h.name, &z)) h = z;
+    else if (e->kind == 0) { h.typeflag = '5'; if (h.name.empty() || h.name.back() != '/') h.name += "/"; }
     else if (e->kind == 1) { h.typeflag = '0'; h.size = (int64_t)e->size; }
     else if (e->kind == 2 || e->kind == 3) { h.typeflag = e->kind == 2 ? '2' : '1'; h.linkname = e->link_target ? e->link_target : ""; }
     else return MI_ERR_INVALID;

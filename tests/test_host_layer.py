@@ -464,3 +464,145 @@ def test_a_failing_sink_fails_the_layer(tmp_path, level):
         finally:
             if make_fd is not None:
                 os.close(fd)
+
+
+def test_mem_layer_test_go_cases_replayed(tmp_path):
+    """lib/snapshot/mem_layer_test.go: TestCreateHeader (:27-90: a directory's header name ends in "/", a regular file's
+    and a symlink's do not, the types), TestAddHeader (:92-149: a destination whose base name has the whiteout prefix is
+    filed as a whiteout -- committed header-only, a zero header carrying only the name) and TestAddWhiteout (:151-186:
+    "<dir>/.wh.<base>", and a path that already has the prefix is refused)."""
+    src = tmp_path / "test"
+    src.write_bytes(b"content that a whiteout must not carry")
+    # TestCreateHeader: dst "/tmp/testDest"
+    h = M.layer_header_bytes({"relpath": "/tmp/testDest", "kind": M.KIND_DIR, "mode": 0o40700})
+    assert h[:13] == b"tmp/testDest/" and h[13] == 0 and h[156:157] == b"5"
+    h = M.layer_header_bytes({"relpath": "/tmp/testDest", "kind": M.KIND_FILE, "mode": 0o100600, "size": 0})
+    assert h[:12] == b"tmp/testDest" and h[12] == 0 and h[156:157] == b"0"
+    h = M.layer_header_bytes({"relpath": "/tmp/testDest", "kind": M.KIND_SYMLINK, "mode": 0o120777, "link_target": str(src)})
+    assert h[:12] == b"tmp/testDest" and h[12] == 0 and h[156:157] == b"2"
+    # TestAddHeader/Whiteout: dst "/tmp/.wh.testDest" -> whiteout of "/tmp/testDest", hdr.Name "tmp/.wh.testDest"
+    zero = M.layer_header_bytes({"relpath": "/tmp/.wh.testDest", "kind": M.KIND_FILE, "mode": 0o100644, "size": 38,
+                                 "uid": 5, "gid": 6, "mtime_sec": 77})
+    assert len(zero) == 512 and zero[:16] == b"tmp/.wh.testDest" and zero[16] == 0 and zero[156:157] == b"0"
+    assert zero[100:108] == b"0000000\x00" and zero[108:116] == b"0000000\x00" and zero[116:124] == b"0000000\x00"
+    assert zero[124:136] == b"00000000000\x00" and zero[136:148] == b"00000000000\x00"     # size 0, mtime 0: a zero tar.Header
+    fd = os.open(tmp_path / "l.tar", os.O_WRONLY | os.O_CREAT, 0o644)
+    with M.Layer(out_fd=fd, gzip_level=M.GZIP_OFF) as layer:
+        layer.add({"relpath": "/tmp/.wh.testDest", "kind": M.KIND_FILE, "mode": 0o100644, "size": 38, "uid": 5, "gid": 6,
+                   "mtime_sec": 77}, str(src))
+        layer.add_whiteout("/tmp/testDest2")                                   # TestAddWhiteout/RegularFile
+        with pytest.raises(M.MiError):
+            layer.add_whiteout("/tmp/.wh.testDest")                            # TestAddWhiteout/RejectWhiteout
+    os.close(fd)
+    fd = os.open(tmp_path / "l.tar", os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+    with M.Layer(out_fd=fd, gzip_level=M.GZIP_OFF) as layer:
+        layer.add({"relpath": "/tmp/.wh.testDest", "kind": M.KIND_FILE, "mode": 0o100644, "size": 38, "uid": 5, "gid": 6,
+                   "mtime_sec": 77}, str(src))
+        layer.add_whiteout("/tmp/testDest2")
+        pair = layer.finish()
+    os.close(fd)
+    raw = (tmp_path / "l.tar").read_bytes()
+    assert len(raw) == 512 + 512 + 1024 and raw[:512] == zero and pair["n_entries"] == 2      # header-only, both
+    assert raw[512:512 + 17] == b"tmp/.wh.testDest2" and raw[512 + 17] == 0
+    # the same zero header whichever way the whiteout was asked for
+    fd = os.open(tmp_path / "m.tar", os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+    with M.Layer(out_fd=fd, gzip_level=M.GZIP_OFF) as layer:
+        layer.add_whiteout("/tmp/testDest")
+        layer.finish()
+    os.close(fd)
+    assert (tmp_path / "m.tar").read_bytes()[:512] == zero
+
+
+def _commit_scan_layer(tmp_path, root, before, tag):
+    """AddLayerByScan + commitLayer with the host entry points: walk, diff against the previous walk, write the changed
+    entries, their carried ancestors and one whiteout per deleted subtree in commit order through the layer writer (gzip
+    on); returns (this walk, the member names read back from the gzip blob as '/'-rooted names, the DigestPair)."""
+    after = M.tree_walk(str(root), mode=M.TREE_SCAN, full=True)
+    flags, wh = M.snapshot_diff(before, after)
+    items = [("entry", e) for e, f in zip(after, flags) if f != M.DIFF_SAME and e["relpath"] not in (".", "")]
+    items += [("whiteout", e) for e, w in zip(before, wh) if w]
+
+    def key(it):
+        e = it[1]
+        return e["relpath"] if it[0] == "entry" else e["relpath"]       # rangeFiles sorts by the map key = the path
+    items.sort(key=key)
+    out = tmp_path / ("layer_%s.tar.gz" % tag)
+    fd = os.open(out, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+    try:
+        with M.Layer(out_fd=fd, gzip_level=M.GZIP_DEFAULT) as layer:
+            for what, e in items:
+                if what == "whiteout":
+                    layer.add_whiteout("/" + e["relpath"].lstrip("/"))
+                else:
+                    layer.add(e, os.path.join(str(root), e["relpath"]) if e["kind"] == M.KIND_FILE else None)
+            pair = layer.finish()
+    finally:
+        os.close(fd)
+    blob = out.read_bytes()
+    assert hashlib.sha256(blob).digest() == pair["gzip_sha256"] and pair["gzip_bytes"] == len(blob)
+    raw = gzip.decompress(blob)
+    assert hashlib.sha256(raw).digest() == pair["tar_sha256"] and pair["tar_bytes"] == len(raw)
+    with tarfile.open(fileobj=io.BytesIO(raw)) as tf:
+        names = ["/" + m.name.lstrip("/") + ("/" if m.isdir() else "") for m in tf.getmembers()]
+    return after, names, pair
+
+
+def test_commit_diffs_sequence_like_the_reference(tmp_path):
+    """lib/builder/step/common_test.go:94-152 (TestCommitDiffs): four RUN steps on one build context and what the gzipped
+    layer tar of each must hold -- here the steps' effects are applied with python and every layer goes walk ->
+    snapshot diff -> commit order -> tar framing -> two stream digests -> gzip, all through the C ABI.  Also
+    TestTarAndGzipDiffsEmpty / AddedFile (:52-92)."""
+    root = tmp_path / "ctx"
+    os.makedirs(root)
+    s0 = M.tree_walk(str(root), mode=M.TREE_SCAN, full=True)
+    # TestTarAndGzipDiffsEmpty: nothing written -> no members (the blob is the gzip of the 1024-byte trailer)
+    s0b, names, pair = _commit_scan_layer(tmp_path, root, s0, "empty")
+    assert names == [] and pair["tar_bytes"] == 1024 and pair["tar_digest"].hex() == EMPTY_TAR_TRAILER_DIGEST
+    # "touch file1 && touch file2"   (== TestTarAndGzipDiffsAddedFile for the first of them)
+    (root / "file1").write_bytes(b"")
+    (root / "file2").write_bytes(b"")
+    s1, names, _ = _commit_scan_layer(tmp_path, root, s0b, "a")
+    assert sorted(names) == ["/file1", "/file2"]
+    # "mkdir dir1 && rm file1"
+    os.makedirs(root / "dir1")
+    os.unlink(root / "file1")
+    s2, names, _ = _commit_scan_layer(tmp_path, root, s1, "b")
+    assert sorted(names) == ["/.wh.file1", "/dir1/"]
+    # "rm -rf dir1"
+    shutil.rmtree(root / "dir1")
+    s3, names, _ = _commit_scan_layer(tmp_path, root, s2, "c")
+    assert names == ["/.wh.dir1"]
+    # "ls ./": no files were tarred
+    s4, names, pair = _commit_scan_layer(tmp_path, root, s3, "d")
+    assert names == [] and pair["tar_digest"].hex() == EMPTY_TAR_TRAILER_DIGEST
+
+
+def test_write_entry_cases_through_the_tar_command(tmp_path):
+    """lib/tario/write_test.go:29-201 (TestWriteEntry: WriteDirectory, WriteHardLink, WriteSymlink, WriteRegularFile), the
+    reference's own way of checking its writer: untar with the `tar` command and look at what lands on disk -- a 0777
+    directory keeps its permission bits, a hard link (Typeflag TypeLink, Size 0, Linkname relative) shares the inode of
+    its target and reads its bytes, a symlink keeps its target, a regular file its bytes and mode."""
+    if not shutil.which("tar"):
+        pytest.skip("no tar binary")
+    src = tmp_path / "src"
+    src.mkdir()
+    (src / "test").write_bytes(b"test data")
+    os.chmod(src / "test", 0o777)
+    fd = os.open(tmp_path / "t.tar", os.O_WRONLY | os.O_CREAT, 0o644)
+    with M.Layer(out_fd=fd, gzip_level=M.GZIP_OFF) as layer:
+        layer.add({"relpath": "/d/dir777", "kind": M.KIND_DIR, "mode": 0o40777, "mtime_sec": 1_500_000_000})
+        layer.add({"relpath": "/d/test", "kind": M.KIND_FILE, "mode": 0o100777, "size": 9, "mtime_sec": 1_500_000_001},
+                  str(src / "test"))
+        layer.add({"relpath": "/d/link", "kind": M.KIND_HARDLINK, "mode": 0o100777, "link_target": "d/test"})
+        layer.add({"relpath": "/d/sym", "kind": M.KIND_SYMLINK, "mode": 0o120777, "link_target": "test"})
+        layer.finish()
+    os.close(fd)
+    out = tmp_path / "out"
+    out.mkdir()
+    subprocess.check_call(["tar", "-xf", str(tmp_path / "t.tar"), "-C", str(out), "--no-same-owner", "-p"])
+    assert os.lstat(out / "d" / "dir777").st_mode & 0o777 == 0o777
+    st_t, st_l = os.lstat(out / "d" / "test"), os.lstat(out / "d" / "link")
+    assert st_l.st_mode & 0o777 == 0o777 and (out / "d" / "link").read_bytes() == b"test data"
+    assert st_t.st_ino == st_l.st_ino and st_l.st_nlink > 1
+    assert os.readlink(out / "d" / "sym") == "test" and (out / "d" / "sym").read_bytes() == b"test data"
+    assert int(st_t.st_mtime) == 1_500_000_001

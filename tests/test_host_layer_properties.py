@@ -17,7 +17,7 @@ from hypothesis import HealthCheck, example, given, settings, strategies as st
 import makisu_amd as M
 
 SEG = st.text(alphabet=st.characters(blacklist_characters="/\x00", blacklist_categories=("Cs",)), min_size=1, max_size=70) \
-    .filter(lambda s: s not in (".", ".."))
+    .filter(lambda s: s not in (".", "..") and not s.startswith(".wh."))
 ASCII_SEG = st.text(alphabet="abcXYZ019-_.+ ", min_size=1, max_size=120).filter(lambda s: s.strip(". ") != "" and s not in (".", ".."))
 
 
