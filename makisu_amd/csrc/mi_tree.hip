@@ -775,6 +775,15 @@ extern "C" int mi_entries_apply_layer_filtered(const mi_tree_entry* base, uint64
         const int rc = apply(j, path_of(layer[j]));
         if (rc) return rc;
     }
+    // contentMemFile.updateMemFS (mem_layer.go:55-82), applied by MemFS.merge in sorted order -- parents first: an
+    // entry whose parent is neither in the tree nor in the layer fails the merge ("missing intermediate directory";
+    // TestUpdateMemFS/SkipDirCausesError, mem_fs_test.go:246-264).  Checked on the result: every path the layer
+    // brought must have all its ancestors there.
+    for (auto& kv : tree) {
+        if (!kv.second.side) continue;
+        for (std::string d = mi_walk::dir_of(kv.first); d != "/" && !d.empty(); d = mi_walk::dir_of(d))
+            if (!tree.count(d)) return MI_ERR_INVALID;
+    }
     *n_out = tree.size();
     if (cap < tree.size()) return MI_ERR_CAPACITY;
     uint64_t k = 0;
