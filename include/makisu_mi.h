@@ -558,6 +558,13 @@ typedef struct {
     const char*        dst;
     uint32_t           uid, gid;
 } mi_copy_op;
+/* NewCopyOperation's parameter check and destination (lib/snapshot/copy_op.go:44-81, 149-180): no sources, several
+ * sources with a dst that is not in directory format (trailing "/", "." or ".."), or a relative dst without an
+ * absolute work_dir are MI_ERR_INVALID ("check copy param: ..."); otherwise dst_out = dst if absolute, else
+ * filepath.Join(work_dir, dst) with a trailing "/" kept.  mi_snapshot_copy_ops applies the same check to the (already
+ * resolved, hence absolute) dst of every op.  Host logic.                                                        */
+int  mi_copy_op_resolve(uint64_t n_srcs, const char* work_dir, const char* dst, char* dst_out, uint64_t cap,
+                        char* err, uint64_t err_cap);
 typedef struct mi_copy_layer mi_copy_layer;
 int  mi_snapshot_copy_ops(const mi_tree_entry* tree, uint64_t n_tree, const char* tree_root,
                           const mi_copy_op* ops, uint64_t n_ops, int64_t now_sec,

@@ -240,6 +240,7 @@ def load_library(rebuild=False):
                               C.POINTER(C.c_int)], C.c_int),
         "mi_snapshot_copy_ops": ([C.POINTER(TreeEntry), u64, C.c_char_p, C.POINTER(CopyOp), u64, C.c_int64,
                                   C.POINTER(vp), u64p, C.c_char_p, u64], C.c_int),
+        "mi_copy_op_resolve": ([u64, C.c_char_p, C.c_char_p, C.c_char_p, u64, C.c_char_p, u64], C.c_int),
         "mi_copy_layer_entries": ([vp, C.POINTER(TreeEntry), C.POINTER(C.c_char_p), u64], C.c_int),
         "mi_copy_layer_free": ([vp], None),
         "mi_layer_config_default": ([C.POINTER(LayerConfig)], C.c_int),
@@ -458,6 +459,17 @@ def tree_walk(root, rel_base=None, blacklist=(), mode=TREE_CONTEXT, full=False):
                  e.file_index, e.size, e.kind, e.mode) for e in arr[:n.value]]
     finally:
         L.mi_tree_free(h)
+
+
+def copy_op_resolve(n_srcs, work_dir, dst):
+    """mi_copy_op_resolve: NewCopyOperation's checks + resolveDestination; returns the absolute dst."""
+    out = C.create_string_buffer(4096)
+    err = C.create_string_buffer(300)
+    rc = load_library().mi_copy_op_resolve(n_srcs, os.fsencode(work_dir) if work_dir is not None else None, os.fsencode(dst), out,
+                              len(out), err, len(err))
+    if rc:
+        raise MiError(rc, err.value.decode(errors="replace"))
+    return os.fsdecode(out.value)
 
 
 def copy_ops_layer(tree, tree_root, ops, now_sec=0):

@@ -1026,6 +1026,37 @@ struct mi_copy_layer {
     std::vector<mi_copy::Node> nodes;                       // commit order
 };
 
+// isDirFormat / checkCopyParams / resolveDestination (lib/snapshot/copy_op.go:149-180)
+static bool copy_dst_is_dir_format(const std::string& dst) {
+    return (!dst.empty() && dst.back() == '/') || dst == "." || dst == "..";
+}
+static std::string copy_check_params(uint64_t n_srcs, const char* work_dir, const std::string& dst) {
+    if (n_srcs == 0) return "srcs cannot be empty";
+    if (n_srcs > 1 && !copy_dst_is_dir_format(dst)) return "tarring multiple sources, destination must end with \"/\"";
+    if ((dst.empty() || dst[0] != '/') && !(work_dir && work_dir[0] == '/'))
+        return "dst is not absolute path, must specify absolute working directory";
+    return "";
+}
+
+extern "C" int mi_copy_op_resolve(uint64_t n_srcs, const char* work_dir, const char* dst, char* dst_out,
+                                  uint64_t cap, char* err, uint64_t err_cap) {
+    if (!dst || !dst_out) return MI_ERR_INVALID;
+    const std::string d = dst;
+    const std::string bad = copy_check_params(n_srcs, work_dir, d);
+    if (!bad.empty()) {
+        if (err && err_cap) snprintf(err, (size_t)err_cap, "check copy param: %s", bad.c_str());
+        return MI_ERR_INVALID;
+    }
+    std::string r = d;
+    if (d[0] != '/') {                                      // filepath.Join cleans; the trailing "/" is put back
+        r = mi_walk::abs_path(std::string(work_dir) + "/" + d);
+        if (copy_dst_is_dir_format(d) && r.back() != '/') r += "/";
+    }
+    if (cap < r.size() + 1) return MI_ERR_CAPACITY;
+    memcpy(dst_out, r.c_str(), r.size() + 1);
+    return MI_OK;
+}
+
 extern "C" int mi_snapshot_copy_ops(const mi_tree_entry* tree, uint64_t n_tree, const char* tree_root,
                                     const mi_copy_op* ops, uint64_t n_ops, int64_t now_sec,
                                     mi_copy_layer** out, uint64_t* n_entries, char* err, uint64_t err_cap) {
@@ -1055,7 +1086,11 @@ extern "C" int mi_snapshot_copy_ops(const mi_tree_entry* tree, uint64_t n_tree, 
     }
     for (uint64_t k = 0; k < n_ops && !fs.rc; ++k) {
         const mi_copy_op& c = ops[k];
-        if (!c.src_root || !c.dst || (c.n_srcs && !c.srcs) || c.n_srcs == 0) return MI_ERR_INVALID;
+        if (!c.src_root || !c.dst || (c.n_srcs && !c.srcs)) return MI_ERR_INVALID;
+        {   // what NewCopyOperation refuses (copy_op.go:48-50): the dst here is the resolved one, so it is absolute
+            const std::string bad = copy_check_params(c.n_srcs, nullptr, c.dst);
+            if (!bad.empty()) { put_err("check copy param: " + bad); return MI_ERR_INVALID; }
+        }
         const std::string src_root = mi_walk::abs_path(c.src_root);
         std::string dst = c.dst;
         bool create_dst = true;

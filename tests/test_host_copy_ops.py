@@ -166,3 +166,42 @@ def test_copy_layer_feeds_the_layer_writer(tmp_path):
         assert tf.extractfile("srv/app/main.py").read() == b"print(1)\n"
         assert tf.getmember("srv/app/main.py").uid == UID
     assert pair["n_entries"] == 5
+
+
+def test_new_copy_operation_checks_replayed(tmp_path):
+    """lib/snapshot/copy_op_test.go:36-72 (TestNewCopyOperation: four parameter sets NewCopyOperation must refuse) and
+    resolveDestination (copy_op.go:149-159), through mi_copy_op_resolve; mi_snapshot_copy_ops refuses the same on the
+    resolved dst."""
+    import makisu_amd as M
+    import pytest
+    for n_srcs, work_dir, dst in ((0, "", "/test2/test.txt"),            # srcs cannot be empty
+                                  (2, "", "/target/test"),               # several sources, dst not in directory format
+                                  (2, "", "target/test"),                # ... and relative
+                                  (2, "wrk/", "target/test/")):          # relative dst, work dir not absolute
+        with pytest.raises(M.MiError) as ei:
+            M.copy_op_resolve(n_srcs, work_dir, dst)
+        assert "check copy param" in str(ei.value)
+    assert M.copy_op_resolve(1, "", "/test2/test.txt") == "/test2/test.txt"
+    assert M.copy_op_resolve(1, "/work", "test2/test.txt") == "/work/test2/test.txt"
+    assert M.copy_op_resolve(2, "/work", "sub/") == "/work/sub/"          # the trailing "/" is preserved
+    assert M.copy_op_resolve(2, "/work/", ".") == "/work/" and M.copy_op_resolve(1, "/work/a", "..") == "/work/"
+    assert M.copy_op_resolve(1, "/work", "a//b/../c") == "/work/a/c"      # filepath.Join cleans
+    # the layer builder itself
+    src = tmp_path / "src"
+    (src / "dir").mkdir(parents=True)
+    (src / "file").write_bytes(b"x")
+    (src / "dir" / "a").write_bytes(b"y")
+    root = tmp_path / "root"
+    root.mkdir()
+    tree = M.tree_walk(str(root), mode=M.TREE_SCAN, full=True)
+    op = {"src_root": str(src), "srcs": ["file", "dir/"], "dst": "/target/test"}
+    with pytest.raises(M.MiError) as ei:
+        M.copy_ops_layer(tree, str(root), [op])
+    assert "destination must end with" in str(ei.value)
+    with pytest.raises(M.MiError) as ei:
+        M.copy_ops_layer(tree, str(root), [dict(op, srcs=[])])
+    assert "srcs cannot be empty" in str(ei.value)
+    with pytest.raises(M.MiError):
+        M.copy_ops_layer(tree, str(root), [dict(op, dst="target/test/")])           # not absolute: resolve it first
+    got = M.copy_ops_layer(tree, str(root), [dict(op, dst="/target/test/")])
+    assert [e["relpath"] for e in got] == ["target", "target/test", "target/test/a", "target/test/file"]
