@@ -205,3 +205,62 @@ def test_new_copy_operation_checks_replayed(tmp_path):
         M.copy_ops_layer(tree, str(root), [dict(op, dst="target/test/")])           # not absolute: resolve it first
     got = M.copy_ops_layer(tree, str(root), [dict(op, dst="/target/test/")])
     assert [e["relpath"] for e in got] == ["target", "target/test", "target/test/a", "target/test/file"]
+
+
+def test_copy_layer_equals_scan_layer_of_the_same_copy(tmp_path):
+    """The intent of lib/snapshot/mem_fs_test.go:1118-1197 (TestAddLayersEqual: the layer of a COPY built from copy ops,
+    the layer a scan finds after the same copy was really made, and the layer committed from the entries themselves are
+    one and the same tarball): here the copy-op layer (mi_snapshot_copy_ops) and the scan layer (walk + mi_snapshot_diff)
+    of the same copy, both framed by mi_layer, must be byte-identical."""
+    import hashlib
+    import shutil
+    import makisu_amd as M
+    now = 1_600_000_000
+    src = tmp_path / "srcroot"
+    (src / "test1" / "test2").mkdir(parents=True)
+    (src / "test1" / "test4" / "test5").mkdir(parents=True)
+    (src / "test1" / "test2" / "test3.txt").write_bytes(b"hello")
+    (src / "test1" / "test4" / "test5" / "test6.txt").write_bytes(b"hello")
+    for p, _, fs in os.walk(src):
+        for n in fs:
+            os.utime(os.path.join(p, n), (now - 50, now - 50))
+        os.utime(p, (now - 60, now - 60))
+    root = tmp_path / "root"
+    root.mkdir()
+    before = M.tree_walk(str(root), mode=M.TREE_SCAN, full=True)
+    uid, gid = os.getuid(), os.getgid()
+    dst = M.copy_op_resolve(2, "/wrk", "dst/")
+    assert dst == "/wrk/dst/"
+    lay1 = M.copy_ops_layer(before, str(root), [{"src_root": str(src), "srcs": ["/test1/test2/test3.txt", "/test1/test4"],
+                                                 "dst": dst, "uid": uid, "gid": gid}], now_sec=now)
+    assert [e["relpath"] for e in lay1] == ["wrk", "wrk/dst", "wrk/dst/test3.txt", "wrk/dst/test5", "wrk/dst/test5/test6.txt"]
+
+    def frame(entries, src_of, name):
+        out = tmp_path / name
+        fd = os.open(out, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+        try:
+            with M.Layer(out_fd=fd, gzip_level=M.GZIP_OFF) as layer:
+                for e in entries:
+                    layer.add(e, src_of(e) if e["kind"] == M.KIND_FILE else None)
+                pair = layer.finish()
+        finally:
+            os.close(fd)
+        return out.read_bytes(), pair
+
+    raw1, pair1 = frame(lay1, lambda e: e["src"], "copy.tar")
+    # really make the copy, with the attributes the copy would give (directories the step creates: now, 0755)
+    os.makedirs(root / "wrk" / "dst" / "test5")
+    shutil.copy2(src / "test1" / "test2" / "test3.txt", root / "wrk" / "dst" / "test3.txt")
+    shutil.copy2(src / "test1" / "test4" / "test5" / "test6.txt", root / "wrk" / "dst" / "test5" / "test6.txt")
+    for rel in ("wrk", "wrk/dst"):
+        os.chmod(root / rel, 0o755)
+        os.utime(root / rel, (now, now))
+    st5 = os.lstat(src / "test1" / "test4" / "test5")
+    os.chmod(root / "wrk" / "dst" / "test5", st5.st_mode & 0o7777)
+    os.utime(root / "wrk" / "dst" / "test5", (st5.st_mtime, st5.st_mtime))
+    after = M.tree_walk(str(root), mode=M.TREE_SCAN, full=True)
+    flags, wh = M.snapshot_diff(before, after)
+    lay2 = [e for e, f in zip(after, flags) if f != M.DIFF_SAME and e["relpath"] not in (".", "")]
+    assert not any(wh) and [e["relpath"] for e in lay2] == [e["relpath"] for e in lay1]
+    raw2, pair2 = frame(lay2, lambda e: os.path.join(str(root), e["relpath"]), "scan.tar")
+    assert raw1 == raw2 and pair1["tar_sha256"] == pair2["tar_sha256"] == hashlib.sha256(raw1).digest()
