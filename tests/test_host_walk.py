@@ -586,3 +586,21 @@ def test_parallel_walk_reports_the_first_error_in_walk_order(tmp_path, engine_li
         assert ei.value.code == -1
         msgs.append(str(ei.value))
     assert msgs[0] == msgs[1]
+
+
+def test_compare_fs_case_through_the_snapshot_diff(engine_lib):
+    """lib/snapshot/mem_fs_test.go:1198-1289 (TestCompareFS: two trees sharing /common; /common/test1 only in the first,
+    /common/test2 only in the second, /common/world with another mode in each): compareNode's three sets are what
+    mi_snapshot_diff reports between the two entry lists -- gone from `after` (a whiteout), new or different in `after`
+    (changed) -- in either direction."""
+    import makisu_amd
+    D = lambda p: {"relpath": p, "kind": makisu_amd.KIND_DIR, "mode": 0o40755, "mtime_sec": 5}                      # noqa: E731
+    F = lambda p, m: {"relpath": p, "kind": makisu_amd.KIND_FILE, "mode": 0o100000 | m, "size": 5, "mtime_sec": 5}  # noqa: E731
+    fs1 = makisu_amd.apply_layer([], [D("/common"), D("/common/test1"), F("/common/world", 0o711)])
+    fs2 = makisu_amd.apply_layer([], [D("/common"), D("/common/test2"), F("/common/world", 0o755)])
+    changed, carried, whiteouts = _diff_names(fs1, fs2)
+    assert whiteouts == ["/common/test1"]                                   # missing2: only the first tree has it
+    assert changed == ["/common/test2", "/common/world"]                    # missing1 + diff
+    assert carried == ["/common"]                                           # the unchanged parent travels with them
+    changed, carried, whiteouts = _diff_names(fs2, fs1)
+    assert whiteouts == ["/common/test2"] and changed == ["/common/test1", "/common/world"]
