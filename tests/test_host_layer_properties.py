@@ -191,3 +191,16 @@ def test_whole_layers_frame_and_digest(tmp_path_factory, items):
     got = M.tar_entries(out)
     assert [g["relpath"].strip("/") for g in got] == [rel.strip("/") for rel, *_ in items]
     assert [g["size"] for g in got] == [len(data) for _, _, data, *_ in items]
+
+
+_PSEG = st.text(alphabet=st.characters(blacklist_characters="\x00/", blacklist_categories=("Cs",)), min_size=1, max_size=12) \
+    .filter(lambda s: s not in (".", ".."))
+
+
+@settings(max_examples=300, deadline=None)
+@given(st.lists(st.lists(_PSEG, min_size=1, max_size=4).map(lambda p: "/".join(p)), min_size=0, max_size=40, unique=True))
+def test_commit_order_is_sort_strings_on_the_absolute_paths(names):
+    """memLayer.rangeFiles (lib/snapshot/mem_layer.go:232-244): sort.Strings over the layer's keys -- byte order of the
+    absolute destination paths, whatever the characters."""
+    got = [names[k] for k in M.commit_order(names)]
+    assert got == sorted(names, key=lambda s: ("/" + s).encode("utf-8"))
