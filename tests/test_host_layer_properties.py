@@ -204,3 +204,46 @@ def test_commit_order_is_sort_strings_on_the_absolute_paths(names):
     absolute destination paths, whatever the characters."""
     got = [names[k] for k in M.commit_order(names)]
     assert got == sorted(names, key=lambda s: ("/" + s).encode("utf-8"))
+
+
+def _similar_restated(a, b, ignore_time):
+    """tario.IsSimilarHeader (lib/tario/compare.go:24-120) on entry dicts: a symlink by its target alone; a hard link by
+    mtime (whole seconds), target, uid, gid, mode; a directory by mtime, uid, gid, mode; a regular file by those and
+    size.  Another type on the other side is never similar."""
+    if a["kind"] != b["kind"]:
+        return False
+    if a["kind"] == M.KIND_SYMLINK:
+        return a.get("link_target") == b.get("link_target")
+    same = (ignore_time or a["mtime_sec"] == b["mtime_sec"]) and a["uid"] == b["uid"] and a["gid"] == b["gid"] and \
+        (a["mode"] & 0o7777) == (b["mode"] & 0o7777)
+    if a["kind"] == M.KIND_HARDLINK:
+        # the reference holds hard-link targets as absolute paths (UpdateFromTarReader, lib/snapshot/mem_fs.go:217-219:
+        # "Docker hard link names are all absolute, but don't have a leading slash"); entries here keep the tar's form,
+        # so the comparison makes them absolute
+        ab = lambda t: "/" + (t or "").lstrip("/")                                  # noqa: E731
+        return same and ab(a.get("link_target")) == ab(b.get("link_target"))
+    if a["kind"] == M.KIND_FILE:
+        return same and a["size"] == b["size"]
+    return same
+
+
+_ENTRY = st.fixed_dictionaries({
+    "kind": st.sampled_from([M.KIND_DIR, M.KIND_FILE, M.KIND_SYMLINK, M.KIND_HARDLINK]),
+    "perm": st.sampled_from([0o644, 0o755, 0o4755, 0o1777]), "uid": st.sampled_from([0, 1000]), "gid": st.sampled_from([0, 7]),
+    "mtime_sec": st.sampled_from([5, 6]), "size": st.sampled_from([0, 10]), "link_target": st.sampled_from(["a", "/a", "b"]),
+    "relpath": st.sampled_from(["x", "y/z"])})
+
+
+@settings(max_examples=2000, deadline=None)
+@given(_ENTRY, _ENTRY, st.booleans())
+def test_entry_similar_equals_the_restated_predicate(a, b, ignore_time):
+    def full(d):
+        t = {M.KIND_DIR: 0o40000, M.KIND_FILE: 0o100000, M.KIND_SYMLINK: 0o120000, M.KIND_HARDLINK: 0o100000}[d["kind"]]
+        e = dict(d, mode=d["perm"] | t)
+        if d["kind"] not in (M.KIND_SYMLINK, M.KIND_HARDLINK):
+            e["link_target"] = None
+        if d["kind"] != M.KIND_FILE:
+            e["size"] = 0
+        return e
+    ea, eb = full(a), full(b)
+    assert M.entry_similar(ea, eb, ignore_time=ignore_time) == _similar_restated(ea, eb, ignore_time)
