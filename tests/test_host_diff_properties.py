@@ -1,0 +1,126 @@
+"""Differential test of mi_snapshot_diff (csrc/mi_tree.hip) against a python model of what the reference's scan does:
+MemFS.createLayerByScan walks the disk in filepath.Walk order and calls maybeAddToLayer for every path
+(lib/snapshot/mem_fs.go:315-341, 440-483): isUpdated against the in-memory tree (:487-503, tario.IsSimilarHeader), then
+the changed path's ancestors (addAncestors :505-566) and the path itself go into the layer and the tree; for a directory
+that was already in the tree, every child the tree holds and the disk no longer has is whited out -- one whiteout per
+deleted subtree -- with its ancestors carried too.  The model below does exactly that on entry lists (a path is "on
+disk" iff the second list has it); trees are generated, then mutated: entries added, deleted, retyped, touched."""
+import posixpath
+
+from hypothesis import HealthCheck, event, given, settings, strategies as st
+
+import makisu_amd as M
+
+NAMES = ["a", "b", "c", "d"]
+
+
+def _similar(x, y):
+    return M.entry_similar(x, y)
+
+
+def model_scan_layer(before, after):
+    """-> (set of paths the layer holds as content entries, set of deleted paths it holds whiteouts for)"""
+    tree = {"/" + e["relpath"]: e for e in before}                     # path -> entry; children by prefix
+    on_disk = {"/" + e["relpath"] for e in after}
+    content, whiteouts = set(), set()
+
+    def children(p):
+        pre = p.rstrip("/") + "/"
+        return sorted(q for q in tree if q.startswith(pre) and "/" not in q[len(pre):])
+
+    def drop_subtree(p):
+        for q in [q for q in tree if q == p or q.startswith(p + "/")]:
+            del tree[q]
+
+    def add_ancestors(p):
+        d = posixpath.dirname(p)
+        chain = []
+        while d != "/":
+            chain.append(d)
+            d = posixpath.dirname(d)
+        for d in reversed(chain):
+            if d in tree:                                              # always, for a walk: parents come first
+                content.add(d)
+
+    for e in after:                                                    # filepath.Walk order
+        p = "/" + e["relpath"]
+        old = tree.get(p)
+        updated = old is None or not _similar(old, e)
+        if updated:
+            add_ancestors(p)
+            content.add(p)
+            if old is not None and e["kind"] != M.KIND_DIR:            # a non-directory replaces the node AND its children
+                drop_subtree(p)
+            tree[p] = e
+        if e["kind"] == M.KIND_DIR and old is not None:
+            for c in children(p):
+                if c not in on_disk:
+                    whiteouts.add(c)
+                    content.discard(c)                                  # the layer's key for that path is the whiteout now
+                    drop_subtree(c)
+                    add_ancestors(c)
+    return content, whiteouts
+
+
+@st.composite
+def tree_pairs(draw):
+    def gen_tree(depth, prefix):
+        out = []
+        for n in draw(st.lists(st.sampled_from(NAMES), unique=True, max_size=4)):
+            rel = prefix + n
+            kind = draw(st.sampled_from([M.KIND_DIR, M.KIND_DIR, M.KIND_FILE, M.KIND_SYMLINK]))
+            if depth >= 3 and kind == M.KIND_DIR:
+                kind = M.KIND_FILE
+            e = {"relpath": rel, "kind": kind, "uid": 0, "gid": 0, "mtime_sec": draw(st.sampled_from([1, 2])),
+                 "mode": {M.KIND_DIR: 0o40755, M.KIND_FILE: 0o100644, M.KIND_SYMLINK: 0o120777}[kind],
+                 "size": draw(st.sampled_from([3, 4])) if kind == M.KIND_FILE else 0,
+                 "link_target": draw(st.sampled_from(["x", "y"])) if kind == M.KIND_SYMLINK else None}
+            out.append(e)
+            if kind == M.KIND_DIR:
+                out += gen_tree(depth + 1, rel + "/")
+        return out
+
+    def walk_order(es):
+        return sorted(es, key=lambda e: e["relpath"].split("/"))       # lexical per directory, a directory before its children
+
+    before = walk_order(gen_tree(0, ""))
+    # mutate: delete some subtrees, touch or retype some entries, turn a directory into a file, graft new paths in
+    after, gone = [], []
+    for e in before:
+        if any(e["relpath"].startswith(g) for g in gone):
+            continue
+        r = draw(st.integers(0, 9))
+        e2 = dict(e)
+        if r in (0, 4):                                                         # the path and everything below it
+            gone.append(e["relpath"] + "/")
+            continue
+        if r == 1:
+            e2["mtime_sec"] = 3 - e["mtime_sec"]
+        elif r == 2 and e["kind"] != M.KIND_DIR:                                 # file <-> symlink
+            e2.update({"kind": M.KIND_SYMLINK, "mode": 0o120777, "size": 0, "link_target": "x"} if e["kind"] == M.KIND_FILE
+                      else {"kind": M.KIND_FILE, "mode": 0o100644, "size": 3, "link_target": None})
+        elif r == 3 and e["kind"] == M.KIND_DIR:                                 # directory -> file: its children are gone
+            e2.update({"kind": M.KIND_FILE, "mode": 0o100644, "size": 4})
+            gone.append(e["relpath"] + "/")
+        after.append(e2)
+    have = {e["relpath"]: e for e in after}
+    for e in gen_tree(0, ""):
+        parent = posixpath.dirname(e["relpath"])
+        if e["relpath"] not in have and (parent == "" or (parent in have and have[parent]["kind"] == M.KIND_DIR)):
+            after.append(e)
+            have[e["relpath"]] = e
+    return before, walk_order(after)
+
+
+@settings(max_examples=400, deadline=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.filter_too_much])
+@given(tree_pairs())
+def test_snapshot_diff_equals_the_scan_model(pair):
+    before, after = pair
+    flags, wh = M.snapshot_diff(before, after)
+    got_content = {"/" + e["relpath"] for e, f in zip(after, flags) if f != M.DIFF_SAME}
+    got_wh = {"/" + e["relpath"] for e, w in zip(before, wh) if w}
+    want_content, want_wh = model_scan_layer(before, after)
+    event("whiteouts: %d" % min(len(want_wh), 3))
+    event("content entries: %s" % ("0" if not want_content else "1-3" if len(want_content) < 4 else "4+"))
+    assert got_wh == want_wh, (sorted(got_wh), sorted(want_wh))
+    assert got_content == want_content, (sorted(got_content), sorted(want_content))
