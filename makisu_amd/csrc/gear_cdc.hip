@@ -19,11 +19,12 @@
 //      = exactly one cache line, touched once), the next piece in flight while the
 //      current one is hashed; it warms h over the 64 bytes before its run (6 % extra
 //      reads, L2 hits: they are the previous lane's last line);
-//   2. the Gear table lives in LDS, replicated kCopies times and interleaved so lanes
-//      that differ in (lane % kCopies) never share a bank: the byte-indexed
-//      ds_read_b64 lookups -- the dominant LDS traffic, 8 B per input byte -- stay
-//      near conflict-free.  No file bytes are staged in LDS, so the LDS budget goes
-//      to the table copies and the per-wave candidate bitmaps;
+//   2. the Gear table lives in LDS, replicated and interleaved so lanes that differ in
+//      (lane % copies) never share a bank: the byte-indexed ds_read_b64 lookups -- the
+//      dominant LDS traffic, 8 B per input byte -- are conflict-free with the 32 copies of
+//      the marking kernels (entry stride 256 B: the data byte is byte 1 of the address, one
+//      v_perm_b32) and near it with the 8 copies of the kernels that also keep per-wave
+//      candidate bitmaps.  No file bytes are staged in LDS;
 //   3. h rolls with one v_lshl_add_u64 per byte; the candidate test costs half a VALU
 //      op per byte (v_min3_u32 over the high words of 16 consecutive hashes, a slow
 //      path only when the minimum passes the mask); hits set bits in the wave's LDS
@@ -33,8 +34,8 @@
 //      (__ballot + popcount prefix sums) -- one ballot per cut --, and from the bitmap with
 //      wave-wide find-first-set (64 lanes x 64 bits per step, __ballot + ctz) when a tile
 //      has too many candidates for the list; chunk ends go to the segment's u32 list in HBM.
-// Small files (<= one tile): one wave per file, four files per workgroup, no
-// workgroup barrier at all.  Large files: GROUPS of four tiles (256 KiB) that are marked AND
+// Small files (<= one tile): one wave per file, eight files per workgroup, no
+// workgroup barrier behind the table load.  Large files: GROUPS of four tiles (256 KiB) that are marked AND
 // cut in parallel -- every group selects speculatively as if a cut fell on its first byte,
 // a second pass re-selects from the previous group's speculative exit until it meets the
 // speculative cut list again (Gear + min/max re-synchronises within a few chunks), and a

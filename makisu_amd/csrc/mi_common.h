@@ -14,10 +14,13 @@ typedef uint64_t u64;
 typedef int64_t  i64;
 
 // ---- Gear-CDC tile geometry (gear_cdc.hip) ------------------------------------
-constexpr int kGearWG     = 256;                 // threads per workgroup (4 waves, 3 workgroups per CU)
+constexpr int kGearWG     = 256;                 // threads per workgroup of the kernels that keep bitmaps and of the
+                                                 // group kernels (4 waves = the 4 tiles of a group); the bitmap-free
+                                                 // marking kernels run 512 threads around one 64 KiB table (gear_cdc.hip)
 constexpr int kGearTile   = 65536;               // bytes of file one wave marks at a time
 constexpr int kGearHalo   = 64;                  // Gear window: h depends on <= 64 bytes
-constexpr int kGearTableCopies = 8;              // LDS replicas of the Gear table
+constexpr int kGearTableCopies = 8;              // LDS replicas of the Gear table in the kernels that keep bitmaps (32 in
+                                                 // the marking kernels)
 
 // ---- SHA-256 work queues (sha256.hip) ----------------------------------------
 constexpr int kShaQueues  = 8;                   // one head word per XCD (block b runs on XCD b % 8)

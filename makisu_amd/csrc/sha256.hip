@@ -7,15 +7,19 @@
 // string, keeps its 8-word state and 16-word schedule in VGPRs and runs the 64
 // rounds with v_alignbit_b32 (rotates), v_bitop3_b32 (xor3 / Ch / Maj in one op) and v_add3_u32.
 //
-// Roofline: this kernel is VALU-integer bound, not HBM bound: ~1650 VALU ops per
-// 64-byte block against 256 CU x 128 lanes/clk.  HBM traffic is
+// Roofline: this kernel is VALU-integer bound, not HBM bound: 1 460 VALU instructions per
+// 64-byte block (1 399 of them the compression), and every one of them costs an issue slot of
+// its SIMD whatever its "rate" -- DESIGN.md 4.2, profiles/r03_ubench_mix.txt.  HBM traffic is
 // 1 byte read per byte hashed + 32 bytes written per string.
 //
 // Scheduling: strings have very different lengths (2 KiB..64 KiB chunks), so lanes
-// pull work from kShaQueues global queues holding the items longest-first (LPT):
-// a lane that finishes its string takes the next one instead of idling until the
-// slowest lane of its wave is done.  Dequeues are aggregated per wave (one atomic
-// for all lanes that finished in the same iteration).
+// pull work from global queues holding the items longest-first (LPT): a lane that
+// finishes its string takes the next one instead of idling until the slowest lane of
+// its wave is done.  Dequeues are aggregated per wave (one atomic for all lanes that
+// finished in the same iteration).  Two waves share every SIMD and the issue arbiter
+// prefers the older one (3.5 against 12 us per block): the wave that ARRIVES FIRST on a
+// SIMD takes the longest quarter of the strings, the other(s) the rest (two ranges of
+// kShaQueues queues; whoever runs dry continues in the other range).
 #include "mi_common.h"
 
 #include <stdio.h>
