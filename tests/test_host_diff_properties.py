@@ -112,7 +112,7 @@ def tree_pairs(draw):
     return before, walk_order(after)
 
 
-@settings(max_examples=400, deadline=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.filter_too_much])
+@settings(max_examples=400, deadline=None, derandomize=True, database=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.filter_too_much])
 @given(tree_pairs())
 def test_snapshot_diff_equals_the_scan_model(pair):
     before, after = pair

@@ -50,7 +50,7 @@ def _fits_ustar(e, name):
     return True
 
 
-@settings(max_examples=300, deadline=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.filter_too_much])
+@settings(max_examples=300, deadline=None, derandomize=True, database=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.filter_too_much])
 @given(entries())
 @example({"relpath": "a" * 100, "kind": 1, "mode": 0o100644, "uid": 0, "gid": 0, "mtime_sec": 1, "size": 1})
 @example({"relpath": "a" * 101, "kind": 1, "mode": 0o100644, "uid": 0, "gid": 0, "mtime_sec": 1, "size": 1})
@@ -148,7 +148,7 @@ def small_layers(draw):
     return items
 
 
-@settings(max_examples=60, deadline=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.filter_too_much])
+@settings(max_examples=60, deadline=None, derandomize=True, database=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.filter_too_much])
 @given(small_layers())
 def test_whole_layers_frame_and_digest(tmp_path_factory, items):
     """Whole streams: every member's header and bytes come back through tarfile, the stream is blocks of 512 with the
@@ -197,7 +197,7 @@ _PSEG = st.text(alphabet=st.characters(blacklist_characters="\x00/", blacklist_c
     .filter(lambda s: s not in (".", ".."))
 
 
-@settings(max_examples=300, deadline=None)
+@settings(max_examples=300, deadline=None, derandomize=True, database=None)
 @given(st.lists(st.lists(_PSEG, min_size=1, max_size=4).map(lambda p: "/".join(p)), min_size=0, max_size=40, unique=True))
 def test_commit_order_is_sort_strings_on_the_absolute_paths(names):
     """memLayer.rangeFiles (lib/snapshot/mem_layer.go:232-244): sort.Strings over the layer's keys -- byte order of the
@@ -234,7 +234,7 @@ _ENTRY = st.fixed_dictionaries({
     "relpath": st.sampled_from(["x", "y/z"])})
 
 
-@settings(max_examples=2000, deadline=None)
+@settings(max_examples=2000, deadline=None, derandomize=True, database=None)
 @given(_ENTRY, _ENTRY, st.booleans())
 def test_entry_similar_equals_the_restated_predicate(a, b, ignore_time):
     def full(d):

@@ -53,7 +53,7 @@ def _write(path, fmt, ms):
             tf.addfile(ti)
 
 
-@settings(max_examples=120, deadline=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.filter_too_much,
+@settings(max_examples=120, deadline=None, derandomize=True, database=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.filter_too_much,
                                                                    HealthCheck.function_scoped_fixture])
 @given(ms=members(ascii_only=False), fmt=st.sampled_from([tarfile.PAX_FORMAT, tarfile.GNU_FORMAT]))
 def test_reader_lists_pax_and_gnu_archives_like_tarfile(tmp_path_factory, ms, fmt):
@@ -62,7 +62,7 @@ def test_reader_lists_pax_and_gnu_archives_like_tarfile(tmp_path_factory, ms, fm
     _compare_with_tarfile(path)
 
 
-@settings(max_examples=60, deadline=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.filter_too_much,
+@settings(max_examples=60, deadline=None, derandomize=True, database=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.filter_too_much,
                                                                   HealthCheck.function_scoped_fixture])
 @given(ms=members(ascii_only=True))
 def test_reader_lists_ustar_archives_like_tarfile(tmp_path_factory, ms):
