@@ -485,9 +485,9 @@ void mi_tar_free(mi_tar* tar);
  * directory on a directory only updates the directory; anything else replaces the old path and
  * its subtree.  Result: the merged tree in sorted-path order, entry k = layer[index[k]] if
  * from_layer[k] else base[index[k]].  *n_out = its size (MI_ERR_CAPACITY if cap is smaller;
- * call with cap 0 to size).  A layer entry whose parent directory is neither in the tree nor
- * in the layer fails the merge with MI_ERR_INVALID, like contentMemFile.updateMemFS's "missing
- * intermediate directory" (lib/snapshot/mem_layer.go:55-82).  Host logic.                     */
+ * call with cap 0 to size).  A layer entry whose parent directory is in neither list is kept as
+ * it is: the directories UpdateFromTarReader would create for it (addAncestors, mem_fs.go:546-563)
+ * are not synthesized.  Host logic.                                                            */
 int mi_entries_apply_layer(const mi_tree_entry* base, uint64_t n_base, const mi_tree_entry* layer,
                            uint64_t n_layer, uint8_t* from_layer, uint64_t* index, uint64_t cap,
                            uint64_t* n_out);

@@ -775,15 +775,11 @@ extern "C" int mi_entries_apply_layer_filtered(const mi_tree_entry* base, uint64
         const int rc = apply(j, path_of(layer[j]));
         if (rc) return rc;
     }
-    // contentMemFile.updateMemFS (mem_layer.go:55-82), applied by MemFS.merge in sorted order -- parents first: an
-    // entry whose parent is neither in the tree nor in the layer fails the merge ("missing intermediate directory";
-    // TestUpdateMemFS/SkipDirCausesError, mem_fs_test.go:246-264).  Checked on the result: every path the layer
-    // brought must have all its ancestors there.
-    for (auto& kv : tree) {
-        if (!kv.second.side) continue;
-        for (std::string d = mi_walk::dir_of(kv.first); d != "/" && !d.empty(); d = mi_walk::dir_of(d))
-            if (!tree.count(d)) return MI_ERR_INVALID;
-    }
+    // (A layer entry whose parent directory is in neither list stays as it is.  UpdateFromTarReader would CREATE the
+    // missing directories first -- maybeAddToLayer -> addAncestors, mem_fs.go:455-458, 546-563: the nearest ancestor's
+    // mode, mtime = now, uid/gid 0 -- which cannot be said with (from_layer, index) pairs; the next scan then reports
+    // the real directory as changed either way.  The "missing intermediate directory" error of
+    // contentMemFile.updateMemFS is only reachable through the reference's test-only MemFS.merge, testutils_test.go:31.)
     *n_out = tree.size();
     if (cap < tree.size()) return MI_ERR_CAPACITY;
     uint64_t k = 0;

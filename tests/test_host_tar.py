@@ -363,15 +363,12 @@ def test_apply_layer_filter_drops_what_the_scan_walk_skips(tmp_path):
     metadata) must not enter the tree, or mi_snapshot_diff writes whiteouts for them."""
     root = str(tmp_path / "rootfs")
     layer = [_e("bin", 0), _e("bin/sh", 1, size=10), _e("proc", 0), _e("proc/cpuinfo", 1, size=1),
-             _e("dev", 0), _e("dev/null", 4, mode=0o666), _e(".wh..wh.plnk", 0),
+             _e("dev", 0), _e("dev/null", 4, mode=0o666), _e(".wh..wh.plnk", 0), _e(".wh..wh.plnk/x", 1),
              _e("etc", 0), _e("etc/passwd", 1, size=5), _e("var/.wh..wh.opq", 1)]
     merged = M.apply_layer([], layer, root=root, blacklist=[root + "/proc"])
-    assert [m["relpath"] for m in merged] == ["bin", "bin/sh", "dev", "etc", "etc/passwd"]
-    # shouldSkip looks at the BASE name only (utils.go:38): a file INSIDE the skipped ".wh..wh.plnk" directory is not
-    # skipped, reaches the merge without its parent, and the merge fails -- "missing intermediate directory"
-    # (contentMemFile.updateMemFS, mem_layer.go:55-82), here as there
-    with pytest.raises(M.MiError):
-        M.apply_layer([], layer + [_e(".wh..wh.plnk/x", 1)], root=root, blacklist=[root + "/proc"])
+    # (".wh..wh.plnk/x" stays: shouldSkip looks at the BASE name only, utils.go:38 -- the reference keeps it too,
+    # creating the skipped parent directory for it on the way: maybeAddToLayer -> addAncestors, mem_fs.go:455-458)
+    assert [m["relpath"] for m in merged] == [".wh..wh.plnk/x", "bin", "bin/sh", "dev", "etc", "etc/passwd"]
     # unfiltered (root=None): everything is kept, and a special file recurring in a later layer no
     # longer aborts the merge (it simply replaces the old entry)
     all_ = M.apply_layer([], layer)
@@ -416,9 +413,9 @@ def test_snapshot_diff_asks_the_disk_before_writing_a_whiteout(tmp_path):
 
 
 def test_update_mem_fs_cases_replayed():
-    """lib/snapshot/mem_fs_test.go:164-344 (TestUpdateMemFS): Simple, Mutation, TrailingSlashes, SkipDirCausesError,
-    WhiteoutExistingDir, WhiteoutNonexistentNotCausingError -- MemFS.merge of one layer after another, here
-    mi_entries_apply_layer on entry lists."""
+    """lib/snapshot/mem_fs_test.go:164-344 (TestUpdateMemFS): Simple, Mutation, TrailingSlashes, WhiteoutExistingDir,
+    WhiteoutNonexistentNotCausingError -- one layer after another into the tree, here mi_entries_apply_layer on entry
+    lists."""
     def names(x):
         return sorted("/" + e["relpath"].strip("/") for e in x)
     D = lambda p, mode=0o755: _e(p, 0, mode=0o40000 | mode)                    # noqa: E731
@@ -433,9 +430,11 @@ def test_update_mem_fs_cases_replayed():
     fs = M.apply_layer(M.apply_layer([], [D("test1/")]), [D("test1/test2/")])
     assert names(fs) == ["/test1", "/test1/test2"]
     assert names(M.apply_layer(fs, [D("/test1", 0o700)])) == ["/test1", "/test1/test2"]          # one node per path
-    # SkipDirCausesError: /test1/test2/test3 without /test1/test2
-    with pytest.raises(M.MiError):
-        M.apply_layer([], [D("/test1"), D("/test1/test2/test3")])
+    # (SkipDirCausesError is a property of the reference's test-only MemFS.merge, testutils_test.go:31-42: the real
+    # path, UpdateFromTarReader -> maybeAddToLayer -> addAncestors, creates the missing /test1/test2 instead of
+    # failing; here the entry is kept without its parent, see the header)
+    fs = M.apply_layer([], [D("/test1"), D("/test1/test2/test3")])
+    assert names(fs) == ["/test1", "/test1/test2/test3"]
     # WhiteoutExistingDir: the subtree goes
     l1 = [D("/test11"), D("/test11/test12"), F("/test11/test12/test.txt")]
     fs = M.apply_layer(M.apply_layer([], l1), [D("/test11"), D("/test11/.wh.test12")])
