@@ -158,6 +158,18 @@ class ClockSampler:
         return out
 
 
+def default_inflight(config, exchange):
+    """Batches in flight when --inflight is not given.
+    Without an exchange: ONE batch at a time.  Two in flight are 3-6 % faster (the second batch's passes fill the first
+    one's tails -- reported as `two_batches_in_flight`), but their persistent hashing grids then share the SIMDs for most
+    of their lives and the span of a launch (6-8 ms between its events, in the bench and in rocprof alike) says nothing
+    about the kernel (4.2 ms).  With an exchange there is host-synchronised work to hide: two batches, three for the
+    small config."""
+    if not exchange:
+        return 1
+    return 3 if config == "c2" else 2
+
+
 def usable_cores():
     """Host cores this process may actually use: the affinity mask, capped by a cgroup CPU quota
     (cpu.max / cpu.cfs_quota_us) when one is set -- os.cpu_count() alone reports the node's cores
@@ -362,13 +374,7 @@ def main():
     config = args.config if args.config != "auto" else ("c2" if world == 1 else "c4")
     exchange = world > 1 or args.force_exchange
     if args.inflight <= 0:
-        # Without an exchange: ONE batch at a time.  Two in flight are 2-3 % faster (the second batch's
-        # passes fill the first one's tails -- reported as `two_batches_in_flight` below), but their
-        # persistent hashing grids then share the SIMDs for most of their lives and the span of a launch
-        # (7.9 ms between its events, in the bench and in rocprof alike) says nothing about the kernel
-        # (4.2 ms).  With an exchange there is host-synchronised work to hide: two batches, three for
-        # the small config.
-        args.inflight = (3 if config == "c2" else 2) if exchange else 1
+        args.inflight = default_inflight(config, exchange)
     if args.steps <= 0:
         args.steps = {"c2": 20, "c3": 3, "c4": 3, "c5": 4, "c5u": 5}[config]
     if args.warmup < 0:

@@ -1,6 +1,7 @@
 """CPU tests of BASELINE.json's config generators (makisu_amd/workloads.py): every rank must derive
 the same job from nothing but (config, rank, world), and the closed forms bench.py checks the GPU
 against must hold by construction."""
+import os
 import numpy as np
 
 from makisu_amd import workloads as W
@@ -110,3 +111,16 @@ def test_c5_several_ranks_split_the_large_files_into_parts():
     assert n_parts == world * int((sizes >= 256 * W.MIB).sum()) > 0
     loads = [s.n_bytes for s in shards]
     assert max(loads) / (sum(loads) / world) == shards[0].imbalance
+
+
+def test_bench_default_batches_in_flight():
+    """bench.py: one batch at a time on one GPU without an exchange (its kernel durations are then the kernels' own),
+    two with an exchange to hide, three for the small config."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert [bench.default_inflight(c, False) for c in ("c2", "c3", "c4", "c5", "c5u")] == [1, 1, 1, 1, 1]
+    assert bench.default_inflight("c2", True) == 3 and bench.default_inflight("c4", True) == 2
+    assert bench.default_inflight("c5", True) == 2
