@@ -478,16 +478,20 @@ int  mi_tar_inflate(const char* blob_path, const char* tar_path_out, uint64_t* t
 int  mi_tar_entries(const mi_tar* tar, mi_tree_entry* out, uint64_t* data_offsets, uint64_t cap);
 void mi_tar_free(mi_tar* tar);
 
-/* A layer's entries applied on top of a tree -- MemFS.UpdateFromTarReader / untarOneItem
- * (lib/snapshot/mem_fs.go:165-255, 571-660) on entry lists: ".wh.<name>" markers delete
- * <dir>/<name> with its subtree and are not part of the result; an entry whose header is
- * similar to the one already there changes nothing (the OLD entry stays, :607-613); a
- * directory on a directory only updates the directory; anything else replaces the old path and
- * its subtree.  Result: the merged tree in sorted-path order, entry k = layer[index[k]] if
- * from_layer[k] else base[index[k]].  *n_out = its size (MI_ERR_CAPACITY if cap is smaller;
- * call with cap 0 to size).  A layer entry whose parent directory is in neither list is kept as
- * it is: the directories UpdateFromTarReader would create for it (addAncestors, mem_fs.go:546-563)
- * are not synthesized.  Host logic.                                                            */
+/* A layer's entries applied on top of a tree -- MemFS.UpdateFromTarReader (lib/snapshot/mem_fs.go:165-255:
+ * maybeAddToLayer :440-458, isUpdated :487-503, addAncestors :505-566, updateMemFS lib/snapshot/mem_layer.go:50-76,
+ * 104-125) on entry lists, header by header on a tree of the reference's shape: ".wh.<name>" markers delete
+ * <dir>/<name> with its subtree and are not part of the result; an entry whose header is similar to the one
+ * already there changes nothing (the OLD entry stays); a directory keeps what the tree holds below its path,
+ * anything else replaces the path and its subtree; a symlink or file that is somebody's ancestor loses the
+ * children it had; "./" never replaces the root.  Result: the merged tree in sorted-path order, entry k =
+ * layer[index[k]] if from_layer[k] else base[index[k]].  *n_out = its size (MI_ERR_CAPACITY if cap is smaller;
+ * call with cap 0 to size).  The directories addAncestors CREATES for an entry whose parents are in neither
+ * list (the nearest ancestor's mode, mtime = now) are in the tree while the layer is applied but, having no entry
+ * to point at, not in the result: the entry comes back without them.  Where the reference fails the build --
+ * "missing intermediate directory" for an entry two levels below a symlink or file, "symlink loop" -- the call
+ * returns MI_ERR_INVALID and mi_last_error(NULL) the reference's message ("add hdr from tar to layer: ...").
+ * Host logic.                                                                                              */
 int mi_entries_apply_layer(const mi_tree_entry* base, uint64_t n_base, const mi_tree_entry* layer,
                            uint64_t n_layer, uint8_t* from_layer, uint64_t* index, uint64_t cap,
                            uint64_t* n_out);

@@ -400,7 +400,8 @@ def apply_layer(base, layer, root=None, blacklist=()):
         ab, len(base), al, len(layer), os.fsencode(root) if root is not None else None, bl, len(blacklist),
         src.ctypes.data, idx.ctypes.data_as(C.POINTER(C.c_uint64)), cap, C.byref(n))
     if rc:
-        raise MiError(rc, "mi_entries_apply_layer")
+        why = load_library().mi_last_error(None) if rc == -1 else b""
+        raise MiError(rc, "mi_entries_apply_layer" + (": " + why.decode("utf-8", "replace") if why else ""))
     return [(layer if src[k] else base)[int(idx[k])] for k in range(n.value)]
 
 

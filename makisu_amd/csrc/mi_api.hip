@@ -1359,7 +1359,11 @@ int mi_batch_read_back(mi_batch* b, void* out, uint64_t cap) {
 }
 
 void** mi_batch_tree_slot(mi_batch* b) { return &b->tree; }
-void mi_set_error(mi_batch* b, const char* msg) { b->ctx->err = msg; }
+void mi_set_error(mi_batch* b, const char* msg) {                // b NULL: the message mi_last_error(NULL) returns
+    if (b) { b->ctx->err = msg; return; }
+    std::lock_guard<std::mutex> g(g_err_mu);
+    g_create_err = msg;
+}
 
 int mi_batch_free(mi_batch* b) {
     if (!b) return MI_ERR_INVALID;

@@ -41,6 +41,7 @@
 
 #include <algorithm>
 #include <condition_variable>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -85,6 +86,27 @@ static std::string clean_rooted(const std::string& p) {
     std::string out;
     for (const std::string& el : parts) out += "/" + el;
     return out.empty() ? "/" : out;
+}
+// Go's path.Clean for ANY path (filepath.Join's result): as above, but a relative path keeps its leading ".." elements
+// and an empty result is ".".
+static std::string clean_any(const std::string& p) {
+    if (!p.empty() && p[0] == '/') return clean_rooted(p);
+    std::vector<std::string> parts;
+    size_t i = 0;
+    while (i < p.size()) {
+        while (i < p.size() && p[i] == '/') ++i;
+        size_t j = i;
+        while (j < p.size() && p[j] != '/') ++j;
+        if (j > i) {
+            const std::string el = p.substr(i, j - i);
+            if (el == "..") { if (!parts.empty() && parts.back() != "..") parts.pop_back(); else parts.push_back(el); }
+            else if (el != ".") parts.push_back(el);
+        }
+        i = j;
+    }
+    std::string out;
+    for (const std::string& el : parts) out += (out.empty() ? "" : "/") + el;
+    return out.empty() ? "." : out;
 }
 static std::string abs_path(const std::string& p) {          // pathutils.AbsPath (lib/pathutils/path.go:41-43)
     return clean_rooted(p);                                  // path.Join("/", strings.TrimRight(p, "/"))
@@ -689,19 +711,30 @@ extern "C" int mi_snapshot_diff(const mi_snapshot_side* before, const mi_snapsho
 }
 
 // Applying a layer's entries on top of a tree, the way MemFS.UpdateFromTarReader does header by
-// header (lib/snapshot/mem_fs.go:165-255) through maybeAddToLayer / updateMemFS:
+// header (lib/snapshot/mem_fs.go:165-255) through maybeAddToLayer / addAncestors / updateMemFS, on a tree of the
+// reference's own shape (a node = a header and a children map):
 //   * with a filter (root != NULL) every header first passes the reference's skip rules on
 //     path = filepath.Join(root, hdr.Name): AUFS metadata (".wh..wh." base names), blacklist
 //     descendants, special files (shouldSkip, utils.go:37-52), mountpoints and everything under
 //     one (mountutils.IsMounted) never enter the tree -- so /proc, /dev/null, /etc/resolv.conf of a
 //     base image are not "deleted" later when the scan walk skips them too;
-//   * hard links wait for a second pass after every other entry (:219-236), and their targets
-//     compare as pathutils.AbsPath(linkname) (:214-216);
-//   * a whiteout marker ".wh.<name>" removes <dir>/<name> and everything below it, and is not
-//     itself part of the tree;
-//   * an entry whose header is similar to what is already there changes nothing -- the old entry
-//     (and so the old content) stays; a directory arriving on a directory only updates the
-//     directory, its children stay; anything else replaces the old path together with its subtree.
+//   * hard links wait for a second pass after every other entry (:219-236), one header per path (the reference keeps
+//     them in a map and ranges over it in no particular order; here: sorted by path), and their targets compare as
+//     pathutils.AbsPath(linkname) (:214-216);
+//   * the root is never touched ("./" of a layer: "Root itself is not added to layers", :447);
+//   * an entry whose header is similar to what is already at its path changes nothing -- the old entry (and so the
+//     old content) stays;
+//   * otherwise its ancestors come first (addAncestors :505-566): a directory on the way stays as it is, a symlink or
+//     file on the way LOSES its children (it is re-added through updateMemFS, which only lets directories keep them), a
+//     symlink then sends the walk to its target and ends it, and what is missing of the entry's own prefix is created
+//     as directories -- these carry no entry of either list, so they are never part of the result, but they are in
+//     the tree while the layer is applied;
+//   * then the entry itself (mem_layer.go:50-76, 197-212): a whiteout marker ".wh.<name>" removes <dir>/<name> with
+//     everything below it and is not itself part of the tree; a directory takes over what the tree holds below its
+//     path, whatever was AT the path before; anything else replaces the path together with its subtree;
+//   * where the reference gives up, so does this call, MI_ERR_INVALID with the reference's words in
+//     mi_last_error(NULL): "missing intermediate directory" (an entry two levels below a symlink or file: updateMemFS
+//     finds nothing to descend into), "symlink loop" (depth 1024).
 // Output: the merged tree in sorted-path order as (from_layer, index) pairs.
 extern "C" int mi_entries_apply_layer_filtered(const mi_tree_entry* base, uint64_t n_base,
                                                const mi_tree_entry* layer, uint64_t n_layer, const char* root,
@@ -733,60 +766,191 @@ extern "C" int mi_entries_apply_layer_filtered(const mi_tree_entry* base, uint64
             if (mi_walk::has_prefix(on_disk, t.back() == '/' ? t : t + "/")) return true;
         return false;
     };
-    struct Ref { uint8_t side; uint64_t idx; };
-    std::map<std::string, Ref> tree;
-    for (uint64_t i = 0; i < n_base; ++i) tree[path_of(base[i])] = Ref{0, i};
-    auto remove_subtree = [&](const std::string& p) {
-        tree.erase(p);
-        const std::string pre = p == "/" ? p : p + "/";
-        for (auto it = tree.lower_bound(pre); it != tree.end() && mi_walk::has_prefix(it->first, pre);)
-            it = tree.erase(it);
+    // The tree in the reference's own shape -- memFSNode: a header and a children map (mem_fs.go:33-47) -- because
+    // isUpdated, addAncestors and updateMemFS walk it part by part through nodes of ANY type, and what they do to a
+    // file or symlink that has children differs from what a flat path map would do.
+    struct Node {
+        uint8_t side = 2;                      // 0 base[idx], 1 layer[idx], 2 a directory made up by addAncestors
+        uint64_t idx = 0;
+        uint8_t kind = 0;
+        std::map<std::string, std::unique_ptr<Node>> children;
     };
-    auto apply = [&](uint64_t j, const std::string& p) -> int {
-        const std::string name = mi_walk::base_of(p);
-        if (mi_walk::has_prefix(name, ".wh.")) {
-            const std::string dir = mi_walk::dir_of(p);
-            remove_subtree((dir == "/" ? "" : dir) + "/" + name.substr(4));
-            return MI_OK;
+    Node tree_root;
+    auto parts_of = [](const std::string& p) {                                 // pathutils.SplitPath
+        std::vector<std::string> out;
+        size_t i = 0;
+        while (i < p.size()) {
+            while (i < p.size() && p[i] == '/') ++i;
+            size_t j = i;
+            while (j < p.size() && p[j] != '/') ++j;
+            if (j > i) out.push_back(p.substr(i, j - i));
+            i = j;
         }
-        auto it = tree.find(p);
-        if (it != tree.end()) {
-            const mi_tree_entry& old = it->second.side ? layer[it->second.idx] : base[it->second.idx];
-            int similar = 0;
-            if (old.kind <= 3 && layer[j].kind <= 3) {                        // special files never compare equal
-                const int rc = mi_entry_similar(&old, &layer[j], 0, nullptr, nullptr, &similar);
+        return out;
+    };
+    auto join_abs = [](const std::vector<std::string>& ps, size_t n) {         // AbsPath(filepath.Join(parts[:n]...))
+        std::string q;
+        for (size_t k = 0; k < n; ++k) q += "/" + ps[k];
+        return mi_walk::abs_path(q);
+    };
+    auto entry_of = [&](const Node& n) -> const mi_tree_entry* {
+        return n.side == 0 ? &base[n.idx] : n.side == 1 ? &layer[n.idx] : nullptr;
+    };
+    std::string fail_msg;
+    // contentMemFile.updateMemFS (mem_layer.go:50-76): the node at dst is replaced; the new node takes over the old
+    // node's children iff the NEW header is a directory; a missing part before the last one is an error
+    auto put = [&](const std::string& dst, uint8_t side, uint64_t idx, uint8_t kind) -> bool {
+        const std::vector<std::string> ps = parts_of(dst);
+        Node* cur = &tree_root;
+        for (size_t i = 0; i < ps.size(); ++i) {
+            auto it = cur->children.find(ps[i]);
+            const bool last = i + 1 == ps.size();
+            if (it != cur->children.end()) {
+                if (!last) { cur = it->second.get(); continue; }
+                std::unique_ptr<Node> nn(new Node);
+                nn->side = side; nn->idx = idx; nn->kind = kind;
+                if (kind == 0) nn->children = std::move(it->second->children);
+                it->second = std::move(nn);
+            } else if (last) {
+                std::unique_ptr<Node> nn(new Node);
+                nn->side = side; nn->idx = idx; nn->kind = kind;
+                cur->children[ps[i]] = std::move(nn);
+            } else {
+                fail_msg = "missing intermediate directory " + ps[i] + " in " + dst;
+                return false;
+            }
+        }
+        return true;
+    };
+    // whiteoutMemFile.updateMemFS (mem_layer.go:104-125)
+    auto wipe = [&](const std::string& del) -> bool {
+        const std::vector<std::string> ps = parts_of(del);
+        Node* cur = &tree_root;
+        for (size_t i = 0; i < ps.size(); ++i) {
+            auto it = cur->children.find(ps[i]);
+            const bool last = i + 1 == ps.size();
+            if (it != cur->children.end()) {
+                if (last) cur->children.erase(it);
+                else cur = it->second.get();
+            } else if (!last) {
+                fail_msg = "missing intermediate dir " + ps[i] + " in " + del;
+                return false;
+            }                                                                   // else "Trying to whiteout nonexistent path"
+        }
+        return true;
+    };
+    // addAncestors (mem_fs.go:505-566) with inclusive = false.  Re-adding an existing ancestor "as it is" through
+    // updateMemFS changes nothing for a directory and drops the children of anything else; a symlink sends the walk
+    // to its target (filepath.Join(linkname, the remaining parts), from the tree's root) and ends it; any other
+    // non-directory lets the walk go on one part further WITHOUT descending (:535-549); what is then still missing of
+    // dst's own prefix is created as directories.
+    std::function<bool(const std::string&, int)> add_ancestors = [&](const std::string& dst, int depth) -> bool {
+        if (depth >= 1024) { fail_msg = "symlink loop at " + dst; return false; }
+        const std::vector<std::string> ps = parts_of(dst);
+        const size_t end = ps.empty() ? 0 : ps.size() - 1;
+        Node* cur = &tree_root;
+        size_t i = 0;
+        for (; i < end; ++i) {
+            auto it = cur->children.find(ps[i]);
+            if (it == cur->children.end()) break;
+            Node* n = it->second.get();
+            if (n->kind == 0) { cur = n; continue; }
+            n->children.clear();
+            if (n->kind == 2) {
+                const mi_tree_entry* e = entry_of(*n);
+                std::string target = e && e->link_target ? e->link_target : "";
+                for (size_t k = i + 1; k < ps.size(); ++k) target += "/" + ps[k];
+                target = mi_walk::clean_any(target);
+                if (!add_ancestors(target, depth + 1)) {
+                    fail_msg = "get symlink target ancestors " + target + ": " + fail_msg;
+                    return false;
+                }
+                return true;
+            }
+        }
+        for (size_t j = i; j < end; ++j)
+            if (!put(join_abs(ps, j + 1), 2, 0, 0)) return false;
+        return true;
+    };
+    // the base list: nodes at their paths, parents that are not listed made up on the way (they carry no entry)
+    for (uint64_t i = 0; i < n_base; ++i) {
+        const std::vector<std::string> ps = parts_of(path_of(base[i]));
+        Node* cur = &tree_root;
+        for (const std::string& part : ps) {
+            std::unique_ptr<Node>& slot = cur->children[part];
+            if (!slot) slot.reset(new Node);
+            cur = slot.get();
+        }
+        cur->side = 0; cur->idx = i; cur->kind = base[i].kind;                  // (the root too, if the base lists it:
+                                                                                //  it comes back, nothing ever replaces it)
+    }
+    // maybeAddToLayer (mem_fs.go:440-458) with createWhiteout = false
+    auto apply = [&](uint64_t j, const std::string& p) -> int {
+        if (p == "/") return MI_OK;                                             // "Root itself is not added to layers"
+        const std::vector<std::string> ps = parts_of(p);
+        Node* cur = &tree_root;                                                 // isUpdated (:487-503)
+        bool found = true;
+        for (const std::string& part : ps) {
+            auto it = cur->children.find(part);
+            if (it == cur->children.end()) { found = false; break; }
+            cur = it->second.get();
+        }
+        if (found) {
+            const mi_tree_entry* old = entry_of(*cur);                          // a made-up directory's mtime is "now":
+            int similar = 0;                                                    // never similar to a header from a tar
+            if (old && old->kind <= 3 && layer[j].kind <= 3) {                  // special files never compare equal
+                const int rc = mi_entry_similar(old, &layer[j], 0, nullptr, nullptr, &similar);
                 if (rc) return rc;
             }
-            if (similar) return MI_OK;                                        // already there
-            if (!(old.kind == 0 && layer[j].kind == 0)) remove_subtree(p);    // dir on dir: children stay
+            if (similar) return MI_OK;                                          // already there: the OLD entry stays
         }
-        tree[p] = Ref{1, j};
+        if (!add_ancestors(p, 0)) { fail_msg = "add ancestors of " + p + ": " + fail_msg; return MI_ERR_INVALID; }
+        const std::string name = ps.back();
+        if (mi_walk::has_prefix(name, ".wh.")) {                                // memLayer.addHeader (:197-212)
+            const std::string dir = mi_walk::dir_of(p);
+            if (!wipe((dir == "/" ? "" : dir) + "/" + name.substr(4))) {
+                fail_msg = "update memfs with file " + p + ": " + fail_msg;
+                return MI_ERR_INVALID;
+            }
+            return MI_OK;
+        }
+        if (!put(p, 1, j, layer[j].kind)) { fail_msg = "update memfs with file " + p + ": " + fail_msg; return MI_ERR_INVALID; }
         return MI_OK;
     };
-    std::vector<uint64_t> hardlinks;
+    auto failed = [&](int rc) {
+        if (!fail_msg.empty()) mi_set_error(nullptr, ("add hdr from tar to layer: " + fail_msg).c_str());
+        return rc;
+    };
+    std::map<std::string, uint64_t> hardlinks;                                  // "hardlinks[path] = hdr": one per path
     for (uint64_t j = 0; j < n_layer; ++j) {
         const std::string p = path_of(layer[j]);
         if (skipped(layer[j], p)) continue;
-        if (layer[j].kind == 3) { hardlinks.push_back(j); continue; }
+        if (layer[j].kind == 3) { hardlinks[p] = j; continue; }
         const int rc = apply(j, p);
-        if (rc) return rc;
+        if (rc) return failed(rc);
     }
-    for (uint64_t j : hardlinks) {
-        const int rc = apply(j, path_of(layer[j]));
-        if (rc) return rc;
+    for (auto& kv : hardlinks) {
+        const int rc = apply(kv.second, kv.first);
+        if (rc) return failed(rc);
     }
-    // (A layer entry whose parent directory is in neither list stays as it is.  UpdateFromTarReader would CREATE the
-    // missing directories first -- maybeAddToLayer -> addAncestors, mem_fs.go:455-458, 546-563: the nearest ancestor's
-    // mode, mtime = now, uid/gid 0 -- which cannot be said with (from_layer, index) pairs; the next scan then reports
-    // the real directory as changed either way.  The "missing intermediate directory" error of
-    // contentMemFile.updateMemFS is only reachable through the reference's test-only MemFS.merge, testutils_test.go:31.)
-    *n_out = tree.size();
-    if (cap < tree.size()) return MI_ERR_CAPACITY;
-    uint64_t k = 0;
-    for (auto& kv : tree) {
-        from_layer[k] = kv.second.side;
-        index[k] = kv.second.idx;
-        ++k;
+    // the merged tree in sorted-path order; made-up directories are not entries of either list and stay out
+    std::vector<std::pair<std::string, const Node*>> flat;
+    std::function<void(const Node&, const std::string&)> collect = [&](const Node& n, const std::string& p) {
+        for (auto& kv : n.children) {
+            const std::string q = p + "/" + kv.first;
+            if (kv.second->side != 2) flat.emplace_back(q, kv.second.get());
+            collect(*kv.second, q);
+        }
+    };
+    if (tree_root.side == 0) flat.emplace_back("/", &tree_root);
+    collect(tree_root, "");
+    std::sort(flat.begin(), flat.end(), [](const std::pair<std::string, const Node*>& x,
+                                           const std::pair<std::string, const Node*>& y) { return x.first < y.first; });
+    *n_out = flat.size();
+    if (cap < flat.size()) return MI_ERR_CAPACITY;
+    for (size_t k = 0; k < flat.size(); ++k) {
+        from_layer[k] = flat[k].second->side;
+        index[k] = flat[k].second->idx;
     }
     return MI_OK;
 }
