@@ -551,8 +551,12 @@ int mi_snapshot_diff(const mi_snapshot_side* before, const mi_snapshot_side* aft
  * The destination directory chain is ensured first (existing ancestors are carried into the layer,
  * symlinks on the way followed, missing directories created with the op's uid/gid), then every
  * walked source path (snapshot walk rules, no blacklist) gets its header with the op's uid/gid and
- * is added iff tario.IsSimilarHeader says it differs from what the tree holds.  No whiteouts: a
- * copy never deletes.  Result: the layer's entries in commit order (mi_copy_layer_entries), each
+ * is added iff tario.IsSimilarHeader says it differs from what the tree holds.  A single FILE
+ * source skips the first step, so its dst stays as spelled: right below a symlink it becomes a
+ * child of the link's node (`COPY f /lib/f` with /lib -> usr/lib: the layer holds lib, lib/f, usr,
+ * usr/lib), deeper it fails as in the reference ("missing intermediate directory").  No scan
+ * whiteouts: a copy never deletes -- except by NAME: a source called ".wh.<x>" is a whiteout of its
+ * sibling <x>, filed under that path (memLayer.addHeader, mem_layer.go:197-212).  Result: the layer's entries in commit order (mi_copy_layer_entries), each
  * with the path its bytes are read from ("" for created directories) -- feed them to mi_layer_add
  * and the regular files to a batch.  The caller's tree is not modified.  Host logic.           */
 typedef struct {

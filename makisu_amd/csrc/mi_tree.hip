@@ -511,6 +511,167 @@ static void walk_root(Walker* w, const std::string& root) {
 
 }  // namespace mi_walk
 
+// The in-memory tree of the reference's own shape -- memFSNode: a header and a children map (lib/snapshot/mem_fs.go:33-47)
+// -- with the four operations every layer-building path goes through: isUpdated's walk (:487-503), addAncestors
+// (:505-566), contentMemFile.updateMemFS (lib/snapshot/mem_layer.go:50-76) and whiteoutMemFile.updateMemFS (:104-125).
+// They walk part by part through nodes of ANY type, and what they do to a file or symlink that has children (or is
+// somebody's ancestor) is not what a flat path map would do, so both users -- the layer merge and the copy-op layer --
+// share this one.  Nodes carry a caller-owned payload index.
+namespace mi_memfs {
+
+struct Node {
+    int64_t ref = -1;                          // caller's payload; -1 = none
+    uint8_t kind = 0;                          // 0 dir, 1 regular, 2 symlink, 3 hard link, 4 special
+    std::string link;                          // symlink target
+    std::map<std::string, std::unique_ptr<Node>> children;
+};
+
+struct Tree {
+    Node root;
+    std::string err;                           // why the last failing call failed, in the reference's words
+    // memLayer.addHeader's bookkeeping (l.files[...] = ...): every header that goes through addHeader -- the entry
+    // itself, each existing ancestor re-added on the way, each directory created
+    std::function<void(const std::string& dst, int64_t ref)> on_add;
+    // the header of a directory addAncestors creates (createHeader from lastAncestor's FileInfo, ModTime = now, the
+    // given uid/gid, :551-559) -> its payload
+    std::function<int64_t(const std::string& dst, const Node& last_ancestor, uint32_t uid, uint32_t gid)> make_dir;
+
+    static std::vector<std::string> parts(const std::string& p) {               // pathutils.SplitPath
+        std::vector<std::string> out;
+        size_t i = 0;
+        while (i < p.size()) {
+            while (i < p.size() && p[i] == '/') ++i;
+            size_t j = i;
+            while (j < p.size() && p[j] != '/') ++j;
+            if (j > i) out.push_back(p.substr(i, j - i));
+            i = j;
+        }
+        return out;
+    }
+    static std::string join_abs(const std::vector<std::string>& ps, size_t n) {  // AbsPath(filepath.Join(parts[:n]...))
+        std::string q;
+        for (size_t k = 0; k < n; ++k) q += "/" + ps[k];
+        return mi_walk::abs_path(q);
+    }
+    Node* find(const std::string& p) {                                          // isUpdated's walk; nullptr = "new"
+        Node* cur = &root;
+        for (const std::string& part : parts(p)) {
+            auto it = cur->children.find(part);
+            if (it == cur->children.end()) return nullptr;
+            cur = it->second.get();
+        }
+        return cur;
+    }
+    // a listed tree: the node at its path, parents that are not listed created on the way (no payload)
+    void load(const std::string& p, int64_t ref, uint8_t kind, const char* link) {
+        Node* cur = &root;
+        for (const std::string& part : parts(p)) {
+            std::unique_ptr<Node>& slot = cur->children[part];
+            if (!slot) slot.reset(new Node);
+            cur = slot.get();
+        }
+        cur->ref = ref; cur->kind = kind; cur->link = link ? link : "";
+    }
+    // contentMemFile.updateMemFS: the node at dst is replaced; the new node takes over the old node's children iff
+    // the NEW header is a directory; a missing part before the last one is an error
+    bool put(const std::string& dst, int64_t ref, uint8_t kind, const std::string& link) {
+        if (on_add) on_add(dst, ref);
+        const std::vector<std::string> ps = parts(dst);
+        Node* cur = &root;
+        for (size_t i = 0; i < ps.size(); ++i) {
+            auto it = cur->children.find(ps[i]);
+            const bool last = i + 1 == ps.size();
+            if (it != cur->children.end() && !last) { cur = it->second.get(); continue; }
+            if (it == cur->children.end() && !last) {
+                err = "missing intermediate directory " + ps[i] + " in " + dst;
+                return false;
+            }
+            std::unique_ptr<Node> nn(new Node);
+            nn->ref = ref; nn->kind = kind; nn->link = link;
+            if (it != cur->children.end()) {
+                if (kind == 0) nn->children = std::move(it->second->children);
+                it->second = std::move(nn);
+            } else {
+                cur->children[ps[i]] = std::move(nn);
+            }
+        }
+        return true;
+    }
+    // whiteoutMemFile.updateMemFS
+    bool wipe(const std::string& del) {
+        const std::vector<std::string> ps = parts(del);
+        Node* cur = &root;
+        for (size_t i = 0; i < ps.size(); ++i) {
+            auto it = cur->children.find(ps[i]);
+            const bool last = i + 1 == ps.size();
+            if (it != cur->children.end()) {
+                if (last) cur->children.erase(it);
+                else cur = it->second.get();
+            } else if (!last) {
+                err = "missing intermediate dir " + ps[i] + " in " + del;
+                return false;
+            }                                                                   // else "Trying to whiteout nonexistent path"
+        }
+        return true;
+    }
+    // l.addHeader(src, dst, hdr).updateMemFS(tree) (mem_layer.go:197-212): a ".wh.<name>" base name is a whiteout of
+    // its sibling <name>, filed under THAT path; anything else is content
+    bool add(const std::string& dst, int64_t ref, uint8_t kind, const std::string& link) {
+        const std::string name = mi_walk::base_of(dst);
+        if (!mi_walk::has_prefix(name, ".wh.")) return put(dst, ref, kind, link);
+        if (on_add) on_add(dst, ref);
+        const std::string dir = mi_walk::dir_of(dst);
+        return wipe((dir == "/" ? "" : dir) + "/" + name.substr(4));
+    }
+    // addAncestors.  Re-adding an existing ancestor "as it is" through updateMemFS changes nothing for a directory and
+    // drops the children of anything else; a symlink sends the walk to its target (filepath.Join(linkname, the
+    // remaining parts), from the tree's root) and ends it; any other non-directory lets the walk go on one part further
+    // WITHOUT descending (the switch at :535-549 has no case for it); what is then still missing of dst's own prefix
+    // is created as directories.  resolved = "the resolved dst path to the best of its knowledge".
+    bool add_ancestors(const std::string& dst, bool inclusive, int depth, uint32_t uid, uint32_t gid,
+                       std::string* resolved) {
+        if (depth >= 1024) {                       // (by now dst is the link's target joined to itself a thousand times)
+            err = "symlink loop at " + (dst.size() > 160 ? dst.substr(0, 160) + "..." : dst);
+            return false;
+        }
+        const std::vector<std::string> ps = parts(dst);
+        const size_t end = inclusive ? ps.size() : (ps.empty() ? 0 : ps.size() - 1);
+        Node* cur = &root;
+        const Node* last_ancestor = &root;
+        std::string cur_path;                                                   // "" = the root
+        size_t i = 0;
+        for (; i < end; ++i) {
+            auto it = cur->children.find(ps[i]);
+            if (it == cur->children.end()) break;
+            Node* n = it->second.get();
+            const std::string n_path = cur_path + "/" + ps[i];
+            if (on_add) on_add(n_path, n->ref);
+            if (n->kind == 0) { last_ancestor = n; cur = n; cur_path = n_path; continue; }
+            n->children.clear();
+            if (n->kind == 2) {
+                std::string target = n->link;
+                for (size_t k = i + 1; k < ps.size(); ++k) target += "/" + ps[k];
+                target = mi_walk::clean_any(target);
+                if (!add_ancestors(target, inclusive, depth + 1, uid, gid, resolved)) {
+                    // (the reference wraps the error once per level; the outermost wrap is the one that says where)
+                    if (depth == 0) err = "get symlink target ancestors " + target + ": " + err;
+                    return false;
+                }
+                return true;
+            }
+        }
+        for (size_t j = i; j < end; ++j) {
+            const std::string q = join_abs(ps, j + 1);
+            const int64_t ref = make_dir ? make_dir(q, *last_ancestor, uid, gid) : -1;
+            if (!put(q, ref, 0, std::string())) { err = "update memfs with ancestor " + q + ": " + err; return false; }
+        }
+        if (resolved) *resolved = dst;
+        return true;
+    }
+};
+
+}  // namespace mi_memfs
+
 using mi_walk::Tree;
 
 // the batch keeps its tree behind an opaque pointer (mi_api.hip owns the slot)
@@ -766,136 +927,22 @@ extern "C" int mi_entries_apply_layer_filtered(const mi_tree_entry* base, uint64
             if (mi_walk::has_prefix(on_disk, t.back() == '/' ? t : t + "/")) return true;
         return false;
     };
-    // The tree in the reference's own shape -- memFSNode: a header and a children map (mem_fs.go:33-47) -- because
-    // isUpdated, addAncestors and updateMemFS walk it part by part through nodes of ANY type, and what they do to a
-    // file or symlink that has children differs from what a flat path map would do.
-    struct Node {
-        uint8_t side = 2;                      // 0 base[idx], 1 layer[idx], 2 a directory made up by addAncestors
-        uint64_t idx = 0;
-        uint8_t kind = 0;
-        std::map<std::string, std::unique_ptr<Node>> children;
+    // nodes: ref = i for base[i], n_base + j for layer[j], -1 for the directories addAncestors makes up
+    mi_memfs::Tree t;
+    auto entry_of = [&](const mi_memfs::Node& n) -> const mi_tree_entry* {
+        return n.ref < 0 ? nullptr : (uint64_t)n.ref < n_base ? &base[n.ref] : &layer[n.ref - n_base];
     };
-    Node tree_root;
-    auto parts_of = [](const std::string& p) {                                 // pathutils.SplitPath
-        std::vector<std::string> out;
-        size_t i = 0;
-        while (i < p.size()) {
-            while (i < p.size() && p[i] == '/') ++i;
-            size_t j = i;
-            while (j < p.size() && p[j] != '/') ++j;
-            if (j > i) out.push_back(p.substr(i, j - i));
-            i = j;
-        }
-        return out;
-    };
-    auto join_abs = [](const std::vector<std::string>& ps, size_t n) {         // AbsPath(filepath.Join(parts[:n]...))
-        std::string q;
-        for (size_t k = 0; k < n; ++k) q += "/" + ps[k];
-        return mi_walk::abs_path(q);
-    };
-    auto entry_of = [&](const Node& n) -> const mi_tree_entry* {
-        return n.side == 0 ? &base[n.idx] : n.side == 1 ? &layer[n.idx] : nullptr;
-    };
-    std::string fail_msg;
-    // contentMemFile.updateMemFS (mem_layer.go:50-76): the node at dst is replaced; the new node takes over the old
-    // node's children iff the NEW header is a directory; a missing part before the last one is an error
-    auto put = [&](const std::string& dst, uint8_t side, uint64_t idx, uint8_t kind) -> bool {
-        const std::vector<std::string> ps = parts_of(dst);
-        Node* cur = &tree_root;
-        for (size_t i = 0; i < ps.size(); ++i) {
-            auto it = cur->children.find(ps[i]);
-            const bool last = i + 1 == ps.size();
-            if (it != cur->children.end()) {
-                if (!last) { cur = it->second.get(); continue; }
-                std::unique_ptr<Node> nn(new Node);
-                nn->side = side; nn->idx = idx; nn->kind = kind;
-                if (kind == 0) nn->children = std::move(it->second->children);
-                it->second = std::move(nn);
-            } else if (last) {
-                std::unique_ptr<Node> nn(new Node);
-                nn->side = side; nn->idx = idx; nn->kind = kind;
-                cur->children[ps[i]] = std::move(nn);
-            } else {
-                fail_msg = "missing intermediate directory " + ps[i] + " in " + dst;
-                return false;
-            }
-        }
-        return true;
-    };
-    // whiteoutMemFile.updateMemFS (mem_layer.go:104-125)
-    auto wipe = [&](const std::string& del) -> bool {
-        const std::vector<std::string> ps = parts_of(del);
-        Node* cur = &tree_root;
-        for (size_t i = 0; i < ps.size(); ++i) {
-            auto it = cur->children.find(ps[i]);
-            const bool last = i + 1 == ps.size();
-            if (it != cur->children.end()) {
-                if (last) cur->children.erase(it);
-                else cur = it->second.get();
-            } else if (!last) {
-                fail_msg = "missing intermediate dir " + ps[i] + " in " + del;
-                return false;
-            }                                                                   // else "Trying to whiteout nonexistent path"
-        }
-        return true;
-    };
-    // addAncestors (mem_fs.go:505-566) with inclusive = false.  Re-adding an existing ancestor "as it is" through
-    // updateMemFS changes nothing for a directory and drops the children of anything else; a symlink sends the walk
-    // to its target (filepath.Join(linkname, the remaining parts), from the tree's root) and ends it; any other
-    // non-directory lets the walk go on one part further WITHOUT descending (:535-549); what is then still missing of
-    // dst's own prefix is created as directories.
-    std::function<bool(const std::string&, int)> add_ancestors = [&](const std::string& dst, int depth) -> bool {
-        if (depth >= 1024) { fail_msg = "symlink loop at " + dst; return false; }
-        const std::vector<std::string> ps = parts_of(dst);
-        const size_t end = ps.empty() ? 0 : ps.size() - 1;
-        Node* cur = &tree_root;
-        size_t i = 0;
-        for (; i < end; ++i) {
-            auto it = cur->children.find(ps[i]);
-            if (it == cur->children.end()) break;
-            Node* n = it->second.get();
-            if (n->kind == 0) { cur = n; continue; }
-            n->children.clear();
-            if (n->kind == 2) {
-                const mi_tree_entry* e = entry_of(*n);
-                std::string target = e && e->link_target ? e->link_target : "";
-                for (size_t k = i + 1; k < ps.size(); ++k) target += "/" + ps[k];
-                target = mi_walk::clean_any(target);
-                if (!add_ancestors(target, depth + 1)) {
-                    fail_msg = "get symlink target ancestors " + target + ": " + fail_msg;
-                    return false;
-                }
-                return true;
-            }
-        }
-        for (size_t j = i; j < end; ++j)
-            if (!put(join_abs(ps, j + 1), 2, 0, 0)) return false;
-        return true;
-    };
-    // the base list: nodes at their paths, parents that are not listed made up on the way (they carry no entry)
+    bool base_has_root = false;
     for (uint64_t i = 0; i < n_base; ++i) {
-        const std::vector<std::string> ps = parts_of(path_of(base[i]));
-        Node* cur = &tree_root;
-        for (const std::string& part : ps) {
-            std::unique_ptr<Node>& slot = cur->children[part];
-            if (!slot) slot.reset(new Node);
-            cur = slot.get();
-        }
-        cur->side = 0; cur->idx = i; cur->kind = base[i].kind;                  // (the root too, if the base lists it:
-                                                                                //  it comes back, nothing ever replaces it)
+        const std::string p = path_of(base[i]);
+        if (p == "/") base_has_root = true;                                     // it comes back: nothing replaces it
+        t.load(p, (int64_t)i, base[i].kind, base[i].link_target);
     }
+    std::string fail_msg;
     // maybeAddToLayer (mem_fs.go:440-458) with createWhiteout = false
     auto apply = [&](uint64_t j, const std::string& p) -> int {
         if (p == "/") return MI_OK;                                             // "Root itself is not added to layers"
-        const std::vector<std::string> ps = parts_of(p);
-        Node* cur = &tree_root;                                                 // isUpdated (:487-503)
-        bool found = true;
-        for (const std::string& part : ps) {
-            auto it = cur->children.find(part);
-            if (it == cur->children.end()) { found = false; break; }
-            cur = it->second.get();
-        }
-        if (found) {
+        if (const mi_memfs::Node* cur = t.find(p)) {                            // isUpdated (:487-503)
             const mi_tree_entry* old = entry_of(*cur);                          // a made-up directory's mtime is "now":
             int similar = 0;                                                    // never similar to a header from a tar
             if (old && old->kind <= 3 && layer[j].kind <= 3) {                  // special files never compare equal
@@ -904,17 +951,14 @@ extern "C" int mi_entries_apply_layer_filtered(const mi_tree_entry* base, uint64
             }
             if (similar) return MI_OK;                                          // already there: the OLD entry stays
         }
-        if (!add_ancestors(p, 0)) { fail_msg = "add ancestors of " + p + ": " + fail_msg; return MI_ERR_INVALID; }
-        const std::string name = ps.back();
-        if (mi_walk::has_prefix(name, ".wh.")) {                                // memLayer.addHeader (:197-212)
-            const std::string dir = mi_walk::dir_of(p);
-            if (!wipe((dir == "/" ? "" : dir) + "/" + name.substr(4))) {
-                fail_msg = "update memfs with file " + p + ": " + fail_msg;
-                return MI_ERR_INVALID;
-            }
-            return MI_OK;
+        if (!t.add_ancestors(p, false, 0, 0, 0, nullptr)) {
+            fail_msg = "add ancestors of " + p + ": " + t.err;
+            return MI_ERR_INVALID;
         }
-        if (!put(p, 1, j, layer[j].kind)) { fail_msg = "update memfs with file " + p + ": " + fail_msg; return MI_ERR_INVALID; }
+        if (!t.add(p, (int64_t)(n_base + j), layer[j].kind, layer[j].link_target ? layer[j].link_target : "")) {
+            fail_msg = "update memfs with file " + p + ": " + t.err;
+            return MI_ERR_INVALID;
+        }
         return MI_OK;
     };
     auto failed = [&](int rc) {
@@ -934,23 +978,27 @@ extern "C" int mi_entries_apply_layer_filtered(const mi_tree_entry* base, uint64
         if (rc) return failed(rc);
     }
     // the merged tree in sorted-path order; made-up directories are not entries of either list and stay out
-    std::vector<std::pair<std::string, const Node*>> flat;
-    std::function<void(const Node&, const std::string&)> collect = [&](const Node& n, const std::string& p) {
+    std::vector<std::pair<std::string, const mi_memfs::Node*>> flat;
+    std::function<void(const mi_memfs::Node&, const std::string&)> collect = [&](const mi_memfs::Node& n,
+                                                                                 const std::string& p) {
         for (auto& kv : n.children) {
             const std::string q = p + "/" + kv.first;
-            if (kv.second->side != 2) flat.emplace_back(q, kv.second.get());
+            if (kv.second->ref >= 0) flat.emplace_back(q, kv.second.get());
             collect(*kv.second, q);
         }
     };
-    if (tree_root.side == 0) flat.emplace_back("/", &tree_root);
-    collect(tree_root, "");
-    std::sort(flat.begin(), flat.end(), [](const std::pair<std::string, const Node*>& x,
-                                           const std::pair<std::string, const Node*>& y) { return x.first < y.first; });
+    if (base_has_root) flat.emplace_back("/", &t.root);
+    collect(t.root, "");
+    std::sort(flat.begin(), flat.end(), [](const std::pair<std::string, const mi_memfs::Node*>& x,
+                                           const std::pair<std::string, const mi_memfs::Node*>& y) {
+        return x.first < y.first;
+    });
     *n_out = flat.size();
     if (cap < flat.size()) return MI_ERR_CAPACITY;
     for (size_t k = 0; k < flat.size(); ++k) {
-        from_layer[k] = flat[k].second->side;
-        index[k] = flat[k].second->idx;
+        const int64_t ref = flat[k].second->ref;
+        from_layer[k] = (uint64_t)ref >= n_base;
+        index[k] = (uint64_t)ref >= n_base ? (uint64_t)ref - n_base : (uint64_t)ref;
     }
     return MI_OK;
 }
@@ -1018,99 +1066,55 @@ struct Node {
     std::string src;
 };
 struct Fs {
-    std::map<std::string, Node> tree;      // key = absolute dst path ("/" = root)
-    std::map<std::string, Node> layer;     // memLayer.files, keyed by dst
+    mi_memfs::Tree t;                      // fs.tree; a node's ref indexes `nodes`
+    std::vector<Node> nodes;
+    std::map<std::string, int64_t> layer;  // memLayer.files: keyed by dst -- by the DELETED path for a ".wh." name
     std::string root;                      // fs.tree.src
     int64_t now = 0;
     std::string err;
     int rc = MI_OK;
 
     bool fail(int code, const std::string& m) { if (!rc) { rc = code; err = m; } return false; }
+    int64_t keep(const Node& n) { nodes.push_back(n); return (int64_t)nodes.size() - 1; }
 
-    void update_memfs(const std::string& dst, const Node& n) {          // contentMemFile.updateMemFS
-        if (n.e.kind != 0) {                                            // not a directory: children go
-            const std::string pre = dst == "/" ? dst : dst + "/";
-            for (auto it = tree.lower_bound(pre); it != tree.end() && mi_walk::has_prefix(it->first, pre);)
-                it = tree.erase(it);
-        }
-        tree[dst] = n;
-    }
-    void add_header(const std::string& dst, const Node& n) {
-        layer[dst] = n;
-        // contentMemFile.updateMemFS walks the tree part by part (mem_layer.go:57-80): every
-        // intermediate node has to exist ("missing intermediate directory"); a symlink in the
-        // path has no children, so a destination spelled THROUGH a link fails here exactly as it
-        // does in the reference (addAncestors' resolved path is only used by the createDst branch)
-        for (std::string d = mi_walk::dir_of(dst); d != "/" && d != "."; d = mi_walk::dir_of(d)) {
-            auto it = tree.find(d);
-            if (it == tree.end() || it->second.e.kind == 2) {
-                fail(MI_ERR_INVALID, "update memfs with file " + dst + ": missing intermediate directory " +
-                                         mi_walk::base_of(d) + " in " + dst);
-                return;
+    Fs() {
+        t.on_add = [this](const std::string& dst, int64_t ref) {               // memLayer.addHeader (mem_layer.go:197-212)
+            if (ref < 0) {                                                      // a parent the caller's list left out
+                Node d;
+                d.e.mode = (uint32_t)(S_IFDIR | 0755); d.e.kind = 0; d.e.relpath = dst.substr(1); d.e.mtime = now;
+                ref = keep(d);
+                if (mi_memfs::Node* n = t.find(dst)) n->ref = ref;
             }
-        }
-        update_memfs(dst, n);
-    }
-    static std::vector<std::string> split(const std::string& p) {       // pathutils.SplitPath
-        std::vector<std::string> parts;
-        size_t i = 0;
-        while (i < p.size()) {
-            while (i < p.size() && p[i] == '/') ++i;
-            size_t j = i;
-            while (j < p.size() && p[j] != '/') ++j;
-            if (j > i) parts.push_back(p.substr(i, j - i));
-            i = j;
-        }
-        return parts;
-    }
-    static std::string join(const std::vector<std::string>& parts, size_t n) {
-        std::string s;
-        for (size_t i = 0; i < n; ++i) s += "/" + parts[i];
-        return s.empty() ? "/" : s;
-    }
-    // addAncestors (mem_fs.go:505-566); returns the resolved dst
-    std::string add_ancestors(const std::string& dst, bool inclusive, int depth, uint32_t uid, uint32_t gid) {
-        if (depth >= 1024) { fail(MI_ERR_INVALID, "symlink loop at " + dst); return dst; }
-        const std::vector<std::string> parts = split(dst);
-        const size_t end = inclusive ? parts.size() : (parts.empty() ? 0 : parts.size() - 1);
-        std::string curr = "/", last_ancestor = "/";
-        size_t i = 0;
-        for (; i < end; ++i) {
-            const std::string child = (curr == "/" ? "" : curr) + "/" + parts[i];
-            auto it = tree.find(child);
-            if (it == tree.end()) break;
-            const Node n = it->second;                                  // copy: add_header mutates the map
-            add_header(child, n);
-            if (n.e.kind == 0) {
-                last_ancestor = child;
-                curr = child;
-            } else if (n.e.kind == 2) {                                 // add ancestors of the symlink target too
-                std::string target = n.e.link;
-                for (size_t k = i + 1; k < parts.size(); ++k) target += "/" + parts[k];
-                return add_ancestors(mi_walk::clean_rooted(target), inclusive, depth + 1, uid, gid);
+            const std::string name = mi_walk::base_of(dst);
+            if (mi_walk::has_prefix(name, ".wh.")) {
+                const std::string dir = mi_walk::dir_of(dst);
+                layer[(dir == "/" ? "" : dir) + "/" + name.substr(4)] = ref;
+            } else {
+                layer[dst] = ref;
             }
-            // any other type: the walk goes on below the same directory (the reference's switch
-            // has no case for it)
-        }
-        for (size_t j = i; j < end; ++j) {                              // missing intermediate directories
-            const std::string p = join(parts, j + 1);
-            Node d;
-            auto la = tree.find(last_ancestor);
-            d.e.mode = la != tree.end() ? la->second.e.mode : (uint32_t)(S_IFDIR | 0755);
+        };
+        t.make_dir = [this](const std::string& dst, const mi_memfs::Node& last_ancestor, uint32_t uid, uint32_t gid) {
+            Node d;                                                             // mem_fs.go:551-559
+            d.e.mode = last_ancestor.ref >= 0 ? nodes[last_ancestor.ref].e.mode : (uint32_t)(S_IFDIR | 0755);
             d.e.kind = 0;
-            d.e.relpath = p.substr(1);
+            d.e.relpath = dst.substr(1);
             d.e.mtime = now;
             d.e.uid = uid;
             d.e.gid = gid;
-            add_header(p, d);
-        }
-        return dst;
+            return keep(d);
+        };
+    }
+    // addAncestors (mem_fs.go:505-566); returns the resolved dst
+    std::string add_ancestors(const std::string& dst, bool inclusive, uint32_t uid, uint32_t gid) {
+        std::string resolved = dst;
+        if (!t.add_ancestors(dst, inclusive, 0, uid, gid, &resolved)) fail(MI_ERR_INVALID, "add ancestors of " + dst + ": " + t.err);
+        return resolved;
     }
     // maybeAddToLayer(l, src, dst, hdr, createWhiteout = false)
     void maybe_add(const std::string& src, const std::string& dst, Node n) {
         bool updated = true;
-        auto it = tree.find(dst);
-        if (it != tree.end()) {
+        const mi_memfs::Node* cur = t.find(dst);                                // isUpdated (:487-503)
+        if (cur && cur->ref >= 0) {
             mi_tree_entry a, b;
             auto fill = [](const Node& x, mi_tree_entry* o) {
                 memset(o, 0, sizeof *o);
@@ -1119,7 +1123,7 @@ struct Fs {
                 o->size = x.e.size; o->mtime_sec = x.e.mtime; o->mode = x.e.mode; o->kind = x.e.kind;
                 o->uid = x.e.uid; o->gid = x.e.gid; o->file_index = -1;
             };
-            fill(it->second, &a);
+            fill(nodes[cur->ref], &a);
             fill(n, &b);
             int similar = 0;
             if (a.kind <= 3 && b.kind <= 3 && mi_entry_similar(&a, &b, 0, nullptr, nullptr, &similar) != MI_OK) {
@@ -1129,10 +1133,15 @@ struct Fs {
             updated = !similar;
         }
         if (updated && dst != "/") {
-            add_ancestors(dst, false, 0, 0, 0);
+            add_ancestors(dst, false, 0, 0);
             if (rc) return;
             n.src = src;
-            add_header(dst, n);
+            // updateMemFS walks the tree part by part (mem_layer.go:57-80): every part before the last has to be a
+            // node -- of any type.  A destination spelled THROUGH a symlink therefore works one level below the
+            // link (the link node takes the child) and fails deeper ("missing intermediate directory"): what
+            // addAncestors created lies on the link's TARGET, and its resolved path is only used by the createDst branch
+            if (!t.add(dst, keep(n), n.e.kind, n.e.has_link ? n.e.link : std::string()))
+                fail(MI_ERR_INVALID, "update memfs with file " + dst + ": " + t.err);
         }
     }
 };
@@ -1144,7 +1153,7 @@ static bool eval_symlinks(const std::string& p, const std::string& root, std::st
     std::string cur = p;
     for (int walked = 0; walked <= 255;) {
         // resolve the first symlink found walking the components of cur
-        const std::vector<std::string> parts = Fs::split(cur);
+        const std::vector<std::string> parts = mi_memfs::Tree::parts(cur);
         std::string acc;
         bool replaced = false;
         for (size_t i = 0; i < parts.size(); ++i) {
@@ -1231,7 +1240,7 @@ extern "C" int mi_snapshot_copy_ops(const mi_tree_entry* tree, uint64_t n_tree, 
         r.e.mode = S_IFDIR | 0755;
         struct stat st;
         if (lstat(fs.root.c_str(), &st) == 0) { r.e.mode = st.st_mode; r.e.mtime = st.st_mtime; r.e.uid = st.st_uid; r.e.gid = st.st_gid; }
-        fs.tree["/"] = r;
+        fs.t.root.ref = fs.keep(r);
     }
     for (uint64_t i = 0; i < n_tree; ++i) {
         const mi_tree_entry& e = tree[i];
@@ -1242,7 +1251,7 @@ extern "C" int mi_snapshot_copy_ops(const mi_tree_entry* tree, uint64_t n_tree, 
         n.e.kind = e.kind; n.e.mode = e.mode; n.e.mtime = e.mtime_sec; n.e.uid = e.uid; n.e.gid = e.gid; n.e.size = e.size;
         if (e.link_target) { n.e.link = e.link_target; n.e.has_link = true; }
         n.src = fs.root == "/" ? p : fs.root + (p == "/" ? "" : p);
-        fs.tree[p] = n;
+        fs.t.load(p, fs.keep(n), n.e.kind, e.link_target);
     }
     for (uint64_t k = 0; k < n_ops && !fs.rc; ++k) {
         const mi_copy_op& c = ops[k];
@@ -1261,7 +1270,7 @@ extern "C" int mi_snapshot_copy_ops(const mi_tree_entry* tree, uint64_t n_tree, 
             if (!S_ISDIR(st.st_mode)) create_dst = false;            // case 1: file onto file
         }
         if (create_dst) {
-            std::string resolved = fs.add_ancestors(mi_walk::abs_path(dst), true, 0, c.uid, c.gid);
+            std::string resolved = fs.add_ancestors(mi_walk::abs_path(dst), true, c.uid, c.gid);
             if (fs.rc) break;
             if (resolved.empty() || resolved.back() != '/') resolved += "/";
             dst = resolved;
@@ -1306,7 +1315,7 @@ extern "C" int mi_snapshot_copy_ops(const mi_tree_entry* tree, uint64_t n_tree, 
     }
     if (fs.rc) { put_err(fs.err); return fs.rc; }
     mi_copy_layer* l = new mi_copy_layer();
-    for (auto& kv : fs.layer) l->nodes.push_back(kv.second);             // std::map order == sort.Strings order
+    for (auto& kv : fs.layer) l->nodes.push_back(fs.nodes[kv.second]);   // std::map order == sort.Strings order
     *out = l;
     if (n_entries) *n_entries = l->nodes.size();
     return MI_OK;

@@ -196,7 +196,7 @@ def test_apply_layer_equals_update_from_tar_reader(layers):
             event("the reference fails: " + " ".join(str(e).split(" ")[:2]))
             with pytest.raises(M.MiError) as ei:
                 M.apply_layer(merged, layer)
-            assert ei.value.code == -1 and str(e) in str(ei.value)          # MI_ERR_INVALID
+            assert ei.value.code == -1 and str(e)[:150] in str(ei.value)    # MI_ERR_INVALID (a looping path is cut short)
             break
         merged = M.apply_layer(merged, layer)
         want = flatten(tree)

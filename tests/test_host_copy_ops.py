@@ -133,6 +133,40 @@ def test_destination_through_a_symlink(tmp_path):
     assert "missing intermediate directory" in str(ei.value)
 
 
+def test_file_copied_to_a_name_right_below_a_symlink(tmp_path):
+    """`COPY f /lib/f` on an image whose /lib is a link to usr/lib (single file source: no createDst, the destination
+    stays spelled through the link).  maybeAddToLayer -> addAncestors carries the link and the existing ancestors of
+    its target (mem_fs.go:531-548), then contentMemFile.updateMemFS descends into the LINK's node -- any node will
+    do, mem_layer.go:57-68 -- and hangs the file below it: the layer holds lib, lib/f and usr, usr/lib."""
+    tree = _tree(tmp_path, [("/usr/lib", "d", ""), ("/lib", "l", str(tmp_path / "usr/lib")), ("/src/f", "f", "x")])
+    got = _by_dst(M.copy_ops_layer(tree, str(tmp_path), [_op(tmp_path, ["/src/f"], "/lib/f")]))
+    assert sorted(got) == ["/lib", "/lib/f", "/usr", "/usr/lib"]
+    assert got["/lib"]["kind"] == M.KIND_SYMLINK and got["/lib/f"]["src"] == str(tmp_path / "src/f")
+    # a second file below the link in the same layer: the link is re-added on the way and comes back WITHOUT the child
+    # it had in the tree (updateMemFS lets only directories keep children) -- the layer still holds both files
+    got = _by_dst(M.copy_ops_layer(tree, str(tmp_path), [_op(tmp_path, ["/src/f"], "/lib/f"),
+                                                          _op(tmp_path, ["/src/f"], "/lib/g")]))
+    assert sorted(got) == ["/lib", "/lib/f", "/lib/g", "/usr", "/usr/lib"]
+
+
+def test_a_source_named_like_a_whiteout_is_filed_under_the_path_it_deletes(tmp_path):
+    """memLayer.addHeader (mem_layer.go:197-212): a dst whose base name starts with ".wh." becomes a whiteoutMemFile
+    keyed by the DELETED path, so rangeFiles' sort.Strings (:232-244) places it there -- and it removes that path
+    from the tree, so a later copy of the same file is new again."""
+    tree = _tree(tmp_path, [("/dst", "d", ""), ("/dst/zz", "f", "old"), ("/src/a", "f", "1"), ("/src/.wh.zz", "f", ""),
+                            ("/src/m", "f", "2"), ("/again/zz", "f", "old")])
+    layer = M.copy_ops_layer(tree, str(tmp_path), [_op(tmp_path, ["/src"], "/dst/")])
+    assert [e["relpath"] for e in layer] == ["dst", "dst/a", "dst/m", "dst/.wh.zz"]
+    assert [e["relpath"] for e in layer] == [layer[k]["relpath"] for k in M.commit_order([e["relpath"] for e in layer])]
+    st = os.lstat(tmp_path / "dst/zz")
+    os.utime(tmp_path / "again/zz", (st.st_mtime, st.st_mtime))
+    own = {"uid": st.st_uid, "gid": st.st_gid}
+    same = dict(_op(tmp_path, ["/again/zz"], "/dst/zz"), **own)
+    assert M.copy_ops_layer(tree, str(tmp_path), [same]) == []                        # similar header: nothing to add
+    both = M.copy_ops_layer(tree, str(tmp_path), [dict(_op(tmp_path, ["/src/.wh.zz"], "/dst/"), **own), same])
+    assert "dst/zz" in [e["relpath"] for e in both]        # (the marker and the file share one key: the file, added last, stays)
+
+
 def test_symlink_loop_and_errors(tmp_path):
     tree = _tree(tmp_path, [("/a", "l", str(tmp_path / "a" / "b")), ("/src/f", "f", "x")])   # /a -> /a/b -> ...
     with pytest.raises(M.MiError) as ei:
