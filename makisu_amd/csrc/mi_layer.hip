@@ -209,9 +209,7 @@ private:
         Block in;
         Bytes out;
         uint32_t crc = 0;
-        bool ok = true, done = false;
-        std::mutex m;
-        std::condition_variable cv;
+        bool ok = true, done = false;                             // guarded by pm_, announced on dcv_
     };
     void emit(const uint8_t* p, size_t n) {
         sha_.update(p, n);
@@ -223,8 +221,8 @@ private:
         std::shared_ptr<Job> j = inflight_.front();
         inflight_.pop_front();
         {
-            std::unique_lock<std::mutex> lk(j->m);
-            j->cv.wait(lk, [&] { return j->done; });
+            std::unique_lock<std::mutex> lk(pm_);
+            dcv_.wait(lk, [&] { return j->done; });
         }
         if (!j->ok) { set_error("deflate failed"); return; }
         if (failed()) return;
@@ -259,11 +257,11 @@ private:
                 j->crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), j->in->data(), (uInt)j->in->size());
             }
             {
-                std::lock_guard<std::mutex> g(j->m);
+                std::lock_guard<std::mutex> g(pm_);
                 j->ok = ok;
                 j->done = true;
             }
-            j->cv.notify_all();
+            dcv_.notify_all();
         }
         if (ready) deflateEnd(&z);
     }
@@ -280,7 +278,7 @@ private:
     size_t window_ = 2;
     std::vector<std::thread> pool_;
     std::mutex pm_;
-    std::condition_variable pcv_;
+    std::condition_variable pcv_, dcv_;                            // work to do / a job done
     std::deque<std::shared_ptr<Job>> todo_, inflight_;
     bool stop_ = false;
     uint32_t crc_ = 0;
