@@ -573,6 +573,23 @@ typedef struct {
  * resolved, hence absolute) dst of every op.  Host logic.                                                        */
 int  mi_copy_op_resolve(uint64_t n_srcs, const char* work_dir, const char* dst, char* dst_out, uint64_t cap,
                         char* err, uint64_t err_cap);
+/* The rest of the caller's side of a COPY/ADD step.
+ * mi_resolve_chown: NewCopyOperation's --chown handling (lib/snapshot/copy_op.go:51-60 -> utils.ResolveChown,
+ *   lib/utils/utils.go:186-228): "" = 0:0; "<user>[:<group>]", each a decimal number or a name from the user / group
+ *   database; no group = the uid; chown together with preserve_owner (--archive) is an error.  MI_ERR_INVALID + the
+ *   reference's message in err.
+ * mi_path_match: path/filepath.Match of the Go toolchain the reference builds with ('*' and '?' never match '/',
+ *   "[^a-c]" classes on runes, '\\' escapes; MI_ERR_INVALID = ErrBadPattern).
+ * mi_context_sources: addCopyStep.resolveFromPaths (lib/builder/step/add_copy_step.go:171-185): every source is joined
+ *   to the context root and expanded with filepath.Glob (matches of one pattern in sorted order); a pattern that
+ *   matches nothing, or is malformed, stands for itself.  out = the resolved paths, NUL-terminated, back to back (*n_out
+ *   paths, *bytes_out bytes; MI_ERR_CAPACITY if cap is smaller: call with cap 0 to size).  Each goes to
+ *   mi_batch_add_tree(..., rel_base = context dir, MI_TREE_CONTEXT) in this order for the cache ID, and -- trimmed of
+ *   the root -- into mi_copy_op.srcs.  Host logic.                                                                */
+int  mi_resolve_chown(const char* chown, int preserve_owner, int64_t* uid, int64_t* gid, char* err, uint64_t err_cap);
+int  mi_path_match(const char* pattern, const char* name, int* matched);
+int  mi_context_sources(const char* context_root, const char* const* from_paths, uint64_t n_paths, char* out,
+                        uint64_t cap, uint64_t* n_out, uint64_t* bytes_out);
 typedef struct mi_copy_layer mi_copy_layer;
 int  mi_snapshot_copy_ops(const mi_tree_entry* tree, uint64_t n_tree, const char* tree_root,
                           const mi_copy_op* ops, uint64_t n_ops, int64_t now_sec,

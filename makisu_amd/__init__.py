@@ -241,6 +241,9 @@ def load_library(rebuild=False):
         "mi_snapshot_copy_ops": ([C.POINTER(TreeEntry), u64, C.c_char_p, C.POINTER(CopyOp), u64, C.c_int64,
                                   C.POINTER(vp), u64p, C.c_char_p, u64], C.c_int),
         "mi_copy_op_resolve": ([u64, C.c_char_p, C.c_char_p, C.c_char_p, u64, C.c_char_p, u64], C.c_int),
+        "mi_resolve_chown": ([C.c_char_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_char_p, u64], C.c_int),
+        "mi_path_match": ([C.c_char_p, C.c_char_p, C.POINTER(C.c_int)], C.c_int),
+        "mi_context_sources": ([C.c_char_p, C.POINTER(C.c_char_p), u64, C.c_char_p, u64, u64p, u64p], C.c_int),
         "mi_copy_layer_entries": ([vp, C.POINTER(TreeEntry), C.POINTER(C.c_char_p), u64], C.c_int),
         "mi_copy_layer_free": ([vp], None),
         "mi_layer_config_default": ([C.POINTER(LayerConfig)], C.c_int),
@@ -471,6 +474,40 @@ def copy_op_resolve(n_srcs, work_dir, dst):
     if rc:
         raise MiError(rc, err.value.decode(errors="replace"))
     return os.fsdecode(out.value)
+
+
+def resolve_chown(chown, preserve_owner=False):
+    """mi_resolve_chown: (uid, gid) of a --chown string, the way utils.ResolveChown reads it."""
+    uid, gid = C.c_int64(), C.c_int64()
+    err = C.create_string_buffer(300)
+    rc = load_library().mi_resolve_chown(os.fsencode(chown), int(preserve_owner), C.byref(uid), C.byref(gid), err, len(err))
+    if rc:
+        raise MiError(rc, err.value.decode(errors="replace"))
+    return uid.value, gid.value
+
+
+def path_match(pattern, name):
+    """mi_path_match: Go's filepath.Match; raises MiError(MI_ERR_INVALID) for ErrBadPattern."""
+    m = C.c_int()
+    rc = load_library().mi_path_match(os.fsencode(pattern), os.fsencode(name), C.byref(m))
+    if rc:
+        raise MiError(rc, "syntax error in pattern")
+    return bool(m.value)
+
+
+def context_sources(context_root, from_paths):
+    """mi_context_sources: addCopyStep.resolveFromPaths -- the sources joined to the context root and globbed."""
+    arr = (C.c_char_p * max(len(from_paths), 1))(*[os.fsencode(x) for x in from_paths])
+    n, nbytes = C.c_uint64(), C.c_uint64()
+    L = load_library()
+    rc = L.mi_context_sources(os.fsencode(context_root), arr, len(from_paths), None, 0, C.byref(n), C.byref(nbytes))
+    if rc not in (0, -7):
+        raise MiError(rc, "mi_context_sources")
+    buf = C.create_string_buffer(max(nbytes.value, 1))
+    rc = L.mi_context_sources(os.fsencode(context_root), arr, len(from_paths), buf, nbytes.value, C.byref(n), C.byref(nbytes))
+    if rc:
+        raise MiError(rc, "mi_context_sources")
+    return [os.fsdecode(x) for x in buf.raw[:nbytes.value].split(b"\0")[:n.value]]
 
 
 def copy_ops_layer(tree, tree_root, ops, now_sec=0):

@@ -32,6 +32,8 @@
 #include <dirent.h>
 #include <errno.h>
 #include <fcntl.h>
+#include <grp.h>
+#include <pwd.h>
 #include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -1205,6 +1207,261 @@ static std::string copy_check_params(uint64_t n_srcs, const char* work_dir, cons
     if ((dst.empty() || dst[0] != '/') && !(work_dir && work_dir[0] == '/'))
         return "dst is not absolute path, must specify absolute working directory";
     return "";
+}
+
+// ---- the caller's side of a COPY/ADD step: --chown and the source patterns ------------------------------------------
+//
+// utils.ResolveChown (lib/utils/utils.go:186-228): "<user>[:<group>]", each a number (strconv.Atoi: an optional sign and
+// decimal digits) or a name looked up in the user / group database; no group = the uid; more than one ':' is an error.
+static bool go_atoi(const std::string& t, long long* v) {
+    size_t i = 0;
+    if (!t.empty() && (t[0] == '+' || t[0] == '-')) i = 1;
+    if (i == t.size()) return false;
+    long long x = 0;
+    for (size_t k = i; k < t.size(); ++k) {
+        if (t[k] < '0' || t[k] > '9') return false;
+        x = x * 10 + (t[k] - '0');
+        if (x > 0x7fffffffffffll / 16) return false;                            // out of int range long before it matters
+    }
+    *v = t[0] == '-' ? -x : x;
+    return true;
+}
+extern "C" int mi_resolve_chown(const char* chown, int preserve_owner, int64_t* uid, int64_t* gid, char* err,
+                                uint64_t err_cap) {
+    auto put_err = [&](const std::string& m) { if (err && err_cap) snprintf(err, (size_t)err_cap, "%s", m.c_str()); };
+    if (!uid || !gid) return MI_ERR_INVALID;
+    *uid = *gid = 0;
+    const std::string c = chown ? chown : "";
+    if (!c.empty() && preserve_owner) { put_err("both chown and archive are true"); return MI_ERR_INVALID; }   // copy_op.go:52-55
+    if (c.empty()) return MI_OK;
+    std::vector<std::string> split(1);
+    for (char ch : c) { if (ch == ':') split.emplace_back(); else split.back() += ch; }
+    if (split.size() > 2) { put_err("resolve chown str: failed to split on ':'"); return MI_ERR_INVALID; }
+    long long u = 0, g = 0;
+    if (!go_atoi(split[0], &u)) {
+        struct passwd pw, *res = nullptr;
+        std::vector<char> buf(1 << 16);
+        if (split[0].empty() || getpwnam_r(split[0].c_str(), &pw, buf.data(), buf.size(), &res) != 0 || !res) {
+            put_err("resolve chown str: failed to look up user '" + split[0] + "'");
+            return MI_ERR_INVALID;
+        }
+        u = (long long)pw.pw_uid;
+    }
+    if (split.size() == 1) { *uid = *gid = u; return MI_OK; }
+    if (!go_atoi(split[1], &g)) {
+        struct group gr, *res = nullptr;
+        std::vector<char> buf(1 << 16);
+        if (split[1].empty() || getgrnam_r(split[1].c_str(), &gr, buf.data(), buf.size(), &res) != 0 || !res) {
+            put_err("resolve chown str: failed to look up group '" + split[0] + "'");   // (the reference names the USER here, :221)
+            return MI_ERR_INVALID;
+        }
+        g = (long long)gr.gr_gid;
+    }
+    *uid = u; *gid = g;
+    return MI_OK;
+}
+
+// path/filepath.Match and Glob as the Go 1.14 toolchain the reference builds with defines them (Makefile:34) --
+// resolveFromPaths (lib/builder/step/add_copy_step.go:171-185) runs every source of a COPY/ADD through Glob:
+//   '*' any run of non-'/' characters, '?' one non-'/' character, '[' ['^'] ranges ']' a character class (not empty;
+//   lo '-' hi; characters are runes), '\\' escapes the next character; the whole name has to match.  A malformed
+//   pattern is ErrBadPattern -- but only where matching GETS to the bad part (1.14 stops at the end of the name).
+namespace mi_glob {
+
+static size_t rune_at(const std::string& s, size_t i, uint32_t* r) {           // utf8.DecodeRuneInString
+    const unsigned char c = (unsigned char)s[i];
+    auto cont = [&](size_t k) { return i + k < s.size() && ((unsigned char)s[i + k] & 0xC0) == 0x80; };
+    if (c < 0x80) { *r = c; return 1; }
+    if (c >= 0xC2 && c <= 0xDF && cont(1)) { *r = ((c & 0x1Fu) << 6) | ((unsigned char)s[i + 1] & 0x3Fu); return 2; }
+    if (c >= 0xE0 && c <= 0xEF && cont(1) && cont(2)) {
+        const uint32_t v = ((c & 0x0Fu) << 12) | (((unsigned char)s[i + 1] & 0x3Fu) << 6) | ((unsigned char)s[i + 2] & 0x3Fu);
+        if (v >= 0x800 && !(v >= 0xD800 && v <= 0xDFFF)) { *r = v; return 3; }
+    }
+    if (c >= 0xF0 && c <= 0xF4 && cont(1) && cont(2) && cont(3)) {
+        const uint32_t v = ((c & 0x07u) << 18) | (((unsigned char)s[i + 1] & 0x3Fu) << 12) |
+                           (((unsigned char)s[i + 2] & 0x3Fu) << 6) | ((unsigned char)s[i + 3] & 0x3Fu);
+        if (v >= 0x10000 && v <= 0x10FFFF) { *r = v; return 4; }
+    }
+    *r = 0xFFFD;                                                                // RuneError, width 1
+    return 1;
+}
+
+// getEsc: one possibly escaped character of a class; false = ErrBadPattern
+static bool get_esc(const std::string& chunk, size_t* at, uint32_t* r) {
+    size_t i = *at;
+    if (i >= chunk.size() || chunk[i] == '-' || chunk[i] == ']') return false;
+    if (chunk[i] == '\\') { if (++i >= chunk.size()) return false; }
+    const size_t n = rune_at(chunk, i, r);
+    bool ok = !(*r == 0xFFFD && n == 1);
+    i += n;
+    if (i >= chunk.size()) ok = false;
+    *at = i;
+    return ok;
+}
+
+// matchChunk: does chunk (no '*') match a prefix of s[from:]?  rest = where the match ends
+static bool match_chunk(const std::string& chunk, const std::string& s, size_t from, size_t* rest, bool* bad) {
+    size_t c = 0, i = from;
+    while (c < chunk.size()) {
+        if (i >= s.size()) return false;
+        switch (chunk[c]) {
+            case '[': {
+                uint32_t r;
+                i += rune_at(s, i, &r);
+                if (++c >= chunk.size()) { *bad = true; return false; }
+                const bool negated = chunk[c] == '^';
+                if (negated) ++c;
+                bool match = false;
+                for (int nrange = 0;; ++nrange) {
+                    if (c < chunk.size() && chunk[c] == ']' && nrange > 0) { ++c; break; }
+                    uint32_t lo, hi;
+                    if (!get_esc(chunk, &c, &lo)) { *bad = true; return false; }
+                    hi = lo;
+                    if (chunk[c] == '-') {
+                        ++c;
+                        if (!get_esc(chunk, &c, &hi)) { *bad = true; return false; }
+                    }
+                    if (lo <= r && r <= hi) match = true;
+                }
+                if (match == negated) return false;
+                break;
+            }
+            case '?': {
+                if (s[i] == '/') return false;
+                uint32_t r;
+                i += rune_at(s, i, &r);
+                ++c;
+                break;
+            }
+            case '\\':
+                if (++c >= chunk.size()) { *bad = true; return false; }
+                /* fallthrough */
+            default:
+                if (chunk[c] != s[i]) return false;
+                ++i; ++c;
+        }
+    }
+    *rest = i;
+    return true;
+}
+
+static bool match(const std::string& pattern, const std::string& name, bool* bad) {
+    size_t p = 0, n = 0;
+    *bad = false;
+    while (p < pattern.size()) {
+        bool star = false;                                                      // scanChunk
+        while (p < pattern.size() && pattern[p] == '*') { ++p; star = true; }
+        bool inrange = false;
+        size_t e = p;
+        for (; e < pattern.size(); ++e) {
+            const char ch = pattern[e];
+            if (ch == '\\') { if (e + 1 < pattern.size()) ++e; }
+            else if (ch == '[') inrange = true;
+            else if (ch == ']') inrange = false;
+            else if (ch == '*' && !inrange) break;
+        }
+        const std::string chunk = pattern.substr(p, e - p);
+        p = e;
+        if (star && chunk.empty()) return name.find('/', n) == std::string::npos;   // a trailing * takes the rest
+        size_t t = 0;
+        const bool ok = match_chunk(chunk, name, n, &t, bad);
+        if (ok && (t == name.size() || p < pattern.size())) { n = t; continue; }
+        if (*bad) return false;
+        if (star) {
+            bool advanced = false;
+            for (size_t i = n; i < name.size() && name[i] != '/'; ++i) {
+                if (match_chunk(chunk, name, i + 1, &t, bad)) {
+                    if (p >= pattern.size() && t < name.size()) continue;       // last chunk: the name has to end here
+                    n = t;
+                    advanced = true;
+                    break;
+                }
+                if (*bad) return false;
+            }
+            if (advanced) continue;
+        }
+        return false;
+    }
+    return n == name.size();
+}
+
+static bool has_meta(const std::string& s) { return s.find_first_of("*?[\\") != std::string::npos; }
+
+// glob(dir, pattern, matches): the names of dir that match, sorted, joined to dir; I/O errors are ignored
+static bool glob_dir(const std::string& dir, const std::string& pattern, std::vector<std::string>* out) {
+    struct stat st;
+    if (stat(dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return true;
+    DIR* d = opendir(dir.c_str());
+    if (!d) return true;
+    std::vector<std::string> names;
+    while (struct dirent* de = readdir(d)) {
+        const std::string n = de->d_name;
+        if (n != "." && n != "..") names.push_back(n);
+    }
+    closedir(d);
+    std::sort(names.begin(), names.end());
+    for (const std::string& n : names) {
+        bool bad = false;
+        if (match(pattern, n, &bad)) {
+            std::string j = dir == "." ? n : (dir.back() == '/' ? dir + n : dir + "/" + n);   // filepath.Join(dir, n)
+            out->push_back(dir == "." ? j : (dir[0] == '/' ? mi_walk::clean_rooted(j) : mi_walk::clean_any(j)));
+        }
+        if (bad) return false;
+    }
+    return true;
+}
+
+static bool glob(const std::string& pattern, std::vector<std::string>* out) {   // false = ErrBadPattern
+    bool bad = false;
+    match(pattern, "", &bad);
+    if (bad) return false;
+    if (!has_meta(pattern)) {
+        struct stat st;
+        if (lstat(pattern.c_str(), &st) == 0) out->push_back(pattern);
+        return true;
+    }
+    const size_t cut = pattern.find_last_of('/');                               // filepath.Split
+    std::string dir = cut == std::string::npos ? "" : pattern.substr(0, cut + 1);
+    const std::string file = cut == std::string::npos ? pattern : pattern.substr(cut + 1);
+    if (dir.empty()) dir = ".";                                                 // cleanGlobPath
+    else if (dir != "/") dir.pop_back();
+    if (!has_meta(dir)) return glob_dir(dir, file, out);
+    if (dir == pattern) return false;                                           // "Prevent infinite recursion"
+    std::vector<std::string> dirs;
+    if (!glob(dir, &dirs)) return false;
+    for (const std::string& d : dirs)
+        if (!glob_dir(d, file, out)) return false;
+    return true;
+}
+
+}  // namespace mi_glob
+
+extern "C" int mi_path_match(const char* pattern, const char* name, int* matched) {
+    if (!pattern || !name || !matched) return MI_ERR_INVALID;
+    bool bad = false;
+    *matched = mi_glob::match(pattern, name, &bad) ? 1 : 0;
+    return bad ? MI_ERR_INVALID : MI_OK;                                        // ErrBadPattern
+}
+
+// resolveFromPaths: every source joined to the context root and globbed; no match (or a bad pattern) = the joined
+// path itself.  out = the resolved paths, NUL-terminated, back to back.
+extern "C" int mi_context_sources(const char* context_root, const char* const* from_paths, uint64_t n_paths,
+                                  char* out, uint64_t cap, uint64_t* n_out, uint64_t* bytes_out) {
+    if (!context_root || (n_paths && !from_paths) || !n_out || !bytes_out || (cap && !out)) return MI_ERR_INVALID;
+    std::string all;
+    uint64_t n = 0;
+    for (uint64_t i = 0; i < n_paths; ++i) {
+        const std::string joined0 = std::string(context_root) + "/" + (from_paths[i] ? from_paths[i] : "");
+        const std::string source = joined0[0] == '/' ? mi_walk::clean_rooted(joined0) : mi_walk::clean_any(joined0);
+        std::vector<std::string> m;
+        if (!mi_glob::glob(source, &m) || m.empty()) m.assign(1, source);
+        for (const std::string& x : m) { all += x; all.push_back('\0'); ++n; }
+    }
+    *n_out = n;
+    *bytes_out = all.size();
+    if (cap < all.size()) return MI_ERR_CAPACITY;
+    if (!all.empty()) memcpy(out, all.data(), all.size());
+    return MI_OK;
 }
 
 extern "C" int mi_copy_op_resolve(uint64_t n_srcs, const char* work_dir, const char* dst, char* dst_out,
