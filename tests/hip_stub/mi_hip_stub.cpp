@@ -1,0 +1,249 @@
+// mi_hip_stub.cpp -- a TEST DOUBLE for the HIP runtime: the thirty hip* entry points libmakisu_mi.so imports, implemented
+// on host memory and host threads, so that the library's HOST side -- reader threads, pinned slabs, the inline window,
+// arena growth, the order of copies, events and waits, the API's state machine -- runs on a box without a GPU, and runs
+// under ThreadSanitizer.  Test infrastructure only (LD_PRELOAD=<this .so>, tests/test_host_hip_double.py); nothing in
+// the product knows about it.
+//
+// What it models, and how strictly:
+//   * device memory is host memory (hipMalloc = aligned_alloc), filled with 0xDD so that a byte no copy ever wrote is
+//     not a plausible zero;
+//   * a stream is a THREAD with a queue: hipMemcpyAsync / hipMemsetAsync / event records / event waits / kernel
+//     launches are queued and executed in order by that thread, asynchronously to the caller -- also for pageable host
+//     memory, which the real runtime stages synchronously; the caller's buffer must stay untouched until the stream has
+//     been synchronised, or the race detector sees the stream's thread and the caller on the same bytes;
+//   * streams are independent of each other (all are "non-blocking"): only hipStreamSynchronize, hipEventSynchronize and
+//     hipStreamWaitEvent order work across them.  The synchronous hipMemcpy copies at once, on the calling thread,
+//     WITHOUT waiting for any stream -- the NULL stream's implicit synchronisation does not exist for non-blocking
+//     streams, so relying on it is a bug the detector should see;
+//   * kernels do not run: a launch is a queued no-op (device results stay 0xDD).  MI_HIP_STUB_KERNEL_US=<n> makes each
+//     launch take n microseconds of stream time, to move the interleavings;
+//   * MI_HIP_STUB_COPY_US=<n>: every queued copy sleeps n microseconds before it copies (widens race windows).
+#include <hip/hip_runtime_api.h>
+
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <thread>
+
+namespace {
+
+long env_us(const char* name) {
+    const char* e = getenv(name);
+    return e ? atol(e) : 0;
+}
+const long kCopyUs = env_us("MI_HIP_STUB_COPY_US");
+const long kKernelUs = env_us("MI_HIP_STUB_KERNEL_US");
+
+struct Stream {
+    std::mutex mu;
+    std::condition_variable cv_work, cv_idle;
+    std::deque<std::function<void()>> q;
+    bool busy = false, stop = false;
+    std::thread th;
+    Stream() : th([this] { run(); }) {}
+    ~Stream() {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            stop = true;
+        }
+        cv_work.notify_all();
+        th.join();
+    }
+    void run() {
+        for (;;) {
+            std::function<void()> f;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [&] { return stop || !q.empty(); });
+                if (q.empty()) return;
+                f = std::move(q.front());
+                q.pop_front();
+                busy = true;
+            }
+            f();
+            {
+                std::lock_guard<std::mutex> g(mu);
+                busy = false;
+            }
+            cv_idle.notify_all();
+        }
+    }
+    void push(std::function<void()> f) {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            q.push_back(std::move(f));
+        }
+        cv_work.notify_one();
+    }
+    void sync() {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_idle.wait(lk, [&] { return q.empty() && !busy; });
+    }
+};
+
+struct Event {
+    std::mutex mu;
+    std::condition_variable cv;
+    uint64_t recorded = 0, done = 0;                // generations: a record is complete when done >= its number
+    std::chrono::steady_clock::time_point at;
+};
+
+Stream* null_stream() {                              // the library never uses it; kept for completeness
+    static Stream* s = new Stream();
+    return s;
+}
+Stream* S(hipStream_t s) { return s ? (Stream*)s : null_stream(); }
+
+struct LaunchCfg { dim3 grid, block; size_t shmem; hipStream_t stream; };
+thread_local LaunchCfg t_cfg;
+thread_local int t_device = 0;
+
+std::atomic<long> g_live_allocs{0};
+
+}  // namespace
+
+extern "C" {
+
+hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+hipError_t hipGetDevice(int* d) { *d = t_device; return hipSuccess; }
+hipError_t hipSetDevice(int d) { if (d != 0) return hipErrorInvalidDevice; t_device = d; return hipSuccess; }
+hipError_t hipGetDevicePropertiesR0600(hipDeviceProp_tR0600* p, int d) {
+    if (d != 0) return hipErrorInvalidDevice;
+    memset(p, 0, sizeof *p);
+    snprintf(p->name, sizeof p->name, "HIP test double (no GPU)");
+    snprintf(p->gcnArchName, sizeof p->gcnArchName, "gfx950:sramecc+:xnack-");
+    p->multiProcessorCount = 256;
+    p->totalGlobalMem = 288ull << 30;
+    p->clockRate = 2400000;
+    p->warpSize = 64;
+    p->maxThreadsPerBlock = 1024;
+    p->sharedMemPerBlock = 160 << 10;
+    p->maxSharedMemoryPerMultiProcessor = 160 << 10;
+    return hipSuccess;
+}
+const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : "error (HIP test double)"; }
+hipError_t hipGetLastError(void) { return hipSuccess; }
+
+hipError_t hipMalloc(void** p, size_t n) {
+    void* q = aligned_alloc(4096, (n + 4095) / 4096 * 4096 + 4096);
+    if (!q) return hipErrorOutOfMemory;
+    memset(q, 0xDD, n);
+    *p = q;
+    ++g_live_allocs;
+    return hipSuccess;
+}
+hipError_t hipFree(void* p) { if (p) { free(p); --g_live_allocs; } return hipSuccess; }
+hipError_t hipHostMalloc(void** p, size_t n, unsigned int) {
+    void* q = aligned_alloc(4096, (n + 4095) / 4096 * 4096 + 4096);
+    if (!q) return hipErrorOutOfMemory;
+    memset(q, 0xCC, n);
+    *p = q;
+    ++g_live_allocs;
+    return hipSuccess;
+}
+hipError_t hipHostFree(void* p) { if (p) { free(p); --g_live_allocs; } return hipSuccess; }
+
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned int) { *s = (hipStream_t) new Stream(); return hipSuccess; }
+hipError_t hipStreamDestroy(hipStream_t s) { if (s) { ((Stream*)s)->sync(); delete (Stream*)s; } return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t s) { S(s)->sync(); return hipSuccess; }
+
+hipError_t hipMemcpy(void* dst, const void* src, size_t n, hipMemcpyKind) {
+    if (n) memmove(dst, src, n);                     // at once, on the caller: no implicit wait for any stream
+    return hipSuccess;
+}
+hipError_t hipMemcpyAsync(void* dst, const void* src, size_t n, hipMemcpyKind, hipStream_t s) {
+    S(s)->push([=] {
+        if (kCopyUs) usleep((useconds_t)kCopyUs);
+        if (n) memmove(dst, src, n);
+    });
+    return hipSuccess;
+}
+hipError_t hipMemsetAsync(void* dst, int v, size_t n, hipStream_t s) {
+    S(s)->push([=] { if (n) memset(dst, v, n); });
+    return hipSuccess;
+}
+
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = (hipEvent_t) new Event(); return hipSuccess; }
+hipError_t hipEventCreate(hipEvent_t* e) { return hipEventCreateWithFlags(e, 0); }
+hipError_t hipEventDestroy(hipEvent_t e) { delete (Event*)e; return hipSuccess; }
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) {
+    Event* ev = (Event*)e;
+    uint64_t gen;
+    {
+        std::lock_guard<std::mutex> g(ev->mu);
+        gen = ++ev->recorded;
+    }
+    S(s)->push([ev, gen] {
+        {
+            std::lock_guard<std::mutex> g(ev->mu);
+            if (ev->done < gen) ev->done = gen;
+            ev->at = std::chrono::steady_clock::now();
+        }
+        ev->cv.notify_all();
+    });
+    return hipSuccess;
+}
+hipError_t hipEventSynchronize(hipEvent_t e) {
+    Event* ev = (Event*)e;
+    std::unique_lock<std::mutex> lk(ev->mu);
+    const uint64_t gen = ev->recorded;
+    ev->cv.wait(lk, [&] { return ev->done >= gen; });
+    return hipSuccess;
+}
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned int) {
+    Event* ev = (Event*)e;
+    uint64_t gen;
+    {
+        std::lock_guard<std::mutex> g(ev->mu);
+        gen = ev->recorded;                          // the most recent record at the time of the call
+    }
+    S(s)->push([ev, gen] {
+        std::unique_lock<std::mutex> lk(ev->mu);
+        ev->cv.wait(lk, [&] { return ev->done >= gen; });
+    });
+    return hipSuccess;
+}
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
+    Event *x = (Event*)a, *y = (Event*)b;
+    std::chrono::steady_clock::time_point ta, tb;
+    {
+        std::lock_guard<std::mutex> g(x->mu);
+        ta = x->at;
+    }
+    {
+        std::lock_guard<std::mutex> g(y->mu);
+        tb = y->at;
+    }
+    *ms = std::chrono::duration<float, std::milli>(tb - ta).count();
+    return hipSuccess;
+}
+
+hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+hipError_t hipLaunchKernel(const void*, dim3, dim3, void**, size_t, hipStream_t s) {
+    S(s)->push([] { if (kKernelUs) usleep((useconds_t)kKernelUs); });
+    return hipSuccess;
+}
+hipError_t __hipPushCallConfiguration(dim3 grid, dim3 block, size_t shmem, hipStream_t s) {
+    t_cfg = LaunchCfg{grid, block, shmem, s};
+    return hipSuccess;
+}
+hipError_t __hipPopCallConfiguration(dim3* grid, dim3* block, size_t* shmem, hipStream_t* s) {
+    *grid = t_cfg.grid; *block = t_cfg.block; *shmem = t_cfg.shmem; *s = t_cfg.stream;
+    return hipSuccess;
+}
+void** __hipRegisterFatBinary(const void*) { static void* h[1]; return h; }
+void __hipRegisterFunction(void**, const void*, char*, const char*, unsigned int, void*, void*, void*, void*, int*) {}
+void __hipRegisterVar(void**, void*, char*, const char*, int, size_t, int, int) {}
+void __hipUnregisterFatBinary(void**) {}
+
+long mi_hip_stub_live_allocations(void) { return g_live_allocs.load(); }
+
+}  // extern "C"

@@ -1,0 +1,160 @@
+"""Scenarios for tests/test_host_hip_double.py: the library's host-fed path on the HIP test double (mi_hip_stub.cpp).
+Run with LD_PRELOAD=<the double>; kernels do not run there, so what is checked is what the HOST side is responsible for:
+every byte of every file, buffer and range lands in the batch's arena where the file table says, whatever the order of
+adds, the number of reader threads, the slab size, arena growth under way, batch reuse, two batches alternating -- and
+errors stay with the batch they belong to.  Prints one "OK <name>" line per scenario."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import makisu_amd as M  # noqa: E402
+
+
+def make_files(d, sizes, seed):
+    rng = np.random.default_rng(seed)
+    os.makedirs(d, exist_ok=True)
+    out = []
+    for i, sz in enumerate(sizes):
+        p = os.path.join(d, "f%05d" % i)
+        data = rng.integers(0, 256, sz, dtype=np.uint8).tobytes()
+        with open(p, "wb") as f:
+            f.write(data)
+        out.append((p, data))
+    return out
+
+
+def check(b, want, name):
+    got = bytes(b.read_back())
+    if got != want:
+        n = min(len(got), len(want))
+        first = next((i for i in range(n) if got[i] != want[i]), n)
+        raise SystemExit("%s: arena differs from the files at byte %d of %d (got %r, want %r)" %
+                         (name, first, len(want), got[first:first + 8], want[first:first + 8]))
+
+
+def scenario_mix(tmp, threads, slab):
+    """big and small files through every door, in one batch"""
+    rng = np.random.default_rng(7)
+    sizes = [0, 1, 7, 100, 4095, 4096, 4097, 70000, slab - 1, slab, slab + 1, 3 * slab + 5, 1 << 20] + \
+        [int(x) for x in rng.integers(0, 20000, 300)]
+    files = make_files(os.path.join(tmp, "mix"), sizes, 11)
+    with M.Engine(n_streams=threads, staging_bytes=slab) as eng, eng.batch() as b:
+        want = b""
+        for k, (p, data) in enumerate(files[:100]):
+            if k % 3 == 0:
+                b.add_path(p)
+            elif k % 3 == 1:
+                b.add_bytes(data)                       # small ones: the inline window; large: reader threads
+            else:
+                b.add_path_range(p, 0, len(data))
+            want += data
+        b.add_paths([p for p, _ in files[100:250]])     # opened by the reader threads
+        want += b"".join(d for _, d in files[100:250])
+        p, data = files[12]                             # a range out of the middle of a file
+        b.add_path_range(p, 1000, 50000)
+        want += data[1000:51000]
+        big = rng.integers(0, 256, 5 * slab + 17, dtype=np.uint8).tobytes()
+        b.add_bytes(big)
+        want += big
+        n = b.add_tree(os.path.join(tmp, "mix"))         # the whole directory once more, in walk order
+        want += b"".join(d for _, d in sorted(files))
+        assert n == len(files) + 1
+        b.run()
+        assert b.counts()[0] == 100 + 150 + 2 + len(files) and b.counts()[2] == len(want)
+        check(b, want, "mix")
+
+
+def scenario_growth_and_reuse(tmp, threads, slab):
+    """tiny hints: the arena grows again and again while readers are busy; then the batch is reset and reused"""
+    files = make_files(os.path.join(tmp, "grow"), [3 * slab + 1] * 6 + [5000] * 200 + [slab * 4] * 3, 13)
+    with M.Engine(n_streams=threads, staging_bytes=slab) as eng, eng.batch(1, 1) as b:
+        for rnd in range(3):
+            want = b""
+            order = files if rnd % 2 == 0 else files[::-1]
+            for k, (p, data) in enumerate(order):
+                if k % 2:
+                    b.add_path(p)
+                else:
+                    b.add_bytes(data)
+                want += data
+            b.run()
+            check(b, want, "growth round %d" % rnd)
+            b.reset()
+
+
+def scenario_two_batches(tmp, threads, slab):
+    """two batches of one ctx alternate: one is submitted while the other is being fed by the same reader threads"""
+    files = make_files(os.path.join(tmp, "two"), [2 * slab + 3, 100, slab, 9000, 12] * 20, 17)
+    with M.Engine(n_streams=threads, staging_bytes=slab) as eng, eng.batch() as b0, eng.batch() as b1:
+        bs = [b0, b1]
+        wants = [b"", b""]
+        for step in range(6):
+            cur, other = bs[step % 2], bs[(step + 1) % 2]
+            if step >= 2:
+                cur.wait()
+                check(cur, wants[step % 2], "two batches, step %d" % step)
+                cur.reset()
+            sel = files[step * 7 % 50:][:40]
+            cur.add_paths([p for p, _ in sel[:20]])
+            for p, data in sel[20:]:
+                cur.add_bytes(data)
+            wants[step % 2] = b"".join(d for _, d in sel)
+            cur.submit()
+            del other
+        for k in (0, 1):
+            bs[k].wait()
+            check(bs[k], wants[k], "two batches, end %d" % k)
+
+
+def scenario_errors(tmp, threads, slab):
+    """a file that is gone, a file that shrank: the batch that holds it fails -- and keeps failing -- the other does not"""
+    files = make_files(os.path.join(tmp, "err"), [slab + 10, 3000, 40000], 23)
+    with M.Engine(n_streams=threads, staging_bytes=slab) as eng, eng.batch() as bad, eng.batch() as good:
+        gone = os.path.join(tmp, "err", "gone")
+        bad.add_paths([files[0][0], gone, files[2][0]], sizes=[slab + 10, 10000, 40000])   # deferred open: the reader
+                                                                                            # thread finds it missing
+        good.add_path(files[2][0])
+        good.add_bytes(files[0][1])
+        for _ in range(2):                              # sticky
+            try:
+                bad.run()
+            except M.MiError as e:
+                assert e.code == -5 and "gone" in str(e), str(e)
+            else:
+                raise SystemExit("a batch with a missing file ran")
+        good.run()
+        check(good, files[2][1] + files[0][1], "the other batch")
+        bad.reset()                                     # the error goes with the contents
+        bad.add_path(files[1][0])
+        bad.run()
+        check(bad, files[1][1], "the failed batch after reset")
+        short = os.path.join(tmp, "err", "short")
+        open(short, "wb").write(b"y" * 100)
+        bad.reset()
+        bad.add_paths([short], sizes=[5000])            # shorter than the size given
+        try:
+            bad.run()
+        except M.MiError as e:
+            assert "shorter than the size given" in str(e), str(e)
+        else:
+            raise SystemExit("a short file was staged")
+
+
+def main():
+    tmp = sys.argv[1]
+    threads = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+    slab = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
+    only = sys.argv[4].split(",") if len(sys.argv) > 4 else None
+    for name, fn in [("mix", scenario_mix), ("growth", scenario_growth_and_reuse), ("two", scenario_two_batches),
+                     ("errors", scenario_errors)]:
+        if only and name not in only:
+            continue
+        fn(tmp, threads, slab)
+        print("OK", name, flush=True)
+
+
+if __name__ == "__main__":
+    main()

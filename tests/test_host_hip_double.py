@@ -1,0 +1,56 @@
+"""The library's host-fed path on a HIP runtime TEST DOUBLE (tests/hip_stub/mi_hip_stub.cpp: device memory = host memory,
+a stream = a thread with a queue, copies asynchronous to the caller, kernels queued no-ops), so that reader threads,
+pinned slabs, the inline window, arena growth, batch reuse and two batches in flight run HERE, without a GPU -- and, with
+tools/tsan_host_tests.sh, under ThreadSanitizer, where a slab refilled before its copy has completed, an arena moved
+under a copy in flight or a result read before its stream was synchronised is a reported race between the stream's
+thread and the caller's, not a once-in-a-thousand-runs wrong chunk count.
+
+What is checked is what the host side answers for: every byte of every file, range and buffer lies in the batch's arena
+where the file table says (mi_batch_read_back), and errors stay with their batch.  tario.WriteEntry's contract --
+io.CopyN delivers exactly the file's bytes, lib/tario/write.go:43-45."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STUB_DIR = os.path.join(ROOT, "tests", "hip_stub")
+STUB = os.path.join(STUB_DIR, "libmi_hip_stub.so")
+
+
+@pytest.fixture(scope="module")
+def hip_double(engine_lib):
+    src = os.path.join(STUB_DIR, "mi_hip_stub.cpp")
+    if not os.path.exists(STUB) or os.path.getmtime(STUB) < os.path.getmtime(src):
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__",
+                               "-I/opt/rocm/include", src, "-o", STUB, "-lpthread"])
+    return STUB
+
+
+def _run(stub, tmp, threads, slab, extra_env=None):
+    env = dict(os.environ, LD_PRELOAD=(os.environ.get("LD_PRELOAD", "") + " " + stub).strip())
+    env.update(extra_env or {})
+    p = subprocess.run([sys.executable, os.path.join(STUB_DIR, "scenarios.py"), str(tmp), str(threads), str(slab)],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert [ln for ln in p.stdout.splitlines() if ln.startswith("OK ")] == ["OK mix", "OK growth", "OK two", "OK errors"]
+
+
+@pytest.mark.parametrize("threads,slab", [(1, 65536), (4, 65536), (16, 131072), (3, 1 << 20)])
+def test_every_staged_byte_lands_where_the_file_table_says(hip_double, tmp_path, threads, slab):
+    _run(hip_double, tmp_path, threads, slab)
+
+
+def test_with_slow_copies(hip_double, tmp_path):
+    """every queued copy takes 100 us longer: what returns early shows"""
+    _run(hip_double, tmp_path, 8, 65536, {"MI_HIP_STUB_COPY_US": "100"})
+
+
+def test_the_double_is_not_the_product():
+    """nothing under makisu_amd/ or include/ knows about the double"""
+    for base in ("makisu_amd", "include"):
+        for dp, _, fns in os.walk(os.path.join(ROOT, base)):
+            for fn in fns:
+                if fn.endswith((".py", ".hip", ".h")):
+                    assert "hip_stub" not in open(os.path.join(dp, fn), errors="replace").read(), fn

@@ -1,5 +1,6 @@
 #!/bin/bash
-# The threaded host code (parallel walk, the layer writer's tee / sink threads / deflate pool, the tar reader) under
+# The threaded host code (parallel walk, the layer writer's tee / sink threads / deflate pool, the tar reader, and -- on
+# the HIP test double of tests/hip_stub -- the reader threads, pinned slabs and stream ordering of the host-fed path) under
 # ThreadSanitizer -- the reference runs its tests with `go test -race`.  No GPU needed.  Reports go to $OUT/report.*;
 # the script fails if there is one.
 #   tools/tsan_host_tests.sh [pytest args; default: the host test files]
@@ -22,7 +23,8 @@ cd "$ROOT"
 ARGS=("$@")
 [ ${#ARGS[@]} -eq 0 ] && ARGS=(tests/test_host_walk.py tests/test_host_layer.py tests/test_host_layer_properties.py
                                 tests/test_host_tar.py tests/test_host_tar_properties.py tests/test_host_copy_ops.py
-                                tests/test_host_apply_properties.py tests/test_host_diff_properties.py)
+                                tests/test_host_apply_properties.py tests/test_host_diff_properties.py
+                                tests/test_host_hip_double.py)
 LD_PRELOAD=$RT TSAN_OPTIONS=halt_on_error=0:report_signal_unsafe=0:exitcode=0:log_path="$OUT/report" \
     MAKISU_MI_LIB="$OUT/libmakisu_mi.so" python -m pytest -q -p no:cacheprovider "${ARGS[@]}"
 if ls "$OUT"/report.* >/dev/null 2>&1; then
