@@ -143,13 +143,41 @@ def scenario_errors(tmp, threads, slab):
             raise SystemExit("a short file was staged")
 
 
+def scenario_api(tmp, threads, slab):
+    """the order of calls: what comes too early, twice or too late is MI_ERR_STATE and changes nothing"""
+    def code(fn):
+        try:
+            fn()
+        except M.MiError as e:
+            return e.code
+        return 0
+    with M.Engine(n_streams=threads, staging_bytes=slab) as eng, eng.batch() as b:
+        assert [code(b.files), code(b.chunks), code(b.read_back), code(b.wait)] == [-6, -6, -6, -6]
+        data = os.urandom(3 * slab + 5)
+        b.add_bytes(data)
+        b.add_bytes(b"")
+        assert code(b.submit) == 0 and code(b.submit) == -6 and code(lambda: b.add_bytes(b"x")) == -6
+        assert code(b.wait) == 0 and code(b.wait) == -6 and code(b.run) == -6 and code(b.rerun) == 0
+        assert code(lambda: b.add_bytes(b"x")) == -6
+        assert len(b.files()) == 2 and b.counts()[2] == len(data)
+        check(b, data, "api")
+        assert code(lambda: b.context_checksum(b"", [("a", None, 0)])) == -6       # needs MI_FLAG_FILE_CRC32
+        b.reset()
+        assert code(lambda: b.add_tree(os.path.join(tmp, "nowhere"))) == -5
+        assert code(lambda: b.add_path(os.path.join(tmp, "nowhere"), size=10)) == -5
+        assert code(lambda: b.add_path_range(__file__, 10, 1 << 40)) == -5           # shorter than the range given
+        b.add_bytes(b"after the errors")
+        b.run()
+        check(b, b"after the errors", "api, after errors")
+
+
 def main():
     tmp = sys.argv[1]
     threads = int(sys.argv[2]) if len(sys.argv) > 2 else 4
     slab = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
     only = sys.argv[4].split(",") if len(sys.argv) > 4 else None
     for name, fn in [("mix", scenario_mix), ("growth", scenario_growth_and_reuse), ("two", scenario_two_batches),
-                     ("errors", scenario_errors)]:
+                     ("errors", scenario_errors), ("api", scenario_api)]:
         if only and name not in only:
             continue
         fn(tmp, threads, slab)
