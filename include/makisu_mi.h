@@ -598,6 +598,44 @@ int  mi_copy_layer_entries(const mi_copy_layer* layer, mi_tree_entry* out, const
                            uint64_t cap);
 void mi_copy_layer_free(mi_copy_layer* layer);
 
+/* ---- MemFS as a handle: the reference's type (lib/snapshot/mem_fs.go:59-125) ------------------------------------- *
+ * One tree for the life of a build, nodes of the reference's shape (header + children + the path the content came
+ * from).  The stateless calls above (mi_entries_apply_layer, mi_snapshot_diff, mi_snapshot_copy_ops) answer one
+ * question each on entry lists; this keeps what lies between the questions -- the directories addAncestors created
+ * (they are nodes like any other here, and part of mi_memfs_entries), and memFSNode.src, which is what isOnDisk asks
+ * the disk about (mem_fs.go:49-57: a file a COPY step added is "on disk" while its SOURCE exists, whether or not the
+ * step modified the file system).
+ *   mi_memfs_create           NewMemFS(clk, root, blacklist): the root's header from lstat(root); now_sec = the clock
+ *                             (mtime of created directories; mi_memfs_set_clock moves it).
+ *   mi_memfs_update_from_entries  UpdateFromTarReader with untar = false on a layer's entries (mi_tar_entries): the
+ *                             per-header filter (shouldSkip with the blacklist, IsMounted), hard links in a second
+ *                             pass, *n_merged = "Merged %d headers from tar to memfs".
+ *   mi_memfs_add_layer_by_scan    createLayerByScan on a walk of the root (mi_tree_walk / mi_batch_add_tree with
+ *                             MI_TREE_SCAN, rel_base = root, the same blacklist): every walked path through
+ *                             maybeAddToLayer with createWhiteout -- changed paths with their ancestors, one whiteout
+ *                             per deleted subtree (if the child's src is really gone).  roots / root_stride: chunk roots
+ *                             by file_index, kept in the tree, so that the NEXT scan's isUpdated is content-aware
+ *                             (NULL = the reference's metadata-only rule).
+ *   mi_memfs_add_layer_by_copy_ops   AddLayerByCopyOps: mi_snapshot_copy_ops against this tree.
+ * Both return the layer in commit order as an mi_copy_layer (mi_copy_layer_entries: headers + the path each entry's
+ * bytes are read from; a whiteout is an entry named ".wh.<x>" without content) and fold it into the tree.  A failing
+ * call returns the error code, mi_memfs_error() the reference's message, and leaves the handle usable.
+ *   mi_memfs_entries          the tree in sorted-path order (src_paths may be NULL; cap 0 sizes).
+ *   mi_memfs_reset            MemFS.Reset: the tree is emptied, the root stays.                       Host logic. */
+typedef struct mi_memfs mi_memfs;
+int  mi_memfs_create(const char* root, const char* const* blacklist, uint64_t n_blacklist, int64_t now_sec,
+                     mi_memfs** out);
+void mi_memfs_free(mi_memfs* fs);
+const char* mi_memfs_error(const mi_memfs* fs);
+int  mi_memfs_set_clock(mi_memfs* fs, int64_t now_sec);
+int  mi_memfs_reset(mi_memfs* fs);
+int  mi_memfs_update_from_entries(mi_memfs* fs, const mi_tree_entry* layer, uint64_t n_layer, uint64_t* n_merged);
+int  mi_memfs_add_layer_by_scan(mi_memfs* fs, const mi_tree_entry* walked, uint64_t n, const void* roots,
+                                uint64_t root_stride, mi_copy_layer** out, uint64_t* n_entries);
+int  mi_memfs_add_layer_by_copy_ops(mi_memfs* fs, const mi_copy_op* ops, uint64_t n_ops, mi_copy_layer** out,
+                                    uint64_t* n_entries);
+int  mi_memfs_entries(const mi_memfs* fs, mi_tree_entry* out, const char** src_paths, uint64_t cap, uint64_t* n_out);
+
 /* ---- the layer writer: tar framing + the two serial layer digests (host threads) ---------- *
  * step.tarAndGzipDiffs + MemFS.commitLayer (lib/builder/step/common.go:35-111,
  * lib/snapshot/mem_fs.go:424-433) behind the ABI: the shim hands over the layer's entries in

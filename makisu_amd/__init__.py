@@ -244,6 +244,15 @@ def load_library(rebuild=False):
         "mi_resolve_chown": ([C.c_char_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_char_p, u64], C.c_int),
         "mi_path_match": ([C.c_char_p, C.c_char_p, C.POINTER(C.c_int)], C.c_int),
         "mi_context_sources": ([C.c_char_p, C.POINTER(C.c_char_p), u64, C.c_char_p, u64, u64p, u64p], C.c_int),
+        "mi_memfs_create": ([C.c_char_p, C.POINTER(C.c_char_p), u64, C.c_int64, C.POINTER(vp)], C.c_int),
+        "mi_memfs_free": ([vp], None),
+        "mi_memfs_error": ([vp], C.c_char_p),
+        "mi_memfs_set_clock": ([vp, C.c_int64], C.c_int),
+        "mi_memfs_reset": ([vp], C.c_int),
+        "mi_memfs_update_from_entries": ([vp, C.POINTER(TreeEntry), u64, u64p], C.c_int),
+        "mi_memfs_add_layer_by_scan": ([vp, C.POINTER(TreeEntry), u64, vp, u64, C.POINTER(vp), u64p], C.c_int),
+        "mi_memfs_add_layer_by_copy_ops": ([vp, C.POINTER(CopyOp), u64, C.POINTER(vp), u64p], C.c_int),
+        "mi_memfs_entries": ([vp, C.POINTER(TreeEntry), C.POINTER(C.c_char_p), u64, u64p], C.c_int),
         "mi_copy_layer_entries": ([vp, C.POINTER(TreeEntry), C.POINTER(C.c_char_p), u64], C.c_int),
         "mi_copy_layer_free": ([vp], None),
         "mi_layer_config_default": ([C.POINTER(LayerConfig)], C.c_int),
@@ -510,12 +519,7 @@ def context_sources(context_root, from_paths):
     return [os.fsdecode(x) for x in buf.raw[:nbytes.value].split(b"\0")[:n.value]]
 
 
-def copy_ops_layer(tree, tree_root, ops, now_sec=0):
-    """mi_snapshot_copy_ops: tree = list of entry dicts, ops = list of dicts(src_root, srcs, dst, uid,
-    gid).  Returns the layer as a list of entry dicts (commit order) with an extra "src" key."""
-    L = load_library()
-    keep = []
-    arr = _entry_array(tree, keep)
+def _copy_op_array(ops, keep):
     cops = (CopyOp * max(len(ops), 1))()
     for i, o in enumerate(ops):
         srcs = [os.fsencode(x) for x in o["srcs"]]
@@ -525,26 +529,127 @@ def copy_ops_layer(tree, tree_root, ops, now_sec=0):
         cops[i].srcs, cops[i].n_srcs = sarr, len(srcs)
         cops[i].dst = os.fsencode(o["dst"])
         cops[i].uid, cops[i].gid = o.get("uid", 0), o.get("gid", 0)
-    h, n = C.c_void_p(), C.c_uint64()
-    err = C.create_string_buffer(600)
-    rc = L.mi_snapshot_copy_ops(arr, len(tree), os.fsencode(tree_root), cops, len(ops), now_sec, C.byref(h),
-                                C.byref(n), err, len(err))
-    if rc:
-        raise MiError(rc, "mi_snapshot_copy_ops: %s" % err.value.decode(errors="replace"))
+    return cops
+
+
+def _take_copy_layer(L, h, n):
+    """mi_copy_layer -> list of entry dicts (commit order) with an extra "src" key; frees the handle."""
     try:
-        out = (TreeEntry * max(n.value, 1))()
-        srcp = (C.c_char_p * max(n.value, 1))()
-        rc = L.mi_copy_layer_entries(h, out, srcp, n.value)
+        out = (TreeEntry * max(n, 1))()
+        srcp = (C.c_char_p * max(n, 1))()
+        rc = L.mi_copy_layer_entries(h, out, srcp, n)
         if rc:
             raise MiError(rc, "mi_copy_layer_entries")
         res = []
-        for i in range(n.value):
+        for i in range(n):
             d = _entry_dict(out[i])
             d["src"] = os.fsdecode(srcp[i]) if srcp[i] is not None else ""
             res.append(d)
         return res
     finally:
         L.mi_copy_layer_free(h)
+
+
+def copy_ops_layer(tree, tree_root, ops, now_sec=0):
+    """mi_snapshot_copy_ops: tree = list of entry dicts, ops = list of dicts(src_root, srcs, dst, uid,
+    gid).  Returns the layer as a list of entry dicts (commit order) with an extra "src" key."""
+    L = load_library()
+    keep = []
+    arr = _entry_array(tree, keep)
+    cops = _copy_op_array(ops, keep)
+    h, n = C.c_void_p(), C.c_uint64()
+    err = C.create_string_buffer(600)
+    rc = L.mi_snapshot_copy_ops(arr, len(tree), os.fsencode(tree_root), cops, len(ops), now_sec, C.byref(h),
+                                C.byref(n), err, len(err))
+    if rc:
+        raise MiError(rc, "mi_snapshot_copy_ops: %s" % err.value.decode(errors="replace"))
+    return _take_copy_layer(L, h, n.value)
+
+
+class MemFS:
+    """mi_memfs_*: the reference's MemFS (lib/snapshot/mem_fs.go) as a handle -- one tree for the life of a build.
+
+    fs = MemFS(root, blacklist); fs.update_from_entries(tar_entries); layer = fs.add_layer_by_scan(walk_entries);
+    layer = fs.add_layer_by_copy_ops([op, ...]); fs.entries()."""
+
+    def __init__(self, root, blacklist=(), now_sec=0):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        bl = (C.c_char_p * max(len(blacklist), 1))(*[os.fsencode(x) for x in blacklist])
+        rc = self._lib.mi_memfs_create(os.fsencode(root), bl, len(blacklist), now_sec, C.byref(self._h))
+        if rc:
+            raise MiError(rc, "mi_memfs_create: unable to stat root dir: %s" % root)
+        self.root, self.blacklist = root, list(blacklist)
+
+    def _check(self, rc, what):
+        if rc:
+            raise MiError(rc, "%s: %s" % (what, self._lib.mi_memfs_error(self._h).decode(errors="replace")))
+
+    def close(self):
+        if self._h:
+            self._lib.mi_memfs_free(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_clock(self, now_sec):
+        self._check(self._lib.mi_memfs_set_clock(self._h, now_sec), "mi_memfs_set_clock")
+
+    def reset(self):
+        self._check(self._lib.mi_memfs_reset(self._h), "mi_memfs_reset")
+
+    def update_from_entries(self, layer):
+        """UpdateFromTarReader (untar = false); returns the number of headers merged."""
+        keep = []
+        arr = _entry_array(layer, keep)
+        n = C.c_uint64()
+        self._check(self._lib.mi_memfs_update_from_entries(self._h, arr, len(layer), C.byref(n)), "mi_memfs_update_from_entries")
+        return n.value
+
+    def add_layer_by_scan(self, walked, roots=None):
+        """createLayerByScan on a walk of the root (tree_walk(root, root, blacklist, TREE_SCAN, full=True)); roots: an
+        (n_files, 32) uint8 array indexed by file_index, or None."""
+        keep = []
+        arr = _entry_array(walked, keep)
+        h, n = C.c_void_p(), C.c_uint64()
+        rp, stride = None, 0
+        if roots is not None:
+            roots = np.ascontiguousarray(roots, dtype=np.uint8)
+            rp, stride = roots.ctypes.data, roots.strides[0] if roots.ndim == 2 else 32
+        self._check(self._lib.mi_memfs_add_layer_by_scan(self._h, arr, len(walked), rp, stride, C.byref(h), C.byref(n)),
+                    "mi_memfs_add_layer_by_scan")
+        return _take_copy_layer(self._lib, h, n.value)
+
+    def add_layer_by_copy_ops(self, ops):
+        keep = []
+        cops = _copy_op_array(ops, keep)
+        h, n = C.c_void_p(), C.c_uint64()
+        self._check(self._lib.mi_memfs_add_layer_by_copy_ops(self._h, cops, len(ops), C.byref(h), C.byref(n)),
+                    "mi_memfs_add_layer_by_copy_ops")
+        return _take_copy_layer(self._lib, h, n.value)
+
+    def scan(self):
+        """walk the root with this MemFS's blacklist, then add_layer_by_scan"""
+        return self.add_layer_by_scan(tree_walk(self.root, self.root, self.blacklist, TREE_SCAN, full=True))
+
+    def entries(self):
+        n = C.c_uint64()
+        rc = self._lib.mi_memfs_entries(self._h, None, None, 0, C.byref(n))
+        if rc not in (0, -7):
+            self._check(rc, "mi_memfs_entries")
+        out = (TreeEntry * max(n.value, 1))()
+        srcp = (C.c_char_p * max(n.value, 1))()
+        self._check(self._lib.mi_memfs_entries(self._h, out, srcp, n.value, C.byref(n)), "mi_memfs_entries")
+        res = []
+        for i in range(n.value):
+            d = _entry_dict(out[i])
+            d["src"] = os.fsdecode(srcp[i]) if srcp[i] is not None else ""
+            res.append(d)
+        return res
 
 
 class Layer:

@@ -519,7 +519,7 @@ static void walk_root(Walker* w, const std::string& root) {
 // They walk part by part through nodes of ANY type, and what they do to a file or symlink that has children (or is
 // somebody's ancestor) is not what a flat path map would do, so both users -- the layer merge and the copy-op layer --
 // share this one.  Nodes carry a caller-owned payload index.
-namespace mi_memfs {
+namespace mi_memtree {
 
 struct Node {
     int64_t ref = -1;                          // caller's payload; -1 = none
@@ -672,7 +672,7 @@ struct Tree {
     }
 };
 
-}  // namespace mi_memfs
+}  // namespace mi_memtree
 
 using mi_walk::Tree;
 
@@ -930,8 +930,8 @@ extern "C" int mi_entries_apply_layer_filtered(const mi_tree_entry* base, uint64
         return false;
     };
     // nodes: ref = i for base[i], n_base + j for layer[j], -1 for the directories addAncestors makes up
-    mi_memfs::Tree t;
-    auto entry_of = [&](const mi_memfs::Node& n) -> const mi_tree_entry* {
+    mi_memtree::Tree t;
+    auto entry_of = [&](const mi_memtree::Node& n) -> const mi_tree_entry* {
         return n.ref < 0 ? nullptr : (uint64_t)n.ref < n_base ? &base[n.ref] : &layer[n.ref - n_base];
     };
     bool base_has_root = false;
@@ -944,7 +944,7 @@ extern "C" int mi_entries_apply_layer_filtered(const mi_tree_entry* base, uint64
     // maybeAddToLayer (mem_fs.go:440-458) with createWhiteout = false
     auto apply = [&](uint64_t j, const std::string& p) -> int {
         if (p == "/") return MI_OK;                                             // "Root itself is not added to layers"
-        if (const mi_memfs::Node* cur = t.find(p)) {                            // isUpdated (:487-503)
+        if (const mi_memtree::Node* cur = t.find(p)) {                            // isUpdated (:487-503)
             const mi_tree_entry* old = entry_of(*cur);                          // a made-up directory's mtime is "now":
             int similar = 0;                                                    // never similar to a header from a tar
             if (old && old->kind <= 3 && layer[j].kind <= 3) {                  // special files never compare equal
@@ -980,8 +980,8 @@ extern "C" int mi_entries_apply_layer_filtered(const mi_tree_entry* base, uint64
         if (rc) return failed(rc);
     }
     // the merged tree in sorted-path order; made-up directories are not entries of either list and stay out
-    std::vector<std::pair<std::string, const mi_memfs::Node*>> flat;
-    std::function<void(const mi_memfs::Node&, const std::string&)> collect = [&](const mi_memfs::Node& n,
+    std::vector<std::pair<std::string, const mi_memtree::Node*>> flat;
+    std::function<void(const mi_memtree::Node&, const std::string&)> collect = [&](const mi_memtree::Node& n,
                                                                                  const std::string& p) {
         for (auto& kv : n.children) {
             const std::string q = p + "/" + kv.first;
@@ -991,8 +991,8 @@ extern "C" int mi_entries_apply_layer_filtered(const mi_tree_entry* base, uint64
     };
     if (base_has_root) flat.emplace_back("/", &t.root);
     collect(t.root, "");
-    std::sort(flat.begin(), flat.end(), [](const std::pair<std::string, const mi_memfs::Node*>& x,
-                                           const std::pair<std::string, const mi_memfs::Node*>& y) {
+    std::sort(flat.begin(), flat.end(), [](const std::pair<std::string, const mi_memtree::Node*>& x,
+                                           const std::pair<std::string, const mi_memtree::Node*>& y) {
         return x.first < y.first;
     });
     *n_out = flat.size();
@@ -1065,10 +1065,12 @@ namespace mi_copy {
 
 struct Node {
     mi_walk::Entry e;          // relpath = dst without the leading "/"
-    std::string src;
+    std::string src;           // where the content is read from; what memFSNode.isOnDisk looks at
+    bool has_root = false;     // chunk root of the content, when the caller scanned it (content-aware isUpdated)
+    uint8_t root[32];
 };
 struct Fs {
-    mi_memfs::Tree t;                      // fs.tree; a node's ref indexes `nodes`
+    mi_memtree::Tree t;                      // fs.tree; a node's ref indexes `nodes`
     std::vector<Node> nodes;
     std::map<std::string, int64_t> layer;  // memLayer.files: keyed by dst -- by the DELETED path for a ".wh." name
     std::string root;                      // fs.tree.src
@@ -1085,7 +1087,7 @@ struct Fs {
                 Node d;
                 d.e.mode = (uint32_t)(S_IFDIR | 0755); d.e.kind = 0; d.e.relpath = dst.substr(1); d.e.mtime = now;
                 ref = keep(d);
-                if (mi_memfs::Node* n = t.find(dst)) n->ref = ref;
+                if (mi_memtree::Node* n = t.find(dst)) n->ref = ref;
             }
             const std::string name = mi_walk::base_of(dst);
             if (mi_walk::has_prefix(name, ".wh.")) {
@@ -1095,7 +1097,7 @@ struct Fs {
                 layer[dst] = ref;
             }
         };
-        t.make_dir = [this](const std::string& dst, const mi_memfs::Node& last_ancestor, uint32_t uid, uint32_t gid) {
+        t.make_dir = [this](const std::string& dst, const mi_memtree::Node& last_ancestor, uint32_t uid, uint32_t gid) {
             Node d;                                                             // mem_fs.go:551-559
             d.e.mode = last_ancestor.ref >= 0 ? nodes[last_ancestor.ref].e.mode : (uint32_t)(S_IFDIR | 0755);
             d.e.kind = 0;
@@ -1112,10 +1114,24 @@ struct Fs {
         if (!t.add_ancestors(dst, inclusive, 0, uid, gid, &resolved)) fail(MI_ERR_INVALID, "add ancestors of " + dst + ": " + t.err);
         return resolved;
     }
-    // maybeAddToLayer(l, src, dst, hdr, createWhiteout = false)
-    void maybe_add(const std::string& src, const std::string& dst, Node n) {
+    // memLayer.addWhiteout (mem_layer.go:214-228) + whiteoutMemFile.updateMemFS
+    bool add_whiteout(const std::string& p) {
+        const std::string name = mi_walk::base_of(p);
+        if (mi_walk::has_prefix(name, ".wh.")) return fail(MI_ERR_INVALID, "add whiteout to layer " + p + ": base name contains whiteout prefix: " + p);
+        const std::string dir = mi_walk::dir_of(p);
+        Node w;
+        w.e.kind = 1;
+        w.e.mode = 0;
+        w.e.relpath = ((dir == "/" ? "" : dir) + "/.wh." + name).substr(1);
+        layer[p] = keep(w);
+        if (!t.wipe(p)) return fail(MI_ERR_INVALID, "update memfs with whiteout " + p + ": " + t.err);
+        return true;
+    }
+    // maybeAddToLayer(l, src, dst, hdr, createWhiteout) (mem_fs.go:440-483)
+    void maybe_add(const std::string& src, const std::string& dst, Node n, bool create_whiteout = false) {
         bool updated = true;
-        const mi_memfs::Node* cur = t.find(dst);                                // isUpdated (:487-503)
+        mi_memtree::Node* cur = t.find(dst);                                      // isUpdated (:487-503)
+        const bool had_node = cur != nullptr;
         if (cur && cur->ref >= 0) {
             mi_tree_entry a, b;
             auto fill = [](const Node& x, mi_tree_entry* o) {
@@ -1128,7 +1144,9 @@ struct Fs {
             fill(nodes[cur->ref], &a);
             fill(n, &b);
             int similar = 0;
-            if (a.kind <= 3 && b.kind <= 3 && mi_entry_similar(&a, &b, 0, nullptr, nullptr, &similar) != MI_OK) {
+            const Node& o = nodes[cur->ref];
+            if (a.kind <= 3 && b.kind <= 3 &&
+                mi_entry_similar(&a, &b, 0, o.has_root ? o.root : nullptr, n.has_root ? n.root : nullptr, &similar) != MI_OK) {
                 fail(MI_ERR_INVALID, "check header " + dst + ": unsupported type");
                 return;
             }
@@ -1142,8 +1160,34 @@ struct Fs {
             // node -- of any type.  A destination spelled THROUGH a symlink therefore works one level below the
             // link (the link node takes the child) and fails deeper ("missing intermediate directory"): what
             // addAncestors created lies on the link's TARGET, and its resolved path is only used by the createDst branch
-            if (!t.add(dst, keep(n), n.e.kind, n.e.has_link ? n.e.link : std::string()))
+            if (!t.add(dst, keep(n), n.e.kind, n.e.has_link ? n.e.link : std::string())) {
                 fail(MI_ERR_INVALID, "update memfs with file " + dst + ": " + t.err);
+                return;
+            }
+        }
+        // "Handle deletions.  Note: Only one whiteout file is needed for a deleted subtree." (:460-480): the children
+        // the tree held for this directory BEFORE the call (n, isUpdated's node) that are no longer on disk
+        if (create_whiteout && n.e.kind == 0 && had_node) {
+            mi_memtree::Node* dir = t.find(dst);
+            if (!dir) return;
+            std::vector<std::string> names;
+            for (auto& kv : dir->children) names.push_back(kv.first);
+            for (const std::string& name : names) {
+                auto it = dir->children.find(name);
+                if (it == dir->children.end()) continue;
+                const std::string child = (dst == "/" ? "" : dst) + "/" + name;
+                const int64_t ref = it->second->ref;
+                const std::string& child_src = ref >= 0 ? nodes[ref].src : std::string();
+                struct stat st;                                                 // memFSNode.isOnDisk (:49-57)
+                if (lstat(child_src.c_str(), &st) == 0) continue;
+                if (errno != ENOENT && errno != ENOTDIR) {
+                    fail(MI_ERR_IO, "check on disk " + child + ": lstat " + child_src + ": " + strerror(errno));
+                    return;
+                }
+                if (!add_whiteout(child)) return;
+                add_ancestors(child, false, 0, 0);
+                if (rc) return;
+            }
         }
     }
 };
@@ -1155,7 +1199,7 @@ static bool eval_symlinks(const std::string& p, const std::string& root, std::st
     std::string cur = p;
     for (int walked = 0; walked <= 255;) {
         // resolve the first symlink found walking the components of cur
-        const std::vector<std::string> parts = mi_memfs::Tree::parts(cur);
+        const std::vector<std::string> parts = mi_memtree::Tree::parts(cur);
         std::string acc;
         bool replaced = false;
         for (size_t i = 0; i < parts.size(); ++i) {
@@ -1483,33 +1527,10 @@ extern "C" int mi_copy_op_resolve(uint64_t n_srcs, const char* work_dir, const c
     return MI_OK;
 }
 
-extern "C" int mi_snapshot_copy_ops(const mi_tree_entry* tree, uint64_t n_tree, const char* tree_root,
-                                    const mi_copy_op* ops, uint64_t n_ops, int64_t now_sec,
-                                    mi_copy_layer** out, uint64_t* n_entries, char* err, uint64_t err_cap) {
-    auto put_err = [&](const std::string& m) { if (err && err_cap) snprintf(err, (size_t)err_cap, "%s", m.c_str()); };
-    if ((n_tree && !tree) || (n_ops && !ops) || !out || !tree_root) return MI_ERR_INVALID;
-    mi_copy::Fs fs;
-    fs.root = mi_walk::abs_path(tree_root);
-    fs.now = now_sec;
-    {   // the root node always exists (NewMemFS stats it)
-        mi_copy::Node r;
-        r.e.kind = 0;
-        r.e.mode = S_IFDIR | 0755;
-        struct stat st;
-        if (lstat(fs.root.c_str(), &st) == 0) { r.e.mode = st.st_mode; r.e.mtime = st.st_mtime; r.e.uid = st.st_uid; r.e.gid = st.st_gid; }
-        fs.t.root.ref = fs.keep(r);
-    }
-    for (uint64_t i = 0; i < n_tree; ++i) {
-        const mi_tree_entry& e = tree[i];
-        mi_copy::Node n;
-        const char* rp = e.relpath ? e.relpath : "";
-        const std::string p = mi_walk::abs_path(strcmp(rp, ".") == 0 ? "" : rp);
-        n.e.relpath = p == "/" ? "" : p.substr(1);
-        n.e.kind = e.kind; n.e.mode = e.mode; n.e.mtime = e.mtime_sec; n.e.uid = e.uid; n.e.gid = e.gid; n.e.size = e.size;
-        if (e.link_target) { n.e.link = e.link_target; n.e.has_link = true; }
-        n.src = fs.root == "/" ? p : fs.root + (p == "/" ? "" : p);
-        fs.t.load(p, fs.keep(n), n.e.kind, e.link_target);
-    }
+// addToLayer (mem_fs.go:343-421) for each op, against fs.t, into fs.layer; fs.rc / fs.err carry what maybeAddToLayer
+// refuses, *err_out everything else
+static int copy_ops_into(mi_copy::Fs& fs, const mi_copy_op* ops, uint64_t n_ops, std::string* err_out) {
+    auto put_err = [&](const std::string& m) { *err_out = m; };
     for (uint64_t k = 0; k < n_ops && !fs.rc; ++k) {
         const mi_copy_op& c = ops[k];
         if (!c.src_root || !c.dst || (c.n_srcs && !c.srcs)) return MI_ERR_INVALID;
@@ -1571,10 +1592,222 @@ extern "C" int mi_snapshot_copy_ops(const mi_tree_entry* tree, uint64_t n_tree, 
         }
     }
     if (fs.rc) { put_err(fs.err); return fs.rc; }
+    return MI_OK;
+}
+
+extern "C" int mi_snapshot_copy_ops(const mi_tree_entry* tree, uint64_t n_tree, const char* tree_root,
+                                    const mi_copy_op* ops, uint64_t n_ops, int64_t now_sec,
+                                    mi_copy_layer** out, uint64_t* n_entries, char* err, uint64_t err_cap) {
+    auto put_err = [&](const std::string& m) { if (err && err_cap) snprintf(err, (size_t)err_cap, "%s", m.c_str()); };
+    if ((n_tree && !tree) || (n_ops && !ops) || !out || !tree_root) return MI_ERR_INVALID;
+    mi_copy::Fs fs;
+    fs.root = mi_walk::abs_path(tree_root);
+    fs.now = now_sec;
+    {   // the root node always exists (NewMemFS stats it)
+        mi_copy::Node r;
+        r.e.kind = 0;
+        r.e.mode = S_IFDIR | 0755;
+        struct stat st;
+        if (lstat(fs.root.c_str(), &st) == 0) { r.e.mode = st.st_mode; r.e.mtime = st.st_mtime; r.e.uid = st.st_uid; r.e.gid = st.st_gid; }
+        fs.t.root.ref = fs.keep(r);
+    }
+    for (uint64_t i = 0; i < n_tree; ++i) {
+        const mi_tree_entry& e = tree[i];
+        mi_copy::Node n;
+        const char* rp = e.relpath ? e.relpath : "";
+        const std::string p = mi_walk::abs_path(strcmp(rp, ".") == 0 ? "" : rp);
+        n.e.relpath = p == "/" ? "" : p.substr(1);
+        n.e.kind = e.kind; n.e.mode = e.mode; n.e.mtime = e.mtime_sec; n.e.uid = e.uid; n.e.gid = e.gid; n.e.size = e.size;
+        if (e.link_target) { n.e.link = e.link_target; n.e.has_link = true; }
+        n.src = fs.root == "/" ? p : fs.root + (p == "/" ? "" : p);
+        fs.t.load(p, fs.keep(n), n.e.kind, e.link_target);
+    }
+    std::string e;
+    const int rc = copy_ops_into(fs, ops, n_ops, &e);
+    if (rc) { put_err(e); return rc; }
     mi_copy_layer* l = new mi_copy_layer();
     for (auto& kv : fs.layer) l->nodes.push_back(fs.nodes[kv.second]);   // std::map order == sort.Strings order
     *out = l;
     if (n_entries) *n_entries = l->nodes.size();
+    return MI_OK;
+}
+
+// ---- MemFS as a handle: the reference's type (lib/snapshot/mem_fs.go:59-125) behind the ABI ---------------------------
+// One tree for the life of a build, as in the reference: base layers are merged into it (UpdateFromTarReader), every
+// step's layer is computed against it and folds into it (AddLayerByScan / AddLayerByCopyOps).  What the stateless calls
+// above cannot keep between calls is kept here: the directories addAncestors created, and for every node the path its
+// content came from (memFSNode.src -- what isOnDisk looks at: a copied file is "on disk" while its SOURCE is).
+struct mi_memfs {
+    mi_copy::Fs fs;
+    std::vector<std::string> blacklist;
+    std::string err;
+};
+
+static mi_copy_layer* memfs_take_layer(mi_memfs* m) {
+    mi_copy_layer* l = new mi_copy_layer();
+    for (auto& kv : m->fs.layer) l->nodes.push_back(m->fs.nodes[kv.second]);     // std::map order == sort.Strings order
+    m->fs.layer.clear();
+    return l;
+}
+static int memfs_fail(mi_memfs* m) {
+    m->err = m->fs.err;
+    const int rc = m->fs.rc;
+    m->fs.rc = MI_OK;                                                             // the handle stays usable, like the
+    m->fs.err.clear();                                                            // reference's MemFS after an error
+    m->fs.layer.clear();
+    return rc;
+}
+
+extern "C" int mi_memfs_create(const char* root, const char* const* blacklist, uint64_t n_blacklist, int64_t now_sec,
+                               mi_memfs** out) {
+    if (!root || !out || (n_blacklist && !blacklist)) return MI_ERR_INVALID;
+    struct stat st;
+    if (lstat(root, &st) != 0) return MI_ERR_IO;                                  // "unable to stat root dir"
+    mi_memfs* m = new mi_memfs();
+    m->fs.root = mi_walk::abs_path(root);
+    m->fs.now = now_sec;
+    mi_copy::Node r;
+    r.e.kind = 0;
+    r.e.mode = st.st_mode; r.e.mtime = st.st_mtime; r.e.uid = st.st_uid; r.e.gid = st.st_gid;
+    r.src = m->fs.root;
+    m->fs.t.root.ref = m->fs.keep(r);
+    for (uint64_t i = 0; i < n_blacklist; ++i) m->blacklist.push_back(blacklist[i] ? blacklist[i] : "");
+    *out = m;
+    return MI_OK;
+}
+extern "C" void mi_memfs_free(mi_memfs* m) { delete m; }
+extern "C" const char* mi_memfs_error(const mi_memfs* m) { return m ? m->err.c_str() : ""; }
+extern "C" int mi_memfs_set_clock(mi_memfs* m, int64_t now_sec) {
+    if (!m) return MI_ERR_INVALID;
+    m->fs.now = now_sec;
+    return MI_OK;
+}
+extern "C" int mi_memfs_reset(mi_memfs* m) {                                      // MemFS.Reset (:127-130)
+    if (!m) return MI_ERR_INVALID;
+    m->fs.t.root.children.clear();
+    return MI_OK;
+}
+
+// MemFS.UpdateFromTarReader (:165-255) with untar = false, on a layer's entries (mi_tar_entries)
+extern "C" int mi_memfs_update_from_entries(mi_memfs* m, const mi_tree_entry* layer, uint64_t n_layer,
+                                            uint64_t* n_merged) {
+    if (!m || (n_layer && !layer)) return MI_ERR_INVALID;
+    mi_copy::Fs& fs = m->fs;
+    fs.layer.clear();
+    const mi_walk::MountTable& mt = mi_walk::mountpoints();
+    if (!mt.error.empty()) { m->err = "check if mounted: " + mt.error; return MI_ERR_IO; }
+    std::vector<std::string> bl;
+    for (const std::string& b : m->blacklist) bl.push_back(mi_walk::abs_path(b));
+    auto path_of = [](const mi_tree_entry& e) {
+        const char* rp = e.relpath ? e.relpath : "";
+        return mi_walk::abs_path(strcmp(rp, ".") == 0 ? "" : rp);
+    };
+    auto skipped = [&](const mi_tree_entry& e, const std::string& p) {            // shouldSkip + IsMounted (:190-199)
+        const std::string on_disk = fs.root == "/" ? p : fs.root + (p == "/" ? "" : p);
+        if (mi_walk::has_prefix(mi_walk::base_of(p), ".wh..wh.")) return true;
+        if (mi_walk::is_descendant_of_any(on_disk, bl) || e.kind > 3) return true;
+        if (mt.targets.count(on_disk)) return true;
+        for (const std::string& t : mt.targets)
+            if (mi_walk::has_prefix(on_disk, t.back() == '/' ? t : t + "/")) return true;
+        return false;
+    };
+    auto one = [&](const mi_tree_entry& e, const std::string& p) {
+        mi_copy::Node n;
+        n.e.relpath = p == "/" ? "" : p.substr(1);
+        n.e.kind = e.kind; n.e.mode = e.mode; n.e.mtime = e.mtime_sec; n.e.uid = e.uid; n.e.gid = e.gid; n.e.size = e.size;
+        if (e.link_target) {
+            n.e.has_link = true;                                                  // "Docker hard link names are all absolute,
+            n.e.link = e.kind == 3 ? mi_walk::abs_path(e.link_target) : e.link_target;   //  but don't have a leading slash"
+        }
+        // src: the reference passes AbsPath(hdr.Name) (:225) -- the path the entry is untarred to when the root is "/",
+        // as in every real build; under another root that is filepath.Join(root, name), and isOnDisk must look THERE
+        fs.maybe_add(fs.root == "/" ? p : fs.root + (p == "/" ? "" : p), p, n, false);
+    };
+    std::map<std::string, uint64_t> hardlinks;
+    for (uint64_t j = 0; j < n_layer && !fs.rc; ++j) {
+        const std::string p = path_of(layer[j]);
+        if (skipped(layer[j], p)) continue;
+        if (layer[j].kind == 3) { hardlinks[p] = j; continue; }
+        one(layer[j], p);
+    }
+    for (auto& kv : hardlinks) {
+        if (fs.rc) break;
+        one(layer[kv.second], kv.first);
+    }
+    if (fs.rc) { fs.err = "add hdr from tar to layer: " + fs.err; return memfs_fail(m); }
+    if (n_merged) *n_merged = fs.layer.size();                                    // "Merged %d headers from tar to memfs"
+    fs.layer.clear();
+    return MI_OK;
+}
+
+// MemFS.createLayerByScan (:315-341) on a walk of the root (mi_tree_walk / mi_batch_add_tree with MI_TREE_SCAN,
+// rel_base = root): every walked path through maybeAddToLayer with createWhiteout = true
+extern "C" int mi_memfs_add_layer_by_scan(mi_memfs* m, const mi_tree_entry* walked, uint64_t n, const void* roots,
+                                          uint64_t root_stride, mi_copy_layer** out, uint64_t* n_entries) {
+    if (!m || (n && !walked) || !out) return MI_ERR_INVALID;
+    mi_copy::Fs& fs = m->fs;
+    fs.layer.clear();
+    for (uint64_t i = 0; i < n && !fs.rc; ++i) {
+        const mi_tree_entry& e = walked[i];
+        const char* rp = e.relpath ? e.relpath : "";
+        const std::string p = mi_walk::abs_path(strcmp(rp, ".") == 0 ? "" : rp);
+        mi_copy::Node nd;
+        nd.e.relpath = p == "/" ? "" : p.substr(1);
+        nd.e.kind = e.kind; nd.e.mode = e.mode; nd.e.mtime = e.mtime_sec; nd.e.uid = e.uid; nd.e.gid = e.gid; nd.e.size = e.size;
+        if (e.link_target) { nd.e.has_link = true; nd.e.link = e.link_target; }
+        if (roots && e.kind == 1 && e.file_index >= 0) {
+            nd.has_root = true;
+            memcpy(nd.root, (const uint8_t*)roots + (uint64_t)e.file_index * root_stride, 32);
+        }
+        const std::string src = fs.root == "/" ? p : fs.root + (p == "/" ? "" : p);
+        fs.maybe_add(src, p, nd, true);
+    }
+    if (fs.rc) { fs.err = "add to layer: " + fs.err; return memfs_fail(m); }
+    mi_copy_layer* l = memfs_take_layer(m);
+    if (n_entries) *n_entries = l->nodes.size();
+    *out = l;
+    return MI_OK;
+}
+
+// MemFS.AddLayerByCopyOps (:276-289): the ops against THIS tree, which they update
+extern "C" int mi_memfs_add_layer_by_copy_ops(mi_memfs* m, const mi_copy_op* ops, uint64_t n_ops, mi_copy_layer** out,
+                                              uint64_t* n_entries) {
+    if (!m || (n_ops && !ops) || !out) return MI_ERR_INVALID;
+    m->fs.layer.clear();
+    std::string e;
+    const int rc = copy_ops_into(m->fs, ops, n_ops, &e);
+    if (rc) { if (m->fs.rc) return memfs_fail(m); m->err = e; m->fs.layer.clear(); return rc; }
+    mi_copy_layer* l = memfs_take_layer(m);
+    if (n_entries) *n_entries = l->nodes.size();
+    *out = l;
+    return MI_OK;
+}
+
+// the tree, sorted by path (directories made up by addAncestors included: they are nodes like any other)
+extern "C" int mi_memfs_entries(const mi_memfs* m, mi_tree_entry* out, const char** src_paths, uint64_t cap, uint64_t* n_out) {
+    if (!m || !n_out || (cap && !out)) return MI_ERR_INVALID;
+    std::vector<std::pair<std::string, int64_t>> flat;
+    std::function<void(const mi_memtree::Node&, const std::string&)> collect = [&](const mi_memtree::Node& n, const std::string& p) {
+        for (auto& kv : n.children) {
+            const std::string q = p + "/" + kv.first;
+            if (kv.second->ref >= 0) flat.emplace_back(q, kv.second->ref);
+            collect(*kv.second, q);
+        }
+    };
+    collect(m->fs.t.root, "");
+    std::sort(flat.begin(), flat.end());
+    *n_out = flat.size();
+    if (cap < flat.size()) return MI_ERR_CAPACITY;
+    for (size_t i = 0; i < flat.size(); ++i) {
+        const mi_copy::Node& n = m->fs.nodes[flat[i].second];
+        memset(&out[i], 0, sizeof out[i]);
+        out[i].relpath = n.e.relpath.c_str();
+        out[i].link_target = n.e.has_link ? n.e.link.c_str() : nullptr;
+        out[i].file_index = -1;
+        out[i].size = n.e.size; out[i].mtime_sec = n.e.mtime; out[i].mode = n.e.mode; out[i].kind = n.e.kind;
+        out[i].uid = n.e.uid; out[i].gid = n.e.gid;
+        if (src_paths) src_paths[i] = n.src.c_str();
+    }
     return MI_OK;
 }
 
@@ -1587,7 +1820,7 @@ extern "C" int mi_copy_layer_entries(const mi_copy_layer* l, mi_tree_entry* out,
         memset(&out[i], 0, sizeof out[i]);
         out[i].relpath = n.e.relpath.c_str();
         out[i].link_target = n.e.has_link ? n.e.link.c_str() : nullptr;
-        out[i].file_index = n.e.kind == 1 ? n_regular++ : -1;
+        out[i].file_index = n.e.kind == 1 && !mi_walk::has_prefix(mi_walk::base_of(n.e.relpath), ".wh.") ? n_regular++ : -1;   // a whiteout has no content
         out[i].size = n.e.size;
         out[i].mtime_sec = n.e.mtime;
         out[i].mode = n.e.mode;

@@ -1,0 +1,245 @@
+"""CPU tests of mi_memfs_*: the reference's MemFS (lib/snapshot/mem_fs.go) as a handle -- one tree for the life of a build.
+
+Replayed: TestAddLayerByScanWhiteout (mem_fs_test.go:1038-1116), TestCreateLayerByScan's Simple / Symlink / Whiteout
+(:572-686), TestUpdateMemFS (:164-344), TestAddLayersEqual's intent (:1118-1196), a FROM + COPY + RUN sequence the way
+build_stage.go drives MemFS (UpdateFromTar, AddLayerByCopyOps, AddLayerByScan) -- and, on generated sequences, the handle
+against the stateless calls it generalises (mi_snapshot_diff, mi_entries_apply_layer) and against the line-by-line model
+of tests/test_host_apply_properties.py, made-up directories included."""
+import os
+import shutil
+
+import pytest
+from hypothesis import given, settings, strategies as st
+
+import makisu_amd as M
+from test_host_apply_properties import Node, _abs, _entry, flatten, model_update_from_tar, ReferenceFails
+
+
+def _mk(root, spec):
+    for p, kind, content in spec:
+        full = os.path.join(root, p.lstrip("/"))
+        if kind == "d":
+            os.makedirs(full, exist_ok=True)
+        elif kind == "f":
+            os.makedirs(os.path.dirname(full), exist_ok=True)
+            with open(full, "w") as f:
+                f.write(content)
+            os.chmod(full, 0o755)
+        else:
+            os.makedirs(os.path.dirname(full), exist_ok=True)
+            os.symlink(content, full)
+
+
+def _names(layer):
+    return ["/" + e["relpath"] for e in layer]
+
+
+def test_add_layer_by_scan_whiteout_replayed(tmp_path):
+    """six entries under /test1 -> a layer of 6; RemoveAll(/test1) -> a layer of ONE entry, the whiteout of /test1"""
+    root = str(tmp_path)
+    _mk(root, [("/test1", "d", ""), ("/test1/test2", "d", ""), ("/test1/test2/test3.txt", "f", "hello"), ("/test1/test4", "d", ""),
+               ("/test1/test4/test5", "d", ""), ("/test1/test4/test5/test6.txt", "f", "hello")])
+    with M.MemFS(root) as fs:
+        l1 = fs.scan()
+        assert len(l1) == 6 and _names(l1) == sorted(_names(l1))
+        assert [e["src"] for e in l1] == [root + p for p in _names(l1)]
+        assert fs.scan() == []                                  # nothing changed: an empty layer
+        shutil.rmtree(os.path.join(root, "test1"))
+        l2 = fs.scan()
+        assert _names(l2) == ["/.wh.test1"] and l2[0]["src"] == "" and l2[0]["file_index"] == -1
+        assert fs.entries() == [] and fs.scan() == []
+
+
+def test_create_layer_by_scan_replayed(tmp_path):
+    """Simple: new paths with their (new) directories; Symlink: the target as written; Whiteout: a removed file in a
+    directory that stays -> the directory is carried as an ancestor beside the whiteout"""
+    root = str(tmp_path)
+    _mk(root, [("/test1/test2/test3.txt", "f", "hello"), ("/test1/link", "l", "test2/test3.txt"),
+               ("/test1/abs", "l", os.path.join(root, "test1/test2"))])
+    with M.MemFS(root) as fs:
+        l1 = fs.scan()
+        by = {"/" + e["relpath"]: e for e in l1}
+        assert sorted(by) == ["/test1", "/test1/abs", "/test1/link", "/test1/test2", "/test1/test2/test3.txt"]
+        assert by["/test1/link"]["link_target"] == "test2/test3.txt"
+        assert by["/test1/abs"]["link_target"] == "/test1/test2"          # createHeader trims the root (mem_layer.go:176-184)
+        os.unlink(os.path.join(root, "test1/test2/test3.txt"))
+        l2 = fs.scan()
+        # the directory's mtime changed with the unlink: it is in the layer as a changed entry, its parent as an ancestor
+        assert _names(l2) == ["/test1", "/test1/test2", "/test1/test2/.wh.test3.txt"]
+        assert [e["relpath"] for e in fs.entries()] == ["test1", "test1/abs", "test1/link", "test1/test2"]
+
+
+def test_update_mem_fs_through_the_real_path():
+    """TestUpdateMemFS (mem_fs_test.go:164-344) through UpdateFromTarReader -> maybeAddToLayer: where the test-only
+    MemFS.merge fails with "missing intermediate directory" (SkipDirCausesError), the real path CREATES the directory --
+    mode of the nearest ancestor, mtime = the clock, uid/gid 0 (addAncestors :551-559) -- and here it is part of the tree."""
+    D = lambda p, mode=0o755, **kw: dict({"relpath": p, "kind": M.KIND_DIR, "mode": 0o40000 | mode, "mtime_sec": 100, "size": 0}, **kw)   # noqa: E731
+    F = lambda p, mode=0o755: {"relpath": p, "kind": M.KIND_FILE, "mode": 0o100000 | mode, "mtime_sec": 100, "size": 5}                   # noqa: E731
+    rel = lambda fs: [e["relpath"] for e in fs.entries()]                                                                                 # noqa: E731
+    with M.MemFS("/tmp", now_sec=777) as fs:
+        assert fs.update_from_entries([D("/test1"), D("/test1/test2")]) == 2 and rel(fs) == ["test1", "test1/test2"]       # Simple
+        assert fs.update_from_entries([F("/test1", 0o777)]) == 1 and rel(fs) == ["test1"]                                    # Mutation
+        fs.reset()
+        assert fs.update_from_entries([D("test1/"), D("test1/test2/")]) == 2 and rel(fs) == ["test1", "test1/test2"]         # TrailingSlashes
+        assert fs.update_from_entries([D("test1/"), D("test1/test2/")]) == 0                                                 # similar: nothing merged
+        fs.reset()
+        assert fs.update_from_entries([D("/test1", 0o700), D("/test1/test2/test3")]) == 3                                   # SkipDir...: + the made-up one
+        made = fs.entries()[1]
+        assert made["relpath"] == "test1/test2" and made["kind"] == M.KIND_DIR and made["mode"] & 0o7777 == 0o700
+        assert (made["mtime_sec"], made["uid"], made["gid"], made["src"]) == (777, 0, 0, "")
+        fs.reset()
+        l1 = [D("/test11"), D("/test11/test12"), F("/test11/test12/test.txt")]
+        fs.update_from_entries(l1)
+        # WhiteoutExistingDir: two headers in the merged layer -- the whiteout and /test11, carried as its ancestor
+        assert fs.update_from_entries([D("/test11"), D("/test11/.wh.test12")]) == 2 and rel(fs) == ["test11"]
+        fs.reset()
+        fs.update_from_entries(l1)
+        fs.update_from_entries([D("/test11"), D("/test11/.wh.test13")])                                                     # WhiteoutNonexistent...
+        assert rel(fs) == ["test11", "test11/test12", "test11/test12/test.txt"]
+        with pytest.raises(M.MiError) as ei:                                                                                 # the reference's failure
+            fs.update_from_entries([{"relpath": "lnk", "kind": M.KIND_SYMLINK, "mode": 0o120777, "mtime_sec": 1, "size": 0,
+                                     "link_target": "/test11"}, F("lnk/a/b")])
+        assert "add hdr from tar to layer: update memfs with file /lnk/a/b: missing intermediate directory a in /lnk/a/b" in str(ei.value)
+        assert fs.update_from_entries([F("/after")]) == 1                                                                    # the handle stays usable
+
+
+def test_from_copy_run_sequence(tmp_path):
+    """The calls build_stage.go makes for `FROM base; COPY src /app/; RUN touch/rm`: the base layer's headers merged (the
+    files are on disk: modifyfs), a copy layer whose nodes remember their SOURCE, a scan layer.  isOnDisk asks about a node's
+    src (mem_fs.go:49-57): /app/a.txt was not copied to disk (no modifyfs for this step) -- yet the scan writes no whiteout
+    for it, because its source still exists; once the source is gone too, the next scan does."""
+    root = str(tmp_path / "rootfs")
+    ctx = str(tmp_path / "ctx")
+    _mk(root, [("/etc/conf", "f", "base"), ("/usr/bin/tool", "f", "tool"), ("/app", "d", "")])
+    _mk(ctx, [("/src/a.txt", "f", "A"), ("/src/sub/b.txt", "f", "B")])
+    base = [e for e in M.tree_walk(root, root, (), M.TREE_SCAN, full=True) if e["relpath"] != "."]
+    with M.MemFS(root) as fs:
+        assert fs.update_from_entries(base) == len(base)
+        assert fs.scan() == []                                                   # disk == tree
+        op = {"src_root": ctx, "srcs": ["src"], "dst": "/app/", "uid": 0, "gid": 0}
+        layer = fs.add_layer_by_copy_ops([op])
+        assert _names(layer) == ["/app", "/app/a.txt", "/app/sub", "/app/sub/b.txt"]
+        assert {e["relpath"]: e["src"] for e in layer}["app/a.txt"] == ctx + "/src/a.txt"
+        assert _names(fs.add_layer_by_copy_ops([op])) == ["/app"]                # the same copy again: only the destination,
+                                                                                 # which addAncestors always carries
+        # RUN: one file appears, one base file disappears; the copied files are NOT on disk under /app
+        _mk(root, [("/app/gen.txt", "f", "generated")])
+        os.unlink(os.path.join(root, "usr/bin/tool"))
+        l3 = fs.scan()
+        names = _names(l3)
+        assert "/app/gen.txt" in names and "/usr/bin/.wh.tool" in names
+        assert not any(".wh.a.txt" in n or ".wh.sub" in n for n in names)         # their sources exist
+        shutil.rmtree(os.path.join(ctx, "src"))
+        os.utime(os.path.join(root, "app"), (5, 5))                              # /app is "changed", so it is looked at again
+        l4 = fs.scan()
+        assert "/app/.wh.a.txt" in _names(l4) and "/app/.wh.sub" in _names(l4)
+
+
+def test_copy_layer_and_scan_layer_agree(tmp_path):
+    """TestAddLayersEqual's intent (mem_fs_test.go:1118-1196): the layer of a copy and the layer of a scan after doing
+    that copy on disk hold the same paths with the same headers (mtime of created directories aside)."""
+    root = str(tmp_path / "rootfs")
+    ctx = str(tmp_path / "ctx")
+    os.makedirs(root)
+    _mk(ctx, [("/c/x", "f", "1"), ("/c/d/y", "f", "22"), ("/c/l", "l", "x")])
+    st = os.lstat(ctx)
+    with M.MemFS(root) as a, M.MemFS(root) as b:
+        la = a.add_layer_by_copy_ops([{"src_root": ctx, "srcs": ["c"], "dst": "/dst/", "uid": st.st_uid, "gid": st.st_gid}])
+        shutil.copytree(os.path.join(ctx, "c"), os.path.join(root, "dst"), symlinks=True)
+        lb = b.scan()
+        key = lambda e: (e["relpath"], e["kind"], e["mode"], e["size"], e["link_target"], e["uid"], e["gid"])   # noqa: E731
+        assert [key(e) for e in la] == [key(e) for e in lb]
+
+
+# ---- generated sequences: the handle against the stateless calls and the model ------------------------------------------
+
+def _plain(e):
+    return {k: e.get(k) for k in ("relpath", "kind", "mode", "mtime_sec", "uid", "gid", "size", "link_target")}
+
+
+@settings(max_examples=300, deadline=None, derandomize=True, database=None)
+@given(st.lists(st.lists(_entry(), min_size=0, max_size=7), min_size=1, max_size=4))
+def test_update_from_entries_equals_the_model_made_up_directories_included(layers):
+    tree = Node({"kind": M.KIND_DIR, "mode": 0o40755, "mtime_sec": 1, "uid": 0, "gid": 0, "size": 0, "link_target": None,
+                 "relpath": ""}, "/")
+    with M.MemFS("/", now_sec=1 << 40) as fs:
+        for layer in layers:
+            try:
+                model_update_from_tar(tree, layer)
+            except ReferenceFails as e:
+                with pytest.raises(M.MiError) as ei:
+                    fs.update_from_entries(layer)
+                assert str(e)[:150] in str(ei.value)
+                return
+            fs.update_from_entries(layer)
+            got = {"/" + e["relpath"]: e for e in fs.entries()}
+            want = {}
+
+            def walk(n, p):
+                for name, c in n.children.items():
+                    q = p.rstrip("/") + "/" + name
+                    want[q] = c
+                    walk(c, q)
+            walk(tree, "/")
+            assert sorted(got) == sorted(want)
+            for p, node in want.items():
+                g = got[p]
+                if node.made_up:
+                    assert (g["kind"], g["mtime_sec"], g["uid"], g["gid"]) == (M.KIND_DIR, 1 << 40, 0, 0), p
+                else:
+                    h = node.hdr
+                    assert (g["kind"], g["mode"], g["mtime_sec"], g["uid"], g["size"]) == \
+                        (h["kind"], h["mode"], h["mtime_sec"], h["uid"], h["size"]), p
+                    if h["kind"] == M.KIND_SYMLINK:
+                        assert g["link_target"] == h["link_target"]
+                    elif h["kind"] == M.KIND_HARDLINK:
+                        assert g["link_target"] == _abs(h["link_target"])
+        assert flatten(tree).keys() <= got.keys()
+
+
+from test_host_diff_properties import tree_pairs  # noqa: E402
+
+
+def _materialize(root, entries):
+    """the entry list as a real tree: sizes, modes, link targets and (last, deepest first) the mtimes"""
+    for e in entries:
+        full = os.path.join(root, e["relpath"])
+        if e["kind"] == M.KIND_DIR:
+            os.mkdir(full)
+        elif e["kind"] == M.KIND_SYMLINK:
+            os.symlink(e["link_target"], full)
+        else:
+            with open(full, "wb") as f:
+                f.write(b"x" * e["size"])
+        if e["kind"] != M.KIND_SYMLINK:
+            os.chmod(full, e["mode"] & 0o7777)
+    for e in sorted(entries, key=lambda e: -e["relpath"].count("/")):
+        os.utime(os.path.join(root, e["relpath"]), (e["mtime_sec"], e["mtime_sec"]), follow_symlinks=False)
+
+
+@settings(max_examples=150, deadline=None, derandomize=True, database=None)
+@given(tree_pairs())
+def test_scan_layer_of_the_handle_equals_the_stateless_diff(tmp_path_factory, pair):
+    """mi_memfs_add_layer_by_scan against mi_snapshot_diff: the tree holds `before`, the disk holds `after` (generated,
+    mutated, then really created: the handle asks the disk whether a node's source is gone)."""
+    before, after = pair
+    root = str(tmp_path_factory.mktemp("memfs_root"))
+    _materialize(root, after)
+    walked = M.tree_walk(root, root, (), M.TREE_SCAN, full=True)
+    assert [e["relpath"] for e in walked[1:]] == [e["relpath"] for e in after]
+    flags, wh = M.snapshot_diff(before, walked, disk_root=root)          # (with the root: its children can be deleted too)
+    want_content = {"/" + e["relpath"] for e, f in zip(walked, flags) if f != M.DIFF_SAME}
+    want_wh = {"/" + e["relpath"] for e, w in zip(before, wh) if w}
+    with M.MemFS(root) as fs:
+        fs.update_from_entries(before)
+        layer = fs.add_layer_by_scan(walked)
+        got_content, got_wh = set(), set()
+        for e in layer:
+            d, b = os.path.split("/" + e["relpath"])
+            if b.startswith(".wh."):
+                got_wh.add(os.path.join(d, b[4:]))
+            else:
+                got_content.add("/" + e["relpath"])
+        assert got_wh == want_wh and got_content == want_content
+        assert [("/" + e["relpath"]) for e in fs.entries()] == sorted("/" + e["relpath"] for e in after)   # the tree IS the disk now
+        assert fs.add_layer_by_scan(walked) == []
