@@ -49,6 +49,7 @@
 #include <mutex>
 #include <thread>
 #include <set>
+#include <unordered_map>
 #include <string>
 #include <vector>
 
@@ -1072,14 +1073,23 @@ struct Node {
 struct Fs {
     mi_memtree::Tree t;                      // fs.tree; a node's ref indexes `nodes`
     std::vector<Node> nodes;
-    std::map<std::string, int64_t> layer;  // memLayer.files: keyed by dst -- by the DELETED path for a ".wh." name
+    std::unordered_map<std::string, int64_t> layer;   // memLayer.files: keyed by dst -- by the DELETED path for a ".wh."
+                                                       // name; sorted when the layer is taken (rangeFiles, mem_layer.go:232-244)
+    std::vector<Node> sorted_layer() const {
+        std::vector<std::pair<std::string, int64_t>> keys(layer.begin(), layer.end());
+        std::sort(keys.begin(), keys.end());                                        // sort.Strings on the keys
+        std::vector<Node> out;
+        out.reserve(keys.size());
+        for (auto& kv : keys) out.push_back(nodes[kv.second]);
+        return out;
+    }
     std::string root;                      // fs.tree.src
     int64_t now = 0;
     std::string err;
     int rc = MI_OK;
 
     bool fail(int code, const std::string& m) { if (!rc) { rc = code; err = m; } return false; }
-    int64_t keep(const Node& n) { nodes.push_back(n); return (int64_t)nodes.size() - 1; }
+    int64_t keep(Node n) { nodes.push_back(std::move(n)); return (int64_t)nodes.size() - 1; }
 
     Fs() {
         t.on_add = [this](const std::string& dst, int64_t ref) {               // memLayer.addHeader (mem_layer.go:197-212)
@@ -1156,11 +1166,13 @@ struct Fs {
             add_ancestors(dst, false, 0, 0);
             if (rc) return;
             n.src = src;
+            const uint8_t kind = n.e.kind;
+            const std::string link = n.e.has_link ? n.e.link : std::string();
             // updateMemFS walks the tree part by part (mem_layer.go:57-80): every part before the last has to be a
             // node -- of any type.  A destination spelled THROUGH a symlink therefore works one level below the
             // link (the link node takes the child) and fails deeper ("missing intermediate directory"): what
             // addAncestors created lies on the link's TARGET, and its resolved path is only used by the createDst branch
-            if (!t.add(dst, keep(n), n.e.kind, n.e.has_link ? n.e.link : std::string())) {
+            if (!t.add(dst, keep(std::move(n)), kind, link)) {
                 fail(MI_ERR_INVALID, "update memfs with file " + dst + ": " + t.err);
                 return;
             }
@@ -1626,7 +1638,7 @@ extern "C" int mi_snapshot_copy_ops(const mi_tree_entry* tree, uint64_t n_tree, 
     const int rc = copy_ops_into(fs, ops, n_ops, &e);
     if (rc) { put_err(e); return rc; }
     mi_copy_layer* l = new mi_copy_layer();
-    for (auto& kv : fs.layer) l->nodes.push_back(fs.nodes[kv.second]);   // std::map order == sort.Strings order
+    l->nodes = fs.sorted_layer();
     *out = l;
     if (n_entries) *n_entries = l->nodes.size();
     return MI_OK;
@@ -1645,7 +1657,7 @@ struct mi_memfs {
 
 static mi_copy_layer* memfs_take_layer(mi_memfs* m) {
     mi_copy_layer* l = new mi_copy_layer();
-    for (auto& kv : m->fs.layer) l->nodes.push_back(m->fs.nodes[kv.second]);     // std::map order == sort.Strings order
+    l->nodes = m->fs.sorted_layer();
     m->fs.layer.clear();
     return l;
 }
@@ -1702,13 +1714,15 @@ extern "C" int mi_memfs_update_from_entries(mi_memfs* m, const mi_tree_entry* la
         const char* rp = e.relpath ? e.relpath : "";
         return mi_walk::abs_path(strcmp(rp, ".") == 0 ? "" : rp);
     };
+    std::vector<std::string> below_mount;                                         // "<target>/": isMounted's prefixes
+    for (const std::string& t : mt.targets) below_mount.push_back(t.back() == '/' ? t : t + "/");
     auto skipped = [&](const mi_tree_entry& e, const std::string& p) {            // shouldSkip + IsMounted (:190-199)
         const std::string on_disk = fs.root == "/" ? p : fs.root + (p == "/" ? "" : p);
         if (mi_walk::has_prefix(mi_walk::base_of(p), ".wh..wh.")) return true;
-        if (mi_walk::is_descendant_of_any(on_disk, bl) || e.kind > 3) return true;
+        if (e.kind > 3 || (!bl.empty() && mi_walk::is_descendant_of_any(on_disk, bl))) return true;
         if (mt.targets.count(on_disk)) return true;
-        for (const std::string& t : mt.targets)
-            if (mi_walk::has_prefix(on_disk, t.back() == '/' ? t : t + "/")) return true;
+        for (const std::string& t : below_mount)
+            if (mi_walk::has_prefix(on_disk, t)) return true;
         return false;
     };
     auto one = [&](const mi_tree_entry& e, const std::string& p) {
@@ -1721,9 +1735,10 @@ extern "C" int mi_memfs_update_from_entries(mi_memfs* m, const mi_tree_entry* la
         }
         // src: the reference passes AbsPath(hdr.Name) (:225) -- the path the entry is untarred to when the root is "/",
         // as in every real build; under another root that is filepath.Join(root, name), and isOnDisk must look THERE
-        fs.maybe_add(fs.root == "/" ? p : fs.root + (p == "/" ? "" : p), p, n, false);
+        fs.maybe_add(fs.root == "/" ? p : fs.root + (p == "/" ? "" : p), p, std::move(n), false);
     };
     std::map<std::string, uint64_t> hardlinks;
+    fs.nodes.reserve(fs.nodes.size() + n_layer);
     for (uint64_t j = 0; j < n_layer && !fs.rc; ++j) {
         const std::string p = path_of(layer[j]);
         if (skipped(layer[j], p)) continue;
