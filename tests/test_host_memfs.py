@@ -243,3 +243,38 @@ def test_scan_layer_of_the_handle_equals_the_stateless_diff(tmp_path_factory, pa
         assert got_wh == want_wh and got_content == want_content
         assert [("/" + e["relpath"]) for e in fs.entries()] == sorted("/" + e["relpath"] for e in after)   # the tree IS the disk now
         assert fs.add_layer_by_scan(walked) == []
+
+
+def test_plain_c_build_stage(tmp_path):
+    """tests/cabi/memfs_driver.c: NewMemFS, a scan layer, a RUN step, another scan layer -- from plain C against the
+    header; the layers are those the python harness gets, and extracting one over the other reproduces the root."""
+    import hashlib
+    import subprocess
+    import tarfile
+    exe = str(tmp_path / "memfs_driver")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["gcc", "-O1", "-Wall", "-Werror", "-I", os.path.join(repo, "include"),
+                           os.path.join(repo, "tests", "cabi", "memfs_driver.c"), "-o", exe,
+                           "-L", os.path.join(repo, "makisu_amd"), "-lmakisu_mi", "-Wl,-rpath," + os.path.join(repo, "makisu_amd")])
+    root = str(tmp_path / "root")
+    _mk(root, [("/etc/passwd", "f", "root"), ("/etc/deep/er/x.conf", "f", "x"), ("/bin/tool", "f", "t" * 70000),
+               ("/bin/alias", "l", "tool")])
+    twin = str(tmp_path / "twin")
+    shutil.copytree(root, twin, symlinks=True)
+    cmd = "cd %s && rm -rf etc/deep bin/tool && echo more >> etc/passwd && mkdir new && echo hi > new/f"
+    out = subprocess.run([exe, root, cmd % root, str(tmp_path / "1.tar"), str(tmp_path / "2.tar")], check=True,
+                         capture_output=True, text=True).stdout.splitlines()
+    names = {k: [ln.split(" ", 2)[2] for ln in out if ln.startswith("E %d " % k)] for k in (1, 2)}
+    layers = {int(ln.split()[1]): ln.split()[2:] for ln in out if ln.startswith("L ")}
+    for k in (1, 2):
+        assert layers[k][1] == hashlib.sha256((tmp_path / ("%d.tar" % k)).read_bytes()).hexdigest()
+        assert int(layers[k][0]) == len(names[k])
+    assert names[2] == ["bin", "bin/.wh.tool", "etc", "etc/.wh.deep", "etc/passwd", "new", "new/f"]
+    with M.MemFS(twin) as fs:                                    # the same stage through the python harness, on a twin
+        assert [e["relpath"] for e in fs.scan()] == names[1]
+        subprocess.check_call(cmd % twin, shell=True)
+        assert [e["relpath"] for e in fs.scan()] == names[2]
+        assert int([ln for ln in out if ln.startswith("T ")][0].split()[1]) == len(fs.entries())
+    with tarfile.open(tmp_path / "2.tar") as tf:
+        assert [m.name.rstrip("/") for m in tf.getmembers()] == names[2]
+        assert tf.extractfile("etc/passwd").read() == b"rootmore\n" and tf.getmember("bin/.wh.tool").size == 0
