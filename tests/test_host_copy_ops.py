@@ -298,3 +298,24 @@ def test_copy_layer_equals_scan_layer_of_the_same_copy(tmp_path):
     assert not any(wh) and [e["relpath"] for e in lay2] == [e["relpath"] for e in lay1]
     raw2, pair2 = frame(lay2, lambda e: os.path.join(str(root), e["relpath"]), "scan.tar")
     assert raw1 == raw2 and pair1["tar_sha256"] == pair2["tar_sha256"] == hashlib.sha256(raw1).digest()
+
+
+def test_eval_symlinks_cases_replayed(tmp_path):
+    """lib/snapshot/utils_test.go:86-147 (TestEvalSymlink: no_symlinks, simple_case, layered): a copy's source is resolved
+    through the symlinks inside the source root -- relative ones, absolute ones that point into the root, a linked
+    directory in the middle of the path -- and the layer reads the bytes from where the chain ends."""
+    r = tmp_path / "r"
+    (r / "dir1").mkdir(parents=True)
+    (r / "dir1" / "tmp1").write_text("one")
+    (r / "test1").write_text("t1")
+    os.symlink("test1", r / "link2")                         # relative
+    os.symlink(str(r / "link2"), r / "link3")                # absolute, inside the root, to another link
+    (r / "dir2").mkdir()
+    os.symlink(str(r / "dir1"), r / "dir2" / "dir3")         # a linked directory on the way
+    def src_of(path):                                        # noqa: E306
+        layer = M.copy_ops_layer([], str(tmp_path / "fsroot"), [_op(r, [path], "/dst/x")])
+        return _by_dst(layer)["/dst/x"]["src"]
+    (tmp_path / "fsroot").mkdir()
+    assert src_of("dir1/tmp1") == str(r / "dir1" / "tmp1")
+    assert src_of("link2") == str(r / "test1") and src_of("link3") == str(r / "test1")
+    assert src_of("dir2/dir3/tmp1") == str(r / "dir1" / "tmp1")
