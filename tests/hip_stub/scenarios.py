@@ -171,13 +171,32 @@ def scenario_api(tmp, threads, slab):
         check(b, b"after the errors", "api, after errors")
 
 
+def scenario_two_ctxs(tmp, threads, slab):
+    """"multiple ctxs may run concurrently" (include/makisu_mi.h): two engines driven from two host threads at once"""
+    import threading
+    errs = []
+
+    def work(k):
+        try:
+            scenario_growth_and_reuse(os.path.join(tmp, "ctx%d" % k), threads, slab)
+            scenario_api(os.path.join(tmp, "ctx%d" % k), threads, slab)
+        except BaseException as e:                      # noqa: BLE001
+            errs.append(repr(e))
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+
+
 def main():
     tmp = sys.argv[1]
     threads = int(sys.argv[2]) if len(sys.argv) > 2 else 4
     slab = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
     only = sys.argv[4].split(",") if len(sys.argv) > 4 else None
     for name, fn in [("mix", scenario_mix), ("growth", scenario_growth_and_reuse), ("two", scenario_two_batches),
-                     ("errors", scenario_errors), ("api", scenario_api)]:
+                     ("errors", scenario_errors), ("api", scenario_api), ("two_ctxs", scenario_two_ctxs)]:
         if only and name not in only:
             continue
         fn(tmp, threads, slab)
