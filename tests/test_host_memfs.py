@@ -278,3 +278,31 @@ def test_plain_c_build_stage(tmp_path):
     with tarfile.open(tmp_path / "2.tar") as tf:
         assert [m.name.rstrip("/") for m in tf.getmembers()] == names[2]
         assert tf.extractfile("etc/passwd").read() == b"rootmore\n" and tf.getmember("bin/.wh.tool").size == 0
+
+
+def test_content_roots_make_the_next_scan_content_aware(tmp_path):
+    """isUpdated's seam.  A same-size, same-second edit is invisible to tario.IsSimilarHeader; with
+    the chunk roots of each scan kept in the tree (here: stand-in 32-byte values, on the GPU box the batch's roots), the
+    next scan sees it -- and only it."""
+    import numpy as np
+    root = str(tmp_path)
+    _mk(root, [("/a/x", "f", "1111"), ("/a/y", "f", "2222"), ("/b", "f", "3333")])
+    for p in ("a/x", "a/y", "b", "a"):
+        os.utime(os.path.join(root, p), (1000, 1000))
+    walked = M.tree_walk(root, root, (), M.TREE_SCAN, full=True)
+    files = [e for e in walked if e["kind"] == M.KIND_FILE]
+    assert [e["file_index"] for e in files] == [0, 1, 2]
+    r1 = np.arange(3 * 32, dtype=np.uint8).reshape(3, 32)
+    with M.MemFS(root) as fs:
+        assert len(fs.add_layer_by_scan(walked, r1)) == 4
+        with open(os.path.join(root, "a/y"), "w") as f:            # same size; mtime put back: the header is identical
+            f.write("zzzz")
+        os.utime(os.path.join(root, "a/y"), (1000, 1000))
+        os.utime(os.path.join(root, "a"), (1000, 1000))
+        walked2 = M.tree_walk(root, root, (), M.TREE_SCAN, full=True)
+        assert [{k: v for k, v in e.items()} for e in walked2] == walked
+        r2 = r1.copy()
+        r2[1, 7] ^= 1                                                # what the GPU would report for the new content
+        assert fs.add_layer_by_scan(walked2, None) == []             # the reference's rule: nothing changed
+        assert [e["relpath"] for e in fs.add_layer_by_scan(walked2, r2)] == ["a", "a/y"]
+        assert fs.add_layer_by_scan(walked2, r2) == []               # the new root is the tree's now
