@@ -50,7 +50,9 @@
 #include <thread>
 #include <set>
 #include <unordered_map>
+#include <unordered_set>
 #include <string>
+#include <string_view>
 #include <vector>
 
 namespace mi_walk {
@@ -113,6 +115,27 @@ static std::string clean_any(const std::string& p) {
 }
 static std::string abs_path(const std::string& p) {          // pathutils.AbsPath (lib/pathutils/path.go:41-43)
     return clean_rooted(p);                                  // path.Join("/", strings.TrimRight(p, "/"))
+}
+// AbsPath of a relative path as the walks and tar readers write them: when it is already clean (no empty, "." or ".."
+// element) that is "/" + the path without trailing slashes; anything else takes the general route
+static std::string abs_path_of_rel(const char* rel) {
+    if (rel[0] == '.' && rel[1] == 0) return "/";
+    size_t n = strlen(rel);
+    while (n && rel[n - 1] == '/') --n;
+    bool clean = n > 0 && rel[0] != '/';
+    for (size_t i = 0; clean && i < n; ++i) {
+        if (rel[i] == '/' && (i + 1 >= n || rel[i + 1] == '/')) clean = false;
+        if (rel[i] == '.' && (i == 0 || rel[i - 1] == '/')) {
+            const size_t k = rel[i + 1] == '.' ? i + 2 : i + 1;
+            if (k >= n || rel[k] == '/') clean = false;
+        }
+    }
+    if (!clean) return abs_path(rel);
+    std::string out;
+    out.reserve(n + 1);
+    out.push_back('/');
+    out.append(rel, n);
+    return out;
 }
 static std::string dir_of(const std::string& p) {            // path.Dir for clean absolute paths
     size_t i = p.find_last_of('/');
@@ -526,7 +549,7 @@ struct Node {
     int64_t ref = -1;                          // caller's payload; -1 = none
     uint8_t kind = 0;                          // 0 dir, 1 regular, 2 symlink, 3 hard link, 4 special
     std::string link;                          // symlink target
-    std::map<std::string, std::unique_ptr<Node>> children;
+    std::map<std::string, std::unique_ptr<Node>, std::less<>> children;       // std::less<>: looked up by string_view
 };
 
 struct Tree {
@@ -558,10 +581,17 @@ struct Tree {
     }
     Node* find(const std::string& p) {                                          // isUpdated's walk; nullptr = "new"
         Node* cur = &root;
-        for (const std::string& part : parts(p)) {
-            auto it = cur->children.find(part);
-            if (it == cur->children.end()) return nullptr;
-            cur = it->second.get();
+        size_t i = 0;
+        while (i < p.size()) {                                                  // SplitPath's parts, without the vector
+            while (i < p.size() && p[i] == '/') ++i;
+            size_t j = i;
+            while (j < p.size() && p[j] != '/') ++j;
+            if (j > i) {
+                auto it = cur->children.find(std::string_view(p.data() + i, j - i));
+                if (it == cur->children.end()) return nullptr;
+                cur = it->second.get();
+            }
+            i = j;
         }
         return cur;
     }
@@ -1084,6 +1114,7 @@ struct Fs {
         return out;
     }
     std::string root;                      // fs.tree.src
+    const std::unordered_set<std::string_view>* walked = nullptr;   // the scan under way: the paths its walk lists
     int64_t now = 0;
     std::string err;
     int rc = MI_OK;
@@ -1182,20 +1213,30 @@ struct Fs {
         if (create_whiteout && n.e.kind == 0 && had_node) {
             mi_memtree::Node* dir = t.find(dst);
             if (!dir) return;
-            std::vector<std::string> names;
-            for (auto& kv : dir->children) names.push_back(kv.first);
-            for (const std::string& name : names) {
-                auto it = dir->children.find(name);
-                if (it == dir->children.end()) continue;
-                const std::string child = (dst == "/" ? "" : dst) + "/" + name;
-                const int64_t ref = it->second->ref;
+            std::vector<std::string> gone;                                      // (wiping changes the map: collect first)
+            std::string child = dst == "/" ? "/" : dst + "/";
+            const size_t stem = child.size();
+            for (auto& kv : dir->children) {
+                child.resize(stem);
+                child += kv.first;
+                const int64_t ref = kv.second->ref;
                 const std::string& child_src = ref >= 0 ? nodes[ref].src : std::string();
-                struct stat st;                                                 // memFSNode.isOnDisk (:49-57)
+                // memFSNode.isOnDisk (:49-57) is an lstat of the node's source.  When that source is the node's own place
+                // under the root and the walk of THIS scan lists it, the walk has just lstat'ed it: no second one (the
+                // reference pays it for every node of the tree on every scan)
+                if (walked && child_src.size() == (root == "/" ? 0 : root.size()) + child.size() && walked->count(std::string_view(child)) &&
+                    child_src.compare(child_src.size() - child.size(), child.size(), child) == 0 &&
+                    (root == "/" || child_src.compare(0, root.size(), root) == 0))
+                    continue;
+                struct stat st;
                 if (lstat(child_src.c_str(), &st) == 0) continue;
                 if (errno != ENOENT && errno != ENOTDIR) {
                     fail(MI_ERR_IO, "check on disk " + child + ": lstat " + child_src + ": " + strerror(errno));
                     return;
                 }
+                gone.push_back(child);
+            }
+            for (const std::string& child : gone) {
                 if (!add_whiteout(child)) return;
                 add_ancestors(child, false, 0, 0);
                 if (rc) return;
@@ -1762,10 +1803,19 @@ extern "C" int mi_memfs_add_layer_by_scan(mi_memfs* m, const mi_tree_entry* walk
     if (!m || (n && !walked) || !out) return MI_ERR_INVALID;
     mi_copy::Fs& fs = m->fs;
     fs.layer.clear();
+    std::unordered_set<std::string_view> on_walk;                               // views into `paths`
+    std::vector<std::string> paths(n);
+    on_walk.reserve(n * 2);
+    for (uint64_t i = 0; i < n; ++i) {
+        const char* rp = walked[i].relpath ? walked[i].relpath : "";
+        paths[i] = mi_walk::abs_path_of_rel(rp);
+        on_walk.insert(std::string_view(paths[i]));
+    }
+    fs.walked = &on_walk;
+    struct Unset { mi_copy::Fs& f; ~Unset() { f.walked = nullptr; } } unset{fs};
     for (uint64_t i = 0; i < n && !fs.rc; ++i) {
         const mi_tree_entry& e = walked[i];
-        const char* rp = e.relpath ? e.relpath : "";
-        const std::string p = mi_walk::abs_path(strcmp(rp, ".") == 0 ? "" : rp);
+        const std::string& p = paths[i];
         mi_copy::Node nd;
         nd.e.relpath = p == "/" ? "" : p.substr(1);
         nd.e.kind = e.kind; nd.e.mode = e.mode; nd.e.mtime = e.mtime_sec; nd.e.uid = e.uid; nd.e.gid = e.gid; nd.e.size = e.size;
@@ -1775,7 +1825,7 @@ extern "C" int mi_memfs_add_layer_by_scan(mi_memfs* m, const mi_tree_entry* walk
             memcpy(nd.root, (const uint8_t*)roots + (uint64_t)e.file_index * root_stride, 32);
         }
         const std::string src = fs.root == "/" ? p : fs.root + (p == "/" ? "" : p);
-        fs.maybe_add(src, p, nd, true);
+        fs.maybe_add(src, p, std::move(nd), true);
     }
     if (fs.rc) { fs.err = "add to layer: " + fs.err; return memfs_fail(m); }
     mi_copy_layer* l = memfs_take_layer(m);
