@@ -630,6 +630,16 @@ const char* mi_memfs_error(const mi_memfs* fs);
 int  mi_memfs_set_clock(mi_memfs* fs, int64_t now_sec);
 int  mi_memfs_reset(mi_memfs* fs);
 int  mi_memfs_update_from_entries(mi_memfs* fs, const mi_tree_entry* layer, uint64_t n_layer, uint64_t* n_merged);
+/* UpdateFromTarReader with untar = true (the FROM step / a cached layer applied with --modifyfs): the entries of a PLAIN
+ * tar -- mi_tar_entries(tar) with their data offsets; a gzip blob goes through mi_tar_inflate first -- are written below
+ * the root as MemFS.untarOneItem does (lib/snapshot/mem_fs.go:571-718): a ".wh.<x>" entry removes <x>; what is already
+ * on disk with a similar header stays; a directory on a directory is updated in place (tario.ApplyHeader: chown, chmod,
+ * mtime); anything else is removed and created again; an absolute symlink target is re-rooted; hard links come last; the
+ * mtimes of the parent directories are put back at the end -- and every header is merged into the tree as above.  After
+ * it a scan of the root finds nothing to add.  Needs the privileges the reference needs (chown).  MI_ERR_IO + the
+ * reference's message ("untar one item <path>: ...") on failure.                                                  */
+int  mi_memfs_untar(mi_memfs* fs, const char* tar_path, const mi_tree_entry* layer, const uint64_t* data_offsets,
+                    uint64_t n_layer, uint64_t* n_merged);
 int  mi_memfs_add_layer_by_scan(mi_memfs* fs, const mi_tree_entry* walked, uint64_t n, const void* roots,
                                 uint64_t root_stride, mi_copy_layer** out, uint64_t* n_entries);
 int  mi_memfs_add_layer_by_copy_ops(mi_memfs* fs, const mi_copy_op* ops, uint64_t n_ops, mi_copy_layer** out,

@@ -250,6 +250,7 @@ def load_library(rebuild=False):
         "mi_memfs_set_clock": ([vp, C.c_int64], C.c_int),
         "mi_memfs_reset": ([vp], C.c_int),
         "mi_memfs_update_from_entries": ([vp, C.POINTER(TreeEntry), u64, u64p], C.c_int),
+        "mi_memfs_untar": ([vp, C.c_char_p, C.POINTER(TreeEntry), u64p, u64, u64p], C.c_int),
         "mi_memfs_add_layer_by_scan": ([vp, C.POINTER(TreeEntry), u64, vp, u64, C.POINTER(vp), u64p], C.c_int),
         "mi_memfs_add_layer_by_copy_ops": ([vp, C.POINTER(CopyOp), u64, C.POINTER(vp), u64p], C.c_int),
         "mi_memfs_entries": ([vp, C.POINTER(TreeEntry), C.POINTER(C.c_char_p), u64, u64p], C.c_int),
@@ -608,6 +609,19 @@ class MemFS:
         arr = _entry_array(layer, keep)
         n = C.c_uint64()
         self._check(self._lib.mi_memfs_update_from_entries(self._h, arr, len(layer), C.byref(n)), "mi_memfs_update_from_entries")
+        return n.value
+
+    def update_from_tar(self, tar_path, untar=False):
+        """UpdateFromTarPath on a PLAIN tar: its headers merged into the tree; untar=True also writes it below the root
+        (untarOneItem).  Returns the number of headers merged."""
+        ents = tar_entries(tar_path)
+        if not untar:
+            return self.update_from_entries(ents)
+        keep = []
+        arr = _entry_array(ents, keep)
+        offs = (C.c_uint64 * max(len(ents), 1))(*[e["data_offset"] for e in ents])
+        n = C.c_uint64()
+        self._check(self._lib.mi_memfs_untar(self._h, os.fsencode(tar_path), arr, offs, len(ents), C.byref(n)), "mi_memfs_untar")
         return n.value
 
     def add_layer_by_scan(self, walked, roots=None):

@@ -32,6 +32,7 @@
 #include <dirent.h>
 #include <errno.h>
 #include <fcntl.h>
+#include <ftw.h>
 #include <grp.h>
 #include <pwd.h>
 #include <sched.h>
@@ -1685,6 +1686,131 @@ extern "C" int mi_snapshot_copy_ops(const mi_tree_entry* tree, uint64_t n_tree, 
     return MI_OK;
 }
 
+// ---- untar: MemFS.untarOneItem and tario.ApplyHeader (lib/snapshot/mem_fs.go:571-718, lib/tario/apply.go:23-47) --------
+namespace mi_untar {
+
+static int rm_cb(const char* p, const struct stat*, int, struct FTW*) { return remove(p); }
+static bool remove_all(const std::string& p, std::string* err) {                 // os.RemoveAll
+    struct stat st;
+    if (lstat(p.c_str(), &st) != 0) {
+        if (errno == ENOENT || errno == ENOTDIR) return true;
+        *err = "lstat " + p + ": " + strerror(errno);
+        return false;
+    }
+    if (!S_ISDIR(st.st_mode)) {
+        if (unlink(p.c_str()) == 0 || errno == ENOENT) return true;
+        *err = "unlinkat " + p + ": " + strerror(errno);
+        return false;
+    }
+    if (nftw(p.c_str(), rm_cb, 64, FTW_DEPTH | FTW_PHYS) != 0) { *err = "unlinkat " + p + ": " + strerror(errno); return false; }
+    return true;
+}
+
+// tario.ApplyHeader: owner, then permission bits (chmod after chown: setuid / setgid survive), then mtime; never on a
+// symlink and never FOR a symlink header
+static bool apply_header(const std::string& path, const mi_tree_entry& h, std::string* err) {
+    struct stat st;
+    if (lstat(path.c_str(), &st) != 0) { *err = "lstat " + path + ": " + strerror(errno); return false; }
+    if (S_ISLNK(st.st_mode) || h.kind == 2) { *err = "update symlink instead of file: " + path; return false; }
+    if (chown(path.c_str(), h.uid, h.gid) != 0) { *err = "chown " + path + ": " + strerror(errno); return false; }
+    if (chmod(path.c_str(), h.mode & 07777) != 0) { *err = "chmod " + path + ": " + strerror(errno); return false; }
+    struct timespec ts[2];
+    ts[0].tv_sec = ts[1].tv_sec = (time_t)h.mtime_sec;
+    ts[0].tv_nsec = ts[1].tv_nsec = 0;
+    if (utimensat(AT_FDCWD, path.c_str(), ts, 0) != 0) { *err = "chtimes " + path + ": " + strerror(errno); return false; }
+    return true;
+}
+
+static bool copy_range(int in_fd, uint64_t off, uint64_t len, int out_fd, std::string* err) {
+    std::vector<char> buf(1 << 20);
+    while (len) {
+        const size_t want = len < buf.size() ? (size_t)len : buf.size();
+        const ssize_t r = pread(in_fd, buf.data(), want, (off_t)off);
+        if (r < 0 && errno == EINTR) continue;
+        if (r <= 0) { *err = r == 0 ? "unexpected EOF" : strerror(errno); return false; }
+        size_t done = 0;
+        while (done < (size_t)r) {
+            const ssize_t w = write(out_fd, buf.data() + done, (size_t)r - done);
+            if (w < 0 && errno == EINTR) continue;
+            if (w < 0) { *err = strerror(errno); return false; }
+            done += (size_t)w;
+        }
+        off += (uint64_t)r;
+        len -= (uint64_t)r;
+    }
+    return true;
+}
+
+// untarOneItem(path, header, r): root = fs.tree.src; path = filepath.Join(root, hdr.Name); content of a regular file =
+// [data_off, +size) of tar_fd
+static bool one_item(const std::string& root, const std::string& path, const mi_tree_entry& h, int tar_fd, uint64_t data_off,
+                     std::string* err) {
+    const std::string base = mi_walk::base_of(path), dir = mi_walk::dir_of(path);
+    std::string e;
+    if (mi_walk::has_prefix(base, ".wh.")) {                                     // untarWhiteout
+        if (!remove_all((dir == "/" ? "" : dir) + "/" + base.substr(4), &e)) { *err = "untar dir: untar whiteout: " + e; return false; }
+        return true;
+    }
+    struct stat st;
+    if (lstat(path.c_str(), &st) != 0) {
+        if (errno != ENOENT && errno != ENOTDIR) { *err = "lstat " + path + ": " + strerror(errno); return false; }
+    } else {
+        // the header of what is there (tar.FileInfoHeader), link target trimmed of the root
+        mi_tree_entry local;
+        memset(&local, 0, sizeof local);
+        std::string link;
+        local.relpath = h.relpath && *h.relpath ? h.relpath : "x";              // (only "both names empty" matters to the predicate)
+        local.mode = st.st_mode; local.mtime_sec = st.st_mtime; local.uid = st.st_uid; local.gid = st.st_gid;
+        local.kind = S_ISDIR(st.st_mode) ? 0 : S_ISREG(st.st_mode) ? 1 : S_ISLNK(st.st_mode) ? 2 : 4;
+        local.size = S_ISREG(st.st_mode) ? (uint64_t)st.st_size : 0;
+        if (S_ISLNK(st.st_mode)) {
+            std::vector<char> buf(4096);
+            const ssize_t n = readlink(path.c_str(), buf.data(), buf.size() - 1);
+            if (n < 0) { *err = "read link " + path + ": " + strerror(errno); return false; }
+            link.assign(buf.data(), (size_t)n);
+            if (!link.empty() && link[0] == '/') {
+                if (!mi_walk::has_prefix(link, root)) { *err = "trim link " + link + ": failed to trim root prefix " + root + " from path " + link; return false; }
+                link = mi_walk::abs_path(link.substr(root.size()));
+            }
+            local.link_target = link.c_str();
+        }
+        if (local.kind > 3) { *err = "compare headers " + path + ": unsupported type"; return false; }
+        int similar = 0;
+        mi_tree_entry hh = h;
+        if (!hh.relpath || !*hh.relpath) hh.relpath = "x";
+        if (mi_entry_similar(&local, &hh, 0, nullptr, nullptr, &similar) != MI_OK) { *err = "compare headers " + path + ": unsupported type"; return false; }
+        if (similar) return true;                                                // "already on disk, nothing needs to be done"
+        if (h.kind == 0 && S_ISDIR(st.st_mode)) {                                // existing directories are updated, not deleted
+            if (!apply_header(path, h, &e)) { *err = "update fi " + path + ": " + e; return false; }
+            return true;
+        }
+        if (!remove_all(path, &e)) { *err = "clear existing file " + path + ": " + e; return false; }
+    }
+    if (h.kind == 0) {
+        if (mkdir(path.c_str(), h.mode & 07777) != 0) { *err = "untar dir: create dir " + path + ": " + strerror(errno); return false; }
+        if (!apply_header(path, h, &e)) { *err = "untar dir: update fi " + path + ": " + e; return false; }
+    } else if (h.kind == 2) {
+        std::string target = h.link_target ? h.link_target : "";
+        if (!target.empty() && target[0] == '/') target = mi_walk::abs_path(root + "/" + target);   // filepath.Join(root, target)
+        if (symlink(target.c_str(), path.c_str()) != 0) { *err = "untar symlink: create symlink " + path + " => " + target + ": " + strerror(errno); return false; }
+        if (lchown(path.c_str(), h.uid, h.gid) != 0) { *err = "untar symlink: lchown symlink: " + path; return false; }
+    } else if (h.kind == 3) {
+        const std::string target = mi_walk::abs_path(root + "/" + (h.link_target ? h.link_target : ""));
+        if (link(target.c_str(), path.c_str()) != 0) { *err = "untar hard link: create link " + path + " => " + target + ": " + strerror(errno); return false; }
+        if (!apply_header(path, h, &e)) { *err = "untar hard link: update hard link " + path + ": " + e; return false; }
+    } else {
+        const int fd = open(path.c_str(), O_CREAT | O_TRUNC | O_WRONLY | O_CLOEXEC, h.mode & 07777);
+        if (fd < 0) { *err = "untar file: open file " + path + ": " + strerror(errno); return false; }
+        const bool ok = h.size == 0 || (tar_fd >= 0 && copy_range(tar_fd, data_off, h.size, fd, &e));
+        close(fd);
+        if (!ok) { *err = "untar file: read from file " + path + ": " + (tar_fd < 0 ? "no archive to read from" : e); return false; }
+        if (!apply_header(path, h, &e)) { *err = "untar file: update fi " + path + ": " + e; return false; }
+    }
+    return true;
+}
+
+}  // namespace mi_untar
+
 // ---- MemFS as a handle: the reference's type (lib/snapshot/mem_fs.go:59-125) behind the ABI ---------------------------
 // One tree for the life of a build, as in the reference: base layers are merged into it (UpdateFromTarReader), every
 // step's layer is computed against it and folds into it (AddLayerByScan / AddLayerByCopyOps).  What the stateless calls
@@ -1741,12 +1867,14 @@ extern "C" int mi_memfs_reset(mi_memfs* m) {                                    
     return MI_OK;
 }
 
-// MemFS.UpdateFromTarReader (:165-255) with untar = false, on a layer's entries (mi_tar_entries)
-extern "C" int mi_memfs_update_from_entries(mi_memfs* m, const mi_tree_entry* layer, uint64_t n_layer,
-                                            uint64_t* n_merged) {
-    if (!m || (n_layer && !layer)) return MI_ERR_INVALID;
+// MemFS.UpdateFromTarReader (:165-255) on a layer's entries (mi_tar_entries); tar_fd >= 0: untar = true, a regular file's
+// bytes are [data_offsets[j], +size) of that descriptor
+static int memfs_update(mi_memfs* m, const mi_tree_entry* layer, uint64_t n_layer, int tar_fd, const uint64_t* data_offsets,
+                        bool untar, uint64_t* n_merged) {
     mi_copy::Fs& fs = m->fs;
     fs.layer.clear();
+    std::map<std::string, struct timespec> modtimes;                              // parent directories, to be put back
+    std::string uerr;
     const mi_walk::MountTable& mt = mi_walk::mountpoints();
     if (!mt.error.empty()) { m->err = "check if mounted: " + mt.error; return MI_ERR_IO; }
     std::vector<std::string> bl;
@@ -1766,7 +1894,12 @@ extern "C" int mi_memfs_update_from_entries(mi_memfs* m, const mi_tree_entry* la
             if (mi_walk::has_prefix(on_disk, t)) return true;
         return false;
     };
-    auto one = [&](const mi_tree_entry& e, const std::string& p) {
+    auto disk_path = [&](const std::string& p) { return fs.root == "/" ? p : fs.root + (p == "/" ? "" : p); };
+    auto one = [&](const mi_tree_entry& e, const std::string& p, uint64_t j) {
+        if (untar && !mi_untar::one_item(fs.root, disk_path(p), e, tar_fd, data_offsets ? data_offsets[j] : 0, &uerr)) {
+            fs.fail(MI_ERR_IO, "untar one item " + disk_path(p) + ": " + uerr);
+            return;
+        }
         mi_copy::Node n;
         n.e.relpath = p == "/" ? "" : p.substr(1);
         n.e.kind = e.kind; n.e.mode = e.mode; n.e.mtime = e.mtime_sec; n.e.uid = e.uid; n.e.gid = e.gid; n.e.size = e.size;
@@ -1783,17 +1916,57 @@ extern "C" int mi_memfs_update_from_entries(mi_memfs* m, const mi_tree_entry* la
     for (uint64_t j = 0; j < n_layer && !fs.rc; ++j) {
         const std::string p = path_of(layer[j]);
         if (skipped(layer[j], p)) continue;
+        if (untar) {                                                              // "Record the modtime of the parent directory to
+            const std::string parent = mi_walk::dir_of(disk_path(p));             //  reset it after we deal with all of the other files"
+            if (!modtimes.count(parent)) {
+                struct stat st;
+                if (lstat(parent.c_str(), &st) != 0) {
+                    fs.fail(MI_ERR_IO, "stat parent dir of " + disk_path(p) + ": " + strerror(errno));
+                    break;
+                }
+                modtimes[parent] = st.st_mtim;
+            }
+        }
         if (layer[j].kind == 3) { hardlinks[p] = j; continue; }
-        one(layer[j], p);
+        one(layer[j], p, j);
     }
     for (auto& kv : hardlinks) {
         if (fs.rc) break;
-        one(layer[kv.second], kv.first);
+        one(layer[kv.second], kv.first, kv.second);
     }
-    if (fs.rc) { fs.err = "add hdr from tar to layer: " + fs.err; return memfs_fail(m); }
+    const bool untar_failed = fs.rc == MI_ERR_IO;
+    if (fs.rc) { if (!untar_failed) fs.err = "add hdr from tar to layer: " + fs.err; return memfs_fail(m); }
+    for (auto& kv : modtimes) {                                                   // "Reset the mod times on all of the directory we changed"
+        struct timespec ts[2] = {kv.second, kv.second};
+        if (utimensat(AT_FDCWD, kv.first.c_str(), ts, 0) != 0) {
+            m->err = "chtimes on parent directory " + kv.first + ": " + strerror(errno);
+            fs.layer.clear();
+            return MI_ERR_IO;
+        }
+    }
     if (n_merged) *n_merged = fs.layer.size();                                    // "Merged %d headers from tar to memfs"
     fs.layer.clear();
     return MI_OK;
+}
+
+extern "C" int mi_memfs_update_from_entries(mi_memfs* m, const mi_tree_entry* layer, uint64_t n_layer,
+                                            uint64_t* n_merged) {
+    if (!m || (n_layer && !layer)) return MI_ERR_INVALID;
+    return memfs_update(m, layer, n_layer, -1, nullptr, false, n_merged);
+}
+
+// UpdateFromTarReader with untar = true: the entries of a PLAIN tar (mi_tar_entries of tar_path with their data offsets;
+// a gzip blob goes through mi_tar_inflate first) are written below the root as untarOneItem does -- whiteouts delete,
+// what is already there and similar stays, a directory on a directory is updated in place, anything else is replaced;
+// hard links last; the parents' mtimes are put back -- and merged into the tree
+extern "C" int mi_memfs_untar(mi_memfs* m, const char* tar_path, const mi_tree_entry* layer, const uint64_t* data_offsets,
+                              uint64_t n_layer, uint64_t* n_merged) {
+    if (!m || !tar_path || (n_layer && (!layer || !data_offsets))) return MI_ERR_INVALID;
+    const int fd = open(tar_path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) { m->err = std::string("open tar file ") + tar_path + ": " + strerror(errno); return MI_ERR_IO; }
+    const int rc = memfs_update(m, layer, n_layer, fd, data_offsets, true, n_merged);
+    close(fd);
+    return rc;
 }
 
 // MemFS.createLayerByScan (:315-341) on a walk of the root (mi_tree_walk / mi_batch_add_tree with MI_TREE_SCAN,
