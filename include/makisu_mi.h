@@ -590,6 +590,19 @@ int  mi_resolve_chown(const char* chown, int preserve_owner, int64_t* uid, int64
 int  mi_path_match(const char* pattern, const char* name, int* matched);
 int  mi_context_sources(const char* context_root, const char* const* from_paths, uint64_t n_paths, char* out,
                         uint64_t cap, uint64_t* n_out, uint64_t* bytes_out);
+/* CopyOperation.Execute (lib/snapshot/copy_op.go:83-147) over fileio.Copier (lib/fileio/copy.go): the on-disk copy of the
+ * step, for builds that modify the file system.  op as for mi_snapshot_copy_ops (dst resolved; "dir/" = copy INTO it).
+ * flags: MI_COPY_CHOWN --chown was given (owner = op->uid/gid for everything copied and for a destination directory
+ * that has to be created); MI_COPY_INTERNAL the sources are a previous stage's (--from: no blacklist, owners kept);
+ * MI_COPY_PRESERVE_OWNER --archive (a created destination directory gets the source's owner).  Without flags: from the
+ * context, everything owned by 0:0.  Missing ancestors of the destination are created 0755 root:root; permission bits
+ * are kept, mtimes are not; a symlink is copied as a link; special files are skipped; a source directory that contains
+ * the destination does not recurse into it.  MI_ERR_IO + the reference's message.  Host logic.                        */
+#define MI_COPY_CHOWN          0x1u
+#define MI_COPY_INTERNAL       0x2u
+#define MI_COPY_PRESERVE_OWNER 0x4u
+int  mi_copy_op_execute(const mi_copy_op* op, uint32_t flags, const char* const* blacklist, uint64_t n_blacklist,
+                        char* err, uint64_t err_cap);
 typedef struct mi_copy_layer mi_copy_layer;
 int  mi_snapshot_copy_ops(const mi_tree_entry* tree, uint64_t n_tree, const char* tree_root,
                           const mi_copy_op* ops, uint64_t n_ops, int64_t now_sec,

@@ -254,6 +254,7 @@ def load_library(rebuild=False):
         "mi_memfs_add_layer_by_scan": ([vp, C.POINTER(TreeEntry), u64, vp, u64, C.POINTER(vp), u64p], C.c_int),
         "mi_memfs_add_layer_by_copy_ops": ([vp, C.POINTER(CopyOp), u64, C.POINTER(vp), u64p], C.c_int),
         "mi_memfs_entries": ([vp, C.POINTER(TreeEntry), C.POINTER(C.c_char_p), u64, u64p], C.c_int),
+        "mi_copy_op_execute": ([C.POINTER(CopyOp), C.c_uint32, C.POINTER(C.c_char_p), u64, C.c_char_p, u64], C.c_int),
         "mi_copy_layer_entries": ([vp, C.POINTER(TreeEntry), C.POINTER(C.c_char_p), u64], C.c_int),
         "mi_copy_layer_free": ([vp], None),
         "mi_layer_config_default": ([C.POINTER(LayerConfig)], C.c_int),
@@ -549,6 +550,21 @@ def _take_copy_layer(L, h, n):
         return res
     finally:
         L.mi_copy_layer_free(h)
+
+
+COPY_CHOWN, COPY_INTERNAL, COPY_PRESERVE_OWNER = 1, 2, 4
+
+
+def copy_op_execute(op, chown=False, internal=False, preserve_owner=False, blacklist=()):
+    """mi_copy_op_execute: CopyOperation.Execute -- the on-disk copy of a COPY/ADD step."""
+    keep = []
+    cops = _copy_op_array([op], keep)
+    bl = (C.c_char_p * max(len(blacklist), 1))(*[os.fsencode(x) for x in blacklist])
+    err = C.create_string_buffer(600)
+    flags = (COPY_CHOWN if chown else 0) | (COPY_INTERNAL if internal else 0) | (COPY_PRESERVE_OWNER if preserve_owner else 0)
+    rc = load_library().mi_copy_op_execute(cops, flags, bl, len(blacklist), err, len(err))
+    if rc:
+        raise MiError(rc, "mi_copy_op_execute: %s" % err.value.decode(errors="replace"))
 
 
 def copy_ops_layer(tree, tree_root, ops, now_sec=0):

@@ -1686,6 +1686,203 @@ extern "C" int mi_snapshot_copy_ops(const mi_tree_entry* tree, uint64_t n_tree, 
     return MI_OK;
 }
 
+// ---- CopyOperation.Execute: the on-disk copy of a COPY/ADD step with --modifyfs (lib/snapshot/copy_op.go:83-147) over
+// fileio.Copier (lib/fileio/copy.go:31-394).  Owners: --chown -> the op's uid/gid for the destination directory if it
+// has to be created and, always, for everything copied; from the context without --chown -> the same with 0:0; --from
+// --archive -> a created destination directory gets the source's owner, everything copied keeps its own; --from alone ->
+// owners as they are (a created destination directory: root).  Permission bits travel with the files; mtimes do not.
+namespace mi_copyexec {
+
+struct Owner { bool set = false; uint32_t uid = 0, gid = 0; bool overwrite = false; };
+struct Copier {
+    std::vector<std::string> blacklist;
+    Owner dst_dir, children;
+    std::string err;
+
+    bool fail(const std::string& m) { err = m; return false; }
+    bool blacklisted(const std::string& p) const { return mi_walk::is_descendant_of_any(p, blacklist); }
+
+    bool mkdir_all(const std::string& dst) {                                     // Copier.mkdirAll (:336-393)
+        if (dst.empty()) return fail("empty dst directory");
+        const std::string abs = mi_walk::abs_path(dst);                          // callers pass absolute paths
+        std::string cur;
+        const std::vector<std::string> ps = mi_memtree::Tree::parts(abs);
+        for (size_t k = 0; k + 1 < ps.size(); ++k) {
+            cur += "/" + ps[k];
+            struct stat st;
+            if (lstat(cur.c_str(), &st) == 0) continue;
+            if (errno != ENOENT) return fail("stat " + cur + ": " + strerror(errno));
+            if (mkdir(cur.c_str(), 0755) != 0) return fail("mkdir " + cur + " with default mode 0755: " + strerror(errno));
+            if (chown(cur.c_str(), 0, 0) != 0) return fail("chown " + cur + " with default owner (0:0): " + strerror(errno));
+        }
+        struct stat st;
+        if (lstat(abs.c_str(), &st) != 0) {
+            if (errno != ENOENT) return fail("stat " + abs + ": " + strerror(errno));
+            if (mkdir(abs.c_str(), 0755) != 0) return fail("mkdir " + abs + " with default mode 0755: " + strerror(errno));
+            const uint32_t u = dst_dir.set ? dst_dir.uid : 0, g = dst_dir.set ? dst_dir.gid : 0;
+            if (chown(abs.c_str(), u, g) != 0) return fail("chown " + abs + ": " + strerror(errno));
+        } else if (dst_dir.set && dst_dir.overwrite) {
+            if (chown(abs.c_str(), dst_dir.uid, dst_dir.gid) != 0) return fail("chown " + abs + ": " + strerror(errno));
+        }
+        return true;
+    }
+    bool copy_symlink(const std::string& src, const std::string& dst) {          // :232-247
+        struct stat st;
+        if (lstat(dst.c_str(), &st) == 0 && remove(dst.c_str()) != 0)
+            return fail("remove existing file " + dst + ": " + strerror(errno));
+        std::vector<char> buf(4096);
+        const ssize_t n = readlink(src.c_str(), buf.data(), buf.size() - 1);
+        if (n < 0) return fail("read link " + src + ": " + strerror(errno));
+        const std::string target(buf.data(), (size_t)n);
+        if (symlink(target.c_str(), dst.c_str()) != 0)
+            return fail("write link " + dst + " with content " + target + ": " + strerror(errno));
+        return true;
+    }
+    bool copy_file(const std::string& src, const std::string& dst) {             // copyFile + copyRegularFile (:160-230)
+        struct stat fi;
+        if (lstat(src.c_str(), &fi) != 0) return fail("lstat " + src + ": " + strerror(errno));
+        // (a blacklisted SOURCE FILE is only logged here -- the reference's else-if chain goes on to copy it; blacklisted
+        // entries below a copied directory never get this far)
+        if (!blacklisted(src) && !S_ISREG(fi.st_mode) && !S_ISDIR(fi.st_mode) && !S_ISLNK(fi.st_mode)) return true;   // special file
+        if (S_ISLNK(fi.st_mode)) return copy_symlink(src, dst);                  // never chown'ed: that would hit the target
+        struct stat dt;
+        if (lstat(dst.c_str(), &dt) == 0) {
+            if (chmod(dst.c_str(), 0777) != 0) return fail("chmod " + dst + ": " + strerror(errno));
+        } else if (errno != ENOENT) {
+            return fail("lstat " + dst + ": " + strerror(errno));
+        }
+        const int r = open(src.c_str(), O_RDONLY | O_CLOEXEC);
+        if (r < 0) return fail("open " + dst + ": " + strerror(errno));
+        const int w = open(dst.c_str(), O_WRONLY | O_CREAT | O_CLOEXEC, 0777);
+        if (w < 0) { const int e = errno; close(r); return fail("create " + dst + ": " + strerror(e)); }
+        bool ok = ftruncate(w, 0) == 0;
+        std::string e = ok ? "" : std::string("truncate ") + dst + ": " + strerror(errno);
+        std::vector<char> buf(1 << 20);
+        while (ok) {
+            const ssize_t n = read(r, buf.data(), buf.size());
+            if (n < 0 && errno == EINTR) continue;
+            if (n < 0) { ok = false; e = "copy " + src + " to " + dst + ": " + strerror(errno); break; }
+            if (n == 0) break;
+            for (ssize_t done = 0; done < n;) {
+                const ssize_t k = write(w, buf.data() + done, (size_t)(n - done));
+                if (k < 0 && errno == EINTR) continue;
+                if (k < 0) { ok = false; e = "copy " + src + " to " + dst + ": " + strerror(errno); break; }
+                done += k;
+            }
+        }
+        close(r);
+        close(w);
+        if (!ok) return fail(e);
+        const uint32_t u = children.set && children.overwrite ? children.uid : fi.st_uid;
+        const uint32_t g = children.set && children.overwrite ? children.gid : fi.st_gid;
+        if (chown(dst.c_str(), u, g) != 0) return fail("chown " + dst + ": " + strerror(errno));
+        if (chmod(dst.c_str(), fi.st_mode & 07777) != 0) return fail("chmod " + dst + ": " + strerror(errno));   // after chown
+        return true;
+    }
+    bool copy_dir(const std::string& src, const std::string& dst) {              // copyDir (:289-330): one directory, no contents
+        struct stat si;
+        if (lstat(src.c_str(), &si) != 0) return fail("lstat " + src + ": " + strerror(errno));
+        if (!S_ISDIR(si.st_mode)) return fail("source " + src + " is not a directory");
+        if (blacklisted(src)) return true;
+        struct stat di;
+        if (lstat(dst.c_str(), &di) != 0) {
+            if (errno != ENOENT) return fail("lstat " + dst + ": " + strerror(errno));
+            if (mkdir(dst.c_str(), si.st_mode & 07777) != 0) return fail("mkdir " + dst + ": " + strerror(errno));
+        } else if (!S_ISDIR(di.st_mode)) {
+            return fail("dst is not a directory");
+        }
+        if (chmod(dst.c_str(), si.st_mode & 07777) != 0) return fail("chmod " + dst + ": " + strerror(errno));
+        const uint32_t u = children.set && children.overwrite ? children.uid : si.st_uid;
+        const uint32_t g = children.set && children.overwrite ? children.gid : si.st_gid;
+        if (chown(dst.c_str(), u, g) != 0) return fail("chown " + dst + ": " + strerror(errno));
+        return true;
+    }
+    bool copy_dir_contents(const std::string& src, const std::string& dst, const std::string& orig_dst) {   // :252-285
+        DIR* d = opendir(src.c_str());
+        if (!d) return fail("read dir " + src + ": " + strerror(errno));
+        std::vector<std::string> names;
+        while (struct dirent* de = readdir(d)) {
+            const std::string n = de->d_name;
+            if (n != "." && n != "..") names.push_back(n);
+        }
+        closedir(d);
+        std::sort(names.begin(), names.end());                                   // ioutil.ReadDir sorts by name
+        for (const std::string& n : names) {
+            const std::string cs = (src == "/" ? "" : src) + "/" + n, cd = (dst == "/" ? "" : dst) + "/" + n;
+            if (blacklisted(cs) || cs == orig_dst) continue;                     // "Silently break infinite loop"
+            struct stat st;
+            if (lstat(cs.c_str(), &st) != 0) return fail("lstat " + cs + ": " + strerror(errno));
+            if (S_ISDIR(st.st_mode)) {
+                if (!copy_dir(cs, cd)) return fail("copy dir " + cs + " to " + cd + ": " + err);
+                if (!copy_dir_contents(cs, cd, orig_dst)) return fail("copy dir contents " + cs + " to " + cd + ": " + err);
+            } else if (!copy_file(cs, cd)) {
+                return fail("copy file " + cs + " to " + cd + ": " + err);
+            }
+        }
+        return true;
+    }
+    bool CopyFile(const std::string& src, const std::string& dst) {              // :122-130
+        const std::string dir = mi_walk::dir_of(dst);
+        if (!mkdir_all(dir)) return fail("mkdir all " + dir + ": " + err);
+        return copy_file(src, dst);
+    }
+    bool CopyDir(const std::string& src, const std::string& dst) {               // :142-156
+        if (blacklisted(src)) return true;
+        if (!mkdir_all(dst)) return fail("mkdir all " + dst + ": " + err);
+        return copy_dir_contents(src, dst, mi_walk::abs_path(dst));
+    }
+};
+
+}  // namespace mi_copyexec
+
+extern "C" int mi_copy_op_execute(const mi_copy_op* op, uint32_t flags, const char* const* blacklist, uint64_t n_blacklist,
+                                  char* err, uint64_t err_cap) {
+    auto put_err = [&](const std::string& m) { if (err && err_cap) snprintf(err, (size_t)err_cap, "%s", m.c_str()); };
+    if (!op || !op->src_root || !op->dst || (op->n_srcs && !op->srcs) || (n_blacklist && !blacklist)) return MI_ERR_INVALID;
+    const bool chown_given = flags & MI_COPY_CHOWN, internal = flags & MI_COPY_INTERNAL, archive = flags & MI_COPY_PRESERVE_OWNER;
+    if (chown_given && archive) { put_err("both chown and archive are true"); return MI_ERR_INVALID; }
+    const std::string src_root = mi_walk::abs_path(op->src_root);
+    const std::string dst = op->dst;
+    for (uint64_t si = 0; si < op->n_srcs; ++si) {
+        std::string rel, e2;
+        const std::string given = op->srcs[si] ? op->srcs[si] : "";
+        if (!mi_copy::eval_symlinks(mi_walk::abs_path(given), src_root, &rel, &e2)) {
+            put_err("eval symlinks for " + given + ": " + e2);
+            return MI_ERR_IO;
+        }
+        const std::string src = src_root == "/" ? rel : src_root + (rel == "/" ? "" : rel);
+        struct stat fi;
+        if (lstat(src.c_str(), &fi) != 0) { put_err("lstat " + src + ": " + strerror(errno)); return MI_ERR_IO; }
+        mi_copyexec::Copier c;
+        if (!internal)                                                           // "there is no need to blacklist any path" for a
+            for (uint64_t k = 0; k < n_blacklist; ++k) c.blacklist.push_back(blacklist[k] ? blacklist[k] : "");   // checkpointed stage
+        if (chown_given) {
+            c.dst_dir = {true, op->uid, op->gid, false};
+            c.children = {true, op->uid, op->gid, true};
+        } else if (!internal) {
+            c.dst_dir = {true, 0, 0, false};
+            c.children = {true, 0, 0, true};
+        } else if (archive) {
+            c.dst_dir = {true, fi.st_uid, fi.st_gid, false};
+        }
+        bool ok;
+        std::string what;
+        if (S_ISDIR(fi.st_mode)) {
+            ok = c.CopyDir(src, dst);
+            what = "copy dir " + src + " to dir " + dst;
+        } else if (copy_dst_is_dir_format(dst)) {
+            const std::string target = mi_walk::abs_path(dst + "/" + mi_walk::base_of(src));
+            ok = c.CopyFile(src, target);
+            what = "copy file " + src + " to dir " + target;
+        } else {
+            ok = c.CopyFile(src, dst);
+            what = "copy file " + src + " to file " + dst;
+        }
+        if (!ok) { put_err(what + ": " + c.err); return MI_ERR_IO; }
+    }
+    return MI_OK;
+}
+
 // ---- untar: MemFS.untarOneItem and tario.ApplyHeader (lib/snapshot/mem_fs.go:571-718, lib/tario/apply.go:23-47) --------
 namespace mi_untar {
 
