@@ -658,6 +658,10 @@ int  mi_memfs_add_layer_by_scan(mi_memfs* fs, const mi_tree_entry* walked, uint6
 int  mi_memfs_add_layer_by_copy_ops(mi_memfs* fs, const mi_copy_op* ops, uint64_t n_ops, mi_copy_layer** out,
                                     uint64_t* n_entries);
 int  mi_memfs_entries(const mi_memfs* fs, mi_tree_entry* out, const char** src_paths, uint64_t cap, uint64_t* n_out);
+/* MemFS.Checkpoint (mem_fs.go:132-185): what a later stage will COPY --from is copied aside, to new_root + the path it has
+ * below the root (patterns expanded like COPY sources; relative sources are below the root; the blacklist of the handle
+ * applies; a created target directory gets the source's owner, everything copied keeps its own).                    */
+int  mi_memfs_checkpoint(mi_memfs* fs, const char* new_root, const char* const* sources, uint64_t n_sources);
 
 /* ---- the layer writer: tar framing + the two serial layer digests (host threads) ---------- *
  * step.tarAndGzipDiffs + MemFS.commitLayer (lib/builder/step/common.go:35-111,

@@ -254,6 +254,7 @@ def load_library(rebuild=False):
         "mi_memfs_add_layer_by_scan": ([vp, C.POINTER(TreeEntry), u64, vp, u64, C.POINTER(vp), u64p], C.c_int),
         "mi_memfs_add_layer_by_copy_ops": ([vp, C.POINTER(CopyOp), u64, C.POINTER(vp), u64p], C.c_int),
         "mi_memfs_entries": ([vp, C.POINTER(TreeEntry), C.POINTER(C.c_char_p), u64, u64p], C.c_int),
+        "mi_memfs_checkpoint": ([vp, C.c_char_p, C.POINTER(C.c_char_p), u64], C.c_int),
         "mi_copy_op_execute": ([C.POINTER(CopyOp), C.c_uint32, C.POINTER(C.c_char_p), u64, C.c_char_p, u64], C.c_int),
         "mi_copy_layer_entries": ([vp, C.POINTER(TreeEntry), C.POINTER(C.c_char_p), u64], C.c_int),
         "mi_copy_layer_free": ([vp], None),
@@ -661,6 +662,11 @@ class MemFS:
         self._check(self._lib.mi_memfs_add_layer_by_copy_ops(self._h, cops, len(ops), C.byref(h), C.byref(n)),
                     "mi_memfs_add_layer_by_copy_ops")
         return _take_copy_layer(self._lib, h, n.value)
+
+    def checkpoint(self, new_root, sources):
+        """MemFS.Checkpoint: copy what a later stage will COPY --from below new_root."""
+        arr = (C.c_char_p * max(len(sources), 1))(*[os.fsencode(x) for x in sources])
+        self._check(self._lib.mi_memfs_checkpoint(self._h, os.fsencode(new_root), arr, len(sources)), "mi_memfs_checkpoint")
 
     def scan(self):
         """walk the root with this MemFS's blacklist, then add_layer_by_scan"""

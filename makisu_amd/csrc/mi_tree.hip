@@ -2218,6 +2218,40 @@ extern "C" int mi_memfs_add_layer_by_copy_ops(mi_memfs* m, const mi_copy_op* ops
     return MI_OK;
 }
 
+// MemFS.Checkpoint (:132-185): the sources a later stage will COPY --from are moved aside, below new_root, with the
+// layout they have below the root; a pattern is expanded like a COPY source, a directory's created target gets the
+// source's owner, everything copied keeps its own
+extern "C" int mi_memfs_checkpoint(mi_memfs* m, const char* new_root, const char* const* sources, uint64_t n_sources) {
+    if (!m || !new_root || (n_sources && !sources)) return MI_ERR_INVALID;
+    const std::string root = m->fs.root;
+    for (uint64_t i = 0; i < n_sources; ++i) {
+        const std::string given = sources[i] ? sources[i] : "";
+        std::vector<std::string> matches;
+        if (!mi_glob::glob(given, &matches) || matches.empty()) matches.assign(1, given);
+        for (std::string src : matches) {
+            if (src.empty() || src[0] != '/') src = mi_walk::abs_path(root + "/" + src);
+            if (!mi_walk::has_prefix(src, root)) {
+                m->err = "trim src " + src + ": failed to trim root prefix " + root + " from path " + src;
+                return MI_ERR_INVALID;
+            }
+            const std::string dst = mi_walk::abs_path(std::string(new_root) + "/" + src.substr(root.size()));
+            struct stat followed, fi;
+            if (stat(src.c_str(), &followed) != 0) { m->err = "stat " + src + ": " + strerror(errno); return MI_ERR_IO; }
+            if (lstat(src.c_str(), &fi) != 0) { m->err = "lstat " + src + ": " + strerror(errno); return MI_ERR_IO; }
+            mi_copyexec::Copier c;
+            c.blacklist = m->blacklist;
+            c.dst_dir = {true, fi.st_uid, fi.st_gid, false};
+            if (S_ISDIR(followed.st_mode)) {
+                if (!c.CopyDir(src, dst)) { m->err = "copy dir " + src + ": " + c.err; return MI_ERR_IO; }
+            } else if (!c.CopyFile(src, dst)) {
+                m->err = "copy file " + src + ": " + c.err;
+                return MI_ERR_IO;
+            }
+        }
+    }
+    return MI_OK;
+}
+
 // the tree, sorted by path (directories made up by addAncestors included: they are nodes like any other)
 extern "C" int mi_memfs_entries(const mi_memfs* m, mi_tree_entry* out, const char** src_paths, uint64_t cap, uint64_t* n_out) {
     if (!m || !n_out || (cap && !out)) return MI_ERR_INVALID;

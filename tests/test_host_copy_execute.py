@@ -164,3 +164,29 @@ def test_after_the_copy_the_scan_finds_what_the_copy_layer_holds(tmp_path):
         key = lambda e: (e["relpath"], e["kind"], e["mode"], e["size"], e["link_target"], e["uid"], e["gid"])   # noqa: E731
         assert [key(e) for e in la] == [key(e) for e in lb]
         assert [e["relpath"] for e in la] == ["app", "app/data", "app/data/a", "app/data/l", "app/data/sub", "app/data/sub/b"]
+
+
+def test_checkpoint_moves_copy_from_sources_aside(tmp_path):
+    """MemFS.Checkpoint (mem_fs.go:132-185, called by build_stage.go:342-345 at the end of a stage some later stage copies
+    from): sources, given absolute or relative to the root or as patterns, land below new_root with the layout they have
+    below the root; owners are kept, a created target directory takes the source's."""
+    root, sandbox = tmp_path / "root", tmp_path / "sandbox"
+    (root / "out" / "bin").mkdir(parents=True)
+    (root / "out" / "bin" / "tool").write_bytes(b"ELF")
+    (root / "out" / "conf-a.yaml").write_bytes(b"a")
+    (root / "out" / "conf-b.yaml").write_bytes(b"b")
+    (root / "skip").mkdir()
+    (root / "skip" / "x").write_bytes(b"x")
+    for p in (root / "out", root / "out" / "bin", root / "out" / "bin" / "tool"):
+        os.chown(p, 42, 43)
+    with M.MemFS(str(root), blacklist=[str(root / "skip")]) as fs:
+        fs.checkpoint(str(sandbox), [str(root / "out" / "bin"), "out/conf-a.yaml", str(root / "out" / "conf-*.yaml"), "skip"])
+        assert (sandbox / "out" / "bin" / "tool").read_bytes() == b"ELF"
+        assert (sandbox / "out" / "conf-a.yaml").read_bytes() == b"a" and (sandbox / "out" / "conf-b.yaml").read_bytes() == b"b"
+        assert not os.path.lexists(sandbox / "skip")                          # blacklisted: silently left out
+        o = lambda p: (os.lstat(p).st_uid, os.lstat(p).st_gid)                # noqa: E731
+        assert o(sandbox / "out" / "bin") == (42, 43) and o(sandbox / "out" / "bin" / "tool") == (42, 43)
+        assert o(sandbox / "out") == (0, 0)                                   # an ancestor: 0755 root:root
+        with pytest.raises(M.MiError) as ei:
+            fs.checkpoint(str(sandbox), ["/etc/hostname"])                    # outside the root
+        assert "trim src" in str(ei.value)
