@@ -557,7 +557,7 @@ int mi_snapshot_diff(const mi_snapshot_side* before, const mi_snapshot_side* aft
  * usr/lib), deeper it fails as in the reference ("missing intermediate directory").  No scan
  * whiteouts: a copy never deletes -- except by NAME: a source called ".wh.<x>" is a whiteout of its
  * sibling <x>, filed under that path (memLayer.addHeader, mem_layer.go:197-212).  Result: the layer's entries in commit order (mi_copy_layer_entries), each
- * with the path its bytes are read from ("" for created directories) -- feed them to mi_layer_add
+ * with the path its bytes are read from ("/" for created directories, as in the reference) -- feed them to mi_layer_add
  * and the regular files to a batch.  The caller's tree is not modified.  Host logic.           */
 typedef struct {
     const char*        src_root;
@@ -717,6 +717,15 @@ int  mi_layer_add_whiteout(mi_layer* layer, const char* deleted_path);
 int  mi_layer_finish(mi_layer* layer, mi_layer_result* out);
 const char* mi_layer_error(mi_layer* layer);
 void mi_layer_free(mi_layer* layer);
+/* step.commitLayer (lib/builder/step/common.go:67-111) in one call on a MemFS handle: the step's layer by scan
+ * (must_scan: the root is walked here, with the handle's blacklist) or by its copy operations, written through the layer
+ * writer configured by cfg (tarAndGzipDiffs: tar framing, TarDigest, the gzip leg with its digest and size), folded into
+ * the tree.  Neither a scan nor ops: "Nothing to do" -- *committed = 0, res untouched.  layer_out (may be NULL): the
+ * layer's entries and source paths, e.g. to feed the same files to a GPU batch; free with mi_copy_layer_free.  Errors
+ * carry the reference's chain in mi_memfs_error ("failed to generate diff layer: write diffs: ...").  MemFS.sync's
+ * one-second wait stays with the caller.  Host logic.                                                             */
+int  mi_memfs_commit_layer(mi_memfs* fs, int must_scan, const mi_copy_op* ops, uint64_t n_ops, const mi_layer_config* cfg,
+                           mi_layer_result* res, mi_copy_layer** layer_out, int* committed);
 /* The header block(s) mi_layer_add would write for `e` (512 bytes, or 1536+ with a PAX record) in
  * a layer begun with `layer_flags` (MI_LAYER_*).                                                 */
 int  mi_layer_header_bytes(const mi_tree_entry* e, uint32_t layer_flags, uint8_t* out, uint64_t cap, uint64_t* n);

@@ -255,6 +255,8 @@ def load_library(rebuild=False):
         "mi_memfs_add_layer_by_copy_ops": ([vp, C.POINTER(CopyOp), u64, C.POINTER(vp), u64p], C.c_int),
         "mi_memfs_entries": ([vp, C.POINTER(TreeEntry), C.POINTER(C.c_char_p), u64, u64p], C.c_int),
         "mi_memfs_checkpoint": ([vp, C.c_char_p, C.POINTER(C.c_char_p), u64], C.c_int),
+        "mi_memfs_commit_layer": ([vp, C.c_int, C.POINTER(CopyOp), u64, C.POINTER(LayerConfig), C.POINTER(LayerResult),
+                                   C.POINTER(vp), C.POINTER(C.c_int)], C.c_int),
         "mi_copy_op_execute": ([C.POINTER(CopyOp), C.c_uint32, C.POINTER(C.c_char_p), u64, C.c_char_p, u64], C.c_int),
         "mi_copy_layer_entries": ([vp, C.POINTER(TreeEntry), C.POINTER(C.c_char_p), u64], C.c_int),
         "mi_copy_layer_free": ([vp], None),
@@ -662,6 +664,23 @@ class MemFS:
         self._check(self._lib.mi_memfs_add_layer_by_copy_ops(self._h, cops, len(ops), C.byref(h), C.byref(n)),
                     "mi_memfs_add_layer_by_copy_ops")
         return _take_copy_layer(self._lib, h, n.value)
+
+    def commit_layer(self, must_scan=False, ops=(), out_fd=-1, gzip_level=GZIP_DEFAULT):
+        """step.commitLayer: the layer by scan or by copy ops, written through the layer writer.  Returns None when there
+        is nothing to do, else dict(tar_digest, gzip_digest, tar_bytes, gzip_bytes, n_entries, layer=[entries])."""
+        keep = []
+        cops = _copy_op_array(list(ops), keep)
+        cfg = LayerConfig()
+        self._lib.mi_layer_config_default(C.byref(cfg))
+        cfg.out_fd, cfg.gzip_level = out_fd, gzip_level
+        res, h, done = LayerResult(), C.c_void_p(), C.c_int()
+        self._check(self._lib.mi_memfs_commit_layer(self._h, int(must_scan), cops, len(ops), C.byref(cfg), C.byref(res),
+                                                    C.byref(h), C.byref(done)), "mi_memfs_commit_layer")
+        if not done.value:
+            return None
+        return {"tar_digest": Digest.from_raw(res.tar_sha256), "gzip_digest": Digest.from_raw(res.gzip_sha256),
+                "tar_bytes": res.tar_bytes, "gzip_bytes": res.gzip_bytes, "n_entries": res.n_entries,
+                "layer": _take_copy_layer(self._lib, h, int(res.n_entries))}
 
     def checkpoint(self, new_root, sources):
         """MemFS.Checkpoint: copy what a later stage will COPY --from below new_root."""

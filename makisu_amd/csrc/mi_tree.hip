@@ -1091,7 +1091,7 @@ int mi_entry_similar(const mi_tree_entry* a, const mi_tree_entry* b, int ignore_
 //     existing ancestors, then replaces the node: a directory keeps the old node's children, anything
 //     else drops them.
 // Result: the layer's entries in commit order (sorted by dst), each with the path its content is
-// read from ("" for directories the op created).  The caller's tree is not modified; to continue,
+// read from ("/" for directories the op created: memLayer.addHeader("", ...) -> AbsPath("")).  The caller's tree is not modified; to continue,
 // apply the layer to it with mi_entries_apply_layer.
 namespace mi_copy {
 
@@ -1128,6 +1128,7 @@ struct Fs {
             if (ref < 0) {                                                      // a parent the caller's list left out
                 Node d;
                 d.e.mode = (uint32_t)(S_IFDIR | 0755); d.e.kind = 0; d.e.relpath = dst.substr(1); d.e.mtime = now;
+                d.src = "/";
                 ref = keep(d);
                 if (mi_memtree::Node* n = t.find(dst)) n->ref = ref;
             }
@@ -1147,6 +1148,7 @@ struct Fs {
             d.e.mtime = now;
             d.e.uid = uid;
             d.e.gid = gid;
+            d.src = "/";                       // l.addHeader("", curr, hdr): src = AbsPath("") -- isOnDisk says yes, always
             return keep(d);
         };
     }
@@ -2215,6 +2217,56 @@ extern "C" int mi_memfs_add_layer_by_copy_ops(mi_memfs* m, const mi_copy_op* ops
     mi_copy_layer* l = memfs_take_layer(m);
     if (n_entries) *n_entries = l->nodes.size();
     *out = l;
+    return MI_OK;
+}
+
+// step.commitLayer (lib/builder/step/common.go:67-111) on the handle: the step's layer by scan (ctx.MustScan) or by its
+// copy operations, through tarAndGzipDiffs' pipeline (the layer writer: tar framing, TarDigest, gzip leg, its digest and
+// size), folded into the tree; nothing to do = *committed 0.  The walk of a scan happens here, with the handle's
+// blacklist.  (MemFS.sync's one-second wait before either stays with the caller.)
+extern "C" int mi_memfs_commit_layer(mi_memfs* m, int must_scan, const mi_copy_op* ops, uint64_t n_ops,
+                                     const mi_layer_config* cfg, mi_layer_result* res, mi_copy_layer** layer_out,
+                                     int* committed) {
+    if (!m || !cfg || !res || !committed || (n_ops && !ops)) return MI_ERR_INVALID;
+    *committed = 0;
+    if (layer_out) *layer_out = nullptr;
+    if (!must_scan && n_ops == 0) return MI_OK;                                   // "Nothing to do, return."
+    mi_copy_layer* cl = nullptr;
+    uint64_t ne = 0;
+    int rc;
+    if (must_scan) {
+        std::vector<const char*> bl;
+        for (const std::string& b : m->blacklist) bl.push_back(b.c_str());
+        mi_tree* t = nullptr;
+        uint64_t n = 0;
+        rc = mi_tree_walk(m->fs.root.c_str(), m->fs.root.c_str(), bl.empty() ? nullptr : bl.data(), bl.size(), MI_TREE_SCAN, &t, &n);
+        if (rc) { m->err = "failed to generate diff layer: write diffs: create layer by scan: walk " + m->fs.root; return rc; }
+        std::vector<mi_tree_entry> walked(n ? n : 1);
+        rc = mi_tree_entries(t, walked.data(), n);
+        if (!rc) rc = mi_memfs_add_layer_by_scan(m, walked.data(), n, nullptr, 0, &cl, &ne);
+        mi_tree_free(t);
+        if (rc) { m->err = "failed to generate diff layer: write diffs: create layer by scan: " + m->err; return rc; }
+    } else {
+        rc = mi_memfs_add_layer_by_copy_ops(m, ops, n_ops, &cl, &ne);
+        if (rc) { m->err = "failed to generate diff layer: write diffs: create layer by copy ops: " + m->err; return rc; }
+    }
+    std::vector<mi_tree_entry> ents(ne ? ne : 1);
+    std::vector<const char*> srcs(ne ? ne : 1);
+    rc = mi_copy_layer_entries(cl, ents.data(), srcs.data(), ne);
+    mi_layer* lw = nullptr;
+    if (!rc) rc = mi_layer_begin(cfg, &lw);
+    for (uint64_t i = 0; i < ne && !rc; ++i) {
+        rc = mi_layer_add(lw, &ents[i], ents[i].kind == 1 && srcs[i] && srcs[i][0] ? srcs[i] : nullptr);
+        if (rc) m->err = std::string("failed to generate diff layer: write diffs: commit layer: ") + mi_layer_error(lw);
+    }
+    if (!rc) {
+        rc = mi_layer_finish(lw, res);
+        if (rc) m->err = std::string("failed to generate diff layer: ") + mi_layer_error(lw);
+    }
+    if (lw) mi_layer_free(lw);
+    if (rc) { mi_copy_layer_free(cl); return rc; }
+    *committed = 1;
+    if (layer_out) *layer_out = cl; else mi_copy_layer_free(cl);
     return MI_OK;
 }
 

@@ -49,7 +49,7 @@ def test_file_to_dir_file(tmp_path):                         # "file dir/file"
     # the missing parent: created with default owner 0/0 (maybeAddToLayer's addAncestors(..., 0, 0, 0)),
     # the clock's time, and no source
     d = got["/test2"]
-    assert d["kind"] == M.KIND_DIR and d["src"] == "" and d["mtime_sec"] == 77 and (d["uid"], d["gid"]) == (0, 0)
+    assert d["kind"] == M.KIND_DIR and d["src"] == "/" and d["mtime_sec"] == 77 and (d["uid"], d["gid"]) == (0, 0)
     assert [e["relpath"] for e in layer] == ["test2", "test2/test.txt"]          # commit order
 
 

@@ -86,7 +86,7 @@ def test_update_mem_fs_through_the_real_path():
         assert fs.update_from_entries([D("/test1", 0o700), D("/test1/test2/test3")]) == 3                                   # SkipDir...: + the made-up one
         made = fs.entries()[1]
         assert made["relpath"] == "test1/test2" and made["kind"] == M.KIND_DIR and made["mode"] & 0o7777 == 0o700
-        assert (made["mtime_sec"], made["uid"], made["gid"], made["src"]) == (777, 0, 0, "")
+        assert (made["mtime_sec"], made["uid"], made["gid"], made["src"]) == (777, 0, 0, "/")
         fs.reset()
         l1 = [D("/test11"), D("/test11/test12"), F("/test11/test12/test.txt")]
         fs.update_from_entries(l1)
@@ -306,3 +306,43 @@ def test_content_roots_make_the_next_scan_content_aware(tmp_path):
         assert fs.add_layer_by_scan(walked2, None) == []             # the reference's rule: nothing changed
         assert [e["relpath"] for e in fs.add_layer_by_scan(walked2, r2)] == ["a", "a/y"]
         assert fs.add_layer_by_scan(walked2, r2) == []               # the new root is the tree's now
+
+
+def test_commit_layer_in_one_call(tmp_path):
+    """step.commitLayer (common.go:67-111) on the handle: nothing to do / by copy ops / by scan -- the DigestPair's numbers
+    are those of the blob it wrote, and the same layer written by hand through the layer writer has the same TarDigest."""
+    import gzip
+    import hashlib
+    import io
+    import tarfile
+    root, ctx = str(tmp_path / "root"), str(tmp_path / "ctx")
+    _mk(root, [("/etc/conf", "f", "base")])
+    _mk(ctx, [("/src/a.txt", "f", "A" * 5000), ("/src/sub/b.txt", "f", "B")])
+    with M.MemFS(root) as fs:
+        assert fs.commit_layer() is None                                        # "Nothing to do, return."
+        fd = os.open(str(tmp_path / "1.tar.gz"), os.O_WRONLY | os.O_CREAT, 0o644)
+        pair = fs.commit_layer(must_scan=True, out_fd=fd)
+        os.close(fd)
+        blob = (tmp_path / "1.tar.gz").read_bytes()
+        raw = gzip.decompress(blob)
+        assert pair["gzip_digest"].hex() == hashlib.sha256(blob).hexdigest() and pair["gzip_bytes"] == len(blob)
+        assert pair["tar_digest"].hex() == hashlib.sha256(raw).hexdigest() and pair["tar_bytes"] == len(raw)
+        with tarfile.open(fileobj=io.BytesIO(raw)) as tf:
+            assert [m.name.rstrip("/") for m in tf.getmembers()] == ["etc", "etc/conf"] == [e["relpath"] for e in pair["layer"]]
+        op = {"src_root": ctx, "srcs": ["src"], "dst": "/app/", "uid": 0, "gid": 0}
+        fd = os.open(str(tmp_path / "2.tar"), os.O_WRONLY | os.O_CREAT, 0o644)
+        pair2 = fs.commit_layer(ops=[op], out_fd=fd, gzip_level=M.GZIP_OFF)
+        os.close(fd)
+        raw2 = (tmp_path / "2.tar").read_bytes()
+        assert pair2["tar_digest"].hex() == hashlib.sha256(raw2).hexdigest() and pair2["n_entries"] == 4
+        with tarfile.open(fileobj=io.BytesIO(raw2)) as tf:
+            assert tf.extractfile("app/a.txt").read() == b"A" * 5000
+        empty = fs.commit_layer(must_scan=True)                                  # nothing changed on disk: an EMPTY layer is
+        assert empty["n_entries"] == 0 and empty["tar_bytes"] == 1024            # still a layer (the tar trailer, 5f70bf18...)
+        assert empty["tar_digest"].hex() == "5f70bf18a086007016e948b04aed3b82103a36bea41755b6cddfaf10ace3c6ef"
+    with M.MemFS(root) as twin:                                                  # by hand: the same TarDigest
+        layer = twin.scan()
+        with M.Layer(out_fd=-1) as lw:
+            for e in layer:
+                lw.add(e, e["src"] if e["kind"] == M.KIND_FILE else None)
+            assert lw.finish()["tar_digest"] == pair["tar_digest"]
