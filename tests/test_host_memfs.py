@@ -346,3 +346,18 @@ def test_commit_layer_in_one_call(tmp_path):
             for e in layer:
                 lw.add(e, e["src"] if e["kind"] == M.KIND_FILE else None)
             assert lw.finish()["tar_digest"] == pair["tar_digest"]
+
+
+@settings(max_examples=500, deadline=None, derandomize=True, database=None)
+@given(st.lists(st.sampled_from(["a", "b", ".", "..", "", "a.", ".a", "..a", "a..", "...", "a b"]), min_size=1, max_size=5),
+       st.sampled_from(["", "/", "./", "//"]), st.sampled_from(["", "/", "//", "/."]))
+def test_scan_and_merge_read_a_path_the_same_way(tmp_path_factory, parts, head, tail):
+    """both doors normalise an entry's name like pathutils.AbsPath (path.Join("/", TrimRight(p, "/"))): the scan takes a
+    short cut for names that are already clean, the merge never does"""
+    rel = head + "/".join(parts) + tail
+    root = str(tmp_path_factory.mktemp("norm"))
+    e = {"relpath": rel, "kind": M.KIND_DIR, "mode": 0o40755, "mtime_sec": 3, "uid": 0, "gid": 0, "size": 0}
+    with M.MemFS(root) as a, M.MemFS(root) as b:
+        a.add_layer_by_scan([e])
+        b.update_from_entries([e])
+        assert [x["relpath"] for x in a.entries()] == [x["relpath"] for x in b.entries()], rel
