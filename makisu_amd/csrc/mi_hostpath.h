@@ -1,0 +1,171 @@
+// mi_hostpath.h -- what the host-side restatements of lib/snapshot share: the walk's entry record, Go's path rules
+// (path.Clean / filepath.Join, pathutils.AbsPath / IsDescendantOfAny), the mount table of lib/mountutils.  Header-only;
+// no device code.  Users: mi_tree.hip (walks, stateless diffs), mi_memfs.hip (MemFS, copy ops, untar).
+#pragma once
+#include "../../include/makisu_mi.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <set>
+#include <string>
+#include <vector>
+
+namespace mi_walk {
+
+
+struct Entry {
+    std::string relpath, link;
+    bool has_link = false;
+    int64_t file_index = -1;
+    uint32_t mode = 0;
+    uint64_t size = 0;
+    int64_t mtime = 0;
+    uint8_t kind = 0;      // 0 dir, 1 regular, 2 symlink
+    uint32_t uid = 0, gid = 0;
+};
+
+struct Tree {
+    std::vector<Entry> entries;
+};
+
+// Go's path.Clean for a ROOTED path (what path.Join("/", p) returns): single slashes, no "."
+// elements, ".." removes the element before it, ".." at the root disappears.
+inline std::string clean_rooted(const std::string& p) {
+    std::vector<std::string> parts;
+    size_t i = 0;
+    while (i < p.size()) {
+        while (i < p.size() && p[i] == '/') ++i;
+        size_t j = i;
+        while (j < p.size() && p[j] != '/') ++j;
+        if (j > i) {
+            const std::string el = p.substr(i, j - i);
+            if (el == "..") { if (!parts.empty()) parts.pop_back(); }
+            else if (el != ".") parts.push_back(el);
+        }
+        i = j;
+    }
+    std::string out;
+    for (const std::string& el : parts) out += "/" + el;
+    return out.empty() ? "/" : out;
+}
+// Go's path.Clean for ANY path (filepath.Join's result): as above, but a relative path keeps its leading ".." elements
+// and an empty result is ".".
+inline std::string clean_any(const std::string& p) {
+    if (!p.empty() && p[0] == '/') return clean_rooted(p);
+    std::vector<std::string> parts;
+    size_t i = 0;
+    while (i < p.size()) {
+        while (i < p.size() && p[i] == '/') ++i;
+        size_t j = i;
+        while (j < p.size() && p[j] != '/') ++j;
+        if (j > i) {
+            const std::string el = p.substr(i, j - i);
+            if (el == "..") { if (!parts.empty() && parts.back() != "..") parts.pop_back(); else parts.push_back(el); }
+            else if (el != ".") parts.push_back(el);
+        }
+        i = j;
+    }
+    std::string out;
+    for (const std::string& el : parts) out += (out.empty() ? "" : "/") + el;
+    return out.empty() ? "." : out;
+}
+inline std::string abs_path(const std::string& p) {          // pathutils.AbsPath (lib/pathutils/path.go:41-43)
+    return clean_rooted(p);                                  // path.Join("/", strings.TrimRight(p, "/"))
+}
+// AbsPath of a relative path as the walks and tar readers write them: when it is already clean (no empty, "." or ".."
+// element) that is "/" + the path without trailing slashes; anything else takes the general route
+inline std::string abs_path_of_rel(const char* rel) {
+    if (rel[0] == '.' && rel[1] == 0) return "/";
+    size_t n = strlen(rel);
+    while (n && rel[n - 1] == '/') --n;
+    bool clean = n > 0 && rel[0] != '/';
+    for (size_t i = 0; clean && i < n; ++i) {
+        if (rel[i] == '/' && (i + 1 >= n || rel[i + 1] == '/')) clean = false;
+        if (rel[i] == '.' && (i == 0 || rel[i - 1] == '/')) {
+            const size_t k = rel[i + 1] == '.' ? i + 2 : i + 1;
+            if (k >= n || rel[k] == '/') clean = false;
+        }
+    }
+    if (!clean) return abs_path(rel);
+    std::string out;
+    out.reserve(n + 1);
+    out.push_back('/');
+    out.append(rel, n);
+    return out;
+}
+inline std::string dir_of(const std::string& p) {            // path.Dir for clean absolute paths
+    size_t i = p.find_last_of('/');
+    if (i == std::string::npos) return ".";
+    if (i == 0) return "/";
+    return p.substr(0, i);
+}
+inline std::string base_of(const std::string& p) {
+    size_t i = p.find_last_of('/');
+    return i == std::string::npos ? p : p.substr(i + 1);
+}
+inline bool has_prefix(const std::string& s, const std::string& pre) {
+    return s.size() >= pre.size() && memcmp(s.data(), pre.data(), pre.size()) == 0;
+}
+inline bool is_descendant_of_any(const std::string& path, const std::vector<std::string>& anc) {
+    const std::string p = abs_path(path);
+    for (const std::string& a0 : anc) {
+        const std::string a = abs_path(a0);
+        std::string d = dir_of(p);
+        if (d.back() != '/') d += "/";
+        if (p == a || a == "/" || has_prefix(d, a + "/")) return true;
+    }
+    return false;
+}
+inline std::string rel_to(const std::string& base, const std::string& path) {   // filepath.Rel, descendants only
+    const std::string b = abs_path(base), p = abs_path(path);
+    if (p == b) return ".";
+    if (b == "/") return p.substr(1);
+    if (has_prefix(p, b + "/")) return p.substr(b.size() + 1);
+    return std::string();                                                        // outside: caller errors
+}
+
+// mountutils' table (lib/mountutils/mountutils.go:54-93): targets of /proc/mounts except "/";
+// a missing file means "no mountpoints", a line with fewer than four fields is an error that
+// fails every walk ("cannot parse mounts file").  MI_MOUNTS_FILE names another file, the way
+// the reference's tests swap mountInfo.mountsFile (mountutils_test.go:25-45).
+struct MountTable {
+    std::set<std::string> targets;
+    std::string error;
+};
+inline const MountTable& mountpoints() {
+    static MountTable mt;
+    static std::once_flag once;                              // like the reference's sync.Once
+    std::call_once(once, [] {
+        const char* over = getenv("MI_MOUNTS_FILE");
+        const std::string file = over && *over ? over : "/proc/mounts";
+        FILE* f = fopen(file.c_str(), "r");
+        if (!f) return;                                      // "Skipping mountmanager init"
+        char* line = nullptr;                                // getline: overlay mounts list every lower
+        size_t cap = 0;                                      // layer on ONE line, easily > 8 KiB
+        ssize_t got;
+        while ((got = getline(&line, &cap, f)) >= 0) {
+            size_t n = (size_t)got;
+            while (n && (line[n - 1] == '\n')) line[--n] = 0;
+            if (n == 0) continue;
+            char* sp1 = strchr(line, ' ');
+            char* sp2 = sp1 ? strchr(sp1 + 1, ' ') : nullptr;
+            char* sp3 = sp2 ? strchr(sp2 + 1, ' ') : nullptr;
+            if (!sp3) { mt.error = "cannot parse mounts file " + file; break; }
+            std::string target(sp1 + 1, sp2);
+            if (target != "/") mt.targets.insert(target);    // "/" skipped as the reference does
+        }
+        free(line);
+        fclose(f);
+    });
+    return mt;
+}
+
+
+// the snapshot walk of `src` (scan rules, no blacklist), entries relative to src ("." first); absolute symlink targets
+// lose link_root (createHeader trims by the MemFS root).  Defined in mi_tree.hip, beside the walkers.
+int scan_walk_collect(const std::string& src, const std::string& link_root, Tree* out, std::string* err);
+
+}  // namespace mi_walk

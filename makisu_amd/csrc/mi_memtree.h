@@ -1,0 +1,177 @@
+// mi_memtree.h -- the reference's in-memory tree (memFSNode) and the operations every layer-building path goes through.
+// Header-only; users: mi_tree.hip (the stateless layer merge), mi_memfs.hip (copy ops, the MemFS handle).
+#pragma once
+#include "mi_hostpath.h"
+
+#include <functional>
+#include <map>
+#include <memory>
+#include <string_view>
+
+// The in-memory tree of the reference's own shape -- memFSNode: a header and a children map (lib/snapshot/mem_fs.go:33-47)
+// -- with the four operations every layer-building path goes through: isUpdated's walk (:487-503), addAncestors
+// (:505-566), contentMemFile.updateMemFS (lib/snapshot/mem_layer.go:50-76) and whiteoutMemFile.updateMemFS (:104-125).
+// They walk part by part through nodes of ANY type, and what they do to a file or symlink that has children (or is
+// somebody's ancestor) is not what a flat path map would do, so both users -- the layer merge and the copy-op layer --
+// share this one.  Nodes carry a caller-owned payload index.
+namespace mi_memtree {
+
+struct Node {
+    int64_t ref = -1;                          // caller's payload; -1 = none
+    uint8_t kind = 0;                          // 0 dir, 1 regular, 2 symlink, 3 hard link, 4 special
+    std::string link;                          // symlink target
+    std::map<std::string, std::unique_ptr<Node>, std::less<>> children;       // std::less<>: looked up by string_view
+};
+
+struct Tree {
+    Node root;
+    std::string err;                           // why the last failing call failed, in the reference's words
+    // memLayer.addHeader's bookkeeping (l.files[...] = ...): every header that goes through addHeader -- the entry
+    // itself, each existing ancestor re-added on the way, each directory created
+    std::function<void(const std::string& dst, int64_t ref)> on_add;
+    // the header of a directory addAncestors creates (createHeader from lastAncestor's FileInfo, ModTime = now, the
+    // given uid/gid, :551-559) -> its payload
+    std::function<int64_t(const std::string& dst, const Node& last_ancestor, uint32_t uid, uint32_t gid)> make_dir;
+
+    static std::vector<std::string> parts(const std::string& p) {               // pathutils.SplitPath
+        std::vector<std::string> out;
+        size_t i = 0;
+        while (i < p.size()) {
+            while (i < p.size() && p[i] == '/') ++i;
+            size_t j = i;
+            while (j < p.size() && p[j] != '/') ++j;
+            if (j > i) out.push_back(p.substr(i, j - i));
+            i = j;
+        }
+        return out;
+    }
+    static std::string join_abs(const std::vector<std::string>& ps, size_t n) {  // AbsPath(filepath.Join(parts[:n]...))
+        std::string q;
+        for (size_t k = 0; k < n; ++k) q += "/" + ps[k];
+        return mi_walk::abs_path(q);
+    }
+    Node* find(const std::string& p) {                                          // isUpdated's walk; nullptr = "new"
+        Node* cur = &root;
+        size_t i = 0;
+        while (i < p.size()) {                                                  // SplitPath's parts, without the vector
+            while (i < p.size() && p[i] == '/') ++i;
+            size_t j = i;
+            while (j < p.size() && p[j] != '/') ++j;
+            if (j > i) {
+                auto it = cur->children.find(std::string_view(p.data() + i, j - i));
+                if (it == cur->children.end()) return nullptr;
+                cur = it->second.get();
+            }
+            i = j;
+        }
+        return cur;
+    }
+    // a listed tree: the node at its path, parents that are not listed created on the way (no payload)
+    void load(const std::string& p, int64_t ref, uint8_t kind, const char* link) {
+        Node* cur = &root;
+        for (const std::string& part : parts(p)) {
+            std::unique_ptr<Node>& slot = cur->children[part];
+            if (!slot) slot.reset(new Node);
+            cur = slot.get();
+        }
+        cur->ref = ref; cur->kind = kind; cur->link = link ? link : "";
+    }
+    // contentMemFile.updateMemFS: the node at dst is replaced; the new node takes over the old node's children iff
+    // the NEW header is a directory; a missing part before the last one is an error
+    bool put(const std::string& dst, int64_t ref, uint8_t kind, const std::string& link) {
+        if (on_add) on_add(dst, ref);
+        const std::vector<std::string> ps = parts(dst);
+        Node* cur = &root;
+        for (size_t i = 0; i < ps.size(); ++i) {
+            auto it = cur->children.find(ps[i]);
+            const bool last = i + 1 == ps.size();
+            if (it != cur->children.end() && !last) { cur = it->second.get(); continue; }
+            if (it == cur->children.end() && !last) {
+                err = "missing intermediate directory " + ps[i] + " in " + dst;
+                return false;
+            }
+            std::unique_ptr<Node> nn(new Node);
+            nn->ref = ref; nn->kind = kind; nn->link = link;
+            if (it != cur->children.end()) {
+                if (kind == 0) nn->children = std::move(it->second->children);
+                it->second = std::move(nn);
+            } else {
+                cur->children[ps[i]] = std::move(nn);
+            }
+        }
+        return true;
+    }
+    // whiteoutMemFile.updateMemFS
+    bool wipe(const std::string& del) {
+        const std::vector<std::string> ps = parts(del);
+        Node* cur = &root;
+        for (size_t i = 0; i < ps.size(); ++i) {
+            auto it = cur->children.find(ps[i]);
+            const bool last = i + 1 == ps.size();
+            if (it != cur->children.end()) {
+                if (last) cur->children.erase(it);
+                else cur = it->second.get();
+            } else if (!last) {
+                err = "missing intermediate dir " + ps[i] + " in " + del;
+                return false;
+            }                                                                   // else "Trying to whiteout nonexistent path"
+        }
+        return true;
+    }
+    // l.addHeader(src, dst, hdr).updateMemFS(tree) (mem_layer.go:197-212): a ".wh.<name>" base name is a whiteout of
+    // its sibling <name>, filed under THAT path; anything else is content
+    bool add(const std::string& dst, int64_t ref, uint8_t kind, const std::string& link) {
+        const std::string name = mi_walk::base_of(dst);
+        if (!mi_walk::has_prefix(name, ".wh.")) return put(dst, ref, kind, link);
+        if (on_add) on_add(dst, ref);
+        const std::string dir = mi_walk::dir_of(dst);
+        return wipe((dir == "/" ? "" : dir) + "/" + name.substr(4));
+    }
+    // addAncestors.  Re-adding an existing ancestor "as it is" through updateMemFS changes nothing for a directory and
+    // drops the children of anything else; a symlink sends the walk to its target (filepath.Join(linkname, the
+    // remaining parts), from the tree's root) and ends it; any other non-directory lets the walk go on one part further
+    // WITHOUT descending (the switch at :535-549 has no case for it); what is then still missing of dst's own prefix
+    // is created as directories.  resolved = "the resolved dst path to the best of its knowledge".
+    bool add_ancestors(const std::string& dst, bool inclusive, int depth, uint32_t uid, uint32_t gid,
+                       std::string* resolved) {
+        if (depth >= 1024) {                       // (by now dst is the link's target joined to itself a thousand times)
+            err = "symlink loop at " + (dst.size() > 160 ? dst.substr(0, 160) + "..." : dst);
+            return false;
+        }
+        const std::vector<std::string> ps = parts(dst);
+        const size_t end = inclusive ? ps.size() : (ps.empty() ? 0 : ps.size() - 1);
+        Node* cur = &root;
+        const Node* last_ancestor = &root;
+        std::string cur_path;                                                   // "" = the root
+        size_t i = 0;
+        for (; i < end; ++i) {
+            auto it = cur->children.find(ps[i]);
+            if (it == cur->children.end()) break;
+            Node* n = it->second.get();
+            const std::string n_path = cur_path + "/" + ps[i];
+            if (on_add) on_add(n_path, n->ref);
+            if (n->kind == 0) { last_ancestor = n; cur = n; cur_path = n_path; continue; }
+            n->children.clear();
+            if (n->kind == 2) {
+                std::string target = n->link;
+                for (size_t k = i + 1; k < ps.size(); ++k) target += "/" + ps[k];
+                target = mi_walk::clean_any(target);
+                if (!add_ancestors(target, inclusive, depth + 1, uid, gid, resolved)) {
+                    // (the reference wraps the error once per level; the outermost wrap is the one that says where)
+                    if (depth == 0) err = "get symlink target ancestors " + target + ": " + err;
+                    return false;
+                }
+                return true;
+            }
+        }
+        for (size_t j = i; j < end; ++j) {
+            const std::string q = join_abs(ps, j + 1);
+            const int64_t ref = make_dir ? make_dir(q, *last_ancestor, uid, gid) : -1;
+            if (!put(q, ref, 0, std::string())) { err = "update memfs with ancestor " + q + ": " + err; return false; }
+        }
+        if (resolved) *resolved = dst;
+        return true;
+    }
+};
+
+}  // namespace mi_memtree

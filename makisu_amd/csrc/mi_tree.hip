@@ -27,7 +27,11 @@
 // sequence filepath.Walk produces, stopping at the first error in THAT order.  Same entries, same
 // order, same errors (tests/test_host_walk.py compares the two on randomized trees); MI_WALK_THREADS
 // (1 = the sequential walker below, the reference's shape) overrides the thread count.
-#include "../../include/makisu_mi.h"
+//
+// Also here, on entry lists and without state: the commit order, tario.IsSimilarHeader, the scan's layer diff
+// (mi_snapshot_diff) and the layer merge (mi_entries_apply_layer).  MemFS itself, the copy ops and what surrounds a
+// COPY step: mi_memfs.hip.
+#include "mi_memtree.h"
 
 #include <dirent.h>
 #include <errno.h>
@@ -57,153 +61,6 @@
 #include <vector>
 
 namespace mi_walk {
-
-struct Entry {
-    std::string relpath, link;
-    bool has_link = false;
-    int64_t file_index = -1;
-    uint32_t mode = 0;
-    uint64_t size = 0;
-    int64_t mtime = 0;
-    uint8_t kind = 0;      // 0 dir, 1 regular, 2 symlink
-    uint32_t uid = 0, gid = 0;
-};
-
-struct Tree {
-    std::vector<Entry> entries;
-};
-
-// Go's path.Clean for a ROOTED path (what path.Join("/", p) returns): single slashes, no "."
-// elements, ".." removes the element before it, ".." at the root disappears.
-static std::string clean_rooted(const std::string& p) {
-    std::vector<std::string> parts;
-    size_t i = 0;
-    while (i < p.size()) {
-        while (i < p.size() && p[i] == '/') ++i;
-        size_t j = i;
-        while (j < p.size() && p[j] != '/') ++j;
-        if (j > i) {
-            const std::string el = p.substr(i, j - i);
-            if (el == "..") { if (!parts.empty()) parts.pop_back(); }
-            else if (el != ".") parts.push_back(el);
-        }
-        i = j;
-    }
-    std::string out;
-    for (const std::string& el : parts) out += "/" + el;
-    return out.empty() ? "/" : out;
-}
-// Go's path.Clean for ANY path (filepath.Join's result): as above, but a relative path keeps its leading ".." elements
-// and an empty result is ".".
-static std::string clean_any(const std::string& p) {
-    if (!p.empty() && p[0] == '/') return clean_rooted(p);
-    std::vector<std::string> parts;
-    size_t i = 0;
-    while (i < p.size()) {
-        while (i < p.size() && p[i] == '/') ++i;
-        size_t j = i;
-        while (j < p.size() && p[j] != '/') ++j;
-        if (j > i) {
-            const std::string el = p.substr(i, j - i);
-            if (el == "..") { if (!parts.empty() && parts.back() != "..") parts.pop_back(); else parts.push_back(el); }
-            else if (el != ".") parts.push_back(el);
-        }
-        i = j;
-    }
-    std::string out;
-    for (const std::string& el : parts) out += (out.empty() ? "" : "/") + el;
-    return out.empty() ? "." : out;
-}
-static std::string abs_path(const std::string& p) {          // pathutils.AbsPath (lib/pathutils/path.go:41-43)
-    return clean_rooted(p);                                  // path.Join("/", strings.TrimRight(p, "/"))
-}
-// AbsPath of a relative path as the walks and tar readers write them: when it is already clean (no empty, "." or ".."
-// element) that is "/" + the path without trailing slashes; anything else takes the general route
-static std::string abs_path_of_rel(const char* rel) {
-    if (rel[0] == '.' && rel[1] == 0) return "/";
-    size_t n = strlen(rel);
-    while (n && rel[n - 1] == '/') --n;
-    bool clean = n > 0 && rel[0] != '/';
-    for (size_t i = 0; clean && i < n; ++i) {
-        if (rel[i] == '/' && (i + 1 >= n || rel[i + 1] == '/')) clean = false;
-        if (rel[i] == '.' && (i == 0 || rel[i - 1] == '/')) {
-            const size_t k = rel[i + 1] == '.' ? i + 2 : i + 1;
-            if (k >= n || rel[k] == '/') clean = false;
-        }
-    }
-    if (!clean) return abs_path(rel);
-    std::string out;
-    out.reserve(n + 1);
-    out.push_back('/');
-    out.append(rel, n);
-    return out;
-}
-static std::string dir_of(const std::string& p) {            // path.Dir for clean absolute paths
-    size_t i = p.find_last_of('/');
-    if (i == std::string::npos) return ".";
-    if (i == 0) return "/";
-    return p.substr(0, i);
-}
-static std::string base_of(const std::string& p) {
-    size_t i = p.find_last_of('/');
-    return i == std::string::npos ? p : p.substr(i + 1);
-}
-static bool has_prefix(const std::string& s, const std::string& pre) {
-    return s.size() >= pre.size() && memcmp(s.data(), pre.data(), pre.size()) == 0;
-}
-static bool is_descendant_of_any(const std::string& path, const std::vector<std::string>& anc) {
-    const std::string p = abs_path(path);
-    for (const std::string& a0 : anc) {
-        const std::string a = abs_path(a0);
-        std::string d = dir_of(p);
-        if (d.back() != '/') d += "/";
-        if (p == a || a == "/" || has_prefix(d, a + "/")) return true;
-    }
-    return false;
-}
-static std::string rel_to(const std::string& base, const std::string& path) {   // filepath.Rel, descendants only
-    const std::string b = abs_path(base), p = abs_path(path);
-    if (p == b) return ".";
-    if (b == "/") return p.substr(1);
-    if (has_prefix(p, b + "/")) return p.substr(b.size() + 1);
-    return std::string();                                                        // outside: caller errors
-}
-
-// mountutils' table (lib/mountutils/mountutils.go:54-93): targets of /proc/mounts except "/";
-// a missing file means "no mountpoints", a line with fewer than four fields is an error that
-// fails every walk ("cannot parse mounts file").  MI_MOUNTS_FILE names another file, the way
-// the reference's tests swap mountInfo.mountsFile (mountutils_test.go:25-45).
-struct MountTable {
-    std::set<std::string> targets;
-    std::string error;
-};
-static const MountTable& mountpoints() {
-    static MountTable mt;
-    static std::once_flag once;                              // like the reference's sync.Once
-    std::call_once(once, [] {
-        const char* over = getenv("MI_MOUNTS_FILE");
-        const std::string file = over && *over ? over : "/proc/mounts";
-        FILE* f = fopen(file.c_str(), "r");
-        if (!f) return;                                      // "Skipping mountmanager init"
-        char* line = nullptr;                                // getline: overlay mounts list every lower
-        size_t cap = 0;                                      // layer on ONE line, easily > 8 KiB
-        ssize_t got;
-        while ((got = getline(&line, &cap, f)) >= 0) {
-            size_t n = (size_t)got;
-            while (n && (line[n - 1] == '\n')) line[--n] = 0;
-            if (n == 0) continue;
-            char* sp1 = strchr(line, ' ');
-            char* sp2 = sp1 ? strchr(sp1 + 1, ' ') : nullptr;
-            char* sp3 = sp2 ? strchr(sp2 + 1, ' ') : nullptr;
-            if (!sp3) { mt.error = "cannot parse mounts file " + file; break; }
-            std::string target(sp1 + 1, sp2);
-            if (target != "/") mt.targets.insert(target);    // "/" skipped as the reference does
-        }
-        free(line);
-        fclose(f);
-    });
-    return mt;
-}
 
 struct Walker {
     mi_batch* batch;
@@ -536,175 +393,21 @@ static void walk_root(Walker* w, const std::string& root) {
     pw.finish();
 }
 
+// the walk the copy ops need (mi_memfs.hip): one source, scan rules, no blacklist
+int scan_walk_collect(const std::string& src, const std::string& link_root, Tree* out, std::string* err) {
+    Walker w;
+    w.batch = nullptr;
+    w.rel_base = src;
+    w.mode = MI_TREE_SCAN;
+    w.tree = out;
+    w.link_root = link_root;
+    w.visit(src);
+    if (w.rc && err) *err = w.err;
+    return w.rc;
+}
+
 }  // namespace mi_walk
 
-// The in-memory tree of the reference's own shape -- memFSNode: a header and a children map (lib/snapshot/mem_fs.go:33-47)
-// -- with the four operations every layer-building path goes through: isUpdated's walk (:487-503), addAncestors
-// (:505-566), contentMemFile.updateMemFS (lib/snapshot/mem_layer.go:50-76) and whiteoutMemFile.updateMemFS (:104-125).
-// They walk part by part through nodes of ANY type, and what they do to a file or symlink that has children (or is
-// somebody's ancestor) is not what a flat path map would do, so both users -- the layer merge and the copy-op layer --
-// share this one.  Nodes carry a caller-owned payload index.
-namespace mi_memtree {
-
-struct Node {
-    int64_t ref = -1;                          // caller's payload; -1 = none
-    uint8_t kind = 0;                          // 0 dir, 1 regular, 2 symlink, 3 hard link, 4 special
-    std::string link;                          // symlink target
-    std::map<std::string, std::unique_ptr<Node>, std::less<>> children;       // std::less<>: looked up by string_view
-};
-
-struct Tree {
-    Node root;
-    std::string err;                           // why the last failing call failed, in the reference's words
-    // memLayer.addHeader's bookkeeping (l.files[...] = ...): every header that goes through addHeader -- the entry
-    // itself, each existing ancestor re-added on the way, each directory created
-    std::function<void(const std::string& dst, int64_t ref)> on_add;
-    // the header of a directory addAncestors creates (createHeader from lastAncestor's FileInfo, ModTime = now, the
-    // given uid/gid, :551-559) -> its payload
-    std::function<int64_t(const std::string& dst, const Node& last_ancestor, uint32_t uid, uint32_t gid)> make_dir;
-
-    static std::vector<std::string> parts(const std::string& p) {               // pathutils.SplitPath
-        std::vector<std::string> out;
-        size_t i = 0;
-        while (i < p.size()) {
-            while (i < p.size() && p[i] == '/') ++i;
-            size_t j = i;
-            while (j < p.size() && p[j] != '/') ++j;
-            if (j > i) out.push_back(p.substr(i, j - i));
-            i = j;
-        }
-        return out;
-    }
-    static std::string join_abs(const std::vector<std::string>& ps, size_t n) {  // AbsPath(filepath.Join(parts[:n]...))
-        std::string q;
-        for (size_t k = 0; k < n; ++k) q += "/" + ps[k];
-        return mi_walk::abs_path(q);
-    }
-    Node* find(const std::string& p) {                                          // isUpdated's walk; nullptr = "new"
-        Node* cur = &root;
-        size_t i = 0;
-        while (i < p.size()) {                                                  // SplitPath's parts, without the vector
-            while (i < p.size() && p[i] == '/') ++i;
-            size_t j = i;
-            while (j < p.size() && p[j] != '/') ++j;
-            if (j > i) {
-                auto it = cur->children.find(std::string_view(p.data() + i, j - i));
-                if (it == cur->children.end()) return nullptr;
-                cur = it->second.get();
-            }
-            i = j;
-        }
-        return cur;
-    }
-    // a listed tree: the node at its path, parents that are not listed created on the way (no payload)
-    void load(const std::string& p, int64_t ref, uint8_t kind, const char* link) {
-        Node* cur = &root;
-        for (const std::string& part : parts(p)) {
-            std::unique_ptr<Node>& slot = cur->children[part];
-            if (!slot) slot.reset(new Node);
-            cur = slot.get();
-        }
-        cur->ref = ref; cur->kind = kind; cur->link = link ? link : "";
-    }
-    // contentMemFile.updateMemFS: the node at dst is replaced; the new node takes over the old node's children iff
-    // the NEW header is a directory; a missing part before the last one is an error
-    bool put(const std::string& dst, int64_t ref, uint8_t kind, const std::string& link) {
-        if (on_add) on_add(dst, ref);
-        const std::vector<std::string> ps = parts(dst);
-        Node* cur = &root;
-        for (size_t i = 0; i < ps.size(); ++i) {
-            auto it = cur->children.find(ps[i]);
-            const bool last = i + 1 == ps.size();
-            if (it != cur->children.end() && !last) { cur = it->second.get(); continue; }
-            if (it == cur->children.end() && !last) {
-                err = "missing intermediate directory " + ps[i] + " in " + dst;
-                return false;
-            }
-            std::unique_ptr<Node> nn(new Node);
-            nn->ref = ref; nn->kind = kind; nn->link = link;
-            if (it != cur->children.end()) {
-                if (kind == 0) nn->children = std::move(it->second->children);
-                it->second = std::move(nn);
-            } else {
-                cur->children[ps[i]] = std::move(nn);
-            }
-        }
-        return true;
-    }
-    // whiteoutMemFile.updateMemFS
-    bool wipe(const std::string& del) {
-        const std::vector<std::string> ps = parts(del);
-        Node* cur = &root;
-        for (size_t i = 0; i < ps.size(); ++i) {
-            auto it = cur->children.find(ps[i]);
-            const bool last = i + 1 == ps.size();
-            if (it != cur->children.end()) {
-                if (last) cur->children.erase(it);
-                else cur = it->second.get();
-            } else if (!last) {
-                err = "missing intermediate dir " + ps[i] + " in " + del;
-                return false;
-            }                                                                   // else "Trying to whiteout nonexistent path"
-        }
-        return true;
-    }
-    // l.addHeader(src, dst, hdr).updateMemFS(tree) (mem_layer.go:197-212): a ".wh.<name>" base name is a whiteout of
-    // its sibling <name>, filed under THAT path; anything else is content
-    bool add(const std::string& dst, int64_t ref, uint8_t kind, const std::string& link) {
-        const std::string name = mi_walk::base_of(dst);
-        if (!mi_walk::has_prefix(name, ".wh.")) return put(dst, ref, kind, link);
-        if (on_add) on_add(dst, ref);
-        const std::string dir = mi_walk::dir_of(dst);
-        return wipe((dir == "/" ? "" : dir) + "/" + name.substr(4));
-    }
-    // addAncestors.  Re-adding an existing ancestor "as it is" through updateMemFS changes nothing for a directory and
-    // drops the children of anything else; a symlink sends the walk to its target (filepath.Join(linkname, the
-    // remaining parts), from the tree's root) and ends it; any other non-directory lets the walk go on one part further
-    // WITHOUT descending (the switch at :535-549 has no case for it); what is then still missing of dst's own prefix
-    // is created as directories.  resolved = "the resolved dst path to the best of its knowledge".
-    bool add_ancestors(const std::string& dst, bool inclusive, int depth, uint32_t uid, uint32_t gid,
-                       std::string* resolved) {
-        if (depth >= 1024) {                       // (by now dst is the link's target joined to itself a thousand times)
-            err = "symlink loop at " + (dst.size() > 160 ? dst.substr(0, 160) + "..." : dst);
-            return false;
-        }
-        const std::vector<std::string> ps = parts(dst);
-        const size_t end = inclusive ? ps.size() : (ps.empty() ? 0 : ps.size() - 1);
-        Node* cur = &root;
-        const Node* last_ancestor = &root;
-        std::string cur_path;                                                   // "" = the root
-        size_t i = 0;
-        for (; i < end; ++i) {
-            auto it = cur->children.find(ps[i]);
-            if (it == cur->children.end()) break;
-            Node* n = it->second.get();
-            const std::string n_path = cur_path + "/" + ps[i];
-            if (on_add) on_add(n_path, n->ref);
-            if (n->kind == 0) { last_ancestor = n; cur = n; cur_path = n_path; continue; }
-            n->children.clear();
-            if (n->kind == 2) {
-                std::string target = n->link;
-                for (size_t k = i + 1; k < ps.size(); ++k) target += "/" + ps[k];
-                target = mi_walk::clean_any(target);
-                if (!add_ancestors(target, inclusive, depth + 1, uid, gid, resolved)) {
-                    // (the reference wraps the error once per level; the outermost wrap is the one that says where)
-                    if (depth == 0) err = "get symlink target ancestors " + target + ": " + err;
-                    return false;
-                }
-                return true;
-            }
-        }
-        for (size_t j = i; j < end; ++j) {
-            const std::string q = join_abs(ps, j + 1);
-            const int64_t ref = make_dir ? make_dir(q, *last_ancestor, uid, gid) : -1;
-            if (!put(q, ref, 0, std::string())) { err = "update memfs with ancestor " + q + ": " + err; return false; }
-        }
-        if (resolved) *resolved = dst;
-        return true;
-    }
-};
-
-}  // namespace mi_memtree
 
 using mi_walk::Tree;
 
@@ -1073,1284 +776,3 @@ int mi_entry_similar(const mi_tree_entry* a, const mi_tree_entry* b, int ignore_
 }
 
 }  // extern "C"
-
-// ---- MemFS.AddLayerByCopyOps: the layer a COPY / ADD step creates, on entry lists -----------------
-// addToLayer + maybeAddToLayer(createWhiteout = false) + addAncestors + isUpdated + createHeader
-// (lib/snapshot/mem_fs.go:276-289, 343-421, 440-503, 505-566; mem_layer.go:152-190) and
-// CopyOperation's source resolution (copy_op.go, utils.go:249-327), restated on a path-keyed tree:
-//   * a single non-directory source copies onto dst (or into dst + "/" + base when dst ends with "/");
-//     otherwise dst is ensured to exist -- every EXISTING ancestor is carried into the layer, a
-//     symlink on the way is followed (its target joined with the rest of the path, the reference's
-//     own rule, depth-limited), missing directories are created with the last existing ancestor's
-//     mode, the op's uid/gid and mtime = now -- and the sources' CONTENTS are copied below it;
-//   * sources are resolved through symlinks inside src_root (a link leaving the root is an error)
-//     and walked like every snapshot walk (".wh..wh." names, special files and mountpoints skipped;
-//     no blacklist: the reference passes nil here);
-//   * every walked path gets createHeader's header with the op's uid/gid and is added iff isUpdated
-//     says so (tario.IsSimilarHeader against what the tree holds); adding a path first carries its
-//     existing ancestors, then replaces the node: a directory keeps the old node's children, anything
-//     else drops them.
-// Result: the layer's entries in commit order (sorted by dst), each with the path its content is
-// read from ("/" for directories the op created: memLayer.addHeader("", ...) -> AbsPath("")).  The caller's tree is not modified; to continue,
-// apply the layer to it with mi_entries_apply_layer.
-namespace mi_copy {
-
-struct Node {
-    mi_walk::Entry e;          // relpath = dst without the leading "/"
-    std::string src;           // where the content is read from; what memFSNode.isOnDisk looks at
-    bool has_root = false;     // chunk root of the content, when the caller scanned it (content-aware isUpdated)
-    uint8_t root[32];
-};
-struct Fs {
-    mi_memtree::Tree t;                      // fs.tree; a node's ref indexes `nodes`
-    std::vector<Node> nodes;
-    std::unordered_map<std::string, int64_t> layer;   // memLayer.files: keyed by dst -- by the DELETED path for a ".wh."
-                                                       // name; sorted when the layer is taken (rangeFiles, mem_layer.go:232-244)
-    std::vector<Node> sorted_layer() const {
-        std::vector<std::pair<std::string, int64_t>> keys(layer.begin(), layer.end());
-        std::sort(keys.begin(), keys.end());                                        // sort.Strings on the keys
-        std::vector<Node> out;
-        out.reserve(keys.size());
-        for (auto& kv : keys) out.push_back(nodes[kv.second]);
-        return out;
-    }
-    std::string root;                      // fs.tree.src
-    const std::unordered_set<std::string_view>* walked = nullptr;   // the scan under way: the paths its walk lists
-    int64_t now = 0;
-    std::string err;
-    int rc = MI_OK;
-
-    bool fail(int code, const std::string& m) { if (!rc) { rc = code; err = m; } return false; }
-    int64_t keep(Node n) { nodes.push_back(std::move(n)); return (int64_t)nodes.size() - 1; }
-
-    Fs() {
-        t.on_add = [this](const std::string& dst, int64_t ref) {               // memLayer.addHeader (mem_layer.go:197-212)
-            if (ref < 0) {                                                      // a parent the caller's list left out
-                Node d;
-                d.e.mode = (uint32_t)(S_IFDIR | 0755); d.e.kind = 0; d.e.relpath = dst.substr(1); d.e.mtime = now;
-                d.src = "/";
-                ref = keep(d);
-                if (mi_memtree::Node* n = t.find(dst)) n->ref = ref;
-            }
-            const std::string name = mi_walk::base_of(dst);
-            if (mi_walk::has_prefix(name, ".wh.")) {
-                const std::string dir = mi_walk::dir_of(dst);
-                layer[(dir == "/" ? "" : dir) + "/" + name.substr(4)] = ref;
-            } else {
-                layer[dst] = ref;
-            }
-        };
-        t.make_dir = [this](const std::string& dst, const mi_memtree::Node& last_ancestor, uint32_t uid, uint32_t gid) {
-            Node d;                                                             // mem_fs.go:551-559
-            d.e.mode = last_ancestor.ref >= 0 ? nodes[last_ancestor.ref].e.mode : (uint32_t)(S_IFDIR | 0755);
-            d.e.kind = 0;
-            d.e.relpath = dst.substr(1);
-            d.e.mtime = now;
-            d.e.uid = uid;
-            d.e.gid = gid;
-            d.src = "/";                       // l.addHeader("", curr, hdr): src = AbsPath("") -- isOnDisk says yes, always
-            return keep(d);
-        };
-    }
-    // addAncestors (mem_fs.go:505-566); returns the resolved dst
-    std::string add_ancestors(const std::string& dst, bool inclusive, uint32_t uid, uint32_t gid) {
-        std::string resolved = dst;
-        if (!t.add_ancestors(dst, inclusive, 0, uid, gid, &resolved)) fail(MI_ERR_INVALID, "add ancestors of " + dst + ": " + t.err);
-        return resolved;
-    }
-    // memLayer.addWhiteout (mem_layer.go:214-228) + whiteoutMemFile.updateMemFS
-    bool add_whiteout(const std::string& p) {
-        const std::string name = mi_walk::base_of(p);
-        if (mi_walk::has_prefix(name, ".wh.")) return fail(MI_ERR_INVALID, "add whiteout to layer " + p + ": base name contains whiteout prefix: " + p);
-        const std::string dir = mi_walk::dir_of(p);
-        Node w;
-        w.e.kind = 1;
-        w.e.mode = 0;
-        w.e.relpath = ((dir == "/" ? "" : dir) + "/.wh." + name).substr(1);
-        layer[p] = keep(w);
-        if (!t.wipe(p)) return fail(MI_ERR_INVALID, "update memfs with whiteout " + p + ": " + t.err);
-        return true;
-    }
-    // maybeAddToLayer(l, src, dst, hdr, createWhiteout) (mem_fs.go:440-483)
-    void maybe_add(const std::string& src, const std::string& dst, Node n, bool create_whiteout = false) {
-        bool updated = true;
-        mi_memtree::Node* cur = t.find(dst);                                      // isUpdated (:487-503)
-        const bool had_node = cur != nullptr;
-        if (cur && cur->ref >= 0) {
-            mi_tree_entry a, b;
-            auto fill = [](const Node& x, mi_tree_entry* o) {
-                memset(o, 0, sizeof *o);
-                o->relpath = x.e.relpath.empty() ? "" : x.e.relpath.c_str();
-                o->link_target = x.e.has_link ? x.e.link.c_str() : nullptr;
-                o->size = x.e.size; o->mtime_sec = x.e.mtime; o->mode = x.e.mode; o->kind = x.e.kind;
-                o->uid = x.e.uid; o->gid = x.e.gid; o->file_index = -1;
-            };
-            fill(nodes[cur->ref], &a);
-            fill(n, &b);
-            int similar = 0;
-            const Node& o = nodes[cur->ref];
-            if (a.kind <= 3 && b.kind <= 3 &&
-                mi_entry_similar(&a, &b, 0, o.has_root ? o.root : nullptr, n.has_root ? n.root : nullptr, &similar) != MI_OK) {
-                fail(MI_ERR_INVALID, "check header " + dst + ": unsupported type");
-                return;
-            }
-            updated = !similar;
-        }
-        if (updated && dst != "/") {
-            add_ancestors(dst, false, 0, 0);
-            if (rc) return;
-            n.src = src;
-            const uint8_t kind = n.e.kind;
-            const std::string link = n.e.has_link ? n.e.link : std::string();
-            // updateMemFS walks the tree part by part (mem_layer.go:57-80): every part before the last has to be a
-            // node -- of any type.  A destination spelled THROUGH a symlink therefore works one level below the
-            // link (the link node takes the child) and fails deeper ("missing intermediate directory"): what
-            // addAncestors created lies on the link's TARGET, and its resolved path is only used by the createDst branch
-            if (!t.add(dst, keep(std::move(n)), kind, link)) {
-                fail(MI_ERR_INVALID, "update memfs with file " + dst + ": " + t.err);
-                return;
-            }
-        }
-        // "Handle deletions.  Note: Only one whiteout file is needed for a deleted subtree." (:460-480): the children
-        // the tree held for this directory BEFORE the call (n, isUpdated's node) that are no longer on disk
-        if (create_whiteout && n.e.kind == 0 && had_node) {
-            mi_memtree::Node* dir = t.find(dst);
-            if (!dir) return;
-            std::vector<std::string> gone;                                      // (wiping changes the map: collect first)
-            std::string child = dst == "/" ? "/" : dst + "/";
-            const size_t stem = child.size();
-            for (auto& kv : dir->children) {
-                child.resize(stem);
-                child += kv.first;
-                const int64_t ref = kv.second->ref;
-                const std::string& child_src = ref >= 0 ? nodes[ref].src : std::string();
-                // memFSNode.isOnDisk (:49-57) is an lstat of the node's source.  When that source is the node's own place
-                // under the root and the walk of THIS scan lists it, the walk has just lstat'ed it: no second one (the
-                // reference pays it for every node of the tree on every scan)
-                if (walked && child_src.size() == (root == "/" ? 0 : root.size()) + child.size() && walked->count(std::string_view(child)) &&
-                    child_src.compare(child_src.size() - child.size(), child.size(), child) == 0 &&
-                    (root == "/" || child_src.compare(0, root.size(), root) == 0))
-                    continue;
-                struct stat st;
-                if (lstat(child_src.c_str(), &st) == 0) continue;
-                if (errno != ENOENT && errno != ENOTDIR) {
-                    fail(MI_ERR_IO, "check on disk " + child + ": lstat " + child_src + ": " + strerror(errno));
-                    return;
-                }
-                gone.push_back(child);
-            }
-            for (const std::string& child : gone) {
-                if (!add_whiteout(child)) return;
-                add_ancestors(child, false, 0, 0);
-                if (rc) return;
-            }
-        }
-    }
-};
-
-// evalSymlinks (utils.go:249-327): resolves the symlinks of p inside root; a link that leaves the
-// root is an error.  Returns the path relative to root ("/"-rooted).
-static bool eval_symlinks(const std::string& p, const std::string& root, std::string* out, std::string* err) {
-    if (p.empty()) { *out = p; return true; }
-    std::string cur = p;
-    for (int walked = 0; walked <= 255;) {
-        // resolve the first symlink found walking the components of cur
-        const std::vector<std::string> parts = mi_memtree::Tree::parts(cur);
-        std::string acc;
-        bool replaced = false;
-        for (size_t i = 0; i < parts.size(); ++i) {
-            const std::string here = acc + "/" + parts[i];
-            struct stat st;
-            if (lstat((root + here).c_str(), &st) != 0) { *err = "walk link: lstat: " + here + ": " + strerror(errno); return false; }
-            if (S_ISLNK(st.st_mode)) {
-                std::vector<char> buf(4096);
-                const ssize_t n = readlink((root + here).c_str(), buf.data(), buf.size() - 1);
-                if (n < 0) { *err = "readlink " + here + ": " + strerror(errno); return false; }
-                std::string target(buf.data(), (size_t)n);
-                if (!target.empty() && target[0] == '/') {
-                    if (!mi_walk::has_prefix(target, root)) {
-                        *err = "link points outside of root: " + root + here + " -> " + target;
-                        return false;
-                    }
-                    target = target.substr(root.size());
-                    if (target.empty() || target[0] != '/') target = "/" + target;
-                } else {
-                    target = acc + "/" + target;                         // relative to the link's directory
-                }
-                for (size_t k = i + 1; k < parts.size(); ++k) target += "/" + parts[k];
-                cur = mi_walk::clean_rooted(target);
-                ++walked;
-                replaced = true;
-                break;
-            }
-            acc = here;
-        }
-        if (!replaced) { *out = mi_walk::abs_path(cur); return true; }
-    }
-    *err = "eval symlinks: too many links";
-    return false;
-}
-
-}  // namespace mi_copy
-
-struct mi_copy_layer {
-    std::vector<mi_copy::Node> nodes;                       // commit order
-};
-
-// isDirFormat / checkCopyParams / resolveDestination (lib/snapshot/copy_op.go:149-180)
-static bool copy_dst_is_dir_format(const std::string& dst) {
-    return (!dst.empty() && dst.back() == '/') || dst == "." || dst == "..";
-}
-static std::string copy_check_params(uint64_t n_srcs, const char* work_dir, const std::string& dst) {
-    if (n_srcs == 0) return "srcs cannot be empty";
-    if (n_srcs > 1 && !copy_dst_is_dir_format(dst)) return "tarring multiple sources, destination must end with \"/\"";
-    if ((dst.empty() || dst[0] != '/') && !(work_dir && work_dir[0] == '/'))
-        return "dst is not absolute path, must specify absolute working directory";
-    return "";
-}
-
-// ---- the caller's side of a COPY/ADD step: --chown and the source patterns ------------------------------------------
-//
-// utils.ResolveChown (lib/utils/utils.go:186-228): "<user>[:<group>]", each a number (strconv.Atoi: an optional sign and
-// decimal digits) or a name looked up in the user / group database; no group = the uid; more than one ':' is an error.
-static bool go_atoi(const std::string& t, long long* v) {
-    size_t i = 0;
-    if (!t.empty() && (t[0] == '+' || t[0] == '-')) i = 1;
-    if (i == t.size()) return false;
-    long long x = 0;
-    for (size_t k = i; k < t.size(); ++k) {
-        if (t[k] < '0' || t[k] > '9') return false;
-        x = x * 10 + (t[k] - '0');
-        if (x > 0x7fffffffffffll / 16) return false;                            // out of int range long before it matters
-    }
-    *v = t[0] == '-' ? -x : x;
-    return true;
-}
-extern "C" int mi_resolve_chown(const char* chown, int preserve_owner, int64_t* uid, int64_t* gid, char* err,
-                                uint64_t err_cap) {
-    auto put_err = [&](const std::string& m) { if (err && err_cap) snprintf(err, (size_t)err_cap, "%s", m.c_str()); };
-    if (!uid || !gid) return MI_ERR_INVALID;
-    *uid = *gid = 0;
-    const std::string c = chown ? chown : "";
-    if (!c.empty() && preserve_owner) { put_err("both chown and archive are true"); return MI_ERR_INVALID; }   // copy_op.go:52-55
-    if (c.empty()) return MI_OK;
-    std::vector<std::string> split(1);
-    for (char ch : c) { if (ch == ':') split.emplace_back(); else split.back() += ch; }
-    if (split.size() > 2) { put_err("resolve chown str: failed to split on ':'"); return MI_ERR_INVALID; }
-    long long u = 0, g = 0;
-    if (!go_atoi(split[0], &u)) {
-        struct passwd pw, *res = nullptr;
-        std::vector<char> buf(1 << 16);
-        if (split[0].empty() || getpwnam_r(split[0].c_str(), &pw, buf.data(), buf.size(), &res) != 0 || !res) {
-            put_err("resolve chown str: failed to look up user '" + split[0] + "'");
-            return MI_ERR_INVALID;
-        }
-        u = (long long)pw.pw_uid;
-    }
-    if (split.size() == 1) { *uid = *gid = u; return MI_OK; }
-    if (!go_atoi(split[1], &g)) {
-        struct group gr, *res = nullptr;
-        std::vector<char> buf(1 << 16);
-        if (split[1].empty() || getgrnam_r(split[1].c_str(), &gr, buf.data(), buf.size(), &res) != 0 || !res) {
-            put_err("resolve chown str: failed to look up group '" + split[0] + "'");   // (the reference names the USER here, :221)
-            return MI_ERR_INVALID;
-        }
-        g = (long long)gr.gr_gid;
-    }
-    *uid = u; *gid = g;
-    return MI_OK;
-}
-
-// path/filepath.Match and Glob as the Go 1.14 toolchain the reference builds with defines them (Makefile:34) --
-// resolveFromPaths (lib/builder/step/add_copy_step.go:171-185) runs every source of a COPY/ADD through Glob:
-//   '*' any run of non-'/' characters, '?' one non-'/' character, '[' ['^'] ranges ']' a character class (not empty;
-//   lo '-' hi; characters are runes), '\\' escapes the next character; the whole name has to match.  A malformed
-//   pattern is ErrBadPattern -- but only where matching GETS to the bad part (1.14 stops at the end of the name).
-namespace mi_glob {
-
-static size_t rune_at(const std::string& s, size_t i, uint32_t* r) {           // utf8.DecodeRuneInString
-    const unsigned char c = (unsigned char)s[i];
-    auto cont = [&](size_t k) { return i + k < s.size() && ((unsigned char)s[i + k] & 0xC0) == 0x80; };
-    if (c < 0x80) { *r = c; return 1; }
-    if (c >= 0xC2 && c <= 0xDF && cont(1)) { *r = ((c & 0x1Fu) << 6) | ((unsigned char)s[i + 1] & 0x3Fu); return 2; }
-    if (c >= 0xE0 && c <= 0xEF && cont(1) && cont(2)) {
-        const uint32_t v = ((c & 0x0Fu) << 12) | (((unsigned char)s[i + 1] & 0x3Fu) << 6) | ((unsigned char)s[i + 2] & 0x3Fu);
-        if (v >= 0x800 && !(v >= 0xD800 && v <= 0xDFFF)) { *r = v; return 3; }
-    }
-    if (c >= 0xF0 && c <= 0xF4 && cont(1) && cont(2) && cont(3)) {
-        const uint32_t v = ((c & 0x07u) << 18) | (((unsigned char)s[i + 1] & 0x3Fu) << 12) |
-                           (((unsigned char)s[i + 2] & 0x3Fu) << 6) | ((unsigned char)s[i + 3] & 0x3Fu);
-        if (v >= 0x10000 && v <= 0x10FFFF) { *r = v; return 4; }
-    }
-    *r = 0xFFFD;                                                                // RuneError, width 1
-    return 1;
-}
-
-// getEsc: one possibly escaped character of a class; false = ErrBadPattern
-static bool get_esc(const std::string& chunk, size_t* at, uint32_t* r) {
-    size_t i = *at;
-    if (i >= chunk.size() || chunk[i] == '-' || chunk[i] == ']') return false;
-    if (chunk[i] == '\\') { if (++i >= chunk.size()) return false; }
-    const size_t n = rune_at(chunk, i, r);
-    bool ok = !(*r == 0xFFFD && n == 1);
-    i += n;
-    if (i >= chunk.size()) ok = false;
-    *at = i;
-    return ok;
-}
-
-// matchChunk: does chunk (no '*') match a prefix of s[from:]?  rest = where the match ends
-static bool match_chunk(const std::string& chunk, const std::string& s, size_t from, size_t* rest, bool* bad) {
-    size_t c = 0, i = from;
-    while (c < chunk.size()) {
-        if (i >= s.size()) return false;
-        switch (chunk[c]) {
-            case '[': {
-                uint32_t r;
-                i += rune_at(s, i, &r);
-                if (++c >= chunk.size()) { *bad = true; return false; }
-                const bool negated = chunk[c] == '^';
-                if (negated) ++c;
-                bool match = false;
-                for (int nrange = 0;; ++nrange) {
-                    if (c < chunk.size() && chunk[c] == ']' && nrange > 0) { ++c; break; }
-                    uint32_t lo, hi;
-                    if (!get_esc(chunk, &c, &lo)) { *bad = true; return false; }
-                    hi = lo;
-                    if (chunk[c] == '-') {
-                        ++c;
-                        if (!get_esc(chunk, &c, &hi)) { *bad = true; return false; }
-                    }
-                    if (lo <= r && r <= hi) match = true;
-                }
-                if (match == negated) return false;
-                break;
-            }
-            case '?': {
-                if (s[i] == '/') return false;
-                uint32_t r;
-                i += rune_at(s, i, &r);
-                ++c;
-                break;
-            }
-            case '\\':
-                if (++c >= chunk.size()) { *bad = true; return false; }
-                /* fallthrough */
-            default:
-                if (chunk[c] != s[i]) return false;
-                ++i; ++c;
-        }
-    }
-    *rest = i;
-    return true;
-}
-
-static bool match(const std::string& pattern, const std::string& name, bool* bad) {
-    size_t p = 0, n = 0;
-    *bad = false;
-    while (p < pattern.size()) {
-        bool star = false;                                                      // scanChunk
-        while (p < pattern.size() && pattern[p] == '*') { ++p; star = true; }
-        bool inrange = false;
-        size_t e = p;
-        for (; e < pattern.size(); ++e) {
-            const char ch = pattern[e];
-            if (ch == '\\') { if (e + 1 < pattern.size()) ++e; }
-            else if (ch == '[') inrange = true;
-            else if (ch == ']') inrange = false;
-            else if (ch == '*' && !inrange) break;
-        }
-        const std::string chunk = pattern.substr(p, e - p);
-        p = e;
-        if (star && chunk.empty()) return name.find('/', n) == std::string::npos;   // a trailing * takes the rest
-        size_t t = 0;
-        const bool ok = match_chunk(chunk, name, n, &t, bad);
-        if (ok && (t == name.size() || p < pattern.size())) { n = t; continue; }
-        if (*bad) return false;
-        if (star) {
-            bool advanced = false;
-            for (size_t i = n; i < name.size() && name[i] != '/'; ++i) {
-                if (match_chunk(chunk, name, i + 1, &t, bad)) {
-                    if (p >= pattern.size() && t < name.size()) continue;       // last chunk: the name has to end here
-                    n = t;
-                    advanced = true;
-                    break;
-                }
-                if (*bad) return false;
-            }
-            if (advanced) continue;
-        }
-        return false;
-    }
-    return n == name.size();
-}
-
-static bool has_meta(const std::string& s) { return s.find_first_of("*?[\\") != std::string::npos; }
-
-// glob(dir, pattern, matches): the names of dir that match, sorted, joined to dir; I/O errors are ignored
-static bool glob_dir(const std::string& dir, const std::string& pattern, std::vector<std::string>* out) {
-    struct stat st;
-    if (stat(dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return true;
-    DIR* d = opendir(dir.c_str());
-    if (!d) return true;
-    std::vector<std::string> names;
-    while (struct dirent* de = readdir(d)) {
-        const std::string n = de->d_name;
-        if (n != "." && n != "..") names.push_back(n);
-    }
-    closedir(d);
-    std::sort(names.begin(), names.end());
-    for (const std::string& n : names) {
-        bool bad = false;
-        if (match(pattern, n, &bad)) {
-            std::string j = dir == "." ? n : (dir.back() == '/' ? dir + n : dir + "/" + n);   // filepath.Join(dir, n)
-            out->push_back(dir == "." ? j : (dir[0] == '/' ? mi_walk::clean_rooted(j) : mi_walk::clean_any(j)));
-        }
-        if (bad) return false;
-    }
-    return true;
-}
-
-static bool glob(const std::string& pattern, std::vector<std::string>* out) {   // false = ErrBadPattern
-    bool bad = false;
-    match(pattern, "", &bad);
-    if (bad) return false;
-    if (!has_meta(pattern)) {
-        struct stat st;
-        if (lstat(pattern.c_str(), &st) == 0) out->push_back(pattern);
-        return true;
-    }
-    const size_t cut = pattern.find_last_of('/');                               // filepath.Split
-    std::string dir = cut == std::string::npos ? "" : pattern.substr(0, cut + 1);
-    const std::string file = cut == std::string::npos ? pattern : pattern.substr(cut + 1);
-    if (dir.empty()) dir = ".";                                                 // cleanGlobPath
-    else if (dir != "/") dir.pop_back();
-    if (!has_meta(dir)) return glob_dir(dir, file, out);
-    if (dir == pattern) return false;                                           // "Prevent infinite recursion"
-    std::vector<std::string> dirs;
-    if (!glob(dir, &dirs)) return false;
-    for (const std::string& d : dirs)
-        if (!glob_dir(d, file, out)) return false;
-    return true;
-}
-
-}  // namespace mi_glob
-
-extern "C" int mi_path_match(const char* pattern, const char* name, int* matched) {
-    if (!pattern || !name || !matched) return MI_ERR_INVALID;
-    bool bad = false;
-    *matched = mi_glob::match(pattern, name, &bad) ? 1 : 0;
-    return bad ? MI_ERR_INVALID : MI_OK;                                        // ErrBadPattern
-}
-
-// resolveFromPaths: every source joined to the context root and globbed; no match (or a bad pattern) = the joined
-// path itself.  out = the resolved paths, NUL-terminated, back to back.
-extern "C" int mi_context_sources(const char* context_root, const char* const* from_paths, uint64_t n_paths,
-                                  char* out, uint64_t cap, uint64_t* n_out, uint64_t* bytes_out) {
-    if (!context_root || (n_paths && !from_paths) || !n_out || !bytes_out || (cap && !out)) return MI_ERR_INVALID;
-    std::string all;
-    uint64_t n = 0;
-    for (uint64_t i = 0; i < n_paths; ++i) {
-        const std::string joined0 = std::string(context_root) + "/" + (from_paths[i] ? from_paths[i] : "");
-        const std::string source = joined0[0] == '/' ? mi_walk::clean_rooted(joined0) : mi_walk::clean_any(joined0);
-        std::vector<std::string> m;
-        if (!mi_glob::glob(source, &m) || m.empty()) m.assign(1, source);
-        for (const std::string& x : m) { all += x; all.push_back('\0'); ++n; }
-    }
-    *n_out = n;
-    *bytes_out = all.size();
-    if (cap < all.size()) return MI_ERR_CAPACITY;
-    if (!all.empty()) memcpy(out, all.data(), all.size());
-    return MI_OK;
-}
-
-extern "C" int mi_copy_op_resolve(uint64_t n_srcs, const char* work_dir, const char* dst, char* dst_out,
-                                  uint64_t cap, char* err, uint64_t err_cap) {
-    if (!dst || !dst_out) return MI_ERR_INVALID;
-    const std::string d = dst;
-    const std::string bad = copy_check_params(n_srcs, work_dir, d);
-    if (!bad.empty()) {
-        if (err && err_cap) snprintf(err, (size_t)err_cap, "check copy param: %s", bad.c_str());
-        return MI_ERR_INVALID;
-    }
-    std::string r = d;
-    if (d[0] != '/') {                                      // filepath.Join cleans; the trailing "/" is put back
-        r = mi_walk::abs_path(std::string(work_dir) + "/" + d);
-        if (copy_dst_is_dir_format(d) && r.back() != '/') r += "/";
-    }
-    if (cap < r.size() + 1) return MI_ERR_CAPACITY;
-    memcpy(dst_out, r.c_str(), r.size() + 1);
-    return MI_OK;
-}
-
-// addToLayer (mem_fs.go:343-421) for each op, against fs.t, into fs.layer; fs.rc / fs.err carry what maybeAddToLayer
-// refuses, *err_out everything else
-static int copy_ops_into(mi_copy::Fs& fs, const mi_copy_op* ops, uint64_t n_ops, std::string* err_out) {
-    auto put_err = [&](const std::string& m) { *err_out = m; };
-    for (uint64_t k = 0; k < n_ops && !fs.rc; ++k) {
-        const mi_copy_op& c = ops[k];
-        if (!c.src_root || !c.dst || (c.n_srcs && !c.srcs)) return MI_ERR_INVALID;
-        {   // what NewCopyOperation refuses (copy_op.go:48-50): the dst here is the resolved one, so it is absolute
-            const std::string bad = copy_check_params(c.n_srcs, nullptr, c.dst);
-            if (!bad.empty()) { put_err("check copy param: " + bad); return MI_ERR_INVALID; }
-        }
-        const std::string src_root = mi_walk::abs_path(c.src_root);
-        std::string dst = c.dst;
-        bool create_dst = true;
-        if (c.n_srcs == 1) {
-            struct stat st;
-            const std::string s0 = src_root + mi_walk::abs_path(c.srcs[0] ? c.srcs[0] : "");
-            if (stat(s0.c_str(), &st) != 0) { put_err("stat src " + s0 + ": " + strerror(errno)); return MI_ERR_IO; }
-            if (!S_ISDIR(st.st_mode)) create_dst = false;            // case 1: file onto file
-        }
-        if (create_dst) {
-            std::string resolved = fs.add_ancestors(mi_walk::abs_path(dst), true, c.uid, c.gid);
-            if (fs.rc) break;
-            if (resolved.empty() || resolved.back() != '/') resolved += "/";
-            dst = resolved;
-        }
-        const bool dst_is_dir = !dst.empty() && dst.back() == '/';
-        for (uint64_t si = 0; si < c.n_srcs && !fs.rc; ++si) {
-            std::string rel, e2;
-            if (!mi_copy::eval_symlinks(mi_walk::abs_path(c.srcs[si] ? c.srcs[si] : ""), src_root, &rel, &e2)) {
-                put_err("eval symlinks for " + std::string(c.srcs[si] ? c.srcs[si] : "") + ": " + e2);
-                return MI_ERR_IO;
-            }
-            const std::string src = src_root == "/" ? rel : src_root + (rel == "/" ? "" : rel);
-            mi_walk::Tree walked;
-            mi_walk::Walker w;
-            w.batch = nullptr;
-            w.rel_base = src;
-            w.mode = MI_TREE_SCAN;                                      // shouldSkip with a nil blacklist
-            w.tree = &walked;
-            w.link_root = fs.root;                                      // createHeader trims by the MEMFS root
-            w.visit(src);
-            if (w.rc) { put_err("copy src " + src + ": " + w.err); return w.rc; }
-            for (const mi_walk::Entry& we : walked.entries) {
-                const bool is_src = we.relpath == ".";
-                std::string curr_dst;
-                if (is_src) {
-                    if (we.kind == 0) continue;                         // the directory itself: contents only
-                    curr_dst = !dst_is_dir ? dst : mi_walk::clean_rooted(dst + "/" + mi_walk::base_of(src));
-                } else {
-                    curr_dst = mi_walk::clean_rooted(dst + "/" + we.relpath);
-                }
-                curr_dst = mi_walk::abs_path(curr_dst);
-                mi_copy::Node n;
-                n.e = we;
-                n.e.relpath = curr_dst == "/" ? "" : curr_dst.substr(1);
-                n.e.uid = c.uid;
-                n.e.gid = c.gid;
-                const std::string curr_src = is_src ? src : src + "/" + we.relpath;
-                fs.maybe_add(curr_src, curr_dst, n);
-                if (fs.rc) break;
-            }
-        }
-    }
-    if (fs.rc) { put_err(fs.err); return fs.rc; }
-    return MI_OK;
-}
-
-extern "C" int mi_snapshot_copy_ops(const mi_tree_entry* tree, uint64_t n_tree, const char* tree_root,
-                                    const mi_copy_op* ops, uint64_t n_ops, int64_t now_sec,
-                                    mi_copy_layer** out, uint64_t* n_entries, char* err, uint64_t err_cap) {
-    auto put_err = [&](const std::string& m) { if (err && err_cap) snprintf(err, (size_t)err_cap, "%s", m.c_str()); };
-    if ((n_tree && !tree) || (n_ops && !ops) || !out || !tree_root) return MI_ERR_INVALID;
-    mi_copy::Fs fs;
-    fs.root = mi_walk::abs_path(tree_root);
-    fs.now = now_sec;
-    {   // the root node always exists (NewMemFS stats it)
-        mi_copy::Node r;
-        r.e.kind = 0;
-        r.e.mode = S_IFDIR | 0755;
-        struct stat st;
-        if (lstat(fs.root.c_str(), &st) == 0) { r.e.mode = st.st_mode; r.e.mtime = st.st_mtime; r.e.uid = st.st_uid; r.e.gid = st.st_gid; }
-        fs.t.root.ref = fs.keep(r);
-    }
-    for (uint64_t i = 0; i < n_tree; ++i) {
-        const mi_tree_entry& e = tree[i];
-        mi_copy::Node n;
-        const char* rp = e.relpath ? e.relpath : "";
-        const std::string p = mi_walk::abs_path(strcmp(rp, ".") == 0 ? "" : rp);
-        n.e.relpath = p == "/" ? "" : p.substr(1);
-        n.e.kind = e.kind; n.e.mode = e.mode; n.e.mtime = e.mtime_sec; n.e.uid = e.uid; n.e.gid = e.gid; n.e.size = e.size;
-        if (e.link_target) { n.e.link = e.link_target; n.e.has_link = true; }
-        n.src = fs.root == "/" ? p : fs.root + (p == "/" ? "" : p);
-        fs.t.load(p, fs.keep(n), n.e.kind, e.link_target);
-    }
-    std::string e;
-    const int rc = copy_ops_into(fs, ops, n_ops, &e);
-    if (rc) { put_err(e); return rc; }
-    mi_copy_layer* l = new mi_copy_layer();
-    l->nodes = fs.sorted_layer();
-    *out = l;
-    if (n_entries) *n_entries = l->nodes.size();
-    return MI_OK;
-}
-
-// ---- CopyOperation.Execute: the on-disk copy of a COPY/ADD step with --modifyfs (lib/snapshot/copy_op.go:83-147) over
-// fileio.Copier (lib/fileio/copy.go:31-394).  Owners: --chown -> the op's uid/gid for the destination directory if it
-// has to be created and, always, for everything copied; from the context without --chown -> the same with 0:0; --from
-// --archive -> a created destination directory gets the source's owner, everything copied keeps its own; --from alone ->
-// owners as they are (a created destination directory: root).  Permission bits travel with the files; mtimes do not.
-namespace mi_copyexec {
-
-struct Owner { bool set = false; uint32_t uid = 0, gid = 0; bool overwrite = false; };
-struct Copier {
-    std::vector<std::string> blacklist;
-    Owner dst_dir, children;
-    std::string err;
-
-    bool fail(const std::string& m) { err = m; return false; }
-    bool blacklisted(const std::string& p) const { return mi_walk::is_descendant_of_any(p, blacklist); }
-
-    bool mkdir_all(const std::string& dst) {                                     // Copier.mkdirAll (:336-393)
-        if (dst.empty()) return fail("empty dst directory");
-        const std::string abs = mi_walk::abs_path(dst);                          // callers pass absolute paths
-        std::string cur;
-        const std::vector<std::string> ps = mi_memtree::Tree::parts(abs);
-        for (size_t k = 0; k + 1 < ps.size(); ++k) {
-            cur += "/" + ps[k];
-            struct stat st;
-            if (lstat(cur.c_str(), &st) == 0) continue;
-            if (errno != ENOENT) return fail("stat " + cur + ": " + strerror(errno));
-            if (mkdir(cur.c_str(), 0755) != 0) return fail("mkdir " + cur + " with default mode 0755: " + strerror(errno));
-            if (chown(cur.c_str(), 0, 0) != 0) return fail("chown " + cur + " with default owner (0:0): " + strerror(errno));
-        }
-        struct stat st;
-        if (lstat(abs.c_str(), &st) != 0) {
-            if (errno != ENOENT) return fail("stat " + abs + ": " + strerror(errno));
-            if (mkdir(abs.c_str(), 0755) != 0) return fail("mkdir " + abs + " with default mode 0755: " + strerror(errno));
-            const uint32_t u = dst_dir.set ? dst_dir.uid : 0, g = dst_dir.set ? dst_dir.gid : 0;
-            if (chown(abs.c_str(), u, g) != 0) return fail("chown " + abs + ": " + strerror(errno));
-        } else if (dst_dir.set && dst_dir.overwrite) {
-            if (chown(abs.c_str(), dst_dir.uid, dst_dir.gid) != 0) return fail("chown " + abs + ": " + strerror(errno));
-        }
-        return true;
-    }
-    bool copy_symlink(const std::string& src, const std::string& dst) {          // :232-247
-        struct stat st;
-        if (lstat(dst.c_str(), &st) == 0 && remove(dst.c_str()) != 0)
-            return fail("remove existing file " + dst + ": " + strerror(errno));
-        std::vector<char> buf(4096);
-        const ssize_t n = readlink(src.c_str(), buf.data(), buf.size() - 1);
-        if (n < 0) return fail("read link " + src + ": " + strerror(errno));
-        const std::string target(buf.data(), (size_t)n);
-        if (symlink(target.c_str(), dst.c_str()) != 0)
-            return fail("write link " + dst + " with content " + target + ": " + strerror(errno));
-        return true;
-    }
-    bool copy_file(const std::string& src, const std::string& dst) {             // copyFile + copyRegularFile (:160-230)
-        struct stat fi;
-        if (lstat(src.c_str(), &fi) != 0) return fail("lstat " + src + ": " + strerror(errno));
-        // (a blacklisted SOURCE FILE is only logged here -- the reference's else-if chain goes on to copy it; blacklisted
-        // entries below a copied directory never get this far)
-        if (!blacklisted(src) && !S_ISREG(fi.st_mode) && !S_ISDIR(fi.st_mode) && !S_ISLNK(fi.st_mode)) return true;   // special file
-        if (S_ISLNK(fi.st_mode)) return copy_symlink(src, dst);                  // never chown'ed: that would hit the target
-        struct stat dt;
-        if (lstat(dst.c_str(), &dt) == 0) {
-            if (chmod(dst.c_str(), 0777) != 0) return fail("chmod " + dst + ": " + strerror(errno));
-        } else if (errno != ENOENT) {
-            return fail("lstat " + dst + ": " + strerror(errno));
-        }
-        const int r = open(src.c_str(), O_RDONLY | O_CLOEXEC);
-        if (r < 0) return fail("open " + dst + ": " + strerror(errno));
-        const int w = open(dst.c_str(), O_WRONLY | O_CREAT | O_CLOEXEC, 0777);
-        if (w < 0) { const int e = errno; close(r); return fail("create " + dst + ": " + strerror(e)); }
-        bool ok = ftruncate(w, 0) == 0;
-        std::string e = ok ? "" : std::string("truncate ") + dst + ": " + strerror(errno);
-        std::vector<char> buf(1 << 20);
-        while (ok) {
-            const ssize_t n = read(r, buf.data(), buf.size());
-            if (n < 0 && errno == EINTR) continue;
-            if (n < 0) { ok = false; e = "copy " + src + " to " + dst + ": " + strerror(errno); break; }
-            if (n == 0) break;
-            for (ssize_t done = 0; done < n;) {
-                const ssize_t k = write(w, buf.data() + done, (size_t)(n - done));
-                if (k < 0 && errno == EINTR) continue;
-                if (k < 0) { ok = false; e = "copy " + src + " to " + dst + ": " + strerror(errno); break; }
-                done += k;
-            }
-        }
-        close(r);
-        close(w);
-        if (!ok) return fail(e);
-        const uint32_t u = children.set && children.overwrite ? children.uid : fi.st_uid;
-        const uint32_t g = children.set && children.overwrite ? children.gid : fi.st_gid;
-        if (chown(dst.c_str(), u, g) != 0) return fail("chown " + dst + ": " + strerror(errno));
-        if (chmod(dst.c_str(), fi.st_mode & 07777) != 0) return fail("chmod " + dst + ": " + strerror(errno));   // after chown
-        return true;
-    }
-    bool copy_dir(const std::string& src, const std::string& dst) {              // copyDir (:289-330): one directory, no contents
-        struct stat si;
-        if (lstat(src.c_str(), &si) != 0) return fail("lstat " + src + ": " + strerror(errno));
-        if (!S_ISDIR(si.st_mode)) return fail("source " + src + " is not a directory");
-        if (blacklisted(src)) return true;
-        struct stat di;
-        if (lstat(dst.c_str(), &di) != 0) {
-            if (errno != ENOENT) return fail("lstat " + dst + ": " + strerror(errno));
-            if (mkdir(dst.c_str(), si.st_mode & 07777) != 0) return fail("mkdir " + dst + ": " + strerror(errno));
-        } else if (!S_ISDIR(di.st_mode)) {
-            return fail("dst is not a directory");
-        }
-        if (chmod(dst.c_str(), si.st_mode & 07777) != 0) return fail("chmod " + dst + ": " + strerror(errno));
-        const uint32_t u = children.set && children.overwrite ? children.uid : si.st_uid;
-        const uint32_t g = children.set && children.overwrite ? children.gid : si.st_gid;
-        if (chown(dst.c_str(), u, g) != 0) return fail("chown " + dst + ": " + strerror(errno));
-        return true;
-    }
-    bool copy_dir_contents(const std::string& src, const std::string& dst, const std::string& orig_dst) {   // :252-285
-        DIR* d = opendir(src.c_str());
-        if (!d) return fail("read dir " + src + ": " + strerror(errno));
-        std::vector<std::string> names;
-        while (struct dirent* de = readdir(d)) {
-            const std::string n = de->d_name;
-            if (n != "." && n != "..") names.push_back(n);
-        }
-        closedir(d);
-        std::sort(names.begin(), names.end());                                   // ioutil.ReadDir sorts by name
-        for (const std::string& n : names) {
-            const std::string cs = (src == "/" ? "" : src) + "/" + n, cd = (dst == "/" ? "" : dst) + "/" + n;
-            if (blacklisted(cs) || cs == orig_dst) continue;                     // "Silently break infinite loop"
-            struct stat st;
-            if (lstat(cs.c_str(), &st) != 0) return fail("lstat " + cs + ": " + strerror(errno));
-            if (S_ISDIR(st.st_mode)) {
-                if (!copy_dir(cs, cd)) return fail("copy dir " + cs + " to " + cd + ": " + err);
-                if (!copy_dir_contents(cs, cd, orig_dst)) return fail("copy dir contents " + cs + " to " + cd + ": " + err);
-            } else if (!copy_file(cs, cd)) {
-                return fail("copy file " + cs + " to " + cd + ": " + err);
-            }
-        }
-        return true;
-    }
-    bool CopyFile(const std::string& src, const std::string& dst) {              // :122-130
-        const std::string dir = mi_walk::dir_of(dst);
-        if (!mkdir_all(dir)) return fail("mkdir all " + dir + ": " + err);
-        return copy_file(src, dst);
-    }
-    bool CopyDir(const std::string& src, const std::string& dst) {               // :142-156
-        if (blacklisted(src)) return true;
-        if (!mkdir_all(dst)) return fail("mkdir all " + dst + ": " + err);
-        return copy_dir_contents(src, dst, mi_walk::abs_path(dst));
-    }
-};
-
-}  // namespace mi_copyexec
-
-extern "C" int mi_copy_op_execute(const mi_copy_op* op, uint32_t flags, const char* const* blacklist, uint64_t n_blacklist,
-                                  char* err, uint64_t err_cap) {
-    auto put_err = [&](const std::string& m) { if (err && err_cap) snprintf(err, (size_t)err_cap, "%s", m.c_str()); };
-    if (!op || !op->src_root || !op->dst || (op->n_srcs && !op->srcs) || (n_blacklist && !blacklist)) return MI_ERR_INVALID;
-    const bool chown_given = flags & MI_COPY_CHOWN, internal = flags & MI_COPY_INTERNAL, archive = flags & MI_COPY_PRESERVE_OWNER;
-    if (chown_given && archive) { put_err("both chown and archive are true"); return MI_ERR_INVALID; }
-    const std::string src_root = mi_walk::abs_path(op->src_root);
-    const std::string dst = op->dst;
-    for (uint64_t si = 0; si < op->n_srcs; ++si) {
-        std::string rel, e2;
-        const std::string given = op->srcs[si] ? op->srcs[si] : "";
-        if (!mi_copy::eval_symlinks(mi_walk::abs_path(given), src_root, &rel, &e2)) {
-            put_err("eval symlinks for " + given + ": " + e2);
-            return MI_ERR_IO;
-        }
-        const std::string src = src_root == "/" ? rel : src_root + (rel == "/" ? "" : rel);
-        struct stat fi;
-        if (lstat(src.c_str(), &fi) != 0) { put_err("lstat " + src + ": " + strerror(errno)); return MI_ERR_IO; }
-        mi_copyexec::Copier c;
-        if (!internal)                                                           // "there is no need to blacklist any path" for a
-            for (uint64_t k = 0; k < n_blacklist; ++k) c.blacklist.push_back(blacklist[k] ? blacklist[k] : "");   // checkpointed stage
-        if (chown_given) {
-            c.dst_dir = {true, op->uid, op->gid, false};
-            c.children = {true, op->uid, op->gid, true};
-        } else if (!internal) {
-            c.dst_dir = {true, 0, 0, false};
-            c.children = {true, 0, 0, true};
-        } else if (archive) {
-            c.dst_dir = {true, fi.st_uid, fi.st_gid, false};
-        }
-        bool ok;
-        std::string what;
-        if (S_ISDIR(fi.st_mode)) {
-            ok = c.CopyDir(src, dst);
-            what = "copy dir " + src + " to dir " + dst;
-        } else if (copy_dst_is_dir_format(dst)) {
-            const std::string target = mi_walk::abs_path(dst + "/" + mi_walk::base_of(src));
-            ok = c.CopyFile(src, target);
-            what = "copy file " + src + " to dir " + target;
-        } else {
-            ok = c.CopyFile(src, dst);
-            what = "copy file " + src + " to file " + dst;
-        }
-        if (!ok) { put_err(what + ": " + c.err); return MI_ERR_IO; }
-    }
-    return MI_OK;
-}
-
-// ---- untar: MemFS.untarOneItem and tario.ApplyHeader (lib/snapshot/mem_fs.go:571-718, lib/tario/apply.go:23-47) --------
-namespace mi_untar {
-
-static int rm_cb(const char* p, const struct stat*, int, struct FTW*) { return remove(p); }
-static bool remove_all(const std::string& p, std::string* err) {                 // os.RemoveAll
-    struct stat st;
-    if (lstat(p.c_str(), &st) != 0) {
-        if (errno == ENOENT || errno == ENOTDIR) return true;
-        *err = "lstat " + p + ": " + strerror(errno);
-        return false;
-    }
-    if (!S_ISDIR(st.st_mode)) {
-        if (unlink(p.c_str()) == 0 || errno == ENOENT) return true;
-        *err = "unlinkat " + p + ": " + strerror(errno);
-        return false;
-    }
-    if (nftw(p.c_str(), rm_cb, 64, FTW_DEPTH | FTW_PHYS) != 0) { *err = "unlinkat " + p + ": " + strerror(errno); return false; }
-    return true;
-}
-
-// tario.ApplyHeader: owner, then permission bits (chmod after chown: setuid / setgid survive), then mtime; never on a
-// symlink and never FOR a symlink header
-static bool apply_header(const std::string& path, const mi_tree_entry& h, std::string* err) {
-    struct stat st;
-    if (lstat(path.c_str(), &st) != 0) { *err = "lstat " + path + ": " + strerror(errno); return false; }
-    if (S_ISLNK(st.st_mode) || h.kind == 2) { *err = "update symlink instead of file: " + path; return false; }
-    if (chown(path.c_str(), h.uid, h.gid) != 0) { *err = "chown " + path + ": " + strerror(errno); return false; }
-    if (chmod(path.c_str(), h.mode & 07777) != 0) { *err = "chmod " + path + ": " + strerror(errno); return false; }
-    struct timespec ts[2];
-    ts[0].tv_sec = ts[1].tv_sec = (time_t)h.mtime_sec;
-    ts[0].tv_nsec = ts[1].tv_nsec = 0;
-    if (utimensat(AT_FDCWD, path.c_str(), ts, 0) != 0) { *err = "chtimes " + path + ": " + strerror(errno); return false; }
-    return true;
-}
-
-static bool copy_range(int in_fd, uint64_t off, uint64_t len, int out_fd, std::string* err) {
-    std::vector<char> buf(1 << 20);
-    while (len) {
-        const size_t want = len < buf.size() ? (size_t)len : buf.size();
-        const ssize_t r = pread(in_fd, buf.data(), want, (off_t)off);
-        if (r < 0 && errno == EINTR) continue;
-        if (r <= 0) { *err = r == 0 ? "unexpected EOF" : strerror(errno); return false; }
-        size_t done = 0;
-        while (done < (size_t)r) {
-            const ssize_t w = write(out_fd, buf.data() + done, (size_t)r - done);
-            if (w < 0 && errno == EINTR) continue;
-            if (w < 0) { *err = strerror(errno); return false; }
-            done += (size_t)w;
-        }
-        off += (uint64_t)r;
-        len -= (uint64_t)r;
-    }
-    return true;
-}
-
-// untarOneItem(path, header, r): root = fs.tree.src; path = filepath.Join(root, hdr.Name); content of a regular file =
-// [data_off, +size) of tar_fd
-static bool one_item(const std::string& root, const std::string& path, const mi_tree_entry& h, int tar_fd, uint64_t data_off,
-                     std::string* err) {
-    const std::string base = mi_walk::base_of(path), dir = mi_walk::dir_of(path);
-    std::string e;
-    if (mi_walk::has_prefix(base, ".wh.")) {                                     // untarWhiteout
-        if (!remove_all((dir == "/" ? "" : dir) + "/" + base.substr(4), &e)) { *err = "untar dir: untar whiteout: " + e; return false; }
-        return true;
-    }
-    struct stat st;
-    if (lstat(path.c_str(), &st) != 0) {
-        if (errno != ENOENT && errno != ENOTDIR) { *err = "lstat " + path + ": " + strerror(errno); return false; }
-    } else {
-        // the header of what is there (tar.FileInfoHeader), link target trimmed of the root
-        mi_tree_entry local;
-        memset(&local, 0, sizeof local);
-        std::string link;
-        local.relpath = h.relpath && *h.relpath ? h.relpath : "x";              // (only "both names empty" matters to the predicate)
-        local.mode = st.st_mode; local.mtime_sec = st.st_mtime; local.uid = st.st_uid; local.gid = st.st_gid;
-        local.kind = S_ISDIR(st.st_mode) ? 0 : S_ISREG(st.st_mode) ? 1 : S_ISLNK(st.st_mode) ? 2 : 4;
-        local.size = S_ISREG(st.st_mode) ? (uint64_t)st.st_size : 0;
-        if (S_ISLNK(st.st_mode)) {
-            std::vector<char> buf(4096);
-            const ssize_t n = readlink(path.c_str(), buf.data(), buf.size() - 1);
-            if (n < 0) { *err = "read link " + path + ": " + strerror(errno); return false; }
-            link.assign(buf.data(), (size_t)n);
-            if (!link.empty() && link[0] == '/') {
-                if (!mi_walk::has_prefix(link, root)) { *err = "trim link " + link + ": failed to trim root prefix " + root + " from path " + link; return false; }
-                link = mi_walk::abs_path(link.substr(root.size()));
-            }
-            local.link_target = link.c_str();
-        }
-        if (local.kind > 3) { *err = "compare headers " + path + ": unsupported type"; return false; }
-        int similar = 0;
-        mi_tree_entry hh = h;
-        if (!hh.relpath || !*hh.relpath) hh.relpath = "x";
-        if (mi_entry_similar(&local, &hh, 0, nullptr, nullptr, &similar) != MI_OK) { *err = "compare headers " + path + ": unsupported type"; return false; }
-        if (similar) return true;                                                // "already on disk, nothing needs to be done"
-        if (h.kind == 0 && S_ISDIR(st.st_mode)) {                                // existing directories are updated, not deleted
-            if (!apply_header(path, h, &e)) { *err = "update fi " + path + ": " + e; return false; }
-            return true;
-        }
-        if (!remove_all(path, &e)) { *err = "clear existing file " + path + ": " + e; return false; }
-    }
-    if (h.kind == 0) {
-        if (mkdir(path.c_str(), h.mode & 07777) != 0) { *err = "untar dir: create dir " + path + ": " + strerror(errno); return false; }
-        if (!apply_header(path, h, &e)) { *err = "untar dir: update fi " + path + ": " + e; return false; }
-    } else if (h.kind == 2) {
-        std::string target = h.link_target ? h.link_target : "";
-        if (!target.empty() && target[0] == '/') target = mi_walk::abs_path(root + "/" + target);   // filepath.Join(root, target)
-        if (symlink(target.c_str(), path.c_str()) != 0) { *err = "untar symlink: create symlink " + path + " => " + target + ": " + strerror(errno); return false; }
-        if (lchown(path.c_str(), h.uid, h.gid) != 0) { *err = "untar symlink: lchown symlink: " + path; return false; }
-    } else if (h.kind == 3) {
-        const std::string target = mi_walk::abs_path(root + "/" + (h.link_target ? h.link_target : ""));
-        if (link(target.c_str(), path.c_str()) != 0) { *err = "untar hard link: create link " + path + " => " + target + ": " + strerror(errno); return false; }
-        if (!apply_header(path, h, &e)) { *err = "untar hard link: update hard link " + path + ": " + e; return false; }
-    } else {
-        const int fd = open(path.c_str(), O_CREAT | O_TRUNC | O_WRONLY | O_CLOEXEC, h.mode & 07777);
-        if (fd < 0) { *err = "untar file: open file " + path + ": " + strerror(errno); return false; }
-        const bool ok = h.size == 0 || (tar_fd >= 0 && copy_range(tar_fd, data_off, h.size, fd, &e));
-        close(fd);
-        if (!ok) { *err = "untar file: read from file " + path + ": " + (tar_fd < 0 ? "no archive to read from" : e); return false; }
-        if (!apply_header(path, h, &e)) { *err = "untar file: update fi " + path + ": " + e; return false; }
-    }
-    return true;
-}
-
-}  // namespace mi_untar
-
-// ---- MemFS as a handle: the reference's type (lib/snapshot/mem_fs.go:59-125) behind the ABI ---------------------------
-// One tree for the life of a build, as in the reference: base layers are merged into it (UpdateFromTarReader), every
-// step's layer is computed against it and folds into it (AddLayerByScan / AddLayerByCopyOps).  What the stateless calls
-// above cannot keep between calls is kept here: the directories addAncestors created, and for every node the path its
-// content came from (memFSNode.src -- what isOnDisk looks at: a copied file is "on disk" while its SOURCE is).
-struct mi_memfs {
-    mi_copy::Fs fs;
-    std::vector<std::string> blacklist;
-    std::string err;
-};
-
-static mi_copy_layer* memfs_take_layer(mi_memfs* m) {
-    mi_copy_layer* l = new mi_copy_layer();
-    l->nodes = m->fs.sorted_layer();
-    m->fs.layer.clear();
-    return l;
-}
-static int memfs_fail(mi_memfs* m) {
-    m->err = m->fs.err;
-    const int rc = m->fs.rc;
-    m->fs.rc = MI_OK;                                                             // the handle stays usable, like the
-    m->fs.err.clear();                                                            // reference's MemFS after an error
-    m->fs.layer.clear();
-    return rc;
-}
-
-extern "C" int mi_memfs_create(const char* root, const char* const* blacklist, uint64_t n_blacklist, int64_t now_sec,
-                               mi_memfs** out) {
-    if (!root || !out || (n_blacklist && !blacklist)) return MI_ERR_INVALID;
-    struct stat st;
-    if (lstat(root, &st) != 0) return MI_ERR_IO;                                  // "unable to stat root dir"
-    mi_memfs* m = new mi_memfs();
-    m->fs.root = mi_walk::abs_path(root);
-    m->fs.now = now_sec;
-    mi_copy::Node r;
-    r.e.kind = 0;
-    r.e.mode = st.st_mode; r.e.mtime = st.st_mtime; r.e.uid = st.st_uid; r.e.gid = st.st_gid;
-    r.src = m->fs.root;
-    m->fs.t.root.ref = m->fs.keep(r);
-    for (uint64_t i = 0; i < n_blacklist; ++i) m->blacklist.push_back(blacklist[i] ? blacklist[i] : "");
-    *out = m;
-    return MI_OK;
-}
-extern "C" void mi_memfs_free(mi_memfs* m) { delete m; }
-extern "C" const char* mi_memfs_error(const mi_memfs* m) { return m ? m->err.c_str() : ""; }
-extern "C" int mi_memfs_set_clock(mi_memfs* m, int64_t now_sec) {
-    if (!m) return MI_ERR_INVALID;
-    m->fs.now = now_sec;
-    return MI_OK;
-}
-extern "C" int mi_memfs_reset(mi_memfs* m) {                                      // MemFS.Reset (:127-130)
-    if (!m) return MI_ERR_INVALID;
-    m->fs.t.root.children.clear();
-    return MI_OK;
-}
-
-// MemFS.UpdateFromTarReader (:165-255) on a layer's entries (mi_tar_entries); tar_fd >= 0: untar = true, a regular file's
-// bytes are [data_offsets[j], +size) of that descriptor
-static int memfs_update(mi_memfs* m, const mi_tree_entry* layer, uint64_t n_layer, int tar_fd, const uint64_t* data_offsets,
-                        bool untar, uint64_t* n_merged) {
-    mi_copy::Fs& fs = m->fs;
-    fs.layer.clear();
-    std::map<std::string, struct timespec> modtimes;                              // parent directories, to be put back
-    std::string uerr;
-    const mi_walk::MountTable& mt = mi_walk::mountpoints();
-    if (!mt.error.empty()) { m->err = "check if mounted: " + mt.error; return MI_ERR_IO; }
-    std::vector<std::string> bl;
-    for (const std::string& b : m->blacklist) bl.push_back(mi_walk::abs_path(b));
-    auto path_of = [](const mi_tree_entry& e) {
-        const char* rp = e.relpath ? e.relpath : "";
-        return mi_walk::abs_path(strcmp(rp, ".") == 0 ? "" : rp);
-    };
-    std::vector<std::string> below_mount;                                         // "<target>/": isMounted's prefixes
-    for (const std::string& t : mt.targets) below_mount.push_back(t.back() == '/' ? t : t + "/");
-    auto skipped = [&](const mi_tree_entry& e, const std::string& p) {            // shouldSkip + IsMounted (:190-199)
-        const std::string on_disk = fs.root == "/" ? p : fs.root + (p == "/" ? "" : p);
-        if (mi_walk::has_prefix(mi_walk::base_of(p), ".wh..wh.")) return true;
-        if (e.kind > 3 || (!bl.empty() && mi_walk::is_descendant_of_any(on_disk, bl))) return true;
-        if (mt.targets.count(on_disk)) return true;
-        for (const std::string& t : below_mount)
-            if (mi_walk::has_prefix(on_disk, t)) return true;
-        return false;
-    };
-    auto disk_path = [&](const std::string& p) { return fs.root == "/" ? p : fs.root + (p == "/" ? "" : p); };
-    auto one = [&](const mi_tree_entry& e, const std::string& p, uint64_t j) {
-        if (untar && !mi_untar::one_item(fs.root, disk_path(p), e, tar_fd, data_offsets ? data_offsets[j] : 0, &uerr)) {
-            fs.fail(MI_ERR_IO, "untar one item " + disk_path(p) + ": " + uerr);
-            return;
-        }
-        mi_copy::Node n;
-        n.e.relpath = p == "/" ? "" : p.substr(1);
-        n.e.kind = e.kind; n.e.mode = e.mode; n.e.mtime = e.mtime_sec; n.e.uid = e.uid; n.e.gid = e.gid; n.e.size = e.size;
-        if (e.link_target) {
-            n.e.has_link = true;                                                  // "Docker hard link names are all absolute,
-            n.e.link = e.kind == 3 ? mi_walk::abs_path(e.link_target) : e.link_target;   //  but don't have a leading slash"
-        }
-        // src: the reference passes AbsPath(hdr.Name) (:225) -- the path the entry is untarred to when the root is "/",
-        // as in every real build; under another root that is filepath.Join(root, name), and isOnDisk must look THERE
-        fs.maybe_add(fs.root == "/" ? p : fs.root + (p == "/" ? "" : p), p, std::move(n), false);
-    };
-    std::map<std::string, uint64_t> hardlinks;
-    fs.nodes.reserve(fs.nodes.size() + n_layer);
-    for (uint64_t j = 0; j < n_layer && !fs.rc; ++j) {
-        const std::string p = path_of(layer[j]);
-        if (skipped(layer[j], p)) continue;
-        if (untar) {                                                              // "Record the modtime of the parent directory to
-            const std::string parent = mi_walk::dir_of(disk_path(p));             //  reset it after we deal with all of the other files"
-            if (!modtimes.count(parent)) {
-                struct stat st;
-                if (lstat(parent.c_str(), &st) != 0) {
-                    fs.fail(MI_ERR_IO, "stat parent dir of " + disk_path(p) + ": " + strerror(errno));
-                    break;
-                }
-                modtimes[parent] = st.st_mtim;
-            }
-        }
-        if (layer[j].kind == 3) { hardlinks[p] = j; continue; }
-        one(layer[j], p, j);
-    }
-    for (auto& kv : hardlinks) {
-        if (fs.rc) break;
-        one(layer[kv.second], kv.first, kv.second);
-    }
-    const bool untar_failed = fs.rc == MI_ERR_IO;
-    if (fs.rc) { if (!untar_failed) fs.err = "add hdr from tar to layer: " + fs.err; return memfs_fail(m); }
-    for (auto& kv : modtimes) {                                                   // "Reset the mod times on all of the directory we changed"
-        struct timespec ts[2] = {kv.second, kv.second};
-        if (utimensat(AT_FDCWD, kv.first.c_str(), ts, 0) != 0) {
-            m->err = "chtimes on parent directory " + kv.first + ": " + strerror(errno);
-            fs.layer.clear();
-            return MI_ERR_IO;
-        }
-    }
-    if (n_merged) *n_merged = fs.layer.size();                                    // "Merged %d headers from tar to memfs"
-    fs.layer.clear();
-    return MI_OK;
-}
-
-extern "C" int mi_memfs_update_from_entries(mi_memfs* m, const mi_tree_entry* layer, uint64_t n_layer,
-                                            uint64_t* n_merged) {
-    if (!m || (n_layer && !layer)) return MI_ERR_INVALID;
-    return memfs_update(m, layer, n_layer, -1, nullptr, false, n_merged);
-}
-
-// UpdateFromTarReader with untar = true: the entries of a PLAIN tar (mi_tar_entries of tar_path with their data offsets;
-// a gzip blob goes through mi_tar_inflate first) are written below the root as untarOneItem does -- whiteouts delete,
-// what is already there and similar stays, a directory on a directory is updated in place, anything else is replaced;
-// hard links last; the parents' mtimes are put back -- and merged into the tree
-extern "C" int mi_memfs_untar(mi_memfs* m, const char* tar_path, const mi_tree_entry* layer, const uint64_t* data_offsets,
-                              uint64_t n_layer, uint64_t* n_merged) {
-    if (!m || !tar_path || (n_layer && (!layer || !data_offsets))) return MI_ERR_INVALID;
-    const int fd = open(tar_path, O_RDONLY | O_CLOEXEC);
-    if (fd < 0) { m->err = std::string("open tar file ") + tar_path + ": " + strerror(errno); return MI_ERR_IO; }
-    const int rc = memfs_update(m, layer, n_layer, fd, data_offsets, true, n_merged);
-    close(fd);
-    return rc;
-}
-
-// MemFS.createLayerByScan (:315-341) on a walk of the root (mi_tree_walk / mi_batch_add_tree with MI_TREE_SCAN,
-// rel_base = root): every walked path through maybeAddToLayer with createWhiteout = true
-extern "C" int mi_memfs_add_layer_by_scan(mi_memfs* m, const mi_tree_entry* walked, uint64_t n, const void* roots,
-                                          uint64_t root_stride, mi_copy_layer** out, uint64_t* n_entries) {
-    if (!m || (n && !walked) || !out) return MI_ERR_INVALID;
-    mi_copy::Fs& fs = m->fs;
-    fs.layer.clear();
-    std::unordered_set<std::string_view> on_walk;                               // views into `paths`
-    std::vector<std::string> paths(n);
-    on_walk.reserve(n * 2);
-    for (uint64_t i = 0; i < n; ++i) {
-        const char* rp = walked[i].relpath ? walked[i].relpath : "";
-        paths[i] = mi_walk::abs_path_of_rel(rp);
-        on_walk.insert(std::string_view(paths[i]));
-    }
-    fs.walked = &on_walk;
-    struct Unset { mi_copy::Fs& f; ~Unset() { f.walked = nullptr; } } unset{fs};
-    for (uint64_t i = 0; i < n && !fs.rc; ++i) {
-        const mi_tree_entry& e = walked[i];
-        const std::string& p = paths[i];
-        mi_copy::Node nd;
-        nd.e.relpath = p == "/" ? "" : p.substr(1);
-        nd.e.kind = e.kind; nd.e.mode = e.mode; nd.e.mtime = e.mtime_sec; nd.e.uid = e.uid; nd.e.gid = e.gid; nd.e.size = e.size;
-        if (e.link_target) { nd.e.has_link = true; nd.e.link = e.link_target; }
-        if (roots && e.kind == 1 && e.file_index >= 0) {
-            nd.has_root = true;
-            memcpy(nd.root, (const uint8_t*)roots + (uint64_t)e.file_index * root_stride, 32);
-        }
-        const std::string src = fs.root == "/" ? p : fs.root + (p == "/" ? "" : p);
-        fs.maybe_add(src, p, std::move(nd), true);
-    }
-    if (fs.rc) { fs.err = "add to layer: " + fs.err; return memfs_fail(m); }
-    mi_copy_layer* l = memfs_take_layer(m);
-    if (n_entries) *n_entries = l->nodes.size();
-    *out = l;
-    return MI_OK;
-}
-
-// MemFS.AddLayerByCopyOps (:276-289): the ops against THIS tree, which they update
-extern "C" int mi_memfs_add_layer_by_copy_ops(mi_memfs* m, const mi_copy_op* ops, uint64_t n_ops, mi_copy_layer** out,
-                                              uint64_t* n_entries) {
-    if (!m || (n_ops && !ops) || !out) return MI_ERR_INVALID;
-    m->fs.layer.clear();
-    std::string e;
-    const int rc = copy_ops_into(m->fs, ops, n_ops, &e);
-    if (rc) { if (m->fs.rc) return memfs_fail(m); m->err = e; m->fs.layer.clear(); return rc; }
-    mi_copy_layer* l = memfs_take_layer(m);
-    if (n_entries) *n_entries = l->nodes.size();
-    *out = l;
-    return MI_OK;
-}
-
-// step.commitLayer (lib/builder/step/common.go:67-111) on the handle: the step's layer by scan (ctx.MustScan) or by its
-// copy operations, through tarAndGzipDiffs' pipeline (the layer writer: tar framing, TarDigest, gzip leg, its digest and
-// size), folded into the tree; nothing to do = *committed 0.  The walk of a scan happens here, with the handle's
-// blacklist.  (MemFS.sync's one-second wait before either stays with the caller.)
-extern "C" int mi_memfs_commit_layer(mi_memfs* m, int must_scan, const mi_copy_op* ops, uint64_t n_ops,
-                                     const mi_layer_config* cfg, mi_layer_result* res, mi_copy_layer** layer_out,
-                                     int* committed) {
-    if (!m || !cfg || !res || !committed || (n_ops && !ops)) return MI_ERR_INVALID;
-    *committed = 0;
-    if (layer_out) *layer_out = nullptr;
-    if (!must_scan && n_ops == 0) return MI_OK;                                   // "Nothing to do, return."
-    mi_copy_layer* cl = nullptr;
-    uint64_t ne = 0;
-    int rc;
-    if (must_scan) {
-        std::vector<const char*> bl;
-        for (const std::string& b : m->blacklist) bl.push_back(b.c_str());
-        mi_tree* t = nullptr;
-        uint64_t n = 0;
-        rc = mi_tree_walk(m->fs.root.c_str(), m->fs.root.c_str(), bl.empty() ? nullptr : bl.data(), bl.size(), MI_TREE_SCAN, &t, &n);
-        if (rc) { m->err = "failed to generate diff layer: write diffs: create layer by scan: walk " + m->fs.root; return rc; }
-        std::vector<mi_tree_entry> walked(n ? n : 1);
-        rc = mi_tree_entries(t, walked.data(), n);
-        if (!rc) rc = mi_memfs_add_layer_by_scan(m, walked.data(), n, nullptr, 0, &cl, &ne);
-        mi_tree_free(t);
-        if (rc) { m->err = "failed to generate diff layer: write diffs: create layer by scan: " + m->err; return rc; }
-    } else {
-        rc = mi_memfs_add_layer_by_copy_ops(m, ops, n_ops, &cl, &ne);
-        if (rc) { m->err = "failed to generate diff layer: write diffs: create layer by copy ops: " + m->err; return rc; }
-    }
-    std::vector<mi_tree_entry> ents(ne ? ne : 1);
-    std::vector<const char*> srcs(ne ? ne : 1);
-    rc = mi_copy_layer_entries(cl, ents.data(), srcs.data(), ne);
-    mi_layer* lw = nullptr;
-    if (!rc) rc = mi_layer_begin(cfg, &lw);
-    for (uint64_t i = 0; i < ne && !rc; ++i) {
-        rc = mi_layer_add(lw, &ents[i], ents[i].kind == 1 && srcs[i] && srcs[i][0] ? srcs[i] : nullptr);
-        if (rc) m->err = std::string("failed to generate diff layer: write diffs: commit layer: ") + mi_layer_error(lw);
-    }
-    if (!rc) {
-        rc = mi_layer_finish(lw, res);
-        if (rc) m->err = std::string("failed to generate diff layer: ") + mi_layer_error(lw);
-    }
-    if (lw) mi_layer_free(lw);
-    if (rc) { mi_copy_layer_free(cl); return rc; }
-    *committed = 1;
-    if (layer_out) *layer_out = cl; else mi_copy_layer_free(cl);
-    return MI_OK;
-}
-
-// MemFS.Checkpoint (:132-185): the sources a later stage will COPY --from are moved aside, below new_root, with the
-// layout they have below the root; a pattern is expanded like a COPY source, a directory's created target gets the
-// source's owner, everything copied keeps its own
-extern "C" int mi_memfs_checkpoint(mi_memfs* m, const char* new_root, const char* const* sources, uint64_t n_sources) {
-    if (!m || !new_root || (n_sources && !sources)) return MI_ERR_INVALID;
-    const std::string root = m->fs.root;
-    for (uint64_t i = 0; i < n_sources; ++i) {
-        const std::string given = sources[i] ? sources[i] : "";
-        std::vector<std::string> matches;
-        if (!mi_glob::glob(given, &matches) || matches.empty()) matches.assign(1, given);
-        for (std::string src : matches) {
-            if (src.empty() || src[0] != '/') src = mi_walk::abs_path(root + "/" + src);
-            if (!mi_walk::has_prefix(src, root)) {
-                m->err = "trim src " + src + ": failed to trim root prefix " + root + " from path " + src;
-                return MI_ERR_INVALID;
-            }
-            const std::string dst = mi_walk::abs_path(std::string(new_root) + "/" + src.substr(root.size()));
-            struct stat followed, fi;
-            if (stat(src.c_str(), &followed) != 0) { m->err = "stat " + src + ": " + strerror(errno); return MI_ERR_IO; }
-            if (lstat(src.c_str(), &fi) != 0) { m->err = "lstat " + src + ": " + strerror(errno); return MI_ERR_IO; }
-            mi_copyexec::Copier c;
-            c.blacklist = m->blacklist;
-            c.dst_dir = {true, fi.st_uid, fi.st_gid, false};
-            if (S_ISDIR(followed.st_mode)) {
-                if (!c.CopyDir(src, dst)) { m->err = "copy dir " + src + ": " + c.err; return MI_ERR_IO; }
-            } else if (!c.CopyFile(src, dst)) {
-                m->err = "copy file " + src + ": " + c.err;
-                return MI_ERR_IO;
-            }
-        }
-    }
-    return MI_OK;
-}
-
-// the tree, sorted by path (directories made up by addAncestors included: they are nodes like any other)
-extern "C" int mi_memfs_entries(const mi_memfs* m, mi_tree_entry* out, const char** src_paths, uint64_t cap, uint64_t* n_out) {
-    if (!m || !n_out || (cap && !out)) return MI_ERR_INVALID;
-    std::vector<std::pair<std::string, int64_t>> flat;
-    std::function<void(const mi_memtree::Node&, const std::string&)> collect = [&](const mi_memtree::Node& n, const std::string& p) {
-        for (auto& kv : n.children) {
-            const std::string q = p + "/" + kv.first;
-            if (kv.second->ref >= 0) flat.emplace_back(q, kv.second->ref);
-            collect(*kv.second, q);
-        }
-    };
-    collect(m->fs.t.root, "");
-    std::sort(flat.begin(), flat.end());
-    *n_out = flat.size();
-    if (cap < flat.size()) return MI_ERR_CAPACITY;
-    for (size_t i = 0; i < flat.size(); ++i) {
-        const mi_copy::Node& n = m->fs.nodes[flat[i].second];
-        memset(&out[i], 0, sizeof out[i]);
-        out[i].relpath = n.e.relpath.c_str();
-        out[i].link_target = n.e.has_link ? n.e.link.c_str() : nullptr;
-        out[i].file_index = -1;
-        out[i].size = n.e.size; out[i].mtime_sec = n.e.mtime; out[i].mode = n.e.mode; out[i].kind = n.e.kind;
-        out[i].uid = n.e.uid; out[i].gid = n.e.gid;
-        if (src_paths) src_paths[i] = n.src.c_str();
-    }
-    return MI_OK;
-}
-
-extern "C" int mi_copy_layer_entries(const mi_copy_layer* l, mi_tree_entry* out, const char** src_paths, uint64_t cap) {
-    if (!l || (cap && !out)) return MI_ERR_INVALID;
-    if (cap < l->nodes.size()) return MI_ERR_CAPACITY;
-    int64_t n_regular = 0;
-    for (size_t i = 0; i < l->nodes.size(); ++i) {
-        const mi_copy::Node& n = l->nodes[i];
-        memset(&out[i], 0, sizeof out[i]);
-        out[i].relpath = n.e.relpath.c_str();
-        out[i].link_target = n.e.has_link ? n.e.link.c_str() : nullptr;
-        out[i].file_index = n.e.kind == 1 && !mi_walk::has_prefix(mi_walk::base_of(n.e.relpath), ".wh.") ? n_regular++ : -1;   // a whiteout has no content
-        out[i].size = n.e.size;
-        out[i].mtime_sec = n.e.mtime;
-        out[i].mode = n.e.mode;
-        out[i].kind = n.e.kind;
-        out[i].uid = n.e.uid;
-        out[i].gid = n.e.gid;
-        if (src_paths) src_paths[i] = n.src.c_str();
-    }
-    return MI_OK;
-}
-
-extern "C" void mi_copy_layer_free(mi_copy_layer* l) { delete l; }

@@ -1,4 +1,4 @@
-"""Differential test of the copy-op layer (mi_memfs_add_layer_by_copy_ops / mi_snapshot_copy_ops, csrc/mi_tree.hip) against
+"""Differential test of the copy-op layer (mi_memfs_add_layer_by_copy_ops / mi_snapshot_copy_ops, csrc/mi_memfs.hip) against
 the line-by-line model of MemFS.addToLayer in tests/model_memfs.py: generated base trees (with files, symlinks and
 directories in the way), a generated source tree really on disk, one or two COPY operations whose destinations are
 existing paths, new paths, paths below files and below symlinks, with and without the trailing slash -- the layer's keys,
