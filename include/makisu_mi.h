@@ -622,7 +622,9 @@ void mi_copy_layer_free(mi_copy_layer* layer);
  *                             (mtime of created directories; mi_memfs_set_clock moves it).
  *   mi_memfs_update_from_entries  UpdateFromTarReader with untar = false on a layer's entries (mi_tar_entries): the
  *                             per-header filter (shouldSkip with the blacklist, IsMounted), hard links in a second
- *                             pass, *n_merged = "Merged %d headers from tar to memfs".
+ *                             pass, *n_merged = "Merged %d headers from tar to memfs".  A merged node's source is
+ *                             filepath.Join(root, name) -- the reference passes AbsPath(name), the same path under
+ *                             the root "/" of every real build; under another root isOnDisk must look below it.
  *   mi_memfs_add_layer_by_scan    createLayerByScan on a walk of the root (mi_tree_walk / mi_batch_add_tree with
  *                             MI_TREE_SCAN, rel_base = root, the same blacklist): every walked path through
  *                             maybeAddToLayer with createWhiteout -- changed paths with their ancestors, one whiteout

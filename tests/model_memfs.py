@@ -151,8 +151,9 @@ class ModelFS:
             self.add_ancestors(abs_path(dst), False)
             self.add_header(Node(hdr, abs_path(dst), abs_path(src)))
 
-    # -- UpdateFromTarReader, untar = false (:165-255)
-    def update_from_tar(self, layer):
+    # -- UpdateFromTarReader, untar = false (:165-255).  src_of(p): the reference passes AbsPath(hdr.Name), the path the
+    #    entry is untarred to under the root "/"; the library joins it to ITS root (include/makisu_mi.h says so)
+    def update_from_tar(self, layer, src_of=lambda p: p):
         self.layer = {}
         links = {}
         for e in layer:
@@ -160,9 +161,30 @@ class ModelFS:
             if e["kind"] == M.KIND_HARDLINK:
                 links[p] = e
             else:
-                self.maybe_add(p, p, e)
+                self.maybe_add(src_of(p), p, e)
         for p in sorted(links):                               # (Go ranges over the map in no particular order)
-            self.maybe_add(p, p, links[p])
+            self.maybe_add(src_of(p), p, links[p])
+
+    # -- createLayerByScan (:315-341): walked = [(src, dst, hdr)] in filepath.Walk order, the root first
+    def scan(self, walked, on_disk):
+        self.layer = {}
+        for src, dst, hdr in walked:
+            n = self.tree                                     # isUpdated -> (updated, node)
+            for part in parts(dst):
+                n = n.children.get(part) if n is not None else None
+            updated = n is None or not similar(n.hdr, hdr)
+            if updated and dst != "/":
+                self.add_ancestors(abs_path(dst), False)
+                self.add_header(Node(hdr, abs_path(dst), abs_path(src)))
+            if hdr["kind"] == M.KIND_DIR and n is not None:   # "Only one whiteout file is needed for a deleted subtree."
+                for child in list(n.children.values()):
+                    if not on_disk(child.src):
+                        d, b = posixpath.split(child.dst)
+                        if b.startswith(".wh."):
+                            raise ReferenceFails("base name contains whiteout prefix: " + child.dst)
+                        self.layer[child.dst] = ("whiteout", posixpath.join(d, ".wh." + b))
+                        self._delete(child.dst)
+                        self.add_ancestors(child.dst, False)
 
     # -- addToLayer (:343-421); walk_entries(src) -> the snapshot walk of a source: [(currSrc, entry dict)], src itself first
     def add_to_layer(self, op, walk_entries, is_dir):
