@@ -636,7 +636,8 @@ void mi_copy_layer_free(mi_copy_layer* layer);
  * bytes are read from; a whiteout is an entry named ".wh.<x>" without content) and fold it into the tree.  A failing
  * call returns the error code, mi_memfs_error() the reference's message, and leaves the handle usable.
  *   mi_memfs_entries          the tree in sorted-path order (src_paths may be NULL; cap 0 sizes).
- *   mi_memfs_reset            MemFS.Reset: the tree is emptied, the root stays.                       Host logic. */
+ *   mi_memfs_reset            MemFS.Reset: the tree is emptied, the root stays.
+ * A handle is not re-entrant (the reference serialises MemFS with one mutex); handles are independent.  Host logic. */
 typedef struct mi_memfs mi_memfs;
 int  mi_memfs_create(const char* root, const char* const* blacklist, uint64_t n_blacklist, int64_t now_sec,
                      mi_memfs** out);

@@ -20,6 +20,8 @@
 #include <unordered_map>
 #include <unordered_set>
 
+extern "C" void mi_set_error(mi_batch* b, const char* msg);   // b NULL: the message mi_last_error(NULL) returns
+
 
 // ---- MemFS.AddLayerByCopyOps: the layer a COPY / ADD step creates, on entry lists -----------------
 // addToLayer + maybeAddToLayer(createWhiteout = false) + addAncestors + isUpdated + createHeader
@@ -264,11 +266,11 @@ static bool go_atoi(const std::string& t, long long* v) {
     size_t i = 0;
     if (!t.empty() && (t[0] == '+' || t[0] == '-')) i = 1;
     if (i == t.size()) return false;
+    if (t.size() - i > 18) return false;                                        // beyond int64: Atoi reports a range error
     long long x = 0;
     for (size_t k = i; k < t.size(); ++k) {
         if (t[k] < '0' || t[k] > '9') return false;
         x = x * 10 + (t[k] - '0');
-        if (x > 0x7fffffffffffll / 16) return false;                            // out of int range long before it matters
     }
     *v = t[0] == '-' ? -x : x;
     return true;
@@ -686,8 +688,9 @@ struct Copier {
         struct stat fi;
         if (lstat(src.c_str(), &fi) != 0) return fail("lstat " + src + ": " + strerror(errno));
         // (a blacklisted SOURCE FILE is only logged here -- the reference's else-if chain goes on to copy it; blacklisted
-        // entries below a copied directory never get this far)
-        if (!blacklisted(src) && !S_ISREG(fi.st_mode) && !S_ISDIR(fi.st_mode) && !S_ISLNK(fi.st_mode)) return true;   // special file
+        // entries below a copied directory never get this far.  The same chain would also skip the special-file test for
+        // it and open a blacklisted FIFO for reading; that one corner is not followed: a special file is never opened)
+        if (!S_ISREG(fi.st_mode) && !S_ISDIR(fi.st_mode) && !S_ISLNK(fi.st_mode)) return true;
         if (S_ISLNK(fi.st_mode)) return copy_symlink(src, dst);                  // never chown'ed: that would hit the target
         struct stat dt;
         if (lstat(dst.c_str(), &dt) == 0) {
@@ -982,7 +985,10 @@ extern "C" int mi_memfs_create(const char* root, const char* const* blacklist, u
                                mi_memfs** out) {
     if (!root || !out || (n_blacklist && !blacklist)) return MI_ERR_INVALID;
     struct stat st;
-    if (lstat(root, &st) != 0) return MI_ERR_IO;                                  // "unable to stat root dir"
+    if (lstat(root, &st) != 0) {
+        mi_set_error(nullptr, (std::string("unable to stat root dir: ") + root).c_str());      // mi_last_error(NULL)
+        return MI_ERR_IO;
+    }
     mi_memfs* m = new mi_memfs();
     m->fs.root = mi_walk::abs_path(root);
     m->fs.now = now_sec;
@@ -1196,7 +1202,8 @@ extern "C" int mi_memfs_commit_layer(mi_memfs* m, int must_scan, const mi_copy_o
     std::vector<const char*> srcs(ne ? ne : 1);
     rc = mi_copy_layer_entries(cl, ents.data(), srcs.data(), ne);
     mi_layer* lw = nullptr;
-    if (!rc) rc = mi_layer_begin(cfg, &lw);
+    if (rc) m->err = "failed to generate diff layer: layer entries";
+    if (!rc && (rc = mi_layer_begin(cfg, &lw))) m->err = "failed to generate diff layer: the layer writer refused its configuration";
     for (uint64_t i = 0; i < ne && !rc; ++i) {
         rc = mi_layer_add(lw, &ents[i], ents[i].kind == 1 && srcs[i] && srcs[i][0] ? srcs[i] : nullptr);
         if (rc) m->err = std::string("failed to generate diff layer: write diffs: commit layer: ") + mi_layer_error(lw);
