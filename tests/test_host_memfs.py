@@ -361,3 +361,44 @@ def test_scan_and_merge_read_a_path_the_same_way(tmp_path_factory, parts, head, 
         a.add_layer_by_scan([e])
         b.update_from_entries([e])
         assert [x["relpath"] for x in a.entries()] == [x["relpath"] for x in b.entries()], rel
+
+
+def test_c1_scan_and_commit_of_the_reference_build_context(tmp_path):
+    """BASELINE.json configs[0]: "lib/snapshot scan+commit of testdata/build-context ... (plumbing, no GPU)" -- the
+    reference's own fixture tree (28 files, 10 355 bytes; tests/golden/build_context_c1.json carries it) through NewMemFS,
+    AddLayerByScan and commitLayer: every file arrives in the layer tar with its bytes (SHA-256 per file as the fixture
+    states), in sort.Strings order, directories before their content; the DigestPair is that of the blob; a second
+    commit is the empty layer; a COPY of the tree elsewhere frames to the same members under the new prefix."""
+    import base64
+    import gzip
+    import hashlib
+    import io
+    import json
+    import tarfile
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "build_context_c1.json")))["entries"]
+    root = tmp_path / "root"
+    for e in gold:
+        p = root / "ctx" / e["path"]
+        p.parent.mkdir(parents=True, exist_ok=True)
+        p.write_bytes(base64.b64decode(e["b64"]))
+    assert len(gold) == 28 and sum(e["size"] for e in gold) == 10355
+    with M.MemFS(str(root)) as fs:
+        fd = os.open(str(tmp_path / "layer.tar.gz"), os.O_WRONLY | os.O_CREAT, 0o644)
+        pair = fs.commit_layer(must_scan=True, out_fd=fd)
+        os.close(fd)
+        blob = (tmp_path / "layer.tar.gz").read_bytes()
+        raw = gzip.decompress(blob)
+        assert pair["tar_digest"] == "sha256:" + hashlib.sha256(raw).hexdigest()
+        assert pair["gzip_digest"] == "sha256:" + hashlib.sha256(blob).hexdigest() and pair["gzip_bytes"] == len(blob)
+        with tarfile.open(fileobj=io.BytesIO(raw)) as tf:
+            members = tf.getmembers()
+            names = [m.name.rstrip("/") for m in members]
+            assert names == sorted(names) and names[0] == "ctx"
+            files = {m.name: hashlib.sha256(tf.extractfile(m).read()).hexdigest() for m in members if m.isfile()}
+        assert files == {"ctx/" + e["path"]: e["sha256"] for e in gold}
+        assert all(m.uname == "" and m.gname == "" for m in members)                 # createHeader blanks the names
+        assert fs.commit_layer(must_scan=True)["tar_bytes"] == 1024                   # nothing changed: the empty layer
+        op = {"src_root": str(root), "srcs": ["ctx"], "dst": "/app/", "uid": 0, "gid": 0}
+        copied = fs.commit_layer(ops=[op])
+        assert [e["relpath"] for e in copied["layer"]][1:] == ["app/" + n[len("ctx/"):] for n in names[1:]]
+        assert copied["n_entries"] == len(names)
