@@ -211,6 +211,11 @@ int mi_batch_add_path(mi_batch* b, const char* path, uint64_t size, uint64_t use
  * (MI_ERR_IO naming the path).  user_tags may be NULL (tags 0).                              */
 int mi_batch_add_paths(mi_batch* b, uint64_t n, const char* const* paths, const uint64_t* sizes,
                        const uint64_t* user_tags);
+/* Room for what is known to come (more_files files of more_bytes bytes in total): the arena grows once, now.  Growing
+ * under way is correct but costs -- the reader threads are drained first and what the arena holds is moved -- so a
+ * caller that knows a layer's size (after its walk; mi_batch_begin's hints serve the same purpose for a fresh batch)
+ * says so.  mi_batch_add_tree does it by itself: its enumeration runs ahead of the files it hands over.            */
+int mi_batch_reserve(mi_batch* batch, uint64_t more_files, uint64_t more_bytes);
 /* The same for a byte range of a file -- a member of an uncompressed layer tar, whose ranges
  * mi_tar_entries lists: the file's bytes are [offset, offset + size) of `path`.             */
 int mi_batch_add_path_range(mi_batch* b, const char* path, uint64_t offset, uint64_t size,

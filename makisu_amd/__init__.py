@@ -185,6 +185,7 @@ def load_library(rebuild=False):
         "mi_batch_begin": ([vp, u64, u64, C.POINTER(vp)], C.c_int),
         "mi_batch_add_bytes": ([vp, vp, u64, u64], C.c_int),
         "mi_batch_add_path": ([vp, C.c_char_p, u64, u64], C.c_int),
+        "mi_batch_reserve": ([vp, u64, u64], C.c_int),
         "mi_batch_add_path_range": ([vp, C.c_char_p, u64, u64, u64], C.c_int),
         "mi_batch_add_paths": ([vp, u64, C.POINTER(C.c_char_p), u64p, u64p], C.c_int),
         "mi_batch_add_synthetic": ([vp, u64, u64p, u64p, u64], C.c_int),
@@ -1039,6 +1040,10 @@ class Batch:
             np.ascontiguousarray(data).view(np.uint8)
         self._check(self._lib.mi_batch_add_bytes(self._h, a.ctypes.data if a.size else None,
                                                  a.size, tag))
+
+    def reserve(self, more_files, more_bytes):
+        """mi_batch_reserve: room for what is known to come, so that the arena does not grow under way."""
+        self._check(self._lib.mi_batch_reserve(self._h, more_files, more_bytes))
 
     def add_path(self, path, size=None, tag=0):
         if size is None:

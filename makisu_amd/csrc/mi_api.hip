@@ -917,6 +917,25 @@ int mi_batch_add_paths(mi_batch* b, uint64_t n, const char* const* paths, const 
     return rc;
 }
 
+// Room for what the caller knows is coming: the arena grows ONCE, now, instead of in steps under way -- every growth has
+// to drain the reader threads first (copies in flight target the old arena) and moves what the arena already holds.
+int mi_batch_reserve(mi_batch* b, uint64_t more_files, uint64_t more_bytes) {
+    if (!b) return MI_ERR_INVALID;
+    mi_ctx* c = b->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (b->staged) return fail(c, MI_ERR_STATE, "batch already ran; begin a new batch");
+    if (more_files == 0 && more_bytes == 0) return MI_OK;
+    b->files.reserve(b->files.size() + more_files);
+    u64 want = align_up(b->arena_used, kFileAlign) + more_bytes + (more_files + 1) * kFileAlign;
+    if (want + 4096 > b->arena.bytes) {
+        // it has to grow: then by a step worth the drain -- at least twice what there is, at least 64 MiB (a walk that
+        // reserves as it enumerates would otherwise grow a 400 MB layer fifteen times)
+        const u64 step = 2 * b->arena.bytes > (64ull << 20) ? 2 * b->arena.bytes : (64ull << 20);
+        if (want < step) want = step;
+    }
+    return arena_reserve(b, want);
+}
+
 // A file that is a byte range of another file: a member of an uncompressed layer tar
 // (mi_tar_entries gives the ranges).
 int mi_batch_add_path_range(mi_batch* b, const char* path, uint64_t offset, uint64_t size, uint64_t user_tag) {

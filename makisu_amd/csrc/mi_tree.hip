@@ -47,6 +47,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <functional>
 #include <map>
@@ -79,8 +80,22 @@ struct Walker {
     uint64_t batch_files = 0;                                // files the batch holds + pending ones
     bool counted = false;
 
+    // what the (parallel) enumeration has seen so far, ahead of what was handed over: the arena is sized for it
+    const std::atomic<uint64_t>* ahead_files = nullptr;
+    const std::atomic<uint64_t>* ahead_bytes = nullptr;
+    uint64_t handed_files = 0, handed_bytes = 0;
+
     void flush_pending() {
         if (pend_path.empty() || !batch) return;
+        if (ahead_files) {
+            const uint64_t f = ahead_files->load(std::memory_order_relaxed), by = ahead_bytes->load(std::memory_order_relaxed);
+            if (f > handed_files || by > handed_bytes) {
+                const int r = mi_batch_reserve(batch, f > handed_files ? f - handed_files : 0, by > handed_bytes ? by - handed_bytes : 0);
+                if (r && !rc) { rc = r; return; }
+            }
+            handed_files += pend_path.size();
+            for (uint64_t sz : pend_size) handed_bytes += sz;
+        }
         std::vector<const char*> ptrs(pend_path.size());
         for (size_t i = 0; i < ptrs.size(); ++i) ptrs[i] = pend_path[i].c_str();
         const int r = mi_batch_add_paths(batch, ptrs.size(), ptrs.data(), pend_size.data(), pend_tag.data());
@@ -210,6 +225,7 @@ struct DirRec {
 };
 
 struct ParallelWalker {
+    std::atomic<uint64_t> seen_files{0}, seen_bytes{0};        // regular files enumerated so far (the batch reserves for them)
     Walker* w;                           // rules, rel_base, blacklist, mode; receives the entries
     std::mutex mu;
     std::condition_variable cv, cv_done; // work for the readers / a finished directory for the assembly
@@ -266,6 +282,10 @@ struct ParallelWalker {
             c.uid = (uint32_t)st.st_uid;
             c.gid = (uint32_t)st.st_gid;
             c.size = (uint64_t)st.st_size;
+            if (S_ISREG(st.st_mode)) {
+                seen_files.fetch_add(1, std::memory_order_relaxed);
+                seen_bytes.fetch_add((uint64_t)st.st_size, std::memory_order_relaxed);
+            }
             if (S_ISDIR(st.st_mode)) {
                 c.sub.reset(new DirRec());
                 c.sub->path = path;
@@ -385,6 +405,9 @@ static void walk_root(Walker* w, const std::string& root) {
     if (w->rc || !S_ISDIR(st.st_mode)) return;
     ParallelWalker pw;
     pw.w = w;
+    w->ahead_files = &pw.seen_files;
+    w->ahead_bytes = &pw.seen_bytes;
+    struct Detach { Walker* w; ~Detach() { w->ahead_files = w->ahead_bytes = nullptr; } } detach{w};
     DirRec top;
     top.path = root;
     const std::string root_rel = w->tree->entries.back().relpath;   // the root's own entry was just emitted (a copy:

@@ -107,6 +107,7 @@ thread_local LaunchCfg t_cfg;
 thread_local int t_device = 0;
 
 std::atomic<long> g_live_allocs{0};
+std::atomic<long> g_big_mallocs{0};                  // hipMalloc calls of a MiB and more: arenas (re)allocated
 
 }  // namespace
 
@@ -138,6 +139,7 @@ hipError_t hipMalloc(void** p, size_t n) {
     memset(q, 0xDD, n);
     *p = q;
     ++g_live_allocs;
+    if (n >= (1u << 20)) ++g_big_mallocs;
     return hipSuccess;
 }
 hipError_t hipFree(void* p) { if (p) { free(p); --g_live_allocs; } return hipSuccess; }
@@ -245,5 +247,6 @@ void __hipRegisterVar(void**, void*, char*, const char*, int, size_t, int, int) 
 void __hipUnregisterFatBinary(void**) {}
 
 long mi_hip_stub_live_allocations(void) { return g_live_allocs.load(); }
+long mi_hip_stub_big_mallocs(void) { return g_big_mallocs.load(); }
 
 }  // extern "C"

@@ -171,6 +171,33 @@ def scenario_api(tmp, threads, slab):
         check(b, b"after the errors", "api, after errors")
 
 
+def scenario_tree_reserves_ahead(tmp, threads, slab):
+    """mi_batch_add_tree without size hints: the enumeration runs ahead of the files handed over and the arena is sized
+    for what it has seen -- a handful of (re)allocations for a tree of 6 000 files, not one per 1.5x step"""
+    import ctypes
+    rng = np.random.default_rng(5)
+    d = os.path.join(tmp, "tree")
+    want = {}
+    for k in range(30):
+        os.makedirs(os.path.join(d, "d%02d" % k), exist_ok=True)
+        for f in range(200):
+            data = rng.integers(0, 256, 6000, dtype=np.uint8).tobytes()
+            p = os.path.join(d, "d%02d" % k, "f%03d" % f)
+            with open(p, "wb") as fh:
+                fh.write(data)
+            want[p] = data
+    big = ctypes.CDLL(None).mi_hip_stub_big_mallocs
+    big.restype = ctypes.c_long
+    with M.Engine(n_streams=threads, staging_bytes=slab) as eng, eng.batch() as b:
+        before = big()
+        b.add_tree(d)
+        b.run()
+        grown = big() - before
+        check(b, b"".join(want[p] for p in sorted(want)), "tree")
+        assert grown <= 4, "the 36 MB arena was allocated %d times" % grown
+        print("   arena allocations for 6 000 files without hints:", grown, flush=True)
+
+
 def scenario_two_ctxs(tmp, threads, slab):
     """"multiple ctxs may run concurrently" (include/makisu_mi.h): two engines driven from two host threads at once"""
     import threading
@@ -196,7 +223,8 @@ def main():
     slab = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
     only = sys.argv[4].split(",") if len(sys.argv) > 4 else None
     for name, fn in [("mix", scenario_mix), ("growth", scenario_growth_and_reuse), ("two", scenario_two_batches),
-                     ("errors", scenario_errors), ("api", scenario_api), ("two_ctxs", scenario_two_ctxs)]:
+                     ("errors", scenario_errors), ("api", scenario_api), ("tree", scenario_tree_reserves_ahead),
+                     ("two_ctxs", scenario_two_ctxs)]:
         if only and name not in only:
             continue
         fn(tmp, threads, slab)
