@@ -164,3 +164,25 @@ def test_context_sources_glob(tmp_path):
     assert R("main.go/*") == P("main.go/*")                    # not a directory: ignored like an I/O error
     assert R("*.go", "src/a/*") == P("main.go", "src/a/x.go", "src/a/y.go")
     assert R() == []
+
+
+@settings(max_examples=3000, deadline=None, derandomize=True, database=None)
+@given(st.text(alphabet=["a", "b", "[", "]", "^", "-", "\\", "*", "?", "/", ".", "☺", "\udcff"], max_size=10),
+       st.text(alphabet=["a", "b", "[", "]", "-", "\\", "*", "/", ".", "☺", "\udcff"], max_size=8))
+def test_any_pattern_is_a_verdict_or_a_bad_pattern(pattern, name):
+    """malformed patterns, stray escapes, open classes, bytes that are not UTF-8: true, false or ErrBadPattern -- never a
+    crash (this file runs in the sanitizer builds too)"""
+    try:
+        assert M.path_match(pattern, name) in (True, False)
+    except M.MiError as e:
+        assert e.code == -1
+
+
+@settings(max_examples=500, deadline=None, derandomize=True, database=None)
+@given(st.text(alphabet=["0", "1", "9", ":", "-", "+", "r", "o", "t", " ", "☺"], max_size=24))
+def test_any_chown_string_resolves_or_fails(chown):
+    try:
+        uid, gid = M.resolve_chown(chown)
+        assert isinstance(uid, int) and isinstance(gid, int)
+    except M.MiError as e:
+        assert e.code == -1
