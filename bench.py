@@ -17,6 +17,15 @@ duplicate marking).
                 part per GPU); the job-wide unique-chunk count is checked against the generator's
                 closed form.  --config c5u: rounds 1-2's log-uniform stand-in 2^U(10,30)
 
+How it is launched decides who runs the N > 1 job (the digest exchange is the LIBRARY's own RCCL binding,
+csrc/mi_comm.hip, either way -- what a Go host calls; `--exchange torch` keeps the torch.distributed driver):
+  python bench.py --gpus N                       ONE process, N ctxs, one host thread per device:
+                                                 mi_comm_init_all + mi_dedup_allgather_all, no torch in the job
+  python -m torch.distributed.run ... bench.py   one process per GPU: mi_comm_init_rank + mi_dedup_allgather; torch
+                                                 ships the 128-byte id and runs the host-side barrier (gloo)
+Both refuse to print a line unless ncclCommCount says N, and both first run the N = 1 form of the same per-GPU work
+(`n1_same_run`) so that the line carries `efficiency_vs_n1`.
+
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     -- the dominant kernel (sha256_items_kernel, chunk pass): algorithmic bytes
                   per launch / its average launch duration measured with HIP events on the
@@ -159,14 +168,15 @@ class ClockSampler:
 
 
 def default_inflight(config, exchange):
-    """Batches in flight when --inflight is not given.
-    Without an exchange: ONE batch at a time.  Two in flight are 3-6 % faster (the second batch's passes fill the first
-    one's tails -- reported as `two_batches_in_flight`), but their persistent hashing grids then share the SIMDs for most
-    of their lives and the span of a launch (6-8 ms between its events, in the bench and in rocprof alike) says nothing
-    about the kernel (4.2 ms).  With an exchange there is host-synchronised work to hide: two batches, three for the
-    small config."""
+    """Batches in flight when --inflight is not given: TWO -- the steady state of a host that has the next layer
+    ready while one is scanned (the second batch's passes fill the first one's tails, and an exchange hides behind
+    the other batch's kernels); three for the small config with an exchange.  `value` is that
+    rate, as in rounds 1-2.  With two batches in flight their persistent hashing grids share the SIMDs, so the span
+    between a launch's events (6-8 ms) says nothing about the kernel (4.2 ms): `roofline` therefore comes from
+    the SERIAL steps run right after the timed region (one batch at a time, the kernel has the GPU to itself),
+    and `one_batch_at_a_time` carries round 3's form of the headline."""
     if not exchange:
-        return 1
+        return 2
     return 3 if config == "c2" else 2
 
 
@@ -326,6 +336,249 @@ def host_fed_rate(eng, n_files=48, file_bytes=128 << 20, rounds=4):
             pass
 
 
+def make_shard(W, config, args, rank, world, generation):
+    """One rank's share of a config; `generation` = which of the in-flight batches (distinct content each)."""
+    if config == "c2":
+        return W.c2(rank, world, args.files or 100000, generation)
+    if config == "c3":
+        return W.c3(rank, world, args.files or 1000, generation=generation)
+    if config == "c4":
+        return W.c4(rank, world, args.files or 1250000, generation)
+    if config == "c5u":
+        return W.c5u(rank, world, int((args.bytes_per_gpu or 32) * W.GIB), generation)
+    return W.c5(rank, world, int((args.bytes_per_gpu or 64) * W.GIB), generation,
+                split_threshold=args.split_mib * W.MIB)
+
+
+def n1_leg(makisu_amd, W, config, args, dev_index, inflight):
+    """The N = 1 form of the same per-GPU work, in THIS run on THIS device, before the N-rank job: the config with
+    world = 1 (the same files per GPU -- weak scaling), in-batch duplicate marking, no exchange, the same number
+    of batches in flight.  `efficiency_vs_n1` = value(N) / (N x this)."""
+    import torch
+    eng = makisu_amd.Engine(device=dev_index)
+    batches, nbytes = [], 0
+    for g in range(inflight):
+        sh = make_shard(W, config, args, 0, 1, g)
+        b = eng.batch(sh.n_files, W.batch_bytes_hint(sh))
+        W.fill_batch(b, sh)
+        b.run()
+        batches.append(b)
+        nbytes = sh.n_bytes
+
+    def run(n):
+        pending = []
+        for k in range(n):
+            if len(pending) == inflight:
+                batches[pending.pop(0)].wait()
+            batches[k % inflight].submit()
+            pending.append(k % inflight)
+        for i in pending:
+            batches[i].wait()
+
+    run(max(1, args.warmup))
+    torch.cuda.synchronize(dev_index)
+    t0 = time.perf_counter()
+    run(args.steps)
+    torch.cuda.synchronize(dev_index)
+    dt = time.perf_counter() - t0
+    for b in batches:
+        b.free()
+    eng.close()
+    return {"value": round(nbytes * args.steps / dt / 2**30, 2), "unit": "GiB/s",
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "steps": args.steps, "batches_in_flight": inflight,
+            "bytes_per_step": int(nbytes)}
+
+
+def closed_form_check(got, expect):
+    """Distinct contents are independent random streams, so chunks of different contents differ -- except the
+    shortest ones: a cut candidate on a file's second-to-last byte leaves a 1-BYTE tail chunk (P = 2^-13 per
+    file), and there are only 256 of those.  Measured on a C4 shard (1.25 M files, 9 023 970 chunks): 21 such
+    coincidences, every one a pair of equal 1-byte chunks.  The closed form therefore holds up to ~1e-5."""
+    coincidences = int(expect) - int(got) if got is not None else None
+    return {"n_unique": int(got) if got is not None else None, "closed_form": int(expect),
+            "short_chunk_coincidences": coincidences,
+            "ok": got is not None and 0 <= coincidences <= 2 + int(expect) // 50000}
+
+
+def single_process_job(args):
+    """`python bench.py --gpus N` without torchrun: ONE process drives N devices -- the shape a Go host has
+    (INTEGRATION.md "Multi-GPU from Go"): one ctx per device, one host thread per device for everything that is
+    per-device (generation, submit, wait), mi_comm_init_all once, and per step ONE mi_dedup_allgather_all over
+    the N batches (csrc/mi_comm.hip: the N all-gathers in one group, every rank marks its own rows).  No torch in
+    the job: torch only answers "how many devices" and synchronises them around the timed region."""
+    import concurrent.futures as cf
+    import torch
+    import makisu_amd
+    from makisu_amd import distributed as mdist
+    from makisu_amd import workloads as W
+
+    n = args.gpus
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the hot path)")
+    forced = os.environ.get("MI_BENCH_FORCE_DEVICE")          # self-test: all ranks on one GPU (needs the RCCL double)
+    if forced is None and torch.cuda.device_count() < n:
+        raise SystemExit("--gpus %d but this node shows %d device(s) (WORLD_SIZE is not set: this is the "
+                         "single-process form, one ctx per device)" % (n, torch.cuda.device_count()))
+    devs = [int(forced)] * n if forced is not None else list(range(n))
+    config = args.config if args.config != "auto" else "c4"
+    if config == "c3":
+        raise SystemExit("c3 is BASELINE.json's one-GPU streaming config; N > 1 runs c4 (default), c5, c5u or c2")
+    inflight = args.inflight if args.inflight > 0 else default_inflight(config, True)
+    if args.steps <= 0:
+        args.steps = {"c2": 20, "c4": 3, "c5": 4, "c5u": 5}[config]
+    if args.warmup < 0:
+        args.warmup = 3 if config == "c2" else 1
+    pool = cf.ThreadPoolExecutor(n)
+
+    def each(fn):                                              # one host thread per device
+        return list(pool.map(fn, range(n)))
+
+    n1 = None if args.no_n1 else n1_leg(makisu_amd, W, config, args, devs[0], inflight)
+
+    engines = each(lambda r: makisu_amd.Engine(device=devs[r], flags=makisu_amd.FLAG_NO_DEDUP))
+    info = engines[0].device_info()
+    makisu_amd.comm_init_all(engines)
+    rccl_ranks = [e.comm_ranks() for e in engines]             # ncclCommCount of the library's own communicators
+    if rccl_ranks != [n] * n:
+        raise SystemExit("the collective library sees %s rank(s), --gpus says %d: no line" % (rccl_ranks, n))
+    shards = [[make_shard(W, config, args, r, n, g) for g in range(inflight)] for r in range(n)]
+
+    def build(r):
+        out = []
+        for sh in shards[r]:
+            b = engines[r].batch(sh.n_files, W.batch_bytes_hint(sh))
+            out.append((b, W.fill_batch(b, sh)))
+        return out
+    built = each(build)
+    part_rounds = 0
+    if any(sh.parts is not None for row in shards for sh in row):
+        for g in range(inflight):                              # the parts' owners agree on the boundary cuts, once
+            part_rounds = max(part_rounds, mdist.resolve_parts_local([built[r][g] for r in range(n)]))
+    batches = [[bk[0] for bk in row] for row in built]
+    each(lambda r: [b.run() for b in batches[r]])              # generates the data on the device, first pass
+
+    rec = {"step_ms": [[] for _ in range(n)], "sha_ms": [[] for _ in range(n)], "cdc_ms": [[] for _ in range(n)],
+           "gather_ms": [[] for _ in range(n)], "mark_ms": [[] for _ in range(n)], "exchange_host_ms": []}
+    checks = {}
+
+    def finish(g, record):
+        each(lambda r: batches[r][g].wait())
+        t0 = time.perf_counter()
+        n_total, n_unique = makisu_amd.dedup_allgather_all([batches[r][g] for r in range(n)])
+        x_ms = (time.perf_counter() - t0) * 1e3
+        if record:
+            rec["exchange_host_ms"].append(x_ms)
+            for r in range(n):
+                st = engines[r].stats()
+                ga, ma = engines[r].comm_exchange_ms()
+                rec["step_ms"][r].append(st["ms_total"])
+                rec["sha_ms"][r].append(st["ms_sha_chunks"])
+                rec["cdc_ms"][r].append(st["ms_cdc"])
+                rec["gather_ms"][r].append(ga)
+                rec["mark_ms"][r].append(ma)
+            checks[g] = (n_total, n_unique, [engines[r].stats()["n_chunks"] for r in range(n)])
+
+    def run_steps(k_steps, record):
+        pending = []
+        for k in range(k_steps):
+            if len(pending) == inflight:
+                finish(pending.pop(0), record)
+            g = k % inflight
+            each(lambda r: batches[r][g].submit())
+            pending.append(g)
+        while pending:
+            finish(pending.pop(0), record)
+
+    def sync_all():
+        for d in sorted(set(devs)):
+            torch.cuda.synchronize(d)
+
+    run_steps(args.warmup, False)
+    sync_all()
+    t0 = time.perf_counter()
+    run_steps(args.steps, True)
+    sync_all()
+    dt = time.perf_counter() - t0
+
+    job_bytes = sum(shards[r][0].n_bytes for r in range(n))
+    value = job_bytes * args.steps / dt / 2**30
+    # the dominant kernel one batch at a time on rank 0, the other ranks idle: its own duration
+    serial_sha, st = [], None
+    for i in range(2 + min(7, max(3, args.steps))):
+        batches[0][0].submit()
+        batches[0][0].wait()
+        st = engines[0].stats()
+        if i >= 2:
+            serial_sha.append(st["ms_sha_chunks"])
+    alg = st["bytes_in"] + 52 * st["n_chunks"]
+    s_ms = float(np.mean(serial_sha))
+    valu_roof = max(engines[0].sha_valu_roof(w, 0) / 1e9 for w in (8, 4))
+    # closed form of the job-wide unique count
+    g_last = (args.steps - 1) % inflight
+    n_total, n_unique, per_rank_chunks = checks[g_last]
+    if config in ("c5", "c5u"):
+        expect = sum(int(batches[r][g_last].files()["n_chunks"][shards[r][g_last].originals].sum()) for r in range(n))
+    else:
+        expect = n_total                                      # c2 / c4: every content is distinct
+    desc = shards[0][0]
+    mean = lambda rows: [round(float(np.mean(x)), 4) for x in rows]     # noqa: E731
+    out = {
+        "metric": "GiB/s hashed (Gear CDC + SHA-256 per chunk)",
+        "value": round(value, 2), "unit": "GiB/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": "%s (seed 0x%X, device-resident), Gear CDC mask 13 bits / min 2 KiB / max 64 KiB, SHA-256 per "
+                               "chunk, per-file chunk root; digest-set all-gather over RCCL inside the library "
+                               "(mi_dedup_allgather_all) + job-wide duplicate marking; %d batches in flight per GPU"
+                               % (desc.describe, desc.seed, inflight),
+                   "name": config, "files_per_gpu": int(desc.n_files), "bytes_per_gpu": int(desc.n_bytes),
+                   "job_bytes_per_step": int(job_bytes), "chunks_per_rank_last_batch": [int(x) for x in per_rank_chunks],
+                   "parallelism": "files sharded x%d (%s)" % (n, "LPT by bytes" if config in ("c5", "c5u") else "file index mod N"),
+                   "launch": "single process, %d ctxs, one host thread per device (mi_comm_init_all)" % n,
+                   "batches_in_flight": inflight, "exchange": "native", "rccl_ranks": n,
+                   "rccl_library": os.environ.get("MI_RCCL_LIB", "librccl (dlopen)"),
+                   "devices": devs, "device": info["name"].strip(), "n_cu": info["n_cu"]},
+        "per_rank": {"step_ms": mean(rec["step_ms"]), "cdc_ms": mean(rec["cdc_ms"]), "sha_chunks_ms": mean(rec["sha_ms"]),
+                     "exchange_gather_ms": mean(rec["gather_ms"]), "marking_ms": mean(rec["mark_ms"]),
+                     "note": "device time per batch from HIP events (step = first kernel start to last kernel end of the "
+                             "batch's pipeline, sharing the GPU with the other batch in flight; gather = the slab "
+                             "all-gather on the ctx stream; marking = padding squeeze + job-wide marking of the rank's rows)"},
+        "exchange_host_ms_avg": round(float(np.mean(rec["exchange_host_ms"])), 4),
+        "n1_same_run": n1,
+        "efficiency_vs_n1": round(value / (n * n1["value"]), 4) if n1 else None,
+        "dedup_check": dict(closed_form_check(n_unique, expect), n_total=int(n_total)),
+        "roofline": {"bound": "hbm", "kernel": "sha256_items_kernel (chunk pass)",
+                     "achieved": round(alg / (s_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(alg / (s_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
+                     "algorithmic_bytes_per_launch": int(alg), "avg_launch_ms": round(s_ms, 4),
+                     "valu_roof_GBps": round(valu_roof, 1),
+                     "frac_of_valu_roof": round(alg / (s_ms * 1e-3) / 1e9 / valu_roof, 4),
+                     "path_frac": round(job_bytes / n * 1.006 / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS, 4),
+                     "note": "rank 0's chunk pass one batch at a time right after the timed region (HIP events on the "
+                             "batch's stream, the other ranks idle); in the timed region the launches of the batches in "
+                             "flight share the SIMDs (per_rank.sha_chunks_ms); path_frac = a rank's whole step, "
+                             "algorithmic bytes / ms_per_step / peak"},
+    }
+    if config in ("c5", "c5u"):
+        out["config"].update({"lpt_imbalance_max_over_mean_bytes": round(desc.imbalance, 6),
+                              "files_split_into_parts_job": getattr(desc, "n_split_files_job", 0),
+                              "part_boundary_rounds": part_rounds})
+    for row in batches:
+        for b in row:
+            b.free()
+    for e in engines:
+        e.comm_destroy()
+        e.close()
+    pool.shutdown()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:                                           # noqa: BLE001
+        pass
+    sys.stderr.flush()
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -338,22 +591,31 @@ def main():
     ap.add_argument("--split-mib", type=int, default=256,
                     help="c5 with N > 1: files of this many MiB and more are split into one part per GPU")
     ap.add_argument("--inflight", type=int, default=0,
-                    help="batches in flight (default: 1 = one batch at a time on one GPU without an exchange, "
-                         "where every kernel then has the GPU to itself and its event-bracketed duration is its "
-                         "own; 2 with an exchange to hide, 3 for c2 with an exchange)")
-    ap.add_argument("--no-inflight-extra", action="store_true",
-                    help="c2, one GPU: skip the extra region with two batches in flight")
+                    help="batches in flight (default 2; 3 for c2 with an exchange; 1 = one batch at a time: every "
+                         "kernel then has the GPU to itself in the timed region too -- the form the rocprof kernel "
+                         "trace under profiles/ is taken with)")
+    ap.add_argument("--no-n1", action="store_true",
+                    help="N > 1: skip the N = 1 leg that `efficiency_vs_n1` comes from")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-fed", action="store_true", help="c3: skip the host-fed leg")
-    ap.add_argument("--backend", default="nccl",
-                    help="torch.distributed backend (nccl = RCCL; gloo only for the single-GPU "
-                         "self-test of the N>1 logic)")
-    ap.add_argument("--exchange", default="torch", choices=["torch", "native"],
-                    help="who runs the digest all-gather: torch.distributed (default) or the library's "
-                         "own RCCL binding, mi_dedup_allgather (what a Go host uses)")
+    ap.add_argument("--backend", default="auto",
+                    help="torch.distributed backend under torchrun: auto = gloo with --exchange native (torch then "
+                         "only ships the id and runs the host-side barrier and reductions -- the one RCCL "
+                         "communicator in the process is the library's), nccl (= RCCL) with --exchange torch")
+    ap.add_argument("--exchange", default="native", choices=["torch", "native"],
+                    help="who runs the digest all-gather: the library's own RCCL binding (default: "
+                         "mi_dedup_allgather / mi_dedup_allgather_all, what a Go host uses) or torch.distributed")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the digest exchange + global marking even with one rank (self-test)")
     args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world == 1 and args.gpus > 1:
+        return single_process_job(args)                      # launched bare: one process, N ctxs
 
     import torch
     import torch.distributed as dist
@@ -361,11 +623,6 @@ def main():
     from makisu_amd import distributed as mdist
     from makisu_amd import workloads as W
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the hot path)")
     dev_index = int(os.environ.get("MI_BENCH_FORCE_DEVICE", local_rank))   # self-test: all ranks on one GPU
@@ -379,32 +636,69 @@ def main():
         args.steps = {"c2": 20, "c3": 3, "c4": 3, "c5": 4, "c5u": 5}[config]
     if args.warmup < 0:
         args.warmup = 3 if config == "c2" else 1
+    backend = args.backend
+    if backend == "auto":
+        backend = "gloo" if args.exchange == "native" else "nccl"
     if exchange or world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        if args.backend == "nccl":
+        if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    red_dev = device if backend == "nccl" else torch.device("cpu")   # small host-side reductions
+
+    def all_ranks(v):                                         # a python value of every rank, rank order
+        if not (dist.is_initialized() and world > 1):
+            return [v]
+        out = [None] * world
+        dist.all_gather_object(out, v)
+        return out
+
+    # the N = 1 form of the same per-GPU work, every rank on its own GPU at the same time, before the job
+    n1 = None
+    if world > 1 and not args.no_n1 and config != "c3":
+        n1_mine = n1_leg(makisu_amd, W, config, args, dev_index, args.inflight)
+        vals = all_ranks(n1_mine["value"])
+        n1 = dict(n1_mine, value=round(float(np.mean(vals)), 2), per_rank_value=vals,
+                  note="every rank ran the config with world = 1 on its own GPU at the same time; value = mean")
 
     # with more than one rank the global marking after the all-gather supersedes the in-batch one
     eng = makisu_amd.Engine(device=dev_index,
                             flags=makisu_amd.FLAG_NO_DEDUP if exchange else 0)
     info = eng.device_info()
+    exchange_note = None
     if exchange and args.exchange == "native":
-        uid = [eng.comm_unique_id() if rank == 0 else None]
-        if world > 1:
-            dist.broadcast_object_list(uid, src=0)          # torchrun only ships the 128-byte id
-        eng.comm_init_rank(world, rank, uid[0])
+        # torchrun only ships the 128-byte id.  Should the library's communicator not come up on some rank
+        # (it has met real RCCL with more than one rank on few machines), every rank falls back to the torch
+        # driver of the same exchange and the line says so -- a first contact must still yield a line.
+        err = None
+        try:
+            uid = [eng.comm_unique_id() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(uid, src=0)
+            eng.comm_init_rank(world, rank, uid[0])
+        except Exception as e:                                  # noqa: BLE001
+            err = "rank %d: %s" % (rank, e)
+        errs = [e for e in all_ranks(err) if e]
+        if errs:
+            if err is None:
+                eng.comm_destroy()
+            args.exchange = "torch"
+            exchange_note = "native communicator failed (%s): torch.distributed drives the exchange" % "; ".join(errs)[:400]
+            print("bench.py: " + exchange_note, file=sys.stderr)
+    torch_group = None
+    if exchange and args.exchange == "torch" and backend != "nccl" and args.backend == "auto" and world > 1:
+        torch_group = dist.new_group(backend="nccl")            # the fallback's RCCL group
     # how many ranks the collective library itself sees -- a scaling line must be able to prove its N
     rccl_ranks = None
     if exchange:
         if args.exchange == "native":
             rccl_ranks = eng.comm_ranks()                    # ncclCommCount of the library's own communicator
-        elif args.backend == "nccl":
-            rccl_ranks = dist.get_world_size()               # torch's NCCL(=RCCL) group, created with device_id above
+        elif backend == "nccl" or torch_group is not None:
+            rccl_ranks = dist.get_world_size(torch_group)    # torch's NCCL(=RCCL) group
         if rccl_ranks is not None and rccl_ranks != args.gpus and (world > 1 or args.force_exchange):
-            raise SystemExit("the collective library sees %d rank(s), --gpus says %d" % (rccl_ranks, args.gpus))
+            raise SystemExit("the collective library sees %d rank(s), --gpus says %d: no line" % (rccl_ranks, args.gpus))
 
     # The rank's share of the config, as `inflight` batches of distinct content.  Step k runs on
     # batch k % inflight: every step is a complete pass (all outputs recomputed); a step is
@@ -412,16 +706,7 @@ def main():
     # pass of the other.  c3 cuts the rank's 1000 files into `inflight` parts that
     # together make ONE step (125 GiB fits HBM once, not twice).
     def make(generation):
-        if config == "c2":
-            return W.c2(rank, world, args.files or 100000, generation)
-        if config == "c3":
-            return W.c3(rank, world, args.files or 1000, generation=generation)
-        if config == "c4":
-            return W.c4(rank, world, args.files or 1250000, generation)
-        if config == "c5u":
-            return W.c5u(rank, world, int((args.bytes_per_gpu or 32) * W.GIB), generation)
-        return W.c5(rank, world, int((args.bytes_per_gpu or 64) * W.GIB), generation,
-                    split_threshold=args.split_mib * W.MIB)
+        return make_shard(W, config, args, rank, world, generation)
 
     # c3's host-fed leg runs FIRST: right after the resident batches are freed the driver is still
     # wiping their 130 GB of VRAM on the SDMA engines the H2D copies need (measured: 18 GB/s then,
@@ -446,42 +731,28 @@ def main():
     batches = []
     part_rounds = 0
     for sh in shards:
-        b = eng.batch(sh.n_files, sh.n_bytes + (sh.n_files + 8) * 4096 + (len(sh.parts or ()) << 19))
-        if sh.parts is None:
-            b.add_synthetic(sh.sizes, sh.cids, seed=sh.seed)
-        else:
-            # c5 on several GPUs: runs of whole files, and parts of the files that were split
-            keys, i, n = [], 0, sh.n_files
-            while i < n:
-                if sh.parts[i][3] < 0:
-                    j = i
-                    while j < n and sh.parts[j][3] < 0:
-                        j += 1
-                    b.add_synthetic(sh.sizes[i:j], sh.cids[i:j], seed=sh.seed)
-                    i = j
-                else:
-                    fsize, begin, end, pno = sh.parts[i]
-                    b.add_synthetic_part(fsize, int(sh.cids[i]), begin, end, seed=sh.seed)
-                    keys.append((int(sh.cids[i]) * 4 * sh.n_global_files + int(sh.global_index[i]), pno))
-                    i += 1
+        b = eng.batch(sh.n_files, W.batch_bytes_hint(sh))
+        keys = W.fill_batch(b, sh)
         if config in ("c5", "c5u") and world > 1:
             # the parts' owners agree on the cuts at the part boundaries (8 bytes per boundary over the
             # host group; every rank calls, also one that owns no part); later steps reuse the entries
-            part_rounds = max(part_rounds, mdist.resolve_parts(b, keys if sh.parts is not None else []))
+            part_rounds = max(part_rounds, mdist.resolve_parts(b, keys))
         b.run()                                   # generates the data on the device, first pass
         batches.append(b)
     launches_per_step = len(batches) if split else 1
     sha_ms, sha_alg_bytes, stats_sum, checks = [], [], {}, {}
+    xrec = {"host_ms": [], "gather_ms": [], "mark_ms": [], "step_ms": []}
 
     def finish(i, record):
         b = batches[i]
         b.wait()
         n_unique = None
+        t_x = time.perf_counter()
         if exchange:
             if args.exchange == "native":
                 _, n_unique, _ = b.dedup_allgather()      # RCCL inside the library
             else:
-                _, n_unique, _, _ = mdist.global_dedup(eng, b, device)
+                _, n_unique, _, _ = mdist.global_dedup(eng, b, device, group=torch_group)
         if record:
             st = eng.stats()
             sha_ms.append(st["ms_sha_chunks"])
@@ -490,6 +761,13 @@ def main():
                 if k.startswith("ms_"):
                     stats_sum[k] = stats_sum.get(k, 0.0) + v
             checks[i] = (st["n_chunks"], n_unique if exchange else st["n_unique"])
+            xrec["step_ms"].append(st["ms_total"])
+            if exchange:
+                xrec["host_ms"].append((time.perf_counter() - t_x) * 1e3)
+                if args.exchange == "native":
+                    ga, ma = eng.comm_exchange_ms()
+                    xrec["gather_ms"].append(ga)
+                    xrec["mark_ms"].append(ma)
 
     def run_steps(n, record, inflight=None):
         inflight = inflight or args.inflight
@@ -502,8 +780,6 @@ def main():
             pending.append(i)
         while pending:
             finish(pending.pop(0), record)
-
-    red_dev = device if args.backend == "nccl" else torch.device("cpu")   # small host-side reductions
 
     def fence():
         torch.cuda.synchronize(device)
@@ -529,12 +805,6 @@ def main():
     dt = time.perf_counter() - t0
     clocks = sampler.stop() if rank == 0 else None
     chunks_last_batch = int(eng.stats()["n_chunks"])            # of the timed region's last step
-    # the SHA-256 VALU roof of THIS device in THIS run, right behind the timed region (same thermal and
-    # power state): best of three 10 ms launches of the compression alone
-    sampler.start()
-    roofs = {w: eng.sha_valu_roof(w, 0) / 1e9 for w in (8, 4)}   # waves per SIMD: the denser form draws more power
-    valu_roof = max(roofs.values())
-    roof_clocks = sampler.stop() if rank == 0 else None
     if dist.is_initialized() and world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -547,48 +817,43 @@ def main():
     else:
         job_bytes = step_bytes * world
 
-    # Outside the timed region: a few SERIAL steps (one batch at a time) so the dominant
-    # kernel's launch duration can also be read without another batch sharing the GPU.
-    serial_sha_ms, serial_phase = [], {}
+    # Right behind the timed region: the SAME steps ONE batch at a time (no exchange), so that every kernel has
+    # the GPU to itself and the event-bracketed duration of a launch is the kernel's own -- `roofline` is taken
+    # from these launches when the timed region keeps several batches in flight.  2 untimed steps (the clock
+    # ramps up again after the host-side pause), then --steps timed ones.
+    serial_sha_ms, serial_alg, serial_phase, one_at_a_time = [], [], {}, None
     if args.inflight > 1:
         torch.cuda.synchronize(device)
-        for i in range(9):                                   # 2 untimed (the clock ramps up again after the
-            batches[0].submit()                              # host-side pause) + the median of 7
-            batches[0].wait()
-            st = eng.stats()
-            if i >= 2:
+        n_serial = args.steps * launches_per_step
+        acc = {}
+        for i in range(2 * launches_per_step + n_serial):
+            if i == 2 * launches_per_step:
+                torch.cuda.synchronize(device)
+                t1 = time.perf_counter()
+            b = batches[i % len(batches)]
+            b.submit()
+            b.wait()
+            if i >= 2 * launches_per_step:
+                st = eng.stats()
                 serial_sha_ms.append(st["ms_sha_chunks"])
-        serial_phase = {k: round(v, 4) for k, v in st.items() if k.startswith("ms_")}
-        serial_alg = st["bytes_in"] + 52 * st["n_chunks"]
-
-    # c2 on one GPU: the same steps with TWO batches in flight (a second batch of distinct content), outside
-    # the timed region -- what a host that always has the next layer ready gets.
-    two_in_flight = None
-    if config == "c2" and world == 1 and not exchange and args.inflight == 1 and not args.no_inflight_extra:
-        sh2 = make(1)
-        b_extra = eng.batch(sh2.n_files, sh2.n_bytes + (sh2.n_files + 8) * 4096)
-        b_extra.add_synthetic(sh2.sizes, sh2.cids, seed=sh2.seed)
-        b_extra.run()
-        batches.append(b_extra)
-        keep = (list(sha_ms), list(sha_alg_bytes), dict(stats_sum), dict(checks))
-        del sha_ms[:], sha_alg_bytes[:]
-        run_steps(args.warmup, False, inflight=2)
+                serial_alg.append(st["bytes_in"] + 52 * st["n_chunks"])
+                for k, v in st.items():
+                    if k.startswith("ms_"):
+                        acc[k] = acc.get(k, 0.0) + v
         torch.cuda.synchronize(device)
-        t1 = time.perf_counter()
-        run_steps(args.steps, True, inflight=2)
-        torch.cuda.synchronize(device)
-        dt2 = time.perf_counter() - t1
-        two_in_flight = {"value": round(step_bytes * args.steps / dt2 / 2**30, 2), "unit": "GiB/s",
-                         "ms_per_step": round(dt2 / args.steps * 1e3, 4), "steps": args.steps,
-                         "sha_chunk_pass_span_ms": round(float(np.mean(sha_ms)), 4),
-                         "note": "same steps, a second batch of distinct content submitted while the first runs; "
-                                 "the span of a hashing launch now includes the time it shares the SIMDs with the "
-                                 "other batch's passes"}
-        sha_ms[:], sha_alg_bytes[:] = keep[0], keep[1]
-        stats_sum.clear(); stats_sum.update(keep[2])
-        checks.clear(); checks.update(keep[3])
-        batches.pop()
-        b_extra.free()
+        dt1 = time.perf_counter() - t1
+        serial_phase = {k: round(v / n_serial, 4) for k, v in sorted(acc.items())}
+        if not exchange:
+            one_at_a_time = {"value": round(step_bytes * args.steps / dt1 / 2**30, 2), "unit": "GiB/s",
+                             "ms_per_step": round(dt1 / args.steps * 1e3, 4), "steps": args.steps,
+                             "note": "the same steps one batch at a time, right after the timed region: round 3's "
+                                     "form of the headline (BENCH_r03: 1053.77 GiB/s, 5.7921 ms)"}
+    # the SHA-256 VALU roof of THIS device in THIS run, right behind the serial steps (same thermal and
+    # power state): best of three 10 ms launches of the compression alone
+    sampler.start()
+    roofs = {w: eng.sha_valu_roof(w, 0) / 1e9 for w in (8, 4)}   # waves per SIMD: the denser form draws more power
+    valu_roof = max(roofs.values())
+    roof_clocks = sampler.stop() if rank == 0 else None
 
     # The same pass with the OTHER load scheme (quad-cooperative: far fewer address translations), a few
     # serial steps on a second ctx: on a box whose lane-owned launches run well below the VALU roof this
@@ -623,22 +888,16 @@ def main():
             t = torch.tensor([expect], dtype=torch.int64, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             expect = int(t.item())
-        got = checks[0][1]
-        # Distinct contents are independent random streams, so chunks of different contents differ --
-        # except the shortest ones: a cut candidate on a file's second-to-last byte leaves a 1-BYTE
-        # tail chunk (P = 2^-13 per file), and there are only 256 of those.  Measured on a C4 shard
-        # (1.25 M files, 9 023 970 chunks): 21 such coincidences, every one a pair of equal 1-byte
-        # chunks (tools/debug_c4_dups.py).  The closed form therefore holds up to ~1e-5.
-        coincidences = int(expect) - int(got) if got is not None else None
-        dedup_check = {"n_unique": int(got) if got is not None else None, "closed_form": int(expect),
-                       "short_chunk_coincidences": coincidences,
-                       "ok": got is not None and 0 <= coincidences <= 2 + int(expect) // 50000}
+        dedup_check = closed_form_check(checks[0][1], expect)
 
     value = job_bytes * args.steps / dt / 2**30
     # dominant kernel: SHA-256 per chunk.  Algorithmic bytes per launch: every file byte read
     # once + 32 B digest written per chunk + the 20 B queue descriptor read per chunk.
-    alg_bytes = float(np.mean(sha_alg_bytes))
-    sha_avg_ms = float(np.mean(sha_ms))
+    span_ms = float(np.mean(sha_ms))                             # timed region: shared with the other batches in flight
+    if serial_sha_ms:
+        alg_bytes, sha_avg_ms = float(np.mean(serial_alg)), float(np.mean(serial_sha_ms))
+    else:
+        alg_bytes, sha_avg_ms = float(np.mean(sha_alg_bytes)), span_ms
     achieved = alg_bytes / (sha_avg_ms * 1e-3) / 1e9
     traffic, traffic_src = None, None
     tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
@@ -649,7 +908,8 @@ def main():
             traffic_src = tj.get("source")
         except Exception:
             traffic = None
-    st = eng.stats()
+    mode = ("%d batches in flight (value, ms_per_step); roofline from the one-batch-at-a-time steps of the same run"
+            % args.inflight) if args.inflight > 1 else "one batch at a time (value, ms_per_step and roofline alike)"
     out = {
         "metric": "GiB/s hashed (Gear CDC + SHA-256 per chunk)",
         "value": round(value, 2), "unit": "GiB/s", "n_gpus": world, "steps": args.steps,
@@ -657,18 +917,21 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u32", "data": "synthetic",
         "config": {"workload": "%s (seed 0x%X, device-resident), Gear CDC mask 13 bits / min 2 KiB / "
-                               "max 64 KiB, SHA-256 per chunk, per-file chunk root, duplicate marking%s"
+                               "max 64 KiB, SHA-256 per chunk, per-file chunk root, duplicate marking%s; %s"
                                % (desc_shard.describe, desc_shard.seed,
                                   "; digest-set all-gather over RCCL (%s) + job-wide marking" % args.exchange
-                                  if exchange else ""),
+                                  if exchange else "", mode),
                    "name": config, "files_per_gpu": int(sum(s.n_files for s in shards) if split else shards[0].n_files),
                    "bytes_per_gpu": int(step_bytes), "job_bytes_per_step": int(job_bytes),
                    "chunks_last_batch": chunks_last_batch,
                    "parallelism": "files sharded x%d (%s)" % (world, "LPT by bytes" if config in ("c5", "c5u") else "file index mod N"),
+                   "launch": "one process per GPU" if world > 1 else "one process, one GPU",
                    "batches_in_flight": args.inflight, "launches_per_step": launches_per_step,
                    "exchange": (args.exchange if exchange else None),
                    "rccl_ranks": rccl_ranks,
-                   "exchange_backend": (args.backend if exchange else None),
+                   "exchange_backend": (("library RCCL binding; torch.distributed %s for the id, barrier and scalars" % backend)
+                                        if exchange and args.exchange == "native" else
+                                        ("nccl" if torch_group is not None else backend) if exchange else None),
                    "device": info["name"].strip(), "n_cu": info["n_cu"],
                    "results": "left on the device (16 B of counts read back per batch); mi_batch_chunks_view / "
                               "mi_batch_files bring 64 B per chunk + 96 B per file to the host on demand "
@@ -679,6 +942,8 @@ def main():
                      "traffic_from_profile_run": traffic_src,
                      "algorithmic_bytes_per_launch": int(alg_bytes),
                      "avg_launch_ms": round(sha_avg_ms, 4),
+                     "avg_launch_ms_from": ("the %d one-batch-at-a-time steps right after the timed region" % len(serial_sha_ms))
+                                           if serial_sha_ms else "the timed region",
                      "valu_roof_GBps": round(valu_roof, 1),
                      "valu_roof_source": "mi_sha_valu_roof in this run, right after the timed region: the 64-round "
                                          "compression alone on every SIMD (no memory traffic), best of 3 launches at 8 and "
@@ -690,37 +955,48 @@ def main():
                      "path_frac": round(job_bytes / world * 1.006 / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS, 4),
                      "note": "SHA-256 is integer-VALU bound on CDNA4 (valu_roof_GBps, measured in this run); "
                              "the HBM fraction cannot exceed valu_roof / peak. "
-                             "achieved/avg_launch_ms are from the timed region (HIP events around the launch on "
-                             "the batch's stream)%s; path_frac = whole CDC+SHA step per GPU, algorithmic "
-                             "bytes / ms_per_step / peak"
-                             % (": one batch at a time, the kernel has the GPU to itself" if args.inflight == 1 else
-                                ", where the kernel shares the GPU with the other in-flight batches' passes; "
-                                "serial_* = the same kernel with one batch at a time (median of 7 extra untimed steps)")},
+                             "achieved/avg_launch_ms: HIP events around the launch on the batch's stream, %s; "
+                             "path_frac = whole CDC+SHA step per GPU, algorithmic bytes / ms_per_step / peak"
+                             % ("one batch at a time in the timed region, the kernel has the GPU to itself" if args.inflight == 1 else
+                                "from the one-batch-at-a-time steps of this run; in the timed region the kernel shares the "
+                                "SIMDs with the other in-flight batches' passes and the span between its events is "
+                                "inflight_span_ms")},
         "phase_ms_avg": {k: round(v / max(1, len(sha_ms)), 4) for k, v in sorted(stats_sum.items())},
-        "phase_note": "per-batch stream timelines; with several batches in flight a phase's span "
-                      "includes time it shared the GPU with the other batches",
+        "phase_note": "per-batch stream timelines of the timed region; with several batches in flight a phase's span "
+                      "includes time it shared the GPU with the other batches; serial_phase_ms = one batch at a time",
     }
     if args.inflight == 1:
         out["serial_phase_ms"] = dict(out["phase_ms_avg"])      # one batch at a time: the timed region IS serial
-    if two_in_flight:
-        out["two_batches_in_flight"] = two_in_flight
+    else:
+        out["serial_phase_ms"] = serial_phase
+        out["roofline"]["inflight_span_ms"] = round(span_ms, 4)
+    if one_at_a_time:
+        out["one_batch_at_a_time"] = one_at_a_time
+    if exchange_note:
+        out["config"]["exchange_note"] = exchange_note
     if config in ("c5", "c5u"):
         out["config"].update({"lpt_imbalance_max_over_mean_bytes": round(desc_shard.imbalance, 6),
                               "files_split_into_parts_job": getattr(desc_shard, "n_split_files_job", 0),
                               "parts_this_rank": sum(1 for p_ in (desc_shard.parts or ()) if p_[3] >= 0),
                               "part_boundary_rounds": part_rounds})
+    if exchange:
+        mine = {"step_ms": round(float(np.mean(xrec["step_ms"])), 4),
+                "exchange_host_ms": round(float(np.mean(xrec["host_ms"])), 4),
+                "exchange_gather_ms": round(float(np.mean(xrec["gather_ms"])), 4) if xrec["gather_ms"] else None,
+                "marking_ms": round(float(np.mean(xrec["mark_ms"])), 4) if xrec["mark_ms"] else None}
+        rows = all_ranks(mine)
+        out["per_rank"] = {k: [r_[k] for r_ in rows] for k in mine}
+        out["per_rank"]["note"] = ("step = device time of a batch's pipeline (first kernel start to last kernel end, sharing "
+                                   "the GPU with the other batch in flight); exchange_host = wall time of the exchange call; "
+                                   "gather / marking = device time of the slab all-gather and of the job-wide marking "
+                                   "(HIP events on the ctx stream, native exchange only)")
+    if world > 1:
+        out["n1_same_run"] = n1
+        out["efficiency_vs_n1"] = round(value / (world * n1["value"]), 4) if n1 else None
     if clocks is not None:
         out["clocks"] = {"timed_region": clocks, "valu_roof_launches": roof_clocks}
     if dedup_check:
         out["dedup_check"] = dedup_check
-    if serial_sha_ms:
-        s_ms = float(np.median(serial_sha_ms))
-        s_ach = serial_alg / (s_ms * 1e-3) / 1e9
-        out["roofline"].update({"serial_avg_launch_ms": round(s_ms, 4),
-                                "serial_achieved": round(s_ach, 1),
-                                "serial_frac": round(s_ach / HBM_PEAK_GBPS, 4),
-                                "serial_frac_of_valu_roof": round(s_ach / valu_roof, 4)})
-        out["serial_phase_ms"] = serial_phase
     if other_scheme:
         out["roofline"]["other_load_scheme_serial"] = other_scheme
     if rank == 0 and world == 1:
@@ -730,6 +1006,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(desc_shard)
     for b in batches:
         b.free()
+    if exchange and args.exchange == "native":
+        eng.comm_destroy()
     eng.close()
     if dist.is_initialized():
         dist.barrier()

@@ -265,8 +265,9 @@ int mi_batch_free(mi_batch* b);
 int mi_batch_stage_stats(mi_batch* b, mi_stage_stats* out);
 /* What the first verification mismatch of the batch looked like -- arena range, reader thread, both
  * pairs of sums, how many bytes differed and what the GPU held there (zeros / the 0xA5 fill / other
- * data), whether a second copy repaired it; "" if every span verified.  Valid until the batch is
- * reset or freed.                                                                              */
+ * data), whether a second copy repaired it; "" if every span verified.  Call it after staging has
+ * ended (mi_batch_run / _submit / _scan_cuts returned): the reader threads write the note while they
+ * stage.  The pointer is valid until the batch is reset or freed.                                */
 const char* mi_batch_stage_note(mi_batch* b);
 
 /* ---- parts: ONE file split across batches / GPUs (files >= 256 MiB) ------------- *
@@ -366,6 +367,10 @@ int mi_comm_ranks(mi_ctx* ctx, int* n_ranks);
 int mi_dedup_allgather(mi_batch* b, uint64_t* n_total, uint64_t* n_unique,
                        uint64_t* first_global);
 int mi_dedup_allgather_all(mi_batch** batches, int n, uint64_t* n_total, uint64_t* n_unique);
+/* Device time of the ctx's LAST exchange, from HIP events on the ctx stream (what a scaling line
+ * reports beside its rate): ms_gather = the slab all-gather (xGMI time), ms_marking = squeezing the padding
+ * out + the job-wide marking of this rank's rows.  Both 0 before the first exchange with rows.          */
+int mi_comm_exchange_ms(mi_ctx* ctx, double* ms_gather, double* ms_marking);
 
 /* ---- COPY/ADD context checksum (addCopyStep.SetCacheID seam) ------------------------ *
  * Reproduces the ONE running CRC32-IEEE the reference feeds at plan time

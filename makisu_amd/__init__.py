@@ -278,6 +278,7 @@ def load_library(rebuild=False):
         "mi_comm_init_all": ([C.POINTER(vp), C.c_int], C.c_int),
         "mi_comm_destroy": ([vp], C.c_int),
         "mi_comm_ranks": ([vp, C.POINTER(C.c_int)], C.c_int),
+        "mi_comm_exchange_ms": ([vp, C.POINTER(C.c_double), C.POINTER(C.c_double)], C.c_int),
         "mi_dedup_allgather": ([vp, u64p, u64p, u64p], C.c_int),
         "mi_dedup_allgather_all": ([C.POINTER(vp), C.c_int, u64p, u64p], C.c_int),
         "mi_index_create": ([vp, u64, C.POINTER(vp)], C.c_int),
@@ -987,6 +988,12 @@ class Engine:
         n = C.c_int()
         self._check(self._lib.mi_comm_ranks(self._h, C.byref(n)))
         return n.value
+
+    def comm_exchange_ms(self):
+        """(ms_gather, ms_marking) of this ctx's last exchange, device time from HIP events."""
+        a, b = C.c_double(), C.c_double()
+        self._check(self._lib.mi_comm_exchange_ms(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def dedup_mark_range(self, d_digests_ptr, n_total, own_first, own_n, d_dup_of_own_ptr):
         """dup_of (global indices) for the rows [own_first, own_first+own_n) of a job-wide,

@@ -82,15 +82,15 @@ int arena_reserve(mi_batch* b, u64 want) {
     int rc = staging_sync(b);                       // copies in flight target the old arena
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    u64 alloc = want + want / 2;
+    u64 alloc = guard_alloc() ? ((want + 255) & ~255ull) : want + want / 2;   // under the guard: the 4 KiB and no more
     void* np = nullptr;
-    hipError_t e = hipMalloc(&np, alloc);
-    if (e != hipSuccess) { alloc = want; HIPCHK(c, hipMalloc(&np, alloc)); }
+    hipError_t e = dev_alloc(&np, alloc);
+    if (e != hipSuccess) { alloc = want; HIPCHK(c, dev_alloc(&np, alloc)); }
     if (b->arena.p && b->arena_used) {
         const u64 keep = b->arena_used < b->arena.bytes ? b->arena_used : b->arena.bytes;
         HIPCHK(c, hipMemcpy(np, b->arena.p, keep, hipMemcpyDeviceToDevice));
     }
-    if (b->arena.p) (void)hipFree(b->arena.p);
+    if (b->arena.p) (void)dev_free(b->arena.p);
     b->arena.p = np;
     b->arena.bytes = alloc;
     if (c->verify_staging) {
@@ -473,7 +473,8 @@ int submit_pipeline_enqueue(mi_batch* b) {
                         sha, ncu, 0, s);
     if (c->cfg.flags & MI_FLAG_FILE_SHA256)
         launch_sha256_items(kShaFiles, b->arena.as<u8>(), d_off, d_size, nullptr, (u32)nf, nullptr,
-                            heads(2), roles(1), false, b->file_sha.as<u8>(), sha, ncu, b->arena_used, s);
+                            heads(2), nullptr, false, b->file_sha.as<u8>(), sha, ncu, b->arena_used, s);   // files come in
+                            // arrival order, not longest-first: no "long" range to hand to a SIMD's first wave (flat sharing)
     if (c->cfg.flags & MI_FLAG_FILE_CRC32) {
         HIPCHK(c, b->tile_raw.ensure(b->n_tiles * 4 + 16));
         HIPCHK(c, b->crc_d.ensure(nf * 4));
@@ -927,7 +928,8 @@ int mi_batch_reserve(mi_batch* b, uint64_t more_files, uint64_t more_bytes) {
     if (more_files == 0 && more_bytes == 0) return MI_OK;
     b->files.reserve(b->files.size() + more_files);
     u64 want = align_up(b->arena_used, kFileAlign) + more_bytes + (more_files + 1) * kFileAlign;
-    if (want + 4096 > b->arena.bytes) {
+    if (guard_alloc()) want = align_up(b->arena_used, kFileAlign) + more_bytes;     // the audit: exactly what was said
+    else if (want + 4096 > b->arena.bytes) {
         // it has to grow: then by a step worth the drain -- at least twice what there is, at least 64 MiB (a walk that
         // reserves as it enumerates would otherwise grow a 400 MB layer fifteen times)
         const u64 step = 2 * b->arena.bytes > (64ull << 20) ? 2 * b->arena.bytes : (64ull << 20);
@@ -1389,6 +1391,10 @@ int mi_batch_free(mi_batch* b) {
     if (b->tree) { mi_batch_tree_free(b->tree); b->tree = nullptr; }
     mi_ctx* c = b->ctx;
     (void)hipSetDevice(c->device);
+    if (b->in_flight) {                         // submitted and never waited for: the stream is drained below
+        b->in_flight = false;
+        if (c->batches_in_flight > 0) --c->batches_in_flight;
+    }
     (void)staging_sync(b);                      // reader threads may still hold pieces of this batch
     for (int i = 0; i < 2; ++i) {
         if (b->ring_ev[i]) (void)hipEventDestroy(b->ring_ev[i]);
@@ -1551,7 +1557,7 @@ int mi_sha256_many(mi_ctx* c, const void* data, const uint64_t* offsets, const u
         if (e == hipSuccess) e = hipMemcpy(d_len.p, lens, n * 8, hipMemcpyHostToDevice);
         if (e == hipSuccess) {
             launch_sha256_items(kShaBlobs, d_data.as<u8>(), d_off.as<u64>(), d_len.as<u64>(), nullptr, (u32)n,
-                                nullptr, c->heads.as<u32>(), c->heads.as<u32>() + kShaHeadWords, true, d_out.as<u8>(), c->sha,
+                                nullptr, c->heads.as<u32>(), nullptr, true, d_out.as<u8>(), c->sha,      // blobs in arrival order: flat sharing
                                 c->prop.multiProcessorCount, span, c->stream);
             e = hipStreamSynchronize(c->stream);
         }

@@ -8,8 +8,9 @@
 //     to its peers by any side channel, every rank calls mi_comm_init_rank, then
 //     mi_dedup_allgather(batch) after each mi_batch_run/wait;
 //   single process, n GPUs (the natural shape for a Go host: one ctx per device):
-//     mi_comm_init_all(ctxs, n) and mi_dedup_allgather_all(batches, n) -- the n collectives
-//     are issued inside one ncclGroupStart/End.
+//     mi_comm_init_all(ctxs, n) and mi_dedup_allgather_all(batches, n) -- the row counts are host
+//     knowledge there (no counts collective, no host sync before the slabs), every allocation and
+//     pad copy happens BEFORE the group, and the group holds nothing but the n ncclAllGather calls.
 // Exchange: counts first (one u64 per rank), then slabs padded to the largest count in one
 // ncclAllGather -- every xGMI link carries exactly one peer's slab, no ring of 7 hops --
 // then the padding is squeezed out with device copies and the rank marks ITS OWN rows against
@@ -96,7 +97,14 @@ struct Exchange {
     DevBuf counts, slab, gathered, compact, dup;
     u64* pin = nullptr;                 // pinned: [0] this rank's scalar, [1 .. nranks] gathered scalars
     size_t pin_words = 0;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};   // before the slab all-gather / after it / after the marking
+    bool timed = false;                 // the three events of the last exchange were recorded
 };
+int ensure_events(mi_ctx* c, Exchange* x) {
+    for (auto& e : x->ev)
+        if (!e) HIPCHK(c, hipEventCreate(&e));
+    return MI_OK;
+}
 int ensure_pin(mi_ctx* c, Exchange* x) {
     const size_t want = (size_t)c->comm_nranks + 1;
     if (x->pin_words >= want) return MI_OK;
@@ -126,24 +134,45 @@ int exchange_counts_enqueue(mi_batch* b) {
     return MI_OK;
 }
 
-int exchange_slabs_enqueue(mi_batch* b, std::vector<u64>& counts, u64* max_out) {
+// the gathered counts on the host (sync 1 of 2 of the multi-process form: the slab size is a host decision)
+int exchange_counts_read(mi_batch* b, std::vector<u64>& counts, u64* max_out) {
     mi_ctx* c = b->ctx;
     Exchange* x = exchange_of(c);
     counts.resize((size_t)c->comm_nranks);
     HIPCHK(c, hipMemcpyAsync(x->pin + 1, x->counts.p, 8 * counts.size(), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));            // sync 1 of 2: the slab size is a host decision
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     u64 m = 0;
     for (size_t r = 0; r < counts.size(); ++r) { counts[r] = x->pin[1 + r]; m = counts[r] > m ? counts[r] : m; }
     *max_out = m;
+    return MI_OK;
+}
+
+// Everything the slab all-gather needs that is not the collective itself: the receive buffer, and -- when a
+// peer holds more rows than this batch's digest buffer has room for -- a padded copy to send from.  No
+// collective call in here, so it may run outside any group.
+int exchange_slabs_prepare(mi_batch* b, u64 n_ranks, u64 m, const void** send_out) {
+    mi_ctx* c = b->ctx;
+    Exchange* x = exchange_of(c);
+    int rc = ensure_events(c, x);
+    if (rc) return rc;
+    x->timed = false;
+    *send_out = b->digests.p;                              // rows past n_chunks are padding nobody reads
     if (m == 0) return MI_OK;
-    HIPCHK(c, x->gathered.ensure(m * 32 * counts.size()));
-    const void* send = b->digests.p;                       // rows past n_chunks are padding nobody reads
+    HIPCHK(c, x->gathered.ensure(m * 32 * n_ranks));
     if (m * 32 > b->digests.bytes) {                       // a peer holds more rows than this batch could
         HIPCHK(c, x->slab.ensure(m * 32));
         if (b->n_chunks)
             HIPCHK(c, hipMemcpyAsync(x->slab.p, b->digests.p, b->n_chunks * 32, hipMemcpyDeviceToDevice, c->stream));
-        send = x->slab.p;
+        *send_out = x->slab.p;
     }
+    HIPCHK(c, hipEventRecord(x->ev[0], c->stream));
+    return MI_OK;
+}
+
+int exchange_slabs_enqueue(mi_batch* b, const void* send, u64 m) {
+    mi_ctx* c = b->ctx;
+    Exchange* x = exchange_of(c);
+    if (m == 0) return MI_OK;
     NCCLCHK(c, rccl()->AllGather(send, x->gathered.p, m * 32, ncclUint8, (ncclComm_t)c->comm, c->stream));
     return MI_OK;
 }
@@ -158,6 +187,7 @@ int mark_and_rewrite(mi_batch* b, const std::vector<u64>& counts, u64 m, uint64_
         total += counts[r];
     }
     const u8* glob = x->gathered.as<u8>();
+    if (m) HIPCHK(c, hipEventRecord(x->ev[1], c->stream));
     bool ragged = false;
     for (u64 v : counts) ragged |= (v != m);
     if (ragged && total) {                                   // squeeze the padding out, rank-major
@@ -176,6 +206,10 @@ int mark_and_rewrite(mi_batch* b, const std::vector<u64>& counts, u64 m, uint64_
     HIPCHK(c, b->dup_of.ensure(b->n_chunks * 8 + 16));      // absent when the ctx has MI_FLAG_NO_DEDUP
     int rc = mi_dedup_mark_range_enqueue(c, glob, total, first, b->n_chunks, b->dup_of.p);
     if (rc) return rc;
+    if (m) {
+        HIPCHK(c, hipEventRecord(x->ev[2], c->stream));
+        x->timed = true;
+    }
     b->results_valid = false;
     if (n_total) *n_total = total;
     if (first_global) *first_global = first;
@@ -271,11 +305,28 @@ int mi_comm_destroy(mi_ctx* c) {
         Exchange* x = (Exchange*)c->comm_scratch;
         x->counts.release(); x->slab.release(); x->gathered.release(); x->compact.release(); x->dup.release();
         if (x->pin) (void)hipHostFree(x->pin);
+        for (auto e : x->ev) if (e) (void)hipEventDestroy(e);
         delete x;
         c->comm_scratch = nullptr;
     }
     c->comm_rank = 0;
     c->comm_nranks = 1;
+    return MI_OK;
+}
+
+int mi_comm_exchange_ms(mi_ctx* c, double* ms_gather, double* ms_marking) {
+    if (!c) return MI_ERR_INVALID;
+    if (ms_gather) *ms_gather = 0;
+    if (ms_marking) *ms_marking = 0;
+    Exchange* x = (Exchange*)c->comm_scratch;
+    if (!x || !x->timed) return MI_OK;                     // no exchange yet, or one without rows
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventSynchronize(x->ev[2]));
+    float a = 0, b = 0;
+    HIPCHK(c, hipEventElapsedTime(&a, x->ev[0], x->ev[1]));
+    HIPCHK(c, hipEventElapsedTime(&b, x->ev[1], x->ev[2]));
+    if (ms_gather) *ms_gather = a;
+    if (ms_marking) *ms_marking = b;
     return MI_OK;
 }
 
@@ -289,7 +340,12 @@ int mi_dedup_allgather(mi_batch* b, uint64_t* n_total, uint64_t* n_unique, uint6
     if (rc) return rc;
     std::vector<u64> counts;
     u64 m = 0;
-    rc = exchange_slabs_enqueue(b, counts, &m);
+    rc = exchange_counts_read(b, counts, &m);
+    if (rc) return rc;
+    const void* send = nullptr;
+    rc = exchange_slabs_prepare(b, counts.size(), m, &send);
+    if (rc) return rc;
+    rc = exchange_slabs_enqueue(b, send, m);
     if (rc) return rc;
     rc = mark_and_rewrite(b, counts, m, n_total, first_global);
     if (rc) return rc;
@@ -314,26 +370,30 @@ int mi_dedup_allgather_all(mi_batch** batches, int n, uint64_t* n_total, uint64_
     }
     mi_ctx* c0 = batches[0]->ctx;
     int rc = MI_OK;
-    NCCLCHK(c0, rccl()->GroupStart());
-    for (int i = 0; i < n && !rc; ++i) {
-        (void)hipSetDevice(batches[i]->ctx->device);
-        rc = exchange_counts_enqueue(batches[i]);
+    // every rank's row count is known to this process: no counts collective, no host sync before the slabs
+    std::vector<u64> counts((size_t)n);
+    u64 m = 0;
+    for (int i = 0; i < n; ++i) { counts[(size_t)i] = batches[i]->n_chunks; m = counts[(size_t)i] > m ? counts[(size_t)i] : m; }
+    std::vector<const void*> send((size_t)n, nullptr);
+    for (int i = 0; i < n; ++i) {              // allocations and pad copies: outside the group
+        HIPCHK(batches[i]->ctx, hipSetDevice(batches[i]->ctx->device));
+        rc = exchange_slabs_prepare(batches[i], (u64)n, m, &send[(size_t)i]);
+        if (rc) return rc;
     }
-    NCCLCHK(c0, rccl()->GroupEnd());
-    if (rc) return rc;
-    std::vector<std::vector<u64>> counts((size_t)n);
-    std::vector<u64> maxes((size_t)n, 0);
     NCCLCHK(c0, rccl()->GroupStart());
-    for (int i = 0; i < n && !rc; ++i) {
+    for (int i = 0; i < n && !rc; ++i) {       // the group holds the n collectives and nothing else
         (void)hipSetDevice(batches[i]->ctx->device);
-        rc = exchange_slabs_enqueue(batches[i], counts[(size_t)i], &maxes[(size_t)i]);
+        rc = exchange_slabs_enqueue(batches[i], send[(size_t)i], m);
     }
-    NCCLCHK(c0, rccl()->GroupEnd());
-    if (rc) return rc;
+    {
+        const ncclResult_t r_ = rccl()->GroupEnd();        // always closed, also after a failed enqueue
+        if (rc) return rc;
+        if (r_ != ncclSuccess) return fail(c0, MI_ERR_HIP, "ncclGroupEnd failed: %s", rccl()->GetErrorString(r_));
+    }
     for (int i = 0; i < n; ++i) {              // every rank's marking enqueued on its own stream ...
         (void)hipSetDevice(batches[i]->ctx->device);
         uint64_t nt = 0;
-        rc = mark_and_rewrite(batches[i], counts[(size_t)i], maxes[(size_t)i], &nt, nullptr);
+        rc = mark_and_rewrite(batches[i], counts, m, &nt, nullptr);
         if (rc) return rc;
         if (n_total) *n_total = nt;
     }

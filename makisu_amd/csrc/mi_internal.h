@@ -11,18 +11,26 @@
 
 namespace mi {
 
+// mi_alloc.hip: hipMalloc / hipFree, or -- MI_GUARD_ALLOC=1, the over-read audit -- allocations that end on an
+// unmapped page, sized exactly as asked
+bool       guard_alloc();
+hipError_t dev_alloc(void** p, size_t bytes);
+hipError_t dev_free(void* p);
+
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
     hipError_t ensure(size_t want) {
         if (want <= bytes) return hipSuccess;
-        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
-        size_t alloc = want + want / 8 + 256;
-        hipError_t e = hipMalloc(&p, alloc);
+        if (p) { (void)dev_free(p); p = nullptr; bytes = 0; }
+        // 256 bytes of slack behind every buffer: the hashing kernels read up to 67 bytes past a string's end
+        // (sha256.hip); one eighth on top so that a buffer that grows does not grow every time (not under the guard)
+        size_t alloc = guard_alloc() ? ((want + 255) & ~(size_t)255) + 256 : want + want / 8 + 256;
+        hipError_t e = dev_alloc(&p, alloc);
         if (e == hipSuccess) bytes = alloc;
         return e;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    void release() { if (p) (void)dev_free(p); p = nullptr; bytes = 0; }
     template <typename T> T* as() const { return (T*)p; }
 };
 

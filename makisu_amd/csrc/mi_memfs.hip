@@ -266,11 +266,12 @@ static bool go_atoi(const std::string& t, long long* v) {
     size_t i = 0;
     if (!t.empty() && (t[0] == '+' || t[0] == '-')) i = 1;
     if (i == t.size()) return false;
-    if (t.size() - i > 18) return false;                                        // beyond int64: Atoi reports a range error
     long long x = 0;
     for (size_t k = i; k < t.size(); ++k) {
         if (t[k] < '0' || t[k] > '9') return false;
-        x = x * 10 + (t[k] - '0');
+        const int d = t[k] - '0';
+        if (x > (9223372036854775807LL - d) / 10) return false;                  // beyond int64: Atoi reports a range error
+        x = x * 10 + d;
     }
     *v = t[0] == '-' ? -x : x;
     return true;
@@ -523,7 +524,8 @@ extern "C" int mi_copy_op_resolve(uint64_t n_srcs, const char* work_dir, const c
         return MI_ERR_INVALID;
     }
     std::string r = d;
-    if (d[0] != '/') {                                      // filepath.Join cleans; the trailing "/" is put back
+    if (d[0] != '/') {                                      // filepath.Join cleans; the trailing "/" is put back (the reference
+                                                            // appends it even to a joined "/", giving "//": the same path once cleaned)
         r = mi_walk::abs_path(std::string(work_dir) + "/" + d);
         if (copy_dst_is_dir_format(d) && r.back() != '/') r += "/";
     }

@@ -512,9 +512,12 @@ int stage_verify_final(mi_batch* b) {
             if (!bad) first_bad = i;
             ++bad;
         }
-    b->stage_stats.final_spans += n;
-    b->stage_stats.final_mismatches += bad;
-    b->stage_stats.ms_verify += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    {
+        std::lock_guard<std::mutex> g(b->span_mu);
+        b->stage_stats.final_spans += n;
+        b->stage_stats.final_mismatches += bad;
+        b->stage_stats.ms_verify += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
     if (!bad) return MI_OK;
     const StageSpan& sp = spans[first_bad];
     char head[320];
@@ -526,7 +529,10 @@ int stage_verify_final(mi_batch* b) {
              sp.thread == kStageInlineThread ? 0u : sp.thread, (unsigned long long)sp.s1, (unsigned long long)sp.s2,
              (unsigned long long)sums[2 * first_bad], (unsigned long long)sums[2 * first_bad + 1]);
     const std::string msg = head + describe_span(b->arena.as<u8>() + sp.off, nullptr, sp.len, c->stream);
-    if (b->stage_note.empty()) b->stage_note = msg;
+    {
+        std::lock_guard<std::mutex> g(b->span_mu);
+        if (b->stage_note.empty()) b->stage_note = msg;
+    }
     fprintf(stderr, "makisu_mi: %s\n", msg.c_str());
     b->stage_err = msg;                                        // sticky (stager_drain / stage_batch)
     return fail(c, MI_ERR_IO, "%s", msg.c_str());

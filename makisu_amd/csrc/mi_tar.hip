@@ -305,6 +305,7 @@ static int parse(Source& src, Tar* t) {
             it.file_index = n_regular++;
             if (src.gz && size > 0) { open_member = it.name; open_member_end = data + (uint64_t)size; }
         }
+        else if (src.gz && skip > 0) { open_member = it.name; open_member_end = data + (uint64_t)size; }   // any other member with a data area
         t->items.push_back(it);
         off = data + skip;
     }

@@ -174,6 +174,34 @@ def c5u(rank=0, world=1, bytes_per_gpu=32 * GIB, generation=0, lo_log2=10, hi_lo
 CONFIGS = {"c2": c2, "c3": c3, "c4": c4, "c5": c5, "c5u": c5u}
 
 
+def batch_bytes_hint(sh):
+    """Arena bytes a batch of this shard needs (files on 256-byte boundaries, halos of the parts)."""
+    return sh.n_bytes + (sh.n_files + 8) * 4096 + (len(sh.parts or ()) << 19)
+
+
+def fill_batch(b, sh):
+    """Adds a shard's items to a batch: runs of whole files through add_synthetic, the parts of split files
+    (c5 on several GPUs) through add_synthetic_part.  Returns the keys of the parts in the order b.parts()
+    lists them -- (file key, part number), what resolve_parts / resolve_parts_local exchange -- [] without."""
+    if sh.parts is None:
+        b.add_synthetic(sh.sizes, sh.cids, seed=sh.seed)
+        return []
+    keys, i, n = [], 0, sh.n_files
+    while i < n:
+        if sh.parts[i][3] < 0:
+            j = i
+            while j < n and sh.parts[j][3] < 0:
+                j += 1
+            b.add_synthetic(sh.sizes[i:j], sh.cids[i:j], seed=sh.seed)
+            i = j
+        else:
+            fsize, begin, end, pno = sh.parts[i]
+            b.add_synthetic_part(fsize, int(sh.cids[i]), begin, end, seed=sh.seed)
+            keys.append((int(sh.cids[i]) * 4 * sh.n_global_files + int(sh.global_index[i]), pno))
+            i += 1
+    return keys
+
+
 PART_ALIGN = 256 * KIB          # MI_PART_ALIGN: part bounds are multiples of the 256 KiB CDC group
 
 

@@ -4,7 +4,7 @@ VERDICT r1: "full-size configs are property-checked, not oracle-checked".  The o
 synthetic file inside its worker threads (mi_ref_scan_synthetic), so the whole of C2 (6.25 GiB)
 costs it about a second on the GPU box's host cores and never has to exist in host memory:
   C2  all 100 000 x 64 KiB files                                     (configs[1], full size)
-  C3  60 x 128 MiB                                                   (configs[2] shape, 10x round 1)
+  C3  all 1 000 x 128 MiB files as one 134 GB batch                  (configs[2], full size: round 4)
   C4  two ranks' shards of file index mod 8, job-wide marking        (configs[3] shape)
   C4  one rank's FULL shard, 1.25 M x 64 KiB = 76 GiB                (configs[3], full size per rank)
   C5  one GPU's full Zipf shard (3 350 files 1 KiB..1 GiB, 57 GiB), 90 % duplicates  (configs[4], full size)
@@ -70,13 +70,19 @@ def test_c2_full_size_every_row(oracle, eng):
     assert len(chunks) > 700000 and nu == len(chunks) - len(dup) and (dup["length"] <= 2).all() and len(dup) <= 3
 
 
-def test_c3_sixty_128mib_files(oracle, eng):
+@pytest.mark.timeout(900)
+def test_c3_full_size_every_row(oracle, eng):
+    """BASELINE.json configs[2] as written and as `bench.py --config c3` times it: 1 000 x 128 MiB as ONE
+    134 GB batch (13.1 M chunks), every row against the oracle; a third of the files repeat earlier ones, so
+    the duplicate marking has 4.4 M rows to find (rounds 1-3 checked 6 and 60 files)."""
     from makisu_amd import workloads as W
-    sh = W.c3(0, 1, 60)
-    sh.cids[40:] = sh.cids[:20]                            # a third of the files repeat earlier ones
+    sh = W.c3(0, 1, 1000)
+    sh.cids[667:] = sh.cids[:333]
     files, chunks, nu = _check_shard(oracle, eng, sh)
-    assert (chunks["dup_of"][chunks["file_index"] >= 40] >= 0).all()
-    assert np.array_equal(files["chunk_root"][40:], files["chunk_root"][:20])
+    assert sh.n_bytes == 1000 * (128 << 20) and len(chunks) > 13_000_000
+    assert (chunks["dup_of"][chunks["file_index"] >= 667] >= 0).all()
+    assert np.array_equal(files["chunk_root"][667:], files["chunk_root"][:333])
+    assert 0 <= int(files["n_chunks"][:667].sum()) - nu <= 2      # (two 1-byte tail chunks may coincide)
 
 
 def _closed_form_in_shard(sh, files):
@@ -180,7 +186,7 @@ def test_bench_c4_two_ranks_on_one_gpu_gloo():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", "29577", os.path.join(ROOT, "bench.py"),
            "--gpus", "2", "--config", "c4", "--files", "20000", "--steps", "2", "--warmup", "1",
-           "--backend", "gloo", "--no-cpu-baseline"]
+           "--exchange", "torch", "--backend", "gloo", "--no-cpu-baseline"]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=800)
     assert out.returncode == 0, out.stderr[-3000:]
     import json
@@ -201,7 +207,7 @@ def test_bench_c5_two_ranks_split_files_on_one_gpu_gloo():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", "29579", os.path.join(ROOT, "bench.py"),
            "--gpus", "2", "--config", "c5", "--bytes-per-gpu", "3", "--split-mib", "32", "--steps", "2",
-           "--warmup", "1", "--backend", "gloo", "--no-cpu-baseline"]
+           "--warmup", "1", "--exchange", "torch", "--backend", "gloo", "--no-cpu-baseline"]
     out = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=800)
     assert out.returncode == 0, out.stderr[-3000:]
     import json

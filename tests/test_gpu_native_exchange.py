@@ -8,7 +8,15 @@ product's code: counts all-gather, padded slabs, the ragged squeeze, `first_glob
 marking of a rank's own rows, the summed first-occurrence counts.  Checked against the oracle's
 duplicate marking of the concatenated rank-major digest set.  Ragged on purpose: one rank holds many
 more rows than the others (its peers' digest buffers are too small for the padded slab -> the copy
-path), one rank holds NO rows, contents repeat across ranks."""
+path), one rank holds NO rows, contents repeat across ranks.
+
+Round 4: the rank count BASELINE.json's configs[3] / [4] name -- EIGHT -- in both forms
+(8 processes; 8 ctxs of one process): the ragged shape with one rank holding 8x the rows of the others and one
+holding none, C4's eight `index mod 8` shards (20 000 files each), and the Zipf C5 mix with its large files
+split into 8 parts (`split_threshold` 32 MiB; the owners agree on the boundary cuts over a gloo group or, in
+one process, through resolve_parts_local) -- `dup_of`, `first_global`, `n_total`, `n_unique` against the
+oracle's marking of the rank-major concatenation; and `bench.py --gpus 8` launched BARE (no torchrun) prints a
+C4 line of the library's own exchange with `rccl_ranks: 8`."""
 import os
 import subprocess
 import sys
@@ -34,12 +42,12 @@ def stub():
 
 
 def rank_files(rank, n):
-    """(sizes, content ids) of a rank: rank 0 many rows, the last rank none (n >= 3) or one tiny file,
-    every rank repeats some of rank 0's contents."""
+    """(sizes, content ids) of a rank: rank 0 many rows (at 8 ranks: 8x the rows of the next largest), the
+    last rank none (n >= 3) or one tiny file, every rank repeats some of rank 0's contents."""
     if n >= 3 and rank == n - 1:
         return [], []
     if rank == 0:
-        sizes = [65536] * 40 + [300000, 5, 0, 1 << 20]
+        sizes = [65536] * (40 if n < 8 else 160) + [300000, 5, 0, 1 << 20]
         cids = list(range(100, 100 + len(sizes)))
         return sizes, cids
     sizes = [65536] * (3 + rank) + [2048, 300000]
@@ -57,8 +65,31 @@ import makisu_amd
 from test_gpu_native_exchange import rank_files, SEED
 """
 
+CHILD_COMMON += r"""
+from makisu_amd import workloads as W
+from makisu_amd import distributed as mdist
+
+def shard_of(case, rank, n):
+    if case == "c4":
+        return W.c4(rank, n, 20000)
+    return W.c5(rank, n, 1 * W.GIB, split_threshold=32 * W.MIB)          # 8 GiB job-wide at n = 8
+
+def fill(case, b, rank, n):
+    # adds the rank's items; returns the keys of its parts ([] without split files)
+    if case == "ragged":
+        sizes, cids = rank_files(rank, n)
+        if sizes:
+            b.add_synthetic(sizes, cids, seed=SEED)
+        return []
+    return W.fill_batch(b, shard_of(case, rank, n))
+"""
+
 CHILD_RANK = CHILD_COMMON + r"""
 rank, n, d = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+case = sys.argv[4] if len(sys.argv) > 4 else "ragged"
+if case == "c5":                                              # the parts' owners talk over a host group
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method="file://" + os.path.join(d, "store"), rank=rank, world_size=n)
 with makisu_amd.Engine(flags=makisu_amd.FLAG_NO_DEDUP) as e:
     if rank == 0:
         uid = e.comm_unique_id()
@@ -71,13 +102,15 @@ with makisu_amd.Engine(flags=makisu_amd.FLAG_NO_DEDUP) as e:
     assert e.comm_ranks() == 0
     e.comm_init_rank(n, rank, uid)
     assert e.comm_ranks() == n
-    sizes, cids = rank_files(rank, n)
     with e.batch() as b:
-        if sizes:
-            b.add_synthetic(sizes, cids, seed=SEED)
+        keys = fill(case, b, rank, n)
+        if case == "c5":
+            mdist.resolve_parts(b, keys)
         b.run()
         for rep in range(2):                                  # twice: the exchange buffers are reused
             n_total, n_unique, first = b.dedup_allgather()
+        ga, ma = e.comm_exchange_ms()
+        assert ga >= 0 and ma >= 0 and (ga + ma > 0 or n_total == 0), (ga, ma)
         ch = b.chunks().copy()
     np.savez(os.path.join(d, "out%%d.npz" %% rank), sha=ch["sha256"], dup=ch["dup_of"],
              scal=np.array([n_total, n_unique, first], dtype=np.int64))
@@ -87,17 +120,20 @@ print("OK")
 
 CHILD_ALL = CHILD_COMMON + r"""
 n, d = int(sys.argv[1]), sys.argv[2]
+case = sys.argv[3] if len(sys.argv) > 3 else "ragged"
 engines = [makisu_amd.Engine(flags=makisu_amd.FLAG_NO_DEDUP) for _ in range(n)]      # n ctxs on the one GPU
 makisu_amd.comm_init_all(engines)
 assert [e.comm_ranks() for e in engines] == [n] * n
-batches = []
+batches, owners = [], []
 for r, e in enumerate(engines):
-    sizes, cids = rank_files(r, n)
     b = e.batch()
-    if sizes:
-        b.add_synthetic(sizes, cids, seed=SEED)
-    b.run()
+    owners.append((b, fill(case, b, r, n)))
     batches.append(b)
+if case == "c5":
+    assert sum(len(k) for _, k in owners) >= n                # at least one file really is split into n parts
+    mdist.resolve_parts_local(owners)
+for b in batches:
+    b.run()
 for rep in range(2):
     n_total, n_unique = makisu_amd.dedup_allgather_all(batches)
 first = 0
@@ -113,7 +149,7 @@ print("OK")
 """
 
 
-def _check(oracle, d, n):
+def _check(oracle, d, n, case="ragged"):
     outs = [np.load(os.path.join(d, "out%d.npz" % r)) for r in range(n)]
     allrows = np.concatenate([o["sha"].reshape(-1, 32) for o in outs])
     want, want_unique = oracle.dedup_mt(allrows, 4)
@@ -124,35 +160,106 @@ def _check(oracle, d, n):
         assert (n_total, n_unique, fg) == (len(allrows), want_unique, first), (r, n_total, n_unique, fg)
         assert np.array_equal(o["dup"], want[first:first + rows]), "rank %d: dup_of differs from the oracle" % r
         first += rows
-    # the shape the test is about: ragged, a rank without rows, duplicates across ranks
     counts = [len(o["dup"]) for o in outs]
-    assert max(counts) > 4 * sorted(counts)[-2] or n == 2
-    assert (n < 3) or counts[-1] == 0
-    assert want_unique < len(allrows)
-    assert any((o["dup"] >= 0).any() and r > 0 for r, o in enumerate(outs))
+    if case == "ragged":
+        # the shape the test is about: ragged, a rank without rows, duplicates across ranks
+        assert max(counts) > 4 * sorted(counts)[-2] or n == 2
+        assert n < 8 or max(counts) >= 8 * sorted(counts)[-2]       # the padded slab dwarfs every peer's digest buffer
+        assert (n < 3) or counts[-1] == 0
+        assert want_unique < len(allrows)
+        assert any((o["dup"] >= 0).any() and r > 0 for r, o in enumerate(outs))
+    elif case == "c4":
+        assert min(counts) > 100000 and len(allrows) - want_unique <= 2     # distinct contents (1-byte tails may coincide)
+    else:
+        assert want_unique < len(allrows) // 2                       # 90 % of the files are copies
+        assert any((o["dup"] >= 0).any() and r > 0 for r, o in enumerate(outs))
     return counts
 
 
-@pytest.mark.parametrize("n", [2, 3])
-def test_native_exchange_n_processes_on_one_gpu(oracle, stub, tmp_path, n):
+CASES = [(2, "ragged"), (3, "ragged"), (8, "ragged"), (8, "c4"), (8, "c5")]
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("n,case", CASES)
+def test_native_exchange_n_processes_on_one_gpu(oracle, stub, tmp_path, n, case):
     env = dict(os.environ, MI_RCCL_LIB=stub, MI_RCCL_STUB_SLOT_MB="1")     # 1 MiB slots: rank 0's slab takes rounds
-    procs = [subprocess.Popen([sys.executable, "-c", CHILD_RANK % {"root": ROOT}, str(r), str(n), str(tmp_path)],
+    procs = [subprocess.Popen([sys.executable, "-c", CHILD_RANK % {"root": ROOT}, str(r), str(n), str(tmp_path), case],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(n)]
-    outs = [p.communicate(timeout=300) for p in procs]
+    outs = [p.communicate(timeout=800) for p in procs]
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0 and "OK" in so, so[-1000:] + se[-3000:]
-    _check(oracle, str(tmp_path), n)
+    _check(oracle, str(tmp_path), n, case)
 
 
-@pytest.mark.parametrize("n", [2, 3])
-def test_native_exchange_n_ctxs_in_one_process(oracle, stub, tmp_path, n):
-    """mi_comm_init_all + mi_dedup_allgather_all: the group-start / enqueue / group-end interleaving over
-    n ctxs of one process -- code that had never run with n > 1."""
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("n,case", CASES)
+def test_native_exchange_n_ctxs_in_one_process(oracle, stub, tmp_path, n, case):
+    """mi_comm_init_all + mi_dedup_allgather_all over n ctxs of one process: host-known counts, every
+    allocation and pad copy before the group, the group holding the n all-gathers and nothing else."""
     env = dict(os.environ, MI_RCCL_LIB=stub)
-    r = subprocess.run([sys.executable, "-c", CHILD_ALL % {"root": ROOT}, str(n), str(tmp_path)], env=env,
-                       capture_output=True, text=True, timeout=300)
+    r = subprocess.run([sys.executable, "-c", CHILD_ALL % {"root": ROOT}, str(n), str(tmp_path), case], env=env,
+                       capture_output=True, text=True, timeout=800)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
-    _check(oracle, str(tmp_path), n)
+    _check(oracle, str(tmp_path), n, case)
+
+
+def _bench_line(out):
+    import json
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    return json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+@pytest.mark.timeout(900)
+def test_bench_bare_gpus_8_is_the_library_exchange(stub):
+    """`python bench.py --gpus 8` WITHOUT torchrun: one process, eight ctxs (all on this GPU here), the library's
+    own communicator (mi_comm_init_all) and exchange -- a C4 line with rccl_ranks 8, the closed-form unique
+    count, per-rank step / exchange / marking times and efficiency_vs_n1 from the same run."""
+    env = dict(os.environ, MI_BENCH_FORCE_DEVICE="0", MI_RCCL_LIB=stub)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--files", "20000",
+                          "--steps", "2", "--warmup", "1"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=800)
+    j = _bench_line(out)
+    assert j["n_gpus"] == 8 and j["config"]["name"] == "c4" and j["config"]["rccl_ranks"] == 8
+    assert j["config"]["exchange"] == "native" and "single process" in j["config"]["launch"]
+    assert j["config"]["job_bytes_per_step"] == 8 * 20000 * 65536
+    assert j["dedup_check"]["ok"] and j["dedup_check"]["n_total"] == sum(j["config"]["chunks_per_rank_last_batch"])
+    for k in ("step_ms", "exchange_gather_ms", "marking_ms", "sha_chunks_ms"):       # (the double gathers on the host: ~0 ms)
+        assert len(j["per_rank"][k]) == 8 and all(v > 0 or k == "exchange_gather_ms" for v in j["per_rank"][k]), (k, j["per_rank"][k])
+    assert j["n1_same_run"]["value"] > 0 and 0 < j["efficiency_vs_n1"] < 1.5
+    assert j["roofline"]["frac"] > 0
+
+
+@pytest.mark.timeout(900)
+def test_bench_bare_refuses_without_enough_ranks(stub):
+    """No line when the node cannot give the job its N devices (here: one GPU, no forced device)."""
+    env = dict(os.environ, MI_RCCL_LIB=stub)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MI_BENCH_FORCE_DEVICE"):
+        env.pop(k, None)
+    import torch
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("this node has 8 devices")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--files", "2000"], env=env,
+                         cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and not [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert "device(s)" in out.stderr
+
+
+@pytest.mark.timeout(900)
+def test_bench_torchrun_defaults_to_the_native_exchange(stub):
+    """The driver's launch line (torch.distributed.run, one process per GPU): the exchange is the library's
+    (mi_comm_init_rank + mi_dedup_allgather), torch ships the id and runs the host-side barrier over gloo."""
+    env = dict(os.environ, MI_BENCH_FORCE_DEVICE="0", MI_RCCL_LIB=stub, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4",
+           "--master-addr", "127.0.0.1", "--master-port", "29583", os.path.join(ROOT, "bench.py"),
+           "--gpus", "4", "--files", "20000", "--steps", "2", "--warmup", "1"]
+    j = _bench_line(subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=800))
+    assert j["n_gpus"] == 4 and j["config"]["name"] == "c4" and j["config"]["rccl_ranks"] == 4
+    assert j["config"]["exchange"] == "native" and "gloo" in j["config"]["exchange_backend"]
+    assert "exchange_note" not in j["config"]
+    assert j["dedup_check"]["ok"], j["dedup_check"]
+    assert len(j["per_rank"]["step_ms"]) == 4 and all(v > 0 for v in j["per_rank"]["marking_ms"])
+    assert len(j["n1_same_run"]["per_rank_value"]) == 4 and j["efficiency_vs_n1"] > 0
 
 
 def test_stub_refuses_what_real_rccl_would_hang_on(stub, tmp_path):

@@ -1,0 +1,191 @@
+"""Over-read audit (VERDICT r3 weak #4b): the kernels read past the end of what they hash BY DESIGN -- up to 63
+bytes behind a SHA-256 string (67 with the cooperative loads, 3 in front of an unaligned one), whole 128-byte
+pieces in the Gear marking, 16-byte units in the CRC tiles -- and rely on slack the host code adds behind every
+buffer (256 bytes behind a DevBuf, 4 KiB behind the arena).  Here the hardware checks that reliance:
+MI_GUARD_ALLOC=1 (csrc/mi_alloc.hip) builds every device allocation from the HIP virtual-memory calls so that it
+holds exactly the bytes asked for and ENDS ON AN UNMAPPED PAGE; a load that leaves the slack kills the process
+with "Memory access fault by GPU".  Each scenario runs in its own process on shapes whose last string / file /
+tile ends on the last byte the engine put into the buffer -- the arena sized exactly (mi_batch_reserve), every
+residue of the last file's length, both SHA load schemes, the file pass, the CRC tiles, the root pass over
+digest arrays, mi_sha256_many, the large-file kernels, host-fed bytes -- and must finish with the digests
+hashlib and zlib give.  The reference's contract at this place: tario.WriteEntry copies exactly h.Size bytes
+(lib/tario/write.go:43-45).
+
+MI_TEST_GUARD_FAULT=1 adds the positive control (a read 2 KiB past a guarded buffer must kill the process); it
+is opt-in because a deliberate GPU fault has no place in a suite that shares its box with what runs next
+(profiles/r04_overread_audit.txt holds one run of it)."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+COMMON = r"""
+import hashlib, os, sys, zlib
+import numpy as np
+sys.path.insert(0, %(root)r)
+import makisu_amd as M
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+scheme = {"lane": M.SHA_LOADS_LANE, "coop": M.SHA_LOADS_COOP}[sys.argv[2] if len(sys.argv) > 2 else "lane"]
+
+def blob(n):
+    return rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+
+def check_batch(eng, blobs, reserve_exact=True, via="bytes", tmp=None):
+    # the LAST file ends on the last byte the engine puts into the arena
+    b = eng.batch()
+    if reserve_exact:
+        b.reserve(len(blobs), sum((len(x) + 255) // 256 * 256 for x in blobs[:-1]) + len(blobs[-1]))
+    for i, x in enumerate(blobs):
+        if via == "bytes":
+            b.add_bytes(x, i)
+        else:
+            p = os.path.join(tmp, "f%%d" %% i)
+            open(p, "wb").write(x)
+            b.add_path(p, len(x), i)
+    b.run()
+    files, chunks = b.files(), b.chunks()
+    assert len(files) == len(blobs)
+    for i, x in enumerate(blobs):
+        f = files[i]
+        assert bytes(f["file_sha256"]) == hashlib.sha256(x).digest(), ("file sha", i, len(x))
+        assert int(f["crc32"]) == zlib.crc32(x), ("crc", i, len(x))
+        first, n = int(f["first_chunk"]), int(f["n_chunks"])
+        at = 0
+        for c in chunks[first:first + n]:
+            assert int(c["offset"]) == at
+            piece = x[at:at + int(c["length"])]
+            assert bytes(c["sha256"]) == hashlib.sha256(piece).digest(), ("chunk sha", i, at)
+            at += int(c["length"])
+        assert at == len(x)
+        digs = b"".join(bytes(c["sha256"]) for c in chunks[first:first + n])
+        assert bytes(f["chunk_root"]) == M.chunk_root(digs), ("root", i)
+    b.free()
+    return len(chunks)
+"""
+
+SCENARIOS = {
+    # every residue of the last file's length mod 256 (and so mod 16 / 64 / 128), small files
+    "small_tails": r"""
+with M.Engine(flags=M.FLAG_FILE_SHA256 | M.FLAG_FILE_CRC32, sha_load_scheme=scheme) as e:
+    for last in list(range(1, 130)) + [191, 192, 193, 255, 256, 257, 4095, 4096, 4097, 65535, 65536]:
+        check_batch(e, [blob(3000), blob(777), blob(last)])
+    check_batch(e, [blob(1)])
+    check_batch(e, [blob(65536)] * 3 + [blob(65536 - 1)])
+print("OK")
+""",
+    # the tile / group kernels: files above 64 KiB whose last tile is a few bytes, or full
+    "large_tails": r"""
+with M.Engine(flags=M.FLAG_FILE_SHA256 | M.FLAG_FILE_CRC32, sha_load_scheme=scheme) as e:
+    for size in (65537, 65536 + 63, 131072, 262144 - 1, 262144, 262144 + 1, 262144 * 3 + 17, 262144 * 2 + 65536,
+                 1048576 + 127, 5 * 262144 + 65535):
+        check_batch(e, [blob(100), blob(size)])
+    check_batch(e, [blob(262144 * 4), blob(9), blob(262144 * 4 + 33)])
+print("OK")
+""",
+    # no candidates (32 mask bits): every chunk is max_size long -- digest arrays of 1, 64, 65, 4097 rows through the root pass
+    "root_pass": r"""
+with M.Engine(flags=M.FLAG_FILE_SHA256, sha_load_scheme=scheme, min_size=64, max_size=128, mask_bits=32) as e:
+    for n_chunks in (1, 2, 63, 64, 65, 127, 128, 129, 4096, 4097):
+        b = e.batch()
+        data = blob(128 * n_chunks - 5)
+        b.reserve(1, len(data))
+        b.add_bytes(data, 0)
+        b.run()
+        f, ch = b.files()[0], b.chunks()
+        assert int(f["n_chunks"]) == n_chunks == len(ch)
+        assert bytes(f["chunk_root"]) == M.chunk_root(b"".join(bytes(c["sha256"]) for c in ch))
+        assert bytes(f["file_sha256"]) == hashlib.sha256(data).digest()
+        b.free()
+print("OK")
+""",
+    "sha256_many": r"""
+with M.Engine(sha_load_scheme=scheme) as e:
+    for trial in range(6):
+        lens = [int(x) for x in rng.integers(0, 300, 40)] + [trial, 64 * trial + 55, 64 * trial + 56, 64 * trial + 63, 64 * trial + 64]
+        lens.append([1, 63, 64, 65, 119, 120][trial])          # the LAST blob ends the staging buffer
+        blobs = [blob(n) for n in lens]
+        got = e.sha256_many(blobs)
+        assert got == [hashlib.sha256(x).digest() for x in blobs], trial
+    got = e.sha256_many([blob(1 << 20), blob(3)])
+    assert len(got) == 2
+print("OK")
+""",
+    # the same through the reader threads: files from disk, and an arena that was NOT reserved (it grows)
+    "host_fed": r"""
+import tempfile
+with tempfile.TemporaryDirectory() as tmp, M.Engine(flags=M.FLAG_FILE_SHA256 | M.FLAG_FILE_CRC32, sha_load_scheme=scheme) as e:
+    check_batch(e, [blob(5000), blob(1 << 20), blob(77)], via="path", tmp=tmp)
+    check_batch(e, [blob(3 << 20), blob(65536 + 1)], via="path", tmp=tmp)
+    check_batch(e, [blob(100000), blob(2 << 20), blob(1)], reserve_exact=False)
+    check_batch(e, [blob(9 << 20)], reserve_exact=True)          # larger than a slab: pieces
+print("OK")
+""",
+    # duplicate marking, the chunk index and the packed row view over exactly-sized tables
+    "tables": r"""
+with M.Engine(sha_load_scheme=scheme) as e:
+    x = blob(200000)
+    b = e.batch()
+    for i in range(7):
+        b.add_bytes(x if i % 2 else blob(65536 + i), i)
+    b.run()
+    ch = b.chunks()
+    view = b.chunks_view()
+    assert np.array_equal(view["sha256"], ch["sha256"]) and (ch["dup_of"] >= 0).any()
+    with e.index() as ix:
+        ix.add_batch(b)
+        ix.add_batch(b)
+        assert len(ix) == len({bytes(c) for c in ch["sha256"]})
+    b.free()
+print("OK")
+""",
+}
+
+FAULT = r"""
+with M.Engine() as e:
+    b = e.batch()
+    b.add_bytes(blob(65536 * 4), 0)
+    b.run()
+    ptr, n = b.device_digests()
+    out = e.batch()                                  # device memory for the answers: ~8 000 rows x 32 B, enough for n + 4096 words
+    out.add_bytes(blob(64 << 20), 0)
+    out.run()
+    dptr, _ = out.device_digests()
+    print("READING PAST THE GUARD", flush=True)
+    e.dedup_mark(ptr, n + 4096, dptr)                # 128 KiB of rows that do not exist: must never return
+print("SURVIVED")
+"""
+
+
+def _run(name, body, scheme, timeout=600):
+    env = dict(os.environ, MI_GUARD_ALLOC="1")
+    code = COMMON % {"root": ROOT} + textwrap.dedent(body)
+    return subprocess.run([sys.executable, "-c", code, "7", scheme], env=env, capture_output=True, text=True,
+                          timeout=timeout)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("scheme", ["lane", "coop"])
+@pytest.mark.parametrize("name", sorted(SCENARIOS))
+def test_no_read_leaves_the_slack(name, scheme):
+    r = _run(name, SCENARIOS[name], scheme)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), \
+        "%s/%s died or differed:\n%s\n%s" % (name, scheme, r.stdout[-1500:], r.stderr[-3000:])
+
+
+def test_guard_mode_is_off_by_default_and_costs_nothing(engine_lib):
+    """the product never turns the guard on by itself: only the environment variable does"""
+    src = open(os.path.join(ROOT, "makisu_amd", "csrc", "mi_alloc.hip")).read()
+    assert src.count('getenv("MI_GUARD_ALLOC")') == 1
+    assert "MI_GUARD_ALLOC" not in open(os.path.join(ROOT, "makisu_amd", "__init__.py")).read()
+
+
+@pytest.mark.skipif(os.environ.get("MI_TEST_GUARD_FAULT") != "1", reason="deliberate GPU fault: opt-in (MI_TEST_GUARD_FAULT=1)")
+def test_the_guard_has_teeth():
+    r = _run("fault", FAULT, "lane", timeout=120)
+    assert "READING PAST THE GUARD" in r.stdout and "SURVIVED" not in r.stdout and r.returncode != 0, r.stdout + r.stderr[-2000:]
+    print(r.stderr[-600:])

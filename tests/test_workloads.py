@@ -114,13 +114,13 @@ def test_c5_several_ranks_split_the_large_files_into_parts():
 
 
 def test_bench_default_batches_in_flight():
-    """bench.py: one batch at a time on one GPU without an exchange (its kernel durations are then the kernels' own),
-    two with an exchange to hide, three for the small config."""
+    """bench.py: two batches in flight (the steady state `value` is quoted on since round 4, as in rounds 1-2; the
+    roofline comes from the one-batch-at-a-time steps of the same run), three for the small config with an exchange."""
     import importlib.util
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(root, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    assert [bench.default_inflight(c, False) for c in ("c2", "c3", "c4", "c5", "c5u")] == [1, 1, 1, 1, 1]
+    assert [bench.default_inflight(c, False) for c in ("c2", "c3", "c4", "c5", "c5u")] == [2, 2, 2, 2, 2]
     assert bench.default_inflight("c2", True) == 3 and bench.default_inflight("c4", True) == 2
     assert bench.default_inflight("c5", True) == 2
