@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 3
+#define MI_ABI_VERSION 4
 
 enum {
     MI_OK = 0,
@@ -488,36 +488,6 @@ int  mi_tar_inflate(const char* blob_path, const char* tar_path_out, uint64_t* t
 int  mi_tar_entries(const mi_tar* tar, mi_tree_entry* out, uint64_t* data_offsets, uint64_t cap);
 void mi_tar_free(mi_tar* tar);
 
-/* A layer's entries applied on top of a tree -- MemFS.UpdateFromTarReader (lib/snapshot/mem_fs.go:165-255:
- * maybeAddToLayer :440-458, isUpdated :487-503, addAncestors :505-566, updateMemFS lib/snapshot/mem_layer.go:50-76,
- * 104-125) on entry lists, header by header on a tree of the reference's shape: ".wh.<name>" markers delete
- * <dir>/<name> with its subtree and are not part of the result; an entry whose header is similar to the one
- * already there changes nothing (the OLD entry stays); a directory keeps what the tree holds below its path,
- * anything else replaces the path and its subtree; a symlink or file that is somebody's ancestor loses the
- * children it had; "./" never replaces the root.  Result: the merged tree in sorted-path order, entry k =
- * layer[index[k]] if from_layer[k] else base[index[k]].  *n_out = its size (MI_ERR_CAPACITY if cap is smaller;
- * call with cap 0 to size).  The directories addAncestors CREATES for an entry whose parents are in neither
- * list (the nearest ancestor's mode, mtime = now) are in the tree while the layer is applied but, having no entry
- * to point at, not in the result: the entry comes back without them.  Where the reference fails the build --
- * "missing intermediate directory" for an entry two levels below a symlink or file, "symlink loop" -- the call
- * returns MI_ERR_INVALID and mi_last_error(NULL) the reference's message ("add hdr from tar to layer: ...").
- * Host logic.                                                                                              */
-int mi_entries_apply_layer(const mi_tree_entry* base, uint64_t n_base, const mi_tree_entry* layer,
-                           uint64_t n_layer, uint8_t* from_layer, uint64_t* index, uint64_t cap,
-                           uint64_t* n_out);
-/* The same with UpdateFromTarReader's per-header filter (mem_fs.go:190-199): with `root` = the
- * directory the layers are (or would be) untarred to, a header is dropped when shouldSkip says so
- * for filepath.Join(root, name) -- ".wh..wh." AUFS metadata, blacklist descendants, special files
- * (kind 4), mountpoints -- or when it lies under a mountpoint (mountutils.IsMounted).  Use it for
- * base layers, so that /proc, /sys, /dev nodes or /etc/resolv.conf of the base image never enter
- * the "before" side of mi_snapshot_diff (the scan walk skips them too).  Hard links are applied
- * in a second pass after all other entries (:219-236).  root NULL = no filter.               */
-int mi_entries_apply_layer_filtered(const mi_tree_entry* base, uint64_t n_base,
-                                    const mi_tree_entry* layer, uint64_t n_layer, const char* root,
-                                    const char* const* blacklist, uint64_t n_blacklist,
-                                    uint8_t* from_layer, uint64_t* index, uint64_t cap,
-                                    uint64_t* n_out);
-
 /* The layer diff of a scan, on two walks -- what MemFS.createLayerByScan + maybeAddToLayer
  * (lib/snapshot/mem_fs.go:315-341, 440-480) decide against the in-memory tree:
  *   after_flags[i]      MI_DIFF_CHANGED  the path is new or mi_entry_similar says it changed
@@ -553,7 +523,7 @@ int mi_snapshot_diff(const mi_snapshot_side* before, const mi_snapshot_side* aft
  * addToLayer + maybeAddToLayer + addAncestors (lib/snapshot/mem_fs.go:276-289, 343-421, 440-566)
  * and CopyOperation's source handling (lib/snapshot/copy_op.go:29-100, utils.go:249-327):
  *   tree / tree_root  the merged view so far (entries with relpaths below tree_root, e.g. the
- *                     result of mi_entries_apply_layer) and the directory it describes;
+ *                     result of mi_memfs_entries) and the directory it describes;
  *   ops               one per COPY/ADD: srcs relative to src_root (symlinks inside src_root are
  *                     resolved, one leaving it is an error), dst absolute, "dir/" = copy INTO it;
  *                     a single non-directory source with a dst not ending in "/" copies onto dst;
@@ -579,55 +549,24 @@ typedef struct {
 /* NewCopyOperation's parameter check and destination (lib/snapshot/copy_op.go:44-81, 149-180): no sources, several
  * sources with a dst that is not in directory format (trailing "/", "." or ".."), or a relative dst without an
  * absolute work_dir are MI_ERR_INVALID ("check copy param: ..."); otherwise dst_out = dst if absolute, else
- * filepath.Join(work_dir, dst) with a trailing "/" kept.  mi_snapshot_copy_ops applies the same check to the (already
- * resolved, hence absolute) dst of every op.  Host logic.                                                        */
+ * filepath.Join(work_dir, dst) with a trailing "/" kept.  mi_memfs_add_layer_by_copy_ops applies the same check to the
+ * (already resolved, hence absolute) dst of every op.  Host logic.                                                        */
 int  mi_copy_op_resolve(uint64_t n_srcs, const char* work_dir, const char* dst, char* dst_out, uint64_t cap,
                         char* err, uint64_t err_cap);
-/* The rest of the caller's side of a COPY/ADD step.
- * mi_resolve_chown: NewCopyOperation's --chown handling (lib/snapshot/copy_op.go:51-60 -> utils.ResolveChown,
- *   lib/utils/utils.go:186-228): "" = 0:0; "<user>[:<group>]", each a decimal number or a name from the user / group
- *   database; no group = the uid; chown together with preserve_owner (--archive) is an error.  MI_ERR_INVALID + the
- *   reference's message in err.
- * mi_path_match: path/filepath.Match of the Go toolchain the reference builds with ('*' and '?' never match '/',
- *   "[^a-c]" classes on runes, '\\' escapes; MI_ERR_INVALID = ErrBadPattern).
- * mi_context_sources: addCopyStep.resolveFromPaths (lib/builder/step/add_copy_step.go:171-185): every source is joined
- *   to the context root and expanded with filepath.Glob (matches of one pattern in sorted order); a pattern that
- *   matches nothing, or is malformed, stands for itself.  out = the resolved paths, NUL-terminated, back to back (*n_out
- *   paths, *bytes_out bytes; MI_ERR_CAPACITY if cap is smaller: call with cap 0 to size).  Each goes to
- *   mi_batch_add_tree(..., rel_base = context dir, MI_TREE_CONTEXT) in this order for the cache ID, and -- trimmed of
- *   the root -- into mi_copy_op.srcs.  Host logic.                                                                */
-int  mi_resolve_chown(const char* chown, int preserve_owner, int64_t* uid, int64_t* gid, char* err, uint64_t err_cap);
-int  mi_path_match(const char* pattern, const char* name, int* matched);
-int  mi_context_sources(const char* context_root, const char* const* from_paths, uint64_t n_paths, char* out,
-                        uint64_t cap, uint64_t* n_out, uint64_t* bytes_out);
-/* CopyOperation.Execute (lib/snapshot/copy_op.go:83-147) over fileio.Copier (lib/fileio/copy.go): the on-disk copy of the
- * step, for builds that modify the file system.  op as for mi_snapshot_copy_ops (dst resolved; "dir/" = copy INTO it).
- * flags: MI_COPY_CHOWN --chown was given (owner = op->uid/gid for everything copied and for a destination directory
- * that has to be created); MI_COPY_INTERNAL the sources are a previous stage's (--from: no blacklist, owners kept);
- * MI_COPY_PRESERVE_OWNER --archive (a created destination directory gets the source's owner).  Without flags: from the
- * context, everything owned by 0:0.  Missing ancestors of the destination are created 0755 root:root; permission bits
- * are kept, mtimes are not; a symlink is copied as a link; special files are skipped; a source directory that contains
- * the destination does not recurse into it.  MI_ERR_IO + the reference's message.  Host logic.                        */
-#define MI_COPY_CHOWN          0x1u
-#define MI_COPY_INTERNAL       0x2u
-#define MI_COPY_PRESERVE_OWNER 0x4u
-int  mi_copy_op_execute(const mi_copy_op* op, uint32_t flags, const char* const* blacklist, uint64_t n_blacklist,
-                        char* err, uint64_t err_cap);
 typedef struct mi_copy_layer mi_copy_layer;
-int  mi_snapshot_copy_ops(const mi_tree_entry* tree, uint64_t n_tree, const char* tree_root,
-                          const mi_copy_op* ops, uint64_t n_ops, int64_t now_sec,
-                          mi_copy_layer** out, uint64_t* n_entries, char* err, uint64_t err_cap);
 int  mi_copy_layer_entries(const mi_copy_layer* layer, mi_tree_entry* out, const char** src_paths,
                            uint64_t cap);
 void mi_copy_layer_free(mi_copy_layer* layer);
 
 /* ---- MemFS as a handle: the reference's type (lib/snapshot/mem_fs.go:59-125) ------------------------------------- *
  * One tree for the life of a build, nodes of the reference's shape (header + children + the path the content came
- * from).  The stateless calls above (mi_entries_apply_layer, mi_snapshot_diff, mi_snapshot_copy_ops) answer one
- * question each on entry lists; this keeps what lies between the questions -- the directories addAncestors created
- * (they are nodes like any other here, and part of mi_memfs_entries), and memFSNode.src, which is what isOnDisk asks
- * the disk about (mem_fs.go:49-57: a file a COPY step added is "on disk" while its SOURCE exists, whether or not the
- * step modified the file system).
+ * from).  This is the ONE implementation of the layer merge and of the copy-op layer behind this header (until ABI 3
+ * there were stateless twins on entry lists, mi_entries_apply_layer and mi_snapshot_copy_ops; they could not name the
+ * directories addAncestors creates and are gone).  The handle keeps what lies between a build's steps -- those
+ * directories (nodes like any other, part of mi_memfs_entries) and memFSNode.src, which is what isOnDisk asks the
+ * disk about (mem_fs.go:49-57: a file a COPY step added is "on disk" while its SOURCE exists, whether or not the step
+ * modified the file system).  mi_snapshot_diff above stays as the stateless form of ONE question (the scan diff of two
+ * walks), held against mi_memfs_add_layer_by_scan on generated trees.
  *   mi_memfs_create           NewMemFS(clk, root, blacklist): the root's header from lstat(root); now_sec = the clock
  *                             (mtime of created directories; mi_memfs_set_clock moves it).
  *   mi_memfs_update_from_entries  UpdateFromTarReader with untar = false on a layer's entries (mi_tar_entries): the
@@ -641,7 +580,7 @@ void mi_copy_layer_free(mi_copy_layer* layer);
  *                             per deleted subtree (if the child's src is really gone).  roots / root_stride: chunk roots
  *                             by file_index, kept in the tree, so that the NEXT scan's isUpdated is content-aware
  *                             (NULL = the reference's metadata-only rule).
- *   mi_memfs_add_layer_by_copy_ops   AddLayerByCopyOps: mi_snapshot_copy_ops against this tree.
+ *   mi_memfs_add_layer_by_copy_ops   AddLayerByCopyOps (mem_fs.go:276-289): addToLayer per mi_copy_op against this tree.
  * Both return the layer in commit order as an mi_copy_layer (mi_copy_layer_entries: headers + the path each entry's
  * bytes are read from; a whiteout is an entry named ".wh.<x>" without content) and fold it into the tree.  A failing
  * call returns the error code, mi_memfs_error() the reference's message, and leaves the handle usable.
@@ -656,25 +595,11 @@ const char* mi_memfs_error(const mi_memfs* fs);
 int  mi_memfs_set_clock(mi_memfs* fs, int64_t now_sec);
 int  mi_memfs_reset(mi_memfs* fs);
 int  mi_memfs_update_from_entries(mi_memfs* fs, const mi_tree_entry* layer, uint64_t n_layer, uint64_t* n_merged);
-/* UpdateFromTarReader with untar = true (the FROM step / a cached layer applied with --modifyfs): the entries of a PLAIN
- * tar -- mi_tar_entries(tar) with their data offsets; a gzip blob goes through mi_tar_inflate first -- are written below
- * the root as MemFS.untarOneItem does (lib/snapshot/mem_fs.go:571-718): a ".wh.<x>" entry removes <x>; what is already
- * on disk with a similar header stays; a directory on a directory is updated in place (tario.ApplyHeader: chown, chmod,
- * mtime); anything else is removed and created again; an absolute symlink target is re-rooted; hard links come last; the
- * mtimes of the parent directories are put back at the end -- and every header is merged into the tree as above.  After
- * it a scan of the root finds nothing to add.  Needs the privileges the reference needs (chown).  MI_ERR_IO + the
- * reference's message ("untar one item <path>: ...") on failure.                                                  */
-int  mi_memfs_untar(mi_memfs* fs, const char* tar_path, const mi_tree_entry* layer, const uint64_t* data_offsets,
-                    uint64_t n_layer, uint64_t* n_merged);
 int  mi_memfs_add_layer_by_scan(mi_memfs* fs, const mi_tree_entry* walked, uint64_t n, const void* roots,
                                 uint64_t root_stride, mi_copy_layer** out, uint64_t* n_entries);
 int  mi_memfs_add_layer_by_copy_ops(mi_memfs* fs, const mi_copy_op* ops, uint64_t n_ops, mi_copy_layer** out,
                                     uint64_t* n_entries);
 int  mi_memfs_entries(const mi_memfs* fs, mi_tree_entry* out, const char** src_paths, uint64_t cap, uint64_t* n_out);
-/* MemFS.Checkpoint (mem_fs.go:132-185): what a later stage will COPY --from is copied aside, to new_root + the path it has
- * below the root (patterns expanded like COPY sources; relative sources are below the root; the blacklist of the handle
- * applies; a created target directory gets the source's owner, everything copied keeps its own).                    */
-int  mi_memfs_checkpoint(mi_memfs* fs, const char* new_root, const char* const* sources, uint64_t n_sources);
 
 /* ---- the layer writer: tar framing + the two serial layer digests (host threads) ---------- *
  * step.tarAndGzipDiffs + MemFS.commitLayer (lib/builder/step/common.go:35-111,

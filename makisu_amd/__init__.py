@@ -228,10 +228,6 @@ def load_library(rebuild=False):
         "mi_tree_free": ([vp], None),
         "mi_entries_commit_order": ([C.POINTER(TreeEntry), u64, u64p], C.c_int),
         "mi_snapshot_diff": ([C.POINTER(SnapshotSide), C.POINTER(SnapshotSide), C.c_int, vp, vp], C.c_int),
-        "mi_entries_apply_layer": ([C.POINTER(TreeEntry), u64, C.POINTER(TreeEntry), u64, vp, u64p, u64, u64p],
-                                   C.c_int),
-        "mi_entries_apply_layer_filtered": ([C.POINTER(TreeEntry), u64, C.POINTER(TreeEntry), u64, C.c_char_p,
-                                             C.POINTER(C.c_char_p), u64, vp, u64p, u64, u64p], C.c_int),
         "mi_tar_open": ([C.c_char_p, C.POINTER(vp), u64p], C.c_int),
         "mi_tar_open_ex": ([C.c_char_p, C.POINTER(vp), u64p, C.POINTER(C.c_int), C.c_char_p, u64], C.c_int),
         "mi_tar_inflate": ([C.c_char_p, C.c_char_p, u64p, vp, vp, C.c_char_p, u64], C.c_int),
@@ -239,8 +235,6 @@ def load_library(rebuild=False):
         "mi_tar_free": ([vp], None),
         "mi_entry_similar": ([C.POINTER(TreeEntry), C.POINTER(TreeEntry), C.c_int, vp, vp,
                               C.POINTER(C.c_int)], C.c_int),
-        "mi_snapshot_copy_ops": ([C.POINTER(TreeEntry), u64, C.c_char_p, C.POINTER(CopyOp), u64, C.c_int64,
-                                  C.POINTER(vp), u64p, C.c_char_p, u64], C.c_int),
         "mi_copy_op_resolve": ([u64, C.c_char_p, C.c_char_p, C.c_char_p, u64, C.c_char_p, u64], C.c_int),
         "mi_resolve_chown": ([C.c_char_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_char_p, u64], C.c_int),
         "mi_path_match": ([C.c_char_p, C.c_char_p, C.POINTER(C.c_int)], C.c_int),
@@ -405,23 +399,23 @@ def _entry_array(dicts, keep):
 
 
 def apply_layer(base, layer, root=None, blacklist=()):
-    """mi_entries_apply_layer[_filtered] on two lists of entry dicts: the merged list (the dicts
-    themselves, in sorted-path order).  root: apply UpdateFromTarReader's skip rules for layers
-    untarred to that directory (blacklist, special files, ".wh..wh." metadata, mounts)."""
-    keep = []
-    ab, al = _entry_array(base, keep), _entry_array(layer, keep)
-    cap = len(base) + len(layer)
-    src = np.zeros(max(cap, 1), dtype=np.uint8)
-    idx = np.zeros(max(cap, 1), dtype=np.uint64)
-    n = C.c_uint64()
-    bl = (C.c_char_p * max(len(blacklist), 1))(*[os.fsencode(x) for x in blacklist])
-    rc = load_library().mi_entries_apply_layer_filtered(
-        ab, len(base), al, len(layer), os.fsencode(root) if root is not None else None, bl, len(blacklist),
-        src.ctypes.data, idx.ctypes.data_as(C.POINTER(C.c_uint64)), cap, C.byref(n))
-    if rc:
-        why = load_library().mi_last_error(None) if rc == -1 else b""
-        raise MiError(rc, "mi_entries_apply_layer" + (": " + why.decode("utf-8", "replace") if why else ""))
-    return [(layer if src[k] else base)[int(idx[k])] for k in range(n.value)]
+    """Harness helper over the MemFS handle (the library has ONE layer merge, mi_memfs_update_from_entries):
+    UpdateFromTarReader of `base`, then of `layer`, into a fresh tree; returns mi_memfs_entries -- the merged tree in
+    sorted-path order as entry dicts (relpaths without the leading "/", a "src" key; the directories addAncestors
+    created are entries like any other).  root = the directory the layers are (or would be) untarred to: its
+    blacklist / mountpoint filter applies; None = an empty scratch directory, where nothing is mounted or
+    blacklisted (special files and ".wh..wh." metadata are skipped either way, as in the reference)."""
+    import tempfile
+    scratch = tempfile.mkdtemp(prefix="mi_memfs_") if root is None else None
+    try:
+        with MemFS(root if root is not None else scratch, blacklist) as fs:
+            if base:
+                fs.update_from_entries(base)
+            fs.update_from_entries(layer)
+            return fs.entries()
+    finally:
+        if scratch:
+            os.rmdir(scratch)
 
 
 def snapshot_diff(before, after, ignore_time=False, roots_before=None, roots_after=None, disk_root=None):
@@ -573,19 +567,13 @@ def copy_op_execute(op, chown=False, internal=False, preserve_owner=False, black
 
 
 def copy_ops_layer(tree, tree_root, ops, now_sec=0):
-    """mi_snapshot_copy_ops: tree = list of entry dicts, ops = list of dicts(src_root, srcs, dst, uid,
-    gid).  Returns the layer as a list of entry dicts (commit order) with an extra "src" key."""
-    L = load_library()
-    keep = []
-    arr = _entry_array(tree, keep)
-    cops = _copy_op_array(ops, keep)
-    h, n = C.c_void_p(), C.c_uint64()
-    err = C.create_string_buffer(600)
-    rc = L.mi_snapshot_copy_ops(arr, len(tree), os.fsencode(tree_root), cops, len(ops), now_sec, C.byref(h),
-                                C.byref(n), err, len(err))
-    if rc:
-        raise MiError(rc, "mi_snapshot_copy_ops: %s" % err.value.decode(errors="replace"))
-    return _take_copy_layer(L, h, n.value)
+    """Harness helper over the MemFS handle: a tree rooted at tree_root (an existing directory) that holds `tree`
+    (entry dicts, merged as a base layer would be), then AddLayerByCopyOps(ops) -- ops = dicts(src_root, srcs, dst,
+    uid, gid).  Returns the layer as entry dicts in commit order with an extra "src" key."""
+    with MemFS(tree_root, now_sec=now_sec) as fs:
+        if tree:
+            fs.update_from_entries(tree)
+        return fs.add_layer_by_copy_ops(ops)
 
 
 class MemFS:

@@ -1,11 +1,13 @@
 // mi_memfs.hip -- the reference's MemFS and what surrounds a COPY/ADD step, on the host (no device code here):
-//   * the copy-op layer (MemFS.addToLayer) on entry lists and, as a handle, MemFS itself: UpdateFromTarReader with and
-//     without untar, AddLayerByScan, AddLayerByCopyOps, step.commitLayer in one call, Checkpoint, Reset;
+//   * MemFS as a handle -- the one implementation of the layer merge and the copy-op layer (MemFS.addToLayer):
+//     UpdateFromTarReader with and without untar, AddLayerByScan, AddLayerByCopyOps, step.commitLayer in one call,
+//     Checkpoint, Reset;
 //   * CopyOperation.Execute over fileio.Copier; MemFS.untarOneItem + tario.ApplyHeader;
 //   * the caller's side of the step: --chown (utils.ResolveChown), source patterns (filepath.Match / Glob as
 //     addCopyStep.resolveFromPaths uses them), NewCopyOperation's checks.
 // Every function cites the Go it restates; the tree they share is mi_memtree.h, the walks are mi_tree.hip's.
 #include "mi_memtree.h"
+#include "../../include/makisu_mi_host.h"      // the optional helpers defined here (Execute, chown, glob, untar, checkpoint)
 
 #include <dirent.h>
 #include <errno.h>
@@ -594,43 +596,6 @@ static int copy_ops_into(mi_copy::Fs& fs, const mi_copy_op* ops, uint64_t n_ops,
         }
     }
     if (fs.rc) { put_err(fs.err); return fs.rc; }
-    return MI_OK;
-}
-
-extern "C" int mi_snapshot_copy_ops(const mi_tree_entry* tree, uint64_t n_tree, const char* tree_root,
-                                    const mi_copy_op* ops, uint64_t n_ops, int64_t now_sec,
-                                    mi_copy_layer** out, uint64_t* n_entries, char* err, uint64_t err_cap) {
-    auto put_err = [&](const std::string& m) { if (err && err_cap) snprintf(err, (size_t)err_cap, "%s", m.c_str()); };
-    if ((n_tree && !tree) || (n_ops && !ops) || !out || !tree_root) return MI_ERR_INVALID;
-    mi_copy::Fs fs;
-    fs.root = mi_walk::abs_path(tree_root);
-    fs.now = now_sec;
-    {   // the root node always exists (NewMemFS stats it)
-        mi_copy::Node r;
-        r.e.kind = 0;
-        r.e.mode = S_IFDIR | 0755;
-        struct stat st;
-        if (lstat(fs.root.c_str(), &st) == 0) { r.e.mode = st.st_mode; r.e.mtime = st.st_mtime; r.e.uid = st.st_uid; r.e.gid = st.st_gid; }
-        fs.t.root.ref = fs.keep(r);
-    }
-    for (uint64_t i = 0; i < n_tree; ++i) {
-        const mi_tree_entry& e = tree[i];
-        mi_copy::Node n;
-        const char* rp = e.relpath ? e.relpath : "";
-        const std::string p = mi_walk::abs_path(strcmp(rp, ".") == 0 ? "" : rp);
-        n.e.relpath = p == "/" ? "" : p.substr(1);
-        n.e.kind = e.kind; n.e.mode = e.mode; n.e.mtime = e.mtime_sec; n.e.uid = e.uid; n.e.gid = e.gid; n.e.size = e.size;
-        if (e.link_target) { n.e.link = e.link_target; n.e.has_link = true; }
-        n.src = fs.root == "/" ? p : fs.root + (p == "/" ? "" : p);
-        fs.t.load(p, fs.keep(n), n.e.kind, e.link_target);
-    }
-    std::string e;
-    const int rc = copy_ops_into(fs, ops, n_ops, &e);
-    if (rc) { put_err(e); return rc; }
-    mi_copy_layer* l = new mi_copy_layer();
-    l->nodes = fs.sorted_layer();
-    *out = l;
-    if (n_entries) *n_entries = l->nodes.size();
     return MI_OK;
 }
 

@@ -1,5 +1,5 @@
 // mi_memtree.h -- the reference's in-memory tree (memFSNode) and the operations every layer-building path goes through.
-// Header-only; users: mi_tree.hip (the stateless layer merge), mi_memfs.hip (copy ops, the MemFS handle).
+// Header-only; user: mi_memfs.hip (the MemFS handle: layer merge, scan layer, copy ops).
 #pragma once
 #include "mi_hostpath.h"
 

@@ -631,145 +631,6 @@ extern "C" int mi_snapshot_diff(const mi_snapshot_side* before, const mi_snapsho
     return MI_OK;
 }
 
-// Applying a layer's entries on top of a tree, the way MemFS.UpdateFromTarReader does header by
-// header (lib/snapshot/mem_fs.go:165-255) through maybeAddToLayer / addAncestors / updateMemFS, on a tree of the
-// reference's own shape (a node = a header and a children map):
-//   * with a filter (root != NULL) every header first passes the reference's skip rules on
-//     path = filepath.Join(root, hdr.Name): AUFS metadata (".wh..wh." base names), blacklist
-//     descendants, special files (shouldSkip, utils.go:37-52), mountpoints and everything under
-//     one (mountutils.IsMounted) never enter the tree -- so /proc, /dev/null, /etc/resolv.conf of a
-//     base image are not "deleted" later when the scan walk skips them too;
-//   * hard links wait for a second pass after every other entry (:219-236), one header per path (the reference keeps
-//     them in a map and ranges over it in no particular order; here: sorted by path), and their targets compare as
-//     pathutils.AbsPath(linkname) (:214-216);
-//   * the root is never touched ("./" of a layer: "Root itself is not added to layers", :447);
-//   * an entry whose header is similar to what is already at its path changes nothing -- the old entry (and so the
-//     old content) stays;
-//   * otherwise its ancestors come first (addAncestors :505-566): a directory on the way stays as it is, a symlink or
-//     file on the way LOSES its children (it is re-added through updateMemFS, which only lets directories keep them), a
-//     symlink then sends the walk to its target and ends it, and what is missing of the entry's own prefix is created
-//     as directories -- these carry no entry of either list, so they are never part of the result, but they are in
-//     the tree while the layer is applied;
-//   * then the entry itself (mem_layer.go:50-76, 197-212): a whiteout marker ".wh.<name>" removes <dir>/<name> with
-//     everything below it and is not itself part of the tree; a directory takes over what the tree holds below its
-//     path, whatever was AT the path before; anything else replaces the path together with its subtree;
-//   * where the reference gives up, so does this call, MI_ERR_INVALID with the reference's words in
-//     mi_last_error(NULL): "missing intermediate directory" (an entry two levels below a symlink or file: updateMemFS
-//     finds nothing to descend into), "symlink loop" (depth 1024).
-// Output: the merged tree in sorted-path order as (from_layer, index) pairs.
-extern "C" int mi_entries_apply_layer_filtered(const mi_tree_entry* base, uint64_t n_base,
-                                               const mi_tree_entry* layer, uint64_t n_layer, const char* root,
-                                               const char* const* blacklist, uint64_t n_blacklist,
-                                               uint8_t* from_layer, uint64_t* index, uint64_t cap,
-                                               uint64_t* n_out) {
-    if ((n_base && !base) || (n_layer && !layer) || !n_out || (cap && (!from_layer || !index)) ||
-        (n_blacklist && !blacklist))
-        return MI_ERR_INVALID;
-    auto path_of = [](const mi_tree_entry& e) {
-        const char* rp = e.relpath ? e.relpath : "";
-        return mi_walk::abs_path(strcmp(rp, ".") == 0 ? "" : rp);
-    };
-    std::vector<std::string> bl;
-    for (uint64_t i = 0; i < n_blacklist; ++i) bl.push_back(mi_walk::abs_path(blacklist[i] ? blacklist[i] : ""));
-    const std::string root_abs = root ? mi_walk::abs_path(root) : std::string();
-    const mi_walk::MountTable* mt = nullptr;
-    if (root) {
-        mt = &mi_walk::mountpoints();
-        if (!mt->error.empty()) return MI_ERR_IO;                              // "check if mounted"
-    }
-    auto skipped = [&](const mi_tree_entry& e, const std::string& p) {
-        if (!root) return false;
-        const std::string on_disk = root_abs == "/" ? p : root_abs + (p == "/" ? "" : p);
-        if (mi_walk::has_prefix(mi_walk::base_of(p), ".wh..wh.")) return true;
-        if (mi_walk::is_descendant_of_any(on_disk, bl) || e.kind > 3) return true;
-        if (mt->targets.count(on_disk)) return true;
-        for (const std::string& t : mt->targets)                               // isMounted: below a mountpoint
-            if (mi_walk::has_prefix(on_disk, t.back() == '/' ? t : t + "/")) return true;
-        return false;
-    };
-    // nodes: ref = i for base[i], n_base + j for layer[j], -1 for the directories addAncestors makes up
-    mi_memtree::Tree t;
-    auto entry_of = [&](const mi_memtree::Node& n) -> const mi_tree_entry* {
-        return n.ref < 0 ? nullptr : (uint64_t)n.ref < n_base ? &base[n.ref] : &layer[n.ref - n_base];
-    };
-    bool base_has_root = false;
-    for (uint64_t i = 0; i < n_base; ++i) {
-        const std::string p = path_of(base[i]);
-        if (p == "/") base_has_root = true;                                     // it comes back: nothing replaces it
-        t.load(p, (int64_t)i, base[i].kind, base[i].link_target);
-    }
-    std::string fail_msg;
-    // maybeAddToLayer (mem_fs.go:440-458) with createWhiteout = false
-    auto apply = [&](uint64_t j, const std::string& p) -> int {
-        if (p == "/") return MI_OK;                                             // "Root itself is not added to layers"
-        if (const mi_memtree::Node* cur = t.find(p)) {                            // isUpdated (:487-503)
-            const mi_tree_entry* old = entry_of(*cur);                          // a made-up directory's mtime is "now":
-            int similar = 0;                                                    // never similar to a header from a tar
-            if (old && old->kind <= 3 && layer[j].kind <= 3) {                  // special files never compare equal
-                const int rc = mi_entry_similar(old, &layer[j], 0, nullptr, nullptr, &similar);
-                if (rc) return rc;
-            }
-            if (similar) return MI_OK;                                          // already there: the OLD entry stays
-        }
-        if (!t.add_ancestors(p, false, 0, 0, 0, nullptr)) {
-            fail_msg = "add ancestors of " + p + ": " + t.err;
-            return MI_ERR_INVALID;
-        }
-        if (!t.add(p, (int64_t)(n_base + j), layer[j].kind, layer[j].link_target ? layer[j].link_target : "")) {
-            fail_msg = "update memfs with file " + p + ": " + t.err;
-            return MI_ERR_INVALID;
-        }
-        return MI_OK;
-    };
-    auto failed = [&](int rc) {
-        if (!fail_msg.empty()) mi_set_error(nullptr, ("add hdr from tar to layer: " + fail_msg).c_str());
-        return rc;
-    };
-    std::map<std::string, uint64_t> hardlinks;                                  // "hardlinks[path] = hdr": one per path
-    for (uint64_t j = 0; j < n_layer; ++j) {
-        const std::string p = path_of(layer[j]);
-        if (skipped(layer[j], p)) continue;
-        if (layer[j].kind == 3) { hardlinks[p] = j; continue; }
-        const int rc = apply(j, p);
-        if (rc) return failed(rc);
-    }
-    for (auto& kv : hardlinks) {
-        const int rc = apply(kv.second, kv.first);
-        if (rc) return failed(rc);
-    }
-    // the merged tree in sorted-path order; made-up directories are not entries of either list and stay out
-    std::vector<std::pair<std::string, const mi_memtree::Node*>> flat;
-    std::function<void(const mi_memtree::Node&, const std::string&)> collect = [&](const mi_memtree::Node& n,
-                                                                                 const std::string& p) {
-        for (auto& kv : n.children) {
-            const std::string q = p + "/" + kv.first;
-            if (kv.second->ref >= 0) flat.emplace_back(q, kv.second.get());
-            collect(*kv.second, q);
-        }
-    };
-    if (base_has_root) flat.emplace_back("/", &t.root);
-    collect(t.root, "");
-    std::sort(flat.begin(), flat.end(), [](const std::pair<std::string, const mi_memtree::Node*>& x,
-                                           const std::pair<std::string, const mi_memtree::Node*>& y) {
-        return x.first < y.first;
-    });
-    *n_out = flat.size();
-    if (cap < flat.size()) return MI_ERR_CAPACITY;
-    for (size_t k = 0; k < flat.size(); ++k) {
-        const int64_t ref = flat[k].second->ref;
-        from_layer[k] = (uint64_t)ref >= n_base;
-        index[k] = (uint64_t)ref >= n_base ? (uint64_t)ref - n_base : (uint64_t)ref;
-    }
-    return MI_OK;
-}
-
-extern "C" int mi_entries_apply_layer(const mi_tree_entry* base, uint64_t n_base, const mi_tree_entry* layer,
-                                      uint64_t n_layer, uint8_t* from_layer, uint64_t* index, uint64_t cap,
-                                      uint64_t* n_out) {
-    return mi_entries_apply_layer_filtered(base, n_base, layer, n_layer, nullptr, nullptr, 0, from_layer, index,
-                                           cap, n_out);
-}
-
 // tario.IsSimilarHeader (lib/tario/compare.go:24-117) on walk entries, plus the optional
 // content roots (see the header)
 int mi_entry_similar(const mi_tree_entry* a, const mi_tree_entry* b, int ignore_time,

@@ -9,27 +9,51 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HEADER = os.path.join(ROOT, "include", "makisu_mi.h")
+HEADER = os.path.join(ROOT, "include", "makisu_mi.h")               # the drop-in boundary (SURVEY.md 8b + rows a1-a14)
+HOST_HEADER = os.path.join(ROOT, "include", "makisu_mi_host.h")     # optional host helpers, outside the contract
+
+# the optional set is FROZEN (what SURVEY.md section 2 marks out of scope stays where it is)
+HOST_HELPERS = ["mi_context_sources", "mi_copy_op_execute", "mi_memfs_checkpoint", "mi_memfs_untar", "mi_path_match",
+                "mi_resolve_chown"]
 
 
-def _declared_functions():
-    src = open(HEADER).read()
+def _declared_functions(header=HEADER):
+    src = open(header).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(mi_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_library_exports_every_declared_symbol(engine_lib):
-    names = _declared_functions()
-    assert len(names) >= 20
-    for n in names:
-        assert hasattr(engine_lib, n), "header declares %s but the library does not export it" % n
+    core, host = _declared_functions(), _declared_functions(HOST_HEADER)
+    assert len(core) >= 20 and host == HOST_HELPERS and not set(core) & set(host)
+    for n in core + host:
+        assert hasattr(engine_lib, n), "a header declares %s but the library does not export it" % n
     # and the binding covers all of them
-    assert set(engine_lib._mi_symbols) == set(names)
+    assert set(engine_lib._mi_symbols) == set(core) | set(host)
+
+
+def test_the_core_export_set(engine_lib):
+    """SURVEY.md 8(b)'s list is in the core header, the stateless twins of the layer merge are gone (one MemFS), and the
+    library exports nothing beyond the two headers."""
+    core = set(_declared_functions())
+    for n in ("mi_ctx_create", "mi_ctx_destroy", "mi_batch_begin", "mi_batch_add_path", "mi_batch_add_bytes", "mi_batch_run",
+              "mi_batch_submit", "mi_batch_wait", "mi_batch_files", "mi_batch_chunks", "mi_batch_free", "mi_dedup_allgather",
+              "mi_get_stats", "mi_last_error", "mi_context_checksum", "mi_layer_begin", "mi_layer_finish",
+              "mi_memfs_update_from_entries", "mi_memfs_add_layer_by_scan", "mi_memfs_add_layer_by_copy_ops",
+              "mi_memfs_commit_layer", "mi_entry_similar", "mi_entries_commit_order", "mi_cache_create_entry"):
+        assert n in core, n
+    for gone in ("mi_entries_apply_layer", "mi_entries_apply_layer_filtered", "mi_snapshot_copy_ops"):
+        assert gone not in core and not hasattr(engine_lib, gone), gone
+    out = subprocess.check_output(["nm", "-D", "--defined-only", os.path.join(ROOT, "makisu_amd", "libmakisu_mi.so")]).decode()
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln and ln.split()[-1].startswith("mi_")}
+    internal = {"mi_set_error", "mi_batch_tree_slot", "mi_batch_tree_free", "mi_dedup_mark_range_enqueue"}       # cross-file helpers of the library itself
+    extra = exported - core - set(HOST_HELPERS) - internal
+    assert not extra, "exported but declared in neither header: %s" % sorted(extra)
 
 
 def test_abi_version_and_defaults(engine_lib):
     import makisu_amd
-    assert engine_lib.mi_abi_version() == 3
+    assert engine_lib.mi_abi_version() == 4
     cfg = makisu_amd.default_config()
     assert cfg.struct_size == C.sizeof(makisu_amd.Config)
     assert (cfg.gear_seed, cfg.mask_bits, cfg.min_size, cfg.max_size) == (0x4D414B49, 13, 2048, 65536)

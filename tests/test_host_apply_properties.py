@@ -1,5 +1,5 @@
-"""Differential test of mi_entries_apply_layer (csrc/mi_tree.hip) against a python model of MemFS.UpdateFromTarReader
-(lib/snapshot/mem_fs.go:165-255) on a NESTED tree, the reference's own shape (memFSNode: header + children map):
+"""A python model of MemFS.UpdateFromTarReader (lib/snapshot/mem_fs.go:165-255) on a NESTED tree, the reference's own
+shape (memFSNode: header + children map), and unit cases of the layer merge:
 
   * every header except hard links goes through maybeAddToLayer in stream order, the hard links after them (:214-236);
   * maybeAddToLayer (:440-458): isUpdated walks the children maps part by part (:487-503) -- a missing part means
@@ -8,17 +8,18 @@
     memLayer.addHeader(...).updateMemFS (mem_layer.go:50-76, 104-125): a ".wh.<name>" base name deletes the sibling
     <name>, anything else replaces the node and takes over the old node's children iff the NEW header is a directory.
 
-The C ABI answers with (from_layer, index) pairs, so it cannot say "a directory that was in neither list": the model
-marks the directories addAncestors creates and the comparison leaves them out (include/makisu_mi.h says so).  Apart
-from that the two must agree on every generated sequence -- entries without parents, files and symlinks that get
-children (and lose them when they are re-added as somebody's ancestor), directories arriving on files, whiteouts of
-what is not there, "./" entries, the same path twice -- and where the reference gives up ("missing intermediate
-directory" below a symlink, "symlink loop") the call fails with the same message."""
+The library has ONE implementation of this merge since round 4 -- the MemFS handle (mi_memfs_update_from_entries;
+the stateless mi_entries_apply_layer, which could not name the directories addAncestors creates, is gone).  The
+differential test of the handle against this model over generated layer sequences -- entries without parents, files
+and symlinks that get children (and lose them when they are re-added as somebody's ancestor), directories arriving on
+files, whiteouts of what is not there, "./" entries, the same path twice, the reference's two failures with its own
+words -- is tests/test_host_memfs.py::test_update_from_entries_equals_the_model_made_up_directories_included; the
+cases below go through makisu_amd.apply_layer, a harness helper that merges two entry lists on a fresh handle."""
 import posixpath
 
 import pytest
 
-from hypothesis import event, given, settings, strategies as st
+from hypothesis import strategies as st
 
 import makisu_amd as M
 
@@ -183,44 +184,13 @@ def _entry(draw, allow_marker=True):
     return e
 
 
-@settings(max_examples=600, deadline=None, derandomize=True, database=None)
-@given(st.lists(st.lists(_entry(), min_size=0, max_size=7), min_size=1, max_size=4))
-def test_apply_layer_equals_update_from_tar_reader(layers):
-    tree = Node({"kind": M.KIND_DIR, "mode": 0o40755, "mtime_sec": 1, "uid": 0, "gid": 0, "size": 0, "link_target": None,
-                 "relpath": ""}, "/")
-    merged = []
-    for n, layer in enumerate(layers):
-        try:
-            model_update_from_tar(tree, layer)
-        except ReferenceFails as e:                           # the build stops there; so does the call, same words
-            event("the reference fails: " + " ".join(str(e).split(" ")[:2]))
-            with pytest.raises(M.MiError) as ei:
-                M.apply_layer(merged, layer)
-            assert ei.value.code == -1 and str(e)[:150] in str(ei.value)    # MI_ERR_INVALID (a looping path is cut short)
-            break
-        merged = M.apply_layer(merged, layer)
-        want = flatten(tree)
-        got = {_abs(e["relpath"]): e for e in merged}
-        assert len(got) == len(merged), "one entry per path"
-        assert sorted(got) == sorted(want), (n, layer)
-        for p in want:
-            assert got[p] is want[p] or got[p] == want[p], (n, p)
-        assert [_abs(e["relpath"]) for e in merged] == sorted(got), "sorted-path order"
-    else:
-        event("the reference fails: no")
-    flat = [e for layer in layers for e in layer]
-    want = flatten(tree)
-    event("markers: %d" % min(2, sum(posixpath.basename(_abs(e["relpath"])).startswith(".wh.") for e in flat)))
-    event("orphans: %s" % any(posixpath.dirname(p) not in want and posixpath.dirname(p) != "/" for p in want))
-
-
 def test_the_root_of_a_layer_never_replaces_the_root():
     """mem_fs.go:447: "Root itself is not added to layers" -- a layer's "./" header changes nothing."""
     D = lambda p, **kw: dict({"relpath": p, "kind": M.KIND_DIR, "mode": 0o40755, "mtime_sec": 100, "size": 0}, **kw)   # noqa: E731
-    base = [D(""), D("a")]
+    base = [D(""), D("a")]                                      # (the root is the handle's own node, not an entry of the tree)
     for name in ("./", ".", "/", ""):
         out = M.apply_layer(base, [D(name, mode=0o40700, mtime_sec=7), D("b")])
-        assert [(e["relpath"], e["mode"]) for e in out] == [("", 0o40755), ("a", 0o40755), ("b", 0o40755)]
+        assert [(e["relpath"], e["mode"]) for e in out] == [("a", 0o40755), ("b", 0o40755)]
     assert [e["relpath"] for e in M.apply_layer([], [D("./"), D("b")])] == ["b"]
 
 
@@ -234,9 +204,10 @@ def test_a_directory_takes_over_the_children_whatever_it_replaces():
     assert names(fs) == ["a", "a/x"]
     assert names(M.apply_layer(fs, [D("a")])) == ["a", "a/x"]        # the directory keeps it
     assert names(M.apply_layer(fs, [dict(F("a"), size=4)])) == ["a"]  # another file does not
-    fs = M.apply_layer([], [F("p/q/r")])                             # p and p/q were never listed
-    assert names(M.apply_layer(fs, [F("p/q")])) == ["p/q"]
-    assert names(M.apply_layer(fs, [D("p/q")])) == ["p/q", "p/q/r"]
+    fs = M.apply_layer([], [F("p/q/r")])                             # p and p/q were never listed: addAncestors made them
+    assert names(fs) == ["p", "p/q", "p/q/r"] and [e["kind"] for e in fs] == [M.KIND_DIR, M.KIND_DIR, M.KIND_FILE]
+    assert names(M.apply_layer(fs, [F("p/q")])) == ["p", "p/q"]
+    assert names(M.apply_layer(fs, [D("p/q")])) == ["p", "p/q", "p/q/r"]
 
 
 def test_entries_below_a_symlink_the_way_the_reference_treats_them():
@@ -259,5 +230,5 @@ def test_entries_below_a_symlink_the_way_the_reference_treats_them():
     with pytest.raises(M.MiError) as ei:
         M.apply_layer(base, [L("loop", "/loop"), F("loop/x")])
     assert "add ancestors of /loop/x: " in str(ei.value) and "symlink loop at /loop/x" in str(ei.value)
-    # the target's ancestors are created (not listed: they were in neither list), the entry itself stays where it is
-    assert names(M.apply_layer([], [L("l", "/t/u"), F("l/f")])) == ["l", "l/f"]
+    # the target's ancestors are created (entries of the tree like any other), the entry itself stays where it is
+    assert names(M.apply_layer([], [L("l", "/t/u"), F("l/f")])) == ["l", "l/f", "t", "t/u"]

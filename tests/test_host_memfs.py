@@ -157,7 +157,7 @@ def _plain(e):
     return {k: e.get(k) for k in ("relpath", "kind", "mode", "mtime_sec", "uid", "gid", "size", "link_target")}
 
 
-@settings(max_examples=300, deadline=None, derandomize=True, database=None)
+@settings(max_examples=600, deadline=None, derandomize=True, database=None)
 @given(st.lists(st.lists(_entry(), min_size=0, max_size=7), min_size=1, max_size=4))
 def test_update_from_entries_equals_the_model_made_up_directories_included(layers):
     tree = Node({"kind": M.KIND_DIR, "mode": 0o40755, "mtime_sec": 1, "uid": 0, "gid": 0, "size": 0, "link_target": None,

@@ -241,8 +241,8 @@ def _extract_like_untar_one_item(root, tar_path):
 
 
 def test_apply_layer_matches_sequential_extraction(tmp_path):
-    """mi_entries_apply_layer over three layer tars == the paths (and kinds, sizes) left on disk
-    after extracting the same tars in order with untarOneItem's rules."""
+    """The layer merge (mi_memfs_update_from_entries, through makisu_amd.apply_layer) over three layer tars == the
+    paths (and kinds, sizes) left on disk after extracting the same tars in order with untarOneItem's rules."""
     import makisu_amd
     t = 1500000000
     l1 = _layer_tar(str(tmp_path / "l1.tar"), [
@@ -264,7 +264,7 @@ def test_apply_layer_matches_sequential_extraction(tmp_path):
         (".wh.link", "f", b"", t + 9)])                               # top-level whiteout
     root = tmp_path / "fs"
     os.makedirs(root)
-    tree = [{"relpath": ".", "kind": 0, "mode": 0o40755}]
+    tree = []
     for tar_path in (l1, l2, l3):
         layer = makisu_amd.tar_entries(tar_path)
         tree = makisu_amd.apply_layer(tree, layer)
@@ -282,10 +282,9 @@ def test_apply_layer_matches_sequential_extraction(tmp_path):
         assert rels == sorted(rels, key=lambda r: ("/" if r == "." else "/" + r).encode())
     final = {e["relpath"]: e for e in tree}
     assert "link" not in final and "etc/conf.d/b" not in final and final["etc/conf.d"]["kind"] == 1
-    assert final["usr/bin/tool"]["data_offset"] > 0 and final["usr/share/doc/new"]["size"] == 1
-    # the "similar header" quirk: layer 2's usr/bin/tool did NOT replace layer 1's entry
-    l1_tool = [e for e in makisu_amd.tar_entries(l1) if e["relpath"] == "usr/bin/tool"][0]
-    assert final["usr/bin/tool"]["data_offset"] == l1_tool["data_offset"]
+    assert final["usr/share/doc/new"]["size"] == 1
+    # (the "similar header" quirk -- layer 2's usr/bin/tool does NOT replace layer 1's entry -- shows in nothing the tree
+    # keeps: test_hard_links_are_applied_after_everything_else holds "the OLD entry stays" on a field that differs)
 
 
 # ---- round 2: stored (gzip) layers, UpdateFromTarReader's filter, hard-link pass, isOnDisk ----
@@ -362,19 +361,21 @@ def test_apply_layer_filter_drops_what_the_scan_walk_skips(tmp_path):
     """base-image entries the SCAN walk never reports (blacklist, special files, AUFS
     metadata) must not enter the tree, or mi_snapshot_diff writes whiteouts for them."""
     root = str(tmp_path / "rootfs")
+    os.makedirs(root)                                          # NewMemFS stats its root
     layer = [_e("bin", 0), _e("bin/sh", 1, size=10), _e("proc", 0), _e("proc/cpuinfo", 1, size=1),
              _e("dev", 0), _e("dev/null", 4, mode=0o666), _e(".wh..wh.plnk", 0), _e(".wh..wh.plnk/x", 1),
              _e("etc", 0), _e("etc/passwd", 1, size=5), _e("var/.wh..wh.opq", 1)]
     merged = M.apply_layer([], layer, root=root, blacklist=[root + "/proc"])
     # (".wh..wh.plnk/x" stays: shouldSkip looks at the BASE name only, utils.go:38 -- the reference keeps it too,
     # creating the skipped parent directory for it on the way: maybeAddToLayer -> addAncestors, mem_fs.go:455-458)
-    assert [m["relpath"] for m in merged] == [".wh..wh.plnk/x", "bin", "bin/sh", "dev", "etc", "etc/passwd"]
-    # unfiltered (root=None): everything is kept, and a special file recurring in a later layer no
-    # longer aborts the merge (it simply replaces the old entry)
-    all_ = M.apply_layer([], layer)
-    assert "dev/null" in [m["relpath"] for m in all_]
-    again = M.apply_layer(all_, [_e("dev/null", 4, mode=0o600)])
-    assert [m for m in again if m["relpath"] == "dev/null"][0]["mode"] == 0o600
+    assert [m["relpath"] for m in merged] == [".wh..wh.plnk", ".wh..wh.plnk/x", "bin", "bin/sh", "dev", "etc", "etc/passwd"]
+    # without a blacklist /proc stays; special files and AUFS metadata are skipped whatever the root (shouldSkip), and a
+    # special file recurring in a later layer does not abort the merge
+    plain = M.apply_layer([], layer)
+    assert [m["relpath"] for m in plain] == [".wh..wh.plnk", ".wh..wh.plnk/x", "bin", "bin/sh", "dev", "etc", "etc/passwd", "proc",
+                                             "proc/cpuinfo"]
+    drop_src = lambda es: [{k: v for k, v in e.items() if k != "src"} for e in es]                   # noqa: E731
+    assert drop_src(M.apply_layer(plain, [_e("dev/null", 4, mode=0o600)])) == drop_src(plain)
 
 
 def test_hard_links_are_applied_after_everything_else():
@@ -390,7 +391,8 @@ def test_hard_links_are_applied_after_everything_else():
         assert M.entry_similar(base[2], dict(base[2], link_target=other))
     assert not M.entry_similar(base[2], dict(base[2], link_target="a/g"))
     same = M.apply_layer(base, [dict(base[2], link_target="/a/f")])
-    assert [m for m in same if m["relpath"] == "a/h"][0]["link_target"] == "a/f"      # similar: the OLD entry stays
+    assert [m for m in same if m["relpath"] == "a/h"][0]["link_target"] == "/a/f"     # (stored as AbsPath, mem_fs.go:214-216)
+    assert [m for m in same if m["relpath"] == "a/h"][0]["mtime_sec"] == 100          # similar: the OLD entry stays
 
 
 def test_snapshot_diff_asks_the_disk_before_writing_a_whiteout(tmp_path):
@@ -414,8 +416,8 @@ def test_snapshot_diff_asks_the_disk_before_writing_a_whiteout(tmp_path):
 
 def test_update_mem_fs_cases_replayed():
     """lib/snapshot/mem_fs_test.go:164-344 (TestUpdateMemFS): Simple, Mutation, TrailingSlashes, WhiteoutExistingDir,
-    WhiteoutNonexistentNotCausingError -- one layer after another into the tree, here mi_entries_apply_layer on entry
-    lists."""
+    WhiteoutNonexistentNotCausingError -- one layer after another into the tree (makisu_amd.apply_layer: two merges on
+    a fresh MemFS handle)."""
     def names(x):
         return sorted("/" + e["relpath"].strip("/") for e in x)
     D = lambda p, mode=0o755: _e(p, 0, mode=0o40000 | mode)                    # noqa: E731
@@ -431,10 +433,9 @@ def test_update_mem_fs_cases_replayed():
     assert names(fs) == ["/test1", "/test1/test2"]
     assert names(M.apply_layer(fs, [D("/test1", 0o700)])) == ["/test1", "/test1/test2"]          # one node per path
     # (SkipDirCausesError is a property of the reference's test-only MemFS.merge, testutils_test.go:31-42: the real
-    # path, UpdateFromTarReader -> maybeAddToLayer -> addAncestors, creates the missing /test1/test2 instead of
-    # failing; here the entry is kept without its parent, see the header)
+    # path, UpdateFromTarReader -> maybeAddToLayer -> addAncestors, creates the missing /test1/test2 instead of failing)
     fs = M.apply_layer([], [D("/test1"), D("/test1/test2/test3")])
-    assert names(fs) == ["/test1", "/test1/test2/test3"]
+    assert names(fs) == ["/test1", "/test1/test2", "/test1/test2/test3"]
     # WhiteoutExistingDir: the subtree goes
     l1 = [D("/test11"), D("/test11/test12"), F("/test11/test12/test.txt")]
     fs = M.apply_layer(M.apply_layer([], l1), [D("/test11"), D("/test11/.wh.test12")])

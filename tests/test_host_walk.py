@@ -599,8 +599,8 @@ def test_compare_fs_case_through_the_snapshot_diff(engine_lib):
     fs1 = makisu_amd.apply_layer([], [D("/common"), D("/common/test1"), F("/common/world", 0o711)])
     fs2 = makisu_amd.apply_layer([], [D("/common"), D("/common/test2"), F("/common/world", 0o755)])
     changed, carried, whiteouts = _diff_names(fs1, fs2)
-    assert whiteouts == ["/common/test1"]                                   # missing2: only the first tree has it
-    assert changed == ["/common/test2", "/common/world"]                    # missing1 + diff
-    assert carried == ["/common"]                                           # the unchanged parent travels with them
+    assert whiteouts == ["common/test1"]                                    # missing2: only the first tree has it
+    assert changed == ["common/test2", "common/world"]                      # missing1 + diff
+    assert carried == ["common"]                                            # the unchanged parent travels with them
     changed, carried, whiteouts = _diff_names(fs2, fs1)
-    assert whiteouts == ["/common/test2"] and changed == ["/common/test1", "/common/world"]
+    assert whiteouts == ["common/test2"] and changed == ["common/test1", "common/world"]
