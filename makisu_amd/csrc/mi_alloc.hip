@@ -13,7 +13,10 @@
 // (lib/tario/write.go:43-45), no more.
 #include "mi_internal.h"
 
+#include <stdio.h>
 #include <stdlib.h>
+
+#include <atomic>
 
 #include <mutex>
 #include <unordered_map>
@@ -21,15 +24,30 @@
 namespace mi {
 
 namespace {
-struct GuardRec { void* va; size_t reserved, mapped; hipMemGenericAllocationHandle_t handle; };
+struct GuardRec { void* va; size_t reserved, mapped; hipMemGenericAllocationHandle_t handle; unsigned long long seq; size_t bytes; };
+std::atomic<unsigned long long> g_seq{0};
 std::mutex g_mu;
 std::unordered_map<void*, GuardRec> g_recs;
 }  // namespace
 
-bool guard_alloc() {
-    static const bool on = [] { const char* v = getenv("MI_GUARD_ALLOC"); return v && *v && *v != '0'; }();
+// MI_GUARD_ALLOC=1: guarded allocations, and a freed buffer's address range is NEVER handed out again -- it stays
+// reserved and unmapped, so a use after free faults too, whatever is allocated later.  (MI_GUARD_ALLOC=3 gives the
+// range back with hipMemAddressFree.  On ROCm 7.0.2 that breaks batches whose arena grows: a range released and
+// reserved again within microseconds -- a new mapping at an address that has just been unmapped -- ends in faults at
+// addresses near no buffer of the trace, or in bytes that are not the ones copied, while the same run with the
+// ranges kept (every stale pointer of this library would fault there) is clean: profiles/r04_overread_audit.txt.
+// The product never does this -- it uses hipMalloc / hipFree -- so it is kept only as a way to show the effect.)
+// MI_GUARD_TRACE=1 writes one line per allocation and free to stderr (sequence number, range, bytes), so that the
+// address a fault names can be placed: behind a live buffer's slack, or inside a freed one.
+static int guard_mode() {
+    static const int m = [] { const char* v = getenv("MI_GUARD_ALLOC"); return v && *v ? atoi(v) : 0; }();
+    return m;
+}
+static bool guard_trace() {
+    static const bool on = [] { const char* v = getenv("MI_GUARD_TRACE"); return v && *v && *v != '0'; }();
     return on;
 }
+bool guard_alloc() { return guard_mode() > 0; }
 
 hipError_t dev_alloc(void** p, size_t bytes) {
     if (!guard_alloc()) return hipMalloc(p, bytes);
@@ -46,7 +64,7 @@ hipError_t dev_alloc(void** p, size_t bytes) {
     if (gran < 4096) gran = 4096;
     const size_t need = (bytes + 255) & ~(size_t)255;            // the buffer keeps its 256-byte alignment
     const size_t mapped = (need + gran - 1) / gran * gran;
-    GuardRec r{nullptr, mapped + gran, mapped, {}};
+    GuardRec r{nullptr, mapped + gran, mapped, {}, g_seq.fetch_add(1), bytes};
     e = hipMemAddressReserve(&r.va, r.reserved, gran, nullptr, 0);
     if (e != hipSuccess) return e;
     e = hipMemCreate(&r.handle, mapped, &prop, 0);
@@ -67,6 +85,8 @@ hipError_t dev_alloc(void** p, size_t bytes) {
     // the buffer ends within 255 bytes of the guard page, and exactly on it whenever `bytes` is a multiple of 256
     // (under the guard the arena and every DevBuf are)
     *p = (u8*)r.va + (mapped - need);
+    if (guard_trace())
+        fprintf(stderr, "mi_guard alloc #%llu [%p, +%zu) guard page at %p\n", r.seq, *p, bytes, (void*)((u8*)r.va + mapped));
     std::lock_guard<std::mutex> g(g_mu);
     g_recs[*p] = r;
     return hipSuccess;
@@ -83,9 +103,10 @@ hipError_t dev_free(void* p) {
         g_recs.erase(it);
     }
     (void)hipDeviceSynchronize();                                // hipFree's implicit wait for work that still uses it
+    if (guard_trace()) fprintf(stderr, "mi_guard free  #%llu [%p, +%zu)\n", r.seq, p, r.bytes);
     hipError_t e = hipMemUnmap(r.va, r.mapped);
     (void)hipMemRelease(r.handle);
-    (void)hipMemAddressFree(r.va, r.reserved);
+    if (guard_mode() == 3) (void)hipMemAddressFree(r.va, r.reserved);  // else the range stays reserved, unmapped, for good
     return e;
 }
 

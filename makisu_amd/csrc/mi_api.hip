@@ -918,6 +918,41 @@ int mi_batch_add_paths(mi_batch* b, uint64_t n, const char* const* paths, const 
     return rc;
 }
 
+// For the tree walk (mi_tree.hip), which reads small files where it lists them: a block of host memory that holds files
+// as they are to lie in the arena goes in as ONE piece of the arena (*at_out = where), copied by the reader threads;
+// release(release_arg) is called when the block is no longer needed.  The files themselves are then table rows
+// (mi_batch_add_placed): where a file lies in the arena has nothing to do with its index.
+extern "C" int mi_batch_add_block(mi_batch* b, const void* src, uint64_t len, void (*release)(void*), void* release_arg,
+                                  uint64_t* at_out) {
+    std::shared_ptr<void> keep(release_arg, release ? release : +[](void*) {});
+    if (!b || !src || !at_out) return MI_ERR_INVALID;
+    mi_ctx* c = b->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (b->staged) return fail(c, MI_ERR_STATE, "batch already ran; begin a new batch");
+    int rc = staging_flush(b);                    // the inline window may hold bytes of earlier small adds
+    if (rc) return rc;
+    const u64 at = align_up(b->arena_used, kFileAlign);
+    rc = arena_reserve(b, at + align_up(len, kFileAlign));
+    if (rc == MI_OK) rc = ensure_stager(c);
+    if (rc) return rc;
+    b->arena_used = at + len;
+    *at_out = at;
+    rc = stager_put_block(c->stager, b, at, src, len, std::move(keep));
+    b->staged_any = true;
+    return rc;
+}
+extern "C" int mi_batch_add_placed(mi_batch* b, uint64_t n, const uint64_t* arena_off, const uint64_t* sizes,
+                                   const uint64_t* tags) {
+    if (!b || (n && (!arena_off || !sizes))) return MI_ERR_INVALID;
+    if (b->staged) return fail(b->ctx, MI_ERR_STATE, "batch already ran; begin a new batch");
+    for (u64 i = 0; i < n; ++i) {
+        if (arena_off[i] + sizes[i] > b->arena_used) return fail(b->ctx, MI_ERR_INVALID, "mi_batch_add_placed: outside the arena");
+        b->files.push_back({arena_off[i], sizes[i], tags ? tags[i] : 0});
+        b->total_bytes += sizes[i];
+    }
+    return MI_OK;
+}
+
 // Room for what the caller knows is coming: the arena grows ONCE, now, instead of in steps under way -- every growth has
 // to drain the reader threads first (copies in flight target the old arena) and moves what the arena already holds.
 int mi_batch_reserve(mi_batch* b, uint64_t more_files, uint64_t more_bytes) {

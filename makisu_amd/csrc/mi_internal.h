@@ -5,6 +5,8 @@
 #include "../../include/makisu_mi.h"
 #include "mi_common.h"
 
+#include <memory>
+
 #include <mutex>
 #include <string>
 #include <vector>
@@ -72,6 +74,7 @@ int     stager_put_bytes(Stager* st, mi_batch* b, u64 arena_off, const void* src
 int     stager_put_file(Stager* st, mi_batch* b, u64 arena_off, int fd, u64 file_off, u64 len, const char* path);
 int     stager_put_paths(Stager* st, mi_batch* b, u64 n, const char* const* paths, const u64* arena_off,
                          const u64* len);
+int     stager_put_block(Stager* st, mi_batch* b, u64 arena_off, const void* src, u64 len, std::shared_ptr<void> keep);
 int     stager_drain(Stager* st, mi_batch* b);
 
 }  // namespace mi

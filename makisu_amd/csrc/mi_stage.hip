@@ -44,10 +44,11 @@ struct StageLatch {                      // completion of one blocking mi_batch_
 struct StageItem {
     mi_batch* batch;
     u64 arena_off, len;
-    const u8* src;                       // caller memory (valid until its latch opens) or nullptr
+    const u8* src;                       // caller memory (valid until its latch opens), memory `keep` owns, or nullptr
     std::shared_ptr<StageFile> file;     // ... or a file range
     u64 file_off;
     StageLatch* latch;
+    std::shared_ptr<void> keep;          // owner of `src` for blocks handed over for good (stager_put_block)
 };
 
 // Files per run: a slab of tiny files would otherwise be ONE thread's work for milliseconds (2 048
@@ -429,6 +430,26 @@ int stager_put_file(Stager* st, mi_batch* b, u64 arena_off, int fd, u64 file_off
     f->fd = fd;
     f->path = path ? path : "";
     if (len) enqueue(st, b, arena_off, len, nullptr, f, file_off, nullptr);
+    return MI_OK;
+}
+
+// A block of host memory that already holds the bytes of [arena_off, +len) -- the files a directory reader of the tree
+// walk read where it listed them (mi_tree.hip), laid out as they lie in the arena.  `keep` owns the block; the call
+// returns at once, the block is let go of when its last piece sits in a slab.
+int stager_put_block(Stager* st, mi_batch* b, u64 arena_off, const void* src, u64 len, std::shared_ptr<void> keep) {
+    if (len == 0) return MI_OK;
+    std::vector<StageItem> items;
+    for (u64 done = 0; done < len;) {
+        const u64 take = len - done < st->slab_bytes ? len - done : st->slab_bytes;
+        items.push_back({b, arena_off + done, take, (const u8*)src + done, nullptr, 0, nullptr, keep});
+        done += take;
+    }
+    {
+        std::lock_guard<std::mutex> g(st->mu);
+        b->stage_pending += items.size();
+        for (auto& it : items) st->queue.push_back(std::move(it));
+    }
+    st->cv_work.notify_one();
     return MI_OK;
 }
 

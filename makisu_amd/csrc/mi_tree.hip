@@ -44,6 +44,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
+#include <sys/syscall.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -60,6 +61,13 @@
 #include <string>
 #include <string_view>
 #include <vector>
+
+// mi_api.hip, for the walk's small files read in place: a block of host memory as one piece of the arena, and the table
+// rows of files that lie in it
+extern "C" int mi_batch_add_block(mi_batch* b, const void* src, uint64_t len, void (*release)(void*), void* release_arg,
+                                  uint64_t* at_out);
+extern "C" int mi_batch_add_placed(mi_batch* b, uint64_t n, const uint64_t* arena_off, const uint64_t* sizes,
+                                   const uint64_t* tags);
 
 namespace mi_walk {
 
@@ -85,14 +93,44 @@ struct Walker {
     const std::atomic<uint64_t>* ahead_bytes = nullptr;
     uint64_t handed_files = 0, handed_bytes = 0;
 
+    // files whose bytes a directory reader already read (ParallelWalker::read_dir) and that lie in the arena as part of
+    // their directory's block: table rows only
+    std::vector<uint64_t> place_off, place_size, place_tag;
+
+    // the arena is sized for what the enumeration has seen, which runs ahead of what has been handed over
+    bool reserve_ahead() {
+        if (!ahead_files) return true;
+        const uint64_t f = ahead_files->load(std::memory_order_relaxed), by = ahead_bytes->load(std::memory_order_relaxed);
+        if (f > handed_files || by > handed_bytes) {
+            const int r = mi_batch_reserve(batch, f > handed_files ? f - handed_files : 0, by > handed_bytes ? by - handed_bytes : 0);
+            if (r && !rc) { rc = r; return false; }
+        }
+        return true;
+    }
+    void flush_placed() {
+        if (place_off.empty() || !batch) return;
+        const int r = mi_batch_add_placed(batch, place_off.size(), place_off.data(), place_size.data(), place_tag.data());
+        if (r && !rc) rc = r;
+        place_off.clear();
+        place_size.clear();
+        place_tag.clear();
+    }
+    // one directory's block (its small files, laid out as they are to lie in the arena) becomes a piece of the arena
+    bool place_block(const std::shared_ptr<uint8_t[]>& blob, uint64_t len, uint64_t n_files, uint64_t* at) {
+        if (!reserve_ahead()) return false;
+        handed_files += n_files;
+        handed_bytes += len;
+        auto* keep = new std::shared_ptr<uint8_t[]>(blob);
+        const int r = mi_batch_add_block(batch, blob.get(), len, [](void* p) { delete (std::shared_ptr<uint8_t[]>*)p; }, keep, at);
+        if (r && !rc) rc = r;
+        return r == MI_OK;
+    }
+
     void flush_pending() {
+        flush_placed();
         if (pend_path.empty() || !batch) return;
         if (ahead_files) {
-            const uint64_t f = ahead_files->load(std::memory_order_relaxed), by = ahead_bytes->load(std::memory_order_relaxed);
-            if (f > handed_files || by > handed_bytes) {
-                const int r = mi_batch_reserve(batch, f > handed_files ? f - handed_files : 0, by > handed_bytes ? by - handed_bytes : 0);
-                if (r && !rc) { rc = r; return; }
-            }
+            if (!reserve_ahead()) return;
             handed_files += pend_path.size();
             for (uint64_t sz : pend_size) handed_bytes += sz;
         }
@@ -119,7 +157,9 @@ struct Walker {
     // readlink result of a symlink.  A directory's children are the caller's business.
     // rel (optional): the path's relpath when the caller already knows it (a child's is its parent's
     // plus its name; filepath.Rel per entry costs more than the lstat it follows)
-    void emit(const std::string& path, const struct stat& st, const std::string* link, const std::string* rel = nullptr) {
+    // placed (optional): the file's bytes are in the arena already, at this offset (its directory's block)
+    void emit(const std::string& path, const struct stat& st, const std::string* link, const std::string* rel = nullptr,
+              const uint64_t* placed = nullptr) {
         Entry e;
         e.relpath = rel ? *rel : rel_to(rel_base, path);
         if (e.relpath.empty()) {
@@ -157,10 +197,20 @@ struct Walker {
             if (batch) {
                 if (!counted) { mi_batch_counts(batch, &batch_files, nullptr, nullptr); counted = true; }
                 e.file_index = (int64_t)batch_files++;
-                pend_path.push_back(path);
-                pend_size.push_back(e.size);
-                pend_tag.push_back(tree->entries.size());
-                if (pend_path.size() >= 1024) { flush_pending(); if (rc) return; }
+                if (placed) {                               // (the batch's file table keeps the walk's order: one kind of
+                    if (!pend_path.empty()) flush_pending();   // pending row at a time)
+                    place_off.push_back(*placed);
+                    place_size.push_back(e.size);
+                    place_tag.push_back(tree->entries.size());
+                    if (place_off.size() >= 4096) flush_placed();
+                } else {
+                    flush_placed();
+                    pend_path.push_back(path);
+                    pend_size.push_back(e.size);
+                    pend_tag.push_back(tree->entries.size());
+                    if (pend_path.size() >= 1024) flush_pending();
+                }
+                if (rc) return;
             } else {
                 e.file_index = n_regular;                   // listing only: running file ordinal
             }
@@ -212,8 +262,9 @@ struct Child {
     uint64_t size = 0;
     int64_t mtime = 0;
     bool skip = false;
-    int rc = MI_OK;                      // this path's own failure (lstat / readlink / skip-rule error)
+    int rc = MI_OK;                      // this path's own failure (lstat / readlink / skip-rule / read error)
     std::string err;
+    uint64_t blob_off = ~0ull;           // a regular file that was read where it was listed: its place in the directory's block
     std::unique_ptr<DirRec> sub;         // a directory that is entered
 };
 struct DirRec {
@@ -222,7 +273,47 @@ struct DirRec {
     int rc = MI_OK;                      // opening / reading the directory failed
     std::string err;
     bool done = false;                   // read completely (guarded by ParallelWalker::mu)
+    // the directory's small regular files, read by the thread that listed them, laid out as they will lie in the arena
+    // (each on a 256-byte boundary): ONE piece of the arena, copied by the reader threads of mi_stage.hip
+    std::shared_ptr<uint8_t[]> blob;
+    uint64_t blob_len = 0, blob_files = 0;
 };
+
+// Small files are read WHERE THEY ARE LISTED (round 4).  Until then every regular file went to the reader threads of
+// mi_stage.hip as a path: a second path walk, an open, a pread and a close per file there -- and open / close take the
+// lock of the file-descriptor table, which all threads of a process share: on the GPU box 100 000 4 KiB files took
+// 95-135 ms with 4, 8, 16 or 32 threads alike (profiles/r04_ubench_small_file_reads.txt).  The directory readers of the
+// walk are threads of this library that touch nothing but files, so they LEAVE the shared table -- unshare(CLONE_FILES),
+// then close_range over their private copy -- and open / read / close against a table of their own: the same files in
+// 56 / 42 / 29 ms with 8 / 16 / 32 threads.  (A thread that may not unshare -- a seccomp profile without it -- reads
+// through the shared table: correct, slower.)  What a reader thread of mi_stage.hip is left with is a memcpy into its
+// pinned slab and the host-to-device copy.  Bounded: files up to MI_WALK_INLINE_MAX_KIB (default 32) KiB -- the block
+// costs a second copy of the bytes, which pays while the per-file system calls dominate: 100 000 x 4 KiB 3.2-3.9 ->
+// 8.5-9.9 GB/s end to end, but 50 000 x 64 KiB 40 -> 17 GB/s when those were read this way too
+// (profiles/r04_many_small_files.txt) -- and at most MI_WALK_INLINE_MB (default 1024) MiB of blocks alive at a time;
+// beyond either a file goes the old way, as a path.  MI_WALK_UNSHARE=0 keeps the shared table (ThreadSanitizer models
+// descriptors per process and takes two threads' private "fd 4" for one).
+static uint64_t inline_file_max() {
+    static const uint64_t v = [] {
+        const char* e = getenv("MI_WALK_INLINE_MAX_KIB");
+        const long kib = e && *e ? atol(e) : 32;
+        return kib <= 0 ? 0ull : (uint64_t)kib << 10;
+    }();
+    return v;
+}
+static bool walk_unshare() {
+    static const bool on = [] { const char* e = getenv("MI_WALK_UNSHARE"); return !(e && *e == '0'); }();
+    return on;
+}
+static std::atomic<uint64_t> g_inline_bytes{0};
+static uint64_t inline_budget() {
+    static const uint64_t v = [] {
+        const char* e = getenv("MI_WALK_INLINE_MB");
+        const long mb = e && *e ? atol(e) : 1024;
+        return mb <= 0 ? 0ull : (uint64_t)mb << 20;
+    }();
+    return v;
+}
 
 struct ParallelWalker {
     std::atomic<uint64_t> seen_files{0}, seen_bytes{0};        // regular files enumerated so far (the batch reserves for them)
@@ -232,6 +323,7 @@ struct ParallelWalker {
     std::vector<DirRec*> stack;          // LIFO: close to the depth-first order the assembly wants
     size_t outstanding = 0;              // directories queued or being read
     bool abort = false;                  // the assembly stopped (an error): the readers only drain
+    bool inline_reads = false;           // a batch is attached: small files are read where they are listed
     std::vector<std::thread> pool;
 
     // Walker::should_skip without side effects on the shared walker: a broken mounts table is the
@@ -297,6 +389,7 @@ struct ParallelWalker {
                 c.link.assign(buf, (size_t)n);
             }
         }
+        if (inline_reads) read_small_files(d, fd);
         closedir(dir);                                       // closes fd
         if (!subs.empty()) {
             std::lock_guard<std::mutex> g(mu);
@@ -306,7 +399,63 @@ struct ParallelWalker {
         }
     }
 
+    // the directory's small regular files into one block; a file that cannot be read is that child's error (reported
+    // by the assembly in walk order, with the words the reader threads use)
+    void read_small_files(DirRec* d, int dfd) {
+        uint64_t total = 0, n = 0;
+        for (Child& c : d->kids) {
+            if (c.rc || c.skip || !S_ISREG(c.mode) || c.size > inline_file_max()) continue;
+            c.blob_off = (total + 255) & ~255ull;
+            total = c.blob_off + c.size;
+            ++n;
+        }
+        if (n == 0) return;
+        const uint64_t held = g_inline_bytes.fetch_add(total) + total;
+        if (held > inline_budget() && held != total) {       // too much host memory in blocks already: these go as paths
+            g_inline_bytes.fetch_sub(total);
+            for (Child& c : d->kids) c.blob_off = ~0ull;
+            return;
+        }
+        uint8_t* buf = total ? new (std::nothrow) uint8_t[total] : nullptr;
+        if (total && !buf) {
+            g_inline_bytes.fetch_sub(total);
+            for (Child& c : d->kids) c.blob_off = ~0ull;
+            return;
+        }
+        d->blob = std::shared_ptr<uint8_t[]>(buf, [total](uint8_t* p) { delete[] p; g_inline_bytes.fetch_sub(total); });
+        d->blob_len = total;
+        d->blob_files = n;
+        uint64_t end = 0;
+        for (Child& c : d->kids) {
+            if (c.blob_off == ~0ull) continue;
+            if (c.blob_off > end) memset(buf + end, 0, c.blob_off - end);       // alignment gap
+            end = c.blob_off + c.size;
+            if (c.size == 0) continue;
+            const int fd = openat(dfd, c.name.c_str(), O_RDONLY | O_CLOEXEC | O_NOFOLLOW);
+            if (fd < 0) {
+                c.rc = MI_ERR_IO;
+                c.err = "open " + (d->path == "/" ? "/" + c.name : d->path + "/" + c.name) + ": " + strerror(errno);
+                continue;
+            }
+            uint64_t got = 0;
+            while (got < c.size) {
+                const ssize_t r = pread(fd, buf + c.blob_off + got, c.size - got, (off_t)got);
+                if (r < 0 && errno == EINTR) continue;
+                if (r <= 0) {
+                    c.rc = MI_ERR_IO;
+                    c.err = "read " + (d->path == "/" ? "/" + c.name : d->path + "/" + c.name) + ": " +
+                            (r == 0 ? std::string("file shorter than the size given") : std::string(strerror(errno)));
+                    break;
+                }
+                got += (uint64_t)r;
+            }
+            close(fd);
+        }
+    }
+
     void worker() {
+        if (inline_reads && walk_unshare() && unshare(CLONE_FILES) == 0)   // a descriptor table of this thread's own (see above);
+            (void)syscall(SYS_close_range, 3u, ~0u, 0u);     // it starts empty: the copies of the process's descriptors go
         for (;;) {
             DirRec* d = nullptr;
             bool skip_read = false;
@@ -356,6 +505,11 @@ struct ParallelWalker {
         if (w->rc) return;
         wait_done(d);                                        // usually is: the readers go depth-first too
         if (d->rc) { w->rc = d->rc; w->err = d->err; return; }
+        uint64_t block_at = 0;
+        if (d->blob_len || d->blob_files) {
+            if (d->blob_len) { if (!w->place_block(d->blob, d->blob_len, d->blob_files, &block_at)) return; }
+            else { w->handed_files += d->blob_files; }           // empty files only: rows without bytes
+        }
         std::string path, crel;
         for (const Child& c : d->kids) {
             if (c.rc) { w->rc = c.rc; w->err = c.err; return; }
@@ -369,7 +523,8 @@ struct ParallelWalker {
             st.st_uid = c.uid;
             st.st_gid = c.gid;
             st.st_size = (off_t)c.size;
-            w->emit(path, st, S_ISLNK(c.mode) ? &c.link : nullptr, &crel);
+            const uint64_t placed = block_at + (c.blob_off == ~0ull ? 0 : c.blob_off);
+            w->emit(path, st, S_ISLNK(c.mode) ? &c.link : nullptr, &crel, c.blob_off == ~0ull ? nullptr : &placed);
             if (w->rc) return;
             if (c.sub) { assemble(c.sub.get(), crel); if (w->rc) return; }
         }
@@ -405,6 +560,10 @@ static void walk_root(Walker* w, const std::string& root) {
     if (w->rc || !S_ISDIR(st.st_mode)) return;
     ParallelWalker pw;
     pw.w = w;
+    if (w->batch && inline_budget()) {
+        const char* e = getenv("MI_WALK_INLINE");
+        pw.inline_reads = !(e && *e == '0');
+    }
     w->ahead_files = &pw.seen_files;
     w->ahead_bytes = &pw.seen_bytes;
     struct Detach { Walker* w; ~Detach() { w->ahead_files = w->ahead_bytes = nullptr; } } detach{w};

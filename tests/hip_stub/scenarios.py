@@ -196,6 +196,43 @@ def scenario_tree_reserves_ahead(tmp, threads, slab):
         check(b, b"".join(want[p] for p in sorted(want)), "tree")
         assert grown <= 4, "the 36 MB arena was allocated %d times" % grown
         print("   arena allocations for 6 000 files without hints:", grown, flush=True)
+    # a mixed tree: small files are read where the walk lists them (one block per directory), larger ones go to the reader
+    # threads as paths, empty files are rows without bytes; nested directories, a symlink, names that sort between them --
+    # the file table keeps filepath.Walk's order whatever way the bytes took
+    d2 = os.path.join(tmp, "mixed")
+    want2 = {}
+    sizes = [0, 1, 255, 256, 257, 4096, 32768, 32769, 70000, 300000, 1 << 20, 5, 0, 33]
+    for k, rel in enumerate(["a/x", "a/y/z", "a/y", "b", ".", "a/y/z/deep/er", "c c", "a.b"]):
+        os.makedirs(os.path.join(d2, rel), exist_ok=True)
+        for j, n in enumerate(sizes[k:] + sizes[:k]):
+            data = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+            p = os.path.join(d2, rel, "f%02d-%d" % (j, n)) if rel != "." else os.path.join(d2, "f%02d-%d" % (j, n))
+            with open(p, "wb") as fh:
+                fh.write(data)
+            want2[os.path.normpath(p)] = data
+    os.symlink("f00-0", os.path.join(d2, "a", "link"))
+
+    def walk_order(root):                                   # filepath.Walk: lexical, a directory before its contents
+        out = []
+        for name in sorted(os.listdir(root)):
+            p = os.path.join(root, name)
+            if os.path.islink(p):
+                continue
+            if os.path.isdir(p):
+                out += walk_order(p)
+            else:
+                out.append(p)
+        return out
+    with M.Engine(n_streams=threads, staging_bytes=slab) as eng, eng.batch() as b:
+        n_entries = b.add_tree(d2)
+        b.run()
+        order = walk_order(d2)
+        assert len(order) == len(want2) == len(b.files())
+        check(b, b"".join(want2[os.path.normpath(p)] for p in order), "tree (mixed)")
+        ents = b.tree_entries(n_entries)
+        files = [e for e in ents if e[4] == M.KIND_FILE]
+        assert [e[2] for e in files] == list(range(len(files))), "file indices follow the walk"
+        assert [e[3] for e in files] == [len(want2[os.path.normpath(p)]) for p in order]
 
 
 def scenario_two_ctxs(tmp, threads, slab):

@@ -42,6 +42,16 @@ def test_every_staged_byte_lands_where_the_file_table_says(hip_double, tmp_path,
     _run(hip_double, tmp_path, threads, slab)
 
 
+def test_with_the_walk_handing_every_file_over_as_a_path(hip_double, tmp_path):
+    """MI_WALK_INLINE=0: no file is read where it is listed (round 3's way); the same bytes, the same order"""
+    _run(hip_double, tmp_path, 4, 65536, {"MI_WALK_INLINE": "0"})
+
+
+def test_with_a_block_budget_that_runs_out(hip_double, tmp_path):
+    """MI_WALK_INLINE_MB=1: after a megabyte of blocks alive the directories' files go as paths again -- mixed ways"""
+    _run(hip_double, tmp_path, 4, 65536, {"MI_WALK_INLINE_MB": "1"})
+
+
 def test_with_slow_copies(hip_double, tmp_path):
     """every queued copy takes 100 us longer: what returns early shows"""
     _run(hip_double, tmp_path, 8, 65536, {"MI_HIP_STUB_COPY_US": "100"})

@@ -33,7 +33,16 @@ def main():
                 paths.append(p)
         n, total = len(paths), len(paths) * (kib << 10)
         with M.Engine() as e:
+            if os.environ.get("PREWARM"):                      # what of the first run's cost is the ctx's first host-fed batch?
+                t0 = time.perf_counter()
+                w = e.batch(1, 4 << 20)
+                w.add_bytes(bytes(4 << 20), 0)
+                w.run()
+                w.free()
+                print("prewarm: a 4 MiB host-fed batch first: %.1f ms" % ((time.perf_counter() - t0) * 1e3), flush=True)
+            t0 = time.perf_counter()
             b = e.batch(n, total)
+            print("batch begin with hints (%d files, %d MB): %.1f ms" % (n, total >> 20, (time.perf_counter() - t0) * 1e3), flush=True)
             for rep in range(3):
                 b.reset()
                 t0 = time.perf_counter()

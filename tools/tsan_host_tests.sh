@@ -2,7 +2,8 @@
 # The threaded host code (parallel walk, the layer writer's tee / sink threads / deflate pool, the tar reader, and -- on
 # the HIP test double of tests/hip_stub -- the reader threads, pinned slabs and stream ordering of the host-fed path) under
 # ThreadSanitizer -- the reference runs its tests with `go test -race`.  No GPU needed.  Reports go to $OUT/report.*;
-# the script fails if there is one.
+# the script fails if there is one.  (MI_WALK_UNSHARE=0: the walk's directory readers keep the process's descriptor table --
+# the detector models descriptors per process and reports two threads' private "fd 4" as one.)
 #   tools/tsan_host_tests.sh [pytest args; default: the host test files]
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
@@ -25,7 +26,7 @@ ARGS=("$@")
                                 tests/test_host_tar.py tests/test_host_tar_properties.py tests/test_host_copy_ops.py
                                 tests/test_host_apply_properties.py tests/test_host_diff_properties.py
                                 tests/test_host_hip_double.py)
-LD_PRELOAD=$RT TSAN_OPTIONS=halt_on_error=0:report_signal_unsafe=0:exitcode=0:log_path="$OUT/report" \
+MI_WALK_UNSHARE=0 LD_PRELOAD=$RT TSAN_OPTIONS=halt_on_error=0:report_signal_unsafe=0:exitcode=0:log_path="$OUT/report" \
     MAKISU_MI_LIB="$OUT/libmakisu_mi.so" python -m pytest -q -p no:cacheprovider "${ARGS[@]}"
 if ls "$OUT"/report.* >/dev/null 2>&1; then
     grep -h "SUMMARY" "$OUT"/report.* | sort | uniq -c
