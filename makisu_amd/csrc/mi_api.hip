@@ -120,10 +120,22 @@ int ensure_ring(mi_batch* b) {
 
 int ensure_stager(mi_ctx* c) {
     if (!c->stager) c->stager = stager_create(c, c->stage_threads, c->staging_bytes);
-    if (!c->stager)
-        return fail(c, MI_ERR_NOMEM, "host-fed staging: none of the %u reader threads could allocate its "
-                    "%llu-byte pinned slab and copy stream", c->stage_threads, (unsigned long long)c->staging_bytes);
+    if (!c->stager_checked) {
+        if (!stager_ready(c->stager)) {
+            stager_destroy(c->stager);
+            c->stager = nullptr;
+            return fail(c, MI_ERR_NOMEM, "host-fed staging: none of the %u reader threads could allocate its "
+                        "%llu-byte pinned slab and copy stream", c->stage_threads, (unsigned long long)c->staging_bytes);
+        }
+        c->stager_checked = true;
+    }
     return MI_OK;
+}
+// host-fed bytes are on their way (a tree walk has begun): the reader threads set up while the walk lists its first
+// directories; the first block or path that reaches them waits for whoever is not ready yet
+extern "C" void mi_batch_expect_host_bytes(mi_batch* b) {
+    mi_ctx* c = b->ctx;
+    if (!c->stager) c->stager = stager_create(c, c->stage_threads, c->staging_bytes);
 }
 
 int staging_flush(mi_batch* b) {

@@ -67,8 +67,8 @@ int stage_verify_final(mi_batch* b);
 
 // mi_stage.hip: reader threads + pinned slabs behind mi_batch_add_path / large mi_batch_add_bytes
 struct Stager;
-// nullptr when no reader thread could get its pinned slab and stream
-Stager* stager_create(mi_ctx* c, u32 n_threads, u64 slab_bytes);
+Stager* stager_create(mi_ctx* c, u32 n_threads, u64 slab_bytes);   // returns at once: the readers set up behind it
+bool    stager_ready(Stager* st);                                   // waits for them; false: none got slab + stream
 void    stager_destroy(Stager* st);
 int     stager_put_bytes(Stager* st, mi_batch* b, u64 arena_off, const void* src, u64 len);
 int     stager_put_file(Stager* st, mi_batch* b, u64 arena_off, int fd, u64 file_off, u64 len, const char* path);
@@ -85,6 +85,7 @@ struct mi_ctx {
     hipDeviceProp_t prop;
     hipStream_t stream = nullptr;        // ctx-level work (mi_dedup_mark, mi_sha256_many, uploads)
     mi::Stager* stager = nullptr;        // reader threads + pinned slabs, created on the first host-fed add
+    bool stager_checked = false;         // ... and found able to take work (stager_ready)
     mi::u32 stage_threads = 0;
     size_t staging_bytes = 0;            // bytes per pinned slab (reader threads, per-batch inline ring)
     int live_children = 0;               // batches + indexes that still point at this ctx

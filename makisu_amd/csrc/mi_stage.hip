@@ -369,21 +369,22 @@ void worker(Stager* st, u32 tid) {
 
 }  // namespace
 
+// The reader threads start setting up (a pinned slab and a copy stream each: milliseconds) and the call returns;
+// stager_ready waits for them -- whoever knows early that host-fed bytes are coming (the tree walk) starts the
+// readers first and meets them when the first bytes are there.
 Stager* stager_create(mi_ctx* c, u32 n_threads, u64 slab_bytes) {
     Stager* st = new Stager();
     st->ctx = c;
     st->slab_bytes = slab_bytes;
     st->init_left = n_threads;
     for (u32 i = 0; i < n_threads; ++i) st->threads.emplace_back(worker, st, i);
-    {
-        std::unique_lock<std::mutex> lk(st->mu);
-        st->cv_init.wait(lk, [&] { return st->init_left == 0; });
-    }
-    if (st->n_ok == 0) {                                       // nobody could take work: say so now, not per batch
-        stager_destroy(st);
-        return nullptr;
-    }
     return st;
+}
+// true when at least one reader thread got its slab and stream (false: nobody can take work -- say so now, not per batch)
+bool stager_ready(Stager* st) {
+    std::unique_lock<std::mutex> lk(st->mu);
+    st->cv_init.wait(lk, [&] { return st->init_left == 0; });
+    return st->n_ok != 0;
 }
 
 void stager_destroy(Stager* st) {

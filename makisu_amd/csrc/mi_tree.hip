@@ -43,12 +43,14 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <sys/syscall.h>
 #include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <map>
@@ -68,6 +70,7 @@ extern "C" int mi_batch_add_block(mi_batch* b, const void* src, uint64_t len, vo
                                   uint64_t* at_out);
 extern "C" int mi_batch_add_placed(mi_batch* b, uint64_t n, const uint64_t* arena_off, const uint64_t* sizes,
                                    const uint64_t* tags);
+extern "C" void mi_batch_expect_host_bytes(mi_batch* b);
 
 namespace mi_walk {
 
@@ -301,6 +304,74 @@ static uint64_t inline_file_max() {
     }();
     return v;
 }
+// The blocks' memory: recycled, not returned.  A 2 MB block from the C library is its own mapping -- page faults for
+// every one of its pages, by 16 threads in one address space, and an unmap when the reader threads let go of it: 100 000
+// 4 KiB files then spend more time faulting than reading.  Freed blocks wait here by size class (powers of two from
+// 64 KiB; at most 512 MiB kept), and since a block lives only until a reader thread has copied it, a walk cycles through
+// a few tens of megabytes.
+struct BlockPool {
+    std::mutex mu;
+    std::vector<uint8_t*> free_[16];                          // class k: 64 KiB << k
+    uint64_t kept = 0;
+    static int cls(uint64_t n) { int k = 0; while ((65536ull << k) < n && k < 15) ++k; return k; }
+    static uint64_t cap(int k) { return 65536ull << k; }
+    // memory of a class: from 2 MiB up its own mapping on a 2 MiB boundary, advised to use huge pages -- the first touch
+    // of a 2 MB block is then one fault, not 512 taken by 16 threads under one address-space lock (the first walk of a
+    // process: 330 ms of the directory readers' 900 ms went into faults, profiles/r04_many_small_files.txt)
+    static uint8_t* fresh(uint64_t capacity) {
+        if (capacity < (2ull << 20)) return new (std::nothrow) uint8_t[capacity];
+        void* p = mmap(nullptr, capacity + (2ull << 20), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (p == MAP_FAILED) return nullptr;
+        uint8_t* a = (uint8_t*)(((uintptr_t)p + (2ull << 20) - 1) & ~((uintptr_t)(2ull << 20) - 1));
+        if (a > (uint8_t*)p) munmap(p, (size_t)(a - (uint8_t*)p));
+        const uint64_t tail = (uint64_t)((uint8_t*)p + capacity + (2ull << 20) - (a + capacity));
+        if (tail) munmap(a + capacity, tail);
+        (void)madvise(a, capacity, MADV_HUGEPAGE);
+        return a;
+    }
+    static void release(uint8_t* p, uint64_t capacity) {
+        if (capacity < (2ull << 20)) delete[] p; else munmap(p, capacity);
+    }
+    uint8_t* get(uint64_t n, uint64_t* cap_out) {
+        const int k = cls(n);
+        if (cap(k) < n) {                                                             // beyond the largest class
+            *cap_out = (n + (2ull << 20) - 1) & ~((2ull << 20) - 1);
+            return fresh(*cap_out);
+        }
+        *cap_out = cap(k);
+        {
+            std::lock_guard<std::mutex> g(mu);
+            if (!free_[k].empty()) {
+                uint8_t* p = free_[k].back();
+                free_[k].pop_back();
+                kept -= cap(k);
+                return p;
+            }
+        }
+        return fresh(cap(k));
+    }
+    void put(uint8_t* p, uint64_t capacity) {
+        const int k = cls(capacity);
+        if (cap(k) == capacity) {
+            std::lock_guard<std::mutex> g(mu);
+            if (kept + capacity <= (512ull << 20)) { free_[k].push_back(p); kept += capacity; return; }
+        }
+        release(p, capacity);
+    }
+};
+static BlockPool& block_pool() { static BlockPool* p = new BlockPool(); return *p; }   // never destroyed: blocks may outlive exit handlers
+
+// MI_WALK_TIMING=1: one line per walk on stderr -- where the directory readers' time went (summed over the threads) and
+// when the assembly and the readers were done
+static bool walk_timing() {
+    static const bool on = [] { const char* e = getenv("MI_WALK_TIMING"); return e && *e && *e != '0'; }();
+    return on;
+}
+static std::atomic<uint64_t> g_ns_list{0}, g_ns_stat{0}, g_ns_block{0}, g_ns_read{0}, g_ns_unshare{0};
+static inline uint64_t now_ns() {
+    return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 static bool walk_unshare() {
     static const bool on = [] { const char* e = getenv("MI_WALK_UNSHARE"); return !(e && *e == '0'); }();
     return on;
@@ -349,6 +420,7 @@ struct ParallelWalker {
             if (fd >= 0) close(fd);
             return;
         }
+        const uint64_t tl0 = walk_timing() ? now_ns() : 0;
         std::vector<std::string> names;
         while (struct dirent* de = readdir(dir)) {
             if (!strcmp(de->d_name, ".") || !strcmp(de->d_name, "..")) continue;
@@ -357,6 +429,8 @@ struct ParallelWalker {
         std::sort(names.begin(), names.end());              // sort.Strings: bytewise
         d->kids.resize(names.size());
         std::vector<DirRec*> subs;
+        const uint64_t ts0 = tl0 ? now_ns() : 0;
+        if (tl0) g_ns_list += ts0 - tl0;
         for (size_t i = 0; i < names.size(); ++i) {
             Child& c = d->kids[i];
             c.name.swap(names[i]);
@@ -389,6 +463,7 @@ struct ParallelWalker {
                 c.link.assign(buf, (size_t)n);
             }
         }
+        if (ts0) g_ns_stat += now_ns() - ts0;
         if (inline_reads) read_small_files(d, fd);
         closedir(dir);                                       // closes fd
         if (!subs.empty()) {
@@ -416,16 +491,24 @@ struct ParallelWalker {
             for (Child& c : d->kids) c.blob_off = ~0ull;
             return;
         }
-        uint8_t* buf = total ? new (std::nothrow) uint8_t[total] : nullptr;
+        uint64_t capacity = 0;
+        const uint64_t tb0 = walk_timing() ? now_ns() : 0;
+        uint8_t* buf = total ? block_pool().get(total, &capacity) : nullptr;
+        if (tb0 && buf) { memset(buf, 0, 1); g_ns_block += now_ns() - tb0; }
         if (total && !buf) {
             g_inline_bytes.fetch_sub(total);
             for (Child& c : d->kids) c.blob_off = ~0ull;
             return;
         }
-        d->blob = std::shared_ptr<uint8_t[]>(buf, [total](uint8_t* p) { delete[] p; g_inline_bytes.fetch_sub(total); });
+        d->blob = std::shared_ptr<uint8_t[]>(buf, [total, capacity](uint8_t* p) {
+            if (p) block_pool().put(p, capacity);
+            g_inline_bytes.fetch_sub(total);
+        });
         d->blob_len = total;
         d->blob_files = n;
         uint64_t end = 0;
+        const uint64_t tr0 = walk_timing() ? now_ns() : 0;
+        struct AddUp { uint64_t t0; ~AddUp() { if (t0) g_ns_read += now_ns() - t0; } } add_up{tr0};
         for (Child& c : d->kids) {
             if (c.blob_off == ~0ull) continue;
             if (c.blob_off > end) memset(buf + end, 0, c.blob_off - end);       // alignment gap
@@ -454,8 +537,10 @@ struct ParallelWalker {
     }
 
     void worker() {
+        const uint64_t tu0 = walk_timing() ? now_ns() : 0;
         if (inline_reads && walk_unshare() && unshare(CLONE_FILES) == 0)   // a descriptor table of this thread's own (see above);
             (void)syscall(SYS_close_range, 3u, ~0u, 0u);     // it starts empty: the copies of the process's descriptors go
+        if (tu0) g_ns_unshare += now_ns() - tu0;
         for (;;) {
             DirRec* d = nullptr;
             bool skip_read = false;
@@ -570,9 +655,18 @@ static void walk_root(Walker* w, const std::string& root) {
     DirRec top;
     top.path = root;
     const std::string root_rel = w->tree->entries.back().relpath;   // the root's own entry was just emitted (a copy:
+    const uint64_t tw0 = walk_timing() ? now_ns() : 0;
+    if (tw0) { g_ns_list = 0; g_ns_stat = 0; g_ns_block = 0; g_ns_read = 0; g_ns_unshare = 0; }
     pw.start(&top, nt);                                               // the vector grows under the assembly)
     pw.assemble(&top, root_rel);       // behind the readers: files reach the batch while the walk goes on
+    const uint64_t tw1 = tw0 ? now_ns() : 0;
     pw.finish();
+    if (tw0)
+        fprintf(stderr, "mi_walk: %u threads; assembly done after %.1f ms, threads joined after %.1f ms; summed over the threads: "
+                "unshare %.1f ms, readdir + sort %.1f, fstatat + rules %.1f, block from the pool (first byte touched) %.1f, "
+                "open + pread + close %.1f; %llu files seen\n", nt, (tw1 - tw0) / 1e6, (now_ns() - tw0) / 1e6,
+                g_ns_unshare.load() / 1e6, g_ns_list.load() / 1e6, g_ns_stat.load() / 1e6, g_ns_block.load() / 1e6,
+                g_ns_read.load() / 1e6, (unsigned long long)pw.seen_files.load());
 }
 
 // the walk the copy ops need (mi_memfs.hip): one source, scan rules, no blacklist
@@ -613,6 +707,7 @@ int mi_batch_add_tree(mi_batch* b, const char* root, const char* rel_base, const
     for (uint64_t i = 0; i < n_blacklist; ++i) w.blacklist.push_back(blacklist[i]);
     std::string r = root;
     while (r.size() > 1 && r.back() == '/') r.pop_back();
+    mi_batch_expect_host_bytes(b);                           // the reader threads set up while the walk begins
     mi_walk::walk_root(&w, r);
     w.flush_pending();
     if (w.rc) {

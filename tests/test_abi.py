@@ -47,7 +47,7 @@ def test_the_core_export_set(engine_lib):
     out = subprocess.check_output(["nm", "-D", "--defined-only", os.path.join(ROOT, "makisu_amd", "libmakisu_mi.so")]).decode()
     exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln and ln.split()[-1].startswith("mi_")}
     internal = {"mi_set_error", "mi_batch_tree_slot", "mi_batch_tree_free", "mi_dedup_mark_range_enqueue", "mi_batch_add_block",
-                "mi_batch_add_placed"}       # cross-file helpers of the library itself
+                "mi_batch_add_placed", "mi_batch_expect_host_bytes"}       # cross-file helpers of the library itself
     extra = exported - core - set(HOST_HELPERS) - internal
     assert not extra, "exported but declared in neither header: %s" % sorted(extra)
 
