@@ -165,6 +165,11 @@ typedef struct {
 
 /* ---- context ----------------------------------------------------------------- */
 int  mi_abi_version(void);
+/* Diagnostics: from now on every chunk-pass launch of this ctx runs the recording instantiation of the hashing kernel
+ * and appends one record per wave to `path` (where it ran, when, how much it hashed: tools/sha_wave_stats.py reads it);
+ * each such launch is followed by a stream synchronize -- never on a ctx whose time is measured.  NULL or "" turns it
+ * off.  MI_SHA_WAVE_STATS=<file> in the environment of mi_ctx_create does the same for the new ctx.              */
+int  mi_debug_sha_wave_stats(mi_ctx* ctx, const char* path);
 int  mi_config_default(mi_config* cfg);
 int  mi_ctx_create(const mi_config* cfg, mi_ctx** out);
 /* Batches and indexes hold a pointer to their ctx: free them first (mi_batch_free /

@@ -174,6 +174,7 @@ def load_library(rebuild=False):
     vp, u64, u64p = C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)
     sigs = {
         "mi_abi_version": ([], C.c_int),
+        "mi_debug_sha_wave_stats": ([vp, C.c_char_p], C.c_int),
         "mi_config_default": ([C.POINTER(Config)], C.c_int),
         "mi_ctx_create": ([C.POINTER(Config), C.POINTER(vp)], C.c_int),
         "mi_ctx_destroy": ([vp], C.c_int),

@@ -616,6 +616,13 @@ void mi_batch_tree_free(void* tree);                   // mi_tree.hip
 
 int mi_abi_version(void) { return MI_ABI_VERSION; }
 
+int mi_debug_sha_wave_stats(mi_ctx* c, const char* path) {
+    if (!c) return MI_ERR_INVALID;
+    c->sha_wave_stats = path ? path : "";
+    c->sha.wave_stats_path = c->sha_wave_stats.empty() ? nullptr : c->sha_wave_stats.c_str();
+    return MI_OK;
+}
+
 int mi_config_default(mi_config* cfg) {
     if (!cfg) return MI_ERR_INVALID;
     memset(cfg, 0, sizeof *cfg);
@@ -740,6 +747,7 @@ int mi_ctx_create(const mi_config* cfg, mi_ctx** out) {
     if (const char* e = getenv("MI_SHA_PIN_BLOCKS")) c->sha.pin_blocks_per_cu = atoi(e) != 0;
     if (const char* e = getenv("MI_SHA_ROLES")) c->sha.roles = atoi(e) != 0;
     if (const char* e = getenv("MI_SHA_PRIO")) c->sha.prio = atoi(e) != 0;
+    if (const char* e = getenv("MI_SHA_WAVE_STATS")) (void)mi_debug_sha_wave_stats(c, e);     // diagnostics, read per ctx here
     if (const char* e = getenv("MI_SHA_LONG_SHIFT")) {
         const int v = atoi(e);
         if (v >= 0 && v <= 16) c->sha.long_shift = v;

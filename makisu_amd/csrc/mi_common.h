@@ -125,6 +125,8 @@ struct ShaTune {
                                              // priorities cost 2 % (5.72 vs 5.61 ms per C2 step): off.
     int long_shift = 2;                      // the first n >> long_shift strings (the longest) go to the wave that
                                              // arrived first on each SIMD and runs at priority (sha256.hip roles)
+    const char* wave_stats_path = nullptr;   // diagnostics (mi_debug_sha_wave_stats): per-wave records of every chunk pass
+                                             // of this ctx are appended to this file; the ctx owns the string
 };
 // n = string count (or its upper bound when d_n, a device word holding the real count, is given)
 // d_heads and d_roles must be zero on entry unless zero_heads (then the launcher clears them first)

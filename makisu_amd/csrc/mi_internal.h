@@ -99,6 +99,7 @@ struct mi_ctx {
     bool sha_done_set = false;           // (the next one waits for it: mi_api.hip submit_pipeline)
     bool serialize_sha = false;          // MI_SHA_SERIALIZE=0: let the chunk passes of two batches overlap
     mi::ShaTune sha;                     // per ctx (mi_config.sha_*), not per process
+    std::string sha_wave_stats;          // mi_debug_sha_wave_stats: the file sha.wave_stats_path points at
     bool verify_staging = false;         // MI_FLAG_VERIFY_STAGING
     // fault injection for the tests of that flag (MI_STAGE_FAULT=copy:N | final:N): the N-th span a
     // reader copies loses 4 KiB right after its copy / just before the end-of-staging pass

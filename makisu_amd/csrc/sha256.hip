@@ -463,6 +463,38 @@ void sha256_items_kernel(const u8* __restrict__ base, const u64* __restrict__ of
     }
 }
 
+// Diagnostics (mi_debug_sha_wave_stats / MI_SHA_WAVE_STATS=<file> at ctx creation): the chunk pass with the per-wave
+// record -- appended to `path` per launch: {grid, waves per workgroup, coop, n}, then 8 words per wave: HW_ID, XCC_ID |
+// role << 8, start on the 100 MHz wall clock (low word), ticks in the loop-top s_waitcnt, duration, loop iterations,
+// lane-blocks hashed, iterations with all 64 lanes mid-string (tools/sha_wave_stats.py reads it).  The launch is followed
+// by a stream synchronize and a read-back: a ctx that records is not a ctx to time anything else on.
+static void launch_sha256_chunks_recorded(bool coop, u32 grid, size_t lds_pad, const u8* d_base, const u64* d_off,
+                                          const u64* d_len, const u32* d_order, u32 n, const u64* d_n, u32* d_heads,
+                                          u32* d_roles, u32 shift_flags, u8* d_out, const char* path, hipStream_t s) {
+    u32* d_stats = nullptr;
+    const size_t stats_words = (size_t)grid * (kShaWG / 64) * 8;
+    if (hipMalloc((void**)&d_stats, stats_words * sizeof(u32)) != hipSuccess) d_stats = nullptr;
+    else (void)hipMemsetAsync(d_stats, 0, stats_words * sizeof(u32), s);
+    if (coop)
+        hipLaunchKernelGGL((sha256_items_kernel<kShaChunks, true, true>), dim3(grid), dim3(kShaWG), lds_pad, s, d_base, d_off,
+                           d_len, d_order, n, d_n, d_heads, d_roles, shift_flags, d_out, d_stats);
+    else
+        hipLaunchKernelGGL((sha256_items_kernel<kShaChunks, false, true>), dim3(grid), dim3(kShaWG), lds_pad, s, d_base, d_off,
+                           d_len, d_order, n, d_n, d_heads, d_roles, shift_flags, d_out, d_stats);
+    if (!d_stats) return;
+    std::vector<u32> h(stats_words);
+    if (hipStreamSynchronize(s) == hipSuccess &&
+        hipMemcpy(h.data(), d_stats, stats_words * sizeof(u32), hipMemcpyDeviceToHost) == hipSuccess) {
+        if (FILE* f = fopen(path, "ab")) {
+            const u32 hdr[4] = {grid, (u32)(kShaWG / 64), coop ? 1u : 0u, n};
+            fwrite(hdr, sizeof(u32), 4, f);
+            fwrite(h.data(), sizeof(u32), stats_words, f);
+            fclose(f);
+        }
+    }
+    (void)hipFree(d_stats);
+}
+
 // With the TLB out of the way (cooperative loads) a third workgroup per CU pays (161 VGPRs: three
 // waves per SIMD fit): 26 GB arena 1.43 (byte loads, 2/CU) -> 1.57 (cooperative, 2/CU) -> 1.63 TB/s
 // (cooperative, 3/CU); on 6.5 GB three are slower with either scheme (coarser tail).
@@ -511,47 +543,23 @@ void launch_sha256_items(ShaPass pass, const u8* d_base, const u64* d_off, const
     // keep the grid a multiple of the queue count so every queue has the same number of pullers
     if (grid >= (u32)kShaQueues) grid -= grid % kShaQueues;
     if (grid == 0) grid = 1;
-    // Diagnostics: MI_SHA_WAVE_STATS=<file> appends, for every chunk-pass launch, one record per wave
-    // ({grid, waves per workgroup, coop, n} header, then 8 words per wave: HW_ID, XCC_ID | role << 8, start on the
-    // 100 MHz wall clock (low word), ticks in the loop-top s_waitcnt, duration, loop iterations, lane-blocks hashed, iterations with all 64 lanes mid-string) -- tools/sha_wave_stats.py reads it.  The launch
-    // is followed by a stream synchronize then: never set it for a measurement of anything else.
-    static const char* const stats_path = getenv("MI_SHA_WAVE_STATS");
-    u32* d_stats = nullptr;
-    const size_t stats_words = (size_t)grid * (kShaWG / 64) * 8;
-    if (stats_path && *stats_path && pass == kShaChunks) {
-        if (hipMalloc((void**)&d_stats, stats_words * sizeof(u32)) != hipSuccess) d_stats = nullptr;
-        else (void)hipMemsetAsync(d_stats, 0, stats_words * sizeof(u32), s);
-    }
 #define MI_SHA_LAUNCH(P, C)                                                                   \
     hipLaunchKernelGGL((sha256_items_kernel<P, C>), dim3(grid), dim3(kShaWG), lds_pad, s, d_base, d_off, \
                        d_len, d_order, n, d_n, d_heads, d_roles, (u32)tune.long_shift | (tune.prio ? 0u : 0x100u), d_out, nullptr)
-#define MI_SHA_LAUNCH_STATS(C)                                                                \
-    hipLaunchKernelGGL((sha256_items_kernel<kShaChunks, C, true>), dim3(grid), dim3(kShaWG), lds_pad, s, d_base, d_off, \
-                       d_len, d_order, n, d_n, d_heads, d_roles, (u32)tune.long_shift | (tune.prio ? 0u : 0x100u), d_out, d_stats)
     switch (pass) {
         case kShaChunks:
-            if (d_stats) { if (coop) MI_SHA_LAUNCH_STATS(true); else MI_SHA_LAUNCH_STATS(false); }
-            else if (coop) MI_SHA_LAUNCH(kShaChunks, true); else MI_SHA_LAUNCH(kShaChunks, false);
+            if (tune.wave_stats_path) {      // diagnostics, per ctx (mi_debug_sha_wave_stats): the recording instantiation
+                launch_sha256_chunks_recorded(coop, grid, lds_pad, d_base, d_off, d_len, d_order, n, d_n, d_heads, d_roles,
+                                              (u32)tune.long_shift | (tune.prio ? 0u : 0x100u), d_out, tune.wave_stats_path, s);
+                break;
+            }
+            if (coop) MI_SHA_LAUNCH(kShaChunks, true); else MI_SHA_LAUNCH(kShaChunks, false);
             break;
         case kShaRoots:  MI_SHA_LAUNCH(kShaRoots, false); break;
         case kShaFiles:  if (coop) MI_SHA_LAUNCH(kShaFiles, true); else MI_SHA_LAUNCH(kShaFiles, false); break;
         default:         if (coop) MI_SHA_LAUNCH(kShaBlobs, true); else MI_SHA_LAUNCH(kShaBlobs, false); break;
     }
 #undef MI_SHA_LAUNCH
-#undef MI_SHA_LAUNCH_STATS
-    if (d_stats) {
-        std::vector<u32> h(stats_words);
-        if (hipStreamSynchronize(s) == hipSuccess &&
-            hipMemcpy(h.data(), d_stats, stats_words * sizeof(u32), hipMemcpyDeviceToHost) == hipSuccess) {
-            if (FILE* f = fopen(stats_path, "ab")) {
-                const u32 hdr[4] = {grid, (u32)(kShaWG / 64), coop ? 1u : 0u, n};
-                fwrite(hdr, sizeof(u32), 4, f);
-                fwrite(h.data(), sizeof(u32), stats_words, f);
-                fclose(f);
-            }
-        }
-        (void)hipFree(d_stats);
-    }
 }
 
 // ---- the VALU roof of this file's compression, measured on the device it runs on ------------------
