@@ -203,6 +203,35 @@ def test_native_exchange_n_ctxs_in_one_process(oracle, stub, tmp_path, n, case):
     _check(oracle, str(tmp_path), n, case)
 
 
+def test_plain_c_exchange(oracle, stub, tmp_path):
+    """The single-process form from plain C (tests/cabi/exchange_driver.c: one ctx per rank, a host thread per rank for
+    the scan, mi_comm_init_all, mi_dedup_allgather_all twice) with 8 ranks on this GPU: the printed dup_of of every rank
+    is the oracle's marking of the rank-major concatenation; half of the job's chunks repeat the previous rank's."""
+    exe = str(tmp_path / "exchange_driver")
+    subprocess.check_call(["gcc", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cabi", "exchange_driver.c"), "-o", exe,
+                           "-L", os.path.join(ROOT, "makisu_amd"), "-lmakisu_mi", "-lpthread",
+                           "-Wl,-rpath," + os.path.join(ROOT, "makisu_amd")])
+    n, per = 8, 600
+    out = subprocess.run([exe, str(n), str(per), "0"], env=dict(os.environ, MI_RCCL_LIB=stub), capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0, out.stdout[-500:] + out.stderr[-2000:]
+    lines = out.stdout.splitlines()
+    ranks = [ln.split() for ln in lines if ln.startswith("K ")]
+    rows = [ln.split() for ln in lines if ln.startswith("C ")]
+    n_total, n_unique, seen = (int(x) for x in lines[-1].split()[1:])
+    assert lines[-1].startswith("T ") and seen == n and len(ranks) == n and len(rows) == n_total
+    sha = np.array([bytearray.fromhex(r[3][len("sha256:"):]) for r in rows], dtype=np.uint8)
+    want, want_unique = oracle.dedup_mt(sha, 4)
+    assert np.array_equal(np.array([int(r[2]) for r in rows], dtype=np.int64), want) and n_unique == want_unique
+    first = 0
+    for r, (_, rank, nc, fg, dups, gather, marking) in enumerate(ranks):
+        assert (int(rank), int(fg)) == (r, first) and float(marking) > 0
+        assert r == 0 or int(dups) > int(nc) // 3                    # the first half of the rank repeats its predecessor
+        first += int(nc)
+    assert n_unique < 0.65 * n_total
+
+
 def _bench_line(out):
     import json
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]

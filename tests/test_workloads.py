@@ -121,6 +121,6 @@ def test_bench_default_batches_in_flight():
     spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(root, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    assert [bench.default_inflight(c, False) for c in ("c2", "c3", "c4", "c5", "c5u")] == [2, 2, 2, 2, 2]
+    assert [bench.default_inflight(c, False) for c in ("c2", "c3", "c4", "c5", "c5u")] == [2, 1, 2, 2, 2]
     assert bench.default_inflight("c2", True) == 3 and bench.default_inflight("c4", True) == 2
     assert bench.default_inflight("c5", True) == 2
