@@ -212,6 +212,41 @@ def test_bulk_add_paths_and_tree_walk_with_deferred_opens(oracle, tmp_path):
                 b.run()
 
 
+def test_tree_walk_blocks_verified_and_reused(oracle, tmp_path):
+    """Round 4: the walk's directory readers read files up to 32 KiB where they list them -- one block of host memory per
+    directory, one piece of the arena each -- and larger ones still go to the reader threads as paths.  A nested tree that
+    mixes both (and empty files, and directories with a single file) through ONE batch that is reset and walked three
+    times, every staged span verified (MI_FLAG_VERIFY_STAGING sums the blocks' copies like any other): bit-exact against
+    the oracle in filepath.Walk order each time, no mismatching span."""
+    import makisu_amd
+    rng = np.random.default_rng(21)
+    root = tmp_path / "tree"
+    blobs = {}
+    k = 0
+    for d in ["", "a", "a/b", "a/b/c", "z z", "m", "m/only"]:
+        (root / d).mkdir(parents=True, exist_ok=True)
+        n_files = 1 if d == "m/only" else 400
+        for _ in range(n_files):
+            n = int(rng.choice([0, 1, 255, 256, 4096, 20000, 32768, 32769, 70000, 400000], p=[.05, .1, .1, .1, .3, .2, .05, .04, .04, .02]))
+            p = root / d / ("f%05d" % k)
+            data = oracle.synth_fill(SEED, 9000 + k, 0, n).tobytes()
+            p.write_bytes(data)
+            blobs[str(p)] = data
+            k += 1
+    with makisu_amd.Engine(flags=makisu_amd.FLAG_VERIFY_STAGING) as e:
+        b = e.batch()
+        for rep in range(3):
+            b.reset()
+            ents = b.tree_entries(b.add_tree(str(root)))
+            order = [os.path.normpath(os.path.join(str(root), en[0])) for en in ents if en[4] == makisu_amd.KIND_FILE]
+            assert len(order) == len(blobs) and [en[2] for en in ents if en[4] == makisu_amd.KIND_FILE] == list(range(len(order)))
+            b.run()
+            _same(b.files(), b.chunks(), *_oracle_rows(oracle, [blobs[p] for p in order], e.cfg))
+            st = b.stage_stats()
+            assert st["spans"] > 0 and st["verified_spans"] == st["spans"] and st["mismatches"] == 0 and st["final_mismatches"] == 0, st
+        b.free()
+
+
 def test_reader_run_never_writes_over_an_inline_region(oracle, tmp_path):
     """A reader thread copies a run of queued files as ONE span; a small mi_batch_add_bytes that lies
     BETWEEN two such files travels through the batch's inline window instead.  With one (busy) reader
