@@ -124,3 +124,40 @@ def test_bench_default_batches_in_flight():
     assert [bench.default_inflight(c, False) for c in ("c2", "c3", "c4", "c5", "c5u")] == [2, 1, 2, 2, 2]
     assert bench.default_inflight("c2", True) == 3 and bench.default_inflight("c4", True) == 2
     assert bench.default_inflight("c5", True) == 2
+
+
+def test_fill_batch_hands_over_whole_files_in_runs_and_parts_one_by_one():
+    """workloads.fill_batch (bench.py and the exchange tests add a shard's items through it): runs of whole files go through
+    add_synthetic in shard order, every part of a split file through add_synthetic_part, and the returned keys name the
+    parts in the order the batch lists them -- (file key, part number), equal on every rank that holds a part of that file."""
+    class FakeBatch:
+        def __init__(self):
+            self.calls = []
+
+        def add_synthetic(self, sizes, cids, seed):
+            self.calls.append(("files", [int(x) for x in sizes], [int(x) for x in cids], seed))
+
+        def add_synthetic_part(self, fsize, cid, begin, end, seed):
+            self.calls.append(("part", int(fsize), int(cid), int(begin), int(end), seed))
+
+    world = 4
+    shards = [W.c5(r, world, bytes_per_gpu=2 * W.GIB, split_threshold=32 * W.MIB) for r in range(world)]
+    all_keys = {}
+    for r, sh in enumerate(shards):
+        fb = FakeBatch()
+        keys = W.fill_batch(fb, sh)
+        n_parts = sum(1 for p in sh.parts if p[3] >= 0)
+        assert len(keys) == n_parts == sum(1 for c in fb.calls if c[0] == "part") > 0
+        handed = []
+        for c in fb.calls:                                       # the items in shard order, whichever call carried them
+            handed += [("f", n) for n in c[1]] if c[0] == "files" else [("p", c[4] - c[3])]
+        assert [n for _, n in handed] == [int(x) for x in sh.sizes]
+        assert [k == "p" for k, _ in handed] == [p[3] >= 0 for p in sh.parts]
+        assert W.batch_bytes_hint(sh) >= sh.n_bytes + len(sh.parts) * 262144       # room for the parts' halos
+        for key in keys:
+            all_keys.setdefault(key[0], []).append((key[1], r))
+    for fkey, parts in all_keys.items():                         # every split file: parts 0 .. world-1, one per rank
+        assert sorted(p for p, _ in parts) == list(range(world)) and len({rk for _, rk in parts}) == world
+    whole = W.c4(1, 8, 1000)
+    fb = FakeBatch()
+    assert W.fill_batch(fb, whole) == [] and len(fb.calls) == 1 and fb.calls[0][0] == "files"
