@@ -428,9 +428,13 @@ typedef struct {
                                   inodes like the reference's snapshot may set it)       */
     uint32_t    uid, gid;
 } mi_tree_entry;
-/* Regular files are handed to the batch in bulk while the walk goes on (mi_batch_add_paths: the
- * reader threads open them); a file that vanishes or shrinks between the walk's lstat and the read
- * fails mi_batch_run / mi_batch_submit with MI_ERR_IO naming it.                                 */
+/* Regular files reach the batch while the walk goes on.  Files up to 32 KiB (MI_WALK_INLINE_MAX_KIB) are read by the
+ * walk's own directory readers where they are listed -- one block of host memory per directory, one piece of the arena
+ * each; those threads work on a file-descriptor table of their own (unshare(CLONE_FILES); where that is refused, on
+ * the shared one) -- and a file that cannot be opened, or has shrunk since its lstat, fails THIS call with MI_ERR_IO
+ * naming it, at its place in walk order.  Larger files are handed over in bulk as paths (mi_batch_add_paths: the
+ * reader threads open them); one of those that vanishes or shrinks fails mi_batch_run / mi_batch_submit.
+ * MI_WALK_INLINE=0: every file as a path.  Where a file lies in the arena is independent of its index.            */
 int mi_batch_add_tree(mi_batch* b, const char* root, const char* rel_base,
                       const char* const* blacklist, uint64_t n_blacklist, uint32_t mode,
                       uint64_t* n_entries);

@@ -450,7 +450,8 @@ int stager_put_block(Stager* st, mi_batch* b, u64 arena_off, const void* src, u6
         b->stage_pending += items.size();
         for (auto& it : items) st->queue.push_back(std::move(it));
     }
-    st->cv_work.notify_one();
+    if (len > st->slab_bytes) st->cv_work.notify_all();        // several pieces: several readers
+    else st->cv_work.notify_one();
     return MI_OK;
 }
 
