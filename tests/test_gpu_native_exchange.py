@@ -309,3 +309,19 @@ def test_stub_refuses_what_real_rccl_would_hang_on(stub, tmp_path):
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MI_RCCL_LIB=stub), capture_output=True,
                        text=True, timeout=300)
     assert "REFUSED" in r.stdout and "invalid usage" in r.stdout, r.stdout[-1000:] + r.stderr[-2000:]
+
+
+@pytest.mark.timeout(900)
+def test_bench_torchrun_c5_split_files_through_the_native_exchange(stub):
+    """bench.py --gpus 2 --config c5 as the driver would launch it: the Zipf mix LPT-sharded over two ranks, files >= 32 MiB
+    split into two parts whose owners agree on the boundary cuts (resolve_parts over the gloo plumbing), and the digest
+    exchange the LIBRARY's (mi_dedup_allgather on the double) -- the job-wide unique count = the generator's closed form."""
+    env = dict(os.environ, MI_BENCH_FORCE_DEVICE="0", MI_RCCL_LIB=stub, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29585", os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--config", "c5", "--bytes-per-gpu", "3", "--split-mib", "32", "--steps", "2", "--warmup", "1"]
+    j = _bench_line(subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=800))
+    assert j["n_gpus"] == 2 and j["config"]["name"] == "c5" and j["config"]["exchange"] == "native" and j["config"]["rccl_ranks"] == 2
+    assert j["config"]["parts_this_rank"] > 0 and j["config"]["files_split_into_parts_job"] > 0
+    assert j["dedup_check"]["ok"], j["dedup_check"]
+    assert j["n1_same_run"]["value"] > 0 and len(j["per_rank"]["marking_ms"]) == 2
