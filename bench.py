@@ -680,12 +680,17 @@ def main():
             if world > 1:
                 dist.broadcast_object_list(uid, src=0)
             eng.comm_init_rank(world, rank, uid[0])
+            if os.environ.get("MI_BENCH_FAIL_NATIVE_ON_RANK") == str(rank):      # self-test of the fallback
+                raise RuntimeError("simulated failure after the communicator came up")
         except Exception as e:                                  # noqa: BLE001
             err = "rank %d: %s" % (rank, e)
         errs = [e for e in all_ranks(err) if e]
         if errs:
-            if err is None:
-                eng.comm_destroy()
+            try:
+                if eng.comm_ranks():
+                    eng.comm_destroy()
+            except Exception:                                   # noqa: BLE001
+                pass
             args.exchange = "torch"
             exchange_note = "native communicator failed (%s): torch.distributed drives the exchange" % "; ".join(errs)[:400]
             print("bench.py: " + exchange_note, file=sys.stderr)

@@ -325,3 +325,18 @@ def test_bench_torchrun_c5_split_files_through_the_native_exchange(stub):
     assert j["config"]["parts_this_rank"] > 0 and j["config"]["files_split_into_parts_job"] > 0
     assert j["dedup_check"]["ok"], j["dedup_check"]
     assert j["n1_same_run"]["value"] > 0 and len(j["per_rank"]["marking_ms"]) == 2
+
+
+@pytest.mark.timeout(900)
+def test_bench_falls_back_to_the_torch_driver_when_a_rank_loses_its_communicator(stub):
+    """A first contact with several GPUs must yield a line: if the library's communicator does not come up on SOME rank, every
+    rank hears of it (over the host group), drops its communicator and the torch.distributed driver runs the same exchange
+    -- the line says so.  Simulated on rank 1 of 2 (both on this GPU; the torch driver over gloo here)."""
+    env = dict(os.environ, MI_BENCH_FORCE_DEVICE="0", MI_RCCL_LIB=stub, MASTER_ADDR="127.0.0.1", MI_BENCH_FAIL_NATIVE_ON_RANK="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29587", os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--files", "20000", "--steps", "2", "--warmup", "1", "--backend", "gloo"]
+    j = _bench_line(subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=800))
+    assert j["config"]["exchange"] == "torch" and "simulated failure" in j["config"]["exchange_note"]
+    assert j["config"]["rccl_ranks"] is None                      # gloo counted the ranks, not RCCL: the line cannot claim it
+    assert j["dedup_check"]["ok"] and j["n_gpus"] == 2
