@@ -675,22 +675,35 @@ def main():
         # (it has met real RCCL with more than one rank on few machines), every rank falls back to the torch
         # driver of the same exchange and the line says so -- a first contact must still yield a line.
         err = None
+        dbg = (lambda m: print("bench.py[%d]: %s" % (rank, m), file=sys.stderr, flush=True)) if os.environ.get("MI_BENCH_DEBUG") else (lambda m: None)
         try:
-            uid = [eng.comm_unique_id() if rank == 0 else None]
+            uid = [None]
+            if rank == 0:
+                try:
+                    uid[0] = eng.comm_unique_id()
+                except Exception as e:                          # noqa: BLE001  (the peers wait for SOMETHING from rank 0)
+                    uid[0] = ("no id", str(e))
             if world > 1:
                 dist.broadcast_object_list(uid, src=0)
+            dbg("id shipped")
+            if isinstance(uid[0], tuple):
+                raise RuntimeError("rank 0 could not create the communicator id: %s" % uid[0][1])
             eng.comm_init_rank(world, rank, uid[0])
+            dbg("communicator up")
             if os.environ.get("MI_BENCH_FAIL_NATIVE_ON_RANK") == str(rank):      # self-test of the fallback
                 raise RuntimeError("simulated failure after the communicator came up")
         except Exception as e:                                  # noqa: BLE001
             err = "rank %d: %s" % (rank, e)
+        dbg("err = %r" % (err,))
         errs = [e for e in all_ranks(err) if e]
+        dbg("all ranks heard: %r" % (errs,))
         if errs:
             try:
                 if eng.comm_ranks():
                     eng.comm_destroy()
             except Exception:                                   # noqa: BLE001
                 pass
+            dbg("communicator dropped")
             args.exchange = "torch"
             exchange_note = "native communicator failed (%s): torch.distributed drives the exchange" % "; ".join(errs)[:400]
             print("bench.py: " + exchange_note, file=sys.stderr)

@@ -340,3 +340,11 @@ def test_bench_falls_back_to_the_torch_driver_when_a_rank_loses_its_communicator
     assert j["config"]["exchange"] == "torch" and "simulated failure" in j["config"]["exchange_note"]
     assert j["config"]["rccl_ranks"] is None                      # gloo counted the ranks, not RCCL: the line cannot claim it
     assert j["dedup_check"]["ok"] and j["n_gpus"] == 2
+    # ... and when rank 0 cannot even create the communicator id (no collective library to load), its peers, who wait for
+    # the id, are told so instead of waiting for ever
+    env = dict(env, MI_RCCL_LIB="/nonexistent/librccl.so")
+    env.pop("MI_BENCH_FAIL_NATIVE_ON_RANK")
+    cmd[cmd.index("29587")] = "29589"
+    j = _bench_line(subprocess.run(cmd + ["--no-n1"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=300))
+    assert j["config"]["exchange"] == "torch" and "could not create the communicator id" in j["config"]["exchange_note"]
+    assert j["dedup_check"]["ok"]
