@@ -261,8 +261,16 @@ __device__ __forceinline__ void mark_tile(const u8* __restrict__ fptr, u64 ts, u
     u32 hh[16];
     if (ts + run0 != 0) {                                // warm the window: 64 bytes before my run
         u32x4 wq[4];
+#ifdef MI_GEAR_EXPERIMENT_NO_WARMUP_LINE
+        // MEASUREMENT ONLY (wrong cuts near run starts): the warm-up taken from the lane's OWN first line, i.e. the same
+        // instructions and registers without the extra cache line -- the most any scheme that gets the neighbour's tail
+        // for free could save (profiles/r04_gear_ab.txt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wq[i] = *(const u32x4*)(p + 16 * i);
+#else
 #pragma unroll
         for (int i = 0; i < 4; ++i) wq[i] = *(const u32x4*)(p - 64 + 16 * i);
+#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i) roll16<kC>(h, wq[i], tab, hh);
     }
