@@ -97,6 +97,16 @@ int main(void) {
     assert got == want
 
 
+def test_both_headers_are_plain_c(tmp_path):
+    """the boundary and the optional helpers compile as C89-with-stdint consumers see them (gcc -std=c99 -pedantic), alone
+    and together, and the optional header pulls in the core one"""
+    for body in ('#include "makisu_mi.h"\n', '#include "makisu_mi_host.h"\n', '#include "makisu_mi.h"\n#include "makisu_mi_host.h"\n'):
+        src = tmp_path / "c.c"
+        src.write_text(body + "int main(void) { mi_config c; int (*f)(void) = mi_abi_version; (void)c; (void)f; return 0; }\n")
+        subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-c", "-I", os.path.join(ROOT, "include"), str(src),
+                               "-o", str(tmp_path / "c.o")])
+
+
 def test_invalid_config_is_rejected(engine_lib):
     import makisu_amd
     for kw in ({"min_size": 32}, {"max_size": 1024, "min_size": 2048}, {"mask_bits": 33}, {"sha_load_scheme": 3}):
