@@ -161,3 +161,17 @@ def test_fill_batch_hands_over_whole_files_in_runs_and_parts_one_by_one():
     whole = W.c4(1, 8, 1000)
     fb = FakeBatch()
     assert W.fill_batch(fb, whole) == [] and len(fb.calls) == 1 and fb.calls[0][0] == "files"
+
+
+def test_bench_closed_form_check_tolerates_only_one_byte_tail_coincidences():
+    """bench.py's dedup_check: the job-wide unique count may fall short of the generator's closed form by the handful of
+    equal 1-byte tail chunks distinct contents can share (2 + closed_form / 50 000), never exceed it, never be missing"""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_test2", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    ok = lambda got, want: bench.closed_form_check(got, want)["ok"]            # noqa: E731
+    assert ok(721319, 721319) and ok(9023949, 9023970) and ok(100, 102)
+    assert not ok(103, 102) and not ok(99, 102) and not ok(None, 5) and not ok(9023000, 9023970)
+    assert bench.closed_form_check(9023949, 9023970)["short_chunk_coincidences"] == 21
