@@ -15,9 +15,9 @@ $T python bench.py 2> $out/bench.err | grep "^{" | tail -1 > $out/${tag}_bench_n
 tail -c 300 $out/${tag}_bench_n1.json; echo
 # one batch at a time (every kernel has the GPU to itself: the durations `roofline` is computed from -- the bench takes them
 # from its own one-at-a-time steps), and the bench's default form (two batches in flight in the timed region, then serial steps)
-$T rocprofv3 --kernel-trace --stats -d $out/kt -o kt -- python bench.py --steps 10 --warmup 2 --inflight 1 --no-cpu-baseline > $out/kt.log 2>&1
+$T rocprofv3 --kernel-trace --stats -d $out/kt -o kt -- python bench.py --steps 40 --warmup 2 --inflight 1 --no-cpu-baseline > $out/kt.log 2>&1
 $T rocprofv3 --kernel-trace --stats -d $out/kts -o kts -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline > $out/kts.log 2>&1
-{ echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 2 --inflight 1 --no-cpu-baseline   (one batch at a time: a launch's duration is the kernel's own -- what roofline.avg_launch_ms measures)"; summ $out/kt; } > $out/${tag}_kernel_trace_stats.txt 2>&1
+{ echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 40 --warmup 2 --inflight 1 --no-cpu-baseline   (one batch at a time: a launch's duration is the kernel's own -- what roofline.avg_launch_ms measures)"; summ $out/kt; } > $out/${tag}_kernel_trace_stats.txt 2>&1
 { echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline   (the default command: 12 steps with two batches in flight -- launches overlap --, then 12 one at a time)"; summ $out/kts; } > $out/${tag}_kernel_trace_stats_default.txt 2>&1
 # HBM traffic: one --pmc pass per counter, kernel trace only
 $T rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/fetch -o fetch -- python bench.py --steps 3 --warmup 1 --inflight 1 --no-cpu-baseline > $out/fetch.log 2>&1
