@@ -44,6 +44,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
+#include <sys/resource.h>
 #include <sys/stat.h>
 #include <sys/syscall.h>
 #include <unistd.h>
@@ -395,6 +396,14 @@ struct ParallelWalker {
     size_t outstanding = 0;              // directories queued or being read
     bool abort = false;                  // the assembly stopped (an error): the readers only drain
     bool inline_reads = false;           // a batch is attached: small files are read where they are listed
+    static thread_local bool own_table;  // this directory reader left the process's descriptor table (worker())
+    static uint64_t fd_budget() {        // descriptors a thread may hold at once (its table's soft limit)
+        static const uint64_t v = [] {
+            struct rlimit rl;
+            return getrlimit(RLIMIT_NOFILE, &rl) == 0 && rl.rlim_cur != RLIM_INFINITY ? (uint64_t)rl.rlim_cur : 1024ull;
+        }();
+        return v;
+    }
     std::vector<std::thread> pool;
 
     // Walker::should_skip without side effects on the shared walker: a broken mounts table is the
@@ -421,22 +430,37 @@ struct ParallelWalker {
             return;
         }
         const uint64_t tl0 = walk_timing() ? now_ns() : 0;
-        std::vector<std::string> names;
+        std::vector<std::pair<std::string, unsigned char>> names;   // name, d_type
         while (struct dirent* de = readdir(dir)) {
             if (!strcmp(de->d_name, ".") || !strcmp(de->d_name, "..")) continue;
-            names.push_back(de->d_name);
+            names.emplace_back(de->d_name, de->d_type);
         }
-        std::sort(names.begin(), names.end());              // sort.Strings: bytewise
+        std::sort(names.begin(), names.end(),               // sort.Strings: bytewise
+                  [](const std::pair<std::string, unsigned char>& a, const std::pair<std::string, unsigned char>& b) { return a.first < b.first; });
         d->kids.resize(names.size());
         std::vector<DirRec*> subs;
+        // A regular file that will be read here anyway is OPENED first and its header taken from the descriptor (fstat): one
+        // path lookup per file instead of two.  Only on a descriptor table of this thread's own (every file of the directory is
+        // open at once until the block is laid out) and only while the directory fits the table.
+        std::vector<int> fds;
+        const bool open_first = inline_reads && own_table && names.size() + 64 <= fd_budget();
+        if (open_first) fds.assign(names.size(), -1);
         const uint64_t ts0 = tl0 ? now_ns() : 0;
         if (tl0) g_ns_list += ts0 - tl0;
         for (size_t i = 0; i < names.size(); ++i) {
             Child& c = d->kids[i];
-            c.name.swap(names[i]);
+            c.name.swap(names[i].first);
             const std::string path = d->path == "/" ? "/" + c.name : d->path + "/" + c.name;
             struct stat st;
-            if (fstatat(fd, c.name.c_str(), &st, AT_SYMLINK_NOFOLLOW) != 0) {
+            bool have = false;
+            if (open_first && names[i].second == DT_REG) {
+                const int f = openat(fd, c.name.c_str(), O_RDONLY | O_CLOEXEC | O_NOFOLLOW | O_NONBLOCK);
+                if (f >= 0) {
+                    if (fstat(f, &st) == 0 && S_ISREG(st.st_mode)) { fds[i] = f; have = true; }
+                    else close(f);                           // no longer what readdir said: the lstat below decides
+                }                                            // (unreadable, gone, a link by now: likewise)
+            }
+            if (!have && fstatat(fd, c.name.c_str(), &st, AT_SYMLINK_NOFOLLOW) != 0) {
                 c.rc = MI_ERR_IO;
                 c.err = "lstat " + path + ": " + strerror(errno);
                 continue;
@@ -464,7 +488,8 @@ struct ParallelWalker {
             }
         }
         if (ts0) g_ns_stat += now_ns() - ts0;
-        if (inline_reads) read_small_files(d, fd);
+        if (inline_reads) read_small_files(d, fd, fds);
+        for (int f : fds) if (f >= 0) close(f);              // skipped, too large for a block, or no block to be had
         closedir(dir);                                       // closes fd
         if (!subs.empty()) {
             std::lock_guard<std::mutex> g(mu);
@@ -476,7 +501,8 @@ struct ParallelWalker {
 
     // the directory's small regular files into one block; a file that cannot be read is that child's error (reported
     // by the assembly in walk order, with the words the reader threads use)
-    void read_small_files(DirRec* d, int dfd) {
+    // fds (may be empty): descriptors read_dir already holds, by child index; taken (closed, set to -1) as they are read
+    void read_small_files(DirRec* d, int dfd, std::vector<int>& fds) {
         uint64_t total = 0, n = 0;
         for (Child& c : d->kids) {
             if (c.rc || c.skip || !S_ISREG(c.mode) || c.size > inline_file_max()) continue;
@@ -509,12 +535,15 @@ struct ParallelWalker {
         uint64_t end = 0;
         const uint64_t tr0 = walk_timing() ? now_ns() : 0;
         struct AddUp { uint64_t t0; ~AddUp() { if (t0) g_ns_read += now_ns() - t0; } } add_up{tr0};
-        for (Child& c : d->kids) {
+        for (size_t ci = 0; ci < d->kids.size(); ++ci) {
+            Child& c = d->kids[ci];
             if (c.blob_off == ~0ull) continue;
             if (c.blob_off > end) memset(buf + end, 0, c.blob_off - end);       // alignment gap
             end = c.blob_off + c.size;
             if (c.size == 0) continue;
-            const int fd = openat(dfd, c.name.c_str(), O_RDONLY | O_CLOEXEC | O_NOFOLLOW);
+            int fd = -1;
+            if (!fds.empty() && fds[ci] >= 0) { fd = fds[ci]; fds[ci] = -1; }
+            else fd = openat(dfd, c.name.c_str(), O_RDONLY | O_CLOEXEC | O_NOFOLLOW);
             if (fd < 0) {
                 c.rc = MI_ERR_IO;
                 c.err = "open " + (d->path == "/" ? "/" + c.name : d->path + "/" + c.name) + ": " + strerror(errno);
@@ -538,8 +567,11 @@ struct ParallelWalker {
 
     void worker() {
         const uint64_t tu0 = walk_timing() ? now_ns() : 0;
-        if (inline_reads && walk_unshare() && unshare(CLONE_FILES) == 0)   // a descriptor table of this thread's own (see above);
+        own_table = false;
+        if (inline_reads && walk_unshare() && unshare(CLONE_FILES) == 0) { // a descriptor table of this thread's own (see above);
             (void)syscall(SYS_close_range, 3u, ~0u, 0u);     // it starts empty: the copies of the process's descriptors go
+            own_table = true;
+        }
         if (tu0) g_ns_unshare += now_ns() - tu0;
         for (;;) {
             DirRec* d = nullptr;
@@ -615,6 +647,8 @@ struct ParallelWalker {
         }
     }
 };
+
+thread_local bool ParallelWalker::own_table = false;
 
 static unsigned walk_threads() {
     if (const char* e = getenv("MI_WALK_THREADS")) {

@@ -47,6 +47,23 @@ def test_with_the_walk_handing_every_file_over_as_a_path(hip_double, tmp_path):
     _run(hip_double, tmp_path, 4, 65536, {"MI_WALK_INLINE": "0"})
 
 
+def test_with_the_shared_descriptor_table(hip_double, tmp_path):
+    """MI_WALK_UNSHARE=0: the directory readers keep the process's table -- lstat first, then open, one file at a time"""
+    _run(hip_double, tmp_path, 4, 65536, {"MI_WALK_UNSHARE": "0"})
+
+
+def test_with_a_descriptor_limit_below_the_directory_sizes(hip_double, tmp_path):
+    """a soft RLIMIT_NOFILE of 128: the 200-file directories of the scenario do not fit a reader's table -- they are read
+    the lstat-first way, one descriptor at a time"""
+    import resource
+    soft, hard = resource.getrlimit(resource.RLIMIT_NOFILE)
+    env = dict(os.environ, LD_PRELOAD=(os.environ.get("LD_PRELOAD", "") + " " + hip_double).strip())
+    p = subprocess.run([sys.executable, os.path.join(STUB_DIR, "scenarios.py"), str(tmp_path), "4", "65536"], env=env,
+                       capture_output=True, text=True, timeout=900,
+                       preexec_fn=lambda: resource.setrlimit(resource.RLIMIT_NOFILE, (128, hard)))
+    assert p.returncode == 0 and "OK tree" in p.stdout, p.stdout[-800:] + p.stderr[-1500:]
+
+
 def test_with_a_block_budget_that_runs_out(hip_double, tmp_path):
     """MI_WALK_INLINE_MB=1: after a megabyte of blocks alive the directories' files go as paths again -- mixed ways"""
     _run(hip_double, tmp_path, 4, 65536, {"MI_WALK_INLINE_MB": "1"})
