@@ -428,7 +428,7 @@ typedef struct {
                                   inodes like the reference's snapshot may set it)       */
     uint32_t    uid, gid;
 } mi_tree_entry;
-/* Regular files reach the batch while the walk goes on.  Files up to 32 KiB (MI_WALK_INLINE_MAX_KIB) are read by the
+/* Regular files reach the batch while the walk goes on.  Files up to 16 KiB (MI_WALK_INLINE_MAX_KIB) are read by the
  * walk's own directory readers where they are listed -- one block of host memory per directory, one piece of the arena
  * each; those threads work on a file-descriptor table of their own (unshare(CLONE_FILES); where that is refused, on
  * the shared one) -- and a file that cannot be opened, or has shrunk since its lstat, fails THIS call with MI_ERR_IO

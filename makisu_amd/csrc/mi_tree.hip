@@ -291,16 +291,16 @@ struct DirRec {
 // then close_range over their private copy -- and open / read / close against a table of their own: the same files in
 // 56 / 42 / 29 ms with 8 / 16 / 32 threads.  (A thread that may not unshare -- a seccomp profile without it -- reads
 // through the shared table: correct, slower.)  What a reader thread of mi_stage.hip is left with is a memcpy into its
-// pinned slab and the host-to-device copy.  Bounded: files up to MI_WALK_INLINE_MAX_KIB (default 32) KiB -- the block
-// costs a second copy of the bytes, which pays while the per-file system calls dominate: 100 000 x 4 KiB 3.2-3.9 ->
-// 8.5-9.9 GB/s end to end, but 50 000 x 64 KiB 40 -> 17 GB/s when those were read this way too
+// pinned slab and the host-to-device copy.  Bounded: files up to MI_WALK_INLINE_MAX_KIB (default 16) KiB -- the block
+// costs a second copy of the bytes, which pays while the per-file system calls dominate: 100 000 x 4 KiB 4.5-5.3 ->
+// 9-12.5 GB/s end to end; at 16 KiB both ways give 22 GB/s, at 32 KiB paths 27 against 24, at 64 KiB 42 against 32
 // (profiles/r04_many_small_files.txt) -- and at most MI_WALK_INLINE_MB (default 1024) MiB of blocks alive at a time;
 // beyond either a file goes the old way, as a path.  MI_WALK_UNSHARE=0 keeps the shared table (ThreadSanitizer models
 // descriptors per process and takes two threads' private "fd 4" for one).
 static uint64_t inline_file_max() {
     static const uint64_t v = [] {
         const char* e = getenv("MI_WALK_INLINE_MAX_KIB");
-        const long kib = e && *e ? atol(e) : 32;
+        const long kib = e && *e ? atol(e) : 16;
         return kib <= 0 ? 0ull : (uint64_t)kib << 10;
     }();
     return v;

@@ -201,7 +201,7 @@ def scenario_tree_reserves_ahead(tmp, threads, slab):
     # the file table keeps filepath.Walk's order whatever way the bytes took
     d2 = os.path.join(tmp, "mixed")
     want2 = {}
-    sizes = [0, 1, 255, 256, 257, 4096, 32768, 32769, 70000, 300000, 1 << 20, 5, 0, 33]
+    sizes = [0, 1, 255, 256, 257, 4096, 16384, 16385, 32768, 70000, 300000, 1 << 20, 5, 0, 33]
     for k, rel in enumerate(["a/x", "a/y/z", "a/y", "b", ".", "a/y/z/deep/er", "c c", "a.b"]):
         os.makedirs(os.path.join(d2, rel), exist_ok=True)
         for j, n in enumerate(sizes[k:] + sizes[:k]):

@@ -213,7 +213,7 @@ def test_bulk_add_paths_and_tree_walk_with_deferred_opens(oracle, tmp_path):
 
 
 def test_tree_walk_blocks_verified_and_reused(oracle, tmp_path):
-    """Round 4: the walk's directory readers read files up to 32 KiB where they list them -- one block of host memory per
+    """Round 4: the walk's directory readers read files up to 16 KiB where they list them -- one block of host memory per
     directory, one piece of the arena each -- and larger ones still go to the reader threads as paths.  A nested tree that
     mixes both (and empty files, and directories with a single file) through ONE batch that is reset and walked three
     times, every staged span verified (MI_FLAG_VERIFY_STAGING sums the blocks' copies like any other): bit-exact against
@@ -227,7 +227,7 @@ def test_tree_walk_blocks_verified_and_reused(oracle, tmp_path):
         (root / d).mkdir(parents=True, exist_ok=True)
         n_files = 1 if d == "m/only" else 400
         for _ in range(n_files):
-            n = int(rng.choice([0, 1, 255, 256, 4096, 20000, 32768, 32769, 70000, 400000], p=[.05, .1, .1, .1, .3, .2, .05, .04, .04, .02]))
+            n = int(rng.choice([0, 1, 255, 256, 4096, 12000, 16384, 16385, 70000, 400000], p=[.05, .1, .1, .1, .3, .2, .05, .04, .04, .02]))
             p = root / d / ("f%05d" % k)
             data = oracle.synth_fill(SEED, 9000 + k, 0, n).tobytes()
             p.write_bytes(data)
