@@ -931,6 +931,10 @@ class Engine:
         self._check(self._lib.mi_sha_valu_roof(self._h, waves_per_simd, blocks, C.byref(v)))
         return v.value
 
+    def debug_sha_wave_stats(self, path):
+        """mi_debug_sha_wave_stats: per-wave records of every chunk pass of THIS ctx go to `path` (None: off)."""
+        self._check(self._lib.mi_debug_sha_wave_stats(self._h, os.fsencode(path) if path else None))
+
     def stats(self):
         st = Stats()
         self._check(self._lib.mi_get_stats(self._h, C.byref(st)))

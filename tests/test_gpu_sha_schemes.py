@@ -183,3 +183,29 @@ def test_wave_stats_record(tmp_path):
                        timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "OK" in r.stdout
+
+
+def test_wave_stats_are_a_ctx_setting(tmp_path):
+    """mi_debug_sha_wave_stats (round 4: the record left the launch path's process-wide getenv): one ctx records, another
+    of the same process does not; turned off, the ctx stops; the digests are the same either way."""
+    import numpy as np
+    import makisu_amd
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import sha_wave_stats as WS
+    path = str(tmp_path / "waves.bin")
+    sizes = [65536] * 2000
+    with makisu_amd.Engine() as quiet, makisu_amd.Engine() as e:
+        e.debug_sha_wave_stats(path)
+        with e.batch() as b, quiet.batch() as q:
+            b.add_synthetic(sizes, None)
+            q.add_synthetic(sizes, None)
+            q.run()
+            assert not os.path.exists(path)                       # the other ctx's launches leave no record
+            b.run()
+            assert np.array_equal(b.chunks()["sha256"], q.chunks()["sha256"])
+            assert len(WS.read_records(path)) == 1
+            b.rerun()
+            assert len(WS.read_records(path)) == 2
+            e.debug_sha_wave_stats(None)
+            b.rerun()
+            assert len(WS.read_records(path)) == 2
