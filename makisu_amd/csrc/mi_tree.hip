@@ -308,56 +308,92 @@ static uint64_t inline_file_max() {
 // The blocks' memory: recycled, not returned.  A 2 MB block from the C library is its own mapping -- page faults for
 // every one of its pages, by 16 threads in one address space, and an unmap when the reader threads let go of it: 100 000
 // 4 KiB files then spend more time faulting than reading.  Freed blocks wait here by size class (powers of two from
-// 64 KiB; at most 512 MiB kept), and since a block lives only until a reader thread has copied it, a walk cycles through
-// a few tens of megabytes.
+// 64 KiB; at most 512 MiB kept resident), and since a block lives only until a reader thread has copied it, a walk
+// cycles through a few tens of megabytes.
+// New blocks are CARVED from 32 MiB slabs (one mmap on a 2 MiB boundary, advised to use huge pages, never unmapped):
+// a mapping of its own per block cost three address-space calls (mmap, the munmap that trims it to the boundary,
+// madvise), each under the address-space lock in write mode with 16 directory readers faulting beside it -- a
+// process's first walk spent 100-180 ms of its readers' time there (profiles/r04_many_small_files.txt).  With slabs
+// it is one such call per 16 blocks of 2 MiB, and a block's first touch is one huge-page fault.  A block beyond the
+// resident limit gives its pages back (MADV_DONTNEED) and keeps its address range for the next taker.
 struct BlockPool {
+    static constexpr uint64_t kSlab = 32ull << 20, kHuge = 2ull << 20;
     std::mutex mu;
-    std::vector<uint8_t*> free_[16];                          // class k: 64 KiB << k
-    uint64_t kept = 0;
+    std::vector<uint8_t*> free_[16];                          // class k: 64 KiB << k; resident blocks
+    std::vector<uint8_t*> cold_[16];                          // carved blocks whose pages were given back
+    uint64_t kept = 0;                                        // bytes in free_
+    uint8_t* slab_at = nullptr;                               // the current slab's unused tail
+    uint64_t slab_left = 0;
+    uint64_t n_slabs = 0, n_carved = 0, n_own = 0;            // MI_WALK_TIMING
     static int cls(uint64_t n) { int k = 0; while ((65536ull << k) < n && k < 15) ++k; return k; }
     static uint64_t cap(int k) { return 65536ull << k; }
-    // memory of a class: from 2 MiB up its own mapping on a 2 MiB boundary, advised to use huge pages -- the first touch
-    // of a 2 MB block is then one fault, not 512 taken by 16 threads under one address-space lock (the first walk of a
-    // process: 330 ms of the directory readers' 900 ms went into faults, profiles/r04_many_small_files.txt)
-    static uint8_t* fresh(uint64_t capacity) {
-        if (capacity < (2ull << 20)) return new (std::nothrow) uint8_t[capacity];
-        void* p = mmap(nullptr, capacity + (2ull << 20), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    static bool carved(uint64_t capacity) { return capacity <= kSlab / 2; }   // larger blocks are mappings of their own
+    static uint8_t* map_aligned(uint64_t bytes) {
+        void* p = mmap(nullptr, bytes + kHuge, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
         if (p == MAP_FAILED) return nullptr;
-        uint8_t* a = (uint8_t*)(((uintptr_t)p + (2ull << 20) - 1) & ~((uintptr_t)(2ull << 20) - 1));
+        uint8_t* a = (uint8_t*)(((uintptr_t)p + kHuge - 1) & ~((uintptr_t)kHuge - 1));
         if (a > (uint8_t*)p) munmap(p, (size_t)(a - (uint8_t*)p));
-        const uint64_t tail = (uint64_t)((uint8_t*)p + capacity + (2ull << 20) - (a + capacity));
-        if (tail) munmap(a + capacity, tail);
-        (void)madvise(a, capacity, MADV_HUGEPAGE);
+        const uint64_t tail = (uint64_t)((uint8_t*)p + bytes + kHuge - (a + bytes));
+        if (tail) munmap(a + bytes, tail);
+        (void)madvise(a, bytes, MADV_HUGEPAGE);
         return a;
     }
-    static void release(uint8_t* p, uint64_t capacity) {
-        if (capacity < (2ull << 20)) delete[] p; else munmap(p, capacity);
+    uint8_t* carve(uint64_t capacity) {                       // mu held
+        const uint64_t align = capacity < kHuge ? capacity : kHuge;   // capacities are powers of two
+        uint64_t skip = slab_at ? (align - ((uintptr_t)slab_at & (align - 1))) & (align - 1) : 0;
+        if (!slab_at || skip + capacity > slab_left) {
+            uint8_t* s = map_aligned(kSlab);                  // what is left of the old slab is lost (< one block)
+            if (!s) return nullptr;
+            slab_at = s;
+            slab_left = kSlab;
+            skip = 0;
+            ++n_slabs;
+        }
+        uint8_t* p = slab_at + skip;
+        slab_at = p + capacity;
+        slab_left -= skip + capacity;
+        ++n_carved;
+        return p;
     }
     uint8_t* get(uint64_t n, uint64_t* cap_out) {
         const int k = cls(n);
         if (cap(k) < n) {                                                             // beyond the largest class
-            *cap_out = (n + (2ull << 20) - 1) & ~((2ull << 20) - 1);
-            return fresh(*cap_out);
+            *cap_out = (n + kHuge - 1) & ~(kHuge - 1);
+            std::lock_guard<std::mutex> g(mu);
+            ++n_own;
+            return map_aligned(*cap_out);
         }
         *cap_out = cap(k);
-        {
-            std::lock_guard<std::mutex> g(mu);
-            if (!free_[k].empty()) {
-                uint8_t* p = free_[k].back();
-                free_[k].pop_back();
-                kept -= cap(k);
-                return p;
-            }
+        std::lock_guard<std::mutex> g(mu);
+        if (!free_[k].empty()) {
+            uint8_t* p = free_[k].back();
+            free_[k].pop_back();
+            kept -= cap(k);
+            return p;
         }
-        return fresh(cap(k));
+        if (!cold_[k].empty()) {
+            uint8_t* p = cold_[k].back();
+            cold_[k].pop_back();
+            return p;
+        }
+        if (carved(cap(k))) return carve(cap(k));
+        ++n_own;
+        return map_aligned(cap(k));
     }
     void put(uint8_t* p, uint64_t capacity) {
         const int k = cls(capacity);
         if (cap(k) == capacity) {
-            std::lock_guard<std::mutex> g(mu);
+            std::unique_lock<std::mutex> g(mu);
             if (kept + capacity <= (512ull << 20)) { free_[k].push_back(p); kept += capacity; return; }
+            if (carved(capacity)) {                           // part of a slab: the pages go, the range stays
+                g.unlock();
+                (void)madvise(p, capacity, MADV_DONTNEED);
+                g.lock();
+                cold_[k].push_back(p);
+                return;
+            }
         }
-        release(p, capacity);
+        munmap(p, capacity);
     }
 };
 static BlockPool& block_pool() { static BlockPool* p = new BlockPool(); return *p; }   // never destroyed: blocks may outlive exit handlers
@@ -377,7 +413,8 @@ static bool walk_unshare() {
     static const bool on = [] { const char* e = getenv("MI_WALK_UNSHARE"); return !(e && *e == '0'); }();
     return on;
 }
-static std::atomic<uint64_t> g_inline_bytes{0};
+static std::atomic<uint64_t> g_inline_bytes{0};                    // bytes in blocks alive now
+static std::atomic<uint64_t> g_inline_peak{0}, g_inline_files{0};  // MI_WALK_TIMING: the most there were; files read into blocks
 static uint64_t inline_budget() {
     static const uint64_t v = [] {
         const char* e = getenv("MI_WALK_INLINE_MB");
@@ -430,7 +467,11 @@ struct ParallelWalker {
             return;
         }
         const uint64_t tl0 = walk_timing() ? now_ns() : 0;
-        std::vector<std::pair<std::string, unsigned char>> names;   // name, d_type
+        // name, d_type -- scratch of this thread that keeps its capacity from directory to directory (a process's first
+        // walk grows 16 fresh heaps at once; every growth step is an address-space call beside the others' page faults)
+        static thread_local std::vector<std::pair<std::string, unsigned char>> names;
+        static thread_local std::string path;
+        names.clear();
         while (struct dirent* de = readdir(dir)) {
             if (!strcmp(de->d_name, ".") || !strcmp(de->d_name, "..")) continue;
             names.emplace_back(de->d_name, de->d_type);
@@ -450,7 +491,9 @@ struct ParallelWalker {
         for (size_t i = 0; i < names.size(); ++i) {
             Child& c = d->kids[i];
             c.name.swap(names[i].first);
-            const std::string path = d->path == "/" ? "/" + c.name : d->path + "/" + c.name;
+            path.assign(d->path == "/" ? "" : d->path);
+            path += '/';
+            path += c.name;
             struct stat st;
             bool have = false;
             if (open_first && names[i].second == DT_REG) {
@@ -512,6 +555,7 @@ struct ParallelWalker {
         }
         if (n == 0) return;
         const uint64_t held = g_inline_bytes.fetch_add(total) + total;
+        if (walk_timing()) { uint64_t pk = g_inline_peak.load(); while (held > pk && !g_inline_peak.compare_exchange_weak(pk, held)) {} }
         if (held > inline_budget() && held != total) {       // too much host memory in blocks already: these go as paths
             g_inline_bytes.fetch_sub(total);
             for (Child& c : d->kids) c.blob_off = ~0ull;
@@ -532,6 +576,7 @@ struct ParallelWalker {
         });
         d->blob_len = total;
         d->blob_files = n;
+        if (walk_timing()) g_inline_files += n;
         uint64_t end = 0;
         const uint64_t tr0 = walk_timing() ? now_ns() : 0;
         struct AddUp { uint64_t t0; ~AddUp() { if (t0) g_ns_read += now_ns() - t0; } } add_up{tr0};
@@ -618,13 +663,17 @@ struct ParallelWalker {
     // the caller): children in order, a directory child followed by its subtree; the first failure
     // in THAT order is the walk's failure
     // rel = the directory's own relpath ("." for the base itself)
-    void assemble(const DirRec* d, const std::string& rel) {
+    void assemble(DirRec* d, const std::string& rel) {
         if (w->rc) return;
         wait_done(d);                                        // usually is: the readers go depth-first too
         if (d->rc) { w->rc = d->rc; w->err = d->err; return; }
         uint64_t block_at = 0;
         if (d->blob_len || d->blob_files) {
-            if (d->blob_len) { if (!w->place_block(d->blob, d->blob_len, d->blob_files, &block_at)) return; }
+            if (d->blob_len) {
+                const bool placed = w->place_block(d->blob, d->blob_len, d->blob_files, &block_at);
+                d->blob.reset();                             // the stager's pieces own the block now: it goes back to the pool when
+                if (!placed) return;                         // the last of them sits in a slab, not when the walk ends
+            }
             else { w->handed_files += d->blob_files; }           // empty files only: rows without bytes
         }
         std::string path, crel;
@@ -690,7 +739,7 @@ static void walk_root(Walker* w, const std::string& root) {
     top.path = root;
     const std::string root_rel = w->tree->entries.back().relpath;   // the root's own entry was just emitted (a copy:
     const uint64_t tw0 = walk_timing() ? now_ns() : 0;
-    if (tw0) { g_ns_list = 0; g_ns_stat = 0; g_ns_block = 0; g_ns_read = 0; g_ns_unshare = 0; }
+    if (tw0) { g_ns_list = 0; g_ns_stat = 0; g_ns_block = 0; g_ns_read = 0; g_ns_unshare = 0; g_inline_peak = 0; g_inline_files = 0; }
     pw.start(&top, nt);                                               // the vector grows under the assembly)
     pw.assemble(&top, root_rel);       // behind the readers: files reach the batch while the walk goes on
     const uint64_t tw1 = tw0 ? now_ns() : 0;
@@ -698,9 +747,11 @@ static void walk_root(Walker* w, const std::string& root) {
     if (tw0)
         fprintf(stderr, "mi_walk: %u threads; assembly done after %.1f ms, threads joined after %.1f ms; summed over the threads: "
                 "unshare %.1f ms, readdir + sort %.1f, fstatat + rules %.1f, block from the pool (first byte touched) %.1f, "
-                "open + pread + close %.1f; %llu files seen\n", nt, (tw1 - tw0) / 1e6, (now_ns() - tw0) / 1e6,
+                "open + pread + close %.1f; %llu files seen; block pool so far: %llu slabs, %llu blocks carved, %llu mappings of "
+                "their own, at most %.1f MB of blocks alive, %llu files read into blocks\n", nt, (tw1 - tw0) / 1e6, (now_ns() - tw0) / 1e6,
                 g_ns_unshare.load() / 1e6, g_ns_list.load() / 1e6, g_ns_stat.load() / 1e6, g_ns_block.load() / 1e6,
-                g_ns_read.load() / 1e6, (unsigned long long)pw.seen_files.load());
+                g_ns_read.load() / 1e6, (unsigned long long)pw.seen_files.load(), (unsigned long long)block_pool().n_slabs,
+                (unsigned long long)block_pool().n_carved, (unsigned long long)block_pool().n_own, g_inline_peak.load() / 1e6, (unsigned long long)g_inline_files.load());
 }
 
 // the walk the copy ops need (mi_memfs.hip): one source, scan rules, no blacklist

@@ -254,6 +254,26 @@ def scenario_two_ctxs(tmp, threads, slab):
     assert not errs, errs
 
 
+def scenario_blocks_recycle(tmp, threads, slab):
+    """100 directories of small files, a batch with size hints (its arena is there before the walk): what the walk reports
+    about its blocks (MI_WALK_TIMING=1, stderr) is checked by the caller; here, the bytes"""
+    rng = np.random.default_rng(9)
+    d = os.path.join(tmp, "recycle")
+    want = {}
+    for k in range(100):
+        os.makedirs(os.path.join(d, "d%03d" % k), exist_ok=True)
+        for f in range(100):
+            data = rng.integers(0, 256, 12000, dtype=np.uint8).tobytes()
+            p = os.path.join(d, "d%03d" % k, "f%03d" % f)
+            with open(p, "wb") as fh:
+                fh.write(data)
+            want[p] = data
+    with M.Engine(n_streams=threads, staging_bytes=slab) as eng, eng.batch(10000, 10000 * 12288) as b:
+        b.add_tree(d)
+        b.run()
+        check(b, b"".join(want[p] for p in sorted(want)), "recycle")
+
+
 def main():
     tmp = sys.argv[1]
     threads = int(sys.argv[2]) if len(sys.argv) > 2 else 4
@@ -261,8 +281,8 @@ def main():
     only = sys.argv[4].split(",") if len(sys.argv) > 4 else None
     for name, fn in [("mix", scenario_mix), ("growth", scenario_growth_and_reuse), ("two", scenario_two_batches),
                      ("errors", scenario_errors), ("api", scenario_api), ("tree", scenario_tree_reserves_ahead),
-                     ("two_ctxs", scenario_two_ctxs)]:
-        if only and name not in only:
+                     ("two_ctxs", scenario_two_ctxs), ("recycle", scenario_blocks_recycle)]:
+        if (name not in only) if only else name == "recycle":    # "recycle" runs only when asked for
             continue
         fn(tmp, threads, slab)
         print("OK", name, flush=True)

@@ -69,6 +69,26 @@ def test_with_a_block_budget_that_runs_out(hip_double, tmp_path):
     _run(hip_double, tmp_path, 4, 65536, {"MI_WALK_INLINE_MB": "1"})
 
 
+def test_a_block_goes_back_to_the_pool_when_it_is_copied_not_when_the_walk_ends(hip_double, tmp_path):
+    """A directory's block is let go of when the reader threads have copied it: a walk over 100 directories cycles through
+    a few tens of blocks.  (Until round 4's last session the walk's own record of a directory kept its block until the
+    walk ended: every directory needed a block of its own -- a process's first walk touched as much fresh block memory as
+    the tree holds small files, and MI_WALK_INLINE_MB bounded the small files of a whole TREE that could take this way,
+    not the blocks alive at a time.)"""
+    import re
+    env = dict(os.environ, LD_PRELOAD=(os.environ.get("LD_PRELOAD", "") + " " + hip_double).strip(),
+               MI_WALK_THREADS="4", MI_WALK_TIMING="1")
+    p = subprocess.run([sys.executable, os.path.join(STUB_DIR, "scenarios.py"), str(tmp_path), "4", str(1 << 20), "recycle"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "OK recycle" in p.stdout, p.stdout[-800:] + p.stderr[-1500:]
+    line = [ln for ln in p.stderr.splitlines() if ln.startswith("mi_walk:")][0]
+    m = re.search(r"(\d+) blocks carved, .* at most ([0-9.]+) MB of blocks alive, (\d+) files read into blocks", line)
+    assert m, line
+    assert int(m.group(3)) == 10000, line                   # every file went the block way (120 MB, far below the budget)
+    assert int(m.group(1)) <= 60, line                      # ... through far fewer blocks than there are directories
+    assert float(m.group(2)) <= 0.6 * 120, line
+
+
 def test_with_slow_copies(hip_double, tmp_path):
     """every queued copy takes 100 us longer: what returns early shows"""
     _run(hip_double, tmp_path, 8, 65536, {"MI_HIP_STUB_COPY_US": "100"})
