@@ -45,6 +45,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# one process per GPU shares device memory with its peers (RCCL over xGMI) through dmabuf handles: the host driver of this
+# pool supports nothing else, and the HIP runtime reads the switch when it starts -- so before anything loads it
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 SEED = 0x4D414B49
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
