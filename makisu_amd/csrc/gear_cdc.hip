@@ -217,9 +217,16 @@ __device__ __forceinline__ void hash16(u64& h, const u32x4 v, u32 tab, u32 thres
     roll16<kC>(h, v, tab, hh);
     // (a v_min3_u32 chain would be 8 ops instead of the 11 hipcc emits, but it is one dependent
     // chain: A/B on one box, 1.50 ms against 1.46 ms for the compiler's tree)
+#ifdef MI_GEAR_MIN3_TREE                                  // experiments: 7 x v_min3_u32 + 1 v_min_u32, depth 3
+    auto m3 = [](u32 a, u32 b, u32 c) { return min(min(a, b), c); };
+    const u32 t0 = m3(hh[0], hh[1], hh[2]), t1 = m3(hh[3], hh[4], hh[5]), t2 = m3(hh[6], hh[7], hh[8]),
+              t3 = m3(hh[9], hh[10], hh[11]), t4 = m3(hh[12], hh[13], hh[14]);
+    const u32 m = min(m3(t0, t1, t2), m3(t3, t4, hh[15]));
+#else
     u32 m = 0xFFFFFFFFu;
 #pragma unroll
     for (int k = 0; k < 16; k += 2) m = min(m, min(hh[k], hh[k + 1]));
+#endif
     if (m <= thresh_m1) {                                // rare: a candidate among these 16 bytes
         // (positions at or past the file end are not filtered here: selection never looks
         // beyond the tile's last byte, and at most one lane hashes up to 127 slack bytes)
@@ -477,6 +484,9 @@ void gear_cdc_small_fast_kernel(const u8* __restrict__ data, const u64* __restri
     u64* table = (u64*)smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     u32* cand_list = (u32*)(smem + kFastListOff) + wave * 64;
+#ifdef MI_GEAR_PRIO                                       // experiments: the marking's waves above another batch's hashing
+    __builtin_amdgcn_s_setprio(MI_GEAR_PRIO);
+#endif
     load_table<kFastCopies, kFastWG>(table, gear_table, tid);
     __syncthreads();
     const u32 lane_tab = lds_lane_table<kFastCopies>(table, lane);
