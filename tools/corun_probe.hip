@@ -4,7 +4,7 @@
 // (waves that only occupy slots).  The co-runner is timed alone and beside the step as well (its iteration count is fixed,
 // so its duration says how much of ITS resource the engine's passes took).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude tools/corun_probe.hip -Lmakisu_amd -lmakisu_mi -o tools/bin/corun_probe
-//   LD_LIBRARY_PATH=makisu_amd tools/bin/corun_probe [waves per SIMD of the co-runner: 1]
+//   tools/bin/corun_probe [waves per SIMD of the co-runner: 1] [mask of co-runner kinds: 0x1F]
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -83,6 +83,7 @@ struct Probe { const char* name; int kind; uint32_t iters; };
 
 int main(int argc, char** argv) {
     const int per_simd = argc > 1 ? atoi(argv[1]) : 1;
+    const unsigned kinds = argc > 2 ? (unsigned)strtoul(argv[2], nullptr, 0) : 0x1Fu;   // bit k: run co-runner kind k
     mi_ctx* ctx = nullptr;
     mi_config cfg;
     mi_config_default(&cfg);
@@ -141,6 +142,7 @@ int main(int argc, char** argv) {
     Probe probes[] = {{"dependent VALU ops", 0, 2000}, {"ds_read_b64, no bank conflicts", 1, 2000}, {"streaming global loads", 2, 2000},
                       {"scalar ALU ops", 3, 2000}, {"s_sleep", 4, 2000}};
     for (Probe& p : probes) {
+        if (!(kinds >> p.kind & 1u)) continue;
         // size the co-runner to ~30 ms alone: it must outlast three steps
         double t = time_alone(p.kind, p.iters);
         p.iters = (uint32_t)(p.iters * 30.0 / (t > 0.01 ? t : 0.01));
