@@ -33,7 +33,7 @@ def content(rng, n, ident):
     if kind == 7:                                              # random with a zero run somewhere inside
         a = bytearray(rng.integers(0, 256, int(n), dtype=np.uint8).tobytes())
         lo = int(rng.integers(0, n))
-        hi = min(int(n), lo + int(rng.integers(1, 200000)))
+        hi = min(int(n), lo + int(rng.integers(1, 200000 if n < (1 << 20) else 3000000)))
         a[lo:hi] = bytes(hi - lo)
         return bytes(a)
     if kind == 8:
@@ -56,14 +56,17 @@ def one_case(rng, case):
             sizes.append(int(rng.integers(0, 300)))
         else:
             sizes.append(int(rng.integers(0, cap)))
+    if rng.integers(0, 6) == 0:                                 # a few LARGE files: groups, speculation, the per-file fix-up
+        sizes = [int(rng.integers(1 << 20, 36 << 20)) + int(rng.choice([0, 1, -1, 65536, 262144])) * int(rng.integers(0, 2))
+                 for _ in range(int(rng.integers(1, 4)))]
     sizes = [max(0, s) for s in sizes]
     while sum(sizes) > 40_000_000:
         sizes[int(np.argmax(sizes))] //= 2
     blobs = [content(rng, s, case * 1000 + i) for i, s in enumerate(sizes)]
-    if n_files > 2 and rng.integers(0, 2):                      # duplicates: whole files and prefixes
+    if len(blobs) > 2 and rng.integers(0, 2):                      # duplicates: whole files and prefixes
         blobs[-1] = blobs[0]
         blobs[-2] = blobs[0][:len(blobs[0]) // 2]
-    desc = "mask %d min %d max %d, %d files, %d bytes" % (mask_bits, min_size, max_size, n_files, sum(len(b) for b in blobs))
+    desc = "mask %d min %d max %d, %d files, %d bytes" % (mask_bits, min_size, max_size, len(blobs), sum(len(b) for b in blobs))
     with makisu_amd.Engine(mask_bits=mask_bits, min_size=min_size, max_size=max_size) as e:
         with e.batch(len(blobs), sum(len(b) for b in blobs)) as b:
             for i, blob in enumerate(blobs):
