@@ -305,6 +305,14 @@ void put_str(uint8_t* b, size_t n, const std::string& s) {      // formatter.for
     const size_t c = s.size() < n ? s.size() : n;
     memcpy(b, s.data(), c);
     if (s.size() < n) b[s.size()] = 0;
+    // "Some buggy readers treat regular files with a trailing slash in the V7 path field as a directory even though the
+    // full path recorded elsewhere (e.g., via PAX record) contains no trailing slash": a string cut at the field's end
+    // right behind a "/" gets a NUL where its trailing slashes begin (that one byte only)
+    if (s.size() > n && b[n - 1] == '/') {
+        size_t k = n;
+        while (k > 0 && s[k - 1] == '/') --k;
+        b[k] = 0;
+    }
 }
 void put_octal(uint8_t* b, int n, int64_t x) {     // formatter.formatOctal: zero-padded, NUL-terminated
     if (!fits_octal(n, x)) x = 0;                  // the PAX record carries the real value

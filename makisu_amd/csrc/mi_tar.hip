@@ -14,10 +14,30 @@
 // tar, which mi_tar_inflate writes out (returning its SHA-256 -- the layer's tar digest / diffID)
 // so that mi_batch_add_path_range can read the members from it.
 //
-// Format: POSIX ustar / pax (typeflags 'x' and 'g': path, linkpath, size, uid, gid, mtime) and
-// the GNU extensions Go's archive/tar and docker write (typeflags 'L' / 'K' long name / link,
-// base-256 numeric fields, the old-GNU magic).  Checked against Python's tarfile on ustar, pax
-// and GNU archives and on the reference's own layer fixture (tests/test_host_tar.py).
+// Format: POSIX ustar / pax (typeflag 'x': path, linkpath, size, uid, gid, mtime) and the GNU
+// extensions Go's archive/tar and docker write (typeflags 'L' / 'K' long name / link, base-256
+// numeric fields, the old-GNU magic).  Checked against Python's tarfile on ustar, pax and GNU
+// archives and on the reference's own layer fixture (tests/test_host_tar.py).
+//
+// WHAT IS AN ARCHIVE, what is its end and what is an error follow the reader the reference
+// calls -- archive/tar of the Go 1.14 toolchain (Makefile:34; not under /root/reference: restated
+// from the published source, reader.go next / readHeader / parsePAX, strconv.go parseNumeric /
+// parsePAXRecord / parsePAXTime / mergePAX), not POSIX and not tarfile, where they differ:
+//   * the archive ends at two zero blocks, at ONE zero block followed by the end of the data, or
+//     at the end of the data on a block boundary (also inside a member's padding); a zero block
+//     followed by a non-zero block and a last block of 1..511 bytes are errors ("read header: ...",
+//     mem_fs.go:185);
+//   * a numeric field is trimmed of spaces and NULs on both sides, cut at its first NUL and must
+//     then be octal digits only; base-256 values beyond 63 bits are errors;
+//   * a pax record is "<len> <key>=<value>\n" with len >= 5, the newline where len says, a key
+//     that is not empty; a record with an EMPTY value keeps the header's own field; size, uid, gid
+//     must be decimal int64 and the three times "[-]digits[.digits]" -- anything else fails the
+//     archive; of several 'x' headers before one member the last one counts;
+//   * a GLOBAL pax header ('g') is an entry of its own (kind 4, the header's name) and its records
+//     touch NO later member (archive/tar hands it to the caller and merges nothing);
+//   * a GNU long name / link wins over a pax path / linkpath (merged first), and an empty one
+//     changes nothing;
+//   * the size field of a link, symlink, device, directory or fifo header describes no data.
 #include "../../include/makisu_mi.h"
 
 #include <errno.h>
@@ -59,31 +79,36 @@ static std::string field(const unsigned char* p, size_t n) {        // NUL-termi
     return std::string((const char*)p, k);
 }
 
-// numeric field: octal text (leading spaces / trailing space or NUL), or GNU base-256 (top bit set)
+// numeric field as archive/tar's parseNumeric reads it: GNU base-256 (top bit set: big-endian two's
+// complement, at most 63 bits of magnitude), else octal text -- spaces and NULs trimmed on both sides, cut at
+// the first NUL, then octal digits only; an empty field reads as 0
 static bool number(const unsigned char* p, size_t n, int64_t* out) {
-    if (p[0] & 0x80) {                                       // GNU base-256, big-endian two's complement
-        const bool neg = (p[0] & 0x40) != 0;
-        uint64_t v = neg ? ~0ull : 0;
+    if (n && (p[0] & 0x80)) {
+        const unsigned char inv = (p[0] & 0x40) ? 0xff : 0x00;
+        uint64_t x = 0;
         for (size_t i = 0; i < n; ++i) {
-            unsigned char c = p[i];
-            if (i == 0) c = neg ? (unsigned char)(c | 0x80) : (unsigned char)(c & 0x7f);   // the flag bit is not data
-            if (n - i > 8) {                                 // beyond 64 bits: must be sign extension
-                if (c != (neg ? 0xff : 0x00)) return false;
-                continue;
-            }
-            v = (v << 8) | c;
+            unsigned char c = (unsigned char)(p[i] ^ inv);
+            if (i == 0) c &= 0x7f;                           // the flag bit is not data
+            if (x >> 56) return false;                       // beyond 64 bits
+            x = (x << 8) | c;
         }
-        *out = (int64_t)v;
+        if (x >> 63) return false;
+        *out = inv ? (int64_t)~x : (int64_t)x;
         return true;
     }
-    size_t i = 0;
-    while (i < n && (p[i] == ' ')) ++i;
+    size_t a = 0, b = n;
+    while (a < b && (p[a] == ' ' || p[a] == 0)) ++a;
+    while (b > a && (p[b - 1] == ' ' || p[b - 1] == 0)) --b;
+    for (size_t i = a; i < b; ++i) if (p[i] == 0) { b = i; break; }
+    *out = 0;
+    if (a == b) return true;                                 // nothing but padding
     uint64_t v = 0;
-    bool any = false;
-    for (; i < n && p[i] >= '0' && p[i] <= '7'; ++i) { v = (v << 3) | (uint64_t)(p[i] - '0'); any = true; }
-    for (; i < n; ++i) if (p[i] != ' ' && p[i] != 0) return false;
+    for (size_t i = a; i < b; ++i) {
+        if (p[i] < '0' || p[i] > '7' || (v >> 61)) return false;
+        v = (v << 3) | (uint64_t)(p[i] - '0');
+    }
     *out = (int64_t)v;
-    return any || n == 0 || p[0] == 0 || p[0] == ' ';      // an empty field reads as 0
+    return true;
 }
 
 static bool all_zero(const unsigned char* b) {
@@ -103,19 +128,60 @@ static bool checksum_ok(const unsigned char* b) {
     return want == u || want == s;
 }
 
-// "len key=value\n" records
+// strconv.ParseInt(s, 10, 64): an optional sign, decimal digits and nothing else, within int64
+static bool parse_int64(const std::string& s, int64_t* out) {
+    size_t i = 0;
+    bool neg = false;
+    if (i < s.size() && (s[i] == '+' || s[i] == '-')) { neg = s[i] == '-'; ++i; }
+    if (i == s.size()) return false;
+    uint64_t v = 0;
+    for (; i < s.size(); ++i) {
+        if (s[i] < '0' || s[i] > '9') return false;
+        const uint64_t d = (uint64_t)(s[i] - '0');
+        if (v > (~0ull - d) / 10) return false;
+        v = v * 10 + d;
+    }
+    if (v > (neg ? (1ull << 63) : (1ull << 63) - 1)) return false;
+    *out = neg ? (int64_t)(0 - v) : (int64_t)v;
+    return true;
+}
+
+// parsePAXTime, down to what the reference keeps of it -- whole seconds (tario.IsSimilarHeader and WriteHeader
+// Truncate to the second, lib/tario/compare.go:70-72, write.go:56: rounding DOWN): "[-]digits[.digits]", the
+// fraction cut to nanoseconds; a fraction of a negative time moves it further from zero
+static bool pax_seconds(const std::string& s, int64_t* out) {
+    const size_t dot = s.find('.');
+    const std::string ss = s.substr(0, dot), sn = dot == std::string::npos ? std::string() : s.substr(dot + 1);
+    int64_t secs = 0;
+    if (!parse_int64(ss, &secs)) return false;
+    bool frac = false;
+    for (size_t i = 0; i < sn.size(); ++i) {
+        if (sn[i] < '0' || sn[i] > '9') return false;
+        if (i < 9 && sn[i] != '0') frac = true;
+    }
+    if (frac && ss[0] == '-' && secs > INT64_MIN) --secs;
+    *out = secs;
+    return true;
+}
+
+// "len key=value\n" records (parsePAXRecord + validPAXRecord); a later record of a key replaces an earlier one
 static bool parse_pax(const std::string& body, std::map<std::string, std::string>* kv) {
     size_t at = 0;
     while (at < body.size()) {
-        size_t sp = body.find(' ', at);
+        const size_t sp = body.find(' ', at);
         if (sp == std::string::npos) return false;
-        const long len = strtol(body.substr(at, sp - at).c_str(), nullptr, 10);
-        if (len <= 0 || at + (size_t)len > body.size()) return false;
-        const std::string rec = body.substr(sp + 1, at + (size_t)len - sp - 2);   // without the '\n'
+        int64_t len = 0;
+        if (!parse_int64(body.substr(at, sp - at), &len) || len < 5 || (uint64_t)len > body.size() - at) return false;
+        const size_t end = at + (size_t)len;                  // one past the record's newline
+        if (end < sp + 2 || body[end - 1] != '\n') return false;
+        const std::string rec = body.substr(sp + 1, end - 1 - (sp + 1));
         const size_t eq = rec.find('=');
-        if (eq == std::string::npos) return false;
-        (*kv)[rec.substr(0, eq)] = rec.substr(eq + 1);
-        at += (size_t)len;
+        if (eq == std::string::npos || eq == 0) return false;
+        const std::string key = rec.substr(0, eq), val = rec.substr(eq + 1);
+        const bool text = key == "path" || key == "linkpath" || key == "uname" || key == "gname";
+        if ((text ? val : key).find('\0') != std::string::npos) return false;
+        (*kv)[key] = val;
+        at = end;
     }
     return true;
 }
@@ -203,21 +269,35 @@ struct Source {
         }
         return inflate_some((unsigned char*)dst, n) == n;
     }
+    // up to n bytes at uncompressed offset off: fewer (0 included) at the end of the data; error set on failure
+    size_t read_upto(uint64_t off, void* dst, size_t n) {
+        if (!gz) {
+            if (off >= size) return 0;
+            const size_t m = (size_t)(size - off < n ? size - off : n);
+            return read_at(off, dst, m) ? m : 0;
+        }
+        if (off < pos) { error = "gzip source cannot seek backwards"; return 0; }
+        while (pos < off) {
+            const uint64_t skip = off - pos;
+            if (inflate_some(nullptr, (size_t)(skip > (1u << 30) ? (1u << 30) : skip)) == 0) return 0;   // ends before `off`
+        }
+        return inflate_some((unsigned char*)dst, n);
+    }
     // can [off, off+n) exist?  (plain files: bounds check; gzip: only known by reading on)
     bool has_range(uint64_t off, uint64_t n) const { return gz || off + n <= size; }
 };
 
 static int parse(Source& src, Tar* t) {
     uint64_t off = 0;
-    std::map<std::string, std::string> global_pax, next_pax;
-    std::string gnu_name, gnu_link;
-    bool has_gnu_name = false, has_gnu_link = false;
+    std::map<std::string, std::string> next_pax;               // the records of the last 'x' header before this member
+    std::string gnu_name, gnu_link;                            // 'L' / 'K' before this member ("" = none)
     int64_t n_regular = 0;
     unsigned char blk[512];
     std::string open_member;                                   // gzip source: the entry whose data must reach `off`
     uint64_t open_member_end = 0;                              // ... its last byte + 1 (padding not counted)
     for (;;) {
-        if (!src.read_at(off, blk, 512)) {
+        const size_t got = src.read_upto(off, blk, 512);
+        if (got < 512) {
             if (!src.error.empty()) { t->error = src.error; return MI_ERR_IO; }
             // a gzip stream is only as long as it inflates to: if it ended inside the previous
             // entry's data, say what the plain-tar path says for the same archive
@@ -225,21 +305,39 @@ static int parse(Source& src, Tar* t) {
                 t->error = "entry " + open_member + " runs past the end of the archive";
                 return MI_ERR_INVALID;
             }
-            break;                                             // end of data without the zero blocks
+            if (got) { t->error = "unexpected end of the archive inside the header at offset " + std::to_string(off); return MI_ERR_INVALID; }
+            break;                                             // end of data without the zero blocks (io.EOF from readHeader)
         }
         open_member.clear();
-        if (all_zero(blk)) break;                              // end-of-archive marker
+        if (all_zero(blk)) {                                   // end-of-archive marker: a second zero block, or nothing at all, after it
+            const size_t more = src.read_upto(off + 512, blk, 512);
+            if (!src.error.empty()) { t->error = src.error; return MI_ERR_IO; }
+            if (more == 0 || (more == 512 && all_zero(blk))) break;
+            t->error = more < 512 ? "unexpected end of the archive after a zero block at offset " + std::to_string(off)
+                                  : "a zero block is followed by a header at offset " + std::to_string(off + 512);
+            return MI_ERR_INVALID;
+        }
         if (!checksum_ok(blk)) { t->error = "bad tar header checksum at offset " + std::to_string(off); return MI_ERR_INVALID; }
-        int64_t size = 0, mode = 0, uid = 0, gid = 0, mtime = 0;
+        const bool ustar = memcmp(blk + 257, "ustar\0", 6) == 0;                   // POSIX ustar / pax, or star with its trailer
+        const bool star = ustar && memcmp(blk + 508, "tar\0", 4) == 0;
+        const bool gnu = memcmp(blk + 257, "ustar  \0", 8) == 0;                   // old GNU: magic and version in one
+        int64_t size = 0, mode = 0, uid = 0, gid = 0, mtime = 0, dev = 0;
         if (!number(blk + 124, 12, &size) || !number(blk + 100, 8, &mode) || !number(blk + 108, 8, &uid) ||
-            !number(blk + 116, 8, &gid) || !number(blk + 136, 12, &mtime) || size < 0) {
+            !number(blk + 116, 8, &gid) || !number(blk + 136, 12, &mtime) ||
+            ((ustar || gnu) && (!number(blk + 329, 8, &dev) || !number(blk + 337, 8, &dev))) ||
+            (star && (!number(blk + 476, 12, &dev) || !number(blk + 488, 12, &dev)))) {
             t->error = "bad numeric field in the tar header at offset " + std::to_string(off);
             return MI_ERR_INVALID;
         }
         const unsigned char type = blk[156];
+        const bool header_only = type == '1' || type == '2' || type == '3' || type == '4' || type == '5' || type == '6';
+        if (size < 0 && !header_only) {
+            t->error = "negative size in the tar header at offset " + std::to_string(off);
+            return MI_ERR_INVALID;
+        }
         const uint64_t data = off + 512;
-        const uint64_t padded = ((uint64_t)size + 511) & ~511ull;
-        if (type == 'x' || type == 'g' || type == 'L' || type == 'K') {           // metadata for the next entry
+        if (type == 'x' || type == 'g' || type == 'L' || type == 'K') {           // metadata: for the next member, or ('g') for nobody
+            const uint64_t padded = ((uint64_t)size + 511) & ~511ull;
             if ((uint64_t)size > (64u << 20) || !src.has_range(data, (uint64_t)size)) {
                 t->error = "truncated extended header at offset " + std::to_string(off);
                 return MI_ERR_INVALID;
@@ -249,36 +347,65 @@ static int parse(Source& src, Tar* t) {
                 t->error = src.error.empty() ? "truncated extended header at offset " + std::to_string(off) : src.error;
                 return MI_ERR_INVALID;
             }
-            if (type == 'L' || type == 'K') {
-                const std::string v = body.substr(0, body.find('\0'));
-                if (type == 'L') { gnu_name = v; has_gnu_name = true; }
-                else { gnu_link = v; has_gnu_link = true; }
-            } else if (!parse_pax(body, type == 'g' ? &global_pax : &next_pax)) {
-                t->error = "malformed pax record at offset " + std::to_string(off);
+            off = data + padded;
+            if (type == 'L') { gnu_name = body.substr(0, body.find('\0')); continue; }
+            if (type == 'K') { gnu_link = body.substr(0, body.find('\0')); continue; }
+            std::map<std::string, std::string> recs;
+            if (!parse_pax(body, &recs)) {
+                t->error = "malformed pax record at offset " + std::to_string(data - 512);
                 return MI_ERR_INVALID;
             }
-            off = data + padded;
+            if (type == 'x') { next_pax.swap(recs); continue; }
+            // 'g': handed to the caller as a member of its own -- only its name (a non-empty path record replaces it)
+            // and its typeflag survive; no later member sees its records
+            // (and what an 'x', 'L' or 'K' before it said is dropped with it: they live for one call of Next)
+            Item g;
+            g.name = field(blk, 100);
+            if (ustar) { const std::string prefix = field(blk + 345, star ? 131 : 155); if (!prefix.empty()) g.name = prefix + "/" + g.name; }
+            auto gp = recs.find("path");
+            if (gp != recs.end() && !gp->second.empty()) g.name = gp->second;
+            g.kind = 4;
+            t->items.push_back(g);
+            next_pax.clear();
+            gnu_name.clear();
+            gnu_link.clear();
             continue;
         }
         Item it;
         it.name = field(blk, 100);
-        if (memcmp(blk + 257, "ustar\0", 6) == 0) {            // POSIX ustar (not old GNU "ustar  "): prefix field
-            const std::string prefix = field(blk + 345, 155);
+        if (ustar) {                                            // (not old GNU): the prefix field, 131 bytes wide in star's layout
+            const std::string prefix = field(blk + 345, star ? 131 : 155);
             if (!prefix.empty()) it.name = prefix + "/" + it.name;
         }
         it.link = field(blk + 157, 100);
-        std::map<std::string, std::string> kv = global_pax;
-        for (auto& p : next_pax) kv[p.first] = p.second;
+        // mergePAX: a record with an empty value keeps the header's own field; a number or a time that does not
+        // parse fails the archive
+        bool pax_ok = true;
+        for (const auto& kv : next_pax) {
+            const std::string& k = kv.first;
+            const std::string& v = kv.second;
+            int64_t ignored = 0;
+            if (v.empty()) continue;
+            if (k == "path") it.name = v;
+            else if (k == "linkpath") it.link = v;
+            else if (k == "size") pax_ok &= parse_int64(v, &size);
+            else if (k == "uid") pax_ok &= parse_int64(v, &uid);
+            else if (k == "gid") pax_ok &= parse_int64(v, &gid);
+            else if (k == "mtime") pax_ok &= pax_seconds(v, &mtime);
+            else if (k == "atime" || k == "ctime") pax_ok &= pax_seconds(v, &ignored);
+        }
         next_pax.clear();
-        if (has_gnu_name) it.name = gnu_name;
-        if (has_gnu_link) it.link = gnu_link;
-        has_gnu_name = has_gnu_link = false;
-        if (kv.count("path")) it.name = kv["path"];
-        if (kv.count("linkpath")) it.link = kv["linkpath"];
-        if (kv.count("size")) size = strtoll(kv["size"].c_str(), nullptr, 10);
-        if (kv.count("uid")) uid = strtoll(kv["uid"].c_str(), nullptr, 10);
-        if (kv.count("gid")) gid = strtoll(kv["gid"].c_str(), nullptr, 10);
-        if (kv.count("mtime")) mtime = (int64_t)floor(strtod(kv["mtime"].c_str(), nullptr));   // whole seconds
+        if (!gnu_name.empty()) it.name = gnu_name;              // after the pax records: a GNU long name wins
+        if (!gnu_link.empty()) it.link = gnu_link;
+        gnu_name.clear();
+        gnu_link.clear();
+        // "Legacy archives use trailing slash for directories": decided on the final name, and from here on the
+        // member is header-only like any directory -- its size field describes no data
+        const bool legacy_dir = type == 0 && !it.name.empty() && it.name.back() == '/';
+        if (!pax_ok || (size < 0 && !header_only && !legacy_dir)) {
+            t->error = "bad pax value for the member at offset " + std::to_string(off);
+            return MI_ERR_INVALID;
+        }
         uint32_t type_bits = 0;
         switch (type) {
             case '0': case 0: case '7': it.kind = 1; type_bits = S_IFREG; break;
@@ -290,22 +417,25 @@ static int parse(Source& src, Tar* t) {
             case '6': it.kind = 4; type_bits = S_IFIFO; break;
             default:  it.kind = 4; break;
         }
-        if (type == 0 && !it.name.empty() && it.name.back() == '/') { it.kind = 0; type_bits = S_IFDIR; }   // pre-POSIX tars
+        if (legacy_dir) { it.kind = 0; type_bits = S_IFDIR; }
         it.has_link = it.kind == 2 || it.kind == 3;
         it.mode = ((uint32_t)mode & 07777u) | type_bits;
         it.uid = (uint32_t)uid;
         it.gid = (uint32_t)gid;
         it.mtime = mtime;
-        const bool has_data = it.kind == 1 || (it.kind == 4 && type != '3' && type != '4' && type != '6');
         it.size = it.kind == 1 ? (uint64_t)size : 0;
         it.data_off = it.kind == 1 ? data : 0;
-        const uint64_t skip = (it.kind == 1 || has_data) ? (((uint64_t)size + 511) & ~511ull) : 0;
+        const uint64_t skip = header_only || legacy_dir ? 0 : (((uint64_t)size + 511) & ~511ull);
         if (it.kind == 1) {
             if (!src.has_range(data, (uint64_t)size)) { t->error = "entry " + it.name + " runs past the end of the archive"; return MI_ERR_INVALID; }
             it.file_index = n_regular++;
             if (src.gz && size > 0) { open_member = it.name; open_member_end = data + (uint64_t)size; }
         }
         else if (src.gz && skip > 0) { open_member = it.name; open_member_end = data + (uint64_t)size; }   // any other member with a data area
+        else if (!src.gz && skip > 0 && !src.has_range(data, (uint64_t)size)) {
+            t->error = "entry " + it.name + " runs past the end of the archive";
+            return MI_ERR_INVALID;
+        }
         t->items.push_back(it);
         off = data + skip;
     }

@@ -133,6 +133,18 @@ def test_directory_names_carry_a_trailing_slash_and_formats(tmp_path):
     rec = b"%d path=%s\n" % (len(name) + 10, name.encode())
     assert h[512:512 + len(rec)] == rec and int(h[124:135], 8) == len(rec)
     assert h[1024:1024 + 100] == name.encode()[:100] and h[1024 + 156:1024 + 157] == b"0"
+    # a name cut at the field's end right behind a "/" gets a NUL where the trailing slashes begin (formatString: "Some
+    # buggy readers treat regular files with a trailing slash in the V7 path field as a directory"); one byte only
+    name = "d" * 99 + "/" + "f" * 120
+    h = M.layer_header_bytes({"relpath": name, "kind": M.KIND_FILE, "mode": 0o600, "size": 5})
+    assert len(h) == 1536 and h[1024:1024 + 100] == b"d" * 99 + b"\x00"
+    name = "d" * 97 + "///" + "f" * 120
+    h = M.layer_header_bytes({"relpath": name, "kind": M.KIND_FILE, "mode": 0o600, "size": 5})
+    assert h[1024:1024 + 100] == b"d" * 97 + b"\x00//"
+    link = "t" * 99 + "/" + "u" * 30                      # the link field is written by the same formatter
+    h = M.layer_header_bytes({"relpath": "l", "kind": M.KIND_SYMLINK, "mode": 0o120777, "link_target": link})
+    assert len(h) == 1536 and b" linkpath=" + link.encode() + b"\n" in h[512:1024]
+    assert h[1024 + 157:1024 + 257] == b"t" * 99 + b"\x00"
     # large uid -> PAX uid record, field zeroed
     h = M.layer_header_bytes({"relpath": "f", "kind": M.KIND_FILE, "mode": 0o600, "size": 1, "uid": 3000000})
     assert len(h) == 1536 and b" uid=3000000\n" in h[512:1024] and h[1024 + 108:1024 + 116] == b"0000000\x00"

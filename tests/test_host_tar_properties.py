@@ -14,6 +14,9 @@ from test_host_tar import _compare_with_tarfile
 
 SEG = st.text(alphabet=st.characters(blacklist_characters="/\x00\n", blacklist_categories=("Cs",)), min_size=1, max_size=60) \
     .filter(lambda s: s not in (".", "..") and not s.startswith(".wh."))
+# sub-second mtimes whose str() is plain "digits.digits": tarfile writes str(float) into the pax record, and an exponent
+# form ("1e-05") is no time to archive/tar's parsePAXTime -- the reference fails such an archive (test_host_tar.py)
+FRAC = st.integers(0, 2 * 10**12).map(lambda v: v / 1000)
 ASEG = st.text(alphabet="abcdXYZ0189-_.+", min_size=1, max_size=110).filter(lambda s: s.strip(".") != "" and not s.startswith(".wh."))
 
 
@@ -32,8 +35,8 @@ def members(draw, ascii_only):
                     "mode": draw(st.integers(0, 0o7777)),
                     "uid": draw(st.one_of(st.integers(0, 2097151), st.integers(2097152, 2**31 - 1))) if not ascii_only
                     else draw(st.integers(0, 2097151)),
-                    "mtime": draw(st.one_of(st.integers(0, 2**33 - 1), st.floats(0, 2e9, allow_nan=False)) if ascii_only else
-                                  st.one_of(st.integers(0, 2**36), st.floats(0, 2e9, allow_nan=False), st.integers(-2**31, -1))),
+                    "mtime": draw(st.one_of(st.integers(0, 2**33 - 1), FRAC) if ascii_only else
+                                  st.one_of(st.integers(0, 2**36), FRAC, st.integers(-2**31, -1))),
                     "link": "/".join(draw(st.lists(seg, min_size=1, max_size=4)))})
     return out
 
