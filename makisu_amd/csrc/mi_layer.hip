@@ -488,7 +488,7 @@ struct mi_layer {
     DigestSink tar;
     std::unique_ptr<GzipSink> gz;
     std::shared_ptr<Bytes> cur;
-    uint64_t n_entries = 0, tar_bytes = 0;
+    uint64_t n_entries = 0;
     bool finished = false, failed = false;
 
     int fail(int code, const char* fmt, ...) {
@@ -518,7 +518,6 @@ struct mi_layer {
         return cur->data() + at;
     }
     void append(const uint8_t* p, size_t n) {
-        tar_bytes += n;
         while (n) {
             size_t take = n;
             uint8_t* dst = room(&take);
@@ -642,7 +641,6 @@ int mi_layer_add(mi_layer* l, const mi_tree_entry* e, const char* src_path) {
                 }
                 got += (size_t)r;
             }
-            l->tar_bytes += take;
             off += take;
             left -= take;
         }

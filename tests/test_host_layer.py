@@ -141,6 +141,9 @@ def test_directory_names_carry_a_trailing_slash_and_formats(tmp_path):
     name = "d" * 97 + "///" + "f" * 120
     h = M.layer_header_bytes({"relpath": name, "kind": M.KIND_FILE, "mode": 0o600, "size": 5})
     assert h[1024:1024 + 100] == b"d" * 97 + b"\x00//"
+    # ... and only a string that was CUT: a directory name of exactly 100 bytes keeps its slash
+    h = M.layer_header_bytes({"relpath": "e" * 99, "kind": M.KIND_DIR, "mode": 0o40755})
+    assert len(h) == 512 and h[:100] == b"e" * 99 + b"/"
     link = "t" * 99 + "/" + "u" * 30                      # the link field is written by the same formatter
     h = M.layer_header_bytes({"relpath": "l", "kind": M.KIND_SYMLINK, "mode": 0o120777, "link_target": link})
     assert len(h) == 1536 and b" linkpath=" + link.encode() + b"\n" in h[512:1024]
@@ -230,6 +233,12 @@ def test_whiteouts_hardlinks_and_errors(tmp_path):
         with pytest.raises(M.MiError) as ei:
             layer.add({"relpath": "dev/null", "kind": 4, "mode": 0o666})         # write.go:49-51
         assert "unsupported type" in str(ei.value)
+        # a failed layer stays failed: nothing more goes in, and it does not finish
+        with pytest.raises(M.MiError) as ei:
+            layer.add({"relpath": "fine", "kind": M.KIND_DIR, "mode": 0o40755})
+        assert "finished or failed" in str(ei.value)
+        with pytest.raises(M.MiError):
+            layer.finish()
     with M.Layer(gzip_level=M.GZIP_OFF) as layer:
         with pytest.raises(M.MiError) as ei:
             layer.add({"relpath": "nope", "kind": M.KIND_FILE, "mode": 0o600, "size": 1}, str(tmp_path / "missing"))
@@ -263,9 +272,15 @@ def test_cache_entry_codec():
     for bad in ("", "nocomma", t.hex(), t.hex() + "," + "zz" * 32, t.hex()[:-1] + "," + g.hex()):
         with pytest.raises(ValueError):
             M.cache_parse_entry(bad)
+    up = M.cache_parse_entry(t.hex().upper() + "," + g.hex().upper())     # hex is hex: "ABCDEF" as "abcdef"
+    assert (up[0].hex(), up[1].hex()) == (t.hex(), g.hex())
     # the layer writer's pair feeds the codec directly
     with M.Layer() as layer:
         pair = layer.finish()
+        with pytest.raises(M.MiError):                         # a finished layer is finished
+            layer.finish()
+        with pytest.raises(M.MiError):
+            layer.add({"relpath": "late", "kind": M.KIND_DIR, "mode": 0o40755})
     e = M.cache_create_entry(pair["tar_sha256"], pair["gzip_sha256"])
     assert M.cache_parse_entry(e) == (pair["tar_digest"], pair["gzip_digest"])
 
@@ -330,6 +345,9 @@ def test_parallel_gzip_is_one_member_and_independent_of_the_thread_count(tmp_pat
             os.close(fd)
             blob = out.read_bytes()
             assert hashlib.sha256(blob).hexdigest() == pair["gzip_digest"].hex() and len(blob) == pair["gzip_bytes"]
+            # the member's header as compress/gzip (and pgzip) write it: deflate, no flags, no mtime, XFL 2 for the best
+            # compression / 4 for the best speed / else 0, OS 255 "unknown"
+            assert blob[:10] == bytes([0x1f, 0x8b, 8, 0, 0, 0, 0, 0, {9: 2, 1: 4}.get(level, 0), 255])
             d = zlib.decompressobj(16 + 15)                       # gzip framing, exactly one member
             tar_bytes = d.decompress(blob) + d.flush()
             assert d.eof and d.unused_data == b""
@@ -429,6 +447,52 @@ def test_go_written_layer_is_reframed_byte_for_byte(tmp_path, go_layer_tar):
         json.load(open(os.path.join(GOLDEN, "sha256_reference_fixtures.json")))["vectors"][0]["file_b64"]))
     inf = M.tar_inflate(str(blob_path))
     assert inf["tar_digest"] == "sha256:" + GO_LAYER_TAR_DIGEST and inf["tar_bytes"] == 1308672
+
+
+def test_pax_extended_header_block_byte_for_byte():
+    """writeRawFile's block for the 'x' member laid out by hand (archive/tar writer.go: name = toASCII(path.Join(dir,
+    "PaxHeaders.0", file)) cut to 100 bytes, mode / uid / gid / mtime 0 as zero-padded octal, the records' length as the
+    size, typeflag 'x', magic "ustar\\0" + "00", NO uname / gname / device fields, checksum 6 digits + NUL + space) and the
+    main header that follows it (templateV7Plus with toASCII strings; numbers that do not fit written as zero)."""
+    def fin(b):
+        b[148:156] = b" " * 8
+        b[148:156] = b"%06o\x00 " % sum(b)
+        return bytes(b)
+
+    name = "caf\u00e9/" + "n" * 120                      # non-ASCII AND too long: a path record, no prefix split
+    e = {"relpath": name, "kind": M.KIND_FILE, "mode": 0o100640, "size": 5, "uid": 3000000, "gid": 12, "mtime_sec": 77}
+    h = M.layer_header_bytes(e)
+    raw_name = name.encode()
+    recs = b"".join(sorted([b"%d path=%s\n" % (len(raw_name) + 10, raw_name), b"15 uid=3000000\n"]))   # (3 digits + " path=" + "\n")
+    x = bytearray(512)
+    xname = ("caf/PaxHeaders.0/" + "n" * 120).encode()[:100]
+    x[0:len(xname)] = xname
+    x[100:108] = x[108:116] = x[116:124] = b"0000000\x00"
+    x[124:136] = b"%011o\x00" % len(recs)
+    x[136:148] = b"00000000000\x00"
+    x[156:157] = b"x"
+    x[257:265] = b"ustar\x0000"
+    assert h[:512] == fin(x)
+    assert h[512:1024] == recs + bytes(512 - len(recs))
+    m = bytearray(512)
+    ascii_name = ("caf/" + "n" * 120).encode()
+    m[0:100] = ascii_name[:100]
+    m[100:108] = b"0000640\x00"
+    m[108:116] = b"0000000\x00"                            # the uid does not fit: zero, the record carries it
+    m[116:124] = b"0000014\x00"
+    m[124:136] = b"00000000005\x00"
+    m[136:148] = b"00000000115\x00"
+    m[156:157] = b"0"
+    m[257:265] = b"ustar\x0000"
+    m[329:337] = m[337:345] = b"0000000\x00"
+    assert h[1024:] == fin(m) and len(h) == 1536
+    # a lone byte 0x80 is not ASCII either (isASCII: c >= 0x80)
+    h = M.layer_header_bytes({"relpath": "a\udc80b", "kind": M.KIND_FILE, "mode": 0o600, "size": 0})
+    assert len(h) == 1536 and h[512:512 + 12] == b"12 path=a\x80b\n" and h[1024:1027] == b"ab\x00"
+    # a name of exactly 100 bytes is not split, slashes or not (splitUSTARPath: length <= nameSize)
+    name = "d" * 49 + "/" + "f" * 50
+    h = M.layer_header_bytes({"relpath": name, "kind": M.KIND_FILE, "mode": 0o600, "size": 0})
+    assert len(h) == 512 and h[:100] == name.encode() and h[345:500] == bytes(155)
 
 
 def test_pax_name_is_path_cleaned_like_go():

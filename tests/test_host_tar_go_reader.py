@@ -4,6 +4,7 @@ may look like, which pax records count, what a global header is.  python cannot 
 blocks are laid out by hand; every expectation cites the rule of reader.go / strconv.go it restates (the Go source is not
 under /root/reference: restated from the published algorithm, see csrc/mi_tar.hip's header)."""
 import gzip
+import stat
 
 import pytest
 
@@ -141,11 +142,34 @@ def test_pax_records_as_merge_pax_applies_them(tmp_path):
                       (b"uid", b"9223372036854775808")):
         refused(tmp_path, pax([rec(key, text)]) + block(b"f") + END)
     assert member([rec(b"uid", b"9223372036854775807")])[0]["uid"] == 0xffffffff     # fits int64; the entry holds 32 bits
+    for huge in (b"99999999999999999999999", b"18446744073709551616", b"-9223372036854775809"):
+        refused(tmp_path, pax([rec(b"uid", huge)]) + block(b"f") + END)
+        refused(tmp_path, pax([rec(b"mtime", huge + b".5")]) + block(b"f") + END)
+    assert member([rec(b"mtime", b"-9223372036854775808")])[0]["mtime_sec"] == -2**63
+    assert member([b"5 a=\n"])[0]["relpath"] == "name-in-header"                     # the shortest record there is
     # parsePAXRecord: n >= 5, n within the body, a newline where n says, a key, no NUL where text is expected
     for bad in (b"4 a=\n", b"3 =\n", b"99 path=x\n", b"10 path=xy\n", b"9 path=x\n\n", b"6 =ab\n", b"7 pathx\n", b"x path=a\n",
                 b"11 path=a\x00b\n", b"10 a\x00b=cd\n", b"-5 a=\n", b"10 path=xyz"):
         refused(tmp_path, pax([bad]) + block(b"f") + END)
     assert member([rec(b"comment", b"a\x00b")])[0]["relpath"] == "name-in-header"       # a NUL in another key's VALUE is fine
+    # an extended header whose body fills its blocks exactly has no padding; through a gzip stream the same archive
+    # lists the same
+    for total in (512, 1024):
+        filler = rec(b"comment", b"c" * 400)
+        body = [rec(b"path", b"exact/fit")] + [filler] * (total // 512)
+        short = total - sum(len(r) for r in body)
+        body.append(rec(b"comment", b"c" * (short - len(rec(b"comment", b"")))))
+        if sum(len(r) for r in body) != total:             # (the length's own digits moved it by one)
+            body[-1] = rec(b"comment", b"c" * (short - len(rec(b"comment", b"")) - (sum(len(r) for r in body) - total)))
+        assert sum(len(r) for r in body) == total
+        raw = pax(body) + block(b"f", size=2) + pad(b"ok") + block(b"next") + END
+        for gz in (False, True):
+            e = entries(tmp_path, raw, gz)
+            assert [(x["relpath"], x["size"]) for x in e] == [("exact/fit", 2), ("next", 0)]
+            assert e[0]["data_offset"] == 512 + total + 512
+    longname = block(b"././@LongLink", size=512, typ=b"L", magic=b"ustar  \x00") + b"L" * 511 + b"\x00"
+    for gz in (False, True):
+        assert [x["relpath"] for x in entries(tmp_path, longname + block(b"short") + block(b"next") + END, gz)] == ["L" * 511, "next"]
     # size: the member's data area follows the record, not the header field
     e = entries(tmp_path, pax([rec(b"size", b"700")]) + block(b"big", size=1) + pad(b"y" * 700) + block(b"next") + END)
     assert [(x["relpath"], x["size"]) for x in e] == [("big", 700), ("next", 0)]
@@ -194,10 +218,11 @@ def test_gnu_long_names_against_pax_paths(tmp_path):
 
 def test_header_only_types_have_no_data_area(tmp_path):
     # isHeaderOnlyType: link, symlink, char, block, dir, fifo -- whatever their size field says
-    for typ, kind in ((b"1", 3), (b"2", 2), (b"3", 4), (b"4", 4), (b"5", 0), (b"6", 4)):
+    for typ, kind, fmt in ((b"1", 3, stat.S_IFREG), (b"2", 2, stat.S_IFLNK), (b"3", 4, stat.S_IFCHR), (b"4", 4, stat.S_IFBLK),
+                           (b"5", 0, stat.S_IFDIR), (b"6", 4, stat.S_IFIFO)):
         e = entries(tmp_path, block(b"h", size=1024, typ=typ, link=b"t") + block(b"next", size=2) + pad(b"ok") + END)
         assert [(x["relpath"], x["kind"]) for x in e] == [("h", kind), ("next", 1)], typ
-        assert e[1]["data_offset"] == 1024
+        assert e[1]["data_offset"] == 1024 and stat.S_IFMT(e[0]["mode"]) == fmt and e[0]["mode"] & 0o7777 == 0o644
     # "Legacy archives use trailing slash for directories": typeflag NUL + a name ending in "/" is a directory -- decided on
     # the FINAL name, and then header-only too
     e = entries(tmp_path, block(b"old/", size=512, typ=b"\x00", magic=b"") + block(b"next") + END)
@@ -208,6 +233,19 @@ def test_header_only_types_have_no_data_area(tmp_path):
     e = entries(tmp_path, block(b"odd", size=600, typ=b"Z") + pad(b"z" * 600) + block(b"next") + END)
     assert [(x["relpath"], x["kind"]) for x in e] == [("odd", 4), ("next", 1)]
     refused(tmp_path, block(b"odd", size=600, typ=b"Z") + b"z" * 100)
+
+
+def test_field_widths(tmp_path):
+    # a name and a link target of exactly 100 bytes have no NUL: the field's width ends them
+    e = entries(tmp_path, block(b"n" * 100, typ=b"2", link=b"t" * 100, magic=b"") + END)[0]
+    assert e["relpath"] == "n" * 100 and e["link_target"] == "t" * 100
+    # a checksum of six significant octal digits (many high bytes in the block)
+    raw = block(b"\xff" * 100, typ=b"2", link=b"\xfe" * 100, magic=b"ustar  \x00")
+    assert int(raw[148:154], 8) >= 0o100000
+    assert len(entries(tmp_path, raw + END)) == 1
+    bad = bytearray(raw)
+    bad[148:149] = b"0"                                     # the leading digit counts
+    refused(tmp_path, bytes(bad) + END)
 
 
 def test_prefix_field_by_format(tmp_path):
