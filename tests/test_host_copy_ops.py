@@ -319,3 +319,29 @@ def test_eval_symlinks_cases_replayed(tmp_path):
     assert src_of("dir1/tmp1") == str(r / "dir1" / "tmp1")
     assert src_of("link2") == str(r / "test1") and src_of("link3") == str(r / "test1")
     assert src_of("dir2/dir3/tmp1") == str(r / "dir1" / "tmp1")
+
+
+def test_source_errors_of_eval_symlinks(tmp_path):
+    """evalSymlinks (lib/snapshot/utils.go:249-327): a cycle of links ends at "too many links" (walkLink: more than 255
+    walked), a source that is not there at "walk link: lstat", a link out of the root at "points outside of root".  A
+    SINGLE source is os.Stat'ed first (mem_fs.go:358-360): the kernel's own verdict comes before any of these."""
+    tree = _tree(tmp_path, [("/d", "d", ""), ("/d/f", "f", "x"), ("/a", "l", "b"), ("/b", "l", "a")])
+    os.symlink("/etc", tmp_path / "out")                      # (after the walk: a scan refuses such a link itself)
+    for src, words in (("/a", "too many links"), ("/missing", "lstat"), ("/d/missing/deeper", "lstat"),
+                       ("/out", "outside of root")):
+        with pytest.raises(M.MiError) as ei:
+            M.copy_ops_layer(tree, str(tmp_path), [_op(tmp_path, [src, "/d/f"], "/dst/")])
+        assert words in str(ei.value), (src, str(ei.value))
+        if src != "/out":
+            with pytest.raises(M.MiError) as ei:
+                M.copy_ops_layer(tree, str(tmp_path), [_op(tmp_path, [src], "/dst/")])
+            assert "stat src" in str(ei.value), (src, str(ei.value))
+    # 255 links in a row are still walked (beyond the kernel's own limit of 40 nothing can be stat'ed: two sources) ...
+    chain = [("/c0", "f", "end"), ("/other", "f", "o")] + [("/c%d" % i, "l", "c%d" % (i - 1)) for i in range(1, 256)]
+    tree = _tree(tmp_path / "chain", chain)
+    got = _by_dst(M.copy_ops_layer(tree, str(tmp_path / "chain"), [_op(tmp_path / "chain", ["/c255", "/other"], "/dst/")]))
+    assert got["/dst/c0"]["src"] == str(tmp_path / "chain" / "c0")
+    os.symlink("c255", tmp_path / "chain" / "c256")            # ... the 256th is one too many
+    with pytest.raises(M.MiError) as ei:
+        M.copy_ops_layer(tree, str(tmp_path / "chain"), [_op(tmp_path / "chain", ["/c256", "/other"], "/dst/")])
+    assert "too many links" in str(ei.value)

@@ -402,3 +402,29 @@ def test_c1_scan_and_commit_of_the_reference_build_context(tmp_path):
         copied = fs.commit_layer(ops=[op])
         assert [e["relpath"] for e in copied["layer"]][1:] == ["app/" + n[len("ctx/"):] for n in names[1:]]
         assert copied["n_entries"] == len(names)
+
+
+def test_a_file_named_like_a_whiteout_is_keyed_by_the_path_it_deletes(tmp_path):
+    """memLayer.addHeader (mem_layer.go:197-212): a path whose base name has the ".wh." prefix is filed under the path it
+    DELETES -- rangeFiles sorts those keys (:232-244), so /d/.wh.m is committed where /d/m would be (between /d/a and
+    /d/z), not where its own name sorts ('.' < 'a'); and at the root the key is /gone, not //gone."""
+    root = str(tmp_path)
+    _mk(root, [("/d/a", "f", "1"), ("/d/.wh.m", "f", ""), ("/d/z", "f", "2"), ("/.wh.gone", "f", ""), ("/e", "f", "3"), ("/h", "f", "4")])
+    with M.MemFS(root) as fs:
+        layer = fs.scan()
+        assert _names(layer) == ["/d", "/d/a", "/d/.wh.m", "/d/z", "/e", "/.wh.gone", "/h"]
+        assert [e["file_index"] for e in layer] == [-1, 0, -1, 1, 2, -1, 3]      # a whiteout has no content
+
+
+def test_a_hard_link_that_did_not_change_is_not_merged_again(tmp_path):
+    """isUpdated through tario.IsSimilarHeader's hard-link case (compare.go:62-83): same target, owner, mode and second ->
+    similar -> the second merge of the same member adds nothing; another target does."""
+    base = [{"relpath": "bin", "kind": M.KIND_DIR, "mode": 0o40755, "mtime_sec": 5},
+            {"relpath": "bin/busybox", "kind": M.KIND_FILE, "mode": 0o100755, "size": 9, "mtime_sec": 5},
+            {"relpath": "bin/sh", "kind": M.KIND_HARDLINK, "mode": 0o100755, "mtime_sec": 5, "link_target": "bin/busybox"}]
+    with M.MemFS(str(tmp_path)) as fs:
+        assert fs.update_from_entries(base) == 3
+        assert fs.update_from_entries(base) == 0
+        assert fs.update_from_entries([dict(base[2], mtime_sec=6)]) == 2         # the link and its directory
+        assert fs.update_from_entries([dict(base[2], mtime_sec=6, link_target="/bin/busybox")]) == 0   # AbsPath either way
+        assert fs.update_from_entries([dict(base[2], mtime_sec=6, link_target="bin/other")]) == 2
