@@ -472,10 +472,15 @@ int mi_entry_similar(const mi_tree_entry* a, const mi_tree_entry* b, int ignore_
 /* ---- a layer tar as a source: entries and the byte range of every file, no extraction ---- *
  * MemFS.UpdateFromTarReader (lib/snapshot/mem_fs.go:165-255) fills the in-memory tree from the
  * headers of base / cached layers.  mi_tar_open reads the headers of an UNCOMPRESSED tar (ustar,
- * pax 'x'/'g' records, GNU long names / base-256 numbers -- what Go's archive/tar and docker
+ * pax 'x' records, GNU long names / base-256 numbers -- what Go's archive/tar and docker
  * write) and lists them as mi_tree_entry rows: relpath = the cleaned header name ("." for the
  * root, no leading or trailing "/"), kind 0 directory / 1 regular / 2 symlink / 3 hard link /
- * 4 other (device, fifo), file_index = ordinal among the regular files.  data_offsets[i]
+ * 4 other (device, fifo, a pax GLOBAL header -- which archive/tar hands to its caller as a member
+ * and applies to nobody), file_index = ordinal among the regular files.  What ends an archive and
+ * what fails it follow archive/tar's reader, not POSIX (csrc/mi_tar.hip lists the rules): one zero
+ * block + end of data is an end, a zero block + a header or a last block of 1..511 bytes is
+ * MI_ERR_INVALID ("read header: ...", mem_fs.go:185), as are malformed numbers, pax records and
+ * pax times.  data_offsets[i]
  * (optional) = where entry i's bytes start in the archive (regular files only): a file is one
  * contiguous range of the tar.  Whiteout markers (".wh.<name>") are listed as the entries they
  * are.  Strings live until mi_tar_free.  Host logic.                                        */

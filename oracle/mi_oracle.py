@@ -12,10 +12,13 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libmi_oracle.so")
+# MI_ORACLE_LIB: another build of the oracle (tools/mutate_host.py --oracle holds tests/test_oracle.py against mutants of it)
+_LIB_PATH = os.environ.get("MI_ORACLE_LIB") or os.path.join(_HERE, "libmi_oracle.so")
 
 
 def build(force=False):
+    if os.environ.get("MI_ORACLE_LIB"):
+        return _LIB_PATH
     deps = [os.path.join(_HERE, f) for f in ("mi_oracle.c", "mi_oracle_abi.c", "mi_oracle.h", "Makefile")]
     deps.append(os.path.join(os.path.dirname(_HERE), "include", "makisu_mi.h"))
     if (not force and os.path.exists(_LIB_PATH)

@@ -37,6 +37,16 @@ def tree(tmp_path):
     os.symlink("/no/such", b / "dangling")
     os.symlink("a", b / "dirlink")                      # a symlink to a directory is NOT descended into
     os.mkfifo(b / "a" / "fifo")
+    # every kind utils.IsSpecialFile names (lib/utils/utils.go:161-163); device nodes where this process may make them
+    import socket
+    sk = socket.socket(socket.AF_UNIX)
+    sk.bind(str(b / "a" / "sock"))
+    sk.close()
+    try:
+        os.mknod(b / "a" / "chr", 0o600 | stat.S_IFCHR, os.makedev(1, 3))
+        os.mknod(b / "z" / "blk", 0o600 | stat.S_IFBLK, os.makedev(7, 0))
+    except PermissionError:
+        pass
     return b
 
 
@@ -48,7 +58,7 @@ def test_context_walk_matches_go_order(tree, engine_lib):
     assert got[0][0] == "."
     kinds = {g[0]: g[4] for g in got}
     assert kinds["a"] == 0 and kinds["a/x.txt"] == 1 and kinds["a/lnk"] == 2 and kinds["dirlink"] == 2
-    assert "a/fifo" not in kinds                       # utils.IsSpecialFile
+    assert not {"a/fifo", "a/sock", "a/chr", "z/blk"} & set(kinds)      # utils.IsSpecialFile
     assert not any(k.startswith("dirlink/") for k in kinds)
     links = {g[0]: g[1] for g in got if g[4] == 2}
     assert links == {"a/lnk": "x.txt", "dangling": "/no/such", "dirlink": "a"}
@@ -75,7 +85,7 @@ def test_scan_walk_should_skip(tree, engine_lib):
     assert not any(".wh..wh." in g for g in got)        # AUFS metadata pruned with its subtree
     assert not any(g == "ctx/a/deep" or g.startswith("ctx/a/deep/") for g in got)
     assert not any(g == "ctx/a.d" or g.startswith("ctx/a.d/") for g in got)   # trailing "/" normalised (AbsPath)
-    assert "ctx/a/x.txt" in got and "ctx/a/fifo" not in got
+    assert "ctx/a/x.txt" in got and not {"ctx/a/fifo", "ctx/a/sock", "ctx/a/chr", "ctx/z/blk"} & set(got)
     # blacklisting "/" prunes everything (ancestor == "/" rule, path.go:29)
     assert makisu_amd.tree_walk(str(tree), blacklist=["/"], mode=makisu_amd.TREE_SCAN) == []
     # a path that only shares a name prefix with a blacklisted dir is NOT a descendant

@@ -88,19 +88,30 @@ def run_mutant(k, args, src_lines, site, objs_other, flags):
         f.writelines(src_lines[: ln - 1] + [new_line] + src_lines[ln:])
     obj = os.path.join(work, base.replace(".hip", ".o"))
     lib = os.path.join(work, "libmakisu_mi.so")
-    cc = [B.HIPCC] + flags + ["-I", os.path.dirname(os.path.abspath(args.source)), "-c", mutated, "-o", obj]
-    r = subprocess.run(cc, capture_output=True, text=True)
     tag = "%s:%d  [%s]  %s  ->  %s" % (base, ln, name, line.strip()[:110], new_line.strip()[:110])
-    if r.returncode != 0:
-        shutil.rmtree(work, ignore_errors=True)
-        return ("nocompile", tag, "")
-    link = [B.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", "-Wl,--no-undefined", obj] + objs_other + \
-           ["-ldl", "-lpthread", "-lz", "-o", lib]
-    r = subprocess.run(link, capture_output=True, text=True)
-    if r.returncode != 0:
-        shutil.rmtree(work, ignore_errors=True)
-        return ("nocompile", tag, "")
-    env = dict(os.environ, MAKISU_MI_LIB=lib, PYTHONDONTWRITEBYTECODE="1")
+    if args.oracle:                                           # the CPU oracle: plain C, one compile + link
+        odir = os.path.join(ROOT, "oracle")
+        lib = os.path.join(work, "libmi_oracle.so")
+        cc = ["gcc", "-O1", "-fPIC", "-std=gnu11", "-pthread", "-w", "-shared", "-I", odir, "-I", os.path.join(ROOT, "include"),
+              "-o", lib, mutated] + [os.path.join(odir, f) for f in ("mi_oracle.c", "mi_oracle_abi.c") if f != base] + ["-lpthread"]
+        r = subprocess.run(cc, capture_output=True, text=True)
+        if r.returncode != 0:
+            shutil.rmtree(work, ignore_errors=True)
+            return ("nocompile", tag, "")
+        env = dict(os.environ, MI_ORACLE_LIB=lib, PYTHONDONTWRITEBYTECODE="1")
+    else:
+        cc = [B.HIPCC] + flags + ["-I", os.path.dirname(os.path.abspath(args.source)), "-c", mutated, "-o", obj]
+        r = subprocess.run(cc, capture_output=True, text=True)
+        if r.returncode != 0:
+            shutil.rmtree(work, ignore_errors=True)
+            return ("nocompile", tag, "")
+        link = [B.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-fno-gpu-rdc", "-Wl,--no-undefined", obj] + objs_other + \
+               ["-ldl", "-lpthread", "-lz", "-o", lib]
+        r = subprocess.run(link, capture_output=True, text=True)
+        if r.returncode != 0:
+            shutil.rmtree(work, ignore_errors=True)
+            return ("nocompile", tag, "")
+        env = dict(os.environ, MAKISU_MI_LIB=lib, PYTHONDONTWRITEBYTECODE="1")
     try:
         r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "not gpu", "-p", "no:cacheprovider"] + args.tests,
                            cwd=ROOT, env=env, capture_output=True, text=True, timeout=args.timeout)
@@ -126,6 +137,7 @@ def main():
     ap.add_argument("--timeout", type=int, default=240)
     ap.add_argument("--work", default="/tmp/mi_mut")
     ap.add_argument("--out", default="")
+    ap.add_argument("--oracle", action="store_true", help="the source is a file of oracle/ (gcc, MI_ORACLE_LIB)")
     args = ap.parse_args()
     B.build()
     with open(args.source) as f:
