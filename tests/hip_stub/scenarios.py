@@ -109,6 +109,21 @@ def scenario_two_batches(tmp, threads, slab):
             check(bs[k], wants[k], "two batches, end %d" % k)
 
 
+def scenario_interleaved(tmp, threads, slab):
+    """two batches of one ctx fed file by file in turn, files of one size: the readers' queue holds A's and B's pieces
+    alternately at the SAME arena offsets -- a run of pieces that travels as one copy must stay inside one batch"""
+    fa = make_files(os.path.join(tmp, "ila"), [4096] * 150, 31)
+    fb = make_files(os.path.join(tmp, "ilb"), [4096] * 150, 37)
+    with M.Engine(n_streams=threads, staging_bytes=slab) as eng, eng.batch(300, 2 << 20) as a, eng.batch(300, 2 << 20) as b:
+        for (pa, _), (pb, _) in zip(fa, fb):
+            a.add_path(pa)
+            b.add_path(pb)
+        a.run()
+        b.run()
+        check(a, b"".join(d for _, d in fa), "interleaved fills, batch a")
+        check(b, b"".join(d for _, d in fb), "interleaved fills, batch b")
+
+
 def scenario_errors(tmp, threads, slab):
     """a file that is gone, a file that shrank: the batch that holds it fails -- and keeps failing -- the other does not"""
     files = make_files(os.path.join(tmp, "err"), [slab + 10, 3000, 40000], 23)
@@ -279,7 +294,7 @@ def main():
     threads = int(sys.argv[2]) if len(sys.argv) > 2 else 4
     slab = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
     only = sys.argv[4].split(",") if len(sys.argv) > 4 else None
-    for name, fn in [("mix", scenario_mix), ("growth", scenario_growth_and_reuse), ("two", scenario_two_batches),
+    for name, fn in [("mix", scenario_mix), ("growth", scenario_growth_and_reuse), ("two", scenario_two_batches), ("interleaved", scenario_interleaved),
                      ("errors", scenario_errors), ("api", scenario_api), ("tree", scenario_tree_reserves_ahead),
                      ("two_ctxs", scenario_two_ctxs), ("recycle", scenario_blocks_recycle)]:
         if (name not in only) if only else name == "recycle":    # "recycle" runs only when asked for
