@@ -38,6 +38,9 @@
 //   * a GNU long name / link wins over a pax path / linkpath (merged first), and an empty one
 //     changes nothing;
 //   * the size field of a link, symlink, device, directory or fifo header describes no data.
+// NOT restated: sparse members (GNU 'S', pax GNU.sparse.*), which archive/tar expands to their logical size -- they are
+// listed with the bytes the archive holds for them (docker and makisu write none); a global header's node in the tree
+// (the reference keeps one of an "unsupported type" that fails its next scan; mi_memfs leaves kind 4 out).
 #include "../../include/makisu_mi.h"
 
 #include <errno.h>
