@@ -397,13 +397,14 @@ int submit_pipeline_enqueue(mi_batch* b) {
     u32* d_cursor = (u32*)(ctl + kCtlCursorOff);
     u32* d_hist = (u32*)(ctl + kCtlHistOff);
     const u64* d_n = d_total;
-    const int ncu = c->prop.multiProcessorCount;
+    const int ncu = b->n_cu ? b->n_cu : c->prop.multiProcessorCount;
     // Pin the hashing workgroups to their CUs (sha256.hip launch_sha256_items) when this batch has the GPU to
     // itself: a crowded CU then costs the launch up to 25 %.  With another batch in flight the passes of the
     // two fill each other's gaps, the step is the same either way (5.8 ms on C2), and the unused LDS the pin
     // reserves would only keep the other batch's Gear workgroups off the CU (measured: -1.3 %).
     ShaTune sha = c->sha;
-    sha.pin_blocks_per_cu = c->sha.pin_blocks_per_cu && c->batches_in_flight == 0;
+    sha.pin_blocks_per_cu = c->sha.pin_blocks_per_cu && (c->batches_in_flight == 0 || b->n_cu);   // (a batch with CUs of its
+                                                                                                 //  own has them to itself)
 
     HIPCHK(c, hipEventRecord(b->ev[0], s));
     HIPCHK(c, hipMemsetAsync(ctl, 0, kCtlBytes, s));
@@ -828,7 +829,14 @@ int mi_batch_begin(mi_ctx* c, uint64_t n_files_hint, uint64_t bytes_hint, mi_bat
     memset(&b->stats, 0, sizeof b->stats);
     memset(&b->stage_stats, 0, sizeof b->stage_stats);
     b->files.reserve(n_files_hint);
-    hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+    hipError_t e = hipErrorUnknown;
+    if (!c->batch_cu_masks.empty()) {                   // MI_BATCH_CU_MASKS: this batch's share of the compute units
+        const size_t k = c->next_cu_mask++ % c->batch_cu_masks.size();
+        e = hipExtStreamCreateWithCUMask(&b->stream, (uint32_t)c->batch_cu_masks[k].size(), c->batch_cu_masks[k].data());
+        if (e == hipSuccess) b->n_cu = c->batch_cu_counts[k];
+        else (void)hipGetLastError();                   // a runtime without it: the whole device, as always
+    }
+    if (e != hipSuccess) e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
     for (auto& ev : b->ev) if (e == hipSuccess) e = hipEventCreate(&ev);
     if (e == hipSuccess) e = hipHostMalloc((void**)&b->h_counts, 16, hipHostMallocDefault);
     ++c->live_children;                                 // mi_batch_free undoes it (error paths included)

@@ -154,6 +154,7 @@ hipError_t hipHostMalloc(void** p, size_t n, unsigned int) {
 hipError_t hipHostFree(void* p) { if (p) { free(p); --g_live_allocs; } return hipSuccess; }
 
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned int) { *s = (hipStream_t) new Stream(); return hipSuccess; }
+hipError_t hipExtStreamCreateWithCUMask(hipStream_t* s, uint32_t, const uint32_t*) { *s = (hipStream_t) new Stream(); return hipSuccess; }
 hipError_t hipStreamDestroy(hipStream_t s) { if (s) { ((Stream*)s)->sync(); delete (Stream*)s; } return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t s) { S(s)->sync(); return hipSuccess; }
 
