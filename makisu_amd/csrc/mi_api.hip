@@ -647,6 +647,45 @@ const char* mi_last_error(mi_ctx* ctx) {
     return copy.c_str();
 }
 
+// MI_BATCH_CU_MASKS="0-127,128-255" / "0-63+128-191,64-127+192-255": one comma-separated set of compute units per batch
+// in flight, a set = '+'-joined `a-b` ranges or single numbers (bit i of the mask = compute unit i as the runtime counts
+// them).  Anything malformed or out of the device's range leaves the knob off: an experiment must not half-apply.
+static void parse_cu_masks(mi_ctx* c, const char* s) {
+    const int ncu = c->prop.multiProcessorCount;
+    if (ncu <= 0 || !*s) return;
+    std::vector<std::vector<u32>> masks;
+    std::vector<int> counts;
+    const char* p = s;
+    for (;;) {
+        std::vector<u32> m((size_t)(ncu + 31) / 32, 0u);
+        int n = 0;
+        for (;;) {
+            char* end = nullptr;
+            const long a = strtol(p, &end, 10);
+            if (end == p) return;
+            long b = a;
+            p = end;
+            if (*p == '-') {
+                b = strtol(p + 1, &end, 10);
+                if (end == p + 1) return;
+                p = end;
+            }
+            if (a < 0 || b < a || b >= ncu) return;
+            for (long i = a; i <= b; ++i)
+                if (!(m[(size_t)i >> 5] >> (i & 31) & 1u)) { m[(size_t)i >> 5] |= 1u << (i & 31); ++n; }
+            if (*p != '+') break;
+            ++p;
+        }
+        masks.push_back(std::move(m));
+        counts.push_back(n);
+        if (*p == 0) break;
+        if (*p != ',') return;
+        ++p;
+    }
+    c->batch_cu_masks = std::move(masks);
+    c->batch_cu_counts = std::move(counts);
+}
+
 int mi_ctx_create(const mi_config* cfg, mi_ctx** out) {
     if (!cfg || !out) return fail(nullptr, MI_ERR_INVALID, "mi_ctx_create: null argument");
     if (cfg->struct_size != sizeof(mi_config))
@@ -699,6 +738,7 @@ int mi_ctx_create(const mi_config* cfg, mi_ctx** out) {
     for (auto& e : c->ev) CREATE_CHK(hipEventCreate(&e));
     CREATE_CHK(hipEventCreateWithFlags(&c->sha_done, hipEventDisableTiming));
     if (const char* e = getenv("MI_SHA_SERIALIZE")) c->serialize_sha = atoi(e) != 0;
+    if (const char* e = getenv("MI_BATCH_CU_MASKS")) parse_cu_masks(c, e);
     // host-fed staging (mi_stage.hip): slab bytes and reader threads; both lazily allocated
     c->staging_bytes = cfg->staging_bytes ? cfg->staging_bytes : (8ull << 20);
     if (c->staging_bytes < (1ull << 16)) c->staging_bytes = 1ull << 16;
