@@ -8,6 +8,22 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# MI_PROPERTY_SOAK=<factor>: the property tests (hypothesis) leave their fixed seed and run <factor> times their
+# examples -- every run of the suite explores the same cases by design (derandomize=True: a red test must stay red);
+# a soak explores new ones.  tools/property_soak.sh runs it against the ASan + UBSan build of the library.
+_SOAK = float(os.environ.get("MI_PROPERTY_SOAK", "0") or 0)
+if _SOAK > 0:
+    import hypothesis
+    _init = hypothesis.settings.__init__
+
+    def _soak_init(self, parent=None, **kw):
+        if kw.get("derandomize") is True and "max_examples" in kw:      # a test's own settings, not the library's defaults
+            kw["max_examples"] = max(1, int(kw["max_examples"] * _SOAK))
+            kw["derandomize"] = False
+        _init(self, parent, **kw)
+    hypothesis.settings.__init__ = _soak_init
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -2,7 +2,7 @@
 # The CPU suite against a build of the library with AddressSanitizer + UndefinedBehaviorSanitizer on the HOST code
 # (device code is compiled as usual: -fno-gpu-sanitize).  No GPU needed: everything `-m "not gpu"` reaches -- walks, the
 # layer merge and diff, copy ops, the tar reader and writer, the layer pipeline, the codecs -- runs instrumented.
-#   tools/asan_host_tests.sh [pytest args]
+#   tools/asan_host_tests.sh [pytest args]        (MI_ASAN_TARGET="<files>": those test files instead of all of tests/)
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=${MI_ASAN_DIR:-/tmp/mi_asan}
@@ -19,4 +19,4 @@ wait
     -shared-libsan "$OUT"/*.o -ldl -lpthread -lz -o "$OUT/libmakisu_mi.so"
 cd "$ROOT"
 LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
-    MAKISU_MI_LIB="$OUT/libmakisu_mi.so" python -m pytest tests -q -m "not gpu" -p no:cacheprovider "$@"
+    MAKISU_MI_LIB="$OUT/libmakisu_mi.so" python -m pytest ${MI_ASAN_TARGET:-tests} -q -m "not gpu" -p no:cacheprovider "$@"
