@@ -67,6 +67,10 @@ MATCH_CASES = [
     ("*[^a]*", "[/", False),                                   # the first fit of a chunk is final: no backtracking into it
     ("", "", True), ("", "a", False), ("*", "", True), ("*", "a/b", False), ("?", "", False),
     (".*", ".hidden", True), ("*", ".hidden", True),           # no special case for a leading dot
+    # the star slides BYTE by byte (Match: "look for match skipping i+1 bytes") while '?' and classes decode runes: a star
+    # may stop inside a rune, and what is left decodes as one RuneError per byte (found by tools/property_soak.sh)
+    ("*[^☺]", "☺", True), ("*??", "☺", True), ("*???", "☺", False), ("?", "☺", True), ("??", "☺", False),
+    ("*[^☺][^☺]", "☺", True), ("[^☺]", "☺", False), ("*α", "☺α", True),
 ]
 
 
@@ -131,6 +135,8 @@ def test_well_formed_patterns_match_like_their_regular_expression(pattern, name)
     # nothing but a literal matches '/'.  A negated class does match '/', where the star cannot follow: "*[^a]*" against
     # "[/" is false in Go, true for a backtracking matcher.  Those pairs are left to the table.)
     assume(not ("/" in name and "[^" in pattern))
+    # (and the star slides byte by byte: behind it, '?' and classes may meet the tail of a rune -- the table has those)
+    assume(not ("*" in pattern and not name.isascii() and ("?" in pattern or "[" in pattern)))
     assert M.path_match(pattern, name) == bool(_to_regex(pattern).fullmatch(name)), (pattern, name)
 
 

@@ -9,7 +9,7 @@ FACTOR=${1:-10}
 cd "$ROOT"
 FILES=$(grep -l "^from hypothesis\|^import hypothesis" tests/test_*.py)
 if [ "${2:-}" = asan ]; then
-    MI_PROPERTY_SOAK=$FACTOR MI_ASAN_TARGET="$FILES" tools/asan_host_tests.sh -x
+    MI_PROPERTY_SOAK=$FACTOR MI_ASAN_TARGET="$FILES" tools/asan_host_tests.sh
 else
-    MI_PROPERTY_SOAK=$FACTOR python -m pytest -q -x -m "not gpu" -p no:cacheprovider $FILES
+    MI_PROPERTY_SOAK=$FACTOR python -m pytest -q -m "not gpu" -p no:cacheprovider $FILES
 fi
