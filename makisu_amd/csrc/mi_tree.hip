@@ -878,21 +878,111 @@ void mi_batch_tree_free(void* tree) { delete (Tree*)tree; }
 // deletes (dir + name without the prefix).  This is NOT the walk order ("a-b" sorts before
 // "a/x": '-' < '/'), so the shim needs it to line the engine's per-file results up with the tar
 // stream.  order_out[k] = index of the k-th entry to commit; equal keys keep their input order.
+// How: the keys are laid out in contiguous arenas (no string per entry), and the order is a STABLE NATURAL MERGE SORT of
+// the indices -- maximal non-decreasing runs are found first and merged pairwise.  A walk hands its entries over almost
+// sorted (filepath.Walk order differs from sort.Strings only where a name holds a byte below '/': "a.txt" before "a/x"),
+// so there are few runs and the cost is a few passes instead of log2(n): 100 000 walk-ordered entries 50 -> 11 ms, a
+// million 600 -> 50 ms, ten million 0.56 s (8 cores of this container, measured beside another job); shuffled input
+// 110 -> 50 ms per 100 000, 2.7 -> 0.19 s per million.  From 131 072 entries on, blocks of the input are
+// keyed and sorted by up to 16 threads (MI_WALK_THREADS) and merged pairwise (C4 names 10 M entries).
+namespace {
+struct KeyRef { const char* p; uint32_t len; };
+inline bool key_less(const KeyRef& a, const KeyRef& b) {       // bytewise, like Go's string comparison
+    const uint32_t m = a.len < b.len ? a.len : b.len;
+    const int c = m ? memcmp(a.p, b.p, m) : 0;
+    return c < 0 || (c == 0 && a.len < b.len);
+}
+// the key of one entry appended to `arena`: AbsPath(dst), a whiteout marker under the path it deletes
+inline void append_key(const char* rp, std::string* arena) {
+    rp = rp ? rp : "";
+    const size_t at = arena->size();
+    if (strcmp(rp, ".") == 0) rp = "";
+    *arena += *rp ? mi_walk::abs_path_of_rel(rp) : mi_walk::abs_path("");
+    const size_t cut = arena->find_last_of('/');               // the key starts with '/': found at or after `at`
+    if (cut != std::string::npos && cut >= at && arena->compare(cut + 1, 4, ".wh.") == 0 && arena->size() - cut - 1 >= 4)
+        arena->erase(cut + 1, 4);
+}
+// stable: idx[0, n) by keys; tmp = scratch of n words
+void natural_merge_sort(uint64_t* idx, uint64_t* tmp, size_t n, const KeyRef* keys) {
+    if (n < 2) return;
+    auto less = [keys](uint64_t a, uint64_t b) { return key_less(keys[a], keys[b]); };
+    std::vector<size_t> runs, next;                              // run boundaries: k runs = k + 1 entries
+    runs.push_back(0);
+    for (size_t i = 1; i < n; ++i)
+        if (less(idx[i], idx[i - 1])) runs.push_back(i);
+    runs.push_back(n);
+    uint64_t *src = idx, *dst = tmp;
+    while (runs.size() > 2) {
+        next.clear();
+        next.push_back(0);
+        size_t r = 0;
+        for (; r + 2 < runs.size(); r += 2) {
+            std::merge(src + runs[r], src + runs[r + 1], src + runs[r + 1], src + runs[r + 2], dst + runs[r], less);
+            next.push_back(runs[r + 2]);
+        }
+        if (r + 1 < runs.size()) {                               // an odd run at the end travels as it is
+            std::copy(src + runs[r], src + runs[r + 1], dst + runs[r]);
+            next.push_back(runs[r + 1]);
+        }
+        std::swap(src, dst);
+        runs.swap(next);
+    }
+    if (src != idx) std::copy(src, src + n, idx);
+}
+}  // namespace
+
 int mi_entries_commit_order(const mi_tree_entry* entries, uint64_t n, uint64_t* order_out) {
     if ((n && !entries) || (n && !order_out)) return MI_ERR_INVALID;
-    std::vector<std::string> keys((size_t)n);
-    for (uint64_t i = 0; i < n; ++i) {
-        const char* rp = entries[i].relpath ? entries[i].relpath : "";
-        std::string dst = mi_walk::abs_path(strcmp(rp, ".") == 0 ? "" : rp);
-        const size_t cut = dst.find_last_of('/');
-        const std::string dir = dst.substr(0, cut + 1), base = dst.substr(cut + 1);
-        keys[(size_t)i] = mi_walk::has_prefix(base, ".wh.") ? dir + base.substr(4) : dst;
+    if (n == 0) return MI_OK;
+    const uint64_t kBlockMin = 65536;
+    unsigned nt = (unsigned)std::min<uint64_t>(mi_walk::walk_threads(), n / kBlockMin);
+    if (nt < 1) nt = 1;
+    std::vector<uint64_t> bounds(nt + 1);
+    for (unsigned t = 0; t <= nt; ++t) bounds[t] = n * t / nt;
+    std::vector<KeyRef> keys((size_t)n);
+    std::vector<std::string> arenas(nt);
+    std::vector<uint64_t> tmp((size_t)n);
+    auto block = [&](unsigned t) {                               // keys of the block, then the block sorted in place
+        const uint64_t lo = bounds[t], hi = bounds[t + 1];
+        std::string& arena = arenas[t];
+        std::vector<uint64_t> at((size_t)(hi - lo) + 1);
+        for (uint64_t i = lo; i < hi; ++i) { at[(size_t)(i - lo)] = arena.size(); append_key(entries[i].relpath, &arena); }
+        at[(size_t)(hi - lo)] = arena.size();
+        for (uint64_t i = lo; i < hi; ++i) {
+            keys[(size_t)i].p = arena.data() + at[(size_t)(i - lo)];
+            keys[(size_t)i].len = (uint32_t)(at[(size_t)(i - lo) + 1] - at[(size_t)(i - lo)]);
+            order_out[i] = i;
+        }
+        natural_merge_sort(order_out + lo, tmp.data() + lo, (size_t)(hi - lo), keys.data());
+    };
+    if (nt == 1) { block(0); return MI_OK; }
+    {
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; ++t) th.emplace_back(block, t);
+        block(0);
+        for (auto& x : th) x.join();
     }
-    std::vector<uint64_t> idx((size_t)n);
-    for (uint64_t i = 0; i < n; ++i) idx[(size_t)i] = i;
-    std::stable_sort(idx.begin(), idx.end(),
-                     [&](uint64_t a, uint64_t b) { return keys[(size_t)a] < keys[(size_t)b]; });   // bytewise
-    for (uint64_t i = 0; i < n; ++i) order_out[i] = idx[(size_t)i];
+    auto less = [&keys](uint64_t a, uint64_t b) { return key_less(keys[(size_t)a], keys[(size_t)b]); };
+    uint64_t *src = order_out, *dst = tmp.data();
+    while (bounds.size() > 2) {                                  // sorted blocks merged pairwise, a thread per pair
+        std::vector<uint64_t> next;
+        next.push_back(0);
+        std::vector<std::thread> th;
+        size_t r = 0;
+        for (; r + 2 < bounds.size(); r += 2) {
+            const uint64_t a = bounds[r], b = bounds[r + 1], c = bounds[r + 2];
+            th.emplace_back([=] { std::merge(src + a, src + b, src + b, src + c, dst + a, less); });
+            next.push_back(c);
+        }
+        if (r + 1 < bounds.size()) {
+            std::copy(src + bounds[r], src + bounds[r + 1], dst + bounds[r]);
+            next.push_back(bounds[r + 1]);
+        }
+        for (auto& x : th) x.join();
+        std::swap(src, dst);
+        bounds.swap(next);
+    }
+    if (src != order_out) std::copy(src, src + n, order_out);
     return MI_OK;
 }
 

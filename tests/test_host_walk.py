@@ -260,6 +260,39 @@ def test_commit_order_is_sorted_dst_paths_not_walk_order(tree, engine_lib):
     assert makisu_amd.commit_order([]) == []
 
 
+@pytest.mark.parametrize("shape", ["walk", "random", "reversed"])
+@pytest.mark.parametrize("threads", ["1", "3", "5"])
+def test_commit_order_at_scale_runs_blocks_and_threads(engine_lib, monkeypatch, shape, threads):
+    """300 000 entries (C2 holds 100 000, C4 ten million: SURVEY 8a a7): the order is found by merging the input's
+    non-decreasing runs, block-wise on several threads from 131 072 entries on -- the same answer as Python's stable
+    sort of the keys for an input in walk order (few runs), shuffled (runs of two) and reversed (runs of one), with
+    whiteout markers beside the paths they hide (equal keys: input order) and names on both sides of '/'"""
+    import random
+    import makisu_amd
+    monkeypatch.setenv("MI_WALK_THREADS", threads)
+    rng = random.Random(7)
+    rels = ["."]
+    for d in range(3000):
+        dn = "d%04d" % d
+        rels.append(dn)
+        rels += ["%s/f%05d%s" % (dn, k, rng.choice(["", ".txt", "-x", " y"])) for k in range(96)]
+        rels += ["%s.d" % dn, "%s-e" % dn, "%s/.wh.f%05d" % (dn, rng.randrange(96)), "%s/.wh.gone" % dn]
+    if shape == "walk":
+        rels.sort(key=lambda r: r.split("/"))
+    elif shape == "random":
+        rng.shuffle(rels)
+    else:
+        rels.sort(reverse=True)
+
+    def key(r):
+        dst = "/" if r == "." else "/" + r
+        d, b = dst.rsplit("/", 1)
+        return ((d + "/" + b[4:]) if b.startswith(".wh.") else dst).encode()
+
+    assert len(rels) > 2 * 131072
+    assert makisu_amd.commit_order(rels) == sorted(range(len(rels)), key=lambda i: key(rels[i]))
+
+
 # ---- mi_snapshot_diff: createLayerByScan + maybeAddToLayer on two walks ----------------------
 def _diff_names(before, after, **kw):
     import makisu_amd
