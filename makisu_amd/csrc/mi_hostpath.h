@@ -96,6 +96,23 @@ inline std::string abs_path_of_rel(const char* rel) {
     out.append(rel, n);
     return out;
 }
+// the same into a buffer that keeps its capacity (a walk's million paths: no allocation per path)
+inline void abs_path_of_rel_into(const char* rel, std::string* out) {
+    if (rel[0] == '.' && rel[1] == 0) { out->assign("/"); return; }
+    size_t n = strlen(rel);
+    while (n && rel[n - 1] == '/') --n;
+    bool clean = n > 0 && rel[0] != '/';
+    for (size_t i = 0; clean && i < n; ++i) {
+        if (rel[i] == '/' && (i + 1 >= n || rel[i + 1] == '/')) clean = false;
+        if (rel[i] == '.' && (i == 0 || rel[i - 1] == '/')) {
+            const size_t k = rel[i + 1] == '.' ? i + 2 : i + 1;
+            if (k >= n || rel[k] == '/') clean = false;
+        }
+    }
+    if (!clean) { *out = abs_path(rel); return; }
+    out->assign(1, '/');
+    out->append(rel, n);
+}
 inline std::string dir_of(const std::string& p) {            // path.Dir for clean absolute paths
     size_t i = p.find_last_of('/');
     if (i == std::string::npos) return ".";

@@ -19,6 +19,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <unordered_map>
 #include <unordered_set>
 
@@ -66,7 +67,11 @@ struct Fs {
         return out;
     }
     std::string root;                      // fs.tree.src
-    const std::unordered_set<std::string_view>* walked = nullptr;   // the scan under way: the paths its walk lists
+    // the scan under way: "its walk lists this path".  Nodes the tree held when the scan began carry the answer as a
+    // mark (Node::seen == scan_mark, set in one pass over the walk); for a node made DURING the scan the set of the walk's
+    // paths is asked -- built the first time that happens, which a scan of an unchanged tree never sees
+    uint32_t scan_mark = 0;                                          // 0 = no scan under way
+    std::function<bool(const std::string&)> listed_by_walk;          // the fallback
     int64_t now = 0;
     std::string err;
     int rc = MI_OK;
@@ -162,26 +167,30 @@ struct Fs {
                 return;
             }
         }
-        // "Handle deletions.  Note: Only one whiteout file is needed for a deleted subtree." (:460-480): the children
-        // the tree held for this directory BEFORE the call (n, isUpdated's node) that are no longer on disk
-        if (create_whiteout && n.e.kind == 0 && had_node) {
+        if (create_whiteout && n.e.kind == 0 && had_node) whiteout_missing_children(dst);
+    }
+    // "Handle deletions.  Note: Only one whiteout file is needed for a deleted subtree." (:460-480): the children
+    // the tree holds for this directory that are no longer on disk
+    void whiteout_missing_children(const std::string& dst) {
+        {
             mi_memtree::Node* dir = t.find(dst);
             if (!dir) return;
             std::vector<std::string> gone;                                      // (wiping changes the map: collect first)
-            std::string child = dst == "/" ? "/" : dst + "/";
-            const size_t stem = child.size();
+            const std::string stem = dst == "/" ? "/" : dst + "/";
+            const size_t root_len = root == "/" ? 0 : root.size();
             for (auto& kv : dir->children) {
-                child.resize(stem);
-                child += kv.first;
                 const int64_t ref = kv.second->ref;
                 const std::string& child_src = ref >= 0 ? nodes[ref].src : std::string();
                 // memFSNode.isOnDisk (:49-57) is an lstat of the node's source.  When that source is the node's own place
                 // under the root and the walk of THIS scan lists it, the walk has just lstat'ed it: no second one (the
                 // reference pays it for every node of the tree on every scan)
-                if (walked && child_src.size() == (root == "/" ? 0 : root.size()) + child.size() && walked->count(std::string_view(child)) &&
-                    child_src.compare(child_src.size() - child.size(), child.size(), child) == 0 &&
-                    (root == "/" || child_src.compare(0, root.size(), root) == 0))
+                if (scan_mark && child_src.size() == root_len + stem.size() + kv.first.size() &&
+                    memcmp(child_src.data(), root.data(), root_len) == 0 &&
+                    memcmp(child_src.data() + root_len, stem.data(), stem.size()) == 0 &&
+                    memcmp(child_src.data() + root_len + stem.size(), kv.first.data(), kv.first.size()) == 0 &&
+                    (kv.second->seen == scan_mark || (listed_by_walk && listed_by_walk(stem + kv.first))))
                     continue;
+                const std::string child = stem + kv.first;
                 struct stat st;
                 if (lstat(child_src.c_str(), &st) == 0) continue;
                 if (errno != ENOENT && errno != ENOTDIR) {
@@ -196,6 +205,25 @@ struct Fs {
                 if (rc) return;
             }
         }
+    }
+    // isUpdated (:487-503) on a walk entry as it comes, before any node is built for it: true = the tree holds this path
+    // with a header tario.IsSimilarHeader calls similar (and, when both sides carry one, the same content root) --
+    // maybeAddToLayer then adds nothing.  The scan's common case: most of a tree does not change between two steps.
+    bool holds_similar(const std::string& dst, const mi_tree_entry& e, const uint8_t* content_root) {
+        mi_memtree::Node* cur = t.find(dst);
+        if (!cur || cur->ref < 0 || e.kind > 3) return false;
+        const Node& o = nodes[cur->ref];
+        if (o.e.kind > 3) return false;
+        mi_tree_entry a, b = e;
+        memset(&a, 0, sizeof a);
+        a.relpath = o.e.relpath.empty() ? "" : o.e.relpath.c_str();
+        a.link_target = o.e.has_link ? o.e.link.c_str() : nullptr;
+        a.size = o.e.size; a.mtime_sec = o.e.mtime; a.mode = o.e.mode; a.kind = o.e.kind;
+        a.uid = o.e.uid; a.gid = o.e.gid; a.file_index = -1;
+        b.relpath = dst.c_str() + 1;                                             // dst without its leading "/"
+        b.file_index = -1;
+        int similar = 0;
+        return mi_entry_similar(&a, &b, 0, o.has_root ? o.root : nullptr, content_root, &similar) == MI_OK && similar;
     }
 };
 
@@ -978,6 +1006,7 @@ extern "C" int mi_memfs_set_clock(mi_memfs* m, int64_t now_sec) {
 extern "C" int mi_memfs_reset(mi_memfs* m) {                                      // MemFS.Reset (:127-130)
     if (!m) return MI_ERR_INVALID;
     m->fs.t.root.children.clear();
+    m->fs.t.shape_changed();
     return MI_OK;
 }
 
@@ -1090,19 +1119,36 @@ extern "C" int mi_memfs_add_layer_by_scan(mi_memfs* m, const mi_tree_entry* walk
     if (!m || (n && !walked) || !out) return MI_ERR_INVALID;
     mi_copy::Fs& fs = m->fs;
     fs.layer.clear();
-    std::unordered_set<std::string_view> on_walk;                               // views into `paths`
-    std::vector<std::string> paths(n);
-    on_walk.reserve(n * 2);
+    // pass 1: the nodes the tree holds for the walk's paths are marked "listed by this scan's walk"
+    static std::atomic<uint32_t> g_scan_mark{0};
+    uint32_t mark = ++g_scan_mark;
+    if (mark == 0) mark = ++g_scan_mark;
+    std::string p;                                                              // one buffer for every path of the walk
     for (uint64_t i = 0; i < n; ++i) {
-        const char* rp = walked[i].relpath ? walked[i].relpath : "";
-        paths[i] = mi_walk::abs_path_of_rel(rp);
-        on_walk.insert(std::string_view(paths[i]));
+        mi_walk::abs_path_of_rel_into(walked[i].relpath ? walked[i].relpath : "", &p);
+        if (mi_memtree::Node* nd = fs.t.find(p)) nd->seen = mark;
     }
-    fs.walked = &on_walk;
-    struct Unset { mi_copy::Fs& f; ~Unset() { f.walked = nullptr; } } unset{fs};
+    std::unordered_set<std::string> on_walk;                                    // the fallback, built when first asked
+    bool on_walk_built = false;
+    fs.scan_mark = mark;
+    fs.listed_by_walk = [&](const std::string& q) {
+        if (!on_walk_built) {
+            on_walk.reserve(n * 2);
+            for (uint64_t i = 0; i < n; ++i) on_walk.insert(mi_walk::abs_path_of_rel(walked[i].relpath ? walked[i].relpath : ""));
+            on_walk_built = true;
+        }
+        return on_walk.count(q) != 0;
+    };
+    struct Unset { mi_copy::Fs& f; ~Unset() { f.scan_mark = 0; f.listed_by_walk = nullptr; } } unset{fs};
     for (uint64_t i = 0; i < n && !fs.rc; ++i) {
         const mi_tree_entry& e = walked[i];
-        const std::string& p = paths[i];
+        mi_walk::abs_path_of_rel_into(e.relpath ? e.relpath : "", &p);
+        const uint8_t* content_root =
+            roots && e.kind == 1 && e.file_index >= 0 ? (const uint8_t*)roots + (uint64_t)e.file_index * root_stride : nullptr;
+        if (fs.holds_similar(p, e, content_root)) {                               // nothing to add; a directory's deletions
+            if (e.kind == 0) fs.whiteout_missing_children(p);                     // are still looked for (maybe_add's tail)
+            continue;
+        }
         mi_copy::Node nd;
         nd.e.relpath = p == "/" ? "" : p.substr(1);
         nd.e.kind = e.kind; nd.e.mode = e.mode; nd.e.mtime = e.mtime_sec; nd.e.uid = e.uid; nd.e.gid = e.gid; nd.e.size = e.size;

