@@ -1004,13 +1004,17 @@ extern "C" int mi_snapshot_diff(const mi_snapshot_side* before, const mi_snapsho
         return MI_ERR_INVALID;
     auto path_of = [](const mi_tree_entry& e) {
         const char* rp = e.relpath ? e.relpath : "";
-        return mi_walk::abs_path(strcmp(rp, ".") == 0 ? "" : rp);
+        return *rp ? mi_walk::abs_path_of_rel(rp) : mi_walk::abs_path("");
     };
     auto root_of = [](const mi_snapshot_side* s, const mi_tree_entry& e) -> const uint8_t* {
         if (!s->roots || e.kind != 1 || e.file_index < 0) return nullptr;
         return (const uint8_t*)s->roots + (uint64_t)e.file_index * s->root_stride;
     };
-    std::map<std::string, uint64_t> old_at, new_at;
+    // path -> index, the LAST entry of a path winning (hashed: the order the paths are visited in decides nothing --
+    // flags are only raised, SAME -> ANCESTOR -> CHANGED)
+    std::unordered_map<std::string, uint64_t> old_at, new_at;
+    old_at.reserve(before->n * 2);
+    new_at.reserve(after->n * 2);
     for (uint64_t i = 0; i < before->n; ++i) old_at[path_of(before->entries[i])] = i;
     for (uint64_t i = 0; i < after->n; ++i) new_at[path_of(after->entries[i])] = i;
     for (uint64_t i = 0; i < after->n; ++i) after_flags[i] = MI_DIFF_SAME;
@@ -1019,7 +1023,11 @@ extern "C" int mi_snapshot_diff(const mi_snapshot_side* before, const mi_snapsho
         std::string d = mi_walk::dir_of(p);
         while (d != "/" && d != ".") {
             auto it = new_at.find(d);
-            if (it != new_at.end() && after_flags[it->second] == MI_DIFF_SAME) after_flags[it->second] = MI_DIFF_ANCESTOR;
+            if (it != new_at.end()) {
+                // an ancestor that is already carried (or changed) has had ITS ancestors carried then: the chain is done
+                if (after_flags[it->second] != MI_DIFF_SAME) return;
+                after_flags[it->second] = MI_DIFF_ANCESTOR;
+            }
             d = mi_walk::dir_of(d);
         }
     };

@@ -50,6 +50,26 @@ def test_add_layer_by_scan_whiteout_replayed(tmp_path):
         assert fs.entries() == [] and fs.scan() == []
 
 
+def test_the_walks_word_is_taken_for_a_node_made_during_the_scan(tmp_path):
+    """isOnDisk is an lstat of the node's source; a path this scan's WALK lists has just been lstat'ed, so the walk's
+    word is taken instead.  For the nodes the tree held when the scan began that word is a mark on the node; for a node
+    made DURING the scan it is the set of the walk's paths.  A walk handed over out of order -- a new file before its
+    directory -- makes the directory's deletion check meet such a node: listed by the walk (and, here, not on disk at
+    all: the entries are made up), it gets no whiteout."""
+    root = str(tmp_path)
+    D = lambda p: {"relpath": p, "kind": M.KIND_DIR, "mode": 0o40755, "mtime_sec": 100, "size": 0}        # noqa: E731
+    F = lambda p, t=100: {"relpath": p, "kind": M.KIND_FILE, "mode": 0o100644, "mtime_sec": t, "size": 5}   # noqa: E731
+    with M.MemFS(root) as fs:
+        assert _names(fs.add_layer_by_scan([D("d"), F("d/old")])) == ["/d", "/d/old"]
+        # second scan: d/new comes BEFORE d; d/old is listed too (a marked node), d/gone never existed
+        layer = fs.add_layer_by_scan([F("d/new"), D("d"), F("d/old")])
+        assert _names(layer) == ["/d", "/d/new"]                 # d as the new file's ancestor; no whiteout of d/new
+        assert [e["relpath"] for e in fs.entries()] == ["d", "d/new", "d/old"]
+        # and a path the walk does NOT list, whose source is not on disk, is whited out (the same check, the other way)
+        layer = fs.add_layer_by_scan([D("d"), F("d/new")])
+        assert _names(layer) == ["/d", "/d/.wh.old"]
+
+
 def test_create_layer_by_scan_replayed(tmp_path):
     """Simple: new paths with their (new) directories; Symlink: the target as written; Whiteout: a removed file in a
     directory that stays -> the directory is carried as an ancestor beside the whiteout"""
@@ -242,6 +262,46 @@ def test_scan_layer_of_the_handle_equals_the_stateless_diff(tmp_path_factory, pa
                 got_content.add("/" + e["relpath"])
         assert got_wh == want_wh and got_content == want_content
         assert [("/" + e["relpath"]) for e in fs.entries()] == sorted("/" + e["relpath"] for e in after)   # the tree IS the disk now
+        assert fs.add_layer_by_scan(walked) == []
+
+
+def test_merge_and_scan_of_sixty_thousand_entries_equal_the_stateless_diff(tmp_path):
+    """C2's entry count is 100 000, C4's ten million: at that size the handle answers
+    directory-by-directory input from what it keeps between two entries -- the parent node of the last lookup, the last
+    addAncestors chain, marks for "the walk lists this path".  300 directories x 200 files three levels down, merged as a
+    layer, then scanned against a walk in which files changed, went, came, one directory went with everything in it
+    and one came: the layer is the stateless diff's (mi_snapshot_diff shares none of that state), the tree is the walk."""
+    import random
+    rng = random.Random(11)
+    D = lambda p: {"relpath": p, "kind": M.KIND_DIR, "mode": 0o40755, "mtime_sec": 100, "size": 0, "uid": 0, "gid": 0}          # noqa: E731
+    F = lambda p, t=100: {"relpath": p, "kind": M.KIND_FILE, "mode": 0o100644, "mtime_sec": t, "size": 5, "uid": 0, "gid": 0}    # noqa: E731
+    before = [D("top"), D("top/mid")]
+    for d in range(300):
+        dn = "top/mid/d%03d" % d
+        before.append(D(dn))
+        before += [F("%s/f%03d" % (dn, k)) for k in range(200)]
+    after = []
+    for e in before:
+        p = e["relpath"]
+        if p.startswith("top/mid/d123"):
+            continue                                              # a directory gone with all it held
+        if e["kind"] == M.KIND_FILE and rng.random() < 0.002:
+            continue                                              # a file gone
+        after.append(F(p, 200) if e["kind"] == M.KIND_FILE and rng.random() < 0.003 else e)
+    after += [D("top/mid/new")] + [F("top/mid/new/n%02d" % k) for k in range(50)] + [F("top/mid/d007/zz-added")]
+    after.sort(key=lambda e: e["relpath"].split("/"))              # filepath.Walk order
+    root = str(tmp_path)                                           # nothing of it is on disk: a missing path IS gone
+    walked = [dict(D("."), relpath=".")] + after
+    flags, wh = M.snapshot_diff(before, walked)
+    want = sorted(["/" + e["relpath"] for e, f in zip(walked, flags) if f != M.DIFF_SAME] +
+                  [os.path.join(os.path.dirname("/" + e["relpath"]), ".wh." + os.path.basename(e["relpath"])) for e, w in zip(before, wh) if w],
+                  key=lambda q: os.path.join(os.path.dirname(q), os.path.basename(q)[4:]) if os.path.basename(q).startswith(".wh.") else q)
+    with M.MemFS(root) as fs:
+        assert fs.update_from_entries(before) == len(before)
+        layer = fs.add_layer_by_scan(walked)
+        assert _names(layer) == want and len(want) > 300
+        assert "/top/mid/.wh.d123" in want and not any(q.startswith("/top/mid/d123/") for q in want)     # one whiteout for the subtree
+        assert [e["relpath"] for e in fs.entries()] == sorted(e["relpath"] for e in after)
         assert fs.add_layer_by_scan(walked) == []
 
 
