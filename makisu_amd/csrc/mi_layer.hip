@@ -316,9 +316,8 @@ void put_str(uint8_t* b, size_t n, const std::string& s) {      // formatter.for
 }
 void put_octal(uint8_t* b, int n, int64_t x) {     // formatter.formatOctal: zero-padded, NUL-terminated
     if (!fits_octal(n, x)) x = 0;                  // the PAX record carries the real value
-    char tmp[32];
-    snprintf(tmp, sizeof tmp, "%0*llo", n - 1, (unsigned long long)x);
-    memcpy(b, tmp, (size_t)n - 1);
+    uint64_t v = (uint64_t)x;                      // (fits: at most n - 1 digits)
+    for (int i = n - 2; i >= 0; --i) { b[i] = (uint8_t)('0' + (v & 7)); v >>= 3; }
     b[n - 1] = 0;
 }
 // splitUSTARPath: name = prefix + "/" + suffix with len(prefix) <= 155, len(suffix) <= 100
