@@ -1133,7 +1133,8 @@ static int memfs_update(mi_memfs* m, const mi_tree_entry* layer, uint64_t n_laye
         fs.maybe_add(fs.root == "/" ? p : fs.root + (p == "/" ? "" : p), p, std::move(n), false);
     };
     std::map<std::string, uint64_t> hardlinks;
-    fs.nodes.reserve(fs.nodes.size() + n_layer);
+    // (with room to spare: the first header a later step adds must not be the one that moves a million nodes)
+    fs.nodes.reserve(fs.nodes.size() + n_layer + n_layer / 4 + 1024);
     fs.layer.reserve(n_layer + n_layer / 8 + 16);                                 // (its entries: the layer's paths and their ancestors)
     for (uint64_t j = 0; j < n_layer && !fs.rc; ++j) {
         const std::string p = path_of(layer[j]);
@@ -1213,6 +1214,7 @@ extern "C" int mi_memfs_add_layer_by_scan(mi_memfs* m, const mi_tree_entry* walk
     fs.scan_mark = mark;
     fs.listed_by_walk = [&](const std::string& q) {
         if (!on_walk_built) {
+            if (memfs_timing()) fprintf(stderr, "mi_memfs scan: the set of the walk's paths is built (asked about %s)\n", q.c_str());
             on_walk.reserve(n * 2);
             for (uint64_t i = 0; i < n; ++i) on_walk.insert(mi_walk::abs_path_of_rel(walked[i].relpath ? walked[i].relpath : ""));
             on_walk_built = true;
