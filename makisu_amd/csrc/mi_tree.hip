@@ -882,7 +882,7 @@ void mi_batch_tree_free(void* tree) { delete (Tree*)tree; }
 // the indices -- maximal non-decreasing runs are found first and merged pairwise.  A walk hands its entries over almost
 // sorted (filepath.Walk order differs from sort.Strings only where a name holds a byte below '/': "a.txt" before "a/x"),
 // so there are few runs and the cost is a few passes instead of log2(n): 100 000 walk-ordered entries 50 -> 11 ms, a
-// million 600 -> 50 ms, ten million 0.56 s (8 cores of this container, measured beside another job); shuffled input
+// million 600 -> 50-130 ms, ten million 0.6-1.4 s (more directories: more runs; 8 cores of this container); shuffled input
 // 110 -> 50 ms per 100 000, 2.7 -> 0.19 s per million.  From 131 072 entries on, blocks of the input are
 // keyed and sorted by up to 16 threads (MI_WALK_THREADS) and merged pairwise (C4 names 10 M entries).
 namespace {
