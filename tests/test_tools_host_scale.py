@@ -1,0 +1,25 @@
+"""tools/host_scale_bench.py (the host rows at C2 / C4 entry counts, profiles/r04_host_scale.txt) keeps running: a small
+count through the same code, every line there, the scan's layers of the sizes the generator implies."""
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_host_scale_bench_runs_and_reports_every_row(engine_lib):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "host_scale_bench.py"), "20000"], capture_output=True, text=True,
+                       timeout=600)
+    assert p.returncode == 0, p.stdout + p.stderr
+    out = p.stdout
+    for row in ("mi_entries_commit_order, walk-ordered input", "mi_entries_commit_order, shuffled input",
+                "mi_memfs_update_from_entries (layer merge)", "mi_memfs_add_layer_by_scan, 0.1 % changed",
+                "mi_memfs_add_layer_by_scan, nothing changed", "mi_snapshot_diff (stateless twin)", "mi_layer_add, header-only members"):
+        assert row in out, out
+    assert "20200 entries (200 directories of 100 files)" in out
+    assert re.search(r"layer merge\)\s+[\d.]+ s\s+[\d.]+ us / entry\s+\(20200 merged\)", out), out
+    # 21 entries changed (every 1000th of 20 200): each with its directory carried along unless it IS a directory
+    m = re.search(r"0\.1 % changed\s+[\d.]+ s\s+[\d.]+ us / entry\s+\(layer of (\d+)\)", out)
+    assert m and 21 <= int(m.group(1)) <= 42, out
+    assert re.search(r"nothing changed\s+[\d.]+ s\s+[\d.]+ us / entry\s+\(layer of 0\)", out), out
