@@ -895,12 +895,10 @@ inline bool key_less(const KeyRef& a, const KeyRef& b) {       // bytewise, like
 // the key of one entry appended to `arena`: AbsPath(dst), a whiteout marker under the path it deletes
 inline void append_key(const char* rp, std::string* arena) {
     rp = rp ? rp : "";
-    const size_t at = arena->size();
     if (strcmp(rp, ".") == 0) rp = "";
     *arena += *rp ? mi_walk::abs_path_of_rel(rp) : mi_walk::abs_path("");
-    const size_t cut = arena->find_last_of('/');               // the key starts with '/': found at or after `at`
-    if (cut != std::string::npos && cut >= at && arena->compare(cut + 1, 4, ".wh.") == 0 && arena->size() - cut - 1 >= 4)
-        arena->erase(cut + 1, 4);
+    const size_t cut = arena->find_last_of('/');               // the key starts with '/': the last one lies in THIS key
+    if (arena->compare(cut + 1, 4, ".wh.") == 0) arena->erase(cut + 1, 4);
 }
 // stable: idx[0, n) by keys; tmp = scratch of n words
 void natural_merge_sort(uint64_t* idx, uint64_t* tmp, size_t n, const KeyRef* keys) {

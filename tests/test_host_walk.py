@@ -258,10 +258,18 @@ def test_commit_order_is_sorted_dst_paths_not_walk_order(tree, engine_lib):
     # equal keys (a whiteout marker and the file it hides) keep input order; empty input is fine
     assert makisu_amd.commit_order(["d/.wh.x", "d/x", "d/.wh.x"]) == [0, 1, 2]
     assert makisu_amd.commit_order([]) == []
+    import ctypes as C
+    out = (C.c_uint64 * 2)()
+    ents = (makisu_amd.TreeEntry * 2)()
+    ents[0].relpath, ents[1].relpath = b"b", b"a"
+    L = makisu_amd.load_library()
+    assert L.mi_entries_commit_order(None, 2, out) == -1 and L.mi_entries_commit_order(ents, 2, None) == -1      # MI_ERR_INVALID
+    assert L.mi_entries_commit_order(None, 0, None) == 0
+    assert L.mi_entries_commit_order(ents, 2, out) == 0 and list(out) == [1, 0]
 
 
 @pytest.mark.parametrize("shape", ["walk", "random", "reversed"])
-@pytest.mark.parametrize("threads", ["1", "3", "5"])
+@pytest.mark.parametrize("threads", ["1", "2", "3", "5"])
 def test_commit_order_at_scale_runs_blocks_and_threads(engine_lib, monkeypatch, shape, threads):
     """300 000 entries (C2 holds 100 000, C4 ten million: SURVEY 8a a7): the order is found by merging the input's
     non-decreasing runs, block-wise on several threads from 131 072 entries on -- the same answer as Python's stable
