@@ -159,14 +159,11 @@ struct Fs {
     struct { bool valid = false; std::string parent; uint64_t gen = 0; } anc_memo;
     uint64_t n_anc_calls = 0, n_anc_memo = 0;                                   // MI_MEMFS_TIMING
     void clear_layer() { layer.clear(); anc_memo.valid = false; }
-    static size_t parent_len(const std::string& dst) {                          // of a clean absolute path; npos = do not memo
+    // where dst splits into parent and name; npos = do not memo.  (dst is AbsPath's result in every caller -- the merge,
+    // the scan, the copy ops: "/", then clean elements; so its parent IS the chain addAncestors walks.)
+    static size_t parent_len(const std::string& dst) {
         const size_t cut = dst.find_last_of('/');
-        if (dst.size() < 2 || dst[0] != '/' || cut == std::string::npos || cut + 1 >= dst.size()) return std::string::npos;
-        for (size_t i = 1; i < dst.size(); ++i)                                   // "//", "/./", "/../": the general way
-            if (dst[i - 1] == '/' && (dst[i] == '/' || (dst[i] == '.' && (i + 1 == dst.size() || dst[i + 1] == '/' ||
-                                                       (dst[i + 1] == '.' && (i + 2 == dst.size() || dst[i + 2] == '/'))))))
-                return std::string::npos;
-        return cut;
+        return (dst.size() < 2 || dst[0] != '/' || cut + 1 >= dst.size()) ? std::string::npos : cut;
     }
     std::string add_ancestors(const std::string& dst, bool inclusive, uint32_t uid, uint32_t gid) {
         const size_t plen = inclusive ? std::string::npos : parent_len(dst);
