@@ -453,7 +453,10 @@ int mi_context_checksum_tree(mi_batch* b, const void* prefix, uint64_t prefix_le
 /* The order MemFS.commitLayer writes entries in (memLayer.rangeFiles, lib/snapshot/
  * mem_layer.go:232-244: sort.Strings over the absolute dst paths; a whiteout marker
  * ".wh.<name>" sorts under the path it deletes, addHeader :190-211) -- not the walk order
- * ("a-b" < "a/x").  order_out[k] = index of the k-th entry to commit.  Host logic.        */
+ * ("a-b" < "a/x").  order_out[k] = index of the k-th entry to commit; equal keys keep their input
+ * order.  The input's sorted runs are merged (a walk's order is nearly this one: 0.13 us per entry);
+ * from 131 072 entries on, blocks are sorted on up to 16 threads of the library's own
+ * (MI_WALK_THREADS) that end with the call.  Host logic.                                    */
 int mi_entries_commit_order(const mi_tree_entry* entries, uint64_t n, uint64_t* order_out);
 
 /* "Did this path change?" -- tario.IsSimilarHeader (lib/tario/compare.go:24-117), the test
