@@ -265,6 +265,23 @@ def test_scan_layer_of_the_handle_equals_the_stateless_diff(tmp_path_factory, pa
         assert fs.add_layer_by_scan(walked) == []
 
 
+def test_paths_longer_than_any_small_buffer(tmp_path):
+    """a path of 3 000 bytes (a layer's map looks keys up through a 512-byte scratch buffer; the tree, the memo and the
+    walk's path buffer have no such limit either): merged, merged again unchanged, changed, scanned, whited out"""
+    D = lambda p: {"relpath": p, "kind": M.KIND_DIR, "mode": 0o40755, "mtime_sec": 100, "size": 0}        # noqa: E731
+    F = lambda p, t=100: {"relpath": p, "kind": M.KIND_FILE, "mode": 0o100644, "mtime_sec": t, "size": 5}   # noqa: E731
+    deep = "/".join(["d" * 250] * 11)                            # 11 levels of 250 bytes
+    chain = ["/".join(deep.split("/")[:k]) for k in range(1, 12)]
+    with M.MemFS(str(tmp_path)) as fs:
+        assert fs.update_from_entries([D(c) for c in chain] + [F(deep + "/a"), F(deep + "/b")]) == 13
+        assert fs.update_from_entries([F(deep + "/a"), F(deep + "/b")]) == 0
+        assert fs.update_from_entries([F(deep + "/a", 200), F(deep + "/b", 200), F(deep + "/c")]) == 11 + 3      # the chain is carried once
+        walked = [D(".")] + [D(c) for c in chain] + [F(deep + "/a", 200), F(deep + "/c")]
+        layer = fs.add_layer_by_scan(walked)
+        assert _names(layer) == ["/" + c for c in chain] + ["/" + deep + "/.wh.b"]
+        assert [e["relpath"] for e in fs.entries()] == chain + [deep + "/a", deep + "/c"]
+
+
 def test_merge_and_scan_of_sixty_thousand_entries_equal_the_stateless_diff(tmp_path):
     """C2's entry count is 100 000, C4's ten million: at that size the handle answers
     directory-by-directory input from what it keeps between two entries -- the parent node of the last lookup, the last
