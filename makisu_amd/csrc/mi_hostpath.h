@@ -8,6 +8,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+
 #include <mutex>
 #include <set>
 #include <string>
@@ -142,6 +144,44 @@ inline std::string rel_to(const std::string& base, const std::string& path) {   
     if (b == "/") return p.substr(1);
     if (has_prefix(p, b + "/")) return p.substr(b.size() + 1);
     return std::string();                                                        // outside: caller errors
+}
+
+// Sorting paths the way Go compares strings (bytewise), for inputs that arrive nearly sorted -- a walk's order, a layer's
+// keys in the order a walk put them in: a STABLE NATURAL MERGE SORT of indices.  Maximal non-decreasing runs are found
+// first and merged pairwise, so the cost is a few passes instead of log2(n) (users: mi_entries_commit_order in
+// mi_tree.hip, the layer's commit order in mi_memfs.hip).
+struct KeyRef { const char* p; uint32_t len; };
+inline bool key_less(const KeyRef& a, const KeyRef& b) {       // bytewise, like Go's string comparison
+    const uint32_t m = a.len < b.len ? a.len : b.len;
+    const int c = m ? memcmp(a.p, b.p, m) : 0;
+    return c < 0 || (c == 0 && a.len < b.len);
+}
+// stable: idx[0, n) by keys; tmp = scratch of n words
+inline void natural_merge_sort(uint64_t* idx, uint64_t* tmp, size_t n, const KeyRef* keys) {
+    if (n < 2) return;
+    auto less = [keys](uint64_t a, uint64_t b) { return key_less(keys[a], keys[b]); };
+    std::vector<size_t> runs, next;                              // run boundaries: k runs = k + 1 entries
+    runs.push_back(0);
+    for (size_t i = 1; i < n; ++i)
+        if (less(idx[i], idx[i - 1])) runs.push_back(i);
+    runs.push_back(n);
+    uint64_t *src = idx, *dst = tmp;
+    while (runs.size() > 2) {
+        next.clear();
+        next.push_back(0);
+        size_t r = 0;
+        for (; r + 2 < runs.size(); r += 2) {
+            std::merge(src + runs[r], src + runs[r + 1], src + runs[r + 1], src + runs[r + 2], dst + runs[r], less);
+            next.push_back(runs[r + 2]);
+        }
+        if (r + 1 < runs.size()) {                               // an odd run at the end travels as it is
+            std::copy(src + runs[r], src + runs[r + 1], dst + runs[r]);
+            next.push_back(runs[r + 1]);
+        }
+        std::swap(src, dst);
+        runs.swap(next);
+    }
+    if (src != idx) std::copy(src, src + n, idx);
 }
 
 // mountutils' table (lib/mountutils/mountutils.go:54-93): targets of /proc/mounts except "/";

@@ -74,9 +74,11 @@ struct LayerMap {
         touched = true;
         auto it = m->find(std::pmr::string(key.data(), key.size(), &scratch));
         scratch.release();
-        if (it != m->end()) it->second = ref;
-        else m->emplace(std::piecewise_construct, std::forward_as_tuple(key.data(), key.size()), std::forward_as_tuple(ref));
+        if (it != m->end()) { it->second = ref; return; }
+        auto at = m->emplace(std::piecewise_construct, std::forward_as_tuple(key.data(), key.size()), std::forward_as_tuple(ref)).first;
+        seq.push_back(&*at);                                                       // (a table's elements do not move)
     }
+    std::vector<const Map::value_type*> seq;                                       // the keys in the order they came
     size_t size() const { return m->size(); }
     void reserve(size_t n) { touched = true; m->reserve(n); }
     void clear() {
@@ -84,6 +86,7 @@ struct LayerMap {
         m->~Map();
         pool.release();
         m = new (store) Map(&pool);
+        seq.clear();
         touched = false;
     }
 private:
@@ -96,14 +99,19 @@ struct Fs {
     std::vector<Node> nodes;
     LayerMap layer;                          // memLayer.files: keyed by dst -- by the DELETED path for a ".wh." name;
                                              // sorted when the layer is taken (rangeFiles, mem_layer.go:232-244)
-    std::vector<Node> sorted_layer() const {
-        std::vector<std::pair<std::string, int64_t>> keys;
-        keys.reserve(layer.m->size());
-        for (const auto& kv : *layer.m) keys.emplace_back(std::string(kv.first.data(), kv.first.size()), kv.second);
-        std::sort(keys.begin(), keys.end());                                        // sort.Strings on the keys
+    std::vector<Node> sorted_layer() const {                                        // sort.Strings on the keys: they came in
+        const size_t n = layer.seq.size();                                          // walk order, which is nearly sorted
+        std::vector<mi_walk::KeyRef> keys(n);
+        std::vector<uint64_t> idx(n), tmp(n);
+        for (size_t i = 0; i < n; ++i) {
+            keys[i].p = layer.seq[i]->first.data();
+            keys[i].len = (uint32_t)layer.seq[i]->first.size();
+            idx[i] = i;
+        }
+        mi_walk::natural_merge_sort(idx.data(), tmp.data(), n, keys.data());
         std::vector<Node> out;
-        out.reserve(keys.size());
-        for (auto& kv : keys) out.push_back(nodes[kv.second]);
+        out.reserve(n);
+        for (size_t i = 0; i < n; ++i) out.push_back(nodes[layer.seq[idx[i]]->second]);
         return out;
     }
     std::string root;                      // fs.tree.src
@@ -1059,9 +1067,13 @@ struct MemfsTimer {
     }
 };
 static mi_copy_layer* memfs_take_layer(mi_memfs* m) {
+    const auto t0 = std::chrono::steady_clock::now();
     mi_copy_layer* l = new mi_copy_layer();
     l->nodes = m->fs.sorted_layer();
     m->fs.clear_layer();
+    if (memfs_timing())
+        fprintf(stderr, "mi_memfs: a layer of %zu entries put in commit order and handed over in %.3f s\n", l->nodes.size(),
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     return l;
 }
 static int memfs_fail(mi_memfs* m) {

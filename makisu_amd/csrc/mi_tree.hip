@@ -886,12 +886,9 @@ void mi_batch_tree_free(void* tree) { delete (Tree*)tree; }
 // 110 -> 50 ms per 100 000, 2.7 -> 0.19 s per million.  From 131 072 entries on, blocks of the input are
 // keyed and sorted by up to 16 threads (MI_WALK_THREADS) and merged pairwise (C4 names 10 M entries).
 namespace {
-struct KeyRef { const char* p; uint32_t len; };
-inline bool key_less(const KeyRef& a, const KeyRef& b) {       // bytewise, like Go's string comparison
-    const uint32_t m = a.len < b.len ? a.len : b.len;
-    const int c = m ? memcmp(a.p, b.p, m) : 0;
-    return c < 0 || (c == 0 && a.len < b.len);
-}
+using mi_walk::KeyRef;
+using mi_walk::key_less;
+using mi_walk::natural_merge_sort;
 // the key of one entry appended to `arena`: AbsPath(dst), a whiteout marker under the path it deletes
 inline void append_key(const char* rp, std::string* arena) {
     rp = rp ? rp : "";
@@ -899,33 +896,6 @@ inline void append_key(const char* rp, std::string* arena) {
     *arena += *rp ? mi_walk::abs_path_of_rel(rp) : mi_walk::abs_path("");
     const size_t cut = arena->find_last_of('/');               // the key starts with '/': the last one lies in THIS key
     if (arena->compare(cut + 1, 4, ".wh.") == 0) arena->erase(cut + 1, 4);
-}
-// stable: idx[0, n) by keys; tmp = scratch of n words
-void natural_merge_sort(uint64_t* idx, uint64_t* tmp, size_t n, const KeyRef* keys) {
-    if (n < 2) return;
-    auto less = [keys](uint64_t a, uint64_t b) { return key_less(keys[a], keys[b]); };
-    std::vector<size_t> runs, next;                              // run boundaries: k runs = k + 1 entries
-    runs.push_back(0);
-    for (size_t i = 1; i < n; ++i)
-        if (less(idx[i], idx[i - 1])) runs.push_back(i);
-    runs.push_back(n);
-    uint64_t *src = idx, *dst = tmp;
-    while (runs.size() > 2) {
-        next.clear();
-        next.push_back(0);
-        size_t r = 0;
-        for (; r + 2 < runs.size(); r += 2) {
-            std::merge(src + runs[r], src + runs[r + 1], src + runs[r + 1], src + runs[r + 2], dst + runs[r], less);
-            next.push_back(runs[r + 2]);
-        }
-        if (r + 1 < runs.size()) {                               // an odd run at the end travels as it is
-            std::copy(src + runs[r], src + runs[r + 1], dst + runs[r]);
-            next.push_back(runs[r + 1]);
-        }
-        std::swap(src, dst);
-        runs.swap(next);
-    }
-    if (src != idx) std::copy(src, src + n, idx);
 }
 }  // namespace
 
