@@ -1132,10 +1132,6 @@ static int memfs_update(mi_memfs* m, const mi_tree_entry* layer, uint64_t n_laye
     if (!mt.error.empty()) { m->err = "check if mounted: " + mt.error; return MI_ERR_IO; }
     std::vector<std::string> bl;
     for (const std::string& b : m->blacklist) bl.push_back(mi_walk::abs_path(b));
-    auto path_of = [](const mi_tree_entry& e) {
-        const char* rp = e.relpath ? e.relpath : "";
-        return *rp ? mi_walk::abs_path_of_rel(rp) : mi_walk::abs_path("");
-    };
     std::vector<std::string> below_mount;                                         // "<target>/": isMounted's prefixes
     for (const std::string& t : mt.targets) below_mount.push_back(t.back() == '/' ? t : t + "/");
     // "is this directory at or below a mountpoint" is asked once per directory, not per entry (entries come
@@ -1164,6 +1160,7 @@ static int memfs_update(mi_memfs* m, const mi_tree_entry* layer, uint64_t n_laye
         return mdir_below;
     };
     auto disk_path = [&](const std::string& p) { return fs.root == "/" ? p : fs.root + (p == "/" ? "" : p); };
+    std::string src_buf;
     auto one = [&](const mi_tree_entry& e, const std::string& p, uint64_t j) {
         if (untar && !mi_untar::one_item(fs.root, disk_path(p), e, tar_fd, data_offsets ? data_offsets[j] : 0, &uerr)) {
             fs.fail(MI_ERR_IO, "untar one item " + disk_path(p) + ": " + uerr);
@@ -1178,14 +1175,16 @@ static int memfs_update(mi_memfs* m, const mi_tree_entry* layer, uint64_t n_laye
         }
         // src: the reference passes AbsPath(hdr.Name) (:225) -- the path the entry is untarred to when the root is "/",
         // as in every real build; under another root that is filepath.Join(root, name), and isOnDisk must look THERE
-        fs.maybe_add(fs.root == "/" ? p : fs.root + (p == "/" ? "" : p), p, std::move(n), false);
+        if (fs.root == "/") src_buf = p; else { src_buf = fs.root; if (p != "/") src_buf += p; }
+        fs.maybe_add(src_buf, p, std::move(n), false);
     };
     std::map<std::string, uint64_t> hardlinks;
     // (with room to spare: the first header a later step adds must not be the one that moves a million nodes)
     fs.nodes.reserve(fs.nodes.size() + n_layer + n_layer / 4 + 1024);
     fs.layer.reserve(n_layer + n_layer / 8 + 16);                                 // (its entries: the layer's paths and their ancestors)
+    std::string p;                                                                // one buffer for every header's path
     for (uint64_t j = 0; j < n_layer && !fs.rc; ++j) {
-        const std::string p = path_of(layer[j]);
+        mi_walk::abs_path_of_rel_into(layer[j].relpath ? layer[j].relpath : "", &p);
         if (skipped(layer[j], p)) continue;
         if (untar) {                                                              // "Record the modtime of the parent directory to
             const std::string parent = mi_walk::dir_of(disk_path(p));             //  reset it after we deal with all of the other files"
