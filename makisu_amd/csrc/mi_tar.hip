@@ -439,7 +439,7 @@ static int parse(Source& src, Tar* t) {
             t->error = "entry " + it.name + " runs past the end of the archive";
             return MI_ERR_INVALID;
         }
-        t->items.push_back(it);
+        t->items.push_back(std::move(it));
         off = data + skip;
     }
     return MI_OK;
@@ -448,6 +448,20 @@ static int parse(Source& src, Tar* t) {
 // header name -> the relpath form the walks use: no leading "/" or "./", no trailing "/", "." for
 // the root (pathutils.RelPath + AbsPath semantics of untarOneItem's filepath.Join(root, hdr.Name))
 static std::string rel_name(const std::string& n) {
+    {   // what archives hold almost always: clean elements, at most slashes at the ends -- no element list for those
+        size_t a = 0, b = n.size();
+        while (a < b && n[a] == '/') ++a;
+        while (b > a && n[b - 1] == '/') --b;
+        bool clean = b > a;
+        for (size_t i = a; clean && i < b; ++i) {
+            if (n[i] == '/' && n[i + 1] == '/') clean = false;                   // (i + 1 < b: b - 1 is not a slash)
+            if (n[i] == '.' && (i == a || n[i - 1] == '/')) {
+                const size_t k = (i + 1 < b && n[i + 1] == '.') ? i + 2 : i + 1;
+                if (k >= b || n[k] == '/') clean = false;                        // a "." or ".." element
+            }
+        }
+        if (clean) return n.substr(a, b - a);
+    }
     std::vector<std::string> parts;
     size_t i = 0;
     while (i < n.size()) {
