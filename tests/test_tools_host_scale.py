@@ -23,3 +23,14 @@ def test_host_scale_bench_runs_and_reports_every_row(engine_lib):
     m = re.search(r"0\.1 % changed\s+[\d.]+ s\s+[\d.]+ us / entry\s+\(layer of (\d+)\)", out)
     assert m and 21 <= int(m.group(1)) <= 42, out
     assert re.search(r"nothing changed\s+[\d.]+ s\s+[\d.]+ us / entry\s+\(layer of 0\)", out), out
+
+
+def test_the_gpu_side_shell_tools_parse():
+    """tools/*.sh run on the GPU box where a syntax error costs a call: `bash -n` each of them here"""
+    import glob
+    scripts = sorted(glob.glob(os.path.join(ROOT, "tools", "*.sh")))
+    assert len(scripts) >= 10
+    for s in scripts:
+        p = subprocess.run(["bash", "-n", s], capture_output=True, text=True)
+        assert p.returncode == 0, (s, p.stderr)
+        assert os.access(s, os.X_OK), s + " is not executable"
