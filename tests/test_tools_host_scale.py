@@ -34,3 +34,13 @@ def test_the_gpu_side_shell_tools_parse():
         p = subprocess.run(["bash", "-n", s], capture_output=True, text=True)
         assert p.returncode == 0, (s, p.stderr)
         assert os.access(s, os.X_OK), s + " is not executable"
+
+
+def test_the_python_tools_compile():
+    """... and the python ones (probes that drive the binding on the GPU box): a syntax error is found here"""
+    import ast
+    import glob
+    tools = sorted(glob.glob(os.path.join(ROOT, "tools", "*.py"))) + [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")]
+    assert len(tools) >= 20
+    for t in tools:
+        ast.parse(open(t).read(), t)
