@@ -44,3 +44,22 @@ def test_the_python_tools_compile():
     assert len(tools) >= 20
     for t in tools:
         ast.parse(open(t).read(), t)
+
+
+def test_the_python_tools_name_things_the_binding_has(engine_lib):
+    """a probe that calls `makisu_amd.<something>` that does not exist is 45 s of GPU time for a python exception
+    (tools/experiments/README.md, round 4): every attribute the tools take from the binding's module exists"""
+    import glob
+    import importlib.util
+    import makisu_amd
+    missing = []
+    for t in sorted(glob.glob(os.path.join(ROOT, "tools", "*.py"))) + [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")]:
+        src = open(t).read()
+        if "makisu_amd" not in src:
+            continue
+        for alias in set(re.findall(r"import makisu_amd as (\w+)", src)) | {"makisu_amd"}:
+            for m in re.finditer(r"(?<![\w.])%s\.([A-Za-z_]\w*)" % re.escape(alias), src):
+                name = m.group(1)
+                if not hasattr(makisu_amd, name) and importlib.util.find_spec("makisu_amd." + name) is None:
+                    missing.append((os.path.basename(t), name))
+    assert not missing, sorted(set(missing))
