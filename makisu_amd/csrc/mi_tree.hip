@@ -970,37 +970,50 @@ extern "C" int mi_snapshot_diff(const mi_snapshot_side* before, const mi_snapsho
     if (!before || !after || (before->n && !before->entries) || (after->n && !after->entries) ||
         (after->n && !after_flags) || (before->n && !before_whiteout))
         return MI_ERR_INVALID;
-    auto path_of = [](const mi_tree_entry& e) {
-        const char* rp = e.relpath ? e.relpath : "";
-        return *rp ? mi_walk::abs_path_of_rel(rp) : mi_walk::abs_path("");
-    };
     auto root_of = [](const mi_snapshot_side* s, const mi_tree_entry& e) -> const uint8_t* {
         if (!s->roots || e.kind != 1 || e.file_index < 0) return nullptr;
         return (const uint8_t*)s->roots + (uint64_t)e.file_index * s->root_stride;
     };
     // path -> index, the LAST entry of a path winning (hashed: the order the paths are visited in decides nothing --
-    // flags are only raised, SAME -> ANCESTOR -> CHANGED)
-    std::unordered_map<std::string, uint64_t> old_at, new_at;
-    old_at.reserve(before->n * 2);
-    new_at.reserve(after->n * 2);
-    for (uint64_t i = 0; i < before->n; ++i) old_at[path_of(before->entries[i])] = i;
-    for (uint64_t i = 0; i < after->n; ++i) new_at[path_of(after->entries[i])] = i;
+    // flags are only raised, SAME -> ANCESTOR -> CHANGED).  The paths of a side lie in one arena; the tables key views of it.
+    using PathTable = std::unordered_map<std::string_view, uint64_t>;
+    auto index_side = [](const mi_snapshot_side* side, std::string* arena, PathTable* at) {
+        std::vector<uint64_t> off((size_t)side->n + 1);
+        std::string p;
+        for (uint64_t i = 0; i < side->n; ++i) {
+            mi_walk::abs_path_of_rel_into(side->entries[i].relpath ? side->entries[i].relpath : "", &p);
+            off[(size_t)i] = arena->size();
+            arena->append(p);
+        }
+        off[(size_t)side->n] = arena->size();
+        at->reserve((size_t)side->n * 2);                        // (the arena is complete: its views stay where they are)
+        for (uint64_t i = 0; i < side->n; ++i)
+            (*at)[std::string_view(arena->data() + off[(size_t)i], (size_t)(off[(size_t)i + 1] - off[(size_t)i]))] = i;
+    };
+    std::string old_paths, new_paths;
+    PathTable old_at, new_at;
+    index_side(before, &old_paths, &old_at);
+    index_side(after, &new_paths, &new_at);
     for (uint64_t i = 0; i < after->n; ++i) after_flags[i] = MI_DIFF_SAME;
     for (uint64_t i = 0; i < before->n; ++i) before_whiteout[i] = 0;
-    auto carry_ancestors = [&](const std::string& p) {
-        std::string d = mi_walk::dir_of(p);
-        while (d != "/" && d != ".") {
+    static const std::string_view kRoot("/");
+    auto parent_of = [](std::string_view p) -> std::string_view {          // path.Dir of a clean absolute path; "" = none
+        const size_t cut = p.rfind('/');
+        if (cut == std::string_view::npos) return std::string_view();
+        return cut == 0 ? kRoot : p.substr(0, cut);
+    };
+    auto carry_ancestors = [&](std::string_view p) {
+        for (std::string_view d = parent_of(p); !d.empty() && d != kRoot; d = parent_of(d)) {
             auto it = new_at.find(d);
             if (it != new_at.end()) {
                 // an ancestor that is already carried (or changed) has had ITS ancestors carried then: the chain is done
                 if (after_flags[it->second] != MI_DIFF_SAME) return;
                 after_flags[it->second] = MI_DIFF_ANCESTOR;
             }
-            d = mi_walk::dir_of(d);
         }
     };
     for (auto& kv : new_at) {
-        if (kv.first == "/") continue;                       // "Root itself is not added to layers"
+        if (kv.first == kRoot) continue;                     // "Root itself is not added to layers"
         const mi_tree_entry& e = after->entries[kv.second];
         bool updated = true;
         auto it = old_at.find(kv.first);
@@ -1017,15 +1030,14 @@ extern "C" int mi_snapshot_diff(const mi_snapshot_side* before, const mi_snapsho
         }
     }
     for (auto& kv : old_at) {
-        if (kv.first == "/" || new_at.count(kv.first)) continue;
-        const std::string parent = mi_walk::dir_of(kv.first);
-        auto pit = new_at.find(parent);
+        if (kv.first == kRoot || new_at.count(kv.first)) continue;
+        auto pit = new_at.find(parent_of(kv.first));
         if (pit == new_at.end() || after->entries[pit->second].kind != 0) continue;   // deeper in a deleted subtree,
                                                                                        // or its parent became a file
         if (after->disk_root) {
             // child.isOnDisk() (mem_fs.go:49-57, 466): a path the walk no longer lists because it is now
             // skipped (a new mountpoint, a blacklisted dir) is still on disk and gets NO whiteout
-            const std::string on_disk = std::string(after->disk_root) + (kv.first == "/" ? "" : kv.first);
+            const std::string on_disk = std::string(after->disk_root) + std::string(kv.first);
             struct stat st;
             if (lstat(on_disk.c_str(), &st) == 0) continue;
             if (errno != ENOENT && errno != ENOTDIR) return MI_ERR_IO;           // "check on disk"
