@@ -15,4 +15,4 @@ echo "== 1. round check"; timeout 420 tools/gpu_round_check.sh 2>&1 | tee $out/r
 echo "== 2. core profiles"; PARTS=core timeout 240 tools/round_profiles.sh r05 2>&1 | tee $out/round_profiles.txt | tail -15
 echo "== 3. partition probe"; timeout 330 tools/cu_partition_probe.sh 2>&1 | tee $out/cu_partition_probe.txt
 echo "== 4. host rows"
-{ MI_WALK_TIMING=1 MI_MEMFS_TIMING=1 timeout 170 python tools/many_small_files.py 200 500 4; timeout 170 python tools/host_scale_bench.py 1000000; } 2>&1 | tee $out/host_rows.txt | tail -30
+{ MI_WALK_TIMING=1 timeout 170 python tools/many_small_files.py 200 500 4; timeout 170 python tools/commit_layer_bench.py 100000 4096; timeout 170 python tools/host_scale_bench.py 1000000; } 2>&1 | tee $out/host_rows.txt | tail -30
