@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MI_ABI_VERSION 4
+#define MI_ABI_VERSION 5
 
 enum {
     MI_OK = 0,
@@ -251,6 +251,15 @@ int mi_batch_chunks(mi_batch* b, mi_chunk_result* out, uint64_t cap);
  * buffer (packed on the device, one device-to-host copy), valid until the batch is submitted
  * again, marked globally, reset or freed.  What a cgo shim reads through unsafe.Slice.          */
 int mi_batch_chunks_view(mi_batch* b, const mi_chunk_result** rows, uint64_t* n_chunks);
+/* The per-file chunk roots alone, 32 bytes per file in add order (cap = rows `out` has room for): what a content-aware
+ * MemFS.isUpdated compares (lib/snapshot/mem_fs.go:487-503) -- one copy of n_files x 32 bytes, none of the chunk rows.   */
+int mi_batch_roots(mi_batch* b, uint8_t* out, uint64_t cap);
+/* Bytes [offset, offset + len) of file `file_index` as they lie in HBM -- the bytes the scan saw -- through a pinned
+ * window of the batch (a fetch brings neighbours along: files staged together are asked for together).  From the moment
+ * the batch is staged (mi_batch_run / _submit + _wait / _scan_cuts returned) until it is reset or freed; not while in
+ * flight; not for parts.  What the layer writer reads when a commit takes its files from the batch
+ * (mi_layer_add_batch_file) instead of reading them from disk a second time (lib/tario/write.go:43-45 reads once).     */
+int mi_batch_read_file(mi_batch* b, uint64_t file_index, uint64_t offset, void* dst, uint64_t len);
 /* Device pointer to the batch's n_chunks x 32-byte digest array (valid until
  * mi_batch_free); what a rank contributes to the all-gather.        */
 int mi_batch_device_digests(mi_batch* b, const void** d_digests, uint64_t* n_chunks);
@@ -595,8 +604,10 @@ void mi_copy_layer_free(mi_copy_layer* layer);
  *                             MI_TREE_SCAN, rel_base = root, the same blacklist): every walked path through
  *                             maybeAddToLayer with createWhiteout -- changed paths with their ancestors, one whiteout
  *                             per deleted subtree (if the child's src is really gone).  roots / root_stride: chunk roots
- *                             by file_index, kept in the tree, so that the NEXT scan's isUpdated is content-aware
- *                             (NULL = the reference's metadata-only rule).
+ *                             by file_index, kept in the tree -- for changed paths with their new node, for unchanged
+ *                             files that had none as the root they have now -- so that the NEXT scan's isUpdated is
+ *                             content-aware (NULL = the reference's metadata-only rule).  mi_memfs_commit_layer with
+ *                             a ctx does walk, GPU scan, this call and the layer tar in one.
  *   mi_memfs_add_layer_by_copy_ops   AddLayerByCopyOps (mem_fs.go:276-289): addToLayer per mi_copy_op against this tree.
  * Both return the layer in commit order as an mi_copy_layer (mi_copy_layer_entries: headers + the path each entry's
  * bytes are read from; a whiteout is an entry named ".wh.<x>" without content) and fold it into the tree.  A failing
@@ -605,6 +616,7 @@ void mi_copy_layer_free(mi_copy_layer* layer);
  *   mi_memfs_reset            MemFS.Reset: the tree is emptied, the root stays.
  * A handle is not re-entrant (the reference serialises MemFS with one mutex); handles are independent.  Host logic. */
 typedef struct mi_memfs mi_memfs;
+typedef struct mi_index mi_index;         /* the chunk index, below */
 int  mi_memfs_create(const char* root, const char* const* blacklist, uint64_t n_blacklist, int64_t now_sec,
                      mi_memfs** out);
 void mi_memfs_free(mi_memfs* fs);
@@ -667,6 +679,14 @@ int  mi_layer_begin(const mi_layer_config* cfg, mi_layer** out);
  * base name carries the whiteout prefix ".wh." is written as a whiteout -- a zero header with only that name,
  * no content -- whatever the entry is (memLayer.addHeader, lib/snapshot/mem_layer.go:197-212).                */
 int  mi_layer_add(mi_layer* layer, const mi_tree_entry* e, const char* src_path);
+/* The same entry with its content taken from a staged batch: the header as mi_layer_add writes it, then file
+ * `file_index` of `batch` -- the bytes the GPU scanned, read back from HBM (mi_batch_read_file) -- instead of a second
+ * read of the path.  The tar then holds exactly the bytes the file's chunk root describes, whatever has happened to the
+ * file since it was staged; e->size must be the staged size (MI_ERR_INVALID otherwise).  Entries without content
+ * (directories, links, whiteouts by name) are written as by mi_layer_add.                                              */
+int  mi_layer_add_batch_file(mi_layer* layer, const mi_tree_entry* e, mi_batch* batch, uint64_t file_index);
+/* What this writer read from disk itself so far: files it opened, bytes it read (mi_layer_add with a src_path).        */
+int  mi_layer_io_counts(mi_layer* layer, uint64_t* files_opened, uint64_t* file_bytes_read);
 /* whiteoutMemFile.commit (mem_layer.go:101-132): a zero header named <dir>/.wh.<base>.          */
 int  mi_layer_add_whiteout(mi_layer* layer, const char* deleted_path);
 int  mi_layer_finish(mi_layer* layer, mi_layer_result* out);
@@ -676,11 +696,62 @@ void mi_layer_free(mi_layer* layer);
  * (must_scan: the root is walked here, with the handle's blacklist) or by its copy operations, written through the layer
  * writer configured by cfg (tarAndGzipDiffs: tar framing, TarDigest, the gzip leg with its digest and size), folded into
  * the tree.  Neither a scan nor ops: "Nothing to do" -- *committed = 0, res untouched.  layer_out (may be NULL): the
- * layer's entries and source paths, e.g. to feed the same files to a GPU batch; free with mi_copy_layer_free.  Errors
- * carry the reference's chain in mi_memfs_error ("failed to generate diff layer: write diffs: ...").  MemFS.sync's
- * one-second wait stays with the caller.  Host logic.                                                             */
-int  mi_memfs_commit_layer(mi_memfs* fs, int must_scan, const mi_copy_op* ops, uint64_t n_ops, const mi_layer_config* cfg,
-                           mi_layer_result* res, mi_copy_layer** layer_out, int* committed);
+ * layer's entries and source paths (mi_copy_layer_entries) and chunk roots (mi_copy_layer_roots); free with
+ * mi_copy_layer_free.  Errors carry the reference's chain in mi_memfs_error ("failed to generate diff layer: write
+ * diffs: ...").  MemFS.sync's one-second wait stays with the caller.
+ *
+ * ctx == NULL: the reference's commit, byte for byte -- tario.IsSimilarHeader decides what changed
+ * (lib/tario/compare.go:24-120), the writer reads the changed files from disk (lib/tario/write.go:28-52).  Host logic.
+ *
+ * ctx != NULL: the CONTENT-AWARE commit -- the seam this library exists for (lib/snapshot/mem_fs.go:315-341,440-503 +
+ * lib/builder/step/common.go:67-111 as one flow):
+ *   1. the root (must_scan) or the ops' sources are walked and every regular file listed is staged into one batch of
+ *      `ctx` while the walk goes on: each file is opened once and read once;
+ *   2. the GPU cuts and hashes them (Gear CDC, SHA-256 per chunk, one chunk root per file);
+ *   3. createLayerByScan / addToLayer run with the roots: a path is in the layer if its header changed (the reference's
+ *      rule) OR its content did -- a same-size edit within the same second, invisible to the reference, is caught.  A
+ *      file the tree holds without a root (merged from a base layer, committed with ctx == NULL) and whose header is
+ *      unchanged takes the root it has now; from the next commit on its content is watched;
+ *   4. the layer writer frames the tar; file content comes from HBM (mi_layer_add_batch_file): the tar holds the bytes
+ *      the stored root describes, even if the file was written to after it was staged;
+ *   5. with an index set (mi_memfs_set_index) the batch's chunk digests are added to it (mi_index_add_batch).
+ * The handle keeps the batch (device memory sized by the largest commit so far) for its next commit; it belongs to
+ * `ctx`: free the handle, or call mi_memfs_release_device, before mi_ctx_destroy.  A tree larger than the device's free
+ * memory fails with MI_ERR_NOMEM and leaves the tree as it was.  mi_memfs_commit_stats: what the last commit did.     */
+typedef struct {
+    uint64_t n_walked;           /* paths the walk(s) listed                                                    */
+    uint64_t n_scanned_files;    /* regular files staged and scanned on the GPU (0 with ctx == NULL)            */
+    uint64_t scanned_bytes;
+    uint64_t n_chunks;
+    uint64_t n_layer_entries;    /* headers in the layer                                                        */
+    uint64_t n_layer_files;      /* ... of them regular files with content                                      */
+    uint64_t layer_file_bytes;
+    uint64_t n_content_changed;  /* files IsSimilarHeader calls similar whose chunk roots differ: in the layer  */
+    uint64_t n_roots_learned;    /* unchanged files that had no root in the tree and have one now               */
+    uint64_t n_index_new, n_index_known;   /* mi_index_add_batch's counts (index set)                           */
+    uint64_t files_opened;       /* file descriptors whose content was read, by every thread of the library ... */
+    uint64_t file_bytes_read;    /* ... and the bytes read from them, during this commit (process-wide counters:
+                                    a commit running beside another one counts both)                            */
+    double   s_walk_stage;       /* walk (+ staging, which goes on behind it)                                   */
+    double   s_scan;             /* end of staging + the GPU passes + the roots' way back                       */
+    double   s_diff;             /* createLayerByScan / addToLayer + commit order                               */
+    double   s_write;            /* tar framing, digests, gzip leg                                              */
+    double   s_total;
+} mi_commit_stats;
+int  mi_memfs_commit_layer(mi_memfs* fs, mi_ctx* ctx, int must_scan, const mi_copy_op* ops, uint64_t n_ops,
+                           const mi_layer_config* cfg, mi_layer_result* res, mi_copy_layer** layer_out, int* committed);
+int  mi_memfs_commit_stats(const mi_memfs* fs, mi_commit_stats* out);
+/* From now on every content-aware commit of this handle adds its batch to `index` (NULL: stop).  The index must belong
+ * to the ctx the commits run on and outlive them; the handle does not own it.                                          */
+int  mi_memfs_set_index(mi_memfs* fs, mi_index* index);
+/* Gives back the batch a content-aware commit left with the handle (its arena holds the scanned tree's bytes).          */
+int  mi_memfs_release_device(mi_memfs* fs);
+/* The chunk root the tree holds for `path` ("/"-rooted, relative to the handle's root): *has_root = 0 when the path was
+ * never scanned; MI_ERR_INVALID when the tree does not hold the path.                                                  */
+int  mi_memfs_root_of(const mi_memfs* fs, const char* path, uint8_t* root_out, int* has_root);
+/* The chunk roots of a layer's entries, in mi_copy_layer_entries' order: roots = n x 32 bytes, has_root = n flags
+ * (regular files of a content-aware commit carry one; everything else zeros).                                          */
+int  mi_copy_layer_roots(const mi_copy_layer* layer, uint8_t* roots, uint8_t* has_root, uint64_t cap);
 /* The header block(s) mi_layer_add would write for `e` (512 bytes, or 1536+ with a PAX record) in
  * a layer begun with `layer_flags` (MI_LAYER_*).                                                 */
 int  mi_layer_header_bytes(const mi_tree_entry* e, uint32_t layer_flags, uint8_t* out, uint64_t cap, uint64_t* n);
@@ -722,7 +793,6 @@ int mi_sha256_many(mi_ctx* ctx, const void* data, const uint64_t* offsets,
  * 0 - dup_of already says so), then the new digests are added.  known may be NULL.
  * mi_index_export / mi_index_import move the set as a flat blob of 32-byte digests
  * (order unspecified) so the shim can keep it behind keyvalue.Store.Put/Get.      */
-typedef struct mi_index mi_index;
 int  mi_index_create(mi_ctx* ctx, uint64_t capacity_hint, mi_index** out);
 void mi_index_free(mi_index* index);
 int  mi_index_count(mi_index* index, uint64_t* n_digests);

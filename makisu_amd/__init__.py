@@ -110,6 +110,16 @@ class LayerResult(C.Structure):
 GZIP_OFF, GZIP_DEFAULT = -2, -1
 
 
+class CommitStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("n_walked", "n_scanned_files", "scanned_bytes", "n_chunks", "n_layer_entries",
+                                          "n_layer_files", "layer_file_bytes", "n_content_changed", "n_roots_learned",
+                                          "n_index_new", "n_index_known", "files_opened", "file_bytes_read")] + \
+               [(n, C.c_double) for n in ("s_walk_stage", "s_scan", "s_diff", "s_write", "s_total")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
 class PartState(C.Structure):
     """mi_part_state: one part of a split file (include/makisu_mi.h "parts")."""
     _fields_ = [("file_index", C.c_uint64), ("file_size", C.c_uint64), ("begin", C.c_uint64),
@@ -251,8 +261,17 @@ def load_library(rebuild=False):
         "mi_memfs_add_layer_by_copy_ops": ([vp, C.POINTER(CopyOp), u64, C.POINTER(vp), u64p], C.c_int),
         "mi_memfs_entries": ([vp, C.POINTER(TreeEntry), C.POINTER(C.c_char_p), u64, u64p], C.c_int),
         "mi_memfs_checkpoint": ([vp, C.c_char_p, C.POINTER(C.c_char_p), u64], C.c_int),
-        "mi_memfs_commit_layer": ([vp, C.c_int, C.POINTER(CopyOp), u64, C.POINTER(LayerConfig), C.POINTER(LayerResult),
+        "mi_memfs_commit_layer": ([vp, vp, C.c_int, C.POINTER(CopyOp), u64, C.POINTER(LayerConfig), C.POINTER(LayerResult),
                                    C.POINTER(vp), C.POINTER(C.c_int)], C.c_int),
+        "mi_memfs_commit_stats": ([vp, C.POINTER(CommitStats)], C.c_int),
+        "mi_memfs_set_index": ([vp, vp], C.c_int),
+        "mi_memfs_release_device": ([vp], C.c_int),
+        "mi_memfs_root_of": ([vp, C.c_char_p, vp, C.POINTER(C.c_int)], C.c_int),
+        "mi_copy_layer_roots": ([vp, vp, vp, u64], C.c_int),
+        "mi_batch_roots": ([vp, vp, u64], C.c_int),
+        "mi_batch_read_file": ([vp, u64, u64, vp, u64], C.c_int),
+        "mi_layer_add_batch_file": ([vp, C.POINTER(TreeEntry), vp, u64], C.c_int),
+        "mi_layer_io_counts": ([vp, u64p, u64p], C.c_int),
         "mi_copy_op_execute": ([C.POINTER(CopyOp), C.c_uint32, C.POINTER(C.c_char_p), u64, C.c_char_p, u64], C.c_int),
         "mi_copy_layer_entries": ([vp, C.POINTER(TreeEntry), C.POINTER(C.c_char_p), u64], C.c_int),
         "mi_copy_layer_free": ([vp], None),
@@ -535,17 +554,25 @@ def _copy_op_array(ops, keep):
 
 
 def _take_copy_layer(L, h, n):
-    """mi_copy_layer -> list of entry dicts (commit order) with an extra "src" key; frees the handle."""
+    """mi_copy_layer -> list of entry dicts (commit order) with an extra "src" key and, for regular files of a
+    content-aware commit, "root" (32 bytes); frees the handle."""
     try:
         out = (TreeEntry * max(n, 1))()
         srcp = (C.c_char_p * max(n, 1))()
         rc = L.mi_copy_layer_entries(h, out, srcp, n)
         if rc:
             raise MiError(rc, "mi_copy_layer_entries")
+        roots = np.zeros((max(n, 1), 32), dtype=np.uint8)
+        has = np.zeros(max(n, 1), dtype=np.uint8)
+        rc = L.mi_copy_layer_roots(h, roots.ctypes.data, has.ctypes.data, n)
+        if rc:
+            raise MiError(rc, "mi_copy_layer_roots")
         res = []
         for i in range(n):
             d = _entry_dict(out[i])
             d["src"] = os.fsdecode(srcp[i]) if srcp[i] is not None else ""
+            if has[i]:
+                d["root"] = roots[i].tobytes()
             res.append(d)
         return res
     finally:
@@ -656,22 +683,47 @@ class MemFS:
                     "mi_memfs_add_layer_by_copy_ops")
         return _take_copy_layer(self._lib, h, n.value)
 
-    def commit_layer(self, must_scan=False, ops=(), out_fd=-1, gzip_level=GZIP_DEFAULT):
-        """step.commitLayer: the layer by scan or by copy ops, written through the layer writer.  Returns None when there
-        is nothing to do, else dict(tar_digest, gzip_digest, tar_bytes, gzip_bytes, n_entries, layer=[entries])."""
+    def commit_layer(self, must_scan=False, ops=(), out_fd=-1, gzip_level=GZIP_DEFAULT, engine=None, mode_with_type=False):
+        """step.commitLayer: the layer by scan or by copy ops, written through the layer writer.  engine = an Engine: the
+        content-aware commit (walk + stage + GPU scan + diff with chunk roots + tar from HBM, one call); None: the
+        reference's.  Returns None when there is nothing to do, else dict(tar_digest, gzip_digest, tar_bytes, gzip_bytes,
+        n_entries, layer=[entries, with "root" for scanned files], stats={...})."""
         keep = []
         cops = _copy_op_array(list(ops), keep)
         cfg = LayerConfig()
         self._lib.mi_layer_config_default(C.byref(cfg))
         cfg.out_fd, cfg.gzip_level = out_fd, gzip_level
+        if mode_with_type:
+            cfg.flags |= LAYER_MODE_WITH_TYPE
         res, h, done = LayerResult(), C.c_void_p(), C.c_int()
-        self._check(self._lib.mi_memfs_commit_layer(self._h, int(must_scan), cops, len(ops), C.byref(cfg), C.byref(res),
+        ctx = engine._h if engine is not None else None
+        self._check(self._lib.mi_memfs_commit_layer(self._h, ctx, int(must_scan), cops, len(ops), C.byref(cfg), C.byref(res),
                                                     C.byref(h), C.byref(done)), "mi_memfs_commit_layer")
         if not done.value:
             return None
         return {"tar_digest": Digest.from_raw(res.tar_sha256), "gzip_digest": Digest.from_raw(res.gzip_sha256),
                 "tar_bytes": res.tar_bytes, "gzip_bytes": res.gzip_bytes, "n_entries": res.n_entries,
-                "layer": _take_copy_layer(self._lib, h, int(res.n_entries))}
+                "layer": _take_copy_layer(self._lib, h, int(res.n_entries)), "stats": self.commit_stats()}
+
+    def commit_stats(self):
+        st = CommitStats()
+        self._check(self._lib.mi_memfs_commit_stats(self._h, C.byref(st)), "mi_memfs_commit_stats")
+        return st.as_dict()
+
+    def set_index(self, index):
+        """every content-aware commit adds its batch's chunks to `index` (a ChunkIndex of the same Engine); None stops"""
+        self._index = index                                   # (kept alive)
+        self._check(self._lib.mi_memfs_set_index(self._h, index._h if index is not None else None), "mi_memfs_set_index")
+
+    def release_device(self):
+        self._check(self._lib.mi_memfs_release_device(self._h), "mi_memfs_release_device")
+
+    def root_of(self, path):
+        """the chunk root the tree holds for a path ("/"-rooted below the root), or None if it was never scanned"""
+        out = (C.c_uint8 * 32)()
+        has = C.c_int()
+        self._check(self._lib.mi_memfs_root_of(self._h, os.fsencode(path), out, C.byref(has)), "mi_memfs_root_of")
+        return bytes(out) if has.value else None
 
     def checkpoint(self, new_root, sources):
         """MemFS.Checkpoint: copy what a later stage will COPY --from below new_root."""

@@ -13,6 +13,7 @@
 // ctx-level work, n_streams copy streams for staging.
 // There is no CPU fallback anywhere in this file.
 #include "mi_internal.h"
+#include "mi_hostpath.h"      // mi_io
 
 #include <errno.h>
 #include <fcntl.h>
@@ -23,6 +24,7 @@
 #include <string.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <chrono>
 #include <mutex>
 #include <string>
@@ -337,6 +339,7 @@ int submit_pipeline_enqueue(mi_batch* b) {
     hipStream_t s = b->stream;
     const u64 nf = b->files.size();
     b->results_valid = false;
+    b->h_roots_valid = false;
     memset(&b->stats, 0, sizeof b->stats);
     b->stats.bytes_in = b->total_bytes;
     b->stats.n_files = nf;
@@ -613,7 +616,6 @@ int fetch_results(mi_batch* b) {
 // ================================ C ABI ============================================
 extern "C" {
 
-void mi_batch_tree_free(void* tree);                   // mi_tree.hip
 
 int mi_abi_version(void) { return MI_ABI_VERSION; }
 
@@ -926,6 +928,7 @@ static int add_file_range(mi_batch* b, const char* path, uint64_t offset, uint64
     HIPCHK(c, hipSetDevice(c->device));
     int fd = open(path, O_RDONLY | O_CLOEXEC);
     if (fd < 0) return fail(c, MI_ERR_IO, "open %s: %s", path, strerror(errno));
+    mi_io::content_opens.fetch_add(1, std::memory_order_relaxed);
     struct stat sb;
     if (fstat(fd, &sb) != 0) {
         int rc = fail(c, MI_ERR_IO, "stat %s: %s", path, strerror(errno));
@@ -1014,7 +1017,8 @@ extern "C" int mi_batch_add_placed(mi_batch* b, uint64_t n, const uint64_t* aren
     if (!b || (n && (!arena_off || !sizes))) return MI_ERR_INVALID;
     if (b->staged) return fail(b->ctx, MI_ERR_STATE, "batch already ran; begin a new batch");
     for (u64 i = 0; i < n; ++i) {
-        if (arena_off[i] + sizes[i] > b->arena_used) return fail(b->ctx, MI_ERR_INVALID, "mi_batch_add_placed: outside the arena");
+        if (sizes[i] > b->arena_used || arena_off[i] > b->arena_used - sizes[i])          // (no sum: it could wrap)
+            return fail(b->ctx, MI_ERR_INVALID, "mi_batch_add_placed: outside the arena");
         b->files.push_back({arena_off[i], sizes[i], tags ? tags[i] : 0});
         b->total_bytes += sizes[i];
     }
@@ -1391,6 +1395,8 @@ int mi_batch_reset(mi_batch* b) {
     b->staged_any = false;
     b->ms_h2d = 0;
     b->staged = b->ran = b->results_valid = false;
+    b->h_roots_valid = false;
+    b->rb_len = 0;                                      // the window held bytes of the old arena contents
     b->n_chunks = b->total_slots = 0;
     b->h_files.clear();
     memset(&b->stats, 0, sizeof b->stats);
@@ -1482,6 +1488,78 @@ int mi_batch_read_back(mi_batch* b, void* out, uint64_t cap) {
     return MI_OK;
 }
 
+// The per-file chunk roots alone, 32 bytes a file in add order: one device-to-host copy of n_files x 32 bytes, without
+// the chunk rows mi_batch_files / _chunks bring along.
+int mi_batch_roots(mi_batch* b, uint8_t* out, uint64_t cap) {
+    if (!b || (!out && cap)) return MI_ERR_INVALID;
+    mi_ctx* c = b->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!b->ran) return fail(c, MI_ERR_STATE, "roots requested before mi_batch_run");
+    const u64 nf = b->files.size();
+    if (cap < nf) return fail(c, MI_ERR_CAPACITY, "root buffer holds %llu rows, need %llu", (unsigned long long)cap, (unsigned long long)nf);
+    if (!b->h_roots_valid) {
+        b->h_roots.resize(nf * 32);
+        if (nf) HIPCHK(c, hipMemcpy(b->h_roots.data(), b->roots.p, nf * 32, hipMemcpyDeviceToHost));
+        b->h_roots_valid = true;
+    }
+    if (nf) memcpy(out, b->h_roots.data(), nf * 32);
+    return MI_OK;
+}
+
+// Bytes [offset, offset + len) of file `file_index` as they lie in HBM, through a pinned window: a fetch brings more than
+// was asked for (files that were staged together lie together; a layer's files are asked for in nearly that order), and
+// the next fetch's length follows how much of the last one was used -- 256 KiB when a layer picks single files out of a
+// tree, 8 MiB when it streams.
+constexpr u64 kReadWinBytes = 8ull << 20, kReadWinMin = 256ull << 10;
+int mi_batch_read_file(mi_batch* b, uint64_t file_index, uint64_t offset, void* dst, uint64_t len) {
+    if (!b || (!dst && len)) return MI_ERR_INVALID;
+    mi_ctx* c = b->ctx;
+    if (!b->staged || b->in_flight) return fail(c, MI_ERR_STATE, "mi_batch_read_file: the batch is not staged, or in flight");
+    if (file_index >= b->files.size()) return fail(c, MI_ERR_INVALID, "mi_batch_read_file: no file %llu", (unsigned long long)file_index);
+    const mi_batch::FileRec& f = b->files[file_index];
+    if (f.part >= 0) return fail(c, MI_ERR_INVALID, "mi_batch_read_file: file %llu is a part", (unsigned long long)file_index);
+    if (offset > f.size || len > f.size - offset)
+        return fail(c, MI_ERR_INVALID, "mi_batch_read_file: [%llu, +%llu) is outside file %llu of %llu bytes", (unsigned long long)offset,
+                    (unsigned long long)len, (unsigned long long)file_index, (unsigned long long)f.size);
+    if (!len) return MI_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!b->rb_win) {
+        HIPCHK(c, hipHostMalloc(&b->rb_win, kReadWinBytes, hipHostMallocDefault));
+        b->rb_next = kReadWinMin;
+        b->rb_len = 0;
+    }
+    u64 at = f.off + offset;
+    u8* d = (u8*)dst;
+    ++b->rb_hits;
+    while (len) {
+        if (!(b->rb_len && at >= b->rb_start && at < b->rb_start + b->rb_len)) {
+            if (b->rb_len) b->rb_next = b->rb_hits > 2 ? std::min(b->rb_next * 2, kReadWinBytes) : std::max(b->rb_next / 2, kReadWinMin);
+            u64 want = std::max(b->rb_next, std::min(len, kReadWinBytes));
+            want = std::min(want, b->arena_used - at);
+            HIPCHK(c, hipMemcpyAsync(b->rb_win, b->arena.as<u8>() + at, want, hipMemcpyDeviceToHost, b->stream));
+            HIPCHK(c, hipStreamSynchronize(b->stream));
+            b->rb_start = at;
+            b->rb_len = want;
+            b->rb_hits = 1;
+            ++b->rb_fetches;
+            b->rb_bytes += want;
+        }
+        const u64 take = std::min(len, b->rb_start + b->rb_len - at);
+        memcpy(d, (const u8*)b->rb_win + (at - b->rb_start), take);
+        d += take;
+        at += take;
+        len -= take;
+    }
+    return MI_OK;
+}
+
+int mi_batch_file_size(mi_batch* b, uint64_t file_index, uint64_t* size) {       // (internal: mi_layer.hip)
+    if (!b || !size || file_index >= b->files.size() || b->files[file_index].part >= 0) return MI_ERR_INVALID;
+    *size = b->files[file_index].size;
+    return MI_OK;
+}
+const char* mi_last_error_of_batch(mi_batch* b) { return b ? b->ctx->err.c_str() : ""; }
+
 void** mi_batch_tree_slot(mi_batch* b) { return &b->tree; }
 void mi_set_error(mi_batch* b, const char* msg) {                // b NULL: the message mi_last_error(NULL) returns
     if (b) { b->ctx->err = msg; return; }
@@ -1510,6 +1588,7 @@ int mi_batch_free(mi_batch* b) {
     for (auto e : b->ev) if (e) (void)hipEventDestroy(e);
     if (b->h_counts) (void)hipHostFree(b->h_counts);
     if (b->rows_h) (void)hipHostFree(b->rows_h);
+    if (b->rb_win) (void)hipHostFree(b->rb_win);
     DevBuf* bufs[] = {&b->root_addr, &b->root_cnt, &b->rseg_cnt, &b->rseg_first, &b->rseg_total,
                       &b->root_items_off, &b->root_items_len, &b->root_level[0], &b->root_level[1],
                       &b->root_level[2], &b->root_level[3], &b->root_level[4], &b->root_addr2, &b->root_cnt2,

@@ -3,17 +3,25 @@
 // no device code.  Users: mi_tree.hip (walks, stateless diffs), mi_memfs.hip (MemFS, copy ops, untar).
 #pragma once
 #include "../../include/makisu_mi.h"
+#include "mi_local.h"
 
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
-
+#include <atomic>
 #include <mutex>
 #include <set>
 #include <string>
 #include <vector>
+
+// What the library's own threads read of file CONTENT, process-wide: descriptors whose bytes were read, and the bytes
+// (the walk's directory readers, the reader threads of mi_stage.hip; the layer writer counts its own).  A commit that reads
+// every file once shows n_files and the files' bytes here (mi_commit_stats).
+namespace mi_io {
+extern std::atomic<uint64_t> content_opens, content_bytes;
+}
 
 namespace mi_walk {
 
@@ -224,5 +232,6 @@ inline const MountTable& mountpoints() {
 // the snapshot walk of `src` (scan rules, no blacklist), entries relative to src ("." first); absolute symlink targets
 // lose link_root (createHeader trims by the MemFS root).  Defined in mi_tree.hip, beside the walkers.
 int scan_walk_collect(const std::string& src, const std::string& link_root, Tree* out, std::string* err);
+int scan_walk_collect_batch(const std::string& src, const std::string& link_root, Tree* out, std::string* err, mi_batch* b);
 
 }  // namespace mi_walk

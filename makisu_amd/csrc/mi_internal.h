@@ -4,6 +4,7 @@
 
 #include "../../include/makisu_mi.h"
 #include "mi_common.h"
+#include "mi_local.h"
 
 #include <memory>
 
@@ -181,13 +182,17 @@ struct mi_batch {
     mi::DevBuf rows_d, file_base;        // chunk rows packed on the device; per-file offset base (parts)
     void* rows_h = nullptr;              // ... and in pinned host memory (what mi_batch_chunks_view hands out)
     size_t rows_h_bytes = 0;
+    // mi_batch_read_file: the pinned window staged bytes come back through (the layer writer's source when a commit
+    // reads its files from HBM instead of a second time from disk)
+    void* rb_win = nullptr;
+    mi::u64 rb_start = 0, rb_len = 0;    // the arena range the window holds now
+    mi::u64 rb_next = 0, rb_hits = 0;    // next fetch's length (adapts to how much of a fetch was asked for), reads served
+    mi::u64 rb_fetches = 0, rb_bytes = 0;
+    std::vector<mi::u8> h_roots;         // mi_batch_roots: the 32 bytes per file isUpdated needs, nothing else
+    bool h_roots_valid = false;
 };
 
 
-// mi_api.hip, for mi_comm.hip: job-wide marking of a rank's own rows, enqueued on the ctx stream; the
-// first-occurrence count stays in ctx->dd_nuniq (device)
-extern "C" int mi_dedup_mark_range_enqueue(mi_ctx* c, const void* d_digests, uint64_t n_total, uint64_t own_first,
-                                           uint64_t own_n, void* d_dup_of_own);
 
 #define HIPCHK(c, call)                                                                     \
     do {                                                                                    \

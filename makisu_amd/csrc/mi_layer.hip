@@ -30,6 +30,7 @@
 // the gzip digest is a faithful DigestPair member for THIS writer, not comparable across writers.
 #include "../../include/makisu_mi.h"
 #include "host_sha256.h"
+#include "mi_local.h"             // mi_batch_file_size, mi_last_error_of_batch
 
 #include <errno.h>
 #include <fcntl.h>
@@ -488,6 +489,7 @@ struct mi_layer {
     std::unique_ptr<GzipSink> gz;
     std::shared_ptr<Bytes> cur;
     uint64_t n_entries = 0;
+    uint64_t files_opened = 0, file_bytes_read = 0;    // what this writer read from disk itself (mi_layer_io_counts)
     bool finished = false, failed = false;
 
     int fail(int code, const char* fmt, ...) {
@@ -589,7 +591,11 @@ static int add_header(mi_layer* l, const Hdr& h) {
     return MI_OK;
 }
 
-int mi_layer_add(mi_layer* l, const mi_tree_entry* e, const char* src_path) {
+// One entry: header, then -- a regular file -- exactly e->size bytes from ONE of two sources: the file at src_path
+// (io.CopyN over os.Open, lib/tario/write.go:36-45), or file `batch_file` of a staged batch, i.e. the bytes the GPU scanned
+// (mi_batch_read_file): what the content-aware commit uses, so that a file is read from disk once and the tar holds the
+// very bytes its chunk root describes.
+static int layer_add_entry(mi_layer* l, const mi_tree_entry* e, const char* src_path, mi_batch* batch, uint64_t batch_file) {
     if (!l || !e || !e->relpath) return MI_ERR_INVALID;
     if (l->finished || l->failed) return l->fail(MI_ERR_STATE, "layer is finished or failed");
     Hdr h;
@@ -617,10 +623,11 @@ int mi_layer_add(mi_layer* l, const mi_tree_entry* e, const char* src_path) {
             return l->fail(MI_ERR_INVALID, "content commit %s: unsupported type %u", h.name.c_str(), (unsigned)e->kind);
     }
     int fd = -1;
-    if (e->kind == 1) {                                         // open before the header, like os.Open failing first would
+    if (e->kind == 1 && !batch) {                               // open before the header, like os.Open failing first would
         if (!src_path) return l->fail(MI_ERR_INVALID, "content commit %s: no source path", h.name.c_str());
         fd = open(src_path, O_RDONLY | O_CLOEXEC);
         if (fd < 0) return l->fail(MI_ERR_IO, "open src file %s: %s", src_path, strerror(errno));
+        ++l->files_opened;
     }
     int rc = add_header(l, h);
     if (rc) { if (fd >= 0) close(fd); return rc; }
@@ -629,24 +636,57 @@ int mi_layer_add(mi_layer* l, const mi_tree_entry* e, const char* src_path) {
         while (left) {
             size_t take = left > kBlockBytes ? kBlockBytes : (size_t)left;
             uint8_t* dst = l->room(&take);
-            size_t got = 0;
-            while (got < take) {
-                const ssize_t r = pread(fd, dst + got, take - got, (off_t)(off + got));
-                if (r < 0 && errno == EINTR) continue;
-                if (r <= 0) {
-                    close(fd);
-                    return l->fail(MI_ERR_IO, "copy file %s to tar writer: %s", src_path,
-                                   r == 0 ? "unexpected EOF" : strerror(errno));
+            if (batch) {
+                const int brc = mi_batch_read_file(batch, batch_file, off, dst, take);
+                if (brc) return l->fail(brc, "copy file %s to tar writer: staged file %llu: %s", h.name.c_str(),
+                                        (unsigned long long)batch_file, mi_last_error_of_batch(batch));
+            } else {
+                size_t got = 0;
+                while (got < take) {
+                    const ssize_t r = pread(fd, dst + got, take - got, (off_t)(off + got));
+                    if (r < 0 && errno == EINTR) continue;
+                    if (r <= 0) {
+                        close(fd);
+                        return l->fail(MI_ERR_IO, "copy file %s to tar writer: %s", src_path,
+                                       r == 0 ? "unexpected EOF" : strerror(errno));
+                    }
+                    got += (size_t)r;
                 }
-                got += (size_t)r;
+                l->file_bytes_read += take;
             }
             off += take;
             left -= take;
         }
-        close(fd);
+        if (fd >= 0) close(fd);
         l->append(nullptr, (size_t)((512 - e->size % 512) % 512));   // tar.Writer pads at the next header
     }
     return l->sink_error();
+}
+
+int mi_layer_add(mi_layer* l, const mi_tree_entry* e, const char* src_path) {
+    return layer_add_entry(l, e, src_path, nullptr, 0);
+}
+
+int mi_layer_add_batch_file(mi_layer* l, const mi_tree_entry* e, mi_batch* batch, uint64_t file_index) {
+    if (!batch) return MI_ERR_INVALID;
+    if (l && e && e->kind == 1) {
+        uint64_t nf = 0;
+        mi_batch_counts(batch, &nf, nullptr, nullptr);
+        uint64_t staged = 0;
+        if (file_index >= nf || mi_batch_file_size(batch, file_index, &staged) != MI_OK)
+            return l->fail(MI_ERR_INVALID, "content commit %s: the batch holds no file %llu", e->relpath ? e->relpath : "", (unsigned long long)file_index);
+        if (staged != e->size)
+            return l->fail(MI_ERR_INVALID, "content commit %s: the entry says %llu bytes, the staged file has %llu", e->relpath ? e->relpath : "",
+                           (unsigned long long)e->size, (unsigned long long)staged);
+    }
+    return layer_add_entry(l, e, nullptr, batch, file_index);
+}
+
+int mi_layer_io_counts(mi_layer* l, uint64_t* files_opened, uint64_t* file_bytes_read) {
+    if (!l) return MI_ERR_INVALID;
+    if (files_opened) *files_opened = l->files_opened;
+    if (file_bytes_read) *file_bytes_read = l->file_bytes_read;
+    return MI_OK;
 }
 
 int mi_layer_add_whiteout(mi_layer* l, const char* deleted_path) {

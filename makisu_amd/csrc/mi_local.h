@@ -1,0 +1,28 @@
+// mi_local.h -- the library's own cross-file helpers: C linkage (the translation units name them without sharing C++
+// headers), HIDDEN visibility -- they are not part of the ABI and `nm -D libmakisu_mi.so` does not list them
+// (tests/test_abi.py: the library exports what the two public headers declare and nothing else).
+#pragma once
+#include "../../include/makisu_mi.h"
+
+#define MI_LOCAL __attribute__((visibility("hidden")))
+
+extern "C" {
+// mi_api.hip
+MI_LOCAL void        mi_set_error(mi_batch* b, const char* msg);     // b NULL: the message mi_last_error(NULL) returns
+MI_LOCAL void**      mi_batch_tree_slot(mi_batch* b);                // the batch's walk record (mi_tree.hip owns its type)
+MI_LOCAL int         mi_batch_file_size(mi_batch* b, uint64_t file_index, uint64_t* size);
+MI_LOCAL const char* mi_last_error_of_batch(mi_batch* b);
+// the walk's small files read in place: a block of host memory as one piece of the arena, and the table rows of files
+// that lie in it; "host-fed bytes are on their way" (the reader threads set up behind the walk's first directories)
+MI_LOCAL int  mi_batch_add_block(mi_batch* b, const void* src, uint64_t len, void (*release)(void*), void* release_arg,
+                                 uint64_t* at_out);
+MI_LOCAL int  mi_batch_add_placed(mi_batch* b, uint64_t n, const uint64_t* arena_off, const uint64_t* sizes,
+                                  const uint64_t* tags);
+MI_LOCAL void mi_batch_expect_host_bytes(mi_batch* b);
+// job-wide marking of a rank's own rows, enqueued on the ctx stream; the first-occurrence count stays in
+// ctx->dd_nuniq (device).  For mi_comm.hip
+MI_LOCAL int  mi_dedup_mark_range_enqueue(mi_ctx* c, const void* d_digests, uint64_t n_total, uint64_t own_first,
+                                          uint64_t own_n, void* d_dup_of_own);
+// mi_tree.hip
+MI_LOCAL void mi_batch_tree_free(void* tree);
+}

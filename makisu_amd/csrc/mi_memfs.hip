@@ -26,7 +26,6 @@
 #include <unordered_map>
 #include <unordered_set>
 
-extern "C" void mi_set_error(mi_batch* b, const char* msg);   // b NULL: the message mi_last_error(NULL) returns
 
 
 // ---- MemFS.AddLayerByCopyOps: the layer a COPY / ADD step creates, on entry lists -----------------
@@ -55,6 +54,7 @@ struct Node {
     std::string src;           // where the content is read from; what memFSNode.isOnDisk looks at
     bool has_root = false;     // chunk root of the content, when the caller scanned it (content-aware isUpdated)
     uint8_t root[32];
+    int64_t batch_file = -1;   // a content-aware commit under way: the file's row in the commit's batch -- its bytes lie in HBM
 };
 // memLayer.files: path -> header.  A merged base image puts a million keys in and throws them away when the merge is done
 // (only their number is reported): from the C library's heap that is a million small allocations, a million frees, and --
@@ -166,6 +166,9 @@ struct Fs {
     // the layer map has not been emptied -- and such a call returns at once (a merge of 10^6 entries: 3.4 -> 1.6 us each, with the kept parent node of mi_memtree.h).
     struct { bool valid = false; std::string parent; uint64_t gen = 0; } anc_memo;
     uint64_t n_anc_calls = 0, n_anc_memo = 0;                                   // MI_MEMFS_TIMING
+    // content-aware isUpdated, counted per layer (mi_commit_stats): files whose header tario.IsSimilarHeader calls similar
+    // and whose chunk roots differ; unchanged files whose node had no root yet and took the scan's
+    uint64_t n_content_changed = 0, n_roots_learned = 0;
     void clear_layer() { layer.clear(); anc_memo.valid = false; }
     // where dst splits into parent and name; npos = do not memo.  (dst is AbsPath's result in every caller -- the merge,
     // the scan, the copy ops: "/", then clean elements; so its parent IS the chain addAncestors walks.)
@@ -237,6 +240,15 @@ struct Fs {
                 return;
             }
             updated = !similar;
+            if (similar && n.has_root && !o.has_root && n.e.kind == 1 && o.e.kind == 1) {   // the first content scan of an unchanged
+                Node& held = nodes[cur->ref];                                                // file: its root is known from now on
+                held.has_root = true;
+                memcpy(held.root, n.root, 32);
+                ++n_roots_learned;
+            } else if (!similar && o.has_root && n.has_root && a.kind == 1 && b.kind == 1) {
+                int meta = 0;
+                if (mi_entry_similar(&a, &b, 0, nullptr, nullptr, &meta) == MI_OK && meta) ++n_content_changed;
+            }
         }
         if (updated && dst != "/") {
             add_ancestors(dst, false, 0, 0);
@@ -311,7 +323,14 @@ struct Fs {
         b.relpath = dst.c_str() + 1;                                             // dst without its leading "/"
         b.file_index = -1;
         int similar = 0;
-        return mi_entry_similar(&a, &b, 0, o.has_root ? o.root : nullptr, content_root, &similar) == MI_OK && similar;
+        if (mi_entry_similar(&a, &b, 0, o.has_root ? o.root : nullptr, content_root, &similar) != MI_OK) return false;
+        if (similar && content_root && !o.has_root && o.e.kind == 1 && b.kind == 1) {    // (as in maybe_add)
+            Node& held = nodes[cur->ref];
+            held.has_root = true;
+            memcpy(held.root, content_root, 32);
+            ++n_roots_learned;
+        }                                                                                // (a content-only change is counted
+        return similar != 0;                                                             //  where it is added: maybe_add)
     }
 };
 
@@ -653,44 +672,79 @@ extern "C" int mi_copy_op_resolve(uint64_t n_srcs, const char* work_dir, const c
 }
 
 // addToLayer (mem_fs.go:343-421) for each op, against fs.t, into fs.layer; fs.rc / fs.err carry what maybeAddToLayer
-// refuses, *err_out everything else
-static int copy_ops_into(mi_copy::Fs& fs, const mi_copy_op* ops, uint64_t n_ops, std::string* err_out) {
-    auto put_err = [&](const std::string& m) { *err_out = m; };
-    for (uint64_t k = 0; k < n_ops && !fs.rc; ++k) {
+// refuses, *err_out everything else.
+// In two steps.  PLAN: what the ops read from the DISK -- the parameter check, the stat of a single source, evalSymlinks,
+// the walk of every source -- for all ops, in order, stopping at the first failure.  None of it depends on the tree, so
+// it can run ahead; with a batch attached the walks stage every regular file on the GPU while they list it (an entry's
+// file_index = its row).  APPLY: the ops against the tree, in order, each failure raised where the interleaved loop of the
+// reference raises it (an op-2 source that does not exist fails after op 1 has been applied, not before).  Between the
+// two, a content-aware commit runs the batch: the apply step then sees a chunk root for every regular file.
+struct CopySrcPlan { std::string src; mi_walk::Tree walked; };
+struct CopyOpPlan {
+    std::string src_root, dst;
+    bool create_dst = true;
+    std::vector<CopySrcPlan> srcs;
+};
+struct CopyPlan {
+    std::vector<CopyOpPlan> ops;
+    int err_rc = MI_OK;                 // the failure planning stopped at ...
+    std::string err;
+    bool err_before_dst = false;        // ... raised before the last planned op touches the tree / after its planned sources
+    uint64_t n_walked = 0;
+};
+static void copy_ops_plan(const mi_copy::Fs& fs, const mi_copy_op* ops, uint64_t n_ops, mi_batch* batch, CopyPlan* plan) {
+    auto stop = [&](int rc, const std::string& m, bool before_dst) { plan->err_rc = rc; plan->err = m; plan->err_before_dst = before_dst; };
+    for (uint64_t k = 0; k < n_ops; ++k) {
         const mi_copy_op& c = ops[k];
-        if (!c.src_root || !c.dst || (c.n_srcs && !c.srcs)) return MI_ERR_INVALID;
+        plan->ops.emplace_back();
+        CopyOpPlan& op = plan->ops.back();
+        if (!c.src_root || !c.dst || (c.n_srcs && !c.srcs)) return stop(MI_ERR_INVALID, "", true);
         {   // what NewCopyOperation refuses (copy_op.go:48-50): the dst here is the resolved one, so it is absolute
             const std::string bad = copy_check_params(c.n_srcs, nullptr, c.dst);
-            if (!bad.empty()) { put_err("check copy param: " + bad); return MI_ERR_INVALID; }
+            if (!bad.empty()) return stop(MI_ERR_INVALID, "check copy param: " + bad, true);
         }
-        const std::string src_root = mi_walk::abs_path(c.src_root);
-        std::string dst = c.dst;
-        bool create_dst = true;
+        op.src_root = mi_walk::abs_path(c.src_root);
+        op.dst = c.dst;
         if (c.n_srcs == 1) {
             struct stat st;
-            const std::string s0 = src_root + mi_walk::abs_path(c.srcs[0] ? c.srcs[0] : "");
-            if (stat(s0.c_str(), &st) != 0) { put_err("stat src " + s0 + ": " + strerror(errno)); return MI_ERR_IO; }
-            if (!S_ISDIR(st.st_mode)) create_dst = false;            // case 1: file onto file
+            const std::string s0 = op.src_root + mi_walk::abs_path(c.srcs[0] ? c.srcs[0] : "");
+            if (stat(s0.c_str(), &st) != 0) return stop(MI_ERR_IO, "stat src " + s0 + ": " + strerror(errno), true);
+            if (!S_ISDIR(st.st_mode)) op.create_dst = false;          // case 1: file onto file
         }
-        if (create_dst) {
+        for (uint64_t si = 0; si < c.n_srcs; ++si) {
+            std::string rel, e2;
+            if (!mi_copy::eval_symlinks(mi_walk::abs_path(c.srcs[si] ? c.srcs[si] : ""), op.src_root, &rel, &e2))
+                return stop(MI_ERR_IO, "eval symlinks for " + std::string(c.srcs[si] ? c.srcs[si] : "") + ": " + e2, false);
+            CopySrcPlan sp;
+            sp.src = op.src_root == "/" ? rel : op.src_root + (rel == "/" ? "" : rel);
+            std::string werr;                                           // shouldSkip with a nil blacklist; createHeader
+            const int wrc = batch ? mi_walk::scan_walk_collect_batch(sp.src, fs.root, &sp.walked, &werr, batch)   // trims link targets
+                                  : mi_walk::scan_walk_collect(sp.src, fs.root, &sp.walked, &werr);               // by the MEMFS root
+            if (wrc) return stop(wrc, "copy src " + sp.src + ": " + werr, false);
+            plan->n_walked += sp.walked.entries.size();
+            op.srcs.push_back(std::move(sp));
+        }
+    }
+}
+// roots: 32 bytes per batch row (NULL: the reference's metadata-only isUpdated)
+static int copy_ops_apply(mi_copy::Fs& fs, const mi_copy_op* ops, const CopyPlan& plan, const uint8_t* roots, std::string* err_out) {
+    auto put_err = [&](const std::string& m) { *err_out = m; };
+    for (size_t k = 0; k < plan.ops.size() && !fs.rc; ++k) {
+        const CopyOpPlan& op = plan.ops[k];
+        const mi_copy_op& c = ops[k];
+        const bool last = k + 1 == plan.ops.size();
+        if (last && plan.err_rc && plan.err_before_dst) { put_err(plan.err); return plan.err_rc; }
+        std::string dst = op.dst;
+        if (op.create_dst) {
             std::string resolved = fs.add_ancestors(mi_walk::abs_path(dst), true, c.uid, c.gid);
             if (fs.rc) break;
             if (resolved.empty() || resolved.back() != '/') resolved += "/";
             dst = resolved;
         }
         const bool dst_is_dir = !dst.empty() && dst.back() == '/';
-        for (uint64_t si = 0; si < c.n_srcs && !fs.rc; ++si) {
-            std::string rel, e2;
-            if (!mi_copy::eval_symlinks(mi_walk::abs_path(c.srcs[si] ? c.srcs[si] : ""), src_root, &rel, &e2)) {
-                put_err("eval symlinks for " + std::string(c.srcs[si] ? c.srcs[si] : "") + ": " + e2);
-                return MI_ERR_IO;
-            }
-            const std::string src = src_root == "/" ? rel : src_root + (rel == "/" ? "" : rel);
-            mi_walk::Tree walked;                                       // shouldSkip with a nil blacklist; createHeader
-            std::string werr;                                           // trims link targets by the MEMFS root
-            const int wrc = mi_walk::scan_walk_collect(src, fs.root, &walked, &werr);
-            if (wrc) { put_err("copy src " + src + ": " + werr); return wrc; }
-            for (const mi_walk::Entry& we : walked.entries) {
+        for (size_t si = 0; si < op.srcs.size() && !fs.rc; ++si) {
+            const std::string& src = op.srcs[si].src;
+            for (const mi_walk::Entry& we : op.srcs[si].walked.entries) {
                 const bool is_src = we.relpath == ".";
                 std::string curr_dst;
                 if (is_src) {
@@ -705,14 +759,26 @@ static int copy_ops_into(mi_copy::Fs& fs, const mi_copy_op* ops, uint64_t n_ops,
                 n.e.relpath = curr_dst == "/" ? "" : curr_dst.substr(1);
                 n.e.uid = c.uid;
                 n.e.gid = c.gid;
+                n.e.file_index = -1;
+                if (roots && we.kind == 1 && we.file_index >= 0) {
+                    n.batch_file = we.file_index;
+                    n.has_root = true;
+                    memcpy(n.root, roots + (uint64_t)we.file_index * 32, 32);
+                }
                 const std::string curr_src = is_src ? src : src + "/" + we.relpath;
                 fs.maybe_add(curr_src, curr_dst, n);
                 if (fs.rc) break;
             }
         }
+        if (!fs.rc && last && plan.err_rc) { put_err(plan.err); return plan.err_rc; }
     }
     if (fs.rc) { put_err(fs.err); return fs.rc; }
     return MI_OK;
+}
+static int copy_ops_into(mi_copy::Fs& fs, const mi_copy_op* ops, uint64_t n_ops, std::string* err_out) {
+    CopyPlan plan;
+    copy_ops_plan(fs, ops, n_ops, nullptr, &plan);
+    return copy_ops_apply(fs, ops, plan, nullptr, err_out);
 }
 
 // ---- CopyOperation.Execute: the on-disk copy of a COPY/ADD step with --modifyfs (lib/snapshot/copy_op.go:83-147) over
@@ -1047,6 +1113,14 @@ struct mi_memfs {
     mi_copy::Fs fs;
     std::vector<std::string> blacklist;
     std::string err;
+    // the content-aware commit (mi_memfs_commit_layer with a ctx): ONE batch, kept between commits -- its arena and tables
+    // are sized by the first commit and reused by the next (mi_batch_reset)
+    mi_batch* batch = nullptr;
+    mi_ctx* batch_ctx = nullptr;
+    mi_index* index = nullptr;           // mi_memfs_set_index: every content-aware commit adds its batch's chunks
+    mi_commit_stats last;                // of the last mi_memfs_commit_layer
+    mi_memfs() { memset(&last, 0, sizeof last); }
+    ~mi_memfs() { if (batch) mi_batch_free(batch); }
 };
 
 // MI_MEMFS_TIMING=1: one line per merge / scan on stderr
@@ -1241,8 +1315,9 @@ extern "C" int mi_memfs_untar(mi_memfs* m, const char* tar_path, const mi_tree_e
 
 // MemFS.createLayerByScan (:315-341) on a walk of the root (mi_tree_walk / mi_batch_add_tree with MI_TREE_SCAN,
 // rel_base = root): every walked path through maybeAddToLayer with createWhiteout = true
-extern "C" int mi_memfs_add_layer_by_scan(mi_memfs* m, const mi_tree_entry* walked, uint64_t n, const void* roots,
-                                          uint64_t root_stride, mi_copy_layer** out, uint64_t* n_entries) {
+// from_batch: the walk is a batch's (mi_batch_add_tree) -- an entry's file_index is its row there, and the layer's nodes keep it
+static int memfs_scan(mi_memfs* m, const mi_tree_entry* walked, uint64_t n, const void* roots, uint64_t root_stride, bool from_batch,
+                      mi_copy_layer** out, uint64_t* n_entries) {
     if (!m || (n && !walked) || !out) return MI_ERR_INVALID;
     mi_copy::Fs& fs = m->fs;
     MemfsTimer timer("scan", fs, n);
@@ -1286,6 +1361,7 @@ extern "C" int mi_memfs_add_layer_by_scan(mi_memfs* m, const mi_tree_entry* walk
             nd.has_root = true;
             memcpy(nd.root, (const uint8_t*)roots + (uint64_t)e.file_index * root_stride, 32);
         }
+        if (from_batch && e.kind == 1 && e.file_index >= 0) nd.batch_file = e.file_index;
         const std::string src = fs.root == "/" ? p : fs.root + (p == "/" ? "" : p);
         fs.maybe_add(src, p, std::move(nd), true);
     }
@@ -1294,6 +1370,11 @@ extern "C" int mi_memfs_add_layer_by_scan(mi_memfs* m, const mi_tree_entry* walk
     if (n_entries) *n_entries = l->nodes.size();
     *out = l;
     return MI_OK;
+}
+
+extern "C" int mi_memfs_add_layer_by_scan(mi_memfs* m, const mi_tree_entry* walked, uint64_t n, const void* roots,
+                                          uint64_t root_stride, mi_copy_layer** out, uint64_t* n_entries) {
+    return memfs_scan(m, walked, n, roots, root_stride, false, out, n_entries);
 }
 
 // MemFS.AddLayerByCopyOps (:276-289): the ops against THIS tree, which they update
@@ -1314,50 +1395,199 @@ extern "C" int mi_memfs_add_layer_by_copy_ops(mi_memfs* m, const mi_copy_op* ops
 // copy operations, through tarAndGzipDiffs' pipeline (the layer writer: tar framing, TarDigest, gzip leg, its digest and
 // size), folded into the tree; nothing to do = *committed 0.  The walk of a scan happens here, with the handle's
 // blacklist.  (MemFS.sync's one-second wait before either stays with the caller.)
-extern "C" int mi_memfs_commit_layer(mi_memfs* m, int must_scan, const mi_copy_op* ops, uint64_t n_ops,
-                                     const mi_layer_config* cfg, mi_layer_result* res, mi_copy_layer** layer_out,
-                                     int* committed) {
-    if (!m || !cfg || !res || !committed || (n_ops && !ops)) return MI_ERR_INVALID;
-    *committed = 0;
-    if (layer_out) *layer_out = nullptr;
-    if (!must_scan && n_ops == 0) return MI_OK;                                   // "Nothing to do, return."
-    mi_copy_layer* cl = nullptr;
-    uint64_t ne = 0;
-    int rc;
-    if (must_scan) {
-        std::vector<const char*> bl;
-        for (const std::string& b : m->blacklist) bl.push_back(b.c_str());
-        mi_tree* t = nullptr;
-        uint64_t n = 0;
-        rc = mi_tree_walk(m->fs.root.c_str(), m->fs.root.c_str(), bl.empty() ? nullptr : bl.data(), bl.size(), MI_TREE_SCAN, &t, &n);
-        if (rc) { m->err = "failed to generate diff layer: write diffs: create layer by scan: walk " + m->fs.root; return rc; }
-        std::vector<mi_tree_entry> walked(n ? n : 1);
-        rc = mi_tree_entries(t, walked.data(), n);
-        if (!rc) rc = mi_memfs_add_layer_by_scan(m, walked.data(), n, nullptr, 0, &cl, &ne);
-        mi_tree_free(t);
-        if (rc) { m->err = "failed to generate diff layer: write diffs: create layer by scan: " + m->err; return rc; }
-    } else {
-        rc = mi_memfs_add_layer_by_copy_ops(m, ops, n_ops, &cl, &ne);
-        if (rc) { m->err = "failed to generate diff layer: write diffs: create layer by copy ops: " + m->err; return rc; }
-    }
+//
+// ctx == NULL: the reference's commit -- headers decide what changed (tario.IsSimilarHeader), the layer writer reads the
+// changed files from disk.
+// ctx != NULL: THE SEAM the GPU path exists for (mem_fs.go:315-341,487-503 + common.go:67-111 in one flow):
+//     walk + stage   the root (must_scan) or the ops' sources are walked and every regular file they list is staged into
+//                    ONE batch while the walk goes on (mi_batch_add_tree's way: small files read where they are listed,
+//                    large ones by the reader threads) -- each file is opened and read ONCE;
+//     scan           Gear CDC + SHA-256 per chunk + per-file chunk roots on the GPU (mi_batch_run);
+//     diff           createLayerByScan / addToLayer with the roots: a path is in the layer if its header changed OR its
+//                    content did (same size, same second, other bytes: invisible to the reference); unchanged files whose
+//                    node had no root yet take theirs, so the next commit can tell;
+//     write          the layer writer frames the tar; a regular file's bytes come from HBM -- the very bytes the root
+//                    describes (mi_layer_add_batch_file) -- not from a second read of a file that may have moved on;
+//     index          optionally (mi_memfs_set_index) the batch's chunk digests join the chunk index.
+static double secs_since(const std::chrono::steady_clock::time_point& t0) {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+static int memfs_commit_write(mi_memfs* m, mi_copy_layer* cl, uint64_t ne, const mi_layer_config* cfg, mi_layer_result* res,
+                              mi_batch* batch) {
     std::vector<mi_tree_entry> ents(ne ? ne : 1);
     std::vector<const char*> srcs(ne ? ne : 1);
-    rc = mi_copy_layer_entries(cl, ents.data(), srcs.data(), ne);
+    int rc = mi_copy_layer_entries(cl, ents.data(), srcs.data(), ne);
     mi_layer* lw = nullptr;
     if (rc) m->err = "failed to generate diff layer: layer entries";
     if (!rc && (rc = mi_layer_begin(cfg, &lw))) m->err = "failed to generate diff layer: the layer writer refused its configuration";
     for (uint64_t i = 0; i < ne && !rc; ++i) {
-        rc = mi_layer_add(lw, &ents[i], ents[i].kind == 1 && srcs[i] && srcs[i][0] ? srcs[i] : nullptr);
+        const mi_copy::Node& nd = cl->nodes[i];
+        if (ents[i].kind == 1 && ents[i].file_index >= 0) { ++m->last.n_layer_files; m->last.layer_file_bytes += ents[i].size; }
+        if (batch && ents[i].kind == 1 && ents[i].file_index >= 0 && nd.batch_file >= 0)
+            rc = mi_layer_add_batch_file(lw, &ents[i], batch, (uint64_t)nd.batch_file);
+        else
+            rc = mi_layer_add(lw, &ents[i], ents[i].kind == 1 && srcs[i] && srcs[i][0] ? srcs[i] : nullptr);
         if (rc) m->err = std::string("failed to generate diff layer: write diffs: commit layer: ") + mi_layer_error(lw);
     }
     if (!rc) {
         rc = mi_layer_finish(lw, res);
         if (rc) m->err = std::string("failed to generate diff layer: ") + mi_layer_error(lw);
     }
-    if (lw) mi_layer_free(lw);
+    if (lw) {
+        uint64_t o = 0, by = 0;
+        mi_layer_io_counts(lw, &o, &by);
+        m->last.files_opened += o;
+        m->last.file_bytes_read += by;
+        mi_layer_free(lw);
+    }
+    return rc;
+}
+
+extern "C" int mi_memfs_commit_layer(mi_memfs* m, mi_ctx* ctx, int must_scan, const mi_copy_op* ops, uint64_t n_ops,
+                                     const mi_layer_config* cfg, mi_layer_result* res, mi_copy_layer** layer_out,
+                                     int* committed) {
+    if (!m || !cfg || !res || !committed || (n_ops && !ops)) return MI_ERR_INVALID;
+    *committed = 0;
+    if (layer_out) *layer_out = nullptr;
+    memset(&m->last, 0, sizeof m->last);
+    if (!must_scan && n_ops == 0) return MI_OK;                                   // "Nothing to do, return."
+    const auto t_all = std::chrono::steady_clock::now();
+    const uint64_t opens0 = mi_io::content_opens.load(), bytes0 = mi_io::content_bytes.load();
+    mi_copy::Fs& fs = m->fs;
+    fs.n_content_changed = fs.n_roots_learned = 0;
+    mi_copy_layer* cl = nullptr;
+    uint64_t ne = 0;
+    int rc;
+    const char* how = must_scan ? "create layer by scan: " : "create layer by copy ops: ";
+    auto fail_with = [&](int code, const std::string& what) {
+        m->err = std::string("failed to generate diff layer: write diffs: ") + how + what;
+        return code;
+    };
+    mi_batch* b = nullptr;
+    if (ctx) {
+        if (m->batch && m->batch_ctx != ctx) { mi_batch_free(m->batch); m->batch = nullptr; }
+        if (m->batch) rc = mi_batch_reset(m->batch);
+        else { rc = mi_batch_begin(ctx, 0, 0, &m->batch); m->batch_ctx = ctx; }
+        if (rc) return fail_with(rc, std::string("gpu scan: ") + mi_last_error(ctx));
+        b = m->batch;
+    }
+    std::vector<uint8_t> roots;
+    auto run_batch = [&]() -> int {                                               // scan what has been staged; the roots
+        uint64_t nf = 0, nbytes = 0;
+        mi_batch_counts(b, &nf, nullptr, &nbytes);
+        m->last.n_scanned_files = nf;
+        m->last.scanned_bytes = nbytes;
+        if (!nf) return MI_OK;
+        const auto t0 = std::chrono::steady_clock::now();
+        int r = mi_batch_run(b);
+        if (!r) { roots.resize(nf * 32); r = mi_batch_roots(b, roots.data(), nf); }
+        m->last.s_scan = secs_since(t0);
+        if (!r) mi_batch_counts(b, nullptr, &m->last.n_chunks, nullptr);
+        return r;
+    };
+    if (must_scan) {
+        std::vector<const char*> bl;
+        for (const std::string& s : m->blacklist) bl.push_back(s.c_str());
+        uint64_t n = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        std::vector<mi_tree_entry> walked;
+        mi_tree* t = nullptr;
+        if (b) {
+            rc = mi_batch_add_tree(b, fs.root.c_str(), fs.root.c_str(), bl.empty() ? nullptr : bl.data(), bl.size(), MI_TREE_SCAN, &n);
+            if (rc) return fail_with(rc, "walk " + fs.root + ": " + mi_last_error(ctx));
+            walked.resize(n ? n : 1);
+            rc = mi_batch_tree_entries(b, walked.data(), n);
+        } else {
+            rc = mi_tree_walk(fs.root.c_str(), fs.root.c_str(), bl.empty() ? nullptr : bl.data(), bl.size(), MI_TREE_SCAN, &t, &n);
+            if (rc) return fail_with(rc, "walk " + fs.root);
+            walked.resize(n ? n : 1);
+            rc = mi_tree_entries(t, walked.data(), n);
+        }
+        m->last.n_walked = n;
+        m->last.s_walk_stage = secs_since(t0);
+        if (!rc && b && (rc = run_batch())) { if (t) mi_tree_free(t); return fail_with(rc, std::string("gpu scan: ") + mi_last_error(ctx)); }
+        const auto t1 = std::chrono::steady_clock::now();
+        if (!rc) rc = memfs_scan(m, walked.data(), n, roots.empty() ? nullptr : roots.data(), 32, b != nullptr, &cl, &ne);
+        m->last.s_diff = secs_since(t1);
+        if (t) mi_tree_free(t);
+        if (rc) return fail_with(rc, m->err);
+    } else {
+        fs.clear_layer();
+        CopyPlan plan;
+        const auto t0 = std::chrono::steady_clock::now();
+        copy_ops_plan(fs, ops, n_ops, b, &plan);
+        m->last.n_walked = plan.n_walked;
+        m->last.s_walk_stage = secs_since(t0);
+        // (a plan that stopped at a failure is applied up to it: the failure is the apply step's to raise, in its place.
+        //  What was staged until then is scanned all the same -- the ops before the failing one are applied WITH roots.)
+        if (b && (rc = run_batch())) return fail_with(rc, std::string("gpu scan: ") + mi_last_error(ctx));
+        const auto t1 = std::chrono::steady_clock::now();
+        std::string e;
+        rc = copy_ops_apply(fs, ops, plan, roots.empty() ? nullptr : roots.data(), &e);
+        if (rc) {
+            if (fs.rc) rc = memfs_fail(m); else { m->err = e; fs.clear_layer(); }
+            return fail_with(rc, m->err);
+        }
+        cl = memfs_take_layer(m);
+        ne = cl->nodes.size();
+        m->last.s_diff = secs_since(t1);
+    }
+    m->last.n_layer_entries = ne;
+    m->last.n_content_changed = fs.n_content_changed;
+    m->last.n_roots_learned = fs.n_roots_learned;
+    const auto t2 = std::chrono::steady_clock::now();
+    rc = memfs_commit_write(m, cl, ne, cfg, res, b);
+    m->last.s_write = secs_since(t2);
+    if (!rc && b && m->index && m->last.n_scanned_files) {
+        rc = mi_index_add_batch(m->index, b, nullptr, 0, &m->last.n_index_new, &m->last.n_index_known);
+        if (rc) m->err = std::string("failed to generate diff layer: chunk index: ") + mi_last_error(ctx);
+    }
+    m->last.files_opened += mi_io::content_opens.load() - opens0;
+    m->last.file_bytes_read += mi_io::content_bytes.load() - bytes0;
+    m->last.s_total = secs_since(t_all);
+    for (mi_copy::Node& nd : cl->nodes) nd.batch_file = -1;                       // (rows of a batch the caller does not hold)
     if (rc) { mi_copy_layer_free(cl); return rc; }
     *committed = 1;
     if (layer_out) *layer_out = cl; else mi_copy_layer_free(cl);
+    return MI_OK;
+}
+
+extern "C" int mi_memfs_commit_stats(const mi_memfs* m, mi_commit_stats* out) {
+    if (!m || !out) return MI_ERR_INVALID;
+    *out = m->last;
+    return MI_OK;
+}
+extern "C" int mi_memfs_set_index(mi_memfs* m, mi_index* index) {
+    if (!m) return MI_ERR_INVALID;
+    m->index = index;
+    return MI_OK;
+}
+// the commit's batch (its arena holds the last scanned tree's bytes) is given back; the next content-aware commit begins anew
+extern "C" int mi_memfs_release_device(mi_memfs* m) {
+    if (!m) return MI_ERR_INVALID;
+    int rc = MI_OK;
+    if (m->batch) rc = mi_batch_free(m->batch);
+    m->batch = nullptr;
+    m->batch_ctx = nullptr;
+    return rc;
+}
+// the chunk root the tree holds for a path (absolute, below the root "/"): what the next isUpdated compares
+extern "C" int mi_memfs_root_of(const mi_memfs* m, const char* path, uint8_t* root_out, int* has_root) {
+    if (!m || !path || !has_root) return MI_ERR_INVALID;
+    *has_root = 0;
+    const mi_memtree::Node* nd = const_cast<mi_memtree::Tree&>(m->fs.t).find_walk(mi_walk::abs_path(path));
+    if (!nd || nd->ref < 0) return MI_ERR_INVALID;
+    const mi_copy::Node& n = m->fs.nodes[nd->ref];
+    if (n.has_root) { *has_root = 1; if (root_out) memcpy(root_out, n.root, 32); }
+    return MI_OK;
+}
+extern "C" int mi_copy_layer_roots(const mi_copy_layer* l, uint8_t* roots, uint8_t* has_root, uint64_t cap) {
+    if (!l || (cap && (!roots || !has_root))) return MI_ERR_INVALID;
+    if (cap < l->nodes.size()) return MI_ERR_CAPACITY;
+    for (size_t i = 0; i < l->nodes.size(); ++i) {
+        has_root[i] = l->nodes[i].has_root ? 1 : 0;
+        if (l->nodes[i].has_root) memcpy(roots + i * 32, l->nodes[i].root, 32); else memset(roots + i * 32, 0, 32);
+    }
     return MI_OK;
 }
 

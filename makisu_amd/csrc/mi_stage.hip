@@ -10,6 +10,7 @@
 // landed) -- stage_sum_kernel below, the one kernel of this file --, copied again if the sums
 // differ, and summed once more when staging ends (stage_verify_final).
 #include "mi_internal.h"
+#include "mi_hostpath.h"      // mi_io: what was read of file content
 
 #include <errno.h>
 #include <fcntl.h>
@@ -31,8 +32,14 @@ namespace mi {
 
 struct StageFile {                       // a source file shared by its pieces
     int fd;                              // open (mi_batch_add_path: checked at the call), or -1:
-    std::string path;                    // ... the reader thread opens `path` for each piece itself
-    ~StageFile() { if (fd >= 0) close(fd); }
+    std::string path;                    // ... the reader thread that takes the file's FIRST piece opens `path`, the others
+    std::mutex mu;                       // read through the same descriptor: one open per file, and every piece of a file
+    u64 pieces_left = 0;                 // that is renamed over under way comes from the same inode.  Closed with the LAST
+    ~StageFile() { if (fd >= 0) close(fd); }   // piece read (under mu), not when the last item lets go: a run of small files
+    void piece_read() {                  // must not hold a descriptor per file until its copy is done
+        std::lock_guard<std::mutex> g(mu);
+        if (pieces_left && --pieces_left == 0 && fd >= 0) { close(fd); fd = -1; }
+    }
 };
 
 struct StageLatch {                      // completion of one blocking mi_batch_add_bytes call
@@ -261,11 +268,17 @@ void worker(Stager* st, u32 tid) {
                 memcpy(dst, it.src, it.len);
             } else {
                 // a deferred file (bulk adds, tree walks) is opened HERE, by one of several threads
-                int fd = it.file->fd, own = -1;
-                if (fd < 0) {
-                    own = fd = open(it.file->path.c_str(), O_RDONLY | O_CLOEXEC);
-                    if (fd < 0) { err = "open " + it.file->path + ": " + strerror(errno); break; }
+                int fd;
+                {
+                    std::lock_guard<std::mutex> g(it.file->mu);
+                    if (it.file->fd < 0) {
+                        it.file->fd = open(it.file->path.c_str(), O_RDONLY | O_CLOEXEC);   // closed with the file's last piece
+                        if (it.file->fd >= 0) mi_io::content_opens.fetch_add(1, std::memory_order_relaxed);
+                    }
+                    fd = it.file->fd;
                 }
+                if (fd < 0) { err = "open " + it.file->path + ": " + strerror(errno); break; }
+                mi_io::content_bytes.fetch_add(it.len, std::memory_order_relaxed);
                 u64 got = 0;
                 while (got < it.len) {
                     const ssize_t r = pread(fd, dst + got, it.len - got, (off_t)(it.file_off + got));
@@ -277,7 +290,7 @@ void worker(Stager* st, u32 tid) {
                     }
                     got += (u64)r;
                 }
-                if (own >= 0) close(own);
+                it.file->piece_read();
             }
             end = it.arena_off + it.len;
         }
@@ -408,6 +421,7 @@ static void enqueue(Stager* st, mi_batch* b, u64 arena_off, u64 len, const u8* s
         done += take;
     }
     if (latch) latch->left = items.size();
+    if (file) file->pieces_left = items.size();
     {
         std::lock_guard<std::mutex> g(st->mu);
         b->stage_pending += items.size();
@@ -469,6 +483,7 @@ int stager_put_paths(Stager* st, mi_batch* b, u64 n, const char* const* paths, c
             const u64 take = len[i] - done < st->slab_bytes ? len[i] - done : st->slab_bytes;
             items.push_back({b, arena_off[i] + done, take, nullptr, f, done, nullptr});
             done += take;
+            ++f->pieces_left;
         }
     }
     if (items.empty()) return MI_OK;

@@ -65,13 +65,10 @@
 #include <string_view>
 #include <vector>
 
-// mi_api.hip, for the walk's small files read in place: a block of host memory as one piece of the arena, and the table
-// rows of files that lie in it
-extern "C" int mi_batch_add_block(mi_batch* b, const void* src, uint64_t len, void (*release)(void*), void* release_arg,
-                                  uint64_t* at_out);
-extern "C" int mi_batch_add_placed(mi_batch* b, uint64_t n, const uint64_t* arena_off, const uint64_t* sizes,
-                                   const uint64_t* tags);
-extern "C" void mi_batch_expect_host_bytes(mi_batch* b);
+
+namespace mi_io {
+std::atomic<uint64_t> content_opens{0}, content_bytes{0};
+}
 
 namespace mi_walk {
 
@@ -413,6 +410,11 @@ static bool walk_unshare() {
     static const bool on = [] { const char* e = getenv("MI_WALK_UNSHARE"); return !(e && *e == '0'); }();
     return on;
 }
+static bool walk_close_range() {                                     // MI_WALK_CLOSE_RANGE=0: as if the kernel had no close_range
+    static const bool on = [] { const char* e = getenv("MI_WALK_CLOSE_RANGE"); return !(e && *e == '0'); }();
+    return on;
+}
+#define MI_CLOSE_RANGE_UNSHARE (1u << 1)                              // linux/close_range.h (absent from older kernel headers)
 static std::atomic<uint64_t> g_inline_bytes{0};                    // bytes in blocks alive now
 static std::atomic<uint64_t> g_inline_peak{0}, g_inline_files{0};  // MI_WALK_TIMING: the most there were; files read into blocks
 static uint64_t inline_budget() {
@@ -556,7 +558,8 @@ struct ParallelWalker {
         if (n == 0) return;
         const uint64_t held = g_inline_bytes.fetch_add(total) + total;
         if (walk_timing()) { uint64_t pk = g_inline_peak.load(); while (held > pk && !g_inline_peak.compare_exchange_weak(pk, held)) {} }
-        if (held > inline_budget() && held != total) {       // too much host memory in blocks already: these go as paths
+        if (held > inline_budget()) {                        // too much host memory in blocks already -- or this one directory
+                                                             // alone is more than the budget: these files go as paths
             g_inline_bytes.fetch_sub(total);
             for (Child& c : d->kids) c.blob_off = ~0ull;
             return;
@@ -587,6 +590,8 @@ struct ParallelWalker {
             end = c.blob_off + c.size;
             if (c.size == 0) continue;
             int fd = -1;
+            mi_io::content_opens.fetch_add(1, std::memory_order_relaxed);
+            mi_io::content_bytes.fetch_add(c.size, std::memory_order_relaxed);
             if (!fds.empty() && fds[ci] >= 0) { fd = fds[ci]; fds[ci] = -1; }
             else fd = openat(dfd, c.name.c_str(), O_RDONLY | O_CLOEXEC | O_NOFOLLOW);
             if (fd < 0) {
@@ -613,10 +618,15 @@ struct ParallelWalker {
     void worker() {
         const uint64_t tu0 = walk_timing() ? now_ns() : 0;
         own_table = false;
-        if (inline_reads && walk_unshare() && unshare(CLONE_FILES) == 0) { // a descriptor table of this thread's own (see above);
-            (void)syscall(SYS_close_range, 3u, ~0u, 0u);     // it starts empty: the copies of the process's descriptors go
+        // A descriptor table of this thread's own (see above), and an EMPTY one: close_range with CLOSE_RANGE_UNSHARE does both
+        // in one call -- the table is unshared and the copies of the process's descriptors go.  Where that call does not
+        // exist (kernels before 5.9: ENOSYS) or is refused (a seccomp profile), the thread STAYS on the shared table: a
+        // private table still full of the process's descriptors would hold the host's sockets and pipes open for the whole
+        // walk (a close on the host's side would send no FIN, reach no EOF) and would not have room for open_first's
+        // descriptors.  MI_WALK_CLOSE_RANGE=0 takes that way on purpose (tests).
+        if (inline_reads && walk_unshare() && walk_close_range() &&
+            syscall(SYS_close_range, 3u, ~0u, (unsigned)MI_CLOSE_RANGE_UNSHARE) == 0)
             own_table = true;
-        }
         if (tu0) g_ns_unshare += now_ns() - tu0;
         for (;;) {
             DirRec* d = nullptr;
@@ -767,14 +777,28 @@ int scan_walk_collect(const std::string& src, const std::string& link_root, Tree
     return w.rc;
 }
 
+// the same walk with a batch attached: the source's regular files are staged while it is listed (parallel enumeration,
+// small files read where they are listed), an entry's file_index = its row in the batch
+int scan_walk_collect_batch(const std::string& src, const std::string& link_root, Tree* out, std::string* err, mi_batch* b) {
+    Walker w;
+    w.batch = b;
+    w.rel_base = src;
+    w.mode = MI_TREE_SCAN;
+    w.tree = out;
+    w.link_root = link_root;
+    mi_batch_expect_host_bytes(b);
+    walk_root(&w, src);
+    w.flush_pending();
+    if (w.rc && err) *err = w.err;
+    return w.rc;
+}
+
 }  // namespace mi_walk
 
 
 using mi_walk::Tree;
 
 // the batch keeps its tree behind an opaque pointer (mi_api.hip owns the slot)
-extern "C" void** mi_batch_tree_slot(mi_batch* b);
-extern "C" void mi_set_error(mi_batch* b, const char* msg);
 
 extern "C" {
 

@@ -136,7 +136,7 @@ def test_headers_parse_into_prototypes_and_structs():
     pre = _preprocessed_headers()
     protos, types = _prototypes(pre), _structs(pre)
     assert protos["mi_ctx_create"] == 2 and protos["mi_batch_add_path"] == 4 and protos["mi_abi_version"] == 0
-    assert protos["mi_memfs_commit_layer"] == 8
+    assert protos["mi_memfs_commit_layer"] == 9
     assert {"device", "gear_seed", "mask_bits", "min_size", "max_size", "struct_size"} <= types["mi_config"]
     assert {"tar_sha256", "gzip_sha256", "gzip_bytes"} <= types["mi_layer_result"]
     assert "mi_ctx" in types and "mi_batch" in types and types["mi_ctx"] == set()
