@@ -697,6 +697,8 @@ class MemFS:
             cfg.flags |= LAYER_MODE_WITH_TYPE
         res, h, done = LayerResult(), C.c_void_p(), C.c_int()
         ctx = engine._h if engine is not None else None
+        if engine is not None:
+            engine._children.add(self)                        # the handle keeps a batch of that ctx: given back before it dies
         self._check(self._lib.mi_memfs_commit_layer(self._h, ctx, int(must_scan), cops, len(ops), C.byref(cfg), C.byref(res),
                                                     C.byref(h), C.byref(done)), "mi_memfs_commit_layer")
         if not done.value:
@@ -716,7 +718,10 @@ class MemFS:
         self._check(self._lib.mi_memfs_set_index(self._h, index._h if index is not None else None), "mi_memfs_set_index")
 
     def release_device(self):
-        self._check(self._lib.mi_memfs_release_device(self._h), "mi_memfs_release_device")
+        if self._h:
+            self._check(self._lib.mi_memfs_release_device(self._h), "mi_memfs_release_device")
+
+    free = release_device                                     # what Engine.close asks of its children
 
     def root_of(self, path):
         """the chunk root the tree holds for a path ("/"-rooted below the root), or None if it was never scanned"""
@@ -777,6 +782,17 @@ class Layer:
         keep = []
         arr = _entry_array([entry], keep)
         self._check(self._lib.mi_layer_add(self._h, arr, os.fsencode(src_path) if src_path is not None else None))
+
+    def add_batch_file(self, entry, batch, file_index):
+        """the entry with its content taken from a staged batch (the bytes the GPU scanned), not from a path"""
+        keep = []
+        arr = _entry_array([entry], keep)
+        self._check(self._lib.mi_layer_add_batch_file(self._h, arr, batch._h, file_index))
+
+    def io_counts(self):
+        o, b = C.c_uint64(), C.c_uint64()
+        self._check(self._lib.mi_layer_io_counts(self._h, C.byref(o), C.byref(b)))
+        return o.value, b.value
 
     def add_whiteout(self, deleted_path):
         self._check(self._lib.mi_layer_add_whiteout(self._h, os.fsencode(deleted_path)))
@@ -1201,6 +1217,21 @@ class Batch:
         out = np.zeros(max(n, 1), dtype=CHUNK_DTYPE)
         self._check(self._lib.mi_batch_chunks(self._h, out.ctypes.data, n))
         return out[:n]
+
+    def roots(self):
+        """the per-file chunk roots alone: an (n_files, 32) uint8 array"""
+        n = self.counts()[0]
+        out = np.zeros((max(n, 1), 32), dtype=np.uint8)
+        self._check(self._lib.mi_batch_roots(self._h, out.ctypes.data, n))
+        return out[:n]
+
+    def read_file(self, file_index, offset=0, length=None):
+        """bytes [offset, offset + length) of a staged file as they lie in HBM"""
+        if length is None:
+            raise ValueError("length")
+        out = np.zeros(max(length, 1), dtype=np.uint8)
+        self._check(self._lib.mi_batch_read_file(self._h, file_index, offset, out.ctypes.data, length))
+        return out[:length].tobytes()
 
     def chunks_view(self):
         """The chunk rows WITHOUT a copy: a numpy array over the batch's own pinned buffer, valid

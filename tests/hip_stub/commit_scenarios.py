@@ -1,0 +1,137 @@
+"""Scenarios for tests/test_host_commit_double.py: the HOST side of the content-aware commit (mi_memfs_commit_layer with a
+ctx) on the HIP test double.  Kernels do not run there -- every chunk root is the double's fill pattern, all alike -- so
+what is checked is what the host answers for: the walk hands every file to ONE batch, each file is opened and read once,
+the diff runs on the batch's rows, and the layer writer takes every file's bytes out of the arena (device memory = host
+memory here) from the place the file table says, whatever order the bytes arrived in.  The tar must equal the reference's
+commit (ctx == NULL), byte for byte.  Run with LD_PRELOAD=<the double>; prints one "OK <name>" line per scenario."""
+import base64
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import makisu_amd as M  # noqa: E402
+from commit_cases import commit_to_bytes, make_tree, proc_io, tar_members, write_file  # noqa: E402
+
+MTIME = 1_600_000_000
+
+
+def scenario_scan(tmp, eng):
+    root = os.path.join(tmp, "scan_root")
+    files = make_tree(root, seed=31, mtime=MTIME)
+    nonempty = [d for d in files.values() if d]
+    with M.MemFS(root) as fs, M.MemFS(root) as plain:
+        with M.MemFS(root) as probe:                                       # (digests only: nothing of the tar is read back here)
+            r0, _ = proc_io()
+            probe.commit_layer(must_scan=True, engine=eng, gzip_level=M.GZIP_OFF)
+            r1, _ = proc_io()
+        res, raw = commit_to_bytes(fs, tmp, "s0.tar", must_scan=True, engine=eng)
+        assert {n: d for n, m, d in tar_members(raw) if m.isfile()} == files
+        st = res["stats"]
+        total = sum(map(len, nonempty))
+        assert (st["n_scanned_files"], st["scanned_bytes"]) == (len(files), total), st
+        assert (st["files_opened"], st["file_bytes_read"]) == (len(nonempty), total), st      # one open, one read per file
+        assert total <= r1 - r0 <= total + (256 << 10), (r1 - r0, total)                        # ... as the kernel counts it
+        assert st["n_layer_files"] == len(files) and st["n_layer_entries"] == res["n_entries"]
+        res0, raw0 = commit_to_bytes(plain, tmp, "s0p.tar", must_scan=True)
+        assert raw0 == raw                                                                      # the reference's tar
+        assert res0["stats"]["files_opened"] == len(files) and res0["stats"]["file_bytes_read"] == total   # (its writer reads once
+                                                                                                             #  too, and opens empty files)
+        res, raw = commit_to_bytes(fs, tmp, "s1.tar", must_scan=True, engine=eng)
+        assert res["n_entries"] == 0 and raw == bytes(1024)
+        # a changed file (new mtime, new size): that file + its ancestors, its bytes from the arena of the REUSED batch
+        rel = "d03/nested/deeper/f003.bin"
+        new = os.urandom(len(files[rel]) + 77)
+        write_file(os.path.join(root, rel), new, 0o755, MTIME + 5)
+        os.utime(os.path.join(root, "d03/nested/deeper"), (MTIME, MTIME))
+        res, raw = commit_to_bytes(fs, tmp, "s2.tar", must_scan=True, engine=eng)
+        assert [e["relpath"] for e in res["layer"]] == ["d03", "d03/nested", "d03/nested/deeper", rel]
+        assert [(n, d) for n, m, d in tar_members(raw) if m.isfile()] == [(rel, new)]
+        res0, raw0 = commit_to_bytes(plain, tmp, "s2p.tar", must_scan=True)
+        assert raw0 == raw
+        # a deleted directory: one whiteout, nothing scanned for it
+        import shutil
+        shutil.rmtree(os.path.join(root, "d04"))
+        os.utime(root, (MTIME, MTIME))
+        res, raw = commit_to_bytes(fs, tmp, "s3.tar", must_scan=True, engine=eng)
+        assert [e["relpath"] for e in res["layer"]] == [".wh.d04"]
+        res0, raw0 = commit_to_bytes(plain, tmp, "s3p.tar", must_scan=True)
+        assert raw0 == raw
+        # the handle gives the device back and takes a fresh batch for the next commit
+        fs.release_device()
+        res, raw = commit_to_bytes(fs, tmp, "s4.tar", must_scan=True, engine=eng)
+        assert res["n_entries"] == 0 and res["stats"]["n_scanned_files"] == len(files) - 9
+    print("OK scan")
+
+
+def scenario_copy(tmp, eng):
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "build_context_c1.json")))["entries"]
+    src_root, root = os.path.join(tmp, "context"), os.path.join(tmp, "copy_root")
+    os.makedirs(root)
+    for e in gold:
+        write_file(os.path.join(src_root, "ctx", e["path"]), base64.b64decode(e["b64"]), 0o644, MTIME)
+    big = os.urandom(3_000_000)                                          # several pieces for the reader threads
+    write_file(os.path.join(src_root, "blob/big.bin"), big, 0o600, MTIME)
+    ops = [{"src_root": src_root, "srcs": ["ctx"], "dst": "/app/"},
+           {"src_root": src_root, "srcs": ["blob/big.bin"], "dst": "/opt/data/big.bin", "uid": 7, "gid": 8},
+           {"src_root": src_root, "srcs": ["ctx/simple", "blob"], "dst": "/both/"}]
+    with M.MemFS(root, now_sec=MTIME) as fs, M.MemFS(root, now_sec=MTIME) as plain:
+        res, raw = commit_to_bytes(fs, tmp, "c0.tar", ops=ops, engine=eng)
+        res0, raw0 = commit_to_bytes(plain, tmp, "c0p.tar", ops=ops)
+        assert raw == raw0
+        mem = {n: d for n, m, d in tar_members(raw) if m.isfile()}
+        assert mem["opt/data/big.bin"] == big == mem["both/big.bin"]
+        for e in gold:
+            assert mem["app/" + e["path"]] == base64.b64decode(e["b64"])
+        st = res["stats"]
+        n_simple = sum(1 for e in gold if e["path"].startswith("simple/"))
+        assert st["n_scanned_files"] == 28 + 1 + n_simple + 1, st          # every op's sources, as often as they are copied
+        assert st["n_layer_files"] == st["n_scanned_files"]
+        # an op that fails where the reference's loop fails: after the ops before it
+        bad = ops[:1] + [{"src_root": src_root, "srcs": ["nope"], "dst": "/x/"}]
+        try:
+            fs.commit_layer(ops=bad, engine=eng)
+            raise SystemExit("a missing source did not fail the commit")
+        except M.MiError as ex:
+            assert "create layer by copy ops: stat src" in str(ex), str(ex)
+        res, raw = commit_to_bytes(fs, tmp, "c1.tar", ops=ops[:1], engine=eng)
+        assert [e["relpath"] for e in res["layer"]] == ["app"]
+    print("OK copy")
+
+
+def scenario_many(tmp, eng):
+    """a few thousand small files in few directories + some large ones, committed twice through one reused batch"""
+    root = os.path.join(tmp, "many_root")
+    rng = np.random.default_rng(2)
+    files = {}
+    for d in range(4):
+        for k in range(700):
+            rel = "m%d/f%04d" % (d, k)
+            size = int(rng.integers(0, 9000)) if k % 50 else int(rng.integers(20_000, 900_000))
+            data = rng.integers(0, 256, size, dtype=np.uint8).tobytes()
+            write_file(os.path.join(root, rel), data, 0o644, MTIME)
+            files[rel] = data
+    with M.MemFS(root) as fs:
+        res, raw = commit_to_bytes(fs, tmp, "m0.tar", must_scan=True, engine=eng)
+        assert {n: d for n, m, d in tar_members(raw) if m.isfile()} == files
+        nonempty = sum(1 for d in files.values() if d)
+        assert res["stats"]["files_opened"] == nonempty
+        victims = ["m1/f0007", "m2/f0050", "m3/f0699"]
+        for rel in victims:
+            files[rel] = os.urandom(len(files[rel]) + 3)
+            write_file(os.path.join(root, rel), files[rel], 0o644, MTIME + 1)
+        res, raw = commit_to_bytes(fs, tmp, "m1.tar", must_scan=True, engine=eng)
+        assert {n: d for n, m, d in tar_members(raw) if m.isfile()} == {r: files[r] for r in victims}
+    print("OK many")
+
+
+if __name__ == "__main__":
+    tmp, threads = sys.argv[1], int(sys.argv[2])
+    with M.Engine(n_streams=threads, staging_bytes=1 << 20) as eng:
+        scenario_scan(tmp, eng)
+        scenario_copy(tmp, eng)
+        scenario_many(tmp, eng)

@@ -1,0 +1,389 @@
+"""GPU tests of THE SEAM as one flow: mi_memfs_commit_layer with a ctx -- walk -> stage -> Gear CDC + SHA-256 on the GPU ->
+createLayerByScan / addToLayer with the chunk roots -> layer tar written from HBM -> DigestPair (+ roots, + chunk index).
+
+Reference behaviour it carries: MemFS.AddLayerByScan / AddLayerByCopyOps (lib/snapshot/mem_fs.go:260-341), isUpdated
+(:487-503 -> tario.IsSimilarHeader, lib/tario/compare.go:24-120), step.commitLayer (lib/builder/step/common.go:67-111),
+tario.WriteEntry (lib/tario/write.go:28-52); replayed cases: TestCreateLayerByScan (mem_fs_test.go:572-686),
+TestAddLayerByScanWhiteout (:1038-1116), C1 = testdata/build-context as a COPY layer.  The oracle (oracle/) is the
+checker for every chunk root; hashlib for every digest; python's tarfile for every member."""
+import base64
+import hashlib
+import json
+import os
+import shutil
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in (ROOT, os.path.join(ROOT, "tests")):                   # (also run as a script, one scenario per process)
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+import makisu_amd as M  # noqa: E402
+from commit_cases import commit_to_bytes, make_tree, oracle_root, proc_io, tar_members, write_file  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+MTIME = 1_600_000_000
+
+
+@pytest.fixture(scope="module")
+def eng():
+    with M.Engine(device=0) as e:
+        yield e
+
+
+def _check_commit_zero(O, eng, root, files, tmp):
+    """case (a): every file of a fresh tree in the layer with its bytes; every stored root = the oracle's"""
+    with M.MemFS(root) as fs, M.MemFS(root) as plain:
+        res, raw = commit_to_bytes(fs, tmp, "l0.tar", must_scan=True, engine=eng)
+        members = tar_members(raw)
+        got = {name: data for name, m, data in members if m.isfile()}
+        assert got == files                                                  # exactly the files, exactly their bytes -- from HBM
+        names = [n for n, _, _ in members]
+        assert names == sorted(names)                                        # rangeFiles' order
+        st = res["stats"]
+        nonempty = [d for d in files.values() if d]
+        assert st["n_scanned_files"] == len(files) and st["scanned_bytes"] == sum(map(len, nonempty))
+        assert st["n_layer_files"] == len(files) and st["layer_file_bytes"] == st["scanned_bytes"]
+        assert st["files_opened"] == len(nonempty) and st["file_bytes_read"] == st["scanned_bytes"]   # ONE open, ONE read each
+        assert st["n_content_changed"] == 0 and st["n_roots_learned"] == 0
+        by = {e["relpath"]: e for e in res["layer"]}
+        for rel, data in files.items():
+            want = oracle_root(O, data)
+            assert by[rel]["root"] == want, rel                              # the layer's record of the file
+            assert fs.root_of("/" + rel) == want, rel                        # ... and the tree's, for the next isUpdated
+        assert fs.root_of("/rel_link") is None and "root" not in by["empty_dir"]
+        # ctx == NULL on the same tree: the reference's commit -- the same tar, byte for byte
+        res0, raw0 = commit_to_bytes(plain, tmp, "l0_plain.tar", must_scan=True)
+        assert raw0 == raw and res0["tar_digest"] == res["tar_digest"]
+        assert all("root" not in e for e in res0["layer"]) and res0["stats"]["n_scanned_files"] == 0
+        # nothing changed since: the empty layer, both ways
+        for f, kw in ((fs, {"engine": eng}), (plain, {})):
+            r, b = commit_to_bytes(f, tmp, "l1.tar", must_scan=True, **kw)
+            assert r["n_entries"] == 0 and b == bytes(1024)
+    return res
+
+
+def test_commit_zero_every_root_is_the_oracles_and_the_tar_is_the_files(oracle, eng, tmp_path):
+    root = str(tmp_path / "root")
+    files = make_tree(root, seed=11, mtime=MTIME)
+    assert any(len(d) > 16384 for d in files.values()) and any(0 < len(d) <= 16384 for d in files.values())
+    assert any(len(d) == 0 for d in files.values())
+    _check_commit_zero(oracle, eng, root, files, tmp_path)
+
+
+@pytest.mark.parametrize("env", [{"MI_WALK_INLINE": "0"}, {"MI_WALK_INLINE_MAX_KIB": "2"}, {"MI_WALK_THREADS": "1"},
+                                 {"MI_WALK_INLINE_MB": "1"}, {"MI_WALK_CLOSE_RANGE": "0"}])
+def test_commit_zero_whichever_way_the_bytes_reach_the_arena(env, tmp_path):
+    """case (f): where a file lies in the arena is independent of its row -- small files travel in their directory's block,
+    larger ones as paths through the reader threads, in whatever order those finish.  The walk's knobs move that boundary
+    (they are read once per process: a process of its own per setting); every root must still land on its node."""
+    p = subprocess.run([sys.executable, os.path.abspath(__file__), str(tmp_path)], env=dict(os.environ, **env),
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "OK commit_zero" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
+
+
+def _rewrite_same_size_same_second(path, rng):
+    st = os.stat(path)
+    data = rng.integers(0, 256, st.st_size, dtype=np.uint8).tobytes()
+    with open(path, "r+b") as f:
+        f.write(data)
+    os.utime(path, ns=(st.st_atime_ns, st.st_mtime_ns))
+    st2 = os.stat(path)
+    assert (st2.st_size, st2.st_mtime_ns, st2.st_mode, st2.st_uid) == (st.st_size, st.st_mtime_ns, st.st_mode, st.st_uid)
+    return data
+
+
+def test_a_same_size_same_second_edit_is_in_the_layer_only_with_the_gpu(oracle, eng, tmp_path):
+    """case (b): the edit tario.IsSimilarHeader cannot see (compare.go:101-103 "ignores path and content").  With a ctx the
+    next commit holds exactly that file and its ancestors; with ctx == NULL it holds nothing -- the reference's answer."""
+    root = str(tmp_path / "root")
+    files = make_tree(root, seed=12, mtime=MTIME)
+    rng = np.random.default_rng(5)
+    with M.MemFS(root) as fs, M.MemFS(root) as plain:
+        commit_to_bytes(fs, tmp_path, "a.tar", must_scan=True, engine=eng)
+        commit_to_bytes(plain, tmp_path, "b.tar", must_scan=True)
+        for rel in ("d01/nested/deeper/f003.bin", "d02/f001.bin"):           # one above the inline limit, one below
+            new = _rewrite_same_size_same_second(os.path.join(root, rel), rng)
+            assert new != files[rel] and len(new) == len(files[rel])
+            files[rel] = new
+            res, raw = commit_to_bytes(fs, tmp_path, "a1.tar", must_scan=True, engine=eng)
+            parts = rel.split("/")
+            want = ["/".join(parts[:k]) for k in range(1, len(parts) + 1)]
+            assert [e["relpath"] for e in res["layer"]] == want               # the file + its ancestors, nothing else
+            assert res["stats"]["n_content_changed"] == 1 and res["stats"]["n_layer_files"] == 1
+            assert [(n, d) for n, m, d in tar_members(raw) if m.isfile()] == [(rel, new)]
+            assert res["layer"][-1]["root"] == oracle_root(oracle, new) == fs.root_of("/" + rel)
+            res0, raw0 = commit_to_bytes(plain, tmp_path, "b1.tar", must_scan=True)
+            assert res0["n_entries"] == 0 and raw0 == bytes(1024)             # invisible without the content scan
+            r, b = commit_to_bytes(fs, tmp_path, "a2.tar", must_scan=True, engine=eng)
+            assert r["n_entries"] == 0 and b == bytes(1024)                   # and seen once
+
+
+def test_roots_are_learned_by_the_first_content_scan_of_an_unchanged_tree(oracle, eng, tmp_path):
+    """A tree committed WITHOUT a ctx (or merged from a base layer) holds no roots.  The first commit with a ctx finds every
+    header unchanged -- an empty layer -- and keeps the roots it computed; from then on content is watched."""
+    root = str(tmp_path / "root")
+    files = make_tree(root, seed=13, mtime=MTIME)
+    rng = np.random.default_rng(6)
+    with M.MemFS(root) as fs:
+        commit_to_bytes(fs, tmp_path, "p.tar", must_scan=True)                # the reference's commit: no roots
+        assert fs.root_of("/d00/f001.bin") is None
+        res, raw = commit_to_bytes(fs, tmp_path, "q.tar", must_scan=True, engine=eng)
+        assert res["n_entries"] == 0 and res["stats"]["n_roots_learned"] == len(files)
+        assert fs.root_of("/d00/f001.bin") == oracle_root(oracle, files["d00/f001.bin"])
+        new = _rewrite_same_size_same_second(os.path.join(root, "d00/f001.bin"), rng)
+        res, raw = commit_to_bytes(fs, tmp_path, "r.tar", must_scan=True, engine=eng)
+        assert [e["relpath"] for e in res["layer"]] == ["d00", "d00/f001.bin"] and res["stats"]["n_roots_learned"] == 0
+        assert fs.root_of("/d00/f001.bin") == oracle_root(oracle, new)
+    # the same through a base layer's headers: UpdateFromTarReader gives the tree its nodes, the first scan their roots
+    with M.MemFS(root) as fs:
+        fs.update_from_entries(M.tree_walk(root, root, (), M.TREE_SCAN, full=True)[1:])
+        res, _ = commit_to_bytes(fs, tmp_path, "s.tar", must_scan=True, engine=eng)
+        assert res["n_entries"] == 0 and res["stats"]["n_roots_learned"] == len(files)
+
+
+def test_scan_cases_of_the_reference_through_the_one_call(oracle, eng, tmp_path):
+    """case (c): TestAddLayerByScanWhiteout + TestCreateLayerByScan's Simple / Symlink / Whiteout, a hard link, a blacklisted
+    directory -- the layer's paths are the reference's, whatever computes the diff"""
+    root = str(tmp_path / "root")
+    for p in ("test1/test2/test3.txt", "test1/test4/test5/test6.txt"):
+        write_file(os.path.join(root, p), b"hello", 0o755)
+    names = lambda res: ["/" + e["relpath"] for e in res["layer"]]            # noqa: E731
+    with M.MemFS(root) as fs:
+        res, raw = commit_to_bytes(fs, tmp_path, "w0.tar", must_scan=True, engine=eng)
+        assert names(res) == ["/test1", "/test1/test2", "/test1/test2/test3.txt", "/test1/test4", "/test1/test4/test5",
+                              "/test1/test4/test5/test6.txt"]
+        a, b = res["layer"][2], res["layer"][5]
+        assert a["root"] == b["root"] == oracle_root(oracle, b"hello")         # equal content, equal roots
+        shutil.rmtree(os.path.join(root, "test1"))
+        res, raw = commit_to_bytes(fs, tmp_path, "w1.tar", must_scan=True, engine=eng)
+        assert names(res) == ["/.wh.test1"] and res["stats"]["n_scanned_files"] == 0
+        assert [(n, m.size) for n, m, _ in tar_members(raw)] == [(".wh.test1", 0)]
+        assert fs.entries() == []
+    root = str(tmp_path / "root2")
+    write_file(os.path.join(root, "test1/test2/test3.txt"), b"hello", 0o755)
+    os.symlink("test2/test3.txt", os.path.join(root, "test1/link"))
+    os.symlink(os.path.join(root, "test1/test2"), os.path.join(root, "test1/abs"))
+    os.link(os.path.join(root, "test1/test2/test3.txt"), os.path.join(root, "test1/hard"))
+    write_file(os.path.join(root, "skipme/secret.bin"), b"x" * 5000)
+    write_file(os.path.join(root, "test1/.wh..wh.aufs"), b"meta")              # AUFS metadata: shouldSkip
+    with M.MemFS(root, blacklist=[os.path.join(root, "skipme")]) as fs:
+        res, raw = commit_to_bytes(fs, tmp_path, "x0.tar", must_scan=True, engine=eng)
+        by = {"/" + e["relpath"]: e for e in res["layer"]}
+        assert sorted(by) == ["/test1", "/test1/abs", "/test1/hard", "/test1/link", "/test1/test2", "/test1/test2/test3.txt"]
+        assert by["/test1/link"]["link_target"] == "test2/test3.txt" and by["/test1/abs"]["link_target"] == "/test1/test2"
+        assert by["/test1/hard"]["root"] == by["/test1/test2/test3.txt"]["root"] == oracle_root(oracle, b"hello")
+        assert res["stats"]["n_scanned_files"] == 2                            # two names of one inode; nothing of skipme
+        os.unlink(os.path.join(root, "test1/test2/test3.txt"))
+        res, raw = commit_to_bytes(fs, tmp_path, "x1.tar", must_scan=True, engine=eng)
+        assert names(res) == ["/test1", "/test1/test2", "/test1/test2/.wh.test3.txt"]
+        assert [e["relpath"] for e in fs.entries()] == ["test1", "test1/abs", "test1/hard", "test1/link", "test1/test2"]
+
+
+def test_c1_build_context_as_a_copy_layer(oracle, eng, tmp_path):
+    """case (d): BASELINE.json configs[0]'s tree (testdata/build-context, carried by tests/golden/build_context_c1.json) as
+    the layer of `COPY ctx /app/`: members, bytes (SHA-256 per file as the fixture states), roots; the same COPY again adds
+    only the destination chain; a same-size same-second edit of one source is in the third layer -- and is not without a
+    ctx."""
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "build_context_c1.json")))["entries"]
+    src_root, root = str(tmp_path / "context"), str(tmp_path / "root")
+    os.makedirs(root)
+    for e in gold:
+        write_file(os.path.join(src_root, "ctx", e["path"]), base64.b64decode(e["b64"]), 0o644, MTIME)
+    for dp, _, _ in os.walk(src_root):
+        os.utime(dp, (MTIME, MTIME))
+    op = {"src_root": src_root, "srcs": ["ctx"], "dst": "/app/", "uid": 0, "gid": 0}
+    with M.MemFS(root, now_sec=MTIME) as fs, M.MemFS(root, now_sec=MTIME) as plain:
+        res, raw = commit_to_bytes(fs, tmp_path, "c0.tar", ops=[op], engine=eng)
+        res0, raw0 = commit_to_bytes(plain, tmp_path, "c0p.tar", ops=[op])
+        assert raw == raw0                                                     # the reference's layer, byte for byte
+        members = tar_members(raw)
+        assert {n: hashlib.sha256(d).hexdigest() for n, m, d in members if m.isfile()} == {"app/" + e["path"]: e["sha256"] for e in gold}
+        st = res["stats"]
+        assert st["n_scanned_files"] == 28 and st["scanned_bytes"] == 10355 and st["files_opened"] == sum(1 for e in gold if e["size"])
+        for e in res["layer"]:
+            if e["kind"] == M.KIND_FILE:
+                data = base64.b64decode(next(g["b64"] for g in gold if "app/" + g["path"] == e["relpath"]))
+                assert e["root"] == oracle_root(oracle, data) == fs.root_of("/" + e["relpath"]), e["relpath"]
+                assert e["src"] == os.path.join(src_root, "ctx", e["relpath"][len("app/"):])
+        res, raw = commit_to_bytes(fs, tmp_path, "c1.tar", ops=[op], engine=eng)
+        assert [e["relpath"] for e in res["layer"]] == ["app"]                 # addAncestors(inclusive) only
+        victim = next(g for g in gold if g["size"] > 100)
+        new = _rewrite_same_size_same_second(os.path.join(src_root, "ctx", victim["path"]), np.random.default_rng(9))
+        res, raw = commit_to_bytes(fs, tmp_path, "c2.tar", ops=[op], engine=eng)
+        got = [(n, d) for n, m, d in tar_members(raw) if m.isfile()]
+        assert got == [("app/" + victim["path"], new)] and res["stats"]["n_content_changed"] == 1
+        commit_to_bytes(plain, tmp_path, "c1p.tar", ops=[op])
+        res0, raw0 = commit_to_bytes(plain, tmp_path, "c2p.tar", ops=[op])
+        assert [e["relpath"] for e in res0["layer"]] == ["app"]                # the reference does not see it
+
+
+def test_copy_ops_errors_keep_their_place(eng, tmp_path):
+    """an op whose source does not exist fails the commit with the reference's chain, after the ops before it were applied"""
+    src_root, root = str(tmp_path / "context"), str(tmp_path / "root")
+    os.makedirs(root)
+    write_file(os.path.join(src_root, "a/x.bin"), b"x" * 3000)
+    ops = [{"src_root": src_root, "srcs": ["a"], "dst": "/one/"}, {"src_root": src_root, "srcs": ["missing"], "dst": "/two/"}]
+    with M.MemFS(root) as fs:
+        with pytest.raises(M.MiError) as ei:
+            fs.commit_layer(ops=ops, engine=eng)
+        assert "failed to generate diff layer: write diffs: create layer by copy ops: stat src" in str(ei.value)
+        assert "one/x.bin" in [e["relpath"] for e in fs.entries()]            # op 1 was applied, as in the interleaved loop
+        assert fs.commit_layer(ops=ops[:1], engine=eng)["n_entries"] == 1      # the handle stays usable: only /one again
+
+
+def test_the_tar_holds_the_bytes_the_root_describes_while_a_file_is_being_rewritten(oracle, eng, tmp_path):
+    """One read per file: a writer keeps rewriting a file (same size) while commits run.  Whatever instant the stager
+    caught, the tar holds THOSE bytes and the stored root is the oracle's root of exactly them (write.go:43-45 reads a file
+    once; a design that reads it a second time for the tar commits bytes its root does not describe)."""
+    root = str(tmp_path / "root")
+    files = make_tree(root, seed=14, n_dirs=2, mtime=MTIME)
+    hot = os.path.join(root, "d00/hot.bin")
+    size = 3 << 20
+    write_file(hot, bytes(size))
+    stop = threading.Event()
+
+    def writer():
+        rng = np.random.default_rng(1)
+        fd = os.open(hot, os.O_WRONLY)
+        while not stop.is_set():
+            os.pwrite(fd, rng.integers(0, 256, size, dtype=np.uint8).tobytes(), 0)
+        os.close(fd)
+    th = threading.Thread(target=writer)
+    th.start()
+    try:
+        seen = set()
+        with M.MemFS(root) as fs:
+            for k in range(8):
+                res, raw = commit_to_bytes(fs, tmp_path, "h%d.tar" % k, must_scan=True, engine=eng)
+                mem = {n: d for n, m, d in tar_members(raw) if m.isfile()}
+                if "d00/hot.bin" not in mem:
+                    continue                                                   # caught between two rewrites: unchanged
+                e = next(x for x in res["layer"] if x["relpath"] == "d00/hot.bin")
+                assert e["root"] == oracle_root(oracle, mem["d00/hot.bin"]) == fs.root_of("/d00/hot.bin")
+                seen.add(e["root"])
+        assert len(seen) >= 2                                                  # the file did move under the commits
+    finally:
+        stop.set()
+        th.join()
+
+
+def test_every_file_is_read_once_as_the_kernel_counts_it(eng, tmp_path):
+    """/proc/self/io around a commit of 64 MiB in files of every size: the process read the files' bytes ONCE (rchar), with
+    a ctx; the reference's commit reads them once too (the tar writer); the GPU commit must not read them twice."""
+    root = str(tmp_path / "root")
+    rng = np.random.default_rng(3)
+    total = 0
+    for i in range(160):
+        size = int(rng.integers(100_000, 700_000))
+        write_file(os.path.join(root, "d%d/f%03d" % (i % 7, i)), rng.integers(0, 256, size, dtype=np.uint8).tobytes())
+        total += size
+    with M.MemFS(root) as fs:
+        r0, _ = proc_io()
+        res = fs.commit_layer(must_scan=True, engine=eng, gzip_level=M.GZIP_OFF)
+        r1, _ = proc_io()
+        assert res["stats"]["file_bytes_read"] == total and res["stats"]["files_opened"] == 160
+        assert total <= r1 - r0 <= total + total // 50 + (1 << 20), (r1 - r0, total)
+
+
+def test_the_commit_feeds_the_chunk_index(oracle, eng, tmp_path):
+    """mi_memfs_set_index: the batch of every content-aware commit joins the index (keyvalue.Store seam) -- a second tree
+    with the same content is all known chunks"""
+    a, b = str(tmp_path / "a"), str(tmp_path / "b")
+    make_tree(a, seed=15, mtime=MTIME)
+    make_tree(b, seed=15, mtime=MTIME)
+    with eng.index() as idx, M.MemFS(a) as fa, M.MemFS(b) as fb:
+        fa.set_index(idx)
+        fb.set_index(idx)
+        ra = fa.commit_layer(must_scan=True, engine=eng)
+        assert ra["stats"]["n_index_known"] == 0 and ra["stats"]["n_index_new"] == len(idx) > 0
+        rb = fb.commit_layer(must_scan=True, engine=eng)
+        assert rb["stats"]["n_index_new"] == 0 and rb["stats"]["n_chunks"] >= rb["stats"]["n_index_known"] > 0
+        assert rb["tar_digest"] == ra["tar_digest"]
+
+
+def test_read_file_serves_any_range_of_any_staged_file(eng):
+    """mi_batch_read_file against the bytes that were added: whole files, ranges across window boundaries, backwards"""
+    rng = np.random.default_rng(8)
+    sizes = [0, 1, 511, 4096, 300_000, 9_000_000, 70_000, 13 << 20]
+    blobs = [rng.integers(0, 256, n, dtype=np.uint8).tobytes() for n in sizes]
+    with eng.batch() as b:
+        for d in blobs:
+            b.add_bytes(d)
+        with pytest.raises(M.MiError):
+            b.read_file(0, 0, 0)                                               # not staged yet
+        b.run()
+        for i in (7, 0, 3, 5, 4, 1, 6, 2):
+            assert b.read_file(i, 0, sizes[i]) == blobs[i]
+        for _ in range(200):
+            i = int(rng.integers(1, len(sizes)))
+            off = int(rng.integers(0, sizes[i]))
+            n = int(rng.integers(0, min(sizes[i] - off, 3 << 20) + 1))
+            assert b.read_file(i, off, n) == blobs[i][off:off + n]
+        assert (b.roots() == b.files()["chunk_root"]).all()
+        for bad in ((len(sizes), 0, 1), (1, 2, 0), (2, 500, 12)):
+            with pytest.raises(M.MiError):
+                b.read_file(*bad)
+
+
+def test_the_layer_writer_takes_content_from_a_batch(eng, tmp_path):
+    """mi_layer_add_batch_file: the same tar as mi_layer_add from the path; a size that is not the staged one is refused"""
+    rng = np.random.default_rng(4)
+    paths = []
+    for i, n in enumerate([5, 70_000, 0, 2_500_000]):
+        p = str(tmp_path / ("f%d" % i))
+        write_file(p, rng.integers(0, 256, n, dtype=np.uint8).tobytes())
+        paths.append((p, n))
+    E = lambda i: {"relpath": "x/f%d" % i, "kind": M.KIND_FILE, "mode": 0o100644, "mtime_sec": 7, "size": paths[i][1]}   # noqa: E731
+    with eng.batch() as b:
+        b.add_paths([p for p, _ in paths])
+        b.run()
+        with M.Layer(gzip_level=M.GZIP_OFF) as la, M.Layer(gzip_level=M.GZIP_OFF) as lb:
+            for i, (p, n) in enumerate(paths):
+                la.add(E(i), p)
+                lb.add_batch_file(E(i), b, i)
+            assert la.io_counts() == (4, sum(n for _, n in paths)) and lb.io_counts() == (0, 0)
+            with pytest.raises(M.MiError) as ei:
+                lb.add_batch_file(dict(E(1), size=69_999), b, 1)
+            assert "staged file has 70000" in str(ei.value)
+            ra = la.finish()
+        with M.Layer(gzip_level=M.GZIP_OFF) as lc:
+            for i in range(4):
+                lc.add_batch_file(E(i), b, i)
+            assert lc.finish()["tar_digest"] == ra["tar_digest"]
+
+
+def test_the_commit_from_plain_c(eng, tmp_path):
+    """case (e): tests/cabi/commit_driver.c -- ctx, MemFS handle, ONE call per commit, the DigestPair and the stats printed;
+    the digests are the ones the Python host gets for the same tree"""
+    exe = str(tmp_path / "commit_driver")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-O1", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cabi", "commit_driver.c"), "-o", exe,
+                           "-L", os.path.join(ROOT, "makisu_amd"), "-lmakisu_mi", "-Wl,-rpath," + os.path.join(ROOT, "makisu_amd")])
+    root = str(tmp_path / "root")
+    make_tree(root, seed=16, mtime=MTIME)
+    victim = os.path.join(root, "d02/f001.bin")
+    out = subprocess.run([exe, root, victim], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = dict(ln.split(" ", 1) for ln in out.stdout.splitlines())
+    assert lines["C0"].split()[0] == lines["P0"].split()[0] != lines["C2"].split()[0]   # with and without a ctx: one tar
+    assert lines["C1"].split()[0] == hashlib.sha256(bytes(1024)).hexdigest()   # nothing changed: the empty layer
+    c2 = lines["C2"].split()
+    assert c2[1] == "entries=2" and c2[2] == "content_changed=1", lines["C2"]  # d02 + the rewritten file
+    c3 = lines["P2"].split()
+    assert c3[1] == "entries=0", lines["P2"]                                   # the same edit without a ctx: nothing
+
+
+if __name__ == "__main__":                                                     # one scenario in a process of its own
+    from oracle import mi_oracle as O
+    O.build()
+    tmp = sys.argv[1]
+    root = os.path.join(tmp, "root")
+    files = make_tree(root, seed=21, mtime=MTIME)
+    with M.Engine(device=0) as e:
+        _check_commit_zero(O, e, root, files, tmp)
+    print("OK commit_zero")

@@ -1,0 +1,37 @@
+"""The HOST side of the content-aware commit -- mi_memfs_commit_layer with a ctx: walk + stage into one batch, the diff on
+the batch's rows, the layer tar written from the arena (lib/snapshot/mem_fs.go:260-341 + lib/builder/step/common.go:67-111
++ lib/tario/write.go:28-52 as one flow) -- on the HIP test double, here, without a GPU (tests/hip_stub/commit_scenarios.py
+says what the double can and cannot show; the roots themselves are tests/test_gpu_commit.py's business)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from test_host_hip_double import STUB_DIR, hip_double  # noqa: F401  (the fixture builds the double when stale)
+
+WANT = ["OK scan", "OK copy", "OK many"]
+
+
+def _run(stub, tmp, threads, extra_env=None):
+    env = dict(os.environ, LD_PRELOAD=(os.environ.get("LD_PRELOAD", "") + " " + stub).strip())
+    env.update(extra_env or {})
+    p = subprocess.run([sys.executable, os.path.join(STUB_DIR, "commit_scenarios.py"), str(tmp), str(threads)], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    assert [ln for ln in p.stdout.splitlines() if ln.startswith("OK ")] == WANT
+
+
+@pytest.mark.parametrize("threads", [1, 4, 16])
+def test_the_commit_reads_each_file_once_and_writes_the_references_tar(hip_double, tmp_path, threads):  # noqa: F811
+    _run(hip_double, tmp_path, threads)
+
+
+@pytest.mark.parametrize("env", [{"MI_WALK_INLINE": "0"}, {"MI_WALK_INLINE_MAX_KIB": "2"}, {"MI_WALK_THREADS": "1"},
+                                 {"MI_WALK_INLINE_MB": "1"}, {"MI_WALK_UNSHARE": "0"}, {"MI_WALK_CLOSE_RANGE": "0"},
+                                 {"MI_HIP_STUB_COPY_US": "50"}])
+def test_whichever_way_the_bytes_reach_the_arena(hip_double, tmp_path, env):  # noqa: F811
+    """the walk's knobs move files between the two ways into the arena (a directory's block / a path for the reader threads)
+    and change the order in which bytes land; MI_WALK_CLOSE_RANGE=0 is the kernel without close_range (the
+    directory readers then stay on the shared descriptor table); slow copies widen every window"""
+    _run(hip_double, tmp_path, 4, env)
