@@ -400,14 +400,13 @@ int submit_pipeline_enqueue(mi_batch* b) {
     u32* d_cursor = (u32*)(ctl + kCtlCursorOff);
     u32* d_hist = (u32*)(ctl + kCtlHistOff);
     const u64* d_n = d_total;
-    const int ncu = b->n_cu ? b->n_cu : c->prop.multiProcessorCount;
+    const int ncu = c->prop.multiProcessorCount;
     // Pin the hashing workgroups to their CUs (sha256.hip launch_sha256_items) when this batch has the GPU to
     // itself: a crowded CU then costs the launch up to 25 %.  With another batch in flight the passes of the
     // two fill each other's gaps, the step is the same either way (5.8 ms on C2), and the unused LDS the pin
     // reserves would only keep the other batch's Gear workgroups off the CU (measured: -1.3 %).
     ShaTune sha = c->sha;
-    sha.pin_blocks_per_cu = c->sha.pin_blocks_per_cu && (c->batches_in_flight == 0 || b->n_cu);   // (a batch with CUs of its
-                                                                                                 //  own has them to itself)
+    sha.pin_blocks_per_cu = c->sha.pin_blocks_per_cu && c->batches_in_flight == 0;
 
     HIPCHK(c, hipEventRecord(b->ev[0], s));
     HIPCHK(c, hipMemsetAsync(ctl, 0, kCtlBytes, s));
@@ -649,45 +648,6 @@ const char* mi_last_error(mi_ctx* ctx) {
     return copy.c_str();
 }
 
-// MI_BATCH_CU_MASKS="0-127,128-255" / "0-63+128-191,64-127+192-255": one comma-separated set of compute units per batch
-// in flight, a set = '+'-joined `a-b` ranges or single numbers (bit i of the mask = compute unit i as the runtime counts
-// them).  Anything malformed or out of the device's range leaves the knob off: an experiment must not half-apply.
-static void parse_cu_masks(mi_ctx* c, const char* s) {
-    const int ncu = c->prop.multiProcessorCount;
-    if (ncu <= 0 || !*s) return;
-    std::vector<std::vector<u32>> masks;
-    std::vector<int> counts;
-    const char* p = s;
-    for (;;) {
-        std::vector<u32> m((size_t)(ncu + 31) / 32, 0u);
-        int n = 0;
-        for (;;) {
-            char* end = nullptr;
-            const long a = strtol(p, &end, 10);
-            if (end == p) return;
-            long b = a;
-            p = end;
-            if (*p == '-') {
-                b = strtol(p + 1, &end, 10);
-                if (end == p + 1) return;
-                p = end;
-            }
-            if (a < 0 || b < a || b >= ncu) return;
-            for (long i = a; i <= b; ++i)
-                if (!(m[(size_t)i >> 5] >> (i & 31) & 1u)) { m[(size_t)i >> 5] |= 1u << (i & 31); ++n; }
-            if (*p != '+') break;
-            ++p;
-        }
-        masks.push_back(std::move(m));
-        counts.push_back(n);
-        if (*p == 0) break;
-        if (*p != ',') return;
-        ++p;
-    }
-    c->batch_cu_masks = std::move(masks);
-    c->batch_cu_counts = std::move(counts);
-}
-
 int mi_ctx_create(const mi_config* cfg, mi_ctx** out) {
     if (!cfg || !out) return fail(nullptr, MI_ERR_INVALID, "mi_ctx_create: null argument");
     if (cfg->struct_size != sizeof(mi_config))
@@ -740,7 +700,6 @@ int mi_ctx_create(const mi_config* cfg, mi_ctx** out) {
     for (auto& e : c->ev) CREATE_CHK(hipEventCreate(&e));
     CREATE_CHK(hipEventCreateWithFlags(&c->sha_done, hipEventDisableTiming));
     if (const char* e = getenv("MI_SHA_SERIALIZE")) c->serialize_sha = atoi(e) != 0;
-    if (const char* e = getenv("MI_BATCH_CU_MASKS")) parse_cu_masks(c, e);
     // host-fed staging (mi_stage.hip): slab bytes and reader threads; both lazily allocated
     c->staging_bytes = cfg->staging_bytes ? cfg->staging_bytes : (8ull << 20);
     if (c->staging_bytes < (1ull << 16)) c->staging_bytes = 1ull << 16;
@@ -871,14 +830,7 @@ int mi_batch_begin(mi_ctx* c, uint64_t n_files_hint, uint64_t bytes_hint, mi_bat
     memset(&b->stats, 0, sizeof b->stats);
     memset(&b->stage_stats, 0, sizeof b->stage_stats);
     b->files.reserve(n_files_hint);
-    hipError_t e = hipErrorUnknown;
-    if (!c->batch_cu_masks.empty()) {                   // MI_BATCH_CU_MASKS: this batch's share of the compute units
-        const size_t k = c->next_cu_mask++ % c->batch_cu_masks.size();
-        e = hipExtStreamCreateWithCUMask(&b->stream, (uint32_t)c->batch_cu_masks[k].size(), c->batch_cu_masks[k].data());
-        if (e == hipSuccess) b->n_cu = c->batch_cu_counts[k];
-        else (void)hipGetLastError();                   // a runtime without it: the whole device, as always
-    }
-    if (e != hipSuccess) e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+    hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
     for (auto& ev : b->ev) if (e == hipSuccess) e = hipEventCreate(&ev);
     if (e == hipSuccess) e = hipHostMalloc((void**)&b->h_counts, 16, hipHostMallocDefault);
     ++c->live_children;                                 // mi_batch_free undoes it (error paths included)

@@ -99,11 +99,6 @@ struct mi_ctx {
     hipEvent_t sha_done = nullptr;       // end of the last chunk pass submitted on this ctx, whatever the batch
     bool sha_done_set = false;           // (the next one waits for it: mi_api.hip submit_pipeline)
     bool serialize_sha = false;          // MI_SHA_SERIALIZE=0: let the chunk passes of two batches overlap
-    // MI_BATCH_CU_MASKS (experiments; unset by default): batch k of this ctx runs on a stream restricted to the k-th set of
-    // compute units -- batches in flight then SHARE THE DEVICE IN SPACE instead of in time (mi_api.hip mi_batch_begin)
-    std::vector<std::vector<mi::u32>> batch_cu_masks;
-    std::vector<int> batch_cu_counts;
-    size_t next_cu_mask = 0;
     mi::ShaTune sha;                     // per ctx (mi_config.sha_*), not per process
     std::string sha_wave_stats;          // mi_debug_sha_wave_stats: the file sha.wave_stats_path points at
     bool verify_staging = false;         // MI_FLAG_VERIFY_STAGING
@@ -120,7 +115,6 @@ struct mi_ctx {
 
 struct mi_batch {
     mi_ctx* ctx;
-    int n_cu = 0;                            // compute units of this batch's stream (MI_BATCH_CU_MASKS); 0 = the device's
     struct FileRec { mi::u64 off, size, tag; int part = -1; };   // part: index into `parts`
     std::vector<FileRec> files;
     std::vector<mi::SynthSpec> synth;

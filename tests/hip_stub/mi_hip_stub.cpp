@@ -154,15 +154,6 @@ hipError_t hipHostMalloc(void** p, size_t n, unsigned int) {
 hipError_t hipHostFree(void* p) { if (p) { free(p); --g_live_allocs; } return hipSuccess; }
 
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned int) { *s = (hipStream_t) new Stream(); return hipSuccess; }
-hipError_t hipExtStreamCreateWithCUMask(hipStream_t* s, uint32_t n, const uint32_t* m) {
-    if (getenv("MI_HIP_STUB_LOG_CUMASK")) {              // what the library asked for (tests/test_host_hip_double.py)
-        fprintf(stderr, "hip_stub cumask %u:", n);
-        for (uint32_t i = 0; i < n; ++i) fprintf(stderr, " %08x", m[i]);
-        fprintf(stderr, "\n");
-    }
-    *s = (hipStream_t) new Stream();
-    return hipSuccess;
-}
 hipError_t hipStreamDestroy(hipStream_t s) { if (s) { ((Stream*)s)->sync(); delete (Stream*)s; } return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t s) { S(s)->sync(); return hipSuccess; }
 

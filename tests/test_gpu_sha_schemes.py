@@ -209,11 +209,3 @@ def test_wave_stats_are_a_ctx_setting(tmp_path):
             e.debug_sha_wave_stats(None)
             b.rerun()
             assert len(WS.read_records(path)) == 2
-
-
-@pytest.mark.skipif(not os.environ.get("MI_RUN_EXPERIMENTS"), reason="experiment knob, never run on a GPU yet: opt in with MI_RUN_EXPERIMENTS=1")
-@pytest.mark.parametrize("masks", ["0-127,128-255", "0-63+128-191,64-127+192-255", "0-255"])
-def test_batches_on_compute_units_of_their_own(masks):
-    """MI_BATCH_CU_MASKS (round 5's first probe, tools/cu_partition_probe.sh): a batch whose stream is restricted to a set
-    of compute units sizes its persistent hashing grid for that set -- same cut points, same digests."""
-    _run_child({"MI_BATCH_CU_MASKS": masks})

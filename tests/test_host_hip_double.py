@@ -101,27 +101,3 @@ def test_the_double_is_not_the_product():
             for fn in fns:
                 if fn.endswith((".py", ".hip", ".h")):
                     assert "hip_stub" not in open(os.path.join(dp, fn), errors="replace").read(), fn
-
-
-@pytest.mark.parametrize("masks,want", [
-    ("0-127,128-255", ["ffffffff ffffffff ffffffff ffffffff 00000000 00000000 00000000 00000000",
-                       "00000000 00000000 00000000 00000000 ffffffff ffffffff ffffffff ffffffff"]),
-    ("0-63+128-191,64-127+192-255", ["ffffffff ffffffff 00000000 00000000 ffffffff ffffffff 00000000 00000000",
-                                     "00000000 00000000 ffffffff ffffffff 00000000 00000000 ffffffff ffffffff"]),
-    ("0-84,85-169,170-255", ["ffffffff ffffffff 001fffff 00000000 00000000 00000000 00000000 00000000",
-                             "00000000 00000000 ffe00000 ffffffff ffffffff 000003ff 00000000 00000000",
-                             "00000000 00000000 00000000 00000000 00000000 fffffc00 ffffffff ffffffff"]),
-    ("3+5-6", ["00000068 00000000 00000000 00000000 00000000 00000000 00000000 00000000"]),
-    # malformed or out of the device's range: the knob stays off as a whole (an experiment must not half-apply)
-    ("0-127,128-256", []), ("0-127,", []), ("5-3", []), ("0-127;128-255", []), ("a", []), ("", []), ("0-127,,128-255", []),
-])
-def test_batch_cu_masks_reach_the_runtime_as_written(hip_double, tmp_path, masks, want):
-    """MI_BATCH_CU_MASKS (experiment knob of tools/cu_partition_probe.sh): batch k of a ctx gets the k-th set, in turn;
-    the masks the runtime is handed are the sets as written, one bit per compute unit of the device's 256"""
-    env = dict(os.environ, LD_PRELOAD=(os.environ.get("LD_PRELOAD", "") + " " + hip_double).strip(),
-               MI_BATCH_CU_MASKS=masks, MI_HIP_STUB_LOG_CUMASK="1")
-    p = subprocess.run([sys.executable, os.path.join(STUB_DIR, "scenarios.py"), str(tmp_path), "2", "65536", "two"],
-                       env=env, capture_output=True, text=True, timeout=300)
-    assert p.returncode == 0 and "OK two" in p.stdout, p.stdout[-800:] + p.stderr[-1500:]
-    got = [ln.split(":", 1)[1].strip() for ln in p.stderr.splitlines() if ln.startswith("hip_stub cumask")]
-    assert got == (want * 2)[:2] if want else got == []
