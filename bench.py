@@ -394,6 +394,60 @@ def n1_leg(makisu_amd, W, config, args, dev_index, inflight):
             "bytes_per_step": int(nbytes)}
 
 
+def with_rows_leg(makisu_amd, W, config, args, dev_index, inflight, value_without):
+    """The timed steps once more with the RESULTS DELIVERED: a ctx with MI_FLAG_PREFETCH_ROWS (mi_batch_wait brings the packed
+    chunk rows to pinned host memory while the other batch in flight keeps the GPU busy), and per step what a host that
+    feeds isUpdated and the chunk index reads: mi_batch_chunks_view (64 B per chunk) + mi_batch_files_view (96 B per file),
+    both in place.  `value` of the main line leaves the rows on the device; this is the rate with them on the host."""
+    import torch
+    eng = makisu_amd.Engine(device=dev_index, flags=makisu_amd.FLAG_PREFETCH_ROWS)
+    batches, nbytes = [], 0
+    for g in range(inflight):
+        sh = make_shard(W, config, args, 0, 1, g)
+        b = eng.batch(sh.n_files, W.batch_bytes_hint(sh))
+        W.fill_batch(b, sh)
+        b.run()
+        batches.append(b)
+        nbytes = sh.n_bytes
+    seen = {"rows": 0, "files": 0, "row_bytes": 0, "check": 0}
+
+    def finish(i):
+        batches[i].wait()                                       # kernels done, rows already in pinned host memory
+        rows = batches[i].chunks_view()
+        files = batches[i].files_view()
+        seen["rows"], seen["files"] = len(rows), len(files)
+        seen["row_bytes"] = rows.nbytes + files.nbytes
+        seen["check"] ^= int(rows["length"][-1]) ^ int(files["n_chunks"][0])   # (touched)
+
+    def run(n):
+        pending = []
+        for k in range(n):
+            if len(pending) == inflight:
+                finish(pending.pop(0))
+            batches[k % inflight].submit()
+            pending.append(k % inflight)
+        for i in pending:
+            finish(i)
+
+    run(max(1, args.warmup))
+    torch.cuda.synchronize(dev_index)
+    t0 = time.perf_counter()
+    run(args.steps)
+    torch.cuda.synchronize(dev_index)
+    dt = time.perf_counter() - t0
+    for b in batches:
+        b.free()
+    eng.close()
+    value = nbytes * args.steps / dt / 2**30
+    return {"value": round(value, 2), "unit": "GiB/s", "ms_per_step": round(dt / args.steps * 1e3, 4), "steps": args.steps,
+            "batches_in_flight": inflight, "rows_per_step": seen["rows"], "files_per_step": seen["files"],
+            "bytes_to_host_per_step": seen["row_bytes"],
+            "vs_rows_left_on_device": round(value / value_without, 4) if value_without else None,
+            "how": "MI_FLAG_PREFETCH_ROWS: mi_batch_wait packs the chunk rows on the device and copies them to the batch's "
+                   "pinned buffers (file rows likewise); per step mi_batch_chunks_view + mi_batch_files_view are read in place by the "
+                   "host thread that then submits the next batch"}
+
+
 def closed_form_check(got, expect):
     """Distinct contents are independent random streams, so chunks of different contents differ -- except the
     shortest ones: a cut candidate on a file's second-to-last byte leaves a 1-BYTE tail chunk (P = 2^-13 per
@@ -403,6 +457,50 @@ def closed_form_check(got, expect):
     return {"n_unique": int(got) if got is not None else None, "closed_form": int(expect),
             "short_chunk_coincidences": coincidences,
             "ok": got is not None and 0 <= coincidences <= 2 + int(expect) // 50000}
+
+
+def reexec_under_torchrun(n, reason):
+    """The bare form could not bring its communicator up (or hung doing so): the same job once more as the driver's other
+    launch form -- one process per GPU under torch.distributed.run, whose own chain (native communicator per rank, then the
+    torch.distributed driver of the same exchange) gets its chance -- so that a first contact with N real GPUs still ends
+    in a line, and the line says which path produced it (config.launch_note).  Replaces this process."""
+    print("bench.py: %s -- re-executing under torch.distributed.run" % reason, file=sys.stderr, flush=True)
+    env = dict(os.environ, MI_BENCH_REEXEC_REASON=reason[:800])
+    port = 29600 + os.getpid() % 300
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execve(sys.executable, cmd, env)
+
+
+def watched(what, seconds, fn):
+    """fn() on a thread of its own; (result, None), or (None, why) when it raised or is still running after `seconds`
+    (0 = no limit).  A call that hangs inside the collective library cannot be cancelled: the caller re-executes."""
+    import threading
+    box = {}
+
+    def run():
+        try:
+            box["ok"] = fn()
+        except BaseException as e:                              # noqa: BLE001
+            box["err"] = "%s failed: %s" % (what, e)
+    t = threading.Thread(target=run, daemon=True)
+    t0 = time.perf_counter()
+    t.start()
+    t.join(seconds if seconds and seconds > 0 else None)
+    if t.is_alive():
+        return None, "%s did not return within %.0f s" % (what, time.perf_counter() - t0)
+    if "err" in box:
+        return None, box["err"]
+    return box.get("ok"), None
+
+
+def nccl_debug_tail(path, limit=600):
+    try:
+        txt = open(path, errors="replace").read().strip()
+        return txt[-limit:] if txt else None
+    except OSError:
+        return None
 
 
 def single_process_job(args):
@@ -438,11 +536,34 @@ def single_process_job(args):
     def each(fn):                                              # one host thread per device
         return list(pool.map(fn, range(n)))
 
-    n1 = None if args.no_n1 else n1_leg(makisu_amd, W, config, args, devs[0], inflight)
+    # the N = 1 form of the same per-GPU work on EVERY device of the job at once (boxes -- and the GPUs of one box -- differ
+    # by a few per cent: efficiency_vs_n1 is against their mean, not against device 0's luck)
+    n1 = None
+    if not args.no_n1:
+        if len(set(devs)) == n:
+            legs = each(lambda r: n1_leg(makisu_amd, W, config, args, devs[r], inflight))
+            vals = [leg["value"] for leg in legs]
+            n1 = dict(legs[0], value=round(float(np.mean(vals)), 2), per_device_value=vals,
+                      note="every device ran the config with world = 1 at the same time, one host thread each; value = mean")
+        else:                                                  # self-test: the ranks share a device
+            n1 = dict(n1_leg(makisu_amd, W, config, args, devs[0], inflight), note="one leg: the ranks of this job share device %d" % devs[0])
 
     engines = each(lambda r: makisu_amd.Engine(device=devs[r], flags=makisu_amd.FLAG_NO_DEDUP))
     info = engines[0].device_info()
-    makisu_amd.comm_init_all(engines)
+    # first contact: the communicator bring-up and, below, the first exchange run under a watchdog.  What RCCL has to say
+    # about a failure (NCCL_DEBUG=WARN, into a file of this job's) travels in the line of whoever finishes the job.
+    import tempfile
+    dbg_file = os.path.join(tempfile.gettempdir(), "mi_bench_nccl_%d.log" % os.getpid())
+    os.environ.setdefault("NCCL_DEBUG", "WARN")
+    os.environ.setdefault("NCCL_DEBUG_FILE", dbg_file)
+
+    def give_up(why):
+        tail = nccl_debug_tail(os.environ.get("NCCL_DEBUG_FILE", dbg_file))
+        reexec_under_torchrun(n, "bare --gpus %d: %s%s" % (n, why, ("; RCCL says: " + tail) if tail else ""))
+
+    _, why = watched("mi_comm_init_all over %d devices" % n, args.watchdog_s, lambda: makisu_amd.comm_init_all(engines))
+    if why:
+        give_up(why)
     rccl_ranks = [e.comm_ranks() for e in engines]             # ncclCommCount of the library's own communicators
     if rccl_ranks != [n] * n:
         raise SystemExit("the collective library sees %s rank(s), --gpus says %d: no line" % (rccl_ranks, n))
@@ -498,6 +619,12 @@ def single_process_job(args):
         for d in sorted(set(devs)):
             torch.cuda.synchronize(d)
 
+    def first_exchange():                                      # one step, alone: submit, wait, the collective, the marking
+        each(lambda r: batches[r][0].submit())
+        finish(0, False)
+    _, why = watched("the first mi_dedup_allgather_all over %d ranks" % n, args.watchdog_s, first_exchange)
+    if why:
+        give_up(why)
     run_steps(args.warmup, False)
     sync_all()
     t0 = time.perf_counter()
@@ -540,7 +667,8 @@ def single_process_job(args):
                    "job_bytes_per_step": int(job_bytes), "chunks_per_rank_last_batch": [int(x) for x in per_rank_chunks],
                    "parallelism": "files sharded x%d (%s)" % (n, "LPT by bytes" if config in ("c5", "c5u") else "file index mod N"),
                    "launch": "single process, %d ctxs, one host thread per device (mi_comm_init_all)" % n,
-                   "batches_in_flight": inflight, "exchange": "native", "rccl_ranks": n,
+                   "batches_in_flight": inflight, "exchange": "native", "rccl_ranks": int(rccl_ranks[0]),
+                   "rccl_ranks_per_ctx": [int(x) for x in rccl_ranks],
                    "rccl_library": os.environ.get("MI_RCCL_LIB", "librccl (dlopen)"),
                    "devices": devs, "device": info["name"].strip(), "n_cu": info["n_cu"]},
         "per_rank": {"step_ms": mean(rec["step_ms"]), "cdc_ms": mean(rec["cdc_ms"]), "sha_chunks_ms": mean(rec["sha_ms"]),
@@ -575,6 +703,8 @@ def single_process_job(args):
         e.comm_destroy()
         e.close()
     pool.shutdown()
+    if not args.no_cpu_baseline:                               # north_star: the host's scanner "in the same run", at N > 1 too
+        out["cpu_baseline"] = cpu_baseline(shards[0][0])
     try:
         import ctypes
         ctypes.CDLL(None).fflush(None)
@@ -603,6 +733,12 @@ def main():
                     help="N > 1: skip the N = 1 leg that `efficiency_vs_n1` comes from")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-fed", action="store_true", help="c3: skip the host-fed leg")
+    ap.add_argument("--no-with-rows", action="store_true", help="N = 1: skip the leg that delivers the result rows to the host")
+    ap.add_argument("--no-commit-e2e", action="store_true",
+                    help="N = 1, c2: skip the commit table (mi_memfs_commit_layer with and without the GPU scan on two trees)")
+    ap.add_argument("--watchdog-s", type=float, default=120.0,
+                    help="bare --gpus N: seconds the communicator bring-up and the first exchange may take before the job is "
+                         "re-executed under torch.distributed.run (0 = wait for ever)")
     ap.add_argument("--backend", default="auto",
                     help="torch.distributed backend under torchrun: auto = gloo with --exchange native (torch then "
                          "only ships the id and runs the host-side barrier and reductions -- the one RCCL "
@@ -997,6 +1133,8 @@ def main():
         out["one_batch_at_a_time"] = one_at_a_time
     if exchange_note:
         out["config"]["exchange_note"] = exchange_note
+    if os.environ.get("MI_BENCH_REEXEC_REASON"):
+        out["config"]["launch_note"] = ("re-executed by the bare single-process form after: " + os.environ["MI_BENCH_REEXEC_REASON"])
     if config in ("c5", "c5u"):
         out["config"].update({"lpt_imbalance_max_over_mean_bytes": round(desc_shard.imbalance, 6),
                               "files_split_into_parts_job": getattr(desc_shard, "n_split_files_job", 0),
@@ -1022,13 +1160,24 @@ def main():
         out["dedup_check"] = dedup_check
     if other_scheme:
         out["roofline"]["other_load_scheme_serial"] = other_scheme
+    for b in batches:
+        b.free()
+    batches = []
     if rank == 0 and world == 1:
         if host_fed:
             out["config"].update(host_fed)
+        if not args.no_with_rows and not exchange and config in ("c2", "c4", "c5", "c5u"):
+            out["with_rows_on_host"] = with_rows_leg(makisu_amd, W, config, args, dev_index, args.inflight, value)
+        if not args.no_commit_e2e and config == "c2" and not exchange:
+            # what the GPU buys (and costs) a BUILD: step.commitLayer end to end on two trees, with the scan inside and
+            # without (tools/commit_layer_bench.py says what each row is)
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from commit_layer_bench import commit_e2e
+            out["commit_e2e"] = {"call": "mi_memfs_commit_layer(fs, ctx | NULL, must_scan = 1, ...), gzip leg off, wall seconds",
+                                 "small_files": commit_e2e(eng, 100000, 4096),
+                                 "large_files": commit_e2e(eng, 48, 128 << 20)}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(desc_shard)
-    for b in batches:
-        b.free()
     if exchange and args.exchange == "native":
         eng.comm_destroy()
     eng.close()

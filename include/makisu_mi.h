@@ -251,6 +251,8 @@ int mi_batch_chunks(mi_batch* b, mi_chunk_result* out, uint64_t cap);
  * buffer (packed on the device, one device-to-host copy), valid until the batch is submitted
  * again, marked globally, reset or freed.  What a cgo shim reads through unsafe.Slice.          */
 int mi_batch_chunks_view(mi_batch* b, const mi_chunk_result** rows, uint64_t* n_chunks);
+/* ... and the file rows the same way (they are packed on the device too and arrive with the same wait).                  */
+int mi_batch_files_view(mi_batch* b, const mi_file_result** rows, uint64_t* n_files);
 /* The per-file chunk roots alone, 32 bytes per file in add order (cap = rows `out` has room for): what a content-aware
  * MemFS.isUpdated compares (lib/snapshot/mem_fs.go:487-503) -- one copy of n_files x 32 bytes, none of the chunk rows.   */
 int mi_batch_roots(mi_batch* b, uint8_t* out, uint64_t cap);

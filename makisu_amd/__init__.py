@@ -215,6 +215,7 @@ def load_library(rebuild=False):
         "mi_batch_files": ([vp, vp, u64], C.c_int),
         "mi_batch_chunks": ([vp, vp, u64], C.c_int),
         "mi_batch_chunks_view": ([vp, C.POINTER(vp), u64p], C.c_int),
+        "mi_batch_files_view": ([vp, C.POINTER(vp), u64p], C.c_int),
         "mi_batch_device_digests": ([vp, C.POINTER(vp), u64p], C.c_int),
         "mi_batch_read_back": ([vp, vp, u64], C.c_int),
         "mi_batch_reset": ([vp], C.c_int),
@@ -1217,6 +1218,15 @@ class Batch:
         out = np.zeros(max(n, 1), dtype=CHUNK_DTYPE)
         self._check(self._lib.mi_batch_chunks(self._h, out.ctypes.data, n))
         return out[:n]
+
+    def files_view(self):
+        """The file rows WITHOUT a copy (same lifetime as chunks_view's)."""
+        p, n = C.c_void_p(), C.c_uint64()
+        self._check(self._lib.mi_batch_files_view(self._h, C.byref(p), C.byref(n)))
+        if n.value == 0:
+            return np.zeros(0, dtype=FILE_DTYPE)
+        buf = (C.c_char * (n.value * FILE_DTYPE.itemsize)).from_address(p.value)
+        return np.frombuffer(buf, dtype=FILE_DTYPE)
 
     def roots(self):
         """the per-file chunk roots alone: an (n_files, 32) uint8 array"""

@@ -545,39 +545,24 @@ int fetch_results(mi_batch* b) {
     if (!b->ran) return fail(c, MI_ERR_STATE, "results requested before mi_batch_run");
     if (b->results_valid) return MI_OK;
     const u64 nf = b->files.size(), nc = b->n_chunks;
-    b->h_files.assign(nf, mi_file_result{});
+    b->n_h_files = 0;
     if (nf) {
-        std::vector<u32> ncs(nf);
-        std::vector<u64> first(nf);
-        std::vector<u8> roots(nf * 32), fsha;
-        HIPCHK(c, hipMemcpy(ncs.data(), b->n_chunks_d.p, nf * 4, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(first.data(), b->first.p, nf * 8, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(roots.data(), b->roots.p, nf * 32, hipMemcpyDeviceToHost));
-        if (c->cfg.flags & MI_FLAG_FILE_SHA256) {
-            fsha.resize(nf * 32);
-            HIPCHK(c, hipMemcpy(fsha.data(), b->file_sha.p, nf * 32, hipMemcpyDeviceToHost));
+        // the file rows are packed by a kernel too: one copy behind the chunk rows' (same stream, one wait for both) instead
+        // of three to five synchronous column copies and a repacking loop on the host
+        static_assert(sizeof(mi_file_result) == 96, "pack_file_rows_kernel writes 96-byte rows");
+        if (nf > b->h_files_cap) {
+            if (b->h_files) (void)hipHostFree(b->h_files);
+            b->h_files = nullptr;
+            b->h_files_cap = 0;
+            const size_t want = nf + nf / 8 + 16;
+            HIPCHK(c, hipHostMalloc((void**)&b->h_files, want * sizeof(mi_file_result), hipHostMallocDefault));
+            b->h_files_cap = want;
         }
-        std::vector<u32> crcs;
-        if (c->cfg.flags & MI_FLAG_FILE_CRC32) {
-            crcs.resize(nf);
-            HIPCHK(c, hipMemcpy(crcs.data(), b->crc_d.p, nf * 4, hipMemcpyDeviceToHost));
-        }
-        for (u64 f = 0; f < nf; ++f) {
-            mi_file_result& r = b->h_files[f];
-            r.user_tag = b->files[f].tag;
-            r.size = b->files[f].size;
-            r.first_chunk = first[f];
-            r.n_chunks = ncs[f];
-            memcpy(r.chunk_root, &roots[f * 32], 32);
-            if (!fsha.empty()) memcpy(r.file_sha256, &fsha[f * 32], 32);
-            if (!crcs.empty()) r.crc32 = crcs[f];
-            if (b->files[f].part >= 0) {                 // a part: its own range; no whole-file values
-                const PartRec& p = b->parts[b->files[f].part];
-                r.size = p.end - p.begin;
-                r.crc32 = 0;
-                memset(r.file_sha256, 0, 32);
-            }
-        }
+        HIPCHK(c, b->file_rows_d.ensure(nf * sizeof(mi_file_result)));
+        launch_pack_file_rows(nf, b->file_size.as<u64>(), b->first.as<u64>(), b->n_chunks_d.as<u32>(),
+                              (c->cfg.flags & MI_FLAG_FILE_CRC32) ? b->crc_d.as<u32>() : nullptr, b->roots.as<u8>(),
+                              (c->cfg.flags & MI_FLAG_FILE_SHA256) ? b->file_sha.as<u8>() : nullptr, b->file_rows_d.p, b->stream);
+        HIPCHK(c, hipMemcpyAsync(b->h_files, b->file_rows_d.p, nf * sizeof(mi_file_result), hipMemcpyDeviceToHost, b->stream));
     }
     if (nc) {
         // rows are packed by a kernel; ONE device-to-host copy into the batch's pinned buffer
@@ -603,9 +588,22 @@ int fetch_results(mi_batch* b) {
         launch_pack_chunk_rows(nc, b->chunk_file.as<u32>(), b->chunk_start.as<u64>(), b->chunk_len.as<u64>(),
                                b->dup_of.as<i64>(), b->digests.as<u8>(), d_base, b->rows_d.p, b->stream);
         HIPCHK(c, hipMemcpyAsync(b->rows_h, b->rows_d.p, bytes, hipMemcpyDeviceToHost, b->stream));
+    }
+    if (nf || nc) {
         HIPCHK(c, hipStreamSynchronize(b->stream));
         HIPCHK(c, hipGetLastError());
     }
+    for (u64 f = 0; f < nf; ++f) {                      // what only the host knows: the caller's tag; a part's own range
+        mi_file_result& r = b->h_files[f];
+        r.user_tag = b->files[f].tag;
+        if (b->files[f].part >= 0) {                    // a part: its own range; no whole-file values
+            const PartRec& p = b->parts[b->files[f].part];
+            r.size = p.end - p.begin;
+            r.crc32 = 0;
+            memset(r.file_sha256, 0, 32);
+        }
+    }
+    b->n_h_files = nf;
     b->results_valid = true;
     return MI_OK;
 }
@@ -1350,7 +1348,7 @@ int mi_batch_reset(mi_batch* b) {
     b->h_roots_valid = false;
     b->rb_len = 0;                                      // the window held bytes of the old arena contents
     b->n_chunks = b->total_slots = 0;
-    b->h_files.clear();
+    b->n_h_files = 0;
     memset(&b->stats, 0, sizeof b->stats);
     return MI_OK;
 }
@@ -1381,10 +1379,20 @@ int mi_batch_files(mi_batch* b, mi_file_result* out, uint64_t cap) {
     HIPCHK(b->ctx, hipSetDevice(b->ctx->device));
     int rc = fetch_results(b);
     if (rc) return rc;
-    if (cap < b->h_files.size())
+    if (cap < b->n_h_files)
         return fail(b->ctx, MI_ERR_CAPACITY, "file result buffer holds %llu rows, need %zu",
-                    (unsigned long long)cap, b->h_files.size());
-    if (!b->h_files.empty()) memcpy(out, b->h_files.data(), b->h_files.size() * sizeof(mi_file_result));
+                    (unsigned long long)cap, b->n_h_files);
+    if (b->n_h_files) memcpy(out, b->h_files, b->n_h_files * sizeof(mi_file_result));
+    return MI_OK;
+}
+
+int mi_batch_files_view(mi_batch* b, const mi_file_result** rows, uint64_t* n_files) {
+    if (!b || !rows) return MI_ERR_INVALID;
+    HIPCHK(b->ctx, hipSetDevice(b->ctx->device));
+    int rc = fetch_results(b);
+    if (rc) return rc;
+    *rows = b->n_h_files ? b->h_files : nullptr;
+    if (n_files) *n_files = b->n_h_files;
     return MI_OK;
 }
 
@@ -1541,6 +1549,7 @@ int mi_batch_free(mi_batch* b) {
     if (b->h_counts) (void)hipHostFree(b->h_counts);
     if (b->rows_h) (void)hipHostFree(b->rows_h);
     if (b->rb_win) (void)hipHostFree(b->rb_win);
+    if (b->h_files) (void)hipHostFree(b->h_files);
     DevBuf* bufs[] = {&b->root_addr, &b->root_cnt, &b->rseg_cnt, &b->rseg_first, &b->rseg_total,
                       &b->root_items_off, &b->root_items_len, &b->root_level[0], &b->root_level[1],
                       &b->root_level[2], &b->root_level[3], &b->root_level[4], &b->root_addr2, &b->root_cnt2,
@@ -1551,7 +1560,7 @@ int mi_batch_free(mi_batch* b) {
                       &b->n_chunks_d, &b->first, &b->scratch,
                       &b->chunk_off, &b->chunk_len, &b->chunk_file, &b->chunk_start, &b->digests, &b->item_off, &b->item_len, &b->roots,
                       &b->file_sha, &b->dup_of, &b->file_flags, &b->part_file, &b->part_group0, &b->part_halo,
-                      &b->part_entry, &b->rows_d, &b->file_base, &b->span_off, &b->span_len, &b->span_sums, &b->dense_list};
+                      &b->part_entry, &b->rows_d, &b->file_rows_d, &b->file_base, &b->span_off, &b->span_len, &b->span_sums, &b->dense_list};
     for (DevBuf* d : bufs) d->release();
     delete b;
     return MI_OK;
@@ -1578,7 +1587,7 @@ int mi_context_checksum(mi_batch* b, const void* prefix, uint64_t prefix_len,
         if (e.link_target) {
             crc = crc32_host_bytes(crc, e.link_target, strlen(e.link_target));
         } else if (e.file_index >= 0) {
-            if ((u64)e.file_index >= b->h_files.size())
+            if ((u64)e.file_index >= b->n_h_files)
                 return fail(c, MI_ERR_INVALID, "entry %llu: file index %lld out of range",
                             (unsigned long long)i, (long long)e.file_index);
             const mi_file_result& fr = b->h_files[(size_t)e.file_index];

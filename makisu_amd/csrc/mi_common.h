@@ -158,6 +158,8 @@ void launch_compact_chunks(const u64* d_file_off, const u64* d_file_seg0, const 
                            u64* d_item_off, u64* d_item_len, hipStream_t s);
 // the chunk table as mi_chunk_result rows (64 B each: file, offset (+ d_file_base[file] when given),
 // length, dup_of, digest)
+void launch_pack_file_rows(u64 n, const u64* d_file_size, const u64* d_first, const u32* d_n_chunks, const u32* d_crc,
+                           const u8* d_roots, const u8* d_file_sha, void* d_rows, hipStream_t s);
 void launch_pack_chunk_rows(u64 n, const u32* d_chunk_file, const u64* d_chunk_start, const u64* d_chunk_len,
                             const i64* d_dup_of, const u8* d_digests, const u64* d_file_base, void* d_rows,
                             hipStream_t s);

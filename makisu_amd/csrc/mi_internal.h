@@ -172,7 +172,9 @@ struct mi_batch {
     mi::u64 n_tiles = 0;
     void* tree = nullptr;                // host-side walk record (mi_tree.hip)
     mi::DevBuf dd_table, dd_slot;
-    std::vector<mi_file_result> h_files;
+    mi_file_result* h_files = nullptr;   // the file rows, packed on the device, in pinned host memory (n_h_files valid rows)
+    size_t n_h_files = 0, h_files_cap = 0;
+    mi::DevBuf file_rows_d;
     mi::DevBuf rows_d, file_base;        // chunk rows packed on the device; per-file offset base (parts)
     void* rows_h = nullptr;              // ... and in pinned host memory (what mi_batch_chunks_view hands out)
     size_t rows_h_bytes = 0;

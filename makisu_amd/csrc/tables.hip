@@ -288,6 +288,41 @@ void pack_chunk_rows_kernel(u64 n, const u32* __restrict__ chunk_file, const u64
     rows[4 * i + 3] = dg[1];
 }
 
+// ... and the file table as mi_file_result rows (96 B each): size, first chunk, chunk count, CRC, chunk root, whole-file
+// digest; the user tag (host knowledge) is left zero for the host to fill in
+__global__ __launch_bounds__(256)
+void pack_file_rows_kernel(u64 n, const u64* __restrict__ file_size, const u64* __restrict__ first,
+                           const u32* __restrict__ n_chunks, const u32* __restrict__ crc, const u8* __restrict__ roots,
+                           const u8* __restrict__ file_sha, u32x4* __restrict__ rows) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64 sz = file_size[i], fc = first[i];
+    u32x4 q0, q1, z;
+    z.x = z.y = z.z = z.w = 0;
+    q0.x = 0; q0.y = 0; q0.z = (u32)sz; q0.w = (u32)(sz >> 32);
+    q1.x = (u32)fc; q1.y = (u32)(fc >> 32); q1.z = n_chunks[i]; q1.w = crc ? crc[i] : 0u;
+    const u32x4* rt = (const u32x4*)(roots + 32 * i);
+    rows[6 * i] = q0;
+    rows[6 * i + 1] = q1;
+    rows[6 * i + 2] = rt[0];
+    rows[6 * i + 3] = rt[1];
+    if (file_sha) {
+        const u32x4* fs = (const u32x4*)(file_sha + 32 * i);
+        rows[6 * i + 4] = fs[0];
+        rows[6 * i + 5] = fs[1];
+    } else {
+        rows[6 * i + 4] = z;
+        rows[6 * i + 5] = z;
+    }
+}
+
+void launch_pack_file_rows(u64 n, const u64* d_file_size, const u64* d_first, const u32* d_n_chunks, const u32* d_crc,
+                           const u8* d_roots, const u8* d_file_sha, void* d_rows, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(pack_file_rows_kernel, dim3((u32)((n + 255) / 256)), dim3(256), 0, s, n, d_file_size, d_first,
+                       d_n_chunks, d_crc, d_roots, d_file_sha, (u32x4*)d_rows);
+}
+
 void launch_pack_chunk_rows(u64 n, const u32* d_chunk_file, const u64* d_chunk_start, const u64* d_chunk_len,
                             const i64* d_dup_of, const u8* d_digests, const u64* d_file_base, void* d_rows,
                             hipStream_t s) {

@@ -145,6 +145,12 @@ ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int
 
 ncclResult_t ncclCommInitAll(ncclComm_t* comms, int ndev, const int* devlist) {
     if (!comms || ndev < 1) return ncclInvalidArgument;
+    // first-contact faults (tests/test_gpu_native_exchange.py): what a host meets when the single-process bring-up does not
+    // work on a node -- an error, or a call that never comes back
+    if (const char* e = getenv("MI_RCCL_STUB_INIT_ALL")) {
+        if (!strcmp(e, "fail")) return ncclSystemError;
+        if (!strncmp(e, "hang", 4)) { for (;;) sleep(1000); }
+    }
     World* w = new World();
     w->n = ndev;
     w->next.assign((size_t)ndev, 0);
@@ -181,6 +187,12 @@ ncclResult_t ncclGroupStart() {
 }
 
 ncclResult_t ncclGroupEnd() {
+    if (const char* e = getenv("MI_RCCL_STUB_INIT_ALL"))       // "exchange-hangs": the communicators came up, the first
+        if (!strcmp(e, "exchange-hangs")) {                    // collective over a single-process world never completes
+            bool world = false;
+            { std::lock_guard<std::mutex> g(g_mu); world = !g_group_worlds.empty(); }
+            if (world) for (;;) sleep(1000);
+        }
     std::lock_guard<std::mutex> g(g_mu);
     if (g_group_depth <= 0) return ncclInvalidUsage;
     if (--g_group_depth > 0) return ncclSuccess;

@@ -378,6 +378,45 @@ def test_the_commit_from_plain_c(eng, tmp_path):
     assert c3[1] == "entries=0", lines["P2"]                                   # the same edit without a ctx: nothing
 
 
+def test_the_commit_table_of_the_bench_line(eng):
+    """tools/commit_layer_bench.commit_e2e (bench.py's `commit_e2e`): three commits with and without the GPU scan -- the
+    rewrites within the same second are in the GPU's layer only, everything else agrees"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from commit_layer_bench import commit_e2e
+    for n, size in ((3000, 4096), (12, 8 << 20)):
+        t = commit_e2e(eng, n, size)
+        new, same, some = t["commits"]
+        assert new["gpu"]["layer_files"] == new["cpu_header_only"]["layer_files"] == n
+        assert new["gpu"]["tar_bytes"] == new["cpu_header_only"]["tar_bytes"]
+        assert new["gpu"]["files_read"] == new["cpu_header_only"]["files_read"] == n        # once each, either way
+        assert same["gpu"]["layer_entries"] == same["cpu_header_only"]["layer_entries"] == 0
+        assert same["gpu"]["files_read"] == n and same["cpu_header_only"]["files_read"] == 0   # the price of watching content
+        k = max(1, n // 1000)
+        hidden = some["gpu"]["content_only_changes"]
+        assert hidden >= 1 and some["gpu"]["layer_files"] == k and some["cpu_header_only"]["layer_files"] == k - hidden
+        for row in t["commits"]:
+            for side in ("gpu", "cpu_header_only"):
+                r = row[side]
+                assert r["s_total"] >= r["s_walk_stage"] + r["s_scan"] + r["s_diff"] + r["s_write"] - 1e-3
+
+
+@pytest.mark.timeout(900)
+def test_the_bench_line_carries_the_products_numbers():
+    """bench.py at N = 1 (a small C2): `with_rows_on_host` -- the steps with the result rows delivered -- and `commit_e2e`
+    beside roofline and cpu_baseline"""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--files", "20000", "--steps", "4", "--warmup", "1",
+                          "--no-commit-e2e"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=800)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    j = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    w = j["with_rows_on_host"]
+    assert w["rows_per_step"] == j["config"]["chunks_last_batch"] and w["files_per_step"] == 20000
+    assert w["bytes_to_host_per_step"] == 64 * w["rows_per_step"] + 96 * 20000 and 0.3 < w["vs_rows_left_on_device"] < 1.2
+    assert j["roofline"]["frac"] > 0 and j["cpu_baseline"]["value"] > 0 and "commit_e2e" not in j
+
+
 if __name__ == "__main__":                                                     # one scenario in a process of its own
     from oracle import mi_oracle as O
     O.build()

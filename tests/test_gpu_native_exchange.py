@@ -257,6 +257,30 @@ def test_bench_bare_gpus_8_is_the_library_exchange(stub):
         assert len(j["per_rank"][k]) == 8 and all(v > 0 or k == "exchange_gather_ms" for v in j["per_rank"][k]), (k, j["per_rank"][k])
     assert j["n1_same_run"]["value"] > 0 and 0 < j["efficiency_vs_n1"] < 1.5
     assert j["roofline"]["frac"] > 0
+    assert j["config"]["rccl_ranks_per_ctx"] == [8] * 8                     # counted (ncclCommCount of every ctx), not assumed
+    assert j["cpu_baseline"]["value"] > 0 and j["cpu_baseline"]["cores"] >= 1   # the host's scanner in the same run, at N > 1 too
+    assert "launch_note" not in j["config"]
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("fault,says", [("fail", "mi_comm_init_all over 4 devices failed"),
+                                        ("hang", "mi_comm_init_all over 4 devices did not return within"),
+                                        ("exchange-hangs", "the first mi_dedup_allgather_all over 4 ranks did not return within")])
+def test_bench_bare_first_contact_always_ends_in_a_line(stub, fault, says):
+    """First contact with N GPUs may not work in the single-process form (ncclCommInitAll failing, or hanging, or the first
+    grouped collective never completing): the bare job says what happened and re-executes itself under
+    torch.distributed.run, whose ranks bring the communicator up one by one -- a line comes out, and it says which path
+    produced it.  (The double plays the faulty library: MI_RCCL_STUB_INIT_ALL.)"""
+    env = dict(os.environ, MI_BENCH_FORCE_DEVICE="0", MI_RCCL_LIB=stub, MI_RCCL_STUB_INIT_ALL=fault)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--files", "8000", "--steps", "2",
+                          "--warmup", "1", "--watchdog-s", "8", "--no-cpu-baseline"], env=env, cwd=ROOT, capture_output=True,
+                         text=True, timeout=800)
+    j = _bench_line(out)
+    assert j["n_gpus"] == 4 and j["config"]["rccl_ranks"] == 4 and j["config"]["launch"] == "one process per GPU"
+    assert says in j["config"]["launch_note"] and "re-executed by the bare single-process form" in j["config"]["launch_note"]
+    assert j["dedup_check"]["ok"] and "re-executing under torch.distributed.run" in out.stderr
 
 
 @pytest.mark.timeout(900)

@@ -1,44 +1,107 @@
-"""step.commitLayer on the host rows alone (no GPU): a tree of n files of `bytes` bytes in /dev/shm, one MemFS handle,
-three commits by scan -- everything new (walk + scan + every file framed into the layer tar and digested), nothing
-changed (walk + scan: the empty layer), one file in ten directories touched.  MI_WALK_TIMING / MI_MEMFS_TIMING lines show
-where the time of each went.  usage: commit_layer_bench.py [files = 100000] [bytes = 4096]"""
+"""step.commitLayer end to end, with and without the GPU scan inside -- what the GPU buys (and costs) a build.
+
+A tree of n files of `bytes` bytes in /dev/shm (page cache: both sides measure work, not a disk), two MemFS handles on
+it -- one committing with a ctx (mi_memfs_commit_layer: walk + stage + GPU scan + content-aware diff + tar from HBM), one
+without (the reference's commit: headers decide, the writer reads the changed files) -- and three commits by scan each:
+    all new            every file framed into the layer tar and digested;
+    nothing changed    the reference: walk + lstat-level diff.  With a ctx: every file is read and hashed again -- the
+                       price of watching content;
+    0.1 % changed      n/1000 files rewritten (same size): nine in ten with a new mtime -- both see them -- one in ten
+                       within the same second -- only the content scan sees those.
+Wall seconds per commit, split as mi_commit_stats splits them.  bench.py puts the table into its JSON line
+(`commit_e2e`); as a program: commit_layer_bench.py [files = 100000] [bytes = 4096]   (needs an MI355X)
+MI_WALK_TIMING / MI_MEMFS_TIMING lines (stderr) show where the host time of each commit went."""
 import os
 import shutil
 import sys
 import time
 
+import numpy as np
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import makisu_amd as M  # noqa: E402
+
+MTIME = 1_700_000_000
+
+
+def _make_tree(root, n, size, per_dir):
+    rng = np.random.default_rng(n ^ size)
+    blob = bytearray(rng.integers(0, 256, size, dtype=np.uint8).tobytes())
+    paths = []
+    for i in range(n):
+        if i % per_dir == 0:
+            dn = os.path.join(root, "d%05d" % (i // per_dir))
+            os.mkdir(dn)
+        blob[:8] = int(i).to_bytes(8, "little")                    # distinct files
+        p = os.path.join(dn, "f%04d" % (i % per_dir))
+        with open(p, "wb") as f:
+            f.write(blob)
+        os.utime(p, (MTIME, MTIME))
+        paths.append(p)
+    return paths
+
+
+def _side(st, res, wall):
+    return {"s_total": round(wall, 4), "s_walk_stage": round(st["s_walk_stage"], 4), "s_scan": round(st["s_scan"], 4),
+            "s_diff": round(st["s_diff"], 4), "s_write": round(st["s_write"], 4), "layer_entries": int(res["n_entries"]),
+            "layer_files": int(st["n_layer_files"]), "tar_bytes": int(res["tar_bytes"]),
+            "files_read": int(st["files_opened"]), "bytes_read": int(st["file_bytes_read"]),
+            "content_only_changes": int(st["n_content_changed"])}
+
+
+def commit_e2e(eng, n_files, file_bytes, base=None, gzip_level=None):
+    """-> dict(tree, commits=[{what, gpu={...}, cpu_header_only={...}}, ...]); gzip off unless gzip_level is given"""
+    base = base or ("/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None)
+    import tempfile
+    root = tempfile.mkdtemp(prefix="mi_commit_e2e_", dir=base)
+    gz = M.GZIP_OFF if gzip_level is None else gzip_level
+    try:
+        per_dir = 200 if file_bytes < (1 << 20) else 8
+        paths = _make_tree(root, n_files, file_bytes, per_dir)
+        rng = np.random.default_rng(3)
+        k = max(1, n_files // 1000)
+        victims = [paths[int(i)] for i in rng.choice(n_files, size=k, replace=False)]
+        out = {"tree": "%d files x %d bytes in %d directories under %s (page cache)" % (n_files, file_bytes, (n_files + per_dir - 1) // per_dir, base or "TMPDIR"),
+               "tree_bytes": n_files * file_bytes, "gzip": "off" if gzip_level is None else gzip_level, "commits": []}
+        with M.MemFS(root) as gpu, M.MemFS(root) as plain:
+            for step, what in enumerate(("all new", "nothing changed", "0.1 % changed")):
+                if step == 2:
+                    n_same_second = 0
+                    for j, p in enumerate(victims):
+                        data = rng.integers(0, 256, file_bytes, dtype=np.uint8).tobytes()
+                        with open(p, "r+b") as f:
+                            f.write(data)
+                        if j % 10 == 9 or j == k - 1:
+                            os.utime(p, (MTIME, MTIME))             # the same second: tario.IsSimilarHeader cannot tell
+                            n_same_second += 1
+                        else:
+                            os.utime(p, (MTIME + 7, MTIME + 7))
+                    what = "%d files rewritten (0.1 %%), %d of them within the same second" % (k, n_same_second)
+                row = {"what": what}
+                for name, fs, kw in (("gpu", gpu, {"engine": eng}), ("cpu_header_only", plain, {})):
+                    t0 = time.perf_counter()
+                    res = fs.commit_layer(must_scan=True, gzip_level=gz, **kw)
+                    row[name] = _side(res["stats"], res, time.perf_counter() - t0)
+                out["commits"].append(row)
+        return out
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
 
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
     size = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
-    root = "/dev/shm/mi_commit_layer_%d_%d_%d" % (n, size, os.getpid())
-    os.makedirs(root)
-    try:
-        blob = os.urandom(size)
-        for d in range(max(1, n // 200)):
-            dn = os.path.join(root, "d%04d" % d)
-            os.mkdir(dn)
-            for k in range(200):
-                with open(os.path.join(dn, "f%03d" % k), "wb") as f:
-                    f.write(blob)
-        os.environ.setdefault("MI_WALK_TIMING", "1")
-        os.environ.setdefault("MI_MEMFS_TIMING", "1")
-        with M.MemFS(root) as fs:
-            for step, what in enumerate(("everything new", "nothing changed", "one file in every tenth directory appended to")):
-                if step == 2:
-                    for d in range(0, max(1, n // 200), 10):
-                        with open(os.path.join(root, "d%04d" % d, "f000"), "ab") as f:
-                            f.write(b"x")
-                t0 = time.perf_counter()
-                res = fs.commit_layer(must_scan=True, gzip_level=M.GZIP_OFF)
-                dt = time.perf_counter() - t0
-                print("commit %d (%s): %.3f s -> %d entries, %d tar bytes, TarDigest %s" %
-                      (step, what, dt, res["n_entries"], res["tar_bytes"], str(res["tar_digest"])[:19]), flush=True)
-    finally:
-        shutil.rmtree(root, ignore_errors=True)
+    with M.Engine(device=0) as eng:
+        res = commit_e2e(eng, n, size)
+    print(res["tree"])
+    for row in res["commits"]:
+        print("  " + row["what"])
+        for side in ("gpu", "cpu_header_only"):
+            r = row[side]
+            print("    %-16s %7.3f s = walk%s %.3f + scan %.3f + diff %.3f + tar %.3f | layer: %d entries, %d files, %d tar bytes | "
+                  "read %d files, %d bytes | content-only changes %d" %
+                  (side, r["s_total"], "+stage" if side == "gpu" else "", r["s_walk_stage"], r["s_scan"], r["s_diff"], r["s_write"],
+                   r["layer_entries"], r["layer_files"], r["tar_bytes"], r["files_read"], r["bytes_read"], r["content_only_changes"]))
 
 
 if __name__ == "__main__":
