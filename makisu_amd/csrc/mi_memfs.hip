@@ -60,17 +60,73 @@ struct Node {
 // (only their number is reported): from the C library's heap that is a million small allocations, a million frees, and --
 // some unrelated allocation later -- a sweep over a million free fragments (measured: 0.3 s added to the next scan that
 // has more than a handful of changes).  So keys and table live in a pool that grows in large blocks and is given back whole.
+// A MERGE (UpdateFromTarReader) never looks at the map again: "Merged %d headers from tar to memfs" is all that is left of
+// it.  In count-only mode the map is therefore a set of 128-bit fingerprints of its keys (two independent 64-bit hashes,
+// open addressing, 16 bytes a key instead of ~130 with two allocations): the number of distinct keys, exact unless two
+// of a layer's paths collide in 128 bits (10^7 keys: 10^-25).  At C4's ten million entries the full map was 1.3 GB of
+// first-touched memory and a microsecond per header (profiles/r05_host_scale.txt).
+struct KeyCounter {
+    struct Fp { uint64_t a, b; };
+    std::vector<Fp> tab;                                                            // a == 0 && b == 0: free
+    size_t n = 0;
+    static Fp fp(const char* p, size_t len) {
+        uint64_t a = 0x9E3779B97F4A7C15ull ^ len, b = 0xC2B2AE3D27D4EB4Full + len;
+        while (len >= 8) {
+            uint64_t w;
+            memcpy(&w, p, 8);
+            a = (a ^ w) * 0xFF51AFD7ED558CCDull; a ^= a >> 32;
+            b = (b + w) * 0xC4CEB9FE1A85EC53ull; b = (b << 29) | (b >> 35);
+            p += 8; len -= 8;
+        }
+        uint64_t w = 0;
+        memcpy(&w, p, len);
+        a = (a ^ w) * 0xFF51AFD7ED558CCDull; a ^= a >> 33; a *= 0xC4CEB9FE1A85EC53ull; a ^= a >> 29;
+        b = (b + w) * 0x9FB21C651E98DF25ull; b ^= b >> 31; b *= 0xFF51AFD7ED558CCDull; b ^= b >> 32;
+        if (!(a | b)) a = 1;
+        return {a, b};
+    }
+    void reserve(size_t keys) {
+        size_t want = 16;
+        while (want < keys * 2) want <<= 1;
+        if (want > tab.size()) rehash(want);
+    }
+    void rehash(size_t cap) {
+        std::vector<Fp> old;
+        old.swap(tab);
+        tab.assign(cap, Fp{0, 0});
+        for (const Fp& f : old) if (f.a | f.b) place(f);
+    }
+    void place(const Fp& f) {
+        size_t i = (size_t)f.a & (tab.size() - 1);
+        while (tab[i].a | tab[i].b) i = (i + 1) & (tab.size() - 1);
+        tab[i] = f;
+    }
+    void add(const char* p, size_t len) {
+        if ((n + 1) * 2 > tab.size()) rehash(tab.empty() ? 1024 : tab.size() * 2);
+        const Fp f = fp(p, len);
+        size_t i = (size_t)f.a & (tab.size() - 1);
+        for (; tab[i].a | tab[i].b; i = (i + 1) & (tab.size() - 1))
+            if (tab[i].a == f.a && tab[i].b == f.b) return;
+        tab[i] = f;
+        ++n;
+    }
+    void clear() { std::vector<Fp>().swap(tab); n = 0; }
+};
+
 struct LayerMap {
     using Map = std::pmr::unordered_map<std::pmr::string, int64_t>;
     std::pmr::monotonic_buffer_resource pool;
     alignas(Map) unsigned char store[sizeof(Map)];
     Map* m;
     bool touched = false;
+    bool count_only = false;                                                        // a merge under way: see KeyCounter
+    KeyCounter counter;
     LayerMap() : m(new (store) Map(&pool)) {}
     ~LayerMap() { m->~Map(); }
     LayerMap(const LayerMap&) = delete;
     LayerMap& operator=(const LayerMap&) = delete;
     void set(const std::string& key, int64_t ref) {                                // l.files[key] = ...
+        if (count_only) { counter.add(key.data(), key.size()); return; }
         touched = true;
         auto it = m->find(std::pmr::string(key.data(), key.size(), &scratch));
         scratch.release();
@@ -79,9 +135,11 @@ struct LayerMap {
         seq.push_back(&*at);                                                       // (a table's elements do not move)
     }
     std::vector<const Map::value_type*> seq;                                       // the keys in the order they came
-    size_t size() const { return m->size(); }
-    void reserve(size_t n) { touched = true; m->reserve(n); }
+    size_t size() const { return count_only ? counter.n : m->size(); }
+    void reserve(size_t n) { if (count_only) { counter.reserve(n); return; } touched = true; m->reserve(n); }
     void clear() {
+        counter.clear();
+        count_only = false;
         if (!touched) return;
         m->~Map();
         pool.release();
@@ -1255,6 +1313,7 @@ static int memfs_update(mi_memfs* m, const mi_tree_entry* layer, uint64_t n_laye
     std::map<std::string, uint64_t> hardlinks;
     // (with room to spare: the first header a later step adds must not be the one that moves a million nodes)
     fs.nodes.reserve(fs.nodes.size() + n_layer + n_layer / 4 + 1024);
+    fs.layer.count_only = true;                                                   // (nothing reads this layer: its size is reported)
     fs.layer.reserve(n_layer + n_layer / 8 + 16);                                 // (its entries: the layer's paths and their ancestors)
     std::string p;                                                                // one buffer for every header's path
     for (uint64_t j = 0; j < n_layer && !fs.rc; ++j) {

@@ -505,3 +505,20 @@ def test_a_hard_link_that_did_not_change_is_not_merged_again(tmp_path):
         assert fs.update_from_entries([dict(base[2], mtime_sec=6)]) == 2         # the link and its directory
         assert fs.update_from_entries([dict(base[2], mtime_sec=6, link_target="/bin/busybox")]) == 0   # AbsPath either way
         assert fs.update_from_entries([dict(base[2], mtime_sec=6, link_target="bin/other")]) == 2
+
+
+def test_merged_header_count_is_the_number_of_distinct_keys(tmp_path):
+    """"Merged %d headers from tar to memfs" (mem_fs.go:250) is len(l.files): a path that occurs twice in a layer, an
+    ancestor re-added by several children, a whiteout filed under the path it deletes -- each key counts once.  The merge
+    keeps fingerprints of the keys instead of the map (nothing reads it again); the count is the map's."""
+    D = lambda p: {"relpath": p, "kind": M.KIND_DIR, "mode": 0o40755, "mtime_sec": 100, "size": 0}                 # noqa: E731
+    F = lambda p, t=100: {"relpath": p, "kind": M.KIND_FILE, "mode": 0o100644, "mtime_sec": t, "size": 5}         # noqa: E731
+    with M.MemFS(str(tmp_path)) as fs:
+        assert fs.update_from_entries([D("a"), F("a/x"), F("a/x", 101), F("a/y"), D("b"), F("b/z")]) == 5     # a/x twice: one key
+        assert fs.update_from_entries([F("a/x", 102), F("a/.wh.x")]) == 2                                          # "a" + "a/x" (both headers file under a/x)
+        assert [e["relpath"] for e in fs.entries()] == ["a", "a/y", "b", "b/z"]
+        many = [D("m")] + [x for d in range(300) for x in [D("m/d%03d" % d)] + [F("m/d%03d/f%03d" % (d, k)) for k in range(40)]]
+        assert fs.update_from_entries(many) == len(many)
+        assert fs.update_from_entries(many) == 0                                                                   # all similar: nothing merged
+        touched = [dict(e, mtime_sec=200) for e in many if e["kind"] == M.KIND_FILE][::7]
+        assert fs.update_from_entries(touched) == len(touched) + len({"m"} | {e["relpath"].rsplit("/", 1)[0] for e in touched})
