@@ -305,7 +305,7 @@ static uint64_t inline_file_max() {
 // The blocks' memory: recycled, not returned.  A 2 MB block from the C library is its own mapping -- page faults for
 // every one of its pages, by 16 threads in one address space, and an unmap when the reader threads let go of it: 100 000
 // 4 KiB files then spend more time faulting than reading.  Freed blocks wait here by size class (powers of two from
-// 64 KiB; at most 512 MiB kept resident), and since a block lives only until a reader thread has copied it, a walk
+// 64 KiB; at most 512 MiB kept resident while a walk runs, 64 MiB between walks: MI_WALK_POOL_MB / MI_WALK_POOL_IDLE_MB), and since a block lives only until a reader thread has copied it, a walk
 // cycles through a few tens of megabytes.
 // New blocks are CARVED from 32 MiB slabs (one mmap on a 2 MiB boundary, advised to use huge pages, never unmapped):
 // a mapping of its own per block cost three address-space calls (mmap, the munmap that trims it to the boundary,
@@ -319,6 +319,46 @@ struct BlockPool {
     std::vector<uint8_t*> free_[16];                          // class k: 64 KiB << k; resident blocks
     std::vector<uint8_t*> cold_[16];                          // carved blocks whose pages were given back
     uint64_t kept = 0;                                        // bytes in free_
+    // what may stay resident: MI_WALK_POOL_MB (default 512) while a walk runs, MI_WALK_POOL_IDLE_MB (default 64) between
+    // walks -- a long-lived host (the Go builder) does not pay half a gigabyte of RSS for ever after its first walk; the
+    // address ranges of carved blocks stay (their pages are given back: MADV_DONTNEED), mappings of their own are unmapped
+    int walks = 0;                                            // walks under way (any thread, any ctx: the pool is the process's)
+    static uint64_t env_mb(const char* name, long dflt) {
+        const char* e = getenv(name);
+        const long mb = e && *e ? atol(e) : dflt;
+        return mb <= 0 ? 0ull : (uint64_t)mb << 20;
+    }
+    uint64_t limit() const {                                  // mu held
+        static const uint64_t busy = env_mb("MI_WALK_POOL_MB", 512), idle = env_mb("MI_WALK_POOL_IDLE_MB", 64);
+        return walks > 0 ? busy : idle;
+    }
+    void walk_begins() { std::lock_guard<std::mutex> g(mu); ++walks; }
+    void walk_ends() {
+        std::vector<std::pair<uint8_t*, uint64_t>> go;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            if (--walks > 0) return;
+            for (int k = 15; k >= 0 && kept > limit(); --k)   // the largest blocks first
+                while (!free_[k].empty() && kept > limit()) {
+                    go.emplace_back(free_[k].back(), cap(k));
+                    free_[k].pop_back();
+                    kept -= cap(k);
+                }
+        }
+        if (const char* e = getenv("MI_WALK_TIMING"); e && *e && *e != '0')
+            fprintf(stderr, "mi_walk: block pool between walks: %.1f MB resident (limit %.0f), %zu blocks given back\n", resident() / 1e6,
+                    (double)(env_mb("MI_WALK_POOL_IDLE_MB", 64) >> 20), go.size());
+        for (auto& b : go) {
+            if (carved(b.second)) {
+                (void)madvise(b.first, b.second, MADV_DONTNEED);
+                std::lock_guard<std::mutex> g(mu);
+                cold_[cls(b.second)].push_back(b.first);
+            } else {
+                munmap(b.first, b.second);
+            }
+        }
+    }
+    uint64_t resident() { std::lock_guard<std::mutex> g(mu); return kept; }
     uint8_t* slab_at = nullptr;                               // the current slab's unused tail
     uint64_t slab_left = 0;
     uint64_t n_slabs = 0, n_carved = 0, n_own = 0;            // MI_WALK_TIMING
@@ -381,7 +421,7 @@ struct BlockPool {
         const int k = cls(capacity);
         if (cap(k) == capacity) {
             std::unique_lock<std::mutex> g(mu);
-            if (kept + capacity <= (512ull << 20)) { free_[k].push_back(p); kept += capacity; return; }
+            if (kept + capacity <= limit()) { free_[k].push_back(p); kept += capacity; return; }
             if (carved(capacity)) {                           // part of a slab: the pages go, the range stays
                 g.unlock();
                 (void)madvise(p, capacity, MADV_DONTNEED);
@@ -742,6 +782,8 @@ static void walk_root(Walker* w, const std::string& root) {
         const char* e = getenv("MI_WALK_INLINE");
         pw.inline_reads = !(e && *e == '0');
     }
+    struct PoolUse { bool on; PoolUse(bool o) : on(o) { if (on) block_pool().walk_begins(); } ~PoolUse() { if (on) block_pool().walk_ends(); } }
+        pool_use(pw.inline_reads);                                  // (blocks still with the reader threads come back under the idle limit)
     w->ahead_files = &pw.seen_files;
     w->ahead_bytes = &pw.seen_bytes;
     struct Detach { Walker* w; ~Detach() { w->ahead_files = w->ahead_bytes = nullptr; } } detach{w};

@@ -89,6 +89,23 @@ def test_a_block_goes_back_to_the_pool_when_it_is_copied_not_when_the_walk_ends(
     assert float(m.group(2)) <= 0.6 * 120, line
 
 
+def test_the_block_pool_gives_its_memory_back_between_walks(hip_double, tmp_path):
+    """the pool of the walk's blocks belongs to the process and outlives every walk -- a long-running host must
+    not keep half a gigabyte resident for ever after its first one.  Between walks at most MI_WALK_POOL_IDLE_MB (default 64)
+    stay; the rest of the pages go back (the carved blocks keep their address range)."""
+    import re
+    env = dict(os.environ, LD_PRELOAD=(os.environ.get("LD_PRELOAD", "") + " " + hip_double).strip(),
+               MI_WALK_THREADS="4", MI_WALK_TIMING="1", MI_WALK_POOL_IDLE_MB="2")
+    p = subprocess.run([sys.executable, os.path.join(STUB_DIR, "scenarios.py"), str(tmp_path), "4", str(1 << 20), "recycle"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "OK recycle" in p.stdout, p.stdout[-800:] + p.stderr[-1500:]
+    lines = [ln for ln in p.stderr.splitlines() if ln.startswith("mi_walk: block pool between walks")]
+    assert lines, p.stderr[-1500:]
+    for ln in lines:
+        m = re.search(r"([0-9.]+) MB resident \(limit 2\)", ln)
+        assert m and float(m.group(1)) <= 2.2, ln
+
+
 def test_with_slow_copies(hip_double, tmp_path):
     """every queued copy takes 100 us longer: what returns early shows"""
     _run(hip_double, tmp_path, 8, 65536, {"MI_HIP_STUB_COPY_US": "100"})
