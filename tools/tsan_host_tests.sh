@@ -25,7 +25,7 @@ ARGS=("$@")
 [ ${#ARGS[@]} -eq 0 ] && ARGS=(tests/test_host_walk.py tests/test_host_layer.py tests/test_host_layer_properties.py
                                 tests/test_host_tar.py tests/test_host_tar_properties.py tests/test_host_copy_ops.py
                                 tests/test_host_apply_properties.py tests/test_host_diff_properties.py
-                                tests/test_host_hip_double.py)
+                                tests/test_host_hip_double.py tests/test_host_commit_double.py)
 MI_WALK_UNSHARE=0 LD_PRELOAD=$RT TSAN_OPTIONS=halt_on_error=0:report_signal_unsafe=0:exitcode=0:log_path="$OUT/report" \
     MAKISU_MI_LIB="$OUT/libmakisu_mi.so" python -m pytest -q -p no:cacheprovider "${ARGS[@]}"
 if ls "$OUT"/report.* >/dev/null 2>&1; then
