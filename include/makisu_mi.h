@@ -717,6 +717,11 @@ void mi_layer_free(mi_layer* layer);
  *   4. the layer writer frames the tar; file content comes from HBM (mi_layer_add_batch_file): the tar holds the bytes
  *      the stored root describes, even if the file was written to after it was staged;
  *   5. with an index set (mi_memfs_set_index) the batch's chunk digests are added to it (mi_index_add_batch).
+ * Steps 2-4 overlap: the scan runs on a thread of the library's own while the committing thread computes the layer and
+ * frames the tar from the bytes that have landed; the diff waits for the scan only where a root DECIDES (a file the tree
+ * holds with a root and an unchanged header).  A file that vanishes or shrinks between the walk and its staging therefore
+ * fails the commit AFTER the tree took the layer -- as a failing tar write does in the reference (MemFS.AddLayerByScan
+ * updates the tree, then writes; lib/snapshot/mem_fs.go:260-274).  MI_COMMIT_PIPELINE=0: one step after the other.
  * The handle keeps the batch (device memory sized by the largest commit so far) for its next commit; it belongs to
  * `ctx`: free the handle, or call mi_memfs_release_device, before mi_ctx_destroy.  A tree larger than the device's free
  * memory fails with MI_ERR_NOMEM and leaves the tree as it was.  mi_memfs_commit_stats: what the last commit did.     */
@@ -734,8 +739,10 @@ typedef struct {
     uint64_t files_opened;       /* file descriptors whose content was read, by every thread of the library ... */
     uint64_t file_bytes_read;    /* ... and the bytes read from them, during this commit (process-wide counters:
                                     a commit running beside another one counts both)                            */
+    uint64_t pipelined;          /* 1: the scan ran beside the diff and the tar writer (its time is not in the sum) */
     double   s_walk_stage;       /* walk (+ staging, which goes on behind it)                                   */
-    double   s_scan;             /* end of staging + the GPU passes + the roots' way back                       */
+    double   s_scan;             /* end of staging + the GPU passes + the roots' way back (pipelined: on a thread
+                                    of its own, overlapping s_diff and s_write)                                 */
     double   s_diff;             /* createLayerByScan / addToLayer + commit order                               */
     double   s_write;            /* tar framing, digests, gzip leg                                              */
     double   s_total;

@@ -48,8 +48,10 @@ int fail(mi_ctx* c, int code, const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    if (c) c->err = buf;
-    else { std::lock_guard<std::mutex> g(g_err_mu); g_create_err = buf; }
+    // (one writer at a time: a pipelined commit has two threads of the library on one ctx -- its scan and its tar writer --
+    //  and a staging failure reaches both)
+    std::lock_guard<std::mutex> g(g_err_mu);
+    if (c) c->err = buf; else g_create_err = buf;
     return code;
 }
 
@@ -77,14 +79,17 @@ int staging_sync(mi_batch* b) {
     return MI_OK;
 }
 
-int arena_reserve(mi_batch* b, u64 want) {
+// told: the caller KNOWS what is coming (a hint of mi_batch_begin, mi_batch_reserve after an enumeration): an eighth on
+// top instead of a half -- fresh device memory costs 68 ms per GiB to allocate on this driver (tools/first_use_probe.py:
+// 1 GiB 0.054 s, 16 GiB 1.09 s), so the first commit of a 6.4 GB tree pays 0.49 s for its arena, not 0.65
+int arena_reserve(mi_batch* b, u64 want, bool told = false) {
     mi_ctx* c = b->ctx;
     want += 4096;                                   // slack: tile loads may touch 15 B past a file
     if (want <= b->arena.bytes) return MI_OK;
     int rc = staging_sync(b);                       // copies in flight target the old arena
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    u64 alloc = guard_alloc() ? ((want + 255) & ~255ull) : want + want / 2;   // under the guard: the 4 KiB and no more
+    u64 alloc = guard_alloc() ? ((want + 255) & ~255ull) : want + (told ? want / 8 : want / 2);   // under the guard: the 4 KiB and no more
     void* np = nullptr;
     hipError_t e = dev_alloc(&np, alloc);
     if (e != hipSuccess) { alloc = want; HIPCHK(c, dev_alloc(&np, alloc)); }
@@ -838,7 +843,7 @@ int mi_batch_begin(mi_ctx* c, uint64_t n_files_hint, uint64_t bytes_hint, mi_bat
         return rc;
     }
     if (bytes_hint) {
-        int rc = arena_reserve(b, bytes_hint + n_files_hint * kFileAlign);
+        int rc = arena_reserve(b, bytes_hint + n_files_hint * kFileAlign, true);
         if (rc) { mi_batch_free(b); return rc; }
     }
     *out = b;
@@ -992,7 +997,7 @@ int mi_batch_reserve(mi_batch* b, uint64_t more_files, uint64_t more_bytes) {
         const u64 step = 2 * b->arena.bytes > (64ull << 20) ? 2 * b->arena.bytes : (64ull << 20);
         if (want < step) want = step;
     }
-    return arena_reserve(b, want);
+    return arena_reserve(b, want, true);
 }
 
 // A file that is a byte range of another file: a member of an uncompressed layer tar
@@ -1471,10 +1476,13 @@ int mi_batch_roots(mi_batch* b, uint8_t* out, uint64_t cap) {
 // the next fetch's length follows how much of the last one was used -- 256 KiB when a layer picks single files out of a
 // tree, 8 MiB when it streams.
 constexpr u64 kReadWinBytes = 8ull << 20, kReadWinMin = 256ull << 10;
-int mi_batch_read_file(mi_batch* b, uint64_t file_index, uint64_t offset, void* dst, uint64_t len) {
+// while_staging: the caller is the pipelined commit (mi_memfs.hip) -- the batch is still being staged and scanned by another
+// thread; the file's bytes are waited for (stager_wait_landed), nothing else of the batch's state is touched
+static int read_file_impl(mi_batch* b, uint64_t file_index, uint64_t offset, void* dst, uint64_t len, bool while_staging) {
     if (!b || (!dst && len)) return MI_ERR_INVALID;
     mi_ctx* c = b->ctx;
-    if (!b->staged || b->in_flight) return fail(c, MI_ERR_STATE, "mi_batch_read_file: the batch is not staged, or in flight");
+    if (!while_staging && (!b->staged || b->in_flight))
+        return fail(c, MI_ERR_STATE, "mi_batch_read_file: the batch is not staged, or in flight");
     if (file_index >= b->files.size()) return fail(c, MI_ERR_INVALID, "mi_batch_read_file: no file %llu", (unsigned long long)file_index);
     const mi_batch::FileRec& f = b->files[file_index];
     if (f.part >= 0) return fail(c, MI_ERR_INVALID, "mi_batch_read_file: file %llu is a part", (unsigned long long)file_index);
@@ -1484,6 +1492,7 @@ int mi_batch_read_file(mi_batch* b, uint64_t file_index, uint64_t offset, void* 
     if (!len) return MI_OK;
     HIPCHK(c, hipSetDevice(c->device));
     if (!b->rb_win) {
+        HIPCHK(c, hipStreamCreateWithFlags(&b->rb_stream, hipStreamNonBlocking));
         HIPCHK(c, hipHostMalloc(&b->rb_win, kReadWinBytes, hipHostMallocDefault));
         b->rb_next = kReadWinMin;
         b->rb_len = 0;
@@ -1496,8 +1505,17 @@ int mi_batch_read_file(mi_batch* b, uint64_t file_index, uint64_t offset, void* 
             if (b->rb_len) b->rb_next = b->rb_hits > 2 ? std::min(b->rb_next * 2, kReadWinBytes) : std::max(b->rb_next / 2, kReadWinMin);
             u64 want = std::max(b->rb_next, std::min(len, kReadWinBytes));
             want = std::min(want, b->arena_used - at);
-            HIPCHK(c, hipMemcpyAsync(b->rb_win, b->arena.as<u8>() + at, want, hipMemcpyDeviceToHost, b->stream));
-            HIPCHK(c, hipStreamSynchronize(b->stream));
+            if (while_staging && c->stager) {
+                // what was asked for is waited for; the window then takes what ELSE has landed behind it (the neighbours that
+                // will be asked for next) and nothing that is still on its way
+                const u64 need = std::min(len, std::min(kReadWinBytes, f.off + f.size - at));
+                u64 landed = ~0ull;
+                const int rc = stager_wait_landed(c->stager, b, at + need, &landed);
+                if (rc) return rc;
+                if (landed != ~0ull) want = std::min(want, std::max(need, landed > at ? landed - at : 0));
+            }
+            HIPCHK(c, hipMemcpyAsync(b->rb_win, b->arena.as<u8>() + at, want, hipMemcpyDeviceToHost, b->rb_stream));
+            HIPCHK(c, hipStreamSynchronize(b->rb_stream));
             b->rb_start = at;
             b->rb_len = want;
             b->rb_hits = 1;
@@ -1512,13 +1530,25 @@ int mi_batch_read_file(mi_batch* b, uint64_t file_index, uint64_t offset, void* 
     }
     return MI_OK;
 }
+int mi_batch_read_file(mi_batch* b, uint64_t file_index, uint64_t offset, void* dst, uint64_t len) {
+    return read_file_impl(b, file_index, offset, dst, len, false);
+}
+int mi_batch_read_file_landed(mi_batch* b, uint64_t file_index, uint64_t offset, void* dst, uint64_t len) {   // (hidden: mi_local.h)
+    return read_file_impl(b, file_index, offset, dst, len, true);
+}
 
 int mi_batch_file_size(mi_batch* b, uint64_t file_index, uint64_t* size) {       // (internal: mi_layer.hip)
     if (!b || !size || file_index >= b->files.size() || b->files[file_index].part >= 0) return MI_ERR_INVALID;
     *size = b->files[file_index].size;
     return MI_OK;
 }
-const char* mi_last_error_of_batch(mi_batch* b) { return b ? b->ctx->err.c_str() : ""; }
+const char* mi_last_error_of_batch(mi_batch* b) {                // (a copy of the caller's own: see mi::fail)
+    static thread_local std::string mine;
+    if (!b) return "";
+    std::lock_guard<std::mutex> g(g_err_mu);
+    mine = b->ctx->err;
+    return mine.c_str();
+}
 
 void** mi_batch_tree_slot(mi_batch* b) { return &b->tree; }
 void mi_set_error(mi_batch* b, const char* msg) {                // b NULL: the message mi_last_error(NULL) returns
@@ -1549,6 +1579,7 @@ int mi_batch_free(mi_batch* b) {
     if (b->h_counts) (void)hipHostFree(b->h_counts);
     if (b->rows_h) (void)hipHostFree(b->rows_h);
     if (b->rb_win) (void)hipHostFree(b->rb_win);
+    if (b->rb_stream) (void)hipStreamDestroy(b->rb_stream);
     if (b->h_files) (void)hipHostFree(b->h_files);
     DevBuf* bufs[] = {&b->root_addr, &b->root_cnt, &b->rseg_cnt, &b->rseg_first, &b->rseg_total,
                       &b->root_items_off, &b->root_items_len, &b->root_level[0], &b->root_level[1],

@@ -9,6 +9,7 @@
 #include <memory>
 
 #include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -77,6 +78,10 @@ int     stager_put_paths(Stager* st, mi_batch* b, u64 n, const char* const* path
                          const u64* len);
 int     stager_put_block(Stager* st, mi_batch* b, u64 arena_off, const void* src, u64 len, std::shared_ptr<void> keep);
 int     stager_drain(Stager* st, mi_batch* b);
+// blocks until every byte of the batch's arena below `upto` that was queued so far has landed in HBM (pieces of one batch are
+// queued in arena order), or the batch's staging failed (MI_ERR_IO with the first failure's message)
+// *landed_out (optional): how far the landed prefix reaches by now (~0: everything queued so far)
+int     stager_wait_landed(Stager* st, mi_batch* b, u64 upto, u64* landed_out);
 
 }  // namespace mi
 
@@ -136,6 +141,8 @@ struct mi_batch {
     bool staged_any = false;
     // reader-thread staging (mi_stage.hip); guarded by the stager's mutex
     mi::u64 stage_pending = 0;   // queued pieces not yet in HBM
+    std::multiset<mi::u64> stage_inflight;   // arena offsets at which the runs a reader thread holds right now begin
+    int stage_waiters = 0;       // threads in stager_wait_landed (every landed run wakes them, not just the last)
     std::string stage_err;       // first read / copy / verification error: STICKY until mi_batch_reset
     std::string stage_note;      // what the first verification mismatch looked like (even if repaired)
     std::mutex span_mu;          // guards the three below (reader threads + the inline window)
@@ -180,6 +187,7 @@ struct mi_batch {
     size_t rows_h_bytes = 0;
     // mi_batch_read_file: the pinned window staged bytes come back through (the layer writer's source when a commit
     // reads its files from HBM instead of a second time from disk)
+    hipStream_t rb_stream = nullptr;     // ... on a stream of its own: a read-back does not queue behind the batch's kernels
     void* rb_win = nullptr;
     mi::u64 rb_start = 0, rb_len = 0;    // the arena range the window holds now
     mi::u64 rb_next = 0, rb_hits = 0;    // next fetch's length (adapts to how much of a fetch was asked for), reads served

@@ -490,6 +490,7 @@ struct mi_layer {
     std::shared_ptr<Bytes> cur;
     uint64_t n_entries = 0;
     uint64_t files_opened = 0, file_bytes_read = 0;    // what this writer read from disk itself (mi_layer_io_counts)
+    bool pipelined = false;                            // batch files are read while the batch is still staged (mi_local.h)
     bool finished = false, failed = false;
 
     int fail(int code, const char* fmt, ...) {
@@ -637,7 +638,8 @@ static int layer_add_entry(mi_layer* l, const mi_tree_entry* e, const char* src_
             size_t take = left > kBlockBytes ? kBlockBytes : (size_t)left;
             uint8_t* dst = l->room(&take);
             if (batch) {
-                const int brc = mi_batch_read_file(batch, batch_file, off, dst, take);
+                const int brc = l->pipelined ? mi_batch_read_file_landed(batch, batch_file, off, dst, take)
+                                             : mi_batch_read_file(batch, batch_file, off, dst, take);
                 if (brc) return l->fail(brc, "copy file %s to tar writer: staged file %llu: %s", h.name.c_str(),
                                         (unsigned long long)batch_file, mi_last_error_of_batch(batch));
             } else {
@@ -681,6 +683,8 @@ int mi_layer_add_batch_file(mi_layer* l, const mi_tree_entry* e, mi_batch* batch
     }
     return layer_add_entry(l, e, nullptr, batch, file_index);
 }
+
+void mi_layer_set_pipelined(mi_layer* l, int on) { if (l) l->pipelined = on != 0; }
 
 int mi_layer_io_counts(mi_layer* l, uint64_t* files_opened, uint64_t* file_bytes_read) {
     if (!l) return MI_ERR_INVALID;

@@ -12,6 +12,11 @@ MI_LOCAL void        mi_set_error(mi_batch* b, const char* msg);     // b NULL: 
 MI_LOCAL void**      mi_batch_tree_slot(mi_batch* b);                // the batch's walk record (mi_tree.hip owns its type)
 MI_LOCAL int         mi_batch_file_size(mi_batch* b, uint64_t file_index, uint64_t* size);
 MI_LOCAL const char* mi_last_error_of_batch(mi_batch* b);
+// mi_batch_read_file for the pipelined commit: the batch is still being staged / scanned on another thread; the call waits
+// until the bytes it is asked for have landed in HBM
+MI_LOCAL int         mi_batch_read_file_landed(mi_batch* b, uint64_t file_index, uint64_t offset, void* dst, uint64_t len);
+// mi_layer.hip: from now on mi_layer_add_batch_file reads through mi_batch_read_file_landed
+MI_LOCAL void        mi_layer_set_pipelined(mi_layer* layer, int on);
 // the walk's small files read in place: a block of host memory as one piece of the arena, and the table rows of files
 // that lie in it; "host-fed bytes are on their way" (the reader threads set up behind the walk's first directories)
 MI_LOCAL int  mi_batch_add_block(mi_batch* b, const void* src, uint64_t len, void (*release)(void*), void* release_arg,

@@ -19,7 +19,10 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <memory_resource>
+#include <mutex>
+#include <thread>
 #include <new>
 #include <chrono>
 #include <atomic>
@@ -55,6 +58,49 @@ struct Node {
     bool has_root = false;     // chunk root of the content, when the caller scanned it (content-aware isUpdated)
     uint8_t root[32];
     int64_t batch_file = -1;   // a content-aware commit under way: the file's row in the commit's batch -- its bytes lie in HBM
+    bool root_pending = false; // ... and its root is still being computed (a pipelined commit: ScanJob); root[] is not valid yet
+};
+
+// The GPU scan of a pipelined commit, on a thread of its own: mi_batch_run (the end of staging, the kernels) and the roots'
+// way back, while the committing thread computes the layer and frames the tar from the bytes that have already landed.
+// Whoever needs a root before the scan is through waits for it (Fs::root_now); everybody else is handed the roots at the end.
+struct ScanJob {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    bool done = false;
+    int rc = MI_OK;
+    std::string err;
+    std::vector<uint8_t> roots;
+    uint64_t n_chunks = 0;
+    double seconds = 0;
+    void start(mi_batch* b, mi_ctx* ctx, uint64_t n_files) {
+        roots.resize(n_files * 32);
+        th = std::thread([this, b, ctx, n_files] {
+            const auto t0 = std::chrono::steady_clock::now();
+            int r = mi_batch_run(b);
+            if (!r) r = mi_batch_roots(b, roots.data(), n_files);
+            uint64_t nc = 0;
+            if (!r) mi_batch_counts(b, nullptr, &nc, nullptr);
+            std::string e = r ? mi_last_error(ctx) : "";
+            {
+                std::lock_guard<std::mutex> g(mu);
+                rc = r;
+                err = std::move(e);
+                n_chunks = nc;
+                seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                done = true;
+            }
+            cv.notify_all();
+        });
+    }
+    const uint8_t* wait_roots() {                              // nullptr: the scan failed (rc, err)
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return done; });
+        return rc ? nullptr : roots.data();
+    }
+    void join() { if (th.joinable()) th.join(); }
+    ~ScanJob() { join(); }
 };
 // memLayer.files: path -> header.  A merged base image puts a million keys in and throws them away when the merge is done
 // (only their number is reported): from the C library's heap that is a million small allocations, a million frees, and --
@@ -227,6 +273,31 @@ struct Fs {
     // content-aware isUpdated, counted per layer (mi_commit_stats): files whose header tario.IsSimilarHeader calls similar
     // and whose chunk roots differ; unchanged files whose node had no root yet and took the scan's
     uint64_t n_content_changed = 0, n_roots_learned = 0;
+    ScanJob* job = nullptr;                                                     // a pipelined commit's scan (else roots come ready)
+    std::vector<int64_t> pending_refs;                                          // nodes whose root[] is filled in when it ends
+    // the root a DECISION needs, now: waits for the scan when the node's root is still on its way (nullptr + rc: it failed)
+    const uint8_t* root_now(Node& x) {
+        if (!x.has_root) return nullptr;
+        if (x.root_pending) {
+            const uint8_t* r = job ? job->wait_roots() : nullptr;
+            if (!r) { fail(MI_ERR_IO, "gpu scan: " + (job ? job->err : std::string("no scan under way"))); return nullptr; }
+            memcpy(x.root, r + 32 * (uint64_t)x.batch_file, 32);
+            x.root_pending = false;
+        }
+        return x.root;
+    }
+    // the scan is through (roots) or has failed (nullptr): every node that was promised a root gets it, or loses the promise
+    void settle_pending(const uint8_t* roots, std::vector<Node>* layer_nodes) {
+        auto settle = [&](Node& x) {
+            if (!x.root_pending) return;
+            x.root_pending = false;
+            if (roots) memcpy(x.root, roots + 32 * (uint64_t)x.batch_file, 32);
+            else x.has_root = false;
+        };
+        for (int64_t ref : pending_refs) settle(nodes[(size_t)ref]);
+        pending_refs.clear();
+        if (layer_nodes) for (Node& x : *layer_nodes) settle(x);
+    }
     void clear_layer() { layer.clear(); anc_memo.valid = false; }
     // where dst splits into parent and name; npos = do not memo.  (dst is AbsPath's result in every caller -- the merge,
     // the scan, the copy ops: "/", then clean elements; so its parent IS the chain addAncestors walks.)
@@ -276,6 +347,7 @@ struct Fs {
     }
     // maybeAddToLayer(l, src, dst, hdr, createWhiteout) (mem_fs.go:440-483)
     void maybe_add(const std::string& src, const std::string& dst, Node n, bool create_whiteout = false) {
+        if (rc) return;
         bool updated = true;
         mi_memtree::Node* cur = t.find(dst);                                      // isUpdated (:487-503)
         const bool had_node = cur != nullptr;
@@ -291,9 +363,14 @@ struct Fs {
             fill(nodes[cur->ref], &a);
             fill(n, &b);
             int similar = 0;
-            const Node& o = nodes[cur->ref];
-            if (a.kind <= 3 && b.kind <= 3 &&
-                mi_entry_similar(&a, &b, 0, o.has_root ? o.root : nullptr, n.has_root ? n.root : nullptr, &similar) != MI_OK) {
+            Node& o = nodes[cur->ref];
+            // the roots decide only when BOTH sides carry one (mi_entry_similar ignores a single one): only then may the
+            // decision have to wait for a scan that is still running
+            const bool both = o.has_root && n.has_root && a.kind == 1 && b.kind == 1;
+            const uint8_t* ra = both ? root_now(o) : nullptr;
+            const uint8_t* rb = both ? root_now(n) : nullptr;
+            if (rc) return;
+            if (a.kind <= 3 && b.kind <= 3 && mi_entry_similar(&a, &b, 0, ra, rb, &similar) != MI_OK) {
                 fail(MI_ERR_INVALID, "check header " + dst + ": unsupported type");
                 return;
             }
@@ -301,7 +378,8 @@ struct Fs {
             if (similar && n.has_root && !o.has_root && n.e.kind == 1 && o.e.kind == 1) {   // the first content scan of an unchanged
                 Node& held = nodes[cur->ref];                                                // file: its root is known from now on
                 held.has_root = true;
-                memcpy(held.root, n.root, 32);
+                if (n.root_pending) { held.root_pending = true; held.batch_file = n.batch_file; pending_refs.push_back(cur->ref); }
+                else memcpy(held.root, n.root, 32);
                 ++n_roots_learned;
             } else if (!similar && o.has_root && n.has_root && a.kind == 1 && b.kind == 1) {
                 int meta = 0;
@@ -315,6 +393,7 @@ struct Fs {
             const uint8_t kind = n.e.kind;
             const std::string link = n.e.has_link ? n.e.link : std::string();
             const int64_t kref = keep(std::move(n));
+            if (nodes[(size_t)kref].root_pending) pending_refs.push_back(kref);
             // updateMemFS walks the tree part by part (mem_layer.go:57-80): every part before the last has to be a
             // node -- of any type.  A destination spelled THROUGH a symlink therefore works one level below the
             // link (the link node takes the child) and fails deeper ("missing intermediate directory"): what
@@ -367,10 +446,11 @@ struct Fs {
     // isUpdated (:487-503) on a walk entry as it comes, before any node is built for it: true = the tree holds this path
     // with a header tario.IsSimilarHeader calls similar (and, when both sides carry one, the same content root) --
     // maybeAddToLayer then adds nothing.  The scan's common case: most of a tree does not change between two steps.
-    bool holds_similar(const std::string& dst, const mi_tree_entry& e, const uint8_t* content_root) {
+    // lazy_file >= 0: the file's root is row lazy_file of a scan that may still be running (content_root is NULL then)
+    bool holds_similar(const std::string& dst, const mi_tree_entry& e, const uint8_t* content_root, int64_t lazy_file = -1) {
         mi_memtree::Node* cur = t.find(dst);
         if (!cur || cur->ref < 0 || e.kind > 3) return false;
-        const Node& o = nodes[cur->ref];
+        Node& o = nodes[cur->ref];
         if (o.e.kind > 3) return false;
         mi_tree_entry a, b = e;
         memset(&a, 0, sizeof a);
@@ -380,12 +460,24 @@ struct Fs {
         a.uid = o.e.uid; a.gid = o.e.gid; a.file_index = -1;
         b.relpath = dst.c_str() + 1;                                             // dst without its leading "/"
         b.file_index = -1;
+        const bool file_has_root = content_root != nullptr || lazy_file >= 0;
+        const uint8_t *ra = nullptr, *rb = nullptr;
+        if (o.has_root && file_has_root && a.kind == 1 && b.kind == 1) {         // both carry a root: it decides -- now
+            ra = root_now(o);
+            rb = content_root;
+            if (!rb && !rc) {
+                const uint8_t* r = job ? job->wait_roots() : nullptr;
+                if (!r) fail(MI_ERR_IO, "gpu scan: " + (job ? job->err : std::string("no scan under way")));
+                else rb = r + 32 * (uint64_t)lazy_file;
+            }
+            if (rc) return false;
+        }
         int similar = 0;
-        if (mi_entry_similar(&a, &b, 0, o.has_root ? o.root : nullptr, content_root, &similar) != MI_OK) return false;
-        if (similar && content_root && !o.has_root && o.e.kind == 1 && b.kind == 1) {    // (as in maybe_add)
-            Node& held = nodes[cur->ref];
-            held.has_root = true;
-            memcpy(held.root, content_root, 32);
+        if (mi_entry_similar(&a, &b, 0, ra, rb, &similar) != MI_OK) return false;
+        if (similar && file_has_root && !o.has_root && o.e.kind == 1 && b.kind == 1) {   // (as in maybe_add)
+            o.has_root = true;
+            if (content_root) memcpy(o.root, content_root, 32);
+            else { o.root_pending = true; o.batch_file = lazy_file; pending_refs.push_back(cur->ref); }
             ++n_roots_learned;
         }                                                                                // (a content-only change is counted
         return similar != 0;                                                             //  where it is added: maybe_add)
@@ -822,6 +914,10 @@ static int copy_ops_apply(mi_copy::Fs& fs, const mi_copy_op* ops, const CopyPlan
                     n.batch_file = we.file_index;
                     n.has_root = true;
                     memcpy(n.root, roots + (uint64_t)we.file_index * 32, 32);
+                } else if (fs.job && we.kind == 1 && we.file_index >= 0) {     // (a pipelined commit: the scan may still be running)
+                    n.batch_file = we.file_index;
+                    n.has_root = true;
+                    n.root_pending = true;
                 }
                 const std::string curr_src = is_src ? src : src + "/" + we.relpath;
                 fs.maybe_add(curr_src, curr_dst, n);
@@ -1406,9 +1502,12 @@ static int memfs_scan(mi_memfs* m, const mi_tree_entry* walked, uint64_t n, cons
     for (uint64_t i = 0; i < n && !fs.rc; ++i) {
         const mi_tree_entry& e = walked[i];
         mi_walk::abs_path_of_rel_into(e.relpath ? e.relpath : "", &p);
+        const bool lazy = !roots && fs.job && from_batch && e.kind == 1 && e.file_index >= 0;   // (the scan may still be running)
         const uint8_t* content_root =
             roots && e.kind == 1 && e.file_index >= 0 ? (const uint8_t*)roots + (uint64_t)e.file_index * root_stride : nullptr;
-        if (fs.holds_similar(p, e, content_root)) {                               // nothing to add; a directory's deletions
+        const bool held = fs.holds_similar(p, e, content_root, lazy ? e.file_index : -1);
+        if (fs.rc) break;
+        if (held) {                                                               // nothing to add; a directory's deletions
             if (e.kind == 0) fs.whiteout_missing_children(p);                     // are still looked for (maybe_add's tail)
             continue;
         }
@@ -1421,6 +1520,7 @@ static int memfs_scan(mi_memfs* m, const mi_tree_entry* walked, uint64_t n, cons
             memcpy(nd.root, (const uint8_t*)roots + (uint64_t)e.file_index * root_stride, 32);
         }
         if (from_batch && e.kind == 1 && e.file_index >= 0) nd.batch_file = e.file_index;
+        if (lazy) { nd.has_root = true; nd.root_pending = true; }
         const std::string src = fs.root == "/" ? p : fs.root + (p == "/" ? "" : p);
         fs.maybe_add(src, p, std::move(nd), true);
     }
@@ -1472,13 +1572,14 @@ static double secs_since(const std::chrono::steady_clock::time_point& t0) {
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 static int memfs_commit_write(mi_memfs* m, mi_copy_layer* cl, uint64_t ne, const mi_layer_config* cfg, mi_layer_result* res,
-                              mi_batch* batch) {
+                              mi_batch* batch, bool pipelined) {
     std::vector<mi_tree_entry> ents(ne ? ne : 1);
     std::vector<const char*> srcs(ne ? ne : 1);
     int rc = mi_copy_layer_entries(cl, ents.data(), srcs.data(), ne);
     mi_layer* lw = nullptr;
     if (rc) m->err = "failed to generate diff layer: layer entries";
     if (!rc && (rc = mi_layer_begin(cfg, &lw))) m->err = "failed to generate diff layer: the layer writer refused its configuration";
+    if (lw && pipelined) mi_layer_set_pipelined(lw, 1);        // a file's bytes are waited for where they have not landed yet
     for (uint64_t i = 0; i < ne && !rc; ++i) {
         const mi_copy::Node& nd = cl->nodes[i];
         if (ents[i].kind == 1 && ents[i].file_index >= 0) { ++m->last.n_layer_files; m->last.layer_file_bytes += ents[i].size; }
@@ -1530,19 +1631,45 @@ extern "C" int mi_memfs_commit_layer(mi_memfs* m, mi_ctx* ctx, int must_scan, co
         if (rc) return fail_with(rc, std::string("gpu scan: ") + mi_last_error(ctx));
         b = m->batch;
     }
+    // PIPELINED (default; MI_COMMIT_PIPELINE=0: one phase after the other): the scan -- the end of staging, the kernels, the
+    // roots' way back -- runs on a thread of its own (ScanJob) while this thread computes the layer and frames the tar from
+    // the bytes that have landed.  The diff waits for the scan only where a root DECIDES (a file the tree holds with a root
+    // and an unchanged header); an all-new layer, a first content scan, a COPY of new files never wait, and their commit
+    // costs what the reference's costs: the serial TarDigest.  Roots that were only to be RECORDED are filled in at the end.
+    static const bool pipeline_on = [] { const char* e = getenv("MI_COMMIT_PIPELINE"); return !(e && *e == '0'); }();
+    mi_copy::ScanJob job;
+    bool piped = false;
     std::vector<uint8_t> roots;
-    auto run_batch = [&]() -> int {                                               // scan what has been staged; the roots
+    auto start_scan = [&]() -> int {                                              // scan what has been staged
         uint64_t nf = 0, nbytes = 0;
         mi_batch_counts(b, &nf, nullptr, &nbytes);
         m->last.n_scanned_files = nf;
         m->last.scanned_bytes = nbytes;
         if (!nf) return MI_OK;
+        if (pipeline_on) {
+            job.start(b, ctx, nf);
+            fs.job = &job;
+            piped = true;
+            return MI_OK;
+        }
         const auto t0 = std::chrono::steady_clock::now();
         int r = mi_batch_run(b);
         if (!r) { roots.resize(nf * 32); r = mi_batch_roots(b, roots.data(), nf); }
         m->last.s_scan = secs_since(t0);
         if (!r) mi_batch_counts(b, nullptr, &m->last.n_chunks, nullptr);
         return r;
+    };
+    // the scan thread is joined and every promised root settled before anything returns (also on the error paths)
+    auto end_scan = [&](std::vector<mi_copy::Node>* layer_nodes) -> int {
+        if (!piped) return MI_OK;
+        const uint8_t* r = job.wait_roots();
+        job.join();
+        fs.job = nullptr;
+        piped = false;
+        fs.settle_pending(r, layer_nodes);
+        m->last.s_scan = job.seconds;
+        m->last.n_chunks = job.n_chunks;
+        return job.rc;
     };
     if (must_scan) {
         std::vector<const char*> bl;
@@ -1564,12 +1691,12 @@ extern "C" int mi_memfs_commit_layer(mi_memfs* m, mi_ctx* ctx, int must_scan, co
         }
         m->last.n_walked = n;
         m->last.s_walk_stage = secs_since(t0);
-        if (!rc && b && (rc = run_batch())) { if (t) mi_tree_free(t); return fail_with(rc, std::string("gpu scan: ") + mi_last_error(ctx)); }
+        if (!rc && b && (rc = start_scan())) { if (t) mi_tree_free(t); return fail_with(rc, std::string("gpu scan: ") + mi_last_error(ctx)); }
         const auto t1 = std::chrono::steady_clock::now();
         if (!rc) rc = memfs_scan(m, walked.data(), n, roots.empty() ? nullptr : roots.data(), 32, b != nullptr, &cl, &ne);
         m->last.s_diff = secs_since(t1);
         if (t) mi_tree_free(t);
-        if (rc) return fail_with(rc, m->err);
+        if (rc) { end_scan(nullptr); return fail_with(rc, m->err); }
     } else {
         fs.clear_layer();
         CopyPlan plan;
@@ -1579,11 +1706,12 @@ extern "C" int mi_memfs_commit_layer(mi_memfs* m, mi_ctx* ctx, int must_scan, co
         m->last.s_walk_stage = secs_since(t0);
         // (a plan that stopped at a failure is applied up to it: the failure is the apply step's to raise, in its place.
         //  What was staged until then is scanned all the same -- the ops before the failing one are applied WITH roots.)
-        if (b && (rc = run_batch())) return fail_with(rc, std::string("gpu scan: ") + mi_last_error(ctx));
+        if (b && (rc = start_scan())) return fail_with(rc, std::string("gpu scan: ") + mi_last_error(ctx));
         const auto t1 = std::chrono::steady_clock::now();
         std::string e;
         rc = copy_ops_apply(fs, ops, plan, roots.empty() ? nullptr : roots.data(), &e);
         if (rc) {
+            end_scan(nullptr);
             if (fs.rc) rc = memfs_fail(m); else { m->err = e; fs.clear_layer(); }
             return fail_with(rc, m->err);
         }
@@ -1595,8 +1723,15 @@ extern "C" int mi_memfs_commit_layer(mi_memfs* m, mi_ctx* ctx, int must_scan, co
     m->last.n_content_changed = fs.n_content_changed;
     m->last.n_roots_learned = fs.n_roots_learned;
     const auto t2 = std::chrono::steady_clock::now();
-    rc = memfs_commit_write(m, cl, ne, cfg, res, b);
+    const bool was_piped = piped;
+    rc = memfs_commit_write(m, cl, ne, cfg, res, b, piped);
     m->last.s_write = secs_since(t2);
+    {   // the scan's verdict: a file that vanished or shrank since the walk fails the commit here -- after the tree took the
+        // layer, as a failing tar write does in the reference (AddLayerByScan updates the tree, then writes)
+        const int src = end_scan(&cl->nodes);
+        if (src && !rc) { rc = src; m->err = "failed to generate diff layer: write diffs: " + std::string(how) + "gpu scan: " + job.err; }
+    }
+    m->last.pipelined = was_piped ? 1 : 0;
     if (!rc && b && m->index && m->last.n_scanned_files) {
         rc = mi_index_add_batch(m->index, b, nullptr, 0, &m->last.n_index_new, &m->last.n_index_known);
         if (rc) m->err = std::string("failed to generate diff layer: chunk index: ") + mi_last_error(ctx);

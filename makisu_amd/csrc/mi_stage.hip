@@ -171,16 +171,6 @@ void item_consumed(const StageItem& it) {
     if (--it.latch->left == 0) it.latch->cv.notify_all();
 }
 
-// the item's bytes are in HBM (or its batch has been marked failed)
-void item_landed(Stager* st, const StageItem& it) {
-    bool wake = false;
-    {
-        std::lock_guard<std::mutex> g(st->mu);
-        wake = --it.batch->stage_pending == 0;
-    }
-    if (wake) st->cv_done.notify_all();
-}
-
 // what the GPU holds in [dev, dev+len) next to what it should hold: one line for the error message
 static std::string describe_span(const u8* dev, const u8* want, u64 len, hipStream_t stream) {
     std::vector<u8> got(len);
@@ -255,6 +245,7 @@ void worker(Stager* st, u32 tid) {
                 run.push_back(f);
                 st->queue.pop_front();
             }
+            run.front().batch->stage_inflight.insert(start);    // (taken back when the run has landed: stager_wait_landed)
         }
         mi_batch* b = run.front().batch;
         const u64 start = run.front().arena_off;
@@ -372,7 +363,16 @@ void worker(Stager* st, u32 tid) {
             std::lock_guard<std::mutex> g(st->mu);
             if (b->stage_err.empty()) b->stage_err = err;
         }
-        for (const StageItem& it : run) item_landed(st, it);
+        {                                                      // the run's bytes are in HBM (or its batch is marked failed)
+            bool wake;
+            {
+                std::lock_guard<std::mutex> g(st->mu);
+                b->stage_inflight.erase(b->stage_inflight.find(start));
+                b->stage_pending -= run.size();
+                wake = b->stage_pending == 0 || b->stage_waiters > 0;
+            }
+            if (wake) st->cv_done.notify_all();
+        }
     }
     if (slab) (void)hipHostFree(slab);
     if (d_sums) (void)hipFree(d_sums);
@@ -505,6 +505,26 @@ int stager_drain(Stager* st, mi_batch* b) {
         std::unique_lock<std::mutex> lk(st->mu);
         st->cv_done.wait(lk, [&] { return b->stage_pending == 0; });
         msg = b->stage_err;
+    }
+    if (!msg.empty()) return fail(b->ctx, MI_ERR_IO, "%s", msg.c_str());
+    return MI_OK;
+}
+
+int stager_wait_landed(Stager* st, mi_batch* b, u64 upto, u64* landed_out) {
+    std::string msg;
+    {
+        std::unique_lock<std::mutex> lk(st->mu);
+        auto landed_upto = [&]() -> u64 {                       // everything below this arena offset has landed
+            u64 m = b->stage_inflight.empty() ? ~0ull : *b->stage_inflight.begin();
+            for (const StageItem& it : st->queue)               // (a batch's pieces are queued in arena order: its first one)
+                if (it.batch == b) { if (it.arena_off < m) m = it.arena_off; break; }
+            return m;
+        };
+        ++b->stage_waiters;
+        st->cv_done.wait(lk, [&] { return !b->stage_err.empty() || landed_upto() >= upto; });
+        --b->stage_waiters;
+        msg = b->stage_err;
+        if (landed_out) *landed_out = landed_upto();            // (~0: everything queued so far)
     }
     if (!msg.empty()) return fail(b->ctx, MI_ERR_IO, "%s", msg.c_str());
     return MI_OK;

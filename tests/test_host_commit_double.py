@@ -29,9 +29,12 @@ def test_the_commit_reads_each_file_once_and_writes_the_references_tar(hip_doubl
 
 @pytest.mark.parametrize("env", [{"MI_WALK_INLINE": "0"}, {"MI_WALK_INLINE_MAX_KIB": "2"}, {"MI_WALK_THREADS": "1"},
                                  {"MI_WALK_INLINE_MB": "1"}, {"MI_WALK_UNSHARE": "0"}, {"MI_WALK_CLOSE_RANGE": "0"},
-                                 {"MI_HIP_STUB_COPY_US": "50"}])
+                                 {"MI_HIP_STUB_COPY_US": "50"}, {"MI_COMMIT_PIPELINE": "0"},
+                                 {"MI_HIP_STUB_COPY_US": "200", "MI_HIP_STUB_KERNEL_US": "2000"}])
 def test_whichever_way_the_bytes_reach_the_arena(hip_double, tmp_path, env):  # noqa: F811
     """the walk's knobs move files between the two ways into the arena (a directory's block / a path for the reader threads)
     and change the order in which bytes land; MI_WALK_CLOSE_RANGE=0 is the kernel without close_range (the
-    directory readers then stay on the shared descriptor table); slow copies widen every window"""
+    directory readers then stay on the shared descriptor table); slow copies widen every window -- the tar writer then
+    runs far ahead of the staging it reads from (the pipelined commit: a file's bytes are waited for); MI_COMMIT_PIPELINE=0 is
+    the commit one phase after the other"""
     _run(hip_double, tmp_path, 4, env)

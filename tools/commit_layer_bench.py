@@ -8,7 +8,8 @@ without (the reference's commit: headers decide, the writer reads the changed fi
                        price of watching content;
     0.1 % changed      n/1000 files rewritten (same size): nine in ten with a new mtime -- both see them -- one in ten
                        within the same second -- only the content scan sees those.
-Wall seconds per commit, split as mi_commit_stats splits them.  bench.py puts the table into its JSON line
+Wall seconds per commit, split as mi_commit_stats splits them (with a ctx the scan runs BESIDE the diff and the tar writer:
+its seconds are not part of the sum).  bench.py puts the table into its JSON line
 (`commit_e2e`); as a program: commit_layer_bench.py [files = 100000] [bytes = 4096]   (needs an MI355X)
 MI_WALK_TIMING / MI_MEMFS_TIMING lines (stderr) show where the host time of each commit went."""
 import os
@@ -46,7 +47,7 @@ def _side(st, res, wall):
             "s_diff": round(st["s_diff"], 4), "s_write": round(st["s_write"], 4), "layer_entries": int(res["n_entries"]),
             "layer_files": int(st["n_layer_files"]), "tar_bytes": int(res["tar_bytes"]),
             "files_read": int(st["files_opened"]), "bytes_read": int(st["file_bytes_read"]),
-            "content_only_changes": int(st["n_content_changed"])}
+            "content_only_changes": int(st["n_content_changed"]), "scan_overlapped": bool(st["pipelined"])}
 
 
 def commit_e2e(eng, n_files, file_bytes, base=None, gzip_level=None):
@@ -98,9 +99,10 @@ def main():
         print("  " + row["what"])
         for side in ("gpu", "cpu_header_only"):
             r = row[side]
-            print("    %-16s %7.3f s = walk%s %.3f + scan %.3f + diff %.3f + tar %.3f | layer: %d entries, %d files, %d tar bytes | "
+            print("    %-16s %7.3f s = walk%s %.3f + diff %.3f + tar %.3f; scan %.3f%s | layer: %d entries, %d files, %d tar bytes | "
                   "read %d files, %d bytes | content-only changes %d" %
-                  (side, r["s_total"], "+stage" if side == "gpu" else "", r["s_walk_stage"], r["s_scan"], r["s_diff"], r["s_write"],
+                  (side, r["s_total"], "+stage" if side == "gpu" else "", r["s_walk_stage"], r["s_diff"], r["s_write"], r["s_scan"],
+                   " (beside diff and tar)" if r["scan_overlapped"] else "",
                    r["layer_entries"], r["layer_files"], r["tar_bytes"], r["files_read"], r["bytes_read"], r["content_only_changes"]))
 
 

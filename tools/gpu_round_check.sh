@@ -23,4 +23,4 @@ MI_BENCH_FORCE_DEVICE=0 MI_RCCL_LIB=$STUB timeout 200 python bench.py --gpus 8 -
 echo "== the driver's launch line, two ranks on this GPU: native exchange, torch ships the id (gloo)"
 MI_BENCH_FORCE_DEVICE=0 MI_RCCL_LIB=$STUB timeout 200 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --files 20000 --steps 4 --warmup 1 2>&1 | tail -2 | cut -c1-500
 echo "== one rank, forced exchange over real RCCL"
-timeout 170 python bench.py --force-exchange --steps 10 --warmup 2 --no-cpu-baseline 2>&1 | tail -1 | cut -c1-420
+timeout 170 python bench.py --force-exchange --steps 10 --warmup 2 --no-cpu-baseline --no-with-rows --no-commit-e2e 2>&1 | tail -1 | cut -c1-420

@@ -15,13 +15,13 @@ $T python bench.py 2> $out/bench.err | grep "^{" | tail -1 > $out/${tag}_bench_n
 tail -c 300 $out/${tag}_bench_n1.json; echo
 # one batch at a time (every kernel has the GPU to itself: the durations `roofline` is computed from -- the bench takes them
 # from its own one-at-a-time steps), and the bench's default form (two batches in flight in the timed region, then serial steps)
-$T rocprofv3 --kernel-trace --stats -d $out/kt -o kt -- python bench.py --steps 40 --warmup 2 --inflight 1 --no-cpu-baseline > $out/kt.log 2>&1
-$T rocprofv3 --kernel-trace --stats -d $out/kts -o kts -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline > $out/kts.log 2>&1
-{ echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 40 --warmup 2 --inflight 1 --no-cpu-baseline   (one batch at a time: a launch's duration is the kernel's own -- what roofline.avg_launch_ms measures)"; summ $out/kt; } > $out/${tag}_kernel_trace_stats.txt 2>&1
-{ echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline   (the default command: 12 steps with two batches in flight -- launches overlap --, then 12 one at a time)"; summ $out/kts; } > $out/${tag}_kernel_trace_stats_default.txt 2>&1
+$T rocprofv3 --kernel-trace --stats -d $out/kt -o kt -- python bench.py --steps 40 --warmup 2 --inflight 1 --no-cpu-baseline --no-with-rows --no-commit-e2e > $out/kt.log 2>&1
+$T rocprofv3 --kernel-trace --stats -d $out/kts -o kts -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-with-rows --no-commit-e2e > $out/kts.log 2>&1
+{ echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 40 --warmup 2 --inflight 1 --no-cpu-baseline --no-with-rows --no-commit-e2e   (one batch at a time: a launch's duration is the kernel's own -- what roofline.avg_launch_ms measures)"; summ $out/kt; } > $out/${tag}_kernel_trace_stats.txt 2>&1
+{ echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-with-rows --no-commit-e2e   (the default command: 12 steps with two batches in flight -- launches overlap --, then 12 one at a time)"; summ $out/kts; } > $out/${tag}_kernel_trace_stats_default.txt 2>&1
 # HBM traffic: one --pmc pass per counter, kernel trace only
-$T rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/fetch -o fetch -- python bench.py --steps 3 --warmup 1 --inflight 1 --no-cpu-baseline > $out/fetch.log 2>&1
-$T rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/write -o write -- python bench.py --steps 3 --warmup 1 --inflight 1 --no-cpu-baseline > $out/write.log 2>&1
+$T rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $out/fetch -o fetch -- python bench.py --steps 3 --warmup 1 --inflight 1 --no-cpu-baseline --no-with-rows --no-commit-e2e > $out/fetch.log 2>&1
+$T rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $out/write -o write -- python bench.py --steps 3 --warmup 1 --inflight 1 --no-cpu-baseline --no-with-rows --no-commit-e2e > $out/write.log 2>&1
 summ $out/fetch > $out/${tag}_fetch.txt 2>&1
 summ $out/write > $out/${tag}_write.txt 2>&1
 cp $out/${tag}_fetch.txt $out/${tag}_pmc_fetch_size.txt; cp $out/${tag}_write.txt $out/${tag}_pmc_write_size.txt
@@ -34,7 +34,7 @@ for scheme in 1000 0; do
   for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
              "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INST_CYCLES_VMEM SQ_LDS_ADDR_CONFLICT"; do
     rm -rf $out/sq
-    MI_SHA_COOP_MIN_GIB=$scheme $T rocprofv3 --pmc $set --kernel-trace -d $out/sq -o sq -- python bench.py --steps 3 --warmup 1 --inflight 1 --no-cpu-baseline > $out/sq.log 2>&1
+    MI_SHA_COOP_MIN_GIB=$scheme $T rocprofv3 --pmc $set --kernel-trace -d $out/sq -o sq -- python bench.py --steps 3 --warmup 1 --inflight 1 --no-cpu-baseline --no-with-rows --no-commit-e2e > $out/sq.log 2>&1
     summ $out/sq 2>&1 | grep -E "gear_|sha256_items_kernel<0" | grep -v "^void mi::sha256_items_kernel<0.*FETCH"
   done
 done
@@ -46,18 +46,18 @@ done
   for f in 0 2; do echo -n "C2 flags=$f: "; timeout 100 python tools/quick_bench.py --steps 10 --flags $f 2>&1 | grep inflight | tail -1; done; } > $out/${tag}_crc_pass.txt
 
 # ---- the other BASELINE configs: bench lines; kernel trace + traffic for C3 and C5 ----
-$T python bench.py --config c3 --no-cpu-baseline > $out/${tag}_bench_c3.json 2> $out/bench_c3.err
-$T python bench.py --config c5 --no-cpu-baseline > $out/${tag}_bench_c5.json 2> $out/bench_c5.err
-$T python bench.py --config c5u --no-cpu-baseline > $out/${tag}_bench_c5u.json 2> $out/bench_c5u.err
-$T python bench.py --config c2 --force-exchange --no-cpu-baseline > $out/${tag}_bench_c2_native_exchange.json 2> $out/bench_x.err
+$T python bench.py --config c3 --no-cpu-baseline --no-with-rows --no-commit-e2e > $out/${tag}_bench_c3.json 2> $out/bench_c3.err
+$T python bench.py --config c5 --no-cpu-baseline --no-with-rows --no-commit-e2e > $out/${tag}_bench_c5.json 2> $out/bench_c5.err
+$T python bench.py --config c5u --no-cpu-baseline --no-with-rows --no-commit-e2e > $out/${tag}_bench_c5u.json 2> $out/bench_c5u.err
+$T python bench.py --config c2 --force-exchange --no-cpu-baseline --no-with-rows --no-commit-e2e > $out/${tag}_bench_c2_native_exchange.json 2> $out/bench_x.err
 # one rank's C4 shard (1.25 M files, 76 GiB) on one GPU
-$T python bench.py --config c4 --no-cpu-baseline --steps 4 --warmup 1 > $out/${tag}_bench_c4_one_shard.json 2> $out/bench_c4.err
+$T python bench.py --config c4 --no-cpu-baseline --no-with-rows --no-commit-e2e --steps 4 --warmup 1 > $out/${tag}_bench_c4_one_shard.json 2> $out/bench_c4.err
 for cfg in c3 c5; do
-  $T rocprofv3 --kernel-trace --stats -d $out/kt_$cfg -o kt -- python bench.py --config $cfg --steps 2 --warmup 1 --inflight 1 --no-cpu-baseline --no-host-fed > $out/kt_$cfg.log 2>&1
-  { echo "# rocprofv3 --kernel-trace --stats -- python bench.py --config $cfg --steps 2 --warmup 1 --inflight 1 --no-cpu-baseline --no-host-fed"; summ $out/kt_$cfg; } > $out/${tag}_kernel_trace_stats_$cfg.txt 2>&1
+  $T rocprofv3 --kernel-trace --stats -d $out/kt_$cfg -o kt -- python bench.py --config $cfg --steps 2 --warmup 1 --inflight 1 --no-cpu-baseline --no-with-rows --no-commit-e2e --no-host-fed > $out/kt_$cfg.log 2>&1
+  { echo "# rocprofv3 --kernel-trace --stats -- python bench.py --config $cfg --steps 2 --warmup 1 --inflight 1 --no-cpu-baseline --no-with-rows --no-commit-e2e --no-host-fed"; summ $out/kt_$cfg; } > $out/${tag}_kernel_trace_stats_$cfg.txt 2>&1
   for ctr in FETCH_SIZE WRITE_SIZE; do
     rm -rf $out/pmc_$cfg
-    $T rocprofv3 --pmc $ctr --kernel-trace -d $out/pmc_$cfg -o p -- python bench.py --config $cfg --steps 1 --warmup 1 --inflight 1 --no-cpu-baseline --no-host-fed > $out/pmc_$cfg.log 2>&1
+    $T rocprofv3 --pmc $ctr --kernel-trace -d $out/pmc_$cfg -o p -- python bench.py --config $cfg --steps 1 --warmup 1 --inflight 1 --no-cpu-baseline --no-with-rows --no-commit-e2e --no-host-fed > $out/pmc_$cfg.log 2>&1
     { echo "# rocprofv3 --pmc $ctr --kernel-trace -- python bench.py --config $cfg --steps 1 --warmup 1 --inflight 1 (counter averages per dispatch, KiB; FETCH_SIZE x2 on gfx950)"; summ $out/pmc_$cfg | grep -E "$ctr" | head -12; } >> $out/${tag}_pmc_$cfg.txt 2>&1
   done
   rm -rf $out/kt_$cfg $out/pmc_$cfg
