@@ -827,7 +827,11 @@ def main():
             dbg("id shipped")
             if isinstance(uid[0], tuple):
                 raise RuntimeError("rank 0 could not create the communicator id: %s" % uid[0][1])
-            eng.comm_init_rank(world, rank, uid[0])
+            # (under the same watchdog as the bare form's bring-up: a rank that hangs in ncclCommInitRank reports it, and all
+            #  ranks fall back together -- the torch driver of the same exchange gets its chance)
+            _, why = watched("mi_comm_init_rank(%d of %d)" % (rank, world), args.watchdog_s, lambda: eng.comm_init_rank(world, rank, uid[0]))
+            if why:
+                raise RuntimeError(why)
             dbg("communicator up")
             if os.environ.get("MI_BENCH_FAIL_NATIVE_ON_RANK") == str(rank):      # self-test of the fallback
                 raise RuntimeError("simulated failure after the communicator came up")
