@@ -267,6 +267,7 @@ def load_library(rebuild=False):
         "mi_memfs_commit_stats": ([vp, C.POINTER(CommitStats)], C.c_int),
         "mi_memfs_set_index": ([vp, vp], C.c_int),
         "mi_memfs_release_device": ([vp], C.c_int),
+        "mi_memfs_reserve_device": ([vp, vp, u64, u64], C.c_int),
         "mi_memfs_root_of": ([vp, C.c_char_p, vp, C.POINTER(C.c_int)], C.c_int),
         "mi_copy_layer_roots": ([vp, vp, vp, u64], C.c_int),
         "mi_batch_roots": ([vp, vp, u64], C.c_int),
@@ -717,6 +718,11 @@ class MemFS:
         """every content-aware commit adds its batch's chunks to `index` (a ChunkIndex of the same Engine); None stops"""
         self._index = index                                   # (kept alive)
         self._check(self._lib.mi_memfs_set_index(self._h, index._h if index is not None else None), "mi_memfs_set_index")
+
+    def reserve_device(self, engine, files, nbytes):
+        """the handle's batch ahead of its first commit (a ctx's first use costs: see the header)"""
+        engine._children.add(self)
+        self._check(self._lib.mi_memfs_reserve_device(self._h, engine._h, files, nbytes), "mi_memfs_reserve_device")
 
     def release_device(self):
         if self._h:

@@ -1756,6 +1756,25 @@ extern "C" int mi_memfs_set_index(mi_memfs* m, mi_index* index) {
     m->index = index;
     return MI_OK;
 }
+// The handle's batch, made ahead of its first commit and sized for `bytes` of files in `files` files: fresh device memory costs
+// 68 ms per GiB to allocate (tools/first_use_probe.py) and the ctx's reader threads 55 ms to come up -- a host that knows what
+// is coming (the base image it is pulling) pays that beside its own work instead of inside the first commit
+extern "C" int mi_memfs_reserve_device(mi_memfs* m, mi_ctx* ctx, uint64_t files, uint64_t bytes) {
+    if (!m || !ctx) return MI_ERR_INVALID;
+    int rc = MI_OK;
+    if (m->batch && m->batch_ctx != ctx) { mi_batch_free(m->batch); m->batch = nullptr; }
+    if (!m->batch) {
+        rc = mi_batch_begin(ctx, files, bytes, &m->batch);
+        m->batch_ctx = ctx;
+    } else {
+        rc = mi_batch_reset(m->batch);
+        if (!rc) rc = mi_batch_reserve(m->batch, files, bytes);
+    }
+    if (!rc) mi_batch_expect_host_bytes(m->batch);                                // (the reader threads set up behind the call)
+    if (rc) m->err = std::string("reserve device memory: ") + mi_last_error(ctx);
+    return rc;
+}
+
 // the commit's batch (its arena holds the last scanned tree's bytes) is given back; the next content-aware commit begins anew
 extern "C" int mi_memfs_release_device(mi_memfs* m) {
     if (!m) return MI_ERR_INVALID;

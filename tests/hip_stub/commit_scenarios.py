@@ -116,6 +116,7 @@ def scenario_many(tmp, eng):
             write_file(os.path.join(root, rel), data, 0o644, MTIME)
             files[rel] = data
     with M.MemFS(root) as fs:
+        fs.reserve_device(eng, len(files), sum(map(len, files.values())))        # the arena and the reader threads, ahead of time
         res, raw = commit_to_bytes(fs, tmp, "m0.tar", must_scan=True, engine=eng)
         assert {n: d for n, m, d in tar_members(raw) if m.isfile()} == files
         nonempty = sum(1 for d in files.values() if d)

@@ -343,6 +343,22 @@ def test_the_commit_feeds_the_chunk_index(oracle, eng, tmp_path):
         assert rb["tar_digest"] == ra["tar_digest"]
 
 
+def test_the_handles_batch_can_be_made_ahead_of_the_first_commit(oracle, eng, tmp_path):
+    """mi_memfs_reserve_device: arena and reader threads before the first commit (a ctx's first use is what costs); too small a
+    guess only means the arena grows, a handle that already committed is re-sized in place"""
+    root = str(tmp_path / "root")
+    files = make_tree(root, seed=17, mtime=MTIME)
+    total = sum(map(len, files.values()))
+    for guess in (total, total // 10):
+        with M.MemFS(root) as fs:
+            fs.reserve_device(eng, len(files), guess)
+            res, raw = commit_to_bytes(fs, tmp_path, "r.tar", must_scan=True, engine=eng)
+            assert {n: d for n, m, d in tar_members(raw) if m.isfile()} == files
+            assert fs.root_of("/d00/f001.bin") == oracle_root(oracle, files["d00/f001.bin"])
+            fs.reserve_device(eng, len(files), 2 * total)
+            assert commit_to_bytes(fs, tmp_path, "r2.tar", must_scan=True, engine=eng)[0]["n_entries"] == 0
+
+
 def test_read_file_serves_any_range_of_any_staged_file(eng):
     """mi_batch_read_file against the bytes that were added: whole files, ranges across window boundaries, backwards"""
     rng = np.random.default_rng(8)
