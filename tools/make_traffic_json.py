@@ -34,7 +34,7 @@ def main():
     out = {
         "round": int(tag.lstrip("r")),
         "source": "profiles/%s_pmc_fetch_size.txt + %s_pmc_write_size.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                  "--kernel-trace -- python bench.py --steps 3 --warmup 1 --inflight 1 --no-cpu-baseline), same "
+                  "--kernel-trace -- python bench.py --steps 3 --warmup 1 --inflight 1 --no-cpu-baseline --no-with-rows --no-commit-e2e), same "
                   "tools/round_profiles.sh run as the round's bench line" % (tag, tag),
         "kernel": "mi::sha256_items_kernel<0, false> (chunk pass), C2 batch",
         "FETCH_SIZE_KiB_raw": fetch[sha][1],
