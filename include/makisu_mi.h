@@ -735,6 +735,7 @@ typedef struct {
     uint64_t layer_file_bytes;
     uint64_t n_content_changed;  /* files IsSimilarHeader calls similar whose chunk roots differ: in the layer  */
     uint64_t n_roots_learned;    /* unchanged files that had no root in the tree and have one now               */
+    uint64_t n_content_trusted;  /* MI_MEMFS_TRUST_CTIME: files that were not read again (their inode is as it was)  */
     uint64_t n_index_new, n_index_known;   /* mi_index_add_batch's counts (index set)                           */
     uint64_t files_opened;       /* file descriptors whose content was read, by every thread of the library ... */
     uint64_t file_bytes_read;    /* ... and the bytes read from them, during this commit (process-wide counters:
@@ -750,6 +751,17 @@ typedef struct {
 int  mi_memfs_commit_layer(mi_memfs* fs, mi_ctx* ctx, int must_scan, const mi_copy_op* ops, uint64_t n_ops,
                            const mi_layer_config* cfg, mi_layer_result* res, mi_copy_layer** layer_out, int* committed);
 int  mi_memfs_commit_stats(const mi_memfs* fs, mi_commit_stats* out);
+/* Options of a handle's content-aware commits (default: none).
+ * MI_MEMFS_TRUST_CTIME: a scan commit does not read a regular file again whose inode is what it was when the tree's root for
+ * it was computed -- same device, inode number, size, mtime and ctime, to the nanosecond.  ctime is the kernel's own record
+ * of the last change of an inode and cannot be set from user space (utimes sets it to "now"), so the same-size same-SECOND
+ * rewrite the reference misses still changes it.  What git calls "racily clean" is handled as git does: a file whose ctime is
+ * not safely older than the moment its content was read (MI_TRUST_CTIME_SLACK_MS, default 20: the kernel's timestamps tick
+ * every 1-4 ms) is read again.  With the option a commit that changed nothing costs a walk and a diff (the reference's
+ * price) instead of a read of the whole tree; the layer, the roots and the DigestPair are the same unless the kernel's
+ * timestamps lie (a clock set back between a write and the next one to the same file).  Scan commits only.                */
+#define MI_MEMFS_TRUST_CTIME 0x1u
+int  mi_memfs_set_options(mi_memfs* fs, uint32_t options);
 /* From now on every content-aware commit of this handle adds its batch to `index` (NULL: stop).  The index must belong
  * to the ctx the commits run on and outlive them; the handle does not own it.                                          */
 int  mi_memfs_set_index(mi_memfs* fs, mi_index* index);

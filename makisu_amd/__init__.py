@@ -99,6 +99,7 @@ class LayerConfig(C.Structure):
 
 
 LAYER_MODE_WITH_TYPE = 0x1
+MEMFS_TRUST_CTIME = 0x1
 
 
 class LayerResult(C.Structure):
@@ -112,7 +113,7 @@ GZIP_OFF, GZIP_DEFAULT = -2, -1
 
 class CommitStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("n_walked", "n_scanned_files", "scanned_bytes", "n_chunks", "n_layer_entries",
-                                          "n_layer_files", "layer_file_bytes", "n_content_changed", "n_roots_learned",
+                                          "n_layer_files", "layer_file_bytes", "n_content_changed", "n_roots_learned", "n_content_trusted",
                                           "n_index_new", "n_index_known", "files_opened", "file_bytes_read", "pipelined")] + \
                [(n, C.c_double) for n in ("s_walk_stage", "s_scan", "s_diff", "s_write", "s_total")]
 
@@ -266,6 +267,7 @@ def load_library(rebuild=False):
                                    C.POINTER(vp), C.POINTER(C.c_int)], C.c_int),
         "mi_memfs_commit_stats": ([vp, C.POINTER(CommitStats)], C.c_int),
         "mi_memfs_set_index": ([vp, vp], C.c_int),
+        "mi_memfs_set_options": ([vp, C.c_uint32], C.c_int),
         "mi_memfs_release_device": ([vp], C.c_int),
         "mi_memfs_reserve_device": ([vp, vp, u64, u64], C.c_int),
         "mi_memfs_root_of": ([vp, C.c_char_p, vp, C.POINTER(C.c_int)], C.c_int),
@@ -723,6 +725,10 @@ class MemFS:
         """the handle's batch ahead of its first commit (a ctx's first use costs: see the header)"""
         engine._children.add(self)
         self._check(self._lib.mi_memfs_reserve_device(self._h, engine._h, files, nbytes), "mi_memfs_reserve_device")
+
+    def set_options(self, trust_ctime=False):
+        """MI_MEMFS_TRUST_CTIME: scan commits do not read files again whose inode is what it was when they were hashed"""
+        self._check(self._lib.mi_memfs_set_options(self._h, MEMFS_TRUST_CTIME if trust_ctime else 0), "mi_memfs_set_options")
 
     def release_device(self):
         if self._h:

@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <functional>
 #include <mutex>
 #include <set>
 #include <string>
@@ -26,6 +27,15 @@ extern std::atomic<uint64_t> content_opens, content_bytes;
 namespace mi_walk {
 
 
+// what the kernel says about an inode beyond the tar header's fields: the identity of a regular file's CONTENT between two
+// scans (MI_MEMFS_TRUST_CTIME: a file whose inode, size, mtime and ctime -- to the nanosecond -- are what they were when its
+// content was last hashed is not read again; ctime cannot be set from user space)
+struct InodeStamp {
+    uint64_t dev = 0, ino = 0;
+    int64_t mtime_ns = 0, ctime_ns = 0;
+    bool operator==(const InodeStamp& o) const { return dev == o.dev && ino == o.ino && mtime_ns == o.mtime_ns && ctime_ns == o.ctime_ns; }
+};
+
 struct Entry {
     std::string relpath, link;
     bool has_link = false;
@@ -35,6 +45,8 @@ struct Entry {
     int64_t mtime = 0;
     uint8_t kind = 0;      // 0 dir, 1 regular, 2 symlink
     uint32_t uid = 0, gid = 0;
+    bool content_known = false;   // a regular file the walk did NOT stage: the caller said its content is known (Walker::content_known)
+    InodeStamp stamp;             // regular files
 };
 
 struct Tree {
@@ -233,5 +245,10 @@ inline const MountTable& mountpoints() {
 // lose link_root (createHeader trims by the MemFS root).  Defined in mi_tree.hip, beside the walkers.
 int scan_walk_collect(const std::string& src, const std::string& link_root, Tree* out, std::string* err);
 int scan_walk_collect_batch(const std::string& src, const std::string& link_root, Tree* out, std::string* err, mi_batch* b);
+// mi_batch_add_tree with the scan rules and a say in which files are staged: known(path on disk, size, stamp) == true means
+// "this file's content is known, do not read it" -- called from the walk's directory readers, several at a time
+int scan_walk_batch_filtered(mi_batch* b, const std::string& root, const std::vector<std::string>& blacklist,
+                             const std::function<bool(const std::string&, uint64_t, const InodeStamp&)>& known, Tree** tree_out,
+                             std::string* err);
 
 }  // namespace mi_walk

@@ -16,9 +16,11 @@
 #include <grp.h>
 #include <pwd.h>
 #include <sys/stat.h>
+#include <time.h>
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <memory_resource>
 #include <mutex>
@@ -59,6 +61,10 @@ struct Node {
     uint8_t root[32];
     int64_t batch_file = -1;   // a content-aware commit under way: the file's row in the commit's batch -- its bytes lie in HBM
     bool root_pending = false; // ... and its root is still being computed (a pipelined commit: ScanJob); root[] is not valid yet
+    // MI_MEMFS_TRUST_CTIME: the inode as it was when the content behind `root` was read, and when that was (CLOCK_REALTIME at
+    // the start of that commit's walk; 0 = never: the root came from elsewhere)
+    mi_walk::InodeStamp stamp;
+    int64_t hashed_at_ns = 0;
 };
 
 // The GPU scan of a pipelined commit, on a thread of its own: mi_batch_run (the end of staging, the kernels) and the roots'
@@ -273,6 +279,26 @@ struct Fs {
     // content-aware isUpdated, counted per layer (mi_commit_stats): files whose header tario.IsSimilarHeader calls similar
     // and whose chunk roots differ; unchanged files whose node had no root yet and took the scan's
     uint64_t n_content_changed = 0, n_roots_learned = 0;
+    bool trust_ctime = false;                                                   // mi_memfs_set_options(MI_MEMFS_TRUST_CTIME)
+    int64_t commit_started_ns = 0;                                              // CLOCK_REALTIME when the commit under way began its walk
+    std::atomic<uint64_t> n_content_trusted{0};                                 // files of this commit that were not read again
+    // "is the content of the regular file at `disk_path` known?" -- asked by the walk's directory readers, several at a time,
+    // while nothing changes the tree (the diff runs after the walk).  Known = the tree holds the path with a root that was
+    // computed from THIS inode in THIS state: same device, inode, size, mtime and ctime to the nanosecond -- and the ctime lies
+    // safely before the moment the content was read (a write in the same clock tick as the recorded ctime would leave no
+    // trace: git's "racily clean" rule; MI_TRUST_CTIME_SLACK_MS, default 20, covers the kernel's coarse clock).
+    bool content_is_known(const std::string& disk_path, uint64_t size, const mi_walk::InodeStamp& st) {
+        static const int64_t slack_ns = [] { const char* e = getenv("MI_TRUST_CTIME_SLACK_MS"); return (int64_t)(e && *e ? atol(e) : 20) * 1000000ll; }();
+        const size_t root_len = root == "/" ? 0 : root.size();
+        if (disk_path.size() <= root_len || memcmp(disk_path.data(), root.data(), root_len) != 0) return false;
+        const mi_memtree::Node* nd = t.find_walk(disk_path.substr(root_len));     // (find_walk keeps no cache: safe from many threads)
+        if (!nd || nd->ref < 0) return false;
+        const Node& x = nodes[(size_t)nd->ref];
+        if (x.e.kind != 1 || !x.has_root || x.root_pending || !x.hashed_at_ns || x.e.size != size || !(x.stamp == st)) return false;
+        if (st.ctime_ns + slack_ns >= x.hashed_at_ns) return false;              // racily clean: read it again
+        n_content_trusted.fetch_add(1, std::memory_order_relaxed);
+        return true;
+    }
     ScanJob* job = nullptr;                                                     // a pipelined commit's scan (else roots come ready)
     std::vector<int64_t> pending_refs;                                          // nodes whose root[] is filled in when it ends
     // the root a DECISION needs, now: waits for the scan when the node's root is still on its way (nullptr + rc: it failed)
@@ -447,11 +473,16 @@ struct Fs {
     // with a header tario.IsSimilarHeader calls similar (and, when both sides carry one, the same content root) --
     // maybeAddToLayer then adds nothing.  The scan's common case: most of a tree does not change between two steps.
     // lazy_file >= 0: the file's root is row lazy_file of a scan that may still be running (content_root is NULL then)
-    bool holds_similar(const std::string& dst, const mi_tree_entry& e, const uint8_t* content_root, int64_t lazy_file = -1) {
+    // stamp (optional): the file's inode as the walk saw it -- recorded with the root whenever THIS commit hashed the content
+    // own_root: the walk did not read the file because its content is KNOWN to be what the tree holds (MI_MEMFS_TRUST_CTIME):
+    // its root is the node's own
+    bool holds_similar(const std::string& dst, const mi_tree_entry& e, const uint8_t* content_root, int64_t lazy_file = -1,
+                       const mi_walk::InodeStamp* stamp = nullptr, bool own_root = false) {
         mi_memtree::Node* cur = t.find(dst);
         if (!cur || cur->ref < 0 || e.kind > 3) return false;
         Node& o = nodes[cur->ref];
         if (o.e.kind > 3) return false;
+        if (own_root && o.has_root && !o.root_pending) content_root = o.root;
         mi_tree_entry a, b = e;
         memset(&a, 0, sizeof a);
         a.relpath = o.e.relpath.empty() ? "" : o.e.relpath.c_str();
@@ -480,7 +511,11 @@ struct Fs {
             else { o.root_pending = true; o.batch_file = lazy_file; pending_refs.push_back(cur->ref); }
             ++n_roots_learned;
         }                                                                                // (a content-only change is counted
-        return similar != 0;                                                             //  where it is added: maybe_add)
+        if (similar && stamp && file_has_root && o.has_root && b.kind == 1) {            //  where it is added: maybe_add)
+            o.stamp = *stamp;                                                            // hashed now, in this state
+            o.hashed_at_ns = commit_started_ns;
+        }
+        return similar != 0;
     }
 };
 
@@ -1471,8 +1506,9 @@ extern "C" int mi_memfs_untar(mi_memfs* m, const char* tar_path, const mi_tree_e
 // MemFS.createLayerByScan (:315-341) on a walk of the root (mi_tree_walk / mi_batch_add_tree with MI_TREE_SCAN,
 // rel_base = root): every walked path through maybeAddToLayer with createWhiteout = true
 // from_batch: the walk is a batch's (mi_batch_add_tree) -- an entry's file_index is its row there, and the layer's nodes keep it
+// wt (optional): the walk's own record of the same entries (inode stamps, which files were not staged because their content is known)
 static int memfs_scan(mi_memfs* m, const mi_tree_entry* walked, uint64_t n, const void* roots, uint64_t root_stride, bool from_batch,
-                      mi_copy_layer** out, uint64_t* n_entries) {
+                      mi_copy_layer** out, uint64_t* n_entries, const mi_walk::Tree* wt = nullptr) {
     if (!m || (n && !walked) || !out) return MI_ERR_INVALID;
     mi_copy::Fs& fs = m->fs;
     MemfsTimer timer("scan", fs, n);
@@ -1505,7 +1541,10 @@ static int memfs_scan(mi_memfs* m, const mi_tree_entry* walked, uint64_t n, cons
         const bool lazy = !roots && fs.job && from_batch && e.kind == 1 && e.file_index >= 0;   // (the scan may still be running)
         const uint8_t* content_root =
             roots && e.kind == 1 && e.file_index >= 0 ? (const uint8_t*)roots + (uint64_t)e.file_index * root_stride : nullptr;
-        const bool held = fs.holds_similar(p, e, content_root, lazy ? e.file_index : -1);
+        const mi_walk::Entry* we = wt && i < wt->entries.size() ? &wt->entries[i] : nullptr;
+        const bool hashed_now = from_batch && e.kind == 1 && e.file_index >= 0 && we;
+        const bool held = fs.holds_similar(p, e, content_root, lazy ? e.file_index : -1, hashed_now ? &we->stamp : nullptr,
+                                           we && we->content_known);       // (not read again: the content the tree knows)
         if (fs.rc) break;
         if (held) {                                                               // nothing to add; a directory's deletions
             if (e.kind == 0) fs.whiteout_missing_children(p);                     // are still looked for (maybe_add's tail)
@@ -1521,6 +1560,7 @@ static int memfs_scan(mi_memfs* m, const mi_tree_entry* walked, uint64_t n, cons
         }
         if (from_batch && e.kind == 1 && e.file_index >= 0) nd.batch_file = e.file_index;
         if (lazy) { nd.has_root = true; nd.root_pending = true; }
+        if (hashed_now && nd.has_root) { nd.stamp = we->stamp; nd.hashed_at_ns = fs.commit_started_ns; }
         const std::string src = fs.root == "/" ? p : fs.root + (p == "/" ? "" : p);
         fs.maybe_add(src, p, std::move(nd), true);
     }
@@ -1678,9 +1718,25 @@ extern "C" int mi_memfs_commit_layer(mi_memfs* m, mi_ctx* ctx, int must_scan, co
         const auto t0 = std::chrono::steady_clock::now();
         std::vector<mi_tree_entry> walked;
         mi_tree* t = nullptr;
+        const mi_walk::Tree* wt = nullptr;
         if (b) {
-            rc = mi_batch_add_tree(b, fs.root.c_str(), fs.root.c_str(), bl.empty() ? nullptr : bl.data(), bl.size(), MI_TREE_SCAN, &n);
-            if (rc) return fail_with(rc, "walk " + fs.root + ": " + mi_last_error(ctx));
+            struct timespec now;
+            clock_gettime(CLOCK_REALTIME, &now);
+            fs.commit_started_ns = (int64_t)now.tv_sec * 1000000000ll + now.tv_nsec;
+            fs.n_content_trusted = 0;
+            if (fs.trust_ctime) {                                                 // files whose inode says "unchanged" are not read
+                mi_walk::Tree* wtree = nullptr;
+                std::string werr;
+                rc = mi_walk::scan_walk_batch_filtered(b, fs.root, m->blacklist,
+                        [&fs](const std::string& path, uint64_t size, const mi_walk::InodeStamp& st) { return fs.content_is_known(path, size, st); },
+                        &wtree, &werr);
+                if (rc) return fail_with(rc, "walk " + fs.root + ": " + (werr.empty() ? mi_last_error(ctx) : werr));
+                n = wtree->entries.size();
+            } else {
+                rc = mi_batch_add_tree(b, fs.root.c_str(), fs.root.c_str(), bl.empty() ? nullptr : bl.data(), bl.size(), MI_TREE_SCAN, &n);
+                if (rc) return fail_with(rc, "walk " + fs.root + ": " + mi_last_error(ctx));
+            }
+            wt = (const mi_walk::Tree*)*mi_batch_tree_slot(b);
             walked.resize(n ? n : 1);
             rc = mi_batch_tree_entries(b, walked.data(), n);
         } else {
@@ -1693,8 +1749,9 @@ extern "C" int mi_memfs_commit_layer(mi_memfs* m, mi_ctx* ctx, int must_scan, co
         m->last.s_walk_stage = secs_since(t0);
         if (!rc && b && (rc = start_scan())) { if (t) mi_tree_free(t); return fail_with(rc, std::string("gpu scan: ") + mi_last_error(ctx)); }
         const auto t1 = std::chrono::steady_clock::now();
-        if (!rc) rc = memfs_scan(m, walked.data(), n, roots.empty() ? nullptr : roots.data(), 32, b != nullptr, &cl, &ne);
+        if (!rc) rc = memfs_scan(m, walked.data(), n, roots.empty() ? nullptr : roots.data(), 32, b != nullptr, &cl, &ne, wt);
         m->last.s_diff = secs_since(t1);
+        m->last.n_content_trusted = fs.n_content_trusted.load();
         if (t) mi_tree_free(t);
         if (rc) { end_scan(nullptr); return fail_with(rc, m->err); }
     } else {
@@ -1749,6 +1806,11 @@ extern "C" int mi_memfs_commit_layer(mi_memfs* m, mi_ctx* ctx, int must_scan, co
 extern "C" int mi_memfs_commit_stats(const mi_memfs* m, mi_commit_stats* out) {
     if (!m || !out) return MI_ERR_INVALID;
     *out = m->last;
+    return MI_OK;
+}
+extern "C" int mi_memfs_set_options(mi_memfs* m, uint32_t options) {
+    if (!m || (options & ~MI_MEMFS_TRUST_CTIME)) return MI_ERR_INVALID;
+    m->fs.trust_ctime = (options & MI_MEMFS_TRUST_CTIME) != 0;
     return MI_OK;
 }
 extern "C" int mi_memfs_set_index(mi_memfs* m, mi_index* index) {

@@ -82,6 +82,17 @@ struct Walker {
     std::string err;
     int rc = MI_OK;
     int64_t n_regular = 0;
+    // optional: "is this regular file's content known?" (path on disk, size, inode stamp) -- such a file gets its entry and
+    // no row in the batch; asked by whoever stats the file (the directory readers: several threads)
+    std::function<bool(const std::string&, uint64_t, const InodeStamp&)> content_known;
+    static InodeStamp stamp_of(const struct stat& st) {
+        InodeStamp s;
+        s.dev = (uint64_t)st.st_dev;
+        s.ino = (uint64_t)st.st_ino;
+        s.mtime_ns = (int64_t)st.st_mtim.tv_sec * 1000000000ll + st.st_mtim.tv_nsec;
+        s.ctime_ns = (int64_t)st.st_ctim.tv_sec * 1000000000ll + st.st_ctim.tv_nsec;
+        return s;
+    }
     // regular files wait here and go to the batch in bulk: the reader threads open them (several
     // at a time) while the walk goes on -- a per-file open + hand-over cost 9 us, the walk's lstat 2
     std::vector<std::string> pend_path;
@@ -159,8 +170,9 @@ struct Walker {
     // rel (optional): the path's relpath when the caller already knows it (a child's is its parent's
     // plus its name; filepath.Rel per entry costs more than the lstat it follows)
     // placed (optional): the file's bytes are in the arena already, at this offset (its directory's block)
+    // known (optional): the answer content_known already gave for this file (the parallel walk asks where it stats)
     void emit(const std::string& path, const struct stat& st, const std::string* link, const std::string* rel = nullptr,
-              const uint64_t* placed = nullptr) {
+              const uint64_t* placed = nullptr, const bool* known = nullptr) {
         Entry e;
         e.relpath = rel ? *rel : rel_to(rel_base, path);
         if (e.relpath.empty()) {
@@ -195,6 +207,13 @@ struct Walker {
         } else {
             e.kind = 1;
             e.size = (uint64_t)st.st_size;
+            e.stamp = stamp_of(st);
+            if (batch && (known ? *known : (content_known && content_known(path, e.size, e.stamp)))) {
+                e.content_known = true;                          // no row: nothing of it is read
+                e.file_index = -1;
+                tree->entries.push_back(std::move(e));
+                return;
+            }
             if (batch) {
                 if (!counted) { mi_batch_counts(batch, &batch_files, nullptr, nullptr); counted = true; }
                 e.file_index = (int64_t)batch_files++;
@@ -262,6 +281,8 @@ struct Child {
     uint32_t mode = 0, uid = 0, gid = 0;
     uint64_t size = 0;
     int64_t mtime = 0;
+    InodeStamp stamp;                    // regular files
+    bool known = false;                  // ... whose content the caller knows (Walker::content_known): not read, not staged
     bool skip = false;
     int rc = MI_OK;                      // this path's own failure (lstat / readlink / skip-rule / read error)
     std::string err;
@@ -558,8 +579,12 @@ struct ParallelWalker {
             c.gid = (uint32_t)st.st_gid;
             c.size = (uint64_t)st.st_size;
             if (S_ISREG(st.st_mode)) {
-                seen_files.fetch_add(1, std::memory_order_relaxed);
-                seen_bytes.fetch_add((uint64_t)st.st_size, std::memory_order_relaxed);
+                c.stamp = Walker::stamp_of(st);
+                c.known = w->batch && w->content_known && w->content_known(path, c.size, c.stamp);
+                if (!c.known) {
+                    seen_files.fetch_add(1, std::memory_order_relaxed);
+                    seen_bytes.fetch_add((uint64_t)st.st_size, std::memory_order_relaxed);
+                }
             }
             if (S_ISDIR(st.st_mode)) {
                 c.sub.reset(new DirRec());
@@ -590,7 +615,7 @@ struct ParallelWalker {
     void read_small_files(DirRec* d, int dfd, std::vector<int>& fds) {
         uint64_t total = 0, n = 0;
         for (Child& c : d->kids) {
-            if (c.rc || c.skip || !S_ISREG(c.mode) || c.size > inline_file_max()) continue;
+            if (c.rc || c.skip || c.known || !S_ISREG(c.mode) || c.size > inline_file_max()) continue;
             c.blob_off = (total + 255) & ~255ull;
             total = c.blob_off + c.size;
             ++n;
@@ -739,8 +764,17 @@ struct ParallelWalker {
             st.st_uid = c.uid;
             st.st_gid = c.gid;
             st.st_size = (off_t)c.size;
+            if (S_ISREG(c.mode)) {                               // the inode stamp as the reader's stat gave it (stamp_of's inverse)
+                st.st_dev = (dev_t)c.stamp.dev;
+                st.st_ino = (ino_t)c.stamp.ino;
+                st.st_mtim.tv_nsec = (long)(c.stamp.mtime_ns - (int64_t)c.mtime * 1000000000ll);
+                const int64_t cs = c.stamp.ctime_ns >= 0 ? c.stamp.ctime_ns / 1000000000ll : -((-c.stamp.ctime_ns + 999999999ll) / 1000000000ll);
+                st.st_ctim.tv_sec = (time_t)cs;
+                st.st_ctim.tv_nsec = (long)(c.stamp.ctime_ns - cs * 1000000000ll);
+            }
             const uint64_t placed = block_at + (c.blob_off == ~0ull ? 0 : c.blob_off);
-            w->emit(path, st, S_ISLNK(c.mode) ? &c.link : nullptr, &crel, c.blob_off == ~0ull ? nullptr : &placed);
+            w->emit(path, st, S_ISLNK(c.mode) ? &c.link : nullptr, &crel, c.blob_off == ~0ull ? nullptr : &placed,
+                    S_ISREG(c.mode) ? &c.known : nullptr);
             if (w->rc) return;
             if (c.sub) { assemble(c.sub.get(), crel); if (w->rc) return; }
         }
@@ -832,6 +866,29 @@ int scan_walk_collect_batch(const std::string& src, const std::string& link_root
     walk_root(&w, src);
     w.flush_pending();
     if (w.rc && err) *err = w.err;
+    return w.rc;
+}
+
+int scan_walk_batch_filtered(mi_batch* b, const std::string& root, const std::vector<std::string>& blacklist,
+                             const std::function<bool(const std::string&, uint64_t, const InodeStamp&)>& known, Tree** tree_out,
+                             std::string* err) {
+    void** slot = mi_batch_tree_slot(b);
+    if (!*slot) *slot = new Tree();
+    Tree* t = (Tree*)*slot;
+    Walker w;
+    w.batch = b;
+    w.rel_base = root;
+    w.mode = MI_TREE_SCAN;
+    w.tree = t;
+    w.blacklist = blacklist;
+    w.content_known = known;
+    std::string r = root;
+    while (r.size() > 1 && r.back() == '/') r.pop_back();
+    mi_batch_expect_host_bytes(b);
+    walk_root(&w, r);
+    w.flush_pending();
+    if (w.rc && err) *err = w.err;
+    if (tree_out) *tree_out = t;
     return w.rc;
 }
 

@@ -130,9 +130,50 @@ def scenario_many(tmp, eng):
     print("OK many")
 
 
+def scenario_trust(tmp, eng):
+    """MI_MEMFS_TRUST_CTIME: a commit does not read again what the kernel says has not changed; it reads what has -- also a
+    rewrite that keeps size and mtime (the ctime moves); a file hashed in the same clock tick as its last change is read again"""
+    import time
+    root = os.path.join(tmp, "trust_root")
+    files = make_tree(root, seed=41, mtime=MTIME)
+    nonempty = sum(1 for d in files.values() if d)
+    time.sleep(0.06)                                                         # (the tree is older than the slack)
+    with M.MemFS(root) as fs:
+        fs.set_options(trust_ctime=True)
+        r = fs.commit_layer(must_scan=True, engine=eng, gzip_level=M.GZIP_OFF)
+        assert r["stats"]["n_content_trusted"] == 0 and r["stats"]["files_opened"] == nonempty
+        r = fs.commit_layer(must_scan=True, engine=eng, gzip_level=M.GZIP_OFF)
+        st = r["stats"]
+        assert r["n_entries"] == 0 and st["n_content_trusted"] == len(files) and st["files_opened"] == 0 and st["n_scanned_files"] == 0, st
+        # a rewrite that keeps size and mtime: the inode's ctime moves -- that file is read again, nothing else
+        victim = os.path.join(root, "d02/f003.bin")
+        sb = os.stat(victim)
+        with open(victim, "r+b") as f:
+            f.write(os.urandom(sb.st_size))
+        os.utime(victim, ns=(sb.st_atime_ns, sb.st_mtime_ns))
+        assert os.stat(victim).st_mtime_ns == sb.st_mtime_ns and os.stat(victim).st_ctime_ns != sb.st_ctime_ns
+        time.sleep(0.06)
+        r = fs.commit_layer(must_scan=True, engine=eng, gzip_level=M.GZIP_OFF)
+        st = r["stats"]
+        assert st["n_content_trusted"] == len(files) - 1 and st["files_opened"] == 1 and st["n_scanned_files"] == 1, st
+        # an ordinary edit (new size): read, in the layer, its bytes from the arena of a batch that holds nothing else
+        new = os.urandom(70001)
+        write_file(os.path.join(root, "d00/f001.bin"), new, 0o644, MTIME + 9)
+        time.sleep(0.06)
+        res, raw = commit_to_bytes(fs, tmp, "t3.tar", must_scan=True, engine=eng)
+        assert [(n, d) for n, m, d in tar_members(raw) if m.isfile()] == [("d00/f001.bin", new)]
+        assert res["stats"]["n_scanned_files"] == 1 and res["stats"]["n_content_trusted"] == len(files) - 1
+        # without the option everything is read again
+        fs.set_options(trust_ctime=False)
+        r = fs.commit_layer(must_scan=True, engine=eng, gzip_level=M.GZIP_OFF)
+        assert r["stats"]["n_content_trusted"] == 0 and r["stats"]["files_opened"] == sum(1 for d in files.values() if d) + (0 if files["d00/f001.bin"] else 1)
+    print("OK trust")
+
+
 if __name__ == "__main__":
     tmp, threads = sys.argv[1], int(sys.argv[2])
     with M.Engine(n_streams=threads, staging_bytes=1 << 20) as eng:
         scenario_scan(tmp, eng)
         scenario_copy(tmp, eng)
         scenario_many(tmp, eng)
+        scenario_trust(tmp, eng)

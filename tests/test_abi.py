@@ -95,6 +95,27 @@ int main(void) {
     assert got == want
 
 
+def test_commit_stats_layout_matches_the_header(tmp_path):
+    """mi_commit_stats field by field: the ctypes mirror has the header's names in the header's order, and the size agrees"""
+    import makisu_amd
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    body = re.search(r"typedef struct \{([^}]*)\} mi_commit_stats;", src).group(1)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if decl:
+            names += [n.strip() for n in decl.split(None, 1)[1].split(",")]
+    assert names == [n for n, _ in makisu_amd.CommitStats._fields_]
+    prog = tmp_path / "cs.c"
+    prog.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "makisu_mi.h"\nint main(void) { printf("%zu %zu %zu\\n", '
+                    'sizeof(mi_commit_stats), offsetof(mi_commit_stats, pipelined), offsetof(mi_commit_stats, s_walk_stage)); return 0; }\n')
+    exe = tmp_path / "cs"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).decode().split()]
+    S = makisu_amd.CommitStats
+    assert got == [C.sizeof(S), S.pipelined.offset, S.s_walk_stage.offset]
+
+
 def test_both_headers_are_plain_c(tmp_path):
     """the boundary and the optional helpers compile as C89-with-stdint consumers see them (gcc -std=c99 -pedantic), alone
     and together, and the optional header pulls in the core one"""

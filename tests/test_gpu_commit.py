@@ -343,6 +343,49 @@ def test_the_commit_feeds_the_chunk_index(oracle, eng, tmp_path):
         assert rb["tar_digest"] == ra["tar_digest"]
 
 
+def test_trusting_the_inode_reads_only_what_changed_and_still_catches_the_same_second_rewrite(oracle, eng, tmp_path):
+    """MI_MEMFS_TRUST_CTIME: files whose inode (device, number, size, mtime, ctime to the nanosecond) is what it was when
+    they were hashed are not read again -- a commit that changed nothing reads nothing -- and the rewrite that keeps size and
+    mtime SECOND (and even the mtime to the nanosecond) is still caught: the kernel moved its ctime.  Layers and roots are
+    those of a handle that reads everything."""
+    import time
+    root = str(tmp_path / "root")
+    files = make_tree(root, seed=18, mtime=MTIME)
+    rng = np.random.default_rng(7)
+    time.sleep(0.06)
+    with M.MemFS(root) as fast, M.MemFS(root) as full:
+        fast.set_options(trust_ctime=True)
+        a, raw_a = commit_to_bytes(fast, tmp_path, "fa.tar", must_scan=True, engine=eng)
+        b, raw_b = commit_to_bytes(full, tmp_path, "fb.tar", must_scan=True, engine=eng)
+        assert raw_a == raw_b and a["stats"]["n_content_trusted"] == 0
+        a, raw_a = commit_to_bytes(fast, tmp_path, "fa.tar", must_scan=True, engine=eng)
+        assert a["n_entries"] == 0 and a["stats"]["n_content_trusted"] == len(files) and a["stats"]["files_opened"] == 0
+        for step, rel in enumerate(("d02/f003.bin", "d01/nested/deeper/f002.bin")):
+            new = _rewrite_same_size_same_second(os.path.join(root, rel), rng)          # (restores atime and mtime to the ns)
+            files[rel] = new
+            time.sleep(0.06)
+            a, raw_a = commit_to_bytes(fast, tmp_path, "fa.tar", must_scan=True, engine=eng)
+            b, raw_b = commit_to_bytes(full, tmp_path, "fb.tar", must_scan=True, engine=eng)
+            assert raw_a == raw_b                                                       # the same layer, byte for byte
+            assert [(n, d) for n, m, d in tar_members(raw_a) if m.isfile()] == [(rel, new)]
+            st = a["stats"]
+            assert st["n_content_changed"] == 1 and st["n_scanned_files"] == 1 and st["files_opened"] == 1, st
+            assert st["n_content_trusted"] == len(files) - 1
+            assert fast.root_of("/" + rel) == full.root_of("/" + rel) == oracle_root(oracle, new)
+        # racily clean: a file hashed within the clock tick of its own last change is not trusted -- it is read once more
+        rel = "d00/f002.bin"
+        files[rel] = _rewrite_same_size_same_second(os.path.join(root, rel), rng)
+        a = fast.commit_layer(must_scan=True, engine=eng)                              # (no pause: hashed right after the write)
+        assert a["stats"]["n_scanned_files"] == 1 and [e["relpath"] for e in a["layer"]][-1] == rel
+        time.sleep(0.06)
+        a = fast.commit_layer(must_scan=True, engine=eng)
+        assert a["n_entries"] == 0 and a["stats"]["n_scanned_files"] == 1 and a["stats"]["n_content_trusted"] == len(files) - 1
+        a = fast.commit_layer(must_scan=True, engine=eng)
+        assert a["n_entries"] == 0 and a["stats"]["n_scanned_files"] == 0 and a["stats"]["n_content_trusted"] == len(files)
+        for rel, data in files.items():
+            assert fast.root_of("/" + rel) == oracle_root(oracle, data), rel
+
+
 def test_the_handles_batch_can_be_made_ahead_of_the_first_commit(oracle, eng, tmp_path):
     """mi_memfs_reserve_device: arena and reader threads before the first commit (a ctx's first use is what costs); too small a
     guess only means the arena grows, a handle that already committed is re-sized in place"""
@@ -549,11 +592,16 @@ def test_the_commit_table_of_the_bench_line(eng):
         k = max(1, n // 1000)
         hidden = some["gpu"]["content_only_changes"]
         assert hidden >= 1 and some["gpu"]["layer_files"] == k and some["cpu_header_only"]["layer_files"] == k - hidden
+        assert new["gpu_trust_ctime"]["tar_bytes"] == new["gpu"]["tar_bytes"] and new["gpu_trust_ctime"]["files_trusted"] == 0
+        assert same["gpu_trust_ctime"]["layer_entries"] == 0 and same["gpu_trust_ctime"]["files_trusted"] >= n - n // 20 - 1   # (the last
+        assert same["gpu_trust_ctime"]["files_read"] == n - same["gpu_trust_ctime"]["files_trusted"]       # files written may be racy)
+        assert some["gpu_trust_ctime"]["layer_files"] == k and some["gpu_trust_ctime"]["content_only_changes"] == hidden
+        assert some["gpu_trust_ctime"]["tar_bytes"] == some["gpu"]["tar_bytes"]
         for row in t["commits"]:
-            for side in ("gpu", "cpu_header_only"):
+            for side in ("gpu", "gpu_trust_ctime", "cpu_header_only"):
                 r = row[side]
                 serial = r["s_walk_stage"] + r["s_diff"] + r["s_write"] + (0 if r["scan_overlapped"] else r["s_scan"])
-                assert r["s_total"] >= serial - 1e-3 and r["scan_overlapped"] == (side == "gpu" and r["files_read"] > 0)
+                assert r["s_total"] >= serial - 1e-3 and r["scan_overlapped"] == (side != "cpu_header_only" and r["files_read"] > 0)
 
 
 @pytest.mark.timeout(900)

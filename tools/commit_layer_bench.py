@@ -2,7 +2,8 @@
 
 A tree of n files of `bytes` bytes in /dev/shm (page cache: both sides measure work, not a disk), two MemFS handles on
 it -- one committing with a ctx (mi_memfs_commit_layer: walk + stage + GPU scan + content-aware diff + tar from HBM), one
-without (the reference's commit: headers decide, the writer reads the changed files) -- and three commits by scan each:
+without (the reference's commit: headers decide, the writer reads the changed files), and a third with a ctx and
+MI_MEMFS_TRUST_CTIME (files whose inode is what it was when they were hashed are not read again) -- and three commits by scan each:
     all new            every file framed into the layer tar and digested;
     nothing changed    the reference: walk + lstat-level diff.  With a ctx: every file is read and hashed again -- the
                        price of watching content;
@@ -47,7 +48,8 @@ def _side(st, res, wall):
             "s_diff": round(st["s_diff"], 4), "s_write": round(st["s_write"], 4), "layer_entries": int(res["n_entries"]),
             "layer_files": int(st["n_layer_files"]), "tar_bytes": int(res["tar_bytes"]),
             "files_read": int(st["files_opened"]), "bytes_read": int(st["file_bytes_read"]),
-            "content_only_changes": int(st["n_content_changed"]), "scan_overlapped": bool(st["pipelined"])}
+            "content_only_changes": int(st["n_content_changed"]), "scan_overlapped": bool(st["pipelined"]),
+            "files_trusted": int(st["n_content_trusted"])}
 
 
 def commit_e2e(eng, n_files, file_bytes, base=None, gzip_level=None):
@@ -59,12 +61,14 @@ def commit_e2e(eng, n_files, file_bytes, base=None, gzip_level=None):
     try:
         per_dir = 200 if file_bytes < (1 << 20) else 8
         paths = _make_tree(root, n_files, file_bytes, per_dir)
+        time.sleep(0.05)
         rng = np.random.default_rng(3)
         k = max(1, n_files // 1000)
         victims = [paths[int(i)] for i in rng.choice(n_files, size=k, replace=False)]
         out = {"tree": "%d files x %d bytes in %d directories under %s (page cache)" % (n_files, file_bytes, (n_files + per_dir - 1) // per_dir, base or "TMPDIR"),
                "tree_bytes": n_files * file_bytes, "gzip": "off" if gzip_level is None else gzip_level, "commits": []}
-        with M.MemFS(root) as gpu, M.MemFS(root) as plain:
+        with M.MemFS(root) as gpu, M.MemFS(root) as trust, M.MemFS(root) as plain:
+            trust.set_options(trust_ctime=True)
             for step, what in enumerate(("all new", "nothing changed", "0.1 % changed")):
                 if step == 2:
                     n_same_second = 0
@@ -78,8 +82,9 @@ def commit_e2e(eng, n_files, file_bytes, base=None, gzip_level=None):
                         else:
                             os.utime(p, (MTIME + 7, MTIME + 7))
                     what = "%d files rewritten (0.1 %%), %d of them within the same second" % (k, n_same_second)
+                    time.sleep(0.05)                                 # (older than the racy-clean slack of MI_MEMFS_TRUST_CTIME)
                 row = {"what": what}
-                for name, fs, kw in (("gpu", gpu, {"engine": eng}), ("cpu_header_only", plain, {})):
+                for name, fs, kw in (("gpu", gpu, {"engine": eng}), ("gpu_trust_ctime", trust, {"engine": eng}), ("cpu_header_only", plain, {})):
                     t0 = time.perf_counter()
                     res = fs.commit_layer(must_scan=True, gzip_level=gz, **kw)
                     row[name] = _side(res["stats"], res, time.perf_counter() - t0)
@@ -97,13 +102,13 @@ def main():
     print(res["tree"])
     for row in res["commits"]:
         print("  " + row["what"])
-        for side in ("gpu", "cpu_header_only"):
+        for side in ("gpu", "gpu_trust_ctime", "cpu_header_only"):
             r = row[side]
             print("    %-16s %7.3f s = walk%s %.3f + diff %.3f + tar %.3f; scan %.3f%s | layer: %d entries, %d files, %d tar bytes | "
-                  "read %d files, %d bytes | content-only changes %d" %
-                  (side, r["s_total"], "+stage" if side == "gpu" else "", r["s_walk_stage"], r["s_diff"], r["s_write"], r["s_scan"],
+                  "read %d files, %d bytes (%d trusted) | content-only changes %d" %
+                  (side, r["s_total"], "+stage" if side.startswith("gpu") else "", r["s_walk_stage"], r["s_diff"], r["s_write"], r["s_scan"],
                    " (beside diff and tar)" if r["scan_overlapped"] else "",
-                   r["layer_entries"], r["layer_files"], r["tar_bytes"], r["files_read"], r["bytes_read"], r["content_only_changes"]))
+                   r["layer_entries"], r["layer_files"], r["tar_bytes"], r["files_read"], r["bytes_read"], r["files_trusted"], r["content_only_changes"]))
 
 
 if __name__ == "__main__":
