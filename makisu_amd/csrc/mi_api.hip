@@ -881,7 +881,17 @@ static int add_file_range(mi_batch* b, const char* path, uint64_t offset, uint64
     if (!b || !path) return MI_ERR_INVALID;
     mi_ctx* c = b->ctx;
     HIPCHK(c, hipSetDevice(c->device));
-    int fd = open(path, O_RDONLY | O_CLOEXEC);
+    // The descriptor travels with the file's pieces until the reader threads have read them: a caller that adds files faster
+    // than they are read can exhaust a small RLIMIT_NOFILE with descriptors of its own queue.  That is not the caller's error:
+    // wait for the readers and try again (only a table that stays full for seconds is reported).
+    int fd = -1;
+    for (int tries = 0;; ++tries) {
+        fd = open(path, O_RDONLY | O_CLOEXEC);
+        if (fd >= 0 || (errno != EMFILE && errno != ENFILE) || !c->stager || tries >= 400) break;
+        const int keep = errno;
+        stager_pause(c->stager, 5);
+        errno = keep;
+    }
     if (fd < 0) return fail(c, MI_ERR_IO, "open %s: %s", path, strerror(errno));
     mi_io::content_opens.fetch_add(1, std::memory_order_relaxed);
     struct stat sb;

@@ -78,6 +78,7 @@ int     stager_put_paths(Stager* st, mi_batch* b, u64 n, const char* const* path
                          const u64* len);
 int     stager_put_block(Stager* st, mi_batch* b, u64 arena_off, const void* src, u64 len, std::shared_ptr<void> keep);
 int     stager_drain(Stager* st, mi_batch* b);
+void    stager_pause(Stager* st, int ms);            // up to `ms` milliseconds, or until a run has landed
 // blocks until every byte of the batch's arena below `upto` that was queued so far has landed in HBM (pieces of one batch are
 // queued in arena order), or the batch's staging failed (MI_ERR_IO with the first failure's message)
 // *landed_out (optional): how far the landed prefix reaches by now (~0: everything queued so far)

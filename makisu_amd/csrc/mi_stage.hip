@@ -73,6 +73,7 @@ struct Stager {
     u32 init_left = 0, n_ok = 0;         // reader threads still setting up / that got slab + stream
     std::atomic<long long> spans_copied{0};   // fault injection (MI_STAGE_FAULT) counts spans with it
     std::condition_variable cv_init;
+    int pausers = 0;                     // threads in stager_pause (an adder waiting for descriptors to come back)
 };
 
 // ---- span sums (MI_FLAG_VERIFY_STAGING) --------------------------------------------------------
@@ -369,7 +370,7 @@ void worker(Stager* st, u32 tid) {
                 std::lock_guard<std::mutex> g(st->mu);
                 b->stage_inflight.erase(b->stage_inflight.find(start));
                 b->stage_pending -= run.size();
-                wake = b->stage_pending == 0 || b->stage_waiters > 0;
+                wake = b->stage_pending == 0 || b->stage_waiters > 0 || st->pausers > 0;
             }
             if (wake) st->cv_done.notify_all();
         }
@@ -508,6 +509,13 @@ int stager_drain(Stager* st, mi_batch* b) {
     }
     if (!msg.empty()) return fail(b->ctx, MI_ERR_IO, "%s", msg.c_str());
     return MI_OK;
+}
+
+void stager_pause(Stager* st, int ms) {
+    std::unique_lock<std::mutex> lk(st->mu);
+    ++st->pausers;
+    st->cv_done.wait_for(lk, std::chrono::milliseconds(ms));
+    --st->pausers;
 }
 
 int stager_wait_landed(Stager* st, mi_batch* b, u64 upto, u64* landed_out) {

@@ -64,6 +64,19 @@ def test_with_a_descriptor_limit_below_the_directory_sizes(hip_double, tmp_path)
     assert p.returncode == 0 and "OK tree" in p.stdout, p.stdout[-800:] + p.stderr[-1500:]
 
 
+def test_an_adder_that_outruns_the_readers_waits_for_descriptors(hip_double, tmp_path):
+    """mi_batch_add_path opens the file in the call and the descriptor travels with the file's pieces until they are read: with
+    a table of 40 descriptors and copies slowed down, 300 adds in a row hold more descriptors than there are -- the call waits
+    for the readers instead of failing with EMFILE (a full table that is the caller's own queue is not the caller's error)"""
+    import resource
+    soft, hard = resource.getrlimit(resource.RLIMIT_NOFILE)
+    env = dict(os.environ, LD_PRELOAD=(os.environ.get("LD_PRELOAD", "") + " " + hip_double).strip(), MI_HIP_STUB_COPY_US="1500")
+    p = subprocess.run([sys.executable, os.path.join(STUB_DIR, "scenarios.py"), str(tmp_path), "2", "65536", "interleaved"], env=env,
+                       capture_output=True, text=True, timeout=900,
+                       preexec_fn=lambda: resource.setrlimit(resource.RLIMIT_NOFILE, (40, hard)))
+    assert p.returncode == 0 and "OK interleaved" in p.stdout, p.stdout[-800:] + p.stderr[-1500:]
+
+
 def test_with_a_block_budget_that_runs_out(hip_double, tmp_path):
     """MI_WALK_INLINE_MB=1: after a megabyte of blocks alive the directories' files go as paths again -- mixed ways"""
     _run(hip_double, tmp_path, 4, 65536, {"MI_WALK_INLINE_MB": "1"})
