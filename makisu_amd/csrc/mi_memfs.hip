@@ -61,9 +61,8 @@ struct Node {
     uint8_t root[32];
     int64_t batch_file = -1;   // a content-aware commit under way: the file's row in the commit's batch -- its bytes lie in HBM
     bool root_pending = false; // ... and its root is still being computed (a pipelined commit: ScanJob); root[] is not valid yet
-    // MI_MEMFS_TRUST_CTIME: the inode as it was when the content behind `root` was read, and when that was (CLOCK_REALTIME at
-    // the start of that commit's walk; 0 = never: the root came from elsewhere)
-    mi_walk::InodeStamp stamp;
+    // MI_MEMFS_TRUST_CTIME: when the content behind `root` was read (CLOCK_REALTIME at the start of that commit's walk; 0 = never:
+    // the root came from elsewhere); the inode as it was then is e.stamp
     int64_t hashed_at_ns = 0;
 };
 
@@ -80,15 +79,15 @@ struct ScanJob {
     std::vector<uint8_t> roots;
     uint64_t n_chunks = 0;
     double seconds = 0;
-    void start(mi_batch* b, mi_ctx* ctx, uint64_t n_files) {
+    void start(mi_batch* b, uint64_t n_files) {
         roots.resize(n_files * 32);
-        th = std::thread([this, b, ctx, n_files] {
+        th = std::thread([this, b, n_files] {
             const auto t0 = std::chrono::steady_clock::now();
             int r = mi_batch_run(b);
             if (!r) r = mi_batch_roots(b, roots.data(), n_files);
             uint64_t nc = 0;
             if (!r) mi_batch_counts(b, nullptr, &nc, nullptr);
-            std::string e = r ? mi_last_error(ctx) : "";
+            std::string e = r ? mi_last_error_of_batch(b) : "";          // (a locked copy: the committing thread may be failing too)
             {
                 std::lock_guard<std::mutex> g(mu);
                 rc = r;
@@ -294,7 +293,7 @@ struct Fs {
         const mi_memtree::Node* nd = t.find_walk(disk_path.substr(root_len));     // (find_walk keeps no cache: safe from many threads)
         if (!nd || nd->ref < 0) return false;
         const Node& x = nodes[(size_t)nd->ref];
-        if (x.e.kind != 1 || !x.has_root || x.root_pending || !x.hashed_at_ns || x.e.size != size || !(x.stamp == st)) return false;
+        if (x.e.kind != 1 || !x.has_root || x.root_pending || !x.hashed_at_ns || x.e.size != size || !(x.e.stamp == st)) return false;
         if (st.ctime_ns + slack_ns >= x.hashed_at_ns) return false;              // racily clean: read it again
         n_content_trusted.fetch_add(1, std::memory_order_relaxed);
         return true;
@@ -512,7 +511,7 @@ struct Fs {
             ++n_roots_learned;
         }                                                                                // (a content-only change is counted
         if (similar && stamp && file_has_root && o.has_root && b.kind == 1) {            //  where it is added: maybe_add)
-            o.stamp = *stamp;                                                            // hashed now, in this state
+            o.e.stamp = *stamp;                                                          // hashed now, in this state
             o.hashed_at_ns = commit_started_ns;
         }
         return similar != 0;
@@ -1560,7 +1559,7 @@ static int memfs_scan(mi_memfs* m, const mi_tree_entry* walked, uint64_t n, cons
         }
         if (from_batch && e.kind == 1 && e.file_index >= 0) nd.batch_file = e.file_index;
         if (lazy) { nd.has_root = true; nd.root_pending = true; }
-        if (hashed_now && nd.has_root) { nd.stamp = we->stamp; nd.hashed_at_ns = fs.commit_started_ns; }
+        if (hashed_now && nd.has_root) { nd.e.stamp = we->stamp; nd.hashed_at_ns = fs.commit_started_ns; }
         const std::string src = fs.root == "/" ? p : fs.root + (p == "/" ? "" : p);
         fs.maybe_add(src, p, std::move(nd), true);
     }
@@ -1687,7 +1686,7 @@ extern "C" int mi_memfs_commit_layer(mi_memfs* m, mi_ctx* ctx, int must_scan, co
         m->last.scanned_bytes = nbytes;
         if (!nf) return MI_OK;
         if (pipeline_on) {
-            job.start(b, ctx, nf);
+            job.start(b, nf);
             fs.job = &job;
             piped = true;
             return MI_OK;
