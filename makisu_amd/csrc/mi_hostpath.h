@@ -45,12 +45,20 @@ struct Entry {
     int64_t mtime = 0;
     uint8_t kind = 0;      // 0 dir, 1 regular, 2 symlink
     uint32_t uid = 0, gid = 0;
-    bool content_known = false;   // a regular file the walk did NOT stage: the caller said its content is known (Walker::content_known)
-    InodeStamp stamp;             // regular files
 };
 
+// a walk's record.  With a batch attached (want_stamps) every entry also has its inode stamp and the answer the caller's
+// content_known gave for it, in two arrays beside the entries: the entry itself stays what the layer merge and the scan keep
+// per node (a tree of ten million entries pays for every byte of it)
 struct Tree {
     std::vector<Entry> entries;
+    bool want_stamps = false;
+    std::vector<InodeStamp> stamps;       // [i] of entries[i]; regular files (zeros otherwise)
+    std::vector<uint8_t> known;           // [i] = 1: a regular file the walk did NOT stage -- its content is known to the caller
+    void push(Entry&& e, const InodeStamp* st = nullptr, bool is_known = false) {
+        entries.push_back(std::move(e));
+        if (want_stamps) { stamps.push_back(st ? *st : InodeStamp()); known.push_back(is_known ? 1 : 0); }
+    }
 };
 
 // Go's path.Clean for a ROOTED path (what path.Join("/", p) returns): single slashes, no "."

@@ -61,10 +61,11 @@ struct Node {
     uint8_t root[32];
     int64_t batch_file = -1;   // a content-aware commit under way: the file's row in the commit's batch -- its bytes lie in HBM
     bool root_pending = false; // ... and its root is still being computed (a pipelined commit: ScanJob); root[] is not valid yet
-    // MI_MEMFS_TRUST_CTIME: when the content behind `root` was read (CLOCK_REALTIME at the start of that commit's walk; 0 = never:
-    // the root came from elsewhere); the inode as it was then is e.stamp
-    int64_t hashed_at_ns = 0;
 };
+// MI_MEMFS_TRUST_CTIME, per node whose root a commit of this handle computed: the inode as it was when the content was read, and
+// when that was (CLOCK_REALTIME at the start of that commit's walk).  Beside the nodes (Fs::hashed, by node index), not in them:
+// a tree merged from base layers and never scanned with a ctx pays nothing for it.
+struct HashedAs { mi_walk::InodeStamp stamp; int64_t at_ns = 0; };
 
 // The GPU scan of a pipelined commit, on a thread of its own: mi_batch_run (the end of staging, the kernels) and the roots'
 // way back, while the committing thread computes the layer and frames the tar from the bytes that have already landed.
@@ -278,6 +279,13 @@ struct Fs {
     // content-aware isUpdated, counted per layer (mi_commit_stats): files whose header tario.IsSimilarHeader calls similar
     // and whose chunk roots differ; unchanged files whose node had no root yet and took the scan's
     uint64_t n_content_changed = 0, n_roots_learned = 0;
+    const mi_walk::InodeStamp* stamp_for_next_keep = nullptr;                   // memfs_scan -> maybe_add: the new node's inode stamp
+    std::vector<HashedAs> hashed;                                               // [node index]; shorter than `nodes`: no record beyond it
+    void record_hashed(int64_t ref, const mi_walk::InodeStamp& st) {
+        if ((size_t)ref >= hashed.size()) hashed.resize(nodes.size());
+        hashed[(size_t)ref].stamp = st;
+        hashed[(size_t)ref].at_ns = commit_started_ns;
+    }
     bool trust_ctime = false;                                                   // mi_memfs_set_options(MI_MEMFS_TRUST_CTIME)
     int64_t commit_started_ns = 0;                                              // CLOCK_REALTIME when the commit under way began its walk
     std::atomic<uint64_t> n_content_trusted{0};                                 // files of this commit that were not read again
@@ -293,8 +301,10 @@ struct Fs {
         const mi_memtree::Node* nd = t.find_walk(disk_path.substr(root_len));     // (find_walk keeps no cache: safe from many threads)
         if (!nd || nd->ref < 0) return false;
         const Node& x = nodes[(size_t)nd->ref];
-        if (x.e.kind != 1 || !x.has_root || x.root_pending || !x.hashed_at_ns || x.e.size != size || !(x.e.stamp == st)) return false;
-        if (st.ctime_ns + slack_ns >= x.hashed_at_ns) return false;              // racily clean: read it again
+        if (x.e.kind != 1 || !x.has_root || x.root_pending || x.e.size != size || (size_t)nd->ref >= hashed.size()) return false;
+        const HashedAs& h = hashed[(size_t)nd->ref];
+        if (!h.at_ns || !(h.stamp == st)) return false;
+        if (st.ctime_ns + slack_ns >= h.at_ns) return false;                     // racily clean: read it again
         n_content_trusted.fetch_add(1, std::memory_order_relaxed);
         return true;
     }
@@ -419,6 +429,8 @@ struct Fs {
             const std::string link = n.e.has_link ? n.e.link : std::string();
             const int64_t kref = keep(std::move(n));
             if (nodes[(size_t)kref].root_pending) pending_refs.push_back(kref);
+            if (stamp_for_next_keep) { record_hashed(kref, *stamp_for_next_keep); stamp_for_next_keep = nullptr; }
+            else if ((size_t)kref < hashed.size()) hashed[(size_t)kref] = HashedAs();
             // updateMemFS walks the tree part by part (mem_layer.go:57-80): every part before the last has to be a
             // node -- of any type.  A destination spelled THROUGH a symlink therefore works one level below the
             // link (the link node takes the child) and fails deeper ("missing intermediate directory"): what
@@ -510,10 +522,8 @@ struct Fs {
             else { o.root_pending = true; o.batch_file = lazy_file; pending_refs.push_back(cur->ref); }
             ++n_roots_learned;
         }                                                                                // (a content-only change is counted
-        if (similar && stamp && file_has_root && o.has_root && b.kind == 1) {            //  where it is added: maybe_add)
-            o.e.stamp = *stamp;                                                          // hashed now, in this state
-            o.hashed_at_ns = commit_started_ns;
-        }
+        if (similar && stamp && file_has_root && o.has_root && b.kind == 1)              //  where it is added: maybe_add)
+            record_hashed(cur->ref, *stamp);                                             // hashed now, in this state
         return similar != 0;
     }
 };
@@ -1540,10 +1550,10 @@ static int memfs_scan(mi_memfs* m, const mi_tree_entry* walked, uint64_t n, cons
         const bool lazy = !roots && fs.job && from_batch && e.kind == 1 && e.file_index >= 0;   // (the scan may still be running)
         const uint8_t* content_root =
             roots && e.kind == 1 && e.file_index >= 0 ? (const uint8_t*)roots + (uint64_t)e.file_index * root_stride : nullptr;
-        const mi_walk::Entry* we = wt && i < wt->entries.size() ? &wt->entries[i] : nullptr;
-        const bool hashed_now = from_batch && e.kind == 1 && e.file_index >= 0 && we;
-        const bool held = fs.holds_similar(p, e, content_root, lazy ? e.file_index : -1, hashed_now ? &we->stamp : nullptr,
-                                           we && we->content_known);       // (not read again: the content the tree knows)
+        const bool have_wt = wt && wt->want_stamps && i < wt->stamps.size();
+        const bool hashed_now = from_batch && e.kind == 1 && e.file_index >= 0 && have_wt;
+        const bool held = fs.holds_similar(p, e, content_root, lazy ? e.file_index : -1, hashed_now ? &wt->stamps[i] : nullptr,
+                                           have_wt && wt->known[i]);       // (not read again: the content the tree knows)
         if (fs.rc) break;
         if (held) {                                                               // nothing to add; a directory's deletions
             if (e.kind == 0) fs.whiteout_missing_children(p);                     // are still looked for (maybe_add's tail)
@@ -1559,9 +1569,10 @@ static int memfs_scan(mi_memfs* m, const mi_tree_entry* walked, uint64_t n, cons
         }
         if (from_batch && e.kind == 1 && e.file_index >= 0) nd.batch_file = e.file_index;
         if (lazy) { nd.has_root = true; nd.root_pending = true; }
-        if (hashed_now && nd.has_root) { nd.e.stamp = we->stamp; nd.hashed_at_ns = fs.commit_started_ns; }
+        fs.stamp_for_next_keep = hashed_now && nd.has_root ? &wt->stamps[i] : nullptr;   // (recorded with the node maybe_add keeps)
         const std::string src = fs.root == "/" ? p : fs.root + (p == "/" ? "" : p);
         fs.maybe_add(src, p, std::move(nd), true);
+        fs.stamp_for_next_keep = nullptr;
     }
     if (fs.rc) { fs.err = "add to layer: " + fs.err; return memfs_fail(m); }
     mi_copy_layer* l = memfs_take_layer(m);

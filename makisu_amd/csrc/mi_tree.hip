@@ -186,7 +186,7 @@ struct Walker {
         e.gid = (uint32_t)st.st_gid;
         if (S_ISDIR(st.st_mode)) {
             e.kind = 0;
-            tree->entries.push_back(std::move(e));
+            tree->push(std::move(e));
         } else if (S_ISLNK(st.st_mode)) {
             e.kind = 2;
             e.link = *link;
@@ -203,15 +203,14 @@ struct Walker {
                 }
                 e.link = abs_path(e.link.substr(lr.size()));
             }
-            tree->entries.push_back(std::move(e));
+            tree->push(std::move(e));
         } else {
             e.kind = 1;
             e.size = (uint64_t)st.st_size;
-            e.stamp = stamp_of(st);
-            if (batch && (known ? *known : (content_known && content_known(path, e.size, e.stamp)))) {
-                e.content_known = true;                          // no row: nothing of it is read
-                e.file_index = -1;
-                tree->entries.push_back(std::move(e));
+            const InodeStamp stamp = stamp_of(st);
+            if (batch && (known ? *known : (content_known && content_known(path, e.size, stamp)))) {
+                e.file_index = -1;                               // no row: nothing of it is read
+                tree->push(std::move(e), &stamp, true);
                 return;
             }
             if (batch) {
@@ -235,7 +234,7 @@ struct Walker {
                 e.file_index = n_regular;                   // listing only: running file ordinal
             }
             ++n_regular;
-            tree->entries.push_back(std::move(e));
+            tree->push(std::move(e), &stamp);
         }
     }
 
@@ -875,6 +874,8 @@ int scan_walk_batch_filtered(mi_batch* b, const std::string& root, const std::ve
     void** slot = mi_batch_tree_slot(b);
     if (!*slot) *slot = new Tree();
     Tree* t = (Tree*)*slot;
+    t->want_stamps = true;
+    if (t->stamps.size() < t->entries.size()) { t->stamps.resize(t->entries.size()); t->known.resize(t->entries.size()); }
     Walker w;
     w.batch = b;
     w.rel_base = root;
@@ -907,6 +908,8 @@ int mi_batch_add_tree(mi_batch* b, const char* root, const char* rel_base, const
     void** slot = mi_batch_tree_slot(b);
     if (!*slot) *slot = new Tree();
     Tree* t = (Tree*)*slot;
+    t->want_stamps = true;                                       // (a commit records the inodes it hashed: mi_memfs.hip)
+    if (t->stamps.size() < t->entries.size()) { t->stamps.resize(t->entries.size()); t->known.resize(t->entries.size()); }
     mi_walk::Walker w;
     w.batch = b;
     w.rel_base = rel_base ? rel_base : root;
