@@ -147,6 +147,11 @@ def test_every_c_reference_of_the_cgo_fragments_resolves():
     protos, types = _prototypes(pre), _structs(pre)
     frags = _go_fragments()
     assert len(frags) >= 6
+    macros = set()
+    for h in ("makisu_mi.h", "makisu_mi_host.h"):
+        macros |= set(re.findall(r"^#define\s+(MI_[A-Z0-9_]+)\s+\(?-?(?:0x)?[0-9a-fA-F]+u?\)?\s*(?:/\*.*)?$",
+                                 open(os.path.join(ROOT, "include", h)).read(), flags=re.M))
+    assert "MI_MEMFS_TRUST_CTIME" in macros and "MI_GZIP_OFF" in macros and "MI_PART_ALIGN" in macros
     # the shim proper is the fragment with the cgo preamble; the later fragments are excerpts of the same file
     preamble = re.search(r"/\*(.*?)\*/\s*import \"C\"", frags[0], flags=re.S)
     assert preamble, "the first go fragment carries the cgo preamble"
@@ -167,6 +172,8 @@ def test_every_c_reference_of_the_cgo_fragments_resolves():
                 n = 0 if not args else len(_split_top_level(args))
                 assert n == protos[name], "C.%s is called with %d argument(s); the header declares %d" % (name, n, protos[name])
                 calls += 1
+                continue
+            if name in macros:                                  # an integer #define: cgo exposes it as a constant
                 continue
             assert name in types or name in protos, "C.%s is declared by neither header" % name
             if name in protos and name not in types:
