@@ -303,8 +303,11 @@ struct Fs {
         const Node& x = nodes[(size_t)nd->ref];
         if (x.e.kind != 1 || !x.has_root || x.root_pending || x.e.size != size || (size_t)nd->ref >= hashed.size()) return false;
         const HashedAs& h = hashed[(size_t)nd->ref];
-        if (!h.at_ns || !(h.stamp == st)) return false;
-        if (st.ctime_ns + slack_ns >= h.at_ns) return false;                     // racily clean: read it again
+        if (!h.at_ns || !(h.stamp == st)) return false;                          // (with a clock that only moves forward the next line
+        if (st.ctime_ns + slack_ns >= h.at_ns) return false;                     //  alone catches every later change: its ctime is
+                                                                                 //  newer than our read.  The equality is what holds
+                                                                                 //  when the clock was set back in between.)  Racily
+                                                                                 //  clean: read it again
         n_content_trusted.fetch_add(1, std::memory_order_relaxed);
         return true;
     }

@@ -36,13 +36,19 @@ def scenario_scan(tmp, eng):
         assert (st["n_scanned_files"], st["scanned_bytes"]) == (len(files), total), st
         assert (st["files_opened"], st["file_bytes_read"]) == (len(nonempty), total), st      # one open, one read per file
         assert total <= r1 - r0 <= total + (256 << 10), (r1 - r0, total)                        # ... as the kernel counts it
-        assert st["n_layer_files"] == len(files) and st["n_layer_entries"] == res["n_entries"]
+        assert st["n_layer_files"] == len(files) and st["n_layer_entries"] == res["n_entries"] and st["layer_file_bytes"] == total
         res0, raw0 = commit_to_bytes(plain, tmp, "s0p.tar", must_scan=True)
         assert raw0 == raw                                                                      # the reference's tar
         assert res0["stats"]["files_opened"] == len(files) and res0["stats"]["file_bytes_read"] == total   # (its writer reads once
                                                                                                              #  too, and opens empty files)
+        import ctypes
+        big_mallocs = ctypes.CDLL(None).mi_hip_stub_big_mallocs                      # (the double counts allocations of a MiB and more)
+        big_mallocs.restype = ctypes.c_long
+        n0 = big_mallocs()
         res, raw = commit_to_bytes(fs, tmp, "s1.tar", must_scan=True, engine=eng)
         assert res["n_entries"] == 0 and raw == bytes(1024)
+        assert big_mallocs() == n0, "the handle's batch is kept between commits: no new arena, no new tables"
+
         # a changed file (new mtime, new size): that file + its ancestors, its bytes from the arena of the REUSED batch
         rel = "d03/nested/deeper/f003.bin"
         new = os.urandom(len(files[rel]) + 77)

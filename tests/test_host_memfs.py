@@ -522,3 +522,27 @@ def test_merged_header_count_is_the_number_of_distinct_keys(tmp_path):
         assert fs.update_from_entries(many) == 0                                                                   # all similar: nothing merged
         touched = [dict(e, mtime_sec=200) for e in many if e["kind"] == M.KIND_FILE][::7]
         assert fs.update_from_entries(touched) == len(touched) + len({"m"} | {e["relpath"].rsplit("/", 1)[0] for e in touched})
+
+
+def test_a_failing_copy_op_leaves_what_the_reference_has_applied_by_then(tmp_path):
+    """addToLayer (mem_fs.go:343-421) handles an op's sources one after the other: a source that does not exist fails the op
+    BEFORE its destination chain is created (the stat comes first); a source that cannot be resolved -- a link leaving the
+    context -- fails it AFTER the chain and the sources before it were applied.  The ops are planned (disk) and applied
+    (tree) in two steps here; every failure keeps its place."""
+    ctx, root = str(tmp_path / "ctx"), str(tmp_path / "root")
+    os.makedirs(root)
+    _mk(ctx, [("/good/a.txt", "f", "a"), ("/good/sub/b.txt", "f", "b"), ("/escape", "l", "/etc")])
+    rel = lambda fs: [e["relpath"] for e in fs.entries()]                                  # noqa: E731
+    with M.MemFS(root) as fs:
+        ops = [{"src_root": ctx, "srcs": ["good"], "dst": "/one/"}, {"src_root": ctx, "srcs": ["missing"], "dst": "/two/"}]
+        with pytest.raises(M.MiError) as ei:
+            fs.add_layer_by_copy_ops(ops)
+        assert "stat src" in str(ei.value)
+        assert rel(fs) == ["one", "one/a.txt", "one/sub", "one/sub/b.txt"]               # op 1 applied; nothing of op 2, not even /two
+    with M.MemFS(root) as fs:
+        ops = [{"src_root": ctx, "srcs": ["good", "escape"], "dst": "/three/"}]
+        with pytest.raises(M.MiError) as ei:
+            fs.add_layer_by_copy_ops(ops)
+        assert "eval symlinks for escape" in str(ei.value) and "outside of root" in str(ei.value)
+        assert rel(fs) == ["three", "three/a.txt", "three/sub", "three/sub/b.txt"]       # the chain and the first source ARE in the tree
+        assert fs.add_layer_by_copy_ops(ops[:0] + [{"src_root": ctx, "srcs": ["good"], "dst": "/three/"}])[0]["relpath"] == "three"
