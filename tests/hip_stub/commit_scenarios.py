@@ -67,6 +67,10 @@ def scenario_scan(tmp, eng):
         assert [e["relpath"] for e in res["layer"]] == [".wh.d04"]
         res0, raw0 = commit_to_bytes(plain, tmp, "s3p.tar", must_scan=True)
         assert raw0 == raw
+        # a handle that never saw a ctx holds no roots; its first commit with one learns them (the layer stays empty)
+        assert plain.root_of("/d00/f001.bin") is None
+        r = plain.commit_layer(must_scan=True, engine=eng, gzip_level=M.GZIP_OFF)
+        assert r["n_entries"] == 0 and r["stats"]["n_roots_learned"] == len(files) - 9 and plain.root_of("/d00/f001.bin") is not None
         # the handle gives the device back and takes a fresh batch for the next commit
         fs.release_device()
         res, raw = commit_to_bytes(fs, tmp, "s4.tar", must_scan=True, engine=eng)
