@@ -1100,26 +1100,67 @@ extern "C" int mi_snapshot_diff(const mi_snapshot_side* before, const mi_snapsho
         if (!s->roots || e.kind != 1 || e.file_index < 0) return nullptr;
         return (const uint8_t*)s->roots + (uint64_t)e.file_index * s->root_stride;
     };
-    // path -> index, the LAST entry of a path winning (hashed: the order the paths are visited in decides nothing --
-    // flags are only raised, SAME -> ANCESTOR -> CHANGED).  The paths of a side lie in one arena; the tables key views of it.
-    using PathTable = std::unordered_map<std::string_view, uint64_t>;
-    auto index_side = [](const mi_snapshot_side* side, std::string* arena, PathTable* at) {
-        std::vector<uint64_t> off((size_t)side->n + 1);
-        std::string p;
-        for (uint64_t i = 0; i < side->n; ++i) {
-            mi_walk::abs_path_of_rel_into(side->entries[i].relpath ? side->entries[i].relpath : "", &p);
-            off[(size_t)i] = arena->size();
-            arena->append(p);
+    // path -> index, the LAST entry of a path winning.  The paths of a side lie in one arena; the table is flat -- a slot holds the
+    // path's 64-bit hash and its entry index, equal hashes are settled on the arena's bytes -- so that an insert or a lookup is
+    // one cache miss and no allocation (a node-based map: two misses and a malloc per path; at ten million entries a side the
+    // diff spent three quarters of its time there: 0.87 -> see profiles/r05_host_scale.txt).
+    struct PathTable {
+        std::string arena;
+        std::vector<uint64_t> off;                               // [i], [i + 1]: entry i's path in the arena
+        std::vector<uint64_t> hash, index;                       // open addressing; index ~0 = free
+        std::vector<uint8_t> superseded;                         // [i] = 1: entry i's path occurs again later (that one counts)
+        uint64_t mask = 0;
+        static uint64_t hash_of(std::string_view p) {
+            uint64_t h = 0x9E3779B97F4A7C15ull ^ p.size();
+            const char* d = p.data();
+            size_t n = p.size();
+            while (n >= 8) { uint64_t w; memcpy(&w, d, 8); h = (h ^ w) * 0xFF51AFD7ED558CCDull; h ^= h >> 32; d += 8; n -= 8; }
+            uint64_t w = 0;
+            memcpy(&w, d, n);
+            h = (h ^ w) * 0xC4CEB9FE1A85EC53ull;
+            h ^= h >> 29; h *= 0xFF51AFD7ED558CCDull; h ^= h >> 32;
+            return h;
         }
-        off[(size_t)side->n] = arena->size();
-        at->reserve((size_t)side->n * 2);                        // (the arena is complete: its views stay where they are)
-        for (uint64_t i = 0; i < side->n; ++i)
-            (*at)[std::string_view(arena->data() + off[(size_t)i], (size_t)(off[(size_t)i + 1] - off[(size_t)i]))] = i;
+        std::string_view path(uint64_t i) const { return std::string_view(arena.data() + off[(size_t)i], (size_t)(off[(size_t)i + 1] - off[(size_t)i])); }
+        void build(const mi_snapshot_side* side) {
+            off.resize((size_t)side->n + 1);
+            std::string p;
+            for (uint64_t i = 0; i < side->n; ++i) {
+                mi_walk::abs_path_of_rel_into(side->entries[i].relpath ? side->entries[i].relpath : "", &p);
+                off[(size_t)i] = arena.size();
+                arena.append(p);
+            }
+            off[(size_t)side->n] = arena.size();
+            uint64_t cap = 16;
+            while (cap < side->n * 2) cap <<= 1;
+            mask = cap - 1;
+            hash.assign((size_t)cap, 0);
+            index.assign((size_t)cap, ~0ull);
+            superseded.assign((size_t)side->n, 0);
+            for (uint64_t i = 0; i < side->n; ++i) {             // (the arena is complete: its views stay where they are)
+                const std::string_view p_i = path(i);
+                const uint64_t h = hash_of(p_i);
+                uint64_t s = h & mask;
+                for (; index[(size_t)s] != ~0ull; s = (s + 1) & mask)
+                    if (hash[(size_t)s] == h && path(index[(size_t)s]) == p_i) {           // the same path again: the last one wins
+                        superseded[(size_t)index[(size_t)s]] = 1;
+                        break;
+                    }
+                hash[(size_t)s] = h;
+                index[(size_t)s] = i;
+            }
+        }
+        uint64_t find(std::string_view p) const {                // ~0: not there
+            if (index.empty()) return ~0ull;
+            const uint64_t h = hash_of(p);
+            for (uint64_t s = h & mask; index[(size_t)s] != ~0ull; s = (s + 1) & mask)
+                if (hash[(size_t)s] == h && path(index[(size_t)s]) == p) return index[(size_t)s];
+            return ~0ull;
+        }
     };
-    std::string old_paths, new_paths;
     PathTable old_at, new_at;
-    index_side(before, &old_paths, &old_at);
-    index_side(after, &new_paths, &new_at);
+    old_at.build(before);
+    new_at.build(after);
     for (uint64_t i = 0; i < after->n; ++i) after_flags[i] = MI_DIFF_SAME;
     for (uint64_t i = 0; i < before->n; ++i) before_whiteout[i] = 0;
     static const std::string_view kRoot("/");
@@ -1130,46 +1171,55 @@ extern "C" int mi_snapshot_diff(const mi_snapshot_side* before, const mi_snapsho
     };
     auto carry_ancestors = [&](std::string_view p) {
         for (std::string_view d = parent_of(p); !d.empty() && d != kRoot; d = parent_of(d)) {
-            auto it = new_at.find(d);
-            if (it != new_at.end()) {
+            const uint64_t at = new_at.find(d);
+            if (at != ~0ull) {
                 // an ancestor that is already carried (or changed) has had ITS ancestors carried then: the chain is done
-                if (after_flags[it->second] != MI_DIFF_SAME) return;
-                after_flags[it->second] = MI_DIFF_ANCESTOR;
+                if (after_flags[at] != MI_DIFF_SAME) return;
+                after_flags[at] = MI_DIFF_ANCESTOR;
             }
         }
     };
-    for (auto& kv : new_at) {
-        if (kv.first == kRoot) continue;                     // "Root itself is not added to layers"
-        const mi_tree_entry& e = after->entries[kv.second];
+    // the entries in the order they came (the memory the caller handed over is walked once, front to back); an entry whose path
+    // occurs again later is not the one the table holds and decides nothing (flags are only raised, SAME -> ANCESTOR -> CHANGED:
+    // the order the paths are visited in decides nothing either)
+    std::vector<uint8_t> still_there((size_t)before->n, 0);   // [j] = 1: the path of `before`'s entry j is one of `after`'s
+    for (uint64_t i = 0; i < after->n; ++i) {
+        const std::string_view p = new_at.path(i);
+        if (p == kRoot) continue;                            // "Root itself is not added to layers"
+        if (new_at.superseded[(size_t)i]) continue;
+        const mi_tree_entry& e = after->entries[i];
         bool updated = true;
-        auto it = old_at.find(kv.first);
-        if (it != old_at.end()) {
-            const mi_tree_entry& o = before->entries[it->second];
+        const uint64_t j = old_at.find(p);
+        if (j != ~0ull) {
+            still_there[(size_t)j] = 1;
+            const mi_tree_entry& o = before->entries[j];
             int similar = 0;
             int rc = mi_entry_similar(&o, &e, ignore_time, root_of(before, o), root_of(after, e), &similar);
             if (rc) return rc;                               // "unsupported type"
             updated = !similar;
         }
         if (updated) {
-            after_flags[kv.second] = MI_DIFF_CHANGED;
-            carry_ancestors(kv.first);
+            after_flags[i] = MI_DIFF_CHANGED;
+            carry_ancestors(p);
         }
     }
-    for (auto& kv : old_at) {
-        if (kv.first == kRoot || new_at.count(kv.first)) continue;
-        auto pit = new_at.find(parent_of(kv.first));
-        if (pit == new_at.end() || after->entries[pit->second].kind != 0) continue;   // deeper in a deleted subtree,
+    for (uint64_t j = 0; j < before->n; ++j) {
+        const std::string_view p = old_at.path(j);
+        if (still_there[(size_t)j] || old_at.superseded[(size_t)j] || p == kRoot) continue;    // (almost every entry: no lookup)
+        if (new_at.find(p) != ~0ull) continue;               // (the root; a path `after` lists only in a superseded entry)
+        const uint64_t par = new_at.find(parent_of(p));
+        if (par == ~0ull || after->entries[par].kind != 0) continue;                  // deeper in a deleted subtree,
                                                                                        // or its parent became a file
         if (after->disk_root) {
             // child.isOnDisk() (mem_fs.go:49-57, 466): a path the walk no longer lists because it is now
             // skipped (a new mountpoint, a blacklisted dir) is still on disk and gets NO whiteout
-            const std::string on_disk = std::string(after->disk_root) + std::string(kv.first);
+            const std::string on_disk = std::string(after->disk_root) + std::string(p);
             struct stat st;
             if (lstat(on_disk.c_str(), &st) == 0) continue;
             if (errno != ENOENT && errno != ENOTDIR) return MI_ERR_IO;           // "check on disk"
         }
-        before_whiteout[kv.second] = 1;
-        carry_ancestors(kv.first);
+        before_whiteout[j] = 1;
+        carry_ancestors(p);
     }
     return MI_OK;
 }
