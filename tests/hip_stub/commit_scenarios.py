@@ -180,6 +180,43 @@ def scenario_trust(tmp, eng):
     print("OK trust")
 
 
+def scenario_slash(tmp, eng):
+    """the root of every real build is "/": the same commit with the handle rooted there (a node's source IS its path, nothing is
+    trimmed), everything but one directory of this test's blacklisted -- with a ctx, with MI_MEMFS_TRUST_CTIME, and without"""
+    import shutil
+    import time
+    if os.geteuid() != 0:
+        print("OK slash")
+        return
+    import fcntl
+    top = "/mi_slash_%d" % os.getpid()
+    lock = open("/tmp/mi_slash.lock", "w")                                   # (one at a time: a sibling's directory appearing at "/"
+    fcntl.flock(lock, fcntl.LOCK_EX)                                         #  between two commits would be part of the second)
+    try:
+        files = make_tree(top, seed=51, n_dirs=3, mtime=MTIME)
+        blacklist = ["/" + n for n in os.listdir("/") if "/" + n != top]
+        time.sleep(0.06)
+        with M.MemFS("/", blacklist=blacklist) as fs, M.MemFS("/", blacklist=blacklist) as plain:
+            fs.set_options(trust_ctime=True)
+            res, raw = commit_to_bytes(fs, tmp, "r0.tar", must_scan=True, engine=eng)
+            res0, raw0 = commit_to_bytes(plain, tmp, "r0p.tar", must_scan=True)
+            assert raw == raw0
+            got = {n: d for n, m, d in tar_members(raw) if m.isfile()}
+            assert got == {top[1:] + "/" + rel: data for rel, data in files.items()}
+            assert all(e["src"] == "/" + e["relpath"] for e in res["layer"])
+            assert fs.root_of(top + "/d00/f001.bin") is not None
+            r = fs.commit_layer(must_scan=True, engine=eng, gzip_level=M.GZIP_OFF)
+            assert r["n_entries"] == 0 and r["stats"]["n_content_trusted"] == len(files) and r["stats"]["files_opened"] == 0, r["stats"]
+            os.unlink(top + "/d00/f001.bin")
+            res, raw = commit_to_bytes(fs, tmp, "r1.tar", must_scan=True, engine=eng)
+            assert [e["relpath"] for e in res["layer"]] == [top[1:], top[1:] + "/d00", top[1:] + "/d00/.wh.f001.bin"]
+    finally:
+        shutil.rmtree(top, ignore_errors=True)
+        fcntl.flock(lock, fcntl.LOCK_UN)
+        lock.close()
+    print("OK slash")
+
+
 if __name__ == "__main__":
     tmp, threads = sys.argv[1], int(sys.argv[2])
     with M.Engine(n_streams=threads, staging_bytes=1 << 20) as eng:
@@ -187,3 +224,4 @@ if __name__ == "__main__":
         scenario_copy(tmp, eng)
         scenario_many(tmp, eng)
         scenario_trust(tmp, eng)
+        scenario_slash(tmp, eng)
