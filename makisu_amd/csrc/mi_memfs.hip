@@ -1,7 +1,10 @@
 // mi_memfs.hip -- the reference's MemFS and what surrounds a COPY/ADD step, on the host (no device code here):
 //   * MemFS as a handle -- the one implementation of the layer merge and the copy-op layer (MemFS.addToLayer):
-//     UpdateFromTarReader with and without untar, AddLayerByScan, AddLayerByCopyOps, step.commitLayer in one call,
-//     Checkpoint, Reset;
+//     UpdateFromTarReader with and without untar, AddLayerByScan, AddLayerByCopyOps, Checkpoint, Reset;
+//   * step.commitLayer in ONE call, mi_memfs_commit_layer -- with a ctx THE SEAM of this library: the walk stages
+//     every file into one batch, the GPU cuts and hashes them, the diff runs with chunk roots (a path is in the layer if its
+//     header changed OR its content did), the layer tar is framed from the bytes in HBM; the scan runs on a thread of its own
+//     beside the diff and the writer (ScanJob), and with MI_MEMFS_TRUST_CTIME only files whose inode changed are read at all;
 //   * CopyOperation.Execute over fileio.Copier; MemFS.untarOneItem + tario.ApplyHeader;
 //   * the caller's side of the step: --chown (utils.ResolveChown), source patterns (filepath.Match / Glob as
 //     addCopyStep.resolveFromPaths uses them), NewCopyOperation's checks.

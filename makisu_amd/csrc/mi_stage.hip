@@ -9,6 +9,10 @@
 // MI_FLAG_VERIFY_STAGING: every copy is summed on the host (in the slab) and on the GPU (where it
 // landed) -- stage_sum_kernel below, the one kernel of this file --, copied again if the sums
 // differ, and summed once more when staging ends (stage_verify_final).
+// A file that is handed over as a path is opened ONCE, by the reader that takes its first piece; the other pieces read
+// through the same descriptor, the last one closes it.  A batch's pieces are queued in arena order, so "everything below
+// arena offset X has landed" is one number (stager_wait_landed): what lets the commit's tar writer read a file out of HBM
+// while files behind it are still on their way.
 #include "mi_internal.h"
 #include "mi_hostpath.h"      // mi_io: what was read of file content
 
