@@ -737,6 +737,8 @@ typedef struct {
     uint64_t n_roots_learned;    /* unchanged files that had no root in the tree and have one now               */
     uint64_t n_content_trusted;  /* MI_MEMFS_TRUST_CTIME: files that were not read again (their inode is as it was)  */
     uint64_t n_index_new, n_index_known;   /* mi_index_add_batch's counts (index set)                           */
+    uint64_t index_new_bytes;    /* ... and the bytes of the chunks no earlier commit held: what a chunk-addressed
+                                    store would have to take in for this commit                                 */
     uint64_t files_opened;       /* file descriptors whose content was read, by every thread of the library ... */
     uint64_t file_bytes_read;    /* ... and the bytes read from them, during this commit (process-wide counters:
                                     a commit running beside another one counts both)                            */

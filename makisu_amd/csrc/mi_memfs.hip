@@ -1806,7 +1806,17 @@ extern "C" int mi_memfs_commit_layer(mi_memfs* m, mi_ctx* ctx, int must_scan, co
     }
     m->last.pipelined = was_piped ? 1 : 0;
     if (!rc && b && m->index && m->last.n_scanned_files) {
-        rc = mi_index_add_batch(m->index, b, nullptr, 0, &m->last.n_index_new, &m->last.n_index_known);
+        // the chunk index (keyvalue.Store seam): which of this commit's chunks no earlier commit held, and how many bytes they
+        // are -- what a chunk-addressed store would have to take in for this layer
+        uint64_t nc = 0;
+        mi_batch_counts(b, nullptr, &nc, nullptr);
+        std::vector<uint8_t> known(nc ? nc : 1);
+        rc = mi_index_add_batch(m->index, b, known.data(), nc, &m->last.n_index_new, &m->last.n_index_known);
+        const mi_chunk_result* rows = nullptr;
+        if (!rc && nc) rc = mi_batch_chunks_view(b, &rows, &nc);
+        if (!rc)
+            for (uint64_t i = 0; i < nc; ++i)
+                if (!known[i] && rows[i].dup_of < 0) m->last.index_new_bytes += rows[i].length;
         if (rc) m->err = std::string("failed to generate diff layer: chunk index: ") + mi_last_error(ctx);
     }
     m->last.files_opened += mi_io::content_opens.load() - opens0;

@@ -338,9 +338,16 @@ def test_the_commit_feeds_the_chunk_index(oracle, eng, tmp_path):
         fb.set_index(idx)
         ra = fa.commit_layer(must_scan=True, engine=eng)
         assert ra["stats"]["n_index_known"] == 0 and ra["stats"]["n_index_new"] == len(idx) > 0
+        assert 0 <= ra["stats"]["scanned_bytes"] - ra["stats"]["index_new_bytes"] <= 4   # random files: every byte is news (but two
+                                                                                           # of the four 1-byte files may be the same byte)
         rb = fb.commit_layer(must_scan=True, engine=eng)
         assert rb["stats"]["n_index_new"] == 0 and rb["stats"]["n_chunks"] >= rb["stats"]["n_index_known"] > 0
-        assert rb["tar_digest"] == ra["tar_digest"]
+        assert rb["tar_digest"] == ra["tar_digest"] and rb["stats"]["index_new_bytes"] == 0
+        # a file that repeats one the index knows (whole) and a new one: only the new one's bytes are news
+        write_file(os.path.join(b, "d00/copy_of_f003.bin"), open(os.path.join(b, "d00/f003.bin"), "rb").read(), 0o644, MTIME)
+        write_file(os.path.join(b, "d00/fresh.bin"), os.urandom(50_000), 0o644, MTIME)
+        rc = fb.commit_layer(must_scan=True, engine=eng)
+        assert rc["stats"]["n_layer_files"] == 2 and rc["stats"]["index_new_bytes"] == 50_000
 
 
 def test_trusting_the_inode_reads_only_what_changed_and_still_catches_the_same_second_rewrite(oracle, eng, tmp_path):
