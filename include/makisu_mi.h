@@ -759,7 +759,7 @@ int  mi_memfs_commit_stats(const mi_memfs* fs, mi_commit_stats* out);
  * of the last change of an inode and cannot be set from user space (utimes sets it to "now"), so the same-size same-SECOND
  * rewrite the reference misses still changes it.  What git calls "racily clean" is handled as git does: a file whose ctime is
  * not safely older than the moment its content was read (MI_TRUST_CTIME_SLACK_MS, default 20: the kernel's timestamps tick
- * every 1-4 ms) is read again.  With the option a commit that changed nothing costs a walk and a diff (the reference's
+ * every 1-4 ms; two seconds for a ctime without a sub-second part -- a file system that keeps whole seconds) is read again.  With the option a commit that changed nothing costs a walk and a diff (the reference's
  * price) instead of a read of the whole tree; the layer, the roots and the DigestPair are the same unless the kernel's
  * timestamps lie (a clock set back between a write and the next one to the same file).  Scan commits only.                */
 #define MI_MEMFS_TRUST_CTIME 0x1u

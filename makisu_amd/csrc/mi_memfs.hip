@@ -306,8 +306,11 @@ struct Fs {
         const Node& x = nodes[(size_t)nd->ref];
         if (x.e.kind != 1 || !x.has_root || x.root_pending || x.e.size != size || (size_t)nd->ref >= hashed.size()) return false;
         const HashedAs& h = hashed[(size_t)nd->ref];
+        // a file system that keeps whole seconds (ext3, FAT, some network mounts) shows as a ctime without a sub-second part:
+        // its racy window is the second (two for FAT), not the kernel's clock tick
+        const int64_t window_ns = st.ctime_ns % 1000000000ll == 0 ? std::max<int64_t>(slack_ns, 2000000000ll) : slack_ns;
         if (!h.at_ns || !(h.stamp == st)) return false;                          // (with a clock that only moves forward the next line
-        if (st.ctime_ns + slack_ns >= h.at_ns) return false;                     //  alone catches every later change: its ctime is
+        if (st.ctime_ns + window_ns >= h.at_ns) return false;                    //  alone catches every later change: its ctime is
                                                                                  //  newer than our read.  The equality is what holds
                                                                                  //  when the clock was set back in between.)  Racily
                                                                                  //  clean: read it again
