@@ -29,7 +29,8 @@ def main():
         for i in range(n):
             blob[:8] = np.frombuffer(np.uint64(i).tobytes(), dtype=np.uint8)
             blob.tofile(os.path.join(root, "f%03d" % i))
-        eng, dt = t(lambda: M.Engine(device=0))
+        ns = int(os.environ.get("MI_PROBE_STREAMS", "0"))
+        eng, dt = t(lambda: M.Engine(device=0, n_streams=ns) if ns else M.Engine(device=0))
         print("mi_ctx_create                      %.3f s" % dt)
         for gb in (1, 4, 8, 16):
             b, dt = t(lambda: eng.batch(0, gb << 30))
@@ -39,13 +40,24 @@ def main():
         _, dt = t(lambda: b.add_bytes(bytes(2 << 20)))
         print("first mi_batch_add_bytes of 2 MiB  %.3f s (the reader threads come up: a pinned slab and a stream each)" % dt)
         b.free()
+        if os.environ.get("MI_PROBE_WARM_GIB"):                  # does the FIRST traffic of the process pay, or every fresh arena's?
+            g = int(os.environ["MI_PROBE_WARM_GIB"])
+            blob1 = np.zeros(g << 30, dtype=np.uint8)
+            for r in range(2):
+                bw = eng.batch()
+                _, dt = t(lambda: (bw.add_bytes(blob1), bw.run()))
+                print("warm-up batch %d: %d GiB from host memory in %.3f s" % (r, g, dt))
+                bw.free()
         b = eng.batch()
         for k in range(3):
             if k:
                 b.reset()
             _, d1 = t(lambda: b.add_tree(root, root, (), M.TREE_SCAN))
             _, d2 = t(b.run)
-            print("round %d: add_tree %.3f s, run %.3f s  (%.1f GB/s end to end)" % (k, d1, d2, n * (mib << 20) / (d1 + d2) / 1e9))
+            st = eng.stats()
+            print("round %d: add_tree %.3f s, run %.3f s  (%.1f GB/s end to end); device: h2d %.1f ms, cdc %.1f, sort %.1f, sha %.1f, files %.1f, "
+                  "dedup %.1f, first kernel to last %.1f" % (k, d1, d2, n * (mib << 20) / (d1 + d2) / 1e9, st["ms_h2d"], st["ms_cdc"], st["ms_sort"],
+                                                        st["ms_sha_chunks"], st["ms_sha_files"], st["ms_dedup"], st["ms_total"]))
         b.free()
         eng.close()
     finally:
