@@ -1,0 +1,68 @@
+"""The content-aware commit on a REAL tree: this image's own /usr (15 GB, 114 000 entries: shared libraries of hundreds of megabytes, tens
+of thousands of small Python files, symlinks with absolute targets, hard links) as the root file system of a build -- a MemFS rooted at "/"
+with every other top-level directory blacklisted.  Three handles: with a ctx, with a ctx and MI_MEMFS_TRUST_CTIME, without a ctx; each commits
+the tree (all new), then again (nothing changed).  Checks: the three layer tars have the same TarDigest; the chunk roots of a random sample
+of files are the oracle's.  Prints the commit table.        usage: real_tree_commit.py [top = /usr] [sample = 300]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import makisu_amd as M  # noqa: E402
+from commit_cases import oracle_root  # noqa: E402
+
+
+def main():
+    top = sys.argv[1] if len(sys.argv) > 1 else "/usr"
+    n_sample = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+    from oracle import mi_oracle as O
+    O.build()
+    first = "/" + top.strip("/").split("/")[0]
+    blacklist = ["/" + n for n in os.listdir("/") if "/" + n != first]
+    if first != top:                                               # a subtree: its siblings on the way down are blacklisted too
+        cur = first
+        for part in top.strip("/").split("/")[1:]:
+            blacklist += [os.path.join(cur, n) for n in os.listdir(cur) if n != part]
+            cur = os.path.join(cur, part)
+    rows = []
+    digests = {}
+    with M.Engine(device=0) as eng:
+        handles = [("gpu", {"engine": eng}, False), ("gpu_trust_ctime", {"engine": eng}, True), ("cpu_header_only", {}, False)]
+        for name, kw, trust in handles:
+            with M.MemFS("/", blacklist=blacklist) as fs:
+                if trust:
+                    fs.set_options(trust_ctime=True)
+                for what in ("all new", "nothing changed"):
+                    t0 = time.perf_counter()
+                    res = fs.commit_layer(must_scan=True, gzip_level=M.GZIP_OFF, **kw)
+                    dt = time.perf_counter() - t0
+                    st = res["stats"]
+                    rows.append((name, what, dt, st, res))
+                    if what == "all new":
+                        digests[name] = str(res["tar_digest"])
+                        if name == "gpu":
+                            files = [e for e in res["layer"] if e["kind"] == M.KIND_FILE and "root" in e and e["size"] <= (64 << 20)]
+                            rng = np.random.default_rng(5)
+                            pick = [files[int(i)] for i in rng.choice(len(files), size=min(n_sample, len(files)), replace=False)]
+                            bad = [e["relpath"] for e in pick if oracle_root(O, open("/" + e["relpath"], "rb").read()) != e["root"]]
+                            n_links = sum(1 for e in res["layer"] if e["kind"] == M.KIND_SYMLINK)
+                            print("%d entries, %d regular files (%.2f GB), %d symlinks, largest file %.0f MB; %d sampled roots against the oracle: %s" %
+                                  (res["n_entries"], st["n_layer_files"], st["layer_file_bytes"] / 1e9, n_links,
+                                   max(e["size"] for e in res["layer"]) / 1e6, len(pick), "all equal" if not bad else "DIFFER: %s" % bad[:5]))
+                            assert not bad
+    for name, what, dt, st, res in rows:
+        print("%-16s %-16s %7.3f s = walk%s %.3f + diff %.3f + tar %.3f; scan %.3f%s | layer %d entries, %d files | read %d files, %.2f GB (%d trusted)" %
+              (name, what, dt, "+stage" if name.startswith("gpu") else "", st["s_walk_stage"], st["s_diff"], st["s_write"], st["s_scan"],
+               " (beside)" if st["pipelined"] else "", res["n_entries"], st["n_layer_files"], st["files_opened"], st["file_bytes_read"] / 1e9,
+               st["n_content_trusted"]))
+    same = len(set(digests.values())) == 1
+    print("TarDigest %s%s" % (digests["gpu"][:26], " -- the same from all three handles" if same else " -- DIFFERENT: %s" % digests))
+    assert same
+
+
+if __name__ == "__main__":
+    main()
