@@ -166,6 +166,40 @@ inline bool is_descendant_of_any(const std::string& path, const std::vector<std:
     }
     return false;
 }
+// The same question for the walks, which ask it of EVERY path they list: the blacklist is cleaned once (AbsPath of each entry),
+// and a path that is already clean and absolute -- what a walk builds by joining names onto its root -- is compared as it stands:
+// no allocation, no path.Join per blacklist entry (a root file system of 114 000 entries with the 26 other top-level directories
+// blacklisted: 0.21 s of walk, 0.14 s of it in this question before; IsDescendantOfAny's answer, lib/pathutils/path.go:24-35)
+inline bool is_clean_abs(const std::string& p) {
+    if (p.empty() || p[0] != '/') return false;
+    if (p.size() == 1) return true;
+    if (p.back() == '/') return false;
+    for (size_t i = 0; i + 1 < p.size(); ++i)
+        if (p[i] == '/') {
+            if (p[i + 1] == '/') return false;
+            if (p[i + 1] == '.') {
+                const size_t k = i + 2 < p.size() && p[i + 2] == '.' ? i + 3 : i + 2;
+                if (k >= p.size() || p[k] == '/') return false;              // a "." or ".." element
+            }
+        }
+    return true;
+}
+inline std::vector<std::string> cleaned_paths(const std::vector<std::string>& paths) {
+    std::vector<std::string> out;
+    for (const std::string& a : paths) out.push_back(abs_path(a));
+    return out;
+}
+inline bool is_descendant_of_any_cleaned(const std::string& path, const std::vector<std::string>& anc_clean,
+                                         const std::vector<std::string>& anc_raw) {
+    if (anc_clean.empty()) return false;
+    if (!is_clean_abs(path)) return is_descendant_of_any(path, anc_raw);
+    for (const std::string& a : anc_clean) {
+        if (a.size() == 1) return true;                                      // "/": everything is below it
+        if (path.size() >= a.size() && memcmp(path.data(), a.data(), a.size()) == 0 && (path.size() == a.size() || path[a.size()] == '/'))
+            return true;
+    }
+    return false;
+}
 inline std::string rel_to(const std::string& base, const std::string& path) {   // filepath.Rel, descendants only
     const std::string b = abs_path(base), p = abs_path(path);
     if (p == b) return ".";

@@ -77,6 +77,21 @@ struct Walker {
     std::string rel_base;
     std::string link_root;     // root that absolute symlink targets lose (empty = rel_base)
     std::vector<std::string> blacklist;
+    std::vector<std::string> blacklist_clean;   // AbsPath of each, made when the first path asks (below_blacklist)
+    std::atomic<bool> blacklist_cleaned{false};          // (asked by several directory readers at once)
+    std::mutex blacklist_mu;
+    bool below_blacklist(const std::string& path) {
+        if (blacklist.empty()) return false;
+        if (!blacklist_cleaned.load(std::memory_order_acquire)) {
+            std::lock_guard<std::mutex> g(blacklist_mu);
+            if (!blacklist_cleaned.load(std::memory_order_relaxed)) { blacklist_clean = cleaned_paths(blacklist); blacklist_cleaned.store(true, std::memory_order_release); }
+        }
+        return is_descendant_of_any_cleaned(path, blacklist_clean, blacklist);
+    }
+    static bool whiteout_meta(const std::string& path) {            // a base name that begins with ".wh..wh." (const.go:17-22)
+        const size_t cut = path.find_last_of('/');
+        return path.compare(cut == std::string::npos ? 0 : cut + 1, 8, ".wh..wh.") == 0;
+    }
     uint32_t mode;
     Tree* tree;
     std::string err;
@@ -158,8 +173,8 @@ struct Walker {
     bool should_skip(const std::string& path, const struct stat& st) {
         const bool special = S_ISCHR(st.st_mode) || S_ISBLK(st.st_mode) || S_ISFIFO(st.st_mode) || S_ISSOCK(st.st_mode);
         if (mode == MI_TREE_CONTEXT) return special;
-        if (has_prefix(base_of(path), ".wh..wh.")) return true;
-        if (is_descendant_of_any(path, blacklist) || special) return true;
+        if (whiteout_meta(path)) return true;
+        if (below_blacklist(path) || special) return true;
         const MountTable& mt = mountpoints();
         if (!mt.error.empty()) { err = "ismount: mountmanager initialize: " + mt.error; rc = MI_ERR_IO; return true; }
         return mt.targets.count(path) != 0;
@@ -510,8 +525,8 @@ struct ParallelWalker {
     bool skip_rule(const std::string& path, const struct stat& st, int* rc, std::string* err) const {
         const bool special = S_ISCHR(st.st_mode) || S_ISBLK(st.st_mode) || S_ISFIFO(st.st_mode) || S_ISSOCK(st.st_mode);
         if (w->mode == MI_TREE_CONTEXT) return special;
-        if (has_prefix(base_of(path), ".wh..wh.")) return true;
-        if (is_descendant_of_any(path, w->blacklist) || special) return true;
+        if (Walker::whiteout_meta(path)) return true;
+        if (w->below_blacklist(path) || special) return true;
         const MountTable& mt = mountpoints();
         if (!mt.error.empty()) { *err = "ismount: mountmanager initialize: " + mt.error; *rc = MI_ERR_IO; return true; }
         return mt.targets.count(path) != 0;

@@ -655,3 +655,26 @@ def test_compare_fs_case_through_the_snapshot_diff(engine_lib):
     assert carried == ["common"]                                            # the unchanged parent travels with them
     changed, carried, whiteouts = _diff_names(fs2, fs1)
     assert whiteouts == ["common/test2"] and changed == ["common/test1", "common/world"]
+
+
+def test_blacklist_spelled_uncleanly_and_the_prefix_trap(tmp_path):
+    """pathutils.IsDescendantOfAny (lib/pathutils/path.go:24-35) cleans both sides (AbsPath) and compares ELEMENTS: a blacklist
+    entry spelled with "//", "/./" or a trailing "/" skips what its clean form skips, and "/r/pre" does not skip "/r/prefix".
+    (The walks clean the blacklist once and compare clean paths as they stand; an unclean ROOT takes the general way.)"""
+    import makisu_amd as M
+    root = str(tmp_path / "r")
+    for rel in ("skip/a", "skip/deep/b", "other/x/c", "other/y", "pre/z", "prefix/keep", "keep"):
+        p = os.path.join(root, rel)
+        os.makedirs(os.path.dirname(p), exist_ok=True)
+        open(p, "w").write("1")
+    bl = [root + "/skip/", root + "//other/./x", root + "/pre"]
+    want = [".", "keep", "other", "other/y", "prefix", "prefix/keep"]
+    for r in (root, root + "/", root + "//", os.path.join(str(tmp_path), ".", "r")):
+        for threads in ("1", "4"):
+            code = ("import sys, makisu_amd as M; print([e['relpath'] for e in M.tree_walk(%r, %r, %r, M.TREE_SCAN, full=True)])" % (r, root, bl))
+            import subprocess
+            import sys
+            out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MI_WALK_THREADS=threads, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))),
+                                 capture_output=True, text=True, timeout=120)
+            assert out.returncode == 0, out.stderr[-800:]
+            assert eval(out.stdout.strip()) == want, (r, threads, out.stdout)
