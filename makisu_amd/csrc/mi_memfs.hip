@@ -1426,7 +1426,7 @@ static int memfs_update(mi_memfs* m, const mi_tree_entry* layer, uint64_t n_laye
         if (e.kind > 3) return true;
         if (fs.root == "/") on_disk_buf = p; else { on_disk_buf = fs.root; if (p != "/") on_disk_buf += p; }
         const std::string& on_disk = on_disk_buf;
-        if (!bl.empty() && mi_walk::is_descendant_of_any(on_disk, bl)) return true;
+        if (!bl.empty() && mi_walk::is_descendant_of_any_cleaned(on_disk, bl, bl)) return true;   // (bl: AbsPath'ed above, once)
         if (mt.targets.empty()) return false;
         if (mt.targets.count(on_disk)) return true;
         const size_t dcut = on_disk.find_last_of('/');
