@@ -759,17 +759,19 @@ int  mi_memfs_commit_stats(const mi_memfs* fs, mi_commit_stats* out);
  * of the last change of an inode and cannot be set from user space (utimes sets it to "now"), so the same-size same-SECOND
  * rewrite the reference misses still changes it.  What git calls "racily clean" is handled as git does: a file whose ctime is
  * not safely older than the moment its content was read (MI_TRUST_CTIME_SLACK_MS, default 20: the kernel's timestamps tick
- * every 1-4 ms; two seconds for a ctime without a sub-second part -- a file system that keeps whole seconds) is read again.  With the option a commit that changed nothing costs a walk and a diff (the reference's
- * price) instead of a read of the whole tree; the layer, the roots and the DigestPair are the same unless the kernel's
- * timestamps lie (a clock set back between a write and the next one to the same file).  Scan commits only.                */
+ * every 1-4 ms; two seconds for a ctime without a sub-second part -- a file system that keeps whole seconds) is read again.
+ * With the option a commit that changed nothing costs a walk and a diff (the reference's price) instead of a read of the
+ * whole tree; the layer, the roots and the DigestPair are the same unless the kernel's timestamps lie (a clock set back
+ * between a write and the next one to the same file).  Scan commits only.                                               */
 #define MI_MEMFS_TRUST_CTIME 0x1u
 int  mi_memfs_set_options(mi_memfs* fs, uint32_t options);
 /* From now on every content-aware commit of this handle adds its batch to `index` (NULL: stop).  The index must belong
  * to the ctx the commits run on and outlive them; the handle does not own it.                                          */
 int  mi_memfs_set_index(mi_memfs* fs, mi_index* index);
 /* The handle's batch ahead of its first content-aware commit, with room for `files` files of `bytes` bytes in total: a
- * ctx's first use costs (fresh device memory: 68 ms per GiB on this driver; the reader threads: 55 ms) -- a host that knows
- * what is coming, e.g. the size of the base image it is pulling, pays them beside its own work.  Optional.               */
+ * ctx's first use costs (the reader threads: 40-55 ms; fresh device memory on a box nobody has allocated on yet: 68 ms per
+ * GiB) -- a host that knows what is coming, e.g. the size of the base image it is pulling, pays them beside its own work.
+ * Optional.                                                                                                              */
 int  mi_memfs_reserve_device(mi_memfs* fs, mi_ctx* ctx, uint64_t files, uint64_t bytes);
 /* Gives back the batch a content-aware commit left with the handle (its arena holds the scanned tree's bytes).          */
 int  mi_memfs_release_device(mi_memfs* fs);
