@@ -723,8 +723,11 @@ void mi_layer_free(mi_layer* layer);
  * fails the commit AFTER the tree took the layer -- as a failing tar write does in the reference (MemFS.AddLayerByScan
  * updates the tree, then writes; lib/snapshot/mem_fs.go:260-274).  MI_COMMIT_PIPELINE=0: one step after the other.
  * The handle keeps the batch (device memory sized by the largest commit so far) for its next commit; it belongs to
- * `ctx`: free the handle, or call mi_memfs_release_device, before mi_ctx_destroy.  A tree larger than the device's free
- * memory fails with MI_ERR_NOMEM and leaves the tree as it was.  mi_memfs_commit_stats: what the last commit did.     */
+ * `ctx`: free the handle, or call mi_memfs_release_device, before mi_ctx_destroy.  A scanned tree larger than the device's
+ * free memory is not refused: its roots are computed in windows (runs of files the device has room for; MI_COMMIT_WINDOW_MB)
+ * and the writer reads the layer's files from disk -- a second read for those, mi_commit_stats.n_windows says so; copy ops
+ * whose sources do not fit fail with MI_ERR_NOMEM and leave the tree as it was.  mi_memfs_commit_stats: what the last
+ * commit did.                                                                                                            */
 typedef struct {
     uint64_t n_walked;           /* paths the walk(s) listed                                                    */
     uint64_t n_scanned_files;    /* regular files staged and scanned on the GPU (0 with ctx == NULL)            */
@@ -743,6 +746,8 @@ typedef struct {
     uint64_t file_bytes_read;    /* ... and the bytes read from them, during this commit (process-wide counters:
                                     a commit running beside another one counts both)                            */
     uint64_t pipelined;          /* 1: the scan ran beside the diff and the tar writer (its time is not in the sum) */
+    uint64_t n_windows;          /* 0 normally; k: the tree did not fit the device and was scanned in k windows (the
+                                    layer's files were then read from disk by the writer: a second read for those)   */
     double   s_walk_stage;       /* walk (+ staging, which goes on behind it)                                   */
     double   s_scan;             /* end of staging + the GPU passes + the roots' way back (pipelined: on a thread
                                     of its own, overlapping s_diff and s_write)                                 */

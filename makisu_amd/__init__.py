@@ -114,7 +114,7 @@ GZIP_OFF, GZIP_DEFAULT = -2, -1
 class CommitStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("n_walked", "n_scanned_files", "scanned_bytes", "n_chunks", "n_layer_entries",
                                           "n_layer_files", "layer_file_bytes", "n_content_changed", "n_roots_learned", "n_content_trusted",
-                                          "n_index_new", "n_index_known", "index_new_bytes", "files_opened", "file_bytes_read", "pipelined")] + \
+                                          "n_index_new", "n_index_known", "index_new_bytes", "files_opened", "file_bytes_read", "pipelined", "n_windows")] + \
                [(n, C.c_double) for n in ("s_walk_stage", "s_scan", "s_diff", "s_write", "s_total")]
 
     def as_dict(self):

@@ -1552,6 +1552,11 @@ int mi_batch_file_size(mi_batch* b, uint64_t file_index, uint64_t* size) {      
     *size = b->files[file_index].size;
     return MI_OK;
 }
+int mi_batch_arena_room(mi_batch* b, uint64_t* bytes) {
+    if (!b || !bytes) return MI_ERR_INVALID;
+    *bytes = b->arena.bytes;
+    return MI_OK;
+}
 const char* mi_last_error_of_batch(mi_batch* b) {                // (a copy of the caller's own: see mi::fail)
     static thread_local std::string mine;
     if (!b) return "";

@@ -286,6 +286,8 @@ inline const MountTable& mountpoints() {
 // the snapshot walk of `src` (scan rules, no blacklist), entries relative to src ("." first); absolute symlink targets
 // lose link_root (createHeader trims by the MemFS root).  Defined in mi_tree.hip, beside the walkers.
 int scan_walk_collect(const std::string& src, const std::string& link_root, Tree* out, std::string* err);
+// the snapshot walk of a root with its blacklist and NO batch, inode stamps recorded (a tree that is scanned in windows)
+int scan_walk_listing(const std::string& root, const std::vector<std::string>& blacklist, Tree* out, std::string* err);
 int scan_walk_collect_batch(const std::string& src, const std::string& link_root, Tree* out, std::string* err, mi_batch* b);
 // mi_batch_add_tree with the scan rules and a say in which files are staged: known(path on disk, size, stamp) == true means
 // "this file's content is known, do not read it" -- called from the walk's directory readers, several at a time

@@ -12,6 +12,8 @@ MI_LOCAL void        mi_set_error(mi_batch* b, const char* msg);     // b NULL: 
 MI_LOCAL void**      mi_batch_tree_slot(mi_batch* b);                // the batch's walk record (mi_tree.hip owns its type)
 MI_LOCAL int         mi_batch_file_size(mi_batch* b, uint64_t file_index, uint64_t* size);
 MI_LOCAL const char* mi_last_error_of_batch(mi_batch* b);
+// what the batch's arena holds now (bytes allocated): the room a window of an oversize tree can count on
+MI_LOCAL int         mi_batch_arena_room(mi_batch* b, uint64_t* bytes);
 // mi_batch_read_file for the pipelined commit: the batch is still being staged / scanned on another thread; the call waits
 // until the bytes it is asked for have landed in HBM
 MI_LOCAL int         mi_batch_read_file_landed(mi_batch* b, uint64_t file_index, uint64_t offset, void* dst, uint64_t len);

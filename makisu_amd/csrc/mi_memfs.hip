@@ -1326,6 +1326,7 @@ struct mi_memfs {
     mi_ctx* batch_ctx = nullptr;
     mi_index* index = nullptr;           // mi_memfs_set_index: every content-aware commit adds its batch's chunks
     mi_commit_stats last;                // of the last mi_memfs_commit_layer
+    bool went_windowed = false;          // the scanned tree did not fit the device (the next full scan goes window by window at once)
     mi_memfs() { memset(&last, 0, sizeof last); }
     ~mi_memfs() { if (batch) mi_batch_free(batch); }
 };
@@ -1560,7 +1561,7 @@ static int memfs_scan(mi_memfs* m, const mi_tree_entry* walked, uint64_t n, cons
         const uint8_t* content_root =
             roots && e.kind == 1 && e.file_index >= 0 ? (const uint8_t*)roots + (uint64_t)e.file_index * root_stride : nullptr;
         const bool have_wt = wt && wt->want_stamps && i < wt->stamps.size();
-        const bool hashed_now = from_batch && e.kind == 1 && e.file_index >= 0 && have_wt;
+        const bool hashed_now = (from_batch || roots) && e.kind == 1 && e.file_index >= 0 && have_wt;   // (a batch's row, or a window's)
         const bool held = fs.holds_similar(p, e, content_root, lazy ? e.file_index : -1, hashed_now ? &wt->stamps[i] : nullptr,
                                            have_wt && wt->known[i]);       // (not read again: the content the tree knows)
         if (fs.rc) break;
@@ -1662,6 +1663,61 @@ static int memfs_commit_write(mi_memfs* m, mi_copy_layer* cl, uint64_t ne, const
     return rc;
 }
 
+// A tree that does not fit the device: the chunk roots of its regular files, computed in WINDOWS -- runs of files (walk order) the
+// batch has room for; each window is staged, scanned and forgotten.  roots: 32 bytes per regular file, by the walk's file ordinal
+// (mi_tree_walk numbers them).  The window: MI_COMMIT_WINDOW_MB, or half of what the batch's arena could be grown to before it
+// failed, at least 64 MiB; a single file larger than the window is tried alone.
+static int commit_roots_by_windows(mi_memfs* m, mi_batch* b, const mi_tree_entry* walked, uint64_t n, std::vector<uint8_t>* roots) {
+    uint64_t window = 0;
+    if (const char* e = getenv("MI_COMMIT_WINDOW_MB")) window = (uint64_t)atol(e) << 20;
+    if (!window) {
+        uint64_t room = 0;
+        mi_batch_arena_room(b, &room);
+        window = room / 2;
+    }
+    if (window < (64ull << 20) && !getenv("MI_COMMIT_WINDOW_MB")) window = 64ull << 20;
+    uint64_t n_files = 0;
+    for (uint64_t i = 0; i < n; ++i) if (walked[i].kind == 1 && walked[i].file_index >= 0) ++n_files;
+    roots->assign(n_files * 32, 0);
+    const std::string& root = m->fs.root;
+    std::vector<std::string> paths;
+    std::vector<const char*> cpaths;
+    std::vector<uint64_t> sizes, ordinals;
+    uint64_t held = 0;
+    auto flush = [&]() -> int {
+        if (paths.empty()) return MI_OK;
+        cpaths.resize(paths.size());
+        for (size_t k = 0; k < paths.size(); ++k) cpaths[k] = paths[k].c_str();
+        int rc = mi_batch_reset(b);
+        if (!rc) rc = mi_batch_add_paths(b, paths.size(), cpaths.data(), sizes.data(), nullptr);
+        if (!rc) rc = mi_batch_run(b);
+        std::vector<uint8_t> r(paths.size() * 32);
+        if (!rc) rc = mi_batch_roots(b, r.data(), paths.size());
+        if (!rc) {
+            uint64_t nc = 0;
+            mi_batch_counts(b, nullptr, &nc, nullptr);
+            m->last.n_chunks += nc;
+            for (size_t k = 0; k < paths.size(); ++k) memcpy(roots->data() + ordinals[k] * 32, r.data() + k * 32, 32);
+            ++m->last.n_windows;
+        }
+        paths.clear(); sizes.clear(); ordinals.clear();
+        held = 0;
+        return rc;
+    };
+    for (uint64_t i = 0; i < n; ++i) {
+        const mi_tree_entry& e = walked[i];
+        if (e.kind != 1 || e.file_index < 0) continue;
+        if (held && held + e.size > window) { const int rc = flush(); if (rc) return rc; }
+        paths.push_back(root == "/" ? "/" + std::string(e.relpath) : root + "/" + e.relpath);
+        sizes.push_back(e.size);
+        ordinals.push_back((uint64_t)e.file_index);
+        held += e.size;
+        m->last.n_scanned_files += 1;
+        m->last.scanned_bytes += e.size;
+    }
+    return flush();
+}
+
 extern "C" int mi_memfs_commit_layer(mi_memfs* m, mi_ctx* ctx, int must_scan, const mi_copy_op* ops, uint64_t n_ops,
                                      const mi_layer_config* cfg, mi_layer_result* res, mi_copy_layer** layer_out,
                                      int* committed) {
@@ -1696,8 +1752,11 @@ extern "C" int mi_memfs_commit_layer(mi_memfs* m, mi_ctx* ctx, int must_scan, co
     // and an unchanged header); an all-new layer, a first content scan, a COPY of new files never wait, and their commit
     // costs what the reference's costs: the serial TarDigest.  Roots that were only to be RECORDED are filled in at the end.
     static const bool pipeline_on = [] { const char* e = getenv("MI_COMMIT_PIPELINE"); return !(e && *e == '0'); }();
+    static const bool force_windows = [] { const char* e = getenv("MI_COMMIT_FORCE_WINDOWS"); return e && *e == '1'; }();   // (tests: as if the
+                                                                                                                            //  tree did not fit)
     mi_copy::ScanJob job;
     bool piped = false;
+    bool windowed = false;                                                        // a scanned tree that does not fit the device
     std::vector<uint8_t> roots;
     auto start_scan = [&]() -> int {                                              // scan what has been staged
         uint64_t nf = 0, nbytes = 0;
@@ -1738,6 +1797,7 @@ extern "C" int mi_memfs_commit_layer(mi_memfs* m, mi_ctx* ctx, int must_scan, co
         std::vector<mi_tree_entry> walked;
         mi_tree* t = nullptr;
         const mi_walk::Tree* wt = nullptr;
+        mi_walk::Tree listing;                                                    // the walk of a tree that is scanned in windows
         if (b) {
             struct timespec now;
             clock_gettime(CLOCK_REALTIME, &now);
@@ -1749,15 +1809,43 @@ extern "C" int mi_memfs_commit_layer(mi_memfs* m, mi_ctx* ctx, int must_scan, co
                 rc = mi_walk::scan_walk_batch_filtered(b, fs.root, m->blacklist,
                         [&fs](const std::string& path, uint64_t size, const mi_walk::InodeStamp& st) { return fs.content_is_known(path, size, st); },
                         &wtree, &werr);
-                if (rc) return fail_with(rc, "walk " + fs.root + ": " + (werr.empty() ? mi_last_error(ctx) : werr));
-                n = wtree->entries.size();
-            } else {
+                if (rc && rc != MI_ERR_NOMEM) return fail_with(rc, "walk " + fs.root + ": " + (werr.empty() ? mi_last_error(ctx) : werr));
+                if (!rc) n = wtree->entries.size();
+            } else if (m->went_windowed || force_windows) {
+                rc = MI_ERR_NOMEM;                                                // (it did not fit last time and everything is read again:
+            } else {                                                              //  straight to the windows)
                 rc = mi_batch_add_tree(b, fs.root.c_str(), fs.root.c_str(), bl.empty() ? nullptr : bl.data(), bl.size(), MI_TREE_SCAN, &n);
-                if (rc) return fail_with(rc, "walk " + fs.root + ": " + mi_last_error(ctx));
+                if (rc && rc != MI_ERR_NOMEM) return fail_with(rc, "walk " + fs.root + ": " + mi_last_error(ctx));
             }
-            wt = (const mi_walk::Tree*)*mi_batch_tree_slot(b);
-            walked.resize(n ? n : 1);
-            rc = mi_batch_tree_entries(b, walked.data(), n);
+            if (rc == MI_ERR_NOMEM) {
+                m->went_windowed = true;
+                // THE TREE DOES NOT FIT THE DEVICE.  The roots are computed window by window -- the walk once more, without a
+                // batch; its regular files through the batch in runs the device has room for -- and the layer's files are
+                // read from disk by the writer: a second read for those, the price of a tree larger than HBM.
+                windowed = true;
+                (void)mi_batch_reset(b);
+                std::string werr;
+                rc = mi_walk::scan_walk_listing(fs.root, m->blacklist, &listing, &werr);
+                if (rc) return fail_with(rc, "walk " + fs.root + ": " + werr);
+                n = listing.entries.size();
+                walked.resize(n ? n : 1);
+                for (uint64_t i = 0; i < n; ++i) {                                // (mi_tree_entries' rows of the same record)
+                    const mi_walk::Entry& e = listing.entries[i];
+                    mi_tree_entry& o = walked[i];
+                    memset(&o, 0, sizeof o);
+                    o.relpath = e.relpath.c_str();
+                    o.link_target = e.has_link ? e.link.c_str() : nullptr;
+                    o.file_index = e.file_index; o.size = e.size; o.mtime_sec = e.mtime; o.mode = e.mode; o.kind = e.kind;
+                    o.uid = e.uid; o.gid = e.gid;
+                }
+                wt = &listing;                                                    // (the inode stamps: a window's files are hashed files)
+                if ((rc = commit_roots_by_windows(m, b, walked.data(), n, &roots)))
+                    return fail_with(rc, std::string("gpu scan (in windows): ") + mi_last_error(ctx));
+            } else {
+                wt = (const mi_walk::Tree*)*mi_batch_tree_slot(b);
+                walked.resize(n ? n : 1);
+                rc = mi_batch_tree_entries(b, walked.data(), n);
+            }
         } else {
             rc = mi_tree_walk(fs.root.c_str(), fs.root.c_str(), bl.empty() ? nullptr : bl.data(), bl.size(), MI_TREE_SCAN, &t, &n);
             if (rc) return fail_with(rc, "walk " + fs.root);
@@ -1766,9 +1854,9 @@ extern "C" int mi_memfs_commit_layer(mi_memfs* m, mi_ctx* ctx, int must_scan, co
         }
         m->last.n_walked = n;
         m->last.s_walk_stage = secs_since(t0);
-        if (!rc && b && (rc = start_scan())) { if (t) mi_tree_free(t); return fail_with(rc, std::string("gpu scan: ") + mi_last_error(ctx)); }
+        if (!rc && b && !windowed && (rc = start_scan())) { if (t) mi_tree_free(t); return fail_with(rc, std::string("gpu scan: ") + mi_last_error(ctx)); }
         const auto t1 = std::chrono::steady_clock::now();
-        if (!rc) rc = memfs_scan(m, walked.data(), n, roots.empty() ? nullptr : roots.data(), 32, b != nullptr, &cl, &ne, wt);
+        if (!rc) rc = memfs_scan(m, walked.data(), n, roots.empty() ? nullptr : roots.data(), 32, b != nullptr && !windowed, &cl, &ne, wt);
         m->last.s_diff = secs_since(t1);
         m->last.n_content_trusted = fs.n_content_trusted.load();
         if (t) mi_tree_free(t);
@@ -1800,7 +1888,7 @@ extern "C" int mi_memfs_commit_layer(mi_memfs* m, mi_ctx* ctx, int must_scan, co
     m->last.n_roots_learned = fs.n_roots_learned;
     const auto t2 = std::chrono::steady_clock::now();
     const bool was_piped = piped;
-    rc = memfs_commit_write(m, cl, ne, cfg, res, b, piped);
+    rc = memfs_commit_write(m, cl, ne, cfg, res, windowed ? nullptr : b, piped);
     m->last.s_write = secs_since(t2);
     {   // the scan's verdict: a file that vanished or shrank since the walk fails the commit here -- after the tree took the
         // layer, as a failing tar write does in the reference (AddLayerByScan updates the tree, then writes)

@@ -883,6 +883,21 @@ int scan_walk_collect_batch(const std::string& src, const std::string& link_root
     return w.rc;
 }
 
+int scan_walk_listing(const std::string& root, const std::vector<std::string>& blacklist, Tree* out, std::string* err) {
+    out->want_stamps = true;
+    Walker w;
+    w.batch = nullptr;
+    w.rel_base = root;
+    w.mode = MI_TREE_SCAN;
+    w.tree = out;
+    w.blacklist = blacklist;
+    std::string r = root;
+    while (r.size() > 1 && r.back() == '/') r.pop_back();
+    walk_root(&w, r);
+    if (w.rc && err) *err = w.err;
+    return w.rc;
+}
+
 int scan_walk_batch_filtered(mi_batch* b, const std::string& root, const std::vector<std::string>& blacklist,
                              const std::function<bool(const std::string&, uint64_t, const InodeStamp&)>& known, Tree** tree_out,
                              std::string* err) {

@@ -217,7 +217,54 @@ def scenario_slash(tmp, eng):
     print("OK slash")
 
 
+def scenario_oversize(tmp, eng):
+    """a tree larger than the device (the double refuses large allocations: MI_HIP_STUB_MALLOC_LIMIT_MB): the commit does not
+    fail -- the roots come window by window, the writer reads the layer's files from disk; the tar is the reference's"""
+    root = os.path.join(tmp, "over_root")
+    rng = np.random.default_rng(9)
+    files = {}
+    for d in range(6):
+        for k in range(12):
+            rel = "o%d/f%02d" % (d, k)
+            size = int(rng.integers(0, 30_000)) if k % 4 else int(rng.integers(300_000, 1_200_000))
+            data = rng.integers(0, 256, size, dtype=np.uint8).tobytes()
+            write_file(os.path.join(root, rel), data, 0o644, MTIME)
+            files[rel] = data
+    total = sum(map(len, files.values()))
+    assert total > 9 << 20
+    with M.MemFS(root) as fs, M.MemFS(root) as plain:
+        if os.environ.get("MI_TEST_TRUST"):
+            fs.set_options(trust_ctime=True)
+        res, raw = commit_to_bytes(fs, tmp, "o0.tar", must_scan=True, engine=eng)
+        st = res["stats"]
+        assert st["n_windows"] >= 4 and st["pipelined"] == 0, st
+        assert st["n_scanned_files"] == len(files) and st["scanned_bytes"] == total
+        assert {n: d for n, m, d in tar_members(raw) if m.isfile()} == files
+        _, raw0 = commit_to_bytes(plain, tmp, "o0p.tar", must_scan=True)
+        assert raw == raw0
+        assert 2 * total <= st["file_bytes_read"] <= 3 * total            # once for the roots, once for the tar (the price) -- and
+                                                                          # what the first attempt had read when it ran out of room
+        assert fs.root_of("/o0/f01") is not None
+        res, raw = commit_to_bytes(fs, tmp, "o1.tar", must_scan=True, engine=eng)
+        assert res["n_entries"] == 0 and res["stats"]["n_windows"] >= 4 and total <= res["stats"]["file_bytes_read"] <= 2 * total
+        if not os.environ.get("MI_TEST_TRUST"):
+            assert res["stats"]["file_bytes_read"] == total               # (no second attempt at one batch: straight to the windows)
+        else:
+            import time
+            time.sleep(0.06)                                              # a window's files were hashed files: their inodes are on record --
+            r3 = fs.commit_layer(must_scan=True, engine=eng, gzip_level=M.GZIP_OFF)   # the next commit trusts them and fits
+            assert r3["n_entries"] == 0 and r3["stats"]["n_windows"] == 0 and r3["stats"]["files_opened"] == 0, r3["stats"]
+        write_file(os.path.join(root, "o3/f05"), b"new" * 1000, 0o644, MTIME + 3)
+        res, raw = commit_to_bytes(fs, tmp, "o2.tar", must_scan=True, engine=eng)
+        assert [(n, d) for n, m, d in tar_members(raw) if m.isfile()] == [("o3/f05", b"new" * 1000)]
+    print("OK oversize")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 3 and sys.argv[3] == "oversize":
+        with M.Engine(n_streams=int(sys.argv[2]), staging_bytes=1 << 20) as eng:
+            scenario_oversize(sys.argv[1], eng)
+        sys.exit(0)
     tmp, threads = sys.argv[1], int(sys.argv[2])
     with M.Engine(n_streams=threads, staging_bytes=1 << 20) as eng:
         scenario_scan(tmp, eng)

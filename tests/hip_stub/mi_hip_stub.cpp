@@ -18,6 +18,7 @@
 //   * kernels do not run: a launch is a queued no-op (device results stay 0xDD).  MI_HIP_STUB_KERNEL_US=<n> makes each
 //     launch take n microseconds of stream time, to move the interleavings;
 //   * MI_HIP_STUB_COPY_US=<n>: every queued copy sleeps n microseconds before it copies (widens race windows).
+//   * MI_HIP_STUB_MALLOC_LIMIT_MB=<n>: hipMalloc of more than n MiB fails with hipErrorOutOfMemory (a tree larger than the device).
 #include <hip/hip_runtime_api.h>
 
 #include <stdint.h>
@@ -134,6 +135,8 @@ const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error
 hipError_t hipGetLastError(void) { return hipSuccess; }
 
 hipError_t hipMalloc(void** p, size_t n) {
+    static const long limit_mb = env_us("MI_HIP_STUB_MALLOC_LIMIT_MB");           // a device with little memory: larger requests fail
+    if (limit_mb > 0 && n > ((size_t)limit_mb << 20)) return hipErrorOutOfMemory;
     void* q = aligned_alloc(4096, (n + 4095) / 4096 * 4096 + 4096);
     if (!q) return hipErrorOutOfMemory;
     memset(q, 0xDD, n);

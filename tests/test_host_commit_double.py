@@ -38,3 +38,17 @@ def test_whichever_way_the_bytes_reach_the_arena(hip_double, tmp_path, env):  # 
     runs far ahead of the staging it reads from (the pipelined commit: a file's bytes are waited for); MI_COMMIT_PIPELINE=0 is
     the commit one phase after the other"""
     _run(hip_double, tmp_path, 4, env)
+
+
+@pytest.mark.parametrize("trust", [False, True])
+def test_a_tree_larger_than_the_device_is_scanned_in_windows(hip_double, tmp_path, trust):  # noqa: F811
+    """the double refuses allocations above 6 MiB: a 9+ MB tree cannot be staged in one batch -- mi_memfs_commit_layer falls back to
+    windows (MI_COMMIT_WINDOW_MB=2) for the roots and to the disk for the tar; with MI_MEMFS_TRUST_CTIME the walk that runs into the
+    limit is the filtered one"""
+    env = dict(os.environ, LD_PRELOAD=(os.environ.get("LD_PRELOAD", "") + " " + hip_double).strip(), MI_HIP_STUB_MALLOC_LIMIT_MB="6",
+               MI_COMMIT_WINDOW_MB="2")
+    if trust:
+        env["MI_TEST_TRUST"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(STUB_DIR, "commit_scenarios.py"), str(tmp_path), "4", "oversize"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "OK oversize" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
