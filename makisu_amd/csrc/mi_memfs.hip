@@ -1841,6 +1841,7 @@ extern "C" int mi_memfs_commit_layer(mi_memfs* m, mi_ctx* ctx, int must_scan, co
                 wt = &listing;                                                    // (the inode stamps: a window's files are hashed files)
                 if ((rc = commit_roots_by_windows(m, b, walked.data(), n, &roots)))
                     return fail_with(rc, std::string("gpu scan (in windows): ") + mi_last_error(ctx));
+                if (m->last.n_windows <= 1) m->went_windowed = false;             // (it has shrunk to one window's worth: one batch next time)
             } else {
                 wt = (const mi_walk::Tree*)*mi_batch_tree_slot(b);
                 walked.resize(n ? n : 1);
