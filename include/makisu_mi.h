@@ -726,7 +726,7 @@ void mi_layer_free(mi_layer* layer);
  * `ctx`: free the handle, or call mi_memfs_release_device, before mi_ctx_destroy.  A scanned tree larger than the device's
  * free memory is not refused: its roots are computed in windows (runs of files the device has room for; MI_COMMIT_WINDOW_MB)
  * and the writer reads the layer's files from disk -- a second read for those, mi_commit_stats.n_windows says so; copy ops
- * whose sources do not fit fail with MI_ERR_NOMEM and leave the tree as it was.  mi_memfs_commit_stats: what the last
+ * whose sources do not fit go the same way (planned again without a batch).  mi_memfs_commit_stats: what the last
  * commit did.                                                                                                            */
 typedef struct {
     uint64_t n_walked;           /* paths the walk(s) listed                                                    */

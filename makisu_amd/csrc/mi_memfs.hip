@@ -1664,10 +1664,12 @@ static int memfs_commit_write(mi_memfs* m, mi_copy_layer* cl, uint64_t ne, const
 }
 
 // A tree that does not fit the device: the chunk roots of its regular files, computed in WINDOWS -- runs of files (walk order) the
-// batch has room for; each window is staged, scanned and forgotten.  roots: 32 bytes per regular file, by the walk's file ordinal
-// (mi_tree_walk numbers them).  The window: MI_COMMIT_WINDOW_MB, or half of what the batch's arena could be grown to before it
-// failed, at least 64 MiB; a single file larger than the window is tried alone.
-static int commit_roots_by_windows(mi_memfs* m, mi_batch* b, const mi_tree_entry* walked, uint64_t n, std::vector<uint8_t>* roots) {
+// batch has room for; each window is staged, scanned and forgotten.  roots: 32 bytes per regular file, by the file's ordinal
+// (a scanned tree: mi_tree_walk's numbering; COPY sources: numbered across the ops' walks).  The window: MI_COMMIT_WINDOW_MB, or
+// half of what the batch's arena could be grown to before it failed, at least 64 MiB; a single file larger than the window is
+// tried alone.
+struct WindowFile { std::string path; uint64_t size, ordinal; };
+static int commit_roots_by_windows(mi_memfs* m, mi_batch* b, const std::vector<WindowFile>& files, std::vector<uint8_t>* roots) {
     uint64_t window = 0;
     if (const char* e = getenv("MI_COMMIT_WINDOW_MB")) window = (uint64_t)atol(e) << 20;
     if (!window) {
@@ -1676,46 +1678,36 @@ static int commit_roots_by_windows(mi_memfs* m, mi_batch* b, const mi_tree_entry
         window = room / 2;
     }
     if (window < (64ull << 20) && !getenv("MI_COMMIT_WINDOW_MB")) window = 64ull << 20;
-    uint64_t n_files = 0;
-    for (uint64_t i = 0; i < n; ++i) if (walked[i].kind == 1 && walked[i].file_index >= 0) ++n_files;
-    roots->assign(n_files * 32, 0);
-    const std::string& root = m->fs.root;
-    std::vector<std::string> paths;
+    roots->assign(files.size() * 32, 0);
     std::vector<const char*> cpaths;
-    std::vector<uint64_t> sizes, ordinals;
-    uint64_t held = 0;
-    auto flush = [&]() -> int {
-        if (paths.empty()) return MI_OK;
-        cpaths.resize(paths.size());
-        for (size_t k = 0; k < paths.size(); ++k) cpaths[k] = paths[k].c_str();
+    std::vector<uint64_t> sizes;
+    auto run = [&](size_t lo, size_t hi) -> int {
+        if (lo == hi) return MI_OK;
+        cpaths.clear(); sizes.clear();
+        for (size_t k = lo; k < hi; ++k) { cpaths.push_back(files[k].path.c_str()); sizes.push_back(files[k].size); }
         int rc = mi_batch_reset(b);
-        if (!rc) rc = mi_batch_add_paths(b, paths.size(), cpaths.data(), sizes.data(), nullptr);
+        if (!rc) rc = mi_batch_add_paths(b, hi - lo, cpaths.data(), sizes.data(), nullptr);
         if (!rc) rc = mi_batch_run(b);
-        std::vector<uint8_t> r(paths.size() * 32);
-        if (!rc) rc = mi_batch_roots(b, r.data(), paths.size());
+        std::vector<uint8_t> r((hi - lo) * 32);
+        if (!rc) rc = mi_batch_roots(b, r.data(), hi - lo);
         if (!rc) {
             uint64_t nc = 0;
             mi_batch_counts(b, nullptr, &nc, nullptr);
             m->last.n_chunks += nc;
-            for (size_t k = 0; k < paths.size(); ++k) memcpy(roots->data() + ordinals[k] * 32, r.data() + k * 32, 32);
+            for (size_t k = lo; k < hi; ++k) memcpy(roots->data() + files[k].ordinal * 32, r.data() + (k - lo) * 32, 32);
             ++m->last.n_windows;
         }
-        paths.clear(); sizes.clear(); ordinals.clear();
-        held = 0;
         return rc;
     };
-    for (uint64_t i = 0; i < n; ++i) {
-        const mi_tree_entry& e = walked[i];
-        if (e.kind != 1 || e.file_index < 0) continue;
-        if (held && held + e.size > window) { const int rc = flush(); if (rc) return rc; }
-        paths.push_back(root == "/" ? "/" + std::string(e.relpath) : root + "/" + e.relpath);
-        sizes.push_back(e.size);
-        ordinals.push_back((uint64_t)e.file_index);
-        held += e.size;
+    size_t lo = 0;
+    uint64_t held = 0;
+    for (size_t i = 0; i < files.size(); ++i) {
+        if (held && held + files[i].size > window) { const int rc = run(lo, i); if (rc) return rc; lo = i; held = 0; }
+        held += files[i].size;
         m->last.n_scanned_files += 1;
-        m->last.scanned_bytes += e.size;
+        m->last.scanned_bytes += files[i].size;
     }
-    return flush();
+    return run(lo, files.size());
 }
 
 extern "C" int mi_memfs_commit_layer(mi_memfs* m, mi_ctx* ctx, int must_scan, const mi_copy_op* ops, uint64_t n_ops,
@@ -1839,7 +1831,12 @@ extern "C" int mi_memfs_commit_layer(mi_memfs* m, mi_ctx* ctx, int must_scan, co
                     o.uid = e.uid; o.gid = e.gid;
                 }
                 wt = &listing;                                                    // (the inode stamps: a window's files are hashed files)
-                if ((rc = commit_roots_by_windows(m, b, walked.data(), n, &roots)))
+                std::vector<WindowFile> wf;
+                for (uint64_t i = 0; i < n; ++i)
+                    if (walked[i].kind == 1 && walked[i].file_index >= 0)
+                        wf.push_back({fs.root == "/" ? "/" + std::string(walked[i].relpath) : fs.root + "/" + walked[i].relpath,
+                                      walked[i].size, (uint64_t)walked[i].file_index});
+                if ((rc = commit_roots_by_windows(m, b, wf, &roots)))
                     return fail_with(rc, std::string("gpu scan (in windows): ") + mi_last_error(ctx));
                 if (m->last.n_windows <= 1) m->went_windowed = false;             // (it has shrunk to one window's worth: one batch next time)
             } else {
@@ -1866,12 +1863,30 @@ extern "C" int mi_memfs_commit_layer(mi_memfs* m, mi_ctx* ctx, int must_scan, co
         fs.clear_layer();
         CopyPlan plan;
         const auto t0 = std::chrono::steady_clock::now();
-        copy_ops_plan(fs, ops, n_ops, b, &plan);
+        if (!(b && force_windows)) copy_ops_plan(fs, ops, n_ops, b, &plan);
+        if (b && (force_windows || plan.err_rc == MI_ERR_NOMEM)) {
+            // THE SOURCES DO NOT FIT THE DEVICE: planned again without a batch (the walks alone), the files numbered across the
+            // ops' walks, their roots window by window; the writer reads the layer's files from disk
+            windowed = true;
+            (void)mi_batch_reset(b);
+            plan = CopyPlan();
+            copy_ops_plan(fs, ops, n_ops, nullptr, &plan);
+            std::vector<WindowFile> wf;
+            for (CopyOpPlan& op : plan.ops)
+                for (CopySrcPlan& sp : op.srcs)
+                    for (mi_walk::Entry& we : sp.walked.entries)
+                        if (we.kind == 1 && we.file_index >= 0) {
+                            we.file_index = (int64_t)wf.size();
+                            wf.push_back({we.relpath == "." ? sp.src : sp.src + "/" + we.relpath, we.size, (uint64_t)we.file_index});
+                        }
+            if ((rc = commit_roots_by_windows(m, b, wf, &roots)))
+                return fail_with(rc, std::string("gpu scan (in windows): ") + mi_last_error(ctx));
+        }
         m->last.n_walked = plan.n_walked;
         m->last.s_walk_stage = secs_since(t0);
         // (a plan that stopped at a failure is applied up to it: the failure is the apply step's to raise, in its place.
         //  What was staged until then is scanned all the same -- the ops before the failing one are applied WITH roots.)
-        if (b && (rc = start_scan())) return fail_with(rc, std::string("gpu scan: ") + mi_last_error(ctx));
+        if (b && !windowed && (rc = start_scan())) return fail_with(rc, std::string("gpu scan: ") + mi_last_error(ctx));
         const auto t1 = std::chrono::steady_clock::now();
         std::string e;
         rc = copy_ops_apply(fs, ops, plan, roots.empty() ? nullptr : roots.data(), &e);

@@ -260,7 +260,60 @@ def scenario_oversize(tmp, eng):
     print("OK oversize")
 
 
+def scenario_oversize_copy(tmp, eng):
+    """COPY sources larger than the device (three ops, one source copied twice): planned again without a batch, the roots window by
+    window by the files' ordinals across the ops' walks, the tar's files from disk; the tar is the reference's, the tree holds
+    the roots (a later COPY of the same bytes with another mtime-less header is told by them: same second, other bytes)"""
+    src_root, root = os.path.join(tmp, "over_ctx"), os.path.join(tmp, "over_copy_root")
+    os.makedirs(root)
+    rng = np.random.default_rng(11)
+    files = {}
+    for d in ("a", "b"):
+        for k in range(14):
+            rel = "%s/f%02d" % (d, k)
+            size = int(rng.integers(0, 30_000)) if k % 3 else int(rng.integers(500_000, 1_300_000))
+            data = rng.integers(0, 256, size, dtype=np.uint8).tobytes()
+            write_file(os.path.join(src_root, rel), data, 0o644, MTIME)
+            files[rel] = data
+    total = sum(map(len, files.values()))
+    assert total > 7 << 20
+    ops = [{"src_root": src_root, "srcs": ["a"], "dst": "/one/"},
+           {"src_root": src_root, "srcs": ["b", "a/f00"], "dst": "/two/", "uid": 3, "gid": 4},
+           {"src_root": src_root, "srcs": ["a/f03"], "dst": "/three/file"}]
+    with M.MemFS(root, now_sec=MTIME) as fs, M.MemFS(root, now_sec=MTIME) as plain:
+        res, raw = commit_to_bytes(fs, tmp, "oc0.tar", ops=ops, engine=eng)
+        st = res["stats"]
+        assert st["n_windows"] >= 3 and st["pipelined"] == 0, st
+        assert st["n_scanned_files"] == 14 + 14 + 1 + 1, st
+        _, raw0 = commit_to_bytes(plain, tmp, "oc0p.tar", ops=ops)
+        assert raw == raw0
+        mem = {n: d for n, m, d in tar_members(raw) if m.isfile()}
+        for k in range(14):
+            assert mem["one/f%02d" % k] == files["a/f%02d" % k] and mem["two/f%02d" % k if k else "two/f00"] in (files["b/f%02d" % k], files["a/f00"])
+        assert mem["three/file"] == files["a/f03"]
+        on_gpu = os.environ.get("MI_TEST_ON_GPU") == "1"                   # (the double launches no kernels: its roots are not roots)
+        if on_gpu:
+            from oracle import mi_oracle as O
+            O.build()
+            from commit_cases import oracle_root
+        for path, rel in (("/one/f05", "a/f05"), ("/two/f07", "b/f07"), ("/three/file", "a/f03")):
+            got = fs.root_of(path)
+            assert got is not None and (not on_gpu or got == oracle_root(O, files[rel])), path
+        if on_gpu:
+            # the same second, the same size, other bytes: only the roots can tell
+            changed = bytearray(files["a/f06"]); changed[len(changed) // 2] ^= 0x40
+            write_file(os.path.join(src_root, "a/f06"), bytes(changed), 0o644, MTIME)
+            res, raw = commit_to_bytes(fs, tmp, "oc1.tar", ops=ops[:1], engine=eng)
+            assert [(n, d) for n, m, d in tar_members(raw) if m.isfile()] == [("one/f06", bytes(changed))], [n for n, m, d in tar_members(raw)]
+            assert res["stats"]["n_content_changed"] == 1 and res["stats"]["n_windows"] >= 2
+    print("OK oversize_copy")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 3 and sys.argv[3] == "oversize_copy":
+        with M.Engine(n_streams=int(sys.argv[2]), staging_bytes=1 << 20) as eng:
+            scenario_oversize_copy(sys.argv[1], eng)
+        sys.exit(0)
     if len(sys.argv) > 3 and sys.argv[3] == "oversize":
         with M.Engine(n_streams=int(sys.argv[2]), staging_bytes=1 << 20) as eng:
             scenario_oversize(sys.argv[1], eng)

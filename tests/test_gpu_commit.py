@@ -91,6 +91,16 @@ def test_commit_zero_whichever_way_the_bytes_reach_the_arena(env, tmp_path):
     assert p.returncode == 0 and "OK commit_zero" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
 
 
+def test_copy_sources_that_do_not_fit_the_device_window_by_window(tmp_path):
+    """COPY ops as if their sources did not fit the device (MI_COMMIT_FORCE_WINDOWS=1, 2 MiB windows): the plan is made without a
+    batch, the files numbered across the ops' walks, the roots computed in windows and = the oracle's; the tar = the header-only
+    commit's; a same-second, same-size rewrite of a source is told by its root (tests/hip_stub/commit_scenarios.py, on the GPU)"""
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hip_stub", "commit_scenarios.py")
+    env = dict(os.environ, MI_COMMIT_FORCE_WINDOWS="1", MI_COMMIT_WINDOW_MB="2", MI_TEST_ON_GPU="1")
+    p = subprocess.run([sys.executable, script, str(tmp_path), "4", "oversize_copy"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "OK oversize_copy" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
+
+
 def _rewrite_same_size_same_second(path, rng):
     st = os.stat(path)
     data = rng.integers(0, 256, st.st_size, dtype=np.uint8).tobytes()

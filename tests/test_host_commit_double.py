@@ -52,3 +52,13 @@ def test_a_tree_larger_than_the_device_is_scanned_in_windows(hip_double, tmp_pat
     p = subprocess.run([sys.executable, os.path.join(STUB_DIR, "commit_scenarios.py"), str(tmp_path), "4", "oversize"], env=env,
                        capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "OK oversize" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
+
+
+def test_copy_sources_larger_than_the_device_go_window_by_window(hip_double, tmp_path):  # noqa: F811
+    """the double refuses allocations above 6 MiB; three COPY ops whose sources hold 7+ MB: the plan runs out of room, is made again
+    without a batch, the roots come in windows (MI_COMMIT_WINDOW_MB=2) -- same tar as the header-only commit, roots in the tree"""
+    env = dict(os.environ, LD_PRELOAD=(os.environ.get("LD_PRELOAD", "") + " " + hip_double).strip(), MI_HIP_STUB_MALLOC_LIMIT_MB="6",
+               MI_COMMIT_WINDOW_MB="2")
+    p = subprocess.run([sys.executable, os.path.join(STUB_DIR, "commit_scenarios.py"), str(tmp_path), "4", "oversize_copy"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "OK oversize_copy" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
