@@ -1,7 +1,8 @@
 """A soak of the content-aware commit on the GPU: tests/test_gpu_commit.py's replay property (a seeded sequence of steps -- new files,
 deletions, same-size same-second rewrites, a symlink retargeted -- committed with a ctx, the layers stacked again: every byte and every
 root must be right after every step) over many seeds, alternately pipelined / phase by phase is a process-wide setting, so: one process
-per mode.  usage: commit_soak.py [first seed = 100] [seeds = 40]      (MI_COMMIT_PIPELINE=0 for the other mode)"""
+per mode.  usage: commit_soak.py [first seed = 100] [seeds = 40]      (MI_COMMIT_PIPELINE=0 for the other mode; MI_SOAK_TRUST=1: the
+handle with MI_MEMFS_TRUST_CTIME; MI_COMMIT_FORCE_WINDOWS=1 MI_COMMIT_WINDOW_MB=1: as if the tree did not fit the device)"""
 import os
 import sys
 import tempfile
@@ -32,8 +33,8 @@ def main():
                 ok += 1
             finally:
                 shutil.rmtree(tmp, ignore_errors=True)
-    print("commit soak: %d of %d seeds replayed to the tree, bytes and roots (MI_COMMIT_PIPELINE=%s)" %
-          (ok, n, os.environ.get("MI_COMMIT_PIPELINE", "1")))
+    print("commit soak: %d of %d seeds replayed to the tree, bytes and roots (MI_COMMIT_PIPELINE=%s, trust_ctime=%s, forced windows=%s)" %
+          (ok, n, os.environ.get("MI_COMMIT_PIPELINE", "1"), os.environ.get("MI_SOAK_TRUST", "0"), os.environ.get("MI_COMMIT_FORCE_WINDOWS", "0")))
 
 
 if __name__ == "__main__":
