@@ -106,9 +106,9 @@ def main():
         print("  " + row["what"])
         for side in ("gpu", "gpu_trust_ctime", "cpu_header_only"):
             r = row[side]
-            print("    %-16s %7.3f s = walk%s %.3f + diff %.3f + tar %.3f; scan %.3f%s | layer: %d entries, %d files, %d tar bytes | "
+            print("    %-16s %7.3f s (the C call %.3f) = walk%s %.3f + diff %.3f + tar %.3f; scan %.3f%s | layer: %d entries, %d files, %d tar bytes | "
                   "read %d files, %d bytes (%d trusted) | content-only changes %d" %
-                  (side, r["s_total"], "+stage" if side.startswith("gpu") else "", r["s_walk_stage"], r["s_diff"], r["s_write"], r["s_scan"],
+                  (side, r["s_total"], r["s_call"], "+stage" if side.startswith("gpu") else "", r["s_walk_stage"], r["s_diff"], r["s_write"], r["s_scan"],
                    " (beside diff and tar)" if r["scan_overlapped"] else "",
                    r["layer_entries"], r["layer_files"], r["tar_bytes"], r["files_read"], r["bytes_read"], r["files_trusted"], r["content_only_changes"]))
 
