@@ -289,9 +289,9 @@ struct Fs {
         hashed[(size_t)ref].stamp = st;
         hashed[(size_t)ref].at_ns = commit_started_ns;
     }
+    const uint64_t id = [] { static std::atomic<uint64_t> n{0}; return ++n; }();    // (a handle's number: never given twice)
     bool trust_ctime = false;                                                   // mi_memfs_set_options(MI_MEMFS_TRUST_CTIME)
     int64_t commit_started_ns = 0;                                              // CLOCK_REALTIME when the commit under way began its walk
-    std::atomic<uint64_t> n_content_trusted{0};                                 // files of this commit that were not read again
     // "is the content of the regular file at `disk_path` known?" -- asked by the walk's directory readers, several at a time,
     // while nothing changes the tree (the diff runs after the walk).  Known = the tree holds the path with a root that was
     // computed from THIS inode in THIS state: same device, inode, size, mtime and ctime to the nanosecond -- and the ctime lies
@@ -301,7 +301,37 @@ struct Fs {
         static const int64_t slack_ns = [] { const char* e = getenv("MI_TRUST_CTIME_SLACK_MS"); return (int64_t)(e && *e ? atol(e) : 20) * 1000000ll; }();
         const size_t root_len = root == "/" ? 0 : root.size();
         if (disk_path.size() <= root_len || memcmp(disk_path.data(), root.data(), root_len) != 0) return false;
-        const mi_memtree::Node* nd = t.find_walk(disk_path.substr(root_len));     // (find_walk keeps no cache: safe from many threads)
+        // A directory reader asks about ONE directory's files, in name order -- the order of the node's children map.  So the
+        // directory's node and a position among its children are kept PER THREAD (the tree's own kept parent belongs to the
+        // committing thread): the next file is the next child, or a few steps on -- not a walk from the root and a search among
+        // thousands of siblings whose map nodes no cache holds (2.4 us per file, summed over the readers, before; the walk of a
+        // million trusted files cost 0.12 s more than the plain walk).  Nothing changes the tree while the walk runs.
+        using Kids = decltype(mi_memtree::Node::children);
+        struct DirMemo { uint64_t fs_id = 0, gen = 0; std::string dir; const mi_memtree::Node* node = nullptr; Kids::const_iterator at; };
+        static thread_local DirMemo memo;
+        const size_t cut = disk_path.find_last_of('/');
+        const mi_memtree::Node* nd = nullptr;
+        if (cut != std::string::npos && cut >= root_len && cut + 1 < disk_path.size()) {
+            const size_t dir_len = cut - root_len;                                // the directory below the root ("" = the root itself)
+            if (!(memo.fs_id == id && memo.gen == t.gen && memo.dir.size() == dir_len &&
+                  memcmp(memo.dir.data(), disk_path.data() + root_len, dir_len) == 0)) {
+                memo.dir.assign(disk_path, root_len, dir_len);
+                memo.node = t.find_walk(memo.dir);                                // (find_walk keeps no cache: safe from many threads)
+                memo.fs_id = id;
+                memo.gen = t.gen;
+                if (memo.node) memo.at = memo.node->children.begin();
+            }
+            if (memo.node) {
+                const std::string_view name(disk_path.data() + cut + 1, disk_path.size() - cut - 1);
+                const Kids& kids = memo.node->children;
+                int steps = 0;
+                while (memo.at != kids.end() && steps < 8 && std::string_view(memo.at->first) < name) { ++memo.at; ++steps; }
+                if (memo.at == kids.end() || std::string_view(memo.at->first) != name) memo.at = kids.lower_bound(name);
+                if (memo.at != kids.end() && std::string_view(memo.at->first) == name) { nd = memo.at->second.get(); ++memo.at; }
+            }
+        } else {
+            nd = t.find_walk(disk_path.substr(root_len));
+        }
         if (!nd || nd->ref < 0) return false;
         const Node& x = nodes[(size_t)nd->ref];
         if (x.e.kind != 1 || !x.has_root || x.root_pending || x.e.size != size || (size_t)nd->ref >= hashed.size()) return false;
@@ -314,8 +344,9 @@ struct Fs {
                                                                                  //  newer than our read.  The equality is what holds
                                                                                  //  when the clock was set back in between.)  Racily
                                                                                  //  clean: read it again
-        n_content_trusted.fetch_add(1, std::memory_order_relaxed);
-        return true;
+        return true;                                                             // (counted after the walk, from its record: a
+                                                                                 //  shared counter here is a cache line sixteen
+                                                                                 //  directory readers fight over)
     }
     ScanJob* job = nullptr;                                                     // a pipelined commit's scan (else roots come ready)
     std::vector<int64_t> pending_refs;                                          // nodes whose root[] is filled in when it ends
@@ -1794,7 +1825,6 @@ extern "C" int mi_memfs_commit_layer(mi_memfs* m, mi_ctx* ctx, int must_scan, co
             struct timespec now;
             clock_gettime(CLOCK_REALTIME, &now);
             fs.commit_started_ns = (int64_t)now.tv_sec * 1000000000ll + now.tv_nsec;
-            fs.n_content_trusted = 0;
             if (fs.trust_ctime) {                                                 // files whose inode says "unchanged" are not read
                 mi_walk::Tree* wtree = nullptr;
                 std::string werr;
@@ -1856,7 +1886,8 @@ extern "C" int mi_memfs_commit_layer(mi_memfs* m, mi_ctx* ctx, int must_scan, co
         const auto t1 = std::chrono::steady_clock::now();
         if (!rc) rc = memfs_scan(m, walked.data(), n, roots.empty() ? nullptr : roots.data(), 32, b != nullptr && !windowed, &cl, &ne, wt);
         m->last.s_diff = secs_since(t1);
-        m->last.n_content_trusted = fs.n_content_trusted.load();
+        if (wt && wt->want_stamps && fs.trust_ctime)                              // files the walk did not read: their content is known
+            for (size_t i = 0; i < wt->known.size() && i < n; ++i) m->last.n_content_trusted += wt->known[i] ? 1 : 0;
         if (t) mi_tree_free(t);
         if (rc) { end_scan(nullptr); return fail_with(rc, m->err); }
     } else {

@@ -180,6 +180,62 @@ def scenario_trust(tmp, eng):
     print("OK trust")
 
 
+def scenario_trust_wide(tmp, eng):
+    """MI_MEMFS_TRUST_CTIME on wide directories that change between commits: the predicate keeps, per directory reader, a place
+    among the directory's children in the tree and expects the next file to be the next child.  So: files deleted in runs (more
+    than the few steps it walks), new names before, between and after the old ones, a directory that was a file, two handles
+    committing in turn (each has its own tree) -- every commit reads exactly the files that are new or changed"""
+    import time
+    rng = np.random.default_rng(77)
+    root = os.path.join(tmp, "wide_root")
+    files = {}
+    for d in ("w0", "w1", "w2/inner"):
+        for k in range(0, 400, 2):                                            # even numbers: room between the names
+            rel = "%s/f%04d" % (d, k)
+            files[rel] = rng.integers(0, 256, int(rng.integers(1, 600)), dtype=np.uint8).tobytes()
+            write_file(os.path.join(root, rel), files[rel], 0o644, MTIME)
+    time.sleep(0.06)
+    with M.MemFS(root) as a, M.MemFS(root) as b:
+        for fs in (a, b):
+            fs.set_options(trust_ctime=True)
+            r = fs.commit_layer(must_scan=True, engine=eng, gzip_level=M.GZIP_OFF)
+            assert r["stats"]["files_opened"] == len(files) and r["stats"]["n_content_trusted"] == 0
+        for step in range(4):
+            touched = set()
+            live = sorted(files)
+            lo = int(rng.integers(0, len(live) - 40))
+            for rel in live[lo:lo + 30]:                                      # a run of deletions
+                os.unlink(os.path.join(root, rel))
+                files.pop(rel)
+            for d in ("w0", "w1", "w2/inner"):
+                for name in ("a_first_%d" % step, "f%04d" % (2 * int(rng.integers(0, 200)) + 1), "f%04d_x%d" % (2 * int(rng.integers(0, 200)), step),
+                             "zz_last_%d" % step):
+                    rel = d + "/" + name
+                    files[rel] = rng.integers(0, 256, int(rng.integers(1, 600)), dtype=np.uint8).tobytes()
+                    write_file(os.path.join(root, rel), files[rel], 0o644, MTIME + step)
+                    touched.add(rel)
+            rewritten = set()
+            for rel in rng.choice(sorted(set(files) - touched), size=7, replace=False):   # rewrites that keep size and mtime
+                rel = str(rel)
+                rewritten.add(rel)
+                pth = os.path.join(root, rel)
+                sb = os.stat(pth)
+                files[rel] = bytes(x ^ 0x5A for x in files[rel])
+                with open(pth, "r+b") as f:
+                    f.write(files[rel])
+                os.utime(pth, ns=(sb.st_atime_ns, sb.st_mtime_ns))
+                touched.add(rel)
+            time.sleep(0.06)
+            for fs in ((a, b) if step % 2 else (b, a)):
+                res, raw = commit_to_bytes(fs, tmp, "w%d.tar" % step, must_scan=True, engine=eng)
+                st = res["stats"]
+                assert st["files_opened"] == len(touched) and st["n_content_trusted"] == len(files) - len(touched), (step, st, len(touched))
+                got = {n: d for n, m, d in tar_members(raw) if m.isfile() and not os.path.basename(n).startswith(".wh.")}
+                in_layer = touched if os.environ.get("MI_TEST_ON_GPU") == "1" else touched - rewritten   # (the double's roots are all
+                assert got == {rel: files[rel] for rel in in_layer}, (step, sorted(set(got) ^ in_layer)[:5])  #  alike: read, not told apart)
+    print("OK trust_wide")
+
+
 def scenario_slash(tmp, eng):
     """the root of every real build is "/": the same commit with the handle rooted there (a node's source IS its path, nothing is
     trimmed), everything but one directory of this test's blacklisted -- with a ctx, with MI_MEMFS_TRUST_CTIME, and without"""
@@ -310,6 +366,10 @@ def scenario_oversize_copy(tmp, eng):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 3 and sys.argv[3] == "trust_wide":
+        with M.Engine(n_streams=int(sys.argv[2]), staging_bytes=1 << 20) as eng:
+            scenario_trust_wide(sys.argv[1], eng)
+        sys.exit(0)
     if len(sys.argv) > 3 and sys.argv[3] == "oversize_copy":
         with M.Engine(n_streams=int(sys.argv[2]), staging_bytes=1 << 20) as eng:
             scenario_oversize_copy(sys.argv[1], eng)
@@ -324,4 +384,5 @@ if __name__ == "__main__":
         scenario_copy(tmp, eng)
         scenario_many(tmp, eng)
         scenario_trust(tmp, eng)
+        scenario_trust_wide(tmp, eng)
         scenario_slash(tmp, eng)

@@ -101,6 +101,16 @@ def test_copy_sources_that_do_not_fit_the_device_window_by_window(tmp_path):
     assert p.returncode == 0 and "OK oversize_copy" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
 
 
+def test_trusting_ctimes_on_wide_directories_that_change(tmp_path):
+    """MI_MEMFS_TRUST_CTIME, the predicate's place among a directory's children (tests/hip_stub/commit_scenarios.py: runs of deletions,
+    new names before / between / after the old ones, rewrites that keep size and mtime, two handles in turn), on the GPU: every
+    commit reads exactly what is new or changed, and the rewrites are in the layer"""
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hip_stub", "commit_scenarios.py")
+    p = subprocess.run([sys.executable, script, str(tmp_path), "4", "trust_wide"], env=dict(os.environ, MI_TEST_ON_GPU="1"),
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "OK trust_wide" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
+
+
 def _rewrite_same_size_same_second(path, rng):
     st = os.stat(path)
     old = open(path, "rb").read()
