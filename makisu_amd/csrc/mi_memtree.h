@@ -57,34 +57,69 @@ struct Tree {
     // The kept node is dropped when the tree changes AT OR ABOVE its path (a node replaced, erased or emptied there);
     // a change elsewhere -- a leaf put below it, above all -- leaves it standing.  `gen` counts every change of shape.
     uint64_t gen = 1;
-    struct { std::string dir; Node* node = nullptr; } last_parent;
+    // One kept parent PER DEPTH: a walk descends and comes back (a/b, a/b/x, a/b/y, a/c), and the directory it comes back to is
+    // still kept at its depth -- with a PLACE among its children: siblings arrive in name order, the order of the children
+    // map, so the next lookup below the same parent is the next child (or a few steps on), not a search among thousands of
+    // siblings whose map nodes no cache holds.  The place is an iterator: any change of shape forgets every place (an erased
+    // child may be the one it points at); the kept nodes follow the rule above.
+    using Kids = decltype(Node::children);
+    struct Kept { std::string dir; Node* node = nullptr; Kids::iterator at; bool placed = false; };
+    std::vector<Kept> kept;                                                     // [depth of dir] ("/a/b": 2)
+    void forget_places() { for (Kept& k : kept) k.placed = false; }
     void shape_changed(const std::string& at) {
         ++gen;
-        if (last_parent.node && last_parent.dir.size() >= at.size() && memcmp(last_parent.dir.data(), at.data(), at.size()) == 0 &&
-            (last_parent.dir.size() == at.size() || last_parent.dir[at.size()] == '/' || at == "/"))
-            last_parent.node = nullptr;
+        for (Kept& k : kept) {
+            k.placed = false;
+            if (k.node && k.dir.size() >= at.size() && memcmp(k.dir.data(), at.data(), at.size()) == 0 &&
+                (k.dir.size() == at.size() || k.dir[at.size()] == '/' || at == "/"))
+                k.node = nullptr;
+        }
     }
-    void shape_reset() { ++gen; last_parent.node = nullptr; }
+    void shape_reset() { ++gen; kept.clear(); }
     // where a clean absolute path splits into parent and name; npos = take the general way
     static size_t parent_cut(const std::string& p) {
         const size_t cut = p.find_last_of('/');
         return (cut == std::string::npos || cut == 0 || cut + 1 >= p.size() || p[0] != '/') ? std::string::npos : cut;
     }
-    Node* parent_node(const std::string& p, size_t cut) {                       // the node of p[0, cut), kept for the next call
-        if (last_parent.node && last_parent.dir.size() == cut && memcmp(last_parent.dir.data(), p.data(), cut) == 0)
-            return last_parent.node;
-        const std::string dir = p.substr(0, cut);
-        Node* parent = find_walk(dir);
-        if (parent) { last_parent.dir = dir; last_parent.node = parent; }
-        return parent;
+    Kept* kept_parent(const std::string& p, size_t cut) {                       // the node of p[0, cut), kept for the next call
+        size_t depth = 0;
+        for (size_t i = 0; i < cut; ++i) depth += p[i] == '/';
+        if (depth >= 64) depth = 63;                                            // (deeper directories share the last slot)
+        if (kept.size() <= depth) kept.resize(depth + 1);
+        Kept& k = kept[depth];
+        if (k.node && k.dir.size() == cut && memcmp(k.dir.data(), p.data(), cut) == 0) return &k;
+        k.dir.assign(p, 0, cut);
+        k.node = find_walk(k.dir);
+        k.placed = false;
+        return k.node ? &k : nullptr;
+    }
+    Node* parent_node(const std::string& p, size_t cut) {
+        Kept* k = kept_parent(p, cut);
+        return k ? k->node : nullptr;
     }
     Node* find(const std::string& p) {                                          // isUpdated's walk; nullptr = "new"
         const size_t cut = parent_cut(p);
         if (cut == std::string::npos) return find_walk(p);
-        Node* parent = parent_node(p, cut);
-        if (!parent) return nullptr;
-        auto it = parent->children.find(std::string_view(p.data() + cut + 1, p.size() - cut - 1));
-        return it == parent->children.end() ? nullptr : it->second.get();
+        Kept* k = kept_parent(p, cut);
+        if (!k) return nullptr;
+        Kids& kids = k->node->children;
+        const std::string_view name(p.data() + cut + 1, p.size() - cut - 1);
+        if (k->placed) {
+            for (int steps = 0; k->at != kids.end() && steps < 4 && std::string_view(k->at->first) < name; ++steps) ++k->at;
+            if (k->at == kids.end()) {                                          // past the last child: a name behind it is new
+                if (kids.empty() || std::string_view(std::prev(kids.end())->first) < name) return nullptr;
+                k->at = kids.lower_bound(name);
+            } else if (std::string_view(k->at->first) != name) {
+                k->at = kids.lower_bound(name);
+            }
+        } else {
+            k->at = kids.lower_bound(name);
+            k->placed = true;
+        }
+        if (k->at == kids.end() || std::string_view(k->at->first) != name) return nullptr;
+        Node* found = k->at->second.get();
+        ++k->at;                                                                // the next sibling: where the next lookup begins
+        return found;
     }
     Node* find_walk(const std::string& p) {
         Node* cur = &root;
@@ -123,7 +158,8 @@ struct Tree {
                 const std::string_view name(dst.data() + cut + 1, dst.size() - cut - 1);
                 std::unique_ptr<Node> nn(new Node);
                 nn->ref = ref; nn->kind = kind; nn->link = link;
-                auto it = parent->children.lower_bound(name);
+                Kids& kids = parent->children;                                  // (names come sorted: mostly behind the last one)
+                auto it = kids.empty() || std::string_view(std::prev(kids.end())->first) < name ? kids.end() : kids.lower_bound(name);
                 if (it != parent->children.end() && it->first == name) {
                     if (kind == 0) nn->children = std::move(it->second->children);
                     shape_changed(dst);                                         // (before the old node goes)
