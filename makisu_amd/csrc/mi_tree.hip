@@ -561,7 +561,9 @@ struct ParallelWalker {
         // path lookup per file instead of two.  Only on a descriptor table of this thread's own (every file of the directory is
         // open at once until the block is laid out) and only while the directory fits the table.
         std::vector<int> fds;
-        const bool open_first = inline_reads && own_table && names.size() + 64 <= fd_budget();
+        // (Not when the caller may know a file's content -- MI_MEMFS_TRUST_CTIME: most files are then not read at all, and an
+        // open + fstat + close each is three system calls where one fstatat does.)
+        const bool open_first = inline_reads && own_table && !w->content_known && names.size() + 64 <= fd_budget();
         if (open_first) fds.assign(names.size(), -1);
         const uint64_t ts0 = tl0 ? now_ns() : 0;
         if (tl0) g_ns_list += ts0 - tl0;
@@ -703,7 +705,8 @@ struct ParallelWalker {
         // private table still full of the process's descriptors would hold the host's sockets and pipes open for the whole
         // walk (a close on the host's side would send no FIN, reach no EOF) and would not have room for open_first's
         // descriptors.  MI_WALK_CLOSE_RANGE=0 takes that way on purpose (tests).
-        if (inline_reads && walk_unshare() && walk_close_range() &&
+        // (Also for a walk that reads nothing: sixteen readers opening and closing directories on ONE table contend for its lock.)
+        if (walk_unshare() && walk_close_range() &&
             syscall(SYS_close_range, 3u, ~0u, (unsigned)MI_CLOSE_RANGE_UNSHARE) == 0)
             own_table = true;
         if (tu0) g_ns_unshare += now_ns() - tu0;
