@@ -533,7 +533,9 @@ struct Fs {
         if (!cur || cur->ref < 0 || e.kind > 3) return false;
         Node& o = nodes[cur->ref];
         if (o.e.kind > 3) return false;
-        if (own_root && o.has_root && !o.root_pending) content_root = o.root;
+        // (own_root: the content IS what the node's root describes -- nothing to compare, and the node's root stays untouched
+        //  in whatever cache line it lies)
+        const bool same_content = own_root && o.has_root && !o.root_pending;
         mi_tree_entry a, b = e;
         memset(&a, 0, sizeof a);
         a.relpath = o.e.relpath.empty() ? "" : o.e.relpath.c_str();
@@ -544,7 +546,7 @@ struct Fs {
         b.file_index = -1;
         const bool file_has_root = content_root != nullptr || lazy_file >= 0;
         const uint8_t *ra = nullptr, *rb = nullptr;
-        if (o.has_root && file_has_root && a.kind == 1 && b.kind == 1) {         // both carry a root: it decides -- now
+        if (!same_content && o.has_root && file_has_root && a.kind == 1 && b.kind == 1) {   // both carry a root: it decides -- now
             ra = root_now(o);
             rb = content_root;
             if (!rb && !rc) {
