@@ -302,10 +302,14 @@ def scenario_oversize(tmp, eng):
                                                                           # what the first attempt had read when it ran out of room
         assert fs.root_of("/o0/f01") is not None
         res, raw = commit_to_bytes(fs, tmp, "o1.tar", must_scan=True, engine=eng)
-        assert res["n_entries"] == 0 and res["stats"]["n_windows"] >= 4 and total <= res["stats"]["file_bytes_read"] <= 2 * total
+        assert res["n_entries"] == 0
         if not os.environ.get("MI_TEST_TRUST"):
+            assert res["stats"]["n_windows"] >= 4
             assert res["stats"]["file_bytes_read"] == total               # (no second attempt at one batch: straight to the windows)
         else:
+            # (right after the first commit: the files written within the racy window of its start are read again -- how many that
+            #  is, and whether they fit the device in one batch, depends on how long the tree took to write)
+            assert res["stats"]["file_bytes_read"] <= 2 * total
             import time
             time.sleep(0.06)                                              # a window's files were hashed files: their inodes are on record --
             r3 = fs.commit_layer(must_scan=True, engine=eng, gzip_level=M.GZIP_OFF)   # the next commit trusts them and fits
