@@ -65,7 +65,6 @@ struct Tree {
     using Kids = decltype(Node::children);
     struct Kept { std::string dir; Node* node = nullptr; Kids::iterator at; bool placed = false; };
     std::vector<Kept> kept;                                                     // [depth of dir] ("/a/b": 2)
-    void forget_places() { for (Kept& k : kept) k.placed = false; }
     void shape_changed(const std::string& at) {
         ++gen;
         for (Kept& k : kept) {

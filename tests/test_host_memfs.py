@@ -524,6 +524,40 @@ def test_merged_header_count_is_the_number_of_distinct_keys(tmp_path):
         assert fs.update_from_entries(touched) == len(touched) + len({"m"} | {e["relpath"].rsplit("/", 1)[0] for e in touched})
 
 
+def test_directories_whose_names_begin_alike_in_a_tars_arbitrary_order(tmp_path):
+    """The tree keeps, per depth, the directory of the last lookup and a place among its children -- matched by the directory's
+    whole path, not a prefix of it.  A tar may list "a", "ab", "abc" and "a/b", "a/bb" in any order, jumping between them; every
+    entry must land below ITS directory, a later layer's changes on the right nodes, and the scan of the same tree finds nothing."""
+    D = lambda p: {"relpath": p, "kind": M.KIND_DIR, "mode": 0o40755, "mtime_sec": 100, "size": 0}                 # noqa: E731
+    F = lambda p, t=100: {"relpath": p, "kind": M.KIND_FILE, "mode": 0o100644, "mtime_sec": t, "size": 5}         # noqa: E731
+    first = [D("a"), D("ab"), D("abc"), F("a/x"), F("ab/x"), F("abc/x"), F("a/y"), F("abc/y"), F("ab/y"), D("a/b"), D("a/bb"),
+             F("a/bb/q"), F("a/b/q"), F("a/bb/r"), F("a/b/r"), F("abc/a"), F("a/a"), F("ab/a")]
+    with M.MemFS(str(tmp_path)) as fs:
+        assert fs.update_from_entries(first) == len(first)
+        assert [e["relpath"] for e in fs.entries()] == sorted(e["relpath"] for e in first)
+        assert fs.update_from_entries(first) == 0
+        second = [F("ab/x", 101), F("a/x", 102), F("abc/x", 103), F("a/b/q", 104), F("a/bb/q", 105), F("a/y", 106), F("abc/y", 107)]
+        assert fs.update_from_entries(second) == len(second) + len({"a", "ab", "abc", "a/b", "a/bb"})
+        got = {e["relpath"]: e["mtime_sec"] for e in fs.entries()}
+        want = {e["relpath"]: e["mtime_sec"] for e in first}
+        want.update({e["relpath"]: e["mtime_sec"] for e in second})
+        assert got == want
+        for e in fs.entries():                                                      # the same tree on disk: the scan finds nothing
+            full = os.path.join(str(tmp_path), e["relpath"])
+            if e["kind"] == M.KIND_DIR:
+                os.makedirs(full, exist_ok=True)
+            else:
+                os.makedirs(os.path.dirname(full), exist_ok=True)
+                with open(full, "w") as f:
+                    f.write("12345")
+                os.chmod(full, 0o644)
+        for e in sorted(fs.entries(), key=lambda e: -e["relpath"].count("/")):
+            os.utime(os.path.join(str(tmp_path), e["relpath"]), (e["mtime_sec"], e["mtime_sec"]))
+        os.chown(str(tmp_path), 0, 0) if os.geteuid() == 0 else None
+        res = fs.commit_layer(must_scan=True, gzip_level=M.GZIP_OFF)
+        assert [e["relpath"] for e in res["layer"]] == []
+
+
 def test_a_failing_copy_op_leaves_what_the_reference_has_applied_by_then(tmp_path):
     """addToLayer (mem_fs.go:343-421) handles an op's sources one after the other: a source that does not exist fails the op
     BEFORE its destination chain is created (the stat comes first); a source that cannot be resolved -- a link leaving the

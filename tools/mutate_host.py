@@ -9,6 +9,8 @@ The report lists the survivors with their line; what was made of them is in tool
 
   python tools/mutate_host.py makisu_amd/csrc/mi_tar.hip --tests tests/test_host_tar.py tests/test_host_tar_fuzz.py \
       --n 60 --jobs 4 --seed 1 [--lines 100-300]
+  a header: python tools/mutate_host.py makisu_amd/csrc/mi_memtree.h --unit makisu_amd/csrc/mi_memfs.hip --tests ...
+      (the unit that includes it is compiled from a copy beside the mutated header, so that ITS include finds the mutant)
 """
 import argparse
 import os
@@ -86,7 +88,11 @@ def run_mutant(k, args, src_lines, site, objs_other, flags):
     mutated = os.path.join(work, base)
     with open(mutated, "w") as f:
         f.writelines(src_lines[: ln - 1] + [new_line] + src_lines[ln:])
-    obj = os.path.join(work, base.replace(".hip", ".o"))
+    unit = mutated
+    if args.unit:                                              # a header: the including unit, copied beside the mutant
+        unit = os.path.join(work, os.path.basename(args.unit))
+        shutil.copy(args.unit, unit)
+    obj = os.path.join(work, os.path.basename(unit).replace(".hip", ".o"))
     lib = os.path.join(work, "libmakisu_mi.so")
     tag = "%s:%d  [%s]  %s  ->  %s" % (base, ln, name, line.strip()[:110], new_line.strip()[:110])
     if args.oracle:                                           # the CPU oracle: plain C, one compile + link
@@ -100,7 +106,7 @@ def run_mutant(k, args, src_lines, site, objs_other, flags):
             return ("nocompile", tag, "")
         env = dict(os.environ, MI_ORACLE_LIB=lib, PYTHONDONTWRITEBYTECODE="1")
     else:
-        cc = [B.HIPCC] + flags + ["-I", os.path.dirname(os.path.abspath(args.source)), "-c", mutated, "-o", obj]
+        cc = [B.HIPCC] + flags + ["-I", os.path.dirname(os.path.abspath(args.source)), "-c", unit, "-o", obj]
         r = subprocess.run(cc, capture_output=True, text=True)
         if r.returncode != 0:
             shutil.rmtree(work, ignore_errors=True)
@@ -138,6 +144,7 @@ def main():
     ap.add_argument("--work", default="/tmp/mi_mut")
     ap.add_argument("--out", default="")
     ap.add_argument("--oracle", action="store_true", help="the source is a file of oracle/ (gcc, MI_ORACLE_LIB)")
+    ap.add_argument("--unit", default="", help="the source is a header: the .hip that includes it")
     args = ap.parse_args()
     B.build()
     with open(args.source) as f:
@@ -157,7 +164,7 @@ def main():
         chosen.append(s)
         if len(chosen) >= args.n:
             break
-    base = os.path.basename(args.source)
+    base = os.path.basename(args.unit or args.source)
     objs_other = [os.path.join(B.OBJ_DIR, s.replace(".hip", ".o")) for s in B.SOURCES if s != base]
     flags = ["--offload-arch=gfx950", "-O1", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-w"] + B.EXTRA.get(base, [])
     os.makedirs(args.work, exist_ok=True)
