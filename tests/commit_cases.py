@@ -58,6 +58,14 @@ def tar_members(raw):
     return out
 
 
+def oracle_chunks(O, data):
+    """the chunk rows the ORACLE gives a file's bytes (one per chunk)"""
+    p = O.CdcParams(SEED, MASK_BITS, MIN_SIZE, MAX_SIZE)
+    a = np.frombuffer(data, dtype=np.uint8) if len(data) else np.zeros(0, dtype=np.uint8)
+    _, rc = O.scan_batch(a, [0], [len(data)], p, True, 1, 0)
+    return rc
+
+
 def oracle_root(O, data):
     """the chunk root the ORACLE gives a file's bytes (Gear CDC with the default parameters, SHA-256 per chunk, root)"""
     p = O.CdcParams(SEED, MASK_BITS, MIN_SIZE, MAX_SIZE)

@@ -101,6 +101,7 @@ def scenario_copy(tmp, eng):
         n_simple = sum(1 for e in gold if e["path"].startswith("simple/"))
         assert st["n_scanned_files"] == 28 + 1 + n_simple + 1, st          # every op's sources, as often as they are copied
         assert st["n_layer_files"] == st["n_scanned_files"]
+        assert st["n_windows"] == 0                                        # (they fit: one batch, staged while the sources are walked)
         # an op that fails where the reference's loop fails: after the ops before it
         bad = ops[:1] + [{"src_root": src_root, "srcs": ["nope"], "dst": "/x/"}]
         try:

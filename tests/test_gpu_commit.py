@@ -24,7 +24,7 @@ for _p in (ROOT, os.path.join(ROOT, "tests")):                   # (also run as 
     if _p not in sys.path:
         sys.path.insert(0, _p)
 import makisu_amd as M  # noqa: E402
-from commit_cases import commit_to_bytes, make_tree, oracle_root, proc_io, tar_members, write_file  # noqa: E402
+from commit_cases import commit_to_bytes, make_tree, oracle_chunks, oracle_root, proc_io, tar_members, write_file  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 MTIME = 1_600_000_000
@@ -54,6 +54,7 @@ def _check_commit_zero(O, eng, root, files, tmp):
         else:
             assert st["files_opened"] == len(nonempty) and st["file_bytes_read"] == st["scanned_bytes"]   # ONE open, ONE read each
         assert st["n_content_changed"] == 0 and st["n_roots_learned"] == 0
+        assert st["n_chunks"] == sum(len(oracle_chunks(O, d)) for d in nonempty)           # (summed over the windows, if any)
         by = {e["relpath"]: e for e in res["layer"]}
         for rel, data in files.items():
             want = oracle_root(O, data)
