@@ -91,6 +91,8 @@ int arena_reserve(mi_batch* b, u64 want, bool told = false) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     u64 alloc = guard_alloc() ? ((want + 255) & ~255ull) : want + (told ? want / 8 : want / 2);   // under the guard: the 4 KiB and no more
     void* np = nullptr;
+    static const bool trace = [] { const char* v = getenv("MI_ARENA_TRACE"); return v && *v == '1'; }();
+    if (trace) fprintf(stderr, "mi_arena: %s %.1f MB -> %.1f MB (used %.1f)\n", told ? "told" : "grow", b->arena.bytes / 1e6, alloc / 1e6, b->arena_used / 1e6);
     hipError_t e = dev_alloc(&np, alloc);
     if (e != hipSuccess) { alloc = want; HIPCHK(c, dev_alloc(&np, alloc)); }
     if (b->arena.p && b->arena_used) {

@@ -1770,6 +1770,30 @@ extern "C" int mi_memfs_commit_layer(mi_memfs* m, mi_ctx* ctx, int must_scan, co
         else { rc = mi_batch_begin(ctx, 0, 0, &m->batch); m->batch_ctx = ctx; }
         if (rc) return fail_with(rc, std::string("gpu scan: ") + mi_last_error(ctx));
         b = m->batch;
+        // A first content scan of a tree the handle already knows (the base image's layers were merged: FROM, then RUN): what the
+        // walk will stage is about what the tree lists -- the arena is made ONCE, for that, instead of growing in steps while the
+        // walk finds out (each step drains the reader threads, moves what the arena holds, and on boxes whose driver charges
+        // fresh device memory by the byte -- 47-68 ms per GiB, tools/first_use_probe.py -- pays for every step's full size:
+        // a 15 GB tree grew 75 MB -> 22 GB in eight steps, 40 GB allocated in all).  Not when inodes are trusted and the tree
+        // has been hashed before (little will be staged); a reservation the device refuses is no error (the walk grows what it
+        // needs, or the commit goes window by window).
+        uint64_t arena_now = 0;
+        mi_batch_arena_room(b, &arena_now);
+        if (must_scan && arena_now == 0 && !(fs.trust_ctime && !fs.hashed.empty()) && !m->went_windowed) {
+            uint64_t files = 0, bytes = 0;
+            std::vector<const mi_memtree::Node*> todo{&fs.t.root};
+            while (!todo.empty()) {
+                const mi_memtree::Node* n = todo.back();
+                todo.pop_back();
+                for (const auto& kv : n->children) {
+                    const mi_memtree::Node* c = kv.second.get();
+                    if (c->kind == 1 && c->ref >= 0) { ++files; bytes += fs.nodes[(size_t)c->ref].e.size; }
+                    if (!c->children.empty()) todo.push_back(c);
+                }
+            }
+            if (files && bytes >= (64ull << 20) && bytes <= (256ull << 30) && mi_batch_reserve(b, files, bytes) != MI_OK)
+                (void)mi_batch_reset(b);
+        }
     }
     // PIPELINED (default; MI_COMMIT_PIPELINE=0: one phase after the other): the scan -- the end of staging, the kernels, the
     // roots' way back -- runs on a thread of its own (ScanJob) while this thread computes the layer and frames the tar from

@@ -237,6 +237,51 @@ def scenario_trust_wide(tmp, eng):
     print("OK trust_wide")
 
 
+def scenario_known_tree(tmp, eng):
+    """FROM, then RUN: the handle has merged the base image's layers, so its first content scan knows about what it will stage --
+    the arena is made once, for that, instead of growing while the walk finds out (the double counts allocations of a MiB and more)"""
+    import ctypes
+    big_mallocs = ctypes.CDLL(None).mi_hip_stub_big_mallocs
+    big_mallocs.restype = ctypes.c_long
+    root = os.path.join(tmp, "known_root")
+    rng = np.random.default_rng(5)
+    entries, files = [], {}
+    for d in range(40):
+        entries.append({"relpath": "k%02d" % d, "kind": M.KIND_DIR, "mode": 0o40755, "mtime_sec": MTIME, "size": 0})
+        for k in range(100):
+            rel = "k%02d/f%02d" % (d, k)
+            data = rng.integers(0, 256, 65_536, dtype=np.uint8).tobytes()
+            write_file(os.path.join(root, rel), data, 0o644, MTIME)
+            files[rel] = data
+            entries.append({"relpath": rel, "kind": M.KIND_FILE, "mode": 0o100644, "mtime_sec": MTIME, "size": len(data)})
+    for d in range(40):
+        os.utime(os.path.join(root, "k%02d" % d), (MTIME, MTIME))
+    counts = {}
+    before = os.environ.get("MI_WALK_THREADS")
+    os.environ["MI_WALK_THREADS"] = "1"                                   # (the sequential walk: no enumeration runs ahead of what is
+    try:                                                                  #  staged, the arena learns the tree's size file by file)
+        for name in ("fresh", "merged"):
+            with M.MemFS(root) as fs:
+                if name == "merged":
+                    assert fs.update_from_entries(entries) == len(entries)
+                n0 = big_mallocs()
+                res, raw = commit_to_bytes(fs, tmp, "k_%s.tar" % name, must_scan=True, engine=eng)
+                counts[name] = big_mallocs() - n0
+                st = res["stats"]
+                assert st["n_scanned_files"] == len(files) and st["files_opened"] == len(files)
+                if name == "fresh":
+                    assert {n: d for n, m, d in tar_members(raw) if m.isfile()} == files
+                else:
+                    assert res["n_entries"] == 0 and st["n_roots_learned"] == len(files)      # the headers are the merged ones: nothing new
+    finally:
+        if before is None:
+            del os.environ["MI_WALK_THREADS"]
+        else:
+            os.environ["MI_WALK_THREADS"] = before
+    assert counts["merged"] < counts["fresh"], counts                     # (262 MB, handed over 1 024 files at a time: three arenas in steps, or one)
+    print("OK known_tree")
+
+
 def scenario_slash(tmp, eng):
     """the root of every real build is "/": the same commit with the handle rooted there (a node's source IS its path, nothing is
     trimmed), everything but one directory of this test's blacklisted -- with a ctx, with MI_MEMFS_TRUST_CTIME, and without"""
@@ -390,4 +435,5 @@ if __name__ == "__main__":
         scenario_many(tmp, eng)
         scenario_trust(tmp, eng)
         scenario_trust_wide(tmp, eng)
+        scenario_known_tree(tmp, eng)
         scenario_slash(tmp, eng)

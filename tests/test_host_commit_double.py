@@ -10,7 +10,7 @@ import pytest
 
 from test_host_hip_double import STUB_DIR, hip_double  # noqa: F401  (the fixture builds the double when stale)
 
-WANT = ["OK scan", "OK copy", "OK many", "OK trust", "OK trust_wide", "OK slash"]
+WANT = ["OK scan", "OK copy", "OK many", "OK trust", "OK trust_wide", "OK known_tree", "OK slash"]
 
 
 def _run(stub, tmp, threads, extra_env=None):
