@@ -774,8 +774,8 @@ int  mi_memfs_set_options(mi_memfs* fs, uint32_t options);
  * to the ctx the commits run on and outlive them; the handle does not own it.                                          */
 int  mi_memfs_set_index(mi_memfs* fs, mi_index* index);
 /* The handle's batch ahead of its first content-aware commit, with room for `files` files of `bytes` bytes in total: a
- * ctx's first use costs (the reader threads: 40-55 ms; fresh device memory on a box nobody has allocated on yet: 68 ms per
- * GiB) -- a host that knows what is coming, e.g. the size of the base image it is pulling, pays them beside its own work.
+ * ctx's first use costs (the reader threads: 40-55 ms; device memory: by the byte on some boxes, 47-68 ms per
+ * GiB at every allocation) -- a host that knows what is coming, e.g. the size of the base image it is pulling, pays them beside its own work.
  * Optional.                                                                                                              */
 int  mi_memfs_reserve_device(mi_memfs* fs, mi_ctx* ctx, uint64_t files, uint64_t bytes);
 /* Gives back the batch a content-aware commit left with the handle (its arena holds the scanned tree's bytes).          */

@@ -80,7 +80,7 @@ int staging_sync(mi_batch* b) {
 }
 
 // told: the caller KNOWS what is coming (a hint of mi_batch_begin, mi_batch_reserve after an enumeration): an eighth on
-// top instead of a half -- fresh device memory costs 68 ms per GiB to allocate on this driver (tools/first_use_probe.py:
+// top instead of a half -- device memory costs up to 68 ms per GiB to allocate on some boxes (tools/first_use_probe.py:
 // 1 GiB 0.054 s, 16 GiB 1.09 s), so the first commit of a 6.4 GB tree pays 0.49 s for its arena, not 0.65
 int arena_reserve(mi_batch* b, u64 want, bool told = false) {
     mi_ctx* c = b->ctx;

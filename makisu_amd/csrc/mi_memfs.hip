@@ -2009,7 +2009,7 @@ extern "C" int mi_memfs_set_index(mi_memfs* m, mi_index* index) {
     return MI_OK;
 }
 // The handle's batch, made ahead of its first commit and sized for `bytes` of files in `files` files: fresh device memory costs
-// 68 ms per GiB to allocate (tools/first_use_probe.py) and the ctx's reader threads 55 ms to come up -- a host that knows what
+// up to 68 ms per GiB to allocate on some boxes (tools/first_use_probe.py) and the ctx's reader threads 55 ms to come up -- a host that knows what
 // is coming (the base image it is pulling) pays that beside its own work instead of inside the first commit
 extern "C" int mi_memfs_reserve_device(mi_memfs* m, mi_ctx* ctx, uint64_t files, uint64_t bytes) {
     if (!m || !ctx) return MI_ERR_INVALID;
