@@ -416,6 +416,10 @@ def scenario_oversize_copy(tmp, eng):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 3 and sys.argv[3] == "known_tree":
+        with M.Engine(n_streams=int(sys.argv[2]), staging_bytes=1 << 20) as eng:
+            scenario_known_tree(sys.argv[1], eng)
+        sys.exit(0)
     if len(sys.argv) > 3 and sys.argv[3] == "trust_wide":
         with M.Engine(n_streams=int(sys.argv[2]), staging_bytes=1 << 20) as eng:
             scenario_trust_wide(sys.argv[1], eng)
@@ -435,5 +439,4 @@ if __name__ == "__main__":
         scenario_many(tmp, eng)
         scenario_trust(tmp, eng)
         scenario_trust_wide(tmp, eng)
-        scenario_known_tree(tmp, eng)
         scenario_slash(tmp, eng)

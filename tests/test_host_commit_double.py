@@ -10,7 +10,7 @@ import pytest
 
 from test_host_hip_double import STUB_DIR, hip_double  # noqa: F401  (the fixture builds the double when stale)
 
-WANT = ["OK scan", "OK copy", "OK many", "OK trust", "OK trust_wide", "OK known_tree", "OK slash"]
+WANT = ["OK scan", "OK copy", "OK many", "OK trust", "OK trust_wide", "OK slash"]
 
 
 def _run(stub, tmp, threads, extra_env=None):
@@ -62,3 +62,12 @@ def test_copy_sources_larger_than_the_device_go_window_by_window(hip_double, tmp
     p = subprocess.run([sys.executable, os.path.join(STUB_DIR, "commit_scenarios.py"), str(tmp_path), "4", "oversize_copy"], env=env,
                        capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "OK oversize_copy" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
+
+
+def test_a_tree_the_handle_knows_gets_its_arena_in_one_piece(hip_double, tmp_path):  # noqa: F811
+    """FROM, then RUN: the handle merged the base layers, its first content scan reserves the arena once for what the tree lists;
+    a handle that knows nothing grows it in steps (the double counts allocations of a MiB and more)"""
+    env = dict(os.environ, LD_PRELOAD=(os.environ.get("LD_PRELOAD", "") + " " + hip_double).strip())
+    p = subprocess.run([sys.executable, os.path.join(STUB_DIR, "commit_scenarios.py"), str(tmp_path), "4", "known_tree"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "OK known_tree" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
