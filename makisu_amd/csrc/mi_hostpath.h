@@ -6,6 +6,7 @@
 #include "mi_local.h"
 
 #include <stdio.h>
+#include <sys/stat.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -54,12 +55,17 @@ struct Tree {
     std::vector<Entry> entries;
     bool want_stamps = false;
     std::vector<InodeStamp> stamps;       // [i] of entries[i]; regular files (zeros otherwise)
-    std::vector<uint8_t> known;           // [i] = 1: a regular file the walk did NOT stage -- its content is known to the caller
-    void push(Entry&& e, const InodeStamp* st = nullptr, bool is_known = false) {
+    std::vector<uint8_t> known;           // [i]: what content_known said -- kContentKnown: a regular file the walk did NOT stage,
+                                          // its content is known to the caller; | kEntryHeld: ... and the entry is what the
+                                          // caller holds for the path, header included (nothing left for the diff to do)
+    void push(Entry&& e, const InodeStamp* st = nullptr, uint8_t known_flags = 0) {
         entries.push_back(std::move(e));
-        if (want_stamps) { stamps.push_back(st ? *st : InodeStamp()); known.push_back(is_known ? 1 : 0); }
+        if (want_stamps) { stamps.push_back(st ? *st : InodeStamp()); known.push_back(known_flags); }
     }
 };
+constexpr uint8_t kContentKnown = 1, kEntryHeld = 2;
+// "is this regular file's content known?" -- asked by whoever stats the file (the directory readers: several threads at a time)
+using KnownFn = std::function<uint8_t(const std::string& path_on_disk, const struct stat& st, const InodeStamp& stamp)>;
 
 // Go's path.Clean for a ROOTED path (what path.Join("/", p) returns): single slashes, no "."
 // elements, ".." removes the element before it, ".." at the root disappears.
@@ -289,10 +295,9 @@ int scan_walk_collect(const std::string& src, const std::string& link_root, Tree
 // the snapshot walk of a root with its blacklist and NO batch, inode stamps recorded (a tree that is scanned in windows)
 int scan_walk_listing(const std::string& root, const std::vector<std::string>& blacklist, Tree* out, std::string* err);
 int scan_walk_collect_batch(const std::string& src, const std::string& link_root, Tree* out, std::string* err, mi_batch* b);
-// mi_batch_add_tree with the scan rules and a say in which files are staged: known(path on disk, size, stamp) == true means
+// mi_batch_add_tree with the scan rules and a say in which files are staged: known(path on disk, stat, stamp) & kContentKnown means
 // "this file's content is known, do not read it" -- called from the walk's directory readers, several at a time
 int scan_walk_batch_filtered(mi_batch* b, const std::string& root, const std::vector<std::string>& blacklist,
-                             const std::function<bool(const std::string&, uint64_t, const InodeStamp&)>& known, Tree** tree_out,
-                             std::string* err);
+                             const KnownFn& known, Tree** tree_out, std::string* err);
 
 }  // namespace mi_walk

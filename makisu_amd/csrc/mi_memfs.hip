@@ -69,6 +69,13 @@ struct Node {
 // when that was (CLOCK_REALTIME at the start of that commit's walk).  Beside the nodes (Fs::hashed, by node index), not in them:
 // a tree merged from base layers and never scanned with a ctx pays nothing for it.
 struct HashedAs { mi_walk::InodeStamp stamp; int64_t at_ns = 0; };
+// a scan's mark ("this scan's walk lists the path", mi_memtree::Node::seen): never 0, never given twice
+static uint32_t next_scan_mark() {
+    static std::atomic<uint32_t> g{0};
+    uint32_t m = ++g;
+    if (m == 0) m = ++g;
+    return m;
+}
 
 // The GPU scan of a pipelined commit, on a thread of its own: mi_batch_run (the end of staging, the kernels) and the roots'
 // way back, while the committing thread computes the layer and frames the tar from the bytes that have already landed.
@@ -290,6 +297,7 @@ struct Fs {
         hashed[(size_t)ref].at_ns = commit_started_ns;
     }
     const uint64_t id = [] { static std::atomic<uint64_t> n{0}; return ++n; }();    // (a handle's number: never given twice)
+    uint32_t reserved_mark = 0;                                                 // the coming scan's mark, taken before its walk (0: none)
     bool trust_ctime = false;                                                   // mi_memfs_set_options(MI_MEMFS_TRUST_CTIME)
     int64_t commit_started_ns = 0;                                              // CLOCK_REALTIME when the commit under way began its walk
     // "is the content of the regular file at `disk_path` known?" -- asked by the walk's directory readers, several at a time,
@@ -297,10 +305,16 @@ struct Fs {
     // computed from THIS inode in THIS state: same device, inode, size, mtime and ctime to the nanosecond -- and the ctime lies
     // safely before the moment the content was read (a write in the same clock tick as the recorded ctime would leave no
     // trace: git's "racily clean" rule; MI_TRUST_CTIME_SLACK_MS, default 20, covers the kernel's coarse clock).
-    bool content_is_known(const std::string& disk_path, uint64_t size, const mi_walk::InodeStamp& st) {
+    // Returns mi_walk::kContentKnown, and with it kEntryHeld when the file's header is also what the node holds (tario.IsSimilarHeader
+    // on a regular file: mode bits, owner, size, whole-second mtime) -- such an entry is nothing to the diff: the node is marked
+    // "listed by this scan's walk" HERE (`mark`: the scan's mark, reserved before the walk), by the reader that stat'ed the file,
+    // and memfs_scan passes it over.  A million unchanged files are then compared by sixteen readers beside their fstatat, not by
+    // the committing thread after the walk.
+    uint8_t content_is_known(const std::string& disk_path, const struct stat& sb, const mi_walk::InodeStamp& st, uint32_t mark) {
+        const uint64_t size = (uint64_t)sb.st_size;
         static const int64_t slack_ns = [] { const char* e = getenv("MI_TRUST_CTIME_SLACK_MS"); return (int64_t)(e && *e ? atol(e) : 20) * 1000000ll; }();
         const size_t root_len = root == "/" ? 0 : root.size();
-        if (disk_path.size() <= root_len || memcmp(disk_path.data(), root.data(), root_len) != 0) return false;
+        if (disk_path.size() <= root_len || memcmp(disk_path.data(), root.data(), root_len) != 0) return 0;
         // A directory reader asks about ONE directory's files, in name order -- the order of the node's children map.  So the
         // directory's node and a position among its children are kept PER THREAD (the tree's own kept parent belongs to the
         // committing thread): the next file is the next child, or a few steps on -- not a walk from the root and a search among
@@ -332,21 +346,25 @@ struct Fs {
         } else {
             nd = t.find_walk(disk_path.substr(root_len));
         }
-        if (!nd || nd->ref < 0) return false;
+        if (!nd || nd->ref < 0) return 0;
         const Node& x = nodes[(size_t)nd->ref];
-        if (x.e.kind != 1 || !x.has_root || x.root_pending || x.e.size != size || (size_t)nd->ref >= hashed.size()) return false;
+        if (x.e.kind != 1 || !x.has_root || x.root_pending || x.e.size != size || (size_t)nd->ref >= hashed.size()) return 0;
         const HashedAs& h = hashed[(size_t)nd->ref];
         // a file system that keeps whole seconds (ext3, FAT, some network mounts) shows as a ctime without a sub-second part:
         // its racy window is the second (two for FAT), not the kernel's clock tick
         const int64_t window_ns = st.ctime_ns % 1000000000ll == 0 ? std::max<int64_t>(slack_ns, 2000000000ll) : slack_ns;
-        if (!h.at_ns || !(h.stamp == st)) return false;                          // (with a clock that only moves forward the next line
-        if (st.ctime_ns + window_ns >= h.at_ns) return false;                    //  alone catches every later change: its ctime is
+        if (!h.at_ns || !(h.stamp == st)) return 0;                             // (with a clock that only moves forward the next line
+        if (st.ctime_ns + window_ns >= h.at_ns) return 0;                       //  alone catches every later change: its ctime is
                                                                                  //  newer than our read.  The equality is what holds
                                                                                  //  when the clock was set back in between.)  Racily
                                                                                  //  clean: read it again
-        return true;                                                             // (counted after the walk, from its record: a
-                                                                                 //  shared counter here is a cache line sixteen
-                                                                                 //  directory readers fight over)
+        // (counted after the walk, from its record: a shared counter here is a cache line sixteen directory readers fight over)
+        if (mark && x.e.mtime == (int64_t)sb.st_mtime && x.e.uid == (uint32_t)sb.st_uid && x.e.gid == (uint32_t)sb.st_gid &&
+            (x.e.mode & 07777u) == ((uint32_t)sb.st_mode & 07777u)) {
+            const_cast<mi_memtree::Node*>(nd)->seen = mark;                      // (this reader's directory, this node: nobody else's)
+            return mi_walk::kContentKnown | mi_walk::kEntryHeld;
+        }
+        return mi_walk::kContentKnown;
     }
     ScanJob* job = nullptr;                                                     // a pipelined commit's scan (else roots come ready)
     std::vector<int64_t> pending_refs;                                          // nodes whose root[] is filled in when it ends
@@ -1566,11 +1584,14 @@ static int memfs_scan(mi_memfs* m, const mi_tree_entry* walked, uint64_t n, cons
     MemfsTimer timer("scan", fs, n);
     fs.clear_layer();
     // pass 1: the nodes the tree holds for the walk's paths are marked "listed by this scan's walk"
-    static std::atomic<uint32_t> g_scan_mark{0};
-    uint32_t mark = ++g_scan_mark;
-    if (mark == 0) mark = ++g_scan_mark;
+    // (a reserved mark: the readers of THIS walk -- wt -- have marked the entries they found held with it)
+    const uint32_t mark = wt && wt->want_stamps && fs.reserved_mark ? fs.reserved_mark : mi_copy::next_scan_mark();
+    fs.reserved_mark = 0;
     std::string p;                                                              // one buffer for every path of the walk
+    const bool have_flags = wt && wt->want_stamps;
+    auto held_by_walk = [&](uint64_t i) { return have_flags && i < wt->known.size() && (wt->known[i] & mi_walk::kEntryHeld); };
     for (uint64_t i = 0; i < n; ++i) {
+        if (held_by_walk(i)) continue;                                           // (marked where it was stat'ed)
         mi_walk::abs_path_of_rel_into(walked[i].relpath ? walked[i].relpath : "", &p);
         if (mi_memtree::Node* nd = fs.t.find(p)) nd->seen = mark;
     }
@@ -1588,6 +1609,7 @@ static int memfs_scan(mi_memfs* m, const mi_tree_entry* walked, uint64_t n, cons
     };
     struct Unset { mi_copy::Fs& f; ~Unset() { f.scan_mark = 0; f.listed_by_walk = nullptr; } } unset{fs};
     for (uint64_t i = 0; i < n && !fs.rc; ++i) {
+        if (held_by_walk(i)) continue;                                           // a regular file, header and content as the tree holds them
         const mi_tree_entry& e = walked[i];
         mi_walk::abs_path_of_rel_into(e.relpath ? e.relpath : "", &p);
         const bool lazy = !roots && fs.job && from_batch && e.kind == 1 && e.file_index >= 0;   // (the scan may still be running)
@@ -1755,6 +1777,7 @@ extern "C" int mi_memfs_commit_layer(mi_memfs* m, mi_ctx* ctx, int must_scan, co
     const uint64_t opens0 = mi_io::content_opens.load(), bytes0 = mi_io::content_bytes.load();
     mi_copy::Fs& fs = m->fs;
     fs.n_content_changed = fs.n_roots_learned = 0;
+    fs.reserved_mark = 0;
     mi_copy_layer* cl = nullptr;
     uint64_t ne = 0;
     int rc;
@@ -1852,12 +1875,15 @@ extern "C" int mi_memfs_commit_layer(mi_memfs* m, mi_ctx* ctx, int must_scan, co
             clock_gettime(CLOCK_REALTIME, &now);
             fs.commit_started_ns = (int64_t)now.tv_sec * 1000000000ll + now.tv_nsec;
             if (fs.trust_ctime) {                                                 // files whose inode says "unchanged" are not read
+                fs.reserved_mark = mi_copy::next_scan_mark();                     // (... and found held are marked by the readers)
                 mi_walk::Tree* wtree = nullptr;
                 std::string werr;
                 rc = mi_walk::scan_walk_batch_filtered(b, fs.root, m->blacklist,
-                        [&fs](const std::string& path, uint64_t size, const mi_walk::InodeStamp& st) { return fs.content_is_known(path, size, st); },
+                        [&fs, mark = fs.reserved_mark](const std::string& path, const struct stat& sb, const mi_walk::InodeStamp& st) {
+                            return fs.content_is_known(path, sb, st, mark);
+                        },
                         &wtree, &werr);
-                if (rc && rc != MI_ERR_NOMEM) return fail_with(rc, "walk " + fs.root + ": " + (werr.empty() ? mi_last_error(ctx) : werr));
+                if (rc && rc != MI_ERR_NOMEM) { fs.reserved_mark = 0; return fail_with(rc, "walk " + fs.root + ": " + (werr.empty() ? mi_last_error(ctx) : werr)); }
                 if (!rc) n = wtree->entries.size();
             } else if (m->went_windowed || force_windows) {
                 rc = MI_ERR_NOMEM;                                                // (it did not fit last time and everything is read again:
@@ -1871,6 +1897,7 @@ extern "C" int mi_memfs_commit_layer(mi_memfs* m, mi_ctx* ctx, int must_scan, co
                 // batch; its regular files through the batch in runs the device has room for -- and the layer's files are
                 // read from disk by the writer: a second read for those, the price of a tree larger than HBM.
                 windowed = true;
+                fs.reserved_mark = 0;                                             // (another walk: another mark)
                 (void)mi_batch_reset(b);
                 std::string werr;
                 rc = mi_walk::scan_walk_listing(fs.root, m->blacklist, &listing, &werr);

@@ -99,7 +99,7 @@ struct Walker {
     int64_t n_regular = 0;
     // optional: "is this regular file's content known?" (path on disk, size, inode stamp) -- such a file gets its entry and
     // no row in the batch; asked by whoever stats the file (the directory readers: several threads)
-    std::function<bool(const std::string&, uint64_t, const InodeStamp&)> content_known;
+    KnownFn content_known;
     static InodeStamp stamp_of(const struct stat& st) {
         InodeStamp s;
         s.dev = (uint64_t)st.st_dev;
@@ -187,7 +187,7 @@ struct Walker {
     // placed (optional): the file's bytes are in the arena already, at this offset (its directory's block)
     // known (optional): the answer content_known already gave for this file (the parallel walk asks where it stats)
     void emit(const std::string& path, const struct stat& st, const std::string* link, const std::string* rel = nullptr,
-              const uint64_t* placed = nullptr, const bool* known = nullptr) {
+              const uint64_t* placed = nullptr, const uint8_t* known = nullptr) {
         Entry e;
         e.relpath = rel ? *rel : rel_to(rel_base, path);
         if (e.relpath.empty()) {
@@ -223,9 +223,10 @@ struct Walker {
             e.kind = 1;
             e.size = (uint64_t)st.st_size;
             const InodeStamp stamp = stamp_of(st);
-            if (batch && (known ? *known : (content_known && content_known(path, e.size, stamp)))) {
+            const uint8_t kf = !batch ? 0 : known ? *known : content_known ? content_known(path, st, stamp) : 0;
+            if (kf & kContentKnown) {
                 e.file_index = -1;                               // no row: nothing of it is read
-                tree->push(std::move(e), &stamp, true);
+                tree->push(std::move(e), &stamp, kf);
                 return;
             }
             if (batch) {
@@ -296,7 +297,7 @@ struct Child {
     uint64_t size = 0;
     int64_t mtime = 0;
     InodeStamp stamp;                    // regular files
-    bool known = false;                  // ... whose content the caller knows (Walker::content_known): not read, not staged
+    uint8_t known = 0;                   // ... whose content the caller knows (Walker::content_known's flags): not read, not staged
     bool skip = false;
     int rc = MI_OK;                      // this path's own failure (lstat / readlink / skip-rule / read error)
     std::string err;
@@ -596,7 +597,7 @@ struct ParallelWalker {
             c.size = (uint64_t)st.st_size;
             if (S_ISREG(st.st_mode)) {
                 c.stamp = Walker::stamp_of(st);
-                c.known = w->batch && w->content_known && w->content_known(path, c.size, c.stamp);
+                c.known = w->batch && w->content_known ? w->content_known(path, st, c.stamp) : 0;
                 if (!c.known) {
                     seen_files.fetch_add(1, std::memory_order_relaxed);
                     seen_bytes.fetch_add((uint64_t)st.st_size, std::memory_order_relaxed);
@@ -902,8 +903,7 @@ int scan_walk_listing(const std::string& root, const std::vector<std::string>& b
 }
 
 int scan_walk_batch_filtered(mi_batch* b, const std::string& root, const std::vector<std::string>& blacklist,
-                             const std::function<bool(const std::string&, uint64_t, const InodeStamp&)>& known, Tree** tree_out,
-                             std::string* err) {
+                             const KnownFn& known, Tree** tree_out, std::string* err) {
     void** slot = mi_batch_tree_slot(b);
     if (!*slot) *slot = new Tree();
     Tree* t = (Tree*)*slot;

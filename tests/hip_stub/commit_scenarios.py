@@ -205,9 +205,14 @@ def scenario_trust_wide(tmp, eng):
             touched = set()
             live = sorted(files)
             lo = int(rng.integers(0, len(live) - 40))
-            for rel in live[lo:lo + 30]:                                      # a run of deletions
+            deleted = live[lo:lo + 30]
+            for rel in deleted:                                               # a run of deletions
                 os.unlink(os.path.join(root, rel))
                 files.pop(rel)
+            for rel in rng.choice(sorted(files), size=3, replace=False):      # a header-only change: the inode's ctime moves with it
+                rel = str(rel)
+                os.chmod(os.path.join(root, rel), 0o600 + step)
+                touched.add(rel)
             for d in ("w0", "w1", "w2/inner"):
                 for name in ("a_first_%d" % step, "f%04d" % (2 * int(rng.integers(0, 200)) + 1), "f%04d_x%d" % (2 * int(rng.integers(0, 200)), step),
                              "zz_last_%d" % step):
@@ -231,7 +236,10 @@ def scenario_trust_wide(tmp, eng):
                 res, raw = commit_to_bytes(fs, tmp, "w%d.tar" % step, must_scan=True, engine=eng)
                 st = res["stats"]
                 assert st["files_opened"] == len(touched) and st["n_content_trusted"] == len(files) - len(touched), (step, st, len(touched))
-                got = {n: d for n, m, d in tar_members(raw) if m.isfile() and not os.path.basename(n).startswith(".wh.")}
+                members = tar_members(raw)
+                gone = sorted(os.path.join(os.path.dirname(n), os.path.basename(n)[4:]) for n, m, d in members if os.path.basename(n).startswith(".wh."))
+                assert gone == sorted(deleted), (step, gone[:3], deleted[:3])     # every deletion has its whiteout, beside files nobody looked at
+                got = {n: d for n, m, d in members if m.isfile() and not os.path.basename(n).startswith(".wh.")}
                 in_layer = touched if os.environ.get("MI_TEST_ON_GPU") == "1" else touched - rewritten   # (the double's roots are all
                 assert got == {rel: files[rel] for rel in in_layer}, (step, sorted(set(got) ^ in_layer)[:5])  #  alike: read, not told apart)
     print("OK trust_wide")
