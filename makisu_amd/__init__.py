@@ -15,7 +15,7 @@ import numpy as np
 from . import build as _build
 
 __all__ = ["Engine", "Batch", "Config", "MiError", "load_library", "FILE_DTYPE", "CHUNK_DTYPE",
-           "FLAG_FILE_SHA256", "FLAG_FILE_CRC32", "FLAG_NO_DEDUP", "FLAG_PREFETCH_ROWS", "FLAG_VERIFY_STAGING",
+           "FLAG_FILE_SHA256", "FLAG_FILE_CRC32", "FLAG_NO_DEDUP", "FLAG_PREFETCH_ROWS", "FLAG_VERIFY_STAGING", "FLAG_FILE_SUMS",
            "SHA_LOADS_AUTO", "SHA_LOADS_LANE", "SHA_LOADS_COOP", "Digest", "digest_hex"]
 
 FLAG_FILE_SHA256 = 0x1
@@ -23,6 +23,7 @@ FLAG_FILE_CRC32 = 0x2
 FLAG_NO_DEDUP = 0x4
 FLAG_PREFETCH_ROWS = 0x8
 FLAG_VERIFY_STAGING = 0x10
+FLAG_FILE_SUMS = 0x20
 SHA_LOADS_AUTO, SHA_LOADS_LANE, SHA_LOADS_COOP = 0, 1, 2
 SHA_SCHED_FLAT = 1                       # mi_config.sha_sched: one range, every wave equal
 
@@ -115,7 +116,8 @@ class CommitStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("n_walked", "n_scanned_files", "scanned_bytes", "n_chunks", "n_layer_entries",
                                           "n_layer_files", "layer_file_bytes", "n_content_changed", "n_roots_learned", "n_content_trusted",
                                           "n_index_new", "n_index_known", "index_new_bytes", "files_opened", "file_bytes_read", "pipelined", "n_windows")] + \
-               [(n, C.c_double) for n in ("s_walk_stage", "s_scan", "s_diff", "s_write", "s_total")]
+               [(n, C.c_double) for n in ("s_walk_stage", "s_scan", "s_diff", "s_write", "s_total")] + \
+               [(n, C.c_uint64) for n in ("n_verified_files", "verified_bytes", "n_refetched")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmakisu_mi.so")
 SOURCES = ["mi_api.hip", "gear_cdc.hip", "sha256.hip", "tables.hip", "crc32.hip", "mi_tree.hip", "mi_comm.hip",
-           "mi_index.hip", "mi_alloc.hip", "mi_tar.hip", "mi_stage.hip", "mi_layer.hip", "mi_memfs.hip"]
+           "mi_index.hip", "mi_alloc.hip", "mi_arena.hip", "mi_tar.hip", "mi_stage.hip", "mi_layer.hip", "mi_memfs.hip"]
 HEADERS = ["mi_common.h", "mi_internal.h", "mi_local.h", "host_sha256.h", "mi_hostpath.h", "mi_memtree.h", os.path.join("..", "..", "include", "makisu_mi.h"),
            os.path.join("..", "..", "include", "makisu_mi_host.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

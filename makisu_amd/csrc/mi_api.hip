@@ -79,13 +79,34 @@ int staging_sync(mi_batch* b) {
     return MI_OK;
 }
 
-// told: the caller KNOWS what is coming (a hint of mi_batch_begin, mi_batch_reserve after an enumeration): an eighth on
-// top instead of a half -- device memory costs up to 68 ms per GiB to allocate on some boxes (tools/first_use_probe.py:
-// 1 GiB 0.054 s, 16 GiB 1.09 s), so the first commit of a 6.4 GB tree pays 0.49 s for its arena, not 0.65
-int arena_reserve(mi_batch* b, u64 want, bool told = false) {
+// Room for `want` bytes.  TWO KINDS OF ARENA, decided when a batch's arena is first made:
+//  * PIECEWISE (mi_arena.hip): a reserved address range mapped piece by piece by a thread of its own.  Growing it moves a
+//    number and nobody waits here; whoever touches device memory waits for the mapper where it touches (arena_wait_mapped).
+//    For batches that LEARN their size as they go -- a tree walk, paths or buffers added without a hint: every content-aware
+//    commit -- where an arena that moves would drain the reader threads and copy itself at every step, on the thread the
+//    commit's tar writer is waiting for.  Only an arena that outgrows its whole address range is drained (its pieces are
+//    mapped again elsewhere).
+//  * PLAIN: one allocation (made again, larger, and copied if it has to grow after all) -- for batches that are TOLD their size
+//    before their first byte (mi_batch_begin's hints, mi_batch_reserve, synthetic files): the headline configurations.  The
+//    hashing kernel's lane-owned 64-byte loads touch 64 pages per wave instruction and run at the speed of the page-table
+//    fragments behind them: one hipMalloc 4.13-4.15 ms per C2 chunk pass, pieces of 1 GiB 4.27, of 256 MiB 4.32, of 32 MiB
+//    5.0-5.3, of 2 MiB 5.83 (profiles/r06_arena_ab.txt) -- a commit, bound by its 2.45 GB/s TarDigest, does not notice; the
+//    headline would.  Also under MI_GUARD_ALLOC (the over-read audit needs the arena to END on an unmapped page) and with
+//    MI_ARENA=malloc (A/B).  told: an eighth on top instead of a half.
+// ahead: the caller is a walk whose enumeration runs ahead of what it hands over (mi_batch_reserve_ahead): told, and piecewise.
+int arena_reserve(mi_batch* b, u64 want, bool told = false, bool ahead = false) {
     mi_ctx* c = b->ctx;
     want += 4096;                                   // slack: tile loads may touch 15 B past a file
     if (want <= b->arena.bytes) return MI_OK;
+    if (!b->arena.p) b->arena_plain = arena_is_plain() || (told && !ahead);
+    if (!b->arena_plain) {
+        if (arena_outgrown(&b->arena, want)) {
+            int rc = staging_sync(b);
+            if (rc) return rc;
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+        return arena_promise(c, &b->arena, want);
+    }
     int rc = staging_sync(b);                       // copies in flight target the old arena
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -158,6 +179,10 @@ int staging_flush(mi_batch* b) {
         b->stage_stats.bytes += b->win_fill;
         if (c->verify_staging) b->stage_spans.push_back(sp);   // summed on the GPU when staging ends
     }
+    {
+        const int rc = arena_wait_mapped(c, &b->arena, b->win_start + b->win_fill);
+        if (rc) return rc;
+    }
     HIPCHK(c, hipMemcpyAsync((u8*)b->arena.p + b->win_start, b->ring[b->cur], b->win_fill,
                              hipMemcpyHostToDevice, b->ring_stream));
     HIPCHK(c, hipEventRecord(b->ring_ev[b->cur], b->ring_stream));
@@ -209,6 +234,7 @@ int batch_add_common(mi_batch* b, u64 len, u64 tag, u64* at) {
     int rc = arena_reserve(b, *at + align_up(len, kFileAlign));
     if (rc) return rc;
     b->files.push_back({*at, len, tag});
+    if (b->keep_sums) b->files.back().sums = b->sum_pool.take(mi_sum::chunks_of(len));
     b->arena_used = *at + len;
     b->total_bytes += len;
     return MI_OK;
@@ -723,7 +749,12 @@ int mi_ctx_create(const mi_config* cfg, mi_ctx** out) {
     if (const char* e = getenv("MI_STAGE_FAULT")) {
         if (!strncmp(e, "copy:", 5)) c->fault_copy = atoll(e + 5);
         if (!strncmp(e, "final:", 6)) c->fault_final = atoll(e + 6);
+        if (!strncmp(e, "readback:", 9)) {
+            c->fault_readback = atoll(e + 9);
+            if (const char* k = strchr(e + 9, ':')) c->fault_readback_n = atoll(k + 1);
+        }
     }
+    c->file_sums = (cfg->flags & MI_FLAG_FILE_SUMS) != 0;
     // Gear table: first 256 outputs of splitmix64(seed)
     u64 table[256];
     u64 st = cfg->gear_seed;
@@ -835,6 +866,7 @@ int mi_batch_begin(mi_ctx* c, uint64_t n_files_hint, uint64_t bytes_hint, mi_bat
     memset(&b->stats, 0, sizeof b->stats);
     memset(&b->stage_stats, 0, sizeof b->stage_stats);
     b->files.reserve(n_files_hint);
+    b->keep_sums = c->file_sums;
     hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
     for (auto& ev : b->ev) if (e == hipSuccess) e = hipEventCreate(&ev);
     if (e == hipSuccess) e = hipHostMalloc((void**)&b->h_counts, 16, hipHostMallocDefault);
@@ -865,11 +897,13 @@ int mi_batch_add_bytes(mi_batch* b, const void* data, uint64_t len, uint64_t use
     if (rc) return rc;
     if (len == 0) return MI_OK;
     const auto t0 = std::chrono::steady_clock::now();
+    mi_sum::FileSum* sums = b->files.back().sums;
     if (len < kInlineBytes) {
+        if (sums) mi_sum::row_add(data, len, 0, sums);           // (the caller's buffer: where these bytes were last known good)
         rc = staging_append(b, at, (const u8*)data, len);
     } else {
         rc = ensure_stager(c);
-        if (!rc) rc = stager_put_bytes(c->stager, b, at, data, len);   // returns when `data` has been consumed
+        if (!rc) rc = stager_put_bytes(c->stager, b, at, data, len, sums);   // returns when `data` has been consumed
         b->staged_any = true;
     }
     b->ms_h2d += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -911,7 +945,7 @@ static int add_file_range(mi_batch* b, const char* path, uint64_t offset, uint64
     if (rc == MI_OK) rc = ensure_stager(c);
     if (rc) { close(fd); return rc; }
     const auto t0 = std::chrono::steady_clock::now();
-    rc = stager_put_file(c->stager, b, at, fd, offset, size, path);       // owns fd from here on
+    rc = stager_put_file(c->stager, b, at, fd, offset, size, path, b->files.back().sums);   // owns fd from here on
     b->staged_any = true;
     b->ms_h2d += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return rc;
@@ -944,13 +978,15 @@ int mi_batch_add_paths(mi_batch* b, uint64_t n, const char* const* paths, const 
     if (rc == MI_OK) rc = ensure_stager(c);
     if (rc) return rc;
     std::vector<u64> at(n);
+    std::vector<mi_sum::FileSum*> sums(b->keep_sums ? n : 0);
     for (u64 i = 0; i < n; ++i) {
         at[i] = align_up(b->arena_used, kFileAlign);
         b->files.push_back({at[i], sizes[i], user_tags ? user_tags[i] : 0});
+        if (b->keep_sums) b->files.back().sums = sums[i] = b->sum_pool.take(mi_sum::chunks_of(sizes[i]));
         b->arena_used = at[i] + sizes[i];
         b->total_bytes += sizes[i];
     }
-    rc = stager_put_paths(c->stager, b, n, paths, at.data(), sizes);
+    rc = stager_put_paths(c->stager, b, n, paths, at.data(), sizes, b->keep_sums ? sums.data() : nullptr);
     b->staged_any = true;
     b->ms_h2d += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return rc;
@@ -979,22 +1015,36 @@ extern "C" int mi_batch_add_block(mi_batch* b, const void* src, uint64_t len, vo
     b->staged_any = true;
     return rc;
 }
+// sums (optional; a batch that keeps sums): 2 words per file -- the (a, b) of mi_filesum.h over the file's bytes as its reader
+// took them out of the file; a placed file is at most one chunk long
 extern "C" int mi_batch_add_placed(mi_batch* b, uint64_t n, const uint64_t* arena_off, const uint64_t* sizes,
-                                   const uint64_t* tags) {
+                                   const uint64_t* tags, const uint64_t* sums) {
     if (!b || (n && (!arena_off || !sizes))) return MI_ERR_INVALID;
     if (b->staged) return fail(b->ctx, MI_ERR_STATE, "batch already ran; begin a new batch");
     for (u64 i = 0; i < n; ++i) {
         if (sizes[i] > b->arena_used || arena_off[i] > b->arena_used - sizes[i])          // (no sum: it could wrap)
             return fail(b->ctx, MI_ERR_INVALID, "mi_batch_add_placed: outside the arena");
         b->files.push_back({arena_off[i], sizes[i], tags ? tags[i] : 0});
+        if (b->keep_sums && sums && sizes[i] <= mi_sum::kChunk) {
+            mi_sum::FileSum* fsum = b->sum_pool.take(1);
+            fsum->a.store(sums[2 * i], std::memory_order_relaxed);
+            fsum->b.store(sums[2 * i + 1], std::memory_order_relaxed);
+            b->files.back().sums = fsum;
+        }
         b->total_bytes += sizes[i];
     }
     return MI_OK;
 }
+extern "C" int mi_batch_keeps_sums(mi_batch* b) { return b && b->keep_sums ? 1 : 0; }
+extern "C" void mi_batch_keep_sums(mi_batch* b, int on) { if (b && b->files.empty()) b->keep_sums = on != 0; }
 
 // Room for what the caller knows is coming: the arena grows ONCE, now, instead of in steps under way -- every growth has
 // to drain the reader threads first (copies in flight target the old arena) and moves what the arena already holds.
-int mi_batch_reserve(mi_batch* b, uint64_t more_files, uint64_t more_bytes) {
+static int batch_reserve(mi_batch* b, uint64_t more_files, uint64_t more_bytes, bool ahead);
+int mi_batch_reserve(mi_batch* b, uint64_t more_files, uint64_t more_bytes) { return batch_reserve(b, more_files, more_bytes, false); }
+// the walk's form (and mi_memfs_reserve_device's): what is coming is known only roughly and keeps growing -- a piecewise arena
+int mi_batch_reserve_ahead(mi_batch* b, uint64_t more_files, uint64_t more_bytes) { return batch_reserve(b, more_files, more_bytes, true); }
+static int batch_reserve(mi_batch* b, uint64_t more_files, uint64_t more_bytes, bool ahead) {
     if (!b) return MI_ERR_INVALID;
     mi_ctx* c = b->ctx;
     HIPCHK(c, hipSetDevice(c->device));
@@ -1003,13 +1053,13 @@ int mi_batch_reserve(mi_batch* b, uint64_t more_files, uint64_t more_bytes) {
     b->files.reserve(b->files.size() + more_files);
     u64 want = align_up(b->arena_used, kFileAlign) + more_bytes + (more_files + 1) * kFileAlign;
     if (guard_alloc()) want = align_up(b->arena_used, kFileAlign) + more_bytes;     // the audit: exactly what was said
-    else if (want + 4096 > b->arena.bytes) {
+    else if ((b->arena.p ? b->arena_plain : !ahead) && want + 4096 > b->arena.bytes) {
         // it has to grow: then by a step worth the drain -- at least twice what there is, at least 64 MiB (a walk that
         // reserves as it enumerates would otherwise grow a 400 MB layer fifteen times)
         const u64 step = 2 * b->arena.bytes > (64ull << 20) ? 2 * b->arena.bytes : (64ull << 20);
         if (want < step) want = step;
     }
-    return arena_reserve(b, want, true);
+    return arena_reserve(b, want, true, ahead);
 }
 
 // A file that is a byte range of another file: a member of an uncompressed layer tar
@@ -1185,6 +1235,8 @@ static int stage_batch(mi_batch* b) {
     if (rc) return rc;
     rc = staging_sync(b);                       // everything the reader threads hold has landed
     if (rc) return rc;
+    rc = arena_wait_mapped(c, &b->arena, b->arena.bytes);   // ... and the kernels may touch the slack behind the last file
+    if (rc) return rc;
     if (!b->stage_err.empty())                  // sticky (a failed final verification, a batch without readers)
         return fail(c, MI_ERR_IO, "%s", b->stage_err.c_str());
     if (c->verify_staging && (rc = stage_verify_final(b))) return rc;
@@ -1337,6 +1389,7 @@ int mi_batch_rerun(mi_batch* b) {
 // Empties the batch for the next set of files; every device allocation (arena, tables) and the
 // pinned window stay, so a host that scans layer after layer pays hipMalloc -- and the driver's
 // clearing of fresh VRAM, which competes with the H2D copies for the SDMA engines -- once.
+static void read_windows_drop(mi_batch* b);
 int mi_batch_reset(mi_batch* b) {
     if (!b) return MI_ERR_INVALID;
     mi_ctx* c = b->ctx;
@@ -1353,6 +1406,7 @@ int mi_batch_reset(mi_batch* b) {
     }
     if (b->tree) { mi_batch_tree_free(b->tree); b->tree = nullptr; }
     b->files.clear();
+    b->sum_pool.clear();
     b->synth.clear();
     b->parts.clear();
     b->cuts_ready = b->parts_dirty = false;
@@ -1363,7 +1417,8 @@ int mi_batch_reset(mi_batch* b) {
     b->ms_h2d = 0;
     b->staged = b->ran = b->results_valid = false;
     b->h_roots_valid = false;
-    b->rb_len = 0;                                      // the window held bytes of the old arena contents
+    read_windows_drop(b);                               // the windows held bytes of the old arena contents
+    b->stage_unordered = false;
     b->n_chunks = b->total_slots = 0;
     b->n_h_files = 0;
     memset(&b->stats, 0, sizeof b->stats);
@@ -1483,11 +1538,42 @@ int mi_batch_roots(mi_batch* b, uint8_t* out, uint64_t cap) {
     return MI_OK;
 }
 
-// Bytes [offset, offset + len) of file `file_index` as they lie in HBM, through a pinned window: a fetch brings more than
-// was asked for (files that were staged together lie together; a layer's files are asked for in nearly that order), and
-// the next fetch's length follows how much of the last one was used -- 256 KiB when a layer picks single files out of a
-// tree, 8 MiB when it streams.
+// Bytes [offset, offset + len) of file `file_index` as they lie in HBM, through pinned windows: a copy brings more than was
+// asked for (files that were staged together lie together; a layer's files are asked for in nearly that order); its length
+// doubles while reads continue where the last window ended -- 256 KiB when a layer picks single files out of a tree, 8 MiB when
+// it streams -- and a reader that streams finds the NEXT range already on its way into the second window: the copy of one
+// overlaps the consumption of the other (round 6: with one window every 1 MiB the tar writer asked for was a copy of 1 MiB it
+// waited for -- 6 192 of them for 48 x 128 MiB -- and while eight reader threads kept PCIe busy each wait was long enough to
+// leave the layer's SHA-256 thread without work: 0.03-0.11 s of a 2.7 s commit, profiles/r06_commit_large_before.txt).
 constexpr u64 kReadWinBytes = 8ull << 20, kReadWinMin = 256ull << 10;
+static int read_windows(mi_batch* b) {
+    mi_ctx* c = b->ctx;
+    if (b->rb[0].p) return MI_OK;
+    HIPCHK(c, hipStreamCreateWithFlags(&b->rb_stream, hipStreamNonBlocking));
+    for (auto& w : b->rb) {
+        HIPCHK(c, hipHostMalloc(&w.p, kReadWinBytes, hipHostMallocDefault));
+        HIPCHK(c, hipEventCreateWithFlags(&w.ev, hipEventDisableTiming));
+        w.len = 0;
+        w.pending = false;
+    }
+    b->rb_next = kReadWinMin;
+    return MI_OK;
+}
+// a copy into a window has completed.  MI_STAGE_FAULT=readback:N[:K] (tests): the N-th .. N+K-1-th arrive with a byte flipped
+static void window_arrived(mi_batch* b, void* p, u64 len) {
+    mi_ctx* c = b->ctx;
+    const long long k = (long long)b->rb_copies++;
+    if (c->fault_readback >= 0 && k >= c->fault_readback && k < c->fault_readback + c->fault_readback_n && len) ((u8*)p)[len / 2] ^= 0x20;
+}
+// nothing of the windows is valid any more (the arena's contents changed); a copy under way is waited for
+static void read_windows_drop(mi_batch* b) {
+    for (auto& w : b->rb) {
+        if (w.pending) (void)hipEventSynchronize(w.ev);
+        w.pending = false;
+        w.len = 0;
+    }
+    b->rb_next = kReadWinMin;
+}
 // while_staging: the caller is the pipelined commit (mi_memfs.hip) -- the batch is still being staged and scanned by another
 // thread; the file's bytes are waited for (stager_wait_landed), nothing else of the batch's state is touched
 static int read_file_impl(mi_batch* b, uint64_t file_index, uint64_t offset, void* dst, uint64_t len, bool while_staging) {
@@ -1503,39 +1589,86 @@ static int read_file_impl(mi_batch* b, uint64_t file_index, uint64_t offset, voi
                     (unsigned long long)len, (unsigned long long)file_index, (unsigned long long)f.size);
     if (!len) return MI_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    if (!b->rb_win) {
-        HIPCHK(c, hipStreamCreateWithFlags(&b->rb_stream, hipStreamNonBlocking));
-        HIPCHK(c, hipHostMalloc(&b->rb_win, kReadWinBytes, hipHostMallocDefault));
-        b->rb_next = kReadWinMin;
-        b->rb_len = 0;
+    {
+        const int rc = read_windows(b);
+        if (rc) return rc;
     }
+    const bool staging = while_staging && c->stager;
+    // the range behind `from` on its way into window `w` (not waited for): as far as the batch's bytes have landed
+    auto prefetch = [&](mi_batch::ReadWin& w, u64 from) -> int {
+        w.len = 0;
+        if (from >= b->arena_used) return MI_OK;
+        u64 want = std::min(b->rb_next, b->arena_used - from);
+        if (staging) {
+            const u64 landed = stager_landed(c->stager, b);
+            if (landed != ~0ull) {
+                if (landed <= from) return MI_OK;
+                want = std::min(want, landed - from);
+            }
+        }
+        HIPCHK(c, hipMemcpyAsync(w.p, b->arena.as<u8>() + from, want, hipMemcpyDeviceToHost, b->rb_stream));
+        HIPCHK(c, hipEventRecord(w.ev, b->rb_stream));
+        w.start = from;
+        w.len = want;
+        w.pending = true;
+        ++b->rb_fetches;
+        b->rb_bytes += want;
+        return MI_OK;
+    };
     u64 at = f.off + offset;
     u8* d = (u8*)dst;
-    ++b->rb_hits;
     while (len) {
-        if (!(b->rb_len && at >= b->rb_start && at < b->rb_start + b->rb_len)) {
-            if (b->rb_len) b->rb_next = b->rb_hits > 2 ? std::min(b->rb_next * 2, kReadWinBytes) : std::max(b->rb_next / 2, kReadWinMin);
+        mi_batch::ReadWin* w = &b->rb[b->rb_cur];
+        if (!(w->len && at >= w->start && at < w->start + w->len)) {
+            mi_batch::ReadWin* nx = &b->rb[b->rb_cur ^ 1];
+            const bool follows = w->len && at == w->start + w->len;     // the reader continues where the window ended: it streams
+            if (nx->len && at >= nx->start && at < nx->start + nx->len) {
+                if (nx->pending) {
+                    const auto tf = std::chrono::steady_clock::now();
+                    HIPCHK(c, hipEventSynchronize(nx->ev));
+                    b->rb_fetch_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - tf).count();
+                    nx->pending = false;
+                    window_arrived(b, nx->p, nx->len);
+                }
+                b->rb_cur ^= 1;
+                if (follows) b->rb_next = std::min(b->rb_next * 2, kReadWinBytes);
+                const int rc = prefetch(*w, nx->start + nx->len);        // the window just left takes what follows the new one
+                if (rc) return rc;
+                continue;
+            }
+            if (nx->pending) { HIPCHK(c, hipEventSynchronize(nx->ev)); nx->pending = false; }
+            nx->len = 0;
+            b->rb_next = follows ? std::min(b->rb_next * 2, kReadWinBytes) : kReadWinMin;
             u64 want = std::max(b->rb_next, std::min(len, kReadWinBytes));
             want = std::min(want, b->arena_used - at);
-            if (while_staging && c->stager) {
+            if (staging) {
                 // what was asked for is waited for; the window then takes what ELSE has landed behind it (the neighbours that
                 // will be asked for next) and nothing that is still on its way
                 const u64 need = std::min(len, std::min(kReadWinBytes, f.off + f.size - at));
                 u64 landed = ~0ull;
+                const auto tw = std::chrono::steady_clock::now();
                 const int rc = stager_wait_landed(c->stager, b, at + need, &landed);
+                b->rb_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
                 if (rc) return rc;
                 if (landed != ~0ull) want = std::min(want, std::max(need, landed > at ? landed - at : 0));
             }
-            HIPCHK(c, hipMemcpyAsync(b->rb_win, b->arena.as<u8>() + at, want, hipMemcpyDeviceToHost, b->rb_stream));
+            const auto tf = std::chrono::steady_clock::now();
+            HIPCHK(c, hipMemcpyAsync(w->p, b->arena.as<u8>() + at, want, hipMemcpyDeviceToHost, b->rb_stream));
             HIPCHK(c, hipStreamSynchronize(b->rb_stream));
-            b->rb_start = at;
-            b->rb_len = want;
-            b->rb_hits = 1;
+            b->rb_fetch_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - tf).count();
+            window_arrived(b, w->p, want);
+            w->start = at;
+            w->len = want;
+            w->pending = false;
             ++b->rb_fetches;
             b->rb_bytes += want;
+            if (follows || want < len) {                                 // streaming (or a read longer than a window): the next range
+                const int rc = prefetch(*nx, at + want);                 // sets out while this one is consumed
+                if (rc) return rc;
+            }
         }
-        const u64 take = std::min(len, b->rb_start + b->rb_len - at);
-        memcpy(d, (const u8*)b->rb_win + (at - b->rb_start), take);
+        const u64 take = std::min(len, w->start + w->len - at);
+        memcpy(d, (const u8*)w->p + (at - w->start), take);
         d += take;
         at += take;
         len -= take;
@@ -1549,6 +1682,44 @@ int mi_batch_read_file_landed(mi_batch* b, uint64_t file_index, uint64_t offset,
     return read_file_impl(b, file_index, offset, dst, len, true);
 }
 
+void mi_batch_read_stats(mi_batch* b, double* wait_s, double* fetch_s, uint64_t* fetches, uint64_t* bytes) {
+    if (wait_s) *wait_s = b ? b->rb_wait_s : 0;
+    if (fetch_s) *fetch_s = b ? b->rb_fetch_s : 0;
+    if (fetches) *fetches = b ? b->rb_fetches : 0;
+    if (bytes) *bytes = b ? b->rb_bytes : 0;
+}
+// the layer writer's check (mi_layer.hip): a file row's chunk sums as they were taken where the bytes were read (NULL: none kept)
+int mi_batch_file_sums(mi_batch* b, uint64_t file_index, const void** sums, uint64_t* n_chunks) {
+    if (!b || !sums || file_index >= b->files.size()) return MI_ERR_INVALID;
+    *sums = b->files[file_index].sums;
+    if (n_chunks) *n_chunks = mi_sum::chunks_of(b->files[file_index].size);
+    return MI_OK;
+}
+void mi_batch_drop_windows(mi_batch* b) { if (b) read_windows_drop(b); }
+// A chunk that came back from HBM with other sums than it went with, twice: WHICH hop?  The chunk once more, by a plain copy
+// into memory of this call's own (not the windows, not their stream): the same sums as at the source -- HBM holds the right
+// bytes and the read-back windows delivered others; other sums -- the arena does not hold what the file had when it was read.
+int mi_batch_explain_chunk(mi_batch* b, uint64_t file_index, uint64_t chunk, char* msg, uint64_t cap) {
+    if (!b || !msg || !cap || file_index >= b->files.size()) return MI_ERR_INVALID;
+    mi_ctx* c = b->ctx;
+    const mi_batch::FileRec& f = b->files[file_index];
+    const u64 off = chunk * mi_sum::kChunk;
+    if (!f.sums || off >= f.size) return MI_ERR_INVALID;
+    const u64 len = std::min(mi_sum::kChunk, f.size - off);
+    std::vector<u8> again(len);
+    (void)hipSetDevice(c->device);
+    const hipError_t e = hipMemcpy(again.data(), b->arena.as<u8>() + f.off + off, len, hipMemcpyDeviceToHost);
+    u64 a = 0, bb = 0;
+    if (e == hipSuccess) mi_sum::chunk_add(again.data(), (size_t)len, 0, &a, &bb);
+    const u64 wa = f.sums[chunk].a.load(), wb = f.sums[chunk].b.load();
+    snprintf(msg, (size_t)cap, "arena [%llu, +%llu) (file %llu, bytes [%llu, +%llu)): sums where the bytes were read %016llx/%016llx; %s",
+             (unsigned long long)(f.off + off), (unsigned long long)len, (unsigned long long)file_index, (unsigned long long)off, (unsigned long long)len,
+             (unsigned long long)wa, (unsigned long long)wb,
+             e != hipSuccess ? "a third copy failed" :
+             a == wa && bb == wb ? "a plain copy out of HBM has them: the arena holds the file's bytes, the hop HBM -> pinned read-back window delivered others, twice"
+                                 : "a plain copy out of HBM has others too: the arena does not hold what the file held when it was read (the hop pinned slab -> HBM, or HBM itself)");
+    return MI_OK;
+}
 int mi_batch_file_size(mi_batch* b, uint64_t file_index, uint64_t* size) {       // (internal: mi_layer.hip)
     if (!b || !size || file_index >= b->files.size() || b->files[file_index].part >= 0) return MI_ERR_INVALID;
     *size = b->files[file_index].size;
@@ -1595,7 +1766,11 @@ int mi_batch_free(mi_batch* b) {
     for (auto e : b->ev) if (e) (void)hipEventDestroy(e);
     if (b->h_counts) (void)hipHostFree(b->h_counts);
     if (b->rows_h) (void)hipHostFree(b->rows_h);
-    if (b->rb_win) (void)hipHostFree(b->rb_win);
+    read_windows_drop(b);
+    for (auto& w : b->rb) {
+        if (w.p) (void)hipHostFree(w.p);
+        if (w.ev) (void)hipEventDestroy(w.ev);
+    }
     if (b->rb_stream) (void)hipStreamDestroy(b->rb_stream);
     if (b->h_files) (void)hipHostFree(b->h_files);
     DevBuf* bufs[] = {&b->root_addr, &b->root_cnt, &b->rseg_cnt, &b->rseg_first, &b->rseg_total,
@@ -1604,12 +1779,13 @@ int mi_batch_free(mi_batch* b) {
                       &b->group_file, &b->group_index, &b->group_recs, &b->tile_lists, &b->tile_fast, &b->large_list,
                       &b->large_group0, &b->seg_file, &b->seg_slot, &b->seg_n, &b->seg_first, &b->seg_group,
                       &b->file_seg0, &b->ends32, &b->tile_file, &b->first_tile, &b->tile_raw, &b->crc_d, &b->ctl, &b->dd_table, &b->dd_slot,
-                      &b->q_off, &b->q_len, &b->q_id,&b->arena, &b->small_list, &b->file_off, &b->file_size, &b->cids,
+                      &b->q_off, &b->q_len, &b->q_id, &b->small_list, &b->file_off, &b->file_size, &b->cids,
                       &b->n_chunks_d, &b->first, &b->scratch,
                       &b->chunk_off, &b->chunk_len, &b->chunk_file, &b->chunk_start, &b->digests, &b->item_off, &b->item_len, &b->roots,
                       &b->file_sha, &b->dup_of, &b->file_flags, &b->part_file, &b->part_group0, &b->part_halo,
                       &b->part_entry, &b->rows_d, &b->file_rows_d, &b->file_base, &b->span_off, &b->span_len, &b->span_sums, &b->dense_list};
     for (DevBuf* d : bufs) d->release();
+    arena_release(&b->arena);
     delete b;
     return MI_OK;
 }

@@ -5,7 +5,9 @@
 #include "../../include/makisu_mi.h"
 #include "mi_common.h"
 #include "mi_local.h"
+#include "mi_filesum.h"
 
+#include <deque>
 #include <memory>
 
 #include <mutex>
@@ -37,6 +39,27 @@ struct DevBuf {
     void release() { if (p) (void)dev_free(p); p = nullptr; bytes = 0; }
     template <typename T> T* as() const { return (T*)p; }
 };
+
+// The arena of a batch (mi_arena.hip): a reserved address range whose front is MAPPED PIECE BY PIECE by a thread of its own, so that
+// an arena that grows never moves (no drain of the reader threads, no device-to-device copy of what it holds) and nobody waits
+// for device memory that is not needed yet: [0, bytes) is PROMISED -- mapped, or about to be; whoever writes or reads device
+// memory at arena offset x first waits for arena_wait_mapped(x).  Under MI_GUARD_ALLOC (the over-read audit) and with
+// MI_ARENA=malloc (A/B measurements) the arena is one dev_alloc that moves when it grows, as it was until round 5 (vm == nullptr).
+struct ArenaVm;
+struct Arena {
+    void* p = nullptr;
+    size_t bytes = 0;
+    ArenaVm* vm = nullptr;
+    template <typename T> T* as() const { return (T*)p; }
+};
+bool arena_is_plain();                                      // MI_GUARD_ALLOC or MI_ARENA=malloc: the moving arena
+// the promise grows to `want` bytes.  outgrown (see arena_outgrown): the caller has drained everything that targets the arena
+int  arena_promise(mi_ctx* c, Arena* a, u64 want);
+bool arena_outgrown(const Arena* a, u64 want);              // `want` does not fit the reserved range: the pieces move to a larger one
+int  arena_wait_mapped(mi_ctx* c, Arena* a, u64 upto, std::string* msg = nullptr);   // MI_ERR_NOMEM when the device ran out under the mapper
+                                                            // (msg: where the message goes instead of the ctx)
+void arena_release(Arena* a);                               // unmaps and frees the pieces; the address range is retired, not reused
+void arena_counts(const Arena* a, u64* mapped, u64* pieces, u64* reserved);
 
 struct SynthSpec { u64 f0, n, seed; std::vector<u64> cids; u64 unit0 = 0; };   // unit0: first 16-byte unit (parts)
 
@@ -72,10 +95,10 @@ struct Stager;
 Stager* stager_create(mi_ctx* c, u32 n_threads, u64 slab_bytes);   // returns at once: the readers set up behind it
 bool    stager_ready(Stager* st);                                   // waits for them; false: none got slab + stream
 void    stager_destroy(Stager* st);
-int     stager_put_bytes(Stager* st, mi_batch* b, u64 arena_off, const void* src, u64 len);
-int     stager_put_file(Stager* st, mi_batch* b, u64 arena_off, int fd, u64 file_off, u64 len, const char* path);
+int     stager_put_bytes(Stager* st, mi_batch* b, u64 arena_off, const void* src, u64 len, mi_sum::FileSum* sums);
+int     stager_put_file(Stager* st, mi_batch* b, u64 arena_off, int fd, u64 file_off, u64 len, const char* path, mi_sum::FileSum* sums);
 int     stager_put_paths(Stager* st, mi_batch* b, u64 n, const char* const* paths, const u64* arena_off,
-                         const u64* len);
+                         const u64* len, mi_sum::FileSum* const* sums);   // sums: NULL, or one pointer per file (the row's chunk sums)
 int     stager_put_block(Stager* st, mi_batch* b, u64 arena_off, const void* src, u64 len, std::shared_ptr<void> keep);
 int     stager_drain(Stager* st, mi_batch* b);
 void    stager_pause(Stager* st, int ms);            // up to `ms` milliseconds, or until a run has landed
@@ -83,6 +106,7 @@ void    stager_pause(Stager* st, int ms);            // up to `ms` milliseconds,
 // queued in arena order), or the batch's staging failed (MI_ERR_IO with the first failure's message)
 // *landed_out (optional): how far the landed prefix reaches by now (~0: everything queued so far)
 int     stager_wait_landed(Stager* st, mi_batch* b, u64 upto, u64* landed_out);
+u64     stager_landed(Stager* st, mi_batch* b);      // the same number, now, without waiting
 
 }  // namespace mi
 
@@ -111,6 +135,9 @@ struct mi_ctx {
     // fault injection for the tests of that flag (MI_STAGE_FAULT=copy:N | final:N): the N-th span a
     // reader copies loses 4 KiB right after its copy / just before the end-of-staging pass
     long long fault_copy = -1, fault_final = -1;
+    // ... and MI_STAGE_FAULT=readback:N[:K]: the N-th (.. N+K-1-th) copy into a read-back window arrives with one byte flipped
+    long long fault_readback = -1, fault_readback_n = 1;
+    bool file_sums = false;              // MI_FLAG_FILE_SUMS: batches of this ctx keep their files' source sums
     mi::CdcParams cdc;
     void* comm = nullptr;                // ncclComm_t when mi_comm_init_* was called (mi_comm.hip)
     int comm_rank = 0, comm_nranks = 1;
@@ -121,7 +148,8 @@ struct mi_ctx {
 
 struct mi_batch {
     mi_ctx* ctx;
-    struct FileRec { mi::u64 off, size, tag; int part = -1; };   // part: index into `parts`
+    struct FileRec { mi::u64 off, size, tag; int part = -1; mi_sum::FileSum* sums = nullptr; };   // part: index into `parts`; sums: per 1 MiB
+                                                                   // chunk, taken where the bytes were read (keep_sums)
     std::vector<FileRec> files;
     std::vector<mi::SynthSpec> synth;
     std::vector<mi::PartRec> parts;          // split files (mi_batch_add_*_part)
@@ -130,7 +158,10 @@ struct mi_batch {
     bool parts_dirty = false;                // a confirmed entry differs from the one the cuts were made with
     mi::u64 total_bytes = 0;     // sum of sizes
     mi::u64 arena_used = 0;      // next free arena offset
-    mi::DevBuf arena;
+    mi::Arena arena;
+    bool keep_sums = false;      // every host-fed file row carries the sums of its bytes as they were READ (mi_filesum.h): what the layer
+    mi_sum::Pool sum_pool;       // writer checks the bytes it frames against (MI_FLAG_FILE_SUMS; always for a MemFS handle's batch)
+    bool arena_plain = false;    // decided when the arena is first made (mi_api.hip arena_reserve): one allocation, or piecewise
     // inline staging window for small mi_batch_add_bytes calls: the batch's OWN two pinned slabs
     // (two batches may be filled at the same time), copied on the batch's own copy stream
     void* ring[2] = {nullptr, nullptr};
@@ -143,6 +174,9 @@ struct mi_batch {
     // reader-thread staging (mi_stage.hip); guarded by the stager's mutex
     mi::u64 stage_pending = 0;   // queued pieces not yet in HBM
     std::multiset<mi::u64> stage_inflight;   // arena offsets at which the runs a reader thread holds right now begin
+    std::deque<mi::u64> stage_queued;        // arena offsets of this batch's queued pieces, in queue order -- ascending (every adder
+                                             // enqueues in arena order; stage_unordered is set if one ever does not): the front is
+    bool stage_unordered = false;            // the lowest offset still queued, which is what stager_wait_landed asks for
     int stage_waiters = 0;       // threads in stager_wait_landed (every landed run wakes them, not just the last)
     std::string stage_err;       // first read / copy / verification error: STICKY until mi_batch_reset
     std::string stage_note;      // what the first verification mismatch looked like (even if repaired)
@@ -189,10 +223,15 @@ struct mi_batch {
     // mi_batch_read_file: the pinned window staged bytes come back through (the layer writer's source when a commit
     // reads its files from HBM instead of a second time from disk)
     hipStream_t rb_stream = nullptr;     // ... on a stream of its own: a read-back does not queue behind the batch's kernels
-    void* rb_win = nullptr;
-    mi::u64 rb_start = 0, rb_len = 0;    // the arena range the window holds now
-    mi::u64 rb_next = 0, rb_hits = 0;    // next fetch's length (adapts to how much of a fetch was asked for), reads served
+    // two windows: the one reads are served from, and the one the NEXT range is on its way into while a streaming reader (the
+    // tar writer) consumes the first -- the writer then never waits for a copy, also while eight reader threads keep PCIe busy
+    struct ReadWin { void* p = nullptr; mi::u64 start = 0, len = 0; bool pending = false; hipEvent_t ev = nullptr; };
+    ReadWin rb[2];
+    int rb_cur = 0;
+    mi::u64 rb_next = 0;                 // next copy's length: doubles while reads continue where the last window ended, else back to the minimum
     mi::u64 rb_fetches = 0, rb_bytes = 0;
+    mi::u64 rb_copies = 0;               // copies into the windows since the ctx was made... per batch (fault injection counts them)
+    double rb_wait_s = 0, rb_fetch_s = 0;   // waited for bytes to land / for the window's copies (MI_LAYER_TIMING)
     std::vector<mi::u8> h_roots;         // mi_batch_roots: the 32 bytes per file isUpdated needs, nothing else
     bool h_roots_valid = false;
 };

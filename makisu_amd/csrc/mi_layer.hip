@@ -31,6 +31,7 @@
 #include "../../include/makisu_mi.h"
 #include "host_sha256.h"
 #include "mi_local.h"             // mi_batch_file_size, mi_last_error_of_batch
+#include "mi_filesum.h"           // the check of bytes that come back from HBM against the sums taken where they were read
 
 #include <errno.h>
 #include <fcntl.h>
@@ -41,6 +42,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <sched.h>
@@ -61,9 +63,15 @@ class Sink {
 public:
     virtual ~Sink() {}
     void start() { th_ = std::thread([this] { run(); }); }
-    void push(const Block& b) {                    // blocks while the sink is 4 blocks behind
+    double idle_s = 0, full_s = 0;                 // MI_LAYER_TIMING: the sink waited for a block / the framer waited for the sink
+    static constexpr size_t kDepth = 8;            // blocks a sink may be behind: one window of a batch's bytes (8 MiB) fits
+    void push(const Block& b) {                    // blocks while the sink is kDepth blocks behind
         std::unique_lock<std::mutex> lk(mu_);
-        cv_.wait(lk, [&] { return q_.size() < 4; });
+        if (q_.size() >= kDepth) {
+            const auto t0 = std::chrono::steady_clock::now();
+            cv_.wait(lk, [&] { return q_.size() < kDepth; });
+            full_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        }
         q_.push_back(b);
         cv_.notify_all();
     }
@@ -99,7 +107,11 @@ private:
             Block b;
             {
                 std::unique_lock<std::mutex> lk(mu_);
-                cv_.wait(lk, [&] { return closed_ || !q_.empty(); });
+                if (!closed_ && q_.empty()) {
+                    const auto t0 = std::chrono::steady_clock::now();
+                    cv_.wait(lk, [&] { return closed_ || !q_.empty(); });
+                    idle_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                }
                 if (q_.empty()) break;
                 b = q_.front();
             }
@@ -491,6 +503,9 @@ struct mi_layer {
     uint64_t n_entries = 0;
     uint64_t files_opened = 0, file_bytes_read = 0;    // what this writer read from disk itself (mi_layer_io_counts)
     bool pipelined = false;                            // batch files are read while the batch is still staged (mi_local.h)
+    mi_batch* timed_batch = nullptr;                   // MI_LAYER_TIMING: the batch whose window this layer read through
+    double read_s = 0;                                 // ... and the seconds the framer spent getting file bytes (either source)
+    std::chrono::steady_clock::time_point t_begin = std::chrono::steady_clock::now();
     bool finished = false, failed = false;
 
     int fail(int code, const char* fmt, ...) {
@@ -503,16 +518,40 @@ struct mi_layer {
         failed = true;
         return code;
     }
-    void flush_block() {
-        if (!cur || cur->empty()) return;
-        Block b = cur;
+    // A chunk of a batch file that has not been held against its source sums yet must not reach the sinks (a SHA-256 stream
+    // cannot be taken back): while `hold` is on, a block that fills up waits in `held` -- a chunk is at most one block long, so
+    // at most one does -- and the chunk can be framed again from its first byte (rewind) after a second fetch from HBM.
+    std::vector<std::shared_ptr<Bytes>> held;
+    bool hold = false;
+    uint64_t n_verified_files = 0, verified_bytes = 0, n_refetched = 0;
+    struct Mark { size_t n_held, cur_size; };
+    Mark mark() const { return Mark{held.size(), cur ? cur->size() : 0}; }
+    void rewind(const Mark& m) {
+        if (held.size() > m.n_held) { cur = held[m.n_held]; held.resize(m.n_held); }
+        if (cur) cur->resize(m.cur_size);
+    }
+    void push_block(const std::shared_ptr<Bytes>& blk) {
+        Block b = blk;
         tar.push(b);                               // the tee: both sinks see the same immutable block
         if (gz) gz->push(b);
+    }
+    void release_hold() {
+        for (auto& blk : held) push_block(blk);
+        held.clear();
+        hold = false;
+    }
+    void flush_block() {
+        if (!cur || cur->empty()) return;
+        push_block(cur);
         cur.reset();
     }
     uint8_t* room(size_t* n) {                     // space in the current block (at most *n bytes)
         if (!cur) { cur = std::make_shared<Bytes>(); cur->reserve(kBlockBytes); }
-        if (cur->size() == kBlockBytes) { flush_block(); cur = std::make_shared<Bytes>(); cur->reserve(kBlockBytes); }
+        if (cur->size() == kBlockBytes) {
+            if (hold) { held.push_back(cur); cur.reset(); } else flush_block();
+            cur = std::make_shared<Bytes>();
+            cur->reserve(kBlockBytes);
+        }
         const size_t left = kBlockBytes - cur->size();
         if (*n > left) *n = left;
         const size_t at = cur->size();
@@ -634,32 +673,71 @@ static int layer_add_entry(mi_layer* l, const mi_tree_entry* e, const char* src_
     if (rc) { if (fd >= 0) close(fd); return rc; }
     if (e->kind == 1) {
         uint64_t left = e->size, off = 0;                       // io.CopyN(w, f, h.Size): exactly Size bytes
+        const auto t_read = std::chrono::steady_clock::now();
+        double pushed0 = l->tar.full_s + (l->gz ? l->gz->full_s : 0);
+        if (batch) l->timed_batch = batch;
+        // A batch file is framed CHUNK BY CHUNK (1 MiB of the file, mi_filesum.h) when the batch kept the sums of its bytes as
+        // they were read: the same sums over what came back from HBM; equal, or the chunk is framed again after a second
+        // fetch, or the layer fails -- io.CopyN's "the bytes or an error" across two PCIe hops.
+        const mi_sum::FileSum* want = nullptr;
+        static const bool verify_on = [] { const char* v = getenv("MI_COMMIT_VERIFY"); return !(v && *v == '0'); }();
+        if (batch && verify_on) { const void* p = nullptr; if (mi_batch_file_sums(batch, batch_file, &p, nullptr) == MI_OK) want = (const mi_sum::FileSum*)p; }
         while (left) {
-            size_t take = left > kBlockBytes ? kBlockBytes : (size_t)left;
-            uint8_t* dst = l->room(&take);
-            if (batch) {
-                const int brc = l->pipelined ? mi_batch_read_file_landed(batch, batch_file, off, dst, take)
-                                             : mi_batch_read_file(batch, batch_file, off, dst, take);
-                if (brc) return l->fail(brc, "copy file %s to tar writer: staged file %llu: %s", h.name.c_str(),
-                                        (unsigned long long)batch_file, mi_last_error_of_batch(batch));
-            } else {
-                size_t got = 0;
-                while (got < take) {
-                    const ssize_t r = pread(fd, dst + got, take - got, (off_t)(off + got));
-                    if (r < 0 && errno == EINTR) continue;
-                    if (r <= 0) {
-                        close(fd);
-                        return l->fail(MI_ERR_IO, "copy file %s to tar writer: %s", src_path,
-                                       r == 0 ? "unexpected EOF" : strerror(errno));
+            const uint64_t chunk_len = want ? std::min<uint64_t>(left, mi_sum::kChunk - off % mi_sum::kChunk) : left;
+            for (int attempt = 0;; ++attempt) {
+                const mi_layer::Mark m = l->mark();
+                if (want) l->hold = true;
+                uint64_t a = 0, b = 0, done = 0;
+                while (done < chunk_len) {
+                    size_t take = chunk_len - done > kBlockBytes ? kBlockBytes : (size_t)(chunk_len - done);
+                    uint8_t* dst = l->room(&take);
+                    if (batch) {
+                        const int brc = l->pipelined ? mi_batch_read_file_landed(batch, batch_file, off + done, dst, take)
+                                                     : mi_batch_read_file(batch, batch_file, off + done, dst, take);
+                        if (brc) return l->fail(brc, "copy file %s to tar writer: staged file %llu: %s", h.name.c_str(),
+                                                (unsigned long long)batch_file, mi_last_error_of_batch(batch));
+                        if (want) mi_sum::chunk_add(dst, take, (size_t)((off + done) % mi_sum::kChunk), &a, &b);
+                    } else {
+                        size_t got = 0;
+                        while (got < take) {
+                            const ssize_t r = pread(fd, dst + got, take - got, (off_t)(off + done + got));
+                            if (r < 0 && errno == EINTR) continue;
+                            if (r <= 0) {
+                                close(fd);
+                                return l->fail(MI_ERR_IO, "copy file %s to tar writer: %s", src_path,
+                                               r == 0 ? "unexpected EOF" : strerror(errno));
+                            }
+                            got += (size_t)r;
+                        }
+                        l->file_bytes_read += take;
                     }
-                    got += (size_t)r;
+                    done += take;
                 }
-                l->file_bytes_read += take;
+                if (!want) break;
+                const uint64_t k = off / mi_sum::kChunk;
+                if (a == want[k].a.load(std::memory_order_relaxed) && b == want[k].b.load(std::memory_order_relaxed)) {
+                    if (attempt) ++l->n_refetched;
+                    l->release_hold();
+                    break;
+                }
+                if (attempt == 0) {                                 // once more, from HBM (not from the window that delivered these)
+                    l->rewind(m);
+                    mi_batch_drop_windows(batch);
+                    continue;
+                }
+                char why[700];
+                why[0] = 0;
+                (void)mi_batch_explain_chunk(batch, batch_file, k, why, sizeof why);
+                return l->fail(MI_ERR_IO, "copy file %s to tar writer: the bytes that came back from HBM are not the bytes that were read from the file "
+                               "(sums %016llx/%016llx, also after a second fetch): %s", h.name.c_str(), (unsigned long long)a, (unsigned long long)b, why);
             }
-            off += take;
-            left -= take;
+            off += chunk_len;
+            left -= chunk_len;
         }
+        if (want) { ++l->n_verified_files; l->verified_bytes += e->size; }
         if (fd >= 0) close(fd);
+        l->read_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_read).count() -
+                     (l->tar.full_s + (l->gz ? l->gz->full_s : 0) - pushed0);
         l->append(nullptr, (size_t)((512 - e->size % 512) % 512));   // tar.Writer pads at the next header
     }
     return l->sink_error();
@@ -685,6 +763,12 @@ int mi_layer_add_batch_file(mi_layer* l, const mi_tree_entry* e, mi_batch* batch
 }
 
 void mi_layer_set_pipelined(mi_layer* l, int on) { if (l) l->pipelined = on != 0; }
+
+void mi_layer_verify_counts(mi_layer* l, uint64_t* files, uint64_t* bytes, uint64_t* refetched) {   // (hidden: mi_local.h)
+    if (files) *files = l ? l->n_verified_files : 0;
+    if (bytes) *bytes = l ? l->verified_bytes : 0;
+    if (refetched) *refetched = l ? l->n_refetched : 0;
+}
 
 int mi_layer_io_counts(mi_layer* l, uint64_t* files_opened, uint64_t* file_bytes_read) {
     if (!l) return MI_ERR_INVALID;
@@ -722,6 +806,16 @@ int mi_layer_finish(mi_layer* l, mi_layer_result* out) {
     if (l->failed) return MI_ERR_STATE;
     int rc = l->sink_error();
     if (rc) return rc;
+    static const bool timing = [] { const char* e = getenv("MI_LAYER_TIMING"); return e && *e == '1'; }();
+    if (timing) {
+        double w = 0, f = 0;
+        uint64_t nf = 0, nb = 0;
+        mi_batch_read_stats(l->timed_batch, &w, &f, &nf, &nb);
+        fprintf(stderr, "mi_layer: %llu tar bytes in %.3f s | framer: %.3f s getting file bytes (from HBM: %.3f s waiting for bytes to land, %.3f s in %llu window "
+                "copies of %llu bytes -- the batch's totals), %.3f s held up by the tar sink%s | tar sink idle %.3f s\n",
+                (unsigned long long)l->tar.bytes, std::chrono::duration<double>(std::chrono::steady_clock::now() - l->t_begin).count(), l->read_s, w, f,
+                (unsigned long long)nf, (unsigned long long)nb, l->tar.full_s, l->gz ? " (+ gzip)" : "", l->tar.idle_s);
+    }
     memset(out, 0, sizeof *out);
     memcpy(out->tar_sha256, l->tar.digest, 32);
     out->tar_bytes = l->tar.bytes;

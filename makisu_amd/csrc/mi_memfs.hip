@@ -1683,6 +1683,11 @@ extern "C" int mi_memfs_add_layer_by_copy_ops(mi_memfs* m, const mi_copy_op* ops
 //     write          the layer writer frames the tar; a regular file's bytes come from HBM -- the very bytes the root
 //                    describes (mi_layer_add_batch_file) -- not from a second read of a file that may have moved on;
 //     index          optionally (mi_memfs_set_index) the batch's chunk digests join the chunk index.
+// MI_COMMIT_VERIFY=0 (measurements): no sums at the source, no check in the layer writer
+static int memfs_verify_on() {
+    static const int on = [] { const char* v = getenv("MI_COMMIT_VERIFY"); return !(v && *v == '0') ? 1 : 0; }();
+    return on;
+}
 static double secs_since(const std::chrono::steady_clock::time_point& t0) {
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
@@ -1713,6 +1718,7 @@ static int memfs_commit_write(mi_memfs* m, mi_copy_layer* cl, uint64_t ne, const
         mi_layer_io_counts(lw, &o, &by);
         m->last.files_opened += o;
         m->last.file_bytes_read += by;
+        mi_layer_verify_counts(lw, &m->last.n_verified_files, &m->last.verified_bytes, &m->last.n_refetched);
         mi_layer_free(lw);
     }
     return rc;
@@ -1792,31 +1798,11 @@ extern "C" int mi_memfs_commit_layer(mi_memfs* m, mi_ctx* ctx, int must_scan, co
         if (m->batch) rc = mi_batch_reset(m->batch);
         else { rc = mi_batch_begin(ctx, 0, 0, &m->batch); m->batch_ctx = ctx; }
         if (rc) return fail_with(rc, std::string("gpu scan: ") + mi_last_error(ctx));
+        mi_batch_keep_sums(m->batch, memfs_verify_on());                          // the tar is framed from HBM: held against what was read
         b = m->batch;
-        // A first content scan of a tree the handle already knows (the base image's layers were merged: FROM, then RUN): what the
-        // walk will stage is about what the tree lists -- the arena is made ONCE, for that, instead of growing in steps while the
-        // walk finds out (each step drains the reader threads, moves what the arena holds, and on boxes whose driver charges
-        // fresh device memory by the byte -- 47-68 ms per GiB, tools/first_use_probe.py -- pays for every step's full size:
-        // a 15 GB tree grew 75 MB -> 22 GB in eight steps, 40 GB allocated in all).  Not when inodes are trusted and the tree
-        // has been hashed before (little will be staged); a reservation the device refuses is no error (the walk grows what it
-        // needs, or the commit goes window by window).
-        uint64_t arena_now = 0;
-        mi_batch_arena_room(b, &arena_now);
-        if (must_scan && arena_now == 0 && !(fs.trust_ctime && !fs.hashed.empty()) && !m->went_windowed) {
-            uint64_t files = 0, bytes = 0;
-            std::vector<const mi_memtree::Node*> todo{&fs.t.root};
-            while (!todo.empty()) {
-                const mi_memtree::Node* n = todo.back();
-                todo.pop_back();
-                for (const auto& kv : n->children) {
-                    const mi_memtree::Node* c = kv.second.get();
-                    if (c->kind == 1 && c->ref >= 0) { ++files; bytes += fs.nodes[(size_t)c->ref].e.size; }
-                    if (!c->children.empty()) todo.push_back(c);
-                }
-            }
-            if (files && bytes >= (64ull << 20) && bytes <= (256ull << 30) && mi_batch_reserve(b, files, bytes) != MI_OK)
-                (void)mi_batch_reset(b);
-        }
+        // (Until round 5 a first content scan of a tree the handle already knew reserved the arena here, once, for what the tree
+        //  lists: an arena that grew in steps drained the reader threads and moved every time.  The arena no longer moves --
+        //  mi_arena.hip: an address range mapped piece by piece behind the walk -- so there is nothing to prepare.)
     }
     // PIPELINED (default; MI_COMMIT_PIPELINE=0: one phase after the other): the scan -- the end of staging, the kernels, the
     // roots' way back -- runs on a thread of its own (ScanJob) while this thread computes the layer and frames the tar from
@@ -2042,13 +2028,14 @@ extern "C" int mi_memfs_reserve_device(mi_memfs* m, mi_ctx* ctx, uint64_t files,
     if (!m || !ctx) return MI_ERR_INVALID;
     int rc = MI_OK;
     if (m->batch && m->batch_ctx != ctx) { mi_batch_free(m->batch); m->batch = nullptr; }
-    if (!m->batch) {
-        rc = mi_batch_begin(ctx, files, bytes, &m->batch);
+    if (!m->batch) {                                                              // (a commit's arena is the piecewise kind: a guess
+        rc = mi_batch_begin(ctx, files, 0, &m->batch);                            //  that is too small costs nothing later)
         m->batch_ctx = ctx;
+        if (!rc) mi_batch_keep_sums(m->batch, memfs_verify_on());
     } else {
         rc = mi_batch_reset(m->batch);
-        if (!rc) rc = mi_batch_reserve(m->batch, files, bytes);
     }
+    if (!rc) rc = mi_batch_reserve_ahead(m->batch, files, bytes);
     if (!rc) mi_batch_expect_host_bytes(m->batch);                                // (the reader threads set up behind the call)
     if (rc) m->err = std::string("reserve device memory: ") + mi_last_error(ctx);
     return rc;

@@ -60,6 +60,8 @@ struct StageItem {
     u64 file_off;
     StageLatch* latch;
     std::shared_ptr<void> keep;          // owner of `src` for blocks handed over for good (stager_put_block)
+    mi_sum::FileSum* sums = nullptr;     // the file row's chunk sums (mi_filesum.h), or nullptr; this piece is bytes
+    u64 row_off = 0;                     // [row_off, row_off + len) of that row
 };
 
 // Files per run: a slab of tiny files would otherwise be ONE thread's work for milliseconds (2 048
@@ -169,6 +171,17 @@ void launch_stage_sums(const u8* base, const u64* d_off, const u64* d_len, u64 n
 
 namespace {
 
+// the batch's own record of what it has queued (under the stager's mutex): pieces leave the queue in the order they came
+void f_batch_push(const StageItem& it) {
+    mi_batch* b = it.batch;
+    if (!b->stage_queued.empty() && it.arena_off < b->stage_queued.back()) b->stage_unordered = true;
+    b->stage_queued.push_back(it.arena_off);
+}
+void f_batch_pop(const StageItem& it) {
+    mi_batch* b = it.batch;
+    if (!b->stage_queued.empty()) b->stage_queued.pop_front();
+}
+
 // the item's source bytes sit in a pinned slab: a blocking adder may return (cgo pointer rule)
 void item_consumed(const StageItem& it) {
     if (!it.latch) return;
@@ -249,6 +262,7 @@ void worker(Stager* st, u32 tid) {
                 prev_end = f.arena_off + f.len;
                 run.push_back(f);
                 st->queue.pop_front();
+                f_batch_pop(run.back());
             }
             run.front().batch->stage_inflight.insert(start);    // (taken back when the run has landed: stager_wait_landed)
         }
@@ -262,6 +276,7 @@ void worker(Stager* st, u32 tid) {
             if (it.arena_off > end) memset((u8*)slab + (end - start), 0, it.arena_off - end);   // alignment gap
             if (it.src) {
                 memcpy(dst, it.src, it.len);
+                if (it.sums) mi_sum::row_add(dst, it.len, it.row_off, it.sums);
             } else {
                 // a deferred file (bulk adds, tree walks) is opened HERE, by one of several threads
                 int fd;
@@ -287,6 +302,9 @@ void worker(Stager* st, u32 tid) {
                     got += (u64)r;
                 }
                 it.file->piece_read();
+                // the sums of the bytes as read() delivered them, taken in the pinned slab before the DMA sees it: what the
+                // layer writer will hold against the bytes that come back from HBM
+                if (it.sums && err.empty()) mi_sum::row_add(dst, it.len, it.row_off, it.sums);
             }
             end = it.arena_off + it.len;
         }
@@ -296,6 +314,10 @@ void worker(Stager* st, u32 tid) {
         double ms_verify = 0;
         u64 mism = 0, repaired = 0;
         std::string note;
+        if (err.empty() && span) {                               // the arena's memory behind this span: mapped by now, nearly always
+            std::string m;
+            if (arena_wait_mapped(c, &b->arena, start + span, &m) != MI_OK) err = "device memory for the staged bytes: " + m;
+        }
         if (err.empty() && span) {
             u8* dev = (u8*)b->arena.p + start;
             auto copy = [&]() -> hipError_t {
@@ -418,11 +440,11 @@ void stager_destroy(Stager* st) {
 
 // Queues [arena_off, +len) of the batch's arena, split into pieces of at most one slab.
 static void enqueue(Stager* st, mi_batch* b, u64 arena_off, u64 len, const u8* src,
-                    const std::shared_ptr<StageFile>& file, u64 file_off, StageLatch* latch) {
+                    const std::shared_ptr<StageFile>& file, u64 file_off, StageLatch* latch, mi_sum::FileSum* sums) {
     std::vector<StageItem> items;
     for (u64 done = 0; done < len;) {
         const u64 take = len - done < st->slab_bytes ? len - done : st->slab_bytes;
-        items.push_back({b, arena_off + done, take, src ? src + done : nullptr, file, file_off + done, latch});
+        items.push_back({b, arena_off + done, take, src ? src + done : nullptr, file, file_off + done, latch, nullptr, sums, done});
         done += take;
     }
     if (latch) latch->left = items.size();
@@ -430,26 +452,26 @@ static void enqueue(Stager* st, mi_batch* b, u64 arena_off, u64 len, const u8* s
     {
         std::lock_guard<std::mutex> g(st->mu);
         b->stage_pending += items.size();
-        for (auto& it : items) st->queue.push_back(std::move(it));
+        for (auto& it : items) { f_batch_push(it); st->queue.push_back(std::move(it)); }
     }
     if (items.size() == 1) st->cv_work.notify_one();      // one small file: one reader, not the whole pool
     else st->cv_work.notify_all();
 }
 
-int stager_put_bytes(Stager* st, mi_batch* b, u64 arena_off, const void* src, u64 len) {
+int stager_put_bytes(Stager* st, mi_batch* b, u64 arena_off, const void* src, u64 len, mi_sum::FileSum* sums) {
     if (len == 0) return MI_OK;
     StageLatch latch;
-    enqueue(st, b, arena_off, len, (const u8*)src, nullptr, 0, &latch);
+    enqueue(st, b, arena_off, len, (const u8*)src, nullptr, 0, &latch, sums);
     std::unique_lock<std::mutex> lk(latch.mu);
     latch.cv.wait(lk, [&] { return latch.left == 0; });          // the engine never retains caller memory
     return MI_OK;
 }
 
-int stager_put_file(Stager* st, mi_batch* b, u64 arena_off, int fd, u64 file_off, u64 len, const char* path) {
+int stager_put_file(Stager* st, mi_batch* b, u64 arena_off, int fd, u64 file_off, u64 len, const char* path, mi_sum::FileSum* sums) {
     auto f = std::make_shared<StageFile>();
     f->fd = fd;
     f->path = path ? path : "";
-    if (len) enqueue(st, b, arena_off, len, nullptr, f, file_off, nullptr);
+    if (len) enqueue(st, b, arena_off, len, nullptr, f, file_off, nullptr, sums);
     return MI_OK;
 }
 
@@ -467,7 +489,7 @@ int stager_put_block(Stager* st, mi_batch* b, u64 arena_off, const void* src, u6
     {
         std::lock_guard<std::mutex> g(st->mu);
         b->stage_pending += items.size();
-        for (auto& it : items) st->queue.push_back(std::move(it));
+        for (auto& it : items) { f_batch_push(it); st->queue.push_back(std::move(it)); }
     }
     if (len > st->slab_bytes) st->cv_work.notify_all();        // several pieces: several readers
     else st->cv_work.notify_one();
@@ -476,7 +498,7 @@ int stager_put_block(Stager* st, mi_batch* b, u64 arena_off, const void* src, u6
 
 // n whole files that the reader threads open themselves: one lock, one wake-up for all of them
 int stager_put_paths(Stager* st, mi_batch* b, u64 n, const char* const* paths, const u64* arena_off,
-                     const u64* len) {
+                     const u64* len, mi_sum::FileSum* const* sums) {
     std::vector<StageItem> items;
     items.reserve(n);
     for (u64 i = 0; i < n; ++i) {
@@ -486,7 +508,7 @@ int stager_put_paths(Stager* st, mi_batch* b, u64 n, const char* const* paths, c
         f->path = paths[i];
         for (u64 done = 0; done < len[i];) {
             const u64 take = len[i] - done < st->slab_bytes ? len[i] - done : st->slab_bytes;
-            items.push_back({b, arena_off[i] + done, take, nullptr, f, done, nullptr});
+            items.push_back({b, arena_off[i] + done, take, nullptr, f, done, nullptr, nullptr, sums ? sums[i] : nullptr, done});
             done += take;
             ++f->pieces_left;
         }
@@ -495,7 +517,7 @@ int stager_put_paths(Stager* st, mi_batch* b, u64 n, const char* const* paths, c
     {
         std::lock_guard<std::mutex> g(st->mu);
         b->stage_pending += items.size();
-        for (auto& it : items) st->queue.push_back(std::move(it));
+        for (auto& it : items) { f_batch_push(it); st->queue.push_back(std::move(it)); }
     }
     st->cv_work.notify_all();
     return MI_OK;
@@ -522,24 +544,36 @@ void stager_pause(Stager* st, int ms) {
     --st->pausers;
 }
 
+// everything of the batch below this arena offset has landed (~0: everything queued so far); under the stager's mutex.
+// The batch keeps the offsets of its queued pieces itself (stage_queued): no walk over the ctx's queue, in which another
+// batch may have thousands of pieces, under the lock every reader thread needs.
+static u64 landed_upto(Stager* st, mi_batch* b) {
+    u64 m = b->stage_inflight.empty() ? ~0ull : *b->stage_inflight.begin();
+    if (b->stage_unordered) {                                  // (an adder that did not enqueue in arena order: the slow, safe way)
+        for (const StageItem& it : st->queue) if (it.batch == b && it.arena_off < m) m = it.arena_off;
+    } else if (!b->stage_queued.empty() && b->stage_queued.front() < m) {
+        m = b->stage_queued.front();
+    }
+    return m;
+}
+
 int stager_wait_landed(Stager* st, mi_batch* b, u64 upto, u64* landed_out) {
     std::string msg;
     {
         std::unique_lock<std::mutex> lk(st->mu);
-        auto landed_upto = [&]() -> u64 {                       // everything below this arena offset has landed
-            u64 m = b->stage_inflight.empty() ? ~0ull : *b->stage_inflight.begin();
-            for (const StageItem& it : st->queue)               // (a batch's pieces are queued in arena order: its first one)
-                if (it.batch == b) { if (it.arena_off < m) m = it.arena_off; break; }
-            return m;
-        };
         ++b->stage_waiters;
-        st->cv_done.wait(lk, [&] { return !b->stage_err.empty() || landed_upto() >= upto; });
+        st->cv_done.wait(lk, [&] { return !b->stage_err.empty() || landed_upto(st, b) >= upto; });
         --b->stage_waiters;
         msg = b->stage_err;
-        if (landed_out) *landed_out = landed_upto();            // (~0: everything queued so far)
+        if (landed_out) *landed_out = landed_upto(st, b);
     }
     if (!msg.empty()) return fail(b->ctx, MI_ERR_IO, "%s", msg.c_str());
     return MI_OK;
+}
+
+u64 stager_landed(Stager* st, mi_batch* b) {
+    std::lock_guard<std::mutex> g(st->mu);
+    return landed_upto(st, b);
 }
 
 // MI_FLAG_VERIFY_STAGING, when staging ends: every span this batch ever copied is summed again

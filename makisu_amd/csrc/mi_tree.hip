@@ -32,6 +32,7 @@
 // (mi_snapshot_diff) and the layer merge (mi_entries_apply_layer).  MemFS itself, the copy ops and what surrounds a
 // COPY step: mi_memfs.hip.
 #include "mi_memtree.h"
+#include "mi_filesum.h"     // the sums of a small file's bytes, taken where the directory reader read them
 
 #include <dirent.h>
 #include <errno.h>
@@ -122,25 +123,27 @@ struct Walker {
 
     // files whose bytes a directory reader already read (ParallelWalker::read_dir) and that lie in the arena as part of
     // their directory's block: table rows only
-    std::vector<uint64_t> place_off, place_size, place_tag;
+    std::vector<uint64_t> place_off, place_size, place_tag, place_sum;   // place_sum: 2 words per file (mi_filesum.h), or empty
 
     // the arena is sized for what the enumeration has seen, which runs ahead of what has been handed over
     bool reserve_ahead() {
         if (!ahead_files) return true;
         const uint64_t f = ahead_files->load(std::memory_order_relaxed), by = ahead_bytes->load(std::memory_order_relaxed);
         if (f > handed_files || by > handed_bytes) {
-            const int r = mi_batch_reserve(batch, f > handed_files ? f - handed_files : 0, by > handed_bytes ? by - handed_bytes : 0);
+            const int r = mi_batch_reserve_ahead(batch, f > handed_files ? f - handed_files : 0, by > handed_bytes ? by - handed_bytes : 0);
             if (r && !rc) { rc = r; return false; }
         }
         return true;
     }
     void flush_placed() {
         if (place_off.empty() || !batch) return;
-        const int r = mi_batch_add_placed(batch, place_off.size(), place_off.data(), place_size.data(), place_tag.data());
+        const int r = mi_batch_add_placed(batch, place_off.size(), place_off.data(), place_size.data(), place_tag.data(),
+                                          place_sum.size() == 2 * place_off.size() ? place_sum.data() : nullptr);
         if (r && !rc) rc = r;
         place_off.clear();
         place_size.clear();
         place_tag.clear();
+        place_sum.clear();
     }
     // one directory's block (its small files, laid out as they are to lie in the arena) becomes a piece of the arena
     bool place_block(const std::shared_ptr<uint8_t[]>& blob, uint64_t len, uint64_t n_files, uint64_t* at) {
@@ -186,8 +189,9 @@ struct Walker {
     // plus its name; filepath.Rel per entry costs more than the lstat it follows)
     // placed (optional): the file's bytes are in the arena already, at this offset (its directory's block)
     // known (optional): the answer content_known already gave for this file (the parallel walk asks where it stats)
+    // sum (with placed, optional): the file's (a, b) of mi_filesum.h as its reader computed them
     void emit(const std::string& path, const struct stat& st, const std::string* link, const std::string* rel = nullptr,
-              const uint64_t* placed = nullptr, const uint8_t* known = nullptr) {
+              const uint64_t* placed = nullptr, const uint8_t* known = nullptr, const uint64_t* sum = nullptr) {
         Entry e;
         e.relpath = rel ? *rel : rel_to(rel_base, path);
         if (e.relpath.empty()) {
@@ -237,6 +241,7 @@ struct Walker {
                     place_off.push_back(*placed);
                     place_size.push_back(e.size);
                     place_tag.push_back(tree->entries.size());
+                    if (sum) { place_sum.push_back(sum[0]); place_sum.push_back(sum[1]); }
                     if (place_off.size() >= 4096) flush_placed();
                 } else {
                     flush_placed();
@@ -302,6 +307,7 @@ struct Child {
     int rc = MI_OK;                      // this path's own failure (lstat / readlink / skip-rule / read error)
     std::string err;
     uint64_t blob_off = ~0ull;           // a regular file that was read where it was listed: its place in the directory's block
+    uint64_t sum[2] = {0, 0};            // ... and the sums of its bytes as read() delivered them (mi_filesum.h; a batch that keeps sums)
     std::unique_ptr<DirRec> sub;         // a directory that is entered
 };
 struct DirRec {
@@ -334,7 +340,8 @@ static uint64_t inline_file_max() {
     static const uint64_t v = [] {
         const char* e = getenv("MI_WALK_INLINE_MAX_KIB");
         const long kib = e && *e ? atol(e) : 16;
-        return kib <= 0 ? 0ull : (uint64_t)kib << 10;
+        const uint64_t v = kib <= 0 ? 0ull : (uint64_t)kib << 10;
+        return v > mi_sum::kChunk ? mi_sum::kChunk : v;          // (a file read in place carries ONE chunk's sums)
     }();
     return v;
 }
@@ -511,6 +518,7 @@ struct ParallelWalker {
     size_t outstanding = 0;              // directories queued or being read
     bool abort = false;                  // the assembly stopped (an error): the readers only drain
     bool inline_reads = false;           // a batch is attached: small files are read where they are listed
+    bool want_sums = false;              // ... and it keeps its files' source sums (mi_batch_keeps_sums)
     static thread_local bool own_table;  // this directory reader left the process's descriptor table (worker())
     static uint64_t fd_budget() {        // descriptors a thread may hold at once (its table's soft limit)
         static const uint64_t v = [] {
@@ -694,6 +702,7 @@ struct ParallelWalker {
                 got += (uint64_t)r;
             }
             close(fd);
+            if (want_sums && !c.rc) mi_sum::chunk_add(buf + c.blob_off, (size_t)c.size, 0, &c.sum[0], &c.sum[1]);
         }
     }
 
@@ -792,7 +801,7 @@ struct ParallelWalker {
             }
             const uint64_t placed = block_at + (c.blob_off == ~0ull ? 0 : c.blob_off);
             w->emit(path, st, S_ISLNK(c.mode) ? &c.link : nullptr, &crel, c.blob_off == ~0ull ? nullptr : &placed,
-                    S_ISREG(c.mode) ? &c.known : nullptr);
+                    S_ISREG(c.mode) ? &c.known : nullptr, c.blob_off != ~0ull && want_sums ? c.sum : nullptr);
             if (w->rc) return;
             if (c.sub) { assemble(c.sub.get(), crel); if (w->rc) return; }
         }
@@ -833,6 +842,7 @@ static void walk_root(Walker* w, const std::string& root) {
     if (w->batch && inline_budget()) {
         const char* e = getenv("MI_WALK_INLINE");
         pw.inline_reads = !(e && *e == '0');
+        pw.want_sums = mi_batch_keeps_sums(w->batch) != 0;
     }
     struct PoolUse { bool on; PoolUse(bool o) : on(o) { if (on) block_pool().walk_begins(); } ~PoolUse() { if (on) block_pool().walk_ends(); } }
         pool_use(pw.inline_reads);                                  // (blocks still with the reader threads come back under the idle limit)

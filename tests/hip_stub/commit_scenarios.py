@@ -246,11 +246,18 @@ def scenario_trust_wide(tmp, eng):
 
 
 def scenario_known_tree(tmp, eng):
-    """FROM, then RUN: the handle has merged the base image's layers, so its first content scan knows about what it will stage --
-    the arena is made once, for that, instead of growing while the walk finds out (the double counts allocations of a MiB and more)"""
+    """THE ARENA NEVER MOVES (mi_arena.hip).  A handle that knows nothing about its tree, a sequential walk (no enumeration runs
+    ahead: the arena learns the tree's size 1 024 files at a time) and 262 MB of files: until round 5 that was three arenas in
+    steps -- each one a drain of the reader threads and a copy of what the last one held; now it is ONE address range whose front
+    is mapped piece by piece, and nothing of a MiB or more is hipMalloc'ed for it.  The same with the range reserved too small
+    (MI_ARENA_RANGE_MB: the pieces are mapped again in a larger range -- they still hold their bytes) and with a mapper that takes
+    2 ms per MiB (MI_HIP_STUB_MAP_US: a box that charges fresh device memory by the byte; readers and tar writer wait where they
+    touch memory the mapper has not reached).  Every variant: the layer tar holds every file's bytes."""
     import ctypes
-    big_mallocs = ctypes.CDLL(None).mi_hip_stub_big_mallocs
-    big_mallocs.restype = ctypes.c_long
+    lib = ctypes.CDLL(None)
+    big_mallocs, vm_ranges, vm_pieces = lib.mi_hip_stub_big_mallocs, lib.mi_hip_stub_vm_ranges, lib.mi_hip_stub_vm_pieces
+    for f in (big_mallocs, vm_ranges, vm_pieces):
+        f.restype = ctypes.c_long
     root = os.path.join(tmp, "known_root")
     rng = np.random.default_rng(5)
     entries, files = [], {}
@@ -264,7 +271,6 @@ def scenario_known_tree(tmp, eng):
             entries.append({"relpath": rel, "kind": M.KIND_FILE, "mode": 0o100644, "mtime_sec": MTIME, "size": len(data)})
     for d in range(40):
         os.utime(os.path.join(root, "k%02d" % d), (MTIME, MTIME))
-    counts = {}
     before = os.environ.get("MI_WALK_THREADS")
     os.environ["MI_WALK_THREADS"] = "1"                                   # (the sequential walk: no enumeration runs ahead of what is
     try:                                                                  #  staged, the arena learns the tree's size file by file)
@@ -272,22 +278,75 @@ def scenario_known_tree(tmp, eng):
             with M.MemFS(root) as fs:
                 if name == "merged":
                     assert fs.update_from_entries(entries) == len(entries)
-                n0 = big_mallocs()
+                n0, r0, p0 = big_mallocs(), vm_ranges(), vm_pieces()
                 res, raw = commit_to_bytes(fs, tmp, "k_%s.tar" % name, must_scan=True, engine=eng)
-                counts[name] = big_mallocs() - n0
                 st = res["stats"]
                 assert st["n_scanned_files"] == len(files) and st["files_opened"] == len(files)
+                ranges, pieces = vm_ranges() - r0, vm_pieces() - p0
+                if os.environ.get("MI_ARENA_RANGE_MB"):
+                    assert ranges >= 2, "a range of %s MiB holds 262 MB?" % os.environ["MI_ARENA_RANGE_MB"]     # (outgrown: a larger one)
+                else:
+                    assert ranges == 1, "the arena moved: %d address ranges" % ranges
+                assert pieces >= 2 and pieces * (2 << 20) >= 262_144_000 // 128, pieces                          # mapped in pieces
                 if name == "fresh":
                     assert {n: d for n, m, d in tar_members(raw) if m.isfile()} == files
                 else:
                     assert res["n_entries"] == 0 and st["n_roots_learned"] == len(files)      # the headers are the merged ones: nothing new
+            assert vm_pieces() == p0, "the handle is closed: its arena's pieces are given back"
     finally:
         if before is None:
             del os.environ["MI_WALK_THREADS"]
         else:
             os.environ["MI_WALK_THREADS"] = before
-    assert counts["merged"] < counts["fresh"], counts                     # (262 MB, handed over 1 024 files at a time: three arenas in steps, or one)
     print("OK known_tree")
+
+
+def scenario_verify(tmp, eng):
+    """END-TO-END BYTE SUMS (mi_filesum.h).  The commit frames the tar from bytes that crossed PCIe twice; every
+    file the writer takes out of HBM is held, 1 MiB chunk by chunk, against sums taken where the bytes were READ.  MI_VERIFY_CASE:
+        clean      nothing is wrong: every layer file verified, nothing fetched twice; the reference's tar
+        readback1  MI_STAGE_FAULT=readback:N -- ONE copy into a read-back window arrives with a flipped byte: the chunk is fetched
+                   again and is right; the commit succeeds, n_refetched = 1, the tar is the reference's
+        readback3  readback:N:3 -- the second fetch is wrong too: MI_ERR_IO naming the file, the arena range and the hop
+                   "HBM -> pinned read-back window" (a third, plain copy finds the arena right)
+        copy       MI_STAGE_FAULT=copy:N -- a staged span loses 4 KiB in HBM right after its copy: no second fetch can help;
+                   MI_ERR_IO naming the hop "pinned slab -> HBM"
+    A tree of files whose sizes are multiples of 256 (no alignment gaps: a flipped byte always lies in some file) that take both
+    ways into the arena -- directory blocks and paths, several chunks, sizes that are not multiples of 8 do not exist here but do
+    in every other scenario, which all run with the check on."""
+    case = os.environ.get("MI_VERIFY_CASE", "clean")
+    root = os.path.join(tmp, "verify_root")
+    rng = np.random.default_rng(77)
+    files = {}
+    for d in range(3):
+        for k, size in enumerate((256, 4096, 12_288, 3 << 20, 1_048_576 + 512, 700_160)):
+            rel = "v%d/f%d.bin" % (d, k)
+            data = rng.integers(1, 256, size, dtype=np.uint8).tobytes()       # (no zero bytes: a range that reads as zeros differs)
+            write_file(os.path.join(root, rel), data, 0o644, MTIME)
+            files[rel] = data
+    for dp, dns, fns in os.walk(root):
+        os.utime(dp, (MTIME, MTIME))
+    with M.MemFS(root) as plain:
+        _, want = commit_to_bytes(plain, tmp, "vp.tar", must_scan=True)
+    with M.MemFS(root) as fs:
+        if case in ("clean", "readback1"):
+            res, raw = commit_to_bytes(fs, tmp, "v.tar", must_scan=True, engine=eng)
+            st = res["stats"]
+            assert raw == want, "the tar is not the reference's"
+            assert st["n_verified_files"] == len(files) == st["n_layer_files"], st
+            assert st["verified_bytes"] == sum(map(len, files.values())), st
+            assert st["n_refetched"] == (1 if case == "readback1" else 0), st
+        else:
+            try:
+                commit_to_bytes(fs, tmp, "v.tar", must_scan=True, engine=eng)
+            except M.MiError as e:
+                msg = str(e)
+                assert "MI_ERR_IO" in msg and "copy file v" in msg and "arena [" in msg and "sums where the bytes were read" in msg, msg
+                hop = "HBM -> pinned read-back window" if case == "readback3" else "pinned slab -> HBM"
+                assert hop in msg, msg
+            else:
+                raise AssertionError("a commit whose bytes changed on the way produced a layer")
+    print("OK verify " + case)
 
 
 def scenario_slash(tmp, eng):
@@ -427,6 +486,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 3 and sys.argv[3] == "known_tree":
         with M.Engine(n_streams=int(sys.argv[2]), staging_bytes=1 << 20) as eng:
             scenario_known_tree(sys.argv[1], eng)
+        sys.exit(0)
+    if len(sys.argv) > 3 and sys.argv[3] == "verify":
+        with M.Engine(n_streams=int(sys.argv[2]), staging_bytes=1 << 20) as eng:
+            scenario_verify(sys.argv[1], eng)
         sys.exit(0)
     if len(sys.argv) > 3 and sys.argv[3] == "trust_wide":
         with M.Engine(n_streams=int(sys.argv[2]), staging_bytes=1 << 20) as eng:

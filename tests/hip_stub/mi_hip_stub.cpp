@@ -19,15 +19,23 @@
 //     launch take n microseconds of stream time, to move the interleavings;
 //   * MI_HIP_STUB_COPY_US=<n>: every queued copy sleeps n microseconds before it copies (widens race windows).
 //   * MI_HIP_STUB_MALLOC_LIMIT_MB=<n>: hipMalloc of more than n MiB fails with hipErrorOutOfMemory (a tree larger than the device).
+//   * the virtual-memory calls (the arena, mi_arena.hip): hipMemAddressReserve = mmap(PROT_NONE); a physical piece (hipMemCreate)
+//     is a memfd filled with 0xDD, hipMemMap maps it MAP_FIXED | MAP_SHARED into the range, hipMemUnmap puts PROT_NONE back --
+//     so a byte touched before the mapper got there, or after the pieces were let go of, is a SEGFAULT here, not a plausible
+//     value, and a piece that is mapped again elsewhere (an arena that outgrew its range) still holds its bytes.  With MI_HIP_STUB_MALLOC_LIMIT_MB the pieces of all arenas together
+//     may not exceed n MiB (hipMemCreate fails beyond, hipMemGetInfo reports what is left).  MI_HIP_STUB_MAP_US=<n>: every
+//     hipMemCreate takes n microseconds per MiB (a box whose driver charges fresh device memory by the byte).
 #include <hip/hip_runtime_api.h>
 
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 #include <unistd.h>
 
 #include <atomic>
+#include <map>
 #include <condition_variable>
 #include <deque>
 #include <functional>
@@ -107,6 +115,11 @@ struct LaunchCfg { dim3 grid, block; size_t shmem; hipStream_t stream; };
 thread_local LaunchCfg t_cfg;
 thread_local int t_device = 0;
 
+const long kMapUs = env_us("MI_HIP_STUB_MAP_US");
+const long kLimitMb = env_us("MI_HIP_STUB_MALLOC_LIMIT_MB");
+std::atomic<long long> g_vm_bytes{0};                 // physical pieces alive (hipMemCreate - hipMemRelease)
+std::atomic<long> g_vm_pieces{0}, g_vm_ranges{0};
+struct VmHandle { size_t bytes; int fd; };
 std::atomic<long> g_live_allocs{0};
 std::atomic<long> g_big_mallocs{0};                  // hipMalloc calls of a MiB and more: arenas (re)allocated
 
@@ -248,6 +261,59 @@ void** __hipRegisterFatBinary(const void*) { static void* h[1]; return h; }
 void __hipRegisterFunction(void**, const void*, char*, const char*, unsigned int, void*, void*, void*, void*, int*) {}
 void __hipRegisterVar(void**, void*, char*, const char*, int, size_t, int, int) {}
 void __hipUnregisterFatBinary(void**) {}
+
+// ---- virtual memory: an address range, physical pieces, mappings ----
+hipError_t hipMemGetInfo(size_t* fr, size_t* total) {
+    const size_t tot = kLimitMb > 0 ? (size_t)kLimitMb << 20 : (size_t)288 << 30;
+    const size_t used = (size_t)g_vm_bytes.load();
+    *total = tot;
+    *fr = used < tot ? tot - used : 0;
+    return hipSuccess;
+}
+hipError_t hipDeviceSynchronize(void) { return hipSuccess; }     // (callers have synchronised their streams: nothing device-wide here)
+hipError_t hipMemGetAllocationGranularity(size_t* g, const hipMemAllocationProp*, hipMemAllocationGranularity_flags) { *g = 4096; return hipSuccess; }
+hipError_t hipMemAddressReserve(void** p, size_t n, size_t, void*, unsigned long long) {
+    void* q = mmap(nullptr, n, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (q == MAP_FAILED) return hipErrorOutOfMemory;
+    *p = q;
+    ++g_vm_ranges;
+    return hipSuccess;
+}
+hipError_t hipMemAddressFree(void* p, size_t n) { munmap(p, n); --g_vm_ranges; return hipSuccess; }
+hipError_t hipMemCreate(hipMemGenericAllocationHandle_t* h, size_t n, const hipMemAllocationProp*, unsigned long long) {
+    if (kLimitMb > 0 && (size_t)g_vm_bytes.load() + n > ((size_t)kLimitMb << 20)) return hipErrorOutOfMemory;
+    if (kMapUs) usleep((useconds_t)(kMapUs * (long)((n + (1u << 20) - 1) >> 20)));
+    const int fd = memfd_create("mi_hip_stub_piece", MFD_CLOEXEC);
+    if (fd < 0 || ftruncate(fd, (off_t)n) != 0) { if (fd >= 0) close(fd); return hipErrorOutOfMemory; }
+    void* q = mmap(nullptr, n, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    if (q == MAP_FAILED) { close(fd); return hipErrorOutOfMemory; }
+    memset(q, 0xDD, n);
+    munmap(q, n);
+    g_vm_bytes += (long long)n;
+    ++g_vm_pieces;
+    *h = (hipMemGenericAllocationHandle_t) new VmHandle{n, fd};
+    return hipSuccess;
+}
+hipError_t hipMemRelease(hipMemGenericAllocationHandle_t h) {
+    VmHandle* v = (VmHandle*)h;
+    g_vm_bytes -= (long long)v->bytes;
+    --g_vm_pieces;
+    close(v->fd);
+    delete v;
+    return hipSuccess;
+}
+hipError_t hipMemMap(void* p, size_t n, size_t, hipMemGenericAllocationHandle_t h, unsigned long long) {
+    VmHandle* v = (VmHandle*)h;
+    if (v->bytes != n) return hipErrorInvalidValue;
+    return mmap(p, n, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_FIXED, v->fd, 0) == p ? hipSuccess : hipErrorInvalidValue;
+}
+hipError_t hipMemSetAccess(void*, size_t, const hipMemAccessDesc*, size_t) { return hipSuccess; }
+hipError_t hipMemUnmap(void* p, size_t n) {
+    return mmap(p, n, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE | MAP_FIXED, -1, 0) == p ? hipSuccess : hipErrorInvalidValue;
+}
+long mi_hip_stub_vm_pieces(void) { return g_vm_pieces.load(); }
+long mi_hip_stub_vm_ranges(void) { return g_vm_ranges.load(); }
+long long mi_hip_stub_vm_bytes(void) { return g_vm_bytes.load(); }
 
 long mi_hip_stub_live_allocations(void) { return g_live_allocs.load(); }
 long mi_hip_stub_big_mallocs(void) { return g_big_mallocs.load(); }

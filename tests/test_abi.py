@@ -52,7 +52,7 @@ def test_the_core_export_set(engine_lib):
 
 def test_abi_version_and_defaults(engine_lib):
     import makisu_amd
-    assert engine_lib.mi_abi_version() == 5
+    assert engine_lib.mi_abi_version() == 6
     cfg = makisu_amd.default_config()
     assert cfg.struct_size == C.sizeof(makisu_amd.Config)
     assert (cfg.gear_seed, cfg.mask_bits, cfg.min_size, cfg.max_size) == (0x4D414B49, 13, 2048, 65536)

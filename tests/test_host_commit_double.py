@@ -45,7 +45,7 @@ def test_a_tree_larger_than_the_device_is_scanned_in_windows(hip_double, tmp_pat
     """the double refuses allocations above 6 MiB: a 9+ MB tree cannot be staged in one batch -- mi_memfs_commit_layer falls back to
     windows (MI_COMMIT_WINDOW_MB=2) for the roots and to the disk for the tar; with MI_MEMFS_TRUST_CTIME the walk that runs into the
     limit is the filtered one"""
-    env = dict(os.environ, LD_PRELOAD=(os.environ.get("LD_PRELOAD", "") + " " + hip_double).strip(), MI_HIP_STUB_MALLOC_LIMIT_MB="6",
+    env = dict(os.environ, LD_PRELOAD=(os.environ.get("LD_PRELOAD", "") + " " + hip_double).strip(), MI_HIP_STUB_MALLOC_LIMIT_MB="6", MI_ARENA_PIECE_MB="2",
                MI_COMMIT_WINDOW_MB="2")
     if trust:
         env["MI_TEST_TRUST"] = "1"
@@ -57,17 +57,38 @@ def test_a_tree_larger_than_the_device_is_scanned_in_windows(hip_double, tmp_pat
 def test_copy_sources_larger_than_the_device_go_window_by_window(hip_double, tmp_path):  # noqa: F811
     """the double refuses allocations above 6 MiB; three COPY ops whose sources hold 7+ MB: the plan runs out of room, is made again
     without a batch, the roots come in windows (MI_COMMIT_WINDOW_MB=2) -- same tar as the header-only commit, roots in the tree"""
-    env = dict(os.environ, LD_PRELOAD=(os.environ.get("LD_PRELOAD", "") + " " + hip_double).strip(), MI_HIP_STUB_MALLOC_LIMIT_MB="6",
+    env = dict(os.environ, LD_PRELOAD=(os.environ.get("LD_PRELOAD", "") + " " + hip_double).strip(), MI_HIP_STUB_MALLOC_LIMIT_MB="6", MI_ARENA_PIECE_MB="2",
                MI_COMMIT_WINDOW_MB="2")
     p = subprocess.run([sys.executable, os.path.join(STUB_DIR, "commit_scenarios.py"), str(tmp_path), "4", "oversize_copy"], env=env,
                        capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "OK oversize_copy" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
 
 
-def test_a_tree_the_handle_knows_gets_its_arena_in_one_piece(hip_double, tmp_path):  # noqa: F811
-    """FROM, then RUN: the handle merged the base layers, its first content scan reserves the arena once for what the tree lists;
-    a handle that knows nothing grows it in steps (the double counts allocations of a MiB and more)"""
+@pytest.mark.parametrize("variant", ["plain", "range_outgrown", "slow_mapper"])
+def test_the_arena_never_moves_while_a_walk_fills_it(hip_double, tmp_path, variant):  # noqa: F811
+    """mi_arena.hip: one address range, mapped piece by piece behind the walk -- also when the range is outgrown (the pieces are
+    mapped again elsewhere, with their bytes) and when the mapper is slower than the readers (a box that charges device memory by
+    the byte): the layer tar holds every file's bytes"""
     env = dict(os.environ, LD_PRELOAD=(os.environ.get("LD_PRELOAD", "") + " " + hip_double).strip())
+    if variant == "range_outgrown":
+        env["MI_ARENA_RANGE_MB"] = "16"
+    if variant == "slow_mapper":
+        env["MI_HIP_STUB_MAP_US"] = "2000"
     p = subprocess.run([sys.executable, os.path.join(STUB_DIR, "commit_scenarios.py"), str(tmp_path), "4", "known_tree"], env=env,
                        capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "OK known_tree" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
+
+
+@pytest.mark.parametrize("case,fault", [("clean", None), ("readback1", "readback:2"), ("readback1", "readback:7"), ("readback3", "readback:3:3"),
+                                        ("copy", "copy:1"), ("copy", "copy:6")])
+@pytest.mark.parametrize("pipeline", ["1", "0"])
+def test_bytes_that_change_on_the_way_fail_the_commit(hip_double, tmp_path, case, fault, pipeline):  # noqa: F811
+    """mi_filesum.h: a flipped byte in the read-back window is repaired by a second fetch (or fails the commit when that is wrong
+    too), 4 KiB lost in HBM after the host-to-device copy fail it -- with the hop named; never a self-consistent corrupted layer
+    (lib/tario/write.go:43-45: the bytes or an error)"""
+    env = dict(os.environ, LD_PRELOAD=(os.environ.get("LD_PRELOAD", "") + " " + hip_double).strip(), MI_VERIFY_CASE=case, MI_COMMIT_PIPELINE=pipeline)
+    if fault:
+        env["MI_STAGE_FAULT"] = fault
+    p = subprocess.run([sys.executable, os.path.join(STUB_DIR, "commit_scenarios.py"), str(tmp_path), "4", "verify"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and ("OK verify " + case) in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]

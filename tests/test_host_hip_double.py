@@ -90,7 +90,9 @@ def test_a_block_goes_back_to_the_pool_when_it_is_copied_not_when_the_walk_ends(
     not the blocks alive at a time.)"""
     import re
     env = dict(os.environ, LD_PRELOAD=(os.environ.get("LD_PRELOAD", "") + " " + hip_double).strip(),
-               MI_WALK_THREADS="4", MI_WALK_TIMING="1")
+               MI_WALK_THREADS="4", MI_WALK_TIMING="1", MI_ARENA_PIECE_MB="2")    # (small pieces: the double's hipMemCreate fills a
+                                                                                  #  piece byte by byte -- readers that wait for a 32 MiB
+                                                                                  #  fill on a busy machine let blocks pile up behind them)
     p = subprocess.run([sys.executable, os.path.join(STUB_DIR, "scenarios.py"), str(tmp_path), "4", str(1 << 20), "recycle"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0 and "OK recycle" in p.stdout, p.stdout[-800:] + p.stderr[-1500:]

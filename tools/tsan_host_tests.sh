@@ -12,7 +12,7 @@ RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.tsan-x86_64.so | he
 mkdir -p "$OUT"
 rm -f "$OUT"/report.*
 FLAGS="--offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -fno-gpu-rdc -fsanitize=thread -fno-gpu-sanitize -shared-libsan -fno-omit-frame-pointer"
-for f in mi_api gear_cdc sha256 tables crc32 mi_tree mi_comm mi_index mi_alloc mi_tar mi_stage mi_layer mi_memfs; do
+for f in mi_api gear_cdc sha256 tables crc32 mi_tree mi_comm mi_index mi_alloc mi_arena mi_tar mi_stage mi_layer mi_memfs; do
     extra=""
     [ "$f" = sha256 ] && extra="-mllvm -amdgpu-atomic-optimizer-strategy=None"
     /opt/rocm/bin/hipcc $FLAGS $extra -c "$ROOT/makisu_amd/csrc/$f.hip" -o "$OUT/$f.o" &
