@@ -32,6 +32,27 @@ extern "C" {
 
 #define MI_ABI_VERSION 6
 
+/* ---- THREE KINDS OF EXPORT (round 6) ------------------------------------------------------------------------------------- *
+ * Every prototype below carries one of three (empty) tags; tests/test_abi.py checks that each export has exactly one, and
+ * tests/test_integration_shim.py that the cgo shim of INTEGRATION.md binds CORE calls only.
+ *
+ * MI_CORE   what a first cgo shim in lib/snapshot binds -- the seam as the reference has it (about thirty calls):
+ *             ctx        mi_abi_version, mi_config_default, mi_ctx_create / _destroy, mi_last_error
+ *             MemFS      mi_memfs_create / _free / _error / _set_clock / _reset / _update_from_entries / _entries / _root_of
+ *             commit     mi_memfs_commit_layer (step.commitLayer in one call: walk, GPU scan, content-aware diff, tar from HBM,
+ *                        DigestPair), mi_memfs_commit_stats, mi_memfs_set_options / _set_index / _reserve_device /
+ *                        _release_device, mi_layer_config_default, mi_copy_layer_entries / _roots / _free
+ *             cache      mi_cache_key / _create_entry / _parse_entry / _parse_entry_str   (cache.Manager's strings)
+ *             index      mi_index_create / _free / _count / _export / _import               (keyvalue.Store seam)
+ *             push       mi_sha256_many                                                     (image.Digester, batched)
+ * MI_BLOCK  the building blocks the commit is made of, for a host that wants to arrange them itself (batches and their
+ *           results, parts of large files, the RCCL exchange, tree walks, the tar reader and the layer writer, the stateless
+ *           forms of the diff, the context checksum): everything INTEGRATION.md's later sections use.
+ * MI_DIAG   measurement and diagnosis (stats, roofs, staging counters, wave records): no product flow depends on them.      */
+#define MI_CORE
+#define MI_BLOCK
+#define MI_DIAG
+
 enum {
     MI_OK = 0,
     MI_ERR_INVALID = -1,     /* bad argument / bad state                         */
@@ -179,24 +200,24 @@ typedef struct {
 } mi_stage_stats;
 
 /* ---- context ----------------------------------------------------------------- */
-int  mi_abi_version(void);
+MI_CORE int  mi_abi_version(void);
 /* Diagnostics: from now on every chunk-pass launch of this ctx runs the recording instantiation of the hashing kernel
  * and appends one record per wave to `path` (where it ran, when, how much it hashed: tools/sha_wave_stats.py reads it);
  * each such launch is followed by a stream synchronize -- never on a ctx whose time is measured.  NULL or "" turns it
  * off.  MI_SHA_WAVE_STATS=<file> in the environment of mi_ctx_create does the same for the new ctx.              */
-int  mi_debug_sha_wave_stats(mi_ctx* ctx, const char* path);
-int  mi_config_default(mi_config* cfg);
-int  mi_ctx_create(const mi_config* cfg, mi_ctx** out);
+MI_DIAG int  mi_debug_sha_wave_stats(mi_ctx* ctx, const char* path);
+MI_CORE int  mi_config_default(mi_config* cfg);
+MI_CORE int  mi_ctx_create(const mi_config* cfg, mi_ctx** out);
 /* Batches and indexes hold a pointer to their ctx: free them first (mi_batch_free /
  * mi_index_free).  With live children the call changes nothing and returns MI_ERR_STATE (the
  * count is in the message) -- a finalizer that runs in the wrong order gets an error, not a
  * use-after-free.  NULL is MI_OK.                                                       */
-int  mi_ctx_destroy(mi_ctx* ctx);
+MI_CORE int  mi_ctx_destroy(mi_ctx* ctx);
 /* ctx may be NULL: returns the message of the last failed mi_ctx_create.           */
-const char* mi_last_error(mi_ctx* ctx);
-int  mi_get_stats(mi_ctx* ctx, mi_stats* out);
+MI_CORE const char* mi_last_error(mi_ctx* ctx);
+MI_DIAG int  mi_get_stats(mi_ctx* ctx, mi_stats* out);
 /* device properties as measured by hipGetDeviceProperties: CUs, clock, HBM bytes   */
-int  mi_device_info(mi_ctx* ctx, int32_t* n_cu, int32_t* clock_mhz, uint64_t* hbm_bytes,
+MI_DIAG int  mi_device_info(mi_ctx* ctx, int32_t* n_cu, int32_t* clock_mhz, uint64_t* hbm_bytes,
                     char* name, size_t name_cap);
 
 /* The integer-VALU roof of SHA-256 on this device, measured now: every lane runs `blocks` 64-round
@@ -204,7 +225,7 @@ int  mi_device_info(mi_ctx* ctx, int32_t* n_cu, int32_t* clock_mhz, uint64_t* hb
  * waves_per_simd waves on every SIMD; *bytes_per_second = 64 bytes per compression over the best of
  * three launches.  0 = defaults (8 waves, 512 blocks: ~10 ms).  bench.py quotes the SHA pass against
  * this number from the same run (SURVEY.md 8d "second roof that actually binds SHA-256").          */
-int  mi_sha_valu_roof(mi_ctx* ctx, uint32_t waves_per_simd, uint32_t blocks, double* bytes_per_second);
+MI_DIAG int  mi_sha_valu_roof(mi_ctx* ctx, uint32_t waves_per_simd, uint32_t blocks, double* bytes_per_second);
 
 /* ---- batch: a set of files scanned in one pass --------------------------------- *
  * Serves the per-entry loop of MemFS.commitLayer -> contentMemFile.commit ->
@@ -213,93 +234,93 @@ int  mi_sha_valu_roof(mi_ctx* ctx, uint32_t waves_per_simd, uint32_t blocks, dou
  * write to the layer tar; directories/links/whiteouts have no bytes and are not
  * added.  Order of results == order of adds (the caller adds in sorted-path order,
  * lib/snapshot/mem_layer.go:232-244).                                              */
-int mi_batch_begin(mi_ctx* ctx, uint64_t n_files_hint, uint64_t bytes_hint, mi_batch** out);
+MI_BLOCK int mi_batch_begin(mi_ctx* ctx, uint64_t n_files_hint, uint64_t bytes_hint, mi_batch** out);
 /* The bytes have been consumed when the call returns (len may be 0): small buffers are copied
  * into the batch's own pinned window by the calling thread, buffers of 1 MiB and more by the
  * ctx's reader threads in parallel.  Two batches of one ctx may be filled at the same time.  */
-int mi_batch_add_bytes(mi_batch* b, const void* data, uint64_t len, uint64_t user_tag);
+MI_BLOCK int mi_batch_add_bytes(mi_batch* b, const void* data, uint64_t len, uint64_t user_tag);
 /* The engine opens `path` and reads exactly `size` bytes (the size at stat time,
  * like io.CopyN(w, f, h.Size) at lib/tario/write.go:43-45).  Short files are an
  * error, extra appended bytes are ignored.  The open and the size check happen in this call;
  * the bytes are read by the ctx's reader threads (several files at once, consecutive small
  * files share one PCIe transfer), so a file that shrinks afterwards fails mi_batch_run /
  * mi_batch_submit with MI_ERR_IO.                                                    */
-int mi_batch_add_path(mi_batch* b, const char* path, uint64_t size, uint64_t user_tag);
+MI_BLOCK int mi_batch_add_path(mi_batch* b, const char* path, uint64_t size, uint64_t user_tag);
 /* Bulk form for MANY files (a layer is mostly small ones): nothing is opened in this call, the reader
  * threads open, read and close the files themselves, several at a time.  The price of the deferred
  * open: a missing or short file does not fail this call but mi_batch_run / mi_batch_submit
  * (MI_ERR_IO naming the path).  user_tags may be NULL (tags 0).                              */
-int mi_batch_add_paths(mi_batch* b, uint64_t n, const char* const* paths, const uint64_t* sizes,
+MI_BLOCK int mi_batch_add_paths(mi_batch* b, uint64_t n, const char* const* paths, const uint64_t* sizes,
                        const uint64_t* user_tags);
 /* Room for what is known to come (more_files files of more_bytes bytes in total): the arena grows once, now.  Growing
  * under way is correct but costs -- the reader threads are drained first and what the arena holds is moved -- so a
  * caller that knows a layer's size (after its walk; mi_batch_begin's hints serve the same purpose for a fresh batch)
  * says so.  mi_batch_add_tree does it by itself: its enumeration runs ahead of the files it hands over.            */
-int mi_batch_reserve(mi_batch* batch, uint64_t more_files, uint64_t more_bytes);
+MI_BLOCK int mi_batch_reserve(mi_batch* batch, uint64_t more_files, uint64_t more_bytes);
 /* The same for a byte range of a file -- a member of an uncompressed layer tar, whose ranges
  * mi_tar_entries lists: the file's bytes are [offset, offset + size) of `path`.             */
-int mi_batch_add_path_range(mi_batch* b, const char* path, uint64_t offset, uint64_t size,
+MI_BLOCK int mi_batch_add_path_range(mi_batch* b, const char* path, uint64_t offset, uint64_t size,
                             uint64_t user_tag);
 /* Device-generated synthetic files (bench / roofline runs):
  * file i has sizes[i] bytes of the counter-mode stream keyed by (seed,
  * content_ids[i]); equal content ids give byte-identical files.  content_ids may be
  * NULL (ids = running file index).  user_tag = content id.                         */
-int mi_batch_add_synthetic(mi_batch* b, uint64_t n_files, const uint64_t* sizes,
+MI_BLOCK int mi_batch_add_synthetic(mi_batch* b, uint64_t n_files, const uint64_t* sizes,
                            const uint64_t* content_ids, uint64_t seed);
 /* Blocking: stage -> Gear CDC -> SHA-256 per chunk -> per-file roots -> dedup.     */
-int mi_batch_run(mi_batch* b);
+MI_BLOCK int mi_batch_run(mi_batch* b);
 /* Re-runs the device pipeline on data already resident from a previous run (bench
  * steps; no re-staging / re-generation).                                            */
-int mi_batch_rerun(mi_batch* b);
+MI_BLOCK int mi_batch_rerun(mi_batch* b);
 /* Asynchronous form: mi_batch_submit stages the batch on first use and ENQUEUES the
  * whole pipeline on the batch's own HIP stream without any host synchronisation, then
  * returns; mi_batch_wait blocks until it has finished and publishes counts and stats.
  * Two batches may be in flight on one ctx: the Gear pass of one overlaps the SHA-256
  * pass of the other (they bind different units of the CU).  mi_batch_run ==
  * submit + wait.  A batch may be submitted again after its wait (same data).         */
-int mi_batch_submit(mi_batch* b);
-int mi_batch_wait(mi_batch* b);
-int mi_batch_counts(mi_batch* b, uint64_t* n_files, uint64_t* n_chunks, uint64_t* n_bytes);
-int mi_batch_files(mi_batch* b, mi_file_result* out, uint64_t cap);
-int mi_batch_chunks(mi_batch* b, mi_chunk_result* out, uint64_t cap);
+MI_BLOCK int mi_batch_submit(mi_batch* b);
+MI_BLOCK int mi_batch_wait(mi_batch* b);
+MI_BLOCK int mi_batch_counts(mi_batch* b, uint64_t* n_files, uint64_t* n_chunks, uint64_t* n_bytes);
+MI_BLOCK int mi_batch_files(mi_batch* b, mi_file_result* out, uint64_t cap);
+MI_BLOCK int mi_batch_chunks(mi_batch* b, mi_chunk_result* out, uint64_t cap);
 /* The same rows without the copy into caller memory: *rows points at the batch's own pinned host
  * buffer (packed on the device, one device-to-host copy), valid until the batch is submitted
  * again, marked globally, reset or freed.  What a cgo shim reads through unsafe.Slice.          */
-int mi_batch_chunks_view(mi_batch* b, const mi_chunk_result** rows, uint64_t* n_chunks);
+MI_BLOCK int mi_batch_chunks_view(mi_batch* b, const mi_chunk_result** rows, uint64_t* n_chunks);
 /* ... and the file rows the same way (they are packed on the device too and arrive with the same wait).                  */
-int mi_batch_files_view(mi_batch* b, const mi_file_result** rows, uint64_t* n_files);
+MI_BLOCK int mi_batch_files_view(mi_batch* b, const mi_file_result** rows, uint64_t* n_files);
 /* The per-file chunk roots alone, 32 bytes per file in add order (cap = rows `out` has room for): what a content-aware
  * MemFS.isUpdated compares (lib/snapshot/mem_fs.go:487-503) -- one copy of n_files x 32 bytes, none of the chunk rows.   */
-int mi_batch_roots(mi_batch* b, uint8_t* out, uint64_t cap);
+MI_BLOCK int mi_batch_roots(mi_batch* b, uint8_t* out, uint64_t cap);
 /* Bytes [offset, offset + len) of file `file_index` as they lie in HBM -- the bytes the scan saw -- through a pinned
  * window of the batch (a fetch brings neighbours along: files staged together are asked for together).  From the moment
  * the batch is staged (mi_batch_run / _submit + _wait / _scan_cuts returned) until it is reset or freed; not while in
  * flight; not for parts.  What the layer writer reads when a commit takes its files from the batch
  * (mi_layer_add_batch_file) instead of reading them from disk a second time (lib/tario/write.go:43-45 reads once).     */
-int mi_batch_read_file(mi_batch* b, uint64_t file_index, uint64_t offset, void* dst, uint64_t len);
+MI_BLOCK int mi_batch_read_file(mi_batch* b, uint64_t file_index, uint64_t offset, void* dst, uint64_t len);
 /* Device pointer to the batch's n_chunks x 32-byte digest array (valid until
  * mi_batch_free); what a rank contributes to the all-gather.        */
-int mi_batch_device_digests(mi_batch* b, const void** d_digests, uint64_t* n_chunks);
+MI_BLOCK int mi_batch_device_digests(mi_batch* b, const void** d_digests, uint64_t* n_chunks);
 /* Copies the batch's file bytes back to the host (tests; cap >= total bytes, files
  * concatenated in add order, no padding).                                           */
-int mi_batch_read_back(mi_batch* b, void* out, uint64_t cap);
+MI_DIAG int mi_batch_read_back(mi_batch* b, void* out, uint64_t cap);
 /* Empties the batch (files, results, recorded walk) but keeps its device memory and pinned window
  * for the next set of files: the way to scan layer after layer without paying allocation -- and
  * the driver's clearing of fresh device memory, which slows the first host-to-device copies into
  * it -- every time.  Not while in flight.                                                  */
-int mi_batch_reset(mi_batch* b);
-int mi_batch_free(mi_batch* b);
+MI_BLOCK int mi_batch_reset(mi_batch* b);
+MI_BLOCK int mi_batch_free(mi_batch* b);
 /* Staging counters since mi_batch_begin / mi_batch_reset (MI_FLAG_VERIFY_STAGING).  A staging
  * failure (a missing, short or unreadable file, a failed copy, a span that does not verify) is
  * STICKY: every later mi_batch_run / _submit / _scan_cuts of the batch returns MI_ERR_IO with the
  * first failure's message until mi_batch_reset -- a failed batch never scans half-staged bytes.   */
-int mi_batch_stage_stats(mi_batch* b, mi_stage_stats* out);
+MI_DIAG int mi_batch_stage_stats(mi_batch* b, mi_stage_stats* out);
 /* What the first verification mismatch of the batch looked like -- arena range, reader thread, both
  * pairs of sums, how many bytes differed and what the GPU held there (zeros / the 0xA5 fill / other
  * data), whether a second copy repaired it; "" if every span verified.  Call it after staging has
  * ended (mi_batch_run / _submit / _scan_cuts returned): the reader threads write the note while they
  * stage.  The pointer is valid until the batch is reset or freed.                                */
-const char* mi_batch_stage_note(mi_batch* b);
+MI_DIAG const char* mi_batch_stage_note(mi_batch* b);
 
 /* ---- parts: ONE file split across batches / GPUs (files >= 256 MiB) ------------- *
  * No reference counterpart: the reference streams a file through one goroutine
@@ -328,23 +349,23 @@ typedef struct {
     uint32_t entry_confirmed;  /* mi_batch_set_part_entry was called (always 1 for begin == 0)     */
     uint32_t cuts_current;     /* 0: the confirmed entry differs, mi_batch_fix_cuts is due         */
 } mi_part_state;
-int mi_batch_add_path_part(mi_batch* b, const char* path, uint64_t file_size, uint64_t begin,
+MI_BLOCK int mi_batch_add_path_part(mi_batch* b, const char* path, uint64_t file_size, uint64_t begin,
                            uint64_t end, uint64_t user_tag);
 /* the part of the synthetic file (seed, content_id) of file_size bytes: same bytes as the range
  * [begin, end) of what mi_batch_add_synthetic generates for that content id                     */
-int mi_batch_add_synthetic_part(mi_batch* b, uint64_t file_size, uint64_t content_id, uint64_t seed,
+MI_BLOCK int mi_batch_add_synthetic_part(mi_batch* b, uint64_t file_size, uint64_t content_id, uint64_t seed,
                                 uint64_t begin, uint64_t end);
 /* The chunk root of a file from its chunk digests (n x 32 bytes, file order) on the host: SHA-256
  * over the concatenation when n <= 64, else the fan-out-64 tree the engine computes per file.  A
  * split file's root = mi_chunk_root over its parts' digests put end to end.                     */
-int mi_chunk_root(const uint8_t* digests, uint64_t n, uint8_t* root_out);
+MI_BLOCK int mi_chunk_root(const uint8_t* digests, uint64_t n, uint8_t* root_out);
 /* Blocking: stages the batch and runs Gear marking + cut selection only.                         */
-int mi_batch_scan_cuts(mi_batch* b);
-int mi_batch_parts(mi_batch* b, mi_part_state* out, uint64_t cap, uint64_t* n_parts);
-int mi_batch_set_part_entry(mi_batch* b, uint64_t file_index, uint64_t entry);
+MI_BLOCK int mi_batch_scan_cuts(mi_batch* b);
+MI_BLOCK int mi_batch_parts(mi_batch* b, mi_part_state* out, uint64_t cap, uint64_t* n_parts);
+MI_BLOCK int mi_batch_set_part_entry(mi_batch* b, uint64_t file_index, uint64_t entry);
 /* Blocking: re-selects the parts whose confirmed entry differs from the one their cuts were made
  * with and refreshes their exits.                                                              */
-int mi_batch_fix_cuts(mi_batch* b);
+MI_BLOCK int mi_batch_fix_cuts(mi_batch* b);
 
 /* ---- cross-batch / cross-GPU dedup --------------------------------------------- *
  * Plugs in where the reference dedups layer blobs by digest
@@ -354,7 +375,7 @@ int mi_batch_fix_cuts(mi_batch* b);
  * every rank).  d_dup_of: device pointer to n x int64, receives for every row the
  * smallest row index with an equal digest, or -1 for first occurrences.
  * n_unique (host, optional) receives the number of -1 rows.                        */
-int mi_dedup_mark(mi_ctx* ctx, const void* d_digests, uint64_t n, void* d_dup_of,
+MI_BLOCK int mi_dedup_mark(mi_ctx* ctx, const void* d_digests, uint64_t n, void* d_dup_of,
                   uint64_t* n_unique);
 /* The same marking for ONE rank of a multi-GPU job: d_digests holds the job-wide, rank-major
  * digest set (n_total rows, after the all-gather); only the rank's own rows
@@ -363,18 +384,18 @@ int mi_dedup_mark(mi_ctx* ctx, const void* d_digests, uint64_t n, void* d_dup_of
  * set, at a fraction of the work: own rows build the table, rows of earlier ranks probe it,
  * rows of later ranks cannot be a minimum and are not touched.  n_own_first = own rows that
  * are the job-wide first occurrence (their sum over ranks = the unique count).          */
-int mi_dedup_mark_range(mi_ctx* ctx, const void* d_digests, uint64_t n_total, uint64_t own_first,
+MI_BLOCK int mi_dedup_mark_range(mi_ctx* ctx, const void* d_digests, uint64_t n_total, uint64_t own_first,
                         uint64_t own_n, void* d_dup_of_own, uint64_t* n_own_first);
 /* Rewrites the batch's dup_of column from a global marking: row i of the batch is
  * global row first_global + i of d_dup_of_global (device, int64).                  */
-int mi_batch_set_global_dedup(mi_batch* b, const void* d_dup_of_global, uint64_t first_global);
+MI_BLOCK int mi_batch_set_global_dedup(mi_batch* b, const void* d_dup_of_global, uint64_t first_global);
 /* mi_dedup_mark_range for a batch's own chunks, written straight into its dup_of column (no
  * intermediate array, no copy): the batch's rows are rows [own_first, own_first + n_chunks) of
  * the job-wide set d_digests_all.                                                        */
-int mi_batch_mark_global(mi_batch* b, const void* d_digests_all, uint64_t n_total,
+MI_BLOCK int mi_batch_mark_global(mi_batch* b, const void* d_digests_all, uint64_t n_total,
                          uint64_t own_first, uint64_t* n_own_first);
 /* Device pointer to the batch's dup_of column (n_chunks x int64; valid until mi_batch_free). */
-int mi_batch_device_dup_of(mi_batch* b, const void** d_dup_of, uint64_t* n_chunks);
+MI_BLOCK int mi_batch_device_dup_of(mi_batch* b, const void** d_dup_of, uint64_t* n_chunks);
 
 /* ---- the digest exchange inside the library: RCCL all-gather over xGMI ---------------- *
  * For hosts without torch (the Go shim).  RCCL is loaded at run time (dlopen), so these
@@ -388,20 +409,20 @@ int mi_batch_device_dup_of(mi_batch* b, const void** d_dup_of, uint64_t* n_chunk
  * sums the ranks' first-occurrence counts into n_unique; collective: every rank must call
  * it.  Outputs are optional.                                                            */
 #define MI_COMM_ID_BYTES 128
-int mi_comm_unique_id(void* id_out /* MI_COMM_ID_BYTES */);
-int mi_comm_init_rank(mi_ctx* ctx, int nranks, int rank, const void* id);
-int mi_comm_init_all(mi_ctx** ctxs, int n);
-int mi_comm_destroy(mi_ctx* ctx);
+MI_BLOCK int mi_comm_unique_id(void* id_out /* MI_COMM_ID_BYTES */);
+MI_BLOCK int mi_comm_init_rank(mi_ctx* ctx, int nranks, int rank, const void* id);
+MI_BLOCK int mi_comm_init_all(mi_ctx** ctxs, int n);
+MI_BLOCK int mi_comm_destroy(mi_ctx* ctx);
 /* How many ranks the ctx's communicator spans (ncclCommCount); 0 without a communicator.  What a
  * scaling run records next to its number: a job that believes it ran on 8 GPUs can prove it.     */
-int mi_comm_ranks(mi_ctx* ctx, int* n_ranks);
-int mi_dedup_allgather(mi_batch* b, uint64_t* n_total, uint64_t* n_unique,
+MI_BLOCK int mi_comm_ranks(mi_ctx* ctx, int* n_ranks);
+MI_BLOCK int mi_dedup_allgather(mi_batch* b, uint64_t* n_total, uint64_t* n_unique,
                        uint64_t* first_global);
-int mi_dedup_allgather_all(mi_batch** batches, int n, uint64_t* n_total, uint64_t* n_unique);
+MI_BLOCK int mi_dedup_allgather_all(mi_batch** batches, int n, uint64_t* n_total, uint64_t* n_unique);
 /* Device time of the ctx's LAST exchange, from HIP events on the ctx stream (what a scaling line
  * reports beside its rate): ms_gather = the slab all-gather (xGMI time), ms_marking = squeezing the padding
  * out + the job-wide marking of this rank's rows.  Both 0 before the first exchange with rows.          */
-int mi_comm_exchange_ms(mi_ctx* ctx, double* ms_gather, double* ms_marking);
+MI_DIAG int mi_comm_exchange_ms(mi_ctx* ctx, double* ms_gather, double* ms_marking);
 
 /* ---- COPY/ADD context checksum (addCopyStep.SetCacheID seam) ------------------------ *
  * Reproduces the ONE running CRC32-IEEE the reference feeds at plan time
@@ -418,7 +439,7 @@ typedef struct {
     const char* link_target;   /* non-NULL for a symlink: os.Readlink(path)              */
     int64_t     file_index;    /* regular file: its index in the batch; otherwise -1     */
 } mi_ctx_entry;
-int mi_context_checksum(mi_batch* b, const void* prefix, uint64_t prefix_len,
+MI_BLOCK int mi_context_checksum(mi_batch* b, const void* prefix, uint64_t prefix_len,
                         const mi_ctx_entry* entries, uint64_t n, uint32_t* crc_out);
 
 /* ---- host-side walks: which files reach the batch, in what order -------------------- *
@@ -461,19 +482,19 @@ typedef struct {
  * naming it, at its place in walk order.  Larger files are handed over in bulk as paths (mi_batch_add_paths: the
  * reader threads open them); one of those that vanishes or shrinks fails mi_batch_run / mi_batch_submit.
  * MI_WALK_INLINE=0: every file as a path.  Where a file lies in the arena is independent of its index.            */
-int mi_batch_add_tree(mi_batch* b, const char* root, const char* rel_base,
+MI_BLOCK int mi_batch_add_tree(mi_batch* b, const char* root, const char* rel_base,
                       const char* const* blacklist, uint64_t n_blacklist, uint32_t mode,
                       uint64_t* n_entries);
-int mi_batch_tree_entries(mi_batch* b, mi_tree_entry* out, uint64_t cap);
+MI_BLOCK int mi_batch_tree_entries(mi_batch* b, mi_tree_entry* out, uint64_t cap);
 /* The same walk on its own -- no ctx, no GPU: lists what mi_batch_add_tree WOULD add and in
  * which order (file_index = running ordinal of the regular files).  Host logic only.      */
 typedef struct mi_tree mi_tree;
-int  mi_tree_walk(const char* root, const char* rel_base, const char* const* blacklist,
+MI_BLOCK int  mi_tree_walk(const char* root, const char* rel_base, const char* const* blacklist,
                   uint64_t n_blacklist, uint32_t mode, mi_tree** out, uint64_t* n_entries);
-int  mi_tree_entries(const mi_tree* tree, mi_tree_entry* out, uint64_t cap);
-void mi_tree_free(mi_tree* tree);
+MI_BLOCK int  mi_tree_entries(const mi_tree* tree, mi_tree_entry* out, uint64_t cap);
+MI_BLOCK void mi_tree_free(mi_tree* tree);
 /* mi_context_checksum over the recorded walk (the batch must have run).                */
-int mi_context_checksum_tree(mi_batch* b, const void* prefix, uint64_t prefix_len,
+MI_BLOCK int mi_context_checksum_tree(mi_batch* b, const void* prefix, uint64_t prefix_len,
                              uint32_t* crc_out);
 
 /* The order MemFS.commitLayer writes entries in (memLayer.rangeFiles, lib/snapshot/
@@ -483,7 +504,7 @@ int mi_context_checksum_tree(mi_batch* b, const void* prefix, uint64_t prefix_le
  * order.  The input's sorted runs are merged (a walk's order is nearly this one: 0.13 us per entry);
  * from 131 072 entries on, blocks are sorted on up to 16 threads of the library's own
  * (MI_WALK_THREADS) that end with the call.  Host logic.                                    */
-int mi_entries_commit_order(const mi_tree_entry* entries, uint64_t n, uint64_t* order_out);
+MI_BLOCK int mi_entries_commit_order(const mi_tree_entry* entries, uint64_t n, uint64_t* order_out);
 
 /* "Did this path change?" -- tario.IsSimilarHeader (lib/tario/compare.go:24-117), the test
  * behind MemFS.isUpdated (lib/snapshot/mem_fs.go:487-503), on walk entries: two entries with
@@ -495,7 +516,7 @@ int mi_entries_commit_order(const mi_tree_entry* entries, uint64_t n, uint64_t* 
  * are equal too -- the reference "ignores path and content" (compare.go:101-103) because it
  * has no cheap content identity; with NULL roots the answer is exactly the reference's.
  * Unknown kind -> MI_ERR_INVALID (the reference's "unsupported type" error).  Host logic.  */
-int mi_entry_similar(const mi_tree_entry* a, const mi_tree_entry* b, int ignore_time,
+MI_BLOCK int mi_entry_similar(const mi_tree_entry* a, const mi_tree_entry* b, int ignore_time,
                      const uint8_t* root_a, const uint8_t* root_b, int* similar);
 
 /* ---- a layer tar as a source: entries and the byte range of every file, no extraction ---- *
@@ -514,22 +535,22 @@ int mi_entry_similar(const mi_tree_entry* a, const mi_tree_entry* b, int ignore_
  * contiguous range of the tar.  Whiteout markers (".wh.<name>") are listed as the entries they
  * are.  Strings live until mi_tar_free.  Host logic.                                        */
 typedef struct mi_tar mi_tar;
-int  mi_tar_open(const char* path, mi_tar** out, uint64_t* n_entries);
+MI_BLOCK int  mi_tar_open(const char* path, mi_tar** out, uint64_t* n_entries);
 /* The same with the failure reason as text (err, err_cap; nothing is printed anywhere) and
  * *is_gzip = 1 when `path` is a gzip blob -- the form layers are stored and pulled in
  * (tario.NewGzipReader, lib/tario/gzip.go:50-53; lib/builder/build_node.go:133-148).  A gzip blob is
  * listed through a streaming inflate; its data offsets are offsets in the UNCOMPRESSED tar.   */
-int  mi_tar_open_ex(const char* path, mi_tar** out, uint64_t* n_entries, int* is_gzip, char* err,
+MI_BLOCK int  mi_tar_open_ex(const char* path, mi_tar** out, uint64_t* n_entries, int* is_gzip, char* err,
                     uint64_t err_cap);
 /* gzip blob -> the uncompressed tar at tar_path_out (NULL = digests only), its size and SHA-256
  * (the layer's TarDigest / diffID) and, optionally, the blob's own SHA-256 (GzipDescriptor.Digest):
  * the reference's fixture pair 393ccd5c... / 4ac76077... (lib/utils/testutil/constants.go:28) is
  * the test.  Then mi_tar_open(tar_path_out) + mi_batch_add_path_range scan the members.  A plain
  * tar is copied through unchanged.  Host logic (zlib, SHA-NI).                                */
-int  mi_tar_inflate(const char* blob_path, const char* tar_path_out, uint64_t* tar_bytes,
+MI_BLOCK int  mi_tar_inflate(const char* blob_path, const char* tar_path_out, uint64_t* tar_bytes,
                     uint8_t* tar_sha256, uint8_t* blob_sha256, char* err, uint64_t err_cap);
-int  mi_tar_entries(const mi_tar* tar, mi_tree_entry* out, uint64_t* data_offsets, uint64_t cap);
-void mi_tar_free(mi_tar* tar);
+MI_BLOCK int  mi_tar_entries(const mi_tar* tar, mi_tree_entry* out, uint64_t* data_offsets, uint64_t cap);
+MI_BLOCK void mi_tar_free(mi_tar* tar);
 
 /* The layer diff of a scan, on two walks -- what MemFS.createLayerByScan + maybeAddToLayer
  * (lib/snapshot/mem_fs.go:315-341, 440-480) decide against the in-memory tree:
@@ -559,7 +580,7 @@ typedef struct {
                                           mountpoint, a blacklisted directory) still exists and gets
                                           no whiteout.                                              */
 } mi_snapshot_side;
-int mi_snapshot_diff(const mi_snapshot_side* before, const mi_snapshot_side* after, int ignore_time,
+MI_BLOCK int mi_snapshot_diff(const mi_snapshot_side* before, const mi_snapshot_side* after, int ignore_time,
                      uint8_t* after_flags, uint8_t* before_whiteout);
 
 /* ---- the layer of a COPY / ADD step: MemFS.AddLayerByCopyOps on entry lists ---------------- *
@@ -594,12 +615,12 @@ typedef struct {
  * absolute work_dir are MI_ERR_INVALID ("check copy param: ..."); otherwise dst_out = dst if absolute, else
  * filepath.Join(work_dir, dst) with a trailing "/" kept.  mi_memfs_add_layer_by_copy_ops applies the same check to the
  * (already resolved, hence absolute) dst of every op.  Host logic.                                                        */
-int  mi_copy_op_resolve(uint64_t n_srcs, const char* work_dir, const char* dst, char* dst_out, uint64_t cap,
+MI_BLOCK int  mi_copy_op_resolve(uint64_t n_srcs, const char* work_dir, const char* dst, char* dst_out, uint64_t cap,
                         char* err, uint64_t err_cap);
 typedef struct mi_copy_layer mi_copy_layer;
-int  mi_copy_layer_entries(const mi_copy_layer* layer, mi_tree_entry* out, const char** src_paths,
+MI_CORE int  mi_copy_layer_entries(const mi_copy_layer* layer, mi_tree_entry* out, const char** src_paths,
                            uint64_t cap);
-void mi_copy_layer_free(mi_copy_layer* layer);
+MI_CORE void mi_copy_layer_free(mi_copy_layer* layer);
 
 /* ---- MemFS as a handle: the reference's type (lib/snapshot/mem_fs.go:59-125) ------------------------------------- *
  * One tree for the life of a build, nodes of the reference's shape (header + children + the path the content came
@@ -634,18 +655,18 @@ void mi_copy_layer_free(mi_copy_layer* layer);
  * A handle is not re-entrant (the reference serialises MemFS with one mutex); handles are independent.  Host logic. */
 typedef struct mi_memfs mi_memfs;
 typedef struct mi_index mi_index;         /* the chunk index, below */
-int  mi_memfs_create(const char* root, const char* const* blacklist, uint64_t n_blacklist, int64_t now_sec,
+MI_CORE int  mi_memfs_create(const char* root, const char* const* blacklist, uint64_t n_blacklist, int64_t now_sec,
                      mi_memfs** out);
-void mi_memfs_free(mi_memfs* fs);
-const char* mi_memfs_error(const mi_memfs* fs);
-int  mi_memfs_set_clock(mi_memfs* fs, int64_t now_sec);
-int  mi_memfs_reset(mi_memfs* fs);
-int  mi_memfs_update_from_entries(mi_memfs* fs, const mi_tree_entry* layer, uint64_t n_layer, uint64_t* n_merged);
-int  mi_memfs_add_layer_by_scan(mi_memfs* fs, const mi_tree_entry* walked, uint64_t n, const void* roots,
+MI_CORE void mi_memfs_free(mi_memfs* fs);
+MI_CORE const char* mi_memfs_error(const mi_memfs* fs);
+MI_CORE int  mi_memfs_set_clock(mi_memfs* fs, int64_t now_sec);
+MI_CORE int  mi_memfs_reset(mi_memfs* fs);
+MI_CORE int  mi_memfs_update_from_entries(mi_memfs* fs, const mi_tree_entry* layer, uint64_t n_layer, uint64_t* n_merged);
+MI_BLOCK int  mi_memfs_add_layer_by_scan(mi_memfs* fs, const mi_tree_entry* walked, uint64_t n, const void* roots,
                                 uint64_t root_stride, mi_copy_layer** out, uint64_t* n_entries);
-int  mi_memfs_add_layer_by_copy_ops(mi_memfs* fs, const mi_copy_op* ops, uint64_t n_ops, mi_copy_layer** out,
+MI_BLOCK int  mi_memfs_add_layer_by_copy_ops(mi_memfs* fs, const mi_copy_op* ops, uint64_t n_ops, mi_copy_layer** out,
                                     uint64_t* n_entries);
-int  mi_memfs_entries(const mi_memfs* fs, mi_tree_entry* out, const char** src_paths, uint64_t cap, uint64_t* n_out);
+MI_CORE int  mi_memfs_entries(const mi_memfs* fs, mi_tree_entry* out, const char** src_paths, uint64_t cap, uint64_t* n_out);
 
 /* ---- the layer writer: tar framing + the two serial layer digests (host threads) ---------- *
  * step.tarAndGzipDiffs + MemFS.commitLayer (lib/builder/step/common.go:35-111,
@@ -690,25 +711,25 @@ typedef struct {
     uint64_t gzip_bytes;       /* GzipDescriptor.Size                                           */
     uint64_t n_entries;
 } mi_layer_result;
-int  mi_layer_config_default(mi_layer_config* cfg);
-int  mi_layer_begin(const mi_layer_config* cfg, mi_layer** out);
+MI_CORE int  mi_layer_config_default(mi_layer_config* cfg);
+MI_BLOCK int  mi_layer_begin(const mi_layer_config* cfg, mi_layer** out);
 /* e->relpath = the entry's dst path; src_path = where a regular file's bytes are read from.  A dst whose
  * base name carries the whiteout prefix ".wh." is written as a whiteout -- a zero header with only that name,
  * no content -- whatever the entry is (memLayer.addHeader, lib/snapshot/mem_layer.go:197-212).                */
-int  mi_layer_add(mi_layer* layer, const mi_tree_entry* e, const char* src_path);
+MI_BLOCK int  mi_layer_add(mi_layer* layer, const mi_tree_entry* e, const char* src_path);
 /* The same entry with its content taken from a staged batch: the header as mi_layer_add writes it, then file
  * `file_index` of `batch` -- the bytes the GPU scanned, read back from HBM (mi_batch_read_file) -- instead of a second
  * read of the path.  The tar then holds exactly the bytes the file's chunk root describes, whatever has happened to the
  * file since it was staged; e->size must be the staged size (MI_ERR_INVALID otherwise).  Entries without content
  * (directories, links, whiteouts by name) are written as by mi_layer_add.                                              */
-int  mi_layer_add_batch_file(mi_layer* layer, const mi_tree_entry* e, mi_batch* batch, uint64_t file_index);
+MI_BLOCK int  mi_layer_add_batch_file(mi_layer* layer, const mi_tree_entry* e, mi_batch* batch, uint64_t file_index);
 /* What this writer read from disk itself so far: files it opened, bytes it read (mi_layer_add with a src_path).        */
-int  mi_layer_io_counts(mi_layer* layer, uint64_t* files_opened, uint64_t* file_bytes_read);
+MI_DIAG int  mi_layer_io_counts(mi_layer* layer, uint64_t* files_opened, uint64_t* file_bytes_read);
 /* whiteoutMemFile.commit (mem_layer.go:101-132): a zero header named <dir>/.wh.<base>.          */
-int  mi_layer_add_whiteout(mi_layer* layer, const char* deleted_path);
-int  mi_layer_finish(mi_layer* layer, mi_layer_result* out);
-const char* mi_layer_error(mi_layer* layer);
-void mi_layer_free(mi_layer* layer);
+MI_BLOCK int  mi_layer_add_whiteout(mi_layer* layer, const char* deleted_path);
+MI_BLOCK int  mi_layer_finish(mi_layer* layer, mi_layer_result* out);
+MI_BLOCK const char* mi_layer_error(mi_layer* layer);
+MI_BLOCK void mi_layer_free(mi_layer* layer);
 /* step.commitLayer (lib/builder/step/common.go:67-111) in one call on a MemFS handle: the step's layer by scan
  * (must_scan: the root is walked here, with the handle's blacklist) or by its copy operations, written through the layer
  * writer configured by cfg (tarAndGzipDiffs: tar framing, TarDigest, the gzip leg with its digest and size), folded into
@@ -774,10 +795,16 @@ typedef struct {
     uint64_t verified_bytes;     /* ... and their bytes                                                          */
     uint64_t n_refetched;        /* 1 MiB chunks that differed and were right at the second fetch from HBM (a commit
                                     with a chunk that differs twice fails)                                         */
+    uint64_t arena_bytes;        /* device memory behind the handle's arena after this commit ...                */
+    uint64_t arena_pieces;       /* ... in how many pieces (the arena of a commit is an address range mapped piece by
+                                    piece behind the walk: csrc/mi_arena.hip) ...                                  */
+    uint64_t arena_moves;        /* ... and how often its base address changed during this commit -- each time the reader
+                                    threads were drained and, until round 5, the arena copied.  0, unless the tree
+                                    outgrew the address range (four times the first estimate, 8 GiB at least)      */
 } mi_commit_stats;
-int  mi_memfs_commit_layer(mi_memfs* fs, mi_ctx* ctx, int must_scan, const mi_copy_op* ops, uint64_t n_ops,
+MI_CORE int  mi_memfs_commit_layer(mi_memfs* fs, mi_ctx* ctx, int must_scan, const mi_copy_op* ops, uint64_t n_ops,
                            const mi_layer_config* cfg, mi_layer_result* res, mi_copy_layer** layer_out, int* committed);
-int  mi_memfs_commit_stats(const mi_memfs* fs, mi_commit_stats* out);
+MI_CORE int  mi_memfs_commit_stats(const mi_memfs* fs, mi_commit_stats* out);
 /* Options of a handle's content-aware commits (default: none).
  * MI_MEMFS_TRUST_CTIME: a scan commit does not read a regular file again whose inode is what it was when the tree's root for
  * it was computed -- same device, inode number, size, mtime and ctime, to the nanosecond.  ctime is the kernel's own record
@@ -789,26 +816,26 @@ int  mi_memfs_commit_stats(const mi_memfs* fs, mi_commit_stats* out);
  * whole tree; the layer, the roots and the DigestPair are the same unless the kernel's timestamps lie (a clock set back
  * between a write and the next one to the same file).  Scan commits only.                                               */
 #define MI_MEMFS_TRUST_CTIME 0x1u
-int  mi_memfs_set_options(mi_memfs* fs, uint32_t options);
+MI_CORE int  mi_memfs_set_options(mi_memfs* fs, uint32_t options);
 /* From now on every content-aware commit of this handle adds its batch to `index` (NULL: stop).  The index must belong
  * to the ctx the commits run on and outlive them; the handle does not own it.                                          */
-int  mi_memfs_set_index(mi_memfs* fs, mi_index* index);
+MI_CORE int  mi_memfs_set_index(mi_memfs* fs, mi_index* index);
 /* The handle's batch ahead of its first content-aware commit, with room for `files` files of `bytes` bytes in total: a
  * ctx's first use costs (the reader threads: 40-55 ms; device memory: by the byte on some boxes, 47-68 ms per
  * GiB at every allocation) -- a host that knows what is coming, e.g. the size of the base image it is pulling, pays them beside its own work.
  * Optional.                                                                                                              */
-int  mi_memfs_reserve_device(mi_memfs* fs, mi_ctx* ctx, uint64_t files, uint64_t bytes);
+MI_CORE int  mi_memfs_reserve_device(mi_memfs* fs, mi_ctx* ctx, uint64_t files, uint64_t bytes);
 /* Gives back the batch a content-aware commit left with the handle (its arena holds the scanned tree's bytes).          */
-int  mi_memfs_release_device(mi_memfs* fs);
+MI_CORE int  mi_memfs_release_device(mi_memfs* fs);
 /* The chunk root the tree holds for `path` ("/"-rooted, relative to the handle's root): *has_root = 0 when the path was
  * never scanned; MI_ERR_INVALID when the tree does not hold the path.                                                  */
-int  mi_memfs_root_of(const mi_memfs* fs, const char* path, uint8_t* root_out, int* has_root);
+MI_CORE int  mi_memfs_root_of(const mi_memfs* fs, const char* path, uint8_t* root_out, int* has_root);
 /* The chunk roots of a layer's entries, in mi_copy_layer_entries' order: roots = n x 32 bytes, has_root = n flags
  * (regular files of a content-aware commit carry one; everything else zeros).                                          */
-int  mi_copy_layer_roots(const mi_copy_layer* layer, uint8_t* roots, uint8_t* has_root, uint64_t cap);
+MI_CORE int  mi_copy_layer_roots(const mi_copy_layer* layer, uint8_t* roots, uint8_t* has_root, uint64_t cap);
 /* The header block(s) mi_layer_add would write for `e` (512 bytes, or 1536+ with a PAX record) in
  * a layer begun with `layer_flags` (MI_LAYER_*).                                                 */
-int  mi_layer_header_bytes(const mi_tree_entry* e, uint32_t layer_flags, uint8_t* out, uint64_t cap, uint64_t* n);
+MI_BLOCK int  mi_layer_header_bytes(const mi_tree_entry* e, uint32_t layer_flags, uint8_t* out, uint64_t cap, uint64_t* n);
 
 /* ---- cache entry codec (cache.Manager seam, lib/cache/cache_manager.go:34-35,239-252) -------- *
  * key   = "makisu_builder_cache_" + cacheID;
@@ -816,14 +843,14 @@ int  mi_layer_header_bytes(const mi_tree_entry* e, uint32_t layer_flags, uint8_t
  *         layer (pass NULL, NULL); parse is parseEntry + PullCache's empty-entry case: *is_empty
  *         = 1 means "cached, and there is no layer"; an entry without "," is MI_ERR_INVALID
  *         (the reference wraps it as ErrorLayerNotFound).                                      */
-int mi_cache_key(const char* cache_id, char* out, uint64_t cap);
-int mi_cache_create_entry(const uint8_t* tar_sha256, const uint8_t* gzip_sha256, char* out, uint64_t cap);
-int mi_cache_parse_entry(const char* entry, int* is_empty, uint8_t* tar_sha256, uint8_t* gzip_sha256);
+MI_CORE int mi_cache_key(const char* cache_id, char* out, uint64_t cap);
+MI_CORE int mi_cache_create_entry(const uint8_t* tar_sha256, const uint8_t* gzip_sha256, char* out, uint64_t cap);
+MI_CORE int mi_cache_parse_entry(const char* entry, int* is_empty, uint8_t* tar_sha256, uint8_t* gzip_sha256);
 /* parseEntry to the letter (cache_manager.go:239-245): the two halves around the FIRST comma, each
  * behind "sha256:", whatever they contain -- the reference does not validate them (the strict form
  * above needs two 64-digit hex halves because it hands out raw digests).  MI_ERR_INVALID without a
  * comma, MI_ERR_CAPACITY if a half does not fit.                                                 */
-int mi_cache_parse_entry_str(const char* entry, char* tar_digest, uint64_t tar_cap, char* gzip_digest,
+MI_CORE int mi_cache_parse_entry_str(const char* entry, char* tar_digest, uint64_t tar_cap, char* gzip_digest,
                              uint64_t gzip_cap);
 
 /* ---- standalone digests (image.Digester seam) ---------------------------------- *
@@ -831,7 +858,7 @@ int mi_cache_parse_entry_str(const char* entry, char* tar_digest, uint64_t tar_c
  * the batched form of image.NewDigester().FromBytes / FromReader
  * (lib/docker/image/digester.go:45-60).  data: host pointer, string i =
  * data[offsets[i] .. offsets[i]+lens[i]).  out: n x 32 bytes.                       */
-int mi_sha256_many(mi_ctx* ctx, const void* data, const uint64_t* offsets,
+MI_CORE int mi_sha256_many(mi_ctx* ctx, const void* data, const uint64_t* offsets,
                    const uint64_t* lens, uint64_t n, uint8_t* out);
 
 /* ---- chunk index: dedup across batches (keyvalue.Store seam) -------------------- *
@@ -847,13 +874,13 @@ int mi_sha256_many(mi_ctx* ctx, const void* data, const uint64_t* offsets,
  * 0 - dup_of already says so), then the new digests are added.  known may be NULL.
  * mi_index_export / mi_index_import move the set as a flat blob of 32-byte digests
  * (order unspecified) so the shim can keep it behind keyvalue.Store.Put/Get.      */
-int  mi_index_create(mi_ctx* ctx, uint64_t capacity_hint, mi_index** out);
-void mi_index_free(mi_index* index);
-int  mi_index_count(mi_index* index, uint64_t* n_digests);
-int  mi_index_add_batch(mi_index* index, mi_batch* b, uint8_t* known, uint64_t cap,
+MI_CORE int  mi_index_create(mi_ctx* ctx, uint64_t capacity_hint, mi_index** out);
+MI_CORE void mi_index_free(mi_index* index);
+MI_CORE int  mi_index_count(mi_index* index, uint64_t* n_digests);
+MI_BLOCK int  mi_index_add_batch(mi_index* index, mi_batch* b, uint8_t* known, uint64_t cap,
                         uint64_t* n_new, uint64_t* n_known);
-int  mi_index_export(mi_index* index, void* out_digests, uint64_t cap_digests);
-int  mi_index_import(mi_index* index, const void* digests, uint64_t n, uint64_t* n_new);
+MI_CORE int  mi_index_export(mi_index* index, void* out_digests, uint64_t cap_digests);
+MI_CORE int  mi_index_import(mi_index* index, const void* digests, uint64_t n, uint64_t* n_new);
 
 #ifdef __cplusplus
 }

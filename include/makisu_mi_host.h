@@ -28,9 +28,9 @@ extern "C" {
  *   paths, *bytes_out bytes; MI_ERR_CAPACITY if cap is smaller: call with cap 0 to size).  Each goes to
  *   mi_batch_add_tree(..., rel_base = context dir, MI_TREE_CONTEXT) in this order for the cache ID, and -- trimmed of
  *   the root -- into mi_copy_op.srcs.  Host logic.                                                                */
-int  mi_resolve_chown(const char* chown, int preserve_owner, int64_t* uid, int64_t* gid, char* err, uint64_t err_cap);
-int  mi_path_match(const char* pattern, const char* name, int* matched);
-int  mi_context_sources(const char* context_root, const char* const* from_paths, uint64_t n_paths, char* out,
+MI_BLOCK int  mi_resolve_chown(const char* chown, int preserve_owner, int64_t* uid, int64_t* gid, char* err, uint64_t err_cap);
+MI_BLOCK int  mi_path_match(const char* pattern, const char* name, int* matched);
+MI_BLOCK int  mi_context_sources(const char* context_root, const char* const* from_paths, uint64_t n_paths, char* out,
                         uint64_t cap, uint64_t* n_out, uint64_t* bytes_out);
 /* CopyOperation.Execute (lib/snapshot/copy_op.go:83-147) over fileio.Copier (lib/fileio/copy.go): the on-disk copy of the
  * step, for builds that modify the file system.  op as for mi_memfs_add_layer_by_copy_ops (dst resolved; "dir/" = copy INTO it).
@@ -43,7 +43,7 @@ int  mi_context_sources(const char* context_root, const char* const* from_paths,
 #define MI_COPY_CHOWN          0x1u
 #define MI_COPY_INTERNAL       0x2u
 #define MI_COPY_PRESERVE_OWNER 0x4u
-int  mi_copy_op_execute(const mi_copy_op* op, uint32_t flags, const char* const* blacklist, uint64_t n_blacklist,
+MI_BLOCK int  mi_copy_op_execute(const mi_copy_op* op, uint32_t flags, const char* const* blacklist, uint64_t n_blacklist,
                         char* err, uint64_t err_cap);
 
 /* UpdateFromTarReader with untar = true (the FROM step / a cached layer applied with --modifyfs): the entries of a PLAIN
@@ -54,13 +54,13 @@ int  mi_copy_op_execute(const mi_copy_op* op, uint32_t flags, const char* const*
  * mtimes of the parent directories are put back at the end -- and every header is merged into the tree as above.  After
  * it a scan of the root finds nothing to add.  Needs the privileges the reference needs (chown).  MI_ERR_IO + the
  * reference's message ("untar one item <path>: ...") on failure.                                                  */
-int  mi_memfs_untar(mi_memfs* fs, const char* tar_path, const mi_tree_entry* layer, const uint64_t* data_offsets,
+MI_BLOCK int  mi_memfs_untar(mi_memfs* fs, const char* tar_path, const mi_tree_entry* layer, const uint64_t* data_offsets,
                     uint64_t n_layer, uint64_t* n_merged);
 
 /* MemFS.Checkpoint (mem_fs.go:132-185): what a later stage will COPY --from is copied aside, to new_root + the path it has
  * below the root (patterns expanded like COPY sources; relative sources are below the root; the blacklist of the handle
  * applies; a created target directory gets the source's owner, everything copied keeps its own).                    */
-int  mi_memfs_checkpoint(mi_memfs* fs, const char* new_root, const char* const* sources, uint64_t n_sources);
+MI_BLOCK int  mi_memfs_checkpoint(mi_memfs* fs, const char* new_root, const char* const* sources, uint64_t n_sources);
 
 
 #ifdef __cplusplus

@@ -49,31 +49,19 @@ namespace mi {
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kCopies      = kGearTableCopies;          // Gear table replicas in LDS (kernels that keep bitmaps)
-#ifndef MI_GEAR_COAL_BYTES
-#define MI_GEAR_COAL_BYTES 0                            // bytes per lane and exchange of mark_tile_coal; 0 = lane-owned
-                                                        // loads, the default: same-box A/B in profiles/r03_gear_ab.txt
-#endif
-#ifndef MI_GEAR_FAST_COPIES                             // 32: 64 KiB table shared by a 512-thread workgroup, two per CU
-#define MI_GEAR_FAST_COPIES (MI_GEAR_COAL_BYTES ? 16 : 32)   // 16: 32 KiB table, 256-thread workgroups, four per CU
-#endif                                                  //     (kept for the coalesced variants, whose stages need the LDS)
-constexpr int kFastCopies  = MI_GEAR_FAST_COPIES;       // ... in the bitmap-free marking kernels (see below)
-#ifndef MI_GEAR_FAST_WG
-#define MI_GEAR_FAST_WG (MI_GEAR_FAST_COPIES == 32 ? 512 : 256)   // the same 16 waves per CU either way
-#endif
-constexpr int kFastWG      = MI_GEAR_FAST_WG;
+// 32 table copies: a 64 KiB table shared by a 512-thread workgroup, two workgroups per CU (16 waves per CU).  The variants that
+// were measured against this one -- 16 copies with 256-thread workgroups, a VGPR budget for more waves per SIMD, 64- and 32-byte
+// pieces, the marking through an LDS exchange of coalesced loads (mark_tile_coal), raised wave priority, a v_min3 tree, the
+// warm-up line taken from the lane's own run (wrong cuts; an upper bound of what a free warm-up could save) -- live as a patch
+// under tools/experiments/gear_cdc_experiments.patch with their numbers (profiles/r03_gear_ab.txt, r04_gear_ab.txt): the
+// shipped source has no switch that changes a cut.
+constexpr int kFastCopies  = 32;                        // ... in the bitmap-free marking kernels (see below)
+constexpr int kFastWG      = 512;
 constexpr int kFastWaves   = kFastWG / 64;
-#ifdef MI_GEAR_FAST_WAVES_PER_SIMD                      // experiments: a VGPR budget for more waves per SIMD (with a
-#define MI_GEAR_FAST_ATTR __attribute__((amdgpu_waves_per_eu(MI_GEAR_FAST_WAVES_PER_SIMD, MI_GEAR_FAST_WAVES_PER_SIMD)))
-#else                                                   // smaller MI_GEAR_PIECE and a larger MI_GEAR_FAST_WG).  Measured: 64-byte
-#define MI_GEAR_FAST_ATTR                               // pieces 1.55 ms at 4 waves, 1.65 at 5, 1.71 at 6; 32-byte pieces 2.4 ms at 8
-#endif                                                  // (profiles/r03_gear_ab.txt) -- whole cache lines per lane matter, waves do not
 
 constexpr int kWavesPerWG  = kGearWG / 64;              // 4
 constexpr int kLaneRun     = kGearTile / 64;            // 1 KiB per lane
-#ifndef MI_GEAR_PIECE
-#define MI_GEAR_PIECE 128
-#endif
-constexpr int kPiece       = MI_GEAR_PIECE;             // bytes per load group (128 = one cache line)
+constexpr int kPiece       = 128;                       // bytes per load group (128 = one cache line)
 constexpr int kPieceUnits  = kPiece / 16;
 constexpr int kBitmapWords = kGearTile / 32;            // u32 words per wave bitmap (8 KiB)
 constexpr int kTableBytes  = 256 * 8 * kCopies;
@@ -92,9 +80,7 @@ constexpr int kTableBytes  = 256 * 8 * kCopies;
 // marking kernels have no barrier behind the table load, a wave is on its own): C2 marking 1.38-1.42 -> 1.33-1.34 ms,
 // step 5.97-6.00 -> 5.80-5.85 ms on one box (profiles/r03_gear_ab.txt).
 constexpr int kFastTableBytes = 256 * 8 * kFastCopies;  // 64 KiB (32 KiB with 16 copies)
-constexpr int kCoalBytes = MI_GEAR_COAL_BYTES;
-
-constexpr int kFastListOff = kFastTableBytes + kFastWaves * 64 * kCoalBytes;      // table | stages | lists
+constexpr int kFastListOff = kFastTableBytes;                                     // table | lists
 constexpr int kFastLdsBytes = kFastListOff + kFastWaves * 64 * 4;
 // LDS: table | one bitmap per wave | one 64-entry candidate list per wave | fast flags
 constexpr int kLdsListOff  = kTableBytes + kWavesPerWG * kBitmapWords * 4;
@@ -217,16 +203,9 @@ __device__ __forceinline__ void hash16(u64& h, const u32x4 v, u32 tab, u32 thres
     roll16<kC>(h, v, tab, hh);
     // (a v_min3_u32 chain would be 8 ops instead of the 11 hipcc emits, but it is one dependent
     // chain: A/B on one box, 1.50 ms against 1.46 ms for the compiler's tree)
-#ifdef MI_GEAR_MIN3_TREE                                  // experiments: 7 x v_min3_u32 + 1 v_min_u32, depth 3
-    auto m3 = [](u32 a, u32 b, u32 c) { return min(min(a, b), c); };
-    const u32 t0 = m3(hh[0], hh[1], hh[2]), t1 = m3(hh[3], hh[4], hh[5]), t2 = m3(hh[6], hh[7], hh[8]),
-              t3 = m3(hh[9], hh[10], hh[11]), t4 = m3(hh[12], hh[13], hh[14]);
-    const u32 m = min(m3(t0, t1, t2), m3(t3, t4, hh[15]));
-#else
     u32 m = 0xFFFFFFFFu;
 #pragma unroll
     for (int k = 0; k < 16; k += 2) m = min(m, min(hh[k], hh[k + 1]));
-#endif
     if (m <= thresh_m1) {                                // rare: a candidate among these 16 bytes
         // (positions at or past the file end are not filtered here: selection never looks
         // beyond the tile's last byte, and at most one lane hashes up to 127 slack bytes)
@@ -268,16 +247,8 @@ __device__ __forceinline__ void mark_tile(const u8* __restrict__ fptr, u64 ts, u
     u32 hh[16];
     if (ts + run0 != 0) {                                // warm the window: 64 bytes before my run
         u32x4 wq[4];
-#ifdef MI_GEAR_EXPERIMENT_NO_WARMUP_LINE
-        // MEASUREMENT ONLY (wrong cuts near run starts): the warm-up taken from the lane's OWN first line, i.e. the same
-        // instructions and registers without the extra cache line -- the most any scheme that gets the neighbour's tail
-        // for free could save (profiles/r04_gear_ab.txt)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) wq[i] = *(const u32x4*)(p + 16 * i);
-#else
 #pragma unroll
         for (int i = 0; i < 4; ++i) wq[i] = *(const u32x4*)(p - 64 + 16 * i);
-#endif
 #pragma unroll
         for (int i = 0; i < 4; ++i) roll16<kC>(h, wq[i], tab, hh);
     }
@@ -293,100 +264,6 @@ __device__ __forceinline__ void mark_tile(const u8* __restrict__ fptr, u64 ts, u
     // (Round 3 tried one piece of registers instead of two -- each 16-byte unit of the next piece requested
     // into the registers of the unit just hashed, 84 VGPRs, five or six waves per SIMD: 2.15-2.28 ms instead
     // of 1.34, profiles/r03_gear_ab.txt; a load per unit means a wait per unit.)
-}
-
-// ---- coalesced form of the marking (round 3) ------------------------------------------------------
-// mark_tile lets every lane stream its own 1 KiB run: each load instruction of the wave touches 64
-// different cache lines, and that ACCESS PATTERN -- not HBM, not the LDS lookups -- bounded the kernel at
-// 4.4 TB/s (profiles/r01_ubench_stream.txt: 3.9-4.2 for the pattern, 6.1-6.4 coalesced; round 3's
-// conflict-free table changed the time by 3 %).  Here the WAVE fetches the next kP bytes of all 64 runs
-// with kP/16 instructions that each read whole (half) cache lines -- lane l takes 16-byte unit
-// l % (kP/16) of owner  (64 / (kP/16)) i + l / (kP/16) -- and the lanes swap the units through a per-wave
-// LDS stage (kP bytes per lane, rows XOR-swizzled so that both the 8-lane write and read passes of the
-// b128 accesses cover all banks): +2 B of LDS traffic per input byte next to the 8 B of table lookups.
-template <int kP>
-struct Coal {
-    static constexpr int kUnits = kP / 16;               // 16-byte units per lane and step (4 or 8)
-    static constexpr int kOwners = 64 / kUnits;          // owners served by one load instruction
-    static constexpr int kStageBytes = 64 * kP;          // per wave
-    static_assert(kP == 64 || kP == 128, "stage rows of 64 or 128 bytes");
-    __device__ static __forceinline__ u32 slot(u32 o, u32 u) { return o * kUnits + (u ^ ((o / (8 / kUnits)) & (kUnits - 1))); }
-};
-
-template <int kC, int kP>
-__device__ __forceinline__ void mark_tile_coal(const u8* __restrict__ fptr, u64 ts, u32 tlen, u32x4* stage,
-                                               u32 tab, u32 thresh_m1, int lane, CandPack& pk, bool& ovf) {
-    typedef Coal<kP> G;
-    pk.a = pk.b = 0;
-    ovf = false;
-    const u8* tile = fptr + ts;
-    const u32 run0 = (u32)lane * kLaneRun;               // tile-relative start of my run
-    const u32 run_len = run0 < tlen ? (tlen - run0 < (u32)kLaneRun ? tlen - run0 : (u32)kLaneRun) : 0u;
-    const int n_steps = (int)((run_len + kP - 1) / kP);  // mine
-    const u32 len0 = tlen < (u32)kLaneRun ? tlen : (u32)kLaneRun;
-    const int n_steps_w = (int)((len0 + kP - 1) / kP);   // lane 0's = the wave's (runs only get shorter)
-    const u32 lim = (tlen + 15u) & ~15u;                 // no load starts beyond the tile's last byte
-    const u32 u = (u32)lane % G::kUnits, orow = (u32)lane / G::kUnits;
-    const u32x4 zero = {0, 0, 0, 0};
-    u32x4 g[G::kUnits], cur[G::kUnits];
-
-    auto fetch = [&](int step) {                         // unit u of step `step` of owners kOwners i + orow
-#pragma unroll
-        for (int i = 0; i < G::kUnits; ++i) {
-            const u32 off = ((u32)G::kOwners * i + orow) * kLaneRun + (u32)step * kP + u * 16u;
-            g[i] = off < lim ? *(const u32x4*)(tile + off) : zero;
-        }
-    };
-    auto exchange = [&]() {                              // g (fetched for others) -> cur (mine)
-#pragma unroll
-        for (int i = 0; i < G::kUnits; ++i) stage[G::slot((u32)G::kOwners * i + orow, u)] = g[i];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-        for (int k = 0; k < G::kUnits; ++k) cur[k] = stage[G::slot((u32)lane, (u32)k)];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();                 // the rows are rewritten by the next exchange
-    };
-
-    // warm-up: the 64 bytes before every run (the previous owner's last bytes; the previous tile's for
-    // lane 0), fetched 16 owners per instruction -- only the first four units of a row are used
-    u64 h = 0;
-    u32 hh[16];
-    {
-        const u32 wu = (u32)lane & 3u, wrow = (u32)lane >> 2;
-        u32x4 w4[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const u32 o = 16u * i + wrow;
-            const bool has = o * kLaneRun < tlen && (ts + o * kLaneRun) != 0;
-            w4[i] = has ? *(const u32x4*)(tile + o * kLaneRun - 64 + wu * 16u) : zero;
-        }
-        fetch(0);                                        // in flight behind them
-#pragma unroll
-        for (int i = 0; i < 4; ++i) stage[G::slot(16u * i + wrow, wu)] = w4[i];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        u32x4 wq[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) wq[k] = stage[G::slot((u32)lane, (u32)k)];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (run_len && ts + run0 != 0) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) roll16<kC>(h, wq[k], tab, hh);
-        }
-    }
-    for (int step = 0; step < n_steps_w; ++step) {
-        exchange();
-        if (step + 1 < n_steps_w) fetch(step + 1);       // in flight while hashing
-        if (step < n_steps) {
-#pragma unroll
-            for (int k = 0; k < G::kUnits; ++k)
-                hash16<kC, false>(h, cur[k], tab, thresh_m1, run0, (u32)(step * kP + k * 16), nullptr, pk, ovf);
-        }
-    }
 }
 
 // Wave-uniform cut selection over one marked tile.  Every cut is handed to emit(cut) (wave-uniform
@@ -473,7 +350,7 @@ __device__ __forceinline__ void load_table(u64* table, const u64* __restrict__ g
 // 64-entry list).  A file with more than 64 candidates (or a lane with more than six) is appended to
 // dense_list and left to gear_cdc_small_kernel, the round-1/2 form with its exact per-wave bitmap,
 // which runs over that list afterwards (n_list_dev: the list's length, known on the device only).
-__global__ __launch_bounds__(kFastWG) MI_GEAR_FAST_ATTR
+__global__ __launch_bounds__(kFastWG)
 void gear_cdc_small_fast_kernel(const u8* __restrict__ data, const u64* __restrict__ file_off,
                                 const u64* __restrict__ file_size, const u32* __restrict__ seg_file,
                                 const u64* __restrict__ seg_slot, u32* __restrict__ ends32,
@@ -484,9 +361,6 @@ void gear_cdc_small_fast_kernel(const u8* __restrict__ data, const u64* __restri
     u64* table = (u64*)smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     u32* cand_list = (u32*)(smem + kFastListOff) + wave * 64;
-#ifdef MI_GEAR_PRIO                                       // experiments: the marking's waves above another batch's hashing
-    __builtin_amdgcn_s_setprio(MI_GEAR_PRIO);
-#endif
     load_table<kFastCopies, kFastWG>(table, gear_table, tid);
     __syncthreads();
     const u32 lane_tab = lds_lane_table<kFastCopies>(table, lane);
@@ -501,11 +375,7 @@ void gear_cdc_small_fast_kernel(const u8* __restrict__ data, const u64* __restri
     if (size) {
         CandPack pk;
         bool ovf;
-        if (kCoalBytes)
-            mark_tile_coal<kFastCopies, kCoalBytes ? kCoalBytes : 64>(data + file_off[f], 0, (u32)size,
-                (u32x4*)(smem + kFastTableBytes) + wave * (kCoalBytes * 4), lane_tab, p.thresh_m1, lane, pk, ovf);
-        else
-            mark_tile<kFastCopies, false>(data + file_off[f], 0, (u32)size, nullptr, lane_tab, p.thresh_m1, lane, pk, ovf);
+        mark_tile<kFastCopies, false>(data + file_off[f], 0, (u32)size, nullptr, lane_tab, p.thresh_m1, lane, pk, ovf);
         if (!cand_compact(pk, ovf, (u32)lane * kLaneRun, lane, cand_list)) {      // wave-uniform
             if (lane == 0) dense_list[atomicAdd(dense_count, 1u)] = s;
             return;
@@ -652,7 +522,7 @@ __device__ __forceinline__ u64 reselect_group(const u32* lists, const u32* bitma
 // workgroup per group (four tiles), no workgroup barrier behind the table load, no loop (a persistent
 // form needs 168+ VGPRs where this one, like the small-file kernel, takes 146: three workgroups per CU).  Per tile: the sorted candidate list (64 x u32, HBM) and
 // tile_fast = 1, or tile_fast = 0 for a DENSE tile (more than 64 candidates: no list).
-__global__ __launch_bounds__(kFastWG) MI_GEAR_FAST_ATTR
+__global__ __launch_bounds__(kFastWG)
 void gear_tile_mark_kernel(const u8* __restrict__ data, const u64* __restrict__ file_off,
                            const u64* __restrict__ file_size, const u32* __restrict__ group_file,
                            const u32* __restrict__ group_index, u32 n_groups,
@@ -681,11 +551,7 @@ void gear_tile_mark_kernel(const u8* __restrict__ data, const u64* __restrict__ 
         const u32 tlen = (u32)((size - ts < (u64)kGearTile) ? (size - ts) : (u64)kGearTile);
         CandPack pk;
         bool ovf;
-        if (kCoalBytes)
-            mark_tile_coal<kFastCopies, kCoalBytes ? kCoalBytes : 64>(data + file_off[f], ts, tlen,
-                (u32x4*)(smem + kFastTableBytes) + wave * (kCoalBytes * 4), lane_tab, p.thresh_m1, lane, pk, ovf);
-        else
-            mark_tile<kFastCopies, false>(data + file_off[f], ts, tlen, nullptr, lane_tab, p.thresh_m1, lane, pk, ovf);
+        mark_tile<kFastCopies, false>(data + file_off[f], ts, tlen, nullptr, lane_tab, p.thresh_m1, lane, pk, ovf);
         fast = cand_compact(pk, ovf, (u32)lane * kLaneRun, lane, cl);
         __builtin_amdgcn_wave_barrier();
         tile_lists[t * 64 + lane] = fast ? cl[lane] : kNoCand;

@@ -14,6 +14,7 @@
 // There is no CPU fallback anywhere in this file.
 #include "mi_internal.h"
 #include "mi_hostpath.h"      // mi_io
+#include "host_sha256.h"      // mi_sha256_many: strings too long for a GPU lane
 
 #include <errno.h>
 #include <fcntl.h>
@@ -26,8 +27,10 @@
 
 #include <algorithm>
 #include <chrono>
+#include <atomic>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -119,6 +122,7 @@ int arena_reserve(mi_batch* b, u64 want, bool told = false, bool ahead = false) 
     if (b->arena.p && b->arena_used) {
         const u64 keep = b->arena_used < b->arena.bytes ? b->arena_used : b->arena.bytes;
         HIPCHK(c, hipMemcpy(np, b->arena.p, keep, hipMemcpyDeviceToDevice));
+        ++b->arena.moves;
     }
     if (b->arena.p) (void)dev_free(b->arena.p);
     b->arena.p = np;
@@ -520,7 +524,7 @@ int submit_pipeline_enqueue(mi_batch* b) {
                         (u32)nf, nullptr, heads(1), nullptr, false, b->roots.as<u8>(),
                         sha, ncu, 0, s);
     if (c->cfg.flags & MI_FLAG_FILE_SHA256)
-        launch_sha256_items(kShaFiles, b->arena.as<u8>(), d_off, d_size, nullptr, (u32)nf, nullptr,
+        launch_sha256_items(kShaFiles, b->arena.as<u8>(), d_off, b->fsha_len.as<u64>(), nullptr, (u32)nf, nullptr,
                             heads(2), nullptr, false, b->file_sha.as<u8>(), sha, ncu, b->arena_used, s);   // files come in
                             // arrival order, not longest-first: no "long" range to hand to a SIMD's first wave (flat sharing)
     if (c->cfg.flags & MI_FLAG_FILE_CRC32) {
@@ -540,6 +544,15 @@ int submit_pipeline_enqueue(mi_batch* b) {
     HIPCHK(c, hipMemcpyAsync(&b->h_counts[0], ctl, 16, hipMemcpyDeviceToHost, s));   // {total, n_unique}
     HIPCHK(c, hipEventRecord(b->ev[5], s));
     HIPCHK(c, hipGetLastError());
+    if ((c->cfg.flags & MI_FLAG_FILE_SHA256) && !b->fsha_host.empty()) {
+        // ... and beside the passes, the long files on the reader threads (they are idle: staging has ended)
+        const size_t k = b->fsha_host.size();
+        std::vector<u64> ho(k), hl(k);
+        for (size_t i = 0; i < k; ++i) { ho[i] = b->files[b->fsha_host[i]].off; hl[i] = b->files[b->fsha_host[i]].size; }
+        b->fsha_host_out.assign(k * 32, 0);
+        if (b->fsha_latch) (void)stager_hash_wait(c, b->fsha_latch);
+        b->fsha_latch = stager_hash_ranges(c->stager, b, k, ho.data(), hl.data(), b->fsha_host_out.data());
+    }
     return MI_OK;
 }
 
@@ -552,6 +565,12 @@ int wait_pipeline(mi_batch* b) {
     if (c->batches_in_flight > 0) --c->batches_in_flight;
     HIPCHK(c, hipStreamSynchronize(b->stream));
     HIPCHK(c, hipGetLastError());
+    if (b->fsha_latch) {
+        mi::HashLatch* l = b->fsha_latch;
+        b->fsha_latch = nullptr;
+        const int rc = stager_hash_wait(c, l);
+        if (rc) return rc;
+    }
     const u64 total = b->h_counts[0];
     if (total > b->total_slots)
         return fail(c, MI_ERR_HIP, "chunk count %llu exceeds its bound %llu",
@@ -626,6 +645,9 @@ int fetch_results(mi_batch* b) {
         HIPCHK(c, hipStreamSynchronize(b->stream));
         HIPCHK(c, hipGetLastError());
     }
+    if ((c->cfg.flags & MI_FLAG_FILE_SHA256) && b->fsha_host_out.size() == b->fsha_host.size() * 32)
+        for (size_t i = 0; i < b->fsha_host.size(); ++i)   // the long files' digests come from the host side of the pass
+            memcpy(b->h_files[b->fsha_host[i]].file_sha256, b->fsha_host_out.data() + 32 * i, 32);
     for (u64 f = 0; f < nf; ++f) {                      // what only the host knows: the caller's tag; a part's own range
         mi_file_result& r = b->h_files[f];
         r.user_tag = b->files[f].tag;
@@ -671,12 +693,13 @@ int mi_config_default(mi_config* cfg) {
     return MI_OK;
 }
 
+// (a copy of the caller's own, taken under the lock every writer holds: a pipelined commit has two threads of the library on one
+//  ctx -- its scan and its tar writer -- and a failure can reach both while the host asks; valid until the calling thread asks again)
 const char* mi_last_error(mi_ctx* ctx) {
-    if (ctx) return ctx->err.c_str();
+    static thread_local std::string mine;
     std::lock_guard<std::mutex> g(g_err_mu);
-    static std::string copy;
-    copy = g_create_err;
-    return copy.c_str();
+    mine = ctx ? ctx->err : g_create_err;
+    return mine.c_str();
 }
 
 int mi_ctx_create(const mi_config* cfg, mi_ctx** out) {
@@ -1312,6 +1335,17 @@ static int stage_batch(mi_batch* b) {
     if ((rc = upload(c, b->large_group0, large_g0))) return rc;
     if ((rc = upload(c, b->file_off, off))) return rc;
     if ((rc = upload(c, b->file_size, size))) return rc;
+    b->fsha_host.clear();
+    if (c->cfg.flags & MI_FLAG_FILE_SHA256) {
+        // whole-file digests: a file too long for a GPU lane goes to the reader threads' SHA-NI streams (route_long_strings);
+        // the GPU pass sees it as an empty string.  (Parts have no whole-file values.)
+        std::vector<u64> fl(size);
+        for (u64 f = 0; f < nf; ++f) if (b->files[f].part >= 0) fl[f] = 0;
+        route_long_strings(fl.data(), nf, c->stage_threads, false, &b->fsha_host);
+        for (u32 f : b->fsha_host) fl[f] = 0;
+        if ((rc = upload(c, b->fsha_len, fl))) return rc;
+        if (!b->fsha_host.empty() && (rc = ensure_stager(c))) return rc;
+    }
     std::vector<u32> fflags, pfile, pg0, phalo;
     if (!b->parts.empty()) {
         fflags.assign(nf, 0u);
@@ -1397,6 +1431,8 @@ int mi_batch_reset(mi_batch* b) {
     if (b->in_flight) return fail(c, MI_ERR_STATE, "batch is in flight; mi_batch_wait first");
     int rc = staging_sync(b);                           // nothing may still be writing into the arena
     (void)rc;                                           // a sticky staging failure ends here
+    if (b->fsha_latch) { (void)stager_hash_wait(c, b->fsha_latch); b->fsha_latch = nullptr; }
+    b->fsha_host.clear();
     b->stage_err.clear();
     b->stage_note.clear();
     {
@@ -1725,6 +1761,15 @@ int mi_batch_file_size(mi_batch* b, uint64_t file_index, uint64_t* size) {      
     *size = b->files[file_index].size;
     return MI_OK;
 }
+int mi_batch_arena_info(mi_batch* b, uint64_t* bytes, uint64_t* pieces, uint64_t* moves) {
+    if (!b) return MI_ERR_INVALID;
+    u64 mapped = 0, n = 0;
+    arena_counts(&b->arena, &mapped, &n, nullptr);
+    if (bytes) *bytes = b->arena.vm ? mapped : b->arena.bytes;
+    if (pieces) *pieces = b->arena.vm ? n : (b->arena.p ? 1 : 0);
+    if (moves) *moves = b->arena.moves;
+    return MI_OK;
+}
 int mi_batch_arena_room(mi_batch* b, uint64_t* bytes) {
     if (!b || !bytes) return MI_ERR_INVALID;
     *bytes = b->arena.bytes;
@@ -1740,9 +1785,8 @@ const char* mi_last_error_of_batch(mi_batch* b) {                // (a copy of t
 
 void** mi_batch_tree_slot(mi_batch* b) { return &b->tree; }
 void mi_set_error(mi_batch* b, const char* msg) {                // b NULL: the message mi_last_error(NULL) returns
-    if (b) { b->ctx->err = msg; return; }
     std::lock_guard<std::mutex> g(g_err_mu);
-    g_create_err = msg;
+    if (b) b->ctx->err = msg; else g_create_err = msg;
 }
 
 int mi_batch_free(mi_batch* b) {
@@ -1755,6 +1799,8 @@ int mi_batch_free(mi_batch* b) {
         if (c->batches_in_flight > 0) --c->batches_in_flight;
     }
     (void)staging_sync(b);                      // reader threads may still hold pieces of this batch
+    if (b->fsha_latch) { (void)stager_hash_wait(c, b->fsha_latch); b->fsha_latch = nullptr; }
+    b->fsha_len.release();
     for (int i = 0; i < 2; ++i) {
         if (b->ring_ev[i]) (void)hipEventDestroy(b->ring_ev[i]);
         if (b->ring[i]) (void)hipHostFree(b->ring[i]);
@@ -1912,27 +1958,78 @@ int mi_sha256_many(mi_ctx* c, const void* data, const uint64_t* offsets, const u
     u64 span = 0;
     for (u64 i = 0; i < n; ++i) if (offsets[i] + lens[i] > span) span = offsets[i] + lens[i];
     if (span && !data) return MI_ERR_INVALID;
+    // A single SHA-256 stream is serial: one GPU lane does 13.5 MB/s, one host core with SHA-NI 2.4 GB/s.
+    // Strings that would hold the launch up -- a `docker save` layer tar handed to `makisu push` (bin/makisu/cmd/push.go:207,230) --
+    // are hashed HERE, one stream per host thread, straight from the caller's memory, while the GPU takes the many short ones
+    // (route_long_strings decides; 8 x 128 MiB: 10 s on eight lanes, 0.06 s on eight cores).  This is not a fallback: it is where
+    // a long Merkle-Damgard stream belongs on this machine.
+    std::vector<u32> to_host;
+    unsigned hw = std::thread::hardware_concurrency();
+    if (const char* e = getenv("MI_SHA_HOST_THREADS")) { const int v = atoi(e); if (v >= 0 && v <= 256) hw = (unsigned)v; }
+    if (hw > 16) hw = 16;
+    route_long_strings(lens, n, hw, true, &to_host);
+    std::vector<std::thread> pool;
+    std::atomic<size_t> next{0};
+    if (!to_host.empty()) {
+        const unsigned nt = hw < to_host.size() ? hw : (unsigned)to_host.size();
+        for (unsigned t = 0; t < nt; ++t)
+            pool.emplace_back([&] {
+                for (;;) {
+                    const size_t k = next.fetch_add(1);
+                    if (k >= to_host.size()) return;
+                    const u32 i = to_host[k];
+                    mi_host::Sha256 sha;
+                    sha.update((const u8*)data + offsets[i], (size_t)lens[i]);
+                    sha.final(out + 32 * (size_t)i);
+                }
+            });
+    }
+    struct Join { std::vector<std::thread>& p; ~Join() { for (auto& t : p) if (t.joinable()) t.join(); } } join{pool};
+    // the rest: compacted (only what the GPU hashes crosses PCIe), one lane per string
+    std::vector<u8> is_host(to_host.empty() ? 0 : n, 0);
+    for (u32 i : to_host) is_host[i] = 1;
+    std::vector<u64> g_off, g_len, g_idx;
+    u64 g_bytes = 0;
+    if (to_host.empty()) {
+        g_bytes = span;
+    } else {
+        for (u64 i = 0; i < n; ++i) if (!is_host[i]) { g_off.push_back(g_bytes); g_len.push_back(lens[i]); g_idx.push_back(i); g_bytes += (lens[i] + 15) & ~15ull; }
+    }
+    const u64 ng = to_host.empty() ? n : g_idx.size();
+    if (ng == 0) return MI_OK;
     DevBuf d_data, d_off, d_len, d_out;
     int rc = MI_OK;
     hipError_t e;
-    if ((e = d_data.ensure(span + 64)) != hipSuccess || (e = d_off.ensure(n * 8)) != hipSuccess ||
-        (e = d_len.ensure(n * 8)) != hipSuccess || (e = d_out.ensure(n * 32)) != hipSuccess) {
+    std::vector<u8> packed, g_out;
+    if (!to_host.empty()) {
+        packed.resize(g_bytes);
+        for (u64 k = 0; k < ng; ++k) memcpy(packed.data() + g_off[k], (const u8*)data + offsets[g_idx[k]], (size_t)g_len[k]);
+        g_out.resize(ng * 32);
+    }
+    const void* src = to_host.empty() ? data : (const void*)packed.data();
+    const u64* src_off = to_host.empty() ? offsets : g_off.data();
+    const u64* src_len = to_host.empty() ? lens : g_len.data();
+    u8* dst = to_host.empty() ? out : g_out.data();
+    if ((e = d_data.ensure(g_bytes + 64)) != hipSuccess || (e = d_off.ensure(ng * 8)) != hipSuccess ||
+        (e = d_len.ensure(ng * 8)) != hipSuccess || (e = d_out.ensure(ng * 32)) != hipSuccess) {
         rc = fail(c, MI_ERR_NOMEM, "mi_sha256_many: %s", hipGetErrorString(e));
     } else {
-        if (span) e = hipMemcpy(d_data.p, data, span, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(d_off.p, offsets, n * 8, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(d_len.p, lens, n * 8, hipMemcpyHostToDevice);
+        if (g_bytes) e = hipMemcpy(d_data.p, src, g_bytes, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d_off.p, src_off, ng * 8, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d_len.p, src_len, ng * 8, hipMemcpyHostToDevice);
         if (e == hipSuccess) {
-            launch_sha256_items(kShaBlobs, d_data.as<u8>(), d_off.as<u64>(), d_len.as<u64>(), nullptr, (u32)n,
+            launch_sha256_items(kShaBlobs, d_data.as<u8>(), d_off.as<u64>(), d_len.as<u64>(), nullptr, (u32)ng,
                                 nullptr, c->heads.as<u32>(), nullptr, true, d_out.as<u8>(), c->sha,      // blobs in arrival order: flat sharing
-                                c->prop.multiProcessorCount, span, c->stream);
+                                c->prop.multiProcessorCount, g_bytes, c->stream);
             e = hipStreamSynchronize(c->stream);
         }
         if (e == hipSuccess) e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpy(out, d_out.p, n * 32, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(dst, d_out.p, ng * 32, hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = fail(c, MI_ERR_HIP, "mi_sha256_many: %s", hipGetErrorString(e));
     }
     d_data.release(); d_off.release(); d_len.release(); d_out.release();
+    if (!rc && !to_host.empty())
+        for (u64 k = 0; k < ng; ++k) memcpy(out + 32 * g_idx[k], g_out.data() + 32 * k, 32);
     return rc;
 }
 

@@ -215,6 +215,7 @@ int arena_promise(mi_ctx* c, Arena* a, u64 want) {
         vm->va = nva;
         vm->reserved = range;
         a->p = nva;
+        ++a->moves;
     }
     if (arena_trace()) fprintf(stderr, "mi_arena: promise %.1f MB -> %.1f MB (%.1f mapped)\n", a->bytes / 1e6, need / 1e6, vm->mapped / 1e6);
     vm->target = need;

@@ -64,7 +64,11 @@ struct Tree {
     }
 };
 constexpr uint8_t kContentKnown = 1, kEntryHeld = 2;
-// "is this regular file's content known?" -- asked by whoever stats the file (the directory readers: several threads at a time)
+// "is this regular file's content known?" -- asked by whoever stats the file (the directory readers: several threads at a time).
+// RULE for everything that runs on a directory reader's thread -- this predicate, a block's release callback, anything a later
+// round hooks in: NO HIP CALL and NO DESCRIPTOR OF THE PROCESS.  Those threads leave the process's descriptor table
+// (close_range(3, ~0, CLOSE_RANGE_UNSHARE) in mi_tree.hip's worker, also when the walk reads nothing): /dev/kfd, /dev/dri/*, the
+// host's sockets and pipes do not exist there; a HIP call would find its driver handles closed.
 using KnownFn = std::function<uint8_t(const std::string& path_on_disk, const struct stat& st, const InodeStamp& stamp)>;
 
 // Go's path.Clean for a ROOTED path (what path.Join("/", p) returns): single slashes, no "."

@@ -50,6 +50,7 @@ struct Arena {
     void* p = nullptr;
     size_t bytes = 0;
     ArenaVm* vm = nullptr;
+    u64 moves = 0;            // times the arena's base address changed while it held bytes (plain: every growth; piecewise: a range outgrown)
     template <typename T> T* as() const { return (T*)p; }
 };
 bool arena_is_plain();                                      // MI_GUARD_ALLOC or MI_ARENA=malloc: the moving arena
@@ -107,6 +108,19 @@ void    stager_pause(Stager* st, int ms);            // up to `ms` milliseconds,
 // *landed_out (optional): how far the landed prefix reaches by now (~0: everything queued so far)
 int     stager_wait_landed(Stager* st, mi_batch* b, u64 upto, u64* landed_out);
 u64     stager_landed(Stager* st, mi_batch* b);      // the same number, now, without waiting
+// Whole-string SHA-256 of n ranges of the batch's arena on the reader threads (each a SHA-NI stream over its pinned slab, the
+// next piece on its way out of HBM while one is hashed): what the hashing pass hands over when a string is too long for a GPU
+// lane (route_long_strings).  Returns at once; wait with stager_hash_wait (MI_ERR_HIP / the first failure's message on the ctx).
+struct HashLatch;
+HashLatch* stager_hash_ranges(Stager* st, mi_batch* b, u64 n, const u64* arena_off, const u64* len, u8* out32);
+int        stager_hash_wait(mi_ctx* c, HashLatch* latch);      // frees the latch
+
+// Which of n strings go to host SHA-NI streams instead of GPU lanes?  One lane hashes 13.5 MB/s (the pass's 1.77 TB/s over
+// 131 072 lanes), one host core 2.2 GB/s: a pass is as long as its longest string on ONE lane unless there are enough strings to
+// keep every lane busy anyway.  The strings are looked at as classes of equal length, longest first; the classes that leave the
+// GPU are those for which max(host time, GPU time of the rest) is smallest.  to_host: indexes, longest first (empty: nothing).
+// host_threads: streams the host side can run at once; h2d: the rest has to cross PCIe first (mi_sha256_many)
+void route_long_strings(const u64* lens, u64 n, u32 host_threads, bool h2d, std::vector<u32>* to_host);
 
 }  // namespace mi
 
@@ -205,6 +219,11 @@ struct mi_batch {
     mi::DevBuf chunk_off, chunk_len, chunk_file, chunk_start, digests;
     mi::DevBuf q_off, q_len, q_id;           // SHA queue descriptors, longest chunk first
     mi::DevBuf item_off, item_len, roots, file_sha, dup_of;
+    // MI_FLAG_FILE_SHA256: files too long for a GPU lane are hashed by the reader threads (route_long_strings)
+    std::vector<mi::u32> fsha_host;              // their rows, longest first (decided when the batch is staged)
+    std::vector<mi::u8> fsha_host_out;           // 32 bytes each, as of the last run
+    mi::DevBuf fsha_len;                         // the GPU pass's lengths: 0 for those rows
+    mi::HashLatch* fsha_latch = nullptr;         // the host side of a run in flight
     mi::DevBuf root_addr, root_cnt, rseg_cnt, rseg_first, rseg_total, root_items_off, root_items_len;
     mi::DevBuf root_level[mi::kMaxRootPasses];   // node digests of the reduction passes
     mi::DevBuf root_addr2, root_cnt2;    // ping-pong partner of root_addr / root_cnt

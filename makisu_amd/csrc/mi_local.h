@@ -14,6 +14,8 @@ MI_LOCAL int         mi_batch_file_size(mi_batch* b, uint64_t file_index, uint64
 MI_LOCAL const char* mi_last_error_of_batch(mi_batch* b);
 // what the batch's arena holds now (bytes allocated): the room a window of an oversize tree can count on
 MI_LOCAL int         mi_batch_arena_room(mi_batch* b, uint64_t* bytes);
+// device memory behind the arena now, in how many pieces (1: one allocation), and how often its base address has changed
+MI_LOCAL int         mi_batch_arena_info(mi_batch* b, uint64_t* bytes, uint64_t* pieces, uint64_t* moves);
 // mi_batch_read_file for the pipelined commit: the batch is still being staged / scanned on another thread; the call waits
 // until the bytes it is asked for have landed in HBM
 MI_LOCAL int         mi_batch_read_file_landed(mi_batch* b, uint64_t file_index, uint64_t offset, void* dst, uint64_t len);

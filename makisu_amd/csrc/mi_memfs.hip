@@ -63,6 +63,9 @@ struct Node {
     bool has_root = false;     // chunk root of the content, when the caller scanned it (content-aware isUpdated)
     uint8_t root[32];
     int64_t batch_file = -1;   // a content-aware commit under way: the file's row in the commit's batch -- its bytes lie in HBM
+    uint32_t batch_gen = 0;    // ... of WHICH commit (Fs::commit_gen): the tree keeps its nodes, a later commit that puts one back into
+                               // its layer "as it is" (addAncestors over a path the tree holds as a file) must not take the old row
+                               // for a row of its own batch -- it reads that file from its source path, as the reference does
     bool root_pending = false; // ... and its root is still being computed (a pipelined commit: ScanJob); root[] is not valid yet
 };
 // MI_MEMFS_TRUST_CTIME, per node whose root a commit of this handle computed: the inode as it was when the content was read, and
@@ -298,6 +301,7 @@ struct Fs {
     }
     const uint64_t id = [] { static std::atomic<uint64_t> n{0}; return ++n; }();    // (a handle's number: never given twice)
     uint32_t reserved_mark = 0;                                                 // the coming scan's mark, taken before its walk (0: none)
+    uint32_t commit_gen = 0;                                                    // which mi_memfs_commit_layer call of this handle is under way (Node::batch_gen)
     bool trust_ctime = false;                                                   // mi_memfs_set_options(MI_MEMFS_TRUST_CTIME)
     int64_t commit_started_ns = 0;                                              // CLOCK_REALTIME when the commit under way began its walk
     // "is the content of the regular file at `disk_path` known?" -- asked by the walk's directory readers, several at a time,
@@ -321,18 +325,19 @@ struct Fs {
         // thousands of siblings whose map nodes no cache holds (2.4 us per file, summed over the readers, before; the walk of a
         // million trusted files cost 0.12 s more than the plain walk).  Nothing changes the tree while the walk runs.
         using Kids = decltype(mi_memtree::Node::children);
-        struct DirMemo { uint64_t fs_id = 0, gen = 0; std::string dir; const mi_memtree::Node* node = nullptr; Kids::const_iterator at; };
+        struct DirMemo { uint64_t fs_id = 0, gen = 0; uint32_t mark = 0; std::string dir; const mi_memtree::Node* node = nullptr; Kids::const_iterator at; };   // (mark: a memo never outlives the walk it was made in)
         static thread_local DirMemo memo;
         const size_t cut = disk_path.find_last_of('/');
         const mi_memtree::Node* nd = nullptr;
         if (cut != std::string::npos && cut >= root_len && cut + 1 < disk_path.size()) {
             const size_t dir_len = cut - root_len;                                // the directory below the root ("" = the root itself)
-            if (!(memo.fs_id == id && memo.gen == t.gen && memo.dir.size() == dir_len &&
+            if (!(memo.fs_id == id && memo.gen == t.gen && memo.mark == mark && memo.dir.size() == dir_len &&
                   memcmp(memo.dir.data(), disk_path.data() + root_len, dir_len) == 0)) {
                 memo.dir.assign(disk_path, root_len, dir_len);
                 memo.node = t.find_walk(memo.dir);                                // (find_walk keeps no cache: safe from many threads)
                 memo.fs_id = id;
                 memo.gen = t.gen;
+                memo.mark = mark;
                 if (memo.node) memo.at = memo.node->children.begin();
             }
             if (memo.node) {
@@ -471,7 +476,7 @@ struct Fs {
             if (similar && n.has_root && !o.has_root && n.e.kind == 1 && o.e.kind == 1) {   // the first content scan of an unchanged
                 Node& held = nodes[cur->ref];                                                // file: its root is known from now on
                 held.has_root = true;
-                if (n.root_pending) { held.root_pending = true; held.batch_file = n.batch_file; pending_refs.push_back(cur->ref); }
+                if (n.root_pending) { held.root_pending = true; held.batch_file = n.batch_file; held.batch_gen = commit_gen; pending_refs.push_back(cur->ref); }
                 else memcpy(held.root, n.root, 32);
                 ++n_roots_learned;
             } else if (!similar && o.has_root && n.has_root && a.kind == 1 && b.kind == 1) {
@@ -579,7 +584,7 @@ struct Fs {
         if (similar && file_has_root && !o.has_root && o.e.kind == 1 && b.kind == 1) {   // (as in maybe_add)
             o.has_root = true;
             if (content_root) memcpy(o.root, content_root, 32);
-            else { o.root_pending = true; o.batch_file = lazy_file; pending_refs.push_back(cur->ref); }
+            else { o.root_pending = true; o.batch_file = lazy_file; o.batch_gen = commit_gen; pending_refs.push_back(cur->ref); }
             ++n_roots_learned;
         }                                                                                // (a content-only change is counted
         if (similar && stamp && file_has_root && o.has_root && b.kind == 1)              //  where it is added: maybe_add)
@@ -1016,10 +1021,12 @@ static int copy_ops_apply(mi_copy::Fs& fs, const mi_copy_op* ops, const CopyPlan
                 n.e.file_index = -1;
                 if (roots && we.kind == 1 && we.file_index >= 0) {
                     n.batch_file = we.file_index;
+                    n.batch_gen = fs.commit_gen;
                     n.has_root = true;
                     memcpy(n.root, roots + (uint64_t)we.file_index * 32, 32);
                 } else if (fs.job && we.kind == 1 && we.file_index >= 0) {     // (a pipelined commit: the scan may still be running)
                     n.batch_file = we.file_index;
+                    n.batch_gen = fs.commit_gen;
                     n.has_root = true;
                     n.root_pending = true;
                 }
@@ -1632,7 +1639,7 @@ static int memfs_scan(mi_memfs* m, const mi_tree_entry* walked, uint64_t n, cons
             nd.has_root = true;
             memcpy(nd.root, (const uint8_t*)roots + (uint64_t)e.file_index * root_stride, 32);
         }
-        if (from_batch && e.kind == 1 && e.file_index >= 0) nd.batch_file = e.file_index;
+        if (from_batch && e.kind == 1 && e.file_index >= 0) { nd.batch_file = e.file_index; nd.batch_gen = fs.commit_gen; }
         if (lazy) { nd.has_root = true; nd.root_pending = true; }
         fs.stamp_for_next_keep = hashed_now && nd.has_root ? &wt->stamps[i] : nullptr;   // (recorded with the node maybe_add keeps)
         const std::string src = fs.root == "/" ? p : fs.root + (p == "/" ? "" : p);
@@ -1703,7 +1710,7 @@ static int memfs_commit_write(mi_memfs* m, mi_copy_layer* cl, uint64_t ne, const
     for (uint64_t i = 0; i < ne && !rc; ++i) {
         const mi_copy::Node& nd = cl->nodes[i];
         if (ents[i].kind == 1 && ents[i].file_index >= 0) { ++m->last.n_layer_files; m->last.layer_file_bytes += ents[i].size; }
-        if (batch && ents[i].kind == 1 && ents[i].file_index >= 0 && nd.batch_file >= 0)
+        if (batch && ents[i].kind == 1 && ents[i].file_index >= 0 && nd.batch_file >= 0 && nd.batch_gen == m->fs.commit_gen)
             rc = mi_layer_add_batch_file(lw, &ents[i], batch, (uint64_t)nd.batch_file);
         else
             rc = mi_layer_add(lw, &ents[i], ents[i].kind == 1 && srcs[i] && srcs[i][0] ? srcs[i] : nullptr);
@@ -1784,6 +1791,7 @@ extern "C" int mi_memfs_commit_layer(mi_memfs* m, mi_ctx* ctx, int must_scan, co
     mi_copy::Fs& fs = m->fs;
     fs.n_content_changed = fs.n_roots_learned = 0;
     fs.reserved_mark = 0;
+    if (++fs.commit_gen == 0) fs.commit_gen = 1;
     mi_copy_layer* cl = nullptr;
     uint64_t ne = 0;
     int rc;
@@ -1793,8 +1801,10 @@ extern "C" int mi_memfs_commit_layer(mi_memfs* m, mi_ctx* ctx, int must_scan, co
         return code;
     };
     mi_batch* b = nullptr;
+    uint64_t moves0 = 0;
     if (ctx) {
         if (m->batch && m->batch_ctx != ctx) { mi_batch_free(m->batch); m->batch = nullptr; }
+        if (m->batch) mi_batch_arena_info(m->batch, nullptr, nullptr, &moves0);
         if (m->batch) rc = mi_batch_reset(m->batch);
         else { rc = mi_batch_begin(ctx, 0, 0, &m->batch); m->batch_ctx = ctx; }
         if (rc) return fail_with(rc, std::string("gpu scan: ") + mi_last_error(ctx));
@@ -1864,6 +1874,7 @@ extern "C" int mi_memfs_commit_layer(mi_memfs* m, mi_ctx* ctx, int must_scan, co
                 fs.reserved_mark = mi_copy::next_scan_mark();                     // (... and found held are marked by the readers)
                 mi_walk::Tree* wtree = nullptr;
                 std::string werr;
+                struct Freeze { mi_memtree::Tree& t; Freeze(mi_memtree::Tree& x) : t(x) { t.frozen = true; } ~Freeze() { t.frozen = false; } } freeze(fs.t);   // (the readers look the tree up)
                 rc = mi_walk::scan_walk_batch_filtered(b, fs.root, m->blacklist,
                         [&fs, mark = fs.reserved_mark](const std::string& path, const struct stat& sb, const mi_walk::InodeStamp& st) {
                             return fs.content_is_known(path, sb, st, mark);
@@ -1999,6 +2010,11 @@ extern "C" int mi_memfs_commit_layer(mi_memfs* m, mi_ctx* ctx, int must_scan, co
     m->last.files_opened += mi_io::content_opens.load() - opens0;
     m->last.file_bytes_read += mi_io::content_bytes.load() - bytes0;
     m->last.s_total = secs_since(t_all);
+    if (b) {
+        uint64_t moves = 0;
+        mi_batch_arena_info(b, &m->last.arena_bytes, &m->last.arena_pieces, &moves);
+        m->last.arena_moves = moves - moves0;
+    }
     for (mi_copy::Node& nd : cl->nodes) nd.batch_file = -1;                       // (rows of a batch the caller does not hold)
     if (rc) { mi_copy_layer_free(cl); return rc; }
     *committed = 1;

@@ -57,6 +57,18 @@ struct Tree {
     // The kept node is dropped when the tree changes AT OR ABOVE its path (a node replaced, erased or emptied there);
     // a change elsewhere -- a leaf put below it, above all -- leaves it standing.  `gen` counts every change of shape.
     uint64_t gen = 1;
+    // While a content-aware scan's walk runs with MI_MEMFS_TRUST_CTIME its directory readers -- several threads -- look paths up
+    // in this tree and mark nodes (Fs::content_is_known): nothing may change its shape meanwhile.  The commit holds the tree
+    // `frozen` for that time; a change of shape while it is (a mutation somebody adds beside the walk some day) is a defect that
+    // would leave those threads with dangling nodes -- it stops the process with a message instead.
+    bool frozen = false;
+    void changing() {
+        if (frozen) {
+            fprintf(stderr, "makisu_mi: the MemFS tree was changed while a scan's walk was reading it from its directory readers (mi_memtree.h: frozen)\n");
+            abort();
+        }
+        ++gen;
+    }
     // One kept parent PER DEPTH: a walk descends and comes back (a/b, a/b/x, a/b/y, a/c), and the directory it comes back to is
     // still kept at its depth -- with a PLACE among its children: siblings arrive in name order, the order of the children
     // map, so the next lookup below the same parent is the next child (or a few steps on), not a search among thousands of
@@ -66,7 +78,7 @@ struct Tree {
     struct Kept { std::string dir; Node* node = nullptr; Kids::iterator at; bool placed = false; };
     std::vector<Kept> kept;                                                     // [depth of dir] ("/a/b": 2)
     void shape_changed(const std::string& at) {
-        ++gen;
+        changing();
         for (Kept& k : kept) {
             k.placed = false;
             if (k.node && k.dir.size() >= at.size() && memcmp(k.dir.data(), at.data(), at.size()) == 0 &&
@@ -74,7 +86,7 @@ struct Tree {
                 k.node = nullptr;
         }
     }
-    void shape_reset() { ++gen; kept.clear(); }
+    void shape_reset() { changing(); kept.clear(); }
     // where a clean absolute path splits into parent and name; npos = take the general way
     static size_t parent_cut(const std::string& p) {
         const size_t cut = p.find_last_of('/');
@@ -164,7 +176,7 @@ struct Tree {
                     shape_changed(dst);                                         // (before the old node goes)
                     it->second = std::move(nn);
                 } else {
-                    ++gen;                                                      // a new leaf: nobody's kept parent
+                    changing();                                                 // a new leaf: nobody's kept parent
                     parent->children.emplace_hint(it, std::string(name), std::move(nn));   // (names come sorted: at the end)
                 }
                 return true;

@@ -15,6 +15,7 @@
 // while files behind it are still on their way.
 #include "mi_internal.h"
 #include "mi_hostpath.h"      // mi_io: what was read of file content
+#include "host_sha256.h"      // strings too long for a GPU lane: a SHA-NI stream per reader thread
 
 #include <errno.h>
 #include <fcntl.h>
@@ -22,6 +23,7 @@
 #include <string.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -68,6 +70,14 @@ struct StageItem {
 // 4 KiB files at ~4 us of open + pread + close each) while the others idle at the end of a batch.
 constexpr size_t kMaxRunItems = 256;
 
+struct HashLatch {                       // completion of one stager_hash_ranges call
+    std::mutex mu;
+    std::condition_variable cv;
+    u64 left = 0;
+    std::string err;
+};
+struct HashJob { mi_batch* batch; u64 arena_off, len; u8* out; HashLatch* latch; };
+
 struct Stager {
     mi_ctx* ctx;
     u64 slab_bytes;
@@ -75,6 +85,7 @@ struct Stager {
     std::mutex mu;
     std::condition_variable cv_work, cv_done;
     std::deque<StageItem> queue;
+    std::deque<HashJob> hash_queue;      // whole strings to hash out of HBM (stager_hash_ranges): taken when no copy is waiting
     bool stop = false;
     u32 init_left = 0, n_ok = 0;         // reader threads still setting up / that got slab + stream
     std::atomic<long long> spans_copied{0};   // fault injection (MI_STAGE_FAULT) counts spans with it
@@ -218,6 +229,39 @@ static std::string describe_span(const u8* dev, const u8* want, u64 len, hipStre
     return buf;
 }
 
+// One string out of HBM through a reader's slab, in two halves: the next piece is on its way while this one is hashed
+// (a piece of 4 MiB: 0.15 ms of PCIe against 1.8 ms of SHA-NI)
+void hash_range(const HashJob& job, u8* slab, u64 slab_bytes, hipStream_t stream) {
+    const u64 half = (slab_bytes / 2) & ~(u64)4095;
+    const u8* src = (const u8*)job.batch->arena.p + job.arena_off;
+    mi_host::Sha256 sha;
+    std::string err;
+    auto fetch = [&](u64 at, int h) -> u64 {
+        const u64 n = job.len - at < half ? job.len - at : half;
+        if (n && err.empty()) {
+            const hipError_t e = hipMemcpyAsync(slab + h * half, src + at, n, hipMemcpyDeviceToHost, stream);
+            if (e != hipSuccess) err = std::string("device-to-host copy (hashing a long string): ") + hipGetErrorString(e);
+        }
+        return n;
+    };
+    u64 at = 0;
+    int h = 0;
+    u64 n = fetch(0, 0);
+    while (n && err.empty()) {
+        const hipError_t e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) { err = std::string("device-to-host copy (hashing a long string): ") + hipGetErrorString(e); break; }
+        const u64 next = fetch(at + n, h ^ 1);
+        sha.update(slab + h * half, (size_t)n);
+        at += n;
+        n = next;
+        h ^= 1;
+    }
+    if (err.empty()) sha.final(job.out);
+    std::lock_guard<std::mutex> g(job.latch->mu);
+    if (!err.empty() && job.latch->err.empty()) job.latch->err = err;
+    if (--job.latch->left == 0) job.latch->cv.notify_all();
+}
+
 // One reader thread: pops a run of queued items whose arena span fits its slab, fills the slab
 // (slab offset = arena offset - span start, so alignment gaps between files travel as they are),
 // issues ONE H2D copy for the span on its own stream and waits for it; the other threads read and
@@ -247,7 +291,14 @@ void worker(Stager* st, u32 tid) {
         run.clear();
         {
             std::unique_lock<std::mutex> lk(st->mu);
-            st->cv_work.wait(lk, [&] { return st->stop || !st->queue.empty(); });
+            st->cv_work.wait(lk, [&] { return st->stop || !st->queue.empty() || !st->hash_queue.empty(); });
+            if (st->queue.empty() && !st->hash_queue.empty()) {
+                const HashJob job = st->hash_queue.front();
+                st->hash_queue.pop_front();
+                lk.unlock();
+                hash_range(job, (u8*)slab, st->slab_bytes, stream);
+                continue;
+            }
             if (st->queue.empty()) break;                      // stop requested and nothing left
             const mi_batch* b = st->queue.front().batch;
             const u64 start = st->queue.front().arena_off;
@@ -420,10 +471,12 @@ Stager* stager_create(mi_ctx* c, u32 n_threads, u64 slab_bytes) {
     for (u32 i = 0; i < n_threads; ++i) st->threads.emplace_back(worker, st, i);
     return st;
 }
-// true when at least one reader thread got its slab and stream (false: nobody can take work -- say so now, not per batch)
+// true when at least one reader thread got its slab and stream (false: nobody can take work -- say so now, not per batch).
+// Returns as soon as the FIRST reader is up: the others join in as they come (a pinned slab takes ~5 ms to allocate and the
+// driver hands them out one after the other -- waiting for all eight kept a cold ctx's first walk 40 ms from its first byte).
 bool stager_ready(Stager* st) {
     std::unique_lock<std::mutex> lk(st->mu);
-    st->cv_init.wait(lk, [&] { return st->init_left == 0; });
+    st->cv_init.wait(lk, [&] { return st->n_ok != 0 || st->init_left == 0; });
     return st->n_ok != 0;
 }
 
@@ -574,6 +627,65 @@ int stager_wait_landed(Stager* st, mi_batch* b, u64 upto, u64* landed_out) {
 u64 stager_landed(Stager* st, mi_batch* b) {
     std::lock_guard<std::mutex> g(st->mu);
     return landed_upto(st, b);
+}
+
+HashLatch* stager_hash_ranges(Stager* st, mi_batch* b, u64 n, const u64* arena_off, const u64* len, u8* out32) {
+    HashLatch* latch = new HashLatch();
+    latch->left = n;
+    if (n == 0) return latch;
+    {
+        std::lock_guard<std::mutex> g(st->mu);
+        for (u64 i = 0; i < n; ++i) st->hash_queue.push_back({b, arena_off[i], len[i], out32 + 32 * i, latch});
+    }
+    st->cv_work.notify_all();
+    return latch;
+}
+
+int stager_hash_wait(mi_ctx* c, HashLatch* latch) {
+    if (!latch) return MI_OK;
+    std::string err;
+    {
+        std::unique_lock<std::mutex> lk(latch->mu);
+        latch->cv.wait(lk, [&] { return latch->left == 0; });
+        err = latch->err;
+    }
+    delete latch;
+    if (!err.empty()) return fail(c, MI_ERR_HIP, "%s", err.c_str());
+    return MI_OK;
+}
+
+void route_long_strings(const u64* lens, u64 n, u32 host_threads, bool h2d, std::vector<u32>* to_host) {
+    to_host->clear();
+    static const bool on_gpu = [] { const char* e = getenv("MI_SHA_LONG_ON_GPU"); return e && *e == '1'; }();   // (tests, A/B: every
+    if (n == 0 || host_threads == 0 || on_gpu) return;                                                          //  string on a lane)
+    constexpr double kLaneBps = 13.5e6, kRoofBps = 1.77e12, kPcieBps = 50e9;
+    const double host_bps = mi_host::Sha256::have_shani() ? 2.2e9 : 0.35e9;
+    u64 lmax = 0, total = 0;
+    for (u64 i = 0; i < n; ++i) { total += lens[i]; if (lens[i] > lmax) lmax = lens[i]; }
+    auto gpu_time = [&](u64 longest, u64 bytes) {                     // a pass over `bytes` whose longest string is `longest`
+        const double lane = longest / kLaneBps, roof = bytes / kRoofBps;
+        return (lane > roof ? lane : roof) + (h2d ? bytes / kPcieBps : 0.0);
+    };
+    // the common case, without a sort: the pass is not held up by its longest string (by more than a launch's own few ms)
+    if (lmax / kLaneBps <= 2.0 * (total / kRoofBps) || lmax / kLaneBps < 5e-3) return;
+    std::vector<u32> idx(n);
+    for (u64 i = 0; i < n; ++i) idx[i] = (u32)i;
+    std::sort(idx.begin(), idx.end(), [&](u32 x, u32 y) { return lens[x] != lens[y] ? lens[x] > lens[y] : x < y; });
+    double best = gpu_time(lmax, total);
+    u64 best_k = 0, moved = 0;
+    for (u64 k = 0; k < n;) {
+        u64 j = k;
+        while (j < n && lens[idx[j]] == lens[idx[k]]) moved += lens[idx[j++]];      // the whole class of this length
+        const u32 streams = host_threads < j ? host_threads : (u32)j;
+        double host = moved / (host_bps * streams);
+        if (lmax / host_bps > host) host = lmax / host_bps;                         // (one stream is one core)
+        const double gpu = j < n ? gpu_time(lens[idx[j]], total - moved) : 0.0;
+        const double t = host > gpu ? host : gpu;
+        if (t < best) { best = t; best_k = j; }
+        if (host > best) break;                                                      // the host side alone is already longer
+        k = j;
+    }
+    to_host->assign(idx.begin(), idx.begin() + best_k);
 }
 
 // MI_FLAG_VERIFY_STAGING, when staging ends: every span this batch ever copied is summed again

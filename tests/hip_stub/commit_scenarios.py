@@ -254,10 +254,14 @@ def scenario_known_tree(tmp, eng):
     2 ms per MiB (MI_HIP_STUB_MAP_US: a box that charges fresh device memory by the byte; readers and tar writer wait where they
     touch memory the mapper has not reached).  Every variant: the layer tar holds every file's bytes."""
     import ctypes
-    lib = ctypes.CDLL(None)
-    big_mallocs, vm_ranges, vm_pieces = lib.mi_hip_stub_big_mallocs, lib.mi_hip_stub_vm_ranges, lib.mi_hip_stub_vm_pieces
-    for f in (big_mallocs, vm_ranges, vm_pieces):
-        f.restype = ctypes.c_long
+    on_gpu = os.environ.get("MI_TEST_ON_GPU") == "1"                      # (no double to ask: mi_commit_stats' arena_* fields alone)
+    if on_gpu:
+        big_mallocs = vm_ranges = vm_pieces = lambda: 0
+    else:
+        lib = ctypes.CDLL(None)
+        big_mallocs, vm_ranges, vm_pieces = lib.mi_hip_stub_big_mallocs, lib.mi_hip_stub_vm_ranges, lib.mi_hip_stub_vm_pieces
+        for f in (big_mallocs, vm_ranges, vm_pieces):
+            f.restype = ctypes.c_long
     root = os.path.join(tmp, "known_root")
     rng = np.random.default_rng(5)
     entries, files = [], {}
@@ -284,15 +288,18 @@ def scenario_known_tree(tmp, eng):
                 assert st["n_scanned_files"] == len(files) and st["files_opened"] == len(files)
                 ranges, pieces = vm_ranges() - r0, vm_pieces() - p0
                 if os.environ.get("MI_ARENA_RANGE_MB"):
-                    assert ranges >= 2, "a range of %s MiB holds 262 MB?" % os.environ["MI_ARENA_RANGE_MB"]     # (outgrown: a larger one)
+                    assert on_gpu or ranges >= 2, "a range of %s MiB holds 262 MB?" % os.environ["MI_ARENA_RANGE_MB"]     # (outgrown: a larger one)
+                    assert st["arena_moves"] >= 1, st
                 else:
-                    assert ranges == 1, "the arena moved: %d address ranges" % ranges
-                assert pieces >= 2 and pieces * (2 << 20) >= 262_144_000 // 128, pieces                          # mapped in pieces
+                    assert on_gpu or ranges == 1, "the arena moved: %d address ranges" % ranges
+                    assert st["arena_moves"] == 0, st
+                assert on_gpu or pieces == st["arena_pieces"], (pieces, st)
+                assert st["arena_pieces"] >= 2 and st["arena_bytes"] >= 262_144_000, st                                    # mapped in pieces
                 if name == "fresh":
                     assert {n: d for n, m, d in tar_members(raw) if m.isfile()} == files
                 else:
                     assert res["n_entries"] == 0 and st["n_roots_learned"] == len(files)      # the headers are the merged ones: nothing new
-            assert vm_pieces() == p0, "the handle is closed: its arena's pieces are given back"
+            assert on_gpu or vm_pieces() == p0, "the handle is closed: its arena's pieces are given back"
     finally:
         if before is None:
             del os.environ["MI_WALK_THREADS"]

@@ -289,6 +289,37 @@ def scenario_blocks_recycle(tmp, threads, slab):
         check(b, b"".join(want[p] for p in sorted(want)), "recycle")
 
 
+def scenario_long_strings(tmp, threads, slab):
+    """Whole-string SHA-256 of strings too long for a GPU lane (route_long_strings): the reader threads hash them out of the arena
+    (MI_FLAG_FILE_SHA256), host threads hash them out of the caller's memory (mi_sha256_many) -- SHA-NI streams, so these digests
+    are RIGHT on the double too (its kernels do not run: the short strings' digests are its fill pattern)."""
+    import hashlib
+    rng = np.random.default_rng(9)
+    long_sizes = [40 << 20, (9 << 20) + 13, 5 << 20]
+    blobs = [rng.integers(0, 256, n, dtype=np.uint8).tobytes() for n in long_sizes + [100, 4096, 0, 70_000]]
+    with M.Engine(n_streams=threads, staging_bytes=slab, flags=M.FLAG_FILE_SHA256) as eng:
+        with eng.batch() as b:
+            paths = []
+            for i, d in enumerate(blobs):
+                if i % 2:
+                    b.add_bytes(d)
+                else:
+                    p = os.path.join(tmp, "long%d" % i)
+                    with open(p, "wb") as fh:
+                        fh.write(d)
+                    b.add_path(p, len(d))
+            b.run()
+            rows = b.files()
+            for i in range(len(long_sizes)):
+                assert rows["file_sha256"][i].tobytes() == hashlib.sha256(blobs[i]).digest(), "file %d" % i
+            b.rerun()
+            assert b.files()["file_sha256"][0].tobytes() == hashlib.sha256(blobs[0]).digest()
+        got = eng.sha256_many(blobs)
+        for i in range(len(long_sizes)):
+            assert got[i] == hashlib.sha256(blobs[i]).digest(), "blob %d" % i
+        assert len(got) == len(blobs)
+
+
 def main():
     tmp = sys.argv[1]
     threads = int(sys.argv[2]) if len(sys.argv) > 2 else 4
@@ -296,8 +327,8 @@ def main():
     only = sys.argv[4].split(",") if len(sys.argv) > 4 else None
     for name, fn in [("mix", scenario_mix), ("growth", scenario_growth_and_reuse), ("two", scenario_two_batches), ("interleaved", scenario_interleaved),
                      ("errors", scenario_errors), ("api", scenario_api), ("tree", scenario_tree_reserves_ahead),
-                     ("two_ctxs", scenario_two_ctxs), ("recycle", scenario_blocks_recycle)]:
-        if (name not in only) if only else name == "recycle":    # "recycle" runs only when asked for
+                     ("two_ctxs", scenario_two_ctxs), ("recycle", scenario_blocks_recycle), ("long_strings", scenario_long_strings)]:
+        if (name not in only) if only else name in ("recycle", "long_strings"):    # these run only when asked for
             continue
         fn(tmp, threads, slab)
         print("OK", name, flush=True)

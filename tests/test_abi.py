@@ -32,6 +32,27 @@ def test_library_exports_every_declared_symbol(engine_lib):
     assert set(engine_lib._mi_symbols) == set(core) | set(host)
 
 
+def test_every_export_is_core_building_block_or_diagnostics():
+    """round 6: the ~115 exports under three banners -- MI_CORE (what a first cgo shim binds), MI_BLOCK
+    (what the commit is made of), MI_DIAG (measurement) -- each prototype tagged once; the core is about thirty calls"""
+    tags = {}
+    for h in (HEADER, HOST_HEADER):
+        src = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+        for m in re.finditer(r"^(MI_CORE|MI_BLOCK|MI_DIAG)\s[^\n(;]*?\b(mi_[a-z0-9_]+)\s*\(", src, flags=re.M):
+            assert m.group(2) not in tags, m.group(2)
+            tags[m.group(2)] = m.group(1)
+    declared = set(_declared_functions()) | set(_declared_functions(HOST_HEADER))
+    assert set(tags) == declared, sorted(declared ^ set(tags))
+    core = sorted(n for n, t in tags.items() if t == "MI_CORE")
+    assert 25 <= len(core) <= 36, core
+    for n in ("mi_ctx_create", "mi_ctx_destroy", "mi_memfs_create", "mi_memfs_commit_layer", "mi_memfs_free", "mi_memfs_set_options",
+              "mi_memfs_set_index", "mi_layer_config_default", "mi_cache_create_entry", "mi_cache_parse_entry", "mi_index_create",
+              "mi_sha256_many"):
+        assert tags[n] == "MI_CORE", n
+    assert all(tags[n] == "MI_BLOCK" for n in HOST_HELPERS)
+    assert {n for n, t in tags.items() if t == "MI_DIAG"} >= {"mi_get_stats", "mi_sha_valu_roof", "mi_batch_stage_stats", "mi_debug_sha_wave_stats"}
+
+
 def test_the_core_export_set(engine_lib):
     """SURVEY.md 8(b)'s list is in the core header, the stateless twins of the layer merge are gone (one MemFS), and the
     library exports nothing beyond the two headers."""

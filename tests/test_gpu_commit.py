@@ -112,6 +112,41 @@ def test_trusting_ctimes_on_wide_directories_that_change(tmp_path):
     assert p.returncode == 0 and "OK trust_wide" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
 
 
+@pytest.mark.parametrize("case,fault", [("clean", None), ("readback1", "readback:2"), ("readback3", "readback:3:3"), ("copy", "copy:1"),
+                                        ("copy", "copy:5")])
+def test_bytes_that_change_on_the_way_fail_the_commit_on_the_gpu(tmp_path, case, fault):
+    """The end-to-end byte sums (csrc/mi_filesum.h) with real DMA on both hops (tests/hip_stub/commit_scenarios.py `verify`): nothing
+    wrong -- every layer file verified, no chunk fetched twice, the reference's tar; one read-back copy with a flipped byte --
+    repaired by the second fetch; three in a row -- MI_ERR_IO naming the hop HBM -> read-back window; 4 KiB lost in HBM after a
+    host-to-device copy -- MI_ERR_IO naming the hop pinned slab -> HBM.  Never a layer (lib/tario/write.go:43-45)."""
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hip_stub", "commit_scenarios.py")
+    env = dict(os.environ, MI_TEST_ON_GPU="1", MI_VERIFY_CASE=case)
+    if fault:
+        env["MI_STAGE_FAULT"] = fault
+    p = subprocess.run([sys.executable, script, str(tmp_path), "4", "verify"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and ("OK verify " + case) in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
+
+
+@pytest.mark.parametrize("env", [{"MI_VERIFY_STAGING": "1"}, {"MI_COMMIT_VERIFY": "0"}, {"MI_ARENA": "malloc"}, {"MI_ARENA_PIECE_MB": "2"},
+                                 {"MI_ARENA_RANGE_MB": "2", "MI_ARENA_PIECE_MB": "2"}])
+def test_commit_zero_with_the_heavier_check_without_any_and_on_either_arena(env, tmp_path):
+    """commit zero (every root the oracle's, the tar the files') with MI_FLAG_VERIFY_STAGING's per-span GPU sums beside the
+    default end-to-end sums; with the end-to-end sums off; with the arena as one allocation that moves (rounds 1-5); with
+    2 MiB pieces; and with an address range of 2 MiB that the tree outgrows (the pieces are mapped again in a larger one)"""
+    p = subprocess.run([sys.executable, os.path.abspath(__file__), str(tmp_path)], env=dict(os.environ, **env),
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "OK commit_zero" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
+
+
+def test_the_arena_never_moves_on_the_gpu(tmp_path):
+    """tests/hip_stub/commit_scenarios.py `known_tree` with real device memory: 262 MB learned 1 024 files at a time -- one address
+    range, pieces mapped behind the walk, every file's bytes in the tar"""
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hip_stub", "commit_scenarios.py")
+    p = subprocess.run([sys.executable, script, str(tmp_path), "4", "known_tree"], env=dict(os.environ, MI_TEST_ON_GPU="1"),
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "OK known_tree" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
+
+
 def _rewrite_same_size_same_second(path, rng):
     st = os.stat(path)
     old = open(path, "rb").read()
@@ -656,6 +691,27 @@ def test_the_bench_line_carries_the_products_numbers():
     assert w["rows_per_step"] == j["config"]["chunks_last_batch"] and w["files_per_step"] == 20000
     assert w["bytes_to_host_per_step"] == 64 * w["rows_per_step"] + 96 * 20000 and 0.3 < w["vs_rows_left_on_device"] < 1.2
     assert j["roofline"]["frac"] > 0 and j["cpu_baseline"]["value"] > 0 and "commit_e2e" not in j
+    assert j["config"]["with_rows_ratio"] == w["vs_rows_left_on_device"]                 # ... where the driver's record keeps it
+
+
+def test_the_commit_table_reaches_the_fields_the_driver_keeps(eng):
+    """the driver's BENCH record keeps `config`, `roofline`, `cpu_baseline` in full and every other key as a
+    name -- bench.py's summary of `commit_e2e` inside `cpu_baseline.commit_s` is built from the table and stays small"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from commit_layer_bench import commit_e2e
+    small, large = commit_e2e(eng, 2000, 4096), commit_e2e(eng, 6, 8 << 20)
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    a = src.index("        try:\n            ce = out.get(\"commit_e2e\") or {}")
+    b = src.index("        except Exception as e:                                      # noqa: BLE001\n            print(\"bench.py: the summary")
+    import textwrap
+    out = {"commit_e2e": {"small_files": small, "large_files": large}, "cpu_baseline": {"value": 1.0}, "config": {},
+           "with_rows_on_host": {"vs_rows_left_on_device": 0.99}}
+    exec(textwrap.dedent(src[a:b]).replace("try:\n", "if True:\n", 1), {"out": out, "round": round})
+    c = out["cpu_baseline"]["commit_s"]
+    assert len(json.dumps(c)) <= 900 and set(c) >= {"all_new", "nothing_changed", "changed_0p1pct", "all_new_gpu_over_header_only"}
+    assert c["all_new"]["large"] == [large["commits"][0][k]["s_total"] for k in ("gpu", "gpu_trust_ctime", "cpu_header_only")]
+    assert c["large_all_new_verified"][0] == 6 and c["large_all_new_verified"][1] == 0 and c["large_all_new_verified"][2] == 0
+    assert out["config"]["with_rows_ratio"] == 0.99
 
 
 if __name__ == "__main__":                                                     # one scenario in a process of its own

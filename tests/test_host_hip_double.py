@@ -133,3 +133,13 @@ def test_the_double_is_not_the_product():
             for fn in fns:
                 if fn.endswith((".py", ".hip", ".h")):
                     assert "hip_stub" not in open(os.path.join(dp, fn), errors="replace").read(), fn
+
+
+@pytest.mark.parametrize("threads,slab", [(4, 1 << 20), (2, 65536)])
+def test_strings_too_long_for_a_gpu_lane_are_hashed_by_host_streams(hip_double, tmp_path, threads, slab):
+    """VERDICT r5 item 3: MI_FLAG_FILE_SHA256 and mi_sha256_many route long strings to SHA-NI streams (the reader threads out of HBM;
+    host threads out of the caller's memory) -- their digests are hashlib's, on the double too"""
+    env = dict(os.environ, LD_PRELOAD=(os.environ.get("LD_PRELOAD", "") + " " + hip_double).strip())
+    p = subprocess.run([sys.executable, os.path.join(STUB_DIR, "scenarios.py"), str(tmp_path), str(threads), str(slab), "long_strings"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "OK long_strings" in p.stdout, p.stdout[-800:] + p.stderr[-1500:]

@@ -1,3 +1,4 @@
+# (round 6: the -D knobs these variants use live in tools/experiments/gear_cdc_experiments.patch -- apply it to a copy of the tree first)
 out=gpurun_out/r04_gear_ab.txt
 export TMPDIR=/tmp
 summ() { db=$(find $1 -name "*_results.db" | head -1); [ -n "$db" ] && python tools/prof_summary.py $db; }

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (round 6: the -D knobs these variants use live in tools/experiments/gear_cdc_experiments.patch -- apply it to a copy of the tree first)
 # Round 4: the candidate test of the marking as 7 v_min3_u32 + 1 v_min_u32 (depth 3) instead of hipcc's 8 v_min + 4 v_min3
 # (tools/build_variants.sh gm3 "-DMI_GEAR_MIN3_TREE" makisu_amd/csrc/gear_cdc.hip).  Same box, alternating.
 out=gpurun_out/gear_min3_ab

@@ -32,7 +32,8 @@ def main():
         blob.tofile(p)
         paths.append(p)
     thr = os.environ.get("MI_STAGE_THREADS", "default")
-    with makisu_amd.Engine() as e:
+    flags = makisu_amd.FLAG_FILE_SUMS if os.environ.get("MI_FEED_SUMS") else 0       # (the end-to-end sums' cost on the reader threads)
+    with makisu_amd.Engine(flags=flags) as e:
         b = e.batch(n, n * size)
         for mode in (os.environ.get("MI_FEED_MODES") or "add_bytes,add_bytes,add_path,add_path,add_bytes,add_path").split(","):
             if os.environ.get("MI_FEED_FRESH"):        # a new arena every pass (fresh VRAM is cleared by the driver)

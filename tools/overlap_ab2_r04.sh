@@ -1,4 +1,5 @@
 #!/bin/bash
+# (round 6: the -D knobs these variants use live in tools/experiments/gear_cdc_experiments.patch -- apply it to a copy of the tree first)
 # Round 4, second look at marking-under-hashing: is the shared resource the address translation (the lane-owned hashing
 # loads touch 64 pages per instruction)?  The cooperative hashing loads ask 15x less of it; at 161 VGPRs two of its waves
 # leave room for ONE marking wave per SIMD (256-thread marking workgroups, -DMI_GEAR_FAST_COPIES=16).

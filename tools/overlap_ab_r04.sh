@@ -1,4 +1,5 @@
 #!/bin/bash
+# (round 6: the -D knobs these variants use live in tools/experiments/gear_cdc_experiments.patch -- apply it to a copy of the tree first)
 # Round 4, last experiment: does the Gear marking of the NEXT batch run under the hashing of the current one when its
 # waves are raised above the hashing's (s_setprio in the marking kernels, -DMI_GEAR_PRIO), and what does the step gain?
 # The marking's 512-thread workgroup needs 2 x 120 VGPRs on every SIMD of a CU; two hashing waves hold 2 x 136: 512 together.
