@@ -9,8 +9,8 @@
  *
  * Conventions (mirror Go's "wrap the error with context" style):
  *   - every function returns int: 0 = MI_OK, <0 = error code;
- *   - mi_last_error(ctx) returns a NUL-terminated message valid until the next
- *     call on that ctx, so the shim can do fmt.Errorf("gpu scan: %s", C.GoString(..));
+ *   - mi_last_error(ctx) returns a NUL-terminated message -- the calling thread's own copy, valid until
+ *     that thread asks again -- so the shim can do fmt.Errorf("gpu scan: %s", C.GoString(..));
  *   - a ctx is not re-entrant but may be called from any OS thread (the engine
  *     calls hipSetDevice itself and keeps no thread-local state -- goroutines
  *     migrate between threads); several ctxs may run concurrently;
@@ -68,7 +68,16 @@ enum {
 #define MI_FLAG_FILE_SHA256 0x1u  /* also compute SHA-256 of each whole file: what
                                      image.Digester.FromReader returns per file in
                                      `makisu push` (bin/makisu/cmd/push.go:207,230;
-                                     lib/docker/image/digester.go:45-52)             */
+                                     lib/docker/image/digester.go:45-52).  One GPU lane per
+                                     file -- 13.5 MB/s a lane, 1.77 TB/s when every lane has
+                                     one -- EXCEPT files that would hold the pass up: a single
+                                     SHA-256 stream is serial and belongs
+                                     on a host core with SHA-NI (2.4 GB/s); such files are hashed
+                                     by the library's reader threads out of HBM while the GPU
+                                     takes the rest (csrc/mi_stage.hip route_long_strings: the
+                                     length classes that make max(host time, GPU time) smallest;
+                                     a 128 MiB file 0.06 s instead of 10 s).  Not a fallback: the
+                                     same digests, each where it is computed fastest          */
 #define MI_FLAG_FILE_CRC32  0x2u  /* also compute CRC32-IEEE of each whole file: the
                                      per-file term of checksumPathContents
                                      (lib/builder/step/add_copy_step.go:194-238)     */
@@ -76,7 +85,10 @@ enum {
 #define MI_FLAG_PREFETCH_ROWS 0x8u /* mi_batch_wait also brings the result rows to the host
                                       (one packed copy, ~1 ms per 700 k chunks, while the
                                       other batch in flight keeps the GPU busy): the
-                                      following mi_batch_chunks_view costs nothing      */
+                                      following mi_batch_chunks_view is a pointer.  The steps
+                                      with the rows delivered run 0.5-2.2 % below the steps
+                                      without (once 5.8 %: profiles/r05_with_rows_repeats.txt,
+                                      `with_rows_on_host` in every bench line)             */
 #define MI_FLAG_VERIFY_STAGING 0x10u /* host-fed batches check their own staged bytes: every
                                       span a reader thread (or the inline window) copies is
                                       summed on the host while it sits in the pinned slab and
@@ -854,10 +866,19 @@ MI_CORE int mi_cache_parse_entry_str(const char* entry, char* tar_digest, uint64
                              uint64_t gzip_cap);
 
 /* ---- standalone digests (image.Digester seam) ---------------------------------- *
- * n independent byte strings -> n SHA-256 digests on the GPU, one lane per string:
- * the batched form of image.NewDigester().FromBytes / FromReader
- * (lib/docker/image/digester.go:45-60).  data: host pointer, string i =
- * data[offsets[i] .. offsets[i]+lens[i]).  out: n x 32 bytes.                       */
+ * n independent byte strings -> n SHA-256 digests: the batched form of
+ * image.NewDigester().FromBytes / FromReader (lib/docker/image/digester.go:45-60;
+ * `makisu push`: bin/makisu/cmd/push.go:207,230).  data: host pointer, string i =
+ * data[offsets[i] .. offsets[i]+lens[i]).  out: n x 32 bytes.
+ * Many short strings (manifests, configs, small files): one GPU lane each.  Long ones -- a
+ * `docker save` layer tar -- on host threads with SHA-NI, one stream per thread, straight from
+ * `data`, beside the GPU's launch: one lane does 13.5 MB/s, one core 2.4 GB/s, and a
+ * Merkle-Damgard stream cannot be split ("must stay on a CPU core").
+ * route_long_strings (csrc/mi_stage.hip) sends the length classes to the host that make
+ * max(host time, GPU time) smallest: eight 128 MiB blobs take 0.06-0.12 s on eight cores
+ * instead of 10 s on eight lanes; 100 000 x 64 KiB stay on the GPU.  MI_SHA_HOST_THREADS
+ * (default: the cores the process may use, at most 16); MI_SHA_LONG_ON_GPU=1 keeps every
+ * string on a lane (tests).                                                                */
 MI_CORE int mi_sha256_many(mi_ctx* ctx, const void* data, const uint64_t* offsets,
                    const uint64_t* lens, uint64_t n, uint8_t* out);
 

@@ -187,6 +187,22 @@ def test_every_c_reference_of_the_cgo_fragments_resolves():
     assert calls >= 30
 
 
+def test_the_shim_proper_binds_core_calls_only():
+    """the exports carry MI_CORE / MI_BLOCK / MI_DIAG; the cgo shim a maintainer adds first -- the fragment with
+    the cgo preamble -- uses the core and nothing else (ctx, MemFS handle, the one-call commit and its options, cache strings,
+    chunk index, push digests); the later fragments are the building blocks' and may use anything"""
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(INCLUDE, "makisu_mi.h")).read(), flags=re.S)
+    tag = {m.group(2): m.group(1) for m in re.finditer(r"^(MI_CORE|MI_BLOCK|MI_DIAG)\s[^\n(;]*?\b(mi_[a-z0-9_]+)\s*\(", src, flags=re.M)}
+    frags = _go_fragments()
+    shim = _strip_go_comments(frags[0])
+    used = sorted(set(re.findall(r"\bC\.(mi_\w+)\s*\(", shim)))
+    assert len(used) >= 15 and "mi_memfs_commit_layer" in used and "mi_memfs_create" in used and "mi_sha256_many" in used, used
+    not_core = [n for n in used if tag.get(n) != "MI_CORE"]
+    assert not not_core, "the core shim calls %s" % not_core
+    later = set(re.findall(r"\bC\.(mi_\w+)\s*\(", "".join(_strip_go_comments(f) for f in frags[1:])))
+    assert any(tag.get(n) == "MI_BLOCK" for n in later)
+
+
 def test_fields_selected_on_c_structs_exist():
     pre = _preprocessed_headers()
     types = _structs(pre)
