@@ -40,7 +40,7 @@ extern "C" {
  *             ctx        mi_abi_version, mi_config_default, mi_ctx_create / _destroy, mi_last_error
  *             MemFS      mi_memfs_create / _free / _error / _set_clock / _reset / _update_from_entries / _entries / _root_of
  *             commit     mi_memfs_commit_layer (step.commitLayer in one call: walk, GPU scan, content-aware diff, tar from HBM,
- *                        DigestPair), mi_memfs_commit_stats, mi_memfs_set_options / _set_index / _reserve_device /
+ *                        DigestPair), mi_memfs_commit_layer_n (the same over several GPUs), mi_memfs_commit_stats, mi_memfs_set_options / _set_index / _reserve_device /
  *                        _release_device, mi_layer_config_default, mi_copy_layer_entries / _roots / _free
  *             cache      mi_cache_key / _create_entry / _parse_entry / _parse_entry_str   (cache.Manager's strings)
  *             index      mi_index_create / _free / _count / _export / _import               (keyvalue.Store seam)
@@ -813,9 +813,21 @@ typedef struct {
     uint64_t arena_moves;        /* ... and how often its base address changed during this commit -- each time the reader
                                     threads were drained and, until round 5, the arena copied.  0, unless the tree
                                     outgrew the address range (four times the first estimate, 8 GiB at least)      */
+    uint64_t n_ctxs;             /* GPUs the commit ran on (mi_memfs_commit_layer_n; 1 otherwise, 0 with ctx == NULL) ... */
+    uint64_t ctx_bytes_max, ctx_bytes_min;   /* ... and the bytes the fullest and the emptiest of them were handed        */
 } mi_commit_stats;
 MI_CORE int  mi_memfs_commit_layer(mi_memfs* fs, mi_ctx* ctx, int must_scan, const mi_copy_op* ops, uint64_t n_ops,
                            const mi_layer_config* cfg, mi_layer_result* res, mi_copy_layer** layer_out, int* committed);
+/* The same commit over n_ctx GPUs of one node, one ctx each (north_star: "file batches shard across the 8 GPUs"): what the walk
+ * hands over goes to the GPU with the fewest bytes so far, every GPU stages through its own reader threads and PCIe link and scans
+ * its share; roots come back in the walk's order, the tar writer reads each file from the GPU that holds it, the chunk index (on
+ * any one of the ctxs) takes the other GPUs' digests through the host.  Layer, roots and DigestPair are those of the one-GPU
+ * commit, byte for byte.  n_ctx = 1: mi_memfs_commit_layer; n_ctx = 0: the reference's commit.  A handle keeps its batches
+ * between commits as long as it is called with the same ctxs.  Files are not split across GPUs.  UNMEASURED on more than one
+ * physical GPU (tested with n ctxs on one device, and on the HIP double): mi_commit_stats.n_ctxs / ctx_bytes_max / _min.        */
+MI_CORE int  mi_memfs_commit_layer_n(mi_memfs* fs, mi_ctx* const* ctxs, uint32_t n_ctx, int must_scan, const mi_copy_op* ops,
+                             uint64_t n_ops, const mi_layer_config* cfg, mi_layer_result* res, mi_copy_layer** layer_out,
+                             int* committed);
 MI_CORE int  mi_memfs_commit_stats(const mi_memfs* fs, mi_commit_stats* out);
 /* Options of a handle's content-aware commits (default: none).
  * MI_MEMFS_TRUST_CTIME: a scan commit does not read a regular file again whose inode is what it was when the tree's root for

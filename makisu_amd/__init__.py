@@ -117,7 +117,8 @@ class CommitStats(C.Structure):
                                           "n_layer_files", "layer_file_bytes", "n_content_changed", "n_roots_learned", "n_content_trusted",
                                           "n_index_new", "n_index_known", "index_new_bytes", "files_opened", "file_bytes_read", "pipelined", "n_windows")] + \
                [(n, C.c_double) for n in ("s_walk_stage", "s_scan", "s_diff", "s_write", "s_total")] + \
-               [(n, C.c_uint64) for n in ("n_verified_files", "verified_bytes", "n_refetched", "arena_bytes", "arena_pieces", "arena_moves")]
+               [(n, C.c_uint64) for n in ("n_verified_files", "verified_bytes", "n_refetched", "arena_bytes", "arena_pieces", "arena_moves",
+                                          "n_ctxs", "ctx_bytes_max", "ctx_bytes_min")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -267,6 +268,8 @@ def load_library(rebuild=False):
         "mi_memfs_checkpoint": ([vp, C.c_char_p, C.POINTER(C.c_char_p), u64], C.c_int),
         "mi_memfs_commit_layer": ([vp, vp, C.c_int, C.POINTER(CopyOp), u64, C.POINTER(LayerConfig), C.POINTER(LayerResult),
                                    C.POINTER(vp), C.POINTER(C.c_int)], C.c_int),
+        "mi_memfs_commit_layer_n": ([vp, C.POINTER(vp), C.c_uint32, C.c_int, C.POINTER(CopyOp), u64, C.POINTER(LayerConfig),
+                                     C.POINTER(LayerResult), C.POINTER(vp), C.POINTER(C.c_int)], C.c_int),
         "mi_memfs_commit_stats": ([vp, C.POINTER(CommitStats)], C.c_int),
         "mi_memfs_set_index": ([vp, vp], C.c_int),
         "mi_memfs_set_options": ([vp, C.c_uint32], C.c_int),
@@ -691,9 +694,9 @@ class MemFS:
 
     def commit_layer(self, must_scan=False, ops=(), out_fd=-1, gzip_level=GZIP_DEFAULT, engine=None, mode_with_type=False):
         """step.commitLayer: the layer by scan or by copy ops, written through the layer writer.  engine = an Engine: the
-        content-aware commit (walk + stage + GPU scan + diff with chunk roots + tar from HBM, one call); None: the
-        reference's.  Returns None when there is nothing to do, else dict(tar_digest, gzip_digest, tar_bytes, gzip_bytes,
-        n_entries, layer=[entries, with "root" for scanned files], stats={...})."""
+        content-aware commit (walk + stage + GPU scan + diff with chunk roots + tar from HBM, one call); a list of Engines: the
+        same over several GPUs (mi_memfs_commit_layer_n); None: the reference's.  Returns None when there is nothing to do, else
+        dict(tar_digest, gzip_digest, tar_bytes, gzip_bytes, n_entries, layer=[entries, with "root" for scanned files], stats={...})."""
         keep = []
         cops = _copy_op_array(list(ops), keep)
         cfg = LayerConfig()
@@ -702,11 +705,18 @@ class MemFS:
         if mode_with_type:
             cfg.flags |= LAYER_MODE_WITH_TYPE
         res, h, done = LayerResult(), C.c_void_p(), C.c_int()
-        ctx = engine._h if engine is not None else None
-        if engine is not None:
-            engine._children.add(self)                        # the handle keeps a batch of that ctx: given back before it dies
-        self._check(self._lib.mi_memfs_commit_layer(self._h, ctx, int(must_scan), cops, len(ops), C.byref(cfg), C.byref(res),
-                                                    C.byref(h), C.byref(done)), "mi_memfs_commit_layer")
+        if isinstance(engine, (list, tuple)):
+            for e in engine:
+                e._children.add(self)
+            ctxs = (C.c_void_p * max(len(engine), 1))(*[e._h for e in engine])
+            self._check(self._lib.mi_memfs_commit_layer_n(self._h, ctxs, len(engine), int(must_scan), cops, len(ops), C.byref(cfg),
+                                                          C.byref(res), C.byref(h), C.byref(done)), "mi_memfs_commit_layer_n")
+        else:
+            ctx = engine._h if engine is not None else None
+            if engine is not None:
+                engine._children.add(self)                    # the handle keeps a batch of that ctx: given back before it dies
+            self._check(self._lib.mi_memfs_commit_layer(self._h, ctx, int(must_scan), cops, len(ops), C.byref(cfg), C.byref(res),
+                                                        C.byref(h), C.byref(done)), "mi_memfs_commit_layer")
         if not done.value:
             return None
         return {"tar_digest": Digest.from_raw(res.tar_sha256), "gzip_digest": Digest.from_raw(res.gzip_sha256),

@@ -167,7 +167,22 @@ int ensure_stager(mi_ctx* c) {
 }
 // host-fed bytes are on their way (a tree walk has begun): the reader threads set up while the walk lists its first
 // directories; the first block or path that reaches them waits for whoever is not ready yet
+// ---- a group of batches behind one handle (mi_internal.h: members) -----------------------------------------------------------
+static inline bool is_group(const mi_batch* b) { return !b->members.empty(); }
+constexpr u64 kGroupAtShift = 48, kGroupAtMask = (1ull << kGroupAtShift) - 1;       // a group's "arena offset": member << 48 | offset
+static int group_fail(mi_batch* h, size_t k, int rc) {
+    std::string m;
+    { std::lock_guard<std::mutex> g(g_err_mu); m = h->members[k]->ctx->err; }
+    return mi::fail(h->ctx, rc, "gpu %zu of %zu: %s", k, h->members.size(), m.c_str());
+}
+static size_t group_least_loaded(const mi_batch* h) {
+    size_t k = 0;
+    for (size_t i = 1; i < h->members.size(); ++i) if (h->member_bytes[i] < h->member_bytes[k]) k = i;
+    return k;
+}
+
 extern "C" void mi_batch_expect_host_bytes(mi_batch* b) {
+    if (is_group(b)) { for (mi_batch* m : b->members) mi_batch_expect_host_bytes(m); return; }
     mi_ctx* c = b->ctx;
     if (!c->stager) c->stager = stager_create(c, c->stage_threads, c->staging_bytes);
 }
@@ -985,6 +1000,29 @@ int mi_batch_add_path(mi_batch* b, const char* path, uint64_t size, uint64_t use
 int mi_batch_add_paths(mi_batch* b, uint64_t n, const char* const* paths, const uint64_t* sizes,
                        const uint64_t* user_tags) {
     if (!b || (n && (!paths || !sizes))) return MI_ERR_INVALID;
+    if (is_group(b)) {
+        // each file to the member with the fewest bytes so far (the streaming form of longest-processing-time-first: the walk
+        // hands files over as it finds them); a member's files keep the walk's order among themselves
+        const size_t nm = b->members.size();
+        std::vector<std::vector<const char*>> mp(nm);
+        std::vector<std::vector<u64>> ms(nm), mt(nm);
+        for (u64 i = 0; i < n; ++i) {
+            const size_t k = group_least_loaded(b);
+            b->member_bytes[k] += sizes[i] + 4096;                 // (a file costs something even when it is empty: rows, a descriptor)
+            b->row_member.push_back((u32)k);
+            b->row_row.push_back(b->members[k]->files.size() + mp[k].size());
+            mp[k].push_back(paths[i]);
+            ms[k].push_back(sizes[i]);
+            mt[k].push_back(user_tags ? user_tags[i] : 0);
+            b->total_bytes += sizes[i];
+        }
+        for (size_t k = 0; k < nm; ++k) {
+            if (mp[k].empty()) continue;
+            const int rc = mi_batch_add_paths(b->members[k], mp[k].size(), mp[k].data(), ms[k].data(), mt[k].data());
+            if (rc) return group_fail(b, k, rc);
+        }
+        return MI_OK;
+    }
     mi_ctx* c = b->ctx;
     HIPCHK(c, hipSetDevice(c->device));
     if (n == 0) return MI_OK;
@@ -1021,6 +1059,15 @@ int mi_batch_add_paths(mi_batch* b, uint64_t n, const char* const* paths, const 
 // (mi_batch_add_placed): where a file lies in the arena has nothing to do with its index.
 extern "C" int mi_batch_add_block(mi_batch* b, const void* src, uint64_t len, void (*release)(void*), void* release_arg,
                                   uint64_t* at_out) {
+    if (b && is_group(b)) {                          // the whole block -- a directory's small files -- to ONE member
+        const size_t k = group_least_loaded(b);
+        uint64_t at = 0;
+        const int rc = mi_batch_add_block(b->members[k], src, len, release, release_arg, &at);
+        if (rc) return group_fail(b, k, rc);
+        b->member_bytes[k] += len;
+        if (at_out) *at_out = ((u64)k << kGroupAtShift) | at;
+        return MI_OK;
+    }
     std::shared_ptr<void> keep(release_arg, release ? release : +[](void*) {});
     if (!b || !src || !at_out) return MI_ERR_INVALID;
     mi_ctx* c = b->ctx;
@@ -1043,6 +1090,27 @@ extern "C" int mi_batch_add_block(mi_batch* b, const void* src, uint64_t len, vo
 extern "C" int mi_batch_add_placed(mi_batch* b, uint64_t n, const uint64_t* arena_off, const uint64_t* sizes,
                                    const uint64_t* tags, const uint64_t* sums) {
     if (!b || (n && (!arena_off || !sizes))) return MI_ERR_INVALID;
+    if (is_group(b)) {                               // rows of blocks that went to different members, in the walk's order
+        const size_t nm = b->members.size();
+        std::vector<std::vector<u64>> mo(nm), ms(nm), mt(nm), mq(nm);
+        for (u64 i = 0; i < n; ++i) {
+            const size_t k = (size_t)(arena_off[i] >> kGroupAtShift);
+            if (k >= nm) return fail(b->ctx, MI_ERR_INVALID, "mi_batch_add_placed: no such member");
+            b->row_member.push_back((u32)k);
+            b->row_row.push_back(b->members[k]->files.size() + mo[k].size());
+            mo[k].push_back(arena_off[i] & kGroupAtMask);
+            ms[k].push_back(sizes[i]);
+            mt[k].push_back(tags ? tags[i] : 0);
+            if (sums) { mq[k].push_back(sums[2 * i]); mq[k].push_back(sums[2 * i + 1]); }
+            b->total_bytes += sizes[i];
+        }
+        for (size_t k = 0; k < nm; ++k) {
+            if (mo[k].empty()) continue;
+            const int rc = mi_batch_add_placed(b->members[k], mo[k].size(), mo[k].data(), ms[k].data(), mt[k].data(), sums ? mq[k].data() : nullptr);
+            if (rc) return group_fail(b, k, rc);
+        }
+        return MI_OK;
+    }
     if (b->staged) return fail(b->ctx, MI_ERR_STATE, "batch already ran; begin a new batch");
     for (u64 i = 0; i < n; ++i) {
         if (sizes[i] > b->arena_used || arena_off[i] > b->arena_used - sizes[i])          // (no sum: it could wrap)
@@ -1058,8 +1126,11 @@ extern "C" int mi_batch_add_placed(mi_batch* b, uint64_t n, const uint64_t* aren
     }
     return MI_OK;
 }
-extern "C" int mi_batch_keeps_sums(mi_batch* b) { return b && b->keep_sums ? 1 : 0; }
-extern "C" void mi_batch_keep_sums(mi_batch* b, int on) { if (b && b->files.empty()) b->keep_sums = on != 0; }
+extern "C" int mi_batch_keeps_sums(mi_batch* b) { return b && (is_group(b) ? b->members[0]->keep_sums : b->keep_sums) ? 1 : 0; }
+extern "C" void mi_batch_keep_sums(mi_batch* b, int on) {
+    if (b && is_group(b)) { if (b->row_member.empty()) for (mi_batch* m : b->members) mi_batch_keep_sums(m, on); return; }
+    if (b && b->files.empty()) b->keep_sums = on != 0;
+}
 
 // Room for what the caller knows is coming: the arena grows ONCE, now, instead of in steps under way -- every growth has
 // to drain the reader threads first (copies in flight target the old arena) and moves what the arena already holds.
@@ -1069,6 +1140,14 @@ int mi_batch_reserve(mi_batch* b, uint64_t more_files, uint64_t more_bytes) { re
 int mi_batch_reserve_ahead(mi_batch* b, uint64_t more_files, uint64_t more_bytes) { return batch_reserve(b, more_files, more_bytes, true); }
 static int batch_reserve(mi_batch* b, uint64_t more_files, uint64_t more_bytes, bool ahead) {
     if (!b) return MI_ERR_INVALID;
+    if (is_group(b)) {                               // every member its share and a quarter (the split is by bytes, not exact)
+        const u64 nm = b->members.size();
+        for (size_t k = 0; k < nm; ++k) {
+            const int rc = batch_reserve(b->members[k], more_files / nm + 1, more_bytes / nm + more_bytes / (4 * nm), ahead);
+            if (rc) return group_fail(b, k, rc);
+        }
+        return MI_OK;
+    }
     mi_ctx* c = b->ctx;
     HIPCHK(c, hipSetDevice(c->device));
     if (b->staged) return fail(c, MI_ERR_STATE, "batch already ran; begin a new batch");
@@ -1405,6 +1484,21 @@ int mi_batch_wait(mi_batch* b) {
 
 int mi_batch_run(mi_batch* b) {
     if (!b) return MI_ERR_INVALID;
+    if (is_group(b)) {                               // every member on a thread of its own: one GPU each
+        const size_t nm = b->members.size();
+        std::vector<int> rcs(nm, MI_OK);
+        std::vector<std::thread> th;
+        for (size_t k = 1; k < nm; ++k) th.emplace_back([&, k] { rcs[k] = mi_batch_run(b->members[k]); });
+        rcs[0] = mi_batch_run(b->members[0]);
+        for (auto& t : th) t.join();
+        b->n_chunks = 0;
+        for (size_t k = 0; k < nm; ++k) {
+            if (rcs[k]) return group_fail(b, k, rcs[k]);
+            b->n_chunks += b->members[k]->n_chunks;
+        }
+        b->ran = true;
+        return MI_OK;
+    }
     if (b->ran || b->in_flight)
         return fail(b->ctx, MI_ERR_STATE, "batch already ran; use mi_batch_rerun");
     int rc = mi_batch_submit(b);
@@ -1426,6 +1520,20 @@ int mi_batch_rerun(mi_batch* b) {
 static void read_windows_drop(mi_batch* b);
 int mi_batch_reset(mi_batch* b) {
     if (!b) return MI_ERR_INVALID;
+    if (is_group(b)) {
+        for (size_t k = 0; k < b->members.size(); ++k) {
+            const int rc = mi_batch_reset(b->members[k]);
+            if (rc) return group_fail(b, k, rc);
+        }
+        if (b->tree) { mi_batch_tree_free(b->tree); b->tree = nullptr; }
+        b->row_member.clear();
+        b->row_row.clear();
+        b->member_bytes.assign(b->members.size(), 0);
+        b->total_bytes = 0;
+        b->n_chunks = 0;
+        b->ran = false;
+        return MI_OK;
+    }
     mi_ctx* c = b->ctx;
     HIPCHK(c, hipSetDevice(c->device));
     if (b->in_flight) return fail(c, MI_ERR_STATE, "batch is in flight; mi_batch_wait first");
@@ -1476,6 +1584,12 @@ const char* mi_batch_stage_note(mi_batch* b) {
 
 int mi_batch_counts(mi_batch* b, uint64_t* n_files, uint64_t* n_chunks, uint64_t* n_bytes) {
     if (!b) return MI_ERR_INVALID;
+    if (is_group(b)) {
+        if (n_files) *n_files = b->row_member.size();
+        if (n_chunks) *n_chunks = b->n_chunks;
+        if (n_bytes) *n_bytes = b->total_bytes;
+        return MI_OK;
+    }
     if (n_files) *n_files = b->files.size();
     if (n_chunks) *n_chunks = b->n_chunks;
     if (n_bytes) *n_bytes = b->total_bytes;
@@ -1560,6 +1674,20 @@ int mi_batch_read_back(mi_batch* b, void* out, uint64_t cap) {
 // the chunk rows mi_batch_files / _chunks bring along.
 int mi_batch_roots(mi_batch* b, uint8_t* out, uint64_t cap) {
     if (!b || (!out && cap)) return MI_ERR_INVALID;
+    if (is_group(b)) {                               // the members' roots, put back into the walk's order
+        if (!b->ran) return fail(b->ctx, MI_ERR_STATE, "roots requested before mi_batch_run");
+        const u64 nf = b->row_member.size();
+        if (cap < nf) return fail(b->ctx, MI_ERR_CAPACITY, "root buffer holds %llu rows, need %llu", (unsigned long long)cap, (unsigned long long)nf);
+        std::vector<std::vector<u8>> mr(b->members.size());
+        for (size_t k = 0; k < b->members.size(); ++k) {
+            const u64 n = b->members[k]->files.size();
+            mr[k].resize(n * 32 + 32);
+            const int rc = mi_batch_roots(b->members[k], mr[k].data(), n);
+            if (rc) return group_fail(b, k, rc);
+        }
+        for (u64 g = 0; g < nf; ++g) memcpy(out + 32 * g, mr[b->row_member[g]].data() + 32 * b->row_row[g], 32);
+        return MI_OK;
+    }
     mi_ctx* c = b->ctx;
     HIPCHK(c, hipSetDevice(c->device));
     if (!b->ran) return fail(c, MI_ERR_STATE, "roots requested before mi_batch_run");
@@ -1614,6 +1742,12 @@ static void read_windows_drop(mi_batch* b) {
 // thread; the file's bytes are waited for (stager_wait_landed), nothing else of the batch's state is touched
 static int read_file_impl(mi_batch* b, uint64_t file_index, uint64_t offset, void* dst, uint64_t len, bool while_staging) {
     if (!b || (!dst && len)) return MI_ERR_INVALID;
+    if (is_group(b)) {                               // from the GPU that holds the file
+        if (file_index >= b->row_member.size()) return fail(b->ctx, MI_ERR_INVALID, "mi_batch_read_file: no file %llu", (unsigned long long)file_index);
+        const size_t k = b->row_member[file_index];
+        const int rc = read_file_impl(b->members[k], b->row_row[file_index], offset, dst, len, while_staging);
+        return rc ? group_fail(b, k, rc) : MI_OK;
+    }
     mi_ctx* c = b->ctx;
     if (!while_staging && (!b->staged || b->in_flight))
         return fail(c, MI_ERR_STATE, "mi_batch_read_file: the batch is not staged, or in flight");
@@ -1719,6 +1853,16 @@ int mi_batch_read_file_landed(mi_batch* b, uint64_t file_index, uint64_t offset,
 }
 
 void mi_batch_read_stats(mi_batch* b, double* wait_s, double* fetch_s, uint64_t* fetches, uint64_t* bytes) {
+    if (b && is_group(b)) {
+        double w = 0, f = 0;
+        uint64_t nf = 0, nb = 0;
+        for (mi_batch* m : b->members) { w += m->rb_wait_s; f += m->rb_fetch_s; nf += m->rb_fetches; nb += m->rb_bytes; }
+        if (wait_s) *wait_s = w;
+        if (fetch_s) *fetch_s = f;
+        if (fetches) *fetches = nf;
+        if (bytes) *bytes = nb;
+        return;
+    }
     if (wait_s) *wait_s = b ? b->rb_wait_s : 0;
     if (fetch_s) *fetch_s = b ? b->rb_fetch_s : 0;
     if (fetches) *fetches = b ? b->rb_fetches : 0;
@@ -1726,16 +1870,28 @@ void mi_batch_read_stats(mi_batch* b, double* wait_s, double* fetch_s, uint64_t*
 }
 // the layer writer's check (mi_layer.hip): a file row's chunk sums as they were taken where the bytes were read (NULL: none kept)
 int mi_batch_file_sums(mi_batch* b, uint64_t file_index, const void** sums, uint64_t* n_chunks) {
+    if (b && is_group(b)) {
+        if (file_index >= b->row_member.size()) return MI_ERR_INVALID;
+        return mi_batch_file_sums(b->members[b->row_member[file_index]], b->row_row[file_index], sums, n_chunks);
+    }
     if (!b || !sums || file_index >= b->files.size()) return MI_ERR_INVALID;
     *sums = b->files[file_index].sums;
     if (n_chunks) *n_chunks = mi_sum::chunks_of(b->files[file_index].size);
     return MI_OK;
 }
-void mi_batch_drop_windows(mi_batch* b) { if (b) read_windows_drop(b); }
+void mi_batch_drop_windows(mi_batch* b) {
+    if (b && is_group(b)) { for (mi_batch* m : b->members) read_windows_drop(m); return; }
+    if (b) read_windows_drop(b);
+}
 // A chunk that came back from HBM with other sums than it went with, twice: WHICH hop?  The chunk once more, by a plain copy
 // into memory of this call's own (not the windows, not their stream): the same sums as at the source -- HBM holds the right
 // bytes and the read-back windows delivered others; other sums -- the arena does not hold what the file had when it was read.
 int mi_batch_explain_chunk(mi_batch* b, uint64_t file_index, uint64_t chunk, char* msg, uint64_t cap) {
+    if (b && is_group(b)) {
+        if (file_index >= b->row_member.size() || !msg || cap < 16) return MI_ERR_INVALID;
+        const int n = snprintf(msg, (size_t)cap, "gpu %u: ", b->row_member[file_index]);
+        return mi_batch_explain_chunk(b->members[b->row_member[file_index]], b->row_row[file_index], chunk, msg + n, cap - (uint64_t)n);
+    }
     if (!b || !msg || !cap || file_index >= b->files.size()) return MI_ERR_INVALID;
     mi_ctx* c = b->ctx;
     const mi_batch::FileRec& f = b->files[file_index];
@@ -1757,12 +1913,24 @@ int mi_batch_explain_chunk(mi_batch* b, uint64_t file_index, uint64_t chunk, cha
     return MI_OK;
 }
 int mi_batch_file_size(mi_batch* b, uint64_t file_index, uint64_t* size) {       // (internal: mi_layer.hip)
+    if (b && is_group(b)) {
+        if (file_index >= b->row_member.size()) return MI_ERR_INVALID;
+        return mi_batch_file_size(b->members[b->row_member[file_index]], b->row_row[file_index], size);
+    }
     if (!b || !size || file_index >= b->files.size() || b->files[file_index].part >= 0) return MI_ERR_INVALID;
     *size = b->files[file_index].size;
     return MI_OK;
 }
 int mi_batch_arena_info(mi_batch* b, uint64_t* bytes, uint64_t* pieces, uint64_t* moves) {
     if (!b) return MI_ERR_INVALID;
+    if (is_group(b)) {
+        uint64_t tb = 0, tp = 0, tm = 0;
+        for (mi_batch* m : b->members) { uint64_t x = 0, y = 0, z = 0; mi_batch_arena_info(m, &x, &y, &z); tb += x; tp += y; tm += z; }
+        if (bytes) *bytes = tb;
+        if (pieces) *pieces = tp;
+        if (moves) *moves = tm;
+        return MI_OK;
+    }
     u64 mapped = 0, n = 0;
     arena_counts(&b->arena, &mapped, &n, nullptr);
     if (bytes) *bytes = b->arena.vm ? mapped : b->arena.bytes;
@@ -1772,6 +1940,11 @@ int mi_batch_arena_info(mi_batch* b, uint64_t* bytes, uint64_t* pieces, uint64_t
 }
 int mi_batch_arena_room(mi_batch* b, uint64_t* bytes) {
     if (!b || !bytes) return MI_ERR_INVALID;
+    if (is_group(b)) {                               // what every member can count on: the smallest
+        *bytes = ~0ull;
+        for (mi_batch* m : b->members) if (m->arena.bytes < *bytes) *bytes = m->arena.bytes;
+        return MI_OK;
+    }
     *bytes = b->arena.bytes;
     return MI_OK;
 }
@@ -1789,8 +1962,54 @@ void mi_set_error(mi_batch* b, const char* msg) {                // b NULL: the 
     if (b) b->ctx->err = msg; else g_create_err = msg;
 }
 
+// One handle over n batches, one per ctx (hidden: mi_memfs_commit_layer_n's batch).  The head belongs to ctxs[0] (its errors are
+// reported there, "gpu k of n: ..." naming the member); it has no device state of its own.
+int mi_batch_group_begin(mi_ctx* const* ctxs, uint32_t n, mi_batch** out) {
+    if (!ctxs || n < 2 || n > 64 || !out) return MI_ERR_INVALID;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (!ctxs[i]) return MI_ERR_INVALID;
+        for (uint32_t j = 0; j < i; ++j) if (ctxs[j] == ctxs[i]) return fail(ctxs[0], MI_ERR_INVALID, "a batch group needs %u DIFFERENT ctxs", n);
+    }
+    mi_batch* h = new mi_batch();
+    h->ctx = ctxs[0];
+    memset(&h->stats, 0, sizeof h->stats);
+    memset(&h->stage_stats, 0, sizeof h->stage_stats);
+    ++h->ctx->live_children;
+    for (uint32_t i = 0; i < n; ++i) {
+        mi_batch* m = nullptr;
+        const int rc = mi_batch_begin(ctxs[i], 0, 0, &m);
+        if (rc) {
+            std::string e;
+            { std::lock_guard<std::mutex> g(g_err_mu); e = ctxs[i]->err; }
+            for (mi_batch* x : h->members) mi_batch_free(x);
+            h->members.clear();
+            --h->ctx->live_children;
+            delete h;
+            return fail(ctxs[0], rc, "gpu %u of %u: %s", i, n, e.c_str());
+        }
+        h->members.push_back(m);
+    }
+    h->member_bytes.assign(n, 0);
+    *out = h;
+    return MI_OK;
+}
+int mi_batch_group_members(mi_batch* b, mi_batch* const** members, const uint64_t** bytes, uint64_t* n) {
+    if (!b || !n) return MI_ERR_INVALID;
+    *n = b->members.size();
+    if (members) *members = b->members.data();
+    if (bytes) *bytes = b->member_bytes.data();
+    return MI_OK;
+}
+
 int mi_batch_free(mi_batch* b) {
     if (!b) return MI_ERR_INVALID;
+    if (is_group(b)) {
+        if (b->tree) { mi_batch_tree_free(b->tree); b->tree = nullptr; }
+        for (mi_batch* m : b->members) mi_batch_free(m);
+        --b->ctx->live_children;
+        delete b;
+        return MI_OK;
+    }
     if (b->tree) { mi_batch_tree_free(b->tree); b->tree = nullptr; }
     mi_ctx* c = b->ctx;
     (void)hipSetDevice(c->device);

@@ -172,6 +172,13 @@ struct mi_batch {
     bool parts_dirty = false;                // a confirmed entry differs from the one the cuts were made with
     mi::u64 total_bytes = 0;     // sum of sizes
     mi::u64 arena_used = 0;      // next free arena offset
+    // A GROUP HEAD (mi_batch_group_begin; mi_memfs_commit_layer_n): no arena, no stream -- a handle behind which the file rows of a
+    // walk are spread over one batch per ctx (one per GPU), each block / file going to the member with the fewest bytes so far.  The
+    // walk and the commit see ONE batch: group row g is row row_row[g] of members[row_member[g]].
+    std::vector<mi_batch*> members;
+    std::vector<mi::u32> row_member;
+    std::vector<mi::u64> row_row;
+    std::vector<mi::u64> member_bytes;
     mi::Arena arena;
     bool keep_sums = false;      // every host-fed file row carries the sums of its bytes as they were READ (mi_filesum.h): what the layer
     mi_sum::Pool sum_pool;       // writer checks the bytes it frames against (MI_FLAG_FILE_SUMS; always for a MemFS handle's batch)

@@ -43,10 +43,17 @@ MI_LOCAL void mi_batch_expect_host_bytes(mi_batch* b);
 // mi_batch_reserve for a walk whose enumeration runs ahead of what it hands over (and for mi_memfs_reserve_device): the arena
 // is the piecewise kind (mi_arena.hip) -- what is coming is known roughly and keeps growing
 MI_LOCAL int  mi_batch_reserve_ahead(mi_batch* b, uint64_t more_files, uint64_t more_bytes);
+// one handle over n batches, one per ctx: what a walk hands over is spread by bytes, the commit sees one batch (mi_internal.h:
+// members); the members and their loads (n = 0: not a group)
+MI_LOCAL int  mi_batch_group_begin(mi_ctx* const* ctxs, uint32_t n, mi_batch** out);
+MI_LOCAL int  mi_batch_group_members(mi_batch* b, mi_batch* const** members, const uint64_t** bytes, uint64_t* n);
 // job-wide marking of a rank's own rows, enqueued on the ctx stream; the first-occurrence count stays in
 // ctx->dd_nuniq (device).  For mi_comm.hip
 MI_LOCAL int  mi_dedup_mark_range_enqueue(mi_ctx* c, const void* d_digests, uint64_t n_total, uint64_t own_first,
                                           uint64_t own_n, void* d_dup_of_own);
+// mi_index.hip: mi_index_add_batch for digests in host memory (a batch of another GPU than the index's)
+MI_LOCAL int  mi_index_add_digests(mi_index* index, const void* digests, uint64_t n, uint8_t* known_out, uint64_t* n_new, uint64_t* n_known);
+MI_LOCAL int  mi_index_same_ctx(mi_index* index, mi_batch* b);
 // mi_tree.hip
 MI_LOCAL void mi_batch_tree_free(void* tree);
 }

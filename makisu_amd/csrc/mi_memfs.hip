@@ -1382,6 +1382,7 @@ struct mi_memfs {
     // are sized by the first commit and reused by the next (mi_batch_reset)
     mi_batch* batch = nullptr;
     mi_ctx* batch_ctx = nullptr;
+    std::vector<mi_ctx*> batch_ctxs;     // ... or, behind the same handle, one batch per ctx (mi_memfs_commit_layer_n: a group)
     mi_index* index = nullptr;           // mi_memfs_set_index: every content-aware commit adds its batch's chunks
     mi_commit_stats last;                // of the last mi_memfs_commit_layer
     bool went_windowed = false;          // the scanned tree did not fit the device (the next full scan goes window by window at once)
@@ -1778,9 +1779,33 @@ static int commit_roots_by_windows(mi_memfs* m, mi_batch* b, const std::vector<W
     return run(lo, files.size());
 }
 
+static int memfs_commit(mi_memfs* m, mi_ctx* const* ctxs, uint32_t n_ctx, int must_scan, const mi_copy_op* ops, uint64_t n_ops,
+                        const mi_layer_config* cfg, mi_layer_result* res, mi_copy_layer** layer_out, int* committed);
 extern "C" int mi_memfs_commit_layer(mi_memfs* m, mi_ctx* ctx, int must_scan, const mi_copy_op* ops, uint64_t n_ops,
                                      const mi_layer_config* cfg, mi_layer_result* res, mi_copy_layer** layer_out,
                                      int* committed) {
+    return memfs_commit(m, ctx ? &ctx : nullptr, ctx ? 1 : 0, must_scan, ops, n_ops, cfg, res, layer_out, committed);
+}
+// THE COMMIT OVER SEVERAL GPUs (north_star: "file batches shard across the 8 GPUs of one node").  One ctx per
+// GPU; what the walk hands over -- a directory's block of small files, a large file -- goes to the GPU with the fewest bytes so
+// far (the streaming form of longest-processing-time-first: a walk does not know its files in advance); every GPU stages through
+// its own reader threads and PCIe link, scans its share, and the committing thread gets the roots back in the walk's order; the
+// tar writer reads each file from the GPU that holds it; the chunk index (on one of the ctxs) takes the other GPUs' digests
+// through the host (32 bytes per chunk).  Everything else -- the diff, the pipelining, the sums, TRUST_CTIME, the windows of a
+// tree that does not fit -- is the one-GPU commit's: behind the handle the n batches look like one (mi_batch_group_begin).
+// n_ctx = 1 is mi_memfs_commit_layer, n_ctx = 0 the reference's commit.  Files are not split across GPUs (a 1 GiB file is 20 ms of
+// one PCIe link; the parts protocol of mi_batch_add_path_part is for scans whose unit is one huge file, not for a layer).
+// UNMEASURED on more than one physical GPU (no such box in this pool): tested with n ctxs on one device and on the HIP double.
+extern "C" int mi_memfs_commit_layer_n(mi_memfs* m, mi_ctx* const* ctxs, uint32_t n_ctx, int must_scan, const mi_copy_op* ops,
+                                       uint64_t n_ops, const mi_layer_config* cfg, mi_layer_result* res,
+                                       mi_copy_layer** layer_out, int* committed) {
+    if (n_ctx && !ctxs) return MI_ERR_INVALID;
+    if (n_ctx > 64) return MI_ERR_INVALID;
+    return memfs_commit(m, ctxs, n_ctx, must_scan, ops, n_ops, cfg, res, layer_out, committed);
+}
+static int memfs_commit(mi_memfs* m, mi_ctx* const* ctxs, uint32_t n_ctx, int must_scan, const mi_copy_op* ops, uint64_t n_ops,
+                        const mi_layer_config* cfg, mi_layer_result* res, mi_copy_layer** layer_out, int* committed) {
+    mi_ctx* const ctx = n_ctx ? ctxs[0] : nullptr;
     if (!m || !cfg || !res || !committed || (n_ops && !ops)) return MI_ERR_INVALID;
     *committed = 0;
     if (layer_out) *layer_out = nullptr;
@@ -1803,10 +1828,15 @@ extern "C" int mi_memfs_commit_layer(mi_memfs* m, mi_ctx* ctx, int must_scan, co
     mi_batch* b = nullptr;
     uint64_t moves0 = 0;
     if (ctx) {
-        if (m->batch && m->batch_ctx != ctx) { mi_batch_free(m->batch); m->batch = nullptr; }
+        const std::vector<mi_ctx*> want(ctxs, ctxs + n_ctx);
+        if (m->batch && (m->batch_ctx != ctx || m->batch_ctxs != want)) { mi_batch_free(m->batch); m->batch = nullptr; }
         if (m->batch) mi_batch_arena_info(m->batch, nullptr, nullptr, &moves0);
         if (m->batch) rc = mi_batch_reset(m->batch);
-        else { rc = mi_batch_begin(ctx, 0, 0, &m->batch); m->batch_ctx = ctx; }
+        else {
+            rc = n_ctx > 1 ? mi_batch_group_begin(ctxs, n_ctx, &m->batch) : mi_batch_begin(ctx, 0, 0, &m->batch);
+            m->batch_ctx = ctx;
+            m->batch_ctxs = want;
+        }
         if (rc) return fail_with(rc, std::string("gpu scan: ") + mi_last_error(ctx));
         mi_batch_keep_sums(m->batch, memfs_verify_on());                          // the tar is framed from HBM: held against what was read
         b = m->batch;
@@ -1995,16 +2025,33 @@ extern "C" int mi_memfs_commit_layer(mi_memfs* m, mi_ctx* ctx, int must_scan, co
     m->last.pipelined = was_piped ? 1 : 0;
     if (!rc && b && m->index && m->last.n_scanned_files) {
         // the chunk index (keyvalue.Store seam): which of this commit's chunks no earlier commit held, and how many bytes they
-        // are -- what a chunk-addressed store would have to take in for this layer
-        uint64_t nc = 0;
-        mi_batch_counts(b, nullptr, &nc, nullptr);
-        std::vector<uint8_t> known(nc ? nc : 1);
-        rc = mi_index_add_batch(m->index, b, known.data(), nc, &m->last.n_index_new, &m->last.n_index_known);
-        const mi_chunk_result* rows = nullptr;
-        if (!rc && nc) rc = mi_batch_chunks_view(b, &rows, &nc);
-        if (!rc)
-            for (uint64_t i = 0; i < nc; ++i)
-                if (!known[i] && rows[i].dup_of < 0) m->last.index_new_bytes += rows[i].length;
+        // are -- what a chunk-addressed store would have to take in for this layer.  A commit over several GPUs feeds the ONE
+        // index batch by batch: the batch on the index's own GPU from device memory, the others' digests through the host.
+        mi_batch* const* members = &b;
+        uint64_t nm = 0;
+        mi_batch_group_members(b, &members, nullptr, &nm);
+        if (nm == 0) { members = &b; nm = 1; }
+        for (uint64_t k = 0; k < nm && !rc; ++k) {
+            mi_batch* mb = members[k];
+            uint64_t nc = 0, nn = 0, nk = 0;
+            mi_batch_counts(mb, nullptr, &nc, nullptr);
+            std::vector<uint8_t> known(nc ? nc : 1);
+            const mi_chunk_result* rows = nullptr;
+            if (nc) rc = mi_batch_chunks_view(mb, &rows, &nc);
+            if (!rc && mi_index_same_ctx(m->index, mb)) {
+                rc = mi_index_add_batch(m->index, mb, known.data(), nc, &nn, &nk);
+            } else if (!rc) {
+                std::vector<uint8_t> dg(nc * 32 + 32);
+                for (uint64_t i = 0; i < nc; ++i) memcpy(dg.data() + 32 * i, rows[i].sha256, 32);
+                rc = mi_index_add_digests(m->index, dg.data(), nc, known.data(), &nn, &nk);
+            }
+            if (!rc) {
+                m->last.n_index_new += nn;
+                m->last.n_index_known += nk;
+                for (uint64_t i = 0; i < nc; ++i)
+                    if (!known[i] && rows[i].dup_of < 0) m->last.index_new_bytes += rows[i].length;
+            }
+        }
         if (rc) m->err = std::string("failed to generate diff layer: chunk index: ") + mi_last_error(ctx);
     }
     m->last.files_opened += mi_io::content_opens.load() - opens0;
@@ -2014,6 +2061,15 @@ extern "C" int mi_memfs_commit_layer(mi_memfs* m, mi_ctx* ctx, int must_scan, co
         uint64_t moves = 0;
         mi_batch_arena_info(b, &m->last.arena_bytes, &m->last.arena_pieces, &moves);
         m->last.arena_moves = moves - moves0;
+        const uint64_t* loads = nullptr;
+        uint64_t nm = 0;
+        mi_batch_group_members(b, nullptr, &loads, &nm);
+        m->last.n_ctxs = nm ? nm : 1;
+        m->last.ctx_bytes_max = m->last.ctx_bytes_min = nm ? loads[0] : m->last.scanned_bytes;
+        for (uint64_t k = 1; k < nm; ++k) {
+            if (loads[k] > m->last.ctx_bytes_max) m->last.ctx_bytes_max = loads[k];
+            if (loads[k] < m->last.ctx_bytes_min) m->last.ctx_bytes_min = loads[k];
+        }
     }
     for (mi_copy::Node& nd : cl->nodes) nd.batch_file = -1;                       // (rows of a batch the caller does not hold)
     if (rc) { mi_copy_layer_free(cl); return rc; }

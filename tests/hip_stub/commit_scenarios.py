@@ -356,6 +356,93 @@ def scenario_verify(tmp, eng):
     print("OK verify " + case)
 
 
+def scenario_many_gpus(tmp, eng):
+    """THE COMMIT OVER SEVERAL CTXS (mi_memfs_commit_layer_n) -- MI_TEST_N_CTXS of them (2 and 8 in the tests), all
+    on the one device there is (the double's, or the box's).  Against the one-ctx commit and the header-only commit of the same
+    tree: the SAME tar, byte for byte; every file opened and read once (/proc/self/io agrees); every root = the one-ctx commit's (on
+    the GPU: = the oracle's); the bytes spread over the ctxs within a factor of two; then the life of a build -- nothing changed
+    (empty layer), a same-size rewrite within the second (on the GPU: caught by its root), a deleted directory (whiteout), a COPY
+    op; a chunk index on ctx 0 fed by all ctxs (as many digests as the one-ctx commit's index holds); a corrupted read-back on
+    whichever ctx serves the second window copy is repaired (MI_STAGE_FAULT=readback:1)."""
+    n = int(os.environ.get("MI_TEST_N_CTXS", "2"))
+    on_gpu = os.environ.get("MI_TEST_ON_GPU") == "1"
+    root = os.path.join(tmp, "many_root")
+    files = make_tree(root, seed=41, n_dirs=10, files_per_dir=12, big_every=3, mtime=MTIME)
+    total = sum(map(len, files.values()))
+    nonempty = [d for d in files.values() if d]
+    engines = [eng] + [M.Engine(n_streams=2, staging_bytes=1 << 20) for _ in range(n - 1)]
+    try:
+        with M.MemFS(root) as many, M.MemFS(root) as one, M.MemFS(root) as plain:
+            idx_many, idx_one = M.ChunkIndex(engines[-1]), M.ChunkIndex(eng)          # (the index of the group on its LAST ctx: every
+                                                                                      #  other ctx's digests reach it through the host)
+            many.set_index(idx_many)
+            one.set_index(idx_one)
+            r0, _ = proc_io()
+            with M.MemFS(root) as probe:                                    # (digests only: nothing of the tar is read back here)
+                probe.commit_layer(must_scan=True, engine=engines, gzip_level=M.GZIP_OFF)
+            r1, _ = proc_io()
+            windowed = os.environ.get("MI_COMMIT_FORCE_WINDOWS") == "1"     # (roots in windows, the tar's files from disk: two reads)
+            assert windowed or total <= r1 - r0 <= total + (512 << 10), (r1 - r0, total)  # one read per file, as the kernel counts it
+            res, raw = commit_to_bytes(many, tmp, "m0.tar", must_scan=True, engine=engines)
+            res1, raw1 = commit_to_bytes(one, tmp, "m0_one.tar", must_scan=True, engine=eng)
+            res0, raw0 = commit_to_bytes(plain, tmp, "m0_plain.tar", must_scan=True)
+            assert raw == raw1 == raw0, "the tar over %d ctxs is not the one-ctx commit's / the reference's" % n
+            st = res["stats"]
+            assert st["n_ctxs"] == n and st["n_scanned_files"] == len(files) and st["scanned_bytes"] == total, st
+            if windowed:
+                assert st["n_windows"] >= 2 and st["n_verified_files"] == 0, st
+            else:
+                assert (st["files_opened"], st["file_bytes_read"]) == (len(nonempty), total), st
+                assert st["n_verified_files"] == len(files) and st["n_refetched"] == (1 if os.environ.get("MI_STAGE_FAULT") else 0), st
+                assert st["ctx_bytes_min"] > 0 and st["ctx_bytes_max"] <= 2 * st["ctx_bytes_min"] + (1 << 20), st     # spread by bytes
+            assert st["n_chunks"] == res1["stats"]["n_chunks"] or not on_gpu
+            by, by1 = {e["relpath"]: e for e in res["layer"]}, {e["relpath"]: e for e in res1["layer"]}
+            assert list(by) == list(by1)
+            if on_gpu:
+                from oracle import mi_oracle as O
+                O.build()
+                from commit_cases import oracle_root
+                for rel, data in files.items():
+                    assert by[rel]["root"] == by1[rel]["root"] == oracle_root(O, data), rel
+                    assert many.root_of("/" + rel) == oracle_root(O, data), rel
+                assert len(idx_many) == len(idx_one) and st["n_index_new"] == res1["stats"]["n_index_new"]
+                assert st["index_new_bytes"] == res1["stats"]["index_new_bytes"]
+            # nothing changed: the empty layer; the handle kept its batches
+            res, raw = commit_to_bytes(many, tmp, "m1.tar", must_scan=True, engine=engines)
+            assert res["n_entries"] == 0 and raw == bytes(1024) and res["stats"]["n_ctxs"] == n
+            # a same-size rewrite within the second + an ordinary edit + a deleted directory
+            rel_a, rel_b = "d02/f001.bin", "d04/f005.bin"
+            new_a = bytearray(files[rel_a]); new_a[len(new_a) // 2] ^= 0x55
+            write_file(os.path.join(root, rel_a), bytes(new_a), 0o644, MTIME)
+            new_b = os.urandom(len(files[rel_b]) + 301)
+            write_file(os.path.join(root, rel_b), new_b, 0o644, MTIME + 9)
+            import shutil
+            shutil.rmtree(os.path.join(root, "d06"))
+            for dp in (root, os.path.join(root, "d02"), os.path.join(root, "d04")):
+                os.utime(dp, (MTIME, MTIME))
+            res, raw = commit_to_bytes(many, tmp, "m2.tar", must_scan=True, engine=engines)
+            got = {nm: d for nm, m_, d in tar_members(raw) if m_.isfile()}
+            assert got.get(rel_b) == new_b and ".wh.d06" in [e["relpath"] for e in res["layer"]], sorted(got)
+            if on_gpu:
+                assert got.get(rel_a) == bytes(new_a) and res["stats"]["n_content_changed"] == 1, sorted(got)
+            # a COPY op over the same ctxs
+            src_root = os.path.join(tmp, "many_src")
+            write_file(os.path.join(src_root, "pkg/a.bin"), os.urandom(70_000), 0o644, MTIME)
+            write_file(os.path.join(src_root, "pkg/b.bin"), os.urandom(3_000), 0o644, MTIME)
+            ops = [{"src_root": src_root, "srcs": ["pkg"], "dst": "/opt/pkg/", "uid": 0, "gid": 0}]
+            res, raw = commit_to_bytes(many, tmp, "m3.tar", ops=ops, engine=engines)
+            res0, raw0 = commit_to_bytes(plain, tmp, "m3_plain_pre.tar", must_scan=True)      # (the plain handle catches up with the edits first)
+            res0, raw0 = commit_to_bytes(plain, tmp, "m3_plain.tar", ops=ops)
+            assert sorted(nm for nm, m_, d in tar_members(raw) if m_.isfile()) == ["opt/pkg/a.bin", "opt/pkg/b.bin"] and raw == raw0
+            # back to ONE ctx on the same handle: the group is given back, a single batch takes over
+            res, raw = commit_to_bytes(many, tmp, "m4.tar", must_scan=True, engine=eng)
+            assert res["n_entries"] == 0 and res["stats"]["n_ctxs"] == 1
+    finally:
+        for e in engines[1:]:
+            e.close()
+    print("OK many_gpus %d" % n)
+
+
 def scenario_slash(tmp, eng):
     """the root of every real build is "/": the same commit with the handle rooted there (a node's source IS its path, nothing is
     trimmed), everything but one directory of this test's blacklisted -- with a ctx, with MI_MEMFS_TRUST_CTIME, and without"""
@@ -493,6 +580,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 3 and sys.argv[3] == "known_tree":
         with M.Engine(n_streams=int(sys.argv[2]), staging_bytes=1 << 20) as eng:
             scenario_known_tree(sys.argv[1], eng)
+        sys.exit(0)
+    if len(sys.argv) > 3 and sys.argv[3] == "many_gpus":
+        with M.Engine(n_streams=int(sys.argv[2]), staging_bytes=1 << 20) as eng:
+            scenario_many_gpus(sys.argv[1], eng)
         sys.exit(0)
     if len(sys.argv) > 3 and sys.argv[3] == "verify":
         with M.Engine(n_streams=int(sys.argv[2]), staging_bytes=1 << 20) as eng:

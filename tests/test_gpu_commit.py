@@ -147,6 +147,18 @@ def test_the_arena_never_moves_on_the_gpu(tmp_path):
     assert p.returncode == 0 and "OK known_tree" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
 
 
+@pytest.mark.parametrize("n,extra", [(2, {}), (8, {}), (3, {"MI_COMMIT_PIPELINE": "0"}), (2, {"MI_STAGE_FAULT": "readback:1"})])
+def test_the_commit_over_several_ctxs_on_the_gpu(tmp_path, n, extra):
+    """mi_memfs_commit_layer_n with n ctxs on the box's one GPU (tests/hip_stub/commit_scenarios.py `many_gpus`): every root = the
+    oracle's = the one-ctx commit's, the tar byte-identical to n = 1 and to the header-only commit, one read per file, the chunk
+    index (on the LAST ctx: every other ctx's digests reach it through the host) holds what the one-ctx commit's holds, a
+    same-second rewrite is caught, a corrupted read-back repaired.  No claim about more than one physical GPU."""
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hip_stub", "commit_scenarios.py")
+    env = dict(os.environ, MI_TEST_ON_GPU="1", MI_TEST_N_CTXS=str(n), **extra)
+    p = subprocess.run([sys.executable, script, str(tmp_path), "4", "many_gpus"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and ("OK many_gpus %d" % n) in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
+
+
 def _rewrite_same_size_same_second(path, rng):
     st = os.stat(path)
     old = open(path, "rb").read()

@@ -92,3 +92,15 @@ def test_bytes_that_change_on_the_way_fail_the_commit(hip_double, tmp_path, case
     p = subprocess.run([sys.executable, os.path.join(STUB_DIR, "commit_scenarios.py"), str(tmp_path), "4", "verify"], env=env,
                        capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and ("OK verify " + case) in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
+
+
+@pytest.mark.parametrize("n,extra", [(2, {}), (8, {}), (3, {"MI_COMMIT_PIPELINE": "0"}), (2, {"MI_STAGE_FAULT": "readback:1"}),
+                                     (4, {"MI_WALK_INLINE": "0"}), (2, {"MI_COMMIT_FORCE_WINDOWS": "1", "MI_COMMIT_WINDOW_MB": "1"})])
+def test_the_commit_over_several_ctxs_writes_the_one_ctx_commits_tar(hip_double, tmp_path, n, extra):  # noqa: F811
+    """mi_memfs_commit_layer_n (north_star: file batches shard across the GPUs of one node; lib/snapshot/mem_fs.go:260-289): the
+    walk's files spread by bytes over n ctxs, one read per file, the tar byte-identical to n = 1 and to the reference's commit; the
+    handle's later commits, a COPY, windows, a repaired read-back fault -- on the HIP double, n ctxs on its one device"""
+    env = dict(os.environ, LD_PRELOAD=(os.environ.get("LD_PRELOAD", "") + " " + hip_double).strip(), MI_TEST_N_CTXS=str(n), **extra)
+    p = subprocess.run([sys.executable, os.path.join(STUB_DIR, "commit_scenarios.py"), str(tmp_path), "4", "many_gpus"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and ("OK many_gpus %d" % n) in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
