@@ -1415,10 +1415,11 @@ static int stage_batch(mi_batch* b) {
     if ((rc = upload(c, b->file_off, off))) return rc;
     if ((rc = upload(c, b->file_size, size))) return rc;
     b->fsha_host.clear();
+    std::vector<u64> fl;                                    // (alive until the uploads below have been waited for)
     if (c->cfg.flags & MI_FLAG_FILE_SHA256) {
         // whole-file digests: a file too long for a GPU lane goes to the reader threads' SHA-NI streams (route_long_strings);
         // the GPU pass sees it as an empty string.  (Parts have no whole-file values.)
-        std::vector<u64> fl(size);
+        fl = size;
         for (u64 f = 0; f < nf; ++f) if (b->files[f].part >= 0) fl[f] = 0;
         route_long_strings(fl.data(), nf, c->stage_threads, false, &b->fsha_host);
         for (u32 f : b->fsha_host) fl[f] = 0;
@@ -2032,11 +2033,11 @@ int mi_batch_free(mi_batch* b) {
     if (b->h_counts) (void)hipHostFree(b->h_counts);
     if (b->rows_h) (void)hipHostFree(b->rows_h);
     read_windows_drop(b);
+    if (b->rb_stream) { (void)hipStreamSynchronize(b->rb_stream); (void)hipStreamDestroy(b->rb_stream); }   // (before its events go)
     for (auto& w : b->rb) {
         if (w.p) (void)hipHostFree(w.p);
         if (w.ev) (void)hipEventDestroy(w.ev);
     }
-    if (b->rb_stream) (void)hipStreamDestroy(b->rb_stream);
     if (b->h_files) (void)hipHostFree(b->h_files);
     DevBuf* bufs[] = {&b->root_addr, &b->root_cnt, &b->rseg_cnt, &b->rseg_first, &b->rseg_total,
                       &b->root_items_off, &b->root_items_len, &b->root_level[0], &b->root_level[1],

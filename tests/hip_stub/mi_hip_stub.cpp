@@ -200,11 +200,9 @@ hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) {
         gen = ++ev->recorded;
     }
     S(s)->push([ev, gen] {
-        {
-            std::lock_guard<std::mutex> g(ev->mu);
-            if (ev->done < gen) ev->done = gen;
-            ev->at = std::chrono::steady_clock::now();
-        }
+        std::lock_guard<std::mutex> g(ev->mu);       // (notified UNDER the lock: a waiter that destroys the event when it returns
+        if (ev->done < gen) ev->done = gen;          //  cannot do so while the broadcast is still touching the condition variable)
+        ev->at = std::chrono::steady_clock::now();
         ev->cv.notify_all();
     });
     return hipSuccess;
