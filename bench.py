@@ -1196,7 +1196,7 @@ def main():
                 commit_e2e(eng, 64, 65536)
                 first = time.perf_counter() - t0
                 return {"call": "mi_memfs_commit_layer(fs, ctx | NULL, must_scan = 1, ...), gzip leg off; s_total = wall seconds around the python harness's call "
-                                "(it builds a dict per layer entry: 0.1 s per 100 000), s_call = the library's own clock around the C call",
+                                "(the layer's entries stay in the library: no per-entry python work in the timed call), s_call = the library's own clock around the C call",
                         "first_use_s": round(first, 4),
                         "first_use": "nine commits of a 64 x 64 KiB tree before the tables (the same three sides, three commits each): the ctx's first "
                                      "host-fed use -- reader threads, pinned slabs, read-back windows -- is in this number, not in the tables",

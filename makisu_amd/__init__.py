@@ -692,11 +692,12 @@ class MemFS:
                     "mi_memfs_add_layer_by_copy_ops")
         return _take_copy_layer(self._lib, h, n.value)
 
-    def commit_layer(self, must_scan=False, ops=(), out_fd=-1, gzip_level=GZIP_DEFAULT, engine=None, mode_with_type=False):
+    def commit_layer(self, must_scan=False, ops=(), out_fd=-1, gzip_level=GZIP_DEFAULT, engine=None, mode_with_type=False, want_layer=True):
         """step.commitLayer: the layer by scan or by copy ops, written through the layer writer.  engine = an Engine: the
         content-aware commit (walk + stage + GPU scan + diff with chunk roots + tar from HBM, one call); a list of Engines: the
         same over several GPUs (mi_memfs_commit_layer_n); None: the reference's.  Returns None when there is nothing to do, else
-        dict(tar_digest, gzip_digest, tar_bytes, gzip_bytes, n_entries, layer=[entries, with "root" for scanned files], stats={...})."""
+        dict(tar_digest, gzip_digest, tar_bytes, gzip_bytes, n_entries, layer=[entries, with "root" for scanned files], stats={...});
+        want_layer=False leaves the layer's entries in the library (layer=None): a timing harness should not measure 100 000 dicts."""
         keep = []
         cops = _copy_op_array(list(ops), keep)
         cfg = LayerConfig()
@@ -705,23 +706,24 @@ class MemFS:
         if mode_with_type:
             cfg.flags |= LAYER_MODE_WITH_TYPE
         res, h, done = LayerResult(), C.c_void_p(), C.c_int()
+        hp = C.byref(h) if want_layer else None
         if isinstance(engine, (list, tuple)):
             for e in engine:
                 e._children.add(self)
             ctxs = (C.c_void_p * max(len(engine), 1))(*[e._h for e in engine])
             self._check(self._lib.mi_memfs_commit_layer_n(self._h, ctxs, len(engine), int(must_scan), cops, len(ops), C.byref(cfg),
-                                                          C.byref(res), C.byref(h), C.byref(done)), "mi_memfs_commit_layer_n")
+                                                          C.byref(res), hp, C.byref(done)), "mi_memfs_commit_layer_n")
         else:
             ctx = engine._h if engine is not None else None
             if engine is not None:
                 engine._children.add(self)                    # the handle keeps a batch of that ctx: given back before it dies
             self._check(self._lib.mi_memfs_commit_layer(self._h, ctx, int(must_scan), cops, len(ops), C.byref(cfg), C.byref(res),
-                                                        C.byref(h), C.byref(done)), "mi_memfs_commit_layer")
+                                                        hp, C.byref(done)), "mi_memfs_commit_layer")
         if not done.value:
             return None
         return {"tar_digest": Digest.from_raw(res.tar_sha256), "gzip_digest": Digest.from_raw(res.gzip_sha256),
                 "tar_bytes": res.tar_bytes, "gzip_bytes": res.gzip_bytes, "n_entries": res.n_entries,
-                "layer": _take_copy_layer(self._lib, h, int(res.n_entries)), "stats": self.commit_stats()}
+                "layer": _take_copy_layer(self._lib, h, int(res.n_entries)) if want_layer else None, "stats": self.commit_stats()}
 
     def commit_stats(self):
         st = CommitStats()

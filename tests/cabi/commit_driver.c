@@ -8,6 +8,8 @@
  *   -- the victim is rewritten: same size, same mtime second, other bytes --
  *   C2 <TarDigest hex> entries=N content_changed=K scanned=F opened=F' read=B
  *   P2 <TarDigest hex> entries=0            tario.IsSimilarHeader does not see it (lib/tario/compare.go:101-103)
+ *   N0 <TarDigest hex> entries=N ctxs=3 verified=F     a third handle, three ctxs on the device: mi_memfs_commit_layer_n over the tree as
+ *                                                      it is now -- the tar of a header-only commit of that tree (N0p)
  * Test infrastructure (tests/test_gpu_commit.py). */
 #define _GNU_SOURCE
 #include <fcntl.h>
@@ -78,6 +80,32 @@ int main(int argc, char** argv) {
     int bad = commit(gpu, ctx, "C0", 0) || commit(plain, NULL, "P0", 0) || commit(gpu, ctx, "C1", 0);
     if (!bad) bad = rewrite_same_size_same_second(argv[2]);
     if (!bad) bad = commit(gpu, ctx, "C2", 1) || commit(plain, NULL, "P2", 0);
+    /* the same call over several ctxs (one per GPU on a real node; three on the one device here) */
+    mi_ctx* more[3] = {ctx, NULL, NULL};
+    mi_memfs *many = NULL, *fresh = NULL;
+    if (!bad) bad = mi_ctx_create(&cfg, &more[1]) || mi_ctx_create(&cfg, &more[2]) || mi_memfs_create(argv[1], NULL, 0, 0, &many) ||
+                    mi_memfs_create(argv[1], NULL, 0, 0, &fresh);
+    if (!bad) {
+        mi_layer_config lc;
+        mi_layer_config_default(&lc);
+        lc.gzip_level = MI_GZIP_OFF;
+        mi_layer_result res;
+        int done = 0;
+        mi_commit_stats st;
+        char hex[65];
+        if (mi_memfs_commit_layer_n(many, more, 3, 1, NULL, 0, &lc, &res, NULL, &done) || !done || mi_memfs_commit_stats(many, &st)) {
+            fprintf(stderr, "N0: mi_memfs_commit_layer_n: %s\n", mi_memfs_error(many));
+            bad = 1;
+        } else {
+            hex32(res.tar_sha256, hex);
+            printf("N0 %s entries=%llu ctxs=%llu verified=%llu\n", hex, (unsigned long long)res.n_entries, (unsigned long long)st.n_ctxs,
+                   (unsigned long long)st.n_verified_files);
+            bad = commit(fresh, NULL, "N0p", 0);
+        }
+    }
+    if (many) mi_memfs_free(many);
+    if (fresh) mi_memfs_free(fresh);
+    for (int i = 1; i < 3; ++i) if (more[i] && mi_ctx_destroy(more[i])) { fprintf(stderr, "mi_ctx_destroy: %s\n", mi_last_error(more[i])); bad = 1; }
     uint8_t root[32];
     int has = 0;
     const char* rel = argv[2] + strlen(argv[1]);

@@ -554,6 +554,9 @@ def test_the_commit_from_plain_c(eng, tmp_path):
     assert c2[1] == "entries=2" and c2[2] == "content_changed=1", lines["C2"]  # d02 + the rewritten file
     c3 = lines["P2"].split()
     assert c3[1] == "entries=0", lines["P2"]                                   # the same edit without a ctx: nothing
+    n0 = lines["N0"].split()                                                    # three ctxs, one call: the header-only commit's tar
+    assert n0[0] == lines["N0p"].split()[0] and n0[2] == "ctxs=3" and n0[1] == lines["N0p"].split()[1], (lines["N0"], lines["N0p"])
+    assert int(n0[3].split("=")[1]) > 0
 
 
 def _content_state(root):
