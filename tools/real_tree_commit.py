@@ -2,7 +2,9 @@
 of thousands of small Python files, symlinks with absolute targets, hard links) as the root file system of a build -- a MemFS rooted at "/"
 with every other top-level directory blacklisted.  Three handles: with a ctx, with a ctx and MI_MEMFS_TRUST_CTIME, without a ctx; each commits
 the tree (all new), then again (nothing changed).  Checks: the three layer tars have the same TarDigest; the chunk roots of a random sample
-of files are the oracle's.  Prints the commit table.        usage: real_tree_commit.py [top = /usr] [sample = 300]"""
+of files are the oracle's.  Prints the commit table.        usage: real_tree_commit.py [top = /usr] [sample = 300]
+MI_REAL_N_CTXS=k adds a fourth handle that commits over k ctxs on the one device (mi_memfs_commit_layer_n); MI_REAL_WARM=1 reads the tree
+once before the handles (the first read of a fresh box pages its image in from remote storage: minutes that are not the engine's)."""
 import os
 import sys
 import time
@@ -30,8 +32,25 @@ def main():
             cur = os.path.join(cur, part)
     rows = []
     digests = {}
+    if os.environ.get("MI_REAL_WARM") == "1":
+        t0, nb = time.perf_counter(), 0
+        for dp, dns, fns in os.walk(top):
+            for fn in fns:
+                p = os.path.join(dp, fn)
+                if os.path.isfile(p) and not os.path.islink(p):
+                    with open(p, "rb") as fh:
+                        while True:
+                            b = fh.read(8 << 20)
+                            if not b:
+                                break
+                            nb += len(b)
+        print("# warm-up read of %s: %.2f GB in %.1f s" % (top, nb / 1e9, time.perf_counter() - t0))
+    k = int(os.environ.get("MI_REAL_N_CTXS", "0"))
+    more = [M.Engine(device=0, n_streams=4) for _ in range(max(0, k - 1))]
     with M.Engine(device=0) as eng:
         handles = [("gpu", {"engine": eng}, False), ("gpu_trust_ctime", {"engine": eng}, True), ("cpu_header_only", {}, False)]
+        if k > 1:
+            handles.append(("gpu_%d_ctxs" % k, {"engine": [eng] + more}, False))
         for name, kw, trust in handles:
             with M.MemFS("/", blacklist=blacklist) as fs:
                 if trust:
@@ -59,8 +78,15 @@ def main():
               (name, what, dt, "+stage" if name.startswith("gpu") else "", st["s_walk_stage"], st["s_diff"], st["s_write"], st["s_scan"],
                " (beside)" if st["pipelined"] else "", res["n_entries"], st["n_layer_files"], st["files_opened"], st["file_bytes_read"] / 1e9,
                st["n_content_trusted"]))
+    for name, what, dt, st, res in rows:
+        if what == "all new" and name.startswith("gpu"):
+            print("%-16s verified %d files, %.2f GB, %d chunks fetched twice; arena %.2f GB in %d pieces, moved %d times; %d ctx(s), bytes per ctx %.2f - %.2f GB" %
+                  (name, st["n_verified_files"], st["verified_bytes"] / 1e9, st["n_refetched"], st["arena_bytes"] / 1e9, st["arena_pieces"], st["arena_moves"],
+                   st["n_ctxs"], st["ctx_bytes_min"] / 1e9, st["ctx_bytes_max"] / 1e9))
+    for e in more:
+        e.close()
     same = len(set(digests.values())) == 1
-    print("TarDigest %s%s" % (digests["gpu"][:26], " -- the same from all three handles" if same else " -- DIFFERENT: %s" % digests))
+    print("TarDigest %s%s" % (digests["gpu"][:26], " -- the same from all %d handles" % len(digests) if same else " -- DIFFERENT: %s" % digests))
     assert same
 
 
