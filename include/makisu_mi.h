@@ -812,7 +812,7 @@ typedef struct {
                                     piece behind the walk: csrc/mi_arena.hip) ...                                  */
     uint64_t arena_moves;        /* ... and how often its base address changed during this commit -- each time the reader
                                     threads were drained and, until round 5, the arena copied.  0, unless the tree
-                                    outgrew the address range (four times the first estimate, 8 GiB at least)      */
+                                    outgrew the address range (four times the first estimate, 32 GiB at least)      */
     uint64_t n_ctxs;             /* GPUs the commit ran on (mi_memfs_commit_layer_n; 1 otherwise, 0 with ctx == NULL) ... */
     uint64_t ctx_bytes_max, ctx_bytes_min;   /* ... and the bytes the fullest and the emptiest of them were handed        */
 } mi_commit_stats;

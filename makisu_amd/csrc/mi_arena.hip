@@ -22,7 +22,7 @@
 // Address ranges are RETIRED, never given back: on this ROCm a mapping placed at an address that has just been unmapped ends in
 // GPU faults or in bytes that are not the ones copied (profiles/r04_overread_audit.txt, mi_alloc.hip on MI_GUARD_ALLOC=3), so an
 // arena's range stays reserved for the life of the process after arena_release (physical memory IS given back).  A range is
-// 8 GiB at least and four times the first promise; an arena that outgrows it has its pieces mapped again in a larger range (no
+// 32 GiB at least and four times the first promise; an arena that outgrows it has its pieces mapped again in a larger range (no
 // copy: the same physical pieces), after the caller drained whatever targets it.
 //
 // What the reference does here: nothing -- tario.WriteEntry (lib/tario/write.go:28-52) streams a file through a 32 KiB buffer.
@@ -41,7 +41,7 @@
 namespace mi {
 
 namespace {
-constexpr u64 kMinRange = 8ull << 30;
+constexpr u64 kMinRange = 32ull << 30;                      // (addresses cost nothing; a 15 GB tree outgrew 8 GiB once: profiles/r06_real_tree_commit.txt)
 // every piece of every arena (the driver's own minimum is 4 KiB): small enough that a batch of a few files does not hold much
 // more than it needs, large enough that a 100 GB arena is a few thousand mappings
 u64 piece_bytes() {
