@@ -1880,6 +1880,16 @@ int mi_batch_file_sums(mi_batch* b, uint64_t file_index, const void** sums, uint
     if (n_chunks) *n_chunks = mi_sum::chunks_of(b->files[file_index].size);
     return MI_OK;
 }
+// the read-back windows (two pinned 8 MiB buffers, a stream, two events) ahead of the first read: mi_memfs_reserve_device
+int mi_batch_prepare_read(mi_batch* b) {
+    if (!b) return MI_ERR_INVALID;
+    if (is_group(b)) {
+        for (size_t k = 0; k < b->members.size(); ++k) { const int rc = mi_batch_prepare_read(b->members[k]); if (rc) return group_fail(b, k, rc); }
+        return MI_OK;
+    }
+    HIPCHK(b->ctx, hipSetDevice(b->ctx->device));
+    return read_windows(b);
+}
 void mi_batch_drop_windows(mi_batch* b) {
     if (b && is_group(b)) { for (mi_batch* m : b->members) read_windows_drop(m); return; }
     if (b) read_windows_drop(b);

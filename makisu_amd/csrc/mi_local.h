@@ -38,6 +38,7 @@ MI_LOCAL int  mi_batch_keeps_sums(mi_batch* b);
 MI_LOCAL void mi_batch_keep_sums(mi_batch* b, int on);
 MI_LOCAL int  mi_batch_file_sums(mi_batch* b, uint64_t file_index, const void** sums, uint64_t* n_chunks);
 MI_LOCAL void mi_batch_drop_windows(mi_batch* b);
+MI_LOCAL int  mi_batch_prepare_read(mi_batch* b);      // the read-back windows now, not at the tar writer's first read
 MI_LOCAL int  mi_batch_explain_chunk(mi_batch* b, uint64_t file_index, uint64_t chunk, char* msg, uint64_t cap);
 MI_LOCAL void mi_batch_expect_host_bytes(mi_batch* b);
 // mi_batch_reserve for a walk whose enumeration runs ahead of what it hands over (and for mi_memfs_reserve_device): the arena

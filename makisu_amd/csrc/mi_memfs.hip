@@ -2108,6 +2108,7 @@ extern "C" int mi_memfs_reserve_device(mi_memfs* m, mi_ctx* ctx, uint64_t files,
         rc = mi_batch_reset(m->batch);
     }
     if (!rc) rc = mi_batch_reserve_ahead(m->batch, files, bytes);
+    if (!rc) rc = mi_batch_prepare_read(m->batch);                                // (the tar writer's windows: 10 ms of pinned allocation)
     if (!rc) mi_batch_expect_host_bytes(m->batch);                                // (the reader threads set up behind the call)
     if (rc) m->err = std::string("reserve device memory: ") + mi_last_error(ctx);
     return rc;
