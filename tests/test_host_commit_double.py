@@ -104,3 +104,13 @@ def test_the_commit_over_several_ctxs_writes_the_one_ctx_commits_tar(hip_double,
     p = subprocess.run([sys.executable, os.path.join(STUB_DIR, "commit_scenarios.py"), str(tmp_path), "4", "many_gpus"], env=env,
                        capture_output=True, text=True, timeout=900)
     assert p.returncode == 0 and ("OK many_gpus %d" % n) in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
+
+
+@pytest.mark.parametrize("pipeline", ["1", "0"])
+def test_a_fault_at_every_place_the_injection_reaches_never_yields_a_wrong_layer(hip_double, pipeline):  # noqa: F811
+    """tools/verify_fault_soak.py on the double: the k-th read-back copy flipped (once; three times running), the k-th staged span
+    losing 4 KiB in HBM, k = 0..9 -- every commit is either the header-only commit's tar or MI_ERR_IO naming the hop"""
+    env = dict(os.environ, LD_PRELOAD=(os.environ.get("LD_PRELOAD", "") + " " + hip_double).strip(), MI_COMMIT_PIPELINE=pipeline)
+    p = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "verify_fault_soak.py"), "10"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "verify fault soak: 30 commits" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
+    assert "copy         failed, hop named                x 10" in p.stdout, p.stdout
