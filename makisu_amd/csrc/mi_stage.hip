@@ -626,8 +626,9 @@ int stager_wait_landed(Stager* st, mi_batch* b, u64 upto, u64* landed_out) {
 
 u64 stager_landed(Stager* st, mi_batch* b) {
     std::lock_guard<std::mutex> g(st->mu);
-    return landed_upto(st, b);
-}
+    if (!b->stage_err.empty()) return 0;                       // a batch whose staging failed has NOTHING a prefetch may read: its readers
+    return landed_upto(st, b);                                 // gave their runs back without landing them (found by failing the mapper
+}                                                              // under the tar writer on the double: a read of arena memory never mapped)
 
 HashLatch* stager_hash_ranges(Stager* st, mi_batch* b, u64 n, const u64* arena_off, const u64* len, u8* out32) {
     HashLatch* latch = new HashLatch();

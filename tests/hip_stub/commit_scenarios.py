@@ -276,7 +276,10 @@ def scenario_known_tree(tmp, eng):
     for d in range(40):
         os.utime(os.path.join(root, "k%02d" % d), (MTIME, MTIME))
     before = os.environ.get("MI_WALK_THREADS")
-    os.environ["MI_WALK_THREADS"] = "1"                                   # (the sequential walk: no enumeration runs ahead of what is
+    if os.environ.get("MI_TEST_PARALLEL_WALK") == "1":                    # the enumeration runs AHEAD of what is staged: the promise is ahead of
+        os.environ["MI_WALK_THREADS"] = "8"                               # the bytes, the mapper works on pieces nobody waits for yet -- and a
+    else:                                                                 # range that is outgrown then finds it in the middle of a piece
+        os.environ["MI_WALK_THREADS"] = "1"                               # (the sequential walk: no enumeration runs ahead of what is
     try:                                                                  #  staged, the arena learns the tree's size file by file)
         for name in ("fresh", "merged"):
             with M.MemFS(root) as fs:
@@ -443,6 +446,40 @@ def scenario_many_gpus(tmp, eng):
     print("OK many_gpus %d" % n)
 
 
+def scenario_mapper_fails(tmp, eng):
+    """the arena's mapper cannot get its k-th piece (MI_HIP_STUB_VM_FAIL: the device runs out under it, or the runtime refuses a map /
+    an access change): the commit FAILS -- an error in the reference's chain that says what happened, no hang (reader threads, scan
+    thread and tar writer all wait for the mapper somewhere), nothing leaked; the handle and the ctx are usable afterwards"""
+    import ctypes
+    lib = ctypes.CDLL(None)
+    vm_pieces = lib.mi_hip_stub_vm_pieces
+    vm_pieces.restype = ctypes.c_long
+    root = os.path.join(tmp, "mapper_root")
+    rng = np.random.default_rng(3)
+    for d in range(6):
+        for k in range(10):
+            write_file(os.path.join(root, "m%d/f%d.bin" % (d, k)), rng.integers(0, 256, 1_500_000, dtype=np.uint8).tobytes(), 0o644, MTIME)
+    for dp, dns, fns in os.walk(root):
+        os.utime(dp, (MTIME, MTIME))
+    p0 = vm_pieces()
+    with M.MemFS(root) as fs:
+        try:
+            commit_to_bytes(fs, tmp, "mf.tar", must_scan=True, engine=eng)
+        except M.MiError as e:
+            msg = str(e)
+            assert "failed to generate diff layer" in msg and "the arena's next" in msg, msg
+            what = os.environ["MI_HIP_STUB_VM_FAIL"].split(":")[0]
+            assert ("hipMemCreate" in msg) == (what == "create") and ("hipMemMap / hipMemSetAccess" in msg) == (what != "create"), msg
+            assert ("MI_ERR_NOMEM" in msg or "MI_ERR_IO" in msg or "MI_ERR_HIP" in msg), msg
+        else:
+            raise AssertionError("a commit whose arena could not be mapped produced a layer")
+    assert vm_pieces() == p0, "pieces leaked: %d" % (vm_pieces() - p0)
+    with M.MemFS(root) as plain:                                              # the process goes on: the reference's commit of the same tree
+        res, raw = commit_to_bytes(plain, tmp, "mf_plain.tar", must_scan=True)
+        assert res["n_entries"] == 66
+    print("OK mapper_fails")
+
+
 def scenario_slash(tmp, eng):
     """the root of every real build is "/": the same commit with the handle rooted there (a node's source IS its path, nothing is
     trimmed), everything but one directory of this test's blacklisted -- with a ctx, with MI_MEMFS_TRUST_CTIME, and without"""
@@ -580,6 +617,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 3 and sys.argv[3] == "known_tree":
         with M.Engine(n_streams=int(sys.argv[2]), staging_bytes=1 << 20) as eng:
             scenario_known_tree(sys.argv[1], eng)
+        sys.exit(0)
+    if len(sys.argv) > 3 and sys.argv[3] == "mapper_fails":
+        with M.Engine(n_streams=int(sys.argv[2]), staging_bytes=1 << 20) as eng:
+            scenario_mapper_fails(sys.argv[1], eng)
         sys.exit(0)
     if len(sys.argv) > 3 and sys.argv[3] == "many_gpus":
         with M.Engine(n_streams=int(sys.argv[2]), staging_bytes=1 << 20) as eng:

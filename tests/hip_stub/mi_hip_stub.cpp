@@ -116,6 +116,22 @@ thread_local LaunchCfg t_cfg;
 thread_local int t_device = 0;
 
 const long kMapUs = env_us("MI_HIP_STUB_MAP_US");
+// MI_HIP_STUB_VM_FAIL=create:k | map:k | access:k : the k-th (0-based) hipMemCreate fails with hipErrorOutOfMemory, the k-th
+// hipMemMap / hipMemSetAccess with hipErrorInvalidValue -- a device that runs out under the mapper, a runtime that refuses a piece
+struct VmFail { int what = 0; long at = -1; };
+VmFail vm_fail() {
+    static const VmFail f = [] {
+        VmFail v;
+        const char* e = getenv("MI_HIP_STUB_VM_FAIL");
+        if (!e) return v;
+        if (!strncmp(e, "create:", 7)) { v.what = 1; v.at = atol(e + 7); }
+        if (!strncmp(e, "map:", 4)) { v.what = 2; v.at = atol(e + 4); }
+        if (!strncmp(e, "access:", 7)) { v.what = 3; v.at = atol(e + 7); }
+        return v;
+    }();
+    return f;
+}
+std::atomic<long> g_vm_calls[4];
 const long kLimitMb = env_us("MI_HIP_STUB_MALLOC_LIMIT_MB");
 std::atomic<long long> g_vm_bytes{0};                 // physical pieces alive (hipMemCreate - hipMemRelease)
 std::atomic<long> g_vm_pieces{0}, g_vm_ranges{0};
@@ -279,6 +295,7 @@ hipError_t hipMemAddressReserve(void** p, size_t n, size_t, void*, unsigned long
 }
 hipError_t hipMemAddressFree(void* p, size_t n) { munmap(p, n); --g_vm_ranges; return hipSuccess; }
 hipError_t hipMemCreate(hipMemGenericAllocationHandle_t* h, size_t n, const hipMemAllocationProp*, unsigned long long) {
+    if (vm_fail().what == 1 && g_vm_calls[1]++ == vm_fail().at) return hipErrorOutOfMemory;
     if (kLimitMb > 0 && (size_t)g_vm_bytes.load() + n > ((size_t)kLimitMb << 20)) return hipErrorOutOfMemory;
     if (kMapUs) usleep((useconds_t)(kMapUs * (long)((n + (1u << 20) - 1) >> 20)));
     const int fd = memfd_create("mi_hip_stub_piece", MFD_CLOEXEC);
@@ -303,9 +320,13 @@ hipError_t hipMemRelease(hipMemGenericAllocationHandle_t h) {
 hipError_t hipMemMap(void* p, size_t n, size_t, hipMemGenericAllocationHandle_t h, unsigned long long) {
     VmHandle* v = (VmHandle*)h;
     if (v->bytes != n) return hipErrorInvalidValue;
+    if (vm_fail().what == 2 && g_vm_calls[2]++ == vm_fail().at) return hipErrorInvalidValue;
     return mmap(p, n, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_FIXED, v->fd, 0) == p ? hipSuccess : hipErrorInvalidValue;
 }
-hipError_t hipMemSetAccess(void*, size_t, const hipMemAccessDesc*, size_t) { return hipSuccess; }
+hipError_t hipMemSetAccess(void*, size_t, const hipMemAccessDesc*, size_t) {
+    if (vm_fail().what == 3 && g_vm_calls[3]++ == vm_fail().at) return hipErrorInvalidValue;
+    return hipSuccess;
+}
 hipError_t hipMemUnmap(void* p, size_t n) {
     return mmap(p, n, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE | MAP_FIXED, -1, 0) == p ? hipSuccess : hipErrorInvalidValue;
 }

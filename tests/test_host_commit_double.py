@@ -64,16 +64,16 @@ def test_copy_sources_larger_than_the_device_go_window_by_window(hip_double, tmp
     assert p.returncode == 0 and "OK oversize_copy" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
 
 
-@pytest.mark.parametrize("variant", ["plain", "range_outgrown", "slow_mapper"])
+@pytest.mark.parametrize("variant", ["plain", "range_outgrown", "slow_mapper", "outgrown_under_a_slow_mapper"])
 def test_the_arena_never_moves_while_a_walk_fills_it(hip_double, tmp_path, variant):  # noqa: F811
     """mi_arena.hip: one address range, mapped piece by piece behind the walk -- also when the range is outgrown (the pieces are
     mapped again elsewhere, with their bytes) and when the mapper is slower than the readers (a box that charges device memory by
     the byte): the layer tar holds every file's bytes"""
     env = dict(os.environ, LD_PRELOAD=(os.environ.get("LD_PRELOAD", "") + " " + hip_double).strip())
-    if variant == "range_outgrown":
+    if variant in ("range_outgrown", "outgrown_under_a_slow_mapper"):
         env["MI_ARENA_RANGE_MB"] = "16"
-    if variant == "slow_mapper":
-        env["MI_HIP_STUB_MAP_US"] = "2000"
+    if variant in ("slow_mapper", "outgrown_under_a_slow_mapper"):       # (the second: a range that is outgrown WHILE the mapper is in the
+        env["MI_HIP_STUB_MAP_US"] = "2000"                                #  middle of a piece -- the pieces move only between two of them)
     p = subprocess.run([sys.executable, os.path.join(STUB_DIR, "commit_scenarios.py"), str(tmp_path), "4", "known_tree"], env=env,
                        capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "OK known_tree" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
@@ -114,3 +114,15 @@ def test_a_fault_at_every_place_the_injection_reaches_never_yields_a_wrong_layer
     p = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "verify_fault_soak.py"), "10"], env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0 and "verify fault soak: 30 commits" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
     assert "copy         failed, hop named                x 10" in p.stdout, p.stdout
+
+
+@pytest.mark.parametrize("fail", ["create:0", "create:2", "map:1", "access:2"])
+@pytest.mark.parametrize("pipeline", ["1", "0"])
+def test_an_arena_that_cannot_be_mapped_fails_the_commit_and_nothing_hangs(hip_double, tmp_path, fail, pipeline):  # noqa: F811
+    """csrc/mi_arena.hip: the mapper thread's k-th piece is refused -- everybody who waits for the mapper (reader threads, the scan's
+    stage_batch, the tar writer's wait for landed bytes) gets the failure instead of waiting for ever; the pieces it did map go back"""
+    env = dict(os.environ, LD_PRELOAD=(os.environ.get("LD_PRELOAD", "") + " " + hip_double).strip(), MI_HIP_STUB_VM_FAIL=fail,
+               MI_COMMIT_PIPELINE=pipeline)
+    p = subprocess.run([sys.executable, os.path.join(STUB_DIR, "commit_scenarios.py"), str(tmp_path), "4", "mapper_fails"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "OK mapper_fails" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
