@@ -318,6 +318,14 @@ def scenario_long_strings(tmp, threads, slab):
         for i in range(len(long_sizes)):
             assert got[i] == hashlib.sha256(blobs[i]).digest(), "blob %d" % i
         assert len(got) == len(blobs)
+        # what route_long_strings must NOT send to the host: many strings of one chunk-sized class (C2's shape) -- every lane is
+        # busy, the pass is at its throughput roof; the double's lanes do not hash, so "stayed on the GPU" shows as "not hashlib's"
+        same = [rng.integers(0, 256, 65536, dtype=np.uint8).tobytes() for _ in range(600)]
+        got = eng.sha256_many(same)
+        assert sum(1 for d, s_ in zip(got, same) if d == hashlib.sha256(s_).digest()) == 0, "chunk-sized strings left the GPU"
+        # ... and a long string beside them leaves it (with them or without: whichever side finishes first by the model)
+        got = eng.sha256_many(same + [blobs[0]])
+        assert got[-1] == hashlib.sha256(blobs[0]).digest()
 
 
 def main():
