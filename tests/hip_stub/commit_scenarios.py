@@ -247,7 +247,7 @@ def scenario_trust_wide(tmp, eng):
 
 def scenario_known_tree(tmp, eng):
     """THE ARENA NEVER MOVES (mi_arena.hip).  A handle that knows nothing about its tree, a sequential walk (no enumeration runs
-    ahead: the arena learns the tree's size 1 024 files at a time) and 262 MB of files: until round 5 that was three arenas in
+    ahead: the arena learns the tree's size 1 024 files at a time) and 94 MB of files: until round 5 that was three arenas in
     steps -- each one a drain of the reader threads and a copy of what the last one held; now it is ONE address range whose front
     is mapped piece by piece, and nothing of a MiB or more is hipMalloc'ed for it.  The same with the range reserved too small
     (MI_ARENA_RANGE_MB: the pieces are mapped again in a larger range -- they still hold their bytes) and with a mapper that takes
@@ -265,16 +265,18 @@ def scenario_known_tree(tmp, eng):
     root = os.path.join(tmp, "known_root")
     rng = np.random.default_rng(5)
     entries, files = [], {}
-    for d in range(40):
+    n_dirs, per_dir = 24, 60                                              # 94 MB: twelve pieces of 8 MiB (the tests' MI_ARENA_PIECE_MB), three of 32
+    for d in range(n_dirs):
         entries.append({"relpath": "k%02d" % d, "kind": M.KIND_DIR, "mode": 0o40755, "mtime_sec": MTIME, "size": 0})
-        for k in range(100):
+        for k in range(per_dir):
             rel = "k%02d/f%02d" % (d, k)
             data = rng.integers(0, 256, 65_536, dtype=np.uint8).tobytes()
             write_file(os.path.join(root, rel), data, 0o644, MTIME)
             files[rel] = data
             entries.append({"relpath": rel, "kind": M.KIND_FILE, "mode": 0o100644, "mtime_sec": MTIME, "size": len(data)})
-    for d in range(40):
+    for d in range(n_dirs):
         os.utime(os.path.join(root, "k%02d" % d), (MTIME, MTIME))
+    total = sum(map(len, files.values()))
     before = os.environ.get("MI_WALK_THREADS")
     if os.environ.get("MI_TEST_PARALLEL_WALK") == "1":                    # the enumeration runs AHEAD of what is staged: the promise is ahead of
         os.environ["MI_WALK_THREADS"] = "8"                               # the bytes, the mapper works on pieces nobody waits for yet -- and a
@@ -291,13 +293,13 @@ def scenario_known_tree(tmp, eng):
                 assert st["n_scanned_files"] == len(files) and st["files_opened"] == len(files)
                 ranges, pieces = vm_ranges() - r0, vm_pieces() - p0
                 if os.environ.get("MI_ARENA_RANGE_MB"):
-                    assert on_gpu or ranges >= 2, "a range of %s MiB holds 262 MB?" % os.environ["MI_ARENA_RANGE_MB"]     # (outgrown: a larger one)
+                    assert on_gpu or ranges >= 2, "a range of %s MiB holds 94 MB?" % os.environ["MI_ARENA_RANGE_MB"]      # (outgrown: a larger one)
                     assert st["arena_moves"] >= 1, st
                 else:
                     assert on_gpu or ranges == 1, "the arena moved: %d address ranges" % ranges
                     assert st["arena_moves"] == 0, st
                 assert on_gpu or pieces == st["arena_pieces"], (pieces, st)
-                assert st["arena_pieces"] >= 2 and st["arena_bytes"] >= 262_144_000, st                                    # mapped in pieces
+                assert st["arena_pieces"] >= 2 and st["arena_bytes"] >= total, st                                          # mapped in pieces
                 if name == "fresh":
                     assert {n: d for n, m, d in tar_members(raw) if m.isfile()} == files
                 else:

@@ -69,7 +69,7 @@ def test_the_arena_never_moves_while_a_walk_fills_it(hip_double, tmp_path, varia
     """mi_arena.hip: one address range, mapped piece by piece behind the walk -- also when the range is outgrown (the pieces are
     mapped again elsewhere, with their bytes) and when the mapper is slower than the readers (a box that charges device memory by
     the byte): the layer tar holds every file's bytes"""
-    env = dict(os.environ, LD_PRELOAD=(os.environ.get("LD_PRELOAD", "") + " " + hip_double).strip())
+    env = dict(os.environ, LD_PRELOAD=(os.environ.get("LD_PRELOAD", "") + " " + hip_double).strip(), MI_ARENA_PIECE_MB="8")
     if variant in ("range_outgrown", "outgrown_under_a_slow_mapper"):
         env["MI_ARENA_RANGE_MB"] = "16"
     if variant in ("slow_mapper", "outgrown_under_a_slow_mapper"):       # (the second: a range that is outgrown WHILE the mapper is in the
@@ -109,11 +109,11 @@ def test_the_commit_over_several_ctxs_writes_the_one_ctx_commits_tar(hip_double,
 @pytest.mark.parametrize("pipeline", ["1", "0"])
 def test_a_fault_at_every_place_the_injection_reaches_never_yields_a_wrong_layer(hip_double, pipeline):  # noqa: F811
     """tools/verify_fault_soak.py on the double: the k-th read-back copy flipped (once; three times running), the k-th staged span
-    losing 4 KiB in HBM, k = 0..9 -- every commit is either the header-only commit's tar or MI_ERR_IO naming the hop"""
+    losing 4 KiB in HBM, k = 0..5 -- every commit is either the header-only commit's tar or MI_ERR_IO naming the hop"""
     env = dict(os.environ, LD_PRELOAD=(os.environ.get("LD_PRELOAD", "") + " " + hip_double).strip(), MI_COMMIT_PIPELINE=pipeline)
-    p = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "verify_fault_soak.py"), "10"], env=env, capture_output=True, text=True, timeout=900)
-    assert p.returncode == 0 and "verify fault soak: 30 commits" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
-    assert "copy         failed, hop named                x 10" in p.stdout, p.stdout
+    p = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "verify_fault_soak.py"), "6"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "verify fault soak: 18 commits" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
+    assert "copy         failed, hop named                x 6" in p.stdout, p.stdout
 
 
 @pytest.mark.parametrize("fail", ["create:0", "create:2", "map:1", "access:2"])
