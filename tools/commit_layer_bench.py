@@ -105,8 +105,9 @@ def commit_e2e(eng, n_files, file_bytes, base=None, gzip_level=None):
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
     size = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+    gz = os.environ.get("MI_BENCH_GZIP")                          # e.g. -1: the reference's default compression (tario.CompressionLevel)
     with M.Engine(device=0) as eng:
-        res = commit_e2e(eng, n, size)
+        res = commit_e2e(eng, n, size, gzip_level=int(gz) if gz not in (None, "") else None)
     print(res["tree"])
     for row in res["commits"]:
         print("  " + row["what"])
