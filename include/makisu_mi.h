@@ -815,6 +815,7 @@ typedef struct {
                                     outgrew the address range (four times the first estimate, 32 GiB at least)      */
     uint64_t n_ctxs;             /* GPUs the commit ran on (mi_memfs_commit_layer_n; 1 otherwise, 0 with ctx == NULL) ... */
     uint64_t ctx_bytes_max, ctx_bytes_min;   /* ... and the bytes the fullest and the emptiest of them were handed        */
+    uint64_t n_split_files;      /* files of 256 MiB and more (MI_COMMIT_SPLIT_MIB) that were split over the GPUs as parts     */
 } mi_commit_stats;
 MI_CORE int  mi_memfs_commit_layer(mi_memfs* fs, mi_ctx* ctx, int must_scan, const mi_copy_op* ops, uint64_t n_ops,
                            const mi_layer_config* cfg, mi_layer_result* res, mi_copy_layer** layer_out, int* committed);
@@ -823,7 +824,9 @@ MI_CORE int  mi_memfs_commit_layer(mi_memfs* fs, mi_ctx* ctx, int must_scan, con
  * its share; roots come back in the walk's order, the tar writer reads each file from the GPU that holds it, the chunk index (on
  * any one of the ctxs) takes the other GPUs' digests through the host.  Layer, roots and DigestPair are those of the one-GPU
  * commit, byte for byte.  n_ctx = 1: mi_memfs_commit_layer; n_ctx = 0: the reference's commit.  A handle keeps its batches
- * between commits as long as it is called with the same ctxs.  Files are not split across GPUs.  UNMEASURED on more than one
+ * between commits as long as it is called with the same ctxs.  A file of 256 MiB and more (MI_COMMIT_SPLIT_MIB) is split over the
+ * GPUs as parts (the parts protocol below: a halo of 256 KiB per boundary is read twice, the file is opened once per part); its root
+ * is mi_chunk_root over the parts' digests, its bytes are checked chunk by chunk like everybody's.  UNMEASURED on more than one
  * physical GPU (tested with n ctxs on one device, and on the HIP double): mi_commit_stats.n_ctxs / ctx_bytes_max / _min.        */
 MI_CORE int  mi_memfs_commit_layer_n(mi_memfs* fs, mi_ctx* const* ctxs, uint32_t n_ctx, int must_scan, const mi_copy_op* ops,
                              uint64_t n_ops, const mi_layer_config* cfg, mi_layer_result* res, mi_copy_layer** layer_out,

@@ -118,7 +118,7 @@ class CommitStats(C.Structure):
                                           "n_index_new", "n_index_known", "index_new_bytes", "files_opened", "file_bytes_read", "pipelined", "n_windows")] + \
                [(n, C.c_double) for n in ("s_walk_stage", "s_scan", "s_diff", "s_write", "s_total")] + \
                [(n, C.c_uint64) for n in ("n_verified_files", "verified_bytes", "n_refetched", "arena_bytes", "arena_pieces", "arena_moves",
-                                          "n_ctxs", "ctx_bytes_max", "ctx_bytes_min")]
+                                          "n_ctxs", "ctx_bytes_max", "ctx_bytes_min", "n_split_files")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

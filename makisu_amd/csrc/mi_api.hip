@@ -169,6 +169,7 @@ int ensure_stager(mi_ctx* c) {
 // directories; the first block or path that reaches them waits for whoever is not ready yet
 // ---- a group of batches behind one handle (mi_internal.h: members) -----------------------------------------------------------
 static inline bool is_group(const mi_batch* b) { return !b->members.empty(); }
+constexpr u32 kGroupSplit = 0xFFFFFFFFu;             // row_member of a file that is split over the members as parts
 constexpr u64 kGroupAtShift = 48, kGroupAtMask = (1ull << kGroupAtShift) - 1;       // a group's "arena offset": member << 48 | offset
 static int group_fail(mi_batch* h, size_t k, int rc) {
     std::string m;
@@ -246,14 +247,15 @@ int staging_append(mi_batch* b, u64 at, const u8* src, u64 len) {
     return MI_OK;
 }
 
-int batch_add_common(mi_batch* b, u64 len, u64 tag, u64* at) {
+int batch_add_common(mi_batch* b, u64 len, u64 tag, u64* at, u64 origin = 0) {
     if (!b) return MI_ERR_INVALID;
     if (b->staged) return fail(b->ctx, MI_ERR_STATE, "batch already ran; begin a new batch");
     *at = align_up(b->arena_used, kFileAlign);
     int rc = arena_reserve(b, *at + align_up(len, kFileAlign));
     if (rc) return rc;
     b->files.push_back({*at, len, tag});
-    if (b->keep_sums) b->files.back().sums = b->sum_pool.take(mi_sum::chunks_of(len));
+    b->files.back().origin = origin;
+    if (b->keep_sums) b->files.back().sums = b->sum_pool.take(mi_sum::chunks_of(origin % mi_sum::kChunk + len));   // (the FILE's 1 MiB grid)
     b->arena_used = *at + len;
     b->total_bytes += len;
     return MI_OK;
@@ -951,7 +953,8 @@ int mi_batch_add_bytes(mi_batch* b, const void* data, uint64_t len, uint64_t use
 // mi_batch_add_path / _range: the file is opened and checked NOW (a missing or short file is the
 // caller's error to see at this call, like the reference's open + CopyN at lib/tario/write.go:37-45);
 // its bytes are read by the reader threads, so a file that shrinks later fails the batch at run time.
-static int add_file_range(mi_batch* b, const char* path, uint64_t offset, uint64_t size, uint64_t user_tag) {
+// origin: the row is a PART of a file whose staged bytes begin at file offset `origin` (= offset); its sums lie on the file's grid
+static int add_file_range(mi_batch* b, const char* path, uint64_t offset, uint64_t size, uint64_t user_tag, uint64_t origin = 0) {
     if (!b || !path) return MI_ERR_INVALID;
     mi_ctx* c = b->ctx;
     HIPCHK(c, hipSetDevice(c->device));
@@ -979,11 +982,11 @@ static int add_file_range(mi_batch* b, const char* path, uint64_t offset, uint64
         return fail(c, MI_ERR_IO, "read %s: file shorter than the size given", path);
     }
     u64 at;
-    int rc = batch_add_common(b, size, user_tag, &at);
+    int rc = batch_add_common(b, size, user_tag, &at, origin);
     if (rc == MI_OK) rc = ensure_stager(c);
     if (rc) { close(fd); return rc; }
     const auto t0 = std::chrono::steady_clock::now();
-    rc = stager_put_file(c->stager, b, at, fd, offset, size, path, b->files.back().sums);   // owns fd from here on
+    rc = stager_put_file(c->stager, b, at, fd, offset, size, path, b->files.back().sums, origin % mi_sum::kChunk);   // owns fd from here on
     b->staged_any = true;
     b->ms_h2d += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return rc;
@@ -1006,7 +1009,43 @@ int mi_batch_add_paths(mi_batch* b, uint64_t n, const char* const* paths, const 
         const size_t nm = b->members.size();
         std::vector<std::vector<const char*>> mp(nm);
         std::vector<std::vector<u64>> ms(nm), mt(nm);
+        static const u64 split_min = [] {
+            const char* e = getenv("MI_COMMIT_SPLIT_MIB");
+            const long v = e && *e ? atol(e) : 256;
+            return v <= 0 ? ~0ull : (u64)v << 20;
+        }();
         for (u64 i = 0; i < n; ++i) {
+            if (sizes[i] >= split_min && sizes[i] >= 2 * mi_sum::kChunk) {
+                // A file of 256 MiB and more is SPLIT: one part per member, at most -- each part to the member with
+                // the fewest bytes so far, staged over that GPU's own link behind its halo (mi_batch_add_path_part).  Parts begin
+                // on MiB boundaries of the file, so every 1 MiB chunk the tar writer checks lies in ONE part's own range.  The
+                // parts' owners agree on the boundary cuts when the group runs (group_resolve_parts).
+                u64 np = std::min<u64>(nm, sizes[i] / (split_min / 2 ? split_min / 2 : 1));
+                if (np < 2) np = 2;
+                const u64 step = (sizes[i] / np + mi_sum::kChunk - 1) / mi_sum::kChunk * mi_sum::kChunk;
+                mi_batch::Split sp;
+                sp.size = sizes[i];
+                for (u64 begin = 0; begin < sizes[i]; begin += step) {
+                    const u64 end = std::min(begin + step, (u64)sizes[i]);
+                    const size_t k = group_least_loaded(b);
+                    // (the member's earlier pending files first: a part is added at once, its row must follow theirs)
+                    if (!mp[k].empty()) {
+                        const int rc0 = mi_batch_add_paths(b->members[k], mp[k].size(), mp[k].data(), ms[k].data(), mt[k].data());
+                        if (rc0) return group_fail(b, k, rc0);
+                        mp[k].clear(); ms[k].clear(); mt[k].clear();
+                    }
+                    const u64 row = b->members[k]->files.size();
+                    const int rc = mi_batch_add_path_part(b->members[k], paths[i], sizes[i], begin, end, user_tags ? user_tags[i] : 0);
+                    if (rc) return group_fail(b, k, rc);
+                    b->member_bytes[k] += end - begin;
+                    sp.parts.push_back({(u32)k, row, begin, end});
+                }
+                b->row_member.push_back(kGroupSplit);
+                b->row_row.push_back(b->splits.size());
+                b->splits.push_back(std::move(sp));
+                b->total_bytes += sizes[i];
+                continue;
+            }
             const size_t k = group_least_loaded(b);
             b->member_bytes[k] += sizes[i] + 4096;                 // (a file costs something even when it is empty: rows, a descriptor)
             b->row_member.push_back((u32)k);
@@ -1234,7 +1273,7 @@ int mi_batch_add_path_part(mi_batch* b, const char* path, uint64_t file_size, ui
     PartRec pr;
     int rc = part_geometry(b, file_size, begin, end, &pr);
     if (rc) return rc;
-    rc = add_file_range(b, path, begin - pr.halo_bytes, pr.halo_bytes + (end - begin), user_tag);
+    rc = add_file_range(b, path, begin - pr.halo_bytes, pr.halo_bytes + (end - begin), user_tag, begin - pr.halo_bytes);
     if (rc) return rc;
     b->files.back().part = (int)b->parts.size();
     b->parts.push_back(pr);
@@ -1483,10 +1522,62 @@ int mi_batch_wait(mi_batch* b) {
     return wait_pipeline(b);
 }
 
+// The parts of the group's split files agree on their boundary cuts (the parts protocol of include/makisu_mi.h, all owners in
+// this process): every member that holds parts makes its cuts under an assumed entry; then, round by round, every part but a
+// file's first is told its predecessor's last cut and the members re-select where that differed -- until no exit moved (one
+// round on ordinary data, at most parts-per-file).
+static int group_resolve_parts(mi_batch* h) {
+    const size_t nm = h->members.size();
+    std::vector<char> holds(nm, 0);
+    for (const mi_batch::Split& sp : h->splits) for (const mi_batch::SplitPart& pt : sp.parts) holds[pt.member] = 1;
+    {
+        std::vector<int> rcs(nm, MI_OK);
+        std::vector<std::thread> th;
+        for (size_t k = 0; k < nm; ++k) if (holds[k]) th.emplace_back([&, k] { rcs[k] = mi_batch_scan_cuts(h->members[k]); });
+        for (auto& t : th) t.join();
+        for (size_t k = 0; k < nm; ++k) if (rcs[k]) return group_fail(h, k, rcs[k]);
+    }
+    for (int round = 0; round < 70; ++round) {
+        std::vector<std::vector<mi_part_state>> st(nm);
+        for (size_t k = 0; k < nm; ++k) {
+            if (!holds[k]) continue;
+            uint64_t np = 0;
+            mi_batch_parts(h->members[k], nullptr, 0, &np);
+            st[k].resize(np ? np : 1);
+            const int rc = mi_batch_parts(h->members[k], st[k].data(), np, &np);
+            if (rc) return group_fail(h, k, rc);
+            st[k].resize(np);
+        }
+        auto state_of = [&](const mi_batch::SplitPart& pt) -> const mi_part_state* {
+            for (const mi_part_state& x : st[pt.member]) if (x.file_index == pt.row) return &x;
+            return nullptr;
+        };
+        bool redo = false;
+        for (const mi_batch::Split& sp : h->splits)
+            for (size_t i = 1; i < sp.parts.size(); ++i) {
+                const mi_part_state *prev = state_of(sp.parts[i - 1]), *cur = state_of(sp.parts[i]);
+                if (!prev || !cur) return mi::fail(h->ctx, MI_ERR_STATE, "a split file's part is not among its member's parts");
+                if (prev->exit != cur->entry) redo = true;
+                if (prev->exit != cur->entry || !cur->entry_confirmed) {
+                    const int rc = mi_batch_set_part_entry(h->members[sp.parts[i].member], sp.parts[i].row, prev->exit);
+                    if (rc) return group_fail(h, sp.parts[i].member, rc);
+                }
+            }
+        for (size_t k = 0; k < nm; ++k)
+            if (holds[k]) { const int rc = mi_batch_fix_cuts(h->members[k]); if (rc) return group_fail(h, k, rc); }
+        if (!redo) return MI_OK;
+    }
+    return mi::fail(h->ctx, MI_ERR_STATE, "the parts of a split file did not agree on their boundary cuts in 70 rounds");
+}
+
 int mi_batch_run(mi_batch* b) {
     if (!b) return MI_ERR_INVALID;
     if (is_group(b)) {                               // every member on a thread of its own: one GPU each
         const size_t nm = b->members.size();
+        if (!b->splits.empty()) {
+            const int rc = group_resolve_parts(b);
+            if (rc) return rc;
+        }
         std::vector<int> rcs(nm, MI_OK);
         std::vector<std::thread> th;
         for (size_t k = 1; k < nm; ++k) th.emplace_back([&, k] { rcs[k] = mi_batch_run(b->members[k]); });
@@ -1529,6 +1620,7 @@ int mi_batch_reset(mi_batch* b) {
         if (b->tree) { mi_batch_tree_free(b->tree); b->tree = nullptr; }
         b->row_member.clear();
         b->row_row.clear();
+        b->splits.clear();
         b->member_bytes.assign(b->members.size(), 0);
         b->total_bytes = 0;
         b->n_chunks = 0;
@@ -1686,7 +1778,23 @@ int mi_batch_roots(mi_batch* b, uint8_t* out, uint64_t cap) {
             const int rc = mi_batch_roots(b->members[k], mr[k].data(), n);
             if (rc) return group_fail(b, k, rc);
         }
-        for (u64 g = 0; g < nf; ++g) memcpy(out + 32 * g, mr[b->row_member[g]].data() + 32 * b->row_row[g], 32);
+        for (u64 g = 0; g < nf; ++g) {
+            if (b->row_member[g] != kGroupSplit) { memcpy(out + 32 * g, mr[b->row_member[g]].data() + 32 * b->row_row[g], 32); continue; }
+            // a split file's root: mi_chunk_root over its parts' chunk digests put end to end (include/makisu_mi.h, "parts")
+            std::vector<u8> dg;
+            for (const mi_batch::SplitPart& pt : b->splits[b->row_row[g]].parts) {
+                const mi_file_result* fr = nullptr;
+                const mi_chunk_result* cr = nullptr;
+                uint64_t n1 = 0, n2 = 0;
+                int rc = mi_batch_files_view(b->members[pt.member], &fr, &n1);
+                if (!rc) rc = mi_batch_chunks_view(b->members[pt.member], &cr, &n2);
+                if (rc) return group_fail(b, pt.member, rc);
+                const mi_file_result& f = fr[pt.row];
+                for (u64 j = 0; j < f.n_chunks; ++j) { const u8* d = cr[f.first_chunk + j].sha256; dg.insert(dg.end(), d, d + 32); }
+            }
+            const int rc = mi_chunk_root(dg.data(), dg.size() / 32, out + 32 * g);
+            if (rc) return fail(b->ctx, rc, "the root of a split file");
+        }
         return MI_OK;
     }
     mi_ctx* c = b->ctx;
@@ -1741,10 +1849,27 @@ static void read_windows_drop(mi_batch* b) {
 }
 // while_staging: the caller is the pipelined commit (mi_memfs.hip) -- the batch is still being staged and scanned by another
 // thread; the file's bytes are waited for (stager_wait_landed), nothing else of the batch's state is touched
-static int read_file_impl(mi_batch* b, uint64_t file_index, uint64_t offset, void* dst, uint64_t len, bool while_staging) {
+// own_range: the row is a PART and `offset` a FILE offset inside the part's own range [begin, end) (a split file of a batch group)
+static int read_file_impl(mi_batch* b, uint64_t file_index, uint64_t offset, void* dst, uint64_t len, bool while_staging, bool own_range = false) {
     if (!b || (!dst && len)) return MI_ERR_INVALID;
-    if (is_group(b)) {                               // from the GPU that holds the file
+    if (is_group(b)) {                               // from the GPU that holds the file -- a split file: from the GPUs that hold its parts
         if (file_index >= b->row_member.size()) return fail(b->ctx, MI_ERR_INVALID, "mi_batch_read_file: no file %llu", (unsigned long long)file_index);
+        if (b->row_member[file_index] == kGroupSplit) {
+            const mi_batch::Split& sp = b->splits[b->row_row[file_index]];
+            if (offset > sp.size || len > sp.size - offset) return fail(b->ctx, MI_ERR_INVALID, "mi_batch_read_file: outside split file %llu", (unsigned long long)file_index);
+            u8* d = (u8*)dst;
+            for (const mi_batch::SplitPart& pt : sp.parts) {
+                if (!len) break;
+                if (offset >= pt.end) continue;
+                const u64 take = std::min(len, pt.end - offset);
+                const int rc = read_file_impl(b->members[pt.member], pt.row, offset, d, take, while_staging, true);
+                if (rc) return group_fail(b, pt.member, rc);
+                d += take;
+                offset += take;
+                len -= take;
+            }
+            return MI_OK;
+        }
         const size_t k = b->row_member[file_index];
         const int rc = read_file_impl(b->members[k], b->row_row[file_index], offset, dst, len, while_staging);
         return rc ? group_fail(b, k, rc) : MI_OK;
@@ -1754,8 +1879,14 @@ static int read_file_impl(mi_batch* b, uint64_t file_index, uint64_t offset, voi
         return fail(c, MI_ERR_STATE, "mi_batch_read_file: the batch is not staged, or in flight");
     if (file_index >= b->files.size()) return fail(c, MI_ERR_INVALID, "mi_batch_read_file: no file %llu", (unsigned long long)file_index);
     const mi_batch::FileRec& f = b->files[file_index];
-    if (f.part >= 0) return fail(c, MI_ERR_INVALID, "mi_batch_read_file: file %llu is a part", (unsigned long long)file_index);
-    if (offset > f.size || len > f.size - offset)
+    if (f.part >= 0) {
+        if (!own_range) return fail(c, MI_ERR_INVALID, "mi_batch_read_file: file %llu is a part", (unsigned long long)file_index);
+        const PartRec& pr = b->parts[f.part];
+        if (offset < pr.begin || offset > pr.end || len > pr.end - offset)
+            return fail(c, MI_ERR_INVALID, "mi_batch_read_file: [%llu, +%llu) is outside the part [%llu, %llu)", (unsigned long long)offset,
+                        (unsigned long long)len, (unsigned long long)pr.begin, (unsigned long long)pr.end);
+        offset -= f.origin;                          // from here on: an offset inside the staged range
+    } else if (offset > f.size || len > f.size - offset)
         return fail(c, MI_ERR_INVALID, "mi_batch_read_file: [%llu, +%llu) is outside file %llu of %llu bytes", (unsigned long long)offset,
                     (unsigned long long)len, (unsigned long long)file_index, (unsigned long long)f.size);
     if (!len) return MI_OK;
@@ -1869,15 +2000,34 @@ void mi_batch_read_stats(mi_batch* b, double* wait_s, double* fetch_s, uint64_t*
     if (fetches) *fetches = b ? b->rb_fetches : 0;
     if (bytes) *bytes = b ? b->rb_bytes : 0;
 }
-// the layer writer's check (mi_layer.hip): a file row's chunk sums as they were taken where the bytes were read (NULL: none kept)
-int mi_batch_file_sums(mi_batch* b, uint64_t file_index, const void** sums, uint64_t* n_chunks) {
-    if (b && is_group(b)) {
+// the layer writer's check (mi_layer.hip): the sums of chunk k (1 MiB of the FILE) of a row as they were taken where the bytes were
+// read; *has = 0: the batch keeps none for this row.  A split file's chunk lies in the own range of exactly one part (parts begin
+// on MiB boundaries of the file).
+static const mi_batch::SplitPart* split_part_of(const mi_batch::Split& sp, u64 file_off) {
+    for (const mi_batch::SplitPart& pt : sp.parts) if (file_off >= pt.begin && file_off < pt.end) return &pt;
+    return nullptr;
+}
+int mi_batch_chunk_sum(mi_batch* b, uint64_t file_index, uint64_t k, uint64_t* sum_a, uint64_t* sum_b, int* has) {
+    if (!b || !has) return MI_ERR_INVALID;
+    *has = 0;
+    if (is_group(b)) {
         if (file_index >= b->row_member.size()) return MI_ERR_INVALID;
-        return mi_batch_file_sums(b->members[b->row_member[file_index]], b->row_row[file_index], sums, n_chunks);
+        if (b->row_member[file_index] == kGroupSplit) {
+            const mi_batch::Split& sp = b->splits[b->row_row[file_index]];
+            const mi_batch::SplitPart* pt = split_part_of(sp, k * mi_sum::kChunk);
+            if (!pt) return sp.size == 0 ? MI_OK : MI_ERR_INVALID;
+            return mi_batch_chunk_sum(b->members[pt->member], pt->row, k, sum_a, sum_b, has);
+        }
+        return mi_batch_chunk_sum(b->members[b->row_member[file_index]], b->row_row[file_index], k, sum_a, sum_b, has);
     }
-    if (!b || !sums || file_index >= b->files.size()) return MI_ERR_INVALID;
-    *sums = b->files[file_index].sums;
-    if (n_chunks) *n_chunks = mi_sum::chunks_of(b->files[file_index].size);
+    if (file_index >= b->files.size()) return MI_ERR_INVALID;
+    const mi_batch::FileRec& f = b->files[file_index];
+    if (!f.sums) return MI_OK;
+    const u64 k0 = f.origin / mi_sum::kChunk;
+    if (k < k0 || k - k0 >= mi_sum::chunks_of(f.origin % mi_sum::kChunk + f.size)) return MI_ERR_INVALID;
+    *has = 1;
+    if (sum_a) *sum_a = f.sums[k - k0].a.load(std::memory_order_relaxed);
+    if (sum_b) *sum_b = f.sums[k - k0].b.load(std::memory_order_relaxed);
     return MI_OK;
 }
 // the read-back windows (two pinned 8 MiB buffers, a stream, two events) ahead of the first read: mi_memfs_reserve_device
@@ -1900,23 +2050,33 @@ void mi_batch_drop_windows(mi_batch* b) {
 int mi_batch_explain_chunk(mi_batch* b, uint64_t file_index, uint64_t chunk, char* msg, uint64_t cap) {
     if (b && is_group(b)) {
         if (file_index >= b->row_member.size() || !msg || cap < 16) return MI_ERR_INVALID;
-        const int n = snprintf(msg, (size_t)cap, "gpu %u: ", b->row_member[file_index]);
-        return mi_batch_explain_chunk(b->members[b->row_member[file_index]], b->row_row[file_index], chunk, msg + n, cap - (uint64_t)n);
+        u32 member = b->row_member[file_index];
+        u64 row = b->row_row[file_index];
+        if (member == kGroupSplit) {
+            const mi_batch::SplitPart* pt = split_part_of(b->splits[row], chunk * mi_sum::kChunk);
+            if (!pt) return MI_ERR_INVALID;
+            member = pt->member;
+            row = pt->row;
+        }
+        const int n = snprintf(msg, (size_t)cap, "gpu %u: ", member);
+        return mi_batch_explain_chunk(b->members[member], row, chunk, msg + n, cap - (uint64_t)n);
     }
     if (!b || !msg || !cap || file_index >= b->files.size()) return MI_ERR_INVALID;
     mi_ctx* c = b->ctx;
     const mi_batch::FileRec& f = b->files[file_index];
-    const u64 off = chunk * mi_sum::kChunk;
-    if (!f.sums || off >= f.size) return MI_ERR_INVALID;
-    const u64 len = std::min(mi_sum::kChunk, f.size - off);
+    const u64 off = chunk * mi_sum::kChunk;                             // in the FILE; the row's bytes begin at f.origin
+    const u64 k0 = f.origin / mi_sum::kChunk;
+    if (!f.sums || off < f.origin - f.origin % mi_sum::kChunk || off >= f.origin + f.size) return MI_ERR_INVALID;
+    const u64 from = off > f.origin ? off : f.origin;                   // (a part's first chunk may begin before its staged bytes)
+    const u64 len = std::min(off + mi_sum::kChunk, f.origin + f.size) - from;
     std::vector<u8> again(len);
     (void)hipSetDevice(c->device);
-    const hipError_t e = hipMemcpy(again.data(), b->arena.as<u8>() + f.off + off, len, hipMemcpyDeviceToHost);
+    const hipError_t e = hipMemcpy(again.data(), b->arena.as<u8>() + f.off + (from - f.origin), len, hipMemcpyDeviceToHost);
     u64 a = 0, bb = 0;
-    if (e == hipSuccess) mi_sum::chunk_add(again.data(), (size_t)len, 0, &a, &bb);
-    const u64 wa = f.sums[chunk].a.load(), wb = f.sums[chunk].b.load();
+    if (e == hipSuccess) mi_sum::chunk_add(again.data(), (size_t)len, (size_t)(from - off), &a, &bb);
+    const u64 wa = f.sums[chunk - k0].a.load(), wb = f.sums[chunk - k0].b.load();
     snprintf(msg, (size_t)cap, "arena [%llu, +%llu) (file %llu, bytes [%llu, +%llu)): sums where the bytes were read %016llx/%016llx; %s",
-             (unsigned long long)(f.off + off), (unsigned long long)len, (unsigned long long)file_index, (unsigned long long)off, (unsigned long long)len,
+             (unsigned long long)(f.off + (from - f.origin)), (unsigned long long)len, (unsigned long long)file_index, (unsigned long long)from, (unsigned long long)len,
              (unsigned long long)wa, (unsigned long long)wb,
              e != hipSuccess ? "a third copy failed" :
              a == wa && bb == wb ? "a plain copy out of HBM has them: the arena holds the file's bytes, the hop HBM -> pinned read-back window delivered others, twice"
@@ -1925,7 +2085,8 @@ int mi_batch_explain_chunk(mi_batch* b, uint64_t file_index, uint64_t chunk, cha
 }
 int mi_batch_file_size(mi_batch* b, uint64_t file_index, uint64_t* size) {       // (internal: mi_layer.hip)
     if (b && is_group(b)) {
-        if (file_index >= b->row_member.size()) return MI_ERR_INVALID;
+        if (file_index >= b->row_member.size() || !size) return MI_ERR_INVALID;
+        if (b->row_member[file_index] == kGroupSplit) { *size = b->splits[b->row_row[file_index]].size; return MI_OK; }
         return mi_batch_file_size(b->members[b->row_member[file_index]], b->row_row[file_index], size);
     }
     if (!b || !size || file_index >= b->files.size() || b->files[file_index].part >= 0) return MI_ERR_INVALID;
@@ -2004,6 +2165,7 @@ int mi_batch_group_begin(mi_ctx* const* ctxs, uint32_t n, mi_batch** out) {
     *out = h;
     return MI_OK;
 }
+uint64_t mi_batch_group_splits(mi_batch* b) { return b ? b->splits.size() : 0; }
 int mi_batch_group_members(mi_batch* b, mi_batch* const** members, const uint64_t** bytes, uint64_t* n) {
     if (!b || !n) return MI_ERR_INVALID;
     *n = b->members.size();

@@ -97,7 +97,8 @@ Stager* stager_create(mi_ctx* c, u32 n_threads, u64 slab_bytes);   // returns at
 bool    stager_ready(Stager* st);                                   // waits for them; false: none got slab + stream
 void    stager_destroy(Stager* st);
 int     stager_put_bytes(Stager* st, mi_batch* b, u64 arena_off, const void* src, u64 len, mi_sum::FileSum* sums);
-int     stager_put_file(Stager* st, mi_batch* b, u64 arena_off, int fd, u64 file_off, u64 len, const char* path, mi_sum::FileSum* sums);
+int     stager_put_file(Stager* st, mi_batch* b, u64 arena_off, int fd, u64 file_off, u64 len, const char* path, mi_sum::FileSum* sums,
+                        u64 row_off0 = 0);      // row_off0: where on the sums' grid the first byte lies (a part: origin mod 1 MiB)
 int     stager_put_paths(Stager* st, mi_batch* b, u64 n, const char* const* paths, const u64* arena_off,
                          const u64* len, mi_sum::FileSum* const* sums);   // sums: NULL, or one pointer per file (the row's chunk sums)
 int     stager_put_block(Stager* st, mi_batch* b, u64 arena_off, const void* src, u64 len, std::shared_ptr<void> keep);
@@ -162,8 +163,10 @@ struct mi_ctx {
 
 struct mi_batch {
     mi_ctx* ctx;
-    struct FileRec { mi::u64 off, size, tag; int part = -1; mi_sum::FileSum* sums = nullptr; };   // part: index into `parts`; sums: per 1 MiB
-                                                                   // chunk, taken where the bytes were read (keep_sums)
+    struct FileRec { mi::u64 off, size, tag; int part = -1; mi_sum::FileSum* sums = nullptr; mi::u64 origin = 0; };   // part: index into `parts`; sums: per 1 MiB
+                                                                   // chunk, taken where the bytes were read (keep_sums); origin: the FILE
+                                                                   // offset of the row's first staged byte (a part: begin - halo; else 0) --
+                                                                   // sums[] lie on the file's 1 MiB grid: sums[k - origin / 1 MiB] is chunk k
     std::vector<FileRec> files;
     std::vector<mi::SynthSpec> synth;
     std::vector<mi::PartRec> parts;          // split files (mi_batch_add_*_part)
@@ -179,6 +182,11 @@ struct mi_batch {
     std::vector<mi::u32> row_member;
     std::vector<mi::u64> row_row;
     std::vector<mi::u64> member_bytes;
+    // a file of MI_COMMIT_SPLIT_MIB (256) MiB and more is SPLIT over the members as parts (mi_batch_add_path_part: the parts protocol):
+    // group row g with row_member[g] == kGroupSplit is splits[row_row[g]]
+    struct SplitPart { mi::u32 member; mi::u64 row, begin, end; };
+    struct Split { mi::u64 size; std::vector<SplitPart> parts; };
+    std::vector<Split> splits;
     mi::Arena arena;
     bool keep_sums = false;      // every host-fed file row carries the sums of its bytes as they were READ (mi_filesum.h): what the layer
     mi_sum::Pool sum_pool;       // writer checks the bytes it frames against (MI_FLAG_FILE_SUMS; always for a MemFS handle's batch)

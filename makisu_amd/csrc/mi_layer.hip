@@ -679,9 +679,9 @@ static int layer_add_entry(mi_layer* l, const mi_tree_entry* e, const char* src_
         // A batch file is framed CHUNK BY CHUNK (1 MiB of the file, mi_filesum.h) when the batch kept the sums of its bytes as
         // they were read: the same sums over what came back from HBM; equal, or the chunk is framed again after a second
         // fetch, or the layer fails -- io.CopyN's "the bytes or an error" across two PCIe hops.
-        const mi_sum::FileSum* want = nullptr;
+        bool want = false;
         static const bool verify_on = [] { const char* v = getenv("MI_COMMIT_VERIFY"); return !(v && *v == '0'); }();
-        if (batch && verify_on) { const void* p = nullptr; if (mi_batch_file_sums(batch, batch_file, &p, nullptr) == MI_OK) want = (const mi_sum::FileSum*)p; }
+        if (batch && verify_on && e->size) { int has = 0; if (mi_batch_chunk_sum(batch, batch_file, 0, nullptr, nullptr, &has) == MI_OK) want = has != 0; }
         while (left) {
             const uint64_t chunk_len = want ? std::min<uint64_t>(left, mi_sum::kChunk - off % mi_sum::kChunk) : left;
             for (int attempt = 0;; ++attempt) {
@@ -715,7 +715,11 @@ static int layer_add_entry(mi_layer* l, const mi_tree_entry* e, const char* src_
                 }
                 if (!want) break;
                 const uint64_t k = off / mi_sum::kChunk;
-                if (a == want[k].a.load(std::memory_order_relaxed) && b == want[k].b.load(std::memory_order_relaxed)) {
+                uint64_t wa = 0, wb = 0;
+                int has = 0;
+                if (mi_batch_chunk_sum(batch, batch_file, k, &wa, &wb, &has) != MI_OK || !has)
+                    return l->fail(MI_ERR_STATE, "copy file %s to tar writer: the batch lost the sums of chunk %llu", h.name.c_str(), (unsigned long long)k);
+                if (a == wa && b == wb) {
                     if (attempt) ++l->n_refetched;
                     l->release_hold();
                     break;
@@ -734,7 +738,7 @@ static int layer_add_entry(mi_layer* l, const mi_tree_entry* e, const char* src_
             off += chunk_len;
             left -= chunk_len;
         }
-        if (want) { ++l->n_verified_files; l->verified_bytes += e->size; }
+        if (want || (batch && verify_on && !e->size && mi_batch_keeps_sums(batch))) { ++l->n_verified_files; l->verified_bytes += e->size; }
         if (fd >= 0) close(fd);
         l->read_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_read).count() -
                      (l->tar.full_s + (l->gz ? l->gz->full_s : 0) - pushed0);

@@ -32,11 +32,11 @@ MI_LOCAL int  mi_batch_add_block(mi_batch* b, const void* src, uint64_t len, voi
 MI_LOCAL int  mi_batch_add_placed(mi_batch* b, uint64_t n, const uint64_t* arena_off, const uint64_t* sizes,
                                   const uint64_t* tags, const uint64_t* sums);
 // the end-to-end byte sums (mi_filesum.h): does the batch keep them (MI_FLAG_FILE_SUMS; a MemFS handle's batch always does --
-// mi_batch_keep_sums, before its first file); a row's chunk sums (mi_sum::FileSum[n_chunks], NULL: none); forget what the
+// mi_batch_keep_sums, before its first file); the sums of chunk k (1 MiB of the file) of a row (*has = 0: none kept); forget what the
 // read-back windows hold (the next read fetches again); which hop lost a chunk (a line for the error message)
 MI_LOCAL int  mi_batch_keeps_sums(mi_batch* b);
 MI_LOCAL void mi_batch_keep_sums(mi_batch* b, int on);
-MI_LOCAL int  mi_batch_file_sums(mi_batch* b, uint64_t file_index, const void** sums, uint64_t* n_chunks);
+MI_LOCAL int  mi_batch_chunk_sum(mi_batch* b, uint64_t file_index, uint64_t chunk, uint64_t* sum_a, uint64_t* sum_b, int* has);
 MI_LOCAL void mi_batch_drop_windows(mi_batch* b);
 MI_LOCAL int  mi_batch_prepare_read(mi_batch* b);      // the read-back windows now, not at the tar writer's first read
 MI_LOCAL int  mi_batch_explain_chunk(mi_batch* b, uint64_t file_index, uint64_t chunk, char* msg, uint64_t cap);
@@ -47,6 +47,7 @@ MI_LOCAL int  mi_batch_reserve_ahead(mi_batch* b, uint64_t more_files, uint64_t 
 // one handle over n batches, one per ctx: what a walk hands over is spread by bytes, the commit sees one batch (mi_internal.h:
 // members); the members and their loads (n = 0: not a group)
 MI_LOCAL int  mi_batch_group_begin(mi_ctx* const* ctxs, uint32_t n, mi_batch** out);
+MI_LOCAL uint64_t mi_batch_group_splits(mi_batch* b);      // files of the group that are split over its members as parts
 MI_LOCAL int  mi_batch_group_members(mi_batch* b, mi_batch* const** members, const uint64_t** bytes, uint64_t* n);
 // job-wide marking of a rank's own rows, enqueued on the ctx stream; the first-occurrence count stays in
 // ctx->dd_nuniq (device).  For mi_comm.hip

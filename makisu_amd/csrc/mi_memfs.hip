@@ -1793,8 +1793,8 @@ extern "C" int mi_memfs_commit_layer(mi_memfs* m, mi_ctx* ctx, int must_scan, co
 // tar writer reads each file from the GPU that holds it; the chunk index (on one of the ctxs) takes the other GPUs' digests
 // through the host (32 bytes per chunk).  Everything else -- the diff, the pipelining, the sums, TRUST_CTIME, the windows of a
 // tree that does not fit -- is the one-GPU commit's: behind the handle the n batches look like one (mi_batch_group_begin).
-// n_ctx = 1 is mi_memfs_commit_layer, n_ctx = 0 the reference's commit.  Files are not split across GPUs (a 1 GiB file is 20 ms of
-// one PCIe link; the parts protocol of mi_batch_add_path_part is for scans whose unit is one huge file, not for a layer).
+// n_ctx = 1 is mi_memfs_commit_layer, n_ctx = 0 the reference's commit.  A file of 256 MiB and more is split over the GPUs as parts
+// (mi_api.hip: the group's mi_batch_add_paths and group_resolve_parts).
 // UNMEASURED on more than one physical GPU (no such box in this pool): tested with n ctxs on one device and on the HIP double.
 extern "C" int mi_memfs_commit_layer_n(mi_memfs* m, mi_ctx* const* ctxs, uint32_t n_ctx, int must_scan, const mi_copy_op* ops,
                                        uint64_t n_ops, const mi_layer_config* cfg, mi_layer_result* res,
@@ -2065,6 +2065,7 @@ static int memfs_commit(mi_memfs* m, mi_ctx* const* ctxs, uint32_t n_ctx, int mu
         uint64_t nm = 0;
         mi_batch_group_members(b, nullptr, &loads, &nm);
         m->last.n_ctxs = nm ? nm : 1;
+        m->last.n_split_files = mi_batch_group_splits(b);
         m->last.ctx_bytes_max = m->last.ctx_bytes_min = nm ? loads[0] : m->last.scanned_bytes;
         for (uint64_t k = 1; k < nm; ++k) {
             if (loads[k] > m->last.ctx_bytes_max) m->last.ctx_bytes_max = loads[k];

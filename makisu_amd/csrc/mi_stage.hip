@@ -493,11 +493,11 @@ void stager_destroy(Stager* st) {
 
 // Queues [arena_off, +len) of the batch's arena, split into pieces of at most one slab.
 static void enqueue(Stager* st, mi_batch* b, u64 arena_off, u64 len, const u8* src,
-                    const std::shared_ptr<StageFile>& file, u64 file_off, StageLatch* latch, mi_sum::FileSum* sums) {
+                    const std::shared_ptr<StageFile>& file, u64 file_off, StageLatch* latch, mi_sum::FileSum* sums, u64 row_off0 = 0) {
     std::vector<StageItem> items;
     for (u64 done = 0; done < len;) {
         const u64 take = len - done < st->slab_bytes ? len - done : st->slab_bytes;
-        items.push_back({b, arena_off + done, take, src ? src + done : nullptr, file, file_off + done, latch, nullptr, sums, done});
+        items.push_back({b, arena_off + done, take, src ? src + done : nullptr, file, file_off + done, latch, nullptr, sums, row_off0 + done});
         done += take;
     }
     if (latch) latch->left = items.size();
@@ -520,11 +520,12 @@ int stager_put_bytes(Stager* st, mi_batch* b, u64 arena_off, const void* src, u6
     return MI_OK;
 }
 
-int stager_put_file(Stager* st, mi_batch* b, u64 arena_off, int fd, u64 file_off, u64 len, const char* path, mi_sum::FileSum* sums) {
+int stager_put_file(Stager* st, mi_batch* b, u64 arena_off, int fd, u64 file_off, u64 len, const char* path, mi_sum::FileSum* sums,
+                    u64 row_off0) {
     auto f = std::make_shared<StageFile>();
     f->fd = fd;
     f->path = path ? path : "";
-    if (len) enqueue(st, b, arena_off, len, nullptr, f, file_off, nullptr, sums);
+    if (len) enqueue(st, b, arena_off, len, nullptr, f, file_off, nullptr, sums, row_off0);
     return MI_OK;
 }
 

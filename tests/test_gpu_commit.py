@@ -147,16 +147,59 @@ def test_the_arena_never_moves_on_the_gpu(tmp_path):
     assert p.returncode == 0 and "OK known_tree" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
 
 
-@pytest.mark.parametrize("n,extra", [(2, {}), (8, {}), (3, {"MI_COMMIT_PIPELINE": "0"}), (2, {"MI_STAGE_FAULT": "readback:1"})])
+@pytest.mark.parametrize("n,extra", [(2, {}), (8, {}), (3, {"MI_COMMIT_PIPELINE": "0"}), (2, {"MI_STAGE_FAULT": "readback:1"}),
+                                     (2, {"MI_COMMIT_SPLIT_MIB": "2"}), (4, {"MI_COMMIT_SPLIT_MIB": "2", "MI_COMMIT_PIPELINE": "0"}),
+                                     (8, {"MI_COMMIT_SPLIT_MIB": "4", "MI_STAGE_FAULT": "readback:3"})])
 def test_the_commit_over_several_ctxs_on_the_gpu(tmp_path, n, extra):
     """mi_memfs_commit_layer_n with n ctxs on the box's one GPU (tests/hip_stub/commit_scenarios.py `many_gpus`): every root = the
     oracle's = the one-ctx commit's, the tar byte-identical to n = 1 and to the header-only commit, one read per file, the chunk
     index (on the LAST ctx: every other ctx's digests reach it through the host) holds what the one-ctx commit's holds, a
-    same-second rewrite is caught, a corrupted read-back repaired.  No claim about more than one physical GPU."""
+    same-second rewrite is caught, a corrupted read-back repaired.  With MI_COMMIT_SPLIT_MIB lowered to 2 / 4 MiB the larger files are
+    SPLIT over the ctxs as parts (what happens to files of 256 MiB and more): their roots -- mi_chunk_root over the parts' digests, the
+    parts having agreed on their boundary cuts -- are the oracle's roots of the whole files, their bytes in the tar are the files',
+    every chunk of them verified.  No claim about more than one physical GPU."""
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hip_stub", "commit_scenarios.py")
     env = dict(os.environ, MI_TEST_ON_GPU="1", MI_TEST_N_CTXS=str(n), **extra)
     p = subprocess.run([sys.executable, script, str(tmp_path), "4", "many_gpus"], env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0 and ("OK many_gpus %d" % n) in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
+
+
+def test_a_file_of_600_mib_is_split_over_three_ctxs_at_the_real_threshold(oracle, eng, tmp_path):
+    """files of 256 MiB and more are split across the GPUs.  One 600 MiB file (+ a 300 MiB one, + small ones) committed over
+    three ctxs with the default MI_COMMIT_SPLIT_MIB: two split files, their roots the ORACLE's roots of the whole files, the TarDigest
+    the header-only commit's, every file's bytes verified against the sums taken where they were read; a rewrite inside the big file
+    that keeps size and second is caught by the next commit"""
+    root = str(tmp_path / "root")
+    rng = np.random.default_rng(600)
+    big = rng.integers(0, 256, 600 << 20, dtype=np.uint8).tobytes()
+    mid = rng.integers(0, 256, (300 << 20) + 777, dtype=np.uint8).tobytes()
+    files = {"blobs/big.bin": big, "blobs/mid.bin": mid, "etc/a.conf": b"a = 1\n" * 100, "etc/b.bin": rng.integers(0, 256, 300_000, dtype=np.uint8).tobytes()}
+    for rel, data in files.items():
+        write_file(os.path.join(root, rel), data, 0o644, MTIME)
+    for dp, dns, fns in os.walk(root):
+        os.utime(dp, (MTIME, MTIME))
+    more = [M.Engine(device=0, n_streams=4) for _ in range(2)]
+    try:
+        with M.MemFS(root) as fs, M.MemFS(root) as plain:
+            res = fs.commit_layer(must_scan=True, gzip_level=M.GZIP_OFF, engine=[eng] + more)
+            res0 = plain.commit_layer(must_scan=True, gzip_level=M.GZIP_OFF)
+            st = res["stats"]
+            assert res["tar_digest"] == res0["tar_digest"] and res["tar_bytes"] == res0["tar_bytes"]
+            assert st["n_split_files"] == 2 and st["n_ctxs"] == 3 and st["n_verified_files"] == 4 and st["n_refetched"] == 0, st
+            assert st["ctx_bytes_max"] <= 2 * st["ctx_bytes_min"], st                                # (200 + 150 MiB against 200: parts of two files)
+            by = {e["relpath"]: e for e in res["layer"]}
+            for rel, data in files.items():
+                assert by[rel]["root"] == oracle_root(oracle, data), rel
+            changed = bytearray(big)
+            changed[(400 << 20) + 5] ^= 0x10                                   # inside the big file's third part, same size, same second
+            write_file(os.path.join(root, "blobs/big.bin"), bytes(changed), 0o644, MTIME)
+            os.utime(os.path.join(root, "blobs"), (MTIME, MTIME))
+            res = fs.commit_layer(must_scan=True, gzip_level=M.GZIP_OFF, engine=[eng] + more)
+            assert [e["relpath"] for e in res["layer"] if e["kind"] == M.KIND_FILE] == ["blobs/big.bin"] and res["stats"]["n_content_changed"] == 1
+            assert {e["relpath"]: e for e in res["layer"]}["blobs/big.bin"]["root"] == oracle_root(oracle, bytes(changed))
+    finally:
+        for e in more:
+            e.close()
 
 
 def _rewrite_same_size_same_second(path, rng):
