@@ -590,7 +590,7 @@ def single_process_job(args):
     def finish(g, record):
         each(lambda r: batches[r][g].wait())
         t0 = time.perf_counter()
-        n_total, n_unique = makisu_amd.dedup_allgather_all([batches[r][g] for r in range(n)])
+        n_total, n_unique = makisu_amd.dedup_allgather_all([batches[r][g] for r in range(n)], form=args.exchange_form)
         x_ms = (time.perf_counter() - t0) * 1e3
         if record:
             rec["exchange_host_ms"].append(x_ms)
@@ -667,7 +667,8 @@ def single_process_job(args):
                    "job_bytes_per_step": int(job_bytes), "chunks_per_rank_last_batch": [int(x) for x in per_rank_chunks],
                    "parallelism": "files sharded x%d (%s)" % (n, "LPT by bytes" if config in ("c5", "c5u") else "file index mod N"),
                    "launch": "single process, %d ctxs, one host thread per device (mi_comm_init_all)" % n,
-                   "batches_in_flight": inflight, "exchange": "native", "rccl_ranks": int(rccl_ranks[0]),
+                   "batches_in_flight": inflight, "exchange": "native", "exchange_form": args.exchange_form,
+                   "rccl_ranks": int(rccl_ranks[0]),
                    "rccl_ranks_per_ctx": [int(x) for x in rccl_ranks],
                    "rccl_library": os.environ.get("MI_RCCL_LIB", "librccl (dlopen)"),
                    "devices": devs, "device": info["name"].strip(), "n_cu": info["n_cu"]},
@@ -749,6 +750,10 @@ def main():
     ap.add_argument("--exchange", default="native", choices=["torch", "native"],
                     help="who runs the digest all-gather: the library's own RCCL binding (default: "
                          "mi_dedup_allgather / mi_dedup_allgather_all, what a Go host uses) or torch.distributed")
+    ap.add_argument("--exchange-form", default="allgather", choices=["allgather", "alltoall"],
+                    help="with --exchange native: the digest all-gather + range marking (default), or the hash-partitioned "
+                         "form -- every digest to ONE owner rank and 8 bytes back (mi_dedup_alltoall: same results; 38.5 "
+                         "bytes per row over xGMI at 8 ranks instead of 224)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the digest exchange + global marking even with one rank (self-test)")
     args = ap.parse_args()
@@ -916,7 +921,7 @@ def main():
         t_x = time.perf_counter()
         if exchange:
             if args.exchange == "native":
-                _, n_unique, _ = b.dedup_allgather()      # RCCL inside the library
+                _, n_unique, _ = (b.dedup_alltoall if args.exchange_form == "alltoall" else b.dedup_allgather)()   # RCCL inside the library
             else:
                 _, n_unique, _, _ = mdist.global_dedup(eng, b, device, group=torch_group)
         if record:
@@ -1094,6 +1099,7 @@ def main():
                    "launch": "one process per GPU" if world > 1 else "one process, one GPU",
                    "batches_in_flight": args.inflight, "launches_per_step": launches_per_step,
                    "exchange": (args.exchange if exchange else None),
+                   "exchange_form": (args.exchange_form if exchange and args.exchange == "native" else None),
                    "rccl_ranks": rccl_ranks,
                    "exchange_backend": (("library RCCL binding; torch.distributed %s for the id, barrier and scalars" % backend)
                                         if exchange and args.exchange == "native" else

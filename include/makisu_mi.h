@@ -412,7 +412,7 @@ MI_BLOCK int mi_batch_device_dup_of(mi_batch* b, const void** d_dup_of, uint64_t
 /* ---- the digest exchange inside the library: RCCL all-gather over xGMI ---------------- *
  * For hosts without torch (the Go shim).  RCCL is loaded at run time (dlopen), so these
  * fail with MI_ERR_NO_DEVICE where no librccl exists (MI_RCCL_LIB=<path> names another library with
- * the same eight nccl* entry points: tests/rccl_stub is one, for n ranks on a single GPU).  Multi-process: rank 0 obtains the
+ * the same nccl* entry points: tests/rccl_stub is one, for n ranks on a single GPU).  Multi-process: rank 0 obtains the
  * id, ships it to the peers, every rank calls mi_comm_init_rank.  Single process driving n
  * devices (one ctx each): mi_comm_init_all + mi_dedup_allgather_all.
  * mi_dedup_allgather: all-gathers the batches' digest arrays (counts first, then slabs
@@ -431,9 +431,20 @@ MI_BLOCK int mi_comm_ranks(mi_ctx* ctx, int* n_ranks);
 MI_BLOCK int mi_dedup_allgather(mi_batch* b, uint64_t* n_total, uint64_t* n_unique,
                        uint64_t* first_global);
 MI_BLOCK int mi_dedup_allgather_all(mi_batch** batches, int n, uint64_t* n_total, uint64_t* n_unique);
+/* The HASH-PARTITIONED form of the same exchange (SURVEY 8e's "optimisation"): same arguments, same results bit for bit,
+ * two all-to-alls (grouped ncclSend / ncclRecv) instead of the all-gather.  Every digest has one OWNER rank, chosen by its
+ * second 8 bytes; a rank sends each owner its share (32-byte digest + 4-byte row, split stably on the device), the owner
+ * marks what it received -- n_total / n rows, each distinct digest of the job counted once -- and sends 8 bytes per row
+ * back.  Per own row at 8 ranks: 38.5 bytes over xGMI instead of 224 received, and a table of 1/8 of the job's rows instead
+ * of own rows probed by every earlier rank's.  At most 64 ranks; MI_ERR_NO_DEVICE if the collective library has no
+ * ncclSend / ncclRecv.  The all-gather form stays the default of bench.py: the exchange is 3-4 % of a C4 step
+ * (DESIGN.md 5), and this form has met only the double's ranks (tests/test_gpu_native_exchange.py), never 8 real ones. */
+MI_BLOCK int mi_dedup_alltoall(mi_batch* b, uint64_t* n_total, uint64_t* n_unique, uint64_t* first_global);
+MI_BLOCK int mi_dedup_alltoall_all(mi_batch** batches, int n, uint64_t* n_total, uint64_t* n_unique);
 /* Device time of the ctx's LAST exchange, from HIP events on the ctx stream (what a scaling line
  * reports beside its rate): ms_gather = the slab all-gather (xGMI time), ms_marking = squeezing the padding
- * out + the job-wide marking of this rank's rows.  Both 0 before the first exchange with rows.          */
+ * out + the job-wide marking of this rank's rows.  Both 0 before the first exchange with rows.  After the all-to-all
+ * form: ms_gather = both all-to-alls, ms_marking = the split + the owner's marking and answers + the scatter.  */
 MI_DIAG int mi_comm_exchange_ms(mi_ctx* ctx, double* ms_gather, double* ms_marking);
 
 /* ---- COPY/ADD context checksum (addCopyStep.SetCacheID seam) ------------------------ *

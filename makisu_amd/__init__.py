@@ -304,6 +304,8 @@ def load_library(rebuild=False):
         "mi_comm_exchange_ms": ([vp, C.POINTER(C.c_double), C.POINTER(C.c_double)], C.c_int),
         "mi_dedup_allgather": ([vp, u64p, u64p, u64p], C.c_int),
         "mi_dedup_allgather_all": ([C.POINTER(vp), C.c_int, u64p, u64p], C.c_int),
+        "mi_dedup_alltoall": ([vp, u64p, u64p, u64p], C.c_int),
+        "mi_dedup_alltoall_all": ([C.POINTER(vp), C.c_int, u64p, u64p], C.c_int),
         "mi_index_create": ([vp, u64, C.POINTER(vp)], C.c_int),
         "mi_index_free": ([vp], None),
         "mi_index_count": ([vp, u64p], C.c_int),
@@ -1106,12 +1108,13 @@ def comm_init_all(engines):
         raise MiError(rc, engines[0]._lib.mi_last_error(engines[0]._h).decode())
 
 
-def dedup_allgather_all(batches):
-    """mi_dedup_allgather_all: the exchange + job-wide marking for the batches of comm_init_all's ctxs,
-    rank order.  Returns (n_total, n_unique)."""
+def dedup_allgather_all(batches, form="allgather"):
+    """mi_dedup_allgather_all (form="alltoall": mi_dedup_alltoall_all, the hash-partitioned form -- same results): the
+    exchange + job-wide marking for the batches of comm_init_all's ctxs, rank order.  Returns (n_total, n_unique)."""
     arr = (C.c_void_p * len(batches))(*[b._h for b in batches])
     a, b_ = C.c_uint64(), C.c_uint64()
-    rc = load_library().mi_dedup_allgather_all(arr, len(batches), C.byref(a), C.byref(b_))
+    fn = {"allgather": "mi_dedup_allgather_all", "alltoall": "mi_dedup_alltoall_all"}[form]
+    rc = getattr(load_library(), fn)(arr, len(batches), C.byref(a), C.byref(b_))
     if rc:
         e = batches[0].engine
         raise MiError(rc, "; ".join(x.engine._lib.mi_last_error(x.engine._h).decode() for x in batches) or str(e))
@@ -1327,6 +1330,13 @@ class Batch:
         Returns (n_total, n_unique, first_global)."""
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
         self._check(self._lib.mi_dedup_allgather(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def dedup_alltoall(self):
+        """Collective: the hash-partitioned form of dedup_allgather (mi_dedup_alltoall) -- every digest travels to ONE
+        owner rank and an 8-byte answer comes back.  Same results: (n_total, n_unique, first_global)."""
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._check(self._lib.mi_dedup_alltoall(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
     def mark_global(self, d_digests_all_ptr, n_total, own_first):

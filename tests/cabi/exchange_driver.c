@@ -1,6 +1,7 @@
 /* A plain-C consumer of the MULTI-GPU interface of include/makisu_mi.h in its single-process form -- what
  * INTEGRATION.md shows for a Go host ("Multi-GPU from Go"): one ctx per device, one host thread per device for the
- * scan, mi_comm_init_all once, mi_dedup_allgather_all per round of batches.
+ * scan, mi_comm_init_all once, mi_dedup_allgather_all per round of batches (MI_EXCHANGE_FORM=alltoall in the environment:
+ * mi_dedup_alltoall_all, the hash-partitioned form of the same exchange).
  * Usage: exchange_driver <n_ranks> <files_per_rank> [device ...]      (no devices given: rank r on device r)
  * Rank r scans files_per_rank synthetic 64 KiB files whose content ids are  r * files_per_rank / 2 + i  -- every
  * rank's first half repeats the previous rank's second half, so half of the job's chunks are cross-rank duplicates.
@@ -57,8 +58,11 @@ int main(int argc, char** argv) {
     for (int r = 0; r < n_ranks; r++) pthread_join(th[r], NULL);
     for (int r = 0; r < n_ranks; r++) if (failed[r]) return 1;
     uint64_t n_total = 0, n_unique = 0;
+    const char* form = getenv("MI_EXCHANGE_FORM");
+    int (*exchange)(mi_batch**, int, uint64_t*, uint64_t*) =
+        form && !strcmp(form, "alltoall") ? mi_dedup_alltoall_all : mi_dedup_allgather_all;
     for (int round = 0; round < 2; round++)                      /* twice: the exchange buffers are reused */
-        if (mi_dedup_allgather_all(batch, n_ranks, &n_total, &n_unique) != MI_OK) {
+        if (exchange(batch, n_ranks, &n_total, &n_unique) != MI_OK) {
             for (int r = 0; r < n_ranks; r++) fprintf(stderr, "exchange: rank %d: %s\n", r, mi_last_error(ctx[r]));
             return 1;
         }

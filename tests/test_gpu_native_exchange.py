@@ -107,8 +107,15 @@ with makisu_amd.Engine(flags=makisu_amd.FLAG_NO_DEDUP) as e:
         if case == "c5":
             mdist.resolve_parts(b, keys)
         b.run()
+        form = os.environ.get("MI_TEST_EXCHANGE_FORM", "allgather")
+        if form == "alltoall":                                # the all-gather form first: the other must leave the same column
+            want = b.dedup_allgather()
+            want_dup = b.chunks()["dup_of"].copy()
         for rep in range(2):                                  # twice: the exchange buffers are reused
-            n_total, n_unique, first = b.dedup_allgather()
+            n_total, n_unique, first = b.dedup_alltoall() if form == "alltoall" else b.dedup_allgather()
+        if form == "alltoall":
+            assert (n_total, n_unique, first) == want, ((n_total, n_unique, first), want)
+            assert np.array_equal(b.chunks()["dup_of"], want_dup)
         ga, ma = e.comm_exchange_ms()
         assert ga >= 0 and ma >= 0 and (ga + ma > 0 or n_total == 0), (ga, ma)
         ch = b.chunks().copy()
@@ -134,8 +141,15 @@ if case == "c5":
     mdist.resolve_parts_local(owners)
 for b in batches:
     b.run()
+form = os.environ.get("MI_TEST_EXCHANGE_FORM", "allgather")
+if form == "alltoall":
+    want = makisu_amd.dedup_allgather_all(batches)
+    want_dup = [b.chunks()["dup_of"].copy() for b in batches]
 for rep in range(2):
-    n_total, n_unique = makisu_amd.dedup_allgather_all(batches)
+    n_total, n_unique = makisu_amd.dedup_allgather_all(batches, form=form)
+if form == "alltoall":
+    assert (n_total, n_unique) == want, ((n_total, n_unique), want)
+    assert all(np.array_equal(b.chunks()["dup_of"], w) for b, w in zip(batches, want_dup))
 first = 0
 for r, b in enumerate(batches):
     ch = b.chunks().copy()
@@ -177,12 +191,15 @@ def _check(oracle, d, n, case="ragged"):
 
 
 CASES = [(2, "ragged"), (3, "ragged"), (8, "ragged"), (8, "c4"), (8, "c5")]
+FORMS = ["allgather", "alltoall"]          # mi_dedup_allgather[_all]; mi_dedup_alltoall[_all] -- the hash-partitioned form, held
+                                           # against the oracle AND, in the same process, against the all-gather form's column
 
 
 @pytest.mark.timeout(900)
+@pytest.mark.parametrize("form", FORMS)
 @pytest.mark.parametrize("n,case", CASES)
-def test_native_exchange_n_processes_on_one_gpu(oracle, stub, tmp_path, n, case):
-    env = dict(os.environ, MI_RCCL_LIB=stub, MI_RCCL_STUB_SLOT_MB="1")     # 1 MiB slots: rank 0's slab takes rounds
+def test_native_exchange_n_processes_on_one_gpu(oracle, stub, tmp_path, n, case, form):
+    env = dict(os.environ, MI_RCCL_LIB=stub, MI_RCCL_STUB_SLOT_MB="1", MI_TEST_EXCHANGE_FORM=form)   # 1 MiB slots: rank 0's slab / share takes rounds
     procs = [subprocess.Popen([sys.executable, "-c", CHILD_RANK % {"root": ROOT}, str(r), str(n), str(tmp_path), case],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(n)]
     outs = [p.communicate(timeout=800) for p in procs]
@@ -192,18 +209,21 @@ def test_native_exchange_n_processes_on_one_gpu(oracle, stub, tmp_path, n, case)
 
 
 @pytest.mark.timeout(900)
+@pytest.mark.parametrize("form", FORMS)
 @pytest.mark.parametrize("n,case", CASES)
-def test_native_exchange_n_ctxs_in_one_process(oracle, stub, tmp_path, n, case):
+def test_native_exchange_n_ctxs_in_one_process(oracle, stub, tmp_path, n, case, form):
     """mi_comm_init_all + mi_dedup_allgather_all over n ctxs of one process: host-known counts, every
-    allocation and pad copy before the group, the group holding the n all-gathers and nothing else."""
-    env = dict(os.environ, MI_RCCL_LIB=stub)
+    allocation and pad copy before the group, the group holding the n all-gathers and nothing else.  (form "alltoall":
+    mi_dedup_alltoall_all -- the shares counted on the devices, two groups of sends and receives.)"""
+    env = dict(os.environ, MI_RCCL_LIB=stub, MI_TEST_EXCHANGE_FORM=form)
     r = subprocess.run([sys.executable, "-c", CHILD_ALL % {"root": ROOT}, str(n), str(tmp_path), case], env=env,
                        capture_output=True, text=True, timeout=800)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-1000:] + r.stderr[-3000:]
     _check(oracle, str(tmp_path), n, case)
 
 
-def test_plain_c_exchange(oracle, stub, tmp_path):
+@pytest.mark.parametrize("form", FORMS)
+def test_plain_c_exchange(oracle, stub, tmp_path, form):
     """The single-process form from plain C (tests/cabi/exchange_driver.c: one ctx per rank, a host thread per rank for
     the scan, mi_comm_init_all, mi_dedup_allgather_all twice) with 8 ranks on this GPU: the printed dup_of of every rank
     is the oracle's marking of the rank-major concatenation; half of the job's chunks repeat the previous rank's."""
@@ -213,8 +233,8 @@ def test_plain_c_exchange(oracle, stub, tmp_path):
                            "-L", os.path.join(ROOT, "makisu_amd"), "-lmakisu_mi", "-lpthread",
                            "-Wl,-rpath," + os.path.join(ROOT, "makisu_amd")])
     n, per = 8, 600
-    out = subprocess.run([exe, str(n), str(per), "0"], env=dict(os.environ, MI_RCCL_LIB=stub), capture_output=True, text=True,
-                         timeout=300)
+    out = subprocess.run([exe, str(n), str(per), "0"], env=dict(os.environ, MI_RCCL_LIB=stub, MI_EXCHANGE_FORM=form),
+                         capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-500:] + out.stderr[-2000:]
     lines = out.stdout.splitlines()
     ranks = [ln.split() for ln in lines if ln.startswith("K ")]

@@ -786,6 +786,10 @@ def test_native_rccl_exchange_single_rank(oracle):
             assert (b.chunks()["dup_of"] == -1).all()            # local marking was off
             n_total, n_unique, first = b.dedup_allgather()
             chunks = b.chunks().copy()
+            # the hash-partitioned form on the REAL library (one rank: the share is a device copy, the counts and the
+            # summed unique count still go through ncclAllGather): same column, same scalars
+            assert b.dedup_alltoall() == (n_total, n_unique, first)
+            assert np.array_equal(b.chunks()["dup_of"], chunks["dup_of"])
         want, uniq = oracle.dedup(chunks["sha256"])
         assert n_total == len(chunks) and first == 0 and n_unique == uniq
         assert np.array_equal(chunks["dup_of"], want)
@@ -812,6 +816,8 @@ def test_native_rccl_init_all_single_device(oracle):
         assert nt.value == len(local) and nu.value == (local < 0).sum()
         # results cache must be refreshed after the rewrite
         assert np.array_equal(b.chunks()["dup_of"], local)
+        assert lib.mi_dedup_alltoall_all(batches, 1, C.byref(nt), C.byref(nu)) == 0, lib.mi_last_error(eng._h)
+        assert nt.value == len(local) and nu.value == (local < 0).sum() and np.array_equal(b.chunks()["dup_of"], local)
 
 
 def test_chunk_root_tree_three_levels(oracle):
