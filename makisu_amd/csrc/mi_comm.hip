@@ -260,6 +260,9 @@ int sum_over_ranks_finish(mi_ctx* c, u64* sum) {
 //   6. the owners' unique counts are summed as in the all-gather form.
 // Per own row at 8 ranks: 44 bytes x 7/8 over xGMI instead of 224, and every rank's table work is n_total / n rows instead of
 // own rows + a probe per earlier row.  Same results, bit for bit (tests/test_gpu_native_exchange.py runs both forms on every case).
+}  // namespace
+
+namespace mi {          // (named kernels: a profile lists them as mi::part_... / mi::answer_...)
 constexpr int kMaxOwners = 64;
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 
@@ -279,38 +282,43 @@ void part_hist_kernel(const u8* __restrict__ dg, u64 n_rows, u32 n, u32* __restr
     if (threadIdx.x < n) hist[(u64)blockIdx.x * n + threadIdx.x] = cnt[threadIdx.x];
 }
 
-// hist[block][owner] -> the block's first position within the owner's share; to[owner] = the share's rows; base[owner] = where
-// the share begins in send order.  One wave per owner walks the blocks 64 at a time.
+// hist[block][owner] -> the block's first position within the owner's share; to[owner] = the share's rows.  One workgroup per
+// owner; its sixteen waves take a sixteenth of the blocks each: sum it, learn what lies before it, scan it (64 blocks a step).
 __global__ __launch_bounds__(1024)
-void part_scan_kernel(u32* __restrict__ hist, u32 n_blocks, u32 n, u64* __restrict__ to, u32* __restrict__ base) {
-    __shared__ u32 tot[kMaxOwners];
-    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (u32 o = wave; o < n; o += 16) {
-        u32 carry = 0;
-        for (u32 b0 = 0; b0 < n_blocks; b0 += 64) {
-            const u32 b = b0 + lane;
-            const u32 v = b < n_blocks ? hist[(u64)b * n + o] : 0u;
-            u32 incl = v;
-            for (int d = 1; d < 64; d <<= 1) {
-                const u32 t = (u32)__shfl_up((int)incl, d, 64);
-                if ((int)lane >= d) incl += t;
-            }
-            if (b < n_blocks) hist[(u64)b * n + o] = carry + incl - v;
-            carry += (u32)__shfl((int)incl, 63, 64);
-        }
-        if (lane == 0) tot[o] = carry;
-    }
+void part_scan_kernel(u32* __restrict__ hist, u32 n_blocks, u32 n, u64* __restrict__ to) {
+    __shared__ u32 wsum[16];
+    const u32 o = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u32 per = (n_blocks + 15) / 16;
+    const u32 lo = wave * per < n_blocks ? wave * per : n_blocks, hi = lo + per < n_blocks ? lo + per : n_blocks;
+    u32 acc = 0;
+    for (u32 b = lo + lane; b < hi; b += 64) acc += hist[(u64)b * n + o];
+    for (int d = 32; d; d >>= 1) acc += (u32)__shfl_xor((int)acc, d, 64);
+    if (lane == 0) wsum[wave] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        u32 run = 0;
-        for (u32 o = 0; o < n; ++o) { base[o] = run; to[o] = tot[o]; run += tot[o]; }
+    u32 carry = 0, all = 0;
+    for (u32 v = 0; v < 16; ++v) { if (v < wave) carry += wsum[v]; all += wsum[v]; }
+    for (u32 b0 = lo; b0 < hi; b0 += 64) {
+        const u32 b = b0 + lane;
+        const u32 v = b < hi ? hist[(u64)b * n + o] : 0u;
+        u32 incl = v;
+        for (int d = 1; d < 64; d <<= 1) {
+            const u32 t = (u32)__shfl_up((int)incl, d, 64);
+            if ((int)lane >= d) incl += t;
+        }
+        if (b < hi) hist[(u64)b * n + o] = carry + incl - v;
+        carry += (u32)__shfl((int)incl, 63, 64);
     }
+    if (threadIdx.x == 0) to[o] = all;
 }
 
 __global__ __launch_bounds__(256)
 void part_scatter_kernel(const u8* __restrict__ dg, u64 n_rows, u32 n, const u32* __restrict__ hist,
-                         const u32* __restrict__ base, u8* __restrict__ out_dg, u32* __restrict__ out_row) {
-    __shared__ u32 wcnt[4][kMaxOwners];
+                         const u64* __restrict__ to, u8* __restrict__ out_dg, u32* __restrict__ out_row) {
+    __shared__ u32 wcnt[4][kMaxOwners], base[kMaxOwners];     // base: where each owner's share begins in send order
+    if (threadIdx.x == 0) {
+        u32 run = 0;
+        for (u32 q = 0; q < n; ++q) { base[q] = run; run += (u32)to[q]; }
+    }
     const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
     const bool live = i < n_rows;
@@ -355,8 +363,12 @@ void answer_scatter_kernel(const i64* __restrict__ back, const u32* __restrict__
     if (p < n_rows) dup_of[row[p]] = back[p];
 }
 
+}  // namespace mi
+
+namespace {
+
 struct Shares {                          // the all-to-all form's state of one ctx (next to its Exchange)
-    DevBuf hist, base, cnt_send, cnt_all, send_dg, send_row, recv_dg, recv_row, ans, back, meta;
+    DevBuf hist, cnt_send, cnt_all, send_dg, send_row, recv_dg, recv_row, ans, back, meta;
     u64* pin = nullptr;
     size_t pin_words = 0;
     std::vector<u64> to, from, soff, roff, first;             // rows per peer and where they lie (send order / received set)
@@ -365,7 +377,7 @@ struct Shares {                          // the all-to-all form's state of one c
     hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     void release() {
         for (auto& e : ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
-        for (DevBuf* d : {&hist, &base, &cnt_send, &cnt_all, &send_dg, &send_row, &recv_dg, &recv_row, &ans, &back, &meta}) d->release();
+        for (DevBuf* d : {&hist, &cnt_send, &cnt_all, &send_dg, &send_row, &recv_dg, &recv_row, &ans, &back, &meta}) d->release();
         if (pin) (void)hipHostFree(pin);
         pin = nullptr;
         pin_words = 0;
@@ -403,7 +415,6 @@ int shares_split_enqueue(mi_batch* b) {
     const u32 n_blocks = (u32)((rows + 255) / 256);
     HIPCHK(c, s->cnt_send.ensure(8 * (size_t)(n + 1)));
     HIPCHK(c, s->cnt_all.ensure(8 * (size_t)(n + 1) * n));
-    HIPCHK(c, s->base.ensure(4 * (size_t)n));
     HIPCHK(c, s->hist.ensure(4 * (size_t)n * (n_blocks ? n_blocks : 1)));
     HIPCHK(c, s->send_dg.ensure(rows * 32 + 32));
     HIPCHK(c, s->send_row.ensure(rows * 4 + 16));
@@ -419,10 +430,10 @@ int shares_split_enqueue(mi_batch* b) {
         return MI_OK;
     }
     hipLaunchKernelGGL(part_hist_kernel, dim3(n_blocks), dim3(256), 0, c->stream, b->digests.as<u8>(), rows, n, s->hist.as<u32>());
-    hipLaunchKernelGGL(part_scan_kernel, dim3(1), dim3(1024), 0, c->stream, s->hist.as<u32>(), n_blocks, n,
-                       s->cnt_send.as<u64>() + 1, s->base.as<u32>());
+    hipLaunchKernelGGL(part_scan_kernel, dim3(n), dim3(1024), 0, c->stream, s->hist.as<u32>(), n_blocks, n,
+                       s->cnt_send.as<u64>() + 1);
     hipLaunchKernelGGL(part_scatter_kernel, dim3(n_blocks), dim3(256), 0, c->stream, b->digests.as<u8>(), rows, n,
-                       s->hist.as<u32>(), s->base.as<u32>(), s->send_dg.as<u8>(), s->send_row.as<u32>());
+                       s->hist.as<u32>(), s->cnt_send.as<u64>() + 1, s->send_dg.as<u8>(), s->send_row.as<u32>());
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(s->ev[1], c->stream));
     return MI_OK;
