@@ -273,13 +273,17 @@ __device__ __forceinline__ u32 owner_of(const u8* dg, u32 n) {
 
 __global__ __launch_bounds__(256)
 void part_hist_kernel(const u8* __restrict__ dg, u64 n_rows, u32 n, u32* __restrict__ hist) {
-    __shared__ u32 cnt[kMaxOwners];
-    if (threadIdx.x < n) cnt[threadIdx.x] = 0;
-    __syncthreads();
+    __shared__ u32 wcnt[4][kMaxOwners];                        // counted by ballot, as the scatter ranks: no LDS atomics
+    const u32 wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
-    if (i < n_rows) atomicAdd(&cnt[owner_of(dg + 32 * i, n)], 1u);
+    const u32 mine = i < n_rows ? owner_of(dg + 32 * i, n) : 0xFFFFFFFFu;
+    for (u32 q = 0; q < n; ++q) {
+        const u64 m = __ballot(mine == q);
+        if (lane == 0) wcnt[wave][q] = (u32)__popcll(m);
+    }
     __syncthreads();
-    if (threadIdx.x < n) hist[(u64)blockIdx.x * n + threadIdx.x] = cnt[threadIdx.x];
+    if (threadIdx.x < n)
+        hist[(u64)blockIdx.x * n + threadIdx.x] = wcnt[0][threadIdx.x] + wcnt[1][threadIdx.x] + wcnt[2][threadIdx.x] + wcnt[3][threadIdx.x];
 }
 
 // hist[block][owner] -> the block's first position within the owner's share; to[owner] = the share's rows.  One workgroup per

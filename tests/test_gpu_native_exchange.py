@@ -271,6 +271,7 @@ def test_bench_bare_gpus_8_is_the_library_exchange(stub):
     j = _bench_line(out)
     assert j["n_gpus"] == 8 and j["config"]["name"] == "c4" and j["config"]["rccl_ranks"] == 8
     assert j["config"]["exchange"] == "native" and "single process" in j["config"]["launch"]
+    assert j["config"]["exchange_form"] == "allgather"                      # the default form
     assert j["config"]["job_bytes_per_step"] == 8 * 20000 * 65536
     assert j["dedup_check"]["ok"] and j["dedup_check"]["n_total"] == sum(j["config"]["chunks_per_rank_last_batch"])
     for k in ("step_ms", "exchange_gather_ms", "marking_ms", "sha_chunks_ms"):       # (the double gathers on the host: ~0 ms)
@@ -280,6 +281,28 @@ def test_bench_bare_gpus_8_is_the_library_exchange(stub):
     assert j["config"]["rccl_ranks_per_ctx"] == [8] * 8                     # counted (ncclCommCount of every ctx), not assumed
     assert j["cpu_baseline"]["value"] > 0 and j["cpu_baseline"]["cores"] >= 1   # the host's scanner in the same run, at N > 1 too
     assert "launch_note" not in j["config"]
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("launch", ["bare", "torchrun"])
+def test_bench_with_the_all_to_all_form(stub, launch):
+    """`bench.py --exchange-form alltoall`, bare (4 ctxs of one process: mi_dedup_alltoall_all) and as the driver launches it
+    (one process per rank: mi_dedup_alltoall): the job-wide unique count is the generator's closed form, the line says which
+    form ran, and the per-rank wire / device-work times are there."""
+    env = dict(os.environ, MI_BENCH_FORCE_DEVICE="0", MI_RCCL_LIB=stub, MASTER_ADDR="127.0.0.1")
+    tail = ["--gpus", "4", "--files", "8000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--exchange-form", "alltoall"]
+    if launch == "bare":
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k, None)
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + tail
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+               "--master-port", "29591", os.path.join(ROOT, "bench.py")] + tail
+    j = _bench_line(subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=800))
+    assert j["n_gpus"] == 4 and j["config"]["exchange"] == "native" and j["config"]["exchange_form"] == "alltoall"
+    assert j["config"]["rccl_ranks"] == 4 and j["dedup_check"]["ok"], j["dedup_check"]
+    assert len(j["per_rank"]["marking_ms"]) == 4 and all(v > 0 for v in j["per_rank"]["marking_ms"])
+    assert "launch_note" not in j["config"] and "exchange_note" not in j["config"]
 
 
 @pytest.mark.timeout(900)
