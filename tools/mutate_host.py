@@ -119,7 +119,7 @@ def run_mutant(k, args, src_lines, site, objs_other, flags):
             return ("nocompile", tag, "")
         env = dict(os.environ, MAKISU_MI_LIB=lib, PYTHONDONTWRITEBYTECODE="1")
     try:
-        r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "not gpu", "-p", "no:cacheprovider"] + args.tests,
+        r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", args.marker, "-p", "no:cacheprovider"] + args.tests,
                            cwd=ROOT, env=env, capture_output=True, text=True, timeout=args.timeout)
         verdict = "killed" if r.returncode != 0 else "SURVIVED"
         detail = ""
@@ -144,6 +144,8 @@ def main():
     ap.add_argument("--work", default="/tmp/mi_mut")
     ap.add_argument("--out", default="")
     ap.add_argument("--oracle", action="store_true", help="the source is a file of oracle/ (gcc, MI_ORACLE_LIB)")
+    ap.add_argument("--marker", default="not gpu", help="pytest -m: 'gpu' on a GPU box holds host code that only runs with real kernels "
+                                                        "(the parts protocol of split files) against the GPU tests")
     ap.add_argument("--unit", default="", help="the source is a header: the .hip that includes it")
     args = ap.parse_args()
     B.build()
