@@ -378,8 +378,12 @@ def scenario_many_gpus(tmp, eng):
     if split_mib <= 8:                                                      # files that are SPLIT over the ctxs as parts (GPU only: the
         rng = np.random.default_rng(43)                                     # parts agree on their boundary cuts through the kernels' records)
         for name, size in (("big/a.bin", 5 << 20), ("big/b.bin", (9 << 20) + 13), ("big/c.bin", split_mib << 20), ("big/d.bin", (split_mib << 20) - 1),
-                           ("big/zeros.bin", 6 << 20)):
+                           ("big/zeros.bin", 6 << 20), ("big/shifted_zeros.bin", (7 << 20) + 5)):
+            # (shifted_zeros: 30 001 random bytes, then zeros -- the forced cuts lie on a grid that begins at the prefix's last content
+            #  cut, so every part's assumed entry is wrong and the owners need a round per boundary to agree: group_resolve_parts' loop)
             data = bytes(size) if "zeros" in name else rng.integers(0, 256, size, dtype=np.uint8).tobytes()
+            if "shifted" in name:
+                data = rng.integers(0, 256, 30001, dtype=np.uint8).tobytes() + data[30001:]
             write_file(os.path.join(root, name), data, 0o644, MTIME)
             files[name] = data
             n_split += 1 if size >= (split_mib << 20) and size >= (2 << 20) else 0

@@ -3,7 +3,9 @@ threshold is lowered to 2 MiB so that a seed's tree holds several of them and a 
 
 Per seed: a tree of 3-6 files of 2-24 MiB (sizes not aligned to anything) and a few small ones; contents by class --
 random bytes; ALL ZEROS and a 4 KiB period (no content cut ever re-synchronises a part's halo: every boundary is settled by
-the rounds of the parts protocol, forced cuts at max_size all the way); random with a long stretch repeated at another
+the rounds of the parts protocol, forced cuts at max_size all the way); the same two behind a random prefix of odd length ("shifted": the forced cuts lie on a grid that
+begins where the prefix's last content cut fell, so every part's assumed entry is wrong and its true one is known only when
+its predecessor's cuts are final -- as many rounds as the file has parts); random with a long stretch repeated at another
 offset -- committed over 2, 3, 4 or 8 ctxs.  Held against: the header-only commit's tar (TarDigest and size), the ORACLE's
 root of every whole file, the byte check's counts (every layer file verified); then one byte of a split file is flipped at
 a random offset, size and second kept: the next commit's layer is that file alone, its root the oracle's again.
@@ -34,6 +36,9 @@ def content(rng, size, kind):
         return bytes(size)
     if kind == "period":
         return (rng.integers(0, 256, 4096, dtype=np.uint8).tobytes() * (size // 4096 + 1))[:size]
+    if kind in ("shifted zeros", "shifted period"):
+        pre = rng.integers(0, 256, int(rng.integers(1, 70_000)) | 1, dtype=np.uint8).tobytes()
+        return (pre + content(rng, size, kind[len("shifted "):]))[:size]
     a = rng.integers(0, 256, size, dtype=np.uint8)
     if kind == "repeat" and size > 6 * MIB:                    # a stretch that occurs twice, the second time across a part boundary
         n = int(rng.integers(MIB, 2 * MIB))
@@ -47,7 +52,7 @@ def one_seed(seed, engines, tmp):
     rng = np.random.default_rng(seed)
     root = str(tmp / "root")
     files = {}
-    kinds = ["random", "zeros", "period", "repeat", "random", "repeat"]
+    kinds = ["random", "zeros", "period", "repeat", "shifted zeros", "shifted period", "shifted zeros"]
     for i in range(int(rng.integers(3, 7))):
         size = int(rng.integers(2 * MIB, 24 * MIB)) + int(rng.integers(0, 4096))
         files["big/f%d.bin" % i] = content(rng, size, kinds[int(rng.integers(0, len(kinds)))])
