@@ -108,7 +108,14 @@ int arena_reserve(mi_batch* b, u64 want, bool told = false, bool ahead = false) 
             if (rc) return rc;
             HIPCHK(c, hipStreamSynchronize(c->stream));
         }
-        return arena_promise(c, &b->arena, want);
+        // Address ranges are never given back (mi_arena.hip): a process that has gone through thousands of walk-fed batches may
+        // find none left.  Such a batch takes ONE allocation that moves when it grows, as every batch did until round 5.
+        bool no_addresses = false;
+        const int rc = arena_promise(c, &b->arena, want, &no_addresses);
+        if (!no_addresses) return rc;
+        static const bool say = [] { const char* v = getenv("MI_ARENA_TRACE"); return v && *v == '1'; }();
+        if (say) fprintf(stderr, "mi_arena: no address range left (%s): this batch's arena is one allocation\n", mi_last_error(c));
+        b->arena_plain = true;
     }
     int rc = staging_sync(b);                       // copies in flight target the old arena
     if (rc) return rc;

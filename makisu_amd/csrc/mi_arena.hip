@@ -23,7 +23,9 @@
 // GPU faults or in bytes that are not the ones copied (profiles/r04_overread_audit.txt, mi_alloc.hip on MI_GUARD_ALLOC=3), so an
 // arena's range stays reserved for the life of the process after arena_release (physical memory IS given back).  A range is
 // 32 GiB at least and four times the first promise; an arena that outgrows it has its pieces mapped again in a larger range (no
-// copy: the same physical pieces), after the caller drained whatever targets it.
+// copy: the same physical pieces), after the caller drained whatever targets it.  A process has 4 094 ranges of 32 GiB
+// (tools/vmm_va_probe.hip, profiles/r06_vmm_va_probe.txt); a batch that finds none left gets a plain arena (arena_reserve,
+// mi_api.hip: arena_promise reports *no_addresses instead of failing the batch).
 //
 // What the reference does here: nothing -- tario.WriteEntry (lib/tario/write.go:28-52) streams a file through a 32 KiB buffer.
 // The arena exists because the GPU scans a whole batch at once.
@@ -147,7 +149,8 @@ void arena_counts(const Arena* a, u64* mapped, u64* pieces, u64* reserved) {
     if (reserved) *reserved = r;
 }
 
-int arena_promise(mi_ctx* c, Arena* a, u64 want) {
+int arena_promise(mi_ctx* c, Arena* a, u64 want, bool* no_addresses) {
+    if (no_addresses) *no_addresses = false;
     if (want <= a->bytes) return MI_OK;
     // The promise moves in whole pieces: a batch that is filled file by file asks here for every file, and neither the free-memory
     // question below nor a wake-up of the mapper is asked per file.  (The arena of rounds 1-5 took a half on top of what was asked.)
@@ -170,6 +173,7 @@ int arena_promise(mi_ctx* c, Arena* a, u64 want) {
         const hipError_t e = hipMemAddressReserve(&vm->va, range, 1ull << 30, nullptr, 0);
         if (e != hipSuccess) {
             delete vm;
+            if (no_addresses) *no_addresses = true;            // (the caller may still take one allocation that moves)
             return fail(c, e == hipErrorOutOfMemory ? MI_ERR_NOMEM : MI_ERR_HIP, "hipMemAddressReserve of %llu bytes for an arena: %s", (unsigned long long)range, hipGetErrorString(e));
         }
         vm->reserved = range;

@@ -55,7 +55,7 @@ struct Arena {
 };
 bool arena_is_plain();                                      // MI_GUARD_ALLOC or MI_ARENA=malloc: the moving arena
 // the promise grows to `want` bytes.  outgrown (see arena_outgrown): the caller has drained everything that targets the arena
-int  arena_promise(mi_ctx* c, Arena* a, u64 want);
+int  arena_promise(mi_ctx* c, Arena* a, u64 want, bool* no_addresses = nullptr);   // *no_addresses: the FIRST reservation found no address range
 bool arena_outgrown(const Arena* a, u64 want);              // `want` does not fit the reserved range: the pieces move to a larger one
 int  arena_wait_mapped(mi_ctx* c, Arena* a, u64 upto, std::string* msg = nullptr);   // MI_ERR_NOMEM when the device ran out under the mapper
                                                             // (msg: where the message goes instead of the ctx)

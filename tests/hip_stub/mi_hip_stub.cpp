@@ -117,7 +117,9 @@ thread_local int t_device = 0;
 
 const long kMapUs = env_us("MI_HIP_STUB_MAP_US");
 // MI_HIP_STUB_VM_FAIL=create:k | map:k | access:k : the k-th (0-based) hipMemCreate fails with hipErrorOutOfMemory, the k-th
-// hipMemMap / hipMemSetAccess with hipErrorInvalidValue -- a device that runs out under the mapper, a runtime that refuses a piece
+// hipMemMap / hipMemSetAccess with hipErrorInvalidValue -- a device that runs out under the mapper, a runtime that refuses a piece;
+// reserve:k : every hipMemAddressReserve from the k-th on fails -- a process that has used up its address space (ranges are never
+// given back, mi_arena.hip)
 struct VmFail { int what = 0; long at = -1; };
 VmFail vm_fail() {
     static const VmFail f = [] {
@@ -127,11 +129,12 @@ VmFail vm_fail() {
         if (!strncmp(e, "create:", 7)) { v.what = 1; v.at = atol(e + 7); }
         if (!strncmp(e, "map:", 4)) { v.what = 2; v.at = atol(e + 4); }
         if (!strncmp(e, "access:", 7)) { v.what = 3; v.at = atol(e + 7); }
+        if (!strncmp(e, "reserve:", 8)) { v.what = 4; v.at = atol(e + 8); }
         return v;
     }();
     return f;
 }
-std::atomic<long> g_vm_calls[4];
+std::atomic<long> g_vm_calls[5];
 const long kLimitMb = env_us("MI_HIP_STUB_MALLOC_LIMIT_MB");
 std::atomic<long long> g_vm_bytes{0};                 // physical pieces alive (hipMemCreate - hipMemRelease)
 std::atomic<long> g_vm_pieces{0}, g_vm_ranges{0};
@@ -287,6 +290,7 @@ hipError_t hipMemGetInfo(size_t* fr, size_t* total) {
 hipError_t hipDeviceSynchronize(void) { return hipSuccess; }     // (callers have synchronised their streams: nothing device-wide here)
 hipError_t hipMemGetAllocationGranularity(size_t* g, const hipMemAllocationProp*, hipMemAllocationGranularity_flags) { *g = 4096; return hipSuccess; }
 hipError_t hipMemAddressReserve(void** p, size_t n, size_t, void*, unsigned long long) {
+    if (vm_fail().what == 4 && g_vm_calls[4]++ >= vm_fail().at) return hipErrorOutOfMemory;
     void* q = mmap(nullptr, n, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
     if (q == MAP_FAILED) return hipErrorOutOfMemory;
     *p = q;

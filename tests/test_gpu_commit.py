@@ -138,6 +138,50 @@ def test_commit_zero_with_the_heavier_check_without_any_and_on_either_arena(env,
     assert p.returncode == 0 and "OK commit_zero" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
 
 
+NO_ADDRESSES = r"""
+import ctypes, os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import makisu_amd as M
+from commit_cases import commit_to_bytes, make_tree, oracle_root
+from oracle import mi_oracle as O
+O.build()
+tmp = sys.argv[1]
+root = os.path.join(tmp, "root")
+files = make_tree(root, seed=77)
+with M.Engine(device=0) as eng:
+    # the HIP runtime this process runs on, by the path it was mapped from; then every 32 GiB address range it will give
+    path = [ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64" in ln][0]
+    hip = ctypes.CDLL(path)
+    hip.hipMemAddressReserve.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_ulonglong]
+    n = 0
+    while True:
+        va = ctypes.c_void_p()
+        if hip.hipMemAddressReserve(ctypes.byref(va), 32 << 30, 1 << 30, None, 0) != 0:
+            break
+        n += 1
+        assert n < 100000
+    assert n > 1000, n
+    with M.MemFS(root) as fs, M.MemFS(root) as plain:
+        res, raw = commit_to_bytes(fs, tmp, "a.tar", must_scan=True, engine=eng)
+        res0, raw0 = commit_to_bytes(plain, tmp, "p.tar", must_scan=True)
+        st = res["stats"]
+        assert raw == raw0 and st["arena_pieces"] == 1 and st["n_verified_files"] == len(files) and st["n_refetched"] == 0, st
+        by = {e["relpath"]: e for e in res["layer"]}
+        for rel, data in files.items():
+            assert by[rel]["root"] == oracle_root(O, data), rel
+print("OK no_addresses", n)
+"""
+
+
+def test_a_process_without_address_ranges_left_still_commits(tmp_path):
+    """csrc/mi_arena.hip never gives an address range back, and a process has 4 094 of an arena's size (tools/vmm_va_probe.hip,
+    profiles/r06_vmm_va_probe.txt).  With all of them taken -- here by the test itself, through the process's own HIP runtime -- a
+    walk-fed batch's arena is ONE allocation that moves when it grows, as every batch's was until round 5: the commit is the
+    reference's, every root the oracle's."""
+    p = subprocess.run([sys.executable, "-c", NO_ADDRESSES % {"root": ROOT}, str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "OK no_addresses" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
+
+
 def test_the_arena_never_moves_on_the_gpu(tmp_path):
     """tests/hip_stub/commit_scenarios.py `known_tree` with real device memory: 262 MB learned 1 024 files at a time -- one address
     range, pieces mapped behind the walk, every file's bytes in the tar"""

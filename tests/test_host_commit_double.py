@@ -116,11 +116,13 @@ def test_a_fault_at_every_place_the_injection_reaches_never_yields_a_wrong_layer
     assert "copy         failed, hop named                x 6" in p.stdout, p.stdout
 
 
-@pytest.mark.parametrize("fail", ["create:0", "create:2", "map:1", "access:2"])
+@pytest.mark.parametrize("fail", ["create:0", "create:2", "map:1", "access:2", "reserve:0"])
 @pytest.mark.parametrize("pipeline", ["1", "0"])
 def test_an_arena_that_cannot_be_mapped_fails_the_commit_and_nothing_hangs(hip_double, tmp_path, fail, pipeline):  # noqa: F811
     """csrc/mi_arena.hip: the mapper thread's k-th piece is refused -- everybody who waits for the mapper (reader threads, the scan's
-    stage_batch, the tar writer's wait for landed bytes) gets the failure instead of waiting for ever; the pieces it did map go back"""
+    stage_batch, the tar writer's wait for landed bytes) gets the failure instead of waiting for ever; the pieces it did map go back.
+    reserve:0 -- the process has no address range left (mi_arena.hip retires them): NOT a failure, the batch's arena is one
+    allocation that moves when it grows, and the commit is the reference's"""
     env = dict(os.environ, LD_PRELOAD=(os.environ.get("LD_PRELOAD", "") + " " + hip_double).strip(), MI_HIP_STUB_VM_FAIL=fail,
                MI_COMMIT_PIPELINE=pipeline)
     p = subprocess.run([sys.executable, os.path.join(STUB_DIR, "commit_scenarios.py"), str(tmp_path), "4", "mapper_fails"], env=env,
