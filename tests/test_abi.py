@@ -192,3 +192,13 @@ def test_product_never_imports_the_oracle():
                     if re.search(r"mi_oracle|mi_ref_|from oracle|import oracle|oracle/", txt):
                         bad.append(os.path.join(dp, fn))
     assert not bad, bad
+
+
+def test_the_drivers_build_check_agrees_with_the_header():
+    """__graft_entry__.build() ends with check_abi(): the library's mi_abi_version() against include/makisu_mi.h's MI_ABI_VERSION (a
+    literal there once outlived an ABI bump and failed the driver's build check with everything built); and no literal is left"""
+    import re
+    import __graft_entry__ as g
+    assert g.check_abi() == int(re.search(r"^#define\s+MI_ABI_VERSION\s+(\d+)", open(os.path.join(ROOT, "include", "makisu_mi.h")).read(), re.M).group(1))
+    src = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    assert "check_abi()" in src.split("def build")[1].split("def check_abi")[0] and not re.search(r"mi_abi_version\(\)\s*==\s*\d", src)
