@@ -225,6 +225,11 @@ MI_CORE int  mi_ctx_create(const mi_config* cfg, mi_ctx** out);
  * count is in the message) -- a finalizer that runs in the wrong order gets an error, not a
  * use-after-free.  NULL is MI_OK.                                                       */
 MI_CORE int  mi_ctx_destroy(mi_ctx* ctx);
+/* Optional: pays NOW what the ctx's first content-aware commit would pay otherwise -- the reader threads with their pinned
+ * slabs and streams, the kernels' code objects (a four-file synthetic batch): 0.05-0.06 s of a first commit's 0.07 where a
+ * later one takes 0.011 (tools/first_commit_probe.py, profiles/r06_first_commit_probe.txt).  Blocking; a host runs it beside its own start-up work (a goroutine)
+ * and joins it before the ctx's next call.  Changes no result and no statistic.                                          */
+MI_BLOCK int mi_ctx_warm(mi_ctx* ctx);
 /* ctx may be NULL: returns the message of the last failed mi_ctx_create.           */
 MI_CORE const char* mi_last_error(mi_ctx* ctx);
 MI_DIAG int  mi_get_stats(mi_ctx* ctx, mi_stats* out);

@@ -188,6 +188,7 @@ def load_library(rebuild=False):
     vp, u64, u64p = C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)
     sigs = {
         "mi_abi_version": ([], C.c_int),
+        "mi_ctx_warm": ([vp], C.c_int),
         "mi_debug_sha_wave_stats": ([vp, C.c_char_p], C.c_int),
         "mi_config_default": ([C.POINTER(Config)], C.c_int),
         "mi_ctx_create": ([C.POINTER(Config), C.POINTER(vp)], C.c_int),
@@ -1013,6 +1014,10 @@ class Engine:
 
     def __exit__(self, *a):
         self.close()
+
+    def warm(self):
+        """mi_ctx_warm: the reader threads, their pinned slabs and the kernels' code objects NOW instead of inside the first commit"""
+        self._check(self._lib.mi_ctx_warm(self._h))
 
     def device_info(self):
         ncu, mhz, mem = C.c_int32(), C.c_int32(), C.c_uint64()

@@ -95,6 +95,7 @@ int stage_verify_final(mi_batch* b);
 struct Stager;
 Stager* stager_create(mi_ctx* c, u32 n_threads, u64 slab_bytes);   // returns at once: the readers set up behind it
 bool    stager_ready(Stager* st);                                   // waits for them; false: none got slab + stream
+bool stager_ready_all(Stager* st);
 void    stager_destroy(Stager* st);
 int     stager_put_bytes(Stager* st, mi_batch* b, u64 arena_off, const void* src, u64 len, mi_sum::FileSum* sums);
 int     stager_put_file(Stager* st, mi_batch* b, u64 arena_off, int fd, u64 file_off, u64 len, const char* path, mi_sum::FileSum* sums,

@@ -480,6 +480,13 @@ bool stager_ready(Stager* st) {
     return st->n_ok != 0;
 }
 
+// ... and when EVERY reader thread is up or has given up (mi_ctx_warm: nothing of it is left for the first walk)
+bool stager_ready_all(Stager* st) {
+    std::unique_lock<std::mutex> lk(st->mu);
+    st->cv_init.wait(lk, [&] { return st->init_left == 0; });
+    return st->n_ok != 0;
+}
+
 void stager_destroy(Stager* st) {
     if (!st) return;
     {

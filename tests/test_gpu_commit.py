@@ -182,6 +182,28 @@ def test_a_process_without_address_ranges_left_still_commits(tmp_path):
     assert p.returncode == 0 and "OK no_addresses" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
 
 
+def test_warming_a_ctx_changes_nothing_but_when_the_first_use_is_paid(oracle, tmp_path):
+    """mi_ctx_warm: reader threads, pinned slabs and the kernels' code objects before the first commit instead of inside it.  The
+    commit after it is the commit without it -- same tar, same roots, same statistics of the ctx's own batches --, twice is harmless,
+    and it works on a ctx that has already run batches"""
+    root = str(tmp_path / "root")
+    files = make_tree(root, seed=5)
+    with M.Engine(device=0) as cold, M.Engine(device=0) as warm:
+        warm.warm()
+        warm.warm()
+        with M.MemFS(root) as a, M.MemFS(root) as b:
+            ra, raw_a = commit_to_bytes(a, str(tmp_path), "cold.tar", must_scan=True, engine=cold)
+            rb, raw_b = commit_to_bytes(b, str(tmp_path), "warm.tar", must_scan=True, engine=warm)
+        assert raw_a == raw_b and [e.get("root") for e in ra["layer"]] == [e.get("root") for e in rb["layer"]]
+        assert {e["relpath"]: e for e in rb["layer"]}[sorted(files)[0]]["root"] == oracle_root(oracle, files[sorted(files)[0]])
+        sa, sb = cold.stats(), warm.stats()
+        assert (sa["n_files"], sa["n_chunks"], sa["bytes_in"]) == (sb["n_files"], sb["n_chunks"], sb["bytes_in"]), (sa, sb)
+        cold.warm()                                                            # after use: nothing to do, and nothing broken
+        with M.MemFS(root) as c:
+            rc_, raw_c = commit_to_bytes(c, str(tmp_path), "again.tar", must_scan=True, engine=cold)
+        assert raw_c == raw_a
+
+
 def test_the_arena_never_moves_on_the_gpu(tmp_path):
     """tests/hip_stub/commit_scenarios.py `known_tree` with real device memory: 262 MB learned 1 024 files at a time -- one address
     range, pieces mapped behind the walk, every file's bytes in the tar"""
