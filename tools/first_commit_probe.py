@@ -60,5 +60,21 @@ for r, root in enumerate(roots):
         t0 = time.perf_counter()
         fs.commit_layer(must_scan=True, gzip_level=M.GZIP_OFF, want_layer=False)
         out.append(("header-only %d" % r, time.perf_counter() - t0))
+# ... and ONE handle that lives on (a build stage): 100 new files per commit, the handle's batch, windows and arena reused
+live = os.path.join(tmp, "live")
+write_file(os.path.join(live, "seed.bin"), b"x" * 1000, 0o644, 1_600_000_000)
+with M.MemFS(live) as fs, M.MemFS(live) as plain:
+    for k in range(4):
+        for i in range(100):
+            write_file(os.path.join(live, "k%d/f%d.bin" % (k, i)), rng.integers(0, 256, 65536, dtype=np.uint8).tobytes(), 0o644, 1_600_000_000)
+        t0 = time.perf_counter()
+        res = fs.commit_layer(must_scan=True, gzip_level=M.GZIP_OFF, engine=eng, want_layer=False)
+        out.append(("same handle %d" % k, time.perf_counter() - t0))
+        if os.environ.get("MI_PROBE_STATS") == "1":
+            st = res["stats"]
+            print("   same handle %d: " % k + " ".join("%s %.4f" % (n, st[n]) for n in ("s_walk_stage", "s_scan", "s_diff", "s_write", "s_total")), file=sys.stderr)
+        t0 = time.perf_counter()
+        plain.commit_layer(must_scan=True, gzip_level=M.GZIP_OFF, want_layer=False)
+        out.append(("header-only", time.perf_counter() - t0))
 eng.close()
 print("%-11s " % mode + "  ".join("%s %.4f" % kv for kv in out))
