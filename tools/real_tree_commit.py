@@ -32,6 +32,7 @@ def main():
             cur = os.path.join(cur, part)
     rows = []
     digests = {}
+    all_roots = {}
     if os.environ.get("MI_REAL_WARM") == "1":
         t0, nb = time.perf_counter(), 0
         for dp, dns, fns in os.walk(top):
@@ -63,6 +64,7 @@ def main():
                     rows.append((name, what, dt, st, res))
                     if what == "all new":
                         digests[name] = str(res["tar_digest"])
+                        all_roots[name] = {e["relpath"]: e["root"] for e in res["layer"] if e["kind"] == M.KIND_FILE and "root" in e}
                         if name == "gpu":
                             files = [e for e in res["layer"] if e["kind"] == M.KIND_FILE and "root" in e and e["size"] <= (64 << 20)]
                             rng = np.random.default_rng(5)
@@ -83,6 +85,20 @@ def main():
             print("%-16s verified %d files, %.2f GB, %d chunks fetched twice; arena %.2f GB in %d pieces, moved %d times; %d ctx(s), bytes per ctx %.2f - %.2f GB" %
                   (name, st["n_verified_files"], st["verified_bytes"] / 1e9, st["n_refetched"], st["arena_bytes"] / 1e9, st["arena_pieces"], st["arena_moves"],
                    st["n_ctxs"], st["ctx_bytes_min"] / 1e9, st["ctx_bytes_max"] / 1e9))
+    # every root of every handle that scanned: the one-ctx commit's -- among them the files of 256 MiB and more, which the commit over
+    # several ctxs SPLITS into parts (their root is computed from the parts' digests) -- and those against the oracle as well
+    gpu_names = [n for n in all_roots if all_roots[n]]
+    for n in gpu_names[1:]:
+        diff = [r for r in all_roots[gpu_names[0]] if all_roots[n].get(r) != all_roots[gpu_names[0]][r]]
+        print("%-16s %d roots, %d differ from %s's%s" % (n, len(all_roots[n]), len(diff), gpu_names[0], (": %s" % diff[:5]) if diff else ""))
+        assert not diff and len(all_roots[n]) == len(all_roots[gpu_names[0]])
+    for name, what, dt, st, res in rows:
+        if what == "all new" and st["n_ctxs"] > 1:
+            big = [e for e in res["layer"] if e["kind"] == M.KIND_FILE and e["size"] >= (256 << 20)]
+            bad = [e["relpath"] for e in big if oracle_root(O, open("/" + e["relpath"], "rb").read()) != e["root"]]
+            print("%-16s %d files split over the ctxs as parts (%d of 256 MiB and more, %.2f GB): their roots against the oracle's of the whole files: %s" %
+                  (name, st["n_split_files"], len(big), sum(e["size"] for e in big) / 1e9, "all equal" if not bad else "DIFFER: %s" % bad))
+            assert not bad and st["n_split_files"] == len(big)
     for e in more:
         e.close()
     same = len(set(digests.values())) == 1
