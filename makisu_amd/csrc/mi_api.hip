@@ -862,13 +862,13 @@ int mi_ctx_warm(mi_ctx* c) {
     int rc = ensure_stager(c);
     if (rc) return rc;
     (void)stager_ready_all(c->stager);
+    const mi_stats keep = c->stats;                           // (the caller's next mi_get_stats is about ITS batches)
     mi_batch* b = nullptr;
     rc = mi_batch_begin(c, 4, 0, &b);
     if (rc) return rc;
     const uint64_t sizes[4] = {65536, 200000, 1, 4097};
     rc = mi_batch_add_synthetic(b, 4, sizes, nullptr, c->cfg.gear_seed);
     if (rc == MI_OK) rc = mi_batch_run(b);
-    const mi_stats keep = c->stats;                           // (the caller's next mi_get_stats is about ITS batches)
     (void)mi_batch_free(b);
     c->stats = keep;
     return rc;

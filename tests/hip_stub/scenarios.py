@@ -186,6 +186,26 @@ def scenario_api(tmp, threads, slab):
         check(b, b"after the errors", "api, after errors")
 
 
+def scenario_warm(tmp, threads, slab):
+    """mi_ctx_warm: all reader threads up and one synthetic batch through the pipeline, before, between and after the ctx's own
+    batches -- their bytes land where they landed without it, and the ctx's statistics are about ITS batches"""
+    with M.Engine(n_streams=threads, staging_bytes=slab) as eng:
+        eng.warm()
+        eng.warm()
+        data = os.urandom(5 * slab + 3)
+        with eng.batch() as b:
+            b.add_bytes(data)
+            b.run()
+            check(b, data, "warm, first batch")
+            before = eng.stats()
+            eng.warm()                                          # with a batch of the caller's alive
+            assert eng.stats() == before
+            b.reset()
+            b.add_bytes(data[:slab + 1])
+            b.run()
+            check(b, data[:slab + 1], "warm, after the warm call")
+
+
 def scenario_tree_reserves_ahead(tmp, threads, slab):
     """mi_batch_add_tree without size hints: the enumeration runs ahead of the files handed over and the arena is sized
     for what it has seen -- a handful of (re)allocations for a tree of 6 000 files, not one per 1.5x step"""
@@ -334,7 +354,7 @@ def main():
     slab = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
     only = sys.argv[4].split(",") if len(sys.argv) > 4 else None
     for name, fn in [("mix", scenario_mix), ("growth", scenario_growth_and_reuse), ("two", scenario_two_batches), ("interleaved", scenario_interleaved),
-                     ("errors", scenario_errors), ("api", scenario_api), ("tree", scenario_tree_reserves_ahead),
+                     ("errors", scenario_errors), ("api", scenario_api), ("warm", scenario_warm), ("tree", scenario_tree_reserves_ahead),
                      ("two_ctxs", scenario_two_ctxs), ("recycle", scenario_blocks_recycle), ("long_strings", scenario_long_strings)]:
         if (name not in only) if only else name in ("recycle", "long_strings"):    # these run only when asked for
             continue

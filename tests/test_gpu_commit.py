@@ -199,6 +199,7 @@ def test_warming_a_ctx_changes_nothing_but_when_the_first_use_is_paid(oracle, tm
         sa, sb = cold.stats(), warm.stats()
         assert (sa["n_files"], sa["n_chunks"], sa["bytes_in"]) == (sb["n_files"], sb["n_chunks"], sb["bytes_in"]), (sa, sb)
         cold.warm()                                                            # after use: nothing to do, and nothing broken
+        assert cold.stats() == sa                                              # ... and the ctx's statistics are still about ITS batches
         with M.MemFS(root) as c:
             rc_, raw_c = commit_to_bytes(c, str(tmp_path), "again.tar", must_scan=True, engine=cold)
         assert raw_c == raw_a

@@ -34,7 +34,7 @@ def _run(stub, tmp, threads, slab, extra_env=None):
     p = subprocess.run([sys.executable, os.path.join(STUB_DIR, "scenarios.py"), str(tmp), str(threads), str(slab)],
                        env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout + p.stderr
-    assert [ln for ln in p.stdout.splitlines() if ln.startswith("OK ")] == ["OK mix", "OK growth", "OK two", "OK interleaved", "OK errors", "OK api", "OK tree", "OK two_ctxs"]
+    assert [ln for ln in p.stdout.splitlines() if ln.startswith("OK ")] == ["OK mix", "OK growth", "OK two", "OK interleaved", "OK errors", "OK api", "OK warm", "OK tree", "OK two_ctxs"]
 
 
 @pytest.mark.parametrize("threads,slab", [(1, 65536), (4, 65536), (16, 131072), (3, 1 << 20)])
