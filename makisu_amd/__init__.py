@@ -110,6 +110,17 @@ class LayerResult(C.Structure):
 
 
 GZIP_OFF, GZIP_DEFAULT = -2, -1
+# tario.SetCompressionLevel's names (lib/tario/gzip.go:28-43; the `--compression` flag of bin/makisu/cmd/build.go) -> the
+# gzip_level of mi_layer_config: "no" is a gzip member of stored blocks (pgzip.NoCompression), not MI_GZIP_OFF
+COMPRESSION_LEVELS = {"no": 0, "speed": 1, "size": 9, "default": GZIP_DEFAULT}
+
+
+def compression_level(name):
+    """tario.SetCompressionLevel (lib/tario/gzip.go:36-43): the level for a name, `invalid compression level <name>` otherwise."""
+    try:
+        return COMPRESSION_LEVELS[name]
+    except (KeyError, TypeError):
+        raise ValueError("invalid compression level %s" % (name,)) from None
 
 
 class CommitStats(C.Structure):

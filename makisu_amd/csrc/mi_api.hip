@@ -101,7 +101,7 @@ int arena_reserve(mi_batch* b, u64 want, bool told = false, bool ahead = false) 
     mi_ctx* c = b->ctx;
     want += 4096;                                   // slack: tile loads may touch 15 B past a file
     if (want <= b->arena.bytes) return MI_OK;
-    if (!b->arena.p) b->arena_plain = arena_is_plain() || (told && !ahead);
+    if (!b->arena.p) b->arena_plain = arena_is_plain() || (told && !ahead && !arena_always_pieces());
     if (!b->arena_plain) {
         if (arena_outgrown(&b->arena, want)) {
             int rc = staging_sync(b);
@@ -468,6 +468,9 @@ int submit_pipeline_enqueue(mi_batch* b) {
     // reserves would only keep the other batch's Gear workgroups off the CU (measured: -1.3 %).
     ShaTune sha = c->sha;
     sha.pin_blocks_per_cu = c->sha.pin_blocks_per_cu && c->batches_in_flight == 0;
+    // an arena of small pieces: the cooperative loads from a much smaller footprint on (ShaTune::coop_min_bytes_pieces)
+    if (const u64 piece = arena_piece_bytes(&b->arena); piece && piece < (256ull << 20) && sha.coop_min_bytes_pieces < sha.coop_min_bytes)
+        sha.coop_min_bytes = sha.coop_min_bytes_pieces;
 
     HIPCHK(c, hipEventRecord(b->ev[0], s));
     HIPCHK(c, hipMemsetAsync(ctl, 0, kCtlBytes, s));
@@ -825,6 +828,7 @@ int mi_ctx_create(const mi_config* cfg, mi_ctx** out) {
         if (v >= 1 && v <= 8) c->sha.blocks_per_cu = v;
     }
     if (const char* e = getenv("MI_SHA_COOP_MIN_GIB")) c->sha.coop_min_bytes = (u64)(atof(e) * 1073741824.0);
+    if (const char* e = getenv("MI_SHA_COOP_MIN_GIB_PIECES")) c->sha.coop_min_bytes_pieces = (u64)(atof(e) * 1073741824.0);
     if (const char* e = getenv("MI_SHA_COOP_BLOCKS_PER_CU")) {
         int v = atoi(e);
         if (v >= 1 && v <= 3) c->sha.coop_blocks_per_cu = v;
@@ -841,8 +845,8 @@ int mi_ctx_create(const mi_config* cfg, mi_ctx** out) {
     if ((cfg->sha_sched >> 8) & 0x1Fu) c->sha.long_shift = (int)((cfg->sha_sched >> 8) & 0x1Fu) - 1;
     if (cfg->sha_blocks_per_cu >= 1 && cfg->sha_blocks_per_cu <= 8) c->sha.blocks_per_cu = (int)cfg->sha_blocks_per_cu;
     if (cfg->sha_coop_min_gib) c->sha.coop_min_bytes = (u64)cfg->sha_coop_min_gib << 30;
-    if (cfg->sha_load_scheme == MI_SHA_LOADS_LANE) c->sha.coop_min_bytes = ~0ull;
-    if (cfg->sha_load_scheme == MI_SHA_LOADS_COOP) c->sha.coop_min_bytes = 0;
+    if (cfg->sha_load_scheme == MI_SHA_LOADS_LANE) c->sha.coop_min_bytes = c->sha.coop_min_bytes_pieces = ~0ull;
+    if (cfg->sha_load_scheme == MI_SHA_LOADS_COOP) c->sha.coop_min_bytes = c->sha.coop_min_bytes_pieces = 0;
     if (cfg->sha_coop_blocks_per_cu >= 1 && cfg->sha_coop_blocks_per_cu <= 3)
         c->sha.coop_blocks_per_cu = (int)cfg->sha_coop_blocks_per_cu;
     memset(&c->stats, 0, sizeof c->stats);

@@ -133,6 +133,12 @@ bool arena_is_plain() {
     static const bool plain = [] { const char* v = getenv("MI_ARENA"); return guard_alloc() || (v && !strcmp(v, "malloc")); }();
     return plain;
 }
+bool arena_always_pieces() {
+    static const bool on = [] { const char* v = getenv("MI_ARENA"); return !guard_alloc() && v && !strcmp(v, "pieces"); }();
+    return on;
+}
+
+u64 arena_piece_bytes(const Arena* a) { return a->vm ? a->vm->piece : 0; }
 
 bool arena_outgrown(const Arena* a, u64 want) { return a->vm && round_up(want, a->vm->piece) > a->vm->reserved; }
 

@@ -54,6 +54,8 @@ struct Arena {
     template <typename T> T* as() const { return (T*)p; }
 };
 bool arena_is_plain();                                      // MI_GUARD_ALLOC or MI_ARENA=malloc: the moving arena
+bool arena_always_pieces();                                 // MI_ARENA=pieces (A/B runs): batches that are told their size are piecewise too
+u64  arena_piece_bytes(const Arena* a);                     // 0: one allocation
 // the promise grows to `want` bytes.  outgrown (see arena_outgrown): the caller has drained everything that targets the arena
 int  arena_promise(mi_ctx* c, Arena* a, u64 want, bool* no_addresses = nullptr);   // *no_addresses: the FIRST reservation found no address range
 bool arena_outgrown(const Arena* a, u64 want);              // `want` does not fit the reserved range: the pieces move to a larger one

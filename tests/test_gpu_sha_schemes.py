@@ -209,3 +209,35 @@ def test_wave_stats_are_a_ctx_setting(tmp_path):
             e.debug_sha_wave_stats(None)
             b.rerun()
             assert len(WS.read_records(path)) == 2
+
+
+def test_an_arena_of_small_pieces_takes_the_cooperative_loads(tmp_path, monkeypatch):
+    """AUTO on an arena mapped piece by piece (a batch that learns its size as it goes: every commit's; csrc/mi_arena.hip):
+    the lane-owned loads run at the speed of the page-table fragments behind 32 MiB pieces, so from
+    ShaTune::coop_min_bytes_pieces on (moved down to 32 MiB here) the chunk pass loads cooperatively -- the wave record's
+    header says which kernel ran; a batch that was told its size (one allocation) of the same content stays lane-owned;
+    the rows are the same either way; a ctx told LANE stays lane-owned on pieces too."""
+    import numpy as np
+    import makisu_amd
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import sha_wave_stats as WS
+    if os.environ.get("MI_ARENA") or os.environ.get("MI_GUARD_ALLOC"):
+        pytest.skip("the arena kind is forced by the environment")
+    monkeypatch.setenv("MI_SHA_COOP_MIN_GIB_PIECES", "0.03125")
+    rng = np.random.default_rng(28)
+    blobs = [rng.integers(0, 256, 1 << 20, dtype=np.uint8).tobytes() for _ in range(48)]
+    rows = {}
+    for name, scheme, told in (("pieces", makisu_amd.SHA_LOADS_AUTO, False), ("plain", makisu_amd.SHA_LOADS_AUTO, True),
+                               ("pieces_lane", makisu_amd.SHA_LOADS_LANE, False)):
+        path = str(tmp_path / (name + ".bin"))
+        with makisu_amd.Engine(sha_load_scheme=scheme) as e:
+            e.debug_sha_wave_stats(path)
+            with (e.batch(len(blobs), len(blobs) << 20) if told else e.batch()) as b:
+                for x in blobs:
+                    b.add_bytes(x)
+                b.run()
+                rows[name] = b.chunks()["sha256"].copy()
+        recs = WS.read_records(path)
+        assert len(recs) == 1
+        assert recs[0]["coop"] == (1 if name == "pieces" else 0), (name, recs[0]["coop"])
+    assert np.array_equal(rows["pieces"], rows["plain"]) and np.array_equal(rows["pieces"], rows["pieces_lane"])

@@ -722,3 +722,34 @@ def test_plain_c_commit_layer(tmp_path):
     before = M.tree_walk(str(a), mode=M.TREE_SCAN, full=True)
     _, names_py, pair = _commit_scan_layer(tmp_path, b, before, "py")
     assert pair["tar_digest"].hex() == t_hex and pair["gzip_digest"].hex() == g_hex
+
+
+def test_compression_level_names_like_the_reference(tmp_path):
+    """lib/tario/gzip_test.go:23-27 TestSetCompressionLevelFail + the map of gzip.go:28-33 (the `--compression` flag): four
+    names and an error that names the offender; "no" is still a gzip member (pgzip.NoCompression: stored blocks, longer than
+    the tar), not a bare tar; every named level inflates to the same tar and TarDigest."""
+    with pytest.raises(ValueError, match="invalid compression level invalid"):
+        M.compression_level("invalid")
+    for bad in ("", "Default", "9", None):
+        with pytest.raises(ValueError, match="invalid compression level"):
+            M.compression_level(bad)
+    assert {n: M.compression_level(n) for n in ("no", "speed", "size", "default")} == \
+        {"no": 0, "speed": 1, "size": 9, "default": M.GZIP_DEFAULT}
+    root = tmp_path / "rootfs"
+    root.mkdir()
+    _build_tree(root)
+    (root / "zeros.bin").write_bytes(bytes(300_000))
+    seen = {}
+    for name in ("no", "speed", "size", "default"):
+        _, _, pair, blob = _write_layer(tmp_path, root, M.compression_level(name))
+        assert blob[:3] == b"\x1f\x8b\x08"
+        seen[name] = (pair["tar_digest"].hex(), len(blob), hashlib.sha256(gzip.decompress(blob)).hexdigest(), pair["tar_bytes"])
+    assert len({v[0] for v in seen.values()}) == 1 and all(v[0] == v[2] for v in seen.values())
+    assert seen["no"][1] > seen["no"][3] > seen["speed"][1] + 290_000 and seen["speed"][1] >= seen["size"][1]
+
+
+def test_digest_hex_parsing_like_the_reference():
+    """lib/docker/image/digest_test.go:28-35 TestDigestHexParsing: Hex() is what follows "sha256:"."""
+    d = M.Digest("sha256:123abc123")
+    assert d.hex() == "123abc123" and d.hex() != M.Digest.from_raw(hashlib.sha256(b"").digest()).hex()
+    assert M.Digest.from_raw(hashlib.sha256(b"").digest()) == "sha256:e3b0c44298fc1c149afbf4c8996fb92427ae41e4649b934ca495991b7852b855"
