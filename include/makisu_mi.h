@@ -141,7 +141,9 @@ typedef struct {
     uint32_t sha_blocks_per_cu;      /* workgroups per CU of the hashing kernels (default 2, 1..8) */
     uint32_t sha_load_scheme;        /* MI_SHA_LOADS_*: how a lane fetches its next block      */
     uint32_t sha_coop_min_gib;       /* MI_SHA_LOADS_AUTO: arena footprint in GiB from which the
-                                        quad-cooperative loads are used (default 9)            */
+                                        quad-cooperative loads are used (default 9; on an arena
+                                        mapped in pieces under 256 MiB -- every walk-fed batch's --
+                                        from 1 GiB on: a quarter of the address translations)  */
     uint32_t sha_coop_blocks_per_cu; /* workgroups per CU with cooperative loads (default: 3 from
                                         24 GiB up, else sha_blocks_per_cu; 1..3)               */
     uint32_t sha_sched;              /* MI_SHA_SCHED_*: how the strings of a hashing launch are shared
