@@ -137,7 +137,7 @@ typedef struct {
                                  and one copy stream each (0 = 8, at most 64)       */
     /* SHA-256 pass tuning, per ctx (0 = the engine's default).  The defaults
      * can also be moved for a whole process by MI_SHA_BLOCKS_PER_CU / MI_SHA_COOP_MIN_GIB /
-     * MI_SHA_COOP_BLOCKS_PER_CU, read at mi_ctx_create; a non-zero field here wins.      */
+     * MI_SHA_COOP_MIN_GIB_PIECES / MI_SHA_COOP_BLOCKS_PER_CU, read at mi_ctx_create; a non-zero field here wins.      */
     uint32_t sha_blocks_per_cu;      /* workgroups per CU of the hashing kernels (default 2, 1..8) */
     uint32_t sha_load_scheme;        /* MI_SHA_LOADS_*: how a lane fetches its next block      */
     uint32_t sha_coop_min_gib;       /* MI_SHA_LOADS_AUTO: arena footprint in GiB from which the
