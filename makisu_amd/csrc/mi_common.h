@@ -119,7 +119,8 @@ struct ShaTune {
                                              // lane-owned loads touch 64 pages per wave instruction and run at the speed of the
                                              // page-table fragments behind them (C2 chunk pass on 32 MiB pieces 5.0-5.3 ms against
                                              // 4.13 on one allocation), the cooperative loads 16 (4.2-4.4 ms on the same pieces:
-                                             // profiles/r06_arena_ab.txt)
+                                             // profiles/r06_arena_ab.txt); below 1 GiB the lane-owned loads win on either kind
+                                             // (profiles/r06_pieces_scheme_ab.txt)
     int coop_blocks_per_cu = 0;              // 0 = 3 from 24 GiB up, else blocks_per_cu
     bool pin_blocks_per_cu = true;           // pad every workgroup's LDS request so that NO CU can take more
                                              // than blocks_per_cu of them (sha256.hip launch_sha256_items)
