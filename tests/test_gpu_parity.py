@@ -324,6 +324,7 @@ print("OK long_strings")
     for env in ({}, {"MI_SHA_LONG_ON_GPU": "1"}):
         p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
         assert p.returncode == 0 and "OK long_strings" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
+        print("\n".join(ln for ln in p.stdout.splitlines() if ln.startswith("eight ")))        # pytest -s: the measured times
 
 
 def test_c1_build_context_on_gpu(oracle):
