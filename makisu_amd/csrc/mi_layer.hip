@@ -247,6 +247,11 @@ private:
         z_stream z;
         memset(&z, 0, sizeof z);
         bool ready = deflateInit2(&z, level_, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) == Z_OK;
+        // the probe of incompressible(): a second, fastest-level stream.  Not at level "no" (everything is stored anyway) and not
+        // with MI_GZIP_PROBE=0 (A/B runs)
+        z_stream zp;
+        memset(&zp, 0, sizeof zp);
+        bool probe_ready = level_ != 0 && probe_enabled() && deflateInit2(&zp, 1, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) == Z_OK;
         for (;;) {
             std::shared_ptr<Job> j;
             {
@@ -257,7 +262,10 @@ private:
                 todo_.pop_front();
             }
             bool ok = ready;
-            if (ok) {
+            if (ok && probe_ready && incompressible(&zp, j->in->data(), j->in->size())) {
+                store(j->in->data(), j->in->size(), &j->out);
+                j->crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), j->in->data(), (uInt)j->in->size());
+            } else if (ok) {
                 deflateReset(&z);
                 j->out.resize(deflateBound(&z, (uLong)j->in->size()) + 16);
                 z.next_in = (Bytef*)j->in->data();
@@ -277,6 +285,53 @@ private:
             dcv_.notify_all();
         }
         if (ready) deflateEnd(&z);
+        if (probe_ready) deflateEnd(&zp);
+    }
+    // A block that will not compress is not worth the search for matches: zlib spends its LONGEST on such data (level 6: 14 MB/s
+    // a thread on random bytes against 20-50 on binaries and text here), and a layer of jars, wheels, images or compressed blobs
+    // is made of it.  Three 8 KiB samples -- the block's first, middle and last -- through the fastest level: when none of them
+    // shrinks by 1/64 the block goes out as stored deflate blocks (byte-aligned like the sync-flushed ones: the member stays
+    // one valid stream, its CRC and length cover the same bytes).  A repeat within deflate's 32 KiB window shows in an 8 KiB
+    // sample or is at most 4 positions long; what the samples miss costs ratio, never correctness.  The reference's
+    // compressor (pgzip over klauspost's deflate, lib/tario/gzip.go:46-48) skips incompressible input in the same spirit; its
+    // bytes are its own either way (the gzip leg is unpinned).  Per block and from the bytes alone: the blob does
+    // not depend on the number of threads.
+    static bool probe_enabled() {
+        static const bool on = [] { const char* v = getenv("MI_GZIP_PROBE"); return !(v && *v == '0'); }();
+        return on;
+    }
+    static bool incompressible(z_stream* zp, const uint8_t* p, size_t n) {
+        constexpr size_t kSample = 8192;
+        if (n < 8 * kSample) return false;
+        uint8_t out[kSample + 256];
+        size_t in_total = 0, out_total = 0;
+        const size_t at[3] = {0, (n / 2) & ~(size_t)4095, n - kSample};
+        for (size_t k = 0; k < 3; ++k) {
+            if (deflateReset(zp) != Z_OK) return false;
+            zp->next_in = (Bytef*)(p + at[k]);
+            zp->avail_in = (uInt)kSample;
+            zp->next_out = out;
+            zp->avail_out = (uInt)sizeof out;
+            const int rc = deflate(zp, Z_SYNC_FLUSH);
+            if (rc != Z_OK && rc != Z_BUF_ERROR) return false;
+            if (zp->avail_in != 0) { out_total += kSample; in_total += kSample; continue; }   // did not even fit: no gain
+            in_total += kSample;
+            out_total += sizeof out - zp->avail_out;
+        }
+        return out_total + in_total / 64 >= in_total;
+    }
+    static void store(const uint8_t* p, size_t n, Bytes* out) {
+        out->resize(n + 5 * (n / 65535 + 1));
+        uint8_t* o = out->data();
+        while (n) {
+            const size_t take = n < 65535 ? n : 65535;
+            *o++ = 0;                                              // BFINAL = 0, BTYPE = 00 (stored); the stream is byte-aligned here
+            *o++ = (uint8_t)take; *o++ = (uint8_t)(take >> 8);
+            *o++ = (uint8_t)~take; *o++ = (uint8_t)(~take >> 8);
+            memcpy(o, p, take);
+            o += take; p += take; n -= take;
+        }
+        out->resize((size_t)(o - out->data()));
     }
     void stop_pool() {
         {

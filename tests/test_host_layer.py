@@ -17,11 +17,14 @@ import io
 import os
 import shutil
 import subprocess
+import sys
 import tarfile
 
 import pytest
 
 import makisu_amd as M
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 EMPTY_TAR_TRAILER_DIGEST = "5f70bf18a086007016e948b04aed3b82103a36bea41755b6cddfaf10ace3c6ef"
 
@@ -753,3 +756,66 @@ def test_digest_hex_parsing_like_the_reference():
     d = M.Digest("sha256:123abc123")
     assert d.hex() == "123abc123" and d.hex() != M.Digest.from_raw(hashlib.sha256(b"").digest()).hex()
     assert M.Digest.from_raw(hashlib.sha256(b"").digest()) == "sha256:e3b0c44298fc1c149afbf4c8996fb92427ae41e4649b934ca495991b7852b855"
+
+
+PROBE_CHILD = r"""
+import gzip, hashlib, os, sys
+sys.path.insert(0, %(root)r)
+import makisu_amd as M
+root, out = sys.argv[1], sys.argv[2]
+ents = [e for e in M.tree_walk(root, None, (), M.TREE_SCAN, full=True) if e["relpath"] not in (".", "")]
+order = M.commit_order([e["relpath"] for e in ents])
+fd = os.open(out, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+with M.Layer(out_fd=fd, gzip_level=M.GZIP_DEFAULT) as layer:
+    for k in order:
+        e = ents[k]
+        layer.add(e, os.path.join(root, e["relpath"]) if e["kind"] == M.KIND_FILE else None)
+    pair = layer.finish()
+os.close(fd)
+blob = open(out, "rb").read()
+assert hashlib.sha256(blob).hexdigest() == pair["gzip_digest"].hex() and len(blob) == pair["gzip_bytes"]
+assert hashlib.sha256(gzip.decompress(blob)).hexdigest() == pair["tar_digest"].hex()
+print(pair["tar_digest"].hex(), pair["tar_bytes"], len(blob))
+"""
+
+
+def test_blocks_that_will_not_compress_are_stored(tmp_path):
+    """The gzip leg (common.go:44-52, lib/tario/gzip.go:46-48) does not search incompressible blocks for matches: three 8 KiB
+    samples of a 1 MiB block through the fastest level, and a block none of which shrinks goes out as stored deflate blocks
+    of 65 535 bytes -- one valid member either way (python's gzip inflates it to the tar the TarDigest names), the same tar
+    and digest with MI_GZIP_PROBE=0, a blob that does not depend on the thread count, and what compresses still does:
+    zeros and a repeated 4 KiB pattern (period inside deflate's window) next to the random file stay small."""
+    import numpy as np
+    root = tmp_path / "rootfs"
+    root.mkdir()
+    rng = np.random.default_rng(7)
+    (root / "a_random.bin").write_bytes(rng.integers(0, 256, 5 << 20, dtype=np.uint8).tobytes())
+    (root / "b_zeros.bin").write_bytes(bytes(3 << 20))
+    (root / "c_pattern.bin").write_bytes(rng.integers(0, 256, 4096, dtype=np.uint8).tobytes() * 768)
+    (root / "d_half.bin").write_bytes(rng.integers(0, 256, 1 << 20, dtype=np.uint8).tobytes() + bytes(1 << 20))
+    full = b"\x00\xff\xff\x00\x00"                                   # a stored block of 65 535 bytes: BFINAL 0, LEN, ~LEN
+
+    def run(tag, **env):
+        out = tmp_path / ("blob." + tag)
+        r = subprocess.run([sys.executable, "-c", PROBE_CHILD % {"root": ROOT}, str(root), str(out)],
+                           env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+        tar_digest, tar_bytes, n = r.stdout.split()
+        return tar_digest, int(tar_bytes), out.read_bytes()
+
+    def stored_runs(blob):                                           # two full stored blocks back to back, anywhere
+        at, n = blob.find(full), 0
+        while at >= 0:
+            n += blob[at + 65540:at + 65545] == full
+            at = blob.find(full, at + 1)
+        return n
+
+    d_on, tar_bytes, on = run("on")
+    d_off, _, off = run("off", MI_GZIP_PROBE="0")
+    d_one, _, one = run("one", MI_GZIP_THREADS="1")
+    d_many, _, many = run("many", MI_GZIP_THREADS="7")
+    assert d_on == d_off == d_one == d_many and on == one == many
+    assert stored_runs(on) >= 4 * 15 and stored_runs(off) == 0       # the random file's blocks but its first (the tar header shrinks)
+    assert on != off and abs(len(on) - len(off)) < tar_bytes // 1000
+    # 6 MiB of the 13 will not compress; the rest (zeros, the pattern, the zero half) takes next to nothing
+    assert (6 << 20) < len(on) < (6 << 20) + (300 << 10)

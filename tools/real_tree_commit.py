@@ -47,6 +47,7 @@ def main():
                             nb += len(b)
         print("# warm-up read of %s: %.2f GB in %.1f s" % (top, nb / 1e9, time.perf_counter() - t0))
     k = int(os.environ.get("MI_REAL_N_CTXS", "0"))
+    gz = int(os.environ["MI_REAL_GZIP"]) if os.environ.get("MI_REAL_GZIP") else M.GZIP_OFF     # -1: tario's default level; unset: the gzip leg off
     more = [M.Engine(device=0, n_streams=4) for _ in range(max(0, k - 1))]
     with M.Engine(device=0) as eng:
         handles = [("gpu", {"engine": eng}, False), ("gpu_trust_ctime", {"engine": eng}, True), ("cpu_header_only", {}, False)]
@@ -58,7 +59,7 @@ def main():
                     fs.set_options(trust_ctime=True)
                 for what in ("all new", "nothing changed"):
                     t0 = time.perf_counter()
-                    res = fs.commit_layer(must_scan=True, gzip_level=M.GZIP_OFF, **kw)
+                    res = fs.commit_layer(must_scan=True, gzip_level=gz, **kw)
                     dt = time.perf_counter() - t0
                     st = res["stats"]
                     rows.append((name, what, dt, st, res))
@@ -80,6 +81,11 @@ def main():
               (name, what, dt, "+stage" if name.startswith("gpu") else "", st["s_walk_stage"], st["s_diff"], st["s_write"], st["s_scan"],
                " (beside)" if st["pipelined"] else "", res["n_entries"], st["n_layer_files"], st["files_opened"], st["file_bytes_read"] / 1e9,
                st["n_content_trusted"]))
+    if gz != M.GZIP_OFF:
+        for name, what, dt, st, res in rows:
+            if what == "all new":
+                print("%-16s gzip level %d (MI_GZIP_PROBE=%s): %.2f GB tar -> %.2f GB blob (%.3f), %s" %
+                      (name, gz, os.environ.get("MI_GZIP_PROBE", "1"), res["tar_bytes"] / 1e9, res["gzip_bytes"] / 1e9, res["gzip_bytes"] / res["tar_bytes"], res["gzip_digest"][:26]))
     for name, what, dt, st, res in rows:
         if what == "all new" and name.startswith("gpu"):
             print("%-16s verified %d files, %.2f GB, %d chunks fetched twice; arena %.2f GB in %d pieces, moved %d times; %d ctx(s), bytes per ctx %.2f - %.2f GB" %
