@@ -722,7 +722,9 @@ MI_CORE int  mi_memfs_entries(const mi_memfs* fs, mi_tree_entry* out, const char
 typedef struct mi_layer mi_layer;
 typedef struct {
     uint32_t struct_size;
-    int32_t  gzip_level;       /* MI_GZIP_OFF, MI_GZIP_DEFAULT or 0..9                          */
+    int32_t  gzip_level;       /* MI_GZIP_OFF, MI_GZIP_DEFAULT or 0..9.  At every level but 0 a 1 MiB
+                                  block that will not compress (three 8 KiB samples of it through
+                                  level 1) is stored, not searched: one valid member either way    */
     int32_t  out_fd;           /* where the layer blob is written; -1 = digests only           */
     uint32_t flags;            /* MI_LAYER_*                                                    */
 } mi_layer_config;
