@@ -306,9 +306,9 @@ private:
         uint8_t out[kSample + 256];
         size_t in_total = 0, out_total = 0;
         const size_t at[3] = {0, (n / 2) & ~(size_t)4095, n - kSample};
-        for (size_t k = 0; k < 3; ++k) {
+        for (const size_t off : at) {
             if (deflateReset(zp) != Z_OK) return false;
-            zp->next_in = (Bytef*)(p + at[k]);
+            zp->next_in = (Bytef*)(p + off);
             zp->avail_in = (uInt)kSample;
             zp->next_out = out;
             zp->avail_out = (uInt)sizeof out;

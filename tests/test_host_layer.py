@@ -819,3 +819,12 @@ def test_blocks_that_will_not_compress_are_stored(tmp_path):
     assert on != off and abs(len(on) - len(off)) < tar_bytes // 1000
     # 6 MiB of the 13 will not compress; the rest (zeros, the pattern, the zero half) takes next to nothing
     assert (6 << 20) < len(on) < (6 << 20) + (300 << 10)
+    # a block too short to sample (under 64 KiB) is deflated as ever: a small layer of text shrinks, one of random bytes cannot
+    small = tmp_path / "small"
+    small.mkdir()
+    (small / "notes.txt").write_bytes(b"the quick brown fox jumps over the lazy dog\n" * 500)
+    _, _, pair, blob = _write_layer(tmp_path, small, M.GZIP_DEFAULT)
+    assert len(blob) < pair["tar_bytes"] // 10 and gzip.decompress(blob)[512:512 + 9] == b"the quick"
+    (small / "notes.txt").write_bytes(rng.integers(0, 256, 22000, dtype=np.uint8).tobytes())
+    _, _, pair, blob = _write_layer(tmp_path, small, M.GZIP_DEFAULT)
+    assert pair["tar_bytes"] - 3000 < len(blob) < pair["tar_bytes"] + 200 and hashlib.sha256(gzip.decompress(blob)).hexdigest() == pair["tar_digest"].hex()
