@@ -824,7 +824,7 @@ def test_the_commit_table_reaches_the_fields_the_driver_keeps(eng):
     name -- bench.py's summary of `commit_e2e` inside `cpu_baseline.commit_s` is built from the table and stays small"""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from commit_layer_bench import commit_e2e
-    small, large = commit_e2e(eng, 2000, 4096), commit_e2e(eng, 6, 8 << 20)
+    small, large = commit_e2e(eng, 2000, 4096, all_new_rounds=3), commit_e2e(eng, 6, 8 << 20)
     src = open(os.path.join(ROOT, "bench.py")).read()
     a = src.index("        try:\n            ce = out.get(\"commit_e2e\") or {}")
     b = src.index("        except Exception as e:                                      # noqa: BLE001\n            print(\"bench.py: the summary")
@@ -835,6 +835,11 @@ def test_the_commit_table_reaches_the_fields_the_driver_keeps(eng):
     c = out["cpu_baseline"]["commit_s"]
     assert len(json.dumps(c)) <= 900 and set(c) >= {"all_new", "nothing_changed", "changed_0p1pct", "all_new_gpu_over_header_only"}
     assert c["all_new"]["large"] == [large["commits"][0][k]["s_total"] for k in ("gpu", "gpu_trust_ctime", "cpu_header_only")]
+    # the small tree's "all new": three rounds on fresh handles, each side's best; the last round is the table's own row
+    rs = small["commits"][0]["all_new_rounds_s"]
+    assert all(len(rs[k]) == 3 and rs[k][-1] == small["commits"][0][k]["s_total"] for k in ("gpu", "gpu_trust_ctime", "cpu_header_only"))
+    assert c["all_new"]["small"] == [min(rs[k]) for k in ("gpu", "gpu_trust_ctime", "cpu_header_only")] and "best of 3" in c["order"]
+    assert c["all_new_gpu_over_header_only"]["small"] == round(min(rs["gpu"]) / min(rs["cpu_header_only"]), 4)
     assert c["large_all_new_verified"][0] == 6 and c["large_all_new_verified"][1] == 0 and c["large_all_new_verified"][2] == 0
     assert out["config"]["with_rows_ratio"] == 0.99
 

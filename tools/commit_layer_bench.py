@@ -56,8 +56,11 @@ def _side(st, res, wall):
             "arena_moves": int(st["arena_moves"]), "arena_pieces": int(st["arena_pieces"])}
 
 
-def commit_e2e(eng, n_files, file_bytes, base=None, gzip_level=None):
-    """-> dict(tree, commits=[{what, gpu={...}, cpu_header_only={...}}, ...]); gzip off unless gzip_level is given"""
+def commit_e2e(eng, n_files, file_bytes, base=None, gzip_level=None, all_new_rounds=1):
+    """-> dict(tree, commits=[{what, gpu={...}, cpu_header_only={...}}, ...]); gzip off unless gzip_level is given.
+    all_new_rounds > 1: a handle can commit a tree "all new" only once, and one sample of a 0.3 s commit moves by 15 % with the host
+    (profiles/r06_bench_n1_*.json: the header-only side 0.318 ... 0.368 s on four boxes) -- so k - 1 more rounds on FRESH handles of
+    the three sides first, all of them in the first row as `all_new_rounds_s` (bench.py's summary takes each side's best)."""
     base = base or ("/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None)
     import tempfile
     root = tempfile.mkdtemp(prefix="mi_commit_e2e_", dir=base)
@@ -71,6 +74,17 @@ def commit_e2e(eng, n_files, file_bytes, base=None, gzip_level=None):
         victims = [paths[int(i)] for i in rng.choice(n_files, size=k, replace=False)]
         out = {"tree": "%d files x %d bytes in %d directories under %s (page cache)" % (n_files, file_bytes, (n_files + per_dir - 1) // per_dir, base or "TMPDIR"),
                "tree_bytes": n_files * file_bytes, "gzip": "off" if gzip_level is None else gzip_level, "commits": []}
+        rounds = {"gpu": [], "gpu_trust_ctime": [], "cpu_header_only": []}
+        for _ in range(max(0, all_new_rounds - 1)):
+            with M.MemFS(root) as gpu, M.MemFS(root) as trust, M.MemFS(root) as plain:
+                trust.set_options(trust_ctime=True)
+                sides = (("gpu", gpu, {"engine": eng}), ("gpu_trust_ctime", trust, {"engine": eng}), ("cpu_header_only", plain, {}))
+                if os.environ.get("MI_BENCH_ORDER") == "cpu_first":
+                    sides = sides[::-1]
+                for name, fs, kw in sides:
+                    t0 = time.perf_counter()
+                    fs.commit_layer(must_scan=True, gzip_level=gz, want_layer=False, **kw)
+                    rounds[name].append(round(time.perf_counter() - t0, 4))
         with M.MemFS(root) as gpu, M.MemFS(root) as trust, M.MemFS(root) as plain:
             trust.set_options(trust_ctime=True)
             for step, what in enumerate(("all new", "nothing changed", "0.1 % changed")):
@@ -96,6 +110,10 @@ def commit_e2e(eng, n_files, file_bytes, base=None, gzip_level=None):
                     res = fs.commit_layer(must_scan=True, gzip_level=gz, want_layer=False, **kw)   # (the layer's entries stay in the library:
                                                                                                     #  100 000 python dicts are not part of a commit)
                     row[name] = _side(res["stats"], res, time.perf_counter() - t0)
+                    if step == 0:
+                        rounds[name].append(row[name]["s_total"])
+                if step == 0 and all_new_rounds > 1:
+                    row["all_new_rounds_s"] = rounds
                 out["commits"].append(row)
         return out
     finally:
